@@ -1,0 +1,173 @@
+/*
+ * nflows_amd.h -- C ABI of libnflows_amd.so, the MI355X (gfx950) implementation of the
+ * bayesiains/nflows coupling-layer hot path (forward / inverse + log|det J|).
+ *
+ * The reference is pure Python and has no FFI; the "interface" each entry point replaces is the
+ * Python functional / method cited next to it (paths relative to the reference repo).  The
+ * reference-side binding a maintainer would add (a ctypes stub inside nflows/transforms) is
+ * shown in INTEGRATION.md; nflows_amd/_native.py is that same binding used by this repo's
+ * drop-in `nflows_amd.transforms` classes.
+ *
+ * Conventions
+ *   - every pointer except `spec` is a DEVICE pointer (HIP, same device as `stream`);
+ *     row-major, densely packed unless a stride argument says otherwise;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream);
+ *     all entry points are asynchronous: they enqueue kernels and return;
+ *   - inputs are borrowed and never written; outputs are caller-allocated;
+ *   - the return value is NFA_OK or an NFA_ERR_* code (argument errors are detected before any
+ *     launch; nothing is enqueued on error);
+ *   - data-dependent errors (the reference's InputOutsideDomain / discriminant assertion) are
+ *     OR-ed into the caller-provided device word `status` (may be NULL = not recorded); the
+ *     caller decides when to read it back.  Kernels never clear it.
+ *   - no global mutable state: entry points are re-entrant across host threads and streams.
+ */
+#ifndef NFLOWS_AMD_H
+#define NFLOWS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFA_ABI_VERSION 1
+
+/* return codes */
+#define NFA_OK 0
+#define NFA_ERR_INVALID_ARGUMENT 1 /* NULL pointer, negative size, bad enum */
+#define NFA_ERR_UNSUPPORTED 2      /* valid request this build has no kernel for */
+#define NFA_ERR_MIN_BIN_WIDTH 3    /* min_bin_width * num_bins > 1  (rational_quadratic.py:86-87) */
+#define NFA_ERR_MIN_BIN_HEIGHT 4   /* min_bin_height * num_bins > 1 (rational_quadratic.py:88-89) */
+#define NFA_ERR_HIP 5              /* a HIP runtime call failed; see nfa_last_hip_error() */
+
+/* bits OR-ed into *status by the kernels */
+#define NFA_STATUS_OUTSIDE_DOMAIN 1   /* transforms/base.py:16 InputOutsideDomain; rational_quadratic.py:81-82 */
+#define NFA_STATUS_NEG_DISCRIMINANT 2 /* rational_quadratic.py:142 assert (discriminant >= 0).all() */
+#define NFA_STATUS_BAD_INDEX 4        /* a transform_idx / perm entry outside [0, features) */
+
+/* tails */
+#define NFA_TAILS_NONE 0   /* rational_quadratic_spline: K+1 derivative logits per element */
+#define NFA_TAILS_LINEAR 1 /* unconstrained_rational_quadratic_spline(tails="linear"): K-1 */
+
+/* affine scale activations (coupling.py:224-225, :263-269) */
+#define NFA_SCALE_DEFAULT 0  /* sigmoid(u + 2) + 1e-3 */
+#define NFA_SCALE_GENERAL 1  /* clamp(softplus(u) + 1e-3, 0, 3) */
+#define NFA_SCALE_ADDITIVE 2 /* AdditiveCouplingTransform: scale == 1, logabsdet == 0 */
+#define NFA_SCALE_GIVEN 3    /* caller evaluated an arbitrary scale_activation into `scale` */
+#define NFA_SCALE_SOFTPLUS 4 /* softplus(u) + 1e-3 (autoregressive.py:101) */
+
+/*
+ * Spline hyper-parameters: the keyword arguments of
+ *   nflows/transforms/splines/rational_quadratic.py:13-25 (unconstrained_...) and :66-80.
+ * Python floats stay doubles here; the kernels round them to fp32 exactly where aten does.
+ */
+typedef struct nfa_rqs_spec {
+    int32_t num_bins;      /* K >= 1 */
+    int32_t tails;         /* NFA_TAILS_* */
+    double left, right;    /* for linear tails: -tail_bound, +tail_bound */
+    double bottom, top;    /* for linear tails: -tail_bound, +tail_bound */
+    double min_bin_width;  /* DEFAULT_MIN_BIN_WIDTH = 1e-3 */
+    double min_bin_height; /* DEFAULT_MIN_BIN_HEIGHT = 1e-3 */
+    double min_derivative; /* DEFAULT_MIN_DERIVATIVE = 1e-3 */
+    double softplus_beta;  /* 1, or ln2/(1-min_derivative) if enable_identity_init (:100-103) */
+    double tail_logit;     /* log(exp(1-min_derivative)-1), the padded boundary logit (:33-36) */
+    double wh_divisor;     /* sqrt(hidden_features) applied to width/height logits
+                              (coupling.py:554-559); 0 = no scaling */
+} nfa_rqs_spec;
+
+int nfa_abi_version(void);
+const char *nfa_build_arch(void);      /* "gfx950" */
+const char *nfa_strerror(int code);
+int nfa_last_hip_error(void);          /* hipError_t of the last NFA_ERR_HIP on this thread */
+
+/*
+ * K1.  Fused rational-quadratic coupling layer given the conditioner output.
+ * Replaces, in one launch:
+ *   CouplingTransform.forward/inverse split + scatter      coupling.py:82-83, 96-98, 111-112, 126-128
+ *   PiecewiseCouplingTransform._coupling_transform         coupling.py:279-293 (reshape, row-sum)
+ *   PiecewiseRationalQuadraticCouplingTransform._piecewise_cdf   coupling.py:549-582
+ *   (un)constrained rational_quadratic_spline               splines/rational_quadratic.py:13-181
+ *   torchutils.searchsorted / sum_except_batch              utils/torchutils.py:134-136, 19-24
+ * and optionally the Permutation that precedes the layer    permutations.py:27-39
+ *
+ *   inputs        [batch, features]
+ *   params        [batch, num_transform * P],  P = 3K-1 (linear tails) or 3K+1; per feature
+ *                 [w_0..w_{K-1}, h_0..h_{K-1}, d...]  (coupling.py:289, 550-552)
+ *   transform_idx [num_transform] int64, the `transform_features` buffer (coupling.py:47-49)
+ *   in_perm       [features] int64 or NULL: the layer sees inputs[:, in_perm]  (a Permutation
+ *                 placed before the layer, fused into the gather)
+ *   out_scatter   [features] int64 or NULL: layer column c is stored at outputs[:, out_scatter[c]],
+ *                 i.e. outputs = index_select(y, 1, argsort(out_scatter)) (a Permutation.inverse
+ *                 placed after the layer, permutations.py:22-24, :44-45, fused into the scatter)
+ *   outputs       [batch, features]; columns not in transform_idx are copied bit-exactly
+ *   logabsdet     [batch]
+ */
+int nfa_rqs_coupling_f32(const float *inputs, const float *params, const int64_t *transform_idx,
+                         const int64_t *in_perm, const int64_t *out_scatter, float *outputs,
+                         float *logabsdet, int32_t *status,
+                         int64_t batch, int32_t features, int32_t num_transform,
+                         const nfa_rqs_spec *spec, int32_t inverse, void *stream);
+
+/*
+ * K5.  Elementwise rational-quadratic functional (no row-sum):
+ *   unconstrained_rational_quadratic_spline / rational_quadratic_spline,
+ *   splines/rational_quadratic.py:13-63 / :66-181, as called from
+ *   autoregressive.py:453-489 and nonlinearities.py:431-467.
+ *   inputs, outputs, logabsdet: [n];  logits: row i at uw + i*stride_w (K floats),
+ *   uh + i*stride_h (K), ud + i*stride_d (K-1 or K+1); strides in elements.
+ */
+int nfa_rqs_elementwise_f32(const float *inputs, const float *unnormalized_widths, int64_t stride_w,
+                            const float *unnormalized_heights, int64_t stride_h,
+                            const float *unnormalized_derivatives, int64_t stride_d, float *outputs,
+                            float *logabsdet, int32_t *status, int64_t n, const nfa_rqs_spec *spec,
+                            int32_t inverse, void *stream);
+
+/*
+ * K2.  Fused affine / additive coupling layer given the conditioner output.
+ *   AffineCouplingTransform._scale_and_shift / _coupling_transform_forward / _inverse
+ *   coupling.py:234-252; AdditiveCouplingTransform coupling.py:255-269; plus the split/scatter
+ *   and optional preceding permutation as in K1.
+ *   params [batch, 2*num_transform] = [shift | unconstrained_scale] (additive: [batch, num_transform])
+ *   scale  [batch, num_transform], only for NFA_SCALE_GIVEN, else NULL
+ */
+int nfa_affine_coupling_f32(const float *inputs, const float *params, const float *scale,
+                            const int64_t *transform_idx, const int64_t *in_perm,
+                            const int64_t *out_scatter, float *outputs, float *logabsdet,
+                            int32_t *status, int64_t batch, int32_t features, int32_t num_transform,
+                            int32_t scale_activation, int32_t inverse, void *stream);
+
+/*
+ * K2b. Elementwise affine transform with interleaved parameters, the autoregressive form:
+ *   MaskedAffineAutoregressiveTransform._elementwise_forward/_inverse, autoregressive.py:96-128
+ *   params [batch, features, 2]: [...,0] = unconstrained scale, [...,1] = shift;
+ *   scale = softplus(u) + 1e-3.  Produces outputs [batch, features] and logabsdet [batch].
+ */
+int nfa_affine_autoregressive_f32(const float *inputs, const float *params, float *outputs,
+                                  float *logabsdet, int64_t batch, int32_t features,
+                                  int32_t inverse, void *stream);
+
+/*
+ * K4.  Column permutation, bit-exact for any 4-byte element type:
+ *   Permutation._permute (dim=1) = torch.index_select(inputs, 1, perm), permutations.py:27-39.
+ *   out[b, c] = in[b, perm[c]]
+ */
+int nfa_permute_cols_b32(const void *inputs, const int64_t *perm, void *outputs, int32_t *status,
+                         int64_t batch, int32_t features, void *stream);
+
+/*
+ * K3.  Per-sample reduction: torchutils.sum_except_batch, utils/torchutils.py:19-24.
+ *   out[b] = sum_c x[b, c]
+ */
+int nfa_rowsum_f32(const float *x, float *out, int64_t rows, int64_t cols, void *stream);
+
+/*
+ * StandardNormal._log_prob fused with the flow's final add (distributions/normal.py:23-33,
+ * flows/base.py:49):  out[b] = -0.5 * sum_c z[b,c]^2 - 0.5*cols*log(2*pi) + (logabsdet ? logabsdet[b] : 0)
+ */
+int nfa_standard_normal_log_prob_f32(const float *z, const float *logabsdet, float *out,
+                                     int64_t rows, int64_t cols, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFLOWS_AMD_H */

@@ -1,0 +1,158 @@
+"""ctypes binding of libnflows_amd.so (the C ABI declared in include/nflows_amd.h).
+
+PyTorch is used here only as the owner of device memory and HIP streams: every call hands raw
+device pointers (`tensor.data_ptr()`) and the current stream handle to the library.  There is
+no CPU or eager fallback: if the shared library is missing or the tensors are not on a HIP
+device, the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libnflows_amd.so")
+
+OK = 0
+ERR_INVALID_ARGUMENT = 1
+ERR_UNSUPPORTED = 2
+ERR_MIN_BIN_WIDTH = 3
+ERR_MIN_BIN_HEIGHT = 4
+ERR_HIP = 5
+
+STATUS_OUTSIDE_DOMAIN = 1
+STATUS_NEG_DISCRIMINANT = 2
+STATUS_BAD_INDEX = 4
+
+TAILS_NONE, TAILS_LINEAR = 0, 1
+SCALE_DEFAULT, SCALE_GENERAL, SCALE_ADDITIVE, SCALE_GIVEN, SCALE_SOFTPLUS = 0, 1, 2, 3, 4
+
+ABI_VERSION = 1
+
+EXPORTS = (
+    "nfa_abi_version",
+    "nfa_build_arch",
+    "nfa_strerror",
+    "nfa_last_hip_error",
+    "nfa_rqs_coupling_f32",
+    "nfa_rqs_elementwise_f32",
+    "nfa_affine_coupling_f32",
+    "nfa_affine_autoregressive_f32",
+    "nfa_permute_cols_b32",
+    "nfa_rowsum_f32",
+    "nfa_standard_normal_log_prob_f32",
+)
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libnflows_amd: %s (code %d)" % (message, code))
+        self.code = code
+
+
+class RqsSpec(ctypes.Structure):
+    """struct nfa_rqs_spec"""
+
+    _fields_ = [
+        ("num_bins", ctypes.c_int32),
+        ("tails", ctypes.c_int32),
+        ("left", ctypes.c_double),
+        ("right", ctypes.c_double),
+        ("bottom", ctypes.c_double),
+        ("top", ctypes.c_double),
+        ("min_bin_width", ctypes.c_double),
+        ("min_bin_height", ctypes.c_double),
+        ("min_derivative", ctypes.c_double),
+        ("softplus_beta", ctypes.c_double),
+        ("tail_logit", ctypes.c_double),
+        ("wh_divisor", ctypes.c_double),
+    ]
+
+
+_lib = None
+
+
+def _declare(lib):
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    sp = ctypes.POINTER(RqsSpec)
+    lib.nfa_abi_version.restype = ctypes.c_int
+    lib.nfa_build_arch.restype = ctypes.c_char_p
+    lib.nfa_strerror.restype = ctypes.c_char_p
+    lib.nfa_strerror.argtypes = [ctypes.c_int]
+    lib.nfa_last_hip_error.restype = ctypes.c_int
+    lib.nfa_rqs_coupling_f32.restype = ctypes.c_int
+    lib.nfa_rqs_coupling_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, sp, i32, vp]
+    lib.nfa_rqs_elementwise_f32.restype = ctypes.c_int
+    lib.nfa_rqs_elementwise_f32.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, i64, sp, i32, vp]
+    lib.nfa_affine_coupling_f32.restype = ctypes.c_int
+    lib.nfa_affine_coupling_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+    lib.nfa_affine_autoregressive_f32.restype = ctypes.c_int
+    lib.nfa_affine_autoregressive_f32.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp]
+    lib.nfa_permute_cols_b32.restype = ctypes.c_int
+    lib.nfa_permute_cols_b32.argtypes = [vp, vp, vp, vp, i64, i32, vp]
+    lib.nfa_rowsum_f32.restype = ctypes.c_int
+    lib.nfa_rowsum_f32.argtypes = [vp, vp, i64, i64, vp]
+    lib.nfa_standard_normal_log_prob_f32.restype = ctypes.c_int
+    lib.nfa_standard_normal_log_prob_f32.argtypes = [vp, vp, vp, i64, i64, vp]
+
+
+def load():
+    """Loads the shared library (once).  Raises NativeLibraryMissing if it has not been built:
+    run `python -c "import __graft_entry__ as g; g.build()"` or `make -C nflows_amd/csrc`."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                "%s not found; nflows_amd has no fallback path. Build it with "
+                "`make -C nflows_amd/csrc` (hipcc --offload-arch=gfx950)." % LIB_PATH
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        missing = [name for name in EXPORTS if not hasattr(lib, name)]
+        if missing:
+            raise NativeLibraryMissing("%s lacks symbols: %s" % (LIB_PATH, ", ".join(missing)))
+        _declare(lib)
+        if lib.nfa_abi_version() != ABI_VERSION:
+            raise NativeLibraryMissing("ABI version mismatch: library %d, binding %d"
+                                       % (lib.nfa_abi_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def check(code):
+    if code == OK:
+        return
+    lib = load()
+    msg = lib.nfa_strerror(code).decode()
+    if code in (ERR_MIN_BIN_WIDTH, ERR_MIN_BIN_HEIGHT):
+        raise ValueError(msg)  # same type and text as rational_quadratic.py:86-89
+    if code == ERR_HIP:
+        msg += " (hipError_t %d)" % lib.nfa_last_hip_error()
+    raise NativeError(code, msg)
+
+
+def require_device_f32(name, t, dim=None):
+    """The product path runs on the GPU only; anything else fails loudly."""
+    if not torch.is_tensor(t):
+        raise TypeError("%s must be a tensor" % name)
+    if not t.is_cuda:
+        raise NotImplementedError(
+            "nflows_amd: %s is on %s; the MI355X path has no CPU fallback (move it to a HIP device)"
+            % (name, t.device))
+    if t.dtype != torch.float32:
+        raise NotImplementedError("nflows_amd: %s has dtype %s; only float32 is implemented"
+                                  % (name, t.dtype))
+    if dim is not None and t.dim() != dim:
+        raise ValueError("%s must be %d-D, got %d-D" % (name, dim, t.dim()))
+    return t
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_handle(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

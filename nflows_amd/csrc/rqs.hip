@@ -1,0 +1,538 @@
+// Rational-quadratic spline kernels for gfx950 (MI355X): K1 fused coupling layer, K5 elementwise.
+//
+// What is computed, per (sample, transformed feature) -- reference lines are
+// nflows/transforms/splines/rational_quadratic.py unless another file is named:
+//   inside-interval test / identity tails         :26, :38-39
+//   w,h logits / sqrt(hidden)                     coupling.py:554-556
+//   softmax -> min + (1-min*K)*p -> cumsum -> knots, forced end knots, bin sizes as knot
+//   differences                                    :91-98, :106-113
+//   bin search (count of x >= knot, last knot + 1e-6)   utils/torchutils.py:134-136
+//   min_d + softplus(d logits) at the bin's two knots   :100-104, :127-128 (tail logit :33-36)
+//   forward rational-quadratic map + log-derivative     :162-181
+//   inverse (quadratic root) + log-derivative           :132-160
+//   split / scatter / per-sample sum of logabsdet       coupling.py:82-83, :96-98, :293
+//
+// Design: HBM-bound streaming kernel.  One workgroup (4 wave64) owns a tile of
+// R whole samples; the tile's conditioner output (R*d_t*P contiguous floats) and inputs are
+// brought in with aligned 16-byte-per-lane loads into LDS, each lane then evaluates one spline
+// from its own P consecutive LDS words (stride P is odd for even K: conflict-free ds_read_b32),
+// results are scattered into an LDS output tile and leave with aligned 16-byte stores; the
+// per-sample logabsdet is a fixed-order wave shuffle reduction.  No atomics on the data path.
+//
+// Arithmetic follows aten's fp32 CPU kernels step by step (fp contraction is off; division
+// and sqrt are IEEE; cumsum and the softmax denominator accumulate in double exactly like
+// aten's cumsum does), so the only differences from the reference are <= 1 ulp in exp/log.
+
+#include "common.hpp"
+
+#include <math.h>
+
+namespace nfa {
+
+struct RqsDev {
+    int K;          // bins
+    int P;          // params per spline: 3K-1 (linear tails) or 3K+1
+    int linear;     // 1: linear tails
+    float left, right, bottom, top;
+    float span_w, span_h;          // (float)(right-left), (float)(top-bottom)
+    float right_eps, top_eps;      // last knot + 1e-6 (searchsorted)
+    float min_w, min_h, min_d;
+    float om_w, om_h;              // (float)(1 - min*K)
+    float beta, tail_logit, divisor;
+};
+
+// Storage of K values per lane: registers when K is a compile-time constant, the lane's own LDS
+// words (updated in place) otherwise.
+template <int KT>
+struct Slots {
+    float v[KT];
+    __device__ __forceinline__ void bind(float*) {}
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <>
+struct Slots<0> {
+    float* s;
+    __device__ __forceinline__ void bind(float* p) { s = p; }
+    __device__ __forceinline__ float get(int i) const { return s[i]; }
+    __device__ __forceinline__ void set(int i, float x) { s[i] = x; }
+};
+
+// softmax numerators exp(u_i - max) in place, returns the fp32 denominator.
+template <int KT>
+__device__ __forceinline__ float softmax_numerators(Slots<KT>& e, const float* logits, int K,
+                                                    float divisor) {
+#pragma clang fp contract(off)
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < (KT > 0 ? KT : K); ++i) {
+        float u = logits[i];
+        if (divisor != 0.0f) u = u / divisor;
+        e.set(i, u);
+        m = fmaxf(m, u);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < (KT > 0 ? KT : K); ++i) {
+        const float ex = expf(e.get(i) - m);
+        e.set(i, ex);
+        s += (double)ex;
+    }
+    return (float)s;
+}
+
+// Walks the K bins, rebuilding knot_i / knot_{i+1} on the fly.
+//   SEARCH : k <- last i with x >= knot_i (== count-1 for monotone knots), picks that bin's knots
+//   !SEARCH: picks the knots of the given bin k
+template <int KT, bool SEARCH>
+__device__ __forceinline__ void walk_bins(const Slots<KT>& e, int K, float denom, float minbin,
+                                          float om, float span, float lo, float hi, float x, int& k,
+                                          float& knot_lo, float& knot_hi) {
+#pragma clang fp contract(off)
+    double acc = 0.0;
+    float prev = lo;
+#pragma unroll
+    for (int i = 0; i < (KT > 0 ? KT : K); ++i) {
+        const float p = e.get(i) / denom;
+        const float w = minbin + om * p;
+        acc += (double)w;
+        const float c = (float)acc;
+        const float next = (i == (KT > 0 ? KT : K) - 1) ? hi : span * c + lo;
+        const bool take = SEARCH ? (x >= prev) : (i == k);
+        if (take) {
+            if (SEARCH) k = i;
+            knot_lo = prev;
+            knot_hi = next;
+        }
+        prev = next;
+    }
+}
+
+__device__ __forceinline__ float softplus_beta(float x, float beta) {
+#pragma clang fp contract(off)
+    const float xb = x * beta;
+    return xb > 20.0f ? x : log1pf(expf(xb)) / beta;
+}
+
+// One spline evaluation.  `sl` = this lane's P logits in LDS (may be clobbered when KT == 0).
+template <int KT, bool INVERSE>
+__device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, float& y, float& lad) {
+#pragma clang fp contract(off)
+    const int K = KT > 0 ? KT : sp.K;
+    if (sp.linear) {
+        if (!(x >= sp.left && x <= sp.right)) {  // NaN falls outside too
+            y = x;
+            lad = 0.0f;
+            return 0;
+        }
+    } else if (x < sp.left || x > sp.right) {
+        y = x;
+        lad = 0.0f;
+        return NFA_STATUS_OUTSIDE_DOMAIN;
+    }
+
+    Slots<KT> ew, eh;
+    ew.bind(sl);
+    eh.bind(sl + K);
+    const float den_w = softmax_numerators<KT>(ew, sl, K, sp.divisor);
+    const float den_h = softmax_numerators<KT>(eh, sl + K, K, sp.divisor);
+
+    int k = -1;
+    float cw0 = 0.f, cw1 = 0.f, ch0 = 0.f, ch1 = 0.f;
+    if (INVERSE) {
+        walk_bins<KT, true>(eh, K, den_h, sp.min_h, sp.om_h, sp.span_h, sp.bottom, sp.top, x, k, ch0, ch1);
+        if (k < 0 || x >= sp.top_eps) {
+            y = x;
+            lad = 0.0f;
+            return NFA_STATUS_OUTSIDE_DOMAIN;
+        }
+        walk_bins<KT, false>(ew, K, den_w, sp.min_w, sp.om_w, sp.span_w, sp.left, sp.right, x, k, cw0, cw1);
+    } else {
+        walk_bins<KT, true>(ew, K, den_w, sp.min_w, sp.om_w, sp.span_w, sp.left, sp.right, x, k, cw0, cw1);
+        if (k < 0 || x >= sp.right_eps) {
+            y = x;
+            lad = 0.0f;
+            return NFA_STATUS_OUTSIDE_DOMAIN;
+        }
+        walk_bins<KT, false>(eh, K, den_h, sp.min_h, sp.om_h, sp.span_h, sp.bottom, sp.top, x, k, ch0, ch1);
+    }
+
+    const float* sd = sl + 2 * K;
+    float u0, u1;
+    if (sp.linear) {  // logits padded with the tail constant on both sides
+        u0 = (k == 0) ? sp.tail_logit : sd[k - 1];
+        u1 = (k == K - 1) ? sp.tail_logit : sd[k];
+    } else {
+        u0 = sd[k];
+        u1 = sd[k + 1];
+    }
+    const float d0 = sp.min_d + softplus_beta(u0, sp.beta);
+    const float d1 = sp.min_d + softplus_beta(u1, sp.beta);
+
+    const float in_w = cw1 - cw0;
+    const float in_h = ch1 - ch0;
+    const float delta = in_h / in_w;
+    const float s = (d0 + d1) - 2.0f * delta;
+    int status = 0;
+
+    if (INVERSE) {
+        const float yc = x - ch0;
+        const float a = yc * s + in_h * (delta - d0);
+        const float b = in_h * d0 - yc * s;
+        const float c = (-delta) * yc;
+        const float disc = b * b - (4.0f * a) * c;
+        if (!(disc >= 0.0f)) status = NFA_STATUS_NEG_DISCRIMINANT;
+        const float root = (2.0f * c) / ((-b) - sqrtf(disc));
+        y = root * in_w + cw0;
+        const float t1mt = root * (1.0f - root);
+        const float den = delta + s * t1mt;
+        const float omr = 1.0f - root;
+        const float dnum = (delta * delta) * ((d1 * (root * root) + (2.0f * delta) * t1mt) + d0 * (omr * omr));
+        lad = -(logf(dnum) - 2.0f * logf(den));
+    } else {
+        const float theta = (x - cw0) / in_w;
+        const float t1mt = theta * (1.0f - theta);
+        const float num = in_h * (delta * (theta * theta) + d0 * t1mt);
+        const float den = delta + s * t1mt;
+        y = ch0 + num / den;
+        const float omt = 1.0f - theta;
+        const float dnum = (delta * delta) * ((d1 * (theta * theta) + (2.0f * delta) * t1mt) + d0 * (omt * omt));
+        lad = logf(dnum) - 2.0f * logf(den);
+    }
+    return status;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: fused coupling layer
+struct CouplingArgs {
+    const float* x;
+    const float* params;
+    const int64_t* tidx;
+    const int64_t* perm;     // in_perm, may be null
+    const int64_t* scatter;  // out_scatter, may be null
+    float* out;
+    float* lad;
+    int32_t* status;  // may be null
+    int64_t batch;
+    int D;   // features
+    int dt;  // transformed features
+    int R;   // samples per tile
+    FastDiv div_dt, div_D;
+    RqsDev sp;
+    // LDS carve-up (float offsets)
+    int off_x, off_out, off_lad, off_idx;
+};
+
+template <int KT, bool INVERSE>
+__global__ void __launch_bounds__(kBlock) rqs_coupling_kernel(const CouplingArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* s_p = lds;
+    float* s_x = lds + a.off_x;
+    float* s_out = lds + a.off_out;
+    float* s_lad = lds + a.off_lad;
+    int* s_tidx = reinterpret_cast<int*>(lds + a.off_idx);  // [dt]
+    int* s_src = s_tidx + a.dt;                             // [D] source column of each output column
+    int* s_dst = s_src + a.D;                               // [D] output position of each column
+    unsigned char* s_ist = reinterpret_cast<unsigned char*>(s_dst + a.D);  // [D] 1 = transformed
+
+    const int tid = threadIdx.x;
+    const int D = a.D, dt = a.dt, P = a.sp.P;
+    int my_status = 0;
+
+    for (int c = tid; c < D; c += kBlock) {
+        int src = c;
+        if (a.perm) {
+            const int64_t p = a.perm[c];
+            if (p < 0 || p >= D) my_status |= NFA_STATUS_BAD_INDEX;
+            src = (int)(p < 0 ? 0 : (p >= D ? D - 1 : p));
+        }
+        int dst = c;
+        if (a.scatter) {
+            const int64_t p = a.scatter[c];
+            if (p < 0 || p >= D) my_status |= NFA_STATUS_BAD_INDEX;
+            dst = (int)(p < 0 ? 0 : (p >= D ? D - 1 : p));
+        }
+        s_src[c] = src;
+        s_dst[c] = dst;
+        s_ist[c] = 0;
+    }
+    __syncthreads();
+    for (int j = tid; j < dt; j += kBlock) {
+        const int64_t t = a.tidx[j];
+        if (t < 0 || t >= D) my_status |= NFA_STATUS_BAD_INDEX;
+        const int col = (int)(t < 0 ? 0 : (t >= D ? D - 1 : t));
+        s_tidx[j] = col;
+        s_ist[col] = 1;
+    }
+    // (visibility of s_tidx / s_ist is covered by the first barrier inside the loop)
+
+    const int64_t num_tiles = (a.batch + a.R - 1) / a.R;
+    for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+        const int64_t row0 = tile * a.R;
+        const int rows = (int)((a.batch - row0) < a.R ? (a.batch - row0) : a.R);
+        const int nitems = rows * dt;
+
+        const int mp = tile_load(a.params + row0 * (int64_t)dt * P, nitems * P, s_p, tid);
+        const int mx = tile_load(a.x + row0 * D, rows * D, s_x, tid);
+        // the output tile is laid out as the 16-byte aligned image of its global destination
+        float* s_o = s_out + tile_store_offset(a.out + row0 * D);
+        __syncthreads();
+
+        // untouched columns: bit-exact copy (with the fused permutation)
+        for (int e = tid; e < rows * D; e += kBlock) {
+            const int r = (int)fastdiv((uint32_t)e, a.div_D);
+            const int c = e - r * D;
+            if (!s_ist[c]) s_o[e - c + s_dst[c]] = s_x[mx + e - c + s_src[c]];
+        }
+        for (int i = tid; i < nitems; i += kBlock) {
+            const int r = (int)fastdiv((uint32_t)i, a.div_dt);
+            const int j = i - r * dt;
+            const int col = s_tidx[j];
+            const float xin = s_x[mx + r * D + s_src[col]];
+            float y, l;
+            my_status |= rqs_eval<KT, INVERSE>(xin, s_p + mp + i * P, a.sp, y, l);
+            s_o[r * D + s_dst[col]] = y;
+            s_lad[i] = l;
+        }
+        __syncthreads();
+
+        tile_store(a.out + row0 * D, rows * D, s_out, tid);
+        // per-sample logabsdet: wave w reduces rows w, w+4, ...
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int r = wave; r < rows; r += kBlock / kWave) {
+            float v = 0.0f;
+            for (int m = lane; m < dt; m += kWave) v += s_lad[r * dt + m];
+            v = wave_sum(v);
+            if (lane == 0) a.lad[row0 + r] = v;
+        }
+        // next iteration's loads only touch s_p / s_x, whose readers all passed the barrier above;
+        // s_out / s_lad are rewritten only after the next iteration's first barrier.
+    }
+    if (my_status && a.status) atomicOr(a.status, my_status);
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: elementwise functional over n independent elements
+struct ElementwiseArgs {
+    const float* x;
+    const float* uw;
+    const float* uh;
+    const float* ud;
+    int64_t sw, sh, sd;  // row strides (elements)
+    float* y;
+    float* lad;
+    int32_t* status;
+    int64_t n;
+    int packed;  // 1: the three logit arrays are one [n, P] buffer starting at uw
+    int nd;      // derivative logits per element
+    int slot;    // LDS words per element when !packed (odd)
+    RqsDev sp;
+};
+
+template <int KT, bool INVERSE>
+__global__ void __launch_bounds__(kBlock) rqs_elementwise_kernel(const ElementwiseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int P = a.sp.P, K = a.sp.K;
+    int my_status = 0;
+    const int64_t num_tiles = (a.n + kBlock - 1) / kBlock;
+    for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+        const int64_t i0 = tile * kBlock;
+        const int cnt = (int)((a.n - i0) < kBlock ? (a.n - i0) : kBlock);
+        float* mine;
+        if (a.packed) {
+            const int mp = tile_load(a.uw + i0 * P, cnt * P, lds, tid);
+            __syncthreads();
+            mine = lds + mp + tid * P;
+        } else {
+            mine = lds + tid * a.slot;
+            if (tid < cnt) {
+                const int64_t i = i0 + tid;
+                for (int q = 0; q < K; ++q) mine[q] = a.uw[i * a.sw + q];
+                for (int q = 0; q < K; ++q) mine[K + q] = a.uh[i * a.sh + q];
+                for (int q = 0; q < a.nd; ++q) mine[2 * K + q] = a.ud[i * a.sd + q];
+            }
+        }
+        if (tid < cnt) {
+            float y, l;
+            my_status |= rqs_eval<KT, INVERSE>(a.x[i0 + tid], mine, a.sp, y, l);
+            a.y[i0 + tid] = y;
+            a.lad[i0 + tid] = l;
+        }
+        if (a.packed) __syncthreads();  // before the next tile overwrites the LDS image
+    }
+    if (my_status && a.status) atomicOr(a.status, my_status);
+}
+
+// ------------------------------------------------------------------------------------------
+static int make_dev_spec(const nfa_rqs_spec* s, RqsDev* d) {
+    if (!s) return NFA_ERR_INVALID_ARGUMENT;
+    if (s->num_bins < 1 || s->num_bins > 4096) return NFA_ERR_INVALID_ARGUMENT;
+    if (s->tails != NFA_TAILS_NONE && s->tails != NFA_TAILS_LINEAR) return NFA_ERR_INVALID_ARGUMENT;
+    if (s->min_bin_width * s->num_bins > 1.0) return NFA_ERR_MIN_BIN_WIDTH;
+    if (s->min_bin_height * s->num_bins > 1.0) return NFA_ERR_MIN_BIN_HEIGHT;
+    d->K = s->num_bins;
+    d->linear = s->tails == NFA_TAILS_LINEAR;
+    d->P = d->linear ? 3 * d->K - 1 : 3 * d->K + 1;
+    d->left = (float)s->left;
+    d->right = (float)s->right;
+    d->bottom = (float)s->bottom;
+    d->top = (float)s->top;
+    d->span_w = (float)(s->right - s->left);
+    d->span_h = (float)(s->top - s->bottom);
+    d->right_eps = d->right + 1e-6f;
+    d->top_eps = d->top + 1e-6f;
+    d->min_w = (float)s->min_bin_width;
+    d->min_h = (float)s->min_bin_height;
+    d->min_d = (float)s->min_derivative;
+    d->om_w = (float)(1.0 - s->min_bin_width * s->num_bins);
+    d->om_h = (float)(1.0 - s->min_bin_height * s->num_bins);
+    d->beta = (float)s->softplus_beta;
+    d->tail_logit = (float)s->tail_logit;
+    d->divisor = (float)s->wh_divisor;
+    return NFA_OK;
+}
+
+constexpr int kMaxDynLds = 64 * 1024;
+
+template <int KT>
+static int launch_coupling(const CouplingArgs& a, int inverse, dim3 grid, size_t lds, hipStream_t st) {
+    if (inverse)
+        hipLaunchKernelGGL((rqs_coupling_kernel<KT, true>), grid, dim3(kBlock), lds, st, a);
+    else
+        hipLaunchKernelGGL((rqs_coupling_kernel<KT, false>), grid, dim3(kBlock), lds, st, a);
+    NFA_HIP_CHECK(hipGetLastError());
+    return NFA_OK;
+}
+
+template <int KT>
+static int launch_elementwise(const ElementwiseArgs& a, int inverse, dim3 grid, size_t lds, hipStream_t st) {
+    if (inverse)
+        hipLaunchKernelGGL((rqs_elementwise_kernel<KT, true>), grid, dim3(kBlock), lds, st, a);
+    else
+        hipLaunchKernelGGL((rqs_elementwise_kernel<KT, false>), grid, dim3(kBlock), lds, st, a);
+    NFA_HIP_CHECK(hipGetLastError());
+    return NFA_OK;
+}
+
+}  // namespace nfa
+
+using namespace nfa;
+
+extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
+                                    const int64_t* transform_idx, const int64_t* in_perm,
+                                    const int64_t* out_scatter, float* outputs, float* logabsdet,
+                                    int32_t* status, int64_t batch,
+                                    int32_t features, int32_t num_transform, const nfa_rqs_spec* spec,
+                                    int32_t inverse, void* stream) {
+    if (batch < 0 || features < 1 || num_transform < 0 || num_transform > features)
+        return NFA_ERR_INVALID_ARGUMENT;
+    CouplingArgs a;
+    int rc = make_dev_spec(spec, &a.sp);
+    if (rc != NFA_OK) return rc;
+    if (batch == 0) return NFA_OK;
+    if (!inputs || !outputs || !logabsdet || (num_transform > 0 && (!params || !transform_idx)))
+        return NFA_ERR_INVALID_ARGUMENT;
+    if (features > 65535) return NFA_ERR_UNSUPPORTED;
+
+    const int P = a.sp.P, D = features, dt = num_transform;
+    // samples per tile: aim at one item per lane, whole samples, LDS within budget
+    int R = dt > 0 ? kBlock / dt : kBlock / (D < kBlock ? D : kBlock);
+    if (R < 1) R = 1;
+    if ((int64_t)R > batch) R = (int)batch;
+    auto lds_floats = [&](int r, int* ox, int* oo, int* ol, int* oi) {
+        int o = round_up4(r * dt * P) + 4;
+        *ox = o;
+        o += round_up4(r * D) + 4;
+        *oo = o;
+        o += round_up4(r * D) + 4;
+        *ol = o;
+        o += round_up4(r * dt);
+        *oi = o;
+        o += dt + 2 * D + (D + 3) / 4;
+        return o;
+    };
+    int ox, oo, ol, oi;
+    while (R > 1 && (size_t)lds_floats(R, &ox, &oo, &ol, &oi) * 4 > (size_t)kMaxDynLds) R >>= 1;
+    const size_t lds = (size_t)lds_floats(R, &ox, &oo, &ol, &oi) * 4;
+    if (lds > (size_t)kMaxDynLds || (int64_t)R * dt >= 65536 || (int64_t)R * D >= 65536)
+        return NFA_ERR_UNSUPPORTED;
+
+    a.x = inputs;
+    a.params = params;
+    a.tidx = transform_idx;
+    a.perm = in_perm;
+    a.scatter = out_scatter;
+    a.out = outputs;
+    a.lad = logabsdet;
+    a.status = status;
+    a.batch = batch;
+    a.D = D;
+    a.dt = dt;
+    a.R = R;
+    a.div_dt = make_fastdiv((uint32_t)(dt > 0 ? dt : 1));
+    a.div_D = make_fastdiv((uint32_t)D);
+    a.off_x = ox;
+    a.off_out = oo;
+    a.off_lad = ol;
+    a.off_idx = oi;
+
+    const int64_t tiles = (batch + R - 1) / R;
+    const int cus = device_cu_count();
+    int per_cu = (int)((size_t)(160 * 1024) / (lds + 256));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    int64_t g = (int64_t)cus * per_cu;
+    if (g > tiles) g = tiles;
+    const dim3 grid((unsigned)g);
+    hipStream_t st = (hipStream_t)stream;
+    switch (a.sp.K) {
+        case 8: return launch_coupling<8>(a, inverse, grid, lds, st);
+        default: return launch_coupling<0>(a, inverse, grid, lds, st);
+    }
+}
+
+extern "C" int nfa_rqs_elementwise_f32(const float* inputs, const float* uw, int64_t stride_w,
+                                       const float* uh, int64_t stride_h, const float* ud,
+                                       int64_t stride_d, float* outputs, float* logabsdet,
+                                       int32_t* status, int64_t n, const nfa_rqs_spec* spec,
+                                       int32_t inverse, void* stream) {
+    if (n < 0) return NFA_ERR_INVALID_ARGUMENT;
+    ElementwiseArgs a;
+    int rc = make_dev_spec(spec, &a.sp);
+    if (rc != NFA_OK) return rc;
+    if (n == 0) return NFA_OK;
+    const int K = a.sp.K, P = a.sp.P;
+    a.nd = a.sp.linear ? K - 1 : K + 1;
+    if (!inputs || !outputs || !logabsdet || !uw || !uh || (a.nd > 0 && !ud))
+        return NFA_ERR_INVALID_ARGUMENT;
+    a.x = inputs;
+    a.uw = uw;
+    a.uh = uh;
+    a.ud = ud;
+    a.sw = stride_w;
+    a.sh = stride_h;
+    a.sd = stride_d;
+    a.y = outputs;
+    a.lad = logabsdet;
+    a.status = status;
+    a.n = n;
+    a.packed = (uh == uw + K) && (a.nd == 0 || ud == uw + 2 * K) && stride_w == P && stride_h == P &&
+               (a.nd == 0 || stride_d == P);
+    a.slot = P | 1;
+    const size_t lds = a.packed ? (size_t)(round_up4(kBlock * P) + 8) * 4 : (size_t)kBlock * a.slot * 4;
+    if (lds > (size_t)kMaxDynLds) return NFA_ERR_UNSUPPORTED;
+    const int64_t tiles = (n + kBlock - 1) / kBlock;
+    const int cus = device_cu_count();
+    int per_cu = (int)((size_t)(160 * 1024) / (lds + 256));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    int64_t g = (int64_t)cus * per_cu;
+    if (g > tiles) g = tiles;
+    const dim3 grid((unsigned)g);
+    hipStream_t st = (hipStream_t)stream;
+    switch (K) {
+        case 8: return launch_elementwise<8>(a, inverse, grid, lds, st);
+        default: return launch_elementwise<0>(a, inverse, grid, lds, st);
+    }
+}

@@ -1,0 +1,69 @@
+"""Residual conditioner network (stays PyTorch-ROCm: its GEMMs run on MFMA through hipBLASLt).
+
+Parameter names and initialisation order match nflows/nn/nets/resnet.py (`initial_layer`,
+`blocks.{i}.linear_layers.{0,1}`, `blocks.{i}.context_layer`, `blocks.{i}.batch_norm_layers`,
+`final_layer`), so reference checkpoints load unchanged and the same seed gives the same weights.
+Exposes `.hidden_features`, which the spline coupling layer reads (coupling.py:554-556).
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+
+class ResidualBlock(nn.Module):
+    """x + W2 * act(W1 * act(x)), optional batch norm, dropout and GLU context gate
+    (resnet.py:9-52)."""
+
+    def __init__(self, features, context_features, activation=F.relu, dropout_probability=0.0,
+                 use_batch_norm=False, zero_initialization=True):
+        super().__init__()
+        self.activation = activation
+        self.use_batch_norm = use_batch_norm
+        if use_batch_norm:
+            self.batch_norm_layers = nn.ModuleList(nn.BatchNorm1d(features, eps=1e-3) for _ in range(2))
+        if context_features is not None:
+            self.context_layer = nn.Linear(context_features, features)
+        self.linear_layers = nn.ModuleList(nn.Linear(features, features) for _ in range(2))
+        self.dropout = nn.Dropout(p=dropout_probability)
+        if zero_initialization:
+            last = self.linear_layers[-1]
+            nn.init.uniform_(last.weight, -1e-3, 1e-3)
+            nn.init.uniform_(last.bias, -1e-3, 1e-3)
+
+    def forward(self, inputs, context=None):
+        h = inputs
+        for step in range(2):
+            if self.use_batch_norm:
+                h = self.batch_norm_layers[step](h)
+            h = self.activation(h)
+            if step == 1:
+                h = self.dropout(h)
+            h = self.linear_layers[step](h)
+        if context is not None:
+            h = F.glu(torch.cat((h, self.context_layer(context)), dim=1), dim=1)
+        return inputs + h
+
+
+class ResidualNet(nn.Module):
+    """Linear -> num_blocks residual blocks -> Linear, on 1-D feature vectors (resnet.py:55-100)."""
+
+    def __init__(self, in_features, out_features, hidden_features, context_features=None,
+                 num_blocks=2, activation=F.relu, dropout_probability=0.0, use_batch_norm=False):
+        super().__init__()
+        self.hidden_features = hidden_features
+        self.context_features = context_features
+        first_in = in_features if context_features is None else in_features + context_features
+        self.initial_layer = nn.Linear(first_in, hidden_features)
+        self.blocks = nn.ModuleList(
+            ResidualBlock(features=hidden_features, context_features=context_features,
+                          activation=activation, dropout_probability=dropout_probability,
+                          use_batch_norm=use_batch_norm)
+            for _ in range(num_blocks))
+        self.final_layer = nn.Linear(hidden_features, out_features)
+
+    def forward(self, inputs, context=None):
+        h = inputs if context is None else torch.cat((inputs, context), dim=1)
+        h = self.initial_layer(h)
+        for block in self.blocks:
+            h = block(h, context=context)
+        return self.final_layer(h)

@@ -1,0 +1,312 @@
+"""Tensor-level entry points of the MI355X hot path.
+
+Each function validates its arguments the way the reference does (same exception types),
+allocates the outputs with PyTorch's caching allocator, and enqueues ONE HIP kernel from
+libnflows_amd.so on the current stream.  There is no eager / CPU implementation behind these
+functions.
+
+Data-dependent errors
+---------------------
+The reference raises `InputOutsideDomain` (rational_quadratic.py:81-82) and asserts a
+non-negative discriminant (:142) by synchronising with the device.  The kernels record the same
+conditions in a per-device status word instead:
+  * constrained splines (tails=None) check it immediately (a sync, exactly as the reference);
+  * linear-tail splines cannot leave their domain; their inverse records a negative
+    discriminant lazily -- call `check_status()` (or set `set_error_mode("immediate")`).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .errors import InputOutsideDomain
+
+_status_words = {}
+_error_mode = "deferred"
+
+
+def set_error_mode(mode):
+    """"deferred" (default): only conditions the reference would raise on *every* call site sync
+    immediately; "immediate": every spline call reads the status word back (one sync per call)."""
+    global _error_mode
+    if mode not in ("deferred", "immediate"):
+        raise ValueError(mode)
+    _error_mode = mode
+
+
+def _status_word(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    w = _status_words.get(key)
+    if w is None:
+        w = torch.zeros(1, dtype=torch.int32, device=device)
+        _status_words[key] = w
+    return w
+
+
+def check_status(device=None):
+    """Reads (and clears) the device status word; raises what the reference would have raised."""
+    devices = [device] if device is not None else None
+    words = []
+    if devices is None:
+        words = list(_status_words.values())
+    else:
+        words = [_status_word(torch.device(device))]
+    for w in words:
+        bits = int(w.item())
+        if bits:
+            w.zero_()
+            if bits & N.STATUS_BAD_INDEX:
+                raise IndexError("nflows_amd: feature index / permutation entry out of range")
+            if bits & N.STATUS_OUTSIDE_DOMAIN:
+                raise InputOutsideDomain()
+            if bits & N.STATUS_NEG_DISCRIMINANT:
+                raise AssertionError("negative discriminant in rational-quadratic inverse")
+
+
+def _no_grad_guard(*tensors):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError(
+            "nflows_amd: the HIP kernels have no backward yet; evaluate under torch.no_grad() "
+            "(density evaluation / sampling), or detach the inputs")
+
+
+def make_rqs_spec(num_bins, tails, tail_bound=1.0, left=0.0, right=1.0, bottom=0.0, top=1.0,
+                  min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3,
+                  enable_identity_init=False, wh_divisor=0.0):
+    """Builds struct nfa_rqs_spec from the reference functional's keyword arguments
+    (rational_quadratic.py:13-25 / :66-80)."""
+    if tails == "linear":
+        left, right, bottom, top = -tail_bound, tail_bound, -tail_bound, tail_bound
+        t = N.TAILS_LINEAR
+    elif tails is None:
+        t = N.TAILS_NONE
+    else:
+        raise RuntimeError("{} tails are not implemented.".format(tails))
+    if min_bin_width * num_bins > 1.0:
+        raise ValueError("Minimal bin width too large for the number of bins")
+    if min_bin_height * num_bins > 1.0:
+        raise ValueError("Minimal bin height too large for the number of bins")
+    beta = float(np.log(2) / (1 - min_derivative)) if enable_identity_init else 1.0
+    tail_logit = float(np.log(np.exp(1 - min_derivative) - 1))
+    return N.RqsSpec(int(num_bins), t, float(left), float(right), float(bottom), float(top),
+                     float(min_bin_width), float(min_bin_height), float(min_derivative), beta,
+                     tail_logit, float(wh_divisor))
+
+
+def _idx(name, t, device, n=None):
+    if t is None:
+        return None
+    if not torch.is_tensor(t) or t.dtype != torch.int64 or t.dim() != 1:
+        raise TypeError("%s must be a 1-D int64 tensor" % name)
+    if t.device != device:
+        raise ValueError("%s is on %s, inputs on %s" % (name, t.device, device))
+    if n is not None and t.numel() != n:
+        raise ValueError("%s must have %d entries, got %d" % (name, n, t.numel()))
+    return t.contiguous()
+
+
+def _after_spline(spec, inverse, device):
+    if spec.tails == N.TAILS_NONE or _error_mode == "immediate":
+        check_status(device)
+
+
+def rqs_coupling(inputs, params, transform_idx, spec, inverse=False, in_perm=None, out_scatter=None):
+    """K1 -- fused rational-quadratic coupling layer.  inputs [B, D], params [B, d_t*P].
+    Returns (outputs [B, D], logabsdet [B])."""
+    N.require_device_f32("inputs", inputs, 2)
+    N.require_device_f32("transform_params", params, 2)
+    _no_grad_guard(inputs, params)
+    dev = inputs.device
+    B, D = inputs.shape
+    tidx = _idx("transform_features", transform_idx, dev)
+    perm = _idx("in_perm", in_perm, dev, D)
+    scat = _idx("out_scatter", out_scatter, dev, D)
+    dt = tidx.numel()
+    P = 3 * spec.num_bins - 1 if spec.tails == N.TAILS_LINEAR else 3 * spec.num_bins + 1
+    if params.shape[0] != B or params.shape[1] != dt * P:
+        raise ValueError("transform_params must be [%d, %d], got %s" % (B, dt * P, tuple(params.shape)))
+    x = inputs.contiguous()
+    p = params.contiguous()
+    out = torch.empty_like(x)
+    lad = torch.empty(B, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_rqs_coupling_f32(N.ptr(x), N.ptr(p), N.ptr(tidx), N.ptr(perm), N.ptr(scat),
+                                           N.ptr(out), N.ptr(lad), N.ptr(_status_word(dev)), B, D, dt,
+                                           ctypes.byref(spec), int(bool(inverse)), N.stream_handle(dev))
+    if rc == N.ERR_UNSUPPORTED:
+        return _rqs_coupling_unfused(x, p, tidx, perm, scat, spec, inverse)
+    N.check(rc)
+    _after_spline(spec, inverse, dev)
+    return out, lad
+
+
+def _rqs_coupling_unfused(x, p, tidx, perm, scat, spec, inverse):
+    """Layers whose sample does not fit the fused kernel's LDS tile (d_t*P > ~12k floats): the same
+    result from the elementwise spline kernel + row-sum kernel + index copies (all on device)."""
+    if perm is not None:
+        x = permute_cols(x, perm)
+    B, D = x.shape
+    dt = tidx.numel()
+    K = spec.num_bins
+    pr = p.view(B * dt, -1)
+    # the divisor is part of the spec, so the packed [N, P] fast path still applies
+    xt = x.index_select(1, tidx).contiguous()
+    y, l = rqs_elementwise(xt.view(-1), pr[:, :K], pr[:, K:2 * K], pr[:, 2 * K:], spec, inverse)
+    out = x.clone()
+    out[:, tidx] = y.view(B, dt)
+    if scat is not None:
+        out = permute_cols(out, torch.argsort(scat))
+    return out, rowsum(l.view(B, dt))
+
+
+def rqs_elementwise(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives,
+                    spec, inverse=False):
+    """K5 -- elementwise functional on tensors of any leading shape S; logits S+[K], S+[K],
+    S+[K-1 | K+1].  Returns (outputs S, logabsdet S)."""
+    N.require_device_f32("inputs", inputs)
+    for nm, t in (("unnormalized_widths", unnormalized_widths),
+                  ("unnormalized_heights", unnormalized_heights),
+                  ("unnormalized_derivatives", unnormalized_derivatives)):
+        N.require_device_f32(nm, t)
+    _no_grad_guard(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives)
+    dev = inputs.device
+    K = spec.num_bins
+    nd = K - 1 if spec.tails == N.TAILS_LINEAR else K + 1
+    shape = inputs.shape
+    if (unnormalized_widths.shape != shape + (K,) or unnormalized_heights.shape != shape + (K,)
+            or unnormalized_derivatives.shape != shape + (nd,)):
+        raise ValueError("spline logits must have shapes %s+[%d], +[%d], +[%d]" % (tuple(shape), K, K, nd))
+    n = inputs.numel()
+    x = inputs.contiguous().view(-1)
+
+    def rows(t, width):
+        """[n, width] view with unit inner stride and a uniform row stride, copying only if needed."""
+        if width == 0:
+            return t.reshape(n, 0), 1
+        try:
+            v = t.view(n, width) if n else t.reshape(n, width)
+        except RuntimeError:
+            v = t.reshape(n, width)
+        if v.stride(1) != 1 or (n > 1 and v.stride(0) < width):
+            v = v.contiguous()
+        return v, (v.stride(0) if n > 1 else width)
+
+    uw, sw = rows(unnormalized_widths, K)
+    uh, sh = rows(unnormalized_heights, K)
+    ud, sd = rows(unnormalized_derivatives, nd)
+    y = torch.empty_like(x)
+    lad = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_rqs_elementwise_f32(N.ptr(x), N.ptr(uw), sw, N.ptr(uh), sh,
+                                              N.ptr(ud) if nd else N.ptr(uw), sd, N.ptr(y), N.ptr(lad),
+                                              N.ptr(_status_word(dev)), n, ctypes.byref(spec),
+                                              int(bool(inverse)), N.stream_handle(dev))
+    N.check(rc)
+    _after_spline(spec, inverse, dev)
+    return y.view(shape), lad.view(shape)
+
+
+def affine_coupling(inputs, params, transform_idx, activation, inverse=False, scale=None,
+                    in_perm=None, out_scatter=None):
+    """K2 -- fused affine/additive coupling.  params [B, 2*d_t] = [shift | scale logits]
+    (additive: [B, d_t])."""
+    N.require_device_f32("inputs", inputs, 2)
+    N.require_device_f32("transform_params", params, 2)
+    _no_grad_guard(inputs, params, scale)
+    dev = inputs.device
+    B, D = inputs.shape
+    tidx = _idx("transform_features", transform_idx, dev)
+    perm = _idx("in_perm", in_perm, dev, D)
+    scat = _idx("out_scatter", out_scatter, dev, D)
+    dt = tidx.numel()
+    pcols = dt if activation == N.SCALE_ADDITIVE else 2 * dt
+    if params.shape[0] != B or params.shape[1] != pcols:
+        raise ValueError("transform_params must be [%d, %d], got %s" % (B, pcols, tuple(params.shape)))
+    if activation == N.SCALE_GIVEN:
+        N.require_device_f32("scale", scale, 2)
+        if tuple(scale.shape) != (B, dt):
+            raise ValueError("scale must be [%d, %d]" % (B, dt))
+        scale = scale.contiguous()
+    x = inputs.contiguous()
+    p = params.contiguous()
+    out = torch.empty_like(x)
+    lad = torch.empty(B, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_affine_coupling_f32(N.ptr(x), N.ptr(p), N.ptr(scale), N.ptr(tidx), N.ptr(perm),
+                                              N.ptr(scat), N.ptr(out), N.ptr(lad),
+                                              N.ptr(_status_word(dev)), B, D, dt, int(activation),
+                                              int(bool(inverse)), N.stream_handle(dev))
+    N.check(rc)
+    return out, lad
+
+
+def affine_autoregressive(inputs, params, inverse=False):
+    """K2b -- elementwise affine with interleaved [B, D, 2] parameters (scale logit, shift)."""
+    N.require_device_f32("inputs", inputs, 2)
+    N.require_device_f32("autoregressive_params", params)
+    _no_grad_guard(inputs, params)
+    B, D = inputs.shape
+    if params.numel() != B * D * 2:
+        raise ValueError("autoregressive_params must hold %d values" % (B * D * 2))
+    dev = inputs.device
+    x = inputs.contiguous()
+    p = params.contiguous()
+    out = torch.empty_like(x)
+    lad = torch.empty(B, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_affine_autoregressive_f32(N.ptr(x), N.ptr(p), N.ptr(out), N.ptr(lad), B, D,
+                                                    int(bool(inverse)), N.stream_handle(dev))
+    N.check(rc)
+    return out, lad
+
+
+def permute_cols(inputs, permutation):
+    """K4 -- torch.index_select(inputs, 1, permutation) for 2-D tensors of 4-byte elements."""
+    if not torch.is_tensor(inputs) or not inputs.is_cuda:
+        raise NotImplementedError("nflows_amd: inputs must live on a HIP device (no CPU fallback)")
+    if inputs.dim() != 2 or inputs.element_size() != 4:
+        raise NotImplementedError("nflows_amd.permute_cols: 2-D tensors of 4-byte elements only")
+    dev = inputs.device
+    B, D = inputs.shape
+    perm = _idx("permutation", permutation, dev, D)
+    x = inputs.contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_permute_cols_b32(N.ptr(x), N.ptr(perm), N.ptr(out), N.ptr(_status_word(dev)),
+                                           B, D, N.stream_handle(dev))
+    N.check(rc)
+    return out
+
+
+def rowsum(x):
+    """K3 -- torch.sum over everything but the batch dimension."""
+    N.require_device_f32("x", x)
+    _no_grad_guard(x)
+    B = x.shape[0]
+    cols = x.numel() // B if B else 0
+    v = x.contiguous().view(B, cols)
+    out = torch.empty(B, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = N.load().nfa_rowsum_f32(N.ptr(v), N.ptr(out), B, cols, N.stream_handle(x.device))
+    N.check(rc)
+    return out
+
+
+def standard_normal_log_prob(z, logabsdet=None):
+    """-0.5*sum(z^2) - 0.5*D*log(2*pi) (+ logabsdet), one kernel."""
+    N.require_device_f32("inputs", z)
+    _no_grad_guard(z, logabsdet)
+    B = z.shape[0]
+    cols = z.numel() // B if B else 1
+    v = z.contiguous().view(B, cols)
+    if logabsdet is not None:
+        N.require_device_f32("logabsdet", logabsdet, 1)
+        logabsdet = logabsdet.contiguous()
+    out = torch.empty(B, dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        rc = N.load().nfa_standard_normal_log_prob_f32(N.ptr(v), N.ptr(logabsdet), N.ptr(out), B, cols,
+                                                       N.stream_handle(z.device))
+    N.check(rc)
+    return out

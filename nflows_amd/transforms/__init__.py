@@ -1,0 +1,6 @@
+from .base import (CompositeTransform, InputOutsideDomain, InverseNotAvailable, InverseTransform,
+                   Transform)
+from .coupling import (AdditiveCouplingTransform, AffineCouplingTransform, CouplingTransform,
+                       PiecewiseRationalQuadraticCouplingTransform)
+from .permutations import Permutation, RandomPermutation, ReversePermutation
+from . import splines

@@ -1,0 +1,216 @@
+"""Coupling layers on the MI355X kernels.
+
+Drop-in for the ★ classes of nflows/transforms/coupling.py: same constructor signatures, buffer
+names (`identity_features`, `transform_features`) and attributes, so a reference `state_dict`
+loads unchanged.  Per layer the host does exactly three things:
+
+  1. gather the identity half (one small index_select -- the conditioner's input),
+  2. run the conditioner (any nn.Module taking (identity_split, context); PyTorch-ROCm GEMMs),
+  3. launch ONE fused HIP kernel (ops.rqs_coupling / ops.affine_coupling) that does the split,
+     the elementwise transform, the per-sample logabsdet sum and the scatter, optionally with
+     the neighbouring column permutation folded in.
+
+Only 2-D float32 inputs on a HIP device are implemented; 4-D image inputs
+(coupling.py:280-285) and the other piecewise families are out of scope and raise.
+"""
+import warnings
+
+import numpy as np
+import torch
+from torch.nn.functional import softplus
+
+from .. import _native as N
+from .. import ops
+from .base import Transform
+from .splines import rational_quadratic
+
+
+class CouplingTransform(Transform):
+    """Base class: mask bookkeeping, conditioner call and the fused-kernel hand-off.
+
+    mask[i] > 0: feature i is transformed; mask[i] <= 0: passed through (coupling.py:25-63)."""
+
+    supports_fused_permutation = True
+
+    def __init__(self, mask, transform_net_create_fn, unconditional_transform=None):
+        mask = torch.as_tensor(mask)
+        if mask.dim() != 1:
+            raise ValueError("Mask must be a 1-dim tensor.")
+        if mask.numel() <= 0:
+            raise ValueError("Mask can't be empty.")
+        super().__init__()
+        self.features = len(mask)
+        columns = torch.arange(self.features)
+        self.register_buffer("identity_features", columns.masked_select(mask <= 0))
+        self.register_buffer("transform_features", columns.masked_select(mask > 0))
+        assert self.num_identity_features + self.num_transform_features == self.features
+
+        self.transform_net = transform_net_create_fn(
+            self.num_identity_features,
+            self.num_transform_features * self._transform_dim_multiplier(),
+        )
+        if unconditional_transform is None:
+            self.unconditional_transform = None
+        else:
+            self.unconditional_transform = unconditional_transform(features=self.num_identity_features)
+
+    @property
+    def num_identity_features(self):
+        return len(self.identity_features)
+
+    @property
+    def num_transform_features(self):
+        return len(self.transform_features)
+
+    # ------------------------------------------------------------------ shared plumbing
+    def _check_inputs(self, inputs):
+        if inputs.dim() not in [2, 4]:
+            raise ValueError("Inputs must be a 2D or a 4D tensor.")
+        if inputs.shape[1] != self.features:
+            raise ValueError("Expected features = {}, got {}.".format(self.features, inputs.shape[1]))
+        if inputs.dim() == 4:
+            raise NotImplementedError(
+                "nflows_amd: 4-D (image) coupling inputs are outside the MI355X hot path")
+        N.require_device_f32("inputs", inputs, 2)
+
+    def forward(self, inputs, context=None, in_perm=None):
+        """outputs[:, identity] = inputs[:, identity]; outputs[:, transform] = f(inputs[:, transform];
+        net(inputs[:, identity])) (coupling.py:73-100).  `in_perm`: treat inputs[:, in_perm] as the
+        layer input (a preceding Permutation, fused)."""
+        self._check_inputs(inputs)
+        id_cols = self.identity_features if in_perm is None else in_perm[self.identity_features]
+        identity_split = inputs.index_select(1, id_cols)
+        transform_params = self.transform_net(identity_split, context)
+        outputs, logabsdet = self._fused_layer(inputs, transform_params, inverse=False, in_perm=in_perm)
+        if self.unconditional_transform is not None:
+            identity_split, logabsdet_identity = self.unconditional_transform(identity_split, context)
+            logabsdet = logabsdet + logabsdet_identity
+            outputs.index_copy_(1, self.identity_features, identity_split)
+        return outputs, logabsdet
+
+    def inverse(self, inputs, context=None, out_scatter=None):
+        """Inverse pass (coupling.py:102-130).  `out_scatter`: store layer column c at
+        outputs[:, out_scatter[c]] (a following Permutation.inverse, fused)."""
+        self._check_inputs(inputs)
+        identity_split = inputs.index_select(1, self.identity_features)
+        logabsdet_identity = None
+        if self.unconditional_transform is not None:
+            identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
+        transform_params = self.transform_net(identity_split, context)
+        outputs, logabsdet = self._fused_layer(inputs, transform_params, inverse=True,
+                                               out_scatter=out_scatter)
+        if self.unconditional_transform is not None:
+            logabsdet = logabsdet + logabsdet_identity
+            cols = self.identity_features if out_scatter is None else out_scatter[self.identity_features]
+            outputs.index_copy_(1, cols, identity_split)
+        return outputs, logabsdet
+
+    def _transform_dim_multiplier(self):
+        """Number of conditioner outputs per transformed feature."""
+        raise NotImplementedError()
+
+    def _fused_layer(self, inputs, transform_params, inverse, in_perm=None, out_scatter=None):
+        raise NotImplementedError()
+
+
+class AffineCouplingTransform(CouplingTransform):
+    """y = x * scale + shift on the transformed half (RealNVP); coupling.py:212-252.
+
+    `scale_activation` may be any callable.  The two predefined ones are evaluated inside the
+    kernel; any other callable is evaluated with PyTorch and the kernel receives the scale."""
+
+    DEFAULT_SCALE_ACTIVATION = lambda x: torch.sigmoid(x + 2) + 1e-3  # noqa: E731
+    GENERAL_SCALE_ACTIVATION = lambda x: (softplus(x) + 1e-3).clamp(0, 3)  # noqa: E731
+
+    def __init__(self, mask, transform_net_create_fn, unconditional_transform=None,
+                 scale_activation=DEFAULT_SCALE_ACTIVATION):
+        self.scale_activation = scale_activation
+        super().__init__(mask, transform_net_create_fn, unconditional_transform)
+
+    def _transform_dim_multiplier(self):
+        return 2
+
+    def _activation_code(self):
+        if self.scale_activation is AffineCouplingTransform.DEFAULT_SCALE_ACTIVATION:
+            return N.SCALE_DEFAULT
+        if self.scale_activation is AffineCouplingTransform.GENERAL_SCALE_ACTIVATION:
+            return N.SCALE_GENERAL
+        return N.SCALE_GIVEN
+
+    def _fused_layer(self, inputs, transform_params, inverse, in_perm=None, out_scatter=None):
+        code = self._activation_code()
+        scale = None
+        if code == N.SCALE_GIVEN:
+            scale = self.scale_activation(transform_params[:, self.num_transform_features:])
+        return ops.affine_coupling(inputs, transform_params, self.transform_features, code,
+                                   inverse=inverse, scale=scale, in_perm=in_perm,
+                                   out_scatter=out_scatter)
+
+
+class AdditiveCouplingTransform(AffineCouplingTransform):
+    """y = x + shift (NICE); logabsdet is exactly zero; coupling.py:255-269."""
+
+    def _transform_dim_multiplier(self):
+        return 1
+
+    def _fused_layer(self, inputs, transform_params, inverse, in_perm=None, out_scatter=None):
+        return ops.affine_coupling(inputs, transform_params, self.transform_features,
+                                   N.SCALE_ADDITIVE, inverse=inverse, in_perm=in_perm,
+                                   out_scatter=out_scatter)
+
+
+class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
+    """Neural-spline-flow coupling layer; coupling.py:502-582.
+
+    Conditioner output per transformed feature: K width logits, K height logits and K-1
+    (tails="linear") or K+1 (tails=None) derivative logits.  Width/height logits are divided by
+    sqrt(hidden_features) of the conditioner when it exposes `hidden_features` /
+    `hidden_channels` (coupling.py:554-559) -- done on the fly inside the kernel, the conditioner
+    output tensor itself is left untouched."""
+
+    def __init__(self, mask, transform_net_create_fn, num_bins=10, tails=None, tail_bound=1.0,
+                 apply_unconditional_transform=False, img_shape=None,
+                 min_bin_width=rational_quadratic.DEFAULT_MIN_BIN_WIDTH,
+                 min_bin_height=rational_quadratic.DEFAULT_MIN_BIN_HEIGHT,
+                 min_derivative=rational_quadratic.DEFAULT_MIN_DERIVATIVE):
+        self.num_bins = num_bins
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.min_derivative = min_derivative
+        self.tails = tails
+        self.tail_bound = tail_bound
+        if apply_unconditional_transform:
+            from .nonlinearities import PiecewiseRationalQuadraticCDF
+
+            def unconditional_transform(features):
+                return PiecewiseRationalQuadraticCDF(
+                    shape=[features] + (img_shape if img_shape else []), num_bins=num_bins,
+                    tails=tails, tail_bound=tail_bound, min_bin_width=min_bin_width,
+                    min_bin_height=min_bin_height, min_derivative=min_derivative)
+        else:
+            unconditional_transform = None
+        super().__init__(mask, transform_net_create_fn, unconditional_transform=unconditional_transform)
+
+    def _transform_dim_multiplier(self):
+        if self.tails == "linear":
+            return self.num_bins * 3 - 1
+        return self.num_bins * 3 + 1
+
+    def _spec(self):
+        if hasattr(self.transform_net, "hidden_features"):
+            divisor = float(np.sqrt(self.transform_net.hidden_features))
+        elif hasattr(self.transform_net, "hidden_channels"):
+            divisor = float(np.sqrt(self.transform_net.hidden_channels))
+        else:
+            warnings.warn("Inputs to the softmax are not scaled down: initialization might be bad.")
+            divisor = 0.0
+        if self.tails is not None and self.tails != "linear":
+            raise RuntimeError("{} tails are not implemented.".format(self.tails))
+        return ops.make_rqs_spec(self.num_bins, self.tails, tail_bound=self.tail_bound,
+                                 min_bin_width=self.min_bin_width,
+                                 min_bin_height=self.min_bin_height,
+                                 min_derivative=self.min_derivative, wh_divisor=divisor)
+
+    def _fused_layer(self, inputs, transform_params, inverse, in_perm=None, out_scatter=None):
+        return ops.rqs_coupling(inputs, transform_params, self.transform_features, self._spec(),
+                                inverse=inverse, in_perm=in_perm, out_scatter=out_scatter)

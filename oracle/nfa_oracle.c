@@ -1,0 +1,369 @@
+/*
+ * oracle/nfa_oracle.c -- TEST INFRASTRUCTURE ONLY.  NOT PRODUCT CODE.
+ *
+ * Plain-C, scalar, single-threaded restatement of the arithmetic on the nflows coupling-layer
+ * hot path.  It exists so that the HIP kernels in nflows_amd/csrc can be checked on a box where
+ * /root/reference is absent.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library; nflows_amd itself never does.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function here against
+ * vectors produced by the real reference (imported from /root/reference in the build container
+ * by tests/golden/make_golden.py, outputs committed under tests/golden/).
+ *
+ * Each function cites the reference lines it restates (paths relative to /root/reference).
+ * The file is compiled twice (REAL=float / REAL=double); the float build rounds after every
+ * arithmetic step exactly where aten's fp32 CPU kernels round (build with -ffp-contract=off),
+ * transcendental functions are evaluated in double and rounded once ("correctly rounded"),
+ * which is within 1 ulp of aten's SLEEF results.  The double build is the fp64 ground truth.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifndef REAL
+#define REAL float
+#endif
+#ifndef SUF
+#define SUF _f32
+#endif
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+#define FN(name) CAT(name, SUF)
+
+/* status bits, identical to include/nflows_amd.h */
+#define ORACLE_STATUS_OUTSIDE_DOMAIN 1
+#define ORACLE_STATUS_NEG_DISCRIMINANT 2
+#define ORACLE_STATUS_BAD_INDEX 4
+
+typedef struct {
+    int32_t num_bins;
+    int32_t tails; /* 0: constrained spline (K+1 derivative logits); 1: linear tails (K-1) */
+    double left, right, bottom, top;
+    double min_bin_width, min_bin_height, min_derivative;
+    double softplus_beta; /* 1, or ln2/(1-min_derivative) when enable_identity_init */
+    double tail_logit;    /* log(exp(1-min_derivative)-1), rational_quadratic.py:34 */
+    double wh_divisor;    /* sqrt(hidden_features) (coupling.py:554-556) or 0 = no scaling */
+} oracle_rqs_spec;
+
+static REAL r_exp(REAL x) { return (REAL)exp((double)x); }
+static REAL r_log(REAL x) { return (REAL)log((double)x); }
+static REAL r_log1p(REAL x) { return (REAL)log1p((double)x); }
+static REAL r_sqrt(REAL x) { return (REAL)sqrt((double)x); }
+
+/* torch.nn.functional.softplus(x, beta, threshold=20) as used at rational_quadratic.py:104,
+ * coupling.py:225, autoregressive.py:101:  x if x*beta > 20 else log1p(exp(x*beta))/beta */
+static REAL softplus(REAL x, REAL beta) {
+    REAL xb = x * beta;
+    if (xb > (REAL)20) return x;
+    return r_log1p(r_exp(xb)) / beta;
+}
+
+/* F.softmax(u, -1) -> min + (1-min*K)*p -> cumsum -> pad 0 -> affine -> forced end knots.
+ * rational_quadratic.py:91-97 (widths) and :106-112 (heights).  knots has K+1 entries.
+ * aten's CPU cumsum of fp32 accumulates in double and rounds every prefix. */
+static void knots_from_logits(const REAL *u, int K, REAL divisor, REAL lo, REAL hi, REAL minbin,
+                              REAL *knots, REAL *scratch) {
+    REAL m = -INFINITY;
+    for (int i = 0; i < K; ++i) {
+        scratch[i] = (divisor != (REAL)0) ? u[i] / divisor : u[i];
+        if (scratch[i] > m) m = scratch[i];
+    }
+    double s = 0.0;
+    for (int i = 0; i < K; ++i) {
+        scratch[i] = r_exp(scratch[i] - m);
+        s += (double)scratch[i];
+    }
+    REAL sum = (REAL)s;
+    REAL one_minus = (REAL)(1.0 - (double)minbin * K); /* python-float arithmetic, then cast */
+    double acc = 0.0;
+    REAL span = (REAL)((double)hi - (double)lo);
+    knots[0] = lo;
+    for (int i = 0; i < K; ++i) {
+        REAL p = scratch[i] / sum;
+        REAL w = minbin + one_minus * p;
+        acc += (double)w;
+        REAL c = (REAL)acc;
+        knots[i + 1] = span * c + lo;
+    }
+    knots[K] = hi;
+}
+
+/* rational_quadratic_spline for ONE element, rational_quadratic.py:66-181.
+ * ud_full points at K+1 derivative logits (already padded for linear tails).
+ * Returns status bits. */
+static int rqs_one(REAL x, const REAL *uw, const REAL *uh, const REAL *ud_full,
+                   const oracle_rqs_spec *sp, int inverse, REAL *y, REAL *lad, int32_t *bin_out) {
+    enum { KMAX = 256 };
+    int K = sp->num_bins;
+    REAL cw[KMAX + 1], ch[KMAX + 1], tmp[KMAX];
+    REAL left = (REAL)sp->left, right = (REAL)sp->right;
+    REAL bottom = (REAL)sp->bottom, top = (REAL)sp->top;
+    REAL div = (REAL)sp->wh_divisor;
+    int status = 0;
+
+    knots_from_logits(uw, K, div, left, right, (REAL)sp->min_bin_width, cw, tmp);
+    knots_from_logits(uh, K, div, bottom, top, (REAL)sp->min_bin_height, ch, tmp);
+
+    /* torchutils.searchsorted, torchutils.py:134-136: last knot += 1e-6, count of >=, minus 1 */
+    const REAL *loc = inverse ? ch : cw;
+    int cnt = 0;
+    for (int j = 0; j <= K; ++j) {
+        REAL kn = loc[j];
+        if (j == K) kn = kn + (REAL)1e-6;
+        if (x >= kn) ++cnt;
+    }
+    int k = cnt - 1;
+    if (bin_out) *bin_out = k;
+    if (k < 0 || k >= K) { /* reference would raise InputOutsideDomain / index error */
+        *y = x;
+        *lad = 0;
+        return ORACLE_STATUS_OUTSIDE_DOMAIN;
+    }
+
+    REAL in_cw = cw[k], in_w = cw[k + 1] - cw[k];       /* :98, :120-121 */
+    REAL in_ch = ch[k], in_h = ch[k + 1] - ch[k];       /* :113, :123, :130 */
+    REAL delta = in_h / in_w;                           /* :124 */
+    REAL beta = (REAL)sp->softplus_beta;
+    REAL mind = (REAL)sp->min_derivative;
+    REAL d0 = mind + softplus(ud_full[k], beta);        /* :104, :127 */
+    REAL d1 = mind + softplus(ud_full[k + 1], beta);    /* :128 */
+    REAL s = (d0 + d1) - (REAL)2 * delta;
+
+    if (inverse) { /* :132-160 */
+        REAL yc = x - in_ch;
+        REAL a = yc * s + in_h * (delta - d0);
+        REAL b = in_h * d0 - yc * s;
+        REAL c = (-delta) * yc;
+        REAL disc = b * b - ((REAL)4 * a) * c;
+        if (!(disc >= (REAL)0)) status |= ORACLE_STATUS_NEG_DISCRIMINANT;
+        REAL root = ((REAL)2 * c) / ((-b) - r_sqrt(disc));
+        *y = root * in_w + in_cw;
+        REAL t1mt = root * ((REAL)1 - root);
+        REAL den = delta + s * t1mt;
+        REAL omr = (REAL)1 - root;
+        REAL dnum = (delta * delta) *
+                    ((d1 * (root * root) + ((REAL)2 * delta) * t1mt) + d0 * (omr * omr));
+        *lad = -(r_log(dnum) - (REAL)2 * r_log(den));
+    } else { /* :162-181 */
+        REAL theta = (x - in_cw) / in_w;
+        REAL t1mt = theta * ((REAL)1 - theta);
+        REAL num = in_h * (delta * (theta * theta) + d0 * t1mt);
+        REAL den = delta + s * t1mt;
+        *y = in_ch + num / den;
+        REAL omt = (REAL)1 - theta;
+        REAL dnum = (delta * delta) *
+                    ((d1 * (theta * theta) + ((REAL)2 * delta) * t1mt) + d0 * (omt * omt));
+        *lad = r_log(dnum) - (REAL)2 * r_log(den);
+    }
+    return status;
+}
+
+/* One element of either functional:
+ *   tails==1: unconstrained_rational_quadratic_spline, rational_quadratic.py:13-63
+ *             (inclusive interval test :26, identity + zero logabsdet outside :38-39,
+ *              derivative logits padded with tail_logit :33-36)
+ *   tails==0: rational_quadratic_spline with a domain check (:81-82). */
+static int rqs_elem(REAL x, const REAL *uw, const REAL *uh, const REAL *ud,
+                    const oracle_rqs_spec *sp, int inverse, REAL *y, REAL *lad, int32_t *bin_out) {
+    enum { KMAX = 256 };
+    int K = sp->num_bins;
+    if (sp->tails == 1) {
+        REAL tb_lo = (REAL)sp->left, tb_hi = (REAL)sp->right;
+        if (!(x >= tb_lo && x <= tb_hi)) {
+            *y = x;
+            *lad = 0;
+            if (bin_out) *bin_out = -1;
+            return 0;
+        }
+        REAL full[KMAX + 1];
+        full[0] = (REAL)sp->tail_logit;
+        for (int i = 0; i < K - 1; ++i) full[i + 1] = ud[i];
+        full[K] = (REAL)sp->tail_logit;
+        return rqs_one(x, uw, uh, full, sp, inverse, y, lad, bin_out);
+    }
+    REAL lo = inverse ? (REAL)sp->bottom : (REAL)sp->left;
+    REAL hi = inverse ? (REAL)sp->top : (REAL)sp->right;
+    (void)lo; (void)hi;
+    /* the reference checks inputs against [left, right] in BOTH directions (:81) */
+    if (x < (REAL)sp->left || x > (REAL)sp->right) {
+        *y = x;
+        *lad = 0;
+        if (bin_out) *bin_out = -1;
+        return ORACLE_STATUS_OUTSIDE_DOMAIN;
+    }
+    return rqs_one(x, uw, uh, ud, sp, inverse, y, lad, bin_out);
+}
+
+/* Elementwise functional over N elements; logits given as three row-strided arrays
+ * (strides in elements).  bins may be NULL. */
+int FN(oracle_rqs_elementwise)(const REAL *x, const REAL *uw, int64_t sw, const REAL *uh, int64_t sh,
+                               const REAL *ud, int64_t sd, int64_t n, const oracle_rqs_spec *sp,
+                               int inverse, REAL *y, REAL *lad, int32_t *bins) {
+    int status = 0;
+    if (sp->num_bins < 1 || sp->num_bins > 256) return -1;
+    for (int64_t i = 0; i < n; ++i)
+        status |= rqs_elem(x[i], uw + i * sw, uh + i * sh, ud + i * sd, sp, inverse, y + i,
+                           lad + i, bins ? bins + i : NULL);
+    return status;
+}
+
+/* torch.sum(x, dim=1) (torchutils.sum_except_batch, torchutils.py:19-24); the oracle
+ * accumulates in double and rounds once, so it is the best fp32 answer, not aten's order. */
+void FN(oracle_rowsum)(const REAL *x, int64_t rows, int64_t cols, REAL *out) {
+    for (int64_t r = 0; r < rows; ++r) {
+        double s = 0.0;
+        for (int64_t c = 0; c < cols; ++c) s += (double)x[r * cols + c];
+        out[r] = (REAL)s;
+    }
+}
+
+/* Permutation._permute on dim 1: out[:, c] = in[:, perm[c]]  (permutations.py:27-39). */
+int FN(oracle_permute_cols)(const REAL *x, const int64_t *perm, int64_t rows, int64_t cols,
+                            REAL *out) {
+    for (int64_t c = 0; c < cols; ++c)
+        if (perm[c] < 0 || perm[c] >= cols) return ORACLE_STATUS_BAD_INDEX;
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < cols; ++c) out[r * cols + c] = x[r * cols + perm[c]];
+    return 0;
+}
+
+/* PiecewiseRationalQuadraticCouplingTransform forward/inverse given the conditioner output:
+ * CouplingTransform.forward/inverse split+scatter (coupling.py:82-83, :96-98, :111-112,
+ * :126-128), params reshape [B, d_t*P] -> [B, d_t, P] (:289), per-feature slices (:550-552),
+ * /sqrt(hidden) on width/height logits (:554-556), functional, row-sum (:293).
+ * in_perm (may be NULL) applies a preceding Permutation: x'[:, c] = x[:, in_perm[c]]
+ * (permutations.py:37); out_scatter (may be NULL) a following Permutation.inverse:
+ * out[:, out_scatter[c]] = y[:, c]  (permutations.py:22-24, :44-45). */
+int FN(oracle_rqs_coupling)(const REAL *x, const REAL *params, const int64_t *transform_idx,
+                            const int64_t *in_perm, const int64_t *out_scatter, int64_t batch, int64_t features,
+                            int64_t num_transform, const oracle_rqs_spec *sp, int inverse,
+                            REAL *out, REAL *logabsdet) {
+    int K = sp->num_bins;
+    if (K < 1 || K > 256) return -1;
+    int64_t P = sp->tails == 1 ? 3 * K - 1 : 3 * K + 1;
+    int status = 0;
+    for (int64_t b = 0; b < batch; ++b) {
+        const REAL *xr = x + b * features;
+        REAL *orow = out + b * features;
+        for (int64_t c = 0; c < features; ++c)
+            orow[out_scatter ? out_scatter[c] : c] = in_perm ? xr[in_perm[c]] : xr[c];
+        double acc = 0.0;
+        for (int64_t j = 0; j < num_transform; ++j) {
+            int64_t col = transform_idx[j];
+            if (col < 0 || col >= features) return ORACLE_STATUS_BAD_INDEX;
+            const REAL *p = params + (b * num_transform + j) * P;
+            REAL xin = in_perm ? xr[in_perm[col]] : xr[col];
+            REAL y, lad;
+            status |= rqs_elem(xin, p, p + K, p + 2 * K, sp, inverse, &y, &lad, NULL);
+            orow[out_scatter ? out_scatter[col] : col] = y;
+            acc += (double)lad;
+        }
+        logabsdet[b] = (REAL)acc;
+    }
+    return status;
+}
+
+/* AffineCouplingTransform / AdditiveCouplingTransform given the conditioner output.
+ * coupling.py:234-252 (shift = first d_t columns, scale logits = last d_t), activations
+ * :224-225, additive :263-269.
+ *   activation 0: sigmoid(u+2)+1e-3   1: clamp(softplus(u)+1e-3, 0, 3)
+ *   activation 2: additive (params has d_t columns; scale == 1, logabsdet == 0 exactly)
+ *   activation 3: `scale` holds a ready-made [B, d_t] scale tensor, params' first d_t cols shift */
+int FN(oracle_affine_coupling)(const REAL *x, const REAL *params, const REAL *scale_in,
+                               const int64_t *transform_idx, const int64_t *in_perm,
+                               const int64_t *out_scatter, int64_t batch, int64_t features,
+                               int64_t num_transform, int activation, int inverse,
+                               REAL *out, REAL *logabsdet) {
+    int64_t pcols = (activation == 2) ? num_transform : 2 * num_transform;
+    for (int64_t b = 0; b < batch; ++b) {
+        const REAL *xr = x + b * features;
+        REAL *orow = out + b * features;
+        for (int64_t c = 0; c < features; ++c)
+            orow[out_scatter ? out_scatter[c] : c] = in_perm ? xr[in_perm[c]] : xr[c];
+        double acc = 0.0;
+        for (int64_t j = 0; j < num_transform; ++j) {
+            int64_t col = transform_idx[j];
+            if (col < 0 || col >= features) return ORACLE_STATUS_BAD_INDEX;
+            REAL shift = params[b * pcols + j];
+            REAL scale;
+            if (activation == 0) {
+                REAL u = params[b * pcols + num_transform + j] + (REAL)2;
+                scale = (REAL)1 / ((REAL)1 + r_exp(-u)) + (REAL)1e-3;
+            } else if (activation == 1) {
+                scale = softplus(params[b * pcols + num_transform + j], (REAL)1) + (REAL)1e-3;
+                if (scale < (REAL)0) scale = 0;
+                if (scale > (REAL)3) scale = 3;
+            } else if (activation == 2) {
+                scale = 1;
+            } else if (activation == 4) { /* autoregressive.py:101 */
+                scale = softplus(params[b * pcols + num_transform + j], (REAL)1) + (REAL)1e-3;
+            } else {
+                scale = scale_in[b * num_transform + j];
+            }
+            REAL xin = in_perm ? xr[in_perm[col]] : xr[col];
+            REAL ls = r_log(scale);
+            if (inverse) {
+                orow[out_scatter ? out_scatter[col] : col] = (xin - shift) / scale;
+                acc -= (double)ls;
+            } else {
+                orow[out_scatter ? out_scatter[col] : col] = xin * scale + shift;
+                acc += (double)ls;
+            }
+        }
+        logabsdet[b] = (REAL)acc;
+    }
+    return 0;
+}
+
+/* StandardNormal._log_prob: -0.5*sum(x^2) - log_z   (distributions/normal.py:23-33). */
+void FN(oracle_standard_normal_log_prob)(const REAL *x, int64_t rows, int64_t cols, REAL *out) {
+    double log_z = 0.5 * (double)cols * log(2.0 * 3.14159265358979323846);
+    for (int64_t r = 0; r < rows; ++r) {
+        double s = 0.0;
+        for (int64_t c = 0; c < cols; ++c) {
+            REAL v = x[r * cols + c];
+            s += (double)(REAL)(v * v);
+        }
+        REAL neg_energy = (REAL)-0.5 * (REAL)s;
+        out[r] = neg_energy - (REAL)log_z; /* 0-dim fp64 buffer is cast to the tensor dtype */
+    }
+}
+
+/* torchutils.searchsorted (utils/torchutils.py:134-136) on explicit knots: the last knot is
+ * nudged by eps, index = (#knots <= x) - 1.  Pins the reference's known-answer test
+ * tests/utils/torchutils_test.py:80-90. */
+void FN(oracle_searchsorted)(const REAL *knots, int64_t num_knots, const REAL *x, int64_t n,
+                             int64_t *idx) {
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t cnt = 0;
+        for (int64_t j = 0; j < num_knots; ++j) {
+            REAL kn = knots[j];
+            if (j == num_knots - 1) kn = kn + (REAL)1e-6;
+            if (x[i] >= kn) ++cnt;
+        }
+        idx[i] = cnt - 1;
+    }
+}
+
+/* MaskedAffineAutoregressiveTransform._elementwise_forward/_inverse (autoregressive.py:96-128):
+ * params [B, D, 2] interleaved, [...,0] = scale logit, [...,1] = shift. */
+void FN(oracle_affine_autoregressive)(const REAL *x, const REAL *params, int64_t batch, int64_t features,
+                                      int inverse, REAL *out, REAL *logabsdet) {
+    for (int64_t b = 0; b < batch; ++b) {
+        double acc = 0.0;
+        for (int64_t c = 0; c < features; ++c) {
+            REAL scale = softplus(params[(b * features + c) * 2], (REAL)1) + (REAL)1e-3;
+            REAL shift = params[(b * features + c) * 2 + 1];
+            REAL ls = r_log(scale);
+            REAL xv = x[b * features + c];
+            if (inverse) {
+                out[b * features + c] = (xv - shift) / scale;
+                acc -= (double)ls;
+            } else {
+                out[b * features + c] = scale * xv + shift;
+                acc += (double)ls;
+            }
+        }
+        logabsdet[b] = (REAL)acc;
+    }
+}

@@ -1,0 +1,410 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by running the REAL reference (bayesiains/nflows at
+/root/reference, imported read-only) on CPU.  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+The reference cannot travel to the GPU box, so the .npz files written next to this script are
+committed; tests compare the C oracle (tests/test_oracle_golden.py) and the HIP path
+(tests/test_gpu_golden.py) against them.  Nothing in nflows_amd imports this file.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+SHIM = os.path.join(os.path.dirname(HERE), "_refshim")
+sys.path.insert(0, SHIM)
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
+from torch import nn  # noqa: E402
+
+from nflows.transforms import splines  # noqa: E402
+from nflows.transforms.base import CompositeTransform, InputOutsideDomain  # noqa: E402
+from nflows.transforms.coupling import (  # noqa: E402
+    AdditiveCouplingTransform,
+    AffineCouplingTransform,
+    PiecewiseRationalQuadraticCouplingTransform,
+)
+from nflows.transforms.permutations import RandomPermutation, ReversePermutation  # noqa: E402
+from nflows.transforms.autoregressive import (  # noqa: E402
+    MaskedAffineAutoregressiveTransform,
+    MaskedPiecewiseRationalQuadraticAutoregressiveTransform,
+)
+from nflows.nn.nets import ResidualNet, MLP  # noqa: E402
+from nflows.flows.base import Flow  # noqa: E402
+from nflows.distributions.normal import StandardNormal  # noqa: E402
+from nflows.utils import torchutils  # noqa: E402
+
+torch.set_num_threads(1)
+warnings.filterwarnings("ignore")
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+# --------------------------------------------------------------------------- functional RQ
+def rqs_cases():
+    out = {}
+    meta = []
+
+    def run(name, x, uw, uh, ud, inverse, **kw):
+        tails = kw.get("tails", "linear")
+        if tails is None:
+            fn = splines.rational_quadratic_spline
+            kw = {k: v for k, v in kw.items() if k != "tails"}
+        else:
+            fn = splines.unconstrained_rational_quadratic_spline
+        y, lad = fn(x.clone(), uw.clone(), uh.clone(), ud.clone(), inverse=inverse, **kw)
+        y64, lad64 = fn(x.double(), uw.double(), uh.double(), ud.double(), inverse=inverse, **kw)
+        out[name + "/x"] = npy(x)
+        out[name + "/uw"] = npy(uw)
+        out[name + "/uh"] = npy(uh)
+        out[name + "/ud"] = npy(ud)
+        out[name + "/y"] = npy(y)
+        out[name + "/lad"] = npy(lad)
+        out[name + "/y64"] = npy(y64)
+        out[name + "/lad64"] = npy(lad64)
+        kw2 = dict(kw)
+        kw2["tails"] = tails
+        meta.append((name, int(inverse), repr(sorted(kw2.items()))))
+
+    g = torch.Generator().manual_seed(20260923)
+
+    def edge(tb):
+        f = np.float32
+        vals = [-tb, tb, np.nextafter(f(tb), f(np.inf)), np.nextafter(f(-tb), f(-np.inf)),
+                np.nextafter(f(tb), f(0)), np.nextafter(f(-tb), f(0)), float("nan"), 1e6, -1e6,
+                0.0, -0.0, float("inf"), float("-inf")]
+        return torch.tensor(vals, dtype=torch.float32)
+
+    for tag, K, tb, n, scale in [("k8_tb3", 8, 3.0, 2048, 2.0), ("k10_tb1", 10, 1.0, 600, 1.0),
+                                 ("k5_tb5", 5, 5.0, 512, 3.0), ("k2_tb3", 2, 3.0, 256, 1.0),
+                                 ("k16_tb4", 16, 4.0, 300, 1.5)]:
+        e = edge(tb)
+        x = torch.cat([tb * torch.randn(n, generator=g), e])
+        N = x.numel()
+        uw = scale * torch.randn(N, K, generator=g)
+        uh = scale * torch.randn(N, K, generator=g)
+        ud = scale * torch.randn(N, K - 1, generator=g)
+        for inv in (False, True):
+            run("unc_%s_%s" % (tag, "inv" if inv else "fwd"), x, uw, uh, ud, inv, tails="linear",
+                tail_bound=tb)
+
+    # non-default minimums, identity-init beta
+    K, tb = 8, 2.0
+    x = tb * 0.8 * torch.randn(400, generator=g)
+    uw, uh, ud = (torch.randn(400, K, generator=g), torch.randn(400, K, generator=g),
+                  torch.randn(400, K - 1, generator=g))
+    for inv in (False, True):
+        run("unc_mins_%d" % inv, x, uw, uh, ud, inv, tails="linear", tail_bound=tb,
+            min_bin_width=1e-2, min_bin_height=2e-2, min_derivative=5e-2)
+        run("unc_idinit_%d" % inv, x, uw, uh, ud, inv, tails="linear", tail_bound=tb,
+            enable_identity_init=True)
+        run("unc_idinit_zero_%d" % inv, x, torch.zeros_like(uw), torch.zeros_like(uh),
+            torch.zeros_like(ud), inv, tails="linear", tail_bound=tb, enable_identity_init=True)
+
+    # extreme logits: softplus threshold (x*beta > 20) and saturated softmax
+    K, tb = 8, 3.0
+    x = tb * torch.randn(512, generator=g)
+    uw = 12 * torch.randn(512, K, generator=g)
+    uh = 12 * torch.randn(512, K, generator=g)
+    ud = 15 * torch.randn(512, K - 1, generator=g)
+    ud[:8, :] = torch.tensor([19.9, 20.0, 20.1, 25.0, -30.0, 40.0, 88.0, -88.0])[:, None]
+    for inv in (False, True):
+        run("unc_extreme_%d" % inv, x, uw, uh, ud, inv, tails="linear", tail_bound=tb)
+
+    # everything in the tails (reference tests/transforms/splines/rational_quadratic_test.py:90-114)
+    x = torch.cat([4 + torch.rand(64, generator=g), -4 - torch.rand(64, generator=g)])
+    uw, uh, ud = (torch.randn(128, 8, generator=g), torch.randn(128, 8, generator=g),
+                  torch.randn(128, 7, generator=g))
+    for inv in (False, True):
+        run("unc_alltails_%d" % inv, x, uw, uh, ud, inv, tails="linear", tail_bound=3.0)
+
+    # constrained spline (tails=None): default unit box and a general box
+    K = 10
+    x = torch.rand(700, generator=g)
+    x[:3] = torch.tensor([0.0, 1.0, 0.5])
+    uw, uh, ud = (torch.randn(700, K, generator=g), torch.randn(700, K, generator=g),
+                  torch.randn(700, K + 1, generator=g))
+    for inv in (False, True):
+        run("con_unit_%d" % inv, x, uw, uh, ud, inv, tails=None)
+    K = 8
+    # the reference checks inputs against [left, right] in both directions
+    x = torch.rand(500, generator=g) * 2.0  # in [0, 2] = [left,right] & [bottom,top] overlap
+    uw, uh, ud = (2 * torch.randn(500, K, generator=g), 2 * torch.randn(500, K, generator=g),
+                  2 * torch.randn(500, K + 1, generator=g))
+    for inv in (False, True):
+        run("con_box_%d" % inv, x, uw, uh, ud, inv, tails=None, left=-1.0, right=2.0, bottom=0.0,
+            top=5.0)
+
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "rqs_functional.npz"), **out)
+    print("rqs_functional:", len(meta), "cases")
+
+
+# --------------------------------------------------------------------------- searchsorted
+def searchsorted_case():
+    # reference tests/utils/torchutils_test.py:80-90
+    bin_locations = torch.linspace(0, 1, 10)
+    left_boundaries = bin_locations[:-1]
+    right_boundaries = bin_locations[:-1] + 0.1
+    mid_points = bin_locations[:-1] + 0.05
+    out = {"knots": npy(bin_locations)}
+    for name, inp in [("left", left_boundaries), ("right", right_boundaries), ("mid", mid_points)]:
+        idx = torchutils.searchsorted(bin_locations[None, :].clone(), inp)
+        out[name + "_in"] = npy(inp)
+        out[name + "_idx"] = npy(idx)
+        assert torch.equal(idx, torch.arange(0, 9))
+    np.savez_compressed(os.path.join(HERE, "searchsorted.npz"), **out)
+    print("searchsorted ok")
+
+
+# --------------------------------------------------------------------------- coupling layers
+class FixedNet(nn.Module):
+    """Stands in for the conditioner: returns a stored tensor (so the fixture pins the coupling
+    arithmetic and not a GEMM)."""
+
+    def __init__(self, table, hidden_features=None):
+        super().__init__()
+        self.table = table
+        if hidden_features is not None:
+            self.hidden_features = hidden_features
+
+    def forward(self, identity, context=None):
+        return self.table.to(identity.dtype).clone()
+
+
+def coupling_cases():
+    out = {}
+    meta = []
+    g = torch.Generator().manual_seed(77)
+
+    def rq(name, D, mask, K, tails, tb, H, B, xgen):
+        d_t = int((torch.as_tensor(mask) > 0).sum())
+        P = 3 * K - 1 if tails == "linear" else 3 * K + 1
+        table = 3.0 * torch.randn(B, d_t * P, generator=g)
+        x = xgen(B, D)
+        for dt_name, dt in (("", torch.float32), ("64", torch.float64)):
+            for inv in (False, True):
+                t = PiecewiseRationalQuadraticCouplingTransform(
+                    mask, lambda i, o: FixedNet(table, H), num_bins=K, tails=tails, tail_bound=tb)
+                fn = t.inverse if inv else t.forward
+                y, lad = fn(x.to(dt))
+                out["%s/%s_y%s" % (name, "inv" if inv else "fwd", dt_name)] = npy(y)
+                out["%s/%s_lad%s" % (name, "inv" if inv else "fwd", dt_name)] = npy(lad)
+        out[name + "/x"] = npy(x)
+        out[name + "/params"] = npy(table)
+        out[name + "/transform_idx"] = npy(t.transform_features)
+        out[name + "/identity_idx"] = npy(t.identity_features)
+        meta.append((name, "rq", repr(dict(D=D, K=K, tails=tails, tail_bound=tb, hidden=H, B=B))))
+
+    rq("rq_d64_k8", 64, torchutils.create_alternating_binary_mask(64, even=True), 8, "linear", 3.0,
+       128, 96, lambda B, D: torch.randn(B, D, generator=g) * 1.5)
+    rq("rq_d64_k8_odd", 64, torchutils.create_alternating_binary_mask(64, even=False), 8, "linear",
+       3.0, 128, 33, lambda B, D: torch.randn(B, D, generator=g) * 1.5)
+    rq("rq_d7_k4_none", 7, torch.tensor([1, 0, 0, 1, 1, 0, 1]), 4, None, 1.0, None, 40,
+       lambda B, D: torch.rand(B, D, generator=g))
+    rq("rq_d10_k10_mid", 10, torchutils.create_mid_split_binary_mask(10), 10, "linear", 1.0, 30, 50,
+       lambda B, D: torch.randn(B, D, generator=g))
+    rq("rq_d5_k5", 5, torch.tensor([0, 1, 1, 0, 1]), 5, "linear", 2.0, 16, 257,
+       lambda B, D: 2 * torch.randn(B, D, generator=g))
+    rq("rq_d96_k6", 96, torchutils.create_alternating_binary_mask(96, even=True), 6, "linear", 4.0,
+       64, 21, lambda B, D: 2 * torch.randn(B, D, generator=g))
+
+    def affine(name, D, mask, B, kind):
+        d_t = int((torch.as_tensor(mask) > 0).sum())
+        mult = 1 if kind == "additive" else 2
+        table = 2.0 * torch.randn(B, d_t * mult, generator=g)
+        x = torch.randn(B, D, generator=g)
+        for dt_name, dt in (("", torch.float32), ("64", torch.float64)):
+            for inv in (False, True):
+                if kind == "additive":
+                    t = AdditiveCouplingTransform(mask, lambda i, o: FixedNet(table))
+                elif kind == "general":
+                    t = AffineCouplingTransform(
+                        mask, lambda i, o: FixedNet(table),
+                        scale_activation=AffineCouplingTransform.GENERAL_SCALE_ACTIVATION)
+                else:
+                    t = AffineCouplingTransform(mask, lambda i, o: FixedNet(table))
+                fn = t.inverse if inv else t.forward
+                y, lad = fn(x.to(dt))
+                out["%s/%s_y%s" % (name, "inv" if inv else "fwd", dt_name)] = npy(y)
+                out["%s/%s_lad%s" % (name, "inv" if inv else "fwd", dt_name)] = npy(lad)
+        out[name + "/x"] = npy(x)
+        out[name + "/params"] = npy(table)
+        out[name + "/transform_idx"] = npy(t.transform_features)
+        meta.append((name, "affine_" + kind, repr(dict(D=D, B=B))))
+
+    for kind in ("default", "general", "additive"):
+        affine("aff_d32_" + kind, 32, torchutils.create_alternating_binary_mask(32, even=True), 80, kind)
+        affine("aff_d5_" + kind, 5, torch.tensor([1, 0, 1, 1, 0]), 37, kind)
+
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "coupling.npz"), **out)
+    print("coupling:", len(meta), "cases")
+
+
+# --------------------------------------------------------------------------- whole flows
+def state_to_np(prefix, module, out):
+    for k, v in module.state_dict().items():
+        out[prefix + "/sd/" + k] = npy(v)
+
+
+class MLPConditioner(nn.Module):
+    """coupling conditioners take (inputs, context); the reference MLP does not."""
+
+    def __init__(self, i, o, hidden):
+        super().__init__()
+        self.mlp = MLP([i], [o], hidden)
+
+    def forward(self, x, context=None):
+        return self.mlp(x)
+
+
+def flow_cases():
+    out = {}
+    meta = []
+
+    def finish(name, flow, x, noise, cfg):
+        flow.eval()
+        with torch.no_grad():
+            lp = flow.log_prob(x)
+            z, lad = flow._transform(x)
+            xs, lad_inv = flow._transform.inverse(noise)
+            f64 = flow.double()
+            lp64 = f64.log_prob(x.double())
+            z64, lad64 = f64._transform(x.double())
+            xs64, ladi64 = f64._transform.inverse(noise.double())
+            flow.float()
+        state_to_np(name, flow, out)
+        for k, v in dict(x=x, noise=noise, log_prob=lp, z=z, lad=lad, inv_x=xs, inv_lad=lad_inv,
+                         log_prob64=lp64, z64=z64, lad64=lad64, inv_x64=xs64,
+                         inv_lad64=ladi64).items():
+            out[name + "/" + k] = npy(v)
+        meta.append((name, repr(cfg)))
+
+    # cfg-4 shaped RQ-NSF coupling flow, shrunk
+    for name, L, D, K, H, B in [("nsf_small", 4, 8, 4, 16, 64), ("nsf_d64", 2, 64, 8, 32, 40)]:
+        torch.manual_seed(0)
+        layers = []
+        for i in range(L):
+            layers.append(RandomPermutation(D))
+            layers.append(PiecewiseRationalQuadraticCouplingTransform(
+                mask=torchutils.create_alternating_binary_mask(D, even=(i % 2 == 0)),
+                transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=H, num_blocks=2),
+                num_bins=K, tails="linear", tail_bound=3.0))
+        flow = Flow(CompositeTransform(layers), StandardNormal([D]))
+        # make the conditioner outputs non-trivial (default init gives near-identity splines)
+        with torch.no_grad():
+            for p_name, p in flow.named_parameters():
+                if "final_layer" in p_name or "linear_layers.1" in p_name:
+                    p.mul_(40.0) if "linear_layers.1" in p_name else p.mul_(6.0)
+        g = torch.Generator().manual_seed(1234)
+        x = torch.randn(B, D, generator=g)
+        noise = torch.randn(B, D, generator=g)
+        finish(name, flow, x, noise, dict(kind="rq_nsf", L=L, D=D, K=K, H=H, B=B, tail_bound=3.0))
+
+    # cfg-2 shaped affine coupling flow, shrunk
+    torch.manual_seed(1)
+    D, L, B = 12, 4, 50
+    layers = []
+    for i in range(L):
+        layers.append(AffineCouplingTransform(
+            mask=torchutils.create_alternating_binary_mask(D, even=(i % 2 == 0)),
+            transform_net_create_fn=lambda i_, o_: MLPConditioner(i_, o_, [24, 24])))
+        layers.append(ReversePermutation(D))
+    flow = Flow(CompositeTransform(layers), StandardNormal([D]))
+    g = torch.Generator().manual_seed(99)
+    finish("affine_small", flow, torch.randn(B, D, generator=g), torch.randn(B, D, generator=g),
+           dict(kind="affine", L=L, D=D, hidden=[24, 24], B=B))
+
+    # cfg-1: README moons flow  (README.md:41-51 of the reference), 2 layers
+    torch.manual_seed(2)
+    layers = []
+    for _ in range(2):
+        layers.append(MaskedAffineAutoregressiveTransform(features=2, hidden_features=4))
+        layers.append(RandomPermutation(features=2))
+    flow = Flow(CompositeTransform(layers), StandardNormal([2]))
+    g = torch.Generator().manual_seed(5)
+    finish("moons_maf", flow, torch.randn(128, 2, generator=g), torch.randn(128, 2, generator=g),
+           dict(kind="maf", L=2, D=2, H=4, B=128))
+
+    # cfg-5 shaped autoregressive RQ spline, shrunk
+    torch.manual_seed(3)
+    D, K, H, B = 12, 8, 32, 48
+    t = MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
+        features=D, hidden_features=H, num_bins=K, tails="linear", tail_bound=3.0, num_blocks=2)
+    with torch.no_grad():
+        for p_name, p in t.named_parameters():
+            if "final_layer" in p_name:
+                p.mul_(5.0)
+    flow = Flow(CompositeTransform([t]), StandardNormal([D]))
+    g = torch.Generator().manual_seed(6)
+    finish("ar_rq_small", flow, 1.5 * torch.randn(B, D, generator=g), torch.randn(B, D, generator=g),
+           dict(kind="ar_rq", D=D, K=K, H=H, B=B, tail_bound=3.0, num_blocks=2))
+
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "flows.npz"), **out)
+    print("flows:", len(meta), "cases")
+
+
+# --------------------------------------------------------------------------- permutations / misc
+def misc_cases():
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(33, 64, generator=g)
+    perm = torch.randperm(64, generator=g)
+    from nflows.transforms.permutations import Permutation
+    p = Permutation(perm)
+    y, lad = p(x)
+    xi, _ = p.inverse(x)
+    out.update(perm_x=npy(x), perm=npy(perm), perm_fwd=npy(y), perm_inv=npy(xi), perm_lad=npy(lad))
+    v = torch.randn(70, 32, generator=g)
+    out.update(rowsum_x=npy(v), rowsum=npy(torchutils.sum_except_batch(v)))
+    n = StandardNormal([64])
+    out.update(normal_lp=npy(n.log_prob(x)))
+    for feats in (7, 8, 64):
+        out["mask_alt_even_%d" % feats] = npy(torchutils.create_alternating_binary_mask(feats, even=True))
+        out["mask_alt_odd_%d" % feats] = npy(torchutils.create_alternating_binary_mask(feats, even=False))
+        out["mask_mid_%d" % feats] = npy(torchutils.create_mid_split_binary_mask(feats))
+    np.savez_compressed(os.path.join(HERE, "misc.npz"), **out)
+    print("misc ok")
+
+
+def error_surface():
+    """Record which exceptions the reference raises so tests can assert the same."""
+    rec = {}
+    x = torch.tensor([0.5, 1.5])
+    uw = torch.zeros(2, 4)
+    try:
+        splines.rational_quadratic_spline(x, uw, uw, torch.zeros(2, 5))
+    except InputOutsideDomain:
+        rec["outside_domain"] = "InputOutsideDomain"
+    try:
+        splines.rational_quadratic_spline(torch.tensor([0.5]), torch.zeros(1, 4), torch.zeros(1, 4),
+                                          torch.zeros(1, 5), min_bin_width=0.3)
+    except ValueError as e:
+        rec["min_width"] = str(e)
+    try:
+        splines.unconstrained_rational_quadratic_spline(torch.tensor([0.5]), torch.zeros(1, 4),
+                                                        torch.zeros(1, 4), torch.zeros(1, 3),
+                                                        tails="cubic")
+    except RuntimeError as e:
+        rec["tails"] = str(e)
+    np.savez_compressed(os.path.join(HERE, "errors.npz"), **{k: np.array(v) for k, v in rec.items()})
+    print("errors:", rec)
+
+
+if __name__ == "__main__":
+    rqs_cases()
+    searchsorted_case()
+    coupling_cases()
+    flow_cases()
+    misc_cases()
+    error_surface()

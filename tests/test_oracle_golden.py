@@ -1,0 +1,121 @@
+"""Pins the CPU oracle (oracle/nfa_oracle.c) against vectors produced by the real reference
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import LAD_TOL, OUT_TOL, assert_fp32_parity, parse_kwargs
+from oracle import capi
+
+
+@pytest.fixture(scope="module")
+def rqs(golden_dir):
+    return np.load(os.path.join(golden_dir, "rqs_functional.npz"))
+
+
+def _cases(golden_dir, fname):
+    g = np.load(os.path.join(golden_dir, fname))
+    return g, [tuple(r) for r in g["meta"]]
+
+
+def test_rqs_functional_fp64_matches_reference_fp64(rqs):
+    """The double build of the oracle restates the algorithm: agrees with the reference run in
+    float64 to 1e-10 on every case (this is the check that the restatement is the same maths)."""
+    for name, inv, kw in rqs["meta"]:
+        kw = parse_kwargs(kw)
+        x, uw, uh, ud = (rqs[name + "/" + k].astype(np.float64) for k in ("x", "uw", "uh", "ud"))
+        spec = capi.make_spec(uw.shape[-1], **kw)
+        y, lad, st = capi.rqs_elementwise(x, uw, uh, ud, spec, inverse=bool(int(inv)))
+        ry, rl = rqs[name + "/y64"], rqs[name + "/lad64"]
+        assert st == 0, name
+        assert np.array_equal(np.isnan(y), np.isnan(ry)), name
+        fin = np.isfinite(ry)
+        assert np.abs(y[fin] - ry[fin]).max() <= 1e-10, name
+        assert np.abs(lad[fin] - rl[fin]).max() <= 1e-10, name
+        assert np.array_equal(y[~fin & ~np.isnan(ry)], ry[~fin & ~np.isnan(ry)]), name
+
+
+def test_rqs_functional_fp32_matches_reference_fp32(rqs):
+    for name, inv, kw in rqs["meta"]:
+        kw = parse_kwargs(kw)
+        x, uw, uh, ud = (rqs[name + "/" + k] for k in ("x", "uw", "uh", "ud"))
+        spec = capi.make_spec(uw.shape[-1], **kw)
+        y, lad, st = capi.rqs_elementwise(x, uw, uh, ud, spec, inverse=bool(int(inv)))
+        assert st == 0, name
+        assert_fp32_parity(y, rqs[name + "/y"], rqs[name + "/y64"], OUT_TOL, name + " y", bulk=0.97)
+        assert_fp32_parity(lad, rqs[name + "/lad"], rqs[name + "/lad64"], LAD_TOL, name + " lad", bulk=0.97)
+        # pass-through elements are bit-exact, logabsdet exactly 0 there (A2)
+        if kw.get("tails") == "linear":
+            tb = np.float32(kw["tail_bound"])
+            outside = ~((x >= -tb) & (x <= tb))
+            assert np.array_equal(y[outside].view(np.uint32), x[outside].view(np.uint32)), name
+            assert np.all(lad[outside] == 0), name
+
+
+def test_searchsorted_known_answer(golden_dir):
+    """reference tests/utils/torchutils_test.py:80-90"""
+    g = np.load(os.path.join(golden_dir, "searchsorted.npz"))
+    for which in ("left", "right", "mid"):
+        idx = capi.searchsorted(g["knots"], g[which + "_in"])
+        assert np.array_equal(idx, g[which + "_idx"])
+        assert np.array_equal(idx, np.arange(9))
+
+
+def test_coupling_layers(golden_dir):
+    g, meta = _cases(golden_dir, "coupling.npz")
+    for name, kind, cfg in meta:
+        cfg = parse_kwargs(cfg)
+        x, params, tidx = g[name + "/x"], g[name + "/params"], g[name + "/transform_idx"]
+        for direction, inv in (("fwd", False), ("inv", True)):
+            ry, rl = g["%s/%s_y" % (name, direction)], g["%s/%s_lad" % (name, direction)]
+            ry64, rl64 = g["%s/%s_y64" % (name, direction)], g["%s/%s_lad64" % (name, direction)]
+            for dt in (np.float32, np.float64):
+                if kind == "rq":
+                    H = cfg["hidden"]
+                    spec = capi.make_spec(cfg["K"], tails=cfg["tails"], tail_bound=cfg["tail_bound"],
+                                          wh_divisor=float(np.sqrt(H)) if H else 0.0)
+                    y, lad, st = capi.rqs_coupling(x.astype(dt), params.astype(dt), tidx, spec, inverse=inv)
+                else:
+                    act = {"affine_default": capi.AFFINE_DEFAULT, "affine_general": capi.AFFINE_GENERAL,
+                           "affine_additive": capi.AFFINE_ADDITIVE}[kind]
+                    y, lad, st = capi.affine_coupling(x.astype(dt), params.astype(dt), tidx, act, inverse=inv)
+                assert st == 0, name
+                if dt is np.float64:
+                    assert np.abs(y - ry64).max() <= 1e-10, (name, direction)
+                    assert np.abs(lad - rl64).max() <= 1e-9, (name, direction)
+                else:
+                    assert_fp32_parity(y, ry, ry64, OUT_TOL, name + direction + " y", bulk=0.97)
+                    assert_fp32_parity(lad, rl, rl64, 2 * LAD_TOL, name + direction + " lad", bulk=0.9)
+                    ident = np.setdiff1d(np.arange(x.shape[1]), tidx)
+                    assert np.array_equal(y[:, ident], x[:, ident]), name
+                    if kind == "affine_additive":
+                        assert np.all(lad == 0), name
+
+
+def test_misc(golden_dir):
+    g = np.load(os.path.join(golden_dir, "misc.npz"))
+    out, st = capi.permute_cols(g["perm_x"], g["perm"])
+    assert st == 0 and np.array_equal(out, g["perm_fwd"])
+    out, _ = capi.permute_cols(g["perm_x"], np.argsort(g["perm"]))
+    assert np.array_equal(out, g["perm_inv"])
+    assert np.abs(capi.rowsum(g["rowsum_x"]) - g["rowsum"]).max() <= 4e-6
+    assert np.abs(capi.standard_normal_log_prob(g["perm_x"]) - g["normal_lp"]).max() <= 3e-5
+
+
+def test_fused_permutation_equals_sequence(golden_dir):
+    """in_perm / out_scatter in the oracle are exactly Permutation then layer / layer then
+    Permutation.inverse."""
+    g, meta = _cases(golden_dir, "coupling.npz")
+    name = "rq_d64_k8"
+    cfg = parse_kwargs([m for m in meta if m[0] == name][0][2])
+    x, params, tidx = g[name + "/x"], g[name + "/params"], g[name + "/transform_idx"]
+    spec = capi.make_spec(cfg["K"], tails=cfg["tails"], tail_bound=cfg["tail_bound"],
+                          wh_divisor=float(np.sqrt(cfg["hidden"])))
+    perm = np.random.RandomState(0).permutation(x.shape[1])
+    y_seq, lad_seq, _ = capi.rqs_coupling(x[:, perm], params, tidx, spec)
+    y_f, lad_f, _ = capi.rqs_coupling(x, params, tidx, spec, in_perm=perm)
+    assert np.array_equal(y_seq, y_f) and np.array_equal(lad_seq, lad_f)
+    y0, lad0, _ = capi.rqs_coupling(x, params, tidx, spec, inverse=True)
+    y_s, lad_s, _ = capi.rqs_coupling(x, params, tidx, spec, inverse=True, out_scatter=perm)
+    assert np.array_equal(y0[:, np.argsort(perm)], y_s) and np.array_equal(lad0, lad_s)
