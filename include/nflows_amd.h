@@ -114,12 +114,14 @@ int nfa_rqs_coupling_f32(const float *inputs, const float *params, const int64_t
  *   splines/rational_quadratic.py:13-63 / :66-181, as called from
  *   autoregressive.py:453-489 and nonlinearities.py:431-467.
  *   inputs, outputs, logabsdet: [n];  logits: row i at uw + i*stride_w (K floats),
- *   uh + i*stride_h (K), ud + i*stride_d (K-1 or K+1); strides in elements.
+ *   uh + i*stride_h (K), ud + i*stride_d (num_derivatives floats); strides in elements.
+ *   num_derivatives = K-1 (linear tails) or K+1; larger values are accepted like the reference
+ *   accepts them (it pads and gathers by bin index, extra logits are never read).
  */
 int nfa_rqs_elementwise_f32(const float *inputs, const float *unnormalized_widths, int64_t stride_w,
                             const float *unnormalized_heights, int64_t stride_h,
-                            const float *unnormalized_derivatives, int64_t stride_d, float *outputs,
-                            float *logabsdet, int32_t *status, int64_t n, const nfa_rqs_spec *spec,
+                            const float *unnormalized_derivatives, int64_t stride_d,
+                            int32_t num_derivatives, float *outputs, float *logabsdet, int32_t *status, int64_t n, const nfa_rqs_spec *spec,
                             int32_t inverse, void *stream);
 
 /*

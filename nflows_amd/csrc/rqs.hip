@@ -31,7 +31,8 @@ namespace nfa {
 
 struct RqsDev {
     int K;          // bins
-    int P;          // params per spline: 3K-1 (linear tails) or 3K+1
+    int P;          // params per spline: 2K + nd
+    int nd;         // derivative logits per spline: K-1 (linear tails) / K+1, or more (extras unused)
     int linear;     // 1: linear tails
     float left, right, bottom, top;
     float span_w, span_h;          // (float)(right-left), (float)(top-bottom)
@@ -161,7 +162,7 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
     float u0, u1;
     if (sp.linear) {  // logits padded with the tail constant on both sides
         u0 = (k == 0) ? sp.tail_logit : sd[k - 1];
-        u1 = (k == K - 1) ? sp.tail_logit : sd[k];
+        u1 = (k >= sp.nd) ? sp.tail_logit : sd[k];  // padded index k+1 past the given logits
     } else {
         u0 = sd[k];
         u1 = sd[k + 1];
@@ -326,6 +327,7 @@ struct ElementwiseArgs {
     int packed;  // 1: the three logit arrays are one [n, P] buffer starting at uw
     int nd;      // derivative logits per element
     int slot;    // LDS words per element when !packed (odd)
+    int T;       // elements per tile (<= kBlock; smaller when K is large)
     RqsDev sp;
 };
 
@@ -335,10 +337,10 @@ __global__ void __launch_bounds__(kBlock) rqs_elementwise_kernel(const Elementwi
     const int tid = threadIdx.x;
     const int P = a.sp.P, K = a.sp.K;
     int my_status = 0;
-    const int64_t num_tiles = (a.n + kBlock - 1) / kBlock;
+    const int64_t num_tiles = (a.n + a.T - 1) / a.T;
     for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-        const int64_t i0 = tile * kBlock;
-        const int cnt = (int)((a.n - i0) < kBlock ? (a.n - i0) : kBlock);
+        const int64_t i0 = tile * a.T;
+        const int cnt = (int)((a.n - i0) < a.T ? (a.n - i0) : a.T);
         float* mine;
         if (a.packed) {
             const int mp = tile_load(a.uw + i0 * P, cnt * P, lds, tid);
@@ -373,7 +375,8 @@ static int make_dev_spec(const nfa_rqs_spec* s, RqsDev* d) {
     if (s->min_bin_height * s->num_bins > 1.0) return NFA_ERR_MIN_BIN_HEIGHT;
     d->K = s->num_bins;
     d->linear = s->tails == NFA_TAILS_LINEAR;
-    d->P = d->linear ? 3 * d->K - 1 : 3 * d->K + 1;
+    d->nd = d->linear ? d->K - 1 : d->K + 1;
+    d->P = 2 * d->K + d->nd;
     d->left = (float)s->left;
     d->right = (float)s->right;
     d->bottom = (float)s->bottom;
@@ -494,16 +497,22 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
 
 extern "C" int nfa_rqs_elementwise_f32(const float* inputs, const float* uw, int64_t stride_w,
                                        const float* uh, int64_t stride_h, const float* ud,
-                                       int64_t stride_d, float* outputs, float* logabsdet,
-                                       int32_t* status, int64_t n, const nfa_rqs_spec* spec,
-                                       int32_t inverse, void* stream) {
+                                       int64_t stride_d, int32_t num_derivatives, float* outputs,
+                                       float* logabsdet, int32_t* status, int64_t n,
+                                       const nfa_rqs_spec* spec, int32_t inverse, void* stream) {
     if (n < 0) return NFA_ERR_INVALID_ARGUMENT;
     ElementwiseArgs a;
     int rc = make_dev_spec(spec, &a.sp);
     if (rc != NFA_OK) return rc;
     if (n == 0) return NFA_OK;
-    const int K = a.sp.K, P = a.sp.P;
-    a.nd = a.sp.linear ? K - 1 : K + 1;
+    const int K = a.sp.K;
+    // the reference pads / gathers whatever width it is given (rational_quadratic.py:33-36,
+    // :127-128): more logits than K-1 (K+1) are legal, the extras are never read
+    if (num_derivatives < a.sp.nd || num_derivatives > 3 * K + 8) return NFA_ERR_INVALID_ARGUMENT;
+    a.sp.nd = num_derivatives;
+    a.sp.P = 2 * K + num_derivatives;
+    const int P = a.sp.P;
+    a.nd = num_derivatives;
     if (!inputs || !outputs || !logabsdet || !uw || !uh || (a.nd > 0 && !ud))
         return NFA_ERR_INVALID_ARGUMENT;
     a.x = inputs;
@@ -520,9 +529,15 @@ extern "C" int nfa_rqs_elementwise_f32(const float* inputs, const float* uw, int
     a.packed = (uh == uw + K) && (a.nd == 0 || ud == uw + 2 * K) && stride_w == P && stride_h == P &&
                (a.nd == 0 || stride_d == P);
     a.slot = P | 1;
-    const size_t lds = a.packed ? (size_t)(round_up4(kBlock * P) + 8) * 4 : (size_t)kBlock * a.slot * 4;
+    int T = kBlock;
+    auto lds_bytes = [&](int t) {
+        return a.packed ? (size_t)(round_up4(t * P) + 8) * 4 : (size_t)t * a.slot * 4;
+    };
+    while (T > 1 && lds_bytes(T) > (size_t)kMaxDynLds) T >>= 1;
+    const size_t lds = lds_bytes(T);
     if (lds > (size_t)kMaxDynLds) return NFA_ERR_UNSUPPORTED;
-    const int64_t tiles = (n + kBlock - 1) / kBlock;
+    a.T = T;
+    const int64_t tiles = (n + T - 1) / T;
     const int cus = device_cu_count();
     int per_cu = (int)((size_t)(160 * 1024) / (lds + 256));
     if (per_cu > 8) per_cu = 8;

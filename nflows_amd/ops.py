@@ -173,11 +173,13 @@ def rqs_elementwise(inputs, unnormalized_widths, unnormalized_heights, unnormali
     _no_grad_guard(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives)
     dev = inputs.device
     K = spec.num_bins
-    nd = K - 1 if spec.tails == N.TAILS_LINEAR else K + 1
+    nd_min = K - 1 if spec.tails == N.TAILS_LINEAR else K + 1
+    nd = unnormalized_derivatives.shape[-1] if unnormalized_derivatives.dim() else -1
     shape = inputs.shape
     if (unnormalized_widths.shape != shape + (K,) or unnormalized_heights.shape != shape + (K,)
-            or unnormalized_derivatives.shape != shape + (nd,)):
-        raise ValueError("spline logits must have shapes %s+[%d], +[%d], +[%d]" % (tuple(shape), K, K, nd))
+            or unnormalized_derivatives.shape[:-1] != shape or nd < nd_min):
+        raise ValueError("spline logits must have shapes %s+[%d], +[%d], +[>=%d]"
+                         % (tuple(shape), K, K, nd_min))
     n = inputs.numel()
     x = inputs.contiguous().view(-1)
 
@@ -200,7 +202,7 @@ def rqs_elementwise(inputs, unnormalized_widths, unnormalized_heights, unnormali
     lad = torch.empty_like(x)
     with torch.cuda.device(dev):
         rc = N.load().nfa_rqs_elementwise_f32(N.ptr(x), N.ptr(uw), sw, N.ptr(uh), sh,
-                                              N.ptr(ud) if nd else N.ptr(uw), sd, N.ptr(y), N.ptr(lad),
+                                              N.ptr(ud) if nd else N.ptr(uw), sd, nd, N.ptr(y), N.ptr(lad),
                                               N.ptr(_status_word(dev)), n, ctypes.byref(spec),
                                               int(bool(inverse)), N.stream_handle(dev))
     N.check(rc)

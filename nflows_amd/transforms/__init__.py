@@ -4,3 +4,6 @@ from .coupling import (AdditiveCouplingTransform, AffineCouplingTransform, Coupl
                        PiecewiseRationalQuadraticCouplingTransform)
 from .permutations import Permutation, RandomPermutation, ReversePermutation
 from . import splines
+from .autoregressive import (AutoregressiveTransform, MaskedAffineAutoregressiveTransform,
+                             MaskedPiecewiseRationalQuadraticAutoregressiveTransform)
+from .made import MADE

@@ -1,0 +1,130 @@
+"""Autoregressive transforms of configs 1 and 5 on the MI355X kernels
+(reference: nflows/transforms/autoregressive.py:25-128 and :404-495).
+
+forward : one MADE pass + ONE fused kernel (elementwise map + per-sample logabsdet sum).
+inverse : the reference's D-step fixed-point loop (autoregressive.py:43-52): every step re-runs
+          MADE on the current outputs and the elementwise inverse over all D features; after
+          step t the first t features are final.  Same semantics, same number of passes.
+"""
+import numpy as np
+import torch
+from torch.nn import functional as F
+
+from .. import _native as N
+from .. import ops
+from . import made as made_module
+from .base import Transform
+from .splines import rational_quadratic
+
+
+class AutoregressiveTransform(Transform):
+    def __init__(self, autoregressive_net):
+        super().__init__()
+        self.autoregressive_net = autoregressive_net
+
+    def forward(self, inputs, context=None):
+        params = self.autoregressive_net(inputs, context)
+        return self._elementwise_forward(inputs, params)
+
+    def inverse(self, inputs, context=None):
+        num_inputs = int(np.prod(inputs.shape[1:]))
+        outputs = torch.zeros_like(inputs)
+        logabsdet = None
+        for _ in range(num_inputs):
+            params = self.autoregressive_net(outputs, context)
+            outputs, logabsdet = self._elementwise_inverse(inputs, params)
+        return outputs, logabsdet
+
+    def _output_dim_multiplier(self):
+        raise NotImplementedError()
+
+    def _elementwise_forward(self, inputs, autoregressive_params):
+        raise NotImplementedError()
+
+    def _elementwise_inverse(self, inputs, autoregressive_params):
+        raise NotImplementedError()
+
+
+class MaskedAffineAutoregressiveTransform(AutoregressiveTransform):
+    """MAF layer: y_d = softplus(u_d)+1e-3) * x_d + shift_d with (u, shift) = MADE(x)
+    (autoregressive.py:64-128); parameters interleaved [B, D, 2]."""
+
+    def __init__(self, features, hidden_features, context_features=None, num_blocks=2,
+                 use_residual_blocks=True, random_mask=False, activation=F.relu,
+                 dropout_probability=0.0, use_batch_norm=False):
+        self.features = features
+        net = made_module.MADE(features=features, hidden_features=hidden_features,
+                               context_features=context_features, num_blocks=num_blocks,
+                               output_multiplier=self._output_dim_multiplier(),
+                               use_residual_blocks=use_residual_blocks, random_mask=random_mask,
+                               activation=activation, dropout_probability=dropout_probability,
+                               use_batch_norm=use_batch_norm)
+        self._epsilon = 1e-3
+        super().__init__(net)
+
+    def _output_dim_multiplier(self):
+        return 2
+
+    def _elementwise_forward(self, inputs, autoregressive_params):
+        return ops.affine_autoregressive(inputs, autoregressive_params, inverse=False)
+
+    def _elementwise_inverse(self, inputs, autoregressive_params):
+        return ops.affine_autoregressive(inputs, autoregressive_params, inverse=True)
+
+
+class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTransform):
+    """Autoregressive neural spline layer (autoregressive.py:404-495): per feature 3K-1 / 3K+1
+    logits from MADE, the RQ functional elementwise, logabsdet summed per sample.  Runs as the
+    fused coupling kernel with every feature transformed (d_t = D)."""
+
+    def __init__(self, features, hidden_features, context_features=None, num_bins=10, tails=None,
+                 tail_bound=1.0, num_blocks=2, use_residual_blocks=True, random_mask=False,
+                 activation=F.relu, dropout_probability=0.0, use_batch_norm=False,
+                 min_bin_width=rational_quadratic.DEFAULT_MIN_BIN_WIDTH,
+                 min_bin_height=rational_quadratic.DEFAULT_MIN_BIN_HEIGHT,
+                 min_derivative=rational_quadratic.DEFAULT_MIN_DERIVATIVE):
+        self.num_bins = num_bins
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.min_derivative = min_derivative
+        self.tails = tails
+        self.tail_bound = tail_bound
+        net = made_module.MADE(features=features, hidden_features=hidden_features,
+                               context_features=context_features, num_blocks=num_blocks,
+                               output_multiplier=self._output_dim_multiplier(),
+                               use_residual_blocks=use_residual_blocks, random_mask=random_mask,
+                               activation=activation, dropout_probability=dropout_probability,
+                               use_batch_norm=use_batch_norm)
+        super().__init__(net)
+        self._all_features = None
+
+    def _output_dim_multiplier(self):
+        if self.tails == "linear":
+            return self.num_bins * 3 - 1
+        if self.tails is None:
+            return self.num_bins * 3 + 1
+        raise ValueError
+
+    def _elementwise(self, inputs, autoregressive_params, inverse=False):
+        N.require_device_f32("inputs", inputs, 2)
+        batch, features = inputs.shape
+        divisor = 0.0
+        if hasattr(self.autoregressive_net, "hidden_features"):
+            divisor = float(np.sqrt(self.autoregressive_net.hidden_features))
+        if self.tails not in (None, "linear"):
+            raise ValueError
+        spec = ops.make_rqs_spec(self.num_bins, self.tails, tail_bound=self.tail_bound,
+                                 min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                                 min_derivative=self.min_derivative, wh_divisor=divisor)
+        cols = self._all_features
+        if cols is None or cols.device != inputs.device or cols.numel() != features:
+            cols = torch.arange(features, device=inputs.device)
+            self._all_features = cols
+        params = autoregressive_params.reshape(batch, features * self._output_dim_multiplier())
+        return ops.rqs_coupling(inputs, params, cols, spec, inverse=inverse)
+
+    def _elementwise_forward(self, inputs, autoregressive_params):
+        return self._elementwise(inputs, autoregressive_params)
+
+    def _elementwise_inverse(self, inputs, autoregressive_params):
+        return self._elementwise(inputs, autoregressive_params, inverse=True)

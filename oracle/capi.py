@@ -105,7 +105,7 @@ def rqs_elementwise(x, uw, uh, ud, spec, inverse=False, return_bins=False):
     uwf = np.ascontiguousarray(uw.reshape(-1, K), dtype=dtype)
     uhf = np.ascontiguousarray(uh.reshape(-1, K), dtype=dtype)
     nd = ud.shape[-1]
-    assert nd == (K - 1 if spec.tails == 1 else K + 1), (nd, K, spec.tails)
+    assert nd >= (K - 1 if spec.tails == 1 else K + 1), (nd, K, spec.tails)
     udf = np.ascontiguousarray(ud.reshape(-1, nd), dtype=dtype) if nd else np.zeros((xf.size, 1), dtype)
     n = xf.size
     y = np.empty(n, dtype)
@@ -114,7 +114,7 @@ def rqs_elementwise(x, uw, uh, ud, spec, inverse=False, return_bins=False):
     fn = getattr(lib(), "oracle_rqs_elementwise" + suf)
     fn.restype = ctypes.c_int
     st = fn(_ptr(xf, ct), _ptr(uwf, ct), ctypes.c_int64(K), _ptr(uhf, ct), ctypes.c_int64(K),
-            _ptr(udf, ct), ctypes.c_int64(max(nd, 1) if nd else 1), ctypes.c_int64(n),
+            _ptr(udf, ct), ctypes.c_int64(max(nd, 1) if nd else 1), ctypes.c_int(nd), ctypes.c_int64(n),
             ctypes.byref(spec), ctypes.c_int(int(inverse)), _ptr(y, ct), _ptr(lad, ct),
             _ptr(bins, ctypes.c_int32))
     out = (y.reshape(shape), lad.reshape(shape), st)

@@ -163,7 +163,7 @@ static int rqs_one(REAL x, const REAL *uw, const REAL *uh, const REAL *ud_full,
  *             (inclusive interval test :26, identity + zero logabsdet outside :38-39,
  *              derivative logits padded with tail_logit :33-36)
  *   tails==0: rational_quadratic_spline with a domain check (:81-82). */
-static int rqs_elem(REAL x, const REAL *uw, const REAL *uh, const REAL *ud,
+static int rqs_elem(REAL x, const REAL *uw, const REAL *uh, const REAL *ud, int nd,
                     const oracle_rqs_spec *sp, int inverse, REAL *y, REAL *lad, int32_t *bin_out) {
     enum { KMAX = 256 };
     int K = sp->num_bins;
@@ -175,10 +175,11 @@ static int rqs_elem(REAL x, const REAL *uw, const REAL *uh, const REAL *ud,
             if (bin_out) *bin_out = -1;
             return 0;
         }
+        /* F.pad(ud, (1, 1)) then [...,0] = [...,-1] = constant (:33-36); only padded entries
+         * 0..K are ever gathered, so with nd > K-1 logits the right constant is never reached */
         REAL full[KMAX + 1];
         full[0] = (REAL)sp->tail_logit;
-        for (int i = 0; i < K - 1; ++i) full[i + 1] = ud[i];
-        full[K] = (REAL)sp->tail_logit;
+        for (int i = 1; i <= K; ++i) full[i] = (i - 1 < nd) ? ud[i - 1] : (REAL)sp->tail_logit;
         return rqs_one(x, uw, uh, full, sp, inverse, y, lad, bin_out);
     }
     REAL lo = inverse ? (REAL)sp->bottom : (REAL)sp->left;
@@ -197,12 +198,13 @@ static int rqs_elem(REAL x, const REAL *uw, const REAL *uh, const REAL *ud,
 /* Elementwise functional over N elements; logits given as three row-strided arrays
  * (strides in elements).  bins may be NULL. */
 int FN(oracle_rqs_elementwise)(const REAL *x, const REAL *uw, int64_t sw, const REAL *uh, int64_t sh,
-                               const REAL *ud, int64_t sd, int64_t n, const oracle_rqs_spec *sp,
-                               int inverse, REAL *y, REAL *lad, int32_t *bins) {
+                               const REAL *ud, int64_t sd, int nd, int64_t n,
+                               const oracle_rqs_spec *sp, int inverse, REAL *y, REAL *lad,
+                               int32_t *bins) {
     int status = 0;
     if (sp->num_bins < 1 || sp->num_bins > 256) return -1;
     for (int64_t i = 0; i < n; ++i)
-        status |= rqs_elem(x[i], uw + i * sw, uh + i * sh, ud + i * sd, sp, inverse, y + i,
+        status |= rqs_elem(x[i], uw + i * sw, uh + i * sh, ud + i * sd, nd, sp, inverse, y + i,
                            lad + i, bins ? bins + i : NULL);
     return status;
 }
@@ -254,7 +256,7 @@ int FN(oracle_rqs_coupling)(const REAL *x, const REAL *params, const int64_t *tr
             const REAL *p = params + (b * num_transform + j) * P;
             REAL xin = in_perm ? xr[in_perm[col]] : xr[col];
             REAL y, lad;
-            status |= rqs_elem(xin, p, p + K, p + 2 * K, sp, inverse, &y, &lad, NULL);
+            status |= rqs_elem(xin, p, p + K, p + 2 * K, (int)(P - 2 * K), sp, inverse, &y, &lad, NULL);
             orow[out_scatter ? out_scatter[col] : col] = y;
             acc += (double)lad;
         }

@@ -1,0 +1,160 @@
+"""Whole-flow parity on the GPU: the drop-in classes, loaded with the reference's weights
+(state_dict keys are identical), against reference outputs stored in tests/golden/flows.npz.
+Run with `-m gpu`."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import parse_kwargs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(cfg):
+    from nflows_amd import configs
+    from nflows_amd.nn.nets import MLP
+    from nflows_amd.transforms import AffineCouplingTransform, CompositeTransform, ReversePermutation
+    from nflows_amd.flows import Flow
+    from nflows_amd.distributions import StandardNormal
+    from nflows_amd.utils import create_alternating_binary_mask
+    kind = cfg["kind"]
+    if kind == "rq_nsf":
+        return configs.rq_nsf_flow(cfg["L"], cfg["D"], cfg["K"], cfg["H"], 2, cfg["tail_bound"])
+    if kind == "affine":
+        class Wrapped(torch.nn.Module):  # same parameter names as the fixture's wrapper module
+            def __init__(self, i, o, hidden):
+                super().__init__()
+                self.mlp = MLP([i], [o], hidden)
+
+            def forward(self, x, context=None):
+                return self.mlp(x)
+        layers = []
+        for i in range(cfg["L"]):
+            layers.append(AffineCouplingTransform(
+                create_alternating_binary_mask(cfg["D"], even=(i % 2 == 0)),
+                lambda i_, o_: Wrapped(i_, o_, cfg["hidden"])))
+            layers.append(ReversePermutation(cfg["D"]))
+        return Flow(CompositeTransform(layers), StandardNormal([cfg["D"]]))
+    if kind == "maf":
+        return configs.moons_maf_flow(cfg["L"], cfg["D"], cfg["H"])
+    if kind == "ar_rq":
+        return configs.ar_rq_flow(cfg["D"], cfg["H"], cfg["K"], cfg["tail_bound"], cfg["num_blocks"])
+    raise KeyError(kind)
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "flows.npz"))
+
+
+def load_state(flow, g, name):
+    prefix = name + "/sd/"
+    sd = {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
+    missing, unexpected = flow.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+
+
+def check(got, ref32, ref64, what, tol):
+    got = got.detach().cpu().numpy().astype(np.float64)
+    e_got = np.abs(got - ref64).max()
+    e_ref = np.abs(ref32.astype(np.float64) - ref64).max()
+    scale = 1 + np.abs(ref64).max()
+    assert e_got <= 4 * e_ref + tol * scale, "%s: err vs fp64 %.3e (reference fp32: %.3e)" % (what, e_got, e_ref)
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_golden_flows(golden, fuse):
+    for name, cfg in golden["meta"]:
+        cfg = parse_kwargs(cfg)
+        flow = build(cfg)
+        load_state(flow, golden, name)
+        flow._transform.fuse_permutations = fuse
+        flow = flow.to(DEV).eval()
+        x = torch.from_numpy(golden[name + "/x"]).to(DEV)
+        noise = torch.from_numpy(golden[name + "/noise"]).to(DEV)
+        with torch.no_grad():
+            lp = flow.log_prob(x)
+            z, lad = flow._transform(x)
+            xs, lad_inv = flow._transform.inverse(noise)
+        import nflows_amd
+        nflows_amd.check_status()
+        d = cfg.get("D", 2)
+        check(z, golden[name + "/z"], golden[name + "/z64"], name + " z", 3e-6)
+        check(lad, golden[name + "/lad"], golden[name + "/lad64"], name + " lad", 3e-6 * d)
+        check(lp, golden[name + "/log_prob"], golden[name + "/log_prob64"], name + " log_prob", 3e-6 * d)
+        check(xs, golden[name + "/inv_x"], golden[name + "/inv_x64"], name + " inv_x", 3e-6)
+        check(lad_inv, golden[name + "/inv_lad"], golden[name + "/inv_lad64"], name + " inv_lad", 3e-6 * d)
+
+
+def test_fused_permutation_is_bit_identical(golden):
+    name = "nsf_d64"
+    cfg = parse_kwargs(dict((n, c) for n, c in golden["meta"])[name])
+    flow = build(cfg)
+    load_state(flow, golden, name)
+    flow = flow.to(DEV).eval()
+    x = torch.from_numpy(golden[name + "/x"]).to(DEV)
+    with torch.no_grad():
+        flow._transform.fuse_permutations = True
+        z1, l1 = flow._transform(x)
+        x1, li1 = flow._transform.inverse(x)
+        flow._transform.fuse_permutations = False
+        z2, l2 = flow._transform(x)
+        x2, li2 = flow._transform.inverse(x)
+    assert torch.equal(z1, z2) and torch.equal(l1, l2)
+    assert torch.equal(x1, x2) and torch.equal(li1, li2)
+
+
+def test_same_seed_same_weights_as_reference(golden):
+    """The conditioners consume the RNG exactly like the reference's, so a user switching
+    frameworks gets the same initial model from the same seed (fixture built with seed 0)."""
+    name = "nsf_d64"
+    cfg = parse_kwargs(dict((n, c) for n, c in golden["meta"])[name])
+    flow = build(cfg)  # seed 0 inside
+    sd = flow.state_dict()
+    k = "_transform._transforms.0._permutation"
+    assert np.array_equal(sd[k].numpy(), golden[name + "/sd/" + k])
+    k = "_transform._transforms.1.transform_net.initial_layer.weight"
+    assert np.array_equal(sd[k].numpy(), golden[name + "/sd/" + k])
+
+
+def test_forward_inverse_consistency_and_sampling():
+    """reference tests/transforms/coupling_test.py:237-254 (eps 1e-3) and flows/base_test.py:54-69."""
+    from nflows_amd import configs
+    flow = configs.rq_nsf_flow(num_layers=4, features=64, num_bins=8, hidden_features=128).to(DEV).eval()
+    with torch.no_grad():
+        x = torch.randn(4096, 64, device=DEV)
+        z, lad = flow._transform(x)
+        xr, lad_inv = flow._transform.inverse(z)
+        assert (xr - x).abs().max().item() < 1e-4
+        assert (lad + lad_inv).abs().max().item() < 1e-3
+        samples, lp = flow.sample_and_log_prob(512)
+        assert samples.shape == (512, 64) and lp.shape == (512,)
+        assert (flow.log_prob(samples) - lp).abs().max().item() < 1e-3
+        s2 = flow.sample(100, batch_size=30)
+        assert s2.shape == (100, 64)
+        noise = flow.transform_to_noise(x)
+        assert torch.equal(noise, z)
+
+
+def test_affine_real_nvp_stack():
+    """configs[1] shape: 8 affine coupling layers, D=32, MLP conditioner, batch 16384."""
+    from nflows_amd import configs
+    flow = configs.affine_coupling_flow(8, 32, (128, 128)).to(DEV).eval()
+    with torch.no_grad():
+        x = torch.randn(16384, 32, device=DEV)
+        z, lad = flow._transform(x)
+        xr, lad_inv = flow._transform.inverse(z)
+        assert (xr - x).abs().max().item() < 1e-5
+        assert (lad + lad_inv).abs().max().item() < 1e-4
+        assert flow.log_prob(x).shape == (16384,)
+
+
+def test_requires_grad_fails_loudly():
+    from nflows_amd import configs
+    flow = configs.rq_nsf_flow(num_layers=1, features=8, num_bins=4, hidden_features=16).to(DEV)
+    x = torch.randn(16, 8, device=DEV)
+    with pytest.raises(NotImplementedError, match="no backward"):
+        flow.log_prob(x)  # parameters require grad and grad mode is on

@@ -1,0 +1,340 @@
+"""Parity of the HIP kernels (through the C ABI) against the CPU oracle and the committed golden
+vectors from the real reference.  Needs an MI355X: run with `-m gpu`.
+
+Tolerances: see tests/helpers.py (bit-exact for index / pass-through work; the stated fp32
+model for everything else).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import LAD_TOL, OUT_TOL, assert_fp32_parity, parse_kwargs
+from oracle import capi
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import nflows_amd
+    from nflows_amd import ops as o
+    assert os.path.exists(nflows_amd.native_library_path())
+    return o
+
+
+def _spec_pair(ops, K, **kw):
+    return ops.make_rqs_spec(K, **kw), capi.make_spec(K, **kw)
+
+
+# ------------------------------------------------------------------------------- K5 vs golden
+def test_rqs_elementwise_golden(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "rqs_functional.npz"))
+    for name, inv, kw in g["meta"]:
+        kw = parse_kwargs(kw)
+        inv = bool(int(inv))
+        x, uw, uh, ud = (g[name + "/" + k] for k in ("x", "uw", "uh", "ud"))
+        K = uw.shape[-1]
+        spec, _ = _spec_pair(ops, K, **kw)
+        y, lad = ops.rqs_elementwise(dev(x), dev(uw), dev(uh), dev(ud), spec, inverse=inv)
+        ops.check_status()
+        y, lad = host(y), host(lad)
+        assert_fp32_parity(y, g[name + "/y"], g[name + "/y64"], OUT_TOL, name + " y", bulk=0.97)
+        assert_fp32_parity(lad, g[name + "/lad"], g[name + "/lad64"], LAD_TOL, name + " lad", bulk=0.97)
+        if kw.get("tails") == "linear":
+            tb = np.float32(kw["tail_bound"])
+            outside = ~((x >= -tb) & (x <= tb))
+            assert np.array_equal(y[outside].view(np.uint32), x[outside].view(np.uint32)), name
+            assert np.all(lad[outside] == 0), name
+
+
+# ------------------------------------------------------------------------------- K5 vs oracle
+@pytest.mark.parametrize("K", [1, 2, 3, 5, 8, 10, 16, 33])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_rqs_elementwise_oracle(ops, K, inverse):
+    rng = np.random.RandomState(100 + K)
+    n = 5000 + K  # ragged: not a multiple of the 256-element tile
+    tb = 3.0
+    x = (tb * 0.9 * rng.randn(n)).astype(np.float32)
+    uw = rng.randn(n, K).astype(np.float32)
+    uh = rng.randn(n, K).astype(np.float32)
+    ud = rng.randn(n, K - 1).astype(np.float32)
+    spec, ospec = _spec_pair(ops, K, tails="linear", tail_bound=tb)
+    y, lad = ops.rqs_elementwise(dev(x), dev(uw), dev(uh), dev(ud), spec, inverse=inverse)
+    oy, ol, st = capi.rqs_elementwise(x, uw, uh, ud, ospec, inverse=inverse)
+    ty, tl, _ = capi.rqs_elementwise(*(a.astype(np.float64) for a in (x, uw, uh, ud)), ospec, inverse=inverse)
+    assert st == 0
+    assert_fp32_parity(host(y), oy, ty, OUT_TOL, "y K=%d" % K)
+    assert_fp32_parity(host(lad), ol, tl, LAD_TOL, "lad K=%d" % K)
+
+
+def test_rqs_elementwise_strided_views(ops):
+    """Logits given as views into one packed [N, P] buffer (the autoregressive layout,
+    autoregressive.py:453-460) and as three separate tensors give the same result."""
+    rng = np.random.RandomState(7)
+    K, n = 8, 3001
+    P = 3 * K - 1
+    packed = rng.randn(n, P).astype(np.float32)
+    x = (2.5 * rng.randn(n)).astype(np.float32)
+    spec, _ = _spec_pair(ops, K, tails="linear", tail_bound=3.0)
+    p = dev(packed)
+    y1, l1 = ops.rqs_elementwise(dev(x), p[:, :K], p[:, K:2 * K], p[:, 2 * K:], spec)
+    y2, l2 = ops.rqs_elementwise(dev(x), p[:, :K].contiguous(), p[:, K:2 * K].contiguous(),
+                                 p[:, 2 * K:].contiguous(), spec)
+    assert torch.equal(y1, y2) and torch.equal(l1, l2)
+    # misaligned packed base (storage offset of 1 float)
+    buf = torch.empty(n * P + 1, device=DEV)
+    buf[1:] = p.view(-1)
+    q = buf[1:].view(n, P)
+    y3, l3 = ops.rqs_elementwise(dev(x), q[:, :K], q[:, K:2 * K], q[:, 2 * K:], spec)
+    assert torch.equal(y1, y3) and torch.equal(l1, l3)
+
+
+def test_rqs_elementwise_shapes_and_empty(ops):
+    K = 4
+    spec, _ = _spec_pair(ops, K, tails="linear", tail_bound=1.0)
+    x = torch.randn(2, 3, 4, device=DEV)
+    uw, uh, ud = torch.randn(2, 3, 4, K, device=DEV), torch.randn(2, 3, 4, K, device=DEV), torch.randn(2, 3, 4, K - 1, device=DEV)
+    y, lad = ops.rqs_elementwise(x, uw, uh, ud, spec)
+    assert y.shape == x.shape and lad.shape == x.shape
+    y0, l0 = ops.rqs_elementwise(x[:0], uw[:0], uh[:0], ud[:0], spec)
+    assert y0.numel() == 0 and l0.numel() == 0
+
+
+def test_rqs_errors(ops):
+    from nflows_amd import InputOutsideDomain
+    from nflows_amd.transforms import splines
+    x = torch.tensor([0.5, 1.5], device=DEV)
+    z = torch.zeros(2, 4, device=DEV)
+    with pytest.raises(InputOutsideDomain):
+        splines.rational_quadratic_spline(x, z, z, torch.zeros(2, 5, device=DEV))
+    with pytest.raises(ValueError, match="Minimal bin width too large"):
+        splines.rational_quadratic_spline(x[:1], z[:1], z[:1], torch.zeros(1, 5, device=DEV), min_bin_width=0.3)
+    with pytest.raises(ValueError, match="Minimal bin height too large"):
+        splines.rational_quadratic_spline(x[:1], z[:1], z[:1], torch.zeros(1, 5, device=DEV), min_bin_height=0.3)
+    with pytest.raises(RuntimeError, match="cubic tails are not implemented"):
+        splines.unconstrained_rational_quadratic_spline(x[:1], z[:1], z[:1], torch.zeros(1, 3, device=DEV), tails="cubic")
+    with pytest.raises(NotImplementedError):
+        splines.unconstrained_rational_quadratic_spline(x[:1].cpu(), z[:1].cpu(), z[:1].cpu(), torch.zeros(1, 3))
+    ops.check_status()  # clean
+
+
+def test_identity_init(ops):
+    """reference tests/transforms/splines/rational_quadratic_test.py:33-62 and :116-146, same
+    inputs (the unconstrained one passes K+1 derivative logits, which the reference accepts)."""
+    from nflows_amd.transforms import splines
+    shape, K = [2, 3, 4], 10
+    z = torch.zeros(*shape, K, device=DEV)
+    zd = torch.zeros(*shape, K + 1, device=DEV)
+    x = torch.rand(*shape, device=DEV)
+    for inv in (False, True):
+        y, lad = splines.rational_quadratic_spline(x, z, z, zd, inverse=inv, enable_identity_init=True)
+        assert (y - x).abs().max().item() < 1e-6 and lad.abs().max().item() < 1e-6
+    tail_bound = 1.0
+    xo = torch.sign(torch.randn(*shape, device=DEV)) * (tail_bound + torch.rand(*shape, device=DEV))
+    y, lad = splines.unconstrained_rational_quadratic_spline(xo, z, z, zd, inverse=False,
+                                                             enable_identity_init=True)
+    assert torch.equal(y, xo) and torch.equal(lad, torch.zeros_like(lad))
+    y, lad = splines.unconstrained_rational_quadratic_spline(x, z, z, zd, inverse=True,
+                                                             enable_identity_init=True)
+    assert (y - x).abs().max().item() < 1e-6 and lad.abs().max().item() < 1e-6
+
+
+# ------------------------------------------------------------------------------- K1 / K2 golden
+def test_coupling_layers_golden(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "coupling.npz"))
+    from nflows_amd import _native as N
+    for name, kind, cfg in g["meta"]:
+        cfg = parse_kwargs(cfg)
+        x, params, tidx = g[name + "/x"], g[name + "/params"], g[name + "/transform_idx"]
+        for direction, inv in (("fwd", False), ("inv", True)):
+            ry, rl = g["%s/%s_y" % (name, direction)], g["%s/%s_lad" % (name, direction)]
+            ry64, rl64 = g["%s/%s_y64" % (name, direction)], g["%s/%s_lad64" % (name, direction)]
+            if kind == "rq":
+                H = cfg["hidden"]
+                spec = ops.make_rqs_spec(cfg["K"], cfg["tails"], tail_bound=cfg["tail_bound"],
+                                         wh_divisor=float(np.sqrt(H)) if H else 0.0)
+                y, lad = ops.rqs_coupling(dev(x), dev(params), dev(tidx), spec, inverse=inv)
+            else:
+                act = {"affine_default": N.SCALE_DEFAULT, "affine_general": N.SCALE_GENERAL,
+                       "affine_additive": N.SCALE_ADDITIVE}[kind]
+                y, lad = ops.affine_coupling(dev(x), dev(params), dev(tidx), act, inverse=inv)
+            ops.check_status()
+            y, lad = host(y), host(lad)
+            assert_fp32_parity(y, ry, ry64, OUT_TOL, name + direction + " y", bulk=0.97)
+            assert_fp32_parity(lad, rl, rl64, 2 * LAD_TOL, name + direction + " lad", bulk=0.9)
+            ident = np.setdiff1d(np.arange(x.shape[1]), tidx)
+            assert np.array_equal(y[:, ident], x[:, ident]), name  # bit-exact pass-through
+            if kind == "affine_additive":
+                assert np.all(lad == 0), name
+
+
+# ------------------------------------------------------------------------------- K1 vs oracle
+@pytest.mark.parametrize("B,D,K,tails", [
+    (1, 64, 8, "linear"), (7, 64, 8, "linear"), (4099, 64, 8, "linear"), (513, 6, 8, "linear"),
+    (300, 64, 10, "linear"), (257, 9, 5, "linear"), (129, 33, 3, None), (64, 2, 8, "linear"),
+    (50, 700, 8, "linear"), (3, 1500, 4, "linear"), (4, 3000, 8, "linear"),
+])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_rqs_coupling_oracle(ops, B, D, K, tails, inverse):
+    rng = np.random.RandomState(B + D + K)
+    mask = rng.rand(D) < 0.5
+    if D == 64:
+        mask = np.arange(D) % 2 == 0
+    mask[0] = True
+    tidx = np.nonzero(mask)[0].astype(np.int64)
+    dt = tidx.size
+    P = 3 * K - 1 if tails == "linear" else 3 * K + 1
+    tb = 3.0
+    if tails == "linear":
+        x = (1.4 * rng.randn(B, D)).astype(np.float32)
+    else:
+        x = rng.rand(B, D).astype(np.float32)
+    params = (1.5 * rng.randn(B, dt * P)).astype(np.float32)
+    kw = dict(tails=tails, tail_bound=tb, wh_divisor=float(np.sqrt(32)))
+    spec, ospec = _spec_pair(ops, K, **kw)
+    y, lad = ops.rqs_coupling(dev(x), dev(params), dev(tidx), spec, inverse=inverse)
+    ops.check_status()
+    oy, ol, st = capi.rqs_coupling(x, params, tidx, ospec, inverse=inverse)
+    ty, tl, _ = capi.rqs_coupling(x.astype(np.float64), params.astype(np.float64), tidx, ospec, inverse=inverse)
+    assert st == 0
+    y, lad = host(y), host(lad)
+    assert_fp32_parity(y, oy, ty, OUT_TOL, "y")
+    assert_fp32_parity(lad, ol, tl, LAD_TOL * max(1, dt // 32), "lad")
+    ident = np.nonzero(~mask)[0]
+    assert np.array_equal(y[:, ident], x[:, ident])
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_coupling_fused_permutation_bit_exact(ops, inverse):
+    """in_perm == Permutation.forward before the layer; out_scatter == Permutation.inverse after
+    it: bit-identical to running the K4 kernel separately."""
+    rng = np.random.RandomState(3)
+    B, D, K = 1000, 64, 8
+    tidx = np.arange(0, D, 2).astype(np.int64)
+    P = 3 * K - 1
+    x = dev((1.5 * rng.randn(B, D)).astype(np.float32))
+    params = dev(rng.randn(B, tidx.size * P).astype(np.float32))
+    perm = dev(rng.permutation(D).astype(np.int64))
+    spec, _ = _spec_pair(ops, K, tails="linear", tail_bound=3.0, wh_divisor=float(np.sqrt(128)))
+    t = dev(tidx)
+    if not inverse:
+        y_seq, l_seq = ops.rqs_coupling(ops.permute_cols(x, perm), params, t, spec)
+        y_f, l_f = ops.rqs_coupling(x, params, t, spec, in_perm=perm)
+    else:
+        y0, l_seq = ops.rqs_coupling(x, params, t, spec, inverse=True)
+        y_seq = ops.permute_cols(y0, torch.argsort(perm))
+        y_f, l_f = ops.rqs_coupling(x, params, t, spec, inverse=True, out_scatter=perm)
+    assert torch.equal(y_seq, y_f) and torch.equal(l_seq, l_f)
+
+
+def test_affine_oracle_and_given_scale(ops):
+    from nflows_amd import _native as N
+    rng = np.random.RandomState(5)
+    for B, D in [(1, 32), (1000, 32), (333, 7), (20, 300)]:
+        mask = rng.rand(D) < 0.5
+        mask[0] = True
+        tidx = np.nonzero(mask)[0].astype(np.int64)
+        dt = tidx.size
+        x = rng.randn(B, D).astype(np.float32)
+        for act, cols in ((N.SCALE_DEFAULT, 2 * dt), (N.SCALE_GENERAL, 2 * dt), (N.SCALE_ADDITIVE, dt)):
+            params = (2 * rng.randn(B, cols)).astype(np.float32)
+            for inv in (False, True):
+                y, lad = ops.affine_coupling(dev(x), dev(params), dev(tidx), act, inverse=inv)
+                oy, ol, _ = capi.affine_coupling(x, params, tidx, act, inverse=inv)
+                ty, tl, _ = capi.affine_coupling(x.astype(np.float64), params.astype(np.float64), tidx, act, inverse=inv)
+                assert_fp32_parity(host(y), oy, ty, OUT_TOL, "affine y")
+                assert_fp32_parity(host(lad), ol, tl, LAD_TOL * max(1, dt // 32), "affine lad")
+        # arbitrary activation evaluated by the caller
+        params = rng.randn(B, 2 * dt).astype(np.float32)
+        scale = np.exp(0.3 * params[:, dt:]).astype(np.float32)
+        y, lad = ops.affine_coupling(dev(x), dev(params), dev(tidx), N.SCALE_GIVEN, scale=dev(scale))
+        oy, ol, _ = capi.affine_coupling(x, params, tidx, capi.AFFINE_GIVEN_SCALE, scale=scale)
+        assert np.abs(host(y) - oy).max() <= 1e-6 and np.abs(host(lad) - ol).max() <= 1e-4
+
+
+def test_affine_autoregressive_oracle(ops):
+    rng = np.random.RandomState(9)
+    for B, D in [(128, 2), (77, 100), (5, 784)]:
+        x = rng.randn(B, D).astype(np.float32)
+        params = rng.randn(B, D * 2).astype(np.float32)
+        for inv in (False, True):
+            y, lad = ops.affine_autoregressive(dev(x), dev(params), inverse=inv)
+            oy, ol = capi.affine_autoregressive(x, params, inverse=inv)
+            assert np.abs(host(y) - oy).max() <= 2e-6 * (1 + np.abs(oy).max())
+            assert np.abs(host(lad) - ol).max() <= 1e-5 * max(1, D // 8)
+
+
+# ------------------------------------------------------------------------------- K4 / K3
+def test_permute_cols_bit_exact(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "misc.npz"))
+    out = ops.permute_cols(dev(g["perm_x"]), dev(g["perm"]))
+    assert np.array_equal(host(out), g["perm_fwd"])
+    out = ops.permute_cols(dev(g["perm_x"]), torch.argsort(dev(g["perm"])))
+    assert np.array_equal(host(out), g["perm_inv"])
+    rng = np.random.RandomState(1)
+    for B, D in [(1, 1), (3, 2), (1000, 64), (4097, 7), (33, 1000), (2, 5000)]:
+        x = rng.randint(-2 ** 31, 2 ** 31 - 1, size=(B, D)).astype(np.int32)  # any 4-byte pattern, incl. NaNs
+        perm = rng.permutation(D).astype(np.int64)
+        out = ops.permute_cols(dev(x), dev(perm))
+        assert np.array_equal(host(out), x[:, perm])
+    ops.check_status()
+    with pytest.raises(IndexError):
+        ops.permute_cols(dev(np.zeros((2, 3), np.float32)), dev(np.array([0, 1, 5], np.int64)))
+        ops.check_status()
+
+
+def test_rowsum_and_normal(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "misc.npz"))
+    assert np.abs(host(ops.rowsum(dev(g["rowsum_x"]))) - g["rowsum"]).max() <= 4e-6
+    assert np.abs(host(ops.standard_normal_log_prob(dev(g["perm_x"]))) - g["normal_lp"]).max() <= 3e-5
+    rng = np.random.RandomState(2)
+    for B, D in [(1, 1), (5, 3), (1000, 64), (17, 1001)]:
+        x = rng.randn(B, D).astype(np.float32)
+        assert np.abs(host(ops.rowsum(dev(x))) - capi.rowsum(x)).max() <= 2e-6 * D
+        lad = rng.randn(B).astype(np.float32)
+        want = capi.standard_normal_log_prob(x) + lad
+        got = host(ops.standard_normal_log_prob(dev(x), dev(lad)))
+        assert np.abs(got - want).max() <= 1e-5 * (1 + np.abs(want).max())
+
+
+# ------------------------------------------------------------------------------- size-independent
+def test_full_size_round_trip_and_properties(ops):
+    """BASELINE cfg-3/4 layer shape (B=65536, D=64, K=8): properties that need no oracle run."""
+    B, D, K = 65536, 64, 8
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(B, D, device=DEV, generator=g)
+    P = 3 * K - 1
+    tidx = torch.arange(0, D, 2, device=DEV)
+    params = torch.randn(B, tidx.numel() * P, device=DEV, generator=g)
+    spec, ospec = _spec_pair(ops, K, tails="linear", tail_bound=3.0, wh_divisor=float(np.sqrt(128)))
+    y, lad = ops.rqs_coupling(x, params, tidx, spec)
+    xr, lad_inv = ops.rqs_coupling(y, params, tidx, spec, inverse=True)
+    ops.check_status()
+    assert torch.equal(y[:, 1::2], x[:, 1::2])          # identity half bit-exact
+    assert (xr - x).abs().max().item() < 1e-5           # per-layer fwd∘inv
+    assert (lad + lad_inv).abs().max().item() < 2e-3     # sum of 32 per-feature log-derivatives
+    assert torch.isfinite(y).all() and torch.isfinite(lad).all()
+    # monotone: ordering of two inputs under the same spline is preserved
+    x2 = x.clone()
+    x2[:, ::2] += 0.01
+    y2, _ = ops.rqs_coupling(x2, params, tidx, spec)
+    assert (y2[:, ::2] >= y[:, ::2]).all()
+    # spot-check 2048 random rows against the oracle
+    rows = torch.randint(0, B, (2048,), generator=torch.Generator().manual_seed(1))
+    oy, ol, _ = capi.rqs_coupling(host(x[rows]), host(params[rows]), host(tidx), ospec)
+    assert np.abs(host(y[rows]) - oy).max() <= 5e-6 and np.abs(host(lad[rows]) - ol).max() <= 5e-5
