@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Flow.log_prob throughput of the 32-layer RQ-NSF coupling flow
+(dim=64, K=8, batch 65536 per GPU) on MI355X, with the spline kernel's HBM roofline fraction
+and the reference-CPU-path baseline (timed through its bit-identical port, oracle/eager.py).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+For N > 1 the driver launches one process per GPU with torch.distributed.run; ranks shard the
+samples (weak scaling: 65536 rows per GPU) and exchange one 16-byte all-reduce per step.
+A "step" is one full log_prob pass over the rank's batch (inputs already resident in HBM) plus
+the log-likelihood reduction.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+T_START = time.perf_counter()
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+class EventHook:
+    """Brackets every K1 launch with HIP events recorded on the stream it is launched on
+    (torch's current stream: ops.py passes exactly that handle to the library)."""
+
+    def __init__(self):
+        self.pairs = []
+        self.bytes = 0
+        self.enabled = False
+
+    def begin(self, name):
+        if not self.enabled:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, start, nbytes):
+        if start is None:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.pairs.append((start, e))
+        self.bytes = nbytes
+
+    def summary(self):
+        if not self.pairs:
+            return None
+        ms = [a.elapsed_time(b) for a, b in self.pairs]
+        return sum(ms) / len(ms), len(ms)
+
+
+def log(msg):
+    print("[bench %.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(flow_cpu, features, sample_rows, budget_s=20.0):
+    """The reference's CPU path, via its bit-identical PyTorch-eager port, on the host cores this
+    process may use.  Bounded: rows are halved until one pass fits the time budget."""
+    from oracle import eager
+    threads = usable_cores()
+    torch.set_num_threads(threads)
+    log("cpu baseline: %d threads (os.cpu_count=%s)" % (threads, os.cpu_count()))
+    rows = sample_rows
+    with torch.no_grad():
+        while True:
+            x = torch.randn(rows, features, generator=torch.Generator().manual_seed(1234))
+            t0 = time.perf_counter()
+            eager.flow_log_prob(flow_cpu, x)  # warm-up pass, also the probe
+            probe = time.perf_counter() - t0
+            log("cpu baseline: %d rows, probe pass %.2f s" % (rows, probe))
+            if probe <= budget_s / 4 or rows <= 512:
+                break
+            rows //= 4
+        reps = max(1, min(3, int(budget_s / max(probe, 1e-3)) - 1))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eager.flow_log_prob(flow_cpu, x)
+        dt = (time.perf_counter() - t0) / reps
+    return {"value": rows / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": "same 32-layer flow and weights, %d rows x %d timed passes of "
+                      "oracle/eager.py (bit-identical to the reference CPU path), %.2f s/pass"
+                      % (rows, reps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=65536)
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=16384)
+    ap.add_argument("--no-fuse", action="store_true", help="run permutations as separate kernels")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    import nflows_amd
+    from nflows_amd import configs, ops, parallel
+    log("imports done; building flow")
+
+    D, K, H = 64, 8, 128
+    flow_cpu = configs.rq_nsf_flow(num_layers=args.layers, features=D, num_bins=K, hidden_features=H,
+                                   num_blocks=2, tail_bound=3.0, seed=0).eval()  # same seed on every rank
+    import copy
+    flow = copy.deepcopy(flow_cpu).to(dev)
+    flow._transform.fuse_permutations = not args.no_fuse
+    B = args.batch_per_gpu
+    x = torch.randn(B, D, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+
+    log("flow on device; warm-up")
+    hook = EventHook()
+    ops.set_launch_hook(hook)
+
+    def step():
+        with torch.no_grad():
+            lp = flow.log_prob(x)
+        return parallel.reduce_log_likelihood(lp)
+
+    for _ in range(args.warmup):
+        acc = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    log("warm-up done; timing %d steps" % args.steps)
+    hook.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        acc = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    hook.enabled = False
+    log("timed region done: %.1f ms/step" % (elapsed / args.steps * 1e3))
+    nflows_amd.check_status()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+    mean_ll = (acc[0] / acc[1]).item()
+
+    # forward∘inverse consistency (second half of the metric), outside the timed region
+    with torch.no_grad():
+        xs = x[:8192]
+        z, lad = flow._transform(xs)
+        xr, lad_inv = flow._transform.inverse(z)
+        err_composite = (xr - xs).abs().max().item()
+        layer = flow._transform._transforms[1]
+        y1, _ = layer(xs)
+        x1, _ = layer.inverse(y1)
+        err_layer = (x1 - xs).abs().max().item()
+
+    if rank == 0:
+        total_rows = B * world
+        k1 = hook.summary()
+        roofline = None
+        if k1 is not None:
+            avg_ms, launches = k1
+            achieved = hook.bytes / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "k1_pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": "rqs_coupling_kernel<8,false>",
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                        "algorithmic_bytes_per_launch": hook.bytes,
+                        "avg_launch_ms": avg_ms, "launches_timed": launches}
+        result = {
+            "metric": "log_prob samples/sec (dim=64, K=8, 32-layer RQ-NSF) + max |fwd∘inv − x|",
+            "value": total_rows * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic standard-Gaussian inputs, random-init weights (seed 0)",
+            "config": {"workload": "%d-layer RQ-NSF coupling flow (RandomPermutation + RQ coupling, "
+                                   "ResidualNet H=128 x2 blocks), dim=64, K=8, tail_bound=3, "
+                                   "batch=%d per GPU, Flow.log_prob + scalar all-reduce" % (args.layers, B),
+                       "global_batch": total_rows, "features": D, "num_bins": K, "layers": args.layers,
+                       "parallelism": "sample-sharded x%d" % world,
+                       "fused_permutations": not args.no_fuse},
+            "fwd_inv_max_err": {"composite_%d_layers" % args.layers: err_composite, "single_layer": err_layer,
+                                "rows": 8192},
+            "mean_log_likelihood": mean_ll,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(flow_cpu, D, args.cpu_rows)
+            result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

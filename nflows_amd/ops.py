@@ -25,6 +25,15 @@ from .errors import InputOutsideDomain
 
 _status_words = {}
 _error_mode = "deferred"
+_launch_hook = None
+
+
+def set_launch_hook(hook):
+    """Measurement aid for bench.py: `hook.begin(name)` / `hook.end(token, algorithmic_bytes)` are
+    called right before / after the K1 kernel is enqueued (on the current stream), so a caller
+    can bracket it with HIP events.  None (default) disables it; nothing else changes."""
+    global _launch_hook
+    _launch_hook = hook
 
 
 def set_error_mode(mode):
@@ -131,10 +140,15 @@ def rqs_coupling(inputs, params, transform_idx, spec, inverse=False, in_perm=Non
     p = params.contiguous()
     out = torch.empty_like(x)
     lad = torch.empty(B, dtype=torch.float32, device=dev)
+    hook = _launch_hook
     with torch.cuda.device(dev):
+        token = hook.begin("rqs_coupling") if hook is not None else None
         rc = N.load().nfa_rqs_coupling_f32(N.ptr(x), N.ptr(p), N.ptr(tidx), N.ptr(perm), N.ptr(scat),
                                            N.ptr(out), N.ptr(lad), N.ptr(_status_word(dev)), B, D, dt,
                                            ctypes.byref(spec), int(bool(inverse)), N.stream_handle(dev))
+        if hook is not None:
+            # algorithmic bytes: inputs + conditioner output + outputs + logabsdet
+            hook.end(token, 4 * (B * D + B * dt * P + B * D + B))
     if rc == N.ERR_UNSUPPORTED:
         return _rqs_coupling_unfused(x, p, tidx, perm, scat, spec, inverse)
     N.check(rc)

@@ -119,3 +119,32 @@ def test_fused_permutation_equals_sequence(golden_dir):
     y0, lad0, _ = capi.rqs_coupling(x, params, tidx, spec, inverse=True)
     y_s, lad_s, _ = capi.rqs_coupling(x, params, tidx, spec, inverse=True, out_scatter=perm)
     assert np.array_equal(y0[:, np.argsort(perm)], y_s) and np.array_equal(lad0, lad_s)
+
+
+# ------------------------------------------------------------------ the PyTorch-eager CPU port
+def test_eager_port_is_bit_identical_to_reference(golden_dir):
+    """oracle/eager.py (the cpu_baseline 'port' of bench.py) reproduces the reference's CPU
+    outputs bit for bit: every functional case and whole-flow log_prob."""
+    import torch
+    from oracle import eager
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(golden_dir, "rqs_functional.npz"))
+    for name, inv, kw in g["meta"]:
+        kw = parse_kwargs(kw)
+        tails = kw.pop("tails")
+        x, uw, uh, ud = (torch.from_numpy(g[name + "/" + k]) for k in ("x", "uw", "uh", "ud"))
+        fn = eager.rqs_unconstrained if tails == "linear" else eager.rqs_constrained
+        y, lad = fn(x, uw, uh, ud, inverse=bool(int(inv)), **kw)
+        assert np.array_equal(y.numpy(), g[name + "/y"], equal_nan=True), name
+        assert np.array_equal(lad.numpy(), g[name + "/lad"], equal_nan=True), name
+    from nflows_amd import configs
+    gf = np.load(os.path.join(golden_dir, "flows.npz"))
+    metas = dict((n, parse_kwargs(c)) for n, c in gf["meta"])
+    for name in ("nsf_small", "nsf_d64"):
+        cfg = metas[name]
+        flow = configs.rq_nsf_flow(cfg["L"], cfg["D"], cfg["K"], cfg["H"], 2, cfg["tail_bound"])
+        prefix = name + "/sd/"
+        flow.load_state_dict({k[len(prefix):]: torch.from_numpy(gf[k]) for k in gf.files if k.startswith(prefix)})
+        with torch.no_grad():
+            lp = eager.flow_log_prob(flow.eval(), torch.from_numpy(gf[name + "/x"]))
+        assert np.array_equal(lp.numpy(), gf[name + "/log_prob"]), name
