@@ -11,7 +11,8 @@ import os
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libnflows_amd.so")
+# NFLOWS_AMD_LIB lets tools/k1_micro.py A/B-test alternative builds of the same C ABI
+LIB_PATH = os.environ.get("NFLOWS_AMD_LIB") or os.path.join(_PKG_DIR, "libnflows_amd.so")
 
 OK = 0
 ERR_INVALID_ARGUMENT = 1

@@ -43,12 +43,37 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, FastDiv f) {
 // (global_load_dwordx4 + ds_write_b128); elements of the first/last float4 that fall outside
 // the range are never read.  Returns the offset (0..3) of src[0] inside dst.
 // dst must be 16-byte aligned and hold ceil((count+3)/4)*4 + 4 floats.
+template <int BLOCK = kBlock, int UNROLL = 6>
 __device__ __forceinline__ int tile_load(const float* __restrict__ src, int count, float* dst,
                                          int tid) {
     const int mis = (int)((reinterpret_cast<uintptr_t>(src) >> 2) & 3);
     const float* win = src - mis;  // 16-byte aligned
     const int nvec = (mis + count + 3) >> 2;
-    for (int v = tid; v < nvec; v += kBlock) {
+#ifndef NFA_NO_UNROLL
+    if (mis == 0 && (count & 3) == 0) {
+        // aligned fast path (workgroup-uniform branch): issue UNROLL independent 16-byte loads per
+        // lane before the first LDS write, so a lane has UNROLL KiB-rows in flight
+        const float4* g = reinterpret_cast<const float4*>(src);
+        float4* l = reinterpret_cast<float4*>(dst);
+        for (int base = 0; base < nvec; base += BLOCK * UNROLL) {
+            float4 r[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                // clamped index: the load is unconditional (stays in registers, no divergence);
+                // lanes past the end re-read the last vector and simply do not store it
+                const int v = base + u * BLOCK + tid;
+                r[u] = g[v < nvec ? v : nvec - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int v = base + u * BLOCK + tid;
+                if (v < nvec) l[v] = r[u];
+            }
+        }
+        return 0;
+    }
+#endif
+    for (int v = tid; v < nvec; v += BLOCK) {
         const int e0 = v * 4 - mis;  // index into src of this vector's first element
         if (e0 >= 0 && e0 + 4 <= count) {
             const float4 q = *reinterpret_cast<const float4*>(win + v * 4);
@@ -69,12 +94,13 @@ __device__ __forceinline__ int tile_load(const float* __restrict__ src, int coun
 __device__ __forceinline__ int tile_store_offset(const float* dst) {
     return (int)((reinterpret_cast<uintptr_t>(dst) >> 2) & 3);
 }
+template <int BLOCK = kBlock>
 __device__ __forceinline__ void tile_store(float* __restrict__ dst, int count, const float* src,
                                            int tid) {
     const int mis = tile_store_offset(dst);
     float* win = dst - mis;
     const int nvec = (mis + count + 3) >> 2;
-    for (int v = tid; v < nvec; v += kBlock) {
+    for (int v = tid; v < nvec; v += BLOCK) {
         const int e0 = v * 4 - mis;
         if (e0 >= 0 && e0 + 4 <= count) {
             *reinterpret_cast<float4*>(win + v * 4) = *reinterpret_cast<const float4*>(src + v * 4);

@@ -26,6 +26,11 @@
 #include "common.hpp"
 
 #include <math.h>
+#include <stdlib.h>
+
+#ifndef NFA_K1_BLOCK_DEFAULT
+#define NFA_K1_BLOCK_DEFAULT 256
+#endif
 
 namespace nfa {
 
@@ -39,7 +44,7 @@ struct RqsDev {
     float right_eps, top_eps;      // last knot + 1e-6 (searchsorted)
     float min_w, min_h, min_d;
     float om_w, om_h;              // (float)(1 - min*K)
-    float beta, tail_logit, divisor;
+    float beta, tail_logit, divisor, rdivisor;  // rdivisor = RN(1/divisor)
 };
 
 // Storage of K values per lane: registers when K is a compile-time constant, the lane's own LDS
@@ -59,23 +64,91 @@ struct Slots<0> {
     __device__ __forceinline__ void set(int i, float x) { s[i] = x; }
 };
 
+// ---- arithmetic building blocks -------------------------------------------------------------
+// a / b given r = RN(1/b): one product, its exact residual (fma) and one correction (fma).
+// This is the final step of the IEEE division algorithm; with a correctly rounded r it returns
+// the correctly rounded quotient (no scaling needed here: |a|, |b| are far from the fp32 limits).
+__device__ __forceinline__ float div_with_rcp(float a, float b, float r) {
+    const float q = a * r;
+#ifdef NFA_X_NOCORR
+    return q;
+#endif
+    const float e = __builtin_fmaf(-q, b, a);
+    return __builtin_fmaf(e, r, q);
+}
+
+// RN(1/b) for b in the normal range: v_rcp_f32 (1 ulp) + one Newton step
+__device__ __forceinline__ float rcp_refined(float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    return __builtin_fmaf(__builtin_fmaf(-b, r0, 1.0f), r0, r0);
+}
+
+// a / b without the denormal / overflow scaling of the generic IEEE expansion (operands here are
+// bin widths, heights and derivatives: well inside the normal range).
+__device__ __forceinline__ float div_normal(float a, float b) {
+    return div_with_rcp(a, b, rcp_refined(b));
+}
+
+// log(u) for normal u: v_log_f32 (log2, 1 ulp) times ln2 carried in two floats
+__device__ __forceinline__ float log_normal(float u) {
+    const float kLn2Hi = 0.693145751953125f;          // ln2, low 11 mantissa bits cleared
+    const float kLn2Lo = 1.42860682030941723212e-06f;  // ln2 - kLn2Hi
+    const float r = __builtin_amdgcn_logf(u);
+    return __builtin_fmaf(r, kLn2Lo, r * kLn2Hi);
+}
+
+// log1p(t), t >= 0: log(u) with u = RN(1 + t) plus the first-order term for the rounding of u.
+// (ocml's log1pf is ~120 VALU instructions; this is 9.)
+__device__ __forceinline__ float log1p_nonneg(float t) {
+    const float u = 1.0f + t;
+    const float c = t - (u - 1.0f);  // exact: what the addition dropped
+    return __builtin_fmaf(c, __builtin_amdgcn_rcpf(u), log_normal(u));
+}
+
+// exp(x) for x <= ~88 without range handling: 2^(x*log2e) with the product carried in two
+// floats; v_exp_f32 (1 ulp) on the high part, first-order correction for the low part.
+// Results below 2^-126 flush to zero (they are added to a softmax denominator >= 1).
+__device__ __forceinline__ float exp_noclamp(float x) {
+    const float kLog2e = 1.44269502162933349609375f;       // RN(log2(e))
+    const float kLog2eLo = 1.925963033500011e-08f;          // log2(e) - kLog2e
+    const float kLn2 = 0.693147182464599609375f;
+    const float hi = x * kLog2e;
+#ifdef NFA_X_FASTEXP
+    return __builtin_amdgcn_exp2f(hi);
+#endif
+    float lo = __builtin_fmaf(x, kLog2e, -hi);
+    lo = __builtin_fmaf(x, kLog2eLo, lo);
+    const float e0 = __builtin_amdgcn_exp2f(hi);
+    return __builtin_fmaf(e0, lo * kLn2, e0);
+}
+
 // softmax numerators exp(u_i - max) in place, returns the fp32 denominator.
+// (aten's softmax sums the numerators in fp32 in a vector-lane order that depends on the host
+// ISA; a balanced tree is the closest ISA-independent choice.)
 template <int KT>
 __device__ __forceinline__ float softmax_numerators(Slots<KT>& e, const float* logits, int K,
-                                                    float divisor) {
+                                                    float divisor, float rdivisor) {
 #pragma clang fp contract(off)
     float m = -INFINITY;
 #pragma unroll
     for (int i = 0; i < (KT > 0 ? KT : K); ++i) {
         float u = logits[i];
-        if (divisor != 0.0f) u = u / divisor;
+        if (divisor != 0.0f) u = div_with_rcp(u, divisor, rdivisor);
         e.set(i, u);
         m = fmaxf(m, u);
     }
-    double s = 0.0;
+    if (KT == 8) {
+        float t[8];
 #pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            t[i] = exp_noclamp(e.get(i) - m);
+            e.set(i, t[i]);
+        }
+        return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    double s = 0.0;  // runtime K: a long sequential fp32 sum would drift; double is exact enough
     for (int i = 0; i < (KT > 0 ? KT : K); ++i) {
-        const float ex = expf(e.get(i) - m);
+        const float ex = exp_noclamp(e.get(i) - m);
         e.set(i, ex);
         s += (double)ex;
     }
@@ -85,18 +158,29 @@ __device__ __forceinline__ float softmax_numerators(Slots<KT>& e, const float* l
 // Walks the K bins, rebuilding knot_i / knot_{i+1} on the fly.
 //   SEARCH : k <- last i with x >= knot_i (== count-1 for monotone knots), picks that bin's knots
 //   !SEARCH: picks the knots of the given bin k
+// The prefix sums are accumulated in double and rounded to fp32 per prefix, which is what
+// aten's CPU cumsum does for float tensors (the double sums are exact for these magnitudes).
 template <int KT, bool SEARCH>
 __device__ __forceinline__ void walk_bins(const Slots<KT>& e, int K, float denom, float minbin,
                                           float om, float span, float lo, float hi, float x, int& k,
                                           float& knot_lo, float& knot_hi) {
 #pragma clang fp contract(off)
+    const float rden = rcp_refined(denom);
+#ifdef NFA_X_F32CUMSUM
+    float acc = 0.0f;
+#else
     double acc = 0.0;
+#endif
     float prev = lo;
 #pragma unroll
     for (int i = 0; i < (KT > 0 ? KT : K); ++i) {
-        const float p = e.get(i) / denom;
+        const float p = div_with_rcp(e.get(i), denom, rden);
         const float w = minbin + om * p;
+#ifdef NFA_X_F32CUMSUM
+        acc += w;
+#else
         acc += (double)w;
+#endif
         const float c = (float)acc;
         const float next = (i == (KT > 0 ? KT : K) - 1) ? hi : span * c + lo;
         const bool take = SEARCH ? (x >= prev) : (i == k);
@@ -112,7 +196,8 @@ __device__ __forceinline__ void walk_bins(const Slots<KT>& e, int K, float denom
 __device__ __forceinline__ float softplus_beta(float x, float beta) {
 #pragma clang fp contract(off)
     const float xb = x * beta;
-    return xb > 20.0f ? x : log1pf(expf(xb)) / beta;
+    const float sp = log1p_nonneg(exp_noclamp(xb));
+    return xb > 20.0f ? x : (beta == 1.0f ? sp : sp / beta);
 }
 
 // One spline evaluation.  `sl` = this lane's P logits in LDS (may be clobbered when KT == 0).
@@ -120,6 +205,11 @@ template <int KT, bool INVERSE>
 __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, float& y, float& lad) {
 #pragma clang fp contract(off)
     const int K = KT > 0 ? KT : sp.K;
+#ifdef NFA_ABLATE_MATH  // experiment only (tools/k1_micro.py): memory pipeline without the arithmetic
+    y = x + sl[0];
+    lad = sl[K];
+    return 0;
+#endif
     if (sp.linear) {
         if (!(x >= sp.left && x <= sp.right)) {  // NaN falls outside too
             y = x;
@@ -135,8 +225,8 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
     Slots<KT> ew, eh;
     ew.bind(sl);
     eh.bind(sl + K);
-    const float den_w = softmax_numerators<KT>(ew, sl, K, sp.divisor);
-    const float den_h = softmax_numerators<KT>(eh, sl + K, K, sp.divisor);
+    const float den_w = softmax_numerators<KT>(ew, sl, K, sp.divisor, sp.rdivisor);
+    const float den_h = softmax_numerators<KT>(eh, sl + K, K, sp.divisor, sp.rdivisor);
 
     int k = -1;
     float cw0 = 0.f, cw1 = 0.f, ch0 = 0.f, ch1 = 0.f;
@@ -158,6 +248,11 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
         walk_bins<KT, false>(eh, K, den_h, sp.min_h, sp.om_h, sp.span_h, sp.bottom, sp.top, x, k, ch0, ch1);
     }
 
+#ifdef NFA_X_NOEVAL
+    y = cw0 + ch0 + cw1 + ch1;
+    lad = (float)k;
+    return 0;
+#endif
     const float* sd = sl + 2 * K;
     float u0, u1;
     if (sp.linear) {  // logits padded with the tail constant on both sides
@@ -172,7 +267,8 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
 
     const float in_w = cw1 - cw0;
     const float in_h = ch1 - ch0;
-    const float delta = in_h / in_w;
+    const float r_w = rcp_refined(in_w);
+    const float delta = div_with_rcp(in_h, in_w, r_w);
     const float s = (d0 + d1) - 2.0f * delta;
     int status = 0;
 
@@ -183,22 +279,22 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
         const float c = (-delta) * yc;
         const float disc = b * b - (4.0f * a) * c;
         if (!(disc >= 0.0f)) status = NFA_STATUS_NEG_DISCRIMINANT;
-        const float root = (2.0f * c) / ((-b) - sqrtf(disc));
+        const float root = div_normal(2.0f * c, (-b) - sqrtf(disc));
         y = root * in_w + cw0;
         const float t1mt = root * (1.0f - root);
         const float den = delta + s * t1mt;
         const float omr = 1.0f - root;
         const float dnum = (delta * delta) * ((d1 * (root * root) + (2.0f * delta) * t1mt) + d0 * (omr * omr));
-        lad = -(logf(dnum) - 2.0f * logf(den));
+        lad = -(log_normal(dnum) - 2.0f * log_normal(den));
     } else {
-        const float theta = (x - cw0) / in_w;
+        const float theta = div_with_rcp(x - cw0, in_w, r_w);
         const float t1mt = theta * (1.0f - theta);
         const float num = in_h * (delta * (theta * theta) + d0 * t1mt);
         const float den = delta + s * t1mt;
-        y = ch0 + num / den;
+        y = ch0 + div_normal(num, den);
         const float omt = 1.0f - theta;
         const float dnum = (delta * delta) * ((d1 * (theta * theta) + (2.0f * delta) * t1mt) + d0 * (omt * omt));
-        lad = logf(dnum) - 2.0f * logf(den);
+        lad = log_normal(dnum) - 2.0f * log_normal(den);
     }
     return status;
 }
@@ -224,8 +320,8 @@ struct CouplingArgs {
     int off_x, off_out, off_lad, off_idx;
 };
 
-template <int KT, bool INVERSE>
-__global__ void __launch_bounds__(kBlock) rqs_coupling_kernel(const CouplingArgs a) {
+template <int KT, bool INVERSE, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) rqs_coupling_kernel(const CouplingArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* s_p = lds;
     float* s_x = lds + a.off_x;
@@ -240,7 +336,7 @@ __global__ void __launch_bounds__(kBlock) rqs_coupling_kernel(const CouplingArgs
     const int D = a.D, dt = a.dt, P = a.sp.P;
     int my_status = 0;
 
-    for (int c = tid; c < D; c += kBlock) {
+    for (int c = tid; c < D; c += BLOCK) {
         int src = c;
         if (a.perm) {
             const int64_t p = a.perm[c];
@@ -258,7 +354,7 @@ __global__ void __launch_bounds__(kBlock) rqs_coupling_kernel(const CouplingArgs
         s_ist[c] = 0;
     }
     __syncthreads();
-    for (int j = tid; j < dt; j += kBlock) {
+    for (int j = tid; j < dt; j += BLOCK) {
         const int64_t t = a.tidx[j];
         if (t < 0 || t >= D) my_status |= NFA_STATUS_BAD_INDEX;
         const int col = (int)(t < 0 ? 0 : (t >= D ? D - 1 : t));
@@ -273,19 +369,19 @@ __global__ void __launch_bounds__(kBlock) rqs_coupling_kernel(const CouplingArgs
         const int rows = (int)((a.batch - row0) < a.R ? (a.batch - row0) : a.R);
         const int nitems = rows * dt;
 
-        const int mp = tile_load(a.params + row0 * (int64_t)dt * P, nitems * P, s_p, tid);
-        const int mx = tile_load(a.x + row0 * D, rows * D, s_x, tid);
+        const int mp = tile_load<BLOCK>(a.params + row0 * (int64_t)dt * P, nitems * P, s_p, tid);
+        const int mx = tile_load<BLOCK>(a.x + row0 * D, rows * D, s_x, tid);
         // the output tile is laid out as the 16-byte aligned image of its global destination
         float* s_o = s_out + tile_store_offset(a.out + row0 * D);
         __syncthreads();
 
         // untouched columns: bit-exact copy (with the fused permutation)
-        for (int e = tid; e < rows * D; e += kBlock) {
+        for (int e = tid; e < rows * D; e += BLOCK) {
             const int r = (int)fastdiv((uint32_t)e, a.div_D);
             const int c = e - r * D;
             if (!s_ist[c]) s_o[e - c + s_dst[c]] = s_x[mx + e - c + s_src[c]];
         }
-        for (int i = tid; i < nitems; i += kBlock) {
+        for (int i = tid; i < nitems; i += BLOCK) {
             const int r = (int)fastdiv((uint32_t)i, a.div_dt);
             const int j = i - r * dt;
             const int col = s_tidx[j];
@@ -297,10 +393,10 @@ __global__ void __launch_bounds__(kBlock) rqs_coupling_kernel(const CouplingArgs
         }
         __syncthreads();
 
-        tile_store(a.out + row0 * D, rows * D, s_out, tid);
+        tile_store<BLOCK>(a.out + row0 * D, rows * D, s_out, tid);
         // per-sample logabsdet: wave w reduces rows w, w+4, ...
         const int wave = tid >> 6, lane = tid & 63;
-        for (int r = wave; r < rows; r += kBlock / kWave) {
+        for (int r = wave; r < rows; r += BLOCK / kWave) {
             float v = 0.0f;
             for (int m = lane; m < dt; m += kWave) v += s_lad[r * dt + m];
             v = wave_sum(v);
@@ -308,6 +404,137 @@ __global__ void __launch_bounds__(kBlock) rqs_coupling_kernel(const CouplingArgs
         }
         // next iteration's loads only touch s_p / s_x, whose readers all passed the barrier above;
         // s_out / s_lad are rewritten only after the next iteration's first barrier.
+    }
+    if (my_status && a.status) atomicOr(a.status, my_status);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// K1, software-pipelined form for 16-byte aligned layouts (d_t*P % 4 == 0, D % 4 == 0, aligned
+// base pointers; the BASELINE shape 32*23 = 736 and D = 64 qualifies).
+//
+// The generic kernel above keeps loads in flight only while a workgroup sits in its load phase.
+// Here every lane carries the NEXT tile in registers (NV float4 of conditioner output + one
+// float4 of inputs): the loads are issued right after the current tile has been written to LDS
+// and stay in flight across the whole evaluation / store phase.  The two workgroup barriers are
+// raw `s_waitcnt lgkmcnt(0); s_barrier` (LDS-only): __syncthreads() would also drain vmcnt and
+// serialise the prefetch.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int KT, bool INVERSE, int NV>
+__global__ void __launch_bounds__(kBlock) rqs_coupling_pipelined(const CouplingArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* s_p = lds;
+    float* s_x = lds + a.off_x;
+    float* s_out = lds + a.off_out;
+    float* s_lad = lds + a.off_lad;
+    int* s_tidx = reinterpret_cast<int*>(lds + a.off_idx);
+    int* s_src = s_tidx + a.dt;
+    int* s_dst = s_src + a.D;
+    unsigned char* s_ist = reinterpret_cast<unsigned char*>(s_dst + a.D);
+
+    const int tid = threadIdx.x;
+    const int D = a.D, dt = a.dt, P = a.sp.P;
+    int my_status = 0;
+
+    for (int c = tid; c < D; c += kBlock) {
+        int src = c, dst = c;
+        if (a.perm) {
+            const int64_t p = a.perm[c];
+            if (p < 0 || p >= D) my_status |= NFA_STATUS_BAD_INDEX;
+            src = (int)(p < 0 ? 0 : (p >= D ? D - 1 : p));
+        }
+        if (a.scatter) {
+            const int64_t p = a.scatter[c];
+            if (p < 0 || p >= D) my_status |= NFA_STATUS_BAD_INDEX;
+            dst = (int)(p < 0 ? 0 : (p >= D ? D - 1 : p));
+        }
+        s_src[c] = src;
+        s_dst[c] = dst;
+        s_ist[c] = 0;
+    }
+    __syncthreads();
+    for (int j = tid; j < dt; j += kBlock) {
+        const int64_t t = a.tidx[j];
+        if (t < 0 || t >= D) my_status |= NFA_STATUS_BAD_INDEX;
+        const int col = (int)(t < 0 ? 0 : (t >= D ? D - 1 : t));
+        s_tidx[j] = col;
+        s_ist[col] = 1;
+    }
+    __syncthreads();
+
+    const int64_t num_tiles = (a.batch + a.R - 1) / a.R;
+    const int row_vec_p = (dt * P) >> 2;  // float4 per sample of conditioner output
+    const int row_vec_x = D >> 2;
+    // explicit scalars, not an array: guarantees the prefetched tile lives in VGPRs
+    float4 pr0, pr1, pr2, pr3, pr4, pr5;
+    float4 xr;
+
+    // Unconditional, index-clamped loads keep pr[]/xr in registers (a conditional refill sends the
+    // array to scratch).  Past the last tile every lane re-reads one float4 of tile 0.
+#define NFA_LD(k)                                                     \
+    if (NV > k) {                                                     \
+        const int v_ = k * kBlock + tid;                              \
+        pr##k = gp_[v_ < nvp_ ? v_ : nvp_ - 1];                       \
+    }
+#define NFA_ST(k)                                                     \
+    if (NV > k) {                                                     \
+        const int v_ = k * kBlock + tid;                              \
+        if (v_ < nvp) reinterpret_cast<float4*>(s_p)[v_] = pr##k;     \
+    }
+#define NFA_ISSUE_TILE(TILE)                                                                   \
+    {                                                                                          \
+        const bool live_ = (TILE) < num_tiles;                                                 \
+        const int64_t row0_ = live_ ? (TILE)*a.R : 0;                                          \
+        const int rows_ = (int)((a.batch - row0_) < a.R ? (a.batch - row0_) : a.R);            \
+        const float4* gp_ = reinterpret_cast<const float4*>(a.params + row0_ * (int64_t)dt * P); \
+        const float4* gx_ = reinterpret_cast<const float4*>(a.x + row0_ * D);                  \
+        const int nvp_ = live_ ? rows_ * row_vec_p : 1, nvx_ = live_ ? rows_ * row_vec_x : 1;  \
+        NFA_LD(0) NFA_LD(1) NFA_LD(2) NFA_LD(3) NFA_LD(4) NFA_LD(5)                            \
+        xr = gx_[tid < nvx_ ? tid : nvx_ - 1];                                                 \
+    }
+
+    int64_t tile = blockIdx.x;
+    NFA_ISSUE_TILE(tile)
+    for (; tile < num_tiles; tile += gridDim.x) {
+        const int64_t row0 = tile * a.R;
+        const int rows = (int)((a.batch - row0) < a.R ? (a.batch - row0) : a.R);
+        const int nitems = rows * dt;
+        const int nvp = rows * row_vec_p, nvx = rows * row_vec_x;
+        NFA_ST(0) NFA_ST(1) NFA_ST(2) NFA_ST(3) NFA_ST(4) NFA_ST(5)
+        if (tid < nvx) reinterpret_cast<float4*>(s_x)[tid] = xr;
+        const int64_t next = tile + gridDim.x;
+        NFA_ISSUE_TILE(next)  // in flight until the next iteration's LDS writes
+        float* s_o = s_out + tile_store_offset(a.out + row0 * D);
+        lds_barrier();
+
+        for (int e = tid; e < rows * D; e += kBlock) {
+            const int r = (int)fastdiv((uint32_t)e, a.div_D);
+            const int c = e - r * D;
+            if (!s_ist[c]) s_o[e - c + s_dst[c]] = s_x[e - c + s_src[c]];
+        }
+        for (int i = tid; i < nitems; i += kBlock) {
+            const int r = (int)fastdiv((uint32_t)i, a.div_dt);
+            const int j = i - r * dt;
+            const int col = s_tidx[j];
+            const float xin = s_x[r * D + s_src[col]];
+            float y, l;
+            my_status |= rqs_eval<KT, INVERSE>(xin, s_p + i * P, a.sp, y, l);
+            s_o[r * D + s_dst[col]] = y;
+            s_lad[i] = l;
+        }
+        lds_barrier();
+
+        tile_store(a.out + row0 * D, rows * D, s_out, tid);
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int r = wave; r < rows; r += kBlock / kWave) {
+            float v = 0.0f;
+            for (int m = lane; m < dt; m += kWave) v += s_lad[r * dt + m];
+            v = wave_sum(v);
+            if (lane == 0) a.lad[row0 + r] = v;
+        }
     }
     if (my_status && a.status) atomicOr(a.status, my_status);
 }
@@ -393,17 +620,28 @@ static int make_dev_spec(const nfa_rqs_spec* s, RqsDev* d) {
     d->beta = (float)s->softplus_beta;
     d->tail_logit = (float)s->tail_logit;
     d->divisor = (float)s->wh_divisor;
+    d->rdivisor = d->divisor != 0.0f ? 1.0f / d->divisor : 0.0f;
     return NFA_OK;
 }
 
 constexpr int kMaxDynLds = 64 * 1024;
 
-template <int KT>
+template <int KT, int BLOCK>
 static int launch_coupling(const CouplingArgs& a, int inverse, dim3 grid, size_t lds, hipStream_t st) {
     if (inverse)
-        hipLaunchKernelGGL((rqs_coupling_kernel<KT, true>), grid, dim3(kBlock), lds, st, a);
+        hipLaunchKernelGGL((rqs_coupling_kernel<KT, true, BLOCK>), grid, dim3(BLOCK), lds, st, a);
     else
-        hipLaunchKernelGGL((rqs_coupling_kernel<KT, false>), grid, dim3(kBlock), lds, st, a);
+        hipLaunchKernelGGL((rqs_coupling_kernel<KT, false, BLOCK>), grid, dim3(BLOCK), lds, st, a);
+    NFA_HIP_CHECK(hipGetLastError());
+    return NFA_OK;
+}
+
+template <int KT, int NV>
+static int launch_pipelined(const CouplingArgs& a, int inverse, dim3 grid, size_t lds, hipStream_t st) {
+    if (inverse)
+        hipLaunchKernelGGL((rqs_coupling_pipelined<KT, true, NV>), grid, dim3(kBlock), lds, st, a);
+    else
+        hipLaunchKernelGGL((rqs_coupling_pipelined<KT, false, NV>), grid, dim3(kBlock), lds, st, a);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
 }
@@ -439,8 +677,13 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
     if (features > 65535) return NFA_ERR_UNSUPPORTED;
 
     const int P = a.sp.P, D = features, dt = num_transform;
+    static const int block_threads = [] {
+        const char* e = getenv("NFA_K1_BLOCK");
+        return e ? atoi(e) : NFA_K1_BLOCK_DEFAULT;
+    }();
+    const int BT = block_threads == 64 ? 64 : kBlock;
     // samples per tile: aim at one item per lane, whole samples, LDS within budget
-    int R = dt > 0 ? kBlock / dt : kBlock / (D < kBlock ? D : kBlock);
+    int R = dt > 0 ? BT / dt : BT / (D < BT ? D : BT);
     if (R < 1) R = 1;
     if ((int64_t)R > batch) R = (int)batch;
     auto lds_floats = [&](int r, int* ox, int* oo, int* ol, int* oi) {
@@ -483,15 +726,45 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
     const int64_t tiles = (batch + R - 1) / R;
     const int cus = device_cu_count();
     int per_cu = (int)((size_t)(160 * 1024) / (lds + 256));
-    if (per_cu > 8) per_cu = 8;
+    const int cap = BT == 64 ? 24 : 8;
+    if (per_cu > cap) per_cu = cap;
     if (per_cu < 1) per_cu = 1;
     int64_t g = (int64_t)cus * per_cu;
     if (g > tiles) g = tiles;
     const dim3 grid((unsigned)g);
     hipStream_t st = (hipStream_t)stream;
+    // aligned layouts take the software-pipelined kernel
+    static const int use_pipe = [] {
+        const char* e = getenv("NFA_K1_PIPELINE");
+        return e ? atoi(e) : 1;
+    }();
+    const int nv = (int)(((int64_t)R * dt * P / 4 + kBlock - 1) / kBlock);
+    const bool aligned = dt > 0 && (dt * P) % 4 == 0 && D % 4 == 0 && R * D / 4 <= kBlock &&
+                         (reinterpret_cast<uintptr_t>(params) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(inputs) & 15) == 0;
+    if (use_pipe && BT == kBlock && aligned && nv <= 6 && a.sp.K == 8) {
+        // one block fewer per CU than LDS alone would allow: the prefetch registers cost occupancy
+        int64_t gp = (int64_t)cus * (per_cu > 4 ? 4 : per_cu);
+        if (gp > tiles) gp = tiles;
+        const dim3 pgrid((unsigned)gp);
+        switch (nv) {
+            case 6: return launch_pipelined<8, 6>(a, inverse, pgrid, lds, st);
+            case 5: return launch_pipelined<8, 5>(a, inverse, pgrid, lds, st);
+            case 4: return launch_pipelined<8, 4>(a, inverse, pgrid, lds, st);
+            case 3: return launch_pipelined<8, 3>(a, inverse, pgrid, lds, st);
+            case 2: return launch_pipelined<8, 2>(a, inverse, pgrid, lds, st);
+            default: return launch_pipelined<8, 1>(a, inverse, pgrid, lds, st);
+        }
+    }
+    if (BT == 64) {
+        switch (a.sp.K) {
+            case 8: return launch_coupling<8, 64>(a, inverse, grid, lds, st);
+            default: return launch_coupling<0, 64>(a, inverse, grid, lds, st);
+        }
+    }
     switch (a.sp.K) {
-        case 8: return launch_coupling<8>(a, inverse, grid, lds, st);
-        default: return launch_coupling<0>(a, inverse, grid, lds, st);
+        case 8: return launch_coupling<8, kBlock>(a, inverse, grid, lds, st);
+        default: return launch_coupling<0, kBlock>(a, inverse, grid, lds, st);
     }
 }
 

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the K1 kernel alone (fused RQ coupling layer, BASELINE layer shape):
+B=65536, D=64, d_t=32, K=8, linear tails.  Prints avg us per launch and algorithmic GB/s.
+
+    NFLOWS_AMD_LIB=/path/to/variant.so python tools/k1_micro.py [--inverse] [--batch B] [--reps N]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nflows_amd import ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=65536)
+ap.add_argument("--features", type=int, default=64)
+ap.add_argument("--bins", type=int, default=8)
+ap.add_argument("--reps", type=int, default=50)
+ap.add_argument("--inverse", action="store_true")
+ap.add_argument("--perm", action="store_true")
+ap.add_argument("--check", action="store_true")
+a = ap.parse_args()
+
+dev = "cuda:0"
+B, D, K = a.batch, a.features, a.bins
+g = torch.Generator(device=dev).manual_seed(0)
+x = torch.randn(B, D, device=dev, generator=g)
+tidx = torch.arange(0, D, 2, device=dev)
+P = 3 * K - 1
+# distinct parameter buffers per rep so that nothing is served from the 256 MiB Infinity Cache
+nbuf = 4
+params = [torch.randn(B, tidx.numel() * P, device=dev, generator=g) for _ in range(nbuf)]
+perm = torch.randperm(D, device=dev) if a.perm else None
+spec = ops.make_rqs_spec(K, "linear", tail_bound=3.0, wh_divisor=float(np.sqrt(128)))
+for i in range(5):
+    y, lad = ops.rqs_coupling(x, params[i % nbuf], tidx, spec, inverse=a.inverse, in_perm=perm)
+torch.cuda.synchronize()
+evs = []
+for i in range(a.reps):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    y, lad = ops.rqs_coupling(x, params[i % nbuf], tidx, spec, inverse=a.inverse, in_perm=perm)
+    e.record()
+    evs.append((s, e))
+torch.cuda.synchronize()
+ms = sorted(s.elapsed_time(e) for s, e in evs)
+med = ms[len(ms) // 2]
+nbytes = 4 * (B * D + B * tidx.numel() * P + B * D + B)
+print("%s lib=%s  median %.1f us  min %.1f us  -> %.0f GB/s algorithmic (median)" % (
+    "inverse" if a.inverse else "forward", os.path.basename(os.environ.get("NFLOWS_AMD_LIB", "default")),
+    med * 1e3, ms[0] * 1e3, nbytes / (med * 1e-3) / 1e9))
+if a.check:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import capi
+    rows = slice(0, 4096)
+    ospec = capi.make_spec(K, tails="linear", tail_bound=3.0, wh_divisor=float(np.sqrt(128)))
+    pidx = None if perm is None else perm.cpu().numpy()
+    oy, ol, _ = capi.rqs_coupling(x[rows].cpu().numpy(), params[(a.reps - 1) % nbuf][rows].cpu().numpy(),
+                                  tidx.cpu().numpy(), ospec, inverse=a.inverse, in_perm=pidx)
+    print("  max |y - oracle| = %.2e   max |lad - oracle| = %.2e" % (
+        np.abs(y[rows].cpu().numpy() - oy).max(), np.abs(lad[rows].cpu().numpy() - ol).max()))
