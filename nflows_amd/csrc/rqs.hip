@@ -201,7 +201,9 @@ __device__ __forceinline__ float softplus_beta(float x, float beta) {
 }
 
 // One spline evaluation.  `sl` = this lane's P logits in LDS (may be clobbered when KT == 0).
-template <int KT, bool INVERSE>
+//   LINEAR = true: linear tails, box [-B, B]^2 (B = sp.right); only sp.right / span_w / right_eps
+//   and the per-side minimums are read, which keeps the kernel's scalar-register footprint down.
+template <int KT, bool INVERSE, bool LINEAR>
 __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, float& y, float& lad) {
 #pragma clang fp contract(off)
     const int K = KT > 0 ? KT : sp.K;
@@ -210,13 +212,21 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
     lad = sl[K];
     return 0;
 #endif
-    if (sp.linear) {
-        if (!(x >= sp.left && x <= sp.right)) {  // NaN falls outside too
+    const float left = LINEAR ? -sp.right : sp.left;
+    const float right = sp.right;
+    const float bottom = LINEAR ? -sp.right : sp.bottom;
+    const float top = LINEAR ? sp.right : sp.top;
+    const float span_w = sp.span_w;
+    const float span_h = LINEAR ? sp.span_w : sp.span_h;
+    const float right_eps = sp.right_eps;
+    const float top_eps = LINEAR ? sp.right_eps : sp.top_eps;
+    if (LINEAR) {
+        if (!(x >= left && x <= right)) {  // NaN falls outside too
             y = x;
             lad = 0.0f;
             return 0;
         }
-    } else if (x < sp.left || x > sp.right) {
+    } else if (x < left || x > right) {
         y = x;
         lad = 0.0f;
         return NFA_STATUS_OUTSIDE_DOMAIN;
@@ -231,21 +241,21 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
     int k = -1;
     float cw0 = 0.f, cw1 = 0.f, ch0 = 0.f, ch1 = 0.f;
     if (INVERSE) {
-        walk_bins<KT, true>(eh, K, den_h, sp.min_h, sp.om_h, sp.span_h, sp.bottom, sp.top, x, k, ch0, ch1);
-        if (k < 0 || x >= sp.top_eps) {
+        walk_bins<KT, true>(eh, K, den_h, sp.min_h, sp.om_h, span_h, bottom, top, x, k, ch0, ch1);
+        if (k < 0 || x >= top_eps) {
             y = x;
             lad = 0.0f;
             return NFA_STATUS_OUTSIDE_DOMAIN;
         }
-        walk_bins<KT, false>(ew, K, den_w, sp.min_w, sp.om_w, sp.span_w, sp.left, sp.right, x, k, cw0, cw1);
+        walk_bins<KT, false>(ew, K, den_w, sp.min_w, sp.om_w, span_w, left, right, x, k, cw0, cw1);
     } else {
-        walk_bins<KT, true>(ew, K, den_w, sp.min_w, sp.om_w, sp.span_w, sp.left, sp.right, x, k, cw0, cw1);
-        if (k < 0 || x >= sp.right_eps) {
+        walk_bins<KT, true>(ew, K, den_w, sp.min_w, sp.om_w, span_w, left, right, x, k, cw0, cw1);
+        if (k < 0 || x >= right_eps) {
             y = x;
             lad = 0.0f;
             return NFA_STATUS_OUTSIDE_DOMAIN;
         }
-        walk_bins<KT, false>(eh, K, den_h, sp.min_h, sp.om_h, sp.span_h, sp.bottom, sp.top, x, k, ch0, ch1);
+        walk_bins<KT, false>(eh, K, den_h, sp.min_h, sp.om_h, span_h, bottom, top, x, k, ch0, ch1);
     }
 
 #ifdef NFA_X_NOEVAL
@@ -255,7 +265,7 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
 #endif
     const float* sd = sl + 2 * K;
     float u0, u1;
-    if (sp.linear) {  // logits padded with the tail constant on both sides
+    if (LINEAR) {  // logits padded with the tail constant on both sides
         u0 = (k == 0) ? sp.tail_logit : sd[k - 1];
         u1 = (k >= sp.nd) ? sp.tail_logit : sd[k];  // padded index k+1 past the given logits
     } else {
@@ -387,7 +397,8 @@ __global__ void __launch_bounds__(BLOCK) rqs_coupling_kernel(const CouplingArgs 
             const int col = s_tidx[j];
             const float xin = s_x[mx + r * D + s_src[col]];
             float y, l;
-            my_status |= rqs_eval<KT, INVERSE>(xin, s_p + mp + i * P, a.sp, y, l);
+            my_status |= a.sp.linear ? rqs_eval<KT, INVERSE, true>(xin, s_p + mp + i * P, a.sp, y, l)
+                                     : rqs_eval<KT, INVERSE, false>(xin, s_p + mp + i * P, a.sp, y, l);
             s_o[r * D + s_dst[col]] = y;
             s_lad[i] = l;
         }
@@ -423,8 +434,12 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int KT, bool INVERSE, int NV>
+template <int KT, bool INVERSE, bool LINEAR, int NV>
 __global__ void __launch_bounds__(kBlock) rqs_coupling_pipelined(const CouplingArgs a) {
+    // Preconditions (checked by the host): every tile is full (a.batch % a.R == 0 here; the host
+    // sends leftover rows to the generic kernel), R*dt <= 256 (one spline per lane),
+    // R*D <= 512 (<= 2 pass-through slots per lane, <= 128 float4 of inputs per tile),
+    // dt*P % 4 == 0, D % 4 == 0, 16-byte aligned params / inputs / outputs.
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* s_p = lds;
     float* s_x = lds + a.off_x;
@@ -436,7 +451,7 @@ __global__ void __launch_bounds__(kBlock) rqs_coupling_pipelined(const CouplingA
     unsigned char* s_ist = reinterpret_cast<unsigned char*>(s_dst + a.D);
 
     const int tid = threadIdx.x;
-    const int D = a.D, dt = a.dt, P = a.sp.P;
+    const int D = a.D, dt = a.dt, P = a.sp.P, R = a.R;
     int my_status = 0;
 
     for (int c = tid; c < D; c += kBlock) {
@@ -465,77 +480,104 @@ __global__ void __launch_bounds__(kBlock) rqs_coupling_pipelined(const CouplingA
     }
     __syncthreads();
 
-    const int64_t num_tiles = (a.batch + a.R - 1) / a.R;
-    const int row_vec_p = (dt * P) >> 2;  // float4 per sample of conditioner output
-    const int row_vec_x = D >> 2;
-    // explicit scalars, not an array: guarantees the prefetched tile lives in VGPRs
+    // ---- per-lane tile-invariant state ------------------------------------------------------
+    const int nitems = R * dt;            // <= 256
+    const int nvp = (nitems * P) >> 2;    // float4 of conditioner output per tile
+    const int nvx = (R * D) >> 2;         // float4 of inputs / outputs per tile (<= 128)
+    const bool has_item = tid < nitems;
+    int it_x = 0, it_y = 0;               // LDS word offsets of this lane's input / output
+    {
+        const int i = has_item ? tid : 0;
+        const int r = (int)fastdiv((uint32_t)i, a.div_dt);
+        const int col = s_tidx[i - r * dt];
+        it_x = r * D + s_src[col];
+        it_y = r * D + s_dst[col];
+    }
+    const float* it_p = s_p + (has_item ? tid : 0) * P;
+    // pass-through copies: elements tid and tid + 256 of the [R, D] tile
+    int cp_src0 = -1, cp_dst0 = 0, cp_src1 = -1, cp_dst1 = 0;
+    {
+        const int e0 = tid, e1 = tid + kBlock;
+        if (e0 < R * D) {
+            const int r = (int)fastdiv((uint32_t)e0, a.div_D), c = e0 - r * D;
+            if (!s_ist[c]) { cp_src0 = e0 - c + s_src[c]; cp_dst0 = e0 - c + s_dst[c]; }
+        }
+        if (e1 < R * D) {
+            const int r = (int)fastdiv((uint32_t)e1, a.div_D), c = e1 - r * D;
+            if (!s_ist[c]) { cp_src1 = e1 - c + s_src[c]; cp_dst1 = e1 - c + s_dst[c]; }
+        }
+    }
+    // logabsdet: when the d_t splines of a sample sit in d_t consecutive lanes of one wave
+    // (d_t a power of two <= 64) the per-sample sum is a butterfly over those lanes
+    const bool lad_shuffle = (dt & (dt - 1)) == 0 && dt <= kWave;
+    const int64_t tile_stride_p = (int64_t)nitems * P;  // floats
+    const int tile_stride_x = R * D;
+
     float4 pr0, pr1, pr2, pr3, pr4, pr5;
     float4 xr;
-
-    // Unconditional, index-clamped loads keep pr[]/xr in registers (a conditional refill sends the
-    // array to scratch).  Past the last tile every lane re-reads one float4 of tile 0.
-#define NFA_LD(k)                                                     \
-    if (NV > k) {                                                     \
-        const int v_ = k * kBlock + tid;                              \
-        pr##k = gp_[v_ < nvp_ ? v_ : nvp_ - 1];                       \
+#define NFA_LD(k)                                                              \
+    if (NV > k) {                                                              \
+        const int v_ = k * kBlock + tid;                                       \
+        pr##k = gp_[v_ < nvp ? v_ : nvp - 1];                                  \
     }
-#define NFA_ST(k)                                                     \
-    if (NV > k) {                                                     \
-        const int v_ = k * kBlock + tid;                              \
-        if (v_ < nvp) reinterpret_cast<float4*>(s_p)[v_] = pr##k;     \
+#define NFA_ST(k)                                                              \
+    if (NV > k) {                                                              \
+        const int v_ = k * kBlock + tid;                                       \
+        if (v_ < nvp) reinterpret_cast<float4*>(s_p)[v_] = pr##k;              \
     }
-#define NFA_ISSUE_TILE(TILE)                                                                   \
-    {                                                                                          \
-        const bool live_ = (TILE) < num_tiles;                                                 \
-        const int64_t row0_ = live_ ? (TILE)*a.R : 0;                                          \
-        const int rows_ = (int)((a.batch - row0_) < a.R ? (a.batch - row0_) : a.R);            \
-        const float4* gp_ = reinterpret_cast<const float4*>(a.params + row0_ * (int64_t)dt * P); \
-        const float4* gx_ = reinterpret_cast<const float4*>(a.x + row0_ * D);                  \
-        const int nvp_ = live_ ? rows_ * row_vec_p : 1, nvx_ = live_ ? rows_ * row_vec_x : 1;  \
-        NFA_LD(0) NFA_LD(1) NFA_LD(2) NFA_LD(3) NFA_LD(4) NFA_LD(5)                            \
-        xr = gx_[tid < nvx_ ? tid : nvx_ - 1];                                                 \
+    // index-clamped, unconditional loads: the tile stays in VGPRs; past the last tile the lanes
+    // re-read tile 0 (L2-resident by then), the data is never used
+#define NFA_ISSUE_TILE(TILE)                                                                    \
+    {                                                                                           \
+        const int64_t t_ = (TILE) < num_tiles ? (TILE) : 0;                                     \
+        const float4* gp_ = reinterpret_cast<const float4*>(a.params + t_ * tile_stride_p);     \
+        const float4* gx_ = reinterpret_cast<const float4*>(a.x + t_ * tile_stride_x);          \
+        NFA_LD(0) NFA_LD(1) NFA_LD(2) NFA_LD(3) NFA_LD(4) NFA_LD(5)                             \
+        xr = gx_[tid < nvx ? tid : nvx - 1];                                                    \
     }
 
+    const int64_t num_tiles = a.batch / R;
     int64_t tile = blockIdx.x;
     NFA_ISSUE_TILE(tile)
     for (; tile < num_tiles; tile += gridDim.x) {
-        const int64_t row0 = tile * a.R;
-        const int rows = (int)((a.batch - row0) < a.R ? (a.batch - row0) : a.R);
-        const int nitems = rows * dt;
-        const int nvp = rows * row_vec_p, nvx = rows * row_vec_x;
         NFA_ST(0) NFA_ST(1) NFA_ST(2) NFA_ST(3) NFA_ST(4) NFA_ST(5)
         if (tid < nvx) reinterpret_cast<float4*>(s_x)[tid] = xr;
         const int64_t next = tile + gridDim.x;
         NFA_ISSUE_TILE(next)  // in flight until the next iteration's LDS writes
-        float* s_o = s_out + tile_store_offset(a.out + row0 * D);
         lds_barrier();
 
-        for (int e = tid; e < rows * D; e += kBlock) {
-            const int r = (int)fastdiv((uint32_t)e, a.div_D);
-            const int c = e - r * D;
-            if (!s_ist[c]) s_o[e - c + s_dst[c]] = s_x[e - c + s_src[c]];
+        if (cp_src0 >= 0) s_out[cp_dst0] = s_x[cp_src0];
+        if (cp_src1 >= 0) s_out[cp_dst1] = s_x[cp_src1];
+        float l = 0.0f;
+        if (has_item) {
+            float y;
+            my_status |= rqs_eval<KT, INVERSE, LINEAR>(s_x[it_x], const_cast<float*>(it_p), a.sp, y, l);
+            s_out[it_y] = y;
         }
-        for (int i = tid; i < nitems; i += kBlock) {
-            const int r = (int)fastdiv((uint32_t)i, a.div_dt);
-            const int j = i - r * dt;
-            const int col = s_tidx[j];
-            const float xin = s_x[r * D + s_src[col]];
-            float y, l;
-            my_status |= rqs_eval<KT, INVERSE>(xin, s_p + i * P, a.sp, y, l);
-            s_o[r * D + s_dst[col]] = y;
-            s_lad[i] = l;
+        const int64_t row0 = tile * R;
+        if (lad_shuffle) {
+            for (int off = dt >> 1; off > 0; off >>= 1) l += __shfl_xor(l, off, kWave);
+            if (has_item && (tid & (dt - 1)) == 0) a.lad[row0 + (tid >> __builtin_ctz(dt))] = l;
+        } else {
+            s_lad[tid] = l;
         }
         lds_barrier();
 
-        tile_store(a.out + row0 * D, rows * D, s_out, tid);
-        const int wave = tid >> 6, lane = tid & 63;
-        for (int r = wave; r < rows; r += kBlock / kWave) {
-            float v = 0.0f;
-            for (int m = lane; m < dt; m += kWave) v += s_lad[r * dt + m];
-            v = wave_sum(v);
-            if (lane == 0) a.lad[row0 + r] = v;
+        if (tid < nvx)
+            reinterpret_cast<float4*>(a.out + row0 * D)[tid] = reinterpret_cast<const float4*>(s_out)[tid];
+        if (!lad_shuffle) {
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int r = wave; r < R; r += kBlock / kWave) {
+                float v = 0.0f;
+                for (int m = lane; m < dt; m += kWave) v += s_lad[r * dt + m];
+                v = wave_sum(v);
+                if (lane == 0) a.lad[row0 + r] = v;
+            }
         }
     }
+#undef NFA_ISSUE_TILE
+#undef NFA_LD
+#undef NFA_ST
     if (my_status && a.status) atomicOr(a.status, my_status);
 }
 
@@ -584,7 +626,8 @@ __global__ void __launch_bounds__(kBlock) rqs_elementwise_kernel(const Elementwi
         }
         if (tid < cnt) {
             float y, l;
-            my_status |= rqs_eval<KT, INVERSE>(a.x[i0 + tid], mine, a.sp, y, l);
+            my_status |= a.sp.linear ? rqs_eval<KT, INVERSE, true>(a.x[i0 + tid], mine, a.sp, y, l)
+                                     : rqs_eval<KT, INVERSE, false>(a.x[i0 + tid], mine, a.sp, y, l);
             a.y[i0 + tid] = y;
             a.lad[i0 + tid] = l;
         }
@@ -638,10 +681,17 @@ static int launch_coupling(const CouplingArgs& a, int inverse, dim3 grid, size_t
 
 template <int KT, int NV>
 static int launch_pipelined(const CouplingArgs& a, int inverse, dim3 grid, size_t lds, hipStream_t st) {
-    if (inverse)
-        hipLaunchKernelGGL((rqs_coupling_pipelined<KT, true, NV>), grid, dim3(kBlock), lds, st, a);
-    else
-        hipLaunchKernelGGL((rqs_coupling_pipelined<KT, false, NV>), grid, dim3(kBlock), lds, st, a);
+    if (a.sp.linear) {
+        if (inverse)
+            hipLaunchKernelGGL((rqs_coupling_pipelined<KT, true, true, NV>), grid, dim3(kBlock), lds, st, a);
+        else
+            hipLaunchKernelGGL((rqs_coupling_pipelined<KT, false, true, NV>), grid, dim3(kBlock), lds, st, a);
+    } else {
+        if (inverse)
+            hipLaunchKernelGGL((rqs_coupling_pipelined<KT, true, false, NV>), grid, dim3(kBlock), lds, st, a);
+        else
+            hipLaunchKernelGGL((rqs_coupling_pipelined<KT, false, false, NV>), grid, dim3(kBlock), lds, st, a);
+    }
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
 }
@@ -739,22 +789,36 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
         return e ? atoi(e) : 1;
     }();
     const int nv = (int)(((int64_t)R * dt * P / 4 + kBlock - 1) / kBlock);
-    const bool aligned = dt > 0 && (dt * P) % 4 == 0 && D % 4 == 0 && R * D / 4 <= kBlock &&
+    const bool aligned = dt > 0 && (dt * P) % 4 == 0 && D % 4 == 0 && R * dt <= kBlock &&
+                         R * D <= 2 * kBlock && (int64_t)R <= batch &&
                          (reinterpret_cast<uintptr_t>(params) & 15) == 0 &&
-                         (reinterpret_cast<uintptr_t>(inputs) & 15) == 0;
+                         (reinterpret_cast<uintptr_t>(inputs) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(outputs) & 15) == 0;
     if (use_pipe && BT == kBlock && aligned && nv <= 6 && a.sp.K == 8) {
+        const int64_t full_rows = (batch / R) * R;
+        CouplingArgs f = a;
+        f.batch = full_rows;
         // one block fewer per CU than LDS alone would allow: the prefetch registers cost occupancy
         int64_t gp = (int64_t)cus * (per_cu > 4 ? 4 : per_cu);
-        if (gp > tiles) gp = tiles;
+        if (gp > full_rows / R) gp = full_rows / R;
         const dim3 pgrid((unsigned)gp);
+        int prc;
         switch (nv) {
-            case 6: return launch_pipelined<8, 6>(a, inverse, pgrid, lds, st);
-            case 5: return launch_pipelined<8, 5>(a, inverse, pgrid, lds, st);
-            case 4: return launch_pipelined<8, 4>(a, inverse, pgrid, lds, st);
-            case 3: return launch_pipelined<8, 3>(a, inverse, pgrid, lds, st);
-            case 2: return launch_pipelined<8, 2>(a, inverse, pgrid, lds, st);
-            default: return launch_pipelined<8, 1>(a, inverse, pgrid, lds, st);
+            case 6: prc = launch_pipelined<8, 6>(f, inverse, pgrid, lds, st); break;
+            case 5: prc = launch_pipelined<8, 5>(f, inverse, pgrid, lds, st); break;
+            case 4: prc = launch_pipelined<8, 4>(f, inverse, pgrid, lds, st); break;
+            case 3: prc = launch_pipelined<8, 3>(f, inverse, pgrid, lds, st); break;
+            case 2: prc = launch_pipelined<8, 2>(f, inverse, pgrid, lds, st); break;
+            default: prc = launch_pipelined<8, 1>(f, inverse, pgrid, lds, st); break;
         }
+        if (prc != NFA_OK || full_rows == batch) return prc;
+        // leftover rows (< R): generic kernel on the tail of every array
+        a.x = inputs + full_rows * D;
+        a.params = params + full_rows * (int64_t)dt * P;
+        a.out = outputs + full_rows * D;
+        a.lad = logabsdet + full_rows;
+        a.batch = batch - full_rows;
+        return launch_coupling<8, kBlock>(a, inverse, dim3(1), lds, st);
     }
     if (BT == 64) {
         switch (a.sp.K) {
