@@ -434,8 +434,18 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+typedef float vec4 __attribute__((ext_vector_type(4)));  // native 16-byte vector
+// conditioner output is read exactly once: optionally mark the loads non-temporal
+#ifdef NFA_NT_LOADS
+#define NFA_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define NFA_STREAM_LOAD(p) (*(p))
+#endif
+#ifndef NFA_PIPE_WAVES
+#define NFA_PIPE_WAVES 4
+#endif
 template <int KT, bool INVERSE, bool LINEAR, int NV>
-__global__ void __launch_bounds__(kBlock) rqs_coupling_pipelined(const CouplingArgs a) {
+__global__ void __launch_bounds__(kBlock, NFA_PIPE_WAVES) rqs_coupling_pipelined(const CouplingArgs a) {
     // Preconditions (checked by the host): every tile is full (a.batch % a.R == 0 here; the host
     // sends leftover rows to the generic kernel), R*dt <= 256 (one spline per lane),
     // R*D <= 512 (<= 2 pass-through slots per lane, <= 128 float4 of inputs per tile),
@@ -513,25 +523,25 @@ __global__ void __launch_bounds__(kBlock) rqs_coupling_pipelined(const CouplingA
     const int64_t tile_stride_p = (int64_t)nitems * P;  // floats
     const int tile_stride_x = R * D;
 
-    float4 pr0, pr1, pr2, pr3, pr4, pr5;
-    float4 xr;
+    vec4 pr0, pr1, pr2, pr3, pr4, pr5;
+    vec4 xr;
 #define NFA_LD(k)                                                              \
     if (NV > k) {                                                              \
         const int v_ = k * kBlock + tid;                                       \
-        pr##k = gp_[v_ < nvp ? v_ : nvp - 1];                                  \
+        pr##k = NFA_STREAM_LOAD(&gp_[v_ < nvp ? v_ : nvp - 1]);                \
     }
 #define NFA_ST(k)                                                              \
     if (NV > k) {                                                              \
         const int v_ = k * kBlock + tid;                                       \
-        if (v_ < nvp) reinterpret_cast<float4*>(s_p)[v_] = pr##k;              \
+        if (v_ < nvp) reinterpret_cast<vec4*>(s_p)[v_] = pr##k;              \
     }
     // index-clamped, unconditional loads: the tile stays in VGPRs; past the last tile the lanes
     // re-read tile 0 (L2-resident by then), the data is never used
 #define NFA_ISSUE_TILE(TILE)                                                                    \
     {                                                                                           \
         const int64_t t_ = (TILE) < num_tiles ? (TILE) : 0;                                     \
-        const float4* gp_ = reinterpret_cast<const float4*>(a.params + t_ * tile_stride_p);     \
-        const float4* gx_ = reinterpret_cast<const float4*>(a.x + t_ * tile_stride_x);          \
+        const vec4* gp_ = reinterpret_cast<const vec4*>(a.params + t_ * tile_stride_p);     \
+        const vec4* gx_ = reinterpret_cast<const vec4*>(a.x + t_ * tile_stride_x);          \
         NFA_LD(0) NFA_LD(1) NFA_LD(2) NFA_LD(3) NFA_LD(4) NFA_LD(5)                             \
         xr = gx_[tid < nvx ? tid : nvx - 1];                                                    \
     }
@@ -541,7 +551,7 @@ __global__ void __launch_bounds__(kBlock) rqs_coupling_pipelined(const CouplingA
     NFA_ISSUE_TILE(tile)
     for (; tile < num_tiles; tile += gridDim.x) {
         NFA_ST(0) NFA_ST(1) NFA_ST(2) NFA_ST(3) NFA_ST(4) NFA_ST(5)
-        if (tid < nvx) reinterpret_cast<float4*>(s_x)[tid] = xr;
+        if (tid < nvx) reinterpret_cast<vec4*>(s_x)[tid] = xr;
         const int64_t next = tile + gridDim.x;
         NFA_ISSUE_TILE(next)  // in flight until the next iteration's LDS writes
         lds_barrier();
@@ -564,7 +574,7 @@ __global__ void __launch_bounds__(kBlock) rqs_coupling_pipelined(const CouplingA
         lds_barrier();
 
         if (tid < nvx)
-            reinterpret_cast<float4*>(a.out + row0 * D)[tid] = reinterpret_cast<const float4*>(s_out)[tid];
+            reinterpret_cast<vec4*>(a.out + row0 * D)[tid] = reinterpret_cast<const vec4*>(s_out)[tid];
         if (!lad_shuffle) {
             const int wave = tid >> 6, lane = tid & 63;
             for (int r = wave; r < R; r += kBlock / kWave) {
@@ -799,7 +809,7 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
         CouplingArgs f = a;
         f.batch = full_rows;
         // one block fewer per CU than LDS alone would allow: the prefetch registers cost occupancy
-        int64_t gp = (int64_t)cus * (per_cu > 4 ? 4 : per_cu);
+        int64_t gp = (int64_t)cus * (per_cu > NFA_PIPE_WAVES ? NFA_PIPE_WAVES : per_cu);
         if (gp > full_rows / R) gp = full_rows / R;
         const dim3 pgrid((unsigned)gp);
         int prc;

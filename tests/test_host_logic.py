@@ -1,0 +1,208 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the header
+declares, the drop-in classes keep the reference's constructor / buffer / state_dict contract,
+argument errors match the reference's, and the product never falls back to a CPU path."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    header = open(os.path.join(ROOT, "include", "nflows_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(nfa_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 11
+    from nflows_amd import _native
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "libnflows_amd.so does not export " + name
+    assert sorted(_native.EXPORTS) == declared  # the Python binding covers the whole ABI
+    loaded = _native.load()
+    assert loaded.nfa_abi_version() == _native.ABI_VERSION
+    assert loaded.nfa_build_arch() == b"gfx950"
+    assert loaded.nfa_strerror(_native.ERR_MIN_BIN_WIDTH) == b"Minimal bin width too large for the number of bins"
+
+
+def test_header_constants_match_binding():
+    header = open(os.path.join(ROOT, "include", "nflows_amd.h")).read()
+    from nflows_amd import _native as N
+    consts = dict(re.findall(r"#define\s+(NFA_[A-Z_]+)\s+(\d+)", header))
+    assert int(consts["NFA_ABI_VERSION"]) == N.ABI_VERSION
+    for py, c in [("OK", "NFA_OK"), ("ERR_INVALID_ARGUMENT", "NFA_ERR_INVALID_ARGUMENT"),
+                  ("ERR_UNSUPPORTED", "NFA_ERR_UNSUPPORTED"), ("ERR_MIN_BIN_WIDTH", "NFA_ERR_MIN_BIN_WIDTH"),
+                  ("ERR_MIN_BIN_HEIGHT", "NFA_ERR_MIN_BIN_HEIGHT"), ("ERR_HIP", "NFA_ERR_HIP"),
+                  ("STATUS_OUTSIDE_DOMAIN", "NFA_STATUS_OUTSIDE_DOMAIN"),
+                  ("STATUS_NEG_DISCRIMINANT", "NFA_STATUS_NEG_DISCRIMINANT"),
+                  ("STATUS_BAD_INDEX", "NFA_STATUS_BAD_INDEX"), ("TAILS_NONE", "NFA_TAILS_NONE"),
+                  ("TAILS_LINEAR", "NFA_TAILS_LINEAR"), ("SCALE_DEFAULT", "NFA_SCALE_DEFAULT"),
+                  ("SCALE_GENERAL", "NFA_SCALE_GENERAL"), ("SCALE_ADDITIVE", "NFA_SCALE_ADDITIVE"),
+                  ("SCALE_GIVEN", "NFA_SCALE_GIVEN"), ("SCALE_SOFTPLUS", "NFA_SCALE_SOFTPLUS")]:
+        assert getattr(N, py) == int(consts[c]), c
+    # struct layout: 2 int32 + 10 doubles, natural alignment
+    assert ctypes.sizeof(N.RqsSpec) == 8 + 10 * 8
+
+
+def test_spec_argument_errors_without_gpu():
+    """Argument validation happens before any launch, so it can be exercised on CPU through the
+    C ABI with NULL pointers and batch 0 / bad specs."""
+    from nflows_amd import _native as N
+    from nflows_amd import ops
+    lib = N.load()
+    with pytest.raises(ValueError, match="Minimal bin width too large"):
+        ops.make_rqs_spec(4, "linear", min_bin_width=0.3)
+    with pytest.raises(ValueError, match="Minimal bin height too large"):
+        ops.make_rqs_spec(4, None, min_bin_height=0.3)
+    with pytest.raises(RuntimeError, match="cubic tails are not implemented"):
+        ops.make_rqs_spec(4, "cubic")
+    spec = ops.make_rqs_spec(8, "linear", tail_bound=3.0)
+    assert spec.left == -3.0 and spec.top == 3.0 and spec.tails == N.TAILS_LINEAR
+    assert abs(spec.tail_logit - np.log(np.exp(1 - 1e-3) - 1)) == 0.0
+    # batch == 0 is a valid no-op; negative sizes and bad enums are rejected
+    null = None
+    assert lib.nfa_rqs_coupling_f32(null, null, null, null, null, null, null, null, 0, 64, 32,
+                                    ctypes.byref(spec), 0, null) == N.OK
+    assert lib.nfa_rqs_coupling_f32(null, null, null, null, null, null, null, null, -1, 64, 32,
+                                    ctypes.byref(spec), 0, null) == N.ERR_INVALID_ARGUMENT
+    assert lib.nfa_rqs_coupling_f32(null, null, null, null, null, null, null, null, 4, 64, 65,
+                                    ctypes.byref(spec), 0, null) == N.ERR_INVALID_ARGUMENT
+    assert lib.nfa_rqs_coupling_f32(null, null, null, null, null, null, null, null, 4, 64, 32,
+                                    ctypes.byref(spec), 0, null) == N.ERR_INVALID_ARGUMENT  # NULL data
+    bad = ops.make_rqs_spec(8, "linear")
+    bad.min_bin_width = 0.5
+    assert lib.nfa_rqs_coupling_f32(null, null, null, null, null, null, null, null, 0, 64, 32,
+                                    ctypes.byref(bad), 0, null) == N.ERR_MIN_BIN_WIDTH
+    assert lib.nfa_affine_coupling_f32(null, null, null, null, null, null, null, null, null, 4, 8, 4,
+                                       99, 0, null) == N.ERR_INVALID_ARGUMENT
+    assert lib.nfa_rowsum_f32(null, null, 0, 5, null) == N.OK
+    assert lib.nfa_permute_cols_b32(null, null, null, null, 3, 0, null) == N.ERR_INVALID_ARGUMENT
+
+
+def test_no_cpu_fallback():
+    from nflows_amd import configs, ops
+    from nflows_amd.transforms import RandomPermutation, splines
+    flow = configs.rq_nsf_flow(num_layers=1, features=8, num_bins=4, hidden_features=16)
+    x = torch.randn(4, 8)
+    with torch.no_grad():
+        with pytest.raises(NotImplementedError, match="no CPU fallback"):
+            flow.log_prob(x)
+        with pytest.raises(NotImplementedError, match="no CPU fallback"):
+            RandomPermutation(8)(x)
+        with pytest.raises(NotImplementedError, match="no CPU fallback"):
+            splines.unconstrained_rational_quadratic_spline(x[:, 0], torch.zeros(4, 4), torch.zeros(4, 4),
+                                                            torch.zeros(4, 3))
+        with pytest.raises(NotImplementedError):
+            ops.rowsum(x)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: no file of the package mentions it."""
+    pkg = os.path.join(ROOT, "nflows_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, re.M), f
+                assert "nfa_oracle" not in text and "oracle/" not in text and "oracle." not in text, f
+
+
+def test_state_dict_contract(golden_dir):
+    """Same buffer / parameter names as the reference: its state_dicts load strictly."""
+    from nflows_amd import configs
+    g = np.load(os.path.join(golden_dir, "flows.npz"))
+    flow = configs.rq_nsf_flow(num_layers=2, features=64, num_bins=8, hidden_features=32)
+    want = sorted(k[len("nsf_d64/sd/"):] for k in g.files if k.startswith("nsf_d64/sd/"))
+    assert sorted(flow.state_dict().keys()) == want
+    assert "_distribution._log_z" not in flow.state_dict()  # non-persistent, like the reference
+    flow = configs.moons_maf_flow()
+    want = sorted(k[len("moons_maf/sd/"):] for k in g.files if k.startswith("moons_maf/sd/"))
+    assert sorted(flow.state_dict().keys()) == want
+    flow = configs.ar_rq_flow(12, 32, 8, 3.0, 2)
+    want = sorted(k[len("ar_rq_small/sd/"):] for k in g.files if k.startswith("ar_rq_small/sd/"))
+    assert sorted(flow.state_dict().keys()) == want
+
+
+def test_constructor_contract_and_errors():
+    from nflows_amd.nn.nets import ResidualNet
+    from nflows_amd.transforms import (AdditiveCouplingTransform, AffineCouplingTransform, Permutation,
+                                       PiecewiseRationalQuadraticCouplingTransform, RandomPermutation,
+                                       ReversePermutation, Transform, InverseNotAvailable)
+    from nflows_amd.utils import create_alternating_binary_mask, create_mid_split_binary_mask
+
+    def net(i, o):
+        return ResidualNet(i, o, hidden_features=16)
+    t = PiecewiseRationalQuadraticCouplingTransform(create_alternating_binary_mask(7), net, num_bins=4,
+                                                    tails="linear", tail_bound=2.0)
+    assert t.features == 7 and t.num_transform_features == 4 and t.num_identity_features == 3
+    assert t.transform_features.tolist() == [0, 2, 4, 6] and t.identity_features.tolist() == [1, 3, 5]
+    assert t.transform_features.dtype == torch.int64
+    assert t._transform_dim_multiplier() == 11 and t.transform_net.final_layer.out_features == 44
+    assert (t.num_bins, t.tails, t.tail_bound, t.min_bin_width) == (4, "linear", 2.0, 1e-3)
+    t2 = PiecewiseRationalQuadraticCouplingTransform(create_mid_split_binary_mask(6), net, num_bins=4)
+    assert t2._transform_dim_multiplier() == 13 and t2.tails is None
+    a = AffineCouplingTransform([1, -1, 1, -1], net)
+    assert a._transform_dim_multiplier() == 2 and a.transform_features.tolist() == [0, 2]
+    assert a.scale_activation is AffineCouplingTransform.DEFAULT_SCALE_ACTIVATION
+    assert AdditiveCouplingTransform([1, 0], net)._transform_dim_multiplier() == 1
+    with pytest.raises(ValueError, match="Mask must be a 1-dim tensor"):
+        AffineCouplingTransform(torch.ones(2, 2), net)
+    with pytest.raises(ValueError, match="Mask can't be empty"):
+        AffineCouplingTransform(torch.ones(0), net)
+    with pytest.raises(ValueError, match="Permutation must be a 1D tensor"):
+        Permutation(torch.zeros(2, 2, dtype=torch.long))
+    with pytest.raises(ValueError, match="dim must be a positive integer"):
+        Permutation(torch.arange(3), dim=0)
+    with pytest.raises(ValueError):
+        RandomPermutation(0)
+    assert ReversePermutation(4)._permutation.tolist() == [3, 2, 1, 0]
+    p = RandomPermutation(16)
+    assert sorted(p._permutation.tolist()) == list(range(16))
+    assert torch.equal(p._inverse_permutation[p._permutation], torch.arange(16))
+    with pytest.raises(InverseNotAvailable):
+        Transform().inverse(torch.zeros(1))
+    with pytest.raises(ValueError, match="Expected features = 7, got 5"):
+        t(torch.zeros(3, 5))
+    with pytest.raises(ValueError, match="Inputs must be a 2D or a 4D tensor"):
+        t(torch.zeros(3))
+
+
+def test_masks_and_leading_dim_helpers(golden_dir):
+    from nflows_amd.utils import torchutils as tu
+    g = np.load(os.path.join(golden_dir, "misc.npz"))
+    for f in (7, 8, 64):
+        assert np.array_equal(tu.create_alternating_binary_mask(f, True).numpy(), g["mask_alt_even_%d" % f])
+        assert np.array_equal(tu.create_alternating_binary_mask(f, False).numpy(), g["mask_alt_odd_%d" % f])
+        assert np.array_equal(tu.create_mid_split_binary_mask(f).numpy(), g["mask_mid_%d" % f])
+    m = tu.create_random_binary_mask(9)
+    assert m.dtype == torch.uint8 and int(m.sum()) == 5
+    x = torch.arange(24).reshape(6, 4)
+    assert tu.split_leading_dim(x, [2, 3]).shape == (2, 3, 4)
+    assert tu.merge_leading_dims(tu.split_leading_dim(x, [2, 3]), 2).equal(x)
+    assert tu.repeat_rows(x[:2], 3).tolist() == [x[0].tolist()] * 3 + [x[1].tolist()] * 3
+    with pytest.raises(TypeError):
+        tu.repeat_rows(x, 0)
+    with pytest.raises(ValueError):
+        tu.merge_leading_dims(x, 3)
+    g2 = np.load(os.path.join(golden_dir, "searchsorted.npz"))
+    for which in ("left", "right", "mid"):
+        idx = tu.searchsorted(torch.from_numpy(g2["knots"])[None, :], torch.from_numpy(g2[which + "_in"]))
+        assert idx.tolist() == list(range(9))
+
+
+def test_distribution_template_methods():
+    from nflows_amd.distributions import Distribution, StandardNormal
+    d = StandardNormal([3])
+    assert d.sample(5).shape == (5, 3)
+    assert d.sample(7, batch_size=3).shape == (7, 3)
+    assert d.sample(2, context=torch.zeros(4, 1)).shape == (4, 2, 3)
+    assert d.mean().tolist() == [0.0, 0.0, 0.0]
+    with pytest.raises(TypeError):
+        d.sample(0)
+    with pytest.raises(ValueError):
+        d.log_prob(torch.zeros(2, 3), context=torch.zeros(3, 1))
+    with pytest.raises(RuntimeError):
+        Distribution()(1)
+    assert "_log_z" not in d.state_dict() and d._log_z.dtype == torch.float64
