@@ -45,6 +45,13 @@ extern "C" {
 #define NFA_STATUS_NEG_DISCRIMINANT 2 /* rational_quadratic.py:142 assert (discriminant >= 0).all() */
 #define NFA_STATUS_BAD_INDEX 4        /* a transform_idx / perm entry outside [0, features) */
 
+/* `flags` argument of the coupling entry points */
+#define NFA_FLAG_INVERSE 1                /* inverse pass (coupling.py:102-130) */
+#define NFA_FLAG_ACCUMULATE_LOGABSDET 2   /* logabsdet[b] += layer sum: the `total_logabsdet +=`
+                                             of CompositeTransform._cascade (base.py:48-51) folded
+                                             into the layer; logabsdet must then hold the running
+                                             total on entry */
+
 /* tails */
 #define NFA_TAILS_NONE 0   /* rational_quadratic_spline: K+1 derivative logits per element */
 #define NFA_TAILS_LINEAR 1 /* unconstrained_rational_quadratic_spline(tails="linear"): K-1 */
@@ -101,12 +108,13 @@ int nfa_last_hip_error(void);          /* hipError_t of the last NFA_ERR_HIP on 
  *                 placed after the layer, permutations.py:22-24, :44-45, fused into the scatter)
  *   outputs       [batch, features]; columns not in transform_idx are copied bit-exactly
  *   logabsdet     [batch]
+ *   flags         NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET
  */
 int nfa_rqs_coupling_f32(const float *inputs, const float *params, const int64_t *transform_idx,
                          const int64_t *in_perm, const int64_t *out_scatter, float *outputs,
                          float *logabsdet, int32_t *status,
                          int64_t batch, int32_t features, int32_t num_transform,
-                         const nfa_rqs_spec *spec, int32_t inverse, void *stream);
+                         const nfa_rqs_spec *spec, int32_t flags, void *stream);
 
 /*
  * K5.  Elementwise rational-quadratic functional (no row-sum):
@@ -136,7 +144,7 @@ int nfa_affine_coupling_f32(const float *inputs, const float *params, const floa
                             const int64_t *transform_idx, const int64_t *in_perm,
                             const int64_t *out_scatter, float *outputs, float *logabsdet,
                             int32_t *status, int64_t batch, int32_t features, int32_t num_transform,
-                            int32_t scale_activation, int32_t inverse, void *stream);
+                            int32_t scale_activation, int32_t flags, void *stream);
 
 /*
  * K2b. Elementwise affine transform with interleaved parameters, the autoregressive form:

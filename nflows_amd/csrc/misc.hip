@@ -63,7 +63,7 @@ struct AffineArgs {
     float* lad;
     int32_t* status;
     int64_t batch;
-    int D, dt, R, pcols, activation, inverse;
+    int D, dt, R, pcols, activation, inverse, accumulate;
     FastDiv div_dt, div_D;
     int off_sc, off_x, off_out, off_lad, off_idx;
 };
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(kBlock) affine_coupling_kernel(const AffineArg
             float v = 0.0f;
             for (int m = lane; m < dt; m += kWave) v += s_lad[r * dt + m];
             v = wave_sum(v);
-            if (lane == 0) a.lad[row0 + r] = v;
+            if (lane == 0) a.lad[row0 + r] = a.accumulate ? a.lad[row0 + r] + v : v;
         }
     }
     if (my_status && a.status) atomicOr(a.status, my_status);
@@ -317,7 +317,9 @@ extern "C" int nfa_affine_coupling_f32(const float* inputs, const float* params,
                                        const int64_t* out_scatter, float* outputs, float* logabsdet,
                                        int32_t* status, int64_t batch,
                                        int32_t features, int32_t num_transform,
-                                       int32_t scale_activation, int32_t inverse, void* stream) {
+                                       int32_t scale_activation, int32_t flags, void* stream) {
+    if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET)) return NFA_ERR_INVALID_ARGUMENT;
+    const int inverse = flags & NFA_FLAG_INVERSE;
     if (batch < 0 || features < 1 || num_transform < 0 || num_transform > features)
         return NFA_ERR_INVALID_ARGUMENT;
     if (scale_activation < NFA_SCALE_DEFAULT || scale_activation > NFA_SCALE_SOFTPLUS)
@@ -365,6 +367,7 @@ extern "C" int nfa_affine_coupling_f32(const float* inputs, const float* params,
     a.R = R;
     a.activation = scale_activation;
     a.inverse = inverse;
+    a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.div_dt = make_fastdiv((uint32_t)(dt > 0 ? dt : 1));
     a.div_D = make_fastdiv((uint32_t)D);
     const int64_t tiles = (batch + R - 1) / R;

@@ -324,6 +324,7 @@ struct CouplingArgs {
     int D;   // features
     int dt;  // transformed features
     int R;   // samples per tile
+    int accumulate;  // 1: logabsdet[b] += sum (caller's running total), 0: logabsdet[b] = sum
     FastDiv div_dt, div_D;
     RqsDev sp;
     // LDS carve-up (float offsets)
@@ -411,7 +412,7 @@ __global__ void __launch_bounds__(BLOCK) rqs_coupling_kernel(const CouplingArgs 
             float v = 0.0f;
             for (int m = lane; m < dt; m += kWave) v += s_lad[r * dt + m];
             v = wave_sum(v);
-            if (lane == 0) a.lad[row0 + r] = v;
+            if (lane == 0) a.lad[row0 + r] = a.accumulate ? a.lad[row0 + r] + v : v;
         }
         // next iteration's loads only touch s_p / s_x, whose readers all passed the barrier above;
         // s_out / s_lad are rewritten only after the next iteration's first barrier.
@@ -567,7 +568,10 @@ __global__ void __launch_bounds__(kBlock, NFA_PIPE_WAVES) rqs_coupling_pipelined
         const int64_t row0 = tile * R;
         if (lad_shuffle) {
             for (int off = dt >> 1; off > 0; off >>= 1) l += __shfl_xor(l, off, kWave);
-            if (has_item && (tid & (dt - 1)) == 0) a.lad[row0 + (tid >> __builtin_ctz(dt))] = l;
+            if (has_item && (tid & (dt - 1)) == 0) {
+                float* dst = a.lad + row0 + (tid >> __builtin_ctz(dt));
+                *dst = a.accumulate ? *dst + l : l;
+            }
         } else {
             s_lad[tid] = l;
         }
@@ -581,7 +585,7 @@ __global__ void __launch_bounds__(kBlock, NFA_PIPE_WAVES) rqs_coupling_pipelined
                 float v = 0.0f;
                 for (int m = lane; m < dt; m += kWave) v += s_lad[r * dt + m];
                 v = wave_sum(v);
-                if (lane == 0) a.lad[row0 + r] = v;
+                if (lane == 0) a.lad[row0 + r] = a.accumulate ? a.lad[row0 + r] + v : v;
             }
         }
     }
@@ -725,7 +729,9 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
                                     const int64_t* out_scatter, float* outputs, float* logabsdet,
                                     int32_t* status, int64_t batch,
                                     int32_t features, int32_t num_transform, const nfa_rqs_spec* spec,
-                                    int32_t inverse, void* stream) {
+                                    int32_t flags, void* stream) {
+    if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET)) return NFA_ERR_INVALID_ARGUMENT;
+    const int inverse = flags & NFA_FLAG_INVERSE;
     if (batch < 0 || features < 1 || num_transform < 0 || num_transform > features)
         return NFA_ERR_INVALID_ARGUMENT;
     CouplingArgs a;
@@ -776,6 +782,7 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
     a.D = D;
     a.dt = dt;
     a.R = R;
+    a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.div_dt = make_fastdiv((uint32_t)(dt > 0 ? dt : 1));
     a.div_D = make_fastdiv((uint32_t)D);
     a.off_x = ox;

@@ -29,9 +29,17 @@ class MLP(nn.Module):
     def forward(self, inputs, context=None):
         if inputs.shape[1:] != self._in_shape:
             raise ValueError("Expected inputs of shape {}, got {}.".format(self._in_shape, inputs.shape[1:]))
-        h = self._activation(self._input_layer(inputs.reshape(-1, int(np.prod(self._in_shape)))))
+        flat = inputs.reshape(-1, int(np.prod(self._in_shape)))
+        if self._activation is F.relu and flat.is_cuda and not torch.is_grad_enabled():
+            # inference on the GPU: bias + ReLU in the GEMM epilogue (hipBLASLt)
+            def act_linear(layer, v):
+                return torch._addmm_activation(layer.bias, v, layer.weight.t())
+        else:
+            def act_linear(layer, v):
+                return self._activation(layer(v))
+        h = act_linear(self._input_layer, flat)
         for layer in self._hidden_layers:
-            h = self._activation(layer(h))
+            h = act_linear(layer, h)
         h = self._output_layer(h)
         if self._activate_output:
             h = self._activation(h)

@@ -30,7 +30,18 @@ class ResidualBlock(nn.Module):
             nn.init.uniform_(last.weight, -1e-3, 1e-3)
             nn.init.uniform_(last.bias, -1e-3, 1e-3)
 
+    def _fused_inference(self, inputs, context):
+        """No-grad HIP path: bias + ReLU of the first linear layer run in the GEMM epilogue
+        (hipBLASLt via torch._addmm_activation) instead of a separate elementwise kernel."""
+        return (context is None and self.activation is F.relu and not self.use_batch_norm
+                and inputs.is_cuda and not torch.is_grad_enabled()
+                and (not self.training or self.dropout.p == 0.0))
+
     def forward(self, inputs, context=None):
+        if self._fused_inference(inputs, context):
+            first, second = self.linear_layers
+            h = torch._addmm_activation(first.bias, F.relu(inputs), first.weight.t())
+            return inputs + torch.addmm(second.bias, h, second.weight.t())
         h = inputs
         for step in range(2):
             if self.use_batch_norm:

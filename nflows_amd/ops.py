@@ -116,12 +116,26 @@ def _idx(name, t, device, n=None):
     return t.contiguous()
 
 
+def _lad_buffer(accumulate_into, batch, device, inverse):
+    """Output buffer and `flags` for the coupling kernels: a fresh [batch] tensor, or the
+    caller's running total (CompositeTransform's `total_logabsdet`) updated in place."""
+    flags = N.FLAG_INVERSE if inverse else 0
+    if accumulate_into is None:
+        return torch.empty(batch, dtype=torch.float32, device=device), flags
+    t = accumulate_into
+    if (t.dtype != torch.float32 or t.device != device or tuple(t.shape) != (batch,)
+            or not t.is_contiguous()):
+        raise ValueError("accumulate_into must be a contiguous float32 [batch] tensor on the inputs' device")
+    return t, flags | N.FLAG_ACCUMULATE_LOGABSDET
+
+
 def _after_spline(spec, inverse, device):
     if spec.tails == N.TAILS_NONE or _error_mode == "immediate":
         check_status(device)
 
 
-def rqs_coupling(inputs, params, transform_idx, spec, inverse=False, in_perm=None, out_scatter=None):
+def rqs_coupling(inputs, params, transform_idx, spec, inverse=False, in_perm=None, out_scatter=None,
+                 accumulate_into=None):
     """K1 -- fused rational-quadratic coupling layer.  inputs [B, D], params [B, d_t*P].
     Returns (outputs [B, D], logabsdet [B])."""
     N.require_device_f32("inputs", inputs, 2)
@@ -139,18 +153,22 @@ def rqs_coupling(inputs, params, transform_idx, spec, inverse=False, in_perm=Non
     x = inputs.contiguous()
     p = params.contiguous()
     out = torch.empty_like(x)
-    lad = torch.empty(B, dtype=torch.float32, device=dev)
+    lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
     hook = _launch_hook
     with torch.cuda.device(dev):
         token = hook.begin("rqs_coupling") if hook is not None else None
         rc = N.load().nfa_rqs_coupling_f32(N.ptr(x), N.ptr(p), N.ptr(tidx), N.ptr(perm), N.ptr(scat),
                                            N.ptr(out), N.ptr(lad), N.ptr(_status_word(dev)), B, D, dt,
-                                           ctypes.byref(spec), int(bool(inverse)), N.stream_handle(dev))
+                                           ctypes.byref(spec), flags, N.stream_handle(dev))
         if hook is not None:
             # algorithmic bytes: inputs + conditioner output + outputs + logabsdet
             hook.end(token, 4 * (B * D + B * dt * P + B * D + B))
     if rc == N.ERR_UNSUPPORTED:
-        return _rqs_coupling_unfused(x, p, tidx, perm, scat, spec, inverse)
+        out, l = _rqs_coupling_unfused(x, p, tidx, perm, scat, spec, inverse)
+        if accumulate_into is not None:
+            accumulate_into += l
+            l = accumulate_into
+        return out, l
     N.check(rc)
     _after_spline(spec, inverse, dev)
     return out, lad
@@ -225,7 +243,7 @@ def rqs_elementwise(inputs, unnormalized_widths, unnormalized_heights, unnormali
 
 
 def affine_coupling(inputs, params, transform_idx, activation, inverse=False, scale=None,
-                    in_perm=None, out_scatter=None):
+                    in_perm=None, out_scatter=None, accumulate_into=None):
     """K2 -- fused affine/additive coupling.  params [B, 2*d_t] = [shift | scale logits]
     (additive: [B, d_t])."""
     N.require_device_f32("inputs", inputs, 2)
@@ -248,12 +266,12 @@ def affine_coupling(inputs, params, transform_idx, activation, inverse=False, sc
     x = inputs.contiguous()
     p = params.contiguous()
     out = torch.empty_like(x)
-    lad = torch.empty(B, dtype=torch.float32, device=dev)
+    lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
     with torch.cuda.device(dev):
         rc = N.load().nfa_affine_coupling_f32(N.ptr(x), N.ptr(p), N.ptr(scale), N.ptr(tidx), N.ptr(perm),
                                               N.ptr(scat), N.ptr(out), N.ptr(lad),
                                               N.ptr(_status_word(dev)), B, D, dt, int(activation),
-                                              int(bool(inverse)), N.stream_handle(dev))
+                                              flags, N.stream_handle(dev))
     N.check(rc)
     return out, lad
 

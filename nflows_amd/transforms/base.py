@@ -63,12 +63,17 @@ class CompositeTransform(Transform):
             nxt = layers[i + 1] if i + 1 < len(layers) else None
             if nxt is not None and _is_column_permutation(t) and _accepts_fused_permutation(nxt, outputs):
                 t._check(outputs)
-                outputs, logabsdet = nxt.forward(outputs, context, in_perm=t._permutation)
+                # permutation folded into the layer's gather, `total += logabsdet` into its kernel
+                outputs, _ = nxt.forward(outputs, context, in_perm=t._permutation,
+                                         logabsdet_accumulator=total)
                 i += 2
+            elif _accepts_fused_permutation(t, outputs):
+                outputs, _ = t.forward(outputs, context, logabsdet_accumulator=total)
+                i += 1
             else:
                 outputs, logabsdet = t(outputs, context)
+                total += logabsdet
                 i += 1
-            total += logabsdet
         return outputs, total
 
     def inverse(self, inputs, context=None):
@@ -84,12 +89,16 @@ class CompositeTransform(Transform):
             if nxt is not None and _is_column_permutation(nxt) and _accepts_fused_permutation(t, outputs):
                 nxt._check(outputs)
                 # Permutation.inverse after the layer == scatter through the forward permutation
-                outputs, logabsdet = t.inverse(outputs, context, out_scatter=nxt._permutation)
+                outputs, _ = t.inverse(outputs, context, out_scatter=nxt._permutation,
+                                       logabsdet_accumulator=total)
                 i += 2
+            elif _accepts_fused_permutation(t, outputs):
+                outputs, _ = t.inverse(outputs, context, logabsdet_accumulator=total)
+                i += 1
             else:
                 outputs, logabsdet = t.inverse(outputs, context)
+                total += logabsdet
                 i += 1
-            total += logabsdet
         return outputs, total
 
 

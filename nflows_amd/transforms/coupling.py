@@ -73,22 +73,39 @@ class CouplingTransform(Transform):
                 "nflows_amd: 4-D (image) coupling inputs are outside the MI355X hot path")
         N.require_device_f32("inputs", inputs, 2)
 
-    def forward(self, inputs, context=None, in_perm=None):
+    def _identity_columns(self, perm):
+        """identity_features seen through a fused permutation, cached per permutation tensor."""
+        if perm is None:
+            return self.identity_features
+        key = (perm.data_ptr(), perm._version, self.identity_features.data_ptr(),
+               self.identity_features._version)
+        cached = getattr(self, "_id_cols_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, perm[self.identity_features])
+            self._id_cols_cache = cached
+        return cached[1]
+
+    def forward(self, inputs, context=None, in_perm=None, logabsdet_accumulator=None):
         """outputs[:, identity] = inputs[:, identity]; outputs[:, transform] = f(inputs[:, transform];
-        net(inputs[:, identity])) (coupling.py:73-100).  `in_perm`: treat inputs[:, in_perm] as the
-        layer input (a preceding Permutation, fused)."""
+        net(inputs[:, identity])) (coupling.py:73-100).
+        `in_perm`: treat inputs[:, in_perm] as the layer input (a preceding Permutation, fused).
+        `logabsdet_accumulator`: a [batch] running total the layer's logabsdet is added to in the
+        kernel (CompositeTransform's `total_logabsdet +=`); it is then also the returned tensor."""
         self._check_inputs(inputs)
-        id_cols = self.identity_features if in_perm is None else in_perm[self.identity_features]
-        identity_split = inputs.index_select(1, id_cols)
+        identity_split = inputs.index_select(1, self._identity_columns(in_perm))
         transform_params = self.transform_net(identity_split, context)
-        outputs, logabsdet = self._fused_layer(inputs, transform_params, inverse=False, in_perm=in_perm)
+        outputs, logabsdet = self._fused_layer(inputs, transform_params, inverse=False, in_perm=in_perm,
+                                               accumulate_into=logabsdet_accumulator)
         if self.unconditional_transform is not None:
             identity_split, logabsdet_identity = self.unconditional_transform(identity_split, context)
-            logabsdet = logabsdet + logabsdet_identity
+            if logabsdet_accumulator is not None:
+                logabsdet += logabsdet_identity
+            else:
+                logabsdet = logabsdet + logabsdet_identity
             outputs.index_copy_(1, self.identity_features, identity_split)
         return outputs, logabsdet
 
-    def inverse(self, inputs, context=None, out_scatter=None):
+    def inverse(self, inputs, context=None, out_scatter=None, logabsdet_accumulator=None):
         """Inverse pass (coupling.py:102-130).  `out_scatter`: store layer column c at
         outputs[:, out_scatter[c]] (a following Permutation.inverse, fused)."""
         self._check_inputs(inputs)
@@ -98,18 +115,22 @@ class CouplingTransform(Transform):
             identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
         transform_params = self.transform_net(identity_split, context)
         outputs, logabsdet = self._fused_layer(inputs, transform_params, inverse=True,
-                                               out_scatter=out_scatter)
+                                               out_scatter=out_scatter,
+                                               accumulate_into=logabsdet_accumulator)
         if self.unconditional_transform is not None:
-            logabsdet = logabsdet + logabsdet_identity
-            cols = self.identity_features if out_scatter is None else out_scatter[self.identity_features]
-            outputs.index_copy_(1, cols, identity_split)
+            if logabsdet_accumulator is not None:
+                logabsdet += logabsdet_identity
+            else:
+                logabsdet = logabsdet + logabsdet_identity
+            outputs.index_copy_(1, self._identity_columns(out_scatter), identity_split)
         return outputs, logabsdet
 
     def _transform_dim_multiplier(self):
         """Number of conditioner outputs per transformed feature."""
         raise NotImplementedError()
 
-    def _fused_layer(self, inputs, transform_params, inverse, in_perm=None, out_scatter=None):
+    def _fused_layer(self, inputs, transform_params, inverse, in_perm=None, out_scatter=None,
+                     accumulate_into=None):
         raise NotImplementedError()
 
 
@@ -137,14 +158,15 @@ class AffineCouplingTransform(CouplingTransform):
             return N.SCALE_GENERAL
         return N.SCALE_GIVEN
 
-    def _fused_layer(self, inputs, transform_params, inverse, in_perm=None, out_scatter=None):
+    def _fused_layer(self, inputs, transform_params, inverse, in_perm=None, out_scatter=None,
+                     accumulate_into=None):
         code = self._activation_code()
         scale = None
         if code == N.SCALE_GIVEN:
             scale = self.scale_activation(transform_params[:, self.num_transform_features:])
         return ops.affine_coupling(inputs, transform_params, self.transform_features, code,
                                    inverse=inverse, scale=scale, in_perm=in_perm,
-                                   out_scatter=out_scatter)
+                                   out_scatter=out_scatter, accumulate_into=accumulate_into)
 
 
 class AdditiveCouplingTransform(AffineCouplingTransform):
@@ -153,10 +175,11 @@ class AdditiveCouplingTransform(AffineCouplingTransform):
     def _transform_dim_multiplier(self):
         return 1
 
-    def _fused_layer(self, inputs, transform_params, inverse, in_perm=None, out_scatter=None):
+    def _fused_layer(self, inputs, transform_params, inverse, in_perm=None, out_scatter=None,
+                     accumulate_into=None):
         return ops.affine_coupling(inputs, transform_params, self.transform_features,
                                    N.SCALE_ADDITIVE, inverse=inverse, in_perm=in_perm,
-                                   out_scatter=out_scatter)
+                                   out_scatter=out_scatter, accumulate_into=accumulate_into)
 
 
 class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
@@ -211,6 +234,8 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
                                  min_bin_height=self.min_bin_height,
                                  min_derivative=self.min_derivative, wh_divisor=divisor)
 
-    def _fused_layer(self, inputs, transform_params, inverse, in_perm=None, out_scatter=None):
+    def _fused_layer(self, inputs, transform_params, inverse, in_perm=None, out_scatter=None,
+                     accumulate_into=None):
         return ops.rqs_coupling(inputs, transform_params, self.transform_features, self._spec(),
-                                inverse=inverse, in_perm=in_perm, out_scatter=out_scatter)
+                                inverse=inverse, in_perm=in_perm, out_scatter=out_scatter,
+                                accumulate_into=accumulate_into)
