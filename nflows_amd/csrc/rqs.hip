@@ -324,6 +324,7 @@ struct CouplingArgs {
     int D;   // features
     int dt;  // transformed features
     int R;   // samples per tile
+    int C;   // splines per LDS chunk; R*dt unless one sample's parameters exceed the LDS budget
     int accumulate;  // 1: logabsdet[b] += sum (caller's running total), 0: logabsdet[b] = sum
     FastDiv div_dt, div_D;
     RqsDev sp;
@@ -380,39 +381,62 @@ __global__ void __launch_bounds__(BLOCK) rqs_coupling_kernel(const CouplingArgs 
         const int rows = (int)((a.batch - row0) < a.R ? (a.batch - row0) : a.R);
         const int nitems = rows * dt;
 
-        const int mp = tile_load<BLOCK>(a.params + row0 * (int64_t)dt * P, nitems * P, s_p, tid);
         const int mx = tile_load<BLOCK>(a.x + row0 * D, rows * D, s_x, tid);
         // the output tile is laid out as the 16-byte aligned image of its global destination
         float* s_o = s_out + tile_store_offset(a.out + row0 * D);
-        __syncthreads();
-
-        // untouched columns: bit-exact copy (with the fused permutation)
-        for (int e = tid; e < rows * D; e += BLOCK) {
-            const int r = (int)fastdiv((uint32_t)e, a.div_D);
-            const int c = e - r * D;
-            if (!s_ist[c]) s_o[e - c + s_dst[c]] = s_x[mx + e - c + s_src[c]];
+        const bool chunked = a.C < nitems;  // only with R == 1: one very wide sample (d_t*P large)
+        float acc = 0.0f;                   // chunked mode: this lane's share of the sample's sum
+        for (int c0 = 0; c0 < nitems; c0 += a.C) {
+            const int cn = (nitems - c0) < a.C ? (nitems - c0) : a.C;
+            const int mp = tile_load<BLOCK>(a.params + (row0 * dt + c0) * (int64_t)P, cn * P, s_p, tid);
+            __syncthreads();
+            if (c0 == 0) {
+                // untouched columns: bit-exact copy (with the fused permutation)
+                for (int e = tid; e < rows * D; e += BLOCK) {
+                    const int r = (int)fastdiv((uint32_t)e, a.div_D);
+                    const int c = e - r * D;
+                    if (!s_ist[c]) s_o[e - c + s_dst[c]] = s_x[mx + e - c + s_src[c]];
+                }
+            }
+            for (int ii = tid; ii < cn; ii += BLOCK) {
+                const int i = c0 + ii;
+                const int r = (int)fastdiv((uint32_t)i, a.div_dt);
+                const int j = i - r * dt;
+                const int col = s_tidx[j];
+                const float xin = s_x[mx + r * D + s_src[col]];
+                float y, l;
+                my_status |= a.sp.linear ? rqs_eval<KT, INVERSE, true>(xin, s_p + mp + ii * P, a.sp, y, l)
+                                         : rqs_eval<KT, INVERSE, false>(xin, s_p + mp + ii * P, a.sp, y, l);
+                s_o[r * D + s_dst[col]] = y;
+                if (chunked)
+                    acc += l;
+                else
+                    s_lad[i] = l;
+            }
+            __syncthreads();  // s_p is overwritten by the next chunk / tile
         }
-        for (int i = tid; i < nitems; i += BLOCK) {
-            const int r = (int)fastdiv((uint32_t)i, a.div_dt);
-            const int j = i - r * dt;
-            const int col = s_tidx[j];
-            const float xin = s_x[mx + r * D + s_src[col]];
-            float y, l;
-            my_status |= a.sp.linear ? rqs_eval<KT, INVERSE, true>(xin, s_p + mp + i * P, a.sp, y, l)
-                                     : rqs_eval<KT, INVERSE, false>(xin, s_p + mp + i * P, a.sp, y, l);
-            s_o[r * D + s_dst[col]] = y;
-            s_lad[i] = l;
-        }
-        __syncthreads();
 
         tile_store<BLOCK>(a.out + row0 * D, rows * D, s_out, tid);
-        // per-sample logabsdet: wave w reduces rows w, w+4, ...
         const int wave = tid >> 6, lane = tid & 63;
-        for (int r = wave; r < rows; r += BLOCK / kWave) {
-            float v = 0.0f;
-            for (int m = lane; m < dt; m += kWave) v += s_lad[r * dt + m];
-            v = wave_sum(v);
-            if (lane == 0) a.lad[row0 + r] = a.accumulate ? a.lad[row0 + r] + v : v;
+        if (chunked) {
+            // one sample: fixed-order reduction of the per-lane partial sums
+            acc = wave_sum(acc);
+            if (lane == 0) s_lad[wave] = acc;
+            __syncthreads();
+            if (tid == 0) {
+                float v = 0.0f;
+                for (int w = 0; w < BLOCK / kWave; ++w) v += s_lad[w];
+                a.lad[row0] = a.accumulate ? a.lad[row0] + v : v;
+            }
+            __syncthreads();
+        } else {
+            // per-sample logabsdet: wave w reduces rows w, w+4, ...
+            for (int r = wave; r < rows; r += BLOCK / kWave) {
+                float v = 0.0f;
+                for (int m = lane; m < dt; m += kWave) v += s_lad[r * dt + m];
+                v = wave_sum(v);
+                if (lane == 0) a.lad[row0 + r] = a.accumulate ? a.lad[row0 + r] + v : v;
+            }
         }
         // next iteration's loads only touch s_p / s_x, whose readers all passed the barrier above;
         // s_out / s_lad are rewritten only after the next iteration's first barrier.
@@ -752,23 +776,34 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
     int R = dt > 0 ? BT / dt : BT / (D < BT ? D : BT);
     if (R < 1) R = 1;
     if ((int64_t)R > batch) R = (int)batch;
+    int C = 0;  // splines per chunk (0 = whole tile)
     auto lds_floats = [&](int r, int* ox, int* oo, int* ol, int* oi) {
-        int o = round_up4(r * dt * P) + 4;
+        const int chunk_items = C > 0 ? C : r * dt;
+        int o = round_up4(chunk_items * P) + 4;
         *ox = o;
         o += round_up4(r * D) + 4;
         *oo = o;
         o += round_up4(r * D) + 4;
         *ol = o;
-        o += round_up4(r * dt);
+        o += round_up4(C > 0 ? kBlock : (r * dt > kBlock / kWave ? r * dt : kBlock / kWave));
         *oi = o;
         o += dt + 2 * D + (D + 3) / 4;
         return o;
     };
     int ox, oo, ol, oi;
     while (R > 1 && (size_t)lds_floats(R, &ox, &oo, &ol, &oi) * 4 > (size_t)kMaxDynLds) R >>= 1;
+    if (R == 1 && (size_t)lds_floats(1, &ox, &oo, &ol, &oi) * 4 > (size_t)kMaxDynLds) {
+        // one sample does not fit: stream its parameters through LDS in chunks of C splines
+        const size_t fixed = (size_t)(2 * (round_up4(D) + 4) + kBlock + dt + 2 * D + (D + 3) / 4 + 8) * 4;
+        if (fixed + (size_t)kBlock * P * 4 > (size_t)kMaxDynLds) return NFA_ERR_UNSUPPORTED;
+        C = (int)(((size_t)kMaxDynLds - fixed) / ((size_t)P * 4));
+        C = (C / kBlock) * kBlock;
+        if (C >= dt) C = 0;
+    }
     const size_t lds = (size_t)lds_floats(R, &ox, &oo, &ol, &oi) * 4;
     if (lds > (size_t)kMaxDynLds || (int64_t)R * dt >= 65536 || (int64_t)R * D >= 65536)
         return NFA_ERR_UNSUPPORTED;
+    a.C = C > 0 ? C : R * dt;
 
     a.x = inputs;
     a.params = params;

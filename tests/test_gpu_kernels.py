@@ -187,7 +187,8 @@ def test_coupling_layers_golden(ops, golden_dir):
 @pytest.mark.parametrize("B,D,K,tails", [
     (1, 64, 8, "linear"), (7, 64, 8, "linear"), (4099, 64, 8, "linear"), (513, 6, 8, "linear"),
     (300, 64, 10, "linear"), (257, 9, 5, "linear"), (129, 33, 3, None), (64, 2, 8, "linear"),
-    (50, 700, 8, "linear"), (3, 1500, 4, "linear"), (4, 3000, 8, "linear"),
+    (50, 700, 8, "linear"), (3, 1500, 4, "linear"), (4, 3000, 8, "linear"), (5, 784, 8, "linear"),
+    (2, 5000, 10, None),
 ])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_rqs_coupling_oracle(ops, B, D, K, tails, inverse):
