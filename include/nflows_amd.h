@@ -117,6 +117,25 @@ int nfa_rqs_coupling_f32(const float *inputs, const float *params, const int64_t
                          const nfa_rqs_spec *spec, int32_t flags, void *stream);
 
 /*
+ * K1-backward.  Gradient of nfa_rqs_coupling_f32 (same arguments, same flags & NFA_FLAG_INVERSE):
+ * what torch.autograd computes through the ~520 eager ops of one reference layer when a user
+ * trains with `loss = -flow.log_prob(x).mean(); loss.backward()` (examples/moons.ipynb cell 3).
+ * The spline is recomputed from (inputs, params); nothing else is saved by the forward pass.
+ *   grad_outputs   [batch, features]        d loss / d outputs
+ *   grad_logabsdet [batch] or NULL (= 0)    d loss / d logabsdet
+ *   grad_inputs    [batch, features]        d loss / d inputs through the layer itself (the path
+ *                  through the conditioner is the caller's: it owns `params`)
+ *   grad_params    [batch, num_transform*P] d loss / d params
+ */
+int nfa_rqs_coupling_backward_f32(const float *inputs, const float *params,
+                                  const int64_t *transform_idx, const int64_t *in_perm,
+                                  const int64_t *out_scatter, const float *grad_outputs,
+                                  const float *grad_logabsdet, float *grad_inputs,
+                                  float *grad_params, int32_t *status, int64_t batch,
+                                  int32_t features, int32_t num_transform,
+                                  const nfa_rqs_spec *spec, int32_t flags, void *stream);
+
+/*
  * K5.  Elementwise rational-quadratic functional (no row-sum):
  *   unconstrained_rational_quadratic_spline / rational_quadratic_spline,
  *   splines/rational_quadratic.py:13-63 / :66-181, as called from

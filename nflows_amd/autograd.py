@@ -1,0 +1,221 @@
+"""Differentiable wrappers around the HIP kernels.
+
+The reference is trained by autograd through eager ops (`loss = -flow.log_prob(x).mean();
+loss.backward()`, examples/moons.ipynb cell 3).  These `torch.autograd.Function`s make the same
+call pattern work on the fused kernels: forward = the forward kernel, backward = ONE HIP kernel
+for the spline layers (`nfa_rqs_coupling_backward_f32`, which recomputes the layer from its
+inputs) and a few elementwise device ops for the cheap affine layers.  Everything stays on the
+GPU; there is no CPU path here either.
+"""
+import ctypes
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _native as N
+
+
+def needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+class RqsCoupling(torch.autograd.Function):
+    """K1 forward + K1-backward."""
+
+    @staticmethod
+    def forward(ctx, inputs, params, tidx, spec, inverse, perm, scat):
+        from . import ops
+        out, lad = ops._rqs_coupling_launch(inputs, params, tidx, spec, inverse, perm, scat, None)
+        ctx.save_for_backward(inputs, params, tidx, perm, scat)
+        ctx.spec = spec
+        ctx.inverse = bool(inverse)
+        return out, lad
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out, g_lad):
+        from . import ops
+        inputs, params, tidx, perm, scat = ctx.saved_tensors
+        B, D = inputs.shape
+        dev = inputs.device
+        g_out = torch.zeros_like(inputs) if g_out is None else g_out.contiguous()
+        g_lad = None if g_lad is None else g_lad.contiguous()
+        g_in = torch.empty_like(inputs)
+        g_params = torch.empty_like(params)
+        with torch.cuda.device(dev):
+            rc = N.load().nfa_rqs_coupling_backward_f32(
+                N.ptr(inputs), N.ptr(params), N.ptr(tidx), N.ptr(perm), N.ptr(scat), N.ptr(g_out),
+                N.ptr(g_lad), N.ptr(g_in), N.ptr(g_params), N.ptr(ops._status_word(dev)), B, D,
+                tidx.numel(), ctypes.byref(ctx.spec), N.FLAG_INVERSE if ctx.inverse else 0,
+                N.stream_handle(dev))
+        N.check(rc)
+        return g_in, g_params, None, None, None, None, None
+
+
+class RqsElementwise(torch.autograd.Function):
+    """K5 forward; backward through the K1-backward kernel on the packed [n, P] logits (one spline
+    per "sample": features = 1)."""
+
+    @staticmethod
+    def forward(ctx, inputs, uw, uh, ud, spec, inverse):
+        from . import ops
+        y, lad = ops._rqs_elementwise_launch(inputs, uw, uh, ud, spec, inverse)
+        ctx.save_for_backward(inputs, uw, uh, ud)
+        ctx.spec = spec
+        ctx.inverse = bool(inverse)
+        return y, lad
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_y, g_lad):
+        from . import ops
+        inputs, uw, uh, ud = ctx.saved_tensors
+        spec = ctx.spec
+        K = spec.num_bins
+        nd_std = K - 1 if spec.tails == N.TAILS_LINEAR else K + 1
+        if ud.shape[-1] != nd_std:
+            raise NotImplementedError("nflows_amd: gradients need exactly %d derivative logits" % nd_std)
+        n = inputs.numel()
+        dev = inputs.device
+        x = inputs.contiguous().view(n, 1)
+        packed = torch.cat((uw.reshape(n, K), uh.reshape(n, K), ud.reshape(n, nd_std)), dim=1).contiguous()
+        g_y = (torch.zeros_like(x) if g_y is None else g_y.contiguous().view(n, 1))
+        g_lad = None if g_lad is None else g_lad.contiguous().view(n)
+        g_in = torch.empty_like(x)
+        g_packed = torch.empty_like(packed)
+        col0 = torch.zeros(1, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            rc = N.load().nfa_rqs_coupling_backward_f32(
+                N.ptr(x), N.ptr(packed), N.ptr(col0), None, None, N.ptr(g_y), N.ptr(g_lad), N.ptr(g_in),
+                N.ptr(g_packed), N.ptr(ops._status_word(dev)), n, 1, 1, ctypes.byref(spec),
+                N.FLAG_INVERSE if ctx.inverse else 0, N.stream_handle(dev))
+        N.check(rc)
+        return (g_in.view(inputs.shape), g_packed[:, :K].reshape(uw.shape),
+                g_packed[:, K:2 * K].reshape(uh.shape), g_packed[:, 2 * K:].reshape(ud.shape), None, None)
+
+
+def _scale_and_grad(u, activation):
+    """scale = act(u) and d scale / d u for the in-kernel activations (coupling.py:224-225,
+    autoregressive.py:101)."""
+    if activation == N.SCALE_DEFAULT:
+        sg = torch.sigmoid(u + 2)
+        return sg + 1e-3, sg * (1 - sg)
+    sp = torch.nn.functional.softplus(u) + 1e-3
+    ds = torch.sigmoid(u)
+    if activation == N.SCALE_GENERAL:
+        inside = (sp >= 0) & (sp <= 3)
+        return sp.clamp(0, 3), ds * inside
+    return sp, ds  # N.SCALE_SOFTPLUS
+
+
+class AffineCoupling(torch.autograd.Function):
+    """K2 forward; backward as a handful of elementwise device ops on the [B, d_t] halves."""
+
+    @staticmethod
+    def forward(ctx, inputs, params, scale, tidx, activation, inverse, perm, scat):
+        from . import ops
+        out, lad = ops._affine_coupling_launch(inputs, params, scale, tidx, activation, inverse, perm, scat, None)
+        ctx.save_for_backward(inputs, params, scale, tidx, perm, scat, out)
+        ctx.activation = activation
+        ctx.inverse = bool(inverse)
+        return out, lad
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out, g_lad):
+        inputs, params, scale, tidx, perm, scat, out = ctx.saved_tensors
+        act = ctx.activation
+        B, D = inputs.shape
+        dt = tidx.numel()
+        g_out = torch.zeros_like(inputs) if g_out is None else g_out
+        g_lad = torch.zeros(B, device=inputs.device) if g_lad is None else g_lad
+        # undo the fused permutations on the gradient side: layer-local column order
+        g_loc = g_out if scat is None else g_out.index_select(1, scat)  # g wrt layer column c
+        src = tidx if perm is None else perm[tidx]
+        dstc = tidx if scat is None else scat[tidx]
+        x_t = inputs.index_select(1, src)          # layer input of the transformed columns
+        y_t = out.index_select(1, dstc)            # layer output of the transformed columns
+        g_t = g_loc.index_select(1, tidx)
+        shift = params[:, :dt]
+        if act == N.SCALE_ADDITIVE:
+            s, ds, u_grad = None, None, None
+        elif act == N.SCALE_GIVEN:
+            s, ds = scale, None
+        else:
+            s, ds = _scale_and_grad(params[:, dt:], act)
+        gl = g_lad[:, None]
+        if act == N.SCALE_ADDITIVE:
+            g_x_t = g_t
+            g_shift = -g_t if ctx.inverse else g_t
+            g_s = None
+        elif not ctx.inverse:  # y = x*s + shift, lad = sum log s
+            g_x_t = g_t * s
+            g_shift = g_t
+            g_s = g_t * x_t + gl / s
+        else:                  # x = (y - shift)/s, lad = -sum log s   (x_t holds y, y_t holds x)
+            g_x_t = g_t / s
+            g_shift = -g_x_t
+            g_s = -g_x_t * y_t - gl / s
+        g_loc_in = g_loc.clone()
+        g_loc_in[:, tidx] = g_x_t
+        g_in = g_loc_in if perm is None else torch.empty_like(g_loc_in).index_copy_(1, perm, g_loc_in)
+        g_scale = None
+        if act == N.SCALE_ADDITIVE:
+            g_params = g_shift
+        elif act == N.SCALE_GIVEN:
+            g_params = torch.cat((g_shift, torch.zeros_like(g_shift)), dim=1)
+            g_scale = g_s
+        else:
+            g_params = torch.cat((g_shift, g_s * ds), dim=1)
+        return g_in, g_params, g_scale, None, None, None, None, None
+
+
+class AffineAutoregressive(torch.autograd.Function):
+    """K2b forward; elementwise device ops backward (params interleaved [B, D, 2])."""
+
+    @staticmethod
+    def forward(ctx, inputs, params, inverse):
+        from . import ops
+        out, lad = ops._affine_autoregressive_launch(inputs, params, inverse)
+        ctx.save_for_backward(inputs, params, out)
+        ctx.inverse = bool(inverse)
+        return out, lad
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out, g_lad):
+        inputs, params, out = ctx.saved_tensors
+        B, D = inputs.shape
+        p = params.reshape(B, D, 2)
+        s, ds = _scale_and_grad(p[..., 0], N.SCALE_SOFTPLUS)
+        g_out = torch.zeros_like(inputs) if g_out is None else g_out
+        gl = (torch.zeros(B, device=inputs.device) if g_lad is None else g_lad)[:, None]
+        if not ctx.inverse:
+            g_in = g_out * s
+            g_shift = g_out
+            g_s = g_out * inputs + gl / s
+        else:
+            g_in = g_out / s
+            g_shift = -g_in
+            g_s = -g_in * out - gl / s
+        g_params = torch.stack((g_s * ds, g_shift), dim=-1).reshape(params.shape)
+        return g_in, g_params, None
+
+
+class StandardNormalLogProb(torch.autograd.Function):
+    """Fused base log-density (+ logabsdet) forward; -z * g backward."""
+
+    @staticmethod
+    def forward(ctx, z, logabsdet):
+        from . import ops
+        out = ops._standard_normal_log_prob_launch(z, logabsdet)
+        ctx.save_for_backward(z)
+        ctx.has_lad = logabsdet is not None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        g_z = -z * g.reshape((-1,) + (1,) * (z.dim() - 1))
+        return g_z, (g if ctx.has_lad else None)

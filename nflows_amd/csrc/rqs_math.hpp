@@ -1,0 +1,320 @@
+// Per-spline arithmetic of the rational-quadratic kernels (shared by the forward kernels in
+// rqs.hip and the backward kernels in rqs_bwd.hip).  gfx950 only.
+#pragma once
+
+#include "common.hpp"
+
+#include <math.h>
+
+namespace nfa {
+
+struct RqsDev {
+    int K;          // bins
+    int P;          // params per spline: 2K + nd
+    int nd;         // derivative logits per spline: K-1 (linear tails) / K+1, or more (extras unused)
+    int linear;     // 1: linear tails
+    float left, right, bottom, top;
+    float span_w, span_h;          // (float)(right-left), (float)(top-bottom)
+    float right_eps, top_eps;      // last knot + 1e-6 (searchsorted)
+    float min_w, min_h, min_d;
+    float om_w, om_h;              // (float)(1 - min*K)
+    float beta, tail_logit, divisor, rdivisor;  // rdivisor = RN(1/divisor)
+};
+
+// Storage of K values per lane: registers when K is a compile-time constant, the lane's own LDS
+// words (updated in place) otherwise.
+template <int KT>
+struct Slots {
+    float v[KT];
+    __device__ __forceinline__ void bind(float*) {}
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <>
+struct Slots<0> {
+    float* s;
+    __device__ __forceinline__ void bind(float* p) { s = p; }
+    __device__ __forceinline__ float get(int i) const { return s[i]; }
+    __device__ __forceinline__ void set(int i, float x) { s[i] = x; }
+};
+
+// ---- arithmetic building blocks -------------------------------------------------------------
+// a / b given r = RN(1/b): one product, its exact residual (fma) and one correction (fma).
+// This is the final step of the IEEE division algorithm; with a correctly rounded r it returns
+// the correctly rounded quotient (no scaling needed here: |a|, |b| are far from the fp32 limits).
+__device__ __forceinline__ float div_with_rcp(float a, float b, float r) {
+    const float q = a * r;
+#ifdef NFA_X_NOCORR
+    return q;
+#endif
+    const float e = __builtin_fmaf(-q, b, a);
+    return __builtin_fmaf(e, r, q);
+}
+
+// RN(1/b) for b in the normal range: v_rcp_f32 (1 ulp) + one Newton step
+__device__ __forceinline__ float rcp_refined(float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    return __builtin_fmaf(__builtin_fmaf(-b, r0, 1.0f), r0, r0);
+}
+
+// a / b without the denormal / overflow scaling of the generic IEEE expansion (operands here are
+// bin widths, heights and derivatives: well inside the normal range).
+__device__ __forceinline__ float div_normal(float a, float b) {
+    return div_with_rcp(a, b, rcp_refined(b));
+}
+
+// log(u) for normal u: v_log_f32 (log2, 1 ulp) times ln2 carried in two floats
+__device__ __forceinline__ float log_normal(float u) {
+    const float kLn2Hi = 0.693145751953125f;          // ln2, low 11 mantissa bits cleared
+    const float kLn2Lo = 1.42860682030941723212e-06f;  // ln2 - kLn2Hi
+    const float r = __builtin_amdgcn_logf(u);
+    return __builtin_fmaf(r, kLn2Lo, r * kLn2Hi);
+}
+
+// log1p(t), t >= 0: log(u) with u = RN(1 + t) plus the first-order term for the rounding of u.
+// (ocml's log1pf is ~120 VALU instructions; this is 9.)
+__device__ __forceinline__ float log1p_nonneg(float t) {
+    const float u = 1.0f + t;
+    const float c = t - (u - 1.0f);  // exact: what the addition dropped
+    return __builtin_fmaf(c, __builtin_amdgcn_rcpf(u), log_normal(u));
+}
+
+// exp(x) for x <= ~88 without range handling: 2^(x*log2e) with the product carried in two
+// floats; v_exp_f32 (1 ulp) on the high part, first-order correction for the low part.
+// Results below 2^-126 flush to zero (they are added to a softmax denominator >= 1).
+__device__ __forceinline__ float exp_noclamp(float x) {
+    const float kLog2e = 1.44269502162933349609375f;       // RN(log2(e))
+    const float kLog2eLo = 1.925963033500011e-08f;          // log2(e) - kLog2e
+    const float kLn2 = 0.693147182464599609375f;
+    const float hi = x * kLog2e;
+#ifdef NFA_X_FASTEXP
+    return __builtin_amdgcn_exp2f(hi);
+#endif
+    float lo = __builtin_fmaf(x, kLog2e, -hi);
+    lo = __builtin_fmaf(x, kLog2eLo, lo);
+    const float e0 = __builtin_amdgcn_exp2f(hi);
+    return __builtin_fmaf(e0, lo * kLn2, e0);
+}
+
+// softmax numerators exp(u_i - max) in place, returns the fp32 denominator.
+// (aten's softmax sums the numerators in fp32 in a vector-lane order that depends on the host
+// ISA; a balanced tree is the closest ISA-independent choice.)
+template <int KT>
+__device__ __forceinline__ float softmax_numerators(Slots<KT>& e, const float* logits, int K,
+                                                    float divisor, float rdivisor) {
+#pragma clang fp contract(off)
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < (KT > 0 ? KT : K); ++i) {
+        float u = logits[i];
+        if (divisor != 0.0f) u = div_with_rcp(u, divisor, rdivisor);
+        e.set(i, u);
+        m = fmaxf(m, u);
+    }
+    if (KT == 8) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            t[i] = exp_noclamp(e.get(i) - m);
+            e.set(i, t[i]);
+        }
+        return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    double s = 0.0;  // runtime K: a long sequential fp32 sum would drift; double is exact enough
+    for (int i = 0; i < (KT > 0 ? KT : K); ++i) {
+        const float ex = exp_noclamp(e.get(i) - m);
+        e.set(i, ex);
+        s += (double)ex;
+    }
+    return (float)s;
+}
+
+// Walks the K bins, rebuilding knot_i / knot_{i+1} on the fly.
+//   SEARCH : k <- last i with x >= knot_i (== count-1 for monotone knots), picks that bin's knots
+//   !SEARCH: picks the knots of the given bin k
+// The prefix sums are accumulated in double and rounded to fp32 per prefix, which is what
+// aten's CPU cumsum does for float tensors (the double sums are exact for these magnitudes).
+template <int KT, bool SEARCH>
+__device__ __forceinline__ void walk_bins(const Slots<KT>& e, int K, float denom, float minbin,
+                                          float om, float span, float lo, float hi, float x, int& k,
+                                          float& knot_lo, float& knot_hi) {
+#pragma clang fp contract(off)
+    const float rden = rcp_refined(denom);
+#ifdef NFA_X_F32CUMSUM
+    float acc = 0.0f;
+#else
+    double acc = 0.0;
+#endif
+    float prev = lo;
+#pragma unroll
+    for (int i = 0; i < (KT > 0 ? KT : K); ++i) {
+        const float p = div_with_rcp(e.get(i), denom, rden);
+        const float w = minbin + om * p;
+#ifdef NFA_X_F32CUMSUM
+        acc += w;
+#else
+        acc += (double)w;
+#endif
+        const float c = (float)acc;
+        const float next = (i == (KT > 0 ? KT : K) - 1) ? hi : span * c + lo;
+        const bool take = SEARCH ? (x >= prev) : (i == k);
+        if (take) {
+            if (SEARCH) k = i;
+            knot_lo = prev;
+            knot_hi = next;
+        }
+        prev = next;
+    }
+}
+
+__device__ __forceinline__ float softplus_beta(float x, float beta) {
+#pragma clang fp contract(off)
+    const float xb = x * beta;
+    const float sp = log1p_nonneg(exp_noclamp(xb));
+    return xb > 20.0f ? x : (beta == 1.0f ? sp : sp / beta);
+}
+
+// One spline evaluation.  `sl` = this lane's P logits in LDS (may be clobbered when KT == 0).
+//   LINEAR = true: linear tails, box [-B, B]^2 (B = sp.right); only sp.right / span_w / right_eps
+//   and the per-side minimums are read, which keeps the kernel's scalar-register footprint down.
+template <int KT, bool INVERSE, bool LINEAR>
+__device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, float& y, float& lad) {
+#pragma clang fp contract(off)
+    const int K = KT > 0 ? KT : sp.K;
+#ifdef NFA_ABLATE_MATH  // experiment only (tools/k1_micro.py): memory pipeline without the arithmetic
+    y = x + sl[0];
+    lad = sl[K];
+    return 0;
+#endif
+    const float left = LINEAR ? -sp.right : sp.left;
+    const float right = sp.right;
+    const float bottom = LINEAR ? -sp.right : sp.bottom;
+    const float top = LINEAR ? sp.right : sp.top;
+    const float span_w = sp.span_w;
+    const float span_h = LINEAR ? sp.span_w : sp.span_h;
+    const float right_eps = sp.right_eps;
+    const float top_eps = LINEAR ? sp.right_eps : sp.top_eps;
+    if (LINEAR) {
+        if (!(x >= left && x <= right)) {  // NaN falls outside too
+            y = x;
+            lad = 0.0f;
+            return 0;
+        }
+    } else if (x < left || x > right) {
+        y = x;
+        lad = 0.0f;
+        return NFA_STATUS_OUTSIDE_DOMAIN;
+    }
+
+    Slots<KT> ew, eh;
+    ew.bind(sl);
+    eh.bind(sl + K);
+    const float den_w = softmax_numerators<KT>(ew, sl, K, sp.divisor, sp.rdivisor);
+    const float den_h = softmax_numerators<KT>(eh, sl + K, K, sp.divisor, sp.rdivisor);
+
+    int k = -1;
+    float cw0 = 0.f, cw1 = 0.f, ch0 = 0.f, ch1 = 0.f;
+    if (INVERSE) {
+        walk_bins<KT, true>(eh, K, den_h, sp.min_h, sp.om_h, span_h, bottom, top, x, k, ch0, ch1);
+        if (k < 0 || x >= top_eps) {
+            y = x;
+            lad = 0.0f;
+            return NFA_STATUS_OUTSIDE_DOMAIN;
+        }
+        walk_bins<KT, false>(ew, K, den_w, sp.min_w, sp.om_w, span_w, left, right, x, k, cw0, cw1);
+    } else {
+        walk_bins<KT, true>(ew, K, den_w, sp.min_w, sp.om_w, span_w, left, right, x, k, cw0, cw1);
+        if (k < 0 || x >= right_eps) {
+            y = x;
+            lad = 0.0f;
+            return NFA_STATUS_OUTSIDE_DOMAIN;
+        }
+        walk_bins<KT, false>(eh, K, den_h, sp.min_h, sp.om_h, span_h, bottom, top, x, k, ch0, ch1);
+    }
+
+#ifdef NFA_X_NOEVAL
+    y = cw0 + ch0 + cw1 + ch1;
+    lad = (float)k;
+    return 0;
+#endif
+    const float* sd = sl + 2 * K;
+    float u0, u1;
+    if (LINEAR) {  // logits padded with the tail constant on both sides
+        u0 = (k == 0) ? sp.tail_logit : sd[k - 1];
+        u1 = (k >= sp.nd) ? sp.tail_logit : sd[k];  // padded index k+1 past the given logits
+    } else {
+        u0 = sd[k];
+        u1 = sd[k + 1];
+    }
+    const float d0 = sp.min_d + softplus_beta(u0, sp.beta);
+    const float d1 = sp.min_d + softplus_beta(u1, sp.beta);
+
+    const float in_w = cw1 - cw0;
+    const float in_h = ch1 - ch0;
+    const float r_w = rcp_refined(in_w);
+    const float delta = div_with_rcp(in_h, in_w, r_w);
+    const float s = (d0 + d1) - 2.0f * delta;
+    int status = 0;
+
+    if (INVERSE) {
+        const float yc = x - ch0;
+        const float a = yc * s + in_h * (delta - d0);
+        const float b = in_h * d0 - yc * s;
+        const float c = (-delta) * yc;
+        const float disc = b * b - (4.0f * a) * c;
+        if (!(disc >= 0.0f)) status = NFA_STATUS_NEG_DISCRIMINANT;
+        const float root = div_normal(2.0f * c, (-b) - sqrtf(disc));
+        y = root * in_w + cw0;
+        const float t1mt = root * (1.0f - root);
+        const float den = delta + s * t1mt;
+        const float omr = 1.0f - root;
+        const float dnum = (delta * delta) * ((d1 * (root * root) + (2.0f * delta) * t1mt) + d0 * (omr * omr));
+        lad = -(log_normal(dnum) - 2.0f * log_normal(den));
+    } else {
+        const float theta = div_with_rcp(x - cw0, in_w, r_w);
+        const float t1mt = theta * (1.0f - theta);
+        const float num = in_h * (delta * (theta * theta) + d0 * t1mt);
+        const float den = delta + s * t1mt;
+        y = ch0 + div_normal(num, den);
+        const float omt = 1.0f - theta;
+        const float dnum = (delta * delta) * ((d1 * (theta * theta) + (2.0f * delta) * t1mt) + d0 * (omt * omt));
+        lad = log_normal(dnum) - 2.0f * log_normal(den);
+    }
+    return status;
+}
+
+
+// host side: nfa_rqs_spec (doubles, as the reference's Python floats) -> fp32 device constants,
+// rounded exactly where aten rounds them
+inline int make_dev_spec(const nfa_rqs_spec* s, RqsDev* d) {
+    if (!s) return NFA_ERR_INVALID_ARGUMENT;
+    if (s->num_bins < 1 || s->num_bins > 4096) return NFA_ERR_INVALID_ARGUMENT;
+    if (s->tails != NFA_TAILS_NONE && s->tails != NFA_TAILS_LINEAR) return NFA_ERR_INVALID_ARGUMENT;
+    if (s->min_bin_width * s->num_bins > 1.0) return NFA_ERR_MIN_BIN_WIDTH;
+    if (s->min_bin_height * s->num_bins > 1.0) return NFA_ERR_MIN_BIN_HEIGHT;
+    d->K = s->num_bins;
+    d->linear = s->tails == NFA_TAILS_LINEAR;
+    d->nd = d->linear ? d->K - 1 : d->K + 1;
+    d->P = 2 * d->K + d->nd;
+    d->left = (float)s->left;
+    d->right = (float)s->right;
+    d->bottom = (float)s->bottom;
+    d->top = (float)s->top;
+    d->span_w = (float)(s->right - s->left);
+    d->span_h = (float)(s->top - s->bottom);
+    d->right_eps = d->right + 1e-6f;
+    d->top_eps = d->top + 1e-6f;
+    d->min_w = (float)s->min_bin_width;
+    d->min_h = (float)s->min_bin_height;
+    d->min_d = (float)s->min_derivative;
+    d->om_w = (float)(1.0 - s->min_bin_width * s->num_bins);
+    d->om_h = (float)(1.0 - s->min_bin_height * s->num_bins);
+    d->beta = (float)s->softplus_beta;
+    d->tail_logit = (float)s->tail_logit;
+    d->divisor = (float)s->wh_divisor;
+    d->rdivisor = d->divisor != 0.0f ? 1.0f / d->divisor : 0.0f;
+    return NFA_OK;
+}
+
+
+}  // namespace nfa

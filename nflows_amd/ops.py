@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from . import _native as N
+from . import autograd as AG
 from .errors import InputOutsideDomain
 
 _status_words = {}
@@ -137,10 +138,10 @@ def _after_spline(spec, inverse, device):
 def rqs_coupling(inputs, params, transform_idx, spec, inverse=False, in_perm=None, out_scatter=None,
                  accumulate_into=None):
     """K1 -- fused rational-quadratic coupling layer.  inputs [B, D], params [B, d_t*P].
-    Returns (outputs [B, D], logabsdet [B])."""
+    Returns (outputs [B, D], logabsdet [B]).  Differentiable (K1-backward kernel) when an input
+    requires grad."""
     N.require_device_f32("inputs", inputs, 2)
     N.require_device_f32("transform_params", params, 2)
-    _no_grad_guard(inputs, params)
     dev = inputs.device
     B, D = inputs.shape
     tidx = _idx("transform_features", transform_idx, dev)
@@ -150,8 +151,23 @@ def rqs_coupling(inputs, params, transform_idx, spec, inverse=False, in_perm=Non
     P = 3 * spec.num_bins - 1 if spec.tails == N.TAILS_LINEAR else 3 * spec.num_bins + 1
     if params.shape[0] != B or params.shape[1] != dt * P:
         raise ValueError("transform_params must be [%d, %d], got %s" % (B, dt * P, tuple(params.shape)))
-    x = inputs.contiguous()
-    p = params.contiguous()
+    if AG.needs_grad(inputs, params):
+        out, lad = AG.RqsCoupling.apply(inputs.contiguous(), params.contiguous(), tidx, spec, bool(inverse),
+                                        perm, scat)
+        if accumulate_into is not None:
+            accumulate_into += lad
+            lad = accumulate_into
+        return out, lad
+    return _rqs_coupling_launch(inputs, params, tidx, spec, inverse, perm, scat, accumulate_into)
+
+
+def _rqs_coupling_launch(inputs, params, tidx, spec, inverse, perm, scat, accumulate_into):
+    dev = inputs.device
+    B, D = inputs.shape
+    dt = tidx.numel()
+    P = 3 * spec.num_bins - 1 if spec.tails == N.TAILS_LINEAR else 3 * spec.num_bins + 1
+    x = inputs.detach().contiguous()
+    p = params.detach().contiguous()
     out = torch.empty_like(x)
     lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
     hook = _launch_hook
@@ -164,6 +180,8 @@ def rqs_coupling(inputs, params, transform_idx, spec, inverse=False, in_perm=Non
             # algorithmic bytes: inputs + conditioner output + outputs + logabsdet
             hook.end(token, 4 * (B * D + B * dt * P + B * D + B))
     if rc == N.ERR_UNSUPPORTED:
+        if torch.is_grad_enabled() and (inputs.requires_grad or params.requires_grad):
+            raise NotImplementedError("nflows_amd: this layer shape has no backward kernel yet")
         out, l = _rqs_coupling_unfused(x, p, tidx, perm, scat, spec, inverse)
         if accumulate_into is not None:
             accumulate_into += l
@@ -202,7 +220,17 @@ def rqs_elementwise(inputs, unnormalized_widths, unnormalized_heights, unnormali
                   ("unnormalized_heights", unnormalized_heights),
                   ("unnormalized_derivatives", unnormalized_derivatives)):
         N.require_device_f32(nm, t)
-    _no_grad_guard(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives)
+    if AG.needs_grad(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives):
+        return AG.RqsElementwise.apply(inputs, unnormalized_widths, unnormalized_heights,
+                                       unnormalized_derivatives, spec, bool(inverse))
+    return _rqs_elementwise_launch(inputs, unnormalized_widths, unnormalized_heights,
+                                   unnormalized_derivatives, spec, inverse)
+
+
+def _rqs_elementwise_launch(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives,
+                            spec, inverse):
+    inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives = (
+        t.detach() for t in (inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives))
     dev = inputs.device
     K = spec.num_bins
     nd_min = K - 1 if spec.tails == N.TAILS_LINEAR else K + 1
@@ -248,7 +276,6 @@ def affine_coupling(inputs, params, transform_idx, activation, inverse=False, sc
     (additive: [B, d_t])."""
     N.require_device_f32("inputs", inputs, 2)
     N.require_device_f32("transform_params", params, 2)
-    _no_grad_guard(inputs, params, scale)
     dev = inputs.device
     B, D = inputs.shape
     tidx = _idx("transform_features", transform_idx, dev)
@@ -263,8 +290,24 @@ def affine_coupling(inputs, params, transform_idx, activation, inverse=False, sc
         if tuple(scale.shape) != (B, dt):
             raise ValueError("scale must be [%d, %d]" % (B, dt))
         scale = scale.contiguous()
-    x = inputs.contiguous()
-    p = params.contiguous()
+    if AG.needs_grad(inputs, params, scale):
+        out, lad = AG.AffineCoupling.apply(inputs.contiguous(), params.contiguous(), scale, tidx,
+                                           int(activation), bool(inverse), perm, scat)
+        if accumulate_into is not None:
+            accumulate_into += lad
+            lad = accumulate_into
+        return out, lad
+    return _affine_coupling_launch(inputs, params, scale, tidx, activation, inverse, perm, scat,
+                                   accumulate_into)
+
+
+def _affine_coupling_launch(inputs, params, scale, tidx, activation, inverse, perm, scat, accumulate_into):
+    dev = inputs.device
+    B, D = inputs.shape
+    dt = tidx.numel()
+    x = inputs.detach().contiguous()
+    p = params.detach().contiguous()
+    scale = None if scale is None else scale.detach().contiguous()
     out = torch.empty_like(x)
     lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
     with torch.cuda.device(dev):
@@ -280,13 +323,19 @@ def affine_autoregressive(inputs, params, inverse=False):
     """K2b -- elementwise affine with interleaved [B, D, 2] parameters (scale logit, shift)."""
     N.require_device_f32("inputs", inputs, 2)
     N.require_device_f32("autoregressive_params", params)
-    _no_grad_guard(inputs, params)
     B, D = inputs.shape
     if params.numel() != B * D * 2:
         raise ValueError("autoregressive_params must hold %d values" % (B * D * 2))
+    if AG.needs_grad(inputs, params):
+        return AG.AffineAutoregressive.apply(inputs.contiguous(), params.contiguous(), bool(inverse))
+    return _affine_autoregressive_launch(inputs, params, inverse)
+
+
+def _affine_autoregressive_launch(inputs, params, inverse):
+    B, D = inputs.shape
     dev = inputs.device
-    x = inputs.contiguous()
-    p = params.contiguous()
+    x = inputs.detach().contiguous()
+    p = params.detach().contiguous()
     out = torch.empty_like(x)
     lad = torch.empty(B, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -331,13 +380,20 @@ def rowsum(x):
 def standard_normal_log_prob(z, logabsdet=None):
     """-0.5*sum(z^2) - 0.5*D*log(2*pi) (+ logabsdet), one kernel."""
     N.require_device_f32("inputs", z)
-    _no_grad_guard(z, logabsdet)
+    if logabsdet is not None:
+        N.require_device_f32("logabsdet", logabsdet, 1)
+    if AG.needs_grad(z, logabsdet):
+        return AG.StandardNormalLogProb.apply(z, logabsdet)
+    return _standard_normal_log_prob_launch(z, logabsdet)
+
+
+def _standard_normal_log_prob_launch(z, logabsdet):
+    z = z.detach()
     B = z.shape[0]
     cols = z.numel() // B if B else 1
     v = z.contiguous().view(B, cols)
     if logabsdet is not None:
-        N.require_device_f32("logabsdet", logabsdet, 1)
-        logabsdet = logabsdet.contiguous()
+        logabsdet = logabsdet.detach().contiguous()
     out = torch.empty(B, dtype=torch.float32, device=z.device)
     with torch.cuda.device(z.device):
         rc = N.load().nfa_standard_normal_log_prob_f32(N.ptr(v), N.ptr(logabsdet), N.ptr(out), B, cols,

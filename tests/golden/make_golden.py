@@ -401,10 +401,119 @@ def error_surface():
     print("errors:", rec)
 
 
+# --------------------------------------------------------------------------- gradients
+class ParamNet(nn.Module):
+    """Conditioner stand-in whose output IS a parameter, so autograd yields d loss / d params."""
+
+    def __init__(self, table, hidden_features=None):
+        super().__init__()
+        self.table = nn.Parameter(table.clone())
+        if hidden_features is not None:
+            self.hidden_features = hidden_features
+
+    def forward(self, identity, context=None):
+        return self.table * 1.0
+
+
+def grad_cases():
+    """Reference autograd through one coupling layer (loss = <y, Wy> + <logabsdet, Wl>) and through
+    a whole flow (loss = -mean log_prob), in float32 and float64."""
+    out = {}
+    meta = []
+    g = torch.Generator().manual_seed(4242)
+
+    def layer(name, kind, D, mask, B, K=8, tails="linear", tb=3.0, H=128, scale=1.5):
+        d_t = int((torch.as_tensor(mask) > 0).sum())
+        if kind == "rq":
+            P = 3 * K - 1 if tails == "linear" else 3 * K + 1
+            table = scale * torch.randn(B, d_t * P, generator=g)
+            x = (torch.randn(B, D, generator=g) * 1.4) if tails == "linear" else torch.rand(B, D, generator=g)
+        else:
+            table = torch.randn(B, d_t * (1 if kind == "additive" else 2), generator=g)
+            x = torch.randn(B, D, generator=g)
+        Wy = torch.randn(B, D, generator=g)
+        Wl = torch.randn(B, generator=g)
+        for dt_name, dtp in (("", torch.float32), ("64", torch.float64)):
+            for inv in (False, True):
+                net = ParamNet(table.to(dtp), H if kind == "rq" else None)
+                if kind == "rq":
+                    t = PiecewiseRationalQuadraticCouplingTransform(mask, lambda i, o: net, num_bins=K,
+                                                                    tails=tails, tail_bound=tb)
+                elif kind == "additive":
+                    t = AdditiveCouplingTransform(mask, lambda i, o: net)
+                elif kind == "general":
+                    t = AffineCouplingTransform(mask, lambda i, o: net,
+                                                scale_activation=AffineCouplingTransform.GENERAL_SCALE_ACTIVATION)
+                else:
+                    t = AffineCouplingTransform(mask, lambda i, o: net)
+                xin = x.to(dtp).clone().requires_grad_(True)
+                y, lad = (t.inverse if inv else t.forward)(xin)
+                loss = (y * Wy.to(dtp)).sum() + (lad * Wl.to(dtp)).sum()
+                loss.backward()
+                tag = "%s/%s" % (name, "inv" if inv else "fwd")
+                out[tag + "_gx" + dt_name] = npy(xin.grad)
+                out[tag + "_gp" + dt_name] = npy(net.table.grad)
+        out[name + "/x"] = npy(x)
+        out[name + "/params"] = npy(table)
+        out[name + "/Wy"] = npy(Wy)
+        out[name + "/Wl"] = npy(Wl)
+        out[name + "/transform_idx"] = npy(t.transform_features)
+        meta.append((name, kind, repr(dict(D=D, K=K, tails=tails, tail_bound=tb, hidden=H, B=B))))
+
+    layer("g_rq_d64_k8", "rq", 64, torchutils.create_alternating_binary_mask(64, even=True), 70)
+    layer("g_rq_d10_k5", "rq", 10, torchutils.create_mid_split_binary_mask(10), 45, K=5, tb=2.0, H=16)
+    layer("g_rq_d6_k4_none", "rq", 6, torch.tensor([1, 0, 1, 0, 0, 1]), 33, K=4, tails=None, tb=1.0, H=None,
+          scale=1.0)
+    layer("g_aff_default", "default", 12, torchutils.create_alternating_binary_mask(12, even=False), 40)
+    layer("g_aff_general", "general", 12, torchutils.create_alternating_binary_mask(12, even=True), 40)
+    layer("g_additive", "additive", 7, torch.tensor([1, 0, 1, 1, 0, 0, 1]), 21)
+
+    # whole flow: -mean log_prob, gradients w.r.t. every parameter and the inputs
+    torch.manual_seed(0)
+    L, D, K, H, B = 3, 8, 4, 16, 48
+    layers = []
+    for i in range(L):
+        layers.append(RandomPermutation(D))
+        layers.append(PiecewiseRationalQuadraticCouplingTransform(
+            mask=torchutils.create_alternating_binary_mask(D, even=(i % 2 == 0)),
+            transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=H, num_blocks=2),
+            num_bins=K, tails="linear", tail_bound=3.0))
+    flow = Flow(CompositeTransform(layers), StandardNormal([D]))
+    with torch.no_grad():
+        for p_name, p in flow.named_parameters():
+            if "final_layer" in p_name:
+                p.mul_(6.0)
+            elif "linear_layers.1" in p_name:
+                p.mul_(40.0)
+    xg = torch.randn(B, D, generator=torch.Generator().manual_seed(77))
+    name = "g_flow_nsf"
+    state_to_np(name, flow, out)
+    out[name + "/x"] = npy(xg)
+    for dt_name, dtp in (("", torch.float32), ("64", torch.float64)):
+        f = flow.double() if dtp is torch.float64 else flow.float()
+        f.zero_grad()
+        xin = xg.to(dtp).clone().requires_grad_(True)
+        loss = -f.log_prob(xin).mean()
+        loss.backward()
+        out[name + "/loss" + dt_name] = npy(loss)
+        out[name + "/gx" + dt_name] = npy(xin.grad)
+        for p_name, p in f.named_parameters():
+            out[name + "/grad" + dt_name + "/" + p_name] = npy(p.grad)
+    flow.float()
+    meta.append((name, "flow", repr(dict(kind="rq_nsf", L=L, D=D, K=K, H=H, B=B, tail_bound=3.0))))
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "grads.npz"), **out)
+    print("grads:", len(meta), "cases")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "grads":
+        grad_cases()
+        sys.exit(0)
     rqs_cases()
     searchsorted_case()
     coupling_cases()
     flow_cases()
     misc_cases()
     error_surface()
+    grad_cases()

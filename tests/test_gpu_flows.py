@@ -152,9 +152,14 @@ def test_affine_real_nvp_stack():
         assert flow.log_prob(x).shape == (16384,)
 
 
-def test_requires_grad_fails_loudly():
+def test_grad_mode_uses_the_backward_kernels():
+    """Parameters require grad and grad mode is on: log_prob builds a graph (tests/test_gpu_grads.py
+    checks the gradients); under no_grad the inference path runs."""
     from nflows_amd import configs
     flow = configs.rq_nsf_flow(num_layers=1, features=8, num_bins=4, hidden_features=16).to(DEV)
     x = torch.randn(16, 8, device=DEV)
-    with pytest.raises(NotImplementedError, match="no backward"):
-        flow.log_prob(x)  # parameters require grad and grad mode is on
+    lp = flow.log_prob(x)
+    assert lp.requires_grad
+    with torch.no_grad():
+        lp2 = flow.log_prob(x)
+    assert not lp2.requires_grad and (lp - lp2).abs().max().item() < 1e-5
