@@ -177,7 +177,10 @@ __device__ __forceinline__ float softplus_beta(float x, float beta) {
 // One spline evaluation.  `sl` = this lane's P logits in LDS (may be clobbered when KT == 0).
 //   LINEAR = true: linear tails, box [-B, B]^2 (B = sp.right); only sp.right / span_w / right_eps
 //   and the per-side minimums are read, which keeps the kernel's scalar-register footprint down.
-template <int KT, bool INVERSE, bool LINEAR>
+//   REGS = true: `sl` points at a per-lane register array (KT > 0, LINEAR): the two derivative
+//   logits are picked with a select chain instead of a dynamic index (which would force the
+//   array into scratch memory).
+template <int KT, bool INVERSE, bool LINEAR, bool REGS = false>
 __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, float& y, float& lad) {
 #pragma clang fp contract(off)
     const int K = KT > 0 ? KT : sp.K;
@@ -239,7 +242,15 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
 #endif
     const float* sd = sl + 2 * K;
     float u0, u1;
-    if (LINEAR) {  // logits padded with the tail constant on both sides
+    if (LINEAR && REGS) {
+        u0 = sp.tail_logit;
+        u1 = sp.tail_logit;
+#pragma unroll
+        for (int q = 0; q < KT - 1; ++q) {
+            u0 = (k == q + 1) ? sd[q] : u0;
+            u1 = (k == q) ? sd[q] : u1;
+        }
+    } else if (LINEAR) {  // logits padded with the tail constant on both sides
         u0 = (k == 0) ? sp.tail_logit : sd[k - 1];
         u1 = (k >= sp.nd) ? sp.tail_logit : sd[k];  // padded index k+1 past the given logits
     } else {

@@ -163,3 +163,24 @@ def test_grad_mode_uses_the_backward_kernels():
     with torch.no_grad():
         lp2 = flow.log_prob(x)
     assert not lp2.requires_grad and (lp - lp2).abs().max().item() < 1e-5
+
+
+def test_hip_graph_replay_is_bit_identical():
+    """A whole log_prob / inverse pass captured into a HIP graph (nflows_amd/graphs.py): the
+    library's launches are captured from PyTorch's current stream like any other kernel."""
+    from nflows_amd import configs
+    from nflows_amd.graphs import GraphedInverse, GraphedLogProb
+    flow = configs.rq_nsf_flow(num_layers=3, features=64, num_bins=8, hidden_features=32).to(DEV).eval()
+    x = torch.randn(2048, 64, device=DEV)
+    g = GraphedLogProb(flow, x)
+    gi = GraphedInverse(flow, x)
+    for _ in range(2):
+        x2 = torch.randn(2048, 64, device=DEV)
+        with torch.no_grad():
+            want = flow.log_prob(x2)
+            wx, wl = flow._transform.inverse(x2)
+        assert torch.equal(g(x2), want)
+        gx, gl = gi(x2)
+        assert torch.equal(gx, wx) and torch.equal(gl, wl)
+    with pytest.raises(ValueError):
+        g(x[:10])
