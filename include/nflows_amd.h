@@ -152,6 +152,20 @@ int nfa_rqs_elementwise_f32(const float *inputs, const float *unnormalized_width
                             int32_t inverse, void *stream);
 
 /*
+ * K6.  Rational-quadratic CDF transform with parameters shared by the whole batch:
+ *   PiecewiseRationalQuadraticCDF._spline, nonlinearities.py:431-467 (what the spline coupling
+ *   layer applies to its identity half when apply_unconditional_transform=True, coupling.py:524-535).
+ *   inputs, outputs [batch, features]; logits [features, K], [features, K], [features, K-1 | K+1];
+ *   logabsdet [batch] = sum over features.  The per-feature knots are built once per workgroup in
+ *   LDS instead of being broadcast to [batch, features, K] as the reference does (:226-227).
+ *   flags: NFA_FLAG_INVERSE.
+ */
+int nfa_rqs_shared_f32(const float *inputs, const float *unnormalized_widths,
+                       const float *unnormalized_heights, const float *unnormalized_derivatives,
+                       float *outputs, float *logabsdet, int32_t *status, int64_t batch,
+                       int32_t features, const nfa_rqs_spec *spec, int32_t flags, void *stream);
+
+/*
  * K2.  Fused affine / additive coupling layer given the conditioner output.
  *   AffineCouplingTransform._scale_and_shift / _coupling_transform_forward / _inverse
  *   coupling.py:234-252; AdditiveCouplingTransform coupling.py:255-269; plus the split/scatter

@@ -174,6 +174,46 @@ __device__ __forceinline__ float softplus_beta(float x, float beta) {
     return xb > 20.0f ? x : (beta == 1.0f ? sp : sp / beta);
 }
 
+// The map inside one bin: knots (cw0, cw1) -> (ch0, ch1), end derivatives d0, d1.
+// forward: rational_quadratic.py:162-181; inverse (quadratic root): :132-160.
+template <bool INVERSE>
+__device__ __forceinline__ int rqs_bin_eval(float x, float cw0, float cw1, float ch0, float ch1, float d0,
+                                            float d1, float& y, float& lad) {
+#pragma clang fp contract(off)
+    const float in_w = cw1 - cw0;
+    const float in_h = ch1 - ch0;
+    const float r_w = rcp_refined(in_w);
+    const float delta = div_with_rcp(in_h, in_w, r_w);
+    const float s = (d0 + d1) - 2.0f * delta;
+    int status = 0;
+
+    if (INVERSE) {
+        const float yc = x - ch0;
+        const float a = yc * s + in_h * (delta - d0);
+        const float b = in_h * d0 - yc * s;
+        const float c = (-delta) * yc;
+        const float disc = b * b - (4.0f * a) * c;
+        if (!(disc >= 0.0f)) status = NFA_STATUS_NEG_DISCRIMINANT;
+        const float root = div_normal(2.0f * c, (-b) - sqrtf(disc));
+        y = root * in_w + cw0;
+        const float t1mt = root * (1.0f - root);
+        const float den = delta + s * t1mt;
+        const float omr = 1.0f - root;
+        const float dnum = (delta * delta) * ((d1 * (root * root) + (2.0f * delta) * t1mt) + d0 * (omr * omr));
+        lad = -(log_normal(dnum) - 2.0f * log_normal(den));
+    } else {
+        const float theta = div_with_rcp(x - cw0, in_w, r_w);
+        const float t1mt = theta * (1.0f - theta);
+        const float num = in_h * (delta * (theta * theta) + d0 * t1mt);
+        const float den = delta + s * t1mt;
+        y = ch0 + div_normal(num, den);
+        const float omt = 1.0f - theta;
+        const float dnum = (delta * delta) * ((d1 * (theta * theta) + (2.0f * delta) * t1mt) + d0 * (omt * omt));
+        lad = log_normal(dnum) - 2.0f * log_normal(den);
+    }
+    return status;
+}
+
 // One spline evaluation.  `sl` = this lane's P logits in LDS (may be clobbered when KT == 0).
 //   LINEAR = true: linear tails, box [-B, B]^2 (B = sp.right); only sp.right / span_w / right_eps
 //   and the per-side minimums are read, which keeps the kernel's scalar-register footprint down.
@@ -260,38 +300,7 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
     const float d0 = sp.min_d + softplus_beta(u0, sp.beta);
     const float d1 = sp.min_d + softplus_beta(u1, sp.beta);
 
-    const float in_w = cw1 - cw0;
-    const float in_h = ch1 - ch0;
-    const float r_w = rcp_refined(in_w);
-    const float delta = div_with_rcp(in_h, in_w, r_w);
-    const float s = (d0 + d1) - 2.0f * delta;
-    int status = 0;
-
-    if (INVERSE) {
-        const float yc = x - ch0;
-        const float a = yc * s + in_h * (delta - d0);
-        const float b = in_h * d0 - yc * s;
-        const float c = (-delta) * yc;
-        const float disc = b * b - (4.0f * a) * c;
-        if (!(disc >= 0.0f)) status = NFA_STATUS_NEG_DISCRIMINANT;
-        const float root = div_normal(2.0f * c, (-b) - sqrtf(disc));
-        y = root * in_w + cw0;
-        const float t1mt = root * (1.0f - root);
-        const float den = delta + s * t1mt;
-        const float omr = 1.0f - root;
-        const float dnum = (delta * delta) * ((d1 * (root * root) + (2.0f * delta) * t1mt) + d0 * (omr * omr));
-        lad = -(log_normal(dnum) - 2.0f * log_normal(den));
-    } else {
-        const float theta = div_with_rcp(x - cw0, in_w, r_w);
-        const float t1mt = theta * (1.0f - theta);
-        const float num = in_h * (delta * (theta * theta) + d0 * t1mt);
-        const float den = delta + s * t1mt;
-        y = ch0 + div_normal(num, den);
-        const float omt = 1.0f - theta;
-        const float dnum = (delta * delta) * ((d1 * (theta * theta) + (2.0f * delta) * t1mt) + d0 * (omt * omt));
-        lad = log_normal(dnum) - 2.0f * log_normal(den);
-    }
-    return status;
+    return rqs_bin_eval<INVERSE>(x, cw0, cw1, ch0, ch1, d0, d1, y, lad);
 }
 
 

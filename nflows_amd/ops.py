@@ -400,3 +400,38 @@ def _standard_normal_log_prob_launch(z, logabsdet):
                                                        N.stream_handle(z.device))
     N.check(rc)
     return out
+
+
+def rqs_shared(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, spec,
+               inverse=False):
+    """K6 -- rational-quadratic CDF transform with batch-shared logits [*shape, K]; inputs
+    [B, *shape].  Returns (outputs, logabsdet [B])."""
+    N.require_device_f32("inputs", inputs)
+    K = spec.num_bins
+    nd = K - 1 if spec.tails == N.TAILS_LINEAR else K + 1
+    B = inputs.shape[0]
+    F = inputs.numel() // B if B else int(np.prod(inputs.shape[1:]))
+    for nm, t, w in (("unnormalized_widths", unnormalized_widths, K),
+                     ("unnormalized_heights", unnormalized_heights, K),
+                     ("unnormalized_derivatives", unnormalized_derivatives, nd)):
+        N.require_device_f32(nm, t)
+        if t.numel() != F * w:
+            raise ValueError("%s must hold %d x %d values" % (nm, F, w))
+    dev = inputs.device
+    x = inputs.detach().contiguous().view(B, F)
+    uw, uh, ud = (t.detach().contiguous() for t in (unnormalized_widths, unnormalized_heights,
+                                                    unnormalized_derivatives))
+    y = torch.empty_like(x)
+    lad = torch.empty(B, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_rqs_shared_f32(N.ptr(x), N.ptr(uw), N.ptr(uh), N.ptr(ud), N.ptr(y), N.ptr(lad),
+                                         N.ptr(_status_word(dev)), B, F, ctypes.byref(spec),
+                                         N.FLAG_INVERSE if inverse else 0, N.stream_handle(dev))
+    if rc == N.ERR_UNSUPPORTED:  # tables do not fit in LDS: broadcast the logits, K5 + K3
+        def share(p, w):
+            return p.view(1, F, w).expand(B, F, w)
+        yy, ll = _rqs_elementwise_launch(x, share(uw, K), share(uh, K), share(ud, nd), spec, inverse)
+        return yy.view(inputs.shape), rowsum(ll)
+    N.check(rc)
+    _after_spline(spec, inverse, dev)
+    return y.view(inputs.shape), lad

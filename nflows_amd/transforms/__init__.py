@@ -7,3 +7,4 @@ from . import splines
 from .autoregressive import (AutoregressiveTransform, MaskedAffineAutoregressiveTransform,
                              MaskedPiecewiseRationalQuadraticAutoregressiveTransform)
 from .made import MADE
+from .nonlinearities import PiecewiseRationalQuadraticCDF

@@ -401,6 +401,61 @@ def error_surface():
     print("errors:", rec)
 
 
+# --------------------------------------------------------------------------- shared-parameter CDF
+def cdf_cases():
+    from nflows.transforms.nonlinearities import PiecewiseRationalQuadraticCDF
+    out = {}
+    meta = []
+    g = torch.Generator().manual_seed(31337)
+    for name, F, K, tails, tb, B in [("cdf_f32_k8", 32, 8, "linear", 3.0, 70), ("cdf_f5_k10", 5, 10, None, 1.0, 33),
+                                     ("cdf_f100_k4", 100, 4, "linear", 2.0, 19)]:
+        torch.manual_seed(5)
+        t = PiecewiseRationalQuadraticCDF([F], num_bins=K, tails=tails, tail_bound=tb)
+        with torch.no_grad():
+            for p in t.parameters():
+                p.copy_(2.0 * torch.randn(p.shape, generator=g))
+        x = (1.5 * torch.randn(B, F, generator=g)) if tails == "linear" else torch.rand(B, F, generator=g)
+        for k, v in t.state_dict().items():
+            out[name + "/sd/" + k] = npy(v)
+        out[name + "/x"] = npy(x)
+        for dt_name, dtp in (("", torch.float32), ("64", torch.float64)):
+            tt = t.double() if dtp is torch.float64 else t.float()
+            with torch.no_grad():
+                for direction, fn in (("fwd", tt.forward), ("inv", tt.inverse)):
+                    y, lad = fn(x.to(dtp))
+                    out["%s/%s_y%s" % (name, direction, dt_name)] = npy(y)
+                    out["%s/%s_lad%s" % (name, direction, dt_name)] = npy(lad)
+        t.float()
+        meta.append((name, repr(dict(F=F, K=K, tails=tails, tail_bound=tb, B=B))))
+    # coupling layer with apply_unconditional_transform=True (coupling.py:524-535)
+    torch.manual_seed(9)
+    D, K, B = 16, 6, 40
+    layer = PiecewiseRationalQuadraticCouplingTransform(
+        torchutils.create_alternating_binary_mask(D), lambda i, o: ResidualNet(i, o, hidden_features=24),
+        num_bins=K, tails="linear", tail_bound=3.0, apply_unconditional_transform=True)
+    with torch.no_grad():
+        for n_, p in layer.named_parameters():
+            if "final_layer" in n_:
+                p.mul_(5.0)
+    x = torch.randn(B, D, generator=g)
+    name = "coupling_uncond"
+    for k, v in layer.state_dict().items():
+        out[name + "/sd/" + k] = npy(v)
+    out[name + "/x"] = npy(x)
+    for dt_name, dtp in (("", torch.float32), ("64", torch.float64)):
+        ll = layer.double() if dtp is torch.float64 else layer.float()
+        with torch.no_grad():
+            for direction, fn in (("fwd", ll.forward), ("inv", ll.inverse)):
+                y, lad = fn(x.to(dtp))
+                out["%s/%s_y%s" % (name, direction, dt_name)] = npy(y)
+                out["%s/%s_lad%s" % (name, direction, dt_name)] = npy(lad)
+    layer.float()
+    meta.append((name, repr(dict(D=D, K=K, B=B, hidden=24))))
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "cdf.npz"), **out)
+    print("cdf:", len(meta), "cases")
+
+
 # --------------------------------------------------------------------------- gradients
 class ParamNet(nn.Module):
     """Conditioner stand-in whose output IS a parameter, so autograd yields d loss / d params."""
@@ -510,6 +565,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "grads":
         grad_cases()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cdf":
+        cdf_cases()
+        sys.exit(0)
     rqs_cases()
     searchsorted_case()
     coupling_cases()
@@ -517,3 +575,4 @@ if __name__ == "__main__":
     misc_cases()
     error_surface()
     grad_cases()
+    cdf_cases()
