@@ -26,13 +26,50 @@ class AutoregressiveTransform(Transform):
         params = self.autoregressive_net(inputs, context)
         return self._elementwise_forward(inputs, params)
 
+    # Set to False to run the reference's loop verbatim (D full passes, autoregressive.py:43-52).
+    columnwise_inverse = True
+
     def inverse(self, inputs, context=None):
+        net = self.autoregressive_net
+        if (self.columnwise_inverse and inputs.dim() == 2 and isinstance(net, made_module.MADE)
+                and net.is_deterministic() and hasattr(self, "_inverse_column")):
+            return self._inverse_columnwise(inputs, context)
+        return self._inverse_reference_loop(inputs, context)
+
+    def _inverse_reference_loop(self, inputs, context=None):
         num_inputs = int(np.prod(inputs.shape[1:]))
         outputs = torch.zeros_like(inputs)
         logabsdet = None
         for _ in range(num_inputs):
             params = self.autoregressive_net(outputs, context)
             outputs, logabsdet = self._elementwise_inverse(inputs, params)
+        return outputs, logabsdet
+
+    def _inverse_columnwise(self, inputs, context=None):
+        """Same result as the reference loop with O(D) instead of O(D^2) work in the output layer
+        and the elementwise transform.
+
+        In the reference loop, iteration t+1 recomputes ALL D*P conditioner outputs and ALL D
+        elementwise inverses, although (by the autoregressive masks) only feature t changes: its
+        parameters depend on features < t, which became final in earlier iterations, and the
+        features it has not reached yet are multiplied by exactly-zero masked weights.  Here step
+        t evaluates the hidden layers on the current outputs (unreached features still zero),
+        takes only feature t's P rows of the final masked layer, inverts that one column and adds
+        its log-derivative.  Identical up to GEMM blocking / summation order."""
+        net = self.autoregressive_net
+        batch, features = inputs.shape
+        mult = self._output_dim_multiplier()
+        final = net.final_layer
+        weight = (final.weight * final.mask).view(features, mult, -1)
+        bias = final.bias.view(features, mult)
+        outputs = torch.zeros_like(inputs)
+        logabsdet = inputs.new_zeros(batch)
+        for t in range(features):
+            h = net.hidden(outputs, context)
+            params_t = torch.addmm(bias[t], h, weight[t].t())
+            column, lad_t = self._inverse_column(inputs[:, t], params_t)
+            outputs[:, t] = column
+            logabsdet = logabsdet + lad_t
         return outputs, logabsdet
 
     def _output_dim_multiplier(self):
@@ -70,6 +107,11 @@ class MaskedAffineAutoregressiveTransform(AutoregressiveTransform):
 
     def _elementwise_inverse(self, inputs, autoregressive_params):
         return ops.affine_autoregressive(inputs, autoregressive_params, inverse=True)
+
+    def _inverse_column(self, column, params):
+        """One feature: params [B, 2] = (scale logit, shift); K2b with a single feature."""
+        out, lad = ops.affine_autoregressive(column.reshape(-1, 1), params, inverse=True)
+        return out.reshape(-1), lad
 
 
 class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTransform):
@@ -116,10 +158,12 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
         spec = ops.make_rqs_spec(self.num_bins, self.tails, tail_bound=self.tail_bound,
                                  min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                                  min_derivative=self.min_derivative, wh_divisor=divisor)
-        cols = self._all_features
-        if cols is None or cols.device != inputs.device or cols.numel() != features:
+        cache = self._all_features if isinstance(self._all_features, dict) else {}
+        cols = cache.get((features, inputs.device))
+        if cols is None:
             cols = torch.arange(features, device=inputs.device)
-            self._all_features = cols
+            cache[(features, inputs.device)] = cols
+            self._all_features = cache
         params = autoregressive_params.reshape(batch, features * self._output_dim_multiplier())
         return ops.rqs_coupling(inputs, params, cols, spec, inverse=inverse)
 
@@ -128,3 +172,8 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
 
     def _elementwise_inverse(self, inputs, autoregressive_params):
         return self._elementwise(inputs, autoregressive_params, inverse=True)
+
+    def _inverse_column(self, column, params):
+        """One feature: params [B, P]; the spline layer kernel with a single (transformed) feature."""
+        out, lad = self._elementwise(column.reshape(-1, 1), params, inverse=True)
+        return out.reshape(-1), lad

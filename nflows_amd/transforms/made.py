@@ -135,7 +135,8 @@ class MADE(nn.Module):
         self.blocks = nn.ModuleList(blocks)
         self.final_layer = MaskedLinear(degrees, features * output_multiplier, features, random_mask, True)
 
-    def forward(self, inputs, context=None):
+    def hidden(self, inputs, context=None):
+        """Activations fed to the final masked layer."""
         h = self.initial_layer(inputs)
         if context is not None:
             h = h + self.activation(self.context_layer(context))
@@ -143,4 +144,17 @@ class MADE(nn.Module):
             h = self.activation(h)
         for block in self.blocks:
             h = block(h, context)
-        return self.final_layer(h)
+        return h
+
+    def forward(self, inputs, context=None):
+        return self.final_layer(self.hidden(inputs, context))
+
+    def is_deterministic(self):
+        """True when two evaluations on the same inputs give the same outputs (no active dropout,
+        no batch-statistics batch norm): the precondition of the column-wise inverse."""
+        for m in self.modules():
+            if isinstance(m, nn.Dropout) and m.p > 0 and m.training:
+                return False
+            if isinstance(m, nn.BatchNorm1d) and m.training:
+                return False
+        return True

@@ -223,3 +223,25 @@ def test_shared_parameter_cdf_and_unconditional_transform(golden_dir):
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in t.parameters())
     import nflows_amd
     nflows_amd.check_status()
+
+
+def test_columnwise_autoregressive_inverse_equals_reference_loop(golden):
+    """f2: the O(D) column-wise inverse gives the reference loop's result (and the reference's
+    fixtures), for the affine MAF and the autoregressive spline."""
+    for name in ("moons_maf", "ar_rq_small"):
+        cfg = parse_kwargs(dict((n, c) for n, c in golden["meta"])[name])
+        flow = build(cfg)
+        load_state(flow, golden, name)
+        flow = flow.to(DEV).eval()
+        noise = torch.from_numpy(golden[name + "/noise"]).to(DEV)
+        with torch.no_grad():
+            xs, lad = flow._transform.inverse(noise)                      # column-wise (default)
+            for t in flow._transform._transforms:
+                if hasattr(t, "columnwise_inverse"):
+                    t.columnwise_inverse = False
+            xr, ladr = flow._transform.inverse(noise)                     # reference loop
+        d = cfg.get("D", 2)
+        assert (xs - xr).abs().max().item() <= 2e-5 * (1 + xr.abs().max().item())
+        assert (lad - ladr).abs().max().item() <= 2e-5 * d
+        check(xs, golden[name + "/inv_x"], golden[name + "/inv_x64"], name + " inv_x", 3e-6)
+        check(lad, golden[name + "/inv_lad"], golden[name + "/inv_lad64"], name + " inv_lad", 3e-6 * d)

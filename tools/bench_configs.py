@@ -64,4 +64,7 @@ with torch.no_grad():
     one = timed(lambda: t._elementwise_inverse(x, t.autoregressive_net(x)), 10)
     report("cfg4 AR-RQ D=784 inverse, ONE of 784 reference iterations", one, 4096,
            extrapolated_full_inverse_s=one * 784)
+    z = torch.randn(4096, 784, device=dev)
+    full = timed(lambda: t.inverse(z), 2, warm=1)
+    report("cfg4 AR-RQ D=784 FULL inverse (sampling), column-wise", full, 4096)
     nflows_amd.check_status()
