@@ -1,4 +1,9 @@
-"""Distribution template methods used by Flow (reference: nflows/distributions/base.py)."""
+"""Distribution template methods used by Flow.
+
+Public surface of nflows/distributions/base.py:16-128: `log_prob(inputs, context)`,
+`sample(num_samples, context, batch_size)`, `sample_and_log_prob`, `mean`; subclasses implement
+`_log_prob`, `_sample`, `_mean`.
+"""
 import torch
 from torch import nn
 
@@ -7,63 +12,60 @@ from ..utils import typechecks as check
 
 
 class NoMeanException(Exception):
-    """Raised when a distribution has no mean."""
+    """The distribution does not define a mean."""
+
+
+def _as_tensor_or_none(value):
+    return None if value is None else torch.as_tensor(value)
 
 
 class Distribution(nn.Module):
-    """log_prob / sample / sample_and_log_prob wrappers around `_log_prob`, `_sample`."""
-
     def forward(self, *args):
         raise RuntimeError("Forward method cannot be called for a Distribution object.")
 
+    # -- density ---------------------------------------------------------------------------
     def log_prob(self, inputs, context=None):
-        """[batch, ...] -> [batch] log-densities; context rows must match inputs rows."""
-        inputs = torch.as_tensor(inputs)
-        if context is not None:
-            context = torch.as_tensor(context)
-            if inputs.shape[0] != context.shape[0]:
-                raise ValueError("Number of input items must be equal to number of context items.")
+        """[batch, ...] -> [batch]; one context row per input row when a context is given."""
+        inputs, context = torch.as_tensor(inputs), _as_tensor_or_none(context)
+        if context is not None and context.shape[0] != inputs.shape[0]:
+            raise ValueError("Number of input items must be equal to number of context items.")
         return self._log_prob(inputs, context)
 
     def _log_prob(self, inputs, context):
         raise NotImplementedError()
 
+    # -- sampling --------------------------------------------------------------------------
     def sample(self, num_samples, context=None, batch_size=None):
-        """num_samples draws (per context row if a context is given), optionally in chunks."""
+        """`num_samples` draws ([context_size, num_samples, ...] with a context); `batch_size`
+        splits the work into chunks that are concatenated."""
         if not check.is_positive_int(num_samples):
             raise TypeError("Number of samples must be a positive integer.")
-        if context is not None:
-            context = torch.as_tensor(context)
+        context = _as_tensor_or_none(context)
         if batch_size is None:
             return self._sample(num_samples, context)
         if not check.is_positive_int(batch_size):
             raise TypeError("Batch size must be a positive integer.")
-        full, rest = divmod(num_samples, batch_size)
-        chunks = [self._sample(batch_size, context) for _ in range(full)]
-        if rest > 0:
-            chunks.append(self._sample(rest, context))
-        return torch.cat(chunks, dim=0)
+        sizes = [batch_size] * (num_samples // batch_size)
+        if num_samples % batch_size:
+            sizes.append(num_samples % batch_size)
+        return torch.cat([self._sample(n, context) for n in sizes], dim=0)
 
     def _sample(self, num_samples, context):
         raise NotImplementedError()
 
     def sample_and_log_prob(self, num_samples, context=None):
-        """Samples together with their log-densities."""
         samples = self.sample(num_samples, context=context)
-        if context is not None:
-            samples = torchutils.merge_leading_dims(samples, num_dims=2)
-            context = torchutils.repeat_rows(context, num_reps=num_samples)
-            assert samples.shape[0] == context.shape[0]
-        log_prob = self.log_prob(samples, context=context)
-        if context is not None:
-            samples = torchutils.split_leading_dim(samples, shape=[-1, num_samples])
-            log_prob = torchutils.split_leading_dim(log_prob, shape=[-1, num_samples])
-        return samples, log_prob
+        if context is None:
+            return samples, self.log_prob(samples)
+        flat = torchutils.merge_leading_dims(samples, num_dims=2)
+        rows = torchutils.repeat_rows(context, num_reps=num_samples)
+        assert flat.shape[0] == rows.shape[0]
+        log_prob = self.log_prob(flat, context=rows)
+        return samples, torchutils.split_leading_dim(log_prob, shape=[-1, num_samples])
 
+    # -- moments ---------------------------------------------------------------------------
     def mean(self, context=None):
-        if context is not None:
-            context = torch.as_tensor(context)
-        return self._mean(context)
+        return self._mean(_as_tensor_or_none(context))
 
     def _mean(self, context):
         raise NoMeanException()

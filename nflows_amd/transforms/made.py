@@ -1,74 +1,84 @@
-"""MADE conditioner for the autoregressive transforms (configs 1 and 5); PyTorch-ROCm GEMMs.
+"""MADE conditioner of the autoregressive transforms (configs 1 and 5); PyTorch-ROCm GEMMs.
 
-Mask / degree rules and parameter names follow nflows/transforms/made.py (`initial_layer`,
-`blocks.{i}.linear_layers.{0,1}` or `blocks.{i}.linear`, `context_layer`, `final_layer`, each
-masked layer with `mask` and `degrees` buffers), so reference checkpoints load unchanged.
-MADE deliberately has no `hidden_features` attribute: the autoregressive spline transform
-therefore applies no 1/sqrt(hidden) scaling (autoregressive.py:464-466).
+Checkpoint-compatible with nflows/transforms/made.py: modules `initial_layer`,
+`blocks.{i}.linear_layers.{0,1}` (residual) or `blocks.{i}.linear` (feed-forward),
+`context_layer`, `final_layer`; every masked layer carries `mask` and `degrees` buffers built by
+the same rules (made.py:42-69).  MADE has no `hidden_features` attribute on purpose: the
+autoregressive spline transform then applies no 1/sqrt(hidden) scaling (autoregressive.py:464-466).
 """
 import torch
 from torch import nn
 from torch.nn import functional as F
 
 
-def _input_degrees(features):
+# ---- degrees and masks ------------------------------------------------------------------------
+# Input feature i has degree i+1.  A hidden unit of degree m may look at inputs of degree <= m,
+# an output unit of degree m only at degrees < m; hidden degrees cycle through 1..D-1.
+
+def input_degrees(features):
     return torch.arange(1, features + 1)
 
 
+def hidden_degrees(units, features, in_degrees, random_mask):
+    if random_mask:
+        lowest = min(int(in_degrees.min()), features - 1)
+        return torch.randint(low=lowest, high=features, size=[units], dtype=torch.long)
+    top, bottom = max(1, features - 1), min(1, features - 1)
+    return torch.arange(units) % top + bottom
+
+
+def output_degrees(units, features):
+    return torch.repeat_interleave(input_degrees(features), units // features)
+
+
 class MaskedLinear(nn.Linear):
-    """Linear layer whose weight is multiplied by a fixed 0/1 mask (made.py:16-72).
+    """y = x (W * mask)^T + b.
 
-    Hidden units get degrees 1..D-1 cyclically (or at random); unit j may see input i iff
-    degree_j >= degree_i (hidden) or degree_j > degree_i (output layer)."""
+    The mask is a constant 0/1 buffer, so the product W * mask is formed on the fly in front of
+    a plain GEMM (hipBLASLt on the MI355X).  The column-wise autoregressive inverse
+    (autoregressive.py in this package) slices `weight * mask` of the OUTPUT layer by feature:
+    rows [f * multiplier, (f + 1) * multiplier) hold feature f's parameters because output
+    degrees are laid out feature-major (`output_degrees`)."""
 
-    def __init__(self, in_degrees, out_features, autoregressive_features, random_mask, is_output,
-                 bias=True):
-        super().__init__(in_features=len(in_degrees), out_features=out_features, bias=bias)
-        mask, degrees = self._get_mask_and_degrees(in_degrees, out_features, autoregressive_features,
-                                                   random_mask, is_output)
-        self.register_buffer("mask", mask)
+    def __init__(self, in_degrees, out_features, autoregressive_features, random_mask, is_output, bias=True):
+        super().__init__(len(in_degrees), out_features, bias=bias)
+        if is_output:
+            degrees = output_degrees(out_features, autoregressive_features)
+            mask = degrees[:, None] > in_degrees
+        else:
+            degrees = hidden_degrees(out_features, autoregressive_features, in_degrees, random_mask)
+            mask = degrees[:, None] >= in_degrees
+        self.register_buffer("mask", mask.float())
         self.register_buffer("degrees", degrees)
 
-    @classmethod
-    def _get_mask_and_degrees(cls, in_degrees, out_features, autoregressive_features, random_mask,
-                              is_output):
-        D = autoregressive_features
-        if is_output:
-            out_degrees = torch.repeat_interleave(_input_degrees(D), out_features // D)
-            mask = (out_degrees[:, None] > in_degrees).float()
-        else:
-            if random_mask:
-                low = min(int(torch.min(in_degrees).item()), D - 1)
-                out_degrees = torch.randint(low=low, high=D, size=[out_features], dtype=torch.long)
-            else:
-                out_degrees = torch.arange(out_features) % max(1, D - 1) + min(1, D - 1)
-            mask = (out_degrees[:, None] >= in_degrees).float()
-        return mask, out_degrees
-
     def forward(self, x):
-        return F.linear(x, self.weight * self.mask, self.bias)
+        return F.linear(x, self.mask * self.weight, self.bias)
+
+
+def _norm(features):
+    return nn.BatchNorm1d(features, eps=1e-3)
 
 
 class MaskedFeedforwardBlock(nn.Module):
-    """(batch norm) -> masked linear -> activation -> dropout (made.py:75-123)."""
+    """dropout(act(masked_linear(norm(x)))), same width in and out."""
 
     def __init__(self, in_degrees, autoregressive_features, context_features=None, random_mask=False,
                  activation=F.relu, dropout_probability=0.0, use_batch_norm=False):
         super().__init__()
-        features = len(in_degrees)
-        self.batch_norm = nn.BatchNorm1d(features, eps=1e-3) if use_batch_norm else None
-        self.linear = MaskedLinear(in_degrees, features, autoregressive_features, random_mask, False)
+        width = len(in_degrees)
+        self.batch_norm = _norm(width) if use_batch_norm else None
+        self.linear = MaskedLinear(in_degrees, width, autoregressive_features, random_mask, is_output=False)
         self.degrees = self.linear.degrees
         self.activation = activation
         self.dropout = nn.Dropout(p=dropout_probability)
 
     def forward(self, inputs, context=None):
-        h = self.batch_norm(inputs) if self.batch_norm else inputs
-        return self.dropout(self.activation(self.linear(h)))
+        normed = inputs if self.batch_norm is None else self.batch_norm(inputs)
+        return self.dropout(self.activation(self.linear(normed)))
 
 
 class MaskedResidualBlock(nn.Module):
-    """x + L1(act(L0(act(x)) + context)) with masked layers (made.py:126-202)."""
+    """x + L1(dropout(act(norm(L0(act(norm(x))) + context_layer(context)))))."""
 
     def __init__(self, in_degrees, autoregressive_features, context_features=None, random_mask=False,
                  activation=F.relu, dropout_probability=0.0, use_batch_norm=False,
@@ -76,40 +86,44 @@ class MaskedResidualBlock(nn.Module):
         if random_mask:
             raise ValueError("Masked residual block can't be used with random masks.")
         super().__init__()
-        features = len(in_degrees)
+        width = len(in_degrees)
         if context_features is not None:
-            self.context_layer = nn.Linear(context_features, features)
+            self.context_layer = nn.Linear(context_features, width)
         self.use_batch_norm = use_batch_norm
         if use_batch_norm:
-            self.batch_norm_layers = nn.ModuleList(nn.BatchNorm1d(features, eps=1e-3) for _ in range(2))
-        first = MaskedLinear(in_degrees, features, autoregressive_features, False, False)
-        second = MaskedLinear(first.degrees, features, autoregressive_features, False, False)
-        self.linear_layers = nn.ModuleList([first, second])
-        self.degrees = second.degrees
-        if not bool(torch.all(self.degrees >= in_degrees)):
+            self.batch_norm_layers = nn.ModuleList([_norm(width), _norm(width)])
+        lower = MaskedLinear(in_degrees, width, autoregressive_features, False, is_output=False)
+        upper = MaskedLinear(lower.degrees, width, autoregressive_features, False, is_output=False)
+        self.linear_layers = nn.ModuleList([lower, upper])
+        self.degrees = upper.degrees
+        if bool((self.degrees < in_degrees).any()):
             raise RuntimeError("In a masked residual block, the output degrees can't be"
                                " less than the corresponding input degrees.")
         self.activation = activation
         self.dropout = nn.Dropout(p=dropout_probability)
         if zero_initialization:
-            nn.init.uniform_(second.weight, a=-1e-3, b=1e-3)
-            nn.init.uniform_(second.bias, a=-1e-3, b=1e-3)
+            for tensor in (upper.weight, upper.bias):
+                nn.init.uniform_(tensor, a=-1e-3, b=1e-3)
 
     def forward(self, inputs, context=None):
-        h = inputs
-        if self.use_batch_norm:
-            h = self.batch_norm_layers[0](h)
-        h = self.linear_layers[0](self.activation(h))
+        lower, upper = self.linear_layers
+        h = self.batch_norm_layers[0](inputs) if self.use_batch_norm else inputs
+        h = lower(self.activation(h))
         if context is not None:
             h = h + self.context_layer(context)
         if self.use_batch_norm:
             h = self.batch_norm_layers[1](h)
-        h = self.linear_layers[1](self.dropout(self.activation(h)))
-        return inputs + h
+        return inputs + upper(self.dropout(self.activation(h)))
 
 
 class MADE(nn.Module):
-    """Masked autoencoder: output block d depends only on inputs < d (made.py:205-283)."""
+    """Masked autoencoder: the `output_multiplier` outputs of feature d depend on features < d.
+
+    Layout of the result: [batch, features * output_multiplier], feature-major, which is exactly
+    the [batch, d_t * P] parameter layout the fused spline kernel consumes with d_t = features
+    (and the interleaved [batch, features, 2] layout of the affine autoregressive kernel).
+    `hidden()` exposes the activations in front of the output layer so that the sampling path can
+    evaluate one feature's parameters at a time."""
 
     def __init__(self, features, hidden_features, context_features=None, num_blocks=2,
                  output_multiplier=1, use_residual_blocks=True, random_mask=False, activation=F.relu,
@@ -117,23 +131,24 @@ class MADE(nn.Module):
         if use_residual_blocks and random_mask:
             raise ValueError("Residual blocks can't be used with random masks.")
         super().__init__()
-        self.initial_layer = MaskedLinear(_input_degrees(features), hidden_features, features,
-                                          random_mask, False)
-        if context_features is not None:
-            self.context_layer = nn.Linear(context_features, hidden_features)
         self.use_residual_blocks = use_residual_blocks
         self.activation = activation
-        block_cls = MaskedResidualBlock if use_residual_blocks else MaskedFeedforwardBlock
-        blocks = []
+        self.initial_layer = MaskedLinear(input_degrees(features), hidden_features, features, random_mask,
+                                          is_output=False)
+        if context_features is not None:
+            self.context_layer = nn.Linear(context_features, hidden_features)
+        block_type = MaskedResidualBlock if use_residual_blocks else MaskedFeedforwardBlock
+        self.blocks = nn.ModuleList()
         degrees = self.initial_layer.degrees
         for _ in range(num_blocks):
-            blocks.append(block_cls(in_degrees=degrees, autoregressive_features=features,
-                                    context_features=context_features, random_mask=random_mask,
-                                    activation=activation, dropout_probability=dropout_probability,
-                                    use_batch_norm=use_batch_norm))
-            degrees = blocks[-1].degrees
-        self.blocks = nn.ModuleList(blocks)
-        self.final_layer = MaskedLinear(degrees, features * output_multiplier, features, random_mask, True)
+            block = block_type(in_degrees=degrees, autoregressive_features=features,
+                               context_features=context_features, random_mask=random_mask,
+                               activation=activation, dropout_probability=dropout_probability,
+                               use_batch_norm=use_batch_norm)
+            self.blocks.append(block)
+            degrees = block.degrees
+        self.final_layer = MaskedLinear(degrees, features * output_multiplier, features, random_mask,
+                                        is_output=True)
 
     def hidden(self, inputs, context=None):
         """Activations fed to the final masked layer."""
@@ -150,8 +165,8 @@ class MADE(nn.Module):
         return self.final_layer(self.hidden(inputs, context))
 
     def is_deterministic(self):
-        """True when two evaluations on the same inputs give the same outputs (no active dropout,
-        no batch-statistics batch norm): the precondition of the column-wise inverse."""
+        """No active dropout and no batch-statistics batch norm: two evaluations on the same inputs
+        agree (precondition of the column-wise autoregressive inverse)."""
         for m in self.modules():
             if isinstance(m, nn.Dropout) and m.p > 0 and m.training:
                 return False

@@ -1,9 +1,13 @@
-"""Column permutations (reference: nflows/transforms/permutations.py).
+"""Column permutations of the hot path.
 
-`forward` is `index_select(inputs, dim, permutation)` with a zero logabsdet, `inverse` selects
-with the inverse permutation.  2-D HIP tensors of 4-byte elements with dim=1 go through the K4
-kernel (bit-exact copy); when the permutation sits next to a coupling layer inside a
-`CompositeTransform` it is not launched at all but folded into that layer's kernel.
+API of nflows/transforms/permutations.py: `Permutation(permutation, dim=1)`,
+`RandomPermutation(features, dim=1)`, `ReversePermutation(features, dim=1)`, buffer
+`_permutation`; forward = index_select with the permutation (:27-39), inverse = index_select
+with its argsort (:22-24, :44-45), logabsdet = zeros.
+
+On a HIP device a 2-D tensor of 4-byte elements permuted along dim 1 is a bit-exact K4 kernel;
+next to a coupling layer inside `CompositeTransform` the permutation is not launched at all
+(folded into that layer's gather / scatter).
 """
 import torch
 
@@ -12,66 +16,67 @@ from ..utils import typechecks as check
 from .base import Transform
 
 
-class Permutation(Transform):
-    """Permutes `dim` of the inputs with a fixed permutation (permutations.py:9-45)."""
+def _require_feature_count(features):
+    if not check.is_positive_int(features):
+        raise ValueError("Number of features must be a positive integer.")
 
+
+class Permutation(Transform):
     def __init__(self, permutation, dim=1):
         if permutation.ndimension() != 1:
             raise ValueError("Permutation must be a 1D tensor.")
         if not check.is_positive_int(dim):
             raise ValueError("dim must be a positive integer.")
         super().__init__()
-        self._dim = dim
         self.register_buffer("_permutation", permutation)
-        self._inv_cache = None  # (version, data_ptr, tensor)
+        self._dim = dim
+        self._argsort_cache = None  # (key, tensor): argsort is recomputed only if the buffer changes
 
     @property
     def _inverse_permutation(self):
-        p = self._permutation
-        key = (p._version, p.data_ptr(), p.device)
-        if self._inv_cache is None or self._inv_cache[0] != key:
-            self._inv_cache = (key, torch.argsort(p))
-        return self._inv_cache[1]
+        buf = self._permutation
+        key = (buf.data_ptr(), buf._version, buf.device)
+        if self._argsort_cache is None or self._argsort_cache[0] != key:
+            self._argsort_cache = (key, torch.argsort(buf))
+        return self._argsort_cache[1]
 
     def _check(self, inputs):
-        if self._dim >= inputs.ndimension():
-            raise ValueError("No dimension {} in inputs.".format(self._dim))
-        if inputs.shape[self._dim] != len(self._permutation):
-            raise ValueError("Dimension {} in inputs must be of size {}.".format(
-                self._dim, len(self._permutation)))
+        dim, size = self._dim, len(self._permutation)
+        if inputs.ndimension() <= dim:
+            raise ValueError("No dimension {} in inputs.".format(dim))
+        if inputs.shape[dim] != size:
+            raise ValueError("Dimension {} in inputs must be of size {}.".format(dim, size))
 
-    def _permute(self, inputs, permutation):
+    def _select(self, inputs, index):
         self._check(inputs)
-        if self._dim == 1 and inputs.dim() == 2 and inputs.is_cuda and inputs.element_size() == 4 \
-                and not (torch.is_grad_enabled() and inputs.requires_grad):
-            outputs = ops.permute_cols(inputs, permutation)
-        elif inputs.is_cuda:
-            outputs = torch.index_select(inputs, self._dim, permutation)  # other ranks / dtypes
-        else:
+        if not inputs.is_cuda:
             raise NotImplementedError(
                 "nflows_amd: inputs on %s; the MI355X path has no CPU fallback" % inputs.device)
-        return outputs, inputs.new_zeros(inputs.shape[0])
+        wants_grad = torch.is_grad_enabled() and inputs.requires_grad
+        if self._dim == 1 and inputs.dim() == 2 and inputs.element_size() == 4 and not wants_grad:
+            permuted = ops.permute_cols(inputs, index)
+        else:  # other ranks / dtypes / autograd: the device's index_select
+            permuted = torch.index_select(inputs, self._dim, index)
+        return permuted, inputs.new_zeros(inputs.shape[0])
 
     def forward(self, inputs, context=None):
-        return self._permute(inputs, self._permutation)
+        return self._select(inputs, self._permutation)
 
     def inverse(self, inputs, context=None):
-        return self._permute(inputs, self._inverse_permutation)
+        return self._select(inputs, self._inverse_permutation)
 
 
 class RandomPermutation(Permutation):
-    """A random permutation fixed at construction (permutations.py:48-54)."""
+    """torch.randperm drawn once at construction (consumes the global RNG like the reference)."""
 
     def __init__(self, features, dim=1):
-        if not check.is_positive_int(features):
-            raise ValueError("Number of features must be a positive integer.")
+        _require_feature_count(features)
         super().__init__(torch.randperm(features), dim)
 
 
 class ReversePermutation(Permutation):
-    """Reverses the order of the features (permutations.py:57-63)."""
+    """features-1, ..., 1, 0."""
 
     def __init__(self, features, dim=1):
-        if not check.is_positive_int(features):
-            raise ValueError("Number of features must be a positive integer.")
+        _require_feature_count(features)
         super().__init__(torch.arange(features - 1, -1, -1), dim)

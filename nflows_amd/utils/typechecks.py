@@ -1,22 +1,27 @@
-"""Small argument predicates (reference: nflows/utils/typechecks.py)."""
+"""Argument predicates used by the host-side classes."""
 import numbers
 
 
-def is_bool(x):
-    return isinstance(x, bool)
+def is_bool(value):
+    return type(value) is bool
 
 
-def is_int(x):
-    return isinstance(x, numbers.Integral) and not isinstance(x, bool)
+def is_int(value):
+    # bool is an Integral in Python; the checks below are about counts, so exclude it
+    return isinstance(value, numbers.Integral) and not is_bool(value)
 
 
-def is_positive_int(x):
-    return is_int(x) and x > 0
+def _int_at_least(value, lowest):
+    return is_int(value) and value >= lowest
 
 
-def is_nonnegative_int(x):
-    return is_int(x) and x >= 0
+def is_positive_int(value):
+    return _int_at_least(value, 1)
 
 
-def is_power_of_two(n):
-    return is_positive_int(n) and (n & (n - 1)) == 0
+def is_nonnegative_int(value):
+    return _int_at_least(value, 0)
+
+
+def is_power_of_two(value):
+    return _int_at_least(value, 1) and value & (value - 1) == 0
