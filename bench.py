@@ -58,6 +58,18 @@ class EventHook:
         return sum(ms) / len(ms), len(ms)
 
 
+def dispatch_durations_ms(capacity):
+    """Per-launch K1 durations from the HIP events the library attached to each dispatch
+    (hipExtLaunchKernelGGL start/stop events on the launch stream): the kernel's own begin/end
+    timestamps, i.e. the quantity rocprofv3's kernel trace reports."""
+    import ctypes
+    from nflows_amd import _native
+    buf = (ctypes.c_float * capacity)()
+    n = ctypes.c_int32(0)
+    _native.check(_native.load().nfa_profile_collect(buf, capacity, ctypes.byref(n)))
+    return [buf[i] for i in range(n.value)]
+
+
 def log(msg):
     print("[bench %.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
@@ -116,6 +128,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=16384)
     ap.add_argument("--no-fuse", action="store_true", help="run permutations as separate kernels")
+    ap.add_argument("--bracket-events", action="store_true",
+                    help="additionally bracket every K1 launch with torch events (includes launch gaps)")
     ap.add_argument("--skip-consistency", action="store_true",
                     help="skip the fwd/inv check (profiling runs: only full-batch launches in the trace)")
     args = ap.parse_args()
@@ -163,7 +177,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     log("warm-up done; timing %d steps" % args.steps)
-    hook.enabled = True
+    hook.enabled = args.bracket_events
+    from nflows_amd import _native
+    max_launches = args.layers * args.steps
+    _native.check(_native.load().nfa_profile_enable(max_launches))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         acc = step()
@@ -172,6 +189,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     hook.enabled = False
+    k1_ms = dispatch_durations_ms(max_launches)
+    _native.check(_native.load().nfa_profile_enable(0))
     log("timed region done: %.1f ms/step" % (elapsed / args.steps * 1e3))
     nflows_amd.check_status()
 
@@ -196,11 +215,12 @@ def main():
 
     if rank == 0:
         total_rows = B * world
-        k1 = hook.summary()
         roofline = None
-        if k1 is not None:
-            avg_ms, launches = k1
-            achieved = hook.bytes / (avg_ms * 1e-3) / 1e9
+        if k1_ms:
+            avg_ms, launches = sum(k1_ms) / len(k1_ms), len(k1_ms)
+            nbytes = 4 * (B * D + B * (D // 2) * (3 * K - 1) + B * D + B)  # 3460 B/sample
+            achieved = nbytes / (avg_ms * 1e-3) / 1e9
+            bracket = hook.summary()
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "k1_pmc_traffic.json")
             if os.path.exists(tpath):
@@ -211,8 +231,11 @@ def main():
             roofline = {"bound": "hbm", "kernel": "nfa::rqs_coupling_pipelined<8, false, true, 6>",
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                        "algorithmic_bytes_per_launch": hook.bytes,
-                        "avg_launch_ms": avg_ms, "launches_timed": launches}
+                        "algorithmic_bytes_per_launch": nbytes,
+                        "avg_launch_ms": avg_ms, "launches_timed": launches,
+                        "timing": "HIP start/stop events attached to each K1 dispatch on its launch "
+                                  "stream (hipExtLaunchKernelGGL), all launches of the timed region",
+                        "bracketing_events_avg_ms": None if bracket is None else bracket[0]}
         result = {
             "metric": "log_prob samples/sec (dim=64, K=8, 32-layer RQ-NSF) + max |fwd∘inv − x|",
             "value": total_rows * args.steps / elapsed,

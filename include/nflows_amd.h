@@ -19,7 +19,8 @@
  *   - data-dependent errors (the reference's InputOutsideDomain / discriminant assertion) are
  *     OR-ed into the caller-provided device word `status` (may be NULL = not recorded); the
  *     caller decides when to read it back.  Kernels never clear it.
- *   - no global mutable state: entry points are re-entrant across host threads and streams.
+ *   - no global mutable state on the data path: entry points are re-entrant across host threads
+ *     and streams (the optional nfa_profile_* measurement aid at the end is the one exception).
  */
 #ifndef NFLOWS_AMD_H
 #define NFLOWS_AMD_H
@@ -209,6 +210,16 @@ int nfa_rowsum_f32(const float *x, float *out, int64_t rows, int64_t cols, void 
  */
 int nfa_standard_normal_log_prob_f32(const float *z, const float *logabsdet, float *out,
                                      int64_t rows, int64_t cols, void *stream);
+
+/*
+ * Measurement aid (bench.py), not part of the data path.  While enabled, every K1 launch
+ * (nfa_rqs_coupling_f32) carries its own start/stop HIP events attached to the dispatch
+ * (hipExtLaunchKernelGGL), up to max_launches; nfa_profile_collect waits for them and returns the
+ * kernels' own durations in launch order (what rocprofv3 --kernel-trace reports), then resets.
+ * max_launches = 0 disables.  This is the library's only global state.
+ */
+int nfa_profile_enable(int32_t max_launches);
+int nfa_profile_collect(float *durations_ms, int32_t capacity, int32_t *count);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,8 @@ EXPORTS = (
     "nfa_permute_cols_b32",
     "nfa_rowsum_f32",
     "nfa_standard_normal_log_prob_f32",
+    "nfa_profile_enable",
+    "nfa_profile_collect",
 )
 
 
@@ -106,6 +108,10 @@ def _declare(lib):
     lib.nfa_rowsum_f32.argtypes = [vp, vp, i64, i64, vp]
     lib.nfa_standard_normal_log_prob_f32.restype = ctypes.c_int
     lib.nfa_standard_normal_log_prob_f32.argtypes = [vp, vp, vp, i64, i64, vp]
+    lib.nfa_profile_enable.restype = ctypes.c_int
+    lib.nfa_profile_enable.argtypes = [i32]
+    lib.nfa_profile_collect.restype = ctypes.c_int
+    lib.nfa_profile_collect.argtypes = [ctypes.POINTER(ctypes.c_float), i32, ctypes.POINTER(i32)]
 
 
 def load():

@@ -25,8 +25,12 @@
 
 #include "rqs_math.hpp"
 
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdlib.h>
+
+#include <mutex>
+#include <vector>
 
 #ifndef NFA_K1_BLOCK_DEFAULT
 #define NFA_K1_BLOCK_DEFAULT 256
@@ -321,7 +325,7 @@ __global__ void __launch_bounds__(kBlock, NFA_PIPE_WAVES) rqs_coupling_pipelined
                 float* dst = a.lad + row0 + (tid >> __builtin_ctz(dt));
                 *dst = a.accumulate ? *dst + l : l;
             }
-        } else {
+        } else if (has_item) {
             s_lad[tid] = l;
         }
         lds_barrier();
@@ -411,12 +415,44 @@ __global__ void __launch_bounds__(kBlock) rqs_elementwise_kernel(const Elementwi
 // ------------------------------------------------------------------------------------------
 constexpr int kMaxDynLds = 64 * 1024;
 
+// ---- optional measurement aid (bench.py): per-launch begin/end timestamps of the K1 kernels.
+// hipExtLaunchKernelGGL attaches a start and a stop event to the dispatch itself, so
+// hipEventElapsedTime(start, stop) is the kernel's own duration on its stream (what rocprofv3's
+// kernel trace reports), free of launch gaps.  Off by default; the only global state in the library.
+struct ProfileState {
+    std::mutex mu;
+    bool enabled = false;
+    size_t capacity = 0;
+    std::vector<hipEvent_t> start, stop;
+};
+static ProfileState g_profile;
+
+template <typename Kernel>
+static void launch_k1(Kernel kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, const CouplingArgs& a) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_profile.mu);
+        if (g_profile.enabled && g_profile.start.size() < g_profile.capacity) {
+            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                g_profile.start.push_back(e0);
+                g_profile.stop.push_back(e1);
+            } else {
+                e0 = e1 = nullptr;
+            }
+        }
+    }
+    if (e0)
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, st, e0, e1, 0, a);
+    else
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, a);
+}
+
 template <int KT, int BLOCK>
 static int launch_coupling(const CouplingArgs& a, int inverse, dim3 grid, size_t lds, hipStream_t st) {
     if (inverse)
-        hipLaunchKernelGGL((rqs_coupling_kernel<KT, true, BLOCK>), grid, dim3(BLOCK), lds, st, a);
+        launch_k1(rqs_coupling_kernel<KT, true, BLOCK>, grid, dim3(BLOCK), lds, st, a);
     else
-        hipLaunchKernelGGL((rqs_coupling_kernel<KT, false, BLOCK>), grid, dim3(BLOCK), lds, st, a);
+        launch_k1(rqs_coupling_kernel<KT, false, BLOCK>, grid, dim3(BLOCK), lds, st, a);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
 }
@@ -425,14 +461,14 @@ template <int KT, int NV>
 static int launch_pipelined(const CouplingArgs& a, int inverse, dim3 grid, size_t lds, hipStream_t st) {
     if (a.sp.linear) {
         if (inverse)
-            hipLaunchKernelGGL((rqs_coupling_pipelined<KT, true, true, NV>), grid, dim3(kBlock), lds, st, a);
+            launch_k1(rqs_coupling_pipelined<KT, true, true, NV>, grid, dim3(kBlock), lds, st, a);
         else
-            hipLaunchKernelGGL((rqs_coupling_pipelined<KT, false, true, NV>), grid, dim3(kBlock), lds, st, a);
+            launch_k1(rqs_coupling_pipelined<KT, false, true, NV>, grid, dim3(kBlock), lds, st, a);
     } else {
         if (inverse)
-            hipLaunchKernelGGL((rqs_coupling_pipelined<KT, true, false, NV>), grid, dim3(kBlock), lds, st, a);
+            launch_k1(rqs_coupling_pipelined<KT, true, false, NV>, grid, dim3(kBlock), lds, st, a);
         else
-            hipLaunchKernelGGL((rqs_coupling_pipelined<KT, false, false, NV>), grid, dim3(kBlock), lds, st, a);
+            launch_k1(rqs_coupling_pipelined<KT, false, false, NV>, grid, dim3(kBlock), lds, st, a);
     }
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
@@ -643,4 +679,31 @@ extern "C" int nfa_rqs_elementwise_f32(const float* inputs, const float* uw, int
         case 8: return launch_elementwise<8>(a, inverse, grid, lds, st);
         default: return launch_elementwise<0>(a, inverse, grid, lds, st);
     }
+}
+
+
+extern "C" int nfa_profile_enable(int32_t max_launches) {
+    if (max_launches < 0) return NFA_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(g_profile.mu);
+    g_profile.enabled = max_launches > 0;
+    g_profile.capacity = (size_t)max_launches;
+    return NFA_OK;
+}
+
+extern "C" int nfa_profile_collect(float* durations_ms, int32_t capacity, int32_t* count) {
+    if (!count || capacity < 0 || (capacity > 0 && !durations_ms)) return NFA_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(g_profile.mu);
+    int32_t n = 0;
+    for (size_t i = 0; i < g_profile.start.size(); ++i) {
+        NFA_HIP_CHECK(hipEventSynchronize(g_profile.stop[i]));
+        float ms = 0.0f;
+        NFA_HIP_CHECK(hipEventElapsedTime(&ms, g_profile.start[i], g_profile.stop[i]));
+        if (n < capacity) durations_ms[n++] = ms;
+        hipEventDestroy(g_profile.start[i]);
+        hipEventDestroy(g_profile.stop[i]);
+    }
+    g_profile.start.clear();
+    g_profile.stop.clear();
+    *count = n;
+    return NFA_OK;
 }

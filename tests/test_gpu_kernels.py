@@ -189,13 +189,16 @@ def test_coupling_layers_golden(ops, golden_dir):
     (300, 64, 10, "linear"), (257, 9, 5, "linear"), (129, 33, 3, None), (64, 2, 8, "linear"),
     (50, 700, 8, "linear"), (3, 1500, 4, "linear"), (4, 3000, 8, "linear"), (5, 784, 8, "linear"),
     (2, 5000, 10, None),
+    # shapes that take the software-pipelined kernel with other tile geometries
+    (1000, 48, 8, "linear"), (777, 32, 8, "linear"), (300, 128, 8, "linear"), (2049, 16, 8, "linear"),
+    (65, 8, 8, "linear"), (999, 64, 8, None),
 ])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_rqs_coupling_oracle(ops, B, D, K, tails, inverse):
     rng = np.random.RandomState(B + D + K)
     mask = rng.rand(D) < 0.5
-    if D == 64:
-        mask = np.arange(D) % 2 == 0
+    if D in (8, 16, 32, 48, 64, 128):
+        mask = np.arange(D) % 2 == 0  # half/half masks: aligned layouts (pipelined kernel)
     mask[0] = True
     tidx = np.nonzero(mask)[0].astype(np.int64)
     dt = tidx.size

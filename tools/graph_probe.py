@@ -11,6 +11,9 @@ def timed(fn, reps):
     torch.cuda.synchronize(); return (time.perf_counter()-t0)/reps*1e3
 for name, flow, B, D in [("affine x8 D=32 B=16384", configs.affine_coupling_flow(8,32,(128,128)), 16384, 32),
                          ("RQ-NSF x32 B=65536", configs.rq_nsf_flow(32,64,8,128), 65536, 64),
+                         ("RQ-NSF x32 B=32768", configs.rq_nsf_flow(32,64,8,128), 32768, 64),
+                         ("RQ-NSF x32 B=16384", configs.rq_nsf_flow(32,64,8,128), 16384, 64),
+                         ("RQ-NSF x32 B=8192", configs.rq_nsf_flow(32,64,8,128), 8192, 64),
                          ("RQ-NSF x32 B=4096", configs.rq_nsf_flow(32,64,8,128), 4096, 64)]:
     flow=flow.to(dev).eval(); x=torch.randn(B,D,device=dev)
     with torch.no_grad():
