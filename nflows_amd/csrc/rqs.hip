@@ -198,8 +198,12 @@ typedef float vec4 __attribute__((ext_vector_type(4)));  // native 16-byte vecto
 #ifndef NFA_PIPE_WAVES
 #define NFA_PIPE_WAVES 4
 #endif
-template <int KT, bool INVERSE, bool LINEAR, int NV>
+template <int KT, bool INVERSE, bool LINEAR>
 __global__ void __launch_bounds__(kBlock, NFA_PIPE_WAVES) rqs_coupling_pipelined(const CouplingArgs a) {
+    // float4 per lane per tile: enough for 256 splines of 3K+1 logits (lanes past the tile's end
+    // re-read its last vector)
+    constexpr int NV = (3 * KT + 1 + 3) / 4;
+    static_assert(NV <= 8, "add prefetch registers");
     // Preconditions (checked by the host): every tile is full (a.batch % a.R == 0 here; the host
     // sends leftover rows to the generic kernel), R*dt <= 256 (one spline per lane),
     // R*D <= 512 (<= 2 pass-through slots per lane, <= 128 float4 of inputs per tile),
@@ -277,7 +281,7 @@ __global__ void __launch_bounds__(kBlock, NFA_PIPE_WAVES) rqs_coupling_pipelined
     const int64_t tile_stride_p = (int64_t)nitems * P;  // floats
     const int tile_stride_x = R * D;
 
-    vec4 pr0, pr1, pr2, pr3, pr4, pr5;
+    vec4 pr0, pr1, pr2, pr3, pr4, pr5, pr6, pr7;
     vec4 xr;
 #define NFA_LD(k)                                                              \
     if (NV > k) {                                                              \
@@ -296,7 +300,7 @@ __global__ void __launch_bounds__(kBlock, NFA_PIPE_WAVES) rqs_coupling_pipelined
         const int64_t t_ = (TILE) < num_tiles ? (TILE) : 0;                                     \
         const vec4* gp_ = reinterpret_cast<const vec4*>(a.params + t_ * tile_stride_p);     \
         const vec4* gx_ = reinterpret_cast<const vec4*>(a.x + t_ * tile_stride_x);          \
-        NFA_LD(0) NFA_LD(1) NFA_LD(2) NFA_LD(3) NFA_LD(4) NFA_LD(5)                             \
+        NFA_LD(0) NFA_LD(1) NFA_LD(2) NFA_LD(3) NFA_LD(4) NFA_LD(5) NFA_LD(6) NFA_LD(7)         \
         xr = gx_[tid < nvx ? tid : nvx - 1];                                                    \
     }
 
@@ -304,7 +308,7 @@ __global__ void __launch_bounds__(kBlock, NFA_PIPE_WAVES) rqs_coupling_pipelined
     int64_t tile = blockIdx.x;
     NFA_ISSUE_TILE(tile)
     for (; tile < num_tiles; tile += gridDim.x) {
-        NFA_ST(0) NFA_ST(1) NFA_ST(2) NFA_ST(3) NFA_ST(4) NFA_ST(5)
+        NFA_ST(0) NFA_ST(1) NFA_ST(2) NFA_ST(3) NFA_ST(4) NFA_ST(5) NFA_ST(6) NFA_ST(7)
         if (tid < nvx) reinterpret_cast<vec4*>(s_x)[tid] = xr;
         const int64_t next = tile + gridDim.x;
         NFA_ISSUE_TILE(next)  // in flight until the next iteration's LDS writes
@@ -457,18 +461,18 @@ static int launch_coupling(const CouplingArgs& a, int inverse, dim3 grid, size_t
     return NFA_OK;
 }
 
-template <int KT, int NV>
+template <int KT>
 static int launch_pipelined(const CouplingArgs& a, int inverse, dim3 grid, size_t lds, hipStream_t st) {
     if (a.sp.linear) {
         if (inverse)
-            launch_k1(rqs_coupling_pipelined<KT, true, true, NV>, grid, dim3(kBlock), lds, st, a);
+            launch_k1(rqs_coupling_pipelined<KT, true, true>, grid, dim3(kBlock), lds, st, a);
         else
-            launch_k1(rqs_coupling_pipelined<KT, false, true, NV>, grid, dim3(kBlock), lds, st, a);
+            launch_k1(rqs_coupling_pipelined<KT, false, true>, grid, dim3(kBlock), lds, st, a);
     } else {
         if (inverse)
-            launch_k1(rqs_coupling_pipelined<KT, true, false, NV>, grid, dim3(kBlock), lds, st, a);
+            launch_k1(rqs_coupling_pipelined<KT, true, false>, grid, dim3(kBlock), lds, st, a);
         else
-            launch_k1(rqs_coupling_pipelined<KT, false, false, NV>, grid, dim3(kBlock), lds, st, a);
+            launch_k1(rqs_coupling_pipelined<KT, false, false>, grid, dim3(kBlock), lds, st, a);
     }
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
@@ -586,22 +590,22 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
                          (reinterpret_cast<uintptr_t>(params) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(inputs) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(outputs) & 15) == 0;
-    if (use_pipe && BT == kBlock && aligned && nv <= 6 && a.sp.K == 8) {
+    const bool pipe_k = a.sp.K == 4 || a.sp.K == 8 || a.sp.K == 10;
+    if (use_pipe && BT == kBlock && aligned && pipe_k && nv <= (3 * a.sp.K + 4) / 4) {
         const int64_t full_rows = (batch / R) * R;
         CouplingArgs f = a;
         f.batch = full_rows;
         // one block fewer per CU than LDS alone would allow: the prefetch registers cost occupancy
-        int64_t gp = (int64_t)cus * (per_cu > NFA_PIPE_WAVES ? NFA_PIPE_WAVES : per_cu);
+        // (K = 4 needs only ~76 VGPRs: 6 waves per SIMD)
+        const int pipe_blocks = a.sp.K <= 4 ? 6 : NFA_PIPE_WAVES;
+        int64_t gp = (int64_t)cus * (per_cu > pipe_blocks ? pipe_blocks : per_cu);
         if (gp > full_rows / R) gp = full_rows / R;
         const dim3 pgrid((unsigned)gp);
         int prc;
-        switch (nv) {
-            case 6: prc = launch_pipelined<8, 6>(f, inverse, pgrid, lds, st); break;
-            case 5: prc = launch_pipelined<8, 5>(f, inverse, pgrid, lds, st); break;
-            case 4: prc = launch_pipelined<8, 4>(f, inverse, pgrid, lds, st); break;
-            case 3: prc = launch_pipelined<8, 3>(f, inverse, pgrid, lds, st); break;
-            case 2: prc = launch_pipelined<8, 2>(f, inverse, pgrid, lds, st); break;
-            default: prc = launch_pipelined<8, 1>(f, inverse, pgrid, lds, st); break;
+        switch (a.sp.K) {
+            case 4: prc = launch_pipelined<4>(f, inverse, pgrid, lds, st); break;
+            case 10: prc = launch_pipelined<10>(f, inverse, pgrid, lds, st); break;
+            default: prc = launch_pipelined<8>(f, inverse, pgrid, lds, st); break;
         }
         if (prc != NFA_OK || full_rows == batch) return prc;
         // leftover rows (< R): generic kernel on the tail of every array
@@ -610,7 +614,11 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
         a.out = outputs + full_rows * D;
         a.lad = logabsdet + full_rows;
         a.batch = batch - full_rows;
-        return launch_coupling<8, kBlock>(a, inverse, dim3(1), lds, st);
+        switch (a.sp.K) {
+            case 4: return launch_coupling<4, kBlock>(a, inverse, dim3(1), lds, st);
+            case 10: return launch_coupling<10, kBlock>(a, inverse, dim3(1), lds, st);
+            default: return launch_coupling<8, kBlock>(a, inverse, dim3(1), lds, st);
+        }
     }
     if (BT == 64) {
         switch (a.sp.K) {
@@ -619,7 +627,9 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
         }
     }
     switch (a.sp.K) {
+        case 4: return launch_coupling<4, kBlock>(a, inverse, grid, lds, st);
         case 8: return launch_coupling<8, kBlock>(a, inverse, grid, lds, st);
+        case 10: return launch_coupling<10, kBlock>(a, inverse, grid, lds, st);
         default: return launch_coupling<0, kBlock>(a, inverse, grid, lds, st);
     }
 }
