@@ -32,9 +32,6 @@
 #include <mutex>
 #include <vector>
 
-#ifndef NFA_K1_BLOCK_DEFAULT
-#define NFA_K1_BLOCK_DEFAULT 256
-#endif
 
 namespace nfa {
 
@@ -511,11 +508,7 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
     if (features > 65535) return NFA_ERR_UNSUPPORTED;
 
     const int P = a.sp.P, D = features, dt = num_transform;
-    static const int block_threads = [] {
-        const char* e = getenv("NFA_K1_BLOCK");
-        return e ? atoi(e) : NFA_K1_BLOCK_DEFAULT;
-    }();
-    const int BT = block_threads == 64 ? 64 : kBlock;
+    const int BT = kBlock;
     // samples per tile: aim at one item per lane, whole samples, LDS within budget
     int R = dt > 0 ? BT / dt : BT / (D < BT ? D : BT);
     if (R < 1) R = 1;
@@ -572,7 +565,7 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
     const int64_t tiles = (batch + R - 1) / R;
     const int cus = device_cu_count();
     int per_cu = (int)((size_t)(160 * 1024) / (lds + 256));
-    const int cap = BT == 64 ? 24 : 8;
+    const int cap = 8;
     if (per_cu > cap) per_cu = cap;
     if (per_cu < 1) per_cu = 1;
     int64_t g = (int64_t)cus * per_cu;
@@ -591,7 +584,7 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
                          (reinterpret_cast<uintptr_t>(inputs) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(outputs) & 15) == 0;
     const bool pipe_k = a.sp.K == 4 || a.sp.K == 8 || a.sp.K == 10;
-    if (use_pipe && BT == kBlock && aligned && pipe_k && nv <= (3 * a.sp.K + 4) / 4) {
+    if (use_pipe && aligned && pipe_k && nv <= (3 * a.sp.K + 4) / 4) {
         const int64_t full_rows = (batch / R) * R;
         CouplingArgs f = a;
         f.batch = full_rows;
@@ -618,12 +611,6 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
             case 4: return launch_coupling<4, kBlock>(a, inverse, dim3(1), lds, st);
             case 10: return launch_coupling<10, kBlock>(a, inverse, dim3(1), lds, st);
             default: return launch_coupling<8, kBlock>(a, inverse, dim3(1), lds, st);
-        }
-    }
-    if (BT == 64) {
-        switch (a.sp.K) {
-            case 8: return launch_coupling<8, 64>(a, inverse, grid, lds, st);
-            default: return launch_coupling<0, 64>(a, inverse, grid, lds, st);
         }
     }
     switch (a.sp.K) {

@@ -245,3 +245,42 @@ def test_columnwise_autoregressive_inverse_equals_reference_loop(golden):
         assert (lad - ladr).abs().max().item() <= 2e-5 * d
         check(xs, golden[name + "/inv_x"], golden[name + "/inv_x64"], name + " inv_x", 3e-6)
         check(lad, golden[name + "/inv_lad"], golden[name + "/inv_lad64"], name + " inv_lad", 3e-6 * d)
+
+
+def test_conditional_flow_with_context():
+    """Context flows to the conditioner (resnet.py:92-100 concatenation + GLU gate) and through
+    Flow._sample's merge/split of leading dims (flows/base.py:62-73), reference
+    tests/flows/base_test.py:13-69 shapes."""
+    from nflows_amd.distributions import StandardNormal
+    from nflows_amd.flows import Flow
+    from nflows_amd.nn.nets import ResidualNet
+    from nflows_amd.transforms import (CompositeTransform, PiecewiseRationalQuadraticCouplingTransform,
+                                       RandomPermutation)
+    from nflows_amd.utils import create_alternating_binary_mask
+    torch.manual_seed(3)
+    D, C = 6, 4
+    layers = []
+    for i in range(3):
+        layers.append(RandomPermutation(D))
+        layers.append(PiecewiseRationalQuadraticCouplingTransform(
+            create_alternating_binary_mask(D, even=(i % 2 == 0)),
+            lambda i_, o_: ResidualNet(i_, o_, hidden_features=32, context_features=8),
+            num_bins=8, tails="linear", tail_bound=3.0))
+    flow = Flow(CompositeTransform(layers), StandardNormal([D]), embedding_net=torch.nn.Linear(C, 8)).to(DEV).eval()
+    x = torch.randn(50, D, device=DEV)
+    ctx = torch.randn(50, C, device=DEV)
+    with torch.no_grad():
+        lp = flow.log_prob(x, context=ctx)
+        assert lp.shape == (50,) and torch.isfinite(lp).all()
+        lp_other = flow.log_prob(x, context=ctx.roll(1, 0))
+        assert (lp - lp_other).abs().max().item() > 1e-4  # the context matters
+        s = flow.sample(7, context=ctx[:5])
+        assert s.shape == (5, 7, D)
+        s2, lp2 = flow.sample_and_log_prob(7, context=ctx[:5])
+        assert s2.shape == (5, 7, D) and lp2.shape == (5, 7)
+        again = flow.log_prob(s2.reshape(35, D), context=ctx[:5].repeat_interleave(7, 0)).reshape(5, 7)
+        assert (again - lp2).abs().max().item() < 1e-3
+        noise = flow.transform_to_noise(x, context=ctx)
+        assert noise.shape == x.shape
+    with pytest.raises(ValueError):
+        flow.log_prob(x, context=ctx[:10])
