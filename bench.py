@@ -128,6 +128,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=16384)
     ap.add_argument("--no-fuse", action="store_true", help="run permutations as separate kernels")
+    ap.add_argument("--no-fuse-linear", action="store_true",
+                    help="leave the conditioner's final Linear to hipBLASLt (GEMM + K1 instead of K7)")
+    ap.add_argument("--skip-k1-roofline", action="store_true")
     ap.add_argument("--bracket-events", action="store_true",
                     help="additionally bracket every K1 launch with torch events (includes launch gaps)")
     ap.add_argument("--skip-consistency", action="store_true",
@@ -159,6 +162,9 @@ def main():
     import copy
     flow = copy.deepcopy(flow_cpu).to(dev)
     flow._transform.fuse_permutations = not args.no_fuse
+    if args.no_fuse_linear:
+        from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform
+        PiecewiseRationalQuadraticCouplingTransform.fuse_final_linear = False
     B = args.batch_per_gpu
     x = torch.randn(B, D, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
 
@@ -215,27 +221,70 @@ def main():
 
     if rank == 0:
         total_rows = B * world
+        from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+        fused_linear = bool(RQ.fuse_final_linear) and not args.no_fuse_linear
+        H_ = 128
+        P_ = 3 * K - 1
+        k1_bytes = 4 * (B * D + B * (D // 2) * P_ + B * D + B)  # 3460 B/sample/layer
+
+        def load_traffic(name):
+            try:
+                return json.load(open(os.path.join(ROOT, "profiles", name))).get("hbm_bytes_per_launch")
+            except Exception:
+                return None
+
         roofline = None
-        if k1_ms:
+        timing_note = ("HIP start/stop events attached to each layer-kernel dispatch on its launch "
+                       "stream (hipExtLaunchKernelGGL), all launches of the timed region")
+        if k1_ms and fused_linear:
+            # dominant kernel = K7: final Linear (fp32 MFMA) + spline layer in one launch.
+            # Bound: fp32 matrix/vector peak (on gfx950 the f32 MFMA runs at the VALU rate).
             avg_ms, launches = sum(k1_ms) / len(k1_ms), len(k1_ms)
-            nbytes = 4 * (B * D + B * (D // 2) * (3 * K - 1) + B * D + B)  # 3460 B/sample
-            achieved = nbytes / (avg_ms * 1e-3) / 1e9
-            bracket = hook.summary()
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "k1_pmc_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": "nfa::rqs_coupling_pipelined<8, false, true, 6>",
+            flops = 2.0 * B * H_ * (D // 2) * P_  # the Linear's FLOPs (padding columns not counted)
+            achieved = flops / (avg_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "nfa::rqs_fused_linear_kernel<false>",
+                        "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
+                        "traffic": load_traffic("k7_pmc_traffic.json"),
+                        "algorithmic_flops_per_launch": flops,
+                        "algorithmic_bytes_per_launch": 4 * (B * D + B * H_ + B * D + B),
+                        "avg_launch_ms": avg_ms, "launches_timed": launches, "timing": timing_note,
+                        "note": "157.3 TFLOP/s is the 2.4 GHz spec peak; a pure chain of "
+                                "v_mfma_f32_32x32x2_f32 sustains 121 TFLOP/s on this chip (DVFS, "
+                                "tools/mfma_probe.hip)"}
+        elif k1_ms:
+            avg_ms, launches = sum(k1_ms) / len(k1_ms), len(k1_ms)
+            achieved = k1_bytes / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "nfa::rqs_coupling_pipelined<8, false, true>",
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                        "algorithmic_bytes_per_launch": nbytes,
-                        "avg_launch_ms": avg_ms, "launches_timed": launches,
-                        "timing": "HIP start/stop events attached to each K1 dispatch on its launch "
-                                  "stream (hipExtLaunchKernelGGL), all launches of the timed region",
-                        "bracketing_events_avg_ms": None if bracket is None else bracket[0]}
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic("k1_pmc_traffic.json"),
+                        "algorithmic_bytes_per_launch": k1_bytes,
+                        "avg_launch_ms": avg_ms, "launches_timed": launches, "timing": timing_note}
+        roofline_k1 = None
+        if fused_linear and not args.skip_k1_roofline:
+            # the HBM-bound spline kernel K1 (what K7 replaces on this shape), measured the same way
+            # in a short separate run with the Linear left to hipBLASLt
+            RQ.fuse_final_linear = False
+            try:
+                with torch.no_grad():
+                    flow.log_prob(x)
+                    torch.cuda.synchronize()
+                    _native.check(_native.load().nfa_profile_enable(args.layers * 3))
+                    for _ in range(3):
+                        flow.log_prob(x)
+                    torch.cuda.synchronize()
+                    ms = dispatch_durations_ms(args.layers * 3)
+                    _native.check(_native.load().nfa_profile_enable(0))
+            finally:
+                RQ.fuse_final_linear = True
+            if ms:
+                a_ms = sum(ms) / len(ms)
+                ach = k1_bytes / (a_ms * 1e-3) / 1e9
+                roofline_k1 = {"bound": "hbm", "kernel": "nfa::rqs_coupling_pipelined<8, false, true>",
+                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": load_traffic("k1_pmc_traffic.json"),
+                               "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_ms": a_ms,
+                               "launches_timed": len(ms),
+                               "note": "not in the timed region: GEMM + K1 path (fuse_final_linear=False)"}
         result = {
             "metric": "log_prob samples/sec (dim=64, K=8, 32-layer RQ-NSF) + max |fwd∘inv − x|",
             "value": total_rows * args.steps / elapsed,
@@ -254,11 +303,13 @@ def main():
                                    "batch=%d per GPU, Flow.log_prob + scalar all-reduce" % (args.layers, B),
                        "global_batch": total_rows, "features": D, "num_bins": K, "layers": args.layers,
                        "parallelism": "sample-sharded x%d" % world,
-                       "fused_permutations": not args.no_fuse},
+                       "fused_permutations": not args.no_fuse,
+                       "final_linear_fused_into_spline_kernel": not args.no_fuse_linear},
             "fwd_inv_max_err": {"composite_%d_layers" % args.layers: err_composite, "single_layer": err_layer,
                                 "rows": 8192},
             "mean_log_likelihood": mean_ll,
             "roofline": roofline,
+            "roofline_k1_unfused": roofline_k1,
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(flow_cpu, D, args.cpu_rows)

@@ -137,6 +137,29 @@ int nfa_rqs_coupling_backward_f32(const float *inputs, const float *params,
                                   const nfa_rqs_spec *spec, int32_t flags, void *stream);
 
 /*
+ * K7.  K1 with the conditioner's output layer folded in: params = hidden @ W^T + b is computed
+ * tile by tile with fp32 MFMA inside the kernel and consumed from LDS, so the [batch, d_t*P]
+ * parameter tensor never goes through HBM (ResidualNet.final_layer, nn/nets/resnet.py:90, :99,
+ * followed by everything nfa_rqs_coupling_f32 replaces).
+ *   hidden        [batch, hidden_features]  input of the final Linear
+ *   weight_packed the Linear's weight [d_t*P, hidden_features], each feature's 23 rows padded
+ *                 to 24 (zero row) and re-tiled for the MFMA B operand:
+ *                 [d_t*24/32 tiles][16][64 lanes][4], lane l element (j4, q) =
+ *                 Wpad[tile*32 + (l & 31)][(l >> 5)*64 + j4*4 + q]
+ *   bias_padded   [d_t*24]
+ * Supported here: num_bins = 8, linear tails, hidden_features = 128, d_t % 4 == 0, d_t <= 64,
+ * features <= 128, batch % 32 == 0; anything else returns NFA_ERR_UNSUPPORTED (callers then run
+ * the GEMM and nfa_rqs_coupling_f32).
+ */
+int nfa_rqs_coupling_fused_linear_f32(const float *inputs, const float *hidden,
+                                      const float *weight_packed, const float *bias_padded,
+                                      const int64_t *transform_idx, const int64_t *in_perm,
+                                      const int64_t *out_scatter, float *outputs, float *logabsdet,
+                                      int32_t *status, int64_t batch, int32_t features,
+                                      int32_t num_transform, int32_t hidden_features,
+                                      const nfa_rqs_spec *spec, int32_t flags, void *stream);
+
+/*
  * K5.  Elementwise rational-quadratic functional (no row-sum):
  *   unconstrained_rational_quadratic_spline / rational_quadratic_spline,
  *   splines/rational_quadratic.py:13-63 / :66-181, as called from

@@ -13,6 +13,8 @@ constexpr int kWave = 64;
 
 int set_hip_error(hipError_t e);  // records e (thread-local) and returns NFA_ERR_HIP
 int device_cu_count();            // multiProcessorCount of the current device (cached)
+// measurement aid (nfa_profile_*): event pair for the next layer-kernel launch, or nulls
+void profile_next_launch(hipEvent_t* start, hipEvent_t* stop);
 
 #define NFA_HIP_CHECK(expr)                                   \
     do {                                                      \

@@ -428,20 +428,26 @@ struct ProfileState {
 };
 static ProfileState g_profile;
 
+// Hands out a start/stop event pair for the next profiled launch (null when profiling is off or
+// the budget is used up).  Shared with the other translation units through common.hpp.
+void profile_next_launch(hipEvent_t* start, hipEvent_t* stop) {
+    *start = *stop = nullptr;
+    std::lock_guard<std::mutex> lock(g_profile.mu);
+    if (g_profile.enabled && g_profile.start.size() < g_profile.capacity) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            g_profile.start.push_back(e0);
+            g_profile.stop.push_back(e1);
+            *start = e0;
+            *stop = e1;
+        }
+    }
+}
+
 template <typename Kernel>
 static void launch_k1(Kernel kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, const CouplingArgs& a) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(g_profile.mu);
-        if (g_profile.enabled && g_profile.start.size() < g_profile.capacity) {
-            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-                g_profile.start.push_back(e0);
-                g_profile.stop.push_back(e1);
-            } else {
-                e0 = e1 = nullptr;
-            }
-        }
-    }
+    profile_next_launch(&e0, &e1);
     if (e0)
         hipExtLaunchKernelGGL(kernel, grid, block, lds, st, e0, e1, 0, a);
     else

@@ -1,0 +1,274 @@
+// K7: conditioner output layer + spline coupling layer in ONE kernel (SURVEY.md section 8f, row f3:
+// "consume the final Linear's tiles from LDS instead of a [B, d_t*P] round trip through HBM").
+//
+//   params = hidden @ W^T + b            Linear(H -> d_t*P), nn/nets/resnet.py:90, :99
+//   outputs, logabsdet = RQ coupling     coupling.py:73-130, :549-582 (exactly K1's arithmetic)
+//
+// The [B, d_t*P] parameter tensor (193 MB per layer at the BASELINE shape, written by the GEMM
+// and read back by K1) never exists: a wave owns 32 samples, keeps their 128 hidden activations
+// in 64 VGPRs as the A operand of v_mfma_f32_32x32x2_f32, streams the weights (pre-packed so that
+// every load is a coalesced 16 bytes per lane; 376 KB, L2-resident) as the B operand, and drops
+// each 32x32 accumulator tile (+ bias) into its private LDS slice.  After three tiles (96 columns
+// = 4 features x 24: the packing pads each feature's 23 logits to 24) the wave evaluates those
+// 4 x 32 splines from LDS and accumulates their log-derivatives.  The f32 MFMA is an exact fp32 FMA
+// chain, so the parameters equal a plain fp32 GEMM up to summation order.
+//
+// Restrictions of this fast path (the host falls back to GEMM + K1 otherwise): K = 8 bins,
+// linear tails (P = 23), hidden width 128, d_t a multiple of 4, batch a multiple of 32 handled
+// here (leftover rows go through the unfused path).
+
+#include "rqs_math.hpp"
+
+#include <hip/hip_ext.h>
+#include <stdlib.h>
+
+#ifndef NFA_K7_STAGGER
+#define NFA_K7_STAGGER 1  // x 8128 cycles
+#endif
+
+namespace nfa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float vec4f __attribute__((ext_vector_type(4)));
+
+constexpr int kH = 128;        // hidden width (GEMM K dimension)
+constexpr int kPP = 24;        // padded logits per feature
+constexpr int kGroupCols = 96; // 3 MFMA tiles = 4 features
+constexpr int kParStride = 97; // LDS row stride of the parameter tile (odd: conflict-free column reads)
+
+struct FusedArgs {
+    const float* x;       // [B, D]
+    const float* hidden;  // [B, 128]
+    const float* wpacked; // [(dt*24/32) tiles][16][64][4]
+    const float* bpad;    // [dt*24]
+    const int64_t* tidx;
+    const int64_t* perm;
+    const int64_t* scatter;
+    float* out;
+    float* lad;
+    int32_t* status;
+    int64_t batch;  // multiple of 32
+    int D, dt, accumulate;
+    RqsDev sp;
+    unsigned long long* trace;  // debug: per-phase timestamps of a few waves (null normally)
+};
+
+template <bool INVERSE>
+__global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_kernel(const FusedArgs a) {
+    __shared__ float s_par_all[(kBlock / kWave) * 32 * kParStride];
+    __shared__ int s_src[128], s_dst[128], s_tsrc[64], s_tdst[64];
+    __shared__ unsigned char s_ist[128];  // 1: column is transformed (written by the spline lanes)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = a.D, dt = a.dt;
+    int my_status = 0;
+    for (int c = tid; c < D; c += kBlock) {
+        int src = c, dst = c;
+        if (a.perm) {
+            const int64_t p = a.perm[c];
+            if (p < 0 || p >= D) my_status |= NFA_STATUS_BAD_INDEX;
+            src = (int)(p < 0 ? 0 : (p >= D ? D - 1 : p));
+        }
+        if (a.scatter) {
+            const int64_t p = a.scatter[c];
+            if (p < 0 || p >= D) my_status |= NFA_STATUS_BAD_INDEX;
+            dst = (int)(p < 0 ? 0 : (p >= D ? D - 1 : p));
+        }
+        s_src[c] = src;
+        s_dst[c] = dst;
+        s_ist[c] = 0;
+    }
+    __syncthreads();
+    if (tid < dt) {
+        const int64_t t = a.tidx[tid];
+        if (t < 0 || t >= D) my_status |= NFA_STATUS_BAD_INDEX;
+        const int col = (int)(t < 0 ? 0 : (t >= D ? D - 1 : t));
+        s_tsrc[tid] = s_src[col];
+        s_tdst[tid] = s_dst[col];
+        s_ist[col] = 1;
+    }
+    __syncthreads();
+
+    // Two waves share each SIMD, hence its one matrix pipe and its VALU issue.  Started together
+    // they stay in lockstep (both in the MFMA phase, then both in the spline phase: no overlap);
+    // delaying the wave in the odd hardware slot by about half an MFMA phase keeps one of them in
+    // the VALU-only spline phase while the other owns the matrix pipe.
+#ifdef NFA_K7_STAGGER_SLEEP
+    // experiment: offset the two workgroups that share a CU (second dispatch round) by a fraction
+    // of a tile so that their non-MFMA sections do not coincide
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(NFA_K7_STAGGER_SLEEP);
+#endif
+    float* s_par = s_par_all + wave * 32 * kParStride;
+    const int half = lane >> 5, r = lane & 31;
+    const int groups = dt >> 2;  // 4 features per group
+    const int64_t num_tiles = a.batch >> 5;
+    const int64_t wave_global = (int64_t)blockIdx.x * (kBlock / kWave) + wave;
+    const int64_t nwaves = (int64_t)gridDim.x * (kBlock / kWave);
+
+    // debug trace: lane 0 of wave 0 of blocks 0 and 256 stamps s_memtime at phase boundaries
+    unsigned long long* tr = nullptr;
+    int ti = 0;
+    if (a.trace && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 256))
+        tr = a.trace + (blockIdx.x ? 256 : 0);
+#define NFA_STAMP() if (tr && ti < 250) tr[ti++] = __builtin_readcyclecounter();
+    for (int64_t tile = wave_global; tile < num_tiles; tile += nwaves) {
+        const int64_t row0 = tile << 5;
+        NFA_STAMP()
+        // ---- pass-through columns of the [32, D] block, bit-exact; 8 rows in flight per lane
+        for (int c = lane; c < D; c += kWave) {
+            if (!s_ist[c]) {
+                const float* src = a.x + row0 * D + s_src[c];
+                float* dst = a.out + row0 * D + s_dst[c];
+#pragma unroll 1
+                for (int rr = 0; rr < 32; rr += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = src[(rr + i) * D];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dst[(rr + i) * D] = v[i];
+                }
+            }
+        }
+        NFA_STAMP()
+        // ---- A operand: hidden[row0 + r][half*64 .. half*64+63]
+        vec4f av[16];
+        const vec4f* hp = reinterpret_cast<const vec4f*>(a.hidden + (row0 + r) * kH + half * 64);
+#pragma unroll
+        for (int j4 = 0; j4 < 16; ++j4) av[j4] = hp[j4];
+
+        float lad_acc = 0.0f;
+        const vec4f* wbase = reinterpret_cast<const vec4f*>(a.wpacked) + lane;
+        vec4f bv[16];
+#pragma unroll
+        for (int j4 = 0; j4 < 16; ++j4) bv[j4] = wbase[j4 * 64];  // B tile 0
+
+        NFA_STAMP()
+        for (int g = 0; g < groups; ++g) {
+            // this group's spline inputs: requested now, consumed after the three MFMA tiles
+            const float xin0 = a.x[(row0 + r) * D + s_tsrc[g * 4 + half]];
+            const float xin1 = a.x[(row0 + r) * D + s_tsrc[g * 4 + half + 2]];
+#pragma unroll 1
+            for (int t = 0; t < 3; ++t) {
+                const int nt = g * 3 + t;
+                f32x16 acc = {0};
+                // next tile's weights are requested before this tile's MFMAs start
+                vec4f bn[16];
+                const int ntn = (nt + 1 < groups * 3) ? nt + 1 : 0;
+                const vec4f* wn = wbase + (size_t)ntn * 16 * 64;
+#pragma unroll
+                for (int j4 = 0; j4 < 16; ++j4) bn[j4] = wn[j4 * 64];
+#ifdef NFA_K7_PIN_PREFETCH
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifndef NFA_K7_NOMFMA
+#pragma unroll
+                for (int j4 = 0; j4 < 16; ++j4) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j4].x, bv[j4].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j4].y, bv[j4].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j4].z, bv[j4].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j4].w, bv[j4].w, acc, 0, 0, 0);
+                }
+#else
+                for (int j4 = 0; j4 < 16; ++j4) acc[j4] = av[j4].x + bv[j4].y;
+#endif
+                NFA_STAMP()
+                const float bias = a.bpad[nt * 32 + r];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int row = (q & 3) + 8 * (q >> 2) + 4 * half;  // C/D map of the 32x32 MFMA
+                    s_par[row * kParStride + t * 32 + r] = acc[q] + bias;
+                }
+#pragma unroll
+                for (int j4 = 0; j4 < 16; ++j4) bv[j4] = bn[j4];
+                NFA_STAMP()
+            }
+            // ---- 4 features x 32 samples from the LDS tile (wave-private: LDS ops of one wave
+            //      execute in order, only the data returns need waiting for)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                const int fl = half + 2 * pass;  // feature within the group
+                const int f = g * 4 + fl;
+                const float xin = pass ? xin1 : xin0;
+                float y, l;
+#ifdef NFA_K7_NOSPLINE
+                y = xin + s_par[r * kParStride + fl * kPP];
+                l = s_par[r * kParStride + fl * kPP + 8];
+#else
+                my_status |= rqs_eval<8, INVERSE, true>(xin, s_par + r * kParStride + fl * kPP, a.sp, y, l);
+#endif
+                a.out[(row0 + r) * D + s_tdst[f]] = y;
+                lad_acc += l;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            NFA_STAMP()
+        }
+        lad_acc += __shfl_xor(lad_acc, 32, kWave);
+        if (half == 0) {
+            float* dst = a.lad + row0 + r;
+            *dst = a.accumulate ? *dst + lad_acc : lad_acc;
+        }
+    }
+    if (my_status && a.status) atomicOr(a.status, my_status);
+}
+
+}  // namespace nfa
+
+using namespace nfa;
+
+static unsigned long long* g_k7_trace = nullptr;
+// debug aid (tools/k7_trace.py): device buffer of 512 uint64 receiving phase timestamps; NULL = off
+extern "C" void nfa_debug_k7_trace(void* device_buffer) { g_k7_trace = (unsigned long long*)device_buffer; }
+
+extern "C" int nfa_rqs_coupling_fused_linear_f32(const float* inputs, const float* hidden,
+                                                 const float* weight_packed, const float* bias_padded,
+                                                 const int64_t* transform_idx, const int64_t* in_perm,
+                                                 const int64_t* out_scatter, float* outputs,
+                                                 float* logabsdet, int32_t* status, int64_t batch,
+                                                 int32_t features, int32_t num_transform,
+                                                 int32_t hidden_features, const nfa_rqs_spec* spec,
+                                                 int32_t flags, void* stream) {
+    if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET)) return NFA_ERR_INVALID_ARGUMENT;
+    if (batch < 0 || features < 1 || num_transform < 1 || num_transform > features)
+        return NFA_ERR_INVALID_ARGUMENT;
+    FusedArgs a;
+    int rc = make_dev_spec(spec, &a.sp);
+    if (rc != NFA_OK) return rc;
+    if (a.sp.K != 8 || !a.sp.linear || hidden_features != kH || (num_transform & 3) != 0 ||
+        num_transform > 64 || features > 128 || (batch & 31) != 0)
+        return NFA_ERR_UNSUPPORTED;
+    if (batch == 0) return NFA_OK;
+    if (!inputs || !hidden || !weight_packed || !bias_padded || !transform_idx || !outputs || !logabsdet)
+        return NFA_ERR_INVALID_ARGUMENT;
+    a.x = inputs;
+    a.hidden = hidden;
+    a.wpacked = weight_packed;
+    a.bpad = bias_padded;
+    a.tidx = transform_idx;
+    a.perm = in_perm;
+    a.scatter = out_scatter;
+    a.out = outputs;
+    a.lad = logabsdet;
+    a.status = status;
+    a.batch = batch;
+    a.D = features;
+    a.dt = num_transform;
+    a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
+    a.trace = g_k7_trace;
+    const int64_t tiles = batch >> 5;
+    int64_t blocks = (tiles + 3) / 4;
+    const int64_t cap = (int64_t)device_cu_count() * 2;
+    if (blocks > cap) blocks = cap;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    profile_next_launch(&e0, &e1);
+    const dim3 grid((unsigned)blocks), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    if (flags & NFA_FLAG_INVERSE) {
+        if (e0) hipExtLaunchKernelGGL(rqs_fused_linear_kernel<true>, grid, block, 0, st, e0, e1, 0, a);
+        else hipLaunchKernelGGL(rqs_fused_linear_kernel<true>, grid, block, 0, st, a);
+    } else {
+        if (e0) hipExtLaunchKernelGGL(rqs_fused_linear_kernel<false>, grid, block, 0, st, e0, e1, 0, a);
+        else hipLaunchKernelGGL(rqs_fused_linear_kernel<false>, grid, block, 0, st, a);
+    }
+    NFA_HIP_CHECK(hipGetLastError());
+    return NFA_OK;
+}

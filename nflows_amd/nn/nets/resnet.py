@@ -72,9 +72,14 @@ class ResidualNet(nn.Module):
             for _ in range(num_blocks))
         self.final_layer = nn.Linear(hidden_features, out_features)
 
-    def forward(self, inputs, context=None):
+    def hidden(self, inputs, context=None):
+        """Activations in front of `final_layer` (the fused spline kernel consumes these and
+        applies `final_layer` itself)."""
         h = inputs if context is None else torch.cat((inputs, context), dim=1)
         h = self.initial_layer(h)
         for block in self.blocks:
             h = block(h, context=context)
-        return self.final_layer(h)
+        return h
+
+    def forward(self, inputs, context=None):
+        return self.final_layer(self.hidden(inputs, context))

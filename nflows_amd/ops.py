@@ -435,3 +435,44 @@ def rqs_shared(inputs, unnormalized_widths, unnormalized_heights, unnormalized_d
     N.check(rc)
     _after_spline(spec, inverse, dev)
     return y.view(inputs.shape), lad
+
+
+def pack_final_linear(weight, bias, num_transform, params_per_feature):
+    """Re-tiles a Linear(H=128 -> d_t*23) for K7's MFMA B operand (layout in include/nflows_amd.h):
+    each feature's 23 rows padded to 24, then [tiles][16][64 lanes][4]."""
+    dt, P = num_transform, params_per_feature
+    H = weight.shape[1]
+    w = weight.detach().view(dt, P, H)
+    w = torch.cat((w, w.new_zeros(dt, 24 - P, H)), dim=1).reshape(dt * 24, H)
+    b = torch.cat((bias.detach().view(dt, P), bias.new_zeros(dt, 24 - P)), dim=1).reshape(dt * 24)
+    tiles = dt * 24 // 32
+    # (tile, r, half, j4, q) -> (tile, j4, half, r, q); lane = half*32 + r
+    wp = w.view(tiles, 32, 2, 16, 4).permute(0, 3, 2, 1, 4).contiguous()
+    return wp, b.contiguous()
+
+
+def rqs_coupling_fused_linear(inputs, hidden, weight_packed, bias_padded, transform_idx, spec,
+                              inverse=False, in_perm=None, out_scatter=None, accumulate_into=None):
+    """K7 -- final Linear of the conditioner + spline coupling layer in one kernel.  Returns None
+    when the shape is outside the fast path (callers then run the GEMM and K1)."""
+    N.require_device_f32("inputs", inputs, 2)
+    N.require_device_f32("hidden", hidden, 2)
+    dev = inputs.device
+    B, D = inputs.shape
+    tidx = _idx("transform_features", transform_idx, dev)
+    perm = _idx("in_perm", in_perm, dev, D)
+    scat = _idx("out_scatter", out_scatter, dev, D)
+    x = inputs.detach().contiguous()
+    h = hidden.detach().contiguous()
+    out = torch.empty_like(x)
+    lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_rqs_coupling_fused_linear_f32(
+            N.ptr(x), N.ptr(h), N.ptr(weight_packed), N.ptr(bias_padded), N.ptr(tidx), N.ptr(perm),
+            N.ptr(scat), N.ptr(out), N.ptr(lad), N.ptr(_status_word(dev)), B, D, tidx.numel(),
+            h.shape[1], ctypes.byref(spec), flags, N.stream_handle(dev))
+    if rc == N.ERR_UNSUPPORTED:
+        return None
+    N.check(rc)
+    _after_spline(spec, inverse, dev)
+    return out, lad

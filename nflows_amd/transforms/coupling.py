@@ -93,9 +93,9 @@ class CouplingTransform(Transform):
         kernel (CompositeTransform's `total_logabsdet +=`); it is then also the returned tensor."""
         self._check_inputs(inputs)
         identity_split = inputs.index_select(1, self._identity_columns(in_perm))
-        transform_params = self.transform_net(identity_split, context)
-        outputs, logabsdet = self._fused_layer(inputs, transform_params, inverse=False, in_perm=in_perm,
-                                               accumulate_into=logabsdet_accumulator)
+        outputs, logabsdet = self._condition_and_transform(
+            inputs, identity_split, context, inverse=False, in_perm=in_perm,
+            accumulate_into=logabsdet_accumulator)
         if self.unconditional_transform is not None:
             identity_split, logabsdet_identity = self.unconditional_transform(identity_split, context)
             if logabsdet_accumulator is not None:
@@ -113,10 +113,9 @@ class CouplingTransform(Transform):
         logabsdet_identity = None
         if self.unconditional_transform is not None:
             identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
-        transform_params = self.transform_net(identity_split, context)
-        outputs, logabsdet = self._fused_layer(inputs, transform_params, inverse=True,
-                                               out_scatter=out_scatter,
-                                               accumulate_into=logabsdet_accumulator)
+        outputs, logabsdet = self._condition_and_transform(
+            inputs, identity_split, context, inverse=True, out_scatter=out_scatter,
+            accumulate_into=logabsdet_accumulator)
         if self.unconditional_transform is not None:
             if logabsdet_accumulator is not None:
                 logabsdet += logabsdet_identity
@@ -124,6 +123,14 @@ class CouplingTransform(Transform):
                 logabsdet = logabsdet + logabsdet_identity
             outputs.index_copy_(1, self._identity_columns(out_scatter), identity_split)
         return outputs, logabsdet
+
+    def _condition_and_transform(self, inputs, identity_split, context, inverse, in_perm=None,
+                                 out_scatter=None, accumulate_into=None):
+        """Conditioner call + fused layer kernel.  Subclasses may replace the pair by a kernel
+        that also contains the conditioner's last layer."""
+        transform_params = self.transform_net(identity_split, context)
+        return self._fused_layer(inputs, transform_params, inverse, in_perm=in_perm,
+                                 out_scatter=out_scatter, accumulate_into=accumulate_into)
 
     def _transform_dim_multiplier(self):
         """Number of conditioner outputs per transformed feature."""
@@ -233,6 +240,58 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
                                  min_bin_width=self.min_bin_width,
                                  min_bin_height=self.min_bin_height,
                                  min_derivative=self.min_derivative, wh_divisor=divisor)
+
+    # K7: fold the conditioner's final Linear into the spline kernel (no [B, d_t*P] round trip
+    # through HBM).  Class-level switch for A/B measurements.
+    fuse_final_linear = True
+
+    def _packed_final_linear(self, layer):
+        key = (layer.weight.data_ptr(), layer.weight._version, layer.bias.data_ptr(), layer.bias._version)
+        cached = getattr(self, "_packed_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, ops.pack_final_linear(layer.weight, layer.bias, self.num_transform_features,
+                                                 self._transform_dim_multiplier()))
+            self._packed_cache = cached
+        return cached[1]
+
+    def _condition_and_transform(self, inputs, identity_split, context, inverse, in_perm=None,
+                                 out_scatter=None, accumulate_into=None):
+        net = self.transform_net
+        final = getattr(net, "final_layer", None)
+        dt = self.num_transform_features
+        eligible = (self.fuse_final_linear and not torch.is_grad_enabled() and self.tails == "linear"
+                    and self.num_bins == 8 and hasattr(net, "hidden") and isinstance(final, torch.nn.Linear)
+                    and final.bias is not None and final.in_features == 128
+                    and getattr(net, "hidden_features", None) == 128 and dt % 4 == 0 and dt <= 64
+                    and self.features <= 128 and inputs.shape[0] >= 32)
+        if not eligible:
+            return super()._condition_and_transform(inputs, identity_split, context, inverse, in_perm,
+                                                    out_scatter, accumulate_into)
+        hidden = net.hidden(identity_split, context)
+        wp, bp = self._packed_final_linear(final)
+        B = inputs.shape[0]
+        full = (B // 32) * 32
+        spec = self._spec()
+        if full == B:
+            res = ops.rqs_coupling_fused_linear(inputs, hidden, wp, bp, self.transform_features, spec,
+                                                inverse, in_perm, out_scatter, accumulate_into)
+            if res is not None:
+                return res
+            return self._fused_layer(inputs, final(hidden), inverse, in_perm=in_perm,
+                                     out_scatter=out_scatter, accumulate_into=accumulate_into)
+        # ragged batch: the multiple-of-32 head through K7, the tail through GEMM + K1
+        acc_head = None if accumulate_into is None else accumulate_into[:full]
+        acc_tail = None if accumulate_into is None else accumulate_into[full:]
+        head = ops.rqs_coupling_fused_linear(inputs[:full], hidden[:full], wp, bp, self.transform_features,
+                                             spec, inverse, in_perm, out_scatter, acc_head)
+        if head is None:
+            return self._fused_layer(inputs, final(hidden), inverse, in_perm=in_perm,
+                                     out_scatter=out_scatter, accumulate_into=accumulate_into)
+        tail = self._fused_layer(inputs[full:], final(hidden[full:]), inverse, in_perm=in_perm,
+                                 out_scatter=out_scatter, accumulate_into=acc_tail)
+        outputs = torch.cat((head[0], tail[0]), dim=0)
+        logabsdet = accumulate_into if accumulate_into is not None else torch.cat((head[1], tail[1]), dim=0)
+        return outputs, logabsdet
 
     def _fused_layer(self, inputs, transform_params, inverse, in_perm=None, out_scatter=None,
                      accumulate_into=None):

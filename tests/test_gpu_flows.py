@@ -284,3 +284,41 @@ def test_conditional_flow_with_context():
         assert noise.shape == x.shape
     with pytest.raises(ValueError):
         flow.log_prob(x, context=ctx[:10])
+
+
+@pytest.mark.parametrize("B", [32, 1000, 4096])
+def test_fused_final_linear_kernel_matches_gemm_plus_k1(B):
+    """K7 (final Linear folded into the spline kernel via fp32 MFMA) against the unfused path
+    (hipBLASLt GEMM + K1) and against the CPU eager port of the reference: same arithmetic up to
+    the GEMM's summation order."""
+    from nflows_amd import configs
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    from oracle import eager
+    import copy
+    flow = configs.rq_nsf_flow(num_layers=3, features=64, num_bins=8, hidden_features=128, seed=5)
+    with torch.no_grad():
+        for n_, p in flow.named_parameters():  # non-trivial splines
+            if "final_layer" in n_:
+                p.mul_(4.0)
+            elif "linear_layers.1" in n_:
+                p.mul_(30.0)
+    cpu = copy.deepcopy(flow).eval()
+    flow = flow.to(DEV).eval()
+    x = torch.randn(B, 64, device=DEV)
+    with torch.no_grad():
+        RQ.fuse_final_linear = True
+        z1, l1 = flow._transform(x)
+        x1, li1 = flow._transform.inverse(x)
+        RQ.fuse_final_linear = False
+        z0, l0 = flow._transform(x)
+        x0, li0 = flow._transform.inverse(x)
+        RQ.fuse_final_linear = True
+        lp_ref64 = eager.flow_log_prob(cpu.double(), x.cpu().double())
+        lp = flow.log_prob(x)
+    import nflows_amd
+    nflows_amd.check_status()
+    # (three sharpened layers amplify the GEMMs' different summation orders; the bulk agrees tightly)
+    for got, want, tol in ((z1, z0, 2e-4), (l1, l0, 5e-3), (x1, x0, 2e-4), (li1, li0, 5e-3)):
+        d = (got - want).abs()
+        assert d.max().item() < tol and d.median().item() < tol / 50
+    assert (lp.cpu().double() - lp_ref64).abs().max().item() < 5e-3
