@@ -49,13 +49,20 @@ struct FusedArgs {
     int32_t* status;
     int64_t batch;  // multiple of 32
     int D, dt, accumulate;
+    FastDiv div_D;
     RqsDev sp;
     unsigned long long* trace;  // debug: per-phase timestamps of a few waves (null normally)
 };
 
 template <bool INVERSE>
 __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_kernel(const FusedArgs a) {
-    __shared__ float s_par_all[(kBlock / kWave) * 32 * kParStride];
+    // dynamic LDS: per wave a [32][97] parameter tile and a [32][dt|1] tile of transformed outputs
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    const int ystride = a.dt | 1;
+    float* s_par_all = lds_dyn;
+    float* s_y_all = lds_dyn + (kBlock / kWave) * 32 * kParStride;
+    __shared__ int s_dinv[128];   // layer column stored at output position p
+    __shared__ int s_slot[128];   // index of a transformed column in transform_idx
     __shared__ int s_src[128], s_dst[128], s_tsrc[64], s_tdst[64];
     __shared__ unsigned char s_ist[128];  // 1: column is transformed (written by the spline lanes)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,8 +83,10 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_kernel(const Fused
         s_src[c] = src;
         s_dst[c] = dst;
         s_ist[c] = 0;
+        s_slot[c] = 0;
     }
     __syncthreads();
+    for (int c = tid; c < D; c += kBlock) s_dinv[s_dst[c]] = c;
     if (tid < dt) {
         const int64_t t = a.tidx[tid];
         if (t < 0 || t >= D) my_status |= NFA_STATUS_BAD_INDEX;
@@ -85,6 +94,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_kernel(const Fused
         s_tsrc[tid] = s_src[col];
         s_tdst[tid] = s_dst[col];
         s_ist[col] = 1;
+        s_slot[col] = tid;
     }
     __syncthreads();
 
@@ -98,6 +108,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_kernel(const Fused
     if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(NFA_K7_STAGGER_SLEEP);
 #endif
     float* s_par = s_par_all + wave * 32 * kParStride;
+    float* s_y = s_y_all + wave * 32 * ystride;
     const int half = lane >> 5, r = lane & 31;
     const int groups = dt >> 2;  // 4 features per group
     const int64_t num_tiles = a.batch >> 5;
@@ -113,21 +124,6 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_kernel(const Fused
     for (int64_t tile = wave_global; tile < num_tiles; tile += nwaves) {
         const int64_t row0 = tile << 5;
         NFA_STAMP()
-        // ---- pass-through columns of the [32, D] block, bit-exact; 8 rows in flight per lane
-        for (int c = lane; c < D; c += kWave) {
-            if (!s_ist[c]) {
-                const float* src = a.x + row0 * D + s_src[c];
-                float* dst = a.out + row0 * D + s_dst[c];
-#pragma unroll 1
-                for (int rr = 0; rr < 32; rr += 8) {
-                    float v[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = src[(rr + i) * D];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) dst[(rr + i) * D] = v[i];
-                }
-            }
-        }
         NFA_STAMP()
         // ---- A operand: hidden[row0 + r][half*64 .. half*64+63]
         vec4f av[16];
@@ -196,12 +192,23 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_kernel(const Fused
 #else
                 my_status |= rqs_eval<8, INVERSE, true>(xin, s_par + r * kParStride + fl * kPP, a.sp, y, l);
 #endif
-                a.out[(row0 + r) * D + s_tdst[f]] = y;
+                s_y[r * ystride + f] = y;
                 lad_acc += l;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             NFA_STAMP()
         }
+        // ---- assemble the 32 output rows: position p holds layer column c = dinv[p]; transformed
+        //      columns come from the LDS y tile, the others are copied bit-exactly from the inputs
+        //      (gathered through the fused permutation).  Rows are written contiguously.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (int e = lane; e < 32 * D; e += kWave) {
+            const int rr = (int)fastdiv((uint32_t)e, a.div_D);
+            const int pcol = e - rr * D;
+            const int c = s_dinv[pcol];
+            a.out[(row0 + rr) * D + pcol] = s_ist[c] ? s_y[rr * ystride + s_slot[c]] : a.x[(row0 + rr) * D + s_src[c]];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         lad_acc += __shfl_xor(lad_acc, 32, kWave);
         if (half == 0) {
             float* dst = a.lad + row0 + r;
@@ -252,6 +259,7 @@ extern "C" int nfa_rqs_coupling_fused_linear_f32(const float* inputs, const floa
     a.batch = batch;
     a.D = features;
     a.dt = num_transform;
+    a.div_D = make_fastdiv((uint32_t)features);
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = g_k7_trace;
     const int64_t tiles = batch >> 5;
@@ -262,12 +270,13 @@ extern "C" int nfa_rqs_coupling_fused_linear_f32(const float* inputs, const floa
     profile_next_launch(&e0, &e1);
     const dim3 grid((unsigned)blocks), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(kBlock / kWave) * 32 * (kParStride + (num_transform | 1)) * sizeof(float);
     if (flags & NFA_FLAG_INVERSE) {
-        if (e0) hipExtLaunchKernelGGL(rqs_fused_linear_kernel<true>, grid, block, 0, st, e0, e1, 0, a);
-        else hipLaunchKernelGGL(rqs_fused_linear_kernel<true>, grid, block, 0, st, a);
+        if (e0) hipExtLaunchKernelGGL(rqs_fused_linear_kernel<true>, grid, block, lds, st, e0, e1, 0, a);
+        else hipLaunchKernelGGL(rqs_fused_linear_kernel<true>, grid, block, lds, st, a);
     } else {
-        if (e0) hipExtLaunchKernelGGL(rqs_fused_linear_kernel<false>, grid, block, 0, st, e0, e1, 0, a);
-        else hipLaunchKernelGGL(rqs_fused_linear_kernel<false>, grid, block, 0, st, a);
+        if (e0) hipExtLaunchKernelGGL(rqs_fused_linear_kernel<false>, grid, block, lds, st, e0, e1, 0, a);
+        else hipLaunchKernelGGL(rqs_fused_linear_kernel<false>, grid, block, lds, st, a);
     }
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;

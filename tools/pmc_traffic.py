@@ -16,29 +16,33 @@ import os
 import sys
 
 
-def mean_counter(d, counter, pat="rqs_coupling_pipelined"):
+def mean_counter(d, counter, pat="rqs_coupling_pipelined", min_grid=512 * 256):
     vals = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if pat in row["Kernel_Name"] and row["Counter_Name"] == counter and int(row["Grid_Size"]) >= 1024 * 256:
+            if pat in row["Kernel_Name"] and row["Counter_Name"] == counter and int(row["Grid_Size"]) >= min_grid:
                 vals.append(float(row["Counter_Value"]))
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
-def main(d, out):
-    fetch, nf = mean_counter(d, "FETCH_SIZE")
-    write, nw = mean_counter(d, "WRITE_SIZE")
-    res = {"kernel": "rqs_coupling_pipelined<8,false,true,6>", "launches_averaged": [nf, nw],
+def main(d, out, pat="rqs_coupling_pipelined", algorithmic=None, command=None):
+    fetch, nf = mean_counter(d, "FETCH_SIZE", pat)
+    write, nw = mean_counter(d, "WRITE_SIZE", pat)
+    res = {"kernel": pat, "launches_averaged": [nf, nw],
            "FETCH_SIZE_raw_KiB": fetch, "WRITE_SIZE_raw_KiB": write,
            "fetch_bytes_corrected_x2": None if fetch is None else fetch * 1024 * 2,
            "write_bytes": None if write is None else write * 1024,
            "hbm_bytes_per_launch": None if fetch is None or write is None else fetch * 2048 + write * 1024,
-           "algorithmic_bytes_per_launch": 4 * (65536 * 64 * 2 + 65536 * 32 * 23 + 65536),
-           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over "
-                     "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline`; gfx950 x2 correction on reads"}
+           "algorithmic_bytes_per_launch": algorithmic if algorithmic is not None
+           else 4 * (65536 * 64 * 2 + 65536 * 32 * 23 + 65536),
+           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `%s`; "
+                     "gfx950 x2 correction on reads" % (command or "python bench.py --steps 3 --warmup 1 --no-cpu-baseline")}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    # pmc_traffic.py <dir> <out.json> [kernel-name-substring] [algorithmic-bytes] [command]
+    main(sys.argv[1], sys.argv[2], *(sys.argv[3:4] or ["rqs_coupling_pipelined"]),
+         algorithmic=int(sys.argv[4]) if len(sys.argv) > 4 else None,
+         command=sys.argv[5] if len(sys.argv) > 5 else None)
