@@ -33,8 +33,6 @@ typedef float vec4f __attribute__((ext_vector_type(4)));
 
 constexpr int kH = 128;        // hidden width (GEMM K dimension)
 constexpr int kPP = 24;        // padded logits per feature
-constexpr int kGroupCols = 96; // 3 MFMA tiles = 4 features
-constexpr int kParStride = 97; // LDS row stride of the parameter tile (odd: conflict-free column reads)
 
 struct FusedArgs {
     const float* x;       // [B, D]
@@ -54,16 +52,26 @@ struct FusedArgs {
     unsigned long long* trace;  // debug: per-phase timestamps of a few waves (null normally)
 };
 
+// Lane-private view of one feature's 24 (23 + pad) logits inside the three accumulators of a group:
+// a lane's 48 accumulator registers are, in order, the logits of its two features (the host packs
+// the weight rows so; see pack order in include/nflows_amd.h).
+#define NFA_K7_FEATURE_A(p, a0, a1)                                                   \
+    float p[24] = {a0[0], a0[1], a0[2],  a0[3],  a0[4],  a0[5],  a0[6],  a0[7],       \
+                   a0[8], a0[9], a0[10], a0[11], a0[12], a0[13], a0[14], a0[15],      \
+                   a1[0], a1[1], a1[2],  a1[3],  a1[4],  a1[5],  a1[6],  a1[7]}
+#define NFA_K7_FEATURE_B(p, a1, a2)                                                   \
+    float p[24] = {a1[8], a1[9], a1[10], a1[11], a1[12], a1[13], a1[14], a1[15],      \
+                   a2[0], a2[1], a2[2],  a2[3],  a2[4],  a2[5],  a2[6],  a2[7],       \
+                   a2[8], a2[9], a2[10], a2[11], a2[12], a2[13], a2[14], a2[15]}
+
 template <bool INVERSE>
 __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_kernel(const FusedArgs a) {
-    // dynamic LDS: per wave a [32][97] parameter tile and a [32][dt|1] tile of transformed outputs
+    // dynamic LDS: per wave a [32][dt|1] tile of transformed outputs
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     const int ystride = a.dt | 1;
-    float* s_par_all = lds_dyn;
-    float* s_y_all = lds_dyn + (kBlock / kWave) * 32 * kParStride;
     __shared__ int s_dinv[128];   // layer column stored at output position p
     __shared__ int s_slot[128];   // index of a transformed column in transform_idx
-    __shared__ int s_src[128], s_dst[128], s_tsrc[64], s_tdst[64];
+    __shared__ int s_src[128], s_dst[128], s_tsrc[64];
     __shared__ unsigned char s_ist[128];  // 1: column is transformed (written by the spline lanes)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = a.D, dt = a.dt;
@@ -92,25 +100,14 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_kernel(const Fused
         if (t < 0 || t >= D) my_status |= NFA_STATUS_BAD_INDEX;
         const int col = (int)(t < 0 ? 0 : (t >= D ? D - 1 : t));
         s_tsrc[tid] = s_src[col];
-        s_tdst[tid] = s_dst[col];
         s_ist[col] = 1;
         s_slot[col] = tid;
     }
     __syncthreads();
 
-    // Two waves share each SIMD, hence its one matrix pipe and its VALU issue.  Started together
-    // they stay in lockstep (both in the MFMA phase, then both in the spline phase: no overlap);
-    // delaying the wave in the odd hardware slot by about half an MFMA phase keeps one of them in
-    // the VALU-only spline phase while the other owns the matrix pipe.
-#ifdef NFA_K7_STAGGER_SLEEP
-    // experiment: offset the two workgroups that share a CU (second dispatch round) by a fraction
-    // of a tile so that their non-MFMA sections do not coincide
-    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(NFA_K7_STAGGER_SLEEP);
-#endif
-    float* s_par = s_par_all + wave * 32 * kParStride;
-    float* s_y = s_y_all + wave * 32 * ystride;
+    float* s_y = lds_dyn + wave * 32 * ystride;
     const int half = lane >> 5, r = lane & 31;
-    const int groups = dt >> 2;  // 4 features per group
+    const int groups = dt >> 2;  // 4 features = 3 MFMA tiles per group
     const int64_t num_tiles = a.batch >> 5;
     const int64_t wave_global = (int64_t)blockIdx.x * (kBlock / kWave) + wave;
     const int64_t nwaves = (int64_t)gridDim.x * (kBlock / kWave);
@@ -124,78 +121,87 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_kernel(const Fused
     for (int64_t tile = wave_global; tile < num_tiles; tile += nwaves) {
         const int64_t row0 = tile << 5;
         NFA_STAMP()
-        NFA_STAMP()
-        // ---- A operand: hidden[row0 + r][half*64 .. half*64+63]
-        vec4f av[16];
+        // ---- hidden^T as the MFMA B operand: lane (sample r, half) holds hidden[row0 + r][half*64 ..+63]
+        vec4f hv[16];
         const vec4f* hp = reinterpret_cast<const vec4f*>(a.hidden + (row0 + r) * kH + half * 64);
 #pragma unroll
-        for (int j4 = 0; j4 < 16; ++j4) av[j4] = hp[j4];
+        for (int j4 = 0; j4 < 16; ++j4) hv[j4] = hp[j4];
 
         float lad_acc = 0.0f;
+        // weights as the A operand, streamed in half tiles (8 x 16 bytes per lane), one ahead
         const vec4f* wbase = reinterpret_cast<const vec4f*>(a.wpacked) + lane;
-        vec4f bv[16];
+        const vec4f* bias_lane = reinterpret_cast<const vec4f*>(a.bpad) + half * 4;
+        vec4f wv[8];
 #pragma unroll
-        for (int j4 = 0; j4 < 16; ++j4) bv[j4] = wbase[j4 * 64];  // B tile 0
+        for (int j = 0; j < 8; ++j) wv[j] = wbase[j * 64];
+        const int num_half_tiles = groups * 6;
 
         NFA_STAMP()
         for (int g = 0; g < groups; ++g) {
             // this group's spline inputs: requested now, consumed after the three MFMA tiles
-            const float xin0 = a.x[(row0 + r) * D + s_tsrc[g * 4 + half]];
-            const float xin1 = a.x[(row0 + r) * D + s_tsrc[g * 4 + half + 2]];
-#pragma unroll 1
-            for (int t = 0; t < 3; ++t) {
-                const int nt = g * 3 + t;
-                f32x16 acc = {0};
-                // next tile's weights are requested before this tile's MFMAs start
-                vec4f bn[16];
-                const int ntn = (nt + 1 < groups * 3) ? nt + 1 : 0;
-                const vec4f* wn = wbase + (size_t)ntn * 16 * 64;
+            const float xin0 = a.x[(row0 + r) * D + s_tsrc[g * 4 + half * 2]];
+            const float xin1 = a.x[(row0 + r) * D + s_tsrc[g * 4 + half * 2 + 1]];
+            f32x16 acc[3];
 #pragma unroll
-                for (int j4 = 0; j4 < 16; ++j4) bn[j4] = wn[j4 * 64];
-#ifdef NFA_K7_PIN_PREFETCH
-                __builtin_amdgcn_sched_barrier(0);
-#endif
+            for (int t = 0; t < 3; ++t) {
+                const vec4f* bp = bias_lane + (size_t)(g * 3 + t) * 8;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const vec4f b = bp[q4];
+                    acc[t][q4 * 4 + 0] = b.x;
+                    acc[t][q4 * 4 + 1] = b.y;
+                    acc[t][q4 * 4 + 2] = b.z;
+                    acc[t][q4 * 4 + 3] = b.w;
+                }
+            }
+#pragma unroll
+            for (int hh = 0; hh < 6; ++hh) {
+                const int ht = g * 6 + hh;
+                const int htn = (ht + 1 < num_half_tiles) ? ht + 1 : 0;
+                const vec4f* wn = wbase + (size_t)htn * 8 * 64;
+                vec4f wnext[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wnext[j] = wn[j * 64];
 #ifndef NFA_K7_NOMFMA
 #pragma unroll
-                for (int j4 = 0; j4 < 16; ++j4) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j4].x, bv[j4].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j4].y, bv[j4].y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j4].z, bv[j4].z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j4].w, bv[j4].w, acc, 0, 0, 0);
+                for (int j = 0; j < 8; ++j) {
+                    const vec4f h4 = hv[(hh & 1) * 8 + j];
+                    acc[hh >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].x, h4.x, acc[hh >> 1], 0, 0, 0);
+                    acc[hh >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].y, h4.y, acc[hh >> 1], 0, 0, 0);
+                    acc[hh >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].z, h4.z, acc[hh >> 1], 0, 0, 0);
+                    acc[hh >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].w, h4.w, acc[hh >> 1], 0, 0, 0);
                 }
 #else
-                for (int j4 = 0; j4 < 16; ++j4) acc[j4] = av[j4].x + bv[j4].y;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[hh >> 1][j] += wv[j].x + hv[(hh & 1) * 8 + j].y;
 #endif
-                NFA_STAMP()
-                const float bias = a.bpad[nt * 32 + r];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int row = (q & 3) + 8 * (q >> 2) + 4 * half;  // C/D map of the 32x32 MFMA
-                    s_par[row * kParStride + t * 32 + r] = acc[q] + bias;
-                }
-#pragma unroll
-                for (int j4 = 0; j4 < 16; ++j4) bv[j4] = bn[j4];
-                NFA_STAMP()
+                for (int j = 0; j < 8; ++j) wv[j] = wnext[j];
             }
-            // ---- 4 features x 32 samples from the LDS tile (wave-private: LDS ops of one wave
-            //      execute in order, only the data returns need waiting for)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll 1
-            for (int pass = 0; pass < 2; ++pass) {
-                const int fl = half + 2 * pass;  // feature within the group
-                const int f = g * 4 + fl;
-                const float xin = pass ? xin1 : xin0;
+            NFA_STAMP()
+            // ---- the lane's two features of this group, straight from the accumulators
+            {
+                NFA_K7_FEATURE_A(p, acc[0], acc[1]);
                 float y, l;
 #ifdef NFA_K7_NOSPLINE
-                y = xin + s_par[r * kParStride + fl * kPP];
-                l = s_par[r * kParStride + fl * kPP + 8];
+                y = xin0 + p[0]; l = p[8];
 #else
-                my_status |= rqs_eval<8, INVERSE, true>(xin, s_par + r * kParStride + fl * kPP, a.sp, y, l);
+                my_status |= rqs_eval<8, INVERSE, true, true>(xin0, p, a.sp, y, l);
 #endif
-                s_y[r * ystride + f] = y;
+                s_y[r * ystride + g * 4 + half * 2] = y;
                 lad_acc += l;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {
+                NFA_K7_FEATURE_B(p, acc[1], acc[2]);
+                float y, l;
+#ifdef NFA_K7_NOSPLINE
+                y = xin1 + p[0]; l = p[8];
+#else
+                my_status |= rqs_eval<8, INVERSE, true, true>(xin1, p, a.sp, y, l);
+#endif
+                s_y[r * ystride + g * 4 + half * 2 + 1] = y;
+                lad_acc += l;
+            }
             NFA_STAMP()
         }
         // ---- assemble the 32 output rows: position p holds layer column c = dinv[p]; transformed
@@ -270,7 +276,7 @@ extern "C" int nfa_rqs_coupling_fused_linear_f32(const float* inputs, const floa
     profile_next_launch(&e0, &e1);
     const dim3 grid((unsigned)blocks), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)(kBlock / kWave) * 32 * (kParStride + (num_transform | 1)) * sizeof(float);
+    const size_t lds = (size_t)(kBlock / kWave) * 32 * (num_transform | 1) * sizeof(float);
     if (flags & NFA_FLAG_INVERSE) {
         if (e0) hipExtLaunchKernelGGL(rqs_fused_linear_kernel<true>, grid, block, lds, st, e0, e1, 0, a);
         else hipLaunchKernelGGL(rqs_fused_linear_kernel<true>, grid, block, lds, st, a);

@@ -437,18 +437,39 @@ def rqs_shared(inputs, unnormalized_widths, unnormalized_heights, unnormalized_d
     return y.view(inputs.shape), lad
 
 
+def _k7_row_order(num_transform):
+    """For every row of the packed (tile-major) weight: which row of the feature-major padded
+    matrix [d_t, 24] it is.  The kernel computes params^T = W_tile @ hidden^T, so lane (sample,
+    half) of a wave receives rows 8*(q//4) + 4*half + q%4 (q = 0..15) of each 32-row tile; the
+    order below makes the 48 values a lane gets from the three tiles of a group exactly the 24 + 24
+    logits of features 4g + 2*half and 4g + 2*half + 1."""
+    i = torch.arange(32)
+    half = (i >> 2) & 1
+    q = ((i >> 3) << 2) | (i & 3)
+    tiles = num_transform * 24 // 32
+    t = torch.arange(tiles)[:, None]
+    idx = (t % 3) * 16 + q[None, :]
+    feat = 4 * (t // 3) + 2 * half[None, :] + idx // 24
+    return (feat * 24 + idx % 24).reshape(-1)  # [tiles * 32]
+
+
 def pack_final_linear(weight, bias, num_transform, params_per_feature):
-    """Re-tiles a Linear(H=128 -> d_t*23) for K7's MFMA B operand (layout in include/nflows_amd.h):
-    each feature's 23 rows padded to 24, then [tiles][16][64 lanes][4]."""
+    """Re-tiles a Linear(H=128 -> d_t*23) for K7's MFMA A operand (layout in include/nflows_amd.h):
+    each feature's 23 rows padded to 24, rows reordered per lane-half (`_k7_row_order`), then
+    [tiles][16][64 lanes][4]; bias in accumulator order [tiles][2 halves][16]."""
     dt, P = num_transform, params_per_feature
     H = weight.shape[1]
+    order = _k7_row_order(dt).to(weight.device)
     w = weight.detach().view(dt, P, H)
-    w = torch.cat((w, w.new_zeros(dt, 24 - P, H)), dim=1).reshape(dt * 24, H)
+    w = torch.cat((w, w.new_zeros(dt, 24 - P, H)), dim=1).reshape(dt * 24, H).index_select(0, order)
     b = torch.cat((bias.detach().view(dt, P), bias.new_zeros(dt, 24 - P)), dim=1).reshape(dt * 24)
+    b = b.index_select(0, order)
     tiles = dt * 24 // 32
     # (tile, r, half, j4, q) -> (tile, j4, half, r, q); lane = half*32 + r
     wp = w.view(tiles, 32, 2, 16, 4).permute(0, 3, 2, 1, 4).contiguous()
-    return wp, b.contiguous()
+    # row i of a tile sits in accumulator register q = 4*(i//8) + i%4 of lane-half (i//4)%2
+    bp = b.view(tiles, 4, 2, 4).permute(0, 2, 1, 3).contiguous()
+    return wp, bp
 
 
 def rqs_coupling_fused_linear(inputs, hidden, weight_packed, bias_padded, transform_idx, spec,
