@@ -52,6 +52,9 @@ extern "C" {
                                              of CompositeTransform._cascade (base.py:48-51) folded
                                              into the layer; logabsdet must then hold the running
                                              total on entry */
+#define NFA_FLAG_WEIGHTS_BF16X3 4         /* nfa_rqs_coupling_fused_linear_f32 only: weight_packed
+                                             holds split-bf16 triples (layout below); the GEMM
+                                             then runs on the bf16 matrix pipe, fp32-accurate */
 
 /* tails */
 #define NFA_TAILS_NONE 0   /* rational_quadratic_spline: K+1 derivative logits per element */
@@ -137,19 +140,28 @@ int nfa_rqs_coupling_backward_f32(const float *inputs, const float *params,
                                   const nfa_rqs_spec *spec, int32_t flags, void *stream);
 
 /*
- * K7.  K1 with the conditioner's output layer folded in: params = hidden @ W^T + b is computed
- * tile by tile with fp32 MFMA inside the kernel and consumed from LDS, so the [batch, d_t*P]
- * parameter tensor never goes through HBM (ResidualNet.final_layer, nn/nets/resnet.py:90, :99,
- * followed by everything nfa_rqs_coupling_f32 replaces).
+ * K7.  K1 with the conditioner's output layer folded in: params^T = W @ hidden^T + b is computed
+ * tile by tile on the matrix cores inside the kernel and consumed from the accumulator
+ * registers, so the [batch, d_t*P] parameter tensor never goes through HBM
+ * (ResidualNet.final_layer, nn/nets/resnet.py:90, :99, followed by everything
+ * nfa_rqs_coupling_f32 replaces).
  *   hidden        [batch, hidden_features]  input of the final Linear
- *   weight_packed the Linear's weight [d_t*P, hidden_features], each feature's 23 rows padded
- *                 to 24 (zero row) and re-tiled for the MFMA B operand:
- *                 [d_t*24/32 tiles][16][64 lanes][4], lane l element (j4, q) =
- *                 Wpad[tile*32 + (l & 31)][(l >> 5)*64 + j4*4 + q]
- *   bias_padded   [d_t*24]
+ *   weight_packed the Linear's weight [d_t*P, hidden_features] re-tiled for the MFMA A operand.
+ *                 Rows: each feature's 23 rows padded to 24 (zero row); row i of 32-row tile t
+ *                 (group g = t/3) is logit (idx % 24) of feature 4g + 2*hf + idx/24, where
+ *                 hf = (i>>2)&1, q = 4*(i>>3) + (i&3), idx = 16*(t%3) + q  -- i.e. the 48
+ *                 accumulator values a lane-half receives from a group's three tiles are the
+ *                 logits of its two features in order (nflows_amd/ops.py:_k7_row_order).
+ *                 Default (fp32 MFMA): float [tiles][16][64 lanes][4], lane l element (j4, c) =
+ *                 Wrows[tile*32 + (l & 31)][(l >> 5)*64 + j4*4 + c].
+ *                 NFA_FLAG_WEIGHTS_BF16X3: bf16 [tiles][3 pieces][8][64 lanes][8], lane l
+ *                 element (piece, ks, j) = piece of Wrows[tile*32 + (l & 31)][(l >> 5)*64 +
+ *                 ks*8 + j], pieces hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid)
+ *                 (round to nearest even).
+ *   bias_padded   [tiles][2 lane-halves][16]: the bias of the rows above in accumulator order
  * Supported here: num_bins = 8, linear tails, hidden_features = 128, d_t % 4 == 0, d_t <= 64,
- * features <= 128, batch % 32 == 0; anything else returns NFA_ERR_UNSUPPORTED (callers then run
- * the GEMM and nfa_rqs_coupling_f32).
+ * features <= 128, batch % 32 == 0 (% 128 with NFA_FLAG_WEIGHTS_BF16X3); anything else returns
+ * NFA_ERR_UNSUPPORTED (callers then run the GEMM and nfa_rqs_coupling_f32).
  */
 int nfa_rqs_coupling_fused_linear_f32(const float *inputs, const float *hidden,
                                       const float *weight_packed, const float *bias_padded,

@@ -25,7 +25,7 @@ STATUS_OUTSIDE_DOMAIN = 1
 STATUS_NEG_DISCRIMINANT = 2
 STATUS_BAD_INDEX = 4
 
-FLAG_INVERSE, FLAG_ACCUMULATE_LOGABSDET = 1, 2
+FLAG_INVERSE, FLAG_ACCUMULATE_LOGABSDET, FLAG_WEIGHTS_BF16X3 = 1, 2, 4
 TAILS_NONE, TAILS_LINEAR = 0, 1
 SCALE_DEFAULT, SCALE_GENERAL, SCALE_ADDITIVE, SCALE_GIVEN, SCALE_SOFTPLUS = 0, 1, 2, 3, 4
 

@@ -32,7 +32,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float vec4f __attribute__((ext_vector_type(4)));
 
 constexpr int kH = 128;        // hidden width (GEMM K dimension)
-constexpr int kPP = 24;        // padded logits per feature
 
 struct FusedArgs {
     const float* x;       // [B, D]
@@ -224,6 +223,189 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_kernel(const Fused
     if (my_status && a.status) atomicOr(a.status, my_status);
 }
 
+// ------------------------------------------------------------------------------------------
+// K7b: the same layer with the GEMM on the bf16 matrix pipe at fp32 accuracy.  Every fp32 operand
+// is the sum of three bf16 numbers (x = hi + mid + lo, exact to 2^-25 |x|); the six largest cross
+// products (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) are accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16 -- 6 x 8 passes per 16 k instead of 8 x 16 passes for the f32 MFMA, and
+// unlike the f32 MFMA it does not occupy the VALU that the spline arithmetic needs.
+// The weight pieces (host-split, 24 KB per 32-row tile) are shared by the four waves of a
+// workgroup through a double-buffered LDS tile; the activations are split once per row tile.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float vec2f __attribute__((ext_vector_type(2)));
+
+constexpr int kWTileVec4 = 3 * 8 * 64;  // one weight tile: [piece][k-step][lane] x 16 bytes
+
+__device__ __forceinline__ void split3(vec2f v, bf16x2& hi, bf16x2& mid, bf16x2& lo) {
+    hi = __builtin_convertvector(v, bf16x2);
+    const vec2f r1 = v - __builtin_convertvector(hi, vec2f);
+    mid = __builtin_convertvector(r1, bf16x2);
+    const vec2f r2 = r1 - __builtin_convertvector(mid, vec2f);
+    lo = __builtin_convertvector(r2, bf16x2);
+}
+
+__device__ __forceinline__ bf16x8 join4(bf16x2 a, bf16x2 b, bf16x2 c, bf16x2 d) {
+    return bf16x8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+
+template <bool INVERSE>
+__global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_bf16_kernel(const FusedArgs a) {
+    // dynamic LDS: two weight tiles, then per wave a [32][dt|1] tile of transformed outputs
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    const int ystride = a.dt | 1;
+    vec4f* s_w = reinterpret_cast<vec4f*>(lds_dyn);
+    __shared__ int s_dinv[128], s_slot[128], s_src[128], s_dst[128], s_tsrc[64];
+    __shared__ unsigned char s_ist[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = a.D, dt = a.dt;
+    int my_status = 0;
+    for (int c = tid; c < D; c += kBlock) {
+        int src = c, dst = c;
+        if (a.perm) {
+            const int64_t p = a.perm[c];
+            if (p < 0 || p >= D) my_status |= NFA_STATUS_BAD_INDEX;
+            src = (int)(p < 0 ? 0 : (p >= D ? D - 1 : p));
+        }
+        if (a.scatter) {
+            const int64_t p = a.scatter[c];
+            if (p < 0 || p >= D) my_status |= NFA_STATUS_BAD_INDEX;
+            dst = (int)(p < 0 ? 0 : (p >= D ? D - 1 : p));
+        }
+        s_src[c] = src;
+        s_dst[c] = dst;
+        s_ist[c] = 0;
+        s_slot[c] = 0;
+    }
+    __syncthreads();
+    for (int c = tid; c < D; c += kBlock) s_dinv[s_dst[c]] = c;
+    if (tid < dt) {
+        const int64_t t = a.tidx[tid];
+        if (t < 0 || t >= D) my_status |= NFA_STATUS_BAD_INDEX;
+        const int col = (int)(t < 0 ? 0 : (t >= D ? D - 1 : t));
+        s_tsrc[tid] = s_src[col];
+        s_ist[col] = 1;
+        s_slot[col] = tid;
+    }
+
+    float* s_y = lds_dyn + 2 * kWTileVec4 * 4 + wave * 32 * ystride;
+    const int half = lane >> 5, r = lane & 31;
+    const int groups = dt >> 2;
+    const int ntiles = groups * 3;
+    const int64_t num_quads = a.batch >> 7;  // 4 waves x 32 samples
+    const vec4f* wg = reinterpret_cast<const vec4f*>(a.wpacked);
+
+    // weight tile 0 -> LDS buffer 0
+    {
+        vec4f w[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i] = wg[tid + i * kBlock];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s_w[tid + i * kBlock] = w[i];
+    }
+    __syncthreads();
+    int it = 0;  // running tile counter: parity selects the LDS buffer holding the current tile
+
+    for (int64_t quad = blockIdx.x; quad < num_quads; quad += gridDim.x) {
+        const int64_t row0 = (quad << 7) + (wave << 5);
+        // ---- hidden^T, split into bf16 pieces: lane (sample r, half) covers k = half*64 + ks*8 + 0..7
+        bf16x8 bh[8], bm[8], bl[8];
+        {
+            const vec4f* hp = reinterpret_cast<const vec4f*>(a.hidden + (row0 + r) * kH + half * 64);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const vec4f v0 = hp[ks * 2], v1 = hp[ks * 2 + 1];
+                bf16x2 h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+                split3(vec2f{v0.x, v0.y}, h0, m0, l0);
+                split3(vec2f{v0.z, v0.w}, h1, m1, l1);
+                split3(vec2f{v1.x, v1.y}, h2, m2, l2);
+                split3(vec2f{v1.z, v1.w}, h3, m3, l3);
+                bh[ks] = join4(h0, h1, h2, h3);
+                bm[ks] = join4(m0, m1, m2, m3);
+                bl[ks] = join4(l0, l1, l2, l3);
+            }
+        }
+        float lad_acc = 0.0f;
+        const vec4f* bias_lane = reinterpret_cast<const vec4f*>(a.bpad) + half * 4;
+
+        for (int g = 0; g < groups; ++g) {
+            const float xin0 = a.x[(row0 + r) * D + s_tsrc[g * 4 + half * 2]];
+            const float xin1 = a.x[(row0 + r) * D + s_tsrc[g * 4 + half * 2 + 1]];
+            f32x16 acc[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int nt = g * 3 + t;
+                {
+                    const vec4f* bp = bias_lane + (size_t)nt * 8;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const vec4f b = bp[q4];
+                        acc[t][q4 * 4 + 0] = b.x;
+                        acc[t][q4 * 4 + 1] = b.y;
+                        acc[t][q4 * 4 + 2] = b.z;
+                        acc[t][q4 * 4 + 3] = b.w;
+                    }
+                }
+                // next tile (wrapping to tile 0 for the next quad): global -> registers now,
+                // registers -> the other LDS buffer after this tile's MFMAs
+                const int ntn = (nt + 1 < ntiles) ? nt + 1 : 0;
+                const vec4f* wn = wg + (size_t)ntn * kWTileVec4;
+                vec4f wnext[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) wnext[i] = wn[tid + i * kBlock];
+
+                const vec4f* cur = s_w + (it & 1) * kWTileVec4 + lane;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(0 * 8 + ks) * 64]);
+                    const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(1 * 8 + ks) * 64]);
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(2 * 8 + ks) * 64]);
+                    // smallest products first
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], acc[t], 0, 0, 0);
+                }
+                vec4f* nxt = s_w + ((it + 1) & 1) * kWTileVec4;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) nxt[tid + i * kBlock] = wnext[i];
+                __syncthreads();
+                ++it;
+            }
+            {
+                NFA_K7_FEATURE_A(p, acc[0], acc[1]);
+                float y, l;
+                my_status |= rqs_eval<8, INVERSE, true, true>(xin0, p, a.sp, y, l);
+                s_y[r * ystride + g * 4 + half * 2] = y;
+                lad_acc += l;
+            }
+            {
+                NFA_K7_FEATURE_B(p, acc[1], acc[2]);
+                float y, l;
+                my_status |= rqs_eval<8, INVERSE, true, true>(xin1, p, a.sp, y, l);
+                s_y[r * ystride + g * 4 + half * 2 + 1] = y;
+                lad_acc += l;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (int e = lane; e < 32 * D; e += kWave) {
+            const int rr = (int)fastdiv((uint32_t)e, a.div_D);
+            const int pcol = e - rr * D;
+            const int c = s_dinv[pcol];
+            a.out[(row0 + rr) * D + pcol] = s_ist[c] ? s_y[rr * ystride + s_slot[c]] : a.x[(row0 + rr) * D + s_src[c]];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        lad_acc += __shfl_xor(lad_acc, 32, kWave);
+        if (half == 0) {
+            float* dst = a.lad + row0 + r;
+            *dst = a.accumulate ? *dst + lad_acc : lad_acc;
+        }
+    }
+    if (my_status && a.status) atomicOr(a.status, my_status);
+}
+
 }  // namespace nfa
 
 using namespace nfa;
@@ -240,14 +422,16 @@ extern "C" int nfa_rqs_coupling_fused_linear_f32(const float* inputs, const floa
                                                  int32_t features, int32_t num_transform,
                                                  int32_t hidden_features, const nfa_rqs_spec* spec,
                                                  int32_t flags, void* stream) {
-    if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET)) return NFA_ERR_INVALID_ARGUMENT;
+    if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_WEIGHTS_BF16X3))
+        return NFA_ERR_INVALID_ARGUMENT;
+    const bool split_bf16 = (flags & NFA_FLAG_WEIGHTS_BF16X3) != 0;
     if (batch < 0 || features < 1 || num_transform < 1 || num_transform > features)
         return NFA_ERR_INVALID_ARGUMENT;
     FusedArgs a;
     int rc = make_dev_spec(spec, &a.sp);
     if (rc != NFA_OK) return rc;
     if (a.sp.K != 8 || !a.sp.linear || hidden_features != kH || (num_transform & 3) != 0 ||
-        num_transform > 64 || features > 128 || (batch & 31) != 0)
+        num_transform > 64 || features > 128 || (batch & (split_bf16 ? 127 : 31)) != 0)
         return NFA_ERR_UNSUPPORTED;
     if (batch == 0) return NFA_OK;
     if (!inputs || !hidden || !weight_packed || !bias_padded || !transform_idx || !outputs || !logabsdet)
@@ -268,21 +452,28 @@ extern "C" int nfa_rqs_coupling_fused_linear_f32(const float* inputs, const floa
     a.div_D = make_fastdiv((uint32_t)features);
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = g_k7_trace;
-    const int64_t tiles = batch >> 5;
-    int64_t blocks = (tiles + 3) / 4;
     const int64_t cap = (int64_t)device_cu_count() * 2;
-    if (blocks > cap) blocks = cap;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     profile_next_launch(&e0, &e1);
-    const dim3 grid((unsigned)blocks), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)(kBlock / kWave) * 32 * (num_transform | 1) * sizeof(float);
-    if (flags & NFA_FLAG_INVERSE) {
-        if (e0) hipExtLaunchKernelGGL(rqs_fused_linear_kernel<true>, grid, block, lds, st, e0, e1, 0, a);
-        else hipLaunchKernelGGL(rqs_fused_linear_kernel<true>, grid, block, lds, st, a);
+    const dim3 block(kBlock);
+    const bool inverse = (flags & NFA_FLAG_INVERSE) != 0;
+    const size_t ybytes = (size_t)(kBlock / kWave) * 32 * (num_transform | 1) * sizeof(float);
+    if (split_bf16) {
+        int64_t blocks = batch >> 7;
+        if (blocks > cap) blocks = cap;
+        const dim3 grid((unsigned)blocks);
+        const size_t lds = ybytes + 2 * kWTileVec4 * 16;
+        auto kern = inverse ? rqs_fused_linear_bf16_kernel<true> : rqs_fused_linear_bf16_kernel<false>;
+        if (e0) hipExtLaunchKernelGGL(kern, grid, block, lds, st, e0, e1, 0, a);
+        else hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     } else {
-        if (e0) hipExtLaunchKernelGGL(rqs_fused_linear_kernel<false>, grid, block, lds, st, e0, e1, 0, a);
-        else hipLaunchKernelGGL(rqs_fused_linear_kernel<false>, grid, block, lds, st, a);
+        int64_t blocks = ((batch >> 5) + 3) / 4;
+        if (blocks > cap) blocks = cap;
+        const dim3 grid((unsigned)blocks);
+        auto kern = inverse ? rqs_fused_linear_kernel<true> : rqs_fused_linear_kernel<false>;
+        if (e0) hipExtLaunchKernelGGL(kern, grid, block, ybytes, st, e0, e1, 0, a);
+        else hipLaunchKernelGGL(kern, grid, block, ybytes, st, a);
     }
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;

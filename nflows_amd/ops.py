@@ -453,10 +453,20 @@ def _k7_row_order(num_transform):
     return (feat * 24 + idx % 24).reshape(-1)  # [tiles * 32]
 
 
-def pack_final_linear(weight, bias, num_transform, params_per_feature):
+def split_bf16x3(w):
+    """fp32 -> three bf16 tensors with w == hi + mid + lo up to 2^-25 |w| (round to nearest even)."""
+    hi = w.to(torch.bfloat16)
+    r1 = w - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    return hi, mid, lo
+
+
+def pack_final_linear(weight, bias, num_transform, params_per_feature, split_bf16=False):
     """Re-tiles a Linear(H=128 -> d_t*23) for K7's MFMA A operand (layout in include/nflows_amd.h):
     each feature's 23 rows padded to 24, rows reordered per lane-half (`_k7_row_order`), then
-    [tiles][16][64 lanes][4]; bias in accumulator order [tiles][2 halves][16]."""
+    fp32 [tiles][16][64 lanes][4], or with split_bf16 bf16 [tiles][3][8][64 lanes][8]; bias in
+    accumulator order [tiles][2 halves][16]."""
     dt, P = num_transform, params_per_feature
     H = weight.shape[1]
     order = _k7_row_order(dt).to(weight.device)
@@ -466,7 +476,11 @@ def pack_final_linear(weight, bias, num_transform, params_per_feature):
     b = b.index_select(0, order)
     tiles = dt * 24 // 32
     # (tile, r, half, j4, q) -> (tile, j4, half, r, q); lane = half*32 + r
-    wp = w.view(tiles, 32, 2, 16, 4).permute(0, 3, 2, 1, 4).contiguous()
+    if split_bf16:
+        # (piece, tile, r, half, ks, j) -> (tile, piece, ks, half, r, j)
+        wp = torch.stack(split_bf16x3(w)).view(3, tiles, 32, 2, 8, 8).permute(1, 0, 4, 3, 2, 5).contiguous()
+    else:
+        wp = w.view(tiles, 32, 2, 16, 4).permute(0, 3, 2, 1, 4).contiguous()
     # row i of a tile sits in accumulator register q = 4*(i//8) + i%4 of lane-half (i//4)%2
     bp = b.view(tiles, 4, 2, 4).permute(0, 2, 1, 3).contiguous()
     return wp, bp
@@ -487,6 +501,8 @@ def rqs_coupling_fused_linear(inputs, hidden, weight_packed, bias_padded, transf
     h = hidden.detach().contiguous()
     out = torch.empty_like(x)
     lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
+    if weight_packed.dtype == torch.bfloat16:
+        flags |= N.FLAG_WEIGHTS_BF16X3
     with torch.cuda.device(dev):
         rc = N.load().nfa_rqs_coupling_fused_linear_f32(
             N.ptr(x), N.ptr(h), N.ptr(weight_packed), N.ptr(bias_padded), N.ptr(tidx), N.ptr(perm),

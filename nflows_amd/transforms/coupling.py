@@ -13,6 +13,7 @@ loads unchanged.  Per layer the host does exactly three things:
 Only 2-D float32 inputs on a HIP device are implemented; 4-D image inputs
 (coupling.py:280-285) and the other piecewise families are out of scope and raise.
 """
+import os
 import warnings
 
 import numpy as np
@@ -244,13 +245,18 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
     # K7: fold the conditioner's final Linear into the spline kernel (no [B, d_t*P] round trip
     # through HBM).  Class-level switch for A/B measurements.
     fuse_final_linear = True
+    # GEMM engine of K7: "bf16x3" = split-bf16 operands on the bf16 matrix pipe (fp32-accurate,
+    # default), "f32" = v_mfma_f32_32x32x2_f32
+    final_linear_engine = os.environ.get("NFA_K7_ENGINE", "bf16x3")
 
     def _packed_final_linear(self, layer):
-        key = (layer.weight.data_ptr(), layer.weight._version, layer.bias.data_ptr(), layer.bias._version)
+        split = self.final_linear_engine == "bf16x3"
+        key = (layer.weight.data_ptr(), layer.weight._version, layer.bias.data_ptr(), layer.bias._version,
+               split)
         cached = getattr(self, "_packed_cache", None)
         if cached is None or cached[0] != key:
             cached = (key, ops.pack_final_linear(layer.weight, layer.bias, self.num_transform_features,
-                                                 self._transform_dim_multiplier()))
+                                                 self._transform_dim_multiplier(), split_bf16=split))
             self._packed_cache = cached
         return cached[1]
 
@@ -263,14 +269,15 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
                     and self.num_bins == 8 and hasattr(net, "hidden") and isinstance(final, torch.nn.Linear)
                     and final.bias is not None and final.in_features == 128
                     and getattr(net, "hidden_features", None) == 128 and dt % 4 == 0 and dt <= 64
-                    and self.features <= 128 and inputs.shape[0] >= 32)
+                    and self.features <= 128 and inputs.shape[0] >= 128)
         if not eligible:
             return super()._condition_and_transform(inputs, identity_split, context, inverse, in_perm,
                                                     out_scatter, accumulate_into)
         hidden = net.hidden(identity_split, context)
         wp, bp = self._packed_final_linear(final)
         B = inputs.shape[0]
-        full = (B // 32) * 32
+        rows = 128 if wp.dtype == torch.bfloat16 else 32  # rows per workgroup / per wave
+        full = (B // rows) * rows
         spec = self._spec()
         if full == B:
             res = ops.rqs_coupling_fused_linear(inputs, hidden, wp, bp, self.transform_features, spec,
@@ -279,7 +286,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
                 return res
             return self._fused_layer(inputs, final(hidden), inverse, in_perm=in_perm,
                                      out_scatter=out_scatter, accumulate_into=accumulate_into)
-        # ragged batch: the multiple-of-32 head through K7, the tail through GEMM + K1
+        # ragged batch: the full row blocks through K7, the tail through GEMM + K1
         acc_head = None if accumulate_into is None else accumulate_into[:full]
         acc_tail = None if accumulate_into is None else accumulate_into[full:]
         head = ops.rqs_coupling_fused_linear(inputs[:full], hidden[:full], wp, bp, self.transform_features,
