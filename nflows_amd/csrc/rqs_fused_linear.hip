@@ -304,10 +304,20 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_bf16_kernel(const 
         for (int i = 0; i < 6; ++i) s_w[tid + i * kBlock] = w[i];
     }
     __syncthreads();
+#ifdef NFA_K7B_STAGGER
+    // experiment: offset the second workgroup resident on a CU by about half a group period so
+    // that its MFMA phases meet the other workgroup's spline (VALU) phases
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(NFA_K7B_STAGGER);
+#endif
     int it = 0;  // running tile counter: parity selects the LDS buffer holding the current tile
 
+    unsigned long long* tr = nullptr;  // debug trace (tools/k7_trace.py)
+    int ti = 0;
+    if (a.trace && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 256))
+        tr = a.trace + (blockIdx.x ? 256 : 0);
     for (int64_t quad = blockIdx.x; quad < num_quads; quad += gridDim.x) {
         const int64_t row0 = (quad << 7) + (wave << 5);
+        NFA_STAMP()
         // ---- hidden^T, split into bf16 pieces: lane (sample r, half) covers k = half*64 + ks*8 + 0..7
         bf16x8 bh[8], bm[8], bl[8];
         {
@@ -327,6 +337,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_bf16_kernel(const 
         }
         float lad_acc = 0.0f;
         const vec4f* bias_lane = reinterpret_cast<const vec4f*>(a.bpad) + half * 4;
+        NFA_STAMP()
 
         for (int g = 0; g < groups; ++g) {
             const float xin0 = a.x[(row0 + r) * D + s_tsrc[g * 4 + half * 2]];
@@ -355,11 +366,17 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_bf16_kernel(const 
                 for (int i = 0; i < 6; ++i) wnext[i] = wn[tid + i * kBlock];
 
                 const vec4f* cur = s_w + (it & 1) * kWTileVec4 + lane;
+#ifndef NFA_K7_NOMFMA
+                bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(0 * 8) * 64]);
+                bf16x8 am = __builtin_bit_cast(bf16x8, cur[(1 * 8) * 64]);
+                bf16x8 al = __builtin_bit_cast(bf16x8, cur[(2 * 8) * 64]);
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(0 * 8 + ks) * 64]);
-                    const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(1 * 8 + ks) * 64]);
-                    const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(2 * 8 + ks) * 64]);
+                    // the next k-step's weight fragments are requested before this step's MFMAs
+                    const int kn = ks < 7 ? ks + 1 : 7;
+                    const bf16x8 nh = __builtin_bit_cast(bf16x8, cur[(0 * 8 + kn) * 64]);
+                    const bf16x8 nm = __builtin_bit_cast(bf16x8, cur[(1 * 8 + kn) * 64]);
+                    const bf16x8 nl = __builtin_bit_cast(bf16x8, cur[(2 * 8 + kn) * 64]);
                     // smallest products first
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], acc[t], 0, 0, 0);
@@ -367,34 +384,59 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_bf16_kernel(const 
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[ks], acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[ks], acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], acc[t], 0, 0, 0);
+                    ah = nh;
+                    am = nm;
+                    al = nl;
                 }
+#else
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    acc[t][ks] += cur[ks * 64].x + __builtin_bit_cast(vec4f, bh[ks]).x + __builtin_bit_cast(vec4f, bm[ks]).y + __builtin_bit_cast(vec4f, bl[ks]).z;
+#endif
+                NFA_STAMP()
                 vec4f* nxt = s_w + ((it + 1) & 1) * kWTileVec4;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) nxt[tid + i * kBlock] = wnext[i];
                 __syncthreads();
                 ++it;
+                NFA_STAMP()
             }
             {
-                NFA_K7_FEATURE_A(p, acc[0], acc[1]);
-                float y, l;
-                my_status |= rqs_eval<8, INVERSE, true, true>(xin0, p, a.sp, y, l);
-                s_y[r * ystride + g * 4 + half * 2] = y;
-                lad_acc += l;
+                NFA_K7_FEATURE_A(pa, acc[0], acc[1]);
+                NFA_K7_FEATURE_B(pb, acc[1], acc[2]);
+                float y0, l0, y1, l1;
+#ifdef NFA_K7_NOSPLINE
+                y0 = xin0 + pa[0] + pa[23]; l0 = pa[8] + pa[16];
+                y1 = xin1 + pb[0] + pb[23]; l1 = pb[8] + pb[16];
+#else
+                my_status |= rqs_eval_flat8<INVERSE>(xin0, pa, a.sp, y0, l0);
+                my_status |= rqs_eval_flat8<INVERSE>(xin1, pb, a.sp, y1, l1);
+#endif
+                s_y[r * ystride + g * 4 + half * 2] = y0;
+                s_y[r * ystride + g * 4 + half * 2 + 1] = y1;
+                lad_acc += l0;
+                lad_acc += l1;
             }
-            {
-                NFA_K7_FEATURE_B(p, acc[1], acc[2]);
-                float y, l;
-                my_status |= rqs_eval<8, INVERSE, true, true>(xin1, p, a.sp, y, l);
-                s_y[r * ystride + g * 4 + half * 2 + 1] = y;
-                lad_acc += l;
-            }
+            NFA_STAMP()
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        for (int e = lane; e < 32 * D; e += kWave) {
-            const int rr = (int)fastdiv((uint32_t)e, a.div_D);
-            const int pcol = e - rr * D;
-            const int c = s_dinv[pcol];
-            a.out[(row0 + rr) * D + pcol] = s_ist[c] ? s_y[rr * ystride + s_slot[c]] : a.x[(row0 + rr) * D + s_src[c]];
+        for (int e0 = lane; e0 < 32 * D; e0 += kWave * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {  // all eight gathers in flight before the first store
+                const int e = e0 + u * kWave;
+                v[u] = 0.0f;
+                if (e < 32 * D) {
+                    const int rr = (int)fastdiv((uint32_t)e, a.div_D);
+                    const int c = s_dinv[e - rr * D];
+                    v[u] = s_ist[c] ? s_y[rr * ystride + s_slot[c]] : a.x[(row0 + rr) * D + s_src[c]];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * kWave;
+                if (e < 32 * D) a.out[row0 * D + e] = v[u];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         lad_acc += __shfl_xor(lad_acc, 32, kWave);
@@ -402,6 +444,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_bf16_kernel(const 
             float* dst = a.lad + row0 + r;
             *dst = a.accumulate ? *dst + lad_acc : lad_acc;
         }
+        NFA_STAMP()
     }
     if (my_status && a.status) atomicOr(a.status, my_status);
 }

@@ -303,6 +303,46 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
     return rqs_bin_eval<INVERSE>(x, cw0, cw1, ch0, ch1, d0, d1, y, lad);
 }
 
+// Branch-free form of rqs_eval<8, INVERSE, LINEAR = true, REGS = true>: same arithmetic, same
+// results, but the tail / not-found cases are selected at the end instead of returning early, so
+// that two independent evaluations placed back to back form one basic block and the scheduler
+// can interleave their dependent chains (K7: a lane evaluates two features per group).
+template <bool INVERSE>
+__device__ __forceinline__ int rqs_eval_flat8(float x, const float* sl, const RqsDev& sp, float& y, float& lad) {
+#pragma clang fp contract(off)
+    constexpr int KT = 8;
+    const float right = sp.right, left = -sp.right;
+    const bool inside = (x >= left && x <= right);  // NaN is outside
+    Slots<KT> ew, eh;
+    const float den_w = softmax_numerators<KT>(ew, sl, KT, sp.divisor, sp.rdivisor);
+    const float den_h = softmax_numerators<KT>(eh, sl + KT, KT, sp.divisor, sp.rdivisor);
+    int k = -1;
+    float cw0 = 0.f, cw1 = 0.f, ch0 = 0.f, ch1 = 0.f;
+    if (INVERSE) {
+        walk_bins<KT, true>(eh, KT, den_h, sp.min_h, sp.om_h, sp.span_w, left, right, x, k, ch0, ch1);
+        walk_bins<KT, false>(ew, KT, den_w, sp.min_w, sp.om_w, sp.span_w, left, right, x, k, cw0, cw1);
+    } else {
+        walk_bins<KT, true>(ew, KT, den_w, sp.min_w, sp.om_w, sp.span_w, left, right, x, k, cw0, cw1);
+        walk_bins<KT, false>(eh, KT, den_h, sp.min_h, sp.om_h, sp.span_w, left, right, x, k, ch0, ch1);
+    }
+    const bool found = (k >= 0) && !(x >= sp.right_eps);
+    const float* sd = sl + 2 * KT;
+    float u0 = sp.tail_logit, u1 = sp.tail_logit;
+#pragma unroll
+    for (int q = 0; q < KT - 1; ++q) {
+        u0 = (k == q + 1) ? sd[q] : u0;
+        u1 = (k == q) ? sd[q] : u1;
+    }
+    const float d0 = sp.min_d + softplus_beta(u0, sp.beta);
+    const float d1 = sp.min_d + softplus_beta(u1, sp.beta);
+    float ye, le;
+    const int st = rqs_bin_eval<INVERSE>(x, cw0, cw1, ch0, ch1, d0, d1, ye, le);
+    const bool valid = inside && found;
+    y = valid ? ye : x;
+    lad = valid ? le : 0.0f;
+    return inside ? (found ? st : NFA_STATUS_OUTSIDE_DOMAIN) : 0;
+}
+
 
 // host side: nfa_rqs_spec (doubles, as the reference's Python floats) -> fp32 device constants,
 // rounded exactly where aten rounds them

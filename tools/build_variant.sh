@@ -1,10 +1,17 @@
 #!/bin/bash
-# tools/build_variant.sh <name> [extra hipcc flags...]  -> build_variants/<name>.so (experiments only)
+# tools/build_variant.sh <name> <source.hip> [extra hipcc flags...]  -> build_variants/<name>.so
+# (experiments only: one source of nflows_amd/csrc recompiled with extra -D flags, linked with the
+# regular objects; select it at run time with NFLOWS_AMD_LIB=build_variants/<name>.so)
 set -e
 R=/root/repo
-N=$1; shift
+N=$1; SRC=$2; shift; shift
 mkdir -p $R/build_variants
-HF="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -I$R/include -I$R/nflows_amd/csrc"
-/opt/rocm/bin/hipcc $HF "$@" -c $R/nflows_amd/csrc/rqs.hip -o /tmp/rqs_$N.o 2>/tmp/build_$N.log || { tail -5 /tmp/build_$N.log; exit 1; }
-[ -f $R/nflows_amd/csrc/misc.o ] || make -C $R/nflows_amd/csrc -s
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_variants/$N.so /tmp/rqs_$N.o $R/nflows_amd/csrc/misc.o $R/nflows_amd/csrc/rqs_bwd.o
+HF="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -I$R/include -I$R/nflows_amd/csrc"
+make -C $R/nflows_amd/csrc -s
+/opt/rocm/bin/hipcc $HF "$@" -c $R/nflows_amd/csrc/$SRC -o /tmp/var_$N.o 2>/tmp/build_$N.log || { tail -5 /tmp/build_$N.log; exit 1; }
+OBJS=""
+for f in rqs rqs_bwd rqs_shared rqs_fused_linear misc; do
+  if [ "$f.hip" == "$SRC" ]; then OBJS="$OBJS /tmp/var_$N.o"; else OBJS="$OBJS $R/nflows_amd/csrc/$f.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_variants/$N.so $OBJS
+echo built $R/build_variants/$N.so
