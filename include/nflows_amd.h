@@ -172,6 +172,39 @@ int nfa_rqs_coupling_fused_linear_f32(const float *inputs, const float *hidden,
                                       const nfa_rqs_spec *spec, int32_t flags, void *stream);
 
 /*
+ * K8.  A whole neural-spline coupling layer: the ResidualNet conditioner (nn/nets/resnet.py:55-100:
+ * initial_layer, num_blocks x ResidualBlock (ReLU, no batch norm / dropout / context),
+ * final_layer) computed inside the kernel on the bf16 matrix pipe at fp32 accuracy (split-bf16
+ * operands, see NFA_FLAG_WEIGHTS_BF16X3), followed by everything nfa_rqs_coupling_f32 replaces.
+ * Activations and spline parameters never leave the register file; HBM traffic is inputs +
+ * outputs + logabsdet.
+ *   identity_idx   int64 [d_i]  CouplingTransform.identity_features (coupling.py:44-56): the
+ *                  conditioner's input columns, in its input order (seen through in_perm)
+ *   weights_packed bf16, [stages][1536 x 8]: 24 KB stages in consumption order --
+ *                  stage 0: initial_layer [2 k-steps][4 tiles][3 pieces][64 lanes][8], lane l
+ *                    element j = piece of W[32*tile + (l&31)][16*ks + 8*(l>>5) + j] (columns
+ *                    >= d_i zero);
+ *                  then for every block, for linear_layers[0] and [1], 4 stages
+ *                    [2 k-steps (ks = 2*stage + kk)][4 tiles][3 pieces][64 lanes][8] with
+ *                    element j = piece of W[32*tile + (l&31)][col(ks, l>>5, j)],
+ *                    col(ks, hf, j) = 32*(ks/2) + 16*(ks%2) + 8*(j/4) + 4*hf + j%4;
+ *                  then final_layer, one stage per 32-row tile, [3 pieces][8 k-steps][64 lanes][8],
+ *                    rows as in K7 (padded / reordered), columns col(ks, l>>5, j).
+ *   bias_packed    float: initial_layer [4 tiles][2 lane-halves][16], every hidden Linear the
+ *                  same, final_layer [tiles][2][16] (rows as in K7)
+ * Supported: num_bins = 8, linear tails, hidden_features = 128, d_i <= 32, d_t % 4 == 0,
+ * d_t <= 64, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
+ */
+int nfa_rqs_coupling_resnet_f32(const float *inputs, const void *weights_packed,
+                                const float *bias_packed, const int64_t *transform_idx,
+                                const int64_t *identity_idx, const int64_t *in_perm,
+                                const int64_t *out_scatter, float *outputs, float *logabsdet,
+                                int32_t *status, int64_t batch, int32_t features,
+                                int32_t num_transform, int32_t num_identity,
+                                int32_t hidden_features, int32_t num_blocks,
+                                const nfa_rqs_spec *spec, int32_t flags, void *stream);
+
+/*
  * K5.  Elementwise rational-quadratic functional (no row-sum):
  *   unconstrained_rational_quadratic_spline / rational_quadratic_spline,
  *   splines/rational_quadratic.py:13-63 / :66-181, as called from

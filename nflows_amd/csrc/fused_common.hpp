@@ -1,0 +1,123 @@
+// Pieces shared by the kernels that compute conditioner GEMMs on the matrix cores inside the
+// spline coupling kernel (rqs_fused_linear.hip: K7 / K7b, rqs_resnet.hip: K8).
+#pragma once
+
+#include "rqs_math.hpp"
+
+namespace nfa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float vec4f __attribute__((ext_vector_type(4)));
+
+// Lane-private view of one feature's 24 (23 + pad) logits inside the three accumulators of a group:
+// a lane's 48 accumulator registers are, in order, the logits of its two features (the host packs
+// the weight rows so; see pack order in include/nflows_amd.h).
+#define NFA_K7_FEATURE_A(p, a0, a1)                                                   \
+    float p[24] = {a0[0], a0[1], a0[2],  a0[3],  a0[4],  a0[5],  a0[6],  a0[7],       \
+                   a0[8], a0[9], a0[10], a0[11], a0[12], a0[13], a0[14], a0[15],      \
+                   a1[0], a1[1], a1[2],  a1[3],  a1[4],  a1[5],  a1[6],  a1[7]}
+#define NFA_K7_FEATURE_B(p, a1, a2)                                                   \
+    float p[24] = {a1[8], a1[9], a1[10], a1[11], a1[12], a1[13], a1[14], a1[15],      \
+                   a2[0], a2[1], a2[2],  a2[3],  a2[4],  a2[5],  a2[6],  a2[7],       \
+                   a2[8], a2[9], a2[10], a2[11], a2[12], a2[13], a2[14], a2[15]}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float vec2f __attribute__((ext_vector_type(2)));
+
+constexpr int kWTileVec4 = 3 * 8 * 64;  // one weight tile: [piece][k-step][lane] x 16 bytes
+
+__device__ __forceinline__ void split3(vec2f v, bf16x2& hi, bf16x2& mid, bf16x2& lo) {
+    hi = __builtin_convertvector(v, bf16x2);
+    const vec2f r1 = v - __builtin_convertvector(hi, vec2f);
+    mid = __builtin_convertvector(r1, bf16x2);
+    const vec2f r2 = r1 - __builtin_convertvector(mid, vec2f);
+    lo = __builtin_convertvector(r2, bf16x2);
+}
+
+__device__ __forceinline__ bf16x8 join4(bf16x2 a, bf16x2 b, bf16x2 c, bf16x2 d) {
+    return bf16x8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+
+// Column bookkeeping of one coupling layer with its neighbouring permutations folded in, built
+// once per workgroup in LDS.  Layer column c is read from input column src[c] and written to
+// output position dst[c]; dinv is the inverse of dst.
+struct LayerTables {
+    int dinv[128];   // layer column stored at output position p
+    int slot[128];   // index of a transformed column in transform_idx
+    int src[128], dst[128];
+    int tsrc[64];    // input column of transformed feature f
+    int isrc[64];    // input column of identity feature i (K8 only)
+    unsigned char ist[128];  // 1: column is transformed
+};
+
+// Returns status bits (NFA_STATUS_BAD_INDEX).  Ends with a workgroup barrier.
+__device__ __forceinline__ int build_layer_tables(LayerTables& t, const int64_t* perm, const int64_t* scatter,
+                                                  const int64_t* tidx, const int64_t* iidx, int D, int dt,
+                                                  int di, int tid, int nthreads) {
+    int st = 0;
+    for (int c = tid; c < D; c += nthreads) {
+        int src = c, dst = c;
+        if (perm) {
+            const int64_t p = perm[c];
+            if (p < 0 || p >= D) st |= NFA_STATUS_BAD_INDEX;
+            src = (int)(p < 0 ? 0 : (p >= D ? D - 1 : p));
+        }
+        if (scatter) {
+            const int64_t p = scatter[c];
+            if (p < 0 || p >= D) st |= NFA_STATUS_BAD_INDEX;
+            dst = (int)(p < 0 ? 0 : (p >= D ? D - 1 : p));
+        }
+        t.src[c] = src;
+        t.dst[c] = dst;
+        t.ist[c] = 0;
+        t.slot[c] = 0;
+    }
+    __syncthreads();
+    for (int c = tid; c < D; c += nthreads) t.dinv[t.dst[c]] = c;
+    if (tid < dt) {
+        const int64_t v = tidx[tid];
+        if (v < 0 || v >= D) st |= NFA_STATUS_BAD_INDEX;
+        const int col = (int)(v < 0 ? 0 : (v >= D ? D - 1 : v));
+        t.tsrc[tid] = t.src[col];
+        t.ist[col] = 1;
+        t.slot[col] = tid;
+    }
+    if (iidx && tid < di) {
+        const int64_t v = iidx[tid];
+        if (v < 0 || v >= D) st |= NFA_STATUS_BAD_INDEX;
+        t.isrc[tid] = t.src[(int)(v < 0 ? 0 : (v >= D ? D - 1 : v))];
+    }
+    __syncthreads();
+    return st;
+}
+
+// One wave writes its 32 output rows contiguously: position p holds layer column c = dinv[p];
+// transformed columns come from the wave's LDS y tile, the others are copied bit-exactly from the
+// inputs (gathered through the fused permutation).  Eight gathers are in flight per store batch.
+__device__ __forceinline__ void assemble_rows(const LayerTables& t, const float* s_y, int ystride,
+                                              const float* x, float* out, int64_t row0, int D,
+                                              FastDiv div_D, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (int e0 = lane; e0 < 32 * D; e0 += kWave * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * kWave;
+            v[u] = 0.0f;
+            if (e < 32 * D) {
+                const int rr = (int)fastdiv((uint32_t)e, div_D);
+                const int c = t.dinv[e - rr * D];
+                v[u] = t.ist[c] ? s_y[rr * ystride + t.slot[c]] : x[(row0 + rr) * D + t.src[c]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * kWave;
+            if (e < 32 * D) out[row0 * D + e] = v[u];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+}  // namespace nfa

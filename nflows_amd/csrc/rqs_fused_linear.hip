@@ -17,7 +17,7 @@
 // linear tails (P = 23), hidden width 128, d_t a multiple of 4, batch a multiple of 32 handled
 // here (leftover rows go through the unfused path).
 
-#include "rqs_math.hpp"
+#include "fused_common.hpp"
 
 #include <hip/hip_ext.h>
 #include <stdlib.h>
@@ -27,9 +27,6 @@
 #endif
 
 namespace nfa {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float vec4f __attribute__((ext_vector_type(4)));
 
 constexpr int kH = 128;        // hidden width (GEMM K dimension)
 
@@ -50,18 +47,6 @@ struct FusedArgs {
     RqsDev sp;
     unsigned long long* trace;  // debug: per-phase timestamps of a few waves (null normally)
 };
-
-// Lane-private view of one feature's 24 (23 + pad) logits inside the three accumulators of a group:
-// a lane's 48 accumulator registers are, in order, the logits of its two features (the host packs
-// the weight rows so; see pack order in include/nflows_amd.h).
-#define NFA_K7_FEATURE_A(p, a0, a1)                                                   \
-    float p[24] = {a0[0], a0[1], a0[2],  a0[3],  a0[4],  a0[5],  a0[6],  a0[7],       \
-                   a0[8], a0[9], a0[10], a0[11], a0[12], a0[13], a0[14], a0[15],      \
-                   a1[0], a1[1], a1[2],  a1[3],  a1[4],  a1[5],  a1[6],  a1[7]}
-#define NFA_K7_FEATURE_B(p, a1, a2)                                                   \
-    float p[24] = {a1[8], a1[9], a1[10], a1[11], a1[12], a1[13], a1[14], a1[15],      \
-                   a2[0], a2[1], a2[2],  a2[3],  a2[4],  a2[5],  a2[6],  a2[7],       \
-                   a2[8], a2[9], a2[10], a2[11], a2[12], a2[13], a2[14], a2[15]}
 
 template <bool INVERSE>
 __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_kernel(const FusedArgs a) {
@@ -231,24 +216,6 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_kernel(const Fused
 // unlike the f32 MFMA it does not occupy the VALU that the spline arithmetic needs.
 // The weight pieces (host-split, 24 KB per 32-row tile) are shared by the four waves of a
 // workgroup through a double-buffered LDS tile; the activations are split once per row tile.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float vec2f __attribute__((ext_vector_type(2)));
-
-constexpr int kWTileVec4 = 3 * 8 * 64;  // one weight tile: [piece][k-step][lane] x 16 bytes
-
-__device__ __forceinline__ void split3(vec2f v, bf16x2& hi, bf16x2& mid, bf16x2& lo) {
-    hi = __builtin_convertvector(v, bf16x2);
-    const vec2f r1 = v - __builtin_convertvector(hi, vec2f);
-    mid = __builtin_convertvector(r1, bf16x2);
-    const vec2f r2 = r1 - __builtin_convertvector(mid, vec2f);
-    lo = __builtin_convertvector(r2, bf16x2);
-}
-
-__device__ __forceinline__ bf16x8 join4(bf16x2 a, bf16x2 b, bf16x2 c, bf16x2 d) {
-    return bf16x8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
-}
-
 template <bool INVERSE>
 __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_bf16_kernel(const FusedArgs a) {
     // dynamic LDS: two weight tiles, then per wave a [32][dt|1] tile of transformed outputs

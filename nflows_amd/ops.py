@@ -486,6 +486,86 @@ def pack_final_linear(weight, bias, num_transform, params_per_feature, split_bf1
     return wp, bp
 
 
+def _k8_column_order():
+    """Input feature consumed at (k-step ks, lane-half hf, element j) of a GEMM whose input is the
+    previous layer's accumulator tiles: tile ks//2, register 8*(ks%2) + j of lane-half hf holds
+    feature 32*(ks//2) + 16*(ks%2) + 8*(j//4) + 4*hf + j%4 (MFMA 32x32 C/D layout)."""
+    ks = torch.arange(8)[:, None, None]
+    hf = torch.arange(2)[None, :, None]
+    j = torch.arange(8)[None, None, :]
+    return (32 * (ks // 2) + 16 * (ks % 2) + 8 * (j // 4) + 4 * hf + j % 4).reshape(-1)  # [ks][hf][j]
+
+
+def _bias_accumulator_order(b):
+    """[tiles*32] -> [tiles][2 lane-halves][16]: row i of a tile sits in accumulator register
+    q = 4*(i//8) + i%4 of lane-half (i//4)%2."""
+    return b.view(-1, 4, 2, 4).permute(0, 2, 1, 3).reshape(-1)
+
+
+def pack_resnet_conditioner(net, num_transform, params_per_feature):
+    """Packs a ResidualNet (initial_layer, blocks[*].linear_layers[0,1], final_layer) for K8
+    (layout in include/nflows_amd.h): every weight as split-bf16 triples in 24 KB stages, in the
+    order the kernel consumes them, and all biases in accumulator order.  Returns (weights
+    [stages, 1536*8] bf16, biases [128 + 256*num_blocks + d_t*24] fp32)."""
+    dt, P = num_transform, params_per_feature
+    dev = net.final_layer.weight.device
+    order_k = _k8_column_order().to(dev)
+
+    def pieces(w):
+        return torch.stack(split_bf16x3(w))  # [3, ...]
+
+    stages, biases = [], []
+    wi = net.initial_layer.weight.detach().float()
+    di = wi.shape[1]
+    wi = torch.cat((wi, wi.new_zeros(128, 32 - di)), dim=1)  # k = kk*16 + hf*8 + j
+    # (p, t, i, kk, hf, j) -> (kk, t, p, hf, i, j)
+    stages.append(pieces(wi).view(3, 4, 32, 2, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(1, -1))
+    biases.append(_bias_accumulator_order(net.initial_layer.bias.detach().float()))
+    for block in net.blocks:
+        for lin in block.linear_layers:
+            w = lin.weight.detach().float().index_select(1, order_k)  # columns in (ks, hf, j) order
+            # (p, t, i, s, kk, hf, j) -> (s, kk, t, p, hf, i, j): stage s holds k-steps 2s, 2s+1
+            stages.append(pieces(w).view(3, 4, 32, 4, 2, 2, 8).permute(3, 4, 1, 0, 5, 2, 6).reshape(4, -1))
+            biases.append(_bias_accumulator_order(lin.bias.detach().float()))
+    order_r = _k7_row_order(dt).to(dev)
+    wf = net.final_layer.weight.detach().float().view(dt, P, 128)
+    wf = torch.cat((wf, wf.new_zeros(dt, 24 - P, 128)), dim=1).reshape(dt * 24, 128)
+    wf = wf.index_select(0, order_r).index_select(1, order_k)
+    bf = torch.cat((net.final_layer.bias.detach().float().view(dt, P),
+                    wf.new_zeros(dt, 24 - P)), dim=1).reshape(dt * 24).index_select(0, order_r)
+    tiles = dt * 24 // 32
+    # (p, tile, i, ks, hf, j) -> (tile, p, ks, hf, i, j)
+    stages.append(pieces(wf).view(3, tiles, 32, 8, 2, 8).permute(1, 0, 3, 4, 2, 5).reshape(tiles, -1))
+    biases.append(_bias_accumulator_order(bf))
+    return torch.cat(stages, dim=0).contiguous(), torch.cat(biases).contiguous()
+
+
+def rqs_coupling_resnet(inputs, weights_packed, bias_packed, transform_idx, identity_idx, num_blocks, spec,
+                        inverse=False, in_perm=None, out_scatter=None, accumulate_into=None):
+    """K8 -- ResidualNet conditioner + spline coupling layer in one kernel.  Returns None when the
+    shape is outside the fast path."""
+    N.require_device_f32("inputs", inputs, 2)
+    dev = inputs.device
+    B, D = inputs.shape
+    tidx = _idx("transform_features", transform_idx, dev)
+    iidx = _idx("identity_features", identity_idx, dev)
+    perm = _idx("in_perm", in_perm, dev, D)
+    scat = _idx("out_scatter", out_scatter, dev, D)
+    x = inputs.detach().contiguous()
+    out = torch.empty_like(x)
+    lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_rqs_coupling_resnet_f32(
+            N.ptr(x), N.ptr(weights_packed), N.ptr(bias_packed), N.ptr(tidx), N.ptr(iidx), N.ptr(perm),
+            N.ptr(scat), N.ptr(out), N.ptr(lad), N.ptr(_status_word(dev)), B, D, tidx.numel(),
+            iidx.numel(), 128, num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))
+    if rc == N.ERR_UNSUPPORTED:
+        return None
+    N.check(rc)
+    _after_spline(spec, inverse, dev)
+    return out, lad
+
+
 def rqs_coupling_fused_linear(inputs, hidden, weight_packed, bias_padded, transform_idx, spec,
                               inverse=False, in_perm=None, out_scatter=None, accumulate_into=None):
     """K7 -- final Linear of the conditioner + spline coupling layer in one kernel.  Returns None

@@ -93,6 +93,10 @@ class CouplingTransform(Transform):
         `logabsdet_accumulator`: a [batch] running total the layer's logabsdet is added to in the
         kernel (CompositeTransform's `total_logabsdet +=`); it is then also the returned tensor."""
         self._check_inputs(inputs)
+        if self.unconditional_transform is None:
+            whole = self._whole_layer(inputs, context, False, in_perm, None, logabsdet_accumulator)
+            if whole is not None:
+                return whole
         identity_split = inputs.index_select(1, self._identity_columns(in_perm))
         outputs, logabsdet = self._condition_and_transform(
             inputs, identity_split, context, inverse=False, in_perm=in_perm,
@@ -110,6 +114,10 @@ class CouplingTransform(Transform):
         """Inverse pass (coupling.py:102-130).  `out_scatter`: store layer column c at
         outputs[:, out_scatter[c]] (a following Permutation.inverse, fused)."""
         self._check_inputs(inputs)
+        if self.unconditional_transform is None:
+            whole = self._whole_layer(inputs, context, True, None, out_scatter, logabsdet_accumulator)
+            if whole is not None:
+                return whole
         identity_split = inputs.index_select(1, self.identity_features)
         logabsdet_identity = None
         if self.unconditional_transform is not None:
@@ -124,6 +132,10 @@ class CouplingTransform(Transform):
                 logabsdet = logabsdet + logabsdet_identity
             outputs.index_copy_(1, self._identity_columns(out_scatter), identity_split)
         return outputs, logabsdet
+
+    def _whole_layer(self, inputs, context, inverse, in_perm, out_scatter, accumulate_into):
+        """Hook for a kernel that contains the conditioner as well; None = not applicable."""
+        return None
 
     def _condition_and_transform(self, inputs, identity_split, context, inverse, in_perm=None,
                                  out_scatter=None, accumulate_into=None):
@@ -248,6 +260,58 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
     # GEMM engine of K7: "bf16x3" = split-bf16 operands on the bf16 matrix pipe (fp32-accurate,
     # default), "f32" = v_mfma_f32_32x32x2_f32
     final_linear_engine = os.environ.get("NFA_K7_ENGINE", "bf16x3")
+
+    # K8: the whole ResidualNet conditioner inside the spline kernel (class-level switch)
+    fuse_conditioner = os.environ.get("NFA_K8", "1") != "0"
+
+    def _resnet_eligible(self, context):
+        net = self.transform_net
+        from ..nn.nets.resnet import ResidualNet
+        return (self.fuse_conditioner and self.fuse_final_linear and not torch.is_grad_enabled()
+                and context is None and type(net) is ResidualNet and net.context_features is None
+                and net.hidden_features == 128 and self.tails == "linear" and self.num_bins == 8
+                and self.num_identity_features <= 32 and self.num_transform_features % 4 == 0
+                and self.num_transform_features <= 64 and self.features <= 128
+                and all(b.activation is torch.nn.functional.relu and not b.use_batch_norm
+                        and (not b.training or b.dropout.p == 0.0) for b in net.blocks))
+
+    def _packed_resnet(self):
+        net = self.transform_net
+        key = tuple((p.data_ptr(), p._version) for p in net.parameters())
+        cached = getattr(self, "_packed_resnet_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, ops.pack_resnet_conditioner(net, self.num_transform_features,
+                                                       self._transform_dim_multiplier()))
+            self._packed_resnet_cache = cached
+        return cached[1]
+
+    def _whole_layer(self, inputs, context, inverse, in_perm, out_scatter, accumulate_into):
+        B = inputs.shape[0]
+        if B < 128 or not self._resnet_eligible(context):
+            return None
+        wp, bp = self._packed_resnet()
+        nb = len(self.transform_net.blocks)
+        spec = self._spec()
+        full = (B // 128) * 128
+        if full == B:
+            return ops.rqs_coupling_resnet(inputs, wp, bp, self.transform_features, self.identity_features,
+                                           nb, spec, inverse, in_perm, out_scatter, accumulate_into)
+        # ragged batch: full 128-row blocks here, the tail through the PyTorch conditioner + K1
+        acc_head = None if accumulate_into is None else accumulate_into[:full]
+        acc_tail = None if accumulate_into is None else accumulate_into[full:]
+        head = ops.rqs_coupling_resnet(inputs[:full], wp, bp, self.transform_features,
+                                       self.identity_features, nb, spec, inverse, in_perm, out_scatter,
+                                       acc_head)
+        if head is None:
+            return None
+        tail_in = inputs[full:]
+        cols = self._identity_columns(in_perm) if not inverse else self.identity_features
+        params = self.transform_net(tail_in.index_select(1, cols), None)
+        tail = self._fused_layer(tail_in, params, inverse, in_perm=in_perm, out_scatter=out_scatter,
+                                 accumulate_into=acc_tail)
+        outputs = torch.cat((head[0], tail[0]), dim=0)
+        logabsdet = accumulate_into if accumulate_into is not None else torch.cat((head[1], tail[1]), dim=0)
+        return outputs, logabsdet
 
     def _packed_final_linear(self, layer):
         split = self.final_linear_engine == "bf16x3"

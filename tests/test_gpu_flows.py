@@ -286,13 +286,29 @@ def test_conditional_flow_with_context():
         flow.log_prob(x, context=ctx[:10])
 
 
-@pytest.mark.parametrize("B", [32, 1000, 4096])
-def test_fused_final_linear_kernel_matches_gemm_plus_k1(B):
-    """K7 (final Linear folded into the spline kernel via fp32 MFMA) against the unfused path
-    (hipBLASLt GEMM + K1) and against the CPU eager port of the reference: same arithmetic up to
-    the GEMM's summation order."""
-    from nflows_amd import configs
+def _select_fused_path(path):
+    """k8: whole ResidualNet in the spline kernel; k7b / k7: only the final Linear (split-bf16 /
+    fp32 MFMA); none: PyTorch conditioner + K1."""
     from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    RQ.fuse_conditioner = path == "k8"
+    RQ.fuse_final_linear = path != "none"
+    RQ.final_linear_engine = "f32" if path == "k7" else "bf16x3"
+
+
+@pytest.fixture
+def restore_fused_path():
+    yield
+    _select_fused_path("k8")
+
+
+@pytest.mark.parametrize("path", ["k8", "k7b", "k7"])
+@pytest.mark.parametrize("B", [32, 1000, 4096])
+def test_fused_conditioner_kernels_match_gemm_plus_k1(B, path, restore_fused_path):
+    """K8 (whole ResidualNet conditioner inside the spline kernel, split-bf16 MFMA), K7b and K7
+    (final Linear only; split-bf16 / fp32 MFMA) against the unfused path (hipBLASLt GEMMs + K1)
+    and against the CPU eager port of the reference in float64: same arithmetic up to the GEMMs'
+    summation order."""
+    from nflows_amd import configs
     from oracle import eager
     import copy
     flow = configs.rq_nsf_flow(num_layers=3, features=64, num_bins=8, hidden_features=128, seed=5)
@@ -306,15 +322,14 @@ def test_fused_final_linear_kernel_matches_gemm_plus_k1(B):
     flow = flow.to(DEV).eval()
     x = torch.randn(B, 64, device=DEV)
     with torch.no_grad():
-        RQ.fuse_final_linear = True
+        _select_fused_path(path)
         z1, l1 = flow._transform(x)
         x1, li1 = flow._transform.inverse(x)
-        RQ.fuse_final_linear = False
+        lp = flow.log_prob(x)
+        _select_fused_path("none")
         z0, l0 = flow._transform(x)
         x0, li0 = flow._transform.inverse(x)
-        RQ.fuse_final_linear = True
         lp_ref64 = eager.flow_log_prob(cpu.double(), x.cpu().double())
-        lp = flow.log_prob(x)
     import nflows_amd
     nflows_amd.check_status()
     # (three sharpened layers amplify the GEMMs' different summation orders; the bulk agrees tightly)
@@ -322,3 +337,46 @@ def test_fused_final_linear_kernel_matches_gemm_plus_k1(B):
         d = (got - want).abs()
         assert d.max().item() < tol and d.median().item() < tol / 50
     assert (lp.cpu().double() - lp_ref64).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("features,blocks", [(16, 1), (24, 3), (64, 0), (128, 2)])
+def test_whole_layer_kernel_shapes(features, blocks, restore_fused_path):
+    """K8 on other layer geometries (d_i = d_t = 8 .. 64 -> d_i > 32 falls back), block counts,
+    ragged batches, NaN / out-of-range inputs: equal to the unfused path within the GEMM noise,
+    pass-through columns bit-exact, NaN pattern identical."""
+    from nflows_amd import configs
+    flow = configs.rq_nsf_flow(num_layers=2, features=features, num_bins=8, hidden_features=128,
+                               num_blocks=blocks, seed=11).to(DEV).eval()
+    with torch.no_grad():
+        for n_, p in flow.named_parameters():
+            if "final_layer" in n_:
+                p.mul_(3.0)
+            elif "linear_layers.1" in n_:
+                p.mul_(20.0)
+    x = torch.randn(128 * 3 + 37, features, device=DEV) * 1.5
+    x[5, 0] = float("nan")
+    x[6, 1] = 7.5
+    clean = torch.nan_to_num(x, nan=0.25)  # (NaN parameters trip the reference's discriminant assert)
+    with torch.no_grad():
+        _select_fused_path("k8")
+        z1, l1 = flow._transform(x)
+        x1, li1 = flow._transform.inverse(clean)
+        _select_fused_path("none")
+        z0, l0 = flow._transform(x)
+        x0, li0 = flow._transform.inverse(clean)
+    import nflows_amd
+    nflows_amd.check_status()
+    assert torch.isnan(z0).any()
+    for got, want, tol in ((z1, z0, 2e-4), (l1, l0, 5e-3), (x1, x0, 2e-4), (li1, li0, 5e-3)):
+        assert torch.equal(torch.isnan(got), torch.isnan(want))
+        ok = torch.isfinite(want)
+        d = (got[ok] - want[ok]).abs()
+        assert d.max().item() < tol and d.median().item() < tol / 50
+    layer = flow._transform._transforms[1]
+    ident = layer.identity_features
+    with torch.no_grad():
+        _select_fused_path("k8")
+        y, _ = layer(x)
+    assert torch.equal(y[:, ident].isnan(), x[:, ident].isnan())
+    keep = ~x[:, ident].isnan()
+    assert torch.equal(y[:, ident][keep], x[:, ident][keep])
