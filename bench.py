@@ -25,6 +25,7 @@ if ROOT not in sys.path:
 
 T_START = time.perf_counter()
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PFLOP/s headline includes sparsity)
 
 
 class EventHook:
@@ -128,6 +129,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=16384)
     ap.add_argument("--no-fuse", action="store_true", help="run permutations as separate kernels")
+    ap.add_argument("--path", choices=["k8", "k7b", "k7", "k1"], default="k8",
+                    help="layer kernel: k8 = whole ResidualNet conditioner + spline in one kernel "
+                         "(default), k7b / k7 = only the final Linear fused (split-bf16 / fp32 MFMA), "
+                         "k1 = PyTorch conditioner + spline kernel")
     ap.add_argument("--no-fuse-linear", action="store_true",
                     help="leave the conditioner's final Linear to hipBLASLt (GEMM + K1 instead of K7)")
     ap.add_argument("--skip-k1-roofline", action="store_true")
@@ -162,9 +167,16 @@ def main():
     import copy
     flow = copy.deepcopy(flow_cpu).to(dev)
     flow._transform.fuse_permutations = not args.no_fuse
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+
+    def select_path(path):
+        RQ.fuse_conditioner = path == "k8"
+        RQ.fuse_final_linear = path != "k1"
+        RQ.final_linear_engine = "f32" if path == "k7" else "bf16x3"
+
     if args.no_fuse_linear:
-        from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform
-        PiecewiseRationalQuadraticCouplingTransform.fuse_final_linear = False
+        args.path = "k1"
+    select_path(args.path)
     B = args.batch_per_gpu
     x = torch.randn(B, D, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
 
@@ -221,11 +233,12 @@ def main():
 
     if rank == 0:
         total_rows = B * world
-        from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
-        fused_linear = bool(RQ.fuse_final_linear) and not args.no_fuse_linear
         H_ = 128
         P_ = 3 * K - 1
-        k1_bytes = 4 * (B * D + B * (D // 2) * P_ + B * D + B)  # 3460 B/sample/layer
+        dt_ = D // 2
+        nb_ = 2
+        k1_bytes = 4 * (B * D + B * dt_ * P_ + B * D + B)  # 3460 B/sample/layer
+        io_bytes = 4 * (B * D + B * D + B)                 # inputs + outputs + logabsdet
 
         def load_traffic(name):
             try:
@@ -233,37 +246,50 @@ def main():
             except Exception:
                 return None
 
-        roofline = None
         timing_note = ("HIP start/stop events attached to each layer-kernel dispatch on its launch "
                        "stream (hipExtLaunchKernelGGL), all launches of the timed region")
-        if k1_ms and fused_linear:
-            # dominant kernel = K7: final Linear (fp32 MFMA) + spline layer in one launch.
-            # Bound: fp32 matrix/vector peak (on gfx950 the f32 MFMA runs at the VALU rate).
-            avg_ms, launches = sum(k1_ms) / len(k1_ms), len(k1_ms)
-            flops = 2.0 * B * H_ * (D // 2) * P_  # the Linear's FLOPs (padding columns not counted)
-            achieved = flops / (avg_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "nfa::rqs_fused_linear_kernel<false>",
-                        "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
-                        "traffic": load_traffic("k7_pmc_traffic.json"),
-                        "algorithmic_flops_per_launch": flops,
-                        "algorithmic_bytes_per_launch": 4 * (B * D + B * H_ + B * D + B),
-                        "avg_launch_ms": avg_ms, "launches_timed": launches, "timing": timing_note,
-                        "note": "157.3 TFLOP/s is the 2.4 GHz spec peak; a pure chain of "
-                                "v_mfma_f32_32x32x2_f32 sustains 121 TFLOP/s on this chip (DVFS, "
-                                "tools/mfma_probe.hip)"}
-        elif k1_ms:
-            avg_ms, launches = sum(k1_ms) / len(k1_ms), len(k1_ms)
-            achieved = k1_bytes / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "nfa::rqs_coupling_pipelined<8, false, true>",
-                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic("k1_pmc_traffic.json"),
-                        "algorithmic_bytes_per_launch": k1_bytes,
-                        "avg_launch_ms": avg_ms, "launches_timed": launches, "timing": timing_note}
+
+        def roofline_of(path, ms):
+            avg_ms, launches = sum(ms) / len(ms), len(ms)
+            common = {"avg_launch_ms": avg_ms, "launches_timed": launches, "timing": timing_note}
+            if path in ("k8", "k7b"):
+                # GEMMs on the bf16 matrix pipe with split-bf16 operands: 6 bf16 products per fp32
+                # multiply-add; flops of the unpadded layers
+                macs = dt_ * P_ * H_ + ((D - dt_) * H_ + nb_ * 2 * H_ * H_ if path == "k8" else 0)
+                flops = 6 * 2.0 * B * macs
+                ach = flops / (avg_ms * 1e-3) / 1e12
+                r = {"bound": "mfma",
+                     "kernel": "nfa::rqs_resnet_kernel<false>" if path == "k8" else "nfa::rqs_fused_linear_bf16_kernel<false>",
+                     "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
+                     "traffic": load_traffic("k8_pmc_traffic.json" if path == "k8" else "k7b_pmc_traffic.json"),
+                     "algorithmic_flops_per_launch": flops,
+                     "algorithmic_bytes_per_launch": io_bytes + (4 * B * H_ if path == "k7b" else 0),
+                     "fp32_equivalent_tflops": ach / 6,
+                     "note": "achieved = 6 x (fp32 multiply-adds of the layer's GEMMs) x 2 / time: every fp32 "
+                             "operand is three bf16 pieces and six cross products run on the bf16 pipe "
+                             "(fp32-accurate); peak = dense bf16 MFMA peak.  As fp32 GEMM work this is "
+                             "%.1f TFLOP/s (fp32 matrix peak: 157.3)" % (ach / 6)}
+            elif path == "k7":
+                flops = 2.0 * B * H_ * dt_ * P_
+                ach = flops / (avg_ms * 1e-3) / 1e12
+                r = {"bound": "mfma", "kernel": "nfa::rqs_fused_linear_kernel<false>", "achieved": ach,
+                     "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
+                     "traffic": load_traffic("k7_pmc_traffic.json"), "algorithmic_flops_per_launch": flops,
+                     "algorithmic_bytes_per_launch": io_bytes + 4 * B * H_}
+            else:
+                ach = k1_bytes / (avg_ms * 1e-3) / 1e9
+                r = {"bound": "hbm", "kernel": "nfa::rqs_coupling_pipelined<8, false, true>", "achieved": ach,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": load_traffic("k1_pmc_traffic.json"), "algorithmic_bytes_per_launch": k1_bytes}
+            r.update(common)
+            return r
+
+        roofline = roofline_of(args.path, k1_ms) if k1_ms else None
         roofline_k1 = None
-        if fused_linear and not args.skip_k1_roofline:
-            # the HBM-bound spline kernel K1 (what K7 replaces on this shape), measured the same way
-            # in a short separate run with the Linear left to hipBLASLt
-            RQ.fuse_final_linear = False
+        if args.path != "k1" and not args.skip_k1_roofline:
+            # the HBM-bound spline kernel K1 (what the fused kernels replace on this shape), measured
+            # the same way in a short separate run with the conditioner left to PyTorch / hipBLASLt
+            select_path("k1")
             try:
                 with torch.no_grad():
                     flow.log_prob(x)
@@ -275,16 +301,10 @@ def main():
                     ms = dispatch_durations_ms(args.layers * 3)
                     _native.check(_native.load().nfa_profile_enable(0))
             finally:
-                RQ.fuse_final_linear = True
+                select_path(args.path)
             if ms:
-                a_ms = sum(ms) / len(ms)
-                ach = k1_bytes / (a_ms * 1e-3) / 1e9
-                roofline_k1 = {"bound": "hbm", "kernel": "nfa::rqs_coupling_pipelined<8, false, true>",
-                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": load_traffic("k1_pmc_traffic.json"),
-                               "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_ms": a_ms,
-                               "launches_timed": len(ms),
-                               "note": "not in the timed region: GEMM + K1 path (fuse_final_linear=False)"}
+                roofline_k1 = roofline_of("k1", ms)
+                roofline_k1["note"] = "not in the timed region: PyTorch conditioner + K1 path (--path k1)"
         result = {
             "metric": "log_prob samples/sec (dim=64, K=8, 32-layer RQ-NSF) + max |fwd∘inv − x|",
             "value": total_rows * args.steps / elapsed,
@@ -304,7 +324,10 @@ def main():
                        "global_batch": total_rows, "features": D, "num_bins": K, "layers": args.layers,
                        "parallelism": "sample-sharded x%d" % world,
                        "fused_permutations": not args.no_fuse,
-                       "final_linear_fused_into_spline_kernel": not args.no_fuse_linear},
+                       "layer_kernel": {"k8": "K8: ResidualNet conditioner + spline layer in one kernel",
+                                        "k7b": "K7b: final Linear (split-bf16 MFMA) + spline layer",
+                                        "k7": "K7: final Linear (fp32 MFMA) + spline layer",
+                                        "k1": "PyTorch conditioner + K1 spline layer"}[args.path]},
             "fwd_inv_max_err": {"composite_%d_layers" % args.layers: err_composite, "single_layer": err_layer,
                                 "rows": 8192},
             "mean_log_likelihood": mean_ll,

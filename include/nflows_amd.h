@@ -56,6 +56,10 @@ extern "C" {
                                              holds split-bf16 triples (layout below); the GEMM
                                              then runs on the bf16 matrix pipe, fp32-accurate */
 
+#define NFA_FLAG_LOGITS_LOG2E 8           /* nfa_rqs_coupling_resnet_f32 only: the width / height
+                                             rows of the packed final layer carry an extra factor
+                                             log2(e), the kernel takes 2^x of their differences */
+
 /* tails */
 #define NFA_TAILS_NONE 0   /* rational_quadratic_spline: K+1 derivative logits per element */
 #define NFA_TAILS_LINEAR 1 /* unconstrained_rational_quadratic_spline(tails="linear"): K-1 */
@@ -176,31 +180,37 @@ int nfa_rqs_coupling_fused_linear_f32(const float *inputs, const float *hidden,
  * initial_layer, num_blocks x ResidualBlock (ReLU, no batch norm / dropout / context),
  * final_layer) computed inside the kernel on the bf16 matrix pipe at fp32 accuracy (split-bf16
  * operands, see NFA_FLAG_WEIGHTS_BF16X3), followed by everything nfa_rqs_coupling_f32 replaces.
- * Activations and spline parameters never leave the register file; HBM traffic is inputs +
- * outputs + logabsdet.
- *   identity_idx   int64 [d_i]  CouplingTransform.identity_features (coupling.py:44-56): the
- *                  conditioner's input columns, in its input order (seen through in_perm)
- *   weights_packed bf16, [stages][1536 x 8]: 24 KB stages in consumption order --
- *                  stage 0: initial_layer [2 k-steps][4 tiles][3 pieces][64 lanes][8], lane l
- *                    element j = piece of W[32*tile + (l&31)][16*ks + 8*(l>>5) + j] (columns
- *                    >= d_i zero);
- *                  then for every block, for linear_layers[0] and [1], 4 stages
- *                    [2 k-steps (ks = 2*stage + kk)][4 tiles][3 pieces][64 lanes][8] with
- *                    element j = piece of W[32*tile + (l&31)][col(ks, l>>5, j)],
+ * Activations and spline parameters never leave the register file; HBM traffic is one coalesced
+ * read of inputs and one coalesced write of outputs + logabsdet.
+ *   layer_tables   int32 [224], the layer's column bookkeeping with both neighbouring
+ *                  permutations folded in (layer column c is read from input column src[c] =
+ *                  in_perm[c] and stored at output position dst[c] = out_scatter[c]):
+ *                  [0, 128): output position of the layer column read from input column i;
+ *                  [128, 160): output position of identity feature i (identity_features,
+ *                  coupling.py:44-56, in the conditioner's input order);
+ *                  [160, 224): output position of transformed feature f (transform_features).
+ *                  Entries outside [0, features) set NFA_STATUS_BAD_INDEX.
+ *   weights_packed bf16, [stages][768 x 8]: 12 KB stages in consumption order --
+ *                  initial_layer, 2 stages (k-step ks = 0, 1): [4 tiles][3 pieces][64 lanes][8],
+ *                    lane l element j = piece of W[32*tile + (l&31)][16*ks + 8*(l>>5) + j]
+ *                    (columns >= d_i zero);
+ *                  for every block, linear_layers[0] then [1], 8 stages (ks = 0..7) of the same
+ *                    shape with element j = piece of W[32*tile + (l&31)][col(ks, l>>5, j)],
  *                    col(ks, hf, j) = 32*(ks/2) + 16*(ks%2) + 8*(j/4) + 4*hf + j%4;
- *                  then final_layer, one stage per 32-row tile, [3 pieces][8 k-steps][64 lanes][8],
- *                    rows as in K7 (padded / reordered), columns col(ks, l>>5, j).
+ *                  final_layer, two stages per 32-row tile (k-steps 4*s .. 4*s+3):
+ *                    [3 pieces][4 k-steps][64 lanes][8], rows as in K7 (padded / reordered),
+ *                    columns col(ks, l>>5, j); the rows of width and height logits (and their
+ *                    biases) multiplied by 1/sqrt(hidden_features) (coupling.py:554-556;
+ *                    spec->wh_divisor is ignored), and by log2(e) with NFA_FLAG_LOGITS_LOG2E.
  *   bias_packed    float: initial_layer [4 tiles][2 lane-halves][16], every hidden Linear the
  *                  same, final_layer [tiles][2][16] (rows as in K7)
  * Supported: num_bins = 8, linear tails, hidden_features = 128, d_i <= 32, d_t % 4 == 0,
- * d_t <= 64, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
+ * d_t <= 64, features % 4 == 0, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
  */
 int nfa_rqs_coupling_resnet_f32(const float *inputs, const void *weights_packed,
-                                const float *bias_packed, const int64_t *transform_idx,
-                                const int64_t *identity_idx, const int64_t *in_perm,
-                                const int64_t *out_scatter, float *outputs, float *logabsdet,
-                                int32_t *status, int64_t batch, int32_t features,
-                                int32_t num_transform, int32_t num_identity,
+                                const float *bias_packed, const int32_t *layer_tables,
+                                float *outputs, float *logabsdet, int32_t *status, int64_t batch,
+                                int32_t features, int32_t num_transform, int32_t num_identity,
                                 int32_t hidden_features, int32_t num_blocks,
                                 const nfa_rqs_spec *spec, int32_t flags, void *stream);
 

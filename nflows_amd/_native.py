@@ -25,7 +25,7 @@ STATUS_OUTSIDE_DOMAIN = 1
 STATUS_NEG_DISCRIMINANT = 2
 STATUS_BAD_INDEX = 4
 
-FLAG_INVERSE, FLAG_ACCUMULATE_LOGABSDET, FLAG_WEIGHTS_BF16X3 = 1, 2, 4
+FLAG_INVERSE, FLAG_ACCUMULATE_LOGABSDET, FLAG_WEIGHTS_BF16X3, FLAG_LOGITS_LOG2E = 1, 2, 4, 8
 TAILS_NONE, TAILS_LINEAR = 0, 1
 SCALE_DEFAULT, SCALE_GENERAL, SCALE_ADDITIVE, SCALE_GIVEN, SCALE_SOFTPLUS = 0, 1, 2, 3, 4
 
@@ -99,7 +99,7 @@ def _declare(lib):
     lib.nfa_rqs_coupling_fused_linear_f32.restype = ctypes.c_int
     lib.nfa_rqs_coupling_fused_linear_f32.argtypes = [vp] * 10 + [i64, i32, i32, i32, sp, i32, vp]
     lib.nfa_rqs_coupling_resnet_f32.restype = ctypes.c_int
-    lib.nfa_rqs_coupling_resnet_f32.argtypes = [vp] * 10 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
+    lib.nfa_rqs_coupling_resnet_f32.argtypes = [vp] * 7 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
     lib.nfa_rqs_elementwise_f32.restype = ctypes.c_int
     lib.nfa_rqs_elementwise_f32.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, i64, sp, i32, vp]
     lib.nfa_rqs_shared_f32.restype = ctypes.c_int

@@ -6,6 +6,11 @@
 
 namespace nfa {
 
+// debug aid (tools/k7_trace.py, tools/k8_trace.py): device buffer of 512 uint64 that lane 0 of
+// wave 0 of workgroups 0 and 256 fills with cycle-counter stamps at phase boundaries; null = off
+extern unsigned long long* g_k7_trace;
+#define NFA_STAMP() if (tr && ti < 250) tr[ti++] = __builtin_readcyclecounter();
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float vec4f __attribute__((ext_vector_type(4)));
 

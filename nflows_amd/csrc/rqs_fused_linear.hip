@@ -101,7 +101,6 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_kernel(const Fused
     int ti = 0;
     if (a.trace && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 256))
         tr = a.trace + (blockIdx.x ? 256 : 0);
-#define NFA_STAMP() if (tr && ti < 250) tr[ti++] = __builtin_readcyclecounter();
     for (int64_t tile = wave_global; tile < num_tiles; tile += nwaves) {
         const int64_t row0 = tile << 5;
         NFA_STAMP()
@@ -420,9 +419,9 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_bf16_kernel(const 
 
 using namespace nfa;
 
-static unsigned long long* g_k7_trace = nullptr;
+unsigned long long* nfa::g_k7_trace = nullptr;
 // debug aid (tools/k7_trace.py): device buffer of 512 uint64 receiving phase timestamps; NULL = off
-extern "C" void nfa_debug_k7_trace(void* device_buffer) { g_k7_trace = (unsigned long long*)device_buffer; }
+extern "C" void nfa_debug_k7_trace(void* device_buffer) { nfa::g_k7_trace = (unsigned long long*)device_buffer; }
 
 extern "C" int nfa_rqs_coupling_fused_linear_f32(const float* inputs, const float* hidden,
                                                  const float* weight_packed, const float* bias_padded,

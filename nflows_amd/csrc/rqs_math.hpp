@@ -307,15 +307,36 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
 // results, but the tail / not-found cases are selected at the end instead of returning early, so
 // that two independent evaluations placed back to back form one basic block and the scheduler
 // can interleave their dependent chains (K7: a lane evaluates two features per group).
-template <bool INVERSE>
+// softmax numerators of 8 logits that the producer already scaled by log2(e) (the scale folded
+// into the weights of the GEMM that makes them): 2^(u_i - max), one v_exp_f32 each
+__device__ __forceinline__ float softmax_numerators_log2(Slots<8>& e, const float* logits) {
+#pragma clang fp contract(off)
+    float m = logits[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) m = fmaxf(m, logits[i]);
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        t[i] = __builtin_amdgcn_exp2f(logits[i] - m);
+        e.set(i, t[i]);
+    }
+    return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+}
+
+// PRESCALED: 0 = width / height logits as the conditioner produced them (divided by sp.divisor
+// here), 1 = already divided, 2 = already divided and multiplied by log2(e)
+template <bool INVERSE, int PRESCALED = 0>
 __device__ __forceinline__ int rqs_eval_flat8(float x, const float* sl, const RqsDev& sp, float& y, float& lad) {
 #pragma clang fp contract(off)
     constexpr int KT = 8;
     const float right = sp.right, left = -sp.right;
     const bool inside = (x >= left && x <= right);  // NaN is outside
     Slots<KT> ew, eh;
-    const float den_w = softmax_numerators<KT>(ew, sl, KT, sp.divisor, sp.rdivisor);
-    const float den_h = softmax_numerators<KT>(eh, sl + KT, KT, sp.divisor, sp.rdivisor);
+    const float div = PRESCALED ? 0.0f : sp.divisor;
+    const float den_w = PRESCALED == 2 ? softmax_numerators_log2(ew, sl)
+                                       : softmax_numerators<KT>(ew, sl, KT, div, sp.rdivisor);
+    const float den_h = PRESCALED == 2 ? softmax_numerators_log2(eh, sl + KT)
+                                       : softmax_numerators<KT>(eh, sl + KT, KT, div, sp.rdivisor);
     int k = -1;
     float cw0 = 0.f, cw1 = 0.f, ch0 = 0.f, ch1 = 0.f;
     if (INVERSE) {

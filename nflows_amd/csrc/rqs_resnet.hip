@@ -2,24 +2,31 @@
 // (nn/nets/resnet.py:55-100: Linear(d_i -> 128), num_blocks x [ReLU, Linear, ReLU, Linear, +skip],
 // Linear(128 -> d_t*23)) followed by everything K1 replaces (coupling.py:73-130, :549-582).
 //
-//   * A wave owns 32 samples for the whole layer.  Their activations never leave the register
-//     file: every GEMM is computed transposed (out^T = W x act^T), so the 32x32 accumulator tiles
-//     a lane holds after one layer are -- up to a fixed permutation of the k index that the host
-//     applies to the next layer's weight columns -- exactly the MFMA B operand of the next layer.
+//   * A wave owns 32 samples for the whole layer.  Their rows are read once, coalesced, into a
+//     wave-private LDS tile laid out by OUTPUT position (both fused permutations applied); the
+//     conditioner inputs and the spline inputs are picked from that tile, the spline results
+//     overwrite their positions, and the tile is written out as whole rows: HBM sees one coalesced
+//     read of the inputs and one coalesced write of the outputs, pass-through columns bit-exact.
+//   * Activations never leave the register file: every GEMM is computed transposed
+//     (out^T = W x act^T), so the 32x32 accumulator tiles a lane holds after one layer are -- up to
+//     a fixed permutation of the k index that the host applies to the next layer's weight
+//     columns -- exactly the MFMA B operand of the next layer.
 //   * GEMMs run on the bf16 matrix pipe at fp32 accuracy: operands are split into three bf16
 //     pieces (x = hi + mid + lo), six cross products per k-step (see K7b in rqs_fused_linear.hip).
 //     Weights are split on the host, activations in registers right after each layer.
 //   * The weights of the whole layer (984 KB as bf16 triples at the BASELINE shape) are streamed
-//     through a double-buffered 24 KB LDS stage shared by the four waves of the workgroup.
+//     by LDS-DMA (global_load_lds, no staging registers) through a ring of three 12 KB stages
+//     shared by the four waves of the workgroup, two stages ahead of the MFMAs.
 //   * The residual input is not kept in fp32: it is rebuilt from its three pieces (exact to
 //     2^-25 |h|) when the skip connection is added, and the first ReLU of a block is applied to
 //     the pieces on the fly (sign of the leading piece), which keeps the kernel inside 256 VGPRs.
 //   * The last GEMM's accumulators are the spline logits of the lane's own two features per
-//     group; they are evaluated straight from registers (as in K7).
+//     group; they are evaluated straight from registers (as in K7).  The 1/sqrt(hidden) scale of
+//     the width / height logits (coupling.py:554-556) is folded into those weight rows by the host.
 //
 // Restrictions (the host falls back to PyTorch GEMMs + K7/K1 otherwise): K = 8 bins, linear
 // tails, hidden width 128, ReLU, no context / batch norm / active dropout, d_i <= 32,
-// d_t % 4 == 0, d_t <= 64, D <= 128, batch % 128 == 0 here (leftover rows: other path).
+// d_t % 4 == 0, d_t <= 64, D % 4 == 0, D <= 128, batch % 128 == 0 here (leftover rows: other path).
 
 #include "fused_common.hpp"
 
@@ -27,50 +34,53 @@
 
 namespace nfa {
 
-typedef short short2v __attribute__((ext_vector_type(2)));
-typedef short short8v __attribute__((ext_vector_type(8)));
+constexpr int kStageVec4 = 768;    // 12 KB: [4 tiles][3 pieces][64 lanes] or [3 pieces][4 k-steps][64 lanes] x 16 B
+constexpr int kRing = 3;
+constexpr int kRowPad = 33;        // row tile: [output position][33]: conflict-free both ways
+constexpr int kTabIn2Pos = 0, kTabIdPos = 128, kTabTrPos = 160, kTabSize = 224;
 
 struct ResnetArgs {
     const float* x;      // [B, D]
-    const vec4f* w;      // [num_stages][1536] x 16 bytes, layout in include/nflows_amd.h
+    const vec4f* w;      // [num_stages][768] x 16 bytes, layout in include/nflows_amd.h
     const float* bias;   // accumulator-order biases of all GEMMs
-    const int64_t* tidx;
-    const int64_t* iidx;
-    const int64_t* perm;
-    const int64_t* scatter;
+    const int32_t* tables;
     float* out;
     float* lad;
     int32_t* status;
     int64_t batch;  // multiple of 128
     int D, dt, di, num_blocks, num_stages, accumulate;
-    FastDiv div_D;
     RqsDev sp;
+    unsigned long long* trace;
 };
 
-// weight stream: the stage after the current one is fetched global -> registers while the current
-// one is consumed from LDS, then stored into the other LDS buffer
+// Weight stream through the LDS ring.  Stage s lives in slot s % 3; while stage s is consumed,
+// stage s+1 has landed (or is landing) and stage s+2 is being requested.
 struct WeightStream {
-    vec4f* s_w;
     const vec4f* w;
-    int it;          // stages consumed so far: parity selects the LDS buffer holding the current one
-    int next_stage;  // index (in the layer's stage list) of the stage to fetch next
+    vec4f* ring;
+    int slot;        // ring slot of the stage being consumed
+    int fetch;       // stage index (in the layer's list) to request next
     int num_stages;
     int tid;
 };
 
-__device__ __forceinline__ void stage_fetch(const WeightStream& sm, vec4f (&wnext)[6]) {
-    const vec4f* wn = sm.w + (size_t)sm.next_stage * kWTileVec4;
+__device__ __forceinline__ void stream_request(WeightStream& sm) {
+    const int dst_slot = sm.slot >= 1 ? sm.slot - 1 : kRing - 1;  // (slot + 2) % 3
+    const vec4f* src = sm.w + (size_t)sm.fetch * kStageVec4 + sm.tid;
+    vec4f* dst = sm.ring + dst_slot * kStageVec4 + sm.tid;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) wnext[i] = wn[sm.tid + i * kBlock];
+    for (int i = 0; i < 3; ++i)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + i * kBlock),
+            (__attribute__((address_space(3))) void*)(dst + i * kBlock), 16, 0, 0);
+    sm.fetch = (sm.fetch + 1 == sm.num_stages) ? 0 : sm.fetch + 1;
 }
 
-__device__ __forceinline__ void stage_commit(WeightStream& sm, const vec4f (&wnext)[6]) {
-    vec4f* nxt = sm.s_w + ((sm.it + 1) & 1) * kWTileVec4;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) nxt[sm.tid + i * kBlock] = wnext[i];
-    __syncthreads();
-    ++sm.it;
-    sm.next_stage = (sm.next_stage + 1 == sm.num_stages) ? 0 : sm.next_stage + 1;
+// end of a stage: the next stage's three LDS-DMA requests of this wave have landed (the three
+// younger ones of the stage after it may still be in flight), every wave is done reading
+__device__ __forceinline__ void stream_advance(WeightStream& sm) {
+    asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    sm.slot = (sm.slot + 1 == kRing) ? 0 : sm.slot + 1;
 }
 
 #define NFA_MFMA6(acc, ah, am, al, bh, bm, bl)                                        \
@@ -81,41 +91,50 @@ __device__ __forceinline__ void stage_commit(WeightStream& sm, const vec4f (&wne
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);              \
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0)
 
+typedef unsigned uvec4 __attribute__((ext_vector_type(4)));
+
 // ReLU applied to a value given as bf16 pieces: all three are cleared where the leading piece is
 // negative and not a NaN (bf16 bit patterns 0x8000..0xFF80 = int16 <= -128), so that NaNs keep
-// propagating like torch.relu's.
+// propagating like torch.relu's.  Three packed-int16 instructions make the mask of two values.
 __device__ __forceinline__ void relu_pieces(bf16x8& h, bf16x8& m, bf16x8& l) {
-    const short8v hs = __builtin_bit_cast(short8v, h);
-    const short8v zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    const short8v neg = (__builtin_elementwise_min(hs, zero) + (short)127) >> 15;  // -1 where cleared
-    h = __builtin_bit_cast(bf16x8, (short8v)(hs & ~neg));
-    m = __builtin_bit_cast(bf16x8, (short8v)(__builtin_bit_cast(short8v, m) & ~neg));
-    l = __builtin_bit_cast(bf16x8, (short8v)(__builtin_bit_cast(short8v, l) & ~neg));
+    uvec4 hw = __builtin_bit_cast(uvec4, h), mw = __builtin_bit_cast(uvec4, m), lw = __builtin_bit_cast(uvec4, l);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned keep;
+        asm("v_pk_min_i16 %0, %1, 0\n\t"
+            "v_pk_add_i16 %0, %0, %2\n\t"
+            "v_pk_ashrrev_i16 %0, %3, %0\n\t"
+            "v_not_b32 %0, %0"
+            : "=&v"(keep)
+            : "v"(hw[i]), "s"(0x007F007Fu), "s"(0x000F000Fu));  // (packed inline constants fill one half only)
+        hw[i] &= keep;
+        mw[i] &= keep;
+        lw[i] &= keep;
+    }
+    h = __builtin_bit_cast(bf16x8, hw);
+    m = __builtin_bit_cast(bf16x8, mw);
+    l = __builtin_bit_cast(bf16x8, lw);
 }
 
-// out^T[128 x 32 samples] += W[128 x (16*NKS)] x act^T, act given as pieces; NKS/2 stages of
-// [2 k-steps][4 tiles][3 pieces][64 lanes] x 16 bytes
+// out^T[128 x 32 samples] += W[128 x (16*NKS)] x act^T, act given as pieces; one stage
+// ([4 tiles][3 pieces][64 lanes] x 16 bytes) per k-step
 template <bool RELU, int NKS>
 __device__ __forceinline__ void gemm_128_out(f32x16 (&acc)[4], const bf16x8 (&ph)[8], const bf16x8 (&pm)[8],
                                              const bf16x8 (&pl)[8], WeightStream& sm, int lane) {
 #pragma unroll
-    for (int st = 0; st < NKS / 2; ++st) {
-        vec4f wnext[6];
-        stage_fetch(sm, wnext);
-        const vec4f* cur = sm.s_w + (sm.it & 1) * kWTileVec4 + lane;
+    for (int ks = 0; ks < NKS; ++ks) {
+        stream_request(sm);
+        const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
+        bf16x8 bh = ph[ks], bm = pm[ks], bl = pl[ks];
+        if (RELU) relu_pieces(bh, bm, bl);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 bh = ph[st * 2 + kk], bm = pm[st * 2 + kk], bl = pl[st * 2 + kk];
-            if (RELU) relu_pieces(bh, bm, bl);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[((kk * 4 + t) * 3 + 0) * 64]);
-                const bf16x8 am = __builtin_bit_cast(bf16x8, cur[((kk * 4 + t) * 3 + 1) * 64]);
-                const bf16x8 al = __builtin_bit_cast(bf16x8, cur[((kk * 4 + t) * 3 + 2) * 64]);
-                NFA_MFMA6(acc[t], ah, am, al, bh, bm, bl);
-            }
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(t * 3 + 0) * 64]);
+            const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(t * 3 + 1) * 64]);
+            const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(t * 3 + 2) * 64]);
+            NFA_MFMA6(acc[t], ah, am, al, bh, bm, bl);
         }
-        stage_commit(sm, wnext);
+        stream_advance(sm);
     }
 }
 
@@ -158,51 +177,87 @@ __device__ __forceinline__ void load_bias_tile(f32x16& acc, const float* bias_ti
     }
 }
 
-template <bool INVERSE>
+// PRESCALED: 1 = the host folded 1/sqrt(hidden) into the width / height rows of the final layer,
+// 2 = 1/sqrt(hidden) and log2(e) (NFA_FLAG_LOGITS_LOG2E: softmax numerators are then one v_exp_f32)
+template <bool INVERSE, int PRESCALED>
 __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs a) {
-    // dynamic LDS: two weight stages, then per wave a [32][dt|1] tile of transformed outputs
+    // dynamic LDS: the weight ring, then per wave a [D][33] row tile
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-    __shared__ LayerTables T;
+    __shared__ int s_tab[kTabSize];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = a.D, dt = a.dt;
-    const int ystride = dt | 1;
-    int my_status = build_layer_tables(T, a.perm, a.scatter, a.tidx, a.iidx, D, dt, a.di, tid, kBlock);
+    int my_status = 0;
+    if (tid < kTabSize) {
+        int v = a.tables[tid];
+        const bool used = tid < kTabIdPos ? tid < D : (tid < kTabTrPos ? tid - kTabIdPos < a.di : tid - kTabTrPos < dt);
+        if (used && (v < 0 || v >= D)) my_status |= NFA_STATUS_BAD_INDEX;
+        s_tab[tid] = v < 0 ? 0 : (v >= D ? D - 1 : v);
+    }
 
     WeightStream sm;
-    sm.s_w = reinterpret_cast<vec4f*>(lds_dyn);
     sm.w = a.w;
-    sm.it = 0;
-    sm.next_stage = (a.num_stages > 1) ? 1 : 0;
+    sm.ring = reinterpret_cast<vec4f*>(lds_dyn);
+    sm.slot = 1;  // so that the first two requests go to slots 0 and 1
+    sm.fetch = 0;
     sm.num_stages = a.num_stages;
     sm.tid = tid;
-    float* s_y = lds_dyn + 2 * kWTileVec4 * 4 + wave * 32 * ystride;
+    stream_request(sm);  // stage 0 -> slot 0
+    sm.slot = 2;
+    stream_request(sm);  // stage 1 -> slot 1
+    sm.slot = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    float* s_row = lds_dyn + kRing * kStageVec4 * 4 + wave * D * kRowPad;
     const int half = lane >> 5, r = lane & 31;
     const int groups = dt >> 2;
     const int64_t num_quads = a.batch >> 7;
 
-    {  // stage 0 -> LDS buffer 0
-        vec4f w0[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) w0[i] = a.w[tid + i * kBlock];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) sm.s_w[tid + i * kBlock] = w0[i];
-    }
-    __syncthreads();
-
+    unsigned long long* tr = nullptr;
+    int ti = 0;
+    if (a.trace && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 256))
+        tr = a.trace + (blockIdx.x ? 256 : 0);
     for (int64_t quad = blockIdx.x; quad < num_quads; quad += gridDim.x) {
         const int64_t row0 = (quad << 7) + (wave << 5);
-        const float* xrow = a.x + (row0 + r) * D;
+        NFA_STAMP()
+        // ---- the wave's 32 rows: one coalesced read, scattered into the tile by output position
+        {
+            const vec4f* xv = reinterpret_cast<const vec4f*>(a.x + row0 * D);
+            const int nvec = D * 8;  // 32 * D / 4
+            for (int e0 = lane; e0 < nvec; e0 += kWave * 4) {
+                vec4f v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * kWave;
+                    v[u] = xv[e < nvec ? e : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * kWave;
+                    if (e < nvec) {
+                        const int rr = (e * 4) / D, c0 = e * 4 - rr * D;
+                        s_row[s_tab[kTabIn2Pos + c0 + 0] * kRowPad + rr] = v[u].x;
+                        s_row[s_tab[kTabIn2Pos + c0 + 1] * kRowPad + rr] = v[u].y;
+                        s_row[s_tab[kTabIn2Pos + c0 + 2] * kRowPad + rr] = v[u].z;
+                        s_row[s_tab[kTabIn2Pos + c0 + 3] * kRowPad + rr] = v[u].w;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
         const float* bias = a.bias + half * 16;  // + 32 per tile
         bf16x8 ph[8], pm[8], pl[8];  // the current activations (128 k per sample) as bf16 pieces
 
-        // ---- identity features, gathered through the fused permutation: k = ks*16 + half*8 + j
+        // ---- identity features: k = ks*16 + half*8 + j
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int i = ks * 16 + half * 8 + j;
-                const float xv = xrow[T.isrc[i < a.di ? i : 0]];
+                const float xv = s_row[s_tab[kTabIdPos + i] * kRowPad + r];
                 v[j] = i < a.di ? xv : 0.0f;
             }
             bf16x2 hh[4], mm[4], ll[4];
@@ -212,6 +267,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
             pm[ks] = join4(mm[0], mm[1], mm[2], mm[3]);
             pl[ks] = join4(ll[0], ll[1], ll[2], ll[3]);
         }
+        NFA_STAMP()
 
         // ---- initial layer: h = W_i x + b_i
         {
@@ -224,6 +280,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                 tile_to_pieces<false>(h[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
         }
         bias += 128;
+        NFA_STAMP()
 
         // ---- residual blocks: h += W_1 relu(W_0 relu(h) + b_0) + b_1
         for (int blk = 0; blk < a.num_blocks; ++blk) {
@@ -231,6 +288,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
 #pragma unroll
             for (int t = 0; t < 4; ++t) load_bias_tile(u[t], bias + t * 32);
             gemm_128_out<true, 8>(u, ph, pm, pl, sm, lane);
+            NFA_STAMP()
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 load_bias_tile(v[t], bias + 128 + t * 32);
@@ -238,53 +296,83 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                 add_pieces(v[t], 8, ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
                 tile_to_pieces<true>(u[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
             }
+            NFA_STAMP()
             gemm_128_out<false, 8>(v, ph, pm, pl, sm, lane);
+            NFA_STAMP()
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 tile_to_pieces<false>(v[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
             bias += 256;
+            NFA_STAMP()
         }
 
         // ---- final layer, three 32-row tiles (= 4 features) at a time, and the splines
         float lad_acc = 0.0f;
         for (int g = 0; g < groups; ++g) {
-            const float xin0 = a.x[(row0 + r) * D + T.tsrc[g * 4 + half * 2]];
-            const float xin1 = a.x[(row0 + r) * D + T.tsrc[g * 4 + half * 2 + 1]];
+            float* slot0 = s_row + s_tab[kTabTrPos + g * 4 + half * 2] * kRowPad + r;
+            float* slot1 = s_row + s_tab[kTabTrPos + g * 4 + half * 2 + 1] * kRowPad + r;
+            const float xin0 = *slot0, xin1 = *slot1;
             f32x16 acc[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 load_bias_tile(acc[t], bias + (g * 3 + t) * 32);
-                vec4f wnext[6];
-                stage_fetch(sm, wnext);
-                const vec4f* cur = sm.s_w + (sm.it & 1) * kWTileVec4 + lane;
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(0 * 8 + ks) * 64]);
-                    const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(1 * 8 + ks) * 64]);
-                    const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(2 * 8 + ks) * 64]);
-                    NFA_MFMA6(acc[t], ah, am, al, ph[ks], pm[ks], pl[ks]);
+                for (int hs = 0; hs < 2; ++hs) {  // half tile: k-steps 4*hs .. 4*hs+3, [3 pieces][4][64 lanes]
+                    stream_request(sm);
+                    const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const int ks = hs * 4 + k4;
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(0 * 4 + k4) * 64]);
+                        const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(1 * 4 + k4) * 64]);
+                        const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(2 * 4 + k4) * 64]);
+                        NFA_MFMA6(acc[t], ah, am, al, ph[ks], pm[ks], pl[ks]);
+                    }
+                    stream_advance(sm);
                 }
-                stage_commit(sm, wnext);
             }
+            NFA_STAMP()
             {
                 NFA_K7_FEATURE_A(pa, acc[0], acc[1]);
                 NFA_K7_FEATURE_B(pb, acc[1], acc[2]);
                 float y0, l0, y1, l1;
-                my_status |= rqs_eval_flat8<INVERSE>(xin0, pa, a.sp, y0, l0);
-                my_status |= rqs_eval_flat8<INVERSE>(xin1, pb, a.sp, y1, l1);
-                s_y[r * ystride + g * 4 + half * 2] = y0;
-                s_y[r * ystride + g * 4 + half * 2 + 1] = y1;
+                my_status |= rqs_eval_flat8<INVERSE, PRESCALED>(xin0, pa, a.sp, y0, l0);
+                my_status |= rqs_eval_flat8<INVERSE, PRESCALED>(xin1, pb, a.sp, y1, l1);
+                *slot0 = y0;
+                *slot1 = y1;
                 lad_acc += l0;
                 lad_acc += l1;
             }
+            NFA_STAMP()
         }
-        assemble_rows(T, s_y, ystride, a.x, a.out, row0, D, a.div_D, lane);
+
+        // ---- the tile is the output: 32 whole rows, 16 bytes per lane per store
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            vec4f* ov = reinterpret_cast<vec4f*>(a.out + row0 * D);
+            const int nvec = D * 8;
+            for (int e = lane; e < nvec; e += kWave) {
+                const int rr = (e * 4) / D, c0 = e * 4 - rr * D;
+                vec4f v;
+                v.x = s_row[(c0 + 0) * kRowPad + rr];
+                v.y = s_row[(c0 + 1) * kRowPad + rr];
+                v.z = s_row[(c0 + 2) * kRowPad + rr];
+                v.w = s_row[(c0 + 3) * kRowPad + rr];
+                ov[e] = v;
+            }
+        }
         lad_acc += __shfl_xor(lad_acc, 32, kWave);
         if (half == 0) {
             float* dst = a.lad + row0 + r;
             *dst = a.accumulate ? *dst + lad_acc : lad_acc;
         }
+        NFA_STAMP()
+        // stores and LDS-DMA requests complete out of order with each other: drain before the next
+        // row block counts outstanding requests again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two stages requested past the end
     if (my_status && a.status) atomicOr(a.status, my_status);
 }
 
@@ -293,14 +381,14 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
 using namespace nfa;
 
 extern "C" int nfa_rqs_coupling_resnet_f32(const float* inputs, const void* weights_packed,
-                                           const float* bias_packed, const int64_t* transform_idx,
-                                           const int64_t* identity_idx, const int64_t* in_perm,
-                                           const int64_t* out_scatter, float* outputs, float* logabsdet,
-                                           int32_t* status, int64_t batch, int32_t features,
-                                           int32_t num_transform, int32_t num_identity,
-                                           int32_t hidden_features, int32_t num_blocks,
-                                           const nfa_rqs_spec* spec, int32_t flags, void* stream) {
-    if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET)) return NFA_ERR_INVALID_ARGUMENT;
+                                           const float* bias_packed, const int32_t* layer_tables,
+                                           float* outputs, float* logabsdet, int32_t* status,
+                                           int64_t batch, int32_t features, int32_t num_transform,
+                                           int32_t num_identity, int32_t hidden_features,
+                                           int32_t num_blocks, const nfa_rqs_spec* spec, int32_t flags,
+                                           void* stream) {
+    if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_LOGITS_LOG2E))
+        return NFA_ERR_INVALID_ARGUMENT;
     if (batch < 0 || features < 1 || num_transform < 1 || num_identity < 1 ||
         num_transform + num_identity > features || num_blocks < 0)
         return NFA_ERR_INVALID_ARGUMENT;
@@ -308,18 +396,16 @@ extern "C" int nfa_rqs_coupling_resnet_f32(const float* inputs, const void* weig
     int rc = make_dev_spec(spec, &a.sp);
     if (rc != NFA_OK) return rc;
     if (a.sp.K != 8 || !a.sp.linear || hidden_features != 128 || (num_transform & 3) != 0 ||
-        num_transform > 64 || num_identity > 32 || features > 128 || (batch & 127) != 0 || num_blocks > 64)
+        num_transform > 64 || num_identity > 32 || features > 128 || (features & 3) != 0 ||
+        (batch & 127) != 0 || num_blocks > 64)
         return NFA_ERR_UNSUPPORTED;
     if (batch == 0) return NFA_OK;
-    if (!inputs || !weights_packed || !bias_packed || !transform_idx || !identity_idx || !outputs || !logabsdet)
+    if (!inputs || !weights_packed || !bias_packed || !layer_tables || !outputs || !logabsdet)
         return NFA_ERR_INVALID_ARGUMENT;
     a.x = inputs;
     a.w = reinterpret_cast<const vec4f*>(weights_packed);
     a.bias = bias_packed;
-    a.tidx = transform_idx;
-    a.iidx = identity_idx;
-    a.perm = in_perm;
-    a.scatter = out_scatter;
+    a.tables = layer_tables;
     a.out = outputs;
     a.lad = logabsdet;
     a.status = status;
@@ -328,18 +414,29 @@ extern "C" int nfa_rqs_coupling_resnet_f32(const float* inputs, const void* weig
     a.dt = num_transform;
     a.di = num_identity;
     a.num_blocks = num_blocks;
-    a.num_stages = 1 + 8 * num_blocks + num_transform * 24 / 32;
-    a.div_D = make_fastdiv((uint32_t)features);
+    a.num_stages = 2 + 16 * num_blocks + 2 * (num_transform * 24 / 32);
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
+    a.trace = g_k7_trace;
+    const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float);
     int64_t blocks = batch >> 7;
-    const int64_t cap = (int64_t)device_cu_count() * 2;
+    const int64_t per_cu = lds + 1024 <= 80 * 1024 ? 2 : 1;
+    const int64_t cap = (int64_t)device_cu_count() * per_cu;
     if (blocks > cap) blocks = cap;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     profile_next_launch(&e0, &e1);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks), block(kBlock);
-    const size_t lds = (size_t)(kBlock / kWave) * 32 * (num_transform | 1) * sizeof(float) + 2 * kWTileVec4 * 16;
-    auto kern = (flags & NFA_FLAG_INVERSE) ? rqs_resnet_kernel<true> : rqs_resnet_kernel<false>;
+    const bool inv = (flags & NFA_FLAG_INVERSE) != 0, l2e = (flags & NFA_FLAG_LOGITS_LOG2E) != 0;
+    auto kern = inv ? (l2e ? rqs_resnet_kernel<true, 2> : rqs_resnet_kernel<true, 1>)
+                    : (l2e ? rqs_resnet_kernel<false, 2> : rqs_resnet_kernel<false, 1>);
+    if (lds > 64 * 1024) {
+        static bool raised[4] = {false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
+        const int which = (inv ? 1 : 0) + (l2e ? 2 : 0);
+        if (!raised[which]) {
+            NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            raised[which] = true;
+        }
+    }
     if (e0) hipExtLaunchKernelGGL(kern, grid, block, lds, st, e0, e1, 0, a);
     else hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     NFA_HIP_CHECK(hipGetLastError());

@@ -502,12 +502,14 @@ def _bias_accumulator_order(b):
     return b.view(-1, 4, 2, 4).permute(0, 2, 1, 3).reshape(-1)
 
 
-def pack_resnet_conditioner(net, num_transform, params_per_feature):
+def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False):
     """Packs a ResidualNet (initial_layer, blocks[*].linear_layers[0,1], final_layer) for K8
-    (layout in include/nflows_amd.h): every weight as split-bf16 triples in 24 KB stages, in the
-    order the kernel consumes them, and all biases in accumulator order.  Returns (weights
-    [stages, 1536*8] bf16, biases [128 + 256*num_blocks + d_t*24] fp32)."""
+    (layout in include/nflows_amd.h): every weight as split-bf16 triples in 12 KB stages, in the
+    order the kernel consumes them, all biases in accumulator order, and the 1/sqrt(hidden) scale
+    of the width / height logits (coupling.py:554-556) folded into the final layer's rows
+    (times log2(e) with `log2e`).  Returns (weights [stages, 768*8] bf16, biases fp32)."""
     dt, P = num_transform, params_per_feature
+    K = (P + 1) // 3
     dev = net.final_layer.weight.device
     order_k = _k8_column_order().to(dev)
 
@@ -517,48 +519,61 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature):
     stages, biases = [], []
     wi = net.initial_layer.weight.detach().float()
     di = wi.shape[1]
-    wi = torch.cat((wi, wi.new_zeros(128, 32 - di)), dim=1)  # k = kk*16 + hf*8 + j
-    # (p, t, i, kk, hf, j) -> (kk, t, p, hf, i, j)
-    stages.append(pieces(wi).view(3, 4, 32, 2, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(1, -1))
+    wi = torch.cat((wi, wi.new_zeros(128, 32 - di)), dim=1)  # k = ks*16 + hf*8 + j
+    # (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j)
+    stages.append(pieces(wi).view(3, 4, 32, 2, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(2, -1))
     biases.append(_bias_accumulator_order(net.initial_layer.bias.detach().float()))
     for block in net.blocks:
         for lin in block.linear_layers:
             w = lin.weight.detach().float().index_select(1, order_k)  # columns in (ks, hf, j) order
-            # (p, t, i, s, kk, hf, j) -> (s, kk, t, p, hf, i, j): stage s holds k-steps 2s, 2s+1
-            stages.append(pieces(w).view(3, 4, 32, 4, 2, 2, 8).permute(3, 4, 1, 0, 5, 2, 6).reshape(4, -1))
+            # (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j): one stage per k-step
+            stages.append(pieces(w).view(3, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1))
             biases.append(_bias_accumulator_order(lin.bias.detach().float()))
+    scale = torch.ones(P, dtype=torch.float64, device=dev)
+    scale[:2 * K] = (math.log2(math.e) if log2e else 1.0) / math.sqrt(net.hidden_features)
+    wf = (net.final_layer.weight.detach().double().view(dt, P, 128) * scale[None, :, None]).float()
+    bf = (net.final_layer.bias.detach().double().view(dt, P) * scale[None, :]).float()
     order_r = _k7_row_order(dt).to(dev)
-    wf = net.final_layer.weight.detach().float().view(dt, P, 128)
     wf = torch.cat((wf, wf.new_zeros(dt, 24 - P, 128)), dim=1).reshape(dt * 24, 128)
     wf = wf.index_select(0, order_r).index_select(1, order_k)
-    bf = torch.cat((net.final_layer.bias.detach().float().view(dt, P),
-                    wf.new_zeros(dt, 24 - P)), dim=1).reshape(dt * 24).index_select(0, order_r)
+    bf = torch.cat((bf, bf.new_zeros(dt, 24 - P)), dim=1).reshape(dt * 24).index_select(0, order_r)
     tiles = dt * 24 // 32
-    # (p, tile, i, ks, hf, j) -> (tile, p, ks, hf, i, j)
-    stages.append(pieces(wf).view(3, tiles, 32, 8, 2, 8).permute(1, 0, 3, 4, 2, 5).reshape(tiles, -1))
+    # (p, tile, i, hs, k4, hf, j) -> (tile, hs, p, k4, hf, i, j): two stages per tile
+    stages.append(pieces(wf).view(3, tiles, 32, 2, 4, 2, 8).permute(1, 3, 0, 4, 5, 2, 6).reshape(tiles * 2, -1))
     biases.append(_bias_accumulator_order(bf))
     return torch.cat(stages, dim=0).contiguous(), torch.cat(biases).contiguous()
 
 
-def rqs_coupling_resnet(inputs, weights_packed, bias_packed, transform_idx, identity_idx, num_blocks, spec,
-                        inverse=False, in_perm=None, out_scatter=None, accumulate_into=None):
+def coupling_layer_tables(features, transform_idx, identity_idx, in_perm=None, out_scatter=None):
+    """int32 [224] column bookkeeping for K8 (layout in include/nflows_amd.h), built on the device."""
+    dev = transform_idx.device
+    cols = torch.arange(features, device=dev)
+    src = cols if in_perm is None else in_perm.to(dev)
+    dst = cols if out_scatter is None else out_scatter.to(dev)
+    t = torch.zeros(224, dtype=torch.int64, device=dev)
+    t[:features] = torch.zeros(features, dtype=torch.int64, device=dev).index_copy_(0, src, dst)
+    t[128:128 + identity_idx.numel()] = dst[identity_idx]
+    t[160:160 + transform_idx.numel()] = dst[transform_idx]
+    return t.to(torch.int32)
+
+
+def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transform, num_identity, num_blocks,
+                        spec, inverse=False, accumulate_into=None, log2e=False):
     """K8 -- ResidualNet conditioner + spline coupling layer in one kernel.  Returns None when the
     shape is outside the fast path."""
     N.require_device_f32("inputs", inputs, 2)
     dev = inputs.device
     B, D = inputs.shape
-    tidx = _idx("transform_features", transform_idx, dev)
-    iidx = _idx("identity_features", identity_idx, dev)
-    perm = _idx("in_perm", in_perm, dev, D)
-    scat = _idx("out_scatter", out_scatter, dev, D)
     x = inputs.detach().contiguous()
     out = torch.empty_like(x)
     lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
+    if log2e:
+        flags |= N.FLAG_LOGITS_LOG2E
     with torch.cuda.device(dev):
         rc = N.load().nfa_rqs_coupling_resnet_f32(
-            N.ptr(x), N.ptr(weights_packed), N.ptr(bias_packed), N.ptr(tidx), N.ptr(iidx), N.ptr(perm),
-            N.ptr(scat), N.ptr(out), N.ptr(lad), N.ptr(_status_word(dev)), B, D, tidx.numel(),
-            iidx.numel(), 128, num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))
+            N.ptr(x), N.ptr(weights_packed), N.ptr(bias_packed), N.ptr(tables), N.ptr(out), N.ptr(lad),
+            N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128, num_blocks,
+            ctypes.byref(spec), flags, N.stream_handle(dev))
     if rc == N.ERR_UNSUPPORTED:
         return None
     N.check(rc)

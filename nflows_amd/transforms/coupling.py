@@ -275,33 +275,52 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
                 and all(b.activation is torch.nn.functional.relu and not b.use_batch_norm
                         and (not b.training or b.dropout.p == 0.0) for b in net.blocks))
 
+    # experiment switch: fold log2(e) into the width / height logits as well (one v_exp_f32 per
+    # softmax numerator)
+    resnet_log2e = os.environ.get("NFA_K8_LOG2E", "0") != "0"
+
     def _packed_resnet(self):
         net = self.transform_net
-        key = tuple((p.data_ptr(), p._version) for p in net.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in net.parameters()) + (self.resnet_log2e,)
         cached = getattr(self, "_packed_resnet_cache", None)
         if cached is None or cached[0] != key:
             cached = (key, ops.pack_resnet_conditioner(net, self.num_transform_features,
-                                                       self._transform_dim_multiplier()))
+                                                       self._transform_dim_multiplier(),
+                                                       log2e=self.resnet_log2e))
             self._packed_resnet_cache = cached
         return cached[1]
 
+    def _layer_tables(self, in_perm, out_scatter):
+        key = tuple(None if t is None else (t.data_ptr(), t._version) for t in
+                    (in_perm, out_scatter, self.transform_features, self.identity_features))
+        cache = self.__dict__.setdefault("_layer_tables_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) > 8:
+                cache.clear()
+            hit = ops.coupling_layer_tables(self.features, self.transform_features, self.identity_features,
+                                            in_perm, out_scatter)
+            cache[key] = hit
+        return hit
+
     def _whole_layer(self, inputs, context, inverse, in_perm, out_scatter, accumulate_into):
         B = inputs.shape[0]
-        if B < 128 or not self._resnet_eligible(context):
+        if B < 128 or self.features % 4 != 0 or not self._resnet_eligible(context):
             return None
         wp, bp = self._packed_resnet()
+        tables = self._layer_tables(in_perm, out_scatter)
         nb = len(self.transform_net.blocks)
+        dt, di = self.num_transform_features, self.num_identity_features
         spec = self._spec()
         full = (B // 128) * 128
         if full == B:
-            return ops.rqs_coupling_resnet(inputs, wp, bp, self.transform_features, self.identity_features,
-                                           nb, spec, inverse, in_perm, out_scatter, accumulate_into)
+            return ops.rqs_coupling_resnet(inputs, wp, bp, tables, dt, di, nb, spec, inverse, accumulate_into,
+                                           log2e=self.resnet_log2e)
         # ragged batch: full 128-row blocks here, the tail through the PyTorch conditioner + K1
         acc_head = None if accumulate_into is None else accumulate_into[:full]
         acc_tail = None if accumulate_into is None else accumulate_into[full:]
-        head = ops.rqs_coupling_resnet(inputs[:full], wp, bp, self.transform_features,
-                                       self.identity_features, nb, spec, inverse, in_perm, out_scatter,
-                                       acc_head)
+        head = ops.rqs_coupling_resnet(inputs[:full], wp, bp, tables, dt, di, nb, spec, inverse, acc_head,
+                                       log2e=self.resnet_log2e)
         if head is None:
             return None
         tail_in = inputs[full:]
