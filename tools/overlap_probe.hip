@@ -11,7 +11,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-enum { R_IDLE = 0, R_MFMA = 1, R_VALU = 2, R_BOTH = 3, R_MFMA32 = 4, R_BOTH32 = 5 };
+enum { R_IDLE = 0, R_MFMA = 1, R_VALU = 2, R_BOTH = 3, R_MFMA32 = 4, R_BOTH32 = 5, R_VALU_PRIO = 6, R_MFMA_PRIO = 7 };
 
 struct Roles { int r[16]; };
 
@@ -44,6 +44,20 @@ __global__ void __launch_bounds__(1024) probe(Roles roles, int iters, float* out
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = __builtin_fmaf(v[j], c, d);
         }
+    } else if (role == R_VALU_PRIO) {
+        __builtin_amdgcn_s_setprio(3);
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = __builtin_fmaf(v[j], c, d);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    } else if (role == R_MFMA_PRIO) {
+        __builtin_amdgcn_s_setprio(3);
+        for (int i = 0; i < iters; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
     } else if (role == R_BOTH) {
         for (int i = 0; i < iters; ++i) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
@@ -108,6 +122,10 @@ int main() {
     run("1 wave/SIMD: f32 MFMA+VALU same wave", 4, {5, 5, 5, 5}, it);
     run("2 waves/SIMD: bf16 MFMA | VALU", 8, {1, 1, 1, 1, 2, 2, 2, 2}, it);
     run("2 waves/SIMD: f32 MFMA | VALU", 8, {4, 4, 4, 4, 2, 2, 2, 2}, it);
+    run("2/SIMD: bf16 MFMA | VALU prio3", 8, {1, 1, 1, 1, 6, 6, 6, 6}, it);
+    run("2/SIMD: VALU prio3 | bf16 MFMA", 8, {6, 6, 6, 6, 1, 1, 1, 1}, it);
+    run("2/SIMD: VALU | bf16 MFMA", 8, {2, 2, 2, 2, 1, 1, 1, 1}, it);
+    run("2/SIMD: VALU | bf16 MFMA prio3", 8, {2, 2, 2, 2, 7, 7, 7, 7}, it);
     run("2 waves/SIMD: bf16 MFMA | bf16 MFMA", 8, {1, 1, 1, 1, 1, 1, 1, 1}, it);
     run("2 waves/SIMD: VALU | VALU", 8, {2, 2, 2, 2, 2, 2, 2, 2}, it);
     run("2 waves/SIMD: both | both (bf16)", 8, {3, 3, 3, 3, 3, 3, 3, 3}, it);
