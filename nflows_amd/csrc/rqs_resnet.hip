@@ -101,7 +101,9 @@ __device__ __forceinline__ void relu_pieces(bf16x8& h, bf16x8& m, bf16x8& l) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         unsigned keep;
-        asm("v_pk_min_i16 %0, %1, 0\n\t"
+        // volatile: recomputed at every use (the first Linear of a block applies it once per output
+        // tile); merged into one evaluation the ReLU'd copies would occupy 96 more registers
+        asm volatile("v_pk_min_i16 %0, %1, 0\n\t"
             "v_pk_add_i16 %0, %0, %2\n\t"
             "v_pk_ashrrev_i16 %0, %3, %0\n\t"
             "v_not_b32 %0, %0"
@@ -116,23 +118,45 @@ __device__ __forceinline__ void relu_pieces(bf16x8& h, bf16x8& m, bf16x8& l) {
     l = __builtin_bit_cast(bf16x8, lw);
 }
 
-// out^T[128 x 32 samples] += W[128 x (16*NKS)] x act^T, act given as pieces; one stage
-// ([4 tiles][3 pieces][64 lanes] x 16 bytes) per k-step
-template <bool RELU, int NKS>
-__device__ __forceinline__ void gemm_128_out(f32x16 (&acc)[4], const bf16x8 (&ph)[8], const bf16x8 (&pm)[8],
-                                             const bf16x8 (&pl)[8], WeightStream& sm, int lane) {
+// k-major GEMM (all four output tiles accumulate together, the input pieces of a k-step are dead
+// after it): out^T[128 x 32 samples] += W[128 x 16*NKS] x act^T; one stage ([4 tiles][3 pieces]
+// [64 lanes] x 16 bytes) per k-step
+template <int NKS>
+__device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const bf16x8 (&ph)[8], const bf16x8 (&pm)[8],
+                                            const bf16x8 (&pl)[8], WeightStream& sm, int lane) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         stream_request(sm);
         const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
-        bf16x8 bh = ph[ks], bm = pm[ks], bl = pl[ks];
-        if (RELU) relu_pieces(bh, bm, bl);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(t * 3 + 0) * 64]);
             const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(t * 3 + 1) * 64]);
             const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(t * 3 + 2) * 64]);
-            NFA_MFMA6(acc[t], ah, am, al, bh, bm, bl);
+            NFA_MFMA6(acc[t], ah, am, al, ph[ks], pm[ks], pl[ks]);
+        }
+        stream_advance(sm);
+    }
+}
+
+// one 32-row output tile of a 128-wide layer: acc += W_tile[32 x 128] x act^T, act given as pieces
+// (ReLU applied to them on the fly if RELU); two stages of [3 pieces][4 k-steps][64 lanes] x 16 bytes
+template <bool RELU>
+__device__ __forceinline__ void gemm_tile(f32x16& acc, const bf16x8 (&ph)[8], const bf16x8 (&pm)[8],
+                                          const bf16x8 (&pl)[8], WeightStream& sm, int lane) {
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs) {
+        stream_request(sm);
+        const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const int ks = hs * 4 + k4;
+            bf16x8 bh = ph[ks], bm = pm[ks], bl = pl[ks];
+            if (RELU) relu_pieces(bh, bm, bl);
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(0 * 4 + k4) * 64]);
+            const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(1 * 4 + k4) * 64]);
+            const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(2 * 4 + k4) * 64]);
+            NFA_MFMA6(acc, ah, am, al, bh, bm, bl);
         }
         stream_advance(sm);
     }
@@ -209,7 +233,6 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
     __syncthreads();
 
     float* s_row = lds_dyn + kRing * kStageVec4 * 4 + wave * D * kRowPad;
-    const int half = lane >> 5, r = lane & 31;
     const int groups = dt >> 2;
     const int64_t num_quads = a.batch >> 7;
 
@@ -219,6 +242,11 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         tr = a.trace + (blockIdx.x ? 256 : 0);
     for (int64_t quad = blockIdx.x; quad < num_quads; quad += gridDim.x) {
         const int64_t row0 = (quad << 7) + (wave << 5);
+        // (lane-derived values are made opaque per iteration: hoisted out of this loop they would
+        // stay live through the whole kernel and push the register allocation into scratch)
+        int lane_here = lane, di = a.di;
+        asm volatile("" : "+v"(lane_here), "+s"(di));
+        const int half = lane_here >> 5, r = lane_here & 31;
         NFA_STAMP()
         // ---- the wave's 32 rows: one coalesced read, scattered into the tile by output position
         {
@@ -258,7 +286,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
             for (int j = 0; j < 8; ++j) {
                 const int i = ks * 16 + half * 8 + j;
                 const float xv = s_row[s_tab[kTabIdPos + i] * kRowPad + r];
-                v[j] = i < a.di ? xv : 0.0f;
+                v[j] = i < di ? xv : 0.0f;
             }
             bf16x2 hh[4], mm[4], ll[4];
 #pragma unroll
@@ -274,7 +302,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
             f32x16 h[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) load_bias_tile(h[t], bias + t * 32);
-            gemm_128_out<false, 2>(h, ph, pm, pl, sm, lane);
+            gemm_kmajor<2>(h, ph, pm, pl, sm, lane);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 tile_to_pieces<false>(h[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
@@ -282,32 +310,43 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         bias += 128;
         NFA_STAMP()
 
-        // ---- residual blocks: h += W_1 relu(W_0 relu(h) + b_0) + b_1
+        // ---- residual blocks: h += W_1 relu(W_0 relu(h) + b_0) + b_1.  First Linear one 32-feature
+        //      output tile at a time (its input, the h pieces, must survive for the skip connection,
+        //      so only 16 accumulator registers are live beside them and the growing relu(u) pieces)
+#ifndef NFA_K8_NO_BLOCKS
         for (int blk = 0; blk < a.num_blocks; ++blk) {
-            f32x16 u[4], v[4];
+            bf16x8 qh[8], qm[8], ql[8];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) load_bias_tile(u[t], bias + t * 32);
-            gemm_128_out<true, 8>(u, ph, pm, pl, sm, lane);
+            for (int t = 0; t < 4; ++t) {
+                f32x16 u;
+                load_bias_tile(u, bias + t * 32);
+                gemm_tile<true>(u, ph, pm, pl, sm, lane);
+                tile_to_pieces<true>(u, qh[2 * t], qm[2 * t], ql[2 * t], qh[2 * t + 1], qm[2 * t + 1], ql[2 * t + 1]);
+            }
             NFA_STAMP()
+            // second Linear k-major: the skip connection is added up front (after which the old h
+            // pieces are dead), the relu(u) pieces die k-step by k-step
+            f32x16 v[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 load_bias_tile(v[t], bias + 128 + t * 32);
                 add_pieces(v[t], 0, ph[2 * t], pm[2 * t], pl[2 * t]);
                 add_pieces(v[t], 8, ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
-                tile_to_pieces<true>(u[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
             }
-            NFA_STAMP()
-            gemm_128_out<false, 8>(v, ph, pm, pl, sm, lane);
-            NFA_STAMP()
+            gemm_kmajor<8>(v, qh, qm, ql, sm, lane);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 tile_to_pieces<false>(v[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
             bias += 256;
             NFA_STAMP()
         }
+#endif
 
         // ---- final layer, three 32-row tiles (= 4 features) at a time, and the splines
         float lad_acc = 0.0f;
+#ifdef NFA_K8_NO_FINAL
+        for (int ks = 0; ks < 8; ++ks) lad_acc += (float)ph[ks][0] + (float)pm[ks][1] + (float)pl[ks][2];
+#else
         for (int g = 0; g < groups; ++g) {
             float* slot0 = s_row + s_tab[kTabTrPos + g * 4 + half * 2] * kRowPad + r;
             float* slot1 = s_row + s_tab[kTabTrPos + g * 4 + half * 2 + 1] * kRowPad + r;
@@ -316,20 +355,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 load_bias_tile(acc[t], bias + (g * 3 + t) * 32);
-#pragma unroll
-                for (int hs = 0; hs < 2; ++hs) {  // half tile: k-steps 4*hs .. 4*hs+3, [3 pieces][4][64 lanes]
-                    stream_request(sm);
-                    const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
-#pragma unroll
-                    for (int k4 = 0; k4 < 4; ++k4) {
-                        const int ks = hs * 4 + k4;
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(0 * 4 + k4) * 64]);
-                        const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(1 * 4 + k4) * 64]);
-                        const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(2 * 4 + k4) * 64]);
-                        NFA_MFMA6(acc[t], ah, am, al, ph[ks], pm[ks], pl[ks]);
-                    }
-                    stream_advance(sm);
-                }
+                gemm_tile<false>(acc[t], ph, pm, pl, sm, lane);
             }
             NFA_STAMP()
             {
@@ -345,6 +371,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
             }
             NFA_STAMP()
         }
+#endif
 
         // ---- the tile is the output: 32 whole rows, 16 bytes per lane per store
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

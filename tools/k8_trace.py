@@ -25,12 +25,12 @@ for blk in (0, 1):
     s = t[blk * 256: blk * 256 + 250]; s = s[s > 0]
     d = np.diff(s)
     print("block %d: %d stamps, first at +%d, total %d cycles" % (blk * 256, len(s), s[0] - base, s[-1] - s[0]))
-    print("  x gather + split: %d   initial layer (+ pieces): %d" % (d[0], d[1]))
+    print("  rows -> LDS tile, identity pieces: %d   initial layer (+ pieces): %d" % (d[0], d[1]))
     for b in range(2):
-        o = 2 + 4 * b
-        print("  block %d: gemm0 %d  skip+relu+pieces %d  gemm1 %d  pieces %d" % (b, d[o], d[o + 1], d[o + 2], d[o + 3]))
-    o = 10
+        o = 2 + 2 * b
+        print("  block %d: first Linear (tile-major, + relu pieces) %d   skip + second Linear (k-major) + pieces %d" % (b, d[o], d[o + 1]))
+    o = 6
     g = d[o:o + 16].reshape(8, 2)
     print("  final groups [3 tiles mfma, 2 splines]:", g.tolist())
-    print("  assembly:", d[o + 16:].tolist())
-    print("  sums: hidden gemms %d  final mfma %d  spline %d" % (d[2] + d[4] + d[6] + d[8], g[:, 0].sum(), g[:, 1].sum()))
+    print("  output rows + logabsdet:", d[o + 16:].tolist())
+    print("  sums: hidden gemms %d  final mfma %d  spline %d" % (d[2:6].sum(), g[:, 0].sum(), g[:, 1].sum()))
