@@ -195,14 +195,15 @@ int nfa_rqs_coupling_fused_linear_f32(const float *inputs, const float *hidden,
  *                    lane l element j = piece of W[32*tile + (l&31)][16*ks + 8*(l>>5) + j]
  *                    (columns >= d_i zero);
  *                  with col(ks, hf, j) = 32*(ks/2) + 16*(ks%2) + 8*(j/4) + 4*hf + j%4:
- *                  for every block: linear_layers[0] tile-major, two stages per 32-row tile
- *                    (k-steps 4*s .. 4*s+3), [3 pieces][4 k-steps][64 lanes][8], element j = piece
- *                    of W[32*tile + (l&31)][col(ks, l>>5, j)]; then linear_layers[1] k-major,
- *                    8 stages (ks = 0..7) of [4 tiles][3 pieces][64 lanes][8];
- *                  final_layer tile-major like linear_layers[0];
- *                  final_layer rows as in K7 (padded / reordered); the rows of width and height logits (and their
- *                    biases) multiplied by 1/sqrt(hidden_features) (coupling.py:554-556;
- *                    spec->wh_divisor is ignored), and by log2(e) with NFA_FLAG_LOGITS_LOG2E.
+ *                  for every block, linear_layers[0] then [1]: 8 stages (ks = 0..7) of
+ *                    [4 tiles][3 pieces][64 lanes][8], element j = piece of
+ *                    W[32*tile + (l&31)][col(ks, l>>5, j)];
+ *                  final_layer: two stages per 32-row tile (k-steps 4*s .. 4*s+3),
+ *                    [3 pieces][4 k-steps][64 lanes][8], same element rule;
+ *                  final_layer's rows are padded / reordered as in K7; its width and height
+ *                    rows (and their biases) are multiplied by 1/sqrt(hidden_features)
+ *                    (coupling.py:554-556; spec->wh_divisor is ignored here), and by log2(e)
+ *                    with NFA_FLAG_LOGITS_LOG2E.
  *   bias_packed    float: initial_layer [4 tiles][2 lane-halves][16], every hidden Linear the
  *                  same, final_layer [tiles][2][16] (rows as in K7)
  * Supported: num_bins = 8, linear tails, hidden_features = 128, d_i <= 32, d_t % 4 == 0,

@@ -62,6 +62,7 @@ struct WeightStream {
     int fetch;       // stage index (in the layer's list) to request next
     int num_stages;
     int tid;
+    int prio;        // experiment NFA_K8_ALT_PRIO: issue priority alternates every N stages
 };
 
 __device__ __forceinline__ void stream_request(WeightStream& sm) {
@@ -81,6 +82,11 @@ __device__ __forceinline__ void stream_request(WeightStream& sm) {
 __device__ __forceinline__ void stream_advance(WeightStream& sm) {
     asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     sm.slot = (sm.slot + 1 == kRing) ? 0 : sm.slot + 1;
+#ifdef NFA_K8_ALT_PRIO
+    sm.prio += 1;
+    if (sm.prio & NFA_K8_ALT_PRIO) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 #define NFA_MFMA6(acc, ah, am, al, bh, bm, bl)                                        \
@@ -101,8 +107,8 @@ __device__ __forceinline__ void relu_pieces(bf16x8& h, bf16x8& m, bf16x8& l) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         unsigned keep;
-        // volatile: recomputed at every use (the first Linear of a block applies it once per output
-        // tile); merged into one evaluation the ReLU'd copies would occupy 96 more registers
+        // (volatile: a pure statement may be hoisted or merged by the compiler, and ReLU'd copies
+        // kept alive beside the originals would not fit the register file)
         asm volatile("v_pk_min_i16 %0, %1, 0\n\t"
             "v_pk_add_i16 %0, %0, %2\n\t"
             "v_pk_ashrrev_i16 %0, %3, %0\n\t"
@@ -121,19 +127,21 @@ __device__ __forceinline__ void relu_pieces(bf16x8& h, bf16x8& m, bf16x8& l) {
 // k-major GEMM (all four output tiles accumulate together, the input pieces of a k-step are dead
 // after it): out^T[128 x 32 samples] += W[128 x 16*NKS] x act^T; one stage ([4 tiles][3 pieces]
 // [64 lanes] x 16 bytes) per k-step
-template <int NKS>
+template <bool RELU, int NKS>
 __device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const bf16x8 (&ph)[8], const bf16x8 (&pm)[8],
                                             const bf16x8 (&pl)[8], WeightStream& sm, int lane) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         stream_request(sm);
         const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
+        bf16x8 bh = ph[ks], bm = pm[ks], bl = pl[ks];
+        if (RELU) relu_pieces(bh, bm, bl);  // (the input pieces themselves stay: skip connection)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(t * 3 + 0) * 64]);
             const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(t * 3 + 1) * 64]);
             const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(t * 3 + 2) * 64]);
-            NFA_MFMA6(acc[t], ah, am, al, ph[ks], pm[ks], pl[ks]);
+            NFA_MFMA6(acc[t], ah, am, al, bh, bm, bl);
         }
         stream_advance(sm);
     }
@@ -218,6 +226,11 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         s_tab[tid] = v < 0 ? 0 : (v >= D ? D - 1 : v);
     }
 
+#ifdef NFA_K8_YOUNG_PRIO
+    // experiment: the second workgroup resident on a CU loses every issue arbitration by age;
+    // a static priority evens the two out
+    if (blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(NFA_K8_YOUNG_PRIO);
+#endif
     WeightStream sm;
     sm.w = a.w;
     sm.ring = reinterpret_cast<vec4f*>(lds_dyn);
@@ -225,6 +238,11 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
     sm.fetch = 0;
     sm.num_stages = a.num_stages;
     sm.tid = tid;
+#ifdef NFA_K8_ALT_PRIO
+    sm.prio = (blockIdx.x >= (gridDim.x >> 1)) ? NFA_K8_ALT_PRIO : 0;
+#else
+    sm.prio = 0;
+#endif
     stream_request(sm);  // stage 0 -> slot 0
     sm.slot = 2;
     stream_request(sm);  // stage 1 -> slot 1
@@ -302,7 +320,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
             f32x16 h[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) load_bias_tile(h[t], bias + t * 32);
-            gemm_kmajor<2>(h, ph, pm, pl, sm, lane);
+            gemm_kmajor<false, 2>(h, ph, pm, pl, sm, lane);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 tile_to_pieces<false>(h[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
@@ -310,22 +328,24 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         bias += 128;
         NFA_STAMP()
 
-        // ---- residual blocks: h += W_1 relu(W_0 relu(h) + b_0) + b_1.  First Linear one 32-feature
-        //      output tile at a time (its input, the h pieces, must survive for the skip connection,
-        //      so only 16 accumulator registers are live beside them and the growing relu(u) pieces)
+        // ---- residual blocks: h += W_1 relu(W_0 relu(h) + b_0) + b_1, both Linears k-major.
+        //      Register budget: the h pieces (96) must survive the first Linear for the skip
+        //      connection; u (64 accumulators) turns into the relu(u) pieces (96) tile by tile, then
+        //      the skip is added into the second Linear's accumulators tile by tile (the h pieces
+        //      die), whose input pieces die k-step by k-step.
 #ifndef NFA_K8_NO_BLOCKS
         for (int blk = 0; blk < a.num_blocks; ++blk) {
             bf16x8 qh[8], qm[8], ql[8];
+            {
+                f32x16 u[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                f32x16 u;
-                load_bias_tile(u, bias + t * 32);
-                gemm_tile<true>(u, ph, pm, pl, sm, lane);
-                tile_to_pieces<true>(u, qh[2 * t], qm[2 * t], ql[2 * t], qh[2 * t + 1], qm[2 * t + 1], ql[2 * t + 1]);
+                for (int t = 0; t < 4; ++t) load_bias_tile(u[t], bias + t * 32);
+                gemm_kmajor<true, 8>(u, ph, pm, pl, sm, lane);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    tile_to_pieces<true>(u[t], qh[2 * t], qm[2 * t], ql[2 * t], qh[2 * t + 1], qm[2 * t + 1], ql[2 * t + 1]);
             }
             NFA_STAMP()
-            // second Linear k-major: the skip connection is added up front (after which the old h
-            // pieces are dead), the relu(u) pieces die k-step by k-step
             f32x16 v[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -333,7 +353,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                 add_pieces(v[t], 0, ph[2 * t], pm[2 * t], pl[2 * t]);
                 add_pieces(v[t], 8, ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
             }
-            gemm_kmajor<8>(v, qh, qm, ql, sm, lane);
+            gemm_kmajor<false, 8>(v, qh, qm, ql, sm, lane);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 tile_to_pieces<false>(v[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);

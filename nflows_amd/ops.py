@@ -524,14 +524,10 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False)
     stages.append(pieces(wi).view(3, 4, 32, 2, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(2, -1))
     biases.append(_bias_accumulator_order(net.initial_layer.bias.detach().float()))
     for block in net.blocks:
-        for which, lin in enumerate(block.linear_layers):
+        for lin in block.linear_layers:
             w = lin.weight.detach().float().index_select(1, order_k)  # columns in (ks, hf, j) order
-            if which == 0:
-                # tile-major: (p, tile, i, hs, k4, hf, j) -> (tile, hs, p, k4, hf, i, j), two stages per tile
-                stages.append(pieces(w).view(3, 4, 32, 2, 4, 2, 8).permute(1, 3, 0, 4, 5, 2, 6).reshape(8, -1))
-            else:
-                # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one stage per k-step
-                stages.append(pieces(w).view(3, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1))
+            # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one stage per k-step
+            stages.append(pieces(w).view(3, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1))
             biases.append(_bias_accumulator_order(lin.bias.detach().float()))
     scale = torch.ones(P, dtype=torch.float64, device=dev)
     scale[:2 * K] = (math.log2(math.e) if log2e else 1.0) / math.sqrt(net.hidden_features)
