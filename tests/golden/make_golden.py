@@ -561,7 +561,63 @@ def grad_cases():
     print("grads:", len(meta), "cases")
 
 
+def flow_h128_case():
+    """BASELINE layer shape (D = 64, K = 8, ResidualNet H = 128 x 2 blocks): the shape family the
+    whole-layer kernel (K8) and the fused-final-Linear kernels (K7 / K7b) serve.  The weights are
+    not stored (656 KB per layer): they are rebuilt from the seed, which the drop-in classes
+    reproduce bit for bit (test_same_seed_same_weights_as_reference); per-parameter checksums are
+    stored to make a drifted RNG visible."""
+    out = {}
+    L, D, K, H, B = 2, 64, 8, 128, 160
+    torch.manual_seed(0)
+    layers = []
+    for i in range(L):
+        layers.append(RandomPermutation(D))
+        layers.append(PiecewiseRationalQuadraticCouplingTransform(
+            mask=torchutils.create_alternating_binary_mask(D, even=(i % 2 == 0)),
+            transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=H, num_blocks=2),
+            num_bins=K, tails="linear", tail_bound=3.0))
+    flow = Flow(CompositeTransform(layers), StandardNormal([D]))
+    with torch.no_grad():
+        for p_name, p in flow.named_parameters():
+            if "final_layer" in p_name:
+                p.mul_(4.0)
+            elif "linear_layers.1" in p_name:
+                p.mul_(30.0)
+    g = torch.Generator().manual_seed(4321)
+    x = 1.2 * torch.randn(B, D, generator=g)
+    noise = torch.randn(B, D, generator=g)
+    flow.eval()
+    with torch.no_grad():
+        lp = flow.log_prob(x)
+        z, lad = flow._transform(x)
+        xs, lad_inv = flow._transform.inverse(noise)
+        f64 = flow.double()
+        lp64 = f64.log_prob(x.double())
+        z64, lad64 = f64._transform(x.double())
+        xs64, ladi64 = f64._transform.inverse(noise.double())
+        flow.float()
+    name = "nsf_h128"
+    for k, v in dict(x=x, noise=noise, log_prob=lp, z=z, lad=lad, inv_x=xs, inv_lad=lad_inv,
+                     log_prob64=lp64, z64=z64, lad64=lad64, inv_x64=xs64, inv_lad64=ladi64).items():
+        out[name + "/" + k] = npy(v)
+    names, sums = [], []
+    for k, v in flow.state_dict().items():
+        names.append(k)
+        sums.append([float(v.double().sum()), float(v.double().abs().sum())])
+    out[name + "/param_names"] = np.array(names).astype(str)
+    out[name + "/param_checksums"] = np.array(sums, dtype=np.float64)
+    out["meta"] = np.array([(name, repr(dict(kind="rq_nsf", L=L, D=D, K=K, H=H, B=B, tail_bound=3.0,
+                                              seed=0, scale_final=4.0, scale_linear1=30.0)))],
+                           dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "flows_h128.npz"), **out)
+    print("flows_h128: 1 case")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "h128":
+        flow_h128_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "grads":
         grad_cases()
         sys.exit(0)
@@ -576,3 +632,4 @@ if __name__ == "__main__":
     error_surface()
     grad_cases()
     cdf_cases()
+    flow_h128_case()

@@ -380,3 +380,68 @@ def test_whole_layer_kernel_shapes(features, blocks, restore_fused_path):
     assert torch.equal(y[:, ident].isnan(), x[:, ident].isnan())
     keep = ~x[:, ident].isnan()
     assert torch.equal(y[:, ident][keep], x[:, ident][keep])
+
+
+@pytest.mark.parametrize("path", ["k8", "k7b", "k7", "none"])
+def test_baseline_layer_shape_against_reference_vectors(golden_dir, path, restore_fused_path):
+    """tests/golden/flows_h128.npz: outputs of the REAL reference (fp32 and fp64) for a 2-layer
+    RQ-NSF flow at the BASELINE layer shape (D = 64, K = 8, ResidualNet H = 128, 160 rows: one
+    128-row block for the fused kernels + a ragged tail).  Every layer-kernel path must meet the
+    fp32 parity model: error against the reference's fp64 result <= 4x the reference-fp32's own."""
+    from test_oracle_golden import _h128_flow
+    flow, g, name = _h128_flow(golden_dir)
+    flow = flow.to(DEV)
+    x = torch.from_numpy(g[name + "/x"]).to(DEV)
+    noise = torch.from_numpy(g[name + "/noise"]).to(DEV)
+    d = x.shape[1]
+    _select_fused_path(path)
+    with torch.no_grad():
+        lp = flow.log_prob(x)
+        z, lad = flow._transform(x)
+        xs, lad_inv = flow._transform.inverse(noise)
+    import nflows_amd
+    nflows_amd.check_status()
+    check(z, g[name + "/z"], g[name + "/z64"], path + " z", 3e-6)
+    check(lad, g[name + "/lad"], g[name + "/lad64"], path + " lad", 3e-6 * d)
+    check(lp, g[name + "/log_prob"], g[name + "/log_prob64"], path + " log_prob", 3e-6 * d)
+    check(xs, g[name + "/inv_x"], g[name + "/inv_x64"], path + " inv_x", 3e-6)
+    check(lad_inv, g[name + "/inv_lad"], g[name + "/inv_lad64"], path + " inv_lad", 3e-6 * d)
+    # bulk agreement with the reference's fp32 output itself
+    from helpers import bulk_fraction
+    assert bulk_fraction(z.cpu().numpy(), g[name + "/z"], 2e-5) >= 0.99
+    assert bulk_fraction(xs.cpu().numpy(), g[name + "/inv_x"], 2e-5) >= 0.99
+
+
+def test_whole_layer_kernel_abi_contract(restore_fused_path):
+    """K8 through the C ABI: unsupported shapes are refused before anything is enqueued, bad table
+    entries are reported through the status word, a corrupted table cannot write out of bounds."""
+    import ctypes
+    from nflows_amd import _native as N, ops, configs
+    flow = configs.rq_nsf_flow(num_layers=1, features=64, num_bins=8, hidden_features=128, seed=3).to(DEV).eval()
+    layer = flow._transform._transforms[1]
+    wp, bp = ops.pack_resnet_conditioner(layer.transform_net, 32, 23)
+    tables = ops.coupling_layer_tables(64, layer.transform_features, layer.identity_features)
+    spec = layer._spec()
+    x = torch.randn(256, 64, device=DEV)
+    y, lad = ops.rqs_coupling_resnet(x, wp, bp, tables, 32, 32, 2, spec)
+    ops.check_status()
+    assert torch.equal(y[:, layer.identity_features], x[:, layer.identity_features])
+    # batch not a multiple of 128, K != 8: refused
+    assert ops.rqs_coupling_resnet(x[:200], wp, bp, tables, 32, 32, 2, spec) is None
+    spec4 = ops.make_rqs_spec(4, "linear", tail_bound=3.0)
+    assert ops.rqs_coupling_resnet(x, wp, bp, tables, 32, 32, 2, spec4) is None
+    lib = N.load()
+    out, l2 = torch.empty_like(x), torch.empty(256, device=DEV)
+    st = torch.zeros(1, dtype=torch.int32, device=DEV)
+    def call(tab, flags=0, batch=256):
+        return lib.nfa_rqs_coupling_resnet_f32(N.ptr(x), N.ptr(wp), N.ptr(bp), N.ptr(tab), N.ptr(out), N.ptr(l2),
+                                               N.ptr(st), batch, 64, 32, 32, 128, 2, ctypes.byref(spec), flags,
+                                               N.stream_handle(x.device))
+    assert call(tables, flags=64) == N.ERR_INVALID_ARGUMENT
+    assert call(None) == N.ERR_INVALID_ARGUMENT
+    assert call(tables, batch=0) == N.OK
+    bad = tables.clone()
+    bad[160 + 5] = 64  # transformed feature 5 stored at a position outside the row
+    assert call(bad) == N.OK
+    torch.cuda.synchronize()
+    assert st.item() & N.STATUS_BAD_INDEX

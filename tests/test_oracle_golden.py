@@ -148,3 +148,36 @@ def test_eager_port_is_bit_identical_to_reference(golden_dir):
         with torch.no_grad():
             lp = eager.flow_log_prob(flow.eval(), torch.from_numpy(gf[name + "/x"]))
         assert np.array_equal(lp.numpy(), gf[name + "/log_prob"]), name
+
+
+def _h128_flow(golden_dir):
+    """The flow of tests/golden/flows_h128.npz rebuilt from its seed (weights are not stored)."""
+    import torch
+    from nflows_amd import configs
+    g = np.load(os.path.join(golden_dir, "flows_h128.npz"))
+    name, cfg = g["meta"][0]
+    cfg = parse_kwargs(cfg)
+    flow = configs.rq_nsf_flow(cfg["L"], cfg["D"], cfg["K"], cfg["H"], 2, cfg["tail_bound"], seed=cfg["seed"])
+    with torch.no_grad():
+        for n_, p in flow.named_parameters():
+            if "final_layer" in n_:
+                p.mul_(cfg["scale_final"])
+            elif "linear_layers.1" in n_:
+                p.mul_(cfg["scale_linear1"])
+    sd = flow.state_dict()
+    assert list(sd.keys()) == list(g[name + "/param_names"])
+    sums = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in sd.values()])
+    assert np.array_equal(sums, g[name + "/param_checksums"]), "seeded weights differ from the reference's"
+    return flow.eval(), g, name
+
+
+def test_eager_port_bit_identical_at_baseline_layer_shape(golden_dir):
+    """Same as above on the BASELINE layer shape (D = 64, K = 8, ResidualNet H = 128): the weights
+    rebuilt from the seed equal the reference's, and the eager port's log_prob is bit-identical."""
+    import torch
+    from oracle import eager
+    torch.set_num_threads(1)
+    flow, g, name = _h128_flow(golden_dir)
+    with torch.no_grad():
+        lp = eager.flow_log_prob(flow, torch.from_numpy(g[name + "/x"]))
+    assert np.array_equal(lp.numpy(), g[name + "/log_prob"])
