@@ -292,14 +292,23 @@ int nfa_standard_normal_log_prob_f32(const float *z, const float *logabsdet, flo
                                      int64_t rows, int64_t cols, void *stream);
 
 /*
- * Measurement aid (bench.py), not part of the data path.  While enabled, every K1 launch
- * (nfa_rqs_coupling_f32) carries its own start/stop HIP events attached to the dispatch
+ * Measurement aids (bench.py, tools/), not part of the data path; the library's only global state.
+ *
+ * While enabled, every launch of a coupling-layer kernel (nfa_rqs_coupling_f32, _fused_linear_f32,
+ * _resnet_f32) carries its own start/stop HIP events attached to the dispatch
  * (hipExtLaunchKernelGGL), up to max_launches; nfa_profile_collect waits for them and returns the
  * kernels' own durations in launch order (what rocprofv3 --kernel-trace reports), then resets.
- * max_launches = 0 disables.  This is the library's only global state.
+ * max_launches = 0 disables.
  */
 int nfa_profile_enable(int32_t max_launches);
 int nfa_profile_collect(float *durations_ms, int32_t capacity, int32_t *count);
+
+/*
+ * Phase timeline of the fused kernels (tools/k7_trace.py, tools/k8_trace.py): device_buffer =
+ * 512 uint64 on the device that lane 0 of wave 0 of workgroups 0 and 256 fills with
+ * cycle-counter stamps at phase boundaries of the next launches; NULL switches it off.
+ */
+void nfa_debug_k7_trace(void *device_buffer);
 
 #ifdef __cplusplus
 }

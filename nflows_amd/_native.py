@@ -49,6 +49,7 @@ EXPORTS = (
     "nfa_standard_normal_log_prob_f32",
     "nfa_profile_enable",
     "nfa_profile_collect",
+    "nfa_debug_k7_trace",
 )
 
 
