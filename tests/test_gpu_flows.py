@@ -445,3 +445,39 @@ def test_whole_layer_kernel_abi_contract(restore_fused_path):
     assert call(bad) == N.OK
     torch.cuda.synchronize()
     assert st.item() & N.STATUS_BAD_INDEX
+
+
+def test_whole_layer_kernel_persistent_loop(restore_fused_path):
+    """More 128-row blocks than resident workgroups (2 per CU): every workgroup walks several
+    blocks, re-starting the weight stream from stage 0 each time.  Compared with the PyTorch
+    conditioner + K1 path on the first, middle and last rows; forward and inverse."""
+    from nflows_amd import configs
+    flow = configs.rq_nsf_flow(num_layers=1, features=64, num_bins=8, hidden_features=128, seed=2).to(DEV).eval()
+    with torch.no_grad():
+        for n_, p in flow.named_parameters():
+            if "final_layer" in n_:
+                p.mul_(4.0)
+            elif "linear_layers.1" in n_:
+                p.mul_(30.0)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    B = 128 * (2 * cus * 2 + 37)  # > 2 blocks per resident workgroup, not a multiple of the grid
+    x = torch.randn(B, 64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    rows = torch.cat((torch.arange(0, 512), torch.arange(B // 2 - 256, B // 2 + 256), torch.arange(B - 512, B))).to(DEV)
+    with torch.no_grad():
+        _select_fused_path("k8")
+        z1, l1 = flow._transform(x)
+        x1, li1 = flow._transform.inverse(x)
+        _select_fused_path("none")
+        z0, l0 = flow._transform(x[rows])
+        x0, li0 = flow._transform.inverse(x[rows])
+    import nflows_amd
+    nflows_amd.check_status()
+    for got, want, tol in ((z1[rows], z0, 2e-5), (l1[rows], l0, 5e-4), (x1[rows], x0, 2e-5), (li1[rows], li0, 5e-4)):
+        d = (got - want).abs()
+        assert d.max().item() < tol, d.max().item()
+    assert torch.isfinite(z1).all() and torch.isfinite(l1).all()
+    # every row was written: round trip over the whole batch
+    with torch.no_grad():
+        _select_fused_path("k8")
+        back, _ = flow._transform.inverse(z1)
+    assert (back - x).abs().max().item() < 1e-4
