@@ -123,6 +123,40 @@ def rqs_elementwise(x, uw, uh, ud, spec, inverse=False, return_bins=False):
     return out
 
 
+def linear_spline(x, unnormalized_pdf, spec, inverse=False):
+    """splines/linear.py: x [...], unnormalized_pdf [..., K]; spec.tails = 1 -> unconstrained."""
+    dtype = x.dtype
+    suf, ct = _dt(dtype)
+    K = spec.num_bins
+    xf = np.ascontiguousarray(x.reshape(-1))
+    pf = np.ascontiguousarray(unnormalized_pdf.reshape(-1, K), dtype=dtype)
+    y = np.empty(xf.size, dtype)
+    lad = np.empty(xf.size, dtype)
+    fn = getattr(lib(), "oracle_linear_spline" + suf)
+    fn.restype = ctypes.c_int
+    st = fn(_ptr(xf, ct), _ptr(pf, ct), ctypes.c_int64(K), ctypes.c_int64(xf.size), ctypes.byref(spec),
+            ctypes.c_int(int(inverse)), _ptr(y, ct), _ptr(lad, ct))
+    return y.reshape(x.shape), lad.reshape(x.shape), st
+
+
+def quadratic_spline(x, uw, uh, spec, inverse=False):
+    """splines/quadratic.py: uw [..., K], uh [..., K-1] (boundary heights derived) or [..., K+1]."""
+    dtype = x.dtype
+    suf, ct = _dt(dtype)
+    K = spec.num_bins
+    nh = uh.shape[-1]
+    xf = np.ascontiguousarray(x.reshape(-1))
+    wf = np.ascontiguousarray(uw.reshape(-1, K), dtype=dtype)
+    hf = np.ascontiguousarray(uh.reshape(-1, nh), dtype=dtype)
+    y = np.empty(xf.size, dtype)
+    lad = np.empty(xf.size, dtype)
+    fn = getattr(lib(), "oracle_quadratic_spline" + suf)
+    fn.restype = ctypes.c_int
+    st = fn(_ptr(xf, ct), _ptr(wf, ct), ctypes.c_int64(K), _ptr(hf, ct), ctypes.c_int64(nh), ctypes.c_int(nh),
+            ctypes.c_int64(xf.size), ctypes.byref(spec), ctypes.c_int(int(inverse)), _ptr(y, ct), _ptr(lad, ct))
+    return y.reshape(x.shape), lad.reshape(x.shape), st
+
+
 def rqs_coupling(x, params, transform_idx, spec, inverse=False, in_perm=None, out_scatter=None):
     dtype = x.dtype
     suf, ct = _dt(dtype)

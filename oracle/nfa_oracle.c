@@ -369,3 +369,208 @@ void FN(oracle_affine_autoregressive)(const REAL *x, const REAL *params, int64_t
         logabsdet[b] = (REAL)acc;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Sibling piecewise-polynomial splines.
+ * The spec's box, tails and minimum sizes are read; derivative fields are unused. */
+
+/* F.softmax over K logits (optionally divided by `divisor` first), fp32 sum accumulated in double
+ * like knots_from_logits above */
+static void softmax_k(const REAL *u, int K, REAL divisor, REAL *p) {
+    REAL m = -INFINITY;
+    for (int i = 0; i < K; ++i) {
+        p[i] = (divisor != (REAL)0) ? u[i] / divisor : u[i];
+        if (p[i] > m) m = p[i];
+    }
+    double s = 0.0;
+    for (int i = 0; i < K; ++i) {
+        p[i] = r_exp(p[i] - m);
+        s += (double)p[i];
+    }
+    REAL sum = (REAL)s;
+    for (int i = 0; i < K; ++i) p[i] = p[i] / sum;
+}
+
+/* torchutils.searchsorted (torchutils.py:134-136) over knots[0..K], last knot + 1e-6 */
+static int search_knots(const REAL *knots, int K, REAL x) {
+    int cnt = 0;
+    for (int j = 0; j <= K; ++j) {
+        REAL kn = knots[j];
+        if (j == K) kn = kn + (REAL)1e-6;
+        if (x >= kn) ++cnt;
+    }
+    return cnt - 1;
+}
+
+static REAL clamp01(REAL v) { /* torch.clamp(v, 0, 1): NaN stays NaN */
+    if (v < (REAL)0) return (REAL)0;
+    if (v > (REAL)1) return (REAL)1;
+    return v;
+}
+
+/* linear_spline for ONE element: splines/linear.py:40-105 */
+static int linear_one(REAL x, const REAL *updf, const oracle_rqs_spec *sp, int inverse, REAL *y, REAL *lad) {
+    enum { KMAX = 256 };
+    int K = sp->num_bins;
+    REAL pdf[KMAX], cdf[KMAX + 1];
+    REAL left = (REAL)sp->left, right = (REAL)sp->right, bottom = (REAL)sp->bottom;
+    if (x < left || x > right) { /* :47-48 (compares against left/right in both directions) */
+        *y = x;
+        *lad = 0;
+        return ORACLE_STATUS_OUTSIDE_DOMAIN;
+    }
+    REAL u = inverse ? (x - bottom) / (REAL)(sp->top - sp->bottom) : (x - left) / (REAL)(sp->right - sp->left);
+    softmax_k(updf, K, (REAL)0, pdf);
+    double acc = 0.0;
+    cdf[0] = 0;
+    for (int i = 0; i < K; ++i) {
+        acc += (double)pdf[i];
+        cdf[i + 1] = (REAL)acc;
+    }
+    cdf[K] = (REAL)1;
+    REAL out;
+    if (inverse) {
+        int k = search_knots(cdf, K, u);
+        if (k < 0 || k >= K) {
+            *y = x;
+            *lad = 0;
+            return ORACLE_STATUS_OUTSIDE_DOMAIN;
+        }
+        /* torch.linspace(0, 1, K+1) (linear.py:67-71) is a float32 tensor whatever the input
+         * dtype: start + i*step for the first half, end - (K-i)*step for the second, in float */
+        float step = 1.0f / (float)K;
+        float fb0 = (k < (K + 1) / 2) ? (float)k * step : 1.0f - (float)(K - k) * step;
+        float fb1 = (k + 1 < (K + 1) / 2) ? (float)(k + 1) * step : 1.0f - (float)(K - k - 1) * step;
+        REAL b0 = (REAL)fb0, b1 = (REAL)fb1;
+        /* torchutils.searchsorted adds its eps to the last knot IN PLACE (torchutils.py:135), so the
+         * slope / offset of the last bin (linear.py:73-76) see cdf[K] = 1 + 1e-6 */
+        cdf[K] = cdf[K] + (REAL)1e-6;
+        REAL slope = (cdf[k + 1] - cdf[k]) / (b1 - b0);
+        REAL offset = cdf[k + 1] - slope * b1;
+        out = clamp01((u - offset) / slope);
+        *lad = -r_log(slope);
+    } else {
+        REAL pos = u * (REAL)K;
+        int k = (int)floor((double)pos);
+        if (k >= K) k = K - 1;
+        REAL alpha = pos - (REAL)k;
+        out = cdf[k];
+        out = out + alpha * pdf[k];
+        out = clamp01(out);
+        *lad = r_log(pdf[k]) - (REAL)log(1.0 / K);
+    }
+    if (inverse) *y = out * (REAL)(sp->right - sp->left) + left;
+    else *y = out * (REAL)(sp->top - sp->bottom) + bottom;
+    return 0;
+}
+
+/* quadratic_spline for ONE element: splines/quadratic.py:55-159.  nh = K-1 (boundary heights
+ * derived, :93-107) or K+1 */
+static int quadratic_one(REAL x, const REAL *uw, const REAL *uh, int nh, const oracle_rqs_spec *sp,
+                         int inverse, REAL *y, REAL *lad) {
+    enum { KMAX = 256 };
+    int K = sp->num_bins;
+    REAL w[KMAX], he[KMAX + 1], h[KMAX + 1], lcdf[KMAX + 1], loc[KMAX + 1];
+    REAL left = (REAL)sp->left, right = (REAL)sp->right, bottom = (REAL)sp->bottom;
+    REAL minw = (REAL)sp->min_bin_width, minh = (REAL)sp->min_bin_height;
+    if (x < left || x > right) {
+        *y = x;
+        *lad = 0;
+        return ORACLE_STATUS_OUTSIDE_DOMAIN;
+    }
+    REAL u = inverse ? (x - bottom) / (REAL)(sp->top - sp->bottom) : (x - left) / (REAL)(sp->right - sp->left);
+    softmax_k(uw, K, (REAL)sp->wh_divisor, w);
+    REAL one_minus = (REAL)(1.0 - sp->min_bin_width * K);
+    for (int i = 0; i < K; ++i) w[i] = minw + one_minus * w[i];
+    REAL div = (REAL)sp->wh_divisor;
+    if (nh == K - 1) {
+        for (int i = 0; i < nh; ++i) {
+            REAL v = (div != (REAL)0) ? uh[i] / div : uh[i];
+            he[i + 1] = softplus(v, (REAL)1) + (REAL)1e-3;
+        }
+        REAL fw = (REAL)0.5 * w[0], lw = (REAL)0.5 * w[K - 1];
+        REAL s = 0; /* torch.sum over K-2 terms, fp32 */
+        for (int i = 0; i + 1 < nh; ++i) s += ((he[i + 1] + he[i + 2]) / (REAL)2) * w[i + 1];
+        REAL num = (REAL)0.5 * fw * he[1] + (REAL)0.5 * lw * he[nh] + s;
+        REAL c = num / ((REAL)1 - (REAL)0.5 * fw - (REAL)0.5 * lw);
+        he[0] = c;
+        he[K] = c;
+    } else {
+        for (int i = 0; i <= K; ++i) {
+            REAL v = (div != (REAL)0) ? uh[i] / div : uh[i];
+            he[i] = softplus(v, (REAL)1) + (REAL)1e-3;
+        }
+    }
+    REAL area = 0;
+    for (int i = 0; i < K; ++i) area += ((he[i] + he[i + 1]) / (REAL)2) * w[i];
+    REAL om_h = (REAL)(1.0 - sp->min_bin_height);
+    for (int i = 0; i <= K; ++i) h[i] = minh + om_h * (he[i] / area);
+    double a1 = 0.0, a2 = 0.0;
+    lcdf[0] = 0;
+    loc[0] = 0;
+    for (int i = 0; i < K; ++i) {
+        a1 += (double)(((h[i] + h[i + 1]) / (REAL)2) * w[i]);
+        lcdf[i + 1] = (REAL)a1;
+        a2 += (double)w[i];
+        loc[i + 1] = (REAL)a2;
+    }
+    lcdf[K] = (REAL)1;
+    loc[K] = (REAL)1;
+    int k = search_knots(inverse ? lcdf : loc, K, u);
+    if (k < 0 || k >= K) {
+        *y = x;
+        *lad = 0;
+        return ORACLE_STATUS_OUTSIDE_DOMAIN;
+    }
+    REAL bw = w[k], hl = h[k], hr = h[k + 1];
+    REAL a = (REAL)0.5 * (hr - hl) * bw, b = hl * bw, c = lcdf[k];
+    REAL out;
+    if (inverse) {
+        REAL c_ = c - u;
+        REAL alpha = (-b + r_sqrt(b * b - (REAL)4 * a * c_)) / ((REAL)2 * a);
+        out = clamp01(alpha * bw + loc[k]);
+        *lad = -r_log(alpha * (hr - hl) + hl);
+    } else {
+        REAL alpha = (u - loc[k]) / bw;
+        out = clamp01(a * (alpha * alpha) + b * alpha + c);
+        *lad = r_log(alpha * (hr - hl) + hl);
+    }
+    if (inverse) *y = out * (REAL)(sp->right - sp->left) + left;
+    else *y = out * (REAL)(sp->top - sp->bottom) + bottom;
+    return 0;
+}
+
+/* linear_spline / unconstrained_linear_spline (tails = 1: box [-B, B]^2 with B = sp->right,
+ * outside elements pass through, splines/linear.py:9-37) over n elements */
+int FN(oracle_linear_spline)(const REAL *x, const REAL *updf, int64_t stride, int64_t n,
+                             const oracle_rqs_spec *sp, int inverse, REAL *y, REAL *lad) {
+    int status = 0;
+    if (sp->num_bins < 1 || sp->num_bins > 256) return -1;
+    for (int64_t i = 0; i < n; ++i) {
+        REAL B = (REAL)sp->right;
+        if (sp->tails == 1 && !(x[i] >= -B && x[i] <= B)) {
+            y[i] = x[i];
+            lad[i] = 0;
+            continue;
+        }
+        status |= linear_one(x[i], updf + i * stride, sp, inverse, y + i, lad + i);
+    }
+    return status;
+}
+
+int FN(oracle_quadratic_spline)(const REAL *x, const REAL *uw, int64_t sw, const REAL *uh, int64_t sh,
+                                int nh, int64_t n, const oracle_rqs_spec *sp, int inverse, REAL *y,
+                                REAL *lad) {
+    int status = 0;
+    if (sp->num_bins < 1 || sp->num_bins > 256) return -1;
+    for (int64_t i = 0; i < n; ++i) {
+        REAL B = (REAL)sp->right;
+        if (sp->tails == 1 && !(x[i] >= -B && x[i] <= B)) {
+            y[i] = x[i];
+            lad[i] = 0;
+            continue;
+        }
+        status |= quadratic_one(x[i], uw + i * sw, uh + i * sh, nh, sp, inverse, y + i, lad + i);
+    }
+    return status;
+}

@@ -561,6 +561,56 @@ def grad_cases():
     print("grads:", len(meta), "cases")
 
 
+def sibling_spline_cases():
+    """Linear and quadratic splines (splines/linear.py, splines/quadratic.py): constrained and
+    unconstrained, forward and inverse, fp32 and fp64."""
+    out = {}
+    meta = []
+    g = torch.Generator().manual_seed(2024)
+
+    def finish(name, kind, fn, x, logits, kw):
+        for dtp, suf in ((torch.float32, ""), (torch.float64, "64")):
+            args = [t.to(dtp) for t in logits]
+            for inverse in (False, True):
+                y, lad = fn(x.to(dtp), *args, inverse=inverse, **kw)
+                out["%s/%s%s" % (name, "inv_" if inverse else "", "y" + suf)] = npy(y)
+                out["%s/%s%s" % (name, "inv_" if inverse else "", "lad" + suf)] = npy(lad)
+        out[name + "/x"] = npy(x)
+        for i, t in enumerate(logits):
+            out["%s/logits%d" % (name, i)] = npy(t)
+        meta.append((name, kind, repr(kw)))
+
+    for K, n, scale in ((10, 400, 2.0), (4, 257, 4.0), (33, 300, 1.0)):
+        # constrained: inputs in [0, 1] with the end points and bin boundaries included
+        x = torch.rand(n, generator=g)
+        x[:6] = torch.tensor([0.0, 1.0, 0.5, 1.0 / K, 1.0 - 1.0 / K, 1e-7])
+        pdf = scale * torch.randn(n, K, generator=g)
+        finish("lin_k%d" % K, "linear", splines.linear_spline, x, [pdf], {})
+        uw = scale * torch.randn(n, K, generator=g)
+        uh = scale * torch.randn(n, K + 1, generator=g)
+        finish("quad_k%d" % K, "quadratic", splines.quadratic_spline, x, [uw, uh], {})
+        # unconstrained: linear tails outside [-B, B]
+        B = 3.0
+        xu = 2.2 * torch.randn(n, generator=g)
+        xu[:8] = torch.tensor([-B, B, 0.0, B + 1e-3, -B - 1e-3, float("nan"), 2.9999998, -2.9999998])
+        finish("ulin_k%d" % K, "linear", splines.unconstrained_linear_spline, xu, [pdf],
+               dict(tail_bound=B, tails="linear"))
+        uh1 = scale * torch.randn(n, K - 1, generator=g)
+        finish("uquad_k%d" % K, "quadratic", splines.unconstrained_quadratic_spline, xu, [uw, uh1],
+               dict(tail_bound=B, tails="linear"))
+    # shaped inputs and a non-default box
+    x = 0.5 + torch.rand(3, 5, 7, generator=g)
+    finish("lin_box", "linear", splines.linear_spline, x, [torch.randn(3, 5, 7, 6, generator=g)],
+           dict(left=0.5, right=1.5, bottom=-1.0, top=2.0))
+    x = 0.5 + torch.rand(3, 5, 7, generator=g)  # inverse of this case needs inputs in [bottom, top] = same box
+    finish("quad_box", "quadratic", splines.quadratic_spline, x,
+           [torch.randn(3, 5, 7, 6, generator=g), torch.randn(3, 5, 7, 7, generator=g)],
+           dict(left=0.5, right=1.5, bottom=0.5, top=1.5, min_bin_width=1e-2, min_bin_height=1e-2))
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "splines_lq.npz"), **out)
+    print("sibling splines:", len(meta), "cases")
+
+
 def flow_h128_case():
     """BASELINE layer shape (D = 64, K = 8, ResidualNet H = 128 x 2 blocks): the shape family the
     whole-layer kernel (K8) and the fused-final-Linear kernels (K7 / K7b) serve.  The weights are
@@ -615,6 +665,9 @@ def flow_h128_case():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "lq":
+        sibling_spline_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "h128":
         flow_h128_case()
         sys.exit(0)
@@ -633,3 +686,4 @@ if __name__ == "__main__":
     grad_cases()
     cdf_cases()
     flow_h128_case()
+    sibling_spline_cases()

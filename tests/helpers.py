@@ -50,3 +50,22 @@ def assert_fp32_parity(got, ref, truth, tol, what="", bulk=0.99, factor=4.0):
 def parse_kwargs(text):
     import ast
     return dict(ast.literal_eval(text))
+
+
+def assert_sibling_spline_parity(got, ref, truth, tol, cap, what=""):
+    """Linear / quadratic splines: same bulk criterion as assert_fp32_parity (>= 97 % of the elements
+    within tol * (1 + |ref|) of the reference's fp32 output), identical NaN pattern, and the error
+    against the reference's float64 result bounded by max(4 x the reference-fp32's own, cap).
+    `cap` is there because these splines have elements whose result moves by 1e3 ulp when one
+    intermediate prefix sum moves by one ulp (a bin of minimal width next to a steep one: the
+    quadratic inverse divides a difference of two nearly equal cdf values by a tiny 2a); the
+    reference's own fp32 error at such an element is a matter of luck, not a bound."""
+    got, ref, truth = np.asarray(got), np.asarray(ref), np.asarray(truth)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), what + ": NaN pattern differs"
+    frac = bulk_fraction(got, ref, tol)
+    assert frac >= 0.97, "%s: only %.4f of elements within %g" % (what, frac, tol)
+    fin = np.isfinite(ref) & np.isfinite(truth)
+    if fin.any():
+        e_got = np.abs(got[fin].astype(np.float64) - truth[fin]).max()
+        e_ref = np.abs(ref[fin].astype(np.float64) - truth[fin]).max()
+        assert e_got <= max(4.0 * e_ref, cap), "%s: max err vs fp64 %.3e (reference fp32: %.3e)" % (what, e_got, e_ref)

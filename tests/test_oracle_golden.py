@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import LAD_TOL, OUT_TOL, assert_fp32_parity, parse_kwargs
+from helpers import LAD_TOL, OUT_TOL, assert_fp32_parity, assert_sibling_spline_parity, parse_kwargs
 from oracle import capi
 
 
@@ -181,3 +181,45 @@ def test_eager_port_bit_identical_at_baseline_layer_shape(golden_dir):
     with torch.no_grad():
         lp = eager.flow_log_prob(flow, torch.from_numpy(g[name + "/x"]))
     assert np.array_equal(lp.numpy(), g[name + "/log_prob"])
+
+
+def sibling_cases(golden_dir):
+    """(name, kind, oracle function, logits, spec, reference arrays) for tests/golden/splines_lq.npz"""
+    g = np.load(os.path.join(golden_dir, "splines_lq.npz"))
+    for name, kind, kw in g["meta"]:
+        kw = parse_kwargs(kw)
+        logits = [g["%s/logits%d" % (name, i)] for i in range(1 if kind == "linear" else 2)]
+        K = logits[0].shape[-1]
+        spec_kw = dict(kw)
+        if spec_kw.get("tails") != "linear":
+            spec_kw["tails"] = None
+        yield str(name), str(kind), logits, K, spec_kw, g
+
+
+def test_linear_and_quadratic_splines_match_reference(golden_dir):
+    """oracle/nfa_oracle.c linear_one / quadratic_one against the real reference: the double build
+    to 1e-10 of its float64 results, the float build within the fp32 parity model."""
+    for name, kind, logits, K, kw, g in sibling_cases(golden_dir):
+        x = g[name + "/x"]
+        for inverse in (False, True):
+            pre = name + ("/inv_" if inverse else "/")
+            for dt in (np.float64, np.float32):
+                spec = capi.make_spec(K, **kw)
+                args = [a.astype(dt) for a in logits]
+                fn = capi.linear_spline if kind == "linear" else capi.quadratic_spline
+                y, lad, st = fn(x.astype(dt), *args, spec, inverse=inverse)
+                assert st == 0, (name, inverse)
+                if dt is np.float64:
+                    ry, rl = g[pre + "y64"], g[pre + "lad64"]
+                    assert np.array_equal(np.isnan(y), np.isnan(ry)), name
+                    fin = np.isfinite(ry)
+                    assert np.abs(y[fin] - ry[fin]).max() <= 1e-9, (name, inverse)
+                    assert np.abs(lad[fin] - rl[fin]).max() <= 1e-9, (name, inverse)
+                else:
+                    assert_sibling_spline_parity(y, g[pre + "y"], g[pre + "y64"], OUT_TOL, 5e-5, name + " y")
+                    assert_sibling_spline_parity(lad, g[pre + "lad"], g[pre + "lad64"], LAD_TOL, 1e-3, name + " lad")
+                    if kw.get("tails") == "linear":
+                        tb = np.float32(kw["tail_bound"])
+                        outside = ~((x >= -tb) & (x <= tb))
+                        assert np.array_equal(y[outside].view(np.uint32), x[outside].view(np.uint32)), name
+                        assert np.all(lad[outside] == 0), name
