@@ -233,6 +233,28 @@ int nfa_rqs_elementwise_f32(const float *inputs, const float *unnormalized_width
                             int32_t inverse, void *stream);
 
 /*
+ * K9.  The spline's siblings as elementwise functionals (no row-sum), same calling convention as
+ * nfa_rqs_elementwise_f32; spec supplies num_bins, tails (NFA_TAILS_LINEAR: box = +-right,
+ * elements outside pass through with logabsdet 0), the box, and for the quadratic spline
+ * min_bin_width / min_bin_height / wh_divisor; the derivative fields are ignored.
+ *
+ *   linear_spline / unconstrained_linear_spline, splines/linear.py:40-105 / :9-37
+ *     unnormalized_pdf  [n, K] rows `stride` floats apart
+ *   quadratic_spline / unconstrained_quadratic_spline, splines/quadratic.py:55-159 / :11-52
+ *     unnormalized_widths [n, K]; unnormalized_heights [n, num_heights], num_heights = K+1, or K-1
+ *     (the two boundary heights are then derived so that they normalise to 1, :93-107)
+ * A constrained input outside [left, right] sets NFA_STATUS_OUTSIDE_DOMAIN.
+ */
+int nfa_linear_spline_f32(const float *inputs, const float *unnormalized_pdf, int64_t stride,
+                          float *outputs, float *logabsdet, int32_t *status, int64_t n,
+                          const nfa_rqs_spec *spec, int32_t inverse, void *stream);
+int nfa_quadratic_spline_f32(const float *inputs, const float *unnormalized_widths, int64_t stride_w,
+                             const float *unnormalized_heights, int64_t stride_h,
+                             int32_t num_heights, float *outputs, float *logabsdet,
+                             int32_t *status, int64_t n, const nfa_rqs_spec *spec,
+                             int32_t inverse, void *stream);
+
+/*
  * K6.  Rational-quadratic CDF transform with parameters shared by the whole batch:
  *   PiecewiseRationalQuadraticCDF._spline, nonlinearities.py:431-467 (what the spline coupling
  *   layer applies to its identity half when apply_unconditional_transform=True, coupling.py:524-535).

@@ -1,0 +1,334 @@
+// K9: the rational-quadratic spline's siblings as elementwise functionals (SURVEY.md section 8f,
+// row f4): piecewise-linear (splines/linear.py:9-105) and piecewise-quadratic
+// (splines/quadratic.py:11-159) splines, constrained and with linear tails, forward and inverse.
+//
+// Same skeleton as K5: a tile of T elements per workgroup pass, every lane stages its own logits
+// in an LDS slot (coalesced when the logit arrays are one packed [n, P] view, a per-lane strided
+// gather otherwise), runs softmax -> prefix sums -> bin search -> per-bin polynomial on them in
+// place, and writes its output and log-derivative.  Arithmetic follows the reference step by step
+// (fp contraction off, IEEE division, prefix sums accumulated in double like aten's CPU cumsum);
+// the reference's quirks that are visible in the results are reproduced and marked below.
+
+#include "rqs_math.hpp"
+
+namespace nfa {
+
+enum { kLinear = 0, kQuadratic = 1 };
+
+struct LqArgs {
+    const float* x;
+    const float* a0;  // linear: unnormalized pdf [.., K]; quadratic: unnormalized widths [.., K]
+    const float* a1;  // quadratic: unnormalized heights [.., nh]
+    int64_t s0, s1;   // element strides of the rows of a0 / a1
+    float* y;
+    float* lad;
+    int32_t* status;
+    int64_t n;
+    int K, nh, slot, T, packed, unconstrained;
+    float left, right, bottom, top;     // box (unconstrained: +-tail_bound)
+    float span_in, span_out;            // (float)(right - left), (float)(top - bottom)
+    float min_w, min_h, om_w, om_h;     // quadratic: minimums, (float)(1 - min_w*K), (float)(1 - min_h)
+    float divisor, rdivisor;            // quadratic: logits / divisor first (0 = no scaling)
+    float log_bin_width;                // linear: (float)log(1/K)
+};
+
+__device__ __forceinline__ float clamp01(float v) {  // torch.clamp(v, 0, 1): NaN stays NaN
+    return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+}
+
+// softmax of K logits in place (optionally divided by `divisor` first); the fp32 denominator is
+// accumulated in double (a long sequential fp32 sum would drift from aten's blocked sum)
+__device__ __forceinline__ void softmax_in_place(float* p, int K, float divisor, float rdivisor) {
+#pragma clang fp contract(off)
+    float m = -INFINITY;
+    for (int i = 0; i < K; ++i) {
+        float u = p[i];
+        if (divisor != 0.0f) u = div_with_rcp(u, divisor, rdivisor);
+        p[i] = u;
+        m = fmaxf(m, u);
+    }
+    double s = 0.0;
+    for (int i = 0; i < K; ++i) {
+        const float e = exp_noclamp(p[i] - m);
+        p[i] = e;
+        s += (double)e;
+    }
+    const float sum = (float)s;
+    for (int i = 0; i < K; ++i) p[i] = p[i] / sum;
+}
+
+// splines/linear.py:40-105.  p: the lane's K logits (overwritten).  u: input already inside the box.
+template <bool INVERSE>
+__device__ __forceinline__ int linear_eval(float x, float* p, const LqArgs& a, float& y, float& lad) {
+#pragma clang fp contract(off)
+    const int K = a.K;
+    const float u = INVERSE ? (x - a.bottom) / a.span_out : (x - a.left) / a.span_in;
+    softmax_in_place(p, K, 0.0f, 0.0f);
+    float out;
+    if (INVERSE) {
+        // cdf = pad0(cumsum(pdf)) with cdf[K] = 1; searchsorted adds 1e-6 to the last knot IN PLACE
+        // (torchutils.py:135), so the last bin's slope and offset see 1 + 1e-6 as well (quirk)
+        double acc = 0.0;
+        float prev = 0.0f, lo = 0.0f, hi = 0.0f;
+        int k = -1;
+        for (int i = 0; i < K; ++i) {
+            acc += (double)p[i];
+            const float next = (i == K - 1) ? 1.0f + 1e-6f : (float)acc;
+            if (u >= prev) {
+                k = i;
+                lo = prev;
+                hi = next;
+            }
+            prev = next;
+        }
+        if (k < 0 || u >= prev) {
+            y = x;
+            lad = 0.0f;
+            return NFA_STATUS_OUTSIDE_DOMAIN;
+        }
+        // torch.linspace(0, 1, K + 1) in float32: start + i*step below the middle, end - (K-i)*step above
+        const float step = 1.0f / (float)K;
+        const int half = (K + 1) / 2;
+        const float b0 = (k < half) ? (float)k * step : 1.0f - (float)(K - k) * step;
+        const float b1 = (k + 1 < half) ? (float)(k + 1) * step : 1.0f - (float)(K - k - 1) * step;
+        const float slope = (hi - lo) / (b1 - b0);
+        const float offset = hi - slope * b1;
+        out = clamp01((u - offset) / slope);
+        lad = -log_normal(slope);
+    } else {
+        const float pos = u * (float)K;
+        int k = (int)floorf(pos);
+        k = k >= K ? K - 1 : (k < 0 ? 0 : k);
+        const float alpha = pos - (float)k;
+        double acc = 0.0;
+        for (int i = 0; i < k; ++i) acc += (double)p[i];
+        const float pk = p[k];
+        out = clamp01((float)acc + alpha * pk);
+        lad = log_normal(pk) - a.log_bin_width;
+    }
+    y = INVERSE ? out * a.span_in + a.left : out * a.span_out + a.bottom;
+    return 0;
+}
+
+// splines/quadratic.py:55-159.  w: K width logits (overwritten by the widths); h: K+1 slots, the
+// nh height logits sit at h[1..nh] (nh = K-1) or h[0..K] (nh = K+1) and are overwritten by the heights.
+template <bool INVERSE>
+__device__ __forceinline__ int quadratic_eval(float x, float* w, float* h, const LqArgs& a, float& y, float& lad) {
+#pragma clang fp contract(off)
+    const int K = a.K;
+    const float u = INVERSE ? (x - a.bottom) / a.span_out : (x - a.left) / a.span_in;
+    softmax_in_place(w, K, a.divisor, a.rdivisor);
+    for (int i = 0; i < K; ++i) w[i] = a.min_w + a.om_w * w[i];
+    const int first = (a.nh == K - 1) ? 1 : 0;
+    for (int i = first; i < first + a.nh; ++i) {
+        float v = h[i];
+        if (a.divisor != 0.0f) v = div_with_rcp(v, a.divisor, a.rdivisor);
+        h[i] = softplus_beta(v, 1.0f) + 1e-3f;
+    }
+    if (a.nh == K - 1) {  // boundary heights such that the normalised ones are exactly 1 (:93-107)
+        const float fw = 0.5f * w[0], lw = 0.5f * w[K - 1];
+        float s = 0.0f;
+        for (int i = 1; i + 1 < K; ++i) s += ((h[i] + h[i + 1]) / 2.0f) * w[i];
+        const float num = (0.5f * fw) * h[1] + (0.5f * lw) * h[K - 1] + s;
+        const float c = num / ((1.0f - 0.5f * fw) - 0.5f * lw);
+        h[0] = c;
+        h[K] = c;
+    }
+    float area = 0.0f;
+    for (int i = 0; i < K; ++i) area += ((h[i] + h[i + 1]) / 2.0f) * w[i];
+    for (int i = 0; i <= K; ++i) h[i] = a.min_h + a.om_h * (h[i] / area);
+
+    // knots: bin_left_cdf (searched in the inverse) and bin_locations (searched forward), both
+    // pad0(cumsum(.)) with the last entry forced to 1 (+1e-6 for the search)
+    double acc_c = 0.0, acc_l = 0.0;
+    float pc = 0.0f, pl = 0.0f, c0 = 0.0f, l0 = 0.0f;
+    int k = -1;
+    for (int i = 0; i < K; ++i) {
+        acc_c += (double)(((h[i] + h[i + 1]) / 2.0f) * w[i]);
+        acc_l += (double)w[i];
+        const bool last = i == K - 1;
+        const float nc = last ? 1.0f : (float)acc_c, nl = last ? 1.0f : (float)acc_l;
+        if (u >= (INVERSE ? pc : pl)) {
+            k = i;
+            c0 = pc;
+            l0 = pl;
+        }
+        pc = nc;
+        pl = nl;
+    }
+    if (k < 0 || u >= 1.0f + 1e-6f) {
+        y = x;
+        lad = 0.0f;
+        return NFA_STATUS_OUTSIDE_DOMAIN;
+    }
+    const float bw = w[k], hl = h[k], hr = h[k + 1];
+    const float qa = (0.5f * (hr - hl)) * bw, qb = hl * bw, qc = c0;
+    float out;
+    if (INVERSE) {
+        const float c_ = qc - u;
+        const float alpha = (-qb + sqrtf(qb * qb - (4.0f * qa) * c_)) / (2.0f * qa);
+        out = clamp01(alpha * bw + l0);
+        lad = -log_normal(alpha * (hr - hl) + hl);
+    } else {
+        const float alpha = (u - l0) / bw;
+        out = clamp01((qa * (alpha * alpha) + qb * alpha) + qc);
+        lad = log_normal(alpha * (hr - hl) + hl);
+    }
+    y = INVERSE ? out * a.span_in + a.left : out * a.span_out + a.bottom;
+    return 0;
+}
+
+template <int KIND, bool INVERSE>
+__global__ void __launch_bounds__(kBlock) spline_lq_kernel(const LqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int K = a.K;
+    const int P = KIND == kLinear ? K : K + a.nh;
+    int my_status = 0;
+    const int64_t num_tiles = (a.n + a.T - 1) / a.T;
+    for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+        const int64_t i0 = tile * a.T;
+        const int cnt = (int)((a.n - i0) < a.T ? (a.n - i0) : a.T);
+        // every lane owns `slot` floats: [K widths / pdf logits][K+1 heights]
+        float* mine = lds + tid * a.slot;
+        if (a.packed) {
+            // one contiguous [n, P] view: coalesced loads, scattered into the lanes' slots
+            const float* src = a.a0 + i0 * P;
+            const int total = cnt * P;
+            const int hshift = (KIND == kQuadratic && a.nh == K - 1) ? 1 : 0;
+            for (int e = tid; e < total; e += blockDim.x) {
+                const int who = e / P, q = e - who * P;
+                lds[who * a.slot + (q < K ? q : q + hshift)] = src[e];
+            }
+            __syncthreads();
+        } else if (tid < cnt) {
+            const int64_t i = i0 + tid;
+            for (int q = 0; q < K; ++q) mine[q] = a.a0[i * a.s0 + q];
+            if (KIND == kQuadratic) {
+                const int first = (a.nh == K - 1) ? 1 : 0;
+                for (int q = 0; q < a.nh; ++q) mine[K + first + q] = a.a1[i * a.s1 + q];
+            }
+        }
+        if (tid < cnt) {
+            const float x = a.x[i0 + tid];
+            float y = x, l = 0.0f;
+            // linear tails: elements outside [-B, B] (NaN included) pass through (linear.py:12-22)
+            const bool inside = x >= a.left && x <= a.right;
+            if (inside) {
+                my_status |= KIND == kLinear ? linear_eval<INVERSE>(x, mine, a, y, l)
+                                             : quadratic_eval<INVERSE>(x, mine, mine + K, a, y, l);
+            } else if (!a.unconstrained) {
+                my_status |= NFA_STATUS_OUTSIDE_DOMAIN;  // linear.py:47-48 / quadratic.py:66-67
+            }
+            a.y[i0 + tid] = y;
+            a.lad[i0 + tid] = l;
+        }
+        __syncthreads();  // before the next tile overwrites the slots
+    }
+    if (my_status && a.status) atomicOr(a.status, my_status);
+}
+
+static int launch_lq(LqArgs& a, int kind, int inverse, hipStream_t st) {
+    const int K = a.K;
+    a.slot = (kind == kLinear ? K : 2 * K + 1) | 1;  // odd stride: conflict-free per-lane walks
+    int T = kBlock;
+    while (T > 32 && (size_t)T * a.slot * 4 > (size_t)64 * 1024) T >>= 1;
+    if ((size_t)T * a.slot * 4 > (size_t)64 * 1024) return NFA_ERR_UNSUPPORTED;
+    a.T = T;
+    const size_t lds = (size_t)T * a.slot * 4;
+    const int64_t tiles = (a.n + T - 1) / T;
+    int per_cu = (int)((size_t)(160 * 1024) / (lds + 256));
+    per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
+    int64_t g = (int64_t)device_cu_count() * per_cu;
+    if (g > tiles) g = tiles;
+    const dim3 grid((unsigned)g), block((unsigned)T);
+    if (kind == kLinear) {
+        if (inverse) hipLaunchKernelGGL((spline_lq_kernel<kLinear, true>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((spline_lq_kernel<kLinear, false>), grid, block, lds, st, a);
+    } else {
+        if (inverse) hipLaunchKernelGGL((spline_lq_kernel<kQuadratic, true>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((spline_lq_kernel<kQuadratic, false>), grid, block, lds, st, a);
+    }
+    NFA_HIP_CHECK(hipGetLastError());
+    return NFA_OK;
+}
+
+static int fill_common(LqArgs& a, const nfa_rqs_spec* spec) {
+    if (!spec) return NFA_ERR_INVALID_ARGUMENT;
+    if (spec->num_bins < 1 || spec->num_bins > 4096) return NFA_ERR_INVALID_ARGUMENT;
+    if (spec->tails != NFA_TAILS_NONE && spec->tails != NFA_TAILS_LINEAR) return NFA_ERR_INVALID_ARGUMENT;
+    a.K = spec->num_bins;
+    a.unconstrained = spec->tails == NFA_TAILS_LINEAR;
+    a.left = (float)spec->left;
+    a.right = (float)spec->right;
+    a.bottom = (float)spec->bottom;
+    a.top = (float)spec->top;
+    a.span_in = (float)(spec->right - spec->left);
+    a.span_out = (float)(spec->top - spec->bottom);
+    a.log_bin_width = (float)log(1.0 / (double)spec->num_bins);
+    a.min_w = (float)spec->min_bin_width;
+    a.min_h = (float)spec->min_bin_height;
+    a.om_w = (float)(1.0 - spec->min_bin_width * spec->num_bins);
+    a.om_h = (float)(1.0 - spec->min_bin_height);
+    a.divisor = (float)spec->wh_divisor;
+    a.rdivisor = a.divisor != 0.0f ? 1.0f / a.divisor : 0.0f;
+    return NFA_OK;
+}
+
+}  // namespace nfa
+
+using namespace nfa;
+
+extern "C" int nfa_linear_spline_f32(const float* inputs, const float* unnormalized_pdf, int64_t stride,
+                                     float* outputs, float* logabsdet, int32_t* status, int64_t n,
+                                     const nfa_rqs_spec* spec, int32_t inverse, void* stream) {
+    if (n < 0) return NFA_ERR_INVALID_ARGUMENT;
+    LqArgs a;
+    int rc = fill_common(a, spec);
+    if (rc != NFA_OK) return rc;
+    if (n == 0) return NFA_OK;
+    if (!inputs || !unnormalized_pdf || !outputs || !logabsdet) return NFA_ERR_INVALID_ARGUMENT;
+    a.x = inputs;
+    a.a0 = unnormalized_pdf;
+    a.a1 = nullptr;
+    a.s0 = stride;
+    a.s1 = 0;
+    a.nh = 0;
+    a.y = outputs;
+    a.lad = logabsdet;
+    a.status = status;
+    a.n = n;
+    a.packed = stride == a.K;
+    return launch_lq(a, kLinear, inverse, (hipStream_t)stream);
+}
+
+extern "C" int nfa_quadratic_spline_f32(const float* inputs, const float* unnormalized_widths,
+                                        int64_t stride_w, const float* unnormalized_heights,
+                                        int64_t stride_h, int32_t num_heights, float* outputs,
+                                        float* logabsdet, int32_t* status, int64_t n,
+                                        const nfa_rqs_spec* spec, int32_t inverse, void* stream) {
+    if (n < 0) return NFA_ERR_INVALID_ARGUMENT;
+    LqArgs a;
+    int rc = fill_common(a, spec);
+    if (rc != NFA_OK) return rc;
+    if (spec->min_bin_width * spec->num_bins > 1.0) return NFA_ERR_MIN_BIN_WIDTH;
+    if (spec->min_bin_height * spec->num_bins > 1.0) return NFA_ERR_MIN_BIN_HEIGHT;
+    if (num_heights != a.K - 1 && num_heights != a.K + 1) return NFA_ERR_INVALID_ARGUMENT;
+    if (a.K < 2 && num_heights == a.K - 1) return NFA_ERR_INVALID_ARGUMENT;
+    if (n == 0) return NFA_OK;
+    if (!inputs || !unnormalized_widths || !unnormalized_heights || !outputs || !logabsdet)
+        return NFA_ERR_INVALID_ARGUMENT;
+    a.x = inputs;
+    a.a0 = unnormalized_widths;
+    a.a1 = unnormalized_heights;
+    a.s0 = stride_w;
+    a.s1 = stride_h;
+    a.nh = num_heights;
+    a.y = outputs;
+    a.lad = logabsdet;
+    a.status = status;
+    a.n = n;
+    const int P = a.K + num_heights;
+    a.packed = (unnormalized_heights == unnormalized_widths + a.K) && stride_w == P && stride_h == P;
+    return launch_lq(a, kQuadratic, inverse, (hipStream_t)stream);
+}

@@ -270,6 +270,75 @@ def _rqs_elementwise_launch(inputs, unnormalized_widths, unnormalized_heights, u
     return y.view(shape), lad.view(shape)
 
 
+def _logit_rows(t, n, width):
+    """[n, width] view with unit inner stride and a uniform row stride, copying only if needed."""
+    try:
+        v = t.view(n, width) if n else t.reshape(n, width)
+    except RuntimeError:
+        v = t.reshape(n, width)
+    if v.stride(1) != 1 or (n > 1 and v.stride(0) < width):
+        v = v.contiguous()
+    return v, (v.stride(0) if n > 1 else width)
+
+
+def _no_backward_yet(what, *tensors):
+    if AG.needs_grad(*tensors):
+        raise NotImplementedError("nflows_amd: %s has no backward kernel yet; evaluate under "
+                                  "torch.no_grad() or detach the inputs" % what)
+
+
+def linear_spline(inputs, unnormalized_pdf, spec, inverse=False):
+    """K9 -- piecewise-linear spline functional (splines/linear.py) on tensors of any leading shape
+    S; unnormalized_pdf S+[K].  Returns (outputs S, logabsdet S)."""
+    N.require_device_f32("inputs", inputs)
+    N.require_device_f32("unnormalized_pdf", unnormalized_pdf)
+    _no_backward_yet("the linear spline", inputs, unnormalized_pdf)
+    K = spec.num_bins
+    shape = inputs.shape
+    if unnormalized_pdf.shape != shape + (K,):
+        raise ValueError("unnormalized_pdf must have shape %s+[%d]" % (tuple(shape), K))
+    dev = inputs.device
+    n = inputs.numel()
+    x = inputs.detach().contiguous().view(-1)
+    pdf, stride = _logit_rows(unnormalized_pdf.detach(), n, K)
+    y, lad = torch.empty_like(x), torch.empty_like(x)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_linear_spline_f32(N.ptr(x), N.ptr(pdf), stride, N.ptr(y), N.ptr(lad),
+                                            N.ptr(_status_word(dev)), n, ctypes.byref(spec),
+                                            int(bool(inverse)), N.stream_handle(dev))
+    N.check(rc)
+    _after_spline(spec, inverse, dev)
+    return y.view(shape), lad.view(shape)
+
+
+def quadratic_spline(inputs, unnormalized_widths, unnormalized_heights, spec, inverse=False):
+    """K9 -- piecewise-quadratic spline functional (splines/quadratic.py); widths S+[K], heights
+    S+[K-1] (boundary heights derived) or S+[K+1]."""
+    N.require_device_f32("inputs", inputs)
+    N.require_device_f32("unnormalized_widths", unnormalized_widths)
+    N.require_device_f32("unnormalized_heights", unnormalized_heights)
+    _no_backward_yet("the quadratic spline", inputs, unnormalized_widths, unnormalized_heights)
+    K = spec.num_bins
+    shape = inputs.shape
+    nh = unnormalized_heights.shape[-1] if unnormalized_heights.dim() else -1
+    if (unnormalized_widths.shape != shape + (K,) or unnormalized_heights.shape[:-1] != shape
+            or nh not in (K - 1, K + 1)):
+        raise ValueError("spline logits must have shapes %s+[%d], +[%d or %d]" % (tuple(shape), K, K - 1, K + 1))
+    dev = inputs.device
+    n = inputs.numel()
+    x = inputs.detach().contiguous().view(-1)
+    uw, sw = _logit_rows(unnormalized_widths.detach(), n, K)
+    uh, sh = _logit_rows(unnormalized_heights.detach(), n, nh)
+    y, lad = torch.empty_like(x), torch.empty_like(x)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_quadratic_spline_f32(N.ptr(x), N.ptr(uw), sw, N.ptr(uh), sh, nh, N.ptr(y), N.ptr(lad),
+                                               N.ptr(_status_word(dev)), n, ctypes.byref(spec),
+                                               int(bool(inverse)), N.stream_handle(dev))
+    N.check(rc)
+    _after_spline(spec, inverse, dev)
+    return y.view(shape), lad.view(shape)
+
+
 def affine_coupling(inputs, params, transform_idx, activation, inverse=False, scale=None,
                     in_perm=None, out_scatter=None, accumulate_into=None):
     """K2 -- fused affine/additive coupling.  params [B, 2*d_t] = [shift | scale logits]

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import LAD_TOL, OUT_TOL, assert_fp32_parity, parse_kwargs
+from helpers import LAD_TOL, OUT_TOL, assert_fp32_parity, assert_sibling_spline_parity, parse_kwargs
 from oracle import capi
 
 pytestmark = pytest.mark.gpu
@@ -342,3 +342,87 @@ def test_full_size_round_trip_and_properties(ops):
     rows = torch.randint(0, B, (2048,), generator=torch.Generator().manual_seed(1))
     oy, ol, _ = capi.rqs_coupling(host(x[rows]), host(params[rows]), host(tidx), ospec)
     assert np.abs(host(y[rows]) - oy).max() <= 5e-6 and np.abs(host(lad[rows]) - ol).max() <= 5e-5
+
+
+# ------------------------------------------------------------------ K9: linear / quadratic splines
+def test_linear_and_quadratic_splines_golden(ops, golden_dir):
+    """K9 through the drop-in functionals against the real reference's vectors
+    (tests/golden/splines_lq.npz): constrained / linear tails, forward / inverse, shaped inputs."""
+    from nflows_amd.transforms import splines
+    g = np.load(os.path.join(golden_dir, "splines_lq.npz"))
+    for name, kind, kw in g["meta"]:
+        kw = parse_kwargs(kw)
+        x = dev(g[name + "/x"])
+        logits = [dev(g["%s/logits%d" % (name, i)]) for i in range(1 if kind == "linear" else 2)]
+        unconstrained = kw.get("tails") == "linear"
+        fn = {("linear", False): splines.linear_spline, ("linear", True): splines.unconstrained_linear_spline,
+              ("quadratic", False): splines.quadratic_spline,
+              ("quadratic", True): splines.unconstrained_quadratic_spline}[(str(kind), unconstrained)]
+        for inverse in (False, True):
+            pre = name + ("/inv_" if inverse else "/")
+            y, lad = fn(x, *logits, inverse=inverse, **kw)
+            ops.check_status()
+            assert y.shape == x.shape and lad.shape == x.shape
+            assert_sibling_spline_parity(host(y), g[pre + "y"], g[pre + "y64"], OUT_TOL, 5e-5, name + " y")
+            assert_sibling_spline_parity(host(lad), g[pre + "lad"], g[pre + "lad64"], LAD_TOL, 1e-3, name + " lad")
+            if unconstrained:
+                tb = np.float32(kw["tail_bound"])
+                xs = g[name + "/x"]
+                outside = ~((xs >= -tb) & (xs <= tb))
+                assert np.array_equal(host(y)[outside].view(np.uint32), xs[outside].view(np.uint32)), name
+                assert np.all(host(lad)[outside] == 0), name
+
+
+@pytest.mark.parametrize("K", [3, 8, 40])
+def test_linear_and_quadratic_splines_oracle(ops, K):
+    """Fresh inputs, packed and strided logit layouts, against the C oracle (float build)."""
+    from nflows_amd.transforms import splines
+    rng = np.random.RandomState(K)
+    n = 3000
+    x = (2.0 * rng.randn(n)).astype(np.float32)
+    blob = (1.5 * rng.randn(n, 2 * K - 1 + 5)).astype(np.float32)   # widths | heights | unrelated columns
+    spec = capi.make_spec(K, tails="linear", tail_bound=3.0)
+    uw, uh = blob[:, :K], blob[:, K:2 * K - 1]
+    for inverse in (False, True):
+        oy, ol, st = capi.quadratic_spline(x, uw, uh, spec, inverse=inverse)
+        assert st == 0
+        t = dev(blob)
+        y, lad = splines.unconstrained_quadratic_spline(dev(x), t[:, :K], t[:, K:2 * K - 1], inverse=inverse, tail_bound=3.0)
+        packed = dev(np.ascontiguousarray(blob[:, :2 * K - 1]))
+        y2, lad2 = splines.unconstrained_quadratic_spline(dev(x), packed[:, :K], packed[:, K:], inverse=inverse, tail_bound=3.0)
+        assert torch.equal(y, y2) and torch.equal(lad, lad2)      # strided gather == packed tile path
+        assert np.mean(np.abs(host(y) - oy) <= OUT_TOL * (1 + np.abs(oy))) >= 0.97
+        assert np.mean(np.abs(host(lad) - ol) <= LAD_TOL * (1 + np.abs(ol))) >= 0.97
+        oy, ol, st = capi.linear_spline(x, uw, spec, inverse=inverse)
+        y, lad = splines.unconstrained_linear_spline(dev(x), t[:, :K], inverse=inverse, tail_bound=3.0)
+        y2, lad2 = splines.unconstrained_linear_spline(dev(x), dev(np.ascontiguousarray(uw)), inverse=inverse, tail_bound=3.0)
+        assert torch.equal(y, y2) and torch.equal(lad, lad2)
+        assert np.mean(np.abs(host(y) - oy) <= OUT_TOL * (1 + np.abs(oy))) >= 0.97
+        assert np.mean(np.abs(host(lad) - ol) <= LAD_TOL * (1 + np.abs(ol))) >= 0.97
+    ops.check_status()
+    # round trip
+    xs = dev(np.clip(x, -2.999, 2.999))
+    y, lad = splines.unconstrained_quadratic_spline(xs, t[:, :K], t[:, K:2 * K - 1], tail_bound=3.0)
+    xr, lad_inv = splines.unconstrained_quadratic_spline(y, t[:, :K], t[:, K:2 * K - 1], inverse=True, tail_bound=3.0)
+    assert (xr - xs).abs().median().item() < 1e-5 and (lad + lad_inv).abs().median().item() < 1e-4
+
+
+def test_linear_and_quadratic_spline_errors(ops):
+    from nflows_amd import InputOutsideDomain
+    from nflows_amd.transforms import splines
+    x = torch.tensor([0.5, 1.5], device=DEV)
+    z = torch.zeros(2, 4, device=DEV)
+    with pytest.raises(InputOutsideDomain):
+        splines.linear_spline(x, z)
+    with pytest.raises(InputOutsideDomain):
+        splines.quadratic_spline(x, z, torch.zeros(2, 5, device=DEV))
+    with pytest.raises(ValueError, match="Minimal bin width too large"):
+        splines.quadratic_spline(x[:1], z[:1], torch.zeros(1, 5, device=DEV), min_bin_width=0.3)
+    with pytest.raises(RuntimeError, match="cubic tails are not implemented"):
+        splines.unconstrained_linear_spline(x[:1], z[:1], tails="cubic")
+    with pytest.raises(AssertionError):
+        splines.unconstrained_quadratic_spline(x[:1], z[:1], torch.zeros(1, 5, device=DEV))
+    e = torch.zeros(0, device=DEV)
+    y, lad = splines.linear_spline(e, torch.zeros(0, 4, device=DEV))
+    assert y.shape == (0,) and lad.shape == (0,)
+    ops.check_status()
