@@ -1,2 +1,2 @@
-from .resnet import ResidualBlock, ResidualNet
+from .resnet import ConvResidualBlock, ConvResidualNet, ResidualBlock, ResidualNet
 from .mlp import MLP

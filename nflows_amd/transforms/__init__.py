@@ -1,10 +1,12 @@
 from .base import (CompositeTransform, InputOutsideDomain, InverseNotAvailable, InverseTransform,
                    Transform)
 from .coupling import (AdditiveCouplingTransform, AffineCouplingTransform, CouplingTransform,
+                       PiecewiseLinearCouplingTransform, PiecewiseQuadraticCouplingTransform,
                        PiecewiseRationalQuadraticCouplingTransform)
 from .permutations import Permutation, RandomPermutation, ReversePermutation
 from . import splines
 from .autoregressive import (AutoregressiveTransform, MaskedAffineAutoregressiveTransform,
                              MaskedPiecewiseRationalQuadraticAutoregressiveTransform)
 from .made import MADE
-from .nonlinearities import PiecewiseRationalQuadraticCDF
+from .nonlinearities import (PiecewiseLinearCDF, PiecewiseQuadraticCDF,
+                            PiecewiseRationalQuadraticCDF)

@@ -10,8 +10,10 @@ loads unchanged.  Per layer the host does exactly three things:
      the elementwise transform, the per-sample logabsdet sum and the scatter, optionally with
      the neighbouring column permutation folded in.
 
-Only 2-D float32 inputs on a HIP device are implemented; 4-D image inputs
-(coupling.py:280-285) and the other piecewise families are out of scope and raise.
+The fused kernels serve 2-D float32 inputs.  4-D image inputs (coupling.py:280-285) and the
+linear / quadratic piecewise families take the generic path of `CouplingTransform._generic`: the
+reference's own sequence (split, conditioner, elementwise spline functional, sum, merge) with the
+functional running as one HIP kernel (K5 / K9) on strided views.
 """
 import os
 import warnings
@@ -22,7 +24,9 @@ from torch.nn.functional import softplus
 
 from .. import _native as N
 from .. import ops
+from ..utils import torchutils
 from .base import Transform
+from . import splines
 from .splines import rational_quadratic
 
 
@@ -31,7 +35,8 @@ class CouplingTransform(Transform):
 
     mask[i] > 0: feature i is transformed; mask[i] <= 0: passed through (coupling.py:25-63)."""
 
-    supports_fused_permutation = True
+    supports_fused_permutation = True   # 2-D inputs go through one fused kernel per layer
+    supports_image_inputs = False       # 4-D inputs allowed (generic path)
 
     def __init__(self, mask, transform_net_create_fn, unconditional_transform=None):
         mask = torch.as_tensor(mask)
@@ -69,10 +74,10 @@ class CouplingTransform(Transform):
             raise ValueError("Inputs must be a 2D or a 4D tensor.")
         if inputs.shape[1] != self.features:
             raise ValueError("Expected features = {}, got {}.".format(self.features, inputs.shape[1]))
-        if inputs.dim() == 4:
+        if inputs.dim() == 4 and not self.supports_image_inputs:
             raise NotImplementedError(
-                "nflows_amd: 4-D (image) coupling inputs are outside the MI355X hot path")
-        N.require_device_f32("inputs", inputs, 2)
+                "nflows_amd: 4-D (image) inputs are implemented for the piecewise spline couplings only")
+        N.require_device_f32("inputs", inputs, inputs.dim())
 
     def _identity_columns(self, perm):
         """identity_features seen through a fused permutation, cached per permutation tensor."""
@@ -93,6 +98,8 @@ class CouplingTransform(Transform):
         `logabsdet_accumulator`: a [batch] running total the layer's logabsdet is added to in the
         kernel (CompositeTransform's `total_logabsdet +=`); it is then also the returned tensor."""
         self._check_inputs(inputs)
+        if inputs.dim() == 4 or not self.supports_fused_permutation:
+            return self._generic(inputs, context, False, logabsdet_accumulator)
         if self.unconditional_transform is None:
             whole = self._whole_layer(inputs, context, False, in_perm, None, logabsdet_accumulator)
             if whole is not None:
@@ -114,6 +121,8 @@ class CouplingTransform(Transform):
         """Inverse pass (coupling.py:102-130).  `out_scatter`: store layer column c at
         outputs[:, out_scatter[c]] (a following Permutation.inverse, fused)."""
         self._check_inputs(inputs)
+        if inputs.dim() == 4 or not self.supports_fused_permutation:
+            return self._generic(inputs, context, True, logabsdet_accumulator)
         if self.unconditional_transform is None:
             whole = self._whole_layer(inputs, context, True, None, out_scatter, logabsdet_accumulator)
             if whole is not None:
@@ -136,6 +145,40 @@ class CouplingTransform(Transform):
     def _whole_layer(self, inputs, context, inverse, in_perm, out_scatter, accumulate_into):
         """Hook for a kernel that contains the conditioner as well; None = not applicable."""
         return None
+
+    def _generic(self, inputs, context, inverse, logabsdet_accumulator):
+        """The reference's sequence (coupling.py:73-130) for inputs [B, C] or [B, C, H, W]: split on
+        dim 1, conditioner on the identity part, `_elementwise` on the other, merge."""
+        identity_split = inputs.index_select(1, self.identity_features)
+        transform_split = inputs.index_select(1, self.transform_features)
+        logabsdet = None
+        if inverse and self.unconditional_transform is not None:
+            identity_split, logabsdet = self.unconditional_transform.inverse(identity_split, context)
+        transform_params = self.transform_net(identity_split, context)
+        if inputs.dim() == 4:
+            b, c, h, w = transform_split.shape
+            transform_params = transform_params.reshape(b, c, -1, h, w).permute(0, 1, 3, 4, 2)
+        else:
+            b, d = transform_split.shape
+            transform_params = transform_params.reshape(b, d, -1)
+        transform_split, lad_elementwise = self._elementwise(transform_split, transform_params, inverse)
+        lad_split = torchutils.sum_except_batch(lad_elementwise)
+        logabsdet = lad_split if logabsdet is None else logabsdet + lad_split
+        if not inverse and self.unconditional_transform is not None:
+            identity_split, lad_identity = self.unconditional_transform(identity_split, context)
+            logabsdet = logabsdet + lad_identity
+        outputs = torch.empty_like(inputs)
+        outputs.index_copy_(1, self.identity_features, identity_split)
+        outputs.index_copy_(1, self.transform_features, transform_split)
+        if logabsdet_accumulator is not None:
+            logabsdet_accumulator += logabsdet
+            logabsdet = logabsdet_accumulator
+        return outputs, logabsdet
+
+    def _elementwise(self, inputs, transform_params, inverse):
+        """Elementwise transform of the transformed part given per-element parameters
+        [..., params]; returns (outputs, logabsdet) of the inputs' shape (generic path only)."""
+        raise NotImplementedError("nflows_amd: {} has no generic path".format(type(self).__name__))
 
     def _condition_and_transform(self, inputs, identity_split, context, inverse, in_perm=None,
                                  out_scatter=None, accumulate_into=None):
@@ -211,6 +254,8 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
     `hidden_channels` (coupling.py:554-559) -- done on the fly inside the kernel, the conditioner
     output tensor itself is left untouched."""
 
+    supports_image_inputs = True
+
     def __init__(self, mask, transform_net_create_fn, num_bins=10, tails=None, tail_bound=1.0,
                  apply_unconditional_transform=False, img_shape=None,
                  min_bin_width=rational_quadratic.DEFAULT_MIN_BIN_WIDTH,
@@ -253,6 +298,11 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
                                  min_bin_width=self.min_bin_width,
                                  min_bin_height=self.min_bin_height,
                                  min_derivative=self.min_derivative, wh_divisor=divisor)
+
+    def _elementwise(self, inputs, transform_params, inverse):
+        K = self.num_bins
+        return ops.rqs_elementwise(inputs, transform_params[..., :K], transform_params[..., K:2 * K],
+                                   transform_params[..., 2 * K:], self._spec(), inverse)
 
     # K7: fold the conditioner's final Linear into the spline kernel (no [B, d_t*P] round trip
     # through HBM).  Class-level switch for A/B measurements.
@@ -388,3 +438,80 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         return ops.rqs_coupling(inputs, transform_params, self.transform_features, self._spec(),
                                 inverse=inverse, in_perm=in_perm, out_scatter=out_scatter,
                                 accumulate_into=accumulate_into)
+
+
+class PiecewiseLinearCouplingTransform(CouplingTransform):
+    """Piecewise-linear coupling layer (Mueller et al. 2018); coupling.py:297-350.  The conditioner
+    emits K pdf logits per transformed element."""
+
+    supports_fused_permutation = False
+    supports_image_inputs = True
+
+    def __init__(self, mask, transform_net_create_fn, num_bins=10, tails=None, tail_bound=1.0,
+                 apply_unconditional_transform=False, img_shape=None):
+        self.num_bins = num_bins
+        self.tails = tails
+        self.tail_bound = tail_bound
+        if apply_unconditional_transform:
+            from .nonlinearities import PiecewiseLinearCDF
+
+            def unconditional_transform(features):
+                return PiecewiseLinearCDF(shape=[features] + (img_shape if img_shape else []), num_bins=num_bins,
+                                          tails=tails, tail_bound=tail_bound)
+        else:
+            unconditional_transform = None
+        super().__init__(mask, transform_net_create_fn, unconditional_transform=unconditional_transform)
+
+    def _transform_dim_multiplier(self):
+        return self.num_bins
+
+    def _elementwise(self, inputs, transform_params, inverse):
+        if self.tails is None:
+            return splines.linear_spline(inputs, transform_params, inverse=inverse)
+        return splines.unconstrained_linear_spline(inputs, transform_params, inverse=inverse, tails=self.tails,
+                                                   tail_bound=self.tail_bound)
+
+
+class PiecewiseQuadraticCouplingTransform(CouplingTransform):
+    """Piecewise-quadratic coupling layer (Mueller et al. 2018); coupling.py:353-429.  K width
+    logits and K+1 (tails=None) / K-1 (linear tails) height logits per transformed element, both
+    divided by sqrt(hidden_features) when the conditioner exposes it (coupling.py:408-410)."""
+
+    supports_fused_permutation = False
+    supports_image_inputs = True
+
+    def __init__(self, mask, transform_net_create_fn, num_bins=10, tails=None, tail_bound=1.0,
+                 apply_unconditional_transform=False, img_shape=None,
+                 min_bin_width=splines.quadratic.DEFAULT_MIN_BIN_WIDTH,
+                 min_bin_height=splines.quadratic.DEFAULT_MIN_BIN_HEIGHT):
+        self.num_bins = num_bins
+        self.tails = tails
+        self.tail_bound = tail_bound
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        if apply_unconditional_transform:
+            from .nonlinearities import PiecewiseQuadraticCDF
+
+            def unconditional_transform(features):
+                return PiecewiseQuadraticCDF(shape=[features] + (img_shape if img_shape else []),
+                                             num_bins=num_bins, tails=tails, tail_bound=tail_bound,
+                                             min_bin_width=min_bin_width, min_bin_height=min_bin_height)
+        else:
+            unconditional_transform = None
+        super().__init__(mask, transform_net_create_fn, unconditional_transform=unconditional_transform)
+
+    def _transform_dim_multiplier(self):
+        return self.num_bins * 2 - 1 if self.tails == "linear" else self.num_bins * 2 + 1
+
+    def _elementwise(self, inputs, transform_params, inverse):
+        if self.tails is not None and self.tails != "linear":
+            raise RuntimeError("{} tails are not implemented.".format(self.tails))
+        K = self.num_bins
+        divisor = 0.0
+        if hasattr(self.transform_net, "hidden_features"):
+            divisor = float(np.sqrt(self.transform_net.hidden_features))
+        spec = ops.make_rqs_spec(K, self.tails, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
+                                 min_bin_height=self.min_bin_height, wh_divisor=divisor)
+        if self.tails == "linear":
+            assert transform_params.shape[-1] == 2 * K - 1  # quadratic.py:34
+        return ops.quadratic_spline(inputs, transform_params[..., :K], transform_params[..., K:], spec, inverse)

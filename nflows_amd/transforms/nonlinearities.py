@@ -1,6 +1,6 @@
-"""Batch-shared rational-quadratic CDF transform (reference: nflows/transforms/nonlinearities.py
-:386-467), the only member of that module on the hot path: the spline coupling layer applies it to
-its identity half when `apply_unconditional_transform=True` (coupling.py:524-535).
+"""Batch-shared spline CDF transforms (reference: nflows/transforms/nonlinearities.py:230-319,
+:386-467), the members of that module on the hot path: the spline coupling layers apply them to
+their identity half when `apply_unconditional_transform=True` (coupling.py:318-330, :524-535).
 
 Parameters have shape [*shape, K] and are shared by every sample.  Without grad the K6 kernel
 builds each feature's knots once per workgroup in LDS; with grad the logits are broadcast over
@@ -16,6 +16,7 @@ from .. import ops
 from ..utils import torchutils
 from .base import Transform
 from .splines import rational_quadratic
+from . import splines
 
 
 class PiecewiseRationalQuadraticCDF(Transform):
@@ -69,6 +70,71 @@ class PiecewiseRationalQuadraticCDF(Transform):
                                  min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                                  min_derivative=self.min_derivative)
         return ops.rqs_shared(inputs, uw, uh, ud, spec, inverse)
+
+    def forward(self, inputs, context=None):
+        return self._spline(inputs, inverse=False)
+
+    def inverse(self, inputs, context=None):
+        return self._spline(inputs, inverse=True)
+
+
+def _share_across_batch(params, batch_size):
+    return params[None, ...].expand(batch_size, *params.shape)
+
+
+class PiecewiseLinearCDF(Transform):
+    """Piecewise-linear CDF with one parameter set [*shape, K] shared by every sample
+    (nonlinearities.py:230-263)."""
+
+    def __init__(self, shape, num_bins=10, tails=None, tail_bound=1.0):
+        super().__init__()
+        self.tail_bound = tail_bound
+        self.tails = tails
+        self.unnormalized_pdf = nn.Parameter(torch.randn(*shape, num_bins))
+
+    def _spline(self, inputs, inverse=False):
+        pdf = _share_across_batch(self.unnormalized_pdf, inputs.shape[0])
+        if self.tails is None:
+            outputs, logabsdet = splines.linear_spline(inputs, pdf, inverse=inverse)
+        else:
+            outputs, logabsdet = splines.unconstrained_linear_spline(inputs, pdf, inverse=inverse, tails=self.tails,
+                                                                     tail_bound=self.tail_bound)
+        return outputs, torchutils.sum_except_batch(logabsdet)
+
+    def forward(self, inputs, context=None):
+        return self._spline(inputs, inverse=False)
+
+    def inverse(self, inputs, context=None):
+        return self._spline(inputs, inverse=True)
+
+
+class PiecewiseQuadraticCDF(Transform):
+    """Piecewise-quadratic CDF, parameters shared by every sample (nonlinearities.py:266-319):
+    K width logits and K+1 (tails=None) or K-1 (linear tails) height logits per element."""
+
+    def __init__(self, shape, num_bins=10, tails=None, tail_bound=1.0,
+                 min_bin_width=splines.quadratic.DEFAULT_MIN_BIN_WIDTH,
+                 min_bin_height=splines.quadratic.DEFAULT_MIN_BIN_HEIGHT):
+        super().__init__()
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.tail_bound = tail_bound
+        self.tails = tails
+        self.unnormalized_widths = nn.Parameter(torch.randn(*shape, num_bins))
+        self.unnormalized_heights = nn.Parameter(torch.randn(*shape, num_bins + 1 if tails is None else num_bins - 1))
+
+    def _spline(self, inputs, inverse=False):
+        uw = _share_across_batch(self.unnormalized_widths, inputs.shape[0])
+        uh = _share_across_batch(self.unnormalized_heights, inputs.shape[0])
+        if self.tails is None:
+            outputs, logabsdet = splines.quadratic_spline(inputs, uw, uh, inverse=inverse,
+                                                          min_bin_width=self.min_bin_width,
+                                                          min_bin_height=self.min_bin_height)
+        else:
+            outputs, logabsdet = splines.unconstrained_quadratic_spline(
+                inputs, uw, uh, inverse=inverse, tails=self.tails, tail_bound=self.tail_bound,
+                min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height)
+        return outputs, torchutils.sum_except_batch(logabsdet)
 
     def forward(self, inputs, context=None):
         return self._spline(inputs, inverse=False)

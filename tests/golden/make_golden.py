@@ -28,6 +28,8 @@ from nflows.transforms.base import CompositeTransform, InputOutsideDomain  # noq
 from nflows.transforms.coupling import (  # noqa: E402
     AdditiveCouplingTransform,
     AffineCouplingTransform,
+    PiecewiseLinearCouplingTransform,
+    PiecewiseQuadraticCouplingTransform,
     PiecewiseRationalQuadraticCouplingTransform,
 )
 from nflows.transforms.permutations import RandomPermutation, ReversePermutation  # noqa: E402
@@ -35,7 +37,7 @@ from nflows.transforms.autoregressive import (  # noqa: E402
     MaskedAffineAutoregressiveTransform,
     MaskedPiecewiseRationalQuadraticAutoregressiveTransform,
 )
-from nflows.nn.nets import ResidualNet, MLP  # noqa: E402
+from nflows.nn.nets import ResidualNet, ConvResidualNet, MLP  # noqa: E402
 from nflows.flows.base import Flow  # noqa: E402
 from nflows.distributions.normal import StandardNormal  # noqa: E402
 from nflows.utils import torchutils  # noqa: E402
@@ -611,6 +613,68 @@ def sibling_spline_cases():
     print("sibling splines:", len(meta), "cases")
 
 
+def sibling_coupling_cases():
+    """Coupling layers outside the fused kernels: linear / quadratic piecewise couplings on [B, D]
+    and spline couplings on [B, C, H, W] images with a ConvResidualNet conditioner."""
+    out = {}
+    meta = []
+
+    def finish(name, t, x, noise, cfg):
+        t.eval()
+        with torch.no_grad():
+            z, lad = t(x)
+            xs, lad_inv = t.inverse(noise)
+            t64 = t.double()
+            z64, lad64 = t64(x.double())
+            xs64, ladi64 = t64.inverse(noise.double())
+            t.float()
+        state_to_np(name, t, out)
+        for k, v in dict(x=x, noise=noise, z=z, lad=lad, inv_x=xs, inv_lad=lad_inv, z64=z64, lad64=lad64,
+                         inv_x64=xs64, inv_lad64=ladi64).items():
+            out[name + "/" + k] = npy(v)
+        meta.append((name, repr(cfg)))
+
+    def sharpen(t, f_final, f_last):
+        with torch.no_grad():
+            for p_name, p in t.named_parameters():
+                if "final_layer" in p_name:
+                    p.mul_(f_final)
+                elif "linear_layers.1" in p_name or "conv_layers.1" in p_name:
+                    p.mul_(f_last)
+
+    g = torch.Generator().manual_seed(77)
+    D, H, B, K = 6, 16, 50, 5
+    for kind, cls, extra in (("linear", PiecewiseLinearCouplingTransform, {}),
+                             ("quadratic", PiecewiseQuadraticCouplingTransform, {}),
+                             ("quadratic_uncond", PiecewiseQuadraticCouplingTransform,
+                              dict(apply_unconditional_transform=True))):
+        torch.manual_seed(11)
+        layers = []
+        for i in range(2):
+            layers.append(RandomPermutation(D))
+            layers.append(cls(mask=torchutils.create_alternating_binary_mask(D, even=(i % 2 == 0)),
+                              transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=H, num_blocks=1),
+                              num_bins=K, tails="linear", tail_bound=3.0, **extra))
+        t = CompositeTransform(layers)
+        sharpen(t, 5.0, 30.0)
+        finish("c2d_" + kind, t, 1.5 * torch.randn(B, D, generator=g), 1.5 * torch.randn(B, D, generator=g),
+               dict(kind=kind, D=D, H=H, K=K, L=2, tail_bound=3.0, **extra))
+
+    C, Hh, Ww, Bi, Kc = 4, 5, 3, 6, 4
+    for kind, cls in (("rq", PiecewiseRationalQuadraticCouplingTransform), ("quadratic", PiecewiseQuadraticCouplingTransform),
+                      ("linear", PiecewiseLinearCouplingTransform)):
+        torch.manual_seed(12)
+        t = cls(mask=torchutils.create_alternating_binary_mask(C, even=True),
+                transform_net_create_fn=lambda i_, o_: ConvResidualNet(i_, o_, hidden_channels=8, num_blocks=1),
+                num_bins=Kc, tails="linear", tail_bound=2.0)
+        sharpen(t, 5.0, 30.0)
+        finish("img_" + kind, t, torch.randn(Bi, C, Hh, Ww, generator=g), torch.randn(Bi, C, Hh, Ww, generator=g),
+               dict(kind=kind, C=C, hidden_channels=8, K=Kc, tail_bound=2.0))
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "couplings_lq.npz"), **out)
+    print("sibling couplings:", len(meta), "cases")
+
+
 def flow_h128_case():
     """BASELINE layer shape (D = 64, K = 8, ResidualNet H = 128 x 2 blocks): the shape family the
     whole-layer kernel (K8) and the fused-final-Linear kernels (K7 / K7b) serve.  The weights are
@@ -667,6 +731,7 @@ def flow_h128_case():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "lq":
         sibling_spline_cases()
+        sibling_coupling_cases()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "h128":
         flow_h128_case()
@@ -687,3 +752,4 @@ if __name__ == "__main__":
     cdf_cases()
     flow_h128_case()
     sibling_spline_cases()
+    sibling_coupling_cases()

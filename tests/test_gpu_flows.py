@@ -481,3 +481,54 @@ def test_whole_layer_kernel_persistent_loop(restore_fused_path):
         _select_fused_path("k8")
         back, _ = flow._transform.inverse(z1)
     assert (back - x).abs().max().item() < 1e-4
+
+
+def test_sibling_couplings_against_reference_vectors(golden_dir):
+    """tests/golden/couplings_lq.npz: piecewise-linear / -quadratic coupling layers on [B, D] (two
+    layers with permutations, linear tails, one case with apply_unconditional_transform) and spline
+    couplings on [B, C, H, W] images with a ConvResidualNet conditioner, against the real
+    reference's fp32 / fp64 outputs; reference state_dicts load unchanged."""
+    from nflows_amd.nn.nets import ConvResidualNet, ResidualNet
+    from nflows_amd.transforms import (CompositeTransform, PiecewiseLinearCouplingTransform,
+                                       PiecewiseQuadraticCouplingTransform,
+                                       PiecewiseRationalQuadraticCouplingTransform, RandomPermutation)
+    from nflows_amd.utils import create_alternating_binary_mask
+    g = np.load(os.path.join(golden_dir, "couplings_lq.npz"))
+    classes = {"linear": PiecewiseLinearCouplingTransform, "quadratic": PiecewiseQuadraticCouplingTransform,
+               "quadratic_uncond": PiecewiseQuadraticCouplingTransform,
+               "rq": PiecewiseRationalQuadraticCouplingTransform}
+    for name, cfg in g["meta"]:
+        cfg = parse_kwargs(cfg)
+        cls = classes[cfg["kind"]]
+        if name.startswith("c2d_"):
+            layers = []
+            for i in range(cfg["L"]):
+                layers.append(RandomPermutation(cfg["D"]))
+                layers.append(cls(mask=create_alternating_binary_mask(cfg["D"], even=(i % 2 == 0)),
+                                  transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=cfg["H"], num_blocks=1),
+                                  num_bins=cfg["K"], tails="linear", tail_bound=cfg["tail_bound"],
+                                  apply_unconditional_transform=cfg.get("apply_unconditional_transform", False)))
+            t = CompositeTransform(layers)
+        else:
+            t = cls(mask=create_alternating_binary_mask(cfg["C"], even=True),
+                    transform_net_create_fn=lambda i_, o_: ConvResidualNet(i_, o_, hidden_channels=cfg["hidden_channels"], num_blocks=1),
+                    num_bins=cfg["K"], tails="linear", tail_bound=cfg["tail_bound"])
+        load_state(t, g, name)
+        t = t.to(DEV).eval()
+        x = torch.from_numpy(g[name + "/x"]).to(DEV)
+        noise = torch.from_numpy(g[name + "/noise"]).to(DEV)
+        per_sample = x[0].numel()
+        with torch.no_grad():
+            z, lad = t(x)
+            xs, lad_inv = t.inverse(noise)
+        import nflows_amd
+        nflows_amd.check_status()
+        assert z.shape == x.shape and lad.shape == (x.shape[0],)
+        check(z, g[name + "/z"], g[name + "/z64"], name + " z", 1e-5)
+        check(lad, g[name + "/lad"], g[name + "/lad64"], name + " lad", 1e-5 * per_sample)
+        check(xs, g[name + "/inv_x"], g[name + "/inv_x64"], name + " inv_x", 1e-5)
+        check(lad_inv, g[name + "/inv_lad"], g[name + "/inv_lad64"], name + " inv_lad", 1e-5 * per_sample)
+        # pass-through part bit-exact
+        if not cfg.get("apply_unconditional_transform", False) and not name.startswith("c2d_"):
+            ident = t.identity_features
+            assert torch.equal(z[:, ident], x[:, ident])
