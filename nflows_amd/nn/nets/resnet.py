@@ -1,34 +1,86 @@
-"""Residual conditioner network (stays PyTorch-ROCm: its GEMMs run on MFMA through hipBLASLt).
+"""Residual conditioner networks for feature vectors and for image maps.
+
+The whole-layer kernel (K8) absorbs a plain `ResidualNet`; every other configuration runs here as
+PyTorch-ROCm modules (GEMMs / convolutions on the matrix cores through hipBLASLt / MIOpen).
 
 Parameter names and initialisation order match nflows/nn/nets/resnet.py (`initial_layer`,
-`blocks.{i}.linear_layers.{0,1}`, `blocks.{i}.context_layer`, `blocks.{i}.batch_norm_layers`,
-`final_layer`), so reference checkpoints load unchanged and the same seed gives the same weights.
-Exposes `.hidden_features`, which the spline coupling layer reads (coupling.py:554-556).
+`blocks.{i}.linear_layers.{0,1}` / `conv_layers.{0,1}`, `blocks.{i}.context_layer`,
+`blocks.{i}.batch_norm_layers`, `final_layer`), so reference checkpoints load unchanged and the
+same seed gives the same weights.  The nets expose `.hidden_features` / `.hidden_channels`, which
+the spline coupling layers read (coupling.py:554-559).
+
+Vector and image variants share one implementation: they differ only in the layer type (Linear /
+1x1 and 3x3 Conv2d), the batch-norm type and the attribute name of the two main layers.
 """
 import torch
 from torch import nn
 from torch.nn import functional as F
 
 
-class ResidualBlock(nn.Module):
-    """x + W2 * act(W1 * act(x)), optional batch norm, dropout and GLU context gate
-    (resnet.py:9-52)."""
+def _dense(n_in, n_out, kernel_size=None):
+    return nn.Linear(n_in, n_out)
 
-    def __init__(self, features, context_features, activation=F.relu, dropout_probability=0.0,
-                 use_batch_norm=False, zero_initialization=True):
+
+def _conv(n_in, n_out, kernel_size=1):
+    return nn.Conv2d(n_in, n_out, kernel_size=kernel_size, padding=kernel_size // 2)
+
+
+class _Block(nn.Module):
+    """x + L2(drop(act(bn(L1(act(bn(x))))))), optionally gated by a context through a GLU
+    (resnet.py:9-52 for vectors, :103-149 for maps)."""
+
+    _layers_name = None   # "linear_layers" / "conv_layers": the reference's attribute names
+
+    def __init__(self, width, context_width, activation, dropout_probability, use_batch_norm,
+                 zero_initialization):
         super().__init__()
         self.activation = activation
         self.use_batch_norm = use_batch_norm
-        if use_batch_norm:
-            self.batch_norm_layers = nn.ModuleList(nn.BatchNorm1d(features, eps=1e-3) for _ in range(2))
-        if context_features is not None:
-            self.context_layer = nn.Linear(context_features, features)
-        self.linear_layers = nn.ModuleList(nn.Linear(features, features) for _ in range(2))
+        # registration order = the reference's, so that a seed reproduces its weights
+        self._register_in_reference_order(width, context_width, use_batch_norm)
         self.dropout = nn.Dropout(p=dropout_probability)
         if zero_initialization:
-            last = self.linear_layers[-1]
+            last = self._main()[-1]
             nn.init.uniform_(last.weight, -1e-3, 1e-3)
             nn.init.uniform_(last.bias, -1e-3, 1e-3)
+
+    def _register_in_reference_order(self, width, context_width, use_batch_norm):
+        raise NotImplementedError()
+
+    def _main(self):
+        return getattr(self, self._layers_name)
+
+    def _generic_forward(self, inputs, context):
+        first, second = self._main()
+        h = inputs
+        if self.use_batch_norm:
+            h = self.batch_norm_layers[0](h)
+        h = first(self.activation(h))
+        if self.use_batch_norm:
+            h = self.batch_norm_layers[1](h)
+        h = second(self.dropout(self.activation(h)))
+        if context is not None:
+            h = F.glu(torch.cat((h, self.context_layer(context)), dim=1), dim=1)
+        return inputs + h
+
+    def forward(self, inputs, context=None):
+        return self._generic_forward(inputs, context)
+
+
+class ResidualBlock(_Block):
+    _layers_name = "linear_layers"
+
+    def __init__(self, features, context_features, activation=F.relu, dropout_probability=0.0,
+                 use_batch_norm=False, zero_initialization=True):
+        super().__init__(features, context_features, activation, dropout_probability, use_batch_norm,
+                         zero_initialization)
+
+    def _register_in_reference_order(self, width, context_width, use_batch_norm):
+        if use_batch_norm:
+            self.batch_norm_layers = nn.ModuleList(nn.BatchNorm1d(width, eps=1e-3) for _ in range(2))
+        if context_width is not None:
+            self.context_layer = _dense(context_width, width)
+        self.linear_layers = nn.ModuleList(_dense(width, width) for _ in range(2))
 
     def _fused_inference(self, inputs, context):
         """No-grad HIP path: bias + ReLU of the first linear layer run in the GEMM epilogue
@@ -42,39 +94,44 @@ class ResidualBlock(nn.Module):
             first, second = self.linear_layers
             h = torch._addmm_activation(first.bias, F.relu(inputs), first.weight.t())
             return inputs + torch.addmm(second.bias, h, second.weight.t())
-        h = inputs
-        for step in range(2):
-            if self.use_batch_norm:
-                h = self.batch_norm_layers[step](h)
-            h = self.activation(h)
-            if step == 1:
-                h = self.dropout(h)
-            h = self.linear_layers[step](h)
-        if context is not None:
-            h = F.glu(torch.cat((h, self.context_layer(context)), dim=1), dim=1)
-        return inputs + h
+        return self._generic_forward(inputs, context)
 
 
-class ResidualNet(nn.Module):
-    """Linear -> num_blocks residual blocks -> Linear, on 1-D feature vectors (resnet.py:55-100)."""
+class ConvResidualBlock(_Block):
+    _layers_name = "conv_layers"
 
-    def __init__(self, in_features, out_features, hidden_features, context_features=None,
-                 num_blocks=2, activation=F.relu, dropout_probability=0.0, use_batch_norm=False):
-        super().__init__()
-        self.hidden_features = hidden_features
-        self.context_features = context_features
-        first_in = in_features if context_features is None else in_features + context_features
-        self.initial_layer = nn.Linear(first_in, hidden_features)
+    def __init__(self, channels, context_channels=None, activation=F.relu, dropout_probability=0.0,
+                 use_batch_norm=False, zero_initialization=True):
+        super().__init__(channels, context_channels, activation, dropout_probability, use_batch_norm,
+                         zero_initialization)
+
+    def _register_in_reference_order(self, width, context_width, use_batch_norm):
+        if context_width is not None:
+            self.context_layer = _conv(context_width, width, kernel_size=1)
+        if use_batch_norm:
+            self.batch_norm_layers = nn.ModuleList(nn.BatchNorm2d(width, eps=1e-3) for _ in range(2))
+        self.conv_layers = nn.ModuleList(_conv(width, width, kernel_size=3) for _ in range(2))
+
+
+class _Net(nn.Module):
+    """first layer (context concatenated to the input if given) -> blocks -> last layer."""
+
+    _block = None
+    _make = None
+
+    def _build(self, n_in, n_out, width, context_width, num_blocks, activation, dropout_probability,
+               use_batch_norm):
+        make = type(self)._make
+        self.initial_layer = make(n_in if context_width is None else n_in + context_width, width)
         self.blocks = nn.ModuleList(
-            ResidualBlock(features=hidden_features, context_features=context_features,
-                          activation=activation, dropout_probability=dropout_probability,
-                          use_batch_norm=use_batch_norm)
+            type(self)._block(width, context_width, activation=activation,
+                              dropout_probability=dropout_probability, use_batch_norm=use_batch_norm)
             for _ in range(num_blocks))
-        self.final_layer = nn.Linear(hidden_features, out_features)
+        self.final_layer = make(width, n_out)
 
     def hidden(self, inputs, context=None):
-        """Activations in front of `final_layer` (the fused spline kernel consumes these and
-        applies `final_layer` itself)."""
+        """Activations in front of `final_layer` (the fused spline kernels K7 / K7b consume these
+        and apply `final_layer` themselves)."""
         h = inputs if context is None else torch.cat((inputs, context), dim=1)
         h = self.initial_layer(h)
         for block in self.blocks:
@@ -85,62 +142,32 @@ class ResidualNet(nn.Module):
         return self.final_layer(self.hidden(inputs, context))
 
 
-class ConvResidualBlock(nn.Module):
-    """ResidualBlock on [B, C, H, W] maps: 3x3 convolutions, optional batch norm, dropout and a
-    1x1-convolved GLU context gate (resnet.py:103-149).  Parameter names match the reference
-    (`conv_layers.{0,1}`, `context_layer`, `batch_norm_layers`)."""
+class ResidualNet(_Net):
+    """Linear -> num_blocks residual blocks -> Linear, on feature vectors (resnet.py:55-100)."""
 
-    def __init__(self, channels, context_channels=None, activation=F.relu, dropout_probability=0.0,
-                 use_batch_norm=False, zero_initialization=True):
+    _block = ResidualBlock
+    _make = staticmethod(_dense)
+
+    def __init__(self, in_features, out_features, hidden_features, context_features=None,
+                 num_blocks=2, activation=F.relu, dropout_probability=0.0, use_batch_norm=False):
         super().__init__()
-        self.activation = activation
-        if context_channels is not None:
-            self.context_layer = nn.Conv2d(context_channels, channels, kernel_size=1, padding=0)
-        self.use_batch_norm = use_batch_norm
-        if use_batch_norm:
-            self.batch_norm_layers = nn.ModuleList(nn.BatchNorm2d(channels, eps=1e-3) for _ in range(2))
-        self.conv_layers = nn.ModuleList(nn.Conv2d(channels, channels, kernel_size=3, padding=1) for _ in range(2))
-        self.dropout = nn.Dropout(p=dropout_probability)
-        if zero_initialization:
-            last = self.conv_layers[-1]
-            nn.init.uniform_(last.weight, -1e-3, 1e-3)
-            nn.init.uniform_(last.bias, -1e-3, 1e-3)
-
-    def forward(self, inputs, context=None):
-        h = inputs
-        for step in range(2):
-            if self.use_batch_norm:
-                h = self.batch_norm_layers[step](h)
-            h = self.activation(h)
-            if step == 1:
-                h = self.dropout(h)
-            h = self.conv_layers[step](h)
-        if context is not None:
-            h = F.glu(torch.cat((h, self.context_layer(context)), dim=1), dim=1)
-        return inputs + h
+        self.hidden_features = hidden_features
+        self.context_features = context_features
+        self._build(in_features, out_features, hidden_features, context_features, num_blocks, activation,
+                    dropout_probability, use_batch_norm)
 
 
-class ConvResidualNet(nn.Module):
-    """1x1 conv -> num_blocks ConvResidualBlocks -> 1x1 conv (resnet.py:152-205); the conditioner of
-    the image coupling layers.  Exposes `.hidden_channels` (coupling.py:557-559)."""
+class ConvResidualNet(_Net):
+    """1x1 conv -> num_blocks blocks of 3x3 convs -> 1x1 conv, on [B, C, H, W] maps
+    (resnet.py:152-205); the conditioner of the image coupling layers."""
+
+    _block = ConvResidualBlock
+    _make = staticmethod(_conv)
 
     def __init__(self, in_channels, out_channels, hidden_channels, context_channels=None, num_blocks=2,
                  activation=F.relu, dropout_probability=0.0, use_batch_norm=False):
         super().__init__()
         self.context_channels = context_channels
         self.hidden_channels = hidden_channels
-        first_in = in_channels if context_channels is None else in_channels + context_channels
-        self.initial_layer = nn.Conv2d(first_in, hidden_channels, kernel_size=1, padding=0)
-        self.blocks = nn.ModuleList(
-            ConvResidualBlock(channels=hidden_channels, context_channels=context_channels,
-                              activation=activation, dropout_probability=dropout_probability,
-                              use_batch_norm=use_batch_norm)
-            for _ in range(num_blocks))
-        self.final_layer = nn.Conv2d(hidden_channels, out_channels, kernel_size=1, padding=0)
-
-    def forward(self, inputs, context=None):
-        h = inputs if context is None else torch.cat((inputs, context), dim=1)
-        h = self.initial_layer(h)
-        for block in self.blocks:
-            h = block(h, context)
-        return self.final_layer(h)
+        self._build(in_channels, out_channels, hidden_channels, context_channels, num_blocks, activation,
+                    dropout_probability, use_batch_norm)
