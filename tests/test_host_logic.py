@@ -30,7 +30,7 @@ def test_library_exports_every_header_symbol():
 def test_header_constants_match_binding():
     header = open(os.path.join(ROOT, "include", "nflows_amd.h")).read()
     from nflows_amd import _native as N
-    consts = dict(re.findall(r"#define\s+(NFA_[A-Z_]+)\s+(\d+)", header))
+    consts = dict(re.findall(r"#define\s+(NFA_[A-Z0-9_]+)\s+(\d+)", header))
     assert int(consts["NFA_ABI_VERSION"]) == N.ABI_VERSION
     for py, c in [("OK", "NFA_OK"), ("ERR_INVALID_ARGUMENT", "NFA_ERR_INVALID_ARGUMENT"),
                   ("ERR_UNSUPPORTED", "NFA_ERR_UNSUPPORTED"), ("ERR_MIN_BIN_WIDTH", "NFA_ERR_MIN_BIN_WIDTH"),
@@ -38,6 +38,8 @@ def test_header_constants_match_binding():
                   ("STATUS_OUTSIDE_DOMAIN", "NFA_STATUS_OUTSIDE_DOMAIN"),
                   ("STATUS_NEG_DISCRIMINANT", "NFA_STATUS_NEG_DISCRIMINANT"),
                   ("STATUS_BAD_INDEX", "NFA_STATUS_BAD_INDEX"), ("TAILS_NONE", "NFA_TAILS_NONE"),
+                  ("FLAG_INVERSE", "NFA_FLAG_INVERSE"), ("FLAG_ACCUMULATE_LOGABSDET", "NFA_FLAG_ACCUMULATE_LOGABSDET"),
+                  ("FLAG_WEIGHTS_BF16X3", "NFA_FLAG_WEIGHTS_BF16X3"), ("FLAG_LOGITS_LOG2E", "NFA_FLAG_LOGITS_LOG2E"),
                   ("TAILS_LINEAR", "NFA_TAILS_LINEAR"), ("SCALE_DEFAULT", "NFA_SCALE_DEFAULT"),
                   ("SCALE_GENERAL", "NFA_SCALE_GENERAL"), ("SCALE_ADDITIVE", "NFA_SCALE_ADDITIVE"),
                   ("SCALE_GIVEN", "NFA_SCALE_GIVEN"), ("SCALE_SOFTPLUS", "NFA_SCALE_SOFTPLUS")]:
@@ -206,3 +208,137 @@ def test_distribution_template_methods():
     with pytest.raises(RuntimeError):
         Distribution()(1)
     assert "_log_z" not in d.state_dict() and d._log_z.dtype == torch.float64
+
+
+def test_whole_layer_packing_is_a_lossless_rearrangement():
+    """Host side of K8 (ops.pack_resnet_conditioner, runs on CPU tensors): emulate what the kernel
+    computes with the packed weights -- every GEMM transposed, the k index permuted the way the
+    accumulator layout of the previous layer dictates, three bf16 pieces per weight -- and compare
+    with the PyTorch network in float64.  Checks the stage order, the column / row permutations,
+    the bias order and the folded 1/sqrt(hidden) scale without a GPU."""
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import ResidualNet
+    torch.manual_seed(0)
+    dt, di, K, P = 8, 6, 8, 23
+    net = ResidualNet(di, dt * P, hidden_features=128, num_blocks=2).double()
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.copy_(torch.randn_like(p_) * 0.3)
+    wp, bp = ops.pack_resnet_conditioner(net.float(), dt, P)
+    net = net.double()
+    tiles = dt * 24 // 32
+    assert wp.shape == (2 + 16 * 2 + 2 * tiles, 768 * 8) and wp.dtype == torch.bfloat16
+    assert bp.shape == (128 + 256 * 2 + tiles * 32,)
+    w = wp.double().view(-1, 768, 8)          # [stage][vec4 slot][8 bf16]
+    x = torch.randn(32, di, dtype=torch.float64)    # one wave's 32 samples
+    lane_r = torch.arange(64) % 32
+    lane_h = torch.arange(64) // 32
+
+    def acc_to_features(acc):   # acc[t][lane][q] -> [sample, feature]
+        out = torch.zeros(32, 32 * acc.shape[0], dtype=torch.float64)
+        for t in range(acc.shape[0]):
+            for q in range(16):
+                feat = 32 * t + 8 * (q // 4) + 4 * lane_h + q % 4
+                out[lane_r, feat] = acc[t, :, q]
+        return out
+
+    def bias_tiles(off, n):     # [n tiles][2 halves][16] -> acc[t][lane][q]
+        b = bp[off:off + n * 32].double().view(n, 2, 16)
+        return b[:, lane_h, :].clone()
+
+    def mfma(acc_t, a_frag, b_frag):
+        # a_frag[lane][8]: weights of out-row (lane % 32), k = (lane // 32, j); b_frag[lane][8]: acts of
+        # sample (lane % 32); D[i][n] = sum_k A[i][k] B[k][n]; lane l holds column n = l % 32, rows by q
+        A = torch.zeros(32, 16, dtype=torch.float64)
+        Bm = torch.zeros(16, 32, dtype=torch.float64)
+        for l in range(64):
+            A[l % 32, 8 * (l // 32):8 * (l // 32) + 8] = a_frag[l]
+            Bm[8 * (l // 32):8 * (l // 32) + 8, l % 32] = b_frag[l]
+        Dm = A @ Bm
+        for l in range(64):
+            for q in range(16):
+                acc_t[l, q] += Dm[8 * (q // 4) + 4 * (l // 32) + q % 4, l % 32]
+
+    def pieces_sum(stage, base):   # hi + mid + lo of the A fragment starting at vec4 slot `base`
+        return w[stage, base:base + 64] + w[stage, base + 64:base + 128] + w[stage, base + 128:base + 192]
+
+    # activations as the B operand of k-step ks: lane holds 8 values
+    def b_from_acc(acc, ks):       # previous layer's accumulators -> [lane][8]
+        return acc[ks // 2][:, 8 * (ks % 2):8 * (ks % 2) + 8]
+
+    stage = 0
+    bx = torch.zeros(2, 64, 8, dtype=torch.float64)
+    for ks in range(2):
+        for l in range(64):
+            for j in range(8):
+                i = ks * 16 + (l // 32) * 8 + j
+                bx[ks, l, j] = x[l % 32, i] if i < di else 0.0
+    h = bias_tiles(0, 4)
+    for ks in range(2):                              # initial layer: k-major [4 tiles][3 pieces][64]
+        for t in range(4):
+            mfma(h[t], pieces_sum(stage, (t * 3) * 64), bx[ks])
+        stage += 1
+    boff = 128
+    for blk in range(2):
+        for which in range(2):
+            src = torch.relu(h) if which == 0 else u
+            acc = bias_tiles(boff, 4)
+            if which == 1:
+                acc = acc + h
+            for ks in range(8):
+                for t in range(4):
+                    mfma(acc[t], pieces_sum(stage, (t * 3) * 64), b_from_acc(src, ks))
+                stage += 1
+            boff += 128
+            if which == 0:
+                u = torch.relu(acc)
+            else:
+                h = acc
+    got_hidden = acc_to_features(h)
+    want_hidden = net.hidden(x)
+    assert (got_hidden - want_hidden).abs().max().item() < 2e-6 * want_hidden.abs().max().item()  # bf16x3 weights
+    # final layer: tile-major, two stages per tile [3 pieces][4 k-steps][64]; rows in K7 order
+    out = torch.zeros(tiles, 64, 16, dtype=torch.float64)
+    bfin = bias_tiles(boff, tiles)
+    for t in range(tiles):
+        out[t] = bfin[t]
+        for hs in range(2):
+            for k4 in range(4):
+                a_frag = sum(w[stage, (p_ * 4 + k4) * 64:(p_ * 4 + k4) * 64 + 64] for p_ in range(3))
+                mfma(out[t], a_frag, b_from_acc(h, hs * 4 + k4))
+            stage += 1
+    assert stage == wp.shape[0]
+    want = net.final_layer(want_hidden).view(32, dt, P).clone()
+    want[..., :2 * K] /= np.sqrt(128.0)              # the folded 1/sqrt(hidden) scale
+    for g in range(dt // 4):
+        for half in range(2):
+            lanes = torch.arange(32) + 32 * half
+            vals = torch.cat([out[3 * g + t][lanes] for t in range(3)], dim=1)   # [32 samples][48]
+            for f in range(2):
+                feature = 4 * g + 2 * half + f
+                got = vals[:, 24 * f:24 * f + 23]
+                ref = want[:, feature]
+                assert (got - ref).abs().max().item() < 5e-6 * (1 + ref.abs().max().item()), (g, half, f)
+                assert vals[:, 24 * f + 23].abs().max().item() == 0.0              # the pad row
+
+
+def test_layer_tables_follow_the_fused_permutations():
+    from nflows_amd import ops
+    D = 12
+    g = torch.Generator().manual_seed(4)
+    perm, scat = torch.randperm(D, generator=g), torch.randperm(D, generator=g)
+    tidx, iidx = torch.arange(0, D, 2), torch.arange(1, D, 2)
+    t = ops.coupling_layer_tables(D, tidx, iidx, perm, scat)
+    assert t.dtype == torch.int32 and t.shape == (224,)
+    x = torch.randn(3, D)
+    layer_in = x[:, perm]                         # what Permutation.forward hands to the layer
+    layer_out = layer_in.clone()                  # pass-through
+    final = torch.empty_like(x)
+    final[:, scat] = layer_out                    # Permutation.inverse after the layer
+    tile = torch.empty_like(x)
+    tile[:, t[:D].long()] = x                     # the kernel's scatter of an input row
+    assert torch.equal(tile, final)
+    assert torch.equal(tile[:, t[128:128 + iidx.numel()].long()], layer_in[:, iidx])
+    assert torch.equal(tile[:, t[160:160 + tidx.numel()].long()], layer_in[:, tidx])
+    ident = ops.coupling_layer_tables(D, tidx, iidx)
+    assert torch.equal(ident[:D].long(), torch.arange(D))
