@@ -37,10 +37,14 @@ __device__ __forceinline__ float clamp01(float v) {  // torch.clamp(v, 0, 1): Na
 }
 
 // softmax of K logits in place (optionally divided by `divisor` first); the fp32 denominator is
-// accumulated in double (a long sequential fp32 sum would drift from aten's blocked sum)
-__device__ __forceinline__ void softmax_in_place(float* p, int K, float divisor, float rdivisor) {
+// accumulated in double (a long sequential fp32 sum would drift from aten's blocked sum).
+// KT > 0: K known at compile time, loops unroll and `p` may be a register array.
+template <int KT>
+__device__ __forceinline__ void softmax_in_place(float* p, int Krt, float divisor, float rdivisor) {
 #pragma clang fp contract(off)
+    const int K = KT > 0 ? KT : Krt;
     float m = -INFINITY;
+#pragma unroll
     for (int i = 0; i < K; ++i) {
         float u = p[i];
         if (divisor != 0.0f) u = div_with_rcp(u, divisor, rdivisor);
@@ -48,22 +52,26 @@ __device__ __forceinline__ void softmax_in_place(float* p, int K, float divisor,
         m = fmaxf(m, u);
     }
     double s = 0.0;
+#pragma unroll
     for (int i = 0; i < K; ++i) {
         const float e = exp_noclamp(p[i] - m);
         p[i] = e;
         s += (double)e;
     }
     const float sum = (float)s;
-    for (int i = 0; i < K; ++i) p[i] = p[i] / sum;
+    const float rsum = rcp_refined(sum);  // a / b from RN(1/b): the correctly rounded quotient
+#pragma unroll
+    for (int i = 0; i < K; ++i) p[i] = div_with_rcp(p[i], sum, rsum);
 }
 
-// splines/linear.py:40-105.  p: the lane's K logits (overwritten).  u: input already inside the box.
-template <bool INVERSE>
+// splines/linear.py:40-105.  p: the lane's K logits (overwritten).  x is inside the box.
+// No data-dependent indexing: the bin is picked while walking the prefix sums.
+template <int KT, bool INVERSE>
 __device__ __forceinline__ int linear_eval(float x, float* p, const LqArgs& a, float& y, float& lad) {
 #pragma clang fp contract(off)
-    const int K = a.K;
+    const int K = KT > 0 ? KT : a.K;
     const float u = INVERSE ? (x - a.bottom) / a.span_out : (x - a.left) / a.span_in;
-    softmax_in_place(p, K, 0.0f, 0.0f);
+    softmax_in_place<KT>(p, K, 0.0f, 0.0f);
     float out;
     if (INVERSE) {
         // cdf = pad0(cumsum(pdf)) with cdf[K] = 1; searchsorted adds 1e-6 to the last knot IN PLACE
@@ -71,6 +79,7 @@ __device__ __forceinline__ int linear_eval(float x, float* p, const LqArgs& a, f
         double acc = 0.0;
         float prev = 0.0f, lo = 0.0f, hi = 0.0f;
         int k = -1;
+#pragma unroll
         for (int i = 0; i < K; ++i) {
             acc += (double)p[i];
             const float next = (i == K - 1) ? 1.0f + 1e-6f : (float)acc;
@@ -101,9 +110,16 @@ __device__ __forceinline__ int linear_eval(float x, float* p, const LqArgs& a, f
         k = k >= K ? K - 1 : (k < 0 ? 0 : k);
         const float alpha = pos - (float)k;
         double acc = 0.0;
-        for (int i = 0; i < k; ++i) acc += (double)p[i];
-        const float pk = p[k];
-        out = clamp01((float)acc + alpha * pk);
+        float ck = 0.0f, pk = 0.0f;  // cdf[k], pdf[k]
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            if (i == k) {
+                ck = (float)acc;
+                pk = p[i];
+            }
+            acc += (double)p[i];
+        }
+        out = clamp01(ck + alpha * pk);
         lad = log_normal(pk) - a.log_bin_width;
     }
     y = INVERSE ? out * a.span_in + a.left : out * a.span_out + a.bottom;
@@ -112,22 +128,26 @@ __device__ __forceinline__ int linear_eval(float x, float* p, const LqArgs& a, f
 
 // splines/quadratic.py:55-159.  w: K width logits (overwritten by the widths); h: K+1 slots, the
 // nh height logits sit at h[1..nh] (nh = K-1) or h[0..K] (nh = K+1) and are overwritten by the heights.
-template <bool INVERSE>
+template <int KT, bool INVERSE>
 __device__ __forceinline__ int quadratic_eval(float x, float* w, float* h, const LqArgs& a, float& y, float& lad) {
 #pragma clang fp contract(off)
-    const int K = a.K;
+    const int K = KT > 0 ? KT : a.K;
     const float u = INVERSE ? (x - a.bottom) / a.span_out : (x - a.left) / a.span_in;
-    softmax_in_place(w, K, a.divisor, a.rdivisor);
+    softmax_in_place<KT>(w, K, a.divisor, a.rdivisor);
+#pragma unroll
     for (int i = 0; i < K; ++i) w[i] = a.min_w + a.om_w * w[i];
-    const int first = (a.nh == K - 1) ? 1 : 0;
-    for (int i = first; i < first + a.nh; ++i) {
+    const bool derived = a.nh == K - 1;
+#pragma unroll
+    for (int i = 0; i <= K; ++i) {
+        if (derived && (i == 0 || i == K)) continue;
         float v = h[i];
         if (a.divisor != 0.0f) v = div_with_rcp(v, a.divisor, a.rdivisor);
         h[i] = softplus_beta(v, 1.0f) + 1e-3f;
     }
-    if (a.nh == K - 1) {  // boundary heights such that the normalised ones are exactly 1 (:93-107)
+    if (derived) {  // boundary heights such that the normalised ones are exactly 1 (:93-107)
         const float fw = 0.5f * w[0], lw = 0.5f * w[K - 1];
         float s = 0.0f;
+#pragma unroll
         for (int i = 1; i + 1 < K; ++i) s += ((h[i] + h[i + 1]) / 2.0f) * w[i];
         const float num = (0.5f * fw) * h[1] + (0.5f * lw) * h[K - 1] + s;
         const float c = num / ((1.0f - 0.5f * fw) - 0.5f * lw);
@@ -135,14 +155,19 @@ __device__ __forceinline__ int quadratic_eval(float x, float* w, float* h, const
         h[K] = c;
     }
     float area = 0.0f;
+#pragma unroll
     for (int i = 0; i < K; ++i) area += ((h[i] + h[i + 1]) / 2.0f) * w[i];
-    for (int i = 0; i <= K; ++i) h[i] = a.min_h + a.om_h * (h[i] / area);
+    const float rarea = rcp_refined(area);
+#pragma unroll
+    for (int i = 0; i <= K; ++i) h[i] = a.min_h + a.om_h * div_with_rcp(h[i], area, rarea);
 
     // knots: bin_left_cdf (searched in the inverse) and bin_locations (searched forward), both
-    // pad0(cumsum(.)) with the last entry forced to 1 (+1e-6 for the search)
+    // pad0(cumsum(.)) with the last entry forced to 1 (+1e-6 for the search); the bin's width and
+    // end heights are picked during the walk
     double acc_c = 0.0, acc_l = 0.0;
-    float pc = 0.0f, pl = 0.0f, c0 = 0.0f, l0 = 0.0f;
+    float pc = 0.0f, pl = 0.0f, c0 = 0.0f, l0 = 0.0f, bw = 0.0f, hl = 0.0f, hr = 0.0f;
     int k = -1;
+#pragma unroll
     for (int i = 0; i < K; ++i) {
         acc_c += (double)(((h[i] + h[i + 1]) / 2.0f) * w[i]);
         acc_l += (double)w[i];
@@ -152,6 +177,9 @@ __device__ __forceinline__ int quadratic_eval(float x, float* w, float* h, const
             k = i;
             c0 = pc;
             l0 = pl;
+            bw = w[i];
+            hl = h[i];
+            hr = h[i + 1];
         }
         pc = nc;
         pl = nl;
@@ -161,7 +189,6 @@ __device__ __forceinline__ int quadratic_eval(float x, float* w, float* h, const
         lad = 0.0f;
         return NFA_STATUS_OUTSIDE_DOMAIN;
     }
-    const float bw = w[k], hl = h[k], hr = h[k + 1];
     const float qa = (0.5f * (hr - hl)) * bw, qb = hl * bw, qc = c0;
     float out;
     if (INVERSE) {
@@ -178,7 +205,7 @@ __device__ __forceinline__ int quadratic_eval(float x, float* w, float* h, const
     return 0;
 }
 
-template <int KIND, bool INVERSE>
+template <int KIND, int KT, bool INVERSE>
 __global__ void __launch_bounds__(kBlock) spline_lq_kernel(const LqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -191,11 +218,16 @@ __global__ void __launch_bounds__(kBlock) spline_lq_kernel(const LqArgs a) {
         const int cnt = (int)((a.n - i0) < a.T ? (a.n - i0) : a.T);
         // every lane owns `slot` floats: [K widths / pdf logits][K+1 heights]
         float* mine = lds + tid * a.slot;
-        if (a.packed) {
-            // one contiguous [n, P] view: coalesced loads, scattered into the lanes' slots
+        const int hshift = (KIND == kQuadratic && a.nh == K - 1) ? 1 : 0;
+        if (a.packed && KT > 0) {
+            // one contiguous [n, P] view, K known at compile time: the tile's image is staged as it
+            // is (16-byte coalesced loads) and every lane copies its row to registers below
+            const int mp = tile_load(a.a0 + i0 * P, cnt * P, lds, tid);
+            __syncthreads();
+            mine = lds + mp + tid * P;
+        } else if (a.packed) {
             const float* src = a.a0 + i0 * P;
             const int total = cnt * P;
-            const int hshift = (KIND == kQuadratic && a.nh == K - 1) ? 1 : 0;
             for (int e = tid; e < total; e += blockDim.x) {
                 const int who = e / P, q = e - who * P;
                 lds[who * a.slot + (q < K ? q : q + hshift)] = src[e];
@@ -204,10 +236,8 @@ __global__ void __launch_bounds__(kBlock) spline_lq_kernel(const LqArgs a) {
         } else if (tid < cnt) {
             const int64_t i = i0 + tid;
             for (int q = 0; q < K; ++q) mine[q] = a.a0[i * a.s0 + q];
-            if (KIND == kQuadratic) {
-                const int first = (a.nh == K - 1) ? 1 : 0;
-                for (int q = 0; q < a.nh; ++q) mine[K + first + q] = a.a1[i * a.s1 + q];
-            }
+            if (KIND == kQuadratic)
+                for (int q = 0; q < a.nh; ++q) mine[K + hshift + q] = a.a1[i * a.s1 + q];
         }
         if (tid < cnt) {
             const float x = a.x[i0 + tid];
@@ -215,8 +245,24 @@ __global__ void __launch_bounds__(kBlock) spline_lq_kernel(const LqArgs a) {
             // linear tails: elements outside [-B, B] (NaN included) pass through (linear.py:12-22)
             const bool inside = x >= a.left && x <= a.right;
             if (inside) {
-                my_status |= KIND == kLinear ? linear_eval<INVERSE>(x, mine, a, y, l)
-                                             : quadratic_eval<INVERSE>(x, mine, mine + K, a, y, l);
+                if (KT > 0) {  // K known at compile time: the lane's logits move to registers
+                    float reg[KIND == kLinear ? (KT > 0 ? KT : 1) : 2 * (KT > 0 ? KT : 1) + 1];
+                    if (a.packed) {  // row of P logits: heights shifted by one slot when two are derived
+#pragma unroll
+                        for (int q = 0; q < (KIND == kLinear ? KT : 2 * KT + 1); ++q) {
+                            const int srcq = q < KT ? q : q - hshift;
+                            reg[q] = (q >= KT && (srcq < KT || srcq >= P)) ? 0.0f : mine[srcq];
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < (KIND == kLinear ? KT : 2 * KT + 1); ++q) reg[q] = mine[q];
+                    }
+                    my_status |= KIND == kLinear ? linear_eval<KT, INVERSE>(x, reg, a, y, l)
+                                                 : quadratic_eval<KT, INVERSE>(x, reg, reg + KT, a, y, l);
+                } else {
+                    my_status |= KIND == kLinear ? linear_eval<0, INVERSE>(x, mine, a, y, l)
+                                                 : quadratic_eval<0, INVERSE>(x, mine, mine + K, a, y, l);
+                }
             } else if (!a.unconstrained) {
                 my_status |= NFA_STATUS_OUTSIDE_DOMAIN;  // linear.py:47-48 / quadratic.py:66-67
             }
@@ -235,20 +281,28 @@ static int launch_lq(LqArgs& a, int kind, int inverse, hipStream_t st) {
     while (T > 32 && (size_t)T * a.slot * 4 > (size_t)64 * 1024) T >>= 1;
     if ((size_t)T * a.slot * 4 > (size_t)64 * 1024) return NFA_ERR_UNSUPPORTED;
     a.T = T;
-    const size_t lds = (size_t)T * a.slot * 4;
+    const size_t lds = (size_t)T * a.slot * 4 + 64;  // + slack of the staged tile image (tile_load)
     const int64_t tiles = (a.n + T - 1) / T;
     int per_cu = (int)((size_t)(160 * 1024) / (lds + 256));
     per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
     int64_t g = (int64_t)device_cu_count() * per_cu;
     if (g > tiles) g = tiles;
     const dim3 grid((unsigned)g), block((unsigned)T);
+#define NFA_LQ_LAUNCH(KIND_, KT_)                                                                       \
+    do {                                                                                              \
+        if (inverse) hipLaunchKernelGGL((spline_lq_kernel<KIND_, KT_, true>), grid, block, lds, st, a); \
+        else hipLaunchKernelGGL((spline_lq_kernel<KIND_, KT_, false>), grid, block, lds, st, a);       \
+    } while (0)
     if (kind == kLinear) {
-        if (inverse) hipLaunchKernelGGL((spline_lq_kernel<kLinear, true>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((spline_lq_kernel<kLinear, false>), grid, block, lds, st, a);
+        if (K == 8) NFA_LQ_LAUNCH(kLinear, 8);
+        else if (K == 10) NFA_LQ_LAUNCH(kLinear, 10);   // the reference's default num_bins
+        else NFA_LQ_LAUNCH(kLinear, 0);
     } else {
-        if (inverse) hipLaunchKernelGGL((spline_lq_kernel<kQuadratic, true>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((spline_lq_kernel<kQuadratic, false>), grid, block, lds, st, a);
+        if (K == 8) NFA_LQ_LAUNCH(kQuadratic, 8);
+        else if (K == 10) NFA_LQ_LAUNCH(kQuadratic, 10);
+        else NFA_LQ_LAUNCH(kQuadratic, 0);
     }
+#undef NFA_LQ_LAUNCH
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
 }
