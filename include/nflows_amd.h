@@ -182,16 +182,17 @@ int nfa_rqs_coupling_fused_linear_f32(const float *inputs, const float *hidden,
  * operands, see NFA_FLAG_WEIGHTS_BF16X3), followed by everything nfa_rqs_coupling_f32 replaces.
  * Activations and spline parameters never leave the register file; HBM traffic is one coalesced
  * read of inputs and one coalesced write of outputs + logabsdet.
- *   layer_tables   int32 [224], the layer's column bookkeeping with both neighbouring
+ *   layer_tables   int32 [256], the layer's column bookkeeping with both neighbouring
  *                  permutations folded in (layer column c is read from input column src[c] =
  *                  in_perm[c] and stored at output position dst[c] = out_scatter[c]):
  *                  [0, 128): output position of the layer column read from input column i;
- *                  [128, 160): output position of identity feature i (identity_features,
+ *                  [128, 192): output position of identity feature i (identity_features,
  *                  coupling.py:44-56, in the conditioner's input order);
- *                  [160, 224): output position of transformed feature f (transform_features).
+ *                  [192, 256): output position of transformed feature f (transform_features).
  *                  Entries outside [0, features) set NFA_STATUS_BAD_INDEX.
  *   weights_packed bf16, [stages][768 x 8]: 12 KB stages in consumption order --
- *                  initial_layer, 2 stages (k-step ks = 0, 1): [4 tiles][3 pieces][64 lanes][8],
+ *                  initial_layer, 2 stages (d_i <= 32) or 4 (d_i <= 64), k-step ks = 0, 1, ..:
+ *                    [4 tiles][3 pieces][64 lanes][8],
  *                    lane l element j = piece of W[32*tile + (l&31)][16*ks + 8*(l>>5) + j]
  *                    (columns >= d_i zero);
  *                  with col(ks, hf, j) = 32*(ks/2) + 16*(ks%2) + 8*(j/4) + 4*hf + j%4:
@@ -206,7 +207,7 @@ int nfa_rqs_coupling_fused_linear_f32(const float *inputs, const float *hidden,
  *                    with NFA_FLAG_LOGITS_LOG2E.
  *   bias_packed    float: initial_layer [4 tiles][2 lane-halves][16], every hidden Linear the
  *                  same, final_layer [tiles][2][16] (rows as in K7)
- * Supported: num_bins = 8, linear tails, hidden_features = 128, d_i <= 32, d_t % 4 == 0,
+ * Supported: num_bins = 8, linear tails, hidden_features = 128, d_i <= 64, d_t % 4 == 0,
  * d_t <= 64, features % 4 == 0, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
  */
 int nfa_rqs_coupling_resnet_f32(const float *inputs, const void *weights_packed,

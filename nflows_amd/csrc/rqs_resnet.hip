@@ -25,7 +25,7 @@
 //     the width / height logits (coupling.py:554-556) is folded into those weight rows by the host.
 //
 // Restrictions (the host falls back to PyTorch GEMMs + K7/K1 otherwise): K = 8 bins, linear
-// tails, hidden width 128, ReLU, no context / batch norm / active dropout, d_i <= 32,
+// tails, hidden width 128, ReLU, no context / batch norm / active dropout, d_i <= 64,
 // d_t % 4 == 0, d_t <= 64, D % 4 == 0, D <= 128, batch % 128 == 0 here (leftover rows: other path).
 
 #include "fused_common.hpp"
@@ -37,7 +37,7 @@ namespace nfa {
 constexpr int kStageVec4 = 768;    // 12 KB: [4 tiles][3 pieces][64 lanes] or [3 pieces][4 k-steps][64 lanes] x 16 B
 constexpr int kRing = 3;
 constexpr int kRowPad = 33;        // row tile: [output position][33]: conflict-free both ways
-constexpr int kTabIn2Pos = 0, kTabIdPos = 128, kTabTrPos = 160, kTabSize = 224;
+constexpr int kTabIn2Pos = 0, kTabIdPos = 128, kTabTrPos = 192, kTabSize = 256;
 
 struct ResnetArgs {
     const float* x;      // [B, D]
@@ -211,7 +211,8 @@ __device__ __forceinline__ void load_bias_tile(f32x16& acc, const float* bias_ti
 
 // PRESCALED: 1 = the host folded 1/sqrt(hidden) into the width / height rows of the final layer,
 // 2 = 1/sqrt(hidden) and log2(e) (NFA_FLAG_LOGITS_LOG2E: softmax numerators are then one v_exp_f32)
-template <bool INVERSE, int PRESCALED>
+// INIT_KS: k-steps of the initial layer, 2 (d_i <= 32) or 4 (d_i <= 64)
+template <bool INVERSE, int PRESCALED, int INIT_KS>
 __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs a) {
     // dynamic LDS: the weight ring, then per wave a [D][33] row tile
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
 
         // ---- identity features: k = ks*16 + half*8 + j
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < INIT_KS; ++ks) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
             f32x16 h[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) load_bias_tile(h[t], bias + t * 32);
-            gemm_kmajor<false, 2>(h, ph, pm, pl, sm, lane);
+            gemm_kmajor<false, INIT_KS>(h, ph, pm, pl, sm, lane);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 tile_to_pieces<false>(h[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
@@ -443,7 +444,7 @@ extern "C" int nfa_rqs_coupling_resnet_f32(const float* inputs, const void* weig
     int rc = make_dev_spec(spec, &a.sp);
     if (rc != NFA_OK) return rc;
     if (a.sp.K != 8 || !a.sp.linear || hidden_features != 128 || (num_transform & 3) != 0 ||
-        num_transform > 64 || num_identity > 32 || features > 128 || (features & 3) != 0 ||
+        num_transform > 64 || num_identity > 64 || features > 128 || (features & 3) != 0 ||
         (batch & 127) != 0 || num_blocks > 64)
         return NFA_ERR_UNSUPPORTED;
     if (batch == 0) return NFA_OK;
@@ -461,7 +462,8 @@ extern "C" int nfa_rqs_coupling_resnet_f32(const float* inputs, const void* weig
     a.dt = num_transform;
     a.di = num_identity;
     a.num_blocks = num_blocks;
-    a.num_stages = 2 + 16 * num_blocks + 2 * (num_transform * 24 / 32);
+    const int init_ks = num_identity > 32 ? 4 : 2;
+    a.num_stages = init_ks + 16 * num_blocks + 2 * (num_transform * 24 / 32);
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = g_k7_trace;
     const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float);
@@ -474,11 +476,20 @@ extern "C" int nfa_rqs_coupling_resnet_f32(const float* inputs, const void* weig
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks), block(kBlock);
     const bool inv = (flags & NFA_FLAG_INVERSE) != 0, l2e = (flags & NFA_FLAG_LOGITS_LOG2E) != 0;
-    auto kern = inv ? (l2e ? rqs_resnet_kernel<true, 2> : rqs_resnet_kernel<true, 1>)
-                    : (l2e ? rqs_resnet_kernel<false, 2> : rqs_resnet_kernel<false, 1>);
+    void (*kern)(const ResnetArgs) = nullptr;
+#define NFA_K8_PICK(INV_, PRE_)                                                                    \
+    kern = init_ks == 4 ? rqs_resnet_kernel<INV_, PRE_, 4> : rqs_resnet_kernel<INV_, PRE_, 2>
+    if (inv) {
+        if (l2e) NFA_K8_PICK(true, 2);
+        else NFA_K8_PICK(true, 1);
+    } else {
+        if (l2e) NFA_K8_PICK(false, 2);
+        else NFA_K8_PICK(false, 1);
+    }
+#undef NFA_K8_PICK
     if (lds > 64 * 1024) {
-        static bool raised[4] = {false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
-        const int which = (inv ? 1 : 0) + (l2e ? 2 : 0);
+        static bool raised[8] = {false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
+        const int which = (inv ? 1 : 0) + (l2e ? 2 : 0) + (init_ks == 4 ? 4 : 0);
         if (!raised[which]) {
             NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
             raised[which] = true;

@@ -588,9 +588,10 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False)
     stages, biases = [], []
     wi = net.initial_layer.weight.detach().float()
     di = wi.shape[1]
-    wi = torch.cat((wi, wi.new_zeros(128, 32 - di)), dim=1)  # k = ks*16 + hf*8 + j
+    init_ks = 4 if di > 32 else 2                              # k-steps of the initial layer
+    wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
     # (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j)
-    stages.append(pieces(wi).view(3, 4, 32, 2, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(2, -1))
+    stages.append(pieces(wi).view(3, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks, -1))
     biases.append(_bias_accumulator_order(net.initial_layer.bias.detach().float()))
     for block in net.blocks:
         for lin in block.linear_layers:
@@ -614,15 +615,15 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False)
 
 
 def coupling_layer_tables(features, transform_idx, identity_idx, in_perm=None, out_scatter=None):
-    """int32 [224] column bookkeeping for K8 (layout in include/nflows_amd.h), built on the device."""
+    """int32 [256] column bookkeeping for K8 (layout in include/nflows_amd.h), built on the device."""
     dev = transform_idx.device
     cols = torch.arange(features, device=dev)
     src = cols if in_perm is None else in_perm.to(dev)
     dst = cols if out_scatter is None else out_scatter.to(dev)
-    t = torch.zeros(224, dtype=torch.int64, device=dev)
+    t = torch.zeros(256, dtype=torch.int64, device=dev)
     t[:features] = torch.zeros(features, dtype=torch.int64, device=dev).index_copy_(0, src, dst)
     t[128:128 + identity_idx.numel()] = dst[identity_idx]
-    t[160:160 + transform_idx.numel()] = dst[transform_idx]
+    t[192:192 + transform_idx.numel()] = dst[transform_idx]
     return t.to(torch.int32)
 
 

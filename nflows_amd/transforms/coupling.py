@@ -320,7 +320,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         return (self.fuse_conditioner and self.fuse_final_linear and not torch.is_grad_enabled()
                 and context is None and type(net) is ResidualNet and net.context_features is None
                 and net.hidden_features == 128 and self.tails == "linear" and self.num_bins == 8
-                and self.num_identity_features <= 32 and self.num_transform_features % 4 == 0
+                and self.num_identity_features <= 64 and self.num_transform_features % 4 == 0
                 and self.num_transform_features <= 64 and self.features <= 128
                 and all(b.activation is torch.nn.functional.relu and not b.use_batch_norm
                         and (not b.training or b.dropout.p == 0.0) for b in net.blocks))

@@ -341,7 +341,7 @@ def test_fused_conditioner_kernels_match_gemm_plus_k1(B, path, restore_fused_pat
 
 @pytest.mark.parametrize("features,blocks", [(16, 1), (24, 3), (64, 0), (128, 2)])
 def test_whole_layer_kernel_shapes(features, blocks, restore_fused_path):
-    """K8 on other layer geometries (d_i = d_t = 8 .. 64 -> d_i > 32 falls back), block counts,
+    """K8 on other layer geometries (d_i = d_t = 8 .. 64), block counts,
     ragged batches, NaN / out-of-range inputs: equal to the unfused path within the GEMM noise,
     pass-through columns bit-exact, NaN pattern identical."""
     from nflows_amd import configs
@@ -441,7 +441,7 @@ def test_whole_layer_kernel_abi_contract(restore_fused_path):
     assert call(None) == N.ERR_INVALID_ARGUMENT
     assert call(tables, batch=0) == N.OK
     bad = tables.clone()
-    bad[160 + 5] = 64  # transformed feature 5 stored at a position outside the row
+    bad[192 + 5] = 64  # transformed feature 5 stored at a position outside the row
     assert call(bad) == N.OK
     torch.cuda.synchronize()
     assert st.item() & N.STATUS_BAD_INDEX

@@ -329,7 +329,7 @@ def test_layer_tables_follow_the_fused_permutations():
     perm, scat = torch.randperm(D, generator=g), torch.randperm(D, generator=g)
     tidx, iidx = torch.arange(0, D, 2), torch.arange(1, D, 2)
     t = ops.coupling_layer_tables(D, tidx, iidx, perm, scat)
-    assert t.dtype == torch.int32 and t.shape == (224,)
+    assert t.dtype == torch.int32 and t.shape == (256,)
     x = torch.randn(3, D)
     layer_in = x[:, perm]                         # what Permutation.forward hands to the layer
     layer_out = layer_in.clone()                  # pass-through
@@ -339,6 +339,6 @@ def test_layer_tables_follow_the_fused_permutations():
     tile[:, t[:D].long()] = x                     # the kernel's scatter of an input row
     assert torch.equal(tile, final)
     assert torch.equal(tile[:, t[128:128 + iidx.numel()].long()], layer_in[:, iidx])
-    assert torch.equal(tile[:, t[160:160 + tidx.numel()].long()], layer_in[:, tidx])
+    assert torch.equal(tile[:, t[192:192 + tidx.numel()].long()], layer_in[:, tidx])
     ident = ops.coupling_layer_tables(D, tidx, iidx)
     assert torch.equal(ident[:D].long(), torch.arange(D))
