@@ -244,6 +244,9 @@ int nfa_rqs_elementwise_f32(const float *inputs, const float *unnormalized_width
  *   quadratic_spline / unconstrained_quadratic_spline, splines/quadratic.py:55-159 / :11-52
  *     unnormalized_widths [n, K]; unnormalized_heights [n, num_heights], num_heights = K+1, or K-1
  *     (the two boundary heights are then derived so that they normalise to 1, :93-107)
+ *   cubic_spline / unconstrained_cubic_spline, splines/cubic.py:63-267 / :15-60
+ *     unnormalized_widths, unnormalized_heights [n, K]; unnorm_derivatives_left / _right [n, 1]
+ *     (eps = 1e-5 and quadratic_threshold = 1e-3, the reference's defaults, are built in)
  * A constrained input outside [left, right] sets NFA_STATUS_OUTSIDE_DOMAIN.
  */
 int nfa_linear_spline_f32(const float *inputs, const float *unnormalized_pdf, int64_t stride,
@@ -254,6 +257,12 @@ int nfa_quadratic_spline_f32(const float *inputs, const float *unnormalized_widt
                              int32_t num_heights, float *outputs, float *logabsdet,
                              int32_t *status, int64_t n, const nfa_rqs_spec *spec,
                              int32_t inverse, void *stream);
+int nfa_cubic_spline_f32(const float *inputs, const float *unnormalized_widths, int64_t stride_w,
+                         const float *unnormalized_heights, int64_t stride_h,
+                         const float *unnorm_derivatives_left, int64_t stride_l,
+                         const float *unnorm_derivatives_right, int64_t stride_r, float *outputs,
+                         float *logabsdet, int32_t *status, int64_t n, const nfa_rqs_spec *spec,
+                         int32_t inverse, void *stream);
 
 /*
  * K6.  Rational-quadratic CDF transform with parameters shared by the whole batch:

@@ -1,6 +1,7 @@
 // K9: the rational-quadratic spline's siblings as elementwise functionals (SURVEY.md section 8f,
-// row f4): piecewise-linear (splines/linear.py:9-105) and piecewise-quadratic
-// (splines/quadratic.py:11-159) splines, constrained and with linear tails, forward and inverse.
+// row f4): piecewise-linear (splines/linear.py:9-105), piecewise-quadratic
+// (splines/quadratic.py:11-159) and piecewise-cubic (splines/cubic.py:15-267) splines, constrained
+// and with linear tails, forward and inverse.
 //
 // Same skeleton as K5: a tile of T elements per workgroup pass, every lane stages its own logits
 // in an LDS slot (coalesced when the logit arrays are one packed [n, P] view, a per-lane strided
@@ -13,13 +14,15 @@
 
 namespace nfa {
 
-enum { kLinear = 0, kQuadratic = 1 };
+enum { kLinear = 0, kQuadratic = 1, kCubic = 2 };
 
 struct LqArgs {
     const float* x;
     const float* a0;  // linear: unnormalized pdf [.., K]; quadratic: unnormalized widths [.., K]
-    const float* a1;  // quadratic: unnormalized heights [.., nh]
-    int64_t s0, s1;   // element strides of the rows of a0 / a1
+    const float* a1;  // quadratic: unnormalized heights [.., nh]; cubic: [.., K]
+    const float* a2;  // cubic: left / right boundary-derivative logits [.., 1]
+    const float* a3;
+    int64_t s0, s1, s2, s3;  // element strides of the rows of a0 .. a3
     float* y;
     float* lad;
     int32_t* status;
@@ -27,7 +30,8 @@ struct LqArgs {
     int K, nh, slot, T, packed, unconstrained;
     float left, right, bottom, top;     // box (unconstrained: +-tail_bound)
     float span_in, span_out;            // (float)(right - left), (float)(top - bottom)
-    float min_w, min_h, om_w, om_h;     // quadratic: minimums, (float)(1 - min_w*K), (float)(1 - min_h)
+    float min_w, min_h, om_w, om_h;     // minimums, (float)(1 - min_w*K), quadratic: (float)(1 - min_h)
+    float om_hk;                        // cubic: (float)(1 - min_h*K)
     float divisor, rdivisor;            // quadratic: logits / divisor first (0 = no scaling)
     float log_bin_width;                // linear: (float)log(1/K)
 };
@@ -205,12 +209,134 @@ __device__ __forceinline__ int quadratic_eval(float x, float* w, float* h, const
     return 0;
 }
 
+// torchutils.cbrt (torchutils.py:139-141): sign(x) * exp(log|x| / 3)
+__device__ __forceinline__ float cbrt_like_reference(float x) {
+#pragma clang fp contract(off)
+    const float sg = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
+    return sg * expf(logf(fabsf(x)) / 3.0f);
+}
+
+__device__ __forceinline__ float sign_of(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+// splines/cubic.py:63-267.  w / h: K width / height logits (overwritten by the bin widths / heights),
+// udl / udr: the two boundary-derivative logits.  The coefficients of the searched bin are formed
+// from its neighbours during one walk over the bins (no data-dependent indexing).
+template <int KT, bool INVERSE>
+__device__ __forceinline__ int cubic_eval(float x, float* w, float* h, float udl, float udr, const LqArgs& a,
+                                          float& y, float& lad) {
+#pragma clang fp contract(off)
+    const int K = KT > 0 ? KT : a.K;
+    const float u = INVERSE ? (x - a.bottom) / a.span_out : (x - a.left) / a.span_in;
+    softmax_in_place<KT>(w, K, a.divisor, a.rdivisor);
+    softmax_in_place<KT>(h, K, a.divisor, a.rdivisor);
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        w[i] = a.min_w + a.om_w * w[i];
+        h[i] = a.min_h + a.om_hk * h[i];
+    }
+    // walk: knots (double-accumulated prefix sums, last forced to 1), slopes h/w, interior
+    // derivatives 2*min(|s_i|, |s_i+1|, weighted mean) (:116-135); the bin's left / right
+    // derivative, slope, width and left knots are captured when the search passes it
+    double acc_w = 0.0, acc_h = 0.0;
+    float pw = 0.0f, ph = 0.0f;                 // knot_i of cumwidths / cumheights
+    float d_prev = 0.0f;                        // derivative at knot_i
+    float s_prev = 0.0f, w_prev = 0.0f;         // slope / width of bin i-1
+    int k = -1;
+    float lcw = 0.0f, rcw = 0.0f, lch = 0.0f, bw = 0.0f, bs = 0.0f, dl = 0.0f, dr = 0.0f;
+    bool take_right = false;                    // the bin picked in the previous iteration still needs its right derivative
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const float wi = w[i], si = h[i] / wi;
+        float d_i;                              // derivative at knot_i
+        if (i == 0) {
+            d_i = ((1.0f / (1.0f + expf(-udl))) * 3.0f) * si;
+        } else {
+            const float m1 = fminf(fabsf(s_prev), fabsf(si));
+            const float m2 = (0.5f * (wi * s_prev + w_prev * si)) / (w_prev + wi);
+            d_i = fminf(m1, m2) * (sign_of(s_prev) + sign_of(si));
+        }
+        if (take_right) {
+            dr = d_i;
+            take_right = false;
+        }
+        acc_w += (double)wi;
+        acc_h += (double)h[i];
+        const bool last = i == K - 1;
+        const float nw = last ? 1.0f : (float)acc_w, nh = last ? 1.0f : (float)acc_h;
+        if (u >= (INVERSE ? ph : pw)) {
+            k = i;
+            lcw = pw;
+            rcw = nw;
+            lch = ph;
+            bw = wi;
+            bs = si;
+            dl = d_i;
+            take_right = true;
+        }
+        pw = nw;
+        ph = nh;
+        d_prev = d_i;
+        s_prev = si;
+        w_prev = wi;
+    }
+    if (take_right) dr = ((1.0f / (1.0f + expf(-udr))) * 3.0f) * s_prev;  // the last bin: right boundary derivative
+    (void)d_prev;
+    if (k < 0 || u >= 1.0f + 1e-6f) {
+        y = x;
+        lad = 0.0f;
+        return NFA_STATUS_OUTSIDE_DOMAIN;
+    }
+    const float ca = ((dl + dr) - 2.0f * bs) / (bw * bw);
+    const float cb = ((3.0f * bs - 2.0f * dl) - dr) / bw;
+    const float cc = dl, cd = lch;
+    if (INVERSE) {
+        const float b_ = (cb / ca) / 3.0f, c_ = (cc / ca) / 3.0f, d_ = (cd - u) / ca;
+        const float d1 = -(b_ * b_) + c_;
+        const float d2 = (-c_) * b_ + d_;
+        const float d3 = b_ * d_ - c_ * c_;
+        const float disc = (4.0f * d1) * d3 - d2 * d2;
+        const float dep1 = (-2.0f * b_) * d1 + d2;
+        float out = 0.0f;
+        if (disc < 0.0f) {  // one real root
+            const float sq = sqrtf(-disc);
+            const float p = cbrt_like_reference((-dep1 + sq) / 2.0f);
+            const float q = cbrt_like_reference((-dep1 - sq) / 2.0f);
+            out = ((p + q) - b_) + lcw;
+        } else if (disc >= 0.0f) {  // three real roots: the one inside the bin (+- eps)
+            const float theta = atan2f(sqrtf(disc), -dep1) / 3.0f;
+            const float c1 = cosf(theta), s1 = sinf(theta);
+            const float hs3 = 0.8660254037844386f;  // 0.5 * sqrt(3)
+            const float scale = 2.0f * sqrtf(-d1);
+            const float shift = -b_ + lcw;
+            const float r1 = c1 * scale + shift;
+            const float r2 = (-0.5f * c1 - hs3 * s1) * scale + shift;
+            const float r3 = (-0.5f * c1 + hs3 * s1) * scale + shift;
+            const float lo = lcw - 1e-5f, hi = rcw + 1e-5f;
+            const bool m1 = lo < r1 && r1 < hi, m2 = lo < r2 && r2 < hi, m3 = lo < r3 && r3 < hi;
+            out = m1 ? r1 : (m2 ? r2 : (m3 ? r3 : r1));
+        }
+        if (fabsf(ca) < 1e-3f) {  // almost quadratic (:219-226)
+            const float alpha = (-cc + sqrtf(cc * cc - (4.0f * cb) * (cd - u))) / (2.0f * cb);
+            out = alpha + lcw;
+        }
+        const float so = out - lcw;
+        lad = -logf(((3.0f * ca) * (so * so) + (2.0f * cb) * so) + cc);
+        y = out * a.span_in + a.left;
+    } else {
+        const float si = u - lcw;
+        const float out = ((ca * ((si * si) * si) + cb * (si * si)) + cc * si) + cd;
+        lad = logf(((3.0f * ca) * (si * si) + (2.0f * cb) * si) + cc);
+        y = out * a.span_out + a.bottom;
+    }
+    return 0;
+}
+
 template <int KIND, int KT, bool INVERSE>
 __global__ void __launch_bounds__(kBlock) spline_lq_kernel(const LqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int K = a.K;
-    const int P = KIND == kLinear ? K : K + a.nh;
+    const int P = KIND == kLinear ? K : (KIND == kCubic ? 2 * K + 2 : K + a.nh);
     int my_status = 0;
     const int64_t num_tiles = (a.n + a.T - 1) / a.T;
     for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
@@ -238,6 +364,11 @@ __global__ void __launch_bounds__(kBlock) spline_lq_kernel(const LqArgs a) {
             for (int q = 0; q < K; ++q) mine[q] = a.a0[i * a.s0 + q];
             if (KIND == kQuadratic)
                 for (int q = 0; q < a.nh; ++q) mine[K + hshift + q] = a.a1[i * a.s1 + q];
+            if (KIND == kCubic) {
+                for (int q = 0; q < K; ++q) mine[K + q] = a.a1[i * a.s1 + q];
+                mine[2 * K] = a.a2[i * a.s2];
+                mine[2 * K + 1] = a.a3[i * a.s3];
+            }
         }
         if (tid < cnt) {
             const float x = a.x[i0 + tid];
@@ -245,23 +376,27 @@ __global__ void __launch_bounds__(kBlock) spline_lq_kernel(const LqArgs a) {
             // linear tails: elements outside [-B, B] (NaN included) pass through (linear.py:12-22)
             const bool inside = x >= a.left && x <= a.right;
             if (inside) {
+                constexpr int kRegs = KIND == kLinear ? (KT > 0 ? KT : 1) : 2 * (KT > 0 ? KT : 1) + 2;
                 if (KT > 0) {  // K known at compile time: the lane's logits move to registers
-                    float reg[KIND == kLinear ? (KT > 0 ? KT : 1) : 2 * (KT > 0 ? KT : 1) + 1];
-                    if (a.packed) {  // row of P logits: heights shifted by one slot when two are derived
+                    float reg[kRegs];
+                    if (a.packed && KIND == kQuadratic) {  // heights shifted by one slot when two are derived
 #pragma unroll
-                        for (int q = 0; q < (KIND == kLinear ? KT : 2 * KT + 1); ++q) {
+                        for (int q = 0; q < 2 * KT + 1; ++q) {
                             const int srcq = q < KT ? q : q - hshift;
                             reg[q] = (q >= KT && (srcq < KT || srcq >= P)) ? 0.0f : mine[srcq];
                         }
                     } else {
 #pragma unroll
-                        for (int q = 0; q < (KIND == kLinear ? KT : 2 * KT + 1); ++q) reg[q] = mine[q];
+                        for (int q = 0; q < (KIND == kLinear ? KT : (KIND == kCubic ? 2 * KT + 2 : 2 * KT + 1)); ++q)
+                            reg[q] = mine[q];
                     }
-                    my_status |= KIND == kLinear ? linear_eval<KT, INVERSE>(x, reg, a, y, l)
-                                                 : quadratic_eval<KT, INVERSE>(x, reg, reg + KT, a, y, l);
+                    if (KIND == kLinear) my_status |= linear_eval<KT, INVERSE>(x, reg, a, y, l);
+                    else if (KIND == kQuadratic) my_status |= quadratic_eval<KT, INVERSE>(x, reg, reg + KT, a, y, l);
+                    else my_status |= cubic_eval<KT, INVERSE>(x, reg, reg + KT, reg[2 * KT], reg[2 * KT + 1], a, y, l);
                 } else {
-                    my_status |= KIND == kLinear ? linear_eval<0, INVERSE>(x, mine, a, y, l)
-                                                 : quadratic_eval<0, INVERSE>(x, mine, mine + K, a, y, l);
+                    if (KIND == kLinear) my_status |= linear_eval<0, INVERSE>(x, mine, a, y, l);
+                    else if (KIND == kQuadratic) my_status |= quadratic_eval<0, INVERSE>(x, mine, mine + K, a, y, l);
+                    else my_status |= cubic_eval<0, INVERSE>(x, mine, mine + K, mine[2 * K], mine[2 * K + 1], a, y, l);
                 }
             } else if (!a.unconstrained) {
                 my_status |= NFA_STATUS_OUTSIDE_DOMAIN;  // linear.py:47-48 / quadratic.py:66-67
@@ -276,7 +411,7 @@ __global__ void __launch_bounds__(kBlock) spline_lq_kernel(const LqArgs a) {
 
 static int launch_lq(LqArgs& a, int kind, int inverse, hipStream_t st) {
     const int K = a.K;
-    a.slot = (kind == kLinear ? K : 2 * K + 1) | 1;  // odd stride: conflict-free per-lane walks
+    a.slot = (kind == kLinear ? K : (kind == kCubic ? 2 * K + 2 : 2 * K + 1)) | 1;  // odd stride: conflict-free per-lane walks
     int T = kBlock;
     while (T > 32 && (size_t)T * a.slot * 4 > (size_t)64 * 1024) T >>= 1;
     if ((size_t)T * a.slot * 4 > (size_t)64 * 1024) return NFA_ERR_UNSUPPORTED;
@@ -297,10 +432,14 @@ static int launch_lq(LqArgs& a, int kind, int inverse, hipStream_t st) {
         if (K == 8) NFA_LQ_LAUNCH(kLinear, 8);
         else if (K == 10) NFA_LQ_LAUNCH(kLinear, 10);   // the reference's default num_bins
         else NFA_LQ_LAUNCH(kLinear, 0);
-    } else {
+    } else if (kind == kQuadratic) {
         if (K == 8) NFA_LQ_LAUNCH(kQuadratic, 8);
         else if (K == 10) NFA_LQ_LAUNCH(kQuadratic, 10);
         else NFA_LQ_LAUNCH(kQuadratic, 0);
+    } else {
+        if (K == 8) NFA_LQ_LAUNCH(kCubic, 8);
+        else if (K == 10) NFA_LQ_LAUNCH(kCubic, 10);
+        else NFA_LQ_LAUNCH(kCubic, 0);
     }
 #undef NFA_LQ_LAUNCH
     NFA_HIP_CHECK(hipGetLastError());
@@ -324,6 +463,7 @@ static int fill_common(LqArgs& a, const nfa_rqs_spec* spec) {
     a.min_h = (float)spec->min_bin_height;
     a.om_w = (float)(1.0 - spec->min_bin_width * spec->num_bins);
     a.om_h = (float)(1.0 - spec->min_bin_height);
+    a.om_hk = (float)(1.0 - spec->min_bin_height * spec->num_bins);
     a.divisor = (float)spec->wh_divisor;
     a.rdivisor = a.divisor != 0.0f ? 1.0f / a.divisor : 0.0f;
     return NFA_OK;
@@ -344,9 +484,9 @@ extern "C" int nfa_linear_spline_f32(const float* inputs, const float* unnormali
     if (!inputs || !unnormalized_pdf || !outputs || !logabsdet) return NFA_ERR_INVALID_ARGUMENT;
     a.x = inputs;
     a.a0 = unnormalized_pdf;
-    a.a1 = nullptr;
+    a.a1 = a.a2 = a.a3 = nullptr;
     a.s0 = stride;
-    a.s1 = 0;
+    a.s1 = a.s2 = a.s3 = 0;
     a.nh = 0;
     a.y = outputs;
     a.lad = logabsdet;
@@ -375,8 +515,10 @@ extern "C" int nfa_quadratic_spline_f32(const float* inputs, const float* unnorm
     a.x = inputs;
     a.a0 = unnormalized_widths;
     a.a1 = unnormalized_heights;
+    a.a2 = a.a3 = nullptr;
     a.s0 = stride_w;
     a.s1 = stride_h;
+    a.s2 = a.s3 = 0;
     a.nh = num_heights;
     a.y = outputs;
     a.lad = logabsdet;
@@ -385,4 +527,42 @@ extern "C" int nfa_quadratic_spline_f32(const float* inputs, const float* unnorm
     const int P = a.K + num_heights;
     a.packed = (unnormalized_heights == unnormalized_widths + a.K) && stride_w == P && stride_h == P;
     return launch_lq(a, kQuadratic, inverse, (hipStream_t)stream);
+}
+
+extern "C" int nfa_cubic_spline_f32(const float* inputs, const float* unnormalized_widths, int64_t stride_w,
+                                    const float* unnormalized_heights, int64_t stride_h,
+                                    const float* unnorm_derivatives_left, int64_t stride_l,
+                                    const float* unnorm_derivatives_right, int64_t stride_r,
+                                    float* outputs, float* logabsdet, int32_t* status, int64_t n,
+                                    const nfa_rqs_spec* spec, int32_t inverse, void* stream) {
+    if (n < 0) return NFA_ERR_INVALID_ARGUMENT;
+    LqArgs a;
+    int rc = fill_common(a, spec);
+    if (rc != NFA_OK) return rc;
+    if (spec->min_bin_width * spec->num_bins > 1.0) return NFA_ERR_MIN_BIN_WIDTH;
+    if (spec->min_bin_height * spec->num_bins > 1.0) return NFA_ERR_MIN_BIN_HEIGHT;
+    if (n == 0) return NFA_OK;
+    if (!inputs || !unnormalized_widths || !unnormalized_heights || !unnorm_derivatives_left ||
+        !unnorm_derivatives_right || !outputs || !logabsdet)
+        return NFA_ERR_INVALID_ARGUMENT;
+    a.x = inputs;
+    a.a0 = unnormalized_widths;
+    a.a1 = unnormalized_heights;
+    a.a2 = unnorm_derivatives_left;
+    a.a3 = unnorm_derivatives_right;
+    a.s0 = stride_w;
+    a.s1 = stride_h;
+    a.s2 = stride_l;
+    a.s3 = stride_r;
+    a.nh = a.K;
+    a.y = outputs;
+    a.lad = logabsdet;
+    a.status = status;
+    a.n = n;
+    const int P = 2 * a.K + 2;
+    a.packed = unnormalized_heights == unnormalized_widths + a.K &&
+               unnorm_derivatives_left == unnormalized_widths + 2 * a.K &&
+               unnorm_derivatives_right == unnormalized_widths + 2 * a.K + 1 && stride_w == P &&
+               stride_h == P && stride_l == P && stride_r == P;
+    return launch_lq(a, kCubic, inverse, (hipStream_t)stream);
 }

@@ -339,6 +339,37 @@ def quadratic_spline(inputs, unnormalized_widths, unnormalized_heights, spec, in
     return y.view(shape), lad.view(shape)
 
 
+def cubic_spline(inputs, unnormalized_widths, unnormalized_heights, unnorm_derivatives_left,
+                 unnorm_derivatives_right, spec, inverse=False):
+    """K9 -- piecewise-cubic spline functional (splines/cubic.py); widths / heights S+[K], the two
+    boundary-derivative logits S+[1]."""
+    tensors = (inputs, unnormalized_widths, unnormalized_heights, unnorm_derivatives_left, unnorm_derivatives_right)
+    for nm, t in zip(("inputs", "unnormalized_widths", "unnormalized_heights", "unnorm_derivatives_left",
+                      "unnorm_derivatives_right"), tensors):
+        N.require_device_f32(nm, t)
+    _no_backward_yet("the cubic spline", *tensors)
+    K = spec.num_bins
+    shape = inputs.shape
+    if (unnormalized_widths.shape != shape + (K,) or unnormalized_heights.shape != shape + (K,)
+            or unnorm_derivatives_left.shape != shape + (1,) or unnorm_derivatives_right.shape != shape + (1,)):
+        raise ValueError("spline logits must have shapes %s+[%d], +[%d], +[1], +[1]" % (tuple(shape), K, K))
+    dev = inputs.device
+    n = inputs.numel()
+    x = inputs.detach().contiguous().view(-1)
+    uw, sw = _logit_rows(unnormalized_widths.detach(), n, K)
+    uh, sh = _logit_rows(unnormalized_heights.detach(), n, K)
+    dl, sl = _logit_rows(unnorm_derivatives_left.detach(), n, 1)
+    dr, sr = _logit_rows(unnorm_derivatives_right.detach(), n, 1)
+    y, lad = torch.empty_like(x), torch.empty_like(x)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_cubic_spline_f32(N.ptr(x), N.ptr(uw), sw, N.ptr(uh), sh, N.ptr(dl), sl, N.ptr(dr), sr,
+                                           N.ptr(y), N.ptr(lad), N.ptr(_status_word(dev)), n, ctypes.byref(spec),
+                                           int(bool(inverse)), N.stream_handle(dev))
+    N.check(rc)
+    _after_spline(spec, inverse, dev)
+    return y.view(shape), lad.view(shape)
+
+
 def affine_coupling(inputs, params, transform_idx, activation, inverse=False, scale=None,
                     in_perm=None, out_scatter=None, accumulate_into=None):
     """K2 -- fused affine/additive coupling.  params [B, 2*d_t] = [shift | scale logits]

@@ -4,4 +4,5 @@ from .rational_quadratic import (DEFAULT_MIN_BIN_HEIGHT, DEFAULT_MIN_BIN_WIDTH,
 from . import rational_quadratic
 from .linear import linear_spline, unconstrained_linear_spline
 from .quadratic import quadratic_spline, unconstrained_quadratic_spline
-from . import linear, quadratic
+from .cubic import cubic_spline, unconstrained_cubic_spline
+from . import cubic, linear, quadratic

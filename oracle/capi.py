@@ -157,6 +157,26 @@ def quadratic_spline(x, uw, uh, spec, inverse=False):
     return y.reshape(x.shape), lad.reshape(x.shape), st
 
 
+def cubic_spline(x, uw, uh, udl, udr, spec, inverse=False):
+    """splines/cubic.py: uw, uh [..., K]; udl, udr [..., 1] boundary-derivative logits."""
+    dtype = x.dtype
+    suf, ct = _dt(dtype)
+    K = spec.num_bins
+    xf = np.ascontiguousarray(x.reshape(-1))
+    wf = np.ascontiguousarray(uw.reshape(-1, K), dtype=dtype)
+    hf = np.ascontiguousarray(uh.reshape(-1, K), dtype=dtype)
+    lf = np.ascontiguousarray(udl.reshape(-1), dtype=dtype)
+    rf = np.ascontiguousarray(udr.reshape(-1), dtype=dtype)
+    y = np.empty(xf.size, dtype)
+    lad = np.empty(xf.size, dtype)
+    fn = getattr(lib(), "oracle_cubic_spline" + suf)
+    fn.restype = ctypes.c_int
+    st = fn(_ptr(xf, ct), _ptr(wf, ct), ctypes.c_int64(K), _ptr(hf, ct), ctypes.c_int64(K), _ptr(lf, ct),
+            ctypes.c_int64(1), _ptr(rf, ct), ctypes.c_int64(1), ctypes.c_int64(xf.size), ctypes.byref(spec),
+            ctypes.c_int(int(inverse)), _ptr(y, ct), _ptr(lad, ct))
+    return y.reshape(x.shape), lad.reshape(x.shape), st
+
+
 def rqs_coupling(x, params, transform_idx, spec, inverse=False, in_perm=None, out_scatter=None):
     dtype = x.dtype
     suf, ct = _dt(dtype)

@@ -574,3 +574,135 @@ int FN(oracle_quadratic_spline)(const REAL *x, const REAL *uw, int64_t sw, const
     }
     return status;
 }
+
+/* cubic_spline for ONE element: splines/cubic.py:63-267 (Steffen-style monotone cubic, inverse by
+ * Blinn's cubic solver with a quadratic fall-back for |a| < quadratic_threshold).  udl / udr: the
+ * two boundary-derivative logits. */
+static REAL r_cbrt(REAL x) { /* torchutils.cbrt: sign(x) * exp(log|x| / 3) (torchutils.py:139-141) */
+    REAL sg = (x > 0) ? (REAL)1 : ((x < 0) ? (REAL)-1 : (REAL)0);
+    REAL ax = x < 0 ? -x : x;
+    return sg * r_exp(r_log(ax) / (REAL)3);
+}
+
+static int cubic_one(REAL x, const REAL *uw, const REAL *uh, REAL udl, REAL udr, const oracle_rqs_spec *sp,
+                     int inverse, REAL *y, REAL *lad) {
+    enum { KMAX = 256 };
+    int K = sp->num_bins;
+    REAL w[KMAX], h[KMAX], cw[KMAX + 1], ch[KMAX + 1], sl[KMAX], dv[KMAX + 1];
+    REAL left = (REAL)sp->left, right = (REAL)sp->right, bottom = (REAL)sp->bottom;
+    REAL eps = (REAL)1e-5, qthr = (REAL)1e-3; /* DEFAULT_EPS, DEFAULT_QUADRATIC_THRESHOLD */
+    if (K < 1) return -1;
+    sl[0] = 0;
+    if (x < left || x > right) {
+        *y = x;
+        *lad = 0;
+        return ORACLE_STATUS_OUTSIDE_DOMAIN;
+    }
+    REAL u = inverse ? (x - bottom) / (REAL)(sp->top - sp->bottom) : (x - left) / (REAL)(sp->right - sp->left);
+    REAL div = (REAL)sp->wh_divisor;
+    softmax_k(uw, K, div, w);
+    softmax_k(uh, K, div, h);
+    REAL omw = (REAL)(1.0 - sp->min_bin_width * K), omh = (REAL)(1.0 - sp->min_bin_height * K);
+    double aw = 0.0, ah = 0.0;
+    cw[0] = 0;
+    ch[0] = 0;
+    for (int i = 0; i < K; ++i) {
+        w[i] = (REAL)sp->min_bin_width + omw * w[i];
+        h[i] = (REAL)sp->min_bin_height + omh * h[i];
+        aw += (double)w[i];
+        ah += (double)h[i];
+        cw[i + 1] = (REAL)aw;
+        ch[i + 1] = (REAL)ah;
+    }
+    cw[K] = 1;
+    ch[K] = 1;
+    for (int i = 0; i < K; ++i) sl[i] = h[i] / w[i];
+    for (int i = 0; i + 1 < K; ++i) {
+        REAL a0 = sl[i] < 0 ? -sl[i] : sl[i], a1 = sl[i + 1] < 0 ? -sl[i + 1] : sl[i + 1];
+        REAL m1 = a0 < a1 ? a0 : a1;
+        REAL m2 = (REAL)0.5 * (w[i + 1] * sl[i] + w[i] * sl[i + 1]) / (w[i] + w[i + 1]);
+        REAL m = m1 < m2 ? m1 : m2;
+        REAL s0 = sl[i] > 0 ? (REAL)1 : (sl[i] < 0 ? (REAL)-1 : (REAL)0);
+        REAL s1 = sl[i + 1] > 0 ? (REAL)1 : (sl[i + 1] < 0 ? (REAL)-1 : (REAL)0);
+        dv[i + 1] = m * (s0 + s1);
+    }
+    dv[0] = ((REAL)1 / ((REAL)1 + r_exp(-udl))) * (REAL)3 * sl[0];
+    dv[K] = ((REAL)1 / ((REAL)1 + r_exp(-udr))) * (REAL)3 * sl[K - 1];
+    int k = search_knots(inverse ? ch : cw, K, u);
+    if (k < 0 || k >= K) {
+        *y = x;
+        *lad = 0;
+        return ORACLE_STATUS_OUTSIDE_DOMAIN;
+    }
+    REAL a = (dv[k] + dv[k + 1] - (REAL)2 * sl[k]) / (w[k] * w[k]);
+    REAL b = ((REAL)3 * sl[k] - (REAL)2 * dv[k] - dv[k + 1]) / w[k];
+    REAL c = dv[k];
+    REAL d = ch[k];
+    REAL lcw = cw[k], rcw = cw[k + 1];
+    REAL out;
+    if (inverse) {
+        REAL b_ = (b / a) / (REAL)3, c_ = (c / a) / (REAL)3, d_ = (d - u) / a;
+        REAL d1 = -(b_ * b_) + c_;
+        REAL d2 = -c_ * b_ + d_;
+        REAL d3 = b_ * d_ - c_ * c_;
+        REAL disc = (REAL)4 * d1 * d3 - d2 * d2;
+        REAL dep1 = (REAL)-2 * b_ * d1 + d2;
+        REAL dep2 = d1;
+        out = 0;
+        if (disc < 0) {
+            REAL sq = r_sqrt(-disc);
+            REAL p = r_cbrt((-dep1 + sq) / (REAL)2);
+            REAL q = r_cbrt((-dep1 - sq) / (REAL)2);
+            out = (p + q) - b_ + lcw;
+        } else if (disc >= 0) {
+            REAL theta = (REAL)atan2((double)r_sqrt(disc), (double)(-dep1));
+            theta = theta / (REAL)3;
+            REAL c1 = (REAL)cos((double)theta), s1 = (REAL)sin((double)theta);
+            REAL half_sqrt3 = (REAL)(0.5 * sqrt(3.0));
+            REAL r1 = c1;
+            REAL r2 = (REAL)-0.5 * c1 - half_sqrt3 * s1;
+            REAL r3 = (REAL)-0.5 * c1 + half_sqrt3 * s1;
+            REAL scale = (REAL)2 * r_sqrt(-dep2);
+            REAL shift = -b_ + lcw;
+            r1 = r1 * scale + shift;
+            r2 = r2 * scale + shift;
+            r3 = r3 * scale + shift;
+            int m1 = ((lcw - eps) < r1) && (r1 < (rcw + eps));
+            int m2 = ((lcw - eps) < r2) && (r2 < (rcw + eps));
+            int m3 = ((lcw - eps) < r3) && (r3 < (rcw + eps));
+            out = m1 ? r1 : (m2 ? r2 : (m3 ? r3 : r1)); /* argsort(masks, descending)[0] */
+        }
+        REAL aa = a < 0 ? -a : a;
+        if (aa < qthr) { /* almost quadratic (:219-226) */
+            REAL qa = b, qb = c, qc = d - u;
+            REAL alpha = (-qb + r_sqrt(qb * qb - (REAL)4 * qa * qc)) / ((REAL)2 * qa);
+            out = alpha + lcw;
+        }
+        REAL so = out - lcw;
+        *lad = -r_log((REAL)3 * a * (so * so) + (REAL)2 * b * so + c);
+        *y = out * (REAL)(sp->right - sp->left) + left;
+    } else {
+        REAL si = u - lcw;
+        out = a * (si * si * si) + b * (si * si) + c * si + d;
+        *lad = r_log((REAL)3 * a * (si * si) + (REAL)2 * b * si + c);
+        *y = out * (REAL)(sp->top - sp->bottom) + bottom;
+    }
+    return 0;
+}
+
+int FN(oracle_cubic_spline)(const REAL *x, const REAL *uw, int64_t sw, const REAL *uh, int64_t sh,
+                            const REAL *udl, int64_t sdl, const REAL *udr, int64_t sdr, int64_t n,
+                            const oracle_rqs_spec *sp, int inverse, REAL *y, REAL *lad) {
+    int status = 0;
+    if (sp->num_bins < 1 || sp->num_bins > 256) return -1;
+    for (int64_t i = 0; i < n; ++i) {
+        REAL B = (REAL)sp->right;
+        if (sp->tails == 1 && !(x[i] >= -B && x[i] <= B)) {
+            y[i] = x[i];
+            lad[i] = 0;
+            continue;
+        }
+        status |= cubic_one(x[i], uw + i * sw, uh + i * sh, udl[i * sdl], udr[i * sdr], sp, inverse, y + i, lad + i);
+    }
+    return status;
+}

@@ -675,6 +675,39 @@ def sibling_coupling_cases():
     print("sibling couplings:", len(meta), "cases")
 
 
+def cubic_spline_cases():
+    """Cubic spline (splines/cubic.py): constrained and linear tails, forward and inverse."""
+    out = {}
+    meta = []
+    g = torch.Generator().manual_seed(31337)
+
+    def finish(name, fn, x, logits, kw):
+        for dtp, suf in ((torch.float32, ""), (torch.float64, "64")):
+            args = [t.to(dtp) for t in logits]
+            for inverse in (False, True):
+                y, lad = fn(x.to(dtp), *args, inverse=inverse, **kw)
+                out["%s/%s%s" % (name, "inv_" if inverse else "", "y" + suf)] = npy(y)
+                out["%s/%s%s" % (name, "inv_" if inverse else "", "lad" + suf)] = npy(lad)
+        out[name + "/x"] = npy(x)
+        for i, t in enumerate(logits):
+            out["%s/logits%d" % (name, i)] = npy(t)
+        meta.append((name, "cubic", repr(kw)))
+
+    for K, n, scale in ((10, 400, 1.0), (4, 257, 2.0), (8, 300, 0.5)):
+        x = torch.rand(n, generator=g)
+        x[:6] = torch.tensor([0.0, 1.0, 0.5, 1.0 / K, 1.0 - 1.0 / K, 1e-7])
+        logits = [scale * torch.randn(n, K, generator=g), scale * torch.randn(n, K, generator=g),
+                  torch.randn(n, 1, generator=g), torch.randn(n, 1, generator=g)]
+        finish("cub_k%d" % K, splines.cubic_spline, x, logits, {})
+        B = 3.0
+        xu = 2.2 * torch.randn(n, generator=g)
+        xu[:8] = torch.tensor([-B, B, 0.0, B + 1e-3, -B - 1e-3, float("nan"), 2.9999998, -2.9999998])
+        finish("ucub_k%d" % K, splines.unconstrained_cubic_spline, xu, logits, dict(tail_bound=B, tails="linear"))
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "splines_cubic.npz"), **out)
+    print("cubic splines:", len(meta), "cases")
+
+
 def flow_h128_case():
     """BASELINE layer shape (D = 64, K = 8, ResidualNet H = 128 x 2 blocks): the shape family the
     whole-layer kernel (K8) and the fused-final-Linear kernels (K7 / K7b) serve.  The weights are
@@ -729,6 +762,9 @@ def flow_h128_case():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "cubic":
+        cubic_spline_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lq":
         sibling_spline_cases()
         sibling_coupling_cases()
@@ -753,3 +789,4 @@ if __name__ == "__main__":
     flow_h128_case()
     sibling_spline_cases()
     sibling_coupling_cases()
+    cubic_spline_cases()

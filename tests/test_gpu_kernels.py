@@ -426,3 +426,35 @@ def test_linear_and_quadratic_spline_errors(ops):
     y, lad = splines.linear_spline(e, torch.zeros(0, 4, device=DEV))
     assert y.shape == (0,) and lad.shape == (0,)
     ops.check_status()
+
+
+def test_cubic_spline_golden(ops, golden_dir):
+    """K9 (cubic) through the drop-in functionals against the real reference's vectors
+    (tests/golden/splines_cubic.npz)."""
+    from nflows_amd.transforms import splines
+    g = np.load(os.path.join(golden_dir, "splines_cubic.npz"))
+    for name, kind, kw in g["meta"]:
+        kw = parse_kwargs(kw)
+        x = dev(g[name + "/x"])
+        logits = [dev(g["%s/logits%d" % (name, i)]) for i in range(4)]
+        fn = splines.unconstrained_cubic_spline if kw.get("tails") == "linear" else splines.cubic_spline
+        for inverse in (False, True):
+            pre = name + ("/inv_" if inverse else "/")
+            y, lad = fn(x, *logits, inverse=inverse, **kw)
+            ops.check_status()
+            assert_sibling_spline_parity(host(y), g[pre + "y"], g[pre + "y64"], OUT_TOL, 5e-5, name + " y")
+            assert_sibling_spline_parity(host(lad), g[pre + "lad"], g[pre + "lad64"], LAD_TOL, 1e-3, name + " lad")
+    # other K (runtime-K path), strided logits, round trip
+    rng = np.random.RandomState(5)
+    n, K = 2000, 6
+    x = dev(np.clip(1.5 * rng.randn(n), -2.99, 2.99).astype(np.float32))
+    blob = dev((0.7 * rng.randn(n, 2 * K + 2 + 3)).astype(np.float32))
+    args = (blob[:, :K], blob[:, K:2 * K], blob[:, 2 * K:2 * K + 1], blob[:, 2 * K + 1:2 * K + 2])
+    y, lad = splines.unconstrained_cubic_spline(x, *args, tail_bound=3.0)
+    oy, ol, st = capi.cubic_spline(host(x), *[host(t) for t in args], capi.make_spec(K, tails="linear", tail_bound=3.0))
+    assert st == 0
+    assert np.mean(np.abs(host(y) - oy) <= OUT_TOL * (1 + np.abs(oy))) >= 0.97
+    assert np.mean(np.abs(host(lad) - ol) <= LAD_TOL * (1 + np.abs(ol))) >= 0.97
+    xr, lad_inv = splines.unconstrained_cubic_spline(y, *args, inverse=True, tail_bound=3.0)
+    ops.check_status()
+    assert (xr - x).abs().median().item() < 1e-5 and (lad + lad_inv).abs().median().item() < 1e-4

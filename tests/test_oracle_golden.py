@@ -223,3 +223,31 @@ def test_linear_and_quadratic_splines_match_reference(golden_dir):
                         outside = ~((x >= -tb) & (x <= tb))
                         assert np.array_equal(y[outside].view(np.uint32), x[outside].view(np.uint32)), name
                         assert np.all(lad[outside] == 0), name
+
+
+def test_cubic_spline_matches_reference(golden_dir):
+    """oracle/nfa_oracle.c cubic_one against the real reference (tests/golden/splines_cubic.npz)."""
+    g = np.load(os.path.join(golden_dir, "splines_cubic.npz"))
+    for name, kind, kw in g["meta"]:
+        kw = parse_kwargs(kw)
+        x = g[name + "/x"]
+        logits = [g["%s/logits%d" % (name, i)] for i in range(4)]
+        K = logits[0].shape[-1]
+        spec_kw = dict(kw)
+        if spec_kw.get("tails") != "linear":
+            spec_kw["tails"] = None
+        for inverse in (False, True):
+            pre = name + ("/inv_" if inverse else "/")
+            for dt in (np.float64, np.float32):
+                spec = capi.make_spec(K, **spec_kw)
+                y, lad, st = capi.cubic_spline(x.astype(dt), *[a.astype(dt) for a in logits], spec, inverse=inverse)
+                assert st == 0, (name, inverse)
+                if dt is np.float64:
+                    ry, rl = g[pre + "y64"], g[pre + "lad64"]
+                    assert np.array_equal(np.isnan(y), np.isnan(ry)), name
+                    fin = np.isfinite(ry) & np.isfinite(rl)
+                    assert np.abs(y[fin] - ry[fin]).max() <= 1e-9, (name, inverse)
+                    assert np.abs(lad[fin] - rl[fin]).max() <= 1e-8, (name, inverse)
+                else:
+                    assert_sibling_spline_parity(y, g[pre + "y"], g[pre + "y64"], OUT_TOL, 5e-5, name + " y")
+                    assert_sibling_spline_parity(lad, g[pre + "lad"], g[pre + "lad64"], LAD_TOL, 1e-3, name + " lad")
