@@ -1,12 +1,13 @@
 from .base import (CompositeTransform, InputOutsideDomain, InverseNotAvailable, InverseTransform,
                    Transform)
 from .coupling import (AdditiveCouplingTransform, AffineCouplingTransform, CouplingTransform,
-                       PiecewiseLinearCouplingTransform, PiecewiseQuadraticCouplingTransform,
+                       PiecewiseCubicCouplingTransform, PiecewiseLinearCouplingTransform,
+                       PiecewiseQuadraticCouplingTransform,
                        PiecewiseRationalQuadraticCouplingTransform)
 from .permutations import Permutation, RandomPermutation, ReversePermutation
 from . import splines
 from .autoregressive import (AutoregressiveTransform, MaskedAffineAutoregressiveTransform,
                              MaskedPiecewiseRationalQuadraticAutoregressiveTransform)
 from .made import MADE
-from .nonlinearities import (PiecewiseLinearCDF, PiecewiseQuadraticCDF,
+from .nonlinearities import (PiecewiseCubicCDF, PiecewiseLinearCDF, PiecewiseQuadraticCDF,
                             PiecewiseRationalQuadraticCDF)

@@ -515,3 +515,48 @@ class PiecewiseQuadraticCouplingTransform(CouplingTransform):
         if self.tails == "linear":
             assert transform_params.shape[-1] == 2 * K - 1  # quadratic.py:34
         return ops.quadratic_spline(inputs, transform_params[..., :K], transform_params[..., K:], spec, inverse)
+
+
+class PiecewiseCubicCouplingTransform(CouplingTransform):
+    """Piecewise-cubic coupling layer (Durkan et al. 2019, "Cubic-spline flows"); coupling.py:429-499.
+    Per transformed element K width logits, K height logits (both divided by sqrt(hidden_features)
+    when the conditioner exposes it) and the two boundary-derivative logits."""
+
+    supports_fused_permutation = False
+    supports_image_inputs = True
+
+    def __init__(self, mask, transform_net_create_fn, num_bins=10, tails=None, tail_bound=1.0,
+                 apply_unconditional_transform=False, img_shape=None,
+                 min_bin_width=splines.cubic.DEFAULT_MIN_BIN_WIDTH,
+                 min_bin_height=splines.cubic.DEFAULT_MIN_BIN_HEIGHT):
+        self.num_bins = num_bins
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.tails = tails
+        self.tail_bound = tail_bound
+        if apply_unconditional_transform:
+            from .nonlinearities import PiecewiseCubicCDF
+
+            def unconditional_transform(features):
+                return PiecewiseCubicCDF(shape=[features] + (img_shape if img_shape else []), num_bins=num_bins,
+                                         tails=tails, tail_bound=tail_bound, min_bin_width=min_bin_width,
+                                         min_bin_height=min_bin_height)
+        else:
+            unconditional_transform = None
+        super().__init__(mask, transform_net_create_fn, unconditional_transform=unconditional_transform)
+
+    def _transform_dim_multiplier(self):
+        return self.num_bins * 2 + 2
+
+    def _elementwise(self, inputs, transform_params, inverse):
+        if self.tails is not None and self.tails != "linear":
+            raise RuntimeError("{} tails are not implemented.".format(self.tails))
+        K = self.num_bins
+        divisor = 0.0
+        if hasattr(self.transform_net, "hidden_features"):
+            divisor = float(np.sqrt(self.transform_net.hidden_features))
+        spec = ops.make_rqs_spec(K, self.tails, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
+                                 min_bin_height=self.min_bin_height, wh_divisor=divisor)
+        return ops.cubic_spline(inputs, transform_params[..., :K], transform_params[..., K:2 * K],
+                                transform_params[..., 2 * K:2 * K + 1], transform_params[..., 2 * K + 1:2 * K + 2],
+                                spec, inverse)

@@ -141,3 +141,41 @@ class PiecewiseQuadraticCDF(Transform):
 
     def inverse(self, inputs, context=None):
         return self._spline(inputs, inverse=True)
+
+
+class PiecewiseCubicCDF(Transform):
+    """Piecewise-cubic CDF, parameters shared by every sample (nonlinearities.py:322-383)."""
+
+    def __init__(self, shape, num_bins=10, tails=None, tail_bound=1.0,
+                 min_bin_width=splines.cubic.DEFAULT_MIN_BIN_WIDTH,
+                 min_bin_height=splines.cubic.DEFAULT_MIN_BIN_HEIGHT):
+        super().__init__()
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.tail_bound = tail_bound
+        self.tails = tails
+        self.unnormalized_widths = nn.Parameter(torch.randn(*shape, num_bins))
+        self.unnormalized_heights = nn.Parameter(torch.randn(*shape, num_bins))
+        self.unnorm_derivatives_left = nn.Parameter(torch.randn(*shape, 1))
+        self.unnorm_derivatives_right = nn.Parameter(torch.randn(*shape, 1))
+
+    def _spline(self, inputs, inverse=False):
+        batch = inputs.shape[0]
+        params = [_share_across_batch(p, batch) for p in (self.unnormalized_widths, self.unnormalized_heights,
+                                                          self.unnorm_derivatives_left,
+                                                          self.unnorm_derivatives_right)]
+        if self.tails is None:
+            outputs, logabsdet = splines.cubic_spline(inputs, *params, inverse=inverse,
+                                                      min_bin_width=self.min_bin_width,
+                                                      min_bin_height=self.min_bin_height)
+        else:
+            outputs, logabsdet = splines.unconstrained_cubic_spline(
+                inputs, *params, inverse=inverse, tails=self.tails, tail_bound=self.tail_bound,
+                min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height)
+        return outputs, torchutils.sum_except_batch(logabsdet)
+
+    def forward(self, inputs, context=None):
+        return self._spline(inputs, inverse=False)
+
+    def inverse(self, inputs, context=None):
+        return self._spline(inputs, inverse=True)

@@ -28,6 +28,7 @@ from nflows.transforms.base import CompositeTransform, InputOutsideDomain  # noq
 from nflows.transforms.coupling import (  # noqa: E402
     AdditiveCouplingTransform,
     AffineCouplingTransform,
+    PiecewiseCubicCouplingTransform,
     PiecewiseLinearCouplingTransform,
     PiecewiseQuadraticCouplingTransform,
     PiecewiseRationalQuadraticCouplingTransform,
@@ -675,6 +676,66 @@ def sibling_coupling_cases():
     print("sibling couplings:", len(meta), "cases")
 
 
+def cubic_coupling_cases():
+    """PiecewiseCubicCouplingTransform on [B, D] (with and without the unconditional CDF on the
+    identity half) and on images."""
+    out = {}
+    meta = []
+    g = torch.Generator().manual_seed(909)
+
+    def finish(name, t, x, noise, cfg):
+        t.eval()
+        with torch.no_grad():
+            z, lad = t(x)
+            xs, lad_inv = t.inverse(noise)
+            t64 = t.double()
+            z64, lad64 = t64(x.double())
+            xs64, ladi64 = t64.inverse(noise.double())
+            t.float()
+        state_to_np(name, t, out)
+        for k, v in dict(x=x, noise=noise, z=z, lad=lad, inv_x=xs, inv_lad=lad_inv, z64=z64, lad64=lad64,
+                         inv_x64=xs64, inv_lad64=ladi64).items():
+            out[name + "/" + k] = npy(v)
+        meta.append((name, repr(cfg)))
+
+    D, H, B, K = 6, 16, 50, 5
+    for tag, extra in (("plain", {}), ("uncond", dict(apply_unconditional_transform=True))):
+        torch.manual_seed(21)
+        layers = []
+        for i in range(2):
+            layers.append(RandomPermutation(D))
+            layers.append(PiecewiseCubicCouplingTransform(
+                mask=torchutils.create_alternating_binary_mask(D, even=(i % 2 == 0)),
+                transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=H, num_blocks=1),
+                num_bins=K, tails="linear", tail_bound=3.0, **extra))
+        t = CompositeTransform(layers)
+        with torch.no_grad():
+            for p_name, p in t.named_parameters():
+                if "final_layer" in p_name:
+                    p.mul_(3.0)
+                elif "linear_layers.1" in p_name:
+                    p.mul_(30.0)
+        finish("c2d_cubic_" + tag, t, 1.5 * torch.randn(B, D, generator=g), 1.5 * torch.randn(B, D, generator=g),
+               dict(kind="cubic", D=D, H=H, K=K, L=2, tail_bound=3.0, **extra))
+    torch.manual_seed(22)
+    C = 4
+    t = PiecewiseCubicCouplingTransform(
+        mask=torchutils.create_alternating_binary_mask(C, even=True),
+        transform_net_create_fn=lambda i_, o_: ConvResidualNet(i_, o_, hidden_channels=8, num_blocks=1),
+        num_bins=4, tails="linear", tail_bound=2.0)
+    with torch.no_grad():
+        for p_name, p in t.named_parameters():
+            if "final_layer" in p_name:
+                p.mul_(3.0)
+            elif "conv_layers.1" in p_name:
+                p.mul_(30.0)
+    finish("img_cubic", t, torch.randn(6, C, 5, 3, generator=g), torch.randn(6, C, 5, 3, generator=g),
+           dict(kind="cubic", C=C, hidden_channels=8, K=4, tail_bound=2.0))
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "couplings_cubic.npz"), **out)
+    print("cubic couplings:", len(meta), "cases")
+
+
 def cubic_spline_cases():
     """Cubic spline (splines/cubic.py): constrained and linear tails, forward and inverse."""
     out = {}
@@ -764,6 +825,7 @@ def flow_h128_case():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cubic":
         cubic_spline_cases()
+        cubic_coupling_cases()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lq":
         sibling_spline_cases()
@@ -790,3 +852,4 @@ if __name__ == "__main__":
     sibling_spline_cases()
     sibling_coupling_cases()
     cubic_spline_cases()
+    cubic_coupling_cases()

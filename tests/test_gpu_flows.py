@@ -484,20 +484,21 @@ def test_whole_layer_kernel_persistent_loop(restore_fused_path):
 
 
 def test_sibling_couplings_against_reference_vectors(golden_dir):
-    """tests/golden/couplings_lq.npz: piecewise-linear / -quadratic coupling layers on [B, D] (two
-    layers with permutations, linear tails, one case with apply_unconditional_transform) and spline
-    couplings on [B, C, H, W] images with a ConvResidualNet conditioner, against the real
-    reference's fp32 / fp64 outputs; reference state_dicts load unchanged."""
+    """tests/golden/couplings_lq.npz, couplings_cubic.npz: piecewise-linear / -quadratic / -cubic
+    coupling layers on [B, D] (two layers with permutations, linear tails, cases with
+    apply_unconditional_transform) and spline couplings on [B, C, H, W] images with a
+    ConvResidualNet conditioner, against the real reference's fp32 / fp64 outputs; reference
+    state_dicts load unchanged."""
     from nflows_amd.nn.nets import ConvResidualNet, ResidualNet
-    from nflows_amd.transforms import (CompositeTransform, PiecewiseLinearCouplingTransform,
-                                       PiecewiseQuadraticCouplingTransform,
+    from nflows_amd.transforms import (CompositeTransform, PiecewiseCubicCouplingTransform,
+                                       PiecewiseLinearCouplingTransform, PiecewiseQuadraticCouplingTransform,
                                        PiecewiseRationalQuadraticCouplingTransform, RandomPermutation)
     from nflows_amd.utils import create_alternating_binary_mask
-    g = np.load(os.path.join(golden_dir, "couplings_lq.npz"))
     classes = {"linear": PiecewiseLinearCouplingTransform, "quadratic": PiecewiseQuadraticCouplingTransform,
-               "quadratic_uncond": PiecewiseQuadraticCouplingTransform,
+               "quadratic_uncond": PiecewiseQuadraticCouplingTransform, "cubic": PiecewiseCubicCouplingTransform,
                "rq": PiecewiseRationalQuadraticCouplingTransform}
-    for name, cfg in g["meta"]:
+    files = [np.load(os.path.join(golden_dir, f)) for f in ("couplings_lq.npz", "couplings_cubic.npz")]
+    for g, name, cfg in [(g_, n_, c_) for g_ in files for n_, c_ in g_["meta"]]:
         cfg = parse_kwargs(cfg)
         cls = classes[cfg["kind"]]
         if name.startswith("c2d_"):
