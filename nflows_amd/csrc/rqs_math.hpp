@@ -325,26 +325,41 @@ __device__ __forceinline__ float softmax_numerators_log2(Slots<8>& e, const floa
 
 // PRESCALED: 0 = width / height logits as the conditioner produced them (divided by sp.divisor
 // here), 1 = already divided, 2 = already divided and multiplied by log2(e)
-template <bool INVERSE, int PRESCALED = 0>
-__device__ __forceinline__ int rqs_eval_flat8(float x, const float* sl, const RqsDev& sp, float& y, float& lad) {
+//
+// The evaluation comes in two halves so that a caller can place them in different scheduling
+// regions (K8 folds them into the two weight stages of an MFMA tile): the softmax numerators of
+// both logit sets, then the walks over the bins, the derivatives and the map inside the bin.
+struct FlatEvalState {
+    Slots<8> ew, eh;
+    float den_w, den_h;
+};
+
+template <int PRESCALED>
+__device__ __forceinline__ void rqs_flat8_numerators(const float* sl, const RqsDev& sp, FlatEvalState& st) {
+#pragma clang fp contract(off)
+    constexpr int KT = 8;
+    const float div = PRESCALED ? 0.0f : sp.divisor;
+    st.den_w = PRESCALED == 2 ? softmax_numerators_log2(st.ew, sl)
+                              : softmax_numerators<KT>(st.ew, sl, KT, div, sp.rdivisor);
+    st.den_h = PRESCALED == 2 ? softmax_numerators_log2(st.eh, sl + KT)
+                              : softmax_numerators<KT>(st.eh, sl + KT, KT, div, sp.rdivisor);
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ int rqs_flat8_finish(float x, const float* sl, const RqsDev& sp, const FlatEvalState& st,
+                                                float& y, float& lad) {
 #pragma clang fp contract(off)
     constexpr int KT = 8;
     const float right = sp.right, left = -sp.right;
     const bool inside = (x >= left && x <= right);  // NaN is outside
-    Slots<KT> ew, eh;
-    const float div = PRESCALED ? 0.0f : sp.divisor;
-    const float den_w = PRESCALED == 2 ? softmax_numerators_log2(ew, sl)
-                                       : softmax_numerators<KT>(ew, sl, KT, div, sp.rdivisor);
-    const float den_h = PRESCALED == 2 ? softmax_numerators_log2(eh, sl + KT)
-                                       : softmax_numerators<KT>(eh, sl + KT, KT, div, sp.rdivisor);
     int k = -1;
     float cw0 = 0.f, cw1 = 0.f, ch0 = 0.f, ch1 = 0.f;
     if (INVERSE) {
-        walk_bins<KT, true>(eh, KT, den_h, sp.min_h, sp.om_h, sp.span_w, left, right, x, k, ch0, ch1);
-        walk_bins<KT, false>(ew, KT, den_w, sp.min_w, sp.om_w, sp.span_w, left, right, x, k, cw0, cw1);
+        walk_bins<KT, true>(st.eh, KT, st.den_h, sp.min_h, sp.om_h, sp.span_w, left, right, x, k, ch0, ch1);
+        walk_bins<KT, false>(st.ew, KT, st.den_w, sp.min_w, sp.om_w, sp.span_w, left, right, x, k, cw0, cw1);
     } else {
-        walk_bins<KT, true>(ew, KT, den_w, sp.min_w, sp.om_w, sp.span_w, left, right, x, k, cw0, cw1);
-        walk_bins<KT, false>(eh, KT, den_h, sp.min_h, sp.om_h, sp.span_w, left, right, x, k, ch0, ch1);
+        walk_bins<KT, true>(st.ew, KT, st.den_w, sp.min_w, sp.om_w, sp.span_w, left, right, x, k, cw0, cw1);
+        walk_bins<KT, false>(st.eh, KT, st.den_h, sp.min_h, sp.om_h, sp.span_w, left, right, x, k, ch0, ch1);
     }
     const bool found = (k >= 0) && !(x >= sp.right_eps);
     const float* sd = sl + 2 * KT;
@@ -357,11 +372,18 @@ __device__ __forceinline__ int rqs_eval_flat8(float x, const float* sl, const Rq
     const float d0 = sp.min_d + softplus_beta(u0, sp.beta);
     const float d1 = sp.min_d + softplus_beta(u1, sp.beta);
     float ye, le;
-    const int st = rqs_bin_eval<INVERSE>(x, cw0, cw1, ch0, ch1, d0, d1, ye, le);
+    const int status = rqs_bin_eval<INVERSE>(x, cw0, cw1, ch0, ch1, d0, d1, ye, le);
     const bool valid = inside && found;
     y = valid ? ye : x;
     lad = valid ? le : 0.0f;
-    return inside ? (found ? st : NFA_STATUS_OUTSIDE_DOMAIN) : 0;
+    return inside ? (found ? status : NFA_STATUS_OUTSIDE_DOMAIN) : 0;
+}
+
+template <bool INVERSE, int PRESCALED = 0>
+__device__ __forceinline__ int rqs_eval_flat8(float x, const float* sl, const RqsDev& sp, float& y, float& lad) {
+    FlatEvalState st;
+    rqs_flat8_numerators<PRESCALED>(sl, sp, st);
+    return rqs_flat8_finish<INVERSE>(x, sl, sp, st, y, lad);
 }
 
 
