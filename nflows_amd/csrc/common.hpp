@@ -51,7 +51,6 @@ __device__ __forceinline__ int tile_load(const float* __restrict__ src, int coun
     const int mis = (int)((reinterpret_cast<uintptr_t>(src) >> 2) & 3);
     const float* win = src - mis;  // 16-byte aligned
     const int nvec = (mis + count + 3) >> 2;
-#ifndef NFA_NO_UNROLL
     if (mis == 0 && (count & 3) == 0) {
         // aligned fast path (workgroup-uniform branch): issue UNROLL independent 16-byte loads per
         // lane before the first LDS write, so a lane has UNROLL KiB-rows in flight
@@ -74,7 +73,6 @@ __device__ __forceinline__ int tile_load(const float* __restrict__ src, int coun
         }
         return 0;
     }
-#endif
     for (int v = tid; v < nvec; v += BLOCK) {
         const int e0 = v * 4 - mis;  // index into src of this vector's first element
         if (e0 >= 0 && e0 + 4 <= count) {

@@ -331,16 +331,8 @@ __global__ void __launch_bounds__(kBlock, NFA_PIPE_WAVES) rqs_coupling_pipelined
         }
         lds_barrier();
 
-#ifndef NFA_X_NOSTORE
-        if (tid < nvx) {
-#ifdef NFA_X_NTSTORE
-            __builtin_nontemporal_store(reinterpret_cast<const vec4*>(s_out)[tid],
-                                        reinterpret_cast<vec4*>(a.out + row0 * D) + tid);
-#else
+        if (tid < nvx)
             reinterpret_cast<vec4*>(a.out + row0 * D)[tid] = reinterpret_cast<const vec4*>(s_out)[tid];
-#endif
-        }
-#endif
         if (!lad_shuffle) {
             const int wave = tid >> 6, lane = tid & 63;
             for (int r = wave; r < R; r += kBlock / kWave) {

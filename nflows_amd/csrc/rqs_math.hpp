@@ -44,9 +44,6 @@ struct Slots<0> {
 // the correctly rounded quotient (no scaling needed here: |a|, |b| are far from the fp32 limits).
 __device__ __forceinline__ float div_with_rcp(float a, float b, float r) {
     const float q = a * r;
-#ifdef NFA_X_NOCORR
-    return q;
-#endif
     const float e = __builtin_fmaf(-q, b, a);
     return __builtin_fmaf(e, r, q);
 }
@@ -87,9 +84,6 @@ __device__ __forceinline__ float exp_noclamp(float x) {
     const float kLog2eLo = 1.925963033500011e-08f;          // log2(e) - kLog2e
     const float kLn2 = 0.693147182464599609375f;
     const float hi = x * kLog2e;
-#ifdef NFA_X_FASTEXP
-    return __builtin_amdgcn_exp2f(hi);
-#endif
     float lo = __builtin_fmaf(x, kLog2e, -hi);
     lo = __builtin_fmaf(x, kLog2eLo, lo);
     const float e0 = __builtin_amdgcn_exp2f(hi);
@@ -140,21 +134,13 @@ __device__ __forceinline__ void walk_bins(const Slots<KT>& e, int K, float denom
                                           float& knot_lo, float& knot_hi) {
 #pragma clang fp contract(off)
     const float rden = rcp_refined(denom);
-#ifdef NFA_X_F32CUMSUM
-    float acc = 0.0f;
-#else
     double acc = 0.0;
-#endif
     float prev = lo;
 #pragma unroll
     for (int i = 0; i < (KT > 0 ? KT : K); ++i) {
         const float p = div_with_rcp(e.get(i), denom, rden);
         const float w = minbin + om * p;
-#ifdef NFA_X_F32CUMSUM
-        acc += w;
-#else
         acc += (double)w;
-#endif
         const float c = (float)acc;
         const float next = (i == (KT > 0 ? KT : K) - 1) ? hi : span * c + lo;
         const bool take = SEARCH ? (x >= prev) : (i == k);
@@ -224,11 +210,6 @@ template <int KT, bool INVERSE, bool LINEAR, bool REGS = false>
 __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, float& y, float& lad) {
 #pragma clang fp contract(off)
     const int K = KT > 0 ? KT : sp.K;
-#ifdef NFA_ABLATE_MATH  // experiment only (tools/k1_micro.py): memory pipeline without the arithmetic
-    y = x + sl[0];
-    lad = sl[K];
-    return 0;
-#endif
     const float left = LINEAR ? -sp.right : sp.left;
     const float right = sp.right;
     const float bottom = LINEAR ? -sp.right : sp.bottom;
@@ -275,11 +256,6 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
         walk_bins<KT, false>(eh, K, den_h, sp.min_h, sp.om_h, span_h, bottom, top, x, k, ch0, ch1);
     }
 
-#ifdef NFA_X_NOEVAL
-    y = cw0 + ch0 + cw1 + ch1;
-    lad = (float)k;
-    return 0;
-#endif
     const float* sd = sl + 2 * K;
     float u0, u1;
     if (LINEAR && REGS) {

@@ -62,7 +62,6 @@ struct WeightStream {
     int fetch;       // stage index (in the layer's list) to request next
     int num_stages;
     int tid;
-    int prio;        // experiment NFA_K8_ALT_PRIO: issue priority alternates every N stages
 };
 
 __device__ __forceinline__ void stream_request(WeightStream& sm) {
@@ -82,11 +81,6 @@ __device__ __forceinline__ void stream_request(WeightStream& sm) {
 __device__ __forceinline__ void stream_advance(WeightStream& sm) {
     asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     sm.slot = (sm.slot + 1 == kRing) ? 0 : sm.slot + 1;
-#ifdef NFA_K8_ALT_PRIO
-    sm.prio += 1;
-    if (sm.prio & NFA_K8_ALT_PRIO) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-#endif
 }
 
 #define NFA_MFMA6(acc, ah, am, al, bh, bm, bl)                                        \
@@ -227,11 +221,6 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         s_tab[tid] = v < 0 ? 0 : (v >= D ? D - 1 : v);
     }
 
-#ifdef NFA_K8_YOUNG_PRIO
-    // experiment: the second workgroup resident on a CU loses every issue arbitration by age;
-    // a static priority evens the two out
-    if (blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(NFA_K8_YOUNG_PRIO);
-#endif
     WeightStream sm;
     sm.w = a.w;
     sm.ring = reinterpret_cast<vec4f*>(lds_dyn);
@@ -239,11 +228,6 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
     sm.fetch = 0;
     sm.num_stages = a.num_stages;
     sm.tid = tid;
-#ifdef NFA_K8_ALT_PRIO
-    sm.prio = (blockIdx.x >= (gridDim.x >> 1)) ? NFA_K8_ALT_PRIO : 0;
-#else
-    sm.prio = 0;
-#endif
     stream_request(sm);  // stage 0 -> slot 0
     sm.slot = 2;
     stream_request(sm);  // stage 1 -> slot 1
@@ -334,7 +318,6 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         //      connection; u (64 accumulators) turns into the relu(u) pieces (96) tile by tile, then
         //      the skip is added into the second Linear's accumulators tile by tile (the h pieces
         //      die), whose input pieces die k-step by k-step.
-#ifndef NFA_K8_NO_BLOCKS
         for (int blk = 0; blk < a.num_blocks; ++blk) {
             bf16x8 qh[8], qm[8], ql[8];
             {
@@ -361,13 +344,9 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
             bias += 256;
             NFA_STAMP()
         }
-#endif
 
         // ---- final layer, three 32-row tiles (= 4 features) at a time, and the splines
         float lad_acc = 0.0f;
-#ifdef NFA_K8_NO_FINAL
-        for (int ks = 0; ks < 8; ++ks) lad_acc += (float)ph[ks][0] + (float)pm[ks][1] + (float)pl[ks][2];
-#else
         for (int g = 0; g < groups; ++g) {
             float* slot0 = s_row + s_tab[kTabTrPos + g * 4 + half * 2] * kRowPad + r;
             float* slot1 = s_row + s_tab[kTabTrPos + g * 4 + half * 2 + 1] * kRowPad + r;
@@ -392,7 +371,6 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
             }
             NFA_STAMP()
         }
-#endif
 
         // ---- the tile is the output: 32 whole rows, 16 bytes per lane per store
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
