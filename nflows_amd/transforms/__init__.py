@@ -7,6 +7,9 @@ from .coupling import (AdditiveCouplingTransform, AffineCouplingTransform, Coupl
 from .permutations import Permutation, RandomPermutation, ReversePermutation
 from . import splines
 from .autoregressive import (AutoregressiveTransform, MaskedAffineAutoregressiveTransform,
+                             MaskedPiecewiseCubicAutoregressiveTransform,
+                             MaskedPiecewiseLinearAutoregressiveTransform,
+                             MaskedPiecewiseQuadraticAutoregressiveTransform,
                              MaskedPiecewiseRationalQuadraticAutoregressiveTransform)
 from .made import MADE
 from .nonlinearities import (PiecewiseCubicCDF, PiecewiseLinearCDF, PiecewiseQuadraticCDF,

@@ -15,6 +15,8 @@ from .. import ops
 from . import made as made_module
 from .base import Transform
 from .splines import rational_quadratic
+from . import splines
+from ..utils import torchutils
 
 
 class AutoregressiveTransform(Transform):
@@ -177,3 +179,121 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
         """One feature: params [B, P]; the spline layer kernel with a single (transformed) feature."""
         out, lad = self._elementwise(column.reshape(-1, 1), params, inverse=True)
         return out.reshape(-1), lad
+
+
+class _SiblingSplineAutoregressiveTransform(AutoregressiveTransform):
+    """Shared part of the linear / quadratic / cubic autoregressive spline layers
+    (autoregressive.py:196-401): MADE emits `_output_dim_multiplier()` logits per feature, the
+    spline functional (K9) runs elementwise, logabsdet is summed per sample."""
+
+    def _make_net(self, features, hidden_features, context_features, num_blocks, use_residual_blocks,
+                  random_mask, activation, dropout_probability, use_batch_norm):
+        return made_module.MADE(features=features, hidden_features=hidden_features,
+                                context_features=context_features, num_blocks=num_blocks,
+                                output_multiplier=self._output_dim_multiplier(),
+                                use_residual_blocks=use_residual_blocks, random_mask=random_mask,
+                                activation=activation, dropout_probability=dropout_probability,
+                                use_batch_norm=use_batch_norm)
+
+    def _wh_divisor(self):
+        net = self.autoregressive_net
+        return float(np.sqrt(net.hidden_features)) if hasattr(net, "hidden_features") else 0.0
+
+    def _functional(self, inputs, params, inverse):
+        """inputs [...], params [..., multiplier] -> (outputs, logabsdet) elementwise"""
+        raise NotImplementedError()
+
+    def _elementwise(self, inputs, autoregressive_params, inverse=False):
+        params = autoregressive_params.view(inputs.shape[0], self.features, self._output_dim_multiplier())
+        outputs, logabsdet = self._functional(inputs, params, inverse)
+        return outputs, torchutils.sum_except_batch(logabsdet)
+
+    def _elementwise_forward(self, inputs, autoregressive_params):
+        return self._elementwise(inputs, autoregressive_params)
+
+    def _elementwise_inverse(self, inputs, autoregressive_params):
+        return self._elementwise(inputs, autoregressive_params, inverse=True)
+
+    def _inverse_column(self, column, params):
+        return self._functional(column, params, True)
+
+
+class MaskedPiecewiseLinearAutoregressiveTransform(_SiblingSplineAutoregressiveTransform):
+    """autoregressive.py:196-246: piecewise-linear CDF on [0, 1] per feature."""
+
+    def __init__(self, num_bins, features, hidden_features, context_features=None, num_blocks=2,
+                 use_residual_blocks=True, random_mask=False, activation=F.relu, dropout_probability=0.0,
+                 use_batch_norm=False):
+        self.num_bins = num_bins
+        self.features = features
+        super().__init__(self._make_net(features, hidden_features, context_features, num_blocks,
+                                        use_residual_blocks, random_mask, activation, dropout_probability,
+                                        use_batch_norm))
+
+    def _output_dim_multiplier(self):
+        return self.num_bins
+
+    def _functional(self, inputs, params, inverse):
+        return splines.linear_spline(inputs, params, inverse=inverse)
+
+
+class MaskedPiecewiseQuadraticAutoregressiveTransform(_SiblingSplineAutoregressiveTransform):
+    """autoregressive.py:249-334.  Only the width logits are divided by sqrt(hidden_features) when
+    the net exposes it (:304-306; the height scaling is commented out in the reference)."""
+
+    def __init__(self, features, hidden_features, context_features=None, num_bins=10, num_blocks=2,
+                 tails=None, tail_bound=1.0, use_residual_blocks=True, random_mask=False, activation=F.relu,
+                 dropout_probability=0.0, use_batch_norm=False,
+                 min_bin_width=rational_quadratic.DEFAULT_MIN_BIN_WIDTH,
+                 min_bin_height=rational_quadratic.DEFAULT_MIN_BIN_HEIGHT,
+                 min_derivative=rational_quadratic.DEFAULT_MIN_DERIVATIVE):
+        self.num_bins = num_bins
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.min_derivative = min_derivative
+        self.tails = tails
+        self.tail_bound = tail_bound
+        self.features = features
+        super().__init__(self._make_net(features, hidden_features, context_features, num_blocks,
+                                        use_residual_blocks, random_mask, activation, dropout_probability,
+                                        use_batch_norm))
+
+    def _output_dim_multiplier(self):
+        return self.num_bins * 2 - 1 if self.tails == "linear" else self.num_bins * 2 + 1
+
+    def _functional(self, inputs, params, inverse):
+        K = self.num_bins
+        uw, uh = params[..., :K], params[..., K:]
+        if self._wh_divisor():
+            uw = uw / self._wh_divisor()
+        kw = dict(inverse=inverse, min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height)
+        if self.tails is None:
+            return splines.quadratic_spline(inputs, uw, uh, **kw)
+        if self.tails == "linear":
+            return splines.unconstrained_quadratic_spline(inputs, uw, uh, tails=self.tails,
+                                                          tail_bound=self.tail_bound, **kw)
+        raise ValueError
+
+
+class MaskedPiecewiseCubicAutoregressiveTransform(_SiblingSplineAutoregressiveTransform):
+    """autoregressive.py:337-401: cubic spline on [0, 1] per feature."""
+
+    def __init__(self, num_bins, features, hidden_features, context_features=None, num_blocks=2,
+                 use_residual_blocks=True, random_mask=False, activation=F.relu, dropout_probability=0.0,
+                 use_batch_norm=False):
+        self.num_bins = num_bins
+        self.features = features
+        super().__init__(self._make_net(features, hidden_features, context_features, num_blocks,
+                                        use_residual_blocks, random_mask, activation, dropout_probability,
+                                        use_batch_norm))
+
+    def _output_dim_multiplier(self):
+        return self.num_bins * 2 + 2
+
+    def _functional(self, inputs, params, inverse):
+        K = self.num_bins
+        uw, uh = params[..., :K], params[..., K:2 * K]
+        if self._wh_divisor():
+            uw, uh = uw / self._wh_divisor(), uh / self._wh_divisor()
+        return splines.cubic_spline(inputs, uw, uh, params[..., 2 * K:2 * K + 1], params[..., 2 * K + 1:2 * K + 2],
+                                    inverse=inverse)

@@ -36,6 +36,9 @@ from nflows.transforms.coupling import (  # noqa: E402
 from nflows.transforms.permutations import RandomPermutation, ReversePermutation  # noqa: E402
 from nflows.transforms.autoregressive import (  # noqa: E402
     MaskedAffineAutoregressiveTransform,
+    MaskedPiecewiseCubicAutoregressiveTransform,
+    MaskedPiecewiseLinearAutoregressiveTransform,
+    MaskedPiecewiseQuadraticAutoregressiveTransform,
     MaskedPiecewiseRationalQuadraticAutoregressiveTransform,
 )
 from nflows.nn.nets import ResidualNet, ConvResidualNet, MLP  # noqa: E402
@@ -676,6 +679,51 @@ def sibling_coupling_cases():
     print("sibling couplings:", len(meta), "cases")
 
 
+def sibling_autoregressive_cases():
+    """Masked autoregressive layers on the linear / quadratic / cubic splines
+    (autoregressive.py:196-401), forward and the reference's D-pass inverse."""
+    out = {}
+    meta = []
+    g = torch.Generator().manual_seed(515)
+    D, H, B, K = 6, 16, 40, 5
+    cases = [
+        ("ar_linear", lambda: MaskedPiecewiseLinearAutoregressiveTransform(K, D, H), "unit"),
+        ("ar_quadratic", lambda: MaskedPiecewiseQuadraticAutoregressiveTransform(D, H, num_bins=K, tails="linear",
+                                                                                 tail_bound=3.0), "real"),
+        ("ar_quadratic_box", lambda: MaskedPiecewiseQuadraticAutoregressiveTransform(D, H, num_bins=K), "unit"),
+        ("ar_cubic", lambda: MaskedPiecewiseCubicAutoregressiveTransform(K, D, H), "unit"),
+    ]
+    for name, make, domain in cases:
+        torch.manual_seed(31)
+        t = make()
+        with torch.no_grad():
+            for p_name, p in t.named_parameters():
+                if "final_layer" in p_name:
+                    p.mul_(3.0)
+        if domain == "unit":
+            x = 0.02 + 0.96 * torch.rand(B, D, generator=g)
+            noise = 0.02 + 0.96 * torch.rand(B, D, generator=g)
+        else:
+            x = 1.5 * torch.randn(B, D, generator=g)
+            noise = 1.5 * torch.randn(B, D, generator=g)
+        t.eval()
+        with torch.no_grad():
+            z, lad = t(x)
+            xs, lad_inv = t.inverse(noise)
+            t64 = t.double()
+            z64, lad64 = t64(x.double())
+            xs64, ladi64 = t64.inverse(noise.double())
+            t.float()
+        state_to_np(name, t, out)
+        for k, v in dict(x=x, noise=noise, z=z, lad=lad, inv_x=xs, inv_lad=lad_inv, z64=z64, lad64=lad64,
+                         inv_x64=xs64, inv_lad64=ladi64).items():
+            out[name + "/" + k] = npy(v)
+        meta.append((name, repr(dict(D=D, H=H, K=K))))
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "ar_siblings.npz"), **out)
+    print("sibling autoregressive:", len(meta), "cases")
+
+
 def cubic_coupling_cases():
     """PiecewiseCubicCouplingTransform on [B, D] (with and without the unconditional CDF on the
     identity half) and on images."""
@@ -823,6 +871,9 @@ def flow_h128_case():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ar":
+        sibling_autoregressive_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cubic":
         cubic_spline_cases()
         cubic_coupling_cases()
@@ -853,3 +904,4 @@ if __name__ == "__main__":
     sibling_coupling_cases()
     cubic_spline_cases()
     cubic_coupling_cases()
+    sibling_autoregressive_cases()

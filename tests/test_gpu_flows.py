@@ -533,3 +533,36 @@ def test_sibling_couplings_against_reference_vectors(golden_dir):
         if not cfg.get("apply_unconditional_transform", False) and not name.startswith("c2d_"):
             ident = t.identity_features
             assert torch.equal(z[:, ident], x[:, ident])
+
+
+@pytest.mark.parametrize("columnwise", [True, False])
+def test_sibling_autoregressive_layers_against_reference_vectors(golden_dir, columnwise):
+    """tests/golden/ar_siblings.npz: masked autoregressive layers on the linear / quadratic / cubic
+    splines, forward and inverse (column-wise and the reference's D-pass loop), against the real
+    reference; its state_dicts load unchanged."""
+    from nflows_amd.transforms import (MaskedPiecewiseCubicAutoregressiveTransform,
+                                       MaskedPiecewiseLinearAutoregressiveTransform,
+                                       MaskedPiecewiseQuadraticAutoregressiveTransform)
+    g = np.load(os.path.join(golden_dir, "ar_siblings.npz"))
+    for name, cfg in g["meta"]:
+        cfg = parse_kwargs(cfg)
+        D, H, K = cfg["D"], cfg["H"], cfg["K"]
+        t = {"ar_linear": lambda: MaskedPiecewiseLinearAutoregressiveTransform(K, D, H),
+             "ar_quadratic": lambda: MaskedPiecewiseQuadraticAutoregressiveTransform(D, H, num_bins=K, tails="linear",
+                                                                                     tail_bound=3.0),
+             "ar_quadratic_box": lambda: MaskedPiecewiseQuadraticAutoregressiveTransform(D, H, num_bins=K),
+             "ar_cubic": lambda: MaskedPiecewiseCubicAutoregressiveTransform(K, D, H)}[str(name)]()
+        load_state(t, g, name)
+        t = t.to(DEV).eval()
+        t.columnwise_inverse = columnwise
+        x = torch.from_numpy(g[name + "/x"]).to(DEV)
+        noise = torch.from_numpy(g[name + "/noise"]).to(DEV)
+        with torch.no_grad():
+            z, lad = t(x)
+            xs, lad_inv = t.inverse(noise)
+        import nflows_amd
+        nflows_amd.check_status()
+        check(z, g[name + "/z"], g[name + "/z64"], name + " z", 1e-5)
+        check(lad, g[name + "/lad"], g[name + "/lad64"], name + " lad", 1e-5 * D)
+        check(xs, g[name + "/inv_x"], g[name + "/inv_x64"], name + " inv_x", 1e-5)
+        check(lad_inv, g[name + "/inv_lad"], g[name + "/inv_lad64"], name + " inv_lad", 1e-5 * D)
