@@ -271,23 +271,31 @@ def main():
         timing_note = ("HIP start/stop events attached to each layer-kernel dispatch on its launch "
                        "stream (hipExtLaunchKernelGGL), all launches of the timed region")
 
-        def roofline_of(path, ms):
+        def roofline_of(path, ms, launches_per_step):
+            """`launches_per_step` layer-kernel dispatches make one step of `args.layers` layers: 32
+            (one layer per launch) or 1 (the run of K8 layers in a single launch)."""
             avg_ms, launches = sum(ms) / len(ms), len(ms)
-            common = {"avg_launch_ms": avg_ms, "launches_timed": launches, "timing": timing_note}
+            layers_per_launch = args.layers / launches_per_step
+            common = {"avg_launch_ms": avg_ms, "launches_timed": launches, "layers_per_launch": layers_per_launch,
+                      "timing": timing_note}
             if path in ("k8", "k7b"):
                 # GEMMs on the bf16 matrix pipe with split-bf16 operands: 6 bf16 products per fp32
                 # multiply-add (DESIGN.md section 4); flops of the unpadded layers
                 macs = dt_ * P_ * H_ + ((D - dt_) * H_ + nb_ * 2 * H_ * H_ if path == "k8" else 0)
-                flops = 6 * 2.0 * B * macs
+                flops = 6 * 2.0 * B * macs * layers_per_launch
                 ach = flops / (avg_ms * 1e-3) / 1e12
+                # HBM: a run of layers reads its rows once and writes them once, and streams every
+                # layer's packed weights (bf16 triples in 12 KB stages) once
+                k8_weights = layers_per_launch * (2 + 16 * nb_ + 2 * (dt_ * 24 // 32)) * 12288
+                bytes_ = io_bytes + k8_weights if path == "k8" else (io_bytes + 4 * B * H_) * layers_per_launch
                 r = {"bound": "mfma",
-                     "kernel": "nfa::rqs_resnet_kernel<false>" if path == "k8" else "nfa::rqs_fused_linear_bf16_kernel<false>",
+                     "kernel": "nfa::rqs_resnet_kernel<false, 1, 2>" if path == "k8" else "nfa::rqs_fused_linear_bf16_kernel<false>",
                      "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
                      "traffic": load_traffic("k8_pmc_traffic.json" if path == "k8" else "k7b_pmc_traffic.json"),
                      "algorithmic_flops_per_launch": flops,
-                     "algorithmic_bytes_per_launch": io_bytes + (4 * B * H_ if path == "k7b" else 0),
+                     "algorithmic_bytes_per_launch": bytes_,
                      "fp32_equivalent_tflops": ach / 6,
-                     "note": "achieved = 6 x (fp32 multiply-adds of the layer's GEMMs) x 2 / time: every fp32 "
+                     "note": "achieved = 6 x (fp32 multiply-adds of the layers' GEMMs) x 2 / time: every fp32 "
                              "operand is three bf16 pieces and six cross products run on the bf16 pipe "
                              "(fp32-accurate); peak = dense bf16 MFMA peak.  As fp32 GEMM work this is "
                              "%.1f TFLOP/s (fp32 matrix peak: 157.3)" % (ach / 6)}
@@ -306,7 +314,7 @@ def main():
             r.update(common)
             return r
 
-        roofline = roofline_of(args.path, k1_ms) if k1_ms else None
+        roofline = roofline_of(args.path, k1_ms, len(k1_ms) / args.steps) if k1_ms else None
         roofline_k1 = None
         if args.path != "k1" and not args.skip_k1_roofline:
             # the HBM-bound spline kernel K1 (what the fused kernels replace on this shape), measured
@@ -325,7 +333,7 @@ def main():
             finally:
                 select_path(args.path)
             if ms:
-                roofline_k1 = roofline_of("k1", ms)
+                roofline_k1 = roofline_of("k1", ms, args.layers)
                 roofline_k1["note"] = "not in the timed region: PyTorch conditioner + K1 path (--path k1)"
         result = {
             "metric": "log_prob samples/sec (dim=64, K=8, 32-layer RQ-NSF) + max |fwd∘inv − x|",
@@ -346,7 +354,8 @@ def main():
                        "global_batch": total_rows, "features": D, "num_bins": K, "layers": args.layers,
                        "parallelism": "sample-sharded x%d" % world,
                        "fused_permutations": not args.no_fuse,
-                       "layer_kernel": {"k8": "K8: ResidualNet conditioner + spline layer in one kernel",
+                       "layer_kernel": {"k8": "K8: ResidualNet conditioner + spline layer in one kernel, the run of "
+                                              "layers in one launch",
                                         "k7b": "K7b: final Linear (split-bf16 MFMA) + spline layer",
                                         "k7": "K7: final Linear (fp32 MFMA) + spline layer",
                                         "k1": "PyTorch conditioner + K1 spline layer"}[args.path]},

@@ -183,12 +183,15 @@ int nfa_rqs_coupling_fused_linear_f32(const float *inputs, const float *hidden,
  * Activations and spline parameters never leave the register file; HBM traffic is one coalesced
  * read of inputs and one coalesced write of outputs + logabsdet.
  *   layer_tables   int32 [256], the layer's column bookkeeping with both neighbouring
- *                  permutations folded in (layer column c is read from input column src[c] =
- *                  in_perm[c] and stored at output position dst[c] = out_scatter[c]):
- *                  [0, 128): output position of the layer column read from input column i;
- *                  [128, 192): output position of identity feature i (identity_features,
- *                  coupling.py:44-56, in the conditioner's input order);
- *                  [192, 256): output position of transformed feature f (transform_features).
+ *                  permutations folded in (layer column c reads input column src[c] =
+ *                  in_perm[c] and its output is stored at position dst[c] = out_scatter[c]).
+ *                  The kernel keeps each sample's row in a tile whose slot j holds input column j;
+ *                  features are transformed in place:
+ *                  [0, 64): slot of identity feature i (identity_features, coupling.py:44-56, in
+ *                  the conditioner's input order) = src[identity_features[i]];
+ *                  [64, 128): slot of transformed feature f = src[transform_features[f]];
+ *                  [128, 256): for every output position p the slot stored there
+ *                  (= src[c] for the column c with dst[c] = p).
  *                  Entries outside [0, features) set NFA_STATUS_BAD_INDEX.
  *   weights_packed bf16, [stages][768 x 8]: 12 KB stages in consumption order --
  *                  initial_layer, 2 stages (d_i <= 32) or 4 (d_i <= 64), k-step ks = 0, 1, ..:
@@ -216,6 +219,26 @@ int nfa_rqs_coupling_resnet_f32(const float *inputs, const void *weights_packed,
                                 int32_t features, int32_t num_transform, int32_t num_identity,
                                 int32_t hidden_features, int32_t num_blocks,
                                 const nfa_rqs_spec *spec, int32_t flags, void *stream);
+
+/*
+ * K8 over a run of layers.  Rows of a flow are independent, so num_layers coupling layers of the
+ * K8 shape family (same features / d_t / d_i / num_blocks / spec; CompositeTransform._cascade,
+ * transforms/base.py:45-52, over [Permutation, coupling] pairs) run back to back on the same rows
+ * in ONE launch: the row tile stays in LDS, inputs are read once and outputs written once for the
+ * whole run, logabsdet is the sum over the layers.
+ *   weights_packed / bias_packed  the layers' K8 blobs concatenated in execution order
+ *   flow_tables  int32 [(num_layers + 1) * 128]: per layer [0, 64) identity slots and [64, 128)
+ *                transformed slots as above, but relative to the FIRST layer's input columns (slot
+ *                j = input column j of the run; every permutation between the layers is composed
+ *                into the tables, the tile itself never moves); the last 128 entries give the
+ *                slot stored at every output position of the run.
+ */
+int nfa_rqs_flow_resnet_f32(const float *inputs, const void *weights_packed,
+                            const float *bias_packed, const int32_t *flow_tables,
+                            int32_t num_layers, float *outputs, float *logabsdet, int32_t *status,
+                            int64_t batch, int32_t features, int32_t num_transform,
+                            int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
+                            const nfa_rqs_spec *spec, int32_t flags, void *stream);
 
 /*
  * K5.  Elementwise rational-quadratic functional (no row-sum):

@@ -40,6 +40,7 @@ EXPORTS = (
     "nfa_rqs_coupling_backward_f32",
     "nfa_rqs_coupling_fused_linear_f32",
     "nfa_rqs_coupling_resnet_f32",
+    "nfa_rqs_flow_resnet_f32",
     "nfa_linear_spline_f32",
     "nfa_quadratic_spline_f32",
     "nfa_cubic_spline_f32",
@@ -108,6 +109,8 @@ def _declare(lib):
     lib.nfa_quadratic_spline_f32.argtypes = [vp, vp, i64, vp, i64, i32, vp, vp, vp, i64, sp, i32, vp]
     lib.nfa_cubic_spline_f32.restype = ctypes.c_int
     lib.nfa_cubic_spline_f32.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, i64, sp, i32, vp]
+    lib.nfa_rqs_flow_resnet_f32.restype = ctypes.c_int
+    lib.nfa_rqs_flow_resnet_f32.argtypes = [vp] * 4 + [i32] + [vp] * 3 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
     lib.nfa_rqs_coupling_resnet_f32.restype = ctypes.c_int
     lib.nfa_rqs_coupling_resnet_f32.argtypes = [vp] * 7 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
     lib.nfa_rqs_elementwise_f32.restype = ctypes.c_int

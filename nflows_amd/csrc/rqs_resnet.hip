@@ -37,18 +37,18 @@ namespace nfa {
 constexpr int kStageVec4 = 768;    // 12 KB: [4 tiles][3 pieces][64 lanes] or [3 pieces][4 k-steps][64 lanes] x 16 B
 constexpr int kRing = 3;
 constexpr int kRowPad = 33;        // row tile: [output position][33]: conflict-free both ways
-constexpr int kTabIn2Pos = 0, kTabIdPos = 128, kTabTrPos = 192, kTabSize = 256;
+constexpr int kTabId = 0, kTabTr = 64, kTabLayer = 128;   // per-layer table: identity slots, transformed slots
 
 struct ResnetArgs {
     const float* x;      // [B, D]
-    const vec4f* w;      // [num_stages][768] x 16 bytes, layout in include/nflows_amd.h
-    const float* bias;   // accumulator-order biases of all GEMMs
-    const int32_t* tables;
+    const vec4f* w;      // [num_layers * stages_per_layer][768] x 16 bytes, layout in include/nflows_amd.h
+    const float* bias;   // accumulator-order biases of all GEMMs, layer after layer
+    const int32_t* tables;  // [num_layers][128] slots of the identity / transformed features, then [128] final
     float* out;
     float* lad;
     int32_t* status;
     int64_t batch;  // multiple of 128
-    int D, dt, di, num_blocks, num_stages, accumulate;
+    int D, dt, di, num_blocks, num_layers, num_stages, bias_per_layer, accumulate;
     RqsDev sp;
     unsigned long long* trace;
 };
@@ -206,19 +206,30 @@ __device__ __forceinline__ void load_bias_tile(f32x16& acc, const float* bias_ti
 // PRESCALED: 1 = the host folded 1/sqrt(hidden) into the width / height rows of the final layer,
 // 2 = 1/sqrt(hidden) and log2(e) (NFA_FLAG_LOGITS_LOG2E: softmax numerators are then one v_exp_f32)
 // INIT_KS: k-steps of the initial layer, 2 (d_i <= 32) or 4 (d_i <= 64)
+//
+// The kernel runs num_layers coupling layers back to back on the same 32 rows per wave: rows of a
+// flow are independent, so a workgroup can take its 128 rows through every layer without meeting
+// the others.  The row tile never moves between layers: slot j of the tile is input column j of
+// the first layer; every layer reads its identity / transformed features from, and writes its
+// spline results back to, fixed slots given by its table (the host composes all the permutations
+// between the layers into these tables), and the last table says which slot ends up at which
+// output position.  Weights and biases of all layers form one stream in execution order.
 template <bool INVERSE, int PRESCALED, int INIT_KS>
 __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs a) {
     // dynamic LDS: the weight ring, then per wave a [D][33] row tile
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-    __shared__ int s_tab[kTabSize];
+    __shared__ int s_tab[2][kTabLayer];   // tables of the current and the next layer
+    __shared__ int s_final[128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = a.D, dt = a.dt;
     int my_status = 0;
-    if (tid < kTabSize) {
-        int v = a.tables[tid];
-        const bool used = tid < kTabIdPos ? tid < D : (tid < kTabTrPos ? tid - kTabIdPos < a.di : tid - kTabTrPos < dt);
+    auto checked = [&](int v, bool used) {
         if (used && (v < 0 || v >= D)) my_status |= NFA_STATUS_BAD_INDEX;
-        s_tab[tid] = v < 0 ? 0 : (v >= D ? D - 1 : v);
+        return v < 0 ? 0 : (v >= D ? D - 1 : v);
+    };
+    if (tid < kTabLayer) {
+        s_tab[0][tid] = checked(a.tables[tid], tid < kTabTr ? tid < a.di : tid - kTabTr < dt);
+        s_final[tid] = checked(a.tables[a.num_layers * kTabLayer + tid], tid < D);
     }
 
     WeightStream sm;
@@ -226,7 +237,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
     sm.ring = reinterpret_cast<vec4f*>(lds_dyn);
     sm.slot = 1;  // so that the first two requests go to slots 0 and 1
     sm.fetch = 0;
-    sm.num_stages = a.num_stages;
+    sm.num_stages = a.num_stages * a.num_layers;
     sm.tid = tid;
     stream_request(sm);  // stage 0 -> slot 0
     sm.slot = 2;
@@ -238,6 +249,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
     float* s_row = lds_dyn + kRing * kStageVec4 * 4 + wave * D * kRowPad;
     const int groups = dt >> 2;
     const int64_t num_quads = a.batch >> 7;
+    int tb = 0;  // which half of s_tab holds the current layer's table
 
     unsigned long long* tr = nullptr;
     int ti = 0;
@@ -251,7 +263,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         asm volatile("" : "+v"(lane_here), "+s"(di));
         const int half = lane_here >> 5, r = lane_here & 31;
         NFA_STAMP()
-        // ---- the wave's 32 rows: one coalesced read, scattered into the tile by output position
+        // ---- the wave's 32 rows: one coalesced read; slot j of the tile = input column j
         {
             const vec4f* xv = reinterpret_cast<const vec4f*>(a.x + row0 * D);
             const int nvec = D * 8;  // 32 * D / 4
@@ -267,10 +279,10 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                     const int e = e0 + u * kWave;
                     if (e < nvec) {
                         const int rr = (e * 4) / D, c0 = e * 4 - rr * D;
-                        s_row[s_tab[kTabIn2Pos + c0 + 0] * kRowPad + rr] = v[u].x;
-                        s_row[s_tab[kTabIn2Pos + c0 + 1] * kRowPad + rr] = v[u].y;
-                        s_row[s_tab[kTabIn2Pos + c0 + 2] * kRowPad + rr] = v[u].z;
-                        s_row[s_tab[kTabIn2Pos + c0 + 3] * kRowPad + rr] = v[u].w;
+                        s_row[(c0 + 0) * kRowPad + rr] = v[u].x;
+                        s_row[(c0 + 1) * kRowPad + rr] = v[u].y;
+                        s_row[(c0 + 2) * kRowPad + rr] = v[u].z;
+                        s_row[(c0 + 3) * kRowPad + rr] = v[u].w;
                     }
                 }
             }
@@ -278,113 +290,130 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        const float* bias = a.bias + half * 16;  // + 32 per tile
-        bf16x8 ph[8], pm[8], pl[8];  // the current activations (128 k per sample) as bf16 pieces
-
-        // ---- identity features: k = ks*16 + half*8 + j
-#pragma unroll
-        for (int ks = 0; ks < INIT_KS; ++ks) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = ks * 16 + half * 8 + j;
-                const float xv = s_row[s_tab[kTabIdPos + i] * kRowPad + r];
-                v[j] = i < di ? xv : 0.0f;
+        float lad_acc = 0.0f;
+        for (int layer = 0; layer < a.num_layers; ++layer) {
+            // the two workgroups resident on a CU take turns at the higher issue priority: issue
+            // arbitration on a SIMD is strictly by priority, then age, so without this the younger
+            // workgroup loses every slot and finishes the run alone (measured: -3 % run time)
+            if ((layer + (blockIdx.x >= (gridDim.x >> 1) ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+            const int* tab = s_tab[tb];
+            // the next layer's table (the first one again after the last: next row block) goes to
+            // the other half now; it is read only after this layer's many stage barriers
+            if (tid < kTabLayer) {
+                const int nl = layer + 1 < a.num_layers ? layer + 1 : 0;
+                s_tab[tb ^ 1][tid] = checked(a.tables[nl * kTabLayer + tid], tid < kTabTr ? tid < a.di : tid - kTabTr < dt);
             }
-            bf16x2 hh[4], mm[4], ll[4];
-#pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) split3(vec2f{v[j2 * 2], v[j2 * 2 + 1]}, hh[j2], mm[j2], ll[j2]);
-            ph[ks] = join4(hh[0], hh[1], hh[2], hh[3]);
-            pm[ks] = join4(mm[0], mm[1], mm[2], mm[3]);
-            pl[ks] = join4(ll[0], ll[1], ll[2], ll[3]);
-        }
-        NFA_STAMP()
+            const float* bias = a.bias + (size_t)layer * a.bias_per_layer + half * 16;  // + 32 per tile
+            bf16x8 ph[8], pm[8], pl[8];  // the current activations (128 k per sample) as bf16 pieces
 
-        // ---- initial layer: h = W_i x + b_i
-        {
-            f32x16 h[4];
+            // ---- identity features: k = ks*16 + half*8 + j
 #pragma unroll
-            for (int t = 0; t < 4; ++t) load_bias_tile(h[t], bias + t * 32);
-            gemm_kmajor<false, INIT_KS>(h, ph, pm, pl, sm, lane);
+            for (int ks = 0; ks < INIT_KS; ++ks) {
+                float v[8];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                tile_to_pieces<false>(h[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
-        }
-        bias += 128;
-        NFA_STAMP()
+                for (int j = 0; j < 8; ++j) {
+                    const int i = ks * 16 + half * 8 + j;
+                    const float xv = s_row[tab[kTabId + i] * kRowPad + r];
+                    v[j] = i < di ? xv : 0.0f;
+                }
+                bf16x2 hh[4], mm[4], ll[4];
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) split3(vec2f{v[j2 * 2], v[j2 * 2 + 1]}, hh[j2], mm[j2], ll[j2]);
+                ph[ks] = join4(hh[0], hh[1], hh[2], hh[3]);
+                pm[ks] = join4(mm[0], mm[1], mm[2], mm[3]);
+                pl[ks] = join4(ll[0], ll[1], ll[2], ll[3]);
+            }
+            NFA_STAMP()
 
-        // ---- residual blocks: h += W_1 relu(W_0 relu(h) + b_0) + b_1, both Linears k-major.
-        //      Register budget: the h pieces (96) must survive the first Linear for the skip
-        //      connection; u (64 accumulators) turns into the relu(u) pieces (96) tile by tile, then
-        //      the skip is added into the second Linear's accumulators tile by tile (the h pieces
-        //      die), whose input pieces die k-step by k-step.
-        for (int blk = 0; blk < a.num_blocks; ++blk) {
-            bf16x8 qh[8], qm[8], ql[8];
+            // ---- initial layer: h = W_i x + b_i
             {
-                f32x16 u[4];
+                f32x16 h[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) load_bias_tile(u[t], bias + t * 32);
-                gemm_kmajor<true, 8>(u, ph, pm, pl, sm, lane);
+                for (int t = 0; t < 4; ++t) load_bias_tile(h[t], bias + t * 32);
+                gemm_kmajor<false, INIT_KS>(h, ph, pm, pl, sm, lane);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    tile_to_pieces<true>(u[t], qh[2 * t], qm[2 * t], ql[2 * t], qh[2 * t + 1], qm[2 * t + 1], ql[2 * t + 1]);
+                    tile_to_pieces<false>(h[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
             }
+            bias += 128;
             NFA_STAMP()
-            f32x16 v[4];
+
+            // ---- residual blocks: h += W_1 relu(W_0 relu(h) + b_0) + b_1, both Linears k-major.
+            //      Register budget: the h pieces (96) must survive the first Linear for the skip
+            //      connection; u (64 accumulators) turns into the relu(u) pieces (96) tile by tile,
+            //      then the skip is added into the second Linear's accumulators tile by tile (the h
+            //      pieces die), whose input pieces die k-step by k-step.
+            for (int blk = 0; blk < a.num_blocks; ++blk) {
+                bf16x8 qh[8], qm[8], ql[8];
+                {
+                    f32x16 u[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                load_bias_tile(v[t], bias + 128 + t * 32);
-                add_pieces(v[t], 0, ph[2 * t], pm[2 * t], pl[2 * t]);
-                add_pieces(v[t], 8, ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
+                    for (int t = 0; t < 4; ++t) load_bias_tile(u[t], bias + t * 32);
+                    gemm_kmajor<true, 8>(u, ph, pm, pl, sm, lane);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        tile_to_pieces<true>(u[t], qh[2 * t], qm[2 * t], ql[2 * t], qh[2 * t + 1], qm[2 * t + 1], ql[2 * t + 1]);
+                }
+                NFA_STAMP()
+                f32x16 v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    load_bias_tile(v[t], bias + 128 + t * 32);
+                    add_pieces(v[t], 0, ph[2 * t], pm[2 * t], pl[2 * t]);
+                    add_pieces(v[t], 8, ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
+                }
+                gemm_kmajor<false, 8>(v, qh, qm, ql, sm, lane);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    tile_to_pieces<false>(v[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
+                bias += 256;
+                NFA_STAMP()
             }
-            gemm_kmajor<false, 8>(v, qh, qm, ql, sm, lane);
+
+            // ---- final layer, three 32-row tiles (= 4 features) at a time, and the splines; the
+            //      results replace the inputs in their slots
+            for (int g = 0; g < groups; ++g) {
+                float* slot0 = s_row + tab[kTabTr + g * 4 + half * 2] * kRowPad + r;
+                float* slot1 = s_row + tab[kTabTr + g * 4 + half * 2 + 1] * kRowPad + r;
+                const float xin0 = *slot0, xin1 = *slot1;
+                f32x16 acc[3];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                tile_to_pieces<false>(v[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
-            bias += 256;
-            NFA_STAMP()
+                for (int t = 0; t < 3; ++t) {
+                    load_bias_tile(acc[t], bias + (g * 3 + t) * 32);
+                    gemm_tile<false>(acc[t], ph, pm, pl, sm, lane);
+                }
+                NFA_STAMP()
+                {
+                    NFA_K7_FEATURE_A(pa, acc[0], acc[1]);
+                    NFA_K7_FEATURE_B(pb, acc[1], acc[2]);
+                    float y0, l0, y1, l1;
+                    my_status |= rqs_eval_flat8<INVERSE, PRESCALED>(xin0, pa, a.sp, y0, l0);
+                    my_status |= rqs_eval_flat8<INVERSE, PRESCALED>(xin1, pb, a.sp, y1, l1);
+                    *slot0 = y0;
+                    *slot1 = y1;
+                    lad_acc += l0;
+                    lad_acc += l1;
+                }
+                NFA_STAMP()
+            }
+            tb ^= 1;
+            // this wave's spline results must be visible to its own gathers of the next layer
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 
-        // ---- final layer, three 32-row tiles (= 4 features) at a time, and the splines
-        float lad_acc = 0.0f;
-        for (int g = 0; g < groups; ++g) {
-            float* slot0 = s_row + s_tab[kTabTrPos + g * 4 + half * 2] * kRowPad + r;
-            float* slot1 = s_row + s_tab[kTabTrPos + g * 4 + half * 2 + 1] * kRowPad + r;
-            const float xin0 = *slot0, xin1 = *slot1;
-            f32x16 acc[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                load_bias_tile(acc[t], bias + (g * 3 + t) * 32);
-                gemm_tile<false>(acc[t], ph, pm, pl, sm, lane);
-            }
-            NFA_STAMP()
-            {
-                NFA_K7_FEATURE_A(pa, acc[0], acc[1]);
-                NFA_K7_FEATURE_B(pb, acc[1], acc[2]);
-                float y0, l0, y1, l1;
-                my_status |= rqs_eval_flat8<INVERSE, PRESCALED>(xin0, pa, a.sp, y0, l0);
-                my_status |= rqs_eval_flat8<INVERSE, PRESCALED>(xin1, pb, a.sp, y1, l1);
-                *slot0 = y0;
-                *slot1 = y1;
-                lad_acc += l0;
-                lad_acc += l1;
-            }
-            NFA_STAMP()
-        }
-
-        // ---- the tile is the output: 32 whole rows, 16 bytes per lane per store
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- output rows: position p of a row comes from slot final[p]; 16 bytes per lane per store
         {
             vec4f* ov = reinterpret_cast<vec4f*>(a.out + row0 * D);
             const int nvec = D * 8;
             for (int e = lane; e < nvec; e += kWave) {
                 const int rr = (e * 4) / D, c0 = e * 4 - rr * D;
                 vec4f v;
-                v.x = s_row[(c0 + 0) * kRowPad + rr];
-                v.y = s_row[(c0 + 1) * kRowPad + rr];
-                v.z = s_row[(c0 + 2) * kRowPad + rr];
-                v.w = s_row[(c0 + 3) * kRowPad + rr];
+                v.x = s_row[s_final[c0 + 0] * kRowPad + rr];
+                v.y = s_row[s_final[c0 + 1] * kRowPad + rr];
+                v.z = s_row[s_final[c0 + 2] * kRowPad + rr];
+                v.w = s_row[s_final[c0 + 3] * kRowPad + rr];
                 ov[e] = v;
             }
         }
@@ -406,32 +435,30 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
 
 using namespace nfa;
 
-extern "C" int nfa_rqs_coupling_resnet_f32(const float* inputs, const void* weights_packed,
-                                           const float* bias_packed, const int32_t* layer_tables,
-                                           float* outputs, float* logabsdet, int32_t* status,
-                                           int64_t batch, int32_t features, int32_t num_transform,
-                                           int32_t num_identity, int32_t hidden_features,
-                                           int32_t num_blocks, const nfa_rqs_spec* spec, int32_t flags,
-                                           void* stream) {
+static int launch_resnet_layers(const float* inputs, const void* weights_packed, const float* bias_packed,
+                                const int32_t* tables, int32_t num_layers, float* outputs, float* logabsdet,
+                                int32_t* status, int64_t batch, int32_t features, int32_t num_transform,
+                                int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
+                                const nfa_rqs_spec* spec, int32_t flags, void* stream) {
     if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_LOGITS_LOG2E))
         return NFA_ERR_INVALID_ARGUMENT;
     if (batch < 0 || features < 1 || num_transform < 1 || num_identity < 1 ||
-        num_transform + num_identity > features || num_blocks < 0)
+        num_transform + num_identity > features || num_blocks < 0 || num_layers < 1)
         return NFA_ERR_INVALID_ARGUMENT;
     ResnetArgs a;
     int rc = make_dev_spec(spec, &a.sp);
     if (rc != NFA_OK) return rc;
     if (a.sp.K != 8 || !a.sp.linear || hidden_features != 128 || (num_transform & 3) != 0 ||
         num_transform > 64 || num_identity > 64 || features > 128 || (features & 3) != 0 ||
-        (batch & 127) != 0 || num_blocks > 64)
+        (batch & 127) != 0 || num_blocks > 64 || num_layers > 4096)
         return NFA_ERR_UNSUPPORTED;
     if (batch == 0) return NFA_OK;
-    if (!inputs || !weights_packed || !bias_packed || !layer_tables || !outputs || !logabsdet)
+    if (!inputs || !weights_packed || !bias_packed || !tables || !outputs || !logabsdet)
         return NFA_ERR_INVALID_ARGUMENT;
     a.x = inputs;
     a.w = reinterpret_cast<const vec4f*>(weights_packed);
     a.bias = bias_packed;
-    a.tables = layer_tables;
+    a.tables = tables;
     a.out = outputs;
     a.lad = logabsdet;
     a.status = status;
@@ -440,13 +467,15 @@ extern "C" int nfa_rqs_coupling_resnet_f32(const float* inputs, const void* weig
     a.dt = num_transform;
     a.di = num_identity;
     a.num_blocks = num_blocks;
+    a.num_layers = num_layers;
     const int init_ks = num_identity > 32 ? 4 : 2;
     a.num_stages = init_ks + 16 * num_blocks + 2 * (num_transform * 24 / 32);
+    a.bias_per_layer = 128 + 256 * num_blocks + num_transform * 24;
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = g_k7_trace;
     const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float);
     int64_t blocks = batch >> 7;
-    const int64_t per_cu = lds + 1024 <= 80 * 1024 ? 2 : 1;
+    const int64_t per_cu = lds + 2048 <= 80 * 1024 ? 2 : 1;
     const int64_t cap = (int64_t)device_cu_count() * per_cu;
     if (blocks > cap) blocks = cap;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -469,7 +498,7 @@ extern "C" int nfa_rqs_coupling_resnet_f32(const float* inputs, const void* weig
         static bool raised[8] = {false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
         const int which = (inv ? 1 : 0) + (l2e ? 2 : 0) + (init_ks == 4 ? 4 : 0);
         if (!raised[which]) {
-            NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
             raised[which] = true;
         }
     }
@@ -477,4 +506,28 @@ extern "C" int nfa_rqs_coupling_resnet_f32(const float* inputs, const void* weig
     else hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
+}
+
+extern "C" int nfa_rqs_coupling_resnet_f32(const float* inputs, const void* weights_packed,
+                                           const float* bias_packed, const int32_t* layer_tables,
+                                           float* outputs, float* logabsdet, int32_t* status,
+                                           int64_t batch, int32_t features, int32_t num_transform,
+                                           int32_t num_identity, int32_t hidden_features,
+                                           int32_t num_blocks, const nfa_rqs_spec* spec, int32_t flags,
+                                           void* stream) {
+    return launch_resnet_layers(inputs, weights_packed, bias_packed, layer_tables, 1, outputs, logabsdet, status,
+                                batch, features, num_transform, num_identity, hidden_features, num_blocks, spec,
+                                flags, stream);
+}
+
+extern "C" int nfa_rqs_flow_resnet_f32(const float* inputs, const void* weights_packed,
+                                       const float* bias_packed, const int32_t* flow_tables,
+                                       int32_t num_layers, float* outputs, float* logabsdet,
+                                       int32_t* status, int64_t batch, int32_t features,
+                                       int32_t num_transform, int32_t num_identity,
+                                       int32_t hidden_features, int32_t num_blocks,
+                                       const nfa_rqs_spec* spec, int32_t flags, void* stream) {
+    return launch_resnet_layers(inputs, weights_packed, bias_packed, flow_tables, num_layers, outputs, logabsdet,
+                                status, batch, features, num_transform, num_identity, hidden_features, num_blocks,
+                                spec, flags, stream);
 }

@@ -646,22 +646,44 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False)
 
 
 def coupling_layer_tables(features, transform_idx, identity_idx, in_perm=None, out_scatter=None):
-    """int32 [256] column bookkeeping for K8 (layout in include/nflows_amd.h), built on the device."""
-    dev = transform_idx.device
-    cols = torch.arange(features, device=dev)
-    src = cols if in_perm is None else in_perm.to(dev)
-    dst = cols if out_scatter is None else out_scatter.to(dev)
-    t = torch.zeros(256, dtype=torch.int64, device=dev)
-    t[:features] = torch.zeros(features, dtype=torch.int64, device=dev).index_copy_(0, src, dst)
-    t[128:128 + identity_idx.numel()] = dst[identity_idx]
-    t[192:192 + transform_idx.numel()] = dst[transform_idx]
-    return t.to(torch.int32)
+    """int32 [256] column bookkeeping of ONE layer for K8 (layout in include/nflows_amd.h), built on
+    the device: the row tile's slot j holds input column j; [0, 64) slots of the identity features,
+    [64, 128) slots of the transformed features (their results stay there), [128, 256) the slot that
+    ends up at every output position."""
+    return flow_layer_tables(features, [(transform_idx, identity_idx, in_perm, out_scatter)])
+
+
+def flow_layer_tables(features, layers):
+    """Tables of a run of coupling layers executed back to back on one row tile (K8 with
+    num_layers > 1).  `layers`: (transform_idx, identity_idx, in_perm, out_scatter) per layer in
+    execution order; layer column c reads logical column in_perm[c] of its input and leaves its
+    output at logical position out_scatter[c].  The tile never moves: `where[j]` tracks the slot
+    holding logical column j, every layer reads / overwrites the slots of its features, and the
+    last 128 entries say which slot ends up at which output position.  int32 [(L + 1) * 128]."""
+    dev = layers[0][0].device
+    where = torch.arange(features, device=dev)
+    rows = []
+    for tidx, iidx, perm, scat in layers:
+        slot_of_column = where if perm is None else where[perm.to(dev)]
+        row = torch.zeros(128, dtype=torch.int64, device=dev)
+        row[:iidx.numel()] = slot_of_column[iidx]
+        row[64:64 + tidx.numel()] = slot_of_column[tidx]
+        rows.append(row)
+        if scat is None:
+            where = slot_of_column
+        else:
+            where = torch.zeros_like(slot_of_column).index_copy_(0, scat.to(dev), slot_of_column)
+    final = torch.zeros(128, dtype=torch.int64, device=dev)
+    final[:features] = where
+    rows.append(final)
+    return torch.cat(rows).to(torch.int32)
 
 
 def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transform, num_identity, num_blocks,
-                        spec, inverse=False, accumulate_into=None, log2e=False):
-    """K8 -- ResidualNet conditioner + spline coupling layer in one kernel.  Returns None when the
-    shape is outside the fast path."""
+                        spec, inverse=False, accumulate_into=None, log2e=False, num_layers=1):
+    """K8 -- ResidualNet conditioner + spline coupling layer in one kernel; with num_layers > 1 a
+    whole run of such layers (weights / biases concatenated in execution order, tables from
+    `flow_layer_tables`).  Returns None when the shape is outside the fast path."""
     N.require_device_f32("inputs", inputs, 2)
     dev = inputs.device
     B, D = inputs.shape
@@ -671,9 +693,9 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
     if log2e:
         flags |= N.FLAG_LOGITS_LOG2E
     with torch.cuda.device(dev):
-        rc = N.load().nfa_rqs_coupling_resnet_f32(
-            N.ptr(x), N.ptr(weights_packed), N.ptr(bias_packed), N.ptr(tables), N.ptr(out), N.ptr(lad),
-            N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128, num_blocks,
+        rc = N.load().nfa_rqs_flow_resnet_f32(
+            N.ptr(x), N.ptr(weights_packed), N.ptr(bias_packed), N.ptr(tables), num_layers, N.ptr(out),
+            N.ptr(lad), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128, num_blocks,
             ctypes.byref(spec), flags, N.stream_handle(dev))
     if rc == N.ERR_UNSUPPORTED:
         return None

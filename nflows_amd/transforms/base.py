@@ -35,12 +35,120 @@ def _accepts_fused_permutation(t, inputs):
 
 
 class CompositeTransform(Transform):
-    """Applies transforms in the given order; log-determinants add up (base.py:45-52)."""
+    """Applies transforms in the given order; log-determinants add up (base.py:45-52).
+
+    Two levels of fusion on 2-D inputs (`fuse_permutations`): a column Permutation next to a
+    coupling layer is folded into that layer's kernel, and a run of consecutive
+    [Permutation, spline coupling] pairs whose conditioners the whole-layer kernel (K8) covers is
+    executed in ONE launch (`fuse_layer_runs`): rows are independent across the whole run, so the
+    kernel walks its rows through every layer without leaving LDS."""
+
+    fuse_layer_runs = True  # class-level switch for A/B measurements
 
     def __init__(self, transforms, fuse_permutations=True):
         super().__init__()
         self._transforms = nn.ModuleList(transforms)
         self.fuse_permutations = fuse_permutations
+
+    # ------------------------------------------------------------------ runs of K8 layers
+    @staticmethod
+    def _run_signature(coupling):
+        return (coupling.features, coupling.num_transform_features, coupling.num_identity_features,
+                len(coupling.transform_net.blocks), coupling.num_bins, coupling.tail_bound,
+                coupling.min_bin_width, coupling.min_bin_height, coupling.min_derivative,
+                getattr(coupling, "resnet_log2e", False))
+
+    def _collect_run(self, layers, start, inputs, context, inverse):
+        """Longest run of units starting at `start`: forward a unit is [column Permutation]? +
+        eligible coupling, inverse (layers already reversed) eligible coupling + [Permutation]?.
+        Returns (units, next_index) with units = [(coupling, permutation or None)]."""
+        units = []
+        if not (self.fuse_layer_runs and inputs.dim() == 2 and inputs.shape[0] >= 128
+                and inputs.shape[1] % 4 == 0):
+            return units, start
+
+        def eligible(t):
+            check = getattr(t, "_resnet_eligible", None)
+            return (check is not None and t.unconditional_transform is None and t.features == inputs.shape[1]
+                    and check(context))
+        i, signature = start, None
+        while i < len(layers):
+            perm = None
+            if not inverse:
+                if _is_column_permutation(layers[i]) and i + 1 < len(layers) and eligible(layers[i + 1]):
+                    perm, coupling, step = layers[i], layers[i + 1], 2
+                elif eligible(layers[i]):
+                    coupling, step = layers[i], 1
+                else:
+                    break
+            else:
+                if not eligible(layers[i]):
+                    break
+                coupling, step = layers[i], 1
+                if i + 1 < len(layers) and _is_column_permutation(layers[i + 1]):
+                    perm, step = layers[i + 1], 2
+            sig = self._run_signature(coupling)
+            if signature is not None and sig != signature:
+                break
+            signature = sig
+            units.append((coupling, perm))
+            i += step
+        if len(units) < 2:
+            return [], start
+        return units, i
+
+    def _run_plan(self, units, inverse):
+        """Concatenated K8 blobs and the composed tables of a run, cached until a weight or a
+        permutation changes."""
+        from .. import ops
+        packed = [c._packed_resnet() for c, _ in units]
+        key = (inverse, tuple(id(c) for c, _ in units),
+               tuple(c._packed_resnet_cache[0] for c, _ in units),
+               tuple(None if p is None else (p._permutation.data_ptr(), p._permutation._version) for _, p in units))
+        cache = self.__dict__.setdefault("_run_plans", {})
+        plan = cache.get(key)
+        if plan is None:
+            if len(cache) > 4:
+                cache.clear()
+            weights = torch.cat([w for w, _ in packed], dim=0).contiguous()
+            biases = torch.cat([b for _, b in packed]).contiguous()
+            spec_layers = []
+            for c, p in units:
+                perm = None if p is None else p._permutation
+                spec_layers.append((c.transform_features, c.identity_features,
+                                    None if inverse else perm, perm if inverse else None))
+            tables = ops.flow_layer_tables(units[0][0].features, spec_layers)
+            plan = (weights, biases, tables)
+            cache[key] = plan
+        return plan
+
+    def _run_fused(self, units, inputs, total, context, inverse):
+        from .. import ops
+        first = units[0][0]
+        for _, p in units:
+            if p is not None:
+                p._check(inputs)
+        batch = inputs.shape[0]
+        full = (batch // 128) * 128
+        weights, biases, tables = self._run_plan(units, inverse)
+        head = ops.rqs_coupling_resnet(
+            inputs[:full], weights, biases, tables, first.num_transform_features, first.num_identity_features,
+            len(first.transform_net.blocks), first._spec(), inverse, total[:full],
+            log2e=getattr(first, "resnet_log2e", False), num_layers=len(units))
+        if head is None:
+            return None
+        if full == batch:
+            return head[0]
+        # ragged batch: the last rows layer by layer (PyTorch conditioner + K1)
+        tail, tail_total = inputs[full:], total[full:]
+        for coupling, perm in units:
+            if inverse:
+                tail, _ = coupling.inverse(tail, context, out_scatter=None if perm is None else perm._permutation,
+                                           logabsdet_accumulator=tail_total)
+            else:
+                tail, _ = coupling.forward(tail, context, in_perm=None if perm is None else perm._permutation,
+                                           logabsdet_accumulator=tail_total)
+        return torch.cat((head[0], tail), dim=0)
 
     @staticmethod
     def _cascade(inputs, funcs, context):
@@ -59,6 +167,12 @@ class CompositeTransform(Transform):
         total = inputs.new_zeros(inputs.shape[0])
         i = 0
         while i < len(layers):
+            units, after = self._collect_run(layers, i, outputs, context, inverse=False)
+            if units:
+                fused = self._run_fused(units, outputs, total, context, inverse=False)
+                if fused is not None:
+                    outputs, i = fused, after
+                    continue
             t = layers[i]
             nxt = layers[i + 1] if i + 1 < len(layers) else None
             if nxt is not None and _is_column_permutation(t) and _accepts_fused_permutation(nxt, outputs):
@@ -84,6 +198,12 @@ class CompositeTransform(Transform):
         total = inputs.new_zeros(inputs.shape[0])
         i = 0
         while i < len(layers):
+            units, after = self._collect_run(layers, i, outputs, context, inverse=True)
+            if units:
+                fused = self._run_fused(units, outputs, total, context, inverse=True)
+                if fused is not None:
+                    outputs, i = fused, after
+                    continue
             t = layers[i]
             nxt = layers[i + 1] if i + 1 < len(layers) else None
             if nxt is not None and _is_column_permutation(nxt) and _accepts_fused_permutation(t, outputs):

@@ -441,7 +441,7 @@ def test_whole_layer_kernel_abi_contract(restore_fused_path):
     assert call(None) == N.ERR_INVALID_ARGUMENT
     assert call(tables, batch=0) == N.OK
     bad = tables.clone()
-    bad[192 + 5] = 64  # transformed feature 5 stored at a position outside the row
+    bad[64 + 5] = 64  # transformed feature 5 read from a slot outside the row
     assert call(bad) == N.OK
     torch.cuda.synchronize()
     assert st.item() & N.STATUS_BAD_INDEX

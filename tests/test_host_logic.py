@@ -330,15 +330,28 @@ def test_layer_tables_follow_the_fused_permutations():
     tidx, iidx = torch.arange(0, D, 2), torch.arange(1, D, 2)
     t = ops.coupling_layer_tables(D, tidx, iidx, perm, scat)
     assert t.dtype == torch.int32 and t.shape == (256,)
-    x = torch.randn(3, D)
+    x = torch.randn(3, D)                         # tile slot j = input column j
     layer_in = x[:, perm]                         # what Permutation.forward hands to the layer
-    layer_out = layer_in.clone()                  # pass-through
+    assert torch.equal(x[:, t[:iidx.numel()].long()], layer_in[:, iidx])
+    assert torch.equal(x[:, t[64:64 + tidx.numel()].long()], layer_in[:, tidx])
     final = torch.empty_like(x)
-    final[:, scat] = layer_out                    # Permutation.inverse after the layer
-    tile = torch.empty_like(x)
-    tile[:, t[:D].long()] = x                     # the kernel's scatter of an input row
-    assert torch.equal(tile, final)
-    assert torch.equal(tile[:, t[128:128 + iidx.numel()].long()], layer_in[:, iidx])
-    assert torch.equal(tile[:, t[192:192 + tidx.numel()].long()], layer_in[:, tidx])
+    final[:, scat] = layer_in                     # Permutation.inverse after a pass-through layer
+    assert torch.equal(x[:, t[128:128 + D].long()], final)
     ident = ops.coupling_layer_tables(D, tidx, iidx)
-    assert torch.equal(ident[:D].long(), torch.arange(D))
+    assert torch.equal(ident[128:128 + D].long(), torch.arange(D))
+    # a run of three layers: emulate the data movement with plain tensors
+    layers, ref = [], x.clone()
+    tile = x.clone()
+    perms = [torch.randperm(D, generator=g) for _ in range(3)]
+    for i, p_ in enumerate(perms):
+        ti, ii = (tidx, iidx) if i % 2 == 0 else (iidx, tidx)
+        layers.append((ti, ii, p_, None))
+    tabs = ops.flow_layer_tables(D, layers).view(4, 128).long()
+    for i, (ti, ii, p_, _) in enumerate(layers):
+        ref = ref[:, p_]
+        assert torch.equal(tile[:, tabs[i, :ii.numel()]], ref[:, ii])
+        assert torch.equal(tile[:, tabs[i, 64:64 + ti.numel()]], ref[:, ti])
+        ref = ref.clone()
+        ref[:, ti] = ref[:, ti] * 2 + 1            # stand-in for the spline
+        tile[:, tabs[i, 64:64 + ti.numel()]] = tile[:, tabs[i, 64:64 + ti.numel()]] * 2 + 1
+    assert torch.equal(tile[:, tabs[3, :D]], ref)
