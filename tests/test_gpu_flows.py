@@ -447,12 +447,14 @@ def test_whole_layer_kernel_abi_contract(restore_fused_path):
     assert st.item() & N.STATUS_BAD_INDEX
 
 
-def test_whole_layer_kernel_persistent_loop(restore_fused_path):
+@pytest.mark.parametrize("layers", [1, 3])
+def test_whole_layer_kernel_persistent_loop(layers, restore_fused_path):
     """More 128-row blocks than resident workgroups (2 per CU): every workgroup walks several
-    blocks, re-starting the weight stream from stage 0 each time.  Compared with the PyTorch
-    conditioner + K1 path on the first, middle and last rows; forward and inverse."""
+    blocks, re-starting the weight stream (and, for a run of layers, the layer tables) from the
+    first layer each time.  Compared with the PyTorch conditioner + K1 path on the first, middle
+    and last rows; forward and inverse."""
     from nflows_amd import configs
-    flow = configs.rq_nsf_flow(num_layers=1, features=64, num_bins=8, hidden_features=128, seed=2).to(DEV).eval()
+    flow = configs.rq_nsf_flow(num_layers=layers, features=64, num_bins=8, hidden_features=128, seed=2).to(DEV).eval()
     with torch.no_grad():
         for n_, p in flow.named_parameters():
             if "final_layer" in n_:
@@ -472,15 +474,16 @@ def test_whole_layer_kernel_persistent_loop(restore_fused_path):
         x0, li0 = flow._transform.inverse(x[rows])
     import nflows_amd
     nflows_amd.check_status()
+    scale = layers * layers  # (sharpened layers amplify the GEMMs' different summation orders)
     for got, want, tol in ((z1[rows], z0, 2e-5), (l1[rows], l0, 5e-4), (x1[rows], x0, 2e-5), (li1[rows], li0, 5e-4)):
         d = (got - want).abs()
-        assert d.max().item() < tol, d.max().item()
+        assert d.max().item() < tol * scale and d.median().item() < tol, (d.max().item(), d.median().item())
     assert torch.isfinite(z1).all() and torch.isfinite(l1).all()
     # every row was written: round trip over the whole batch
     with torch.no_grad():
         _select_fused_path("k8")
         back, _ = flow._transform.inverse(z1)
-    assert (back - x).abs().max().item() < 1e-4
+    assert (back - x).abs().max().item() < 1e-4 * layers
 
 
 def test_sibling_couplings_against_reference_vectors(golden_dir):
