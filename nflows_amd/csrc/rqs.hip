@@ -694,8 +694,8 @@ extern "C" int nfa_profile_collect(float* durations_ms, int32_t capacity, int32_
         float ms = 0.0f;
         NFA_HIP_CHECK(hipEventElapsedTime(&ms, g_profile.start[i], g_profile.stop[i]));
         if (n < capacity) durations_ms[n++] = ms;
-        hipEventDestroy(g_profile.start[i]);
-        hipEventDestroy(g_profile.stop[i]);
+        (void)hipEventDestroy(g_profile.start[i]);
+        (void)hipEventDestroy(g_profile.stop[i]);
     }
     g_profile.start.clear();
     g_profile.stop.clear();
