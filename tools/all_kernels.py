@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""One table of every kernel of the library at a representative size on one MI355X: launch time
+(median of 30, HIP events) and the rate of ALGORITHMIC bytes (or flops) against the chip's peak.
+Writes markdown to stdout:  python tools/all_kernels.py > profiles/r1_kernel_table.md"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nflows_amd
+from nflows_amd import ops, configs
+from nflows_amd.transforms import splines
+from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+
+dev = "cuda:0"
+g = torch.Generator(device=dev).manual_seed(0)
+rows = []
+
+
+def timeit(fn, reps=30, inner=10):
+    """Per-call GPU time: `inner` calls captured into one HIP graph (the host is out of the loop, so
+    kernels of a few microseconds are not hidden behind Python's launch overhead), median of `reps`
+    replays divided by `inner`."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(inner):
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); graph.replay(); e.record(); evs.append((s, e))
+    torch.cuda.synchronize()
+    return sorted(a.elapsed_time(b) for a, b in evs)[reps // 2] * 1e3 / inner  # us
+
+
+def timeit_eager(fn, reps=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record(); evs.append((s, e))
+    torch.cuda.synchronize()
+    return sorted(a.elapsed_time(b) for a, b in evs)[reps // 2] * 1e3
+
+
+def add(kernel, what, us, nbytes=None, flops=None, peak_note=""):
+    if nbytes is not None:
+        rate = "%.0f GB/s (%.0f %% of 8 TB/s)" % (nbytes / us / 1e3, nbytes / us / 1e3 / 80.0)
+    else:
+        rate = "%.0f TFLOP/s %s" % (flops / us / 1e6, peak_note)
+    rows.append("| %s | %s | %.1f | %s |" % (kernel, what, us, rate))
+
+
+with torch.no_grad():
+    B, D, K, H = 65536, 64, 8, 128
+    x = torch.randn(B, D, device=dev, generator=g)
+    tidx = torch.arange(0, D, 2, device=dev)
+    P = 3 * K - 1
+    params = torch.randn(B, 32 * P, device=dev, generator=g)
+    spec = ops.make_rqs_spec(K, "linear", tail_bound=3.0, wh_divisor=float(np.sqrt(H)))
+    k1_bytes = 4 * (2 * B * D + B * 32 * P + B)
+    add("K1 `rqs_coupling_pipelined`", "RQ coupling layer, B=65536 D=64 K=8", timeit(lambda: ops.rqs_coupling(x, params, tidx, spec)), k1_bytes)
+    add("K1 inverse", "same", timeit(lambda: ops.rqs_coupling(x, params, tidx, spec, inverse=True)), k1_bytes)
+    gx = torch.randn(B, D, device=dev, generator=g); gl = torch.randn(B, device=dev, generator=g)
+    xr = x.clone().requires_grad_(True); pr = params.clone().requires_grad_(True)
+    with torch.enable_grad():
+        y, lad = ops.rqs_coupling(xr, pr, tidx, spec)
+    def bwd():
+        torch.autograd.grad((y, lad), (xr, pr), (gx, gl), retain_graph=True)
+    add("K1-backward `rqs_coupling_backward_kernel`", "same layer, grads wrt inputs and params", timeit_eager(bwd), 2 * k1_bytes)
+
+    N = B * 32
+    xe = torch.randn(N, device=dev, generator=g) * 1.5
+    r = torch.randn(N, P, device=dev, generator=g)
+    add("K5 `rqs_elementwise_kernel`", "RQ functional, 2.1 M elements, K=8", timeit(lambda: splines.unconstrained_rational_quadratic_spline(xe, r[:, :K], r[:, K:2 * K], r[:, 2 * K:], tail_bound=3.0)), 4 * N * (P + 3))
+    p = torch.randn(N, K, device=dev, generator=g)
+    add("K9 linear", "linear spline functional, 2.1 M elements, K=8", timeit(lambda: splines.unconstrained_linear_spline(xe, p, tail_bound=3.0)), 4 * N * (K + 3))
+    q = torch.randn(N, 2 * K - 1, device=dev, generator=g)
+    add("K9 quadratic", "quadratic spline functional, same", timeit(lambda: splines.unconstrained_quadratic_spline(xe, q[:, :K], q[:, K:], tail_bound=3.0)), 4 * N * (2 * K - 1 + 3))
+    c = torch.randn(N, 2 * K + 2, device=dev, generator=g)
+    add("K9 cubic", "cubic spline functional, same", timeit(lambda: splines.unconstrained_cubic_spline(xe, c[:, :K], c[:, K:2 * K], c[:, 2 * K:2 * K + 1], c[:, 2 * K + 1:], tail_bound=3.0)), 4 * N * (2 * K + 2 + 3))
+    add("K9 cubic inverse", "same", timeit(lambda: splines.unconstrained_cubic_spline(xe, c[:, :K], c[:, K:2 * K], c[:, 2 * K:2 * K + 1], c[:, 2 * K + 1:], inverse=True, tail_bound=3.0)), 4 * N * (2 * K + 2 + 3))
+
+    uw = torch.rand(32, K, device=dev, generator=g); ud = torch.rand(32, K - 1, device=dev, generator=g)
+    xs = torch.randn(B, 32, device=dev, generator=g)
+    add("K6 `rqs_shared_kernel`", "batch-shared RQ CDF, B=65536 F=32", timeit(lambda: ops.rqs_shared(xs, uw, uw, ud, ops.make_rqs_spec(K, "linear", tail_bound=3.0), False)), 4 * (2 * B * 32 + B))
+
+    B2, D2 = 16384, 32
+    x2 = torch.randn(B2, D2, device=dev, generator=g); p2 = torch.randn(B2, 32, device=dev, generator=g)
+    t2 = torch.arange(0, D2, 2, device=dev)
+    add("K2 `affine_coupling_kernel`", "affine coupling layer, B=16384 D=32", timeit(lambda: ops.affine_coupling(x2, p2, t2, nflows_amd._native.SCALE_DEFAULT)), 4 * (2 * B2 * D2 + B2 * 32 + B2))
+    perm = torch.randperm(D, device=dev, generator=g)
+    add("K4 `permute_cols_kernel`", "column permutation, B=65536 D=64", timeit(lambda: ops.permute_cols(x, perm)), 8 * B * D)
+    add("K3 `rowsum_kernel`", "row sum, B=65536 D=64", timeit(lambda: ops.rowsum(x)), 4 * (B * D + B))
+    add("K3 normal log-prob", "base density + logabsdet, B=65536 D=64", timeit(lambda: ops.standard_normal_log_prob(x, gl)), 4 * (B * D + 2 * B))
+
+    # fused conditioner kernels on one layer and on the 32-layer run
+    flow = configs.rq_nsf_flow(num_layers=32, features=D, num_bins=K, hidden_features=H, seed=0).to(dev).eval()
+    layer = flow._transform._transforms[1]
+    macs_final, macs_all = 32 * P * H, 32 * H + 4 * H * H + 32 * P * H
+    for path, name in (("k7", "K7 `rqs_fused_linear_kernel` (fp32 MFMA)"), ("k7b", "K7b `rqs_fused_linear_bf16_kernel`")):
+        RQ.fuse_conditioner, RQ.fuse_final_linear, RQ.final_linear_engine = False, True, ("f32" if path == "k7" else "bf16x3")
+        hid = layer.transform_net.hidden(x.index_select(1, layer.identity_features))
+        wp, bp = layer._packed_final_linear(layer.transform_net.final_layer)
+        us = timeit(lambda: ops.rqs_coupling_fused_linear(x, hid, wp, bp, layer.transform_features, layer._spec()))
+        if path == "k7":
+            add(name, "final Linear + spline layer, B=65536", us, flops=2.0 * B * macs_final, peak_note="(fp32 matrix peak 157)")
+        else:
+            add(name, "same, split-bf16", us, flops=12.0 * B * macs_final, peak_note="bf16 (peak 2 500); fp32-equivalent %.0f" % (2.0 * B * macs_final / us / 1e6))
+    RQ.fuse_conditioner, RQ.fuse_final_linear, RQ.final_linear_engine = True, True, "bf16x3"
+    us = timeit(lambda: layer(x))
+    add("K8 `rqs_resnet_kernel`, 1 layer", "ResidualNet conditioner + spline layer, B=65536", us, flops=12.0 * B * macs_all, peak_note="bf16 (peak 2 500); fp32-equivalent %.0f" % (2.0 * B * macs_all / us / 1e6))
+    us = timeit(lambda: flow._transform(x), reps=10, inner=2)
+    add("K8, run of 32 layers", "the whole BASELINE transform in one launch, B=65536", us, flops=32 * 12.0 * B * macs_all, peak_note="bf16 (peak 2 500); fp32-equivalent %.0f" % (32 * 2.0 * B * macs_all / us / 1e6))
+    nflows_amd.check_status()
+
+print("# Kernel table (round 1, 1 x MI355X; `python tools/all_kernels.py`)\n")
+print("GPU time per call: 10 calls captured in one HIP graph, median of 30 replays / 10 (the backward through")
+print("autograd is timed eagerly); rates are ALGORITHMIC bytes or flops per launch over that time.  The helper")
+print("kernels next to a call (output allocation is free, a status-word memset is not) are included.\n")
+print("| kernel | workload | µs | rate |")
+print("|---|---|---|---|")
+print("\n".join(rows))
