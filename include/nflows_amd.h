@@ -25,6 +25,7 @@
 #ifndef NFLOWS_AMD_H
 #define NFLOWS_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -345,6 +346,22 @@ int nfa_rowsum_f32(const float *x, float *out, int64_t rows, int64_t cols, void 
  */
 int nfa_standard_normal_log_prob_f32(const float *z, const float *logabsdet, float *out,
                                      int64_t rows, int64_t cols, void *stream);
+
+/*
+ * K10.  Weight and bias gradient of a conditioner layer y = x W^T + b (torch.nn.Linear; the
+ * reference's conditioners nn/nets/resnet.py:44,49,94,99 and nn/nets/mlp.py:47-68 reach it through
+ * autograd when a flow is trained, examples/moons.ipynb cell 3):
+ *   grad_weight[O, I] = grad_outputs[B, O]^T . inputs[B, I]      grad_bias[O] = sum_b grad_outputs[b, :]
+ * The reduction runs over the batch: the batch is split over the chip (fp32 matrix cores, LDS-DMA
+ * ring), partial results go to `workspace` (nfa_linear_wgrad_workspace_bytes(...) bytes of device
+ * memory, contents undefined before and after) and are summed in a fixed order: results are
+ * deterministic.  grad_bias may be NULL.  in_features and out_features must be multiples of 4 and
+ * inputs / grad_outputs 16-byte aligned, otherwise NFA_ERR_UNSUPPORTED.  flags must be 0.
+ */
+size_t nfa_linear_wgrad_workspace_bytes(int64_t batch, int32_t in_features, int32_t out_features);
+int nfa_linear_wgrad_f32(const float *inputs, const float *grad_outputs, float *grad_weight,
+                         float *grad_bias, void *workspace, int64_t batch, int32_t in_features,
+                         int32_t out_features, int32_t flags, void *stream);
 
 /*
  * Measurement aids (bench.py, tools/), not part of the data path; the library's only global state.

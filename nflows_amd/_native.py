@@ -51,6 +51,8 @@ EXPORTS = (
     "nfa_permute_cols_b32",
     "nfa_rowsum_f32",
     "nfa_standard_normal_log_prob_f32",
+    "nfa_linear_wgrad_workspace_bytes",
+    "nfa_linear_wgrad_f32",
     "nfa_profile_enable",
     "nfa_profile_collect",
     "nfa_debug_k7_trace",
@@ -127,6 +129,10 @@ def _declare(lib):
     lib.nfa_rowsum_f32.argtypes = [vp, vp, i64, i64, vp]
     lib.nfa_standard_normal_log_prob_f32.restype = ctypes.c_int
     lib.nfa_standard_normal_log_prob_f32.argtypes = [vp, vp, vp, i64, i64, vp]
+    lib.nfa_linear_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    lib.nfa_linear_wgrad_workspace_bytes.argtypes = [i64, i32, i32]
+    lib.nfa_linear_wgrad_f32.restype = ctypes.c_int
+    lib.nfa_linear_wgrad_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
     lib.nfa_profile_enable.restype = ctypes.c_int
     lib.nfa_profile_enable.argtypes = [i32]
     lib.nfa_profile_collect.restype = ctypes.c_int

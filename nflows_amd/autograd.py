@@ -219,3 +219,35 @@ class StandardNormalLogProb(torch.autograd.Function):
         (z,) = ctx.saved_tensors
         g_z = -z * g.reshape((-1,) + (1,) * (z.dim() - 1))
         return g_z, (g if ctx.has_lad else None)
+
+
+class Linear(torch.autograd.Function):
+    """y = x W^T + b (the conditioner layers).  Forward and the input gradient are library GEMMs;
+    the weight and bias gradients -- a product whose reduction runs over the whole batch into a tiny
+    result, which the library tiles into a handful of workgroups -- come from K10
+    (`nfa_linear_wgrad_f32`: batch split over the chip, fp32 matrix cores, fixed-order sum)."""
+
+    @staticmethod
+    def forward(ctx, inputs, weight, bias):
+        ctx.save_for_backward(inputs, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(inputs, weight, bias)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out):
+        from . import ops
+        inputs, weight = ctx.saved_tensors
+        g_out = g_out.contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        g_in = g_out @ weight if need_x else None
+        g_w = g_b = None
+        if need_w or need_b:
+            got = ops.linear_wgrad(inputs, g_out, need_bias=need_b)
+            if got is None:  # widths the kernel does not take
+                g_w = g_out.t() @ inputs if need_w else None
+                g_b = g_out.sum(0) if need_b else None
+            else:
+                g_w, g_b = got
+        return g_in, (g_w if need_w else None), g_b

@@ -1,0 +1,274 @@
+// K10: weight and bias gradient of a conditioner layer  y = x W^T + b  (torch.nn.Linear):
+//     grad_weight[O, I] = grad_outputs[B, O]^T . inputs[B, I]        grad_bias[O] = sum_b grad_outputs[b, :]
+// The reference trains through autograd (examples/moons.ipynb cell 3); its conditioner layers are
+// nn/nets/resnet.py:44,49,94,99 and nn/nets/mlp.py:47-68.  For these layers the reduction runs
+// over the BATCH (65 536 rows) while the result is tiny (128 x 128): the library GEMM behind
+// autograd tiles the result only (16 workgroups on a 256-CU chip, 223 us per layer measured,
+// 56 % of the whole training step, profiles/r1_train_kernel_stats.csv).  Here the batch is split:
+//
+//   wgrad_partial_kernel   grid (result blocks, batch slices): a workgroup streams its rows of
+//                          grad_outputs and inputs through a 3-slot LDS ring with LDS-DMA
+//                          (global_load_lds, 16 bytes per lane, no VGPR round trip) and feeds them
+//                          to v_mfma_f32_32x32x2_f32 -- rows of the two arrays ARE the k-index of
+//                          this product, so both MFMA operands are plain row reads: lanes 0-31 take
+//                          32 consecutive columns of row 2s, lanes 32-63 of row 2s+1.  True fp32
+//                          products and sums.  Each wave owns TO x TI tiles of 32 x 32; the wave on
+//                          the first input tile also sums the grad_outputs values it loads: the
+//                          bias gradient.  Partials go to a workspace [slices][O*I + O].
+//   wgrad_reduce_kernel    sums the slices in a fixed order (deterministic, no atomics) and adds
+//                          the rows behind the last full 32-row stage.
+//
+// Bound: fp32 MFMA issue (64 cycles per 32x32x2) or HBM (each input element is read once per
+// result block column/row it belongs to); for 128 x 128 at B = 65 536 both are ~14 us.
+
+#include "fused_common.hpp"
+
+#include <stdlib.h>
+
+namespace nfa {
+
+constexpr int kWgRows = 32;  // batch rows per stage
+constexpr int kWgRing = 3;
+
+struct WgradArgs {
+    const float* x;   // [B, I]
+    const float* gy;  // [B, O]
+    float* ws;        // [ksplit][O*I + O]
+    int I, O;
+    int stages_total;  // full 32-row stages of the batch
+    int ksplit;
+    int blocks_i;
+};
+
+template <int TO, int TI, int WO, int WI>
+__global__ void __launch_bounds__(kBlock) wgrad_partial_kernel(const WgradArgs a) {
+    static_assert(WO * WI == 4, "four waves per workgroup");
+    constexpr int BO = 32 * TO * WO, BI = 32 * TI * WI;
+    constexpr int VA = BO / 4, VB = BI / 4;  // float4 per staged row
+    constexpr int NA = (kWgRows * VA) / kBlock, NB = (kWgRows * VB + kBlock - 1) / kBlock;
+    static_assert(NA * kBlock == kWgRows * VA && kWgRows * VB >= kBlock, "whole requests only");
+    constexpr int NREQ = NA + NB;
+    constexpr int kStage = kWgRows * (VA + VB);  // float4 per ring slot
+    extern __shared__ __attribute__((aligned(16))) vec4f wg_ring[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ln = lane & 31, lh = lane >> 5;
+    const int wo = wave / WI, wi = wave % WI;
+    const int bo = blockIdx.x / a.blocks_i, bi = blockIdx.x - bo * a.blocks_i;
+    const int ob = bo * BO, ib = bi * BI;
+    const int kz = blockIdx.y;
+    const int s_begin = (int)(((int64_t)a.stages_total * kz) / a.ksplit);
+    const int s_end = (int)(((int64_t)a.stages_total * (kz + 1)) / a.ksplit);
+    const int O = a.O, I = a.I;
+
+    // this thread's share of a stage: NA float4 of grad_outputs, NB of inputs.  Columns past the
+    // arrays' width are clamped onto valid ones: they only reach result elements that are never stored.
+    int col_a = ob + (tid % VA) * 4, col_b = ib + (tid % VB) * 4;
+    if (col_a > O - 4) col_a = O - 4;
+    if (col_b > I - 4) col_b = I - 4;
+    const float* src_a = a.gy + (int64_t)(tid / VA) * O + col_a;
+    const float* src_b = a.x + (int64_t)(tid / VB) * I + col_b;
+    constexpr int rows_per_req_a = kBlock / VA, rows_per_req_b = kBlock / VB;
+
+    auto request = [&](int stage, int slot) {
+        const float* ga = src_a + (int64_t)stage * kWgRows * O;
+        const float* gb = src_b + (int64_t)stage * kWgRows * I;
+        vec4f* dst = wg_ring + slot * kStage + tid;
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + (int64_t)q * rows_per_req_a * O),
+                                             (__attribute__((address_space(3))) void*)(dst + q * kBlock), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (int64_t)q * rows_per_req_b * I),
+                                             (__attribute__((address_space(3))) void*)(dst + kWgRows * VA + q * kBlock), 16, 0, 0);
+    };
+    // the next stage's requests of this wave have landed (those of the stage after it may still be
+    // in flight) and every wave is done with the slot that is overwritten next
+    auto advance = [&]() {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(NREQ) : "memory");
+    };
+
+    f32x16 acc[TO][TI];
+#pragma unroll
+    for (int to = 0; to < TO; ++to)
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[to][ti][j] = 0.0f;
+    float colsum[TO];
+#pragma unroll
+    for (int to = 0; to < TO; ++to) colsum[to] = 0.0f;
+
+    const int last = s_end - 1;
+    request(s_begin, 0);
+    request(s_begin + 1 <= last ? s_begin + 1 : last, 1);
+    advance();
+    int slot = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int ahead = s + 2 <= last ? s + 2 : last;  // (past the end: a harmless re-read into the free slot)
+        request(ahead, slot >= 1 ? slot - 1 : kWgRing - 1);
+        const float* sa = reinterpret_cast<const float*>(wg_ring + slot * kStage) + lh * BO + wo * 32 * TO + ln;
+        const float* sb = reinterpret_cast<const float*>(wg_ring + slot * kStage + kWgRows * VA) + lh * BI + wi * 32 * TI + ln;
+        // operands are read two k-steps ahead of the MFMAs that consume them (an LDS read issued
+        // behind the four MFMAs of a k-step would otherwise land after the matrix pipe has drained)
+        constexpr int NK = kWgRows / 2;
+        float av[NK][TO], bv[NK][TI];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+            for (int to = 0; to < TO; ++to) av[k2][to] = sa[k2 * 2 * BO + to * 32];
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) bv[k2][ti] = sb[k2 * 2 * BI + ti * 32];
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < NK; ++k2) {
+            if (k2 + 2 < NK) {
+#pragma unroll
+                for (int to = 0; to < TO; ++to) av[k2 + 2][to] = sa[(k2 + 2) * 2 * BO + to * 32];
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) bv[k2 + 2][ti] = sb[(k2 + 2) * 2 * BI + ti * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the reads to their first use)
+#pragma unroll
+            for (int to = 0; to < TO; ++to) {
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti)
+                    acc[to][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k2][to], bv[k2][ti], acc[to][ti], 0, 0, 0);
+                if (wi == 0) colsum[to] += av[k2][to];
+            }
+        }
+        advance();
+        slot = slot + 1 == kWgRing ? 0 : slot + 1;
+    }
+
+    float* out = a.ws + (int64_t)kz * ((int64_t)O * I + O);
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+        const int o0 = ob + wo * 32 * TO + to * 32;
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+            const int i = ib + wi * 32 * TI + ti * 32 + ln;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int o = o0 + 8 * (j >> 2) + 4 * lh + (j & 3);
+                if (o < O && i < I) out[(int64_t)o * I + i] = acc[to][ti][j];
+            }
+        }
+        if (wi == 0 && bi == 0) {  // (wave-uniform)
+            const float v = colsum[to] + __shfl_xor(colsum[to], 32, kWave);
+            if (lh == 0 && o0 + ln < O) out[(int64_t)O * I + o0 + ln] = v;
+        }
+    }
+}
+
+// grad_weight / grad_bias = sum over slices (fixed order) + the rows behind the last full stage
+__global__ void __launch_bounds__(kBlock) wgrad_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ x,
+                                                              const float* __restrict__ gy, float* __restrict__ gw,
+                                                              float* __restrict__ gb, int I, int O, int ksplit,
+                                                              int64_t tail_begin, int64_t batch) {
+    __shared__ float part[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, p = tid >> 6;
+    const int64_t n_w = (int64_t)O * I, stride = n_w + O;
+    const int64_t n = gb ? stride : n_w;
+    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t ec = e < n ? e : n - 1;
+    // slice quarter p: ksplit*p/4 .. ksplit*(p+1)/4
+    const int k0 = (int)(((int64_t)ksplit * p) / 4), k1 = (int)(((int64_t)ksplit * (p + 1)) / 4);
+    float v = 0.0f;
+    const float* src = ws + ec;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)(k + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; k < k1; ++k) v += src[(int64_t)k * stride];
+    part[p][lane] = v;
+    __syncthreads();
+    if (p != 0 || e >= n) return;
+    v = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    if (e < n_w) {
+        const int o = (int)(e / I), i = (int)(e - (int64_t)o * I);
+        for (int64_t r = tail_begin; r < batch; ++r) v += gy[r * O + o] * x[r * I + i];
+        gw[e] = v;
+    } else {
+        const int o = (int)(e - n_w);
+        for (int64_t r = tail_begin; r < batch; ++r) v += gy[r * O + o];
+        gb[o] = v;
+    }
+}
+
+struct WgradPlan {
+    int variant;  // 0: 128 x 128 result blocks, 1: 128 x 32
+    int blocks_o, blocks_i, stages_total, ksplit;
+};
+
+static WgradPlan plan_wgrad(int64_t batch, int I, int O) {
+    WgradPlan p;
+    p.variant = I <= 32 ? 1 : 0;
+    const int BO = 128, BI = p.variant ? 32 : 128;
+    p.blocks_o = (O + BO - 1) / BO;
+    p.blocks_i = (I + BI - 1) / BI;
+    p.stages_total = (int)(batch / kWgRows);
+    int ks = device_cu_count() / (p.blocks_o * p.blocks_i);
+    if (ks < 1) ks = 1;
+    if (ks > p.stages_total) ks = p.stages_total;
+    p.ksplit = ks;
+    return p;
+}
+
+}  // namespace nfa
+
+using namespace nfa;
+
+extern "C" size_t nfa_linear_wgrad_workspace_bytes(int64_t batch, int32_t in_features, int32_t out_features) {
+    if (batch < 0 || in_features < 1 || out_features < 1) return 0;
+    const WgradPlan p = plan_wgrad(batch, in_features, out_features);
+    return (size_t)(p.ksplit > 0 ? p.ksplit : 1) * ((size_t)out_features * in_features + out_features) * sizeof(float);
+}
+
+extern "C" int nfa_linear_wgrad_f32(const float* inputs, const float* grad_outputs, float* grad_weight,
+                                    float* grad_bias, void* workspace, int64_t batch, int32_t in_features,
+                                    int32_t out_features, int32_t flags, void* stream) {
+    if (flags != 0 || batch < 0 || in_features < 1 || out_features < 1) return NFA_ERR_INVALID_ARGUMENT;
+    if (!grad_weight || (batch > 0 && (!inputs || !grad_outputs))) return NFA_ERR_INVALID_ARGUMENT;
+    const int I = in_features, O = out_features;
+    if ((I & 3) || (O & 3) || (reinterpret_cast<uintptr_t>(inputs) & 15) || (reinterpret_cast<uintptr_t>(grad_outputs) & 15))
+        return NFA_ERR_UNSUPPORTED;  // (the LDS-DMA moves aligned 16-byte pieces of a row)
+    if ((int64_t)O * I + O > (int64_t)1 << 30) return NFA_ERR_UNSUPPORTED;
+    const WgradPlan p = plan_wgrad(batch, I, O);
+    if (p.ksplit > 0 && !workspace) return NFA_ERR_INVALID_ARGUMENT;
+    hipStream_t st = (hipStream_t)stream;
+    if (p.ksplit > 0) {
+        WgradArgs a;
+        a.x = inputs;
+        a.gy = grad_outputs;
+        a.ws = static_cast<float*>(workspace);
+        a.I = I;
+        a.O = O;
+        a.stages_total = p.stages_total;
+        a.ksplit = p.ksplit;
+        a.blocks_i = p.blocks_i;
+        const dim3 grid((unsigned)(p.blocks_o * p.blocks_i), (unsigned)p.ksplit);
+        if (p.variant == 0) {
+            constexpr size_t lds = (size_t)kWgRing * kWgRows * (128 + 128) * 4;
+            static const hipError_t attr = hipFuncSetAttribute((const void*)wgrad_partial_kernel<2, 2, 2, 2>,
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            NFA_HIP_CHECK(attr);
+            hipLaunchKernelGGL((wgrad_partial_kernel<2, 2, 2, 2>), grid, dim3(kBlock), lds, st, a);
+        } else {
+            constexpr size_t lds = (size_t)kWgRing * kWgRows * (128 + 32) * 4;
+            hipLaunchKernelGGL((wgrad_partial_kernel<1, 1, 4, 1>), grid, dim3(kBlock), lds, st, a);
+        }
+        NFA_HIP_CHECK(hipGetLastError());
+    }
+    const int64_t n = (int64_t)O * I + (grad_bias ? O : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(kBlock), 0, st,
+                       static_cast<const float*>(workspace), inputs, grad_outputs, grad_weight, grad_bias, I, O,
+                       p.ksplit, (int64_t)p.stages_total * kWgRows, batch);
+    NFA_HIP_CHECK(hipGetLastError());
+    return NFA_OK;
+}

@@ -326,7 +326,178 @@ __global__ void __launch_bounds__(kBlock) rqs_coupling_backward_kernel(const Bwd
     if (my_status && a.status) atomicOr(a.status, my_status);
 }
 
+// ------------------------------------------------------------------------------------------
+// Software-pipelined form for 16-byte aligned layouts with full tiles (the scheme of the forward
+// kernel `rqs_coupling_pipelined`, rqs.hip): every lane carries the NEXT tile -- NV float4 of
+// conditioner output, one float4 each of inputs and upstream gradients, its row's grad_logabsdet
+// -- in registers while the current tile is differentiated and stored, so HBM reads stay in flight
+// during the whole evaluation.  Workgroup barriers are LDS-only (`s_waitcnt lgkmcnt(0); s_barrier`).
+// A lane differentiates one spline in place in the LDS image of the conditioner output; the image
+// then leaves as NV coalesced float4 stores per lane.
+__device__ __forceinline__ void lds_only_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+typedef float vec4 __attribute__((ext_vector_type(4)));
+
+template <int KT, bool INVERSE, bool LINEAR>
+__global__ void __launch_bounds__(kBlock, 3) rqs_coupling_backward_pipelined(const BwdArgs a) {
+    constexpr int NV = (3 * KT + (LINEAR ? -1 : 1) + 3) / 4;
+    static_assert(NV <= 8, "add prefetch registers");
+    // Preconditions (checked by the host): a.batch % a.R == 0, R*dt <= 256, R*D <= 512,
+    // dt*P % 4 == 0, D % 4 == 0, all five arrays 16-byte aligned.
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* s_p = lds;
+    float* s_x = lds + a.off_x;
+    float* s_gy = lds + a.off_gy;
+    float* s_gi = lds + a.off_gx;
+    int* s_tidx = reinterpret_cast<int*>(lds + a.off_idx);
+    int* s_src = s_tidx + a.dt;
+    int* s_dst = s_src + a.D;
+    unsigned char* s_ist = reinterpret_cast<unsigned char*>(s_dst + a.D);
+
+    const int tid = threadIdx.x;
+    const int D = a.D, dt = a.dt, P = a.sp.P, R = a.R;
+    int my_status = 0;
+    for (int c = tid; c < D; c += kBlock) {
+        int src = c, dst = c;
+        if (a.perm) {
+            const int64_t p = a.perm[c];
+            if (p < 0 || p >= D) my_status |= NFA_STATUS_BAD_INDEX;
+            src = (int)(p < 0 ? 0 : (p >= D ? D - 1 : p));
+        }
+        if (a.scatter) {
+            const int64_t p = a.scatter[c];
+            if (p < 0 || p >= D) my_status |= NFA_STATUS_BAD_INDEX;
+            dst = (int)(p < 0 ? 0 : (p >= D ? D - 1 : p));
+        }
+        s_src[c] = src;
+        s_dst[c] = dst;
+        s_ist[c] = 0;
+    }
+    __syncthreads();
+    for (int j = tid; j < dt; j += kBlock) {
+        const int64_t t = a.tidx[j];
+        if (t < 0 || t >= D) my_status |= NFA_STATUS_BAD_INDEX;
+        const int col = (int)(t < 0 ? 0 : (t >= D ? D - 1 : t));
+        s_tidx[j] = col;
+        s_ist[col] = 1;
+    }
+    __syncthreads();
+
+    const int nitems = R * dt;          // <= 256
+    const int nvp = (nitems * P) >> 2;  // float4 of conditioner output (and of its gradient) per tile
+    const int nvx = (R * D) >> 2;       // float4 of inputs / gradients per tile (<= 128)
+    const bool has_item = tid < nitems;
+    int it_in = 0, it_out = 0, it_row = 0;
+    {
+        const int i = has_item ? tid : 0;
+        it_row = (int)fastdiv((uint32_t)i, a.div_dt);
+        const int col = s_tidx[i - it_row * dt];
+        it_in = it_row * D + s_src[col];   // the spline's input, and where its input gradient goes
+        it_out = it_row * D + s_dst[col];  // where its upstream gradient sits
+    }
+    float* it_p = s_p + (has_item ? tid : 0) * P;
+    // pass-through columns: out[:, dst[c]] = in[:, src[c]]  =>  gin[:, src[c]] = gout[:, dst[c]]
+    int cp_from0 = -1, cp_to0 = 0, cp_from1 = -1, cp_to1 = 0;
+    {
+        const int e0 = tid, e1 = tid + kBlock;
+        if (e0 < R * D) {
+            const int r = (int)fastdiv((uint32_t)e0, a.div_D), c = e0 - r * D;
+            if (!s_ist[c]) { cp_from0 = e0 - c + s_dst[c]; cp_to0 = e0 - c + s_src[c]; }
+        }
+        if (e1 < R * D) {
+            const int r = (int)fastdiv((uint32_t)e1, a.div_D), c = e1 - r * D;
+            if (!s_ist[c]) { cp_from1 = e1 - c + s_dst[c]; cp_to1 = e1 - c + s_src[c]; }
+        }
+    }
+    const int64_t tile_stride_p = (int64_t)nitems * P;
+    const int tile_stride_x = R * D;
+
+    vec4 pr0, pr1, pr2, pr3, pr4, pr5, pr6, pr7;
+    vec4 xr, gr;
+    float glr = 0.0f;
+#define NFA_LD(k)                                                  \
+    if (NV > k) {                                                  \
+        const int v_ = k * kBlock + tid;                           \
+        pr##k = gp_[v_ < nvp ? v_ : nvp - 1];                      \
+    }
+#define NFA_ST(k)                                                  \
+    if (NV > k) {                                                  \
+        const int v_ = k * kBlock + tid;                           \
+        if (v_ < nvp) reinterpret_cast<vec4*>(s_p)[v_] = pr##k;    \
+    }
+#define NFA_GST(k)                                                 \
+    if (NV > k) {                                                  \
+        const int v_ = k * kBlock + tid;                           \
+        if (v_ < nvp) gq_[v_] = reinterpret_cast<const vec4*>(s_p)[v_]; \
+    }
+    // index-clamped, unconditional loads; past the last tile the lanes re-read tile 0 (unused)
+#define NFA_ISSUE_TILE(TILE)                                                                 \
+    {                                                                                        \
+        const int64_t t_ = (TILE) < num_tiles ? (TILE) : 0;                                  \
+        const vec4* gp_ = reinterpret_cast<const vec4*>(a.params + t_ * tile_stride_p);      \
+        const vec4* gx_ = reinterpret_cast<const vec4*>(a.x + t_ * tile_stride_x);          \
+        const vec4* gg_ = reinterpret_cast<const vec4*>(a.gout + t_ * tile_stride_x);       \
+        NFA_LD(0) NFA_LD(1) NFA_LD(2) NFA_LD(3) NFA_LD(4) NFA_LD(5) NFA_LD(6) NFA_LD(7)      \
+        xr = gx_[tid < nvx ? tid : nvx - 1];                                                 \
+        gr = gg_[tid < nvx ? tid : nvx - 1];                                                 \
+        if (a.glad) glr = a.glad[t_ * R + it_row];                                           \
+    }
+
+    const int64_t num_tiles = a.batch / R;
+    int64_t tile = blockIdx.x;
+    NFA_ISSUE_TILE(tile)
+    for (; tile < num_tiles; tile += gridDim.x) {
+        NFA_ST(0) NFA_ST(1) NFA_ST(2) NFA_ST(3) NFA_ST(4) NFA_ST(5) NFA_ST(6) NFA_ST(7)
+        if (tid < nvx) {
+            reinterpret_cast<vec4*>(s_x)[tid] = xr;
+            reinterpret_cast<vec4*>(s_gy)[tid] = gr;
+        }
+        const float gl = glr;
+        const int64_t next = tile + gridDim.x;
+        NFA_ISSUE_TILE(next)  // in flight until the next iteration's LDS writes
+        lds_only_barrier();
+
+        if (cp_from0 >= 0) s_gi[cp_to0] = s_gy[cp_from0];
+        if (cp_from1 >= 0) s_gi[cp_to1] = s_gy[cp_from1];
+        if (has_item)
+            s_gi[it_in] = rqs_backward<KT, INVERSE, LINEAR>(s_x[it_in], it_p, a.sp, s_gy[it_out], gl, my_status);
+        lds_only_barrier();
+
+        const int64_t row0 = tile * R;
+        vec4* gq_ = reinterpret_cast<vec4*>(a.gparams + tile * tile_stride_p);
+        NFA_GST(0) NFA_GST(1) NFA_GST(2) NFA_GST(3) NFA_GST(4) NFA_GST(5) NFA_GST(6) NFA_GST(7)
+        if (tid < nvx)
+            reinterpret_cast<vec4*>(a.gin + row0 * D)[tid] = reinterpret_cast<const vec4*>(s_gi)[tid];
+        lds_only_barrier();  // the image has been read out before the next tile overwrites it
+    }
+#undef NFA_ISSUE_TILE
+#undef NFA_LD
+#undef NFA_ST
+#undef NFA_GST
+    if (my_status && a.status) atomicOr(a.status, my_status);
+}
+
 constexpr int kMaxDynLdsBwd = 64 * 1024;
+
+template <int KT>
+static int launch_backward_pipelined(const BwdArgs& a, int inverse, dim3 grid, size_t lds, hipStream_t st) {
+    if (a.sp.linear) {
+        if (inverse)
+            hipLaunchKernelGGL((rqs_coupling_backward_pipelined<KT, true, true>), grid, dim3(kBlock), lds, st, a);
+        else
+            hipLaunchKernelGGL((rqs_coupling_backward_pipelined<KT, false, true>), grid, dim3(kBlock), lds, st, a);
+    } else {
+        if (inverse)
+            hipLaunchKernelGGL((rqs_coupling_backward_pipelined<KT, true, false>), grid, dim3(kBlock), lds, st, a);
+        else
+            hipLaunchKernelGGL((rqs_coupling_backward_pipelined<KT, false, false>), grid, dim3(kBlock), lds, st, a);
+    }
+    NFA_HIP_CHECK(hipGetLastError());
+    return NFA_OK;
+}
+
 
 template <int KT>
 static int launch_backward(const BwdArgs& a, int inverse, dim3 grid, size_t lds, hipStream_t st) {
@@ -412,6 +583,32 @@ extern "C" int nfa_rqs_coupling_backward_f32(const float* inputs, const float* p
     int64_t g = (int64_t)device_cu_count() * per_cu;
     if (g > tiles) g = tiles;
     const int inverse = flags & NFA_FLAG_INVERSE;
+    // aligned layouts with K = 8 take the software-pipelined kernel; leftover rows (< R) follow in
+    // one workgroup of the generic kernel
+    static const int use_pipe = [] {
+        const char* e = getenv("NFA_K1_BWD_PIPELINE");
+        return e ? atoi(e) : 1;
+    }();
+    auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (use_pipe && a.sp.K == 8 && C == 0 && dt > 0 && (dt * P) % 4 == 0 && D % 4 == 0 && R * dt <= kBlock &&
+        R * D <= 2 * kBlock && (int64_t)R <= batch && aligned16(params) && aligned16(inputs) &&
+        aligned16(grad_outputs) && aligned16(grad_inputs) && aligned16(grad_params)) {
+        const int64_t full_rows = (batch / R) * R;
+        BwdArgs f = a;
+        f.batch = full_rows;
+        int64_t gp = (int64_t)device_cu_count() * (per_cu > 3 ? 3 : per_cu);
+        if (gp > full_rows / R) gp = full_rows / R;
+        rc = launch_backward_pipelined<8>(f, inverse, dim3((unsigned)gp), lds, (hipStream_t)stream);
+        if (rc != NFA_OK || full_rows == batch) return rc;
+        a.x = inputs + full_rows * D;
+        a.params = params + full_rows * (int64_t)dt * P;
+        a.gout = grad_outputs + full_rows * D;
+        a.glad = grad_logabsdet ? grad_logabsdet + full_rows : nullptr;
+        a.gin = grad_inputs + full_rows * D;
+        a.gparams = grad_params + full_rows * (int64_t)dt * P;
+        a.batch = batch - full_rows;
+        return launch_backward<8>(a, inverse, dim3(1), lds, (hipStream_t)stream);
+    }
     switch (a.sp.K) {
         case 8: return launch_backward<8>(a, inverse, dim3((unsigned)g), lds, (hipStream_t)stream);
         default: return launch_backward<0>(a, inverse, dim3((unsigned)g), lds, (hipStream_t)stream);

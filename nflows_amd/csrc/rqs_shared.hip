@@ -29,7 +29,7 @@ struct SharedArgs {
     int R;            // rows per tile
     FastDiv div_F;
     RqsDev sp;
-    int off_x, off_lad;
+    int off_x, off_lad, off_raw;
 };
 
 template <bool INVERSE>
@@ -47,20 +47,32 @@ __global__ void __launch_bounds__(kBlock) rqs_shared_kernel(const SharedArgs a) 
     const float span_w = a.sp.span_w, span_h = linear ? a.sp.span_w : a.sp.span_h;
     int my_status = 0;
 
-    // ---- per-feature tables (one lane per feature; scratch for the softmax numerators is the
-    //      table's own height/derivative area, overwritten afterwards)
-    for (int f = tid; f < F; f += kBlock) {
+    // ---- per-feature tables.  All logits are first staged into LDS by the whole workgroup (one
+    //      round of global latency instead of 3K dependent ones per lane), then one lane per
+    //      (feature, role) builds the width knots, the height knots or the knot derivatives; the
+    //      softmax numerators overwrite the staged logits in place.
+    float* s_raw = lds + a.off_raw;  // [F][K] width logits | [F][K] height logits | [F][nd] derivative logits
+    const int nd = a.sp.nd;
+    for (int i = tid; i < F * K; i += kBlock) {
+        s_raw[i] = a.uw[i];
+        s_raw[F * K + i] = a.uh[i];
+    }
+    for (int i = tid; i < F * nd; i += kBlock) s_raw[2 * F * K + i] = a.ud[i];
+    __syncthreads();
+    for (int task = tid; task < 3 * F; task += kBlock) {
+        const int role = (int)fastdiv((uint32_t)task, a.div_F);
+        const int f = task - role * F;
         float* tab = s_tab + f * T;
-        for (int side = 0; side < 2; ++side) {
-            const float* u = (side ? a.uh : a.uw) + (int64_t)f * K;
+        if (role < 2) {
+            const int side = role;
+            float* tmp = s_raw + side * F * K + f * K;
             float* knots = tab + side * (K + 1);
-            float* tmp = tab + 2 * (K + 1);  // K values fit in the derivative area (K+1 words)
             const float lo = side ? bottom : left, hi = side ? top : right;
             const float span = side ? span_h : span_w;
             const float minbin = side ? a.sp.min_h : a.sp.min_w, om = side ? a.sp.om_h : a.sp.om_w;
             float m = -INFINITY;
             for (int i = 0; i < K; ++i) {
-                float v = u[i];
+                float v = tmp[i];
                 if (a.sp.divisor != 0.0f) v = div_with_rcp(v, a.sp.divisor, a.sp.rdivisor);
                 tmp[i] = v;
                 m = fmaxf(m, v);
@@ -80,16 +92,17 @@ __global__ void __launch_bounds__(kBlock) rqs_shared_kernel(const SharedArgs a) 
                 acc += (double)w;
                 knots[i + 1] = (i == K - 1) ? hi : span * (float)acc + lo;
             }
-        }
-        float* dv = tab + 2 * (K + 1);
-        const float* ud = a.ud + (int64_t)f * a.sp.nd;
-        for (int i = 0; i <= K; ++i) {
-            float logit;
-            if (linear)
-                logit = (i == 0 || i - 1 >= a.sp.nd) ? a.sp.tail_logit : ud[i - 1];
-            else
-                logit = ud[i];
-            dv[i] = a.sp.min_d + softplus_beta(logit, a.sp.beta);
+        } else {
+            float* dv = tab + 2 * (K + 1);
+            const float* ud = s_raw + 2 * F * K + f * nd;
+            for (int i = 0; i <= K; ++i) {
+                float logit;
+                if (linear)
+                    logit = (i == 0 || i - 1 >= nd) ? a.sp.tail_logit : ud[i - 1];
+                else
+                    logit = ud[i];
+                dv[i] = a.sp.min_d + softplus_beta(logit, a.sp.beta);
+            }
         }
     }
     __syncthreads();
@@ -172,6 +185,8 @@ extern "C" int nfa_rqs_shared_f32(const float* inputs, const float* unnormalized
         o += round_up4(r * F) + 8;
         a.off_lad = (int)o;
         o += round_up4(r * F);
+        a.off_raw = (int)o;  // staged logits: only live while the tables are built
+        o += round_up4(F * (2 * K + a.sp.nd));
         return o;
     };
     while (R > 1 && lds_floats(R) * 4 > 64 * 1024) R >>= 1;

@@ -63,3 +63,66 @@ class GraphedInverse:
         self._static_in.copy_(noise)
         self._graph.replay()
         return self._static_out
+
+
+class GraphedTrainStep:
+    """Replays one whole optimisation step -- `loss = -flow.log_prob(x).mean()`, `loss.backward()`,
+    `optimizer.step()`: the reference's training loop, examples/moons.ipynb cell 3 -- from ONE HIP
+    graph.  A 32-layer flow enqueues ~1 500 kernels per step (conditioner GEMMs and their
+    gradients, the layer kernels and their backward kernels, the optimizer); eagerly the step is
+    bound by the host, replayed it is bound by the GPU.
+
+    The optimizer must be capture-safe: its state may not live on the host
+    (`torch.optim.Adam(..., capturable=True)`; plain SGD qualifies as is).
+
+    Usage:
+        opt = torch.optim.Adam(flow.parameters(), lr=1e-4, capturable=True)
+        step = GraphedTrainStep(flow, opt, example_inputs)     # warms up on a side stream, captures
+        for x in batches:                                       # same shape as example_inputs
+            loss = step(x)                                      # 0-dim tensor, valid until the next call
+
+    Drop every reference to losses / outputs of earlier EAGER steps first: a live autograd graph
+    keeps its AccumulateGrad nodes bound to the stream they were created on, and the engine would
+    then synchronise the capturing stream with that one in the middle of the capture.
+
+    The warm-up runs `warmup` REAL optimisation steps on `example_inputs` (PyTorch's whole-network
+    capture recipe needs the optimizer state and the gradient buffers to exist before capture).
+    `loss_fn(flow, inputs) -> 0-dim tensor` replaces the default negative mean log-likelihood.
+    """
+
+    def __init__(self, flow, optimizer, example_inputs, loss_fn=None, warmup=3):
+        if not example_inputs.is_cuda:
+            raise NotImplementedError("nflows_amd: HIP graphs need inputs on a HIP device")
+        if optimizer.defaults.get("capturable") is False:
+            raise ValueError("GraphedTrainStep needs a capture-safe optimizer: construct it with capturable=True")
+        self.flow = flow
+        self.optimizer = optimizer
+        self._loss_fn = loss_fn if loss_fn is not None else (lambda f, x: -f.log_prob(x).mean())
+        self._static_in = example_inputs.detach().clone()
+        device = example_inputs.device
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._eager_step()
+        torch.cuda.current_stream(device).wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)  # gradients are (re)allocated inside the graph's pool
+        with torch.cuda.graph(self._graph):
+            self._static_loss = self._loss_fn(flow, self._static_in)
+            self._static_loss.backward()
+            optimizer.step()
+
+    def _eager_step(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self._loss_fn(self.flow, self._static_in)
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+    def __call__(self, inputs):
+        if inputs.shape != self._static_in.shape or inputs.dtype != self._static_in.dtype:
+            raise ValueError("GraphedTrainStep was captured for %s %s" % (tuple(self._static_in.shape), self._static_in.dtype))
+        self._static_in.copy_(inputs)
+        self._graph.replay()
+        return self._static_loss

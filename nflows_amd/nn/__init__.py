@@ -1,1 +1,1 @@
-from . import nets
+from . import functional, nets

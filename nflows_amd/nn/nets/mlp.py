@@ -12,6 +12,8 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from ..functional import apply_layer
+
 
 class MLP(nn.Module):
     def __init__(self, in_shape, out_shape, hidden_sizes, activation=F.relu, activate_output=False):
@@ -31,7 +33,7 @@ class MLP(nn.Module):
     def _activated(self, layer, v, fused):
         if fused:
             return torch._addmm_activation(layer.bias, v, layer.weight.t())
-        return self._activation(layer(v))
+        return self._activation(apply_layer(layer, v))
 
     def forward(self, inputs, context=None):
         if inputs.shape[1:] != self._in_shape:
@@ -40,7 +42,7 @@ class MLP(nn.Module):
         fused = self._activation is F.relu and h.is_cuda and not torch.is_grad_enabled()
         for layer in [self._input_layer, *self._hidden_layers]:
             h = self._activated(layer, h, fused)
-        h = self._output_layer(h)
+        h = apply_layer(self._output_layer, h)
         if self._activate_output:
             h = self._activation(h)
         return h.reshape(-1, *self._out_shape)

@@ -16,6 +16,8 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from ..functional import apply_layer
+
 
 def _dense(n_in, n_out, kernel_size=None):
     return nn.Linear(n_in, n_out)
@@ -55,10 +57,10 @@ class _Block(nn.Module):
         h = inputs
         if self.use_batch_norm:
             h = self.batch_norm_layers[0](h)
-        h = first(self.activation(h))
+        h = apply_layer(first, self.activation(h))
         if self.use_batch_norm:
             h = self.batch_norm_layers[1](h)
-        h = second(self.dropout(self.activation(h)))
+        h = apply_layer(second, self.dropout(self.activation(h)))
         if context is not None:
             h = F.glu(torch.cat((h, self.context_layer(context)), dim=1), dim=1)
         return inputs + h
@@ -133,13 +135,13 @@ class _Net(nn.Module):
         """Activations in front of `final_layer` (the fused spline kernels K7 / K7b consume these
         and apply `final_layer` themselves)."""
         h = inputs if context is None else torch.cat((inputs, context), dim=1)
-        h = self.initial_layer(h)
+        h = apply_layer(self.initial_layer, h)
         for block in self.blocks:
             h = block(h, context=context)
         return h
 
     def forward(self, inputs, context=None):
-        return self.final_layer(self.hidden(inputs, context))
+        return apply_layer(self.final_layer, self.hidden(inputs, context))
 
 
 class ResidualNet(_Net):

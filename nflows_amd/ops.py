@@ -502,6 +502,38 @@ def _standard_normal_log_prob_launch(z, logabsdet):
     return out
 
 
+def linear_wgrad(inputs, grad_outputs, need_bias=True):
+    """K10 -- gradients of y = x W^T + b with respect to W and b for x [B, I], dL/dy [B, O]:
+    (grad_weight [O, I], grad_bias [O] or None).  The reduction over the batch is split over the
+    chip and summed in a fixed order (deterministic).  Returns None when the layer shape has no
+    kernel (widths not multiples of 4): callers then use the library GEMM."""
+    N.require_device_f32("inputs", inputs, 2)
+    N.require_device_f32("grad_outputs", grad_outputs, 2)
+    if inputs.shape[0] != grad_outputs.shape[0]:
+        raise ValueError("inputs and grad_outputs must have the same number of rows")
+    B, I = inputs.shape
+    O = grad_outputs.shape[1]
+    if I % 4 or O % 4:
+        return None
+    x, gy = inputs.contiguous(), grad_outputs.contiguous()
+    if x.data_ptr() % 16:
+        x = x.clone()
+    if gy.data_ptr() % 16:
+        gy = gy.clone()
+    dev = x.device
+    lib = N.load()
+    gw = torch.empty(O, I, dtype=torch.float32, device=dev)
+    gb = torch.empty(O, dtype=torch.float32, device=dev) if need_bias else None
+    ws = torch.empty(max(1, lib.nfa_linear_wgrad_workspace_bytes(B, I, O) // 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nfa_linear_wgrad_f32(N.ptr(x), N.ptr(gy), N.ptr(gw), N.ptr(gb), N.ptr(ws), B, I, O, 0,
+                                      N.stream_handle(dev))
+    if rc == N.ERR_UNSUPPORTED:
+        return None
+    N.check(rc)
+    return gw, gb
+
+
 def rqs_shared(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, spec,
                inverse=False):
     """K6 -- rational-quadratic CDF transform with batch-shared logits [*shape, K]; inputs

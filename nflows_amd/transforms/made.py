@@ -10,6 +10,8 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from ..nn.functional import linear
+
 
 # ---- degrees and masks ------------------------------------------------------------------------
 # Input feature i has degree i+1.  A hidden unit of degree m may look at inputs of degree <= m,
@@ -52,7 +54,7 @@ class MaskedLinear(nn.Linear):
         self.register_buffer("degrees", degrees)
 
     def forward(self, x):
-        return F.linear(x, self.mask * self.weight, self.bias)
+        return linear(x, self.mask * self.weight, self.bias)
 
 
 def _norm(features):

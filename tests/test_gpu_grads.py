@@ -88,10 +88,24 @@ def test_flow_training_gradients_match_reference(G):
 def test_rqs_coupling_gradients_vs_eager_autograd(B, D, K, tails, inverse, perm):
     """Fresh shapes (ragged batches, odd K, wide rows, fused permutations): HIP backward vs
     autograd through the CPU eager port in float64 (truth) and float32 (the reference's own path)."""
+    _check_coupling_gradients(B, D, K, tails, inverse, perm, alternating=False)
+
+
+@pytest.mark.parametrize("B,D,K,tails,inverse,perm", [
+    (264, 64, 8, "linear", False, "in"), (259, 64, 8, "linear", True, "out"), (512, 64, 8, "linear", False, None),
+    (96, 16, 8, None, False, "out"), (70, 16, 8, None, True, "in"), (1030, 128, 8, "linear", False, None),
+])
+def test_rqs_coupling_gradients_pipelined_kernel(B, D, K, tails, inverse, perm):
+    """Alternating masks at K = 8 (d_t * P a multiple of 4): the software-pipelined backward kernel,
+    with and without leftover rows behind the last full tile."""
+    _check_coupling_gradients(B, D, K, tails, inverse, perm, alternating=True)
+
+
+def _check_coupling_gradients(B, D, K, tails, inverse, perm, alternating):
     from nflows_amd import ops
     from oracle import eager
     rng = np.random.RandomState(B * 7 + D + K)
-    mask = rng.rand(D) < 0.5
+    mask = (np.arange(D) % 2 == 0) if alternating else rng.rand(D) < 0.5
     mask[0] = True
     tidx = np.nonzero(mask)[0]
     ident = np.nonzero(~mask)[0]
@@ -193,3 +207,93 @@ def test_training_loop_on_gpu_reduces_nll():
         first = loss.item() if first is None else first
         last = loss.item()
     assert last < first - 0.5
+
+
+def test_graphed_training_step_matches_eager_steps():
+    """`GraphedTrainStep` (forward + backward + Adam in ONE HIP graph) follows the same loss
+    trajectory as the eager loop from the same initial weights and batches."""
+    import copy
+    import nflows_amd
+    from nflows_amd import configs
+    from nflows_amd.graphs import GraphedTrainStep
+    torch.manual_seed(0)
+    flow_a = configs.rq_nsf_flow(num_layers=4, features=16, num_bins=8, hidden_features=32).to(DEV).train()
+    flow_b = copy.deepcopy(flow_a)
+    batches = [torch.randn(512, 16, device=DEV) * 0.8 + 0.2 for _ in range(6)]
+    warm = 2
+
+    opt_a = torch.optim.Adam(flow_a.parameters(), lr=1e-3, capturable=True)
+    eager_losses = []
+    for i, xb in enumerate([batches[0]] * warm + batches):  # the graphed step warms up on batches[0]
+        opt_a.zero_grad(set_to_none=True)
+        loss = -flow_a.log_prob(xb).mean()
+        loss.backward()
+        opt_a.step()
+        if i >= warm:
+            eager_losses.append(loss.item())
+
+    opt_b = torch.optim.Adam(flow_b.parameters(), lr=1e-3, capturable=True)
+    step = GraphedTrainStep(flow_b, opt_b, batches[0], warmup=warm)
+    graphed_losses = [step(xb).item() for xb in batches]
+    nflows_amd.check_status()
+    np.testing.assert_allclose(graphed_losses, eager_losses, rtol=2e-5, atol=2e-5)
+    assert graphed_losses[-1] < graphed_losses[0]
+    with pytest.raises(ValueError):
+        step(batches[0][:100])
+    with pytest.raises(ValueError):
+        GraphedTrainStep(flow_b, torch.optim.Adam(flow_b.parameters(), lr=1e-3), batches[0])
+
+
+@pytest.mark.parametrize("B,I,O", [
+    (4096, 128, 128), (4100, 32, 128), (1000, 128, 736), (31, 128, 128), (2048, 64, 96), (5000, 200, 40),
+    (64, 4, 4), (65536, 128, 128), (33, 16, 260),
+])
+def test_linear_wgrad_kernel(B, I, O):
+    """K10 (weight / bias gradient of a conditioner layer, batch split over the chip) against the
+    float64 product: at most 4x as far from it as the library's fp32 GEMM, and deterministic."""
+    from nflows_amd import ops
+    g = torch.Generator().manual_seed(B + I + O)
+    x = torch.randn(B, I, generator=g)
+    gy = torch.randn(B, O, generator=g) * torch.rand(1, O, generator=g)
+    gw64 = (gy.double().t() @ x.double()).numpy()
+    gb64 = gy.double().sum(0).numpy()
+    xd, gyd = x.to(DEV), gy.to(DEV)
+    gw, gb = ops.linear_wgrad(xd, gyd)
+    close_to_truth(gw, (gyd.t() @ xd).cpu().numpy(), gw64, "grad_weight", tol=2e-6)
+    close_to_truth(gb, gyd.sum(0).cpu().numpy(), gb64, "grad_bias", tol=2e-6)
+    gw2, gb2 = ops.linear_wgrad(xd, gyd)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    gw3, none = ops.linear_wgrad(xd, gyd, need_bias=False)
+    assert none is None and torch.equal(gw3, gw)
+    # a contiguous view that is not 16-byte aligned is copied; odd widths have no kernel
+    flat = torch.cat([torch.zeros(1), x.reshape(-1)]).to(DEV)
+    shifted = flat[1:].view(B, I)
+    assert shifted.data_ptr() % 16 != 0
+    assert torch.equal(ops.linear_wgrad(shifted, gyd)[0], gw)
+    assert ops.linear_wgrad(torch.randn(B, I + 1, device=DEV), gyd) is None
+    with pytest.raises(NotImplementedError):
+        ops.linear_wgrad(x, gyd)
+
+
+def test_conditioner_training_gradients_through_wgrad_kernel(monkeypatch):
+    """ResidualNet / MLP / MADE under autograd: parameter and input gradients with K10 in the loop
+    equal those of the plain library path."""
+    import nflows_amd.nn.functional as NF
+    from nflows_amd.nn.nets import MLP, ResidualNet
+    from nflows_amd.transforms.made import MADE
+    torch.manual_seed(3)
+    nets = [ResidualNet(32, 736, 128, num_blocks=2), MLP([16], [32], [64, 64]), MADE(12, 32, output_multiplier=2, num_blocks=2)]
+    for net in nets:
+        net = net.to(DEV)
+        x = torch.randn(3000, net.initial_layer.in_features if hasattr(net, "initial_layer") else (16 if isinstance(net, MLP) else 12), device=DEV)
+        w = torch.randn(3000, 1, device=DEV)
+        grads = {}
+        for rows in (0, 1 << 40):
+            monkeypatch.setattr(NF, "_WGRAD_MIN_ROWS", rows)
+            net.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            (net(xi) * w).sum().backward()
+            grads[rows] = [xi.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+        for a, b in zip(grads[0], grads[1 << 40]):
+            scale = 1.0 + b.abs().max().item()
+            assert (a - b).abs().max().item() <= 2e-5 * scale

@@ -76,7 +76,7 @@ with torch.no_grad():
         y, lad = ops.rqs_coupling(xr, pr, tidx, spec)
     def bwd():
         torch.autograd.grad((y, lad), (xr, pr), (gx, gl), retain_graph=True)
-    add("K1-backward `rqs_coupling_backward_kernel`", "same layer, grads wrt inputs and params", timeit_eager(bwd), 2 * k1_bytes)
+    add("K1-backward `rqs_coupling_backward_pipelined`", "same layer, grads wrt inputs and params (through autograd)", timeit(bwd), 2 * k1_bytes)
 
     N = B * 32
     xe = torch.randn(N, device=dev, generator=g) * 1.5
@@ -93,6 +93,11 @@ with torch.no_grad():
     uw = torch.rand(32, K, device=dev, generator=g); ud = torch.rand(32, K - 1, device=dev, generator=g)
     xs = torch.randn(B, 32, device=dev, generator=g)
     add("K6 `rqs_shared_kernel`", "batch-shared RQ CDF, B=65536 F=32", timeit(lambda: ops.rqs_shared(xs, uw, uw, ud, ops.make_rqs_spec(K, "linear", tail_bound=3.0), False)), 4 * (2 * B * 32 + B))
+
+    for I, O in ((128, 128), (128, 736)):
+        xa = torch.randn(B, I, device=dev, generator=g); ga = torch.randn(B, O, device=dev, generator=g)
+        add("K10 `wgrad_partial_kernel` + `wgrad_reduce_kernel`", "weight + bias gradient of Linear(%d -> %d), B=65536" % (I, O),
+            timeit(lambda: ops.linear_wgrad(xa, ga)), flops=2.0 * B * I * O, peak_note="(fp32 matrix peak 157); library GEMM + column sum: %.0f us" % timeit(lambda: (ga.t() @ xa, ga.sum(0))))
 
     B2, D2 = 16384, 32
     x2 = torch.randn(B2, D2, device=dev, generator=g); p2 = torch.randn(B2, 32, device=dev, generator=g)
@@ -125,7 +130,7 @@ with torch.no_grad():
 
 print("# Kernel table (round 1, 1 x MI355X; `python tools/all_kernels.py`)\n")
 print("GPU time per call: 10 calls captured in one HIP graph, median of 30 replays / 10 (the backward through")
-print("autograd is timed eagerly); rates are ALGORITHMIC bytes or flops per launch over that time.  The helper")
+print("autograd is captured the same way); rates are ALGORITHMIC bytes or flops per launch over that time.  The helper")
 print("kernels next to a call (output allocation is free, a status-word memset is not) are included.\n")
 print("| kernel | workload | µs | rate |")
 print("|---|---|---|---|")
