@@ -71,12 +71,14 @@ with torch.no_grad():
     add("K1 `rqs_coupling_pipelined`", "RQ coupling layer, B=65536 D=64 K=8", timeit(lambda: ops.rqs_coupling(x, params, tidx, spec)), k1_bytes)
     add("K1 inverse", "same", timeit(lambda: ops.rqs_coupling(x, params, tidx, spec, inverse=True)), k1_bytes)
     gx = torch.randn(B, D, device=dev, generator=g); gl = torch.randn(B, device=dev, generator=g)
-    xr = x.clone().requires_grad_(True); pr = params.clone().requires_grad_(True)
-    with torch.enable_grad():
-        y, lad = ops.rqs_coupling(xr, pr, tidx, spec)
-    def bwd():
-        torch.autograd.grad((y, lad), (xr, pr), (gx, gl), retain_graph=True)
-    add("K1-backward `rqs_coupling_backward_pipelined`", "same layer, grads wrt inputs and params (through autograd)", timeit(bwd), 2 * k1_bytes)
+    gin, gpar = torch.empty_like(x), torch.empty_like(params)
+    from nflows_amd import _native as NA
+    import ctypes
+    def bwd():  # the C entry point itself (what nflows_amd.autograd.RqsCoupling.backward calls)
+        NA.check(NA.load().nfa_rqs_coupling_backward_f32(
+            NA.ptr(x), NA.ptr(params), NA.ptr(tidx), None, None, NA.ptr(gx), NA.ptr(gl), NA.ptr(gin), NA.ptr(gpar),
+            NA.ptr(ops._status_word(x.device)), B, D, tidx.numel(), ctypes.byref(spec), 0, NA.stream_handle(x.device)))
+    add("K1-backward `rqs_coupling_backward_pipelined`", "same layer, grads wrt inputs and params", timeit(bwd), 2 * k1_bytes)
 
     N = B * 32
     xe = torch.randn(N, device=dev, generator=g) * 1.5
@@ -130,7 +132,7 @@ with torch.no_grad():
 
 print("# Kernel table (round 1, 1 x MI355X; `python tools/all_kernels.py`)\n")
 print("GPU time per call: 10 calls captured in one HIP graph, median of 30 replays / 10 (the backward through")
-print("autograd is captured the same way); rates are ALGORITHMIC bytes or flops per launch over that time.  The helper")
+print("C entry point is called directly); rates are ALGORITHMIC bytes or flops per launch over that time.  The helper")
 print("kernels next to a call (output allocation is free, a status-word memset is not) are included.\n")
 print("| kernel | workload | µs | rate |")
 print("|---|---|---|---|")
