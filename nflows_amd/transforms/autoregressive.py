@@ -57,7 +57,7 @@ class AutoregressiveTransform(Transform):
         features it has not reached yet are multiplied by exactly-zero masked weights.  Here step
         t evaluates the hidden layers on the current outputs (unreached features still zero),
         takes only feature t's P rows of the final masked layer, inverts that one column and adds
-        its log-derivative.  Identical up to GEMM blocking / summation order."""
+        its log-derivative.  Identical up to summation order."""
         net = self.autoregressive_net
         batch, features = inputs.shape
         mult = self._output_dim_multiplier()
@@ -66,12 +66,31 @@ class AutoregressiveTransform(Transform):
         bias = final.bias.view(features, mult)
         outputs = torch.zeros_like(inputs)
         logabsdet = inputs.new_zeros(batch)
-        for t in range(features):
-            h = net.hidden(outputs, context)
-            params_t = torch.addmm(bias[t], h, weight[t].t())
-            column, lad_t = self._inverse_column(inputs[:, t], params_t)
-            outputs[:, t] = column
-            logabsdet = logabsdet + lad_t
+        if torch.is_grad_enabled():
+            for t in range(features):
+                h = net.hidden(outputs, context)
+                params_t = torch.addmm(bias[t], h, weight[t].t())
+                column, lad_t = self._inverse_column(inputs[:, t], params_t)
+                outputs[:, t] = column
+                logabsdet = logabsdet + lad_t
+            return outputs, logabsdet
+        # No-grad (sampling): `weight * mask` of every layer is formed once, and the first layer's
+        # output -- bias + sum over the features found so far of column (x) masked weight column --
+        # is carried along and grows by one rank-1 term per step (all still-zero features contribute
+        # exact zeros to the reference's full product).
+        first = net.initial_layer
+        with net.frozen_masks():
+            first_weight = first.masked_weight().t().contiguous()  # [D, H]: row t = feature t's weights
+            pre = first.bias.detach().expand(batch, -1).contiguous() if first.bias is not None \
+                else inputs.new_zeros(batch, first_weight.shape[1])
+            for t in range(features):
+                h = net.hidden_from_initial(pre, context)
+                params_t = torch.addmm(bias[t], h, weight[t].t())
+                column, lad_t = self._inverse_column(inputs[:, t], params_t)
+                outputs[:, t] = column
+                logabsdet += lad_t
+                if t + 1 < features:
+                    pre.addr_(column, first_weight[t])
         return outputs, logabsdet
 
     def _output_dim_multiplier(self):

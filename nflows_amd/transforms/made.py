@@ -53,8 +53,15 @@ class MaskedLinear(nn.Linear):
         self.register_buffer("mask", mask.float())
         self.register_buffer("degrees", degrees)
 
+    # `weight * mask` kept across calls while the weights are known not to change (the sampling
+    # loop evaluates the net once per feature); set / cleared by MADE.frozen_masks
+    _frozen_weight = None
+
+    def masked_weight(self):
+        return self._frozen_weight if self._frozen_weight is not None else self.mask * self.weight
+
     def forward(self, x):
-        return linear(x, self.mask * self.weight, self.bias)
+        return linear(x, self.masked_weight(), self.bias)
 
 
 def _norm(features):
@@ -152,9 +159,32 @@ class MADE(nn.Module):
         self.final_layer = MaskedLinear(degrees, features * output_multiplier, features, random_mask,
                                         is_output=True)
 
+    def frozen_masks(self):
+        """Context manager: every masked layer forms `weight * mask` once instead of per call.
+        Only for no-grad evaluation with fixed weights (the autoregressive sampling loop)."""
+        import contextlib
+        net = self
+
+        @contextlib.contextmanager
+        def scope():
+            layers = [m for m in net.modules() if isinstance(m, MaskedLinear)]
+            try:
+                with torch.no_grad():
+                    for m in layers:
+                        m._frozen_weight = m.mask * m.weight
+                yield
+            finally:
+                for m in layers:
+                    m._frozen_weight = None
+        return scope()
+
     def hidden(self, inputs, context=None):
         """Activations fed to the final masked layer."""
-        h = self.initial_layer(inputs)
+        return self.hidden_from_initial(self.initial_layer(inputs), context)
+
+    def hidden_from_initial(self, h, context=None):
+        """`hidden` given the output of `initial_layer` (the sampling loop updates that output by one
+        rank-1 term per step instead of re-running the [B, D] x [D, H] product)."""
         if context is not None:
             h = h + self.activation(self.context_layer(context))
         if not self.use_residual_blocks:

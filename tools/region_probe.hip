@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256, 1) probe(const vec4f* w, float* out, int 
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int r = 0; r < regions; ++r) {
         const vec4f* cur = ring + (r & 1) * 768 + lane;
-        if (MODE & 1) {
+        if (MODE != 4 && (MODE & 1)) {
             if (PREFETCH) {  // all 12 fragments of the region requested up front
                 bf16x8 a[12];
 #pragma unroll
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256, 1) probe(const vec4f* w, float* out, int 
                 }
             }
         }
-        if (MODE & 2) {  // ~130 VALU ops incl. 16 exps: the size of one spline chunk
+        if (MODE != 4 && (MODE & 2)) {  // ~130 VALU ops incl. 16 exps: the size of one spline chunk
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 float t = v[j] * 0.7f - 0.3f;
@@ -61,6 +61,28 @@ __global__ void __launch_bounds__(256, 1) probe(const vec4f* w, float* out, int 
                 t = __builtin_fmaf(t, 0.3f, -0.1f);
                 t = t - v[(j + 5) & 15] * 0.001f;
                 v[j] = t * 0.5f + 0.1f;
+            }
+        }
+        if (MODE == 4) {
+            // both, hand-placed: fragments up front, then 1-2 MFMAs, a fence, one 8-op slice of the VALU
+            // chunk, a fence ... (sched_barrier(0): nothing may be scheduled across)
+            bf16x8 a[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) a[i] = __builtin_bit_cast(bf16x8, cur[i * 64]);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(3 * j / 2) % 12], b, acc, 0, 0, 0);
+                if (j & 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(3 * j / 2 + 1) % 12], b, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                float t = v[j] * 0.7f - 0.3f;
+                t = __builtin_amdgcn_exp2f(t);
+                t = __builtin_fmaf(t, 0.5f, v[(j + 1) & 15]);
+                t = __builtin_fmaf(t, t, 0.25f);
+                t = t * 0.9f + 0.01f;
+                t = __builtin_fmaf(t, 0.3f, -0.1f);
+                t = t - v[(j + 5) & 15] * 0.001f;
+                v[j] = t * 0.5f + 0.1f;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -95,5 +117,6 @@ int main() {
     run<2, 0>("VALU chunk (~130 ops, 16 exp)", w, out, cyc);
     run<3, 0>("both, fragments per k-step", w, out, cyc);
     run<3, 1>("both, fragments up front", w, out, cyc);
+    run<4, 0>("both, hand-placed with sched_barrier fences", w, out, cyc);
     return 0;
 }
