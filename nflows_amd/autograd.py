@@ -251,3 +251,67 @@ class Linear(torch.autograd.Function):
             else:
                 g_w, g_b = got
         return g_in, (g_w if need_w else None), g_b
+
+
+def _dense_rows(t, n, width):
+    return t.detach().reshape(n, width).contiguous()
+
+
+class LinearSpline(torch.autograd.Function):
+    """K9 linear spline forward + `nfa_linear_spline_backward_f32`."""
+
+    @staticmethod
+    def forward(ctx, inputs, unnormalized_pdf, spec, inverse):
+        from . import ops
+        y, lad = ops._linear_spline_launch(inputs, unnormalized_pdf, spec, inverse)
+        ctx.save_for_backward(inputs, unnormalized_pdf)
+        ctx.spec, ctx.inverse = spec, bool(inverse)
+        return y, lad
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_y, g_lad):
+        inputs, pdf = ctx.saved_tensors
+        K = ctx.spec.num_bins
+        n, dev = inputs.numel(), inputs.device
+        x = inputs.detach().contiguous().view(-1)
+        rows = _dense_rows(pdf, n, K)
+        g_y = torch.zeros_like(x) if g_y is None else g_y.contiguous().view(-1)
+        g_lad = None if g_lad is None else g_lad.contiguous().view(-1)
+        g_in, g_rows = torch.empty_like(x), torch.empty_like(rows)
+        with torch.cuda.device(dev):
+            rc = N.load().nfa_linear_spline_backward_f32(
+                N.ptr(x), N.ptr(rows), N.ptr(g_y), N.ptr(g_lad), N.ptr(g_in), N.ptr(g_rows), n,
+                ctypes.byref(ctx.spec), int(ctx.inverse), N.stream_handle(dev))
+        N.check(rc)
+        return g_in.view(inputs.shape), g_rows.view(pdf.shape), None, None
+
+
+class QuadraticSpline(torch.autograd.Function):
+    """K9 quadratic spline forward + `nfa_quadratic_spline_backward_f32`."""
+
+    @staticmethod
+    def forward(ctx, inputs, unnormalized_widths, unnormalized_heights, spec, inverse):
+        from . import ops
+        y, lad = ops._quadratic_spline_launch(inputs, unnormalized_widths, unnormalized_heights, spec, inverse)
+        ctx.save_for_backward(inputs, unnormalized_widths, unnormalized_heights)
+        ctx.spec, ctx.inverse = spec, bool(inverse)
+        return y, lad
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_y, g_lad):
+        inputs, uw, uh = ctx.saved_tensors
+        K, nh = ctx.spec.num_bins, uh.shape[-1]
+        n, dev = inputs.numel(), inputs.device
+        x = inputs.detach().contiguous().view(-1)
+        w_rows, h_rows = _dense_rows(uw, n, K), _dense_rows(uh, n, nh)
+        g_y = torch.zeros_like(x) if g_y is None else g_y.contiguous().view(-1)
+        g_lad = None if g_lad is None else g_lad.contiguous().view(-1)
+        g_in, g_w, g_h = torch.empty_like(x), torch.empty_like(w_rows), torch.empty_like(h_rows)
+        with torch.cuda.device(dev):
+            rc = N.load().nfa_quadratic_spline_backward_f32(
+                N.ptr(x), N.ptr(w_rows), N.ptr(h_rows), nh, N.ptr(g_y), N.ptr(g_lad), N.ptr(g_in), N.ptr(g_w),
+                N.ptr(g_h), n, ctypes.byref(ctx.spec), int(ctx.inverse), N.stream_handle(dev))
+        N.check(rc)
+        return g_in.view(inputs.shape), g_w.view(uw.shape), g_h.view(uh.shape), None, None

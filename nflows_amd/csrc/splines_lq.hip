@@ -469,6 +469,313 @@ static int fill_common(LqArgs& a, const nfa_rqs_spec* spec) {
     return NFA_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Backward of the linear and quadratic spline functionals (the reference differentiates them by
+// autograd through the eager ops of splines/linear.py:40-105 and splines/quadratic.py:55-159).
+// One lane per element: it rebuilds the spline from the logits with the forward kernels' own
+// arithmetic (same knots, same bin), then applies the closed-form adjoints of the map inside the
+// bin, of the prefix sums, of the height normalisation and of the softmax / softplus.
+// Logit rows are dense ([n, K], [n, nh]); the lane's working set lives in its LDS slot.
+struct LqBwdArgs {
+    const float* x;
+    const float* a0;  // [n, K] pdf / width logits
+    const float* a1;  // [n, nh] height logits (quadratic)
+    const float* gy;  // [n] upstream gradient of outputs
+    const float* gl;  // [n] upstream gradient of logabsdet (may be null)
+    float* gx;        // [n]
+    float* g0;        // [n, K]
+    float* g1;        // [n, nh]
+    int64_t n;
+    LqArgs f;         // the forward description (box, minimums, divisor)
+};
+
+__device__ __forceinline__ float sigmoid_of(float v) { return v > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-v)); }
+
+template <bool INVERSE>
+__global__ void __launch_bounds__(kBlock) linear_spline_backward_kernel(const LqBwdArgs b) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LqArgs& a = b.f;
+    const int K = a.K;
+    float* pdf = lds + threadIdx.x * a.slot;  // K probabilities, then their adjoints in place
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = b.x[i];
+        const float gy = b.gy[i], gl = b.gl ? b.gl[i] : 0.0f;
+        float* g0 = b.g0 + i * K;
+        if (!(x >= a.left && x <= a.right)) {  // tails (identity) or outside the box: no logit gradient
+            b.gx[i] = gy;
+            for (int q = 0; q < K; ++q) g0[q] = 0.0f;
+            continue;
+        }
+        for (int q = 0; q < K; ++q) pdf[q] = b.a0[i * K + q];
+        softmax_in_place<0>(pdf, K, 0.0f, 0.0f);
+        const float u = INVERSE ? (x - a.bottom) / a.span_out : (x - a.left) / a.span_in;
+        int k = -1;
+        float g_u = 0.0f, g_lo = 0.0f, g_hi = 0.0f, g_pk = 0.0f;  // adjoints of u, cdf[k], cdf[k+1], pdf[k]
+        bool hi_is_sum = false;
+        if (!INVERSE) {
+            const float pos = u * (float)K;
+            k = (int)floorf(pos);
+            k = k >= K ? K - 1 : (k < 0 ? 0 : k);
+            const float alpha = pos - (float)k;
+            double acc = 0.0;
+            for (int q = 0; q < k; ++q) acc += (double)pdf[q];
+            const float pk = pdf[k];
+            const float out = (float)acc + alpha * pk;
+            const float g_out = (out < 0.0f || out > 1.0f) ? 0.0f : gy * a.span_out;  // torch.clamp
+            g_lo = g_out;
+            g_pk = g_out * alpha + gl / pk;
+            g_u = g_out * pk * (float)K;
+        } else {
+            double acc = 0.0;
+            float prev = 0.0f, lo = 0.0f, hi = 0.0f;
+            for (int q = 0; q < K; ++q) {
+                acc += (double)pdf[q];
+                const float next = (q == K - 1) ? 1.0f + 1e-6f : (float)acc;
+                if (u >= prev) {
+                    k = q;
+                    lo = prev;
+                    hi = next;
+                }
+                prev = next;
+            }
+            if (k < 0 || u >= prev) {  // the forward pass flagged it
+                b.gx[i] = gy;
+                for (int q = 0; q < K; ++q) g0[q] = 0.0f;
+                continue;
+            }
+            const float step = 1.0f / (float)K;
+            const int half = (K + 1) / 2;
+            const float b0 = (k < half) ? (float)k * step : 1.0f - (float)(K - k) * step;
+            const float b1 = (k + 1 < half) ? (float)(k + 1) * step : 1.0f - (float)(K - k - 1) * step;
+            const float db = b1 - b0;
+            const float slope = (hi - lo) / db;
+            const float offset = hi - slope * b1;
+            const float q_ = (u - offset) / slope;
+            const float g_out = (q_ < 0.0f || q_ > 1.0f) ? 0.0f : gy * a.span_in;
+            g_u = g_out / slope;
+            const float g_off = -g_out / slope;
+            float g_slope = -g_out * q_ / slope - gl / slope;  // lad = -log(slope)
+            g_hi = g_off;
+            g_slope -= g_off * b1;
+            g_hi += g_slope / db;
+            g_lo = -g_slope / db;
+            hi_is_sum = k < K - 1;  // the last knot is the constant 1 (+1e-6)
+        }
+        // cdf[k] = sum_{q<k} pdf[q], cdf[k+1] = sum_{q<=k} pdf[q]; then the softmax
+        float dot = 0.0f;
+        for (int q = 0; q < K; ++q) {
+            float g = 0.0f;
+            if (q < k) g += g_lo;
+            if (q <= k && hi_is_sum) g += g_hi;
+            if (q == k) g += g_pk;
+            dot += g * pdf[q];
+        }
+        for (int q = 0; q < K; ++q) {
+            float g = 0.0f;
+            if (q < k) g += g_lo;
+            if (q <= k && hi_is_sum) g += g_hi;
+            if (q == k) g += g_pk;
+            g0[q] = pdf[q] * (g - dot);
+        }
+        b.gx[i] = INVERSE ? g_u / a.span_out : g_u / a.span_in;
+    }
+}
+
+template <bool INVERSE>
+__global__ void __launch_bounds__(kBlock) quadratic_spline_backward_kernel(const LqBwdArgs b) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LqArgs& a = b.f;
+    const int K = a.K, nh = a.nh;
+    const bool derived = nh == K - 1;
+    const int hs = derived ? 1 : 0;  // height logit q sits at slot q + hs
+    // per lane: W[K] | H[K+1] (unnormalised) | Hn[K+1] | gW[K] | gHn[K+1] (later gH)
+    float* W = lds + threadIdx.x * a.slot;
+    float* H = W + K;
+    float* Hn = H + K + 1;
+    float* gW = Hn + K + 1;
+    float* gH = gW + K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = b.x[i];
+        const float gy = b.gy[i], gl = b.gl ? b.gl[i] : 0.0f;
+        float* g0 = b.g0 + i * K;
+        float* g1 = b.g1 + i * nh;
+        bool live = x >= a.left && x <= a.right;
+        int k = -1;
+        float u = 0.0f, c0 = 0.0f, l0 = 0.0f, area = 1.0f, cst = 0.0f, cden = 1.0f;
+        if (live) {
+            u = INVERSE ? (x - a.bottom) / a.span_out : (x - a.left) / a.span_in;
+            for (int q = 0; q < K; ++q) W[q] = b.a0[i * K + q];
+            softmax_in_place<0>(W, K, a.divisor, a.rdivisor);
+            for (int q = 0; q < K; ++q) W[q] = a.min_w + a.om_w * W[q];
+            for (int q = 0; q < nh; ++q) {
+                float v = b.a1[i * nh + q];
+                if (a.divisor != 0.0f) v = div_with_rcp(v, a.divisor, a.rdivisor);
+                H[q + hs] = softplus_beta(v, 1.0f) + 1e-3f;
+            }
+            if (derived) {
+                const float fw = 0.5f * W[0], lw = 0.5f * W[K - 1];
+                float s = 0.0f;
+                for (int q = 1; q + 1 < K; ++q) s += ((H[q] + H[q + 1]) / 2.0f) * W[q];
+                const float num = (0.5f * fw) * H[1] + (0.5f * lw) * H[K - 1] + s;
+                cden = (1.0f - 0.5f * fw) - 0.5f * lw;
+                cst = num / cden;
+                H[0] = cst;
+                H[K] = cst;
+            }
+            area = 0.0f;
+            for (int q = 0; q < K; ++q) area += ((H[q] + H[q + 1]) / 2.0f) * W[q];
+            const float rarea = rcp_refined(area);
+            for (int q = 0; q <= K; ++q) Hn[q] = a.min_h + a.om_h * div_with_rcp(H[q], area, rarea);
+            double acc_c = 0.0, acc_l = 0.0;
+            float pc = 0.0f, pl = 0.0f;
+            for (int q = 0; q < K; ++q) {
+                acc_c += (double)(((Hn[q] + Hn[q + 1]) / 2.0f) * W[q]);
+                acc_l += (double)W[q];
+                const bool last = q == K - 1;
+                const float nc = last ? 1.0f : (float)acc_c, nl = last ? 1.0f : (float)acc_l;
+                if (u >= (INVERSE ? pc : pl)) {
+                    k = q;
+                    c0 = pc;
+                    l0 = pl;
+                }
+                pc = nc;
+                pl = nl;
+            }
+            if (k < 0 || u >= 1.0f + 1e-6f) live = false;
+        }
+        if (!live) {
+            b.gx[i] = gy;
+            for (int q = 0; q < K; ++q) g0[q] = 0.0f;
+            for (int q = 0; q < nh; ++q) g1[q] = 0.0f;
+            continue;
+        }
+        for (int q = 0; q < K; ++q) gW[q] = 0.0f;
+        for (int q = 0; q <= K; ++q) gH[q] = 0.0f;  // adjoints of the normalised heights first
+        const float bw = W[k], hl = Hn[k], hr = Hn[k + 1], dH = hr - hl;
+        const float qa = (0.5f * dH) * bw, qb = hl * bw;
+        float g_u, g_c0, g_l0, g_a, g_b, g_dH, g_hl, g_bw;
+        if (!INVERSE) {
+            const float alpha = (u - l0) / bw;
+            const float out = (qa * (alpha * alpha) + qb * alpha) + c0;
+            const float g_out = (out < 0.0f || out > 1.0f) ? 0.0f : gy * a.span_out;
+            const float D = alpha * dH + hl;
+            const float g_D = gl / D;
+            const float g_alpha = g_out * (2.0f * qa * alpha + qb) + g_D * dH;
+            g_a = g_out * alpha * alpha;
+            g_b = g_out * alpha;
+            g_c0 = g_out;
+            g_dH = g_D * alpha;
+            g_hl = g_D;
+            g_bw = -g_alpha * alpha / bw;
+            g_l0 = -g_alpha / bw;
+            g_u = g_alpha / bw;
+        } else {
+            const float c_ = c0 - u;
+            const float disc = qb * qb - (4.0f * qa) * c_;
+            const float r = sqrtf(disc);
+            const float alpha = (-qb + r) / (2.0f * qa);
+            const float out = alpha * bw + l0;
+            const float g_out = (out < 0.0f || out > 1.0f) ? 0.0f : gy * a.span_in;
+            const float D = alpha * dH + hl;
+            const float g_D = -gl / D;
+            const float g_alpha = g_out * bw + g_D * dH;
+            g_bw = g_out * alpha;
+            g_l0 = g_out;
+            g_dH = g_D * alpha;
+            g_hl = g_D;
+            const float inv2a = 1.0f / (2.0f * qa);
+            g_b = -g_alpha * inv2a;
+            g_a = -g_alpha * alpha / qa;
+            const float g_disc = (g_alpha * inv2a) / (2.0f * r);
+            g_b += 2.0f * qb * g_disc;
+            g_a -= 4.0f * c_ * g_disc;
+            const float g_c_ = -4.0f * qa * g_disc;
+            g_c0 = g_c_;
+            g_u = -g_c_;
+        }
+        // a = 0.5 dH bw, b = hl bw
+        g_dH += 0.5f * bw * g_a;
+        g_bw += 0.5f * dH * g_a + hl * g_b;
+        g_hl += bw * g_b;
+        gH[k + 1] += g_dH;
+        gH[k] += g_hl - g_dH;
+        gW[k] += g_bw;
+        // c0 = sum_{q<k} 0.5 (Hn[q] + Hn[q+1]) W[q],  l0 = sum_{q<k} W[q]
+        for (int q = 0; q < k; ++q) {
+            gH[q] += 0.5f * W[q] * g_c0;
+            gH[q + 1] += 0.5f * W[q] * g_c0;
+            gW[q] += 0.5f * (Hn[q] + Hn[q + 1]) * g_c0 + g_l0;
+        }
+        // Hn = min_h + om_h H / area,  area = sum 0.5 (H[q] + H[q+1]) W[q]
+        float g_area = 0.0f;
+        for (int q = 0; q <= K; ++q) {
+            g_area -= gH[q] * H[q];
+            gH[q] = a.om_h * gH[q] / area;  // now the adjoint of H[q] (first part)
+        }
+        g_area = a.om_h * g_area / (area * area);
+        for (int q = 0; q < K; ++q) {
+            gH[q] += 0.5f * W[q] * g_area;
+            gH[q + 1] += 0.5f * W[q] * g_area;
+            gW[q] += 0.5f * (H[q] + H[q + 1]) * g_area;
+        }
+        if (derived) {  // H[0] = H[K] = num / cden
+            const float g_c = gH[0] + gH[K];
+            const float g_num = g_c / cden, g_den = -g_c * cst / cden;
+            gW[0] += 0.25f * H[1] * g_num - 0.25f * g_den;
+            gW[K - 1] += 0.25f * H[K - 1] * g_num - 0.25f * g_den;
+            gH[1] += 0.25f * W[0] * g_num;
+            gH[K - 1] += 0.25f * W[K - 1] * g_num;
+            for (int q = 1; q + 1 < K; ++q) {
+                gH[q] += 0.5f * W[q] * g_num;
+                gH[q + 1] += 0.5f * W[q] * g_num;
+                gW[q] += 0.5f * (H[q] + H[q + 1]) * g_num;
+            }
+        }
+        const float sc = a.divisor != 0.0f ? a.rdivisor : 1.0f;
+        for (int q = 0; q < nh; ++q) {
+            float v = b.a1[i * nh + q];
+            if (a.divisor != 0.0f) v = div_with_rcp(v, a.divisor, a.rdivisor);
+            g1[q] = gH[q + hs] * sigmoid_of(v) * sc;
+        }
+        // W = min_w + om_w softmax(logits / divisor)
+        float dot = 0.0f;
+        for (int q = 0; q < K; ++q) {
+            const float sw = (W[q] - a.min_w) / a.om_w;
+            dot += a.om_w * gW[q] * sw;
+        }
+        for (int q = 0; q < K; ++q) {
+            const float sw = (W[q] - a.min_w) / a.om_w;
+            g0[q] = sw * (a.om_w * gW[q] - dot) * sc;
+        }
+        b.gx[i] = INVERSE ? g_u / a.span_out : g_u / a.span_in;
+    }
+}
+
+static int launch_lq_backward(LqBwdArgs& b, int kind, int inverse, hipStream_t st) {
+    const int K = b.f.K;
+    b.f.slot = (kind == kLinear ? K : 5 * K + 3) | 1;  // odd stride: conflict-free per-lane walks
+    int T = kBlock;
+    while (T > 64 && (size_t)T * b.f.slot * 4 > (size_t)64 * 1024) T >>= 1;
+    if ((size_t)T * b.f.slot * 4 > (size_t)64 * 1024) return NFA_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)T * b.f.slot * 4;
+    int64_t g = (b.n + T - 1) / T;
+    const int64_t cap = (int64_t)device_cu_count() * 8;
+    if (g > cap) g = cap;
+    const dim3 grid((unsigned)g), block((unsigned)T);
+    if (kind == kLinear) {
+        if (inverse) hipLaunchKernelGGL(linear_spline_backward_kernel<true>, grid, block, lds, st, b);
+        else hipLaunchKernelGGL(linear_spline_backward_kernel<false>, grid, block, lds, st, b);
+    } else {
+        if (inverse) hipLaunchKernelGGL(quadratic_spline_backward_kernel<true>, grid, block, lds, st, b);
+        else hipLaunchKernelGGL(quadratic_spline_backward_kernel<false>, grid, block, lds, st, b);
+    }
+    NFA_HIP_CHECK(hipGetLastError());
+    return NFA_OK;
+}
+
 }  // namespace nfa
 
 using namespace nfa;
@@ -565,4 +872,59 @@ extern "C" int nfa_cubic_spline_f32(const float* inputs, const float* unnormaliz
                unnorm_derivatives_right == unnormalized_widths + 2 * a.K + 1 && stride_w == P &&
                stride_h == P && stride_l == P && stride_r == P;
     return launch_lq(a, kCubic, inverse, (hipStream_t)stream);
+}
+
+extern "C" int nfa_linear_spline_backward_f32(const float* inputs, const float* unnormalized_pdf,
+                                              const float* grad_outputs, const float* grad_logabsdet,
+                                              float* grad_inputs, float* grad_unnormalized_pdf, int64_t n,
+                                              const nfa_rqs_spec* spec, int32_t inverse, void* stream) {
+    if (n < 0) return NFA_ERR_INVALID_ARGUMENT;
+    LqBwdArgs b;
+    int rc = fill_common(b.f, spec);
+    if (rc != NFA_OK) return rc;
+    if (n == 0) return NFA_OK;
+    if (!inputs || !unnormalized_pdf || !grad_outputs || !grad_inputs || !grad_unnormalized_pdf)
+        return NFA_ERR_INVALID_ARGUMENT;
+    b.x = inputs;
+    b.a0 = unnormalized_pdf;
+    b.a1 = nullptr;
+    b.gy = grad_outputs;
+    b.gl = grad_logabsdet;
+    b.gx = grad_inputs;
+    b.g0 = grad_unnormalized_pdf;
+    b.g1 = nullptr;
+    b.n = n;
+    b.f.nh = 0;
+    return launch_lq_backward(b, kLinear, inverse, (hipStream_t)stream);
+}
+
+extern "C" int nfa_quadratic_spline_backward_f32(const float* inputs, const float* unnormalized_widths,
+                                                 const float* unnormalized_heights, int32_t num_heights,
+                                                 const float* grad_outputs, const float* grad_logabsdet,
+                                                 float* grad_inputs, float* grad_unnormalized_widths,
+                                                 float* grad_unnormalized_heights, int64_t n,
+                                                 const nfa_rqs_spec* spec, int32_t inverse, void* stream) {
+    if (n < 0) return NFA_ERR_INVALID_ARGUMENT;
+    LqBwdArgs b;
+    int rc = fill_common(b.f, spec);
+    if (rc != NFA_OK) return rc;
+    if (spec->min_bin_width * spec->num_bins > 1.0) return NFA_ERR_MIN_BIN_WIDTH;
+    if (spec->min_bin_height * spec->num_bins > 1.0) return NFA_ERR_MIN_BIN_HEIGHT;
+    if (num_heights != b.f.K - 1 && num_heights != b.f.K + 1) return NFA_ERR_INVALID_ARGUMENT;
+    if (b.f.K < 2 && num_heights == b.f.K - 1) return NFA_ERR_INVALID_ARGUMENT;
+    if (n == 0) return NFA_OK;
+    if (!inputs || !unnormalized_widths || !unnormalized_heights || !grad_outputs || !grad_inputs ||
+        !grad_unnormalized_widths || !grad_unnormalized_heights)
+        return NFA_ERR_INVALID_ARGUMENT;
+    b.x = inputs;
+    b.a0 = unnormalized_widths;
+    b.a1 = unnormalized_heights;
+    b.gy = grad_outputs;
+    b.gl = grad_logabsdet;
+    b.gx = grad_inputs;
+    b.g0 = grad_unnormalized_widths;
+    b.g1 = grad_unnormalized_heights;
+    b.n = n;
+    b.f.nh = num_heights;
+    return launch_lq_backward(b, kQuadratic, inverse, (hipStream_t)stream);
 }

@@ -292,7 +292,12 @@ def linear_spline(inputs, unnormalized_pdf, spec, inverse=False):
     S; unnormalized_pdf S+[K].  Returns (outputs S, logabsdet S)."""
     N.require_device_f32("inputs", inputs)
     N.require_device_f32("unnormalized_pdf", unnormalized_pdf)
-    _no_backward_yet("the linear spline", inputs, unnormalized_pdf)
+    if AG.needs_grad(inputs, unnormalized_pdf):
+        return AG.LinearSpline.apply(inputs, unnormalized_pdf, spec, bool(inverse))
+    return _linear_spline_launch(inputs, unnormalized_pdf, spec, inverse)
+
+
+def _linear_spline_launch(inputs, unnormalized_pdf, spec, inverse):
     K = spec.num_bins
     shape = inputs.shape
     if unnormalized_pdf.shape != shape + (K,):
@@ -317,7 +322,12 @@ def quadratic_spline(inputs, unnormalized_widths, unnormalized_heights, spec, in
     N.require_device_f32("inputs", inputs)
     N.require_device_f32("unnormalized_widths", unnormalized_widths)
     N.require_device_f32("unnormalized_heights", unnormalized_heights)
-    _no_backward_yet("the quadratic spline", inputs, unnormalized_widths, unnormalized_heights)
+    if AG.needs_grad(inputs, unnormalized_widths, unnormalized_heights):
+        return AG.QuadraticSpline.apply(inputs, unnormalized_widths, unnormalized_heights, spec, bool(inverse))
+    return _quadratic_spline_launch(inputs, unnormalized_widths, unnormalized_heights, spec, inverse)
+
+
+def _quadratic_spline_launch(inputs, unnormalized_widths, unnormalized_heights, spec, inverse):
     K = spec.num_bins
     shape = inputs.shape
     nh = unnormalized_heights.shape[-1] if unnormalized_heights.dim() else -1

@@ -617,6 +617,58 @@ def sibling_spline_cases():
     print("sibling splines:", len(meta), "cases")
 
 
+def sibling_spline_grad_cases():
+    """Gradients of the linear / quadratic spline functionals by the reference's own autograd
+    (fp32 and fp64): d(sum(y * Wy) + sum(lad * Wl)) / d(inputs, logits), forward and inverse."""
+    out = {}
+    meta = []
+    g = torch.Generator().manual_seed(4242)
+
+    def finish(name, kind, fn, x, logits, kw):
+        wy = torch.randn(x.shape, generator=g)
+        wl = torch.randn(x.shape, generator=g)
+        for dtp, suf in ((torch.float32, ""), (torch.float64, "64")):
+            for inverse in (False, True):
+                xi = x.to(dtp).clone().requires_grad_(True)
+                args = [t.to(dtp).clone().requires_grad_(True) for t in logits]
+                y, lad = fn(xi, *args, inverse=inverse, **kw)
+                ((y * wy.to(dtp)).sum() + (lad * wl.to(dtp)).sum()).backward()
+                pre = "%s/%s" % (name, "inv_" if inverse else "")
+                out[pre + "gx" + suf] = npy(xi.grad)
+                for i, t in enumerate(args):
+                    out["%sglogits%d%s" % (pre, i, suf)] = npy(t.grad)
+        out[name + "/x"] = npy(x)
+        out[name + "/wy"] = npy(wy)
+        out[name + "/wl"] = npy(wl)
+        for i, t in enumerate(logits):
+            out["%s/logits%d" % (name, i)] = npy(t)
+        meta.append((name, kind, repr(kw)))
+
+    for K, n, scale in ((10, 300, 1.5), (4, 130, 2.5), (17, 200, 1.0)):
+        x = 0.02 + 0.96 * torch.rand(n, generator=g)  # away from the clamp at the box ends
+        pdf = scale * torch.randn(n, K, generator=g)
+        finish("lin_k%d" % K, "linear", splines.linear_spline, x, [pdf], {})
+        uw = scale * torch.randn(n, K, generator=g)
+        uh = scale * torch.randn(n, K + 1, generator=g)
+        finish("quad_k%d" % K, "quadratic", splines.quadratic_spline, x, [uw, uh], {})
+        B = 3.0
+        xu = 2.0 * torch.randn(n, generator=g)
+        xu[:3] = torch.tensor([B + 0.5, -B - 0.25, 0.0])
+        finish("ulin_k%d" % K, "linear", splines.unconstrained_linear_spline, xu, [pdf], dict(tail_bound=B, tails="linear"))
+        uh1 = scale * torch.randn(n, K - 1, generator=g)
+        finish("uquad_k%d" % K, "quadratic", splines.unconstrained_quadratic_spline, xu, [uw, uh1],
+               dict(tail_bound=B, tails="linear"))
+    x = 0.55 + 0.9 * torch.rand(3, 5, 7, generator=g)
+    finish("lin_box", "linear", splines.linear_spline, x, [torch.randn(3, 5, 7, 6, generator=g)],
+           dict(left=0.5, right=1.5, bottom=0.5, top=1.5))
+    finish("quad_box", "quadratic", splines.quadratic_spline, x,
+           [torch.randn(3, 5, 7, 6, generator=g), torch.randn(3, 5, 7, 7, generator=g)],
+           dict(left=0.5, right=1.5, bottom=0.5, top=1.5, min_bin_width=1e-2, min_bin_height=1e-2))
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "splines_lq_grads.npz"), **out)
+    print("sibling spline gradients:", len(meta), "cases")
+
+
 def sibling_coupling_cases():
     """Coupling layers outside the fused kernels: linear / quadratic piecewise couplings on [B, D]
     and spline couplings on [B, C, H, W] images with a ConvResidualNet conditioner."""
@@ -878,6 +930,9 @@ if __name__ == "__main__":
         cubic_spline_cases()
         cubic_coupling_cases()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "lqgrads":
+        sibling_spline_grad_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lq":
         sibling_spline_cases()
         sibling_coupling_cases()
@@ -901,6 +956,7 @@ if __name__ == "__main__":
     cdf_cases()
     flow_h128_case()
     sibling_spline_cases()
+    sibling_spline_grad_cases()
     sibling_coupling_cases()
     cubic_spline_cases()
     cubic_coupling_cases()

@@ -297,3 +297,55 @@ def test_conditioner_training_gradients_through_wgrad_kernel(monkeypatch):
         for a, b in zip(grads[0], grads[1 << 40]):
             scale = 1.0 + b.abs().max().item()
             assert (a - b).abs().max().item() <= 2e-5 * scale
+
+
+def test_sibling_spline_gradients_match_reference_autograd(golden_dir):
+    """tests/golden/splines_lq_grads.npz: gradients of the linear / quadratic spline functionals
+    (forward and inverse, constrained and with linear tails) from the reference's autograd."""
+    from nflows_amd.transforms import splines
+    G = np.load(os.path.join(golden_dir, "splines_lq_grads.npz"))
+    fns = {"lin": splines.linear_spline, "ulin": splines.unconstrained_linear_spline,
+           "quad": splines.quadratic_spline, "uquad": splines.unconstrained_quadratic_spline}
+    for name, kind, kw in G["meta"]:
+        fn = fns[name.split("_")[0]]
+        kwargs = parse_kwargs(kw)
+        n_logits = 1 if kind == "linear" else 2
+        for inverse in (False, True):
+            pre = "%s/%s" % (name, "inv_" if inverse else "")
+            x = dev(G[name + "/x"]).requires_grad_(True)
+            logits = [dev(G["%s/logits%d" % (name, i)]).requires_grad_(True) for i in range(n_logits)]
+            y, lad = fn(x, *logits, inverse=inverse, **kwargs)
+            ((y * dev(G[name + "/wy"])).sum() + (lad * dev(G[name + "/wl"])).sum()).backward()
+            close_to_truth(x.grad, G[pre + "gx"], G[pre + "gx64"], pre + "gx")
+            for i, t in enumerate(logits):
+                close_to_truth(t.grad, G["%sglogits%d" % (pre, i)], G["%sglogits%d64" % (pre, i)], "%sglogits%d" % (pre, i))
+    import nflows_amd
+    nflows_amd.ops._status_word(torch.device(DEV)).zero_()
+
+
+def test_sibling_spline_layers_train():
+    """A coupling flow on piecewise-linear / -quadratic layers takes optimisation steps (the
+    reference's training loop) and lowers its loss."""
+    from nflows_amd import transforms as T
+    from nflows_amd.distributions import StandardNormal
+    from nflows_amd.flows import Flow
+    from nflows_amd.nn.nets import ResidualNet
+    from nflows_amd.utils import torchutils
+    torch.manual_seed(1)
+    for cls, kw in ((T.PiecewiseLinearCouplingTransform, dict(num_bins=8, tails="linear", tail_bound=4.0)),
+                    (T.PiecewiseQuadraticCouplingTransform, dict(num_bins=8, tails="linear", tail_bound=4.0))):
+        layers = []
+        for i in range(2):
+            layers.append(cls(torchutils.create_alternating_binary_mask(6, even=(i % 2 == 0)),
+                              lambda a, b: ResidualNet(a, b, 32, num_blocks=1), **kw))
+        flow = Flow(T.CompositeTransform(layers), StandardNormal([6])).to(DEV).train()
+        opt = torch.optim.Adam(flow.parameters(), lr=5e-3)
+        data = torch.randn(2048, 6, device=DEV) * 0.6 + 0.4
+        losses = []
+        for _ in range(40):
+            opt.zero_grad()
+            loss = -flow.log_prob(data).mean()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        assert np.isfinite(losses).all() and losses[-1] < losses[0] - 0.05, losses[::10]

@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(256, 1) probe(const vec4f* w, float* out, int 
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < 768 * 2; i += 256) ring[i] = w[i];
     __syncthreads();
-    f32x16 acc = {0};
+    f32x16 acc = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
     bf16x8 b;
     for (int j = 0; j < 8; ++j) b[j] = (__bf16)(0.01f * (lane + j));
     float v[16];
@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256, 1) probe(const vec4f* w, float* out, int 
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int r = 0; r < regions; ++r) {
         const vec4f* cur = ring + (r & 1) * 768 + lane;
-        if (MODE != 4 && (MODE & 1)) {
+        if (MODE < 4 && (MODE & 1)) {
             if (PREFETCH) {  // all 12 fragments of the region requested up front
                 bf16x8 a[12];
 #pragma unroll
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256, 1) probe(const vec4f* w, float* out, int 
                 }
             }
         }
-        if (MODE != 4 && (MODE & 2)) {  // ~130 VALU ops incl. 16 exps: the size of one spline chunk
+        if (MODE < 4 && (MODE & 2)) {  // ~130 VALU ops incl. 16 exps: the size of one spline chunk
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 float t = v[j] * 0.7f - 0.3f;
@@ -61,6 +61,21 @@ __global__ void __launch_bounds__(256, 1) probe(const vec4f* w, float* out, int 
                 t = __builtin_fmaf(t, 0.3f, -0.1f);
                 t = t - v[(j + 5) & 15] * 0.001f;
                 v[j] = t * 0.5f + 0.1f;
+            }
+        }
+        if (MODE == 8 || MODE == 9) {
+            // 24 MFMAs spread over four independent accumulators: round robin (8) or in four chains of
+            // six dependent ones (9, the order of K8's k-major GEMM)
+            bf16x8 a[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) a[i] = __builtin_bit_cast(bf16x8, cur[i * 64]);
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                const int t = MODE == 8 ? (i & 3) : (i / 6);
+                if (t == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % 12], b, acc, 0, 0, 0);
+                if (t == 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % 12], b, acc1, 0, 0, 0);
+                if (t == 2) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % 12], b, acc2, 0, 0, 0);
+                if (t == 3) acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % 12], b, acc3, 0, 0, 0);
             }
         }
         if (MODE == 4) {
@@ -89,7 +104,7 @@ __global__ void __launch_bounds__(256, 1) probe(const vec4f* w, float* out, int 
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     float s = 0.f;
-    for (int j = 0; j < 16; ++j) s += v[j] + acc[j];
+    for (int j = 0; j < 16; ++j) s += v[j] + acc[j] + acc1[j] + acc2[j] + acc3[j];
     if (s == 1.2345f) out[0] = s;
     if (tid == 0 && blockIdx.x == 0) cyc[0] = (t1 - t0) / regions;
 }
@@ -118,5 +133,7 @@ int main() {
     run<3, 0>("both, fragments per k-step", w, out, cyc);
     run<3, 1>("both, fragments up front", w, out, cyc);
     run<4, 0>("both, hand-placed with sched_barrier fences", w, out, cyc);
+    run<8, 0>("24 MFMAs, 4 accumulators round robin", w, out, cyc);
+    run<9, 0>("24 MFMAs, 4 chains of 6 dependent", w, out, cyc);
     return 0;
 }
