@@ -348,10 +348,10 @@ int nfa_standard_normal_log_prob_f32(const float *z, const float *logabsdet, flo
                                      int64_t rows, int64_t cols, void *stream);
 
 /*
- * Backward of the linear and quadratic spline functionals (the reference differentiates
- * splines/linear.py:40-105 and splines/quadratic.py:55-159 by autograd through their eager ops).
- * Dense rows: unnormalized_pdf / unnormalized_widths [n, num_bins], unnormalized_heights
- * [n, num_heights]; grad_outputs, grad_logabsdet (may be NULL = 0), grad_inputs [n]; the logit
+ * Backward of the linear, quadratic and cubic spline functionals (the reference differentiates
+ * splines/linear.py:40-105, splines/quadratic.py:55-159 and splines/cubic.py:63-267 by autograd
+ * through their eager ops).  Dense rows: unnormalized_pdf / unnormalized_widths [n, num_bins],
+ * unnormalized_heights [n, num_heights] (cubic: [n, num_bins]), boundary-derivative logits [n]; grad_outputs, grad_logabsdet (may be NULL = 0), grad_inputs [n]; the logit
  * gradients have the logits' shapes.  `inputs` are the inputs of the pass that is differentiated
  * (inverse != 0: of the inverse pass).  Elements in the linear tails / outside the box get
  * grad_inputs = grad_outputs and zero logit gradients.
@@ -366,6 +366,16 @@ int nfa_quadratic_spline_backward_f32(const float *inputs, const float *unnormal
                                       float *grad_inputs, float *grad_unnormalized_widths,
                                       float *grad_unnormalized_heights, int64_t n,
                                       const nfa_rqs_spec *spec, int32_t inverse, void *stream);
+
+int nfa_cubic_spline_backward_f32(const float *inputs, const float *unnormalized_widths,
+                                  const float *unnormalized_heights,
+                                  const float *unnorm_derivatives_left,
+                                  const float *unnorm_derivatives_right, const float *grad_outputs,
+                                  const float *grad_logabsdet, float *grad_inputs,
+                                  float *grad_unnormalized_widths, float *grad_unnormalized_heights,
+                                  float *grad_unnorm_derivatives_left,
+                                  float *grad_unnorm_derivatives_right, int64_t n,
+                                  const nfa_rqs_spec *spec, int32_t inverse, void *stream);
 
 /*
  * K10.  Weight and bias gradient of a conditioner layer y = x W^T + b (torch.nn.Linear; the

@@ -46,6 +46,7 @@ EXPORTS = (
     "nfa_cubic_spline_f32",
     "nfa_linear_spline_backward_f32",
     "nfa_quadratic_spline_backward_f32",
+    "nfa_cubic_spline_backward_f32",
     "nfa_rqs_elementwise_f32",
     "nfa_rqs_shared_f32",
     "nfa_affine_coupling_f32",
@@ -117,6 +118,8 @@ def _declare(lib):
     lib.nfa_linear_spline_backward_f32.argtypes = [vp] * 6 + [i64, sp, i32, vp]
     lib.nfa_quadratic_spline_backward_f32.restype = ctypes.c_int
     lib.nfa_quadratic_spline_backward_f32.argtypes = [vp, vp, vp, i32] + [vp] * 5 + [i64, sp, i32, vp]
+    lib.nfa_cubic_spline_backward_f32.restype = ctypes.c_int
+    lib.nfa_cubic_spline_backward_f32.argtypes = [vp] * 12 + [i64, sp, i32, vp]
     lib.nfa_rqs_flow_resnet_f32.restype = ctypes.c_int
     lib.nfa_rqs_flow_resnet_f32.argtypes = [vp] * 4 + [i32] + [vp] * 3 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
     lib.nfa_rqs_coupling_resnet_f32.restype = ctypes.c_int

@@ -315,3 +315,37 @@ class QuadraticSpline(torch.autograd.Function):
                 N.ptr(g_h), n, ctypes.byref(ctx.spec), int(ctx.inverse), N.stream_handle(dev))
         N.check(rc)
         return g_in.view(inputs.shape), g_w.view(uw.shape), g_h.view(uh.shape), None, None
+
+
+class CubicSpline(torch.autograd.Function):
+    """K9 cubic spline forward + `nfa_cubic_spline_backward_f32`."""
+
+    @staticmethod
+    def forward(ctx, inputs, uw, uh, udl, udr, spec, inverse):
+        from . import ops
+        y, lad = ops._cubic_spline_launch(inputs, uw, uh, udl, udr, spec, inverse)
+        ctx.save_for_backward(inputs, uw, uh, udl, udr)
+        ctx.spec, ctx.inverse = spec, bool(inverse)
+        return y, lad
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_y, g_lad):
+        inputs, uw, uh, udl, udr = ctx.saved_tensors
+        K = ctx.spec.num_bins
+        n, dev = inputs.numel(), inputs.device
+        x = inputs.detach().contiguous().view(-1)
+        w_rows, h_rows = _dense_rows(uw, n, K), _dense_rows(uh, n, K)
+        l_rows, r_rows = _dense_rows(udl, n, 1), _dense_rows(udr, n, 1)
+        g_y = torch.zeros_like(x) if g_y is None else g_y.contiguous().view(-1)
+        g_lad = None if g_lad is None else g_lad.contiguous().view(-1)
+        g_in, g_w, g_h = torch.empty_like(x), torch.empty_like(w_rows), torch.empty_like(h_rows)
+        g_l, g_r = torch.empty_like(l_rows), torch.empty_like(r_rows)
+        with torch.cuda.device(dev):
+            rc = N.load().nfa_cubic_spline_backward_f32(
+                N.ptr(x), N.ptr(w_rows), N.ptr(h_rows), N.ptr(l_rows), N.ptr(r_rows), N.ptr(g_y), N.ptr(g_lad),
+                N.ptr(g_in), N.ptr(g_w), N.ptr(g_h), N.ptr(g_l), N.ptr(g_r), n, ctypes.byref(ctx.spec),
+                int(ctx.inverse), N.stream_handle(dev))
+        N.check(rc)
+        return (g_in.view(inputs.shape), g_w.view(uw.shape), g_h.view(uh.shape), g_l.view(udl.shape),
+                g_r.view(udr.shape), None, None)

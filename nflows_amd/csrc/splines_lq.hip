@@ -218,6 +218,45 @@ __device__ __forceinline__ float cbrt_like_reference(float x) {
 
 __device__ __forceinline__ float sign_of(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
 
+// Root of ca s^3 + cb s^2 + cc s + cd = u reported as lcw + s, by the reference's case analysis
+// (cubic.py:151-226): one real root, three real roots (the one inside the bin, +- 1e-5), and the
+// "almost quadratic" override for |ca| < 1e-3.
+__device__ __forceinline__ float cubic_inverse_root(float ca, float cb, float cc, float cd, float u, float lcw,
+                                                    float rcw, bool& almost_quadratic) {
+#pragma clang fp contract(off)
+    const float b_ = (cb / ca) / 3.0f, c_ = (cc / ca) / 3.0f, d_ = (cd - u) / ca;
+    const float d1 = -(b_ * b_) + c_;
+    const float d2 = (-c_) * b_ + d_;
+    const float d3 = b_ * d_ - c_ * c_;
+    const float disc = (4.0f * d1) * d3 - d2 * d2;
+    const float dep1 = (-2.0f * b_) * d1 + d2;
+    float out = 0.0f;
+    if (disc < 0.0f) {  // one real root
+        const float sq = sqrtf(-disc);
+        const float p = cbrt_like_reference((-dep1 + sq) / 2.0f);
+        const float q = cbrt_like_reference((-dep1 - sq) / 2.0f);
+        out = ((p + q) - b_) + lcw;
+    } else if (disc >= 0.0f) {  // three real roots: the one inside the bin (+- eps)
+        const float theta = atan2f(sqrtf(disc), -dep1) / 3.0f;
+        const float c1 = cosf(theta), s1 = sinf(theta);
+        const float hs3 = 0.8660254037844386f;  // 0.5 * sqrt(3)
+        const float scale = 2.0f * sqrtf(-d1);
+        const float shift = -b_ + lcw;
+        const float r1 = c1 * scale + shift;
+        const float r2 = (-0.5f * c1 - hs3 * s1) * scale + shift;
+        const float r3 = (-0.5f * c1 + hs3 * s1) * scale + shift;
+        const float lo = lcw - 1e-5f, hi = rcw + 1e-5f;
+        const bool m1 = lo < r1 && r1 < hi, m2 = lo < r2 && r2 < hi, m3 = lo < r3 && r3 < hi;
+        out = m1 ? r1 : (m2 ? r2 : (m3 ? r3 : r1));
+    }
+    if (fabsf(ca) < 1e-3f) {  // almost quadratic (:219-226)
+        const float alpha = (-cc + sqrtf(cc * cc - (4.0f * cb) * (cd - u))) / (2.0f * cb);
+        out = alpha + lcw;
+    }
+    almost_quadratic = fabsf(ca) < 1e-3f;
+    return out;
+}
+
 // splines/cubic.py:63-267.  w / h: K width / height logits (overwritten by the bin widths / heights),
 // udl / udr: the two boundary-derivative logits.  The coefficients of the searched bin are formed
 // from its neighbours during one walk over the bins (no data-dependent indexing).
@@ -290,35 +329,9 @@ __device__ __forceinline__ int cubic_eval(float x, float* w, float* h, float udl
     const float cb = ((3.0f * bs - 2.0f * dl) - dr) / bw;
     const float cc = dl, cd = lch;
     if (INVERSE) {
-        const float b_ = (cb / ca) / 3.0f, c_ = (cc / ca) / 3.0f, d_ = (cd - u) / ca;
-        const float d1 = -(b_ * b_) + c_;
-        const float d2 = (-c_) * b_ + d_;
-        const float d3 = b_ * d_ - c_ * c_;
-        const float disc = (4.0f * d1) * d3 - d2 * d2;
-        const float dep1 = (-2.0f * b_) * d1 + d2;
-        float out = 0.0f;
-        if (disc < 0.0f) {  // one real root
-            const float sq = sqrtf(-disc);
-            const float p = cbrt_like_reference((-dep1 + sq) / 2.0f);
-            const float q = cbrt_like_reference((-dep1 - sq) / 2.0f);
-            out = ((p + q) - b_) + lcw;
-        } else if (disc >= 0.0f) {  // three real roots: the one inside the bin (+- eps)
-            const float theta = atan2f(sqrtf(disc), -dep1) / 3.0f;
-            const float c1 = cosf(theta), s1 = sinf(theta);
-            const float hs3 = 0.8660254037844386f;  // 0.5 * sqrt(3)
-            const float scale = 2.0f * sqrtf(-d1);
-            const float shift = -b_ + lcw;
-            const float r1 = c1 * scale + shift;
-            const float r2 = (-0.5f * c1 - hs3 * s1) * scale + shift;
-            const float r3 = (-0.5f * c1 + hs3 * s1) * scale + shift;
-            const float lo = lcw - 1e-5f, hi = rcw + 1e-5f;
-            const bool m1 = lo < r1 && r1 < hi, m2 = lo < r2 && r2 < hi, m3 = lo < r3 && r3 < hi;
-            out = m1 ? r1 : (m2 ? r2 : (m3 ? r3 : r1));
-        }
-        if (fabsf(ca) < 1e-3f) {  // almost quadratic (:219-226)
-            const float alpha = (-cc + sqrtf(cc * cc - (4.0f * cb) * (cd - u))) / (2.0f * cb);
-            out = alpha + lcw;
-        }
+        bool almost_quadratic;
+        const float out = cubic_inverse_root(ca, cb, cc, cd, u, lcw, rcw, almost_quadratic);
+        (void)almost_quadratic;
         const float so = out - lcw;
         lad = -logf(((3.0f * ca) * (so * so) + (2.0f * cb) * so) + cc);
         y = out * a.span_in + a.left;
@@ -480,12 +493,16 @@ static int fill_common(LqArgs& a, const nfa_rqs_spec* spec) {
 struct LqBwdArgs {
     const float* x;
     const float* a0;  // [n, K] pdf / width logits
-    const float* a1;  // [n, nh] height logits (quadratic)
+    const float* a1;  // [n, nh] height logits (quadratic), [n, K] (cubic)
+    const float* a2;  // [n] left / right boundary-derivative logits (cubic)
+    const float* a3;
     const float* gy;  // [n] upstream gradient of outputs
     const float* gl;  // [n] upstream gradient of logabsdet (may be null)
     float* gx;        // [n]
     float* g0;        // [n, K]
     float* g1;        // [n, nh]
+    float* g2;        // [n] (cubic)
+    float* g3;
     int64_t n;
     LqArgs f;         // the forward description (box, minimums, divisor)
 };
@@ -754,9 +771,208 @@ __global__ void __launch_bounds__(kBlock) quadratic_spline_backward_kernel(const
     }
 }
 
+// Cubic spline (splines/cubic.py:63-267).  Only the searched bin's cubic matters: its coefficients
+// depend on the prefix sums below it, on its own width / height and on the knot derivatives at its
+// two ends, each a function of the two bins that meet there (or of a boundary logit).  The inverse
+// direction differentiates the root implicitly (ds/dp = -(dF/dp) / F'(s)), which equals the derivative
+// of whichever closed-form root the forward pass took; the "almost quadratic" override (:219-226)
+// has its own explicit formula and is differentiated as such.
+template <bool INVERSE>
+__global__ void __launch_bounds__(kBlock) cubic_spline_backward_kernel(const LqBwdArgs b) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const LqArgs& a = b.f;
+    const int K = a.K;
+    float* w = lds + threadIdx.x * a.slot;  // widths | heights | their adjoints
+    float* h = w + K;
+    float* gw = h + K;
+    float* gh = gw + K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = b.x[i];
+        const float gy = b.gy[i], gl = b.gl ? b.gl[i] : 0.0f;
+        float* g0 = b.g0 + i * K;
+        float* g1 = b.g1 + i * K;
+        bool live = x >= a.left && x <= a.right;
+        int k = -1;
+        float u = 0.0f, lcw = 0.0f, rcw = 0.0f, lch = 0.0f;
+        if (live) {
+            u = INVERSE ? (x - a.bottom) / a.span_out : (x - a.left) / a.span_in;
+            for (int q = 0; q < K; ++q) {
+                w[q] = b.a0[i * K + q];
+                h[q] = b.a1[i * K + q];
+            }
+            softmax_in_place<0>(w, K, a.divisor, a.rdivisor);
+            softmax_in_place<0>(h, K, a.divisor, a.rdivisor);
+            for (int q = 0; q < K; ++q) {
+                w[q] = a.min_w + a.om_w * w[q];
+                h[q] = a.min_h + a.om_hk * h[q];
+            }
+            double acc_w = 0.0, acc_h = 0.0;
+            float pw = 0.0f, ph = 0.0f;
+            for (int q = 0; q < K; ++q) {
+                acc_w += (double)w[q];
+                acc_h += (double)h[q];
+                const bool last = q == K - 1;
+                const float nw = last ? 1.0f : (float)acc_w, nh = last ? 1.0f : (float)acc_h;
+                if (u >= (INVERSE ? ph : pw)) {
+                    k = q;
+                    lcw = pw;
+                    rcw = nw;
+                    lch = ph;
+                }
+                pw = nw;
+                ph = nh;
+            }
+            if (k < 0 || u >= 1.0f + 1e-6f) live = false;
+        }
+        if (!live) {
+            b.gx[i] = gy;
+            for (int q = 0; q < K; ++q) {
+                g0[q] = 0.0f;
+                g1[q] = 0.0f;
+            }
+            b.g2[i] = 0.0f;
+            b.g3[i] = 0.0f;
+            continue;
+        }
+        const float udl = b.a2[i], udr = b.a3[i];
+        const float sgl = 1.0f / (1.0f + expf(-udl)), sgr = 1.0f / (1.0f + expf(-udr));
+        // knot derivative at the left end of bin j (j = 0: boundary logit) -- value only
+        auto knot_derivative = [&](int j) -> float {
+            if (j == 0) return (sgl * 3.0f) * (h[0] / w[0]);
+            if (j == K) return (sgr * 3.0f) * (h[K - 1] / w[K - 1]);
+            const float sp = h[j - 1] / w[j - 1], sn = h[j] / w[j];
+            const float m1 = fminf(fabsf(sp), fabsf(sn));
+            const float m2 = (0.5f * (w[j] * sp + w[j - 1] * sn)) / (w[j - 1] + w[j]);
+            return fminf(m1, m2) * (sign_of(sp) + sign_of(sn));
+        };
+        const float bw = w[k], bs = h[k] / w[k];
+        const float dl = knot_derivative(k), dr = knot_derivative(k + 1);
+        const float ca = ((dl + dr) - 2.0f * bs) / (bw * bw);
+        const float cb = ((3.0f * bs - 2.0f * dl) - dr) / bw;
+        const float cc = dl, cd = lch;
+        float g_ca, g_cb, g_cc, g_cd, g_u, g_lcw;
+        if (!INVERSE) {
+            const float s = u - lcw;
+            const float P = ((3.0f * ca) * (s * s) + (2.0f * cb) * s) + cc;  // f'(s)
+            const float g_out = gy * a.span_out;
+            const float g_P = gl / P;
+            const float g_s = g_out * P + g_P * (6.0f * ca * s + 2.0f * cb);
+            g_ca = g_out * s * s * s + g_P * 3.0f * s * s;
+            g_cb = g_out * s * s + g_P * 2.0f * s;
+            g_cc = g_out * s + g_P;
+            g_cd = g_out;
+            g_u = g_s;
+            g_lcw = -g_s;
+        } else {
+            bool almost_quadratic;
+            const float out = cubic_inverse_root(ca, cb, cc, cd, u, lcw, rcw, almost_quadratic);
+            const float s = out - lcw;
+            const float P = ((3.0f * ca) * (s * s) + (2.0f * cb) * s) + cc;
+            const float g_out = gy * a.span_in;
+            const float g_P = -gl / P;  // lad = -log P
+            const float g_s = g_out + g_P * (6.0f * ca * s + 2.0f * cb);
+            g_ca = g_P * 3.0f * s * s;
+            g_cb = g_P * 2.0f * s;
+            g_cc = g_P;
+            g_cd = 0.0f;
+            g_lcw = g_out;  // out = lcw + s
+            if (almost_quadratic) {  // s = (-cc + sqrt(cc^2 - 4 cb (cd - u))) / (2 cb)
+                const float r = sqrtf(cc * cc - (4.0f * cb) * (cd - u));
+                g_cc += g_s * (-1.0f + cc / r) / (2.0f * cb);
+                g_cb += g_s * (-(cd - u) / (r * cb) - s / cb);
+                g_cd += -g_s / r;
+                g_u = g_s / r;
+            } else {  // F(s) = ca s^3 + cb s^2 + cc s + cd - u = 0
+                const float t = g_s / P;
+                g_ca -= t * s * s * s;
+                g_cb -= t * s * s;
+                g_cc -= t * s;
+                g_cd -= t;
+                g_u = t;
+            }
+        }
+        // ca = (dl + dr - 2 bs) / bw^2,  cb = (3 bs - 2 dl - dr) / bw,  cc = dl,  cd = lch
+        const float rb = 1.0f / bw, rb2 = rb * rb;
+        const float g_dl = g_ca * rb2 - 2.0f * g_cb * rb + g_cc;
+        const float g_dr = g_ca * rb2 - g_cb * rb;
+        const float g_bs = -2.0f * g_ca * rb2 + 3.0f * g_cb * rb;
+        const float g_bw = -2.0f * g_ca * ca * rb - g_cb * cb * rb;
+        for (int q = 0; q < K; ++q) {
+            gw[q] = q < k ? g_lcw : 0.0f;   // lcw = sum_{q<k} w, lch = sum_{q<k} h
+            gh[q] = q < k ? g_cd : 0.0f;
+        }
+        gw[k] += g_bw - g_bs * bs * rb;     // bs = h[k] / w[k]
+        gh[k] += g_bs * rb;
+        float g_udl = 0.0f, g_udr = 0.0f;
+        // adjoint of the knot derivative at the left end of bin j
+        auto knot_derivative_adjoint = [&](int j, float g) {
+            if (j == 0) {
+                const float s0 = h[0] / w[0];
+                g_udl += g * 3.0f * s0 * sgl * (1.0f - sgl);
+                gh[0] += g * 3.0f * sgl / w[0];
+                gw[0] -= g * 3.0f * sgl * s0 / w[0];
+                return;
+            }
+            if (j == K) {
+                const float s0 = h[K - 1] / w[K - 1];
+                g_udr += g * 3.0f * s0 * sgr * (1.0f - sgr);
+                gh[K - 1] += g * 3.0f * sgr / w[K - 1];
+                gw[K - 1] -= g * 3.0f * sgr * s0 / w[K - 1];
+                return;
+            }
+            const float wp = w[j - 1], wn = w[j];
+            const float sp = h[j - 1] / wp, sn = h[j] / wn;
+            const float sg = sign_of(sp) + sign_of(sn);
+            const float m1 = fminf(fabsf(sp), fabsf(sn));
+            const float den = wp + wn;
+            const float m2 = (0.5f * (wn * sp + wp * sn)) / den;
+            float g_sp = 0.0f, g_sn = 0.0f;
+            const float gm = g * sg;
+            if (m1 < m2 || (m1 == m2)) {
+                const float share = m1 == m2 ? 0.5f : 1.0f;  // torch.min splits ties
+                if (fabsf(sp) < fabsf(sn)) g_sp += share * gm * sign_of(sp);
+                else if (fabsf(sn) < fabsf(sp)) g_sn += share * gm * sign_of(sn);
+                else {
+                    g_sp += 0.5f * share * gm * sign_of(sp);
+                    g_sn += 0.5f * share * gm * sign_of(sn);
+                }
+            }
+            if (m2 < m1 || (m1 == m2)) {
+                const float share = m1 == m2 ? 0.5f : 1.0f;
+                const float gm2 = share * gm;
+                g_sp += gm2 * 0.5f * wn / den;
+                g_sn += gm2 * 0.5f * wp / den;
+                gw[j] += gm2 * (0.5f * sp / den - m2 / den);
+                gw[j - 1] += gm2 * (0.5f * sn / den - m2 / den);
+            }
+            gh[j - 1] += g_sp / wp;
+            gw[j - 1] -= g_sp * sp / wp;
+            gh[j] += g_sn / wn;
+            gw[j] -= g_sn * sn / wn;
+        };
+        knot_derivative_adjoint(k, g_dl);
+        knot_derivative_adjoint(k + 1, g_dr);
+        // w = min_w + om_w softmax(logits / divisor), h = min_h + om_hk softmax(logits / divisor)
+        const float sc = a.divisor != 0.0f ? a.rdivisor : 1.0f;
+        float dot_w = 0.0f, dot_h = 0.0f;
+        for (int q = 0; q < K; ++q) {
+            dot_w += a.om_w * gw[q] * ((w[q] - a.min_w) / a.om_w);
+            dot_h += a.om_hk * gh[q] * ((h[q] - a.min_h) / a.om_hk);
+        }
+        for (int q = 0; q < K; ++q) {
+            g0[q] = ((w[q] - a.min_w) / a.om_w) * (a.om_w * gw[q] - dot_w) * sc;
+            g1[q] = ((h[q] - a.min_h) / a.om_hk) * (a.om_hk * gh[q] - dot_h) * sc;
+        }
+        b.g2[i] = g_udl;
+        b.g3[i] = g_udr;
+        b.gx[i] = INVERSE ? g_u / a.span_out : g_u / a.span_in;
+    }
+}
+
 static int launch_lq_backward(LqBwdArgs& b, int kind, int inverse, hipStream_t st) {
     const int K = b.f.K;
-    b.f.slot = (kind == kLinear ? K : 5 * K + 3) | 1;  // odd stride: conflict-free per-lane walks
+    b.f.slot = (kind == kLinear ? K : (kind == kCubic ? 4 * K : 5 * K + 3)) | 1;  // odd stride: conflict-free per-lane walks
     int T = kBlock;
     while (T > 64 && (size_t)T * b.f.slot * 4 > (size_t)64 * 1024) T >>= 1;
     if ((size_t)T * b.f.slot * 4 > (size_t)64 * 1024) return NFA_ERR_UNSUPPORTED;
@@ -768,9 +984,12 @@ static int launch_lq_backward(LqBwdArgs& b, int kind, int inverse, hipStream_t s
     if (kind == kLinear) {
         if (inverse) hipLaunchKernelGGL(linear_spline_backward_kernel<true>, grid, block, lds, st, b);
         else hipLaunchKernelGGL(linear_spline_backward_kernel<false>, grid, block, lds, st, b);
-    } else {
+    } else if (kind == kQuadratic) {
         if (inverse) hipLaunchKernelGGL(quadratic_spline_backward_kernel<true>, grid, block, lds, st, b);
         else hipLaunchKernelGGL(quadratic_spline_backward_kernel<false>, grid, block, lds, st, b);
+    } else {
+        if (inverse) hipLaunchKernelGGL(cubic_spline_backward_kernel<true>, grid, block, lds, st, b);
+        else hipLaunchKernelGGL(cubic_spline_backward_kernel<false>, grid, block, lds, st, b);
     }
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
@@ -887,7 +1106,8 @@ extern "C" int nfa_linear_spline_backward_f32(const float* inputs, const float* 
         return NFA_ERR_INVALID_ARGUMENT;
     b.x = inputs;
     b.a0 = unnormalized_pdf;
-    b.a1 = nullptr;
+    b.a1 = b.a2 = b.a3 = nullptr;
+    b.g2 = b.g3 = nullptr;
     b.gy = grad_outputs;
     b.gl = grad_logabsdet;
     b.gx = grad_inputs;
@@ -919,6 +1139,8 @@ extern "C" int nfa_quadratic_spline_backward_f32(const float* inputs, const floa
     b.x = inputs;
     b.a0 = unnormalized_widths;
     b.a1 = unnormalized_heights;
+    b.a2 = b.a3 = nullptr;
+    b.g2 = b.g3 = nullptr;
     b.gy = grad_outputs;
     b.gl = grad_logabsdet;
     b.gx = grad_inputs;
@@ -927,4 +1149,41 @@ extern "C" int nfa_quadratic_spline_backward_f32(const float* inputs, const floa
     b.n = n;
     b.f.nh = num_heights;
     return launch_lq_backward(b, kQuadratic, inverse, (hipStream_t)stream);
+}
+
+extern "C" int nfa_cubic_spline_backward_f32(const float* inputs, const float* unnormalized_widths,
+                                             const float* unnormalized_heights,
+                                             const float* unnorm_derivatives_left,
+                                             const float* unnorm_derivatives_right, const float* grad_outputs,
+                                             const float* grad_logabsdet, float* grad_inputs,
+                                             float* grad_unnormalized_widths, float* grad_unnormalized_heights,
+                                             float* grad_unnorm_derivatives_left,
+                                             float* grad_unnorm_derivatives_right, int64_t n,
+                                             const nfa_rqs_spec* spec, int32_t inverse, void* stream) {
+    if (n < 0) return NFA_ERR_INVALID_ARGUMENT;
+    LqBwdArgs b;
+    int rc = fill_common(b.f, spec);
+    if (rc != NFA_OK) return rc;
+    if (spec->min_bin_width * spec->num_bins > 1.0) return NFA_ERR_MIN_BIN_WIDTH;
+    if (spec->min_bin_height * spec->num_bins > 1.0) return NFA_ERR_MIN_BIN_HEIGHT;
+    if (n == 0) return NFA_OK;
+    if (!inputs || !unnormalized_widths || !unnormalized_heights || !unnorm_derivatives_left ||
+        !unnorm_derivatives_right || !grad_outputs || !grad_inputs || !grad_unnormalized_widths ||
+        !grad_unnormalized_heights || !grad_unnorm_derivatives_left || !grad_unnorm_derivatives_right)
+        return NFA_ERR_INVALID_ARGUMENT;
+    b.x = inputs;
+    b.a0 = unnormalized_widths;
+    b.a1 = unnormalized_heights;
+    b.a2 = unnorm_derivatives_left;
+    b.a3 = unnorm_derivatives_right;
+    b.gy = grad_outputs;
+    b.gl = grad_logabsdet;
+    b.gx = grad_inputs;
+    b.g0 = grad_unnormalized_widths;
+    b.g1 = grad_unnormalized_heights;
+    b.g2 = grad_unnorm_derivatives_left;
+    b.g3 = grad_unnorm_derivatives_right;
+    b.n = n;
+    b.f.nh = b.f.K;
+    return launch_lq_backward(b, kCubic, inverse, (hipStream_t)stream);
 }

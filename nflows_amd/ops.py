@@ -281,12 +281,6 @@ def _logit_rows(t, n, width):
     return v, (v.stride(0) if n > 1 else width)
 
 
-def _no_backward_yet(what, *tensors):
-    if AG.needs_grad(*tensors):
-        raise NotImplementedError("nflows_amd: %s has no backward kernel yet; evaluate under "
-                                  "torch.no_grad() or detach the inputs" % what)
-
-
 def linear_spline(inputs, unnormalized_pdf, spec, inverse=False):
     """K9 -- piecewise-linear spline functional (splines/linear.py) on tensors of any leading shape
     S; unnormalized_pdf S+[K].  Returns (outputs S, logabsdet S)."""
@@ -357,7 +351,13 @@ def cubic_spline(inputs, unnormalized_widths, unnormalized_heights, unnorm_deriv
     for nm, t in zip(("inputs", "unnormalized_widths", "unnormalized_heights", "unnorm_derivatives_left",
                       "unnorm_derivatives_right"), tensors):
         N.require_device_f32(nm, t)
-    _no_backward_yet("the cubic spline", *tensors)
+    if AG.needs_grad(*tensors):
+        return AG.CubicSpline.apply(*tensors, spec, bool(inverse))
+    return _cubic_spline_launch(*tensors, spec, inverse)
+
+
+def _cubic_spline_launch(inputs, unnormalized_widths, unnormalized_heights, unnorm_derivatives_left,
+                         unnorm_derivatives_right, spec, inverse):
     K = spec.num_bins
     shape = inputs.shape
     if (unnormalized_widths.shape != shape + (K,) or unnormalized_heights.shape != shape + (K,)

@@ -618,7 +618,7 @@ def sibling_spline_cases():
 
 
 def sibling_spline_grad_cases():
-    """Gradients of the linear / quadratic spline functionals by the reference's own autograd
+    """Gradients of the linear / quadratic / cubic spline functionals by the reference's own autograd
     (fp32 and fp64): d(sum(y * Wy) + sum(lad * Wl)) / d(inputs, logits), forward and inverse."""
     out = {}
     meta = []
@@ -658,6 +658,14 @@ def sibling_spline_grad_cases():
         uh1 = scale * torch.randn(n, K - 1, generator=g)
         finish("uquad_k%d" % K, "quadratic", splines.unconstrained_quadratic_spline, xu, [uw, uh1],
                dict(tail_bound=B, tails="linear"))
+    for K, n, scale in ((10, 300, 1.0), (4, 130, 2.0), (8, 200, 0.5)):
+        x = 0.02 + 0.96 * torch.rand(n, generator=g)
+        logits = [scale * torch.randn(n, K, generator=g), scale * torch.randn(n, K, generator=g),
+                  torch.randn(n, 1, generator=g), torch.randn(n, 1, generator=g)]
+        finish("cub_k%d" % K, "cubic", splines.cubic_spline, x, logits, {})
+        xu = 2.0 * torch.randn(n, generator=g)
+        xu[:3] = torch.tensor([3.5, -3.25, 0.0])
+        finish("ucub_k%d" % K, "cubic", splines.unconstrained_cubic_spline, xu, logits, dict(tail_bound=3.0, tails="linear"))
     x = 0.55 + 0.9 * torch.rand(3, 5, 7, generator=g)
     finish("lin_box", "linear", splines.linear_spline, x, [torch.randn(3, 5, 7, 6, generator=g)],
            dict(left=0.5, right=1.5, bottom=0.5, top=1.5))

@@ -300,16 +300,17 @@ def test_conditioner_training_gradients_through_wgrad_kernel(monkeypatch):
 
 
 def test_sibling_spline_gradients_match_reference_autograd(golden_dir):
-    """tests/golden/splines_lq_grads.npz: gradients of the linear / quadratic spline functionals
+    """tests/golden/splines_lq_grads.npz: gradients of the linear / quadratic / cubic spline functionals
     (forward and inverse, constrained and with linear tails) from the reference's autograd."""
     from nflows_amd.transforms import splines
     G = np.load(os.path.join(golden_dir, "splines_lq_grads.npz"))
     fns = {"lin": splines.linear_spline, "ulin": splines.unconstrained_linear_spline,
-           "quad": splines.quadratic_spline, "uquad": splines.unconstrained_quadratic_spline}
+           "quad": splines.quadratic_spline, "uquad": splines.unconstrained_quadratic_spline,
+           "cub": splines.cubic_spline, "ucub": splines.unconstrained_cubic_spline}
     for name, kind, kw in G["meta"]:
         fn = fns[name.split("_")[0]]
         kwargs = parse_kwargs(kw)
-        n_logits = 1 if kind == "linear" else 2
+        n_logits = {"linear": 1, "quadratic": 2, "cubic": 4}[kind]
         for inverse in (False, True):
             pre = "%s/%s" % (name, "inv_" if inverse else "")
             x = dev(G[name + "/x"]).requires_grad_(True)
@@ -333,7 +334,8 @@ def test_sibling_spline_layers_train():
     from nflows_amd.utils import torchutils
     torch.manual_seed(1)
     for cls, kw in ((T.PiecewiseLinearCouplingTransform, dict(num_bins=8, tails="linear", tail_bound=4.0)),
-                    (T.PiecewiseQuadraticCouplingTransform, dict(num_bins=8, tails="linear", tail_bound=4.0))):
+                    (T.PiecewiseQuadraticCouplingTransform, dict(num_bins=8, tails="linear", tail_bound=4.0)),
+                    (T.PiecewiseCubicCouplingTransform, dict(num_bins=8, tails="linear", tail_bound=4.0))):
         layers = []
         for i in range(2):
             layers.append(cls(torchutils.create_alternating_binary_mask(6, even=(i % 2 == 0)),
