@@ -20,7 +20,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_k8/$c -o p -- $BENCH --skip-k1-roofline > $OUT/pmc_k8_$c.log 2>&1
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_k1/$c -o p -- $BENCH --path k1 > $OUT/pmc_k1_$c.log 2>&1
 done
-python $ROOTDIR/tools/pmc_traffic.py $OUT/pmc_k8 $ROOTDIR/profiles/k8_pmc_traffic.json rqs_resnet_kernel 33816576 \
+python $ROOTDIR/tools/pmc_traffic.py $OUT/pmc_k8 $ROOTDIR/profiles/k8_pmc_traffic.json rqs_resnet_kernel 66060288 \
   "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --skip-consistency --skip-k1-roofline"
 python $ROOTDIR/tools/pmc_traffic.py $OUT/pmc_k1 $ROOTDIR/profiles/k1_pmc_traffic.json rqs_coupling_pipelined 226754560 \
   "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --skip-consistency --path k1"

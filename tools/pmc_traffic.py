@@ -37,6 +37,12 @@ def main(d, out, pat="rqs_coupling_pipelined", algorithmic=None, command=None):
            else 4 * (65536 * 64 * 2 + 65536 * 32 * 23 + 65536),
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `%s`; "
                      "gfx950 x2 correction on reads" % (command or "python bench.py --steps 3 --warmup 1 --no-cpu-baseline")}
+    try:  # an explanatory note written into the previous file by hand travels along
+        note = json.load(open(out)).get("note")
+        if note:
+            res["note"] = note
+    except (OSError, ValueError):
+        pass
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 
