@@ -363,6 +363,204 @@ __device__ __forceinline__ int rqs_eval_flat8(float x, const float* sl, const Rq
 }
 
 
+// rqs_eval_flat8 cut into small slices: the same operations in the same order (bit-identical
+// results), exposed a few instructions at a time so that a GEMM loop can issue one MFMA between two
+// slices.  On gfx950 an MFMA holds the issue port for ~16 of its 32 cycles; VALU work that sits in
+// the instruction stream right behind it fills the rest (tools/region_probe.hip).
+//   num_w<S>, num_h<S>  S in [0, kNumSlices):    softmax numerators of the width / height logits
+//   finish<S>           S in [0, kFinishSlices): the two walks over the bins, the derivatives, the
+//                                                map inside the bin; the last slice selects y / lad
+template <bool INVERSE, int PRESCALED>
+struct FlatSteps {
+    static_assert(PRESCALED == 1 || PRESCALED == 2, "logits already divided by sqrt(hidden)");
+    static constexpr int kNumSlices = 20;
+    static constexpr int kWalk = 24;                           // 8 bins x 3 slices
+    static constexpr int kFinishSlices = 1 + kWalk + 1 + kWalk + 6 + 5 + 1;  // = 62
+    static constexpr int kFirstWalkSlices = 1 + kWalk;  // these read only the first walk's numerators
+    static constexpr bool kInverse = INVERSE;
+    float ew[8], eh[8];  // logits, then softmax numerators
+    float sd[7];         // derivative logits
+    float x;
+    float den_w, den_h, rden, prev;
+    double acc;
+    int k;
+    float cw0, cw1, ch0, ch1, u0, u1, d0, d1;
+    float y, lad;
+    int status;
+    float t0, t1, t2, t3, t4, t5;  // values that cross slice boundaries
+
+    float m_w, m_h, lo_w, lo_h;  // per logit set, so that the two numerator passes can alternate
+
+    template <int S>
+    __device__ __forceinline__ void numerators(float (&e)[8], float& den, float& m, float& tl) {
+#pragma clang fp contract(off)
+        if constexpr (S == 0) {          // max of the first four
+            if (PRESCALED == 2) m = fmaxf(fmaxf(fmaxf(e[0], e[1]), e[2]), e[3]);
+            else m = fmaxf(fmaxf(fmaxf(fmaxf(-INFINITY, e[0]), e[1]), e[2]), e[3]);
+        } else if constexpr (S == 1) {
+            m = fmaxf(fmaxf(fmaxf(fmaxf(m, e[4]), e[5]), e[6]), e[7]);
+        } else if constexpr (S < 18) {   // one logit in two slices: exponent in two floats | 2^hi (1 + lo ln2)
+            constexpr int I = (S - 2) >> 1;
+            if constexpr (PRESCALED == 2) {
+                if constexpr (((S - 2) & 1) == 0) e[I] = __builtin_amdgcn_exp2f(e[I] - m);
+            } else if constexpr (((S - 2) & 1) == 0) {
+                const float kLog2e = 1.44269502162933349609375f, kLog2eLo = 1.925963033500011e-08f;
+                const float v = e[I] - m;
+                const float hi = v * kLog2e;
+                float lo = __builtin_fmaf(v, kLog2e, -hi);
+                lo = __builtin_fmaf(v, kLog2eLo, lo);
+                e[I] = hi;
+                tl = lo;
+            } else {
+                const float kLn2 = 0.693147182464599609375f;
+                const float e0 = __builtin_amdgcn_exp2f(e[I]);
+                e[I] = __builtin_fmaf(e0, tl * kLn2, e0);
+            }
+        } else if constexpr (S == 18) {
+            tl = (e[0] + e[1]) + (e[2] + e[3]);
+        } else {
+            den = tl + ((e[4] + e[5]) + (e[6] + e[7]));
+        }
+    }
+    template <int S>
+    __device__ __forceinline__ void num_w() { numerators<S>(ew, den_w, m_w, lo_w); }
+    template <int S>
+    __device__ __forceinline__ void num_h() { numerators<S>(eh, den_h, m_h, lo_h); }
+
+    // one bin of a walk (walk_bins) in three slices; SEARCH picks the bin x falls into, otherwise
+    // bin k is picked
+    template <bool SEARCH, int I, int PART>
+    __device__ __forceinline__ void bin(const float (&e)[8], float den, float minbin, float om, const RqsDev& sp,
+                                        float& knot_lo, float& knot_hi) {
+#pragma clang fp contract(off)
+        if constexpr (PART == 0) {
+            const float p = div_with_rcp(e[I], den, rden);
+            t1 = minbin + om * p;
+        } else if constexpr (PART == 1) {
+            acc += (double)t1;
+            const float c = (float)acc;
+            t2 = (I == 7) ? sp.right : sp.span_w * c + (-sp.right);
+        } else {
+            const bool take = SEARCH ? (x >= prev) : (I == k);
+            if (take) {
+                if (SEARCH) k = I;
+                knot_lo = prev;
+                knot_hi = t2;
+            }
+            prev = t2;
+            if (!SEARCH && I < 7) {  // the bin's two derivative logits (select chain, no indexing)
+                u0 = (k == I + 1) ? sd[I < 7 ? I : 0] : u0;
+                u1 = (k == I) ? sd[I < 7 ? I : 0] : u1;
+            }
+        }
+    }
+
+    // min_d + softplus_beta(u, beta) in three slices (exp | log1p | select)
+    template <int PART>
+    __device__ __forceinline__ void derivative(float u, float& d, const RqsDev& sp) {
+#pragma clang fp contract(off)
+        if constexpr (PART == 0) {
+            t3 = u * sp.beta;
+            t4 = exp_noclamp(t3);
+        } else if constexpr (PART == 1) {
+            t4 = log1p_nonneg(t4);
+        } else {
+            d = sp.min_d + (t3 > 20.0f ? u : (sp.beta == 1.0f ? t4 : t4 / sp.beta));
+        }
+    }
+
+    template <int S>
+    __device__ __forceinline__ void finish(const RqsDev& sp) {
+#pragma clang fp contract(off)
+        constexpr int W1 = 1, MID = W1 + kWalk, W2 = MID + 1, D0 = W2 + kWalk, BE = D0 + 6, LAST = BE + 5;
+        static_assert(LAST + 1 == kFinishSlices, "slice map");
+        if constexpr (S == 0) {
+            k = -1;
+            cw0 = cw1 = ch0 = ch1 = 0.0f;
+            rden = rcp_refined(INVERSE ? den_h : den_w);
+            acc = 0.0;
+            prev = -sp.right;
+        } else if constexpr (S < MID) {
+            constexpr int I = (S - W1) / 3, PART = (S - W1) % 3;
+            if (INVERSE) bin<true, I, PART>(eh, den_h, sp.min_h, sp.om_h, sp, ch0, ch1);
+            else bin<true, I, PART>(ew, den_w, sp.min_w, sp.om_w, sp, cw0, cw1);
+        } else if constexpr (S == MID) {
+            rden = rcp_refined(INVERSE ? den_w : den_h);
+            acc = 0.0;
+            prev = -sp.right;
+            u0 = sp.tail_logit;
+            u1 = sp.tail_logit;
+        } else if constexpr (S < D0) {
+            constexpr int I = (S - W2) / 3, PART = (S - W2) % 3;
+            if (INVERSE) bin<false, I, PART>(ew, den_w, sp.min_w, sp.om_w, sp, cw0, cw1);
+            else bin<false, I, PART>(eh, den_h, sp.min_h, sp.om_h, sp, ch0, ch1);
+        } else if constexpr (S < D0 + 3) {
+            derivative<S - D0>(u0, d0, sp);
+        } else if constexpr (S < BE) {
+            derivative<S - D0 - 3>(u1, d1, sp);
+        } else if constexpr (S < LAST) {
+            bin_eval<S - BE>();
+        } else {
+            const bool inside = (x >= -sp.right && x <= sp.right);  // NaN is outside
+            const bool found = (k >= 0) && !(x >= sp.right_eps);
+            const bool valid = inside && found;
+            y = valid ? y : x;
+            lad = valid ? lad : 0.0f;
+            status = inside ? (found ? status : NFA_STATUS_OUTSIDE_DOMAIN) : 0;
+        }
+    }
+
+    // rqs_bin_eval in five slices
+    float in_w, in_h, r_w, delta, s_, th, t1mt, den;
+    template <int PART>
+    __device__ __forceinline__ void bin_eval() {
+#pragma clang fp contract(off)
+        if constexpr (PART == 0) {
+            in_w = cw1 - cw0;
+            in_h = ch1 - ch0;
+            r_w = rcp_refined(in_w);
+            delta = div_with_rcp(in_h, in_w, r_w);
+            s_ = (d0 + d1) - 2.0f * delta;
+            status = 0;
+        } else if constexpr (INVERSE) {
+            if constexpr (PART == 1) {
+                const float yc = x - ch0;
+                const float a = yc * s_ + in_h * (delta - d0);
+                const float b = in_h * d0 - yc * s_;
+                const float c = (-delta) * yc;
+                t0 = b * b - (4.0f * a) * c;   // discriminant
+                t1 = 2.0f * c;
+                t2 = -b;
+            } else if constexpr (PART == 2) {
+                if (!(t0 >= 0.0f)) status = NFA_STATUS_NEG_DISCRIMINANT;
+                th = div_normal(t1, t2 - sqrtf(t0));  // root
+                y = th * in_w + cw0;
+            } else if constexpr (PART == 3) {
+                t1mt = th * (1.0f - th);
+                den = delta + s_ * t1mt;
+                const float omr = 1.0f - th;
+                t5 = (delta * delta) * ((d1 * (th * th) + (2.0f * delta) * t1mt) + d0 * (omr * omr));
+            } else {
+                lad = -(log_normal(t5) - 2.0f * log_normal(den));
+            }
+        } else {
+            if constexpr (PART == 1) {
+                th = div_with_rcp(x - cw0, in_w, r_w);
+                t1mt = th * (1.0f - th);
+                t0 = in_h * (delta * (th * th) + d0 * t1mt);  // numerator
+            } else if constexpr (PART == 2) {
+                den = delta + s_ * t1mt;
+                y = ch0 + div_normal(t0, den);
+            } else if constexpr (PART == 3) {
+                const float omt = 1.0f - th;
+                t5 = (delta * delta) * ((d1 * (th * th) + (2.0f * delta) * t1mt) + d0 * (omt * omt));
+            } else {
+                lad = log_normal(t5) - 2.0f * log_normal(den);
+            }
+        }
+    }
+};
+
 // host side: nfa_rqs_spec (doubles, as the reference's Python floats) -> fp32 device constants,
 // rounded exactly where aten rounds them
 inline int make_dev_spec(const nfa_rqs_spec* s, RqsDev* d) {

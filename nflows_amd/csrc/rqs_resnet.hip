@@ -31,6 +31,7 @@
 #include "fused_common.hpp"
 
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 
 namespace nfa {
 
@@ -164,6 +165,119 @@ __device__ __forceinline__ void gemm_tile(f32x16& acc, const bf16x8 (&ph)[8], co
     }
 }
 
+// ---- the final layer with the spline evaluation woven into its MFMAs ------------------------
+// A lane's two features of a group (A, B) draw their 24 + 24 logits from the group's three
+// accumulator tiles: A = T0[0:16] (widths, heights) + T1[0:7] (derivatives), B = T1[8:16] +
+// T2[0:16].  The evaluation is cut into three units, each started once its tiles are complete
+// and executed one FlatSteps piece per MFMA of the NEXT tile (same 48 accumulator registers as
+// the plain loop: a tile's registers are recycled when its unit is done):
+//     U0 = numerators of A                  during T1's MFMAs
+//     U1 = finish A, width numerators of B  during T2's MFMAs
+//     U2 = height numerators of B, finish B during T0's MFMAs of the next group
+// `sched_barrier(0)` around every piece keeps hipcc from regrouping MFMAs and VALU work.
+enum { kUnitNone = 0, kUnitNumA = 1, kUnitFinishA = 2, kUnitFinishB = 3 };
+
+template <int UNIT, class Steps>
+constexpr int spline_unit_slices() {
+    return UNIT == kUnitNumA ? 2 * Steps::kNumSlices
+                             : (UNIT == kUnitNone ? 0 : Steps::kNumSlices + Steps::kFinishSlices);
+}
+
+// Slice I of a unit.  Where two parts of a unit do not depend on each other their slices alternate,
+// so that the VALU stream between two MFMAs holds two independent dependency chains:
+//   U0: width / height numerators of A alternate
+//   U1: finish A alternates with the width numerators of B (3 : 1)
+//   U2: height numerators of B, interleaved with B's first walk when that walk reads the widths
+//       (forward direction; the inverse searches the heights first)
+template <int UNIT, int I, class Steps>
+__device__ __forceinline__ void spline_unit_slice(Steps& fa, Steps& fb, const RqsDev& sp) {
+    constexpr int N = Steps::kNumSlices;
+    if constexpr (UNIT == kUnitNumA) {
+        if constexpr ((I & 1) == 0) fa.template num_w<(I >> 1)>();
+        else fa.template num_h<(I >> 1)>();
+    } else if constexpr (UNIT == kUnitFinishA) {
+        // positions 3, 7, 11, ... (the first N of them) carry B's numerators
+        if constexpr ((I & 3) == 3 && (I >> 2) < N) fb.template num_w<(I >> 2)>();
+        else fa.template finish<I - ((I >> 2) < N ? (I >> 2) : N)>(sp);
+    } else if constexpr (UNIT == kUnitFinishB) {
+        static_assert(N <= Steps::kFirstWalkSlices, "the alternating part stays inside the first walk");
+        if constexpr (Steps::kInverse) {
+            if constexpr (I < N) fb.template num_h<I>();
+            else fb.template finish<I - N>(sp);
+        } else if constexpr (I < 2 * N) {
+            if constexpr ((I & 1) == 0) fb.template num_h<(I >> 1)>();
+            else fb.template finish<(I >> 1)>(sp);
+        } else {
+            fb.template finish<I - N>(sp);
+        }
+    }
+}
+
+template <int UNIT, int I, int END, class Steps>
+__device__ __forceinline__ void spline_unit_range(Steps& fa, Steps& fb, const RqsDev& sp) {
+    if constexpr (I < END) {
+        spline_unit_slice<UNIT, I>(fa, fb, sp);
+        spline_unit_range<UNIT, I + 1, END>(fa, fb, sp);
+    }
+}
+
+// the slices of a unit spread evenly over the 48 MFMA slots of a tile
+template <int UNIT, int SLOT, class Steps>
+__device__ __forceinline__ void spline_unit_step(Steps& fa, Steps& fb, const RqsDev& sp) {
+    constexpr int N = spline_unit_slices<UNIT, Steps>();
+    spline_unit_range<UNIT, (SLOT * N) / 48, ((SLOT + 1) * N) / 48>(fa, fb, sp);
+}
+
+#define NFA_PUMP(SLOT, A_, B_)                                           \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, acc, 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+    spline_unit_step<UNIT, SLOT>(fa, fb, sp);                            \
+    __builtin_amdgcn_sched_barrier(0)
+
+// one k-step (six MFMAs, one unit piece behind each); fh / fm / fl hold this k-step's weight
+// fragments on entry and the next k-step's on exit (requested five MFMAs ahead of their use)
+template <int UNIT, int KS, class Steps>
+__device__ __forceinline__ void kstep_pumped(f32x16& acc, bf16x8 bh, bf16x8 bm, bf16x8 bl, vec4f& fh, vec4f& fm,
+                                             vec4f& fl, const vec4f* cur, Steps& fa, Steps& fb, const RqsDev& sp) {
+    constexpr int K4 = KS & 3;
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, fh), am = __builtin_bit_cast(bf16x8, fm),
+                 al = __builtin_bit_cast(bf16x8, fl);
+    NFA_PUMP(KS * 6 + 0, al, bh);
+    if (K4 < 3) {
+        fh = cur[(0 * 4 + K4 + 1) * 64];
+        fm = cur[(1 * 4 + K4 + 1) * 64];
+        fl = cur[(2 * 4 + K4 + 1) * 64];
+    }
+    NFA_PUMP(KS * 6 + 1, ah, bl);
+    NFA_PUMP(KS * 6 + 2, am, bm);
+    NFA_PUMP(KS * 6 + 3, am, bh);
+    NFA_PUMP(KS * 6 + 4, ah, bm);
+    NFA_PUMP(KS * 6 + 5, ah, bh);
+}
+#undef NFA_PUMP
+
+template <int UNIT, int HS, class Steps>
+__device__ __forceinline__ void stage_pumped(f32x16& acc, const bf16x8 (&ph)[8], const bf16x8 (&pm)[8],
+                                             const bf16x8 (&pl)[8], WeightStream& sm, int lane, Steps& fa,
+                                             Steps& fb, const RqsDev& sp) {
+    stream_request(sm);
+    const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
+    vec4f fh = cur[0 * 4 * 64], fm = cur[1 * 4 * 64], fl = cur[2 * 4 * 64];
+    kstep_pumped<UNIT, HS * 4 + 0>(acc, ph[HS * 4 + 0], pm[HS * 4 + 0], pl[HS * 4 + 0], fh, fm, fl, cur, fa, fb, sp);
+    kstep_pumped<UNIT, HS * 4 + 1>(acc, ph[HS * 4 + 1], pm[HS * 4 + 1], pl[HS * 4 + 1], fh, fm, fl, cur, fa, fb, sp);
+    kstep_pumped<UNIT, HS * 4 + 2>(acc, ph[HS * 4 + 2], pm[HS * 4 + 2], pl[HS * 4 + 2], fh, fm, fl, cur, fa, fb, sp);
+    kstep_pumped<UNIT, HS * 4 + 3>(acc, ph[HS * 4 + 3], pm[HS * 4 + 3], pl[HS * 4 + 3], fh, fm, fl, cur, fa, fb, sp);
+    stream_advance(sm);
+}
+
+template <int UNIT, class Steps>
+__device__ __forceinline__ void gemm_tile_pumped(f32x16& acc, const bf16x8 (&ph)[8], const bf16x8 (&pm)[8],
+                                                 const bf16x8 (&pl)[8], WeightStream& sm, int lane, Steps& fa,
+                                                 Steps& fb, const RqsDev& sp) {
+    stage_pumped<UNIT, 0>(acc, ph, pm, pl, sm, lane, fa, fb, sp);
+    stage_pumped<UNIT, 1>(acc, ph, pm, pl, sm, lane, fa, fb, sp);
+}
+
 // accumulator tile t, registers 8*hk .. 8*hk+7  ->  pieces of k-step 2t + hk
 template <bool RELU>
 __device__ __forceinline__ void tile_to_pieces(const f32x16& a, bf16x8& h0, bf16x8& m0, bf16x8& l0,
@@ -214,7 +328,7 @@ __device__ __forceinline__ void load_bias_tile(f32x16& acc, const float* bias_ti
 // spline results back to, fixed slots given by its table (the host composes all the permutations
 // between the layers into these tables), and the last table says which slot ends up at which
 // output position.  Weights and biases of all layers form one stream in execution order.
-template <bool INVERSE, int PRESCALED, int INIT_KS>
+template <bool INVERSE, int PRESCALED, int INIT_KS, bool PIPE = false>
 __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs a) {
     // dynamic LDS: the weight ring, then per wave a [D][33] row tile
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
@@ -247,6 +361,9 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
     __syncthreads();
 
     float* s_row = lds_dyn + kRing * kStageVec4 * 4 + wave * D * kRowPad;
+    // PIPE: the final layer's biases of the current layer, staged once per layer (the woven loop
+    // cannot afford an L2 round trip in front of every tile)
+    float* s_fbias = lds_dyn + kRing * kStageVec4 * 4 + (kBlock / kWave) * D * kRowPad;
     const int groups = dt >> 2;
     const int64_t num_quads = a.batch >> 7;
     int tb = 0;  // which half of s_tab holds the current layer's table
@@ -337,6 +454,12 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                     tile_to_pieces<false>(h[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
             }
             bias += 128;
+            if (PIPE) {
+                // (every wave has passed a stage barrier of this layer: nobody reads the previous
+                // layer's biases any more; the blocks' barriers come before the first use)
+                const float* fbias = a.bias + (size_t)layer * a.bias_per_layer + 128 + 256 * a.num_blocks;
+                for (int i = tid; i < dt * 24; i += kBlock) s_fbias[i] = fbias[i];
+            }
             NFA_STAMP()
 
             // ---- residual blocks: h += W_1 relu(W_0 relu(h) + b_0) + b_1, both Linears k-major.
@@ -371,31 +494,82 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                 NFA_STAMP()
             }
 
-            // ---- final layer, three 32-row tiles (= 4 features) at a time, and the splines; the
-            //      results replace the inputs in their slots
-            for (int g = 0; g < groups; ++g) {
-                float* slot0 = s_row + tab[kTabTr + g * 4 + half * 2] * kRowPad + r;
-                float* slot1 = s_row + tab[kTabTr + g * 4 + half * 2 + 1] * kRowPad + r;
-                const float xin0 = *slot0, xin1 = *slot1;
+            if constexpr (PIPE) {
+                // ---- final layer with the spline evaluation woven into the MFMAs (see gemm_tile_pumped)
+                using Steps = FlatSteps<INVERSE, PRESCALED>;
+                Steps fa, fb;
+                float* slot_b = nullptr;
+                const float* fbias = s_fbias + half * 16;
                 f32x16 acc[3];
+                auto commit = [&](Steps& f, float* slot) {
+                    *slot = f.y;
+                    lad_acc += f.lad;
+                    my_status |= f.status;
+                };
+                for (int g = 0; g < groups; ++g) {
+                    float* slot0 = s_row + tab[kTabTr + g * 4 + half * 2] * kRowPad + r;
+                    float* slot1 = s_row + tab[kTabTr + g * 4 + half * 2 + 1] * kRowPad + r;
+                    load_bias_tile(acc[0], fbias + (g * 3 + 0) * 32);
+                    if (g > 0) {
+                        gemm_tile_pumped<kUnitFinishB>(acc[0], ph, pm, pl, sm, lane, fa, fb, a.sp);
+                        commit(fb, slot_b);
+                    } else {
+                        gemm_tile<false>(acc[0], ph, pm, pl, sm, lane);
+                    }
+                    fa.x = *slot0;
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    load_bias_tile(acc[t], bias + (g * 3 + t) * 32);
-                    gemm_tile<false>(acc[t], ph, pm, pl, sm, lane);
+                    for (int j = 0; j < 8; ++j) {
+                        fa.ew[j] = acc[0][j];
+                        fa.eh[j] = acc[0][8 + j];
+                    }
+                    load_bias_tile(acc[1], fbias + (g * 3 + 1) * 32);
+                    gemm_tile_pumped<kUnitNumA>(acc[1], ph, pm, pl, sm, lane, fa, fb, a.sp);
+                    fb.x = *slot1;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (j < 7) fa.sd[j] = acc[1][j];
+                        fb.ew[j] = acc[1][8 + j];
+                    }
+                    load_bias_tile(acc[2], fbias + (g * 3 + 2) * 32);
+                    gemm_tile_pumped<kUnitFinishA>(acc[2], ph, pm, pl, sm, lane, fa, fb, a.sp);
+                    commit(fa, slot0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        fb.eh[j] = acc[2][j];
+                        if (j < 7) fb.sd[j] = acc[2][8 + j];
+                    }
+                    slot_b = slot1;
                 }
+                spline_unit_range<kUnitFinishB, 0, spline_unit_slices<kUnitFinishB, Steps>()>(fa, fb, a.sp);
+                commit(fb, slot_b);
                 NFA_STAMP()
-                {
-                    NFA_K7_FEATURE_A(pa, acc[0], acc[1]);
-                    NFA_K7_FEATURE_B(pb, acc[1], acc[2]);
-                    float y0, l0, y1, l1;
-                    my_status |= rqs_eval_flat8<INVERSE, PRESCALED>(xin0, pa, a.sp, y0, l0);
-                    my_status |= rqs_eval_flat8<INVERSE, PRESCALED>(xin1, pb, a.sp, y1, l1);
-                    *slot0 = y0;
-                    *slot1 = y1;
-                    lad_acc += l0;
-                    lad_acc += l1;
+            } else {
+                // ---- final layer, three 32-row tiles (= 4 features) at a time, and the splines; the
+                //      results replace the inputs in their slots
+                for (int g = 0; g < groups; ++g) {
+                    float* slot0 = s_row + tab[kTabTr + g * 4 + half * 2] * kRowPad + r;
+                    float* slot1 = s_row + tab[kTabTr + g * 4 + half * 2 + 1] * kRowPad + r;
+                    const float xin0 = *slot0, xin1 = *slot1;
+                    f32x16 acc[3];
+    #pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        load_bias_tile(acc[t], bias + (g * 3 + t) * 32);
+                        gemm_tile<false>(acc[t], ph, pm, pl, sm, lane);
+                    }
+                    NFA_STAMP()
+                    {
+                        NFA_K7_FEATURE_A(pa, acc[0], acc[1]);
+                        NFA_K7_FEATURE_B(pb, acc[1], acc[2]);
+                        float y0, l0, y1, l1;
+                        my_status |= rqs_eval_flat8<INVERSE, PRESCALED>(xin0, pa, a.sp, y0, l0);
+                        my_status |= rqs_eval_flat8<INVERSE, PRESCALED>(xin1, pb, a.sp, y1, l1);
+                        *slot0 = y0;
+                        *slot1 = y1;
+                        lad_acc += l0;
+                        lad_acc += l1;
+                    }
+                    NFA_STAMP()
                 }
-                NFA_STAMP()
             }
             tb ^= 1;
             // this wave's spline results must be visible to its own gathers of the next layer
@@ -473,7 +647,16 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     a.bias_per_layer = 128 + 256 * num_blocks + num_transform * 24;
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = g_k7_trace;
-    const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float);
+    // final layer with the spline evaluation woven into its MFMAs (forward and inverse of the
+    // d_i <= 32 shape family without the log2(e) fold); same results bit for bit as the plain loop,
+    // which NFA_K8_PIPE=0 brings back for A/B runs
+    static const int use_pipe = [] {
+        const char* e = getenv("NFA_K8_PIPE");
+        return e ? atoi(e) : 1;
+    }();
+    const bool pipe = use_pipe && init_ks == 2 && !(flags & NFA_FLAG_LOGITS_LOG2E);
+    const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float) +
+                       (pipe ? (size_t)num_transform * 24 * sizeof(float) : 0);
     int64_t blocks = batch >> 7;
     const int64_t per_cu = lds + 2048 <= 80 * 1024 ? 2 : 1;
     const int64_t cap = (int64_t)device_cu_count() * per_cu;
@@ -494,9 +677,10 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         else NFA_K8_PICK(false, 1);
     }
 #undef NFA_K8_PICK
+    if (pipe) kern = inv ? rqs_resnet_kernel<true, 1, 2, true> : rqs_resnet_kernel<false, 1, 2, true>;
     if (lds > 64 * 1024) {
-        static bool raised[8] = {false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
-        const int which = (inv ? 1 : 0) + (l2e ? 2 : 0) + (init_ks == 4 ? 4 : 0);
+        static bool raised[10] = {false, false, false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
+        const int which = pipe ? 8 + (inv ? 1 : 0) : (inv ? 1 : 0) + (l2e ? 2 : 0) + (init_ks == 4 ? 4 : 0);
         if (!raised[which]) {
             NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
             raised[which] = true;

@@ -569,3 +569,33 @@ def test_sibling_autoregressive_layers_against_reference_vectors(golden_dir, col
         check(lad, g[name + "/lad"], g[name + "/lad64"], name + " lad", 1e-5 * D)
         check(xs, g[name + "/inv_x"], g[name + "/inv_x64"], name + " inv_x", 1e-5)
         check(lad_inv, g[name + "/inv_lad"], g[name + "/inv_lad64"], name + " inv_lad", 1e-5 * D)
+
+
+def test_woven_final_layer_is_bit_identical_to_the_plain_loop(tmp_path):
+    """K8 evaluates the splines between the MFMAs of its final layer (gemm_tile_pumped); with
+    NFA_K8_PIPE=0 the evaluation follows the tiles as one block.  Same operations in the same order:
+    outputs and logabsdet agree bit for bit, forward and inverse, tails and NaN included.  (The
+    switch is read once per process, hence the two child processes.)"""
+    import subprocess
+    import sys
+    script = tmp_path / "child.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import nflows_amd\n"
+        "from nflows_amd import configs\n"
+        "flow = configs.rq_nsf_flow(num_layers=5, features=64, num_bins=8, hidden_features=128, seed=2).cuda().eval()\n"
+        "x = 1.4 * torch.randn(1024, 64, generator=torch.Generator().manual_seed(9)).cuda()\n"
+        "x[:4, :8] = torch.tensor([3.0, -3.0, 3.5, float('nan'), 0.0, 2.9999998, -7.0, 1e-8]).cuda()\n"
+        "with torch.no_grad():\n"
+        "    y, lad = flow._transform(x)\n"
+        "    xi, ladi = flow._transform.inverse(torch.nan_to_num(y))\n"
+        "np.savez(sys.argv[1], y=y.cpu().numpy(), lad=lad.cpu().numpy(), xi=xi.cpu().numpy(), ladi=ladi.cpu().numpy())\n"
+        % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for flag in ("0", "1"):
+        out = str(tmp_path / ("pipe%s.npz" % flag))
+        subprocess.check_call([sys.executable, str(script), out], env=dict(os.environ, NFA_K8_PIPE=flag))
+        outs.append(np.load(out))
+    for key in ("y", "lad", "xi", "ladi"):
+        assert np.array_equal(outs[0][key], outs[1][key], equal_nan=True), key

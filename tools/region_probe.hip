@@ -78,6 +78,31 @@ __global__ void __launch_bounds__(256, 1) probe(const vec4f* w, float* out, int 
                 if (t == 3) acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % 12], b, acc3, 0, 0, 0);
             }
         }
+        if (MODE == 5 || MODE == 6 || MODE == 7) {
+            // 16 dependent MFMAs alone (5) / each followed by one 8-op slice of the VALU chunk (6)
+            bf16x8 a[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) a[i] = __builtin_bit_cast(bf16x8, cur[i * 64]);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (MODE == 7 && (j & 1)) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j % 12], b, acc1, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j % 12], b, acc, 0, 0, 0);
+                if (MODE >= 6) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    float t = v[j] * 0.7f - 0.3f;
+                    t = __builtin_amdgcn_exp2f(t);
+                    t = __builtin_fmaf(t, 0.5f, v[(j + 1) & 15]);
+                    t = __builtin_fmaf(t, t, 0.25f);
+                    t = t * 0.9f + 0.01f;
+                    t = __builtin_fmaf(t, 0.3f, -0.1f);
+                    t = t - v[(j + 5) & 15] * 0.001f;
+                    t = t * 0.5f + 0.1f;
+                    asm volatile("" : "+v"(t));  // (keeps the slices from being packed pairwise into v_pk_*)
+                    v[j] = t;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
         if (MODE == 4) {
             // both, hand-placed: fragments up front, then 1-2 MFMAs, a fence, one 8-op slice of the VALU
             // chunk, a fence ... (sched_barrier(0): nothing may be scheduled across)
@@ -133,6 +158,9 @@ int main() {
     run<3, 0>("both, fragments per k-step", w, out, cyc);
     run<3, 1>("both, fragments up front", w, out, cyc);
     run<4, 0>("both, hand-placed with sched_barrier fences", w, out, cyc);
+    run<5, 0>("16 dependent MFMAs", w, out, cyc);
+    run<6, 0>("16 MFMAs, each followed by one VALU slice (fenced)", w, out, cyc);
+    run<7, 0>("16 MFMAs on two alternating accumulators, each followed by one VALU slice", w, out, cyc);
     run<8, 0>("24 MFMAs, 4 accumulators round robin", w, out, cyc);
     run<9, 0>("24 MFMAs, 4 chains of 6 dependent", w, out, cyc);
     return 0;
