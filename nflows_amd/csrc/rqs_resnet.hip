@@ -647,14 +647,14 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     a.bias_per_layer = 128 + 256 * num_blocks + num_transform * 24;
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = g_k7_trace;
-    // final layer with the spline evaluation woven into its MFMAs (forward and inverse of the
-    // d_i <= 32 shape family without the log2(e) fold); same results bit for bit as the plain loop,
+    // final layer with the spline evaluation woven into its MFMAs (not with the log2(e) fold); same
+    // results bit for bit as the plain loop,
     // which NFA_K8_PIPE=0 brings back for A/B runs
     static const int use_pipe = [] {
         const char* e = getenv("NFA_K8_PIPE");
         return e ? atoi(e) : 1;
     }();
-    const bool pipe = use_pipe && init_ks == 2 && !(flags & NFA_FLAG_LOGITS_LOG2E);
+    const bool pipe = use_pipe && !(flags & NFA_FLAG_LOGITS_LOG2E);
     const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float) +
                        (pipe ? (size_t)num_transform * 24 * sizeof(float) : 0);
     int64_t blocks = batch >> 7;
@@ -677,10 +677,13 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         else NFA_K8_PICK(false, 1);
     }
 #undef NFA_K8_PICK
-    if (pipe) kern = inv ? rqs_resnet_kernel<true, 1, 2, true> : rqs_resnet_kernel<false, 1, 2, true>;
+    if (pipe) {
+        if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, true> : rqs_resnet_kernel<false, 1, 4, true>;
+        else kern = inv ? rqs_resnet_kernel<true, 1, 2, true> : rqs_resnet_kernel<false, 1, 2, true>;
+    }
     if (lds > 64 * 1024) {
-        static bool raised[10] = {false, false, false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
-        const int which = pipe ? 8 + (inv ? 1 : 0) : (inv ? 1 : 0) + (l2e ? 2 : 0) + (init_ks == 4 ? 4 : 0);
+        static bool raised[12] = {false, false, false, false, false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
+        const int which = pipe ? 8 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) : (inv ? 1 : 0) + (l2e ? 2 : 0) + (init_ks == 4 ? 4 : 0);
         if (!raised[which]) {
             NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
             raised[which] = true;
