@@ -225,7 +225,12 @@ __device__ __forceinline__ void spline_unit_range(Steps& fa, Steps& fb, const Rq
 template <int UNIT, int SLOT, class Steps>
 __device__ __forceinline__ void spline_unit_step(Steps& fa, Steps& fb, const RqsDev& sp) {
     constexpr int N = spline_unit_slices<UNIT, Steps>();
+#ifdef NFA_NO_WEAVE
+    // measurement aid: same pipeline, but a unit runs as one block behind the tile's last MFMA
+    if constexpr (SLOT == 47) spline_unit_range<UNIT, 0, N>(fa, fb, sp);
+#else
     spline_unit_range<UNIT, (SLOT * N) / 48, ((SLOT + 1) * N) / 48>(fa, fb, sp);
+#endif
 }
 
 #define NFA_PUMP(SLOT, A_, B_)                                           \

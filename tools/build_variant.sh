@@ -10,7 +10,7 @@ HF="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math 
 make -C $R/nflows_amd/csrc -s
 /opt/rocm/bin/hipcc $HF "$@" -c $R/nflows_amd/csrc/$SRC -o /tmp/var_$N.o 2>/tmp/build_$N.log || { tail -5 /tmp/build_$N.log; exit 1; }
 OBJS=""
-for f in rqs rqs_bwd rqs_shared rqs_fused_linear rqs_resnet splines_lq misc; do
+for f in rqs rqs_bwd rqs_shared rqs_fused_linear rqs_resnet splines_lq linear_wgrad misc; do
   if [ "$f.hip" == "$SRC" ]; then OBJS="$OBJS /tmp/var_$N.o"; else OBJS="$OBJS $R/nflows_amd/csrc/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_variants/$N.so $OBJS
