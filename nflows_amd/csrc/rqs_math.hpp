@@ -302,9 +302,9 @@ __device__ __forceinline__ float softmax_numerators_log2(Slots<8>& e, const floa
 // PRESCALED: 0 = width / height logits as the conditioner produced them (divided by sp.divisor
 // here), 1 = already divided, 2 = already divided and multiplied by log2(e)
 //
-// The evaluation comes in two halves so that a caller can place them in different scheduling
-// regions (K8 folds them into the two weight stages of an MFMA tile): the softmax numerators of
-// both logit sets, then the walks over the bins, the derivatives and the map inside the bin.
+// The evaluation comes in two halves: the softmax numerators of both logit sets, then the walks
+// over the bins, the derivatives and the map inside the bin (FlatSteps below cuts the same
+// operations into slices for K8's woven final layer).
 struct FlatEvalState {
     Slots<8> ew, eh;
     float den_w, den_h;
