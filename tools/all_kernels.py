@@ -92,6 +92,26 @@ with torch.no_grad():
     add("K9 cubic", "cubic spline functional, same", timeit(lambda: splines.unconstrained_cubic_spline(xe, c[:, :K], c[:, K:2 * K], c[:, 2 * K:2 * K + 1], c[:, 2 * K + 1:], tail_bound=3.0)), 4 * N * (2 * K + 2 + 3))
     add("K9 cubic inverse", "same", timeit(lambda: splines.unconstrained_cubic_spline(xe, c[:, :K], c[:, K:2 * K], c[:, 2 * K:2 * K + 1], c[:, 2 * K + 1:], inverse=True, tail_bound=3.0)), 4 * N * (2 * K + 2 + 3))
 
+    # backward kernels of the sibling splines (C entry points, dense logit rows)
+    lib = NA.load()
+    lspec = ops.make_rqs_spec(K, "linear", tail_bound=3.0)
+    gy1, gl1 = torch.randn(N, device=dev, generator=g), torch.randn(N, device=dev, generator=g)
+    gxe = torch.empty_like(xe)
+    gp_ = torch.empty_like(p)
+    add("K9 linear backward", "grads wrt inputs and logits, same elements", timeit(lambda: NA.check(lib.nfa_linear_spline_backward_f32(
+        NA.ptr(xe), NA.ptr(p), NA.ptr(gy1), NA.ptr(gl1), NA.ptr(gxe), NA.ptr(gp_), N, ctypes.byref(lspec), 0, NA.stream_handle(xe.device)))),
+        4 * N * (2 * K + 4))
+    qw, qh = q[:, :K].contiguous(), q[:, K:].contiguous()
+    gqw, gqh = torch.empty_like(qw), torch.empty_like(qh)
+    add("K9 quadratic backward", "same", timeit(lambda: NA.check(lib.nfa_quadratic_spline_backward_f32(
+        NA.ptr(xe), NA.ptr(qw), NA.ptr(qh), K - 1, NA.ptr(gy1), NA.ptr(gl1), NA.ptr(gxe), NA.ptr(gqw), NA.ptr(gqh), N,
+        ctypes.byref(lspec), 0, NA.stream_handle(xe.device)))), 4 * N * (2 * (2 * K - 1) + 4))
+    cw, ch, cl, cr = (c[:, :K].contiguous(), c[:, K:2 * K].contiguous(), c[:, 2 * K].contiguous(), c[:, 2 * K + 1].contiguous())
+    gcw, gch, gcl, gcr = torch.empty_like(cw), torch.empty_like(ch), torch.empty_like(cl), torch.empty_like(cr)
+    add("K9 cubic backward", "same", timeit(lambda: NA.check(lib.nfa_cubic_spline_backward_f32(
+        NA.ptr(xe), NA.ptr(cw), NA.ptr(ch), NA.ptr(cl), NA.ptr(cr), NA.ptr(gy1), NA.ptr(gl1), NA.ptr(gxe), NA.ptr(gcw), NA.ptr(gch),
+        NA.ptr(gcl), NA.ptr(gcr), N, ctypes.byref(lspec), 0, NA.stream_handle(xe.device)))), 4 * N * (2 * (2 * K + 2) + 4))
+
     uw = torch.rand(32, K, device=dev, generator=g); ud = torch.rand(32, K - 1, device=dev, generator=g)
     xs = torch.randn(B, 32, device=dev, generator=g)
     add("K6 `rqs_shared_kernel`", "batch-shared RQ CDF, B=65536 F=32", timeit(lambda: ops.rqs_shared(xs, uw, uw, ud, ops.make_rqs_spec(K, "linear", tail_bound=3.0), False)), 4 * (2 * B * 32 + B))
