@@ -464,6 +464,8 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                 // layer's biases any more; the blocks' barriers come before the first use)
                 const float* fbias = a.bias + (size_t)layer * a.bias_per_layer + 128 + 256 * a.num_blocks;
                 for (int i = tid; i < dt * 24; i += kBlock) s_fbias[i] = fbias[i];
+                // without residual blocks the final layer follows at once: no stage barrier in between
+                if (a.num_blocks == 0) __syncthreads();
             }
             NFA_STAMP()
 
