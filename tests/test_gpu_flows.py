@@ -571,8 +571,8 @@ def test_sibling_autoregressive_layers_against_reference_vectors(golden_dir, col
         check(lad_inv, g[name + "/inv_lad"], g[name + "/inv_lad64"], name + " inv_lad", 1e-5 * D)
 
 
-@pytest.mark.parametrize("features", [64, 128, 24])
-def test_woven_final_layer_is_bit_identical_to_the_plain_loop(tmp_path, features):
+@pytest.mark.parametrize("features,blocks", [(64, 2), (128, 2), (24, 1), (64, 0)])
+def test_woven_final_layer_is_bit_identical_to_the_plain_loop(tmp_path, features, blocks):
     """K8 evaluates the splines between the MFMAs of its final layer (gemm_tile_pumped); with
     NFA_K8_PIPE=0 the evaluation follows the tiles as one block.  Same operations in the same order:
     outputs and logabsdet agree bit for bit, forward and inverse, tails and NaN included.  (The
@@ -585,8 +585,8 @@ def test_woven_final_layer_is_bit_identical_to_the_plain_loop(tmp_path, features
         "sys.path.insert(0, %r)\n"
         "import nflows_amd\n"
         "from nflows_amd import configs\n"
-        "D = int(sys.argv[2])\n"
-        "flow = configs.rq_nsf_flow(num_layers=5, features=D, num_bins=8, hidden_features=128, seed=2).cuda().eval()\n"
+        "D, NB = int(sys.argv[2]), int(sys.argv[3])\n"
+        "flow = configs.rq_nsf_flow(num_layers=5, features=D, num_bins=8, hidden_features=128, num_blocks=NB, seed=2).cuda().eval()\n"
         "x = 1.4 * torch.randn(1024, D, generator=torch.Generator().manual_seed(9)).cuda()\n"
         "x[:4, :8] = torch.tensor([3.0, -3.0, 3.5, float('nan'), 0.0, 2.9999998, -7.0, 1e-8]).cuda()\n"
         "with torch.no_grad():\n"
@@ -597,7 +597,7 @@ def test_woven_final_layer_is_bit_identical_to_the_plain_loop(tmp_path, features
     outs = []
     for flag in ("0", "1"):
         out = str(tmp_path / ("pipe%s.npz" % flag))
-        subprocess.check_call([sys.executable, str(script), out, str(features)], env=dict(os.environ, NFA_K8_PIPE=flag))
+        subprocess.check_call([sys.executable, str(script), out, str(features), str(blocks)], env=dict(os.environ, NFA_K8_PIPE=flag))
         outs.append(np.load(out))
     for key in ("y", "lad", "xi", "ladi"):
         assert np.array_equal(outs[0][key], outs[1][key], equal_nan=True), key
