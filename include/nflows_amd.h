@@ -205,14 +205,18 @@ int nfa_rqs_coupling_fused_linear_f32(const float *inputs, const float *hidden,
  *                    W[32*tile + (l&31)][col(ks, l>>5, j)];
  *                  final_layer: two stages per 32-row tile (k-steps 4*s .. 4*s+3),
  *                    [3 pieces][4 k-steps][64 lanes][8], same element rule;
- *                  final_layer's rows are padded / reordered as in K7; its width and height
+ *                  final_layer's rows are padded / reordered as in K7 (num_bins = 10: every
+ *                    feature's 29 rows padded to 32, two tiles per group of two features, row i of
+ *                    tile t = logit 16*(t%2) + 4*(i/8) + i%4 of feature 2*(t/2) + (i/4)%2);
+ *                    its width and height
  *                    rows (and their biases) are multiplied by 1/sqrt(hidden_features)
  *                    (coupling.py:554-556; spec->wh_divisor is ignored here), and by log2(e)
  *                    with NFA_FLAG_LOGITS_LOG2E.
  *   bias_packed    float: initial_layer [4 tiles][2 lane-halves][16], every hidden Linear the
  *                  same, final_layer [tiles][2][16] (rows as in K7)
- * Supported: num_bins = 8, linear tails, hidden_features = 128, d_i <= 64, d_t % 4 == 0,
- * d_t <= 64, features % 4 == 0, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
+ * Supported: num_bins = 8 or 10 (the reference's default; not with NFA_FLAG_LOGITS_LOG2E), linear
+ * tails, hidden_features = 128, d_i <= 64, d_t % 4 == 0, d_t <= 64, features % 4 == 0,
+ * features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
  */
 int nfa_rqs_coupling_resnet_f32(const float *inputs, const void *weights_packed,
                                 const float *bias_packed, const int32_t *layer_tables,

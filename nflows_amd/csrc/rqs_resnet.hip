@@ -24,7 +24,7 @@
 //     group; they are evaluated straight from registers (as in K7).  The 1/sqrt(hidden) scale of
 //     the width / height logits (coupling.py:554-556) is folded into those weight rows by the host.
 //
-// Restrictions (the host falls back to PyTorch GEMMs + K7/K1 otherwise): K = 8 bins, linear
+// Restrictions (the host falls back to PyTorch GEMMs + K7/K1 otherwise): K = 8 or 10 bins, linear
 // tails, hidden width 128, ReLU, no context / batch norm / active dropout, d_i <= 64,
 // d_t % 4 == 0, d_t <= 64, D % 4 == 0, D <= 128, batch % 128 == 0 here (leftover rows: other path).
 
@@ -333,8 +333,9 @@ __device__ __forceinline__ void load_bias_tile(f32x16& acc, const float* bias_ti
 // spline results back to, fixed slots given by its table (the host composes all the permutations
 // between the layers into these tables), and the last table says which slot ends up at which
 // output position.  Weights and biases of all layers form one stream in execution order.
-template <bool INVERSE, int PRESCALED, int INIT_KS, bool PIPE = false>
+template <bool INVERSE, int PRESCALED, int INIT_KS, bool PIPE = false, int KB = 8>
 __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs a) {
+    static_assert(KB == 8 || (KB == 10 && !PIPE && PRESCALED == 1), "10 bins: plain loop only");
     // dynamic LDS: the weight ring, then per wave a [D][33] row tile
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     __shared__ int s_tab[2][kTabLayer];   // tables of the current and the next layer
@@ -501,7 +502,34 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                 NFA_STAMP()
             }
 
-            if constexpr (PIPE) {
+            if constexpr (KB == 10) {
+                // ---- final layer for 10 bins (the reference's default): 29 logits per feature padded
+                //      to 32 rows, two 32-row tiles per group; the rows are ordered so that the 32
+                //      accumulator values of lane-half h are the logits of feature 2g + h
+                RqsDev sp10 = a.sp;
+                sp10.divisor = 0.0f;  // 1/sqrt(hidden) is folded into the weight rows
+                for (int g = 0; g < (dt >> 1); ++g) {
+                    float* slot = s_row + tab[kTabTr + g * 2 + half] * kRowPad + r;
+                    const float xin = *slot;
+                    f32x16 acc[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        load_bias_tile(acc[t], bias + (g * 2 + t) * 32);
+                        gemm_tile<false>(acc[t], ph, pm, pl, sm, lane);
+                    }
+                    float p[32];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        p[q] = acc[0][q];
+                        p[16 + q] = acc[1][q];
+                    }
+                    float y, l;
+                    my_status |= rqs_eval<10, INVERSE, true, true>(xin, p, sp10, y, l);
+                    *slot = y;
+                    lad_acc += l;
+                }
+                NFA_STAMP()
+            } else if constexpr (PIPE) {
                 // ---- final layer with the spline evaluation woven into the MFMAs (see gemm_tile_pumped)
                 using Steps = FlatSteps<INVERSE, PRESCALED>;
                 Steps fa, fb;
@@ -629,7 +657,9 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     ResnetArgs a;
     int rc = make_dev_spec(spec, &a.sp);
     if (rc != NFA_OK) return rc;
-    if (a.sp.K != 8 || !a.sp.linear || hidden_features != 128 || (num_transform & 3) != 0 ||
+    const int rows_per_feature = a.sp.K == 10 ? 32 : 24;
+    if ((a.sp.K != 8 && a.sp.K != 10) || (a.sp.K == 10 && (flags & NFA_FLAG_LOGITS_LOG2E)) || !a.sp.linear ||
+        hidden_features != 128 || (num_transform & 3) != 0 ||
         num_transform > 64 || num_identity > 64 || features > 128 || (features & 3) != 0 ||
         (batch & 127) != 0 || num_blocks > 64 || num_layers > 4096)
         return NFA_ERR_UNSUPPORTED;
@@ -650,8 +680,8 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     a.num_blocks = num_blocks;
     a.num_layers = num_layers;
     const int init_ks = num_identity > 32 ? 4 : 2;
-    a.num_stages = init_ks + 16 * num_blocks + 2 * (num_transform * 24 / 32);
-    a.bias_per_layer = 128 + 256 * num_blocks + num_transform * 24;
+    a.num_stages = init_ks + 16 * num_blocks + 2 * (num_transform * rows_per_feature / 32);
+    a.bias_per_layer = 128 + 256 * num_blocks + num_transform * rows_per_feature;
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = g_k7_trace;
     // final layer with the spline evaluation woven into its MFMAs (not with the log2(e) fold); same
@@ -661,7 +691,7 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         const char* e = getenv("NFA_K8_PIPE");
         return e ? atoi(e) : 1;
     }();
-    const bool pipe = use_pipe && !(flags & NFA_FLAG_LOGITS_LOG2E);
+    const bool pipe = use_pipe && !(flags & NFA_FLAG_LOGITS_LOG2E) && a.sp.K == 8;
     const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float) +
                        (pipe ? (size_t)num_transform * 24 * sizeof(float) : 0);
     int64_t blocks = batch >> 7;
@@ -684,13 +714,18 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         else NFA_K8_PICK(false, 1);
     }
 #undef NFA_K8_PICK
+    if (a.sp.K == 10) {
+        if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, false, 10> : rqs_resnet_kernel<false, 1, 4, false, 10>;
+        else kern = inv ? rqs_resnet_kernel<true, 1, 2, false, 10> : rqs_resnet_kernel<false, 1, 2, false, 10>;
+    }
     if (pipe) {
         if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, true> : rqs_resnet_kernel<false, 1, 4, true>;
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, true> : rqs_resnet_kernel<false, 1, 2, true>;
     }
     if (lds > 64 * 1024) {
-        static bool raised[12] = {false, false, false, false, false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
-        const int which = pipe ? 8 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) : (inv ? 1 : 0) + (l2e ? 2 : 0) + (init_ks == 4 ? 4 : 0);
+        static bool raised[16] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
+        const int which = a.sp.K == 10 ? 12 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
+                          : pipe ? 8 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) : (inv ? 1 : 0) + (l2e ? 2 : 0) + (init_ks == 4 ? 4 : 0);
         if (!raised[which]) {
             NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
             raised[which] = true;

@@ -595,6 +595,17 @@ def _k7_row_order(num_transform):
     return (feat * 24 + idx % 24).reshape(-1)  # [tiles * 32]
 
 
+def _k8_row_order_32(num_transform):
+    """The same for features padded to 32 rows (10 bins: 29 logits): two tiles per group, the 32
+    values a lane-half gets from them are the logits of feature 2g + half."""
+    i = torch.arange(32)
+    half = (i >> 2) & 1
+    q = ((i >> 3) << 2) | (i & 3)
+    t = torch.arange(num_transform)[:, None]  # one tile per feature on average
+    feat = 2 * (t // 2) + half[None, :]
+    return (feat * 32 + (t % 2) * 16 + q[None, :]).reshape(-1)  # [tiles * 32]
+
+
 def split_bf16x3(w):
     """fp32 -> three bf16 tensors with w == hi + mid + lo up to 2^-25 |w| (round to nearest even)."""
     hi = w.to(torch.bfloat16)
@@ -676,11 +687,12 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False)
     scale[:2 * K] = (math.log2(math.e) if log2e else 1.0) / math.sqrt(net.hidden_features)
     wf = (net.final_layer.weight.detach().double().view(dt, P, 128) * scale[None, :, None]).float()
     bf = (net.final_layer.bias.detach().double().view(dt, P) * scale[None, :]).float()
-    order_r = _k7_row_order(dt).to(dev)
-    wf = torch.cat((wf, wf.new_zeros(dt, 24 - P, 128)), dim=1).reshape(dt * 24, 128)
+    R = 24 if P <= 24 else 32  # rows per feature after padding (8 bins: 23 -> 24; 10 bins: 29 -> 32)
+    order_r = (_k7_row_order(dt) if R == 24 else _k8_row_order_32(dt)).to(dev)
+    wf = torch.cat((wf, wf.new_zeros(dt, R - P, 128)), dim=1).reshape(dt * R, 128)
     wf = wf.index_select(0, order_r).index_select(1, order_k)
-    bf = torch.cat((bf, bf.new_zeros(dt, 24 - P)), dim=1).reshape(dt * 24).index_select(0, order_r)
-    tiles = dt * 24 // 32
+    bf = torch.cat((bf, bf.new_zeros(dt, R - P)), dim=1).reshape(dt * R).index_select(0, order_r)
+    tiles = dt * R // 32
     # (p, tile, i, hs, k4, hf, j) -> (tile, hs, p, k4, hf, i, j): two stages per tile
     stages.append(pieces(wf).view(3, tiles, 32, 2, 4, 2, 8).permute(1, 3, 0, 4, 5, 2, 6).reshape(tiles * 2, -1))
     biases.append(_bias_accumulator_order(bf))

@@ -319,7 +319,8 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         from ..nn.nets.resnet import ResidualNet
         return (self.fuse_conditioner and self.fuse_final_linear and not torch.is_grad_enabled()
                 and context is None and type(net) is ResidualNet and net.context_features is None
-                and net.hidden_features == 128 and self.tails == "linear" and self.num_bins == 8
+                and net.hidden_features == 128 and self.tails == "linear" and self.num_bins in (8, 10)
+                and not (self.num_bins == 10 and self.resnet_log2e)
                 and self.num_identity_features <= 64 and self.num_transform_features % 4 == 0
                 and self.num_transform_features <= 64 and self.features <= 128
                 and all(b.activation is torch.nn.functional.relu and not b.use_batch_norm

@@ -339,15 +339,17 @@ def test_fused_conditioner_kernels_match_gemm_plus_k1(B, path, restore_fused_pat
     assert (lp.cpu().double() - lp_ref64).abs().max().item() < 5e-3
 
 
-@pytest.mark.parametrize("features,blocks", [(16, 1), (24, 3), (64, 0), (128, 2)])
-def test_whole_layer_kernel_shapes(features, blocks, restore_fused_path):
+@pytest.mark.parametrize("features,blocks,bins", [(16, 1, 8), (24, 3, 8), (64, 0, 8), (128, 2, 8),
+                                                  (64, 2, 10), (128, 1, 10), (8, 0, 10)])
+def test_whole_layer_kernel_shapes(features, blocks, bins, restore_fused_path):
     """K8 on other layer geometries (d_i = d_t = 8 .. 64), block counts,
     ragged batches, NaN / out-of-range inputs: equal to the unfused path within the GEMM noise,
     pass-through columns bit-exact, NaN pattern identical."""
     from nflows_amd import configs
-    flow = configs.rq_nsf_flow(num_layers=2, features=features, num_bins=8, hidden_features=128,
+    flow = configs.rq_nsf_flow(num_layers=2, features=features, num_bins=bins, hidden_features=128,
                                num_blocks=blocks, seed=11).to(DEV).eval()
     with torch.no_grad():
+        assert flow._transform._transforms[1]._resnet_eligible(None)
         for n_, p in flow.named_parameters():
             if "final_layer" in n_:
                 p.mul_(3.0)
