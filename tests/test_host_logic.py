@@ -210,7 +210,8 @@ def test_distribution_template_methods():
     assert "_log_z" not in d.state_dict() and d._log_z.dtype == torch.float64
 
 
-def test_whole_layer_packing_is_a_lossless_rearrangement():
+@pytest.mark.parametrize("K", [8, 10])
+def test_whole_layer_packing_is_a_lossless_rearrangement(K):
     """Host side of K8 (ops.pack_resnet_conditioner, runs on CPU tensors): emulate what the kernel
     computes with the packed weights -- every GEMM transposed, the k index permuted the way the
     accumulator layout of the previous layer dictates, three bf16 pieces per weight -- and compare
@@ -219,14 +220,15 @@ def test_whole_layer_packing_is_a_lossless_rearrangement():
     from nflows_amd import ops
     from nflows_amd.nn.nets import ResidualNet
     torch.manual_seed(0)
-    dt, di, K, P = 8, 6, 8, 23
+    dt, di, P = 8, 6, 3 * K - 1
+    R = 24 if K == 8 else 32                        # rows per feature after padding
     net = ResidualNet(di, dt * P, hidden_features=128, num_blocks=2).double()
     with torch.no_grad():
         for p_ in net.parameters():
             p_.copy_(torch.randn_like(p_) * 0.3)
     wp, bp = ops.pack_resnet_conditioner(net.float(), dt, P)
     net = net.double()
-    tiles = dt * 24 // 32
+    tiles = dt * R // 32
     assert wp.shape == (2 + 16 * 2 + 2 * tiles, 768 * 8) and wp.dtype == torch.bfloat16
     assert bp.shape == (128 + 256 * 2 + tiles * 32,)
     w = wp.double().view(-1, 768, 8)          # [stage][vec4 slot][8 bf16]
@@ -310,6 +312,15 @@ def test_whole_layer_packing_is_a_lossless_rearrangement():
     assert stage == wp.shape[0]
     want = net.final_layer(want_hidden).view(32, dt, P).clone()
     want[..., :2 * K] /= np.sqrt(128.0)              # the folded 1/sqrt(hidden) scale
+    if K == 10:  # two tiles per group: the 32 values of a lane-half are feature 2g + half
+        for g in range(dt // 2):
+            for half in range(2):
+                lanes = torch.arange(32) + 32 * half
+                vals = torch.cat([out[2 * g + t][lanes] for t in range(2)], dim=1)   # [32 samples][32]
+                ref = want[:, 2 * g + half]
+                assert (vals[:, :P] - ref).abs().max().item() < 5e-6 * (1 + ref.abs().max().item()), (g, half)
+                assert vals[:, P:].abs().max().item() == 0.0                         # the pad rows
+        return
     for g in range(dt // 4):
         for half in range(2):
             lanes = torch.arange(32) + 32 * half
