@@ -289,7 +289,7 @@ def main():
                 k8_weights = layers_per_launch * (2 + 16 * nb_ + 2 * (dt_ * 24 // 32)) * 12288
                 bytes_ = io_bytes + k8_weights if path == "k8" else (io_bytes + 4 * B * H_) * layers_per_launch
                 r = {"bound": "mfma",
-                     "kernel": ("nfa::rqs_resnet_kernel<false, 1, 2, true>" if os.environ.get("NFA_K8_PIPE", "1") != "0" else "nfa::rqs_resnet_kernel<false, 1, 2, false>") if path == "k8" else "nfa::rqs_fused_linear_bf16_kernel<false>",
+                     "kernel": ("nfa::rqs_resnet_kernel<false, 1, 2, %s, 8>" % os.environ.get("NFA_K8_PIPE", "2")) if path == "k8" else "nfa::rqs_fused_linear_bf16_kernel<false>",
                      "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
                      "traffic": load_traffic("k8_pmc_traffic.json" if path == "k8" else "k7b_pmc_traffic.json"),
                      "algorithmic_flops_per_launch": flops,

@@ -370,7 +370,14 @@ __device__ __forceinline__ int rqs_eval_flat8(float x, const float* sl, const Rq
 //   num_w<S>, num_h<S>  S in [0, kNumSlices):    softmax numerators of the width / height logits
 //   finish<S>           S in [0, kFinishSlices): the two walks over the bins, the derivatives, the
 //                                                map inside the bin; the last slice selects y / lad
-template <bool INVERSE, int PRESCALED>
+//
+// FAST = true trades the reference's exact rounding sequence for fewer instructions where the
+// logits carry more noise than the rounding anyway (K8's logits come out of an in-kernel GEMM
+// whose summation order differs from the reference's: ~1e-6 relative): the exponent of a softmax
+// numerator is one rounded product instead of a two-float one, the bin size is
+// fma(e, om / den, min) instead of min + om * RN(e / den), a knot is one fma.  Prefix sums stay in
+// double.  Not bit-identical to the plain evaluation; same error class (tests/test_gpu_flows.py).
+template <bool INVERSE, int PRESCALED, bool FAST = false>
 struct FlatSteps {
     static_assert(PRESCALED == 1 || PRESCALED == 2, "logits already divided by sqrt(hidden)");
     static constexpr int kNumSlices = 20;
@@ -403,6 +410,8 @@ struct FlatSteps {
             constexpr int I = (S - 2) >> 1;
             if constexpr (PRESCALED == 2) {
                 if constexpr (((S - 2) & 1) == 0) e[I] = __builtin_amdgcn_exp2f(e[I] - m);
+            } else if constexpr (FAST) {
+                if constexpr (((S - 2) & 1) == 0) e[I] = __builtin_amdgcn_exp2f((e[I] - m) * 1.44269502162933349609375f);
             } else if constexpr (((S - 2) & 1) == 0) {
                 const float kLog2e = 1.44269502162933349609375f, kLog2eLo = 1.925963033500011e-08f;
                 const float v = e[I] - m;
@@ -434,12 +443,17 @@ struct FlatSteps {
                                         float& knot_lo, float& knot_hi) {
 #pragma clang fp contract(off)
         if constexpr (PART == 0) {
-            const float p = div_with_rcp(e[I], den, rden);
-            t1 = minbin + om * p;
+            if constexpr (FAST) {
+                t1 = __builtin_fmaf(e[I], rden, minbin);  // rden holds om / den here
+            } else {
+                const float p = div_with_rcp(e[I], den, rden);
+                t1 = minbin + om * p;
+            }
         } else if constexpr (PART == 1) {
             acc += (double)t1;
             const float c = (float)acc;
-            t2 = (I == 7) ? sp.right : sp.span_w * c + (-sp.right);
+            if constexpr (FAST) t2 = (I == 7) ? sp.right : __builtin_fmaf(sp.span_w, c, -sp.right);
+            else t2 = (I == 7) ? sp.right : sp.span_w * c + (-sp.right);
         } else {
             const bool take = SEARCH ? (x >= prev) : (I == k);
             if (take) {
@@ -478,6 +492,7 @@ struct FlatSteps {
             k = -1;
             cw0 = cw1 = ch0 = ch1 = 0.0f;
             rden = rcp_refined(INVERSE ? den_h : den_w);
+            if constexpr (FAST) rden *= INVERSE ? sp.om_h : sp.om_w;
             acc = 0.0;
             prev = -sp.right;
         } else if constexpr (S < MID) {
@@ -486,6 +501,7 @@ struct FlatSteps {
             else bin<true, I, PART>(ew, den_w, sp.min_w, sp.om_w, sp, cw0, cw1);
         } else if constexpr (S == MID) {
             rden = rcp_refined(INVERSE ? den_w : den_h);
+            if constexpr (FAST) rden *= INVERSE ? sp.om_w : sp.om_h;
             acc = 0.0;
             prev = -sp.right;
             u0 = sp.tail_logit;

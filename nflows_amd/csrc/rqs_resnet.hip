@@ -333,9 +333,9 @@ __device__ __forceinline__ void load_bias_tile(f32x16& acc, const float* bias_ti
 // spline results back to, fixed slots given by its table (the host composes all the permutations
 // between the layers into these tables), and the last table says which slot ends up at which
 // output position.  Weights and biases of all layers form one stream in execution order.
-template <bool INVERSE, int PRESCALED, int INIT_KS, bool PIPE = false, int KB = 8>
+template <bool INVERSE, int PRESCALED, int INIT_KS, int PIPE = 0, int KB = 8>  // PIPE: 0 plain loop, 1 woven, 2 woven with FlatSteps<FAST>
 __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs a) {
-    static_assert(KB == 8 || (KB == 10 && !PIPE && PRESCALED == 1), "10 bins: plain loop only");
+    static_assert(KB == 8 || (KB == 10 && PIPE == 0 && PRESCALED == 1), "10 bins: plain loop only");
     // dynamic LDS: the weight ring, then per wave a [D][33] row tile
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     __shared__ int s_tab[2][kTabLayer];   // tables of the current and the next layer
@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                     tile_to_pieces<false>(h[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
             }
             bias += 128;
-            if (PIPE) {
+            if (PIPE != 0) {
                 // (every wave has passed a stage barrier of this layer: nobody reads the previous
                 // layer's biases any more; the blocks' barriers come before the first use)
                 const float* fbias = a.bias + (size_t)layer * a.bias_per_layer + 128 + 256 * a.num_blocks;
@@ -529,9 +529,9 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                     lad_acc += l;
                 }
                 NFA_STAMP()
-            } else if constexpr (PIPE) {
+            } else if constexpr (PIPE != 0) {
                 // ---- final layer with the spline evaluation woven into the MFMAs (see gemm_tile_pumped)
-                using Steps = FlatSteps<INVERSE, PRESCALED>;
+                using Steps = FlatSteps<INVERSE, PRESCALED, PIPE == 2>;
                 Steps fa, fb;
                 float* slot_b = nullptr;
                 const float* fbias = s_fbias + half * 16;
@@ -684,12 +684,13 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     a.bias_per_layer = 128 + 256 * num_blocks + num_transform * rows_per_feature;
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = g_k7_trace;
-    // final layer with the spline evaluation woven into its MFMAs (not with the log2(e) fold); same
-    // results bit for bit as the plain loop,
-    // which NFA_K8_PIPE=0 brings back for A/B runs
+    // final layer with the spline evaluation woven into its MFMAs (not with the log2(e) fold):
+    //   2 (default)  woven, FlatSteps<FAST>: cheaper rounding sequence, same error class
+    //   1            woven, same results bit for bit as the plain loop
+    //   0            the plain loop
     static const int use_pipe = [] {
         const char* e = getenv("NFA_K8_PIPE");
-        return e ? atoi(e) : 1;
+        return e ? atoi(e) : 2;
     }();
     const bool pipe = use_pipe && !(flags & NFA_FLAG_LOGITS_LOG2E) && a.sp.K == 8;
     const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float) +
@@ -715,16 +716,20 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     }
 #undef NFA_K8_PICK
     if (a.sp.K == 10) {
-        if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, false, 10> : rqs_resnet_kernel<false, 1, 4, false, 10>;
-        else kern = inv ? rqs_resnet_kernel<true, 1, 2, false, 10> : rqs_resnet_kernel<false, 1, 2, false, 10>;
+        if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 0, 10> : rqs_resnet_kernel<false, 1, 4, 0, 10>;
+        else kern = inv ? rqs_resnet_kernel<true, 1, 2, 0, 10> : rqs_resnet_kernel<false, 1, 2, 0, 10>;
     }
-    if (pipe) {
-        if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, true> : rqs_resnet_kernel<false, 1, 4, true>;
-        else kern = inv ? rqs_resnet_kernel<true, 1, 2, true> : rqs_resnet_kernel<false, 1, 2, true>;
+    if (pipe && use_pipe == 2) {
+        if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 2> : rqs_resnet_kernel<false, 1, 4, 2>;
+        else kern = inv ? rqs_resnet_kernel<true, 1, 2, 2> : rqs_resnet_kernel<false, 1, 2, 2>;
+    } else if (pipe) {
+        if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 1> : rqs_resnet_kernel<false, 1, 4, 1>;
+        else kern = inv ? rqs_resnet_kernel<true, 1, 2, 1> : rqs_resnet_kernel<false, 1, 2, 1>;
     }
     if (lds > 64 * 1024) {
-        static bool raised[16] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
-        const int which = a.sp.K == 10 ? 12 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
+        static bool raised[20] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
+        const int which = (pipe && use_pipe == 2) ? 16 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
+                          : a.sp.K == 10 ? 12 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
                           : pipe ? 8 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) : (inv ? 1 : 0) + (l2e ? 2 : 0) + (init_ks == 4 ? 4 : 0);
         if (!raised[which]) {
             NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));

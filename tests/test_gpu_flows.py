@@ -576,9 +576,9 @@ def test_sibling_autoregressive_layers_against_reference_vectors(golden_dir, col
 @pytest.mark.parametrize("features,blocks", [(64, 2), (128, 2), (24, 1), (64, 0)])
 def test_woven_final_layer_is_bit_identical_to_the_plain_loop(tmp_path, features, blocks):
     """K8 evaluates the splines between the MFMAs of its final layer (gemm_tile_pumped); with
-    NFA_K8_PIPE=0 the evaluation follows the tiles as one block.  Same operations in the same order:
-    outputs and logabsdet agree bit for bit, forward and inverse, tails and NaN included.  (The
-    switch is read once per process, hence the two child processes.)"""
+    NFA_K8_PIPE=0 the evaluation follows the tiles as one block.  NFA_K8_PIPE=1: same operations in
+    the same order, outputs and logabsdet agree bit for bit, forward and inverse, tails and NaN
+    included.  (The switch is read once per process, hence the child processes.)"""
     import subprocess
     import sys
     script = tmp_path / "child.py"
@@ -597,9 +597,18 @@ def test_woven_final_layer_is_bit_identical_to_the_plain_loop(tmp_path, features
         "np.savez(sys.argv[1], y=y.cpu().numpy(), lad=lad.cpu().numpy(), xi=xi.cpu().numpy(), ladi=ladi.cpu().numpy())\n"
         % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     outs = []
-    for flag in ("0", "1"):
+    for flag in ("0", "1", "2"):
         out = str(tmp_path / ("pipe%s.npz" % flag))
         subprocess.check_call([sys.executable, str(script), out, str(features), str(blocks)], env=dict(os.environ, NFA_K8_PIPE=flag))
         outs.append(np.load(out))
     for key in ("y", "lad", "xi", "ladi"):
         assert np.array_equal(outs[0][key], outs[1][key], equal_nan=True), key
+    # NFA_K8_PIPE=2 (the default: woven, cheaper rounding sequence in the evaluation) is not
+    # bit-identical; it stays within the noise the in-kernel GEMMs put on the logits anyway
+    # (logabsdet: a sum over 5 layers x d_t features of values of order 1, i.e. a few ulp of ~30)
+    for key, tol, typical in (("y", 2e-5, 1e-6), ("lad", 4e-4, 4e-5), ("xi", 2e-5, 1e-6), ("ladi", 4e-4, 4e-5)):
+        a, b = outs[0][key], outs[2][key]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), key
+        ok = ~np.isnan(a)
+        d = np.abs(a[ok] - b[ok])
+        assert d.max() <= tol and np.median(d) <= typical, (key, d.max(), np.median(d))
