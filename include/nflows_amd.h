@@ -214,6 +214,11 @@ int nfa_rqs_coupling_fused_linear_f32(const float *inputs, const float *hidden,
  *                    with NFA_FLAG_LOGITS_LOG2E.
  *   bias_packed    float: initial_layer [4 tiles][2 lane-halves][16], every hidden Linear the
  *                  same, final_layer [tiles][2][16] (rows as in K7)
+ * Numerics: the GEMMs are fp32-accurate but sum in another order than the reference's, so results
+ * agree with nfa_rqs_coupling_f32 on the reference's own parameters to ~1e-6 relative, not bit for
+ * bit; for num_bins = 8 the spline evaluation therefore uses a shorter rounding sequence than the
+ * other kernels (same error class as the reference's fp32 path; environment NFA_K8_PIPE=1 selects
+ * the reference's exact sequence, =0 additionally the unwoven loop).
  * Supported: num_bins = 8 or 10 (the reference's default; not with NFA_FLAG_LOGITS_LOG2E), linear
  * tails, hidden_features = 128, d_i <= 64, d_t % 4 == 0, d_t <= 64, features % 4 == 0,
  * features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
