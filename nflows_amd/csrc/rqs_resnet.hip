@@ -692,7 +692,8 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         const char* e = getenv("NFA_K8_PIPE");
         return e ? atoi(e) : 2;
     }();
-    const bool pipe = use_pipe && !(flags & NFA_FLAG_LOGITS_LOG2E) && a.sp.K == 8;
+    // (with the log2(e) fold only the default woven form exists)
+    const bool pipe = use_pipe && a.sp.K == 8 && (!(flags & NFA_FLAG_LOGITS_LOG2E) || use_pipe == 2);
     const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float) +
                        (pipe ? (size_t)num_transform * 24 * sizeof(float) : 0);
     int64_t blocks = batch >> 7;
@@ -719,7 +720,10 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 0, 10> : rqs_resnet_kernel<false, 1, 4, 0, 10>;
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 0, 10> : rqs_resnet_kernel<false, 1, 2, 0, 10>;
     }
-    if (pipe && use_pipe == 2) {
+    if (pipe && use_pipe == 2 && l2e) {
+        if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 2, 4, 2> : rqs_resnet_kernel<false, 2, 4, 2>;
+        else kern = inv ? rqs_resnet_kernel<true, 2, 2, 2> : rqs_resnet_kernel<false, 2, 2, 2>;
+    } else if (pipe && use_pipe == 2) {
         if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 2> : rqs_resnet_kernel<false, 1, 4, 2>;
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 2> : rqs_resnet_kernel<false, 1, 2, 2>;
     } else if (pipe) {
@@ -727,8 +731,8 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 1> : rqs_resnet_kernel<false, 1, 2, 1>;
     }
     if (lds > 64 * 1024) {
-        static bool raised[20] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
-        const int which = (pipe && use_pipe == 2) ? 16 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
+        static bool raised[24] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
+        const int which = (pipe && use_pipe == 2) ? 16 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (l2e ? 4 : 0)
                           : a.sp.K == 10 ? 12 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
                           : pipe ? 8 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) : (inv ? 1 : 0) + (l2e ? 2 : 0) + (init_ks == 4 ? 4 : 0);
         if (!raised[which]) {

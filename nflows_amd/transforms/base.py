@@ -56,7 +56,7 @@ class CompositeTransform(Transform):
         return (coupling.features, coupling.num_transform_features, coupling.num_identity_features,
                 len(coupling.transform_net.blocks), coupling.num_bins, coupling.tail_bound,
                 coupling.min_bin_width, coupling.min_bin_height, coupling.min_derivative,
-                getattr(coupling, "resnet_log2e", False))
+                coupling._log2e() if hasattr(coupling, "_log2e") else False)
 
     def _collect_run(self, layers, start, inputs, context, inverse):
         """Longest run of units starting at `start`: forward a unit is [column Permutation]? +
@@ -134,7 +134,7 @@ class CompositeTransform(Transform):
         head = ops.rqs_coupling_resnet(
             inputs[:full], weights, biases, tables, first.num_transform_features, first.num_identity_features,
             len(first.transform_net.blocks), first._spec(), inverse, total[:full],
-            log2e=getattr(first, "resnet_log2e", False), num_layers=len(units))
+            log2e=first._log2e() if hasattr(first, "_log2e") else False, num_layers=len(units))
         if head is None:
             return None
         if full == batch:

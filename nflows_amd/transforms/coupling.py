@@ -320,7 +320,6 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         return (self.fuse_conditioner and self.fuse_final_linear and not torch.is_grad_enabled()
                 and context is None and type(net) is ResidualNet and net.context_features is None
                 and net.hidden_features == 128 and self.tails == "linear" and self.num_bins in (8, 10)
-                and not (self.num_bins == 10 and self.resnet_log2e)
                 and self.num_identity_features <= 64 and self.num_transform_features % 4 == 0
                 and self.num_transform_features <= 64 and self.features <= 128
                 and all(b.activation is torch.nn.functional.relu and not b.use_batch_norm
@@ -330,14 +329,18 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
     # softmax numerator)
     resnet_log2e = os.environ.get("NFA_K8_LOG2E", "0") != "0"
 
+    def _log2e(self):
+        """The fold is implemented for the 8-bin evaluation only."""
+        return self.resnet_log2e and self.num_bins == 8
+
     def _packed_resnet(self):
         net = self.transform_net
-        key = tuple((p.data_ptr(), p._version) for p in net.parameters()) + (self.resnet_log2e,)
+        key = tuple((p.data_ptr(), p._version) for p in net.parameters()) + (self._log2e(),)
         cached = getattr(self, "_packed_resnet_cache", None)
         if cached is None or cached[0] != key:
             cached = (key, ops.pack_resnet_conditioner(net, self.num_transform_features,
                                                        self._transform_dim_multiplier(),
-                                                       log2e=self.resnet_log2e))
+                                                       log2e=self._log2e()))
             self._packed_resnet_cache = cached
         return cached[1]
 
@@ -366,12 +369,12 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         full = (B // 128) * 128
         if full == B:
             return ops.rqs_coupling_resnet(inputs, wp, bp, tables, dt, di, nb, spec, inverse, accumulate_into,
-                                           log2e=self.resnet_log2e)
+                                           log2e=self._log2e())
         # ragged batch: full 128-row blocks here, the tail through the PyTorch conditioner + K1
         acc_head = None if accumulate_into is None else accumulate_into[:full]
         acc_tail = None if accumulate_into is None else accumulate_into[full:]
         head = ops.rqs_coupling_resnet(inputs[:full], wp, bp, tables, dt, di, nb, spec, inverse, acc_head,
-                                       log2e=self.resnet_log2e)
+                                       log2e=self._log2e())
         if head is None:
             return None
         tail_in = inputs[full:]
