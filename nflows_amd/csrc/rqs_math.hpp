@@ -462,9 +462,9 @@ struct FlatSteps {
                 knot_hi = t2;
             }
             prev = t2;
-            if (!SEARCH && I < 7) {  // the bin's two derivative logits (select chain, no indexing)
-                u0 = (k == I + 1) ? sd[I < 7 ? I : 0] : u0;
-                u1 = (k == I) ? sd[I < 7 ? I : 0] : u1;
+            if (!SEARCH) {  // the bin's two derivative logits (select chain on the same compare, no indexing)
+                if (I >= 1) u0 = take ? sd[I >= 1 ? I - 1 : 0] : u0;
+                if (I < 7) u1 = take ? sd[I < 7 ? I : 0] : u1;
             }
         }
     }
@@ -473,13 +473,15 @@ struct FlatSteps {
     template <int PART>
     __device__ __forceinline__ void derivative(float u, float& d, const RqsDev& sp) {
 #pragma clang fp contract(off)
+        // (callers guarantee beta == 1: the coupling layers never enable the identity initialisation,
+        // coupling.py:572-582; softplus_beta's general form carries an IEEE division per call)
         if constexpr (PART == 0) {
-            t3 = u * sp.beta;
+            t3 = u;
             t4 = exp_noclamp(t3);
         } else if constexpr (PART == 1) {
             t4 = log1p_nonneg(t4);
         } else {
-            d = sp.min_d + (t3 > 20.0f ? u : (sp.beta == 1.0f ? t4 : t4 / sp.beta));
+            d = sp.min_d + (t3 > 20.0f ? u : t4);
         }
     }
 

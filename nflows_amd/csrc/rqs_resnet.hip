@@ -658,6 +658,7 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     int rc = make_dev_spec(spec, &a.sp);
     if (rc != NFA_OK) return rc;
     const int rows_per_feature = a.sp.K == 10 ? 32 : 24;
+    if (a.sp.beta != 1.0f) return NFA_ERR_UNSUPPORTED;  // (identity initialisation: functional callers only)
     if ((a.sp.K != 8 && a.sp.K != 10) || (a.sp.K == 10 && (flags & NFA_FLAG_LOGITS_LOG2E)) || !a.sp.linear ||
         hidden_features != 128 || (num_transform & 3) != 0 ||
         num_transform > 64 || num_identity > 64 || features > 128 || (features & 3) != 0 ||
