@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Secondary baseline: the reference's own op sequence (its bit-identical eager port,
+"""(measurement script, not collected by pytest; lives under tests/ because it runs the oracle)
+Secondary baseline: the reference's own op sequence (its bit-identical eager port,
 oracle/eager.py) run as PyTorch-eager ON THE SAME MI355X, next to the fused kernels.  Informational."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

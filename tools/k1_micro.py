@@ -21,7 +21,6 @@ ap.add_argument("--bins", type=int, default=8)
 ap.add_argument("--reps", type=int, default=50)
 ap.add_argument("--inverse", action="store_true")
 ap.add_argument("--perm", action="store_true")
-ap.add_argument("--check", action="store_true")
 a = ap.parse_args()
 
 dev = "cuda:0"
@@ -52,13 +51,3 @@ nbytes = 4 * (B * D + B * tidx.numel() * P + B * D + B)
 print("%s lib=%s  median %.1f us  min %.1f us  -> %.0f GB/s algorithmic (median)" % (
     "inverse" if a.inverse else "forward", os.path.basename(os.environ.get("NFLOWS_AMD_LIB", "default")),
     med * 1e3, ms[0] * 1e3, nbytes / (med * 1e-3) / 1e9))
-if a.check:
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from oracle import capi
-    rows = slice(0, 4096)
-    ospec = capi.make_spec(K, tails="linear", tail_bound=3.0, wh_divisor=float(np.sqrt(128)))
-    pidx = None if perm is None else perm.cpu().numpy()
-    oy, ol, _ = capi.rqs_coupling(x[rows].cpu().numpy(), params[(a.reps - 1) % nbuf][rows].cpu().numpy(),
-                                  tidx.cpu().numpy(), ospec, inverse=a.inverse, in_perm=pidx)
-    print("  max |y - oracle| = %.2e   max |lad - oracle| = %.2e" % (
-        np.abs(y[rows].cpu().numpy() - oy).max(), np.abs(lad[rows].cpu().numpy() - ol).max()))
