@@ -109,6 +109,11 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, re.M), f
                 assert "nfa_oracle" not in text and "oracle/" not in text and "oracle." not in text, f
+    # measurement scripts under tools/ do not use it either (those that do live under tests/)
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py"):
+            text = open(os.path.join(ROOT, "tools", f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", text, re.M), f
 
 
 def test_state_dict_contract(golden_dir):
