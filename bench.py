@@ -316,7 +316,7 @@ def main():
 
         roofline = roofline_of(args.path, k1_ms, len(k1_ms) / args.steps) if k1_ms else None
         roofline_k1 = None
-        if args.path != "k1" and not args.skip_k1_roofline:
+        if args.path != "k1" and not args.skip_k1_roofline and world == 1:  # (N = 1 only: the other ranks are done)
             # the HBM-bound spline kernel K1 (what the fused kernels replace on this shape), measured
             # the same way in a short separate run with the conditioner left to PyTorch / hipBLASLt
             select_path("k1")
@@ -374,6 +374,7 @@ def main():
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
