@@ -152,10 +152,18 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    # NFA_BENCH_BACKEND=gloo: dry run of the multi-rank control flow on a box with fewer GPUs than
+    # ranks (ranks share devices; numbers are meaningless) -- the real runs use RCCL
+    backend = os.environ.get("NFA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
