@@ -612,3 +612,45 @@ def test_woven_final_layer_is_bit_identical_to_the_plain_loop(tmp_path, features
         ok = ~np.isnan(a)
         d = np.abs(a[ok] - b[ok])
         assert d.max() <= tol and np.median(d) <= typical, (key, d.max(), np.median(d))
+
+
+def test_whole_layer_kernel_random_geometries(restore_fused_path):
+    """Seeded sweep over layer geometries the parametrised tests do not hit: random (non-alternating)
+    masks with d_t a multiple of 4, d_i and d_t up to 64, 8 and 10 bins, 0..3 residual blocks, with
+    and without neighbouring permutations, ragged batches.  K8 against the unfused path."""
+    import nflows_amd
+    from nflows_amd import transforms as T
+    from nflows_amd.nn.nets import ResidualNet
+    rng = np.random.RandomState(20260924)
+    for case in range(12):
+        D = int(rng.choice([8, 12, 20, 36, 64, 96, 128]))
+        dt = int(rng.choice([v for v in range(4, min(D, 68), 4) if D - v <= 64 and D - v >= 1]))
+        bins = int(rng.choice([8, 10]))
+        blocks = int(rng.randint(0, 4))
+        mask = np.zeros(D, dtype=np.int64)
+        mask[rng.permutation(D)[:dt]] = 1
+        torch.manual_seed(1000 + case)
+        layers = []
+        for i in range(3):
+            if rng.rand() < 0.7:
+                layers.append(T.RandomPermutation(D))
+            m = torch.from_numpy(mask if i % 2 == 0 else np.roll(mask, 1))
+            layers.append(T.PiecewiseRationalQuadraticCouplingTransform(
+                m, lambda a, b, nb=blocks: ResidualNet(a, b, hidden_features=128, num_blocks=nb),
+                num_bins=bins, tails="linear", tail_bound=3.0))
+        t = T.CompositeTransform(layers).to(DEV).eval()
+        B = int(rng.choice([128, 256 + 17, 1024, 1000]))
+        x = torch.randn(B, D, device=DEV) * 1.3
+        with torch.no_grad():
+            _select_fused_path("k8")
+            assert all(l._resnet_eligible(None) for l in layers if hasattr(l, "_resnet_eligible")), (D, dt)
+            z1, l1 = t(x)
+            x1, li1 = t.inverse(z1)
+            _select_fused_path("none")
+            z0, l0 = t(x)
+            x0, li0 = t.inverse(z1)
+        nflows_amd.check_status()
+        what = "case %d: D=%d d_t=%d bins=%d blocks=%d B=%d" % (case, D, dt, bins, blocks, B)
+        for got, want, tol in ((z1, z0, 1e-4), (l1, l0, 2e-3), (x1, x0, 1e-4), (li1, li0, 2e-3)):
+            d = (got - want).abs()
+            assert d.max().item() < tol and d.median().item() < tol / 30, (what, d.max().item(), d.median().item())
