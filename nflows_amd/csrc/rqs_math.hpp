@@ -377,16 +377,17 @@ __device__ __forceinline__ int rqs_eval_flat8(float x, const float* sl, const Rq
 // numerator is one rounded product instead of a two-float one, the bin size is
 // fma(e, om / den, min) instead of min + om * RN(e / den), a knot is one fma.  Prefix sums stay in
 // double.  Not bit-identical to the plain evaluation; same error class (tests/test_gpu_flows.py).
-template <bool INVERSE, int PRESCALED, bool FAST = false>
+template <bool INVERSE, int PRESCALED, bool FAST = false, int KT = 8>
 struct FlatSteps {
     static_assert(PRESCALED == 1 || PRESCALED == 2, "logits already divided by sqrt(hidden)");
-    static constexpr int kNumSlices = 20;
-    static constexpr int kWalk = 24;                           // 8 bins x 3 slices
-    static constexpr int kFinishSlices = 1 + kWalk + 1 + kWalk + 6 + 5 + 1;  // = 62
+    static_assert(KT == 8 || (KT == 10 && FAST && PRESCALED == 1), "10 bins: the shorter sequence only");
+    static constexpr int kNumSlices = 2 * KT + 4;
+    static constexpr int kWalk = 3 * KT;                       // KT bins x 3 slices
+    static constexpr int kFinishSlices = 1 + kWalk + 1 + kWalk + 6 + 5 + 1;  // = 62 for 8 bins
     static constexpr int kFirstWalkSlices = 1 + kWalk;  // these read only the first walk's numerators
     static constexpr bool kInverse = INVERSE;
-    float ew[8], eh[8];  // logits, then softmax numerators
-    float sd[7];         // derivative logits
+    float ew[KT], eh[KT];  // logits, then softmax numerators
+    float sd[KT - 1];      // derivative logits
     float x;
     float den_w, den_h, rden, prev;
     double acc;
@@ -399,14 +400,15 @@ struct FlatSteps {
     float m_w, m_h, lo_w, lo_h;  // per logit set, so that the two numerator passes can alternate
 
     template <int S>
-    __device__ __forceinline__ void numerators(float (&e)[8], float& den, float& m, float& tl) {
+    __device__ __forceinline__ void numerators(float (&e)[KT], float& den, float& m, float& tl) {
 #pragma clang fp contract(off)
         if constexpr (S == 0) {          // max of the first four
             if (PRESCALED == 2) m = fmaxf(fmaxf(fmaxf(e[0], e[1]), e[2]), e[3]);
             else m = fmaxf(fmaxf(fmaxf(fmaxf(-INFINITY, e[0]), e[1]), e[2]), e[3]);
         } else if constexpr (S == 1) {
             m = fmaxf(fmaxf(fmaxf(fmaxf(m, e[4]), e[5]), e[6]), e[7]);
-        } else if constexpr (S < 18) {   // one logit in two slices: exponent in two floats | 2^hi (1 + lo ln2)
+            if constexpr (KT == 10) m = fmaxf(fmaxf(m, e[8]), e[9]);
+        } else if constexpr (S < 2 + 2 * KT) {   // one logit in two slices: exponent in two floats | 2^hi (1 + lo ln2)
             constexpr int I = (S - 2) >> 1;
             if constexpr (PRESCALED == 2) {
                 if constexpr (((S - 2) & 1) == 0) e[I] = __builtin_amdgcn_exp2f(e[I] - m);
@@ -425,10 +427,11 @@ struct FlatSteps {
                 const float e0 = __builtin_amdgcn_exp2f(e[I]);
                 e[I] = __builtin_fmaf(e0, tl * kLn2, e0);
             }
-        } else if constexpr (S == 18) {
+        } else if constexpr (S == 2 + 2 * KT) {
             tl = (e[0] + e[1]) + (e[2] + e[3]);
         } else {
             den = tl + ((e[4] + e[5]) + (e[6] + e[7]));
+            if constexpr (KT == 10) den += e[8] + e[9];
         }
     }
     template <int S>
@@ -439,7 +442,7 @@ struct FlatSteps {
     // one bin of a walk (walk_bins) in three slices; SEARCH picks the bin x falls into, otherwise
     // bin k is picked
     template <bool SEARCH, int I, int PART>
-    __device__ __forceinline__ void bin(const float (&e)[8], float den, float minbin, float om, const RqsDev& sp,
+    __device__ __forceinline__ void bin(const float (&e)[KT], float den, float minbin, float om, const RqsDev& sp,
                                         float& knot_lo, float& knot_hi) {
 #pragma clang fp contract(off)
         if constexpr (PART == 0) {
@@ -452,8 +455,8 @@ struct FlatSteps {
         } else if constexpr (PART == 1) {
             acc += (double)t1;
             const float c = (float)acc;
-            if constexpr (FAST) t2 = (I == 7) ? sp.right : __builtin_fmaf(sp.span_w, c, -sp.right);
-            else t2 = (I == 7) ? sp.right : sp.span_w * c + (-sp.right);
+            if constexpr (FAST) t2 = (I == KT - 1) ? sp.right : __builtin_fmaf(sp.span_w, c, -sp.right);
+            else t2 = (I == KT - 1) ? sp.right : sp.span_w * c + (-sp.right);
         } else {
             const bool take = SEARCH ? (x >= prev) : (I == k);
             if (take) {
@@ -464,7 +467,7 @@ struct FlatSteps {
             prev = t2;
             if (!SEARCH) {  // the bin's two derivative logits (select chain on the same compare, no indexing)
                 if (I >= 1) u0 = take ? sd[I >= 1 ? I - 1 : 0] : u0;
-                if (I < 7) u1 = take ? sd[I < 7 ? I : 0] : u1;
+                if (I < KT - 1) u1 = take ? sd[I < KT - 1 ? I : 0] : u1;
             }
         }
     }
@@ -578,6 +581,24 @@ struct FlatSteps {
         }
     }
 };
+
+// every slice of a FlatSteps evaluation in order (callers that do not interleave it with anything)
+template <int PHASE, int I, class Steps>
+__device__ __forceinline__ void flat_steps_run(Steps& f, const RqsDev& sp) {
+    constexpr int N = PHASE == 2 ? Steps::kFinishSlices : Steps::kNumSlices;
+    if constexpr (I < N) {
+        if constexpr (PHASE == 0) f.template num_w<I>();
+        else if constexpr (PHASE == 1) f.template num_h<I>();
+        else f.template finish<I>(sp);
+        flat_steps_run<PHASE, I + 1>(f, sp);
+    }
+}
+template <class Steps>
+__device__ __forceinline__ void flat_steps_all(Steps& f, const RqsDev& sp) {
+    flat_steps_run<0, 0>(f, sp);
+    flat_steps_run<1, 0>(f, sp);
+    flat_steps_run<2, 0>(f, sp);
+}
 
 // host side: nfa_rqs_spec (doubles, as the reference's Python floats) -> fp32 device constants,
 // rounded exactly where aten rounds them

@@ -523,10 +523,19 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                         p[q] = acc[0][q];
                         p[16 + q] = acc[1][q];
                     }
-                    float y, l;
-                    my_status |= rqs_eval<10, INVERSE, true, true>(xin, p, sp10, y, l);
-                    *slot = y;
-                    lad_acc += l;
+                    // (the shorter rounding sequence, as for 8 bins: see FlatSteps<FAST>)
+                    FlatSteps<INVERSE, 1, true, 10> f;
+                    f.x = xin;
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) {
+                        f.ew[j] = p[j];
+                        f.eh[j] = p[10 + j];
+                        if (j < 9) f.sd[j] = p[20 + j];
+                    }
+                    flat_steps_all(f, sp10);
+                    *slot = f.y;
+                    lad_acc += f.lad;
+                    my_status |= f.status;
                 }
                 NFA_STAMP()
             } else if constexpr (PIPE != 0) {
