@@ -181,12 +181,14 @@ __device__ __forceinline__ void gemm_tile(f32x16& acc, const bf16x8 (&ph)[8], co
 //     U1 = finish A, width numerators of B  during T2's MFMAs
 //     U2 = height numerators of B, finish B during T0's MFMAs of the next group
 // `sched_barrier(0)` around every piece keeps hipcc from regrouping MFMAs and VALU work.
-enum { kUnitNone = 0, kUnitNumA = 1, kUnitFinishA = 2, kUnitFinishB = 3 };
+enum { kUnitNone = 0, kUnitNumA = 1, kUnitFinishA = 2, kUnitFinishB = 3,
+       kUnitNumW10 = 4, kUnitRest10 = 5 };  // 10 bins: one feature per lane-half, widths | heights + finish
 
 template <int UNIT, class Steps>
 constexpr int spline_unit_slices() {
     return UNIT == kUnitNumA ? 2 * Steps::kNumSlices
-                             : (UNIT == kUnitNone ? 0 : Steps::kNumSlices + Steps::kFinishSlices);
+           : UNIT == kUnitNumW10 ? Steps::kNumSlices
+                                 : (UNIT == kUnitNone ? 0 : Steps::kNumSlices + Steps::kFinishSlices);
 }
 
 // Slice I of a unit.  Where two parts of a unit do not depend on each other their slices alternate,
@@ -198,7 +200,12 @@ constexpr int spline_unit_slices() {
 template <int UNIT, int I, class Steps>
 __device__ __forceinline__ void spline_unit_slice(Steps& fa, Steps& fb, const RqsDev& sp) {
     constexpr int N = Steps::kNumSlices;
-    if constexpr (UNIT == kUnitNumA) {
+    if constexpr (UNIT == kUnitNumW10) {
+        fa.template num_w<I>();
+    } else if constexpr (UNIT == kUnitRest10) {
+        if constexpr (I < N) fa.template num_h<I>();
+        else fa.template finish<I - N>(sp);
+    } else if constexpr (UNIT == kUnitNumA) {
         if constexpr ((I & 1) == 0) fa.template num_w<(I >> 1)>();
         else fa.template num_h<(I >> 1)>();
     } else if constexpr (UNIT == kUnitFinishA) {
@@ -341,7 +348,7 @@ __device__ __forceinline__ void load_bias_tile(f32x16& acc, const float* bias_ti
 // output position.  Weights and biases of all layers form one stream in execution order.
 template <bool INVERSE, int PRESCALED, int INIT_KS, int PIPE = 0, int KB = 8>  // PIPE: 0 plain loop, 1 woven, 2 woven with FlatSteps<FAST>
 __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs a) {
-    static_assert(KB == 8 || (KB == 10 && PIPE == 0 && PRESCALED == 1), "10 bins: plain loop only");
+    static_assert(KB == 8 || (KB == 10 && PIPE != 1 && PRESCALED == 1), "10 bins: plain loop, or woven with the shorter sequence");
     // dynamic LDS: the weight ring, then per wave a [D][33] row tile
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     __shared__ int s_tab[2][kTabLayer];   // tables of the current and the next layer
@@ -470,7 +477,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                 // (every wave has passed a stage barrier of this layer: nobody reads the previous
                 // layer's biases any more; the blocks' barriers come before the first use)
                 const float* fbias = a.bias + (size_t)layer * a.bias_per_layer + 128 + 256 * a.num_blocks;
-                for (int i = tid; i < dt * 24; i += kBlock) s_fbias[i] = fbias[i];
+                for (int i = tid; i < dt * (KB == 10 ? 32 : 24); i += kBlock) s_fbias[i] = fbias[i];
                 // without residual blocks the final layer follows at once: no stage barrier in between
                 if (a.num_blocks == 0) __syncthreads();
             }
@@ -508,7 +515,48 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                 NFA_STAMP()
             }
 
-            if constexpr (KB == 10) {
+            if constexpr (KB == 10 && PIPE == 2) {
+                // ---- 10 bins, woven: the feature's width numerators (tile 0 holds the ten width
+                //      logits) run between the MFMAs of tile 1, everything else between those of the
+                //      next group's tile 0; one FlatSteps object, 32 accumulator registers
+                using Steps = FlatSteps<INVERSE, 1, true, 10>;
+                Steps f;
+                const float* fbias = s_fbias + half * 16;
+                const int groups10 = dt >> 1;
+                f32x16 acc0, acc1;
+                float hrest[6];
+                float* slot = s_row + tab[kTabTr + half] * kRowPad + r;
+                load_bias_tile(acc0, fbias);
+                gemm_tile<false>(acc0, ph, pm, pl, sm, lane);
+                for (int g = 0; g < groups10; ++g) {
+                    f.x = *slot;
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) f.ew[j] = acc0[j];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) hrest[j] = acc0[10 + j];
+                    load_bias_tile(acc1, fbias + (g * 2 + 1) * 32);
+                    gemm_tile_pumped<kUnitNumW10>(acc1, ph, pm, pl, sm, lane, f, f, a.sp);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) f.eh[j] = hrest[j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f.eh[6 + j] = acc1[j];
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) f.sd[j] = acc1[4 + j];
+                    if (g + 1 < groups10) {
+                        float* next_slot = s_row + tab[kTabTr + (g + 1) * 2 + half] * kRowPad + r;
+                        load_bias_tile(acc0, fbias + (g * 2 + 2) * 32);
+                        gemm_tile_pumped<kUnitRest10>(acc0, ph, pm, pl, sm, lane, f, f, a.sp);
+                        *slot = f.y;
+                        slot = next_slot;
+                    } else {
+                        spline_unit_range<kUnitRest10, 0, spline_unit_slices<kUnitRest10, Steps>()>(f, f, a.sp);
+                        *slot = f.y;
+                    }
+                    lad_acc += f.lad;
+                    my_status |= f.status;
+                }
+                NFA_STAMP()
+            } else if constexpr (KB == 10) {
                 // ---- final layer for 10 bins (the reference's default): 29 logits per feature padded
                 //      to 32 rows, two 32-row tiles per group; the rows are ordered so that the 32
                 //      accumulator values of lane-half h are the logits of feature 2g + h
@@ -709,9 +757,10 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         return e ? atoi(e) : 2;
     }();
     // (with the log2(e) fold only the default woven form exists)
-    const bool pipe = use_pipe && a.sp.K == 8 && (!(flags & NFA_FLAG_LOGITS_LOG2E) || use_pipe == 2);
+    const bool pipe = use_pipe && ((a.sp.K == 8 && (!(flags & NFA_FLAG_LOGITS_LOG2E) || use_pipe == 2)) ||
+                                  (a.sp.K == 10 && use_pipe == 2));
     const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float) +
-                       (pipe ? (size_t)num_transform * 24 * sizeof(float) : 0);
+                       (pipe ? (size_t)num_transform * rows_per_feature * sizeof(float) : 0);
     int64_t blocks = batch >> 7;
     const int64_t per_cu = lds + 2048 <= 80 * 1024 ? 2 : 1;
     const int64_t cap = (int64_t)device_cu_count() * per_cu;
@@ -732,11 +781,13 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         else NFA_K8_PICK(false, 1);
     }
 #undef NFA_K8_PICK
-    if (a.sp.K == 10) {
+    if (a.sp.K == 10 && pipe) {
+        if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 2, 10> : rqs_resnet_kernel<false, 1, 4, 2, 10>;
+        else kern = inv ? rqs_resnet_kernel<true, 1, 2, 2, 10> : rqs_resnet_kernel<false, 1, 2, 2, 10>;
+    } else if (a.sp.K == 10) {
         if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 0, 10> : rqs_resnet_kernel<false, 1, 4, 0, 10>;
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 0, 10> : rqs_resnet_kernel<false, 1, 2, 0, 10>;
-    }
-    if (pipe && use_pipe == 2 && l2e) {
+    } else if (pipe && use_pipe == 2 && l2e) {
         if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 2, 4, 2> : rqs_resnet_kernel<false, 2, 4, 2>;
         else kern = inv ? rqs_resnet_kernel<true, 2, 2, 2> : rqs_resnet_kernel<false, 2, 2, 2>;
     } else if (pipe && use_pipe == 2) {
@@ -747,9 +798,9 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 1> : rqs_resnet_kernel<false, 1, 2, 1>;
     }
     if (lds > 64 * 1024) {
-        static bool raised[24] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
-        const int which = (pipe && use_pipe == 2) ? 16 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (l2e ? 4 : 0)
-                          : a.sp.K == 10 ? 12 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
+        static bool raised[28] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
+        const int which = a.sp.K == 10 ? (pipe ? 24 : 12) + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
+                          : (pipe && use_pipe == 2) ? 16 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (l2e ? 4 : 0)
                           : pipe ? 8 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) : (inv ? 1 : 0) + (l2e ? 2 : 0) + (init_ks == 4 ? 4 : 0);
         if (!raised[which]) {
             NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
