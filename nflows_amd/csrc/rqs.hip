@@ -112,6 +112,17 @@ __global__ void __launch_bounds__(BLOCK) rqs_coupling_kernel(const CouplingArgs 
         float* s_o = s_out + tile_store_offset(a.out + row0 * D);
         const bool chunked = a.C < nitems;  // only with R == 1: one very wide sample (d_t*P large)
         float acc = 0.0f;                   // chunked mode: this lane's share of the sample's sum
+        if (nitems == 0) {
+            // a mask without transformed features (num_transform == 0): the layer is the fused
+            // permutation alone; the chunk loop below, which normally hosts this copy, never runs
+            __syncthreads();
+            for (int e = tid; e < rows * D; e += BLOCK) {
+                const int r = (int)fastdiv((uint32_t)e, a.div_D);
+                const int c = e - r * D;
+                s_o[e - c + s_dst[c]] = s_x[mx + e - c + s_src[c]];
+            }
+            __syncthreads();
+        }
         for (int c0 = 0; c0 < nitems; c0 += a.C) {
             const int cn = (nitems - c0) < a.C ? (nitems - c0) : a.C;
             const int mp = tile_load<BLOCK>(a.params + (row0 * dt + c0) * (int64_t)P, cn * P, s_p, tid);

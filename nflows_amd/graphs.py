@@ -16,7 +16,11 @@ import torch
 
 
 class GraphedLogProb:
-    """Replays `flow.log_prob(inputs)` (no grad) for a fixed input shape."""
+    """Replays `flow.log_prob(inputs)` (no grad) for a fixed input shape.
+
+    The captured kernels read the weights of capture time: parameters updated in place are seen
+    by the library GEMMs, but the whole-layer kernels read packed copies made before the capture.
+    Re-capture (build a new GraphedLogProb) after changing weights."""
 
     def __init__(self, flow, example_inputs, warmup=3):
         if not example_inputs.is_cuda:

@@ -49,20 +49,36 @@ def sharded_log_likelihood(flow, local_inputs, context=None, group=None):
 
 
 def gather_log_prob(local_log_prob, group=None):
-    """Per-sample log-densities of the whole batch on every rank (equal-sized row blocks)."""
+    """Per-sample log-densities of the whole batch on every rank, in rank order.  Row blocks may
+    differ in size (`row_block` hands out blocks that differ by one row when the batch does not
+    divide evenly): the counts are exchanged first and the blocks padded to the largest, so every
+    rank posts receive buffers of the same size (a mismatch hangs or fails in RCCL)."""
     world = _world(group)
     if world == 1:
         return local_log_prob
-    parts = [torch.empty_like(local_log_prob) for _ in range(world)]
-    dist.all_gather(parts, local_log_prob.contiguous(), group=group)
-    return torch.cat(parts, dim=0)
+    local = local_log_prob.contiguous().reshape(-1)
+    count = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    counts = [torch.empty_like(count) for _ in range(world)]
+    dist.all_gather(counts, count, group=group)
+    counts = [int(c.item()) for c in counts]
+    longest = max(counts)
+    padded = local if local.numel() == longest else torch.cat((local, local.new_zeros(longest - local.numel())))
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[:n] for p, n in zip(parts, counts)], dim=0)
 
 
 def broadcast_model(module, src=0, group=None):
     """Replicates parameters and buffers from `src` (once, at start-up; ~17 MB for the 32-layer
-    flow).  Building every replica from the same seed makes this unnecessary."""
+    flow).  Building every replica from the same seed makes this unnecessary.  The tensors are
+    written in place under no_grad (their version counters advance) and the layers' packed-weight
+    caches are dropped explicitly, so the fused kernels never see weights from before the
+    broadcast."""
     if _world(group) == 1:
         return module
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src, group=group)
+    from . import invalidate_packed_weights
+    invalidate_packed_weights()
     return module

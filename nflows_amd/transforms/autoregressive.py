@@ -67,10 +67,15 @@ class AutoregressiveTransform(Transform):
         outputs = torch.zeros_like(inputs)
         logabsdet = inputs.new_zeros(batch)
         if torch.is_grad_enabled():
+            # differentiable form (training an inverse autoregressive flow, reparameterised
+            # sampling): the tensor handed to the conditioner is saved by its first layer for the
+            # weight gradient, so it is never written again -- every step writes its column into a
+            # fresh copy, like the reference's out-of-place loop (autoregressive.py:43-52)
             for t in range(features):
                 h = net.hidden(outputs, context)
                 params_t = torch.addmm(bias[t], h, weight[t].t())
                 column, lad_t = self._inverse_column(inputs[:, t], params_t)
+                outputs = outputs.clone()
                 outputs[:, t] = column
                 logabsdet = logabsdet + lad_t
             return outputs, logabsdet

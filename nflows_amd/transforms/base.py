@@ -6,17 +6,35 @@ Mirrors nflows/transforms/base.py: `Transform.forward/inverse(inputs, context=No
 MI355X-specific addition: `CompositeTransform` recognises a column `Permutation` that is
 adjacent to a coupling layer and hands the permutation to the coupling kernel (gather on the way
 in for `forward`, scatter on the way out for `inverse`), which removes one full read+write pass
-over the [batch, features] activations per layer.  Results are bit-identical to running the two
-transforms one after the other.
+over the [batch, features] activations per layer.  Folding a permutation is bit-identical to
+running the two transforms one after the other (it only changes which column a kernel reads or
+writes).  The whole-layer kernel is a different matter: it computes the conditioner's GEMMs in its
+own summation order, so its results agree with the layer-by-layer path to fp32 rounding, not bit
+for bit, and on a ragged batch the first 128 * floor(B / 128) rows take it while the remaining
+rows take the PyTorch conditioner + spline-kernel path.  A row's result is therefore reproducible
+for a fixed batch size, and independent of the batch size only within that tolerance (rows inside
+the full blocks are bit-identical whatever the batch).  `CompositeTransform.fuse_layer_runs = False` and
+`PiecewiseRationalQuadraticCouplingTransform.fuse_conditioner = False` select the layer-by-layer
+path everywhere.
 """
 import torch
 from torch import nn
 
+from .. import _cache
 from ..errors import InputOutsideDomain, InverseNotAvailable  # noqa: F401  (re-exported)
 
 
 class Transform(nn.Module):
     """Base class of all transforms."""
+
+    # weights arriving through load_state_dict / .to() / .cuda() / .double(): drop the packed copies
+    def _load_from_state_dict(self, *args, **kwargs):
+        _cache.invalidate()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, *args, **kwargs):
+        _cache.invalidate()
+        return super()._apply(*args, **kwargs)
 
     def forward(self, inputs, context=None):
         raise NotImplementedError()
@@ -102,7 +120,7 @@ class CompositeTransform(Transform):
         permutation changes."""
         from .. import ops
         packed = [c._packed_resnet() for c, _ in units]
-        key = (inverse, tuple(id(c) for c, _ in units),
+        key = (_cache.epoch(), inverse, tuple(id(c) for c, _ in units),
                tuple(c._packed_resnet_cache[0] for c, _ in units),
                tuple(None if p is None else (p._permutation.data_ptr(), p._permutation._version) for _, p in units))
         cache = self.__dict__.setdefault("_run_plans", {})

@@ -22,6 +22,7 @@ import numpy as np
 import torch
 from torch.nn.functional import softplus
 
+from .. import _cache
 from .. import _native as N
 from .. import ops
 from ..utils import torchutils
@@ -320,7 +321,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         return (self.fuse_conditioner and self.fuse_final_linear and not torch.is_grad_enabled()
                 and context is None and type(net) is ResidualNet and net.context_features is None
                 and net.hidden_features == 128 and self.tails == "linear" and self.num_bins in (8, 10)
-                and self.num_identity_features <= 64 and self.num_transform_features % 4 == 0
+                and 1 <= self.num_identity_features <= 64 and self.num_transform_features % 4 == 0
                 and self.num_transform_features <= 64 and self.features <= 128
                 and all(b.activation is torch.nn.functional.relu and not b.use_batch_norm
                         and (not b.training or b.dropout.p == 0.0) for b in net.blocks))
@@ -335,7 +336,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
 
     def _packed_resnet(self):
         net = self.transform_net
-        key = tuple((p.data_ptr(), p._version) for p in net.parameters()) + (self._log2e(),)
+        key = (_cache.epoch(),) + tuple((p.data_ptr(), p._version) for p in net.parameters()) + (self._log2e(),)
         cached = getattr(self, "_packed_resnet_cache", None)
         if cached is None or cached[0] != key:
             cached = (key, ops.pack_resnet_conditioner(net, self.num_transform_features,
@@ -388,8 +389,8 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
 
     def _packed_final_linear(self, layer):
         split = self.final_linear_engine == "bf16x3"
-        key = (layer.weight.data_ptr(), layer.weight._version, layer.bias.data_ptr(), layer.bias._version,
-               split)
+        key = (_cache.epoch(), layer.weight.data_ptr(), layer.weight._version, layer.bias.data_ptr(),
+               layer.bias._version, split)
         cached = getattr(self, "_packed_cache", None)
         if cached is None or cached[0] != key:
             cached = (key, ops.pack_final_linear(layer.weight, layer.bias, self.num_transform_features,

@@ -13,7 +13,8 @@ Restated reference code (paths relative to /root/reference):
   nflows/transforms/coupling.py:73-130, 279-293, 549-582    coupling layer around the spline
   nflows/transforms/coupling.py:234-252                     affine coupling
   nflows/transforms/permutations.py:27-45                   permutation
-  nflows/transforms/base.py:45-60, flows/base.py:42-49      cascade, log_prob
+  nflows/transforms/base.py:45-60, flows/base.py:42-49      cascade (both directions), log_prob
+  nflows/transforms/autoregressive.py:38-41, 453-489        autoregressive RQ layer, forward
 """
 import numpy as np
 import torch
@@ -155,24 +156,55 @@ def standard_normal_log_prob(z):
     return -0.5 * torch.sum(z ** 2, dim=[1]) - log_z
 
 
-def flow_log_prob(flow, x):
-    """Flow._log_prob for a CompositeTransform of Permutation / RQ-coupling / affine-coupling
-    layers built with nflows_amd classes (used only for their parameters, buffers and
-    conditioner modules, all on CPU)."""
+def ar_rq_layer_forward(x, made, num_bins, tail_bound):
+    """MaskedPiecewiseRationalQuadraticAutoregressiveTransform.forward with tails="linear"
+    (autoregressive.py:38-41, 453-489): one MADE pass, params viewed [B, D, P]; no 1/sqrt(hidden)
+    scaling because MADE has no `hidden_features` attribute."""
+    params = made(x, None)
+    b, d = x.shape
+    params = params.view(b, d, -1)
+    uw = params[..., :num_bins]
+    uh = params[..., num_bins:2 * num_bins]
+    ud = params[..., 2 * num_bins:]
+    if hasattr(made, "hidden_features"):
+        uw /= np.sqrt(made.hidden_features)
+        uh /= np.sqrt(made.hidden_features)
+    y, lad = rqs_unconstrained(x, uw, uh, ud, inverse=False, tail_bound=tail_bound)
+    return y, torch.sum(lad, dim=[1])
+
+
+def _layer(t, h, inverse):
+    name = type(t).__name__
+    if name.endswith("Permutation"):
+        perm = torch.argsort(t._permutation) if inverse else t._permutation  # permutations.py:22-45
+        h = torch.index_select(h, 1, perm)
+        return h, h.new_zeros(h.shape[0])
+    if name == "PiecewiseRationalQuadraticCouplingTransform":
+        return rq_coupling_layer(h, t.transform_net, t.identity_features, t.transform_features,
+                                 t.num_bins, t.tail_bound,
+                                 getattr(t.transform_net, "hidden_features", None), inverse=inverse)
+    if name == "AffineCouplingTransform":
+        return affine_coupling_layer(h, t.transform_net, t.identity_features, t.transform_features,
+                                     inverse=inverse)
+    if name == "MaskedPiecewiseRationalQuadraticAutoregressiveTransform" and not inverse:
+        return ar_rq_layer_forward(h, t.autoregressive_net, t.num_bins, t.tail_bound)
+    raise NotImplementedError(name + (" inverse" if inverse else ""))
+
+
+def flow_transform(flow, x, inverse=False):
+    """CompositeTransform.forward / .inverse (transforms/base.py:45-60) of a flow built with
+    nflows_amd classes (used only for their parameters, buffers and conditioner modules, all on
+    CPU): returns (outputs, total logabsdet)."""
     total = x.new_zeros(x.shape[0])
     h = x
-    for t in flow._transform._transforms:
-        name = type(t).__name__
-        if name.endswith("Permutation"):
-            h = torch.index_select(h, 1, t._permutation)
-            lad = h.new_zeros(h.shape[0])
-        elif name == "PiecewiseRationalQuadraticCouplingTransform":
-            h, lad = rq_coupling_layer(h, t.transform_net, t.identity_features, t.transform_features,
-                                       t.num_bins, t.tail_bound,
-                                       getattr(t.transform_net, "hidden_features", None))
-        elif name == "AffineCouplingTransform":
-            h, lad = affine_coupling_layer(h, t.transform_net, t.identity_features, t.transform_features)
-        else:
-            raise NotImplementedError(name)
+    layers = list(flow._transform._transforms)
+    for t in (reversed(layers) if inverse else layers):
+        h, lad = _layer(t, h, inverse)
         total += lad
-    return standard_normal_log_prob(h) + total
+    return h, total
+
+
+def flow_log_prob(flow, x):
+    """Flow._log_prob (flows/base.py:42-49)."""
+    z, total = flow_transform(flow, x)
+    return standard_normal_log_prob(z) + total

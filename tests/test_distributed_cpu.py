@@ -59,9 +59,17 @@ def _worker(rank, world, port, out_path):
         lp_local = _EagerFlow(flow).log_prob(x[lo:hi]).detach()
         acc = parallel.reduce_log_likelihood(lp_local)
         assert acc[1].item() == 101
-        if world == 2 and (hi - lo) * 2 == x.shape[0]:
-            pass
-        np.save(out_path % rank, np.array([total.item(), mean.item(), acc[0].item()]))
+        # per-sample values on every rank: the blocks differ by one row (101 = 51 + 50)
+        everything = parallel.gather_log_prob(lp_local)
+        assert everything.shape == (101,)
+        assert torch.equal(everything[lo:hi], lp_local)
+        # a replica that started from other weights is overwritten by rank 0's
+        other = configs.rq_nsf_flow(num_layers=2, features=8, num_bins=4, hidden_features=16, seed=rank).eval()
+        parallel.broadcast_model(other)
+        for a, b in zip(other.state_dict().values(), flow.state_dict().values()):
+            assert torch.equal(a, b)
+        np.save(out_path % rank, np.array([total.item(), mean.item(), acc[0].item(),
+                                           everything.double().sum().item()]))
     finally:
         dist.destroy_process_group()
 
@@ -81,3 +89,4 @@ def test_sharded_log_likelihood_world2(tmp_path):
     assert np.array_equal(r0, r1)                      # every rank holds the same answer
     assert abs(r0[0] - want) <= 1e-9 * abs(want) + 1e-9  # fp64-accumulated sum of the same fp32 values
     assert abs(r0[1] - want / 101) <= 1e-9
+    assert abs(r0[3] - want) <= 1e-9 * abs(want) + 1e-9  # the gathered per-sample values are the whole batch

@@ -1,0 +1,200 @@
+"""The HIP path at the BASELINE.json configurations, in its DEFAULT mode, against the oracle.
+
+For every sized configuration the drop-in flow is evaluated on the GPU at
+the stated batch size and compared with oracle/eager.py (bit-identical to the reference's CPU path,
+tests/test_oracle_golden.py) evaluated in float32 and in float64 on the same weights and rows:
+
+    err(HIP fp32 vs float64)  <=  2 x err(reference fp32 vs float64)  + floor
+
+for the maximum, the mean and the 99.9 % quantile of the absolute error of z, logabsdet and
+log_prob (at depth 32 the reference's own fp32 error is 1e-4 .. 1e-3, so its
+error against the float64 evaluation of the same flow is the yardstick, not a fixed tolerance).
+The floors are the single-layer tolerances of tests/helpers.py scaled with the magnitude:
+2e-6 (1 + max|z|) for outputs, 2e-5 (1 + max|.|) for log-determinants and log-densities.
+Achieved figures are printed (pytest -s) and appended to gpurun_out/parity_report.jsonl.
+
+Rows the oracle does not visit (it takes seconds per 16 384 rows) are covered by a size-independent
+property: rows are independent, so evaluating a strided subset alone must reproduce the full-batch
+results of those rows bit for bit.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import LAD_TOL, OUT_TOL, bulk_fraction
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FACTOR = 2.0  # native error <= 2 x the reference's own fp32 error
+
+
+def _report(entry):
+    root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = os.path.join(root, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.jsonl"), "a") as f:
+            f.write(json.dumps(entry) + "\n")
+    except OSError:
+        pass
+    print("\n[parity] " + json.dumps(entry))
+
+
+def _stats(err):
+    err = err.reshape(-1)
+    return {"max": float(err.max()), "mean": float(err.mean()), "q999": float(np.quantile(err, 0.999))}
+
+
+def compare(config, what, got, ref32, truth, tol):
+    """got / ref32: float32 arrays, truth: float64.  Asserts the 2x bound on max, mean and the
+    99.9 % quantile; returns the figures."""
+    got64 = got.astype(np.float64)
+    assert np.array_equal(np.isfinite(got), np.isfinite(ref32)), "%s %s: non-finite pattern differs" % (config, what)
+    fin = np.isfinite(truth)
+    e_got = _stats(np.abs(got64 - truth)[fin])
+    e_ref = _stats(np.abs(ref32.astype(np.float64) - truth)[fin])
+    floor = tol * (1.0 + float(np.abs(truth[fin]).max()))
+    entry = {"config": config, "what": what, "rows": int(got.shape[0]), "hip_vs_fp64": e_got,
+             "reference_fp32_vs_fp64": e_ref, "floor": floor,
+             "bulk_within_tol_of_reference_fp32": bulk_fraction(got, ref32, tol), "tol": tol}
+    _report(entry)
+    for k in ("max", "mean", "q999"):
+        assert e_got[k] <= FACTOR * e_ref[k] + floor, (
+            "%s %s: %s error vs float64 %.3e exceeds %.1f x the reference fp32's %.3e (+ %.1e)"
+            % (config, what, k, e_got[k], FACTOR, e_ref[k], floor))
+    return entry
+
+
+def oracle_eval(flow_cpu, x_cpu, need=("z", "lad", "lp")):
+    """float32 and float64 evaluation of the eager port on the host."""
+    from oracle import eager
+    threads = torch.get_num_threads()
+    out = {}
+    with torch.no_grad():
+        for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+            f = flow_cpu.to(dt)
+            z, lad = eager.flow_transform(f, x_cpu.to(dt))
+            lp = eager.standard_normal_log_prob(z) + lad
+            out["z" + tag], out["lad" + tag], out["lp" + tag] = z.numpy(), lad.numpy(), lp.numpy()
+        flow_cpu.float()
+    torch.set_num_threads(threads)
+    return out
+
+
+def hip_eval(flow_cpu, x_cpu):
+    import copy
+    import nflows_amd
+    flow = copy.deepcopy(flow_cpu).float().to(DEV).eval()
+    x = x_cpu.to(DEV)
+    with torch.no_grad():
+        z, lad = flow._transform(x)
+        lp = flow.log_prob(x)
+    nflows_amd.check_status()
+    return flow, z, lad, lp
+
+
+def check_flow(config, flow_cpu, x_cpu, oracle_rows):
+    """Full batch on the GPU; the oracle on `oracle_rows` (an index tensor); row independence for
+    the rest."""
+    flow, z, lad, lp = hip_eval(flow_cpu, x_cpu)
+    sub = x_cpu[oracle_rows]
+    o = oracle_eval(flow_cpu, sub)
+    idx = oracle_rows.to(DEV)
+    zs, lads, lps = (t[idx].cpu().numpy() for t in (z, lad, lp))
+    d = x_cpu.shape[1]
+    compare(config, "z", zs, o["z32"], o["z64"], OUT_TOL)
+    compare(config, "logabsdet", lads, o["lad32"], o["lad64"], LAD_TOL)
+    compare(config, "log_prob", lps, o["lp32"], o["lp64"], LAD_TOL)
+    if len(oracle_rows) < x_cpu.shape[0]:
+        # size-independent property: the same rows evaluated alone (another batch size, other
+        # positions in the launch grid) give the same bits
+        with torch.no_grad():
+            z2, lad2 = flow._transform(sub.to(DEV))
+        assert torch.equal(z2, z[idx]) and torch.equal(lad2, lad[idx]), config + ": rows are not independent of the batch"
+    return flow
+
+
+def bench_rows(batch=65536, features=64):
+    """bench.py's own input batch on rank 0."""
+    return torch.randn(batch, features, generator=torch.Generator().manual_seed(1234))
+
+
+def test_headline_32_layer_flow_default_mode():
+    """configs[3] / north-star at one GPU: 32 x (RandomPermutation + RQ coupling), D = 64, K = 8,
+    ResidualNet H = 128, seed-0 weights, B = 65 536 of bench.py's own rows; the oracle visits the
+    first 16 384."""
+    from nflows_amd import configs
+    flow_cpu = configs.rq_nsf_flow(num_layers=32, features=64, num_bins=8, hidden_features=128, seed=0).eval()
+    x = bench_rows()
+    check_flow("cfg4_32layer_d64_k8_b65536", flow_cpu, x, torch.arange(16384))
+
+
+def test_config3_16_layer_flow():
+    """configs[2]: 16 layers, B = 65 536; the oracle visits every fourth row."""
+    from nflows_amd import configs
+    flow_cpu = configs.rq_nsf_flow(num_layers=16, features=64, num_bins=8, hidden_features=128, seed=0).eval()
+    x = bench_rows()
+    check_flow("cfg3_16layer_d64_k8_b65536", flow_cpu, x, torch.arange(0, 65536, 4))
+
+
+def test_config2_affine_stack():
+    """configs[1]: 8 x AffineCouplingTransform, D = 32, MLP [128, 128] conditioner, B = 16 384 (all
+    rows through the oracle)."""
+    from nflows_amd import configs
+    flow_cpu = configs.affine_coupling_flow(num_layers=8, features=32, hidden_sizes=(128, 128), seed=0).eval()
+    x = torch.randn(16384, 32, generator=torch.Generator().manual_seed(1234))
+    check_flow("cfg2_8layer_affine_d32_b16384", flow_cpu, x, torch.arange(16384))
+
+
+def test_config5_autoregressive_forward():
+    """configs[4] forward pass: MaskedPiecewiseRationalQuadraticAutoregressiveTransform, D = 784,
+    K = 8, H = 256, B = 4 096; the oracle visits the first 1 024 rows."""
+    from nflows_amd import configs
+    flow_cpu = configs.ar_rq_flow(features=784, hidden_features=256, num_bins=8, tail_bound=3.0, seed=0).eval()
+    x = torch.randn(4096, 784, generator=torch.Generator().manual_seed(1234))
+    check_flow("cfg5_ar_rq_d784_k8_b4096_forward", flow_cpu, x, torch.arange(1024))
+
+
+def test_ten_bin_flow():
+    """The reference's default bin count (10) on the 32-layer flow, 8 192 rows."""
+    from nflows_amd import configs
+    flow_cpu = configs.rq_nsf_flow(num_layers=32, features=64, num_bins=10, hidden_features=128, seed=0).eval()
+    x = bench_rows(8192)
+    check_flow("32layer_d64_k10_b8192", flow_cpu, x, torch.arange(8192))
+
+
+def test_forward_inverse_consistency_against_the_reference():
+    """Second half of the metric: max |inv(fwd(x)) - x| of the 32-layer composite on the 8 192 rows
+    bench.py uses, next to the reference's own fp32 figure on the same rows and weights, and the
+    inverse pass itself (z -> x) against the float64 inverse."""
+    from nflows_amd import configs
+    from oracle import eager
+    import nflows_amd
+    flow_cpu = configs.rq_nsf_flow(num_layers=32, features=64, num_bins=8, hidden_features=128, seed=0).eval()
+    xs = bench_rows()[:8192]
+    with torch.no_grad():
+        z32, _ = eager.flow_transform(flow_cpu, xs)
+        xr32, lad_inv32 = eager.flow_transform(flow_cpu, z32, inverse=True)
+        f64 = flow_cpu.double()
+        xr64, lad_inv64 = eager.flow_transform(f64, z32.double(), inverse=True)  # truth of the inverse pass on z32
+        flow_cpu.float()
+    ref = (xr32 - xs).abs().numpy()
+    import copy
+    flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+    with torch.no_grad():
+        z, _ = flow._transform(xs.to(DEV))
+        xr, _ = flow._transform.inverse(z)
+        xi, lad_inv = flow._transform.inverse(z32.to(DEV))
+    nflows_amd.check_status()
+    got = (xr.cpu() - xs).abs().numpy()
+    e_got, e_ref = _stats(got), _stats(ref)
+    _report({"config": "cfg4_fwd_inv_8192_rows", "what": "|inv(fwd(x)) - x|", "hip": e_got, "reference_fp32": e_ref})
+    floor = OUT_TOL * (1 + float(xs.abs().max()))
+    for k in ("max", "mean", "q999"):
+        assert e_got[k] <= FACTOR * e_ref[k] + floor, (
+            "fwd/inv consistency: %s %.3e exceeds %.1f x the reference fp32's %.3e" % (k, e_got[k], FACTOR, e_ref[k]))
+    compare("cfg4_inverse_pass_8192_rows", "x", xi.cpu().numpy(), xr32.numpy(), xr64.numpy(), OUT_TOL)
+    compare("cfg4_inverse_pass_8192_rows", "logabsdet", lad_inv.cpu().numpy(), lad_inv32.numpy(), lad_inv64.numpy(), LAD_TOL)

@@ -371,3 +371,28 @@ def test_layer_tables_follow_the_fused_permutations():
         ref[:, ti] = ref[:, ti] * 2 + 1            # stand-in for the spline
         tile[:, tabs[i, 64:64 + ti.numel()]] = tile[:, tabs[i, 64:64 + ti.numel()]] * 2 + 1
     assert torch.equal(tile[:, tabs[3, :D]], ref)
+
+
+def test_packed_weight_caches_follow_weight_updates():
+    """The re-tiled conditioner weights of the whole-layer kernels are cached per layer.  In-place
+    updates under no_grad and load_state_dict are noticed; a write through `.data` is not (it does
+    not advance the version counter) until `nflows_amd.invalidate_packed_weights()` is called."""
+    import torch
+    import nflows_amd
+    from nflows_amd import configs
+    flow = configs.rq_nsf_flow(num_layers=2, features=8, num_bins=8, hidden_features=128, seed=0).eval()
+    layer = flow._transform._transforms[1]
+    w0 = layer._packed_resnet()[0].clone()
+    assert layer._packed_resnet()[0].data_ptr() == layer._packed_resnet()[0].data_ptr()  # cached
+    with torch.no_grad():
+        layer.transform_net.final_layer.weight.mul_(2.0)
+    w1 = layer._packed_resnet()[0].clone()
+    assert not torch.equal(w0, w1)
+    layer.transform_net.final_layer.weight.data.mul_(0.5)       # invisible to the version counter
+    assert torch.equal(layer._packed_resnet()[0], w1)            # ... so the stale copy is served
+    nflows_amd.invalidate_packed_weights()
+    assert torch.equal(layer._packed_resnet()[0], w0)
+    sd = {k: v.clone() for k, v in flow.state_dict().items()}
+    sd["_transform._transforms.1.transform_net.final_layer.weight"] *= 3.0
+    flow.load_state_dict(sd)
+    assert not torch.equal(layer._packed_resnet()[0], w0)

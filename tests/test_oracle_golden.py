@@ -1,6 +1,7 @@
 """Pins the CPU oracle (oracle/nfa_oracle.c) against vectors produced by the real reference
 (tests/golden/make_golden.py).  CPU only."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -147,7 +148,46 @@ def test_eager_port_is_bit_identical_to_reference(golden_dir):
         flow.load_state_dict({k[len(prefix):]: torch.from_numpy(gf[k]) for k in gf.files if k.startswith(prefix)})
         with torch.no_grad():
             lp = eager.flow_log_prob(flow.eval(), torch.from_numpy(gf[name + "/x"]))
+            z, lad = eager.flow_transform(flow, torch.from_numpy(gf[name + "/x"]))
+            xi, ladi = eager.flow_transform(flow, torch.from_numpy(gf[name + "/noise"]), inverse=True)
         assert np.array_equal(lp.numpy(), gf[name + "/log_prob"]), name
+        assert np.array_equal(z.numpy(), gf[name + "/z"]) and np.array_equal(lad.numpy(), gf[name + "/lad"]), name
+        assert np.array_equal(xi.numpy(), gf[name + "/inv_x"]), name
+        assert np.array_equal(ladi.numpy(), gf[name + "/inv_lad"]), name
+
+
+def test_eager_port_other_configs_bit_identical(golden_dir):
+    """The eager port on the affine stack (configs[1]'s layer type) in both directions and on the
+    autoregressive RQ layer's forward pass (configs[4]): bit-identical to the reference, in float32
+    and float64 (the float64 evaluation of the port is the ground truth of the GPU parity tests)."""
+    import torch
+    from oracle import eager
+    torch.set_num_threads(1)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_flows import build
+    gf = np.load(os.path.join(golden_dir, "flows.npz"))
+    metas = dict((n, parse_kwargs(c)) for n, c in gf["meta"])
+    for name in ("affine_small", "ar_rq_small", "nsf_d64"):
+        flow = build(metas[name])
+        prefix = name + "/sd/"
+        flow.load_state_dict({k[len(prefix):]: torch.from_numpy(gf[k]) for k in gf.files if k.startswith(prefix)})
+        flow = flow.eval()
+        x, noise = torch.from_numpy(gf[name + "/x"]), torch.from_numpy(gf[name + "/noise"])
+        with torch.no_grad():
+            z, lad = eager.flow_transform(flow, x)
+            lp = eager.flow_log_prob(flow, x)
+            assert np.array_equal(z.numpy(), gf[name + "/z"]), name
+            assert np.array_equal(lad.numpy(), gf[name + "/lad"]), name
+            assert np.array_equal(lp.numpy(), gf[name + "/log_prob"]), name
+            if name != "ar_rq_small":
+                xi, ladi = eager.flow_transform(flow, noise, inverse=True)
+                assert np.array_equal(xi.numpy(), gf[name + "/inv_x"]), name
+                assert np.array_equal(ladi.numpy(), gf[name + "/inv_lad"]), name
+            flow64 = flow.double()
+            z64, lad64 = eager.flow_transform(flow64, x.double())
+            assert np.abs(z64.numpy() - gf[name + "/z64"]).max() <= 1e-12, name
+            assert np.abs(lad64.numpy() - gf[name + "/lad64"]).max() <= 1e-11, name
+            flow.float()
 
 
 def _h128_flow(golden_dir):
