@@ -251,6 +251,53 @@ int nfa_rqs_flow_resnet_f32(const float *inputs, const void *weights_packed,
                             const nfa_rqs_spec *spec, int32_t flags, void *stream);
 
 /*
+ * K8h: the same run of whole coupling layers with the conditioner's GEMMs on the f16 matrix pipe
+ * from TWO f16 pieces per fp32 operand (x = hi + lo, three cross products per k-step; fp32-accurate:
+ * measured max / rms error against float64 equal to a sequential fp32 fma chain's,
+ * profiles/r2/f16x2_probe.txt) -- half the matrix-pipe work and two thirds of the weight bytes
+ * of the three-piece bf16 scheme above.  Replaces the same reference code (coupling.py:73-130,
+ * 549-582, nn/nets/resnet.py:92-100, transforms/base.py:45-52).
+ *   weights_packed f16, [stages][512 x 8]: 8 KB stages in consumption order; every GEMM's weights
+ *                  are multiplied by a power of two T before the split (max |w T| in [2^13, 2^14),
+ *                  which keeps the low pieces in the normal f16 range) --
+ *                  initial_layer, one stage per k-step: [4 tiles][2 pieces][64 lanes][8], element
+ *                    rule as for K8; hidden Linears the same, 8 stages each; final_layer: two stages
+ *                    per 32-row tile, [2 pieces][4 k-steps][64 lanes][8], rows ordered / padded /
+ *                    pre-divided by sqrt(hidden_features) as for K8.
+ *   bias_packed    float, per GEMM a 4-float header {out_scale, skip_scale, 0, 0} then the biases in
+ *                  accumulator order times the scale of their accumulators: with hidden activations
+ *                  kept at scale S, initial_layer: biases x T, out_scale = S / T; a block's first
+ *                  Linear: biases x S T, out_scale = 1 / T; its second: the same and skip_scale = T
+ *                  (the skip connection enters the accumulators as S T h); final_layer: biases x S T,
+ *                  header {kappa = 1 / (S T), 1 / kappa, 0, 0}: the spline evaluation reads logits =
+ *                  accumulators x kappa.
+ *   redo_blocks    int32 [batch / 128], written by the kernel: 0 = the 128-row block is done, 1 = it
+ *                  produced a non-finite value (an activation beyond the f16 range, or non-finite
+ *                  inputs) and NOTHING of it was written (outputs, logabsdet, status): the caller
+ *                  runs nfa_rqs_flow_resnet_redo_f32 -- the K8 kernel above restricted to the
+ *                  flagged blocks, same tables, its own (bf16) weight / bias blobs -- right behind
+ *                  it on the same stream; no host synchronisation in between.
+ * Supported: num_bins = 8, linear tails, hidden_features = 128, d_i <= 64, d_t % 4 == 0,
+ * d_t <= 64, features % 4 == 0, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
+ */
+int nfa_rqs_flow_resnet_f16x2_f32(const float *inputs, const void *weights_packed,
+                                  const float *bias_packed, const int32_t *flow_tables,
+                                  int32_t num_layers, float *outputs, float *logabsdet,
+                                  int32_t *redo_blocks, int32_t *status, int64_t batch,
+                                  int32_t features, int32_t num_transform, int32_t num_identity,
+                                  int32_t hidden_features, int32_t num_blocks,
+                                  const nfa_rqs_spec *spec, int32_t flags, void *stream);
+
+/* nfa_rqs_flow_resnet_f32 on the row blocks with redo_blocks[block] != 0 only (second pass of K8h). */
+int nfa_rqs_flow_resnet_redo_f32(const float *inputs, const void *weights_packed,
+                                 const float *bias_packed, const int32_t *flow_tables,
+                                 int32_t num_layers, float *outputs, float *logabsdet,
+                                 const int32_t *redo_blocks, int32_t *status, int64_t batch,
+                                 int32_t features, int32_t num_transform, int32_t num_identity,
+                                 int32_t hidden_features, int32_t num_blocks,
+                                 const nfa_rqs_spec *spec, int32_t flags, void *stream);
+
+/*
  * K5.  Elementwise rational-quadratic functional (no row-sum):
  *   unconstrained_rational_quadratic_spline / rational_quadratic_spline,
  *   splines/rational_quadratic.py:13-63 / :66-181, as called from

@@ -32,12 +32,20 @@ typedef float vec2f __attribute__((ext_vector_type(2)));
 
 constexpr int kWTileVec4 = 3 * 8 * 64;  // one weight tile: [piece][k-step][lane] x 16 bytes
 
+// (No packed fp32 arithmetic beside MFMAs: see rqs_resnet_f16.hip.  The residuals are computed per
+// element and pinned against re-vectorisation; the MFMA files are built with -fno-slp-vectorize.)
 __device__ __forceinline__ void split3(vec2f v, bf16x2& hi, bf16x2& mid, bf16x2& lo) {
     hi = __builtin_convertvector(v, bf16x2);
-    const vec2f r1 = v - __builtin_convertvector(hi, vec2f);
-    mid = __builtin_convertvector(r1, bf16x2);
-    const vec2f r2 = r1 - __builtin_convertvector(mid, vec2f);
-    lo = __builtin_convertvector(r2, bf16x2);
+    const vec2f h = __builtin_convertvector(hi, vec2f);
+    float a0 = v[0] - h[0], a1 = v[1] - h[1];
+    asm volatile("" : "+v"(a0));
+    asm volatile("" : "+v"(a1));
+    mid = __builtin_convertvector(vec2f{a0, a1}, bf16x2);
+    const vec2f m = __builtin_convertvector(mid, vec2f);
+    float b0 = a0 - m[0], b1 = a1 - m[1];
+    asm volatile("" : "+v"(b0));
+    asm volatile("" : "+v"(b1));
+    lo = __builtin_convertvector(vec2f{b0, b1}, bf16x2);
 }
 
 __device__ __forceinline__ bf16x8 join4(bf16x2 a, bf16x2 b, bf16x2 c, bf16x2 d) {

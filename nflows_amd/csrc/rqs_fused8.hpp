@@ -1,0 +1,243 @@
+// Spline evaluation of K8h's woven final layer (csrc/rqs_resnet_f16.hip): 8 bins, linear tails,
+// logits handed over at scale 1/kappa straight from the MFMA accumulators.
+//
+// Same function as rational_quadratic.py:66-181 (+ :13-63 for the tails), arranged for the lowest
+// VALU instruction count -- the layer kernel is bound by VALU issue, not by the matrix pipe:
+//   * softmax numerators as 2^(fma(e, log2e*kappa, -max*log2e*kappa)): two instructions per logit;
+//     the rounding of the shared term is common to all eight numerators and cancels in the
+//     normalisation;
+//   * ONE walk over the bins instead of two: knot_{i+1} = knot_i + fma(numerator_i, 2B(1-8 min)/den,
+//     2B min) for widths and heights side by side (fp32 running sums; the reference rounds each
+//     normalised bin to fp32, sums in double and rounds every knot -- the same error class), and on
+//     the compare x >= knot_i of the searched axis the candidates of BOTH axes and the two
+//     derivative logits are selected with the same condition.  No bin index, no second walk;
+//   * first / last knot exactly -B / +B as the reference forces them, bin sizes as knot
+//     differences;
+//   * softplus and the logarithms on v_exp_f32 / v_log_f32 (1 ulp) with first-order corrections
+//     where the argument is near 1, divisions as reciprocal + one residual correction.
+// The evaluation is cut into slices of 2-8 instructions (num_w / num_h / finish) so that the GEMM
+// loop can issue one MFMA between two slices.  Error class: the reference's own fp32 path
+// (tests/test_gpu_headline_parity.py holds the kernel to 2x the reference's error against float64).
+#pragma once
+
+#include "rqs_math.hpp"
+
+namespace nfa {
+
+template <bool INVERSE>
+struct FusedSteps8 {
+    static constexpr int kNumSlices = 12;
+    static constexpr int kWalkSlices = 3 + 2 * 7;               // setup x 2, bin 0, bins 1..7 x (knots | select)
+    static constexpr int kBinSlices = INVERSE ? 9 : 7;
+    static constexpr int kFinishSlices = kWalkSlices + 6 + kBinSlices + 1;
+    static constexpr int kFirstWalkSlices = 0;                  // (no part of finish runs on one numerator set alone)
+    static constexpr bool kInverse = INVERSE;
+
+    float ew[8], eh[8];   // logits (scaled), then softmax numerators
+    float sd[7];          // derivative logits (scaled)
+    float x;
+    float kl2e, kappa, tail_s;   // log2(e) * kappa, kappa, tail_logit / kappa (uniform)
+    float m_w, m_h, den_w, den_h, tw_, th_;
+    float aw, ah, kw, kh, kwn, khn;
+    float cw0, cw1, ch0, ch1, u0, u1, d0, d1;
+    float y, lad;
+    int status;
+    float t3, t4;
+    float in_w, in_h, r_w, delta, s_, th, t1mt, den, t0, t1, t2, t5;
+
+    template <int S>
+    __device__ __forceinline__ void numerators(float (&e)[8], float& den_, float& m, float& t) {
+        if constexpr (S == 0) {
+            m = __builtin_fmaxf(__builtin_fmaxf(e[0], e[1]), e[2]);      // (v_max3_f32)
+            m = __builtin_fmaxf(__builtin_fmaxf(m, e[3]), e[4]);
+        } else if constexpr (S == 1) {
+            m = __builtin_fmaxf(__builtin_fmaxf(m, e[5]), e[6]);
+            m = __builtin_fmaxf(m, e[7]) * kl2e;                          // max * log2e * kappa
+        } else if constexpr (S < 10) {
+            e[S - 2] = __builtin_amdgcn_exp2f(__builtin_fmaf(e[S - 2], kl2e, -m));
+        } else if constexpr (S == 10) {
+            t = (e[0] + e[1]) + (e[2] + e[3]);
+        } else {
+            den_ = t + ((e[4] + e[5]) + (e[6] + e[7]));
+        }
+    }
+    template <int S>
+    __device__ __forceinline__ void num_w() { numerators<S>(ew, den_w, m_w, tw_); }
+    template <int S>
+    __device__ __forceinline__ void num_h() { numerators<S>(eh, den_h, m_h, th_); }
+
+    // min_d + softplus(u * kappa) in three slices (exp | log1p | select)
+    template <int PART>
+    __device__ __forceinline__ void derivative(float u, float& d, const RqsDev& sp) {
+        if constexpr (PART == 0) {
+            t3 = u * kappa;
+            t4 = __builtin_amdgcn_exp2f(t3 * 1.44269502162933349609375f);
+        } else if constexpr (PART == 1) {
+            const float u1p = 1.0f + t4;
+            const float c = t4 - (u1p - 1.0f);   // what the addition dropped
+            const float lg = __builtin_amdgcn_logf(u1p) * 0.693147182464599609375f;
+            t4 = __builtin_fmaf(c, __builtin_amdgcn_rcpf(u1p), lg);
+        } else {
+            d = sp.min_d + (t3 > 20.0f ? t3 : t4);
+        }
+    }
+
+    template <int S>
+    __device__ __forceinline__ void finish(const RqsDev& sp) {
+        constexpr int W = kWalkSlices, D0 = W, BE = D0 + 6, LAST = BE + kBinSlices;
+        static_assert(LAST + 1 == kFinishSlices, "slice map");
+        const float B = sp.right;
+        if constexpr (S == 0) {
+            const float r0 = __builtin_amdgcn_rcpf(den_w);
+            const float r = __builtin_fmaf(__builtin_fmaf(-den_w, r0, 1.0f), r0, r0);
+            aw = r * (sp.span_w * sp.om_w);
+        } else if constexpr (S == 1) {
+            const float r0 = __builtin_amdgcn_rcpf(den_h);
+            const float r = __builtin_fmaf(__builtin_fmaf(-den_h, r0, 1.0f), r0, r0);
+            ah = r * (sp.span_w * sp.om_h);
+        } else if constexpr (S == 2) {   // bin 0: always a candidate
+            kw = -B + __builtin_fmaf(ew[0], aw, sp.span_w * sp.min_w);
+            kh = -B + __builtin_fmaf(eh[0], ah, sp.span_w * sp.min_h);
+            cw0 = -B;
+            ch0 = -B;
+            cw1 = kw;
+            ch1 = kh;
+            u0 = tail_s;
+            u1 = sd[0];
+        } else if constexpr (S < W) {
+            constexpr int I = (S - 3) / 2 + 1, PART = (S - 3) % 2;   // bins 1..7
+            if constexpr (PART == 0) {        // the bin's upper knots (kw / kh hold its lower ones)
+                if constexpr (I < 7) {
+                    kwn = kw + __builtin_fmaf(ew[I], aw, sp.span_w * sp.min_w);
+                    khn = kh + __builtin_fmaf(eh[I], ah, sp.span_w * sp.min_h);
+                } else {
+                    kwn = B;
+                    khn = B;
+                }
+            } else {
+                const bool take = x >= (INVERSE ? kh : kw);
+                cw0 = take ? kw : cw0;
+                cw1 = take ? kwn : cw1;
+                ch0 = take ? kh : ch0;
+                ch1 = take ? khn : ch1;
+                u0 = take ? sd[I - 1] : u0;
+                u1 = take ? (I < 7 ? sd[I < 7 ? I : 0] : tail_s) : u1;
+                kw = kwn;
+                kh = khn;
+            }
+        } else if constexpr (S < D0 + 3) {
+            derivative<S - D0>(u0, d0, sp);
+        } else if constexpr (S < BE) {
+            derivative<S - D0 - 3>(u1, d1, sp);
+        } else if constexpr (S < LAST) {
+            bin_eval<S - BE>();
+        } else {
+            const bool inside = (x >= -B && x <= B);  // NaN is outside
+            y = inside ? y : x;
+            lad = inside ? lad : 0.0f;
+            status = inside ? status : 0;
+        }
+    }
+
+    // the map inside the bin (rational_quadratic.py:132-181) in seven slices
+    template <int PART>
+    __device__ __forceinline__ void bin_eval() {
+        if constexpr (PART == 0) {
+            in_w = cw1 - cw0;
+            in_h = ch1 - ch0;
+            const float r0 = __builtin_amdgcn_rcpf(in_w);
+            r_w = __builtin_fmaf(__builtin_fmaf(-in_w, r0, 1.0f), r0, r0);
+            status = 0;
+        } else if constexpr (PART == 1) {
+            const float q = in_h * r_w;
+            delta = __builtin_fmaf(__builtin_fmaf(-q, in_w, in_h), r_w, q);
+            s_ = __builtin_fmaf(-2.0f, delta, d0 + d1);
+        } else if constexpr (INVERSE) {
+            if constexpr (PART == 2) {
+                const float yc = x - ch0;
+                const float ys = yc * s_;
+                const float a = __builtin_fmaf(in_h, delta - d0, ys);
+                const float b = __builtin_fmaf(in_h, d0, -ys);
+                const float c = -delta * yc;
+                t0 = __builtin_fmaf(b, b, -4.0f * a * c);   // discriminant
+                t1 = 2.0f * c;
+                t2 = -b;
+            } else if constexpr (PART == 3) {
+                if (!(t0 >= 0.0f)) status = NFA_STATUS_NEG_DISCRIMINANT;
+                const float dn = t2 - __builtin_sqrtf(t0);
+                const float r0 = __builtin_amdgcn_rcpf(dn);
+                const float r = __builtin_fmaf(__builtin_fmaf(-dn, r0, 1.0f), r0, r0);
+                const float q = t1 * r;
+                th = __builtin_fmaf(__builtin_fmaf(-q, dn, t1), r, q);   // root of the quadratic (:144)
+            } else if constexpr (PART == 4) {
+                // One Newton step on the FORWARD map g(theta) of this bin, evaluated the way the forward
+                // pass evaluates it: the quadratic formula loses digits where b^2 ~ 4ac or the
+                // denominator is small, and whatever it loses reappears as forward/inverse inconsistency
+                // (amplified by every following layer).  g'(theta) = in_h delta^2 (...) / den^2 is the
+                // quantity the log-determinant needs anyway.
+                const float omr = 1.0f - th;
+                t1mt = th * omr;
+                den = __builtin_fmaf(s_, t1mt, delta);
+                t0 = in_h * __builtin_fmaf(delta, th * th, d0 * t1mt);   // numerator of g - ch0
+                t1 = omr * omr;
+            } else if constexpr (PART == 5) {
+                float c = d0 * t1;
+                c = __builtin_fmaf(delta + delta, t1mt, c);
+                c = __builtin_fmaf(d1, th * th, c);
+                t5 = (delta * delta) * c;                                 // den^2 g' / in_h
+                const float r0 = __builtin_amdgcn_rcpf(den);
+                const float r = __builtin_fmaf(__builtin_fmaf(-den, r0, 1.0f), r0, r0);
+                const float q = t0 * r;
+                const float g = ch0 + __builtin_fmaf(__builtin_fmaf(-q, den, t0), r, q);
+                t2 = x - g;                                               // residual in y
+            } else if constexpr (PART == 6) {
+                const float slope = in_h * t5;                            // g' den^2
+                const float r0 = __builtin_amdgcn_rcpf(slope);
+                const float r = __builtin_fmaf(__builtin_fmaf(-slope, r0, 1.0f), r0, r0);
+                const float step = (t2 * den) * (den * r);
+                // (a bin visited through a NaN / degenerate path keeps the closed-form root)
+                th = (__builtin_fabsf(step) <= 0.25f) ? th + step : th;
+                y = __builtin_fmaf(th, in_w, cw0);
+            } else if constexpr (PART == 7) {
+                const float omr = 1.0f - th;
+                t1mt = th * omr;
+                den = __builtin_fmaf(s_, t1mt, delta);
+                float c = d0 * (omr * omr);
+                c = __builtin_fmaf(delta + delta, t1mt, c);
+                c = __builtin_fmaf(d1, th * th, c);
+                t5 = (delta * delta) * c;
+            } else {
+                const float l1 = __builtin_amdgcn_logf(t5), l2 = __builtin_amdgcn_logf(den);
+                lad = -(__builtin_fmaf(-2.0f, l2, l1) * 0.693147182464599609375f);
+            }
+        } else {
+            if constexpr (PART == 2) {
+                const float xc = x - cw0;
+                const float q = xc * r_w;
+                th = __builtin_fmaf(__builtin_fmaf(-q, in_w, xc), r_w, q);
+                const float omt = 1.0f - th;
+                t1mt = th * omt;
+                t1 = omt * omt;
+            } else if constexpr (PART == 3) {
+                t2 = th * th;
+                t0 = in_h * __builtin_fmaf(delta, t2, d0 * t1mt);   // numerator
+                den = __builtin_fmaf(s_, t1mt, delta);
+            } else if constexpr (PART == 4) {
+                const float r0 = __builtin_amdgcn_rcpf(den);
+                const float r = __builtin_fmaf(__builtin_fmaf(-den, r0, 1.0f), r0, r0);
+                const float q = t0 * r;
+                y = ch0 + __builtin_fmaf(__builtin_fmaf(-q, den, t0), r, q);
+            } else if constexpr (PART == 5) {
+                float c = d0 * t1;
+                c = __builtin_fmaf(delta + delta, t1mt, c);
+                c = __builtin_fmaf(d1, t2, c);
+                t5 = (delta * delta) * c;
+            } else {
+                const float l1 = __builtin_amdgcn_logf(t5), l2 = __builtin_amdgcn_logf(den);
+                lad = __builtin_fmaf(-2.0f, l2, l1) * 0.693147182464599609375f;
+            }
+        }
+    }
+};
+
+}  // namespace nfa

@@ -377,10 +377,17 @@ __device__ __forceinline__ int rqs_eval_flat8(float x, const float* sl, const Rq
 // numerator is one rounded product instead of a two-float one, the bin size is
 // fma(e, om / den, min) instead of min + om * RN(e / den), a knot is one fma.  Prefix sums stay in
 // double.  Not bit-identical to the plain evaluation; same error class (tests/test_gpu_flows.py).
-template <bool INVERSE, int PRESCALED, bool FAST = false, int KT = 8>
+//
+// SCALED = true (K8h, rqs_resnet_f16.hip): the logits handed over are kappa^-1 times the true ones
+// (a power of two: the f16 weight pieces of the GEMM that makes them are pre-scaled so that their
+// low pieces stay in the normal f16 range); the factor rides on multiplications that exist anyway
+// (`kl2e` = log2(e) * kappa in the softmax exponents) or costs one product (derivative logits).
+template <bool INVERSE, int PRESCALED, bool FAST = false, int KT = 8, bool SCALED = false>
 struct FlatSteps {
     static_assert(PRESCALED == 1 || PRESCALED == 2, "logits already divided by sqrt(hidden)");
     static_assert(KT == 8 || (KT == 10 && FAST && PRESCALED == 1), "10 bins: the shorter sequence only");
+    static_assert(!SCALED || (FAST && PRESCALED == 1), "scaled logits: the shorter sequence only");
+    float kl2e, kappa, tail_s;  // SCALED: log2(e) * kappa, kappa, tail_logit / kappa
     static constexpr int kNumSlices = 2 * KT + 4;
     static constexpr int kWalk = 3 * KT;                       // KT bins x 3 slices
     static constexpr int kFinishSlices = 1 + kWalk + 1 + kWalk + 6 + 5 + 1;  // = 62 for 8 bins
@@ -413,7 +420,8 @@ struct FlatSteps {
             if constexpr (PRESCALED == 2) {
                 if constexpr (((S - 2) & 1) == 0) e[I] = __builtin_amdgcn_exp2f(e[I] - m);
             } else if constexpr (FAST) {
-                if constexpr (((S - 2) & 1) == 0) e[I] = __builtin_amdgcn_exp2f((e[I] - m) * 1.44269502162933349609375f);
+                if constexpr (((S - 2) & 1) == 0)
+                    e[I] = __builtin_amdgcn_exp2f((e[I] - m) * (SCALED ? kl2e : 1.44269502162933349609375f));
             } else if constexpr (((S - 2) & 1) == 0) {
                 const float kLog2e = 1.44269502162933349609375f, kLog2eLo = 1.925963033500011e-08f;
                 const float v = e[I] - m;
@@ -479,12 +487,12 @@ struct FlatSteps {
         // (callers guarantee beta == 1: the coupling layers never enable the identity initialisation,
         // coupling.py:572-582; softplus_beta's general form carries an IEEE division per call)
         if constexpr (PART == 0) {
-            t3 = u;
+            t3 = SCALED ? u * kappa : u;
             t4 = exp_noclamp(t3);
         } else if constexpr (PART == 1) {
             t4 = log1p_nonneg(t4);
         } else {
-            d = sp.min_d + (t3 > 20.0f ? u : t4);
+            d = sp.min_d + (t3 > 20.0f ? t3 : t4);
         }
     }
 
@@ -509,8 +517,8 @@ struct FlatSteps {
             if constexpr (FAST) rden *= INVERSE ? sp.om_w : sp.om_h;
             acc = 0.0;
             prev = -sp.right;
-            u0 = sp.tail_logit;
-            u1 = sp.tail_logit;
+            u0 = SCALED ? tail_s : sp.tail_logit;
+            u1 = u0;
         } else if constexpr (S < D0) {
             constexpr int I = (S - W2) / 3, PART = (S - W2) % 3;
             if (INVERSE) bin<false, I, PART>(ew, den_w, sp.min_w, sp.om_w, sp, cw0, cw1);

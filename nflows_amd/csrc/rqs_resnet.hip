@@ -52,6 +52,7 @@ struct ResnetArgs {
     int D, dt, di, num_blocks, num_layers, num_stages, bias_per_layer, accumulate;
     RqsDev sp;
     unsigned long long* trace;
+    const int32_t* redo;  // optional [batch / 128]: only row blocks with a non-zero entry are processed
 };
 
 // Weight stream through the LDS ring.  Stage s lives in slot s % 3; while stage s is consumed,
@@ -392,6 +393,8 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
     if (a.trace && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 256))
         tr = a.trace + (blockIdx.x ? 256 : 0);
     for (int64_t quad = blockIdx.x; quad < num_quads; quad += gridDim.x) {
+        // second pass behind the f16 kernel (rqs_resnet_f16.hip): only the row blocks it gave up on
+        if (a.redo && a.redo[quad] == 0) continue;
         const int64_t row0 = (quad << 7) + (wave << 5);
         // (lane-derived values are made opaque per iteration: hoisted out of this loop they would
         // stay live through the whole kernel and push the register allocation into scratch)
@@ -711,7 +714,8 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
                                 const int32_t* tables, int32_t num_layers, float* outputs, float* logabsdet,
                                 int32_t* status, int64_t batch, int32_t features, int32_t num_transform,
                                 int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
-                                const nfa_rqs_spec* spec, int32_t flags, void* stream) {
+                                const nfa_rqs_spec* spec, int32_t flags, void* stream,
+                                const int32_t* redo = nullptr) {
     if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_LOGITS_LOG2E))
         return NFA_ERR_INVALID_ARGUMENT;
     if (batch < 0 || features < 1 || num_transform < 1 || num_identity < 1 ||
@@ -748,6 +752,7 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     a.bias_per_layer = 128 + 256 * num_blocks + num_transform * rows_per_feature;
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = g_k7_trace;
+    a.redo = redo;
     // final layer with the spline evaluation woven into its MFMAs (not with the log2(e) fold):
     //   2 (default)  woven, FlatSteps<FAST>: cheaper rounding sequence, same error class
     //   1            woven, same results bit for bit as the plain loop
@@ -766,7 +771,7 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     const int64_t cap = (int64_t)device_cu_count() * per_cu;
     if (blocks > cap) blocks = cap;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    profile_next_launch(&e0, &e1);
+    if (!redo) profile_next_launch(&e0, &e1);  // (the second pass is not the measured kernel)
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks), block(kBlock);
     const bool inv = (flags & NFA_FLAG_INVERSE) != 0, l2e = (flags & NFA_FLAG_LOGITS_LOG2E) != 0;
@@ -835,4 +840,17 @@ extern "C" int nfa_rqs_flow_resnet_f32(const float* inputs, const void* weights_
     return launch_resnet_layers(inputs, weights_packed, bias_packed, flow_tables, num_layers, outputs, logabsdet,
                                 status, batch, features, num_transform, num_identity, hidden_features, num_blocks,
                                 spec, flags, stream);
+}
+
+extern "C" int nfa_rqs_flow_resnet_redo_f32(const float* inputs, const void* weights_packed,
+                                            const float* bias_packed, const int32_t* flow_tables,
+                                            int32_t num_layers, float* outputs, float* logabsdet,
+                                            const int32_t* redo_blocks, int32_t* status, int64_t batch,
+                                            int32_t features, int32_t num_transform, int32_t num_identity,
+                                            int32_t hidden_features, int32_t num_blocks,
+                                            const nfa_rqs_spec* spec, int32_t flags, void* stream) {
+    if (!redo_blocks) return NFA_ERR_INVALID_ARGUMENT;
+    return launch_resnet_layers(inputs, weights_packed, bias_packed, flow_tables, num_layers, outputs, logabsdet,
+                                status, batch, features, num_transform, num_identity, hidden_features, num_blocks,
+                                spec, flags, stream, redo_blocks);
 }

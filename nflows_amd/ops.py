@@ -16,6 +16,7 @@ conditions in a per-device status word instead:
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -699,6 +700,79 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False)
     return torch.cat(stages, dim=0).contiguous(), torch.cat(biases).contiguous()
 
 
+def split_f16x2(w):
+    """fp32 -> two f16 tensors with w == hi + lo up to 2^-24 |w| while the low piece stays in the
+    normal f16 range (round to nearest even both times)."""
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
+    return hi, lo
+
+
+def _f16_weight_scale(w):
+    """Power of two T with max |w T| in [2^13, 2^14): the high pieces stay far from the f16
+    overflow (65504), and every weight down to 2^-16 of the largest has a low piece in the normal
+    f16 range, i.e. is represented to 2^-24 relative."""
+    m = float(w.abs().max())
+    if not math.isfinite(m) or m == 0.0:
+        return 1.0
+    return 2.0 ** (13 - math.floor(math.log2(m)))
+
+
+def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scale=1.0):
+    """Packs a ResidualNet for K8h (csrc/rqs_resnet_f16.hip; layout in include/nflows_amd.h): every
+    weight as TWO f16 pieces of (weight x T), T a power of two chosen per GEMM, in 8 KB stages in
+    consumption order; per GEMM a header {out_scale, skip_scale, 0, 0} followed by the biases in
+    accumulator order, pre-multiplied by the scale their accumulators carry.  Hidden activations live
+    at scale S = `act_scale` (a power of two).  8 bins only.  Returns (weights [stages, 4096] f16,
+    biases fp32)."""
+    dt, P = num_transform, params_per_feature
+    K = (P + 1) // 3
+    if P != 23:
+        raise ValueError("K8h packs 8-bin linear-tail layers")
+    S = float(act_scale)
+    dev = net.final_layer.weight.device
+    order_k = _k8_column_order().to(dev)
+
+    def pieces(w):
+        return torch.stack(split_f16x2(w))  # [2, ...]
+
+    def header(a, b):
+        return torch.tensor([a, b, 0.0, 0.0], dtype=torch.float32, device=dev)
+
+    stages, blob = [], []
+    wi = net.initial_layer.weight.detach().float()
+    di = wi.shape[1]
+    init_ks = 4 if di > 32 else 2
+    wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
+    T = _f16_weight_scale(wi)
+    # (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j): one stage per k-step
+    stages.append(pieces(wi * T).view(2, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks, -1))
+    blob += [header(S / T, 0.0), _bias_accumulator_order(net.initial_layer.bias.detach().float() * T)]
+    for block in net.blocks:
+        for which, lin in enumerate(block.linear_layers):
+            w = lin.weight.detach().float().index_select(1, order_k)  # columns in (ks, hf, j) order
+            T = _f16_weight_scale(w)
+            stages.append(pieces(w * T).view(2, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1))
+            # accumulators = S T (W a + b) [+ S T h for the block's second layer: skip_scale = T]
+            blob += [header(1.0 / T, T if which == 1 else 0.0),
+                     _bias_accumulator_order(lin.bias.detach().float() * (S * T))]
+    scale = torch.ones(P, dtype=torch.float64, device=dev)
+    scale[:2 * K] = 1.0 / math.sqrt(net.hidden_features)
+    wf = (net.final_layer.weight.detach().double().view(dt, P, 128) * scale[None, :, None]).float()
+    bf = (net.final_layer.bias.detach().double().view(dt, P) * scale[None, :]).float()
+    order_r = _k7_row_order(dt).to(dev)
+    wf = torch.cat((wf, wf.new_zeros(dt, 24 - P, 128)), dim=1).reshape(dt * 24, 128)
+    wf = wf.index_select(0, order_r).index_select(1, order_k)
+    bf = torch.cat((bf, bf.new_zeros(dt, 24 - P)), dim=1).reshape(dt * 24).index_select(0, order_r)
+    T = _f16_weight_scale(wf)
+    tiles = dt * 24 // 32
+    # (p, tile, i, hs, k4, hf, j) -> (tile, hs, p, k4, hf, i, j): two stages per tile
+    stages.append(pieces(wf * T).view(2, tiles, 32, 2, 4, 2, 8).permute(1, 3, 0, 4, 5, 2, 6).reshape(tiles * 2, -1))
+    # the spline evaluation reads logits = accumulators x kappa, kappa = 1 / (S T)
+    blob += [header(1.0 / (S * T), S * T), _bias_accumulator_order(bf * (S * T))]
+    return torch.cat(stages, dim=0).contiguous(), torch.cat(blob).contiguous()
+
+
 def coupling_layer_tables(features, transform_idx, identity_idx, in_perm=None, out_scatter=None):
     """int32 [256] column bookkeeping of ONE layer for K8 (layout in include/nflows_amd.h), built on
     the device: the row tile's slot j holds input column j; [0, 64) slots of the identity features,
@@ -754,6 +828,41 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
     if rc == N.ERR_UNSUPPORTED:
         return None
     N.check(rc)
+    _after_spline(spec, inverse, dev)
+    return out, lad
+
+
+def rqs_coupling_resnet_f16(inputs, packed_f16, packed_exact, tables, num_transform, num_identity, num_blocks,
+                            spec, inverse=False, accumulate_into=None, num_layers=1):
+    """K8h -- the run of whole-layer kernels on the f16 matrix pipe (two f16 pieces per operand),
+    followed by the exact kernel (three bf16 pieces, full fp32 range) on the row blocks the first
+    pass gave up on: blocks with a non-finite result, i.e. an activation beyond the f16 range or
+    non-finite inputs.  `packed_f16` / `packed_exact`: (weights, biases) from
+    pack_resnet_conditioner_f16 / pack_resnet_conditioner.  Returns None when the shape is outside
+    the fast path."""
+    N.require_device_f32("inputs", inputs, 2)
+    dev = inputs.device
+    B, D = inputs.shape
+    x = inputs.detach().contiguous()
+    out = torch.empty_like(x)
+    lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
+    redo = torch.empty(max(1, B // 128), dtype=torch.int32, device=dev)
+    lib = N.load()
+    with torch.cuda.device(dev):
+        rc = lib.nfa_rqs_flow_resnet_f16x2_f32(
+            N.ptr(x), N.ptr(packed_f16[0]), N.ptr(packed_f16[1]), N.ptr(tables), num_layers, N.ptr(out),
+            N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128,
+            num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))
+        if rc == N.ERR_UNSUPPORTED:
+            return None
+        N.check(rc)
+        if os.environ.get("NFA_K8H_NOREDO"):
+            return out, lad
+        rc = lib.nfa_rqs_flow_resnet_redo_f32(
+            N.ptr(x), N.ptr(packed_exact[0]), N.ptr(packed_exact[1]), N.ptr(tables), num_layers, N.ptr(out),
+            N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128,
+            num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))
+        N.check(rc)
     _after_spline(spec, inverse, dev)
     return out, lad
 

@@ -74,7 +74,9 @@ class CompositeTransform(Transform):
         return (coupling.features, coupling.num_transform_features, coupling.num_identity_features,
                 len(coupling.transform_net.blocks), coupling.num_bins, coupling.tail_bound,
                 coupling.min_bin_width, coupling.min_bin_height, coupling.min_derivative,
-                coupling._log2e() if hasattr(coupling, "_log2e") else False)
+                coupling._log2e() if hasattr(coupling, "_log2e") else False,
+                coupling._use_f16() if hasattr(coupling, "_use_f16") else False,
+                getattr(coupling, "conditioner_act_scale", 1.0))
 
     def _collect_run(self, layers, start, inputs, context, inverse):
         """Longest run of units starting at `start`: forward a unit is [column Permutation]? +
@@ -120,8 +122,11 @@ class CompositeTransform(Transform):
         permutation changes."""
         from .. import ops
         packed = [c._packed_resnet() for c, _ in units]
-        key = (_cache.epoch(), inverse, tuple(id(c) for c, _ in units),
+        f16 = units[0][0]._use_f16()
+        packed_f16 = [c._packed_resnet_f16() for c, _ in units] if f16 else None
+        key = (_cache.epoch(), inverse, f16, tuple(id(c) for c, _ in units),
                tuple(c._packed_resnet_cache[0] for c, _ in units),
+               tuple(c._packed_resnet_f16_cache[0] for c, _ in units) if f16 else None,
                tuple(None if p is None else (p._permutation.data_ptr(), p._permutation._version) for _, p in units))
         cache = self.__dict__.setdefault("_run_plans", {})
         plan = cache.get(key)
@@ -136,7 +141,11 @@ class CompositeTransform(Transform):
                 spec_layers.append((c.transform_features, c.identity_features,
                                     None if inverse else perm, perm if inverse else None))
             tables = ops.flow_layer_tables(units[0][0].features, spec_layers)
-            plan = (weights, biases, tables)
+            plan_f16 = None
+            if f16:
+                plan_f16 = (torch.cat([w for w, _ in packed_f16], dim=0).contiguous(),
+                            torch.cat([b for _, b in packed_f16]).contiguous())
+            plan = (weights, biases, tables, plan_f16)
             cache[key] = plan
         return plan
 
@@ -148,11 +157,17 @@ class CompositeTransform(Transform):
                 p._check(inputs)
         batch = inputs.shape[0]
         full = (batch // 128) * 128
-        weights, biases, tables = self._run_plan(units, inverse)
-        head = ops.rqs_coupling_resnet(
-            inputs[:full], weights, biases, tables, first.num_transform_features, first.num_identity_features,
-            len(first.transform_net.blocks), first._spec(), inverse, total[:full],
-            log2e=first._log2e() if hasattr(first, "_log2e") else False, num_layers=len(units))
+        weights, biases, tables, plan_f16 = self._run_plan(units, inverse)
+        if plan_f16 is not None:
+            head = ops.rqs_coupling_resnet_f16(
+                inputs[:full], plan_f16, (weights, biases), tables, first.num_transform_features,
+                first.num_identity_features, len(first.transform_net.blocks), first._spec(), inverse,
+                total[:full], num_layers=len(units))
+        else:
+            head = ops.rqs_coupling_resnet(
+                inputs[:full], weights, biases, tables, first.num_transform_features, first.num_identity_features,
+                len(first.transform_net.blocks), first._spec(), inverse, total[:full],
+                log2e=first._log2e() if hasattr(first, "_log2e") else False, num_layers=len(units))
         if head is None:
             return None
         if full == batch:

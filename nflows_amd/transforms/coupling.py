@@ -334,6 +334,27 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         """The fold is implemented for the 8-bin evaluation only."""
         return self.resnet_log2e and self.num_bins == 8
 
+    # GEMM engine of the whole-layer kernel: "f16x2" = two f16 pieces per operand on the f16 matrix
+    # pipe (K8h; 8 bins; row blocks that leave the f16 range are redone by the bf16x3 kernel),
+    # "bf16x3" = three bf16 pieces (K8)
+    conditioner_engine = os.environ.get("NFA_K8_ENGINE", "f16x2")
+    # scale of the hidden activations' f16 pieces (a power of two; K8h)
+    conditioner_act_scale = float(os.environ.get("NFA_K8_ACT_SCALE", "1"))
+
+    def _use_f16(self):
+        return self.conditioner_engine == "f16x2" and self.num_bins == 8 and not self._log2e()
+
+    def _packed_resnet_f16(self):
+        net = self.transform_net
+        key = (_cache.epoch(), self.conditioner_act_scale) + tuple((p.data_ptr(), p._version) for p in net.parameters())
+        cached = getattr(self, "_packed_resnet_f16_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, ops.pack_resnet_conditioner_f16(net, self.num_transform_features,
+                                                           self._transform_dim_multiplier(),
+                                                           act_scale=self.conditioner_act_scale))
+            self._packed_resnet_f16_cache = cached
+        return cached[1]
+
     def _packed_resnet(self):
         net = self.transform_net
         key = (_cache.epoch(),) + tuple((p.data_ptr(), p._version) for p in net.parameters()) + (self._log2e(),)
@@ -368,14 +389,21 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         dt, di = self.num_transform_features, self.num_identity_features
         spec = self._spec()
         full = (B // 128) * 128
+        if self._use_f16():
+            f16 = self._packed_resnet_f16()
+
+            def run(rows, acc):
+                return ops.rqs_coupling_resnet_f16(rows, f16, (wp, bp), tables, dt, di, nb, spec, inverse, acc)
+        else:
+            def run(rows, acc):
+                return ops.rqs_coupling_resnet(rows, wp, bp, tables, dt, di, nb, spec, inverse, acc,
+                                               log2e=self._log2e())
         if full == B:
-            return ops.rqs_coupling_resnet(inputs, wp, bp, tables, dt, di, nb, spec, inverse, accumulate_into,
-                                           log2e=self._log2e())
+            return run(inputs, accumulate_into)
         # ragged batch: full 128-row blocks here, the tail through the PyTorch conditioner + K1
         acc_head = None if accumulate_into is None else accumulate_into[:full]
         acc_tail = None if accumulate_into is None else accumulate_into[full:]
-        head = ops.rqs_coupling_resnet(inputs[:full], wp, bp, tables, dt, di, nb, spec, inverse, acc_head,
-                                       log2e=self._log2e())
+        head = run(inputs[:full], acc_head)
         if head is None:
             return None
         tail_in = inputs[full:]

@@ -654,3 +654,47 @@ def test_whole_layer_kernel_random_geometries(restore_fused_path):
         for got, want, tol in ((z1, z0, 1e-4), (l1, l0, 2e-3), (x1, x0, 1e-4), (li1, li0, 2e-3)):
             d = (got - want).abs()
             assert d.max().item() < tol and d.median().item() < tol / 30, (what, d.max().item(), d.median().item())
+
+
+def test_f16_engine_hands_out_of_range_blocks_to_the_exact_kernel(monkeypatch):
+    """K8h computes the conditioner on f16 pieces: a 128-row block in which an activation leaves the
+    f16 range (here an identity feature of 1e6), or whose inputs are not finite, is not written by it
+    but redone by the bf16x3 kernel right behind it -- those blocks equal the bf16x3 engine's results
+    bit for bit (NaN pattern included), every other block is the f16 engine's own result."""
+    from nflows_amd import configs
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    import nflows_amd
+    flow = configs.rq_nsf_flow(num_layers=3, features=64, num_bins=8, hidden_features=128, seed=0)
+    with torch.no_grad():
+        for name, p in flow.named_parameters():
+            if "final_layer" in name:
+                p.mul_(4.0)
+            elif "linear_layers.1" in name:
+                p.mul_(30.0)
+    flow = flow.to(DEV).eval()
+    x = torch.randn(640, 64, generator=torch.Generator().manual_seed(2)).to(DEV)
+    x[130, 5] = 1.0e6
+    x[300, 7] = float("nan")
+    x[301, 9] = float("inf")
+    results = {}
+    for engine in ("f16x2", "bf16x3"):
+        monkeypatch.setattr(RQ, "conditioner_engine", engine)
+        with torch.no_grad():
+            z, lad = flow._transform(x)
+            nflows_amd.check_status()
+            xi, ladi = flow._transform.inverse(x)
+            # (a NaN input fails the inverse's discriminant check, as it fails the reference's
+            # assert, rational_quadratic.py:142: the status word reports it for either engine)
+            with pytest.raises(AssertionError):
+                nflows_amd.check_status()
+        results[engine] = [t.cpu().numpy() for t in (z, lad, xi, ladi)]
+    for got, want in zip(results["f16x2"], results["bf16x3"]):
+        for block in (1, 2):          # rows 128..255 (overflow) and 256..383 (non-finite inputs)
+            rows = slice(128 * block, 128 * (block + 1))
+            assert np.array_equal(got[rows], want[rows], equal_nan=True)
+        for block in (0, 3, 4):
+            rows = slice(128 * block, 128 * (block + 1))
+            assert np.isfinite(got[rows]).all()
+            assert np.abs(got[rows] - want[rows]).max() <= 2e-4 * (1 + np.abs(want[rows]).max())
+    # the two engines are different computations: somewhere outside the redone blocks they differ
+    assert not np.array_equal(results["f16x2"][0][:128], results["bf16x3"][0][:128])

@@ -338,6 +338,119 @@ def test_whole_layer_packing_is_a_lossless_rearrangement(K):
                 assert vals[:, 24 * f + 23].abs().max().item() == 0.0              # the pad row
 
 
+@pytest.mark.parametrize("act_scale", [1.0, 16.0])
+def test_f16_whole_layer_packing_carries_the_scales(act_scale):
+    """Host side of K8h (ops.pack_resnet_conditioner_f16): emulate the kernel's data flow with the
+    packed blobs -- transposed GEMMs on two f16 weight pieces pre-scaled by a power of two per GEMM,
+    the 4-float headers {out_scale, skip_scale} in front of the pre-scaled biases, activations at
+    scale S, the final layer's logits = accumulators x kappa -- and compare with the PyTorch
+    network in float64.  Checks stage order, permutations, scales and the folded 1/sqrt(hidden)."""
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import ResidualNet
+    torch.manual_seed(0)
+    K, dt, di = 8, 8, 6
+    P = 3 * K - 1
+    net = ResidualNet(di, dt * P, hidden_features=128, num_blocks=2).double()
+    with torch.no_grad():
+        for i_, p_ in enumerate(net.parameters()):
+            p_.copy_(torch.randn_like(p_) * (0.3 if i_ % 3 else 0.004))   # GEMMs of very different magnitudes
+    wp, bp = ops.pack_resnet_conditioner_f16(net.float(), dt, P, act_scale=act_scale)
+    net = net.double()
+    tiles = dt * 24 // 32
+    H = 4  # header floats
+    assert wp.shape == (2 + 16 * 2 + 2 * tiles, 512 * 8) and wp.dtype == torch.float16
+    assert bp.shape == ((H + 128) * 5 + H + tiles * 32,)
+    assert torch.isfinite(wp.float()).all() and wp.float().abs().max() < 2 ** 14
+    w = wp.double().view(-1, 512, 8)
+    x = torch.randn(32, di, dtype=torch.float64)
+    lane_r = torch.arange(64) % 32
+    lane_h = torch.arange(64) // 32
+
+    def acc_to_features(acc):
+        out = torch.zeros(32, 32 * acc.shape[0], dtype=torch.float64)
+        for t in range(acc.shape[0]):
+            for q in range(16):
+                out[lane_r, 32 * t + 8 * (q // 4) + 4 * lane_h + q % 4] = acc[t, :, q]
+        return out
+
+    def bias_tiles(off, n):
+        return bp[off:off + n * 32].double().view(n, 2, 16)[:, lane_h, :].clone()
+
+    def mfma(acc_t, a_frag, b_frag):
+        A = torch.zeros(32, 16, dtype=torch.float64)
+        Bm = torch.zeros(16, 32, dtype=torch.float64)
+        for l in range(64):
+            A[l % 32, 8 * (l // 32):8 * (l // 32) + 8] = a_frag[l]
+            Bm[8 * (l // 32):8 * (l // 32) + 8, l % 32] = b_frag[l]
+        Dm = A @ Bm
+        for l in range(64):
+            for q in range(16):
+                acc_t[l, q] += Dm[8 * (q // 4) + 4 * (l // 32) + q % 4, l % 32]
+
+    def b_from_acc(acc, ks):
+        return acc[ks // 2][:, 8 * (ks % 2):8 * (ks % 2) + 8]
+
+    stage, off = 0, 0
+    bx = torch.zeros(2, 64, 8, dtype=torch.float64)
+    for ks in range(2):
+        for l in range(64):
+            for j in range(8):
+                i = ks * 16 + (l // 32) * 8 + j
+                bx[ks, l, j] = x[l % 32, i] if i < di else 0.0
+    out_scale = bp[off].double()
+    h = bias_tiles(off + H, 4)
+    for ks in range(2):                               # initial layer: [4 tiles][2 pieces][64 lanes]
+        for t in range(4):
+            mfma(h[t], w[stage, (t * 2) * 64:(t * 2) * 64 + 64] + w[stage, (t * 2 + 1) * 64:(t * 2 + 1) * 64 + 64], bx[ks])
+        stage += 1
+    h = h * out_scale                                 # = S x hidden
+    off += H + 128
+    for blk in range(2):
+        for which in range(2):
+            out_scale, skip_scale = bp[off].double(), bp[off + 1].double()
+            src = torch.relu(h) if which == 0 else u
+            acc = bias_tiles(off + H, 4)
+            if which == 1:
+                acc = acc + h * skip_scale
+            else:
+                assert skip_scale == 0
+            for ks in range(8):
+                for t in range(4):
+                    mfma(acc[t], w[stage, (t * 2) * 64:(t * 2) * 64 + 64] + w[stage, (t * 2 + 1) * 64:(t * 2 + 1) * 64 + 64],
+                         b_from_acc(src, ks))
+                stage += 1
+            off += H + 128
+            if which == 0:
+                u = torch.relu(acc * out_scale)
+            else:
+                h = acc * out_scale
+    want_hidden = net.hidden(x)
+    got_hidden = acc_to_features(h) / act_scale
+    assert (got_hidden - want_hidden).abs().max().item() < 1e-6 * want_hidden.abs().max().item()
+    kappa, inv_kappa = bp[off].double(), bp[off + 1].double()
+    assert kappa * inv_kappa == 1.0
+    out = bias_tiles(off + H, tiles)
+    for t in range(tiles):
+        for hs in range(2):
+            for k4 in range(4):
+                a_frag = w[stage, k4 * 64:k4 * 64 + 64] + w[stage, (4 + k4) * 64:(4 + k4) * 64 + 64]
+                mfma(out[t], a_frag, b_from_acc(h, hs * 4 + k4))
+            stage += 1
+    assert stage == wp.shape[0] and off + H + tiles * 32 == bp.numel()
+    out = out * kappa
+    want = net.final_layer(want_hidden).view(32, dt, P).clone()
+    want[..., :2 * K] /= np.sqrt(128.0)
+    for g in range(dt // 4):
+        for half in range(2):
+            lanes = torch.arange(32) + 32 * half
+            vals = torch.cat([out[3 * g + t][lanes] for t in range(3)], dim=1)
+            for f in range(2):
+                ref = want[:, 4 * g + 2 * half + f]
+                got = vals[:, 24 * f:24 * f + 23]
+                assert (got - ref).abs().max().item() < 2e-6 * (1 + ref.abs().max().item()), (g, half, f)
+                assert vals[:, 24 * f + 23].abs().max().item() == 0.0
+
+
 def test_layer_tables_follow_the_fused_permutations():
     from nflows_amd import ops
     D = 12

@@ -6,11 +6,11 @@ set -e
 R=/root/repo
 N=$1; SRC=$2; shift; shift
 mkdir -p $R/build_variants
-HF="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -I$R/include -I$R/nflows_amd/csrc"
+HF="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fhip-fp32-correctly-rounded-divide-sqrt -I$R/include -I$R/nflows_amd/csrc"
 make -C $R/nflows_amd/csrc -s
 /opt/rocm/bin/hipcc $HF "$@" -c $R/nflows_amd/csrc/$SRC -o /tmp/var_$N.o 2>/tmp/build_$N.log || { tail -5 /tmp/build_$N.log; exit 1; }
 OBJS=""
-for f in rqs rqs_bwd rqs_shared rqs_fused_linear rqs_resnet splines_lq linear_wgrad misc; do
+for f in rqs rqs_bwd rqs_shared rqs_fused_linear rqs_resnet rqs_resnet_f16 splines_lq linear_wgrad misc; do
   if [ "$f.hip" == "$SRC" ]; then OBJS="$OBJS /tmp/var_$N.o"; else OBJS="$OBJS $R/nflows_amd/csrc/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_variants/$N.so $OBJS
