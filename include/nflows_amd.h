@@ -262,8 +262,9 @@ int nfa_rqs_flow_resnet_f32(const float *inputs, const void *weights_packed,
  *                  which keeps the low pieces in the normal f16 range) --
  *                  initial_layer, one stage per k-step: [4 tiles][2 pieces][64 lanes][8], element
  *                    rule as for K8; hidden Linears the same, 8 stages each; final_layer: two stages
- *                    per 32-row tile, [2 pieces][4 k-steps][64 lanes][8], rows ordered / padded /
- *                    pre-divided by sqrt(hidden_features) as for K8.
+ *                    per 32-row tile, [4 k-steps][2 pieces][64 lanes][8] (every stage is four
+ *                    (hi, lo) fragment pairs), rows ordered / padded / pre-divided by
+ *                    sqrt(hidden_features) as for K8.
  *   bias_packed    float, per GEMM a 4-float header {out_scale, skip_scale, 0, 0} then the biases in
  *                  accumulator order times the scale of their accumulators: with hidden activations
  *                  kept at scale S, initial_layer: biases x T, out_scale = S / T; a block's first

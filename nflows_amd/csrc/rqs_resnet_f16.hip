@@ -53,7 +53,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 namespace k8h {
 
 constexpr int kStageVec4 = 512;    // 8 KB: [4 tiles][2 pieces][64 lanes] or [2 pieces][4 k-steps][64 lanes] x 16 B
-constexpr int kRing = 3;
+constexpr int kRing = 6;           // five stages in flight behind the one being consumed
 constexpr int kRowPad = 33;
 constexpr int kTabId = 0, kTabTr = 64, kTabLayer = 128;
 constexpr int kHdr = 4;            // floats in front of every GEMM's biases: {out_scale, skip_scale, 0, 0}
@@ -70,44 +70,98 @@ struct Args {
     int64_t batch;
     int D, dt, di, num_blocks, num_layers, num_stages, bias_per_layer, accumulate;
     RqsDev sp;
+    unsigned long long* trace;  // debug: [gridDim.x][64] cycle stamps of wave 0 (first row block), null = off
 };
 
+#define NFA_HSTAMP() if (tr && ti < 32) tr[ti++] = __builtin_readcyclecounter();
+
+// NW = waves per workgroup (4 or 8) sharing the ring
+template <int NW_>
 struct WeightStream {
+    static constexpr int NW = NW_;
     const vec4f* w;
     vec4f* ring;
     int slot, fetch, num_stages, tid;
 };
 
-__device__ __forceinline__ void stream_request(WeightStream& sm) {
-    const int dst_slot = sm.slot >= 1 ? sm.slot - 1 : kRing - 1;  // (slot + 2) % 3
+// Why the ring is deep: an LDS-DMA request lands 1-2 microseconds after it was issued when every CU
+// streams, and the bytes a CU receives per second are (bytes in flight) / (that latency).  With two
+// 8 KB stages in flight per workgroup the kernel ran at the speed of this stream (24 GB/s per CU,
+// every stage barrier waiting for its data: tools/k8h_trace.py); five stages in flight cover it.
+// Eight waves sharing one ring (one workgroup per CU) also halve the bytes a CU has to pull.
+template <class SM>
+__device__ __forceinline__ void stream_request(SM& sm) {
+    constexpr int NW = SM::NW, kThreads = NW * kWave;
+    const int dst_slot = sm.slot >= 1 ? sm.slot - 1 : kRing - 1;  // (slot + kRing - 1) % kRing
     const char* stage = reinterpret_cast<const char*>(sm.w) + (size_t)sm.fetch * (kStageVec4 * 16);
     const int wave = __builtin_amdgcn_readfirstlane(sm.tid >> 6);
     char* slot = reinterpret_cast<char*>(sm.ring) + dst_slot * (kStageVec4 * 16) + wave * (kWave * 16);
     const unsigned lane_off = (unsigned)sm.tid * 16u;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 8 / NW; ++i)
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)((stage + i * kBlock * 16) + lane_off),
-            (__attribute__((address_space(3))) void*)(slot + i * kBlock * 16), 16, 0, 0);
+            (const __attribute__((address_space(1))) void*)((stage + i * kThreads * 16) + lane_off),
+            (__attribute__((address_space(3))) void*)(slot + i * kThreads * 16), 16, 0, 0);
     sm.fetch = (sm.fetch + 1 == sm.num_stages) ? 0 : sm.fetch + 1;
 }
 
-// end of a stage: this wave's two requests of the next stage have landed (the two of the stage
-// after it may still be in flight), every wave is done reading
-__device__ __forceinline__ void stream_advance(WeightStream& sm) {
-#ifdef NFA_K8H_DRAIN
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
+// end of stage s: this wave's requests of stage s + 2 have landed (those of the three stages after
+// it may still be in flight), every wave is done reading stage s.  Stage s + 1 was complete one
+// barrier earlier, which is what lets a wave read the first weight fragments of the NEXT stage while
+// it still issues the MFMAs of the current one (no LDS latency in front of any MFMA).
+template <class SM>
+__device__ __forceinline__ void stream_advance(SM& sm) {
+    if constexpr (SM::NW == 8) asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     sm.slot = (sm.slot + 1 == kRing) ? 0 : sm.slot + 1;
 }
 
-#ifdef NFA_DBG_F
-typedef __bf16 dbg_bf16x8 __attribute__((ext_vector_type(8)));
-#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, x_, y_, z_) \
-    __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dbg_bf16x8, a_), __builtin_bit_cast(dbg_bf16x8, b_), c_, x_, y_, z_)
-#endif
+// A stage is four fragment pairs (hi, lo pieces of a 32 x 16 weight block): pair g at vec4 offsets
+// g * 128 (hi) and g * 128 + 64 (lo).  k-major stages: pair g = output tile g of one k-step; final
+// layer: pair g = k-step g of one half tile.  `fr` always holds the pair the next MFMAs need; its
+// successor -- the next pair of this stage or pair 0 of the next stage -- is requested from LDS
+// before those MFMAs are issued.
+struct Frags {
+    vec4f h, l;
+};
+
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
+}
+
+// (cur / nxt: LDS byte addresses of this lane's 16 bytes in the current / the next stage)
+template <class SM>
+__device__ __forceinline__ void stage_begin(SM& sm, unsigned& cur, unsigned& nxt, int lane) {
+    stream_request(sm);
+    const unsigned base = lds_address(sm.ring) + (unsigned)lane * 16u;
+    cur = base + (unsigned)sm.slot * (kStageVec4 * 16);
+    nxt = base + (unsigned)(sm.slot + 1 == kRing ? 0 : sm.slot + 1) * (kStageVec4 * 16);
+}
+
+// The fragment reads are written as asm: hipcc waits for every LDS read it knows about with
+// lgkmcnt(0), i.e. also for the pair requested a moment ago for the NEXT group, which puts the full
+// LDS latency in front of every second MFMA group (measured: 850-1200 cycles per k-step of twelve
+// MFMAs instead of ~450).  Here the pair in `fr` is awaited with a counted lgkmcnt(2): LDS reads
+// return in order, so with the two reads of the following pair as the only younger requests `fr` has
+// landed (other LDS / scalar-memory traffic can only make the wait stricter, never weaker).
+template <int G>
+__device__ __forceinline__ Frags next_frags(unsigned cur, unsigned nxt) {
+    Frags f;
+    if constexpr (G < 3) {
+        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                     : "=v"(f.h), "=v"(f.l)
+                     : "v"(cur), "i"((G + 1) * 2048), "i"((G + 1) * 2048 + 1024));
+    } else {
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=v"(f.h), "=v"(f.l) : "v"(nxt));
+    }
+    return f;
+}
+
+// `fr` has landed (its successor's two reads are the only younger requests of this wave)
+__device__ __forceinline__ void await_frags(Frags& fr) {
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fr.h), "+v"(fr.l));
+}
+
 // smallest terms first
 #define NFA_MFMA3(acc, ah, al, bh, bl)                                            \
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);           \
@@ -183,44 +237,74 @@ __device__ __forceinline__ void mfma_drain_h(const f32x16& a) {
 #endif
 }
 
-// k-major GEMM: out^T[128 x 32 samples] += W[128 x 16*NKS] x act^T; one 8 KB stage
-// ([4 tiles][2 pieces][64 lanes] x 16 bytes) per k-step
-template <bool RELU, int NKS>
+__device__ __forceinline__ void mfma_drain_t(const f32x16& a) {
+    const int t = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a[0]));
+    asm volatile("" ::"s"(t));
+}
+
+// k-major GEMM: out^T[128 x 32 samples] += W[128 x 16*NKS] x act^T; one 8 KB stage per k-step
+template <bool RELU, int NKS, class SM>
 __device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const f16x8 (&ph)[8], const f16x8 (&pl)[8],
-                                            WeightStream& sm, int lane) {
+                                            SM& sm, Frags& fr, int lane, unsigned long long* ft = nullptr) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-        stream_request(sm);
-        const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
+        unsigned cur, nxt;
+#ifdef NFA_K8H_FINE_TRACE
+        if (ft) ft[3 * ks] = __builtin_readcyclecounter();
+#endif
+        stage_begin(sm, cur, nxt, lane);
         f16x8 bh = ph[ks], bl = pl[ks];
         if (RELU) relu_pieces(bh, bl);  // (the input pieces themselves stay: skip connection)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const f16x8 ah = __builtin_bit_cast(f16x8, cur[(t * 2 + 0) * 64]);
-            const f16x8 al = __builtin_bit_cast(f16x8, cur[(t * 2 + 1) * 64]);
+            Frags nf;
+            if (t == 0) nf = next_frags<0>(cur, nxt);
+            else if (t == 1) nf = next_frags<1>(cur, nxt);
+            else if (t == 2) nf = next_frags<2>(cur, nxt);
+            else nf = next_frags<3>(cur, nxt);
+            await_frags(fr);
+            __builtin_amdgcn_sched_barrier(0);
+            const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);
             NFA_MFMA3(acc[t], ah, al, bh, bl);
             mfma_drain_h(acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
+            fr = nf;
         }
         mfma_drain(acc[3]);
+#ifdef NFA_K8H_FINE_TRACE
+        if (ft) { mfma_drain_t(acc[3]); ft[3 * ks + 1] = __builtin_readcyclecounter(); }
+#endif
         stream_advance(sm);
+#ifdef NFA_K8H_FINE_TRACE
+        if (ft) ft[3 * ks + 2] = __builtin_readcyclecounter();
+#endif
     }
 }
 
 // one 32-row output tile of the final layer without anything woven in (the first tile of a layer):
 // two stages of [2 pieces][4 k-steps][64 lanes] x 16 bytes
+template <class SM>
 __device__ __forceinline__ void gemm_tile(f32x16& acc, const f16x8 (&ph)[8], const f16x8 (&pl)[8],
-                                          WeightStream& sm, int lane) {
+                                          SM& sm, Frags& fr, int lane) {
 #pragma unroll
     for (int hs = 0; hs < 2; ++hs) {
-        stream_request(sm);
-        const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
+        unsigned cur, nxt;
+        stage_begin(sm, cur, nxt, lane);
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
             const int ks = hs * 4 + k4;
-            const f16x8 ah = __builtin_bit_cast(f16x8, cur[(0 * 4 + k4) * 64]);
-            const f16x8 al = __builtin_bit_cast(f16x8, cur[(1 * 4 + k4) * 64]);
+            Frags nf;
+            if (k4 == 0) nf = next_frags<0>(cur, nxt);
+            else if (k4 == 1) nf = next_frags<1>(cur, nxt);
+            else if (k4 == 2) nf = next_frags<2>(cur, nxt);
+            else nf = next_frags<3>(cur, nxt);
+            await_frags(fr);
+            __builtin_amdgcn_sched_barrier(0);
+            const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);
             NFA_MFMA3(acc, ah, al, ph[ks], pl[ks]);
             mfma_drain_h(acc);
+            __builtin_amdgcn_sched_barrier(0);
+            fr = nf;
         }
         mfma_drain(acc);
         stream_advance(sm);
@@ -278,40 +362,37 @@ __device__ __forceinline__ void spline_unit_step(Steps& fa, Steps& fb, const Rqs
     __builtin_amdgcn_sched_barrier(0)
 
 template <int UNIT, int KS, class Steps>
-__device__ __forceinline__ void kstep_pumped(f32x16& acc, f16x8 bh, f16x8 bl, vec4f& fh, vec4f& fl,
-                                             const vec4f* cur, Steps& fa, Steps& fb, const RqsDev& sp) {
-    constexpr int K4 = KS & 3;
-    const f16x8 ah = __builtin_bit_cast(f16x8, fh), al = __builtin_bit_cast(f16x8, fl);
+__device__ __forceinline__ void kstep_pumped(f32x16& acc, f16x8 bh, f16x8 bl, Frags& fr, unsigned cur,
+                                             unsigned nxt, Steps& fa, Steps& fb, const RqsDev& sp) {
+    const Frags nf = next_frags<(KS & 3)>(cur, nxt);   // the next k-step's fragments, three MFMAs ahead of their use
+    await_frags(fr);
+    const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);
+    fr = nf;
     NFA_PUMP(KS * 3 + 0, al, bh);
-    if (K4 < 3) {  // the next k-step's fragments, two MFMAs ahead of their use
-        fh = cur[(0 * 4 + K4 + 1) * 64];
-        fl = cur[(1 * 4 + K4 + 1) * 64];
-    }
     NFA_PUMP(KS * 3 + 1, ah, bl);
     NFA_PUMP(KS * 3 + 2, ah, bh);
     mfma_drain(acc);
 }
 #undef NFA_PUMP
 
-template <int UNIT, int HS, class Steps>
+template <int UNIT, int HS, class Steps, class SM>
 __device__ __forceinline__ void stage_pumped(f32x16& acc, const f16x8 (&ph)[8], const f16x8 (&pl)[8],
-                                             WeightStream& sm, int lane, Steps& fa, Steps& fb, const RqsDev& sp) {
-    stream_request(sm);
-    const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
-    vec4f fh = cur[0 * 4 * 64], fl = cur[1 * 4 * 64];
-    kstep_pumped<UNIT, HS * 4 + 0>(acc, ph[HS * 4 + 0], pl[HS * 4 + 0], fh, fl, cur, fa, fb, sp);
-    kstep_pumped<UNIT, HS * 4 + 1>(acc, ph[HS * 4 + 1], pl[HS * 4 + 1], fh, fl, cur, fa, fb, sp);
-    kstep_pumped<UNIT, HS * 4 + 2>(acc, ph[HS * 4 + 2], pl[HS * 4 + 2], fh, fl, cur, fa, fb, sp);
-    kstep_pumped<UNIT, HS * 4 + 3>(acc, ph[HS * 4 + 3], pl[HS * 4 + 3], fh, fl, cur, fa, fb, sp);
+                                             SM& sm, Frags& fr, int lane, Steps& fa, Steps& fb, const RqsDev& sp) {
+    unsigned cur, nxt;
+    stage_begin(sm, cur, nxt, lane);
+    kstep_pumped<UNIT, HS * 4 + 0>(acc, ph[HS * 4 + 0], pl[HS * 4 + 0], fr, cur, nxt, fa, fb, sp);
+    kstep_pumped<UNIT, HS * 4 + 1>(acc, ph[HS * 4 + 1], pl[HS * 4 + 1], fr, cur, nxt, fa, fb, sp);
+    kstep_pumped<UNIT, HS * 4 + 2>(acc, ph[HS * 4 + 2], pl[HS * 4 + 2], fr, cur, nxt, fa, fb, sp);
+    kstep_pumped<UNIT, HS * 4 + 3>(acc, ph[HS * 4 + 3], pl[HS * 4 + 3], fr, cur, nxt, fa, fb, sp);
     stream_advance(sm);
 }
 
-template <int UNIT, class Steps>
+template <int UNIT, class Steps, class SM>
 __device__ __forceinline__ void gemm_tile_pumped(f32x16& acc, const f16x8 (&ph)[8], const f16x8 (&pl)[8],
-                                                 WeightStream& sm, int lane, Steps& fa, Steps& fb,
+                                                 SM& sm, Frags& fr, int lane, Steps& fa, Steps& fb,
                                                  const RqsDev& sp) {
-    stage_pumped<UNIT, 0>(acc, ph, pl, sm, lane, fa, fb, sp);
-    stage_pumped<UNIT, 1>(acc, ph, pl, sm, lane, fa, fb, sp);
+    stage_pumped<UNIT, 0>(acc, ph, pl, sm, fr, lane, fa, fb, sp);
+    stage_pumped<UNIT, 1>(acc, ph, pl, sm, fr, lane, fa, fb, sp);
 }
 
 // accumulator tile t (times `scale`, a power of two), registers 8*hk .. 8*hk+7 -> pieces of k-step 2t + hk
@@ -356,12 +437,13 @@ __device__ __forceinline__ void load_bias_tile(f32x16& acc, const float* bias_ti
 
 __device__ __forceinline__ bool not_finite(float v) { return !(__builtin_fabsf(v) < INFINITY); }
 
-template <bool INVERSE, int INIT_KS>
-__global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16_kernel(const Args a) {
+template <bool INVERSE, int INIT_KS, int NW>
+__global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Args a) {
+    constexpr int kThreads = NW * kWave;
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     __shared__ int s_tab[2][kTabLayer];
     __shared__ int s_final[128];
-    __shared__ int s_bad[kBlock / kWave];
+    __shared__ int s_bad[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = a.D, dt = a.dt;
     int my_status = 0;
@@ -374,28 +456,38 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16_kernel(const Args a)
         s_final[tid] = checked(a.tables[a.num_layers * kTabLayer + tid], tid < D);
     }
 
-    WeightStream sm;
+    WeightStream<NW> sm;
     sm.w = a.w;
     sm.ring = reinterpret_cast<vec4f*>(lds_dyn);
-    sm.slot = 1;
     sm.fetch = 0;
     sm.num_stages = a.num_stages * a.num_layers;
     sm.tid = tid;
-    stream_request(sm);  // stage 0 -> slot 0
-    sm.slot = 2;
-    stream_request(sm);  // stage 1 -> slot 1
+#pragma unroll
+    for (int j = 0; j < kRing - 1; ++j) {   // stages 0 .. kRing-2 -> slots 0 .. kRing-2
+        sm.slot = j + 1 == kRing ? 0 : j + 1;
+        stream_request(sm);
+    }
     sm.slot = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    Frags fr;   // the weight fragments the next MFMAs need (carried across stages, layers and row blocks)
+    fr.h = sm.ring[lane];
+    fr.l = sm.ring[64 + lane];
 
     float* s_row = lds_dyn + kRing * kStageVec4 * 4 + wave * D * kRowPad;
-    float* s_fbias = lds_dyn + kRing * kStageVec4 * 4 + (kBlock / kWave) * D * kRowPad;
+    float* s_fbias = lds_dyn + kRing * kStageVec4 * 4 + NW * D * kRowPad;
     const int groups = dt >> 2;
-    const int64_t num_quads = a.batch >> 7;
+    const int64_t num_quads = a.batch / (32 * NW);   // row blocks of this workgroup size
     int tb = 0;
 
+    unsigned long long* tr = nullptr;
+    int ti = 1;
+    if (a.trace && lane == 0 && wave == 0) {
+        tr = a.trace + (size_t)blockIdx.x * 64;
+        tr[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // HW_ID, XCC_ID
+    }
     for (int64_t quad = blockIdx.x; quad < num_quads; quad += gridDim.x) {
-        const int64_t row0 = (quad << 7) + (wave << 5);
+        const int64_t row0 = quad * (32 * NW) + (wave << 5);
         int lane_here = lane, di = a.di;
         asm volatile("" : "+v"(lane_here), "+s"(di));
         const int half = lane_here >> 5, r = lane_here & 31;
@@ -444,6 +536,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16_kernel(const Args a)
             }
             const float* gemm = a.bias + (size_t)layer * a.bias_per_layer;   // header + biases of the next GEMM
             f16x8 ph[8], pl[8];  // the current activations (128 k per sample) as f16 pieces
+            NFA_HSTAMP()
 
             // ---- identity features (scale 1): k = ks*16 + half*8 + j
 #pragma unroll
@@ -469,17 +562,18 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16_kernel(const Args a)
                 f32x16 h[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) load_bias_tile(h[t], bias + t * 32);
-                gemm_kmajor<false, INIT_KS>(h, ph, pl, sm, lane);
+                gemm_kmajor<false, INIT_KS>(h, ph, pl, sm, fr, lane);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     tile_to_pieces<false>(h[t], out_scale, ph[2 * t], pl[2 * t], ph[2 * t + 1], pl[2 * t + 1]);
             }
             gemm += kHdr + 128;
+            NFA_HSTAMP()
             {
                 // the final layer's header and biases of this layer go to LDS once (every wave has
                 // passed a stage barrier of this layer: nobody reads the previous layer's any more)
                 const float* fb = a.bias + (size_t)layer * a.bias_per_layer + (kHdr + 128) * (1 + 2 * a.num_blocks);
-                for (int i = tid; i < kHdr + dt * 24; i += kBlock) s_fbias[i] = fb[i];
+                for (int i = tid; i < kHdr + dt * 24; i += kThreads) s_fbias[i] = fb[i];
                 if (a.num_blocks == 0) __syncthreads();
             }
 
@@ -492,12 +586,13 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16_kernel(const Args a)
                     f32x16 u[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) load_bias_tile(u[t], bias + t * 32);
-                    gemm_kmajor<true, 8>(u, ph, pl, sm, lane);
+                    gemm_kmajor<true, 8>(u, ph, pl, sm, fr, lane);
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
                         tile_to_pieces<true>(u[t], out_scale, qh[2 * t], ql[2 * t], qh[2 * t + 1], ql[2 * t + 1]);
                 }
                 gemm += kHdr + 128;
+                NFA_HSTAMP()
                 const float out_scale = gemm[0], skip_scale = gemm[1];
                 const float* bias = gemm + kHdr + half * 16;
                 f32x16 v[4];
@@ -507,11 +602,12 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16_kernel(const Args a)
                     add_pieces(v[t], 0, ph[2 * t], pl[2 * t], skip_scale);
                     add_pieces(v[t], 8, ph[2 * t + 1], pl[2 * t + 1], skip_scale);
                 }
-                gemm_kmajor<false, 8>(v, qh, ql, sm, lane);
+                gemm_kmajor<false, 8>(v, qh, ql, sm, fr, lane, (tr && layer == 0 && blk == 0) ? tr + 36 : nullptr);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     tile_to_pieces<false>(v[t], out_scale, ph[2 * t], pl[2 * t], ph[2 * t + 1], pl[2 * t + 1]);
                 gemm += kHdr + 128;
+                NFA_HSTAMP()
             }
 
             // ---- final layer with the spline evaluation woven into the MFMAs
@@ -541,7 +637,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16_kernel(const Args a)
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
                         load_bias_tile(acc[t], fbias + (g * 3 + t) * 32);
-                        gemm_tile(acc[t], ph, pl, sm, lane);
+                        gemm_tile(acc[t], ph, pl, sm, fr, lane);
                     }
                     fa.x = *slot0;
                     fb.x = *slot1;
@@ -566,10 +662,10 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16_kernel(const Args a)
                     float* slot1 = s_row + tab[kTabTr + g * 4 + half * 2 + 1] * kRowPad + r;
                     load_bias_tile(acc[0], fbias + (g * 3 + 0) * 32);
                     if (g > 0) {
-                        gemm_tile_pumped<kUnitFinishB>(acc[0], ph, pl, sm, lane, fa, fb, a.sp);
+                        gemm_tile_pumped<kUnitFinishB>(acc[0], ph, pl, sm, fr, lane, fa, fb, a.sp);
                         commit(fb, slot_b);
                     } else {
-                        gemm_tile(acc[0], ph, pl, sm, lane);
+                        gemm_tile(acc[0], ph, pl, sm, fr, lane);
                     }
                     fa.x = *slot0;
 #pragma unroll
@@ -578,7 +674,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16_kernel(const Args a)
                         fa.eh[j] = acc[0][8 + j];
                     }
                     load_bias_tile(acc[1], fbias + (g * 3 + 1) * 32);
-                    gemm_tile_pumped<kUnitNumA>(acc[1], ph, pl, sm, lane, fa, fb, a.sp);
+                    gemm_tile_pumped<kUnitNumA>(acc[1], ph, pl, sm, fr, lane, fa, fb, a.sp);
                     fb.x = *slot1;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -586,7 +682,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16_kernel(const Args a)
                         fb.ew[j] = acc[1][8 + j];
                     }
                     load_bias_tile(acc[2], fbias + (g * 3 + 2) * 32);
-                    gemm_tile_pumped<kUnitFinishA>(acc[2], ph, pl, sm, lane, fa, fb, a.sp);
+                    gemm_tile_pumped<kUnitFinishA>(acc[2], ph, pl, sm, fr, lane, fa, fb, a.sp);
                     commit(fa, slot0);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -594,12 +690,14 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16_kernel(const Args a)
                         if (j < 7) fb.sd[j] = acc[2][8 + j];
                     }
                     slot_b = slot1;
+                    NFA_HSTAMP()
                 }
                 spline_unit_range<kUnitFinishB, 0, spline_unit_slices<kUnitFinishB, Steps>()>(fa, fb, a.sp);
 #endif
                 commit(fb, slot_b);
             }
             tb ^= 1;
+            NFA_HSTAMP()
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #ifdef NFA_DBG_B
@@ -623,7 +721,10 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16_kernel(const Args a)
         const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
         if (lane == 0) s_bad[wave] = wave_bad ? 1 : 0;
         __syncthreads();
-        quad_bad = (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) != 0;
+        int any_bad = 0;
+#pragma unroll
+        for (int w_ = 0; w_ < NW; ++w_) any_bad |= s_bad[w_];
+        quad_bad = any_bad != 0;
         }
         if (!quad_bad) {
             vec4f* ov = reinterpret_cast<vec4f*>(a.out + row0 * D);
@@ -642,7 +743,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16_kernel(const Args a)
             }
             my_status |= quad_status;
         }
-        if (tid == 0) a.redo[quad] = quad_bad ? 1 : 0;
+        if (tid < NW / 4) a.redo[quad * (NW / 4) + tid] = quad_bad ? 1 : 0;   // one flag per 128 rows
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // s_bad is rewritten by the next row block
     }
@@ -695,36 +796,43 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* we
     a.num_stages = init_ks + 16 * num_blocks + 2 * (num_transform * 24 / 32);
     a.bias_per_layer = (k8h::kHdr + 128) * (1 + 2 * num_blocks) + k8h::kHdr + num_transform * 24;
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
+    a.trace = g_k7_trace;
+    // workgroups of eight waves (256 rows, one per CU, one weight stream per CU) when the batch gives
+    // every CU one; otherwise four waves (128 rows)
+    const int cus = device_cu_count();
+    static const int force_nw = getenv("NFA_K8H_WAVES") ? atoi(getenv("NFA_K8H_WAVES")) : 0;
+    int nw = ((batch & 255) == 0 && (batch >> 8) >= cus) ? 8 : 4;
+    if (force_nw == 4 || (force_nw == 8 && (batch & 255) == 0)) nw = force_nw;
     const size_t lds = (size_t)k8h::kRing * k8h::kStageVec4 * 16 +
-                       (size_t)(kBlock / kWave) * features * k8h::kRowPad * sizeof(float) +
+                       (size_t)nw * features * k8h::kRowPad * sizeof(float) +
                        (size_t)(k8h::kHdr + num_transform * 24) * sizeof(float);
-    int64_t blocks = batch >> 7;
-    int64_t per_cu = lds + 2048 <= 80 * 1024 ? 2 : 1;
-    static const int debug_one_per_cu = getenv("NFA_K8H_ONE_PER_CU") ? 1 : 0;
-    size_t lds_launch = lds;
-    if (debug_one_per_cu) { per_cu = 1; lds_launch = 100 * 1024; }
-    static const int debug_lds_extra = getenv("NFA_K8H_LDS_EXTRA") ? atoi(getenv("NFA_K8H_LDS_EXTRA")) : 0;
-    lds_launch += debug_lds_extra;
-    static const int debug_nocheck = getenv("NFA_K8H_NOCHECK") ? 1 : 0;
-    if (debug_nocheck) a.accumulate |= 2;
-    const int64_t cap = (int64_t)device_cu_count() * per_cu;
+    if (lds + 2048 > 160 * 1024) nw = 4;
+    const size_t lds_launch = (size_t)k8h::kRing * k8h::kStageVec4 * 16 +
+                              (size_t)nw * features * k8h::kRowPad * sizeof(float) +
+                              (size_t)(k8h::kHdr + num_transform * 24) * sizeof(float);
+    int64_t blocks = batch / (32 * nw);
+    const int64_t per_cu = (nw == 4 && lds_launch + 2048 <= 80 * 1024) ? 2 : 1;
+    const int64_t cap = (int64_t)cus * per_cu;
     if (blocks > cap) blocks = cap;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     profile_next_launch(&e0, &e1);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)blocks), block(kBlock);
+    const dim3 grid((unsigned)blocks), block(nw * kWave);
     const bool inv = (flags & NFA_FLAG_INVERSE) != 0;
     void (*kern)(const k8h::Args) = nullptr;
-    int which = 0;
-    if (init_ks == 4) {
-        kern = inv ? k8h::rqs_resnet_f16_kernel<true, 4> : k8h::rqs_resnet_f16_kernel<false, 4>;
-        which = inv ? 3 : 2;
-    } else {
-        kern = inv ? k8h::rqs_resnet_f16_kernel<true, 2> : k8h::rqs_resnet_f16_kernel<false, 2>;
-        which = inv ? 1 : 0;
+    const int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0);
+    switch (which) {
+        case 0: kern = k8h::rqs_resnet_f16_kernel<false, 2, 4>; break;
+        case 1: kern = k8h::rqs_resnet_f16_kernel<true, 2, 4>; break;
+        case 2: kern = k8h::rqs_resnet_f16_kernel<false, 4, 4>; break;
+        case 3: kern = k8h::rqs_resnet_f16_kernel<true, 4, 4>; break;
+        case 4: kern = k8h::rqs_resnet_f16_kernel<false, 2, 8>; break;
+        case 5: kern = k8h::rqs_resnet_f16_kernel<true, 2, 8>; break;
+        case 6: kern = k8h::rqs_resnet_f16_kernel<false, 4, 8>; break;
+        default: kern = k8h::rqs_resnet_f16_kernel<true, 4, 8>; break;
     }
     if (lds_launch > 64 * 1024) {
-        static bool raised[4] = {false, false, false, false};
+        static bool raised[8] = {false, false, false, false, false, false, false, false};
         if (!raised[which]) {
             NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
             raised[which] = true;

@@ -766,8 +766,9 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
     bf = torch.cat((bf, bf.new_zeros(dt, 24 - P)), dim=1).reshape(dt * 24).index_select(0, order_r)
     T = _f16_weight_scale(wf)
     tiles = dt * 24 // 32
-    # (p, tile, i, hs, k4, hf, j) -> (tile, hs, p, k4, hf, i, j): two stages per tile
-    stages.append(pieces(wf * T).view(2, tiles, 32, 2, 4, 2, 8).permute(1, 3, 0, 4, 5, 2, 6).reshape(tiles * 2, -1))
+    # (p, tile, i, hs, k4, hf, j) -> (tile, hs, k4, p, hf, i, j): two stages per tile, every stage four
+    # (hi, lo) fragment pairs like the k-major stages (there: one pair per output tile)
+    stages.append(pieces(wf * T).view(2, tiles, 32, 2, 4, 2, 8).permute(1, 3, 4, 0, 5, 2, 6).reshape(tiles * 2, -1))
     # the spline evaluation reads logits = accumulators x kappa, kappa = 1 / (S T)
     blob += [header(1.0 / (S * T), S * T), _bias_accumulator_order(bf * (S * T))]
     return torch.cat(stages, dim=0).contiguous(), torch.cat(blob).contiguous()

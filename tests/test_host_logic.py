@@ -433,7 +433,7 @@ def test_f16_whole_layer_packing_carries_the_scales(act_scale):
     for t in range(tiles):
         for hs in range(2):
             for k4 in range(4):
-                a_frag = w[stage, k4 * 64:k4 * 64 + 64] + w[stage, (4 + k4) * 64:(4 + k4) * 64 + 64]
+                a_frag = w[stage, (2 * k4) * 64:(2 * k4) * 64 + 64] + w[stage, (2 * k4 + 1) * 64:(2 * k4 + 1) * 64 + 64]
                 mfma(out[t], a_frag, b_from_acc(h, hs * 4 + k4))
             stage += 1
     assert stage == wp.shape[0] and off + H + tiles * 32 == bp.numel()
