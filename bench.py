@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """Headline benchmark: Flow.log_prob throughput of the 32-layer RQ-NSF coupling flow
-(dim=64, K=8, batch 65536 per GPU) on MI355X, with the spline kernel's HBM roofline fraction
-and the reference-CPU-path baseline (timed through its bit-identical port, oracle/eager.py).
+(dim=64, K=8) on MI355X, with the layer kernel's roofline fraction and the reference-CPU-path
+baseline (the reference classes where /root/reference exists, else their bit-identical port).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-For N > 1 the driver launches one process per GPU with torch.distributed.run; ranks shard the
-samples (weak scaling: 65536 rows per GPU) and exchange one 16-byte all-reduce per step.
-A "step" is one full log_prob pass over the rank's batch (inputs already resident in HBM) plus
-the log-likelihood reduction.  Rank 0 prints ONE JSON line.
+N = 1: batch 65 536 on one GPU (the north-star's single-GPU configuration).  N > 1 (one process per
+GPU, launched by torch.distributed.run): BASELINE configs[3] as named -- a global batch of 262 144
+rows sharded over the N ranks (32 768 per GPU at N = 8), one 16-byte all-reduce per step; the
+per-GPU work shrinks as N grows ("scaling": "strong"); a weak-scaling figure at 65 536 rows per GPU is
+added as an extra field.  A "step" is one full log_prob pass over the rank's rows (inputs already
+resident in HBM) plus the log-likelihood reduction.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -90,33 +92,95 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(flow_cpu, features, sample_rows, budget_s=20.0):
-    """The reference's CPU path, via its bit-identical PyTorch-eager port, on the host cores this
-    process may use.  Bounded: rows are halved until one pass fits the time budget."""
+def _reference_flow(flow_cpu):
+    """The unmodified reference classes (bayesiains/nflows imported from /root/reference, present in
+    the build container only) carrying the same weights, or None where the reference is absent."""
+    ref_root = "/root/reference"
+    if not os.path.isdir(os.path.join(ref_root, "nflows")):
+        return None
+    try:
+        shim = os.path.join(ROOT, "tests", "_refshim")
+        for p_ in (shim, ref_root):
+            if p_ not in sys.path:
+                sys.path.insert(0, p_)
+        from nflows.distributions.normal import StandardNormal
+        from nflows.flows.base import Flow
+        from nflows.nn.nets import ResidualNet
+        from nflows.transforms.base import CompositeTransform
+        from nflows.transforms.coupling import PiecewiseRationalQuadraticCouplingTransform
+        from nflows.transforms.permutations import RandomPermutation
+        from nflows.utils.torchutils import create_alternating_binary_mask
+        layers = []
+        ours = list(flow_cpu._transform._transforms)
+        for i in range(len(ours) // 2):
+            c = ours[2 * i + 1]
+            layers.append(RandomPermutation(c.features))
+            layers.append(PiecewiseRationalQuadraticCouplingTransform(
+                mask=create_alternating_binary_mask(c.features, even=(i % 2 == 0)),
+                transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=128, num_blocks=2),
+                num_bins=c.num_bins, tails="linear", tail_bound=c.tail_bound))
+        ref = Flow(CompositeTransform(layers), StandardNormal([ours[1].features]))
+        ref.load_state_dict(flow_cpu.state_dict(), strict=True)
+        return ref.eval()
+    except Exception as e:  # the port below is bit-identical to it
+        log("reference import failed (%r): timing the port" % (e,))
+        return None
+
+
+def cpu_baseline(flow_cpu, features, sample_rows, x_consistency=None, budget_s=20.0):
+    """The reference's CPU path on the host cores this process may use: the unmodified reference
+    classes when /root/reference is importable (build container), else their bit-identical
+    PyTorch-eager port (oracle/eager.py; tests/test_oracle_golden.py pins it bit for bit).  Bounded:
+    rows are reduced until one pass fits the time budget.  Also reports a one-thread figure and the
+    reference's own forward/inverse consistency error on the rows bench.py uses for the HIP path."""
     from oracle import eager
     threads = usable_cores()
-    torch.set_num_threads(threads)
-    log("cpu baseline: %d threads (os.cpu_count=%s)" % (threads, os.cpu_count()))
-    rows = sample_rows
-    with torch.no_grad():
+    ref = _reference_flow(flow_cpu)
+    kind = "reference" if ref is not None else "port"
+    if ref is not None:
+        def run(x):
+            return ref.log_prob(x)
+    else:
+        def run(x):
+            return eager.flow_log_prob(flow_cpu, x)
+
+    def timed(rows, nthreads, budget):
+        torch.set_num_threads(nthreads)
         while True:
             x = torch.randn(rows, features, generator=torch.Generator().manual_seed(1234))
             t0 = time.perf_counter()
-            eager.flow_log_prob(flow_cpu, x)  # warm-up pass, also the probe
+            run(x)  # warm-up pass, also the probe
             probe = time.perf_counter() - t0
-            log("cpu baseline: %d rows, probe pass %.2f s" % (rows, probe))
-            if probe <= budget_s / 4 or rows <= 512:
+            log("cpu baseline (%s, %d threads): %d rows, probe pass %.2f s" % (kind, nthreads, rows, probe))
+            if probe <= budget / 4 or rows <= 512:
                 break
             rows //= 4
-        reps = max(1, min(3, int(budget_s / max(probe, 1e-3)) - 1))
+        reps = max(1, min(3, int(budget / max(probe, 1e-3)) - 1))
         t0 = time.perf_counter()
         for _ in range(reps):
-            eager.flow_log_prob(flow_cpu, x)
-        dt = (time.perf_counter() - t0) / reps
-    return {"value": rows / dt, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": "same 32-layer flow and weights, %d rows x %d timed passes of "
-                      "oracle/eager.py (bit-identical to the reference CPU path), %.2f s/pass"
-                      % (rows, reps, dt)}
+            run(x)
+        return rows, reps, (time.perf_counter() - t0) / reps
+
+    with torch.no_grad():
+        rows, reps, dt = timed(sample_rows, threads, budget_s * 0.6)
+        rows1, reps1, dt1 = timed(max(512, sample_rows // 8), 1, budget_s * 0.25)
+        consistency = None
+        if x_consistency is not None:
+            torch.set_num_threads(threads)
+            xs = x_consistency
+            z, _ = eager.flow_transform(flow_cpu, xs)
+            xr, _ = eager.flow_transform(flow_cpu, z, inverse=True)
+            err = (xr - xs).abs()
+            consistency = {"max": err.max().item(), "mean": err.mean().item(),
+                           "q999": torch.quantile(err.flatten()[:2 ** 24].double(), 0.999).item(), "rows": xs.shape[0]}
+    out = {"value": rows / dt, "unit": "samples/s", "cores": threads, "kind": kind,
+           "sample": "same 32-layer flow and weights, %d rows x %d timed passes of %s, %.2f s/pass"
+                     % (rows, reps, "the reference classes imported from /root/reference" if ref is not None
+                        else "oracle/eager.py (bit-identical port of the reference CPU path)", dt),
+           "one_thread": {"value": rows1 / dt1, "unit": "samples/s", "rows": rows1, "passes": reps1}}
+    if consistency is not None:
+        out["reference_fwd_inv_err_same_rows"] = consistency
+    return out
 
 
 def main():
@@ -124,7 +188,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-per-gpu", type=int, default=65536)
+    ap.add_argument("--batch-per-gpu", type=int, default=None,
+                    help="rows per GPU (default: 65536 at one GPU, 262144 / N at N GPUs)")
+    ap.add_argument("--steady-seconds", type=float, default=1.0,
+                    help="length of the additional steady-state measurement (extra field; 0 = skip)")
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=16384)
@@ -187,7 +254,14 @@ def main():
     if args.no_fuse_linear:
         args.path = "k1"
     select_path(args.path)
-    B = args.batch_per_gpu
+    CONFIG4_GLOBAL = 262144
+    if args.batch_per_gpu is not None:
+        B = args.batch_per_gpu
+    elif world == 1:
+        B = 65536
+    else:
+        lo, hi = parallel.row_block(CONFIG4_GLOBAL, rank, world)
+        B = hi - lo
     x = torch.randn(B, D, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
 
     log("flow on device; warm-up")
@@ -228,6 +302,53 @@ def main():
     elapsed = t.item()
     mean_ll = (acc[0] / acc[1]).item()
 
+    # steady state: the same step repeated for >= --steady-seconds (the timed region above is
+    # K steps of a few milliseconds; this one shows what a long-running job sustains)
+    steady = None
+    if args.steady_seconds > 0:
+        n_batch = max(10, args.steps)
+        done, t0 = 0, time.perf_counter()
+        if world > 1:
+            dist.barrier()
+        while True:
+            for _ in range(n_batch):
+                step()
+            torch.cuda.synchronize()
+            done += n_batch
+            stop = torch.tensor([1.0 if time.perf_counter() - t0 >= args.steady_seconds else 0.0], device=dev)
+            if world > 1:
+                dist.all_reduce(stop, op=dist.ReduceOp.MAX)
+            if stop.item() > 0:
+                break
+        if world > 1:
+            dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        steady = {"steps": done, "seconds": dt.item(), "ms_per_step": dt.item() / done * 1e3}
+    # weak-scaling extra (N > 1): 65 536 rows on every GPU
+    weak = None
+    if world > 1 and args.batch_per_gpu is None:
+        xw = torch.randn(65536, D, generator=torch.Generator().manual_seed(4321 + rank)).to(dev)
+
+        def step_w():
+            with torch.no_grad():
+                return parallel.reduce_log_likelihood(flow.log_prob(xw))
+        for _ in range(3):
+            step_w()
+        dist.barrier()
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        for _ in range(args.steps):
+            step_w()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dtw = torch.tensor([time.perf_counter() - tw], dtype=torch.float64, device=dev)
+        dist.all_reduce(dtw, op=dist.ReduceOp.MAX)
+        weak = {"rows_per_gpu": 65536, "ms_per_step": dtw.item() / args.steps * 1e3,
+                "value": 65536 * world * args.steps / dtw.item(), "unit": "samples/s"}
+        del xw
+
     # the same step replayed from a HIP graph (host out of the loop): reported beside the headline
     # number, which keeps per-dispatch events and therefore launches from the host
     graph_ms = None
@@ -249,20 +370,23 @@ def main():
             log("HIP-graph timing skipped: %r" % (e,))
 
     # forward∘inverse consistency (second half of the metric), outside the timed region
-    err_composite = err_layer = None
+    err_composite = err_layer = err_stats = None
     xs = x[:8192]
     with torch.no_grad():
         if not args.skip_consistency:
             z, lad = flow._transform(xs)
             xr, lad_inv = flow._transform.inverse(z)
-            err_composite = (xr - xs).abs().max().item()
+            err_t = (xr - xs).abs()
+            err_composite = err_t.max().item()
+            err_stats = {"mean": err_t.mean().item(), "q999": torch.quantile(err_t.flatten().double(), 0.999).item(),
+                         "count_above_1e-3": int((err_t > 1e-3).sum().item())}
             layer = flow._transform._transforms[1]
             y1, _ = layer(xs)
             x1, _ = layer.inverse(y1)
             err_layer = (x1 - xs).abs().max().item()
 
     if rank == 0:
-        total_rows = B * world
+        total_rows = (CONFIG4_GLOBAL if (world > 1 and args.batch_per_gpu is None) else B * world)
         H_ = 128
         P_ = 3 * K - 1
         dt_ = D // 2
@@ -287,26 +411,41 @@ def main():
             common = {"avg_launch_ms": avg_ms, "launches_timed": launches, "layers_per_launch": layers_per_launch,
                       "timing": timing_note}
             if path in ("k8", "k7b"):
-                # GEMMs on the bf16 matrix pipe with split-bf16 operands: 6 bf16 products per fp32
-                # multiply-add; flops of the unpadded layers
+                # GEMMs on the matrix pipe with split operands: K8h = two f16
+                # pieces, 3 products per fp32 multiply-add; K8 / K7b = three bf16 pieces, 6 products.
+                # Flops of the unpadded layers; f16 and bf16 MFMA have the same dense peak.
+                f16 = path == "k8" and RQ.conditioner_engine == "f16x2"
+                products = 3 if f16 else 6
                 macs = dt_ * P_ * H_ + ((D - dt_) * H_ + nb_ * 2 * H_ * H_ if path == "k8" else 0)
-                flops = 6 * 2.0 * B * macs * layers_per_launch
+                fp32_flops = 2.0 * B * macs * layers_per_launch
+                flops = products * fp32_flops
                 ach = flops / (avg_ms * 1e-3) / 1e12
                 # HBM: a run of layers reads its rows once and writes them once, and streams every
-                # layer's packed weights (bf16 triples in 12 KB stages) once
-                k8_weights = layers_per_launch * (2 + 16 * nb_ + 2 * (dt_ * 24 // 32)) * 12288
+                # layer's packed weights (8 KB stages of f16 pairs / 12 KB stages of bf16 triples) once
+                k8_weights = layers_per_launch * (2 + 16 * nb_ + 2 * (dt_ * 24 // 32)) * (8192 if f16 else 12288)
                 bytes_ = io_bytes + k8_weights if path == "k8" else (io_bytes + 4 * B * H_) * layers_per_launch
-                r = {"bound": "mfma",
-                     "kernel": ("nfa::rqs_resnet_kernel<false, 1, 2, %s, 8>" % os.environ.get("NFA_K8_PIPE", "2")) if path == "k8" else "nfa::rqs_fused_linear_bf16_kernel<false>",
+                traffic_file = ("k8h_pmc_traffic.json" if f16 else "k8_pmc_traffic.json") if path == "k8" else "k7b_pmc_traffic.json"
+                kernel = ("nfa::k8h::rqs_resnet_f16_kernel<false, 2, %d>" % (8 if (B % 256 == 0 and B // 256 >= 256) else 4) if f16
+                          else "nfa::rqs_resnet_kernel<false, 1, 2, %s, 8>" % os.environ.get("NFA_K8_PIPE", "2")) if path == "k8" \
+                    else "nfa::rqs_fused_linear_bf16_kernel<false>"
+                r = {"bound": "mfma", "kernel": kernel,
                      "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
-                     "traffic": load_traffic("k8_pmc_traffic.json" if path == "k8" else "k7b_pmc_traffic.json"),
+                     "traffic": load_traffic(traffic_file),
+                     "traffic_from": "profiles/" + traffic_file + " (rocprofv3 --pmc passes of this command, not re-measured in this run)",
                      "algorithmic_flops_per_launch": flops,
                      "algorithmic_bytes_per_launch": bytes_,
-                     "fp32_equivalent_tflops": ach / 6,
-                     "note": "achieved = 6 x (fp32 multiply-adds of the layers' GEMMs) x 2 / time: every fp32 "
-                             "operand is three bf16 pieces and six cross products run on the bf16 pipe "
-                             "(fp32-accurate); peak = dense bf16 MFMA peak.  As fp32 GEMM work this is "
-                             "%.1f TFLOP/s (fp32 matrix peak: 157.3)" % (ach / 6)}
+                     "fp32_flops_per_launch": fp32_flops,
+                     "fp32_equivalent_tflops": ach / products,
+                     "frac_of_fp32_matrix_peak": ach / products / 157.3,
+                     "frac_of_hbm_peak_by_survey_bytes": (k1_bytes * layers_per_launch / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
+                     "note": "achieved = %d x (fp32 multiply-adds of the layers' GEMMs) x 2 / time: every fp32 operand "
+                             "is %s and %d cross products per multiply-add run on the %s matrix pipe (fp32-accurate); "
+                             "peak = dense 16-bit MFMA peak.  The same launch expressed as fp32 GEMM work: %.1f TFLOP/s "
+                             "(fp32 matrix peak 157.3); expressed in SURVEY 8d's unfused HBM bytes (3460 B/sample/layer): "
+                             "%.0f GB/s-equivalent of 8000"
+                             % (products, "two f16 pieces" if f16 else "three bf16 pieces", products,
+                                "f16" if f16 else "bf16", ach / products,
+                                k1_bytes * layers_per_launch / (avg_ms * 1e-3) / 1e9)}
             elif path == "k7":
                 flops = 2.0 * B * H_ * dt_ * P_
                 ach = flops / (avg_ms * 1e-3) / 1e12
@@ -352,23 +491,28 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (world > 1 and args.batch_per_gpu is None) else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic standard-Gaussian inputs, random-init weights (seed 0)",
             "config": {"workload": "%d-layer RQ-NSF coupling flow (RandomPermutation + RQ coupling, "
                                    "ResidualNet H=128 x2 blocks), dim=64, K=8, tail_bound=3, "
-                                   "batch=%d per GPU, Flow.log_prob + scalar all-reduce" % (args.layers, B),
+                                   "batch=%d on rank 0 (%s), Flow.log_prob + scalar all-reduce"
+                                   % (args.layers, B, "BASELINE configs[3]: 262144 rows sharded over %d GPUs" % world
+                                      if (world > 1 and args.batch_per_gpu is None) else "one GPU's rows"),
                        "global_batch": total_rows, "features": D, "num_bins": K, "layers": args.layers,
                        "parallelism": "sample-sharded x%d" % world,
                        "fused_permutations": not args.no_fuse,
-                       "layer_kernel": {"k8": "K8: ResidualNet conditioner + spline layer in one kernel, the run of "
-                                              "layers in one launch",
+                       "layer_kernel": {"k8": "K8h: ResidualNet conditioner (GEMMs on two f16 pieces per operand) + spline "
+                                              "layer in one kernel, the run of layers in one launch"
+                                              if RQ.conditioner_engine == "f16x2" else
+                                              "K8: ResidualNet conditioner (three bf16 pieces) + spline layer in one kernel, "
+                                              "the run of layers in one launch",
                                         "k7b": "K7b: final Linear (split-bf16 MFMA) + spline layer",
                                         "k7": "K7: final Linear (fp32 MFMA) + spline layer",
                                         "k1": "PyTorch conditioner + K1 spline layer"}[args.path]},
             "fwd_inv_max_err": {"composite_%d_layers" % args.layers: err_composite, "single_layer": err_layer,
-                                "rows": 8192},
+                                "rows": 8192, "composite_stats": err_stats},
             "mean_log_likelihood": mean_ll,
             "roofline": roofline,
             "roofline_k1_unfused": roofline_k1,
@@ -377,8 +521,18 @@ def main():
             result["hip_graph_replay"] = {"ms_per_step": graph_ms, "value": total_rows / (graph_ms * 1e-3),
                                           "note": "same step (incl. copying the batch into the graph's input "
                                                   "buffer) replayed from one captured HIP graph; not the headline"}
+        if steady is not None:
+            result["steady_state"] = dict(steady, value=total_rows * steady["steps"] / steady["seconds"], unit="samples/s",
+                                          note=">= %.1f s of back-to-back steps, same launch path as the timed region"
+                                               % args.steady_seconds)
+        if weak is not None:
+            result["weak_scaling_extra"] = weak
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(flow_cpu, D, args.cpu_rows)
+            result["cpu_baseline"] = cpu_baseline(flow_cpu, D, args.cpu_rows,
+                                                  x_consistency=None if args.skip_consistency else xs.cpu())
+            ref_c = result["cpu_baseline"].get("reference_fwd_inv_err_same_rows")
+            if ref_c is not None:
+                result["fwd_inv_max_err"]["reference_fp32_same_rows"] = ref_c
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result))
     if world > 1:

@@ -257,21 +257,33 @@ int nfa_rqs_flow_resnet_f32(const float *inputs, const void *weights_packed,
  * profiles/r2/f16x2_probe.txt) -- half the matrix-pipe work and two thirds of the weight bytes
  * of the three-piece bf16 scheme above.  Replaces the same reference code (coupling.py:73-130,
  * 549-582, nn/nets/resnet.py:92-100, transforms/base.py:45-52).
- *   weights_packed f16, [stages][512 x 8]: 8 KB stages in consumption order; every GEMM's weights
- *                  are multiplied by a power of two T before the split (max |w T| in [2^13, 2^14),
- *                  which keeps the low pieces in the normal f16 range) --
- *                  initial_layer, one stage per k-step: [4 tiles][2 pieces][64 lanes][8], element
- *                    rule as for K8; hidden Linears the same, 8 stages each; final_layer: two stages
- *                    per 32-row tile, [4 k-steps][2 pieces][64 lanes][8] (every stage is four
- *                    (hi, lo) fragment pairs), rows ordered / padded / pre-divided by
- *                    sqrt(hidden_features) as for K8.
- *   bias_packed    float, per GEMM a 4-float header {out_scale, skip_scale, 0, 0} then the biases in
- *                  accumulator order times the scale of their accumulators: with hidden activations
- *                  kept at scale S, initial_layer: biases x T, out_scale = S / T; a block's first
- *                  Linear: biases x S T, out_scale = 1 / T; its second: the same and skip_scale = T
- *                  (the skip connection enters the accumulators as S T h); final_layer: biases x S T,
- *                  header {kappa = 1 / (S T), 1 / kappa, 0, 0}: the spline evaluation reads logits =
- *                  accumulators x kappa.
+ *   stream_packed  8 KB stages in consumption order, layer after layer; everything a layer needs
+ *                  reaches the kernel through this one LDS-DMA stream.  Per layer:
+ *                  (1) `param_stages` PARAMETER stages = 2048 * param_stages 32-bit words:
+ *                      words [0, 64)  int32 slots of the identity features, [64, 128) of the
+ *                      transformed features (the per-layer rows of `flow_tables` above, relative
+ *                      to the first layer's input columns); then per GEMM -- initial_layer, every
+ *                      block's two Linears, final_layer -- a 4-float header {out_scale, skip_scale,
+ *                      0, 0} followed by the biases in accumulator order ([tiles][2 lane-halves][16],
+ *                      final_layer rows as in K7) times the scale their accumulators carry.  With the
+ *                      pieces of hidden activations kept at scale S and every GEMM's weights
+ *                      multiplied by a power of two T before the split (max |w T| in [2^13, 2^14),
+ *                      which keeps the low pieces in the normal f16 range): initial_layer biases x T,
+ *                      out_scale = S / T; a block's first Linear biases x S T, out_scale = 1 / T; its
+ *                      second the same and skip_scale = S T / (scale of the fp32 residual stream,
+ *                      i.e. of the GEMM that wrote it last); final_layer biases x S T, header
+ *                      {kappa = 1 / (S T), 1 / kappa, 0, 0}: the spline evaluation reads logits =
+ *                      accumulators x kappa.  Zero-padded to whole stages.
+ *                  (2) WEIGHT stages, f16 [512 x 8]: four (hi, lo) fragment pairs of
+ *                      [64 lanes][8]; lane l element j of a pair for (tile, k-step ks) = piece of
+ *                      W'[32 tile + (l & 31)][column(ks, l >> 5, j)], W' = W x T.  initial_layer
+ *                      (column = 16 ks + 8 (l >> 5) + j, columns >= d_i zero; 2 k-steps for d_i <= 32,
+ *                      4 otherwise) and hidden Linears (column rule col(ks, hf, j) of K8; 8 k-steps):
+ *                      one stage per k-step, pair g = output tile g.  final_layer: two stages per
+ *                      32-row tile, stage 2 tile + hs = pairs (tile, ks = 4 hs + 0..3); rows ordered /
+ *                      padded / pre-divided by sqrt(hidden_features) as for K8.
+ *   final_positions int32 [128]: the slot stored at every output position of the run (the last
+ *                  128 entries of `flow_tables`).
  *   redo_blocks    int32 [batch / 128], written by the kernel: 0 = the 128-row block is done, 1 = it
  *                  produced a non-finite value (an activation beyond the f16 range, or non-finite
  *                  inputs) and NOTHING of it was written (outputs, logabsdet, status): the caller
@@ -281,10 +293,9 @@ int nfa_rqs_flow_resnet_f32(const float *inputs, const void *weights_packed,
  * Supported: num_bins = 8, linear tails, hidden_features = 128, d_i <= 64, d_t % 4 == 0,
  * d_t <= 64, features % 4 == 0, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
  */
-int nfa_rqs_flow_resnet_f16x2_f32(const float *inputs, const void *weights_packed,
-                                  const float *bias_packed, const int32_t *flow_tables,
-                                  int32_t num_layers, float *outputs, float *logabsdet,
-                                  int32_t *redo_blocks, int32_t *status, int64_t batch,
+int nfa_rqs_flow_resnet_f16x2_f32(const float *inputs, const void *stream_packed, int32_t param_stages,
+                                  const int32_t *final_positions, int32_t num_layers, float *outputs,
+                                  float *logabsdet, int32_t *redo_blocks, int32_t *status, int64_t batch,
                                   int32_t features, int32_t num_transform, int32_t num_identity,
                                   int32_t hidden_features, int32_t num_blocks,
                                   const nfa_rqs_spec *spec, int32_t flags, void *stream);

@@ -124,9 +124,10 @@ def _declare(lib):
     lib.nfa_cubic_spline_backward_f32.argtypes = [vp] * 12 + [i64, sp, i32, vp]
     lib.nfa_rqs_flow_resnet_f32.restype = ctypes.c_int
     lib.nfa_rqs_flow_resnet_f32.argtypes = [vp] * 4 + [i32] + [vp] * 3 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
-    for fn in (lib.nfa_rqs_flow_resnet_redo_f32, lib.nfa_rqs_flow_resnet_f16x2_f32):
-        fn.restype = ctypes.c_int
-        fn.argtypes = [vp] * 4 + [i32] + [vp] * 4 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
+    lib.nfa_rqs_flow_resnet_redo_f32.restype = ctypes.c_int
+    lib.nfa_rqs_flow_resnet_redo_f32.argtypes = [vp] * 4 + [i32] + [vp] * 4 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
+    lib.nfa_rqs_flow_resnet_f16x2_f32.restype = ctypes.c_int
+    lib.nfa_rqs_flow_resnet_f16x2_f32.argtypes = [vp, vp, i32, vp, i32] + [vp] * 4 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
     lib.nfa_rqs_coupling_resnet_f32.restype = ctypes.c_int
     lib.nfa_rqs_coupling_resnet_f32.argtypes = [vp] * 7 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
     lib.nfa_rqs_elementwise_f32.restype = ctypes.c_int

@@ -719,12 +719,19 @@ def _f16_weight_scale(w):
 
 
 def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scale=1.0):
-    """Packs a ResidualNet for K8h (csrc/rqs_resnet_f16.hip; layout in include/nflows_amd.h): every
-    weight as TWO f16 pieces of (weight x T), T a power of two chosen per GEMM, in 8 KB stages in
-    consumption order; per GEMM a header {out_scale, skip_scale, 0, 0} followed by the biases in
-    accumulator order, pre-multiplied by the scale their accumulators carry.  Hidden activations live
-    at scale S = `act_scale` (a power of two).  8 bins only.  Returns (weights [stages, 4096] f16,
-    biases fp32)."""
+    """Packs a ResidualNet for K8h (csrc/rqs_resnet_f16.hip; layout in include/nflows_amd.h).
+
+    Weights: every GEMM's weights as TWO f16 pieces of (weight x T), T a power of two chosen per
+    GEMM, in 8 KB stages of four (hi, lo) fragment pairs -- initial and hidden Linears k-major: one
+    stage per k-step, pair g = output tile g; final Linear tile-major: two stages per 32-row tile,
+    pair g of stage hs = k-step 4 hs + g.
+    Parameters (fp32 words behind the 128 table words of a layer's parameter stage): per GEMM a
+    header {out_scale, skip_scale, 0, 0} followed by the biases in accumulator order, pre-multiplied
+    by the scale their accumulators carry.  Hidden activations' pieces live at scale S = `act_scale`
+    (a power of two); the residual stream stays in fp32 accumulators at the scale of the GEMM that
+    wrote it last, and a block's second Linear multiplies it by skip_scale = (its own scale) /
+    (that scale) when it prepares its accumulators.  8 bins only.
+    Returns (weights [stages, 4096] f16, parameter words fp32)."""
     dt, P = num_transform, params_per_feature
     K = (P + 1) // 3
     if P != 23:
@@ -745,17 +752,21 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
     init_ks = 4 if di > 32 else 2
     wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
     T = _f16_weight_scale(wi)
-    # (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j): one stage per k-step
+    # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one stage of four tile pairs per k-step
     stages.append(pieces(wi * T).view(2, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks, -1))
     blob += [header(S / T, 0.0), _bias_accumulator_order(net.initial_layer.bias.detach().float() * T)]
+    stream_scale = T          # scale of the fp32 residual stream after the initial layer (inputs at scale 1)
     for block in net.blocks:
         for which, lin in enumerate(block.linear_layers):
             w = lin.weight.detach().float().index_select(1, order_k)  # columns in (ks, hf, j) order
             T = _f16_weight_scale(w)
+            # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one stage per k-step
             stages.append(pieces(w * T).view(2, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1))
-            # accumulators = S T (W a + b) [+ S T h for the block's second layer: skip_scale = T]
-            blob += [header(1.0 / T, T if which == 1 else 0.0),
-                     _bias_accumulator_order(lin.bias.detach().float() * (S * T))]
+            if which == 0:   # accumulators = S T (W relu(h) + b)
+                blob += [header(1.0 / T, 0.0), _bias_accumulator_order(lin.bias.detach().float() * (S * T))]
+            else:            # accumulators = S T (W relu(u) + b + h), h taken from the stream at stream_scale
+                blob += [header(1.0 / T, S * T / stream_scale), _bias_accumulator_order(lin.bias.detach().float() * (S * T))]
+                stream_scale = S * T
     scale = torch.ones(P, dtype=torch.float64, device=dev)
     scale[:2 * K] = 1.0 / math.sqrt(net.hidden_features)
     wf = (net.final_layer.weight.detach().double().view(dt, P, 128) * scale[None, :, None]).float()
@@ -766,12 +777,33 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
     bf = torch.cat((bf, bf.new_zeros(dt, 24 - P)), dim=1).reshape(dt * 24).index_select(0, order_r)
     T = _f16_weight_scale(wf)
     tiles = dt * 24 // 32
-    # (p, tile, i, hs, k4, hf, j) -> (tile, hs, k4, p, hf, i, j): two stages per tile, every stage four
-    # (hi, lo) fragment pairs like the k-major stages (there: one pair per output tile)
     stages.append(pieces(wf * T).view(2, tiles, 32, 2, 4, 2, 8).permute(1, 3, 4, 0, 5, 2, 6).reshape(tiles * 2, -1))
     # the spline evaluation reads logits = accumulators x kappa, kappa = 1 / (S T)
     blob += [header(1.0 / (S * T), S * T), _bias_accumulator_order(bf * (S * T))]
     return torch.cat(stages, dim=0).contiguous(), torch.cat(blob).contiguous()
+
+
+K8H_PARAM_STAGE_WORDS = 2048
+
+
+def build_f16_stream(layer_packs, tables):
+    """The stream K8h consumes for a run of layers: per layer its parameter stage(s) -- 128 table
+    words (int32: slots of the identity / transformed features, from `flow_layer_tables`) followed
+    by the layer's parameter words, zero-padded to whole 8 KB stages -- and then its weight stages.
+    `layer_packs`: [(weights, parameter words)] from pack_resnet_conditioner_f16 in execution
+    order; `tables`: int32 [(L + 1) * 128].  Returns (stream [stages, 4096] f16, parameter stages
+    per layer, final table int32 [128])."""
+    L = len(layer_packs)
+    words = 128 + layer_packs[0][1].numel()
+    P = (words + K8H_PARAM_STAGE_WORDS - 1) // K8H_PARAM_STAGE_WORDS
+    parts = []
+    for l, (w, prm) in enumerate(layer_packs):
+        block = torch.zeros(P * K8H_PARAM_STAGE_WORDS, dtype=torch.float32, device=w.device)
+        block[:128] = tables[l * 128:(l + 1) * 128].contiguous().view(torch.float32)
+        block[128:128 + prm.numel()] = prm
+        parts.append(block.view(torch.float16).view(P, 4096))
+        parts.append(w)
+    return torch.cat(parts, dim=0).contiguous(), P, tables[L * 128:(L + 1) * 128].contiguous()
 
 
 def coupling_layer_tables(features, transform_idx, identity_idx, in_perm=None, out_scatter=None):
@@ -833,14 +865,15 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
     return out, lad
 
 
-def rqs_coupling_resnet_f16(inputs, packed_f16, packed_exact, tables, num_transform, num_identity, num_blocks,
+def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transform, num_identity, num_blocks,
                             spec, inverse=False, accumulate_into=None, num_layers=1):
     """K8h -- the run of whole-layer kernels on the f16 matrix pipe (two f16 pieces per operand),
     followed by the exact kernel (three bf16 pieces, full fp32 range) on the row blocks the first
     pass gave up on: blocks with a non-finite result, i.e. an activation beyond the f16 range or
-    non-finite inputs.  `packed_f16` / `packed_exact`: (weights, biases) from
-    pack_resnet_conditioner_f16 / pack_resnet_conditioner.  Returns None when the shape is outside
-    the fast path."""
+    non-finite inputs.  `stream_f16`: (stream, parameter stages per layer, final table) from
+    `build_f16_stream`; `packed_exact`: (weights, biases) from pack_resnet_conditioner; `tables`:
+    the run's `flow_layer_tables` (for the exact kernel).  Returns None when the shape is outside the
+    fast path."""
     N.require_device_f32("inputs", inputs, 2)
     dev = inputs.device
     B, D = inputs.shape
@@ -849,9 +882,10 @@ def rqs_coupling_resnet_f16(inputs, packed_f16, packed_exact, tables, num_transf
     lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
     redo = torch.empty(max(1, B // 128), dtype=torch.int32, device=dev)
     lib = N.load()
+    stream, param_stages, final_table = stream_f16
     with torch.cuda.device(dev):
         rc = lib.nfa_rqs_flow_resnet_f16x2_f32(
-            N.ptr(x), N.ptr(packed_f16[0]), N.ptr(packed_f16[1]), N.ptr(tables), num_layers, N.ptr(out),
+            N.ptr(x), N.ptr(stream), param_stages, N.ptr(final_table), num_layers, N.ptr(out),
             N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128,
             num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))
         if rc == N.ERR_UNSUPPORTED:

@@ -141,10 +141,7 @@ class CompositeTransform(Transform):
                 spec_layers.append((c.transform_features, c.identity_features,
                                     None if inverse else perm, perm if inverse else None))
             tables = ops.flow_layer_tables(units[0][0].features, spec_layers)
-            plan_f16 = None
-            if f16:
-                plan_f16 = (torch.cat([w for w, _ in packed_f16], dim=0).contiguous(),
-                            torch.cat([b for _, b in packed_f16]).contiguous())
+            plan_f16 = ops.build_f16_stream(packed_f16, tables) if f16 else None
             plan = (weights, biases, tables, plan_f16)
             cache[key] = plan
         return plan

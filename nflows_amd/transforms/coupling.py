@@ -355,6 +355,19 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
             self._packed_resnet_f16_cache = cached
         return cached[1]
 
+    def _f16_stream(self, tables):
+        """K8h stream of this layer alone (its parameter stage carries `tables`), cached per table set."""
+        pack = self._packed_resnet_f16()
+        key = (self._packed_resnet_f16_cache[0], tables.data_ptr(), tables._version)
+        cache = self.__dict__.setdefault("_f16_stream_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) > 8:
+                cache.clear()
+            hit = ops.build_f16_stream([pack], tables)
+            cache[key] = hit
+        return hit
+
     def _packed_resnet(self):
         net = self.transform_net
         key = (_cache.epoch(),) + tuple((p.data_ptr(), p._version) for p in net.parameters()) + (self._log2e(),)
@@ -390,7 +403,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         spec = self._spec()
         full = (B // 128) * 128
         if self._use_f16():
-            f16 = self._packed_resnet_f16()
+            f16 = self._f16_stream(tables)
 
             def run(rows, acc):
                 return ops.rqs_coupling_resnet_f16(rows, f16, (wp, bp), tables, dt, di, nb, spec, inverse, acc)

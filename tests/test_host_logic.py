@@ -340,11 +340,12 @@ def test_whole_layer_packing_is_a_lossless_rearrangement(K):
 
 @pytest.mark.parametrize("act_scale", [1.0, 16.0])
 def test_f16_whole_layer_packing_carries_the_scales(act_scale):
-    """Host side of K8h (ops.pack_resnet_conditioner_f16): emulate the kernel's data flow with the
-    packed blobs -- transposed GEMMs on two f16 weight pieces pre-scaled by a power of two per GEMM,
-    the 4-float headers {out_scale, skip_scale} in front of the pre-scaled biases, activations at
-    scale S, the final layer's logits = accumulators x kappa -- and compare with the PyTorch
-    network in float64.  Checks stage order, permutations, scales and the folded 1/sqrt(hidden)."""
+    """Host side of K8h (ops.pack_resnet_conditioner_f16 / build_f16_stream): emulate the kernel's
+    data flow with the packed stream -- the parameter stage (tables, per-GEMM headers {out_scale,
+    skip_scale}, pre-scaled biases), every GEMM tile-major on two f16 weight pieces pre-scaled by a
+    power of two, pieces of the activations at scale S, the residual stream kept in fp32 at the
+    scale of the GEMM that wrote it, the final layer's logits = accumulators x kappa -- and compare
+    with the PyTorch network in float64."""
     from nflows_amd import ops
     from nflows_amd.nn.nets import ResidualNet
     torch.manual_seed(0)
@@ -354,14 +355,22 @@ def test_f16_whole_layer_packing_carries_the_scales(act_scale):
     with torch.no_grad():
         for i_, p_ in enumerate(net.parameters()):
             p_.copy_(torch.randn_like(p_) * (0.3 if i_ % 3 else 0.004))   # GEMMs of very different magnitudes
-    wp, bp = ops.pack_resnet_conditioner_f16(net.float(), dt, P, act_scale=act_scale)
+    wp, prm = ops.pack_resnet_conditioner_f16(net.float(), dt, P, act_scale=act_scale)
     net = net.double()
     tiles = dt * 24 // 32
     H = 4  # header floats
     assert wp.shape == (2 + 16 * 2 + 2 * tiles, 512 * 8) and wp.dtype == torch.float16
-    assert bp.shape == ((H + 128) * 5 + H + tiles * 32,)
+    assert prm.shape == ((H + 128) * 5 + H + tiles * 32,)
     assert torch.isfinite(wp.float()).all() and wp.float().abs().max() < 2 ** 14
+    # the stream of a one-layer run: parameter stage + weight stages
+    tables = torch.arange(256, dtype=torch.int32)
+    stream, pstages, final = ops.build_f16_stream([(wp, prm)], tables)
+    assert pstages == 1 and stream.shape == (1 + wp.shape[0], 4096) and torch.equal(final, tables[128:])
+    words = stream[0].view(torch.float32)
+    assert torch.equal(words[:128].view(torch.int32), tables[:128]) and torch.equal(words[128:128 + prm.numel()], prm)
+    assert torch.equal(stream[1:], wp)
     w = wp.double().view(-1, 512, 8)
+    bp = prm
     x = torch.randn(32, di, dtype=torch.float64)
     lane_r = torch.arange(64) % 32
     lane_h = torch.arange(64) // 32
@@ -387,8 +396,28 @@ def test_f16_whole_layer_packing_carries_the_scales(act_scale):
             for q in range(16):
                 acc_t[l, q] += Dm[8 * (q // 4) + 4 * (l // 32) + q % 4, l % 32]
 
-    def b_from_acc(acc, ks):
+    def pair(stage, g):       # fragment pair g of a stage: hi + lo
+        return w[stage, (2 * g) * 64:(2 * g) * 64 + 64] + w[stage, (2 * g + 1) * 64:(2 * g + 1) * 64 + 64]
+
+    def b_from_acc(acc, ks):  # pieces of k-step ks = tile ks // 2, registers 8 (ks % 2) ..
         return acc[ks // 2][:, 8 * (ks % 2):8 * (ks % 2) + 8]
+
+    def k_major(stage0, acc, src):      # a 128 -> 128 GEMM, one stage per k-step, pair g = tile g
+        st = stage0
+        for ks in range(8):
+            for t in range(4):
+                mfma(acc[t], pair(st, t), b_from_acc(src, ks))
+            st += 1
+        return st
+
+    def tile_major(stage0, acc, src):   # the final GEMM, two stages per tile
+        st = stage0
+        for t in range(acc.shape[0]):
+            for hs in range(2):
+                for g in range(4):
+                    mfma(acc[t], pair(st, g), b_from_acc(src, hs * 4 + g))
+                st += 1
+        return st
 
     stage, off = 0, 0
     bx = torch.zeros(2, 64, 8, dtype=torch.float64)
@@ -398,44 +427,34 @@ def test_f16_whole_layer_packing_carries_the_scales(act_scale):
                 i = ks * 16 + (l // 32) * 8 + j
                 bx[ks, l, j] = x[l % 32, i] if i < di else 0.0
     out_scale = bp[off].double()
-    h = bias_tiles(off + H, 4)
-    for ks in range(2):                               # initial layer: [4 tiles][2 pieces][64 lanes]
+    hacc = bias_tiles(off + H, 4)                     # the fp32 residual stream
+    for ks in range(2):                               # initial layer: k-major
         for t in range(4):
-            mfma(h[t], w[stage, (t * 2) * 64:(t * 2) * 64 + 64] + w[stage, (t * 2 + 1) * 64:(t * 2 + 1) * 64 + 64], bx[ks])
+            mfma(hacc[t], pair(stage, t), bx[ks])
         stage += 1
-    h = h * out_scale                                 # = S x hidden
+    hp = torch.relu(hacc * out_scale)                 # pieces of relu(h) at scale S
     off += H + 128
     for blk in range(2):
-        for which in range(2):
-            out_scale, skip_scale = bp[off].double(), bp[off + 1].double()
-            src = torch.relu(h) if which == 0 else u
-            acc = bias_tiles(off + H, 4)
-            if which == 1:
-                acc = acc + h * skip_scale
-            else:
-                assert skip_scale == 0
-            for ks in range(8):
-                for t in range(4):
-                    mfma(acc[t], w[stage, (t * 2) * 64:(t * 2) * 64 + 64] + w[stage, (t * 2 + 1) * 64:(t * 2 + 1) * 64 + 64],
-                         b_from_acc(src, ks))
-                stage += 1
-            off += H + 128
-            if which == 0:
-                u = torch.relu(acc * out_scale)
-            else:
-                h = acc * out_scale
+        out_scale = bp[off].double()
+        assert bp[off + 1] == 0
+        u = bias_tiles(off + H, 4)
+        stage = k_major(stage, u, hp)
+        q = torch.relu(u * out_scale)
+        off += H + 128
+        out_scale, ratio = bp[off].double(), bp[off + 1].double()
+        hacc = hacc * ratio + bias_tiles(off + H, 4)  # skip connection: the stream itself, rescaled
+        stage = k_major(stage, hacc, q)
+        hp = hacc * out_scale
+        if blk == 0:
+            hp = torch.relu(hp)
+        off += H + 128
     want_hidden = net.hidden(x)
-    got_hidden = acc_to_features(h) / act_scale
+    got_hidden = acc_to_features(hp) / act_scale
     assert (got_hidden - want_hidden).abs().max().item() < 1e-6 * want_hidden.abs().max().item()
     kappa, inv_kappa = bp[off].double(), bp[off + 1].double()
     assert kappa * inv_kappa == 1.0
     out = bias_tiles(off + H, tiles)
-    for t in range(tiles):
-        for hs in range(2):
-            for k4 in range(4):
-                a_frag = w[stage, (2 * k4) * 64:(2 * k4) * 64 + 64] + w[stage, (2 * k4 + 1) * 64:(2 * k4 + 1) * 64 + 64]
-                mfma(out[t], a_frag, b_from_acc(h, hs * 4 + k4))
-            stage += 1
+    stage = tile_major(stage, out, hp)
     assert stage == wp.shape[0] and off + H + tiles * 32 == bp.numel()
     out = out * kappa
     want = net.final_layer(want_hidden).view(32, dt, P).clone()
