@@ -1,5 +1,6 @@
 from .base import (CompositeTransform, InputOutsideDomain, InverseNotAvailable, InverseTransform,
-                   Transform)
+                   MultiscaleCompositeTransform, Transform)
+from .standard import AffineScalarTransform, AffineTransform, IdentityTransform, PointwiseAffineTransform
 from .coupling import (AdditiveCouplingTransform, AffineCouplingTransform, CouplingTransform,
                        PiecewiseCubicCouplingTransform, PiecewiseLinearCouplingTransform,
                        PiecewiseQuadraticCouplingTransform,

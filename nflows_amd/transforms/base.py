@@ -252,6 +252,88 @@ class CompositeTransform(Transform):
         return outputs, total
 
 
+class MultiscaleCompositeTransform(Transform):
+    """Real NVP's multiscale architecture (nflows/transforms/base.py:63-212): after every transform
+    but the last the result is halved along `split_dim`; the first half leaves as output (flattened),
+    the second half feeds the next transform.  Bookkeeping only -- the transforms added do the work.
+    Outputs are always [batch, total]."""
+
+    def __init__(self, num_transforms, split_dim=1):
+        if not (isinstance(split_dim, int) and split_dim > 0):
+            raise TypeError("Split dimension must be a positive integer.")
+        super().__init__()
+        self._transforms = nn.ModuleList()
+        self._output_shapes = []
+        self._num_transforms = num_transforms
+        self._split_dim = split_dim
+
+    def add_transform(self, transform, transform_output_shape):
+        """To be called `num_transforms` times.  `transform_output_shape`: the shape of one sample
+        leaving `transform`.  Returns the shape that continues to the next transform (None after the
+        last one)."""
+        if len(self._transforms) == self._num_transforms:
+            raise RuntimeError("Adding more than {} transforms is not allowed.".format(self._num_transforms))
+        axis = self._split_dim - 1
+        if axis >= len(transform_output_shape):
+            raise ValueError("No split_dim in output shape")
+        if transform_output_shape[axis] < 2:
+            raise ValueError("Size of dimension {} must be at least 2.".format(self._split_dim))
+        self._transforms.append(transform)
+        if len(self._transforms) == self._num_transforms:   # the last transform's result is not split
+            self._output_shapes.append(tuple(transform_output_shape))
+            return None
+        size = transform_output_shape[axis]
+        leaves, continues = list(transform_output_shape), list(transform_output_shape)
+        leaves[axis] = (size + 1) // 2     # torch.chunk gives the larger half first
+        continues[axis] = size // 2
+        self._output_shapes.append(tuple(leaves))
+        return tuple(continues)
+
+    def _require_complete(self):
+        if self._num_transforms != len(self._transforms):
+            raise RuntimeError("Expecting exactly {} transform(s) to be added.".format(self._num_transforms))
+
+    def forward(self, inputs, context=None):
+        if self._split_dim >= inputs.dim():
+            raise ValueError("No split_dim in inputs.")
+        self._require_complete()
+        batch = inputs.shape[0]
+        total = inputs.new_zeros(batch)
+        pieces = []
+        hiddens = inputs
+        last = len(self._transforms) - 1
+        for i, transform in enumerate(self._transforms):
+            result, logabsdet = transform(hiddens, context)
+            total = total + logabsdet
+            if i < last:
+                out, hiddens = torch.chunk(result, chunks=2, dim=self._split_dim)
+                assert tuple(out.shape[1:]) == self._output_shapes[i]
+            else:
+                out = result
+            pieces.append(out.reshape(batch, -1))
+        return torch.cat(pieces, dim=-1), total
+
+    def inverse(self, inputs, context=None):
+        if inputs.dim() != 2:
+            raise ValueError("Expecting NxD inputs")
+        self._require_complete()
+        batch = inputs.shape[0]
+        chunks, start = [], 0
+        for shape in self._output_shapes:
+            n = 1
+            for d in shape:
+                n *= d
+            chunks.append(inputs[:, start:start + n].reshape(batch, *shape))
+            start += n
+        total = inputs.new_zeros(batch)
+        hiddens, logabsdet = self._transforms[-1].inverse(chunks[-1], context)
+        total = total + logabsdet
+        for transform, chunk in zip(reversed(self._transforms[:-1]), reversed(chunks[:-1])):
+            hiddens, logabsdet = transform.inverse(torch.cat((chunk, hiddens), dim=self._split_dim), context)
+            total = total + logabsdet
+        return hiddens, total
+
+
 class InverseTransform(Transform):
     """Swaps forward and inverse of a transform (base.py:215-231)."""
 

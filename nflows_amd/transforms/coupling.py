@@ -212,8 +212,41 @@ class AffineCouplingTransform(CouplingTransform):
         self.scale_activation = scale_activation
         super().__init__(mask, transform_net_create_fn, unconditional_transform)
 
+    supports_image_inputs = True
+
     def _transform_dim_multiplier(self):
         return 2
+
+    def _generic(self, inputs, context, inverse, logabsdet_accumulator):
+        """Image inputs [B, C, H, W] (coupling.py:212-252 applies the same expressions to any rank;
+        the conditioner's channels are [shift block | scale block]): every pixel is a row of C
+        features for the layer kernel, the log-determinant is summed over the pixels afterwards."""
+        if inputs.dim() != 4:
+            return super()._generic(inputs, context, inverse, logabsdet_accumulator)
+        b, c, h, w = inputs.shape
+        identity_split = inputs.index_select(1, self.identity_features)
+        logabsdet = None
+        rows = inputs
+        if self.unconditional_transform is not None:
+            if inverse:
+                identity_split, logabsdet = self.unconditional_transform.inverse(identity_split, context)
+            rows = inputs.clone()
+        transform_params = self.transform_net(identity_split, context)
+        if not inverse and self.unconditional_transform is not None:
+            moved, logabsdet = self.unconditional_transform(identity_split, context)
+            rows.index_copy_(1, self.identity_features, moved)
+        elif self.unconditional_transform is not None:
+            rows.index_copy_(1, self.identity_features, identity_split)
+        pixel_rows = rows.permute(0, 2, 3, 1).reshape(b * h * w, c)
+        pixel_params = transform_params.permute(0, 2, 3, 1).reshape(b * h * w, -1)
+        out_rows, lad_rows = self._fused_layer(pixel_rows, pixel_params, inverse)
+        outputs = out_rows.reshape(b, h, w, c).permute(0, 3, 1, 2).contiguous()
+        lad = lad_rows.reshape(b, h * w).sum(dim=1)
+        logabsdet = lad if logabsdet is None else logabsdet + lad
+        if logabsdet_accumulator is not None:
+            logabsdet_accumulator += logabsdet
+            logabsdet = logabsdet_accumulator
+        return outputs, logabsdet
 
     def _activation_code(self):
         if self.scale_activation is AffineCouplingTransform.DEFAULT_SCALE_ACTIVATION:
