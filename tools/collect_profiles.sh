@@ -2,8 +2,8 @@
 # Regenerates everything under profiles/ that bench.py's JSON line refers to (run on the GPU box
 # from the repo root; results land in gpurun_out/profiles_<tag>/ and are copied into profiles/
 # by hand afterwards):
-#   1. PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs, --kernel-trace only) for K8 (default
-#      path) and K1 (--path k1)                      -> k8_pmc_traffic.json, k1_pmc_traffic.json
+#   1. PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs, --kernel-trace only) for K8h (default
+#      path) and K1 (--path k1)                      -> k8h_pmc_traffic.json, k1_pmc_traffic.json
 #   2. rocprofv3 --kernel-trace --stats of the bench command -> <tag>_kernel_stats_bench.csv
 #   3. the bench line itself (reads the fresh traffic files) -> <tag>_bench_1gpu.json
 #   tools/collect_profiles.sh <tag>
@@ -20,11 +20,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_k8/$c -o p -- $BENCH --skip-k1-roofline > $OUT/pmc_k8_$c.log 2>&1
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_k1/$c -o p -- $BENCH --path k1 > $OUT/pmc_k1_$c.log 2>&1
 done
-python $ROOTDIR/tools/pmc_traffic.py $OUT/pmc_k8 $ROOTDIR/profiles/k8_pmc_traffic.json rqs_resnet_kernel 66060288 \
+python $ROOTDIR/tools/pmc_traffic.py $OUT/pmc_k8 $ROOTDIR/profiles/k8h_pmc_traffic.json rqs_resnet_f16_kernel 55312384 \
   "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --skip-consistency --skip-k1-roofline"
 python $ROOTDIR/tools/pmc_traffic.py $OUT/pmc_k1 $ROOTDIR/profiles/k1_pmc_traffic.json rqs_coupling_pipelined 226754560 \
   "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --skip-consistency --path k1"
-cp $ROOTDIR/profiles/k8_pmc_traffic.json $ROOTDIR/profiles/k1_pmc_traffic.json $OUT/
+cp $ROOTDIR/profiles/k8h_pmc_traffic.json $ROOTDIR/profiles/k1_pmc_traffic.json $OUT/
 # the raw counter CSVs are large; keep only the summaries
 rm -rf $OUT/pmc_k8 $OUT/pmc_k1
 

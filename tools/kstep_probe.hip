@@ -15,8 +15,10 @@ constexpr int kStage = 8192, kRing = 6;
 
 // MODE bits: 1 = A operands from LDS (counted waits), 2 = barrier per k-step, 4 = LDS-DMA request per k-step,
 //            8 = some VALU work per k-step (24 v_fma after the MFMAs), 16 = independent accumulators per product
+//            32 = 64 v_fma per k-step instead of 24; 64 = staggered: the first wave of a SIMD does its VALU work
+//            BEFORE its MFMAs, the second one AFTER them (so that one wave's VALU runs beside the other's MFMAs)
 template <int MODE, int NW>
-__global__ void __launch_bounds__(NW * 64, 2) probe(const vec4f* w, int ksteps, float* out, unsigned long long* span) {
+__global__ void __launch_bounds__(NW * 64, 2) probe(const vec4f* w, int ksteps, float* out, unsigned long long* span, unsigned* hwid) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     vec4f* ring = reinterpret_cast<vec4f*>(lds);
@@ -30,6 +32,9 @@ __global__ void __launch_bounds__(NW * 64, 2) probe(const vec4f* w, int ksteps, 
     for (int j = 0; j < 8; ++j) v[j] = lane + j;
     const unsigned base = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)lds + lane * 16;
     int slot = 0, fetch = 0;
+    // which of the two waves of its SIMD this wave is: MODE & 128 -> by wave parity, else by wave < NW / 2
+    const bool first_of_simd = (MODE & 128) ? (wave & 1) == 0 : wave < NW / 2;
+    if (lane == 0 && blockIdx.x == 0) hwid[wave] = __builtin_amdgcn_s_getreg((15 << 11) | 4);   // HW_ID bits [15:0]
     vec4f fh = ring[lane], fl = ring[64 + lane];
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int ks = 0; ks < ksteps; ++ks) {
@@ -43,6 +48,11 @@ __global__ void __launch_bounds__(NW * 64, 2) probe(const vec4f* w, int ksteps, 
             fetch = fetch + 1 == 64 ? 0 : fetch + 1;
         }
         const unsigned cur = base + slot * kStage, nxt = base + (slot + 1 == kRing ? 0 : slot + 1) * kStage;
+        constexpr int NV = (MODE & 32) ? 64 : 24;
+        if ((MODE & 8) && (MODE & 64) && first_of_simd) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[q & 7]) : "v"(v[(q + 1) & 7]));
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             vec4f nh = fh, nl = fl;
@@ -68,9 +78,9 @@ __global__ void __launch_bounds__(NW * 64, 2) probe(const vec4f* w, int ksteps, 
             fh = nh;
             fl = nl;
         }
-        if (MODE & 8) {
+        if ((MODE & 8) && !((MODE & 64) && first_of_simd)) {
 #pragma unroll
-            for (int q = 0; q < 24; ++q) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[q & 7]) : "v"(v[(q + 1) & 7]));
+            for (int q = 0; q < NV; ++q) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[q & 7]) : "v"(v[(q + 1) & 7]));
         }
         if (MODE & 2) {
             if (MODE & 4) {
@@ -94,14 +104,14 @@ __global__ void __launch_bounds__(NW * 64, 2) probe(const vec4f* w, int ksteps, 
 template <int MODE, int NW>
 static void run(const char* name, const vec4f* w) {
     const int grid = 256, ksteps = 2000;
-    float* out; unsigned long long* sp;
-    hipMalloc(&out, 64); hipMalloc(&sp, grid * 8 * 8);
+    float* out; unsigned long long* sp; unsigned* hw;
+    hipMalloc(&out, 64); hipMalloc(&sp, grid * 8 * 8); hipMalloc(&hw, 64);
     auto k = probe<MODE, NW>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<<<grid, NW * 64, 100 * 1024>>>(w, ksteps, out, sp);
+    k<<<grid, NW * 64, 100 * 1024>>>(w, ksteps, out, sp, hw);
     hipEventRecord(e0);
-    k<<<grid, NW * 64, 100 * 1024>>>(w, ksteps, out, sp);
+    k<<<grid, NW * 64, 100 * 1024>>>(w, ksteps, out, sp, hw);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> s(NW);
@@ -109,7 +119,14 @@ static void run(const char* name, const vec4f* w) {
     unsigned long long mx = 0; for (auto x : s) mx = x > mx ? x : mx;
     printf("%-62s %d waves/SIMD: %7.1f cycles per k-step (12 MFMAs; 384 = pipe time per wave)  [%.3f us per k-step]\n", name, NW / 4,
            (double)mx / ksteps, ms * 1e3 / ksteps);
-    hipFree(out); hipFree(sp);
+    if (MODE & 64) {
+        unsigned h[8];
+        hipMemcpy(h, hw, NW * 4, hipMemcpyDeviceToHost);
+        printf("    SIMD of waves 0..%d (HW_ID[5:4]):", NW - 1);
+        for (int i = 0; i < NW; ++i) printf(" %u", (h[i] >> 4) & 3);
+        printf("\n");
+    }
+    hipFree(out); hipFree(sp); hipFree(hw);
 }
 
 int main() {
@@ -126,5 +143,11 @@ int main() {
     run<7, 8>("+ LDS-DMA request per k-step", w);
     run<15, 8>("+ 24 VALU per k-step", w);
     run<31, 8>("same, products on two accumulators", w);
+    run<15 + 64, 8>("24 VALU per k-step, staggered (wave 0-3 before, 4-7 after)", w);
+    run<15 + 32, 8>("64 VALU per k-step, all after the MFMAs", w);
+    run<15 + 32 + 64, 8>("64 VALU per k-step, staggered", w);
+    run<15 + 32, 4>("64 VALU per k-step, all after the MFMAs", w);
+    run<15 + 64 + 128, 8>("24 VALU per k-step, staggered by wave parity", w);
+    run<15 + 32 + 64 + 128, 8>("64 VALU per k-step, staggered by wave parity", w);
     return 0;
 }
