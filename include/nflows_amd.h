@@ -61,6 +61,15 @@ extern "C" {
                                              rows of the packed final layer carry an extra factor
                                              log2(e), the kernel takes 2^x of their differences */
 
+#define NFA_FLAG_STANDARD_NORMAL_LOG_PROB 16 /* nfa_rqs_flow_resnet_*: the run of layers ends a flow whose base
+                                             density is the standard normal (flows/base.py:42-49 +
+                                             distributions/normal.py:27-33): the `logabsdet` output
+                                             receives log_prob = (-0.5 sum_j z_j^2 - 0.5 D log 2 pi) +
+                                             logabsdet, computed from the row tile before it leaves
+                                             the chip.  Forward pass only */
+#define NFA_FLAG_SKIP_OUTPUTS 32          /* with NFA_FLAG_STANDARD_NORMAL_LOG_PROB: `outputs` (z) is not
+                                             written (may be null): Flow.log_prob never looks at it */
+
 /* tails */
 #define NFA_TAILS_NONE 0   /* rational_quadratic_spline: K+1 derivative logits per element */
 #define NFA_TAILS_LINEAR 1 /* unconstrained_rational_quadratic_spline(tails="linear"): K-1 */
@@ -414,6 +423,16 @@ int nfa_rowsum_f32(const float *x, float *out, int64_t rows, int64_t cols, void 
  */
 int nfa_standard_normal_log_prob_f32(const float *z, const float *logabsdet, float *out,
                                      int64_t rows, int64_t cols, void *stream);
+
+/*
+ * The two numbers a rank contributes to the data-parallel log-likelihood (the reference's training /
+ * evaluation loops call `log_prob(x).mean()` / `.sum()`, e.g. README.md:53-60): out[0] = sum_i values[i]
+ * accumulated in float64 in a fixed order (the same bits every run), out[1] = n.  One launch instead
+ * of a fill + a reduction.  `workspace`: nfa_sum_count_workspace_bytes() bytes, zero before the first
+ * call, left zero by every call, not shared between streams that may run concurrently.
+ */
+size_t nfa_sum_count_workspace_bytes(void);
+int nfa_sum_count_f64(const float *values, int64_t n, double *out, void *workspace, void *stream);
 
 /*
  * Backward of the linear, quadratic and cubic spline functionals (the reference differentiates

@@ -26,6 +26,7 @@ STATUS_NEG_DISCRIMINANT = 2
 STATUS_BAD_INDEX = 4
 
 FLAG_INVERSE, FLAG_ACCUMULATE_LOGABSDET, FLAG_WEIGHTS_BF16X3, FLAG_LOGITS_LOG2E = 1, 2, 4, 8
+FLAG_STANDARD_NORMAL_LOG_PROB, FLAG_SKIP_OUTPUTS = 16, 32
 TAILS_NONE, TAILS_LINEAR = 0, 1
 SCALE_DEFAULT, SCALE_GENERAL, SCALE_ADDITIVE, SCALE_GIVEN, SCALE_SOFTPLUS = 0, 1, 2, 3, 4
 
@@ -56,6 +57,8 @@ EXPORTS = (
     "nfa_permute_cols_b32",
     "nfa_rowsum_f32",
     "nfa_standard_normal_log_prob_f32",
+    "nfa_sum_count_f64",
+    "nfa_sum_count_workspace_bytes",
     "nfa_linear_wgrad_workspace_bytes",
     "nfa_linear_wgrad_f32",
     "nfa_profile_enable",
@@ -144,6 +147,10 @@ def _declare(lib):
     lib.nfa_rowsum_f32.argtypes = [vp, vp, i64, i64, vp]
     lib.nfa_standard_normal_log_prob_f32.restype = ctypes.c_int
     lib.nfa_standard_normal_log_prob_f32.argtypes = [vp, vp, vp, i64, i64, vp]
+    lib.nfa_sum_count_f64.restype = ctypes.c_int
+    lib.nfa_sum_count_f64.argtypes = [vp, i64, vp, vp, vp]
+    lib.nfa_sum_count_workspace_bytes.restype = ctypes.c_size_t
+    lib.nfa_sum_count_workspace_bytes.argtypes = []
     lib.nfa_linear_wgrad_workspace_bytes.restype = ctypes.c_size_t
     lib.nfa_linear_wgrad_workspace_bytes.argtypes = [i64, i32, i32]
     lib.nfa_linear_wgrad_f32.restype = ctypes.c_int

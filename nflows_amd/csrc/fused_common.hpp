@@ -133,4 +133,34 @@ __device__ __forceinline__ void assemble_rows(const LayerTables& t, const float*
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- standard-normal epilogue of the whole-layer kernels (NFA_FLAG_STANDARD_NORMAL_LOG_PROB) ----
+// Sum of squares of the D values of row r of a wave's [D][pad] row tile: the lane pair (r, r + 32)
+// shares the row, lane-half `half` takes slots [half D/2, (half + 1) D/2) (D % 4 == 0), the halves
+// are added across the pair.  Every slot holds one output value whatever column it ends up in, so
+// this is sum_j z_j^2 (in slot order, fp32; normal.py:31 sums in column order: same rounding class).
+__device__ __forceinline__ float tile_row_sumsq(const float* s_row, int D, int half, int r, int pad = 33) {
+    const int n = D >> 1;
+    const float* p = s_row + half * n * pad + r;
+    float a0 = 0.0f, a1 = 0.0f;
+    for (int j = 0; j < n; j += 2) {
+        const float v0 = p[j * pad], v1 = p[(j + 1) * pad];
+        a0 = __builtin_fmaf(v0, v0, a0);
+        a1 = __builtin_fmaf(v1, v1, a1);
+    }
+    float s = a0 + a1;
+    s += __shfl_xor(s, 32, kWave);
+    return s;
+}
+
+static inline float standard_normal_log_z(int features) {
+    return (float)(0.5 * (double)features * 1.8378770664093453);   // log(2 pi)
+}
+
+// NFA_FLAG_STANDARD_NORMAL_LOG_PROB belongs to the forward pass; NFA_FLAG_SKIP_OUTPUTS needs it
+static inline bool density_flags_valid(int32_t flags) {
+    if ((flags & NFA_FLAG_SKIP_OUTPUTS) && !(flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB)) return false;
+    if ((flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB) && (flags & NFA_FLAG_INVERSE)) return false;
+    return true;
+}
+
 }  // namespace nfa

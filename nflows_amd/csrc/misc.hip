@@ -425,6 +425,68 @@ extern "C" int nfa_permute_cols_b32(const void* inputs, const int64_t* perm, voi
     return NFA_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Sum of a vector in float64 + its length: the two numbers a rank contributes to the data-parallel
+// log-likelihood.  Up to 64 workgroups write one partial sum each; the workgroup that draws the
+// last ticket adds the partials in index order (the result does not depend on which one that is)
+// and hands the ticket counter back at zero.
+constexpr int kSumBlocks = 64;
+
+__global__ void __launch_bounds__(kBlock) sum_count_kernel(const float* __restrict__ v, int64_t n,
+                                                           double* __restrict__ out,
+                                                           double* __restrict__ partial, unsigned* ticket) {
+    __shared__ double part[kBlock];
+    __shared__ unsigned drawn;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const float v0 = v[i], v1 = v[i + stride], v2 = v[i + 2 * stride], v3 = v[i + 3 * stride];
+        a0 += (double)v0;
+        a1 += (double)v1;
+        a2 += (double)v2;
+        a3 += (double)v3;
+    }
+    for (; i < n; i += stride) a0 += (double)v[i];
+    part[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    for (int step = kBlock / 2; step > 0; step >>= 1) {
+        if ((int)threadIdx.x < step) part[threadIdx.x] += part[threadIdx.x + step];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&partial[blockIdx.x], part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        drawn = atomicAdd(ticket, 1u);
+    }
+    __syncthreads();
+    if (drawn != gridDim.x - 1) return;
+    __threadfence();
+    if (threadIdx.x == 0) {
+        double total = 0.0;
+        for (unsigned b = 0; b < gridDim.x; ++b)
+            total += __hip_atomic_load(&partial[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out[0] = total;
+        out[1] = (double)n;
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+extern "C" size_t nfa_sum_count_workspace_bytes(void) { return (kSumBlocks + 1) * sizeof(double); }
+
+extern "C" int nfa_sum_count_f64(const float* values, int64_t n, double* out, void* workspace, void* stream) {
+    if (n < 0 || !out || !workspace || (n > 0 && !values)) return NFA_ERR_INVALID_ARGUMENT;
+    int64_t blocks = (n + 4 * kBlock - 1) / (4 * kBlock);
+    if (blocks > kSumBlocks) blocks = kSumBlocks;
+    if (blocks < 1) blocks = 1;
+    double* partial = reinterpret_cast<double*>(workspace);
+    unsigned* ticket = reinterpret_cast<unsigned*>(partial + kSumBlocks);
+    hipLaunchKernelGGL(sum_count_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, values, n,
+                       out, partial, ticket);
+    NFA_HIP_CHECK(hipGetLastError());
+    return NFA_OK;
+}
+
 extern "C" int nfa_rowsum_f32(const float* x, float* out, int64_t rows, int64_t cols, void* stream) {
     if (rows < 0 || cols < 0) return NFA_ERR_INVALID_ARGUMENT;
     if (rows == 0) return NFA_OK;

@@ -53,6 +53,8 @@ struct ResnetArgs {
     RqsDev sp;
     unsigned long long* trace;
     const int32_t* redo;  // optional [batch / 128]: only row blocks with a non-zero entry are processed
+    int normal, skip_out;  // NFA_FLAG_STANDARD_NORMAL_LOG_PROB / NFA_FLAG_SKIP_OUTPUTS
+    float log_z;           // 0.5 D log(2 pi)
 };
 
 // Weight stream through the LDS ring.  Stage s lives in slot s % 3; while stage s is consumed,
@@ -679,7 +681,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         }
 
         // ---- output rows: position p of a row comes from slot final[p]; 16 bytes per lane per store
-        {
+        if (!a.skip_out) {
             vec4f* ov = reinterpret_cast<vec4f*>(a.out + row0 * D);
             const int nvec = D * 8;
             for (int e = lane; e < nvec; e += kWave) {
@@ -693,9 +695,13 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
             }
         }
         lad_acc += __shfl_xor(lad_acc, 32, kWave);
+        float sumsq = 0.0f;
+        if (a.normal) sumsq = tile_row_sumsq(s_row, D, half, r);
         if (half == 0) {
             float* dst = a.lad + row0 + r;
-            *dst = a.accumulate ? *dst + lad_acc : lad_acc;
+            float v = a.accumulate ? *dst + lad_acc : lad_acc;
+            if (a.normal) v = (-0.5f * sumsq - a.log_z) + v;   // normal.py:31-33, flows/base.py:49
+            *dst = v;
         }
         NFA_STAMP()
         // stores and LDS-DMA requests complete out of order with each other: drain before the next
@@ -716,8 +722,10 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
                                 int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
                                 const nfa_rqs_spec* spec, int32_t flags, void* stream,
                                 const int32_t* redo = nullptr) {
-    if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_LOGITS_LOG2E))
+    if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_LOGITS_LOG2E |
+                  NFA_FLAG_STANDARD_NORMAL_LOG_PROB | NFA_FLAG_SKIP_OUTPUTS))
         return NFA_ERR_INVALID_ARGUMENT;
+    if (!density_flags_valid(flags)) return NFA_ERR_INVALID_ARGUMENT;
     if (batch < 0 || features < 1 || num_transform < 1 || num_identity < 1 ||
         num_transform + num_identity > features || num_blocks < 0 || num_layers < 1)
         return NFA_ERR_INVALID_ARGUMENT;
@@ -732,8 +740,12 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         (batch & 127) != 0 || num_blocks > 64 || num_layers > 4096)
         return NFA_ERR_UNSUPPORTED;
     if (batch == 0) return NFA_OK;
-    if (!inputs || !weights_packed || !bias_packed || !tables || !outputs || !logabsdet)
+    if (!inputs || !weights_packed || !bias_packed || !tables || !logabsdet ||
+        (!outputs && !(flags & NFA_FLAG_SKIP_OUTPUTS)))
         return NFA_ERR_INVALID_ARGUMENT;
+    a.normal = (flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB) ? 1 : 0;
+    a.skip_out = (flags & NFA_FLAG_SKIP_OUTPUTS) ? 1 : 0;
+    a.log_z = standard_normal_log_z(features);
     a.x = inputs;
     a.w = reinterpret_cast<const vec4f*>(weights_packed);
     a.bias = bias_packed;

@@ -83,6 +83,8 @@ struct Args {
     int D, dt, di, num_blocks, num_layers, num_stages, param_stages, accumulate;
     RqsDev sp;
     unsigned long long* trace;  // debug: [gridDim.x][64] cycle stamps of wave 0 (first row block), null = off
+    int normal, skip_out;       // NFA_FLAG_STANDARD_NORMAL_LOG_PROB / NFA_FLAG_SKIP_OUTPUTS
+    float log_z;                // 0.5 D log(2 pi)
 };
 
 #define NFA_HSTAMP() if (tr && ti < 63) tr[ti++] = __builtin_readcyclecounter();
@@ -660,13 +662,10 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
         //      the exact kernel redoes it from the inputs.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the stream: ordinary stores / loads follow
         lad_acc += __shfl_xor(lad_acc, 32, kWave);
-        const int nvec = D * 8;
-        bool bad = not_finite(lad_acc);
-        for (int e = lane; e < nvec; e += kWave) {
-            const int rr = (e * 4) / D, c0 = e * 4 - rr * D;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) bad |= not_finite(s_row[s_final[c0 + c] * kRowPad + rr]);
-        }
+        // sum_j z_j^2 of every row: the standard-normal epilogue needs it, and it is non-finite exactly
+        // when one of the row's values is (or a square overflows: such a block is redone like the others)
+        const float sumsq = tile_row_sumsq(s_row, D, half, r);
+        const bool bad = not_finite(lad_acc) || not_finite(sumsq);
         const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
         if (lane == 0) s_bad[wave] = wave_bad ? 1 : 0;
         __syncthreads();
@@ -675,19 +674,24 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
         for (int w_ = 0; w_ < NW; ++w_) any_bad |= s_bad[w_];
         const bool quad_bad = any_bad != 0;
         if (!quad_bad) {
-            vec4f* ov = reinterpret_cast<vec4f*>(a.out + row0 * D);
-            for (int e = lane; e < nvec; e += kWave) {
-                const int rr = (e * 4) / D, c0 = e * 4 - rr * D;
-                vec4f v;
-                v.x = s_row[s_final[c0 + 0] * kRowPad + rr];
-                v.y = s_row[s_final[c0 + 1] * kRowPad + rr];
-                v.z = s_row[s_final[c0 + 2] * kRowPad + rr];
-                v.w = s_row[s_final[c0 + 3] * kRowPad + rr];
-                ov[e] = v;
+            if (!a.skip_out) {
+                const int nvec = D * 8;
+                vec4f* ov = reinterpret_cast<vec4f*>(a.out + row0 * D);
+                for (int e = lane; e < nvec; e += kWave) {
+                    const int rr = (e * 4) / D, c0 = e * 4 - rr * D;
+                    vec4f v;
+                    v.x = s_row[s_final[c0 + 0] * kRowPad + rr];
+                    v.y = s_row[s_final[c0 + 1] * kRowPad + rr];
+                    v.z = s_row[s_final[c0 + 2] * kRowPad + rr];
+                    v.w = s_row[s_final[c0 + 3] * kRowPad + rr];
+                    ov[e] = v;
+                }
             }
             if (half == 0) {
                 float* dst = a.lad + row0 + r;
-                *dst = a.accumulate ? *dst + lad_acc : lad_acc;
+                float v = a.accumulate ? *dst + lad_acc : lad_acc;
+                if (a.normal) v = (-0.5f * sumsq - a.log_z) + v;   // normal.py:31-33, flows/base.py:49
+                *dst = v;
             }
             my_status |= quad_status;
         }
@@ -710,7 +714,10 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* st
                                              int32_t features, int32_t num_transform, int32_t num_identity,
                                              int32_t hidden_features, int32_t num_blocks,
                                              const nfa_rqs_spec* spec, int32_t flags, void* stream) {
-    if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET)) return NFA_ERR_INVALID_ARGUMENT;
+    if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_STANDARD_NORMAL_LOG_PROB |
+                  NFA_FLAG_SKIP_OUTPUTS))
+        return NFA_ERR_INVALID_ARGUMENT;
+    if (!density_flags_valid(flags)) return NFA_ERR_INVALID_ARGUMENT;
     if (batch < 0 || features < 1 || num_transform < 1 || num_identity < 1 ||
         num_transform + num_identity > features || num_blocks < 0 || num_layers < 1 || param_stages < 1)
         return NFA_ERR_INVALID_ARGUMENT;
@@ -725,8 +732,12 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* st
     const int param_words = k8h::kTabWords + (k8h::kHdr + 128) * (1 + 2 * num_blocks) + k8h::kHdr + num_transform * 24;
     if (param_stages * 2048 < param_words || param_stages > 4) return NFA_ERR_INVALID_ARGUMENT;
     if (batch == 0) return NFA_OK;
-    if (!inputs || !stream_packed || !final_positions || !outputs || !logabsdet || !redo_blocks)
+    if (!inputs || !stream_packed || !final_positions || !logabsdet || !redo_blocks ||
+        (!outputs && !(flags & NFA_FLAG_SKIP_OUTPUTS)))
         return NFA_ERR_INVALID_ARGUMENT;
+    a.normal = (flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB) ? 1 : 0;
+    a.skip_out = (flags & NFA_FLAG_SKIP_OUTPUTS) ? 1 : 0;
+    a.log_z = standard_normal_log_z(features);
     a.x = inputs;
     a.w = reinterpret_cast<const vec4f*>(stream_packed);
     a.final_tab = final_positions;

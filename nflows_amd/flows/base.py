@@ -37,8 +37,14 @@ class Flow(Distribution):
 
     def _log_prob(self, inputs, context):
         embedded = self._embedding_net(context)
-        noise, logabsdet = self._transform(inputs, context=embedded)
         base = self._distribution
+        fused = getattr(self._transform, "standard_normal_log_prob", None)
+        if (fused is not None and type(base) is StandardNormal and inputs.is_cuda
+                and inputs.shape[1:] == base._shape):
+            log_prob = fused(inputs, embedded)   # density folded into the last layer's kernel
+            if log_prob is not None:
+                return log_prob
+        noise, logabsdet = self._transform(inputs, context=embedded)
         if type(base) is StandardNormal and noise.is_cuda:
             if noise.shape[1:] != base._shape:
                 raise ValueError("Expected input of shape {}, got {}".format(base._shape, noise.shape[1:]))

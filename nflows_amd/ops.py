@@ -513,6 +513,28 @@ def _standard_normal_log_prob_launch(z, logabsdet):
     return out
 
 
+_sum_workspaces = {}
+
+
+def sum_count(values):
+    """float64 [2] = (sum of `values` accumulated in float64 in a fixed order, number of values), one
+    launch."""
+    N.require_device_f32("values", values)
+    v = values.detach().contiguous().view(-1)
+    dev = v.device
+    out = torch.empty(2, dtype=torch.float64, device=dev)
+    lib = N.load()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream)
+        ws = _sum_workspaces.get(key)
+        if ws is None:
+            ws = torch.zeros(lib.nfa_sum_count_workspace_bytes(), dtype=torch.uint8, device=dev)
+            _sum_workspaces[key] = ws
+        N.check(lib.nfa_sum_count_f64(N.ptr(v), v.numel(), N.ptr(out), N.ptr(ws), N.stream_handle(dev)))
+    return out
+
+
 def linear_wgrad(inputs, grad_outputs, need_bias=True):
     """K10 -- gradients of y = x W^T + b with respect to W and b for x [B, I], dL/dy [B, O]:
     (grad_weight [O, I], grad_bias [O] or None).  The reduction over the batch is split over the
@@ -840,17 +862,30 @@ def flow_layer_tables(features, layers):
     return torch.cat(rows).to(torch.int32)
 
 
+def _density_epilogue(flags, standard_normal_log_prob, inverse, like):
+    """`flags` and the outputs buffer for the whole-layer kernels: with `standard_normal_log_prob` the
+    kernel's second result is the flow's log-density and z never leaves the chip."""
+    if not standard_normal_log_prob:
+        return flags, torch.empty_like(like)
+    if inverse:
+        raise ValueError("the standard-normal epilogue belongs to the forward pass")
+    return flags | N.FLAG_STANDARD_NORMAL_LOG_PROB | N.FLAG_SKIP_OUTPUTS, None
+
+
 def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transform, num_identity, num_blocks,
-                        spec, inverse=False, accumulate_into=None, log2e=False, num_layers=1):
+                        spec, inverse=False, accumulate_into=None, log2e=False, num_layers=1,
+                        standard_normal_log_prob=False):
     """K8 -- ResidualNet conditioner + spline coupling layer in one kernel; with num_layers > 1 a
     whole run of such layers (weights / biases concatenated in execution order, tables from
-    `flow_layer_tables`).  Returns None when the shape is outside the fast path."""
+    `flow_layer_tables`).  Returns (outputs, logabsdet), or (None, log_prob) with
+    `standard_normal_log_prob` (Flow.log_prob with a StandardNormal base: flows/base.py:42-49);
+    None when the shape is outside the fast path."""
     N.require_device_f32("inputs", inputs, 2)
     dev = inputs.device
     B, D = inputs.shape
     x = inputs.detach().contiguous()
-    out = torch.empty_like(x)
     lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
+    flags, out = _density_epilogue(flags, standard_normal_log_prob, inverse, x)
     if log2e:
         flags |= N.FLAG_LOGITS_LOG2E
     with torch.cuda.device(dev):
@@ -866,20 +901,20 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
 
 
 def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transform, num_identity, num_blocks,
-                            spec, inverse=False, accumulate_into=None, num_layers=1):
+                            spec, inverse=False, accumulate_into=None, num_layers=1,
+                            standard_normal_log_prob=False):
     """K8h -- the run of whole-layer kernels on the f16 matrix pipe (two f16 pieces per operand),
     followed by the exact kernel (three bf16 pieces, full fp32 range) on the row blocks the first
     pass gave up on: blocks with a non-finite result, i.e. an activation beyond the f16 range or
     non-finite inputs.  `stream_f16`: (stream, parameter stages per layer, final table) from
     `build_f16_stream`; `packed_exact`: (weights, biases) from pack_resnet_conditioner; `tables`:
-    the run's `flow_layer_tables` (for the exact kernel).  Returns None when the shape is outside the
-    fast path."""
+    the run's `flow_layer_tables` (for the exact kernel).  Results as for `rqs_coupling_resnet`."""
     N.require_device_f32("inputs", inputs, 2)
     dev = inputs.device
     B, D = inputs.shape
     x = inputs.detach().contiguous()
-    out = torch.empty_like(x)
     lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
+    flags, out = _density_epilogue(flags, standard_normal_log_prob, inverse, x)
     redo = torch.empty(max(1, B // 128), dtype=torch.int32, device=dev)
     lib = N.load()
     stream, param_stages, final_table = stream_f16

@@ -30,10 +30,12 @@ def _world(group):
 def reduce_log_likelihood(local_log_prob, group=None):
     """[rows_local] per-sample log-densities -> (global sum, global count) as a float64 tensor of
     shape [2] on the same device; one all-reduce when a process group is initialised."""
-    # two launches: the vector preset to the count, then one reduction (float64 accumulation) that
-    # writes the sum over it
-    acc = torch.full((2,), float(local_log_prob.numel()), dtype=torch.float64, device=local_log_prob.device)
-    torch.sum(local_log_prob.reshape(-1), dim=0, keepdim=True, dtype=torch.float64, out=acc[0:1])
+    if local_log_prob.is_cuda and local_log_prob.dtype == torch.float32:
+        from . import ops
+        acc = ops.sum_count(local_log_prob)     # one launch
+    else:
+        acc = torch.full((2,), float(local_log_prob.numel()), dtype=torch.float64, device=local_log_prob.device)
+        torch.sum(local_log_prob.reshape(-1), dim=0, keepdim=True, dtype=torch.float64, out=acc[0:1])
     if _world(group) > 1:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
     return acc

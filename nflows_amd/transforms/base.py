@@ -146,7 +146,7 @@ class CompositeTransform(Transform):
             cache[key] = plan
         return plan
 
-    def _run_fused(self, units, inputs, total, context, inverse):
+    def _run_fused(self, units, inputs, total, context, inverse, standard_normal_log_prob=False):
         from .. import ops
         first = units[0][0]
         for _, p in units:
@@ -155,16 +155,20 @@ class CompositeTransform(Transform):
         batch = inputs.shape[0]
         full = (batch // 128) * 128
         weights, biases, tables, plan_f16 = self._run_plan(units, inverse)
+        acc = None if total is None else total[:full]
         if plan_f16 is not None:
             head = ops.rqs_coupling_resnet_f16(
                 inputs[:full], plan_f16, (weights, biases), tables, first.num_transform_features,
                 first.num_identity_features, len(first.transform_net.blocks), first._spec(), inverse,
-                total[:full], num_layers=len(units))
+                acc, num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob)
         else:
             head = ops.rqs_coupling_resnet(
                 inputs[:full], weights, biases, tables, first.num_transform_features, first.num_identity_features,
-                len(first.transform_net.blocks), first._spec(), inverse, total[:full],
-                log2e=first._log2e() if hasattr(first, "_log2e") else False, num_layers=len(units))
+                len(first.transform_net.blocks), first._spec(), inverse, acc,
+                log2e=first._log2e() if hasattr(first, "_log2e") else False, num_layers=len(units),
+                standard_normal_log_prob=standard_normal_log_prob)
+        if standard_normal_log_prob:
+            return None if head is None else head[1]
         if head is None:
             return None
         if full == batch:
@@ -179,6 +183,20 @@ class CompositeTransform(Transform):
                 tail, _ = coupling.forward(tail, context, in_perm=None if perm is None else perm._permutation,
                                            logabsdet_accumulator=tail_total)
         return torch.cat((head[0], tail), dim=0)
+
+    def standard_normal_log_prob(self, inputs, context=None):
+        """Flow.log_prob (flows/base.py:42-49) for a StandardNormal base when the whole composite is ONE
+        run of whole-layer kernels and the batch is made of full 128-row blocks: the last layer's
+        kernel adds -0.5 sum z^2 - 0.5 D log(2 pi) to the log-determinant while the rows are still
+        on the chip, and z is never written.  Returns log_prob [batch], or None when the composite
+        does not have that shape (the caller then takes the general route)."""
+        if not self.fuse_permutations or inputs.dim() != 2 or inputs.shape[0] % 128 != 0:
+            return None
+        layers = list(self._transforms)
+        units, after = self._collect_run(layers, 0, inputs, context, inverse=False)
+        if not units or after != len(layers):
+            return None
+        return self._run_fused(units, inputs, None, context, inverse=False, standard_normal_log_prob=True)
 
     @staticmethod
     def _cascade(inputs, funcs, context):

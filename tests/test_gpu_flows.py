@@ -698,3 +698,51 @@ def test_f16_engine_hands_out_of_range_blocks_to_the_exact_kernel(monkeypatch):
             assert np.abs(got[rows] - want[rows]).max() <= 2e-4 * (1 + np.abs(want[rows]).max())
     # the two engines are different computations: somewhere outside the redone blocks they differ
     assert not np.array_equal(results["f16x2"][0][:128], results["bf16x3"][0][:128])
+
+
+@pytest.mark.parametrize("engine,bins", [("f16x2", 8), ("bf16x3", 8), ("bf16x3", 10)])
+def test_standard_normal_density_folded_into_the_last_layer(monkeypatch, engine, bins):
+    """Flow.log_prob of a flow that is one run of whole-layer kernels over a StandardNormal base: the
+    last layer's kernel adds the base density (normal.py:31-33) to the log-determinant and skips the
+    z store (NFA_FLAG_STANDARD_NORMAL_LOG_PROB | NFA_FLAG_SKIP_OUTPUTS).  Equal to the two-step route
+    -- transform, then base density + logabsdet (flows/base.py:42-49) -- to the rounding of one
+    64-term fp32 sum taken in a different order; rows the f16 engine hands to the exact kernel
+    (overflow, NaN, inf) included, with the reference's NaN pattern."""
+    from nflows_amd import configs, ops
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    monkeypatch.setattr(RQ, "conditioner_engine", engine)
+    flow = configs.rq_nsf_flow(num_layers=4, features=64, num_bins=bins, hidden_features=128, seed=3).to(DEV).eval()
+    x = torch.randn(1024, 64, generator=torch.Generator().manual_seed(5)).to(DEV)
+    x[130, 5] = 1.0e6
+    x[300, 7] = float("nan")
+    x[301, 9] = float("inf")
+    with torch.no_grad():
+        assert flow._transform.standard_normal_log_prob(x) is not None       # the folded route is taken
+        lp = flow.log_prob(x)
+        z, lad = flow._transform(x)
+        two_step = ops.standard_normal_log_prob(z, lad)
+        assert flow._transform.standard_normal_log_prob(x[:1000]) is None    # ragged batch: general route
+        lp_ragged = flow.log_prob(x[:1000])
+    lp, two_step, lp_ragged = lp.cpu().numpy(), two_step.cpu().numpy(), lp_ragged.cpu().numpy()
+    assert np.array_equal(np.isnan(lp), np.isnan(two_step))
+    assert np.isnan(lp[300]) and np.isnan(lp[301]) and np.isfinite(lp[130])
+    fin = np.isfinite(two_step)
+    assert np.abs(lp[fin] - two_step[fin]).max() <= 2e-5 * (1 + np.abs(two_step[fin]).max())
+    fin = np.isfinite(lp_ragged[:896])
+    assert np.abs(lp_ragged[:896][fin] - lp[:896][fin]).max() <= 2e-5 * (1 + np.abs(lp[:896][fin]).max())
+    # a base that is not the standard normal, or a composite that is not one run, never takes the fold
+    from nflows_amd.transforms import CompositeTransform, ReversePermutation
+    mixed = CompositeTransform(list(flow._transform._transforms) + [ReversePermutation(64).to(DEV)])
+    with torch.no_grad():
+        assert mixed.standard_normal_log_prob(x) is None
+
+
+def test_sum_count_is_the_float64_sum():
+    from nflows_amd import ops, parallel
+    for n in (1, 1000, 65536, 100001):
+        v = (torch.randn(n, generator=torch.Generator().manual_seed(n)) * 50 - 150).to(DEV)
+        got = ops.sum_count(v).cpu()
+        want = v.double().sum().cpu()
+        assert got[1].item() == n
+        assert abs(got[0].item() - want.item()) <= 1e-12 * max(1.0, abs(want.item()))
+        assert torch.equal(parallel.reduce_log_likelihood(v).cpu(), got)
