@@ -319,6 +319,37 @@ int nfa_rqs_flow_resnet_redo_f32(const float *inputs, const void *weights_packed
                                  const nfa_rqs_spec *spec, int32_t flags, void *stream);
 
 /*
+ * K11.  A run of affine / additive coupling layers with MLP conditioners in ONE launch: per layer
+ *   transform_net = MLP(hidden_sizes = [128] * (1 + num_hidden_layers)) (nn/nets/mlp.py:47-68) +
+ *   CouplingTransform.forward / .inverse (coupling.py:73-130) + AffineCouplingTransform /
+ *   AdditiveCouplingTransform._coupling_transform_* (coupling.py:212-269) + the neighbouring column
+ *   permutations (permutations.py:27-39), and CompositeTransform._cascade's loop over the layers
+ *   (transforms/base.py:45-52).  The GEMMs run on three bf16 pieces per operand (fp32-accurate, full
+ *   fp32 range: no second pass); per element the arithmetic is K2's.
+ *   weights_packed  bf16 stages of 12 KB (768 x 16 B), per layer in the order consumed:
+ *                   _input_layer ([ks][4 tiles][3 pieces][64 lanes][8]; column = 16 ks + 8 (l >> 5) + j,
+ *                   columns >= d_i zero; 2 k-steps for d_i <= 32, else 4), every _hidden_layers[i]
+ *                   (8 k-steps, columns in K8's accumulator order), _output_layer tile-major
+ *                   ([tile][2 half-stages][3 pieces][4 k-steps][64 lanes][8]) with rows ordered so that
+ *                   accumulator register q of lane-half h of tile t is: affine -- q < 8: shift of
+ *                   feature 16 t + 8 h + q, q >= 8: unconstrained scale of feature 16 t + 8 h + q - 8;
+ *                   additive -- shift of feature 32 t + 16 h + q; rows of features >= d_t zero.
+ *   bias_packed     fp32, all GEMMs' biases in accumulator order ([tile][2 lane-halves][16]), layer
+ *                   after layer: 128 + 128 num_hidden_layers + 32 final_tiles floats per layer.
+ *   tables          as for nfa_rqs_flow_resnet_f32 (int32 [(num_layers + 1) * 128]).
+ *   scale_activation NFA_SCALE_DEFAULT | NFA_SCALE_GENERAL | NFA_SCALE_ADDITIVE.
+ *   flags           NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_STANDARD_NORMAL_LOG_PROB
+ *                   | NFA_FLAG_SKIP_OUTPUTS.
+ * Supported: hidden_features = 128, d_i <= 64, d_t <= 64, features % 4 == 0, features <= 128,
+ * batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED (callers then run the conditioner's GEMMs and K2).
+ */
+int nfa_affine_flow_mlp_f32(const float *inputs, const void *weights_packed, const float *bias_packed,
+                            const int32_t *tables, int32_t num_layers, float *outputs, float *logabsdet,
+                            int32_t *status, int64_t batch, int32_t features, int32_t num_transform,
+                            int32_t num_identity, int32_t hidden_features, int32_t num_hidden_layers,
+                            int32_t scale_activation, int32_t flags, void *stream);
+
+/*
  * K5.  Elementwise rational-quadratic functional (no row-sum):
  *   unconstrained_rational_quadratic_spline / rational_quadratic_spline,
  *   splines/rational_quadratic.py:13-63 / :66-181, as called from

@@ -43,6 +43,7 @@ EXPORTS = (
     "nfa_rqs_coupling_resnet_f32",
     "nfa_rqs_flow_resnet_f32",
     "nfa_rqs_flow_resnet_redo_f32",
+    "nfa_affine_flow_mlp_f32",
     "nfa_rqs_flow_resnet_f16x2_f32",
     "nfa_linear_spline_f32",
     "nfa_quadratic_spline_f32",
@@ -127,6 +128,8 @@ def _declare(lib):
     lib.nfa_cubic_spline_backward_f32.argtypes = [vp] * 12 + [i64, sp, i32, vp]
     lib.nfa_rqs_flow_resnet_f32.restype = ctypes.c_int
     lib.nfa_rqs_flow_resnet_f32.argtypes = [vp] * 4 + [i32] + [vp] * 3 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
+    lib.nfa_affine_flow_mlp_f32.restype = ctypes.c_int
+    lib.nfa_affine_flow_mlp_f32.argtypes = [vp] * 4 + [i32] + [vp] * 3 + [i64] + [i32] * 7 + [vp]
     lib.nfa_rqs_flow_resnet_redo_f32.restype = ctypes.c_int
     lib.nfa_rqs_flow_resnet_redo_f32.argtypes = [vp] * 4 + [i32] + [vp] * 4 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
     lib.nfa_rqs_flow_resnet_f16x2_f32.restype = ctypes.c_int

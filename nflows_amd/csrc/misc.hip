@@ -28,27 +28,6 @@ int device_cu_count() {
     return cached[dev];
 }
 
-__device__ __forceinline__ float softplus1(float x) {
-#pragma clang fp contract(off)
-    return x > 20.0f ? x : log1pf(expf(x));
-}
-
-// scale activations, coupling.py:224-225 / autoregressive.py:101
-__device__ __forceinline__ float scale_of(float u, int activation) {
-#pragma clang fp contract(off)
-    if (activation == NFA_SCALE_DEFAULT) {
-        const float v = u + 2.0f;
-        return 1.0f / (1.0f + expf(-v)) + 1e-3f;
-    } else if (activation == NFA_SCALE_GENERAL) {
-        float s = softplus1(u) + 1e-3f;
-        s = s < 0.0f ? 0.0f : s;  // clamp(0, 3); NaN propagates like aten's clamp
-        s = s > 3.0f ? 3.0f : s;
-        return s;
-    } else {  // NFA_SCALE_SOFTPLUS
-        return softplus1(u) + 1e-3f;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // K2: fused affine / additive coupling.  Same tile scheme as the spline layer: R whole samples
 // per workgroup, conditioner output and inputs staged through LDS with 16-byte accesses.

@@ -722,6 +722,88 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False)
     return torch.cat(stages, dim=0).contiguous(), torch.cat(biases).contiguous()
 
 
+def _affine_row_order(num_transform, additive):
+    """For every row of the packed output layer of K11: which conditioner output it is (-1 = zero
+    padding).  Row i of tile t sits in accumulator register q = 4 (i // 8) + i % 4 of lane-half
+    (i // 4) % 2; affine: q < 8 is the shift of feature 16 t + 8 half + q, q >= 8 the unconstrained
+    scale of feature 16 t + 8 half + q - 8 (conditioner outputs [shift block | scale block],
+    coupling.py:228-231); additive: the shift of feature 32 t + 16 half + q."""
+    dt = num_transform
+    per_tile = 32 if additive else 16
+    tiles = (dt + per_tile - 1) // per_tile
+    i = torch.arange(32)
+    half = (i >> 2) & 1
+    q = ((i >> 3) << 2) | (i & 3)
+    t = torch.arange(tiles)[:, None]
+    if additive:
+        feat = 32 * t + 16 * half[None, :] + q[None, :]
+        row = feat
+    else:
+        feat = 16 * t + 8 * half[None, :] + (q & 7)[None, :]
+        row = torch.where((q >= 8)[None, :], dt + feat, feat)
+    return torch.where(feat < dt, row, torch.full_like(row, -1)).reshape(-1)
+
+
+def pack_mlp_conditioner(net, num_transform, additive=False):
+    """Packs an MLP conditioner (nn/nets/mlp.py: _input_layer, _hidden_layers[*], _output_layer; all
+    hidden widths 128) for K11 (layout in include/nflows_amd.h).  Returns (weights [stages, 768*8]
+    bf16, biases fp32)."""
+    dt = num_transform
+    dev = net._output_layer.weight.device
+    order_k = _k8_column_order().to(dev)
+
+    def pieces(w):
+        return torch.stack(split_bf16x3(w))  # [3, ...]
+
+    stages, biases = [], []
+    wi = net._input_layer.weight.detach().float()
+    di = wi.shape[1]
+    init_ks = 4 if di > 32 else 2
+    wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
+    stages.append(pieces(wi).view(3, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks, -1))
+    biases.append(_bias_accumulator_order(net._input_layer.bias.detach().float()))
+    for lin in net._hidden_layers:
+        w = lin.weight.detach().float().index_select(1, order_k)
+        stages.append(pieces(w).view(3, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1))
+        biases.append(_bias_accumulator_order(lin.bias.detach().float()))
+    order_r = _affine_row_order(dt, additive).to(dev)
+    wo = net._output_layer.weight.detach().float()
+    bo = net._output_layer.bias.detach().float()
+    wo = torch.cat((wo, wo.new_zeros(1, 128)), dim=0)     # row -1 = zero padding
+    bo = torch.cat((bo, bo.new_zeros(1)))
+    wf = wo.index_select(0, order_r % wo.shape[0]).index_select(1, order_k)
+    bf = bo.index_select(0, order_r % bo.shape[0])
+    tiles = order_r.numel() // 32
+    # (p, tile, i, hs, k4, hf, j) -> (tile, hs, p, k4, hf, i, j): two stages per tile
+    stages.append(pieces(wf).view(3, tiles, 32, 2, 4, 2, 8).permute(1, 3, 0, 4, 5, 2, 6).reshape(tiles * 2, -1))
+    biases.append(_bias_accumulator_order(bf))
+    return torch.cat(stages, dim=0).contiguous(), torch.cat(biases).contiguous()
+
+
+def affine_flow_mlp(inputs, weights_packed, bias_packed, tables, num_transform, num_identity, num_hidden_layers,
+                    scale_activation, inverse=False, accumulate_into=None, num_layers=1,
+                    standard_normal_log_prob=False):
+    """K11 -- a run of affine / additive coupling layers with their MLP conditioners in one launch
+    (weights / biases of the layers concatenated in execution order, tables from
+    `flow_layer_tables`).  Returns (outputs, logabsdet), or (None, log_prob) with
+    `standard_normal_log_prob`; None when the shape is outside the fast path."""
+    N.require_device_f32("inputs", inputs, 2)
+    dev = inputs.device
+    B, D = inputs.shape
+    x = inputs.detach().contiguous()
+    lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
+    flags, out = _density_epilogue(flags, standard_normal_log_prob, inverse, x)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_affine_flow_mlp_f32(
+            N.ptr(x), N.ptr(weights_packed), N.ptr(bias_packed), N.ptr(tables), num_layers, N.ptr(out),
+            N.ptr(lad), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128, num_hidden_layers,
+            scale_activation, flags, N.stream_handle(dev))
+    if rc == N.ERR_UNSUPPORTED:
+        return None
+    N.check(rc)
+    return out, lad
+
+
 def split_f16x2(w):
     """fp32 -> two f16 tensors with w == hi + lo up to 2^-24 |w| while the low piece stays in the
     normal f16 range (round to nearest even both times)."""

@@ -71,12 +71,7 @@ class CompositeTransform(Transform):
     # ------------------------------------------------------------------ runs of K8 layers
     @staticmethod
     def _run_signature(coupling):
-        return (coupling.features, coupling.num_transform_features, coupling.num_identity_features,
-                len(coupling.transform_net.blocks), coupling.num_bins, coupling.tail_bound,
-                coupling.min_bin_width, coupling.min_bin_height, coupling.min_derivative,
-                coupling._log2e() if hasattr(coupling, "_log2e") else False,
-                coupling._use_f16() if hasattr(coupling, "_use_f16") else False,
-                getattr(coupling, "conditioner_act_scale", 1.0))
+        return coupling._run_signature()
 
     def _collect_run(self, layers, start, inputs, context, inverse):
         """Longest run of units starting at `start`: forward a unit is [column Permutation]? +
@@ -88,9 +83,9 @@ class CompositeTransform(Transform):
             return units, start
 
         def eligible(t):
-            check = getattr(t, "_resnet_eligible", None)
-            return (check is not None and t.unconditional_transform is None and t.features == inputs.shape[1]
-                    and check(context))
+            kind = getattr(t, "_run_kind", None)   # whole-layer kernel this layer can join a run of
+            return (kind is not None and t.unconditional_transform is None and t.features == inputs.shape[1]
+                    and kind(context) is not None)
         i, signature = start, None
         while i < len(layers):
             perm = None
@@ -118,14 +113,16 @@ class CompositeTransform(Transform):
         return units, i
 
     def _run_plan(self, units, inverse):
-        """Concatenated K8 blobs and the composed tables of a run, cached until a weight or a
-        permutation changes."""
+        """Concatenated weight / bias blobs and the composed tables of a run, cached until a weight or a
+        permutation changes.  (weights, biases, tables, f16 stream or None)."""
         from .. import ops
-        packed = [c._packed_resnet() for c, _ in units]
-        f16 = units[0][0]._use_f16()
+        first = units[0][0]
+        mlp = first._run_kind(None) == "k11"
+        packed = [c._packed_mlp() if mlp else c._packed_resnet() for c, _ in units]
+        f16 = (not mlp) and first._use_f16()
         packed_f16 = [c._packed_resnet_f16() for c, _ in units] if f16 else None
         key = (_cache.epoch(), inverse, f16, tuple(id(c) for c, _ in units),
-               tuple(c._packed_resnet_cache[0] for c, _ in units),
+               tuple((c._packed_mlp_cache if mlp else c._packed_resnet_cache)[0] for c, _ in units),
                tuple(c._packed_resnet_f16_cache[0] for c, _ in units) if f16 else None,
                tuple(None if p is None else (p._permutation.data_ptr(), p._permutation._version) for _, p in units))
         cache = self.__dict__.setdefault("_run_plans", {})
@@ -140,7 +137,7 @@ class CompositeTransform(Transform):
                 perm = None if p is None else p._permutation
                 spec_layers.append((c.transform_features, c.identity_features,
                                     None if inverse else perm, perm if inverse else None))
-            tables = ops.flow_layer_tables(units[0][0].features, spec_layers)
+            tables = ops.flow_layer_tables(first.features, spec_layers)
             plan_f16 = ops.build_f16_stream(packed_f16, tables) if f16 else None
             plan = (weights, biases, tables, plan_f16)
             cache[key] = plan
@@ -156,7 +153,12 @@ class CompositeTransform(Transform):
         full = (batch // 128) * 128
         weights, biases, tables, plan_f16 = self._run_plan(units, inverse)
         acc = None if total is None else total[:full]
-        if plan_f16 is not None:
+        if first._run_kind(None) == "k11":
+            head = ops.affine_flow_mlp(
+                inputs[:full], weights, biases, tables, first.num_transform_features, first.num_identity_features,
+                len(first.transform_net._hidden_layers), first._activation_code(), inverse, acc,
+                num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob)
+        elif plan_f16 is not None:
             head = ops.rqs_coupling_resnet_f16(
                 inputs[:full], plan_f16, (weights, biases), tables, first.num_transform_features,
                 first.num_identity_features, len(first.transform_net.blocks), first._spec(), inverse,

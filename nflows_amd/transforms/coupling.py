@@ -248,6 +248,33 @@ class AffineCouplingTransform(CouplingTransform):
             logabsdet = logabsdet_accumulator
         return outputs, logabsdet
 
+    # whole-layer kernel K11 (MLP conditioner inside the layer kernel, runs of layers in one launch)
+    fuse_conditioner = os.environ.get("NFA_K11", "1") != "0"
+
+    def _run_kind(self, context):
+        from ..nn.nets.mlp import MLP
+        net = self.transform_net
+        ok = (self.fuse_conditioner and not torch.is_grad_enabled() and context is None and type(net) is MLP
+              and net._activation is torch.nn.functional.relu and not net._activate_output
+              and all(h == 128 for h in net._hidden_sizes) and self._activation_code() != N.SCALE_GIVEN
+              and 1 <= self.num_identity_features <= 64 and 1 <= self.num_transform_features <= 64
+              and self.features <= 128)
+        return "k11" if ok else None
+
+    def _run_signature(self):
+        return ("k11", self.features, self.num_transform_features, self.num_identity_features,
+                len(self.transform_net._hidden_layers), self._activation_code())
+
+    def _packed_mlp(self):
+        net = self.transform_net
+        key = (_cache.epoch(),) + tuple((p.data_ptr(), p._version) for p in net.parameters())
+        cached = getattr(self, "_packed_mlp_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, ops.pack_mlp_conditioner(net, self.num_transform_features,
+                                                    additive=self._activation_code() == N.SCALE_ADDITIVE))
+            self._packed_mlp_cache = cached
+        return cached[1]
+
     def _activation_code(self):
         if self.scale_activation is AffineCouplingTransform.DEFAULT_SCALE_ACTIVATION:
             return N.SCALE_DEFAULT
@@ -271,6 +298,9 @@ class AdditiveCouplingTransform(AffineCouplingTransform):
 
     def _transform_dim_multiplier(self):
         return 1
+
+    def _activation_code(self):
+        return N.SCALE_ADDITIVE
 
     def _fused_layer(self, inputs, transform_params, inverse, in_perm=None, out_scatter=None,
                      accumulate_into=None):
@@ -347,6 +377,15 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
 
     # K8: the whole ResidualNet conditioner inside the spline kernel (class-level switch)
     fuse_conditioner = os.environ.get("NFA_K8", "1") != "0"
+
+    def _run_kind(self, context):
+        return "k8" if self._resnet_eligible(context) else None
+
+    def _run_signature(self):
+        return ("k8", self.features, self.num_transform_features, self.num_identity_features,
+                len(self.transform_net.blocks), self.num_bins, self.tail_bound,
+                self.min_bin_width, self.min_bin_height, self.min_derivative,
+                self._log2e(), self._use_f16(), self.conditioner_act_scale)
 
     def _resnet_eligible(self, context):
         net = self.transform_net

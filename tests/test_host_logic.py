@@ -528,3 +528,38 @@ def test_packed_weight_caches_follow_weight_updates():
     sd["_transform._transforms.1.transform_net.final_layer.weight"] *= 3.0
     flow.load_state_dict(sd)
     assert not torch.equal(layer._packed_resnet()[0], w0)
+
+
+def test_affine_mlp_packing_orders_the_output_rows_per_lane():
+    """Host side of K11 (ops.pack_mlp_conditioner): the output layer's rows are ordered so that a
+    lane-half's 16 accumulator registers of a tile are [8 shifts | the 8 scales of the same features]
+    (affine) or 16 shifts (additive); padding rows are zero; stage and bias counts as the header says."""
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import MLP
+    for dt, di, additive, hidden in [(16, 16, False, (128, 128)), (20, 12, False, (128,)), (20, 44, True, (128, 128, 128))]:
+        order = ops._affine_row_order(dt, additive)
+        per_tile = 32 if additive else 16
+        tiles = (dt + per_tile - 1) // per_tile
+        assert order.shape == (tiles * 32,)
+        used = order[order >= 0]
+        assert sorted(used.tolist()) == list(range(dt if additive else 2 * dt))   # every output exactly once
+        for t in range(tiles):
+            for i in range(32):
+                half, q = (i >> 2) & 1, ((i >> 3) << 2) | (i & 3)
+                f = (32 * t + 16 * half + q) if additive else (16 * t + 8 * half + (q & 7))
+                want = -1 if f >= dt else (f if additive or q < 8 else dt + f)
+                assert order[t * 32 + i].item() == want
+        torch.manual_seed(0)
+        net = MLP([di], [dt if additive else 2 * dt], list(hidden))
+        w, b = ops.pack_mlp_conditioner(net, dt, additive=additive)
+        init_ks = 4 if di > 32 else 2
+        assert w.shape == (init_ks + 8 * (len(hidden) - 1) + 2 * tiles, 768 * 8) and w.dtype == torch.bfloat16
+        assert b.shape == (128 * len(hidden) + 32 * tiles,)
+        # the biases of the output tiles in accumulator order: [tile][half][16]
+        bo = torch.cat((net._output_layer.bias.detach(), torch.zeros(1)))
+        got = b[128 * len(hidden):].view(tiles, 2, 16)
+        for t in range(tiles):
+            for half in range(2):
+                for q in range(16):
+                    i = 8 * (q // 4) + 4 * half + q % 4
+                    assert got[t, half, q] == bo[order[t * 32 + i]]
