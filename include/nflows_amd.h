@@ -350,6 +350,35 @@ int nfa_affine_flow_mlp_f32(const float *inputs, const void *weights_packed, con
                             int32_t scale_activation, int32_t flags, void *stream);
 
 /*
+ * K12.  The sequential part of AutoregressiveTransform.inverse (autoregressive.py:43-52) for
+ *   MaskedPiecewiseRationalQuadraticAutoregressiveTransform (autoregressive.py:404-495) over a MADE
+ *   conditioner (made.py:233-311) as one persistent kernel: for t = 0 .. sequential_steps - 1 the
+ *   hidden units of degree t (made.py:60-63: they are functions of features < t), feature t's
+ *   3K - 1 output rows, the spline inverse of column t.  Features >= sequential_steps (= the largest
+ *   hidden degree) no longer change any hidden unit; the caller finishes them from `hidden_out` with
+ *   one GEMM and one elementwise launch (K5 / K1).
+ *   packed_floats / packed_ints / layout: built by ops.pack_made_schedule -- per hidden Linear its
+ *     masked weight rows sorted by degree (zero-padded to multiples of 16 columns), biases and unit
+ *     indices in that order and the CSR starts by degree; the first `sequential_steps` features' rows
+ *     of the output layer [t][P][Hp] and biases; `layout` (host memory, int32) holds the counts and
+ *     offsets:
+ *       [num_linears, residual, final_src, stream_vec, num_vectors, Hp, Xp, wf_off, bf_off] then per
+ *       Linear [w_off, b_off, idx_off, start_off, padded_columns, src_vector (-1 = the features),
+ *       add_stream, set_stream].
+ *   outputs     [batch, features]: columns < sequential_steps are written
+ *   logabsdet   [batch]: sum of those columns' log-derivatives (the inverse's sign)
+ *   hidden_out  [batch, hidden_features]: the output layer's input with every hidden unit final
+ * Supported: 8 or 10 bins with linear tails, ReLU, no context / batch norm, per-sample state
+ * (padded features + one vector per hidden Linear [+ the residual stream]) x 16 samples within the LDS;
+ * otherwise NFA_ERR_UNSUPPORTED (callers keep the column-wise host loop).
+ */
+int nfa_made_rqs_inverse_f32(const float *inputs, const float *packed_floats, const int32_t *packed_ints,
+                             const int32_t *layout, int32_t layout_len, float *outputs, float *logabsdet,
+                             float *hidden_out, int32_t *status, int64_t batch, int32_t features,
+                             int32_t hidden_features, int32_t sequential_steps, const nfa_rqs_spec *spec,
+                             void *stream);
+
+/*
  * K5.  Elementwise rational-quadratic functional (no row-sum):
  *   unconstrained_rational_quadratic_spline / rational_quadratic_spline,
  *   splines/rational_quadratic.py:13-63 / :66-181, as called from

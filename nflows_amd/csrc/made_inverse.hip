@@ -1,0 +1,243 @@
+// K12: the sequential part of the autoregressive spline layer's inverse (sampling direction) as ONE
+// persistent kernel -- AutoregressiveTransform.inverse (autoregressive.py:43-52) for
+// MaskedPiecewiseRationalQuadraticAutoregressiveTransform (autoregressive.py:404-495) over a MADE
+// conditioner (made.py:233-311, masked residual / feed-forward blocks :67-231).
+//
+// The reference runs the whole MADE D times.  What actually changes from one iteration to the next is
+// little: a hidden unit of degree d is connected to inputs of degree <= d only (made.py:60-63), i.e. it
+// is a function of features 0 .. d-1 and final as soon as feature d-1 has been found.  So step t
+//   1. evaluates the hidden units of degree t, layer by layer (for H < D - 1 sequential degrees that is
+//      one unit per layer: five 256-term dot products instead of four 256 x 256 products per sample),
+//   2. takes feature t's P rows of the output layer on the hidden vector as it stands (units of higher
+//      degree are still zero and meet exactly-zero masked weights),
+//   3. inverts the spline of feature t and records x_t.
+// After step T - 1 (T = largest hidden degree) plus one more round of unit updates nothing changes
+// any more; the caller finishes features T .. D-1 with one GEMM and one elementwise launch
+// (transforms/autoregressive.py).  Same sums as the reference's masked GEMMs in another order.
+//
+// Samples are independent, so there is no grid-wide step: a single-wave workgroup owns 16 samples for
+// all steps.  Lane = (sample s, quarter q): the four lanes of a sample split every dot product by
+// 16-byte chunks (chunk c belongs to quarter c % 4) and add their parts with two cross-lane exchanges.
+// Per-sample state lives in LDS as [vector][chunk][16 samples][4 floats]: the features found so far
+// and one vector per hidden Linear (its ReLU'd output) plus, for residual nets, the raw residual
+// stream; a lane's read of chunk c is one ds_read_b128, conflict-free across the wave.  Weight rows are
+// pre-masked, sorted by degree and zero-padded on the host; a lane reads its chunks straight from
+// global memory (the four quarters read 64 contiguous bytes, the 16 samples the same address).
+//
+// Supported: 8 or 10 bins with linear tails (P = 23 / 29), ReLU, residual blocks (sequential masks) or
+// feed-forward blocks (any masks), no context, no batch norm; state that fits the LDS.
+
+#include "fused_common.hpp"
+
+#include <hip/hip_ext.h>
+#include <stdlib.h>
+
+namespace nfa {
+
+constexpr int kMadeMaxLinears = 12;
+constexpr int kMadeSamples = 16;   // per wave
+
+struct MadeInvArgs {
+    const float* z;          // [B, D] values to invert
+    float* x;                // [B, D] features found (columns < T written)
+    float* lad;              // [B]   sum of the log-derivatives of columns < T
+    float* hidden;           // [B, H] the output layer's input once all hidden units are final
+    const float* wts;        // packed floats (rows, biases), offsets below
+    const int32_t* ints;     // packed ints (unit indices, CSR starts)
+    int32_t* status;
+    int64_t batch;
+    int D, H, Hp, Xp, T, P, num_linears, residual, final_src, stream_vec, num_vectors;
+    // per hidden Linear l: rows [H][kp], bias [H], idx [H], start [T + 2]
+    int w_off[kMadeMaxLinears], b_off[kMadeMaxLinears], idx_off[kMadeMaxLinears], start_off[kMadeMaxLinears];
+    int kp[kMadeMaxLinears], src[kMadeMaxLinears], add_stream[kMadeMaxLinears], set_stream[kMadeMaxLinears];
+    int wf_off, bf_off;      // output layer rows [T][P][Hp], biases [T][P]
+    RqsDev sp;
+};
+
+// one lane's part of `R` dot products of weight rows (global, `pitch` floats apart) with a state vector
+// (LDS): chunks q, q + 4, ... of `chunks`; then the sum over the four quarters (all four lanes get it)
+template <int R>
+__device__ __forceinline__ void dot_rows(float (&acc)[R], const float* rows, int pitch, const float* vec, int chunks,
+                                         int q, int s, int nrows) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+    for (int c = q; c < chunks; c += 4) {
+        const vec4f v = *reinterpret_cast<const vec4f*>(vec + (c * kMadeSamples + s) * 4);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (r < nrows) {
+                const vec4f w = *reinterpret_cast<const vec4f*>(rows + (size_t)r * pitch + c * 4);
+                acc[r] = __builtin_fmaf(w.x, v.x, acc[r]);
+                acc[r] = __builtin_fmaf(w.y, v.y, acc[r]);
+                acc[r] = __builtin_fmaf(w.z, v.z, acc[r]);
+                acc[r] = __builtin_fmaf(w.w, v.w, acc[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        acc[r] += __shfl_xor(acc[r], 16, kWave);
+        acc[r] += __shfl_xor(acc[r], 32, kWave);
+    }
+}
+
+__device__ __forceinline__ int state_index(int k, int s) { return ((k >> 2) * kMadeSamples + s) * 4 + (k & 3); }
+
+template <int KT>
+__global__ void __launch_bounds__(kWave) made_rqs_inverse_kernel(const MadeInvArgs a) {
+#pragma clang fp contract(off)
+    constexpr int P = 3 * KT - 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x, s = lane & 15, q = lane >> 4;
+    const int64_t row = (int64_t)blockIdx.x * kMadeSamples + s;
+    const bool live = row < a.batch;
+    const int64_t rrow = live ? row : a.batch - 1;
+    const int vec_floats = (a.Hp >> 2) * kMadeSamples * 4;          // one hidden vector of all 16 samples
+    float* xs = lds;                                                // [Xp / 4][16][4]
+    float* vecs = lds + (a.Xp >> 2) * kMadeSamples * 4;             // [num_vectors][Hp / 4][16][4]
+    for (int i = lane; i < (a.Xp >> 2) * kMadeSamples * 4 + a.num_vectors * vec_floats; i += kWave) lds[i] = 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    float lad_acc = 0.0f;
+    int my_status = 0;
+    const float* zrow = a.z + rrow * a.D;
+    float* stream = a.residual ? vecs + a.stream_vec * vec_floats : nullptr;
+    for (int t = 0; t <= a.T; ++t) {
+        // ---- 1. hidden units of degree t, layer by layer
+        for (int l = 0; l < a.num_linears; ++l) {
+            const int* start = a.ints + a.start_off[l];
+            const int r0 = start[t], r1 = start[t + 1];
+            if (r0 == r1) continue;
+            const float* src = a.src[l] < 0 ? xs : vecs + a.src[l] * vec_floats;
+            const int kp = a.kp[l], chunks = kp >> 2;
+            float* dst = vecs + l * vec_floats;
+            for (int r = r0; r < r1; ++r) {
+                float acc[1];
+                dot_rows<1>(acc, a.wts + a.w_off[l] + (size_t)r * kp, kp, src, chunks, q, s, 1);
+                const int j = a.ints[a.idx_off[l] + r];
+                float v = acc[0] + a.wts[a.b_off[l] + r];
+                const int at = state_index(j, s);
+                if (a.add_stream[l]) v = stream[at] + v;          // residual connection (made.py:128)
+                if (q == 0) {
+                    if (a.set_stream[l]) stream[at] = v;
+                    dst[at] = v < 0.0f ? 0.0f : v;                // ReLU'd for the next Linear (NaN stays)
+                }
+            }
+            // the units just written are inputs of the next Linear (and of this one's later rows: a
+            // unit may be connected to units of its own degree in the previous layer only)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (t == a.T) break;
+        // ---- 2. feature t's P output rows on the hidden vector as it stands
+        const float* fin = vecs + a.final_src * vec_floats;
+        const float* wf = a.wts + a.wf_off + (size_t)t * P * a.Hp;
+        const float* bf = a.wts + a.bf_off + t * P;
+        float p[P];
+        constexpr int RB = 8;
+#pragma unroll
+        for (int p0 = 0; p0 < P; p0 += RB) {
+            float acc[RB];
+            dot_rows<RB>(acc, wf + (size_t)p0 * a.Hp, a.Hp, fin, a.Hp >> 2, q, s, P - p0 < RB ? P - p0 : RB);
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if (p0 + r < P) p[p0 + r] = acc[r] + bf[p0 + r];
+        }
+        // ---- 3. invert feature t (rational_quadratic.py:66-181 through the same evaluation as K5)
+        float y, l;
+        my_status |= rqs_eval<KT, true, true, true>(zrow[t], p, a.sp, y, l);
+        lad_acc += l;
+        if (q == 0) {
+            if (t < a.Xp) xs[state_index(t, s)] = y;
+            if (live) a.x[row * a.D + t] = y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (live && q == 0) a.lad[row] = lad_acc;
+    // the final hidden vector of every sample: input of the output layer for features >= T
+    {
+        const float* fin = vecs + a.final_src * vec_floats;
+        if (live)
+            for (int k = q; k < a.H; k += 4) a.hidden[row * a.H + k] = fin[state_index(k, s)];
+    }
+    if (!live) my_status = 0;
+    if (my_status && a.status) atomicOr(a.status, my_status);
+}
+
+}  // namespace nfa
+
+using namespace nfa;
+
+extern "C" int nfa_made_rqs_inverse_f32(const float* inputs, const float* packed_floats, const int32_t* packed_ints,
+                                        const int32_t* layout, int32_t layout_len, float* outputs,
+                                        float* logabsdet, float* hidden_out, int32_t* status, int64_t batch,
+                                        int32_t features, int32_t hidden_features, int32_t sequential_steps,
+                                        const nfa_rqs_spec* spec, void* stream) {
+    if (batch < 0 || features < 1 || hidden_features < 1 || sequential_steps < 0 || sequential_steps >= features + 1 ||
+        !layout || layout_len < 8)
+        return NFA_ERR_INVALID_ARGUMENT;
+    MadeInvArgs a;
+    int rc = make_dev_spec(spec, &a.sp);
+    if (rc != NFA_OK) return rc;
+    if (a.sp.beta != 1.0f || !a.sp.linear || (a.sp.K != 8 && a.sp.K != 10)) return NFA_ERR_UNSUPPORTED;
+    // layout: [num_linears, residual, final_src, stream_vec, num_vectors, Hp, Xp, wf_off, bf_off,
+    //          then per Linear: w_off, b_off, idx_off, start_off, kp, src, add_stream, set_stream]
+    const int n = layout[0];
+    if (n < 1 || n > kMadeMaxLinears || layout_len != 9 + 8 * n) return NFA_ERR_INVALID_ARGUMENT;
+    a.num_linears = n;
+    a.residual = layout[1];
+    a.final_src = layout[2];
+    a.stream_vec = layout[3];
+    a.num_vectors = layout[4];
+    a.Hp = layout[5];
+    a.Xp = layout[6];
+    a.wf_off = layout[7];
+    a.bf_off = layout[8];
+    for (int l = 0; l < n; ++l) {
+        const int32_t* e = layout + 9 + 8 * l;
+        a.w_off[l] = e[0];
+        a.b_off[l] = e[1];
+        a.idx_off[l] = e[2];
+        a.start_off[l] = e[3];
+        a.kp[l] = e[4];
+        a.src[l] = e[5];
+        a.add_stream[l] = e[6];
+        a.set_stream[l] = e[7];
+        if ((a.kp[l] & 15) != 0 || a.src[l] >= a.num_vectors) return NFA_ERR_INVALID_ARGUMENT;
+    }
+    if ((a.Hp & 15) != 0 || (a.Xp & 15) != 0 || a.Hp < hidden_features || a.final_src < 0 ||
+        a.final_src >= a.num_vectors || a.num_vectors < n || (a.residual && (a.stream_vec < 0 || a.stream_vec >= a.num_vectors)))
+        return NFA_ERR_INVALID_ARGUMENT;
+    const size_t lds = ((size_t)a.Xp + (size_t)a.num_vectors * a.Hp) * kMadeSamples * sizeof(float);
+    if (lds + 1024 > 160 * 1024) return NFA_ERR_UNSUPPORTED;
+    if (batch == 0) return NFA_OK;
+    if (!inputs || !packed_floats || !packed_ints || !outputs || !logabsdet || !hidden_out) return NFA_ERR_INVALID_ARGUMENT;
+    a.z = inputs;
+    a.x = outputs;
+    a.lad = logabsdet;
+    a.hidden = hidden_out;
+    a.wts = packed_floats;
+    a.ints = packed_ints;
+    a.status = status;
+    a.batch = batch;
+    a.D = features;
+    a.H = hidden_features;
+    a.T = sequential_steps;
+    a.P = a.sp.P;
+    void (*kern)(const MadeInvArgs) = a.sp.K == 8 ? made_rqs_inverse_kernel<8> : made_rqs_inverse_kernel<10>;
+    if (lds > 64 * 1024) {
+        static bool raised[2] = {false, false};
+        const int which = a.sp.K == 8 ? 0 : 1;
+        if (!raised[which]) {
+            NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            raised[which] = true;
+        }
+    }
+    const int64_t blocks = (batch + kMadeSamples - 1) / kMadeSamples;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kWave), lds, (hipStream_t)stream, a);
+    NFA_HIP_CHECK(hipGetLastError());
+    return NFA_OK;
+}

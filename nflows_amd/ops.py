@@ -513,6 +513,100 @@ def _standard_normal_log_prob_launch(z, logabsdet):
     return out
 
 
+def pack_made_schedule(net, sequential_steps, params_per_feature):
+    """Packs a MADE (transforms/made.py) for K12 (csrc/made_inverse.hip): every hidden Linear's masked
+    weight rows sorted by degree, the CSR starts by degree, and the output rows of the first
+    `sequential_steps` features.  Returns (floats, ints, layout list) -- layout in include/nflows_amd.h."""
+    T, P = int(sequential_steps), int(params_per_feature)
+    dev = net.final_layer.weight.device
+    H = net.initial_layer.weight.shape[0]
+    Hp = (H + 15) // 16 * 16
+    Xp = max(16, (T + 15) // 16 * 16)
+    residual = bool(net.use_residual_blocks)
+    linears = [net.initial_layer]
+    for block in net.blocks:
+        linears += list(block.linear_layers) if residual else [block.linear]
+    n = len(linears)
+    floats, ints, per_layer = [], [], []
+    foff = ioff = 0
+
+    def push_f(t):
+        nonlocal foff
+        t = t.reshape(-1).float()
+        pad = (-t.numel()) % 4        # every block starts 16-byte aligned
+        if pad:
+            t = torch.cat((t, t.new_zeros(pad)))
+        floats.append(t)
+        at = foff
+        foff += t.numel()
+        return at
+
+    def push_i(t):
+        nonlocal ioff
+        t = t.reshape(-1).to(torch.int32)
+        ints.append(t)
+        at = ioff
+        ioff += t.numel()
+        return at
+
+    for l, lin in enumerate(linears):
+        w = (lin.weight.detach() * lin.mask).float()
+        deg = lin.degrees.to(torch.int64)
+        order = torch.argsort(deg, stable=True)
+        counts = torch.bincount(deg, minlength=T + 2)[:T + 2]
+        start = torch.cat((counts.new_zeros(1), torch.cumsum(counts, 0)))[:T + 2]   # start[d] = #units of degree < d
+        if l == 0:
+            kp = Xp
+            w = w[:, :min(Xp, w.shape[1])]      # features >= T meet zero masks in every hidden unit
+        else:
+            kp = Hp
+        w = torch.cat((w, w.new_zeros(w.shape[0], kp - w.shape[1])), dim=1)
+        bias = lin.bias.detach().float() if lin.bias is not None else w.new_zeros(w.shape[0])
+        w_off = push_f(w.index_select(0, order))
+        b_off = push_f(bias.index_select(0, order))
+        idx_off = push_i(order)
+        start_off = push_i(start)
+        is_upper = residual and l > 0 and l % 2 == 0          # second Linear of a residual block
+        per_layer.append([w_off, b_off, idx_off, start_off, kp, l - 1,
+                          1 if is_upper else 0, 1 if residual and (l == 0 or is_upper) else 0])
+    final = net.final_layer
+    D = final.weight.shape[0] // P
+    wf = (final.weight.detach() * final.mask).float().view(D, P, H)[:T]
+    wf = torch.cat((wf, wf.new_zeros(T, P, Hp - H)), dim=2)
+    wf_off = push_f(wf)
+    bf_off = push_f(final.bias.detach().float().view(D, P)[:T])
+    num_vectors = n + (1 if residual else 0)
+    layout = [n, int(residual), n if residual else n - 1, n if residual else -1, num_vectors, Hp, Xp, wf_off, bf_off]
+    for e in per_layer:
+        layout += e
+    return torch.cat(floats).contiguous().to(dev), torch.cat(ints).contiguous().to(dev), layout
+
+
+def made_rqs_inverse(inputs, schedule, hidden_features, sequential_steps, spec):
+    """K12 -- the sequential features of the autoregressive spline inverse in one persistent kernel.
+    Returns (outputs [B, D] with columns < sequential_steps filled, their logabsdet [B], hidden [B, H]),
+    or None outside the kernel's shape family."""
+    N.require_device_f32("inputs", inputs, 2)
+    dev = inputs.device
+    B, D = inputs.shape
+    z = inputs.detach().contiguous()
+    out = torch.empty_like(z)
+    lad = torch.empty(B, dtype=torch.float32, device=dev)
+    hidden = torch.empty(B, hidden_features, dtype=torch.float32, device=dev)
+    floats, ints, layout = schedule
+    arr = (ctypes.c_int32 * len(layout))(*layout)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_made_rqs_inverse_f32(
+            N.ptr(z), N.ptr(floats), N.ptr(ints), arr, len(layout), N.ptr(out), N.ptr(lad), N.ptr(hidden),
+            N.ptr(_status_word(dev)), B, D, hidden_features, sequential_steps, ctypes.byref(spec),
+            N.stream_handle(dev))
+    if rc == N.ERR_UNSUPPORTED:
+        return None
+    N.check(rc)
+    _after_spline(spec, True, dev)
+    return out, lad, hidden
+
+
 _sum_workspaces = {}
 
 

@@ -6,10 +6,13 @@ inverse : the reference's D-step fixed-point loop (autoregressive.py:43-52): eve
           MADE on the current outputs and the elementwise inverse over all D features; after
           step t the first t features are final.  Same semantics, same number of passes.
 """
+import os
+
 import numpy as np
 import torch
 from torch.nn import functional as F
 
+from .. import _cache
 from .. import _native as N
 from .. import ops
 from . import made as made_module
@@ -83,20 +86,58 @@ class AutoregressiveTransform(Transform):
         # output -- bias + sum over the features found so far of column (x) masked weight column --
         # is carried along and grows by one rank-1 term per step (all still-zero features contribute
         # exact zeros to the reference's full product).
+        #
+        # The sequential part ends early: a hidden unit of degree d reads features < d only, so once
+        # feature `last` = (largest hidden degree) - 1 is found every hidden activation is final, and
+        # the remaining features -- each a function of that one hidden vector and its own P output
+        # rows -- are inverted together: one GEMM for their parameters, one elementwise launch.
+        # (MADE with H < D - 1 sequential degrees: D = 784, H = 256 leaves 256 sequential steps.)
         first = net.initial_layer
+        sequential = min(features, self._sequential_steps())
         with net.frozen_masks():
-            first_weight = first.masked_weight().t().contiguous()  # [D, H]: row t = feature t's weights
-            pre = first.bias.detach().expand(batch, -1).contiguous() if first.bias is not None \
-                else inputs.new_zeros(batch, first_weight.shape[1])
-            for t in range(features):
-                h = net.hidden_from_initial(pre, context)
-                params_t = torch.addmm(bias[t], h, weight[t].t())
-                column, lad_t = self._inverse_column(inputs[:, t], params_t)
-                outputs[:, t] = column
-                logabsdet += lad_t
-                if t + 1 < features:
-                    pre.addr_(column, first_weight[t])
+            # the sequential features in one persistent kernel where there is one (K12), else step by step
+            fast = self._sequential_kernel(inputs, context, sequential)
+            if fast is not None:
+                outputs, logabsdet, h = fast
+            else:
+                first_weight = first.masked_weight().t().contiguous()  # [D, H]: row t = feature t's weights
+                pre = first.bias.detach().expand(batch, -1).contiguous() if first.bias is not None \
+                    else inputs.new_zeros(batch, first_weight.shape[1])
+                for t in range(sequential):
+                    h = net.hidden_from_initial(pre, context)
+                    params_t = torch.addmm(bias[t], h, weight[t].t())
+                    column, lad_t = self._inverse_column(inputs[:, t], params_t)
+                    outputs[:, t] = column
+                    logabsdet += lad_t
+                    if t + 1 < features:
+                        pre.addr_(column, first_weight[t])
+                if sequential < features:
+                    h = net.hidden_from_initial(pre, context)
+            if sequential < features:
+                rest = features - sequential
+                params = torch.addmm(bias[sequential:].reshape(-1), h, weight[sequential:].reshape(rest * mult, -1).t())
+                columns, lad_rest = self._elementwise_inverse(inputs[:, sequential:].contiguous(),
+                                                              params.view(batch, rest, mult))
+                outputs[:, sequential:] = columns
+                logabsdet += lad_rest
         return outputs, logabsdet
+
+    def _sequential_kernel(self, inputs, context, sequential):
+        """Hook: (outputs with the first `sequential` columns found, their logabsdet, the final hidden
+        vector) from a kernel that runs all sequential steps itself, or None."""
+        return None
+
+    def _sequential_steps(self):
+        """Number of leading features whose inversion changes a hidden activation of the MADE: the
+        largest degree of any hidden unit (made.py: a unit of degree d is connected to inputs of
+        degree <= d, i.e. features 0 .. d - 1)."""
+        cached = self.__dict__.get("_sequential_steps_cache")
+        if cached is None:   # (masks are fixed at construction; one device read, once)
+            net = self.autoregressive_net
+            degrees = [net.initial_layer.degrees] + [b.degrees for b in net.blocks]
+            cached = int(max(int(d.max()) for d in degrees))
+            self.__dict__["_sequential_steps_cache"] = cached
+        return cached
 
     def _output_dim_multiplier(self):
         raise NotImplementedError()
@@ -199,6 +240,28 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
     def _elementwise_inverse(self, inputs, autoregressive_params):
         return self._elementwise(inputs, autoregressive_params, inverse=True)
 
+    # persistent kernel for the sequential features of the inverse (K12, csrc/made_inverse.hip)
+    fuse_sequential_inverse = os.environ.get("NFA_K12", "1") != "0"
+
+    def _sequential_kernel(self, inputs, context, sequential):
+        net = self.autoregressive_net
+        if not (self.fuse_sequential_inverse and context is None and sequential >= 1
+                and isinstance(net, made_module.MADE) and net.activation is F.relu
+                and not hasattr(net, "context_layer") and self.tails == "linear" and self.num_bins in (8, 10)
+                and not any(isinstance(m, torch.nn.BatchNorm1d) for m in net.modules())):
+            return None
+        key = (_cache.epoch(), sequential) + tuple((p.data_ptr(), p._version) for p in net.parameters())
+        cached = self.__dict__.get("_made_schedule_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, ops.pack_made_schedule(net, sequential, self._output_dim_multiplier()))
+            self.__dict__["_made_schedule_cache"] = cached
+        spec = ops.make_rqs_spec(self.num_bins, self.tails, tail_bound=self.tail_bound,
+                                 min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                                 min_derivative=self.min_derivative,
+                                 wh_divisor=float(np.sqrt(net.hidden_features)) if hasattr(net, "hidden_features") else 0.0)
+        hidden_features = net.initial_layer.weight.shape[0]
+        return ops.made_rqs_inverse(inputs, cached[1], hidden_features, sequential, spec)
+
     def _inverse_column(self, column, params):
         """One feature: params [B, P]; the spline layer kernel with a single (transformed) feature."""
         out, lad = self._elementwise(column.reshape(-1, 1), params, inverse=True)
@@ -228,7 +291,8 @@ class _SiblingSplineAutoregressiveTransform(AutoregressiveTransform):
         raise NotImplementedError()
 
     def _elementwise(self, inputs, autoregressive_params, inverse=False):
-        params = autoregressive_params.view(inputs.shape[0], self.features, self._output_dim_multiplier())
+        # (inputs may be a subset of the features: the independent tail of the column-wise inverse)
+        params = autoregressive_params.reshape(inputs.shape[0], inputs.shape[1], self._output_dim_multiplier())
         outputs, logabsdet = self._functional(inputs, params, inverse)
         return outputs, torchutils.sum_except_batch(logabsdet)
 

