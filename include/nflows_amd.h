@@ -357,22 +357,24 @@ int nfa_affine_flow_mlp_f32(const float *inputs, const void *weights_packed, con
  *   3K - 1 output rows, the spline inverse of column t.  Features >= sequential_steps (= the largest
  *   hidden degree) no longer change any hidden unit; the caller finishes them from `hidden_out` with
  *   one GEMM and one elementwise launch (K5 / K1).
- *   packed_floats / packed_ints / layout: built by ops.pack_made_schedule -- per hidden Linear its
- *     masked weight rows sorted by degree (zero-padded to multiples of 16 columns), biases and unit
- *     indices in that order and the CSR starts by degree; the first `sequential_steps` features' rows
- *     of the output layer [t][P][Hp] and biases; `layout` (host memory, int32) holds the counts and
- *     offsets:
- *       [num_linears, residual, final_src, stream_vec, num_vectors, Hp, Xp, wf_off, bf_off] then per
- *       Linear [w_off, b_off, idx_off, start_off, padded_columns, src_vector (-1 = the features),
- *       add_stream, set_stream].
+ *   step_blocks / block_starts / layout: built by ops.pack_made_schedule.  step_blocks holds one
+ *     contiguous fp32 block per step t = 0 .. sequential_steps (the last one only completes the hidden
+ *     vector): [16 ints: units of degree t per hidden Linear (12), offset of the tail section, offset of
+ *     the output rows] [the units' masked weight rows, layer after layer, zero-padded to multiples of 16
+ *     columns] [feature t's 3K - 1 rows of the output layer, Hp columns] [tail: (bias, unit index) per
+ *     unit, then the feature's biases], padded to 1 KB; block_starts int32 [sequential_steps + 2] in
+ *     1 KB grains; `layout` (host memory, int32):
+ *       [num_linears, residual, final_src, stream_vec, num_vectors, Hp, Xp, max_block_floats] then per
+ *       Linear [padded_columns, src_vector (-1 = the features), dst_vector (-1 = none), add_stream,
+ *       set_stream].
  *   outputs     [batch, features]: columns < sequential_steps are written
  *   logabsdet   [batch]: sum of those columns' log-derivatives (the inverse's sign)
  *   hidden_out  [batch, hidden_features]: the output layer's input with every hidden unit final
  * Supported: 8 or 10 bins with linear tails, ReLU, no context / batch norm, per-sample state
- * (padded features + one vector per hidden Linear [+ the residual stream]) x 16 samples within the LDS;
+ * (padded features + one vector per hidden Linear) x 16 samples + two step blocks within the LDS;
  * otherwise NFA_ERR_UNSUPPORTED (callers keep the column-wise host loop).
  */
-int nfa_made_rqs_inverse_f32(const float *inputs, const float *packed_floats, const int32_t *packed_ints,
+int nfa_made_rqs_inverse_f32(const float *inputs, const float *step_blocks, const int32_t *block_starts,
                              const int32_t *layout, int32_t layout_len, float *outputs, float *logabsdet,
                              float *hidden_out, int32_t *status, int64_t batch, int32_t features,
                              int32_t hidden_features, int32_t sequential_steps, const nfa_rqs_spec *spec,

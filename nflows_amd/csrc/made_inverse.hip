@@ -20,9 +20,15 @@
 // 16-byte chunks (chunk c belongs to quarter c % 4) and add their parts with two cross-lane exchanges.
 // Per-sample state lives in LDS as [vector][chunk][16 samples][4 floats]: the features found so far
 // and one vector per hidden Linear (its ReLU'd output) plus, for residual nets, the raw residual
-// stream; a lane's read of chunk c is one ds_read_b128, conflict-free across the wave.  Weight rows are
-// pre-masked, sorted by degree and zero-padded on the host; a lane reads its chunks straight from
-// global memory (the four quarters read 64 contiguous bytes, the 16 samples the same address).
+// stream; a lane's read of chunk c is one ds_read_b128, conflict-free across the wave.
+//
+// Everything step t needs from global memory is ONE contiguous block prepared by the host (weights
+// pre-masked, rows sorted by degree, zero-padded): a header with the number of units per layer, the
+// units' rows, the feature's output rows, the biases and unit indices.  Which block comes next does not
+// depend on data, so block t + 1 is pulled into the other half of an LDS double buffer by LDS-DMA
+// (global_load_lds, no registers, no waiting) while step t computes; the dot products read weights and
+// state from LDS only (a weight read is a 4-address broadcast).  The first version read the rows from
+// global memory inside the dot-product loops and spent its time waiting for L2: 35 us per step.
 //
 // Supported: 8 or 10 bins with linear tails (P = 23 / 29), ReLU, residual blocks (sequential masks) or
 // feed-forward blocks (any masks), no context, no batch norm; state that fits the LDS.
@@ -35,38 +41,39 @@
 namespace nfa {
 
 constexpr int kMadeMaxLinears = 12;
-constexpr int kMadeSamples = 16;   // per wave
+constexpr int kMadeSamples = 16;     // per wave
+constexpr int kMadeHeader = 16;      // ints in front of a step block: units per layer [12], tail offset, output-row offset
+constexpr int kMadeGrain = 256;      // blocks are multiples of 256 floats (one LDS-DMA request of the wave)
 
 struct MadeInvArgs {
     const float* z;          // [B, D] values to invert
     float* x;                // [B, D] features found (columns < T written)
     float* lad;              // [B]   sum of the log-derivatives of columns < T
     float* hidden;           // [B, H] the output layer's input once all hidden units are final
-    const float* wts;        // packed floats (rows, biases), offsets below
-    const int32_t* ints;     // packed ints (unit indices, CSR starts)
+    const float* blocks;     // the step blocks, one after the other
+    const int32_t* block_at; // [T + 2] start of block t in grains
     int32_t* status;
     int64_t batch;
-    int D, H, Hp, Xp, T, P, num_linears, residual, final_src, stream_vec, num_vectors;
-    // per hidden Linear l: rows [H][kp], bias [H], idx [H], start [T + 2]
-    int w_off[kMadeMaxLinears], b_off[kMadeMaxLinears], idx_off[kMadeMaxLinears], start_off[kMadeMaxLinears];
-    int kp[kMadeMaxLinears], src[kMadeMaxLinears], add_stream[kMadeMaxLinears], set_stream[kMadeMaxLinears];
-    int wf_off, bf_off;      // output layer rows [T][P][Hp], biases [T][P]
+    int D, H, Hp, Xp, T, num_linears, residual, final_src, stream_vec, num_vectors, max_block;  // max_block in floats
+    int kp[kMadeMaxLinears], src[kMadeMaxLinears], dst[kMadeMaxLinears], add_stream[kMadeMaxLinears],
+        set_stream[kMadeMaxLinears];
     RqsDev sp;
 };
 
-// one lane's part of `R` dot products of weight rows (global, `pitch` floats apart) with a state vector
-// (LDS): chunks q, q + 4, ... of `chunks`; then the sum over the four quarters (all four lanes get it)
+// one lane's part of `R` dot products of weight rows (`pitch` floats apart) with a state vector, both
+// in LDS: chunks q, q + 4, ... of `chunks`; then the sum over the four quarters (all four lanes get it)
 template <int R>
 __device__ __forceinline__ void dot_rows(float (&acc)[R], const float* rows, int pitch, const float* vec, int chunks,
                                          int q, int s, int nrows) {
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+#pragma unroll 2
     for (int c = q; c < chunks; c += 4) {
         const vec4f v = *reinterpret_cast<const vec4f*>(vec + (c * kMadeSamples + s) * 4);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (r < nrows) {
-                const vec4f w = *reinterpret_cast<const vec4f*>(rows + (size_t)r * pitch + c * 4);
+                const vec4f w = *reinterpret_cast<const vec4f*>(rows + r * pitch + c * 4);
                 acc[r] = __builtin_fmaf(w.x, v.x, acc[r]);
                 acc[r] = __builtin_fmaf(w.y, v.y, acc[r]);
                 acc[r] = __builtin_fmaf(w.z, v.z, acc[r]);
@@ -83,6 +90,16 @@ __device__ __forceinline__ void dot_rows(float (&acc)[R], const float* rows, int
 
 __device__ __forceinline__ int state_index(int k, int s) { return ((k >> 2) * kMadeSamples + s) * 4 + (k & 3); }
 
+// block `t` -> LDS at `dst`: the wave requests one grain (64 lanes x 16 bytes) per instruction
+__device__ __forceinline__ void request_block(const MadeInvArgs& a, int t, float* dst, int lane) {
+    const int g0 = a.block_at[t], g1 = a.block_at[t + 1];
+    const char* src = reinterpret_cast<const char*>(a.blocks) + (size_t)g0 * (kMadeGrain * 4) + lane * 16;
+    char* d = reinterpret_cast<char*>(dst);
+    for (int g = 0; g < g1 - g0; ++g)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)g * (kMadeGrain * 4)),
+                                         (__attribute__((address_space(3))) void*)(d + g * (kMadeGrain * 4)), 16, 0, 0);
+}
+
 template <int KT>
 __global__ void __launch_bounds__(kWave) made_rqs_inverse_kernel(const MadeInvArgs a) {
 #pragma clang fp contract(off)
@@ -93,9 +110,13 @@ __global__ void __launch_bounds__(kWave) made_rqs_inverse_kernel(const MadeInvAr
     const bool live = row < a.batch;
     const int64_t rrow = live ? row : a.batch - 1;
     const int vec_floats = (a.Hp >> 2) * kMadeSamples * 4;          // one hidden vector of all 16 samples
+    const int state_floats = (a.Xp >> 2) * kMadeSamples * 4 + a.num_vectors * vec_floats;
     float* xs = lds;                                                // [Xp / 4][16][4]
     float* vecs = lds + (a.Xp >> 2) * kMadeSamples * 4;             // [num_vectors][Hp / 4][16][4]
-    for (int i = lane; i < (a.Xp >> 2) * kMadeSamples * 4 + a.num_vectors * vec_floats; i += kWave) lds[i] = 0.0f;
+    float* buf0 = lds + state_floats;                               // two step blocks
+    float* buf1 = buf0 + a.max_block;
+    request_block(a, 0, buf0, lane);
+    for (int i = lane; i < state_floats; i += kWave) lds[i] = 0.0f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -104,50 +125,61 @@ __global__ void __launch_bounds__(kWave) made_rqs_inverse_kernel(const MadeInvAr
     int my_status = 0;
     const float* zrow = a.z + rrow * a.D;
     float* stream = a.residual ? vecs + a.stream_vec * vec_floats : nullptr;
+    float z_next = zrow[0];
     for (int t = 0; t <= a.T; ++t) {
+        float* blk = (t & 1) ? buf1 : buf0;
+        // block t has landed (requested a whole step ago), every read of the other half is done
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        const float z_t = z_next;
+        if (t < a.T) {
+            request_block(a, t + 1, (t & 1) ? buf0 : buf1, lane);
+            if (t + 1 < a.T) z_next = zrow[t + 1];
+        }
+        const int* hdr = reinterpret_cast<const int*>(blk);
+        const float* rows = blk + kMadeHeader;
+        const float* tail = blk + hdr[12];          // per unit (bias, index), then the feature's P biases
         // ---- 1. hidden units of degree t, layer by layer
         for (int l = 0; l < a.num_linears; ++l) {
-            const int* start = a.ints + a.start_off[l];
-            const int r0 = start[t], r1 = start[t + 1];
-            if (r0 == r1) continue;
+            const int n = hdr[l];
+            if (n == 0) continue;
             const float* src = a.src[l] < 0 ? xs : vecs + a.src[l] * vec_floats;
             const int kp = a.kp[l], chunks = kp >> 2;
-            float* dst = vecs + l * vec_floats;
-            for (int r = r0; r < r1; ++r) {
+            float* dst = a.dst[l] < 0 ? nullptr : vecs + a.dst[l] * vec_floats;
+            for (int u = 0; u < n; ++u) {
                 float acc[1];
-                dot_rows<1>(acc, a.wts + a.w_off[l] + (size_t)r * kp, kp, src, chunks, q, s, 1);
-                const int j = a.ints[a.idx_off[l] + r];
-                float v = acc[0] + a.wts[a.b_off[l] + r];
+                dot_rows<1>(acc, rows, kp, src, chunks, q, s, 1);
+                rows += kp;
+                const int j = __builtin_bit_cast(int, tail[1]);
+                float v = acc[0] + tail[0];
+                tail += 2;
                 const int at = state_index(j, s);
                 if (a.add_stream[l]) v = stream[at] + v;          // residual connection (made.py:128)
                 if (q == 0) {
                     if (a.set_stream[l]) stream[at] = v;
-                    dst[at] = v < 0.0f ? 0.0f : v;                // ReLU'd for the next Linear (NaN stays)
+                    if (dst) dst[at] = v < 0.0f ? 0.0f : v;       // ReLU'd for the next Linear (NaN stays)
                 }
             }
-            // the units just written are inputs of the next Linear (and of this one's later rows: a
-            // unit may be connected to units of its own degree in the previous layer only)
+            // the units just written are inputs of the next Linear
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if (t == a.T) break;
         // ---- 2. feature t's P output rows on the hidden vector as it stands
         const float* fin = vecs + a.final_src * vec_floats;
-        const float* wf = a.wts + a.wf_off + (size_t)t * P * a.Hp;
-        const float* bf = a.wts + a.bf_off + t * P;
+        const float* wf = blk + hdr[13];
         float p[P];
         constexpr int RB = 8;
 #pragma unroll
         for (int p0 = 0; p0 < P; p0 += RB) {
             float acc[RB];
-            dot_rows<RB>(acc, wf + (size_t)p0 * a.Hp, a.Hp, fin, a.Hp >> 2, q, s, P - p0 < RB ? P - p0 : RB);
+            dot_rows<RB>(acc, wf + p0 * a.Hp, a.Hp, fin, a.Hp >> 2, q, s, P - p0 < RB ? P - p0 : RB);
 #pragma unroll
             for (int r = 0; r < RB; ++r)
-                if (p0 + r < P) p[p0 + r] = acc[r] + bf[p0 + r];
+                if (p0 + r < P) p[p0 + r] = acc[r] + tail[p0 + r];
         }
         // ---- 3. invert feature t (rational_quadratic.py:66-181 through the same evaluation as K5)
         float y, l;
-        my_status |= rqs_eval<KT, true, true, true>(zrow[t], p, a.sp, y, l);
+        my_status |= rqs_eval<KT, true, true, true>(z_t, p, a.sp, y, l);
         lad_acc += l;
         if (q == 0) {
             if (t < a.Xp) xs[state_index(t, s)] = y;
@@ -156,6 +188,7 @@ __global__ void __launch_bounds__(kWave) made_rqs_inverse_kernel(const MadeInvAr
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (live && q == 0) a.lad[row] = lad_acc;
     // the final hidden vector of every sample: input of the output layer for features >= T
     {
@@ -171,22 +204,22 @@ __global__ void __launch_bounds__(kWave) made_rqs_inverse_kernel(const MadeInvAr
 
 using namespace nfa;
 
-extern "C" int nfa_made_rqs_inverse_f32(const float* inputs, const float* packed_floats, const int32_t* packed_ints,
+extern "C" int nfa_made_rqs_inverse_f32(const float* inputs, const float* step_blocks, const int32_t* block_starts,
                                         const int32_t* layout, int32_t layout_len, float* outputs,
                                         float* logabsdet, float* hidden_out, int32_t* status, int64_t batch,
                                         int32_t features, int32_t hidden_features, int32_t sequential_steps,
                                         const nfa_rqs_spec* spec, void* stream) {
-    if (batch < 0 || features < 1 || hidden_features < 1 || sequential_steps < 0 || sequential_steps >= features + 1 ||
+    if (batch < 0 || features < 1 || hidden_features < 1 || sequential_steps < 0 || sequential_steps > features ||
         !layout || layout_len < 8)
         return NFA_ERR_INVALID_ARGUMENT;
     MadeInvArgs a;
     int rc = make_dev_spec(spec, &a.sp);
     if (rc != NFA_OK) return rc;
     if (a.sp.beta != 1.0f || !a.sp.linear || (a.sp.K != 8 && a.sp.K != 10)) return NFA_ERR_UNSUPPORTED;
-    // layout: [num_linears, residual, final_src, stream_vec, num_vectors, Hp, Xp, wf_off, bf_off,
-    //          then per Linear: w_off, b_off, idx_off, start_off, kp, src, add_stream, set_stream]
+    // layout: [num_linears, residual, final_src, stream_vec, num_vectors, Hp, Xp, max_block,
+    //          then per Linear: padded_columns, src, dst, add_stream, set_stream]
     const int n = layout[0];
-    if (n < 1 || n > kMadeMaxLinears || layout_len != 9 + 8 * n) return NFA_ERR_INVALID_ARGUMENT;
+    if (n < 1 || n > kMadeMaxLinears || layout_len != 8 + 5 * n) return NFA_ERR_INVALID_ARGUMENT;
     a.num_linears = n;
     a.residual = layout[1];
     a.final_src = layout[2];
@@ -194,39 +227,35 @@ extern "C" int nfa_made_rqs_inverse_f32(const float* inputs, const float* packed
     a.num_vectors = layout[4];
     a.Hp = layout[5];
     a.Xp = layout[6];
-    a.wf_off = layout[7];
-    a.bf_off = layout[8];
+    a.max_block = layout[7];
     for (int l = 0; l < n; ++l) {
-        const int32_t* e = layout + 9 + 8 * l;
-        a.w_off[l] = e[0];
-        a.b_off[l] = e[1];
-        a.idx_off[l] = e[2];
-        a.start_off[l] = e[3];
-        a.kp[l] = e[4];
-        a.src[l] = e[5];
-        a.add_stream[l] = e[6];
-        a.set_stream[l] = e[7];
-        if ((a.kp[l] & 15) != 0 || a.src[l] >= a.num_vectors) return NFA_ERR_INVALID_ARGUMENT;
+        const int32_t* e = layout + 8 + 5 * l;
+        a.kp[l] = e[0];
+        a.src[l] = e[1];
+        a.dst[l] = e[2];
+        a.add_stream[l] = e[3];
+        a.set_stream[l] = e[4];
+        if ((a.kp[l] & 15) != 0 || a.src[l] >= a.num_vectors || a.dst[l] >= a.num_vectors) return NFA_ERR_INVALID_ARGUMENT;
     }
-    if ((a.Hp & 15) != 0 || (a.Xp & 15) != 0 || a.Hp < hidden_features || a.final_src < 0 ||
-        a.final_src >= a.num_vectors || a.num_vectors < n || (a.residual && (a.stream_vec < 0 || a.stream_vec >= a.num_vectors)))
+    if ((a.Hp & 15) != 0 || (a.Xp & 15) != 0 || a.Hp < hidden_features || a.final_src < 0 || a.num_vectors < 1 ||
+        a.final_src >= a.num_vectors || a.max_block < kMadeGrain || (a.max_block % kMadeGrain) != 0 ||
+        (a.residual && (a.stream_vec < 0 || a.stream_vec >= a.num_vectors)))
         return NFA_ERR_INVALID_ARGUMENT;
-    const size_t lds = ((size_t)a.Xp + (size_t)a.num_vectors * a.Hp) * kMadeSamples * sizeof(float);
+    const size_t lds = (((size_t)a.Xp + (size_t)a.num_vectors * a.Hp) * kMadeSamples + 2 * (size_t)a.max_block) * sizeof(float);
     if (lds + 1024 > 160 * 1024) return NFA_ERR_UNSUPPORTED;
     if (batch == 0) return NFA_OK;
-    if (!inputs || !packed_floats || !packed_ints || !outputs || !logabsdet || !hidden_out) return NFA_ERR_INVALID_ARGUMENT;
+    if (!inputs || !step_blocks || !block_starts || !outputs || !logabsdet || !hidden_out) return NFA_ERR_INVALID_ARGUMENT;
     a.z = inputs;
     a.x = outputs;
     a.lad = logabsdet;
     a.hidden = hidden_out;
-    a.wts = packed_floats;
-    a.ints = packed_ints;
+    a.blocks = step_blocks;
+    a.block_at = block_starts;
     a.status = status;
     a.batch = batch;
     a.D = features;
     a.H = hidden_features;
     a.T = sequential_steps;
-    a.P = a.sp.P;
     void (*kern)(const MadeInvArgs) = a.sp.K == 8 ? made_rqs_inverse_kernel<8> : made_rqs_inverse_kernel<10>;
     if (lds > 64 * 1024) {
         static bool raised[2] = {false, false};

@@ -514,9 +514,12 @@ def _standard_normal_log_prob_launch(z, logabsdet):
 
 
 def pack_made_schedule(net, sequential_steps, params_per_feature):
-    """Packs a MADE (transforms/made.py) for K12 (csrc/made_inverse.hip): every hidden Linear's masked
-    weight rows sorted by degree, the CSR starts by degree, and the output rows of the first
-    `sequential_steps` features.  Returns (floats, ints, layout list) -- layout in include/nflows_amd.h."""
+    """Packs a MADE (transforms/made.py) for K12 (csrc/made_inverse.hip): one contiguous block per step
+    t = 0 .. T holding everything the step reads -- header (units per hidden Linear [12 ints], offset of
+    the tail section, offset of the output rows), the masked weight rows of the units of degree t layer
+    after layer (zero-padded to multiples of 16 columns), feature t's P rows of the output layer (t < T),
+    and the tail section: (bias, unit index) per unit, then the feature's P biases -- padded to 1 KB.
+    Returns (blocks fp32, block starts int32 [T + 2] in 1 KB grains, layout list)."""
     T, P = int(sequential_steps), int(params_per_feature)
     dev = net.final_layer.weight.device
     H = net.initial_layer.weight.shape[0]
@@ -527,59 +530,65 @@ def pack_made_schedule(net, sequential_steps, params_per_feature):
     for block in net.blocks:
         linears += list(block.linear_layers) if residual else [block.linear]
     n = len(linears)
-    floats, ints, per_layer = [], [], []
-    foff = ioff = 0
-
-    def push_f(t):
-        nonlocal foff
-        t = t.reshape(-1).float()
-        pad = (-t.numel()) % 4        # every block starts 16-byte aligned
-        if pad:
-            t = torch.cat((t, t.new_zeros(pad)))
-        floats.append(t)
-        at = foff
-        foff += t.numel()
-        return at
-
-    def push_i(t):
-        nonlocal ioff
-        t = t.reshape(-1).to(torch.int32)
-        ints.append(t)
-        at = ioff
-        ioff += t.numel()
-        return at
-
+    HDR, GRAIN = 16, 256
+    per_layer, sorted_rows, sorted_bias, orders, starts = [], [], [], [], []
     for l, lin in enumerate(linears):
-        w = (lin.weight.detach() * lin.mask).float()
-        deg = lin.degrees.to(torch.int64)
+        w = (lin.weight.detach() * lin.mask).float().cpu()
+        deg = lin.degrees.to(torch.int64).cpu()
         order = torch.argsort(deg, stable=True)
         counts = torch.bincount(deg, minlength=T + 2)[:T + 2]
-        start = torch.cat((counts.new_zeros(1), torch.cumsum(counts, 0)))[:T + 2]   # start[d] = #units of degree < d
+        start = torch.cat((counts.new_zeros(1), torch.cumsum(counts, 0)))   # start[d] = #units of degree < d
+        kp = Xp if l == 0 else Hp
         if l == 0:
-            kp = Xp
             w = w[:, :min(Xp, w.shape[1])]      # features >= T meet zero masks in every hidden unit
-        else:
-            kp = Hp
         w = torch.cat((w, w.new_zeros(w.shape[0], kp - w.shape[1])), dim=1)
-        bias = lin.bias.detach().float() if lin.bias is not None else w.new_zeros(w.shape[0])
-        w_off = push_f(w.index_select(0, order))
-        b_off = push_f(bias.index_select(0, order))
-        idx_off = push_i(order)
-        start_off = push_i(start)
+        bias = lin.bias.detach().float().cpu() if lin.bias is not None else w.new_zeros(w.shape[0])
+        sorted_rows.append(w.index_select(0, order))
+        sorted_bias.append(bias.index_select(0, order))
+        orders.append(order.to(torch.int32))
+        starts.append(start.tolist())
         is_upper = residual and l > 0 and l % 2 == 0          # second Linear of a residual block
-        per_layer.append([w_off, b_off, idx_off, start_off, kp, l - 1,
-                          1 if is_upper else 0, 1 if residual and (l == 0 or is_upper) else 0])
+        last = l == n - 1
+        dst = -1 if (residual and last) else l                # (the residual stream itself feeds the output layer)
+        per_layer.append([kp, l - 1, dst, 1 if is_upper else 0, 1 if residual and (l == 0 or is_upper) else 0])
     final = net.final_layer
     D = final.weight.shape[0] // P
-    wf = (final.weight.detach() * final.mask).float().view(D, P, H)[:T]
+    wf = (final.weight.detach() * final.mask).float().cpu().view(D, P, H)[:T]
     wf = torch.cat((wf, wf.new_zeros(T, P, Hp - H)), dim=2)
-    wf_off = push_f(wf)
-    bf_off = push_f(final.bias.detach().float().view(D, P)[:T])
-    num_vectors = n + (1 if residual else 0)
-    layout = [n, int(residual), n if residual else n - 1, n if residual else -1, num_vectors, Hp, Xp, wf_off, bf_off]
+    bf = final.bias.detach().float().cpu().view(D, P)[:T]
+    blocks, block_at, at = [], [], 0
+    for t in range(T + 1):
+        header = torch.zeros(HDR, dtype=torch.int32)
+        parts, tail = [], []
+        for l in range(n):
+            s0, s1 = starts[l][t], starts[l][t + 1]
+            header[l] = s1 - s0
+            if s1 > s0:
+                parts.append(sorted_rows[l][s0:s1].reshape(-1))
+                pair = torch.stack((sorted_bias[l][s0:s1], orders[l][s0:s1].view(torch.float32)), dim=1)
+                tail.append(pair.reshape(-1))
+        rows_len = sum(p_.numel() for p_ in parts)
+        header[13] = HDR + rows_len                         # output rows
+        if t < T:
+            parts.append(wf[t].reshape(-1))
+            tail.append(bf[t])
+        body_len = sum(p_.numel() for p_ in parts)
+        header[12] = HDR + body_len                         # tail section
+        block = torch.cat([header.view(torch.float32)] + parts + tail)
+        pad = (-block.numel()) % GRAIN
+        if pad:
+            block = torch.cat((block, block.new_zeros(pad)))
+        block_at.append(at)
+        at += block.numel() // GRAIN
+        blocks.append(block)
+    block_at += [at, at]
+    max_block = max(b.numel() for b in blocks)
+    num_vectors = n                                         # residual: n - 1 ReLU'd vectors + the stream
+    final_src = n - 1                                       # residual: the stream lives in the last vector's place
+    layout = [n, int(residual), final_src, n - 1 if residual else -1, num_vectors, Hp, Xp, max_block]
     for e in per_layer:
         layout += e
-    return torch.cat(floats).contiguous().to(dev), torch.cat(ints).contiguous().to(dev), layout
+    return (torch.cat(blocks).contiguous().to(dev), torch.tensor(block_at, dtype=torch.int32, device=dev), layout)
 
 
 def made_rqs_inverse(inputs, schedule, hidden_features, sequential_steps, spec):
