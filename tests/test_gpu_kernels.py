@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import LAD_TOL, OUT_TOL, assert_fp32_parity, assert_sibling_spline_parity, parse_kwargs
+from helpers import LAD_TOL, OUT_TOL, assert_fp32_parity, assert_sibling_spline_parity, conditioning, parse_kwargs
 from oracle import capi
 
 pytestmark = pytest.mark.gpu
@@ -53,8 +53,10 @@ def test_rqs_elementwise_golden(ops, golden_dir):
         y, lad = ops.rqs_elementwise(dev(x), dev(uw), dev(uh), dev(ud), spec, inverse=inv)
         ops.check_status()
         y, lad = host(y), host(lad)
-        assert_fp32_parity(y, g[name + "/y"], g[name + "/y64"], OUT_TOL, name + " y", bulk=0.97)
-        assert_fp32_parity(lad, g[name + "/lad"], g[name + "/lad64"], LAD_TOL, name + " lad", bulk=0.97)
+        _, ospec = _spec_pair(ops, K, **kw)
+        cy, cl = conditioning(lambda *a: capi.rqs_elementwise(*a, ospec, inverse=inv)[:2], (x, uw, uh, ud), (0, 1, 2, 3))
+        assert_fp32_parity(y, g[name + "/y"], g[name + "/y64"], OUT_TOL, name + " y", cond=cy)
+        assert_fp32_parity(lad, g[name + "/lad"], g[name + "/lad64"], LAD_TOL, name + " lad", cond=cl)
         if kw.get("tails") == "linear":
             tb = np.float32(kw["tail_bound"])
             outside = ~((x >= -tb) & (x <= tb))
@@ -78,8 +80,9 @@ def test_rqs_elementwise_oracle(ops, K, inverse):
     oy, ol, st = capi.rqs_elementwise(x, uw, uh, ud, ospec, inverse=inverse)
     ty, tl, _ = capi.rqs_elementwise(*(a.astype(np.float64) for a in (x, uw, uh, ud)), ospec, inverse=inverse)
     assert st == 0
-    assert_fp32_parity(host(y), oy, ty, OUT_TOL, "y K=%d" % K)
-    assert_fp32_parity(host(lad), ol, tl, LAD_TOL, "lad K=%d" % K)
+    cy, cl = conditioning(lambda *a: capi.rqs_elementwise(*a, ospec, inverse=inverse)[:2], (x, uw, uh, ud), (0, 1, 2, 3))
+    assert_fp32_parity(host(y), oy, ty, OUT_TOL, "K5 y K=%d inverse=%s" % (K, inverse), cond=cy)
+    assert_fp32_parity(host(lad), ol, tl, LAD_TOL, "K5 lad K=%d inverse=%s" % (K, inverse), cond=cl)
 
 
 def test_rqs_elementwise_strided_views(ops):
@@ -175,8 +178,17 @@ def test_coupling_layers_golden(ops, golden_dir):
                 y, lad = ops.affine_coupling(dev(x), dev(params), dev(tidx), act, inverse=inv)
             ops.check_status()
             y, lad = host(y), host(lad)
-            assert_fp32_parity(y, ry, ry64, OUT_TOL, name + direction + " y", bulk=0.97)
-            assert_fp32_parity(lad, rl, rl64, 2 * LAD_TOL, name + direction + " lad", bulk=0.9)
+            if kind == "rq":
+                ospec = capi.make_spec(cfg["K"], tails=cfg["tails"], tail_bound=cfg["tail_bound"],
+                                       wh_divisor=float(np.sqrt(H)) if H else 0.0)
+                f64 = lambda xx, pp: capi.rqs_coupling(xx, pp, tidx, ospec, inverse=inv)[:2]      # noqa: E731
+            else:
+                oact = {"affine_default": capi.AFFINE_DEFAULT, "affine_general": capi.AFFINE_GENERAL,
+                        "affine_additive": capi.AFFINE_ADDITIVE}[kind]
+                f64 = lambda xx, pp: capi.affine_coupling(xx, pp, tidx, oact, inverse=inv)[:2]    # noqa: E731
+            cy, cl = conditioning(f64, (x.astype(np.float64), params.astype(np.float64)), (0, 1))
+            assert_fp32_parity(y, ry, ry64, OUT_TOL, name + direction + " y", cond=cy)
+            assert_fp32_parity(lad, rl, rl64, LAD_TOL, name + direction + " lad", cond=cl)
             ident = np.setdiff1d(np.arange(x.shape[1]), tidx)
             assert np.array_equal(y[:, ident], x[:, ident]), name  # bit-exact pass-through
             if kind == "affine_additive":
@@ -217,8 +229,11 @@ def test_rqs_coupling_oracle(ops, B, D, K, tails, inverse):
     ty, tl, _ = capi.rqs_coupling(x.astype(np.float64), params.astype(np.float64), tidx, ospec, inverse=inverse)
     assert st == 0
     y, lad = host(y), host(lad)
-    assert_fp32_parity(y, oy, ty, OUT_TOL, "y")
-    assert_fp32_parity(lad, ol, tl, LAD_TOL * max(1, dt // 32), "lad")
+    cy, cl = conditioning(lambda xx, pp: capi.rqs_coupling(xx, pp, tidx, ospec, inverse=inverse)[:2],
+                          (x.astype(np.float64), params.astype(np.float64)), (0, 1))
+    what = "K1 B=%d D=%d K=%d tails=%s inverse=%s " % (B, D, K, tails, inverse)
+    assert_fp32_parity(y, oy, ty, OUT_TOL, what + "y", cond=cy)
+    assert_fp32_parity(lad, ol, tl, LAD_TOL, what + "lad", cond=cl)
     ident = np.nonzero(~mask)[0]
     assert np.array_equal(y[:, ident], x[:, ident])
 
@@ -261,8 +276,10 @@ def test_affine_oracle_and_given_scale(ops):
                 y, lad = ops.affine_coupling(dev(x), dev(params), dev(tidx), act, inverse=inv)
                 oy, ol, _ = capi.affine_coupling(x, params, tidx, act, inverse=inv)
                 ty, tl, _ = capi.affine_coupling(x.astype(np.float64), params.astype(np.float64), tidx, act, inverse=inv)
-                assert_fp32_parity(host(y), oy, ty, OUT_TOL, "affine y")
-                assert_fp32_parity(host(lad), ol, tl, LAD_TOL * max(1, dt // 32), "affine lad")
+                cy, cl = conditioning(lambda xx, pp: capi.affine_coupling(xx, pp, tidx, act, inverse=inv)[:2],
+                                      (x.astype(np.float64), params.astype(np.float64)), (0, 1))
+                assert_fp32_parity(host(y), oy, ty, OUT_TOL, "K2 y act=%d inverse=%s" % (act, inv), cond=cy)
+                assert_fp32_parity(host(lad), ol, tl, LAD_TOL, "K2 lad act=%d inverse=%s" % (act, inv), cond=cl)
         # arbitrary activation evaluated by the caller
         params = rng.randn(B, 2 * dt).astype(np.float32)
         scale = np.exp(0.3 * params[:, dt:]).astype(np.float32)
