@@ -64,3 +64,23 @@ def ar_rq_flow(features=784, hidden_features=256, num_bins=8, tail_bound=3.0, nu
         features=features, hidden_features=hidden_features, num_bins=num_bins, tails="linear",
         tail_bound=tail_bound, num_blocks=num_blocks)
     return Flow(CompositeTransform([t]), StandardNormal([features]))
+
+
+def conditional_rq_nsf_flow(num_layers=3, features=16, num_bins=8, hidden_features=128, raw_context=5,
+                            context_features=12, tail_bound=3.0, seed=7):
+    """A conditional RQ-NSF coupling flow: ResidualNet conditioners with `context_features` (context
+    concatenated in front of the initial layer, GLU gate per block: resnet.py:9-52, :92-100), the raw
+    context embedded by a Linear (flows/base.py:42-49).  The construction order matches
+    tests/golden/make_golden.py:conditional_flow_case, so the seed reproduces its weights."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    layers = []
+    for i in range(num_layers):
+        layers.append(RandomPermutation(features))
+        layers.append(PiecewiseRationalQuadraticCouplingTransform(
+            mask=create_alternating_binary_mask(features, even=(i % 2 == 0)),
+            transform_net_create_fn=lambda i_, o_: ResidualNet(
+                i_, o_, hidden_features=hidden_features, context_features=context_features, num_blocks=2),
+            num_bins=num_bins, tails="linear", tail_bound=tail_bound))
+    return Flow(CompositeTransform(layers), StandardNormal([features]),
+                embedding_net=torch.nn.Linear(raw_context, context_features))

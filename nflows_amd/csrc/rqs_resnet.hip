@@ -50,6 +50,8 @@ struct ResnetArgs {
     const int32_t* redo;  // optional [batch / 128]: only row blocks with a non-zero entry are processed
     int normal, skip_out;  // NFA_FLAG_STANDARD_NORMAL_LOG_PROB / NFA_FLAG_SKIP_OUTPUTS
     float log_z;           // 0.5 D log(2 pi)
+    const float* ctx;      // [B, ce] context rows of the conditioners (resnet.py:92-100), or null
+    int ce;                // context features (columns of ctx)
 };
 
 // ---- the final layer with the spline evaluation woven into its MFMAs ------------------------
@@ -177,6 +179,38 @@ __device__ __forceinline__ void gemm_tile_pumped(f32x16& acc, const bf16x8 (&ph)
     stage_pumped<UNIT, 1>(acc, ph, pm, pl, sm, lane, fa, fb, sp);
 }
 
+// one 32-row tile of a block's context layer: acc += W_c_tile[32 x ce] x context^T.  ONE stage
+// ([3 pieces][4 k-steps][64 lanes] x 16 bytes, k-steps beyond ce zero); the context pieces are made on
+// the spot from the wave's context tile in LDS (k = ks*16 + half*8 + j)
+__device__ __forceinline__ void gemm_context_tile(f32x16& acc, const float* s_ctx, int ce, int half, int r,
+                                                  WeightStream& sm, int lane) {
+    stream_request(sm);
+    const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
+    const int nks = (ce + 15) >> 4;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+        if (k4 < nks) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = k4 * 16 + half * 8 + j;
+                const float cv = s_ctx[(i < ce ? i : 0) * kRowPad + r];
+                v[j] = i < ce ? cv : 0.0f;
+            }
+            bf16x2 hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) split3(vec2f{v[j2 * 2], v[j2 * 2 + 1]}, hh[j2], mm[j2], ll[j2]);
+            const bf16x8 bh = join4(hh[0], hh[1], hh[2], hh[3]), bm = join4(mm[0], mm[1], mm[2], mm[3]),
+                         bl = join4(ll[0], ll[1], ll[2], ll[3]);
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(0 * 4 + k4) * 64]);
+            const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(1 * 4 + k4) * 64]);
+            const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(2 * 4 + k4) * 64]);
+            NFA_MFMA6(acc, ah, am, al, bh, bm, bl);
+        }
+    }
+    stream_advance(sm);
+}
+
 // PRESCALED: 1 = the host folded 1/sqrt(hidden) into the width / height rows of the final layer,
 // 2 = 1/sqrt(hidden) and log2(e) (NFA_FLAG_LOGITS_LOG2E: softmax numerators are then one v_exp_f32)
 // INIT_KS: k-steps of the initial layer, 2 (d_i <= 32) or 4 (d_i <= 64)
@@ -188,7 +222,10 @@ __device__ __forceinline__ void gemm_tile_pumped(f32x16& acc, const bf16x8 (&ph)
 // spline results back to, fixed slots given by its table (the host composes all the permutations
 // between the layers into these tables), and the last table says which slot ends up at which
 // output position.  Weights and biases of all layers form one stream in execution order.
-template <bool INVERSE, int PRESCALED, int INIT_KS, int PIPE = 0, int KB = 8>  // PIPE: 0 plain loop, 1 woven, 2 woven with FlatSteps<FAST>
+// CTX: the conditioners take a context (resnet.py:9-52, :92-100): its `ce` columns follow the identity
+// features in the initial layer's input, and every residual block's result is multiplied by
+// sigmoid(context_layer(context)) before the skip connection (F.glu of the concatenation).
+template <bool INVERSE, int PRESCALED, int INIT_KS, int PIPE = 0, int KB = 8, bool CTX = false>  // PIPE: 0 plain loop, 1 woven, 2 woven with FlatSteps<FAST>
 __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs a) {
     static_assert(KB == 8 || (KB == 10 && PIPE != 1 && PRESCALED == 1), "10 bins: plain loop, or woven with the shorter sequence");
     // dynamic LDS: the weight ring, then per wave a [D][33] row tile
@@ -225,6 +262,8 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
     // PIPE: the final layer's biases of the current layer, staged once per layer (the woven loop
     // cannot afford an L2 round trip in front of every tile)
     float* s_fbias = lds_dyn + kRing * kStageVec4 * 4 + (kBlock / kWave) * D * kRowPad;
+    // CTX: per wave the [ce][33] context tile of its 32 rows, behind the final-layer biases
+    float* s_ctx = s_fbias + (PIPE != 0 ? dt * (KB == 10 ? 32 : 24) : 0) + wave * a.ce * kRowPad;
     const int groups = dt >> 2;
     const int64_t num_quads = a.batch >> 7;
     int tb = 0;  // which half of s_tab holds the current layer's table
@@ -267,6 +306,13 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                 }
             }
         }
+        if (CTX) {
+            const float* crow = a.ctx + row0 * a.ce;
+            for (int e = lane; e < 32 * a.ce; e += kWave) {
+                const int rr = e / a.ce, c = e - rr * a.ce;
+                s_ctx[c * kRowPad + rr] = crow[e];
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
@@ -294,8 +340,15 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int i = ks * 16 + half * 8 + j;
-                    const float xv = s_row[tab[kTabId + i] * kRowPad + r];
-                    v[j] = i < di ? xv : 0.0f;
+                    if (CTX) {   // input of the initial layer = [identity features | context] (resnet.py:93-94)
+                        const int ic = i - di;
+                        const float xv = i < di ? s_row[tab[kTabId + (i < 64 ? i : 0)] * kRowPad + r]
+                                                : s_ctx[(ic < a.ce ? ic : 0) * kRowPad + r];
+                        v[j] = i < di + a.ce ? xv : 0.0f;
+                    } else {
+                        const float xv = s_row[tab[kTabId + i] * kRowPad + r];
+                        v[j] = i < di ? xv : 0.0f;
+                    }
                 }
                 bf16x2 hh[4], mm[4], ll[4];
 #pragma unroll
@@ -320,7 +373,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
             if (PIPE != 0) {
                 // (every wave has passed a stage barrier of this layer: nobody reads the previous
                 // layer's biases any more; the blocks' barriers come before the first use)
-                const float* fbias = a.bias + (size_t)layer * a.bias_per_layer + 128 + 256 * a.num_blocks;
+                const float* fbias = a.bias + (size_t)layer * a.bias_per_layer + 128 + (CTX ? 384 : 256) * a.num_blocks;
                 for (int i = tid; i < dt * (KB == 10 ? 32 : 24); i += kBlock) s_fbias[i] = fbias[i];
                 // without residual blocks the final layer follows at once: no stage barrier in between
                 if (a.num_blocks == 0) __syncthreads();
@@ -345,17 +398,40 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                 }
                 NFA_STAMP()
                 f32x16 v[4];
+                if constexpr (CTX) {
+                    // temps = W_1 relu(u) + b_1; h += temps * sigmoid(W_c context + b_c)   (resnet.py:46-52)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    load_bias_tile(v[t], bias + 128 + t * 32);
-                    add_pieces(v[t], 0, ph[2 * t], pm[2 * t], pl[2 * t]);
-                    add_pieces(v[t], 8, ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
+                    for (int t = 0; t < 4; ++t) load_bias_tile(v[t], bias + 128 + t * 32);
+                    gemm_kmajor<false, 8>(v, qh, qm, ql, sm, lane);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        f32x16 gate;
+                        load_bias_tile(gate, bias + 256 + t * 32);
+                        gemm_context_tile(gate, s_ctx, a.ce, half, r, sm, lane);
+                        f32x16 hv = {0};
+                        add_pieces(hv, 0, ph[2 * t], pm[2 * t], pl[2 * t]);
+                        add_pieces(hv, 8, ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const float sg = 1.0f / (1.0f + expf(-gate[q]));
+                            v[t][q] = hv[q] + v[t][q] * sg;
+                        }
+                        tile_to_pieces<false>(v[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
+                    }
+                    bias += 384;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        load_bias_tile(v[t], bias + 128 + t * 32);
+                        add_pieces(v[t], 0, ph[2 * t], pm[2 * t], pl[2 * t]);
+                        add_pieces(v[t], 8, ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
+                    }
+                    gemm_kmajor<false, 8>(v, qh, qm, ql, sm, lane);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        tile_to_pieces<false>(v[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
+                    bias += 256;
                 }
-                gemm_kmajor<false, 8>(v, qh, qm, ql, sm, lane);
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    tile_to_pieces<false>(v[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
-                bias += 256;
                 NFA_STAMP()
             }
 
@@ -560,7 +636,8 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
                                 int32_t* status, int64_t batch, int32_t features, int32_t num_transform,
                                 int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
                                 const nfa_rqs_spec* spec, int32_t flags, void* stream,
-                                const int32_t* redo = nullptr) {
+                                const int32_t* redo = nullptr, const float* context = nullptr,
+                                int32_t context_features = 0) {
     if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_LOGITS_LOG2E |
                   NFA_FLAG_STANDARD_NORMAL_LOG_PROB | NFA_FLAG_SKIP_OUTPUTS))
         return NFA_ERR_INVALID_ARGUMENT;
@@ -578,10 +655,18 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         num_transform > 64 || num_identity > 64 || features > 128 || (features & 3) != 0 ||
         (batch & 127) != 0 || num_blocks > 64 || num_layers > 4096)
         return NFA_ERR_UNSUPPORTED;
+    const bool with_ctx = context_features > 0;
+    if (context_features < 0) return NFA_ERR_INVALID_ARGUMENT;
+    // with a context: 8 bins, the default evaluation, identity features + context within the initial
+    // layer's 64 input columns
+    if (with_ctx && (a.sp.K != 8 || (flags & NFA_FLAG_LOGITS_LOG2E) || num_identity + context_features > 64 || redo))
+        return NFA_ERR_UNSUPPORTED;
     if (batch == 0) return NFA_OK;
     if (!inputs || !weights_packed || !bias_packed || !tables || !logabsdet ||
-        (!outputs && !(flags & NFA_FLAG_SKIP_OUTPUTS)))
+        (!outputs && !(flags & NFA_FLAG_SKIP_OUTPUTS)) || (with_ctx && !context))
         return NFA_ERR_INVALID_ARGUMENT;
+    a.ctx = with_ctx ? context : nullptr;
+    a.ce = context_features;
     a.normal = (flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB) ? 1 : 0;
     a.skip_out = (flags & NFA_FLAG_SKIP_OUTPUTS) ? 1 : 0;
     a.log_z = standard_normal_log_z(features);
@@ -598,9 +683,9 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     a.di = num_identity;
     a.num_blocks = num_blocks;
     a.num_layers = num_layers;
-    const int init_ks = num_identity > 32 ? 4 : 2;
-    a.num_stages = init_ks + 16 * num_blocks + 2 * (num_transform * rows_per_feature / 32);
-    a.bias_per_layer = 128 + 256 * num_blocks + num_transform * rows_per_feature;
+    const int init_ks = num_identity + context_features > 32 ? 4 : 2;
+    a.num_stages = init_ks + (with_ctx ? 20 : 16) * num_blocks + 2 * (num_transform * rows_per_feature / 32);
+    a.bias_per_layer = 128 + (with_ctx ? 384 : 256) * num_blocks + num_transform * rows_per_feature;
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = g_k7_trace;
     a.redo = redo;
@@ -615,8 +700,10 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     // (with the log2(e) fold only the default woven form exists)
     const bool pipe = use_pipe && ((a.sp.K == 8 && (!(flags & NFA_FLAG_LOGITS_LOG2E) || use_pipe == 2)) ||
                                   (a.sp.K == 10 && use_pipe == 2));
+    if (with_ctx && !(pipe && use_pipe == 2)) return NFA_ERR_UNSUPPORTED;
     const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float) +
-                       (pipe ? (size_t)num_transform * rows_per_feature * sizeof(float) : 0);
+                       (pipe ? (size_t)num_transform * rows_per_feature * sizeof(float) : 0) +
+                       (size_t)(kBlock / kWave) * context_features * kRowPad * sizeof(float);
     int64_t blocks = batch >> 7;
     const int64_t per_cu = lds + 2048 <= 80 * 1024 ? 2 : 1;
     const int64_t cap = (int64_t)device_cu_count() * per_cu;
@@ -653,7 +740,18 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 1> : rqs_resnet_kernel<false, 1, 4, 1>;
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 1> : rqs_resnet_kernel<false, 1, 2, 1>;
     }
-    if (lds > 64 * 1024) {
+    if (with_ctx) {
+        if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 2, 8, true> : rqs_resnet_kernel<false, 1, 4, 2, 8, true>;
+        else kern = inv ? rqs_resnet_kernel<true, 1, 2, 2, 8, true> : rqs_resnet_kernel<false, 1, 2, 2, 8, true>;
+    }
+    if (with_ctx && lds > 64 * 1024) {
+        static bool raised_ctx[4] = {false, false, false, false};
+        const int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0);
+        if (!raised_ctx[which]) {
+            NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+            raised_ctx[which] = true;
+        }
+    } else if (lds > 64 * 1024) {
         static bool raised[28] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
         const int which = a.sp.K == 10 ? (pipe ? 24 : 12) + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
                           : (pipe && use_pipe == 2) ? 16 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (l2e ? 4 : 0)
@@ -704,4 +802,17 @@ extern "C" int nfa_rqs_flow_resnet_redo_f32(const float* inputs, const void* wei
     return launch_resnet_layers(inputs, weights_packed, bias_packed, flow_tables, num_layers, outputs, logabsdet,
                                 status, batch, features, num_transform, num_identity, hidden_features, num_blocks,
                                 spec, flags, stream, redo_blocks);
+}
+
+extern "C" int nfa_rqs_flow_resnet_context_f32(const float* inputs, const float* context, int32_t context_features,
+                                               const void* weights_packed, const float* bias_packed,
+                                               const int32_t* flow_tables, int32_t num_layers, float* outputs,
+                                               float* logabsdet, int32_t* status, int64_t batch, int32_t features,
+                                               int32_t num_transform, int32_t num_identity,
+                                               int32_t hidden_features, int32_t num_blocks,
+                                               const nfa_rqs_spec* spec, int32_t flags, void* stream) {
+    if (context_features < 1) return NFA_ERR_INVALID_ARGUMENT;
+    return launch_resnet_layers(inputs, weights_packed, bias_packed, flow_tables, num_layers, outputs, logabsdet,
+                                status, batch, features, num_transform, num_identity, hidden_features, num_blocks,
+                                spec, flags, stream, nullptr, context, context_features);
 }

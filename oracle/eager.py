@@ -108,12 +108,12 @@ def rqs_unconstrained(x, uw, uh, ud, inverse=False, tail_bound=1.0, min_bin_widt
 
 
 def rq_coupling_layer(x, net, identity_idx, transform_idx, num_bins, tail_bound, hidden_features,
-                      inverse=False):
+                      inverse=False, context=None):
     """CouplingTransform.forward/inverse + PiecewiseRationalQuadraticCouplingTransform with
     tails="linear" (coupling.py:73-130, 279-293, 549-582)."""
     ident = x[:, identity_idx]
     xt = x[:, transform_idx]
-    params = net(ident, None)
+    params = net(ident, context)          # (resnet.py:92-100: context concatenated, GLU gate per block)
     b, dt = xt.shape
     params = params.reshape(b, dt, -1)
     uw = params[..., :num_bins]
@@ -173,7 +173,7 @@ def ar_rq_layer_forward(x, made, num_bins, tail_bound):
     return y, torch.sum(lad, dim=[1])
 
 
-def _layer(t, h, inverse):
+def _layer(t, h, inverse, context=None):
     name = type(t).__name__
     if name.endswith("Permutation"):
         perm = torch.argsort(t._permutation) if inverse else t._permutation  # permutations.py:22-45
@@ -182,7 +182,8 @@ def _layer(t, h, inverse):
     if name == "PiecewiseRationalQuadraticCouplingTransform":
         return rq_coupling_layer(h, t.transform_net, t.identity_features, t.transform_features,
                                  t.num_bins, t.tail_bound,
-                                 getattr(t.transform_net, "hidden_features", None), inverse=inverse)
+                                 getattr(t.transform_net, "hidden_features", None), inverse=inverse,
+                                 context=context)
     if name == "AffineCouplingTransform":
         return affine_coupling_layer(h, t.transform_net, t.identity_features, t.transform_features,
                                      inverse=inverse)
@@ -191,20 +192,21 @@ def _layer(t, h, inverse):
     raise NotImplementedError(name + (" inverse" if inverse else ""))
 
 
-def flow_transform(flow, x, inverse=False):
+def flow_transform(flow, x, inverse=False, context=None):
     """CompositeTransform.forward / .inverse (transforms/base.py:45-60) of a flow built with
     nflows_amd classes (used only for their parameters, buffers and conditioner modules, all on
-    CPU): returns (outputs, total logabsdet)."""
+    CPU): returns (outputs, total logabsdet).  `context`: already embedded."""
     total = x.new_zeros(x.shape[0])
     h = x
     layers = list(flow._transform._transforms)
     for t in (reversed(layers) if inverse else layers):
-        h, lad = _layer(t, h, inverse)
+        h, lad = _layer(t, h, inverse, context)
         total += lad
     return h, total
 
 
-def flow_log_prob(flow, x):
-    """Flow._log_prob (flows/base.py:42-49)."""
-    z, total = flow_transform(flow, x)
+def flow_log_prob(flow, x, context=None):
+    """Flow._log_prob (flows/base.py:42-49): the context goes through the embedding net first."""
+    embedded = flow._embedding_net(context) if context is not None else None
+    z, total = flow_transform(flow, x, context=embedded)
     return standard_normal_log_prob(z) + total

@@ -930,6 +930,64 @@ def flow_h128_case():
     print("flows_h128: 1 case")
 
 
+def conditional_flow_case():
+    """A conditional flow at the whole-layer kernels' layer shape: RandomPermutation + RQ coupling with
+    ResidualNet(H = 128, 2 blocks, context_features = 12) conditioners (resnet.py:9-52: context
+    concatenated in front of the initial layer, GLU gate per block), context embedded by a Linear
+    (flows/base.py:42-49).  Weights rebuilt from the seed (checksums stored), as in flow_h128_case."""
+    out = {}
+    L, D, K, H, B, C, E = 3, 16, 8, 128, 256, 5, 12
+    torch.manual_seed(7)
+    layers = []
+    for i in range(L):
+        layers.append(RandomPermutation(D))
+        layers.append(PiecewiseRationalQuadraticCouplingTransform(
+            mask=torchutils.create_alternating_binary_mask(D, even=(i % 2 == 0)),
+            transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=H, context_features=E,
+                                                               num_blocks=2),
+            num_bins=K, tails="linear", tail_bound=3.0))
+    flow = Flow(CompositeTransform(layers), StandardNormal([D]), embedding_net=nn.Linear(C, E))
+    with torch.no_grad():
+        for p_name, p in flow.named_parameters():
+            if "final_layer" in p_name:
+                p.mul_(4.0)
+            elif "linear_layers.1" in p_name:
+                p.mul_(30.0)
+            elif "context_layer" in p_name:
+                p.mul_(3.0)
+    g = torch.Generator().manual_seed(77)
+    x = 1.2 * torch.randn(B, D, generator=g)
+    noise = torch.randn(B, D, generator=g)
+    ctx = torch.randn(B, C, generator=g)
+    flow.eval()
+    with torch.no_grad():
+        emb = flow._embedding_net(ctx)
+        lp = flow.log_prob(x, context=ctx)
+        z, lad = flow._transform(x, context=emb)
+        xs, lad_inv = flow._transform.inverse(noise, context=emb)
+        f64 = flow.double()
+        emb64 = f64._embedding_net(ctx.double())
+        lp64 = f64.log_prob(x.double(), context=ctx.double())
+        z64, lad64 = f64._transform(x.double(), context=emb64)
+        xs64, ladi64 = f64._transform.inverse(noise.double(), context=emb64)
+        flow.float()
+    name = "nsf_context_h128"
+    for k, v in dict(x=x, noise=noise, context=ctx, log_prob=lp, z=z, lad=lad, inv_x=xs, inv_lad=lad_inv,
+                     log_prob64=lp64, z64=z64, lad64=lad64, inv_x64=xs64, inv_lad64=ladi64).items():
+        out[name + "/" + k] = npy(v)
+    names, sums = [], []
+    for k, v in flow.state_dict().items():
+        names.append(k)
+        sums.append([float(v.double().sum()), float(v.double().abs().sum())])
+    out[name + "/param_names"] = np.array(names).astype(str)
+    out[name + "/param_checksums"] = np.array(sums, dtype=np.float64)
+    out["meta"] = np.array([(name, repr(dict(kind="rq_nsf_context", L=L, D=D, K=K, H=H, B=B, C=C, E=E, tail_bound=3.0,
+                                              seed=7, scale_final=4.0, scale_linear1=30.0, scale_context=3.0)))],
+                           dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "flows_context.npz"), **out)
+    print("flows_context: 1 case")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ar":
         sibling_autoregressive_cases()
@@ -947,6 +1005,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "h128":
         flow_h128_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "context":
+        conditional_flow_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "grads":
         grad_cases()

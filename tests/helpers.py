@@ -136,3 +136,29 @@ def assert_sibling_spline_parity(got, ref, truth, tol, cap, what=""):
         e_got = np.abs(got[fin].astype(np.float64) - truth[fin]).max()
         e_ref = np.abs(ref[fin].astype(np.float64) - truth[fin]).max()
         assert e_got <= max(4.0 * e_ref, cap), "%s: max err vs fp64 %.3e (reference fp32: %.3e)" % (what, e_got, e_ref)
+
+
+def golden_conditional_flow(golden_dir):
+    """The conditional flow of tests/golden/flows_context.npz rebuilt from its seed (weights are not
+    stored; per-parameter checksums are, and are checked here).  Returns (flow on CPU, npz)."""
+    import torch
+    from nflows_amd import configs
+    g = np.load(os.path.join(golden_dir, "flows_context.npz"))
+    name, cfg = g["meta"][0]
+    cfg = parse_kwargs(cfg)
+    flow = configs.conditional_rq_nsf_flow(cfg["L"], cfg["D"], cfg["K"], cfg["H"], cfg["C"], cfg["E"],
+                                           cfg["tail_bound"], seed=cfg["seed"])
+    with torch.no_grad():
+        for n_, p in flow.named_parameters():
+            if "final_layer" in n_:
+                p.mul_(cfg["scale_final"])
+            elif "linear_layers.1" in n_:
+                p.mul_(cfg["scale_linear1"])
+            elif "context_layer" in n_:
+                p.mul_(cfg["scale_context"])
+    sd = flow.state_dict()
+    for n_, (total, absolute) in zip(g[name + "/param_names"], g[name + "/param_checksums"]):
+        v = sd[str(n_)].double()
+        assert abs(float(v.sum()) - total) <= 1e-9 * (1 + abs(total)), n_
+        assert abs(float(v.abs().sum()) - absolute) <= 1e-9 * (1 + absolute), n_
+    return flow.eval(), g, str(name)

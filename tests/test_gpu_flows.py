@@ -286,6 +286,31 @@ def test_conditional_flow_with_context():
         flow.log_prob(x, context=ctx[:10])
 
 
+def test_conditional_flow_against_reference_vectors(golden_dir):
+    """A conditional flow at the whole-layer kernels' layer shape (H = 128, context embedded by a Linear)
+    against the vectors the real reference produced for it (tests/golden/flows_context.npz; the eager
+    oracle is pinned to the same vectors bit for bit in tests/test_oracle_golden.py): log_prob, the
+    transform in both directions and the log-determinants, each within 4 x the reference-fp32's own
+    error against its float64 result."""
+    from helpers import golden_conditional_flow
+    import nflows_amd
+    flow, g, name = golden_conditional_flow(golden_dir)
+    flow = flow.to(DEV)
+    x, noise, ctx = (torch.from_numpy(g[name + "/" + k]).to(DEV) for k in ("x", "noise", "context"))
+    with torch.no_grad():
+        emb = flow._embedding_net(ctx)
+        lp = flow.log_prob(x, context=ctx)
+        z, lad = flow._transform(x, context=emb)
+        xs, lad_inv = flow._transform.inverse(noise, context=emb)
+    nflows_amd.check_status()
+    d = x.shape[1]
+    check(z, g[name + "/z"], g[name + "/z64"], "z", 3e-6)
+    check(lad, g[name + "/lad"], g[name + "/lad64"], "lad", 3e-6 * d)
+    check(lp, g[name + "/log_prob"], g[name + "/log_prob64"], "log_prob", 3e-6 * d)
+    check(xs, g[name + "/inv_x"], g[name + "/inv_x64"], "inv_x", 3e-6)
+    check(lad_inv, g[name + "/inv_lad"], g[name + "/inv_lad64"], "inv_lad", 3e-6 * d)
+
+
 def _select_fused_path(path):
     """k8: whole ResidualNet in the spline kernel; k7b / k7: only the final Linear (split-bf16 /
     fp32 MFMA); none: PyTorch conditioner + K1."""
