@@ -309,6 +309,27 @@ int nfa_rqs_flow_resnet_f16x2_f32(const float *inputs, const void *stream_packed
                                   int32_t hidden_features, int32_t num_blocks,
                                   const nfa_rqs_spec *spec, int32_t flags, void *stream);
 
+/*
+ * nfa_rqs_flow_resnet_f32 for conditioners that take a context (nn/nets/resnet.py:9-52, :92-100):
+ *   context        [batch, context_features] fp32, the rows handed to every conditioner of the run
+ *                  (Flow._log_prob's embedded context, flows/base.py:42-49).
+ *   weights_packed as for nfa_rqs_coupling_resnet_f32, with (a) the initial layer's columns =
+ *                  [identity features | context] (num_identity + context_features <= 64; 2 k-steps up to 32
+ *                  columns, else 4) and (b) per block, behind its two Linears, four more stages: tile t's
+ *                  32 rows of `context_layer` ([3 pieces][4 k-steps][64 lanes][8], column = 16 ks + 8 (l >> 5)
+ *                  + j, columns >= context_features zero).
+ *   bias_packed    per block 384 floats: linear_layers[0], linear_layers[1], context_layer (accumulator order).
+ * The block computes h + (W_1 relu(W_0 relu(h) + b_0) + b_1) * sigmoid(W_c context + b_c) (F.glu of the
+ * concatenation, resnet.py:46-52).  Supported: as nfa_rqs_flow_resnet_f32 with num_bins = 8 and without
+ * NFA_FLAG_LOGITS_LOG2E; otherwise NFA_ERR_UNSUPPORTED.
+ */
+int nfa_rqs_flow_resnet_context_f32(const float *inputs, const float *context, int32_t context_features,
+                                    const void *weights_packed, const float *bias_packed,
+                                    const int32_t *flow_tables, int32_t num_layers, float *outputs,
+                                    float *logabsdet, int32_t *status, int64_t batch, int32_t features,
+                                    int32_t num_transform, int32_t num_identity, int32_t hidden_features,
+                                    int32_t num_blocks, const nfa_rqs_spec *spec, int32_t flags, void *stream);
+
 /* nfa_rqs_flow_resnet_f32 on the row blocks with redo_blocks[block] != 0 only (second pass of K8h). */
 int nfa_rqs_flow_resnet_redo_f32(const float *inputs, const void *weights_packed,
                                  const float *bias_packed, const int32_t *flow_tables,

@@ -43,6 +43,7 @@ EXPORTS = (
     "nfa_rqs_coupling_resnet_f32",
     "nfa_rqs_flow_resnet_f32",
     "nfa_rqs_flow_resnet_redo_f32",
+    "nfa_rqs_flow_resnet_context_f32",
     "nfa_affine_flow_mlp_f32",
     "nfa_made_rqs_inverse_f32",
     "nfa_rqs_flow_resnet_f16x2_f32",
@@ -131,6 +132,9 @@ def _declare(lib):
     lib.nfa_rqs_flow_resnet_f32.argtypes = [vp] * 4 + [i32] + [vp] * 3 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
     lib.nfa_affine_flow_mlp_f32.restype = ctypes.c_int
     lib.nfa_affine_flow_mlp_f32.argtypes = [vp] * 4 + [i32] + [vp] * 3 + [i64] + [i32] * 7 + [vp]
+    lib.nfa_rqs_flow_resnet_context_f32.restype = ctypes.c_int
+    lib.nfa_rqs_flow_resnet_context_f32.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i64, i32, i32, i32, i32,
+                                                    i32, sp, i32, vp]
     lib.nfa_made_rqs_inverse_f32.restype = ctypes.c_int
     lib.nfa_made_rqs_inverse_f32.argtypes = [vp, vp, vp, ctypes.POINTER(ctypes.c_int32), i32, vp, vp, vp, vp, i64,
                                              i32, i32, i32, sp, vp]

@@ -264,6 +264,9 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
     float* s_fbias = lds_dyn + kRing * kStageVec4 * 4 + (kBlock / kWave) * D * kRowPad;
     // CTX: per wave the [ce][33] context tile of its 32 rows, behind the final-layer biases
     float* s_ctx = s_fbias + (PIPE != 0 ? dt * (KB == 10 ? 32 : 24) : 0) + wave * a.ce * kRowPad;
+    // CTX: per wave the fp32 residual stream h, [4 tiles x 16 registers][64 lanes]
+    [[maybe_unused]] float* s_hacc = s_fbias + (PIPE != 0 ? dt * (KB == 10 ? 32 : 24) : 0) + (kBlock / kWave) * a.ce * kRowPad +
+                                     wave * (64 * kWave);
     const int groups = dt >> 2;
     const int64_t num_quads = a.batch >> 7;
     int tb = 0;  // which half of s_tab holds the current layer's table
@@ -360,14 +363,22 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
             NFA_STAMP()
 
             // ---- initial layer: h = W_i x + b_i
+            // (CTX: the residual stream h is also kept in fp32 in the wave's LDS scratch -- the gated block
+            //  needs h after its second GEMM, and neither its pieces nor its accumulators fit the register
+            //  file next to that GEMM's operands; one tile at a time comes back when the gate is applied)
             {
                 f32x16 h[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) load_bias_tile(h[t], bias + t * 32);
                 gemm_kmajor<false, INIT_KS>(h, ph, pm, pl, sm, lane);
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t) {
                     tile_to_pieces<false>(h[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
+                    if constexpr (CTX) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) s_hacc[(t * 16 + q) * kWave + lane_here] = h[t][q];
+                    }
+                }
             }
             bias += 128;
             if (PIPE != 0) {
@@ -408,15 +419,15 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                         f32x16 gate;
                         load_bias_tile(gate, bias + 256 + t * 32);
                         gemm_context_tile(gate, s_ctx, a.ce, half, r, sm, lane);
-                        f32x16 hv = {0};
-                        add_pieces(hv, 0, ph[2 * t], pm[2 * t], pl[2 * t]);
-                        add_pieces(hv, 8, ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
+                        f32x16 hn;
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {
                             const float sg = 1.0f / (1.0f + expf(-gate[q]));
-                            v[t][q] = hv[q] + v[t][q] * sg;
+                            float* hp = s_hacc + (t * 16 + q) * kWave + lane_here;
+                            hn[q] = *hp + v[t][q] * sg;
+                            *hp = hn[q];
                         }
-                        tile_to_pieces<false>(v[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
+                        tile_to_pieces<false>(hn, ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
                     }
                     bias += 384;
                 } else {
@@ -703,7 +714,8 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     if (with_ctx && !(pipe && use_pipe == 2)) return NFA_ERR_UNSUPPORTED;
     const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float) +
                        (pipe ? (size_t)num_transform * rows_per_feature * sizeof(float) : 0) +
-                       (size_t)(kBlock / kWave) * context_features * kRowPad * sizeof(float);
+                       (size_t)(kBlock / kWave) * context_features * kRowPad * sizeof(float) +
+                       (with_ctx ? (size_t)(kBlock / kWave) * 64 * kWave * sizeof(float) : 0);
     int64_t blocks = batch >> 7;
     const int64_t per_cu = lds + 2048 <= 80 * 1024 ? 2 : 1;
     const int64_t cap = (int64_t)device_cu_count() * per_cu;

@@ -797,7 +797,7 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False)
 
     stages, biases = [], []
     wi = net.initial_layer.weight.detach().float()
-    di = wi.shape[1]
+    di = wi.shape[1]                                           # identity features (+ context features)
     init_ks = 4 if di > 32 else 2                              # k-steps of the initial layer
     wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
     # (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j)
@@ -809,6 +809,12 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False)
             # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one stage per k-step
             stages.append(pieces(w).view(3, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1))
             biases.append(_bias_accumulator_order(lin.bias.detach().float()))
+        if getattr(block, "context_layer", None) is not None:
+            # the GLU gate's Linear, tile-major: one stage per 32-row tile, (p, t, i, k4, hf, j) -> (t, p, k4, hf, i, j)
+            wc = block.context_layer.weight.detach().float()
+            wc = torch.cat((wc, wc.new_zeros(128, 64 - wc.shape[1])), dim=1)
+            stages.append(pieces(wc).view(3, 4, 32, 4, 2, 8).permute(1, 0, 3, 4, 2, 5).reshape(4, -1))
+            biases.append(_bias_accumulator_order(block.context_layer.bias.detach().float()))
     scale = torch.ones(P, dtype=torch.float64, device=dev)
     scale[:2 * K] = (math.log2(math.e) if log2e else 1.0) / math.sqrt(net.hidden_features)
     wf = (net.final_layer.weight.detach().double().view(dt, P, 128) * scale[None, :, None]).float()
@@ -1059,7 +1065,7 @@ def _density_epilogue(flags, standard_normal_log_prob, inverse, like):
 
 def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transform, num_identity, num_blocks,
                         spec, inverse=False, accumulate_into=None, log2e=False, num_layers=1,
-                        standard_normal_log_prob=False):
+                        standard_normal_log_prob=False, context=None):
     """K8 -- ResidualNet conditioner + spline coupling layer in one kernel; with num_layers > 1 a
     whole run of such layers (weights / biases concatenated in execution order, tables from
     `flow_layer_tables`).  Returns (outputs, logabsdet), or (None, log_prob) with
@@ -1074,10 +1080,20 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
     if log2e:
         flags |= N.FLAG_LOGITS_LOG2E
     with torch.cuda.device(dev):
-        rc = N.load().nfa_rqs_flow_resnet_f32(
-            N.ptr(x), N.ptr(weights_packed), N.ptr(bias_packed), N.ptr(tables), num_layers, N.ptr(out),
-            N.ptr(lad), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128, num_blocks,
-            ctypes.byref(spec), flags, N.stream_handle(dev))
+        if context is not None:   # conditioners with a context: [B, context_features] rows
+            N.require_device_f32("context", context, 2)
+            ctx = context.detach().contiguous()
+            if ctx.shape[0] != B:
+                raise ValueError("context must have one row per input row")
+            rc = N.load().nfa_rqs_flow_resnet_context_f32(
+                N.ptr(x), N.ptr(ctx), ctx.shape[1], N.ptr(weights_packed), N.ptr(bias_packed), N.ptr(tables),
+                num_layers, N.ptr(out), N.ptr(lad), N.ptr(_status_word(dev)), B, D, num_transform, num_identity,
+                128, num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))
+        else:
+            rc = N.load().nfa_rqs_flow_resnet_f32(
+                N.ptr(x), N.ptr(weights_packed), N.ptr(bias_packed), N.ptr(tables), num_layers, N.ptr(out),
+                N.ptr(lad), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128, num_blocks,
+                ctypes.byref(spec), flags, N.stream_handle(dev))
     if rc == N.ERR_UNSUPPORTED:
         return None
     N.check(rc)

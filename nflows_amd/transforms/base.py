@@ -117,7 +117,7 @@ class CompositeTransform(Transform):
         permutation changes.  (weights, biases, tables, f16 stream or None)."""
         from .. import ops
         first = units[0][0]
-        mlp = first._run_kind(None) == "k11"
+        mlp = type(first).__name__ in ("AffineCouplingTransform", "AdditiveCouplingTransform")
         packed = [c._packed_mlp() if mlp else c._packed_resnet() for c, _ in units]
         f16 = (not mlp) and first._use_f16()
         packed_f16 = [c._packed_resnet_f16() for c, _ in units] if f16 else None
@@ -153,7 +153,7 @@ class CompositeTransform(Transform):
         full = (batch // 128) * 128
         weights, biases, tables, plan_f16 = self._run_plan(units, inverse)
         acc = None if total is None else total[:full]
-        if first._run_kind(None) == "k11":
+        if type(first).__name__ in ("AffineCouplingTransform", "AdditiveCouplingTransform"):
             head = ops.affine_flow_mlp(
                 inputs[:full], weights, biases, tables, first.num_transform_features, first.num_identity_features,
                 len(first.transform_net._hidden_layers), first._activation_code(), inverse, acc,
@@ -168,7 +168,8 @@ class CompositeTransform(Transform):
                 inputs[:full], weights, biases, tables, first.num_transform_features, first.num_identity_features,
                 len(first.transform_net.blocks), first._spec(), inverse, acc,
                 log2e=first._log2e() if hasattr(first, "_log2e") else False, num_layers=len(units),
-                standard_normal_log_prob=standard_normal_log_prob)
+                standard_normal_log_prob=standard_normal_log_prob,
+                context=None if context is None else context[:full])
         if standard_normal_log_prob:
             return None if head is None else head[1]
         if head is None:
@@ -177,12 +178,13 @@ class CompositeTransform(Transform):
             return head[0]
         # ragged batch: the last rows layer by layer (PyTorch conditioner + K1)
         tail, tail_total = inputs[full:], total[full:]
+        tail_context = None if context is None else context[full:]
         for coupling, perm in units:
             if inverse:
-                tail, _ = coupling.inverse(tail, context, out_scatter=None if perm is None else perm._permutation,
+                tail, _ = coupling.inverse(tail, tail_context, out_scatter=None if perm is None else perm._permutation,
                                            logabsdet_accumulator=tail_total)
             else:
-                tail, _ = coupling.forward(tail, context, in_perm=None if perm is None else perm._permutation,
+                tail, _ = coupling.forward(tail, tail_context, in_perm=None if perm is None else perm._permutation,
                                            logabsdet_accumulator=tail_total)
         return torch.cat((head[0], tail), dim=0)
 

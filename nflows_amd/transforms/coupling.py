@@ -385,13 +385,21 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         return ("k8", self.features, self.num_transform_features, self.num_identity_features,
                 len(self.transform_net.blocks), self.num_bins, self.tail_bound,
                 self.min_bin_width, self.min_bin_height, self.min_derivative,
-                self._log2e(), self._use_f16(), self.conditioner_act_scale)
+                self._log2e(), self._use_f16(), self.conditioner_act_scale,
+                getattr(self.transform_net, "context_features", None))
 
     def _resnet_eligible(self, context):
         net = self.transform_net
         from ..nn.nets.resnet import ResidualNet
+        if context is None:
+            context_ok = net.context_features is None if type(net) is ResidualNet else False
+        else:   # (K8 with a context: 8 bins, identity features + context within the initial layer's 64 columns)
+            context_ok = (type(net) is ResidualNet and net.context_features is not None and context.dim() == 2
+                          and context.shape[1] == net.context_features and context.is_cuda
+                          and context.dtype == torch.float32 and self.num_bins == 8 and not self._log2e()
+                          and self.num_identity_features + net.context_features <= 64)
         return (self.fuse_conditioner and self.fuse_final_linear and not torch.is_grad_enabled()
-                and context is None and type(net) is ResidualNet and net.context_features is None
+                and context_ok and type(net) is ResidualNet
                 and net.hidden_features == 128 and self.tails == "linear" and self.num_bins in (8, 10)
                 and 1 <= self.num_identity_features <= 64 and self.num_transform_features % 4 == 0
                 and self.num_transform_features <= 64 and self.features <= 128
@@ -414,7 +422,9 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
     conditioner_act_scale = float(os.environ.get("NFA_K8_ACT_SCALE", "1"))
 
     def _use_f16(self):
-        return self.conditioner_engine == "f16x2" and self.num_bins == 8 and not self._log2e()
+        """K8h serves conditioners without a context; with one the bf16x3 kernel (K8) runs."""
+        return (self.conditioner_engine == "f16x2" and self.num_bins == 8 and not self._log2e()
+                and getattr(self.transform_net, "context_features", None) is None)
 
     def _packed_resnet_f16(self):
         net = self.transform_net
@@ -482,7 +492,8 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         else:
             def run(rows, acc):
                 return ops.rqs_coupling_resnet(rows, wp, bp, tables, dt, di, nb, spec, inverse, acc,
-                                               log2e=self._log2e())
+                                               log2e=self._log2e(),
+                                               context=None if context is None else context[:rows.shape[0]])
         if full == B:
             return run(inputs, accumulate_into)
         # ragged batch: full 128-row blocks here, the tail through the PyTorch conditioner + K1
@@ -493,7 +504,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
             return None
         tail_in = inputs[full:]
         cols = self._identity_columns(in_perm) if not inverse else self.identity_features
-        params = self.transform_net(tail_in.index_select(1, cols), None)
+        params = self.transform_net(tail_in.index_select(1, cols), None if context is None else context[full:])
         tail = self._fused_layer(tail_in, params, inverse, in_perm=in_perm, out_scatter=out_scatter,
                                  accumulate_into=acc_tail)
         outputs = torch.cat((head[0], tail[0]), dim=0)

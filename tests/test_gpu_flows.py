@@ -299,9 +299,23 @@ def test_conditional_flow_against_reference_vectors(golden_dir):
     x, noise, ctx = (torch.from_numpy(g[name + "/" + k]).to(DEV) for k in ("x", "noise", "context"))
     with torch.no_grad():
         emb = flow._embedding_net(ctx)
+        # the whole conditional flow is one run of the whole-layer kernel (K8 with a context)
+        units, after = flow._transform._collect_run(list(flow._transform._transforms), 0, x, emb, inverse=False)
+        assert len(units) == 3 and after == 6
         lp = flow.log_prob(x, context=ctx)
         z, lad = flow._transform(x, context=emb)
         xs, lad_inv = flow._transform.inverse(noise, context=emb)
+        # ... and equals the layer-by-layer path (PyTorch conditioners + the spline kernel) to fp32 rounding
+        from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+        try:
+            RQ.fuse_conditioner = False
+            z2, lad2 = flow._transform(x, context=emb)
+            lp_ragged = flow.log_prob(x[:200], context=ctx[:200])
+        finally:
+            RQ.fuse_conditioner = True
+        assert (z - z2).abs().max().item() < 2e-4 and (lad - lad2).abs().max().item() < 2e-3
+        lp_ragged_fused = flow.log_prob(x[:200], context=ctx[:200])     # 128 rows fused + 72 rows layer by layer
+        assert (lp_ragged - lp_ragged_fused).abs().max().item() < 2e-3
     nflows_amd.check_status()
     d = x.shape[1]
     check(z, g[name + "/z"], g[name + "/z64"], "z", 3e-6)
