@@ -227,6 +227,45 @@ struct ConvWeave {
     }
 };
 
+// The same conversion cut for the 24 MFMAs of TWO k-steps of a k-major GEMM (12 each): pair J of the
+// tile takes slots 3J (scale, floor), 3J + 1 (high pieces, and their values back in fp32), 3J + 2
+// (residuals, low pieces): 4-6 VALU instructions behind every MFMA, the number that hides.
+struct ConvSlices {
+    const f32x16& src;
+    uvec4 &h0, &l0, &h1, &l1;
+    float scale, floor_;
+    float v0, v1, r0, r1;
+    unsigned hi;
+
+    template <int SLOT>
+    __device__ __forceinline__ void step() {
+        constexpr int J = SLOT / 3, PH = SLOT % 3;
+        if constexpr (PH == 0) {
+            v0 = src[2 * J] * scale;
+            v1 = src[2 * J + 1] * scale;
+            v0 = (v0 < floor_) ? floor_ : v0;   // NaN stays NaN
+            v1 = (v1 < floor_) ? floor_ : v1;
+        } else if constexpr (PH == 1) {
+            const f16x2 h = __builtin_convertvector(vec2f{v0, v1}, f16x2);
+            hi = __builtin_bit_cast(unsigned, h);
+            r0 = v0 - (float)h[0];
+            r1 = v1 - (float)h[1];
+            asm volatile("" : "+v"(r0));
+            asm volatile("" : "+v"(r1));
+        } else {
+            const f16x2 l = __builtin_convertvector(vec2f{r0, r1}, f16x2);
+            const unsigned lo = __builtin_bit_cast(unsigned, l);
+            if constexpr (J < 4) {
+                h0[J] = hi;
+                l0[J] = lo;
+            } else {
+                h1[J - 4] = hi;
+                l1[J - 4] = lo;
+            }
+        }
+    }
+};
+
 // Preparation of the accumulator of the NEXT tile of a skip-connection GEMM: acc = acc * ratio + bias
 // (bias from the layer's parameter block in LDS), four values per slice.
 struct InitWeave {
@@ -374,6 +413,69 @@ __device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const uvec4 (&ph)[
         }
         stream_advance(sm);
     }
+}
+
+// two k-steps of a k-major GEMM with a weave slice behind every MFMA (slots 0 .. 23)
+template <class W, class SM>
+__device__ __forceinline__ void kstep_pair_woven(f32x16 (&acc)[4], uvec4 bh0, uvec4 bl0, uvec4 bh1, uvec4 bl1, SM& sm,
+                                                 Frags& fr, int lane, W&& w) {
+#define NFA_K8H_CELL(T, SLOT, BH, BL)                                                            \
+    {                                                                                            \
+        const Frags nf = next_frags<T>(cur, nxt);                                                \
+        await_frags(fr);                                                                         \
+        const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);  \
+        fr = nf;                                                                                 \
+        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, BH, acc[T], 0, 0, 0);                \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        w.template step<SLOT + 0>();                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, BL, acc[T], 0, 0, 0);                \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        w.template step<SLOT + 1>();                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, BH, acc[T], 0, 0, 0);                \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        w.template step<SLOT + 2>();                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
+    {
+        unsigned cur, nxt;
+        stage_begin(sm, cur, nxt, lane);
+        const f16x8 bh = __builtin_bit_cast(f16x8, bh0), bl = __builtin_bit_cast(f16x8, bl0);
+        NFA_K8H_CELL(0, 0, bh, bl)
+        NFA_K8H_CELL(1, 3, bh, bl)
+        NFA_K8H_CELL(2, 6, bh, bl)
+        NFA_K8H_CELL(3, 9, bh, bl)
+        stream_advance(sm);
+    }
+    {
+        unsigned cur, nxt;
+        stage_begin(sm, cur, nxt, lane);
+        const f16x8 bh = __builtin_bit_cast(f16x8, bh1), bl = __builtin_bit_cast(f16x8, bl1);
+        NFA_K8H_CELL(0, 12, bh, bl)
+        NFA_K8H_CELL(1, 15, bh, bl)
+        NFA_K8H_CELL(2, 18, bh, bl)
+        NFA_K8H_CELL(3, 21, bh, bl)
+        stream_advance(sm);
+    }
+#undef NFA_K8H_CELL
+}
+
+// k-major 128 -> 128 GEMM whose input pieces are made on the way from the accumulator tiles `src` of the
+// previous GEMM (x `scale`, floored at `floor_`): tile 0 is converted up front, tile t + 1 behind the
+// MFMAs of k-steps 2t, 2t + 1 -- which only read the pieces of tile t.
+template <class SM>
+__device__ __forceinline__ void gemm_kmajor_converting(f32x16 (&acc)[4], uvec4 (&ph)[8], uvec4 (&pl)[8],
+                                                       const f32x16 (&src)[4], float scale, float floor_, SM& sm,
+                                                       Frags& fr, int lane) {
+    ConvWeave{src[0], ph[0], pl[0], ph[1], pl[1], scale, floor_}.all();
+    kstep_pair_woven(acc, ph[0], pl[0], ph[1], pl[1], sm, fr, lane,
+                     ConvSlices{src[1], ph[2], pl[2], ph[3], pl[3], scale, floor_});
+    kstep_pair_woven(acc, ph[2], pl[2], ph[3], pl[3], sm, fr, lane,
+                     ConvSlices{src[2], ph[4], pl[4], ph[5], pl[5], scale, floor_});
+    kstep_pair_woven(acc, ph[4], pl[4], ph[5], pl[5], sm, fr, lane,
+                     ConvSlices{src[3], ph[6], pl[6], ph[7], pl[7], scale, floor_});
+    kstep_pair_woven(acc, ph[6], pl[6], ph[7], pl[7], sm, fr, lane, NoWeave{});
 }
 
 __device__ __forceinline__ void load_bias_tile(f32x16& acc, const float* bias_tile_half) {
@@ -544,55 +646,46 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
 #pragma unroll
                 for (int t = 0; t < 4; ++t) load_bias_tile(hacc[t], bias + t * 32);
                 gemm_kmajor<INIT_KS>(hacc, ph, pl, sm, fr, lane);
-                // pieces of (ReLU'd, when a block follows) h
-                const float c_ = gemm[0], fl_ = a.num_blocks > 0 ? 0.0f : -INFINITY;
-                ConvWeave{hacc[0], ph[0], pl[0], ph[1], pl[1], c_, fl_}.all();
-                ConvWeave{hacc[1], ph[2], pl[2], ph[3], pl[3], c_, fl_}.all();
-                ConvWeave{hacc[2], ph[4], pl[4], ph[5], pl[5], c_, fl_}.all();
-                ConvWeave{hacc[3], ph[6], pl[6], ph[7], pl[7], c_, fl_}.all();
             }
+            // (the pieces of a GEMM's result are made by the GEMM that consumes them, behind its MFMAs)
+            float conv_scale = gemm[0];
             gemm += kHdr + 128;
             NFA_HSTAMP()
 
             // ---- residual blocks: h += W_1 relu(W_0 relu(h) + b_0) + b_1
             for (int blk = 0; blk < a.num_blocks; ++blk) {
                 uvec4 qh[8], ql[8];   // pieces of relu(u)
+                f32x16 u[4];
                 {
                     // first Linear on the pieces of relu(h)
                     const float* bias = gemm + kHdr + half * 16;
-                    const float c_ = gemm[0];
-                    f32x16 u[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) load_bias_tile(u[t], bias + t * 32);
-                    gemm_kmajor<8>(u, ph, pl, sm, fr, lane);
-                    ConvWeave{u[0], qh[0], ql[0], qh[1], ql[1], c_, 0.0f}.all();
-                    ConvWeave{u[1], qh[2], ql[2], qh[3], ql[3], c_, 0.0f}.all();
-                    ConvWeave{u[2], qh[4], ql[4], qh[5], ql[5], c_, 0.0f}.all();
-                    ConvWeave{u[3], qh[6], ql[6], qh[7], ql[7], c_, 0.0f}.all();
+                    gemm_kmajor_converting(u, ph, pl, hacc, conv_scale, 0.0f, sm, fr, lane);
+                    conv_scale = gemm[0];
                 }
                 gemm += kHdr + 128;
                 NFA_HSTAMP()
                 {
                     // second Linear accumulates into the residual stream itself: hacc = hacc * ratio + bias
-                    // (the skip connection), then + W_1 relu(u); the new h goes out as pieces (ReLU'd when
-                    // another block follows: the final layer reads h itself)
-                    const bool last = blk + 1 == a.num_blocks;
+                    // (the skip connection), then + W_1 relu(u)
                     const float* bias = gemm + kHdr + half * 16;
-                    const float c_ = gemm[0], ratio = gemm[1];
-                    const float fl_ = last ? -INFINITY : 0.0f;
+                    const float ratio = gemm[1];
                     InitWeave{hacc[0], bias + 0 * 32, ratio}.all();
                     InitWeave{hacc[1], bias + 1 * 32, ratio}.all();
                     InitWeave{hacc[2], bias + 2 * 32, ratio}.all();
                     InitWeave{hacc[3], bias + 3 * 32, ratio}.all();
-                    gemm_kmajor<8>(hacc, qh, ql, sm, fr, lane);
-                    ConvWeave{hacc[0], ph[0], pl[0], ph[1], pl[1], c_, fl_}.all();
-                    ConvWeave{hacc[1], ph[2], pl[2], ph[3], pl[3], c_, fl_}.all();
-                    ConvWeave{hacc[2], ph[4], pl[4], ph[5], pl[5], c_, fl_}.all();
-                    ConvWeave{hacc[3], ph[6], pl[6], ph[7], pl[7], c_, fl_}.all();
+                    gemm_kmajor_converting(hacc, qh, ql, u, conv_scale, 0.0f, sm, fr, lane);
+                    conv_scale = gemm[0];
                 }
                 gemm += kHdr + 128;
                 NFA_HSTAMP()
             }
+            // pieces of h itself for the final layer (no ReLU in front of it: resnet.py:99-100)
+            ConvWeave{hacc[0], ph[0], pl[0], ph[1], pl[1], conv_scale, -INFINITY}.all();
+            ConvWeave{hacc[1], ph[2], pl[2], ph[3], pl[3], conv_scale, -INFINITY}.all();
+            ConvWeave{hacc[2], ph[4], pl[4], ph[5], pl[5], conv_scale, -INFINITY}.all();
+            ConvWeave{hacc[3], ph[6], pl[6], ph[7], pl[7], conv_scale, -INFINITY}.all();
 
             // ---- final layer with the spline evaluation woven into the MFMAs: the three tiles of a group
             //      hold the logits of this lane's two features A, B (A = T0 + T1[0:8], B = T1[8:16] + T2)
