@@ -344,6 +344,32 @@ struct SplineWeave {
     }
 };
 
+// ---- 10 bins (the reference's default): one feature per lane-half and group of two tiles.  The width
+//      numerators run behind the second tile's MFMAs, everything else behind the next group's first tile.
+enum { kUnitNumW10 = 4, kUnitRest10 = 5 };
+
+template <int UNIT, int I, int END, class Steps>
+__device__ __forceinline__ void spline10_range(Steps& f, const RqsDev& sp) {
+    if constexpr (I < END) {
+        constexpr int N = Steps::kNumSlices;
+        if constexpr (UNIT == kUnitNumW10) f.template num_w<I>();
+        else if constexpr (I < N) f.template num_h<I>();
+        else f.template finish<I - N>(sp);
+        spline10_range<UNIT, I + 1, END>(f, sp);
+    }
+}
+
+template <int UNIT, class Steps>
+struct SplineWeave10 {
+    Steps& f;
+    const RqsDev& sp;
+    static constexpr int kCount = UNIT == kUnitNumW10 ? Steps::kNumSlices : Steps::kNumSlices + Steps::kFinishSlices;
+    template <int SLOT>
+    __device__ __forceinline__ void step() {
+        spline10_range<UNIT, (SLOT * kCount) / kSlots, ((SLOT + 1) * kCount) / kSlots>(f, sp);
+    }
+};
+
 // ---- one 32-row output tile: 8 k-steps x 3 products, two stages, a weave slice behind every MFMA
 template <int KS, class W>
 __device__ __forceinline__ void tile_kstep(f32x16& acc, uvec4 bhw, uvec4 blw, Frags& fr, unsigned cur, unsigned nxt, W& w) {
@@ -492,7 +518,7 @@ __device__ __forceinline__ void load_bias_tile(f32x16& acc, const float* bias_ti
 
 __device__ __forceinline__ bool not_finite(float v) { return !(__builtin_fabsf(v) < INFINITY); }
 
-template <bool INVERSE, int INIT_KS, int NW>
+template <bool INVERSE, int INIT_KS, int NW, int KB = 8>
 __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Args a) {
     constexpr int kThreads = NW * kWave;
     // dynamic LDS: the weight ring, per wave a [D][33] row tile, two parameter blocks (current / next layer)
@@ -689,7 +715,52 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
 
             // ---- final layer with the spline evaluation woven into the MFMAs: the three tiles of a group
             //      hold the logits of this lane's two features A, B (A = T0 + T1[0:8], B = T1[8:16] + T2)
-            {
+            if constexpr (KB == 10) {
+                // 29 logits per feature padded to 32 rows = the 16 + 16 accumulator values a lane-half gets
+                // from the two tiles of a group: [10 widths, 6 heights | 4 heights, 9 derivatives, 3 pads]
+                using Steps = FlatSteps<INVERSE, 1, true, 10, true>;
+                Steps f;
+                const float kappa = gemm[0];
+                f.kappa = kappa;
+                f.kl2e = 1.44269502162933349609375f * kappa;
+                f.tail_s = a.sp.tail_logit * gemm[1];
+                const float* fbias = gemm + kHdr + half * 16;
+                const int groups10 = dt >> 1;
+                f32x16 acc0, acc1;
+                float hrest[6];
+                float* slot = s_row + tab[kTabTr + half] * kRowPad + r;
+                SplineWeave10<kUnitNumW10, Steps> wn{f, a.sp};
+                SplineWeave10<kUnitRest10, Steps> wr{f, a.sp};
+                load_bias_tile(acc0, fbias);
+                tile_gemm(acc0, ph, pl, sm, fr, lane, NoWeave{});
+                for (int g = 0; g < groups10; ++g) {
+                    f.x = *slot;
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) f.ew[j] = acc0[j];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) hrest[j] = acc0[10 + j];
+                    load_bias_tile(acc1, fbias + (g * 2 + 1) * 32);
+                    tile_gemm(acc1, ph, pl, sm, fr, lane, wn);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) f.eh[j] = hrest[j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f.eh[6 + j] = acc1[j];
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) f.sd[j] = acc1[4 + j];
+                    if (g + 1 < groups10) {
+                        float* next_slot = s_row + tab[kTabTr + (g + 1) * 2 + half] * kRowPad + r;
+                        load_bias_tile(acc0, fbias + (g * 2 + 2) * 32);
+                        tile_gemm(acc0, ph, pl, sm, fr, lane, wr);
+                        *slot = f.y;
+                        slot = next_slot;
+                    } else {
+                        spline10_range<kUnitRest10, 0, SplineWeave10<kUnitRest10, Steps>::kCount>(f, a.sp);
+                        *slot = f.y;
+                    }
+                    lad_acc += f.lad;
+                    quad_status |= f.status;
+                }
+            } else {
                 using Steps = FusedSteps8<INVERSE>;
                 Steps fa, fb;
                 const float kappa = gemm[0];
@@ -818,11 +889,13 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* st
     int rc = make_dev_spec(spec, &a.sp);
     if (rc != NFA_OK) return rc;
     if (a.sp.beta != 1.0f) return NFA_ERR_UNSUPPORTED;
-    if (a.sp.K != 8 || !a.sp.linear || hidden_features != 128 || (num_transform & 3) != 0 || num_transform > 64 ||
+    if ((a.sp.K != 8 && a.sp.K != 10) || !a.sp.linear || hidden_features != 128 || (num_transform & 3) != 0 || num_transform > 64 ||
         num_identity > 64 || features > 128 || (features & 3) != 0 || (batch & 127) != 0 || num_blocks > 64 ||
         num_layers > 4096)
         return NFA_ERR_UNSUPPORTED;
-    const int param_words = k8h::kTabWords + (k8h::kHdr + 128) * (1 + 2 * num_blocks) + k8h::kHdr + num_transform * 24;
+    const int rows_per_feature = a.sp.K == 10 ? 32 : 24;
+    const int param_words = k8h::kTabWords + (k8h::kHdr + 128) * (1 + 2 * num_blocks) + k8h::kHdr +
+                            num_transform * rows_per_feature;
     if (param_stages * 2048 < param_words || param_stages > 4) return NFA_ERR_INVALID_ARGUMENT;
     if (batch == 0) return NFA_OK;
     if (!inputs || !stream_packed || !final_positions || !logabsdet || !redo_blocks ||
@@ -846,7 +919,7 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* st
     a.num_layers = num_layers;
     a.param_stages = param_stages;
     const int init_ks = num_identity > 32 ? 4 : 2;
-    a.num_stages = param_stages + init_ks + 16 * num_blocks + 2 * (num_transform * 24 / 32);
+    a.num_stages = param_stages + init_ks + 16 * num_blocks + 2 * (num_transform * rows_per_feature / 32);
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = g_k7_trace;
     // workgroups of eight waves (256 rows, one per CU, one weight stream per CU) when the batch gives
@@ -872,7 +945,7 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* st
     const dim3 grid((unsigned)blocks), block(nw * kWave);
     const bool inv = (flags & NFA_FLAG_INVERSE) != 0;
     void (*kern)(const k8h::Args) = nullptr;
-    const int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0);
+    const int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0) + (a.sp.K == 10 ? 8 : 0);
     switch (which) {
         case 0: kern = k8h::rqs_resnet_f16_kernel<false, 2, 4>; break;
         case 1: kern = k8h::rqs_resnet_f16_kernel<true, 2, 4>; break;
@@ -881,10 +954,19 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* st
         case 4: kern = k8h::rqs_resnet_f16_kernel<false, 2, 8>; break;
         case 5: kern = k8h::rqs_resnet_f16_kernel<true, 2, 8>; break;
         case 6: kern = k8h::rqs_resnet_f16_kernel<false, 4, 8>; break;
-        default: kern = k8h::rqs_resnet_f16_kernel<true, 4, 8>; break;
+        case 7: kern = k8h::rqs_resnet_f16_kernel<true, 4, 8>; break;
+        case 8: kern = k8h::rqs_resnet_f16_kernel<false, 2, 4, 10>; break;
+        case 9: kern = k8h::rqs_resnet_f16_kernel<true, 2, 4, 10>; break;
+        case 10: kern = k8h::rqs_resnet_f16_kernel<false, 4, 4, 10>; break;
+        case 11: kern = k8h::rqs_resnet_f16_kernel<true, 4, 4, 10>; break;
+        case 12: kern = k8h::rqs_resnet_f16_kernel<false, 2, 8, 10>; break;
+        case 13: kern = k8h::rqs_resnet_f16_kernel<true, 2, 8, 10>; break;
+        case 14: kern = k8h::rqs_resnet_f16_kernel<false, 4, 8, 10>; break;
+        default: kern = k8h::rqs_resnet_f16_kernel<true, 4, 8, 10>; break;
     }
     if (lds_launch > 64 * 1024) {
-        static bool raised[8] = {false, false, false, false, false, false, false, false};
+        static bool raised[16] = {false, false, false, false, false, false, false, false,
+                                  false, false, false, false, false, false, false, false};
         if (!raised[which]) {
             NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
             raised[which] = true;

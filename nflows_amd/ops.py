@@ -947,8 +947,8 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
     Returns (weights [stages, 4096] f16, parameter words fp32)."""
     dt, P = num_transform, params_per_feature
     K = (P + 1) // 3
-    if P != 23:
-        raise ValueError("K8h packs 8-bin linear-tail layers")
+    if P not in (23, 29):
+        raise ValueError("K8h packs 8- and 10-bin linear-tail layers")
     S = float(act_scale)
     dev = net.final_layer.weight.device
     order_k = _k8_column_order().to(dev)
@@ -984,12 +984,13 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
     scale[:2 * K] = 1.0 / math.sqrt(net.hidden_features)
     wf = (net.final_layer.weight.detach().double().view(dt, P, 128) * scale[None, :, None]).float()
     bf = (net.final_layer.bias.detach().double().view(dt, P) * scale[None, :]).float()
-    order_r = _k7_row_order(dt).to(dev)
-    wf = torch.cat((wf, wf.new_zeros(dt, 24 - P, 128)), dim=1).reshape(dt * 24, 128)
+    R = 24 if P == 23 else 32   # rows per feature after padding
+    order_r = (_k7_row_order(dt) if R == 24 else _k8_row_order_32(dt)).to(dev)
+    wf = torch.cat((wf, wf.new_zeros(dt, R - P, 128)), dim=1).reshape(dt * R, 128)
     wf = wf.index_select(0, order_r).index_select(1, order_k)
-    bf = torch.cat((bf, bf.new_zeros(dt, 24 - P)), dim=1).reshape(dt * 24).index_select(0, order_r)
+    bf = torch.cat((bf, bf.new_zeros(dt, R - P)), dim=1).reshape(dt * R).index_select(0, order_r)
     T = _f16_weight_scale(wf)
-    tiles = dt * 24 // 32
+    tiles = dt * R // 32
     stages.append(pieces(wf * T).view(2, tiles, 32, 2, 4, 2, 8).permute(1, 3, 4, 0, 5, 2, 6).reshape(tiles * 2, -1))
     # the spline evaluation reads logits = accumulators x kappa, kappa = 1 / (S T)
     blob += [header(1.0 / (S * T), S * T), _bias_accumulator_order(bf * (S * T))]

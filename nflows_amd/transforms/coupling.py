@@ -423,7 +423,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
 
     def _use_f16(self):
         """K8h serves conditioners without a context; with one the bf16x3 kernel (K8) runs."""
-        return (self.conditioner_engine == "f16x2" and self.num_bins == 8 and not self._log2e()
+        return (self.conditioner_engine == "f16x2" and self.num_bins in (8, 10) and not self._log2e()
                 and getattr(self.transform_net, "context_features", None) is None)
 
     def _packed_resnet_f16(self):
