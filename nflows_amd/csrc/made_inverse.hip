@@ -15,9 +15,11 @@
 // any more; the caller finishes features T .. D-1 with one GEMM and one elementwise launch
 // (transforms/autoregressive.py).  Same sums as the reference's masked GEMMs in another order.
 //
-// Samples are independent, so there is no grid-wide step: a single-wave workgroup owns 16 samples for
+// Samples are independent, so there is no grid-wide step: a workgroup of four waves owns 16 samples for
 // all steps.  Lane = (sample s, quarter q): the four lanes of a sample split every dot product by
 // 16-byte chunks (chunk c belongs to quarter c % 4) and add their parts with two cross-lane exchanges.
+// The 3K - 1 output rows of a feature are dealt to the four waves (row p to wave p % 4), the few unit
+// rows of a step are wave 0's; three workgroup barriers per step hand the results on through LDS.
 // Per-sample state lives in LDS as [vector][chunk][16 samples][4 floats]: the features found so far
 // and one vector per hidden Linear (its ReLU'd output) plus, for residual nets, the raw residual
 // stream; a lane's read of chunk c is one ds_read_b128, conflict-free across the wave.
@@ -41,7 +43,8 @@
 namespace nfa {
 
 constexpr int kMadeMaxLinears = 12;
-constexpr int kMadeSamples = 16;     // per wave
+constexpr int kMadeSamples = 16;     // per workgroup
+constexpr int kMadeWaves = 4;
 constexpr int kMadeHeader = 16;      // ints in front of a step block: units per layer [12], tail offset, output-row offset
 constexpr int kMadeGrain = 256;      // blocks are multiples of 256 floats (one LDS-DMA request of the wave)
 
@@ -58,27 +61,34 @@ struct MadeInvArgs {
     int kp[kMadeMaxLinears], src[kMadeMaxLinears], dst[kMadeMaxLinears], add_stream[kMadeMaxLinears],
         set_stream[kMadeMaxLinears];
     RqsDev sp;
+    unsigned long long* trace;   // debug (nfa_debug_k7_trace): cycle stamps of workgroup 0, wave 0 over the first steps
 };
 
 // one lane's part of `R` dot products of weight rows (`pitch` floats apart) with a state vector, both
 // in LDS: chunks q, q + 4, ... of `chunks`; then the sum over the four quarters (all four lanes get it)
-template <int R>
+template <int R, int UNROLL>
 __device__ __forceinline__ void dot_rows(float (&acc)[R], const float* rows, int pitch, const float* vec, int chunks,
                                          int q, int s, int nrows) {
+    // (no conditionals inside the loop: rows beyond `nrows` re-read row 0 and their sums are ignored --
+    // a branch per row would keep the compiler from batching the LDS reads of several chunks)
+    const float* rp[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.0f;
-#pragma unroll 2
+    for (int r = 0; r < R; ++r) {
+        acc[r] = 0.0f;
+        rp[r] = rows + (r < nrows ? r : 0) * pitch;
+    }
+    // (deep unrolling: the LDS reads of several chunks are in flight before the first FMA needs one;
+    // a wave runs alone on its SIMD here, nothing else hides the latency)
+#pragma unroll UNROLL
     for (int c = q; c < chunks; c += 4) {
         const vec4f v = *reinterpret_cast<const vec4f*>(vec + (c * kMadeSamples + s) * 4);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if (r < nrows) {
-                const vec4f w = *reinterpret_cast<const vec4f*>(rows + r * pitch + c * 4);
-                acc[r] = __builtin_fmaf(w.x, v.x, acc[r]);
-                acc[r] = __builtin_fmaf(w.y, v.y, acc[r]);
-                acc[r] = __builtin_fmaf(w.z, v.z, acc[r]);
-                acc[r] = __builtin_fmaf(w.w, v.w, acc[r]);
-            }
+            const vec4f w = *reinterpret_cast<const vec4f*>(rp[r] + c * 4);
+            acc[r] = __builtin_fmaf(w.x, v.x, acc[r]);
+            acc[r] = __builtin_fmaf(w.y, v.y, acc[r]);
+            acc[r] = __builtin_fmaf(w.z, v.z, acc[r]);
+            acc[r] = __builtin_fmaf(w.w, v.w, acc[r]);
         }
     }
 #pragma unroll
@@ -90,22 +100,36 @@ __device__ __forceinline__ void dot_rows(float (&acc)[R], const float* rows, int
 
 __device__ __forceinline__ int state_index(int k, int s) { return ((k >> 2) * kMadeSamples + s) * 4 + (k & 3); }
 
-// block `t` -> LDS at `dst`: the wave requests one grain (64 lanes x 16 bytes) per instruction
-__device__ __forceinline__ void request_block(const MadeInvArgs& a, int t, float* dst, int lane) {
+// block `t` -> LDS at `dst`: a wave requests one grain (64 lanes x 16 bytes) per instruction, grain g is
+// wave g % 4's
+__device__ __forceinline__ void request_block(const MadeInvArgs& a, int t, float* dst, int lane, int wave) {
     const int g0 = a.block_at[t], g1 = a.block_at[t + 1];
     const char* src = reinterpret_cast<const char*>(a.blocks) + (size_t)g0 * (kMadeGrain * 4) + lane * 16;
     char* d = reinterpret_cast<char*>(dst);
-    for (int g = 0; g < g1 - g0; ++g)
+    for (int g = wave; g < g1 - g0; g += kMadeWaves)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)g * (kMadeGrain * 4)),
                                          (__attribute__((address_space(3))) void*)(d + g * (kMadeGrain * 4)), 16, 0, 0);
 }
 
 template <int KT>
-__global__ void __launch_bounds__(kWave) made_rqs_inverse_kernel(const MadeInvArgs a) {
+__global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(const MadeInvArgs a) {
 #pragma clang fp contract(off)
     constexpr int P = 3 * KT - 1;
+    constexpr int RB = (P + kMadeWaves - 1) / kMadeWaves;        // output rows of a wave per step
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x, s = lane & 15, q = lane >> 4;
+    __shared__ float s_params[32 * kMadeSamples];                   // a feature's logits of the 16 samples
+    __shared__ int s_cfg[kMadeMaxLinears][5];                       // per Linear: columns, src, dst, add, set (a
+                                                                    // dynamically indexed kernel argument is a
+                                                                    // scalar memory load every time it is read)
+    if (threadIdx.x < kMadeMaxLinears) {
+        const int l = threadIdx.x;
+        s_cfg[l][0] = a.kp[l];
+        s_cfg[l][1] = a.src[l];
+        s_cfg[l][2] = a.dst[l];
+        s_cfg[l][3] = a.add_stream[l];
+        s_cfg[l][4] = a.set_stream[l];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, s = lane & 15, q = lane >> 4;
     const int64_t row = (int64_t)blockIdx.x * kMadeSamples + s;
     const bool live = row < a.batch;
     const int64_t rrow = live ? row : a.batch - 1;
@@ -115,89 +139,111 @@ __global__ void __launch_bounds__(kWave) made_rqs_inverse_kernel(const MadeInvAr
     float* vecs = lds + (a.Xp >> 2) * kMadeSamples * 4;             // [num_vectors][Hp / 4][16][4]
     float* buf0 = lds + state_floats;                               // two step blocks
     float* buf1 = buf0 + a.max_block;
-    request_block(a, 0, buf0, lane);
-    for (int i = lane; i < state_floats; i += kWave) lds[i] = 0.0f;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    request_block(a, 0, buf0, lane, wave);
+    for (int i = threadIdx.x; i < state_floats; i += kMadeWaves * kWave) lds[i] = 0.0f;
 
     float lad_acc = 0.0f;
     int my_status = 0;
     const float* zrow = a.z + rrow * a.D;
     float* stream = a.residual ? vecs + a.stream_vec * vec_floats : nullptr;
     float z_next = zrow[0];
+    unsigned long long* tr = (a.trace && blockIdx.x == 0 && threadIdx.x == 0) ? a.trace : nullptr;
+    int ti = 0;
+#define NFA_K12_STAMP() if (tr && ti < 250) tr[ti++] = __builtin_readcyclecounter();
     for (int t = 0; t <= a.T; ++t) {
         float* blk = (t & 1) ? buf1 : buf0;
-        // block t has landed (requested a whole step ago), every read of the other half is done
+        NFA_K12_STAMP()
+        // block t has landed (every wave's share, requested a whole step ago); everything the previous
+        // step wrote to LDS is visible, every read of the other buffer half is done
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        NFA_K12_STAMP()
         const float z_t = z_next;
         if (t < a.T) {
-            request_block(a, t + 1, (t & 1) ? buf0 : buf1, lane);
+            request_block(a, t + 1, (t & 1) ? buf0 : buf1, lane, wave);
             if (t + 1 < a.T) z_next = zrow[t + 1];
         }
         const int* hdr = reinterpret_cast<const int*>(blk);
-        const float* rows = blk + kMadeHeader;
         const float* tail = blk + hdr[12];          // per unit (bias, index), then the feature's P biases
-        // ---- 1. hidden units of degree t, layer by layer
-        for (int l = 0; l < a.num_linears; ++l) {
-            const int n = hdr[l];
-            if (n == 0) continue;
-            const float* src = a.src[l] < 0 ? xs : vecs + a.src[l] * vec_floats;
-            const int kp = a.kp[l], chunks = kp >> 2;
-            float* dst = a.dst[l] < 0 ? nullptr : vecs + a.dst[l] * vec_floats;
-            for (int u = 0; u < n; ++u) {
-                float acc[1];
-                dot_rows<1>(acc, rows, kp, src, chunks, q, s, 1);
-                rows += kp;
-                const int j = __builtin_bit_cast(int, tail[1]);
-                float v = acc[0] + tail[0];
-                tail += 2;
-                const int at = state_index(j, s);
-                if (a.add_stream[l]) v = stream[at] + v;          // residual connection (made.py:128)
-                if (q == 0) {
-                    if (a.set_stream[l]) stream[at] = v;
-                    if (dst) dst[at] = v < 0.0f ? 0.0f : v;       // ReLU'd for the next Linear (NaN stays)
+        // ---- 1. hidden units of degree t, layer by layer (wave 0; typically one unit per layer)
+        int units = 0;
+        for (int l = 0; l < a.num_linears; ++l) units += hdr[l];
+        if (wave == 0) {
+            const float* rows = blk + kMadeHeader;
+            const float* ut = tail;
+            for (int l = 0; l < a.num_linears; ++l) {
+                const int n = hdr[l];
+                if (n == 0) continue;
+                const int kp = s_cfg[l][0], chunks = kp >> 2, src_v = s_cfg[l][1], dst_v = s_cfg[l][2];
+                const bool add_stream = s_cfg[l][3] != 0, set_stream = s_cfg[l][4] != 0;
+                const float* src = src_v < 0 ? xs : vecs + src_v * vec_floats;
+                float* dst = dst_v < 0 ? nullptr : vecs + dst_v * vec_floats;
+                for (int u = 0; u < n; ++u) {
+                    float acc[1];
+                    dot_rows<1, 8>(acc, rows, kp, src, chunks, q, s, 1);
+                    rows += kp;
+                    const int j = __builtin_bit_cast(int, ut[1]);
+                    float v = acc[0] + ut[0];
+                    ut += 2;
+                    const int at = state_index(j, s);
+                    if (add_stream) v = stream[at] + v;               // residual connection (made.py:128)
+                    if (q == 0) {
+                        if (set_stream) stream[at] = v;
+                        if (dst) dst[at] = v < 0.0f ? 0.0f : v;       // ReLU'd for the next Linear (NaN stays)
+                    }
+                }
+                // the units just written are inputs of the next Linear
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        NFA_K12_STAMP()
+        if (units) __syncthreads();                 // (uniform: the header is the same for every thread)
+        if (t == a.T) break;
+        tail += 2 * units;
+        // ---- 2. feature t's P output rows on the hidden vector as it stands: rows wave, wave + 4, ...
+        {
+            const float* fin = vecs + a.final_src * vec_floats;
+            const float* wf = blk + hdr[13];
+            float acc[RB];
+            const int mine = (P - wave + kMadeWaves - 1) / kMadeWaves;
+            dot_rows<RB, 4>(acc, wf + wave * a.Hp, kMadeWaves * a.Hp, fin, a.Hp >> 2, q, s, mine);
+            if (q == 0) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int p_ = wave + kMadeWaves * i;
+                    if (p_ < P) s_params[p_ * kMadeSamples + s] = acc[i] + tail[p_];
                 }
             }
-            // the units just written are inputs of the next Linear
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (t == a.T) break;
-        // ---- 2. feature t's P output rows on the hidden vector as it stands
-        const float* fin = vecs + a.final_src * vec_floats;
-        const float* wf = blk + hdr[13];
+        NFA_K12_STAMP()
+        __syncthreads();
+        NFA_K12_STAMP()
+        // ---- 3. invert feature t (rational_quadratic.py:66-181 through the same evaluation as K5); every
+        //      thread of a sample does it, one records the result
         float p[P];
-        constexpr int RB = 8;
 #pragma unroll
-        for (int p0 = 0; p0 < P; p0 += RB) {
-            float acc[RB];
-            dot_rows<RB>(acc, wf + p0 * a.Hp, a.Hp, fin, a.Hp >> 2, q, s, P - p0 < RB ? P - p0 : RB);
-#pragma unroll
-            for (int r = 0; r < RB; ++r)
-                if (p0 + r < P) p[p0 + r] = acc[r] + tail[p0 + r];
-        }
-        // ---- 3. invert feature t (rational_quadratic.py:66-181 through the same evaluation as K5)
+        for (int j = 0; j < P; ++j) p[j] = s_params[j * kMadeSamples + s];
         float y, l;
         my_status |= rqs_eval<KT, true, true, true>(z_t, p, a.sp, y, l);
         lad_acc += l;
-        if (q == 0) {
-            if (t < a.Xp) xs[state_index(t, s)] = y;
-            if (live) a.x[row * a.D + t] = y;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // (kept in LDS only: a global store per step would sit in front of the next step's vmcnt(0))
+        if (wave == 0 && q == 0) xs[state_index(t, s)] = y;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (live && q == 0) a.lad[row] = lad_acc;
-    // the final hidden vector of every sample: input of the output layer for features >= T
-    {
+    __syncthreads();
+    // the features found, [16 samples][T] -> the first T columns of the samples' rows
+    if (live)
+        for (int k = q + 4 * wave; k < a.T; k += 4 * kMadeWaves) a.x[row * a.D + k] = xs[state_index(k, s)];
+    if (wave == 0) {
+        if (live && q == 0) a.lad[row] = lad_acc;
+        // the final hidden vector of every sample: input of the output layer for features >= T
         const float* fin = vecs + a.final_src * vec_floats;
         if (live)
             for (int k = q; k < a.H; k += 4) a.hidden[row * a.H + k] = fin[state_index(k, s)];
+        if (!live) my_status = 0;
+        if (my_status && a.status) atomicOr(a.status, my_status);
     }
-    if (!live) my_status = 0;
-    if (my_status && a.status) atomicOr(a.status, my_status);
 }
 
 }  // namespace nfa
@@ -242,7 +288,7 @@ extern "C" int nfa_made_rqs_inverse_f32(const float* inputs, const float* step_b
         (a.residual && (a.stream_vec < 0 || a.stream_vec >= a.num_vectors)))
         return NFA_ERR_INVALID_ARGUMENT;
     const size_t lds = (((size_t)a.Xp + (size_t)a.num_vectors * a.Hp) * kMadeSamples + 2 * (size_t)a.max_block) * sizeof(float);
-    if (lds + 1024 > 160 * 1024) return NFA_ERR_UNSUPPORTED;
+    if (lds + 4096 > 160 * 1024) return NFA_ERR_UNSUPPORTED;   // (+ the 2 KB of logits and alignment)
     if (batch == 0) return NFA_OK;
     if (!inputs || !step_blocks || !block_starts || !outputs || !logabsdet || !hidden_out) return NFA_ERR_INVALID_ARGUMENT;
     a.z = inputs;
@@ -256,17 +302,18 @@ extern "C" int nfa_made_rqs_inverse_f32(const float* inputs, const float* step_b
     a.D = features;
     a.H = hidden_features;
     a.T = sequential_steps;
+    a.trace = g_k7_trace;
     void (*kern)(const MadeInvArgs) = a.sp.K == 8 ? made_rqs_inverse_kernel<8> : made_rqs_inverse_kernel<10>;
     if (lds > 64 * 1024) {
         static bool raised[2] = {false, false};
         const int which = a.sp.K == 8 ? 0 : 1;
         if (!raised[which]) {
-            NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
             raised[which] = true;
         }
     }
     const int64_t blocks = (batch + kMadeSamples - 1) / kMadeSamples;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kWave), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kMadeWaves * kWave), lds, (hipStream_t)stream, a);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
 }
