@@ -299,7 +299,7 @@ int nfa_rqs_flow_resnet_f32(const float *inputs, const void *weights_packed,
  *                  runs nfa_rqs_flow_resnet_redo_f32 -- the K8 kernel above restricted to the
  *                  flagged blocks, same tables, its own (bf16) weight / bias blobs -- right behind
  *                  it on the same stream; no host synchronisation in between.
- * Supported: num_bins = 8 or 10, linear tails, hidden_features = 128, d_i <= 64, d_t % 4 == 0,
+ * Supported: num_bins = 8 or 10, linear tails, hidden_features = 128 (narrower conditioners: zero-padded by the packer), d_i <= 64, d_t % 4 == 0,
  * d_t <= 64, features % 4 == 0, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
  */
 int nfa_rqs_flow_resnet_f16x2_f32(const float *inputs, const void *stream_packed, int32_t param_stages,

@@ -781,6 +781,19 @@ def _bias_accumulator_order(b):
     return b.view(-1, 4, 2, 4).permute(0, 2, 1, 3).reshape(-1)
 
 
+def _pad_to(t, rows=None, cols=None):
+    """Zero-pads a 2-D weight (or a 1-D bias with `rows`) up to the kernels' fixed hidden width: hidden
+    units beyond the network's own have zero weights and biases on both sides, relu(0) = 0, so they
+    change nothing -- a conditioner narrower than 128 runs in the 128-wide kernels as it is."""
+    if t.dim() == 1:
+        return t if rows is None or t.shape[0] == rows else torch.cat((t, t.new_zeros(rows - t.shape[0])))
+    if rows is not None and t.shape[0] < rows:
+        t = torch.cat((t, t.new_zeros(rows - t.shape[0], t.shape[1])), dim=0)
+    if cols is not None and t.shape[1] < cols:
+        t = torch.cat((t, t.new_zeros(t.shape[0], cols - t.shape[1])), dim=1)
+    return t
+
+
 def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False):
     """Packs a ResidualNet (initial_layer, blocks[*].linear_layers[0,1], final_layer) for K8
     (layout in include/nflows_amd.h): every weight as split-bf16 triples in 12 KB stages, in the
@@ -796,28 +809,30 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False)
         return torch.stack(split_bf16x3(w))  # [3, ...]
 
     stages, biases = [], []
-    wi = net.initial_layer.weight.detach().float()
+    H = net.initial_layer.weight.shape[0]                      # <= 128: narrower nets are zero-padded
+    wi = _pad_to(net.initial_layer.weight.detach().float(), rows=128)
     di = wi.shape[1]                                           # identity features (+ context features)
     init_ks = 4 if di > 32 else 2                              # k-steps of the initial layer
     wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
     # (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j)
     stages.append(pieces(wi).view(3, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks, -1))
-    biases.append(_bias_accumulator_order(net.initial_layer.bias.detach().float()))
+    biases.append(_bias_accumulator_order(_pad_to(net.initial_layer.bias.detach().float(), rows=128)))
     for block in net.blocks:
         for lin in block.linear_layers:
-            w = lin.weight.detach().float().index_select(1, order_k)  # columns in (ks, hf, j) order
+            w = _pad_to(lin.weight.detach().float(), rows=128, cols=128).index_select(1, order_k)  # columns in (ks, hf, j) order
             # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one stage per k-step
             stages.append(pieces(w).view(3, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1))
-            biases.append(_bias_accumulator_order(lin.bias.detach().float()))
+            biases.append(_bias_accumulator_order(_pad_to(lin.bias.detach().float(), rows=128)))
         if getattr(block, "context_layer", None) is not None:
             # the GLU gate's Linear, tile-major: one stage per 32-row tile, (p, t, i, k4, hf, j) -> (t, p, k4, hf, i, j)
-            wc = block.context_layer.weight.detach().float()
-            wc = torch.cat((wc, wc.new_zeros(128, 64 - wc.shape[1])), dim=1)
+            wc = _pad_to(block.context_layer.weight.detach().float(), rows=128, cols=64)
             stages.append(pieces(wc).view(3, 4, 32, 4, 2, 8).permute(1, 0, 3, 4, 2, 5).reshape(4, -1))
-            biases.append(_bias_accumulator_order(block.context_layer.bias.detach().float()))
+            biases.append(_bias_accumulator_order(_pad_to(block.context_layer.bias.detach().float(), rows=128)))
     scale = torch.ones(P, dtype=torch.float64, device=dev)
     scale[:2 * K] = (math.log2(math.e) if log2e else 1.0) / math.sqrt(net.hidden_features)
-    wf = (net.final_layer.weight.detach().double().view(dt, P, 128) * scale[None, :, None]).float()
+    wf = net.final_layer.weight.detach().double().view(dt, P, H)
+    wf = torch.cat((wf, wf.new_zeros(dt, P, 128 - H)), dim=2) if H < 128 else wf
+    wf = (wf * scale[None, :, None]).float()
     bf = (net.final_layer.bias.detach().double().view(dt, P) * scale[None, :]).float()
     R = 24 if P <= 24 else 32  # rows per feature after padding (8 bins: 23 -> 24; 10 bins: 29 -> 32)
     order_r = (_k7_row_order(dt) if R == 24 else _k8_row_order_32(dt)).to(dev)
@@ -865,18 +880,18 @@ def pack_mlp_conditioner(net, num_transform, additive=False):
         return torch.stack(split_bf16x3(w))  # [3, ...]
 
     stages, biases = [], []
-    wi = net._input_layer.weight.detach().float()
+    wi = _pad_to(net._input_layer.weight.detach().float(), rows=128)   # hidden widths <= 128 are zero-padded
     di = wi.shape[1]
     init_ks = 4 if di > 32 else 2
     wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
     stages.append(pieces(wi).view(3, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks, -1))
-    biases.append(_bias_accumulator_order(net._input_layer.bias.detach().float()))
+    biases.append(_bias_accumulator_order(_pad_to(net._input_layer.bias.detach().float(), rows=128)))
     for lin in net._hidden_layers:
-        w = lin.weight.detach().float().index_select(1, order_k)
+        w = _pad_to(lin.weight.detach().float(), rows=128, cols=128).index_select(1, order_k)
         stages.append(pieces(w).view(3, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1))
-        biases.append(_bias_accumulator_order(lin.bias.detach().float()))
+        biases.append(_bias_accumulator_order(_pad_to(lin.bias.detach().float(), rows=128)))
     order_r = _affine_row_order(dt, additive).to(dev)
-    wo = net._output_layer.weight.detach().float()
+    wo = _pad_to(net._output_layer.weight.detach().float(), cols=128)
     bo = net._output_layer.bias.detach().float()
     wo = torch.cat((wo, wo.new_zeros(1, 128)), dim=0)     # row -1 = zero padding
     bo = torch.cat((bo, bo.new_zeros(1)))
@@ -960,29 +975,33 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
         return torch.tensor([a, b, 0.0, 0.0], dtype=torch.float32, device=dev)
 
     stages, blob = [], []
-    wi = net.initial_layer.weight.detach().float()
+    H = net.initial_layer.weight.shape[0]                      # <= 128: narrower nets are zero-padded
+    wi = _pad_to(net.initial_layer.weight.detach().float(), rows=128)
     di = wi.shape[1]
     init_ks = 4 if di > 32 else 2
     wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
     T = _f16_weight_scale(wi)
     # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one stage of four tile pairs per k-step
     stages.append(pieces(wi * T).view(2, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks, -1))
-    blob += [header(S / T, 0.0), _bias_accumulator_order(net.initial_layer.bias.detach().float() * T)]
+    blob += [header(S / T, 0.0), _bias_accumulator_order(_pad_to(net.initial_layer.bias.detach().float(), rows=128) * T)]
     stream_scale = T          # scale of the fp32 residual stream after the initial layer (inputs at scale 1)
     for block in net.blocks:
         for which, lin in enumerate(block.linear_layers):
-            w = lin.weight.detach().float().index_select(1, order_k)  # columns in (ks, hf, j) order
+            w = _pad_to(lin.weight.detach().float(), rows=128, cols=128).index_select(1, order_k)  # columns in (ks, hf, j) order
             T = _f16_weight_scale(w)
             # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one stage per k-step
             stages.append(pieces(w * T).view(2, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1))
+            lin_bias = _pad_to(lin.bias.detach().float(), rows=128)
             if which == 0:   # accumulators = S T (W relu(h) + b)
-                blob += [header(1.0 / T, 0.0), _bias_accumulator_order(lin.bias.detach().float() * (S * T))]
+                blob += [header(1.0 / T, 0.0), _bias_accumulator_order(lin_bias * (S * T))]
             else:            # accumulators = S T (W relu(u) + b + h), h taken from the stream at stream_scale
-                blob += [header(1.0 / T, S * T / stream_scale), _bias_accumulator_order(lin.bias.detach().float() * (S * T))]
+                blob += [header(1.0 / T, S * T / stream_scale), _bias_accumulator_order(lin_bias * (S * T))]
                 stream_scale = S * T
     scale = torch.ones(P, dtype=torch.float64, device=dev)
     scale[:2 * K] = 1.0 / math.sqrt(net.hidden_features)
-    wf = (net.final_layer.weight.detach().double().view(dt, P, 128) * scale[None, :, None]).float()
+    wf = net.final_layer.weight.detach().double().view(dt, P, H)
+    wf = torch.cat((wf, wf.new_zeros(dt, P, 128 - H)), dim=2) if H < 128 else wf
+    wf = (wf * scale[None, :, None]).float()
     bf = (net.final_layer.bias.detach().double().view(dt, P) * scale[None, :]).float()
     R = 24 if P == 23 else 32   # rows per feature after padding
     order_r = (_k7_row_order(dt) if R == 24 else _k8_row_order_32(dt)).to(dev)

@@ -256,7 +256,7 @@ class AffineCouplingTransform(CouplingTransform):
         net = self.transform_net
         ok = (self.fuse_conditioner and not torch.is_grad_enabled() and context is None and type(net) is MLP
               and net._activation is torch.nn.functional.relu and not net._activate_output
-              and all(h == 128 for h in net._hidden_sizes) and self._activation_code() != N.SCALE_GIVEN
+              and all(h <= 128 for h in net._hidden_sizes) and self._activation_code() != N.SCALE_GIVEN
               and 1 <= self.num_identity_features <= 64 and 1 <= self.num_transform_features <= 64
               and self.features <= 128)
         return "k11" if ok else None
@@ -400,7 +400,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
                           and self.num_identity_features + net.context_features <= 64)
         return (self.fuse_conditioner and self.fuse_final_linear and not torch.is_grad_enabled()
                 and context_ok and type(net) is ResidualNet
-                and net.hidden_features == 128 and self.tails == "linear" and self.num_bins in (8, 10)
+                and net.hidden_features <= 128 and self.tails == "linear" and self.num_bins in (8, 10)
                 and 1 <= self.num_identity_features <= 64 and self.num_transform_features % 4 == 0
                 and self.num_transform_features <= 64 and self.features <= 128
                 and all(b.activation is torch.nn.functional.relu and not b.use_batch_norm

@@ -880,3 +880,49 @@ def test_persistent_autoregressive_inverse_equals_the_step_by_step_loop(monkeypa
     # forward(inverse(z)) = z as well as the step-by-step loop manages it (scaled weights: steep bins)
     assert (zz - z).abs().max().item() <= 2 * (zz_ref - z).abs().max().item() + 1e-5
     assert (lad + lad_fwd).abs().max().item() <= 2 * (lad_ref + lad_fwd_ref).abs().max().item() + 1e-4
+
+
+@pytest.mark.parametrize("hidden", [30, 64, 96])
+@pytest.mark.parametrize("engine", ["f16x2", "bf16x3"])
+def test_whole_layer_kernels_take_narrower_conditioners(monkeypatch, hidden, engine):
+    """Conditioners narrower than the kernels' 128 hidden units run in them zero-padded (padding units have
+    zero weights and biases on both sides and stay at relu(0) = 0): spline flows on both engines and an
+    affine flow, against the layer-by-layer path.  The 1/sqrt(hidden) scale of the width / height logits
+    (coupling.py:554-556) uses the network's own width."""
+    from nflows_amd import configs
+    from nflows_amd.flows.base import Flow
+    from nflows_amd.distributions.normal import StandardNormal
+    from nflows_amd.nn.nets import MLP
+    from nflows_amd.transforms import (AffineCouplingTransform, CompositeTransform,
+                                       PiecewiseRationalQuadraticCouplingTransform as RQ)
+    from nflows_amd.utils.torchutils import create_alternating_binary_mask
+    monkeypatch.setattr(RQ, "conditioner_engine", engine)
+    flow = configs.rq_nsf_flow(num_layers=4, features=32, num_bins=8, hidden_features=hidden, seed=5)
+    with torch.no_grad():
+        for name, p in flow.named_parameters():
+            if "final_layer" in name:
+                p.mul_(4.0)
+            elif "linear_layers.1" in name:
+                p.mul_(30.0)
+    flow = flow.to(DEV).eval()
+    torch.manual_seed(6)
+    affine = Flow(CompositeTransform([
+        AffineCouplingTransform(create_alternating_binary_mask(32, even=(i % 2 == 0)),
+                                lambda a, b: MLP([a], [b], [hidden, hidden])) for i in range(4)]),
+        StandardNormal([32])).to(DEV).eval()
+    x = torch.randn(512, 32, generator=torch.Generator().manual_seed(7)).to(DEV)
+    for f, cls in ((flow, RQ), (affine, AffineCouplingTransform)):
+        results = {}
+        for fused in (True, False):
+            monkeypatch.setattr(cls, "fuse_conditioner", fused)
+            with torch.no_grad():
+                units, _ = f._transform._collect_run(list(f._transform._transforms), 0, x, None, inverse=False)
+                assert bool(units) == fused
+                z, lad = f._transform(x)
+                lp = f.log_prob(x)
+                xr, _ = f._transform.inverse(z)
+                assert (xr - x).abs().max().item() < 2e-4
+            results[fused] = (z, lad, lp)
+        for got, want in zip(results[True], results[False]):
+            assert torch.isfinite(got).all()
+            assert (got - want).abs().max().item() <= 5e-5 * (1 + want.abs().max().item())
