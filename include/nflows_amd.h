@@ -418,6 +418,18 @@ int nfa_rqs_elementwise_f32(const float *inputs, const float *unnormalized_width
                             int32_t inverse, void *stream);
 
 /*
+ * K5 in float64: the same functional on double tensors (the reference is dtype-generic,
+ * rational_quadratic.py:66-181) -- `.double()` flows and the float64 ground truth of parity checks run
+ * on the device.  Same arguments and status bits as nfa_rqs_elementwise_f32; a plain kernel (one lane per
+ * element, logits read from global memory), not a fast path.
+ */
+int nfa_rqs_elementwise_f64(const double *inputs, const double *unnormalized_widths, int64_t stride_w,
+                            const double *unnormalized_heights, int64_t stride_h,
+                            const double *unnormalized_derivatives, int64_t stride_d,
+                            int32_t num_derivatives, double *outputs, double *logabsdet, int32_t *status,
+                            int64_t n, const nfa_rqs_spec *spec, int32_t inverse, void *stream);
+
+/*
  * K9.  The spline's siblings as elementwise functionals (no row-sum), same calling convention as
  * nfa_rqs_elementwise_f32; spec supplies num_bins, tails (NFA_TAILS_LINEAR: box = +-right,
  * elements outside pass through with logabsdet 0), the box, and for the quadratic spline

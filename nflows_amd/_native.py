@@ -44,6 +44,7 @@ EXPORTS = (
     "nfa_rqs_flow_resnet_f32",
     "nfa_rqs_flow_resnet_redo_f32",
     "nfa_rqs_flow_resnet_context_f32",
+    "nfa_rqs_elementwise_f64",
     "nfa_affine_flow_mlp_f32",
     "nfa_made_rqs_inverse_f32",
     "nfa_rqs_flow_resnet_f16x2_f32",
@@ -135,6 +136,8 @@ def _declare(lib):
     lib.nfa_rqs_flow_resnet_context_f32.restype = ctypes.c_int
     lib.nfa_rqs_flow_resnet_context_f32.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i64, i32, i32, i32, i32,
                                                     i32, sp, i32, vp]
+    lib.nfa_rqs_elementwise_f64.restype = ctypes.c_int
+    lib.nfa_rqs_elementwise_f64.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, i64, sp, i32, vp]
     lib.nfa_made_rqs_inverse_f32.restype = ctypes.c_int
     lib.nfa_made_rqs_inverse_f32.argtypes = [vp, vp, vp, ctypes.POINTER(ctypes.c_int32), i32, vp, vp, vp, vp, i64,
                                              i32, i32, i32, sp, vp]
@@ -220,6 +223,15 @@ def require_device_f32(name, t, dim=None):
     if dim is not None and t.dim() != dim:
         raise ValueError("%s must be %d-D, got %d-D" % (name, dim, t.dim()))
     return t
+
+
+def require_device_real(name, t, dtype, dim=None):
+    """float32 or float64 on the device (the float64 functional path)."""
+    if torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float64 and dtype == torch.float64:
+        if dim is not None and t.dim() != dim:
+            raise ValueError("%s must be %d-D, got %d-D" % (name, dim, t.dim()))
+        return t
+    return require_device_f32(name, t, dim)
 
 
 def ptr(t):

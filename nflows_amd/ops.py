@@ -216,11 +216,15 @@ def rqs_elementwise(inputs, unnormalized_widths, unnormalized_heights, unnormali
                     spec, inverse=False):
     """K5 -- elementwise functional on tensors of any leading shape S; logits S+[K], S+[K],
     S+[K-1 | K+1].  Returns (outputs S, logabsdet S)."""
-    N.require_device_f32("inputs", inputs)
+    dtype = inputs.dtype if torch.is_tensor(inputs) else torch.float32   # float64: the plain K5d kernel
+    N.require_device_real("inputs", inputs, dtype)
     for nm, t in (("unnormalized_widths", unnormalized_widths),
                   ("unnormalized_heights", unnormalized_heights),
                   ("unnormalized_derivatives", unnormalized_derivatives)):
-        N.require_device_f32(nm, t)
+        N.require_device_real(nm, t, dtype)
+    if dtype == torch.float64 and AG.needs_grad(inputs, unnormalized_widths, unnormalized_heights,
+                                                unnormalized_derivatives):
+        raise NotImplementedError("nflows_amd: gradients of the float64 functional are not implemented")
     if AG.needs_grad(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives):
         return AG.RqsElementwise.apply(inputs, unnormalized_widths, unnormalized_heights,
                                        unnormalized_derivatives, spec, bool(inverse))
@@ -261,8 +265,9 @@ def _rqs_elementwise_launch(inputs, unnormalized_widths, unnormalized_heights, u
     ud, sd = rows(unnormalized_derivatives, nd)
     y = torch.empty_like(x)
     lad = torch.empty_like(x)
+    launch = N.load().nfa_rqs_elementwise_f64 if x.dtype == torch.float64 else N.load().nfa_rqs_elementwise_f32
     with torch.cuda.device(dev):
-        rc = N.load().nfa_rqs_elementwise_f32(N.ptr(x), N.ptr(uw), sw, N.ptr(uh), sh,
+        rc = launch(N.ptr(x), N.ptr(uw), sw, N.ptr(uh), sh,
                                               N.ptr(ud) if nd else N.ptr(uw), sd, nd, N.ptr(y), N.ptr(lad),
                                               N.ptr(_status_word(dev)), n, ctypes.byref(spec),
                                               int(bool(inverse)), N.stream_handle(dev))
@@ -489,7 +494,12 @@ def rowsum(x):
 
 
 def standard_normal_log_prob(z, logabsdet=None):
-    """-0.5*sum(z^2) - 0.5*D*log(2*pi) (+ logabsdet), one kernel."""
+    """-0.5*sum(z^2) - 0.5*D*log(2*pi) (+ logabsdet), one kernel (float64: the same expression as device
+    tensor operations, distributions/normal.py:27-33)."""
+    if torch.is_tensor(z) and z.is_cuda and z.dtype == torch.float64:
+        flat = z.reshape(z.shape[0], -1)
+        out = -0.5 * torch.sum(flat ** 2, dim=1) - 0.5 * flat.shape[1] * math.log(2 * math.pi)
+        return out if logabsdet is None else out + logabsdet
     N.require_device_f32("inputs", z)
     if logabsdet is not None:
         N.require_device_f32("logabsdet", logabsdet, 1)

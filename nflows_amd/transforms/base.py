@@ -49,7 +49,8 @@ def _is_column_permutation(t):
 
 
 def _accepts_fused_permutation(t, inputs):
-    return getattr(t, "supports_fused_permutation", False) and inputs.dim() == 2
+    return (getattr(t, "supports_fused_permutation", False) and inputs.dim() == 2
+            and inputs.dtype == torch.float32)   # (float64 flows take the generic device path)
 
 
 class CompositeTransform(Transform):
@@ -79,7 +80,7 @@ class CompositeTransform(Transform):
         Returns (units, next_index) with units = [(coupling, permutation or None)]."""
         units = []
         if not (self.fuse_layer_runs and inputs.dim() == 2 and inputs.shape[0] >= 128
-                and inputs.shape[1] % 4 == 0):
+                and inputs.shape[1] % 4 == 0 and inputs.dtype == torch.float32):
             return units, start
 
         def eligible(t):

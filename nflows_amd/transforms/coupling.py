@@ -78,7 +78,8 @@ class CouplingTransform(Transform):
         if inputs.dim() == 4 and not self.supports_image_inputs:
             raise NotImplementedError(
                 "nflows_amd: 4-D (image) inputs are implemented for the piecewise spline couplings only")
-        N.require_device_f32("inputs", inputs, inputs.dim())
+        # float64: the generic sequence on the device (torch gathers, the float64 functional kernel)
+        N.require_device_real("inputs", inputs, inputs.dtype, inputs.dim())
 
     def _identity_columns(self, perm):
         """identity_features seen through a fused permutation, cached per permutation tensor."""
@@ -99,7 +100,7 @@ class CouplingTransform(Transform):
         `logabsdet_accumulator`: a [batch] running total the layer's logabsdet is added to in the
         kernel (CompositeTransform's `total_logabsdet +=`); it is then also the returned tensor."""
         self._check_inputs(inputs)
-        if inputs.dim() == 4 or not self.supports_fused_permutation:
+        if inputs.dim() == 4 or inputs.dtype == torch.float64 or not self.supports_fused_permutation:
             return self._generic(inputs, context, False, logabsdet_accumulator)
         if self.unconditional_transform is None:
             whole = self._whole_layer(inputs, context, False, in_perm, None, logabsdet_accumulator)
@@ -122,7 +123,7 @@ class CouplingTransform(Transform):
         """Inverse pass (coupling.py:102-130).  `out_scatter`: store layer column c at
         outputs[:, out_scatter[c]] (a following Permutation.inverse, fused)."""
         self._check_inputs(inputs)
-        if inputs.dim() == 4 or not self.supports_fused_permutation:
+        if inputs.dim() == 4 or inputs.dtype == torch.float64 or not self.supports_fused_permutation:
             return self._generic(inputs, context, True, logabsdet_accumulator)
         if self.unconditional_transform is None:
             whole = self._whole_layer(inputs, context, True, None, out_scatter, logabsdet_accumulator)
@@ -222,7 +223,7 @@ class AffineCouplingTransform(CouplingTransform):
         the conditioner's channels are [shift block | scale block]): every pixel is a row of C
         features for the layer kernel, the log-determinant is summed over the pixels afterwards."""
         if inputs.dim() != 4:
-            return super()._generic(inputs, context, inverse, logabsdet_accumulator)
+            return self._generic_float64(inputs, context, inverse, logabsdet_accumulator)
         b, c, h, w = inputs.shape
         identity_split = inputs.index_select(1, self.identity_features)
         logabsdet = None
@@ -274,6 +275,39 @@ class AffineCouplingTransform(CouplingTransform):
                                                     additive=self._activation_code() == N.SCALE_ADDITIVE))
             self._packed_mlp_cache = cached
         return cached[1]
+
+    def _generic_float64(self, inputs, context, inverse, logabsdet_accumulator):
+        """float64 vectors: the reference's expressions (coupling.py:73-130, :228-252) as tensor operations on
+        the device (conditioner outputs [shift block | unconstrained scale block])."""
+        identity_split = inputs.index_select(1, self.identity_features)
+        transform_split = inputs.index_select(1, self.transform_features)
+        logabsdet = None
+        if inverse and self.unconditional_transform is not None:
+            identity_split, logabsdet = self.unconditional_transform.inverse(identity_split, context)
+        params = self.transform_net(identity_split, context)
+        dt = self.num_transform_features
+        shift = params[:, :dt]
+        if self._transform_dim_multiplier() == 1:
+            transform_split = transform_split - shift if inverse else transform_split + shift
+            lad = inputs.new_zeros(inputs.shape[0])
+        else:
+            scale = self.scale_activation(params[:, dt:])
+            log_scale = torch.log(scale).sum(dim=1)
+            if inverse:
+                transform_split, lad = (transform_split - shift) / scale, -log_scale
+            else:
+                transform_split, lad = transform_split * scale + shift, log_scale
+        logabsdet = lad if logabsdet is None else logabsdet + lad
+        if not inverse and self.unconditional_transform is not None:
+            identity_split, lad_identity = self.unconditional_transform(identity_split, context)
+            logabsdet = logabsdet + lad_identity
+        outputs = torch.empty_like(inputs)
+        outputs.index_copy_(1, self.identity_features, identity_split)
+        outputs.index_copy_(1, self.transform_features, transform_split)
+        if logabsdet_accumulator is not None:
+            logabsdet_accumulator += logabsdet
+            logabsdet = logabsdet_accumulator
+        return outputs, logabsdet
 
     def _activation_code(self):
         if self.scale_activation is AffineCouplingTransform.DEFAULT_SCALE_ACTIVATION:

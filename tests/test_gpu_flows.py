@@ -926,3 +926,60 @@ def test_whole_layer_kernels_take_narrower_conditioners(monkeypatch, hidden, eng
         for got, want in zip(results[True], results[False]):
             assert torch.isfinite(got).all()
             assert (got - want).abs().max().item() <= 5e-5 * (1 + want.abs().max().item())
+
+
+def test_float64_flows_run_on_the_device(golden, golden_dir):
+    """`.double()` flows (the reference is dtype-generic): the float64 functional kernel (K5d) + device tensor
+    operations reproduce the reference's float64 results -- the spline coupling flows and the affine flow of
+    tests/golden/flows.npz and the conditional flow of flows_context.npz, log_prob and both directions."""
+    import nflows_amd
+    from helpers import golden_conditional_flow
+    for name, cfg in golden["meta"]:
+        cfg = parse_kwargs(cfg)
+        if cfg["kind"] not in ("rq_nsf", "affine"):
+            continue
+        flow = build(cfg)
+        load_state(flow, golden, name)
+        flow = flow.double().to(DEV).eval()
+        x = torch.from_numpy(golden[name + "/x"]).double().to(DEV)
+        noise = torch.from_numpy(golden[name + "/noise"]).double().to(DEV)
+        with torch.no_grad():
+            lp = flow.log_prob(x)
+            z, lad = flow._transform(x)
+            xs, lad_inv = flow._transform.inverse(noise)
+        nflows_amd.check_status()
+        for got, key in ((lp, "log_prob64"), (z, "z64"), (lad, "lad64"), (xs, "inv_x64"), (lad_inv, "inv_lad64")):
+            assert got.dtype == torch.float64 and got.is_cuda
+            ref = golden[name + "/" + key]
+            assert np.abs(got.cpu().numpy() - ref).max() <= 1e-10 * (1 + np.abs(ref).max()), (name, key)
+    flow, g, name = golden_conditional_flow(golden_dir)
+    flow = flow.double().to(DEV)
+    x, noise, ctx = (torch.from_numpy(g[name + "/" + k]).double().to(DEV) for k in ("x", "noise", "context"))
+    with torch.no_grad():
+        emb = flow._embedding_net(ctx)
+        lp = flow.log_prob(x, context=ctx)
+        z, lad = flow._transform(x, context=emb)
+        xs, lad_inv = flow._transform.inverse(noise, context=emb)
+    for got, key in ((lp, "log_prob64"), (z, "z64"), (lad, "lad64"), (xs, "inv_x64"), (lad_inv, "inv_lad64")):
+        ref = g[name + "/" + key]
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-9 * (1 + np.abs(ref).max()), key
+
+
+def test_float64_functional_matches_the_reference_vectors(golden_dir):
+    """K5d against the float64 results of the reference's functional on the 24 committed cases (edge values,
+    NaN / inf, extreme logits, identity init, constrained boxes)."""
+    from nflows_amd import ops
+    g = np.load(os.path.join(golden_dir, "rqs_functional.npz"))
+    for name, inv, kw in g["meta"]:
+        kw = parse_kwargs(kw)
+        x, uw, uh, ud = (torch.from_numpy(g[name + "/" + k]).double().to(DEV) for k in ("x", "uw", "uh", "ud"))
+        spec = ops.make_rqs_spec(uw.shape[-1], **kw)
+        y, lad = ops.rqs_elementwise(x, uw, uh, ud, spec, inverse=bool(int(inv)))
+        ops.check_status()
+        y, lad = y.cpu().numpy(), lad.cpu().numpy()
+        ry, rl = g[name + "/y64"], g[name + "/lad64"]
+        assert np.array_equal(np.isnan(y), np.isnan(ry)), name
+        fin = np.isfinite(ry)
+        assert np.abs(y[fin] - ry[fin]).max() <= 1e-10, name
+        assert np.abs(lad[fin] - rl[fin]).max() <= 1e-9, name
+        assert np.array_equal(y[~fin & ~np.isnan(ry)], ry[~fin & ~np.isnan(ry)]), name
