@@ -266,9 +266,10 @@ int nfa_rqs_flow_resnet_f32(const float *inputs, const void *weights_packed,
  * profiles/r2/f16x2_probe.txt) -- half the matrix-pipe work and two thirds of the weight bytes
  * of the three-piece bf16 scheme above.  Replaces the same reference code (coupling.py:73-130,
  * 549-582, nn/nets/resnet.py:92-100, transforms/base.py:45-52).
- *   stream_packed  8 KB stages in consumption order, layer after layer; everything a layer needs
+ *   stream_packed  16 KB stages in consumption order, layer after layer; everything a layer needs
  *                  reaches the kernel through this one LDS-DMA stream.  Per layer:
- *                  (1) `param_stages` PARAMETER stages = 2048 * param_stages 32-bit words:
+ *                  (1) `param_stages` PARAMETER stages, each carrying 2048 32-bit words in its first
+ *                      8 KB (the rest unused), together 2048 * param_stages words:
  *                      words [0, 64)  int32 slots of the identity features, [64, 128) of the
  *                      transformed features (the per-layer rows of `flow_tables` above, relative
  *                      to the first layer's input columns); then per GEMM -- initial_layer, every
@@ -283,14 +284,14 @@ int nfa_rqs_flow_resnet_f32(const float *inputs, const void *weights_packed,
  *                      i.e. of the GEMM that wrote it last); final_layer biases x S T, header
  *                      {kappa = 1 / (S T), 1 / kappa, 0, 0}: the spline evaluation reads logits =
  *                      accumulators x kappa.  Zero-padded to whole stages.
- *                  (2) WEIGHT stages, f16 [512 x 8]: four (hi, lo) fragment pairs of
+ *                  (2) WEIGHT stages, f16 [1024 x 8]: eight (hi, lo) fragment pairs of
  *                      [64 lanes][8]; lane l element j of a pair for (tile, k-step ks) = piece of
  *                      W'[32 tile + (l & 31)][column(ks, l >> 5, j)], W' = W x T.  initial_layer
  *                      (column = 16 ks + 8 (l >> 5) + j, columns >= d_i zero; 2 k-steps for d_i <= 32,
  *                      4 otherwise) and hidden Linears (column rule col(ks, hf, j) of K8; 8 k-steps):
- *                      one stage per k-step, pair g = output tile g.  final_layer: two stages per
- *                      32-row tile, stage 2 tile + hs = pairs (tile, ks = 4 hs + 0..3); rows ordered /
- *                      padded / pre-divided by sqrt(hidden_features) as for K8.
+ *                      one stage per TWO k-steps, pair 4 (ks % 2) + t = output tile t.  final_layer: one
+ *                      stage per 32-row tile, pair ks = k-step ks; rows ordered / padded / pre-divided
+ *                      by sqrt(hidden_features) as for K8.
  *   final_positions int32 [128]: the slot stored at every output position of the run (the last
  *                  128 entries of `flow_tables`).
  *   redo_blocks    int32 [batch / 128], written by the kernel: 0 = the 128-row block is done, 1 = it

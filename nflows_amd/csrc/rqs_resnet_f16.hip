@@ -64,8 +64,11 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 namespace k8h {
 
-constexpr int kStageVec4 = 512;    // 8 KB: four (hi, lo) fragment pairs of [64 lanes] x 16 B, or 2048 parameter words
-constexpr int kRing = 6;           // five stages in flight behind the one being consumed
+constexpr int kStageVec4 = 1024;   // 16 KB: eight (hi, lo) fragment pairs of [64 lanes] x 16 B = two k-steps of a
+                                   // k-major GEMM or one 32-row tile of the final layer (one barrier each)
+constexpr int kPairs = 8;          // fragment pairs per stage
+constexpr int kParamVec4 = 512;    // a parameter stage carries 2048 words in its first 8 KB
+constexpr int kRing = 4;           // three stages in flight behind the one being consumed
 constexpr int kRowPad = 33;
 constexpr int kTabId = 0, kTabTr = 64, kTabWords = 128;   // parameter words [0, 128): slots of identity / transformed features
 constexpr int kHdr = 4;            // floats in front of every GEMM's biases: {out_scale, skip_scale, 0, 0}
@@ -107,25 +110,25 @@ __device__ __forceinline__ void stream_request(SM& sm) {
     char* slot = reinterpret_cast<char*>(sm.ring) + dst_slot * (kStageVec4 * 16) + wave * (kWave * 16);
     const unsigned lane_off = (unsigned)sm.tid * 16u;
 #pragma unroll
-    for (int i = 0; i < 8 / NW; ++i)
+    for (int i = 0; i < 16 / NW; ++i)
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)((stage + i * kThreads * 16) + lane_off),
             (__attribute__((address_space(3))) void*)(slot + i * kThreads * 16), 16, 0, 0);
     sm.fetch = (sm.fetch + 1 == sm.num_stages) ? 0 : sm.fetch + 1;
 }
 
-// end of stage s: this wave's requests of stage s + 2 have landed (those of the three stages after
-// it may still be in flight), every wave is done reading stage s.  Stage s + 1 was complete one
+// end of stage s: this wave's requests of stage s + 2 have landed (those of stage s + 3 may still be in
+// flight: 16 / NW per wave), every wave is done reading stage s.  Stage s + 1 was complete one
 // barrier earlier, which is what lets a wave read the first weight fragments of the NEXT stage while
 // it still issues the MFMAs of the current one (no LDS latency in front of any MFMA).
 template <class SM>
 __device__ __forceinline__ void stream_advance(SM& sm) {
-    if constexpr (SM::NW == 8) asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (SM::NW == 8) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     sm.slot = (sm.slot + 1 == kRing) ? 0 : sm.slot + 1;
 }
 
-// A weight stage is four fragment pairs (hi, lo pieces of a 32 x 16 weight block): pair g at byte
+// A weight stage is eight fragment pairs (hi, lo pieces of a 32 x 16 weight block): pair g at byte
 // offsets g * 2048 (hi) and g * 2048 + 1024 (lo) (+ 16 * lane).  `fr` always holds the pair the next
 // MFMAs need; its successor -- the next pair of this stage or pair 0 of the next stage -- is requested
 // from LDS before those MFMAs are issued.
@@ -154,7 +157,7 @@ __device__ __forceinline__ void stage_begin(SM& sm, unsigned& cur, unsigned& nxt
 template <int G>
 __device__ __forceinline__ Frags next_frags(unsigned cur, unsigned nxt) {
     Frags f;
-    if constexpr (G < 3) {
+    if constexpr (G < kPairs - 1) {
         asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
                      : "=v"(f.h), "=v"(f.l)
                      : "v"(cur), "i"((G + 1) * 2048), "i"((G + 1) * 2048 + 1024));
@@ -374,7 +377,7 @@ struct SplineWeave10 {
 template <int KS, class W>
 __device__ __forceinline__ void tile_kstep(f32x16& acc, uvec4 bhw, uvec4 blw, Frags& fr, unsigned cur, unsigned nxt, W& w) {
     const f16x8 bh = __builtin_bit_cast(f16x8, bhw), bl = __builtin_bit_cast(f16x8, blw);
-    const Frags nf = next_frags<(KS & 3)>(cur, nxt);   // the next k-step's fragments, three MFMAs ahead of their use
+    const Frags nf = next_frags<KS>(cur, nxt);   // the next k-step's fragments, three MFMAs ahead of their use
     await_frags(fr);
     const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);
     fr = nf;
@@ -402,8 +405,6 @@ __device__ __forceinline__ void tile_gemm(f32x16& acc, const uvec4 (&ph)[8], con
     tile_kstep<1>(acc, ph[1], pl[1], fr, cur, nxt, w);
     tile_kstep<2>(acc, ph[2], pl[2], fr, cur, nxt, w);
     tile_kstep<3>(acc, ph[3], pl[3], fr, cur, nxt, w);
-    stream_advance(sm);
-    stage_begin(sm, cur, nxt, lane);
     tile_kstep<4>(acc, ph[4], pl[4], fr, cur, nxt, w);
     tile_kstep<5>(acc, ph[5], pl[5], fr, cur, nxt, w);
     tile_kstep<6>(acc, ph[6], pl[6], fr, cur, nxt, w);
@@ -411,43 +412,14 @@ __device__ __forceinline__ void tile_gemm(f32x16& acc, const uvec4 (&ph)[8], con
     stream_advance(sm);
 }
 
-// k-major GEMM over the four output tiles (hidden layers): one stage per k-step, pair g = tile g.
-// All four accumulators advance together, so the input pieces of a k-step are read once.
-template <int NKS, class SM>
-__device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const uvec4 (&ph)[8], const uvec4 (&pl)[8], SM& sm,
-                                            Frags& fr, int lane) {
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        unsigned cur, nxt;
-        stage_begin(sm, cur, nxt, lane);
-        const f16x8 bh = __builtin_bit_cast(f16x8, ph[ks]), bl = __builtin_bit_cast(f16x8, pl[ks]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            Frags nf;
-            if (t == 0) nf = next_frags<0>(cur, nxt);
-            else if (t == 1) nf = next_frags<1>(cur, nxt);
-            else if (t == 2) nf = next_frags<2>(cur, nxt);
-            else nf = next_frags<3>(cur, nxt);
-            await_frags(fr);
-            __builtin_amdgcn_sched_barrier(0);
-            const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);   // (smallest terms first)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            fr = nf;
-        }
-        stream_advance(sm);
-    }
-}
-
-// two k-steps of a k-major GEMM with a weave slice behind every MFMA (slots 0 .. 23)
+// two k-steps of a k-major GEMM = one stage (pair g = tile g of the first k-step, 4 + g of the second) with a
+// weave slice behind every MFMA (slots 0 .. 23)
 template <class W, class SM>
 __device__ __forceinline__ void kstep_pair_woven(f32x16 (&acc)[4], uvec4 bh0, uvec4 bl0, uvec4 bh1, uvec4 bl1, SM& sm,
                                                  Frags& fr, int lane, W&& w) {
-#define NFA_K8H_CELL(T, SLOT, BH, BL)                                                            \
+#define NFA_K8H_CELL(T, G, SLOT, BH, BL)                                                         \
     {                                                                                            \
-        const Frags nf = next_frags<T>(cur, nxt);                                                \
+        const Frags nf = next_frags<G>(cur, nxt);                                                \
         await_frags(fr);                                                                         \
         const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);  \
         fr = nf;                                                                                 \
@@ -464,26 +436,23 @@ __device__ __forceinline__ void kstep_pair_woven(f32x16 (&acc)[4], uvec4 bh0, uv
         w.template step<SLOT + 2>();                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     }
+    unsigned cur, nxt;
+    stage_begin(sm, cur, nxt, lane);
     {
-        unsigned cur, nxt;
-        stage_begin(sm, cur, nxt, lane);
         const f16x8 bh = __builtin_bit_cast(f16x8, bh0), bl = __builtin_bit_cast(f16x8, bl0);
-        NFA_K8H_CELL(0, 0, bh, bl)
-        NFA_K8H_CELL(1, 3, bh, bl)
-        NFA_K8H_CELL(2, 6, bh, bl)
-        NFA_K8H_CELL(3, 9, bh, bl)
-        stream_advance(sm);
+        NFA_K8H_CELL(0, 0, 0, bh, bl)
+        NFA_K8H_CELL(1, 1, 3, bh, bl)
+        NFA_K8H_CELL(2, 2, 6, bh, bl)
+        NFA_K8H_CELL(3, 3, 9, bh, bl)
     }
     {
-        unsigned cur, nxt;
-        stage_begin(sm, cur, nxt, lane);
         const f16x8 bh = __builtin_bit_cast(f16x8, bh1), bl = __builtin_bit_cast(f16x8, bl1);
-        NFA_K8H_CELL(0, 12, bh, bl)
-        NFA_K8H_CELL(1, 15, bh, bl)
-        NFA_K8H_CELL(2, 18, bh, bl)
-        NFA_K8H_CELL(3, 21, bh, bl)
-        stream_advance(sm);
+        NFA_K8H_CELL(0, 4, 12, bh, bl)
+        NFA_K8H_CELL(1, 5, 15, bh, bl)
+        NFA_K8H_CELL(2, 6, 18, bh, bl)
+        NFA_K8H_CELL(3, 7, 21, bh, bl)
     }
+    stream_advance(sm);
 #undef NFA_K8H_CELL
 }
 
@@ -502,6 +471,14 @@ __device__ __forceinline__ void gemm_kmajor_converting(f32x16 (&acc)[4], uvec4 (
     kstep_pair_woven(acc, ph[4], pl[4], ph[5], pl[5], sm, fr, lane,
                      ConvSlices{src[3], ph[6], pl[6], ph[7], pl[7], scale, floor_});
     kstep_pair_woven(acc, ph[6], pl[6], ph[7], pl[7], sm, fr, lane, NoWeave{});
+}
+
+// the initial layer: NKS k-steps (2 or 4) on the pieces of the identity features
+template <int NKS, class SM>
+__device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const uvec4 (&ph)[8], const uvec4 (&pl)[8], SM& sm,
+                                            Frags& fr, int lane) {
+    kstep_pair_woven(acc, ph[0], pl[0], ph[1], pl[1], sm, fr, lane, NoWeave{});
+    if constexpr (NKS == 4) kstep_pair_woven(acc, ph[2], pl[2], ph[3], pl[3], sm, fr, lane, NoWeave{});
 }
 
 __device__ __forceinline__ void load_bias_tile(f32x16& acc, const float* bias_tile_half) {
@@ -555,7 +532,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
 
     float* s_row = lds_dyn + kRing * kStageVec4 * 4 + wave * D * kRowPad;
     float* s_param = lds_dyn + kRing * kStageVec4 * 4 + NW * D * kRowPad;   // [2][param_stages * 2048 words]
-    const int param_words = a.param_stages * (kStageVec4 * 4);
+    const int param_words = a.param_stages * (kParamVec4 * 4);
     const int groups = dt >> 2;
     const int64_t num_quads = a.batch / (32 * NW);   // row blocks of this workgroup size
     int pb = 0;  // which parameter block the current layer uses
@@ -618,8 +595,8 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                 unsigned cur, nxt;
                 stage_begin(sm, cur, nxt, lane);
                 const vec4f* src = sm.ring + sm.slot * kStageVec4;
-                vec4f* dst = reinterpret_cast<vec4f*>(prm) + p * kStageVec4;
-                for (int i = tid; i < kStageVec4; i += kThreads) {
+                vec4f* dst = reinterpret_cast<vec4f*>(prm) + p * kParamVec4;
+                for (int i = tid; i < kParamVec4; i += kThreads) {
                     vec4f v = src[i];
                     if (p == 0 && i < kTabWords / 4) {
                         // (whole-vector bit casts: a bit cast of a single vector ELEMENT reads element 0)
@@ -636,7 +613,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                     }
                     dst[i] = v;
                 }
-                fr = next_frags<3>(cur, nxt);   // pair 0 of the stage behind this one (a weight stage after the last p)
+                fr = next_frags<kPairs - 1>(cur, nxt);   // pair 0 of the stage behind this one (a weight stage after the last p)
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr.h), "+v"(fr.l));
                 stream_advance(sm);
             }
@@ -919,7 +896,7 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* st
     a.num_layers = num_layers;
     a.param_stages = param_stages;
     const int init_ks = num_identity > 32 ? 4 : 2;
-    a.num_stages = param_stages + init_ks + 16 * num_blocks + 2 * (num_transform * rows_per_feature / 32);
+    a.num_stages = param_stages + init_ks / 2 + 8 * num_blocks + num_transform * rows_per_feature / 32;
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = g_k7_trace;
     // workgroups of eight waves (256 rows, one per CU, one weight stream per CU) when the batch gives
@@ -930,7 +907,7 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* st
     if (force_nw == 4 || (force_nw == 8 && (batch & 255) == 0)) nw = force_nw;
     auto lds_for = [&](int n) {
         return (size_t)k8h::kRing * k8h::kStageVec4 * 16 + (size_t)n * features * k8h::kRowPad * sizeof(float) +
-               (size_t)2 * param_stages * k8h::kStageVec4 * 16;
+               (size_t)2 * param_stages * k8h::kParamVec4 * 16;
     };
     if (lds_for(nw) + 2048 > 160 * 1024) nw = 4;
     const size_t lds_launch = lds_for(nw);

@@ -991,8 +991,8 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
     init_ks = 4 if di > 32 else 2
     wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
     T = _f16_weight_scale(wi)
-    # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one stage of four tile pairs per k-step
-    stages.append(pieces(wi * T).view(2, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks, -1))
+    # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one 16 KB stage of 2 x 4 tile pairs per two k-steps
+    stages.append(pieces(wi * T).view(2, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks // 2, -1))
     blob += [header(S / T, 0.0), _bias_accumulator_order(_pad_to(net.initial_layer.bias.detach().float(), rows=128) * T)]
     stream_scale = T          # scale of the fp32 residual stream after the initial layer (inputs at scale 1)
     for block in net.blocks:
@@ -1000,7 +1000,7 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
             w = _pad_to(lin.weight.detach().float(), rows=128, cols=128).index_select(1, order_k)  # columns in (ks, hf, j) order
             T = _f16_weight_scale(w)
             # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one stage per k-step
-            stages.append(pieces(w * T).view(2, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1))
+            stages.append(pieces(w * T).view(2, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(4, -1))
             lin_bias = _pad_to(lin.bias.detach().float(), rows=128)
             if which == 0:   # accumulators = S T (W relu(h) + b)
                 blob += [header(1.0 / T, 0.0), _bias_accumulator_order(lin_bias * (S * T))]
@@ -1020,21 +1020,22 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
     bf = torch.cat((bf, bf.new_zeros(dt, R - P)), dim=1).reshape(dt * R).index_select(0, order_r)
     T = _f16_weight_scale(wf)
     tiles = dt * R // 32
-    stages.append(pieces(wf * T).view(2, tiles, 32, 2, 4, 2, 8).permute(1, 3, 4, 0, 5, 2, 6).reshape(tiles * 2, -1))
+    stages.append(pieces(wf * T).view(2, tiles, 32, 2, 4, 2, 8).permute(1, 3, 4, 0, 5, 2, 6).reshape(tiles, -1))
     # the spline evaluation reads logits = accumulators x kappa, kappa = 1 / (S T)
     blob += [header(1.0 / (S * T), S * T), _bias_accumulator_order(bf * (S * T))]
     return torch.cat(stages, dim=0).contiguous(), torch.cat(blob).contiguous()
 
 
-K8H_PARAM_STAGE_WORDS = 2048
+K8H_PARAM_STAGE_WORDS = 2048     # parameter words per parameter stage (its first 8 KB)
+K8H_STAGE_HALVES = 8192          # f16 values of a 16 KB stage
 
 
 def build_f16_stream(layer_packs, tables):
-    """The stream K8h consumes for a run of layers: per layer its parameter stage(s) -- 128 table
-    words (int32: slots of the identity / transformed features, from `flow_layer_tables`) followed
-    by the layer's parameter words, zero-padded to whole 8 KB stages -- and then its weight stages.
-    `layer_packs`: [(weights, parameter words)] from pack_resnet_conditioner_f16 in execution
-    order; `tables`: int32 [(L + 1) * 128].  Returns (stream [stages, 4096] f16, parameter stages
+    """The stream K8h consumes for a run of layers, in 16 KB stages: per layer its parameter stage(s) --
+    each carries 2048 words in its first 8 KB: 128 table words (int32: slots of the identity /
+    transformed features, from `flow_layer_tables`) followed by the layer's parameter words -- and then its
+    weight stages.  `layer_packs`: [(weights, parameter words)] from pack_resnet_conditioner_f16 in
+    execution order; `tables`: int32 [(L + 1) * 128].  Returns (stream [stages, 8192] f16, parameter stages
     per layer, final table int32 [128])."""
     L = len(layer_packs)
     words = 128 + layer_packs[0][1].numel()
@@ -1044,7 +1045,9 @@ def build_f16_stream(layer_packs, tables):
         block = torch.zeros(P * K8H_PARAM_STAGE_WORDS, dtype=torch.float32, device=w.device)
         block[:128] = tables[l * 128:(l + 1) * 128].contiguous().view(torch.float32)
         block[128:128 + prm.numel()] = prm
-        parts.append(block.view(torch.float16).view(P, 4096))
+        stage = torch.zeros(P, K8H_STAGE_HALVES // 2, dtype=torch.float32, device=w.device)
+        stage[:, :K8H_PARAM_STAGE_WORDS] = block.view(P, K8H_PARAM_STAGE_WORDS)
+        parts.append(stage.view(torch.float16).view(P, K8H_STAGE_HALVES))
         parts.append(w)
     return torch.cat(parts, dim=0).contiguous(), P, tables[L * 128:(L + 1) * 128].contiguous()
 

@@ -359,17 +359,17 @@ def test_f16_whole_layer_packing_carries_the_scales(act_scale):
     net = net.double()
     tiles = dt * 24 // 32
     H = 4  # header floats
-    assert wp.shape == (2 + 16 * 2 + 2 * tiles, 512 * 8) and wp.dtype == torch.float16
+    assert wp.shape == (1 + 8 * 2 + tiles, 1024 * 8) and wp.dtype == torch.float16   # 16 KB stages of eight pairs
     assert prm.shape == ((H + 128) * 5 + H + tiles * 32,)
     assert torch.isfinite(wp.float()).all() and wp.float().abs().max() < 2 ** 14
     # the stream of a one-layer run: parameter stage + weight stages
     tables = torch.arange(256, dtype=torch.int32)
     stream, pstages, final = ops.build_f16_stream([(wp, prm)], tables)
-    assert pstages == 1 and stream.shape == (1 + wp.shape[0], 4096) and torch.equal(final, tables[128:])
+    assert pstages == 1 and stream.shape == (1 + wp.shape[0], 8192) and torch.equal(final, tables[128:])
     words = stream[0].view(torch.float32)
     assert torch.equal(words[:128].view(torch.int32), tables[:128]) and torch.equal(words[128:128 + prm.numel()], prm)
     assert torch.equal(stream[1:], wp)
-    w = wp.double().view(-1, 512, 8)
+    w = wp.double().view(-1, 1024, 8)
     bp = prm
     x = torch.randn(32, di, dtype=torch.float64)
     lane_r = torch.arange(64) % 32
@@ -402,21 +402,20 @@ def test_f16_whole_layer_packing_carries_the_scales(act_scale):
     def b_from_acc(acc, ks):  # pieces of k-step ks = tile ks // 2, registers 8 (ks % 2) ..
         return acc[ks // 2][:, 8 * (ks % 2):8 * (ks % 2) + 8]
 
-    def k_major(stage0, acc, src):      # a 128 -> 128 GEMM, one stage per k-step, pair g = tile g
+    def k_major(stage0, acc, src):      # a 128 -> 128 GEMM: a stage per two k-steps, pair 4 (ks % 2) + t = tile t
         st = stage0
         for ks in range(8):
             for t in range(4):
-                mfma(acc[t], pair(st, t), b_from_acc(src, ks))
-            st += 1
+                mfma(acc[t], pair(st, 4 * (ks % 2) + t), b_from_acc(src, ks))
+            st += ks % 2
         return st
 
-    def tile_major(stage0, acc, src):   # the final GEMM, two stages per tile
+    def tile_major(stage0, acc, src):   # the final GEMM: one stage per tile, pair ks = k-step ks
         st = stage0
         for t in range(acc.shape[0]):
-            for hs in range(2):
-                for g in range(4):
-                    mfma(acc[t], pair(st, g), b_from_acc(src, hs * 4 + g))
-                st += 1
+            for ks in range(8):
+                mfma(acc[t], pair(st, ks), b_from_acc(src, ks))
+            st += 1
         return st
 
     stage, off = 0, 0
@@ -428,10 +427,10 @@ def test_f16_whole_layer_packing_carries_the_scales(act_scale):
                 bx[ks, l, j] = x[l % 32, i] if i < di else 0.0
     out_scale = bp[off].double()
     hacc = bias_tiles(off + H, 4)                     # the fp32 residual stream
-    for ks in range(2):                               # initial layer: k-major
+    for ks in range(2):                               # initial layer: k-major, both k-steps in one stage
         for t in range(4):
-            mfma(hacc[t], pair(stage, t), bx[ks])
-        stage += 1
+            mfma(hacc[t], pair(stage, 4 * ks + t), bx[ks])
+    stage += 1
     hp = torch.relu(hacc * out_scale)                 # pieces of relu(h) at scale S
     off += H + 128
     for blk in range(2):
