@@ -64,7 +64,7 @@ with torch.no_grad():
     x = torch.randn(262144, 64, device=dev)
     report("configs[3] RQ-NSF x32 log_prob, all 262144 rows on one GPU", timed(lambda: flow.log_prob(x), 10, warm=5), 262144)
 
-    # the reference's default of 10 bins on the same flow (bf16x3 engine)
+    # the reference's default of 10 bins on the same flow (K8h; the bf16x3 engine K8 takes 4.0 ms)
     flow = configs.rq_nsf_flow(32, 64, 10, 128).to(dev).eval()
     x = torch.randn(65536, 64, device=dev)
     report("32-layer RQ-NSF with num_bins = 10 (K8, bf16x3), log_prob", timed(lambda: flow.log_prob(x), 20, warm=10), 65536)
