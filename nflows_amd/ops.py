@@ -922,6 +922,12 @@ def affine_flow_mlp(inputs, weights_packed, bias_packed, tables, num_transform, 
     `flow_layer_tables`).  Returns (outputs, logabsdet), or (None, log_prob) with
     `standard_normal_log_prob`; None when the shape is outside the fast path."""
     N.require_device_f32("inputs", inputs, 2)
+    if inputs.shape[0] % 128:
+        return _on_full_blocks(
+            lambda x_, acc_, ctx_: affine_flow_mlp(x_, weights_packed, bias_packed, tables, num_transform, num_identity,
+                                                   num_hidden_layers, scale_activation, inverse, acc_, num_layers,
+                                                   standard_normal_log_prob),
+            inputs, accumulate_into)
     dev = inputs.device
     B, D = inputs.shape
     x = inputs.detach().contiguous()
@@ -1086,6 +1092,28 @@ def flow_layer_tables(features, layers):
     return torch.cat(rows).to(torch.int32)
 
 
+def _on_full_blocks(run, inputs, accumulate_into, context=None):
+    """The whole-layer kernels work on full 128-row blocks.  A ragged batch is padded with zero rows whose
+    results are dropped (rows are independent: a row's result does not depend on the others in its block);
+    `run(inputs, accumulate_into, context)` is the launch on a batch of full blocks."""
+    B = inputs.shape[0]
+    pad = (-B) % 128
+    if pad == 0:
+        return run(inputs, accumulate_into, context)
+    padded = torch.cat((inputs, inputs.new_zeros(pad, inputs.shape[1])), dim=0)
+    padded_context = None if context is None else torch.cat((context, context.new_zeros(pad, context.shape[1])), dim=0)
+    result = run(padded, None, padded_context)
+    if result is None:
+        return None
+    out, lad = result
+    out = None if out is None else out[:B]
+    lad = lad[:B]
+    if accumulate_into is not None:
+        accumulate_into += lad
+        lad = accumulate_into
+    return out, lad
+
+
 def _density_epilogue(flags, standard_normal_log_prob, inverse, like):
     """`flags` and the outputs buffer for the whole-layer kernels: with `standard_normal_log_prob` the
     kernel's second result is the flow's log-density and z never leaves the chip."""
@@ -1105,6 +1133,12 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
     `standard_normal_log_prob` (Flow.log_prob with a StandardNormal base: flows/base.py:42-49);
     None when the shape is outside the fast path."""
     N.require_device_f32("inputs", inputs, 2)
+    if inputs.shape[0] % 128:
+        return _on_full_blocks(
+            lambda x_, acc_, ctx_: rqs_coupling_resnet(x_, weights_packed, bias_packed, tables, num_transform,
+                                                       num_identity, num_blocks, spec, inverse, acc_, log2e,
+                                                       num_layers, standard_normal_log_prob, ctx_),
+            inputs, accumulate_into, context)
     dev = inputs.device
     B, D = inputs.shape
     x = inputs.detach().contiguous()
@@ -1144,6 +1178,12 @@ def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transf
     `build_f16_stream`; `packed_exact`: (weights, biases) from pack_resnet_conditioner; `tables`:
     the run's `flow_layer_tables` (for the exact kernel).  Results as for `rqs_coupling_resnet`."""
     N.require_device_f32("inputs", inputs, 2)
+    if inputs.shape[0] % 128:
+        return _on_full_blocks(
+            lambda x_, acc_, ctx_: rqs_coupling_resnet_f16(x_, stream_f16, packed_exact, tables, num_transform,
+                                                           num_identity, num_blocks, spec, inverse, acc_, num_layers,
+                                                           standard_normal_log_prob),
+            inputs, accumulate_into)
     dev = inputs.device
     B, D = inputs.shape
     x = inputs.detach().contiguous()

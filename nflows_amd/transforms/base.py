@@ -10,10 +10,9 @@ over the [batch, features] activations per layer.  Folding a permutation is bit-
 running the two transforms one after the other (it only changes which column a kernel reads or
 writes).  The whole-layer kernel is a different matter: it computes the conditioner's GEMMs in its
 own summation order, so its results agree with the layer-by-layer path to fp32 rounding, not bit
-for bit, and on a ragged batch the first 128 * floor(B / 128) rows take it while the remaining
-rows take the PyTorch conditioner + spline-kernel path.  A row's result is therefore reproducible
-for a fixed batch size, and independent of the batch size only within that tolerance (rows inside
-the full blocks are bit-identical whatever the batch).  `CompositeTransform.fuse_layer_runs = False` and
+for bit.  It works on full 128-row blocks; a ragged batch is padded with zero rows whose results are
+dropped, so every row takes the same kernel and its result is bit-identical whatever the batch size
+(rows are independent inside a block).  `CompositeTransform.fuse_layer_runs = False` and
 `PiecewiseRationalQuadraticCouplingTransform.fuse_conditioner = False` select the layer-by-layer
 path everywhere.
 """
@@ -79,7 +78,7 @@ class CompositeTransform(Transform):
         eligible coupling, inverse (layers already reversed) eligible coupling + [Permutation]?.
         Returns (units, next_index) with units = [(coupling, permutation or None)]."""
         units = []
-        if not (self.fuse_layer_runs and inputs.dim() == 2 and inputs.shape[0] >= 128
+        if not (self.fuse_layer_runs and inputs.dim() == 2 and inputs.shape[0] >= 1
                 and inputs.shape[1] % 4 == 0 and inputs.dtype == torch.float32):
             return units, start
 
@@ -145,57 +144,41 @@ class CompositeTransform(Transform):
         return plan
 
     def _run_fused(self, units, inputs, total, context, inverse, standard_normal_log_prob=False):
+        """One launch for the run (ragged batches are padded to full 128-row blocks inside `ops`).  Returns
+        the outputs (or log_prob with `standard_normal_log_prob`), or None when the kernel declines."""
         from .. import ops
         first = units[0][0]
         for _, p in units:
             if p is not None:
                 p._check(inputs)
-        batch = inputs.shape[0]
-        full = (batch // 128) * 128
         weights, biases, tables, plan_f16 = self._run_plan(units, inverse)
-        acc = None if total is None else total[:full]
         if type(first).__name__ in ("AffineCouplingTransform", "AdditiveCouplingTransform"):
             head = ops.affine_flow_mlp(
-                inputs[:full], weights, biases, tables, first.num_transform_features, first.num_identity_features,
-                len(first.transform_net._hidden_layers), first._activation_code(), inverse, acc,
+                inputs, weights, biases, tables, first.num_transform_features, first.num_identity_features,
+                len(first.transform_net._hidden_layers), first._activation_code(), inverse, total,
                 num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob)
         elif plan_f16 is not None:
             head = ops.rqs_coupling_resnet_f16(
-                inputs[:full], plan_f16, (weights, biases), tables, first.num_transform_features,
+                inputs, plan_f16, (weights, biases), tables, first.num_transform_features,
                 first.num_identity_features, len(first.transform_net.blocks), first._spec(), inverse,
-                acc, num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob)
+                total, num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob)
         else:
             head = ops.rqs_coupling_resnet(
-                inputs[:full], weights, biases, tables, first.num_transform_features, first.num_identity_features,
-                len(first.transform_net.blocks), first._spec(), inverse, acc,
+                inputs, weights, biases, tables, first.num_transform_features, first.num_identity_features,
+                len(first.transform_net.blocks), first._spec(), inverse, total,
                 log2e=first._log2e() if hasattr(first, "_log2e") else False, num_layers=len(units),
-                standard_normal_log_prob=standard_normal_log_prob,
-                context=None if context is None else context[:full])
-        if standard_normal_log_prob:
-            return None if head is None else head[1]
+                standard_normal_log_prob=standard_normal_log_prob, context=context)
         if head is None:
             return None
-        if full == batch:
-            return head[0]
-        # ragged batch: the last rows layer by layer (PyTorch conditioner + K1)
-        tail, tail_total = inputs[full:], total[full:]
-        tail_context = None if context is None else context[full:]
-        for coupling, perm in units:
-            if inverse:
-                tail, _ = coupling.inverse(tail, tail_context, out_scatter=None if perm is None else perm._permutation,
-                                           logabsdet_accumulator=tail_total)
-            else:
-                tail, _ = coupling.forward(tail, tail_context, in_perm=None if perm is None else perm._permutation,
-                                           logabsdet_accumulator=tail_total)
-        return torch.cat((head[0], tail), dim=0)
+        return head[1] if standard_normal_log_prob else head[0]
 
     def standard_normal_log_prob(self, inputs, context=None):
         """Flow.log_prob (flows/base.py:42-49) for a StandardNormal base when the whole composite is ONE
-        run of whole-layer kernels and the batch is made of full 128-row blocks: the last layer's
+        run of whole-layer kernels: the last layer's
         kernel adds -0.5 sum z^2 - 0.5 D log(2 pi) to the log-determinant while the rows are still
         on the chip, and z is never written.  Returns log_prob [batch], or None when the composite
         does not have that shape (the caller then takes the general route)."""
-        if not self.fuse_permutations or inputs.dim() != 2 or inputs.shape[0] % 128 != 0:
+        if not self.fuse_permutations or inputs.dim() != 2:
             return None
         layers = list(self._transforms)
         units, after = self._collect_run(layers, 0, inputs, context, inverse=False)

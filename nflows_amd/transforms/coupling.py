@@ -509,41 +509,18 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         return hit
 
     def _whole_layer(self, inputs, context, inverse, in_perm, out_scatter, accumulate_into):
-        B = inputs.shape[0]
-        if B < 128 or self.features % 4 != 0 or not self._resnet_eligible(context):
+        if self.features % 4 != 0 or not self._resnet_eligible(context):
             return None
         wp, bp = self._packed_resnet()
         tables = self._layer_tables(in_perm, out_scatter)
         nb = len(self.transform_net.blocks)
         dt, di = self.num_transform_features, self.num_identity_features
         spec = self._spec()
-        full = (B // 128) * 128
-        if self._use_f16():
-            f16 = self._f16_stream(tables)
-
-            def run(rows, acc):
-                return ops.rqs_coupling_resnet_f16(rows, f16, (wp, bp), tables, dt, di, nb, spec, inverse, acc)
-        else:
-            def run(rows, acc):
-                return ops.rqs_coupling_resnet(rows, wp, bp, tables, dt, di, nb, spec, inverse, acc,
-                                               log2e=self._log2e(),
-                                               context=None if context is None else context[:rows.shape[0]])
-        if full == B:
-            return run(inputs, accumulate_into)
-        # ragged batch: full 128-row blocks here, the tail through the PyTorch conditioner + K1
-        acc_head = None if accumulate_into is None else accumulate_into[:full]
-        acc_tail = None if accumulate_into is None else accumulate_into[full:]
-        head = run(inputs[:full], acc_head)
-        if head is None:
-            return None
-        tail_in = inputs[full:]
-        cols = self._identity_columns(in_perm) if not inverse else self.identity_features
-        params = self.transform_net(tail_in.index_select(1, cols), None if context is None else context[full:])
-        tail = self._fused_layer(tail_in, params, inverse, in_perm=in_perm, out_scatter=out_scatter,
-                                 accumulate_into=acc_tail)
-        outputs = torch.cat((head[0], tail[0]), dim=0)
-        logabsdet = accumulate_into if accumulate_into is not None else torch.cat((head[1], tail[1]), dim=0)
-        return outputs, logabsdet
+        if self._use_f16():   # (ragged batches are padded to full 128-row blocks inside `ops`)
+            return ops.rqs_coupling_resnet_f16(inputs, self._f16_stream(tables), (wp, bp), tables, dt, di, nb, spec,
+                                               inverse, accumulate_into)
+        return ops.rqs_coupling_resnet(inputs, wp, bp, tables, dt, di, nb, spec, inverse, accumulate_into,
+                                       log2e=self._log2e(), context=context)
 
     def _packed_final_linear(self, layer):
         split = self.final_linear_engine == "bf16x3"
