@@ -5,11 +5,11 @@ baseline (the reference classes where /root/reference exists, else their bit-ide
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N = 1: batch 65 536 on one GPU (the north-star's single-GPU configuration).  N > 1 (one process per
-GPU, launched by torch.distributed.run): BASELINE configs[3] as named -- a global batch of 262 144
-rows sharded over the N ranks (32 768 per GPU at N = 8), one 16-byte all-reduce per step; the
-per-GPU work shrinks as N grows ("scaling": "strong"); a weak-scaling figure at 65 536 rows per GPU is
-added as an extra field.  A "step" is one full log_prob pass over the rank's rows (inputs already
+The workload is BASELINE configs[3] as named, at every N: a global batch of 262 144 rows, all of them on
+the one GPU at N = 1, sharded over the N ranks otherwise (one process per GPU, launched by
+torch.distributed.run; 32 768 rows per GPU at N = 8), one 16-byte all-reduce per step.  The total work
+is fixed, the per-GPU work shrinks as N grows ("scaling": "strong"); the figure at 65 536 rows per GPU
+(round 1's single-GPU workload; weak scaling for N > 1) is added as an extra field.  A "step" is one full log_prob pass over the rank's rows (inputs already
 resident in HBM) plus the log-likelihood reduction.  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -189,7 +189,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=None,
-                    help="rows per GPU (default: 65536 at one GPU, 262144 / N at N GPUs)")
+                    help="rows per GPU (default: 262144 / N: BASELINE configs[3] over the N GPUs)")
     ap.add_argument("--steady-seconds", type=float, default=1.0,
                     help="length of the additional steady-state measurement (extra field; 0 = skip)")
     ap.add_argument("--layers", type=int, default=32)
@@ -207,6 +207,8 @@ def main():
                     help="do not add the HIP-graph replay timing of the same step (extra field)")
     ap.add_argument("--bracket-events", action="store_true",
                     help="additionally bracket every K1 launch with torch events (includes launch gaps)")
+    ap.add_argument("--skip-extra", action="store_true",
+                    help="skip the extra measurement at 65 536 rows per GPU (profiling runs: one launch size in the trace)")
     ap.add_argument("--skip-consistency", action="store_true",
                     help="skip the fwd/inv check (profiling runs: only full-batch launches in the trace)")
     args = ap.parse_args()
@@ -257,8 +259,6 @@ def main():
     CONFIG4_GLOBAL = 262144
     if args.batch_per_gpu is not None:
         B = args.batch_per_gpu
-    elif world == 1:
-        B = 65536
     else:
         lo, hi = parallel.row_block(CONFIG4_GLOBAL, rank, world)
         B = hi - lo
@@ -326,9 +326,9 @@ def main():
         if world > 1:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         steady = {"steps": done, "seconds": dt.item(), "ms_per_step": dt.item() / done * 1e3}
-    # weak-scaling extra (N > 1): 65 536 rows on every GPU
+    # extra: 65 536 rows on every GPU (round 1's single-GPU workload; weak scaling for N > 1)
     weak = None
-    if world > 1 and args.batch_per_gpu is None:
+    if args.batch_per_gpu is None and not args.skip_extra:
         xw = torch.randn(65536, D, generator=torch.Generator().manual_seed(4321 + rank)).to(dev)
 
         def step_w():
@@ -336,15 +336,18 @@ def main():
                 return parallel.reduce_log_likelihood(flow.log_prob(xw))
         for _ in range(3):
             step_w()
-        dist.barrier()
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
         tw = time.perf_counter()
         for _ in range(args.steps):
             step_w()
-        dist.barrier()
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
         dtw = torch.tensor([time.perf_counter() - tw], dtype=torch.float64, device=dev)
-        dist.all_reduce(dtw, op=dist.ReduceOp.MAX)
+        if world > 1:
+            dist.all_reduce(dtw, op=dist.ReduceOp.MAX)
         weak = {"rows_per_gpu": 65536, "ms_per_step": dtw.item() / args.steps * 1e3,
                 "value": 65536 * world * args.steps / dtw.item(), "unit": "samples/s"}
         del xw
@@ -421,11 +424,12 @@ def main():
                 flops = products * fp32_flops
                 ach = flops / (avg_ms * 1e-3) / 1e12
                 # HBM: a run of layers reads its rows once and writes them once, and streams every
-                # layer's packed weights (8 KB stages of f16 pairs / 12 KB stages of bf16 triples) once
-                k8_weights = layers_per_launch * (2 + 16 * nb_ + 2 * (dt_ * 24 // 32)) * (8192 if f16 else 12288)
+                # layer's packed weights (16 KB stages of f16 pairs / 12 KB stages of bf16 triples) once
+                k8_weights = layers_per_launch * ((2 + 8 * nb_ + dt_ * 24 // 32) * 16384 if f16   # (+ the parameter stage)
+                                                  else (2 + 16 * nb_ + 2 * (dt_ * 24 // 32)) * 12288)
                 bytes_ = io_bytes + k8_weights if path == "k8" else (io_bytes + 4 * B * H_) * layers_per_launch
                 traffic_file = ("k8h_pmc_traffic.json" if f16 else "k8_pmc_traffic.json") if path == "k8" else "k7b_pmc_traffic.json"
-                kernel = ("nfa::k8h::rqs_resnet_f16_kernel<false, 2, %d>" % (8 if (B % 256 == 0 and B // 256 >= 256) else 4) if f16
+                kernel = ("nfa::k8h::rqs_resnet_f16_kernel<false, 2, %d, 8>" % (8 if (B % 256 == 0 and B // 256 >= 256) else 4) if f16
                           else "nfa::rqs_resnet_kernel<false, 1, 2, %s, 8>" % os.environ.get("NFA_K8_PIPE", "2")) if path == "k8" \
                     else "nfa::rqs_fused_linear_bf16_kernel<false>"
                 r = {"bound": "mfma", "kernel": kernel,
@@ -491,15 +495,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if (world > 1 and args.batch_per_gpu is None) else "weak",
+            "scaling": "strong" if args.batch_per_gpu is None else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic standard-Gaussian inputs, random-init weights (seed 0)",
             "config": {"workload": "%d-layer RQ-NSF coupling flow (RandomPermutation + RQ coupling, "
                                    "ResidualNet H=128 x2 blocks), dim=64, K=8, tail_bound=3, "
                                    "batch=%d on rank 0 (%s), Flow.log_prob + scalar all-reduce"
-                                   % (args.layers, B, "BASELINE configs[3]: 262144 rows sharded over %d GPUs" % world
-                                      if (world > 1 and args.batch_per_gpu is None) else "one GPU's rows"),
+                                   % (args.layers, B, "BASELINE configs[3]: 262144 rows over %d GPU%s" % (world, "" if world == 1 else "s")
+                                      if args.batch_per_gpu is None else "--batch-per-gpu"),
                        "global_batch": total_rows, "features": D, "num_bins": K, "layers": args.layers,
                        "parallelism": "sample-sharded x%d" % world,
                        "fused_permutations": not args.no_fuse,
@@ -526,7 +530,7 @@ def main():
                                           note=">= %.1f s of back-to-back steps, same launch path as the timed region"
                                                % args.steady_seconds)
         if weak is not None:
-            result["weak_scaling_extra"] = weak
+            result["rows_65536_per_gpu_extra"] = weak
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(flow_cpu, D, args.cpu_rows,
                                                   x_consistency=None if args.skip_consistency else xs.cpu())

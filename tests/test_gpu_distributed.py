@@ -65,5 +65,5 @@ def test_bench_two_rank_dry_run():
     assert len(lines) == 1
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 262144 and r["scaling"] == "strong"
-    assert r["value"] > 0 and r["weak_scaling_extra"]["rows_per_gpu"] == 65536
+    assert r["value"] > 0 and r["rows_65536_per_gpu_extra"]["rows_per_gpu"] == 65536
     assert abs(r["mean_log_likelihood"]) < 1e3
