@@ -68,7 +68,7 @@ struct MadeInvArgs {
 // in LDS: chunks q, q + 4, ... of `chunks`; then the sum over the four quarters (all four lanes get it)
 template <int R, int UNROLL>
 __device__ __forceinline__ void dot_rows(float (&acc)[R], const float* rows, int pitch, const float* vec, int chunks,
-                                         int q, int s, int nrows) {
+                                         int q, int s, int nrows, int skip_k = -1) {
     // (no conditionals inside the loop: rows beyond `nrows` re-read row 0 and their sums are ignored --
     // a branch per row would keep the compiler from batching the LDS reads of several chunks)
     const float* rp[R];
@@ -81,7 +81,14 @@ __device__ __forceinline__ void dot_rows(float (&acc)[R], const float* rows, int
     // a wave runs alone on its SIMD here, nothing else hides the latency)
 #pragma unroll UNROLL
     for (int c = q; c < chunks; c += 4) {
-        const vec4f v = *reinterpret_cast<const vec4f*>(vec + (c * kMadeSamples + s) * 4);
+        vec4f v = *reinterpret_cast<const vec4f*>(vec + (c * kMadeSamples + s) * 4);
+        if (R > 1) {   // element `skip_k` of the vector is being written by another wave: leave it out
+            const bool hit = c == (skip_k >> 2);
+            v.x = (hit && (skip_k & 3) == 0) ? 0.0f : v.x;
+            v.y = (hit && (skip_k & 3) == 1) ? 0.0f : v.y;
+            v.z = (hit && (skip_k & 3) == 2) ? 0.0f : v.z;
+            v.w = (hit && (skip_k & 3) == 3) ? 0.0f : v.w;
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const vec4f w = *reinterpret_cast<const vec4f*>(rp[r] + c * 4);
@@ -115,7 +122,8 @@ template <int KT>
 __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(const MadeInvArgs a) {
 #pragma clang fp contract(off)
     constexpr int P = 3 * KT - 1;
-    constexpr int RB = (P + kMadeWaves - 1) / kMadeWaves;        // output rows of a wave per step
+    constexpr int kRowWaves = kMadeWaves - 1;                    // waves 1..3 take the output rows while wave 0
+    constexpr int RB = (P + kRowWaves - 1) / kRowWaves;          // walks the step's unit chain
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float s_params[32 * kMadeSamples];                   // a feature's logits of the 16 samples
     __shared__ int s_cfg[kMadeMaxLinears][5];                       // per Linear: columns, src, dst, add, set (a
@@ -165,9 +173,31 @@ __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(co
         }
         const int* hdr = reinterpret_cast<const int*>(blk);
         const float* tail = blk + hdr[12];          // per unit (bias, index), then the feature's P biases
-        // ---- 1. hidden units of degree t, layer by layer (wave 0; typically one unit per layer)
+        // ---- 1. hidden units of degree t, layer by layer (wave 0; typically one unit per layer) and, beside
+        //      it, 2. feature t's P output rows on the hidden vector (waves 1..3; row p is wave 1 + p % 3's).
+        //      The only element of that vector the units of this step change is the new unit of the layer in
+        //      front of the output layer: the row sums leave it out and receive it as a rank-1 term afterwards
+        //      (with more than one such unit in a step the rows simply wait for the units).
         int units = 0;
         for (int l = 0; l < a.num_linears; ++l) units += hdr[l];
+        const int nlast = hdr[a.num_linears - 1];
+        const bool beside = nlast <= 1 && t < a.T;
+        const int jnew = nlast == 1 ? __builtin_bit_cast(int, tail[2 * (units - 1) + 1]) : -1;
+        const float* fin = vecs + a.final_src * vec_floats;
+        const float* wf = blk + hdr[13];
+        const float* fbias = tail + 2 * units;
+        auto output_rows = [&](int skip) {
+            float acc[RB];
+            const int mine = (P - (wave - 1) + kRowWaves - 1) / kRowWaves;
+            dot_rows<RB, 4>(acc, wf + (wave - 1) * a.Hp, kRowWaves * a.Hp, fin, a.Hp >> 2, q, s, mine, skip);
+            if (q == 0) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int p_ = (wave - 1) + kRowWaves * i;
+                    if (p_ < P) s_params[p_ * kMadeSamples + s] = acc[i] + fbias[p_];
+                }
+            }
+        };
         if (wave == 0) {
             const float* rows = blk + kMadeHeader;
             const float* ut = tail;
@@ -196,34 +226,28 @@ __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(co
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-        }
-        NFA_K12_STAMP()
-        if (units) __syncthreads();                 // (uniform: the header is the same for every thread)
-        if (t == a.T) break;
-        tail += 2 * units;
-        // ---- 2. feature t's P output rows on the hidden vector as it stands: rows wave, wave + 4, ...
-        {
-            const float* fin = vecs + a.final_src * vec_floats;
-            const float* wf = blk + hdr[13];
-            float acc[RB];
-            const int mine = (P - wave + kMadeWaves - 1) / kMadeWaves;
-            dot_rows<RB, 4>(acc, wf + wave * a.Hp, kMadeWaves * a.Hp, fin, a.Hp >> 2, q, s, mine);
-            if (q == 0) {
-#pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    const int p_ = wave + kMadeWaves * i;
-                    if (p_ < P) s_params[p_ * kMadeSamples + s] = acc[i] + tail[p_];
-                }
-            }
+        } else if (beside) {
+            output_rows(jnew);
         }
         NFA_K12_STAMP()
         __syncthreads();
+        if (t == a.T) break;
+        if (!beside) {
+            if (wave != 0) output_rows(-1);
+            __syncthreads();
+        }
+        NFA_K12_STAMP()
         NFA_K12_STAMP()
         // ---- 3. invert feature t (rational_quadratic.py:66-181 through the same evaluation as K5); every
         //      thread of a sample does it, one records the result
         float p[P];
 #pragma unroll
         for (int j = 0; j < P; ++j) p[j] = s_params[j * kMadeSamples + s];
+        if (beside && jnew >= 0) {   // the rank-1 term of the unit the row sums left out
+            const float vj = fin[state_index(jnew, s)];
+#pragma unroll
+            for (int j = 0; j < P; ++j) p[j] = __builtin_fmaf(wf[j * a.Hp + jnew], vj, p[j]);
+        }
         float y, l;
         my_status |= rqs_eval<KT, true, true, true>(z_t, p, a.sp, y, l);
         lad_acc += l;

@@ -885,7 +885,10 @@ def test_persistent_autoregressive_inverse_equals_the_step_by_step_loop(monkeypa
         zz_ref, lad_fwd_ref = t(x_ref)
     # forward(inverse(z)) = z as well as the step-by-step loop manages it (scaled weights: steep bins)
     assert (zz - z).abs().max().item() <= 2 * (zz_ref - z).abs().max().item() + 1e-5
-    assert (lad + lad_fwd).abs().max().item() <= 2 * (lad_ref + lad_fwd_ref).abs().max().item() + 1e-4
+    # (with these scaled weights a 1-ulp difference in one found feature moves the forward pass's
+    # log-determinant of that row by 5e-4 -- tools/k12_determinism_probe.py -- so the sum of the two
+    # log-determinants is held to 1e-3 beyond what the step-by-step loop reaches)
+    assert (lad + lad_fwd).abs().max().item() <= 2 * (lad_ref + lad_fwd_ref).abs().max().item() + 1e-3
 
 
 @pytest.mark.parametrize("hidden", [30, 64, 96])
