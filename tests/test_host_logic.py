@@ -562,3 +562,62 @@ def test_affine_mlp_packing_orders_the_output_rows_per_lane():
                 for q in range(16):
                     i = 8 * (q // 4) + 4 * half + q % 4
                     assert got[t, half, q] == bo[order[t * 32 + i]]
+
+
+@pytest.mark.parametrize("residual,random_mask,features,hidden,blocks", [(True, False, 12, 20, 2), (True, False, 40, 16, 1),
+                                                                       (False, True, 12, 24, 2), (False, False, 9, 32, 3)])
+def test_made_schedule_reproduces_the_masked_network(residual, random_mask, features, hidden, blocks):
+    """Host side of K12 (ops.pack_made_schedule): walk the per-step blocks the way the kernel does -- at step t
+    the hidden units of degree t, layer by layer, written into the state vectors; then feature t's output rows
+    on the hidden vector as it stands -- and compare every feature's parameters with the masked network run on
+    the features before it (made.py:233-311).  Also: after the last block the hidden vector is the network's."""
+    from nflows_amd import ops
+    from nflows_amd.transforms import made
+    torch.manual_seed(features * 7 + hidden)
+    P = 5
+    net = made.MADE(features=features, hidden_features=hidden, num_blocks=blocks, output_multiplier=P,
+                    use_residual_blocks=residual, random_mask=random_mask).double()
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.copy_(torch.randn_like(p_) * 0.5)
+    degrees = [net.initial_layer.degrees] + [b.degrees for b in net.blocks]
+    T = int(max(int(d.max()) for d in degrees))
+    blocks_f, block_at, layout = ops.pack_made_schedule(net.float(), T, P)
+    net = net.double()
+    n, is_res, final_src, stream_vec, num_vectors, Hp, Xp, max_block = layout[:8]
+    cfg = [layout[8 + 5 * l:13 + 5 * l] for l in range(n)]
+    assert blocks_f.numel() == int(block_at[-1]) * 256 and max_block % 256 == 0
+    x = torch.randn(features, dtype=torch.float64)
+    xs = torch.zeros(Xp, dtype=torch.float64)
+    vecs = torch.zeros(num_vectors, Hp, dtype=torch.float64)
+    want = net(x[None])[0].view(features, P)
+    for t in range(T + 1):
+        blk = blocks_f[int(block_at[t]) * 256:int(block_at[t + 1]) * 256]
+        hdr = blk[:16].view(torch.int32)
+        rows, tail = 16, int(hdr[12])
+        for l in range(n):
+            kp, src, dst, add_stream, set_stream = cfg[l]
+            for _ in range(int(hdr[l])):
+                w = blk[rows:rows + kp].double()
+                rows += kp
+                bias, j = float(blk[tail]), int(blk[tail + 1:tail + 2].view(torch.int32))
+                tail += 2
+                v = float(w @ (xs[:kp] if src < 0 else vecs[src, :kp])) + bias
+                if add_stream:
+                    v = float(vecs[stream_vec, j]) + v
+                if set_stream:
+                    vecs[stream_vec, j] = v
+                if dst >= 0:
+                    vecs[dst, j] = max(v, 0.0)
+        if t == T:
+            break
+        assert rows == int(hdr[13])
+        wf = blk[rows:rows + P * Hp].double().view(P, Hp)
+        params = wf @ vecs[final_src] + blk[tail:tail + P].double()
+        assert (params - want[t]).abs().max().item() < 1e-5 * (1 + want[t].abs().max().item()), t
+        xs[t] = x[t]          # "feature t found"
+    hidden_want = net.hidden(x[None])[0]
+    assert (vecs[final_src, :hidden] - hidden_want).abs().max().item() < 1e-5 * (1 + hidden_want.abs().max().item())
+    # features beyond T only read that final vector
+    rest = net.final_layer(hidden_want[None])[0].view(features, P)[T:]
+    assert (rest - want[T:]).abs().max().item() < 1e-9
