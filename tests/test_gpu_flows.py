@@ -992,3 +992,39 @@ def test_float64_functional_matches_the_reference_vectors(golden_dir):
         assert np.abs(y[fin] - ry[fin]).max() <= 1e-10, name
         assert np.abs(lad[fin] - rl[fin]).max() <= 1e-9, name
         assert np.array_equal(y[~fin & ~np.isnan(ry)], ry[~fin & ~np.isnan(ry)]), name
+
+
+@pytest.mark.parametrize("engine", ["f16x2", "bf16x3"])
+def test_non_finite_inputs_propagate_like_the_reference(monkeypatch, engine):
+    """Rows with an infinite, NaN or huge identity / transformed feature through a run of whole-layer kernels
+    against the eager oracle (bit-identical to the reference on the CPU): the same NaN pattern and the same
+    infinities in z, logabsdet and log_prob; finite rows unaffected by their neighbours in the block."""
+    import copy
+    from nflows_amd import configs
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    from oracle import eager
+    monkeypatch.setattr(RQ, "conditioner_engine", engine)
+    flow_cpu = configs.rq_nsf_flow(num_layers=3, features=16, num_bins=8, hidden_features=128, seed=9).eval()
+    flow = copy.deepcopy(flow_cpu).to(DEV)
+    x = torch.randn(256, 16, generator=torch.Generator().manual_seed(10))
+    x[3, 0] = float("inf")
+    x[5, 1] = float("-inf")
+    x[7, 2] = float("nan")
+    x[9, 3] = 1.0e30
+    x[140, 4] = float("inf")
+    x[141, 9] = float("nan")
+    with torch.no_grad():
+        z_ref, lad_ref = eager.flow_transform(flow_cpu, x)
+        lp_ref = eager.flow_log_prob(flow_cpu, x)
+        units, _ = flow._transform._collect_run(list(flow._transform._transforms), 0, x.to(DEV), None, inverse=False)
+        assert units
+        z, lad = flow._transform(x.to(DEV))
+        lp = flow.log_prob(x.to(DEV))
+    z, lad, lp = z.cpu().numpy(), lad.cpu().numpy(), lp.cpu().numpy()
+    z_ref, lad_ref, lp_ref = z_ref.numpy(), lad_ref.numpy(), lp_ref.numpy()
+    for got, want, name in ((z, z_ref, "z"), (lad, lad_ref, "logabsdet"), (lp, lp_ref, "log_prob")):
+        assert np.array_equal(np.isnan(got), np.isnan(want)), name
+        inf = np.isinf(want)
+        assert np.array_equal(got[inf], want[inf]), name
+        fin = np.isfinite(want)
+        assert np.abs(got[fin] - want[fin]).max() <= 1e-4 * (1 + np.abs(want[fin]).max()), name
