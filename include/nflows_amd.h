@@ -302,6 +302,8 @@ int nfa_rqs_flow_resnet_f32(const float *inputs, const void *weights_packed,
  *                  it on the same stream; no host synchronisation in between.
  * Supported: num_bins = 8 or 10, linear tails, hidden_features = 128 (narrower conditioners: zero-padded by the packer), d_i <= 64, d_t % 4 == 0,
  * d_t <= 64, features % 4 == 0, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
+ * Table slots may repeat a column (d_t + d_i may exceed features): the host side pads other shapes into
+ * this family with constant columns outside the spline's box (nflows_amd/ops.py: fused_geometry).
  */
 int nfa_rqs_flow_resnet_f16x2_f32(const float *inputs, const void *stream_packed, int32_t param_stages,
                                   const int32_t *final_positions, int32_t num_layers, float *outputs,

@@ -654,7 +654,7 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         return NFA_ERR_INVALID_ARGUMENT;
     if (!density_flags_valid(flags)) return NFA_ERR_INVALID_ARGUMENT;
     if (batch < 0 || features < 1 || num_transform < 1 || num_identity < 1 ||
-        num_transform + num_identity > features || num_blocks < 0 || num_layers < 1)
+        num_transform > features || num_identity > features || num_blocks < 0 || num_layers < 1)
         return NFA_ERR_INVALID_ARGUMENT;
     ResnetArgs a;
     int rc = make_dev_spec(spec, &a.sp);

@@ -860,7 +860,7 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* st
         return NFA_ERR_INVALID_ARGUMENT;
     if (!density_flags_valid(flags)) return NFA_ERR_INVALID_ARGUMENT;
     if (batch < 0 || features < 1 || num_transform < 1 || num_identity < 1 ||
-        num_transform + num_identity > features || num_blocks < 0 || num_layers < 1 || param_stages < 1)
+        num_transform > features || num_identity > features || num_blocks < 0 || num_layers < 1 || param_stages < 1)
         return NFA_ERR_INVALID_ARGUMENT;
     k8h::Args a;
     int rc = make_dev_spec(spec, &a.sp);

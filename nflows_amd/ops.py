@@ -804,7 +804,8 @@ def _pad_to(t, rows=None, cols=None):
     return t
 
 
-def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False):
+def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False, pad_transform_to=None,
+                            pad_identity_to=None):
     """Packs a ResidualNet (initial_layer, blocks[*].linear_layers[0,1], final_layer) for K8
     (layout in include/nflows_amd.h): every weight as split-bf16 triples in 12 KB stages, in the
     order the kernel consumes them, all biases in accumulator order, and the 1/sqrt(hidden) scale
@@ -822,7 +823,7 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False)
     H = net.initial_layer.weight.shape[0]                      # <= 128: narrower nets are zero-padded
     wi = _pad_to(net.initial_layer.weight.detach().float(), rows=128)
     di = wi.shape[1]                                           # identity features (+ context features)
-    init_ks = 4 if di > 32 else 2                              # k-steps of the initial layer
+    init_ks = 4 if max(di, pad_identity_to or 0) > 32 else 2   # k-steps of the initial layer (the run's count)
     wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
     # (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j)
     stages.append(pieces(wi).view(3, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks, -1))
@@ -844,6 +845,10 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False)
     wf = torch.cat((wf, wf.new_zeros(dt, P, 128 - H)), dim=2) if H < 128 else wf
     wf = (wf * scale[None, :, None]).float()
     bf = (net.final_layer.bias.detach().double().view(dt, P) * scale[None, :]).float()
+    if pad_transform_to is not None and pad_transform_to > dt:   # surplus features: zero rows (fused_geometry)
+        wf = torch.cat((wf, wf.new_zeros(pad_transform_to - dt, P, 128)), dim=0)
+        bf = torch.cat((bf, bf.new_zeros(pad_transform_to - dt, P)), dim=0)
+        dt = pad_transform_to
     R = 24 if P <= 24 else 32  # rows per feature after padding (8 bins: 23 -> 24; 10 bins: 29 -> 32)
     order_r = (_k7_row_order(dt) if R == 24 else _k8_row_order_32(dt)).to(dev)
     wf = torch.cat((wf, wf.new_zeros(dt, R - P, 128)), dim=1).reshape(dt * R, 128)
@@ -916,12 +921,19 @@ def pack_mlp_conditioner(net, num_transform, additive=False):
 
 def affine_flow_mlp(inputs, weights_packed, bias_packed, tables, num_transform, num_identity, num_hidden_layers,
                     scale_activation, inverse=False, accumulate_into=None, num_layers=1,
-                    standard_normal_log_prob=False):
+                    standard_normal_log_prob=False, pad=None):
     """K11 -- a run of affine / additive coupling layers with their MLP conditioners in one launch
     (weights / biases of the layers concatenated in execution order, tables from
     `flow_layer_tables`).  Returns (outputs, logabsdet), or (None, log_prob) with
     `standard_normal_log_prob`; None when the shape is outside the fast path."""
     N.require_device_f32("inputs", inputs, 2)
+    if pad is not None and inputs.shape[1] != pad[0]:   # rows padded to a multiple of four columns (tables too)
+        if standard_normal_log_prob:
+            raise ValueError("the standard-normal epilogue sums over the padded row: not with padded features")
+        out = affine_flow_mlp(_pad_columns(inputs, pad[0], pad[1]), weights_packed, bias_packed, tables, num_transform,
+                              num_identity, num_hidden_layers, scale_activation, inverse, accumulate_into, num_layers,
+                              False)
+        return None if out is None else (out[0][:, :inputs.shape[1]], out[1])
     if inputs.shape[0] % 128:
         return _on_full_blocks(
             lambda x_, acc_, ctx_: affine_flow_mlp(x_, weights_packed, bias_packed, tables, num_transform, num_identity,
@@ -962,7 +974,8 @@ def _f16_weight_scale(w):
     return 2.0 ** (13 - math.floor(math.log2(m)))
 
 
-def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scale=1.0):
+def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scale=1.0, pad_transform_to=None,
+                                pad_identity_to=None):
     """Packs a ResidualNet for K8h (csrc/rqs_resnet_f16.hip; layout in include/nflows_amd.h).
 
     Weights: every GEMM's weights as TWO f16 pieces of (weight x T), T a power of two chosen per
@@ -994,7 +1007,7 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
     H = net.initial_layer.weight.shape[0]                      # <= 128: narrower nets are zero-padded
     wi = _pad_to(net.initial_layer.weight.detach().float(), rows=128)
     di = wi.shape[1]
-    init_ks = 4 if di > 32 else 2
+    init_ks = 4 if max(di, pad_identity_to or 0) > 32 else 2
     wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
     T = _f16_weight_scale(wi)
     # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one 16 KB stage of 2 x 4 tile pairs per two k-steps
@@ -1019,6 +1032,10 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
     wf = torch.cat((wf, wf.new_zeros(dt, P, 128 - H)), dim=2) if H < 128 else wf
     wf = (wf * scale[None, :, None]).float()
     bf = (net.final_layer.bias.detach().double().view(dt, P) * scale[None, :]).float()
+    if pad_transform_to is not None and pad_transform_to > dt:   # surplus features: zero rows (fused_geometry)
+        wf = torch.cat((wf, wf.new_zeros(pad_transform_to - dt, P, 128)), dim=0)
+        bf = torch.cat((bf, bf.new_zeros(pad_transform_to - dt, P)), dim=0)
+        dt = pad_transform_to
     R = 24 if P == 23 else 32   # rows per feature after padding
     order_r = (_k7_row_order(dt) if R == 24 else _k8_row_order_32(dt)).to(dev)
     wf = torch.cat((wf, wf.new_zeros(dt, R - P, 128)), dim=1).reshape(dt * R, 128)
@@ -1058,38 +1075,75 @@ def build_f16_stream(layer_packs, tables):
     return torch.cat(parts, dim=0).contiguous(), P, tables[L * 128:(L + 1) * 128].contiguous()
 
 
-def coupling_layer_tables(features, transform_idx, identity_idx, in_perm=None, out_scatter=None):
+def coupling_layer_tables(features, transform_idx, identity_idx, in_perm=None, out_scatter=None,
+                          padded_features=None, padded_transform=None, padded_identity=None):
     """int32 [256] column bookkeeping of ONE layer for K8 (layout in include/nflows_amd.h), built on
     the device: the row tile's slot j holds input column j; [0, 64) slots of the identity features,
     [64, 128) slots of the transformed features (their results stay there), [128, 256) the slot that
     ends up at every output position."""
-    return flow_layer_tables(features, [(transform_idx, identity_idx, in_perm, out_scatter)])
+    return flow_layer_tables(features, [(transform_idx, identity_idx, in_perm, out_scatter)],
+                             padded_features=padded_features, padded_transform=padded_transform,
+                             padded_identity=padded_identity)
 
 
-def flow_layer_tables(features, layers):
+def flow_layer_tables(features, layers, padded_features=None, padded_transform=None, padded_identity=None):
     """Tables of a run of coupling layers executed back to back on one row tile (K8 with
     num_layers > 1).  `layers`: (transform_idx, identity_idx, in_perm, out_scatter) per layer in
     execution order; layer column c reads logical column in_perm[c] of its input and leaves its
     output at logical position out_scatter[c].  The tile never moves: `where[j]` tracks the slot
     holding logical column j, every layer reads / overwrites the slots of its features, and the
-    last 128 entries say which slot ends up at which output position.  int32 [(L + 1) * 128]."""
+    last 128 entries say which slot ends up at which output position.  int32 [(L + 1) * 128].
+
+    `padded_features` / `padded_transform` / `padded_identity` (see `fused_geometry`): the rows the kernel
+    sees have `padded_features` columns (the extra ones pass through every layer and permutation unmoved) and
+    every layer lists `padded_transform` transformed and `padded_identity` identity features, the extra ones
+    all at the first pad column -- which holds a constant outside the spline's box."""
     dev = layers[0][0].device
-    where = torch.arange(features, device=dev)
+    Dp = features if padded_features is None else padded_features
+    extra = torch.arange(features, Dp, device=dev)
+    where = torch.arange(Dp, device=dev)
     rows = []
     for tidx, iidx, perm, scat in layers:
-        slot_of_column = where if perm is None else where[perm.to(dev)]
+        slot_of_column = where if perm is None else where[torch.cat((perm.to(dev), extra))]
         row = torch.zeros(128, dtype=torch.int64, device=dev)
         row[:iidx.numel()] = slot_of_column[iidx]
         row[64:64 + tidx.numel()] = slot_of_column[tidx]
+        if padded_transform is not None and padded_transform > tidx.numel():
+            row[64 + tidx.numel():64 + padded_transform] = slot_of_column[features]   # the spare column
+        if padded_identity is not None and padded_identity > iidx.numel():
+            row[iidx.numel():padded_identity] = slot_of_column[features]
         rows.append(row)
         if scat is None:
             where = slot_of_column
         else:
-            where = torch.zeros_like(slot_of_column).index_copy_(0, scat.to(dev), slot_of_column)
+            where = torch.zeros_like(slot_of_column).index_copy_(0, torch.cat((scat.to(dev), extra)), slot_of_column)
     final = torch.zeros(128, dtype=torch.int64, device=dev)
-    final[:features] = where
+    final[:Dp] = where
     rows.append(final)
     return torch.cat(rows).to(torch.int32)
+
+
+def fused_geometry(features, layers, tail_bound):
+    """What the whole-layer spline kernels are given for a run of layers over `features` columns, `layers` =
+    [(transformed features, identity features)]: one geometry for the whole run, both counts of transformed
+    features in multiples of four.  Returns (padded features, transformed features, identity features, pad
+    value): rows are padded with columns holding a constant outside the spline's box; a layer with fewer
+    transformed features than the run's count gets surplus ones -- zero rows in its packed final layer -- that
+    all read the first pad column, find it outside the box and leave it as it is with a zero
+    log-derivative; a layer with fewer identity features gets surplus ones that read the same column and
+    meet zero weights in its initial layer.  A run of equal layers in multiples of four comes back unchanged."""
+    dt4 = max((dt + 3) // 4 * 4 for dt, _ in layers)
+    di_u = max(di for _, di in layers)
+    need_spare = any(dt != dt4 or di != di_u for dt, di in layers)
+    Dp = (features + (1 if need_spare else 0) + 3) // 4 * 4
+    return Dp, dt4, di_u, 2.0 * float(tail_bound) + 1.0
+
+
+def _pad_columns(inputs, padded_features, value):
+    if inputs.shape[1] == padded_features:
+        return inputs
+    fill = inputs.new_full((inputs.shape[0], padded_features - inputs.shape[1]), value)
+    return torch.cat((inputs, fill), dim=1)
 
 
 def _on_full_blocks(run, inputs, accumulate_into, context=None):
@@ -1126,13 +1180,22 @@ def _density_epilogue(flags, standard_normal_log_prob, inverse, like):
 
 def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transform, num_identity, num_blocks,
                         spec, inverse=False, accumulate_into=None, log2e=False, num_layers=1,
-                        standard_normal_log_prob=False, context=None):
+                        standard_normal_log_prob=False, context=None, pad=None):
     """K8 -- ResidualNet conditioner + spline coupling layer in one kernel; with num_layers > 1 a
     whole run of such layers (weights / biases concatenated in execution order, tables from
     `flow_layer_tables`).  Returns (outputs, logabsdet), or (None, log_prob) with
     `standard_normal_log_prob` (Flow.log_prob with a StandardNormal base: flows/base.py:42-49);
     None when the shape is outside the fast path."""
     N.require_device_f32("inputs", inputs, 2)
+    if pad is not None and inputs.shape[1] != pad[0]:
+        # `pad` = (padded features, pad value) of `fused_geometry`: `num_transform`, the blobs and the tables
+        # are the padded layer's; the pad columns come off the result again
+        if standard_normal_log_prob:
+            raise ValueError("the standard-normal epilogue sums over the padded row: not with padded features")
+        out = rqs_coupling_resnet(_pad_columns(inputs, pad[0], pad[1]), weights_packed, bias_packed, tables,
+                                  num_transform, num_identity, num_blocks, spec, inverse, accumulate_into, log2e,
+                                  num_layers, False, context)
+        return None if out is None else (out[0][:, :inputs.shape[1]], out[1])
     if inputs.shape[0] % 128:
         return _on_full_blocks(
             lambda x_, acc_, ctx_: rqs_coupling_resnet(x_, weights_packed, bias_packed, tables, num_transform,
@@ -1170,7 +1233,7 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
 
 def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transform, num_identity, num_blocks,
                             spec, inverse=False, accumulate_into=None, num_layers=1,
-                            standard_normal_log_prob=False):
+                            standard_normal_log_prob=False, pad=None):
     """K8h -- the run of whole-layer kernels on the f16 matrix pipe (two f16 pieces per operand),
     followed by the exact kernel (three bf16 pieces, full fp32 range) on the row blocks the first
     pass gave up on: blocks with a non-finite result, i.e. an activation beyond the f16 range or
@@ -1178,6 +1241,13 @@ def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transf
     `build_f16_stream`; `packed_exact`: (weights, biases) from pack_resnet_conditioner; `tables`:
     the run's `flow_layer_tables` (for the exact kernel).  Results as for `rqs_coupling_resnet`."""
     N.require_device_f32("inputs", inputs, 2)
+    if pad is not None and inputs.shape[1] != pad[0]:   # (see rqs_coupling_resnet)
+        if standard_normal_log_prob:
+            raise ValueError("the standard-normal epilogue sums over the padded row: not with padded features")
+        out = rqs_coupling_resnet_f16(_pad_columns(inputs, pad[0], pad[1]), stream_f16, packed_exact, tables,
+                                      num_transform, num_identity, num_blocks, spec, inverse, accumulate_into,
+                                      num_layers, False)
+        return None if out is None else (out[0][:, :inputs.shape[1]], out[1])
     if inputs.shape[0] % 128:
         return _on_full_blocks(
             lambda x_, acc_, ctx_: rqs_coupling_resnet_f16(x_, stream_f16, packed_exact, tables, num_transform,

@@ -79,7 +79,7 @@ class CompositeTransform(Transform):
         Returns (units, next_index) with units = [(coupling, permutation or None)]."""
         units = []
         if not (self.fuse_layer_runs and inputs.dim() == 2 and inputs.shape[0] >= 1
-                and inputs.shape[1] % 4 == 0 and inputs.dtype == torch.float32):
+                and inputs.dtype == torch.float32):
             return units, start
 
         def eligible(t):
@@ -110,6 +110,9 @@ class CompositeTransform(Transform):
             i += step
         if len(units) < 2:
             return [], start
+        geometry = units[0][0]._fused_geometry(tuple(c for c, _ in units[1:]))
+        if geometry[0] > 128 or geometry[1] > 64 or geometry[2] > 64:   # the run's padded geometry (ops.fused_geometry)
+            return [], start
         return units, i
 
     def _run_plan(self, units, inverse):
@@ -118,9 +121,10 @@ class CompositeTransform(Transform):
         from .. import ops
         first = units[0][0]
         mlp = type(first).__name__ in ("AffineCouplingTransform", "AdditiveCouplingTransform")
-        packed = [c._packed_mlp() if mlp else c._packed_resnet() for c, _ in units]
+        geometry = first._fused_geometry(tuple(c for c, _ in units[1:]))   # one padded geometry for the run
+        packed = [c._packed_mlp() if mlp else c._packed_resnet(geometry) for c, _ in units]
         f16 = (not mlp) and first._use_f16()
-        packed_f16 = [c._packed_resnet_f16() for c, _ in units] if f16 else None
+        packed_f16 = [c._packed_resnet_f16(geometry) for c, _ in units] if f16 else None
         key = (_cache.epoch(), inverse, f16, tuple(id(c) for c, _ in units),
                tuple((c._packed_mlp_cache if mlp else c._packed_resnet_cache)[0] for c, _ in units),
                tuple(c._packed_resnet_f16_cache[0] for c, _ in units) if f16 else None,
@@ -137,7 +141,10 @@ class CompositeTransform(Transform):
                 perm = None if p is None else p._permutation
                 spec_layers.append((c.transform_features, c.identity_features,
                                     None if inverse else perm, perm if inverse else None))
-            tables = ops.flow_layer_tables(first.features, spec_layers)
+            Dp, dt4, di_u, _ = geometry
+            tables = ops.flow_layer_tables(first.features, spec_layers, padded_features=Dp,
+                                           padded_transform=dt4 if not mlp else None,
+                                           padded_identity=di_u if not mlp else None)
             plan_f16 = ops.build_f16_stream(packed_f16, tables) if f16 else None
             plan = (weights, biases, tables, plan_f16)
             cache[key] = plan
@@ -152,22 +159,26 @@ class CompositeTransform(Transform):
             if p is not None:
                 p._check(inputs)
         weights, biases, tables, plan_f16 = self._run_plan(units, inverse)
+        Dp, dt4, di_u, pad_value = first._fused_geometry(tuple(c for c, _ in units[1:]))
+        pad = (Dp, pad_value)
+        if standard_normal_log_prob and Dp != inputs.shape[1]:
+            return None      # (the epilogue sums over the padded row: odd shapes take the two-step route)
         if type(first).__name__ in ("AffineCouplingTransform", "AdditiveCouplingTransform"):
             head = ops.affine_flow_mlp(
                 inputs, weights, biases, tables, first.num_transform_features, first.num_identity_features,
                 len(first.transform_net._hidden_layers), first._activation_code(), inverse, total,
-                num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob)
+                num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob, pad=pad)
         elif plan_f16 is not None:
             head = ops.rqs_coupling_resnet_f16(
-                inputs, plan_f16, (weights, biases), tables, first.num_transform_features,
-                first.num_identity_features, len(first.transform_net.blocks), first._spec(), inverse,
-                total, num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob)
+                inputs, plan_f16, (weights, biases), tables, dt4,
+                di_u, len(first.transform_net.blocks), first._spec(), inverse,
+                total, num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob, pad=pad)
         else:
             head = ops.rqs_coupling_resnet(
-                inputs, weights, biases, tables, first.num_transform_features, first.num_identity_features,
+                inputs, weights, biases, tables, dt4, di_u,
                 len(first.transform_net.blocks), first._spec(), inverse, total,
                 log2e=first._log2e() if hasattr(first, "_log2e") else False, num_layers=len(units),
-                standard_normal_log_prob=standard_normal_log_prob, context=context)
+                standard_normal_log_prob=standard_normal_log_prob, context=context, pad=pad)
         if head is None:
             return None
         return head[1] if standard_normal_log_prob else head[0]

@@ -259,8 +259,13 @@ class AffineCouplingTransform(CouplingTransform):
               and net._activation is torch.nn.functional.relu and not net._activate_output
               and all(h <= 128 for h in net._hidden_sizes) and self._activation_code() != N.SCALE_GIVEN
               and 1 <= self.num_identity_features <= 64 and 1 <= self.num_transform_features <= 64
-              and self.features <= 128)
+              and self._fused_geometry()[0] <= 128)
         return "k11" if ok else None
+
+    def _fused_geometry(self, others=()):
+        """(padded features, transformed features, identity features, pad value): K11 wants the row length in
+        multiples of four; the pad columns pass through (the layers of a run share their split)."""
+        return (self.features + 3) // 4 * 4, self.num_transform_features, self.num_identity_features, 0.0
 
     def _run_signature(self):
         return ("k11", self.features, self.num_transform_features, self.num_identity_features,
@@ -412,11 +417,21 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
     # K8: the whole ResidualNet conditioner inside the spline kernel (class-level switch)
     fuse_conditioner = os.environ.get("NFA_K8", "1") != "0"
 
+    def _fused_geometry(self, others=()):
+        """(padded features, transformed features, identity features, pad value) the whole-layer kernels are
+        given for this layer -- or for the run of this layer and `others` (ops.fused_geometry)."""
+        layers = [(c.num_transform_features, c.num_identity_features) for c in (self,) + tuple(others)]
+        return ops.fused_geometry(self.features, layers, self.tail_bound)
+
     def _run_kind(self, context):
         return "k8" if self._resnet_eligible(context) else None
 
     def _run_signature(self):
-        return ("k8", self.features, self.num_transform_features, self.num_identity_features,
+        # (layers of one run may differ in their feature split -- odd feature counts under alternating masks --:
+        # the run is given one padded geometry; with a context the initial layer's columns must line up)
+        split = (self.num_transform_features, self.num_identity_features) \
+            if getattr(self.transform_net, "context_features", None) is not None else ()
+        return ("k8", self.features, split,
                 len(self.transform_net.blocks), self.num_bins, self.tail_bound,
                 self.min_bin_width, self.min_bin_height, self.min_derivative,
                 self._log2e(), self._use_f16(), self.conditioner_act_scale,
@@ -435,8 +450,8 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         return (self.fuse_conditioner and self.fuse_final_linear and not torch.is_grad_enabled()
                 and context_ok and type(net) is ResidualNet
                 and net.hidden_features <= 128 and self.tails == "linear" and self.num_bins in (8, 10)
-                and 1 <= self.num_identity_features <= 64 and self.num_transform_features % 4 == 0
-                and self.num_transform_features <= 64 and self.features <= 128
+                and 1 <= self.num_identity_features <= 64 and 1 <= self.num_transform_features
+                and self._fused_geometry()[1] <= 64 and self._fused_geometry()[0] <= 128
                 and all(b.activation is torch.nn.functional.relu and not b.use_batch_norm
                         and (not b.training or b.dropout.p == 0.0) for b in net.blocks))
 
@@ -460,14 +475,16 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         return (self.conditioner_engine == "f16x2" and self.num_bins in (8, 10) and not self._log2e()
                 and getattr(self.transform_net, "context_features", None) is None)
 
-    def _packed_resnet_f16(self):
+    def _packed_resnet_f16(self, geometry=None):
         net = self.transform_net
-        key = (_cache.epoch(), self.conditioner_act_scale) + tuple((p.data_ptr(), p._version) for p in net.parameters())
+        _, dt4, di_u, _ = geometry or self._fused_geometry()
+        key = (_cache.epoch(), self.conditioner_act_scale, dt4, di_u) + tuple((p.data_ptr(), p._version) for p in net.parameters())
         cached = getattr(self, "_packed_resnet_f16_cache", None)
         if cached is None or cached[0] != key:
             cached = (key, ops.pack_resnet_conditioner_f16(net, self.num_transform_features,
                                                            self._transform_dim_multiplier(),
-                                                           act_scale=self.conditioner_act_scale))
+                                                           act_scale=self.conditioner_act_scale,
+                                                           pad_transform_to=dt4, pad_identity_to=di_u))
             self._packed_resnet_f16_cache = cached
         return cached[1]
 
@@ -484,14 +501,16 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
             cache[key] = hit
         return hit
 
-    def _packed_resnet(self):
+    def _packed_resnet(self, geometry=None):
         net = self.transform_net
-        key = (_cache.epoch(),) + tuple((p.data_ptr(), p._version) for p in net.parameters()) + (self._log2e(),)
+        _, dt4, di_u, _ = geometry or self._fused_geometry()
+        key = (_cache.epoch(), dt4, di_u) + tuple((p.data_ptr(), p._version) for p in net.parameters()) + (self._log2e(),)
         cached = getattr(self, "_packed_resnet_cache", None)
         if cached is None or cached[0] != key:
             cached = (key, ops.pack_resnet_conditioner(net, self.num_transform_features,
                                                        self._transform_dim_multiplier(),
-                                                       log2e=self._log2e()))
+                                                       log2e=self._log2e(),
+                                                       pad_transform_to=dt4, pad_identity_to=di_u))
             self._packed_resnet_cache = cached
         return cached[1]
 
@@ -503,24 +522,27 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         if hit is None:
             if len(cache) > 8:
                 cache.clear()
+            Dp, dt4, di_u, _ = self._fused_geometry()
             hit = ops.coupling_layer_tables(self.features, self.transform_features, self.identity_features,
-                                            in_perm, out_scatter)
+                                            in_perm, out_scatter, padded_features=Dp, padded_transform=dt4,
+                                            padded_identity=di_u)
             cache[key] = hit
         return hit
 
     def _whole_layer(self, inputs, context, inverse, in_perm, out_scatter, accumulate_into):
-        if self.features % 4 != 0 or not self._resnet_eligible(context):
+        if not self._resnet_eligible(context):
             return None
         wp, bp = self._packed_resnet()
         tables = self._layer_tables(in_perm, out_scatter)
         nb = len(self.transform_net.blocks)
-        dt, di = self.num_transform_features, self.num_identity_features
+        Dp, dt4, di, pad_value = self._fused_geometry()
         spec = self._spec()
-        if self._use_f16():   # (ragged batches are padded to full 128-row blocks inside `ops`)
-            return ops.rqs_coupling_resnet_f16(inputs, self._f16_stream(tables), (wp, bp), tables, dt, di, nb, spec,
-                                               inverse, accumulate_into)
-        return ops.rqs_coupling_resnet(inputs, wp, bp, tables, dt, di, nb, spec, inverse, accumulate_into,
-                                       log2e=self._log2e(), context=context)
+        # (ragged batches are padded to full 128-row blocks, odd shapes to multiples of four columns, in `ops`)
+        if self._use_f16():
+            return ops.rqs_coupling_resnet_f16(inputs, self._f16_stream(tables), (wp, bp), tables, dt4, di, nb, spec,
+                                               inverse, accumulate_into, pad=(Dp, pad_value))
+        return ops.rqs_coupling_resnet(inputs, wp, bp, tables, dt4, di, nb, spec, inverse, accumulate_into,
+                                       log2e=self._log2e(), context=context, pad=(Dp, pad_value))
 
     def _packed_final_linear(self, layer):
         split = self.final_linear_engine == "bf16x3"

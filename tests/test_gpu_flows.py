@@ -1028,3 +1028,55 @@ def test_non_finite_inputs_propagate_like_the_reference(monkeypatch, engine):
         assert np.array_equal(got[inf], want[inf]), name
         fin = np.isfinite(want)
         assert np.abs(got[fin] - want[fin]).max() <= 1e-4 * (1 + np.abs(want[fin]).max()), name
+
+
+@pytest.mark.parametrize("features", [6, 20, 21, 43, 63])
+@pytest.mark.parametrize("engine", ["f16x2", "bf16x3"])
+def test_whole_layer_kernels_take_any_feature_count(monkeypatch, features, engine):
+    """Shapes whose feature counts are not multiples of four (tabular data: 6, 21, 43, 63 columns; the
+    reference tests' 20 with a 10 / 10 split) run in the whole-layer kernels padded (ops.fused_geometry: pad
+    columns holding a constant outside the spline's box, surplus transformed features reading it and leaving
+    it alone): spline flows on both engines and an affine flow against the layer-by-layer path, batch 300."""
+    from nflows_amd import configs
+    from nflows_amd.flows.base import Flow
+    from nflows_amd.distributions.normal import StandardNormal
+    from nflows_amd.nn.nets import MLP
+    from nflows_amd.transforms import (AffineCouplingTransform, CompositeTransform, RandomPermutation,
+                                       PiecewiseRationalQuadraticCouplingTransform as RQ)
+    from nflows_amd.utils.torchutils import create_alternating_binary_mask
+    monkeypatch.setattr(RQ, "conditioner_engine", engine)
+    flow = configs.rq_nsf_flow(num_layers=4, features=features, num_bins=8, hidden_features=64, seed=features)
+    with torch.no_grad():
+        for name, p in flow.named_parameters():
+            if "final_layer" in name:
+                p.mul_(4.0)
+            elif "linear_layers.1" in name:
+                p.mul_(30.0)
+    flow = flow.to(DEV).eval()
+    torch.manual_seed(features + 1)
+    layers = []
+    for i in range(4):
+        layers.append(RandomPermutation(features))
+        layers.append(AffineCouplingTransform(create_alternating_binary_mask(features, even=(i % 2 == 0)),
+                                              lambda a, b: MLP([a], [b], [128, 128])))
+    affine = Flow(CompositeTransform(layers), StandardNormal([features])).to(DEV).eval()
+    x = torch.randn(300, features, generator=torch.Generator().manual_seed(7)).to(DEV)
+    for f, cls in ((flow, RQ), (affine, AffineCouplingTransform)):
+        results = {}
+        for fused in (True, False):
+            monkeypatch.setattr(cls, "fuse_conditioner", fused)
+            with torch.no_grad():
+                units, _ = f._transform._collect_run(list(f._transform._transforms), 0, x, None, inverse=False)
+                # (an odd feature count under alternating masks gives layers of two splits: the spline run takes
+                # one padded geometry for both; the affine kernel needs equal splits and leaves those flows to
+                # the layer-by-layer path)
+                assert len(units) == (4 if fused and (cls is RQ or features % 2 == 0) else 0)
+                z, lad = f._transform(x)
+                lp = f.log_prob(x)
+                xr, lad_inv = f._transform.inverse(z)
+                assert z.shape == x.shape and (xr - x).abs().max().item() < 2e-4
+                assert (lad + lad_inv).abs().max().item() < 2e-3
+            results[fused] = (z, lad, lp)
+        for got, want in zip(results[True], results[False]):
+            assert torch.isfinite(got).all()
+            assert (got - want).abs().max().item() <= 5e-5 * (1 + want.abs().max().item())
