@@ -323,7 +323,7 @@ int nfa_rqs_flow_resnet_f16x2_f32(const float *inputs, const void *stream_packed
  *                  + j, columns >= context_features zero).
  *   bias_packed    per block 384 floats: linear_layers[0], linear_layers[1], context_layer (accumulator order).
  * The block computes h + (W_1 relu(W_0 relu(h) + b_0) + b_1) * sigmoid(W_c context + b_c) (F.glu of the
- * concatenation, resnet.py:46-52).  Supported: as nfa_rqs_flow_resnet_f32 with num_bins = 8 and without
+ * concatenation, resnet.py:46-52).  Supported: as nfa_rqs_flow_resnet_f32 (8 or 10 bins) without
  * NFA_FLAG_LOGITS_LOG2E; otherwise NFA_ERR_UNSUPPORTED.
  */
 int nfa_rqs_flow_resnet_context_f32(const float *inputs, const float *context, int32_t context_features,

@@ -670,7 +670,7 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     if (context_features < 0) return NFA_ERR_INVALID_ARGUMENT;
     // with a context: 8 bins, the default evaluation, identity features + context within the initial
     // layer's 64 input columns
-    if (with_ctx && (a.sp.K != 8 || (flags & NFA_FLAG_LOGITS_LOG2E) || num_identity + context_features > 64 || redo))
+    if (with_ctx && ((flags & NFA_FLAG_LOGITS_LOG2E) || num_identity + context_features > 64 || redo))
         return NFA_ERR_UNSUPPORTED;
     if (batch == 0) return NFA_OK;
     if (!inputs || !weights_packed || !bias_packed || !tables || !logabsdet ||
@@ -752,13 +752,16 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 1> : rqs_resnet_kernel<false, 1, 4, 1>;
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 1> : rqs_resnet_kernel<false, 1, 2, 1>;
     }
-    if (with_ctx) {
+    if (with_ctx && a.sp.K == 10) {
+        if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 2, 10, true> : rqs_resnet_kernel<false, 1, 4, 2, 10, true>;
+        else kern = inv ? rqs_resnet_kernel<true, 1, 2, 2, 10, true> : rqs_resnet_kernel<false, 1, 2, 2, 10, true>;
+    } else if (with_ctx) {
         if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 2, 8, true> : rqs_resnet_kernel<false, 1, 4, 2, 8, true>;
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 2, 8, true> : rqs_resnet_kernel<false, 1, 2, 2, 8, true>;
     }
     if (with_ctx && lds > 64 * 1024) {
-        static bool raised_ctx[4] = {false, false, false, false};
-        const int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0);
+        static bool raised_ctx[8] = {false, false, false, false, false, false, false, false};
+        const int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (a.sp.K == 10 ? 4 : 0);
         if (!raised_ctx[which]) {
             NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
             raised_ctx[which] = true;

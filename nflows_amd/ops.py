@@ -804,6 +804,18 @@ def _pad_to(t, rows=None, cols=None):
     return t
 
 
+def _initial_weight(net, pad_identity_to):
+    """The initial layer's weight [128, identity features (+ context features)], hidden rows zero-padded;
+    with `pad_identity_to` zero columns stand in for the run's surplus identity features (fused_geometry),
+    in front of the context columns (resnet.py:93-94: the context follows the inputs)."""
+    wi = _pad_to(net.initial_layer.weight.detach().float(), rows=128)
+    ce = getattr(net, "context_features", None) or 0
+    di = wi.shape[1] - ce
+    if pad_identity_to is not None and pad_identity_to > di:
+        wi = torch.cat((wi[:, :di], wi.new_zeros(128, pad_identity_to - di), wi[:, di:]), dim=1)
+    return wi
+
+
 def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False, pad_transform_to=None,
                             pad_identity_to=None):
     """Packs a ResidualNet (initial_layer, blocks[*].linear_layers[0,1], final_layer) for K8
@@ -821,9 +833,9 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False,
 
     stages, biases = [], []
     H = net.initial_layer.weight.shape[0]                      # <= 128: narrower nets are zero-padded
-    wi = _pad_to(net.initial_layer.weight.detach().float(), rows=128)
+    wi = _initial_weight(net, pad_identity_to)
     di = wi.shape[1]                                           # identity features (+ context features)
-    init_ks = 4 if max(di, pad_identity_to or 0) > 32 else 2   # k-steps of the initial layer (the run's count)
+    init_ks = 4 if di > 32 else 2                              # k-steps of the initial layer (the run's count)
     wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
     # (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j)
     stages.append(pieces(wi).view(3, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks, -1))
@@ -1005,9 +1017,9 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
 
     stages, blob = [], []
     H = net.initial_layer.weight.shape[0]                      # <= 128: narrower nets are zero-padded
-    wi = _pad_to(net.initial_layer.weight.detach().float(), rows=128)
+    wi = _initial_weight(net, pad_identity_to)
     di = wi.shape[1]
-    init_ks = 4 if max(di, pad_identity_to or 0) > 32 else 2
+    init_ks = 4 if di > 32 else 2
     wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
     T = _f16_weight_scale(wi)
     # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one 16 KB stage of 2 x 4 tile pairs per two k-steps

@@ -111,7 +111,8 @@ class CompositeTransform(Transform):
         if len(units) < 2:
             return [], start
         geometry = units[0][0]._fused_geometry(tuple(c for c, _ in units[1:]))
-        if geometry[0] > 128 or geometry[1] > 64 or geometry[2] > 64:   # the run's padded geometry (ops.fused_geometry)
+        ce = getattr(getattr(units[0][0], "transform_net", None), "context_features", None) or 0
+        if geometry[0] > 128 or geometry[1] > 64 or geometry[2] + ce > 64:   # the run's padded geometry (ops.fused_geometry)
             return [], start
         return units, i
 

@@ -428,10 +428,8 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
 
     def _run_signature(self):
         # (layers of one run may differ in their feature split -- odd feature counts under alternating masks --:
-        # the run is given one padded geometry; with a context the initial layer's columns must line up)
-        split = (self.num_transform_features, self.num_identity_features) \
-            if getattr(self.transform_net, "context_features", None) is not None else ()
-        return ("k8", self.features, split,
+        # the run is given one padded geometry)
+        return ("k8", self.features,
                 len(self.transform_net.blocks), self.num_bins, self.tail_bound,
                 self.min_bin_width, self.min_bin_height, self.min_derivative,
                 self._log2e(), self._use_f16(), self.conditioner_act_scale,
@@ -442,10 +440,10 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         from ..nn.nets.resnet import ResidualNet
         if context is None:
             context_ok = net.context_features is None if type(net) is ResidualNet else False
-        else:   # (K8 with a context: 8 bins, identity features + context within the initial layer's 64 columns)
+        else:   # (K8 with a context: identity features + context within the initial layer's 64 columns)
             context_ok = (type(net) is ResidualNet and net.context_features is not None and context.dim() == 2
                           and context.shape[1] == net.context_features and context.is_cuda
-                          and context.dtype == torch.float32 and self.num_bins == 8 and not self._log2e()
+                          and context.dtype == torch.float32 and not self._log2e()
                           and self.num_identity_features + net.context_features <= 64)
         return (self.fuse_conditioner and self.fuse_final_linear and not torch.is_grad_enabled()
                 and context_ok and type(net) is ResidualNet

@@ -1080,3 +1080,56 @@ def test_whole_layer_kernels_take_any_feature_count(monkeypatch, features, engin
         for got, want in zip(results[True], results[False]):
             assert torch.isfinite(got).all()
             assert (got - want).abs().max().item() <= 5e-5 * (1 + want.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("features,num_bins,hidden,context_features", [
+    (3, 10, 50, 12),     # a posterior over three parameters given an embedded observation: 10 bins, 50 hidden units
+    (7, 10, 50, 20),
+    (21, 8, 64, 8),      # odd count: the layers of the run have two splits
+    (32, 10, 128, 12),
+])
+def test_conditional_flows_of_any_shape_in_the_whole_layer_kernel(features, num_bins, hidden, context_features):
+    """Conditional spline flows (context in the initial layer + the gate of every block, resnet.py:9-52,
+    :92-100) with 8 or 10 bins, feature counts that need the padded geometry and conditioners narrower than 128
+    run as one launch of the whole-layer kernel: against the eager oracle in float64 (the reference's
+    sequence) and against the layer-by-layer path, forward, inverse and log_prob, ragged batch."""
+    import copy
+    from oracle import eager
+    from nflows_amd import configs
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    flow = configs.conditional_rq_nsf_flow(num_layers=5, features=features, num_bins=num_bins, hidden_features=hidden,
+                                           raw_context=6, context_features=context_features, seed=features)
+    with torch.no_grad():
+        for name, p in flow.named_parameters():
+            if "final_layer" in name:
+                p.mul_(3.0)
+    flow = flow.eval()
+    flow64 = copy.deepcopy(flow).double()
+    flow = flow.to(DEV)
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(333, features, generator=gen) * 1.5
+    ctx = torch.randn(333, 6, generator=gen)
+    with torch.no_grad():
+        emb64 = flow64._embedding_net(ctx.double())
+        z64, lad64 = eager.flow_transform(flow64, x.double(), context=emb64)
+        lp64 = eager.flow_log_prob(flow64, x.double(), context=ctx.double())
+        xd, cd = x.to(DEV), ctx.to(DEV)
+        emb = flow._embedding_net(cd)
+        units, _ = flow._transform._collect_run(list(flow._transform._transforms), 0, xd, emb, inverse=False)
+        assert len(units) == 5
+        z, lad = flow._transform(xd, context=emb)
+        lp = flow.log_prob(xd, context=cd)
+        xr, lad_inv = flow._transform.inverse(z, context=emb)
+        try:
+            RQ.fuse_conditioner = False
+            z2, lad2 = flow._transform(xd, context=emb)
+        finally:
+            RQ.fuse_conditioner = True
+    import nflows_amd
+    nflows_amd.check_status()
+    assert (z.cpu().double() - z64).abs().max().item() < 2e-5 * (1 + z64.abs().max().item())
+    assert (lad.cpu().double() - lad64).abs().max().item() < 5e-5 * (1 + lad64.abs().max().item())
+    assert (lp.cpu().double() - lp64).abs().max().item() < 5e-5 * (1 + lp64.abs().max().item())
+    assert (z - z2).abs().max().item() < 5e-5 and (lad - lad2).abs().max().item() < 5e-4
+    assert (xr - xd).abs().max().item() < 2e-4 and (lad + lad_inv).abs().max().item() < 2e-3
