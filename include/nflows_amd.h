@@ -318,9 +318,11 @@ int nfa_rqs_flow_resnet_f16x2_f32(const float *inputs, const void *stream_packed
  *                  (Flow._log_prob's embedded context, flows/base.py:42-49).
  *   weights_packed as for nfa_rqs_coupling_resnet_f32, with (a) the initial layer's columns =
  *                  [identity features | context] (num_identity + context_features <= 64; 2 k-steps up to 32
- *                  columns, else 4) and (b) per block, behind its two Linears, four more stages: tile t's
- *                  32 rows of `context_layer` ([3 pieces][4 k-steps][64 lanes][8], column = 16 ks + 8 (l >> 5)
- *                  + j, columns >= context_features zero).
+ *                  columns, else 4) and (b) per block, behind its two Linears, `context_layer`: with
+ *                  context_features <= 16 ONE stage laid out like a k-step of the other Linears ([4 tiles]
+ *                  [3 pieces][64 lanes][8], column = 8 (l >> 5) + j); otherwise four stages, tile t's 32 rows
+ *                  each ([3 pieces][4 k-steps][64 lanes][8], column = 16 ks + 8 (l >> 5) + j); columns >=
+ *                  context_features zero.
  *   bias_packed    per block 384 floats: linear_layers[0], linear_layers[1], context_layer (accumulator order).
  * The block computes h + (W_1 relu(W_0 relu(h) + b_0) + b_1) * sigmoid(W_c context + b_c) (F.glu of the
  * concatenation, resnet.py:46-52).  Supported: as nfa_rqs_flow_resnet_f32 (8 or 10 bins) without

@@ -179,9 +179,28 @@ __device__ __forceinline__ void gemm_tile_pumped(f32x16& acc, const bf16x8 (&ph)
     stage_pumped<UNIT, 1>(acc, ph, pm, pl, sm, lane, fa, fb, sp);
 }
 
-// one 32-row tile of a block's context layer: acc += W_c_tile[32 x ce] x context^T.  ONE stage
-// ([3 pieces][4 k-steps][64 lanes] x 16 bytes, k-steps beyond ce zero); the context pieces are made on
-// the spot from the wave's context tile in LDS (k = ks*16 + half*8 + j)
+// bf16 pieces of k-step k4 of the wave's context tile in LDS (k = k4*16 + half*8 + j; columns >= ce are zero)
+__device__ __forceinline__ void context_pieces(const float* s_ctx, int ce, int k4, int half, int r, bf16x8& bh,
+                                               bf16x8& bm, bf16x8& bl) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = k4 * 16 + half * 8 + j;
+        const float cv = s_ctx[(i < ce ? i : 0) * kRowPad + r];
+        v[j] = i < ce ? cv : 0.0f;
+    }
+    bf16x2 hh[4], mm[4], ll[4];
+#pragma unroll
+    for (int j2 = 0; j2 < 4; ++j2) split3(vec2f{v[j2 * 2], v[j2 * 2 + 1]}, hh[j2], mm[j2], ll[j2]);
+    bh = join4(hh[0], hh[1], hh[2], hh[3]);
+    bm = join4(mm[0], mm[1], mm[2], mm[3]);
+    bl = join4(ll[0], ll[1], ll[2], ll[3]);
+}
+
+// one 32-row tile of a block's context layer with more than 16 context features: acc += W_c_tile[32 x ce] x
+// context^T.  ONE stage ([3 pieces][4 k-steps][64 lanes] x 16 bytes, k-steps beyond ce zero) per tile; the
+// context pieces are made on the spot.  (Up to 16 context features the four tiles share one k-major stage:
+// see the kernel.)
 __device__ __forceinline__ void gemm_context_tile(f32x16& acc, const float* s_ctx, int ce, int half, int r,
                                                   WeightStream& sm, int lane) {
     stream_request(sm);
@@ -190,18 +209,8 @@ __device__ __forceinline__ void gemm_context_tile(f32x16& acc, const float* s_ct
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
         if (k4 < nks) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = k4 * 16 + half * 8 + j;
-                const float cv = s_ctx[(i < ce ? i : 0) * kRowPad + r];
-                v[j] = i < ce ? cv : 0.0f;
-            }
-            bf16x2 hh[4], mm[4], ll[4];
-#pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) split3(vec2f{v[j2 * 2], v[j2 * 2 + 1]}, hh[j2], mm[j2], ll[j2]);
-            const bf16x8 bh = join4(hh[0], hh[1], hh[2], hh[3]), bm = join4(mm[0], mm[1], mm[2], mm[3]),
-                         bl = join4(ll[0], ll[1], ll[2], ll[3]);
+            bf16x8 bh, bm, bl;
+            context_pieces(s_ctx, ce, k4, half, r, bh, bm, bl);
             const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(0 * 4 + k4) * 64]);
             const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(1 * 4 + k4) * 64]);
             const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(2 * 4 + k4) * 64]);
@@ -414,21 +423,45 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
 #pragma unroll
                     for (int t = 0; t < 4; ++t) load_bias_tile(v[t], bias + 128 + t * 32);
                     gemm_kmajor<false, 8>(v, qh, qm, ql, sm, lane);
+                    NFA_STAMP()
+                    // up to 16 context features: the gate's four tiles share ONE k-major stage ([4 tiles][3 pieces]
+                    // [64 lanes] x 16 bytes) and one set of context pieces
+                    const bool one_stage = a.ce <= 16;
+                    const vec4f* gcur = nullptr;
+                    bf16x8 cbh, cbm, cbl;
+                    if (one_stage) {
+                        stream_request(sm);
+                        gcur = sm.ring + sm.slot * kStageVec4 + lane;
+                        context_pieces(s_ctx, a.ce, 0, half, r, cbh, cbm, cbl);
+                    }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         f32x16 gate;
                         load_bias_tile(gate, bias + 256 + t * 32);
-                        gemm_context_tile(gate, s_ctx, a.ce, half, r, sm, lane);
+                        if (one_stage) {
+                            const bf16x8 ah = __builtin_bit_cast(bf16x8, gcur[(t * 3 + 0) * 64]);
+                            const bf16x8 am = __builtin_bit_cast(bf16x8, gcur[(t * 3 + 1) * 64]);
+                            const bf16x8 al = __builtin_bit_cast(bf16x8, gcur[(t * 3 + 2) * 64]);
+                            NFA_MFMA6(gate, ah, am, al, cbh, cbm, cbl);
+                        } else {
+                            gemm_context_tile(gate, s_ctx, a.ce, half, r, sm, lane);
+                        }
                         f32x16 hn;
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {
-                            const float sg = 1.0f / (1.0f + expf(-gate[q]));
+                            // sigmoid on v_exp_f32 / v_rcp_f32 (1 ulp each) with one residual correction of the
+                            // reciprocal; the exponent is capped so that 1 + 2^t stays finite (sigmoid < 2^-126 there)
+                            const float e2 = __builtin_amdgcn_exp2f(__builtin_fminf(gate[q] * -1.44269502162933349609375f, 126.0f));
+                            const float dn = 1.0f + e2;
+                            const float r0 = __builtin_amdgcn_rcpf(dn);
+                            const float sg = __builtin_fmaf(__builtin_fmaf(-dn, r0, 1.0f), r0, r0);
                             float* hp = s_hacc + (t * 16 + q) * kWave + lane_here;
                             hn[q] = *hp + v[t][q] * sg;
                             *hp = hn[q];
                         }
                         tile_to_pieces<false>(hn, ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
                     }
+                    if (one_stage) stream_advance(sm);
                     bias += 384;
                 } else {
 #pragma unroll
@@ -695,7 +728,8 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     a.num_blocks = num_blocks;
     a.num_layers = num_layers;
     const int init_ks = num_identity + context_features > 32 ? 4 : 2;
-    a.num_stages = init_ks + (with_ctx ? 20 : 16) * num_blocks + 2 * (num_transform * rows_per_feature / 32);
+    a.num_stages = init_ks + (with_ctx ? (context_features <= 16 ? 17 : 20) : 16) * num_blocks +
+                   2 * (num_transform * rows_per_feature / 32);
     a.bias_per_layer = 128 + (with_ctx ? 384 : 256) * num_blocks + num_transform * rows_per_feature;
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = g_k7_trace;

@@ -847,9 +847,15 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False,
             stages.append(pieces(w).view(3, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1))
             biases.append(_bias_accumulator_order(_pad_to(lin.bias.detach().float(), rows=128)))
         if getattr(block, "context_layer", None) is not None:
-            # the GLU gate's Linear, tile-major: one stage per 32-row tile, (p, t, i, k4, hf, j) -> (t, p, k4, hf, i, j)
-            wc = _pad_to(block.context_layer.weight.detach().float(), rows=128, cols=64)
-            stages.append(pieces(wc).view(3, 4, 32, 4, 2, 8).permute(1, 0, 3, 4, 2, 5).reshape(4, -1))
+            # the GLU gate's Linear.  Up to 16 context features: ONE k-major stage like a k-step of the other
+            # Linears, (p, t, i, hf, j) -> (t, p, hf, i, j); more: tile-major, one stage per 32-row tile,
+            # (p, t, i, k4, hf, j) -> (t, p, k4, hf, i, j)
+            if block.context_layer.weight.shape[1] <= 16:
+                wc = _pad_to(block.context_layer.weight.detach().float(), rows=128, cols=16)
+                stages.append(pieces(wc).view(3, 4, 32, 2, 8).permute(1, 0, 3, 2, 4).reshape(1, -1))
+            else:
+                wc = _pad_to(block.context_layer.weight.detach().float(), rows=128, cols=64)
+                stages.append(pieces(wc).view(3, 4, 32, 4, 2, 8).permute(1, 0, 3, 4, 2, 5).reshape(4, -1))
             biases.append(_bias_accumulator_order(_pad_to(block.context_layer.bias.detach().float(), rows=128)))
     scale = torch.ones(P, dtype=torch.float64, device=dev)
     scale[:2 * K] = (math.log2(math.e) if log2e else 1.0) / math.sqrt(net.hidden_features)
