@@ -335,6 +335,35 @@ int nfa_rqs_flow_resnet_context_f32(const float *inputs, const float *context, i
                                     int32_t num_transform, int32_t num_identity, int32_t hidden_features,
                                     int32_t num_blocks, const nfa_rqs_spec *spec, int32_t flags, void *stream);
 
+/*
+ * nfa_rqs_flow_resnet_f16x2_f32 for conditioners that take a context (K8h with a context; same reference
+ * lines as nfa_rqs_flow_resnet_context_f32).  context_features <= 32 and d_i <= 32: the initial layer always
+ * has four k-steps, columns = [identity features, zero-padded to 32 | context, zero-padded to 32].
+ *   stream_packed  as for nfa_rqs_flow_resnet_f16x2_f32, with per block, behind its two Linears, ONE more
+ *                  weight stage: `context_layer` x T_c as two k-steps laid out like the initial layer's
+ *                  (column = 16 ks + 8 (l >> 5) + j), and behind the block's two parameter groups a third one:
+ *                  header {1 / T_c, 0, 0, 0} + the gate's 128 biases x T_c (accumulator order).  The second
+ *                  Linear's header keeps {out_scale, skip_scale}: the residual stream is multiplied by
+ *                  skip_scale when the gated product is added to it.
+ * The second pass on flagged row blocks is nfa_rqs_flow_resnet_context_redo_f32.
+ */
+int nfa_rqs_flow_resnet_context_f16x2_f32(const float *inputs, const float *context, int32_t context_features,
+                                          const void *stream_packed, int32_t param_stages,
+                                          const int32_t *final_positions, int32_t num_layers, float *outputs,
+                                          float *logabsdet, int32_t *redo_blocks, int32_t *status, int64_t batch,
+                                          int32_t features, int32_t num_transform, int32_t num_identity,
+                                          int32_t hidden_features, int32_t num_blocks,
+                                          const nfa_rqs_spec *spec, int32_t flags, void *stream);
+
+/* nfa_rqs_flow_resnet_context_f32 on the row blocks with redo_blocks[block] != 0 only. */
+int nfa_rqs_flow_resnet_context_redo_f32(const float *inputs, const float *context, int32_t context_features,
+                                         const void *weights_packed, const float *bias_packed,
+                                         const int32_t *flow_tables, int32_t num_layers, float *outputs,
+                                         float *logabsdet, const int32_t *redo_blocks, int32_t *status,
+                                         int64_t batch, int32_t features, int32_t num_transform,
+                                         int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
+                                         const nfa_rqs_spec *spec, int32_t flags, void *stream);
+
 /* nfa_rqs_flow_resnet_f32 on the row blocks with redo_blocks[block] != 0 only (second pass of K8h). */
 int nfa_rqs_flow_resnet_redo_f32(const float *inputs, const void *weights_packed,
                                  const float *bias_packed, const int32_t *flow_tables,

@@ -48,6 +48,8 @@ EXPORTS = (
     "nfa_affine_flow_mlp_f32",
     "nfa_made_rqs_inverse_f32",
     "nfa_rqs_flow_resnet_f16x2_f32",
+    "nfa_rqs_flow_resnet_context_f16x2_f32",
+    "nfa_rqs_flow_resnet_context_redo_f32",
     "nfa_linear_spline_f32",
     "nfa_quadratic_spline_f32",
     "nfa_cubic_spline_f32",
@@ -145,6 +147,12 @@ def _declare(lib):
     lib.nfa_rqs_flow_resnet_redo_f32.argtypes = [vp] * 4 + [i32] + [vp] * 4 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
     lib.nfa_rqs_flow_resnet_f16x2_f32.restype = ctypes.c_int
     lib.nfa_rqs_flow_resnet_f16x2_f32.argtypes = [vp, vp, i32, vp, i32] + [vp] * 4 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
+    lib.nfa_rqs_flow_resnet_context_f16x2_f32.restype = ctypes.c_int
+    lib.nfa_rqs_flow_resnet_context_f16x2_f32.argtypes = [vp, vp, i32, vp, i32, vp, i32] + [vp] * 4 + \
+        [i64, i32, i32, i32, i32, i32, sp, i32, vp]
+    lib.nfa_rqs_flow_resnet_context_redo_f32.restype = ctypes.c_int
+    lib.nfa_rqs_flow_resnet_context_redo_f32.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, i64, i32, i32,
+                                                         i32, i32, i32, sp, i32, vp]
     lib.nfa_rqs_coupling_resnet_f32.restype = ctypes.c_int
     lib.nfa_rqs_coupling_resnet_f32.argtypes = [vp] * 7 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
     lib.nfa_rqs_elementwise_f32.restype = ctypes.c_int

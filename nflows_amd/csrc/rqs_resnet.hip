@@ -320,9 +320,22 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         }
         if (CTX) {
             const float* crow = a.ctx + row0 * a.ce;
-            for (int e = lane; e < 32 * a.ce; e += kWave) {
-                const int rr = e / a.ce, c = e - rr * a.ce;
-                s_ctx[c * kRowPad + rr] = crow[e];
+            const int nctx = 32 * a.ce;
+            for (int e0 = lane; e0 < nctx; e0 += kWave * 4) {   // (four loads in flight per lane, like the rows)
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * kWave;
+                    v[u] = crow[e < nctx ? e : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * kWave;
+                    if (e < nctx) {
+                        const int rr = e / a.ce, c = e - rr * a.ce;
+                        s_ctx[c * kRowPad + rr] = v[u];
+                    }
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -703,7 +716,7 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     if (context_features < 0) return NFA_ERR_INVALID_ARGUMENT;
     // with a context: 8 bins, the default evaluation, identity features + context within the initial
     // layer's 64 input columns
-    if (with_ctx && ((flags & NFA_FLAG_LOGITS_LOG2E) || num_identity + context_features > 64 || redo))
+    if (with_ctx && ((flags & NFA_FLAG_LOGITS_LOG2E) || num_identity + context_features > 64))
         return NFA_ERR_UNSUPPORTED;
     if (batch == 0) return NFA_OK;
     if (!inputs || !weights_packed || !bias_packed || !tables || !logabsdet ||
@@ -864,4 +877,18 @@ extern "C" int nfa_rqs_flow_resnet_context_f32(const float* inputs, const float*
     return launch_resnet_layers(inputs, weights_packed, bias_packed, flow_tables, num_layers, outputs, logabsdet,
                                 status, batch, features, num_transform, num_identity, hidden_features, num_blocks,
                                 spec, flags, stream, nullptr, context, context_features);
+}
+
+extern "C" int nfa_rqs_flow_resnet_context_redo_f32(const float* inputs, const float* context,
+                                                    int32_t context_features, const void* weights_packed,
+                                                    const float* bias_packed, const int32_t* flow_tables,
+                                                    int32_t num_layers, float* outputs, float* logabsdet,
+                                                    const int32_t* redo_blocks, int32_t* status, int64_t batch,
+                                                    int32_t features, int32_t num_transform, int32_t num_identity,
+                                                    int32_t hidden_features, int32_t num_blocks,
+                                                    const nfa_rqs_spec* spec, int32_t flags, void* stream) {
+    if (context_features < 1 || !redo_blocks) return NFA_ERR_INVALID_ARGUMENT;
+    return launch_resnet_layers(inputs, weights_packed, bias_packed, flow_tables, num_layers, outputs, logabsdet,
+                                status, batch, features, num_transform, num_identity, hidden_features, num_blocks,
+                                spec, flags, stream, redo_blocks, context, context_features);
 }

@@ -88,6 +88,8 @@ struct Args {
     unsigned long long* trace;  // debug: [gridDim.x][64] cycle stamps of wave 0 (first row block), null = off
     int normal, skip_out;       // NFA_FLAG_STANDARD_NORMAL_LOG_PROB / NFA_FLAG_SKIP_OUTPUTS
     float log_z;                // 0.5 D log(2 pi)
+    const float* ctx;           // CTX: [batch, ce] context rows (nn/nets/resnet.py:9-52, :92-100)
+    int ce;
 };
 
 #define NFA_HSTAMP() if (tr && ti < 63) tr[ti++] = __builtin_readcyclecounter();
@@ -481,6 +483,31 @@ __device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const uvec4 (&ph)[
     if constexpr (NKS == 4) kstep_pair_woven(acc, ph[2], pl[2], ph[3], pl[3], sm, fr, lane, NoWeave{});
 }
 
+// k-major 128 -> 128 GEMM on finished pieces (the gated block's second Linear)
+template <class SM>
+__device__ __forceinline__ void gemm_kmajor_full(f32x16 (&acc)[4], const uvec4 (&ph)[8], const uvec4 (&pl)[8], SM& sm,
+                                                 Frags& fr, int lane) {
+    kstep_pair_woven(acc, ph[0], pl[0], ph[1], pl[1], sm, fr, lane, NoWeave{});
+    kstep_pair_woven(acc, ph[2], pl[2], ph[3], pl[3], sm, fr, lane, NoWeave{});
+    kstep_pair_woven(acc, ph[4], pl[4], ph[5], pl[5], sm, fr, lane, NoWeave{});
+    kstep_pair_woven(acc, ph[6], pl[6], ph[7], pl[7], sm, fr, lane, NoWeave{});
+}
+
+// the gate of a block with a context: hacc = hacc * ratio + v * sigmoid(g * inv_t), tile by tile.  Sigmoid on
+// v_exp_f32 / v_rcp_f32 with one residual correction of the reciprocal; the exponent is capped so that 1 + 2^t
+// stays finite (sigmoid < 2^-126 there); NaN propagates.
+__device__ __forceinline__ void gate_tile(f32x16& hacc, const f32x16& v, const f32x16& g, float ratio, float inv_t) {
+    const float c = -1.44269502162933349609375f * inv_t;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float e2 = __builtin_amdgcn_exp2f(__builtin_fminf(g[q] * c, 126.0f));
+        const float dn = 1.0f + e2;
+        const float r0 = __builtin_amdgcn_rcpf(dn);
+        const float sg = __builtin_fmaf(__builtin_fmaf(-dn, r0, 1.0f), r0, r0);
+        hacc[q] = __builtin_fmaf(hacc[q], ratio, v[q] * sg);
+    }
+}
+
 __device__ __forceinline__ void load_bias_tile(f32x16& acc, const float* bias_tile_half) {
     const vec4f* bp = reinterpret_cast<const vec4f*>(bias_tile_half);
 #pragma unroll
@@ -495,8 +522,15 @@ __device__ __forceinline__ void load_bias_tile(f32x16& acc, const float* bias_ti
 
 __device__ __forceinline__ bool not_finite(float v) { return !(__builtin_fabsf(v) < INFINITY); }
 
-template <bool INVERSE, int INIT_KS, int NW, int KB = 8>
+// CTX: conditioners with a context.  Its ce <= 32 columns are the initial layer's LAST two k-steps (the host
+// packs the weight as [identity features, zero-padded to 32 | context, zero-padded to 32]: INIT_KS = 4,
+// d_i <= 32), kept as f16 pieces in registers for the whole run; every block ends with the gate
+// h + (W_1 relu(u) + b_1) * sigmoid(W_c context + b_c): the second Linear then has accumulators of its own
+// (its input pieces are finished first: u's registers are needed), the gate's Linear is one more stage
+// (two k-steps, k-major) and the residual stream takes the product in.
+template <bool INVERSE, int INIT_KS, int NW, int KB = 8, bool CTX = false>
 __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Args a) {
+    static_assert(!CTX || INIT_KS == 4, "context: two identity k-steps + two context k-steps");
     constexpr int kThreads = NW * kWave;
     // dynamic LDS: the weight ring, per wave a [D][33] row tile, two parameter blocks (current / next layer)
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
@@ -580,6 +614,26 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        [[maybe_unused]] uvec4 cph[2], cpl[2];   // CTX: this lane's context values as f16 pieces, k = ks*16 + half*8 + j
+        if constexpr (CTX) {
+            const float* crow = a.ctx + (row0 + r) * a.ce;
+            float cv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = (i >> 3) * 16 + half * 8 + (i & 7);
+                cv[i] = crow[c < a.ce ? c : 0];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const int c = (i >> 3) * 16 + half * 8 + (i & 7);
+                unsigned hi, lo;
+                split2(c < a.ce ? cv[i] : 0.0f, c + 1 < a.ce ? cv[i + 1] : 0.0f, hi, lo);
+                cph[i >> 3][(i & 7) >> 1] = hi;
+                cpl[i >> 3][(i & 7) >> 1] = lo;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+
         float lad_acc = 0.0f;
         int quad_status = 0;
         for (int layer = 0; layer < a.num_layers; ++layer) {
@@ -626,7 +680,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
 
             // ---- identity features (scale 1): k = ks*16 + half*8 + j
 #pragma unroll
-            for (int ks = 0; ks < INIT_KS; ++ks) {
+            for (int ks = 0; ks < (CTX ? INIT_KS - 2 : INIT_KS); ++ks) {
                 uvec4 hw, lw;
 #pragma unroll
                 for (int j2 = 0; j2 < 4; ++j2) {
@@ -641,6 +695,12 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                 }
                 ph[ks] = hw;
                 pl[ks] = lw;
+            }
+            if constexpr (CTX) {   // input of the initial layer = [identity features | context] (resnet.py:93-94)
+                ph[INIT_KS - 2] = cph[0];
+                pl[INIT_KS - 2] = cpl[0];
+                ph[INIT_KS - 1] = cph[1];
+                pl[INIT_KS - 1] = cpl[1];
             }
 
             // ---- initial layer (k-major: one stage of four tile pairs per k-step)
@@ -669,7 +729,32 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                 }
                 gemm += kHdr + 128;
                 NFA_HSTAMP()
-                {
+                if constexpr (CTX) {
+                    // temps = W_1 relu(u) + b_1 in accumulators of its own (u's registers: its pieces first) ...
+                    ConvWeave{u[0], qh[0], ql[0], qh[1], ql[1], conv_scale, 0.0f}.all();
+                    ConvWeave{u[1], qh[2], ql[2], qh[3], ql[3], conv_scale, 0.0f}.all();
+                    ConvWeave{u[2], qh[4], ql[4], qh[5], ql[5], conv_scale, 0.0f}.all();
+                    ConvWeave{u[3], qh[6], ql[6], qh[7], ql[7], conv_scale, 0.0f}.all();
+                    const float* bias = gemm + kHdr + half * 16;
+                    const float ratio = gemm[1];
+                    const float next_scale = gemm[0];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) load_bias_tile(u[t], bias + t * 32);
+                    gemm_kmajor_full(u, qh, ql, sm, fr, lane);
+                    gemm += kHdr + 128;
+                    NFA_HSTAMP()
+                    // ... the gate's Linear on the context pieces (one stage), and h = h * ratio + temps * sigmoid(gate)
+                    // (resnet.py:46-52: F.glu of the concatenation)
+                    f32x16 g[4];
+                    const float* gbias = gemm + kHdr + half * 16;
+                    const float inv_t = gemm[0];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) load_bias_tile(g[t], gbias + t * 32);
+                    kstep_pair_woven(g, cph[0], cpl[0], cph[1], cpl[1], sm, fr, lane, NoWeave{});
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) gate_tile(hacc[t], u[t], g[t], ratio, inv_t);
+                    conv_scale = next_scale;
+                } else {
                     // second Linear accumulates into the residual stream itself: hacc = hacc * ratio + bias
                     // (the skip connection), then + W_1 relu(u)
                     const float* bias = gemm + kHdr + half * 16;
@@ -849,12 +934,11 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
 
 using namespace nfa;
 
-extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* stream_packed, int32_t param_stages,
-                                             const int32_t* final_positions, int32_t num_layers, float* outputs,
-                                             float* logabsdet, int32_t* redo_blocks, int32_t* status, int64_t batch,
-                                             int32_t features, int32_t num_transform, int32_t num_identity,
-                                             int32_t hidden_features, int32_t num_blocks,
-                                             const nfa_rqs_spec* spec, int32_t flags, void* stream) {
+static int launch_f16(const float* inputs, const float* context, int32_t context_features, const void* stream_packed,
+                      int32_t param_stages, const int32_t* final_positions, int32_t num_layers, float* outputs,
+                      float* logabsdet, int32_t* redo_blocks, int32_t* status, int64_t batch, int32_t features,
+                      int32_t num_transform, int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
+                      const nfa_rqs_spec* spec, int32_t flags, void* stream) {
     if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_STANDARD_NORMAL_LOG_PROB |
                   NFA_FLAG_SKIP_OUTPUTS))
         return NFA_ERR_INVALID_ARGUMENT;
@@ -870,14 +954,20 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* st
         num_identity > 64 || features > 128 || (features & 3) != 0 || (batch & 127) != 0 || num_blocks > 64 ||
         num_layers > 4096)
         return NFA_ERR_UNSUPPORTED;
+    const bool with_ctx = context_features > 0;
+    if (context_features < 0) return NFA_ERR_INVALID_ARGUMENT;
+    // with a context: two identity k-steps + two context k-steps in the initial layer
+    if (with_ctx && (context_features > 32 || num_identity > 32)) return NFA_ERR_UNSUPPORTED;
     const int rows_per_feature = a.sp.K == 10 ? 32 : 24;
-    const int param_words = k8h::kTabWords + (k8h::kHdr + 128) * (1 + 2 * num_blocks) + k8h::kHdr +
+    const int param_words = k8h::kTabWords + (k8h::kHdr + 128) * (1 + (with_ctx ? 3 : 2) * num_blocks) + k8h::kHdr +
                             num_transform * rows_per_feature;
     if (param_stages * 2048 < param_words || param_stages > 4) return NFA_ERR_INVALID_ARGUMENT;
     if (batch == 0) return NFA_OK;
     if (!inputs || !stream_packed || !final_positions || !logabsdet || !redo_blocks ||
-        (!outputs && !(flags & NFA_FLAG_SKIP_OUTPUTS)))
+        (!outputs && !(flags & NFA_FLAG_SKIP_OUTPUTS)) || (with_ctx && !context))
         return NFA_ERR_INVALID_ARGUMENT;
+    a.ctx = with_ctx ? context : nullptr;
+    a.ce = context_features;
     a.normal = (flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB) ? 1 : 0;
     a.skip_out = (flags & NFA_FLAG_SKIP_OUTPUTS) ? 1 : 0;
     a.log_z = standard_normal_log_z(features);
@@ -895,8 +985,8 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* st
     a.num_blocks = num_blocks;
     a.num_layers = num_layers;
     a.param_stages = param_stages;
-    const int init_ks = num_identity > 32 ? 4 : 2;
-    a.num_stages = param_stages + init_ks / 2 + 8 * num_blocks + num_transform * rows_per_feature / 32;
+    const int init_ks = (with_ctx || num_identity > 32) ? 4 : 2;
+    a.num_stages = param_stages + init_ks / 2 + (with_ctx ? 9 : 8) * num_blocks + num_transform * rows_per_feature / 32;
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = g_k7_trace;
     // workgroups of eight waves (256 rows, one per CU, one weight stream per CU) when the batch gives
@@ -922,8 +1012,17 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* st
     const dim3 grid((unsigned)blocks), block(nw * kWave);
     const bool inv = (flags & NFA_FLAG_INVERSE) != 0;
     void (*kern)(const k8h::Args) = nullptr;
-    const int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0) + (a.sp.K == 10 ? 8 : 0);
+    const int which = with_ctx ? 16 + (inv ? 1 : 0) + (nw == 8 ? 2 : 0) + (a.sp.K == 10 ? 4 : 0)
+                               : (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0) + (a.sp.K == 10 ? 8 : 0);
     switch (which) {
+        case 16: kern = k8h::rqs_resnet_f16_kernel<false, 4, 4, 8, true>; break;
+        case 17: kern = k8h::rqs_resnet_f16_kernel<true, 4, 4, 8, true>; break;
+        case 18: kern = k8h::rqs_resnet_f16_kernel<false, 4, 8, 8, true>; break;
+        case 19: kern = k8h::rqs_resnet_f16_kernel<true, 4, 8, 8, true>; break;
+        case 20: kern = k8h::rqs_resnet_f16_kernel<false, 4, 4, 10, true>; break;
+        case 21: kern = k8h::rqs_resnet_f16_kernel<true, 4, 4, 10, true>; break;
+        case 22: kern = k8h::rqs_resnet_f16_kernel<false, 4, 8, 10, true>; break;
+        case 23: kern = k8h::rqs_resnet_f16_kernel<true, 4, 8, 10, true>; break;
         case 0: kern = k8h::rqs_resnet_f16_kernel<false, 2, 4>; break;
         case 1: kern = k8h::rqs_resnet_f16_kernel<true, 2, 4>; break;
         case 2: kern = k8h::rqs_resnet_f16_kernel<false, 4, 4>; break;
@@ -942,7 +1041,8 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* st
         default: kern = k8h::rqs_resnet_f16_kernel<true, 4, 8, 10>; break;
     }
     if (lds_launch > 64 * 1024) {
-        static bool raised[16] = {false, false, false, false, false, false, false, false,
+        static bool raised[24] = {false, false, false, false, false, false, false, false,
+                                  false, false, false, false, false, false, false, false,
                                   false, false, false, false, false, false, false, false};
         if (!raised[which]) {
             NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
@@ -953,4 +1053,29 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* st
     else hipLaunchKernelGGL(kern, grid, block, lds_launch, st, a);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
+}
+
+extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* stream_packed, int32_t param_stages,
+                                             const int32_t* final_positions, int32_t num_layers, float* outputs,
+                                             float* logabsdet, int32_t* redo_blocks, int32_t* status, int64_t batch,
+                                             int32_t features, int32_t num_transform, int32_t num_identity,
+                                             int32_t hidden_features, int32_t num_blocks,
+                                             const nfa_rqs_spec* spec, int32_t flags, void* stream) {
+    return launch_f16(inputs, nullptr, 0, stream_packed, param_stages, final_positions, num_layers, outputs, logabsdet,
+                      redo_blocks, status, batch, features, num_transform, num_identity, hidden_features, num_blocks,
+                      spec, flags, stream);
+}
+
+extern "C" int nfa_rqs_flow_resnet_context_f16x2_f32(const float* inputs, const float* context,
+                                                     int32_t context_features, const void* stream_packed,
+                                                     int32_t param_stages, const int32_t* final_positions,
+                                                     int32_t num_layers, float* outputs, float* logabsdet,
+                                                     int32_t* redo_blocks, int32_t* status, int64_t batch,
+                                                     int32_t features, int32_t num_transform, int32_t num_identity,
+                                                     int32_t hidden_features, int32_t num_blocks,
+                                                     const nfa_rqs_spec* spec, int32_t flags, void* stream) {
+    if (context_features < 1) return NFA_ERR_INVALID_ARGUMENT;
+    return launch_f16(inputs, context, context_features, stream_packed, param_stages, final_positions, num_layers,
+                      outputs, logabsdet, redo_blocks, status, batch, features, num_transform, num_identity,
+                      hidden_features, num_blocks, spec, flags, stream);
 }

@@ -1023,10 +1023,20 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
 
     stages, blob = [], []
     H = net.initial_layer.weight.shape[0]                      # <= 128: narrower nets are zero-padded
-    wi = _initial_weight(net, pad_identity_to)
-    di = wi.shape[1]
-    init_ks = 4 if di > 32 else 2
-    wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
+    ce = getattr(net, "context_features", None) or 0
+    if ce:
+        # with a context: [identity features, zero-padded to 32 | context, zero-padded to 32] (four k-steps)
+        wi = _pad_to(net.initial_layer.weight.detach().float(), rows=128)
+        di = wi.shape[1] - ce
+        if di > 32 or ce > 32:
+            raise ValueError("K8h with a context takes up to 32 identity and up to 32 context features")
+        wi = torch.cat((wi[:, :di], wi.new_zeros(128, 32 - di), wi[:, di:], wi.new_zeros(128, 32 - ce)), dim=1)
+        init_ks = 4
+    else:
+        wi = _initial_weight(net, pad_identity_to)
+        di = wi.shape[1]
+        init_ks = 4 if di > 32 else 2
+        wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
     T = _f16_weight_scale(wi)
     # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one 16 KB stage of 2 x 4 tile pairs per two k-steps
     stages.append(pieces(wi * T).view(2, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks // 2, -1))
@@ -1044,6 +1054,15 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
             else:            # accumulators = S T (W relu(u) + b + h), h taken from the stream at stream_scale
                 blob += [header(1.0 / T, S * T / stream_scale), _bias_accumulator_order(lin_bias * (S * T))]
                 stream_scale = S * T
+        if ce:
+            # the gate's Linear on the context pieces (scale 1): two k-steps like the initial layer's, one stage;
+            # accumulators = T_c (W_c context + b_c), the kernel takes sigmoid(accumulator / T_c) and adds
+            # (second Linear's accumulators, without h) x that to the stream x skip_scale (resnet.py:46-52)
+            wc = _pad_to(block.context_layer.weight.detach().float(), rows=128, cols=32)
+            Tc = _f16_weight_scale(wc)
+            stages.append(pieces(wc * Tc).view(2, 4, 32, 2, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(1, -1))
+            blob += [header(1.0 / Tc, 0.0),
+                     _bias_accumulator_order(_pad_to(block.context_layer.bias.detach().float(), rows=128) * Tc)]
     scale = torch.ones(P, dtype=torch.float64, device=dev)
     scale[:2 * K] = 1.0 / math.sqrt(net.hidden_features)
     wf = net.final_layer.weight.detach().double().view(dt, P, H)
@@ -1251,7 +1270,7 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
 
 def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transform, num_identity, num_blocks,
                             spec, inverse=False, accumulate_into=None, num_layers=1,
-                            standard_normal_log_prob=False, pad=None):
+                            standard_normal_log_prob=False, pad=None, context=None):
     """K8h -- the run of whole-layer kernels on the f16 matrix pipe (two f16 pieces per operand),
     followed by the exact kernel (three bf16 pieces, full fp32 range) on the row blocks the first
     pass gave up on: blocks with a non-finite result, i.e. an activation beyond the f16 range or
@@ -1264,14 +1283,14 @@ def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transf
             raise ValueError("the standard-normal epilogue sums over the padded row: not with padded features")
         out = rqs_coupling_resnet_f16(_pad_columns(inputs, pad[0], pad[1]), stream_f16, packed_exact, tables,
                                       num_transform, num_identity, num_blocks, spec, inverse, accumulate_into,
-                                      num_layers, False)
+                                      num_layers, False, None, context)
         return None if out is None else (out[0][:, :inputs.shape[1]], out[1])
     if inputs.shape[0] % 128:
         return _on_full_blocks(
             lambda x_, acc_, ctx_: rqs_coupling_resnet_f16(x_, stream_f16, packed_exact, tables, num_transform,
                                                            num_identity, num_blocks, spec, inverse, acc_, num_layers,
-                                                           standard_normal_log_prob),
-            inputs, accumulate_into)
+                                                           standard_normal_log_prob, None, ctx_),
+            inputs, accumulate_into, context)
     dev = inputs.device
     B, D = inputs.shape
     x = inputs.detach().contiguous()
@@ -1280,20 +1299,38 @@ def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transf
     redo = torch.empty(max(1, B // 128), dtype=torch.int32, device=dev)
     lib = N.load()
     stream, param_stages, final_table = stream_f16
+    ctx = None
+    if context is not None:   # conditioners with a context: [B, context_features] rows
+        N.require_device_f32("context", context, 2)
+        ctx = context.detach().contiguous()
+        if ctx.shape[0] != B:
+            raise ValueError("context must have one row per input row")
     with torch.cuda.device(dev):
-        rc = lib.nfa_rqs_flow_resnet_f16x2_f32(
-            N.ptr(x), N.ptr(stream), param_stages, N.ptr(final_table), num_layers, N.ptr(out),
-            N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128,
-            num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))
+        if ctx is None:
+            rc = lib.nfa_rqs_flow_resnet_f16x2_f32(
+                N.ptr(x), N.ptr(stream), param_stages, N.ptr(final_table), num_layers, N.ptr(out),
+                N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128,
+                num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))
+        else:
+            rc = lib.nfa_rqs_flow_resnet_context_f16x2_f32(
+                N.ptr(x), N.ptr(ctx), ctx.shape[1], N.ptr(stream), param_stages, N.ptr(final_table), num_layers,
+                N.ptr(out), N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform, num_identity,
+                128, num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))
         if rc == N.ERR_UNSUPPORTED:
             return None
         N.check(rc)
         if os.environ.get("NFA_K8H_NOREDO"):
             return out, lad
-        rc = lib.nfa_rqs_flow_resnet_redo_f32(
-            N.ptr(x), N.ptr(packed_exact[0]), N.ptr(packed_exact[1]), N.ptr(tables), num_layers, N.ptr(out),
-            N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128,
-            num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))
+        if ctx is None:
+            rc = lib.nfa_rqs_flow_resnet_redo_f32(
+                N.ptr(x), N.ptr(packed_exact[0]), N.ptr(packed_exact[1]), N.ptr(tables), num_layers, N.ptr(out),
+                N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128,
+                num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))
+        else:
+            rc = lib.nfa_rqs_flow_resnet_context_redo_f32(
+                N.ptr(x), N.ptr(ctx), ctx.shape[1], N.ptr(packed_exact[0]), N.ptr(packed_exact[1]), N.ptr(tables),
+                num_layers, N.ptr(out), N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform,
+                num_identity, 128, num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))
         N.check(rc)
     _after_spline(spec, inverse, dev)
     return out, lad

@@ -124,7 +124,7 @@ class CompositeTransform(Transform):
         mlp = type(first).__name__ in ("AffineCouplingTransform", "AdditiveCouplingTransform")
         geometry = first._fused_geometry(tuple(c for c, _ in units[1:]))   # one padded geometry for the run
         packed = [c._packed_mlp() if mlp else c._packed_resnet(geometry) for c, _ in units]
-        f16 = (not mlp) and first._use_f16()
+        f16 = (not mlp) and first._use_f16(geometry)
         packed_f16 = [c._packed_resnet_f16(geometry) for c, _ in units] if f16 else None
         key = (_cache.epoch(), inverse, f16, tuple(id(c) for c, _ in units),
                tuple((c._packed_mlp_cache if mlp else c._packed_resnet_cache)[0] for c, _ in units),
@@ -173,7 +173,8 @@ class CompositeTransform(Transform):
             head = ops.rqs_coupling_resnet_f16(
                 inputs, plan_f16, (weights, biases), tables, dt4,
                 di_u, len(first.transform_net.blocks), first._spec(), inverse,
-                total, num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob, pad=pad)
+                total, num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob, pad=pad,
+                context=context)
         else:
             head = ops.rqs_coupling_resnet(
                 inputs, weights, biases, tables, dt4, di_u,

@@ -468,10 +468,12 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
     # scale of the hidden activations' f16 pieces (a power of two; K8h)
     conditioner_act_scale = float(os.environ.get("NFA_K8_ACT_SCALE", "1"))
 
-    def _use_f16(self):
-        """K8h serves conditioners without a context; with one the bf16x3 kernel (K8) runs."""
+    def _use_f16(self, geometry=None):
+        """K8h serves 8 and 10 bins; with a context up to 32 context features beside up to 32 identity features
+        (of the run's geometry) -- otherwise the bf16x3 kernel (K8) runs."""
+        ce = getattr(self.transform_net, "context_features", None)
         return (self.conditioner_engine == "f16x2" and self.num_bins in (8, 10) and not self._log2e()
-                and getattr(self.transform_net, "context_features", None) is None)
+                and (ce is None or (ce <= 32 and (geometry or self._fused_geometry())[2] <= 32)))
 
     def _packed_resnet_f16(self, geometry=None):
         net = self.transform_net
@@ -538,7 +540,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         # (ragged batches are padded to full 128-row blocks, odd shapes to multiples of four columns, in `ops`)
         if self._use_f16():
             return ops.rqs_coupling_resnet_f16(inputs, self._f16_stream(tables), (wp, bp), tables, dt4, di, nb, spec,
-                                               inverse, accumulate_into, pad=(Dp, pad_value))
+                                               inverse, accumulate_into, pad=(Dp, pad_value), context=context)
         return ops.rqs_coupling_resnet(inputs, wp, bp, tables, dt4, di, nb, spec, inverse, accumulate_into,
                                        log2e=self._log2e(), context=context, pad=(Dp, pad_value))
 

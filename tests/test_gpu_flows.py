@@ -292,7 +292,8 @@ def test_conditional_flow_with_context():
         flow.log_prob(x, context=ctx[:10])
 
 
-def test_conditional_flow_against_reference_vectors(golden_dir):
+@pytest.mark.parametrize("engine", ["f16x2", "bf16x3"])
+def test_conditional_flow_against_reference_vectors(monkeypatch, golden_dir, engine):
     """A conditional flow at the whole-layer kernels' layer shape (H = 128, context embedded by a Linear)
     against the vectors the real reference produced for it (tests/golden/flows_context.npz; the eager
     oracle is pinned to the same vectors bit for bit in tests/test_oracle_golden.py): log_prob, the
@@ -300,12 +301,14 @@ def test_conditional_flow_against_reference_vectors(golden_dir):
     error against its float64 result."""
     from helpers import golden_conditional_flow
     import nflows_amd
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ_
+    monkeypatch.setattr(RQ_, "conditioner_engine", engine)
     flow, g, name = golden_conditional_flow(golden_dir)
     flow = flow.to(DEV)
     x, noise, ctx = (torch.from_numpy(g[name + "/" + k]).to(DEV) for k in ("x", "noise", "context"))
     with torch.no_grad():
         emb = flow._embedding_net(ctx)
-        # the whole conditional flow is one run of the whole-layer kernel (K8 with a context)
+        # the whole conditional flow is one run of the whole-layer kernel (K8h / K8 with a context)
         units, after = flow._transform._collect_run(list(flow._transform._transforms), 0, x, emb, inverse=False)
         assert len(units) == 3 and after == 6
         lp = flow.log_prob(x, context=ctx)
@@ -1089,7 +1092,9 @@ def test_whole_layer_kernels_take_any_feature_count(monkeypatch, features, engin
     (21, 8, 64, 8),      # odd count: the layers of the run have two splits
     (32, 10, 128, 12),
 ])
-def test_conditional_flows_of_any_shape_in_the_whole_layer_kernel(features, num_bins, hidden, context_features):
+@pytest.mark.parametrize("engine", ["f16x2", "bf16x3"])
+def test_conditional_flows_of_any_shape_in_the_whole_layer_kernel(monkeypatch, engine, features, num_bins, hidden,
+                                                                  context_features):
     """Conditional spline flows (context in the initial layer + the gate of every block, resnet.py:9-52,
     :92-100) with 8 or 10 bins, feature counts that need the padded geometry and conditioners narrower than 128
     run as one launch of the whole-layer kernel: against the eager oracle in float64 (the reference's
@@ -1098,6 +1103,7 @@ def test_conditional_flows_of_any_shape_in_the_whole_layer_kernel(features, num_
     from oracle import eager
     from nflows_amd import configs
     from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    monkeypatch.setattr(RQ, "conditioner_engine", engine)
     flow = configs.conditional_rq_nsf_flow(num_layers=5, features=features, num_bins=num_bins, hidden_features=hidden,
                                            raw_context=6, context_features=context_features, seed=features)
     with torch.no_grad():
@@ -1117,7 +1123,7 @@ def test_conditional_flows_of_any_shape_in_the_whole_layer_kernel(features, num_
         xd, cd = x.to(DEV), ctx.to(DEV)
         emb = flow._embedding_net(cd)
         units, _ = flow._transform._collect_run(list(flow._transform._transforms), 0, xd, emb, inverse=False)
-        assert len(units) == 5
+        assert len(units) == 5 and units[0][0]._use_f16() == (engine == "f16x2")
         z, lad = flow._transform(xd, context=emb)
         lp = flow.log_prob(xd, context=cd)
         xr, lad_inv = flow._transform.inverse(z, context=emb)

@@ -338,6 +338,126 @@ def test_whole_layer_packing_is_a_lossless_rearrangement(K):
                 assert vals[:, 24 * f + 23].abs().max().item() == 0.0              # the pad row
 
 
+def _emulate_f16_whole_layer(wp, prm, x, di, dt, K, num_blocks, ctx=None):
+    """The data flow of K8h on ONE 32-row tile, from the packed stream: every GEMM on two f16 weight pieces
+    pre-scaled by a power of two, accumulator <-> piece conversions with the headers' scales, the fp32 residual
+    stream, and -- with `ctx` [32, ce] -- the context k-steps of the initial layer and the gate of every block.
+    Returns (hidden activations x S as [32, 128], logits as [32, dt, 3K - 1] (widths / heights pre-divided by
+    sqrt(hidden)), stages consumed, parameter words consumed)."""
+    H = 4  # header floats
+    P = 3 * K - 1
+    R = 24 if K == 8 else 32
+    tiles = dt * R // 32
+    w = wp.double().view(-1, 1024, 8)
+    bp = prm
+    lane_r = torch.arange(64) % 32
+    lane_h = torch.arange(64) // 32
+
+    def acc_to_features(acc):
+        out = torch.zeros(32, 32 * acc.shape[0], dtype=torch.float64)
+        for t in range(acc.shape[0]):
+            for q in range(16):
+                out[lane_r, 32 * t + 8 * (q // 4) + 4 * lane_h + q % 4] = acc[t, :, q]
+        return out
+
+    def bias_tiles(off, n):
+        return bp[off:off + n * 32].double().view(n, 2, 16)[:, lane_h, :].clone()
+
+    def mfma(acc_t, a_frag, b_frag):
+        A = torch.zeros(32, 16, dtype=torch.float64)
+        Bm = torch.zeros(16, 32, dtype=torch.float64)
+        for l in range(64):
+            A[l % 32, 8 * (l // 32):8 * (l // 32) + 8] = a_frag[l]
+            Bm[8 * (l // 32):8 * (l // 32) + 8, l % 32] = b_frag[l]
+        Dm = A @ Bm
+        for l in range(64):
+            for q in range(16):
+                acc_t[l, q] += Dm[8 * (q // 4) + 4 * (l // 32) + q % 4, l % 32]
+
+    def pair(stage, g):       # fragment pair g of a stage: hi + lo
+        return w[stage, (2 * g) * 64:(2 * g) * 64 + 64] + w[stage, (2 * g + 1) * 64:(2 * g + 1) * 64 + 64]
+
+    def b_from_acc(acc, ks):  # pieces of k-step ks = tile ks // 2, registers 8 (ks % 2) ..
+        return acc[ks // 2][:, 8 * (ks % 2):8 * (ks % 2) + 8]
+
+    def b_from_rows(rows, ks):  # pieces of k-step ks of an input given by rows: k = ks*16 + half*8 + j
+        b = torch.zeros(64, 8, dtype=torch.float64)
+        for l in range(64):
+            for j in range(8):
+                i = ks * 16 + (l // 32) * 8 + j
+                b[l, j] = rows[l % 32, i] if i < rows.shape[1] else 0.0
+        return b
+
+    def k_major(stage0, acc, pieces_of):  # a stage per two k-steps, pair 4 (ks % 2) + t = tile t
+        st = stage0
+        for ks, b in enumerate(pieces_of):
+            for t in range(4):
+                mfma(acc[t], pair(st, 4 * (ks % 2) + t), b)
+            st += ks % 2
+        return st
+
+    def tile_major(stage0, acc, src):   # the final GEMM: one stage per tile, pair ks = k-step ks
+        st = stage0
+        for t in range(acc.shape[0]):
+            for ks in range(8):
+                mfma(acc[t], pair(st, ks), b_from_acc(src, ks))
+            st += 1
+        return st
+
+    stage, off = 0, 0
+    if ctx is None:
+        init_pieces = [b_from_rows(x[:, :di], ks) for ks in range(4 if di > 32 else 2)]
+    else:  # [identity features, zero-padded to 32 | context, zero-padded to 32]
+        cpieces = [b_from_rows(ctx, ks) for ks in range(2)]
+        init_pieces = [b_from_rows(x[:, :di], ks) for ks in range(2)] + cpieces
+    out_scale = bp[off].double()
+    hacc = bias_tiles(off + H, 4)                     # the fp32 residual stream
+    stage = k_major(stage, hacc, init_pieces)
+    hp = torch.relu(hacc * out_scale)                 # pieces of relu(h) at scale S
+    off += H + 128
+    for blk in range(num_blocks):
+        out_scale = bp[off].double()
+        assert bp[off + 1] == 0
+        u = bias_tiles(off + H, 4)
+        stage = k_major(stage, u, [b_from_acc(hp, ks) for ks in range(8)])
+        q = torch.relu(u * out_scale)
+        off += H + 128
+        out_scale, ratio = bp[off].double(), bp[off + 1].double()
+        if ctx is None:
+            hacc = hacc * ratio + bias_tiles(off + H, 4)  # skip connection: the stream itself, rescaled
+            stage = k_major(stage, hacc, [b_from_acc(q, ks) for ks in range(8)])
+            off += H + 128
+        else:
+            v = bias_tiles(off + H, 4)                    # the second Linear alone ...
+            stage = k_major(stage, v, [b_from_acc(q, ks) for ks in range(8)])
+            off += H + 128
+            inv_t = bp[off].double()
+            gate = bias_tiles(off + H, 4)                 # ... the gate's Linear on the context pieces
+            stage = k_major(stage, gate, cpieces)
+            hacc = hacc * ratio + v * torch.sigmoid(gate * inv_t)
+            off += H + 128
+        hp = hacc * out_scale
+        if blk + 1 < num_blocks:
+            hp = torch.relu(hp)
+    hidden = acc_to_features(hp)
+    kappa, inv_kappa = bp[off].double(), bp[off + 1].double()
+    assert kappa * inv_kappa == 1.0
+    out = bias_tiles(off + H, tiles)
+    stage = tile_major(stage, out, hp)
+    off += H + tiles * 32
+    out = out * kappa
+    assert K == 8
+    logits = torch.zeros(32, dt, P, dtype=torch.float64)
+    for g in range(dt // 4):
+        for half in range(2):
+            lanes = torch.arange(32) + 32 * half
+            vals = torch.cat([out[3 * g + t][lanes] for t in range(3)], dim=1)
+            for f in range(2):
+                logits[:, 4 * g + 2 * half + f] = vals[:, 24 * f:24 * f + 23]
+                assert vals[:, 24 * f + 23].abs().max().item() == 0.0
+    return hidden, logits, stage, off
+
+
 @pytest.mark.parametrize("act_scale", [1.0, 16.0])
 def test_f16_whole_layer_packing_carries_the_scales(act_scale):
     """Host side of K8h (ops.pack_resnet_conditioner_f16 / build_f16_stream): emulate the kernel's
@@ -369,104 +489,44 @@ def test_f16_whole_layer_packing_carries_the_scales(act_scale):
     words = stream[0].view(torch.float32)
     assert torch.equal(words[:128].view(torch.int32), tables[:128]) and torch.equal(words[128:128 + prm.numel()], prm)
     assert torch.equal(stream[1:], wp)
-    w = wp.double().view(-1, 1024, 8)
-    bp = prm
     x = torch.randn(32, di, dtype=torch.float64)
-    lane_r = torch.arange(64) % 32
-    lane_h = torch.arange(64) // 32
-
-    def acc_to_features(acc):
-        out = torch.zeros(32, 32 * acc.shape[0], dtype=torch.float64)
-        for t in range(acc.shape[0]):
-            for q in range(16):
-                out[lane_r, 32 * t + 8 * (q // 4) + 4 * lane_h + q % 4] = acc[t, :, q]
-        return out
-
-    def bias_tiles(off, n):
-        return bp[off:off + n * 32].double().view(n, 2, 16)[:, lane_h, :].clone()
-
-    def mfma(acc_t, a_frag, b_frag):
-        A = torch.zeros(32, 16, dtype=torch.float64)
-        Bm = torch.zeros(16, 32, dtype=torch.float64)
-        for l in range(64):
-            A[l % 32, 8 * (l // 32):8 * (l // 32) + 8] = a_frag[l]
-            Bm[8 * (l // 32):8 * (l // 32) + 8, l % 32] = b_frag[l]
-        Dm = A @ Bm
-        for l in range(64):
-            for q in range(16):
-                acc_t[l, q] += Dm[8 * (q // 4) + 4 * (l // 32) + q % 4, l % 32]
-
-    def pair(stage, g):       # fragment pair g of a stage: hi + lo
-        return w[stage, (2 * g) * 64:(2 * g) * 64 + 64] + w[stage, (2 * g + 1) * 64:(2 * g + 1) * 64 + 64]
-
-    def b_from_acc(acc, ks):  # pieces of k-step ks = tile ks // 2, registers 8 (ks % 2) ..
-        return acc[ks // 2][:, 8 * (ks % 2):8 * (ks % 2) + 8]
-
-    def k_major(stage0, acc, src):      # a 128 -> 128 GEMM: a stage per two k-steps, pair 4 (ks % 2) + t = tile t
-        st = stage0
-        for ks in range(8):
-            for t in range(4):
-                mfma(acc[t], pair(st, 4 * (ks % 2) + t), b_from_acc(src, ks))
-            st += ks % 2
-        return st
-
-    def tile_major(stage0, acc, src):   # the final GEMM: one stage per tile, pair ks = k-step ks
-        st = stage0
-        for t in range(acc.shape[0]):
-            for ks in range(8):
-                mfma(acc[t], pair(st, ks), b_from_acc(src, ks))
-            st += 1
-        return st
-
-    stage, off = 0, 0
-    bx = torch.zeros(2, 64, 8, dtype=torch.float64)
-    for ks in range(2):
-        for l in range(64):
-            for j in range(8):
-                i = ks * 16 + (l // 32) * 8 + j
-                bx[ks, l, j] = x[l % 32, i] if i < di else 0.0
-    out_scale = bp[off].double()
-    hacc = bias_tiles(off + H, 4)                     # the fp32 residual stream
-    for ks in range(2):                               # initial layer: k-major, both k-steps in one stage
-        for t in range(4):
-            mfma(hacc[t], pair(stage, 4 * ks + t), bx[ks])
-    stage += 1
-    hp = torch.relu(hacc * out_scale)                 # pieces of relu(h) at scale S
-    off += H + 128
-    for blk in range(2):
-        out_scale = bp[off].double()
-        assert bp[off + 1] == 0
-        u = bias_tiles(off + H, 4)
-        stage = k_major(stage, u, hp)
-        q = torch.relu(u * out_scale)
-        off += H + 128
-        out_scale, ratio = bp[off].double(), bp[off + 1].double()
-        hacc = hacc * ratio + bias_tiles(off + H, 4)  # skip connection: the stream itself, rescaled
-        stage = k_major(stage, hacc, q)
-        hp = hacc * out_scale
-        if blk == 0:
-            hp = torch.relu(hp)
-        off += H + 128
+    hidden, logits, stages, words_used = _emulate_f16_whole_layer(wp, prm, x, di, dt, K, 2)
+    assert stages == wp.shape[0] and words_used == prm.numel()
     want_hidden = net.hidden(x)
-    got_hidden = acc_to_features(hp) / act_scale
-    assert (got_hidden - want_hidden).abs().max().item() < 1e-6 * want_hidden.abs().max().item()
-    kappa, inv_kappa = bp[off].double(), bp[off + 1].double()
-    assert kappa * inv_kappa == 1.0
-    out = bias_tiles(off + H, tiles)
-    stage = tile_major(stage, out, hp)
-    assert stage == wp.shape[0] and off + H + tiles * 32 == bp.numel()
-    out = out * kappa
+    assert (hidden / act_scale - want_hidden).abs().max().item() < 1e-6 * want_hidden.abs().max().item()
     want = net.final_layer(want_hidden).view(32, dt, P).clone()
     want[..., :2 * K] /= np.sqrt(128.0)
-    for g in range(dt // 4):
-        for half in range(2):
-            lanes = torch.arange(32) + 32 * half
-            vals = torch.cat([out[3 * g + t][lanes] for t in range(3)], dim=1)
-            for f in range(2):
-                ref = want[:, 4 * g + 2 * half + f]
-                got = vals[:, 24 * f:24 * f + 23]
-                assert (got - ref).abs().max().item() < 2e-6 * (1 + ref.abs().max().item()), (g, half, f)
-                assert vals[:, 24 * f + 23].abs().max().item() == 0.0
+    assert (logits - want).abs().max().item() < 2e-6 * (1 + want.abs().max().item())
+
+
+def test_f16_whole_layer_packing_with_a_context():
+    """The same for a conditioner with a context (nn/nets/resnet.py:9-52, :92-100): the context columns are
+    the initial layer's last two k-steps, every block carries one more stage (the gate's Linear, two k-steps)
+    and one more parameter group {1 / T_c, 0} + biases x T_c, and the residual stream takes
+    (second Linear) x sigmoid(gate) in, rescaled by the second Linear's skip_scale."""
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import ResidualNet
+    torch.manual_seed(1)
+    K, dt, di, ce = 8, 8, 11, 12
+    P = 3 * K - 1
+    net = ResidualNet(di, dt * P, hidden_features=96, context_features=ce, num_blocks=2).double()
+    with torch.no_grad():
+        for i_, p_ in enumerate(net.parameters()):
+            p_.copy_(torch.randn_like(p_) * (0.3 if i_ % 3 else 0.02))
+    wp, prm = ops.pack_resnet_conditioner_f16(net.float(), dt, P)
+    net = net.double()
+    tiles = dt * 24 // 32
+    assert wp.shape == (2 + 9 * 2 + tiles, 1024 * 8)       # four initial k-steps, nine stages per block
+    assert prm.shape == ((4 + 128) * 7 + 4 + tiles * 32,)
+    x = torch.randn(32, di, dtype=torch.float64)
+    ctx = torch.randn(32, ce, dtype=torch.float64)
+    hidden, logits, stages, words_used = _emulate_f16_whole_layer(wp, prm, x, di, dt, K, 2, ctx=ctx)
+    assert stages == wp.shape[0] and words_used == prm.numel()
+    want = net(x, context=ctx).view(32, dt, P).clone()
+    want[..., :2 * K] /= np.sqrt(96.0)
+    assert (logits - want).abs().max().item() < 2e-6 * (1 + want.abs().max().item())
+    with pytest.raises(ValueError):   # more than 32 identity features beside a context: the bf16x3 kernel's case
+        ops.pack_resnet_conditioner_f16(ResidualNet(40, dt * P, hidden_features=64, context_features=4), dt, P)
 
 
 def test_layer_tables_follow_the_fused_permutations():
