@@ -464,7 +464,9 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                         for (int q = 0; q < 16; ++q) {
                             // sigmoid on v_exp_f32 / v_rcp_f32 (1 ulp each) with one residual correction of the
                             // reciprocal; the exponent is capped so that 1 + 2^t stays finite (sigmoid < 2^-126 there)
-                            const float e2 = __builtin_amdgcn_exp2f(__builtin_fminf(gate[q] * -1.44269502162933349609375f, 126.0f));
+                            float tg = gate[q] * -1.44269502162933349609375f;
+                            tg = tg > 126.0f ? 126.0f : tg;   // (a comparison, not fminf: NaN stays NaN)
+                            const float e2 = __builtin_amdgcn_exp2f(tg);
                             const float dn = 1.0f + e2;
                             const float r0 = __builtin_amdgcn_rcpf(dn);
                             const float sg = __builtin_fmaf(__builtin_fmaf(-dn, r0, 1.0f), r0, r0);

@@ -500,7 +500,9 @@ __device__ __forceinline__ void gate_tile(f32x16& hacc, const f32x16& v, const f
     const float c = -1.44269502162933349609375f * inv_t;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const float e2 = __builtin_amdgcn_exp2f(__builtin_fminf(g[q] * c, 126.0f));
+        float t = g[q] * c;
+        t = t > 126.0f ? 126.0f : t;   // (a comparison, not fminf: NaN stays NaN)
+        const float e2 = __builtin_amdgcn_exp2f(t);
         const float dn = 1.0f + e2;
         const float r0 = __builtin_amdgcn_rcpf(dn);
         const float sg = __builtin_fmaf(__builtin_fmaf(-dn, r0, 1.0f), r0, r0);

@@ -1033,6 +1033,42 @@ def test_non_finite_inputs_propagate_like_the_reference(monkeypatch, engine):
         assert np.abs(got[fin] - want[fin]).max() <= 1e-4 * (1 + np.abs(want[fin]).max()), name
 
 
+@pytest.mark.parametrize("engine", ["f16x2", "bf16x3"])
+def test_non_finite_and_huge_contexts_propagate_like_the_reference(monkeypatch, engine):
+    """The same for a conditional flow: non-finite inputs, a non-finite context value, and context values beyond
+    the f16 range (K8h gives those row blocks up, the exact kernel with a context redoes them) against the
+    eager oracle: same NaN pattern and infinities, finite rows to fp32 accuracy."""
+    import copy
+    from nflows_amd import configs
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    from oracle import eager
+    monkeypatch.setattr(RQ, "conditioner_engine", engine)
+    flow_cpu = configs.conditional_rq_nsf_flow(num_layers=3, features=16, num_bins=8, hidden_features=128,
+                                               raw_context=5, context_features=12, seed=13).eval()
+    flow = copy.deepcopy(flow_cpu).to(DEV)
+    gen = torch.Generator().manual_seed(14)
+    x = torch.randn(384, 16, generator=gen)
+    emb = torch.randn(384, 12, generator=gen)      # the embedded context, handed to the transform directly
+    x[3, 0] = float("inf")
+    x[7, 2] = float("nan")
+    emb[130, 4] = float("nan")
+    emb[131, 5] = float("inf")
+    emb[260, 1] = 3.0e5                             # beyond f16: block 2 is redone by the exact kernel
+    emb[261, 7] = -1.0e9
+    with torch.no_grad():
+        z_ref, lad_ref = eager.flow_transform(flow_cpu, x, context=emb)
+        z, lad = flow._transform(x.to(DEV), context=emb.to(DEV))
+    z, lad = z.cpu().numpy(), lad.cpu().numpy()
+    z_ref, lad_ref = z_ref.numpy(), lad_ref.numpy()
+    for got, want, name in ((z, z_ref, "z"), (lad, lad_ref, "logabsdet")):
+        assert np.array_equal(np.isnan(got), np.isnan(want)), name
+        inf = np.isinf(want)
+        assert np.array_equal(got[inf], want[inf]), name
+        fin = np.isfinite(want)
+        assert np.abs(got[fin] - want[fin]).max() <= 1e-4 * (1 + np.abs(want[fin]).max()), name
+    assert np.isfinite(z_ref[260]).all() and np.isfinite(z_ref[261]).all()   # (huge contexts saturate the gates)
+
+
 @pytest.mark.parametrize("features", [6, 20, 21, 43, 63])
 @pytest.mark.parametrize("engine", ["f16x2", "bf16x3"])
 def test_whole_layer_kernels_take_any_feature_count(monkeypatch, features, engine):
