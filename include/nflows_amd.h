@@ -70,6 +70,12 @@ extern "C" {
 #define NFA_FLAG_SKIP_OUTPUTS 32          /* with NFA_FLAG_STANDARD_NORMAL_LOG_PROB: `outputs` (z) is not
                                              written (may be null): Flow.log_prob never looks at it */
 
+#define NFA_FLAG_PAD_COLUMNS_SHIFT 8       /* with NFA_FLAG_STANDARD_NORMAL_LOG_PROB: bits 8-10 = number of trailing */
+#define NFA_FLAG_PAD_COLUMNS_MASK 0x700   /* columns (0-7) that are the host's padding of the row (they pass through
+                                             every layer, see nflows_amd/ops.py: fused_geometry), not features: the
+                                             density sums over the other `features - n` columns, D = features - n */
+#define NFA_FLAG_PAD_COLUMNS(n) ((n) << NFA_FLAG_PAD_COLUMNS_SHIFT)
+
 /* tails */
 #define NFA_TAILS_NONE 0   /* rational_quadratic_spline: K+1 derivative logits per element */
 #define NFA_TAILS_LINEAR 1 /* unconstrained_rational_quadratic_spline(tails="linear"): K-1 */

@@ -43,6 +43,7 @@ struct AffineMlpArgs {
     int final_tiles;
     int normal, skip_out;   // NFA_FLAG_STANDARD_NORMAL_LOG_PROB / NFA_FLAG_SKIP_OUTPUTS
     float log_z;
+    int Ds;                // columns the density sums over (features minus NFA_FLAG_PAD_COLUMNS)
 };
 
 template <bool INVERSE, int INIT_KS, bool ADDITIVE>
@@ -222,7 +223,7 @@ __global__ void __launch_bounds__(kBlock, 2) affine_mlp_kernel(const AffineMlpAr
         }
         lad_acc += __shfl_xor(lad_acc, 32, kWave);
         float sumsq = 0.0f;
-        if (a.normal) sumsq = tile_row_sumsq(s_row, D, half, r);
+        if (a.normal) sumsq = tile_row_sumsq(s_row, a.Ds, half, r);
         if (half == 0) {
             float* dst = a.lad + row0 + r;
             float v = a.accumulate ? *dst + lad_acc : lad_acc;
@@ -248,7 +249,7 @@ extern "C" int nfa_affine_flow_mlp_f32(const float* inputs, const void* weights_
                                        int32_t num_hidden_layers, int32_t scale_activation, int32_t flags,
                                        void* stream) {
     if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_STANDARD_NORMAL_LOG_PROB |
-                  NFA_FLAG_SKIP_OUTPUTS))
+                  NFA_FLAG_SKIP_OUTPUTS | NFA_FLAG_PAD_COLUMNS_MASK))
         return NFA_ERR_INVALID_ARGUMENT;
     if (!density_flags_valid(flags)) return NFA_ERR_INVALID_ARGUMENT;
     if (batch < 0 || features < 1 || num_transform < 1 || num_identity < 1 ||
@@ -287,7 +288,9 @@ extern "C" int nfa_affine_flow_mlp_f32(const float* inputs, const void* weights_
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.normal = (flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB) ? 1 : 0;
     a.skip_out = (flags & NFA_FLAG_SKIP_OUTPUTS) ? 1 : 0;
-    a.log_z = standard_normal_log_z(features);
+    a.Ds = density_columns(flags, features);
+    if (a.Ds < 1) return NFA_ERR_INVALID_ARGUMENT;
+    a.log_z = standard_normal_log_z(a.Ds);
     const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float);
     int64_t blocks = batch >> 7;
     const int64_t per_cu = lds + 2048 <= 80 * 1024 ? 2 : 1;

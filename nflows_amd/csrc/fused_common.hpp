@@ -139,11 +139,14 @@ __device__ __forceinline__ void assemble_rows(const LayerTables& t, const float*
 // are added across the pair.  Every slot holds one output value whatever column it ends up in, so
 // this is sum_j z_j^2 (in slot order, fp32; normal.py:31 sums in column order: same rounding class).
 __device__ __forceinline__ float tile_row_sumsq(const float* s_row, int D, int half, int r, int pad = 33) {
-    const int n = D >> 1;
-    const float* p = s_row + half * n * pad + r;
+    // lane-half 0 sums slots [0, n), lane-half 1 slots [n, D), n = ceil(D / 2); two accumulators each (for D % 4 == 0
+    // the same order as ever)
+    const int n = (D + 1) >> 1;
+    const int lo = half ? n : 0, hi = half ? D : n;
+    const float* p = s_row + r;
     float a0 = 0.0f, a1 = 0.0f;
-    for (int j = 0; j < n; j += 2) {
-        const float v0 = p[j * pad], v1 = p[(j + 1) * pad];
+    for (int j = lo; j < hi; j += 2) {
+        const float v0 = p[j * pad], v1 = j + 1 < hi ? p[(j + 1) * pad] : 0.0f;
         a0 = __builtin_fmaf(v0, v0, a0);
         a1 = __builtin_fmaf(v1, v1, a1);
     }
@@ -159,8 +162,14 @@ static inline float standard_normal_log_z(int features) {
 // NFA_FLAG_STANDARD_NORMAL_LOG_PROB belongs to the forward pass; NFA_FLAG_SKIP_OUTPUTS needs it
 static inline bool density_flags_valid(int32_t flags) {
     if ((flags & NFA_FLAG_SKIP_OUTPUTS) && !(flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB)) return false;
+    if ((flags & NFA_FLAG_PAD_COLUMNS_MASK) && !(flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB)) return false;
     if ((flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB) && (flags & NFA_FLAG_INVERSE)) return false;
     return true;
+}
+
+// columns the standard-normal epilogue sums over: all but the trailing NFA_FLAG_PAD_COLUMNS
+static inline int density_columns(int32_t flags, int features) {
+    return features - ((flags & NFA_FLAG_PAD_COLUMNS_MASK) >> NFA_FLAG_PAD_COLUMNS_SHIFT);
 }
 
 }  // namespace nfa

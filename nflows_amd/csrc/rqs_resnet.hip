@@ -50,6 +50,7 @@ struct ResnetArgs {
     const int32_t* redo;  // optional [batch / 128]: only row blocks with a non-zero entry are processed
     int normal, skip_out;  // NFA_FLAG_STANDARD_NORMAL_LOG_PROB / NFA_FLAG_SKIP_OUTPUTS
     float log_z;           // 0.5 D log(2 pi)
+    int Ds;                // columns the density sums over (features minus NFA_FLAG_PAD_COLUMNS)
     const float* ctx;      // [B, ce] context rows of the conditioners (resnet.py:92-100), or null
     int ce;                // context features (columns of ctx)
 };
@@ -670,7 +671,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         }
         lad_acc += __shfl_xor(lad_acc, 32, kWave);
         float sumsq = 0.0f;
-        if (a.normal) sumsq = tile_row_sumsq(s_row, D, half, r);
+        if (a.normal) sumsq = tile_row_sumsq(s_row, a.Ds, half, r);
         if (half == 0) {
             float* dst = a.lad + row0 + r;
             float v = a.accumulate ? *dst + lad_acc : lad_acc;
@@ -698,7 +699,7 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
                                 const int32_t* redo = nullptr, const float* context = nullptr,
                                 int32_t context_features = 0) {
     if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_LOGITS_LOG2E |
-                  NFA_FLAG_STANDARD_NORMAL_LOG_PROB | NFA_FLAG_SKIP_OUTPUTS))
+                  NFA_FLAG_STANDARD_NORMAL_LOG_PROB | NFA_FLAG_SKIP_OUTPUTS | NFA_FLAG_PAD_COLUMNS_MASK))
         return NFA_ERR_INVALID_ARGUMENT;
     if (!density_flags_valid(flags)) return NFA_ERR_INVALID_ARGUMENT;
     if (batch < 0 || features < 1 || num_transform < 1 || num_identity < 1 ||
@@ -728,7 +729,9 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     a.ce = context_features;
     a.normal = (flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB) ? 1 : 0;
     a.skip_out = (flags & NFA_FLAG_SKIP_OUTPUTS) ? 1 : 0;
-    a.log_z = standard_normal_log_z(features);
+    a.Ds = density_columns(flags, features);
+    if (a.Ds < 1) return NFA_ERR_INVALID_ARGUMENT;
+    a.log_z = standard_normal_log_z(a.Ds);
     a.x = inputs;
     a.w = reinterpret_cast<const vec4f*>(weights_packed);
     a.bias = bias_packed;

@@ -88,6 +88,7 @@ struct Args {
     unsigned long long* trace;  // debug: [gridDim.x][64] cycle stamps of wave 0 (first row block), null = off
     int normal, skip_out;       // NFA_FLAG_STANDARD_NORMAL_LOG_PROB / NFA_FLAG_SKIP_OUTPUTS
     float log_z;                // 0.5 D log(2 pi)
+    int Ds;                // columns the density sums over (features minus NFA_FLAG_PAD_COLUMNS)
     const float* ctx;           // CTX: [batch, ce] context rows (nn/nets/resnet.py:9-52, :92-100)
     int ce;
 };
@@ -892,7 +893,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
         lad_acc += __shfl_xor(lad_acc, 32, kWave);
         // sum_j z_j^2 of every row: the standard-normal epilogue needs it, and it is non-finite exactly
         // when one of the row's values is (or a square overflows: such a block is redone like the others)
-        const float sumsq = tile_row_sumsq(s_row, D, half, r);
+        const float sumsq = tile_row_sumsq(s_row, a.Ds, half, r);
         const bool bad = not_finite(lad_acc) || not_finite(sumsq);
         const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
         if (lane == 0) s_bad[wave] = wave_bad ? 1 : 0;
@@ -942,7 +943,7 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
                       int32_t num_transform, int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
                       const nfa_rqs_spec* spec, int32_t flags, void* stream) {
     if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_STANDARD_NORMAL_LOG_PROB |
-                  NFA_FLAG_SKIP_OUTPUTS))
+                  NFA_FLAG_SKIP_OUTPUTS | NFA_FLAG_PAD_COLUMNS_MASK))
         return NFA_ERR_INVALID_ARGUMENT;
     if (!density_flags_valid(flags)) return NFA_ERR_INVALID_ARGUMENT;
     if (batch < 0 || features < 1 || num_transform < 1 || num_identity < 1 ||
@@ -972,7 +973,9 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     a.ce = context_features;
     a.normal = (flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB) ? 1 : 0;
     a.skip_out = (flags & NFA_FLAG_SKIP_OUTPUTS) ? 1 : 0;
-    a.log_z = standard_normal_log_z(features);
+    a.Ds = density_columns(flags, features);
+    if (a.Ds < 1) return NFA_ERR_INVALID_ARGUMENT;
+    a.log_z = standard_normal_log_z(a.Ds);
     a.x = inputs;
     a.w = reinterpret_cast<const vec4f*>(stream_packed);
     a.final_tab = final_positions;

@@ -939,30 +939,28 @@ def pack_mlp_conditioner(net, num_transform, additive=False):
 
 def affine_flow_mlp(inputs, weights_packed, bias_packed, tables, num_transform, num_identity, num_hidden_layers,
                     scale_activation, inverse=False, accumulate_into=None, num_layers=1,
-                    standard_normal_log_prob=False, pad=None):
+                    standard_normal_log_prob=False, pad=None, _pad_columns_count=0):
     """K11 -- a run of affine / additive coupling layers with their MLP conditioners in one launch
     (weights / biases of the layers concatenated in execution order, tables from
     `flow_layer_tables`).  Returns (outputs, logabsdet), or (None, log_prob) with
     `standard_normal_log_prob`; None when the shape is outside the fast path."""
     N.require_device_f32("inputs", inputs, 2)
     if pad is not None and inputs.shape[1] != pad[0]:   # rows padded to a multiple of four columns (tables too)
-        if standard_normal_log_prob:
-            raise ValueError("the standard-normal epilogue sums over the padded row: not with padded features")
         out = affine_flow_mlp(_pad_columns(inputs, pad[0], pad[1]), weights_packed, bias_packed, tables, num_transform,
                               num_identity, num_hidden_layers, scale_activation, inverse, accumulate_into, num_layers,
-                              False)
-        return None if out is None else (out[0][:, :inputs.shape[1]], out[1])
+                              standard_normal_log_prob, None, pad[0] - inputs.shape[1])
+        return _without_pad_columns(out, inputs.shape[1])
     if inputs.shape[0] % 128:
         return _on_full_blocks(
             lambda x_, acc_, ctx_: affine_flow_mlp(x_, weights_packed, bias_packed, tables, num_transform, num_identity,
                                                    num_hidden_layers, scale_activation, inverse, acc_, num_layers,
-                                                   standard_normal_log_prob),
+                                                   standard_normal_log_prob, None, _pad_columns_count),
             inputs, accumulate_into)
     dev = inputs.device
     B, D = inputs.shape
     x = inputs.detach().contiguous()
     lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
-    flags, out = _density_epilogue(flags, standard_normal_log_prob, inverse, x)
+    flags, out = _density_epilogue(flags, standard_normal_log_prob, inverse, x, _pad_columns_count)
     with torch.cuda.device(dev):
         rc = N.load().nfa_affine_flow_mlp_f32(
             N.ptr(x), N.ptr(weights_packed), N.ptr(bias_packed), N.ptr(tables), num_layers, N.ptr(out),
@@ -1205,19 +1203,29 @@ def _on_full_blocks(run, inputs, accumulate_into, context=None):
     return out, lad
 
 
-def _density_epilogue(flags, standard_normal_log_prob, inverse, like):
+def _density_epilogue(flags, standard_normal_log_prob, inverse, like, pad_columns=0):
     """`flags` and the outputs buffer for the whole-layer kernels: with `standard_normal_log_prob` the
-    kernel's second result is the flow's log-density and z never leaves the chip."""
+    kernel's second result is the flow's log-density and z never leaves the chip.  `pad_columns`: trailing
+    columns of the rows that are the host's padding (fused_geometry), not features of the density."""
     if not standard_normal_log_prob:
         return flags, torch.empty_like(like)
     if inverse:
         raise ValueError("the standard-normal epilogue belongs to the forward pass")
-    return flags | N.FLAG_STANDARD_NORMAL_LOG_PROB | N.FLAG_SKIP_OUTPUTS, None
+    if not 0 <= pad_columns <= 7:
+        raise ValueError("at most seven pad columns")
+    return flags | N.FLAG_STANDARD_NORMAL_LOG_PROB | N.FLAG_SKIP_OUTPUTS | (pad_columns << N.FLAG_PAD_COLUMNS_SHIFT), None
+
+
+def _without_pad_columns(result, features):
+    """(outputs, logabsdet) of a launch on padded rows -> the caller's columns ((None, log_prob) stays)."""
+    if result is None or result[0] is None:
+        return result
+    return result[0][:, :features], result[1]
 
 
 def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transform, num_identity, num_blocks,
                         spec, inverse=False, accumulate_into=None, log2e=False, num_layers=1,
-                        standard_normal_log_prob=False, context=None, pad=None):
+                        standard_normal_log_prob=False, context=None, pad=None, _pad_columns_count=0):
     """K8 -- ResidualNet conditioner + spline coupling layer in one kernel; with num_layers > 1 a
     whole run of such layers (weights / biases concatenated in execution order, tables from
     `flow_layer_tables`).  Returns (outputs, logabsdet), or (None, log_prob) with
@@ -1227,23 +1235,23 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
     if pad is not None and inputs.shape[1] != pad[0]:
         # `pad` = (padded features, pad value) of `fused_geometry`: `num_transform`, the blobs and the tables
         # are the padded layer's; the pad columns come off the result again
-        if standard_normal_log_prob:
-            raise ValueError("the standard-normal epilogue sums over the padded row: not with padded features")
+        # (the density epilogue is told how many trailing columns are padding)
         out = rqs_coupling_resnet(_pad_columns(inputs, pad[0], pad[1]), weights_packed, bias_packed, tables,
                                   num_transform, num_identity, num_blocks, spec, inverse, accumulate_into, log2e,
-                                  num_layers, False, context)
-        return None if out is None else (out[0][:, :inputs.shape[1]], out[1])
+                                  num_layers, standard_normal_log_prob, context, None, pad[0] - inputs.shape[1])
+        return _without_pad_columns(out, inputs.shape[1])
     if inputs.shape[0] % 128:
         return _on_full_blocks(
             lambda x_, acc_, ctx_: rqs_coupling_resnet(x_, weights_packed, bias_packed, tables, num_transform,
                                                        num_identity, num_blocks, spec, inverse, acc_, log2e,
-                                                       num_layers, standard_normal_log_prob, ctx_),
+                                                       num_layers, standard_normal_log_prob, ctx_, None,
+                                                       _pad_columns_count),
             inputs, accumulate_into, context)
     dev = inputs.device
     B, D = inputs.shape
     x = inputs.detach().contiguous()
     lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
-    flags, out = _density_epilogue(flags, standard_normal_log_prob, inverse, x)
+    flags, out = _density_epilogue(flags, standard_normal_log_prob, inverse, x, _pad_columns_count)
     if log2e:
         flags |= N.FLAG_LOGITS_LOG2E
     with torch.cuda.device(dev):
@@ -1270,7 +1278,7 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
 
 def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transform, num_identity, num_blocks,
                             spec, inverse=False, accumulate_into=None, num_layers=1,
-                            standard_normal_log_prob=False, pad=None, context=None):
+                            standard_normal_log_prob=False, pad=None, context=None, _pad_columns_count=0):
     """K8h -- the run of whole-layer kernels on the f16 matrix pipe (two f16 pieces per operand),
     followed by the exact kernel (three bf16 pieces, full fp32 range) on the row blocks the first
     pass gave up on: blocks with a non-finite result, i.e. an activation beyond the f16 range or
@@ -1279,23 +1287,22 @@ def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transf
     the run's `flow_layer_tables` (for the exact kernel).  Results as for `rqs_coupling_resnet`."""
     N.require_device_f32("inputs", inputs, 2)
     if pad is not None and inputs.shape[1] != pad[0]:   # (see rqs_coupling_resnet)
-        if standard_normal_log_prob:
-            raise ValueError("the standard-normal epilogue sums over the padded row: not with padded features")
         out = rqs_coupling_resnet_f16(_pad_columns(inputs, pad[0], pad[1]), stream_f16, packed_exact, tables,
                                       num_transform, num_identity, num_blocks, spec, inverse, accumulate_into,
-                                      num_layers, False, None, context)
-        return None if out is None else (out[0][:, :inputs.shape[1]], out[1])
+                                      num_layers, standard_normal_log_prob, None, context,
+                                      pad[0] - inputs.shape[1])
+        return _without_pad_columns(out, inputs.shape[1])
     if inputs.shape[0] % 128:
         return _on_full_blocks(
             lambda x_, acc_, ctx_: rqs_coupling_resnet_f16(x_, stream_f16, packed_exact, tables, num_transform,
                                                            num_identity, num_blocks, spec, inverse, acc_, num_layers,
-                                                           standard_normal_log_prob, None, ctx_),
+                                                           standard_normal_log_prob, None, ctx_, _pad_columns_count),
             inputs, accumulate_into, context)
     dev = inputs.device
     B, D = inputs.shape
     x = inputs.detach().contiguous()
     lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
-    flags, out = _density_epilogue(flags, standard_normal_log_prob, inverse, x)
+    flags, out = _density_epilogue(flags, standard_normal_log_prob, inverse, x, _pad_columns_count)
     redo = torch.empty(max(1, B // 128), dtype=torch.int32, device=dev)
     lib = N.load()
     stream, param_stages, final_table = stream_f16

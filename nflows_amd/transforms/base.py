@@ -162,8 +162,6 @@ class CompositeTransform(Transform):
         weights, biases, tables, plan_f16 = self._run_plan(units, inverse)
         Dp, dt4, di_u, pad_value = first._fused_geometry(tuple(c for c, _ in units[1:]))
         pad = (Dp, pad_value)
-        if standard_normal_log_prob and Dp != inputs.shape[1]:
-            return None      # (the epilogue sums over the padded row: odd shapes take the two-step route)
         if type(first).__name__ in ("AffineCouplingTransform", "AdditiveCouplingTransform"):
             head = ops.affine_flow_mlp(
                 inputs, weights, biases, tables, first.num_transform_features, first.num_identity_features,

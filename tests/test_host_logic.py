@@ -42,7 +42,10 @@ def test_header_constants_match_binding():
                   ("FLAG_WEIGHTS_BF16X3", "NFA_FLAG_WEIGHTS_BF16X3"), ("FLAG_LOGITS_LOG2E", "NFA_FLAG_LOGITS_LOG2E"),
                   ("TAILS_LINEAR", "NFA_TAILS_LINEAR"), ("SCALE_DEFAULT", "NFA_SCALE_DEFAULT"),
                   ("SCALE_GENERAL", "NFA_SCALE_GENERAL"), ("SCALE_ADDITIVE", "NFA_SCALE_ADDITIVE"),
-                  ("SCALE_GIVEN", "NFA_SCALE_GIVEN"), ("SCALE_SOFTPLUS", "NFA_SCALE_SOFTPLUS")]:
+                  ("SCALE_GIVEN", "NFA_SCALE_GIVEN"), ("SCALE_SOFTPLUS", "NFA_SCALE_SOFTPLUS"),
+                  ("FLAG_STANDARD_NORMAL_LOG_PROB", "NFA_FLAG_STANDARD_NORMAL_LOG_PROB"),
+                  ("FLAG_SKIP_OUTPUTS", "NFA_FLAG_SKIP_OUTPUTS"),
+                  ("FLAG_PAD_COLUMNS_SHIFT", "NFA_FLAG_PAD_COLUMNS_SHIFT")]:
         assert getattr(N, py) == int(consts[c]), c
     # struct layout: 2 int32 + 10 doubles, natural alignment
     assert ctypes.sizeof(N.RqsSpec) == 8 + 10 * 8
