@@ -1,4 +1,4 @@
-// Spline evaluation of K8h's woven final layer (csrc/rqs_resnet_f16.hip): 8 bins, linear tails,
+// Spline evaluation of K8h's woven final layer (csrc/rqs_resnet_f16.hip): 8 or 10 bins, linear tails,
 // logits handed over at scale 1/kappa straight from the MFMA accumulators.
 //
 // Same function as rational_quadratic.py:66-181 (+ :13-63 for the tails), arranged for the lowest
@@ -6,7 +6,7 @@
 //   * softmax numerators as 2^(fma(e, log2e*kappa, -max*log2e*kappa)): two instructions per logit;
 //     the rounding of the shared term is common to all eight numerators and cancels in the
 //     normalisation;
-//   * ONE walk over the bins instead of two: knot_{i+1} = knot_i + fma(numerator_i, 2B(1-8 min)/den,
+//   * ONE walk over the bins instead of two: knot_{i+1} = knot_i + fma(numerator_i, 2B(1-K min)/den,
 //     2B min) for widths and heights side by side (fp32 running sums; the reference rounds each
 //     normalised bin to fp32, sums in double and rounds every knot -- the same error class), and on
 //     the compare x >= knot_i of the searched axis the candidates of BOTH axes and the two
@@ -24,17 +24,18 @@
 
 namespace nfa {
 
-template <bool INVERSE>
-struct FusedSteps8 {
-    static constexpr int kNumSlices = 12;
-    static constexpr int kWalkSlices = 3 + 2 * 7;               // setup x 2, bin 0, bins 1..7 x (knots | select)
+template <bool INVERSE, int KT = 8>
+struct FusedSteps {
+    static_assert(KT == 8 || KT == 10, "8 or 10 bins");
+    static constexpr int kNumSlices = KT + 4;                   // max x 2, one exponential per logit, sum x 2
+    static constexpr int kWalkSlices = 3 + 2 * (KT - 1);        // setup x 2, bin 0, bins 1..KT-1 x (knots | select)
     static constexpr int kBinSlices = INVERSE ? 9 : 7;
     static constexpr int kFinishSlices = kWalkSlices + 6 + kBinSlices + 1;
     static constexpr int kFirstWalkSlices = 0;                  // (no part of finish runs on one numerator set alone)
     static constexpr bool kInverse = INVERSE;
 
-    float ew[8], eh[8];   // logits (scaled), then softmax numerators
-    float sd[7];          // derivative logits (scaled)
+    float ew[KT], eh[KT];   // logits (scaled), then softmax numerators
+    float sd[KT - 1];       // derivative logits (scaled)
     float x;
     float kl2e, kappa, tail_s;   // log2(e) * kappa, kappa, tail_logit / kappa (uniform)
     float m_w, m_h, den_w, den_h, tw_, th_;
@@ -46,19 +47,21 @@ struct FusedSteps8 {
     float in_w, in_h, r_w, delta, s_, th, t1mt, den, t0, t1, t2, t5;
 
     template <int S>
-    __device__ __forceinline__ void numerators(float (&e)[8], float& den_, float& m, float& t) {
+    __device__ __forceinline__ void numerators(float (&e)[KT], float& den_, float& m, float& t) {
         if constexpr (S == 0) {
             m = __builtin_fmaxf(__builtin_fmaxf(e[0], e[1]), e[2]);      // (v_max3_f32)
             m = __builtin_fmaxf(__builtin_fmaxf(m, e[3]), e[4]);
         } else if constexpr (S == 1) {
             m = __builtin_fmaxf(__builtin_fmaxf(m, e[5]), e[6]);
-            m = __builtin_fmaxf(m, e[7]) * kl2e;                          // max * log2e * kappa
-        } else if constexpr (S < 10) {
+            if constexpr (KT == 10) m = __builtin_fmaxf(__builtin_fmaxf(m, e[7]), e[8]);
+            m = __builtin_fmaxf(m, e[KT - 1]) * kl2e;                     // max * log2e * kappa
+        } else if constexpr (S < 2 + KT) {
             e[S - 2] = __builtin_amdgcn_exp2f(__builtin_fmaf(e[S - 2], kl2e, -m));
-        } else if constexpr (S == 10) {
+        } else if constexpr (S == 2 + KT) {
             t = (e[0] + e[1]) + (e[2] + e[3]);
         } else {
             den_ = t + ((e[4] + e[5]) + (e[6] + e[7]));
+            if constexpr (KT == 10) den_ += e[8] + e[9];
         }
     }
     template <int S>
@@ -105,9 +108,9 @@ struct FusedSteps8 {
             u0 = tail_s;
             u1 = sd[0];
         } else if constexpr (S < W) {
-            constexpr int I = (S - 3) / 2 + 1, PART = (S - 3) % 2;   // bins 1..7
+            constexpr int I = (S - 3) / 2 + 1, PART = (S - 3) % 2;   // bins 1..KT-1
             if constexpr (PART == 0) {        // the bin's upper knots (kw / kh hold its lower ones)
-                if constexpr (I < 7) {
+                if constexpr (I < KT - 1) {
                     kwn = kw + __builtin_fmaf(ew[I], aw, sp.span_w * sp.min_w);
                     khn = kh + __builtin_fmaf(eh[I], ah, sp.span_w * sp.min_h);
                 } else {
@@ -121,7 +124,7 @@ struct FusedSteps8 {
                 ch0 = take ? kh : ch0;
                 ch1 = take ? khn : ch1;
                 u0 = take ? sd[I - 1] : u0;
-                u1 = take ? (I < 7 ? sd[I < 7 ? I : 0] : tail_s) : u1;
+                u1 = take ? (I < KT - 1 ? sd[I < KT - 1 ? I : 0] : tail_s) : u1;
                 kw = kwn;
                 kh = khn;
             }
@@ -239,5 +242,8 @@ struct FusedSteps8 {
         }
     }
 };
+
+template <bool INVERSE>
+using FusedSteps8 = FusedSteps<INVERSE, 8>;
 
 }  // namespace nfa

@@ -783,7 +783,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
             if constexpr (KB == 10) {
                 // 29 logits per feature padded to 32 rows = the 16 + 16 accumulator values a lane-half gets
                 // from the two tiles of a group: [10 widths, 6 heights | 4 heights, 9 derivatives, 3 pads]
-                using Steps = FlatSteps<INVERSE, 1, true, 10, true>;
+                using Steps = FusedSteps<INVERSE, 10>;
                 Steps f;
                 const float kappa = gemm[0];
                 f.kappa = kappa;

@@ -67,7 +67,7 @@ with torch.no_grad():
     # the reference's default of 10 bins on the same flow (K8h; the bf16x3 engine K8 takes 4.0 ms)
     flow = configs.rq_nsf_flow(32, 64, 10, 128).to(dev).eval()
     x = torch.randn(65536, 64, device=dev)
-    report("32-layer RQ-NSF with num_bins = 10 (K8, bf16x3), log_prob", timed(lambda: flow.log_prob(x), 20, warm=10), 65536)
+    report("32-layer RQ-NSF with num_bins = 10, log_prob", timed(lambda: flow.log_prob(x), 20, warm=10), 65536)
 
     # a conditional flow (context 12, embedded from 5): K8 with a context
     flow = configs.conditional_rq_nsf_flow(32, 64, 8, 128, 5, 12).to(dev).eval()
