@@ -18,11 +18,12 @@ BENCH="python $ROOTDIR/bench.py --steps 3 --warmup 1 --no-cpu-baseline --skip-ex
 
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_k8/$c -o p -- $BENCH --skip-k1-roofline > $OUT/pmc_k8_$c.log 2>&1
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_k1/$c -o p -- $BENCH --path k1 > $OUT/pmc_k1_$c.log 2>&1
+  # (SKIP_K1=1: the K1 kernel has not changed since its last collection)
+  [ "${SKIP_K1:-0}" = "1" ] || timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_k1/$c -o p -- $BENCH --path k1 > $OUT/pmc_k1_$c.log 2>&1
 done
 python $ROOTDIR/tools/pmc_traffic.py $OUT/pmc_k8 $ROOTDIR/profiles/k8h_pmc_traffic.json rqs_resnet_f16_kernel 157286400 \
   "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --skip-extra --skip-consistency --skip-k1-roofline"
-python $ROOTDIR/tools/pmc_traffic.py $OUT/pmc_k1 $ROOTDIR/profiles/k1_pmc_traffic.json rqs_coupling_pipelined 226754560 \
+[ "${SKIP_K1:-0}" = "1" ] || python $ROOTDIR/tools/pmc_traffic.py $OUT/pmc_k1 $ROOTDIR/profiles/k1_pmc_traffic.json rqs_coupling_pipelined 226754560 \
   "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --skip-extra --skip-consistency --path k1"
 cp $ROOTDIR/profiles/k8h_pmc_traffic.json $ROOTDIR/profiles/k1_pmc_traffic.json $OUT/
 # the raw counter CSVs are large; keep only the summaries
