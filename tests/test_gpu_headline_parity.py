@@ -68,15 +68,17 @@ def compare(config, what, got, ref32, truth, tol):
     return entry
 
 
-def oracle_eval(flow_cpu, x_cpu, need=("z", "lad", "lp")):
-    """float32 and float64 evaluation of the eager port on the host."""
+def oracle_eval(flow_cpu, x_cpu, need=("z", "lad", "lp"), context=None):
+    """float32 and float64 evaluation of the eager port on the host (`context`: the raw context rows of a
+    conditional flow, embedded by the flow's own embedding net in the same precision)."""
     from oracle import eager
     threads = torch.get_num_threads()
     out = {}
     with torch.no_grad():
         for tag, dt in (("32", torch.float32), ("64", torch.float64)):
             f = flow_cpu.to(dt)
-            z, lad = eager.flow_transform(f, x_cpu.to(dt))
+            emb = None if context is None else f._embedding_net(context.to(dt))
+            z, lad = eager.flow_transform(f, x_cpu.to(dt), context=emb)
             lp = eager.standard_normal_log_prob(z) + lad
             out["z" + tag], out["lad" + tag], out["lp" + tag] = z.numpy(), lad.numpy(), lp.numpy()
         flow_cpu.float()
@@ -84,24 +86,29 @@ def oracle_eval(flow_cpu, x_cpu, need=("z", "lad", "lp")):
     return out
 
 
-def hip_eval(flow_cpu, x_cpu):
+def hip_eval(flow_cpu, x_cpu, context=None):
     import copy
     import nflows_amd
     flow = copy.deepcopy(flow_cpu).float().to(DEV).eval()
     x = x_cpu.to(DEV)
     with torch.no_grad():
-        z, lad = flow._transform(x)
-        lp = flow.log_prob(x)
+        if context is None:
+            z, lad = flow._transform(x)
+            lp = flow.log_prob(x)
+        else:
+            ctx = context.to(DEV)
+            z, lad = flow._transform(x, context=flow._embedding_net(ctx))
+            lp = flow.log_prob(x, context=ctx)
     nflows_amd.check_status()
     return flow, z, lad, lp
 
 
-def check_flow(config, flow_cpu, x_cpu, oracle_rows):
+def check_flow(config, flow_cpu, x_cpu, oracle_rows, context=None):
     """Full batch on the GPU; the oracle on `oracle_rows` (an index tensor); row independence for
     the rest."""
-    flow, z, lad, lp = hip_eval(flow_cpu, x_cpu)
+    flow, z, lad, lp = hip_eval(flow_cpu, x_cpu, context)
     sub = x_cpu[oracle_rows]
-    o = oracle_eval(flow_cpu, sub)
+    o = oracle_eval(flow_cpu, sub, context=None if context is None else context[oracle_rows])
     idx = oracle_rows.to(DEV)
     zs, lads, lps = (t[idx].cpu().numpy() for t in (z, lad, lp))
     d = x_cpu.shape[1]
@@ -112,7 +119,8 @@ def check_flow(config, flow_cpu, x_cpu, oracle_rows):
         # size-independent property: the same rows evaluated alone (another batch size, other
         # positions in the launch grid) give the same bits
         with torch.no_grad():
-            z2, lad2 = flow._transform(sub.to(DEV))
+            emb = None if context is None else flow._embedding_net(context[oracle_rows].to(DEV))
+            z2, lad2 = flow._transform(sub.to(DEV), context=emb)
         assert torch.equal(z2, z[idx]) and torch.equal(lad2, lad[idx]), config + ": rows are not independent of the batch"
     return flow
 
@@ -164,6 +172,17 @@ def test_ten_bin_flow():
     flow_cpu = configs.rq_nsf_flow(num_layers=32, features=64, num_bins=10, hidden_features=128, seed=0).eval()
     x = bench_rows(8192)
     check_flow("32layer_d64_k10_b8192", flow_cpu, x, torch.arange(8192))
+
+
+def test_conditional_32_layer_flow():
+    """The 32-layer flow with conditioners that take a context (12 features embedded from 5 raw ones; K8h with a
+    context), B = 32 768; the oracle visits every fourth row."""
+    from nflows_amd import configs
+    flow_cpu = configs.conditional_rq_nsf_flow(num_layers=32, features=64, num_bins=8, hidden_features=128,
+                                               raw_context=5, context_features=12, seed=0).eval()
+    x = bench_rows(32768)
+    ctx = torch.randn(32768, 5, generator=torch.Generator().manual_seed(4321))
+    check_flow("conditional_32layer_d64_k8_ctx12_b32768", flow_cpu, x, torch.arange(0, 32768, 4), context=ctx)
 
 
 def test_forward_inverse_consistency_against_the_reference():
