@@ -567,6 +567,56 @@ def test_layer_tables_follow_the_fused_permutations():
     assert torch.equal(tile[:, tabs[3, :D]], ref)
 
 
+def test_padded_geometry_of_a_run_with_two_splits():
+    """ops.fused_geometry / flow_layer_tables(padded_*) / the packers' pad_* arguments: a run over an odd feature
+    count under alternating masks (layers of two splits) gets ONE geometry -- row length and transformed count in
+    multiples of four, one identity count --, surplus slots of either kind all point at the first pad column (which
+    no layer moves), surplus transformed features have zero rows in the packed final layer, surplus identity
+    features zero columns in the initial layer (in front of the context columns when there is a context)."""
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import ResidualNet
+    D = 21
+    even, odd = torch.arange(0, D, 2), torch.arange(1, D, 2)        # 11 / 10
+    assert ops.fused_geometry(64, [(32, 32), (32, 32)], 3.0) == (64, 32, 32, 7.0)          # nothing to pad
+    assert ops.fused_geometry(6, [(3, 3)], 3.0) == (8, 4, 3, 7.0)                          # a spare column + rounding
+    assert ops.fused_geometry(20, [(10, 10)], 1.0) == (24, 12, 10, 3.0)
+    Dp, dt4, di_u, value = ops.fused_geometry(D, [(11, 10), (10, 11), (11, 10)], 3.0)
+    assert (Dp, dt4, di_u, value) == (24, 12, 11, 7.0)
+    g = torch.Generator().manual_seed(5)
+    perms = [torch.randperm(D, generator=g) for _ in range(3)]
+    layers = [((even, odd) if i % 2 == 0 else (odd, even)) + (perms[i], None) for i in range(3)]
+    tabs = ops.flow_layer_tables(D, layers, padded_features=Dp, padded_transform=dt4, padded_identity=di_u).view(4, 128).long()
+    x = torch.randn(5, D, generator=g)
+    tile = torch.cat((x, torch.full((5, Dp - D), value)), dim=1)    # what ops._pad_columns hands to the kernel
+    ref = x.clone()
+    for i, (ti, ii, p_, _) in enumerate(layers):
+        ref = ref[:, p_]
+        assert torch.equal(tile[:, tabs[i, :ii.numel()]], ref[:, ii])
+        assert torch.equal(tile[:, tabs[i, 64:64 + ti.numel()]], ref[:, ti])
+        assert (tabs[i, ii.numel():di_u] == D).all() and (tabs[i, 64 + ti.numel():64 + dt4] == D).all()   # the spare column
+        ref = ref.clone()
+        ref[:, ti] = ref[:, ti] * 2 + 1            # stand-in for the spline (identity outside the box: the spare stays)
+        tile[:, tabs[i, 64:64 + ti.numel()]] = tile[:, tabs[i, 64:64 + ti.numel()]] * 2 + 1
+    assert torch.equal(tile[:, tabs[3, :D]], ref)
+    assert torch.equal(tabs[3, D:Dp], torch.arange(D, Dp)) and (tile[:, D:] == value).all()   # pad columns never move
+    # packers: the 10-feature layer of the run (dt = 10 -> 12, d_i = 11 is the run's count already)
+    P = 23
+    torch.manual_seed(0)
+    net = ResidualNet(11, 10 * P, hidden_features=64, num_blocks=1)
+    w_run, b_run = ops.pack_resnet_conditioner(net, 10, P, pad_transform_to=dt4, pad_identity_to=di_u)
+    w_own, b_own = ops.pack_resnet_conditioner(net, 10, P, pad_transform_to=12)
+    assert torch.equal(w_run, w_own) and torch.equal(b_run, b_own)
+    assert w_run.shape[0] == 2 + 16 + 2 * (12 * 24 // 32) and b_run.numel() == 128 + 256 + 12 * 24
+    net11 = ResidualNet(10, 11 * P, hidden_features=64, num_blocks=1)   # the other split: d_i = 10 padded to 11
+    assert ops._initial_weight(net11, 11).shape == (128, 11) and (ops._initial_weight(net11, 11)[:, 10] == 0).all()
+    ctx_net = ResidualNet(10, 11 * P, hidden_features=64, context_features=3, num_blocks=1)
+    wi = ops._initial_weight(ctx_net, 12)           # [identity 10 | zeros 2 | context 3]
+    assert wi.shape == (128, 15) and (wi[:, 10:12] == 0).all()
+    assert torch.equal(wi[:64, 12:], ctx_net.initial_layer.weight.detach()[:, 10:])
+    f16_w, f16_p = ops.pack_resnet_conditioner_f16(net, 10, P, pad_transform_to=dt4, pad_identity_to=di_u)
+    assert f16_w.shape[0] == 1 + 8 + 12 * 24 // 32 and f16_p.numel() == 132 * 3 + 4 + 12 * 24
+
+
 def test_packed_weight_caches_follow_weight_updates():
     """The re-tiled conditioner weights of the whole-layer kernels are cached per layer.  In-place
     updates under no_grad and load_state_dict are noticed; a write through `.data` is not (it does
