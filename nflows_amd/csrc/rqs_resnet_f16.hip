@@ -28,13 +28,13 @@
 //
 // Structure (32 samples per wave, rows in an LDS tile by slot, GEMMs transposed and chained through
 // the register file as in rqs_resnet.hip), and what is different here:
-//   * ONE stream of 8 KB stages per layer feeds everything through LDS-DMA: first the layer's
+//   * ONE stream of 16 KB stages per layer feeds everything through LDS-DMA: first the layer's
 //     PARAMETER stage(s) -- column tables, per-GEMM headers {out_scale, skip_scale}, all biases --
 //     then the weights.  Inside the layer loop a wave issues no global load other than its LDS-DMA
 //     requests: a `s_waitcnt vmcnt(n)` of the compiler for an ordinary load counts on in-order
 //     return, which LDS-DMA requests sharing the counter do not give it.  (The stream is drained
 //     before the ordinary loads / stores at the two ends of a row block.)
-//   * The ring is deep (six slots, five stages in flight) and shared by EIGHT waves (one workgroup
+//   * The ring is deep (four 16 KB slots, three stages in flight) and shared by EIGHT waves (one workgroup
 //     per CU) where the batch allows: a request lands 1-2 us after it was issued, so bytes per
 //     second = bytes in flight / latency; eight waves per stream also halve the bytes per CU.
 //   * Weight fragments are read from LDS one MFMA group ahead by asm reads with a counted lgkmcnt
@@ -48,8 +48,9 @@
 //     accumulator is prepared), ReLU is applied when a tile is converted into pieces, not per k-step.
 //   * No packed fp32 arithmetic (see split2).
 //
-// Restrictions: K = 8 bins, linear tails, hidden width 128, ReLU blocks, d_i <= 64, d_t % 4 == 0,
-// d_t <= 64, D % 4 == 0, D <= 128, batch % 128 == 0.
+// Restrictions: K = 8 or 10 bins, linear tails, hidden width 128 (narrower: zero-padded by the host), ReLU
+// blocks, d_i <= 64, d_t % 4 == 0, d_t <= 64, D % 4 == 0, D <= 128, batch % 128 == 0 (other feature counts
+// and batches: padded by the host); with a context: up to 32 context features beside d_i <= 32.
 
 #include "fused_common.hpp"
 #include "rqs_fused8.hpp"
