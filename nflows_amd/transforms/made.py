@@ -10,6 +10,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from .. import _cache
 from ..nn.functional import linear
 
 
@@ -58,7 +59,19 @@ class MaskedLinear(nn.Linear):
     _frozen_weight = None
 
     def masked_weight(self):
-        return self._frozen_weight if self._frozen_weight is not None else self.mask * self.weight
+        if self._frozen_weight is not None:
+            return self._frozen_weight
+        if torch.is_grad_enabled():
+            return self.mask * self.weight           # (training: autograd needs the product)
+        # no-grad passes: the product is kept until the weight changes (one elementwise launch per layer
+        # and call otherwise -- 18 MB of traffic for the output layer of the D = 784 model); keyed like the
+        # packed-weight caches (_cache.py: writes through `.data` need invalidate_packed_weights())
+        key = (_cache.epoch(), self.weight.data_ptr(), self.weight._version, self.mask.data_ptr())
+        hit = self.__dict__.get("_masked_weight_cache")
+        if hit is None or hit[0] != key:
+            hit = (key, self.mask * self.weight)
+            self.__dict__["_masked_weight_cache"] = hit
+        return hit[1]
 
     def forward(self, x):
         return linear(x, self.masked_weight(), self.bias)

@@ -642,6 +642,34 @@ def test_packed_weight_caches_follow_weight_updates():
     assert not torch.equal(layer._packed_resnet()[0], w0)
 
 
+def test_masked_weights_are_kept_between_no_grad_passes():
+    """MaskedLinear (made.py:71-72: `F.linear(x, weight * mask, bias)`): on no-grad passes the product is formed
+    once and kept until the weight changes (same rules as the packed-weight caches); with grad enabled every call
+    forms it again, so autograd sees it and masked entries get zero gradients."""
+    import nflows_amd
+    from nflows_amd.transforms.made import MADE
+    torch.manual_seed(0)
+    m = MADE(features=6, hidden_features=16, num_blocks=2, output_multiplier=3).eval()
+    x = torch.randn(5, 6)
+    lin = m.final_layer
+    with torch.no_grad():
+        y0 = m(x)
+        kept = lin.__dict__["_masked_weight_cache"][1]
+        assert torch.equal(m(x), y0) and lin.masked_weight().data_ptr() == kept.data_ptr()
+        assert torch.equal(kept, lin.mask * lin.weight)
+        lin.weight.mul_(2.0)                      # in place under no_grad: the version counter advances
+        y2 = m(x)
+        assert not torch.equal(y2, y0) and torch.equal(lin.masked_weight(), lin.mask * lin.weight)
+        lin.weight.data.mul_(0.5)                 # a write the version counter does not see
+        assert torch.equal(m(x), y2)
+        nflows_amd.invalidate_packed_weights()
+        assert torch.equal(m(x), y0)
+    y = m(x)
+    assert y.requires_grad and lin.masked_weight().data_ptr() != lin.__dict__["_masked_weight_cache"][1].data_ptr()
+    y.sum().backward()
+    assert (lin.weight.grad[lin.mask == 0] == 0).all() and lin.weight.grad.abs().sum() > 0
+
+
 def test_affine_mlp_packing_orders_the_output_rows_per_lane():
     """Host side of K11 (ops.pack_mlp_conditioner): the output layer's rows are ordered so that a
     lane-half's 16 accumulator registers of a tile are [8 shifts | the 8 scales of the same features]
