@@ -642,6 +642,71 @@ def test_packed_weight_caches_follow_weight_updates():
     assert not torch.equal(layer._packed_resnet()[0], w0)
 
 
+def test_fusion_planning_of_composite_transforms():
+    """CompositeTransform._collect_run (the host's decision which layers go to a whole-layer kernel as one run)
+    needs no device: shapes inside and outside the kernels' family, the run's padded geometry, the engine."""
+    from nflows_amd import configs
+    from nflows_amd.flows.base import Flow
+    from nflows_amd.distributions.normal import StandardNormal
+    from nflows_amd.nn.nets import MLP
+    from nflows_amd.transforms import (AffineCouplingTransform, CompositeTransform, RandomPermutation,
+                                       PiecewiseRationalQuadraticCouplingTransform as RQ)
+    from nflows_amd.utils.torchutils import create_alternating_binary_mask
+
+    def plan(flow, x, context=None):
+        layers = list(flow._transform._transforms)
+        with torch.no_grad():
+            units, after = flow._transform._collect_run(layers, 0, x, context, inverse=False)
+        return units, after, len(layers)
+
+    # the headline flow: all 32 [permutation, coupling] pairs are one run, nothing to pad, the f16 engine
+    flow = configs.rq_nsf_flow(num_layers=32, features=64, num_bins=8, hidden_features=128, seed=0).eval()
+    units, after, n = plan(flow, torch.randn(8, 64))
+    assert len(units) == 32 and after == n == 64
+    first = units[0][0]
+    assert first._fused_geometry(tuple(c for c, _ in units[1:])) == (64, 32, 32, 2.0 * first.tail_bound + 1.0)
+    assert first._use_f16() == (RQ.conditioner_engine == "f16x2")
+    # ... not with gradients, not in float64, and the inverse direction pairs the other way round
+    units_grad, _ = flow._transform._collect_run(list(flow._transform._transforms), 0, torch.randn(8, 64), None, False)
+    assert units_grad == []
+    assert plan(flow, torch.randn(8, 64, dtype=torch.float64))[0] == []
+    with torch.no_grad():
+        rev = list(reversed(list(flow._transform._transforms)))
+        units_inv, after_inv = flow._transform._collect_run(rev, 0, torch.randn(8, 64), None, inverse=True)
+    assert len(units_inv) == 32 and after_inv == 64 and all(p is not None for _, p in units_inv)
+    # odd feature count under alternating masks: two splits, one padded geometry; 10 bins; a narrow conditioner
+    flow = configs.rq_nsf_flow(num_layers=4, features=21, num_bins=10, hidden_features=50, seed=1).eval()
+    units, after, n = plan(flow, torch.randn(300, 21))
+    assert len(units) == 4 and after == n
+    assert units[0][0]._fused_geometry(tuple(c for c, _ in units[1:]))[:3] == (24, 12, 11)
+    # outside the family: hidden width 256, other tails, more than 128 features
+    assert plan(configs.rq_nsf_flow(num_layers=3, features=16, num_bins=8, hidden_features=256, seed=2).eval(),
+                torch.randn(8, 16))[0] == []
+    assert plan(configs.rq_nsf_flow(num_layers=3, features=132, num_bins=8, hidden_features=128, seed=2).eval(),
+                torch.randn(8, 132))[0] == []
+    # the engine of conditional layers: K8h up to 32 context features beside up to 32 identity features
+    c16 = configs.conditional_rq_nsf_flow(num_layers=2, features=16, num_bins=10, hidden_features=50,
+                                          raw_context=5, context_features=12, seed=3)
+    c80 = configs.conditional_rq_nsf_flow(num_layers=2, features=80, num_bins=8, hidden_features=128,
+                                          raw_context=5, context_features=12, seed=3)
+    c40 = configs.conditional_rq_nsf_flow(num_layers=2, features=16, num_bins=8, hidden_features=128,
+                                          raw_context=5, context_features=40, seed=3)
+    engine = RQ.conditioner_engine == "f16x2"
+    assert c16._transform._transforms[1]._use_f16() == engine
+    assert not c80._transform._transforms[1]._use_f16() and not c40._transform._transforms[1]._use_f16()
+    # affine layers with MLP conditioners: runs need one split (even feature counts under alternating masks)
+    def affine(features):
+        torch.manual_seed(features)
+        layers = []
+        for i in range(3):
+            layers.append(RandomPermutation(features))
+            layers.append(AffineCouplingTransform(create_alternating_binary_mask(features, even=(i % 2 == 0)),
+                                                  lambda a, b: MLP([a], [b], [64, 64])))
+        return Flow(CompositeTransform(layers), StandardNormal([features])).eval()
+    assert len(plan(affine(6), torch.randn(8, 6))[0]) == 3
+    assert plan(affine(7), torch.randn(8, 7))[0] == []
+
+
 def test_masked_weights_are_kept_between_no_grad_passes():
     """MaskedLinear (made.py:71-72: `F.linear(x, weight * mask, bias)`): on no-grad passes the product is formed
     once and kept until the weight changes (same rules as the packed-weight caches); with grad enabled every call
