@@ -52,6 +52,39 @@ def _accepts_fused_permutation(t, inputs):
             and inputs.dtype == torch.float32)   # (float64 flows take the generic device path)
 
 
+def _switch_state():
+    """The class-level A/B switches a run plan depends on."""
+    from .coupling import (AdditiveCouplingTransform, AffineCouplingTransform,
+                           PiecewiseRationalQuadraticCouplingTransform as RQ)
+    return (RQ.fuse_conditioner, RQ.fuse_final_linear, RQ.conditioner_engine, RQ.conditioner_act_scale,
+            RQ.resnet_log2e, AffineCouplingTransform.fuse_conditioner, AdditiveCouplingTransform.fuse_conditioner)
+
+
+def _layer_state(units):
+    """Per-layer attributes a run plan depends on, re-read on every call: the layers' signatures (bins, tails,
+    box, minimum sizes, engine ...), whether their conditioners are in training mode (active dropout), and
+    their unconditional transforms."""
+    # (`_modules[...]`: the plain dict behind `c.transform_net`, without nn.Module's attribute fallback)
+    return [(c._run_signature(), c._modules["transform_net"].training, c._modules.get("unconditional_transform") is None)
+            for c, _ in units]
+
+
+class _Run(list):
+    """The units [(coupling, permutation or None)] of a run, with what is the same on every call kept beside
+    them: the run's padded geometry (ops.fused_geometry over its layers)."""
+
+    def geometry(self):
+        held = self.__dict__.get("_geometry")
+        if held is None:
+            held = self[0][0]._fused_geometry(tuple(c for c, _ in self[1:]))
+            self.__dict__["_geometry"] = held
+        return held
+
+
+def _run_geometry(units):
+    return units.geometry() if isinstance(units, _Run) else units[0][0]._fused_geometry(tuple(c for c, _ in units[1:]))
+
+
 class CompositeTransform(Transform):
     """Applies transforms in the given order; log-determinants add up (base.py:45-52).
 
@@ -74,6 +107,46 @@ class CompositeTransform(Transform):
         return coupling._run_signature()
 
     def _collect_run(self, layers, start, inputs, context, inverse):
+        """`_plan_run` behind a cache: which layers form a run depends on the call's shape (feature count, dtype,
+        context, direction, grad mode), on the A/B switches and on per-layer attributes (`_run_signature`,
+        training mode); the first two make the key, the last are re-read on every call (cheap attribute reads)
+        and compared with what the cached plan saw.  Planning itself costs ~3 us per layer -- a 64-layer
+        composite would spend more host time on it than the kernel takes on a small batch."""
+        if not (self.fuse_layer_runs and inputs.dim() == 2 and inputs.shape[0] >= 1
+                and inputs.dtype == torch.float32):
+            return [], start
+        ctx_key = None if context is None else (context.dim(), tuple(context.shape[1:]), context.dtype, context.is_cuda)
+        key = (start, len(layers), inverse, inputs.shape[1], ctx_key, torch.is_grad_enabled(), _switch_state(),
+               _cache.epoch())
+        cache = self.__dict__.setdefault("_run_cache", {})
+        hit = cache.get(key)
+        if hit is not None:
+            units, after, watched, seen = hit
+            if len(layers) == len(watched) and all(a is b for a, b in zip(layers, watched)) \
+                    and seen == self._watched_state(units, layers, after, inputs.shape[1], context):
+                return units, after
+        units, after = self._plan_run(layers, start, inputs, context, inverse)
+        if units:   # (only runs are kept: "no run here" is decided afresh on every call)
+            units = _Run(units)
+            if len(cache) > 16:
+                cache.clear()
+            cache[key] = (units, after, list(layers), self._watched_state(units, layers, after, inputs.shape[1], context))
+        return units, after
+
+    @staticmethod
+    def _joinable(t, features, context):
+        kind = getattr(t, "_run_kind", None)   # whole-layer kernel this layer can join a run of
+        return (kind is not None and t.unconditional_transform is None and t.features == features
+                and kind(context) is not None)
+
+    def _watched_state(self, units, layers, after, features, context):
+        """What a cached plan is compared with on every call: the state of its layers and of the (up to two)
+        layers behind it -- the run may have ended at one of them for a reason that no longer holds."""
+        behind = [(t._run_signature(), self._joinable(t, features, context)) if hasattr(t, "_run_kind") else None
+                  for t in layers[after:after + 2]]
+        return _layer_state(units), behind
+
+    def _plan_run(self, layers, start, inputs, context, inverse):
         """Longest run of units starting at `start`: forward a unit is [column Permutation]? +
         eligible coupling, inverse (layers already reversed) eligible coupling + [Permutation]?.
         Returns (units, next_index) with units = [(coupling, permutation or None)]."""
@@ -83,9 +156,7 @@ class CompositeTransform(Transform):
             return units, start
 
         def eligible(t):
-            kind = getattr(t, "_run_kind", None)   # whole-layer kernel this layer can join a run of
-            return (kind is not None and t.unconditional_transform is None and t.features == inputs.shape[1]
-                    and kind(context) is not None)
+            return self._joinable(t, inputs.shape[1], context)
         i, signature = start, None
         while i < len(layers):
             perm = None
@@ -110,7 +181,7 @@ class CompositeTransform(Transform):
             i += step
         if len(units) < 2:
             return [], start
-        geometry = units[0][0]._fused_geometry(tuple(c for c, _ in units[1:]))
+        geometry = _run_geometry(units)
         ce = getattr(getattr(units[0][0], "transform_net", None), "context_features", None) or 0
         if geometry[0] > 128 or geometry[1] > 64 or geometry[2] + ce > 64:   # the run's padded geometry (ops.fused_geometry)
             return [], start
@@ -120,21 +191,23 @@ class CompositeTransform(Transform):
         """Concatenated weight / bias blobs and the composed tables of a run, cached until a weight or a
         permutation changes.  (weights, biases, tables, f16 stream or None)."""
         from .. import ops
+        from .coupling import _weights_key
         first = units[0][0]
         mlp = type(first).__name__ in ("AffineCouplingTransform", "AdditiveCouplingTransform")
-        geometry = first._fused_geometry(tuple(c for c, _ in units[1:]))   # one padded geometry for the run
-        packed = [c._packed_mlp() if mlp else c._packed_resnet(geometry) for c, _ in units]
+        geometry = _run_geometry(units)   # one padded geometry for the run
         f16 = (not mlp) and first._use_f16(geometry)
-        packed_f16 = [c._packed_resnet_f16(geometry) for c, _ in units] if f16 else None
-        key = (_cache.epoch(), inverse, f16, tuple(id(c) for c, _ in units),
-               tuple((c._packed_mlp_cache if mlp else c._packed_resnet_cache)[0] for c, _ in units),
-               tuple(c._packed_resnet_f16_cache[0] for c, _ in units) if f16 else None,
-               tuple(None if p is None else (p._permutation.data_ptr(), p._permutation._version) for _, p in units))
+        # (the key reads version counters only; the layers' packed blobs are looked at on a miss)
+        key = (inverse, f16, geometry, first._log2e() if not mlp else None, first.conditioner_act_scale if f16 else None,
+               tuple([id(c) for c, _ in units]),
+               tuple([_weights_key(c, c.transform_net) for c, _ in units]),
+               tuple([None if p is None else (id(p._permutation), p._permutation._version) for _, p in units]))
         cache = self.__dict__.setdefault("_run_plans", {})
         plan = cache.get(key)
         if plan is None:
             if len(cache) > 4:
                 cache.clear()
+            packed = [c._packed_mlp() if mlp else c._packed_resnet(geometry) for c, _ in units]
+            packed_f16 = [c._packed_resnet_f16(geometry) for c, _ in units] if f16 else None
             weights = torch.cat([w for w, _ in packed], dim=0).contiguous()
             biases = torch.cat([b for _, b in packed]).contiguous()
             spec_layers = []
@@ -160,7 +233,7 @@ class CompositeTransform(Transform):
             if p is not None:
                 p._check(inputs)
         weights, biases, tables, plan_f16 = self._run_plan(units, inverse)
-        Dp, dt4, di_u, pad_value = first._fused_geometry(tuple(c for c, _ in units[1:]))
+        Dp, dt4, di_u, pad_value = _run_geometry(units)
         pad = (Dp, pad_value)
         if type(first).__name__ in ("AffineCouplingTransform", "AdditiveCouplingTransform"):
             head = ops.affine_flow_mlp(

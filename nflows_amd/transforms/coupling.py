@@ -31,6 +31,19 @@ from . import splines
 from .splines import rational_quadratic
 
 
+def _weights_key(owner, net):
+    """Cheap fingerprint of a conditioner's weights for the packed-weight caches: the version counters of its
+    parameters, read from a list made once per cache epoch (walking `net.parameters()` costs ~10 us per call and
+    layer: a millisecond per `log_prob` of a 32-layer flow).  In-place updates advance the counters; moves,
+    `load_state_dict` and (re)registered Parameter objects advance the epoch (_cache.py)."""
+    epoch = _cache.epoch()
+    held = owner.__dict__.get("_weights_list")
+    if held is None or held[0] != epoch or held[1] is not net or not _cache.HOOKED:
+        held = (epoch, net, list(net.parameters()))
+        owner.__dict__["_weights_list"] = held
+    return (epoch,) + tuple([p._version for p in held[2]])
+
+
 class CouplingTransform(Transform):
     """Base class: mask bookkeeping, conditioner call and the fused-kernel hand-off.
 
@@ -273,7 +286,7 @@ class AffineCouplingTransform(CouplingTransform):
 
     def _packed_mlp(self):
         net = self.transform_net
-        key = (_cache.epoch(),) + tuple((p.data_ptr(), p._version) for p in net.parameters())
+        key = _weights_key(self, net)
         cached = getattr(self, "_packed_mlp_cache", None)
         if cached is None or cached[0] != key:
             cached = (key, ops.pack_mlp_conditioner(net, self.num_transform_features,
@@ -420,6 +433,13 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
     def _fused_geometry(self, others=()):
         """(padded features, transformed features, identity features, pad value) the whole-layer kernels are
         given for this layer -- or for the run of this layer and `others` (ops.fused_geometry)."""
+        if not others:   # (asked several times per call and layer: kept per tail bound)
+            held = self.__dict__.get("_own_geometry")
+            if held is None or held[0] != self.tail_bound:
+                held = (self.tail_bound, ops.fused_geometry(
+                    self.features, [(self.num_transform_features, self.num_identity_features)], self.tail_bound))
+                self.__dict__["_own_geometry"] = held
+            return held[1]
         layers = [(c.num_transform_features, c.num_identity_features) for c in (self,) + tuple(others)]
         return ops.fused_geometry(self.features, layers, self.tail_bound)
 
@@ -429,11 +449,20 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
     def _run_signature(self):
         # (layers of one run may differ in their feature split -- odd feature counts under alternating masks --:
         # the run is given one padded geometry)
-        return ("k8", self.features,
-                len(self.transform_net.blocks), self.num_bins, self.tail_bound,
+        features, num_blocks, ce = self._static_signature()
+        return ("k8", features, num_blocks, self.num_bins, self.tail_bound,
                 self.min_bin_width, self.min_bin_height, self.min_derivative,
-                self._log2e(), self._use_f16(), self.conditioner_act_scale,
-                getattr(self.transform_net, "context_features", None))
+                self._log2e(), self._use_f16(), self.conditioner_act_scale, ce)
+
+    def _static_signature(self):
+        """(features, residual blocks, context features) of the layer's conditioner: read once per cache epoch
+        (a conditioner swapped for another one registers its Parameters, which advances the epoch)."""
+        held = self.__dict__.get("_static_sig")
+        if held is None or held[0] != _cache.epoch():
+            net = self.transform_net
+            held = (_cache.epoch(), (self.features, len(getattr(net, "blocks", ())), getattr(net, "context_features", None)))
+            self.__dict__["_static_sig"] = held
+        return held[1]
 
     def _resnet_eligible(self, context):
         net = self.transform_net
@@ -471,14 +500,14 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
     def _use_f16(self, geometry=None):
         """K8h serves 8 and 10 bins; with a context up to 32 context features beside up to 32 identity features
         (of the run's geometry) -- otherwise the bf16x3 kernel (K8) runs."""
-        ce = getattr(self.transform_net, "context_features", None)
+        ce = self._static_signature()[2]
         return (self.conditioner_engine == "f16x2" and self.num_bins in (8, 10) and not self._log2e()
                 and (ce is None or (ce <= 32 and (geometry or self._fused_geometry())[2] <= 32)))
 
     def _packed_resnet_f16(self, geometry=None):
         net = self.transform_net
         _, dt4, di_u, _ = geometry or self._fused_geometry()
-        key = (_cache.epoch(), self.conditioner_act_scale, dt4, di_u) + tuple((p.data_ptr(), p._version) for p in net.parameters())
+        key = (self.conditioner_act_scale, dt4, di_u) + _weights_key(self, net)
         cached = getattr(self, "_packed_resnet_f16_cache", None)
         if cached is None or cached[0] != key:
             cached = (key, ops.pack_resnet_conditioner_f16(net, self.num_transform_features,
@@ -504,7 +533,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
     def _packed_resnet(self, geometry=None):
         net = self.transform_net
         _, dt4, di_u, _ = geometry or self._fused_geometry()
-        key = (_cache.epoch(), dt4, di_u) + tuple((p.data_ptr(), p._version) for p in net.parameters()) + (self._log2e(),)
+        key = (dt4, di_u, self._log2e()) + _weights_key(self, net)
         cached = getattr(self, "_packed_resnet_cache", None)
         if cached is None or cached[0] != key:
             cached = (key, ops.pack_resnet_conditioner(net, self.num_transform_features,

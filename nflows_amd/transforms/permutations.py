@@ -41,7 +41,7 @@ class Permutation(Transform):
         return self._argsort_cache[1]
 
     def _check(self, inputs):
-        dim, size = self._dim, len(self._permutation)
+        dim, size = self._dim, self._buffers["_permutation"].shape[0]
         if inputs.ndimension() <= dim:
             raise ValueError("No dimension {} in inputs.".format(dim))
         if inputs.shape[dim] != size:

@@ -707,6 +707,63 @@ def test_fusion_planning_of_composite_transforms():
     assert plan(affine(7), torch.randn(8, 7))[0] == []
 
 
+def test_run_plans_are_cached_and_follow_changes(monkeypatch):
+    """The plan of a run (which layers, their packed weights) is kept between calls -- planning and walking the
+    conditioners' parameters cost more host time than a small batch takes on the GPU -- and is re-made when
+    something it depends on changes: a layer attribute, a conditioner's mode, an A/B switch, a weight (in place),
+    a Parameter object replaced."""
+    from nflows_amd import _cache, configs
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    from nflows_amd.transforms.coupling import _weights_key
+    flow = configs.rq_nsf_flow(num_layers=4, features=16, num_bins=8, hidden_features=64, seed=0).eval()
+    comp = flow._transform
+    x = torch.randn(8, 16)
+
+    def plan():
+        with torch.no_grad():
+            return comp._collect_run(list(comp._transforms), 0, x, None, inverse=False)
+    units, after = plan()
+    assert len(units) == 4 and after == 8
+    assert plan()[0] is units                                   # served from the cache
+    assert units.geometry() == (16, 8, 8, 7.0) and units.geometry() is units.geometry()
+    # a layer attribute the signature holds: the run now ends in front of that layer
+    third = units[2][0]
+    third.tail_bound = 5.0
+    assert len(plan()[0]) == 2
+    third.tail_bound = 3.0
+    assert len(plan()[0]) == 4
+    # a conditioner with active dropout leaves the family
+    third.transform_net.blocks[0].dropout.p = 0.1
+    third.transform_net.train()
+    assert len(plan()[0]) == 2
+    third.transform_net.eval()
+    assert len(plan()[0]) == 4
+    third.transform_net.blocks[0].dropout.p = 0.0
+    # the A/B switches are part of the key
+    monkeypatch.setattr(RQ, "fuse_conditioner", False)
+    assert plan()[0] == []
+    monkeypatch.setattr(RQ, "fuse_conditioner", True)
+    assert len(plan()[0]) == 4
+    # weights: version counters of a list made once per epoch; a replaced Parameter advances the epoch
+    first = units[0][0]
+    k0 = _weights_key(first, first.transform_net)
+    assert _weights_key(first, first.transform_net) == k0
+    with torch.no_grad():
+        first.transform_net.final_layer.bias.add_(1.0)
+    k1 = _weights_key(first, first.transform_net)
+    assert k1 != k0
+    epoch = _cache.epoch()
+    first.transform_net.final_layer.bias = torch.nn.Parameter(torch.zeros_like(first.transform_net.final_layer.bias))
+    assert _cache.epoch() > epoch
+    k2 = _weights_key(first, first.transform_net)
+    assert k2 != k1 and first.__dict__["_weights_list"][2][-1] is first.transform_net.final_layer.bias
+    w_before = first._packed_resnet()[1].clone()
+    with torch.no_grad():
+        first.transform_net.final_layer.bias.add_(2.0)
+    assert not torch.equal(first._packed_resnet()[1], w_before)
+    assert len(plan()[0]) == 4
+
+
 def test_masked_weights_are_kept_between_no_grad_passes():
     """MaskedLinear (made.py:71-72: `F.linear(x, weight * mask, bias)`): on no-grad passes the product is formed
     once and kept until the weight changes (same rules as the packed-weight caches); with grad enabled every call
