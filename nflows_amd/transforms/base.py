@@ -62,11 +62,11 @@ def _switch_state():
 
 def _layer_state(units):
     """Per-layer attributes a run plan depends on, re-read on every call: the layers' signatures (bins, tails,
-    box, minimum sizes, engine ...), whether their conditioners are in training mode (active dropout), and
-    their unconditional transforms."""
+    box, minimum sizes, engine ...), whether their conditioners are in training mode (active dropout), their
+    unconditional transforms, and the A/B switches once more (they may be set on an instance)."""
     # (`_modules[...]`: the plain dict behind `c.transform_net`, without nn.Module's attribute fallback)
-    return [(c._run_signature(), c._modules["transform_net"].training, c._modules.get("unconditional_transform") is None)
-            for c, _ in units]
+    return [(c._run_signature(), c._modules["transform_net"].training, c._modules.get("unconditional_transform") is None,
+             c.fuse_conditioner, getattr(c, "fuse_final_linear", None)) for c, _ in units]
 
 
 class _Run(list):

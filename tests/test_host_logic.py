@@ -744,6 +744,12 @@ def test_run_plans_are_cached_and_follow_changes(monkeypatch):
     assert plan()[0] == []
     monkeypatch.setattr(RQ, "fuse_conditioner", True)
     assert len(plan()[0]) == 4
+    for c, _ in units:                                          # ... and are honoured when set on the instances
+        monkeypatch.setattr(c, "fuse_conditioner", False, raising=False)
+    assert plan()[0] == []
+    for c, _ in units:
+        monkeypatch.delattr(c, "fuse_conditioner")
+    assert len(plan()[0]) == 4
     # weights: version counters of a list made once per epoch; a replaced Parameter advances the epoch
     first = units[0][0]
     k0 = _weights_key(first, first.transform_net)
