@@ -32,8 +32,8 @@ from .splines import rational_quadratic
 
 
 def _weights_key(owner, net):
-    """Cheap fingerprint of a conditioner's weights for the packed-weight caches: the version counters of its
-    parameters, read from a list made once per cache epoch (walking `net.parameters()` costs ~10 us per call and
+    """Cheap fingerprint of a conditioner's weights for the packed-weight caches: storage pointers and version
+    counters of its parameters, read from a list made once per cache epoch (walking `net.parameters()` costs ~10 us per call and
     layer: a millisecond per `log_prob` of a 32-layer flow).  In-place updates advance the counters; moves,
     `load_state_dict` and (re)registered Parameter objects advance the epoch (_cache.py)."""
     epoch = _cache.epoch()
@@ -41,7 +41,8 @@ def _weights_key(owner, net):
     if held is None or held[0] != epoch or held[1] is not net or not _cache.HOOKED:
         held = (epoch, net, list(net.parameters()))
         owner.__dict__["_weights_list"] = held
-    return (epoch,) + tuple([p._version for p in held[2]])
+    # (data_ptr as well: `p.data = other` rebinds the storage without touching the counter)
+    return (epoch,) + tuple([(p.data_ptr(), p._version) for p in held[2]])
 
 
 class CouplingTransform(Transform):

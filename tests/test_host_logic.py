@@ -758,6 +758,10 @@ def test_run_plans_are_cached_and_follow_changes(monkeypatch):
         first.transform_net.final_layer.bias.add_(1.0)
     k1 = _weights_key(first, first.transform_net)
     assert k1 != k0
+    bias = first.transform_net.final_layer.bias
+    bias.data = bias.data.clone()                  # storage rebound, counter untouched: the pointer is in the key
+    assert _weights_key(first, first.transform_net) != k1
+    k1 = _weights_key(first, first.transform_net)
     epoch = _cache.epoch()
     first.transform_net.final_layer.bias = torch.nn.Parameter(torch.zeros_like(first.transform_net.final_layer.bias))
     assert _cache.epoch() > epoch
