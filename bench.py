@@ -295,6 +295,9 @@ def main():
     _native.check(_native.load().nfa_profile_enable(0))
     log("timed region done: %.1f ms/step" % (elapsed / args.steps * 1e3))
     nflows_amd.check_status()
+    # 128-row blocks of the last timed step that left the f16 range and were redone by the exact kernel
+    # (K8h only; 0 = the whole batch ran on the measured kernel)
+    redo_blocks = ops.last_redo_blocks() if args.path == "k8" else None
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -518,6 +521,7 @@ def main():
             "fwd_inv_max_err": {"composite_%d_layers" % args.layers: err_composite, "single_layer": err_layer,
                                 "rows": 8192, "composite_stats": err_stats},
             "mean_log_likelihood": mean_ll,
+            "redo_blocks": redo_blocks,
             "roofline": roofline,
             "roofline_k1_unfused": roofline_k1,
         }

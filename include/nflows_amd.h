@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NFA_ABI_VERSION 1
+#define NFA_ABI_VERSION 3  /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3) */
 
 /* return codes */
 #define NFA_OK 0

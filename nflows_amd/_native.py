@@ -31,7 +31,7 @@ FLAG_PAD_COLUMNS_SHIFT = 8   # bits 8-10: trailing pad columns the density epilo
 TAILS_NONE, TAILS_LINEAR = 0, 1
 SCALE_DEFAULT, SCALE_GENERAL, SCALE_ADDITIVE, SCALE_GIVEN, SCALE_SOFTPLUS = 0, 1, 2, 3, 4
 
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 EXPORTS = (
     "nfa_abi_version",

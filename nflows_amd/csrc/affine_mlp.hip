@@ -310,10 +310,10 @@ extern "C" int nfa_affine_flow_mlp_f32(const float* inputs, const void* weights_
         default: kern = affine_mlp_kernel<true, 4, true>; break;
     }
     if (lds > 64 * 1024) {
-        static bool raised[8] = {false, false, false, false, false, false, false, false};
-        if (!raised[which]) {
-            NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-            raised[which] = true;
+        static unsigned long long raised[8] = {};   // device masks (raise_dynamic_lds)
+        {
+            const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], 160 * 1024 - 2048);
+            if (rc_lds != NFA_OK) return rc_lds;
         }
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -22,6 +22,18 @@ void profile_next_launch(hipEvent_t* start, hipEvent_t* stop);
         if (nfa_e_ != hipSuccess) return nfa::set_hip_error(nfa_e_); \
     } while (0)
 
+// hipFuncSetAttribute applies to the CURRENT device only: the opt-in to more than 64 KB of dynamic LDS is
+// remembered per (kernel, device) -- `seen` is one device bit mask per kernel instance.
+inline int raise_dynamic_lds(const void* kern, unsigned long long* seen, int bytes) {
+    int dev = 0;
+    NFA_HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (dev < 64 && (*seen & bit)) return 0;
+    NFA_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (dev < 64) *seen |= bit;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // Exact division of a small unsigned number by a runtime constant: q = n / d for n < 2^16,
 // 1 <= d < 2^16, with magic = ceil(2^32 / d) computed on the host.

@@ -329,11 +329,11 @@ extern "C" int nfa_made_rqs_inverse_f32(const float* inputs, const float* step_b
     a.trace = g_k7_trace;
     void (*kern)(const MadeInvArgs) = a.sp.K == 8 ? made_rqs_inverse_kernel<8> : made_rqs_inverse_kernel<10>;
     if (lds > 64 * 1024) {
-        static bool raised[2] = {false, false};
+        static unsigned long long raised[2] = {};   // device masks (raise_dynamic_lds)
         const int which = a.sp.K == 8 ? 0 : 1;
-        if (!raised[which]) {
-            NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
-            raised[which] = true;
+        {
+            const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], 160 * 1024 - 4096);
+            if (rc_lds != NFA_OK) return rc_lds;
         }
     }
     const int64_t blocks = (batch + kMadeSamples - 1) / kMadeSamples;

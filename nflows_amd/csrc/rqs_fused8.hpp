@@ -3,9 +3,9 @@
 //
 // Same function as rational_quadratic.py:66-181 (+ :13-63 for the tails), arranged for the lowest
 // VALU instruction count -- the layer kernel is bound by VALU issue, not by the matrix pipe:
-//   * softmax numerators as 2^(fma(e, log2e*kappa, -max*log2e*kappa)): two instructions per logit;
-//     the rounding of the shared term is common to all eight numerators and cancels in the
-//     normalisation;
+//   * softmax numerators as 2^(e * log2e*kappa): two instructions per logit, no maximum subtracted
+//     (round 3; logits beyond the range of 2^t end in a non-finite result, which sends the row block
+//     to the exact kernel);
 //   * ONE walk over the bins instead of two: knot_{i+1} = knot_i + fma(numerator_i, 2B(1-K min)/den,
 //     2B min) for widths and heights side by side (fp32 running sums; the reference rounds each
 //     normalised bin to fp32, sums in double and rounds every knot -- the same error class), and on
@@ -27,8 +27,8 @@ namespace nfa {
 template <bool INVERSE, int KT = 8>
 struct FusedSteps {
     static_assert(KT == 8 || KT == 10, "8 or 10 bins");
-    static constexpr int kNumSlices = KT + 4;                   // max x 2, one exponential per logit, sum x 2
-    static constexpr int kWalkSlices = 3 + 2 * (KT - 1);        // setup x 2, bin 0, bins 1..KT-1 x (knots | select)
+    static constexpr int kNumSlices = KT + 2;                   // one exponential per logit, sum x 2
+    static constexpr int kWalkSlices = 3 + (KT - 1);            // setup x 2, bin 0, bins 1..KT-1
     static constexpr int kBinSlices = INVERSE ? 9 : 7;
     static constexpr int kFinishSlices = kWalkSlices + 6 + kBinSlices + 1;
     static constexpr int kFirstWalkSlices = 0;                  // (no part of finish runs on one numerator set alone)
@@ -38,26 +38,23 @@ struct FusedSteps {
     float sd[KT - 1];       // derivative logits (scaled)
     float x;
     float kl2e, kappa, tail_s;   // log2(e) * kappa, kappa, tail_logit / kappa (uniform)
-    float m_w, m_h, den_w, den_h, tw_, th_;
+    float den_w, den_h, tw_, th_;
     float aw, ah, kw, kh, kwn, khn;
+    unsigned long long take;     // lanes whose x is at or above the lower knot of the bin the next walk slice visits
     float cw0, cw1, ch0, ch1, u0, u1, d0, d1;
     float y, lad;
     int status;
-    float t3, t4;
-    float in_w, in_h, r_w, delta, s_, th, t1mt, den, t0, t1, t2, t5;
+    float t4;
+    float in_w, in_h, r_w, r_den, delta, s_, th, t1mt, den, t0, t1, t2, t5;
 
+    // Softmax numerators 2^(logit x log2(e) x kappa), no maximum subtracted: a set whose exponentials
+    // overflow (a logit beyond +88) or all vanish (all below -87) ends in a non-finite log-derivative, and
+    // the kernel hands such a row block to the exact kernel like every other non-finite result.
     template <int S>
-    __device__ __forceinline__ void numerators(float (&e)[KT], float& den_, float& m, float& t) {
-        if constexpr (S == 0) {
-            m = __builtin_fmaxf(__builtin_fmaxf(e[0], e[1]), e[2]);      // (v_max3_f32)
-            m = __builtin_fmaxf(__builtin_fmaxf(m, e[3]), e[4]);
-        } else if constexpr (S == 1) {
-            m = __builtin_fmaxf(__builtin_fmaxf(m, e[5]), e[6]);
-            if constexpr (KT == 10) m = __builtin_fmaxf(__builtin_fmaxf(m, e[7]), e[8]);
-            m = __builtin_fmaxf(m, e[KT - 1]) * kl2e;                     // max * log2e * kappa
-        } else if constexpr (S < 2 + KT) {
-            e[S - 2] = __builtin_amdgcn_exp2f(__builtin_fmaf(e[S - 2], kl2e, -m));
-        } else if constexpr (S == 2 + KT) {
+    __device__ __forceinline__ void numerators(float (&e)[KT], float& den_, float& t) {
+        if constexpr (S < KT) {
+            e[S] = __builtin_amdgcn_exp2f(e[S] * kl2e);
+        } else if constexpr (S == KT) {
             t = (e[0] + e[1]) + (e[2] + e[3]);
         } else {
             den_ = t + ((e[4] + e[5]) + (e[6] + e[7]));
@@ -65,24 +62,41 @@ struct FusedSteps {
         }
     }
     template <int S>
-    __device__ __forceinline__ void num_w() { numerators<S>(ew, den_w, m_w, tw_); }
+    __device__ __forceinline__ void num_w() { numerators<S>(ew, den_w, tw_); }
     template <int S>
-    __device__ __forceinline__ void num_h() { numerators<S>(eh, den_h, m_h, th_); }
+    __device__ __forceinline__ void num_h() { numerators<S>(eh, den_h, th_); }
 
-    // min_d + softplus(u * kappa) in three slices (exp | log1p | select)
+    // min_d + softplus(u * kappa) in three slices (exp | log1p | add).  No branch for large arguments
+    // (torch's softplus returns the argument beyond 20: the two differ by e^-20 relative 1e-10 there).
     template <int PART>
     __device__ __forceinline__ void derivative(float u, float& d, const RqsDev& sp) {
         if constexpr (PART == 0) {
-            t3 = u * kappa;
-            t4 = __builtin_amdgcn_exp2f(t3 * 1.44269502162933349609375f);
+            t4 = __builtin_amdgcn_exp2f(u * kl2e);
         } else if constexpr (PART == 1) {
             const float u1p = 1.0f + t4;
             const float c = t4 - (u1p - 1.0f);   // what the addition dropped
             const float lg = __builtin_amdgcn_logf(u1p) * 0.693147182464599609375f;
             t4 = __builtin_fmaf(c, __builtin_amdgcn_rcpf(u1p), lg);
         } else {
-            d = sp.min_d + (t3 > 20.0f ? t3 : t4);
+            d = sp.min_d + t4;
         }
+    }
+
+    // One bin of the walk.  The compare for the NEXT bin and the six selects of THIS bin are one asm block
+    // with the compare in front: a v_cndmask needs two wait states behind the VALU instruction that wrote
+    // its mask (hipcc pads compare + select with s_nop 1), here the mask was written a whole slice earlier.
+    __device__ __forceinline__ void walk_select(float next_lower, float cand_u0, float cand_u1) {
+        unsigned long long next;
+        asm("v_cmp_ge_f32 %6, %7, %8\n\t"
+            "v_cndmask_b32 %0, %0, %9, %15\n\t"
+            "v_cndmask_b32 %1, %1, %10, %15\n\t"
+            "v_cndmask_b32 %2, %2, %11, %15\n\t"
+            "v_cndmask_b32 %3, %3, %12, %15\n\t"
+            "v_cndmask_b32 %4, %4, %13, %15\n\t"
+            "v_cndmask_b32 %5, %5, %14, %15"
+            : "+v"(cw0), "+v"(cw1), "+v"(ch0), "+v"(ch1), "+v"(u0), "+v"(u1), "=&s"(next)
+            : "v"(x), "v"(next_lower), "v"(kw), "v"(kwn), "v"(kh), "v"(khn), "v"(cand_u0), "v"(cand_u1), "s"(take));
+        take = next;
     }
 
     template <int S>
@@ -98,36 +112,32 @@ struct FusedSteps {
             const float r0 = __builtin_amdgcn_rcpf(den_h);
             const float r = __builtin_fmaf(__builtin_fmaf(-den_h, r0, 1.0f), r0, r0);
             ah = r * (sp.span_w * sp.om_h);
-        } else if constexpr (S == 2) {   // bin 0: always a candidate
-            kw = -B + __builtin_fmaf(ew[0], aw, sp.span_w * sp.min_w);
-            kh = -B + __builtin_fmaf(eh[0], ah, sp.span_w * sp.min_h);
+        } else if constexpr (S == 2) {   // bin 0: always a candidate; knots of bin 1 and its compare
+            const float k1w = -B + __builtin_fmaf(ew[0], aw, sp.span_w * sp.min_w);
+            const float k1h = -B + __builtin_fmaf(eh[0], ah, sp.span_w * sp.min_h);
             cw0 = -B;
             ch0 = -B;
-            cw1 = kw;
-            ch1 = kh;
+            cw1 = k1w;
+            ch1 = k1h;
             u0 = tail_s;
             u1 = sd[0];
+            kw = k1w;
+            kh = k1h;
+            kwn = k1w + __builtin_fmaf(ew[1], aw, sp.span_w * sp.min_w);
+            khn = k1h + __builtin_fmaf(eh[1], ah, sp.span_w * sp.min_h);
+            asm("v_cmp_ge_f32 %0, %1, %2" : "=s"(take) : "v"(x), "v"(INVERSE ? k1h : k1w));
         } else if constexpr (S < W) {
-            constexpr int I = (S - 3) / 2 + 1, PART = (S - 3) % 2;   // bins 1..KT-1
-            if constexpr (PART == 0) {        // the bin's upper knots (kw / kh hold its lower ones)
-                if constexpr (I < KT - 1) {
-                    kwn = kw + __builtin_fmaf(ew[I], aw, sp.span_w * sp.min_w);
-                    khn = kh + __builtin_fmaf(eh[I], ah, sp.span_w * sp.min_h);
-                } else {
-                    kwn = B;
-                    khn = B;
-                }
-            } else {
-                const bool take = x >= (INVERSE ? kh : kw);
-                cw0 = take ? kw : cw0;
-                cw1 = take ? kwn : cw1;
-                ch0 = take ? kh : ch0;
-                ch1 = take ? khn : ch1;
-                u0 = take ? sd[I - 1] : u0;
-                u1 = take ? (I < KT - 1 ? sd[I < KT - 1 ? I : 0] : tail_s) : u1;
-                kw = kwn;
-                kh = khn;
+            constexpr int I = S - 2;   // bins 1..KT-1: (kw, kh) lower, (kwn, khn) upper knots, `take` = x >= lower
+            float kw2 = B, kh2 = B;    // upper knots of bin I + 1
+            if constexpr (I + 1 < KT - 1) {
+                kw2 = kwn + __builtin_fmaf(ew[I + 1], aw, sp.span_w * sp.min_w);
+                kh2 = khn + __builtin_fmaf(eh[I + 1], ah, sp.span_w * sp.min_h);
             }
+            walk_select(INVERSE ? khn : kwn, sd[I - 1], I < KT - 1 ? sd[I < KT - 1 ? I : 0] : tail_s);
+            kw = kwn;
+            kh = khn;
+            kwn = kw2;
+            khn = kh2;
         } else if constexpr (S < D0 + 3) {
             derivative<S - D0>(u0, d0, sp);
         } else if constexpr (S < BE) {
@@ -230,14 +240,15 @@ struct FusedSteps {
                 const float r = __builtin_fmaf(__builtin_fmaf(-den, r0, 1.0f), r0, r0);
                 const float q = t0 * r;
                 y = ch0 + __builtin_fmaf(__builtin_fmaf(-q, den, t0), r, q);
+                r_den = r;
             } else if constexpr (PART == 5) {
                 float c = d0 * t1;
                 c = __builtin_fmaf(delta + delta, t1mt, c);
                 c = __builtin_fmaf(d1, t2, c);
-                t5 = (delta * delta) * c;
+                t5 = (delta * r_den) * c;
             } else {
-                const float l1 = __builtin_amdgcn_logf(t5), l2 = __builtin_amdgcn_logf(den);
-                lad = __builtin_fmaf(-2.0f, l2, l1) * 0.693147182464599609375f;
+                // log(delta^2 c / den^2) with the reciprocal of den the output needed anyway: one logarithm
+                lad = __builtin_amdgcn_logf((delta * r_den) * t5) * 0.693147182464599609375f;
             }
         }
     }

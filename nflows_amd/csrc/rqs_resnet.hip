@@ -812,20 +812,20 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 2, 8, true> : rqs_resnet_kernel<false, 1, 2, 2, 8, true>;
     }
     if (with_ctx && lds > 64 * 1024) {
-        static bool raised_ctx[8] = {false, false, false, false, false, false, false, false};
+        static unsigned long long raised_ctx[8] = {};   // device masks (raise_dynamic_lds)
         const int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (a.sp.K == 10 ? 4 : 0);
-        if (!raised_ctx[which]) {
-            NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-            raised_ctx[which] = true;
+        {
+            const int rc_lds = raise_dynamic_lds((const void*)kern, &raised_ctx[which], 160 * 1024 - 2048);
+            if (rc_lds != NFA_OK) return rc_lds;
         }
     } else if (lds > 64 * 1024) {
-        static bool raised[28] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};  // opt in to > 64 KB of dynamic LDS once per kernel
+        static unsigned long long raised[28] = {};   // device masks (raise_dynamic_lds)  // opt in to > 64 KB of dynamic LDS once per kernel
         const int which = a.sp.K == 10 ? (pipe ? 24 : 12) + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
                           : (pipe && use_pipe == 2) ? 16 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (l2e ? 4 : 0)
                           : pipe ? 8 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) : (inv ? 1 : 0) + (l2e ? 2 : 0) + (init_ks == 4 ? 4 : 0);
-        if (!raised[which]) {
-            NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-            raised[which] = true;
+        {
+            const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], 160 * 1024 - 2048);
+            if (rc_lds != NFA_OK) return rc_lds;
         }
     }
     if (e0) hipExtLaunchKernelGGL(kern, grid, block, lds, st, e0, e1, 0, a);

@@ -182,16 +182,71 @@ typedef unsigned uvec4 __attribute__((ext_vector_type(4)));
 // co-resident wave that issues MFMAs, the piece conversion written with packed fp32 forms gave
 // nondeterministic 1e-3 relative errors in the pieces of samples 16..31 of a wave (lanes 16-31 /
 // 48-63), only with two waves per SIMD; gone with the packed forms removed.
-// The residuals are computed per element and pinned against re-vectorisation, and the file is
-// compiled with -fno-slp-vectorize.
+// The file is compiled with -fno-slp-vectorize.
+//
+// Piece conversion (round 3): two values v0, v1 (x `scale`, a power of two) -> packed f16 pairs
+//   hi = RN16(v * scale)            v_fma_mixlo_f16 / v_fma_mixhi_f16  (fp32 fma, result rounded to f16)
+//   lo = RN16(v * scale - hi)       the same instructions with the f16 `hi` as negated addend: the
+//                                   product and the difference are exact in fp32 (hi = RN16 of it)
+// four instructions per pair where convert / convert back / subtract / convert took nine.
+// (one asm block per group: hipcc puts an `s_nop 0` between two adjacent asm statements)
+__device__ __forceinline__ void split2_scaled(float v0, float v1, float scale, unsigned& hi, unsigned& lo) {
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h), "=&v"(l)
+        : "v"(v0), "v"(v1), "v"(scale));
+    hi = h;
+    lo = l;
+}
+
+// (inputs at scale 1: the high pieces are one v_cvt_pk_f16_f32)
 __device__ __forceinline__ void split2(float v0, float v1, unsigned& hi, unsigned& lo) {
-    const f16x2 h = __builtin_convertvector(vec2f{v0, v1}, f16x2);
-    float r0 = v0 - (float)h[0], r1 = v1 - (float)h[1];
-    asm volatile("" : "+v"(r0));
-    asm volatile("" : "+v"(r1));
-    const f16x2 l = __builtin_convertvector(vec2f{r0, r1}, f16x2);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
+    unsigned h, l;
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h), "=&v"(l)
+        : "v"(v0), "v"(v1));
+    hi = h;
+    lo = l;
+}
+
+// ReLU as v_max_f32 (one instruction; compare + select is two and a hazard wait).  v_max_f32 returns the
+// other operand for a NaN, so the f16-range check can no longer ride on NaNs surviving the ReLUs: every
+// conversion tracks max |value| instead (`peak`, one v_max3_f32 per pair) and the row block is handed to
+// the exact kernel when a value x scale reaches the f16 overflow threshold.  NaN / inf INPUTS reach the
+// check through the pass-through columns and the final layer (no ReLU in front of it), see the epilogue.
+constexpr float kF16Overflow = 65520.0f;   // RN16 of anything >= this is infinity
+
+// one pair of accumulator values -> (ReLU) -> peak, high pieces, low pieces
+template <bool RELU>
+__device__ __forceinline__ void convert_pair(float s0, float s1, float scale, float& peak, unsigned& hi, unsigned& lo) {
+    unsigned h, l;
+    if constexpr (RELU) {
+        float m0, m1;
+        asm("v_max_f32 %2, %5, 0\n\t"
+            "v_max_f32 %3, %6, 0\n\t"
+            "v_fma_mixlo_f16 %0, %2, %7, 0 op_sel_hi:[0,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %3, %7, 0 op_sel_hi:[0,0,0]\n\t"
+            "v_max3_f32 %4, %4, %2, %3\n\t"
+            "v_fma_mixlo_f16 %1, %2, %7, -%0 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %1, %3, %7, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(h), "=&v"(l), "=&v"(m0), "=&v"(m1), "+v"(peak)
+            : "v"(s0), "v"(s1), "v"(scale));
+    } else {
+        asm("v_fma_mixlo_f16 %0, %3, %5, 0 op_sel_hi:[0,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %4, %5, 0 op_sel_hi:[0,0,0]\n\t"
+            "v_max3_f32 %2, %2, |%3|, |%4|\n\t"
+            "v_fma_mixlo_f16 %1, %3, %5, -%0 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %1, %4, %5, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(h), "=&v"(l), "+v"(peak)
+            : "v"(s0), "v"(s1), "v"(scale));
+    }
+    hi = h;
+    lo = l;
 }
 
 // ---- VALU work woven between the MFMAs of a tile: `step<SLOT>()` runs behind MFMA number SLOT ----
@@ -200,23 +255,21 @@ struct NoWeave {
     __device__ __forceinline__ void step() {}
 };
 
-// Conversion of a finished accumulator tile (times `scale`, a power of two; values below `floor_`
-// -- 0 for a ReLU, -inf for none -- replaced by it, NaN kept) into the f16 pieces of k-steps 2t and
-// 2t + 1 of the next GEMM, one pair of values per slice, behind every other MFMA of the first
-// sixteen.  (Members are references to fixed registers-to-be: one object per tile, nothing
-// re-pointed at run time, so that the arrays behind them stay in registers.)
+// Conversion of a finished accumulator tile (ReLU'd when RELU, times `scale`, a power of two) into the
+// f16 pieces of k-steps 2t and 2t + 1 of the next GEMM, one pair of values per slice, behind every other
+// MFMA of the first sixteen.  (Members are references to fixed registers-to-be: one object per tile,
+// nothing re-pointed at run time, so that the arrays behind them stay in registers.)
+template <bool RELU>
 struct ConvWeave {
     const f32x16& src;            // finished tile
     uvec4 &h0, &l0, &h1, &l1;     // pieces of k-steps 2t, 2t + 1
-    float scale, floor_;
+    float scale;
+    float& peak;                  // max |value| seen (before the scale)
 
     template <int J>
     __device__ __forceinline__ void pair() {
-        float v0 = src[2 * J] * scale, v1 = src[2 * J + 1] * scale;
-        v0 = (v0 < floor_) ? floor_ : v0;   // NaN stays NaN
-        v1 = (v1 < floor_) ? floor_ : v1;
         unsigned hi, lo;
-        split2(v0, v1, hi, lo);
+        convert_pair<RELU>(src[2 * J], src[2 * J + 1], scale, peak, hi, lo);
         if constexpr (J < 4) {
             h0[J] = hi;
             l0[J] = lo;
@@ -235,33 +288,45 @@ struct ConvWeave {
 };
 
 // The same conversion cut for the 24 MFMAs of TWO k-steps of a k-major GEMM (12 each): pair J of the
-// tile takes slots 3J (scale, floor), 3J + 1 (high pieces, and their values back in fp32), 3J + 2
-// (residuals, low pieces): 4-6 VALU instructions behind every MFMA, the number that hides.
+// tile takes slots 3J (ReLU, peak), 3J + 1 (high pieces), 3J + 2 (low pieces): 2-3 VALU instructions
+// behind every MFMA.
+template <bool RELU>
 struct ConvSlices {
     const f32x16& src;
     uvec4 &h0, &l0, &h1, &l1;
-    float scale, floor_;
-    float v0, v1, r0, r1;
+    float scale;
+    float& peak;
+    float v0, v1;
     unsigned hi;
 
     template <int SLOT>
     __device__ __forceinline__ void step() {
         constexpr int J = SLOT / 3, PH = SLOT % 3;
         if constexpr (PH == 0) {
-            v0 = src[2 * J] * scale;
-            v1 = src[2 * J + 1] * scale;
-            v0 = (v0 < floor_) ? floor_ : v0;   // NaN stays NaN
-            v1 = (v1 < floor_) ? floor_ : v1;
+            if constexpr (RELU) {
+                asm("v_max_f32 %0, %3, 0\n\t"
+                    "v_max_f32 %1, %4, 0\n\t"
+                    "v_max3_f32 %2, %2, %0, %1"
+                    : "=&v"(v0), "=&v"(v1), "+v"(peak)
+                    : "v"(src[2 * J]), "v"(src[2 * J + 1]));
+            } else {
+                v0 = src[2 * J];
+                v1 = src[2 * J + 1];
+                asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(peak) : "v"(v0), "v"(v1));
+            }
         } else if constexpr (PH == 1) {
-            const f16x2 h = __builtin_convertvector(vec2f{v0, v1}, f16x2);
-            hi = __builtin_bit_cast(unsigned, h);
-            r0 = v0 - (float)h[0];
-            r1 = v1 - (float)h[1];
-            asm volatile("" : "+v"(r0));
-            asm volatile("" : "+v"(r1));
+            unsigned h;
+            asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\t"
+                "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
+                : "=&v"(h)
+                : "v"(v0), "v"(v1), "v"(scale));
+            hi = h;
         } else {
-            const f16x2 l = __builtin_convertvector(vec2f{r0, r1}, f16x2);
-            const unsigned lo = __builtin_bit_cast(unsigned, l);
+            unsigned lo;
+            asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\t"
+                "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                : "=&v"(lo)
+                : "v"(v0), "v"(v1), "v"(scale), "v"(hi));
             if constexpr (J < 4) {
                 h0[J] = hi;
                 l0[J] = lo;
@@ -461,20 +526,23 @@ __device__ __forceinline__ void kstep_pair_woven(f32x16 (&acc)[4], uvec4 bh0, uv
 }
 
 // k-major 128 -> 128 GEMM whose input pieces are made on the way from the accumulator tiles `src` of the
-// previous GEMM (x `scale`, floored at `floor_`): tile 0 is converted up front, tile t + 1 behind the
-// MFMAs of k-steps 2t, 2t + 1 -- which only read the pieces of tile t.
+// previous GEMM (ReLU, x `scale`): tile 0 is converted up front, tile t + 1 behind the MFMAs of k-steps
+// 2t, 2t + 1 -- which only read the pieces of tile t.  `worst`: running max of |value x scale| over the
+// row block's conversions (the f16-range check).
 template <class SM>
 __device__ __forceinline__ void gemm_kmajor_converting(f32x16 (&acc)[4], uvec4 (&ph)[8], uvec4 (&pl)[8],
-                                                       const f32x16 (&src)[4], float scale, float floor_, SM& sm,
+                                                       const f32x16 (&src)[4], float scale, float& worst, SM& sm,
                                                        Frags& fr, int lane) {
-    ConvWeave{src[0], ph[0], pl[0], ph[1], pl[1], scale, floor_}.all();
+    float peak = 0.0f;
+    ConvWeave<true>{src[0], ph[0], pl[0], ph[1], pl[1], scale, peak}.all();
     kstep_pair_woven(acc, ph[0], pl[0], ph[1], pl[1], sm, fr, lane,
-                     ConvSlices{src[1], ph[2], pl[2], ph[3], pl[3], scale, floor_});
+                     ConvSlices<true>{src[1], ph[2], pl[2], ph[3], pl[3], scale, peak});
     kstep_pair_woven(acc, ph[2], pl[2], ph[3], pl[3], sm, fr, lane,
-                     ConvSlices{src[2], ph[4], pl[4], ph[5], pl[5], scale, floor_});
+                     ConvSlices<true>{src[2], ph[4], pl[4], ph[5], pl[5], scale, peak});
     kstep_pair_woven(acc, ph[4], pl[4], ph[5], pl[5], sm, fr, lane,
-                     ConvSlices{src[3], ph[6], pl[6], ph[7], pl[7], scale, floor_});
+                     ConvSlices<true>{src[3], ph[6], pl[6], ph[7], pl[7], scale, peak});
     kstep_pair_woven(acc, ph[6], pl[6], ph[7], pl[7], sm, fr, lane, NoWeave{});
+    worst = __builtin_fmaxf(worst, peak * scale);
 }
 
 // the initial layer: NKS k-steps (2 or 4) on the pieces of the identity features
@@ -639,6 +707,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
         }
 
         float lad_acc = 0.0f;
+        float worst = 0.0f;   // max |activation x scale| handed to an f16 conversion in this row block
         int quad_status = 0;
         for (int layer = 0; layer < a.num_layers; ++layer) {
             // (the two waves of a SIMD alternate the higher issue priority layer by layer)
@@ -728,17 +797,21 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                     const float* bias = gemm + kHdr + half * 16;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) load_bias_tile(u[t], bias + t * 32);
-                    gemm_kmajor_converting(u, ph, pl, hacc, conv_scale, 0.0f, sm, fr, lane);
+                    gemm_kmajor_converting(u, ph, pl, hacc, conv_scale, worst, sm, fr, lane);
                     conv_scale = gemm[0];
                 }
                 gemm += kHdr + 128;
                 NFA_HSTAMP()
                 if constexpr (CTX) {
                     // temps = W_1 relu(u) + b_1 in accumulators of its own (u's registers: its pieces first) ...
-                    ConvWeave{u[0], qh[0], ql[0], qh[1], ql[1], conv_scale, 0.0f}.all();
-                    ConvWeave{u[1], qh[2], ql[2], qh[3], ql[3], conv_scale, 0.0f}.all();
-                    ConvWeave{u[2], qh[4], ql[4], qh[5], ql[5], conv_scale, 0.0f}.all();
-                    ConvWeave{u[3], qh[6], ql[6], qh[7], ql[7], conv_scale, 0.0f}.all();
+                    {
+                        float peak = 0.0f;
+                        ConvWeave<true>{u[0], qh[0], ql[0], qh[1], ql[1], conv_scale, peak}.all();
+                        ConvWeave<true>{u[1], qh[2], ql[2], qh[3], ql[3], conv_scale, peak}.all();
+                        ConvWeave<true>{u[2], qh[4], ql[4], qh[5], ql[5], conv_scale, peak}.all();
+                        ConvWeave<true>{u[3], qh[6], ql[6], qh[7], ql[7], conv_scale, peak}.all();
+                        worst = __builtin_fmaxf(worst, peak * conv_scale);
+                    }
                     const float* bias = gemm + kHdr + half * 16;
                     const float ratio = gemm[1];
                     const float next_scale = gemm[0];
@@ -767,17 +840,21 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                     InitWeave{hacc[1], bias + 1 * 32, ratio}.all();
                     InitWeave{hacc[2], bias + 2 * 32, ratio}.all();
                     InitWeave{hacc[3], bias + 3 * 32, ratio}.all();
-                    gemm_kmajor_converting(hacc, qh, ql, u, conv_scale, 0.0f, sm, fr, lane);
+                    gemm_kmajor_converting(hacc, qh, ql, u, conv_scale, worst, sm, fr, lane);
                     conv_scale = gemm[0];
                 }
                 gemm += kHdr + 128;
                 NFA_HSTAMP()
             }
             // pieces of h itself for the final layer (no ReLU in front of it: resnet.py:99-100)
-            ConvWeave{hacc[0], ph[0], pl[0], ph[1], pl[1], conv_scale, -INFINITY}.all();
-            ConvWeave{hacc[1], ph[2], pl[2], ph[3], pl[3], conv_scale, -INFINITY}.all();
-            ConvWeave{hacc[2], ph[4], pl[4], ph[5], pl[5], conv_scale, -INFINITY}.all();
-            ConvWeave{hacc[3], ph[6], pl[6], ph[7], pl[7], conv_scale, -INFINITY}.all();
+            {
+                float peak = 0.0f;
+                ConvWeave<false>{hacc[0], ph[0], pl[0], ph[1], pl[1], conv_scale, peak}.all();
+                ConvWeave<false>{hacc[1], ph[2], pl[2], ph[3], pl[3], conv_scale, peak}.all();
+                ConvWeave<false>{hacc[2], ph[4], pl[4], ph[5], pl[5], conv_scale, peak}.all();
+                ConvWeave<false>{hacc[3], ph[6], pl[6], ph[7], pl[7], conv_scale, peak}.all();
+                worst = __builtin_fmaxf(worst, peak * conv_scale);
+            }
 
             // ---- final layer with the spline evaluation woven into the MFMAs: the three tiles of a group
             //      hold the logits of this lane's two features A, B (A = T0 + T1[0:8], B = T1[8:16] + T2)
@@ -895,7 +972,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
         // sum_j z_j^2 of every row: the standard-normal epilogue needs it, and it is non-finite exactly
         // when one of the row's values is (or a square overflows: such a block is redone like the others)
         const float sumsq = tile_row_sumsq(s_row, a.Ds, half, r);
-        const bool bad = not_finite(lad_acc) || not_finite(sumsq);
+        const bool bad = not_finite(lad_acc) || not_finite(sumsq) || !(worst < kF16Overflow);
         const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
         if (lane == 0) s_bad[wave] = wave_bad ? 1 : 0;
         __syncthreads();
@@ -1047,12 +1124,10 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
         default: kern = k8h::rqs_resnet_f16_kernel<true, 4, 8, 10>; break;
     }
     if (lds_launch > 64 * 1024) {
-        static bool raised[24] = {false, false, false, false, false, false, false, false,
-                                  false, false, false, false, false, false, false, false,
-                                  false, false, false, false, false, false, false, false};
-        if (!raised[which]) {
-            NFA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-            raised[which] = true;
+        static unsigned long long raised[24] = {};   // device masks (raise_dynamic_lds)
+        {
+            const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], 160 * 1024 - 2048);
+            if (rc_lds != NFA_OK) return rc_lds;
         }
     }
     if (e0) hipExtLaunchKernelGGL(kern, grid, block, lds_launch, st, e0, e1, 0, a);

@@ -30,6 +30,17 @@ _error_mode = "deferred"
 _launch_hook = None
 
 
+_last_redo = None   # the `redo_blocks` tensor of the most recent K8h launch (flags per 128-row block)
+
+
+def last_redo_blocks():
+    """Number of 128-row blocks the most recent K8h (f16x2) launch handed to the exact kernel because a
+    value left the f16 range or the inputs were non-finite (reads the device flags: synchronises).
+    None if no such launch happened yet.  bench.py reports it; a trained flow that makes this non-zero on
+    ordinary data runs those blocks at the bf16x3 kernel's speed."""
+    return None if _last_redo is None else int(_last_redo.sum().item())
+
+
 def set_launch_hook(hook):
     """Measurement aid for bench.py: `hook.begin(name)` / `hook.end(token, algorithmic_bytes)` are
     called right before / after the K1 kernel is enqueued (on the current stream), so a caller
@@ -1094,8 +1105,14 @@ def build_f16_stream(layer_packs, tables):
     transformed features, from `flow_layer_tables`) followed by the layer's parameter words -- and then its
     weight stages.  `layer_packs`: [(weights, parameter words)] from pack_resnet_conditioner_f16 in
     execution order; `tables`: int32 [(L + 1) * 128].  Returns (stream [stages, 8192] f16, parameter stages
-    per layer, final table int32 [128])."""
+    per layer, final table int32 [128]), or None when a weight or bias is not finite (callers run K8)."""
     L = len(layer_packs)
+    # K8h applies ReLU with v_max_f32, which returns the other operand for a NaN: non-finite WEIGHTS would
+    # not propagate the way torch.relu propagates them.  Such a run is left to the exact kernel (K8 keeps
+    # NaNs through its ReLUs): no stream.  (One synchronising check per weight version.)
+    finite = torch.stack([torch.isfinite(w).all() & torch.isfinite(prm).all() for w, prm in layer_packs]).all()
+    if not bool(finite):
+        return None
     words = 128 + layer_packs[0][1].numel()
     P = (words + K8H_PARAM_STAGE_WORDS - 1) // K8H_PARAM_STAGE_WORDS
     parts = []
@@ -1303,7 +1320,9 @@ def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transf
     x = inputs.detach().contiguous()
     lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
     flags, out = _density_epilogue(flags, standard_normal_log_prob, inverse, x, _pad_columns_count)
+    global _last_redo
     redo = torch.empty(max(1, B // 128), dtype=torch.int32, device=dev)
+    _last_redo = redo
     lib = N.load()
     stream, param_stages, final_table = stream_f16
     ctx = None

@@ -131,13 +131,15 @@ class AutoregressiveTransform(Transform):
         """Number of leading features whose inversion changes a hidden activation of the MADE: the
         largest degree of any hidden unit (made.py: a unit of degree d is connected to inputs of
         degree <= d, i.e. features 0 .. d - 1)."""
+        # (one device read per cache epoch: `degrees` / `mask` are registered buffers, a load_state_dict from a
+        #  checkpoint with other random masks replaces them and advances the epoch)
         cached = self.__dict__.get("_sequential_steps_cache")
-        if cached is None:   # (masks are fixed at construction; one device read, once)
+        if cached is None or cached[0] != _cache.epoch():
             net = self.autoregressive_net
             degrees = [net.initial_layer.degrees] + [b.degrees for b in net.blocks]
-            cached = int(max(int(d.max()) for d in degrees))
+            cached = (_cache.epoch(), int(max(int(d.max()) for d in degrees)))
             self.__dict__["_sequential_steps_cache"] = cached
-        return cached
+        return cached[1]
 
     def _output_dim_multiplier(self):
         raise NotImplementedError()

@@ -31,18 +31,32 @@ from . import splines
 from .splines import rational_quadratic
 
 
+def _held_parameters(net):
+    """[(the `_parameters` dict of a leaf module, name, Parameter)] of every parameter of `net`."""
+    return [(m._parameters, name, p) for m in net.modules() for name, p in m._parameters.items() if p is not None]
+
+
 def _weights_key(owner, net):
     """Cheap fingerprint of a conditioner's weights for the packed-weight caches: storage pointers and version
     counters of its parameters, read from a list made once per cache epoch (walking `net.parameters()` costs ~10 us per call and
     layer: a millisecond per `log_prob` of a 32-layer flow).  In-place updates advance the counters; moves,
-    `load_state_dict` and (re)registered Parameter objects advance the epoch (_cache.py)."""
+    `load_state_dict` and (re)registered Parameter objects advance the epoch (_cache.py).  Swaps that bypass the
+    registration hooks -- `torch.func.functional_call`, `stateless._reparametrize_module`, a direct
+    `module._parameters[name] = other` -- are caught by checking on every call that each held object still IS
+    the entry of its module's `_parameters` dict (a dict lookup and an identity test per parameter)."""
     epoch = _cache.epoch()
     held = owner.__dict__.get("_weights_list")
     if held is None or held[0] != epoch or held[1] is not net or not _cache.HOOKED:
-        held = (epoch, net, list(net.parameters()))
+        held = (epoch, net, _held_parameters(net))
         owner.__dict__["_weights_list"] = held
+    else:
+        for d, name, p in held[2]:
+            if d.get(name) is not p:
+                held = (epoch, net, _held_parameters(net))
+                owner.__dict__["_weights_list"] = held
+                break
     # (data_ptr as well: `p.data = other` rebinds the storage without touching the counter)
-    return (epoch,) + tuple([(p.data_ptr(), p._version) for p in held[2]])
+    return (epoch,) + tuple([(p.data_ptr(), p._version) for _, _, p in held[2]])
 
 
 class CouplingTransform(Transform):
@@ -527,9 +541,9 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         if hit is None:
             if len(cache) > 8:
                 cache.clear()
-            hit = ops.build_f16_stream([pack], tables)
+            hit = ops.build_f16_stream([pack], tables) or False   # (False: non-finite weights, no stream)
             cache[key] = hit
-        return hit
+        return hit or None
 
     def _packed_resnet(self, geometry=None):
         net = self.transform_net
@@ -568,8 +582,9 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         Dp, dt4, di, pad_value = self._fused_geometry()
         spec = self._spec()
         # (ragged batches are padded to full 128-row blocks, odd shapes to multiples of four columns, in `ops`)
-        if self._use_f16():
-            return ops.rqs_coupling_resnet_f16(inputs, self._f16_stream(tables), (wp, bp), tables, dt4, di, nb, spec,
+        stream = self._f16_stream(tables) if self._use_f16() else None   # (None: non-finite weights -> exact kernel)
+        if stream is not None:
+            return ops.rqs_coupling_resnet_f16(inputs, stream, (wp, bp), tables, dt4, di, nb, spec,
                                                inverse, accumulate_into, pad=(Dp, pad_value), context=context)
         return ops.rqs_coupling_resnet(inputs, wp, bp, tables, dt4, di, nb, spec, inverse, accumulate_into,
                                        log2e=self._log2e(), context=context, pad=(Dp, pad_value))

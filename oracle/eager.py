@@ -173,6 +173,25 @@ def ar_rq_layer_forward(x, made, num_bins, tail_bound):
     return y, torch.sum(lad, dim=[1])
 
 
+def ar_rq_layer_inverse(z, made, num_bins, tail_bound):
+    """AutoregressiveTransform.inverse (autoregressive.py:43-52): D passes of the whole MADE over the
+    outputs found so far, each followed by the elementwise spline inverse of ALL features (the last
+    pass's results are returned)."""
+    b, d = z.shape
+    out = torch.zeros_like(z)
+    lad = None
+    for _ in range(d):
+        params = made(out, None).view(b, d, -1)
+        uw = params[..., :num_bins]
+        uh = params[..., num_bins:2 * num_bins]
+        ud = params[..., 2 * num_bins:]
+        if hasattr(made, "hidden_features"):
+            uw /= np.sqrt(made.hidden_features)
+            uh /= np.sqrt(made.hidden_features)
+        out, lad = rqs_unconstrained(z, uw, uh, ud, inverse=True, tail_bound=tail_bound)
+    return out, torch.sum(lad, dim=[1])
+
+
 def _layer(t, h, inverse, context=None):
     name = type(t).__name__
     if name.endswith("Permutation"):
@@ -187,8 +206,9 @@ def _layer(t, h, inverse, context=None):
     if name == "AffineCouplingTransform":
         return affine_coupling_layer(h, t.transform_net, t.identity_features, t.transform_features,
                                      inverse=inverse)
-    if name == "MaskedPiecewiseRationalQuadraticAutoregressiveTransform" and not inverse:
-        return ar_rq_layer_forward(h, t.autoregressive_net, t.num_bins, t.tail_bound)
+    if name == "MaskedPiecewiseRationalQuadraticAutoregressiveTransform":
+        fn = ar_rq_layer_inverse if inverse else ar_rq_layer_forward
+        return fn(h, t.autoregressive_net, t.num_bins, t.tail_bound)
     raise NotImplementedError(name + (" inverse" if inverse else ""))
 
 

@@ -751,6 +751,54 @@ def test_f16_engine_hands_out_of_range_blocks_to_the_exact_kernel(monkeypatch):
     assert not np.array_equal(results["f16x2"][0][:128], results["bf16x3"][0][:128])
 
 
+def test_functional_call_sees_the_supplied_weights():
+    """torch.func.functional_call swaps the modules' `_parameters` entries without registering anything: the
+    packed-weight caches must notice (EMA evaluation, ensembles, hypernetworks) -- the result equals that of a
+    flow that really carries the other weights, and the original weights are back afterwards."""
+    import copy
+    from nflows_amd import configs
+    flow = configs.rq_nsf_flow(num_layers=4, features=64, num_bins=8, hidden_features=128, seed=0).to(DEV).eval()
+    x = torch.randn(512, 64, generator=torch.Generator().manual_seed(5)).to(DEV)
+    gen = torch.Generator().manual_seed(6)
+    other = {n: (p.detach().cpu() * (1.0 + 0.2 * torch.randn(p.shape, generator=gen))).to(DEV)
+             for n, p in flow._transform.named_parameters()}
+    twin = copy.deepcopy(flow)
+    twin._transform.load_state_dict(other, strict=False)
+    with torch.no_grad():
+        z0, lad0 = flow._transform(x)
+        z1, lad1 = torch.func.functional_call(flow._transform, other, (x,))
+        zt, ladt = twin._transform(x)
+        z2, lad2 = flow._transform(x)
+    assert torch.equal(z1, zt) and torch.equal(lad1, ladt)
+    assert torch.equal(z2, z0) and torch.equal(lad2, lad0)
+    assert not torch.equal(z1, z0)
+
+
+def test_f16_engine_leaves_non_finite_weights_to_the_exact_kernel(monkeypatch):
+    """K8h's ReLU is v_max_f32, which does not propagate a NaN the way torch.relu does: a conditioner with a
+    non-finite weight (a diverged training run) must not take the f16 engine.  The packer notices
+    (ops.build_f16_stream) and the run goes to the bf16x3 kernel: same bits as with that engine selected,
+    NaN pattern of the reference (every transformed feature of the poisoned layer's rows)."""
+    from nflows_amd import configs, ops
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    flow = configs.rq_nsf_flow(num_layers=3, features=64, num_bins=8, hidden_features=128, seed=0)
+    with torch.no_grad():
+        flow._transform._transforms[3].transform_net.blocks[0].linear_layers[0].weight[5, 7] = float("nan")
+    flow = flow.to(DEV).eval()
+    x = torch.randn(256, 64, generator=torch.Generator().manual_seed(2)).to(DEV)
+    results = {}
+    for engine in ("f16x2", "bf16x3"):
+        monkeypatch.setattr(RQ, "conditioner_engine", engine)
+        with torch.no_grad():
+            z, lad = flow._transform(x)
+            y1, lad1 = flow._transform._transforms[3](x)       # the layer alone (single-layer path)
+        results[engine] = [t.cpu().numpy() for t in (z, lad, y1, lad1)]
+    ops.check_status()
+    for got, want in zip(results["f16x2"], results["bf16x3"]):
+        assert np.array_equal(got, want, equal_nan=True)
+    assert np.isnan(results["f16x2"][1]).all() and np.isnan(results["f16x2"][3]).all()
+
+
 @pytest.mark.parametrize("engine,bins", [("f16x2", 8), ("bf16x3", 8), ("bf16x3", 10)])
 def test_standard_normal_density_folded_into_the_last_layer(monkeypatch, engine, bins):
     """Flow.log_prob of a flow that is one run of whole-layer kernels over a StandardNormal base: the

@@ -9,8 +9,10 @@ tests/test_oracle_golden.py) evaluated in float32 and in float64 on the same wei
 for the maximum, the mean and the 99.9 % quantile of the absolute error of z, logabsdet and
 log_prob (at depth 32 the reference's own fp32 error is 1e-4 .. 1e-3, so its
 error against the float64 evaluation of the same flow is the yardstick, not a fixed tolerance).
-The floors are the single-layer tolerances of tests/helpers.py scaled with the magnitude:
-2e-6 (1 + max|z|) for outputs, 2e-5 (1 + max|.|) for log-determinants and log-densities.
+The floor (round 3) is FOUR fp32 ULPS of the largest |truth| on the maximum only -- a value of
+magnitude 100 cannot be asked to agree better than its own spacing -- and ZERO on the mean and the
+quantile: those two really assert "at most twice the reference's own error" (round 2 used
+tol (1 + max |truth|) on all three, which was 8-11 x the reference's maximum error for log-densities).
 Achieved figures are printed (pytest -s) and appended to gpurun_out/parity_report.jsonl.
 
 Rows the oracle does not visit (it takes seconds per 16 384 rows) are covered by a size-independent
@@ -56,15 +58,17 @@ def compare(config, what, got, ref32, truth, tol):
     fin = np.isfinite(truth)
     e_got = _stats(np.abs(got64 - truth)[fin])
     e_ref = _stats(np.abs(ref32.astype(np.float64) - truth)[fin])
-    floor = tol * (1.0 + float(np.abs(truth[fin]).max()))
+    floor = 4.0 * 2.0 ** -23 * float(np.abs(truth[fin]).max())   # four ulps of the largest value, maximum only
     entry = {"config": config, "what": what, "rows": int(got.shape[0]), "hip_vs_fp64": e_got,
-             "reference_fp32_vs_fp64": e_ref, "floor": floor,
+             "reference_fp32_vs_fp64": e_ref, "floor_on_max": floor,
+             "ratio": {k: e_got[k] / max(e_ref[k], 1e-300) for k in e_got},
              "bulk_within_tol_of_reference_fp32": bulk_fraction(got, ref32, tol), "tol": tol}
     _report(entry)
     for k in ("max", "mean", "q999"):
-        assert e_got[k] <= FACTOR * e_ref[k] + floor, (
-            "%s %s: %s error vs float64 %.3e exceeds %.1f x the reference fp32's %.3e (+ %.1e)"
-            % (config, what, k, e_got[k], FACTOR, e_ref[k], floor))
+        bound = FACTOR * e_ref[k] + (floor if k == "max" else 0.0)
+        assert e_got[k] <= bound, (
+            "%s %s: %s error vs float64 %.3e exceeds %.1f x the reference fp32's %.3e%s"
+            % (config, what, k, e_got[k], FACTOR, e_ref[k], " (+ %.1e)" % floor if k == "max" else ""))
     return entry
 
 
@@ -211,9 +215,168 @@ def test_forward_inverse_consistency_against_the_reference():
     got = (xr.cpu() - xs).abs().numpy()
     e_got, e_ref = _stats(got), _stats(ref)
     _report({"config": "cfg4_fwd_inv_8192_rows", "what": "|inv(fwd(x)) - x|", "hip": e_got, "reference_fp32": e_ref})
-    floor = OUT_TOL * (1 + float(xs.abs().max()))
+    floor = 4.0 * 2.0 ** -23 * float(xs.abs().max())
     for k in ("max", "mean", "q999"):
-        assert e_got[k] <= FACTOR * e_ref[k] + floor, (
+        assert e_got[k] <= FACTOR * e_ref[k] + (floor if k == "max" else 0.0), (
             "fwd/inv consistency: %s %.3e exceeds %.1f x the reference fp32's %.3e" % (k, e_got[k], FACTOR, e_ref[k]))
     compare("cfg4_inverse_pass_8192_rows", "x", xi.cpu().numpy(), xr32.numpy(), xr64.numpy(), OUT_TOL)
     compare("cfg4_inverse_pass_8192_rows", "logabsdet", lad_inv.cpu().numpy(), lad_inv32.numpy(), lad_inv64.numpy(), LAD_TOL)
+
+
+def _redo_blocks():
+    from nflows_amd import ops
+    return ops.last_redo_blocks()
+
+
+def test_bench_instance_262144_rows_log_prob():
+    """The kernel instance bench.py times: Flow.log_prob of the 32-layer flow on bench.py's own 262 144 rows
+    (8-wave workgroups, four row blocks per workgroup, standard-normal epilogue, z never written).  The
+    oracle visits every 31st row (8 457 rows, every lane position of every wave, every row block); the same
+    rows evaluated alone give the same bits; no row block is handed to the exact kernel."""
+    from nflows_amd import configs
+    import nflows_amd
+    flow_cpu = configs.rq_nsf_flow(num_layers=32, features=64, num_bins=8, hidden_features=128, seed=0).eval()
+    x = torch.randn(262144, 64, generator=torch.Generator().manual_seed(1234))   # bench.py, rank 0
+    import copy
+    flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+    xd = x.to(DEV)
+    with torch.no_grad():
+        lp = flow.log_prob(xd)
+        redo = _redo_blocks()
+        lp_again = flow.log_prob(xd)
+    nflows_amd.check_status()
+    assert redo == 0, "%d row blocks left the f16 range on the bench's own data" % redo
+    assert torch.equal(lp, lp_again)
+    rows = torch.arange(0, 262144, 31)
+    o = oracle_eval(flow_cpu, x[rows])
+    got = lp[rows.to(DEV)].cpu().numpy()
+    compare("bench_instance_262144_rows", "log_prob", got, o["lp32"], o["lp64"], LAD_TOL)
+    with torch.no_grad():
+        solo = flow.log_prob(xd[rows.to(DEV)])
+        z, lad = flow._transform(xd)          # the same launch geometry with outputs written
+    assert torch.equal(solo, lp[rows.to(DEV)]), "rows are not independent of the batch"
+    zs, lads = z[rows.to(DEV)].cpu().numpy(), lad[rows.to(DEV)].cpu().numpy()
+    compare("bench_instance_262144_rows", "z", zs, o["z32"], o["z64"], OUT_TOL)
+    compare("bench_instance_262144_rows", "logabsdet", lads, o["lad32"], o["lad64"], LAD_TOL)
+    # the density epilogue adds -(1/2) sum z^2 - (D/2) log 2 pi to the same logabsdet
+    lp_from_parts = (-0.5 * (z.double() ** 2).sum(1) - 32.0 * np.log(2 * np.pi) + lad.double())
+    assert float((lp.double() - lp_from_parts).abs().max()) <= LAD_TOL * (1 + float(lp.abs().max()))
+
+
+def test_whole_layer_kernel_is_bit_deterministic_across_fresh_flows():
+    """K8h's correctness rests on counted waits (LDS-DMA ring paced by vmcnt(n), weight fragments awaited
+    with lgkmcnt(2)): a wait that is one short shows up as a rare deviation, not as a wrong answer every
+    time.  Twenty fresh flow objects (fresh packed streams at fresh addresses) on the bench's 262 144 rows,
+    each evaluated twice, forward / inverse on 8 192 rows: every result bit-identical to the first."""
+    import copy
+    from nflows_amd import configs
+    flow_cpu = configs.rq_nsf_flow(num_layers=32, features=64, num_bins=8, hidden_features=128, seed=0).eval()
+    x = torch.randn(262144, 64, generator=torch.Generator().manual_seed(1234)).to(DEV)
+    xs = x[:8192]
+    first = None
+    deviations = []
+    for it in range(20):
+        flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+        with torch.no_grad():
+            lp1 = flow.log_prob(x)
+            lp2 = flow.log_prob(x)
+            z, lad = flow._transform(xs)
+            xr, ladi = flow._transform.inverse(z)
+        out = (lp1, z, lad, xr, ladi)
+        if first is None:
+            first = tuple(t.clone() for t in out)
+        if not torch.equal(lp1, lp2):
+            deviations.append((it, "second call", int((lp1 != lp2).sum())))
+        for name, a, b in zip(("log_prob", "z", "lad", "x", "lad_inv"), out, first):
+            if not torch.equal(a, b):
+                deviations.append((it, name, int((a != b).sum())))
+    _report({"config": "k8h_determinism_20_fresh_flows_262144_rows", "deviations": deviations})
+    assert not deviations, deviations
+
+
+def test_config5_autoregressive_inverse_against_the_reference_loop():
+    """configs[4]'s NAMED path: the inverse (sampling direction) of the autoregressive RQ layer at D = 784,
+    H = 256, B = 4 096 -- degree-ordered evaluation + the persistent kernel K12 -- against the reference's
+    784-pass loop (autoregressive.py:43-52, oracle/eager.py: pinned bit for bit on the reference's own
+    vectors) in float32 and float64 on the first 64 rows."""
+    from nflows_amd import configs
+    import copy
+    import nflows_amd
+    flow_cpu = configs.ar_rq_flow(features=784, hidden_features=256, num_bins=8, tail_bound=3.0, seed=0).eval()
+    z = torch.randn(4096, 784, generator=torch.Generator().manual_seed(4321))
+    flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+    with torch.no_grad():
+        x, lad = flow._transform.inverse(z.to(DEV))
+        x_solo, lad_solo = flow._transform.inverse(z[:64].to(DEV))
+    nflows_amd.check_status()
+    assert torch.equal(x_solo, x[:64]) and torch.equal(lad_solo, lad[:64])
+    from oracle import eager
+    with torch.no_grad():
+        x32, lad32 = eager.flow_transform(flow_cpu, z[:64], inverse=True)
+        f64 = flow_cpu.double()
+        x64, lad64 = eager.flow_transform(f64, z[:64].double(), inverse=True)
+        flow_cpu.float()
+    compare("cfg5_ar_rq_d784_k8_b4096_inverse", "x", x[:64].cpu().numpy(), x32.numpy(), x64.numpy(), OUT_TOL)
+    compare("cfg5_ar_rq_d784_k8_b4096_inverse", "logabsdet", lad[:64].cpu().numpy(), lad32.numpy(), lad64.numpy(), LAD_TOL)
+
+
+def _spread_rows(weight, decades, gen):
+    """rows of a weight matrix multiplied by 10^U(-decades/2, decades/2)"""
+    with torch.no_grad():
+        f = 10.0 ** ((torch.rand(weight.shape[0], generator=gen) - 0.5) * decades)
+        weight.mul_(f[:, None] if weight.dim() == 2 else f)
+
+
+@pytest.mark.parametrize("case", ["wide_weights", "large_activations"])
+def test_f16_engine_over_a_wide_dynamic_range(case):
+    """K8h splits every fp32 operand into two f16 pieces after a per-GEMM power-of-two scaling: weights far
+    below their matrix's maximum keep fewer bits, activations beyond 65 504 overflow and must be caught.
+    `wide_weights`: every conditioner matrix gets row magnitudes spread over four decades (1e4) and the
+    matrices of one network differ by another two; inputs as in the bench.  `large_activations`: the same
+    with identity features up to +-3e3 and hidden activations up to ~1e5, and a band of rows scaled down to
+    1e-4.  Both against the float64 oracle with the 2 x rule; the number of row blocks handed to the exact
+    kernel is reported, and in the first case must be zero."""
+    import copy
+    from nflows_amd import configs
+    import nflows_amd
+    gen = torch.Generator().manual_seed(99)
+    flow_cpu = configs.rq_nsf_flow(num_layers=6, features=64, num_bins=8, hidden_features=128, seed=3).eval()
+    for t in flow_cpu._transform._transforms:
+        net = getattr(t, "transform_net", None)
+        if net is None:
+            continue
+        _spread_rows(net.initial_layer.weight, 4.0, gen)
+        with torch.no_grad():
+            net.initial_layer.weight.mul_(0.3)
+        for b_i, block in enumerate(net.blocks):
+            for l_i, lin in enumerate(block.linear_layers):
+                _spread_rows(lin.weight, 4.0, gen)
+                with torch.no_grad():
+                    lin.weight.mul_((0.1, 1.0, 0.03, 0.5)[2 * b_i + l_i])
+        _spread_rows(net.final_layer.weight, 3.0, gen)
+        with torch.no_grad():
+            net.final_layer.weight.mul_(0.5)
+    B = 16384
+    x = torch.randn(B, 64, generator=gen)
+    if case == "large_activations":
+        with torch.no_grad():
+            x[:4096] *= 10.0 ** (torch.rand(4096, 1, generator=gen) * 3.0)        # up to ~3e3 (tails: identity)
+            x[4096:6144] *= 1e-4
+    flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+    with torch.no_grad():
+        z, lad = flow._transform(x.to(DEV))
+        redo = _redo_blocks()
+        lp = flow.log_prob(x.to(DEV))
+    nflows_amd.check_status()
+    rows = torch.arange(0, B, 2)
+    o = oracle_eval(flow_cpu, x[rows])
+    _report({"config": "f16_engine_" + case, "redo_blocks": redo, "of": B // 128,
+             "max_abs_z": float(z.abs().max()), "max_abs_lad": float(lad.abs().max())})
+    idx = rows.to(DEV)
+    compare("f16_engine_" + case, "z", z[idx].cpu().numpy(), o["z32"], o["z64"], OUT_TOL)
+    compare("f16_engine_" + case, "logabsdet", lad[idx].cpu().numpy(), o["lad32"], o["lad64"], LAD_TOL)
+    compare("f16_engine_" + case, "log_prob", lp[idx].cpu().numpy(), o["lp32"], o["lp64"], LAD_TOL)
+    if case == "wide_weights":
+        assert redo == 0, "%d row blocks left the f16 range with moderate activations" % redo
+    else:
+        assert redo < B // 128, "every block was redone: the f16 engine handled nothing"

@@ -766,7 +766,18 @@ def test_run_plans_are_cached_and_follow_changes(monkeypatch):
     first.transform_net.final_layer.bias = torch.nn.Parameter(torch.zeros_like(first.transform_net.final_layer.bias))
     assert _cache.epoch() > epoch
     k2 = _weights_key(first, first.transform_net)
-    assert k2 != k1 and first.__dict__["_weights_list"][2][-1] is first.transform_net.final_layer.bias
+    assert k2 != k1 and first.__dict__["_weights_list"][2][-1][2] is first.transform_net.final_layer.bias
+    # swaps that bypass the registration hooks (torch.func.functional_call / stateless._reparametrize_module):
+    # the held objects are checked against the modules' `_parameters` entries on every call
+    from torch.nn.utils import stateless
+    net = first.transform_net
+    other = {n: p.detach().clone() + 1.0 for n, p in net.named_parameters()}
+    epoch = _cache.epoch()
+    with stateless._reparametrize_module(net, other):
+        inside = _weights_key(first, net)
+        assert _cache.epoch() == epoch and inside != k2
+        assert inside[1:] == tuple((p.data_ptr(), p._version) for p in net.parameters())
+    assert _weights_key(first, net) == k2
     w_before = first._packed_resnet()[1].clone()
     with torch.no_grad():
         first.transform_net.final_layer.bias.add_(2.0)

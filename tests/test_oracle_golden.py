@@ -163,8 +163,8 @@ def test_eager_port_is_bit_identical_to_reference(golden_dir):
 
 
 def test_eager_port_other_configs_bit_identical(golden_dir):
-    """The eager port on the affine stack (configs[1]'s layer type) in both directions and on the
-    autoregressive RQ layer's forward pass (configs[4]): bit-identical to the reference, in float32
+    """The eager port on the affine stack (configs[1]'s layer type) and on the autoregressive RQ layer
+    (configs[4]) in both directions -- the latter's inverse is the reference's D-pass loop -- : bit-identical to the reference, in float32
     and float64 (the float64 evaluation of the port is the ground truth of the GPU parity tests)."""
     import torch
     from oracle import eager
@@ -185,14 +185,17 @@ def test_eager_port_other_configs_bit_identical(golden_dir):
             assert np.array_equal(z.numpy(), gf[name + "/z"]), name
             assert np.array_equal(lad.numpy(), gf[name + "/lad"]), name
             assert np.array_equal(lp.numpy(), gf[name + "/log_prob"]), name
-            if name != "ar_rq_small":
-                xi, ladi = eager.flow_transform(flow, noise, inverse=True)
-                assert np.array_equal(xi.numpy(), gf[name + "/inv_x"]), name
-                assert np.array_equal(ladi.numpy(), gf[name + "/inv_lad"]), name
+            # (ar_rq_small: the reference's D-pass inverse loop, autoregressive.py:43-52)
+            xi, ladi = eager.flow_transform(flow, noise, inverse=True)
+            assert np.array_equal(xi.numpy(), gf[name + "/inv_x"]), name
+            assert np.array_equal(ladi.numpy(), gf[name + "/inv_lad"]), name
             flow64 = flow.double()
             z64, lad64 = eager.flow_transform(flow64, x.double())
             assert np.abs(z64.numpy() - gf[name + "/z64"]).max() <= 1e-12, name
             assert np.abs(lad64.numpy() - gf[name + "/lad64"]).max() <= 1e-11, name
+            xi64, ladi64 = eager.flow_transform(flow64, noise.double(), inverse=True)
+            assert np.abs(xi64.numpy() - gf[name + "/inv_x64"]).max() <= 1e-12, name
+            assert np.abs(ladi64.numpy() - gf[name + "/inv_lad64"]).max() <= 1e-10, name
             flow.float()
 
 
