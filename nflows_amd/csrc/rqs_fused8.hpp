@@ -3,9 +3,9 @@
 //
 // Same function as rational_quadratic.py:66-181 (+ :13-63 for the tails), arranged for the lowest
 // VALU instruction count -- the layer kernel is bound by VALU issue, not by the matrix pipe:
-//   * softmax numerators as 2^(e * log2e*kappa): two instructions per logit, no maximum subtracted
-//     (round 3; logits beyond the range of 2^t end in a non-finite result, which sends the row block
-//     to the exact kernel);
+//   * softmax numerators as 2^(fma(e, log2e*kappa, -max*log2e*kappa)): two instructions per logit;
+//     the rounding of the shared term is common to all eight numerators and cancels in the
+//     normalisation;
 //   * ONE walk over the bins instead of two: knot_{i+1} = knot_i + fma(numerator_i, 2B(1-K min)/den,
 //     2B min) for widths and heights side by side (fp32 running sums; the reference rounds each
 //     normalised bin to fp32, sums in double and rounds every knot -- the same error class), and on
@@ -27,7 +27,7 @@ namespace nfa {
 template <bool INVERSE, int KT = 8>
 struct FusedSteps {
     static_assert(KT == 8 || KT == 10, "8 or 10 bins");
-    static constexpr int kNumSlices = KT + 2;                   // one exponential per logit, sum x 2
+    static constexpr int kNumSlices = KT + 3;                   // max, one exponential per logit, sum x 2
     static constexpr int kWalkSlices = 3 + (KT - 1);            // setup x 2, bin 0, bins 1..KT-1
     static constexpr int kBinSlices = INVERSE ? 9 : 7;
     static constexpr int kFinishSlices = kWalkSlices + 6 + kBinSlices + 1;
@@ -38,23 +38,31 @@ struct FusedSteps {
     float sd[KT - 1];       // derivative logits (scaled)
     float x;
     float kl2e, kappa, tail_s;   // log2(e) * kappa, kappa, tail_logit / kappa (uniform)
-    float den_w, den_h, tw_, th_;
+    float m_w, m_h, den_w, den_h, tw_, th_;
     float aw, ah, kw, kh, kwn, khn;
     unsigned long long take;     // lanes whose x is at or above the lower knot of the bin the next walk slice visits
     float cw0, cw1, ch0, ch1, u0, u1, d0, d1;
     float y, lad;
     int status;
-    float t4;
+    float t3, t4;
     float in_w, in_h, r_w, r_den, delta, s_, th, t1mt, den, t0, t1, t2, t5;
 
-    // Softmax numerators 2^(logit x log2(e) x kappa), no maximum subtracted: a set whose exponentials
-    // overflow (a logit beyond +88) or all vanish (all below -87) ends in a non-finite log-derivative, and
-    // the kernel hands such a row block to the exact kernel like every other non-finite result.
+    // Softmax numerators 2^((logit - max) x log2(e) x kappa): max in one slice (two v_max3_f32 + one
+    // v_max_f32 for 8 bins), then fma + v_exp_f32 per logit; the rounding of the shared term is common to
+    // all numerators and cancels in the normalisation.  (Round 3 tried the numerators without the maximum:
+    // 10 instructions fewer per evaluation, no measurable gain, and logit sets beyond +-87 -- softmax is
+    // shift-invariant, a trained network may sit anywhere -- would have gone to the exact kernel.)
     template <int S>
-    __device__ __forceinline__ void numerators(float (&e)[KT], float& den_, float& t) {
-        if constexpr (S < KT) {
-            e[S] = __builtin_amdgcn_exp2f(e[S] * kl2e);
-        } else if constexpr (S == KT) {
+    __device__ __forceinline__ void numerators(float (&e)[KT], float& den_, float& m, float& t) {
+        if constexpr (S == 0) {
+            m = __builtin_fmaxf(__builtin_fmaxf(e[0], e[1]), e[2]);      // (v_max3_f32)
+            m = __builtin_fmaxf(__builtin_fmaxf(m, e[3]), e[4]);
+            m = __builtin_fmaxf(__builtin_fmaxf(m, e[5]), e[6]);
+            if constexpr (KT == 10) m = __builtin_fmaxf(__builtin_fmaxf(m, e[7]), e[8]);
+            m = __builtin_fmaxf(m, e[KT - 1]) * kl2e;                     // max * log2e * kappa
+        } else if constexpr (S < 1 + KT) {
+            e[S - 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(e[S - 1], kl2e, -m));
+        } else if constexpr (S == 1 + KT) {
             t = (e[0] + e[1]) + (e[2] + e[3]);
         } else {
             den_ = t + ((e[4] + e[5]) + (e[6] + e[7]));
@@ -62,23 +70,24 @@ struct FusedSteps {
         }
     }
     template <int S>
-    __device__ __forceinline__ void num_w() { numerators<S>(ew, den_w, tw_); }
+    __device__ __forceinline__ void num_w() { numerators<S>(ew, den_w, m_w, tw_); }
     template <int S>
-    __device__ __forceinline__ void num_h() { numerators<S>(eh, den_h, th_); }
+    __device__ __forceinline__ void num_h() { numerators<S>(eh, den_h, m_h, th_); }
 
-    // min_d + softplus(u * kappa) in three slices (exp | log1p | add).  No branch for large arguments
-    // (torch's softplus returns the argument beyond 20: the two differ by e^-20 relative 1e-10 there).
+    // min_d + softplus(u * kappa) in three slices, as max(t, 0) + log1p(exp(-|t|)): no overflow for any t (a
+    // derivative logit of 200 is a legitimate slope of 200), full relative accuracy for very negative t.
     template <int PART>
     __device__ __forceinline__ void derivative(float u, float& d, const RqsDev& sp) {
         if constexpr (PART == 0) {
-            t4 = __builtin_amdgcn_exp2f(u * kl2e);
+            t3 = u * kappa;
+            t4 = __builtin_amdgcn_exp2f(-__builtin_fabsf(u * kl2e));
         } else if constexpr (PART == 1) {
             const float u1p = 1.0f + t4;
             const float c = t4 - (u1p - 1.0f);   // what the addition dropped
-            const float lg = __builtin_amdgcn_logf(u1p) * 0.693147182464599609375f;
+            const float lg = __builtin_fmaf(__builtin_amdgcn_logf(u1p), 0.693147182464599609375f, sp.min_d);
             t4 = __builtin_fmaf(c, __builtin_amdgcn_rcpf(u1p), lg);
         } else {
-            d = sp.min_d + t4;
+            d = __builtin_fmaxf(t3, 0.0f) + t4;
         }
     }
 

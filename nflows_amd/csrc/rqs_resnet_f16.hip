@@ -65,6 +65,23 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 namespace k8h {
 
+// Timing ablations (tools/k8h_ablation.sh; results are garbage, never part of the product build):
+//   -DNFA_ABL_NO_MFMA     the matrix instructions are left out (fragment reads, barriers, VALU work stay)
+//   -DNFA_ABL_NO_WEAVE    no spline evaluation and no piece conversion behind the MFMAs
+//   -DNFA_ABL_NO_FRAGS    the weight fragments are not re-read from LDS (same registers for every MFMA)
+//   -DNFA_ABL_NO_BARRIER  the stage barriers are left out (the counted waits stay)
+//   -DNFA_ABL_NO_DMA      no LDS-DMA requests (the ring keeps whatever it holds)
+#ifdef NFA_ABL_NO_MFMA
+#define NFA_K8H_MFMA(a, b, c, x, y, z) (c)
+#else
+#define NFA_K8H_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)
+#endif
+#ifdef NFA_ABL_NO_WEAVE
+#define NFA_K8H_WEAVE(call)
+#else
+#define NFA_K8H_WEAVE(call) call
+#endif
+
 constexpr int kStageVec4 = 1024;   // 16 KB: eight (hi, lo) fragment pairs of [64 lanes] x 16 B = two k-steps of a
                                    // k-major GEMM or one 32-row tile of the final layer (one barrier each)
 constexpr int kPairs = 8;          // fragment pairs per stage
@@ -113,11 +130,13 @@ __device__ __forceinline__ void stream_request(SM& sm) {
     const int wave = __builtin_amdgcn_readfirstlane(sm.tid >> 6);
     char* slot = reinterpret_cast<char*>(sm.ring) + dst_slot * (kStageVec4 * 16) + wave * (kWave * 16);
     const unsigned lane_off = (unsigned)sm.tid * 16u;
+#ifndef NFA_ABL_NO_DMA
 #pragma unroll
     for (int i = 0; i < 16 / NW; ++i)
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)((stage + i * kThreads * 16) + lane_off),
             (__attribute__((address_space(3))) void*)(slot + i * kThreads * 16), 16, 0, 0);
+#endif
     sm.fetch = (sm.fetch + 1 == sm.num_stages) ? 0 : sm.fetch + 1;
 }
 
@@ -127,8 +146,13 @@ __device__ __forceinline__ void stream_request(SM& sm) {
 // it still issues the MFMAs of the current one (no LDS latency in front of any MFMA).
 template <class SM>
 __device__ __forceinline__ void stream_advance(SM& sm) {
+#ifdef NFA_ABL_NO_BARRIER
+    if constexpr (SM::NW == 8) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     if constexpr (SM::NW == 8) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     sm.slot = (sm.slot + 1 == kRing) ? 0 : sm.slot + 1;
 }
 
@@ -161,6 +185,10 @@ __device__ __forceinline__ void stage_begin(SM& sm, unsigned& cur, unsigned& nxt
 template <int G>
 __device__ __forceinline__ Frags next_frags(unsigned cur, unsigned nxt) {
     Frags f;
+#ifdef NFA_ABL_NO_FRAGS
+    asm volatile("" : "=v"(f.h), "=v"(f.l) : "v"(cur), "v"(nxt));
+    return f;
+#endif
     if constexpr (G < kPairs - 1) {
         asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
                      : "=v"(f.h), "=v"(f.l)
@@ -173,6 +201,10 @@ __device__ __forceinline__ Frags next_frags(unsigned cur, unsigned nxt) {
 
 // `fr` has landed (its successor's two reads are the only younger requests of this wave)
 __device__ __forceinline__ void await_frags(Frags& fr) {
+#ifdef NFA_ABL_NO_FRAGS
+    asm volatile("" : "+v"(fr.h), "+v"(fr.l));
+    return;
+#endif
     asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fr.h), "+v"(fr.l));
 }
 
@@ -451,17 +483,17 @@ __device__ __forceinline__ void tile_kstep(f32x16& acc, uvec4 bhw, uvec4 blw, Fr
     const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);
     fr = nf;
     // (smallest terms first)
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+    acc = NFA_K8H_MFMA(al, bh, acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    w.template step<KS * 3 + 0>();
+    NFA_K8H_WEAVE(w.template step<KS * 3 + 0>());
     __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    acc = NFA_K8H_MFMA(ah, bl, acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    w.template step<KS * 3 + 1>();
+    NFA_K8H_WEAVE(w.template step<KS * 3 + 1>());
     __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+    acc = NFA_K8H_MFMA(ah, bh, acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    w.template step<KS * 3 + 2>();
+    NFA_K8H_WEAVE(w.template step<KS * 3 + 2>());
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -492,17 +524,17 @@ __device__ __forceinline__ void kstep_pair_woven(f32x16 (&acc)[4], uvec4 bh0, uv
         await_frags(fr);                                                                         \
         const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);  \
         fr = nf;                                                                                 \
-        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, BH, acc[T], 0, 0, 0);                \
+        acc[T] = NFA_K8H_MFMA(al, BH, acc[T], 0, 0, 0);                \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        w.template step<SLOT + 0>();                                                             \
+        NFA_K8H_WEAVE(w.template step<SLOT + 0>());                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, BL, acc[T], 0, 0, 0);                \
+        acc[T] = NFA_K8H_MFMA(ah, BL, acc[T], 0, 0, 0);                \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        w.template step<SLOT + 1>();                                                             \
+        NFA_K8H_WEAVE(w.template step<SLOT + 1>());                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, BH, acc[T], 0, 0, 0);                \
+        acc[T] = NFA_K8H_MFMA(ah, BH, acc[T], 0, 0, 0);                \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        w.template step<SLOT + 2>();                                                             \
+        NFA_K8H_WEAVE(w.template step<SLOT + 2>());                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     }
     unsigned cur, nxt;
