@@ -86,7 +86,8 @@ constexpr int kStageVec4 = 1024;   // 16 KB: eight (hi, lo) fragment pairs of [6
                                    // k-major GEMM or one 32-row tile of the final layer (one barrier each)
 constexpr int kPairs = 8;          // fragment pairs per stage
 constexpr int kParamVec4 = 512;    // a parameter stage carries 2048 words in its first 8 KB
-constexpr int kRing = 4;           // three stages in flight behind the one being consumed
+constexpr int kRing = 4;           // rigid ring: three stages in flight behind the one being consumed
+constexpr int kRingElastic = 5;    // elastic ring (below): one more slot for the waves that are a stage behind
 constexpr int kRowPad = 33;
 constexpr int kTabId = 0, kTabTr = 64, kTabWords = 128;   // parameter words [0, 128): slots of identity / transformed features
 constexpr int kHdr = 4;            // floats in front of every GEMM's biases: {out_scale, skip_scale, 0, 0}
@@ -101,7 +102,7 @@ struct Args {
     int32_t* redo;             // [batch / 128]: 1 = block not written, run the exact kernel on it
     int32_t* status;
     int64_t batch;
-    int D, dt, di, num_blocks, num_layers, num_stages, param_stages, accumulate;
+    int D, dt, di, num_blocks, num_layers, num_stages, param_stages, param_words, accumulate;
     RqsDev sp;
     unsigned long long* trace;  // debug: [gridDim.x][64] cycle stamps of wave 0 (first row block), null = off
     int normal, skip_out;       // NFA_FLAG_STANDARD_NORMAL_LOG_PROB / NFA_FLAG_SKIP_OUTPUTS
@@ -113,19 +114,49 @@ struct Args {
 
 #define NFA_HSTAMP() if (tr && ti < 63) tr[ti++] = __builtin_readcyclecounter();
 
-// NW = waves per workgroup (4 or 8) sharing the ring
-template <int NW_>
+// NW = waves per workgroup (4 or 8) sharing the ring; RING = slots of 16 KB.
+//
+// RING == kRing (4), the rigid stream: one workgroup barrier at the end of every stage.
+//
+// RING == kRingElastic (5), the elastic stream (round 3).  The per-stage barrier is what keeps the eight waves
+// of a workgroup in lock step -- every stage all of them wait for the slowest, and the two waves of a SIMD meet
+// the same phase (fragment waits, VALU-heavy slices, DMA issue) at the same time (timing ablation: the kernel
+// without its stage barriers runs 26 % faster, profiles/r3/k8h_ablation.txt).  Here a wave may be ONE stage
+// ahead of the slowest one.  sync[slot] counts, per use of the slot, the waves that have (a) finished the
+// stage two before the one the slot holds and (b) seen their own share of the slot's stage land:
+//   end of stage s     own share of s + 2 landed (vmcnt), own reads of s done (lgkmcnt) -> sync[s + 2] += 1
+//   inside stage s     before the first read of stage s + 1 (the fragment pair prefetched behind the last MFMAs
+//                      of s): wait for sync[s + 1] == NW x generation: stage s + 1 is complete, and every wave
+//                      has left stage s - 1
+//   begin of stage s   request stage s + 3 into the slot of stage s - 2 (free: see the previous line, one
+//                      stage earlier).  Three stages in flight as in the rigid ring; slot s - 1 is the one a
+//                      straggler may still be reading.
+// The counter is read at the beginning of the stage (the value is awaited behind the fragment reads, no
+// extra latency) and polled only if that early value was not enough.  Parameter stages end with a real barrier
+// (their contents are copied by all threads for all waves).
+template <int NW_, int RING_>
 struct WeightStream {
-    static constexpr int NW = NW_;
+    static constexpr int NW = NW_, RING = RING_;
+    static constexpr bool ELASTIC = RING_ == kRingElastic;
     const vec4f* w;
     vec4f* ring;
     int slot, fetch, num_stages, tid;
+    unsigned sync;       // ELASTIC: LDS byte address of the [RING] counters
+    unsigned gen;        // ELASTIC: NW x (uses of the current stage's slot so far, this one included)
+    unsigned peek;       // ELASTIC: sync[next slot] as read at the beginning of the stage
 };
+
+template <class SM>
+__device__ __forceinline__ int ring_next(int slot, int by = 1) {
+    const int t = slot + by;
+    return t >= SM::RING ? t - SM::RING : t;
+}
 
 template <class SM>
 __device__ __forceinline__ void stream_request(SM& sm) {
     constexpr int NW = SM::NW, kThreads = NW * kWave;
-    const int dst_slot = sm.slot >= 1 ? sm.slot - 1 : kRing - 1;  // (slot + kRing - 1) % kRing
+    // rigid: the slot of the stage just finished (slot - 1); elastic: the one before that (slot - 2)
+    const int dst_slot = ring_next<SM>(sm.slot, SM::ELASTIC ? SM::RING - 2 : SM::RING - 1);
     const char* stage = reinterpret_cast<const char*>(sm.w) + (size_t)sm.fetch * (kStageVec4 * 16);
     const int wave = __builtin_amdgcn_readfirstlane(sm.tid >> 6);
     char* slot = reinterpret_cast<char*>(sm.ring) + dst_slot * (kStageVec4 * 16) + wave * (kWave * 16);
@@ -140,20 +171,57 @@ __device__ __forceinline__ void stream_request(SM& sm) {
     sm.fetch = (sm.fetch + 1 == sm.num_stages) ? 0 : sm.fetch + 1;
 }
 
-// end of stage s: this wave's requests of stage s + 2 have landed (those of stage s + 3 may still be in
-// flight: 16 / NW per wave), every wave is done reading stage s.  Stage s + 1 was complete one
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
+}
+
+// ELASTIC, inside stage s, in front of the first read of stage s + 1: that stage is complete and the slot the
+// next request goes to is free.  Fast path: the counter value read at the beginning of the stage (it is older
+// than every fragment read still in flight: two of them at the call sites) already says so.
+template <class SM>
+__device__ __forceinline__ void stream_ensure_next(SM& sm) {
+    if constexpr (SM::ELASTIC) {
+        const unsigned need = sm.gen + (sm.slot + 1 == SM::RING ? SM::NW : 0);
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(sm.peek));
+        unsigned seen = __builtin_amdgcn_readfirstlane(sm.peek);
+        if (seen < need) {
+            const unsigned c = sm.sync + 4u * (unsigned)ring_next<SM>(sm.slot);
+            do {
+                __builtin_amdgcn_s_sleep(1);
+                unsigned v;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(c) : "memory");
+                seen = __builtin_amdgcn_readfirstlane(v);
+            } while (seen < need);
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
+// end of stage s.  Rigid: this wave's requests of stage s + 2 have landed (those of stage s + 3 may still be
+// in flight: 16 / NW per wave), every wave is done reading stage s (barrier).  Stage s + 1 was complete one
 // barrier earlier, which is what lets a wave read the first weight fragments of the NEXT stage while
 // it still issues the MFMAs of the current one (no LDS latency in front of any MFMA).
+// Elastic: the same two waits, then the wave's tick on the counter of stage s + 2; `barrier` (parameter
+// stages) additionally brings the workgroup together.
 template <class SM>
-__device__ __forceinline__ void stream_advance(SM& sm) {
+__device__ __forceinline__ void stream_advance(SM& sm, bool barrier = false) {
+    if constexpr (SM::ELASTIC) {
+        if constexpr (SM::NW == 8) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        if ((sm.tid & 63) == 0)
+            asm volatile("ds_add_u32 %0, %1" ::"v"(sm.sync + 4u * (unsigned)ring_next<SM>(sm.slot, 2)), "v"(1u) : "memory");
+        if (barrier) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (sm.slot + 1 == SM::RING) sm.gen += SM::NW;
+    } else {
 #ifdef NFA_ABL_NO_BARRIER
-    if constexpr (SM::NW == 8) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (SM::NW == 8) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 #else
-    if constexpr (SM::NW == 8) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (SM::NW == 8) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
-    sm.slot = (sm.slot + 1 == kRing) ? 0 : sm.slot + 1;
+    }
+    sm.slot = ring_next<SM>(sm.slot);
 }
 
 // A weight stage is eight fragment pairs (hi, lo pieces of a 32 x 16 weight block): pair g at byte
@@ -164,17 +232,15 @@ struct Frags {
     vec4f h, l;
 };
 
-__device__ __forceinline__ unsigned lds_address(const void* p) {
-    return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
-}
-
 // (cur / nxt: LDS byte addresses of this lane's 16 bytes in the current / the next stage)
 template <class SM>
 __device__ __forceinline__ void stage_begin(SM& sm, unsigned& cur, unsigned& nxt, int lane) {
     stream_request(sm);
     const unsigned base = lds_address(sm.ring) + (unsigned)lane * 16u;
     cur = base + (unsigned)sm.slot * (kStageVec4 * 16);
-    nxt = base + (unsigned)(sm.slot + 1 == kRing ? 0 : sm.slot + 1) * (kStageVec4 * 16);
+    nxt = base + (unsigned)ring_next<SM>(sm.slot) * (kStageVec4 * 16);
+    if constexpr (SM::ELASTIC)   // the next stage's counter, awaited in stream_ensure_next
+        asm volatile("ds_read_b32 %0, %1" : "=v"(sm.peek) : "v"(sm.sync + 4u * (unsigned)ring_next<SM>(sm.slot)));
 }
 
 // The fragment reads are written as asm: hipcc waits for every LDS read it knows about with
@@ -475,9 +541,10 @@ struct SplineWeave10 {
 };
 
 // ---- one 32-row output tile: 8 k-steps x 3 products, two stages, a weave slice behind every MFMA
-template <int KS, class W>
-__device__ __forceinline__ void tile_kstep(f32x16& acc, uvec4 bhw, uvec4 blw, Frags& fr, unsigned cur, unsigned nxt, W& w) {
+template <int KS, class W, class SM>
+__device__ __forceinline__ void tile_kstep(f32x16& acc, uvec4 bhw, uvec4 blw, Frags& fr, unsigned cur, unsigned nxt, W& w, SM& sm) {
     const f16x8 bh = __builtin_bit_cast(f16x8, bhw), bl = __builtin_bit_cast(f16x8, blw);
+    if constexpr (KS == kPairs - 1) stream_ensure_next(sm);   // (the next read goes to the next stage)
     const Frags nf = next_frags<KS>(cur, nxt);   // the next k-step's fragments, three MFMAs ahead of their use
     await_frags(fr);
     const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);
@@ -502,14 +569,14 @@ __device__ __forceinline__ void tile_gemm(f32x16& acc, const uvec4 (&ph)[8], con
                                           int lane, W&& w) {
     unsigned cur, nxt;
     stage_begin(sm, cur, nxt, lane);
-    tile_kstep<0>(acc, ph[0], pl[0], fr, cur, nxt, w);
-    tile_kstep<1>(acc, ph[1], pl[1], fr, cur, nxt, w);
-    tile_kstep<2>(acc, ph[2], pl[2], fr, cur, nxt, w);
-    tile_kstep<3>(acc, ph[3], pl[3], fr, cur, nxt, w);
-    tile_kstep<4>(acc, ph[4], pl[4], fr, cur, nxt, w);
-    tile_kstep<5>(acc, ph[5], pl[5], fr, cur, nxt, w);
-    tile_kstep<6>(acc, ph[6], pl[6], fr, cur, nxt, w);
-    tile_kstep<7>(acc, ph[7], pl[7], fr, cur, nxt, w);
+    tile_kstep<0>(acc, ph[0], pl[0], fr, cur, nxt, w, sm);
+    tile_kstep<1>(acc, ph[1], pl[1], fr, cur, nxt, w, sm);
+    tile_kstep<2>(acc, ph[2], pl[2], fr, cur, nxt, w, sm);
+    tile_kstep<3>(acc, ph[3], pl[3], fr, cur, nxt, w, sm);
+    tile_kstep<4>(acc, ph[4], pl[4], fr, cur, nxt, w, sm);
+    tile_kstep<5>(acc, ph[5], pl[5], fr, cur, nxt, w, sm);
+    tile_kstep<6>(acc, ph[6], pl[6], fr, cur, nxt, w, sm);
+    tile_kstep<7>(acc, ph[7], pl[7], fr, cur, nxt, w, sm);
     stream_advance(sm);
 }
 
@@ -520,6 +587,7 @@ __device__ __forceinline__ void kstep_pair_woven(f32x16 (&acc)[4], uvec4 bh0, uv
                                                  Frags& fr, int lane, W&& w) {
 #define NFA_K8H_CELL(T, G, SLOT, BH, BL)                                                         \
     {                                                                                            \
+        if (G == kPairs - 1) stream_ensure_next(sm);                                             \
         const Frags nf = next_frags<G>(cur, nxt);                                                \
         await_frags(fr);                                                                         \
         const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);  \
@@ -632,7 +700,7 @@ __device__ __forceinline__ bool not_finite(float v) { return !(__builtin_fabsf(v
 // h + (W_1 relu(u) + b_1) * sigmoid(W_c context + b_c): the second Linear then has accumulators of its own
 // (its input pieces are finished first: u's registers are needed), the gate's Linear is one more stage
 // (two k-steps, k-major) and the residual stream takes the product in.
-template <bool INVERSE, int INIT_KS, int NW, int KB = 8, bool CTX = false>
+template <bool INVERSE, int INIT_KS, int NW, int KB = 8, bool CTX = false, int RING = kRing>
 __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Args a) {
     static_assert(!CTX || INIT_KS == 4, "context: two identity k-steps + two context k-steps");
     constexpr int kThreads = NW * kWave;
@@ -640,6 +708,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     __shared__ int s_final[128];
     __shared__ int s_bad[NW];
+    __shared__ unsigned s_sync[8];   // elastic stream: per-slot counters (WeightStream)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = a.D, dt = a.dt;
     int my_status = 0;
@@ -650,27 +719,35 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no ordinary load in flight once the stream starts)
 
-    WeightStream<NW> sm;
+    using Stream = WeightStream<NW, RING>;
+    Stream sm;
     sm.w = a.w;
     sm.ring = reinterpret_cast<vec4f*>(lds_dyn);
     sm.fetch = 0;
     sm.num_stages = a.num_stages * a.num_layers;
     sm.tid = tid;
+    sm.sync = lds_address(s_sync);
+    sm.gen = NW;
+    sm.peek = 0;
+    // stages 0 .. 2 -> slots 0 .. 2 (three stages in flight in both forms of the ring)
 #pragma unroll
-    for (int j = 0; j < kRing - 1; ++j) {   // stages 0 .. kRing-2 -> slots 0 .. kRing-2
-        sm.slot = j + 1 == kRing ? 0 : j + 1;
+    for (int j = 0; j < 3; ++j) {
+        sm.slot = ring_next<Stream>(j, Stream::ELASTIC ? 2 : 1);   // (stream_request targets slot - 2 / slot - 1)
         stream_request(sm);
     }
     sm.slot = 0;
+    // (elastic: stages 0 and 1 are complete after the barrier below and never get ticks: start at NW)
+    if (tid < 8) s_sync[tid] = tid < 2 ? NW : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     Frags fr;   // the weight fragments the next MFMAs need (carried across stages, layers and row blocks)
     fr.h = sm.ring[lane];
     fr.l = sm.ring[64 + lane];
 
-    float* s_row = lds_dyn + kRing * kStageVec4 * 4 + wave * D * kRowPad;
-    float* s_param = lds_dyn + kRing * kStageVec4 * 4 + NW * D * kRowPad;   // [2][param_stages * 2048 words]
-    const int param_words = a.param_stages * (kParamVec4 * 4);
+    // a layer's parameter words live in one of two blocks of `pblock` floats (the words actually used)
+    const int pblock = (a.param_words + 3) & ~3;
+    float* s_row = lds_dyn + RING * kStageVec4 * 4 + wave * D * kRowPad;
+    float* s_param = lds_dyn + RING * kStageVec4 * 4 + NW * D * kRowPad;   // [2][pblock]
     const int groups = dt >> 2;
     const int64_t num_quads = a.batch / (32 * NW);   // row blocks of this workgroup size
     int pb = 0;  // which parameter block the current layer uses
@@ -749,13 +826,14 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
             // ---- the layer's parameter stage(s): ring -> parameter block `pb` (table entries clamped
             //      and checked on the way).  Nobody reads block pb any more: its previous user was the
             //      layer before the last, a whole layer of stage barriers ago.
-            float* prm = s_param + pb * param_words;
+            float* prm = s_param + pb * pblock;
             for (int p = 0; p < a.param_stages; ++p) {
                 unsigned cur, nxt;
                 stage_begin(sm, cur, nxt, lane);
                 const vec4f* src = sm.ring + sm.slot * kStageVec4;
                 vec4f* dst = reinterpret_cast<vec4f*>(prm) + p * kParamVec4;
-                for (int i = tid; i < kParamVec4; i += kThreads) {
+                const int used = (pblock >> 2) - p * kParamVec4;   // vec4s of this stage that carry words
+                for (int i = tid; i < (used < kParamVec4 ? used : kParamVec4); i += kThreads) {
                     vec4f v = src[i];
                     if (p == 0 && i < kTabWords / 4) {
                         // (whole-vector bit casts: a bit cast of a single vector ELEMENT reads element 0)
@@ -764,17 +842,18 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                         for (int c = 0; c < 4; ++c) {
                             const int idx = i * 4 + c;
                             const int e = (int)u[c];
-                            const bool used = idx < kTabTr ? idx < a.di : idx - kTabTr < dt;
-                            if (used && (e < 0 || e >= D)) my_status |= NFA_STATUS_BAD_INDEX;
+                            const bool used_entry = idx < kTabTr ? idx < a.di : idx - kTabTr < dt;
+                            if (used_entry && (e < 0 || e >= D)) my_status |= NFA_STATUS_BAD_INDEX;
                             u[c] = (unsigned)(e < 0 ? 0 : (e >= D ? D - 1 : e));
                         }
                         v = __builtin_bit_cast(vec4f, u);
                     }
                     dst[i] = v;
                 }
+                stream_ensure_next(sm);
                 fr = next_frags<kPairs - 1>(cur, nxt);   // pair 0 of the stage behind this one (a weight stage after the last p)
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr.h), "+v"(fr.l));
-                stream_advance(sm);
+                stream_advance(sm, true);   // (every wave reads the parameter block all threads have just written)
             }
             const int* tab = reinterpret_cast<const int*>(prm);
             const float* gemm = prm + kTabWords;   // header + biases of the next GEMM
@@ -1100,6 +1179,7 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     a.num_blocks = num_blocks;
     a.num_layers = num_layers;
     a.param_stages = param_stages;
+    a.param_words = param_words;
     const int init_ks = (with_ctx || num_identity > 32) ? 4 : 2;
     a.num_stages = param_stages + init_ks / 2 + (with_ctx ? 9 : 8) * num_blocks + num_transform * rows_per_feature / 32;
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
@@ -1108,15 +1188,21 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     // every CU one; otherwise four waves (128 rows)
     const int cus = device_cu_count();
     static const int force_nw = getenv("NFA_K8H_WAVES") ? atoi(getenv("NFA_K8H_WAVES")) : 0;
+    static const int force_ring = getenv("NFA_K8H_RING") ? atoi(getenv("NFA_K8H_RING")) : 0;   // 4: rigid stream always
     int nw = ((batch & 255) == 0 && (batch >> 8) >= cus) ? 8 : 4;
     if (force_nw == 4 || (force_nw == 8 && (batch & 255) == 0)) nw = force_nw;
-    auto lds_for = [&](int n) {
-        return (size_t)k8h::kRing * k8h::kStageVec4 * 16 + (size_t)n * features * k8h::kRowPad * sizeof(float) +
-               (size_t)2 * param_stages * k8h::kParamVec4 * 16;
+    const size_t lds_static = 1024;   // s_final, s_bad, s_sync (rounded up)
+    const size_t lds_cap = 160 * 1024 - lds_static;
+    auto lds_for = [&](int n, int ring) {
+        return (size_t)ring * k8h::kStageVec4 * 16 + (size_t)n * features * k8h::kRowPad * sizeof(float) +
+               (size_t)2 * ((param_words + 3) & ~3) * sizeof(float);
     };
-    if (lds_for(nw) + 2048 > 160 * 1024) nw = 4;
-    const size_t lds_launch = lds_for(nw);
-    if (lds_launch + 2048 > 160 * 1024) return NFA_ERR_UNSUPPORTED;
+    if (lds_for(nw, k8h::kRing) > lds_cap) nw = 4;
+    if (lds_for(nw, k8h::kRing) > lds_cap) return NFA_ERR_UNSUPPORTED;
+    // the elastic stream (five slots, counters instead of the per-stage barrier) where it fits: eight-wave
+    // workgroups of the 8-bin kernel without a context (the bench's shape: 161 984 bytes at D = 64)
+    const bool elastic = nw == 8 && !with_ctx && a.sp.K == 8 && force_ring != 4 && lds_for(8, k8h::kRingElastic) <= lds_cap;
+    const size_t lds_launch = lds_for(nw, elastic ? k8h::kRingElastic : k8h::kRing);
     int64_t blocks = batch / (32 * nw);
     const int64_t per_cu = (nw == 4 && lds_launch + 2048 <= 80 * 1024) ? 2 : 1;
     const int64_t cap = (int64_t)cus * per_cu;
@@ -1127,9 +1213,14 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     const dim3 grid((unsigned)blocks), block(nw * kWave);
     const bool inv = (flags & NFA_FLAG_INVERSE) != 0;
     void (*kern)(const k8h::Args) = nullptr;
-    const int which = with_ctx ? 16 + (inv ? 1 : 0) + (nw == 8 ? 2 : 0) + (a.sp.K == 10 ? 4 : 0)
-                               : (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0) + (a.sp.K == 10 ? 8 : 0);
+    int which = with_ctx ? 16 + (inv ? 1 : 0) + (nw == 8 ? 2 : 0) + (a.sp.K == 10 ? 4 : 0)
+                         : (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0) + (a.sp.K == 10 ? 8 : 0);
+    if (elastic) which = 24 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0);
     switch (which) {
+        case 24: kern = k8h::rqs_resnet_f16_kernel<false, 2, 8, 8, false, k8h::kRingElastic>; break;
+        case 25: kern = k8h::rqs_resnet_f16_kernel<true, 2, 8, 8, false, k8h::kRingElastic>; break;
+        case 26: kern = k8h::rqs_resnet_f16_kernel<false, 4, 8, 8, false, k8h::kRingElastic>; break;
+        case 27: kern = k8h::rqs_resnet_f16_kernel<true, 4, 8, 8, false, k8h::kRingElastic>; break;
         case 16: kern = k8h::rqs_resnet_f16_kernel<false, 4, 4, 8, true>; break;
         case 17: kern = k8h::rqs_resnet_f16_kernel<true, 4, 4, 8, true>; break;
         case 18: kern = k8h::rqs_resnet_f16_kernel<false, 4, 8, 8, true>; break;
@@ -1156,9 +1247,9 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
         default: kern = k8h::rqs_resnet_f16_kernel<true, 4, 8, 10>; break;
     }
     if (lds_launch > 64 * 1024) {
-        static unsigned long long raised[24] = {};   // device masks (raise_dynamic_lds)
+        static unsigned long long raised[28] = {};   // device masks (raise_dynamic_lds)
         {
-            const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], 160 * 1024 - 2048);
+            const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], (int)lds_cap);
             if (rc_lds != NFA_OK) return rc_lds;
         }
     }
