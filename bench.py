@@ -433,7 +433,7 @@ def main():
                 bytes_ = io_bytes + k8_weights if path == "k8" else (io_bytes + 4 * B * H_) * layers_per_launch
                 traffic_file = ("k8h_pmc_traffic.json" if f16 else "k8_pmc_traffic.json") if path == "k8" else "k7b_pmc_traffic.json"
                 nw8 = B % 256 == 0 and B // 256 >= 256
-                ring = 5 if (nw8 and os.environ.get("NFA_K8H_RING", "") != "4") else 4   # (elastic stream: DESIGN.md section 4)
+                ring = 5 if (nw8 and os.environ.get("NFA_K8H_RING", "") == "5") else 4   # (5: the elastic-stream experiment)
                 kernel = ("nfa::k8h::rqs_resnet_f16_kernel<false, 2, %d, 8, false, %d>" % (8 if nw8 else 4, ring) if f16
                           else "nfa::rqs_resnet_kernel<false, 1, 2, %s, 8, false>" % os.environ.get("NFA_K8_PIPE", "2")) if path == "k8" \
                     else "nfa::rqs_fused_linear_bf16_kernel<false>"

@@ -144,6 +144,7 @@ struct WeightStream {
     unsigned sync;       // ELASTIC: LDS byte address of the [RING] counters
     unsigned gen;        // ELASTIC: NW x (uses of the current stage's slot so far, this one included)
     unsigned peek;       // ELASTIC: sync[next slot] as read at the beginning of the stage
+    int cell;            // the MFMA cell (0 .. 7) of a stage in which this wave issues its LDS-DMA requests
 };
 
 template <class SM>
@@ -233,9 +234,21 @@ struct Frags {
 };
 
 // (cur / nxt: LDS byte addresses of this lane's 16 bytes in the current / the next stage)
+#ifndef NFA_K8H_DMA_STAGGER
+#define NFA_K8H_DMA_STAGGER 0
+#endif
+
+// NFA_K8H_DMA_STAGGER: 0 = every wave issues its requests at the beginning of the stage (all eight at once,
+// right behind the barrier); 1 / 2 = wave w issues them in MFMA cell w of the stage, in front of / behind the
+// cell's first MFMA (one requesting wave at a time; the target slot is free for the whole stage).
+template <int CELL, class SM>
+__device__ __forceinline__ void stream_request_at(SM& sm) {
+    if (sm.cell == CELL) stream_request(sm);
+}
+
 template <class SM>
-__device__ __forceinline__ void stage_begin(SM& sm, unsigned& cur, unsigned& nxt, int lane) {
-    stream_request(sm);
+__device__ __forceinline__ void stage_begin(SM& sm, unsigned& cur, unsigned& nxt, int lane, bool request_now = NFA_K8H_DMA_STAGGER == 0) {
+    if (request_now) stream_request(sm);
     const unsigned base = lds_address(sm.ring) + (unsigned)lane * 16u;
     cur = base + (unsigned)sm.slot * (kStageVec4 * 16);
     nxt = base + (unsigned)ring_next<SM>(sm.slot) * (kStageVec4 * 16);
@@ -545,6 +558,7 @@ template <int KS, class W, class SM>
 __device__ __forceinline__ void tile_kstep(f32x16& acc, uvec4 bhw, uvec4 blw, Frags& fr, unsigned cur, unsigned nxt, W& w, SM& sm) {
     const f16x8 bh = __builtin_bit_cast(f16x8, bhw), bl = __builtin_bit_cast(f16x8, blw);
     if constexpr (KS == kPairs - 1) stream_ensure_next(sm);   // (the next read goes to the next stage)
+    if constexpr (NFA_K8H_DMA_STAGGER == 1) stream_request_at<KS>(sm);
     const Frags nf = next_frags<KS>(cur, nxt);   // the next k-step's fragments, three MFMAs ahead of their use
     await_frags(fr);
     const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);
@@ -552,6 +566,10 @@ __device__ __forceinline__ void tile_kstep(f32x16& acc, uvec4 bhw, uvec4 blw, Fr
     // (smallest terms first)
     acc = NFA_K8H_MFMA(al, bh, acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NFA_K8H_DMA_STAGGER == 2) {
+        stream_request_at<KS>(sm);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     NFA_K8H_WEAVE(w.template step<KS * 3 + 0>());
     __builtin_amdgcn_sched_barrier(0);
     acc = NFA_K8H_MFMA(ah, bl, acc, 0, 0, 0);
@@ -588,12 +606,17 @@ __device__ __forceinline__ void kstep_pair_woven(f32x16 (&acc)[4], uvec4 bh0, uv
 #define NFA_K8H_CELL(T, G, SLOT, BH, BL)                                                         \
     {                                                                                            \
         if (G == kPairs - 1) stream_ensure_next(sm);                                             \
+        if (NFA_K8H_DMA_STAGGER == 1) stream_request_at<G>(sm);                                  \
         const Frags nf = next_frags<G>(cur, nxt);                                                \
         await_frags(fr);                                                                         \
         const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);  \
         fr = nf;                                                                                 \
         acc[T] = NFA_K8H_MFMA(al, BH, acc[T], 0, 0, 0);                \
         __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (NFA_K8H_DMA_STAGGER == 2) {                                                          \
+            stream_request_at<G>(sm);                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
         NFA_K8H_WEAVE(w.template step<SLOT + 0>());                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         acc[T] = NFA_K8H_MFMA(ah, BL, acc[T], 0, 0, 0);                \
@@ -729,6 +752,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
     sm.sync = lds_address(s_sync);
     sm.gen = NW;
     sm.peek = 0;
+    sm.cell = __builtin_amdgcn_readfirstlane(wave) * (8 / NW);
     // stages 0 .. 2 -> slots 0 .. 2 (three stages in flight in both forms of the ring)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -829,7 +853,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
             float* prm = s_param + pb * pblock;
             for (int p = 0; p < a.param_stages; ++p) {
                 unsigned cur, nxt;
-                stage_begin(sm, cur, nxt, lane);
+                stage_begin(sm, cur, nxt, lane, true);   // (no MFMA cells in a parameter stage)
                 const vec4f* src = sm.ring + sm.slot * kStageVec4;
                 vec4f* dst = reinterpret_cast<vec4f*>(prm) + p * kParamVec4;
                 const int used = (pblock >> 2) - p * kParamVec4;   // vec4s of this stage that carry words
@@ -1188,7 +1212,7 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     // every CU one; otherwise four waves (128 rows)
     const int cus = device_cu_count();
     static const int force_nw = getenv("NFA_K8H_WAVES") ? atoi(getenv("NFA_K8H_WAVES")) : 0;
-    static const int force_ring = getenv("NFA_K8H_RING") ? atoi(getenv("NFA_K8H_RING")) : 0;   // 4: rigid stream always
+    static const int force_ring = getenv("NFA_K8H_RING") ? atoi(getenv("NFA_K8H_RING")) : 0;   // 5: elastic stream (experiment, slower)
     int nw = ((batch & 255) == 0 && (batch >> 8) >= cus) ? 8 : 4;
     if (force_nw == 4 || (force_nw == 8 && (batch & 255) == 0)) nw = force_nw;
     const size_t lds_static = 1024;   // s_final, s_bad, s_sync (rounded up)
@@ -1201,7 +1225,7 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     if (lds_for(nw, k8h::kRing) > lds_cap) return NFA_ERR_UNSUPPORTED;
     // the elastic stream (five slots, counters instead of the per-stage barrier) where it fits: eight-wave
     // workgroups of the 8-bin kernel without a context (the bench's shape: 161 984 bytes at D = 64)
-    const bool elastic = nw == 8 && !with_ctx && a.sp.K == 8 && force_ring != 4 && lds_for(8, k8h::kRingElastic) <= lds_cap;
+    const bool elastic = nw == 8 && !with_ctx && a.sp.K == 8 && force_ring == 5 && lds_for(8, k8h::kRingElastic) <= lds_cap;
     const size_t lds_launch = lds_for(nw, elastic ? k8h::kRingElastic : k8h::kRing);
     int64_t blocks = batch / (32 * nw);
     const int64_t per_cu = (nw == 4 && lds_launch + 2048 <= 80 * 1024) ? 2 : 1;
