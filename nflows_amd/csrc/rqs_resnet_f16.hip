@@ -69,12 +69,22 @@ namespace k8h {
 //   -DNFA_ABL_NO_MFMA     the matrix instructions are left out (fragment reads, barriers, VALU work stay)
 //   -DNFA_ABL_NO_WEAVE    no spline evaluation and no piece conversion behind the MFMAs
 //   -DNFA_ABL_NO_FRAGS    the weight fragments are not re-read from LDS (same registers for every MFMA)
+//   -DNFA_ABL_CONST_FRAGS as NO_FRAGS, but the registers keep REAL weights (the first fragment pair of the layer):
+//                         the matrix instructions see a constant, non-trivial A operand
 //   -DNFA_ABL_NO_BARRIER  the stage barriers are left out (the counted waits stay)
 //   -DNFA_ABL_NO_DMA      no LDS-DMA requests (the ring keeps whatever it holds)
+#ifdef NFA_ABL_CONST_FRAGS
+#define NFA_ABL_NO_FRAGS
+#endif
 #ifdef NFA_ABL_NO_MFMA
 #define NFA_K8H_MFMA(a, b, c, x, y, z) (c)
 #else
 #define NFA_K8H_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)
+#endif
+#ifdef NFA_ABL_CONST_FRAGS
+#define NFA_K8H_KEEP_FRAGS(fr, nf) (void)nf;
+#else
+#define NFA_K8H_KEEP_FRAGS(fr, nf) fr = nf;
 #endif
 #ifdef NFA_ABL_NO_WEAVE
 #define NFA_K8H_WEAVE(call)
@@ -268,6 +278,16 @@ __device__ __forceinline__ Frags next_frags(unsigned cur, unsigned nxt) {
     asm volatile("" : "=v"(f.h), "=v"(f.l) : "v"(cur), "v"(nxt));
     return f;
 #endif
+#ifdef NFA_ABL_DOUBLE_FRAGS   // (energy probe: every fragment pair is read twice into the same registers)
+    if constexpr (G < kPairs - 1) {
+        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\tds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                     : "=v"(f.h), "=v"(f.l)
+                     : "v"(cur), "i"((G + 1) * 2048), "i"((G + 1) * 2048 + 1024));
+    } else {
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=v"(f.h), "=v"(f.l) : "v"(nxt));
+    }
+    return f;
+#endif
     if constexpr (G < kPairs - 1) {
         asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
                      : "=v"(f.h), "=v"(f.l)
@@ -282,6 +302,10 @@ __device__ __forceinline__ Frags next_frags(unsigned cur, unsigned nxt) {
 __device__ __forceinline__ void await_frags(Frags& fr) {
 #ifdef NFA_ABL_NO_FRAGS
     asm volatile("" : "+v"(fr.h), "+v"(fr.l));
+    return;
+#endif
+#ifdef NFA_ABL_DOUBLE_FRAGS
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fr.h), "+v"(fr.l));
     return;
 #endif
     asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fr.h), "+v"(fr.l));
@@ -562,7 +586,11 @@ __device__ __forceinline__ void tile_kstep(f32x16& acc, uvec4 bhw, uvec4 blw, Fr
     const Frags nf = next_frags<KS>(cur, nxt);   // the next k-step's fragments, three MFMAs ahead of their use
     await_frags(fr);
     const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);
+#ifndef NFA_ABL_CONST_FRAGS
     fr = nf;
+#else
+    (void)nf;
+#endif
     // (smallest terms first)
     acc = NFA_K8H_MFMA(al, bh, acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -610,7 +638,7 @@ __device__ __forceinline__ void kstep_pair_woven(f32x16 (&acc)[4], uvec4 bh0, uv
         const Frags nf = next_frags<G>(cur, nxt);                                                \
         await_frags(fr);                                                                         \
         const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);  \
-        fr = nf;                                                                                 \
+        NFA_K8H_KEEP_FRAGS(fr, nf)                                                               \
         acc[T] = NFA_K8H_MFMA(al, BH, acc[T], 0, 0, 0);                \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         if (NFA_K8H_DMA_STAGGER == 2) {                                                          \
@@ -875,7 +903,11 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                     dst[i] = v;
                 }
                 stream_ensure_next(sm);
+#ifdef NFA_ABL_CONST_FRAGS
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=v"(fr.h), "=v"(fr.l) : "v"(nxt));
+#else
                 fr = next_frags<kPairs - 1>(cur, nxt);   // pair 0 of the stage behind this one (a weight stage after the last p)
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr.h), "+v"(fr.l));
                 stream_advance(sm, true);   // (every wave reads the parameter block all threads have just written)
             }
