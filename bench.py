@@ -73,6 +73,74 @@ def dispatch_durations_ms(capacity):
     return [buf[i] for i in range(n.value)]
 
 
+class SmiSampler:
+    """Shader clock and socket power from `rocm-smi`, sampled from a thread while a measurement leg runs (the
+    headline kernel is limited by the chip's power cap, DESIGN.md section 4: the clock it sustains is part of
+    the measurement)."""
+
+    def __init__(self):
+        self.samples = []
+        self._stop = False
+        self._thread = None
+
+    @staticmethod
+    def read():
+        import re
+        import subprocess
+        try:
+            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+        except Exception:
+            return None
+        c = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+        p_ = re.search(r"Graphics Package Power \(W\): ([\d.]+)", out)
+        return (int(c.group(1)) if c else None, float(p_.group(1)) if p_ else None)
+
+    def _run(self):
+        while not self._stop:
+            r = self.read()
+            if r is not None:
+                self.samples.append(r)
+            time.sleep(0.1)
+
+    def __enter__(self):
+        import threading
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        self._thread.join(timeout=15)
+
+    def summary(self):
+        import statistics
+        clk = [c for c, _ in self.samples if c]
+        pw = [p_ for _, p_ in self.samples if p_]
+        if not clk and not pw:
+            return None
+        return {"sclk_mhz_median": statistics.median(clk) if clk else None, "sclk_mhz_min": min(clk) if clk else None,
+                "socket_power_w_median": statistics.median(pw) if pw else None, "samples": len(self.samples),
+                "source": "rocm-smi --showclocks --showpower, sampled during the steady-state leg"}
+
+
+def sustained_mfma_ceiling(seconds=1.5):
+    """tools/bin/mfma_power_probe (built by __graft_entry__.build): the f16 matrix pipe's back-to-back rate
+    under the power cap with zero and with Gaussian operands, measured on this box.  None if the probe is absent."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "bin", "mfma_power_probe")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, str(seconds)], capture_output=True, text=True, timeout=120).stdout
+    except Exception:
+        return None
+    res = {}
+    for kind, shape, val in re.findall(r"mfma_power_probe (\w+) (\w+): ([\d.]+) TFLOP/s", out):
+        res["%s_%s" % (kind, shape)] = float(val)
+    return res or None
+
+
 def log(msg):
     print("[bench %.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
@@ -203,6 +271,8 @@ def main():
     ap.add_argument("--no-fuse-linear", action="store_true",
                     help="leave the conditioner's final Linear to hipBLASLt (GEMM + K1 instead of K7)")
     ap.add_argument("--skip-k1-roofline", action="store_true")
+    ap.add_argument("--skip-mfma-ceiling", action="store_true",
+                    help="do not run tools/bin/mfma_power_probe (the sustained MFMA ceiling under the power cap, ~6 s)")
     ap.add_argument("--skip-graph", action="store_true",
                     help="do not add the HIP-graph replay timing of the same step (extra field)")
     ap.add_argument("--bracket-events", action="store_true",
@@ -313,6 +383,9 @@ def main():
         done, t0 = 0, time.perf_counter()
         if world > 1:
             dist.barrier()
+        smi = SmiSampler() if rank == 0 else None
+        if smi is not None:
+            smi.__enter__()
         while True:
             for _ in range(n_batch):
                 step()
@@ -329,6 +402,9 @@ def main():
         if world > 1:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         steady = {"steps": done, "seconds": dt.item(), "ms_per_step": dt.item() / done * 1e3}
+        if smi is not None:
+            smi.__exit__()
+            steady["clock_and_power"] = smi.summary()
     # extra: 65 536 rows on every GPU (round 1's single-GPU workload; weak scaling for N > 1)
     weak = None
     if args.batch_per_gpu is None and not args.skip_extra:
@@ -471,6 +547,15 @@ def main():
             return r
 
         roofline = roofline_of(args.path, k1_ms, len(k1_ms) / args.steps) if k1_ms else None
+        if roofline is not None and roofline.get("bound") == "mfma" and not args.skip_mfma_ceiling:
+            ceiling = sustained_mfma_ceiling()
+            if ceiling and ceiling.get("gaussian_32x32x16"):
+                roofline["sustained_mfma_ceiling"] = dict(
+                    ceiling, unit="TFLOP/s",
+                    note="v_mfma_f32_32x32x16_f16 issued back to back from registers on every SIMD of this box "
+                         "(tools/mfma_power_probe.hip), by operand data: with zeros the pipe reaches the spec peak, "
+                         "with Gaussian operands the chip's power cap holds it to the `gaussian` figure (clock ~1.75 GHz)")
+                roofline["frac_of_sustained_ceiling"] = roofline["achieved"] / ceiling["gaussian_32x32x16"]
         roofline_k1 = None
         if args.path != "k1" and not args.skip_k1_roofline and world == 1:  # (N = 1 only: the other ranks are done)
             # the HBM-bound spline kernel K1 (what the fused kernels replace on this shape), measured

@@ -36,6 +36,36 @@ def _held_parameters(net):
     return [(m._parameters, name, p) for m in net.modules() for name, p in m._parameters.items() if p is not None]
 
 
+class StalePackedWeights(RuntimeError):
+    """NFA_VERIFY_WEIGHTS: a conditioner's weights changed without any of the signs the packed-weight caches
+    look at (version counters, storage pointers, registrations) -- a write through `.data`, e.g.
+    `p.data.copy_(ema)` or `dist.broadcast(p.data)`.  The fused kernels would have used the OLD weights."""
+
+
+# NFA_VERIFY_WEIGHTS=N (0 = off): every N-th use of a conditioner's cache key re-reads a checksum of its
+# parameters on the device (sum and absolute sum per parameter in float64, one synchronising comparison) and
+# raises StalePackedWeights when it differs from the one taken when the key last changed visibly.
+VERIFY_WEIGHTS_EVERY = int(os.environ.get("NFA_VERIFY_WEIGHTS", "0") or 0)
+
+
+def _checksum(params):
+    with torch.no_grad():
+        return torch.stack([torch.stack((p.detach().double().sum(), p.detach().double().abs().sum())) for p in params])
+
+
+def _verify_weights(owner, key, params):
+    state = owner.__dict__.get("_weights_checksum")
+    if state is None or state[0] != key:
+        owner.__dict__["_weights_checksum"] = [key, _checksum(params), 0]
+        return
+    state[2] += 1
+    if state[2] % VERIFY_WEIGHTS_EVERY == 0 and not torch.equal(_checksum(params), state[1]):
+        owner.__dict__.pop("_weights_checksum", None)
+        raise StalePackedWeights(
+            "the parameters of %s changed through a write the packed-weight caches cannot see (a write through "
+            "`.data`?): call nflows_amd.invalidate_packed_weights() after such writes" % type(owner).__name__)
+
+
 def _weights_key(owner, net):
     """Cheap fingerprint of a conditioner's weights for the packed-weight caches: storage pointers and version
     counters of its parameters, read from a list made once per cache epoch (walking `net.parameters()` costs ~10 us per call and
@@ -43,7 +73,9 @@ def _weights_key(owner, net):
     `load_state_dict` and (re)registered Parameter objects advance the epoch (_cache.py).  Swaps that bypass the
     registration hooks -- `torch.func.functional_call`, `stateless._reparametrize_module`, a direct
     `module._parameters[name] = other` -- are caught by checking on every call that each held object still IS
-    the entry of its module's `_parameters` dict (a dict lookup and an identity test per parameter)."""
+    the entry of its module's `_parameters` dict (a dict lookup and an identity test per parameter).  What no key
+    can see is a write through `.data` into the same storage: NFA_VERIFY_WEIGHTS (above) is the debugging aid for
+    that, `nflows_amd.invalidate_packed_weights()` the remedy."""
     epoch = _cache.epoch()
     held = owner.__dict__.get("_weights_list")
     if held is None or held[0] != epoch or held[1] is not net or not _cache.HOOKED:
@@ -56,7 +88,10 @@ def _weights_key(owner, net):
                 owner.__dict__["_weights_list"] = held
                 break
     # (data_ptr as well: `p.data = other` rebinds the storage without touching the counter)
-    return (epoch,) + tuple([(p.data_ptr(), p._version) for _, _, p in held[2]])
+    key = (epoch,) + tuple([(p.data_ptr(), p._version) for _, _, p in held[2]])
+    if VERIFY_WEIGHTS_EVERY:
+        _verify_weights(owner, key, [p for _, _, p in held[2]])
+    return key
 
 
 class CouplingTransform(Transform):

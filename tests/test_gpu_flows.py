@@ -785,6 +785,30 @@ def test_functional_call_sees_the_supplied_weights():
     assert not torch.equal(z1, z0)
 
 
+def test_verify_weights_mode_on_the_device(monkeypatch):
+    """The whole-layer kernels read packed copies of the conditioner weights: an EMA-style `p.data.copy_()`
+    leaves them stale (documented in nflows_amd/_cache.py).  NFA_VERIFY_WEIGHTS turns the silent wrong answer
+    into StalePackedWeights; invalidate_packed_weights() then gives the result of the new weights."""
+    import copy
+    import nflows_amd
+    from nflows_amd import configs
+    from nflows_amd.transforms import coupling as C
+    flow = configs.rq_nsf_flow(num_layers=4, features=64, num_bins=8, hidden_features=128, seed=0).to(DEV).eval()
+    x = torch.randn(256, 64, generator=torch.Generator().manual_seed(5)).to(DEV)
+    monkeypatch.setattr(C, "VERIFY_WEIGHTS_EVERY", 1)
+    with torch.no_grad():
+        lp0 = flow.log_prob(x)
+        assert torch.equal(flow.log_prob(x), lp0)
+        for p in flow.parameters():
+            p.data.mul_(1.05)
+        with pytest.raises(C.StalePackedWeights):
+            flow.log_prob(x)
+        nflows_amd.invalidate_packed_weights()
+        lp1 = flow.log_prob(x)
+        twin = copy.deepcopy(flow)
+        assert torch.equal(twin.log_prob(x), lp1) and not torch.equal(lp1, lp0)
+
+
 def test_f16_engine_leaves_non_finite_weights_to_the_exact_kernel(monkeypatch):
     """K8h's ReLU is v_max_f32, which does not propagate a NaN the way torch.relu does: a conditioner with a
     non-finite weight (a diverged training run) must not take the f16 engine.  The packer notices

@@ -905,3 +905,34 @@ def test_made_schedule_reproduces_the_masked_network(residual, random_mask, feat
     # features beyond T only read that final vector
     rest = net.final_layer(hidden_want[None])[0].view(features, P)[T:]
     assert (rest - want[T:]).abs().max().item() < 1e-9
+
+
+def test_verify_weights_mode_detects_writes_through_data(monkeypatch):
+    """NFA_VERIFY_WEIGHTS: a write through `.data` (EMA swap, dist.broadcast(p.data)) changes no version
+    counter, no storage pointer and registers nothing -- the cache key stays the same and the fused kernels
+    would use the old packed weights.  With the verify mode on, the next use of the key raises; after
+    invalidate_packed_weights() the new weights are taken."""
+    import nflows_amd
+    from nflows_amd import configs
+    from nflows_amd.transforms import coupling as C
+    flow = configs.rq_nsf_flow(num_layers=2, features=8, num_bins=8, hidden_features=16, seed=0)
+    layer = flow._transform._transforms[1]
+    net = layer.transform_net
+    monkeypatch.setattr(C, "VERIFY_WEIGHTS_EVERY", 1)
+    k0 = C._weights_key(layer, net)
+    assert C._weights_key(layer, net) == k0                 # unchanged weights: passes, same key
+    with torch.no_grad():
+        net.final_layer.bias.add_(1.0)                      # a visible update: new key, new checksum
+    k1 = C._weights_key(layer, net)
+    assert k1 != k0 and C._weights_key(layer, net) == k1
+    net.final_layer.bias.data.mul_(0.5)                     # invisible to the key ...
+    with pytest.raises(C.StalePackedWeights):
+        C._weights_key(layer, net)                          # ... but not to the checksum
+    nflows_amd.invalidate_packed_weights()
+    k2 = C._weights_key(layer, net)
+    assert k2 != k1 and C._weights_key(layer, net) == k2
+    monkeypatch.setattr(C, "VERIFY_WEIGHTS_EVERY", 3)       # every third use of the key only (this is use 2)
+    net.final_layer.bias.data.mul_(2.0)
+    assert C._weights_key(layer, net) == k2
+    with pytest.raises(C.StalePackedWeights):
+        C._weights_key(layer, net)
