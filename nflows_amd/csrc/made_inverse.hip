@@ -16,13 +16,17 @@
 // (transforms/autoregressive.py).  Same sums as the reference's masked GEMMs in another order.
 //
 // Samples are independent, so there is no grid-wide step: a workgroup of four waves owns 16 samples for
-// all steps.  Lane = (sample s, quarter q): the four lanes of a sample split every dot product by
-// 16-byte chunks (chunk c belongs to quarter c % 4) and add their parts with two cross-lane exchanges.
-// The 3K - 1 output rows of a feature are dealt to the four waves (row p to wave p % 4), the few unit
-// rows of a step are wave 0's; three workgroup barriers per step hand the results on through LDS.
-// Per-sample state lives in LDS as [vector][chunk][16 samples][4 floats]: the features found so far
-// and one vector per hidden Linear (its ReLU'd output) plus, for residual nets, the raw residual
-// stream; a lane's read of chunk c is one ds_read_b128, conflict-free across the wave.
+// all steps.  Round 3: every wave owns FOUR of them for the whole step -- unit chain, output rows, spline --
+// with SIXTEEN lanes per sample (lane = (sample sw = lane / 16, part q = lane % 16)): a 256-term dot product
+// is four 16-byte chunks per lane and a four-stage DPP butterfly (quad_perm x 2, row_half_mirror,
+// row_mirror: no LDS round trip), all sixteen lanes end up with every sum, so the 3K - 1 logits of a
+// feature never leave the registers.  (Round 2 gave the chain to wave 0 with four lanes per sample -- 16
+// chunks per lane and two ds_bpermute exchanges per unit, 14.7 k of the step's 18.8 k cycles -- and the
+// output rows to waves 1..3, joined by three workgroup barriers and a rank-1 correction.)  The waves only
+// meet once per step, for the hand-over of the staged block.
+// Per-sample state lives in LDS as [vector][16 samples][chunks, padded to a multiple of 16][4 floats]: the
+// sixteen lanes of a sample read sixteen consecutive chunks (conflict-free; the samples of a wave are a
+// multiple of 64 banks apart), a weight read is one address per part q, broadcast to the four samples.
 //
 // Everything step t needs from global memory is ONE contiguous block prepared by the host (weights
 // pre-masked, rows sorted by degree, zero-padded): a header with the number of units per layer, the
@@ -64,11 +68,26 @@ struct MadeInvArgs {
     unsigned long long* trace;   // debug (nfa_debug_k7_trace): cycle stamps of workgroup 0, wave 0 over the first steps
 };
 
-// one lane's part of `R` dot products of weight rows (`pitch` floats apart) with a state vector, both
-// in LDS: chunks q, q + 4, ... of `chunks`; then the sum over the four quarters (all four lanes get it)
+// sum over the sixteen lanes of a sample (a DPP row), every lane gets it
+__device__ __forceinline__ float row_sum16(float v) {
+    auto dpp = [](float x, int ctrl) {
+        return __builtin_bit_cast(float, ctrl == 0xB1   ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false)
+                                       : ctrl == 0x4E  ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false)
+                                       : ctrl == 0x141 ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false)
+                                                       : __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, false));
+    };
+    v += dpp(v, 0xB1);    // quad_perm [1, 0, 3, 2]
+    v += dpp(v, 0x4E);    // quad_perm [2, 3, 0, 1]
+    v += dpp(v, 0x141);   // row_half_mirror: the other quad of the half row
+    v += dpp(v, 0x140);   // row_mirror: the other half row
+    return v;
+}
+
+// `R` dot products of weight rows (`pitch` floats apart) with one sample's state vector `vec` (its `chunks`
+// 16-byte chunks), both in LDS: this lane takes chunks q, q + 16, ...; every lane of the sample gets the sums
 template <int R, int UNROLL>
 __device__ __forceinline__ void dot_rows(float (&acc)[R], const float* rows, int pitch, const float* vec, int chunks,
-                                         int q, int s, int nrows, int skip_k = -1) {
+                                         int q, int nrows) {
     // (no conditionals inside the loop: rows beyond `nrows` re-read row 0 and their sums are ignored --
     // a branch per row would keep the compiler from batching the LDS reads of several chunks)
     const float* rp[R];
@@ -77,18 +96,9 @@ __device__ __forceinline__ void dot_rows(float (&acc)[R], const float* rows, int
         acc[r] = 0.0f;
         rp[r] = rows + (r < nrows ? r : 0) * pitch;
     }
-    // (deep unrolling: the LDS reads of several chunks are in flight before the first FMA needs one;
-    // a wave runs alone on its SIMD here, nothing else hides the latency)
 #pragma unroll UNROLL
-    for (int c = q; c < chunks; c += 4) {
-        vec4f v = *reinterpret_cast<const vec4f*>(vec + (c * kMadeSamples + s) * 4);
-        if (R > 1) {   // element `skip_k` of the vector is being written by another wave: leave it out
-            const bool hit = c == (skip_k >> 2);
-            v.x = (hit && (skip_k & 3) == 0) ? 0.0f : v.x;
-            v.y = (hit && (skip_k & 3) == 1) ? 0.0f : v.y;
-            v.z = (hit && (skip_k & 3) == 2) ? 0.0f : v.z;
-            v.w = (hit && (skip_k & 3) == 3) ? 0.0f : v.w;
-        }
+    for (int c = q; c < chunks; c += 16) {
+        const vec4f v = *reinterpret_cast<const vec4f*>(vec + c * 4);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const vec4f w = *reinterpret_cast<const vec4f*>(rp[r] + c * 4);
@@ -99,13 +109,11 @@ __device__ __forceinline__ void dot_rows(float (&acc)[R], const float* rows, int
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        acc[r] += __shfl_xor(acc[r], 16, kWave);
-        acc[r] += __shfl_xor(acc[r], 32, kWave);
-    }
+    for (int r = 0; r < R; ++r) acc[r] = row_sum16(acc[r]);
 }
 
-__device__ __forceinline__ int state_index(int k, int s) { return ((k >> 2) * kMadeSamples + s) * 4 + (k & 3); }
+// float offset of element k of a sample's vector whose samples are `pitch` chunks apart
+__device__ __forceinline__ int state_index(int k, int s, int pitch) { return (s * pitch + (k >> 2)) * 4 + (k & 3); }
 
 // block `t` -> LDS at `dst`: a wave requests one grain (64 lanes x 16 bytes) per instruction, grain g is
 // wave g % 4's
@@ -122,10 +130,8 @@ template <int KT>
 __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(const MadeInvArgs a) {
 #pragma clang fp contract(off)
     constexpr int P = 3 * KT - 1;
-    constexpr int kRowWaves = kMadeWaves - 1;                    // waves 1..3 take the output rows while wave 0
-    constexpr int RB = (P + kRowWaves - 1) / kRowWaves;          // walks the step's unit chain
+    constexpr int RB = 8;                                           // output rows per pass of dot_rows
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ float s_params[32 * kMadeSamples];                   // a feature's logits of the 16 samples
     __shared__ int s_cfg[kMadeMaxLinears][5];                       // per Linear: columns, src, dst, add, set (a
                                                                     // dynamically indexed kernel argument is a
                                                                     // scalar memory load every time it is read)
@@ -137,14 +143,15 @@ __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(co
         s_cfg[l][3] = a.add_stream[l];
         s_cfg[l][4] = a.set_stream[l];
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, s = lane & 15, q = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & 15, s = wave * 4 + (lane >> 4);
     const int64_t row = (int64_t)blockIdx.x * kMadeSamples + s;
     const bool live = row < a.batch;
     const int64_t rrow = live ? row : a.batch - 1;
-    const int vec_floats = (a.Hp >> 2) * kMadeSamples * 4;          // one hidden vector of all 16 samples
-    const int state_floats = (a.Xp >> 2) * kMadeSamples * 4 + a.num_vectors * vec_floats;
-    float* xs = lds;                                                // [Xp / 4][16][4]
-    float* vecs = lds + (a.Xp >> 2) * kMadeSamples * 4;             // [num_vectors][Hp / 4][16][4]
+    const int px = ((a.Xp >> 2) + 15) & ~15, ph = ((a.Hp >> 2) + 15) & ~15;   // chunks between two samples
+    const int x_floats = kMadeSamples * px * 4, vec_floats = kMadeSamples * ph * 4;
+    const int state_floats = x_floats + a.num_vectors * vec_floats;
+    float* xs = lds;                                                // [16][px][4]
+    float* vecs = lds + x_floats;                                   // [num_vectors][16][ph][4]
     float* buf0 = lds + state_floats;                               // two step blocks
     float* buf1 = buf0 + a.max_block;
     request_block(a, 0, buf0, lane, wave);
@@ -161,8 +168,8 @@ __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(co
     for (int t = 0; t <= a.T; ++t) {
         float* blk = (t & 1) ? buf1 : buf0;
         NFA_K12_STAMP()
-        // block t has landed (every wave's share, requested a whole step ago); everything the previous
-        // step wrote to LDS is visible, every read of the other buffer half is done
+        // block t has landed (every wave's share, requested a whole step ago), every wave is done with the
+        // other buffer half (and, at t = 0, the state is zeroed)
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
         NFA_K12_STAMP()
@@ -173,101 +180,77 @@ __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(co
         }
         const int* hdr = reinterpret_cast<const int*>(blk);
         const float* tail = blk + hdr[12];          // per unit (bias, index), then the feature's P biases
-        // ---- 1. hidden units of degree t, layer by layer (wave 0; typically one unit per layer) and, beside
-        //      it, 2. feature t's P output rows on the hidden vector (waves 1..3; row p is wave 1 + p % 3's).
-        //      The only element of that vector the units of this step change is the new unit of the layer in
-        //      front of the output layer: the row sums leave it out and receive it as a rank-1 term afterwards
-        //      (with more than one such unit in a step the rows simply wait for the units).
+        // ---- 1. hidden units of degree t, layer by layer (typically one unit per layer), for this wave's samples
         int units = 0;
-        for (int l = 0; l < a.num_linears; ++l) units += hdr[l];
-        const int nlast = hdr[a.num_linears - 1];
-        const bool beside = nlast <= 1 && t < a.T;
-        const int jnew = nlast == 1 ? __builtin_bit_cast(int, tail[2 * (units - 1) + 1]) : -1;
-        const float* fin = vecs + a.final_src * vec_floats;
-        const float* wf = blk + hdr[13];
-        const float* fbias = tail + 2 * units;
-        auto output_rows = [&](int skip) {
-            float acc[RB];
-            const int mine = (P - (wave - 1) + kRowWaves - 1) / kRowWaves;
-            dot_rows<RB, 4>(acc, wf + (wave - 1) * a.Hp, kRowWaves * a.Hp, fin, a.Hp >> 2, q, s, mine, skip);
-            if (q == 0) {
-#pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    const int p_ = (wave - 1) + kRowWaves * i;
-                    if (p_ < P) s_params[p_ * kMadeSamples + s] = acc[i] + fbias[p_];
-                }
-            }
-        };
-        if (wave == 0) {
+        {
             const float* rows = blk + kMadeHeader;
             const float* ut = tail;
             for (int l = 0; l < a.num_linears; ++l) {
                 const int n = hdr[l];
+                units += n;
                 if (n == 0) continue;
                 const int kp = s_cfg[l][0], chunks = kp >> 2, src_v = s_cfg[l][1], dst_v = s_cfg[l][2];
                 const bool add_stream = s_cfg[l][3] != 0, set_stream = s_cfg[l][4] != 0;
-                const float* src = src_v < 0 ? xs : vecs + src_v * vec_floats;
+                const float* src = src_v < 0 ? xs + s * px * 4 : vecs + src_v * vec_floats + s * ph * 4;
                 float* dst = dst_v < 0 ? nullptr : vecs + dst_v * vec_floats;
                 for (int u = 0; u < n; ++u) {
                     float acc[1];
-                    dot_rows<1, 8>(acc, rows, kp, src, chunks, q, s, 1);
+                    dot_rows<1, 4>(acc, rows, kp, src, chunks, q, 1);
                     rows += kp;
                     const int j = __builtin_bit_cast(int, ut[1]);
                     float v = acc[0] + ut[0];
                     ut += 2;
-                    const int at = state_index(j, s);
+                    const int at = state_index(j, s, ph);
                     if (add_stream) v = stream[at] + v;               // residual connection (made.py:128)
                     if (q == 0) {
                         if (set_stream) stream[at] = v;
                         if (dst) dst[at] = v < 0.0f ? 0.0f : v;       // ReLU'd for the next Linear (NaN stays)
                     }
                 }
-                // the units just written are inputs of the next Linear
+                // the units just written are inputs of the next Linear (same wave: LDS is in order)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-        } else if (beside) {
-            output_rows(jnew);
         }
         NFA_K12_STAMP()
-        __syncthreads();
         if (t == a.T) break;
-        if (!beside) {
-            if (wave != 0) output_rows(-1);
-            __syncthreads();
-        }
-        NFA_K12_STAMP()
-        NFA_K12_STAMP()
-        // ---- 3. invert feature t (rational_quadratic.py:66-181 through the same evaluation as K5); every
-        //      thread of a sample does it, one records the result
+        // ---- 2. feature t's P output rows on the hidden vector as it stands: all sums in every lane of the sample
+        const float* fin = vecs + a.final_src * vec_floats + s * ph * 4;
+        const float* wf = blk + hdr[13];
+        const float* fbias = tail + 2 * units;
         float p[P];
 #pragma unroll
-        for (int j = 0; j < P; ++j) p[j] = s_params[j * kMadeSamples + s];
-        if (beside && jnew >= 0) {   // the rank-1 term of the unit the row sums left out
-            const float vj = fin[state_index(jnew, s)];
+        for (int g = 0; g < (P + RB - 1) / RB; ++g) {
+            float acc[RB];
+            const int left = P - g * RB;
+            dot_rows<RB, 4>(acc, wf + g * RB * a.Hp, a.Hp, fin, a.Hp >> 2, q, left < RB ? left : RB);
 #pragma unroll
-            for (int j = 0; j < P; ++j) p[j] = __builtin_fmaf(wf[j * a.Hp + jnew], vj, p[j]);
+            for (int i = 0; i < RB; ++i)
+                if (g * RB + i < P) p[g * RB + i] = acc[i] + fbias[g * RB + i];
         }
+        NFA_K12_STAMP()
+        // ---- 3. invert feature t (rational_quadratic.py:66-181 through the same evaluation as K5); every
+        //      lane of a sample does it, one records the result
         float y, l;
         my_status |= rqs_eval<KT, true, true, true>(z_t, p, a.sp, y, l);
         lad_acc += l;
         // (kept in LDS only: a global store per step would sit in front of the next step's vmcnt(0))
-        if (wave == 0 && q == 0) xs[state_index(t, s)] = y;
+        if (q == 0) xs[state_index(t, s, px)] = y;
+        NFA_K12_STAMP()
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // the features found, [16 samples][T] -> the first T columns of the samples' rows
-    if (live)
-        for (int k = q + 4 * wave; k < a.T; k += 4 * kMadeWaves) a.x[row * a.D + k] = xs[state_index(k, s)];
-    if (wave == 0) {
-        if (live && q == 0) a.lad[row] = lad_acc;
-        // the final hidden vector of every sample: input of the output layer for features >= T
+    // the features found -> the first T columns of the samples' rows; the final hidden vector of every sample:
+    // input of the output layer for features >= T
+    if (live) {
+        for (int k = q; k < a.T; k += 16) a.x[row * a.D + k] = xs[state_index(k, s, px)];
+        if (q == 0) a.lad[row] = lad_acc;
         const float* fin = vecs + a.final_src * vec_floats;
-        if (live)
-            for (int k = q; k < a.H; k += 4) a.hidden[row * a.H + k] = fin[state_index(k, s)];
-        if (!live) my_status = 0;
-        if (my_status && a.status) atomicOr(a.status, my_status);
+        for (int k = q; k < a.H; k += 16) a.hidden[row * a.H + k] = fin[state_index(k, s, ph)];
+    } else {
+        my_status = 0;
     }
+    if (my_status && a.status) atomicOr(a.status, my_status);
 }
 
 }  // namespace nfa
@@ -311,7 +294,8 @@ extern "C" int nfa_made_rqs_inverse_f32(const float* inputs, const float* step_b
         a.final_src >= a.num_vectors || a.max_block < kMadeGrain || (a.max_block % kMadeGrain) != 0 ||
         (a.residual && (a.stream_vec < 0 || a.stream_vec >= a.num_vectors)))
         return NFA_ERR_INVALID_ARGUMENT;
-    const size_t lds = (((size_t)a.Xp + (size_t)a.num_vectors * a.Hp) * kMadeSamples + 2 * (size_t)a.max_block) * sizeof(float);
+    const size_t px = (((size_t)a.Xp >> 2) + 15) & ~(size_t)15, ph = (((size_t)a.Hp >> 2) + 15) & ~(size_t)15;   // chunks per sample
+    const size_t lds = ((px + (size_t)a.num_vectors * ph) * 4 * kMadeSamples + 2 * (size_t)a.max_block) * sizeof(float);
     if (lds + 4096 > 160 * 1024) return NFA_ERR_UNSUPPORTED;   // (+ the 2 KB of logits and alignment)
     if (batch == 0) return NFA_OK;
     if (!inputs || !step_blocks || !block_starts || !outputs || !logabsdet || !hidden_out) return NFA_ERR_INVALID_ARGUMENT;
