@@ -420,10 +420,12 @@ int nfa_affine_flow_mlp_f32(const float *inputs, const void *weights_packed, con
  *   one GEMM and one elementwise launch (K5 / K1).
  *   step_blocks / block_starts / layout: built by ops.pack_made_schedule.  step_blocks holds one
  *     contiguous fp32 block per step t = 0 .. sequential_steps (the last one only completes the hidden
- *     vector): [16 ints: units of degree t per hidden Linear (12), offset of the tail section, offset of
- *     the output rows] [the units' masked weight rows, layer after layer, zero-padded to multiples of 16
- *     columns] [feature t's 3K - 1 rows of the output layer, Hp columns] [tail: (bias, unit index) per
- *     unit, then the feature's biases], padded to 1 KB; block_starts int32 [sequential_steps + 2] in
+ *     vector): [16 ints: number of hidden units of degree t, offset of the unit rows, of the output rows, of the
+ *     output biases (in floats from the block's start)] [unit table, 8 words per unit in layer order: bias,
+ *     unit index, padded columns, source vector (-1 = the features), destination vector (-1 = none),
+ *     add_stream, set_stream, 0] [the units' masked weight rows, zero-padded to multiples of 16 columns]
+ *     [feature t's 3K - 1 rows of the output layer, Hp columns] [its 3K - 1 biases], padded to 1 KB and at
+ *     least 48 floats long; block_starts int32 [sequential_steps + 2] in
  *     1 KB grains; `layout` (host memory, int32):
  *       [num_linears, residual, final_src, stream_vec, num_vectors, Hp, Xp, max_block_floats] then per
  *       Linear [padded_columns, src_vector (-1 = the features), dst_vector (-1 = none), add_stream,

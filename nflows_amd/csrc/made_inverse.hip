@@ -49,7 +49,9 @@ namespace nfa {
 constexpr int kMadeMaxLinears = 12;
 constexpr int kMadeSamples = 16;     // per workgroup
 constexpr int kMadeWaves = 4;
-constexpr int kMadeHeader = 16;      // ints in front of a step block: units per layer [12], tail offset, output-row offset
+constexpr int kMadeHeader = 16;      // ints in front of a step block: {units, offset of the unit rows, of the output rows, of the output biases}
+constexpr int kMadeUnitWords = 8;    // per unit, right behind the header: {bias, index, columns, src vector, dst vector, add_stream, set_stream, 0}
+constexpr int kMadeUnitsAhead = 4;   // unit entries every lane reads together with the header (more units: read one by one)
 constexpr int kMadeGrain = 256;      // blocks are multiples of 256 floats (one LDS-DMA request of the wave)
 
 struct MadeInvArgs {
@@ -112,6 +114,42 @@ __device__ __forceinline__ void dot_rows(float (&acc)[R], const float* rows, int
     for (int r = 0; r < R; ++r) acc[r] = row_sum16(acc[r]);
 }
 
+// the same for exactly 64 chunks (256 columns: BASELINE configs[4]'s hidden width), software-pipelined by hand:
+// the reads of the next 16 chunks are in flight while the current ones are multiplied (hipcc waits for ALL
+// outstanding LDS reads in front of the first FMA of a loop body otherwise: four exposed round trips per call)
+template <int R>
+__device__ __forceinline__ void dot_rows_64(float (&acc)[R], const float* rows, int pitch, const float* vec, int q, int nrows) {
+    const float* rp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        acc[r] = 0.0f;
+        rp[r] = rows + (r < nrows ? r : 0) * pitch + q * 4;
+    }
+    const float* vp = vec + q * 4;
+    vec4f v[2], w[2][R];
+    v[0] = *reinterpret_cast<const vec4f*>(vp);
+#pragma unroll
+    for (int r = 0; r < R; ++r) w[0][r] = *reinterpret_cast<const vec4f*>(rp[r]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cur = i & 1, nxt = cur ^ 1;
+        if (i < 3) {
+            v[nxt] = *reinterpret_cast<const vec4f*>(vp + (i + 1) * 64);
+#pragma unroll
+            for (int r = 0; r < R; ++r) w[nxt][r] = *reinterpret_cast<const vec4f*>(rp[r] + (i + 1) * 64);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            acc[r] = __builtin_fmaf(w[cur][r].x, v[cur].x, acc[r]);
+            acc[r] = __builtin_fmaf(w[cur][r].y, v[cur].y, acc[r]);
+            acc[r] = __builtin_fmaf(w[cur][r].z, v[cur].z, acc[r]);
+            acc[r] = __builtin_fmaf(w[cur][r].w, v[cur].w, acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = row_sum16(acc[r]);
+}
+
 // float offset of element k of a sample's vector whose samples are `pitch` chunks apart
 __device__ __forceinline__ int state_index(int k, int s, int pitch) { return (s * pitch + (k >> 2)) * 4 + (k & 3); }
 
@@ -132,17 +170,6 @@ __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(co
     constexpr int P = 3 * KT - 1;
     constexpr int RB = 8;                                           // output rows per pass of dot_rows
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ int s_cfg[kMadeMaxLinears][5];                       // per Linear: columns, src, dst, add, set (a
-                                                                    // dynamically indexed kernel argument is a
-                                                                    // scalar memory load every time it is read)
-    if (threadIdx.x < kMadeMaxLinears) {
-        const int l = threadIdx.x;
-        s_cfg[l][0] = a.kp[l];
-        s_cfg[l][1] = a.src[l];
-        s_cfg[l][2] = a.dst[l];
-        s_cfg[l][3] = a.add_stream[l];
-        s_cfg[l][4] = a.set_stream[l];
-    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & 15, s = wave * 4 + (lane >> 4);
     const int64_t row = (int64_t)blockIdx.x * kMadeSamples + s;
     const bool live = row < a.batch;
@@ -178,52 +205,59 @@ __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(co
             request_block(a, t + 1, (t & 1) ? buf0 : buf1, lane, wave);
             if (t + 1 < a.T) z_next = zrow[t + 1];
         }
-        const int* hdr = reinterpret_cast<const int*>(blk);
-        const float* tail = blk + hdr[12];          // per unit (bias, index), then the feature's P biases
-        // ---- 1. hidden units of degree t, layer by layer (typically one unit per layer), for this wave's samples
-        int units = 0;
-        {
-            const float* rows = blk + kMadeHeader;
-            const float* ut = tail;
-            for (int l = 0; l < a.num_linears; ++l) {
-                const int n = hdr[l];
-                units += n;
-                if (n == 0) continue;
-                const int kp = s_cfg[l][0], chunks = kp >> 2, src_v = s_cfg[l][1], dst_v = s_cfg[l][2];
-                const bool add_stream = s_cfg[l][3] != 0, set_stream = s_cfg[l][4] != 0;
-                const float* src = src_v < 0 ? xs + s * px * 4 : vecs + src_v * vec_floats + s * ph * 4;
-                float* dst = dst_v < 0 ? nullptr : vecs + dst_v * vec_floats;
-                for (int u = 0; u < n; ++u) {
-                    float acc[1];
-                    dot_rows<1, 4>(acc, rows, kp, src, chunks, q, 1);
-                    rows += kp;
-                    const int j = __builtin_bit_cast(int, ut[1]);
-                    float v = acc[0] + ut[0];
-                    ut += 2;
-                    const int at = state_index(j, s, ph);
-                    if (add_stream) v = stream[at] + v;               // residual connection (made.py:128)
-                    if (q == 0) {
-                        if (set_stream) stream[at] = v;
-                        if (dst) dst[at] = v < 0.0f ? 0.0f : v;       // ReLU'd for the next Linear (NaN stays)
-                    }
-                }
-                // the units just written are inputs of the next Linear (same wave: LDS is in order)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
+        // ---- the step's control data in ONE round trip: header and the first unit entries (a dependent LDS
+        //      read per field was most of the unit chain's time: five to six round trips per unit)
+        typedef int vec4i __attribute__((ext_vector_type(4)));
+        const vec4i* bv = reinterpret_cast<const vec4i*>(blk);
+        const vec4i h0 = bv[0];
+        vec4i ue[kMadeUnitsAhead][2];
+#pragma unroll
+        for (int u = 0; u < kMadeUnitsAhead; ++u) {
+            ue[u][0] = bv[kMadeHeader / 4 + 2 * u];
+            ue[u][1] = bv[kMadeHeader / 4 + 2 * u + 1];
         }
+        const int units = __builtin_amdgcn_readfirstlane(h0.x);
+        const float* rows = blk + __builtin_amdgcn_readfirstlane(h0.y);
+        const float* wf = blk + __builtin_amdgcn_readfirstlane(h0.z);
+        const float* fbias = blk + __builtin_amdgcn_readfirstlane(h0.w);
+        // ---- 1. hidden units of degree t in layer order (typically one unit per layer), for this wave's samples
+        auto unit = [&](vec4i e0, vec4i e1) {
+            const float bias = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(e0.x));
+            const int j = __builtin_amdgcn_readfirstlane(e0.y), kp = __builtin_amdgcn_readfirstlane(e0.z);
+            const int src_v = __builtin_amdgcn_readfirstlane(e0.w), dst_v = __builtin_amdgcn_readfirstlane(e1.x);
+            const bool add_stream = __builtin_amdgcn_readfirstlane(e1.y) != 0, set_stream = __builtin_amdgcn_readfirstlane(e1.z) != 0;
+            const float* src = src_v < 0 ? xs + s * px * 4 : vecs + src_v * vec_floats + s * ph * 4;
+            const int at = state_index(j, s, ph);
+            const float carried = add_stream ? stream[at] : 0.0f;   // (in flight beside the dot product's reads)
+            float acc[1];
+            if (kp == 256) dot_rows_64<1>(acc, rows, kp, src, q, 1);
+            else dot_rows<1, 4>(acc, rows, kp, src, kp >> 2, q, 1);
+            rows += kp;
+            float v = acc[0] + bias;
+            if (add_stream) v = carried + v;                    // residual connection (made.py:128)
+            if (q == 0) {
+                if (set_stream) stream[at] = v;
+                if (dst_v >= 0) vecs[dst_v * vec_floats + at] = v < 0.0f ? 0.0f : v;   // ReLU'd for the next Linear (NaN stays)
+            }
+            // a unit just written is an input of the next Linear (same wave: LDS is in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+#pragma unroll
+        for (int u = 0; u < kMadeUnitsAhead; ++u)
+            if (u < units) unit(ue[u][0], ue[u][1]);
+        for (int u = kMadeUnitsAhead; u < units; ++u) unit(bv[kMadeHeader / 4 + 2 * u], bv[kMadeHeader / 4 + 2 * u + 1]);
         NFA_K12_STAMP()
         if (t == a.T) break;
         // ---- 2. feature t's P output rows on the hidden vector as it stands: all sums in every lane of the sample
         const float* fin = vecs + a.final_src * vec_floats + s * ph * 4;
-        const float* wf = blk + hdr[13];
-        const float* fbias = tail + 2 * units;
         float p[P];
 #pragma unroll
         for (int g = 0; g < (P + RB - 1) / RB; ++g) {
             float acc[RB];
             const int left = P - g * RB;
-            dot_rows<RB, 4>(acc, wf + g * RB * a.Hp, a.Hp, fin, a.Hp >> 2, q, left < RB ? left : RB);
+            if (a.Hp == 256) dot_rows_64<RB>(acc, wf + g * RB * a.Hp, a.Hp, fin, q, left < RB ? left : RB);
+            else dot_rows<RB, 4>(acc, wf + g * RB * a.Hp, a.Hp, fin, a.Hp >> 2, q, left < RB ? left : RB);
 #pragma unroll
             for (int i = 0; i < RB; ++i)
                 if (g * RB + i < P) p[g * RB + i] = acc[i] + fbias[g * RB + i];

@@ -536,10 +536,11 @@ def _standard_normal_log_prob_launch(z, logabsdet):
 
 def pack_made_schedule(net, sequential_steps, params_per_feature):
     """Packs a MADE (transforms/made.py) for K12 (csrc/made_inverse.hip): one contiguous block per step
-    t = 0 .. T holding everything the step reads -- header (units per hidden Linear [12 ints], offset of
-    the tail section, offset of the output rows), the masked weight rows of the units of degree t layer
-    after layer (zero-padded to multiples of 16 columns), feature t's P rows of the output layer (t < T),
-    and the tail section: (bias, unit index) per unit, then the feature's P biases -- padded to 1 KB.
+    t = 0 .. T holding everything the step reads -- header (16 ints: number of units of degree t, offsets of
+    the unit rows / the output rows / the output biases), the unit table (8 words per unit in layer order:
+    bias, unit index, padded columns, source vector (-1 = the features), destination vector (-1 = none),
+    add_stream, set_stream, 0), the units' masked weight rows (zero-padded to multiples of 16 columns),
+    feature t's P rows of the output layer and its P biases (t < T) -- padded to 1 KB.
     Returns (blocks fp32, block starts int32 [T + 2] in 1 KB grains, layout list)."""
     T, P = int(sequential_steps), int(params_per_feature)
     dev = net.final_layer.weight.device
@@ -578,25 +579,35 @@ def pack_made_schedule(net, sequential_steps, params_per_feature):
     wf = torch.cat((wf, wf.new_zeros(T, P, Hp - H)), dim=2)
     bf = final.bias.detach().float().cpu().view(D, P)[:T]
     blocks, block_at, at = [], [], 0
+    UNIT = 8
     for t in range(T + 1):
         header = torch.zeros(HDR, dtype=torch.int32)
-        parts, tail = [], []
+        table, rows = [], []
         for l in range(n):
             s0, s1 = starts[l][t], starts[l][t + 1]
-            header[l] = s1 - s0
-            if s1 > s0:
-                parts.append(sorted_rows[l][s0:s1].reshape(-1))
-                pair = torch.stack((sorted_bias[l][s0:s1], orders[l][s0:s1].view(torch.float32)), dim=1)
-                tail.append(pair.reshape(-1))
-        rows_len = sum(p_.numel() for p_ in parts)
-        header[13] = HDR + rows_len                         # output rows
+            kp, src_v, dst_v, add_stream, set_stream = per_layer[l]
+            for u in range(s0, s1):
+                entry = torch.zeros(UNIT, dtype=torch.int32)
+                entry[0] = sorted_bias[l][u:u + 1].view(torch.int32)[0]
+                entry[1] = orders[l][u]
+                entry[2], entry[3], entry[4], entry[5], entry[6] = kp, src_v, dst_v, add_stream, set_stream
+                table.append(entry.view(torch.float32))
+                rows.append(sorted_rows[l][u])
+        units = len(table)
+        header[0] = units
+        header[1] = HDR + UNIT * units                      # unit rows
+        rows_len = sum(r.numel() for r in rows)
+        header[2] = header[1] + rows_len                    # output rows
+        parts = table + rows
         if t < T:
             parts.append(wf[t].reshape(-1))
-            tail.append(bf[t])
-        body_len = sum(p_.numel() for p_ in parts)
-        header[12] = HDR + body_len                         # tail section
-        block = torch.cat([header.view(torch.float32)] + parts + tail)
+            header[3] = header[2] + wf[t].numel()           # output biases
+            parts.append(bf[t])
+        block = torch.cat([header.view(torch.float32)] + parts)
         pad = (-block.numel()) % GRAIN
+        # (every lane reads the header and four unit entries unconditionally: a block is at least that long)
+        if block.numel() + pad < HDR + UNIT * 4:
+            pad += GRAIN
         if pad:
             block = torch.cat((block, block.new_zeros(pad)))
         block_at.append(at)

@@ -878,26 +878,30 @@ def test_made_schedule_reproduces_the_masked_network(residual, random_mask, feat
     for t in range(T + 1):
         blk = blocks_f[int(block_at[t]) * 256:int(block_at[t + 1]) * 256]
         hdr = blk[:16].view(torch.int32)
-        rows, tail = 16, int(hdr[12])
-        for l in range(n):
-            kp, src, dst, add_stream, set_stream = cfg[l]
-            for _ in range(int(hdr[l])):
-                w = blk[rows:rows + kp].double()
-                rows += kp
-                bias, j = float(blk[tail]), int(blk[tail + 1:tail + 2].view(torch.int32))
-                tail += 2
-                v = float(w @ (xs[:kp] if src < 0 else vecs[src, :kp])) + bias
-                if add_stream:
-                    v = float(vecs[stream_vec, j]) + v
-                if set_stream:
-                    vecs[stream_vec, j] = v
-                if dst >= 0:
-                    vecs[dst, j] = max(v, 0.0)
+        units, rows, out_rows, out_bias = (int(v) for v in hdr[:4])
+        assert rows == 16 + 8 * units and blk.numel() >= 16 + 8 * 4      # (the kernel reads four entries ahead)
+        in_layer_order = []
+        for u in range(units):
+            e = blk[16 + 8 * u:24 + 8 * u]
+            bias = float(e[0])
+            j, kp, src, dst, add_stream, set_stream, zero = (int(v) for v in e[1:].view(torch.int32))
+            assert zero == 0 and [kp, src, dst, add_stream, set_stream] in cfg
+            in_layer_order.append(cfg.index([kp, src, dst, add_stream, set_stream]))
+            w = blk[rows:rows + kp].double()
+            rows += kp
+            v = float(w @ (xs[:kp] if src < 0 else vecs[src, :kp])) + bias
+            if add_stream:
+                v = float(vecs[stream_vec, j]) + v
+            if set_stream:
+                vecs[stream_vec, j] = v
+            if dst >= 0:
+                vecs[dst, j] = max(v, 0.0)
+        assert in_layer_order == sorted(in_layer_order)
         if t == T:
             break
-        assert rows == int(hdr[13])
-        wf = blk[rows:rows + P * Hp].double().view(P, Hp)
-        params = wf @ vecs[final_src] + blk[tail:tail + P].double()
+        assert rows == out_rows and out_bias == out_rows + P * Hp
+        wf = blk[out_rows:out_bias].double().view(P, Hp)
+        params = wf @ vecs[final_src] + blk[out_bias:out_bias + P].double()
         assert (params - want[t]).abs().max().item() < 1e-5 * (1 + want[t].abs().max().item()), t
         xs[t] = x[t]          # "feature t found"
     hidden_want = net.hidden(x[None])[0]

@@ -17,10 +17,10 @@ with torch.no_grad():
 s = buf.cpu().numpy()
 s = s[s > 0]
 d = np.diff(s)
-# per step 5 stamps: loop top | after top wait+barrier | after units | after rows | after rows barrier
+# per step 5 stamps: loop top | after top wait+barrier | after the unit chain | after the output rows | after the spline
 n = (len(s) - 1) // 5
 steps = d[:n * 5].reshape(n, 5)
-print("per step: [top wait + barrier, request + units, output rows, rows barrier, spline -> next top]")
+print("per step: [top wait + barrier, request + unit chain, output rows, spline inverse, loop end -> next top]")
 for i in list(range(0, min(n, 6))) + list(range(max(6, n - 4), n)):
     print("step %3d:" % i, steps[i].tolist(), "total", int(steps[i].sum()))
 print("mean over steps 5..%d:" % n, steps[5:].mean(axis=0).round().tolist(), "total", steps[5:].sum(axis=1).mean().round())
