@@ -51,6 +51,9 @@ constexpr int kMadeSamples = 16;     // per workgroup
 constexpr int kMadeWaves = 4;
 constexpr int kMadeHeader = 16;      // ints in front of a step block: {units, offset of the unit rows, of the output rows, of the output biases}
 constexpr int kMadeUnitWords = 8;    // per unit, right behind the header: {bias, index, columns, src vector, dst vector, add_stream, set_stream, 0}
+#ifndef NFA_K12_ROWS_AHEAD
+#define NFA_K12_ROWS_AHEAD 2   // groups of the output rows' dot products requested ahead (dot_rows_64)
+#endif
 constexpr int kMadeUnitsAhead = 4;   // unit entries every lane reads together with the header (more units: read one by one)
 constexpr int kMadeGrain = 256;      // blocks are multiples of 256 floats (one LDS-DMA request of the wave)
 
@@ -117,37 +120,40 @@ __device__ __forceinline__ void dot_rows(float (&acc)[R], const float* rows, int
 // the same for exactly 64 chunks (256 columns: BASELINE configs[4]'s hidden width), software-pipelined by hand:
 // the reads of the next 16 chunks are in flight while the current ones are multiplied (hipcc waits for ALL
 // outstanding LDS reads in front of the first FMA of a loop body otherwise: four exposed round trips per call)
-template <int R>
+template <int R, int AHEAD>
 __device__ __forceinline__ void dot_rows_64(float (&acc)[R], const float* rows, int pitch, const float* vec, int q, int nrows) {
+    // AHEAD = how many 16-chunk groups are requested before the first one is multiplied (1 .. 4; 4 = everything
+    // up front: right for a single row, whose four FMAs per group hide nothing)
+    static_assert(AHEAD >= 1 && AHEAD <= 4, "");
     const float* rp[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        acc[r] = 0.0f;
-        rp[r] = rows + (r < nrows ? r : 0) * pitch + q * 4;
-    }
+    for (int r = 0; r < R; ++r) rp[r] = rows + (r < nrows ? r : 0) * pitch + q * 4;
     const float* vp = vec + q * 4;
-    vec4f v[2], w[2][R];
-    v[0] = *reinterpret_cast<const vec4f*>(vp);
+    vec4f v[4], w[4][R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) w[0][r] = *reinterpret_cast<const vec4f*>(rp[r]);
+    for (int i = 0; i < AHEAD; ++i) {
+        v[i] = *reinterpret_cast<const vec4f*>(vp + i * 64);
+#pragma unroll
+        for (int r = 0; r < R; ++r) w[i][r] = *reinterpret_cast<const vec4f*>(rp[r] + i * 64);
+    }
+    float part[4][R];   // one partial sum per group: four short dependency chains instead of one of sixteen
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int cur = i & 1, nxt = cur ^ 1;
-        if (i < 3) {
-            v[nxt] = *reinterpret_cast<const vec4f*>(vp + (i + 1) * 64);
+        if (i + AHEAD < 4) {
+            v[i + AHEAD] = *reinterpret_cast<const vec4f*>(vp + (i + AHEAD) * 64);
 #pragma unroll
-            for (int r = 0; r < R; ++r) w[nxt][r] = *reinterpret_cast<const vec4f*>(rp[r] + (i + 1) * 64);
+            for (int r = 0; r < R; ++r) w[i + AHEAD][r] = *reinterpret_cast<const vec4f*>(rp[r] + (i + AHEAD) * 64);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            acc[r] = __builtin_fmaf(w[cur][r].x, v[cur].x, acc[r]);
-            acc[r] = __builtin_fmaf(w[cur][r].y, v[cur].y, acc[r]);
-            acc[r] = __builtin_fmaf(w[cur][r].z, v[cur].z, acc[r]);
-            acc[r] = __builtin_fmaf(w[cur][r].w, v[cur].w, acc[r]);
+            float t = w[i][r].x * v[i].x;
+            t = __builtin_fmaf(w[i][r].y, v[i].y, t);
+            t = __builtin_fmaf(w[i][r].z, v[i].z, t);
+            part[i][r] = __builtin_fmaf(w[i][r].w, v[i].w, t);
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = row_sum16(acc[r]);
+    for (int r = 0; r < R; ++r) acc[r] = row_sum16((part[0][r] + part[1][r]) + (part[2][r] + part[3][r]));
 }
 
 // float offset of element k of a sample's vector whose samples are `pitch` chunks apart
@@ -230,7 +236,7 @@ __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(co
             const int at = state_index(j, s, ph);
             const float carried = add_stream ? stream[at] : 0.0f;   // (in flight beside the dot product's reads)
             float acc[1];
-            if (kp == 256) dot_rows_64<1>(acc, rows, kp, src, q, 1);
+            if (kp == 256) dot_rows_64<1, 4>(acc, rows, kp, src, q, 1);
             else dot_rows<1, 4>(acc, rows, kp, src, kp >> 2, q, 1);
             rows += kp;
             float v = acc[0] + bias;
@@ -256,7 +262,7 @@ __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(co
         for (int g = 0; g < (P + RB - 1) / RB; ++g) {
             float acc[RB];
             const int left = P - g * RB;
-            if (a.Hp == 256) dot_rows_64<RB>(acc, wf + g * RB * a.Hp, a.Hp, fin, q, left < RB ? left : RB);
+            if (a.Hp == 256) dot_rows_64<RB, NFA_K12_ROWS_AHEAD>(acc, wf + g * RB * a.Hp, a.Hp, fin, q, left < RB ? left : RB);
             else dot_rows<RB, 4>(acc, wf + g * RB * a.Hp, a.Hp, fin, a.Hp >> 2, q, left < RB ? left : RB);
 #pragma unroll
             for (int i = 0; i < RB; ++i)
