@@ -81,6 +81,11 @@ namespace k8h {
 #else
 #define NFA_K8H_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)
 #endif
+#ifdef NFA_ABL_CONST_FRAGS
+#define NFA_K8H_KEEP_FRAGS(fr, nf) (void)nf;
+#else
+#define NFA_K8H_KEEP_FRAGS(fr, nf) fr = nf;
+#endif
 #ifdef NFA_ABL_NO_WEAVE
 #define NFA_K8H_WEAVE(call)
 #else
@@ -139,19 +144,16 @@ struct Args {
 // The counter is read at the beginning of the stage (the value is awaited behind the fragment reads, no
 // extra latency) and polled only if that early value was not enough.  Parameter stages end with a real barrier
 // (their contents are copied by all threads for all waves).
-template <int NW_, int RING_, int PF_ = 1>
+template <int NW_, int RING_>
 struct WeightStream {
     static constexpr int NW = NW_, RING = RING_;
-    static constexpr int PF = PF_;   // fragment pairs requested from LDS ahead of the one the MFMAs use (1 or 2)
     static constexpr bool ELASTIC = RING_ == kRingElastic;
-    static_assert(!(ELASTIC && PF_ != 1), "the elastic stream's counted wait assumes one pair ahead");
     const vec4f* w;
     vec4f* ring;
     int slot, fetch, num_stages, tid;
     unsigned sync;       // ELASTIC: LDS byte address of the [RING] counters
     unsigned gen;        // ELASTIC: NW x (uses of the current stage's slot so far, this one included)
     unsigned peek;       // ELASTIC: sync[next slot] as read at the beginning of the stage
-    int cell;            // the MFMA cell (0 .. 7) of a stage in which this wave issues its LDS-DMA requests
 };
 
 template <class SM>
@@ -237,8 +239,7 @@ __device__ __forceinline__ void stream_advance(SM& sm, bool barrier = false) {
 // MFMAs need; its successor -- the next pair of this stage or pair 0 of the next stage -- is requested
 // from LDS before those MFMAs are issued.
 struct Frags {
-    vec4f h, l;      // the pair the next MFMAs use
-    vec4f h2, l2;    // PF == 2: the pair after it (requested one group earlier)
+    vec4f h, l;
 };
 
 // (cur / nxt: LDS byte addresses of this lane's 16 bytes in the current / the next stage)
@@ -255,40 +256,38 @@ __device__ __forceinline__ void stage_begin(SM& sm, unsigned& cur, unsigned& nxt
 }
 
 // The fragment reads are written as asm: hipcc waits for every LDS read it knows about with
-// lgkmcnt(0), i.e. also for the pairs requested a moment ago for the NEXT groups.  Here the pair in
-// `fr` is awaited with a counted lgkmcnt(2 PF): LDS reads return in order, so with the reads of the PF
-// following pairs as the only younger requests `fr` has landed (other LDS / scalar-memory traffic can
+// lgkmcnt(0), i.e. also for the pair requested a moment ago for the NEXT group.  Here the pair in
+// `fr` is awaited with a counted lgkmcnt(2): LDS reads return in order, so with the two reads of the
+// following pair as the only younger requests `fr` has landed (other LDS / scalar-memory traffic can
 // only make the wait stricter, never weaker).
-// read_pair<T>: pair T of the current stage, T >= kPairs: pair T - kPairs of the next stage (complete: see
-// stream_advance).
-template <int T>
-__device__ __forceinline__ void read_pair(vec4f& h, vec4f& l, unsigned cur, unsigned nxt) {
-#ifdef NFA_ABL_NO_FRAGS
-    asm volatile("" : "=v"(h), "=v"(l) : "v"(cur), "v"(nxt));
-    return;
-#endif
-    constexpr int P_ = T < kPairs ? T : T - kPairs;
-#ifdef NFA_ABL_DOUBLE_FRAGS   // (energy probe: every fragment pair is read twice into the same registers)
-    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\tds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
-                 : "=v"(h), "=v"(l)
-                 : "v"(T < kPairs ? cur : nxt), "i"(P_ * 2048), "i"(P_ * 2048 + 1024));
-    return;
-#endif
-    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
-                 : "=v"(h), "=v"(l)
-                 : "v"(T < kPairs ? cur : nxt), "i"(P_ * 2048), "i"(P_ * 2048 + 1024));
-}
-
-// in front of the MFMAs of group G: request the pair PF groups ahead
-template <int G, int PF>
+template <int G>
 __device__ __forceinline__ Frags next_frags(unsigned cur, unsigned nxt) {
     Frags f;
-    read_pair<G + PF>(f.h, f.l, cur, nxt);
+#ifdef NFA_ABL_NO_FRAGS
+    asm volatile("" : "=v"(f.h), "=v"(f.l) : "v"(cur), "v"(nxt));
+    return f;
+#endif
+#ifdef NFA_ABL_DOUBLE_FRAGS   // (energy probe: every fragment pair is read twice into the same registers)
+    if constexpr (G < kPairs - 1) {
+        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\tds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                     : "=v"(f.h), "=v"(f.l)
+                     : "v"(cur), "i"((G + 1) * 2048), "i"((G + 1) * 2048 + 1024));
+    } else {
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=v"(f.h), "=v"(f.l) : "v"(nxt));
+    }
+    return f;
+#endif
+    if constexpr (G < kPairs - 1) {
+        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                     : "=v"(f.h), "=v"(f.l)
+                     : "v"(cur), "i"((G + 1) * 2048), "i"((G + 1) * 2048 + 1024));
+    } else {
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=v"(f.h), "=v"(f.l) : "v"(nxt));
+    }
     return f;
 }
 
-// `fr` (h, l) has landed: the reads of the PF pairs behind it are the only younger requests of this wave
-template <int PF>
+// `fr` has landed (its successor's two reads are the only younger requests of this wave)
 __device__ __forceinline__ void await_frags(Frags& fr) {
 #ifdef NFA_ABL_NO_FRAGS
     asm volatile("" : "+v"(fr.h), "+v"(fr.l));
@@ -298,26 +297,7 @@ __device__ __forceinline__ void await_frags(Frags& fr) {
     asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fr.h), "+v"(fr.l));
     return;
 #endif
-    if constexpr (PF == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fr.h), "+v"(fr.l));
-    else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fr.h), "+v"(fr.l));
-}
-
-// group G is issued: the pair(s) behind it move up, `nf` (requested in front of this group) joins at the end
-template <int PF>
-__device__ __forceinline__ void rotate_frags(Frags& fr, const Frags& nf) {
-#ifdef NFA_ABL_CONST_FRAGS
-    (void)nf;
-    return;
-#endif
-    if constexpr (PF == 2) {
-        fr.h = fr.h2;
-        fr.l = fr.l2;
-        fr.h2 = nf.h;
-        fr.l2 = nf.l;
-    } else {
-        fr.h = nf.h;
-        fr.l = nf.l;
-    }
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fr.h), "+v"(fr.l));
 }
 
 typedef unsigned uvec4 __attribute__((ext_vector_type(4)));
@@ -590,14 +570,19 @@ struct SplineWeave10 {
 template <int KS, class W, class SM>
 __device__ __forceinline__ void tile_kstep(f32x16& acc, uvec4 bhw, uvec4 blw, Frags& fr, unsigned cur, unsigned nxt, W& w, SM& sm) {
     const f16x8 bh = __builtin_bit_cast(f16x8, bhw), bl = __builtin_bit_cast(f16x8, blw);
-    if constexpr (KS == kPairs - SM::PF) stream_ensure_next(sm);   // (the next read goes to the next stage)
-    const Frags nf = next_frags<KS, SM::PF>(cur, nxt);   // fragments of a later k-step, 3 PF MFMAs ahead of their use
-    await_frags<SM::PF>(fr);
+    if constexpr (KS == kPairs - 1) stream_ensure_next(sm);   // (the next read goes to the next stage)
+    const Frags nf = next_frags<KS>(cur, nxt);   // the next k-step's fragments, three MFMAs ahead of their use
+    await_frags(fr);
     const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);
-    rotate_frags<SM::PF>(fr, nf);
+#ifndef NFA_ABL_CONST_FRAGS
+    fr = nf;
+#else
+    (void)nf;
+#endif
     // (smallest terms first)
     acc = NFA_K8H_MFMA(al, bh, acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+
     NFA_K8H_WEAVE(w.template step<KS * 3 + 0>());
     __builtin_amdgcn_sched_barrier(0);
     acc = NFA_K8H_MFMA(ah, bl, acc, 0, 0, 0);
@@ -631,14 +616,13 @@ __device__ __forceinline__ void tile_gemm(f32x16& acc, const uvec4 (&ph)[8], con
 template <class W, class SM>
 __device__ __forceinline__ void kstep_pair_woven(f32x16 (&acc)[4], uvec4 bh0, uvec4 bl0, uvec4 bh1, uvec4 bl1, SM& sm,
                                                  Frags& fr, int lane, W&& w) {
-    using SMT = SM;
 #define NFA_K8H_CELL(T, G, SLOT, BH, BL)                                                         \
     {                                                                                            \
-        if (G == kPairs - SMT::PF) stream_ensure_next(sm);                                       \
-        const Frags nf = next_frags<G, SMT::PF>(cur, nxt);                                       \
-        await_frags<SMT::PF>(fr);                                                                \
+        if (G == kPairs - 1) stream_ensure_next(sm);                                             \
+        const Frags nf = next_frags<G>(cur, nxt);                                                \
+        await_frags(fr);                                                                         \
         const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);  \
-        rotate_frags<SMT::PF>(fr, nf);                                                           \
+        NFA_K8H_KEEP_FRAGS(fr, nf)                                                               \
         acc[T] = NFA_K8H_MFMA(al, BH, acc[T], 0, 0, 0);                \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         NFA_K8H_WEAVE(w.template step<SLOT + 0>());                                                          \
@@ -747,11 +731,8 @@ __device__ __forceinline__ bool not_finite(float v) { return !(__builtin_fabsf(v
 // h + (W_1 relu(u) + b_1) * sigmoid(W_c context + b_c): the second Linear then has accumulators of its own
 // (its input pieces are finished first: u's registers are needed), the gate's Linear is one more stage
 // (two k-steps, k-major) and the residual stream takes the product in.
-// MINW: minimum waves per SIMD the register allocation must allow (2 = 256 VGPRs).  MINW = 1 is the kernel of
-// batches that give a CU a single four-wave workgroup: 512 VGPRs (no scratch), and the weight fragments are
-// requested TWO groups ahead of their MFMAs -- a lone wave has no partner to cover the LDS latency.
-template <bool INVERSE, int INIT_KS, int NW, int KB = 8, bool CTX = false, int RING = kRing, int MINW = 2>
-__global__ void __launch_bounds__(NW * kWave, MINW) rqs_resnet_f16_kernel(const Args a) {
+template <bool INVERSE, int INIT_KS, int NW, int KB = 8, bool CTX = false, int RING = kRing>
+__global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Args a) {
     static_assert(!CTX || INIT_KS == 4, "context: two identity k-steps + two context k-steps");
     constexpr int kThreads = NW * kWave;
     // dynamic LDS: the weight ring, per wave a [D][33] row tile, two parameter blocks (current / next layer)
@@ -769,7 +750,7 @@ __global__ void __launch_bounds__(NW * kWave, MINW) rqs_resnet_f16_kernel(const 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no ordinary load in flight once the stream starts)
 
-    using Stream = WeightStream<NW, RING, MINW == 1 ? 2 : 1>;
+    using Stream = WeightStream<NW, RING>;
     Stream sm;
     sm.w = a.w;
     sm.ring = reinterpret_cast<vec4f*>(lds_dyn);
@@ -779,7 +760,6 @@ __global__ void __launch_bounds__(NW * kWave, MINW) rqs_resnet_f16_kernel(const 
     sm.sync = lds_address(s_sync);
     sm.gen = NW;
     sm.peek = 0;
-    sm.cell = __builtin_amdgcn_readfirstlane(wave) * (8 / NW);
     // stages 0 .. 2 -> slots 0 .. 2 (three stages in flight in both forms of the ring)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -792,12 +772,8 @@ __global__ void __launch_bounds__(NW * kWave, MINW) rqs_resnet_f16_kernel(const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     Frags fr;   // the weight fragments the next MFMAs need (carried across stages, layers and row blocks)
-    fr.h = sm.ring[lane];        // (stage 0 is a parameter stage: placeholders until its end)
+    fr.h = sm.ring[lane];
     fr.l = sm.ring[64 + lane];
-    if constexpr (Stream::PF == 2) {
-        fr.h2 = fr.h;
-        fr.l2 = fr.l;
-    }
 
     // a layer's parameter words live in one of two blocks of `pblock` floats (the words actually used)
     const int pblock = (a.param_words + 3) & ~3;
@@ -906,11 +882,12 @@ __global__ void __launch_bounds__(NW * kWave, MINW) rqs_resnet_f16_kernel(const 
                     dst[i] = v;
                 }
                 stream_ensure_next(sm);
-                // the first pair(s) of the stage behind this one (a weight stage after the last p)
-                read_pair<kPairs>(fr.h, fr.l, cur, nxt);
-                if constexpr (Stream::PF == 2) read_pair<kPairs + 1>(fr.h2, fr.l2, cur, nxt);
-                if constexpr (Stream::PF == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr.h), "+v"(fr.l), "+v"(fr.h2), "+v"(fr.l2));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr.h), "+v"(fr.l));
+#ifdef NFA_ABL_CONST_FRAGS
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=v"(fr.h), "=v"(fr.l) : "v"(nxt));
+#else
+                fr = next_frags<kPairs - 1>(cur, nxt);   // pair 0 of the stage behind this one (a weight stage after the last p)
+#endif
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr.h), "+v"(fr.l));
                 stream_advance(sm, true);   // (every wave reads the parameter block all threads have just written)
             }
             const int* tab = reinterpret_cast<const int*>(prm);
@@ -1270,10 +1247,6 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     const int64_t per_cu = (nw == 4 && lds_launch + 2048 <= 80 * 1024) ? 2 : 1;
     const int64_t cap = (int64_t)cus * per_cu;
     if (blocks > cap) blocks = cap;
-    // a batch that gives no CU more than one four-wave workgroup (e.g. config 4's 32 768-row shard of an 8-GPU
-    // run): the one-wave-per-SIMD kernel (512 VGPRs, fragments two groups ahead)
-    static const int no_lone = getenv("NFA_K8H_NO_LONE") ? atoi(getenv("NFA_K8H_NO_LONE")) : 0;
-    const bool lone = nw == 4 && blocks <= cus && !with_ctx && a.sp.K == 8 && !no_lone;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     profile_next_launch(&e0, &e1);
     hipStream_t st = (hipStream_t)stream;
@@ -1283,18 +1256,13 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     int which = with_ctx ? 16 + (inv ? 1 : 0) + (nw == 8 ? 2 : 0) + (a.sp.K == 10 ? 4 : 0)
                          : (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0) + (a.sp.K == 10 ? 8 : 0);
     if (elastic) which = 24 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0);
-    if (lone) which = 28 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0);
     switch (which) {
-#ifdef NFA_K8H_ELASTIC   // (experiment builds only: measured 3 % slower than the rigid stream)
+#ifdef NFA_K8H_ELASTIC   // (experiment builds only: measured 3 % slower than the rigid stream, profiles/r3/k8h_elastic_stream.txt)
         case 24: kern = k8h::rqs_resnet_f16_kernel<false, 2, 8, 8, false, k8h::kRingElastic>; break;
         case 25: kern = k8h::rqs_resnet_f16_kernel<true, 2, 8, 8, false, k8h::kRingElastic>; break;
         case 26: kern = k8h::rqs_resnet_f16_kernel<false, 4, 8, 8, false, k8h::kRingElastic>; break;
         case 27: kern = k8h::rqs_resnet_f16_kernel<true, 4, 8, 8, false, k8h::kRingElastic>; break;
 #endif
-        case 28: kern = k8h::rqs_resnet_f16_kernel<false, 2, 4, 8, false, k8h::kRing, 1>; break;
-        case 29: kern = k8h::rqs_resnet_f16_kernel<true, 2, 4, 8, false, k8h::kRing, 1>; break;
-        case 30: kern = k8h::rqs_resnet_f16_kernel<false, 4, 4, 8, false, k8h::kRing, 1>; break;
-        case 31: kern = k8h::rqs_resnet_f16_kernel<true, 4, 4, 8, false, k8h::kRing, 1>; break;
         case 16: kern = k8h::rqs_resnet_f16_kernel<false, 4, 4, 8, true>; break;
         case 17: kern = k8h::rqs_resnet_f16_kernel<true, 4, 4, 8, true>; break;
         case 18: kern = k8h::rqs_resnet_f16_kernel<false, 4, 8, 8, true>; break;
@@ -1321,7 +1289,7 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
         default: kern = k8h::rqs_resnet_f16_kernel<true, 4, 8, 10>; break;
     }
     if (lds_launch > 64 * 1024) {
-        static unsigned long long raised[32] = {};   // device masks (raise_dynamic_lds)
+        static unsigned long long raised[28] = {};   // device masks (raise_dynamic_lds)
         {
             const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], (int)lds_cap);
             if (rc_lds != NFA_OK) return rc_lds;
