@@ -189,6 +189,20 @@ def test_conditional_32_layer_flow():
     check_flow("conditional_32layer_d64_k8_ctx12_b32768", flow_cpu, x, torch.arange(0, 32768, 4), context=ctx)
 
 
+def test_conditional_ten_bin_flow_in_the_eight_wave_kernel():
+    """Context + 10 bins at D = 64 (the reference's default bin count on a conditional flow): 2 080 parameter
+    words per layer.  Round 2 gave every layer two 8 KB parameter blocks per parameter stage, which left no
+    room for eight row tiles -- four-wave workgroups, one wave per SIMD; since round 3 a block takes the words it
+    uses and the shape runs in the eight-wave kernel.  B = 65 536, 8 layers; the oracle visits every 16th row,
+    the same rows evaluated alone (four-wave kernel) give the same bits."""
+    from nflows_amd import configs
+    flow_cpu = configs.conditional_rq_nsf_flow(num_layers=8, features=64, num_bins=10, hidden_features=128,
+                                               raw_context=5, context_features=12, seed=0).eval()
+    x = bench_rows(65536)
+    ctx = torch.randn(65536, 5, generator=torch.Generator().manual_seed(4321))
+    check_flow("conditional_8layer_d64_k10_ctx12_b65536", flow_cpu, x, torch.arange(0, 65536, 16), context=ctx)
+
+
 def test_forward_inverse_consistency_against_the_reference():
     """Second half of the metric: max |inv(fwd(x)) - x| of the 32-layer composite on the 8 192 rows
     bench.py uses, next to the reference's own fp32 figure on the same rows and weights, and the

@@ -74,6 +74,12 @@ with torch.no_grad():
     ctx = torch.randn(65536, 5, device=dev)
     report("32-layer conditional RQ-NSF (context 12), log_prob", timed(lambda: flow.log_prob(x, context=ctx), 20, warm=10), 65536)
 
+    # the same with the reference's default of 10 bins (round 3: the parameter blocks take the words they use, so
+    # this shape keeps the eight-wave K8h kernel; round 2 ran it on the bf16x3 kernel in 5.8 ms)
+    flow = configs.conditional_rq_nsf_flow(32, 64, 10, 128, 5, 12).to(dev).eval()
+    report("32-layer conditional RQ-NSF (context 12), num_bins = 10, log_prob",
+           timed(lambda: flow.log_prob(x, context=ctx), 20, warm=10), 65536)
+
     # configs[4]: autoregressive RQ spline, D=784, K=8, batch 4096
     flow = configs.ar_rq_flow(784, 256, 8, 3.0, 2).to(dev).eval()
     x = torch.randn(4096, 784, device=dev)

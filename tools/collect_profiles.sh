@@ -14,7 +14,7 @@ OUT=$ROOTDIR/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $ROOTDIR/bench.py --steps 3 --warmup 1 --no-cpu-baseline --skip-extra --skip-consistency"
+BENCH="python $ROOTDIR/bench.py --steps 3 --warmup 1 --no-cpu-baseline --skip-extra --skip-consistency --skip-mfma-ceiling"
 
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_k8/$c -o p -- $BENCH --skip-k1-roofline > $OUT/pmc_k8_$c.log 2>&1
@@ -29,7 +29,7 @@ cp $ROOTDIR/profiles/k8h_pmc_traffic.json $ROOTDIR/profiles/k1_pmc_traffic.json 
 # the raw counter CSVs are large; keep only the summaries
 rm -rf $OUT/pmc_k8 $OUT/pmc_k1
 
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o k -- python $ROOTDIR/bench.py --no-cpu-baseline --skip-extra > $OUT/stats_bench.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o k -- python $ROOTDIR/bench.py --no-cpu-baseline --skip-extra --skip-mfma-ceiling > $OUT/stats_bench.log 2>&1
 DB=$(find $OUT/stats -name '*.db' | head -1)
 python $ROOTDIR/tools/rocprof_summary.py "$DB" $OUT/${TAG}_kernel_stats_bench.csv
 rm -rf $OUT/stats

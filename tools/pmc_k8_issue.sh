@@ -7,7 +7,7 @@ OUT=$ROOTDIR/gpurun_out/pmc_k8_issue
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $ROOTDIR/bench.py --steps 3 --warmup 1 --no-cpu-baseline --skip-consistency --skip-k1-roofline --skip-graph"
+BENCH="python $ROOTDIR/bench.py --steps 3 --warmup 1 --no-cpu-baseline --skip-consistency --skip-k1-roofline --skip-graph --skip-mfma-ceiling"
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA" "GRBM_GUI_ACTIVE SQ_WAVES"; do
   i=$((i+1))
