@@ -122,7 +122,13 @@ struct Args {
     int ce;
 };
 
-#define NFA_HSTAMP() if (tr && ti < 63) tr[ti++] = __builtin_readcyclecounter();
+// (debug stamps: the switch and the index are wave-uniform -- scalar registers -- and the pointer is rebuilt from the
+//  kernel arguments at every stamp: a per-lane pointer kept for the whole kernel cost three vector registers)
+#define NFA_HSTAMP()                                                                                   \
+    if (tracing && ti < 63) {                                                                          \
+        if (lane == 0) a.trace[(size_t)blockIdx.x * 64 + ti] = __builtin_readcyclecounter();           \
+        ++ti;                                                                                          \
+    }
 
 // NW = waves per workgroup (4 or 8) sharing the ring; RING = slots of 16 KB.
 //
@@ -783,11 +789,11 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
     const int64_t num_quads = a.batch / (32 * NW);   // row blocks of this workgroup size
     int pb = 0;  // which parameter block the current layer uses
 
-    unsigned long long* tr = nullptr;
+    const bool tracing = a.trace != nullptr && __builtin_amdgcn_readfirstlane(wave) == 0;
     int ti = 1;
-    if (a.trace && lane == 0 && wave == 0) {
-        tr = a.trace + (size_t)blockIdx.x * 64;
-        tr[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // HW_ID, XCC_ID
+    if (tracing) {
+        if (lane == 0)
+            a.trace[(size_t)blockIdx.x * 64] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // HW_ID, XCC_ID
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     for (int64_t quad = blockIdx.x; quad < num_quads; quad += gridDim.x) {
