@@ -206,8 +206,8 @@ typedef float vec4 __attribute__((ext_vector_type(4)));  // native 16-byte vecto
 #ifndef NFA_PIPE_WAVES
 #define NFA_PIPE_WAVES 4
 #endif
-template <int KT, bool INVERSE, bool LINEAR, int DEPTH = 1>
-__global__ void __launch_bounds__(kBlock, DEPTH == 2 ? 3 : NFA_PIPE_WAVES) rqs_coupling_pipelined(const CouplingArgs a) {
+template <int KT, bool INVERSE, bool LINEAR>
+__global__ void __launch_bounds__(kBlock, NFA_PIPE_WAVES) rqs_coupling_pipelined(const CouplingArgs a) {
     // float4 per lane per tile: enough for 256 splines of 3K+1 logits (lanes past the tile's end
     // re-read its last vector)
     constexpr int NV = (3 * KT + 1 + 3) / 4;
@@ -289,40 +289,37 @@ __global__ void __launch_bounds__(kBlock, DEPTH == 2 ? 3 : NFA_PIPE_WAVES) rqs_c
     const int64_t tile_stride_p = (int64_t)nitems * P;  // floats
     const int tile_stride_x = R * D;
 
-    // two register sets (p / q): with DEPTH == 2 the lanes carry the next TWO tiles, loaded alternately -- the
-    // loads of tile t + 2 are issued while those of t + 1 may still be in flight (plain loads return in order:
-    // the compiler's counted vmcnt in front of the LDS writes of set p leaves set q's loads alone)
     vec4 pr0, pr1, pr2, pr3, pr4, pr5, pr6, pr7;
-    vec4 qr0, qr1, qr2, qr3, qr4, qr5, qr6, qr7;
-    vec4 xr, yr;
-#define NFA_LD(S, k)                                                           \
+    vec4 xr;
+#define NFA_LD(k)                                                              \
     if (NV > k) {                                                              \
         const int v_ = k * kBlock + tid;                                       \
-        S##r##k = NFA_STREAM_LOAD(&gp_[v_ < nvp ? v_ : nvp - 1]);              \
+        pr##k = NFA_STREAM_LOAD(&gp_[v_ < nvp ? v_ : nvp - 1]);                \
     }
-#define NFA_ST(S, k)                                                           \
+#define NFA_ST(k)                                                              \
     if (NV > k) {                                                              \
         const int v_ = k * kBlock + tid;                                       \
-        if (v_ < nvp) reinterpret_cast<vec4*>(s_p)[v_] = S##r##k;            \
+        if (v_ < nvp) reinterpret_cast<vec4*>(s_p)[v_] = pr##k;              \
     }
     // index-clamped, unconditional loads: the tile stays in VGPRs; past the last tile the lanes
     // re-read tile 0 (L2-resident by then), the data is never used
-#define NFA_ISSUE_TILE(S, X, TILE)                                                              \
+#define NFA_ISSUE_TILE(TILE)                                                                    \
     {                                                                                           \
         const int64_t t_ = (TILE) < num_tiles ? (TILE) : 0;                                     \
         const vec4* gp_ = reinterpret_cast<const vec4*>(a.params + t_ * tile_stride_p);     \
         const vec4* gx_ = reinterpret_cast<const vec4*>(a.x + t_ * tile_stride_x);          \
-        NFA_LD(S, 0) NFA_LD(S, 1) NFA_LD(S, 2) NFA_LD(S, 3) NFA_LD(S, 4) NFA_LD(S, 5) NFA_LD(S, 6) NFA_LD(S, 7) \
-        X = gx_[tid < nvx ? tid : nvx - 1];                                                     \
+        NFA_LD(0) NFA_LD(1) NFA_LD(2) NFA_LD(3) NFA_LD(4) NFA_LD(5) NFA_LD(6) NFA_LD(7)         \
+        xr = gx_[tid < nvx ? tid : nvx - 1];                                                    \
     }
-#define NFA_STORE_TILE(S, X)                                                                    \
-    NFA_ST(S, 0) NFA_ST(S, 1) NFA_ST(S, 2) NFA_ST(S, 3) NFA_ST(S, 4) NFA_ST(S, 5) NFA_ST(S, 6) NFA_ST(S, 7) \
-    if (tid < nvx) reinterpret_cast<vec4*>(s_x)[tid] = X;
 
     const int64_t num_tiles = a.batch / R;
     int64_t tile = blockIdx.x;
-    // everything between the LDS writes of a tile and the store of its results
-    auto process = [&](int64_t tile_) {
+    NFA_ISSUE_TILE(tile)
+    for (; tile < num_tiles; tile += gridDim.x) {
+        NFA_ST(0) NFA_ST(1) NFA_ST(2) NFA_ST(3) NFA_ST(4) NFA_ST(5) NFA_ST(6) NFA_ST(7)
+        if (tid < nvx) reinterpret_cast<vec4*>(s_x)[tid] = xr;
+        const int64_t next = tile + gridDim.x;
+        NFA_ISSUE_TILE(next)  // in flight until the next iteration's LDS writes
         lds_barrier();
 
         if (cp_src0 >= 0) s_out[cp_dst0] = s_x[cp_src0];
@@ -333,7 +330,7 @@ __global__ void __launch_bounds__(kBlock, DEPTH == 2 ? 3 : NFA_PIPE_WAVES) rqs_c
             my_status |= rqs_eval<KT, INVERSE, LINEAR>(s_x[it_x], const_cast<float*>(it_p), a.sp, y, l);
             s_out[it_y] = y;
         }
-        const int64_t row0 = tile_ * R;
+        const int64_t row0 = tile * R;
         if (lad_shuffle) {
             for (int off = dt >> 1; off > 0; off >>= 1) l += __shfl_xor(l, off, kWave);
             if (has_item && (tid & (dt - 1)) == 0) {
@@ -356,30 +353,7 @@ __global__ void __launch_bounds__(kBlock, DEPTH == 2 ? 3 : NFA_PIPE_WAVES) rqs_c
                 if (lane == 0) a.lad[row0 + r] = a.accumulate ? a.lad[row0 + r] + v : v;
             }
         }
-    };
-    if constexpr (DEPTH == 2) {
-        NFA_ISSUE_TILE(p, xr, tile)
-        NFA_ISSUE_TILE(q, yr, tile + gridDim.x)
-        for (; tile < num_tiles; tile += 2 * (int64_t)gridDim.x) {
-            NFA_STORE_TILE(p, xr)
-            NFA_ISSUE_TILE(p, xr, tile + 2 * (int64_t)gridDim.x)
-            process(tile);
-            const int64_t second = tile + gridDim.x;
-            if (second >= num_tiles) break;
-            NFA_STORE_TILE(q, yr)
-            NFA_ISSUE_TILE(q, yr, second + 2 * (int64_t)gridDim.x)
-            process(second);
-        }
-    } else {
-        NFA_ISSUE_TILE(p, xr, tile)
-        for (; tile < num_tiles; tile += gridDim.x) {
-            NFA_STORE_TILE(p, xr)
-            const int64_t next = tile + gridDim.x;
-            NFA_ISSUE_TILE(p, xr, next)  // in flight until the next iteration's LDS writes
-            process(tile);
-        }
     }
-#undef NFA_STORE_TILE
 #undef NFA_ISSUE_TILE
 #undef NFA_LD
 #undef NFA_ST
@@ -494,15 +468,7 @@ static int launch_coupling(const CouplingArgs& a, int inverse, dim3 grid, size_t
 }
 
 template <int KT>
-static int launch_pipelined(const CouplingArgs& a, int inverse, dim3 grid, size_t lds, hipStream_t st, int depth = 1) {
-    if (depth == 2 && KT == 8 && a.sp.linear) {   // (two tiles carried in registers, three workgroups per CU)
-        if (inverse)
-            launch_k1(rqs_coupling_pipelined<8, true, true, 2>, grid, dim3(kBlock), lds, st, a);
-        else
-            launch_k1(rqs_coupling_pipelined<8, false, true, 2>, grid, dim3(kBlock), lds, st, a);
-        NFA_HIP_CHECK(hipGetLastError());
-        return NFA_OK;
-    }
+static int launch_pipelined(const CouplingArgs& a, int inverse, dim3 grid, size_t lds, hipStream_t st) {
     if (a.sp.linear) {
         if (inverse)
             launch_k1(rqs_coupling_pipelined<KT, true, true>, grid, dim3(kBlock), lds, st, a);
@@ -633,9 +599,7 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
         f.batch = full_rows;
         // one block fewer per CU than LDS alone would allow: the prefetch registers cost occupancy
         // (K = 4 needs only ~76 VGPRs: 6 waves per SIMD)
-        static const int depth_env = getenv("NFA_K1_DEPTH") ? atoi(getenv("NFA_K1_DEPTH")) : 1;
-        const int depth = (depth_env == 2 && a.sp.K == 8 && a.sp.linear) ? 2 : 1;
-        const int pipe_blocks = depth == 2 ? 3 : (a.sp.K <= 4 ? 6 : NFA_PIPE_WAVES);
+        const int pipe_blocks = a.sp.K <= 4 ? 6 : NFA_PIPE_WAVES;
         int64_t gp = (int64_t)cus * (per_cu > pipe_blocks ? pipe_blocks : per_cu);
         if (gp > full_rows / R) gp = full_rows / R;
         const dim3 pgrid((unsigned)gp);
@@ -643,7 +607,7 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
         switch (a.sp.K) {
             case 4: prc = launch_pipelined<4>(f, inverse, pgrid, lds, st); break;
             case 10: prc = launch_pipelined<10>(f, inverse, pgrid, lds, st); break;
-            default: prc = launch_pipelined<8>(f, inverse, pgrid, lds, st, depth); break;
+            default: prc = launch_pipelined<8>(f, inverse, pgrid, lds, st); break;
         }
         if (prc != NFA_OK || full_rows == batch) return prc;
         // leftover rows (< R): generic kernel on the tail of every array
