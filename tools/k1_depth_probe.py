@@ -1,6 +1,7 @@
-"""K1 (the unfused spline coupling kernel) at the bench's layer shape, B rows: time per launch and a checksum of
-the results -- run once per setting of NFA_K1_DEPTH (1 = one tile carried in registers, 2 = two), the checksums must
-be equal (same arithmetic, same order).   [NFA_K1_DEPTH=2] python tools/k1_depth_probe.py [rows]"""
+"""K1 (the unfused spline coupling kernel) at the bench's layer shape, B rows: time per launch (parameters rotated
+over four buffers: nothing served from the Infinity Cache) and a checksum of the results.  Round 3 used it to compare
+the kernel with a variant carrying TWO tiles in registers (NFA_K1_DEPTH=2, since removed: slower, same checksum --
+profiles/r3/k1_two_tile_prefetch.txt).   python tools/k1_depth_probe.py [rows]"""
 import hashlib, os, sys
 import numpy as np
 import torch
