@@ -100,7 +100,7 @@ class SmiSampler:
             r = self.read()
             if r is not None:
                 self.samples.append(r)
-            time.sleep(0.1)
+            time.sleep(0.25)
 
     def __enter__(self):
         import threading
