@@ -144,13 +144,32 @@ with torch.no_grad():
         else:
             add(name, "same, split-bf16", us, flops=12.0 * B * macs_final, peak_note="bf16 (peak 2 500); fp32-equivalent %.0f" % (2.0 * B * macs_final / us / 1e6))
     RQ.fuse_conditioner, RQ.fuse_final_linear, RQ.final_linear_engine = True, True, "bf16x3"
-    us = timeit(lambda: layer(x))
-    add("K8 `rqs_resnet_kernel`, 1 layer", "ResidualNet conditioner + spline layer, B=65536", us, flops=12.0 * B * macs_all, peak_note="bf16 (peak 2 500); fp32-equivalent %.0f" % (2.0 * B * macs_all / us / 1e6))
-    us = timeit(lambda: flow._transform(x), reps=10, inner=2)
-    add("K8, run of 32 layers", "the whole BASELINE transform in one launch, B=65536", us, flops=32 * 12.0 * B * macs_all, peak_note="bf16 (peak 2 500); fp32-equivalent %.0f" % (32 * 2.0 * B * macs_all / us / 1e6))
+    for engine, name, products, pipe in (("bf16x3", "K8 `rqs_resnet_kernel` (three bf16 pieces, 6 products)", 6, "bf16"),
+                                         ("f16x2", "K8h `rqs_resnet_f16_kernel` (two f16 pieces, 3 products)", 3, "f16")):
+        RQ.conditioner_engine = engine
+        nflows_amd.invalidate_packed_weights()
+        us = timeit(lambda: layer(x))
+        add(name + ", 1 layer", "ResidualNet conditioner + spline layer, B=65536", us, flops=products * 2.0 * B * macs_all,
+            peak_note="%s (peak 2 500); fp32-equivalent %.0f" % (pipe, 2.0 * B * macs_all / us / 1e6))
+        us = timeit(lambda: flow._transform(x), reps=10, inner=2)
+        add(name.split(" ")[0] + ", run of 32 layers", "the whole BASELINE transform in one launch, B=65536", us,
+            flops=32 * products * 2.0 * B * macs_all,
+            peak_note="%s (peak 2 500); fp32-equivalent %.0f" % (pipe, 32 * 2.0 * B * macs_all / us / 1e6))
+    # K11: a run of affine layers with MLP conditioners (BASELINE configs[1]); K12: the autoregressive inverse (configs[4])
+    aff = configs.affine_coupling_flow(8, 32, (128, 128)).to(dev).eval()
+    xa = torch.randn(16384, 32, device=dev, generator=g)
+    us = timeit(lambda: aff._transform(xa))
+    add("K11 `affine_mlp_kernel`, run of 8 layers", "8 affine coupling layers + MLP conditioners, B=16384 D=32", us,
+        flops=8 * 6 * 2.0 * 16384 * (16 * 128 + 128 * 128 + 128 * 32), peak_note="bf16 (peak 2 500)")
+    ar = configs.ar_rq_flow(784, 256, 8, 3.0, 2).to(dev).eval()
+    za = torch.randn(4096, 784, device=dev, generator=g)
+    t_ar = ar._transform._transforms[0]
+    us = timeit(lambda: t_ar.inverse(za), reps=10, inner=2)
+    rows.append("| K12 `made_rqs_inverse_kernel` + tail | autoregressive RQ inverse, D=784 H=256 B=4096 (256 sequential steps) | %.1f | %.2f us per step and 16 samples: latency-bound |"
+                % (us, us / 256))
     nflows_amd.check_status()
 
-print("# Kernel table (round 1, 1 x MI355X; `python tools/all_kernels.py`)\n")
+print("# Kernel table (round 3, 1 x MI355X; `python tools/all_kernels.py`)\n")
 print("GPU time per call: 10 calls captured in one HIP graph, median of 30 replays / 10 (the backward through")
 print("C entry point is called directly); rates are ALGORITHMIC bytes or flops per launch over that time.  The helper")
 print("kernels next to a call (output allocation is free, a status-word memset is not) are included.\n")
