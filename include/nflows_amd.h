@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NFA_ABI_VERSION 3  /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3) */
+#define NFA_ABI_VERSION 4  /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3) */
 
 /* return codes */
 #define NFA_OK 0
@@ -317,6 +317,29 @@ int nfa_rqs_flow_resnet_f16x2_f32(const float *inputs, const void *stream_packed
                                   int32_t features, int32_t num_transform, int32_t num_identity,
                                   int32_t hidden_features, int32_t num_blocks,
                                   const nfa_rqs_spec *spec, int32_t flags, void *stream);
+
+/*
+ * K8s.  nfa_rqs_flow_resnet_f16x2_f32 (same reference lines: nn/nets/resnet.py:55-100, coupling.py:73-130,
+ * :549-582, a run of layers in one launch, optionally with the base density) on SIXTEEN-sample tiles
+ * (v_mfma_f32_16x16x32_f16): a batch that gives a CU at most one 128-row block -- config 4's 32 768-row shard
+ * of an 8-GPU run, interactive batches -- gets twice the waves with half the matrix work each.  Same arguments,
+ * same semantics (`redo_blocks` included); `stream_packed` has the same stages and parameter words with the
+ * orders of this tile shape (ops.pack_resnet_conditioner_f16(tile16=True)):
+ *   lane l = (sample n = l % 16, lane group g = l / 16); a fragment is [64 lanes][8 halves] with lane l holding
+ *   row 16 T + l % 16, MFMA k position 8 (l / 16) + j; GEMM inputs made of accumulator tiles use the column rule
+ *   col(S, g, j) = 32 S + 16 (j / 4) + 4 g + j % 4; initial / hidden Linears: one stage per 32-wide k-step S,
+ *   pair T = output tile T (16 rows); final Linear: one stage per TWO 16-row tiles, pair 4 (t % 2) + S; its rows
+ *   ordered so that tile 6 G + tau, row 4 g + i = logit 4 tau + i of feature 4 G + g (padded to 24); every GEMM's
+ *   biases in natural row order.
+ * Supported: num_bins = 8, linear tails, no context, hidden_features = 128, d_i <= 64, d_t % 4 == 0, d_t <= 64,
+ * features % 4 == 0, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
+ */
+int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float *inputs, const void *stream_packed, int32_t param_stages,
+                                         const int32_t *final_positions, int32_t num_layers, float *outputs,
+                                         float *logabsdet, int32_t *redo_blocks, int32_t *status, int64_t batch,
+                                         int32_t features, int32_t num_transform, int32_t num_identity,
+                                         int32_t hidden_features, int32_t num_blocks,
+                                         const nfa_rqs_spec *spec, int32_t flags, void *stream);
 
 /*
  * nfa_rqs_flow_resnet_f32 for conditioners that take a context (nn/nets/resnet.py:9-52, :92-100):

@@ -807,6 +807,27 @@ def _k8_column_order():
     return (32 * (ks // 2) + 16 * (ks % 2) + 8 * (j // 4) + 4 * hf + j % 4).reshape(-1)  # [ks][hf][j]
 
 
+def _k8s_column_order():
+    """K8s (16-sample tiles, MFMA 16x16x32): input feature at MFMA k position 32 S + 8 g + j of a GEMM whose input
+    is the previous layer's accumulator tiles -- lane group g holds features 4 g + i (i = 0..3) of every 16-feature
+    tile, k-step S is made of tiles 2 S (j < 4) and 2 S + 1 (j >= 4)."""
+    S = torch.arange(4)[:, None, None]
+    g = torch.arange(4)[None, :, None]
+    j = torch.arange(8)[None, None, :]
+    return (32 * S + 16 * (j // 4) + 4 * g + j % 4).reshape(-1)  # [S][g][j]
+
+
+def _k8s_row_order(num_transform):
+    """K8s: for every row of the packed (tile-major, 16-row tiles) final weight, which row of the feature-major
+    padded matrix [d_t, 24] it is: the six tiles of a group G of four features give lane group g (rows 4 g + i
+    of every tile) the 24 logits of feature 4 G + g, tile tau holding logits 4 tau + i."""
+    tiles = num_transform * 24 // 16
+    t = torch.arange(tiles)[:, None]
+    m = torch.arange(16)[None, :]
+    feat = 4 * (t // 6) + m // 4
+    return (feat * 24 + 4 * (t % 6) + m % 4).reshape(-1)  # [tiles * 16]
+
+
 def _bias_accumulator_order(b):
     """[tiles*32] -> [tiles][2 lane-halves][16]: row i of a tile sits in accumulator register
     q = 4*(i//8) + i%4 of lane-half (i//4)%2."""
@@ -890,7 +911,7 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False,
         bf = torch.cat((bf, bf.new_zeros(pad_transform_to - dt, P)), dim=0)
         dt = pad_transform_to
     R = 24 if P <= 24 else 32  # rows per feature after padding (8 bins: 23 -> 24; 10 bins: 29 -> 32)
-    order_r = (_k7_row_order(dt) if R == 24 else _k8_row_order_32(dt)).to(dev)
+    order_r = (_k8s_row_order(dt) if tile16 else _k7_row_order(dt) if R == 24 else _k8_row_order_32(dt)).to(dev)
     wf = torch.cat((wf, wf.new_zeros(dt, R - P, 128)), dim=1).reshape(dt * R, 128)
     wf = wf.index_select(0, order_r).index_select(1, order_k)
     bf = torch.cat((bf, bf.new_zeros(dt, R - P)), dim=1).reshape(dt * R).index_select(0, order_r)
@@ -1013,7 +1034,7 @@ def _f16_weight_scale(w):
 
 
 def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scale=1.0, pad_transform_to=None,
-                                pad_identity_to=None):
+                                pad_identity_to=None, tile16=False):
     """Packs a ResidualNet for K8h (csrc/rqs_resnet_f16.hip; layout in include/nflows_amd.h).
 
     Weights: every GEMM's weights as TWO f16 pieces of (weight x T), T a power of two chosen per
@@ -1026,6 +1047,9 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
     (a power of two); the residual stream stays in fp32 accumulators at the scale of the GEMM that
     wrote it last, and a block's second Linear multiplies it by skip_scale = (its own scale) /
     (that scale) when it prepares its accumulators.  8 bins only.
+    `tile16`: the same network for K8s (csrc/rqs_resnet_f16s.hip: 16-sample tiles on the 16x16x32 MFMA) -- the same
+    stages and parameter words with the fragments, column / row orders and bias order of that tile shape (no
+    context, 8 bins).
     Returns (weights [stages, 4096] f16, parameter words fp32)."""
     dt, P = num_transform, params_per_feature
     K = (P + 1) // 3
@@ -1033,7 +1057,11 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
         raise ValueError("K8h packs 8- and 10-bin linear-tail layers")
     S = float(act_scale)
     dev = net.final_layer.weight.device
-    order_k = _k8_column_order().to(dev)
+    order_k = (_k8s_column_order() if tile16 else _k8_column_order()).to(dev)
+    if tile16 and (P != 23 or getattr(net, "context_features", None)):
+        raise ValueError("K8s packs 8-bin layers without a context")
+    # accumulator order of a GEMM's biases: K8s holds rows 4 g + i of a 16-row tile in lane group g: natural order
+    bias_order = (lambda b: b) if tile16 else _bias_accumulator_order
 
     def pieces(w):
         return torch.stack(split_f16x2(w))  # [2, ...]
@@ -1058,21 +1086,28 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
         init_ks = 4 if di > 32 else 2
         wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
     T = _f16_weight_scale(wi)
-    # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one 16 KB stage of 2 x 4 tile pairs per two k-steps
-    stages.append(pieces(wi * T).view(2, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks // 2, -1))
-    blob += [header(S / T, 0.0), _bias_accumulator_order(_pad_to(net.initial_layer.bias.detach().float(), rows=128) * T)]
+    if tile16:
+        # k-major, one stage per 32-wide k-step: (p, T, m, S, g, j) -> (S, T, p, g, m, j): pair T of stage S = the
+        # (hi, lo) fragments of tile T, lane g * 16 + m holding k = 32 S + 8 g + j
+        stages.append(pieces(wi * T).view(2, 8, 16, init_ks // 2, 4, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks // 2, -1))
+    else:
+        # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one 16 KB stage of 2 x 4 tile pairs per two k-steps
+        stages.append(pieces(wi * T).view(2, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks // 2, -1))
+    blob += [header(S / T, 0.0), bias_order(_pad_to(net.initial_layer.bias.detach().float(), rows=128) * T)]
     stream_scale = T          # scale of the fp32 residual stream after the initial layer (inputs at scale 1)
     for block in net.blocks:
         for which, lin in enumerate(block.linear_layers):
             w = _pad_to(lin.weight.detach().float(), rows=128, cols=128).index_select(1, order_k)  # columns in (ks, hf, j) order
             T = _f16_weight_scale(w)
-            # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one stage per k-step
-            stages.append(pieces(w * T).view(2, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(4, -1))
+            if tile16:   # (p, T, m, S, g, j) -> (S, T, p, g, m, j), one stage per 32-wide k-step
+                stages.append(pieces(w * T).view(2, 8, 16, 4, 4, 8).permute(3, 1, 0, 4, 2, 5).reshape(4, -1))
+            else:        # k-major: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j), one stage per two k-steps
+                stages.append(pieces(w * T).view(2, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(4, -1))
             lin_bias = _pad_to(lin.bias.detach().float(), rows=128)
             if which == 0:   # accumulators = S T (W relu(h) + b)
-                blob += [header(1.0 / T, 0.0), _bias_accumulator_order(lin_bias * (S * T))]
+                blob += [header(1.0 / T, 0.0), bias_order(lin_bias * (S * T))]
             else:            # accumulators = S T (W relu(u) + b + h), h taken from the stream at stream_scale
-                blob += [header(1.0 / T, S * T / stream_scale), _bias_accumulator_order(lin_bias * (S * T))]
+                blob += [header(1.0 / T, S * T / stream_scale), bias_order(lin_bias * (S * T))]
                 stream_scale = S * T
         if ce:
             # the gate's Linear on the context pieces (scale 1): two k-steps like the initial layer's, one stage;
@@ -1094,15 +1129,20 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
         bf = torch.cat((bf, bf.new_zeros(pad_transform_to - dt, P)), dim=0)
         dt = pad_transform_to
     R = 24 if P == 23 else 32   # rows per feature after padding
-    order_r = (_k7_row_order(dt) if R == 24 else _k8_row_order_32(dt)).to(dev)
+    order_r = (_k8s_row_order(dt) if tile16 else _k7_row_order(dt) if R == 24 else _k8_row_order_32(dt)).to(dev)
     wf = torch.cat((wf, wf.new_zeros(dt, R - P, 128)), dim=1).reshape(dt * R, 128)
     wf = wf.index_select(0, order_r).index_select(1, order_k)
     bf = torch.cat((bf, bf.new_zeros(dt, R - P)), dim=1).reshape(dt * R).index_select(0, order_r)
     T = _f16_weight_scale(wf)
-    tiles = dt * R // 32
-    stages.append(pieces(wf * T).view(2, tiles, 32, 2, 4, 2, 8).permute(1, 3, 4, 0, 5, 2, 6).reshape(tiles, -1))
+    if tile16:
+        # tile-major, two 16-row tiles per stage: (p, tile, m, S, g, j) -> (tile, S, p, g, m, j)
+        tiles = dt * R // 16
+        stages.append(pieces(wf * T).view(2, tiles, 16, 4, 4, 8).permute(1, 3, 0, 4, 2, 5).reshape(tiles // 2, -1))
+    else:
+        tiles = dt * R // 32
+        stages.append(pieces(wf * T).view(2, tiles, 32, 2, 4, 2, 8).permute(1, 3, 4, 0, 5, 2, 6).reshape(tiles, -1))
     # the spline evaluation reads logits = accumulators x kappa, kappa = 1 / (S T)
-    blob += [header(1.0 / (S * T), S * T), _bias_accumulator_order(bf * (S * T))]
+    blob += [header(1.0 / (S * T), S * T), bias_order(bf * (S * T))]
     return torch.cat(stages, dim=0).contiguous(), torch.cat(blob).contiguous()
 
 
@@ -1304,27 +1344,47 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
     return out, lad
 
 
+K8S_ENABLED = os.environ.get("NFA_K8S", "1") != "0"
+_cu_counts = {}
+
+
+def use_tile16(batch, num_bins, context, device):
+    """K8s (16-sample tiles, csrc/rqs_resnet_f16s.hip) serves the batches that give a CU at most ONE 128-row block
+    -- K8h would run them one wave per SIMD (or leave CUs idle): 8 bins, no context.  `NFA_K8S=0` switches it off."""
+    if not K8S_ENABLED or num_bins != 8 or context is not None:
+        return False
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    cus = _cu_counts.get(key)
+    if cus is None:
+        cus = _cu_counts[key] = torch.cuda.get_device_properties(key).multi_processor_count
+    return (batch + 127) // 128 <= cus
+
+
 def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transform, num_identity, num_blocks,
                             spec, inverse=False, accumulate_into=None, num_layers=1,
-                            standard_normal_log_prob=False, pad=None, context=None, _pad_columns_count=0):
+                            standard_normal_log_prob=False, pad=None, context=None, _pad_columns_count=0,
+                            tile16=False):
     """K8h -- the run of whole-layer kernels on the f16 matrix pipe (two f16 pieces per operand),
     followed by the exact kernel (three bf16 pieces, full fp32 range) on the row blocks the first
     pass gave up on: blocks with a non-finite result, i.e. an activation beyond the f16 range or
     non-finite inputs.  `stream_f16`: (stream, parameter stages per layer, final table) from
     `build_f16_stream`; `packed_exact`: (weights, biases) from pack_resnet_conditioner; `tables`:
-    the run's `flow_layer_tables` (for the exact kernel).  Results as for `rqs_coupling_resnet`."""
+    the run's `flow_layer_tables` (for the exact kernel).  `tile16`: `stream_f16` was packed for K8s
+    (pack_resnet_conditioner_f16(tile16=True)) and the launch goes to the 16-sample-tile kernel.
+    Results as for `rqs_coupling_resnet`."""
     N.require_device_f32("inputs", inputs, 2)
     if pad is not None and inputs.shape[1] != pad[0]:   # (see rqs_coupling_resnet)
         out = rqs_coupling_resnet_f16(_pad_columns(inputs, pad[0], pad[1]), stream_f16, packed_exact, tables,
                                       num_transform, num_identity, num_blocks, spec, inverse, accumulate_into,
                                       num_layers, standard_normal_log_prob, None, context,
-                                      pad[0] - inputs.shape[1])
+                                      pad[0] - inputs.shape[1], tile16)
         return _without_pad_columns(out, inputs.shape[1])
     if inputs.shape[0] % 128:
         return _on_full_blocks(
             lambda x_, acc_, ctx_: rqs_coupling_resnet_f16(x_, stream_f16, packed_exact, tables, num_transform,
                                                            num_identity, num_blocks, spec, inverse, acc_, num_layers,
-                                                           standard_normal_log_prob, None, ctx_, _pad_columns_count),
+                                                           standard_normal_log_prob, None, ctx_, _pad_columns_count,
+                                                           tile16),
             inputs, accumulate_into, context)
     dev = inputs.device
     B, D = inputs.shape
@@ -1344,7 +1404,8 @@ def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transf
             raise ValueError("context must have one row per input row")
     with torch.cuda.device(dev):
         if ctx is None:
-            rc = lib.nfa_rqs_flow_resnet_f16x2_f32(
+            entry = lib.nfa_rqs_flow_resnet_f16x2_tile16_f32 if tile16 else lib.nfa_rqs_flow_resnet_f16x2_f32
+            rc = entry(
                 N.ptr(x), N.ptr(stream), param_stages, N.ptr(final_table), num_layers, N.ptr(out),
                 N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128,
                 num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))

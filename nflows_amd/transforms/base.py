@@ -187,7 +187,7 @@ class CompositeTransform(Transform):
             return [], start
         return units, i
 
-    def _run_plan(self, units, inverse):
+    def _run_plan(self, units, inverse, tile16=False):
         """Concatenated weight / bias blobs and the composed tables of a run, cached until a weight or a
         permutation changes.  (weights, biases, tables, f16 stream or None)."""
         from .. import ops
@@ -197,7 +197,8 @@ class CompositeTransform(Transform):
         geometry = _run_geometry(units)   # one padded geometry for the run
         f16 = (not mlp) and first._use_f16(geometry)
         # (the key reads version counters only; the layers' packed blobs are looked at on a miss)
-        key = (inverse, f16, geometry, first._log2e() if not mlp else None, first.conditioner_act_scale if f16 else None,
+        tile16 = tile16 and f16
+        key = (inverse, f16, tile16, geometry, first._log2e() if not mlp else None, first.conditioner_act_scale if f16 else None,
                tuple([id(c) for c, _ in units]),
                tuple([_weights_key(c, c.transform_net) for c, _ in units]),
                tuple([None if p is None else (id(p._permutation), p._permutation._version) for _, p in units]))
@@ -207,7 +208,7 @@ class CompositeTransform(Transform):
             if len(cache) > 4:
                 cache.clear()
             packed = [c._packed_mlp() if mlp else c._packed_resnet(geometry) for c, _ in units]
-            packed_f16 = [c._packed_resnet_f16(geometry) for c, _ in units] if f16 else None
+            packed_f16 = [c._packed_resnet_f16(geometry, tile16) for c, _ in units] if f16 else None
             weights = torch.cat([w for w, _ in packed], dim=0).contiguous()
             biases = torch.cat([b for _, b in packed]).contiguous()
             spec_layers = []
@@ -232,7 +233,10 @@ class CompositeTransform(Transform):
         for _, p in units:
             if p is not None:
                 p._check(inputs)
-        weights, biases, tables, plan_f16 = self._run_plan(units, inverse)
+        # (batches that give a CU at most one 128-row block: the 16-sample-tile kernel K8s and its own stream)
+        tile16 = (hasattr(first, "_use_f16") and inputs.is_cuda
+                  and ops.use_tile16(inputs.shape[0], getattr(first, "num_bins", 0), context, inputs.device))
+        weights, biases, tables, plan_f16 = self._run_plan(units, inverse, tile16)
         Dp, dt4, di_u, pad_value = _run_geometry(units)
         pad = (Dp, pad_value)
         if type(first).__name__ in ("AffineCouplingTransform", "AdditiveCouplingTransform"):
@@ -245,7 +249,7 @@ class CompositeTransform(Transform):
                 inputs, plan_f16, (weights, biases), tables, dt4,
                 di_u, len(first.transform_net.blocks), first._spec(), inverse,
                 total, num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob, pad=pad,
-                context=context)
+                context=context, tile16=tile16 and first._use_f16(_run_geometry(units)))
         else:
             head = ops.rqs_coupling_resnet(
                 inputs, weights, biases, tables, dt4, di_u,

@@ -554,23 +554,26 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         return (self.conditioner_engine == "f16x2" and self.num_bins in (8, 10) and not self._log2e()
                 and (ce is None or (ce <= 32 and (geometry or self._fused_geometry())[2] <= 32)))
 
-    def _packed_resnet_f16(self, geometry=None):
+    def _packed_resnet_f16(self, geometry=None, tile16=False):
+        """(weights, parameter words) for K8h, or -- `tile16` -- for K8s (the 16-sample-tile kernel of small batches)."""
         net = self.transform_net
         _, dt4, di_u, _ = geometry or self._fused_geometry()
-        key = (self.conditioner_act_scale, dt4, di_u) + _weights_key(self, net)
-        cached = getattr(self, "_packed_resnet_f16_cache", None)
+        key = (self.conditioner_act_scale, dt4, di_u, tile16) + _weights_key(self, net)
+        slot = "_packed_resnet_f16s_cache" if tile16 else "_packed_resnet_f16_cache"
+        cached = self.__dict__.get(slot)
         if cached is None or cached[0] != key:
             cached = (key, ops.pack_resnet_conditioner_f16(net, self.num_transform_features,
                                                            self._transform_dim_multiplier(),
                                                            act_scale=self.conditioner_act_scale,
-                                                           pad_transform_to=dt4, pad_identity_to=di_u))
-            self._packed_resnet_f16_cache = cached
+                                                           pad_transform_to=dt4, pad_identity_to=di_u, tile16=tile16))
+            self.__dict__[slot] = cached
         return cached[1]
 
-    def _f16_stream(self, tables):
-        """K8h stream of this layer alone (its parameter stage carries `tables`), cached per table set."""
-        pack = self._packed_resnet_f16()
-        key = (self._packed_resnet_f16_cache[0], tables.data_ptr(), tables._version)
+    def _f16_stream(self, tables, tile16=False):
+        """K8h / K8s stream of this layer alone (its parameter stage carries `tables`), cached per table set."""
+        pack = self._packed_resnet_f16(tile16=tile16)
+        key = (self.__dict__["_packed_resnet_f16s_cache" if tile16 else "_packed_resnet_f16_cache"][0],
+               tables.data_ptr(), tables._version)
         cache = self.__dict__.setdefault("_f16_stream_cache", {})
         hit = cache.get(key)
         if hit is None:
@@ -617,10 +620,12 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         Dp, dt4, di, pad_value = self._fused_geometry()
         spec = self._spec()
         # (ragged batches are padded to full 128-row blocks, odd shapes to multiples of four columns, in `ops`)
-        stream = self._f16_stream(tables) if self._use_f16() else None   # (None: non-finite weights -> exact kernel)
+        tile16 = self._use_f16() and inputs.is_cuda and ops.use_tile16(inputs.shape[0], self.num_bins, context, inputs.device)
+        stream = self._f16_stream(tables, tile16) if self._use_f16() else None   # (None: non-finite weights -> exact kernel)
         if stream is not None:
             return ops.rqs_coupling_resnet_f16(inputs, stream, (wp, bp), tables, dt4, di, nb, spec,
-                                               inverse, accumulate_into, pad=(Dp, pad_value), context=context)
+                                               inverse, accumulate_into, pad=(Dp, pad_value), context=context,
+                                               tile16=tile16)
         return ops.rqs_coupling_resnet(inputs, wp, bp, tables, dt4, di, nb, spec, inverse, accumulate_into,
                                        log2e=self._log2e(), context=context, pad=(Dp, pad_value))
 

@@ -461,6 +461,124 @@ def _emulate_f16_whole_layer(wp, prm, x, di, dt, K, num_blocks, ctx=None):
     return hidden, logits, stage, off
 
 
+def _emulate_f16s_whole_layer(wp, prm, x, di, dt, num_blocks):
+    """The data flow of K8s (csrc/rqs_resnet_f16s.hip) on ONE 16-row tile, from the packed stream: lane l = (sample
+    n = l % 16, lane group g = l // 16); v_mfma_f32_16x16x32_f16 with A[m = l % 16][k = 8 g + j], B[k = 8 g + j][n],
+    D[4 g + i][n]; a k-major stage = the eight output tiles of one 32-wide k-step, a final-layer stage = two 16-row
+    tiles over four k-steps; biases in natural row order; the six tiles of a group of four features give lane group g
+    the 24 logits of feature 4 G + g.  Returns (hidden x S [16, 128], logits [16, dt, 23], stages, words consumed)."""
+    H, P = 4, 23
+    w = wp.double().view(-1, 1024, 8)        # [stage][16 x 64 lanes][8 halves]
+    bp = prm
+    ln = torch.arange(64) % 16
+    lg = torch.arange(64) // 16
+
+    def pair(stage, t):       # fragment pair t of a stage (hi + lo): [64 lanes, 8]
+        return w[stage, (2 * t) * 64:(2 * t) * 64 + 64] + w[stage, (2 * t + 1) * 64:(2 * t + 1) * 64 + 64]
+
+    def mfma(acc_t, a_frag, b_frag):   # acc_t [64 lanes, 4]
+        A = torch.zeros(16, 32, dtype=torch.float64)
+        Bm = torch.zeros(32, 16, dtype=torch.float64)
+        for l in range(64):
+            A[l % 16, 8 * (l // 16):8 * (l // 16) + 8] = a_frag[l]
+            Bm[8 * (l // 16):8 * (l // 16) + 8, l % 16] = b_frag[l]
+        Dm = A @ Bm
+        for i in range(4):
+            acc_t[:, i] += Dm[4 * lg + i, ln]
+
+    def bias_tiles(off, n):   # [n tiles][64 lanes][4]: rows 4 g + i of every 16-row tile, natural order
+        return bp[off:off + n * 16].double().view(n, 4, 4)[:, lg, :].clone()
+
+    def b_from_acc(acc, S):   # pieces of k-step S: tiles 2 S (j < 4) and 2 S + 1 (j >= 4)
+        return torch.cat((acc[2 * S], acc[2 * S + 1]), dim=1)
+
+    def b_from_rows(rows, S):  # k = 32 S + 8 g + j
+        b = torch.zeros(64, 8, dtype=torch.float64)
+        for l in range(64):
+            for j in range(8):
+                i = 32 * S + 8 * (l // 16) + j
+                b[l, j] = rows[l % 16, i] if i < rows.shape[1] else 0.0
+        return b
+
+    def k_major(stage0, acc, pieces_of):
+        st = stage0
+        for b in pieces_of:
+            for t in range(8):
+                mfma(acc[t], pair(st, t), b)
+            st += 1
+        return st
+
+    stage, off = 0, 0
+    out_scale = bp[off].double()
+    hacc = bias_tiles(off + H, 8)
+    stage = k_major(stage, hacc, [b_from_rows(x[:, :di], S) for S in range(2 if di > 32 else 1)])
+    hp = torch.relu(hacc * out_scale)
+    off += H + 128
+    for blk in range(num_blocks):
+        out_scale = bp[off].double()
+        u = bias_tiles(off + H, 8)
+        stage = k_major(stage, u, [b_from_acc(hp, S) for S in range(4)])
+        q = torch.relu(u * out_scale)
+        off += H + 128
+        out_scale, ratio = bp[off].double(), bp[off + 1].double()
+        hacc = hacc * ratio + bias_tiles(off + H, 8)
+        stage = k_major(stage, hacc, [b_from_acc(q, S) for S in range(4)])
+        off += H + 128
+        hp = hacc * out_scale
+        if blk + 1 < num_blocks:
+            hp = torch.relu(hp)
+    hidden = torch.zeros(16, 128, dtype=torch.float64)
+    for t in range(8):
+        for i in range(4):
+            hidden[ln, 16 * t + 4 * lg + i] = hp[t][:, i]
+    kappa, inv_kappa = bp[off].double(), bp[off + 1].double()
+    assert kappa * inv_kappa == 1.0
+    tiles = dt * 24 // 16
+    out = bias_tiles(off + H, tiles)
+    src = [b_from_acc(hp, S) for S in range(4)]
+    for t in range(tiles):     # two tiles per stage: pairs 0..3 / 4..7 = the four k-steps
+        for S in range(4):
+            mfma(out[t], pair(stage + t // 2, 4 * (t % 2) + S), src[S])
+    stage += tiles // 2
+    off += H + tiles * 16
+    out = out * kappa
+    logits = torch.zeros(16, dt, P, dtype=torch.float64)
+    for G in range(dt // 4):
+        vals = torch.cat([out[6 * G + tau] for tau in range(6)], dim=1)    # [64 lanes, 24]
+        for l in range(64):
+            logits[l % 16, 4 * G + l // 16] = vals[l, :23]
+            assert vals[l, 23].abs().item() == 0.0
+    return hidden, logits, stage, off
+
+
+@pytest.mark.parametrize("di", [6, 40])
+def test_f16_tile16_packing_reproduces_the_network(di):
+    """Host side of K8s (ops.pack_resnet_conditioner_f16(tile16=True)): the same stages and parameter words as K8h's
+    stream, with the fragment / column / row / bias orders of the 16x16x32 tile -- emulate the kernel's data flow and
+    compare with the PyTorch network in float64."""
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import ResidualNet
+    torch.manual_seed(2)
+    K, dt = 8, 8
+    P = 3 * K - 1
+    net = ResidualNet(di, dt * P, hidden_features=128, num_blocks=2).double()
+    with torch.no_grad():
+        for i_, p_ in enumerate(net.parameters()):
+            p_.copy_(torch.randn_like(p_) * (0.3 if i_ % 3 else 0.004))
+    wp, prm = ops.pack_resnet_conditioner_f16(net.float(), dt, P, tile16=True)
+    wp32, prm32 = ops.pack_resnet_conditioner_f16(net.float(), dt, P)
+    net = net.double()
+    assert wp.shape == wp32.shape and prm.shape == prm32.shape        # one stream format for both tile shapes
+    x = torch.randn(16, di, dtype=torch.float64)
+    hidden, logits, stages, words_used = _emulate_f16s_whole_layer(wp, prm, x, di, dt, 2)
+    assert stages == wp.shape[0] and words_used == prm.numel()
+    want_hidden = net.hidden(x)
+    assert (hidden - want_hidden).abs().max().item() < 1e-6 * want_hidden.abs().max().item()
+    want = net.final_layer(want_hidden).view(16, dt, P).clone()
+    want[..., :2 * K] /= np.sqrt(128.0)
+    assert (logits - want).abs().max().item() < 2e-6 * (1 + want.abs().max().item())
+
+
 @pytest.mark.parametrize("act_scale", [1.0, 16.0])
 def test_f16_whole_layer_packing_carries_the_scales(act_scale):
     """Host side of K8h (ops.pack_resnet_conditioner_f16 / build_f16_stream): emulate the kernel's
