@@ -911,7 +911,7 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False,
         bf = torch.cat((bf, bf.new_zeros(pad_transform_to - dt, P)), dim=0)
         dt = pad_transform_to
     R = 24 if P <= 24 else 32  # rows per feature after padding (8 bins: 23 -> 24; 10 bins: 29 -> 32)
-    order_r = (_k8s_row_order(dt) if tile16 else _k7_row_order(dt) if R == 24 else _k8_row_order_32(dt)).to(dev)
+    order_r = (_k7_row_order(dt) if R == 24 else _k8_row_order_32(dt)).to(dev)
     wf = torch.cat((wf, wf.new_zeros(dt, R - P, 128)), dim=1).reshape(dt * R, 128)
     wf = wf.index_select(0, order_r).index_select(1, order_k)
     bf = torch.cat((bf, bf.new_zeros(dt, R - P)), dim=1).reshape(dt * R).index_select(0, order_r)
