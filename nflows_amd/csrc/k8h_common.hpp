@@ -302,34 +302,46 @@ __device__ __forceinline__ void split2(float v0, float v1, unsigned& hi, unsigne
 // check through the pass-through columns and the final layer (no ReLU in front of it), see the epilogue.
 constexpr float kF16Overflow = 65520.0f;   // RN16 of anything >= this is infinity
 
-// one pair of accumulator values -> (ReLU) -> peak, high pieces, low pieces
-template <bool RELU>
+// one pair of accumulator values -> (ReLU) -> peak, high pieces, low pieces.
+// GUARD: three wait states in front.  The block's temporaries and results are written by VALU instructions the
+// compiler's hazard recogniser does not look into; placed right behind an MFMA they may land on registers that MFMA
+// still reads as its SrcC (a 16x16 MFMA reads it for three more issue slots).  K8h accumulates in place -- the
+// accumulator registers stay live and cannot be handed to the block --, K8s's four-register accumulators are renamed
+// from MFMA to MFMA, the old ones are free at once: without the guard one wave in a few thousand came out 1e-5 off.
+#define NFA_CONVERT_RELU(PRE)                                                          \
+    asm(PRE "v_max_f32 %2, %5, 0\n\t"                                                   \
+            "v_max_f32 %3, %6, 0\n\t"                                                   \
+            "v_fma_mixlo_f16 %0, %2, %7, 0 op_sel_hi:[0,0,0]\n\t"                       \
+            "v_fma_mixhi_f16 %0, %3, %7, 0 op_sel_hi:[0,0,0]\n\t"                       \
+            "v_max3_f32 %4, %4, %2, %3\n\t"                                             \
+            "v_fma_mixlo_f16 %1, %2, %7, -%0 op_sel_hi:[0,0,1]\n\t"                     \
+            "v_fma_mixhi_f16 %1, %3, %7, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"          \
+        : "=&v"(h), "=&v"(l), "=&v"(m0), "=&v"(m1), "+v"(peak)                         \
+        : "v"(s0), "v"(s1), "v"(scale))
+#define NFA_CONVERT_PLAIN(PRE)                                                         \
+    asm(PRE "v_fma_mixlo_f16 %0, %3, %5, 0 op_sel_hi:[0,0,0]\n\t"                       \
+            "v_fma_mixhi_f16 %0, %4, %5, 0 op_sel_hi:[0,0,0]\n\t"                       \
+            "v_max3_f32 %2, %2, |%3|, |%4|\n\t"                                         \
+            "v_fma_mixlo_f16 %1, %3, %5, -%0 op_sel_hi:[0,0,1]\n\t"                     \
+            "v_fma_mixhi_f16 %1, %4, %5, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"          \
+        : "=&v"(h), "=&v"(l), "+v"(peak)                                               \
+        : "v"(s0), "v"(s1), "v"(scale))
+template <bool RELU, bool GUARD = false>
 __device__ __forceinline__ void convert_pair(float s0, float s1, float scale, float& peak, unsigned& hi, unsigned& lo) {
     unsigned h, l;
     if constexpr (RELU) {
         float m0, m1;
-        asm("v_max_f32 %2, %5, 0\n\t"
-            "v_max_f32 %3, %6, 0\n\t"
-            "v_fma_mixlo_f16 %0, %2, %7, 0 op_sel_hi:[0,0,0]\n\t"
-            "v_fma_mixhi_f16 %0, %3, %7, 0 op_sel_hi:[0,0,0]\n\t"
-            "v_max3_f32 %4, %4, %2, %3\n\t"
-            "v_fma_mixlo_f16 %1, %2, %7, -%0 op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixhi_f16 %1, %3, %7, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-            : "=&v"(h), "=&v"(l), "=&v"(m0), "=&v"(m1), "+v"(peak)
-            : "v"(s0), "v"(s1), "v"(scale));
+        if constexpr (GUARD) NFA_CONVERT_RELU("s_nop 2\n\t");
+        else NFA_CONVERT_RELU("");
     } else {
-        asm("v_fma_mixlo_f16 %0, %3, %5, 0 op_sel_hi:[0,0,0]\n\t"
-            "v_fma_mixhi_f16 %0, %4, %5, 0 op_sel_hi:[0,0,0]\n\t"
-            "v_max3_f32 %2, %2, |%3|, |%4|\n\t"
-            "v_fma_mixlo_f16 %1, %3, %5, -%0 op_sel_hi:[0,0,1]\n\t"
-            "v_fma_mixhi_f16 %1, %4, %5, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-            : "=&v"(h), "=&v"(l), "+v"(peak)
-            : "v"(s0), "v"(s1), "v"(scale));
+        if constexpr (GUARD) NFA_CONVERT_PLAIN("s_nop 2\n\t");
+        else NFA_CONVERT_PLAIN("");
     }
     hi = h;
     lo = l;
 }
-
+#undef NFA_CONVERT_RELU
+#undef NFA_CONVERT_PLAIN
 
 }  // namespace k8h
 }  // namespace nfa

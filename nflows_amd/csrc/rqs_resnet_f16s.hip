@@ -102,16 +102,16 @@ __device__ __forceinline__ void tile_pair_stage(f32x4& a0, f32x4& a1, const uvec
 template <bool RELU>
 __device__ __forceinline__ void convert_kstep(uvec4& h, uvec4& l, const f32x4& t0, const f32x4& t1, float scale, float& peak) {
     unsigned hi, lo;
-    convert_pair<RELU>(t0[0], t0[1], scale, peak, hi, lo);
+    convert_pair<RELU, true>(t0[0], t0[1], scale, peak, hi, lo);
     h[0] = hi;
     l[0] = lo;
-    convert_pair<RELU>(t0[2], t0[3], scale, peak, hi, lo);
+    convert_pair<RELU, true>(t0[2], t0[3], scale, peak, hi, lo);
     h[1] = hi;
     l[1] = lo;
-    convert_pair<RELU>(t1[0], t1[1], scale, peak, hi, lo);
+    convert_pair<RELU, true>(t1[0], t1[1], scale, peak, hi, lo);
     h[2] = hi;
     l[2] = lo;
-    convert_pair<RELU>(t1[2], t1[3], scale, peak, hi, lo);
+    convert_pair<RELU, true>(t1[2], t1[3], scale, peak, hi, lo);
     h[3] = hi;
     l[3] = lo;
 }
@@ -133,7 +133,7 @@ struct ConvWeave16 {
     }
     __device__ __forceinline__ void pair(int j, float v0, float v1) {
         unsigned hi, lo;
-        convert_pair<RELU>(v0, v1, scale, peak, hi, lo);
+        convert_pair<RELU, true>(v0, v1, scale, peak, hi, lo);
         if (j == 0) { h[0] = hi; l[0] = lo; }
         else if (j == 1) { h[1] = hi; l[1] = lo; }
         else if (j == 2) { h[2] = hi; l[2] = lo; }
