@@ -57,6 +57,11 @@ __device__ __forceinline__ void cell(f32x4& acc, uvec4 bhw, uvec4 blw, Frags& fr
     __builtin_amdgcn_sched_barrier(0);
     acc = NFA_K8S_MFMA(ah, bh, acc);
     __builtin_amdgcn_sched_barrier(0);
+    // The operands stay live past the last product: hipcc renames the four-register accumulator from MFMA to MFMA
+    // and, left alone, puts a result on the registers of an A operand that has just had its last use
+    // (`v_mfma v[6:9], v[6:9], ...`) -- observed as one wave in a few thousand 1e-4 off, not reproducible per
+    // launch: the matrix pipe may still be reading the fragment when the first result rows are written.
+    asm volatile("" ::"v"(ah), "v"(al), "v"(bh), "v"(bl));
     w.step(slot0 + 2);
     __builtin_amdgcn_sched_barrier(0);
 }
