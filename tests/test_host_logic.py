@@ -1058,3 +1058,37 @@ def test_verify_weights_mode_detects_writes_through_data(monkeypatch):
     assert C._weights_key(layer, net) == k2
     with pytest.raises(C.StalePackedWeights):
         C._weights_key(layer, net)
+
+
+def test_no_mfma_result_lands_on_its_own_operands():
+    """hipcc (ROCm 7.2) renames the four-register accumulators of v_mfma_f32_16x16x32_f16 from instruction to
+    instruction and, unless the operands are kept live, allocates a RESULT on the registers of the A fragment
+    that instruction has just read (`v_mfma v[6:9], v[6:9], ...`): on the MI355X one wave in a few thousand then came
+    out 1e-4 off, differently from launch to launch (K8s, round 3).  The kernels keep their operands live past the
+    instruction; this test compiles the two f16 whole-layer kernels to assembly and looks at every MFMA."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "nflows_amd", "csrc")
+
+    def regs(op):
+        m = re.match(r"([va])\[(\d+):(\d+)\]", op)
+        if m:
+            return m.group(1), set(range(int(m.group(2)), int(m.group(3)) + 1))
+        m = re.match(r"([va])(\d+)$", op)
+        return (m.group(1), {int(m.group(2))}) if m else ("?", set())
+
+    for name in ("rqs_resnet_f16s.hip", "rqs_resnet_f16.hip"):
+        asm = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
+                              "-fno-fast-math", "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt",
+                              "-I" + os.path.join(root, "include"), "-I" + csrc, "-S", "--cuda-device-only", "-o", "-",
+                              os.path.join(csrc, name)], capture_output=True, text=True, check=True).stdout
+        count = 0
+        for line in asm.splitlines():
+            m = re.match(r"\s+v_mfma_\w+ (\S+), (\S+), (\S+), ", line)
+            if not m:
+                continue
+            count += 1
+            (dk, d), (ak, a), (bk, b) = (regs(x.rstrip(",")) for x in m.groups())
+            assert not (dk == ak and d & a) and not (dk == bk and d & b), (name, line.strip())
+        assert count > 500, (name, count)
