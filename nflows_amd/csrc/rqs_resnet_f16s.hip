@@ -179,6 +179,59 @@ __device__ __forceinline__ void run_range(Steps& f, const RqsDev& sp) {
     }
 }
 
+// Slices of the spline evaluation behind the 24 MFMAs of a stage (`step(slot)` with a slot that is a constant
+// after inlining).  FinishWeave: slices [FIRST, FIRST + COUNT) of finish; NumWeave: the two numerator sets
+// alternating (two independent chains).
+#define NFA_K8S_SLOT_SWITCH(CALL)                                                                          \
+    switch (slot) {                                                                                        \
+        case 0: CALL(0); break; case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break;    \
+        case 4: CALL(4); break; case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break;    \
+        case 8: CALL(8); break; case 9: CALL(9); break; case 10: CALL(10); break; case 11: CALL(11); break; \
+        case 12: CALL(12); break; case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; \
+        case 16: CALL(16); break; case 17: CALL(17); break; case 18: CALL(18); break; case 19: CALL(19); break; \
+        case 20: CALL(20); break; case 21: CALL(21); break; case 22: CALL(22); break; default: CALL(23); break; \
+    }
+
+template <class Steps, int FIRST, int COUNT>
+struct FinishWeave {
+    Steps& f;
+    const RqsDev& sp;
+    template <int SLOT>
+    __device__ __forceinline__ void at() {
+        constexpr int N2 = 2 * Steps::kNumSlices;
+        run_range<Steps, N2 + FIRST + (SLOT * COUNT) / 24, N2 + FIRST + ((SLOT + 1) * COUNT) / 24>(f, sp);
+    }
+    __device__ __forceinline__ void step(int slot) {
+#define NFA_K8S_AT(S) at<S>()
+        NFA_K8S_SLOT_SWITCH(NFA_K8S_AT)
+#undef NFA_K8S_AT
+    }
+};
+
+template <class Steps, int I, int END>
+__device__ __forceinline__ void num_range(Steps& f) {   // slice I: even = width numerators, odd = height numerators
+    if constexpr (I < END) {
+        if constexpr ((I & 1) == 0) f.template num_w<(I >> 1)>();
+        else f.template num_h<(I >> 1)>();
+        num_range<Steps, I + 1, END>(f);
+    }
+}
+
+template <class Steps>
+struct NumWeave {
+    Steps& f;
+    template <int SLOT>
+    __device__ __forceinline__ void at() {
+        constexpr int COUNT = 2 * Steps::kNumSlices;
+        num_range<Steps, (SLOT * COUNT) / 24, ((SLOT + 1) * COUNT) / 24>(f);
+    }
+    __device__ __forceinline__ void step(int slot) {
+#define NFA_K8S_AT(S) at<S>()
+        NFA_K8S_SLOT_SWITCH(NFA_K8S_AT)
+#undef NFA_K8S_AT
+    }
+};
+
 template <bool INVERSE, int INIT_KS>
 __global__ void __launch_bounds__(kWavesPerGroup* kWave, 2) rqs_resnet_f16s_kernel(const Args a) {
     constexpr int NW = kWavesPerGroup, kThreads = NW * kWave;
@@ -376,15 +429,30 @@ __global__ void __launch_bounds__(kWavesPerGroup* kWave, 2) rqs_resnet_f16s_kern
                 f.kl2e = 1.44269502162933349609375f * kappa;
                 f.tail_s = a.sp.tail_logit * gemm[1];   // gemm[1] = 1 / kappa
                 const float* fbias = gemm + kHdr + g * 4;
+                // The evaluation of group G - 1 rides behind the MFMAs of group G: finish in two halves behind
+                // stages 0 and 1 (tiles 0 .. 3 wait in their accumulators meanwhile), both numerator sets of group G
+                // behind stage 2.  One slice or less per MFMA.
+                constexpr int FIN = Steps::kFinishSlices, FIN0 = FIN / 2;
                 NoWeave16 none;
+                FinishWeave<Steps, 0, FIN0> fin0{f, a.sp};
+                FinishWeave<Steps, FIN0, FIN - FIN0> fin1{f, a.sp};
+                NumWeave<Steps> nums{f};
+                float* slot_prev = nullptr;
                 for (int G = 0; G < groups; ++G) {
                     float* slot = s_row + tab[kTabTr + G * 4 + g] * kRowPad16 + n;
                     f32x4 t[6];
 #pragma unroll
                     for (int i = 0; i < 6; ++i) load_bias4(t[i], fbias + (G * 6 + i) * 16);
-                    tile_pair_stage(t[0], t[1], ph, pl, sm, fr, lane, none);
-                    tile_pair_stage(t[2], t[3], ph, pl, sm, fr, lane, none);
-                    tile_pair_stage(t[4], t[5], ph, pl, sm, fr, lane, none);
+                    if (G > 0) {
+                        tile_pair_stage(t[0], t[1], ph, pl, sm, fr, lane, fin0);
+                        tile_pair_stage(t[2], t[3], ph, pl, sm, fr, lane, fin1);
+                        *slot_prev = f.y;
+                        lad_acc += f.lad;
+                        quad_status |= f.status;
+                    } else {
+                        tile_pair_stage(t[0], t[1], ph, pl, sm, fr, lane, none);
+                        tile_pair_stage(t[2], t[3], ph, pl, sm, fr, lane, none);
+                    }
                     f.x = *slot;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -392,14 +460,19 @@ __global__ void __launch_bounds__(kWavesPerGroup* kWave, 2) rqs_resnet_f16s_kern
                         f.ew[4 + j] = t[1][j];
                         f.eh[j] = t[2][j];
                         f.eh[4 + j] = t[3][j];
+                    }
+                    tile_pair_stage(t[4], t[5], ph, pl, sm, fr, lane, nums);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
                         f.sd[j] = t[4][j];
                         if (j < 3) f.sd[4 + j] = t[5][j];
                     }
-                    run_range<Steps, 0, 2 * Steps::kNumSlices + Steps::kFinishSlices>(f, a.sp);
-                    *slot = f.y;
-                    lad_acc += f.lad;
-                    quad_status |= f.status;
+                    slot_prev = slot;
                 }
+                run_range<Steps, 2 * Steps::kNumSlices, 2 * Steps::kNumSlices + FIN>(f, a.sp);
+                *slot_prev = f.y;
+                lad_acc += f.lad;
+                quad_status |= f.status;
             }
             // this wave's spline results must be visible to its own gathers of the next layer
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
