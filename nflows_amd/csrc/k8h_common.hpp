@@ -184,8 +184,13 @@ __device__ __forceinline__ void stream_advance(SM& sm, bool barrier = false) {
         if constexpr (SM::NW == 8) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 #else
-        if constexpr (SM::NW == 8) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // (a deeper rigid ring -- RING slots, RING - 1 stages in flight -- keeps the same rule: stage s + 2's own share
+        //  has landed, the stages behind it, RING - 3 of them, may still be in flight)
+        if constexpr (SM::RING == 7 && SM::NW == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if constexpr (SM::RING == 6 && SM::NW == 8) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if constexpr (SM::NW == 8) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        static_assert(SM::RING == 4 || SM::RING == 5 || (SM::NW == 8 && (SM::RING == 6 || SM::RING == 7)), "ring depth");
 #endif
     }
     sm.slot = ring_next<SM>(sm.slot);

@@ -235,7 +235,9 @@ struct NumWeave {
     }
 };
 
-template <bool INVERSE, int INIT_KS>
+// RING: slots of the weight ring (RING - 1 stages in flight).  A small batch is bound by the bytes one CU has in
+// flight from L2: with 16 rows per wave the row tiles are small enough for seven slots (96 KB in flight instead of 48).
+template <bool INVERSE, int INIT_KS, int RING>
 __global__ void __launch_bounds__(kWavesPerGroup* kWave, 2) rqs_resnet_f16s_kernel(const Args a) {
     constexpr int NW = kWavesPerGroup, kThreads = NW * kWave;
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
@@ -251,7 +253,7 @@ __global__ void __launch_bounds__(kWavesPerGroup* kWave, 2) rqs_resnet_f16s_kern
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no ordinary load in flight once the stream starts)
 
-    using Stream = WeightStream<NW, kRing>;
+    using Stream = WeightStream<NW, RING>;
     Stream sm;
     sm.w = a.w;
     sm.ring = reinterpret_cast<vec4f*>(lds_dyn);
@@ -262,7 +264,7 @@ __global__ void __launch_bounds__(kWavesPerGroup* kWave, 2) rqs_resnet_f16s_kern
     sm.gen = NW;
     sm.peek = 0;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {   // stages 0 .. 2 -> slots 0 .. 2
+    for (int j = 0; j < RING - 1; ++j) {   // stages 0 .. RING - 2 -> slots 0 .. RING - 2
         sm.slot = ring_next<Stream>(j, 1);
         stream_request(sm);
     }
@@ -274,8 +276,8 @@ __global__ void __launch_bounds__(kWavesPerGroup* kWave, 2) rqs_resnet_f16s_kern
     fr.l = sm.ring[64 + lane];
 
     const int pblock = (a.param_words + 3) & ~3;
-    float* s_row = lds_dyn + kRing * kStageVec4 * 4 + wave * D * kRowPad16;
-    float* s_param = lds_dyn + kRing * kStageVec4 * 4 + NW * D * kRowPad16;   // [2][pblock]
+    float* s_row = lds_dyn + RING * kStageVec4 * 4 + wave * D * kRowPad16;
+    float* s_param = lds_dyn + RING * kStageVec4 * 4 + NW * D * kRowPad16;   // [2][pblock]
     const int groups = dt >> 2;
     const int64_t num_quads = a.batch / (16 * NW);
     int pb = 0;
@@ -593,9 +595,13 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float* inputs, const v
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = nullptr;
     const size_t lds_cap = 160 * 1024 - 1024;
-    const size_t lds_launch = (size_t)k8h::kRing * k8h::kStageVec4 * 16 +
-                              (size_t)k8s::kWavesPerGroup * features * k8s::kRowPad16 * sizeof(float) +
-                              (size_t)2 * ((param_words + 3) & ~3) * sizeof(float);
+    auto lds_for = [&](int ring) {
+        return (size_t)ring * k8h::kStageVec4 * 16 + (size_t)k8s::kWavesPerGroup * features * k8s::kRowPad16 * sizeof(float) +
+               (size_t)2 * ((param_words + 3) & ~3) * sizeof(float);
+    };
+    static const int ring_env = getenv("NFA_K8S_RING") ? atoi(getenv("NFA_K8S_RING")) : 7;
+    const int ring = (ring_env == 7 && lds_for(7) <= lds_cap) ? 7 : 4;
+    const size_t lds_launch = lds_for(ring);
     if (lds_launch > lds_cap) return NFA_ERR_UNSUPPORTED;
     const int cus = device_cu_count();
     int64_t blocks = batch / 128;
@@ -606,15 +612,19 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float* inputs, const v
     const dim3 grid((unsigned)blocks), block(k8s::kWavesPerGroup * kWave);
     const bool inv = (flags & NFA_FLAG_INVERSE) != 0;
     void (*kern)(const k8h::Args) = nullptr;
-    const int which = (inv ? 1 : 0) + (init_ks == 2 ? 2 : 0);
+    const int which = (inv ? 1 : 0) + (init_ks == 2 ? 2 : 0) + (ring == 7 ? 4 : 0);
     switch (which) {
-        case 0: kern = k8s::rqs_resnet_f16s_kernel<false, 1>; break;
-        case 1: kern = k8s::rqs_resnet_f16s_kernel<true, 1>; break;
-        case 2: kern = k8s::rqs_resnet_f16s_kernel<false, 2>; break;
-        default: kern = k8s::rqs_resnet_f16s_kernel<true, 2>; break;
+        case 0: kern = k8s::rqs_resnet_f16s_kernel<false, 1, 4>; break;
+        case 1: kern = k8s::rqs_resnet_f16s_kernel<true, 1, 4>; break;
+        case 2: kern = k8s::rqs_resnet_f16s_kernel<false, 2, 4>; break;
+        case 3: kern = k8s::rqs_resnet_f16s_kernel<true, 2, 4>; break;
+        case 4: kern = k8s::rqs_resnet_f16s_kernel<false, 1, 7>; break;
+        case 5: kern = k8s::rqs_resnet_f16s_kernel<true, 1, 7>; break;
+        case 6: kern = k8s::rqs_resnet_f16s_kernel<false, 2, 7>; break;
+        default: kern = k8s::rqs_resnet_f16s_kernel<true, 2, 7>; break;
     }
     if (lds_launch > 64 * 1024) {
-        static unsigned long long raised[4] = {};   // device masks (raise_dynamic_lds)
+        static unsigned long long raised[8] = {};   // device masks (raise_dynamic_lds)
         const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], (int)lds_cap);
         if (rc_lds != NFA_OK) return rc_lds;
     }
