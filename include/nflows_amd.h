@@ -305,7 +305,9 @@ int nfa_rqs_flow_resnet_f32(const float *inputs, const void *weights_packed,
  *                  inputs) and NOTHING of it was written (outputs, logabsdet, status): the caller
  *                  runs nfa_rqs_flow_resnet_redo_f32 -- the K8 kernel above restricted to the
  *                  flagged blocks, same tables, its own (bf16) weight / bias blobs -- right behind
- *                  it on the same stream; no host synchronisation in between.
+ *                  it on the same stream; no host synchronisation in between.  (K8s on 64-row blocks sets
+ *                  bit 1 / bit 2 instead: only the lower / upper 64 rows of the block are open, the other
+ *                  half is written; the redo entry points honour the bits.)
  * Supported: num_bins = 8 or 10, linear tails, hidden_features = 128 (narrower conditioners: zero-padded by the packer), d_i <= 64, d_t % 4 == 0,
  * d_t <= 64, features % 4 == 0, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
  * Table slots may repeat a column (d_t + d_i may exceed features): the host side pads other shapes into
@@ -322,8 +324,9 @@ int nfa_rqs_flow_resnet_f16x2_f32(const float *inputs, const void *stream_packed
  * K8s.  nfa_rqs_flow_resnet_f16x2_f32 (same reference lines: nn/nets/resnet.py:55-100, coupling.py:73-130,
  * :549-582, a run of layers in one launch, optionally with the base density) on SIXTEEN-sample tiles
  * (v_mfma_f32_16x16x32_f16): a batch that gives a CU at most one 128-row block -- config 4's 32 768-row shard
- * of an 8-GPU run, interactive batches -- gets twice the waves with half the matrix work each.  Same arguments,
- * same semantics (`redo_blocks` included); `stream_packed` has the same stages and parameter words with the
+ * of an 8-GPU run, interactive batches -- gets twice the waves with half the matrix work each; a batch with no
+ * more 64-row blocks than CUs runs in four-wave workgroups of 64 rows (one wave per SIMD: a block's 32 layers
+ * take 0.64 instead of 0.86 ms).  Same arguments, same semantics (`redo_blocks`: see there); `stream_packed` has the same stages and parameter words with the
  * orders of this tile shape (ops.pack_resnet_conditioner_f16(tile16=True)):
  *   lane l = (sample n = l % 16, lane group g = l / 16); a fragment is [64 lanes][8 halves] with lane l holding
  *   row 16 T + l % 16, MFMA k position 8 (l / 16) + j; GEMM inputs made of accumulator tiles use the column rule

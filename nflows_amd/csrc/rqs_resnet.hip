@@ -47,7 +47,7 @@ struct ResnetArgs {
     int D, dt, di, num_blocks, num_layers, num_stages, bias_per_layer, accumulate;
     RqsDev sp;
     unsigned long long* trace;
-    const int32_t* redo;  // optional [batch / 128]: only row blocks with a non-zero entry are processed
+    const int32_t* redo;  // optional [batch / 128]: only row blocks with a non-zero entry are processed (bits: see the kernel)
     int normal, skip_out;  // NFA_FLAG_STANDARD_NORMAL_LOG_PROB / NFA_FLAG_SKIP_OUTPUTS
     float log_z;           // 0.5 D log(2 pi)
     int Ds;                // columns the density sums over (features minus NFA_FLAG_PAD_COLUMNS)
@@ -287,7 +287,11 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         tr = a.trace + (blockIdx.x ? 256 : 0);
     for (int64_t quad = blockIdx.x; quad < num_quads; quad += gridDim.x) {
         // second pass behind the f16 kernel (rqs_resnet_f16.hip): only the row blocks it gave up on
-        if (a.redo && a.redo[quad] == 0) continue;
+        // second pass of K8h / K8s: 0 = block done; bit 0 = the whole block is open; bits 1 / 2 = its lower / upper
+        // 64 rows are (K8s's four-wave workgroups: the other half was written, log-determinant accumulated, by them)
+        const int redo_flag = a.redo ? a.redo[quad] : 1;
+        if (redo_flag == 0) continue;
+        const bool write_rows = (redo_flag & 1) || ((redo_flag >> (1 + (wave >> 1))) & 1);
         const int64_t row0 = (quad << 7) + (wave << 5);
         // (lane-derived values are made opaque per iteration: hoisted out of this loop they would
         // stay live through the whole kernel and push the register allocation into scratch)
@@ -656,7 +660,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         }
 
         // ---- output rows: position p of a row comes from slot final[p]; 16 bytes per lane per store
-        if (!a.skip_out) {
+        if (!a.skip_out && write_rows) {
             vec4f* ov = reinterpret_cast<vec4f*>(a.out + row0 * D);
             const int nvec = D * 8;
             for (int e = lane; e < nvec; e += kWave) {
@@ -672,7 +676,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         lad_acc += __shfl_xor(lad_acc, 32, kWave);
         float sumsq = 0.0f;
         if (a.normal) sumsq = tile_row_sumsq(s_row, a.Ds, half, r);
-        if (half == 0) {
+        if (half == 0 && write_rows) {
             float* dst = a.lad + row0 + r;
             float v = a.accumulate ? *dst + lad_acc : lad_acc;
             if (a.normal) v = (-0.5f * sumsq - a.log_z) + v;   // normal.py:31-33, flows/base.py:49

@@ -237,9 +237,9 @@ struct NumWeave {
 
 // RING: slots of the weight ring (RING - 1 stages in flight).  A small batch is bound by the bytes one CU has in
 // flight from L2: with 16 rows per wave the row tiles are small enough for seven slots (96 KB in flight instead of 48).
-template <bool INVERSE, int INIT_KS, int RING>
-__global__ void __launch_bounds__(kWavesPerGroup* kWave, 2) rqs_resnet_f16s_kernel(const Args a) {
-    constexpr int NW = kWavesPerGroup, kThreads = NW * kWave;
+template <bool INVERSE, int INIT_KS, int RING, int NW_ = kWavesPerGroup>
+__global__ void __launch_bounds__(NW_* kWave, 2) rqs_resnet_f16s_kernel(const Args a) {
+    constexpr int NW = NW_, kThreads = NW * kWave;
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     __shared__ int s_final[128];
     __shared__ int s_bad[NW];
@@ -526,7 +526,14 @@ __global__ void __launch_bounds__(kWavesPerGroup* kWave, 2) rqs_resnet_f16s_kern
             }
             my_status |= quad_status;
         }
-        if (tid == 0) a.redo[quad] = quad_bad ? 1 : 0;   // one flag per 128 rows
+        // one flag per 128 rows: 1 = the whole block is open; four-wave workgroups share a flag (zeroed by the
+        // launcher) and set bit 1 / bit 2 for its lower / upper 64 rows -- the half of the OTHER workgroup is written,
+        // its log-determinant accumulated, and must not be written again by the second pass
+        if constexpr (NW == 8) {
+            if (tid == 0) a.redo[quad] = quad_bad ? 1 : 0;
+        } else {
+            if (tid == 0 && quad_bad) atomicOr(a.redo + (quad >> 1), 2 << (quad & 1));
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // s_bad is rewritten by the next row block
     }
@@ -595,24 +602,28 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float* inputs, const v
     a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
     a.trace = nullptr;
     const size_t lds_cap = 160 * 1024 - 1024;
+    const int cus = device_cu_count();
+    // fewer 64-row blocks than CUs: four-wave workgroups (one wave per SIMD) spread the batch over twice the CUs
+    static const int half_env = getenv("NFA_K8S_HALF") ? atoi(getenv("NFA_K8S_HALF")) : 1;
+    const bool half = half_env == 2 || (half_env == 1 && batch / 64 <= cus);
+    const int nw = half ? 4 : k8s::kWavesPerGroup;
     auto lds_for = [&](int ring) {
-        return (size_t)ring * k8h::kStageVec4 * 16 + (size_t)k8s::kWavesPerGroup * features * k8s::kRowPad16 * sizeof(float) +
+        return (size_t)ring * k8h::kStageVec4 * 16 + (size_t)nw * features * k8s::kRowPad16 * sizeof(float) +
                (size_t)2 * ((param_words + 3) & ~3) * sizeof(float);
     };
     static const int ring_env = getenv("NFA_K8S_RING") ? atoi(getenv("NFA_K8S_RING")) : 7;
-    const int ring = (ring_env == 7 && lds_for(7) <= lds_cap) ? 7 : 4;
+    const int ring = (!half && ring_env == 7 && lds_for(7) <= lds_cap) ? 7 : 4;
     const size_t lds_launch = lds_for(ring);
     if (lds_launch > lds_cap) return NFA_ERR_UNSUPPORTED;
-    const int cus = device_cu_count();
-    int64_t blocks = batch / 128;
+    int64_t blocks = batch / (16 * nw);
     if (blocks > cus) blocks = cus;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     profile_next_launch(&e0, &e1);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)blocks), block(k8s::kWavesPerGroup * kWave);
+    const dim3 grid((unsigned)blocks), block(nw * kWave);
     const bool inv = (flags & NFA_FLAG_INVERSE) != 0;
     void (*kern)(const k8h::Args) = nullptr;
-    const int which = (inv ? 1 : 0) + (init_ks == 2 ? 2 : 0) + (ring == 7 ? 4 : 0);
+    const int which = half ? 8 + (inv ? 1 : 0) + (init_ks == 2 ? 2 : 0) : (inv ? 1 : 0) + (init_ks == 2 ? 2 : 0) + (ring == 7 ? 4 : 0);
     switch (which) {
         case 0: kern = k8s::rqs_resnet_f16s_kernel<false, 1, 4>; break;
         case 1: kern = k8s::rqs_resnet_f16s_kernel<true, 1, 4>; break;
@@ -621,10 +632,15 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float* inputs, const v
         case 4: kern = k8s::rqs_resnet_f16s_kernel<false, 1, 7>; break;
         case 5: kern = k8s::rqs_resnet_f16s_kernel<true, 1, 7>; break;
         case 6: kern = k8s::rqs_resnet_f16s_kernel<false, 2, 7>; break;
-        default: kern = k8s::rqs_resnet_f16s_kernel<true, 2, 7>; break;
+        case 7: kern = k8s::rqs_resnet_f16s_kernel<true, 2, 7>; break;
+        case 8: kern = k8s::rqs_resnet_f16s_kernel<false, 1, 4, 4>; break;
+        case 9: kern = k8s::rqs_resnet_f16s_kernel<true, 1, 4, 4>; break;
+        case 10: kern = k8s::rqs_resnet_f16s_kernel<false, 2, 4, 4>; break;
+        default: kern = k8s::rqs_resnet_f16s_kernel<true, 2, 4, 4>; break;
     }
+    if (half) NFA_HIP_CHECK(hipMemsetAsync(redo_blocks, 0, (size_t)(batch / 128) * sizeof(int32_t), st));
     if (lds_launch > 64 * 1024) {
-        static unsigned long long raised[8] = {};   // device masks (raise_dynamic_lds)
+        static unsigned long long raised[12] = {};   // device masks (raise_dynamic_lds)
         const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], (int)lds_cap);
         if (rc_lds != NFA_OK) return rc_lds;
     }

@@ -38,7 +38,7 @@ def last_redo_blocks():
     value left the f16 range or the inputs were non-finite (reads the device flags: synchronises).
     None if no such launch happened yet.  bench.py reports it; a trained flow that makes this non-zero on
     ordinary data runs those blocks at the bf16x3 kernel's speed."""
-    return None if _last_redo is None else int(_last_redo.sum().item())
+    return None if _last_redo is None else int((_last_redo != 0).sum().item())
 
 
 def set_launch_hook(hook):

@@ -261,6 +261,45 @@ def test_small_batch_kernel_on_a_32768_row_shard():
     assert float(err.mean()) < 2e-5 and float(err.max()) < 2e-2
 
 
+def test_small_batch_kernel_four_wave_blocks_on_a_16384_row_shard():
+    """Batches with no more 64-row blocks than CUs run K8s with four-wave workgroups (one wave per SIMD, 64 rows):
+    config 4's per-GPU shard of a 16-GPU run.  The oracle on every 4th row; the same bits as the eight-wave form
+    (the rows as the first half of a 32 768-row batch); two workgroups share one redo flag: a batch whose rows
+    64..127 leave the f16 range has exactly one block redone and rows 0..63 of it are still the oracle's."""
+    from nflows_amd import configs, ops
+    import copy
+    import nflows_amd
+    flow_cpu = configs.rq_nsf_flow(num_layers=32, features=64, num_bins=8, hidden_features=128, seed=0).eval()
+    x = torch.randn(32768, 64, generator=torch.Generator().manual_seed(1234))
+    flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+    xd = x.to(DEV)
+    with torch.no_grad():
+        z_full, lad_full = flow._transform(xd)
+        z, lad = flow._transform(xd[:16384])
+        assert ops.last_redo_blocks() == 0
+        lp = flow.log_prob(xd[:16384])
+        xr, _ = flow._transform.inverse(z)
+        x_hot = xd[:16384].clone()
+        x_hot[64:128] *= 3e4                       # identity features of 3e4 .. 1e5: hidden activations beyond 65 504
+        z_hot, lad_hot = flow._transform(x_hot)
+        redo_hot = ops.last_redo_blocks()
+    nflows_amd.check_status()
+    assert torch.equal(z, z_full[:16384]) and torch.equal(lad, lad_full[:16384]), "four- and eight-wave blocks differ"
+    rows = torch.arange(0, 16384, 4)
+    o = oracle_eval(flow_cpu, x[rows])
+    idx = rows.to(DEV)
+    compare("k8s_32layer_b16384", "z", z[idx].cpu().numpy(), o["z32"], o["z64"], OUT_TOL)
+    compare("k8s_32layer_b16384", "logabsdet", lad[idx].cpu().numpy(), o["lad32"], o["lad64"], LAD_TOL)
+    compare("k8s_32layer_b16384", "log_prob", lp[idx].cpu().numpy(), o["lp32"], o["lp64"], LAD_TOL)
+    err = (xr - xd[:16384]).abs()
+    assert float(err.mean()) < 2e-5 and float(err.max()) < 2e-2
+    assert redo_hot == 1, "%d blocks redone" % redo_hot
+    assert torch.equal(z_hot[128:], z[128:]) and torch.equal(lad_hot[128:], lad[128:])
+    o_hot = oracle_eval(flow_cpu, x_hot[:128].cpu())
+    compare("k8s_shared_redo_flag", "z", z_hot[:128].cpu().numpy(), o_hot["z32"], o_hot["z64"], OUT_TOL, max_factor=4.0)
+    compare("k8s_shared_redo_flag", "logabsdet", lad_hot[:128].cpu().numpy(), o_hot["lad32"], o_hot["lad64"], LAD_TOL, max_factor=4.0)
+
+
 def test_forward_inverse_consistency_against_the_reference():
     """Second half of the metric: max |inv(fwd(x)) - x| of the 32-layer composite on the 8 192 rows
     bench.py uses, next to the reference's own fp32 figure on the same rows and weights, and the
