@@ -847,6 +847,89 @@ def _pad_to(t, rows=None, cols=None):
     return t
 
 
+def _batch_norm_affine(bn):
+    """Eval-mode BatchNorm1d as y = a * x + c (float64), or None when it normalises with batch statistics."""
+    if bn.training or not bn.track_running_stats or bn.running_mean is None or bn.running_var is None:
+        return None
+    a = (bn.running_var.detach().double() + bn.eps).rsqrt()
+    if bn.weight is not None:
+        a = a * bn.weight.detach().double()
+    c = -bn.running_mean.detach().double() * a
+    if bn.bias is not None:
+        c = c + bn.bias.detach().double()
+    return a, c
+
+
+class _FoldedLayer:
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight.float(), bias.float()
+
+
+class _FoldedBlock:
+    context_layer = None
+
+    def __init__(self, linear_layers):
+        self.linear_layers = linear_layers
+
+
+class _FoldedNet:
+    """What the packers read of a ResidualNet (initial_layer, blocks[*].linear_layers, final_layer, widths)."""
+    context_features = None
+
+    def __init__(self, initial_layer, blocks, final_layer, hidden_features):
+        self.initial_layer, self.blocks, self.final_layer = initial_layer, blocks, final_layer
+        self.hidden_features = hidden_features
+
+
+def fold_batch_norm(net):
+    """A ResidualNet whose blocks use batch norm (resnet.py:24-27, :41-47), in eval mode, as an equivalent net
+    WITHOUT it -- weights and biases only, nothing for the kernels to do.  Per block, with BN_i(x) = a_i x + c_i
+    (a = gamma / sqrt(running_var + eps), c = beta - running_mean a):
+      * BN_1 follows linear_0 directly:            W0' = diag(a_1) W0 diag(a_0),  b0' = a_1 b0 + c_1;
+      * BN_0 sits between the residual stream and the ReLU: for a_0 > 0, relu(a_0 x + c_0) = a_0 relu(x + d),
+        d = c_0 / a_0 -- a_0 goes into W0' (above) and the shift into the STREAM: the kernels carry s_k = x_k + d_k
+        instead of x_k, which costs the bias of the layer that produces x_k + d_k and returns - d_k in the bias of
+        the block's second Linear (whose sum x_k + ... would otherwise inherit it): b1' = b1 - d_k + d_{k+1}, the
+        initial layer's b' = b + d_0, d past the last block = 0 (the final layer reads the stream as it is,
+        resnet.py:99).
+    Returns `net` itself when no block uses batch norm, None when the fold does not exist: a block in training
+    mode (batch statistics), a_0 <= 0 or non-finite somewhere, or a context (the GLU gate multiplies b1,
+    resnet.py:49-50).  Sums in float64, one rounding to float32 at the end.  Reads the device (one
+    synchronising check): callers cache the result per weight key."""
+    blocks = list(net.blocks)
+    if not any(getattr(b, "use_batch_norm", False) for b in blocks):
+        return net
+    if getattr(net, "context_features", None) is not None:
+        return None
+    H = net.initial_layer.weight.shape[0]
+    dev = net.initial_layer.weight.device
+    zeros = torch.zeros(H, dtype=torch.float64, device=dev)
+    folded, shifts, ok = [], [], []
+    for b in blocks:
+        w0, b0 = b.linear_layers[0].weight.detach().double(), b.linear_layers[0].bias.detach().double()
+        w1, b1 = b.linear_layers[1].weight.detach().double(), b.linear_layers[1].bias.detach().double()
+        d = zeros
+        if getattr(b, "use_batch_norm", False):
+            bn0, bn1 = _batch_norm_affine(b.batch_norm_layers[0]), _batch_norm_affine(b.batch_norm_layers[1])
+            if bn0 is None or bn1 is None:
+                return None
+            (a0, c0), (a1, c1) = bn0, bn1
+            d = c0 / a0
+            ok.append((a0 > 0).all() & torch.isfinite(d).all())
+            w0 = a1[:, None] * w0 * a0[None, :]
+            b0 = a1 * b0 + c1
+        shifts.append(d)
+        folded.append([w0, b0, w1, b1])
+    if ok and not bool(torch.stack(ok).all()):
+        return None
+    shifts.append(zeros)
+    for k, f in enumerate(folded):
+        f[3] = f[3] - shifts[k] + shifts[k + 1]
+    initial = _FoldedLayer(net.initial_layer.weight.detach(), net.initial_layer.bias.detach().double() + shifts[0])
+    return _FoldedNet(initial, [_FoldedBlock([_FoldedLayer(w0, b0), _FoldedLayer(w1, b1)]) for w0, b0, w1, b1 in folded],
+                      net.final_layer, net.hidden_features)
+
+
 def _initial_weight(net, pad_identity_to):
     """The initial layer's weight [128, identity features (+ context features)], hidden rows zero-padded;
     with `pad_identity_to` zero columns stand in for the run's surplus identity features (fused_geometry),

@@ -32,8 +32,10 @@ from .splines import rational_quadratic
 
 
 def _held_parameters(net):
-    """[(the `_parameters` dict of a leaf module, name, Parameter)] of every parameter of `net`."""
-    return [(m._parameters, name, p) for m in net.modules() for name, p in m._parameters.items() if p is not None]
+    """[(the `_parameters` / `_buffers` dict of a leaf module, name, tensor)] of every parameter and buffer of `net`
+    (buffers: the running statistics of batch-norm layers, folded into the packed weights)."""
+    return ([(m._parameters, name, p) for m in net.modules() for name, p in m._parameters.items() if p is not None] +
+            [(m._buffers, name, b) for m in net.modules() for name, b in m._buffers.items() if b is not None])
 
 
 class StalePackedWeights(RuntimeError):
@@ -529,8 +531,23 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
                 and net.hidden_features <= 128 and self.tails == "linear" and self.num_bins in (8, 10)
                 and 1 <= self.num_identity_features <= 64 and 1 <= self.num_transform_features
                 and self._fused_geometry()[1] <= 64 and self._fused_geometry()[0] <= 128
-                and all(b.activation is torch.nn.functional.relu and not b.use_batch_norm
-                        and (not b.training or b.dropout.p == 0.0) for b in net.blocks))
+                and all(b.activation is torch.nn.functional.relu
+                        and (not b.training or (b.dropout.p == 0.0 and not b.use_batch_norm)) for b in net.blocks)
+                and (not any(b.use_batch_norm for b in net.blocks) or self._folded_net() is not None))
+
+    def _folded_net(self):
+        """The conditioner with its eval-mode batch norms folded into weights and biases (ops.fold_batch_norm),
+        the net itself without batch norm, None when no fold exists; per weight key."""
+        net = self.transform_net
+        if not any(b.use_batch_norm for b in net.blocks):
+            return net
+        key = (tuple(b.training for b in net.blocks),) + _weights_key(self, net)
+        cached = self.__dict__.get("_folded_net_cache")
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                cached = (key, ops.fold_batch_norm(net))
+            self.__dict__["_folded_net_cache"] = cached
+        return cached[1]
 
     # experiment switch: fold log2(e) into the width / height logits as well (one v_exp_f32 per
     # softmax numerator)
@@ -562,7 +579,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         slot = "_packed_resnet_f16s_cache" if tile16 else "_packed_resnet_f16_cache"
         cached = self.__dict__.get(slot)
         if cached is None or cached[0] != key:
-            cached = (key, ops.pack_resnet_conditioner_f16(net, self.num_transform_features,
+            cached = (key, ops.pack_resnet_conditioner_f16(self._folded_net(), self.num_transform_features,
                                                            self._transform_dim_multiplier(),
                                                            act_scale=self.conditioner_act_scale,
                                                            pad_transform_to=dt4, pad_identity_to=di_u, tile16=tile16))
@@ -589,7 +606,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         key = (dt4, di_u, self._log2e()) + _weights_key(self, net)
         cached = getattr(self, "_packed_resnet_cache", None)
         if cached is None or cached[0] != key:
-            cached = (key, ops.pack_resnet_conditioner(net, self.num_transform_features,
+            cached = (key, ops.pack_resnet_conditioner(self._folded_net(), self.num_transform_features,
                                                        self._transform_dim_multiplier(),
                                                        log2e=self._log2e(),
                                                        pad_transform_to=dt4, pad_identity_to=di_u))

@@ -501,3 +501,96 @@ def test_f16_engine_over_a_wide_dynamic_range(case):
         assert redo == 0, "%d row blocks left the f16 range with moderate activations" % redo
     else:
         assert redo < B // 128, "every block was redone: the f16 engine handled nothing"
+
+
+def _batch_norm_flow(seed=11, layers=6, features=64, dropout=0.2):
+    """RQ-NSF flow whose ResidualNet conditioners use batch norm (resnet.py:24-27) and dropout, with running
+    statistics, gains and shifts away from their initial values."""
+    from nflows_amd.flows.base import Flow
+    from nflows_amd.distributions.normal import StandardNormal
+    from nflows_amd.nn.nets import ResidualNet
+    from nflows_amd.transforms import (CompositeTransform, RandomPermutation,
+                                       PiecewiseRationalQuadraticCouplingTransform as RQ)
+    from nflows_amd.utils.torchutils import create_alternating_binary_mask
+    torch.manual_seed(seed)
+    parts = []
+    for i in range(layers):
+        parts.append(RandomPermutation(features))
+        parts.append(RQ(create_alternating_binary_mask(features, even=(i % 2 == 0)),
+                        lambda a, b: ResidualNet(a, b, hidden_features=128, num_blocks=2, use_batch_norm=True,
+                                                 dropout_probability=dropout),
+                        num_bins=8, tails="linear", tail_bound=3.0))
+    flow = Flow(CompositeTransform(parts), StandardNormal([features]))
+    gen = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in flow.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=gen) * 0.3)
+                m.running_var.copy_(torch.rand(m.num_features, generator=gen) * 1.5 + 0.5)
+                m.weight.copy_(torch.rand(m.num_features, generator=gen) + 0.5)
+                m.bias.copy_(torch.randn(m.num_features, generator=gen) * 0.2)
+        for name, p in flow.named_parameters():
+            if "final_layer" in name:
+                p.mul_(4.0)
+            elif "linear_layers.1" in name:
+                p.mul_(30.0)
+    return flow.eval()
+
+
+@pytest.mark.parametrize("engine", ["f16x2", "bf16x3"])
+def test_batch_norm_conditioners_run_in_the_whole_layer_kernels(monkeypatch, engine):
+    """Eval-mode batch norm (and dropout) in the ResidualNet blocks is folded into the packed weights and biases
+    (ops.fold_batch_norm): the flow still runs as ONE launch, and agrees with the float64 evaluation of the
+    reference sequence (batch norm as torch applies it) within twice the reference's own fp32 error.  The fold
+    follows the running statistics (a buffer update is seen), does not exist for a negative gain in front of the
+    ReLU or in training mode -- those run layer by layer, with the same results."""
+    import copy
+    from nflows_amd import ops
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    import nflows_amd
+    monkeypatch.setattr(RQ, "conditioner_engine", engine)
+    flow_cpu = _batch_norm_flow()
+    x_cpu = torch.randn(4096, 64, generator=torch.Generator().manual_seed(3))
+
+    def check(f_cpu, expect_run, what):
+        flow = copy.deepcopy(f_cpu).to(DEV).eval() if not isinstance(f_cpu, tuple) else f_cpu[0]
+        layers = list(flow._transform._transforms)
+        x = x_cpu.to(DEV)
+        calls = []
+        real = ops.rqs_coupling_resnet_f16 if engine == "f16x2" else ops.rqs_coupling_resnet
+        name = "rqs_coupling_resnet_f16" if engine == "f16x2" else "rqs_coupling_resnet"
+        monkeypatch.setattr(ops, name, lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        with torch.no_grad():
+            units, _ = flow._transform._collect_run(layers, 0, x, None, inverse=False)
+            assert bool(units) == expect_run, what
+            z, lad = flow._transform(x)
+            xr, _ = flow._transform.inverse(z)
+        monkeypatch.setattr(ops, name, real)
+        nflows_amd.check_status()
+        if expect_run:
+            assert len(calls) == 2, "forward and inverse: one launch each, got %d" % len(calls)
+        o = oracle_eval(f_cpu if not isinstance(f_cpu, tuple) else f_cpu[1], x_cpu)
+        config = "batch_norm_%s_%s" % (engine, what.replace(" ", "_"))
+        compare(config, "z", z.cpu().numpy(), o["z32"], o["z64"], OUT_TOL, max_factor=4.0)
+        compare(config, "logabsdet", lad.cpu().numpy(), o["lad32"], o["lad64"], LAD_TOL, max_factor=4.0)
+        assert (xr - x).abs().max().item() < 5e-3 and (xr - x).abs().mean().item() < 2e-5
+        return flow
+
+    flow = check(flow_cpu, True, "batch norm folded")
+    # the running statistics move (a training step elsewhere): the packed weights follow
+    with torch.no_grad():
+        for f in (flow, flow_cpu):
+            bn = list(f._transform._transforms)[1].transform_net.blocks[0].batch_norm_layers[0]
+            bn.running_mean.add_(0.25)
+            bn.running_var.mul_(1.5)
+    check((flow, flow_cpu), True, "after a statistics update")
+    # a negative gain in front of the ReLU: no fold, layer by layer
+    neg = copy.deepcopy(flow_cpu)
+    with torch.no_grad():
+        list(neg._transform._transforms)[3].transform_net.blocks[1].batch_norm_layers[0].weight[5] = -0.7
+    check(neg, False, "negative gain")
+    # training mode: batch statistics, active dropout -- never the whole-layer kernel
+    flow.train()
+    with torch.no_grad():
+        units, _ = flow._transform._collect_run(list(flow._transform._transforms), 0, x_cpu.to(DEV), None, inverse=False)
+    assert not units

@@ -650,6 +650,55 @@ def test_f16_whole_layer_packing_with_a_context():
         ops.pack_resnet_conditioner_f16(ResidualNet(40, dt * P, hidden_features=64, context_features=4), dt, P)
 
 
+def test_batch_norm_fold_is_the_same_network():
+    """ops.fold_batch_norm: a ResidualNet with eval-mode batch norm in its blocks (resnet.py:24-27, :41-47) equals,
+    in float64, the plain residual chain over the folded layers -- the stream carrying x + c_0 / a_0 in front of
+    every block; no fold in training mode, with a non-positive gain in front of the ReLU, or with a context."""
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import ResidualNet
+    torch.manual_seed(0)
+    net = ResidualNet(20, 37, hidden_features=48, num_blocks=3, use_batch_norm=True, dropout_probability=0.3).double()
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(48, generator=gen, dtype=torch.float64))
+                m.running_var.copy_(torch.rand(48, generator=gen, dtype=torch.float64) * 3 + 0.1)
+                m.weight.copy_(torch.rand(48, generator=gen, dtype=torch.float64) * 2 + 0.05)
+                m.bias.copy_(torch.randn(48, generator=gen, dtype=torch.float64))
+        for p in net.blocks[1].linear_layers[1].parameters():
+            p.mul_(500.0)
+    assert ops.fold_batch_norm(net) is None            # training mode: batch statistics
+    net.eval()
+    assert ops.fold_batch_norm(ResidualNet(4, 4, hidden_features=8)) is not None
+    plain = ResidualNet(4, 4, hidden_features=8)
+    assert ops.fold_batch_norm(plain) is plain
+    x = torch.randn(257, 20, generator=gen, dtype=torch.float64)
+    with torch.no_grad():
+        want = net(x)
+        # the folded layers are float32 (what the packers read): fold a float64 copy by hand for the identity ...
+        folded = ops.fold_batch_norm(net)
+        assert folded is not None and folded.context_features is None and len(folded.blocks) == 3
+        s = torch.nn.functional.linear(x, folded.initial_layer.weight.double(), folded.initial_layer.bias.double())
+        for b in folded.blocks:
+            h = torch.relu(s)
+            h = torch.nn.functional.linear(h, b.linear_layers[0].weight.double(), b.linear_layers[0].bias.double())
+            h = torch.relu(h)
+            s = s + torch.nn.functional.linear(h, b.linear_layers[1].weight.double(), b.linear_layers[1].bias.double())
+        got = torch.nn.functional.linear(s, folded.final_layer.weight.double(), folded.final_layer.bias.double())
+    # ... up to the float32 rounding of the folded weights and biases
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() < 3e-6 * scale, ((got - want).abs().max().item(), scale)
+    with torch.no_grad():
+        net.blocks[2].batch_norm_layers[0].weight[7] = -0.5
+    assert ops.fold_batch_norm(net) is None
+    with torch.no_grad():
+        net.blocks[2].batch_norm_layers[0].weight[7] = 0.0
+    assert ops.fold_batch_norm(net) is None
+    ctx = ResidualNet(6, 5, hidden_features=8, context_features=3, use_batch_norm=True).eval()
+    assert ops.fold_batch_norm(ctx) is None
+
+
 def test_layer_tables_follow_the_fused_permutations():
     from nflows_amd import ops
     D = 12
