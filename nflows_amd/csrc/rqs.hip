@@ -327,7 +327,12 @@ __global__ void __launch_bounds__(kBlock, NFA_PIPE_WAVES) rqs_coupling_pipelined
         float l = 0.0f;
         if (has_item) {
             float y;
+#ifdef NFA_K1_ABL_NO_EVAL   // (measurement: the kernel's memory structure without the spline arithmetic)
+            y = s_x[it_x] + it_p[3];
+            l = it_p[5];
+#else
             my_status |= rqs_eval<KT, INVERSE, LINEAR>(s_x[it_x], const_cast<float*>(it_p), a.sp, y, l);
+#endif
             s_out[it_y] = y;
         }
         const int64_t row0 = tile * R;
