@@ -431,6 +431,29 @@ def main():
                 "value": 65536 * world * args.steps / dtw.item(), "unit": "samples/s"}
         del xw
 
+    # extra (N = 1): the shards config 4 leaves a GPU at 8 / 16 / 32 GPUs -- the small-batch kernels (K8s: 128-row
+    # blocks at 32 768 rows, four-wave 64-row blocks below), same step as the headline
+    small = None
+    if world == 1 and args.batch_per_gpu is None and not args.skip_extra:
+        small = []
+        for rows_s in (32768, 16384, 8192):
+            xs_ = torch.randn(rows_s, D, generator=torch.Generator().manual_seed(977 + rows_s)).to(dev)
+
+            def step_s():
+                with torch.no_grad():
+                    return parallel.reduce_log_likelihood(flow.log_prob(xs_))
+            for _ in range(5):
+                step_s()
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(args.steps):
+                step_s()
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - ts
+            small.append({"rows": rows_s, "ms_per_step": dts / args.steps * 1e3, "value": rows_s * args.steps / dts,
+                          "unit": "samples/s"})
+            del xs_
+
     # the same step replayed from a HIP graph (host out of the loop): reported beside the headline
     # number, which keeps per-dispatch events and therefore launches from the host
     graph_ms = None
@@ -622,6 +645,8 @@ def main():
                                                % args.steady_seconds)
         if weak is not None:
             result["rows_65536_per_gpu_extra"] = weak
+        if small is not None:
+            result["small_shards_extra"] = small
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(flow_cpu, D, args.cpu_rows,
                                                   x_consistency=None if args.skip_consistency else xs.cpu())

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NFA_ABI_VERSION 4  /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3) */
+#define NFA_ABI_VERSION 5  /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 5) */
 
 /* return codes */
 #define NFA_OK 0
@@ -468,6 +468,35 @@ int nfa_made_rqs_inverse_f32(const float *inputs, const float *step_blocks, cons
                              float *hidden_out, int32_t *status, int64_t batch, int32_t features,
                              int32_t hidden_features, int32_t sequential_steps, const nfa_rqs_spec *spec,
                              void *stream);
+
+/*
+ * K13.  The output layer of a MADE conditioner and the autoregressive spline layer behind it in one kernel:
+ *   params = hidden @ (W * mask)^T + b   (MADE.final_layer, transforms/made.py:261-268, :282; MaskedLinear :71-72)
+ *   outputs, logabsdet = the RQ functional per feature, logabsdet summed per sample
+ *   (MaskedPiecewiseRationalQuadraticAutoregressiveTransform._elementwise, transforms/autoregressive.py:453-489)
+ * -- the forward pass of the layer (autoregressive.py:38-41) behind the hidden layers, and the last pass of its
+ * inverse (:43-52) for the features whose parameters no longer change.  The [batch, num_features * 23] parameter
+ * tensor is never formed.
+ *   inputs / outputs   [batch, row_stride] rows; the kernel reads / writes columns first_column ..
+ *                      first_column + num_features - 1 (feature f of this call = column first_column + f)
+ *   hidden             [batch, hidden_features] the output layer's input
+ *   weight_packed      the num_features * 23 masked rows, per feature padded to 24 rows, features padded to a
+ *                      multiple of 8 (an even number of four-feature groups), hidden width zero-padded to 256; rows in K7's order
+ *                      (nfa_rqs_coupling_fused_linear_f32) as bf16 triples
+ *                      [tiles][3 pieces][16 k-steps][64 lanes][8]: lane l, element (piece, ks, j) = piece of
+ *                      Wrows[tile*32 + (l & 31)][(l >> 5)*128 + ks*8 + j]
+ *   bias_padded        [tiles][2 lane-halves][16] in accumulator order
+ *   logabsdet_partial  [chunks][batch], chunks = ceil(2 ceil(num_features / 8) / NFA_MADE_OUTPUT_GROUPS_PER_CHUNK):
+ *                      chunk c holds the sum over features 4 * 26 c .. of every row; the caller adds the chunks
+ *                      in order (deterministic; no atomics)
+ * flags: NFA_FLAG_INVERSE.  Supported: num_bins = 8, linear tails, hidden_features <= 256 and % 4 == 0,
+ * batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED (callers run the GEMM and nfa_rqs_coupling_f32).
+ */
+#define NFA_MADE_OUTPUT_GROUPS_PER_CHUNK 26
+int nfa_rqs_made_output_f32(const float *inputs, int64_t row_stride, int32_t first_column, const float *hidden,
+                            int32_t hidden_features, const void *weight_packed, const float *bias_padded,
+                            float *outputs, float *logabsdet_partial, int32_t *status, int64_t batch,
+                            int32_t num_features, const nfa_rqs_spec *spec, int32_t flags, void *stream);
 
 /*
  * K5.  Elementwise rational-quadratic functional (no row-sum):

@@ -651,6 +651,91 @@ def made_rqs_inverse(inputs, schedule, hidden_features, sequential_steps, spec):
 _sum_workspaces = {}
 
 
+def pack_made_output(net, params_per_feature, first_feature=0):
+    """The output layer of a MADE (made.py:261-268: weight [D * P, H] times its mask, feature-major rows) for K13
+    (layout in include/nflows_amd.h): the rows of features `first_feature` .. D - 1, per feature padded 23 -> 24,
+    features padded to a multiple of eight (zero rows: an even number of four-feature groups), the hidden width zero-padded to 256, rows in K7's order
+    (`_k7_row_order`), split into three bf16 pieces per weight.  Returns (weights, biases, number of features)."""
+    P = params_per_feature
+    final = net.final_layer
+    with torch.no_grad():
+        W = final.masked_weight().detach().float()
+        H = W.shape[1]
+        D = W.shape[0] // P
+        nf = D - first_feature
+        nf4 = (nf + 7) // 8 * 8   # an even number of four-feature groups
+        w = W.view(D, P, H)[first_feature:]
+        b = final.bias.detach().float().view(D, P)[first_feature:]
+        w = torch.cat((w, w.new_zeros(nf, 24 - P, H)), dim=1)
+        b = torch.cat((b, b.new_zeros(nf, 24 - P)), dim=1)
+        if nf4 > nf:
+            w = torch.cat((w, w.new_zeros(nf4 - nf, 24, H)), dim=0)
+            b = torch.cat((b, b.new_zeros(nf4 - nf, 24)), dim=0)
+        if H < 256:
+            w = torch.cat((w, w.new_zeros(nf4, 24, 256 - H)), dim=2)
+        order = _k7_row_order(nf4).to(W.device)
+        w = w.reshape(nf4 * 24, 256).index_select(0, order)
+        b = b.reshape(nf4 * 24).index_select(0, order)
+        tiles = nf4 * 24 // 32
+        # (piece, tile, r, half, ks, j) -> (tile, piece, ks, half, r, j); column = half*128 + ks*8 + j
+        wp = torch.stack(split_bf16x3(w)).view(3, tiles, 32, 2, 16, 8).permute(1, 0, 4, 3, 2, 5).contiguous()
+        # row i of a tile sits in accumulator register q = 4*(i//8) + i%4 of lane-half (i//4)%2
+        bp = b.view(tiles, 4, 2, 4).permute(0, 2, 1, 3).contiguous()
+    return wp, bp, nf
+
+
+MADE_OUTPUT_GROUPS_PER_CHUNK = 26   # NFA_MADE_OUTPUT_GROUPS_PER_CHUNK (include/nflows_amd.h)
+
+
+def made_output_spline(inputs, hidden, packed, spec, first_column=0, inverse=False, out=None):
+    """K13 -- MADE's output layer + the spline of every feature it parameterises + the per-sample logabsdet sum in
+    one kernel.  inputs [B, D] (the columns from `first_column` on are the spline's inputs), hidden [B, H] (the
+    output layer's input), packed = pack_made_output(net, P, first_feature=first_column).  Returns
+    (outputs [B, D] -- `out` if given, only those columns written --, logabsdet [B] of those columns), or None
+    when the shape is outside the kernel (callers run the GEMM + the spline kernel)."""
+    N.require_device_f32("inputs", inputs, 2)
+    N.require_device_f32("hidden", hidden, 2)
+    wp, bp, nf = packed
+    dev = inputs.device
+    B, D = inputs.shape
+    H = hidden.shape[1]
+    if first_column + nf != D or hidden.shape[0] != B or H > 256 or H % 4 or spec.num_bins != 8 or B == 0:
+        return None
+    x = inputs.detach().contiguous()
+    h = hidden.detach().contiguous()
+    target = out
+    pad = (-B) % 128
+    if pad:   # whole 128-row blocks on padded copies
+        x = torch.cat((x, x.new_zeros(pad, D)), dim=0)
+        h = torch.cat((h, h.new_zeros(pad, H)), dim=0)
+        out = None
+    if out is None:
+        out = torch.empty_like(x)
+    elif (out.dtype != torch.float32 or out.device != dev or tuple(out.shape) != (B, D) or not out.is_contiguous()):
+        raise ValueError("out must be a contiguous float32 [batch, features] tensor on the inputs' device")
+    groups = (nf + 7) // 8 * 2
+    chunks = (groups + MADE_OUTPUT_GROUPS_PER_CHUNK - 1) // MADE_OUTPUT_GROUPS_PER_CHUNK
+    part = torch.empty(chunks, B + pad, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_rqs_made_output_f32(
+            N.ptr(x), D, first_column, N.ptr(h), H, N.ptr(wp), N.ptr(bp), N.ptr(out), N.ptr(part),
+            N.ptr(_status_word(dev)), B + pad, nf, ctypes.byref(spec), N.FLAG_INVERSE if inverse else 0,
+            N.stream_handle(dev))
+    if rc == N.ERR_UNSUPPORTED:
+        return None
+    N.check(rc)
+    lad = part[0] if chunks == 1 else part.sum(dim=0)   # chunk by chunk, the same order on every run
+    if pad:
+        lad = lad[:B]
+        if target is None:
+            out = out[:B]
+        else:
+            target[:, first_column:] = out[:B, first_column:]
+            out = target
+    _after_spline(spec, inverse, dev)
+    return out, lad
+
+
 def sum_count(values):
     """float64 [2] = (sum of `values` accumulated in float64 in a fixed order, number of values), one
     launch."""

@@ -22,6 +22,18 @@ from . import splines
 from ..utils import torchutils
 
 
+class _LazyRows:
+    """`make()[index]`, with `make` called on the first access only."""
+
+    def __init__(self, make):
+        self._make, self._value = make, None
+
+    def __getitem__(self, index):
+        if self._value is None:
+            self._value = self._make()
+        return self._value[index]
+
+
 class AutoregressiveTransform(Transform):
     def __init__(self, autoregressive_net):
         super().__init__()
@@ -65,8 +77,11 @@ class AutoregressiveTransform(Transform):
         batch, features = inputs.shape
         mult = self._output_dim_multiplier()
         final = net.final_layer
-        weight = (final.weight * final.mask).view(features, mult, -1)
         bias = final.bias.view(features, mult)
+        if torch.is_grad_enabled():
+            weight = (final.weight * final.mask).view(features, mult, -1)
+        else:   # (formed on first use: the kernels below pack their own copy of the output layer)
+            weight = _LazyRows(lambda: final.masked_weight().view(features, mult, -1))
         outputs = torch.zeros_like(inputs)
         logabsdet = inputs.new_zeros(batch)
         if torch.is_grad_enabled():
@@ -114,12 +129,17 @@ class AutoregressiveTransform(Transform):
                 if sequential < features:
                     h = net.hidden_from_initial(pre, context)
             if sequential < features:
-                rest = features - sequential
-                params = torch.addmm(bias[sequential:].reshape(-1), h, weight[sequential:].reshape(rest * mult, -1).t())
-                columns, lad_rest = self._elementwise_inverse(inputs[:, sequential:].contiguous(),
-                                                              params.view(batch, rest, mult))
-                outputs[:, sequential:] = columns
-                logabsdet += lad_rest
+                tail = self._output_layer_kernel(inputs, h, sequential, inverse=True, out=outputs) \
+                    if hasattr(self, "_output_layer_kernel") and outputs.is_contiguous() else None
+                if tail is not None:   # (K13: the remaining features' rows of the output layer inside the spline kernel)
+                    logabsdet += tail[1]
+                else:
+                    rest = features - sequential
+                    params = torch.addmm(bias[sequential:].reshape(-1), h, weight[sequential:].reshape(rest * mult, -1).t())
+                    columns, lad_rest = self._elementwise_inverse(inputs[:, sequential:].contiguous(),
+                                                                  params.view(batch, rest, mult))
+                    outputs[:, sequential:] = columns
+                    logabsdet += lad_rest
         return outputs, logabsdet
 
     def _sequential_kernel(self, inputs, context, sequential):
@@ -241,6 +261,49 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
 
     def _elementwise_inverse(self, inputs, autoregressive_params):
         return self._elementwise(inputs, autoregressive_params, inverse=True)
+
+    # the MADE's output layer inside the spline kernel (K13, csrc/made_output.hip): the forward pass and the
+    # last pass of the inverse never form the [batch, features * multiplier] parameter tensor
+    fuse_output_layer = os.environ.get("NFA_K13", "1") != "0"
+
+    def _wh_divisor(self):
+        net = self.autoregressive_net
+        return float(np.sqrt(net.hidden_features)) if hasattr(net, "hidden_features") else 0.0
+
+    def _output_layer_kernel(self, inputs, hidden, first_feature, inverse, out=None):
+        """(outputs with the columns from `first_feature` on written, their logabsdet) from K13, or None."""
+        net = self.autoregressive_net
+        if not (self.fuse_output_layer and isinstance(net, made_module.MADE) and self.tails == "linear"
+                and self.num_bins == 8 and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
+                and not torch.is_grad_enabled() and hidden.shape[1] <= 256 and hidden.shape[1] % 4 == 0
+                and inputs.shape[0] >= 1):
+            return None
+        final = net.final_layer
+        key = (_cache.epoch(), first_feature) + tuple((t.data_ptr(), t._version) for t in (final.weight, final.bias, final.mask))
+        cache = self.__dict__.setdefault("_made_output_cache", {})
+        packed = cache.get(first_feature)
+        if packed is None or packed[0] != key:
+            if len(cache) > 4:
+                cache.clear()
+            packed = (key, ops.pack_made_output(net, self._output_dim_multiplier(), first_feature))
+            cache[first_feature] = packed
+        spec = ops.make_rqs_spec(self.num_bins, self.tails, tail_bound=self.tail_bound,
+                                 min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                                 min_derivative=self.min_derivative, wh_divisor=self._wh_divisor())
+        return ops.made_output_spline(inputs, hidden, packed[1], spec, first_column=first_feature, inverse=inverse,
+                                      out=out)
+
+    def forward(self, inputs, context=None):
+        net = self.autoregressive_net
+        if (self.fuse_output_layer and isinstance(net, made_module.MADE) and inputs.dim() == 2 and inputs.is_cuda
+                and inputs.dtype == torch.float32 and not torch.is_grad_enabled() and self.tails == "linear"
+                and self.num_bins == 8):
+            hidden = net.hidden(inputs, context)
+            fused = self._output_layer_kernel(inputs, hidden, 0, inverse=False)
+            if fused is not None:
+                return fused
+            return self._elementwise_forward(inputs, net.final_layer(hidden))
+        return super().forward(inputs, context)
 
     # persistent kernel for the sequential features of the inverse (K12, csrc/made_inverse.hip)
     fuse_sequential_inverse = os.environ.get("NFA_K12", "1") != "0"

@@ -981,6 +981,54 @@ def test_persistent_autoregressive_inverse_equals_the_step_by_step_loop(monkeypa
     assert (lad + lad_fwd).abs().max().item() <= 2 * (lad_ref + lad_fwd_ref).abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("features,hidden,blocks,residual,random_mask,batch", [
+    (10, 32, 1, True, False, 128),        # features not a multiple of four, one chunk
+    (23, 64, 2, False, True, 1000),       # feed-forward blocks, random masks, a ragged batch
+    (64, 48, 2, True, False, 100),        # H < D - 1: the inverse has a tail of independent features
+    (105, 256, 2, True, False, 300),      # two chunks (26 + 2 groups of four features)
+    (784, 256, 2, True, False, 512),      # BASELINE configs[4] shape: eight chunks
+])
+def test_made_output_layer_inside_the_spline_kernel(monkeypatch, features, hidden, blocks, residual, random_mask, batch):
+    """K13 (csrc/made_output.hip): the MADE's masked output layer, the spline of every feature and the per-sample
+    logabsdet sum in one kernel -- forward pass (autoregressive.py:38-41) and the last pass of the inverse
+    (:43-52: the features behind the last sequential one) -- against the GEMM + spline-kernel path
+    (`fuse_output_layer = False`), which the golden-vector tests tie to the reference."""
+    from nflows_amd import ops
+    from nflows_amd.transforms import MaskedPiecewiseRationalQuadraticAutoregressiveTransform as AR
+    import nflows_amd
+    torch.manual_seed(features + hidden)
+    t = AR(features=features, hidden_features=hidden, num_bins=8, tails="linear", tail_bound=3.0, num_blocks=blocks,
+           use_residual_blocks=residual, random_mask=random_mask).to(DEV).eval()
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(1.5)
+    x = (1.5 * torch.randn(batch, features, generator=torch.Generator().manual_seed(2))).to(DEV)
+    real = ops.made_output_spline
+    calls = []
+
+    def counting(*a, **k):
+        r = real(*a, **k)
+        calls.append(r is not None)
+        return r
+    monkeypatch.setattr(ops, "made_output_spline", counting)
+    results = {}
+    for fused in (True, False):
+        monkeypatch.setattr(AR, "fuse_output_layer", fused)
+        del calls[:]
+        with torch.no_grad():
+            y, lad = t(x)
+            xi, ladi = t.inverse(x)
+            y2, _ = t(x)
+        nflows_amd.check_status()
+        sequential = min(features, t._sequential_steps())
+        assert calls == ([True, True, True] if sequential < features else [True, True]) if fused else calls == []
+        assert torch.equal(y, y2)
+        results[fused] = (y, lad, xi, ladi)
+    for got, want, tol in zip(results[True], results[False], (2e-5, 1e-4, 2e-5, 1e-4)):
+        assert torch.isfinite(got).all()
+        assert (got - want).abs().max().item() <= tol * (1 + want.abs().max().item()), (got - want).abs().max().item()
+
+
 @pytest.mark.parametrize("hidden", [30, 64, 96])
 @pytest.mark.parametrize("engine", ["f16x2", "bf16x3"])
 def test_whole_layer_kernels_take_narrower_conditioners(monkeypatch, hidden, engine):

@@ -699,6 +699,48 @@ def test_batch_norm_fold_is_the_same_network():
     assert ops.fold_batch_norm(ctx) is None
 
 
+@pytest.mark.parametrize("features,hidden,first", [(10, 32, 0), (23, 256, 0), (23, 64, 7), (9, 20, 5)])
+def test_made_output_packing_reproduces_the_output_layer(features, hidden, first):
+    """ops.pack_made_output (K13's weights): summing the three bf16 pieces of every packed element and walking the
+    tiles the way the kernel's lanes do -- row i of a 32-row tile lands in accumulator register 4 (i // 8) + i % 4 of
+    lane-half (i // 4) % 2; the 48 registers a lane-half gets from a group's three tiles are the 24 + 24 logits of
+    features 4 g + 2 half and 4 g + 2 half + 1; k column = half * 128 + 8 ks + j -- gives hidden @ (W * mask)^T + b
+    of the reference's MADE output layer (made.py:261-268, :282) for the features from `first` on."""
+    from nflows_amd import ops
+    from nflows_amd.transforms import made as made_module
+    torch.manual_seed(features * 100 + hidden)
+    P = 23
+    net = made_module.MADE(features=features, hidden_features=hidden, num_blocks=1, output_multiplier=P)
+    with torch.no_grad():
+        net.final_layer.bias.normal_()
+    h = torch.randn(5, hidden)
+    with torch.no_grad():
+        want = net.final_layer(h).view(5, features, P)[:, first:]
+    wp, bp, nf = ops.pack_made_output(net, P, first_feature=first)
+    assert nf == features - first
+    groups = (nf + 7) // 8 * 2
+    tiles = groups * 3
+    assert wp.shape == (tiles, 3, 16, 2, 32, 8) and wp.dtype == torch.bfloat16 and bp.shape == (tiles, 2, 4, 4)
+    w = wp.float().sum(dim=1)                                   # [tile, ks, half, r, j]
+    rows = w.permute(0, 3, 2, 1, 4).reshape(tiles, 32, 256)     # [tile, r, k = half*128 + ks*8 + j]
+    hp = torch.cat((h, h.new_zeros(5, 256 - hidden)), dim=1)
+    i = torch.arange(32)
+    reg, lane_half = 4 * (i // 8) + i % 4, (i // 4) % 2
+    got = torch.zeros(5, groups * 4, 24)
+    for g in range(groups):
+        acc = torch.zeros(5, 3, 2, 16)
+        for t in range(3):
+            tile = g * 3 + t
+            val = hp @ rows[tile].t()                            # [5, 32]
+            acc[:, t, lane_half, reg] = val + bp[tile][lane_half, reg // 4, reg % 4]
+        for half in range(2):
+            got[:, 4 * g + 2 * half] = torch.cat((acc[:, 0, half], acc[:, 1, half, :8]), dim=1)
+            got[:, 4 * g + 2 * half + 1] = torch.cat((acc[:, 1, half, 8:], acc[:, 2, half]), dim=1)
+    scale = want.abs().max().item()
+    assert (got[:, :nf, :P] - want).abs().max().item() < 2e-6 * max(scale, 1.0)
+    assert got[:, :nf, P:].abs().sum().item() == 0.0 and got[:, nf:].abs().sum().item() == 0.0
+
+
 def test_layer_tables_follow_the_fused_permutations():
     from nflows_amd import ops
     D = 12
