@@ -167,6 +167,21 @@ with torch.no_grad():
     us = timeit(lambda: t_ar.inverse(za), reps=10, inner=2)
     rows.append("| K12 `made_rqs_inverse_kernel` + tail | autoregressive RQ inverse, D=784 H=256 B=4096 (256 sequential steps) | %.1f | %.2f us per step and 16 samples: latency-bound |"
                 % (us, us / 256))
+    # K13: the MADE's output layer inside the spline kernel (the layer's forward pass; the hidden layers are library GEMMs)
+    us = timeit(lambda: t_ar(za), reps=10, inner=2)
+    rows.append("| K13 `rqs_made_output_kernel` + the MADE's hidden layers | autoregressive RQ forward (density), D=784 H=256 B=4096 | %.1f | %.0f TFLOP/s bf16 over the whole call (6 products x 37.8 GFLOP in the kernel); %.1f M samples/s |"
+                % (us, 6 * 2.0 * 4096 * 256 * 784 * 23 / us / 1e6, 4096 / us))
+    # K8s: the 32-layer flow on the small-batch kernel (128-row blocks at 32 768 rows, four-wave 64-row blocks below)
+    RQ.conditioner_engine = "f16x2"
+    nflows_amd.invalidate_packed_weights()
+    flow32 = configs.rq_nsf_flow(32, 64, 8, 128).to(dev).eval()
+    macs = 32 * 128 + 4 * 128 * 128 + 128 * 32 * 24
+    for rows_s in (32768, 16384, 8192):
+        xs = torch.randn(rows_s, 64, device=dev, generator=g)
+        us = timeit(lambda: flow32._transform(xs), reps=10, inner=2)
+        rows.append("| K8s `k8s::rqs_resnet_f16s_kernel` (%s), run of 32 layers | the whole BASELINE transform, B=%d | %.1f | %.0f TFLOP/s f16 (peak 2 500); %.1f M samples/s |"
+                    % ("eight waves x 16 rows" if rows_s > 16384 else "four waves x 16 rows", rows_s, us,
+                       32 * 3 * 2.0 * rows_s * macs / us / 1e6, rows_s / us))
     nflows_amd.check_status()
 
 print("# Kernel table (round 3, 1 x MI355X; `python tools/all_kernels.py`)\n")
