@@ -509,13 +509,14 @@ struct LqBwdArgs {
 
 __device__ __forceinline__ float sigmoid_of(float v) { return v > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-v)); }
 
-template <bool INVERSE>
+template <int KT, bool INVERSE>
 __global__ void __launch_bounds__(kBlock) linear_spline_backward_kernel(const LqBwdArgs b) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LqArgs& a = b.f;
-    const int K = a.K;
-    float* pdf = lds + threadIdx.x * a.slot;  // K probabilities, then their adjoints in place
+    const int K = KT > 0 ? KT : a.K;            // KT > 0: the bin loops unroll, slot offsets are immediates
+    const int slot = KT > 0 ? (KT | 1) : a.slot;
+    float* pdf = lds + threadIdx.x * slot;  // K probabilities, then their adjoints in place
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += (int64_t)gridDim.x * blockDim.x) {
         const float x = b.x[i];
         const float gy = b.gy[i], gl = b.gl ? b.gl[i] : 0.0f;
@@ -526,7 +527,7 @@ __global__ void __launch_bounds__(kBlock) linear_spline_backward_kernel(const Lq
             continue;
         }
         for (int q = 0; q < K; ++q) pdf[q] = b.a0[i * K + q];
-        softmax_in_place<0>(pdf, K, 0.0f, 0.0f);
+        softmax_in_place<KT>(pdf, K, 0.0f, 0.0f);
         const float u = INVERSE ? (x - a.bottom) / a.span_out : (x - a.left) / a.span_in;
         int k = -1;
         float g_u = 0.0f, g_lo = 0.0f, g_hi = 0.0f, g_pk = 0.0f;  // adjoints of u, cdf[k], cdf[k+1], pdf[k]
@@ -600,16 +601,20 @@ __global__ void __launch_bounds__(kBlock) linear_spline_backward_kernel(const Lq
     }
 }
 
-template <bool INVERSE>
+template <int KT, bool DERIVED, bool INVERSE>
 __global__ void __launch_bounds__(kBlock) quadratic_spline_backward_kernel(const LqBwdArgs b) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LqArgs& a = b.f;
-    const int K = a.K, nh = a.nh;
-    const bool derived = nh == K - 1;
+    // KT > 0: K and the number of height logits (DERIVED: K - 1, else K + 1) are compile-time constants --
+    // the bin loops unroll and every slot offset is an immediate; KT == 0 reads both from the arguments
+    const int K = KT > 0 ? KT : a.K;
+    const int nh = KT > 0 ? (DERIVED ? KT - 1 : KT + 1) : a.nh;
+    const bool derived = KT > 0 ? DERIVED : nh == K - 1;
     const int hs = derived ? 1 : 0;  // height logit q sits at slot q + hs
+    const int slot = KT > 0 ? ((5 * KT + 3) | 1) : a.slot;
     // per lane: W[K] | H[K+1] (unnormalised) | Hn[K+1] | gW[K] | gHn[K+1] (later gH)
-    float* W = lds + threadIdx.x * a.slot;
+    float* W = lds + threadIdx.x * slot;
     float* H = W + K;
     float* Hn = H + K + 1;
     float* gW = Hn + K + 1;
@@ -625,7 +630,7 @@ __global__ void __launch_bounds__(kBlock) quadratic_spline_backward_kernel(const
         if (live) {
             u = INVERSE ? (x - a.bottom) / a.span_out : (x - a.left) / a.span_in;
             for (int q = 0; q < K; ++q) W[q] = b.a0[i * K + q];
-            softmax_in_place<0>(W, K, a.divisor, a.rdivisor);
+            softmax_in_place<KT>(W, K, a.divisor, a.rdivisor);
             for (int q = 0; q < K; ++q) W[q] = a.min_w + a.om_w * W[q];
             for (int q = 0; q < nh; ++q) {
                 float v = b.a1[i * nh + q];
@@ -777,13 +782,14 @@ __global__ void __launch_bounds__(kBlock) quadratic_spline_backward_kernel(const
 // direction differentiates the root implicitly (ds/dp = -(dF/dp) / F'(s)), which equals the derivative
 // of whichever closed-form root the forward pass took; the "almost quadratic" override (:219-226)
 // has its own explicit formula and is differentiated as such.
-template <bool INVERSE>
+template <int KT, bool INVERSE>
 __global__ void __launch_bounds__(kBlock) cubic_spline_backward_kernel(const LqBwdArgs b) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const LqArgs& a = b.f;
-    const int K = a.K;
-    float* w = lds + threadIdx.x * a.slot;  // widths | heights | their adjoints
+    const int K = KT > 0 ? KT : a.K;            // KT > 0: the bin loops unroll, slot offsets are immediates
+    const int slot = KT > 0 ? ((4 * KT) | 1) : a.slot;
+    float* w = lds + threadIdx.x * slot;  // widths | heights | their adjoints
     float* h = w + K;
     float* gw = h + K;
     float* gh = gw + K;
@@ -801,8 +807,8 @@ __global__ void __launch_bounds__(kBlock) cubic_spline_backward_kernel(const LqB
                 w[q] = b.a0[i * K + q];
                 h[q] = b.a1[i * K + q];
             }
-            softmax_in_place<0>(w, K, a.divisor, a.rdivisor);
-            softmax_in_place<0>(h, K, a.divisor, a.rdivisor);
+            softmax_in_place<KT>(w, K, a.divisor, a.rdivisor);
+            softmax_in_place<KT>(h, K, a.divisor, a.rdivisor);
             for (int q = 0; q < K; ++q) {
                 w[q] = a.min_w + a.om_w * w[q];
                 h[q] = a.min_h + a.om_hk * h[q];
@@ -981,16 +987,30 @@ static int launch_lq_backward(LqBwdArgs& b, int kind, int inverse, hipStream_t s
     const int64_t cap = (int64_t)device_cu_count() * 8;
     if (g > cap) g = cap;
     const dim3 grid((unsigned)g), block((unsigned)T);
+    // K = 8 (the benchmark configurations) and K = 10 (the reference's default num_bins) are compiled with
+    // the bin count as a constant; every other K runs the generic instance (same arithmetic, same results)
+#define NFA_LQB(KERNEL_, ...)                                                                     \
+    do {                                                                                          \
+        if (inverse) hipLaunchKernelGGL((KERNEL_<__VA_ARGS__, true>), grid, block, lds, st, b);   \
+        else hipLaunchKernelGGL((KERNEL_<__VA_ARGS__, false>), grid, block, lds, st, b);          \
+    } while (0)
     if (kind == kLinear) {
-        if (inverse) hipLaunchKernelGGL(linear_spline_backward_kernel<true>, grid, block, lds, st, b);
-        else hipLaunchKernelGGL(linear_spline_backward_kernel<false>, grid, block, lds, st, b);
+        if (K == 8) NFA_LQB(linear_spline_backward_kernel, 8);
+        else if (K == 10) NFA_LQB(linear_spline_backward_kernel, 10);
+        else NFA_LQB(linear_spline_backward_kernel, 0);
     } else if (kind == kQuadratic) {
-        if (inverse) hipLaunchKernelGGL(quadratic_spline_backward_kernel<true>, grid, block, lds, st, b);
-        else hipLaunchKernelGGL(quadratic_spline_backward_kernel<false>, grid, block, lds, st, b);
+        const bool derived = b.f.nh == K - 1;
+        if (K == 8 && derived) NFA_LQB(quadratic_spline_backward_kernel, 8, true);
+        else if (K == 8) NFA_LQB(quadratic_spline_backward_kernel, 8, false);
+        else if (K == 10 && derived) NFA_LQB(quadratic_spline_backward_kernel, 10, true);
+        else if (K == 10) NFA_LQB(quadratic_spline_backward_kernel, 10, false);
+        else NFA_LQB(quadratic_spline_backward_kernel, 0, false);
     } else {
-        if (inverse) hipLaunchKernelGGL(cubic_spline_backward_kernel<true>, grid, block, lds, st, b);
-        else hipLaunchKernelGGL(cubic_spline_backward_kernel<false>, grid, block, lds, st, b);
+        if (K == 8) NFA_LQB(cubic_spline_backward_kernel, 8);
+        else if (K == 10) NFA_LQB(cubic_spline_backward_kernel, 10);
+        else NFA_LQB(cubic_spline_backward_kernel, 0);
     }
+#undef NFA_LQB
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
 }

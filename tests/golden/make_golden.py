@@ -672,6 +672,19 @@ def sibling_spline_grad_cases():
     finish("quad_box", "quadratic", splines.quadratic_spline, x,
            [torch.randn(3, 5, 7, 6, generator=g), torch.randn(3, 5, 7, 7, generator=g)],
            dict(left=0.5, right=1.5, bottom=0.5, top=1.5, min_bin_width=1e-2, min_bin_height=1e-2))
+    # K = 8 (the bin count of the benchmark configurations: the backward kernels have an instance compiled for
+    # it); drawn after everything else so that the cases above keep their random numbers
+    K, n, scale, B = 8, 260, 1.2, 3.0
+    x = 0.02 + 0.96 * torch.rand(n, generator=g)
+    pdf = scale * torch.randn(n, K, generator=g)
+    uw = scale * torch.randn(n, K, generator=g)
+    finish("lin_k8", "linear", splines.linear_spline, x, [pdf], {})
+    finish("quad_k8", "quadratic", splines.quadratic_spline, x, [uw, scale * torch.randn(n, K + 1, generator=g)], {})
+    xu = 2.0 * torch.randn(n, generator=g)
+    xu[:3] = torch.tensor([B + 0.5, -B - 0.25, 0.0])
+    finish("ulin_k8", "linear", splines.unconstrained_linear_spline, xu, [pdf], dict(tail_bound=B, tails="linear"))
+    finish("uquad_k8", "quadratic", splines.unconstrained_quadratic_spline, xu,
+           [uw, scale * torch.randn(n, K - 1, generator=g)], dict(tail_bound=B, tails="linear"))
     out["meta"] = np.array(meta, dtype=object).astype(str)
     np.savez_compressed(os.path.join(HERE, "splines_lq_grads.npz"), **out)
     print("sibling spline gradients:", len(meta), "cases")
