@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NFA_ABI_VERSION 5  /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 5) */
+#define NFA_ABI_VERSION 6  /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 6) */
 
 /* return codes */
 #define NFA_OK 0
@@ -525,6 +525,23 @@ int nfa_rqs_elementwise_f64(const double *inputs, const double *unnormalized_wid
                             const double *unnormalized_derivatives, int64_t stride_d,
                             int32_t num_derivatives, double *outputs, double *logabsdet, int32_t *status,
                             int64_t n, const nfa_rqs_spec *spec, int32_t inverse, void *stream);
+
+/*
+ * K5d-backward.  Gradient of nfa_rqs_elementwise_f64 (same inputs, spec and direction) -- what the reference
+ * obtains from autograd through rational_quadratic.py:13-181 on double tensors (`flow.double()` training,
+ * torch.autograd.gradcheck of a spline layer).  grad_outputs / grad_logabsdet [n] are the upstream gradients
+ * of the two results (either may be NULL = zeros); grad_inputs [n], grad_widths [n, K], grad_heights [n, K]
+ * and grad_derivatives [n, num_derivatives] are dense and written in full.  Elements outside the box
+ * (linear tails: the identity) or that the forward pass flagged get grad_inputs = grad_outputs and zero
+ * logit gradients.  The inverse direction differentiates the root implicitly.  One lane per element.
+ */
+int nfa_rqs_elementwise_backward_f64(const double *inputs, const double *unnormalized_widths, int64_t stride_w,
+                                     const double *unnormalized_heights, int64_t stride_h,
+                                     const double *unnormalized_derivatives, int64_t stride_d,
+                                     int32_t num_derivatives, const double *grad_outputs,
+                                     const double *grad_logabsdet, double *grad_inputs, double *grad_widths,
+                                     double *grad_heights, double *grad_derivatives, int64_t n,
+                                     const nfa_rqs_spec *spec, int32_t inverse, void *stream);
 
 /*
  * K9.  The spline's siblings as elementwise functionals (no row-sum), same calling convention as

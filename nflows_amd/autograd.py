@@ -94,6 +94,49 @@ class RqsElementwise(torch.autograd.Function):
                 g_packed[:, K:2 * K].reshape(uh.shape), g_packed[:, 2 * K:].reshape(ud.shape), None, None)
 
 
+class RqsElementwise64(torch.autograd.Function):
+    """K5d forward; backward through nfa_rqs_elementwise_backward_f64 (float64: `flow.double()` training and
+    gradient checks of the spline layers run on the device; the reference differentiates the same
+    expressions by autograd, rational_quadratic.py:13-181)."""
+
+    @staticmethod
+    def forward(ctx, inputs, uw, uh, ud, spec, inverse):
+        from . import ops
+        y, lad = ops._rqs_elementwise_launch(inputs, uw, uh, ud, spec, inverse)
+        ctx.save_for_backward(inputs, uw, uh, ud)
+        ctx.spec = spec
+        ctx.inverse = bool(inverse)
+        return y, lad
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_y, g_lad):
+        from . import ops
+        inputs, uw, uh, ud = ctx.saved_tensors
+        spec = ctx.spec
+        K = spec.num_bins
+        nd = ud.shape[-1]
+        n = inputs.numel()
+        dev = inputs.device
+        x = inputs.contiguous().view(-1)
+        w, sw = ops._logit_rows(uw, n, K)
+        h, sh = ops._logit_rows(uh, n, K)
+        d, sd = ops._logit_rows(ud, n, nd) if nd else (uw.reshape(n, 0), 1)
+        g_y = None if g_y is None else g_y.contiguous().view(-1)
+        g_lad = None if g_lad is None else g_lad.contiguous().view(-1)
+        g_in = torch.empty_like(x)
+        g_w = torch.empty(n, K, dtype=x.dtype, device=dev)
+        g_h = torch.empty(n, K, dtype=x.dtype, device=dev)
+        g_d = torch.empty(n, nd, dtype=x.dtype, device=dev)
+        with torch.cuda.device(dev):
+            rc = N.load().nfa_rqs_elementwise_backward_f64(
+                N.ptr(x), N.ptr(w), sw, N.ptr(h), sh, N.ptr(d) if nd else N.ptr(w), sd, nd, N.ptr(g_y), N.ptr(g_lad),
+                N.ptr(g_in), N.ptr(g_w), N.ptr(g_h), N.ptr(g_d) if nd else None, n, ctypes.byref(spec),
+                int(ctx.inverse), N.stream_handle(dev))
+        N.check(rc)
+        return (g_in.view(inputs.shape), g_w.view(uw.shape), g_h.view(uh.shape), g_d.view(ud.shape), None, None)
+
+
 def _scale_and_grad(u, activation):
     """scale = act(u) and d scale / d u for the in-kernel activations (coupling.py:224-225,
     autoregressive.py:101)."""

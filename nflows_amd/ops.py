@@ -235,7 +235,8 @@ def rqs_elementwise(inputs, unnormalized_widths, unnormalized_heights, unnormali
         N.require_device_real(nm, t, dtype)
     if dtype == torch.float64 and AG.needs_grad(inputs, unnormalized_widths, unnormalized_heights,
                                                 unnormalized_derivatives):
-        raise NotImplementedError("nflows_amd: gradients of the float64 functional are not implemented")
+        return AG.RqsElementwise64.apply(inputs, unnormalized_widths, unnormalized_heights,
+                                         unnormalized_derivatives, spec, bool(inverse))
     if AG.needs_grad(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives):
         return AG.RqsElementwise.apply(inputs, unnormalized_widths, unnormalized_heights,
                                        unnormalized_derivatives, spec, bool(inverse))

@@ -60,6 +60,102 @@ def test_layer_gradients_match_reference_autograd(G):
     ops.check_status()
 
 
+def test_float64_functional_gradients_match_reference_autograd(G):
+    """K5d-backward (nfa_rqs_elementwise_backward_f64) against the reference's float64 autograd through a spline
+    coupling layer (grads.npz, loss = <y, Wy> + <logabsdet, Wl>): (a) the functional on strided views of the
+    packed table, (b) the whole layer class in double (torch gathers + the functional + index copies), both
+    directions; linear tails with the conditioner's divisor (K = 8, 5) and the constrained spline (K = 4)."""
+    from nflows_amd import ops
+    from nflows_amd import transforms as T
+
+    class Table(torch.nn.Module):
+        def __init__(self, table, hidden):
+            super().__init__()
+            self.table = torch.nn.Parameter(table)
+            if hidden is not None:
+                self.hidden_features = hidden
+
+        def forward(self, inputs, context=None):
+            return self.table
+
+    for name, kind, cfg in G["meta"]:
+        if kind != "rq":
+            continue
+        cfg = parse_kwargs(cfg)
+        K, tails, tb, H = cfg["K"], cfg["tails"], cfg["tail_bound"], cfg["hidden"]
+        P = 3 * K - 1 if tails == "linear" else 3 * K + 1
+        x0, p0 = G[name + "/x"].astype(np.float64), G[name + "/params"].astype(np.float64)
+        tidx_np = G[name + "/transform_idx"]
+        tidx = dev(tidx_np)
+        Wy, Wl = dev(G[name + "/Wy"].astype(np.float64)), dev(G[name + "/Wl"].astype(np.float64))
+        B, D = x0.shape
+        dt = len(tidx_np)
+        mask = np.zeros(D, dtype=np.int64)
+        mask[tidx_np] = 1
+        spec = ops.make_rqs_spec(K, tails, tail_bound=tb, wh_divisor=float(np.sqrt(H)) if H else 0.0)
+        for direction, inv in (("fwd", False), ("inv", True)):
+            tag = "%s/%s" % (name, direction)
+            ref_gx, ref_gp = G[tag + "_gx64"], G[tag + "_gp64"]
+            # (a) the functional
+            xt = dev(x0[:, tidx_np]).requires_grad_(True)
+            p = dev(p0).requires_grad_(True)
+            pr = p.view(B, dt, P)
+            y, lad = ops.rqs_elementwise(xt, pr[..., :K], pr[..., K:2 * K], pr[..., 2 * K:], spec, inverse=inv)
+            assert y.dtype == torch.float64
+            ((y * Wy[:, tidx]).sum() + (lad.sum(dim=1) * Wl).sum()).backward()
+            for got, ref, what in ((xt.grad, ref_gx[:, tidx_np], "gx"), (p.grad, ref_gp, "gparams")):
+                err = (got.cpu().numpy() - ref).__abs__().max()
+                assert err <= 1e-10 * (1 + np.abs(ref).max()), "%s functional %s: %.3e" % (tag, what, err)
+            # (b) the layer class in double
+            net = Table(dev(p0), H)
+            layer = T.PiecewiseRationalQuadraticCouplingTransform(torch.from_numpy(mask), lambda i, o: net, num_bins=K,
+                                                                  tails=tails, tail_bound=tb).to(DEV).double()
+            x = dev(x0).requires_grad_(True)
+            y, lad = (layer.inverse if inv else layer.forward)(x)
+            ((y * Wy).sum() + (lad * Wl).sum()).backward()
+            for got, ref, what in ((x.grad, ref_gx, "gx"), (net.table.grad, ref_gp, "gparams")):
+                err = (got.cpu().numpy() - ref).__abs__().max()
+                assert err <= 1e-10 * (1 + np.abs(ref).max()), "%s layer %s: %.3e" % (tag, what, err)
+    ops.check_status()
+
+
+def test_float64_flow_trains_on_the_device():
+    """`flow.double()` takes optimisation steps on the GPU (the reference is dtype-generic; before K5d-backward the
+    float64 functional refused to differentiate) and torch.autograd.gradcheck accepts the spline layer."""
+    from nflows_amd import transforms as T
+    from nflows_amd.distributions import StandardNormal
+    from nflows_amd.flows import Flow
+    from nflows_amd.nn.nets import ResidualNet
+    from nflows_amd.utils import torchutils
+    from nflows_amd.transforms import splines
+    torch.manual_seed(3)
+    layers = []
+    for i in range(2):
+        layers.append(T.ReversePermutation(4))
+        layers.append(T.PiecewiseRationalQuadraticCouplingTransform(
+            torchutils.create_alternating_binary_mask(4, even=(i % 2 == 0)),
+            lambda a, b: ResidualNet(a, b, 16, num_blocks=1), num_bins=6, tails="linear", tail_bound=3.0))
+    flow = Flow(T.CompositeTransform(layers), StandardNormal([4])).to(DEV).double().train()
+    opt = torch.optim.Adam(flow.parameters(), lr=1e-2)
+    data = torch.randn(512, 4, device=DEV, dtype=torch.float64) * 0.5 + 0.3
+    losses = []
+    for _ in range(30):
+        opt.zero_grad()
+        loss = -flow.log_prob(data).mean()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert np.isfinite(losses).all() and losses[-1] < losses[0] - 0.05, losses[::10]
+    g = torch.Generator().manual_seed(9)
+    x = (2.0 * torch.randn(12, generator=g, dtype=torch.float64)).to(DEV).requires_grad_(True)
+    uw, uh = (torch.randn(12, 5, generator=g, dtype=torch.float64).to(DEV).requires_grad_(True) for _ in range(2))
+    ud = torch.randn(12, 4, generator=g, dtype=torch.float64).to(DEV).requires_grad_(True)
+    for inverse in (False, True):
+        assert torch.autograd.gradcheck(
+            lambda *a: splines.unconstrained_rational_quadratic_spline(*a, inverse=inverse, tails="linear", tail_bound=2.5),
+            (x, uw, uh, ud), eps=1e-6, atol=1e-6, rtol=1e-5)
+
+
 def test_flow_training_gradients_match_reference(G):
     from nflows_amd import configs
     name = "g_flow_nsf"
