@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NFA_ABI_VERSION 6  /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 6) */
+#define NFA_ABI_VERSION 7  /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 7) */
 
 /* return codes */
 #define NFA_OK 0
@@ -542,6 +542,36 @@ int nfa_rqs_elementwise_backward_f64(const double *inputs, const double *unnorma
                                      const double *grad_logabsdet, double *grad_inputs, double *grad_widths,
                                      double *grad_heights, double *grad_derivatives, int64_t n,
                                      const nfa_rqs_spec *spec, int32_t inverse, void *stream);
+
+/*
+ * K14.  The hidden part of a ResidualNet conditioner under TRAINING (nn/nets/resnet.py:92-100 without the final
+ * layer: initial Linear, then blocks h += W_1 relu(W_0 relu(h) + b_0) + b_1; the reference differentiates the eager
+ * ops by autograd, examples/moons.ipynb cell 3) -- one kernel for the forward pass, one for the chain of input
+ * gradients; the weight / bias gradients are nfa_linear_wgrad_f32's on the arrays these two leave behind.
+ *
+ *   forward:  identity_inputs [batch, num_identity] -> hidden [batch, 128];
+ *             saved [2 num_blocks][batch][128]: saved[2k] = relu(h_k), saved[2k+1] = relu(a_k), the inputs of block
+ *             k's two Linears (what the weight gradients need, and the ReLU masks of the backward pass).
+ *   backward: grad_hidden [batch, 128] (+ saved) -> grad_identity_inputs [batch, num_identity] and
+ *             grads [2 num_blocks][batch][128]: grads[2k] = d loss / d h_k (= grad_outputs of the Linear that
+ *             produced h_k: the initial layer for k = 0, block k-1's second Linear otherwise),
+ *             grads[2k+1] = d loss / d a_k (grad_outputs of block k's first Linear).
+ *
+ * weights_packed: split-bf16 triples in 12 KB stages (layout of nfa_rqs_coupling_resnet_f32's hidden layers).
+ *   forward stream: the initial layer ((num_identity > 32 ? 4 : 2) k-major stages), then per block W_0, W_1 (8
+ *   k-major stages each, columns in accumulator order); bias_packed: accumulator-order biases, 128 + 256 per block.
+ *   backward stream: per block from the LAST to the first W_1^T, W_0^T (8 k-major stages each, columns in accumulator
+ *   order), then W_in^T as ceil(num_identity / 32) tile-major tiles of two stages (rows zero-padded to 32).
+ * fp32-accurate products on the bf16 matrix pipe (three pieces per operand, six products), full fp32 range.
+ * NFA_ERR_UNSUPPORTED (the caller keeps the eager path): hidden_features != 128, num_blocks > 3, num_identity > 64
+ * or not a multiple of 4, batch not a multiple of 128.
+ */
+int nfa_resnet_hidden_forward_f32(const float *identity_inputs, const void *weights_packed,
+                                  const float *bias_packed, float *saved, float *hidden, int64_t batch,
+                                  int32_t num_identity, int32_t hidden_features, int32_t num_blocks, void *stream);
+int nfa_resnet_hidden_backward_f32(const float *grad_hidden, const void *weights_packed, const float *saved,
+                                   float *grads, float *grad_identity_inputs, int64_t batch, int32_t num_identity,
+                                   int32_t hidden_features, int32_t num_blocks, void *stream);
 
 /*
  * K9.  The spline's siblings as elementwise functionals (no row-sum), same calling convention as

@@ -31,7 +31,7 @@ FLAG_PAD_COLUMNS_SHIFT = 8   # bits 8-10: trailing pad columns the density epilo
 TAILS_NONE, TAILS_LINEAR = 0, 1
 SCALE_DEFAULT, SCALE_GENERAL, SCALE_ADDITIVE, SCALE_GIVEN, SCALE_SOFTPLUS = 0, 1, 2, 3, 4
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EXPORTS = (
     "nfa_abi_version",
@@ -50,6 +50,8 @@ EXPORTS = (
     "nfa_affine_flow_mlp_f32",
     "nfa_made_rqs_inverse_f32",
     "nfa_rqs_made_output_f32",
+    "nfa_resnet_hidden_forward_f32",
+    "nfa_resnet_hidden_backward_f32",
     "nfa_rqs_flow_resnet_f16x2_f32",
     "nfa_rqs_flow_resnet_f16x2_tile16_f32",
     "nfa_rqs_flow_resnet_context_f16x2_f32",
@@ -144,6 +146,10 @@ def _declare(lib):
                                                     i32, sp, i32, vp]
     lib.nfa_rqs_elementwise_f64.restype = ctypes.c_int
     lib.nfa_rqs_elementwise_f64.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, i64, sp, i32, vp]
+    lib.nfa_resnet_hidden_forward_f32.restype = ctypes.c_int
+    lib.nfa_resnet_hidden_forward_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
+    lib.nfa_resnet_hidden_backward_f32.restype = ctypes.c_int
+    lib.nfa_resnet_hidden_backward_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
     lib.nfa_rqs_elementwise_backward_f64.restype = ctypes.c_int
     lib.nfa_rqs_elementwise_backward_f64.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, vp, vp, vp,
                                                      i64, sp, i32, vp]

@@ -296,6 +296,49 @@ class Linear(torch.autograd.Function):
         return g_in, (g_w if need_w else None), g_b
 
 
+class ResidualNetHidden(torch.autograd.Function):
+    """K14: the hidden part of a ResidualNet (initial Linear + residual blocks, resnet.py:92-99) under autograd --
+    `nfa_resnet_hidden_forward_f32` forward, `nfa_resnet_hidden_backward_f32` for the chain of input gradients, K10
+    (`nfa_linear_wgrad_f32`) for every weight / bias gradient on the arrays the two leave behind.  Arguments: the
+    identity features [B, d_i], then W_in, b_in and (W_0, b_0, W_1, b_1) per block."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        from . import ops
+        nb = (len(params) - 2) // 4
+        blocks = [params[2 + 4 * k: 6 + 4 * k] for k in range(nb)]
+        fwd_w, fwd_b, bwd_w = ops.pack_resnet_hidden_train(params[0], params[1], blocks)
+        hidden, saved = ops.resnet_hidden_forward(x, fwd_w, fwd_b, nb)
+        ctx.save_for_backward(x.detach().contiguous(), saved, bwd_w)
+        ctx.nb = nb
+        return hidden
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_hidden):
+        from . import ops
+        x, saved, bwd_w = ctx.saved_tensors
+        nb = ctx.nb
+        g_hidden = g_hidden.contiguous()
+        g_x, grads = ops.resnet_hidden_backward(g_hidden, bwd_w, saved, x.shape[1])
+        need = ctx.needs_input_grad
+
+        def wgrad(inputs, grad_outputs, need_w, need_b):
+            if not (need_w or need_b):
+                return None, None
+            got = ops.linear_wgrad(inputs, grad_outputs, need_bias=need_b)
+            if got is None:   # widths K10 does not take
+                return (grad_outputs.t() @ inputs if need_w else None), (grad_outputs.sum(0) if need_b else None)
+            return (got[0] if need_w else None), got[1]
+
+        out = [g_x if need[0] else None]
+        out += wgrad(x, grads[0] if nb else g_hidden, need[1], need[2])
+        for k in range(nb):
+            out += wgrad(saved[2 * k], grads[2 * k + 1], need[3 + 4 * k], need[4 + 4 * k])
+            out += wgrad(saved[2 * k + 1], grads[2 * k + 2] if k + 1 < nb else g_hidden, need[5 + 4 * k], need[6 + 4 * k])
+        return tuple(out)
+
+
 def _dense_rows(t, n, width):
     return t.detach().reshape(n, width).contiguous()
 

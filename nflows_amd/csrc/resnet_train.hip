@@ -1,0 +1,405 @@
+// K14: the hidden part of the ResidualNet conditioner (nn/nets/resnet.py:92-100 without the final layer:
+// initial Linear, then blocks h += W_1 relu(W_0 relu(h) + b_0) + b_1) for TRAINING -- one kernel for its forward
+// pass that also leaves behind what the backward pass needs, one kernel for the chain of input gradients.
+// The reference trains through autograd over eager ops (examples/moons.ipynb cell 3: `loss.backward()`); per layer
+// that is five library GEMMs + six elementwise kernels forward and as many backward, each a round trip of a
+// [B, 128] activation through HBM.  Here:
+//
+//   forward  (nfa_resnet_hidden_forward_f32):   x_id [B, d_i] -> h [B, 128], saved[2 k] = relu(h_k) (input of block
+//            k's first Linear), saved[2 k + 1] = relu(a_k) (input of its second Linear): exactly the `inputs` the
+//            weight-gradient kernel K10 wants, and the ReLU masks of the backward pass.  (With no block: nothing.)
+//   backward (nfa_resnet_hidden_backward_f32):  g_h [B, 128] (+ saved) -> per block g_a_k = (g_c W_1) . [a_k > 0]
+//            and g_h_k = g_h_{k+1} + (g_a_k W_0) . [h_k > 0], finally g_x = g_h_0 W_in.  Every g_* that is a
+//            `grad_outputs` of a Linear is written once ([B, 128]) for K10; the weight gradients stay K10's.
+//
+// Same skeleton and GEMM machinery as K8 / K11 (bf16x3_gemm.hpp): a wave owns 32 rows, activations (and
+// gradients) stay in registers as three bf16 pieces -- fp32-accurate products on the bf16 matrix pipe, full fp32
+// range, so gradients need no scaling --, weights (W for the forward stream, W^T for the backward stream, packed
+// by the host) arrive through the LDS-DMA ring.  Activations enter and leave in the MFMA accumulator layout: lane
+// (half, r) holds, of row r and 32-feature tile t, features 8 q4 + 4 half + (0..3) for q4 = 0..3 -- four 16-byte
+// accesses per tile which together cover whole 128-byte lines.
+//
+// Ordinary global LOADS are only issued with the weight ring drained (a `s_waitcnt vmcnt(n)` of the compiler counts
+// on in-order return, which LDS-DMA requests sharing the counter do not give it): both kernels load at the top of
+// a row block and wait for everything.  Stores are issued between the GEMMs: they only make the ring's counted
+// wait more conservative (requests complete in order among themselves; `vmcnt(3)` with stores outstanding still
+// implies that at most the three youngest requests are pending).
+//
+// Restrictions (the host keeps the eager path otherwise): hidden width 128, ReLU, no context / batch norm / active
+// dropout, at most three blocks, d_i <= 64 and d_i % 4 == 0, batch % 128 == 0.
+
+#include "bf16x3_gemm.hpp"
+
+#include <hip/hip_ext.h>
+
+namespace nfa {
+
+struct TrainArgs {
+    const float* x;      // forward: [B, d_i];  backward: g_h [B, 128]
+    const vec4f* w;      // the stream of 12 KB stages
+    const float* bias;   // forward: accumulator-order biases (128 + 256 per block)
+    float* saved;        // [2 nb][B][128] (forward: written, backward: read)
+    float* out;          // forward: h [B, 128];  backward: g_x [B, d_i]
+    float* grads;        // backward: [2 nb][B][128]: grads[2 k] = g_h_k (also the gradient w.r.t. block k's input
+                         // = `grad_outputs` of the Linear in front of it), grads[2 k + 1] = g_a_k
+    int64_t batch;       // multiple of 128
+    int di, num_blocks, num_stages;
+};
+
+// accumulator tile <-> rows of a [B, 128] array: element (row, 32 t + 8 q4 + 4 half + i) = acc[4 q4 + i]
+template <bool RELU>
+__device__ __forceinline__ void store_tile(float* base, int64_t row, int t, int half, const f32x16& a) {
+    vec4f* p = reinterpret_cast<vec4f*>(base + row * 128 + 32 * t + 4 * half);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        vec4f v = {a[4 * q4], a[4 * q4 + 1], a[4 * q4 + 2], a[4 * q4 + 3]};
+        if (RELU) {   // NaN stays NaN (torch.relu)
+            v.x = v.x < 0.0f ? 0.0f : v.x;
+            v.y = v.y < 0.0f ? 0.0f : v.y;
+            v.z = v.z < 0.0f ? 0.0f : v.z;
+            v.w = v.w < 0.0f ? 0.0f : v.w;
+        }
+        p[2 * q4] = v;   // 8 floats = two vec4 apart
+    }
+}
+
+__device__ __forceinline__ void start_stream(WeightStream& sm, const vec4f* w, float* lds, int num_stages, int tid) {
+    sm.w = w;
+    sm.ring = reinterpret_cast<vec4f*>(lds);
+    sm.slot = 1;
+    sm.fetch = 0;
+    sm.num_stages = num_stages;
+    sm.tid = tid;
+    stream_request(sm);  // stage 0 -> slot 0
+    sm.slot = 2;
+    stream_request(sm);  // stage 1 -> slot 1
+    sm.slot = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// one k-step of a k-major GEMM (bf16x3_gemm.hpp: gemm_kmajor): out^T[128 x 32 samples] += W[128 x 16] x act^T,
+// stage = [4 tiles][3 pieces][64 lanes] x 16 bytes
+__device__ __forceinline__ void kstep(f32x16 (&acc)[4], const bf16x8& bh, const bf16x8& bm, const bf16x8& bl,
+                                      WeightStream& sm, int lane) {
+    stream_request(sm);
+    const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(t * 3 + 0) * 64]);
+        const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(t * 3 + 1) * 64]);
+        const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(t * 3 + 2) * 64]);
+        NFA_MFMA6(acc[t], ah, am, al, bh, bm, bl);
+    }
+    stream_advance(sm);
+}
+
+// k-major GEMM over 128 inputs given as four fp32 accumulator tiles (ReLU'd first when RELU): tile t becomes the
+// pieces of k-steps 2 t and 2 t + 1 right before they are consumed, so that no 96-register piece array is ever
+// live next to the accumulators (K8 keeps the residual stream as pieces; here it stays in fp32 tiles)
+template <bool RELU>
+__device__ __forceinline__ void gemm_from_tiles(f32x16 (&acc)[4], const f32x16 (&src)[4], WeightStream& sm, int lane) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        bf16x8 h0, m0, l0, h1, m1, l1;
+        tile_to_pieces<RELU>(src[t], h0, m0, l0, h1, m1, l1);
+        kstep(acc, h0, m0, l0, sm, lane);
+        kstep(acc, h1, m1, l1, sm, lane);
+    }
+}
+
+// one 32-row output tile of a 128-wide layer from fp32 input tiles (bf16x3_gemm.hpp: gemm_tile): two stages of
+// [3 pieces][4 k-steps][64 lanes] x 16 bytes
+__device__ __forceinline__ void gemm_tile_from_tiles(f32x16& acc, const f32x16 (&src)[4], WeightStream& sm, int lane) {
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs) {
+        stream_request(sm);
+        const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            bf16x8 bh[2], bm[2], bl[2];
+            tile_to_pieces<false>(src[2 * hs + tt], bh[0], bm[0], bl[0], bh[1], bm[1], bl[1]);
+#pragma unroll
+            for (int hk = 0; hk < 2; ++hk) {
+                const int k4 = 2 * tt + hk;
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(0 * 4 + k4) * 64]);
+                const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(1 * 4 + k4) * 64]);
+                const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(2 * 4 + k4) * 64]);
+                NFA_MFMA6(acc, ah, am, al, bh[hk], bm[hk], bl[hk]);
+            }
+        }
+        stream_advance(sm);
+    }
+}
+
+template <int INIT_KS>
+__global__ void __launch_bounds__(kBlock, 2) resnet_hidden_forward_kernel(const TrainArgs a) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    WeightStream sm;
+    start_stream(sm, a.w, lds_dyn, a.num_stages, tid);
+    const int64_t num_quads = a.batch >> 7;
+    const int64_t plane = a.batch * 128;   // one saved activation
+    for (int64_t quad = blockIdx.x; quad < num_quads; quad += gridDim.x) {
+        const int64_t row0 = (quad << 7) + (wave << 5);
+        int lane_here = lane, di = a.di;
+        asm volatile("" : "+v"(lane_here), "+s"(di));
+        const int half = lane_here >> 5, r = lane_here & 31;
+        const int64_t row = row0 + r;
+        const float* bias = a.bias + half * 16;  // + 32 per tile
+        f32x16 hs[4];   // the residual stream h of the wave's 32 rows, fp32, accumulator layout
+        // ---- initial layer: h_0 = W_in x + b_in; the row's identity features are k = ks*16 + half*8 + j (zeros past
+        //      d_i), loaded while nothing else is in flight
+        {
+            vec4f xv[INIT_KS][2];
+            const float* xr = a.x + row * di;
+#pragma unroll
+            for (int ks = 0; ks < INIT_KS; ++ks)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int k0 = ks * 16 + half * 8 + g * 4;
+                    xv[ks][g] = k0 < di ? *reinterpret_cast<const vec4f*>(xr + k0) : vec4f{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < 4; ++t) load_bias_tile(hs[t], bias + t * 32);
+#pragma unroll
+            for (int ks = 0; ks < INIT_KS; ++ks) {
+                bf16x2 hh[4], mm[4], ll[4];
+                split3(vec2f{xv[ks][0].x, xv[ks][0].y}, hh[0], mm[0], ll[0]);
+                split3(vec2f{xv[ks][0].z, xv[ks][0].w}, hh[1], mm[1], ll[1]);
+                split3(vec2f{xv[ks][1].x, xv[ks][1].y}, hh[2], mm[2], ll[2]);
+                split3(vec2f{xv[ks][1].z, xv[ks][1].w}, hh[3], mm[3], ll[3]);
+                kstep(hs, join4(hh[0], hh[1], hh[2], hh[3]), join4(mm[0], mm[1], mm[2], mm[3]),
+                      join4(ll[0], ll[1], ll[2], ll[3]), sm, lane);
+            }
+        }
+        bias += 128;
+        // ---- residual blocks: a = W_0 relu(h) + b_0;  h += W_1 relu(a) + b_1
+        for (int blk = 0; blk < a.num_blocks; ++blk) {
+            float* in0 = a.saved + (2 * blk) * plane;
+            float* in1 = a.saved + (2 * blk + 1) * plane;
+            f32x16 u[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                store_tile<true>(in0, row, t, half, hs[t]);    // relu(h): the first Linear's input
+                load_bias_tile(u[t], bias + t * 32);
+            }
+            gemm_from_tiles<true>(u, hs, sm, lane);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                store_tile<true>(in1, row, t, half, u[t]);     // relu(a): the second Linear's input
+                f32x16 b1;
+                load_bias_tile(b1, bias + 128 + t * 32);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) hs[t][q] += b1[q];   // skip connection: accumulate onto h
+            }
+            gemm_from_tiles<true>(hs, u, sm, lane);
+            bias += 256;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) store_tile<false>(a.out, row, t, half, hs[t]);
+        // drain (stores, and the two stages requested past this row block) before the next block's loads
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// 64 ReLU masks of a lane (4 tiles x 16 accumulator registers) as two words: bit 16 t + q of the pair
+struct Mask64 {
+    unsigned lo, hi;   // tiles 0-1, tiles 2-3
+};
+
+// loads the lane's 64 values of a [B, 128] array (accumulator layout); the caller waits
+__device__ __forceinline__ void load_tiles_raw(vec4f (&v)[16], const float* base, int64_t row, int half) {
+    const vec4f* p = reinterpret_cast<const vec4f*>(base + row * 128 + 4 * half);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) v[t * 4 + q4] = p[8 * t + 2 * q4];
+}
+
+__device__ __forceinline__ Mask64 load_mask(const float* base, int64_t row, int half) {
+    vec4f v[16];
+    load_tiles_raw(v, base, row, half);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Mask64 m = {0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const unsigned bits = (v[i].x > 0.0f ? 1u : 0u) | (v[i].y > 0.0f ? 2u : 0u) | (v[i].z > 0.0f ? 4u : 0u) |
+                              (v[i].w > 0.0f ? 8u : 0u);
+        if (i < 8) m.lo |= bits << (4 * i);
+        else m.hi |= bits << (4 * (i - 8));
+    }
+    return m;
+}
+
+// acc[q] = mask bit (16 t + q) ? acc[q] : 0   (threshold_backward: grad * (output > 0))
+__device__ __forceinline__ void apply_mask(f32x16& acc, const Mask64& m, int t) {
+    const unsigned w = (t < 2 ? m.lo : m.hi) >> (16 * (t & 1));
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = ((w >> q) & 1u) ? acc[q] : 0.0f;
+}
+
+__device__ __forceinline__ void zero_tile(f32x16& acc) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+}
+
+template <int NB>   // number of blocks (their masks live in registers): 0 .. 3 (four would spill: no scratch traffic
+                    // may share the counter of the LDS-DMA ring)
+__global__ void __launch_bounds__(kBlock, 2) resnet_hidden_backward_kernel(const TrainArgs a) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    WeightStream sm;
+    start_stream(sm, a.w, lds_dyn, a.num_stages, tid);
+    const int64_t num_quads = a.batch >> 7;
+    const int64_t plane = a.batch * 128;
+    const int tiles_x = (a.di + 31) >> 5;
+    for (int64_t quad = blockIdx.x; quad < num_quads; quad += gridDim.x) {
+        const int64_t row0 = (quad << 7) + (wave << 5);
+        int lane_here = lane, di = a.di;
+        asm volatile("" : "+v"(lane_here), "+s"(di));
+        const int half = lane_here >> 5, r = lane_here & 31;
+        const int64_t row = row0 + r;
+        // ---- with the ring drained: the ReLU masks of every block, then the incoming gradient
+        Mask64 masks[2 * NB > 0 ? 2 * NB : 1];
+#pragma unroll
+        for (int i = 0; i < 2 * NB; ++i) masks[i] = load_mask(a.saved + i * plane, row, half);
+        f32x16 gs[4];   // g_h: the gradient of the residual stream, fp32, accumulator layout
+        {
+            vec4f v[16];
+            load_tiles_raw(v, a.x, row, half);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    gs[t][4 * q4] = v[4 * t + q4].x;
+                    gs[t][4 * q4 + 1] = v[4 * t + q4].y;
+                    gs[t][4 * q4 + 2] = v[4 * t + q4].z;
+                    gs[t][4 * q4 + 3] = v[4 * t + q4].w;
+                }
+        }
+        // ---- blocks, last to first: g_a = (g_h W_1) . [a > 0];  g_h += (g_a W_0) . [h > 0]
+#pragma unroll
+        for (int blk = NB - 1; blk >= 0; --blk) {
+            f32x16 u[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) zero_tile(u[t]);
+            gemm_from_tiles<false>(u, gs, sm, lane);
+            float* ga = a.grads + (2 * blk + 1) * plane;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                apply_mask(u[t], masks[2 * blk + 1], t);
+                store_tile<false>(ga, row, t, half, u[t]);
+            }
+            f32x16 v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) zero_tile(v[t]);
+            gemm_from_tiles<false>(v, u, sm, lane);
+            float* gh = a.grads + (2 * blk) * plane;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                apply_mask(v[t], masks[2 * blk], t);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) gs[t][q] += v[t][q];   // the skip connection's gradient
+                store_tile<false>(gh, row, t, half, gs[t]);
+            }
+        }
+        // ---- initial layer: g_x = g_h_0 W_in, one 32-column tile at a time
+        for (int t = 0; t < tiles_x; ++t) {
+            f32x16 acc;
+            zero_tile(acc);
+            gemm_tile_from_tiles(acc, gs, sm, lane);
+            float* gx = a.out + row * di + 32 * t + 4 * half;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                if (32 * t + 8 * q4 + 4 * half < di)
+                    *reinterpret_cast<vec4f*>(gx + 8 * q4) = vec4f{acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]};
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+static int check_train(int64_t batch, int32_t num_identity, int32_t hidden_features, int32_t num_blocks) {
+    if (batch < 0 || num_identity < 1 || num_blocks < 0) return NFA_ERR_INVALID_ARGUMENT;
+    if (hidden_features != 128 || num_identity > 64 || (num_identity & 3) != 0 || (batch & 127) != 0 || num_blocks > 3)
+        return NFA_ERR_UNSUPPORTED;
+    return NFA_OK;
+}
+
+static dim3 train_grid(int64_t batch) {
+    int64_t blocks = batch >> 7;
+    const int64_t cap = (int64_t)device_cu_count() * 2;
+    return dim3((unsigned)(blocks > cap ? cap : blocks));
+}
+
+}  // namespace nfa
+
+using namespace nfa;
+
+extern "C" int nfa_resnet_hidden_forward_f32(const float* identity_inputs, const void* weights_packed,
+                                             const float* bias_packed, float* saved, float* hidden, int64_t batch,
+                                             int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
+                                             void* stream) {
+    const int rc = check_train(batch, num_identity, hidden_features, num_blocks);
+    if (rc != NFA_OK) return rc;
+    if (batch == 0) return NFA_OK;
+    if (!identity_inputs || !weights_packed || !bias_packed || !hidden || (num_blocks > 0 && !saved))
+        return NFA_ERR_INVALID_ARGUMENT;
+    TrainArgs a;
+    a.x = identity_inputs;
+    a.w = reinterpret_cast<const vec4f*>(weights_packed);
+    a.bias = bias_packed;
+    a.saved = saved;
+    a.out = hidden;
+    a.grads = nullptr;
+    a.batch = batch;
+    a.di = num_identity;
+    a.num_blocks = num_blocks;
+    const int init_ks = num_identity > 32 ? 4 : 2;
+    a.num_stages = init_ks + 16 * num_blocks;
+    const size_t lds = (size_t)kRing * kStageVec4 * 16;
+    hipStream_t st = (hipStream_t)stream;
+    if (init_ks == 2) hipLaunchKernelGGL(resnet_hidden_forward_kernel<2>, train_grid(batch), dim3(kBlock), lds, st, a);
+    else hipLaunchKernelGGL(resnet_hidden_forward_kernel<4>, train_grid(batch), dim3(kBlock), lds, st, a);
+    NFA_HIP_CHECK(hipGetLastError());
+    return NFA_OK;
+}
+
+extern "C" int nfa_resnet_hidden_backward_f32(const float* grad_hidden, const void* weights_packed, const float* saved,
+                                              float* grads, float* grad_identity_inputs, int64_t batch,
+                                              int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
+                                              void* stream) {
+    const int rc = check_train(batch, num_identity, hidden_features, num_blocks);
+    if (rc != NFA_OK) return rc;
+    if (batch == 0) return NFA_OK;
+    if (!grad_hidden || !weights_packed || !grad_identity_inputs || (num_blocks > 0 && (!saved || !grads)))
+        return NFA_ERR_INVALID_ARGUMENT;
+    TrainArgs a;
+    a.x = grad_hidden;
+    a.w = reinterpret_cast<const vec4f*>(weights_packed);
+    a.bias = nullptr;
+    a.saved = const_cast<float*>(saved);
+    a.out = grad_identity_inputs;
+    a.grads = grads;
+    a.batch = batch;
+    a.di = num_identity;
+    a.num_blocks = num_blocks;
+    a.num_stages = 16 * num_blocks + 2 * ((num_identity + 31) / 32);
+    const size_t lds = (size_t)kRing * kStageVec4 * 16;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid = train_grid(batch), block(kBlock);
+    switch (num_blocks) {
+        case 0: hipLaunchKernelGGL(resnet_hidden_backward_kernel<0>, grid, block, lds, st, a); break;
+        case 1: hipLaunchKernelGGL(resnet_hidden_backward_kernel<1>, grid, block, lds, st, a); break;
+        case 2: hipLaunchKernelGGL(resnet_hidden_backward_kernel<2>, grid, block, lds, st, a); break;
+        default: hipLaunchKernelGGL(resnet_hidden_backward_kernel<3>, grid, block, lds, st, a); break;
+    }
+    NFA_HIP_CHECK(hipGetLastError());
+    return NFA_OK;
+}

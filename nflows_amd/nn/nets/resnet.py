@@ -12,6 +12,8 @@ the spline coupling layers read (coupling.py:554-559).
 Vector and image variants share one implementation: they differ only in the layer type (Linear /
 1x1 and 3x3 Conv2d), the batch-norm type and the attribute name of the two main layers.
 """
+import os
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -120,6 +122,8 @@ class _Net(nn.Module):
 
     _block = None
     _make = None
+    # K14 for the hidden part under autograd (class-level switch for A/B measurements; NFA_K14=0 turns it off)
+    fuse_training = os.environ.get("NFA_K14", "1") != "0"
 
     def _build(self, n_in, n_out, width, context_width, num_blocks, activation, dropout_probability,
                use_batch_norm):
@@ -131,9 +135,34 @@ class _Net(nn.Module):
             for _ in range(num_blocks))
         self.final_layer = make(width, n_out)
 
+    def _fused_training(self, inputs, context):
+        """K14 (one kernel for the hidden part's forward pass, one for its input gradients) applies: plain
+        ResidualNet under autograd on the device, ReLU, no context / batch norm / active dropout, the shapes
+        `ops.resnet_hidden_train_supported` lists."""
+        if not (self.fuse_training and type(self) is ResidualNet and context is None and torch.is_grad_enabled()
+                and inputs.is_cuda and inputs.dtype == torch.float32 and inputs.dim() == 2):
+            return False
+        from ... import ops
+        if not ops.resnet_hidden_train_supported(inputs.shape[0], inputs.shape[1], self.hidden_features, len(self.blocks)):
+            return False
+        if inputs.shape[1] != self.initial_layer.in_features:
+            return False
+        for b in self.blocks:
+            if (b.activation is not F.relu or b.use_batch_norm or (b.training and b.dropout.p != 0.0)
+                    or getattr(b, "context_layer", None) is not None):
+                return False
+        return any(p.requires_grad for p in self.parameters()) or inputs.requires_grad
+
     def hidden(self, inputs, context=None):
         """Activations in front of `final_layer` (the fused spline kernels K7 / K7b consume these
         and apply `final_layer` themselves)."""
+        if self._fused_training(inputs, context):
+            from ... import autograd as AG
+            params = [self.initial_layer.weight, self.initial_layer.bias]
+            for b in self.blocks:
+                params += [b.linear_layers[0].weight, b.linear_layers[0].bias, b.linear_layers[1].weight,
+                           b.linear_layers[1].bias]
+            return AG.ResidualNetHidden.apply(inputs, *params)
         h = inputs if context is None else torch.cat((inputs, context), dim=1)
         h = apply_layer(self.initial_layer, h)
         for block in self.blocks:

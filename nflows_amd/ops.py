@@ -1091,6 +1091,79 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False,
     return torch.cat(stages, dim=0).contiguous(), torch.cat(biases).contiguous()
 
 
+def pack_resnet_hidden_train(w_in, b_in, block_params):
+    """Packs the hidden part of a ResidualNet for K14 (nfa_resnet_hidden_forward_f32 / _backward_f32; layout in
+    include/nflows_amd.h).  w_in [128, d_i], b_in [128], block_params = [(W_0, b_0, W_1, b_1), ...] (all 128 wide).
+    Returns (forward stages, forward biases, backward stages): the forward stream is the initial layer + W_0, W_1
+    per block (pack_resnet_conditioner's hidden layers), the backward stream W_1^T, W_0^T per block from the last
+    to the first, then W_in^T tile-major (rows padded to 32)."""
+    dev = w_in.device
+    order_k = _k8_column_order().to(dev)
+
+    def pieces(w):
+        return torch.stack(split_bf16x3(w))  # [3, ...]
+
+    def kmajor(w):   # [128, 128], columns in accumulator order: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j)
+        return pieces(w.index_select(1, order_k)).view(3, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1)
+
+    di = w_in.shape[1]
+    init_ks = 4 if di > 32 else 2
+    wi = w_in.detach().float()
+    wi_padded = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)   # k = ks*16 + hf*8 + j
+    fwd = [pieces(wi_padded).view(3, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks, -1)]
+    bias = [_bias_accumulator_order(b_in.detach().float())]
+    bwd = []
+    for w0, b0, w1, b1 in block_params:
+        w0, w1 = w0.detach().float(), w1.detach().float()
+        fwd += [kmajor(w0), kmajor(w1)]
+        bias += [_bias_accumulator_order(b0.detach().float()), _bias_accumulator_order(b1.detach().float())]
+        bwd = [kmajor(w1.t()), kmajor(w0.t())] + bwd        # last block first
+    tiles = (di + 31) // 32
+    wt = torch.cat((wi.t(), wi.new_zeros(tiles * 32 - di, 128)), dim=0).index_select(1, order_k)   # [tiles*32, 128]
+    # (p, tile, i, hs, k4, hf, j) -> (tile, hs, p, k4, hf, i, j): two stages per tile
+    bwd.append(pieces(wt).view(3, tiles, 32, 2, 4, 2, 8).permute(1, 3, 0, 4, 5, 2, 6).reshape(tiles * 2, -1))
+    return torch.cat(fwd, dim=0).contiguous(), torch.cat(bias).contiguous(), torch.cat(bwd, dim=0).contiguous()
+
+
+def resnet_hidden_train_supported(batch, num_identity, hidden_features, num_blocks):
+    """The shapes K14 takes (everything else keeps the eager path)."""
+    return (hidden_features == 128 and 1 <= num_identity <= 64 and num_identity % 4 == 0 and 0 <= num_blocks <= 3
+            and batch > 0 and batch % 128 == 0)
+
+
+def resnet_hidden_forward(x, fwd_stages, fwd_bias, num_blocks):
+    """K14 forward: identity features [B, d_i] -> (hidden [B, 128], saved [2 num_blocks, B, 128])."""
+    N.require_device_f32("inputs", x, 2)
+    x = x.detach().contiguous()
+    B, di = x.shape
+    dev = x.device
+    hidden = torch.empty(B, 128, dtype=torch.float32, device=dev)
+    saved = torch.empty(2 * num_blocks, B, 128, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_resnet_hidden_forward_f32(N.ptr(x), N.ptr(fwd_stages), N.ptr(fwd_bias),
+                                                    N.ptr(saved) if num_blocks else None, N.ptr(hidden), B, di, 128,
+                                                    num_blocks, N.stream_handle(dev))
+    N.check(rc)
+    return hidden, saved
+
+
+def resnet_hidden_backward(grad_hidden, bwd_stages, saved, num_identity):
+    """K14 backward: d loss / d hidden [B, 128] -> (d loss / d identity features [B, d_i], grads [2 nb, B, 128])."""
+    N.require_device_f32("grad_hidden", grad_hidden, 2)
+    g = grad_hidden.detach().contiguous()
+    B = g.shape[0]
+    dev = g.device
+    nb = saved.shape[0] // 2
+    grads = torch.empty(2 * nb, B, 128, dtype=torch.float32, device=dev)
+    gx = torch.empty(B, num_identity, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_resnet_hidden_backward_f32(N.ptr(g), N.ptr(bwd_stages), N.ptr(saved) if nb else None,
+                                                     N.ptr(grads) if nb else None, N.ptr(gx), B, num_identity, 128, nb,
+                                                     N.stream_handle(dev))
+    N.check(rc)
+    return gx, grads
+
+
 def _affine_row_order(num_transform, additive):
     """For every row of the packed output layer of K11: which conditioner output it is (-1 = zero
     padding).  Row i of tile t sits in accumulator register q = 4 (i // 8) + i % 4 of lane-half

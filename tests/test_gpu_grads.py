@@ -156,6 +156,104 @@ def test_float64_flow_trains_on_the_device():
             (x, uw, uh, ud), eps=1e-6, atol=1e-6, rtol=1e-5)
 
 
+def _k14_net(B, di, nb):
+    from nflows_amd.nn.nets import ResidualNet
+    torch.manual_seed(B + di + nb)
+    net = ResidualNet(di, 40, 128, num_blocks=nb).to(DEV)
+    with torch.no_grad():   # (blocks end in U(-1e-3, 1e-3) layers: scale them up so that every path carries signal)
+        for b in net.blocks:
+            b.linear_layers[1].weight.mul_(60.0)
+            b.linear_layers[1].bias.mul_(60.0)
+    return net
+
+
+@pytest.mark.parametrize("B,di,nb", [(256, 32, 2), (384, 12, 1), (128, 64, 3), (1024, 36, 0)])
+def test_fused_conditioner_training_kernels(B, di, nb, monkeypatch):
+    """K14 (nfa_resnet_hidden_forward_f32 / _backward_f32 + K10) against autograd through the eager modules with the
+    same weights: the net's output, the input gradient and every parameter gradient, judged against float64 -- at
+    most 4 x the eager fp32 path's own error + 1e-6 of the scale.  One / two / four k-steps of identity features,
+    zero to three blocks.  (Small batches: an activation within rounding of zero flips a ReLU mask and moves a
+    gradient by O(weight) in ANY fp32 implementation; the large-batch test below pins the masks instead.)"""
+    import copy
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import ResidualNet
+    net = _k14_net(B, di, nb)
+    x = torch.randn(B, di, device=DEV, requires_grad=True)
+    w = torch.randn(B, 40, device=DEV)
+    calls = []
+    real = ops.resnet_hidden_forward
+    monkeypatch.setattr(ops, "resnet_hidden_forward", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+
+    def run(fused):
+        monkeypatch.setattr(ResidualNet, "fuse_training", fused)
+        net.zero_grad(set_to_none=True)
+        x.grad = None
+        out = net(x)
+        (out * w).sum().backward()
+        return [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+
+    got = run(True)
+    assert len(calls) == 1
+    eager = run(False)
+    assert len(calls) == 1
+    net64 = copy.deepcopy(net).double()
+    x64 = x.detach().double().requires_grad_(True)
+    out64 = net64(x64)
+    (out64 * w.double()).sum().backward()
+    truth = [out64.detach(), x64.grad] + [p.grad for p in net64.parameters()]
+    names = ["output", "grad_inputs"] + [n for n, _ in net.named_parameters()]
+    for name, a, b, t in zip(names, got, eager, truth):
+        scale = 1.0 + t.abs().max().item()
+        e_a, e_b = (a.double() - t).abs().max().item(), (b.double() - t).abs().max().item()
+        assert e_a <= 4 * e_b + 1e-6 * scale, "%s: fused %.3e, eager %.3e, scale %.2e" % (name, e_a, e_b, scale)
+
+
+@pytest.mark.parametrize("B,di,nb", [(65536, 32, 2), (16384, 64, 3), (2048, 8, 1)])
+def test_fused_conditioner_training_kernels_at_size(B, di, nb):
+    """The two K14 kernels at the benchmark's batch (every CU holds two workgroups), every array they write against
+    float64 tensor operations: the forward arrays (hidden, relu(h_k), relu(a_k): continuous in the inputs) within
+    2e-6 of the scale; the backward arrays with the ReLU masks PINNED to the ones the forward kernel produced (a
+    float64 chain through the same masks: gradients are then continuous too) within 2e-6 of the scale; repeated
+    launches bit-identical."""
+    from nflows_amd import ops
+    net = _k14_net(B, di, nb)
+    x = torch.randn(B, di, device=DEV)
+    g = torch.randn(B, 128, device=DEV)
+    blocks = [(b.linear_layers[0].weight, b.linear_layers[0].bias, b.linear_layers[1].weight, b.linear_layers[1].bias)
+              for b in net.blocks]
+    with torch.no_grad():
+        fw, fb, bw = ops.pack_resnet_hidden_train(net.initial_layer.weight, net.initial_layer.bias, blocks)
+        hid, saved = ops.resnet_hidden_forward(x, fw, fb, nb)
+        gx, grads = ops.resnet_hidden_backward(g, bw, saved, di)
+        hid2, saved2 = ops.resnet_hidden_forward(x, fw, fb, nb)
+        gx2, grads2 = ops.resnet_hidden_backward(g, bw, saved2, di)
+        assert torch.equal(hid, hid2) and torch.equal(saved, saved2) and torch.equal(gx, gx2) and torch.equal(grads, grads2)
+        d = lambda t: t.detach().double()
+        h = torch.nn.functional.linear(d(x), d(net.initial_layer.weight), d(net.initial_layer.bias))
+        truth_saved = []
+        for w0, b0, w1, b1 in blocks:
+            t = torch.relu(h)
+            u = torch.relu(torch.nn.functional.linear(t, d(w0), d(b0)))
+            truth_saved += [t, u]
+            h = h + torch.nn.functional.linear(u, d(w1), d(b1))
+
+        def close(name, got, truth):
+            err, scale = (d(got) - truth).abs().max().item(), 1.0 + truth.abs().max().item()
+            assert err <= 2e-6 * scale, "%s: %.3e (scale %.2e)" % (name, err, scale)
+
+        close("hidden", hid, h)
+        for i in range(2 * nb):
+            close("saved[%d]" % i, saved[i], truth_saved[i])
+        gh = d(g)
+        for k in reversed(range(nb)):
+            w0, b0, w1, b1 = blocks[k]
+            ga = (gh @ d(w1)) * (saved[2 * k + 1] > 0)
+            gh = gh + (ga @ d(w0)) * (saved[2 * k] > 0)
+            close("grads[%d]" % (2 * k + 1), grads[2 * k + 1], ga)
+            close("grads[%d]" % (2 * k), grads[2 * k], gh)
+        close("grad_inputs", gx, gh @ d(net.initial_layer.weight))
+
+
 def test_flow_training_gradients_match_reference(G):
     from nflows_amd import configs
     name = "g_flow_nsf"

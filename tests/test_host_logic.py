@@ -1183,3 +1183,45 @@ def test_no_mfma_result_lands_on_its_own_operands():
             (dk, d), (ak, a), (bk, b) = (regs(x.rstrip(",")) for x in m.groups())
             assert not (dk == ak and d & a) and not (dk == bk and d & b), (name, line.strip())
         assert count > 500, (name, count)
+
+
+def test_training_kernel_streams():
+    """K14's packed streams: the forward stream is the hidden-layer prefix of K8's stream (same stages, same
+    biases, bit for bit); every k-major stage group of the backward stream decodes to the TRANSPOSED weight of its
+    Linear in the order the kernel consumes them (last block first: W_1^T, W_0^T), the tail to W_in^T in two-stage
+    tiles with zero rows past d_i."""
+    import torch
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import ResidualNet
+    torch.manual_seed(5)
+    for di, nb in ((32, 2), (12, 1), (48, 3)):
+        net = ResidualNet(di, 8 * 23, 128, num_blocks=nb)
+        blocks = [(b.linear_layers[0].weight, b.linear_layers[0].bias, b.linear_layers[1].weight, b.linear_layers[1].bias)
+                  for b in net.blocks]
+        fwd, bias, bwd = ops.pack_resnet_hidden_train(net.initial_layer.weight, net.initial_layer.bias, blocks)
+        ref_w, ref_b = ops.pack_resnet_conditioner(net, 8, 23)
+        n_fwd = (4 if di > 32 else 2) + 16 * nb
+        assert fwd.shape == (n_fwd, 6144) and torch.equal(fwd.view(torch.int16), ref_w[:n_fwd].view(torch.int16))
+        assert torch.equal(bias, ref_b[:128 + 256 * nb])
+        order_k = ops._k8_column_order()
+
+        def decode_kmajor(stages):   # [8, 6144] -> the [128, 128] matrix whose pieces they hold
+            p = stages.view(8, 4, 3, 2, 32, 8).float().sum(dim=2)          # (ks, t, hf, i, j)
+            m = p.permute(1, 3, 0, 2, 4).reshape(128, 128)                  # rows t*32+i, columns (ks, hf, j)
+            out = torch.empty_like(m)
+            out[:, order_k] = m
+            return out
+
+        at = 0
+        for b in reversed(net.blocks):
+            for lin in (b.linear_layers[1], b.linear_layers[0]):
+                got = decode_kmajor(bwd[at:at + 8])
+                assert torch.allclose(got, lin.weight.detach().t(), rtol=0, atol=1e-7 * lin.weight.abs().max().item() + 1e-9)
+                at += 8
+        tiles = (di + 31) // 32
+        tail = bwd[at:].view(tiles, 2, 3, 4, 2, 32, 8).float().sum(dim=2)    # (tile, hs, k4, hf, i, j)
+        m = tail.permute(0, 4, 1, 2, 3, 5).reshape(tiles * 32, 128)
+        wt = torch.empty_like(m)
+        wt[:, order_k] = m
+        assert torch.allclose(wt[:di], net.initial_layer.weight.detach().t(), rtol=0, atol=1e-8)
+        assert not wt[di:].any() and bwd.shape[0] == 16 * nb + 2 * tiles
