@@ -566,6 +566,14 @@ int nfa_rqs_elementwise_backward_f64(const double *inputs, const double *unnorma
  * NFA_ERR_UNSUPPORTED (the caller keeps the eager path): hidden_features != 128, num_blocks > 3, num_identity > 64
  * or not a multiple of 4, batch not a multiple of 128.
  */
+/* The packer of the two streams (one launch; the weights change with every optimiser step).  block_params: HOST array
+ * of 4 num_blocks device pointers W_0, b_0, W_1, b_1 (fp32, contiguous, [128, 128] / [128]); initial_weight
+ * [128, num_identity].  forward_stages: ((num_identity > 32 ? 4 : 2) + 16 num_blocks) x 12288 bytes, forward_bias:
+ * 128 (1 + 2 num_blocks) floats, backward_stages: (16 num_blocks + 2 ceil(num_identity / 32)) x 12288 bytes. */
+int nfa_pack_resnet_hidden_train_f32(const float *initial_weight, const float *initial_bias,
+                                     const float *const *block_params, int32_t num_identity, int32_t hidden_features,
+                                     int32_t num_blocks, void *forward_stages, float *forward_bias,
+                                     void *backward_stages, void *stream);
 int nfa_resnet_hidden_forward_f32(const float *identity_inputs, const void *weights_packed,
                                   const float *bias_packed, float *saved, float *hidden, int64_t batch,
                                   int32_t num_identity, int32_t hidden_features, int32_t num_blocks, void *stream);

@@ -50,6 +50,7 @@ EXPORTS = (
     "nfa_affine_flow_mlp_f32",
     "nfa_made_rqs_inverse_f32",
     "nfa_rqs_made_output_f32",
+    "nfa_pack_resnet_hidden_train_f32",
     "nfa_resnet_hidden_forward_f32",
     "nfa_resnet_hidden_backward_f32",
     "nfa_rqs_flow_resnet_f16x2_f32",
@@ -146,6 +147,8 @@ def _declare(lib):
                                                     i32, sp, i32, vp]
     lib.nfa_rqs_elementwise_f64.restype = ctypes.c_int
     lib.nfa_rqs_elementwise_f64.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, i64, sp, i32, vp]
+    lib.nfa_pack_resnet_hidden_train_f32.restype = ctypes.c_int
+    lib.nfa_pack_resnet_hidden_train_f32.argtypes = [vp, vp, ctypes.POINTER(vp), i32, i32, i32, vp, vp, vp, vp]
     lib.nfa_resnet_hidden_forward_f32.restype = ctypes.c_int
     lib.nfa_resnet_hidden_forward_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
     lib.nfa_resnet_hidden_backward_f32.restype = ctypes.c_int

@@ -325,6 +325,92 @@ __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_backward_kernel(const
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- the packer: fp32 parameters -> the two streams of split-bf16 stages (weights change every optimiser step, so
+//      packing is part of the training step: one launch, one workgroup per 12 KB stage, one more for the biases).
+//      Same bytes as ops.pack_resnet_hidden_train's tensor-operation reference (split3 rounds like torch's
+//      .to(bfloat16)).
+struct PackArgs {
+    const float* w_in;
+    const float* b_in;
+    const float* blk[3][4];   // W_0, b_0, W_1, b_1 per block
+    __bf16* fwd;
+    float* fwd_bias;
+    __bf16* bwd;
+    int di, nb, init_ks;
+};
+
+// input feature consumed at (k-step ks, lane-half hf, element j) when the GEMM's input is the previous layer's
+// accumulator tiles (ops._k8_column_order)
+__device__ __forceinline__ int acc_col(int ks, int hf, int j) {
+    return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * hf + (j & 3);
+}
+
+__global__ void __launch_bounds__(kBlock) pack_resnet_hidden_kernel(const PackArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;   // grp: tile t (k-major) or k4 (tile-major)
+    const int hf = lane >> 5, i = lane & 31;
+    const int n_fwd = a.init_ks + 16 * a.nb, n_bwd_k = 16 * a.nb, tiles_x = (a.di + 31) >> 5;
+    int s = blockIdx.x;
+    if (s == n_fwd + n_bwd_k + 2 * tiles_x) {   // the biases, accumulator order: [tile][half][q] = b[32 tile + 8 (q / 4) + 4 half + q % 4]
+        for (int e = tid; e < 128 * (1 + 2 * a.nb); e += kBlock) {
+            const int v = e >> 7, r = e & 127;
+            const float* b = v == 0 ? a.b_in : a.blk[(v - 1) >> 1][((v - 1) & 1) ? 3 : 1];
+            const int tile = r >> 5, half = (r >> 4) & 1, q = r & 15;
+            a.fwd_bias[e] = b[32 * tile + 8 * (q >> 2) + 4 * half + (q & 3)];
+        }
+        return;
+    }
+    float v[8];
+    __bf16* dst;
+    bool tile_major = false;
+    if (s < n_fwd) {
+        dst = a.fwd + (size_t)s * 6144;
+        const int row = 32 * grp + i;
+        if (s < a.init_ks) {   // initial layer: k = ks*16 + hf*8 + j, zeros past d_i
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int col = s * 16 + hf * 8 + j;
+                v[j] = col < a.di ? a.w_in[row * a.di + col] : 0.0f;
+            }
+        } else {
+            const int lin = (s - a.init_ks) >> 3, ks = (s - a.init_ks) & 7;
+            const float* w = a.blk[lin >> 1][(lin & 1) ? 2 : 0];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = w[row * 128 + acc_col(ks, hf, j)];
+        }
+    } else if (s < n_fwd + n_bwd_k) {   // W_1^T, W_0^T per block, last block first
+        s -= n_fwd;
+        dst = a.bwd + (size_t)s * 6144;
+        const int lin = s >> 3, ks = s & 7;
+        const float* w = a.blk[a.nb - 1 - (lin >> 1)][(lin & 1) ? 0 : 2];
+        const int row = 32 * grp + i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = w[acc_col(ks, hf, j) * 128 + row];
+    } else {                            // W_in^T, tile-major: [piece][k4][lane], rows past d_i are zero
+        s -= n_fwd;
+        dst = a.bwd + (size_t)s * 6144;
+        const int s2 = s - n_bwd_k, tile = s2 >> 1, hs = s2 & 1;
+        const int row = 32 * tile + i, ks = 4 * hs + grp;
+        tile_major = true;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = row < a.di ? a.w_in[acc_col(ks, hf, j) * a.di + row] : 0.0f;
+    }
+    bf16x2 hh[4], mm[4], ll[4];
+#pragma unroll
+    for (int j2 = 0; j2 < 4; ++j2) split3(vec2f{v[2 * j2], v[2 * j2 + 1]}, hh[j2], mm[j2], ll[j2]);
+    const bf16x8 ph = join4(hh[0], hh[1], hh[2], hh[3]), pm = join4(mm[0], mm[1], mm[2], mm[3]),
+                 pl = join4(ll[0], ll[1], ll[2], ll[3]);
+    bf16x8* out = reinterpret_cast<bf16x8*>(dst);
+    if (tile_major) {   // ((piece * 4 + k4) * 64 + lane)
+        out[(0 * 4 + grp) * 64 + lane] = ph;
+        out[(1 * 4 + grp) * 64 + lane] = pm;
+        out[(2 * 4 + grp) * 64 + lane] = pl;
+    } else {            // ((tile * 3 + piece) * 64 + lane)
+        out[(grp * 3 + 0) * 64 + lane] = ph;
+        out[(grp * 3 + 1) * 64 + lane] = pm;
+        out[(grp * 3 + 2) * 64 + lane] = pl;
+    }
+}
+
 static int check_train(int64_t batch, int32_t num_identity, int32_t hidden_features, int32_t num_blocks) {
     if (batch < 0 || num_identity < 1 || num_blocks < 0) return NFA_ERR_INVALID_ARGUMENT;
     if (hidden_features != 128 || num_identity > 64 || (num_identity & 3) != 0 || (batch & 127) != 0 || num_blocks > 3)
@@ -400,6 +486,35 @@ extern "C" int nfa_resnet_hidden_backward_f32(const float* grad_hidden, const vo
         case 2: hipLaunchKernelGGL(resnet_hidden_backward_kernel<2>, grid, block, lds, st, a); break;
         default: hipLaunchKernelGGL(resnet_hidden_backward_kernel<3>, grid, block, lds, st, a); break;
     }
+    NFA_HIP_CHECK(hipGetLastError());
+    return NFA_OK;
+}
+
+extern "C" int nfa_pack_resnet_hidden_train_f32(const float* initial_weight, const float* initial_bias,
+                                                const float* const* block_params, int32_t num_identity,
+                                                int32_t hidden_features, int32_t num_blocks, void* forward_stages,
+                                                float* forward_bias, void* backward_stages, void* stream) {
+    const int rc = check_train(128, num_identity, hidden_features, num_blocks);
+    if (rc != NFA_OK) return rc;
+    if (!initial_weight || !initial_bias || !forward_stages || !forward_bias || !backward_stages ||
+        (num_blocks > 0 && !block_params))
+        return NFA_ERR_INVALID_ARGUMENT;
+    PackArgs a;
+    a.w_in = initial_weight;
+    a.b_in = initial_bias;
+    for (int k = 0; k < 3; ++k)
+        for (int q = 0; q < 4; ++q) {
+            a.blk[k][q] = k < num_blocks ? block_params[4 * k + q] : nullptr;
+            if (k < num_blocks && !a.blk[k][q]) return NFA_ERR_INVALID_ARGUMENT;
+        }
+    a.fwd = reinterpret_cast<__bf16*>(forward_stages);
+    a.fwd_bias = forward_bias;
+    a.bwd = reinterpret_cast<__bf16*>(backward_stages);
+    a.di = num_identity;
+    a.nb = num_blocks;
+    a.init_ks = num_identity > 32 ? 4 : 2;
+    const int stages = a.init_ks + 32 * num_blocks + 2 * ((num_identity + 31) / 32);
+    hipLaunchKernelGGL(pack_resnet_hidden_kernel, dim3(stages + 1), dim3(kBlock), 0, (hipStream_t)stream, a);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
 }

@@ -1091,14 +1091,46 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False,
     return torch.cat(stages, dim=0).contiguous(), torch.cat(biases).contiguous()
 
 
+_TRAIN_ORDER_K = {}
+
+
 def pack_resnet_hidden_train(w_in, b_in, block_params):
+    """K14's packer as ONE launch (nfa_pack_resnet_hidden_train_f32): fp32 parameters on the device -> (forward stages,
+    forward biases, backward stages), the bytes of `pack_resnet_hidden_train_reference`.  Runs inside every training
+    step (the weights change), including captured ones."""
+    dev = w_in.device
+    if not (w_in.is_cuda and w_in.dtype == torch.float32):
+        return pack_resnet_hidden_train_reference(w_in, b_in, block_params)
+    di, nb = w_in.shape[1], len(block_params)
+    init_ks = 4 if di > 32 else 2
+    tiles = (di + 31) // 32
+    flat = [w_in.detach().contiguous(), b_in.detach().contiguous()]
+    for group in block_params:
+        flat += [t.detach().contiguous() for t in group]
+    for t in flat:
+        if t.dtype != torch.float32 or not t.is_cuda:
+            raise TypeError("nflows_amd: the conditioner's parameters must be float32 tensors on the device")
+    fwd = torch.empty(init_ks + 16 * nb, 6144, dtype=torch.bfloat16, device=dev)
+    bias = torch.empty(128 * (1 + 2 * nb), dtype=torch.float32, device=dev)
+    bwd = torch.empty(16 * nb + 2 * tiles, 6144, dtype=torch.bfloat16, device=dev)
+    ptrs = (ctypes.c_void_p * max(1, 4 * nb))(*[t.data_ptr() for t in flat[2:]])
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_pack_resnet_hidden_train_f32(N.ptr(flat[0]), N.ptr(flat[1]), ptrs, di, w_in.shape[0], nb,
+                                                       N.ptr(fwd), N.ptr(bias), N.ptr(bwd), N.stream_handle(dev))
+    N.check(rc)
+    return fwd, bias, bwd
+
+
+def pack_resnet_hidden_train_reference(w_in, b_in, block_params):
     """Packs the hidden part of a ResidualNet for K14 (nfa_resnet_hidden_forward_f32 / _backward_f32; layout in
     include/nflows_amd.h).  w_in [128, d_i], b_in [128], block_params = [(W_0, b_0, W_1, b_1), ...] (all 128 wide).
     Returns (forward stages, forward biases, backward stages): the forward stream is the initial layer + W_0, W_1
     per block (pack_resnet_conditioner's hidden layers), the backward stream W_1^T, W_0^T per block from the last
     to the first, then W_in^T tile-major (rows padded to 32)."""
     dev = w_in.device
-    order_k = _k8_column_order().to(dev)
+    order_k = _TRAIN_ORDER_K.get(dev)   # (cached per device: this packer runs inside captured training steps,
+    if order_k is None:                 #  where a host-to-device copy is not allowed)
+        order_k = _TRAIN_ORDER_K[dev] = _k8_column_order().to(dev)
 
     def pieces(w):
         return torch.stack(split_bf16x3(w))  # [3, ...]

@@ -208,6 +208,21 @@ def test_fused_conditioner_training_kernels(B, di, nb, monkeypatch):
         assert e_a <= 4 * e_b + 1e-6 * scale, "%s: fused %.3e, eager %.3e, scale %.2e" % (name, e_a, e_b, scale)
 
 
+@pytest.mark.parametrize("di,nb", [(32, 2), (12, 1), (64, 3), (36, 0)])
+def test_training_stream_packer_kernel_matches_the_tensor_reference(di, nb):
+    """nfa_pack_resnet_hidden_train_f32 (one launch inside every training step) writes the bytes of the
+    tensor-operation packer (whose layout the CPU suite decodes: tests/test_host_logic.py)."""
+    from nflows_amd import ops
+    net = _k14_net(128, di, nb)
+    blocks = [(b.linear_layers[0].weight, b.linear_layers[0].bias, b.linear_layers[1].weight, b.linear_layers[1].bias)
+              for b in net.blocks]
+    got = ops.pack_resnet_hidden_train(net.initial_layer.weight, net.initial_layer.bias, blocks)
+    ref = ops.pack_resnet_hidden_train_reference(net.initial_layer.weight, net.initial_layer.bias, blocks)
+    assert got[0].shape == ref[0].shape and torch.equal(got[0].view(torch.int16), ref[0].view(torch.int16))
+    assert torch.equal(got[1], ref[1])
+    assert got[2].shape == ref[2].shape and torch.equal(got[2].view(torch.int16), ref[2].view(torch.int16))
+
+
 @pytest.mark.parametrize("B,di,nb", [(65536, 32, 2), (16384, 64, 3), (2048, 8, 1)])
 def test_fused_conditioner_training_kernels_at_size(B, di, nb):
     """The two K14 kernels at the benchmark's batch (every CU holds two workgroups), every array they write against

@@ -1198,7 +1198,7 @@ def test_training_kernel_streams():
         net = ResidualNet(di, 8 * 23, 128, num_blocks=nb)
         blocks = [(b.linear_layers[0].weight, b.linear_layers[0].bias, b.linear_layers[1].weight, b.linear_layers[1].bias)
                   for b in net.blocks]
-        fwd, bias, bwd = ops.pack_resnet_hidden_train(net.initial_layer.weight, net.initial_layer.bias, blocks)
+        fwd, bias, bwd = ops.pack_resnet_hidden_train_reference(net.initial_layer.weight, net.initial_layer.bias, blocks)
         ref_w, ref_b = ops.pack_resnet_conditioner(net, 8, 23)
         n_fwd = (4 if di > 32 else 2) + 16 * nb
         assert fwd.shape == (n_fwd, 6144) and torch.equal(fwd.view(torch.int16), ref_w[:n_fwd].view(torch.int16))
