@@ -566,16 +566,26 @@ int nfa_rqs_elementwise_backward_f64(const double *inputs, const double *unnorma
  * NFA_ERR_UNSUPPORTED (the caller keeps the eager path): hidden_features != 128, num_blocks > 3, num_identity > 64
  * or not a multiple of 4, batch not a multiple of 128.
  */
-/* The packer of the two streams (one launch; the weights change with every optimiser step).  block_params: HOST array
+/* Optionally the forward kernel also applies the net's final Linear (128 -> out_features, out_features % 4 == 0;
+ * resnet.py:99) behind the blocks: its tile-major stages (ceil(out_features / 32) tiles of two stages, rows
+ * zero-padded to 32) follow the hidden layers in the forward stream, final_bias_packed holds its bias in accumulator
+ * order (32 per tile), params [batch, out_features] receives the conditioner's output; out_features = 0: hidden only.
+ *
+ * The packer of the two streams (one launch; the weights change with every optimiser step).  block_params: HOST array
  * of 4 num_blocks device pointers W_0, b_0, W_1, b_1 (fp32, contiguous, [128, 128] / [128]); initial_weight
- * [128, num_identity].  forward_stages: ((num_identity > 32 ? 4 : 2) + 16 num_blocks) x 12288 bytes, forward_bias:
- * 128 (1 + 2 num_blocks) floats, backward_stages: (16 num_blocks + 2 ceil(num_identity / 32)) x 12288 bytes. */
+ * [128, num_identity]; final_weight [out_features, 128] / final_bias (NULL, 0: none).  forward_stages:
+ * ((num_identity > 32 ? 4 : 2) + 16 num_blocks + 2 ceil(out_features / 32)) x 12288 bytes, forward_bias:
+ * 128 (1 + 2 num_blocks) floats, final_bias_packed: 32 ceil(out_features / 32) floats, backward_stages:
+ * (16 num_blocks + 2 ceil(num_identity / 32)) x 12288 bytes. */
 int nfa_pack_resnet_hidden_train_f32(const float *initial_weight, const float *initial_bias,
-                                     const float *const *block_params, int32_t num_identity, int32_t hidden_features,
-                                     int32_t num_blocks, void *forward_stages, float *forward_bias,
-                                     void *backward_stages, void *stream);
+                                     const float *const *block_params, const float *final_weight,
+                                     const float *final_bias, int32_t out_features, int32_t num_identity,
+                                     int32_t hidden_features, int32_t num_blocks, void *forward_stages,
+                                     float *forward_bias, float *final_bias_packed, void *backward_stages,
+                                     void *stream);
 int nfa_resnet_hidden_forward_f32(const float *identity_inputs, const void *weights_packed,
-                                  const float *bias_packed, float *saved, float *hidden, int64_t batch,
+                                  const float *bias_packed, float *saved, float *hidden,
+                                  const float *final_bias_packed, float *params, int32_t out_features, int64_t batch,
                                   int32_t num_identity, int32_t hidden_features, int32_t num_blocks, void *stream);
 int nfa_resnet_hidden_backward_f32(const float *grad_hidden, const void *weights_packed, const float *saved,
                                    float *grads, float *grad_identity_inputs, int64_t batch, int32_t num_identity,

@@ -148,9 +148,10 @@ def _declare(lib):
     lib.nfa_rqs_elementwise_f64.restype = ctypes.c_int
     lib.nfa_rqs_elementwise_f64.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, i64, sp, i32, vp]
     lib.nfa_pack_resnet_hidden_train_f32.restype = ctypes.c_int
-    lib.nfa_pack_resnet_hidden_train_f32.argtypes = [vp, vp, ctypes.POINTER(vp), i32, i32, i32, vp, vp, vp, vp]
+    lib.nfa_pack_resnet_hidden_train_f32.argtypes = [vp, vp, ctypes.POINTER(vp), vp, vp, i32, i32, i32, i32, vp, vp, vp,
+                                                     vp, vp]
     lib.nfa_resnet_hidden_forward_f32.restype = ctypes.c_int
-    lib.nfa_resnet_hidden_forward_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
+    lib.nfa_resnet_hidden_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp]
     lib.nfa_resnet_hidden_backward_f32.restype = ctypes.c_int
     lib.nfa_resnet_hidden_backward_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
     lib.nfa_rqs_elementwise_backward_f64.restype = ctypes.c_int

@@ -297,31 +297,35 @@ class Linear(torch.autograd.Function):
 
 
 class ResidualNetHidden(torch.autograd.Function):
-    """K14: the hidden part of a ResidualNet (initial Linear + residual blocks, resnet.py:92-99) under autograd --
-    `nfa_resnet_hidden_forward_f32` forward, `nfa_resnet_hidden_backward_f32` for the chain of input gradients, K10
-    (`nfa_linear_wgrad_f32`) for every weight / bias gradient on the arrays the two leave behind.  Arguments: the
-    identity features [B, d_i], then W_in, b_in and (W_0, b_0, W_1, b_1) per block."""
+    """K14: a ResidualNet (initial Linear + residual blocks, and with `with_final` the final Linear: resnet.py:92-100)
+    under autograd -- `nfa_resnet_hidden_forward_f32` forward, `nfa_resnet_hidden_backward_f32` for the chain of input
+    gradients through the hidden part, K10 (`nfa_linear_wgrad_f32`) for every weight / bias gradient on the arrays
+    the two leave behind; the final Linear's input gradient is one library GEMM.  Arguments: the identity features
+    [B, d_i], with_final, then W_in, b_in, (W_0, b_0, W_1, b_1) per block and, with_final, W_f, b_f."""
 
     @staticmethod
-    def forward(ctx, x, *params):
+    def forward(ctx, x, with_final, *params):
         from . import ops
-        nb = (len(params) - 2) // 4
-        blocks = [params[2 + 4 * k: 6 + 4 * k] for k in range(nb)]
-        fwd_w, fwd_b, bwd_w = ops.pack_resnet_hidden_train(params[0], params[1], blocks)
-        hidden, saved = ops.resnet_hidden_forward(x, fwd_w, fwd_b, nb)
+        hidden_params = params[:-2] if with_final else params
+        nb = (len(hidden_params) - 2) // 4
+        blocks = [hidden_params[2 + 4 * k: 6 + 4 * k] for k in range(nb)]
+        final = params[-2:] if with_final else None
+        fwd_w, fwd_b, bwd_w, fbias = ops.pack_resnet_hidden_train(params[0], params[1], blocks, final)
+        hidden, saved, out = ops.resnet_hidden_forward(x, fwd_w, fwd_b, nb, fbias, final[0].shape[0] if with_final else 0)
+        ctx.nb, ctx.with_final = nb, with_final
+        if with_final:
+            ctx.save_for_backward(x.detach().contiguous(), saved, bwd_w, hidden, final[0])
+            return out
         ctx.save_for_backward(x.detach().contiguous(), saved, bwd_w)
-        ctx.nb = nb
         return hidden
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g_hidden):
+    def backward(ctx, g_out):
         from . import ops
-        x, saved, bwd_w = ctx.saved_tensors
         nb = ctx.nb
-        g_hidden = g_hidden.contiguous()
-        g_x, grads = ops.resnet_hidden_backward(g_hidden, bwd_w, saved, x.shape[1])
-        need = ctx.needs_input_grad
+        need = ctx.needs_input_grad[2:]   # per parameter
+        g_out = g_out.contiguous()
 
         def wgrad(inputs, grad_outputs, need_w, need_b):
             if not (need_w or need_b):
@@ -331,12 +335,21 @@ class ResidualNetHidden(torch.autograd.Function):
                 return (grad_outputs.t() @ inputs if need_w else None), (grad_outputs.sum(0) if need_b else None)
             return (got[0] if need_w else None), got[1]
 
-        out = [g_x if need[0] else None]
-        out += wgrad(x, grads[0] if nb else g_hidden, need[1], need[2])
+        tail = ()
+        if ctx.with_final:
+            x, saved, bwd_w, hidden, w_f = ctx.saved_tensors
+            tail = wgrad(hidden, g_out, need[-2], need[-1])
+            g_hidden = g_out @ w_f            # the final Linear's input gradient: one library GEMM
+        else:
+            x, saved, bwd_w = ctx.saved_tensors
+            g_hidden = g_out
+        g_x, grads = ops.resnet_hidden_backward(g_hidden, bwd_w, saved, x.shape[1])
+        out = [g_x if ctx.needs_input_grad[0] else None, None]
+        out += wgrad(x, grads[0] if nb else g_hidden, need[0], need[1])
         for k in range(nb):
-            out += wgrad(saved[2 * k], grads[2 * k + 1], need[3 + 4 * k], need[4 + 4 * k])
-            out += wgrad(saved[2 * k + 1], grads[2 * k + 2] if k + 1 < nb else g_hidden, need[5 + 4 * k], need[6 + 4 * k])
-        return tuple(out)
+            out += wgrad(saved[2 * k], grads[2 * k + 1], need[2 + 4 * k], need[3 + 4 * k])
+            out += wgrad(saved[2 * k + 1], grads[2 * k + 2] if k + 1 < nb else g_hidden, need[4 + 4 * k], need[5 + 4 * k])
+        return tuple(out) + tuple(tail)
 
 
 def _dense_rows(t, n, width):

@@ -44,6 +44,10 @@ struct TrainArgs {
                          // = `grad_outputs` of the Linear in front of it), grads[2 k + 1] = g_a_k
     int64_t batch;       // multiple of 128
     int di, num_blocks, num_stages;
+    // forward, optional: the net's final Linear (128 -> out_features) behind the blocks, its stages appended to the stream
+    const float* fbias;  // accumulator-order bias, 32 per tile (zeros past out_features)
+    float* params;       // [B, out_features]
+    int out_features, final_tiles;
 };
 
 // accumulator tile <-> rows of a [B, 128] array: element (row, 32 t + 8 q4 + 4 half + i) = acc[4 q4 + i]
@@ -200,6 +204,26 @@ __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_forward_kernel(const 
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) store_tile<false>(a.out, row, t, half, hs[t]);
+        // ---- optionally the final Linear: params = W_f h + b_f, one 32-column tile of the [B, out_features] result at a
+        //      time (h as pieces from here on: converted once, the fp32 tiles are dead)
+        if (a.final_tiles > 0) {
+            bf16x8 ph[8], pm[8], pl[8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                tile_to_pieces<false>(hs[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
+            const float* fb = a.fbias + half * 16;
+            const int out_features = a.out_features;
+            for (int t = 0; t < a.final_tiles; ++t) {
+                f32x16 acc;
+                load_bias_tile(acc, fb + t * 32);
+                gemm_tile<false>(acc, ph, pm, pl, sm, lane);
+                float* pp = a.params + row * out_features + 32 * t + 4 * half;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    if (32 * t + 8 * q4 + 4 * half < out_features)
+                        *reinterpret_cast<vec4f*>(pp + 8 * q4) = vec4f{acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]};
+            }
+        }
         // drain (stores, and the two stages requested past this row block) before the next block's loads
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -333,10 +357,13 @@ struct PackArgs {
     const float* w_in;
     const float* b_in;
     const float* blk[3][4];   // W_0, b_0, W_1, b_1 per block
+    const float* w_f;         // optional final Linear [out_features, 128] and its bias
+    const float* b_f;
     __bf16* fwd;
     float* fwd_bias;
+    float* final_bias;        // [final_tiles * 32], accumulator order, zeros past out_features
     __bf16* bwd;
-    int di, nb, init_ks;
+    int di, nb, init_ks, out_features, final_tiles;
 };
 
 // input feature consumed at (k-step ks, lane-half hf, element j) when the GEMM's input is the previous layer's
@@ -348,7 +375,8 @@ __device__ __forceinline__ int acc_col(int ks, int hf, int j) {
 __global__ void __launch_bounds__(kBlock) pack_resnet_hidden_kernel(const PackArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;   // grp: tile t (k-major) or k4 (tile-major)
     const int hf = lane >> 5, i = lane & 31;
-    const int n_fwd = a.init_ks + 16 * a.nb, n_bwd_k = 16 * a.nb, tiles_x = (a.di + 31) >> 5;
+    const int n_hid = a.init_ks + 16 * a.nb, n_fwd = n_hid + 2 * a.final_tiles, n_bwd_k = 16 * a.nb,
+              tiles_x = (a.di + 31) >> 5;
     int s = blockIdx.x;
     if (s == n_fwd + n_bwd_k + 2 * tiles_x) {   // the biases, accumulator order: [tile][half][q] = b[32 tile + 8 (q / 4) + 4 half + q % 4]
         for (int e = tid; e < 128 * (1 + 2 * a.nb); e += kBlock) {
@@ -357,12 +385,24 @@ __global__ void __launch_bounds__(kBlock) pack_resnet_hidden_kernel(const PackAr
             const int tile = r >> 5, half = (r >> 4) & 1, q = r & 15;
             a.fwd_bias[e] = b[32 * tile + 8 * (q >> 2) + 4 * half + (q & 3)];
         }
+        for (int e = tid; e < 32 * a.final_tiles; e += kBlock) {
+            const int tile = e >> 5, half = (e >> 4) & 1, q = e & 15;
+            const int src = 32 * tile + 8 * (q >> 2) + 4 * half + (q & 3);
+            a.final_bias[e] = src < a.out_features ? a.b_f[src] : 0.0f;
+        }
         return;
     }
     float v[8];
     __bf16* dst;
     bool tile_major = false;
-    if (s < n_fwd) {
+    if (s >= n_hid && s < n_fwd) {   // the final Linear, tile-major: [piece][k4][lane], rows past out_features are zero
+        dst = a.fwd + (size_t)s * 6144;
+        const int s2 = s - n_hid, tile = s2 >> 1, hs = s2 & 1;
+        const int row = 32 * tile + i, ks = 4 * hs + grp;
+        tile_major = true;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = row < a.out_features ? a.w_f[row * 128 + acc_col(ks, hf, j)] : 0.0f;
+    } else if (s < n_hid) {
         dst = a.fwd + (size_t)s * 6144;
         const int row = 32 * grp + i;
         if (s < a.init_ks) {   // initial layer: k = ks*16 + hf*8 + j, zeros past d_i
@@ -429,13 +469,17 @@ static dim3 train_grid(int64_t batch) {
 using namespace nfa;
 
 extern "C" int nfa_resnet_hidden_forward_f32(const float* identity_inputs, const void* weights_packed,
-                                             const float* bias_packed, float* saved, float* hidden, int64_t batch,
-                                             int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
-                                             void* stream) {
+                                             const float* bias_packed, float* saved, float* hidden,
+                                             const float* final_bias_packed, float* params, int32_t out_features,
+                                             int64_t batch, int32_t num_identity, int32_t hidden_features,
+                                             int32_t num_blocks, void* stream) {
     const int rc = check_train(batch, num_identity, hidden_features, num_blocks);
     if (rc != NFA_OK) return rc;
+    if (out_features < 0) return NFA_ERR_INVALID_ARGUMENT;
+    if ((out_features & 3) != 0 || out_features > 32 * 1024) return NFA_ERR_UNSUPPORTED;
     if (batch == 0) return NFA_OK;
-    if (!identity_inputs || !weights_packed || !bias_packed || !hidden || (num_blocks > 0 && !saved))
+    if (!identity_inputs || !weights_packed || !bias_packed || !hidden || (num_blocks > 0 && !saved) ||
+        (out_features > 0 && (!final_bias_packed || !params)))
         return NFA_ERR_INVALID_ARGUMENT;
     TrainArgs a;
     a.x = identity_inputs;
@@ -448,7 +492,11 @@ extern "C" int nfa_resnet_hidden_forward_f32(const float* identity_inputs, const
     a.di = num_identity;
     a.num_blocks = num_blocks;
     const int init_ks = num_identity > 32 ? 4 : 2;
-    a.num_stages = init_ks + 16 * num_blocks;
+    a.fbias = final_bias_packed;
+    a.params = params;
+    a.out_features = out_features;
+    a.final_tiles = (out_features + 31) / 32;
+    a.num_stages = init_ks + 16 * num_blocks + 2 * a.final_tiles;
     const size_t lds = (size_t)kRing * kStageVec4 * 16;
     hipStream_t st = (hipStream_t)stream;
     if (init_ks == 2) hipLaunchKernelGGL(resnet_hidden_forward_kernel<2>, train_grid(batch), dim3(kBlock), lds, st, a);
@@ -476,6 +524,10 @@ extern "C" int nfa_resnet_hidden_backward_f32(const float* grad_hidden, const vo
     a.batch = batch;
     a.di = num_identity;
     a.num_blocks = num_blocks;
+    a.fbias = nullptr;
+    a.params = nullptr;
+    a.out_features = 0;
+    a.final_tiles = 0;
     a.num_stages = 16 * num_blocks + 2 * ((num_identity + 31) / 32);
     const size_t lds = (size_t)kRing * kStageVec4 * 16;
     hipStream_t st = (hipStream_t)stream;
@@ -491,13 +543,17 @@ extern "C" int nfa_resnet_hidden_backward_f32(const float* grad_hidden, const vo
 }
 
 extern "C" int nfa_pack_resnet_hidden_train_f32(const float* initial_weight, const float* initial_bias,
-                                                const float* const* block_params, int32_t num_identity,
+                                                const float* const* block_params, const float* final_weight,
+                                                const float* final_bias, int32_t out_features, int32_t num_identity,
                                                 int32_t hidden_features, int32_t num_blocks, void* forward_stages,
-                                                float* forward_bias, void* backward_stages, void* stream) {
+                                                float* forward_bias, float* final_bias_packed, void* backward_stages,
+                                                void* stream) {
     const int rc = check_train(128, num_identity, hidden_features, num_blocks);
     if (rc != NFA_OK) return rc;
+    if (out_features < 0) return NFA_ERR_INVALID_ARGUMENT;
+    if ((out_features & 3) != 0 || out_features > 32 * 1024) return NFA_ERR_UNSUPPORTED;
     if (!initial_weight || !initial_bias || !forward_stages || !forward_bias || !backward_stages ||
-        (num_blocks > 0 && !block_params))
+        (num_blocks > 0 && !block_params) || (out_features > 0 && (!final_weight || !final_bias || !final_bias_packed)))
         return NFA_ERR_INVALID_ARGUMENT;
     PackArgs a;
     a.w_in = initial_weight;
@@ -513,7 +569,12 @@ extern "C" int nfa_pack_resnet_hidden_train_f32(const float* initial_weight, con
     a.di = num_identity;
     a.nb = num_blocks;
     a.init_ks = num_identity > 32 ? 4 : 2;
-    const int stages = a.init_ks + 32 * num_blocks + 2 * ((num_identity + 31) / 32);
+    a.w_f = final_weight;
+    a.b_f = final_bias;
+    a.final_bias = final_bias_packed;
+    a.out_features = out_features;
+    a.final_tiles = (out_features + 31) / 32;
+    const int stages = a.init_ks + 32 * num_blocks + 2 * a.final_tiles + 2 * ((num_identity + 31) / 32);
     hipLaunchKernelGGL(pack_resnet_hidden_kernel, dim3(stages + 1), dim3(kBlock), 0, (hipStream_t)stream, a);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;

@@ -1094,42 +1094,52 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False,
 _TRAIN_ORDER_K = {}
 
 
-def pack_resnet_hidden_train(w_in, b_in, block_params):
+def pack_resnet_hidden_train(w_in, b_in, block_params, final=None):
     """K14's packer as ONE launch (nfa_pack_resnet_hidden_train_f32): fp32 parameters on the device -> (forward stages,
-    forward biases, backward stages), the bytes of `pack_resnet_hidden_train_reference`.  Runs inside every training
-    step (the weights change), including captured ones."""
+    forward biases, backward stages, final-layer bias or None), the bytes of `pack_resnet_hidden_train_reference`.
+    `final` = (weight [out, 128], bias [out]) appends the net's final Linear to the forward stream.  Runs inside
+    every training step (the weights change), including captured ones."""
     dev = w_in.device
     if not (w_in.is_cuda and w_in.dtype == torch.float32):
-        return pack_resnet_hidden_train_reference(w_in, b_in, block_params)
+        return pack_resnet_hidden_train_reference(w_in, b_in, block_params, final)
     di, nb = w_in.shape[1], len(block_params)
     init_ks = 4 if di > 32 else 2
     tiles = (di + 31) // 32
     flat = [w_in.detach().contiguous(), b_in.detach().contiguous()]
     for group in block_params:
         flat += [t.detach().contiguous() for t in group]
-    for t in flat:
+    fin = [t.detach().contiguous() for t in final] if final is not None else []
+    for t in flat + fin:
         if t.dtype != torch.float32 or not t.is_cuda:
             raise TypeError("nflows_amd: the conditioner's parameters must be float32 tensors on the device")
-    fwd = torch.empty(init_ks + 16 * nb, 6144, dtype=torch.bfloat16, device=dev)
+    out = fin[0].shape[0] if fin else 0
+    ft = (out + 31) // 32
+    fwd = torch.empty(init_ks + 16 * nb + 2 * ft, 6144, dtype=torch.bfloat16, device=dev)
     bias = torch.empty(128 * (1 + 2 * nb), dtype=torch.float32, device=dev)
+    fbias = torch.empty(32 * ft, dtype=torch.float32, device=dev) if fin else None
     bwd = torch.empty(16 * nb + 2 * tiles, 6144, dtype=torch.bfloat16, device=dev)
     ptrs = (ctypes.c_void_p * max(1, 4 * nb))(*[t.data_ptr() for t in flat[2:]])
     with torch.cuda.device(dev):
-        rc = N.load().nfa_pack_resnet_hidden_train_f32(N.ptr(flat[0]), N.ptr(flat[1]), ptrs, di, w_in.shape[0], nb,
-                                                       N.ptr(fwd), N.ptr(bias), N.ptr(bwd), N.stream_handle(dev))
+        rc = N.load().nfa_pack_resnet_hidden_train_f32(
+            N.ptr(flat[0]), N.ptr(flat[1]), ptrs, N.ptr(fin[0]) if fin else None, N.ptr(fin[1]) if fin else None, out,
+            di, w_in.shape[0], nb, N.ptr(fwd), N.ptr(bias), N.ptr(fbias), N.ptr(bwd), N.stream_handle(dev))
     N.check(rc)
-    return fwd, bias, bwd
+    return fwd, bias, bwd, fbias
 
 
-def pack_resnet_hidden_train_reference(w_in, b_in, block_params):
-    """Packs the hidden part of a ResidualNet for K14 (nfa_resnet_hidden_forward_f32 / _backward_f32; layout in
-    include/nflows_amd.h).  w_in [128, d_i], b_in [128], block_params = [(W_0, b_0, W_1, b_1), ...] (all 128 wide).
-    Returns (forward stages, forward biases, backward stages): the forward stream is the initial layer + W_0, W_1
-    per block (pack_resnet_conditioner's hidden layers), the backward stream W_1^T, W_0^T per block from the last
-    to the first, then W_in^T tile-major (rows padded to 32)."""
+_TRAIN_ORDER_K = {}
+
+
+def pack_resnet_hidden_train_reference(w_in, b_in, block_params, final=None):
+    """Packs the hidden part of a ResidualNet (and optionally its final Linear) for K14
+    (nfa_resnet_hidden_forward_f32 / _backward_f32; layout in include/nflows_amd.h) with tensor operations.
+    w_in [128, d_i], b_in [128], block_params = [(W_0, b_0, W_1, b_1), ...] (all 128 wide), final = (W_f [out, 128],
+    b_f [out]).  Returns (forward stages, forward biases, backward stages, final bias or None): the forward stream
+    is the initial layer + W_0, W_1 per block (pack_resnet_conditioner's hidden layers) + W_f tile-major, the backward
+    stream W_1^T, W_0^T per block from the last to the first, then W_in^T tile-major (rows padded to 32)."""
     dev = w_in.device
-    order_k = _TRAIN_ORDER_K.get(dev)   # (cached per device: this packer runs inside captured training steps,
-    if order_k is None:                 #  where a host-to-device copy is not allowed)
+    order_k = _TRAIN_ORDER_K.get(dev)
+    if order_k is None:
         order_k = _TRAIN_ORDER_K[dev] = _k8_column_order().to(dev)
 
     def pieces(w):
@@ -1137,6 +1147,12 @@ def pack_resnet_hidden_train_reference(w_in, b_in, block_params):
 
     def kmajor(w):   # [128, 128], columns in accumulator order: (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j)
         return pieces(w.index_select(1, order_k)).view(3, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1)
+
+    def tilemajor(w, rows):   # [rows, 128] -> rows padded to 32 per tile, two stages per tile
+        tiles = (rows + 31) // 32
+        wp = torch.cat((w, w.new_zeros(tiles * 32 - rows, 128)), dim=0).index_select(1, order_k)
+        # (p, tile, i, hs, k4, hf, j) -> (tile, hs, p, k4, hf, i, j)
+        return pieces(wp).view(3, tiles, 32, 2, 4, 2, 8).permute(1, 3, 0, 4, 5, 2, 6).reshape(tiles * 2, -1)
 
     di = w_in.shape[1]
     init_ks = 4 if di > 32 else 2
@@ -1150,11 +1166,14 @@ def pack_resnet_hidden_train_reference(w_in, b_in, block_params):
         fwd += [kmajor(w0), kmajor(w1)]
         bias += [_bias_accumulator_order(b0.detach().float()), _bias_accumulator_order(b1.detach().float())]
         bwd = [kmajor(w1.t()), kmajor(w0.t())] + bwd        # last block first
-    tiles = (di + 31) // 32
-    wt = torch.cat((wi.t(), wi.new_zeros(tiles * 32 - di, 128)), dim=0).index_select(1, order_k)   # [tiles*32, 128]
-    # (p, tile, i, hs, k4, hf, j) -> (tile, hs, p, k4, hf, i, j): two stages per tile
-    bwd.append(pieces(wt).view(3, tiles, 32, 2, 4, 2, 8).permute(1, 3, 0, 4, 5, 2, 6).reshape(tiles * 2, -1))
-    return torch.cat(fwd, dim=0).contiguous(), torch.cat(bias).contiguous(), torch.cat(bwd, dim=0).contiguous()
+    bwd.append(tilemajor(wi.t(), di))
+    fbias = None
+    if final is not None:
+        wf, bf = final[0].detach().float(), final[1].detach().float()
+        out = wf.shape[0]
+        fwd.append(tilemajor(wf, out))
+        fbias = _bias_accumulator_order(torch.cat((bf, bf.new_zeros((out + 31) // 32 * 32 - out)))).contiguous()
+    return torch.cat(fwd, dim=0).contiguous(), torch.cat(bias).contiguous(), torch.cat(bwd, dim=0).contiguous(), fbias
 
 
 def resnet_hidden_train_supported(batch, num_identity, hidden_features, num_blocks):
@@ -1163,20 +1182,24 @@ def resnet_hidden_train_supported(batch, num_identity, hidden_features, num_bloc
             and batch > 0 and batch % 128 == 0)
 
 
-def resnet_hidden_forward(x, fwd_stages, fwd_bias, num_blocks):
-    """K14 forward: identity features [B, d_i] -> (hidden [B, 128], saved [2 num_blocks, B, 128])."""
+def resnet_hidden_forward(x, fwd_stages, fwd_bias, num_blocks, final_bias=None, out_features=0):
+    """K14 forward: identity features [B, d_i] -> (hidden [B, 128], saved [2 num_blocks, B, 128], params [B, out]
+    or None -- the conditioner's output when the final Linear was packed into the stream)."""
     N.require_device_f32("inputs", x, 2)
     x = x.detach().contiguous()
     B, di = x.shape
     dev = x.device
     hidden = torch.empty(B, 128, dtype=torch.float32, device=dev)
     saved = torch.empty(2 * num_blocks, B, 128, dtype=torch.float32, device=dev)
+    params = torch.empty(B, out_features, dtype=torch.float32, device=dev) if final_bias is not None else None
     with torch.cuda.device(dev):
         rc = N.load().nfa_resnet_hidden_forward_f32(N.ptr(x), N.ptr(fwd_stages), N.ptr(fwd_bias),
-                                                    N.ptr(saved) if num_blocks else None, N.ptr(hidden), B, di, 128,
+                                                    N.ptr(saved) if num_blocks else None, N.ptr(hidden),
+                                                    N.ptr(final_bias), N.ptr(params),
+                                                    out_features if final_bias is not None else 0, B, di, 128,
                                                     num_blocks, N.stream_handle(dev))
     N.check(rc)
-    return hidden, saved
+    return hidden, saved, params
 
 
 def resnet_hidden_backward(grad_hidden, bwd_stages, saved, num_identity):

@@ -216,11 +216,13 @@ def test_training_stream_packer_kernel_matches_the_tensor_reference(di, nb):
     net = _k14_net(128, di, nb)
     blocks = [(b.linear_layers[0].weight, b.linear_layers[0].bias, b.linear_layers[1].weight, b.linear_layers[1].bias)
               for b in net.blocks]
-    got = ops.pack_resnet_hidden_train(net.initial_layer.weight, net.initial_layer.bias, blocks)
-    ref = ops.pack_resnet_hidden_train_reference(net.initial_layer.weight, net.initial_layer.bias, blocks)
-    assert got[0].shape == ref[0].shape and torch.equal(got[0].view(torch.int16), ref[0].view(torch.int16))
-    assert torch.equal(got[1], ref[1])
-    assert got[2].shape == ref[2].shape and torch.equal(got[2].view(torch.int16), ref[2].view(torch.int16))
+    for final in (None, (net.final_layer.weight, net.final_layer.bias)):   # (40 outputs: one full tile + 8 rows)
+        got = ops.pack_resnet_hidden_train(net.initial_layer.weight, net.initial_layer.bias, blocks, final)
+        ref = ops.pack_resnet_hidden_train_reference(net.initial_layer.weight, net.initial_layer.bias, blocks, final)
+        assert got[0].shape == ref[0].shape and torch.equal(got[0].view(torch.int16), ref[0].view(torch.int16))
+        assert torch.equal(got[1], ref[1])
+        assert got[2].shape == ref[2].shape and torch.equal(got[2].view(torch.int16), ref[2].view(torch.int16))
+        assert (got[3] is None and ref[3] is None) if final is None else torch.equal(got[3], ref[3])
 
 
 @pytest.mark.parametrize("B,di,nb", [(65536, 32, 2), (16384, 64, 3), (2048, 8, 1)])
@@ -237,12 +239,18 @@ def test_fused_conditioner_training_kernels_at_size(B, di, nb):
     blocks = [(b.linear_layers[0].weight, b.linear_layers[0].bias, b.linear_layers[1].weight, b.linear_layers[1].bias)
               for b in net.blocks]
     with torch.no_grad():
-        fw, fb, bw = ops.pack_resnet_hidden_train(net.initial_layer.weight, net.initial_layer.bias, blocks)
-        hid, saved = ops.resnet_hidden_forward(x, fw, fb, nb)
+        final = (net.final_layer.weight, net.final_layer.bias)
+        fw, fb, bw, fbias = ops.pack_resnet_hidden_train(net.initial_layer.weight, net.initial_layer.bias, blocks, final)
+        hid, saved, out = ops.resnet_hidden_forward(x, fw, fb, nb, fbias, 40)
         gx, grads = ops.resnet_hidden_backward(g, bw, saved, di)
-        hid2, saved2 = ops.resnet_hidden_forward(x, fw, fb, nb)
+        hid2, saved2, out2 = ops.resnet_hidden_forward(x, fw, fb, nb, fbias, 40)
         gx2, grads2 = ops.resnet_hidden_backward(g, bw, saved2, di)
         assert torch.equal(hid, hid2) and torch.equal(saved, saved2) and torch.equal(gx, gx2) and torch.equal(grads, grads2)
+        assert torch.equal(out, out2)
+        # the hidden-only form of the kernel (no final Linear in the stream) gives the same hidden activations
+        fw0, fb0, _, _ = ops.pack_resnet_hidden_train(net.initial_layer.weight, net.initial_layer.bias, blocks)
+        hid0, saved0, none = ops.resnet_hidden_forward(x, fw0, fb0, nb)
+        assert none is None and torch.equal(hid0, hid) and torch.equal(saved0, saved)
         d = lambda t: t.detach().double()
         h = torch.nn.functional.linear(d(x), d(net.initial_layer.weight), d(net.initial_layer.bias))
         truth_saved = []
@@ -257,6 +265,7 @@ def test_fused_conditioner_training_kernels_at_size(B, di, nb):
             assert err <= 2e-6 * scale, "%s: %.3e (scale %.2e)" % (name, err, scale)
 
         close("hidden", hid, h)
+        close("conditioner output", out, torch.nn.functional.linear(h, d(net.final_layer.weight), d(net.final_layer.bias)))
         for i in range(2 * nb):
             close("saved[%d]" % i, saved[i], truth_saved[i])
         gh = d(g)

@@ -1198,11 +1198,27 @@ def test_training_kernel_streams():
         net = ResidualNet(di, 8 * 23, 128, num_blocks=nb)
         blocks = [(b.linear_layers[0].weight, b.linear_layers[0].bias, b.linear_layers[1].weight, b.linear_layers[1].bias)
                   for b in net.blocks]
-        fwd, bias, bwd = ops.pack_resnet_hidden_train_reference(net.initial_layer.weight, net.initial_layer.bias, blocks)
+        fwd, bias, bwd, none = ops.pack_resnet_hidden_train_reference(net.initial_layer.weight, net.initial_layer.bias, blocks)
         ref_w, ref_b = ops.pack_resnet_conditioner(net, 8, 23)
         n_fwd = (4 if di > 32 else 2) + 16 * nb
+        assert none is None
         assert fwd.shape == (n_fwd, 6144) and torch.equal(fwd.view(torch.int16), ref_w[:n_fwd].view(torch.int16))
         assert torch.equal(bias, ref_b[:128 + 256 * nb])
+        # with the final Linear appended (out = 184 -> 6 tiles, the last with 24 rows): the hidden stages are unchanged,
+        # the tail decodes to W_f with zero rows behind it, the bias is in accumulator order
+        fwd2, bias2, bwd2, fbias = ops.pack_resnet_hidden_train_reference(
+            net.initial_layer.weight, net.initial_layer.bias, blocks, (net.final_layer.weight, net.final_layer.bias))
+        out = net.final_layer.out_features
+        ft = (out + 31) // 32
+        assert torch.equal(fwd2[:n_fwd].view(torch.int16), fwd.view(torch.int16)) and fwd2.shape[0] == n_fwd + 2 * ft
+        assert torch.equal(bias2, bias) and torch.equal(bwd2.view(torch.int16), bwd.view(torch.int16))
+        tailf = fwd2[n_fwd:].view(ft, 2, 3, 4, 2, 32, 8).float().sum(dim=2)    # (tile, hs, k4, hf, i, j)
+        mf = tailf.permute(0, 4, 1, 2, 3, 5).reshape(ft * 32, 128)
+        wf = torch.empty_like(mf)
+        wf[:, ops._k8_column_order()] = mf
+        assert torch.allclose(wf[:out], net.final_layer.weight.detach(), rtol=0, atol=1e-8) and not wf[out:].any()
+        bpad = torch.cat((net.final_layer.bias.detach(), torch.zeros(ft * 32 - out)))
+        assert torch.equal(fbias.view(ft, 2, 4, 4).permute(0, 2, 1, 3).reshape(-1), bpad)
         order_k = ops._k8_column_order()
 
         def decode_kmajor(stages):   # [8, 6144] -> the [128, 128] matrix whose pieces they hold

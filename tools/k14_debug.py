@@ -20,7 +20,7 @@ with torch.no_grad():
 x = torch.randn(B, di, device=dev)
 g = torch.randn(B, 128, device=dev)
 blocks = [(b.linear_layers[0].weight, b.linear_layers[0].bias, b.linear_layers[1].weight, b.linear_layers[1].bias) for b in net.blocks]
-fw, fb, bw = ops.pack_resnet_hidden_train(net.initial_layer.weight, net.initial_layer.bias, blocks)
+fw, fb, bw, _ = ops.pack_resnet_hidden_train(net.initial_layer.weight, net.initial_layer.bias, blocks)
 with torch.no_grad():
     # eager reference
     h = torch.nn.functional.linear(x, net.initial_layer.weight, net.initial_layer.bias)
@@ -54,7 +54,7 @@ with torch.no_grad():
 
     for rep in range(reps):
         print("--- repeat", rep)
-        hid, saved = ops.resnet_hidden_forward(x, fw, fb, nb)
+        hid, saved, _ = ops.resnet_hidden_forward(x, fw, fb, nb)
         report("hidden", hid, ref_h)
         for i in range(2 * nb):
             report("saved[%d]" % i, saved[i], ref_saved[i])

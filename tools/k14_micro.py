@@ -42,13 +42,17 @@ def timeit(fn, reps=20, inner=5):
 
 with torch.no_grad():
     pack = lambda: ops.pack_resnet_hidden_train(net.initial_layer.weight, net.initial_layer.bias, blocks)
-    fw, fb, bw = pack()
-    hid, saved = ops.resnet_hidden_forward(x, fw, fb, 2)
+    fw, fb, bw, _ = pack()
+    hid, saved, _ = ops.resnet_hidden_forward(x, fw, fb, 2)
     gx, grads = ops.resnet_hidden_backward(g, bw, saved, 32)
     print("rows %d" % B)
     print("packer (torch ops)            %8.1f us" % timeit(pack))
     print("K14 forward kernel            %8.1f us" % timeit(lambda: ops.resnet_hidden_forward(x, fw, fb, 2)))
     print("K14 backward kernel           %8.1f us" % timeit(lambda: ops.resnet_hidden_backward(g, bw, saved, 32)))
+    fw2, fb2, _, fbias = ops.pack_resnet_hidden_train(net.initial_layer.weight, net.initial_layer.bias, blocks,
+                                                      (net.final_layer.weight, net.final_layer.bias))
+    print("K14 forward + final Linear    %8.1f us" % timeit(lambda: ops.resnet_hidden_forward(x, fw2, fb2, 2, fbias, 736)))
+    print("library final Linear 128->736 %8.1f us" % timeit(lambda: torch.nn.functional.linear(hid, net.final_layer.weight, net.final_layer.bias)))
 
     def wgrads():
         ops.linear_wgrad(x, grads[0])
