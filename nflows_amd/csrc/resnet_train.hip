@@ -67,16 +67,61 @@ __device__ __forceinline__ void store_tile(float* base, int64_t row, int t, int 
     }
 }
 
-__device__ __forceinline__ void start_stream(WeightStream& sm, const vec4f* w, float* lds, int num_stages, int tid) {
+// The weight stream of these kernels: bf16x3_gemm.hpp's ring (12 KB stages, three LDS-DMA requests per stage and
+// wave-quarter, counted waits) with the depth as a build parameter -- kTrainRing slots, kTrainAhead = kTrainRing - 1
+// stages requested ahead of the one being consumed.  Stage c lives in slot c % kTrainRing; at k-step c stage
+// c + kTrainAhead is requested into the slot stage c - 1 left (every wave passed the previous advance's barrier), and
+// the advance waits until only the requests of stages c + 2 .. c + kTrainAhead may be pending:
+// vmcnt(3 (kTrainAhead - 1)).  Measured: six slots (five stages in flight, 72 KB of LDS) against K8 / K11's three
+// change nothing (forward 78.9 vs 77.4 us, with the final Linear 153.0 vs 147.9, backward 90.6 vs 90.2 at 65 536 rows;
+// same results): like K8s' small batches the stage time (1.85 us for 0.32 us of MFMA per wave) is the SIMDs' own --
+// fragment reads, conversions and the per-stage barrier between two co-resident waves --, not the fill rate.
+#ifndef NFA_K14_RING
+#define NFA_K14_RING 3
+#endif
+constexpr int kTrainRing = NFA_K14_RING, kTrainAhead = kTrainRing - 1;
+static_assert(kTrainRing >= 3 && 3 * (kTrainAhead - 1) <= 63, "vmcnt is a 6-bit count");
+
+struct TrainStream {
+    const vec4f* w;
+    vec4f* ring;
+    int slot;        // ring slot of the stage being consumed
+    int fetch;       // stage index (in the stream) to request next
+    int num_stages;
+    int tid;
+};
+
+__device__ __forceinline__ void tstream_request_into(TrainStream& sm, int dst_slot) {
+    const char* stage = reinterpret_cast<const char*>(sm.w) + (size_t)sm.fetch * (kStageVec4 * 16);
+    const int wave = __builtin_amdgcn_readfirstlane(sm.tid >> 6);
+    char* slot = reinterpret_cast<char*>(sm.ring) + dst_slot * (kStageVec4 * 16) + wave * (kWave * 16);
+    const unsigned lane_off = (unsigned)sm.tid * 16u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)((stage + i * kBlock * 16) + lane_off),
+            (__attribute__((address_space(3))) void*)(slot + i * kBlock * 16), 16, 0, 0);
+    sm.fetch = (sm.fetch + 1 == sm.num_stages) ? 0 : sm.fetch + 1;
+}
+
+__device__ __forceinline__ void tstream_request(TrainStream& sm) {
+    const int dst = sm.slot + kTrainAhead;
+    tstream_request_into(sm, dst >= kTrainRing ? dst - kTrainRing : dst);
+}
+
+__device__ __forceinline__ void tstream_advance(TrainStream& sm) {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(3 * (kTrainAhead - 1)) : "memory");
+    sm.slot = (sm.slot + 1 == kTrainRing) ? 0 : sm.slot + 1;
+}
+
+__device__ __forceinline__ void start_stream(TrainStream& sm, const vec4f* w, float* lds, int num_stages, int tid) {
     sm.w = w;
     sm.ring = reinterpret_cast<vec4f*>(lds);
-    sm.slot = 1;
     sm.fetch = 0;
     sm.num_stages = num_stages;
     sm.tid = tid;
-    stream_request(sm);  // stage 0 -> slot 0
-    sm.slot = 2;
-    stream_request(sm);  // stage 1 -> slot 1
+#pragma unroll
+    for (int s = 0; s < kTrainAhead; ++s) tstream_request_into(sm, s);   // stages 0 .. kTrainAhead - 1
     sm.slot = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -85,8 +130,8 @@ __device__ __forceinline__ void start_stream(WeightStream& sm, const vec4f* w, f
 // one k-step of a k-major GEMM (bf16x3_gemm.hpp: gemm_kmajor): out^T[128 x 32 samples] += W[128 x 16] x act^T,
 // stage = [4 tiles][3 pieces][64 lanes] x 16 bytes
 __device__ __forceinline__ void kstep(f32x16 (&acc)[4], const bf16x8& bh, const bf16x8& bm, const bf16x8& bl,
-                                      WeightStream& sm, int lane) {
-    stream_request(sm);
+                                      TrainStream& sm, int lane) {
+    tstream_request(sm);
     const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -95,14 +140,14 @@ __device__ __forceinline__ void kstep(f32x16 (&acc)[4], const bf16x8& bh, const 
         const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(t * 3 + 2) * 64]);
         NFA_MFMA6(acc[t], ah, am, al, bh, bm, bl);
     }
-    stream_advance(sm);
+    tstream_advance(sm);
 }
 
 // k-major GEMM over 128 inputs given as four fp32 accumulator tiles (ReLU'd first when RELU): tile t becomes the
 // pieces of k-steps 2 t and 2 t + 1 right before they are consumed, so that no 96-register piece array is ever
 // live next to the accumulators (K8 keeps the residual stream as pieces; here it stays in fp32 tiles)
 template <bool RELU>
-__device__ __forceinline__ void gemm_from_tiles(f32x16 (&acc)[4], const f32x16 (&src)[4], WeightStream& sm, int lane) {
+__device__ __forceinline__ void gemm_from_tiles(f32x16 (&acc)[4], const f32x16 (&src)[4], TrainStream& sm, int lane) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         bf16x8 h0, m0, l0, h1, m1, l1;
@@ -114,10 +159,10 @@ __device__ __forceinline__ void gemm_from_tiles(f32x16 (&acc)[4], const f32x16 (
 
 // one 32-row output tile of a 128-wide layer from fp32 input tiles (bf16x3_gemm.hpp: gemm_tile): two stages of
 // [3 pieces][4 k-steps][64 lanes] x 16 bytes
-__device__ __forceinline__ void gemm_tile_from_tiles(f32x16& acc, const f32x16 (&src)[4], WeightStream& sm, int lane) {
+__device__ __forceinline__ void gemm_tile_from_tiles(f32x16& acc, const f32x16 (&src)[4], TrainStream& sm, int lane) {
 #pragma unroll
     for (int hs = 0; hs < 2; ++hs) {
-        stream_request(sm);
+        tstream_request(sm);
         const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -132,7 +177,26 @@ __device__ __forceinline__ void gemm_tile_from_tiles(f32x16& acc, const f32x16 (
                 NFA_MFMA6(acc, ah, am, al, bh[hk], bm[hk], bl[hk]);
             }
         }
-        stream_advance(sm);
+        tstream_advance(sm);
+    }
+}
+
+// bf16x3_gemm.hpp's gemm_tile on this file's stream: one 32-row output tile from the 128 inputs given as pieces
+__device__ __forceinline__ void gemm_tile_pieces(f32x16& acc, const bf16x8 (&ph)[8], const bf16x8 (&pm)[8],
+                                                 const bf16x8 (&pl)[8], TrainStream& sm, int lane) {
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs) {
+        tstream_request(sm);
+        const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const int ks = hs * 4 + k4;
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(0 * 4 + k4) * 64]);
+            const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(1 * 4 + k4) * 64]);
+            const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(2 * 4 + k4) * 64]);
+            NFA_MFMA6(acc, ah, am, al, ph[ks], pm[ks], pl[ks]);
+        }
+        tstream_advance(sm);
     }
 }
 
@@ -141,7 +205,7 @@ __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_forward_kernel(const 
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    WeightStream sm;
+    TrainStream sm;
     start_stream(sm, a.w, lds_dyn, a.num_stages, tid);
     const int64_t num_quads = a.batch >> 7;
     const int64_t plane = a.batch * 128;   // one saved activation
@@ -216,7 +280,7 @@ __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_forward_kernel(const 
             for (int t = 0; t < a.final_tiles; ++t) {
                 f32x16 acc;
                 load_bias_tile(acc, fb + t * 32);
-                gemm_tile<false>(acc, ph, pm, pl, sm, lane);
+                gemm_tile_pieces(acc, ph, pm, pl, sm, lane);
                 float* pp = a.params + row * out_features + 32 * t + 4 * half;
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4)
@@ -277,7 +341,7 @@ __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_backward_kernel(const
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    WeightStream sm;
+    TrainStream sm;
     start_stream(sm, a.w, lds_dyn, a.num_stages, tid);
     const int64_t num_quads = a.batch >> 7;
     const int64_t plane = a.batch * 128;
@@ -497,10 +561,15 @@ extern "C" int nfa_resnet_hidden_forward_f32(const float* identity_inputs, const
     a.out_features = out_features;
     a.final_tiles = (out_features + 31) / 32;
     a.num_stages = init_ks + 16 * num_blocks + 2 * a.final_tiles;
-    const size_t lds = (size_t)kRing * kStageVec4 * 16;
+    const size_t lds = (size_t)kTrainRing * kStageVec4 * 16;
     hipStream_t st = (hipStream_t)stream;
-    if (init_ks == 2) hipLaunchKernelGGL(resnet_hidden_forward_kernel<2>, train_grid(batch), dim3(kBlock), lds, st, a);
-    else hipLaunchKernelGGL(resnet_hidden_forward_kernel<4>, train_grid(batch), dim3(kBlock), lds, st, a);
+    void (*kern)(const TrainArgs) = init_ks == 2 ? resnet_hidden_forward_kernel<2> : resnet_hidden_forward_kernel<4>;
+    if (lds > 64 * 1024) {
+        static unsigned long long raised[2] = {};   // device masks (raise_dynamic_lds)
+        const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[init_ks == 2 ? 0 : 1], (int)lds);
+        if (rc_lds != NFA_OK) return rc_lds;
+    }
+    hipLaunchKernelGGL(kern, train_grid(batch), dim3(kBlock), lds, st, a);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
 }
@@ -529,15 +598,18 @@ extern "C" int nfa_resnet_hidden_backward_f32(const float* grad_hidden, const vo
     a.out_features = 0;
     a.final_tiles = 0;
     a.num_stages = 16 * num_blocks + 2 * ((num_identity + 31) / 32);
-    const size_t lds = (size_t)kRing * kStageVec4 * 16;
+    const size_t lds = (size_t)kTrainRing * kStageVec4 * 16;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid = train_grid(batch), block(kBlock);
-    switch (num_blocks) {
-        case 0: hipLaunchKernelGGL(resnet_hidden_backward_kernel<0>, grid, block, lds, st, a); break;
-        case 1: hipLaunchKernelGGL(resnet_hidden_backward_kernel<1>, grid, block, lds, st, a); break;
-        case 2: hipLaunchKernelGGL(resnet_hidden_backward_kernel<2>, grid, block, lds, st, a); break;
-        default: hipLaunchKernelGGL(resnet_hidden_backward_kernel<3>, grid, block, lds, st, a); break;
+    void (*kern)(const TrainArgs) = num_blocks == 0 ? resnet_hidden_backward_kernel<0>
+                                    : num_blocks == 1 ? resnet_hidden_backward_kernel<1>
+                                    : num_blocks == 2 ? resnet_hidden_backward_kernel<2> : resnet_hidden_backward_kernel<3>;
+    if (lds > 64 * 1024) {
+        static unsigned long long raised[4] = {};   // device masks (raise_dynamic_lds)
+        const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[num_blocks], (int)lds);
+        if (rc_lds != NFA_OK) return rc_lds;
     }
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
 }
