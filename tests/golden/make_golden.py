@@ -529,42 +529,48 @@ def grad_cases():
     layer("g_aff_general", "general", 12, torchutils.create_alternating_binary_mask(12, even=True), 40)
     layer("g_additive", "additive", 7, torch.tensor([1, 0, 1, 1, 0, 0, 1]), 21)
 
-    # whole flow: -mean log_prob, gradients w.r.t. every parameter and the inputs
-    torch.manual_seed(0)
-    L, D, K, H, B = 3, 8, 4, 16, 48
-    layers = []
-    for i in range(L):
-        layers.append(RandomPermutation(D))
-        layers.append(PiecewiseRationalQuadraticCouplingTransform(
-            mask=torchutils.create_alternating_binary_mask(D, even=(i % 2 == 0)),
-            transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=H, num_blocks=2),
-            num_bins=K, tails="linear", tail_bound=3.0))
-    flow = Flow(CompositeTransform(layers), StandardNormal([D]))
-    with torch.no_grad():
-        for p_name, p in flow.named_parameters():
-            if "final_layer" in p_name:
-                p.mul_(6.0)
-            elif "linear_layers.1" in p_name:
-                p.mul_(40.0)
-    xg = torch.randn(B, D, generator=torch.Generator().manual_seed(77))
-    name = "g_flow_nsf"
-    state_to_np(name, flow, out)
-    out[name + "/x"] = npy(xg)
-    for dt_name, dtp in (("", torch.float32), ("64", torch.float64)):
-        f = flow.double() if dtp is torch.float64 else flow.float()
-        f.zero_grad()
-        xin = xg.to(dtp).clone().requires_grad_(True)
-        loss = -f.log_prob(xin).mean()
-        loss.backward()
-        out[name + "/loss" + dt_name] = npy(loss)
-        out[name + "/gx" + dt_name] = npy(xin.grad)
-        for p_name, p in f.named_parameters():
-            out[name + "/grad" + dt_name + "/" + p_name] = npy(p.grad)
-    flow.float()
-    meta.append((name, "flow", repr(dict(kind="rq_nsf", L=L, D=D, K=K, H=H, B=B, tail_bound=3.0))))
+    # whole flow: -mean log_prob, gradients w.r.t. every parameter and the inputs.  Two instances: hidden width 16
+    # (the layer-by-layer kernels), and -- drawn after it -- hidden width 128 on a batch of 128 rows (the shape the
+    # conditioner's training kernels K14 take: this is their pin to the reference's own autograd)
+    for name, seed, (L, D, K, H, B) in (("g_flow_nsf", 0, (3, 8, 4, 16, 48)), ("g_flow_nsf_h128", 1, (2, 16, 8, 128, 128))):
+        flow_grad_case(out, meta, name, seed, L, D, K, H, B)
     out["meta"] = np.array(meta, dtype=object).astype(str)
     np.savez_compressed(os.path.join(HERE, "grads.npz"), **out)
     print("grads:", len(meta), "cases")
+
+
+def flow_grad_case(out, meta, name, seed, L, D, K, H, B):
+    if True:
+        torch.manual_seed(seed)
+        layers = []
+        for i in range(L):
+            layers.append(RandomPermutation(D))
+            layers.append(PiecewiseRationalQuadraticCouplingTransform(
+                mask=torchutils.create_alternating_binary_mask(D, even=(i % 2 == 0)),
+                transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=H, num_blocks=2),
+                num_bins=K, tails="linear", tail_bound=3.0))
+        flow = Flow(CompositeTransform(layers), StandardNormal([D]))
+        with torch.no_grad():
+            for p_name, p in flow.named_parameters():
+                if "final_layer" in p_name:
+                    p.mul_(6.0)
+                elif "linear_layers.1" in p_name:
+                    p.mul_(40.0)
+        xg = torch.randn(B, D, generator=torch.Generator().manual_seed(77 + seed))
+        state_to_np(name, flow, out)
+        out[name + "/x"] = npy(xg)
+        for dt_name, dtp in (("", torch.float32), ("64", torch.float64)):
+            f = flow.double() if dtp is torch.float64 else flow.float()
+            f.zero_grad()
+            xin = xg.to(dtp).clone().requires_grad_(True)
+            loss = -f.log_prob(xin).mean()
+            loss.backward()
+            out[name + "/loss" + dt_name] = npy(loss)
+            out[name + "/gx" + dt_name] = npy(xin.grad)
+            for p_name, p in f.named_parameters():
+                out[name + "/grad" + dt_name + "/" + p_name] = npy(p.grad)
+        flow.float()
+        meta.append((name, "flow", repr(dict(kind="rq_nsf", L=L, D=D, K=K, H=H, B=B, tail_bound=3.0))))
 
 
 def sibling_spline_cases():

@@ -278,9 +278,14 @@ def test_fused_conditioner_training_kernels_at_size(B, di, nb):
         close("grad_inputs", gx, gh @ d(net.initial_layer.weight))
 
 
-def test_flow_training_gradients_match_reference(G):
-    from nflows_amd import configs
-    name = "g_flow_nsf"
+@pytest.mark.parametrize("name", ["g_flow_nsf", "g_flow_nsf_h128"])
+def test_flow_training_gradients_match_reference(G, name, monkeypatch):
+    """loss = -mean log_prob through a whole flow: loss, input gradient and every parameter gradient against the
+    REFERENCE's autograd (grads.npz).  The H = 128 instance on 128 rows runs the conditioners through K14 (counted)."""
+    from nflows_amd import configs, ops
+    calls = []
+    real = ops.resnet_hidden_forward
+    monkeypatch.setattr(ops, "resnet_hidden_forward", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     cfg = parse_kwargs(dict((n, c) for n, _, c in G["meta"])[name])
     flow = configs.rq_nsf_flow(cfg["L"], cfg["D"], cfg["K"], cfg["H"], 2, cfg["tail_bound"])
     prefix = name + "/sd/"
@@ -296,6 +301,7 @@ def test_flow_training_gradients_match_reference(G):
         close_to_truth(x.grad, G[name + "/gx"], G[name + "/gx64"], "flow gx")
         for p_name, p in flow.named_parameters():
             close_to_truth(p.grad, G[name + "/grad/" + p_name], G[name + "/grad64/" + p_name], "flow " + p_name)
+    assert len(calls) == (2 * cfg["L"] if cfg["H"] == 128 else 0)
 
 
 @pytest.mark.parametrize("B,D,K,tails,inverse,perm", [
