@@ -255,9 +255,9 @@ extern "C" int nfa_linear_wgrad_f32(const float* inputs, const float* grad_outpu
         const dim3 grid((unsigned)(p.blocks_o * p.blocks_i), (unsigned)p.ksplit);
         if (p.variant == 0) {
             constexpr size_t lds = (size_t)kWgRing * kWgRows * (128 + 128) * 4;
-            static const hipError_t attr = hipFuncSetAttribute((const void*)wgrad_partial_kernel<2, 2, 2, 2>,
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            NFA_HIP_CHECK(attr);
+            static unsigned long long raised = 0;   // device mask (raise_dynamic_lds: the opt-in is per device)
+            const int rc_lds = raise_dynamic_lds((const void*)wgrad_partial_kernel<2, 2, 2, 2>, &raised, (int)lds);
+            if (rc_lds != NFA_OK) return rc_lds;
             hipLaunchKernelGGL((wgrad_partial_kernel<2, 2, 2, 2>), grid, dim3(kBlock), lds, st, a);
         } else {
             constexpr size_t lds = (size_t)kWgRing * kWgRows * (128 + 32) * 4;
