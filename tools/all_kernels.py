@@ -182,6 +182,41 @@ with torch.no_grad():
         rows.append("| K8s `k8s::rqs_resnet_f16s_kernel` (%s), run of 32 layers | the whole BASELINE transform, B=%d | %.1f | %.0f TFLOP/s f16 (peak 2 500); %.1f M samples/s |"
                     % ("eight waves x 16 rows" if rows_s > 16384 else "four waves x 16 rows", rows_s, us,
                        32 * 3 * 2.0 * rows_s * macs / us / 1e6, rows_s / us))
+    # K14: the conditioner under training (forward with the Linears' inputs saved, chain of input gradients, packer)
+    from nflows_amd.nn.nets import ResidualNet
+    net14 = ResidualNet(32, 736, 128, num_blocks=2).to(dev)
+    blocks14 = [(b.linear_layers[0].weight, b.linear_layers[0].bias, b.linear_layers[1].weight, b.linear_layers[1].bias)
+                for b in net14.blocks]
+    final14 = (net14.final_layer.weight, net14.final_layer.bias)
+    pack14 = lambda: ops.pack_resnet_hidden_train(net14.initial_layer.weight, net14.initial_layer.bias, blocks14, final14)
+    fw14, fb14, bw14, fbias14 = pack14()
+    x14 = torch.randn(B, 32, device=dev, generator=g)
+    g14 = torch.randn(B, 128, device=dev, generator=g)
+    _, saved14, _ = ops.resnet_hidden_forward(x14, fw14, fb14, 2, fbias14, 736)
+    fl14 = 2.0 * B * (32 * 128 + 4 * 128 * 128)
+    us = timeit(lambda: ops.resnet_hidden_forward(x14, fw14, fb14, 2, fbias14, 736))
+    rows.append("| K14 `resnet_hidden_forward_kernel<2>` | ResidualNet conditioner under training (32 -> 128 x 2 blocks -> 736), forward + the Linears' inputs saved, B=65536 | %.1f | %.0f TFLOP/s bf16 (6 products; peak 2 500) |"
+                % (us, 6 * (fl14 + 2.0 * B * 128 * 736) / us / 1e6))
+    us = timeit(lambda: ops.resnet_hidden_backward(g14, bw14, saved14, 32))
+    rows.append("| K14 `resnet_hidden_backward_kernel<2>` | chain of input gradients through the two blocks and the initial layer, B=65536 | %.1f | %.0f TFLOP/s bf16 (6 products) |"
+                % (us, 6 * fl14 / us / 1e6))
+    rows.append("| K14 `pack_resnet_hidden_kernel` | both weight streams of one conditioner (80 + 34 stages) | %.1f | launch-bound |" % timeit(pack14))
+    # K5d: the float64 functional and its gradient (correctness path)
+    x64 = xe.double()
+    uw64, uh64, ud64 = r[:, :K].double().contiguous(), r[:, K:2 * K].double().contiguous(), r[:, 2 * K:].double().contiguous()
+    y64, l64 = torch.empty_like(x64), torch.empty_like(x64)
+    s64 = ops.make_rqs_spec(K, "linear", tail_bound=3.0)
+    rows.append("| K5d `rqs_elementwise_f64_kernel` | RQ functional in float64, 2.1 M elements, K=8 | %.1f | %.0f GB/s (the correctness path) |"
+                % ((lambda u: (u, 8 * N * (P + 3) / u / 1e3))(timeit(lambda: NA.check(lib.nfa_rqs_elementwise_f64(
+                    NA.ptr(x64), NA.ptr(uw64), K, NA.ptr(uh64), K, NA.ptr(ud64), K - 1, K - 1, NA.ptr(y64), NA.ptr(l64),
+                    NA.ptr(ops._status_word(x64.device)), N, ctypes.byref(s64), 0, NA.stream_handle(x64.device)))))))
+    gy64, gl64 = gy1.double(), gl1.double()
+    gx64, guw64, guh64, gud64 = torch.empty_like(x64), torch.empty_like(uw64), torch.empty_like(uh64), torch.empty_like(ud64)
+    rows.append("| K5d-backward `rqs_elementwise_backward_f64_kernel` | its gradient, same elements | %.1f | %.0f GB/s |"
+                % ((lambda u: (u, 8 * N * (2 * P + 4) / u / 1e3))(timeit(lambda: NA.check(lib.nfa_rqs_elementwise_backward_f64(
+                    NA.ptr(x64), NA.ptr(uw64), K, NA.ptr(uh64), K, NA.ptr(ud64), K - 1, K - 1, NA.ptr(gy64), NA.ptr(gl64),
+                    NA.ptr(gx64), NA.ptr(guw64), NA.ptr(guh64), NA.ptr(gud64), N, ctypes.byref(s64), 0,
+                    NA.stream_handle(x64.device)))))))
     nflows_amd.check_status()
 
 print("# Kernel table (round 3, 1 x MI355X; `python tools/all_kernels.py`)\n")
