@@ -563,8 +563,9 @@ int nfa_rqs_elementwise_backward_f64(const double *inputs, const double *unnorma
  *   backward stream: per block from the LAST to the first W_1^T, W_0^T (8 k-major stages each, columns in accumulator
  *   order), then W_in^T as ceil(num_identity / 32) tile-major tiles of two stages (rows zero-padded to 32).
  * fp32-accurate products on the bf16 matrix pipe (three pieces per operand, six products), full fp32 range.
- * NFA_ERR_UNSUPPORTED (the caller keeps the eager path): hidden_features != 128, num_blocks > 3, num_identity > 64
- * or not a multiple of 4, batch not a multiple of 128.
+ * NFA_ERR_UNSUPPORTED (the caller keeps the eager path): hidden_features != 128 for the two kernels (the packer takes
+ * 4 <= hidden_features <= 128 in multiples of 4 and pads), num_blocks > 3, num_identity > 64 or not a multiple of 4,
+ * batch not a multiple of 128.
  */
 /* Optionally the forward kernel also applies the net's final Linear (128 -> out_features, out_features % 4 == 0;
  * resnet.py:99) behind the blocks: its tile-major stages (ceil(out_features / 32) tiles of two stages, rows
@@ -572,8 +573,10 @@ int nfa_rqs_elementwise_backward_f64(const double *inputs, const double *unnorma
  * order (32 per tile), params [batch, out_features] receives the conditioner's output; out_features = 0: hidden only.
  *
  * The packer of the two streams (one launch; the weights change with every optimiser step).  block_params: HOST array
- * of 4 num_blocks device pointers W_0, b_0, W_1, b_1 (fp32, contiguous, [128, 128] / [128]); initial_weight
- * [128, num_identity]; final_weight [out_features, 128] / final_bias (NULL, 0: none).  forward_stages:
+ * of 4 num_blocks device pointers W_0, b_0, W_1, b_1 (fp32, contiguous, [H, H] / [H]); initial_weight
+ * [H, num_identity]; final_weight [out_features, H] / final_bias (NULL, 0: none); H = hidden_features of the packer
+ * call, 4 <= H <= 128, H % 4 == 0: a narrower net is zero-padded into the 128-wide streams (its surplus units stay 0
+ * through both passes; the caller pads / slices the [.., 128] arrays at the two ends).  forward_stages:
  * ((num_identity > 32 ? 4 : 2) + 16 num_blocks + 2 ceil(out_features / 32)) x 12288 bytes, forward_bias:
  * 128 (1 + 2 num_blocks) floats, final_bias_packed: 32 ceil(out_features / 32) floats, backward_stages:
  * (16 num_blocks + 2 ceil(num_identity / 32)) x 12288 bytes. */

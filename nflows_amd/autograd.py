@@ -312,43 +312,53 @@ class ResidualNetHidden(torch.autograd.Function):
         final = params[-2:] if with_final else None
         fwd_w, fwd_b, bwd_w, fbias = ops.pack_resnet_hidden_train(params[0], params[1], blocks, final)
         hidden, saved, out = ops.resnet_hidden_forward(x, fwd_w, fwd_b, nb, fbias, final[0].shape[0] if with_final else 0)
-        ctx.nb, ctx.with_final = nb, with_final
+        ctx.nb, ctx.with_final, ctx.H = nb, with_final, params[0].shape[0]   # (H < 128: the arrays are zero-padded to 128)
         if with_final:
             ctx.save_for_backward(x.detach().contiguous(), saved, bwd_w, hidden, final[0])
             return out
         ctx.save_for_backward(x.detach().contiguous(), saved, bwd_w)
-        return hidden
+        return hidden if ctx.H == 128 else hidden[:, :ctx.H]
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_out):
         from . import ops
-        nb = ctx.nb
+        nb, H = ctx.nb, ctx.H
         need = ctx.needs_input_grad[2:]   # per parameter
         g_out = g_out.contiguous()
 
-        def wgrad(inputs, grad_outputs, need_w, need_b):
+        def wgrad(inputs, grad_outputs, need_w, need_b, rows=None, cols=None):
+            """(grad_weight, grad_bias) of a Linear; rows / cols: the net's own width inside the 128-wide arrays"""
             if not (need_w or need_b):
                 return None, None
             got = ops.linear_wgrad(inputs, grad_outputs, need_bias=need_b)
             if got is None:   # widths K10 does not take
-                return (grad_outputs.t() @ inputs if need_w else None), (grad_outputs.sum(0) if need_b else None)
-            return (got[0] if need_w else None), got[1]
+                got = (grad_outputs.t() @ inputs if need_w else None), (grad_outputs.sum(0) if need_b else None)
+            g_w, g_b = (got[0] if need_w else None), got[1]
+            if g_w is not None and (rows is not None or cols is not None):
+                g_w = g_w[:rows, :cols].contiguous()
+            if g_b is not None and rows is not None:
+                g_b = g_b[:rows].contiguous()
+            return g_w, g_b
 
+        narrow = H if H != 128 else None
         tail = ()
         if ctx.with_final:
             x, saved, bwd_w, hidden, w_f = ctx.saved_tensors
-            tail = wgrad(hidden, g_out, need[-2], need[-1])
+            tail = wgrad(hidden, g_out, need[-2], need[-1], cols=narrow)
             g_hidden = g_out @ w_f            # the final Linear's input gradient: one library GEMM
         else:
             x, saved, bwd_w = ctx.saved_tensors
             g_hidden = g_out
+        if narrow is not None:
+            g_hidden = torch.nn.functional.pad(g_hidden, (0, 128 - H))
         g_x, grads = ops.resnet_hidden_backward(g_hidden, bwd_w, saved, x.shape[1])
         out = [g_x if ctx.needs_input_grad[0] else None, None]
-        out += wgrad(x, grads[0] if nb else g_hidden, need[0], need[1])
+        out += wgrad(x, grads[0] if nb else g_hidden, need[0], need[1], rows=narrow)
         for k in range(nb):
-            out += wgrad(saved[2 * k], grads[2 * k + 1], need[2 + 4 * k], need[3 + 4 * k])
-            out += wgrad(saved[2 * k + 1], grads[2 * k + 2] if k + 1 < nb else g_hidden, need[4 + 4 * k], need[5 + 4 * k])
+            out += wgrad(saved[2 * k], grads[2 * k + 1], need[2 + 4 * k], need[3 + 4 * k], rows=narrow, cols=narrow)
+            out += wgrad(saved[2 * k + 1], grads[2 * k + 2] if k + 1 < nb else g_hidden, need[4 + 4 * k], need[5 + 4 * k],
+                         rows=narrow, cols=narrow)
         return tuple(out) + tuple(tail)
 
 

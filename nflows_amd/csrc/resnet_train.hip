@@ -25,8 +25,9 @@
 // wait more conservative (requests complete in order among themselves; `vmcnt(3)` with stores outstanding still
 // implies that at most the three youngest requests are pending).
 //
-// Restrictions (the host keeps the eager path otherwise): hidden width 128, ReLU, no context / batch norm / active
-// dropout, at most three blocks, d_i <= 64 and d_i % 4 == 0, batch % 128 == 0.
+// Restrictions (the host keeps the eager path otherwise): hidden width <= 128 and a multiple of 4 (narrower nets are
+// zero-padded into the 128-wide streams by the packer), ReLU, no context / batch norm / active dropout, at most three
+// blocks, d_i <= 64 and d_i % 4 == 0, batch % 128 == 0.
 
 #include "bf16x3_gemm.hpp"
 
@@ -428,6 +429,7 @@ struct PackArgs {
     float* final_bias;        // [final_tiles * 32], accumulator order, zeros past out_features
     __bf16* bwd;
     int di, nb, init_ks, out_features, final_tiles;
+    int H;   // the net's hidden width (<= 128): rows / columns past it are zero in the streams (units that stay 0)
 };
 
 // input feature consumed at (k-step ks, lane-half hf, element j) when the GEMM's input is the previous layer's
@@ -447,7 +449,8 @@ __global__ void __launch_bounds__(kBlock) pack_resnet_hidden_kernel(const PackAr
             const int v = e >> 7, r = e & 127;
             const float* b = v == 0 ? a.b_in : a.blk[(v - 1) >> 1][((v - 1) & 1) ? 3 : 1];
             const int tile = r >> 5, half = (r >> 4) & 1, q = r & 15;
-            a.fwd_bias[e] = b[32 * tile + 8 * (q >> 2) + 4 * half + (q & 3)];
+            const int src = 32 * tile + 8 * (q >> 2) + 4 * half + (q & 3);
+            a.fwd_bias[e] = src < a.H ? b[src] : 0.0f;
         }
         for (int e = tid; e < 32 * a.final_tiles; e += kBlock) {
             const int tile = e >> 5, half = (e >> 4) & 1, q = e & 15;
@@ -465,7 +468,10 @@ __global__ void __launch_bounds__(kBlock) pack_resnet_hidden_kernel(const PackAr
         const int row = 32 * tile + i, ks = 4 * hs + grp;
         tile_major = true;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = row < a.out_features ? a.w_f[row * 128 + acc_col(ks, hf, j)] : 0.0f;
+        for (int j = 0; j < 8; ++j) {
+            const int col = acc_col(ks, hf, j);
+            v[j] = (row < a.out_features && col < a.H) ? a.w_f[row * a.H + col] : 0.0f;
+        }
     } else if (s < n_hid) {
         dst = a.fwd + (size_t)s * 6144;
         const int row = 32 * grp + i;
@@ -473,13 +479,16 @@ __global__ void __launch_bounds__(kBlock) pack_resnet_hidden_kernel(const PackAr
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int col = s * 16 + hf * 8 + j;
-                v[j] = col < a.di ? a.w_in[row * a.di + col] : 0.0f;
+                v[j] = (col < a.di && row < a.H) ? a.w_in[row * a.di + col] : 0.0f;
             }
         } else {
             const int lin = (s - a.init_ks) >> 3, ks = (s - a.init_ks) & 7;
             const float* w = a.blk[lin >> 1][(lin & 1) ? 2 : 0];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = w[row * 128 + acc_col(ks, hf, j)];
+            for (int j = 0; j < 8; ++j) {
+                const int col = acc_col(ks, hf, j);
+                v[j] = (row < a.H && col < a.H) ? w[row * a.H + col] : 0.0f;
+            }
         }
     } else if (s < n_fwd + n_bwd_k) {   // W_1^T, W_0^T per block, last block first
         s -= n_fwd;
@@ -488,7 +497,10 @@ __global__ void __launch_bounds__(kBlock) pack_resnet_hidden_kernel(const PackAr
         const float* w = a.blk[a.nb - 1 - (lin >> 1)][(lin & 1) ? 0 : 2];
         const int row = 32 * grp + i;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = w[acc_col(ks, hf, j) * 128 + row];
+        for (int j = 0; j < 8; ++j) {
+            const int col = acc_col(ks, hf, j);
+            v[j] = (row < a.H && col < a.H) ? w[col * a.H + row] : 0.0f;
+        }
     } else {                            // W_in^T, tile-major: [piece][k4][lane], rows past d_i are zero
         s -= n_fwd;
         dst = a.bwd + (size_t)s * 6144;
@@ -496,7 +508,10 @@ __global__ void __launch_bounds__(kBlock) pack_resnet_hidden_kernel(const PackAr
         const int row = 32 * tile + i, ks = 4 * hs + grp;
         tile_major = true;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = row < a.di ? a.w_in[acc_col(ks, hf, j) * a.di + row] : 0.0f;
+        for (int j = 0; j < 8; ++j) {
+            const int col = acc_col(ks, hf, j);
+            v[j] = (row < a.di && col < a.H) ? a.w_in[col * a.di + row] : 0.0f;
+        }
     }
     bf16x2 hh[4], mm[4], ll[4];
 #pragma unroll
@@ -515,10 +530,15 @@ __global__ void __launch_bounds__(kBlock) pack_resnet_hidden_kernel(const PackAr
     }
 }
 
-static int check_train(int64_t batch, int32_t num_identity, int32_t hidden_features, int32_t num_blocks) {
+// `hidden_features` is the width of the arrays the two kernels see (always 128); the packer takes narrower nets and
+// pads them into the 128-wide streams (units past the net's width have zero weights and biases on both sides:
+// relu(0) = 0 forward, zero masks backward)
+static int check_train(int64_t batch, int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
+                       bool packer = false) {
     if (batch < 0 || num_identity < 1 || num_blocks < 0) return NFA_ERR_INVALID_ARGUMENT;
-    if (hidden_features != 128 || num_identity > 64 || (num_identity & 3) != 0 || (batch & 127) != 0 || num_blocks > 3)
+    if (packer ? (hidden_features < 4 || hidden_features > 128 || (hidden_features & 3) != 0) : hidden_features != 128)
         return NFA_ERR_UNSUPPORTED;
+    if (num_identity > 64 || (num_identity & 3) != 0 || (batch & 127) != 0 || num_blocks > 3) return NFA_ERR_UNSUPPORTED;
     return NFA_OK;
 }
 
@@ -620,7 +640,7 @@ extern "C" int nfa_pack_resnet_hidden_train_f32(const float* initial_weight, con
                                                 int32_t hidden_features, int32_t num_blocks, void* forward_stages,
                                                 float* forward_bias, float* final_bias_packed, void* backward_stages,
                                                 void* stream) {
-    const int rc = check_train(128, num_identity, hidden_features, num_blocks);
+    const int rc = check_train(0, num_identity, hidden_features, num_blocks, true);
     if (rc != NFA_OK) return rc;
     if (out_features < 0) return NFA_ERR_INVALID_ARGUMENT;
     if ((out_features & 3) != 0 || out_features > 32 * 1024) return NFA_ERR_UNSUPPORTED;
@@ -641,6 +661,7 @@ extern "C" int nfa_pack_resnet_hidden_train_f32(const float* initial_weight, con
     a.di = num_identity;
     a.nb = num_blocks;
     a.init_ks = num_identity > 32 ? 4 : 2;
+    a.H = hidden_features;
     a.w_f = final_weight;
     a.b_f = final_bias;
     a.final_bias = final_bias_packed;

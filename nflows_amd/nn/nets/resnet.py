@@ -175,7 +175,7 @@ class _Net(nn.Module):
     def forward(self, inputs, context=None):
         final = self.final_layer
         if (self._fused_training(inputs, context) and type(final) is nn.Linear and final.bias is not None
-                and final.out_features % 4 == 0 and final.in_features == 128):
+                and final.out_features % 4 == 0 and final.in_features == self.hidden_features):
             # the whole conditioner's forward pass in one kernel (K14 with the final Linear appended)
             from ... import autograd as AG
             return AG.ResidualNetHidden.apply(inputs, True, *self._hidden_parameters(), final.weight, final.bias)

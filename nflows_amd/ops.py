@@ -1156,20 +1156,20 @@ def pack_resnet_hidden_train_reference(w_in, b_in, block_params, final=None):
 
     di = w_in.shape[1]
     init_ks = 4 if di > 32 else 2
-    wi = w_in.detach().float()
+    wi = _pad_to(w_in.detach().float(), rows=128)          # (hidden widths below 128: zero rows / columns)
     wi_padded = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)   # k = ks*16 + hf*8 + j
     fwd = [pieces(wi_padded).view(3, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks, -1)]
-    bias = [_bias_accumulator_order(b_in.detach().float())]
+    bias = [_bias_accumulator_order(_pad_to(b_in.detach().float(), rows=128))]
     bwd = []
     for w0, b0, w1, b1 in block_params:
-        w0, w1 = w0.detach().float(), w1.detach().float()
+        w0, w1 = (_pad_to(w.detach().float(), rows=128, cols=128) for w in (w0, w1))
         fwd += [kmajor(w0), kmajor(w1)]
-        bias += [_bias_accumulator_order(b0.detach().float()), _bias_accumulator_order(b1.detach().float())]
+        bias += [_bias_accumulator_order(_pad_to(b.detach().float(), rows=128)) for b in (b0, b1)]
         bwd = [kmajor(w1.t()), kmajor(w0.t())] + bwd        # last block first
     bwd.append(tilemajor(wi.t(), di))
     fbias = None
     if final is not None:
-        wf, bf = final[0].detach().float(), final[1].detach().float()
+        wf, bf = _pad_to(final[0].detach().float(), cols=128), final[1].detach().float()
         out = wf.shape[0]
         fwd.append(tilemajor(wf, out))
         fbias = _bias_accumulator_order(torch.cat((bf, bf.new_zeros((out + 31) // 32 * 32 - out)))).contiguous()
@@ -1177,9 +1177,9 @@ def pack_resnet_hidden_train_reference(w_in, b_in, block_params, final=None):
 
 
 def resnet_hidden_train_supported(batch, num_identity, hidden_features, num_blocks):
-    """The shapes K14 takes (everything else keeps the eager path)."""
-    return (hidden_features == 128 and 1 <= num_identity <= 64 and num_identity % 4 == 0 and 0 <= num_blocks <= 3
-            and batch > 0 and batch % 128 == 0)
+    """The shapes K14 takes (everything else keeps the eager path); hidden widths below 128 are zero-padded."""
+    return (4 <= hidden_features <= 128 and hidden_features % 4 == 0 and 1 <= num_identity <= 64
+            and num_identity % 4 == 0 and 0 <= num_blocks <= 3 and batch > 0 and batch % 128 == 0)
 
 
 def resnet_hidden_forward(x, fwd_stages, fwd_bias, num_blocks, final_bias=None, out_features=0):

@@ -156,10 +156,10 @@ def test_float64_flow_trains_on_the_device():
             (x, uw, uh, ud), eps=1e-6, atol=1e-6, rtol=1e-5)
 
 
-def _k14_net(B, di, nb):
+def _k14_net(B, di, nb, H=128):
     from nflows_amd.nn.nets import ResidualNet
     torch.manual_seed(B + di + nb)
-    net = ResidualNet(di, 40, 128, num_blocks=nb).to(DEV)
+    net = ResidualNet(di, 40, H, num_blocks=nb).to(DEV)
     with torch.no_grad():   # (blocks end in U(-1e-3, 1e-3) layers: scale them up so that every path carries signal)
         for b in net.blocks:
             b.linear_layers[1].weight.mul_(60.0)
@@ -167,17 +167,18 @@ def _k14_net(B, di, nb):
     return net
 
 
-@pytest.mark.parametrize("B,di,nb", [(256, 32, 2), (384, 12, 1), (128, 64, 3), (1024, 36, 0)])
-def test_fused_conditioner_training_kernels(B, di, nb, monkeypatch):
+@pytest.mark.parametrize("B,di,nb,H", [(256, 32, 2, 128), (384, 12, 1, 128), (128, 64, 3, 128), (1024, 36, 0, 128),
+                                       (256, 8, 2, 64), (128, 20, 1, 52)])
+def test_fused_conditioner_training_kernels(B, di, nb, H, monkeypatch):
     """K14 (nfa_resnet_hidden_forward_f32 / _backward_f32 + K10) against autograd through the eager modules with the
     same weights: the net's output, the input gradient and every parameter gradient, judged against float64 -- at
     most 4 x the eager fp32 path's own error + 1e-6 of the scale.  One / two / four k-steps of identity features,
-    zero to three blocks.  (Small batches: an activation within rounding of zero flips a ReLU mask and moves a
+    zero to three blocks, hidden widths below 128 (zero-padded into the kernels' 128).  (Small batches: an activation within rounding of zero flips a ReLU mask and moves a
     gradient by O(weight) in ANY fp32 implementation; the large-batch test below pins the masks instead.)"""
     import copy
     from nflows_amd import ops
     from nflows_amd.nn.nets import ResidualNet
-    net = _k14_net(B, di, nb)
+    net = _k14_net(B, di, nb, H)
     x = torch.randn(B, di, device=DEV, requires_grad=True)
     w = torch.randn(B, 40, device=DEV)
     calls = []
@@ -203,17 +204,24 @@ def test_fused_conditioner_training_kernels(B, di, nb, monkeypatch):
     truth = [out64.detach(), x64.grad] + [p.grad for p in net64.parameters()]
     names = ["output", "grad_inputs"] + [n for n, _ in net.named_parameters()]
     for name, a, b, t in zip(names, got, eager, truth):
+        assert a.shape == t.shape, name
         scale = 1.0 + t.abs().max().item()
         e_a, e_b = (a.double() - t).abs().max().item(), (b.double() - t).abs().max().item()
         assert e_a <= 4 * e_b + 1e-6 * scale, "%s: fused %.3e, eager %.3e, scale %.2e" % (name, e_a, e_b, scale)
+    # the hidden-only form (what the fused spline kernels' callers use under autograd) has the net's own width
+    monkeypatch.setattr(ResidualNet, "fuse_training", True)
+    hidden = net.hidden(x)
+    assert hidden.shape == (B, H) and hidden.requires_grad and len(calls) == 2
+    monkeypatch.setattr(ResidualNet, "fuse_training", False)
+    assert (hidden - net.hidden(x)).abs().max().item() <= 1e-5 * (1 + hidden.abs().max().item())
 
 
-@pytest.mark.parametrize("di,nb", [(32, 2), (12, 1), (64, 3), (36, 0)])
-def test_training_stream_packer_kernel_matches_the_tensor_reference(di, nb):
+@pytest.mark.parametrize("di,nb,H", [(32, 2, 128), (12, 1, 128), (64, 3, 128), (36, 0, 128), (8, 2, 64), (20, 1, 52)])
+def test_training_stream_packer_kernel_matches_the_tensor_reference(di, nb, H):
     """nfa_pack_resnet_hidden_train_f32 (one launch inside every training step) writes the bytes of the
     tensor-operation packer (whose layout the CPU suite decodes: tests/test_host_logic.py)."""
     from nflows_amd import ops
-    net = _k14_net(128, di, nb)
+    net = _k14_net(128, di, nb, H)
     blocks = [(b.linear_layers[0].weight, b.linear_layers[0].bias, b.linear_layers[1].weight, b.linear_layers[1].bias)
               for b in net.blocks]
     for final in (None, (net.final_layer.weight, net.final_layer.bias)):   # (40 outputs: one full tile + 8 rows)

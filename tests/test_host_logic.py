@@ -1241,3 +1241,15 @@ def test_training_kernel_streams():
         wt[:, order_k] = m
         assert torch.allclose(wt[:di], net.initial_layer.weight.detach().t(), rtol=0, atol=1e-8)
         assert not wt[di:].any() and bwd.shape[0] == 16 * nb + 2 * tiles
+    # a narrower net (52 hidden units) is zero-padded into the same 128-wide streams
+    net = ResidualNet(12, 40, 52, num_blocks=1)
+    b = net.blocks[0]
+    fwd, bias, bwd, fbias = ops.pack_resnet_hidden_train_reference(
+        net.initial_layer.weight, net.initial_layer.bias,
+        [(b.linear_layers[0].weight, b.linear_layers[0].bias, b.linear_layers[1].weight, b.linear_layers[1].bias)],
+        (net.final_layer.weight, net.final_layer.bias))
+    assert fwd.shape == (2 + 16 + 4, 6144) and bwd.shape == (16 + 2, 6144) and bias.shape == (384,) and fbias.shape == (64,)
+    w1t = decode_kmajor(bwd[:8])
+    assert torch.allclose(w1t[:52, :52], b.linear_layers[1].weight.detach().t(), atol=1e-8) and not w1t[52:].any() \
+        and not w1t[:, 52:].any()
+    assert not bias.view(3, 4, 2, 4, 4).permute(0, 1, 3, 2, 4).reshape(3, 128)[:, 52:].any()
