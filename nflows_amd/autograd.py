@@ -310,7 +310,13 @@ class ResidualNetHidden(torch.autograd.Function):
         nb = (len(hidden_params) - 2) // 4
         blocks = [hidden_params[2 + 4 * k: 6 + 4 * k] for k in range(nb)]
         final = params[-2:] if with_final else None
-        fwd_w, fwd_b, bwd_w, fbias = ops.pack_resnet_hidden_train(params[0], params[1], blocks, final)
+        w_in = params[0]
+        ctx.di = x.shape[1]
+        if ctx.di % 4:   # identity features in multiples of four: zero columns on both sides (tabular D = 6, 21, 43, 63 ...)
+            pad = 4 - ctx.di % 4
+            x = torch.nn.functional.pad(x.detach(), (0, pad))
+            w_in = torch.nn.functional.pad(w_in.detach(), (0, pad))
+        fwd_w, fwd_b, bwd_w, fbias = ops.pack_resnet_hidden_train(w_in, params[1], blocks, final)
         hidden, saved, out = ops.resnet_hidden_forward(x, fwd_w, fwd_b, nb, fbias, final[0].shape[0] if with_final else 0)
         ctx.nb, ctx.with_final, ctx.H = nb, with_final, params[0].shape[0]   # (H < 128: the arrays are zero-padded to 128)
         if with_final:
@@ -353,8 +359,9 @@ class ResidualNetHidden(torch.autograd.Function):
         if narrow is not None:
             g_hidden = torch.nn.functional.pad(g_hidden, (0, 128 - H))
         g_x, grads = ops.resnet_hidden_backward(g_hidden, bwd_w, saved, x.shape[1])
-        out = [g_x if ctx.needs_input_grad[0] else None, None]
-        out += wgrad(x, grads[0] if nb else g_hidden, need[0], need[1], rows=narrow)
+        di = ctx.di if ctx.di != x.shape[1] else None      # (x was saved with its pad columns)
+        out = [(g_x if di is None else g_x[:, :di]) if ctx.needs_input_grad[0] else None, None]
+        out += wgrad(x, grads[0] if nb else g_hidden, need[0], need[1], rows=narrow, cols=di)
         for k in range(nb):
             out += wgrad(saved[2 * k], grads[2 * k + 1], need[2 + 4 * k], need[3 + 4 * k], rows=narrow, cols=narrow)
             out += wgrad(saved[2 * k + 1], grads[2 * k + 2] if k + 1 < nb else g_hidden, need[4 + 4 * k], need[5 + 4 * k],

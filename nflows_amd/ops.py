@@ -1179,7 +1179,7 @@ def pack_resnet_hidden_train_reference(w_in, b_in, block_params, final=None):
 def resnet_hidden_train_supported(batch, num_identity, hidden_features, num_blocks):
     """The shapes K14 takes (everything else keeps the eager path); hidden widths below 128 are zero-padded."""
     return (4 <= hidden_features <= 128 and hidden_features % 4 == 0 and 1 <= num_identity <= 64
-            and num_identity % 4 == 0 and 0 <= num_blocks <= 3 and batch > 0 and batch % 128 == 0)
+            and 0 <= num_blocks <= 3 and batch > 0 and batch % 128 == 0)   # (identity features: padded to a multiple of 4)
 
 
 def resnet_hidden_forward(x, fwd_stages, fwd_bias, num_blocks, final_bias=None, out_features=0):

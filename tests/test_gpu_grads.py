@@ -168,12 +168,13 @@ def _k14_net(B, di, nb, H=128):
 
 
 @pytest.mark.parametrize("B,di,nb,H", [(256, 32, 2, 128), (384, 12, 1, 128), (128, 64, 3, 128), (1024, 36, 0, 128),
-                                       (256, 8, 2, 64), (128, 20, 1, 52)])
+                                       (256, 8, 2, 64), (128, 20, 1, 52), (256, 3, 2, 128), (128, 21, 1, 64), (128, 63, 2, 128)])
 def test_fused_conditioner_training_kernels(B, di, nb, H, monkeypatch):
     """K14 (nfa_resnet_hidden_forward_f32 / _backward_f32 + K10) against autograd through the eager modules with the
     same weights: the net's output, the input gradient and every parameter gradient, judged against float64 -- at
     most 4 x the eager fp32 path's own error + 1e-6 of the scale.  One / two / four k-steps of identity features,
-    zero to three blocks, hidden widths below 128 (zero-padded into the kernels' 128).  (Small batches: an activation within rounding of zero flips a ReLU mask and moves a
+    zero to three blocks, hidden widths below 128 (zero-padded into the kernels' 128), identity-feature counts that are
+    not multiples of four (3, 21, 63: zero columns on the host).  (Small batches: an activation within rounding of zero flips a ReLU mask and moves a
     gradient by O(weight) in ANY fp32 implementation; the large-batch test below pins the masks instead.)"""
     import copy
     from nflows_amd import ops
