@@ -1253,3 +1253,94 @@ def test_training_kernel_streams():
     assert torch.allclose(w1t[:52, :52], b.linear_layers[1].weight.detach().t(), atol=1e-8) and not w1t[52:].any() \
         and not w1t[:, 52:].any()
     assert not bias.view(3, 4, 2, 4, 4).permute(0, 1, 3, 2, 4).reshape(3, 128)[:, 52:].any()
+
+
+def test_training_function_wiring_with_emulated_kernels(monkeypatch):
+    """autograd.ResidualNetHidden (K14's host side) with the three kernels and K10 replaced by tensor-operation
+    emulations of their CONTRACTS (include/nflows_amd.h: what each array holds), on the CPU: the gradients it hands
+    back -- order, slicing of padded widths, padding of the incoming gradient, zero columns for identity-feature
+    counts that are not multiples of four, frozen parameters -- equal autograd through the eager modules."""
+    import copy
+    import torch
+    from nflows_amd import autograd as AG
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import ResidualNet
+    book = {}
+
+    def pad2(w, rows, cols):
+        out = w.new_zeros(rows, cols)
+        out[:w.shape[0], :w.shape[1]] = w
+        return out
+
+    def pad1(b, n):
+        return torch.cat((b, b.new_zeros(n - b.shape[0])))
+
+    def pack(w_in, b_in, blocks, final=None):   # the "streams": the weights zero-padded to 128 hidden units
+        key = float(len(book))
+        book[key] = dict(w_in=pad2(w_in.detach(), 128, w_in.shape[1]), b_in=pad1(b_in.detach(), 128),
+                         blocks=[(pad2(w0.detach(), 128, 128), pad1(b0.detach(), 128), pad2(w1.detach(), 128, 128),
+                                  pad1(b1.detach(), 128)) for w0, b0, w1, b1 in blocks],
+                         final=None if final is None else (pad2(final[0].detach(), final[0].shape[0], 128), final[1].detach()))
+        tag = torch.tensor([key], dtype=torch.float64)
+        return tag, tag, tag, (tag if final is not None else None)
+
+    def forward(x, fwd_w, fwd_b, num_blocks, final_bias=None, out_features=0):
+        assert x.shape[1] % 4 == 0 and x.shape[0] % 128 == 0
+        w = book[fwd_w.item()]
+        h = x @ w["w_in"].t() + w["b_in"]
+        saved = []
+        for w0, b0, w1, b1 in w["blocks"]:
+            t = torch.relu(h)
+            u = torch.relu(t @ w0.t() + b0)
+            saved += [t, u]
+            h = h + u @ w1.t() + b1
+        params = None
+        if final_bias is not None:
+            params = h @ w["final"][0].t() + w["final"][1]
+            assert params.shape[1] == out_features
+        return h, (torch.stack(saved) if saved else x.new_zeros(0, x.shape[0], 128)), params
+
+    def backward(grad_hidden, bwd_w, saved, num_identity):
+        assert grad_hidden.shape[1] == 128
+        w = book[bwd_w.item()]
+        nb = saved.shape[0] // 2
+        grads = [None] * (2 * nb)
+        gh = grad_hidden
+        for k in reversed(range(nb)):
+            w0, b0, w1, b1 = w["blocks"][k]
+            ga = (gh @ w1) * (saved[2 * k + 1] > 0)
+            gh = gh + (ga @ w0) * (saved[2 * k] > 0)
+            grads[2 * k + 1], grads[2 * k] = ga, gh
+        gx = gh @ w["w_in"]
+        assert gx.shape[1] == num_identity
+        return gx, (torch.stack(grads) if grads else grad_hidden.new_zeros(0, grad_hidden.shape[0], 128))
+
+    monkeypatch.setattr(ops, "pack_resnet_hidden_train", pack)
+    monkeypatch.setattr(ops, "resnet_hidden_forward", forward)
+    monkeypatch.setattr(ops, "resnet_hidden_backward", backward)
+    monkeypatch.setattr(ops, "linear_wgrad", lambda x, gy, need_bias=True: (gy.t() @ x, gy.sum(0) if need_bias else None))
+    torch.manual_seed(0)
+    for di, H, nb, out, with_final, frozen in ((8, 128, 2, 40, True, ()), (3, 128, 1, 24, True, ()), (21, 52, 2, 40, True, ()),
+                                               (12, 64, 0, 16, True, ()), (8, 128, 2, 40, False, ()), (6, 20, 3, 8, False, ()),
+                                               (8, 128, 1, 40, True, ("initial_layer.bias", "blocks.0.linear_layers.1.weight",
+                                                                      "final_layer.weight"))):
+        net = ResidualNet(di, out, H, num_blocks=nb).double()
+        with torch.no_grad():
+            for b in net.blocks:
+                b.linear_layers[1].weight.mul_(50.0)
+        for name, p in net.named_parameters():
+            p.requires_grad_(name not in frozen)
+        x = torch.randn(256, di, dtype=torch.float64, requires_grad=True)
+        weight = torch.randn(256, out if with_final else H, dtype=torch.float64)
+        ref_net, ref_x = copy.deepcopy(net), x.detach().clone().requires_grad_(True)
+        ((ref_net(ref_x) if with_final else ref_net.hidden(ref_x)) * weight).sum().backward()
+        params = net._hidden_parameters() + ([net.final_layer.weight, net.final_layer.bias] if with_final else [])
+        result = AG.ResidualNetHidden.apply(x, with_final, *params)
+        assert result.shape == weight.shape
+        (result * weight).sum().backward()
+        assert torch.allclose(x.grad, ref_x.grad, rtol=1e-10, atol=1e-12)
+        for (name, p), (_, q) in zip(net.named_parameters(), ref_net.named_parameters()):
+            if name in frozen or (not with_final and name.startswith("final_layer")):
+                assert p.grad is None, name
+            else:
+                assert p.grad.shape == p.shape and torch.allclose(p.grad, q.grad, rtol=1e-10, atol=1e-12), name
