@@ -533,11 +533,7 @@ def main():
                 traffic_file = ("k8h_pmc_traffic.json" if f16 else "k8_pmc_traffic.json") if path == "k8" else "k7b_pmc_traffic.json"
                 nw8 = B % 256 == 0 and B // 256 >= 256
                 ring = 5 if (nw8 and os.environ.get("NFA_K8H_RING", "") == "5") else 4   # (5: the elastic-stream experiment)
-                tile16 = f16 and ops.use_tile16(B, K, None, dev)   # (small shards, e.g. config 4 at 8 GPUs: K8s)
-                kernel = (("nfa::k8s::rqs_resnet_f16s_kernel<false, 2, ...> (16-sample tiles, %s)"
-                           % ("four-wave 64-row blocks" if (B + 63) // 64 <= torch.cuda.get_device_properties(dev).multi_processor_count
-                              else "eight-wave 128-row blocks")) if tile16
-                          else "nfa::k8h::rqs_resnet_f16_kernel<false, 2, %d, 8, false, %d>" % (8 if nw8 else 4, ring) if f16
+                kernel = ("nfa::k8h::rqs_resnet_f16_kernel<false, 2, %d, 8, false, %d>" % (8 if nw8 else 4, ring) if f16
                           else "nfa::rqs_resnet_kernel<false, 1, 2, %s, 8, false>" % os.environ.get("NFA_K8_PIPE", "2")) if path == "k8" \
                     else "nfa::rqs_fused_linear_bf16_kernel<false>"
                 r = {"bound": "mfma", "kernel": kernel,
