@@ -145,8 +145,9 @@ class _Net(nn.Module):
         from ... import ops
         if not ops.resnet_hidden_train_supported(inputs.shape[0], inputs.shape[1], self.hidden_features, len(self.blocks)):
             return False
-        if inputs.shape[1] != self.initial_layer.in_features:
-            return False
+        w = self.initial_layer.weight
+        if inputs.shape[1] != self.initial_layer.in_features or w.dtype != torch.float32 or w.device != inputs.device:
+            return False   # (half-precision or misplaced parameters: the eager modules report it their own way)
         for b in self.blocks:
             if (b.activation is not F.relu or b.use_batch_norm or (b.training and b.dropout.p != 0.0)
                     or getattr(b, "context_layer", None) is not None):
