@@ -1,5 +1,5 @@
 """Test infrastructure: the bodies of the sibling splines' backward kernels (nflows_amd/csrc/splines_lq.hip:
-quadratic_spline_backward_kernel, cubic_spline_backward_kernel) turned into host functions by text substitution
+linear_spline_backward_kernel, quadratic_spline_backward_kernel, cubic_spline_backward_kernel) turned into host functions by text substitution
 -- one "lane", the LDS slot a static array, the device helpers of rqs_math.hpp (refined reciprocals, the custom
 exponential) replaced by their IEEE counterparts -- and compiled with g++.  What this checks is the ALGEBRA of the
 closed-form adjoints as written in the kernel source (against the reference's float64 autograd, to the same
@@ -41,6 +41,13 @@ static void fill(LqBwdArgs& b, int K, int nh, int slot, float lo, float hi) {
     b.f.om_w = (float)(1.0 - 1e-3 * K); b.f.om_h = (float)(1.0 - 1e-3); b.f.om_hk = (float)(1.0 - 1e-3 * K);
     b.f.divisor = 0; b.f.rdivisor = 0;
 }
+extern "C" void linear(int inverse, int64_t n, int K, float lo, float hi, const float* x, const float* pdf, const float* gy,
+                       const float* gl, float* gx, float* g0) {
+    LqBwdArgs b; memset(&b, 0, sizeof b);
+    b.x = x; b.a0 = pdf; b.gy = gy; b.gl = gl; b.gx = gx; b.g0 = g0; b.n = n;
+    fill(b, K, 0, K | 1, lo, hi);
+    if (inverse) linear_host<0, true>(b); else linear_host<0, false>(b);
+}
 extern "C" void quadratic(int inverse, int64_t n, int K, int nh, float lo, float hi, const float* x, const float* w,
                           const float* h, const float* gy, const float* gl, float* gx, float* g0, float* g1) {
     LqBwdArgs b; memset(&b, 0, sizeof b);
@@ -80,6 +87,9 @@ def build(out_dir):
     h0 = src.index("// torchutils.cbrt (torchutils.py:139-141)")
     h1 = src.index("// splines/cubic.py:63-267.  w / h: K width / height logits (overwritten")
     helpers = src[h0:h1].replace("__device__ __forceinline__", "static inline").replace("#pragma clang fp contract(off)", "")
+    lin = _host_body(src, "template <int KT, bool INVERSE>\n__global__ void __launch_bounds__(kBlock) linear_spline_backward_kernel",
+                     "template <int KT, bool DERIVED, bool INVERSE>\n__global__ void __launch_bounds__(kBlock) quadratic_spline_backward_kernel",
+                     "linear_spline_backward_kernel", "linear_host")
     quad = _host_body(src, "template <int KT, bool DERIVED, bool INVERSE>\n__global__ void __launch_bounds__(kBlock) quadratic_spline_backward_kernel",
                       "// Cubic spline (splines/cubic.py:63-267).  Only the searched bin", "quadratic_spline_backward_kernel",
                       "quadratic_host")
@@ -88,10 +98,11 @@ def build(out_dir):
     cpp = os.path.join(out_dir, "lq_backward_host.cpp")
     so = os.path.join(out_dir, "lq_backward_host.so")
     with open(cpp, "w") as f:
-        f.write(HEADER + helpers + quad + cub + TAIL)
+        f.write(HEADER + helpers + lin + quad + cub + TAIL)
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", cpp, "-o", so])
     lib = ctypes.CDLL(so)
     p, f32, i32 = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
+    lib.linear.argtypes = [i32, ctypes.c_int64, i32, f32, f32] + [p] * 6
     lib.quadratic.argtypes = [i32, ctypes.c_int64, i32, i32, f32, f32] + [p] * 8
     lib.cubic.argtypes = [i32, ctypes.c_int64, i32, f32, f32] + [p] * 12
     return lib

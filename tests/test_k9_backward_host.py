@@ -37,6 +37,22 @@ def check(got, G, key, worst):
     worst.append(err / limit)
 
 
+def test_linear_adjoints(lib, G):
+    worst = []
+    for name in ("lin_k8", "lin_k10", "lin_k4", "lin_k17", "ulin_k8", "ulin_k10", "ulin_k4", "ulin_k17"):
+        x = G[name + "/x"].astype(np.float32)
+        pdf = np.ascontiguousarray(G[name + "/logits0"])
+        n, K = x.size, pdf.shape[1]
+        lo, hi = (-3.0, 3.0) if name.startswith("u") else (0.0, 1.0)
+        for inverse in (0, 1):
+            gx, g0 = np.empty(n, np.float32), np.empty_like(pdf)
+            lib.linear(inverse, n, K, lo, hi, P(x), P(pdf), P(G[name + "/wy"]), P(G[name + "/wl"]), P(gx), P(g0))
+            pre = name + "/" + ("inv_" if inverse else "")
+            check(gx, G, pre + "gx", worst)
+            check(g0, G, pre + "glogits0", worst)
+    assert len(worst) == 32
+
+
 def test_quadratic_adjoints(lib, G):
     worst = []
     for name in ("quad_k8", "quad_k10", "quad_k4", "quad_k17", "uquad_k8", "uquad_k10", "uquad_k4", "uquad_k17"):
