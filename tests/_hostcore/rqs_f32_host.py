@@ -1,0 +1,116 @@
+"""Test infrastructure: the fp32 spline arithmetic of the product compiled for the HOST -- nflows_amd/csrc/rqs_math.hpp
+as it is (its `#include "common.hpp"` replaced by a dozen lines that define away `__device__` and map the three gfx950
+builtins it uses -- v_rcp_f32, v_log_f32, v_exp_f32 -- onto 1/x, log2f, exp2f) plus the per-spline gradient function
+`rqs_backward` cut out of rqs_bwd.hip.  The functions are the ones the kernels K1 / K5 (`rqs_eval`), the whole-layer
+kernels (`rqs_eval_flat8`) and K1-backward (`rqs_backward`) call per lane; the hardware's transcendental approximations
+(1 ulp) are the only thing the host build replaces.  Built with g++ into a temporary directory by the CPU suite;
+nothing in the product loads it."""
+import ctypes
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+SHIM = r'''
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include "nflows_amd.h"
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_logf(x) log2f(x)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+namespace nfa { constexpr int kBlock = 256; constexpr int kWave = 64; }
+'''
+
+HARNESS = r'''
+using namespace nfa;
+
+template <int KT, bool INVERSE, bool LINEAR>
+static int forward_all(int64_t n, const RqsDev& sp, const float* x, const float* params, float* y, float* lad) {
+    int status = 0;
+    float slot[3 * 4096 + 2];
+    for (int64_t i = 0; i < n; ++i) {
+        memcpy(slot, params + i * sp.P, sizeof(float) * sp.P);
+        status |= rqs_eval<KT, INVERSE, LINEAR>(x[i], slot, sp, y[i], lad[i]);
+    }
+    return status;
+}
+
+template <int KT, bool INVERSE, bool LINEAR>
+static int backward_all(int64_t n, const RqsDev& sp, const float* x, const float* params, const float* gy, const float* gl,
+                        float* gx, float* gparams) {
+    int status = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        float* slot = gparams + i * sp.P;   // the function overwrites the lane's logits with their gradients
+        memcpy(slot, params + i * sp.P, sizeof(float) * sp.P);
+        gx[i] = rqs_backward<KT, INVERSE, LINEAR>(x[i], slot, sp, gy[i], gl[i], status);
+    }
+    return status;
+}
+
+#define DISPATCH(FN, ...)                                                                                     \
+    do {                                                                                                      \
+        const bool lin = sp.linear != 0;                                                                      \
+        if (kt == 8) return inverse ? (lin ? FN<8, true, true>(__VA_ARGS__) : FN<8, true, false>(__VA_ARGS__)) \
+                                    : (lin ? FN<8, false, true>(__VA_ARGS__) : FN<8, false, false>(__VA_ARGS__)); \
+        if (kt == 10) return inverse ? (lin ? FN<10, true, true>(__VA_ARGS__) : FN<10, true, false>(__VA_ARGS__)) \
+                                     : (lin ? FN<10, false, true>(__VA_ARGS__) : FN<10, false, false>(__VA_ARGS__)); \
+        return inverse ? (lin ? FN<0, true, true>(__VA_ARGS__) : FN<0, true, false>(__VA_ARGS__))              \
+                       : (lin ? FN<0, false, true>(__VA_ARGS__) : FN<0, false, false>(__VA_ARGS__));           \
+    } while (0)
+
+// kt: the compile-time bin count of the instance to run (8, 10) or 0 = the run-time-K instance
+extern "C" int host_rqs_forward(int kt, int inverse, int64_t n, const nfa_rqs_spec* spec, const float* x,
+                                const float* params, float* y, float* lad) {
+    RqsDev sp;
+    if (make_dev_spec(spec, &sp) != NFA_OK) return -1;
+    DISPATCH(forward_all, n, sp, x, params, y, lad);
+}
+
+extern "C" int host_rqs_backward(int kt, int inverse, int64_t n, const nfa_rqs_spec* spec, const float* x,
+                                 const float* params, const float* gy, const float* gl, float* gx, float* gparams) {
+    RqsDev sp;
+    if (make_dev_spec(spec, &sp) != NFA_OK) return -1;
+    DISPATCH(backward_all, n, sp, x, params, gy, gl, gx, gparams);
+}
+
+// the whole-layer kernels' evaluation (8 bins, linear tails): rqs_eval_flat8, logits as the reference defines them
+extern "C" int host_rqs_forward_flat8(int inverse, int64_t n, const nfa_rqs_spec* spec, const float* x,
+                                      const float* params, float* y, float* lad) {
+    RqsDev sp;
+    if (make_dev_spec(spec, &sp) != NFA_OK || sp.K != 8 || !sp.linear) return -1;
+    int status = 0;
+    for (int64_t i = 0; i < n; ++i)
+        status |= inverse ? rqs_eval_flat8<true>(x[i], params + i * sp.P, sp, y[i], lad[i])
+                          : rqs_eval_flat8<false>(x[i], params + i * sp.P, sp, y[i], lad[i]);
+    return status;
+}
+'''
+
+
+def build(out_dir):
+    csrc = os.path.join(ROOT, "nflows_amd", "csrc")
+    math_src = open(os.path.join(csrc, "rqs_math.hpp")).read()
+    assert math_src.count('#include "common.hpp"') == 1
+    bwd_src = open(os.path.join(csrc, "rqs_bwd.hip")).read()
+    start = bwd_src.index("// adjoints of (x, a, b, c, e, d0, d1) for upstream (gy, gl)")
+    stop = bwd_src.index("template <int KT, bool INVERSE>\n__global__ void __launch_bounds__(kBlock) rqs_coupling_backward_kernel")
+    backward = "namespace nfa {\n" + bwd_src[start:stop] + "\n}  // namespace nfa\n"
+    assert "__global__" not in backward and "__shfl" not in backward
+    cpp = os.path.join(out_dir, "rqs_f32_host.cpp")
+    so = os.path.join(out_dir, "rqs_f32_host.so")
+    with open(cpp, "w") as f:
+        f.write(math_src.replace('#include "common.hpp"', SHIM).replace("#pragma once", "", 1) + backward + HARNESS)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
+                           "-I" + os.path.join(ROOT, "include"), cpp, "-o", so])
+    lib = ctypes.CDLL(so)
+    p, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    lib.host_rqs_forward.argtypes = [i32, i32, i64, p, p, p, p, p]
+    lib.host_rqs_backward.argtypes = [i32, i32, i64, p, p, p, p, p, p, p]
+    lib.host_rqs_forward_flat8.argtypes = [i32, i64, p, p, p, p, p]
+    for fn in (lib.host_rqs_forward, lib.host_rqs_backward, lib.host_rqs_forward_flat8):
+        fn.restype = i32
+    return lib

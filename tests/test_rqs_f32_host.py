@@ -1,0 +1,108 @@
+"""The fp32 spline arithmetic of the PRODUCT on the CPU: nflows_amd/csrc/rqs_math.hpp (`rqs_eval`: what K1 / K5 run per
+lane; `rqs_eval_flat8`: the whole-layer kernels' evaluation) and `rqs_backward` of rqs_bwd.hip (K1-backward), compiled for
+the host (tests/_hostcore/rqs_f32_host.py) and held to the reference's vectors with the rules of the GPU parity tests:
+the 24 functional cases of rqs_functional.npz (values, NaN / tail pass-through) and the reference's autograd through a
+spline coupling layer (grads.npz).  The host build replaces only the three hardware transcendentals (1 ulp).  The GPU
+suite remains the parity test proper; this one finds an algebra or indexing slip in the kernel sources without a GPU."""
+import ctypes
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from _hostcore import rqs_f32_host
+from helpers import LAD_TOL, OUT_TOL, assert_fp32_parity, conditioning, parse_kwargs
+from oracle import capi
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    return rqs_f32_host.build(str(tmp_path_factory.mktemp("rqsf32")))
+
+
+def P(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def product_spec(K, **kw):
+    from nflows_amd import ops
+    return ops.make_rqs_spec(K, kw.pop("tails", None), **kw)
+
+
+def packed(uw, uh, ud):
+    n = uw.size // uw.shape[-1]
+    return np.ascontiguousarray(np.concatenate([t.reshape(n, -1) for t in (uw, uh, ud)], axis=1), dtype=np.float32)
+
+
+def test_forward_values_of_the_kernel_source_match_the_reference(lib, golden_dir):
+    G = np.load(os.path.join(golden_dir, "rqs_functional.npz"))
+    runs = 0
+    for name, inv, kw in G["meta"]:
+        kw = parse_kwargs(kw)
+        inverse = bool(int(inv))
+        x, uw, uh, ud = (G[name + "/" + k] for k in ("x", "uw", "uh", "ud"))
+        K = uw.shape[-1]
+        spec = product_spec(K, **dict(kw))
+        ospec = capi.make_spec(K, **kw)
+        cy, cl = conditioning(lambda *a: capi.rqs_elementwise(*a, ospec, inverse=inverse)[:2], (x, uw, uh, ud), (0, 1, 2, 3))
+        xs, pr = np.ascontiguousarray(x.reshape(-1)), packed(uw, uh, ud)
+        instances = [0] + ([K] if K in (8, 10) else [])
+        flat = K == 8 and kw.get("tails") == "linear"
+        for kt in instances + (["flat8"] if flat else []):
+            y, lad = np.empty_like(xs), np.empty_like(xs)
+            if kt == "flat8":
+                status = lib.host_rqs_forward_flat8(int(inverse), xs.size, ctypes.byref(spec), P(xs), P(pr), P(y), P(lad))
+            else:
+                status = lib.host_rqs_forward(kt, int(inverse), xs.size, ctypes.byref(spec), P(xs), P(pr), P(y), P(lad))
+            assert status == 0, (name, kt, status)
+            what = "%s [instance %s]" % (name, kt)
+            assert_fp32_parity(y.reshape(x.shape), G[name + "/y"], G[name + "/y64"], OUT_TOL, what + " y", cond=cy)
+            assert_fp32_parity(lad.reshape(x.shape), G[name + "/lad"], G[name + "/lad64"], LAD_TOL, what + " lad", cond=cl)
+            if kw.get("tails") == "linear":   # pass-through elements are bit-exact, logabsdet exactly 0 there
+                tb = np.float32(kw["tail_bound"])
+                outside = ~((xs >= -tb) & (xs <= tb))
+                assert np.array_equal(y[outside].view(np.uint32), xs[outside].view(np.uint32)), what
+                assert np.all(lad[outside] == 0), what
+            runs += 1
+    assert runs >= 30
+
+
+def test_gradients_of_the_kernel_source_match_the_reference_autograd(lib, golden_dir):
+    """loss = <y, Wy> + <logabsdet, Wl> through a spline coupling layer whose conditioner output is a table
+    (grads.npz): `rqs_backward` per spline with gy = Wy[b, column], gl = Wl[b]; the GPU test's rule (error against the
+    float64 gradient <= 4 x the reference's own fp32 error + 2e-5 x scale)."""
+    import math
+    G = np.load(os.path.join(golden_dir, "grads.npz"))
+    done = 0
+    for name, kind, cfg in G["meta"]:
+        if kind != "rq":
+            continue
+        cfg = parse_kwargs(cfg)
+        K, tails, tb, H = cfg["K"], cfg["tails"], cfg["tail_bound"], cfg["hidden"]
+        nd = K - 1 if tails == "linear" else K + 1
+        Pn = 2 * K + nd
+        x, params = G[name + "/x"], G[name + "/params"]
+        Wy, Wl, tidx = G[name + "/Wy"], G[name + "/Wl"], G[name + "/transform_idx"]
+        B, dt = x.shape[0], len(tidx)
+        spec = product_spec(K, tails=tails, tail_bound=tb, wh_divisor=math.sqrt(H) if H else 0.0)
+        xs = np.ascontiguousarray(x[:, tidx].reshape(-1))
+        pr = np.ascontiguousarray(params.reshape(B * dt, Pn))
+        gy = np.ascontiguousarray(Wy[:, tidx].reshape(-1))
+        gl = np.ascontiguousarray(np.repeat(Wl, dt))
+        for inverse in (False, True):
+            tag = name + ("/inv" if inverse else "/fwd")
+            for kt in [0] + ([K] if K in (8, 10) else []):
+                gx, gp = np.empty_like(xs), np.empty_like(pr)
+                status = lib.host_rqs_backward(kt, int(inverse), xs.size, ctypes.byref(spec), P(xs), P(pr), P(gy), P(gl), P(gx), P(gp))
+                assert status == 0, (tag, kt)
+                for got, ref, truth, what in ((gx, G[tag + "_gx"][:, tidx].reshape(-1), G[tag + "_gx64"][:, tidx].reshape(-1), "gx"),
+                                              (gp.reshape(B, dt * Pn), G[tag + "_gp"], G[tag + "_gp64"], "gparams")):
+                    e_got = np.abs(got.astype(np.float64) - truth).max()
+                    e_ref = np.abs(ref.astype(np.float64) - truth).max()
+                    limit = 4 * e_ref + 2e-5 * (1 + np.abs(truth).max())
+                    assert e_got <= limit, "%s %s [instance %d]: %.3e > %.3e" % (tag, what, kt, e_got, limit)
+                done += 1
+    assert done >= 8
