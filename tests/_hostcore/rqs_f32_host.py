@@ -88,6 +88,43 @@ extern "C" int host_rqs_forward_flat8(int inverse, int64_t n, const nfa_rqs_spec
                           : rqs_eval_flat8<false>(x[i], params + i * sp.P, sp, y[i], lad[i]);
     return status;
 }
+
+// the whole-layer kernel K8's sliced evaluation (rqs_math.hpp: FlatSteps, every slice in order): variant 0 = the
+// reference's exact rounding sequence, 8 bins; 1 = the shorter sequence (FAST), 8 bins; 2 = FAST, 10 bins.  Logits as
+// the kernel sees them: already divided by sqrt(hidden) (PRESCALED = 1; the fixtures carry no divisor).
+template <class Steps, int KT>
+static int flatsteps_all(int64_t n, RqsDev sp, const float* x, const float* params, float* y, float* lad) {
+    sp.divisor = 0.0f;
+    int status = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        Steps f;
+        memset(&f, 0, sizeof f);
+        const float* p = params + i * sp.P;
+        f.x = x[i];
+        for (int j = 0; j < KT; ++j) {
+            f.ew[j] = p[j];
+            f.eh[j] = p[KT + j];
+            if (j < KT - 1) f.sd[j] = p[2 * KT + j];
+        }
+        flat_steps_all(f, sp);
+        y[i] = f.y;
+        lad[i] = f.lad;
+        status |= f.status;
+    }
+    return status;
+}
+
+extern "C" int host_rqs_forward_flatsteps(int variant, int inverse, int64_t n, const nfa_rqs_spec* spec, const float* x,
+                                          const float* params, float* y, float* lad) {
+    RqsDev sp;
+    if (make_dev_spec(spec, &sp) != NFA_OK || !sp.linear || sp.K != (variant == 2 ? 10 : 8)) return -1;
+    if (variant == 0) return inverse ? flatsteps_all<FlatSteps<true, 1, false, 8>, 8>(n, sp, x, params, y, lad)
+                                     : flatsteps_all<FlatSteps<false, 1, false, 8>, 8>(n, sp, x, params, y, lad);
+    if (variant == 1) return inverse ? flatsteps_all<FlatSteps<true, 1, true, 8>, 8>(n, sp, x, params, y, lad)
+                                     : flatsteps_all<FlatSteps<false, 1, true, 8>, 8>(n, sp, x, params, y, lad);
+    return inverse ? flatsteps_all<FlatSteps<true, 1, true, 10>, 10>(n, sp, x, params, y, lad)
+                   : flatsteps_all<FlatSteps<false, 1, true, 10>, 10>(n, sp, x, params, y, lad);
+}
 '''
 
 
@@ -111,6 +148,7 @@ def build(out_dir):
     lib.host_rqs_forward.argtypes = [i32, i32, i64, p, p, p, p, p]
     lib.host_rqs_backward.argtypes = [i32, i32, i64, p, p, p, p, p, p, p]
     lib.host_rqs_forward_flat8.argtypes = [i32, i64, p, p, p, p, p]
-    for fn in (lib.host_rqs_forward, lib.host_rqs_backward, lib.host_rqs_forward_flat8):
+    lib.host_rqs_forward_flatsteps.argtypes = [i32, i32, i64, p, p, p, p, p]
+    for fn in (lib.host_rqs_forward, lib.host_rqs_backward, lib.host_rqs_forward_flat8, lib.host_rqs_forward_flatsteps):
         fn.restype = i32
     return lib

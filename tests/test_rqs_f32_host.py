@@ -50,11 +50,17 @@ def test_forward_values_of_the_kernel_source_match_the_reference(lib, golden_dir
         cy, cl = conditioning(lambda *a: capi.rqs_elementwise(*a, ospec, inverse=inverse)[:2], (x, uw, uh, ud), (0, 1, 2, 3))
         xs, pr = np.ascontiguousarray(x.reshape(-1)), packed(uw, uh, ud)
         instances = [0] + ([K] if K in (8, 10) else [])
-        flat = K == 8 and kw.get("tails") == "linear"
-        for kt in instances + (["flat8"] if flat else []):
+        if kw.get("tails") == "linear":   # the whole-layer kernels' evaluations: flat (K7 / K8 plain loop), sliced (K8)
+            instances += ["flat8"] if K == 8 else []
+            if not kw.get("enable_identity_init"):   # (the sliced form is built for softplus beta = 1: the coupling
+                instances += {8: ["steps0", "steps1"], 10: ["steps2"]}.get(K, [])   # layers never enable the identity init)
+        for kt in instances:
             y, lad = np.empty_like(xs), np.empty_like(xs)
             if kt == "flat8":
                 status = lib.host_rqs_forward_flat8(int(inverse), xs.size, ctypes.byref(spec), P(xs), P(pr), P(y), P(lad))
+            elif str(kt).startswith("steps"):
+                status = lib.host_rqs_forward_flatsteps(int(kt[5:]), int(inverse), xs.size, ctypes.byref(spec), P(xs), P(pr),
+                                                        P(y), P(lad))
             else:
                 status = lib.host_rqs_forward(kt, int(inverse), xs.size, ctypes.byref(spec), P(xs), P(pr), P(y), P(lad))
             assert status == 0, (name, kt, status)
@@ -67,7 +73,7 @@ def test_forward_values_of_the_kernel_source_match_the_reference(lib, golden_dir
                 assert np.array_equal(y[outside].view(np.uint32), xs[outside].view(np.uint32)), what
                 assert np.all(lad[outside] == 0), what
             runs += 1
-    assert runs >= 30
+    assert runs >= 56
 
 
 def test_gradients_of_the_kernel_source_match_the_reference_autograd(lib, golden_dir):
