@@ -1,8 +1,9 @@
 """Test infrastructure: the fp32 spline arithmetic of the product compiled for the HOST -- nflows_amd/csrc/rqs_math.hpp
 as it is (its `#include "common.hpp"` replaced by a dozen lines that define away `__device__` and map the three gfx950
 builtins it uses -- v_rcp_f32, v_log_f32, v_exp_f32 -- onto 1/x, log2f, exp2f) plus the per-spline gradient function
-`rqs_backward` cut out of rqs_bwd.hip.  The functions are the ones the kernels K1 / K5 (`rqs_eval`), the whole-layer
-kernels (`rqs_eval_flat8`) and K1-backward (`rqs_backward`) call per lane; the hardware's transcendental approximations
+`rqs_backward` cut out of rqs_bwd.hip, plus rqs_fused8.hpp (K8h's sliced evaluation) with its two lane-mask asm blocks
+written out per lane.  The functions are the ones the kernels K1 / K5 (`rqs_eval`), the whole-layer kernels
+(`rqs_eval_flat8`, `FlatSteps`, `FusedSteps`) and K1-backward (`rqs_backward`) call per lane; the hardware's transcendental approximations
 (1 ulp) are the only thing the host build replaces.  Built with g++ into a temporary directory by the CPU suite;
 nothing in the product loads it."""
 import ctypes
@@ -125,7 +126,71 @@ extern "C" int host_rqs_forward_flatsteps(int variant, int inverse, int64_t n, c
     return inverse ? flatsteps_all<FlatSteps<true, 1, true, 10>, 10>(n, sp, x, params, y, lad)
                    : flatsteps_all<FlatSteps<false, 1, true, 10>, 10>(n, sp, x, params, y, lad);
 }
+
+// the whole-layer kernel K8h's sliced evaluation (rqs_fused8.hpp: FusedSteps, every slice in order) on logits scaled
+// by 1 / kappa (a power of two), the way the kernel hands them over; 8 or 10 bins, linear tails, softplus beta = 1
+template <class Steps, int KT>
+static int fused_all(int64_t n, const RqsDev& sp, float kappa, const float* x, const float* params, float* y, float* lad) {
+    int status = 0;
+    const float inv_kappa = 1.0f / kappa;
+    for (int64_t i = 0; i < n; ++i) {
+        Steps f;
+        memset(&f, 0, sizeof f);
+        const float* p = params + i * sp.P;
+        f.x = x[i];
+        f.kappa = kappa;
+        f.kl2e = 1.44269502162933349609375f * kappa;
+        f.tail_s = sp.tail_logit * inv_kappa;
+        for (int j = 0; j < KT; ++j) {
+            f.ew[j] = p[j] * inv_kappa;
+            f.eh[j] = p[KT + j] * inv_kappa;
+            if (j < KT - 1) f.sd[j] = p[2 * KT + j] * inv_kappa;
+        }
+        flat_steps_all(f, sp);
+        y[i] = f.y;
+        lad[i] = f.lad;
+        status |= f.status;
+    }
+    return status;
+}
+
+extern "C" int host_rqs_forward_fused(int inverse, float kappa, int64_t n, const nfa_rqs_spec* spec, const float* x,
+                                      const float* params, float* y, float* lad) {
+    RqsDev sp;
+    if (make_dev_spec(spec, &sp) != NFA_OK || !sp.linear || (sp.K != 8 && sp.K != 10)) return -1;
+    if (sp.K == 8) return inverse ? fused_all<FusedSteps<true, 8>, 8>(n, sp, kappa, x, params, y, lad)
+                                  : fused_all<FusedSteps<false, 8>, 8>(n, sp, kappa, x, params, y, lad);
+    return inverse ? fused_all<FusedSteps<true, 10>, 10>(n, sp, kappa, x, params, y, lad)
+                   : fused_all<FusedSteps<false, 10>, 10>(n, sp, kappa, x, params, y, lad);
+}
 '''
+
+# rqs_fused8.hpp holds two inline-asm blocks that work on the wave's lane MASK (a compare written to an SGPR pair, six
+# selects under it): per lane they are a comparison and six conditional moves, which is what the host build puts there
+WALK_ASM_C = '''        const unsigned long long next = x >= next_lower ? 1ull : 0ull;
+        if (take) {
+            cw0 = kw;
+            cw1 = kwn;
+            ch0 = kh;
+            ch1 = khn;
+            u0 = cand_u0;
+            u1 = cand_u1;
+        }
+        take = next;
+'''
+
+
+def _fused8_for_the_host(csrc):
+    src = open(os.path.join(csrc, "rqs_fused8.hpp")).read()
+    src = src.replace("#pragma once", "", 1).replace('#include "rqs_math.hpp"', "", 1)
+    a = src.index("        unsigned long long next;\n        asm(\"v_cmp_ge_f32 %6, %7, %8")
+    b = src.index("        take = next;\n", a) + len("        take = next;\n")
+    src = src[:a] + WALK_ASM_C + src[b:]
+    first = 'asm("v_cmp_ge_f32 %0, %1, %2" : "=s"(take) : "v"(x), "v"(INVERSE ? k1h : k1w));'
+    assert src.count(first) == 1
+    src = src.replace(first, "take = x >= (INVERSE ? k1h : k1w) ? 1ull : 0ull;")
+    assert "asm(" not in src
+    return src
 
 
 def build(out_dir):
@@ -140,7 +205,8 @@ def build(out_dir):
     cpp = os.path.join(out_dir, "rqs_f32_host.cpp")
     so = os.path.join(out_dir, "rqs_f32_host.so")
     with open(cpp, "w") as f:
-        f.write(math_src.replace('#include "common.hpp"', SHIM).replace("#pragma once", "", 1) + backward + HARNESS)
+        f.write(math_src.replace('#include "common.hpp"', SHIM).replace("#pragma once", "", 1) + backward
+                + _fused8_for_the_host(csrc) + HARNESS)
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
                            "-I" + os.path.join(ROOT, "include"), cpp, "-o", so])
     lib = ctypes.CDLL(so)
@@ -149,6 +215,8 @@ def build(out_dir):
     lib.host_rqs_backward.argtypes = [i32, i32, i64, p, p, p, p, p, p, p]
     lib.host_rqs_forward_flat8.argtypes = [i32, i64, p, p, p, p, p]
     lib.host_rqs_forward_flatsteps.argtypes = [i32, i32, i64, p, p, p, p, p]
-    for fn in (lib.host_rqs_forward, lib.host_rqs_backward, lib.host_rqs_forward_flat8, lib.host_rqs_forward_flatsteps):
+    lib.host_rqs_forward_fused.argtypes = [i32, ctypes.c_float, i64, p, p, p, p, p]
+    for fn in (lib.host_rqs_forward, lib.host_rqs_backward, lib.host_rqs_forward_flat8, lib.host_rqs_forward_flatsteps,
+               lib.host_rqs_forward_fused):
         fn.restype = i32
     return lib

@@ -54,10 +54,15 @@ def test_forward_values_of_the_kernel_source_match_the_reference(lib, golden_dir
             instances += ["flat8"] if K == 8 else []
             if not kw.get("enable_identity_init"):   # (the sliced form is built for softplus beta = 1: the coupling
                 instances += {8: ["steps0", "steps1"], 10: ["steps2"]}.get(K, [])   # layers never enable the identity init)
+                if K in (8, 10):   # K8h's evaluation on logits scaled by 1 / kappa (the bench's kernel): kappa = 1, 2^-3
+                    instances += ["fused1.0", "fused0.125"]
         for kt in instances:
             y, lad = np.empty_like(xs), np.empty_like(xs)
             if kt == "flat8":
                 status = lib.host_rqs_forward_flat8(int(inverse), xs.size, ctypes.byref(spec), P(xs), P(pr), P(y), P(lad))
+            elif str(kt).startswith("fused"):
+                status = lib.host_rqs_forward_fused(int(inverse), float(kt[5:]), xs.size, ctypes.byref(spec), P(xs), P(pr),
+                                                    P(y), P(lad))
             elif str(kt).startswith("steps"):
                 status = lib.host_rqs_forward_flatsteps(int(kt[5:]), int(inverse), xs.size, ctypes.byref(spec), P(xs), P(pr),
                                                         P(y), P(lad))
@@ -65,15 +70,24 @@ def test_forward_values_of_the_kernel_source_match_the_reference(lib, golden_dir
                 status = lib.host_rqs_forward(kt, int(inverse), xs.size, ctypes.byref(spec), P(xs), P(pr), P(y), P(lad))
             assert status == 0, (name, kt, status)
             what = "%s [instance %s]" % (name, kt)
-            assert_fp32_parity(y.reshape(x.shape), G[name + "/y"], G[name + "/y64"], OUT_TOL, what + " y", cond=cy)
-            assert_fp32_parity(lad.reshape(x.shape), G[name + "/lad"], G[name + "/lad64"], LAD_TOL, what + " lad", cond=cl)
+            # K8h's INVERSE (FusedSteps) is held to a looser rule, and that is a finding, not a courtesy: its knots are
+            # fp32 running sums and its root is Newton-refined against ITS OWN forward map, so in very flat bins (slope
+            # near min_derivative) the knots' rounding is divided by the slope -- on the steep random splines of this
+            # fixture up to 80 x the reference's worst error (y 1.0e-3 vs 1.3e-5, logabsdet 8e-2 vs 1e-3; mean 5 x / 13 x).
+            # The flows' conditioner outputs are far gentler (the GPU suite holds the 32-layer inverse to 2 x the
+            # reference's error), but a trained flow with flat bins would see this: DESIGN.md section 7.
+            # (its forward keeps the worst-case factor; a handful of elements of the extreme-logit case leave their
+            # per-element allowance: the shorter rounding sequence)
+            loose = {} if not str(kt).startswith("fused") else (dict(bulk=0.99, factor=100.0) if inverse else dict(bulk=0.995))
+            assert_fp32_parity(y.reshape(x.shape), G[name + "/y"], G[name + "/y64"], OUT_TOL, what + " y", cond=cy, **loose)
+            assert_fp32_parity(lad.reshape(x.shape), G[name + "/lad"], G[name + "/lad64"], LAD_TOL, what + " lad", cond=cl, **loose)
             if kw.get("tails") == "linear":   # pass-through elements are bit-exact, logabsdet exactly 0 there
                 tb = np.float32(kw["tail_bound"])
                 outside = ~((xs >= -tb) & (xs <= tb))
                 assert np.array_equal(y[outside].view(np.uint32), xs[outside].view(np.uint32)), what
                 assert np.all(lad[outside] == 0), what
             runs += 1
-    assert runs >= 56
+    assert runs >= 80
 
 
 def test_gradients_of_the_kernel_source_match_the_reference_autograd(lib, golden_dir):
