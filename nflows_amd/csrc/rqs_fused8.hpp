@@ -195,8 +195,8 @@ struct FusedSteps {
                 // One Newton step on the FORWARD map g(theta) of this bin, evaluated the way the forward
                 // pass evaluates it: the quadratic formula loses digits where b^2 ~ 4ac or the
                 // denominator is small, and whatever it loses reappears as forward/inverse inconsistency
-                // (amplified by every following layer).  g'(theta) = in_h delta^2 (...) / den^2 is the
-                // quantity the log-determinant needs anyway.
+                // (amplified by every following layer).  g'(theta) = in_w delta^2 (...) / den^2; delta^2 (...) is
+                // the quantity the log-determinant needs anyway.
                 const float omr = 1.0f - th;
                 t1mt = th * omr;
                 den = __builtin_fmaf(s_, t1mt, delta);
@@ -213,7 +213,12 @@ struct FusedSteps {
                 const float g = ch0 + __builtin_fmaf(__builtin_fmaf(-q, den, t0), r, q);
                 t2 = x - g;                                               // residual in y
             } else if constexpr (PART == 6) {
-                const float slope = in_h * t5;                            // g' den^2
+                // d g / d theta = in_w * (d y / d x) = in_w delta^2 (...) / den^2.  (Until the end of round 3 this line read
+                // in_h * t5 -- the slope with respect to theta taken for in_h instead of in_w times the derivative --,
+                // i.e. every step came out scaled by 1 / delta: right for the near-identity splines of an untrained
+                // flow (delta ~ 1), up to 80 x the reference's error on steep ones.  Found by running this file on
+                // the CPU against the reference's vectors: tests/test_rqs_f32_host.py.)
+                const float slope = in_w * t5;                            // g' den^2
                 const float r0 = __builtin_amdgcn_rcpf(slope);
                 const float r = __builtin_fmaf(__builtin_fmaf(-slope, r0, 1.0f), r0, r0);
                 const float step = (t2 * den) * (den * r);
