@@ -57,13 +57,15 @@ static int backward_all(int64_t n, const RqsDev& sp, const float* x, const float
         const bool lin = sp.linear != 0;                                                                      \
         if (kt == 8) return inverse ? (lin ? FN<8, true, true>(__VA_ARGS__) : FN<8, true, false>(__VA_ARGS__)) \
                                     : (lin ? FN<8, false, true>(__VA_ARGS__) : FN<8, false, false>(__VA_ARGS__)); \
+        if (kt == 4) return inverse ? (lin ? FN<4, true, true>(__VA_ARGS__) : FN<4, true, false>(__VA_ARGS__))   \
+                                    : (lin ? FN<4, false, true>(__VA_ARGS__) : FN<4, false, false>(__VA_ARGS__)); \
         if (kt == 10) return inverse ? (lin ? FN<10, true, true>(__VA_ARGS__) : FN<10, true, false>(__VA_ARGS__)) \
                                      : (lin ? FN<10, false, true>(__VA_ARGS__) : FN<10, false, false>(__VA_ARGS__)); \
         return inverse ? (lin ? FN<0, true, true>(__VA_ARGS__) : FN<0, true, false>(__VA_ARGS__))              \
                        : (lin ? FN<0, false, true>(__VA_ARGS__) : FN<0, false, false>(__VA_ARGS__));           \
     } while (0)
 
-// kt: the compile-time bin count of the instance to run (8, 10) or 0 = the run-time-K instance
+// kt: the compile-time bin count of the instance to run (4, 8, 10) or 0 = the run-time-K instance
 extern "C" int host_rqs_forward(int kt, int inverse, int64_t n, const nfa_rqs_spec* spec, const float* x,
                                 const float* params, float* y, float* lad) {
     RqsDev sp;

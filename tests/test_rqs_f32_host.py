@@ -49,7 +49,7 @@ def test_forward_values_of_the_kernel_source_match_the_reference(lib, golden_dir
         ospec = capi.make_spec(K, **kw)
         cy, cl = conditioning(lambda *a: capi.rqs_elementwise(*a, ospec, inverse=inverse)[:2], (x, uw, uh, ud), (0, 1, 2, 3))
         xs, pr = np.ascontiguousarray(x.reshape(-1)), packed(uw, uh, ud)
-        instances = [0] + ([K] if K in (8, 10) else [])
+        instances = [0] + ([K] if K in (4, 8, 10) else [])
         if kw.get("tails") == "linear":   # the whole-layer kernels' evaluations: flat (K7 / K8 plain loop), sliced (K8)
             instances += ["flat8"] if K == 8 else []
             if not kw.get("enable_identity_init"):   # (the sliced form is built for softplus beta = 1: the coupling
@@ -110,7 +110,7 @@ def test_gradients_of_the_kernel_source_match_the_reference_autograd(lib, golden
         gl = np.ascontiguousarray(np.repeat(Wl, dt))
         for inverse in (False, True):
             tag = name + ("/inv" if inverse else "/fwd")
-            for kt in [0] + ([K] if K in (8, 10) else []):
+            for kt in [0] + ([K] if K in (4, 8, 10) else []):
                 gx, gp = np.empty_like(xs), np.empty_like(pr)
                 status = lib.host_rqs_backward(kt, int(inverse), xs.size, ctypes.byref(spec), P(xs), P(pr), P(gy), P(gl), P(gx), P(gp))
                 assert status == 0, (tag, kt)
