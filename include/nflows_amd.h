@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NFA_ABI_VERSION 7  /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 7) */
+#define NFA_ABI_VERSION 8  /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 7; round 4: 8) */
 
 /* return codes */
 #define NFA_OK 0
@@ -751,6 +751,15 @@ int nfa_linear_wgrad_f32(const float *inputs, const float *grad_outputs, float *
  */
 int nfa_profile_enable(int32_t max_launches);
 int nfa_profile_collect(float *durations_ms, int32_t capacity, int32_t *count);
+
+/*
+ * Name of the layer kernel the calling thread launched last (round 4), e.g.
+ * "k8h::rqs_resnet_f16_kernel<inverse=0, init_ks=2, waves=8, K=8, ctx=0>": the launchers choose the instance from the
+ * batch, the device's CU count and the LDS budget, so the host cannot know it otherwise.  bench.py reports it as
+ * `roofline.kernel`; the engine-coverage parity tests assert it.  Writes a NUL-terminated string of at most
+ * `capacity` bytes (truncated if longer) and returns its untruncated length; an empty string before any launch.
+ */
+int nfa_last_layer_kernel(char *buffer, int32_t capacity);
 
 /*
  * Phase timeline of the fused kernels (tools/k7_trace.py, tools/k8_trace.py): device_buffer =

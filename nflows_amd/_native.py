@@ -31,7 +31,7 @@ FLAG_PAD_COLUMNS_SHIFT = 8   # bits 8-10: trailing pad columns the density epilo
 TAILS_NONE, TAILS_LINEAR = 0, 1
 SCALE_DEFAULT, SCALE_GENERAL, SCALE_ADDITIVE, SCALE_GIVEN, SCALE_SOFTPLUS = 0, 1, 2, 3, 4
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EXPORTS = (
     "nfa_abi_version",
@@ -76,6 +76,7 @@ EXPORTS = (
     "nfa_linear_wgrad_f32",
     "nfa_profile_enable",
     "nfa_profile_collect",
+    "nfa_last_layer_kernel",
     "nfa_debug_k7_trace",
 )
 
@@ -202,6 +203,8 @@ def _declare(lib):
     lib.nfa_profile_enable.argtypes = [i32]
     lib.nfa_profile_collect.restype = ctypes.c_int
     lib.nfa_profile_collect.argtypes = [ctypes.POINTER(ctypes.c_float), i32, ctypes.POINTER(i32)]
+    lib.nfa_last_layer_kernel.restype = ctypes.c_int
+    lib.nfa_last_layer_kernel.argtypes = [ctypes.c_char_p, i32]
 
 
 def load():

@@ -309,6 +309,7 @@ extern "C" int nfa_affine_flow_mlp_f32(const float* inputs, const void* weights_
         case 6: kern = affine_mlp_kernel<false, 4, true>; break;
         default: kern = affine_mlp_kernel<true, 4, true>; break;
     }
+    note_layer_kernel("affine_mlp_kernel<inverse=%d, init_ks=%d, additive=%d>", inv ? 1 : 0, init_ks, additive ? 1 : 0);
     if (lds > 64 * 1024) {
         static unsigned long long raised[8] = {};   // device masks (raise_dynamic_lds)
         {

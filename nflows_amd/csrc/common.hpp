@@ -15,6 +15,8 @@ int set_hip_error(hipError_t e);  // records e (thread-local) and returns NFA_ER
 int device_cu_count();            // multiProcessorCount of the current device (cached)
 // measurement aid (nfa_profile_*): event pair for the next layer-kernel launch, or nulls
 void profile_next_launch(hipEvent_t* start, hipEvent_t* stop);
+// nfa_last_layer_kernel: the launchers of the layer kernels leave the instance they chose (printf-style)
+void note_layer_kernel(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
 #define NFA_HIP_CHECK(expr)                                   \
     do {                                                      \

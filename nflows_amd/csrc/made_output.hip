@@ -15,8 +15,8 @@
 // of a group of four features are ordered so that the 48 accumulator values of a lane are the 24 + 24 logits of
 // its two features (ops._k7_row_order): the spline is evaluated straight from the accumulators.
 //
-// Features are independent given the hidden vector, so the grid is (128-row blocks) x (chunks of up to 25 groups
-// = 100 features): B = 4 096 x D = 784 gives 32 x 8 = 256 workgroups.  A chunk writes its own columns of the
+// Features are independent given the hidden vector, so the grid is (128-row blocks) x (chunks of up to 26 groups
+// = 104 features): B = 4 096 x D = 784 gives 32 x 8 = 256 workgroups.  A chunk writes its own columns of the
 // output rows and ITS part of every row's log-determinant into logabsdet_partial[chunk][row]; the caller adds the
 // chunks up in a fixed order (no atomics: the same bits on every run).
 //
@@ -295,6 +295,7 @@ extern "C" int nfa_rqs_made_output_f32(const float* inputs, int64_t row_stride, 
     const dim3 grid((unsigned)((batch >> 7) * chunks)), block(kBlock);
     const bool inverse = (flags & NFA_FLAG_INVERSE) != 0;
     void (*kern)(const MadeOutArgs) = inverse ? rqs_made_output_kernel<true> : rqs_made_output_kernel<false>;
+    note_layer_kernel("rqs_made_output_kernel<inverse=%d>", inverse ? 1 : 0);
     static unsigned long long raised[2] = {};   // device masks (raise_dynamic_lds)
     const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[inverse ? 1 : 0], (int)lds);
     if (rc_lds != NFA_OK) return rc_lds;

@@ -27,7 +27,10 @@
 
 #include <hip/hip_ext.h>
 #include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 #include <vector>
@@ -452,6 +455,15 @@ void profile_next_launch(hipEvent_t* start, hipEvent_t* stop) {
     }
 }
 
+static thread_local char g_last_layer_kernel[192] = "";
+
+void note_layer_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_layer_kernel, sizeof(g_last_layer_kernel), fmt, ap);
+    va_end(ap);
+}
+
 template <typename Kernel>
 static void launch_k1(Kernel kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, const CouplingArgs& a) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -464,6 +476,7 @@ static void launch_k1(Kernel kernel, dim3 grid, dim3 block, size_t lds, hipStrea
 
 template <int KT, int BLOCK>
 static int launch_coupling(const CouplingArgs& a, int inverse, dim3 grid, size_t lds, hipStream_t st) {
+    note_layer_kernel("rqs_coupling_kernel<K=%d, inverse=%d, block=%d>", KT, inverse ? 1 : 0, BLOCK);
     if (inverse)
         launch_k1(rqs_coupling_kernel<KT, true, BLOCK>, grid, dim3(BLOCK), lds, st, a);
     else
@@ -474,6 +487,7 @@ static int launch_coupling(const CouplingArgs& a, int inverse, dim3 grid, size_t
 
 template <int KT>
 static int launch_pipelined(const CouplingArgs& a, int inverse, dim3 grid, size_t lds, hipStream_t st) {
+    note_layer_kernel("rqs_coupling_pipelined<K=%d, inverse=%d, linear=%d>", KT, inverse ? 1 : 0, a.sp.linear ? 1 : 0);
     if (a.sp.linear) {
         if (inverse)
             launch_k1(rqs_coupling_pipelined<KT, true, true>, grid, dim3(kBlock), lds, st, a);
@@ -692,6 +706,12 @@ extern "C" int nfa_rqs_elementwise_f32(const float* inputs, const float* uw, int
     }
 }
 
+
+extern "C" int nfa_last_layer_kernel(char* buffer, int32_t capacity) {
+    if (capacity < 0 || (capacity > 0 && !buffer)) return NFA_ERR_INVALID_ARGUMENT;
+    if (capacity > 0) snprintf(buffer, (size_t)capacity, "%s", g_last_layer_kernel);
+    return (int)strlen(g_last_layer_kernel);
+}
 
 extern "C" int nfa_profile_enable(int32_t max_launches) {
     if (max_launches < 0) return NFA_ERR_INVALID_ARGUMENT;

@@ -206,7 +206,7 @@ struct FusedSteps {
                 float c = d0 * t1;
                 c = __builtin_fmaf(delta + delta, t1mt, c);
                 c = __builtin_fmaf(d1, th * th, c);
-                t5 = (delta * delta) * c;                                 // den^2 g' / in_h
+                t5 = (delta * delta) * c;                                 // den^2 g' / in_w
                 const float r0 = __builtin_amdgcn_rcpf(den);
                 const float r = __builtin_fmaf(__builtin_fmaf(-den, r0, 1.0f), r0, r0);
                 const float q = t0 * r;
@@ -218,7 +218,11 @@ struct FusedSteps {
                 // i.e. every step came out scaled by 1 / delta: right for the near-identity splines of an untrained
                 // flow (delta ~ 1), up to 80 x the reference's error on steep ones.  Found by running this file on
                 // the CPU against the reference's vectors: tests/test_rqs_f32_host.py.)
+#ifdef NFA_MUTATION_NEWTON_SLOPE   // (tools/build_variant.sh only: the round-3 defect restored, which tests/test_gpu_steep.py must FAIL)
+                const float slope = in_h * t5;
+#else
                 const float slope = in_w * t5;                            // g' den^2
+#endif
                 const float r0 = __builtin_amdgcn_rcpf(slope);
                 const float r = __builtin_fmaf(__builtin_fmaf(-slope, r0, 1.0f), r0, r0);
                 const float step = (t2 * den) * (den * r);

@@ -325,6 +325,7 @@ extern "C" int nfa_rqs_coupling_fused_linear_f32(const float* inputs, const floa
     hipStream_t st = (hipStream_t)stream;
     const dim3 block(kBlock);
     const bool inverse = (flags & NFA_FLAG_INVERSE) != 0;
+    note_layer_kernel("%s<inverse=%d>", split_bf16 ? "rqs_fused_linear_bf16_kernel" : "rqs_fused_linear_kernel", inverse ? 1 : 0);
     const size_t ybytes = (size_t)(kBlock / kWave) * 32 * (num_transform | 1) * sizeof(float);
     if (split_bf16) {
         int64_t blocks = batch >> 7;

@@ -815,6 +815,9 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 2, 8, true> : rqs_resnet_kernel<false, 1, 4, 2, 8, true>;
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 2, 8, true> : rqs_resnet_kernel<false, 1, 2, 2, 8, true>;
     }
+    if (!redo)
+        note_layer_kernel("rqs_resnet_kernel<inverse=%d, init_ks=%d, pipe=%d, K=%d, ctx=%d>", inv ? 1 : 0, init_ks,
+                          pipe ? use_pipe : 0, a.sp.K, with_ctx ? 1 : 0);
     if (with_ctx && lds > 64 * 1024) {
         static unsigned long long raised_ctx[8] = {};   // device masks (raise_dynamic_lds)
         const int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (a.sp.K == 10 ? 4 : 0);

@@ -974,6 +974,8 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
         case 14: kern = k8h::rqs_resnet_f16_kernel<false, 4, 8, 10>; break;
         default: kern = k8h::rqs_resnet_f16_kernel<true, 4, 8, 10>; break;
     }
+    note_layer_kernel("k8h::rqs_resnet_f16_kernel<inverse=%d, init_ks=%d, waves=%d, K=%d, ctx=%d, ring=%d>", inv ? 1 : 0,
+                      init_ks, nw, a.sp.K, with_ctx ? 1 : 0, elastic ? k8h::kRingElastic : k8h::kRing);
     if (lds_launch > 64 * 1024) {
         static unsigned long long raised[28] = {};   // device masks (raise_dynamic_lds)
         {

@@ -638,6 +638,7 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float* inputs, const v
         case 10: kern = k8s::rqs_resnet_f16s_kernel<false, 2, 4, 4>; break;
         default: kern = k8s::rqs_resnet_f16s_kernel<true, 2, 4, 4>; break;
     }
+    note_layer_kernel("k8s::rqs_resnet_f16s_kernel<inverse=%d, init_ks=%d, waves=%d, K=8, ring=%d>", inv ? 1 : 0, init_ks, nw, ring);
     if (half) NFA_HIP_CHECK(hipMemsetAsync(redo_blocks, 0, (size_t)(batch / 128) * sizeof(int32_t), st));
     if (lds_launch > 64 * 1024) {
         static unsigned long long raised[12] = {};   // device masks (raise_dynamic_lds)

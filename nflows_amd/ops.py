@@ -1759,3 +1759,12 @@ def rqs_coupling_fused_linear(inputs, hidden, weight_packed, bias_padded, transf
     N.check(rc)
     _after_spline(spec, inverse, dev)
     return out, lad
+
+
+def last_layer_kernel():
+    """Name of the layer kernel this thread launched last (`nfa_last_layer_kernel`): the launchers pick the instance
+    from the batch, the CU count and the LDS budget."""
+    import ctypes
+    buf = ctypes.create_string_buffer(192)
+    N.load().nfa_last_layer_kernel(buf, 192)
+    return buf.value.decode()

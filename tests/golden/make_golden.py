@@ -1007,6 +1007,121 @@ def conditional_flow_case():
     print("flows_context: 1 case")
 
 
+def steep_flow_cases():
+    """Flows whose conditioner outputs are STEEP, as after training (round 4; every earlier whole-flow fixture is
+    near-identity in the inverse direction, which hid a Newton step scaled by 1 / delta for two rounds):
+    tests/helpers.py:steepen multiplies the width / height rows of every conditioner's output layer until the logits
+    the spline sees are ~ N(0, 2), the derivative rows likewise.  Forward (x -> z, logabsdet, log_prob) and INVERSE
+    (noise -> x, logabsdet) of the reference in fp32 and fp64.  Weights are rebuilt from the seed + steepen() (the
+    drop-in classes consume the RNG like the reference's); per-parameter checksums and the measured logit spreads
+    are stored."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import steepen
+    out = {}
+    meta = []
+
+    def logit_spread(flow, x, K, divisor):
+        spread = []
+
+        def hook(m, i, o):
+            p = o.reshape(o.shape[0], -1, 3 * K - 1)
+            spread.append((float((p[..., :2 * K] / divisor).std()), float(p[..., 2 * K:].std())))
+        hooks = [t.register_forward_hook(hook) for t in nets(flow)]
+        with torch.no_grad():
+            flow._transform(x)
+        for h in hooks:
+            h.remove()
+        return spread
+
+    def nets(flow):
+        for t in flow._transform._transforms:
+            if hasattr(t, "transform_net"):
+                yield t.transform_net
+            elif hasattr(t, "autoregressive_net"):
+                yield t.autoregressive_net
+
+    def finish(name, flow, x, noise, cfg):
+        flow.eval()
+        with torch.no_grad():
+            lp = flow.log_prob(x)
+            z, lad = flow._transform(x)
+            xs, lad_inv = flow._transform.inverse(noise)
+            f64 = flow.double()
+            lp64 = f64.log_prob(x.double())
+            z64, lad64 = f64._transform(x.double())
+            xs64, ladi64 = f64._transform.inverse(noise.double())
+            flow.float()
+        for k, v in dict(x=x, noise=noise, log_prob=lp, z=z, lad=lad, inv_x=xs, inv_lad=lad_inv,
+                         log_prob64=lp64, z64=z64, lad64=lad64, inv_x64=xs64, inv_lad64=ladi64).items():
+            assert torch.isfinite(v).all(), (name, k)
+            out[name + "/" + k] = npy(v)
+        names, sums = [], []
+        for k, v in flow.state_dict().items():
+            names.append(k)
+            sums.append([float(v.double().sum()), float(v.double().abs().sum())])
+        out[name + "/param_names"] = np.array(names).astype(str)
+        out[name + "/param_checksums"] = np.array(sums, dtype=np.float64)
+        meta.append((name, repr(cfg)))
+        print(name, "reference fp32 error vs fp64: z max %.2e mean %.2e | inverse x max %.2e mean %.2e"
+              % (float((z.double() - z64).abs().max()), float((z.double() - z64).abs().mean()),
+                 float((xs.double() - xs64).abs().max()), float((xs.double() - xs64).abs().mean())))
+
+    # the BASELINE layer shape, 8 and 10 bins
+    for name, seed, L, K, wh, ds, hs in (("steep_nsf_k8", 21, 6, 8, 40.0, 4.0, 10.0), ("steep_nsf_k10", 22, 4, 10, 40.0, 4.0, 10.0)):
+        D, H, B = 64, 128, 512
+        torch.manual_seed(seed)
+        layers = []
+        for i in range(L):
+            layers.append(RandomPermutation(D))
+            layers.append(PiecewiseRationalQuadraticCouplingTransform(
+                mask=torchutils.create_alternating_binary_mask(D, even=(i % 2 == 0)),
+                transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=H, num_blocks=2),
+                num_bins=K, tails="linear", tail_bound=3.0))
+        flow = Flow(CompositeTransform(layers), StandardNormal([D]))
+        steepen(flow, K, wh, ds, hs)
+        g = torch.Generator().manual_seed(seed + 100)
+        x = torch.randn(B, D, generator=g)
+        noise = torch.randn(B, D, generator=g)
+        spread = logit_spread(flow.eval(), x, K, float(np.sqrt(H)))
+        finish(name, flow, x, noise, dict(kind="rq_nsf", L=L, D=D, K=K, H=H, B=B, tail_bound=3.0, seed=seed,
+                                          wh_scale=wh, d_scale=ds, hidden_scale=hs,
+                                          logit_std_wh_d_per_layer=[(round(a, 3), round(b, 3)) for a, b in spread]))
+
+    # affine analogue (configs[1]'s layer: AffineCouplingTransform + MLP [128, 128]): scale logits ~ N(0, 2)
+    seed, L, D, B, ds = 23, 4, 32, 512, 8.0
+    torch.manual_seed(seed)
+    layers = []
+    for i in range(L):
+        layers.append(AffineCouplingTransform(
+            mask=torchutils.create_alternating_binary_mask(D, even=(i % 2 == 0)),
+            transform_net_create_fn=lambda i_, o_: MLPConditioner(i_, o_, [128, 128])))
+    flow = Flow(CompositeTransform(layers), StandardNormal([D]))
+    steepen(flow, None, d_scale=ds)
+    g = torch.Generator().manual_seed(seed + 100)
+    finish("steep_affine", flow, torch.randn(B, D, generator=g), torch.randn(B, D, generator=g),
+           dict(kind="affine", L=L, D=D, hidden=[128, 128], B=B, seed=seed, d_scale=ds))
+
+    # autoregressive RQ layer (configs[4]'s transform, shrunk): MADE has no hidden_features attribute, so the logits
+    # are not divided (autoregressive.py:464-466)
+    seed, D, K, H, B, wh, ds = 24, 40, 8, 64, 256, 10.0, 10.0
+    torch.manual_seed(seed)
+    t = MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
+        features=D, hidden_features=H, num_bins=K, tails="linear", tail_bound=3.0, num_blocks=2)
+    flow = Flow(CompositeTransform([t]), StandardNormal([D]))
+    steepen(flow, K, wh, ds)
+    g = torch.Generator().manual_seed(seed + 100)
+    x = 1.5 * torch.randn(B, D, generator=g)
+    noise = torch.randn(B, D, generator=g)
+    spread = logit_spread(flow.eval(), x, K, 1.0)
+    finish("steep_ar_rq", flow, x, noise,
+           dict(kind="ar_rq", D=D, K=K, H=H, B=B, tail_bound=3.0, num_blocks=2, seed=seed, wh_scale=wh, d_scale=ds,
+                logit_std_wh_d_per_layer=[(round(a, 3), round(b, 3)) for a, b in spread]))
+
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "flows_steep.npz"), **out)
+    print("flows_steep:", len(meta), "cases")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ar":
         sibling_autoregressive_cases()
@@ -1031,6 +1146,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "grads":
         grad_cases()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "steep":
+        steep_flow_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cdf":
         cdf_cases()
         sys.exit(0)
@@ -1049,3 +1167,4 @@ if __name__ == "__main__":
     cubic_spline_cases()
     cubic_coupling_cases()
     sibling_autoregressive_cases()
+    steep_flow_cases()

@@ -10,7 +10,10 @@ ground truth `truth` is therefore asserted as:
 
   (a) bulk agreement: >= 99% of finite elements satisfy |got-ref| <= 2e-6 * (1 + |ref|)
       (outputs) / 2e-5 * (1 + |ref|) (log-dets);
-  (b) worst case: max|got-truth| <= 4 * max|ref-truth| + 2e-6 (outputs), + 2e-5 (log-dets);
+  (b) worst case: max|got-truth| <= 4 * max|ref-truth| + 2e-6 (outputs), + 2e-5 (log-dets) -- and, since round 4,
+      the MEAN and the 99.9 % QUANTILE of |got-truth| <= 2 x the reference-fp32's own (`assert_error_ratio`; floor:
+      half an fp32 ulp of the typical magnitude): a maximum is set by the reference's one worst ill-conditioned
+      element and hides a 10-80 x inflation of the typical element (the Newton-slope defect of round 3 passed (b));
   (c) identical NaN / inf pattern, and elements the reference passes through unchanged
       (tails) are bit-equal.
 Integer / index work (permutations, untouched columns) is compared with array_equal.
@@ -68,6 +71,34 @@ def conditioning(fn64, args, perturb, draws=3, seed=0):
     return worst if len(worst) > 1 else worst[0]
 
 
+def error_stats(err):
+    err = np.asarray(err, dtype=np.float64).reshape(-1)
+    return {"max": float(err.max()), "mean": float(err.mean()), "q999": float(np.quantile(err, 0.999))}
+
+
+def assert_error_ratio(got, ref, truth, what="", factor=2.0, max_factor=4.0, max_floor=0.0):
+    """err(got vs float64) <= `factor` x err(reference fp32 vs float64) on the mean and the 99.9 % quantile,
+    `max_factor` x (+ `max_floor`) on the maximum.  Floor on mean / quantile: half an fp32 ulp of the mean magnitude
+    (an fp32 result cannot be asked to sit closer to the truth than its own rounding; it matters only for vectors on
+    which the reference's fp32 happens to be exact).  Returns the figures."""
+    got, ref, truth = (np.asarray(a) for a in (got, ref, truth))
+    fin = np.isfinite(ref) & np.isfinite(truth) & np.isfinite(got)
+    if not fin.any():
+        return None
+    t64 = truth[fin].astype(np.float64)
+    e_got = error_stats(np.abs(got[fin].astype(np.float64) - t64))
+    e_ref = error_stats(np.abs(ref[fin].astype(np.float64) - t64))
+    floor = 2.0 ** -24 * float(np.abs(t64).mean())
+    for k in ("mean", "q999"):
+        # (below 10 000 elements the 99.9 % quantile IS one of the ten worst elements: it gets the maximum's factor)
+        f = max_factor if (k == "q999" and t64.size < 10000) else factor
+        assert e_got[k] <= f * e_ref[k] + floor, (
+            "%s: %s error vs float64 %.3e exceeds %.1f x the reference fp32's %.3e" % (what, k, e_got[k], f, e_ref[k]))
+    assert e_got["max"] <= max_factor * e_ref["max"] + max_floor + floor, (
+        "%s: max error vs float64 %.3e exceeds %.1f x the reference fp32's %.3e" % (what, e_got["max"], max_factor, e_ref["max"]))
+    return {"got": e_got, "reference": e_ref}
+
+
 def assert_fp32_parity(got, ref, truth, tol, what="", bulk=0.999, factor=4.0, cond=None, cond_factor=32.0):
     """Parity of an fp32 result `got` with the reference's fp32 `ref`, given the float64 truth.
     Always: identical NaN / inf pattern, and the worst case max |got - truth| <= factor * max |ref - truth|
@@ -112,6 +143,8 @@ def assert_fp32_parity(got, ref, truth, tol, what="", bulk=0.999, factor=4.0, co
         assert frac_truth >= bulk, "%s: only %.5f of elements within their allowance of the fp64 result" % (what, frac_truth)
         assert frac_ref >= bulk, "%s: only %.5f of elements within twice their allowance of the reference" % (what, frac_ref)
     assert worst_ok, "%s: max err vs fp64 %.3e, reference fp32's own %.3e" % (what, e_got.max(), e_ref.max())
+    # mean and 99.9 % quantile at the 2 x rule (round 4); the maximum stays the rule above
+    assert_error_ratio(got, ref, truth, what, factor=2.0, max_factor=factor, max_floor=tol * (1 + np.abs(t64).max()))
 
 
 def parse_kwargs(text):
@@ -162,3 +195,54 @@ def golden_conditional_flow(golden_dir):
         assert abs(float(v.sum()) - total) <= 1e-9 * (1 + abs(total)), n_
         assert abs(float(v.abs().sum()) - absolute) <= 1e-9 * (1 + absolute), n_
     return flow.eval(), g, str(name)
+
+
+def steepen(module, num_bins=None, wh_scale=1.0, d_scale=1.0, hidden_scale=1.0):
+    """Turns a freshly initialised (near-identity) flow into one with STEEP splines, as after training: every
+    conditioner's output layer (`final_layer`, rows per transformed feature [w_0..w_{K-1}, h_0..h_{K-1}, d_1..d_{K-1}],
+    coupling.py:289, 550-552) gets its width / height rows multiplied by `wh_scale` and its derivative rows by
+    `d_scale`; `num_bins=None`: an affine coupling's [shift | scale logit] halves (coupling.py:235-236), the second
+    half by `d_scale`.  `hidden_scale` multiplies the second Linear of every residual block (non-trivial hidden
+    activations).  Works on the reference's modules and on the drop-in classes alike (same parameter names):
+    tests/golden/make_golden.py and the tests call this one function."""
+    import torch
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if "linear_layers.1" in name:
+                p.mul_(hidden_scale)
+            elif "final_layer" in name or "_output_layer" in name:   # (ResidualNet / MADE; MLP: mlp.py:45)
+                if num_bins is None:
+                    p[p.shape[0] // 2:].mul_(d_scale)
+                else:
+                    P = 3 * num_bins - 1
+                    assert p.shape[0] % P == 0, (name, tuple(p.shape))
+                    v = p.view(p.shape[0] // P, P, *p.shape[1:])
+                    v[:, :2 * num_bins].mul_(wh_scale)
+                    v[:, 2 * num_bins:].mul_(d_scale)
+    return module
+
+
+def steep_flow(golden_dir, name):
+    """A flow of tests/golden/flows_steep.npz rebuilt from its seed and `steepen` (weights are not stored; the
+    per-parameter checksums of the reference's weights are, and are checked here).  Returns (flow on CPU, npz, cfg)."""
+    import torch
+    from nflows_amd import configs
+    g = np.load(os.path.join(golden_dir, "flows_steep.npz"))
+    cfg = parse_kwargs(dict((str(n), str(c)) for n, c in g["meta"])[name])
+    if cfg["kind"] == "rq_nsf":
+        flow = configs.rq_nsf_flow(cfg["L"], cfg["D"], cfg["K"], cfg["H"], 2, cfg["tail_bound"], seed=cfg["seed"])
+        steepen(flow, cfg["K"], cfg["wh_scale"], cfg["d_scale"], cfg["hidden_scale"])
+    elif cfg["kind"] == "affine":
+        flow = configs.affine_coupling_flow(cfg["L"], cfg["D"], tuple(cfg["hidden"]), seed=cfg["seed"])
+        steepen(flow, None, d_scale=cfg["d_scale"])
+    elif cfg["kind"] == "ar_rq":
+        flow = configs.ar_rq_flow(cfg["D"], cfg["H"], cfg["K"], cfg["tail_bound"], cfg["num_blocks"], seed=cfg["seed"])
+        steepen(flow, cfg["K"], cfg["wh_scale"], cfg["d_scale"])
+    else:
+        raise KeyError(cfg["kind"])
+    # (the affine fixture's conditioner is the reference's MLP behind an (inputs, context) wrapper: other parameter
+    #  NAMES, the same values in the same order)
+    sums = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in flow.state_dict().values()])
+    want = g[name + "/param_checksums"]
+    assert sums.shape == want.shape and np.allclose(sums, want, rtol=1e-12, atol=0), "seeded weights differ from the reference's: " + name
+    return flow.eval(), g, cfg

@@ -58,11 +58,13 @@ def load_state(flow, g, name):
 
 
 def check(got, ref32, ref64, what, tol):
-    got = got.detach().cpu().numpy().astype(np.float64)
-    e_got = np.abs(got - ref64).max()
-    e_ref = np.abs(ref32.astype(np.float64) - ref64).max()
+    """Reference vectors with a float64 truth: the maximum within 4 x the reference-fp32's own error + tol x scale, and
+    (round 4) the mean and the 99.9 % quantile within 2 x (helpers.assert_error_ratio) -- a maximum alone is set by the
+    reference's worst ill-conditioned element and let a mis-scaled Newton step through for two rounds."""
+    from helpers import assert_error_ratio
+    got = got.detach().cpu().numpy()
     scale = 1 + np.abs(ref64).max()
-    assert e_got <= 4 * e_ref + tol * scale, "%s: err vs fp64 %.3e (reference fp32: %.3e)" % (what, e_got, e_ref)
+    assert_error_ratio(got, ref32, ref64, what, factor=2.0, max_factor=4.0, max_floor=tol * scale)
 
 
 @pytest.mark.parametrize("fuse", [True, False])

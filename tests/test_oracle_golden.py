@@ -162,6 +162,27 @@ def test_eager_port_is_bit_identical_to_reference(golden_dir):
         assert np.array_equal(ladi.numpy(), gf[name + "/inv_lad"]), name
 
 
+def test_eager_port_bit_identical_on_steep_flows(golden_dir):
+    """tests/golden/flows_steep.npz (round 4): flows with STEEP splines -- logits ~ N(0, 2) as after training --, forward
+    and inverse of the real reference.  The weights rebuilt from seed + helpers.steepen carry the reference's checksums
+    and the eager port reproduces z, logabsdet, log_prob and the inverse pass bit for bit: the GPU tests of
+    tests/test_gpu_steep.py may extend the fixture's 512 rows with the port's own evaluation."""
+    import torch
+    from helpers import steep_flow
+    from oracle import eager
+    torch.set_num_threads(1)
+    for name in ("steep_nsf_k8", "steep_nsf_k10", "steep_affine", "steep_ar_rq"):
+        flow, g, cfg = steep_flow(golden_dir, name)
+        with torch.no_grad():
+            z, lad = eager.flow_transform(flow, torch.from_numpy(g[name + "/x"]))
+            lp = eager.flow_log_prob(flow, torch.from_numpy(g[name + "/x"]))
+            xi, ladi = eager.flow_transform(flow, torch.from_numpy(g[name + "/noise"]), inverse=True)
+        for got, key in ((z, "z"), (lad, "lad"), (lp, "log_prob"), (xi, "inv_x"), (ladi, "inv_lad")):
+            assert np.array_equal(got.numpy(), g[name + "/" + key]), (name, key)
+        if "logit_std_wh_d_per_layer" in cfg:   # the fixture is what it claims to be: logits of spread >= 1
+            assert min(min(pair) for pair in cfg["logit_std_wh_d_per_layer"]) > 1.0, name
+
+
 def test_eager_port_other_configs_bit_identical(golden_dir):
     """The eager port on the affine stack (configs[1]'s layer type) and on the autoregressive RQ layer
     (configs[4]) in both directions -- the latter's inverse is the reference's D-pass loop -- : bit-identical to the reference, in float32
