@@ -368,6 +368,9 @@ def main():
     # 128-row blocks of the last timed step that left the f16 range and were redone by the exact kernel
     # (K8h only; 0 = the whole batch ran on the measured kernel)
     redo_blocks = ops.last_redo_blocks() if args.path == "k8" else None
+    # the instance the library launched last in the timed region (the launchers choose it from the rank's batch, the
+    # CU count and the LDS budget: at N = 8 a rank's 32 768 rows run K8s, not K8h)
+    timed_kernel = ops.last_layer_kernel()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -508,9 +511,10 @@ def main():
         timing_note = ("HIP start/stop events attached to each layer-kernel dispatch on its launch "
                        "stream (hipExtLaunchKernelGGL), all launches of the timed region")
 
-        def roofline_of(path, ms, launches_per_step):
+        def roofline_of(path, ms, launches_per_step, ran=None):
             """`launches_per_step` layer-kernel dispatches make one step of `args.layers` layers: 32
-            (one layer per launch) or 1 (the run of K8 layers in a single launch)."""
+            (one layer per launch) or 1 (the run of K8 layers in a single launch).  `ran`: the kernel name the
+            library reported (nfa_last_layer_kernel) -- `kernel` is then that name, not a guess."""
             avg_ms, launches = sum(ms) / len(ms), len(ms)
             layers_per_launch = args.layers / launches_per_step
             common = {"avg_launch_ms": avg_ms, "launches_timed": launches, "layers_per_launch": layers_per_launch,
@@ -536,7 +540,7 @@ def main():
                 kernel = ("nfa::k8h::rqs_resnet_f16_kernel<false, 2, %d, 8, false, %d>" % (8 if nw8 else 4, ring) if f16
                           else "nfa::rqs_resnet_kernel<false, 1, 2, %s, 8, false>" % os.environ.get("NFA_K8_PIPE", "2")) if path == "k8" \
                     else "nfa::rqs_fused_linear_bf16_kernel<false>"
-                r = {"bound": "mfma", "kernel": kernel,
+                r = {"bound": "mfma", "kernel": ("nfa::" + ran) if ran else kernel,
                      "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
                      "traffic": load_traffic(traffic_file),
                      "traffic_from": "profiles/" + traffic_file + " (rocprofv3 --pmc passes of this command, not re-measured in this run)",
@@ -557,19 +561,19 @@ def main():
             elif path == "k7":
                 flops = 2.0 * B * H_ * dt_ * P_
                 ach = flops / (avg_ms * 1e-3) / 1e12
-                r = {"bound": "mfma", "kernel": "nfa::rqs_fused_linear_kernel<false>", "achieved": ach,
+                r = {"bound": "mfma", "kernel": ("nfa::" + ran) if ran else "nfa::rqs_fused_linear_kernel<false>", "achieved": ach,
                      "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
                      "traffic": load_traffic("k7_pmc_traffic.json"), "algorithmic_flops_per_launch": flops,
                      "algorithmic_bytes_per_launch": io_bytes + 4 * B * H_}
             else:
                 ach = k1_bytes / (avg_ms * 1e-3) / 1e9
-                r = {"bound": "hbm", "kernel": "nfa::rqs_coupling_pipelined<8, false, true>", "achieved": ach,
+                r = {"bound": "hbm", "kernel": ("nfa::" + ran) if ran else "nfa::rqs_coupling_pipelined<8, false, true>", "achieved": ach,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                      "traffic": load_traffic("k1_pmc_traffic.json"), "algorithmic_bytes_per_launch": k1_bytes}
             r.update(common)
             return r
 
-        roofline = roofline_of(args.path, k1_ms, len(k1_ms) / args.steps) if k1_ms else None
+        roofline = roofline_of(args.path, k1_ms, len(k1_ms) / args.steps, ran=timed_kernel) if k1_ms else None
         if roofline is not None and roofline.get("bound") == "mfma" and not args.skip_mfma_ceiling:
             ceiling = sustained_mfma_ceiling()
             if ceiling and ceiling.get("gaussian_32x32x16"):
@@ -594,10 +598,11 @@ def main():
                     torch.cuda.synchronize()
                     ms = dispatch_durations_ms(args.layers * 3)
                     _native.check(_native.load().nfa_profile_enable(0))
+                    k1_ran = ops.last_layer_kernel()
             finally:
                 select_path(args.path)
             if ms:
-                roofline_k1 = roofline_of("k1", ms, args.layers)
+                roofline_k1 = roofline_of("k1", ms, args.layers, ran=k1_ran)
                 roofline_k1["note"] = "not in the timed region: PyTorch conditioner + K1 path (--path k1)"
         result = {
             "metric": "log_prob samples/sec (dim=64, K=8, 32-layer RQ-NSF) + max |fwd∘inv − x|",

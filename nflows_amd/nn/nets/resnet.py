@@ -117,12 +117,43 @@ class ConvResidualBlock(_Block):
         self.conv_layers = nn.ModuleList(_conv(width, width, kernel_size=3) for _ in range(2))
 
 
+def _has_inner_hooks(net):
+    """forward / backward hooks on any module INSIDE the net (the net's own hooks run either way)"""
+    for m in net.modules():
+        if m is net:
+            continue
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None):
+            return True
+    return False
+
+
+class fused_training:
+    """`with fused_training(False): ...` -- the eager conditioner modules under autograd inside the block (double
+    backward, autocast experiments, hooks); restores the previous class-level setting on exit."""
+
+    def __init__(self, enabled):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.saved = _Net.fuse_training
+        _Net.fuse_training = self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        _Net.fuse_training = self.saved
+        return False
+
+
 class _Net(nn.Module):
     """first layer (context concatenated to the input if given) -> blocks -> last layer."""
 
     _block = None
     _make = None
-    # K14 for the hidden part under autograd (class-level switch for A/B measurements; NFA_K14=0 turns it off)
+    # K14 for the hidden part under autograd.  Class-level default from NFA_K14 (0 = off); `net.fuse_training = False`
+    # on an instance, or the context manager `nflows_amd.nn.nets.resnet.fused_training(False)`, switch it at run time.
+    # The fused path is once-differentiable (no double backward: gradient penalties / Jacobian regularisers with
+    # create_graph=True need it OFF), computes in fp32 whatever torch.autocast says, and does not run forward hooks of
+    # the inner layers -- so it steps aside by itself while autocast is active or any inner module carries a hook.
     fuse_training = os.environ.get("NFA_K14", "1") != "0"
 
     def _build(self, n_in, n_out, width, context_width, num_blocks, activation, dropout_probability,
@@ -141,6 +172,8 @@ class _Net(nn.Module):
         `ops.resnet_hidden_train_supported` lists."""
         if not (self.fuse_training and type(self) is ResidualNet and context is None and torch.is_grad_enabled()
                 and inputs.is_cuda and inputs.dtype == torch.float32 and inputs.dim() == 2):
+            return False
+        if torch.is_autocast_enabled() or _has_inner_hooks(self):
             return False
         from ... import ops
         if not ops.resnet_hidden_train_supported(inputs.shape[0], inputs.shape[1], self.hidden_features, len(self.blocks)):
@@ -176,7 +209,8 @@ class _Net(nn.Module):
     def forward(self, inputs, context=None):
         final = self.final_layer
         if (self._fused_training(inputs, context) and type(final) is nn.Linear and final.bias is not None
-                and final.out_features % 4 == 0 and final.in_features == self.hidden_features):
+                and final.out_features % 4 == 0 and final.out_features <= 32768   # (the packer's / kernel's limit)
+                and final.in_features == self.hidden_features):
             # the whole conditioner's forward pass in one kernel (K14 with the final Linear appended)
             from ... import autograd as AG
             return AG.ResidualNetHidden.apply(inputs, True, *self._hidden_parameters(), final.weight, final.bias)

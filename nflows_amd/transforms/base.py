@@ -250,6 +250,15 @@ class CompositeTransform(Transform):
                 di_u, len(first.transform_net.blocks), first._spec(), inverse,
                 total, num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob, pad=pad,
                 context=context, tile16=tile16 and first._use_f16(_run_geometry(units)))
+            if head is None and tile16:
+                # K8s declined (its ring + 16-row buffers + two copies of the parameter words exceed the LDS budget:
+                # about six blocks at D = 128): K8h takes these shapes -- its own stream, the same call
+                weights, biases, tables, plan_f16 = self._run_plan(units, inverse, False)
+                if plan_f16 is not None:
+                    head = ops.rqs_coupling_resnet_f16(
+                        inputs, plan_f16, (weights, biases), tables, dt4, di_u, len(first.transform_net.blocks),
+                        first._spec(), inverse, total, num_layers=len(units),
+                        standard_normal_log_prob=standard_normal_log_prob, pad=pad, context=context, tile16=False)
         else:
             head = ops.rqs_coupling_resnet(
                 inputs, weights, biases, tables, dt4, di_u,

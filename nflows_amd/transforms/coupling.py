@@ -44,18 +44,27 @@ class StalePackedWeights(RuntimeError):
     `p.data.copy_(ema)` or `dist.broadcast(p.data)`.  The fused kernels would have used the OLD weights."""
 
 
-# NFA_VERIFY_WEIGHTS=N (0 = off): every N-th use of a conditioner's cache key re-reads a checksum of its
-# parameters on the device (sum and absolute sum per parameter in float64, one synchronising comparison) and
-# raises StalePackedWeights when it differs from the one taken when the key last changed visibly.
-VERIFY_WEIGHTS_EVERY = int(os.environ.get("NFA_VERIFY_WEIGHTS", "0") or 0)
+# NFA_VERIFY_WEIGHTS=N: every N-th use of a conditioner's cache key re-reads a checksum of its parameters on the
+# device (L1 and L2 norm per parameter, two fused launches and one synchronising comparison) and raises
+# StalePackedWeights when it differs from the one taken when the key last changed visibly.  Default (round 4): every
+# 256th use -- amortised ~ 1 us per layer and call; 0 switches it off, 1 checks every call (debugging).  Skipped while
+# a stream is being captured into a HIP graph (the comparison synchronises).
+VERIFY_WEIGHTS_EVERY = int(os.environ.get("NFA_VERIFY_WEIGHTS", "256") or 0)
 
 
 def _checksum(params):
     with torch.no_grad():
-        return torch.stack([torch.stack((p.detach().double().sum(), p.detach().double().abs().sum())) for p in params])
+        params = [p.detach() for p in params]
+        if not params:
+            return torch.zeros(0)
+        if all(p.is_floating_point() for p in params) and len({(p.device, p.dtype) for p in params}) == 1:
+            return torch.stack(list(torch._foreach_norm(params, 1)) + list(torch._foreach_norm(params, 2)))
+        return torch.stack([torch.stack((p.double().abs().sum(), p.double().pow(2).sum())) for p in params]).reshape(-1)
 
 
 def _verify_weights(owner, key, params):
+    if params and params[0].is_cuda and torch.cuda.is_current_stream_capturing():
+        return
     state = owner.__dict__.get("_weights_checksum")
     if state is None or state[0] != key:
         owner.__dict__["_weights_checksum"] = [key, _checksum(params), 0]
@@ -76,8 +85,8 @@ def _weights_key(owner, net):
     registration hooks -- `torch.func.functional_call`, `stateless._reparametrize_module`, a direct
     `module._parameters[name] = other` -- are caught by checking on every call that each held object still IS
     the entry of its module's `_parameters` dict (a dict lookup and an identity test per parameter).  What no key
-    can see is a write through `.data` into the same storage: NFA_VERIFY_WEIGHTS (above) is the debugging aid for
-    that, `nflows_amd.invalidate_packed_weights()` the remedy."""
+    can see is a write through `.data` into the same storage: NFA_VERIFY_WEIGHTS (above; on by default with a period of
+    256 uses) turns that into an exception, `nflows_amd.invalidate_packed_weights()` the remedy."""
     epoch = _cache.epoch()
     held = owner.__dict__.get("_weights_list")
     if held is None or held[0] != epoch or held[1] is not net or not _cache.HOOKED:
@@ -640,9 +649,16 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         tile16 = self._use_f16() and inputs.is_cuda and ops.use_tile16(inputs.shape[0], self.num_bins, context, inputs.device)
         stream = self._f16_stream(tables, tile16) if self._use_f16() else None   # (None: non-finite weights -> exact kernel)
         if stream is not None:
-            return ops.rqs_coupling_resnet_f16(inputs, stream, (wp, bp), tables, dt4, di, nb, spec,
-                                               inverse, accumulate_into, pad=(Dp, pad_value), context=context,
-                                               tile16=tile16)
+            res = ops.rqs_coupling_resnet_f16(inputs, stream, (wp, bp), tables, dt4, di, nb, spec,
+                                              inverse, accumulate_into, pad=(Dp, pad_value), context=context,
+                                              tile16=tile16)
+            if res is None and tile16:   # (K8s over its LDS budget: K8h with its own stream)
+                stream = self._f16_stream(tables, False)
+                if stream is not None:
+                    res = ops.rqs_coupling_resnet_f16(inputs, stream, (wp, bp), tables, dt4, di, nb, spec,
+                                                      inverse, accumulate_into, pad=(Dp, pad_value), context=context,
+                                                      tile16=False)
+            return res
         return ops.rqs_coupling_resnet(inputs, wp, bp, tables, dt4, di, nb, spec, inverse, accumulate_into,
                                        log2e=self._log2e(), context=context, pad=(Dp, pad_value))
 

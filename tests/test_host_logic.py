@@ -1128,6 +1128,7 @@ def test_verify_weights_mode_detects_writes_through_data(monkeypatch):
     import nflows_amd
     from nflows_amd import configs
     from nflows_amd.transforms import coupling as C
+    default_period = C.VERIFY_WEIGHTS_EVERY
     flow = configs.rq_nsf_flow(num_layers=2, features=8, num_bins=8, hidden_features=16, seed=0)
     layer = flow._transform._transforms[1]
     net = layer.transform_net
@@ -1149,6 +1150,22 @@ def test_verify_weights_mode_detects_writes_through_data(monkeypatch):
     assert C._weights_key(layer, net) == k2
     with pytest.raises(C.StalePackedWeights):
         C._weights_key(layer, net)
+    # the default (round 4): ON with a period of 256 uses -- a stale read is an exception within 256 calls, not a
+    # silently wrong density for the rest of the run
+    import os
+    assert "NFA_VERIFY_WEIGHTS" in os.environ or default_period == 256
+    monkeypatch.setattr(C, "VERIFY_WEIGHTS_EVERY", 256)
+    nflows_amd.invalidate_packed_weights()
+    k3 = C._weights_key(layer, net)
+    net.final_layer.bias.data.add_(0.125)
+    raised_at = None
+    for use in range(1, 300):
+        try:
+            assert C._weights_key(layer, net) == k3
+        except C.StalePackedWeights:
+            raised_at = use
+            break
+    assert raised_at == 256, raised_at
 
 
 def test_no_mfma_result_lands_on_its_own_operands():
