@@ -424,6 +424,183 @@ __global__ void __launch_bounds__(kBlock) rqs_elementwise_kernel(const Elementwi
     if (my_status && a.status) atomicOr(a.status, my_status);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// K1, wave-tile form (round 4): linear tails, K = 8 / 10, d_t a power of two <= 64, D = 2 d_t (alternating masks on
+// power-of-two feature counts: the BASELINE shape d_t = 32, D = 64), 16-byte aligned arrays.
+//
+// The pipelined kernel above carries the next tile in 28 VGPRs per lane (101 in all: four waves per SIMD) and its
+// four waves meet at three workgroup barriers per tile; its ~470 VALU instructions per tile then take as long to
+// issue as the tile's bytes take to arrive, and what one phase waits for the other cannot use.  Here a WAVE owns its
+// tiles: 64 splines = 64 / d_t whole samples, whose conditioner output is one contiguous 256 P-byte chunk.
+//   * The chunk comes in by LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction, no staging registers) into the
+//     wave's private LDS image; a lane copies its P consecutive words out (stride P words, P odd: conflict free)
+//     and the DMA of the wave's NEXT tile is requested right behind those reads, into the same image -- in
+//     flight for the whole evaluation.  One buffer per wave: 6 656 bytes (K = 8), so 5-6 waves per SIMD fit.
+//   * No workgroup barrier anywhere: the only waits are the wave's own vmcnt(0) at the top of a tile and lgkmcnt
+//     for its own LDS reads; the other waves of the SIMD fill every gap.
+//   * The tile's 128 inputs are two coalesced dwords per lane; the spline input of a lane is picked from them with
+//     ds_bpermute, pass-through columns and results meet in a 512-byte output image that leaves as one 16-byte
+//     store per lane of the first half wave.  Same rqs_eval, same bits as the pipelined kernel.
+// cache policy of the LDS-DMA requests: nt (aux = 2) -- the conditioner output is read exactly once; measured on the
+// MI355X at 262 144 rows (profiles/r4/k1_wavetile.txt): memory structure alone 178 -> 157 us per layer, the kernel
+// 204 -> 185-197 us
+#ifndef NFA_WT_AUX
+#define NFA_WT_AUX 2
+#endif
+#ifdef NFA_WT_NT_IO   // (experiment: the input / output rows non-temporal as well)
+#define NFA_WT_LOAD(p) __builtin_nontemporal_load(p)
+#define NFA_WT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define NFA_WT_LOAD(p) (*(p))
+#define NFA_WT_STORE(v, p) (*(p) = (v))
+#endif
+
+template <int KT, bool INVERSE>
+__global__ void __launch_bounds__(kBlock) rqs_coupling_wavetile(const CouplingArgs a) {
+    constexpr int P = 3 * KT - 1;
+    constexpr int kTileBytes = 64 * P * 4;
+    constexpr int NI = (kTileBytes + 1023) / 1024;   // DMA instructions per lane and tile
+    constexpr int kWaveLds = NI * 1024 + 512;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* my = reinterpret_cast<char*>(lds) + wave * kWaveLds;
+    float* s_par = reinterpret_cast<float*>(my);
+    float* s_o = reinterpret_cast<float*>(my + NI * 1024);
+    const int D = a.D, dt = a.dt;
+    const int log_dt = __builtin_ctz(dt), log_D = log_dt + 1;
+    const int RW = 64 >> log_dt;                     // samples per wave tile
+    int my_status = 0;
+
+    // ---- tables (once per wave; the parameter image doubles as scratch) -----------------------------
+    int* t_src = reinterpret_cast<int*>(s_par);
+    int* t_dst = t_src + D;
+    int* t_ist = t_dst + D;
+    int* t_inv = t_ist + D;
+    int* t_col = t_inv + D;
+    for (int c = lane; c < D; c += kWave) {
+        int src = c, dst = c;
+        if (a.perm) {
+            const int64_t q = a.perm[c];
+            if (q < 0 || q >= D) my_status |= NFA_STATUS_BAD_INDEX;
+            src = (int)(q < 0 ? 0 : (q >= D ? D - 1 : q));
+        }
+        if (a.scatter) {
+            const int64_t q = a.scatter[c];
+            if (q < 0 || q >= D) my_status |= NFA_STATUS_BAD_INDEX;
+            dst = (int)(q < 0 ? 0 : (q >= D ? D - 1 : q));
+        }
+        t_src[c] = src;
+        t_dst[c] = dst;
+        t_ist[c] = 0;
+        t_inv[c] = 0;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int j = lane; j < dt; j += kWave) {
+        const int64_t t = a.tidx[j];
+        if (t < 0 || t >= D) my_status |= NFA_STATUS_BAD_INDEX;
+        const int col = (int)(t < 0 ? 0 : (t >= D ? D - 1 : t));
+        t_col[j] = col;
+        t_ist[col] = 1;
+    }
+    for (int c = lane; c < D; c += kWave) t_inv[t_src[c]] = c;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // this lane's spline: sample r_i of the tile, transformed feature j
+    const int r_i = lane >> log_dt;
+    const int col = t_col[lane & (dt - 1)];
+    const int e_x = (r_i << log_D) + t_src[col];     // element of the [RW, D] input tile it reads
+    const int x_sel = (e_x & 63) << 2;               // ds_bpermute address of the lane that loaded it
+    const bool x_hi = e_x >= 64;
+    const int y_off = (r_i << log_D) + t_dst[col];
+    // the two input elements this lane loads (e = lane, lane + 64): where they go when their column passes through
+    int pt_off0, pt_off1;
+    bool pt_ok0, pt_ok1;
+    {
+        const int cs0 = lane & (D - 1), c0 = t_inv[cs0];
+        pt_ok0 = !t_ist[c0];
+        pt_off0 = ((lane >> log_D) << log_D) + t_dst[c0];
+        const int e1 = lane + 64, cs1 = e1 & (D - 1), c1 = t_inv[cs1];
+        pt_ok1 = !t_ist[c1];
+        pt_off1 = ((e1 >> log_D) << log_D) + t_dst[c1];
+    }
+    const bool lad_lane = (lane & (dt - 1)) == 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tables are read: the image may be overwritten
+
+    const int64_t num_tiles = a.batch >> (6 - log_dt);   // batch / RW (the host sends whole tiles)
+    const int64_t total_waves = (int64_t)gridDim.x * (kBlock / kWave);
+    int64_t tile = (int64_t)blockIdx.x * (kBlock / kWave) + wave;
+    const unsigned lane_off = (unsigned)lane * 16u;
+
+#ifdef NFA_K1_ABL_NO_MEM
+#define NFA_WT_REQUEST(TILE) {}
+#else
+#define NFA_WT_REQUEST(TILE)                                                                                   \
+    {                                                                                                          \
+        const char* g_ = reinterpret_cast<const char*>(a.params) + (TILE) * (int64_t)kTileBytes;               \
+        _Pragma("unroll") for (int k_ = 0; k_ < NI; ++k_) {                                                    \
+            unsigned o_ = (unsigned)k_ * 1024u + lane_off;                                                     \
+            if (k_ == NI - 1 && (kTileBytes & 1023)) o_ = o_ < (unsigned)kTileBytes - 16u ? o_ : (unsigned)kTileBytes - 16u; \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g_ + o_),         \
+                                             (__attribute__((address_space(3))) void*)(my + k_ * 1024), 16, 0, NFA_WT_AUX); \
+        }                                                                                                      \
+    }
+#endif
+    float xa0 = 0.0f, xa1 = 0.0f, la = 0.0f;
+    if (tile < num_tiles) {
+        NFA_WT_REQUEST(tile)
+        const float* gx = a.x + tile * 128;
+        xa0 = NFA_WT_LOAD(gx + lane);
+        xa1 = NFA_WT_LOAD(gx + lane + 64);
+        if (a.accumulate && lad_lane) la = a.lad[tile * RW + r_i];
+    }
+    for (; tile < num_tiles; tile += total_waves) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this tile's image and inputs have landed
+        float p[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q) p[q] = s_par[lane * P + q];
+        const float xv0 = xa0, xv1 = xa1, lacc = la;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the image is in registers: it may be refilled
+        {
+            int64_t next = tile + total_waves;
+            next = next < num_tiles ? next : tile;                // (past the end: a harmless re-read)
+            NFA_WT_REQUEST(next)
+#ifndef NFA_K1_ABL_NO_MEM
+            const float* gx = a.x + next * 128;
+            xa0 = NFA_WT_LOAD(gx + lane);
+            xa1 = NFA_WT_LOAD(gx + lane + 64);
+            if (a.accumulate && lad_lane) la = a.lad[next * RW + r_i];
+#else
+            xa0 += 0.001f; xa1 -= 0.001f;
+#endif
+        }
+        const float xs0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(x_sel, __builtin_bit_cast(int, xv0)));
+        const float xs1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(x_sel, __builtin_bit_cast(int, xv1)));
+        const float xs = x_hi ? xs1 : xs0;
+        float y, l;
+#ifdef NFA_K1_ABL_NO_EVAL   // (measurement: the kernel's memory structure without the spline arithmetic)
+        y = xs + p[3] + p[P - 1];
+        l = p[5] + p[11];
+#else
+        my_status |= rqs_eval<KT, INVERSE, true, true>(xs, p, a.sp, y, l);
+#endif
+        if (pt_ok0) s_o[pt_off0] = xv0;
+        if (pt_ok1) s_o[pt_off1] = xv1;
+        s_o[y_off] = y;
+        for (int off = dt >> 1; off > 0; off >>= 1) l += __shfl_xor(l, off, kWave);
+#ifdef NFA_K1_ABL_NO_MEM   // (measurement: the arithmetic + LDS traffic without any global memory access in the loop)
+        if (lad_lane && l == 123.456f) a.lad[tile * RW + r_i] = lacc + l;
+        if (lane < 32 && l == 123.456f) reinterpret_cast<vec4*>(a.out + tile * 128)[lane] = reinterpret_cast<const vec4*>(s_o)[lane];
+#else
+        if (lad_lane) a.lad[tile * RW + r_i] = a.accumulate ? lacc + l : l;
+        if (lane < 32) NFA_WT_STORE(reinterpret_cast<const vec4*>(s_o)[lane], reinterpret_cast<vec4*>(a.out + tile * 128) + lane);
+#endif
+    }
+#undef NFA_WT_REQUEST
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (my_status && a.status) atomicOr(a.status, my_status);
+}
+
 // ------------------------------------------------------------------------------------------
 constexpr int kMaxDynLds = 64 * 1024;
 
@@ -481,6 +658,33 @@ static int launch_coupling(const CouplingArgs& a, int inverse, dim3 grid, size_t
         launch_k1(rqs_coupling_kernel<KT, true, BLOCK>, grid, dim3(BLOCK), lds, st, a);
     else
         launch_k1(rqs_coupling_kernel<KT, false, BLOCK>, grid, dim3(BLOCK), lds, st, a);
+    NFA_HIP_CHECK(hipGetLastError());
+    return NFA_OK;
+}
+
+template <int KT>
+static int launch_wavetile(const CouplingArgs& a, int inverse, hipStream_t st) {
+    constexpr int P = 3 * KT - 1;
+    constexpr int kWaveLds = ((64 * P * 4 + 1023) / 1024) * 1024 + 512;
+    const size_t lds = (size_t)(kBlock / kWave) * kWaveLds;
+    void (*kern)(const CouplingArgs) = inverse ? rqs_coupling_wavetile<KT, true> : rqs_coupling_wavetile<KT, false>;
+    // persistent: exactly the workgroups that are resident together (registers and LDS decide)
+    static int per_cu_cache[2] = {0, 0};
+    int& per_cu = per_cu_cache[inverse ? 1 : 0];
+    if (per_cu == 0) {
+        int n = 0;
+        NFA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kBlock, lds));
+        per_cu = n > 0 ? n : 1;
+        const char* e = getenv("NFA_K1_WT_PER_CU");   // (experiments: fewer resident workgroups)
+        if (e && atoi(e) > 0 && atoi(e) < per_cu) per_cu = atoi(e);
+    }
+    const int log_dt = __builtin_ctz((unsigned)a.dt);
+    const int64_t tiles = a.batch >> (6 - log_dt);
+    int64_t g = (int64_t)device_cu_count() * per_cu;
+    const int64_t need = (tiles + kBlock / kWave - 1) / (kBlock / kWave);
+    if (g > need) g = need;
+    note_layer_kernel("rqs_coupling_wavetile<K=%d, inverse=%d> (%d workgroups per CU)", KT, inverse ? 1 : 0, per_cu);
+    launch_k1(kern, dim3((unsigned)g), dim3(kBlock), lds, st, a);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
 }
@@ -616,6 +820,16 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
         const int64_t full_rows = (batch / R) * R;
         CouplingArgs f = a;
         f.batch = full_rows;
+        // wave tiles (LDS-DMA, no workgroup barriers) where the layout allows: linear tails, 8 / 10 bins, d_t a
+        // power of two with D = 2 d_t; NFA_K1_WAVETILE=0 keeps the register-pipelined kernel (A/B runs)
+        const char* wt_env = getenv("NFA_K1_WAVETILE");
+        const bool wavetile = (!wt_env || atoi(wt_env) != 0) && a.sp.linear && (a.sp.K == 8 || a.sp.K == 10) &&
+                              dt >= 4 && dt <= 64 && (dt & (dt - 1)) == 0 && D == 2 * dt && a.sp.P == 3 * a.sp.K - 1 &&
+                              (reinterpret_cast<uintptr_t>(logabsdet) & 3) == 0;
+        if (wavetile && full_rows > 0) {
+            const int wrc = a.sp.K == 8 ? launch_wavetile<8>(f, inverse, st) : launch_wavetile<10>(f, inverse, st);
+            if (wrc != NFA_OK) return wrc;
+        } else {
         // one block fewer per CU than LDS alone would allow: the prefetch registers cost occupancy
         // (K = 4 needs only ~76 VGPRs: 6 waves per SIMD)
         const int pipe_blocks = a.sp.K <= 4 ? 6 : NFA_PIPE_WAVES;
@@ -628,7 +842,9 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
             case 10: prc = launch_pipelined<10>(f, inverse, pgrid, lds, st); break;
             default: prc = launch_pipelined<8>(f, inverse, pgrid, lds, st); break;
         }
-        if (prc != NFA_OK || full_rows == batch) return prc;
+        if (prc != NFA_OK) return prc;
+        }
+        if (full_rows == batch) return NFA_OK;
         // leftover rows (< R): generic kernel on the tail of every array
         a.x = inputs + full_rows * D;
         a.params = params + full_rows * (int64_t)dt * P;

@@ -45,9 +45,17 @@ for i in range(a.reps):
     e.record()
     evs.append((s, e))
 torch.cuda.synchronize()
-ms = sorted(s.elapsed_time(e) for s, e in evs)
+raw = [s.elapsed_time(e) for s, e in evs]
+if os.environ.get("K1_MICRO_PER_BUFFER"):
+    for b in range(nbuf):
+        sub = sorted(raw[b::nbuf])
+        print("   buffer %d (%x): median %.1f us min %.1f max %.1f" % (b, params[b].data_ptr(), sub[len(sub) // 2] * 1e3, sub[0] * 1e3, sub[-1] * 1e3))
+    print("   first 12 reps:", " ".join("%.0f" % (v * 1e3) for v in raw[:12]))
+ms = sorted(raw)
 med = ms[len(ms) // 2]
 nbytes = 4 * (B * D + B * tidx.numel() * P + B * D + B)
-print("%s lib=%s  median %.1f us  min %.1f us  -> %.0f GB/s algorithmic (median)" % (
+print("%s lib=%s %s B=%d  median %.1f us  min %.1f  p10 %.1f  p90 %.1f us  -> %.0f GB/s algorithmic (median)  [%s]" % (
     "inverse" if a.inverse else "forward", os.path.basename(os.environ.get("NFLOWS_AMD_LIB", "default")),
-    med * 1e3, ms[0] * 1e3, nbytes / (med * 1e-3) / 1e9))
+    " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("NFA_K1")), B,
+    med * 1e3, ms[0] * 1e3, ms[len(ms) // 10] * 1e3, ms[(9 * len(ms)) // 10] * 1e3, nbytes / (med * 1e-3) / 1e9,
+    ops.last_layer_kernel()))
