@@ -187,15 +187,9 @@ __global__ void __launch_bounds__(kBlock, 2) affine_mlp_kernel(const AffineMlpAr
                         if (ADDITIVE) {
                             y = INVERSE ? xin - shift : xin + shift;   // scale == 1: exact, logabsdet 0
                         } else {
-                            const float sc = scale_of(acc[8 + j], a.activation);
-                            const float ls = logf(sc);
-                            if (INVERSE) {
-                                y = (xin - shift) / sc;
-                                lad_acc -= ls;
-                            } else {
-                                y = xin * sc + shift;
-                                lad_acc += ls;
-                            }
+                            float l;
+                            affine_element<INVERSE>(xin, shift, scale_of(acc[8 + j], a.activation), y, l);
+                            lad_acc += l;
                         }
                         *slot = y;
                     }

@@ -137,27 +137,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 inline int round_up4(int n) { return (n + 3) & ~3; }
 
-// ---- scale activations of the affine layers (shared by misc.hip and affine_mlp.hip) ----
-__device__ __forceinline__ float softplus1(float x) {
-#pragma clang fp contract(off)
-    return x > 20.0f ? x : log1pf(expf(x));
-}
-
-// scale activations, coupling.py:224-225 / autoregressive.py:101
-__device__ __forceinline__ float scale_of(float u, int activation) {
-#pragma clang fp contract(off)
-    if (activation == NFA_SCALE_DEFAULT) {
-        const float v = u + 2.0f;
-        return 1.0f / (1.0f + expf(-v)) + 1e-3f;
-    } else if (activation == NFA_SCALE_GENERAL) {
-        float s = softplus1(u) + 1e-3f;
-        s = s < 0.0f ? 0.0f : s;  // clamp(0, 3); NaN propagates like aten's clamp
-        s = s > 3.0f ? 3.0f : s;
-        return s;
-    } else {  // NFA_SCALE_SOFTPLUS
-        return softplus1(u) + 1e-3f;
-    }
-}
-
+}  // namespace nfa
+#include "affine_math.hpp"   // scale activations and the per-element map of the affine layers (K2, K2b, K11)
+namespace nfa {
 
 }  // namespace nfa

@@ -120,14 +120,8 @@ __global__ void __launch_bounds__(kBlock) affine_coupling_kernel(const AffineArg
                 const float sc = a.activation == NFA_SCALE_GIVEN
                                      ? s_sc[ms + i]
                                      : scale_of(s_p[mp + r * pc + dt + j], a.activation);
-                const float ls = logf(sc);
-                if (a.inverse) {
-                    y = (xin - shift) / sc;
-                    l = -ls;
-                } else {
-                    y = xin * sc + shift;
-                    l = ls;
-                }
+                if (a.inverse) affine_element<true>(xin, shift, sc, y, l);
+                else affine_element<false>(xin, shift, sc, y, l);
             }
             s_o[r * D + s_dst[col]] = y;
             s_lad[i] = l;
@@ -162,15 +156,12 @@ __global__ void __launch_bounds__(kBlock) affine_ar_kernel(const float* __restri
         for (int c = lane; c < D; c += kWave) {
             const float2 p = *reinterpret_cast<const float2*>(params + (b * D + c) * 2);
             const float sc = scale_of(p.x, NFA_SCALE_SOFTPLUS);
-            const float ls = logf(sc);
             const float xv = x[b * D + c];
-            if (inverse) {
-                out[b * D + c] = (xv - p.y) / sc;
-                acc -= ls;
-            } else {
-                out[b * D + c] = sc * xv + p.y;
-                acc += ls;
-            }
+            float y, l;
+            if (inverse) affine_element<true>(xv, p.y, sc, y, l);
+            else affine_element<false>(xv, p.y, sc, y, l);
+            out[b * D + c] = y;
+            acc += l;
         }
         acc = wave_sum(acc);
         if (lane == 0) lad[b] = acc;

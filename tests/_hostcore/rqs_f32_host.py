@@ -52,6 +52,28 @@ static int backward_all(int64_t n, const RqsDev& sp, const float* x, const float
     return status;
 }
 
+// the register-array form (REGS = true: K12's per-step evaluation, made_inverse.hip, and K1's wave-tile kernel, rqs.hip):
+// same arithmetic, the two derivative logits picked by a select chain instead of a dynamic index
+template <int KT, bool INVERSE>
+static int forward_regs_all(int64_t n, const RqsDev& sp, const float* x, const float* params, float* y, float* lad) {
+    int status = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        float p[3 * KT - 1];
+        memcpy(p, params + i * sp.P, sizeof p);
+        status |= rqs_eval<KT, INVERSE, true, true>(x[i], p, sp, y[i], lad[i]);
+    }
+    return status;
+}
+
+extern "C" int host_rqs_forward_regs(int kt, int inverse, int64_t n, const nfa_rqs_spec* spec, const float* x,
+                                     const float* params, float* y, float* lad) {
+    RqsDev sp;
+    if (make_dev_spec(spec, &sp) != NFA_OK || !sp.linear || sp.K != kt || sp.P != 3 * kt - 1) return -1;
+    if (kt == 8) return inverse ? forward_regs_all<8, true>(n, sp, x, params, y, lad) : forward_regs_all<8, false>(n, sp, x, params, y, lad);
+    if (kt == 10) return inverse ? forward_regs_all<10, true>(n, sp, x, params, y, lad) : forward_regs_all<10, false>(n, sp, x, params, y, lad);
+    return -1;
+}
+
 #define DISPATCH(FN, ...)                                                                                     \
     do {                                                                                                      \
         const bool lin = sp.linear != 0;                                                                      \
@@ -214,6 +236,8 @@ def build(out_dir):
     lib = ctypes.CDLL(so)
     p, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
     lib.host_rqs_forward.argtypes = [i32, i32, i64, p, p, p, p, p]
+    lib.host_rqs_forward_regs.argtypes = [i32, i32, i64, p, p, p, p, p]
+    lib.host_rqs_forward_regs.restype = i32
     lib.host_rqs_backward.argtypes = [i32, i32, i64, p, p, p, p, p, p, p]
     lib.host_rqs_forward_flat8.argtypes = [i32, i64, p, p, p, p, p]
     lib.host_rqs_forward_flatsteps.argtypes = [i32, i32, i64, p, p, p, p, p]

@@ -50,6 +50,8 @@ def test_forward_values_of_the_kernel_source_match_the_reference(lib, golden_dir
         cy, cl = conditioning(lambda *a: capi.rqs_elementwise(*a, ospec, inverse=inverse)[:2], (x, uw, uh, ud), (0, 1, 2, 3))
         xs, pr = np.ascontiguousarray(x.reshape(-1)), packed(uw, uh, ud)
         instances = [0] + ([K] if K in (4, 8, 10) else [])
+        if kw.get("tails") == "linear" and K in (8, 10) and pr.shape[1] == 3 * K - 1:
+            instances += ["regs"]   # the register-array form: K12's per-step evaluation, K1's wave-tile kernel
         if kw.get("tails") == "linear":   # the whole-layer kernels' evaluations: flat (K7 / K8 plain loop), sliced (K8)
             instances += ["flat8"] if K == 8 else []
             if not kw.get("enable_identity_init"):   # (the sliced form is built for softplus beta = 1: the coupling
@@ -58,7 +60,14 @@ def test_forward_values_of_the_kernel_source_match_the_reference(lib, golden_dir
                     instances += ["fused1.0", "fused0.125"]
         for kt in instances:
             y, lad = np.empty_like(xs), np.empty_like(xs)
-            if kt == "flat8":
+            if kt == "regs":
+                status = lib.host_rqs_forward_regs(K, int(inverse), xs.size, ctypes.byref(spec), P(xs), P(pr), P(y), P(lad))
+                y_lds, lad_lds = np.empty_like(xs), np.empty_like(xs)
+                lib.host_rqs_forward(K, int(inverse), xs.size, ctypes.byref(spec), P(xs), P(pr), P(y_lds), P(lad_lds))
+                # the same bits as the LDS form (only the pick of the two derivative logits differs)
+                assert np.array_equal(y.view(np.uint32), y_lds.view(np.uint32)), name
+                assert np.array_equal(lad.view(np.uint32), lad_lds.view(np.uint32)), name
+            elif kt == "flat8":
                 status = lib.host_rqs_forward_flat8(int(inverse), xs.size, ctypes.byref(spec), P(xs), P(pr), P(y), P(lad))
             elif str(kt).startswith("fused"):
                 status = lib.host_rqs_forward_fused(int(inverse), float(kt[5:]), xs.size, ctypes.byref(spec), P(xs), P(pr),
