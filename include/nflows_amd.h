@@ -741,6 +741,21 @@ int nfa_linear_wgrad_f32(const float *inputs, const float *grad_outputs, float *
                          int32_t out_features, int32_t flags, void *stream);
 
 /*
+ * The same for `count` (1 .. 8) Linear layers of ONE shape in one launch pair (round 4: the four 128 x 128 layers of a
+ * ResidualNet conditioner's two blocks -- resnet.py:44, :49 under autograd).  The problems share the chip: each gets
+ * 1 / count of the batch slices a lone problem would get, i.e. `count` times fewer partial results to write and to
+ * sum and a `count` times longer stream per workgroup (the ring's two-stage ramp is paid once per 32 stages instead
+ * of once per 8 at B = 65 536).  inputs / grad_outputs / grad_weight / grad_bias: HOST arrays of `count` device
+ * pointers (grad_bias may be NULL, or hold NULLs: no bias gradient for those layers); workspace:
+ * nfa_linear_wgrad_batched_workspace_bytes(count, ...) bytes.  Results are bit-identical from call to call (fixed
+ * summation order), not to the single-problem entry point (another number of slices).
+ */
+size_t nfa_linear_wgrad_batched_workspace_bytes(int32_t count, int64_t batch, int32_t in_features, int32_t out_features);
+int nfa_linear_wgrad_batched_f32(int32_t count, const float *const *inputs, const float *const *grad_outputs,
+                                 float *const *grad_weight, float *const *grad_bias, void *workspace, int64_t batch,
+                                 int32_t in_features, int32_t out_features, int32_t flags, void *stream);
+
+/*
  * Measurement aids (bench.py, tools/), not part of the data path; the library's only global state.
  *
  * While enabled, every launch of a coupling-layer kernel (nfa_rqs_coupling_f32, _fused_linear_f32,

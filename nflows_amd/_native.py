@@ -74,6 +74,8 @@ EXPORTS = (
     "nfa_sum_count_workspace_bytes",
     "nfa_linear_wgrad_workspace_bytes",
     "nfa_linear_wgrad_f32",
+    "nfa_linear_wgrad_batched_workspace_bytes",
+    "nfa_linear_wgrad_batched_f32",
     "nfa_profile_enable",
     "nfa_profile_collect",
     "nfa_last_layer_kernel",
@@ -199,6 +201,10 @@ def _declare(lib):
     lib.nfa_linear_wgrad_workspace_bytes.argtypes = [i64, i32, i32]
     lib.nfa_linear_wgrad_f32.restype = ctypes.c_int
     lib.nfa_linear_wgrad_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
+    lib.nfa_linear_wgrad_batched_workspace_bytes.restype = ctypes.c_size_t
+    lib.nfa_linear_wgrad_batched_workspace_bytes.argtypes = [i32, i64, i32, i32]
+    lib.nfa_linear_wgrad_batched_f32.restype = ctypes.c_int
+    lib.nfa_linear_wgrad_batched_f32.argtypes = [i32, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
     lib.nfa_profile_enable.restype = ctypes.c_int
     lib.nfa_profile_enable.argtypes = [i32]
     lib.nfa_profile_collect.restype = ctypes.c_int

@@ -9,6 +9,8 @@ GPU; there is no CPU path here either.
 """
 import ctypes
 
+import os
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -296,6 +298,10 @@ class Linear(torch.autograd.Function):
         return g_in, (g_w if need_w else None), g_b
 
 
+# K10 for the hidden Linears of a conditioner in one launch pair (A/B switch: NFA_K10_BATCHED=0)
+BATCHED_WGRAD = os.environ.get("NFA_K10_BATCHED", "1") != "0"
+
+
 class ResidualNetHidden(torch.autograd.Function):
     """K14: a ResidualNet (initial Linear + residual blocks, and with `with_final` the final Linear: resnet.py:92-100)
     under autograd -- `nfa_resnet_hidden_forward_f32` forward, `nfa_resnet_hidden_backward_f32` for the chain of input
@@ -362,10 +368,23 @@ class ResidualNetHidden(torch.autograd.Function):
         di = ctx.di if ctx.di != x.shape[1] else None      # (x was saved with its pad columns)
         out = [(g_x if di is None else g_x[:, :di]) if ctx.needs_input_grad[0] else None, None]
         out += wgrad(x, grads[0] if nb else g_hidden, need[0], need[1], rows=narrow, cols=di)
+        # the 2 nb hidden Linears (all 128 -> 128 inside the padded arrays): ONE launch pair of K10 when every gradient
+        # is wanted (a training step), layer by layer otherwise
+        hidden_problems = []
         for k in range(nb):
-            out += wgrad(saved[2 * k], grads[2 * k + 1], need[2 + 4 * k], need[3 + 4 * k], rows=narrow, cols=narrow)
-            out += wgrad(saved[2 * k + 1], grads[2 * k + 2] if k + 1 < nb else g_hidden, need[4 + 4 * k], need[5 + 4 * k],
-                         rows=narrow, cols=narrow)
+            hidden_problems.append((saved[2 * k], grads[2 * k + 1]))
+            hidden_problems.append((saved[2 * k + 1], grads[2 * k + 2] if k + 1 < nb else g_hidden))
+        batched = None
+        if nb and all(need[2:2 + 4 * nb]) and 2 * nb <= 8 and BATCHED_WGRAD:
+            batched = ops.linear_wgrad_batched(hidden_problems, need_bias=True)
+        if batched is not None:
+            for g_w, g_b in batched:
+                if narrow is not None:
+                    g_w, g_b = g_w[:narrow, :narrow].contiguous(), g_b[:narrow].contiguous()
+                out += (g_w, g_b)
+        else:
+            for q, (inp, g_o) in enumerate(hidden_problems):
+                out += wgrad(inp, g_o, need[2 + 2 * q], need[3 + 2 * q], rows=narrow, cols=narrow)
         return tuple(out) + tuple(tail)
 
 

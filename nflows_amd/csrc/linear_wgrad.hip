@@ -30,10 +30,12 @@ namespace nfa {
 constexpr int kWgRows = 32;  // batch rows per stage
 constexpr int kWgRing = 3;
 
+constexpr int kWgMaxProblems = 8;   // same-shaped problems per launch (nfa_linear_wgrad_batched_f32)
+
 struct WgradArgs {
-    const float* x;   // [B, I]
-    const float* gy;  // [B, O]
-    float* ws;        // [ksplit][O*I + O]
+    const float* x[kWgMaxProblems];   // [B, I] per problem (blockIdx.z)
+    const float* gy[kWgMaxProblems];  // [B, O]
+    float* ws;        // [problems][ksplit][O*I + O]
     int I, O;
     int stages_total;  // full 32-row stages of the batch
     int ksplit;
@@ -66,8 +68,9 @@ __global__ void __launch_bounds__(kBlock) wgrad_partial_kernel(const WgradArgs a
     int col_a = ob + (tid % VA) * 4, col_b = ib + (tid % VB) * 4;
     if (col_a > O - 4) col_a = O - 4;
     if (col_b > I - 4) col_b = I - 4;
-    const float* src_a = a.gy + (int64_t)(tid / VA) * O + col_a;
-    const float* src_b = a.x + (int64_t)(tid / VB) * I + col_b;
+    const int pz = blockIdx.z;   // the problem of a batched launch
+    const float* src_a = a.gy[pz] + (int64_t)(tid / VA) * O + col_a;
+    const float* src_b = a.x[pz] + (int64_t)(tid / VB) * I + col_b;
     constexpr int rows_per_req_a = kBlock / VA, rows_per_req_b = kBlock / VB;
 
     auto request = [&](int stage, int slot) {
@@ -142,7 +145,7 @@ __global__ void __launch_bounds__(kBlock) wgrad_partial_kernel(const WgradArgs a
         slot = slot + 1 == kWgRing ? 0 : slot + 1;
     }
 
-    float* out = a.ws + (int64_t)kz * ((int64_t)O * I + O);
+    float* out = a.ws + ((int64_t)pz * a.ksplit + kz) * ((int64_t)O * I + O);
 #pragma unroll
     for (int to = 0; to < TO; ++to) {
         const int o0 = ob + wo * 32 * TO + to * 32;
@@ -163,11 +166,22 @@ __global__ void __launch_bounds__(kBlock) wgrad_partial_kernel(const WgradArgs a
 }
 
 // grad_weight / grad_bias = sum over slices (fixed order) + the rows behind the last full stage
-__global__ void __launch_bounds__(kBlock) wgrad_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ x,
-                                                              const float* __restrict__ gy, float* __restrict__ gw,
-                                                              float* __restrict__ gb, int I, int O, int ksplit,
-                                                              int64_t tail_begin, int64_t batch) {
+struct WgradReduceArgs {
+    const float* x[kWgMaxProblems];
+    const float* gy[kWgMaxProblems];
+    float* gw[kWgMaxProblems];
+    float* gb[kWgMaxProblems];   // null: no bias gradient for that problem
+};
+
+__global__ void __launch_bounds__(kBlock) wgrad_reduce_kernel(const float* __restrict__ ws_all, const WgradReduceArgs ra, int I,
+                                                              int O, int ksplit, int64_t tail_begin, int64_t batch) {
     __shared__ float part[4][64];
+    const int pz = blockIdx.y;
+    const float* __restrict__ x = ra.x[pz];
+    const float* __restrict__ gy = ra.gy[pz];
+    float* __restrict__ gw = ra.gw[pz];
+    float* __restrict__ gb = ra.gb[pz];
+    const float* __restrict__ ws = ws_all + (int64_t)pz * ksplit * ((int64_t)O * I + O);
     const int tid = threadIdx.x, lane = tid & 63, p = tid >> 6;
     const int64_t n_w = (int64_t)O * I, stride = n_w + O;
     const int64_t n = gb ? stride : n_w;
@@ -206,14 +220,16 @@ struct WgradPlan {
     int blocks_o, blocks_i, stages_total, ksplit;
 };
 
-static WgradPlan plan_wgrad(int64_t batch, int I, int O) {
+// `count` same-shaped problems share the chip: fewer batch slices each (fewer partial results to write and to sum,
+// a longer stream per workgroup: the two-stage ramp of the ring is paid once per 32 stages instead of once per 8)
+static WgradPlan plan_wgrad(int64_t batch, int I, int O, int count = 1) {
     WgradPlan p;
     p.variant = I <= 32 ? 1 : 0;
     const int BO = 128, BI = p.variant ? 32 : 128;
     p.blocks_o = (O + BO - 1) / BO;
     p.blocks_i = (I + BI - 1) / BI;
     p.stages_total = (int)(batch / kWgRows);
-    int ks = device_cu_count() / (p.blocks_o * p.blocks_i);
+    int ks = device_cu_count() / (p.blocks_o * p.blocks_i * (count > 0 ? count : 1));
     if (ks < 1) ks = 1;
     if (ks > p.stages_total) ks = p.stages_total;
     p.ksplit = ks;
@@ -224,35 +240,56 @@ static WgradPlan plan_wgrad(int64_t batch, int I, int O) {
 
 using namespace nfa;
 
-extern "C" size_t nfa_linear_wgrad_workspace_bytes(int64_t batch, int32_t in_features, int32_t out_features) {
-    if (batch < 0 || in_features < 1 || out_features < 1) return 0;
-    const WgradPlan p = plan_wgrad(batch, in_features, out_features);
-    return (size_t)(p.ksplit > 0 ? p.ksplit : 1) * ((size_t)out_features * in_features + out_features) * sizeof(float);
+extern "C" size_t nfa_linear_wgrad_batched_workspace_bytes(int32_t count, int64_t batch, int32_t in_features,
+                                                           int32_t out_features) {
+    if (count < 1 || count > kWgMaxProblems || batch < 0 || in_features < 1 || out_features < 1) return 0;
+    const WgradPlan p = plan_wgrad(batch, in_features, out_features, count);
+    return (size_t)count * (p.ksplit > 0 ? p.ksplit : 1) * ((size_t)out_features * in_features + out_features) * sizeof(float);
 }
 
-extern "C" int nfa_linear_wgrad_f32(const float* inputs, const float* grad_outputs, float* grad_weight,
-                                    float* grad_bias, void* workspace, int64_t batch, int32_t in_features,
-                                    int32_t out_features, int32_t flags, void* stream) {
-    if (flags != 0 || batch < 0 || in_features < 1 || out_features < 1) return NFA_ERR_INVALID_ARGUMENT;
-    if (!grad_weight || (batch > 0 && (!inputs || !grad_outputs))) return NFA_ERR_INVALID_ARGUMENT;
+extern "C" size_t nfa_linear_wgrad_workspace_bytes(int64_t batch, int32_t in_features, int32_t out_features) {
+    return nfa_linear_wgrad_batched_workspace_bytes(1, batch, in_features, out_features);
+}
+
+extern "C" int nfa_linear_wgrad_batched_f32(int32_t count, const float* const* inputs, const float* const* grad_outputs,
+                                            float* const* grad_weight, float* const* grad_bias, void* workspace,
+                                            int64_t batch, int32_t in_features, int32_t out_features, int32_t flags,
+                                            void* stream) {
+    if (flags != 0 || batch < 0 || in_features < 1 || out_features < 1 || count < 1 || count > kWgMaxProblems)
+        return NFA_ERR_INVALID_ARGUMENT;
+    if (!inputs || !grad_outputs || !grad_weight) return NFA_ERR_INVALID_ARGUMENT;
     const int I = in_features, O = out_features;
-    if ((I & 3) || (O & 3) || (reinterpret_cast<uintptr_t>(inputs) & 15) || (reinterpret_cast<uintptr_t>(grad_outputs) & 15))
-        return NFA_ERR_UNSUPPORTED;  // (the LDS-DMA moves aligned 16-byte pieces of a row)
+    if ((I & 3) || (O & 3)) return NFA_ERR_UNSUPPORTED;  // (the LDS-DMA moves aligned 16-byte pieces of a row)
+    for (int q = 0; q < count; ++q) {
+        if (!grad_weight[q] || (batch > 0 && (!inputs[q] || !grad_outputs[q]))) return NFA_ERR_INVALID_ARGUMENT;
+        if ((reinterpret_cast<uintptr_t>(inputs[q]) & 15) || (reinterpret_cast<uintptr_t>(grad_outputs[q]) & 15))
+            return NFA_ERR_UNSUPPORTED;
+    }
     if ((int64_t)O * I + O > (int64_t)1 << 30) return NFA_ERR_UNSUPPORTED;
-    const WgradPlan p = plan_wgrad(batch, I, O);
+    const WgradPlan p = plan_wgrad(batch, I, O, count);
     if (p.ksplit > 0 && !workspace) return NFA_ERR_INVALID_ARGUMENT;
     hipStream_t st = (hipStream_t)stream;
+    WgradReduceArgs r;
+    for (int q = 0; q < kWgMaxProblems; ++q) {
+        const int s_ = q < count ? q : 0;
+        r.x[q] = inputs[s_];
+        r.gy[q] = grad_outputs[s_];
+        r.gw[q] = grad_weight[s_];
+        r.gb[q] = grad_bias ? grad_bias[s_] : nullptr;
+    }
     if (p.ksplit > 0) {
         WgradArgs a;
-        a.x = inputs;
-        a.gy = grad_outputs;
+        for (int q = 0; q < kWgMaxProblems; ++q) {
+            a.x[q] = r.x[q];
+            a.gy[q] = r.gy[q];
+        }
         a.ws = static_cast<float*>(workspace);
         a.I = I;
         a.O = O;
         a.stages_total = p.stages_total;
         a.ksplit = p.ksplit;
         a.blocks_i = p.blocks_i;
-        const dim3 grid((unsigned)(p.blocks_o * p.blocks_i), (unsigned)p.ksplit);
+        const dim3 grid((unsigned)(p.blocks_o * p.blocks_i), (unsigned)p.ksplit, (unsigned)count);
         if (p.variant == 0) {
             constexpr size_t lds = (size_t)kWgRing * kWgRows * (128 + 128) * 4;
             static unsigned long long raised = 0;   // device mask (raise_dynamic_lds: the opt-in is per device)
@@ -265,10 +302,16 @@ extern "C" int nfa_linear_wgrad_f32(const float* inputs, const float* grad_outpu
         }
         NFA_HIP_CHECK(hipGetLastError());
     }
-    const int64_t n = (int64_t)O * I + (grad_bias ? O : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(kBlock), 0, st,
-                       static_cast<const float*>(workspace), inputs, grad_outputs, grad_weight, grad_bias, I, O,
-                       p.ksplit, (int64_t)p.stages_total * kWgRows, batch);
+    const int64_t n = (int64_t)O * I + O;   // (problems without a bias gradient skip the last O elements themselves)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)count), dim3(kBlock), 0, st,
+                       static_cast<const float*>(workspace), r, I, O, p.ksplit, (int64_t)p.stages_total * kWgRows, batch);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
+}
+
+extern "C" int nfa_linear_wgrad_f32(const float* inputs, const float* grad_outputs, float* grad_weight,
+                                    float* grad_bias, void* workspace, int64_t batch, int32_t in_features,
+                                    int32_t out_features, int32_t flags, void* stream) {
+    return nfa_linear_wgrad_batched_f32(1, &inputs, &grad_outputs, &grad_weight, &grad_bias, workspace, batch, in_features,
+                                        out_features, flags, stream);
 }

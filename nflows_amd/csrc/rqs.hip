@@ -826,9 +826,20 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
         const bool wavetile = (!wt_env || atoi(wt_env) != 0) && a.sp.linear && (a.sp.K == 8 || a.sp.K == 10) &&
                               dt >= 4 && dt <= 64 && (dt & (dt - 1)) == 0 && D == 2 * dt && a.sp.P == 3 * a.sp.K - 1 &&
                               (reinterpret_cast<uintptr_t>(logabsdet) & 3) == 0;
-        if (wavetile && full_rows > 0) {
+        const int64_t wt_rows = wavetile ? (batch >> (6 - __builtin_ctz((unsigned)dt))) << (6 - __builtin_ctz((unsigned)dt)) : 0;
+        if (wavetile && wt_rows > 0) {
+            // whole wave tiles (64 / d_t rows each); the < 64 / d_t rows behind them go to the generic kernel below
+            f.batch = wt_rows;
             const int wrc = a.sp.K == 8 ? launch_wavetile<8>(f, inverse, st) : launch_wavetile<10>(f, inverse, st);
             if (wrc != NFA_OK) return wrc;
+            if (wt_rows == batch) return NFA_OK;
+            a.x = inputs + wt_rows * D;
+            a.params = params + wt_rows * (int64_t)dt * P;
+            a.out = outputs + wt_rows * D;
+            a.lad = logabsdet + wt_rows;
+            a.batch = batch - wt_rows;
+            return a.sp.K == 10 ? launch_coupling<10, kBlock>(a, inverse, dim3(1), lds, st)
+                                : launch_coupling<8, kBlock>(a, inverse, dim3(1), lds, st);
         } else {
         // one block fewer per CU than LDS alone would allow: the prefetch registers cost occupancy
         // (K = 4 needs only ~76 VGPRs: 6 waves per SIMD)

@@ -788,6 +788,45 @@ def linear_wgrad(inputs, grad_outputs, need_bias=True):
     return gw, gb
 
 
+def linear_wgrad_batched(problems, need_bias=True):
+    """K10 for several Linear layers of ONE shape in one launch pair (`nfa_linear_wgrad_batched_f32`: the four
+    128 x 128 layers of a ResidualNet conditioner).  `problems`: [(inputs [B, I], grad_outputs [B, O]), ...], at most 8.
+    Returns [(grad_weight, grad_bias or None), ...], or None when the shape has no kernel."""
+    import ctypes
+    if not 1 <= len(problems) <= 8:
+        raise ValueError("1 .. 8 problems per launch")
+    B, I = problems[0][0].shape
+    O = problems[0][1].shape[1]
+    if I % 4 or O % 4:
+        return None
+    xs, gys = [], []
+    for x, gy in problems:
+        N.require_device_f32("inputs", x, 2)
+        N.require_device_f32("grad_outputs", gy, 2)
+        if tuple(x.shape) != (B, I) or tuple(gy.shape) != (B, O):
+            raise ValueError("the problems of one launch share one shape")
+        x, gy = x.contiguous(), gy.contiguous()
+        xs.append(x.clone() if x.data_ptr() % 16 else x)
+        gys.append(gy.clone() if gy.data_ptr() % 16 else gy)
+    dev = xs[0].device
+    lib = N.load()
+    n = len(problems)
+    gws = torch.empty(n, O, I, dtype=torch.float32, device=dev)
+    gbs = torch.empty(n, O, dtype=torch.float32, device=dev) if need_bias else None
+    ws = torch.empty(max(1, lib.nfa_linear_wgrad_batched_workspace_bytes(n, B, I, O) // 4), dtype=torch.float32, device=dev)
+    arr = ctypes.c_void_p * n
+    a_x = arr(*[t.data_ptr() for t in xs])
+    a_gy = arr(*[t.data_ptr() for t in gys])
+    a_gw = arr(*[gws[q].data_ptr() for q in range(n)])
+    a_gb = arr(*[gbs[q].data_ptr() for q in range(n)]) if need_bias else None
+    with torch.cuda.device(dev):
+        rc = lib.nfa_linear_wgrad_batched_f32(n, a_x, a_gy, a_gw, a_gb, N.ptr(ws), B, I, O, 0, N.stream_handle(dev))
+    if rc == N.ERR_UNSUPPORTED:
+        return None
+    N.check(rc)
+    return [(gws[q], gbs[q] if need_bias else None) for q in range(n)]
+
+
 def rqs_shared(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, spec,
                inverse=False):
     """K6 -- rational-quadratic CDF transform with batch-shared logits [*shape, K]; inputs

@@ -55,7 +55,11 @@ static int run(const float* dv, const std::vector<float>& hv, float scale, unsig
             // (the low piece of an overflowed high piece is NaN / -inf either way: any NaN payload counts as equal)
             const unsigned short a0 = a[i] & 0xffff, a1 = a[i] >> 16, r0 = r[i] & 0xffff, r1 = r[i] >> 16;
             auto nan16 = [](unsigned short x) { return (x & 0x7c00) == 0x7c00 && (x & 0x3ff); };
-            const bool same0 = a0 == r0 || (nan16(a0) && nan16(r0)), same1 = a1 == r1 || (nan16(a1) && nan16(r1));
+            // (and the sign of a zero: the fused form computes v * scale + 0, which turns -0 into +0; a zero piece
+            //  contributes nothing to a product either way)
+            auto zero16 = [](unsigned short x) { return (x & 0x7fff) == 0; };
+            const bool same0 = a0 == r0 || (nan16(a0) && nan16(r0)) || (zero16(a0) && zero16(r0));
+            const bool same1 = a1 == r1 || (nan16(a1) && nan16(r1)) || (zero16(a1) && zero16(r1));
             if (same0 && same1) continue;
             if (bad < 5) printf("  relu %d guard %d scale %g: pair %d word %d: function %08x plain %08x (v = %g, %g)\n", RELU, GUARD, scale,
                                 i / 2, i % 2, a[i], r[i], hv[2 * (i / 2)], hv[2 * (i / 2) + 1]);

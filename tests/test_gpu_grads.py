@@ -537,6 +537,39 @@ def test_linear_wgrad_kernel(B, I, O):
         ops.linear_wgrad(x, gyd)
 
 
+@pytest.mark.parametrize("B,I,O,count", [(65536, 128, 128, 4), (4100, 128, 128, 4), (8192, 32, 128, 2), (2048, 128, 736, 3),
+                                          (37, 64, 64, 8), (4096, 128, 128, 1)])
+def test_batched_linear_wgrad_kernel(B, I, O, count):
+    """K10 for several same-shaped layers in one launch pair (round 4: the four hidden Linears of a conditioner):
+    every problem against the float64 product with the single-problem rule (at most 4x as far from it as the
+    library's fp32 GEMM), deterministic from call to call, per-problem bias switch, and within rounding of the
+    single-problem entry point (another number of batch slices: other summation order)."""
+    from nflows_amd import ops
+    g = torch.Generator().manual_seed(B + I + O + count)
+    probs = []
+    for q in range(count):
+        x = torch.randn(B, I, generator=g) * (0.5 + q)
+        gy = torch.randn(B, O, generator=g) * torch.rand(1, O, generator=g)
+        probs.append((x, gy))
+    dev = [(x.to(DEV), gy.to(DEV)) for x, gy in probs]
+    got = ops.linear_wgrad_batched(dev)
+    again = ops.linear_wgrad_batched(dev)
+    no_bias = ops.linear_wgrad_batched(dev, need_bias=False)
+    for q, ((x, gy), (xd, gyd)) in enumerate(zip(probs, dev)):
+        gw64 = (gy.double().t() @ x.double()).numpy()
+        gb64 = gy.double().sum(0).numpy()
+        close_to_truth(got[q][0], (gyd.t() @ xd).cpu().numpy(), gw64, "grad_weight %d" % q, tol=2e-6)
+        close_to_truth(got[q][1], gyd.sum(0).cpu().numpy(), gb64, "grad_bias %d" % q, tol=2e-6)
+        assert torch.equal(got[q][0], again[q][0]) and torch.equal(got[q][1], again[q][1])
+        assert no_bias[q][1] is None and torch.equal(no_bias[q][0], got[q][0])
+        single = ops.linear_wgrad(xd, gyd)
+        scale = 1.0 + float(single[0].abs().max())
+        assert float((single[0] - got[q][0]).abs().max()) <= 2e-5 * scale
+    with pytest.raises(ValueError):
+        ops.linear_wgrad_batched(dev + [(dev[0][0][:, :4], dev[0][1])])
+    assert ops.linear_wgrad_batched([(torch.randn(B, I + 1, device=DEV), dev[0][1])]) is None
+
+
 def test_conditioner_training_gradients_through_wgrad_kernel(monkeypatch):
     """ResidualNet / MLP / MADE under autograd: parameter and input gradients with K10 in the loop
     equal those of the plain library path."""

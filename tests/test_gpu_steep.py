@@ -14,7 +14,7 @@ only, which the reference's own worst ill-conditioned element dominates.  Here
     is amplified chaotically and the defect below drowned in the reference's own error;
   * every engine that can run the layer is driven explicitly and the kernel that actually ran is read back from the
     library (`nfa_last_layer_kernel`): K8h eight-wave and four-wave, K8s eight-wave and four-wave, K8, K7b, K7,
-    GEMMs + K1; K11 and K2 for the affine analogue; K13 / K12 (+ the column-wise path) for the autoregressive layer;
+    GEMMs + K1 (wave-tile and register-pipelined form); K11 and K2 for the affine analogue; K13 / K12 (+ the column-wise path) for the autoregressive layer;
   * the rule is the headline rule (tests/test_gpu_headline_parity.compare): error against float64 at most 2 x the
     reference-fp32's own on the MEAN and the 99.9 % QUANTILE with no floor (4 x + four ulps on the single worst
     element);
@@ -135,7 +135,9 @@ def _nsf_engines(K):
         "k8h_w8": (dict(path="k8", engine="f16x2"), 65536, True, ("k8h::", "waves=8", "K=%d" % K)),
         "k8h_w4": (dict(path="k8", engine="f16x2"), 16384, False, ("k8h::", "waves=4", "K=%d" % K)),
         "k8": (dict(path="k8", engine="bf16x3"), 16384, True, ("rqs_resnet_kernel<", "K=%d" % K)),
-        "gemm_k1": (dict(path="none", engine="f16x2"), 16384, True, ("rqs_coupling_pipelined<K=%d" % K,)),
+        "gemm_k1": (dict(path="none", engine="f16x2"), 16384, True, ("rqs_coupling_wavetile<K=%d" % K,)),
+        "gemm_k1_pipelined": (dict(path="none", engine="f16x2", env={"NFA_K1_WAVETILE": "0"}), 16384, True,
+                              ("rqs_coupling_pipelined<K=%d" % K,)),
     }
     if K == 8:
         e.update({
@@ -159,8 +161,14 @@ def engine_switches():
         RQ.final_linear_engine = "f32" if path == "k7" else "bf16x3"
         RQ.conditioner_engine = engine
         ops.K8S_ENABLED = k8s
+    saved_env = {k: os.environ.get(k) for k in ("NFA_K1_WAVETILE",)}
     yield select
     RQ.fuse_conditioner, RQ.fuse_final_linear, RQ.final_linear_engine, RQ.conditioner_engine, ops.K8S_ENABLED = saved
+    for k, v in saved_env.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 @pytest.mark.parametrize("case,engine", [("steep_nsf_k8", e) for e in _nsf_engines(8)] +
@@ -176,6 +184,7 @@ def test_steep_coupling_flow_on_every_engine(golden_dir, engine_switches, case, 
     o = _oracle(case, flow_cpu, x, noise)
     flow = copy.deepcopy(flow_cpu).to(DEV).eval()
     engine_switches(switches["path"], switches["engine"], k8s)
+    os.environ.update(switches.get("env", {}))      # (read by the launcher at every launch)
     _status(case, clear=True)
     ran = {}
     with torch.no_grad():
@@ -224,6 +233,7 @@ def test_steep_affine_flow(golden_dir, engine):
     noise = _batch(g, case, "noise", 16384, cfg["D"])
     o = _oracle(case, flow_cpu, x, noise)
     flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+    _status(case, clear=True)
     saved = AC.fuse_conditioner
     try:
         AC.fuse_conditioner = engine == "k11"
@@ -256,6 +266,7 @@ def test_steep_autoregressive_layer(golden_dir, engine):
     try:
         o = _oracle(case, flow_cpu, x, noise, rows=4096)
         flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+        _status(case, clear=True)
         AR.fuse_output_layer = engine == "k13_k12"
         AR.fuse_sequential_inverse = engine == "k13_k12"
         with torch.no_grad():

@@ -37,3 +37,8 @@ for I, O in ((32, 128), (128, 128), (128, 736)):
     t_k = timeit(lambda: ops.linear_wgrad(x, gy))
     t_l = timeit(lambda: (gy.t() @ x, gy.sum(0)))
     print("| %d -> %d | %.1f | %.1f | %.1f | %.0f |" % (I, O, t_k, t_l, 2.0 * B * I * O / t_k / 1e6, 4.0 * B * (I + O) / t_k / 1e3))
+# round 4: the four 128 x 128 layers of a conditioner in ONE launch pair (nfa_linear_wgrad_batched_f32)
+probs = [(torch.randn(B, 128, device=dev), torch.randn(B, 128, device=dev)) for _ in range(4)]
+t4 = timeit(lambda: [ops.linear_wgrad(x_, gy_) for x_, gy_ in probs])
+tb = timeit(lambda: ops.linear_wgrad_batched(probs))
+print("four 128 -> 128 layers: one by one %.1f us, batched %.1f us (%.1f fp32 TFLOP/s)" % (t4, tb, 4 * 2.0 * B * 128 * 128 / tb / 1e6))
