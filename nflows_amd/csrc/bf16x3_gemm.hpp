@@ -49,13 +49,7 @@ __device__ __forceinline__ void stream_advance(WeightStream& sm) {
     sm.slot = (sm.slot + 1 == kRing) ? 0 : sm.slot + 1;
 }
 
-#define NFA_MFMA6(acc, ah, am, al, bh, bm, bl)                                        \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);              \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);              \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);              \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);              \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);              \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0)
+// (NFA_MFMA6, the six products of a k-step, and their order: fused_common.hpp)
 
 typedef unsigned uvec4 __attribute__((ext_vector_type(4)));
 

@@ -4,6 +4,33 @@
 
 #include "rqs_math.hpp"
 
+// Order of the six products.  A v_mfma_f32_32x32x16 whose SECOND operand (srcB: the activation pieces here) differs from
+// the previous instruction's takes ~49 cycles instead of 32 when the two are issued back to back (round 4,
+// tools/mfma_toggle_probe.hip: srcB new on every MFMA 1 192 TFLOP/s at 983 W -- not the power cap --, new on every
+// 4th 1 677 at the cap; a new srcA costs nothing).  NFA_BF16X3_ORDER 1 groups the products by their srcB piece
+// (bh, bh, bh, bm, bm, bl: three changes per k-step instead of six); 0 is the round-1 order (small terms first).
+#ifndef NFA_BF16X3_ORDER
+#define NFA_BF16X3_ORDER 0
+#endif
+#if NFA_BF16X3_ORDER == 0
+#define NFA_MFMA6(acc, ah, am, al, bh, bm, bl)                                        \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);              \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);              \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);              \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);              \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);              \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0)
+#else
+#define NFA_MFMA6(acc, ah, am, al, bh, bm, bl)                                        \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);              \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);              \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);              \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);              \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);              \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0)
+#endif
+
+
 namespace nfa {
 
 // debug aid (tools/k7_trace.py, tools/k8_trace.py): device buffer of 512 uint64 that lane 0 of

@@ -245,12 +245,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_fused_linear_bf16_kernel(const 
                     const bf16x8 nm = __builtin_bit_cast(bf16x8, cur[(1 * 8 + kn) * 64]);
                     const bf16x8 nl = __builtin_bit_cast(bf16x8, cur[(2 * 8 + kn) * 64]);
                     // smallest products first
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[ks], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[ks], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[ks], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], acc[t], 0, 0, 0);
+                    NFA_MFMA6(acc[t], ah, am, al, bh[ks], bm[ks], bl[ks]);   // (bf16x3_gemm.hpp: product order)
                     ah = nh;
                     am = nm;
                     al = nl;

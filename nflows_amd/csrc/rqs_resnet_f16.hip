@@ -252,6 +252,10 @@ struct SplineWeave10 {
     }
 };
 
+#ifndef NFA_K8H_ORDER
+#define NFA_K8H_ORDER 0   // 1: the srcB-grouped order of the three products of a cell (round-4 experiment: no gain, profiles/r4/k8h_mfma_order.txt)
+#endif
+
 // ---- one 32-row output tile: 8 k-steps x 3 products, two stages, a weave slice behind every MFMA
 template <int KS, class W, class SM>
 __device__ __forceinline__ void tile_kstep(f32x16& acc, uvec4 bhw, uvec4 blw, Frags& fr, unsigned cur, unsigned nxt, W& w, SM& sm) {
@@ -265,10 +269,14 @@ __device__ __forceinline__ void tile_kstep(f32x16& acc, uvec4 bhw, uvec4 blw, Fr
 #else
     (void)nf;
 #endif
-    // (smallest terms first)
+    // Order of the three products (round 4): the matrix pipe's energy depends on how often its SECOND operand (srcB: the
+    // activation pieces here) CHANGES between consecutive instructions -- tools/mfma_toggle_probe.hip under the power cap:
+    // srcB new on every MFMA 1 219 TFLOP/s, on every 4th 1 616, never 1 662; a new srcA (the weights) costs nothing --,
+    // and K8h runs at that cap.  The two products on bh are therefore adjacent (bh, bh, bl: two changes per k-step
+    // instead of three).
+#if NFA_K8H_ORDER == 0   // (round 3: smallest terms first)
     acc = NFA_K8H_MFMA(al, bh, acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-
     NFA_K8H_WEAVE(w.template step<KS * 3 + 0>());
     __builtin_amdgcn_sched_barrier(0);
     acc = NFA_K8H_MFMA(ah, bl, acc, 0, 0, 0);
@@ -276,6 +284,17 @@ __device__ __forceinline__ void tile_kstep(f32x16& acc, uvec4 bhw, uvec4 blw, Fr
     NFA_K8H_WEAVE(w.template step<KS * 3 + 1>());
     __builtin_amdgcn_sched_barrier(0);
     acc = NFA_K8H_MFMA(ah, bh, acc, 0, 0, 0);
+#else
+    acc = NFA_K8H_MFMA(al, bh, acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    NFA_K8H_WEAVE(w.template step<KS * 3 + 0>());
+    __builtin_amdgcn_sched_barrier(0);
+    acc = NFA_K8H_MFMA(ah, bh, acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    NFA_K8H_WEAVE(w.template step<KS * 3 + 1>());
+    __builtin_amdgcn_sched_barrier(0);
+    acc = NFA_K8H_MFMA(ah, bl, acc, 0, 0, 0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     NFA_K8H_WEAVE(w.template step<KS * 3 + 2>());
     __builtin_amdgcn_sched_barrier(0);
@@ -309,15 +328,19 @@ __device__ __forceinline__ void kstep_pair_woven(f32x16 (&acc)[4], uvec4 bh0, uv
         await_frags(fr);                                                                         \
         const f16x8 ah = __builtin_bit_cast(f16x8, fr.h), al = __builtin_bit_cast(f16x8, fr.l);  \
         NFA_K8H_KEEP_FRAGS(fr, nf)                                                               \
-        acc[T] = NFA_K8H_MFMA(al, BH, acc[T], 0, 0, 0);                \
+        /* srcB order (see tile_kstep): even cells bh, bh, bl -- odd cells bl, bh, bh: the four cells of a k-step  */ \
+        /* share their pieces, so srcB changes four times per twelve MFMAs instead of eight                          */ \
+        acc[T] = (NFA_K8H_ORDER == 0 || !(G & 1)) ? NFA_K8H_MFMA(al, BH, acc[T], 0, 0, 0)                             \
+                                                  : NFA_K8H_MFMA(ah, BL, acc[T], 0, 0, 0);                            \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         NFA_K8H_WEAVE(w.template step<SLOT + 0>());                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        acc[T] = NFA_K8H_MFMA(ah, BL, acc[T], 0, 0, 0);                \
+        acc[T] = NFA_K8H_ORDER == 0 ? NFA_K8H_MFMA(ah, BL, acc[T], 0, 0, 0) : NFA_K8H_MFMA(ah, BH, acc[T], 0, 0, 0);    \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         NFA_K8H_WEAVE(w.template step<SLOT + 1>());                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        acc[T] = NFA_K8H_MFMA(ah, BH, acc[T], 0, 0, 0);                \
+        acc[T] = NFA_K8H_ORDER == 0 ? NFA_K8H_MFMA(ah, BH, acc[T], 0, 0, 0)                                             \
+                 : (!(G & 1) ? NFA_K8H_MFMA(ah, BL, acc[T], 0, 0, 0) : NFA_K8H_MFMA(al, BH, acc[T], 0, 0, 0));          \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         NFA_K8H_WEAVE(w.template step<SLOT + 2>());                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                       \
