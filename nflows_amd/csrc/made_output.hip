@@ -92,16 +92,22 @@ __global__ void __launch_bounds__(kBlock, 1) rqs_made_output_kernel(const MadeOu
     // biases of the chunk now sit in LDS and the spline inputs are requested a pair of groups ahead.  (Two tiles in
     // flight in two register sets need more than the 512 registers of a lone wave: scratch traffic, which waits on
     // vmcnt as well.)
-    vec4f wa[12];
+    // (round 4) the tiles come in by LDS-DMA: no staging registers, no ds_write pass, and no load the compiler knows
+    // about -- so nothing makes it wait for "all loads" in the middle of a tile.  Tile nt + 1 is requested at the
+    // beginning of tile nt, into the buffer whose readers all passed the barrier behind tile nt - 1, and awaited
+    // (vmcnt(0): the spline inputs of the next pair ride along) in front of the barrier behind tile nt.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lane_off16 = (unsigned)lane * 16u;
+    auto request_tile = [&](int tile_index, int buffer) {
+        const char* src = reinterpret_cast<const char*>(wg + (size_t)tile_index * kMadeOutTileVec4) + wave_u * 1024;
+        char* dst = reinterpret_cast<char*>(s_w + buffer * kMadeOutTileVec4) + wave_u * 1024;
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 4096 + lane_off16),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+    };
     {
-        vec4f w[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) w[i] = wg[tid + i * kBlock];
-        const vec4f* w1 = wg + (size_t)(1 < ntiles ? 1 : 0) * kMadeOutTileVec4;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) wa[i] = w1[tid + i * kBlock];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) s_w[tid + i * kBlock] = w[i];
+        request_tile(0, 0);
         const float* bsrc = a.bpad + (size_t)g0 * 3 * 32;
         for (int i = tid; i < ntiles * 32; i += kBlock) s_bias[i] = bsrc[i];
     }
@@ -137,6 +143,7 @@ __global__ void __launch_bounds__(kBlock, 1) rqs_made_output_kernel(const MadeOu
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0 (LDS-DMA) before the barrier
     __syncthreads();
 
     float lad_acc = 0.0f;
@@ -163,6 +170,7 @@ __global__ void __launch_bounds__(kBlock, 1) rqs_made_output_kernel(const MadeOu
         for (int u = 0; u < 6; ++u) {   // six tiles = two groups: the LDS buffers alternate statically
             const int t = u % 3;
             const int nt = g * 3 + u;
+            request_tile(nt + 1 < ntiles ? nt + 1 : 0, (u + 1) & 1);   // (past the chunk's last: tile 0 again, never used)
             bias_into_tile(acc[t], reinterpret_cast<const vec4f*>(s_bias + nt * 32 + half * 16));
             const vec4f* cur = s_w + (u & 1) * kMadeOutTileVec4 + lane;
             bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(0 * 16) * 64]);
@@ -186,16 +194,8 @@ __global__ void __launch_bounds__(kBlock, 1) rqs_made_output_kernel(const MadeOu
                 am = nm;
                 al = nl;
             }
-            // tile nt + 1 -> the other LDS buffer; the registers refilled with tile nt + 2 (past the chunk's last:
-            // tile 0 again, never used)
-            vec4f* nxt = s_w + ((u + 1) & 1) * kMadeOutTileVec4;
-            const int ntn = (nt + 2 < ntiles) ? nt + 2 : 0;
-            const vec4f* wn = wg + (size_t)ntn * kMadeOutTileVec4;
-#pragma unroll
-            for (int i = 0; i < 12; ++i) nxt[tid + i * kBlock] = wa[i];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) wa[i] = wn[tid + i * kBlock];
-            __syncthreads();
+            // tile nt + 1 has landed (this wave's requests), and every wave is done with tile nt
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (t == 2) {
                 const int gg = g + u / 3;
                 const int f0 = (g0 + gg) * 4 + half * 2;
