@@ -80,6 +80,9 @@ __device__ __forceinline__ void store_tile(float* base, int64_t row, int t, int 
 #ifndef NFA_K14_RING
 #define NFA_K14_RING 3
 #endif
+#ifndef NFA_K14_KSTEP
+#define NFA_K14_KSTEP 0   // 1: the pairwise k-step (round-4 experiment)
+#endif
 constexpr int kTrainRing = NFA_K14_RING, kTrainAhead = kTrainRing - 1;
 static_assert(kTrainRing >= 3 && 3 * (kTrainAhead - 1) <= 63, "vmcnt is a 6-bit count");
 
@@ -134,6 +137,7 @@ __device__ __forceinline__ void kstep(f32x16 (&acc)[4], const bf16x8& bh, const 
                                       TrainStream& sm, int lane) {
     tstream_request(sm);
     const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
+#if NFA_K14_KSTEP == 0   // (round 3: tile by tile, six dependent products each, every read awaited where it is used)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(t * 3 + 0) * 64]);
@@ -141,6 +145,41 @@ __device__ __forceinline__ void kstep(f32x16 (&acc)[4], const bf16x8& bh, const 
         const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(t * 3 + 2) * 64]);
         NFA_MFMA6(acc[t], ah, am, al, bh, bm, bl);
     }
+#else
+    // (round 4) two tiles at a time: their six fragments are requested together, the next pair's while this pair's
+    // twelve MFMAs run; consecutive MFMAs alternate between the two accumulators and are grouped by their srcB piece
+    // (bl, bl, bm, bm, bm, bm, bh x 6: three changes of srcB per twelve instead of twelve)
+    bf16x8 f[2][6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) f[0][q] = __builtin_bit_cast(bf16x8, cur[q * 64]);
+#pragma unroll
+    for (int pair = 0; pair < 2; ++pair) {
+        if (pair == 0) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) f[1][q] = __builtin_bit_cast(bf16x8, cur[(6 + q) * 64]);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 (&g)[6] = f[pair];   // [tile][h, m, l]
+        f32x16& a0 = acc[2 * pair];
+        f32x16& a1 = acc[2 * pair + 1];
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[0], bl, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[3], bl, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[1], bm, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[4], bm, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[0], bm, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[3], bm, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[2], bh, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[5], bh, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[1], bh, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[4], bh, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[0], bh, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[3], bh, a1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     tstream_advance(sm);
 }
 
