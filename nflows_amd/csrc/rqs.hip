@@ -539,10 +539,11 @@ __global__ void __launch_bounds__(kBlock) rqs_coupling_wavetile(const CouplingAr
     {                                                                                                          \
         const char* g_ = reinterpret_cast<const char*>(a.params) + (TILE) * (int64_t)kTileBytes;               \
         _Pragma("unroll") for (int k_ = 0; k_ < NI; ++k_) {                                                    \
-            unsigned o_ = (unsigned)k_ * 1024u + lane_off;                                                     \
-            if (k_ == NI - 1 && (kTileBytes & 1023)) o_ = o_ < (unsigned)kTileBytes - 16u ? o_ : (unsigned)kTileBytes - 16u; \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g_ + o_),         \
-                                             (__attribute__((address_space(3))) void*)(my + k_ * 1024), 16, 0, NFA_WT_AUX); \
+            const unsigned o_ = (unsigned)k_ * 1024u + lane_off;                                               \
+            /* (the last instruction of a 256 P-byte chunk is partial: the lanes past its end sit out) */      \
+            if (k_ < NI - 1 || !(kTileBytes & 1023) || o_ < (unsigned)kTileBytes)                              \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g_ + o_),     \
+                                                 (__attribute__((address_space(3))) void*)(my + k_ * 1024), 16, 0, NFA_WT_AUX); \
         }                                                                                                      \
     }
 #endif

@@ -23,7 +23,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python $ROOTDIR/tools/pmc_traffic.py $OUT/pmc_k8 $ROOTDIR/profiles/k8h_pmc_traffic.json rqs_resnet_f16_kernel 157286400 \
   "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --skip-extra --skip-consistency --skip-k1-roofline"
-[ "${SKIP_K1:-0}" = "1" ] || python $ROOTDIR/tools/pmc_traffic.py $OUT/pmc_k1 $ROOTDIR/profiles/k1_pmc_traffic.json rqs_coupling_pipelined 226754560 \
+[ "${SKIP_K1:-0}" = "1" ] || python $ROOTDIR/tools/pmc_traffic.py $OUT/pmc_k1 $ROOTDIR/profiles/k1_pmc_traffic.json rqs_coupling_wavetile 907018240 \
   "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --skip-extra --skip-consistency --path k1"
 cp $ROOTDIR/profiles/k8h_pmc_traffic.json $ROOTDIR/profiles/k1_pmc_traffic.json $OUT/
 # the raw counter CSVs are large; keep only the summaries
