@@ -88,9 +88,19 @@ __device__ __forceinline__ float row_sum16(float v) {
     return v;
 }
 
+// sum over the LPS lanes of a sample (LPS = 16: a DPP row; LPS = 32 -- round 4, two samples per wave --: the two
+// rows of a 32-lane half exchange their sums through ds_swizzle, lane i <-> i ^ 16)
+template <int LPS>
+__device__ __forceinline__ float sample_sum(float v) {
+    v = row_sum16(v);
+    if constexpr (LPS == 32)
+        v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // and 0x1f, or 0, xor 0x10
+    return v;
+}
+
 // `R` dot products of weight rows (`pitch` floats apart) with one sample's state vector `vec` (its `chunks`
 // 16-byte chunks), both in LDS: this lane takes chunks q, q + 16, ...; every lane of the sample gets the sums
-template <int R, int UNROLL>
+template <int R, int UNROLL, int LPS = 16>
 __device__ __forceinline__ void dot_rows(float (&acc)[R], const float* rows, int pitch, const float* vec, int chunks,
                                          int q, int nrows) {
     // (no conditionals inside the loop: rows beyond `nrows` re-read row 0 and their sums are ignored --
@@ -102,7 +112,7 @@ __device__ __forceinline__ void dot_rows(float (&acc)[R], const float* rows, int
         rp[r] = rows + (r < nrows ? r : 0) * pitch;
     }
 #pragma unroll UNROLL
-    for (int c = q; c < chunks; c += 16) {
+    for (int c = q; c < chunks; c += LPS) {
         const vec4f v = *reinterpret_cast<const vec4f*>(vec + c * 4);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -114,35 +124,37 @@ __device__ __forceinline__ void dot_rows(float (&acc)[R], const float* rows, int
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = row_sum16(acc[r]);
+    for (int r = 0; r < R; ++r) acc[r] = sample_sum<LPS>(acc[r]);
 }
 
 // the same for exactly 64 chunks (256 columns: BASELINE configs[4]'s hidden width), software-pipelined by hand:
 // the reads of the next 16 chunks are in flight while the current ones are multiplied (hipcc waits for ALL
 // outstanding LDS reads in front of the first FMA of a loop body otherwise: four exposed round trips per call)
-template <int R, int AHEAD>
+template <int R, int AHEAD_, int LPS = 16>
 __device__ __forceinline__ void dot_rows_64(float (&acc)[R], const float* rows, int pitch, const float* vec, int q, int nrows) {
-    // AHEAD = how many 16-chunk groups are requested before the first one is multiplied (1 .. 4; 4 = everything
-    // up front: right for a single row, whose four FMAs per group hide nothing)
-    static_assert(AHEAD >= 1 && AHEAD <= 4, "");
+    // G groups of LPS chunks (LPS = 16: four, LPS = 32: two); AHEAD = how many groups are requested before the first
+    // one is multiplied (G = everything up front: right for a single row, whose four FMAs per group hide nothing)
+    constexpr int G = 64 / LPS;
+    constexpr int AHEAD = AHEAD_ < G ? AHEAD_ : G;
+    static_assert(AHEAD >= 1, "");
     const float* rp[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) rp[r] = rows + (r < nrows ? r : 0) * pitch + q * 4;
     const float* vp = vec + q * 4;
-    vec4f v[4], w[4][R];
+    vec4f v[G], w[G][R];
 #pragma unroll
     for (int i = 0; i < AHEAD; ++i) {
-        v[i] = *reinterpret_cast<const vec4f*>(vp + i * 64);
+        v[i] = *reinterpret_cast<const vec4f*>(vp + i * LPS * 4);
 #pragma unroll
-        for (int r = 0; r < R; ++r) w[i][r] = *reinterpret_cast<const vec4f*>(rp[r] + i * 64);
+        for (int r = 0; r < R; ++r) w[i][r] = *reinterpret_cast<const vec4f*>(rp[r] + i * LPS * 4);
     }
-    float part[4][R];   // one partial sum per group: four short dependency chains instead of one of sixteen
+    float part[G][R];   // one partial sum per group: short dependency chains instead of one of sixteen
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (i + AHEAD < 4) {
-            v[i + AHEAD] = *reinterpret_cast<const vec4f*>(vp + (i + AHEAD) * 64);
+    for (int i = 0; i < G; ++i) {
+        if (i + AHEAD < G) {
+            v[i + AHEAD] = *reinterpret_cast<const vec4f*>(vp + (i + AHEAD) * LPS * 4);
 #pragma unroll
-            for (int r = 0; r < R; ++r) w[i + AHEAD][r] = *reinterpret_cast<const vec4f*>(rp[r] + (i + AHEAD) * 64);
+            for (int r = 0; r < R; ++r) w[i + AHEAD][r] = *reinterpret_cast<const vec4f*>(rp[r] + (i + AHEAD) * LPS * 4);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -153,7 +165,12 @@ __device__ __forceinline__ void dot_rows_64(float (&acc)[R], const float* rows, 
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = row_sum16((part[0][r] + part[1][r]) + (part[2][r] + part[3][r]));
+    for (int r = 0; r < R; ++r) {
+        float t;
+        if constexpr (G == 4) t = (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
+        else t = part[0][r] + part[1][r];
+        acc[r] = sample_sum<LPS>(t);
+    }
 }
 
 // float offset of element k of a sample's vector whose samples are `pitch` chunks apart
@@ -161,22 +178,28 @@ __device__ __forceinline__ int state_index(int k, int s, int pitch) { return (s 
 
 // block `t` -> LDS at `dst`: a wave requests one grain (64 lanes x 16 bytes) per instruction, grain g is
 // wave g % 4's
+template <int NW>
 __device__ __forceinline__ void request_block(const MadeInvArgs& a, int t, float* dst, int lane, int wave) {
     const int g0 = a.block_at[t], g1 = a.block_at[t + 1];
     const char* src = reinterpret_cast<const char*>(a.blocks) + (size_t)g0 * (kMadeGrain * 4) + lane * 16;
     char* d = reinterpret_cast<char*>(dst);
-    for (int g = wave; g < g1 - g0; g += kMadeWaves)
+    for (int g = wave; g < g1 - g0; g += NW)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)g * (kMadeGrain * 4)),
                                          (__attribute__((address_space(3))) void*)(d + g * (kMadeGrain * 4)), 16, 0, 0);
 }
 
-template <int KT>
-__global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(const MadeInvArgs a) {
+// LPS = lanes per sample.  16: four waves x four samples (round 3).  32 (round 4): EIGHT waves x two samples -- the same
+// sixteen samples and the same LDS per workgroup, but two waves per SIMD: a batch that gives every CU at most one
+// workgroup (configs[4]: 4 096 samples = 256 workgroups) has nothing else to hide the chain's LDS round trips with.
+template <int KT, int LPS>
+__global__ void __launch_bounds__((LPS / 4) * kWave) made_rqs_inverse_kernel(const MadeInvArgs a) {
 #pragma clang fp contract(off)
     constexpr int P = 3 * KT - 1;
     constexpr int RB = 8;                                           // output rows per pass of dot_rows
+    constexpr int NW = LPS / 4;                                     // waves per workgroup (16 samples)
+    constexpr int SPW = kWave / LPS;                                // samples per wave
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & 15, s = wave * 4 + (lane >> 4);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & (LPS - 1), s = wave * SPW + lane / LPS;
     const int64_t row = (int64_t)blockIdx.x * kMadeSamples + s;
     const bool live = row < a.batch;
     const int64_t rrow = live ? row : a.batch - 1;
@@ -187,8 +210,8 @@ __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(co
     float* vecs = lds + x_floats;                                   // [num_vectors][16][ph][4]
     float* buf0 = lds + state_floats;                               // two step blocks
     float* buf1 = buf0 + a.max_block;
-    request_block(a, 0, buf0, lane, wave);
-    for (int i = threadIdx.x; i < state_floats; i += kMadeWaves * kWave) lds[i] = 0.0f;
+    request_block<NW>(a, 0, buf0, lane, wave);
+    for (int i = threadIdx.x; i < state_floats; i += NW * kWave) lds[i] = 0.0f;
 
     float lad_acc = 0.0f;
     int my_status = 0;
@@ -208,7 +231,7 @@ __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(co
         NFA_K12_STAMP()
         const float z_t = z_next;
         if (t < a.T) {
-            request_block(a, t + 1, (t & 1) ? buf0 : buf1, lane, wave);
+            request_block<NW>(a, t + 1, (t & 1) ? buf0 : buf1, lane, wave);
             if (t + 1 < a.T) z_next = zrow[t + 1];
         }
         // ---- the step's control data in ONE round trip: header and the first unit entries (a dependent LDS
@@ -236,8 +259,8 @@ __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(co
             const int at = state_index(j, s, ph);
             const float carried = add_stream ? stream[at] : 0.0f;   // (in flight beside the dot product's reads)
             float acc[1];
-            if (kp == 256) dot_rows_64<1, 4>(acc, rows, kp, src, q, 1);
-            else dot_rows<1, 4>(acc, rows, kp, src, kp >> 2, q, 1);
+            if (kp == 256) dot_rows_64<1, 4, LPS>(acc, rows, kp, src, q, 1);
+            else dot_rows<1, 4, LPS>(acc, rows, kp, src, kp >> 2, q, 1);
             rows += kp;
             float v = acc[0] + bias;
             if (add_stream) v = carried + v;                    // residual connection (made.py:128)
@@ -262,8 +285,8 @@ __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(co
         for (int g = 0; g < (P + RB - 1) / RB; ++g) {
             float acc[RB];
             const int left = P - g * RB;
-            if (a.Hp == 256) dot_rows_64<RB, NFA_K12_ROWS_AHEAD>(acc, wf + g * RB * a.Hp, a.Hp, fin, q, left < RB ? left : RB);
-            else dot_rows<RB, 4>(acc, wf + g * RB * a.Hp, a.Hp, fin, a.Hp >> 2, q, left < RB ? left : RB);
+            if (a.Hp == 256) dot_rows_64<RB, NFA_K12_ROWS_AHEAD, LPS>(acc, wf + g * RB * a.Hp, a.Hp, fin, q, left < RB ? left : RB);
+            else dot_rows<RB, 4, LPS>(acc, wf + g * RB * a.Hp, a.Hp, fin, a.Hp >> 2, q, left < RB ? left : RB);
 #pragma unroll
             for (int i = 0; i < RB; ++i)
                 if (g * RB + i < P) p[g * RB + i] = acc[i] + fbias[g * RB + i];
@@ -283,10 +306,10 @@ __global__ void __launch_bounds__(kMadeWaves * kWave) made_rqs_inverse_kernel(co
     // the features found -> the first T columns of the samples' rows; the final hidden vector of every sample:
     // input of the output layer for features >= T
     if (live) {
-        for (int k = q; k < a.T; k += 16) a.x[row * a.D + k] = xs[state_index(k, s, px)];
+        for (int k = q; k < a.T; k += LPS) a.x[row * a.D + k] = xs[state_index(k, s, px)];
         if (q == 0) a.lad[row] = lad_acc;
         const float* fin = vecs + a.final_src * vec_floats;
-        for (int k = q; k < a.H; k += 16) a.hidden[row * a.H + k] = fin[state_index(k, s, ph)];
+        for (int k = q; k < a.H; k += LPS) a.hidden[row * a.H + k] = fin[state_index(k, s, ph)];
     } else {
         my_status = 0;
     }
@@ -351,17 +374,24 @@ extern "C" int nfa_made_rqs_inverse_f32(const float* inputs, const float* step_b
     a.H = hidden_features;
     a.T = sequential_steps;
     a.trace = g_k7_trace;
-    void (*kern)(const MadeInvArgs) = a.sp.K == 8 ? made_rqs_inverse_kernel<8> : made_rqs_inverse_kernel<10>;
+    // 32 lanes per sample (eight waves per workgroup: two per SIMD) was built in round 4 on the theory that the step
+    // is a chain of LDS round trips which a second wave on the SIMD would hide; it is slower (every lane of a sample
+    // repeats the spline inversion, the DPP sum grows a ds_swizzle stage): NFA_K12_LPS=32 selects it, 16 is the default
+    const int64_t blocks = (batch + kMadeSamples - 1) / kMadeSamples;
+    const char* lps_env = getenv("NFA_K12_LPS");
+    const int lps = lps_env && atoi(lps_env) == 32 ? 32 : 16;   // (measured: 32 is SLOWER, 2.15 vs 1.97 ms at configs[4] -- profiles/r4/k12_lanes_per_sample.txt)
+    void (*kern)(const MadeInvArgs) = a.sp.K == 8 ? (lps == 32 ? made_rqs_inverse_kernel<8, 32> : made_rqs_inverse_kernel<8, 16>)
+                                                  : (lps == 32 ? made_rqs_inverse_kernel<10, 32> : made_rqs_inverse_kernel<10, 16>);
     if (lds > 64 * 1024) {
-        static unsigned long long raised[2] = {};   // device masks (raise_dynamic_lds)
-        const int which = a.sp.K == 8 ? 0 : 1;
+        static unsigned long long raised[4] = {};   // device masks (raise_dynamic_lds)
+        const int which = (a.sp.K == 8 ? 0 : 1) + (lps == 32 ? 2 : 0);
         {
             const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], 160 * 1024 - 4096);
             if (rc_lds != NFA_OK) return rc_lds;
         }
     }
-    const int64_t blocks = (batch + kMadeSamples - 1) / kMadeSamples;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kMadeWaves * kWave), lds, (hipStream_t)stream, a);
+    note_layer_kernel("made_rqs_inverse_kernel<K=%d, lanes_per_sample=%d>", a.sp.K, lps);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3((lps / 4) * kWave), lds, (hipStream_t)stream, a);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
 }
