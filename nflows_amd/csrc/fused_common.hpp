@@ -12,7 +12,9 @@
 #ifndef NFA_BF16X3_ORDER
 #define NFA_BF16X3_ORDER 0
 #endif
-#if NFA_BF16X3_ORDER == 0
+#ifdef NFA_ABL_NO_MFMA6   // (measurement builds)
+#define NFA_MFMA6(acc, ah, am, al, bh, bm, bl) asm volatile("" :: "v"(ah), "v"(am), "v"(al), "v"(bh), "v"(bm), "v"(bl))
+#elif NFA_BF16X3_ORDER == 0
 #define NFA_MFMA6(acc, ah, am, al, bh, bm, bl)                                        \
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);              \
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);              \

@@ -52,8 +52,22 @@ struct TrainArgs {
 };
 
 // accumulator tile <-> rows of a [B, 128] array: element (row, 32 t + 8 q4 + 4 half + i) = acc[4 q4 + i]
+//
+// Stores (round 4).  In the accumulator layout a lane holds 16-byte pieces of ONE row: a `global_store_dwordx4` of the
+// wave then touches 64 separate 16-byte segments in 32 different 128-byte lines, and the address coalescer handles them
+// one by one -- removing the stores of the saved activations took 26 of the forward kernel's 78 us although they are
+// only 2.2 TB/s of traffic, and spreading them over the GEMMs changed nothing (profiles/r4/k14_ablations.txt).  With
+// NFA_K14_LDS_STORES (default) a tile goes through a wave-private 32 x 36-float LDS image and leaves as four stores
+// of EIGHT FULL 128-byte lines each: lane l writes bytes 16 (l % 8) .. of the tile's 128 bytes of row 8 j + l / 8.
+#ifndef NFA_K14_LDS_STORES
+#define NFA_K14_LDS_STORES 1
+#endif
+constexpr int kTrainTilePitch = 36;                          // floats per row of the staging image (32 + 4: b128 accesses)
+constexpr int kTrainTileFloats = 32 * kTrainTilePitch;       // per wave
+
+// the direct form (round 3): four 16-byte stores per lane, lane (half, r) -> row r
 template <bool RELU>
-__device__ __forceinline__ void store_tile(float* base, int64_t row, int t, int half, const f32x16& a) {
+__device__ __forceinline__ void store_tile_direct(float* base, int64_t row, int t, int half, const f32x16& a) {
     vec4f* p = reinterpret_cast<vec4f*>(base + row * 128 + 32 * t + 4 * half);
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
@@ -66,6 +80,44 @@ __device__ __forceinline__ void store_tile(float* base, int64_t row, int t, int 
         }
         p[2 * q4] = v;   // 8 floats = two vec4 apart
     }
+}
+
+// the staged form: through the wave's LDS image, eight full 128-byte lines per store instruction; `ld` floats between
+// rows, `cols` valid columns of this tile (a multiple of 4)
+template <bool RELU>
+__device__ __forceinline__ void store_tile_staged(float* base, int64_t row, int t, int half, const f32x16& a, float* stage,
+                                                  int ld, int cols) {
+    // `row` = the lane's own row (row0 + r); the wave's first row is row - r
+    const int lane = __lane_id();
+    const int r = lane & 31;
+    float* mine = stage + r * kTrainTilePitch + 4 * half;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        vec4f v = {a[4 * q4], a[4 * q4 + 1], a[4 * q4 + 2], a[4 * q4 + 3]};
+        if (RELU) {
+            v.x = v.x < 0.0f ? 0.0f : v.x;
+            v.y = v.y < 0.0f ? 0.0f : v.y;
+            v.z = v.z < 0.0f ? 0.0f : v.z;
+            v.w = v.w < 0.0f ? 0.0f : v.w;
+        }
+        *reinterpret_cast<vec4f*>(mine + 8 * q4) = v;
+    }
+    const int c = lane & 7, rr = lane >> 3;
+    float* dst = base + (row - r) * ld + 32 * t + 4 * c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const vec4f w = *reinterpret_cast<const vec4f*>(stage + (8 * j + rr) * kTrainTilePitch + 4 * c);
+        if (4 * c < cols) *reinterpret_cast<vec4f*>(dst + (int64_t)(8 * j + rr) * ld) = w;
+    }
+}
+
+template <bool RELU>
+__device__ __forceinline__ void store_tile(float* base, int64_t row, int t, int half, const f32x16& a, float* stage = nullptr) {
+#ifdef NFA_K14_ABL_NO_SAVE   // (measurement: what the activation stores cost; results are garbage downstream)
+    if (a[0] != 123.456f) return;
+#endif
+    if (NFA_K14_LDS_STORES && stage) store_tile_staged<RELU>(base, row, t, half, a, stage, 128, 32);
+    else store_tile_direct<RELU>(base, row, t, half, a);
 }
 
 // The weight stream of these kernels: bf16x3_gemm.hpp's ring (12 KB stages, three LDS-DMA requests per stage and
@@ -114,7 +166,11 @@ __device__ __forceinline__ void tstream_request(TrainStream& sm) {
 }
 
 __device__ __forceinline__ void tstream_advance(TrainStream& sm) {
+#ifdef NFA_K14_ABL_NO_BARRIER
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(3 * (kTrainAhead - 1)) : "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(3 * (kTrainAhead - 1)) : "memory");
+#endif
     sm.slot = (sm.slot + 1 == kTrainRing) ? 0 : sm.slot + 1;
 }
 
@@ -186,10 +242,23 @@ __device__ __forceinline__ void kstep(f32x16 (&acc)[4], const bf16x8& bh, const 
 // k-major GEMM over 128 inputs given as four fp32 accumulator tiles (ReLU'd first when RELU): tile t becomes the
 // pieces of k-steps 2 t and 2 t + 1 right before they are consumed, so that no 96-register piece array is ever
 // live next to the accumulators (K8 keeps the residual stream as pieces; here it stays in fp32 tiles)
-template <bool RELU>
-__device__ __forceinline__ void gemm_from_tiles(f32x16 (&acc)[4], const f32x16 (&src)[4], TrainStream& sm, int lane) {
+// `save` (round 4): the source tiles are ALSO an array the other pass / K10 needs in HBM (forward: relu(h_k), relu(a_k);
+// backward: g_a_k, g_h_k).  Tile t is stored right before the two k-steps that consume it -- four stores per lane in
+// front of 48 MFMAs -- instead of all sixteen at once in front of the GEMM: every workgroup of the launch reaches that
+// point at about the same time, the burst of 33 MB per array waited for itself in the next counted vmcnt (stores share
+// the counter with the ring's requests) and nothing overlapped it: 26 of the forward kernel's 78 us at 65 536 rows
+// (profiles/r4/k14_ablations.txt).
+template <bool RELU, bool SAVE = false>
+__device__ __forceinline__ void gemm_from_tiles(f32x16 (&acc)[4], const f32x16 (&src)[4], TrainStream& sm, int lane,
+                                                float* save = nullptr, int64_t row = 0, int half = 0, float* stage = nullptr) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+#ifndef NFA_K14_BURST_STORES
+        // (SAVE as a template flag or `save` as a run-time pointer: the same code, another register allocation -- hipcc
+        //  spills 12-20 bytes in the forward kernel with the flag and 780 in the backward kernel with the pointer)
+        if constexpr (SAVE) store_tile<RELU>(save, row, t, half, src[t], stage);
+        else if (save) store_tile<RELU>(save, row, t, half, src[t], stage);
+#endif
         bf16x8 h0, m0, l0, h1, m1, l1;
         tile_to_pieces<RELU>(src[t], h0, m0, l0, h1, m1, l1);
         kstep(acc, h0, m0, l0, sm, lane);
@@ -247,6 +316,7 @@ __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_forward_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TrainStream sm;
     start_stream(sm, a.w, lds_dyn, a.num_stages, tid);
+    float* stage = lds_dyn + kTrainRing * kStageVec4 * 4 + wave * kTrainTileFloats;   // this wave's store image
     const int64_t num_quads = a.batch >> 7;
     const int64_t plane = a.batch * 128;   // one saved activation
     for (int64_t quad = blockIdx.x; quad < num_quads; quad += gridDim.x) {
@@ -291,23 +361,31 @@ __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_forward_kernel(const 
             f32x16 u[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                store_tile<true>(in0, row, t, half, hs[t]);    // relu(h): the first Linear's input
+#ifdef NFA_K14_BURST_STORES   // (round 3: all sixteen stores in front of the GEMM)
+                store_tile<true>(in0, row, t, half, hs[t]);
+#endif
                 load_bias_tile(u[t], bias + t * 32);
             }
-            gemm_from_tiles<true>(u, hs, sm, lane);
+            gemm_from_tiles<true>(u, hs, sm, lane, in0, row, half, stage);    // (stores relu(h), the first Linear's input, on the way)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                store_tile<true>(in1, row, t, half, u[t]);     // relu(a): the second Linear's input
+#ifdef NFA_K14_BURST_STORES
+                store_tile<true>(in1, row, t, half, u[t]);
+#endif
                 f32x16 b1;
                 load_bias_tile(b1, bias + 128 + t * 32);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) hs[t][q] += b1[q];   // skip connection: accumulate onto h
             }
-            gemm_from_tiles<true>(hs, u, sm, lane);
+            {
+                // (the second GEMM accumulates INTO hs while it reads u: relu(a), the second Linear's input, is stored
+                //  from u on the way)
+                gemm_from_tiles<true>(hs, u, sm, lane, in1, row, half, stage);
+            }
             bias += 256;
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) store_tile<false>(a.out, row, t, half, hs[t]);
+        for (int t = 0; t < 4; ++t) store_tile<false>(a.out, row, t, half, hs[t], stage);
         // ---- optionally the final Linear: params = W_f h + b_f, one 32-column tile of the [B, out_features] result at a
         //      time (h as pieces from here on: converted once, the fp32 tiles are dead)
         if (a.final_tiles > 0) {
@@ -321,11 +399,7 @@ __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_forward_kernel(const 
                 f32x16 acc;
                 load_bias_tile(acc, fb + t * 32);
                 gemm_tile_pieces(acc, ph, pm, pl, sm, lane);
-                float* pp = a.params + row * out_features + 32 * t + 4 * half;
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4)
-                    if (32 * t + 8 * q4 + 4 * half < out_features)
-                        *reinterpret_cast<vec4f*>(pp + 8 * q4) = vec4f{acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]};
+                store_tile_staged<false>(a.params, row, t, half, acc, stage, out_features, out_features - 32 * t < 32 ? out_features - 32 * t : 32);
             }
         }
         // drain (stores, and the two stages requested past this row block) before the next block's loads
@@ -383,6 +457,9 @@ __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_backward_kernel(const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TrainStream sm;
     start_stream(sm, a.w, lds_dyn, a.num_stages, tid);
+    // (the staged full-line stores measured no gain in this kernel -- 92.1 vs 91.5 us -- and cost 92 bytes of scratch:
+    //  the backward pass keeps the direct stores)
+    float* stage = nullptr;
     const int64_t num_quads = a.batch >> 7;
     const int64_t plane = a.batch * 128;
     const int tiles_x = (a.di + 31) >> 5;
@@ -417,26 +494,51 @@ __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_backward_kernel(const
             f32x16 u[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) zero_tile(u[t]);
+            // (round 4: an array is stored tile by tile by the GEMM that consumes it -- gemm_from_tiles' `save`: g_h of the
+            //  block behind this one here, g_a of this block in the second GEMM, g_h_0 in the initial layer's GEMM below)
+#ifdef NFA_K14_BWD_GH_IN_GEMM
+            if (blk < NB - 1) gemm_from_tiles<false, true>(u, gs, sm, lane, a.grads + (2 * (blk + 1)) * plane, row, half, stage);
+            else gemm_from_tiles<false>(u, gs, sm, lane);
+#else
             gemm_from_tiles<false>(u, gs, sm, lane);
+#endif
             float* ga = a.grads + (2 * blk + 1) * plane;
+            // (three blocks: the interleaved form spills 12 bytes per lane -- scratch reloads share vmcnt with the ring --,
+            //  so that instance keeps the stores in front of the GEMM)
+            constexpr bool kSpread = NB <= 2;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 apply_mask(u[t], masks[2 * blk + 1], t);
-                store_tile<false>(ga, row, t, half, u[t]);
+#ifndef NFA_K14_BURST_STORES
+                if constexpr (!kSpread)
+#endif
+                    store_tile<false>(ga, row, t, half, u[t]);
             }
             f32x16 v[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) zero_tile(v[t]);
-            gemm_from_tiles<false>(v, u, sm, lane);
-            float* gh = a.grads + (2 * blk) * plane;
+#ifndef NFA_K14_BURST_STORES
+            if constexpr (kSpread) gemm_from_tiles<false, true>(v, u, sm, lane, ga, row, half, stage);
+            else
+#endif
+                gemm_from_tiles<false>(v, u, sm, lane);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 apply_mask(v[t], masks[2 * blk], t);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) gs[t][q] += v[t][q];   // the skip connection's gradient
-                store_tile<false>(gh, row, t, half, gs[t]);
+#if defined(NFA_K14_BURST_STORES) || !defined(NFA_K14_BWD_GH_IN_GEMM)
+                store_tile<false>(a.grads + (2 * blk) * plane, row, t, half, gs[t], stage);
+#endif
             }
         }
+#if !defined(NFA_K14_BURST_STORES) && defined(NFA_K14_BWD_GH_IN_GEMM)
+        if (NB > 0) {   // g_h_0 (the initial Linear's grad_outputs): nothing GEMM-shaped left to hide it behind but the
+                        // one or two output tiles of g_x
+#pragma unroll
+            for (int t = 0; t < 4; ++t) store_tile<false>(a.grads, row, t, half, gs[t], stage);
+        }
+#endif
         // ---- initial layer: g_x = g_h_0 W_in, one 32-column tile at a time
         for (int t = 0; t < tiles_x; ++t) {
             f32x16 acc;
@@ -620,7 +722,7 @@ extern "C" int nfa_resnet_hidden_forward_f32(const float* identity_inputs, const
     a.out_features = out_features;
     a.final_tiles = (out_features + 31) / 32;
     a.num_stages = init_ks + 16 * num_blocks + 2 * a.final_tiles;
-    const size_t lds = (size_t)kTrainRing * kStageVec4 * 16;
+    const size_t lds = (size_t)kTrainRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * kTrainTileFloats * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     void (*kern)(const TrainArgs) = init_ks == 2 ? resnet_hidden_forward_kernel<2> : resnet_hidden_forward_kernel<4>;
     if (lds > 64 * 1024) {
@@ -657,7 +759,7 @@ extern "C" int nfa_resnet_hidden_backward_f32(const float* grad_hidden, const vo
     a.out_features = 0;
     a.final_tiles = 0;
     a.num_stages = 16 * num_blocks + 2 * ((num_identity + 31) / 32);
-    const size_t lds = (size_t)kTrainRing * kStageVec4 * 16;
+    const size_t lds = (size_t)kTrainRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * kTrainTileFloats * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid = train_grid(batch), block(kBlock);
     void (*kern)(const TrainArgs) = num_blocks == 0 ? resnet_hidden_backward_kernel<0>
