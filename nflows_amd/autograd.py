@@ -298,6 +298,33 @@ class Linear(torch.autograd.Function):
         return g_in, (g_w if need_w else None), g_b
 
 
+class SelectColumns(torch.autograd.Function):
+    """inputs.index_select(1, columns) for UNIQUE columns (a coupling layer's identity split, coupling.py:82) whose
+    backward writes the gradient with index_copy_ into a zero tensor: torch's own backward is index_add_ -- atomic adds,
+    16 us per layer at 65 536 x 64 against 6 us -- because it cannot know the columns are distinct."""
+
+    @staticmethod
+    def forward(ctx, inputs, columns):
+        ctx.save_for_backward(columns)
+        ctx.width = inputs.shape[1]
+        return inputs.index_select(1, columns)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        (columns,) = ctx.saved_tensors
+        out = grad.new_zeros(grad.shape[0], ctx.width)
+        out.index_copy_(1, columns, grad.contiguous())
+        return out, None
+
+
+def select_columns(inputs, columns):
+    """`inputs[:, columns]` (distinct columns); under autograd through SelectColumns."""
+    if torch.is_grad_enabled() and inputs.requires_grad and inputs.dim() == 2:
+        return SelectColumns.apply(inputs, columns)
+    return inputs.index_select(1, columns)
+
+
 # K10 for the hidden Linears of a conditioner in one launch pair (A/B switch: NFA_K10_BATCHED=0)
 BATCHED_WGRAD = os.environ.get("NFA_K10_BATCHED", "1") != "0"
 

@@ -23,6 +23,7 @@ import torch
 from torch.nn.functional import softplus
 
 from .. import _cache
+from .. import autograd as _autograd
 from .. import _native as N
 from .. import ops
 from ..utils import torchutils
@@ -180,7 +181,7 @@ class CouplingTransform(Transform):
             whole = self._whole_layer(inputs, context, False, in_perm, None, logabsdet_accumulator)
             if whole is not None:
                 return whole
-        identity_split = inputs.index_select(1, self._identity_columns(in_perm))
+        identity_split = _autograd.select_columns(inputs, self._identity_columns(in_perm))
         outputs, logabsdet = self._condition_and_transform(
             inputs, identity_split, context, inverse=False, in_perm=in_perm,
             accumulate_into=logabsdet_accumulator)
@@ -203,7 +204,7 @@ class CouplingTransform(Transform):
             whole = self._whole_layer(inputs, context, True, None, out_scatter, logabsdet_accumulator)
             if whole is not None:
                 return whole
-        identity_split = inputs.index_select(1, self.identity_features)
+        identity_split = _autograd.select_columns(inputs, self.identity_features)
         logabsdet_identity = None
         if self.unconditional_transform is not None:
             identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)

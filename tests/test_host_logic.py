@@ -1336,6 +1336,10 @@ def test_training_function_wiring_with_emulated_kernels(monkeypatch):
     monkeypatch.setattr(ops, "resnet_hidden_forward", forward)
     monkeypatch.setattr(ops, "resnet_hidden_backward", backward)
     monkeypatch.setattr(ops, "linear_wgrad", lambda x, gy, need_bias=True: (gy.t() @ x, gy.sum(0) if need_bias else None))
+    # (round 4: the hidden Linears' weight gradients in one K10 launch pair when every gradient is wanted)
+    batched_calls = []
+    monkeypatch.setattr(ops, "linear_wgrad_batched", lambda problems, need_bias=True: (
+        batched_calls.append(len(problems)), [(gy.t() @ x, gy.sum(0) if need_bias else None) for x, gy in problems])[1])
     torch.manual_seed(0)
     for di, H, nb, out, with_final, frozen in ((8, 128, 2, 40, True, ()), (3, 128, 1, 24, True, ()), (21, 52, 2, 40, True, ()),
                                                (12, 64, 0, 16, True, ()), (8, 128, 2, 40, False, ()), (6, 20, 3, 8, False, ()),
@@ -1361,3 +1365,5 @@ def test_training_function_wiring_with_emulated_kernels(monkeypatch):
                 assert p.grad is None, name
             else:
                 assert p.grad.shape == p.shape and torch.allclose(p.grad, q.grad, rtol=1e-10, atol=1e-12), name
+    # the batched entry served the nets whose hidden gradients were all wanted (2 nb problems each), never a frozen one
+    assert batched_calls == [4, 2, 4, 4, 6], batched_calls
