@@ -1168,6 +1168,25 @@ def test_verify_weights_mode_detects_writes_through_data(monkeypatch):
     assert raised_at == 256, raised_at
 
 
+def test_select_columns_backward_equals_index_select():
+    """autograd.SelectColumns (round 4): the identity split of a coupling layer under autograd -- forward is
+    index_select, backward writes the gradient with index_copy_ into zeros (distinct columns) where torch's own backward
+    is an atomic index_add_.  Same values and gradients as torch's, also when the input feeds a second consumer."""
+    from nflows_amd import autograd as AG
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(7, 10, generator=g, dtype=torch.float64, requires_grad=True)
+    cols = torch.tensor([9, 0, 4, 5])
+    w = torch.randn(7, 4, generator=g, dtype=torch.float64)
+    y = AG.select_columns(x, cols)
+    assert torch.equal(y, x.index_select(1, cols))
+    ((y * w).sum() + (x ** 2).sum()).backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    ((x2.index_select(1, cols) * w).sum() + (x2 ** 2).sum()).backward()
+    assert torch.equal(x.grad, x2.grad)
+    with torch.no_grad():   # no graph: plain index_select
+        assert AG.select_columns(x, cols).grad_fn is None
+
+
 def test_no_mfma_result_lands_on_its_own_operands():
     """hipcc (ROCm 7.2) renames the four-register accumulators of v_mfma_f32_16x16x32_f16 from instruction to
     instruction and, unless the operands are kept live, allocates a RESULT on the registers of the A fragment
