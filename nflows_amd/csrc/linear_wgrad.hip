@@ -165,6 +165,146 @@ __global__ void __launch_bounds__(kBlock) wgrad_partial_kernel(const WgradArgs a
     }
 }
 
+// ---- the same partial products on the bf16 matrix pipe (round 4).  v_mfma_f32_32x32x2_f32 runs at the vector rate
+// (64 cycles for 2 k: under the power cap the chain sustains 121 TFLOP/s); three bf16 pieces per fp32 operand and the
+// six largest cross products on v_mfma_f32_32x32x16_bf16 (fp32 accumulation, fp32-accurate: the scheme of K8 / K14,
+// fused_common.hpp) take 6 x 32 cycles for 16 k -- 2.7 x less matrix-pipe time.  The batch rows are the k index: a lane
+// holds, of its column (feature ln of the tile), the eight rows 16 ks + 8 lh + j -- eight ds_read_b32 a row pitch apart
+// (the same number of LDS reads per 16 rows as the fp32 form) -- and splits them itself: ~56 VALU instructions per
+// fragment that run beside the MFMAs of the previous k-step.  Same ring, same requests, same result layout, same
+// reduction kernel; the bias gradient is summed from the raw fp32 values as before.
+template <int TO, int TI, int WO, int WI, int ROWS>
+__global__ void __launch_bounds__(kBlock) wgrad_partial_bf16_kernel(const WgradArgs a) {
+    static_assert(ROWS == 16 || ROWS == 32, "stage rows");
+    static_assert(WO * WI == 4, "four waves per workgroup");
+    constexpr int BO = 32 * TO * WO, BI = 32 * TI * WI;
+    constexpr int VA = BO / 4, VB = BI / 4;
+    constexpr int NA = (ROWS * VA) / kBlock, NB = (ROWS * VB + kBlock - 1) / kBlock;
+    static_assert(NA * kBlock == ROWS * VA && ROWS * VB >= kBlock, "whole requests only");
+    constexpr int NREQ = NA + NB;
+    constexpr int kStage = ROWS * (VA + VB);
+    extern __shared__ __attribute__((aligned(16))) vec4f wg_ring[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ln = lane & 31, lh = lane >> 5;
+    const int wo = wave / WI, wi = wave % WI;
+    const int bo = blockIdx.x / a.blocks_i, bi = blockIdx.x - bo * a.blocks_i;
+    const int ob = bo * BO, ib = bi * BI;
+    const int kz = blockIdx.y;
+    const int s_begin = (int)(((int64_t)a.stages_total * kz) / a.ksplit);
+    const int s_end = (int)(((int64_t)a.stages_total * (kz + 1)) / a.ksplit);
+    const int O = a.O, I = a.I;
+    int col_a = ob + (tid % VA) * 4, col_b = ib + (tid % VB) * 4;
+    if (col_a > O - 4) col_a = O - 4;
+    if (col_b > I - 4) col_b = I - 4;
+    const int pz = blockIdx.z;
+    const float* src_a = a.gy[pz] + (int64_t)(tid / VA) * O + col_a;
+    const float* src_b = a.x[pz] + (int64_t)(tid / VB) * I + col_b;
+    constexpr int rows_per_req_a = kBlock / VA, rows_per_req_b = kBlock / VB;
+    auto request = [&](int stage, int slot) {
+        const float* ga = src_a + (int64_t)stage * ROWS * O;
+        const float* gb = src_b + (int64_t)stage * ROWS * I;
+        vec4f* dst = wg_ring + slot * kStage + tid;
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + (int64_t)q * rows_per_req_a * O),
+                                             (__attribute__((address_space(3))) void*)(dst + q * kBlock), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (int64_t)q * rows_per_req_b * I),
+                                             (__attribute__((address_space(3))) void*)(dst + ROWS * VA + q * kBlock), 16, 0, 0);
+    };
+    auto advance = [&]() {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(NREQ) : "memory");
+    };
+
+    f32x16 acc[TO][TI];
+#pragma unroll
+    for (int to = 0; to < TO; ++to)
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[to][ti][j] = 0.0f;
+    float colsum[TO];
+#pragma unroll
+    for (int to = 0; to < TO; ++to) colsum[to] = 0.0f;
+
+    // raw fp32 operands of one 16-row k-step: column (ln) of tile to / ti, rows 8 lh + j
+    auto read_raw = [&](const float* sa, const float* sb, int ks, float (&ar)[TO][8], float (&br)[TI][8]) {
+#pragma unroll
+        for (int to = 0; to < TO; ++to)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ar[to][j] = sa[(ks * 16 + j) * BO + to * 32];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) br[ti][j] = sb[(ks * 16 + j) * BI + ti * 32];
+    };
+    auto split8 = [](const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+        bf16x2 hh[4], mm[4], ll[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split3(vec2f{v[2 * q], v[2 * q + 1]}, hh[q], mm[q], ll[q]);
+        h = join4(hh[0], hh[1], hh[2], hh[3]);
+        m = join4(mm[0], mm[1], mm[2], mm[3]);
+        l = join4(ll[0], ll[1], ll[2], ll[3]);
+    };
+
+    const int last = s_end - 1;
+    request(s_begin, 0);
+    request(s_begin + 1 <= last ? s_begin + 1 : last, 1);
+    advance();
+    int slot = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int ahead = s + 2 <= last ? s + 2 : last;
+        request(ahead, slot >= 1 ? slot - 1 : kWgRing - 1);
+        const float* sa = reinterpret_cast<const float*>(wg_ring + slot * kStage) + 8 * lh * BO + wo * 32 * TO + ln;
+        const float* sb = reinterpret_cast<const float*>(wg_ring + slot * kStage + ROWS * VA) + 8 * lh * BI + wi * 32 * TI + ln;
+        constexpr int NK = ROWS / 16;
+        float ar[2][TO][8], br[2][TI][8];
+        read_raw(sa, sb, 0, ar[0], br[0]);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            bf16x8 ah[TO], am[TO], al[TO], bh[TI], bm[TI], bl[TI];
+#pragma unroll
+            for (int to = 0; to < TO; ++to) {
+                split8(ar[ks & 1][to], ah[to], am[to], al[to]);
+                if (wi == 0) {
+                    const float (&v)[8] = ar[ks & 1][to];
+                    colsum[to] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                }
+            }
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) split8(br[ks & 1][ti], bh[ti], bm[ti], bl[ti]);
+            if (ks + 1 < NK) read_raw(sa, sb, ks + 1, ar[(ks + 1) & 1], br[(ks + 1) & 1]);   // in flight beside the MFMAs
+#pragma unroll
+            for (int to = 0; to < TO; ++to)
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) { NFA_MFMA6(acc[to][ti], ah[to], am[to], al[to], bh[ti], bm[ti], bl[ti]); }
+        }
+        advance();
+        slot = slot + 1 == kWgRing ? 0 : slot + 1;
+    }
+
+    float* out = a.ws + ((int64_t)pz * a.ksplit + kz) * ((int64_t)O * I + O);
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+        const int o0 = ob + wo * 32 * TO + to * 32;
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+            const int i = ib + wi * 32 * TI + ti * 32 + ln;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int o = o0 + 8 * (j >> 2) + 4 * lh + (j & 3);
+                if (o < O && i < I) out[(int64_t)o * I + i] = acc[to][ti][j];
+            }
+        }
+        if (wi == 0 && bi == 0) {  // (wave-uniform)
+            const float v = colsum[to] + __shfl_xor(colsum[to], 32, kWave);
+            if (lh == 0 && o0 + ln < O) out[(int64_t)O * I + o0 + ln] = v;
+        }
+    }
+}
+
 // grad_weight / grad_bias = sum over slices (fixed order) + the rows behind the last full stage
 struct WgradReduceArgs {
     const float* x[kWgMaxProblems];
@@ -218,18 +358,37 @@ __global__ void __launch_bounds__(kBlock) wgrad_reduce_kernel(const float* __res
 struct WgradPlan {
     int variant;  // 0: 128 x 128 result blocks, 1: 128 x 32
     int blocks_o, blocks_i, stages_total, ksplit;
+    int rows;     // batch rows per stage
 };
 
 // `count` same-shaped problems share the chip: fewer batch slices each (fewer partial results to write and to sum,
 // a longer stream per workgroup: the two-stage ramp of the ring is paid once per 32 stages instead of once per 8)
+// rows per stage of the 128 x 128 form: 32, or -- NFA_K10_ROWS=16, the bf16 engine only -- 16 with two workgroups per CU
+static int wgrad_rows(int variant, int problems_times_blocks) {
+    const char* e = getenv("NFA_K10_ROWS");
+    const char* eng = getenv("NFA_K10_ENGINE");
+    if (variant != 0 || (eng && eng[0] == 'f')) return kWgRows;
+    if (e) return atoi(e) == 16 ? 16 : kWgRows;
+    // 16-row stages (49 KB of LDS: two workgroups per CU, the split of one runs beside the MFMAs of the other) where the
+    // launch has enough result blocks to feed them: 128 -> 736 110.9 -> 96.3 us, four 128 x 128 layers 75.2 -> 71.4 us;
+    // a lone 128 x 128 problem is better off with 32 rows (30.7 vs 32.0 us)
+    return problems_times_blocks >= 4 ? 16 : kWgRows;
+}
+static int wgrad_wgs_per_cu(int rows) {
+    const char* e = getenv("NFA_K10_WGS");   // (experiment)
+    return rows == 16 ? (e && atoi(e) > 0 ? atoi(e) : 2) : 1;
+}
+
 static WgradPlan plan_wgrad(int64_t batch, int I, int O, int count = 1) {
     WgradPlan p;
     p.variant = I <= 32 ? 1 : 0;
     const int BO = 128, BI = p.variant ? 32 : 128;
     p.blocks_o = (O + BO - 1) / BO;
     p.blocks_i = (I + BI - 1) / BI;
-    p.stages_total = (int)(batch / kWgRows);
-    int ks = device_cu_count() / (p.blocks_o * p.blocks_i * (count > 0 ? count : 1));
+    const int rows = wgrad_rows(p.variant, p.blocks_o * p.blocks_i * (count > 0 ? count : 1));
+    p.rows = rows;
+    p.stages_total = (int)(batch / rows);
+    int ks = device_cu_count() * wgrad_wgs_per_cu(rows) / (p.blocks_o * p.blocks_i * (count > 0 ? count : 1));
     if (ks < 1) ks = 1;
     if (ks > p.stages_total) ks = p.stages_total;
     p.ksplit = ks;
@@ -290,7 +449,19 @@ extern "C" int nfa_linear_wgrad_batched_f32(int32_t count, const float* const* i
         a.ksplit = p.ksplit;
         a.blocks_i = p.blocks_i;
         const dim3 grid((unsigned)(p.blocks_o * p.blocks_i), (unsigned)p.ksplit, (unsigned)count);
-        if (p.variant == 0) {
+        // engine of the 128 x 128 result blocks: "bf16x3" (default since round 4) or "f32" (NFA_K10_ENGINE)
+        const char* eng = getenv("NFA_K10_ENGINE");
+        const bool bf16 = !eng || eng[0] != 'f';
+        if (p.variant == 0 && bf16 && p.rows == 16) {
+            constexpr size_t lds = (size_t)kWgRing * 16 * (128 + 128) * 4;
+            hipLaunchKernelGGL((wgrad_partial_bf16_kernel<2, 2, 2, 2, 16>), grid, dim3(kBlock), lds, st, a);
+        } else if (p.variant == 0 && bf16) {
+            constexpr size_t lds = (size_t)kWgRing * kWgRows * (128 + 128) * 4;
+            static unsigned long long raised_b = 0;   // device mask (raise_dynamic_lds)
+            const int rc_lds = raise_dynamic_lds((const void*)wgrad_partial_bf16_kernel<2, 2, 2, 2, kWgRows>, &raised_b, (int)lds);
+            if (rc_lds != NFA_OK) return rc_lds;
+            hipLaunchKernelGGL((wgrad_partial_bf16_kernel<2, 2, 2, 2, kWgRows>), grid, dim3(kBlock), lds, st, a);
+        } else if (p.variant == 0) {
             constexpr size_t lds = (size_t)kWgRing * kWgRows * (128 + 128) * 4;
             static unsigned long long raised = 0;   // device mask (raise_dynamic_lds: the opt-in is per device)
             const int rc_lds = raise_dynamic_lds((const void*)wgrad_partial_kernel<2, 2, 2, 2>, &raised, (int)lds);
@@ -304,7 +475,7 @@ extern "C" int nfa_linear_wgrad_batched_f32(int32_t count, const float* const* i
     }
     const int64_t n = (int64_t)O * I + O;   // (problems without a bias gradient skip the last O elements themselves)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)count), dim3(kBlock), 0, st,
-                       static_cast<const float*>(workspace), r, I, O, p.ksplit, (int64_t)p.stages_total * kWgRows, batch);
+                       static_cast<const float*>(workspace), r, I, O, p.ksplit, (int64_t)p.stages_total * p.rows, batch);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
 }
