@@ -729,8 +729,10 @@ int nfa_cubic_spline_backward_f32(const float *inputs, const float *unnormalized
  * reference's conditioners nn/nets/resnet.py:44,49,94,99 and nn/nets/mlp.py:47-68 reach it through
  * autograd when a flow is trained, examples/moons.ipynb cell 3):
  *   grad_weight[O, I] = grad_outputs[B, O]^T . inputs[B, I]      grad_bias[O] = sum_b grad_outputs[b, :]
- * The reduction runs over the batch: the batch is split over the chip (fp32 matrix cores, LDS-DMA
- * ring), partial results go to `workspace` (nfa_linear_wgrad_workspace_bytes(...) bytes of device
+ * The reduction runs over the batch: the batch is split over the chip (LDS-DMA ring; since round 4 the products of
+ * layers with more than 32 inputs run on the bf16 matrix cores -- every fp32 operand as three bf16 pieces, six cross
+ * products, fp32 accumulation: fp32-accurate, full fp32 range; the environment variable NFA_K10_ENGINE=f32 selects the
+ * fp32 matrix instruction), partial results go to `workspace` (nfa_linear_wgrad_workspace_bytes(...) bytes of device
  * memory, contents undefined before and after) and are summed in a fixed order: results are
  * deterministic.  grad_bias may be NULL.  in_features and out_features must be multiples of 4 and
  * inputs / grad_outputs 16-byte aligned, otherwise NFA_ERR_UNSUPPORTED.  flags must be 0.

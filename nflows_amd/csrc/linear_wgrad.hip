@@ -20,6 +20,12 @@
 //
 // Bound: fp32 MFMA issue (64 cycles per 32x32x2) or HBM (each input element is read once per
 // result block column/row it belongs to); for 128 x 128 at B = 65 536 both are ~14 us.
+//
+// Round 4: (1) up to eight same-shaped problems per launch pair (blockIdx.z: the four hidden Linears of a conditioner);
+// (2) wgrad_partial_bf16_kernel, the default for the 128 x 128 result blocks: the same ring and layout with the operands
+// split into three bf16 pieces by the lane that reads them and six products per multiply-add on
+// v_mfma_f32_32x32x16_bf16 (fp32-accurate, 2.7 x less matrix-pipe time than the fp32 MFMA), 16-row stages with two
+// workgroups per CU: 128 -> 736 at B = 65 536 130 -> 97 us, four 128 x 128 layers 90 -> 72 us.
 
 #include "fused_common.hpp"
 
