@@ -1,4 +1,4 @@
-// Spline evaluation of K8h's woven final layer (csrc/rqs_resnet_f16.hip): 8 or 10 bins, linear tails,
+// Spline evaluation of K8h's woven final layer (csrc/rqs_resnet_f16.hip): 2 .. 16 bins (8 and 10: the tuned forms), linear tails,
 // logits handed over at scale 1/kappa straight from the MFMA accumulators.
 //
 // Same function as rational_quadratic.py:66-181 (+ :13-63 for the tails), arranged for the lowest
@@ -26,7 +26,7 @@ namespace nfa {
 
 template <bool INVERSE, int KT = 8>
 struct FusedSteps {
-    static_assert(KT == 8 || KT == 10, "8 or 10 bins");
+    static_assert(KT >= 2 && KT <= 16, "2 .. 16 bins (8 and 10 keep their own maximum / sum chains)");
     static constexpr int kNumSlices = KT + 3;                   // max, one exponential per logit, sum x 2
     static constexpr int kWalkSlices = 3 + (KT - 1);            // setup x 2, bin 0, bins 1..KT-1
     static constexpr int kBinSlices = INVERSE ? 9 : 7;
@@ -52,21 +52,46 @@ struct FusedSteps {
     // all numerators and cancels in the normalisation.  (Round 3 tried the numerators without the maximum:
     // 10 instructions fewer per evaluation, no measurable gain, and logit sets beyond +-87 -- softmax is
     // shift-invariant, a trained network may sit anywhere -- would have gone to the exact kernel.)
+    // e[A] + ... + e[B - 1], neighbours paired first (two independent chains for the adder)
+    template <int A, int B>
+    __device__ __forceinline__ static float half_sum(const float (&e)[KT]) {
+        float s0 = e[A], s1 = B - A > 1 ? e[A + 1] : 0.0f;
+#pragma unroll
+        for (int i = A + 2; i < B; i += 2) {
+            s0 += e[i];
+            if (i + 1 < B) s1 += e[i + 1];
+        }
+        return B - A > 1 ? s0 + s1 : s0;
+    }
     template <int S>
     __device__ __forceinline__ void numerators(float (&e)[KT], float& den_, float& m, float& t) {
         if constexpr (S == 0) {
-            m = __builtin_fmaxf(__builtin_fmaxf(e[0], e[1]), e[2]);      // (v_max3_f32)
-            m = __builtin_fmaxf(__builtin_fmaxf(m, e[3]), e[4]);
-            m = __builtin_fmaxf(__builtin_fmaxf(m, e[5]), e[6]);
-            if constexpr (KT == 10) m = __builtin_fmaxf(__builtin_fmaxf(m, e[7]), e[8]);
-            m = __builtin_fmaxf(m, e[KT - 1]) * kl2e;                     // max * log2e * kappa
+            if constexpr (KT == 8 || KT == 10) {
+                m = __builtin_fmaxf(__builtin_fmaxf(e[0], e[1]), e[2]);      // (v_max3_f32)
+                m = __builtin_fmaxf(__builtin_fmaxf(m, e[3]), e[4]);
+                m = __builtin_fmaxf(__builtin_fmaxf(m, e[5]), e[6]);
+                if constexpr (KT == 10) m = __builtin_fmaxf(__builtin_fmaxf(m, e[7]), e[8]);
+                m = __builtin_fmaxf(m, e[KT - 1]) * kl2e;                     // max * log2e * kappa
+            } else {   // other bin counts (round 4): the same chain of v_max3_f32 over however many logits there are
+                m = e[0];
+#pragma unroll
+                for (int i = 1; i + 1 < KT; i += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, e[i]), e[i + 1]);
+                if constexpr (KT % 2 == 0) m = __builtin_fmaxf(m, e[KT - 1]);
+                m *= kl2e;
+            }
         } else if constexpr (S < 1 + KT) {
             e[S - 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(e[S - 1], kl2e, -m));
-        } else if constexpr (S == 1 + KT) {
-            t = (e[0] + e[1]) + (e[2] + e[3]);
-        } else {
-            den_ = t + ((e[4] + e[5]) + (e[6] + e[7]));
-            if constexpr (KT == 10) den_ += e[8] + e[9];
+        } else if constexpr (KT == 8 || KT == 10) {
+            if constexpr (S == 1 + KT) {
+                t = (e[0] + e[1]) + (e[2] + e[3]);
+            } else {
+                den_ = t + ((e[4] + e[5]) + (e[6] + e[7]));
+                if constexpr (KT == 10) den_ += e[8] + e[9];
+            }
+        } else {   // the two halves of the sum in two slices, pairs first
+            constexpr int H = KT / 2;
+            if constexpr (S == 1 + KT) t = half_sum<0, H>(e);
+            else den_ = t + half_sum<H, KT>(e);
         }
     }
     template <int S>

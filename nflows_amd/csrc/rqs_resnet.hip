@@ -237,7 +237,11 @@ __device__ __forceinline__ void gemm_context_tile(f32x16& acc, const float* s_ct
 // sigmoid(context_layer(context)) before the skip connection (F.glu of the concatenation).
 template <bool INVERSE, int PRESCALED, int INIT_KS, int PIPE = 0, int KB = 8, bool CTX = false>  // PIPE: 0 plain loop, 1 woven, 2 woven with FlatSteps<FAST>
 __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs a) {
-    static_assert(KB == 8 || (KB == 10 && PIPE != 1 && PRESCALED == 1), "10 bins: plain loop, or woven with the shorter sequence");
+    static_assert(KB == 8 || (KB == 10 && PIPE != 1 && PRESCALED == 1) || (KB >= 2 && KB <= 16 && PIPE == 0 && PRESCALED == 1 && !CTX),
+                  "10 bins: plain loop, or woven with the shorter sequence; other bin counts (2 .. 16): plain loop, no context");
+    // rows of the final layer per transformed feature (8 bins: 23 logits padded to 24, two features share three tiles;
+    // otherwise 3 K - 1 padded to whole 16-row lane-half shares)
+    constexpr int kFinalRows = KB == 8 ? 24 : 16 * ((3 * KB - 1 + 15) / 16);
     // dynamic LDS: the weight ring, then per wave a [D][33] row tile
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     __shared__ int s_tab[2][kTabLayer];   // tables of the current and the next layer
@@ -273,9 +277,9 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
     // cannot afford an L2 round trip in front of every tile)
     float* s_fbias = lds_dyn + kRing * kStageVec4 * 4 + (kBlock / kWave) * D * kRowPad;
     // CTX: per wave the [ce][33] context tile of its 32 rows, behind the final-layer biases
-    float* s_ctx = s_fbias + (PIPE != 0 ? dt * (KB == 10 ? 32 : 24) : 0) + wave * a.ce * kRowPad;
+    float* s_ctx = s_fbias + (PIPE != 0 ? dt * kFinalRows : 0) + wave * a.ce * kRowPad;
     // CTX: per wave the fp32 residual stream h, [4 tiles x 16 registers][64 lanes]
-    [[maybe_unused]] float* s_hacc = s_fbias + (PIPE != 0 ? dt * (KB == 10 ? 32 : 24) : 0) + (kBlock / kWave) * a.ce * kRowPad +
+    [[maybe_unused]] float* s_hacc = s_fbias + (PIPE != 0 ? dt * kFinalRows : 0) + (kBlock / kWave) * a.ce * kRowPad +
                                      wave * (64 * kWave);
     const int groups = dt >> 2;
     const int64_t num_quads = a.batch >> 7;
@@ -412,7 +416,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                 // (every wave has passed a stage barrier of this layer: nobody reads the previous
                 // layer's biases any more; the blocks' barriers come before the first use)
                 const float* fbias = a.bias + (size_t)layer * a.bias_per_layer + 128 + (CTX ? 384 : 256) * a.num_blocks;
-                for (int i = tid; i < dt * (KB == 10 ? 32 : 24); i += kBlock) s_fbias[i] = fbias[i];
+                for (int i = tid; i < dt * kFinalRows; i += kBlock) s_fbias[i] = fbias[i];
                 // without residual blocks the final layer follows at once: no stage barrier in between
                 if (a.num_blocks == 0) __syncthreads();
             }
@@ -538,6 +542,32 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                     }
                     lad_acc += f.lad;
                     my_status |= f.status;
+                }
+                NFA_STAMP()
+            } else if constexpr (KB != 8 && KB != 10) {
+                // ---- any other bin count (round 4: the second pass behind K8h's instances for 2 .. 16 bins): 3 K - 1
+                //      logits per feature padded to T tiles' lane-half shares (16 T rows), the rows ordered so that the
+                //      16 T accumulator values of lane-half h are the logits of feature 2g + h; evaluated by the
+                //      register instance of K1's function (rqs_math.hpp: rqs_eval<K, ., linear tails, REGS>)
+                constexpr int T = kFinalRows / 16;
+                RqsDev sp0 = a.sp;
+                sp0.divisor = 0.0f;  // 1/sqrt(hidden) is folded into the weight rows
+                for (int g = 0; g < (dt >> 1); ++g) {
+                    float* slot = s_row + tab[kTabTr + g * 2 + half] * kRowPad + r;
+                    const float xin = *slot;
+                    float p[16 * T];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        f32x16 acc;
+                        load_bias_tile(acc, bias + (g * T + t) * 32);
+                        gemm_tile<false>(acc, ph, pm, pl, sm, lane);
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) p[16 * t + q] = acc[q];
+                    }
+                    float y, l;
+                    my_status |= rqs_eval<KB, INVERSE, true, true>(xin, p, sp0, y, l);
+                    *slot = y;
+                    lad_acc += l;
                 }
                 NFA_STAMP()
             } else if constexpr (KB == 10) {
@@ -712,9 +742,11 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     ResnetArgs a;
     int rc = make_dev_spec(spec, &a.sp);
     if (rc != NFA_OK) return rc;
-    const int rows_per_feature = a.sp.K == 10 ? 32 : 24;
+    const bool any_bins = a.sp.K != 8 && a.sp.K != 10;   // 2 .. 16 bins: the plain loop, no context, no log2(e) fold
+    const int rows_per_feature = a.sp.K == 8 ? 24 : 16 * ((3 * a.sp.K - 1 + 15) / 16);
     if (a.sp.beta != 1.0f) return NFA_ERR_UNSUPPORTED;  // (identity initialisation: functional callers only)
-    if ((a.sp.K != 8 && a.sp.K != 10) || (a.sp.K == 10 && (flags & NFA_FLAG_LOGITS_LOG2E)) || !a.sp.linear ||
+    if (a.sp.K < 2 || a.sp.K > 16 || (a.sp.K != 8 && (flags & NFA_FLAG_LOGITS_LOG2E)) || (any_bins && context_features > 0) ||
+        !a.sp.linear ||
         hidden_features != 128 || (num_transform & 3) != 0 ||
         num_transform > 64 || num_identity > 64 || features > 128 || (features & 3) != 0 ||
         (batch & 127) != 0 || num_blocks > 64 || num_layers > 4096)
@@ -765,7 +797,7 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         return e ? atoi(e) : 2;
     }();
     // (with the log2(e) fold only the default woven form exists)
-    const bool pipe = use_pipe && ((a.sp.K == 8 && (!(flags & NFA_FLAG_LOGITS_LOG2E) || use_pipe == 2)) ||
+    const bool pipe = !any_bins && use_pipe && ((a.sp.K == 8 && (!(flags & NFA_FLAG_LOGITS_LOG2E) || use_pipe == 2)) ||
                                   (a.sp.K == 10 && use_pipe == 2));
     if (with_ctx && !(pipe && use_pipe == 2)) return NFA_ERR_UNSUPPORTED;
     const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float) +
@@ -808,6 +840,16 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 1> : rqs_resnet_kernel<false, 1, 4, 1>;
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 1> : rqs_resnet_kernel<false, 1, 2, 1>;
     }
+#define NFA_K8_ANY(KB_)                                                                                      \
+    case KB_:                                                                                                \
+        kern = init_ks == 4 ? (inv ? rqs_resnet_kernel<true, 1, 4, 0, KB_> : rqs_resnet_kernel<false, 1, 4, 0, KB_>)   \
+                            : (inv ? rqs_resnet_kernel<true, 1, 2, 0, KB_> : rqs_resnet_kernel<false, 1, 2, 0, KB_>);  \
+        break;
+    if (any_bins) switch (a.sp.K) {
+        NFA_K8_ANY(2) NFA_K8_ANY(3) NFA_K8_ANY(4) NFA_K8_ANY(5) NFA_K8_ANY(6) NFA_K8_ANY(7) NFA_K8_ANY(9)
+        NFA_K8_ANY(11) NFA_K8_ANY(12) NFA_K8_ANY(13) NFA_K8_ANY(14) NFA_K8_ANY(15) NFA_K8_ANY(16)
+    }
+#undef NFA_K8_ANY
     if (with_ctx && a.sp.K == 10) {
         if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 2, 10, true> : rqs_resnet_kernel<false, 1, 4, 2, 10, true>;
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 2, 10, true> : rqs_resnet_kernel<false, 1, 2, 2, 10, true>;
@@ -826,8 +868,8 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
             if (rc_lds != NFA_OK) return rc_lds;
         }
     } else if (lds > 64 * 1024) {
-        static unsigned long long raised[28] = {};   // device masks (raise_dynamic_lds)  // opt in to > 64 KB of dynamic LDS once per kernel
-        const int which = a.sp.K == 10 ? (pipe ? 24 : 12) + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
+        static unsigned long long raised[32 + 15 * 4] = {};   // device masks (raise_dynamic_lds)  // opt in to > 64 KB of dynamic LDS once per kernel
+        const int which = any_bins ? 32 + (a.sp.K - 2) * 4 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) : a.sp.K == 10 ? (pipe ? 24 : 12) + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
                           : (pipe && use_pipe == 2) ? 16 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (l2e ? 4 : 0)
                           : pipe ? 8 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) : (inv ? 1 : 0) + (l2e ? 2 : 0) + (init_ks == 4 ? 4 : 0);
         {

@@ -48,7 +48,7 @@
 //     accumulator is prepared), ReLU is applied when a tile is converted into pieces, not per k-step.
 //   * No packed fp32 arithmetic (see split2).
 //
-// Restrictions: K = 8 or 10 bins, linear tails, hidden width 128 (narrower: zero-padded by the host), ReLU
+// Restrictions: 2 .. 16 bins (8 and 10: tuned final-layer loops and conditioners with a context), linear tails, hidden width 128 (narrower: zero-padded by the host), ReLU
 // blocks, d_i <= 64, d_t % 4 == 0, d_t <= 64, D % 4 == 0, D <= 128, batch % 128 == 0 (other feature counts
 // and batches: padded by the host); with a context: up to 32 context features beside d_i <= 32.
 
@@ -251,6 +251,67 @@ struct SplineWeave10 {
         spline10_range<UNIT, (SLOT * kCount) / kSlots, ((SLOT + 1) * kCount) / kSlots>(f, sp);
     }
 };
+
+// ---- any other bin count from 2 to 16 (round 4): one feature per lane-half and group of T = ceil((3 K - 1) / 16) tiles
+//      (the lane-half's 16 T accumulator values are the feature's 3 K - 1 logits -- K widths, K heights, K - 1 derivatives
+//      -- then padding).  ONE accumulator tile: a finished tile's sixteen values are copied into the evaluation's arrays
+//      (`take_chunk`) and the accumulator takes the next tile's biases.  What runs behind a tile's MFMAs only needs
+//      logits of EARLIER tiles: the width numerators behind tile 1 (widths: K <= 16 values, all in tile 0), the height
+//      numerators behind tile 2 (T = 3) and everything that is left behind tile 0 of the NEXT group.
+enum { kSeqW = 1, kSeqH = 2, kSeqFinish = 4 };
+
+template <int MASK, class Steps>
+constexpr int spline_seq_count() {
+    return ((MASK & kSeqW) ? Steps::kNumSlices : 0) + ((MASK & kSeqH) ? Steps::kNumSlices : 0) +
+           ((MASK & kSeqFinish) ? Steps::kFinishSlices : 0);
+}
+
+// slices [I, END) of the sequence MASK names: numerators first (width / height alternating when both are in it:
+// two independent chains), then the rest of the evaluation
+template <int MASK, int I, int END, class Steps>
+__device__ __forceinline__ void spline_seq_range(Steps& f, const RqsDev& sp) {
+    if constexpr (I < END) {
+        constexpr int N = Steps::kNumSlices;
+        constexpr bool W = (MASK & kSeqW) != 0, H = (MASK & kSeqH) != 0;
+        constexpr int NUM = (W ? N : 0) + (H ? N : 0);
+        if constexpr (I < NUM) {
+            if constexpr (W && H) {
+                if constexpr ((I & 1) == 0) f.template num_w<(I >> 1)>();
+                else f.template num_h<(I >> 1)>();
+            } else if constexpr (W) {
+                f.template num_w<I>();
+            } else {
+                f.template num_h<I>();
+            }
+        } else {
+            f.template finish<I - NUM>(sp);
+        }
+        spline_seq_range<MASK, I + 1, END>(f, sp);
+    }
+}
+
+template <int MASK, class Steps>
+struct SplineWeaveSeq {
+    Steps& f;
+    const RqsDev& sp;
+    static constexpr int kCount = spline_seq_count<MASK, Steps>();
+    template <int SLOT>
+    __device__ __forceinline__ void step() {
+        spline_seq_range<MASK, (SLOT * kCount) / kSlots, ((SLOT + 1) * kCount) / kSlots>(f, sp);
+    }
+};
+
+// values 16 C .. 16 C + 15 of the lane-half's logits, from the tile that has just been finished
+template <int C, int KB, class Steps>
+__device__ __forceinline__ void take_chunk(Steps& f, const f32x16& acc) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int j = 16 * C + q;
+        if (j < KB) f.ew[j < KB ? j : 0] = acc[q];
+        else if (j < 2 * KB) f.eh[j < 2 * KB ? j - KB : 0] = acc[q];
+        else if (j < 3 * KB - 1) f.sd[j < 3 * KB - 1 ? j - 2 * KB : 0] = acc[q];
+    }
+}
 
 #ifndef NFA_K8H_ORDER
 #define NFA_K8H_ORDER 0   // 1: the srcB-grouped order of the three products of a cell (round-4 experiment: no gain, profiles/r4/k8h_mfma_order.txt)
@@ -758,6 +819,51 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                     lad_acc += f.lad;
                     quad_status |= f.status;
                 }
+            } else if constexpr (KB != 8) {
+                // other bin counts: T tiles per group of two features (one per lane-half), see SplineWeaveSeq
+                constexpr int T = (3 * KB - 1 + 15) / 16;
+                static_assert(T >= 1 && T <= 3, "2 .. 16 bins");
+                using Steps = FusedSteps<INVERSE, KB>;
+                // what is left for the next group's first tile: everything (T = 1), heights + rest (T = 2), the rest (T = 3)
+                constexpr int kRest = T == 1 ? (kSeqW | kSeqH | kSeqFinish) : T == 2 ? (kSeqH | kSeqFinish) : kSeqFinish;
+                Steps f;
+                const float kappa = gemm[0];
+                f.kappa = kappa;
+                f.kl2e = 1.44269502162933349609375f * kappa;
+                f.tail_s = a.sp.tail_logit * gemm[1];
+                const float* fbias = gemm + kHdr + half * 16;
+                const int groups_any = dt >> 1;
+                f32x16 acc;
+                float* slot = s_row + tab[kTabTr + half] * kRowPad + r;
+                load_bias_tile(acc, fbias);
+                tile_gemm(acc, ph, pl, sm, fr, lane, NoWeave{});
+                for (int g = 0; g < groups_any; ++g) {
+                    const float* gb = fbias + g * T * 32;
+                    f.x = *slot;
+                    take_chunk<0, KB>(f, acc);
+                    if constexpr (T >= 2) {
+                        load_bias_tile(acc, gb + 32);
+                        tile_gemm(acc, ph, pl, sm, fr, lane, SplineWeaveSeq<kSeqW, Steps>{f, a.sp});
+                        take_chunk<1, KB>(f, acc);
+                    }
+                    if constexpr (T >= 3) {
+                        load_bias_tile(acc, gb + 64);
+                        tile_gemm(acc, ph, pl, sm, fr, lane, SplineWeaveSeq<kSeqH, Steps>{f, a.sp});
+                        take_chunk<2, KB>(f, acc);
+                    }
+                    if (g + 1 < groups_any) {
+                        float* next_slot = s_row + tab[kTabTr + (g + 1) * 2 + half] * kRowPad + r;
+                        load_bias_tile(acc, gb + T * 32);
+                        tile_gemm(acc, ph, pl, sm, fr, lane, SplineWeaveSeq<kRest, Steps>{f, a.sp});
+                        *slot = f.y;
+                        slot = next_slot;
+                    } else {
+                        spline_seq_range<kRest, 0, spline_seq_count<kRest, Steps>()>(f, a.sp);
+                        *slot = f.y;
+                    }
+                    lad_acc += f.lad;
+                    quad_status |= f.status;
+                }
             } else {
                 using Steps = FusedSteps8<INVERSE>;
                 Steps fa, fb;
@@ -886,7 +992,9 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     int rc = make_dev_spec(spec, &a.sp);
     if (rc != NFA_OK) return rc;
     if (a.sp.beta != 1.0f) return NFA_ERR_UNSUPPORTED;
-    if ((a.sp.K != 8 && a.sp.K != 10) || !a.sp.linear || hidden_features != 128 || (num_transform & 3) != 0 || num_transform > 64 ||
+    // bin counts: 8 and 10 have their own final-layer loops; 2 .. 16 otherwise (no context there)
+    const bool any_bins = a.sp.K != 8 && a.sp.K != 10;
+    if (a.sp.K < 2 || a.sp.K > 16 || (any_bins && context_features > 0) || !a.sp.linear || hidden_features != 128 || (num_transform & 3) != 0 || num_transform > 64 ||
         num_identity > 64 || features > 128 || (features & 3) != 0 || (batch & 127) != 0 || num_blocks > 64 ||
         num_layers > 4096)
         return NFA_ERR_UNSUPPORTED;
@@ -894,7 +1002,9 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     if (context_features < 0) return NFA_ERR_INVALID_ARGUMENT;
     // with a context: two identity k-steps + two context k-steps in the initial layer
     if (with_ctx && (context_features > 32 || num_identity > 32)) return NFA_ERR_UNSUPPORTED;
-    const int rows_per_feature = a.sp.K == 10 ? 32 : 24;
+    // rows of the final layer per transformed feature: 23 logits padded to 24 (8 bins: two features share three
+    // tiles), otherwise 3 K - 1 padded to whole 16-row lane-half shares
+    const int rows_per_feature = a.sp.K == 8 ? 24 : 16 * ((3 * a.sp.K - 1 + 15) / 16);
     const int param_words = k8h::kTabWords + (k8h::kHdr + 128) * (1 + (with_ctx ? 3 : 2) * num_blocks) + k8h::kHdr +
                             num_transform * rows_per_feature;
     if (param_stages * 2048 < param_words || param_stages > 4) return NFA_ERR_INVALID_ARGUMENT;
@@ -965,7 +1075,20 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     int which = with_ctx ? 16 + (inv ? 1 : 0) + (nw == 8 ? 2 : 0) + (a.sp.K == 10 ? 4 : 0)
                          : (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0) + (a.sp.K == 10 ? 8 : 0);
     if (elastic) which = 24 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0);
-    switch (which) {
+    if (any_bins) which = 32 + (a.sp.K - 2) * 8 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0);
+#define NFA_K8H_ANY(KB_)                                                                                             \
+    case KB_:                                                                                                        \
+        kern = nw == 8 ? (init_ks == 4 ? (inv ? k8h::rqs_resnet_f16_kernel<true, 4, 8, KB_> : k8h::rqs_resnet_f16_kernel<false, 4, 8, KB_>)   \
+                                       : (inv ? k8h::rqs_resnet_f16_kernel<true, 2, 8, KB_> : k8h::rqs_resnet_f16_kernel<false, 2, 8, KB_>))  \
+                       : (init_ks == 4 ? (inv ? k8h::rqs_resnet_f16_kernel<true, 4, 4, KB_> : k8h::rqs_resnet_f16_kernel<false, 4, 4, KB_>)   \
+                                       : (inv ? k8h::rqs_resnet_f16_kernel<true, 2, 4, KB_> : k8h::rqs_resnet_f16_kernel<false, 2, 4, KB_>)); \
+        break;
+    if (any_bins) switch (a.sp.K) {
+        NFA_K8H_ANY(2) NFA_K8H_ANY(3) NFA_K8H_ANY(4) NFA_K8H_ANY(5) NFA_K8H_ANY(6) NFA_K8H_ANY(7) NFA_K8H_ANY(9)
+        NFA_K8H_ANY(11) NFA_K8H_ANY(12) NFA_K8H_ANY(13) NFA_K8H_ANY(14) NFA_K8H_ANY(15) NFA_K8H_ANY(16)
+    }
+#undef NFA_K8H_ANY
+    else switch (which) {
 #ifdef NFA_K8H_ELASTIC   // (experiment builds only: measured 3 % slower than the rigid stream, profiles/r3/k8h_elastic_stream.txt)
         case 24: kern = k8h::rqs_resnet_f16_kernel<false, 2, 8, 8, false, k8h::kRingElastic>; break;
         case 25: kern = k8h::rqs_resnet_f16_kernel<true, 2, 8, 8, false, k8h::kRingElastic>; break;
@@ -1000,7 +1123,7 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     note_layer_kernel("k8h::rqs_resnet_f16_kernel<inverse=%d, init_ks=%d, waves=%d, K=%d, ctx=%d, ring=%d>", inv ? 1 : 0,
                       init_ks, nw, a.sp.K, with_ctx ? 1 : 0, elastic ? k8h::kRingElastic : k8h::kRing);
     if (lds_launch > 64 * 1024) {
-        static unsigned long long raised[28] = {};   // device masks (raise_dynamic_lds)
+        static unsigned long long raised[32 + 15 * 8] = {};   // device masks (raise_dynamic_lds)
         {
             const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], (int)lds_cap);
             if (rc_lds != NFA_OK) return rc_lds;

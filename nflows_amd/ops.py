@@ -878,15 +878,25 @@ def _k7_row_order(num_transform):
     return (feat * 24 + idx % 24).reshape(-1)  # [tiles * 32]
 
 
-def _k8_row_order_32(num_transform):
+def _k8_row_order_32(num_transform, tiles_per_group=2):
     """The same for features padded to 32 rows (10 bins: 29 logits): two tiles per group, the 32
-    values a lane-half gets from them are the logits of feature 2g + half."""
+    values a lane-half gets from them are the logits of feature 2g + half.  In general (`tiles_per_group` = T, round 4:
+    any bin count from 2 to 16) a feature's 3 K - 1 logits are padded to 16 T rows and group g's T tiles give lane-half
+    h the 16 T logits of feature 2g + h, tile t of the group holding logits 16 t .. 16 t + 15."""
+    T = tiles_per_group
     i = torch.arange(32)
     half = (i >> 2) & 1
     q = ((i >> 3) << 2) | (i & 3)
-    t = torch.arange(num_transform)[:, None]  # one tile per feature on average
-    feat = 2 * (t // 2) + half[None, :]
-    return (feat * 32 + (t % 2) * 16 + q[None, :]).reshape(-1)  # [tiles * 32]
+    t = torch.arange(num_transform * T // 2)[:, None]  # T / 2 tiles per feature
+    feat = 2 * (t // T) + half[None, :]
+    return (feat * (16 * T) + (t % T) * 16 + q[None, :]).reshape(-1)  # [tiles * 32]
+
+
+def final_rows_per_feature(params_per_feature):
+    """Rows of the packed final layer per transformed feature in the whole-layer kernels: 8 bins (23 logits) -> 24, two
+    features sharing three 32-row tiles; any other bin count -> 3 K - 1 padded to whole lane-half shares of 16."""
+    P = params_per_feature
+    return 24 if P == 23 else 16 * ((P + 15) // 16)
 
 
 def split_bf16x3(w):
@@ -1118,8 +1128,8 @@ def pack_resnet_conditioner(net, num_transform, params_per_feature, log2e=False,
         wf = torch.cat((wf, wf.new_zeros(pad_transform_to - dt, P, 128)), dim=0)
         bf = torch.cat((bf, bf.new_zeros(pad_transform_to - dt, P)), dim=0)
         dt = pad_transform_to
-    R = 24 if P <= 24 else 32  # rows per feature after padding (8 bins: 23 -> 24; 10 bins: 29 -> 32)
-    order_r = (_k7_row_order(dt) if R == 24 else _k8_row_order_32(dt)).to(dev)
+    R = final_rows_per_feature(P)  # rows per feature after padding (8 bins: 23 -> 24; 10 bins: 29 -> 32; ...)
+    order_r = (_k7_row_order(dt) if P == 23 else _k8_row_order_32(dt, R // 16)).to(dev)
     wf = torch.cat((wf, wf.new_zeros(dt, R - P, 128)), dim=1).reshape(dt * R, 128)
     wf = wf.index_select(0, order_r).index_select(1, order_k)
     bf = torch.cat((bf, bf.new_zeros(dt, R - P)), dim=1).reshape(dt * R).index_select(0, order_r)
@@ -1389,8 +1399,8 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
     Returns (weights [stages, 4096] f16, parameter words fp32)."""
     dt, P = num_transform, params_per_feature
     K = (P + 1) // 3
-    if P not in (23, 29):
-        raise ValueError("K8h packs 8- and 10-bin linear-tail layers")
+    if P % 3 != 2 or not 2 <= K <= 16:
+        raise ValueError("K8h packs linear-tail layers of 2 .. 16 bins")
     S = float(act_scale)
     dev = net.final_layer.weight.device
     order_k = (_k8s_column_order() if tile16 else _k8_column_order()).to(dev)
@@ -1464,8 +1474,8 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
         wf = torch.cat((wf, wf.new_zeros(pad_transform_to - dt, P, 128)), dim=0)
         bf = torch.cat((bf, bf.new_zeros(pad_transform_to - dt, P)), dim=0)
         dt = pad_transform_to
-    R = 24 if P == 23 else 32   # rows per feature after padding
-    order_r = (_k8s_row_order(dt) if tile16 else _k7_row_order(dt) if R == 24 else _k8_row_order_32(dt)).to(dev)
+    R = final_rows_per_feature(P)   # rows per feature after padding
+    order_r = (_k8s_row_order(dt) if tile16 else _k7_row_order(dt) if P == 23 else _k8_row_order_32(dt, R // 16)).to(dev)
     wf = torch.cat((wf, wf.new_zeros(dt, R - P, 128)), dim=1).reshape(dt * R, 128)
     wf = wf.index_select(0, order_r).index_select(1, order_k)
     bf = torch.cat((bf, bf.new_zeros(dt, R - P)), dim=1).reshape(dt * R).index_select(0, order_r)

@@ -69,8 +69,12 @@ extern "C" int host_rqs_forward_regs(int kt, int inverse, int64_t n, const nfa_r
                                      const float* params, float* y, float* lad) {
     RqsDev sp;
     if (make_dev_spec(spec, &sp) != NFA_OK || !sp.linear || sp.K != kt || sp.P != 3 * kt - 1) return -1;
-    if (kt == 8) return inverse ? forward_regs_all<8, true>(n, sp, x, params, y, lad) : forward_regs_all<8, false>(n, sp, x, params, y, lad);
-    if (kt == 10) return inverse ? forward_regs_all<10, true>(n, sp, x, params, y, lad) : forward_regs_all<10, false>(n, sp, x, params, y, lad);
+#define REGS_CASE(KT_) case KT_: return inverse ? forward_regs_all<KT_, true>(n, sp, x, params, y, lad) : forward_regs_all<KT_, false>(n, sp, x, params, y, lad);
+    switch (kt) {   // (every bin count the whole-layer kernels are built for: the exact kernel's plain loop runs this instance)
+        REGS_CASE(2) REGS_CASE(3) REGS_CASE(4) REGS_CASE(5) REGS_CASE(6) REGS_CASE(7) REGS_CASE(8) REGS_CASE(9) REGS_CASE(10)
+        REGS_CASE(11) REGS_CASE(12) REGS_CASE(13) REGS_CASE(14) REGS_CASE(15) REGS_CASE(16)
+    }
+#undef REGS_CASE
     return -1;
 }
 
@@ -181,11 +185,15 @@ static int fused_all(int64_t n, const RqsDev& sp, float kappa, const float* x, c
 extern "C" int host_rqs_forward_fused(int inverse, float kappa, int64_t n, const nfa_rqs_spec* spec, const float* x,
                                       const float* params, float* y, float* lad) {
     RqsDev sp;
-    if (make_dev_spec(spec, &sp) != NFA_OK || !sp.linear || (sp.K != 8 && sp.K != 10)) return -1;
-    if (sp.K == 8) return inverse ? fused_all<FusedSteps<true, 8>, 8>(n, sp, kappa, x, params, y, lad)
-                                  : fused_all<FusedSteps<false, 8>, 8>(n, sp, kappa, x, params, y, lad);
-    return inverse ? fused_all<FusedSteps<true, 10>, 10>(n, sp, kappa, x, params, y, lad)
-                   : fused_all<FusedSteps<false, 10>, 10>(n, sp, kappa, x, params, y, lad);
+    if (make_dev_spec(spec, &sp) != NFA_OK || !sp.linear) return -1;
+#define FUSED_CASE(KT_) case KT_: return inverse ? fused_all<FusedSteps<true, KT_>, KT_>(n, sp, kappa, x, params, y, lad) \
+                                                 : fused_all<FusedSteps<false, KT_>, KT_>(n, sp, kappa, x, params, y, lad);
+    switch (sp.K) {
+        FUSED_CASE(2) FUSED_CASE(3) FUSED_CASE(4) FUSED_CASE(5) FUSED_CASE(6) FUSED_CASE(7) FUSED_CASE(8) FUSED_CASE(9) FUSED_CASE(10)
+        FUSED_CASE(11) FUSED_CASE(12) FUSED_CASE(13) FUSED_CASE(14) FUSED_CASE(15) FUSED_CASE(16)
+    }
+#undef FUSED_CASE
+    return -1;
 }
 '''
 

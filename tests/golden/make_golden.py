@@ -1007,7 +1007,19 @@ def conditional_flow_case():
     print("flows_context: 1 case")
 
 
-def steep_flow_cases():
+def bin_count_flow_cases():
+    """Round 4, the whole-layer kernels' other bin counts (2 .. 16 except 8 and 10): two-layer coupling flows with steep
+    splines (the recipe of steep_flow_cases) at D = 32, H = 128, forward and inverse of the reference in fp32 and fp64.
+    tests/golden/flows_bins.npz; weights rebuilt from seed + steepen, checksums stored."""
+    steep_flow_cases(file_name="flows_bins.npz", only_nsf=True, nsf_cases=tuple(
+        ("bins_k%d" % K, 300 + K, 2, K, 60.0, 6.0, 10.0, 32, 128) for K in (2, 3, 4, 5, 6, 7, 9, 11, 12, 13, 16)))
+
+
+STEEP_NSF_CASES = (("steep_nsf_k8", 21, 2, 8, 60.0, 6.0, 10.0, 64, 512), ("steep_nsf_k8_deep", 25, 4, 8, 20.0, 2.0, 10.0, 64, 512),
+                   ("steep_nsf_k10", 22, 2, 10, 60.0, 6.0, 10.0, 64, 512))
+
+
+def steep_flow_cases(file_name="flows_steep.npz", only_nsf=False, nsf_cases=STEEP_NSF_CASES):
     """Flows whose conditioner outputs are STEEP, as after training (round 4; every earlier whole-flow fixture is
     near-identity in the inverse direction, which hid a Newton step scaled by 1 / delta for two rounds):
     tests/helpers.py:steepen multiplies the width / height rows of every conditioner's output layer until the logits
@@ -1072,9 +1084,8 @@ def steep_flow_cases():
     #  returns x (measured: mean |error| 0.7), every fp32 error is then amplified chaotically and a defective
     #  refinement step drowns in the reference's own error.  Two layers at spread ~ 2 (every feature transformed once,
     #  sharp), four layers at spread ~ 1 (deep, round trip asserted), two layers of 10 bins.)
-    for name, seed, L, K, wh, ds, hs in (("steep_nsf_k8", 21, 2, 8, 60.0, 6.0, 10.0), ("steep_nsf_k8_deep", 25, 4, 8, 20.0, 2.0, 10.0),
-                                         ("steep_nsf_k10", 22, 2, 10, 60.0, 6.0, 10.0)):
-        D, H, B = 64, 128, 512
+    for name, seed, L, K, wh, ds, hs, D, B in nsf_cases:
+        H = 128
         torch.manual_seed(seed)
         layers = []
         for i in range(L):
@@ -1092,6 +1103,12 @@ def steep_flow_cases():
         finish(name, flow, x, noise, dict(kind="rq_nsf", L=L, D=D, K=K, H=H, B=B, tail_bound=3.0, seed=seed,
                                           wh_scale=wh, d_scale=ds, hidden_scale=hs,
                                           logit_std_wh_d_per_layer=[(round(a, 3), round(b, 3)) for a, b in spread]))
+
+    if only_nsf:
+        out["meta"] = np.array(meta, dtype=object).astype(str)
+        np.savez_compressed(os.path.join(HERE, file_name), **out)
+        print(file_name, len(meta), "cases")
+        return
 
     # affine analogue (configs[1]'s layer: AffineCouplingTransform + MLP [128, 128]): scale logits ~ N(0, 2)
     seed, L, D, B, ds = 23, 4, 32, 512, 8.0
@@ -1124,7 +1141,7 @@ def steep_flow_cases():
                 logit_std_wh_d_per_layer=[(round(a, 3), round(b, 3)) for a, b in spread]))
 
     out["meta"] = np.array(meta, dtype=object).astype(str)
-    np.savez_compressed(os.path.join(HERE, "flows_steep.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, file_name), **out)
     print("flows_steep:", len(meta), "cases")
 
 
@@ -1155,6 +1172,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "steep":
         steep_flow_cases()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bins":
+        bin_count_flow_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cdf":
         cdf_cases()
         sys.exit(0)
@@ -1174,3 +1194,4 @@ if __name__ == "__main__":
     cubic_coupling_cases()
     sibling_autoregressive_cases()
     steep_flow_cases()
+    bin_count_flow_cases()

@@ -222,12 +222,12 @@ def steepen(module, num_bins=None, wh_scale=1.0, d_scale=1.0, hidden_scale=1.0):
     return module
 
 
-def steep_flow(golden_dir, name):
-    """A flow of tests/golden/flows_steep.npz rebuilt from its seed and `steepen` (weights are not stored; the
+def steep_flow(golden_dir, name, fixture="flows_steep.npz"):
+    """A flow of tests/golden/flows_steep.npz (or `fixture`: flows_bins.npz, the other bin counts) rebuilt from its seed and `steepen` (weights are not stored; the
     per-parameter checksums of the reference's weights are, and are checked here).  Returns (flow on CPU, npz, cfg)."""
     import torch
     from nflows_amd import configs
-    g = np.load(os.path.join(golden_dir, "flows_steep.npz"))
+    g = np.load(os.path.join(golden_dir, fixture))
     cfg = parse_kwargs(dict((str(n), str(c)) for n, c in g["meta"])[name])
     if cfg["kind"] == "rq_nsf":
         flow = configs.rq_nsf_flow(cfg["L"], cfg["D"], cfg["K"], cfg["H"], 2, cfg["tail_bound"], seed=cfg["seed"])

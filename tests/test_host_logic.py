@@ -218,7 +218,7 @@ def test_distribution_template_methods():
     assert "_log_z" not in d.state_dict() and d._log_z.dtype == torch.float64
 
 
-@pytest.mark.parametrize("K", [8, 10])
+@pytest.mark.parametrize("K", [8, 10, 4, 12, 16])
 def test_whole_layer_packing_is_a_lossless_rearrangement(K):
     """Host side of K8 (ops.pack_resnet_conditioner, runs on CPU tensors): emulate what the kernel
     computes with the packed weights -- every GEMM transposed, the k index permuted the way the
@@ -229,7 +229,8 @@ def test_whole_layer_packing_is_a_lossless_rearrangement(K):
     from nflows_amd.nn.nets import ResidualNet
     torch.manual_seed(0)
     dt, di, P = 8, 6, 3 * K - 1
-    R = 24 if K == 8 else 32                        # rows per feature after padding
+    R = ops.final_rows_per_feature(P)               # rows per feature after padding: 24 (8 bins), else whole 16s
+    assert R == {8: 24, 10: 32, 4: 16, 12: 48, 16: 48}[K]
     net = ResidualNet(di, dt * P, hidden_features=128, num_blocks=2).double()
     with torch.no_grad():
         for p_ in net.parameters():
@@ -320,14 +321,15 @@ def test_whole_layer_packing_is_a_lossless_rearrangement(K):
     assert stage == wp.shape[0]
     want = net.final_layer(want_hidden).view(32, dt, P).clone()
     want[..., :2 * K] /= np.sqrt(128.0)              # the folded 1/sqrt(hidden) scale
-    if K == 10:  # two tiles per group: the 32 values of a lane-half are feature 2g + half
+    if K != 8:  # T tiles per group (10 bins: two): the 16 T values of a lane-half are feature 2g + half
+        T = R // 16
         for g in range(dt // 2):
             for half in range(2):
                 lanes = torch.arange(32) + 32 * half
-                vals = torch.cat([out[2 * g + t][lanes] for t in range(2)], dim=1)   # [32 samples][32]
+                vals = torch.cat([out[T * g + t][lanes] for t in range(T)], dim=1)   # [32 samples][16 T]
                 ref = want[:, 2 * g + half]
                 assert (vals[:, :P] - ref).abs().max().item() < 5e-6 * (1 + ref.abs().max().item()), (g, half)
-                assert vals[:, P:].abs().max().item() == 0.0                         # the pad rows
+                assert not vals[:, P:].any()                                          # the pad rows
         return
     for g in range(dt // 4):
         for half in range(2):
@@ -349,7 +351,7 @@ def _emulate_f16_whole_layer(wp, prm, x, di, dt, K, num_blocks, ctx=None):
     sqrt(hidden)), stages consumed, parameter words consumed)."""
     H = 4  # header floats
     P = 3 * K - 1
-    R = 24 if K == 8 else 32
+    R = 24 if K == 8 else 16 * ((P + 15) // 16)
     tiles = dt * R // 32
     w = wp.double().view(-1, 1024, 8)
     bp = prm
@@ -449,8 +451,16 @@ def _emulate_f16_whole_layer(wp, prm, x, di, dt, K, num_blocks, ctx=None):
     stage = tile_major(stage, out, hp)
     off += H + tiles * 32
     out = out * kappa
-    assert K == 8
     logits = torch.zeros(32, dt, P, dtype=torch.float64)
+    if K != 8:   # T tiles per group of two features: lane-half h of group g holds feature 2g + h
+        T = R // 16
+        for g in range(dt // 2):
+            for half in range(2):
+                lanes = torch.arange(32) + 32 * half
+                vals = torch.cat([out[T * g + t][lanes] for t in range(T)], dim=1)
+                logits[:, 2 * g + half] = vals[:, :P]
+                assert not vals[:, P:].any()   # (11 bins: 32 logits, no pad row)
+        return hidden, logits, stage, off
     for g in range(dt // 4):
         for half in range(2):
             lanes = torch.arange(32) + 32 * half
@@ -580,7 +590,7 @@ def test_f16_tile16_packing_reproduces_the_network(di):
 
 
 @pytest.mark.parametrize("act_scale", [1.0, 16.0])
-def test_f16_whole_layer_packing_carries_the_scales(act_scale):
+def test_f16_whole_layer_packing_carries_the_scales(act_scale, K=8):
     """Host side of K8h (ops.pack_resnet_conditioner_f16 / build_f16_stream): emulate the kernel's
     data flow with the packed stream -- the parameter stage (tables, per-GEMM headers {out_scale,
     skip_scale}, pre-scaled biases), every GEMM tile-major on two f16 weight pieces pre-scaled by a
@@ -590,7 +600,7 @@ def test_f16_whole_layer_packing_carries_the_scales(act_scale):
     from nflows_amd import ops
     from nflows_amd.nn.nets import ResidualNet
     torch.manual_seed(0)
-    K, dt, di = 8, 8, 6
+    dt, di = 8, 6
     P = 3 * K - 1
     net = ResidualNet(di, dt * P, hidden_features=128, num_blocks=2).double()
     with torch.no_grad():
@@ -598,7 +608,7 @@ def test_f16_whole_layer_packing_carries_the_scales(act_scale):
             p_.copy_(torch.randn_like(p_) * (0.3 if i_ % 3 else 0.004))   # GEMMs of very different magnitudes
     wp, prm = ops.pack_resnet_conditioner_f16(net.float(), dt, P, act_scale=act_scale)
     net = net.double()
-    tiles = dt * 24 // 32
+    tiles = dt * ops.final_rows_per_feature(P) // 32
     H = 4  # header floats
     assert wp.shape == (1 + 8 * 2 + tiles, 1024 * 8) and wp.dtype == torch.float16   # 16 KB stages of eight pairs
     assert prm.shape == ((H + 128) * 5 + H + tiles * 32,)
@@ -618,6 +628,13 @@ def test_f16_whole_layer_packing_carries_the_scales(act_scale):
     want = net.final_layer(want_hidden).view(32, dt, P).clone()
     want[..., :2 * K] /= np.sqrt(128.0)
     assert (logits - want).abs().max().item() < 2e-6 * (1 + want.abs().max().item())
+
+
+@pytest.mark.parametrize("K", [2, 4, 5, 7, 10, 11, 12, 16])
+def test_f16_whole_layer_packing_of_other_bin_counts(K):
+    """Round 4: the final layer of 2 .. 16 bins -- 3 K - 1 logits per feature padded to whole lane-half shares of 16,
+    T = 1 .. 3 tiles per group of two features -- through the same emulation of K8h's data flow."""
+    test_f16_whole_layer_packing_carries_the_scales(1.0, K)
 
 
 def test_f16_whole_layer_packing_with_a_context():

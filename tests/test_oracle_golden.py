@@ -183,6 +183,30 @@ def test_eager_port_bit_identical_on_steep_flows(golden_dir):
             assert min(min(pair) for pair in cfg["logit_std_wh_d_per_layer"]) > (0.6 if name.endswith("deep") else 1.8), name
 
 
+BIN_COUNTS = (2, 3, 4, 5, 6, 7, 9, 11, 12, 13, 16)
+
+
+def test_eager_port_bit_identical_on_other_bin_counts(golden_dir):
+    """tests/golden/flows_bins.npz (round 4): steep two-layer coupling flows with 2 .. 16 bins (the counts the
+    whole-layer kernels serve besides 8 and 10), forward and inverse of the real reference: the eager port reproduces
+    every vector bit for bit, so tests/test_gpu_bins.py may extend the fixture's rows with the port's evaluation."""
+    import torch
+    from helpers import steep_flow
+    from oracle import eager
+    torch.set_num_threads(1)
+    for K in BIN_COUNTS:
+        name = "bins_k%d" % K
+        flow, g, cfg = steep_flow(golden_dir, name, "flows_bins.npz")
+        assert cfg["K"] == K
+        with torch.no_grad():
+            z, lad = eager.flow_transform(flow, torch.from_numpy(g[name + "/x"]))
+            lp = eager.flow_log_prob(flow, torch.from_numpy(g[name + "/x"]))
+            xi, ladi = eager.flow_transform(flow, torch.from_numpy(g[name + "/noise"]), inverse=True)
+        for got, key in ((z, "z"), (lad, "lad"), (lp, "log_prob"), (xi, "inv_x"), (ladi, "inv_lad")):
+            assert np.array_equal(got.numpy(), g[name + "/" + key]), (name, key)
+        assert min(min(pair) for pair in cfg["logit_std_wh_d_per_layer"]) > 1.5, (name, cfg["logit_std_wh_d_per_layer"])
+
+
 def test_eager_port_other_configs_bit_identical(golden_dir):
     """The eager port on the affine stack (configs[1]'s layer type) and on the autoregressive RQ layer
     (configs[4]) in both directions -- the latter's inverse is the reference's D-pass loop -- : bit-identical to the reference, in float32

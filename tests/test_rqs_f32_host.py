@@ -155,7 +155,7 @@ def test_k8h_inverse_newton_step_has_the_right_slope(lib, golden_dir):
     assert np.abs(back[fin] - xs[fin]).max() <= 1e-4
 
 
-@pytest.mark.parametrize("K", [8, 10])
+@pytest.mark.parametrize("K", [8, 10, 2, 3, 4, 5, 6, 7, 9, 11, 12, 13, 16])
 def test_every_evaluator_stays_in_the_reference_error_class_across_logit_scales(lib, K):
     """Random splines from gentle (logits ~ 0.1 N(0, 1): an untrained flow) to steep (3 N(0, 1)), both directions, every
     per-lane evaluator of the kernels (K1 / K5's rqs_eval, run-time-K and compile-time-K; K7's flat form; K8's sliced
@@ -164,7 +164,10 @@ def test_every_evaluator_stays_in_the_reference_error_class_across_logit_scales(
     inverse sat at 13 x / 80 x here."""
     rng = np.random.RandomState(K)
     n = 20000
-    kinds = ["eval0", "evalK", "fused"] + (["flat8", "steps0", "steps1"] if K == 8 else ["steps2"])
+    # (other bin counts, round 4: the whole-layer kernels run FusedSteps<K> -- K8h -- and rqs_eval's register instance --
+    #  the exact kernel's plain loop)
+    kinds = (["eval0", "evalK", "fused"] + (["flat8", "steps0", "steps1"] if K == 8 else ["steps2"]) if K in (8, 10)
+             else ["eval0", "fused", "regs"] + (["evalK"] if K == 4 else []))
     spec, ospec = product_spec(K, tails="linear", tail_bound=3.0), capi.make_spec(K, tails="linear", tail_bound=3.0)
     for scale in (0.1, 1.0, 3.0):
         x = (rng.randn(n) * 1.3).astype(np.float32)
@@ -184,11 +187,23 @@ def test_every_evaluator_stays_in_the_reference_error_class_across_logit_scales(
                 elif kind == "flat8":
                     lib.host_rqs_forward_flat8(inverse, *args)
                 elif kind == "fused":
-                    lib.host_rqs_forward_fused(inverse, 1.0, *args)
+                    assert lib.host_rqs_forward_fused(inverse, 1.0, *args) == 0
+                elif kind == "regs":
+                    assert lib.host_rqs_forward_regs(K, inverse, *args) == 0
                 else:
                     lib.host_rqs_forward_flatsteps(int(kind[5:]), inverse, *args)
                 for got, truth, ref, what in ((y, y64, y32, "y"), (lad, l64, l32, "logabsdet")):
                     e_got, e_ref = np.abs(got - truth), np.abs(ref - truth)
                     tag = "%s %s scale %.1f %s" % (kind, what, scale, "inverse" if inverse else "forward")
-                    assert e_got.mean() <= 1.6 * e_ref.mean(), "%s: mean %.2e vs %.2e" % (tag, e_got.mean(), e_ref.mean())
-                    assert e_got.max() <= 6.0 * e_ref.max() + 1e-6, "%s: max %.2e vs %.2e" % (tag, e_got.max(), e_ref.max())
+                    # (more than 10 bins: FusedSteps' knots are running fp32 sums, the reference rounds a double-precision
+                    #  cumulative sum once per knot -- at 16 bins and steep logits the mean reaches 1.7 x; the GPU suite's
+                    #  rule for the kernels is 2 x)
+                    mean_rule = 1.6 if K <= 10 else 2.0
+                    assert e_got.mean() <= mean_rule * e_ref.mean(), "%s: mean %.2e vs %.2e" % (tag, e_got.mean(), e_ref.mean())
+                    # (the worst of 20 000 random elements is one ill-conditioned bin: a 5 - 6 x ratio is already there for
+                    #  8 bins; the other bin counts -- fewer samples per bin shape -- get the 99.9 % quantile as the tight
+                    #  rule and a looser bound on the single worst element)
+                    worst = 6.0 if K in (8, 10) else 15.0
+                    assert e_got.max() <= worst * e_ref.max() + 1e-6, "%s: max %.2e vs %.2e" % (tag, e_got.max(), e_ref.max())
+                    q_got, q_ref = np.quantile(e_got, 0.999), np.quantile(e_ref, 0.999)
+                    assert q_got <= 2.0 * q_ref + 1e-7, "%s: q999 %.2e vs %.2e" % (tag, q_got, q_ref)
