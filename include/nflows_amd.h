@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define NFA_ABI_VERSION 8  /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 7; round 4: 8) */
+#define NFA_ABI_VERSION 9  /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 7; round 4: 8,
+                              9: whole-layer kernels for 2 .. 16 bins, nfa_resnet_backward_f32, W_f^T in K14's backward stream) */
 
 /* return codes */
 #define NFA_OK 0
@@ -593,6 +594,19 @@ int nfa_resnet_hidden_forward_f32(const float *identity_inputs, const void *weig
 int nfa_resnet_hidden_backward_f32(const float *grad_hidden, const void *weights_packed, const float *saved,
                                    float *grads, float *grad_identity_inputs, int64_t batch, int32_t num_identity,
                                    int32_t hidden_features, int32_t num_blocks, void *stream);
+/* The backward pass from the conditioner's OUTPUT gradient (round 4): grad_params [batch, out_features] (out_features
+ * % 4 == 0) -- the kernel first forms d loss / d hidden = grad_params W_f (the final Linear's input gradient,
+ * resnet.py:99 under autograd; a library GEMM before) as a k-major GEMM over the out_features columns, writes it to
+ * grad_hidden [batch, 128] (the grad_outputs of the last block's second Linear, for nfa_linear_wgrad_f32) and continues
+ * as nfa_resnet_hidden_backward_f32.  weights_packed: the packer's backward stream of a call WITH the final Linear:
+ * behind W_in^T's stages it carries W_f^T as ceil(out_features / 16) k-major stages (k = column of grad_params in
+ * natural order, zero past out_features, units past hidden_features zero), which this kernel consumes first;
+ * backward_stages of the packer is then (16 num_blocks + 2 ceil(num_identity / 32) + ceil(out_features / 16)) x 12288
+ * bytes, its prefix unchanged (nfa_resnet_hidden_backward_f32 reads only the prefix). */
+int nfa_resnet_backward_f32(const float *grad_params, int32_t out_features, const void *weights_packed,
+                            const float *saved, float *grads, float *grad_hidden, float *grad_identity_inputs,
+                            int64_t batch, int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
+                            void *stream);
 
 /*
  * K9.  The spline's siblings as elementwise functionals (no row-sum), same calling convention as

@@ -31,7 +31,7 @@ FLAG_PAD_COLUMNS_SHIFT = 8   # bits 8-10: trailing pad columns the density epilo
 TAILS_NONE, TAILS_LINEAR = 0, 1
 SCALE_DEFAULT, SCALE_GENERAL, SCALE_ADDITIVE, SCALE_GIVEN, SCALE_SOFTPLUS = 0, 1, 2, 3, 4
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 EXPORTS = (
     "nfa_abi_version",
@@ -53,6 +53,7 @@ EXPORTS = (
     "nfa_pack_resnet_hidden_train_f32",
     "nfa_resnet_hidden_forward_f32",
     "nfa_resnet_hidden_backward_f32",
+    "nfa_resnet_backward_f32",
     "nfa_rqs_flow_resnet_f16x2_f32",
     "nfa_rqs_flow_resnet_f16x2_tile16_f32",
     "nfa_rqs_flow_resnet_context_f16x2_f32",
@@ -157,6 +158,8 @@ def _declare(lib):
     lib.nfa_resnet_hidden_forward_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp]
     lib.nfa_resnet_hidden_backward_f32.restype = ctypes.c_int
     lib.nfa_resnet_hidden_backward_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
+    lib.nfa_resnet_backward_f32.restype = ctypes.c_int
+    lib.nfa_resnet_backward_f32.argtypes = [vp, i32, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
     lib.nfa_rqs_elementwise_backward_f64.restype = ctypes.c_int
     lib.nfa_rqs_elementwise_backward_f64.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, vp, vp, vp,
                                                      i64, sp, i32, vp]

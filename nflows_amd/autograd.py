@@ -333,7 +333,8 @@ class ResidualNetHidden(torch.autograd.Function):
     """K14: a ResidualNet (initial Linear + residual blocks, and with `with_final` the final Linear: resnet.py:92-100)
     under autograd -- `nfa_resnet_hidden_forward_f32` forward, `nfa_resnet_hidden_backward_f32` for the chain of input
     gradients through the hidden part, K10 (`nfa_linear_wgrad_f32`) for every weight / bias gradient on the arrays
-    the two leave behind; the final Linear's input gradient is one library GEMM.  Arguments: the identity features
+    the two leave behind; the final Linear's input gradient is the backward kernel's first GEMM (round 4:
+    `nfa_resnet_backward_f32`; a library GEMM before).  Arguments: the identity features
     [B, d_i], with_final, then W_in, b_in, (W_0, b_0, W_1, b_1) per block and, with_final, W_f, b_f."""
 
     @staticmethod
@@ -382,16 +383,24 @@ class ResidualNetHidden(torch.autograd.Function):
 
         narrow = H if H != 128 else None
         tail = ()
+        fused = None
         if ctx.with_final:
             x, saved, bwd_w, hidden, w_f = ctx.saved_tensors
             tail = wgrad(hidden, g_out, need[-2], need[-1], cols=narrow)
-            g_hidden = g_out @ w_f            # the final Linear's input gradient: one library GEMM
+            # the final Linear's input gradient inside the backward kernel (round 4; its W_f^T stages are in `bwd_w`)
+            if ops.FUSED_FINAL_DGRAD:
+                fused = ops.resnet_backward(g_out, bwd_w, saved, x.shape[1])
+            if fused is None:
+                g_hidden = g_out @ w_f        # ... or one library GEMM
         else:
             x, saved, bwd_w = ctx.saved_tensors
             g_hidden = g_out
-        if narrow is not None:
-            g_hidden = torch.nn.functional.pad(g_hidden, (0, 128 - H))
-        g_x, grads = ops.resnet_hidden_backward(g_hidden, bwd_w, saved, x.shape[1])
+        if fused is not None:
+            g_x, grads, g_hidden = fused      # (g_hidden [B, 128]: zero columns past a narrower net's width)
+        else:
+            if narrow is not None:
+                g_hidden = torch.nn.functional.pad(g_hidden, (0, 128 - H))
+            g_x, grads = ops.resnet_hidden_backward(g_hidden, bwd_w, saved, x.shape[1])
         di = ctx.di if ctx.di != x.shape[1] else None      # (x was saved with its pad columns)
         out = [(g_x if di is None else g_x[:, :di]) if ctx.needs_input_grad[0] else None, None]
         out += wgrad(x, grads[0] if nb else g_hidden, need[0], need[1], rows=narrow, cols=di)

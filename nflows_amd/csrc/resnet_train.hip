@@ -49,6 +49,12 @@ struct TrainArgs {
     const float* fbias;  // accumulator-order bias, 32 per tile (zeros past out_features)
     float* params;       // [B, out_features]
     int out_features, final_tiles;
+    // backward with the final Linear's input gradient (round 4): g_params [B, out_features] instead of g_h -- the kernel
+    // starts with g_h = g_params W_f (k-major over out_features, W_f^T's stages at `final_first` of the backward
+    // stream) and writes g_h to `grad_hidden` for K10 (grad_outputs of the last block's second Linear)
+    const float* gparams;
+    float* grad_hidden;
+    int final_ksteps, final_first;
 };
 
 // accumulator tile <-> rows of a [B, 128] array: element (row, 32 t + 8 q4 + 4 half + i) = acc[4 q4 + i]
@@ -136,7 +142,7 @@ __device__ __forceinline__ void store_tile(float* base, int64_t row, int t, int 
 #define NFA_K14_KSTEP 0   // 1: the pairwise k-step (round-4 experiment)
 #endif
 constexpr int kTrainRing = NFA_K14_RING, kTrainAhead = kTrainRing - 1;
-static_assert(kTrainRing >= 3 && 3 * (kTrainAhead - 1) <= 63, "vmcnt is a 6-bit count");
+static_assert(kTrainRing >= 3 && 5 * (kTrainAhead - 1) <= 63, "vmcnt is a 6-bit count");
 
 struct TrainStream {
     const vec4f* w;
@@ -174,10 +180,11 @@ __device__ __forceinline__ void tstream_advance(TrainStream& sm) {
     sm.slot = (sm.slot + 1 == kTrainRing) ? 0 : sm.slot + 1;
 }
 
-__device__ __forceinline__ void start_stream(TrainStream& sm, const vec4f* w, float* lds, int num_stages, int tid) {
+__device__ __forceinline__ void start_stream(TrainStream& sm, const vec4f* w, float* lds, int num_stages, int tid,
+                                             int first_stage = 0) {
     sm.w = w;
     sm.ring = reinterpret_cast<vec4f*>(lds);
-    sm.fetch = 0;
+    sm.fetch = first_stage;
     sm.num_stages = num_stages;
     sm.tid = tid;
 #pragma unroll
@@ -408,6 +415,64 @@ __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_forward_kernel(const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- the final Linear's input gradient inside the backward kernel (round 4): g_h^T [128 x 32 samples] = W_f^T
+//      [128 x out] g_params^T, k-major over the out_features columns of g_params, 16 per k-step.  The wave's share
+//      of g_params -- 32 rows x 16 columns = 2 KB per k-step -- arrives by LDS-DMA like the weights (ordinary loads
+//      may not share the counter with the ring's requests: see the file header) in a wave-private ring of
+//      kTrainRing 2-KB images behind the weight ring: two requests per k-step (16 rows x 64 bytes each), issued with
+//      the weight stage of the same k-step, kTrainAhead k-steps ahead.  Image layout: row r at 64 r bytes, the
+//      row's four 16-byte chunks XOR-swizzled by (r >> 1) & 3 -- lane (half, r) reads chunks 2 half, 2 half + 1 of
+//      its row (its eight k values, as in the forward kernel's initial layer), eight consecutive lanes hit eight
+//      different bank quads.  Columns past out_features (the last k-step of a width that is not a multiple of 16)
+//      are fetched from the row's last chunk instead: their weights in the stream are zero.
+constexpr int kGpImageBytes = 32 * 64;
+
+__device__ __forceinline__ void gp_request(const float* gparams, int out_features, int64_t row0, int ks, char* image, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 16 * i + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((r >> 1) & 3);
+        int col = ks * 16 + chunk * 4;
+        col = col < out_features ? col : out_features - 4;
+        const float* src = gparams + (row0 + r) * (int64_t)out_features + col;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(image + i * 1024), 16, 0, 0);
+    }
+}
+
+// one k-step of the final Linear's input gradient: requests (weights and g_params of k-step ks + kTrainAhead), the
+// lane's eight values from the image of k-step ks, 24 MFMAs, the counted wait for k-step ks + 1
+__device__ __forceinline__ void kstep_final(f32x16 (&acc)[4], TrainStream& sm, const float* gparams, int out_features,
+                                            int64_t row0, int ks, int final_ksteps, char* images, int lane) {
+    tstream_request(sm);
+    const bool more = ks + kTrainAhead < final_ksteps;   // (wave-uniform)
+    if (more) gp_request(gparams, out_features, row0, ks + kTrainAhead, images + ((ks + kTrainAhead) % kTrainRing) * kGpImageBytes, lane);
+    const int half = lane >> 5, r = lane & 31;
+    const char* img = images + (ks % kTrainRing) * kGpImageBytes + r * 64;
+    const int sw = (r >> 1) & 3;
+    const vec4f v0 = *reinterpret_cast<const vec4f*>(img + (((2 * half) ^ sw) << 4));
+    const vec4f v1 = *reinterpret_cast<const vec4f*>(img + (((2 * half + 1) ^ sw) << 4));
+    bf16x2 hh[4], mm[4], ll[4];
+    split3(vec2f{v0.x, v0.y}, hh[0], mm[0], ll[0]);
+    split3(vec2f{v0.z, v0.w}, hh[1], mm[1], ll[1]);
+    split3(vec2f{v1.x, v1.y}, hh[2], mm[2], ll[2]);
+    split3(vec2f{v1.z, v1.w}, hh[3], mm[3], ll[3]);
+    const bf16x8 bh = join4(hh[0], hh[1], hh[2], hh[3]), bm = join4(mm[0], mm[1], mm[2], mm[3]),
+                 bl = join4(ll[0], ll[1], ll[2], ll[3]);
+    const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(t * 3 + 0) * 64]);
+        const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(t * 3 + 1) * 64]);
+        const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(t * 3 + 2) * 64]);
+        NFA_MFMA6(acc[t], ah, am, al, bh, bm, bl);
+    }
+    // stage ks + 1 (weights and image) has landed when only this k-step's own requests may be pending
+    if (more) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(5 * (kTrainAhead - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(3 * (kTrainAhead - 1)) : "memory");
+    sm.slot = (sm.slot + 1 == kTrainRing) ? 0 : sm.slot + 1;
+}
+
 // 64 ReLU masks of a lane (4 tiles x 16 accumulator registers) as two words: bit 16 t + q of the pair
 struct Mask64 {
     unsigned lo, hi;   // tiles 0-1, tiles 2-3
@@ -449,14 +514,18 @@ __device__ __forceinline__ void zero_tile(f32x16& acc) {
     for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
 }
 
-template <int NB>   // number of blocks (their masks live in registers): 0 .. 3 (four would spill: no scratch traffic
-                    // may share the counter of the LDS-DMA ring)
+template <int NB, bool FINAL = false>   // number of blocks (their masks live in registers): 0 .. 3 (four would spill: no
+                                        // scratch traffic may share the counter of the LDS-DMA ring); FINAL: the incoming
+                                        // gradient is g_params and the final Linear's input gradient is computed first
 __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_backward_kernel(const TrainArgs a) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TrainStream sm;
-    start_stream(sm, a.w, lds_dyn, a.num_stages, tid);
+    start_stream(sm, a.w, lds_dyn, a.num_stages, tid, FINAL ? a.final_first : 0);
+    // FINAL: this wave's ring of g_params images, behind the weight ring
+    [[maybe_unused]] char* gp_images = reinterpret_cast<char*>(lds_dyn + kTrainRing * kStageVec4 * 4) +
+                                       __builtin_amdgcn_readfirstlane(wave) * (kTrainRing * kGpImageBytes);
     // (the staged full-line stores measured no gain in this kernel -- 92.1 vs 91.5 us -- and cost 92 bytes of scratch:
     //  the backward pass keeps the direct stores)
     float* stage = nullptr;
@@ -465,16 +534,38 @@ __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_backward_kernel(const
     const int tiles_x = (a.di + 31) >> 5;
     for (int64_t quad = blockIdx.x; quad < num_quads; quad += gridDim.x) {
         const int64_t row0 = (quad << 7) + (wave << 5);
+        f32x16 gs[4];   // g_h: the gradient of the residual stream, fp32, accumulator layout
+        if constexpr (FINAL) {
+            // ---- g_h = g_params W_f, BEFORE anything else of the row block is live (the masks of two blocks held across
+            //      this loop pushed the allocation into 115 spilled registers): the first kTrainAhead images of the row
+            //      block -- nothing else is in flight, the ring's requests were drained at the end of the previous block
+            int lane_f = lane;
+            asm volatile("" : "+v"(lane_f));
+#pragma unroll
+            for (int ks = 0; ks < kTrainAhead; ++ks)
+                if (ks < a.final_ksteps) gp_request(a.gparams, a.out_features, row0, ks, gp_images + ks * kGpImageBytes, lane_f);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < 4; ++t) zero_tile(gs[t]);
+            for (int ks = 0; ks < a.final_ksteps; ++ks)
+                kstep_final(gs, sm, a.gparams, a.out_features, row0, ks, a.final_ksteps, gp_images, lane_f);
+            // g_h leaves at once (K10's grad_outputs of the last block's second Linear)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) store_tile<false>(a.grad_hidden, row0 + (lane_f & 31), t, lane_f >> 5, gs[t], nullptr);
+            // the masks' ordinary loads follow: everything in flight -- these stores, the ring's two stages ahead -- is
+            // awaited first and the loads are awaited explicitly (load_mask), so no compiler-counted wait meets an LDS-DMA
+            // request
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         int lane_here = lane, di = a.di;
         asm volatile("" : "+v"(lane_here), "+s"(di));
         const int half = lane_here >> 5, r = lane_here & 31;
         const int64_t row = row0 + r;
-        // ---- with the ring drained: the ReLU masks of every block, then the incoming gradient
+        // ---- (without the final Linear: with the ring drained) the ReLU masks of every block, then the incoming gradient
         Mask64 masks[2 * NB > 0 ? 2 * NB : 1];
 #pragma unroll
         for (int i = 0; i < 2 * NB; ++i) masks[i] = load_mask(a.saved + i * plane, row, half);
-        f32x16 gs[4];   // g_h: the gradient of the residual stream, fp32, accumulator layout
-        {
+        if constexpr (!FINAL) {
             vec4f v[16];
             load_tiles_raw(v, a.x, row, half);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -583,9 +674,9 @@ __global__ void __launch_bounds__(kBlock) pack_resnet_hidden_kernel(const PackAr
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;   // grp: tile t (k-major) or k4 (tile-major)
     const int hf = lane >> 5, i = lane & 31;
     const int n_hid = a.init_ks + 16 * a.nb, n_fwd = n_hid + 2 * a.final_tiles, n_bwd_k = 16 * a.nb,
-              tiles_x = (a.di + 31) >> 5;
+              tiles_x = (a.di + 31) >> 5, n_final_t = (a.out_features + 15) >> 4;
     int s = blockIdx.x;
-    if (s == n_fwd + n_bwd_k + 2 * tiles_x) {   // the biases, accumulator order: [tile][half][q] = b[32 tile + 8 (q / 4) + 4 half + q % 4]
+    if (s == n_fwd + n_bwd_k + 2 * tiles_x + n_final_t) {   // the biases, accumulator order: [tile][half][q] = b[32 tile + 8 (q / 4) + 4 half + q % 4]
         for (int e = tid; e < 128 * (1 + 2 * a.nb); e += kBlock) {
             const int v = e >> 7, r = e & 127;
             const float* b = v == 0 ? a.b_in : a.blk[(v - 1) >> 1][((v - 1) & 1) ? 3 : 1];
@@ -641,6 +732,17 @@ __global__ void __launch_bounds__(kBlock) pack_resnet_hidden_kernel(const PackAr
         for (int j = 0; j < 8; ++j) {
             const int col = acc_col(ks, hf, j);
             v[j] = (row < a.H && col < a.H) ? w[col * a.H + row] : 0.0f;
+        }
+    } else if (s >= n_fwd + n_bwd_k + 2 * tiles_x) {   // W_f^T (round 4: the final Linear's input gradient inside the
+        // backward kernel), k-major over the out_features columns of g_params in their natural order: A[h][c] = W_f[c][h]
+        s -= n_fwd;
+        dst = a.bwd + (size_t)s * 6144;
+        const int ks = s - n_bwd_k - 2 * tiles_x;
+        const int row = 32 * grp + i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = ks * 16 + hf * 8 + j;
+            v[j] = (col < a.out_features && row < a.H) ? a.w_f[col * a.H + row] : 0.0f;
         }
     } else {                            // W_in^T, tile-major: [piece][k4][lane], rows past d_i are zero
         s -= n_fwd;
@@ -721,6 +823,9 @@ extern "C" int nfa_resnet_hidden_forward_f32(const float* identity_inputs, const
     a.params = params;
     a.out_features = out_features;
     a.final_tiles = (out_features + 31) / 32;
+    a.gparams = nullptr;
+    a.grad_hidden = nullptr;
+    a.final_ksteps = a.final_first = 0;
     a.num_stages = init_ks + 16 * num_blocks + 2 * a.final_tiles;
     const size_t lds = (size_t)kTrainRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * kTrainTileFloats * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
@@ -735,14 +840,18 @@ extern "C" int nfa_resnet_hidden_forward_f32(const float* identity_inputs, const
     return NFA_OK;
 }
 
-extern "C" int nfa_resnet_hidden_backward_f32(const float* grad_hidden, const void* weights_packed, const float* saved,
-                                              float* grads, float* grad_identity_inputs, int64_t batch,
-                                              int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
-                                              void* stream) {
+static int launch_train_backward(const float* grad_hidden, const float* grad_params, int32_t out_features,
+                                 float* grad_hidden_out, const void* weights_packed, const float* saved, float* grads,
+                                 float* grad_identity_inputs, int64_t batch, int32_t num_identity,
+                                 int32_t hidden_features, int32_t num_blocks, void* stream) {
     const int rc = check_train(batch, num_identity, hidden_features, num_blocks);
     if (rc != NFA_OK) return rc;
+    const bool with_final = grad_params != nullptr || out_features != 0;
+    if (with_final && out_features < 4) return NFA_ERR_INVALID_ARGUMENT;
+    if (with_final && ((out_features & 3) != 0 || out_features > 32 * 1024)) return NFA_ERR_UNSUPPORTED;
     if (batch == 0) return NFA_OK;
-    if (!grad_hidden || !weights_packed || !grad_identity_inputs || (num_blocks > 0 && (!saved || !grads)))
+    if ((!with_final && !grad_hidden) || (with_final && (!grad_params || !grad_hidden_out)) || !weights_packed ||
+        !grad_identity_inputs || (num_blocks > 0 && (!saved || !grads)))
         return NFA_ERR_INVALID_ARGUMENT;
     TrainArgs a;
     a.x = grad_hidden;
@@ -759,20 +868,57 @@ extern "C" int nfa_resnet_hidden_backward_f32(const float* grad_hidden, const vo
     a.out_features = 0;
     a.final_tiles = 0;
     a.num_stages = 16 * num_blocks + 2 * ((num_identity + 31) / 32);
-    const size_t lds = (size_t)kTrainRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * kTrainTileFloats * sizeof(float);
+    a.gparams = grad_params;
+    a.grad_hidden = grad_hidden_out;
+    a.final_ksteps = 0;
+    a.final_first = 0;
+    if (with_final) {   // W_f^T's k-major stages sit behind W_in^T's in the backward stream and are consumed FIRST
+        a.out_features = out_features;
+        a.final_ksteps = (out_features + 15) / 16;
+        a.final_first = a.num_stages;
+        a.num_stages += a.final_ksteps;
+    }
+    // behind the weight ring: the store images (unused here: the backward pass stores directly) or, with the final
+    // Linear, every wave's ring of g_params images
+    const size_t lds = (size_t)kTrainRing * kStageVec4 * 16 +
+                       (with_final ? (size_t)(kBlock / kWave) * kTrainRing * kGpImageBytes
+                                   : (size_t)(kBlock / kWave) * kTrainTileFloats * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid = train_grid(batch), block(kBlock);
-    void (*kern)(const TrainArgs) = num_blocks == 0 ? resnet_hidden_backward_kernel<0>
-                                    : num_blocks == 1 ? resnet_hidden_backward_kernel<1>
-                                    : num_blocks == 2 ? resnet_hidden_backward_kernel<2> : resnet_hidden_backward_kernel<3>;
+    void (*kern)(const TrainArgs) = nullptr;
+    if (with_final)
+        kern = num_blocks == 0 ? resnet_hidden_backward_kernel<0, true> : num_blocks == 1 ? resnet_hidden_backward_kernel<1, true>
+               : num_blocks == 2 ? resnet_hidden_backward_kernel<2, true> : resnet_hidden_backward_kernel<3, true>;
+    else
+        kern = num_blocks == 0 ? resnet_hidden_backward_kernel<0> : num_blocks == 1 ? resnet_hidden_backward_kernel<1>
+               : num_blocks == 2 ? resnet_hidden_backward_kernel<2> : resnet_hidden_backward_kernel<3>;
     if (lds > 64 * 1024) {
-        static unsigned long long raised[4] = {};   // device masks (raise_dynamic_lds)
-        const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[num_blocks], (int)lds);
+        static unsigned long long raised[8] = {};   // device masks (raise_dynamic_lds)
+        const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[num_blocks + (with_final ? 4 : 0)], (int)lds);
         if (rc_lds != NFA_OK) return rc_lds;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
+}
+
+extern "C" int nfa_resnet_hidden_backward_f32(const float* grad_hidden, const void* weights_packed, const float* saved,
+                                              float* grads, float* grad_identity_inputs, int64_t batch,
+                                              int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
+                                              void* stream) {
+    if (!grad_hidden && batch > 0) return NFA_ERR_INVALID_ARGUMENT;
+    return launch_train_backward(grad_hidden, nullptr, 0, nullptr, weights_packed, saved, grads, grad_identity_inputs, batch,
+                                 num_identity, hidden_features, num_blocks, stream);
+}
+
+extern "C" int nfa_resnet_backward_f32(const float* grad_params, int32_t out_features, const void* weights_packed,
+                                       const float* saved, float* grads, float* grad_hidden,
+                                       float* grad_identity_inputs, int64_t batch, int32_t num_identity,
+                                       int32_t hidden_features, int32_t num_blocks, void* stream) {
+    if (out_features < 4) return NFA_ERR_INVALID_ARGUMENT;
+    if (!grad_params && batch > 0) return NFA_ERR_INVALID_ARGUMENT;
+    return launch_train_backward(nullptr, grad_params, out_features, grad_hidden, weights_packed, saved, grads,
+                                 grad_identity_inputs, batch, num_identity, hidden_features, num_blocks, stream);
 }
 
 extern "C" int nfa_pack_resnet_hidden_train_f32(const float* initial_weight, const float* initial_bias,
@@ -808,7 +954,7 @@ extern "C" int nfa_pack_resnet_hidden_train_f32(const float* initial_weight, con
     a.final_bias = final_bias_packed;
     a.out_features = out_features;
     a.final_tiles = (out_features + 31) / 32;
-    const int stages = a.init_ks + 32 * num_blocks + 2 * a.final_tiles + 2 * ((num_identity + 31) / 32);
+    const int stages = a.init_ks + 32 * num_blocks + 2 * a.final_tiles + 2 * ((num_identity + 31) / 32) + (out_features + 15) / 16;
     hipLaunchKernelGGL(pack_resnet_hidden_kernel, dim3(stages + 1), dim3(kBlock), 0, (hipStream_t)stream, a);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;

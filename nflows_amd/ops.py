@@ -1166,7 +1166,8 @@ def pack_resnet_hidden_train(w_in, b_in, block_params, final=None):
     fwd = torch.empty(init_ks + 16 * nb + 2 * ft, 6144, dtype=torch.bfloat16, device=dev)
     bias = torch.empty(128 * (1 + 2 * nb), dtype=torch.float32, device=dev)
     fbias = torch.empty(32 * ft, dtype=torch.float32, device=dev) if fin else None
-    bwd = torch.empty(16 * nb + 2 * tiles, 6144, dtype=torch.bfloat16, device=dev)
+    # (with the final Linear: W_f^T's ceil(out / 16) k-major stages behind W_in^T's -- K14's backward kernel starts with them)
+    bwd = torch.empty(16 * nb + 2 * tiles + (out + 15) // 16, 6144, dtype=torch.bfloat16, device=dev)
     ptrs = (ctypes.c_void_p * max(1, 4 * nb))(*[t.data_ptr() for t in flat[2:]])
     with torch.cuda.device(dev):
         rc = N.load().nfa_pack_resnet_hidden_train_f32(
@@ -1185,7 +1186,9 @@ def pack_resnet_hidden_train_reference(w_in, b_in, block_params, final=None):
     w_in [128, d_i], b_in [128], block_params = [(W_0, b_0, W_1, b_1), ...] (all 128 wide), final = (W_f [out, 128],
     b_f [out]).  Returns (forward stages, forward biases, backward stages, final bias or None): the forward stream
     is the initial layer + W_0, W_1 per block (pack_resnet_conditioner's hidden layers) + W_f tile-major, the backward
-    stream W_1^T, W_0^T per block from the last to the first, then W_in^T tile-major (rows padded to 32)."""
+    stream W_1^T, W_0^T per block from the last to the first, then W_in^T tile-major (rows padded to 32) and -- with
+    `final` -- W_f^T k-major over its out_features columns in their natural order (ceil(out / 16) stages: the final
+    Linear's input gradient, which the backward kernel computes first)."""
     dev = w_in.device
     order_k = _TRAIN_ORDER_K.get(dev)
     if order_k is None:
@@ -1222,6 +1225,9 @@ def pack_resnet_hidden_train_reference(w_in, b_in, block_params, final=None):
         out = wf.shape[0]
         fwd.append(tilemajor(wf, out))
         fbias = _bias_accumulator_order(torch.cat((bf, bf.new_zeros((out + 31) // 32 * 32 - out)))).contiguous()
+        kf = (out + 15) // 16
+        wft = torch.cat((wf.t(), wf.new_zeros(128, 16 * kf - out)), dim=1)   # [128 units, k = ks*16 + hf*8 + j]
+        bwd.append(pieces(wft).view(3, 4, 32, kf, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(kf, -1))
     return torch.cat(fwd, dim=0).contiguous(), torch.cat(bias).contiguous(), torch.cat(bwd, dim=0).contiguous(), fbias
 
 
@@ -1266,6 +1272,34 @@ def resnet_hidden_backward(grad_hidden, bwd_stages, saved, num_identity):
                                                      N.stream_handle(dev))
     N.check(rc)
     return gx, grads
+
+
+# K14's backward kernel starting from d loss / d params (the final Linear's input gradient inside it; A/B switch)
+FUSED_FINAL_DGRAD = os.environ.get("NFA_K14_FINAL_DGRAD", "1") != "0"
+
+
+def resnet_backward(grad_params, bwd_stages, saved, num_identity):
+    """K14 backward from the conditioner's OUTPUT gradient (round 4, `nfa_resnet_backward_f32`): d loss / d params
+    [B, out] -> (d loss / d identity features [B, d_i], grads [2 nb, B, 128], d loss / d hidden [B, 128]); `bwd_stages`
+    packed with the final Linear (its W_f^T stages behind W_in^T's).  None when the kernel does not take the width."""
+    N.require_device_f32("grad_params", grad_params, 2)
+    g = grad_params.detach().contiguous()
+    B, out = g.shape
+    dev = g.device
+    nb = saved.shape[0] // 2
+    if out % 4 or out < 4:
+        return None
+    grads = torch.empty(2 * nb, B, 128, dtype=torch.float32, device=dev)
+    g_hidden = torch.empty(B, 128, dtype=torch.float32, device=dev)
+    gx = torch.empty(B, num_identity, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_resnet_backward_f32(N.ptr(g), out, N.ptr(bwd_stages), N.ptr(saved) if nb else None,
+                                              N.ptr(grads) if nb else None, N.ptr(g_hidden), N.ptr(gx), B, num_identity,
+                                              128, nb, N.stream_handle(dev))
+    if rc == N.ERR_UNSUPPORTED:
+        return None
+    N.check(rc)
+    return gx, grads, g_hidden
 
 
 def _affine_row_order(num_transform, additive):

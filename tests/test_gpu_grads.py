@@ -288,6 +288,54 @@ def test_fused_conditioner_training_kernels_at_size(B, di, nb):
         close("grad_inputs", gx, gh @ d(net.initial_layer.weight))
 
 
+@pytest.mark.parametrize("B,di,nb,out", [(65536, 32, 2, 736), (16384, 64, 3, 40), (2048, 8, 1, 24), (1024, 12, 0, 368), (512, 32, 2, 4)])
+def test_backward_kernel_from_the_output_gradient(B, di, nb, out):
+    """nfa_resnet_backward_f32 (round 4): K14's backward kernel starting from d loss / d params -- the final Linear's
+    input gradient as its first GEMM, g_params streamed through wave-private LDS images by LDS-DMA.  Widths: the
+    benchmark's 736 (46 full k-steps), 40 and 24 and 368 (a last k-step of 8 columns: the clamped chunks meet zero
+    weights), 4 (one quarter k-step).  Against float64 with the forward kernel's masks pinned, within 2e-6 of the scale;
+    d loss / d hidden (written for K10) likewise; repeated launches bit-identical; and against the two-step route
+    (library GEMM + nfa_resnet_hidden_backward_f32) within the same bound."""
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import ResidualNet
+    torch.manual_seed(B + out)
+    net = ResidualNet(di, out, 128, num_blocks=nb).to(DEV)
+    with torch.no_grad():
+        for b in net.blocks:
+            b.linear_layers[1].weight.mul_(40.0)
+        net.final_layer.weight.mul_(30.0)
+    x = torch.randn(B, di, device=DEV)
+    gp = torch.randn(B, out, device=DEV) * torch.exp(2.0 * torch.randn(B, 1, device=DEV))   # (rows of very different scale)
+    blocks = [(b.linear_layers[0].weight, b.linear_layers[0].bias, b.linear_layers[1].weight, b.linear_layers[1].bias)
+              for b in net.blocks]
+    with torch.no_grad():
+        final = (net.final_layer.weight, net.final_layer.bias)
+        fw, fb, bw, fbias = ops.pack_resnet_hidden_train(net.initial_layer.weight, net.initial_layer.bias, blocks, final)
+        hid, saved, params = ops.resnet_hidden_forward(x, fw, fb, nb, fbias, out)
+        gx, grads, ghid = ops.resnet_backward(gp, bw, saved, di)
+        for _ in range(6):
+            gx2, grads2, ghid2 = ops.resnet_backward(gp, bw, saved, di)
+            assert torch.equal(gx, gx2) and torch.equal(grads, grads2) and torch.equal(ghid, ghid2)
+        d = lambda t: t.detach().double()
+
+        def close(name, got, truth):
+            err, scale = (d(got) - truth).abs().max().item(), 1.0 + truth.abs().max().item()
+            assert err <= 2e-6 * scale, "%s: %.3e (scale %.2e)" % (name, err, scale)
+
+        gh = d(gp) @ d(net.final_layer.weight)
+        close("grad_hidden", ghid, gh)
+        for k in reversed(range(nb)):
+            w0, b0, w1, b1 = blocks[k]
+            ga = (gh @ d(w1)) * (saved[2 * k + 1] > 0)
+            gh = gh + (ga @ d(w0)) * (saved[2 * k] > 0)
+            close("grads[%d]" % (2 * k + 1), grads[2 * k + 1], ga)
+            close("grads[%d]" % (2 * k), grads[2 * k], gh)
+        close("grad_inputs", gx, gh @ d(net.initial_layer.weight))
+        # the two-step route of round 3 on the same arrays
+        gx3, grads3 = ops.resnet_hidden_backward(gp @ net.final_layer.weight, bw, saved, di)
+        close("grad_inputs (two-step route)", gx3, gh @ d(net.initial_layer.weight))
+
+
 @pytest.mark.parametrize("name", ["g_flow_nsf", "g_flow_nsf_h128"])
 def test_flow_training_gradients_match_reference(G, name, monkeypatch):
     """loss = -mean log_prob through a whole flow: loss, input gradient and every parameter gradient against the

@@ -1264,7 +1264,14 @@ def test_training_kernel_streams():
         out = net.final_layer.out_features
         ft = (out + 31) // 32
         assert torch.equal(fwd2[:n_fwd].view(torch.int16), fwd.view(torch.int16)) and fwd2.shape[0] == n_fwd + 2 * ft
-        assert torch.equal(bias2, bias) and torch.equal(bwd2.view(torch.int16), bwd.view(torch.int16))
+        # (round 4) the backward stream of a call with the final Linear: the same prefix, then W_f^T as ceil(out / 16)
+        # k-major stages over the columns of g_params in natural order (zero past `out`)
+        kf = (out + 15) // 16
+        assert torch.equal(bias2, bias) and bwd2.shape[0] == bwd.shape[0] + kf
+        assert torch.equal(bwd2[:bwd.shape[0]].view(torch.int16), bwd.view(torch.int16))
+        tail_t = bwd2[bwd.shape[0]:].view(kf, 4, 3, 2, 32, 8).float().sum(dim=2)    # (ks, tile, hf, i, j)
+        wft = tail_t.permute(1, 3, 0, 2, 4).reshape(128, kf * 16)                    # [unit 32 t + i][k = ks*16 + hf*8 + j]
+        assert torch.allclose(wft[:, :out], net.final_layer.weight.detach().t(), rtol=0, atol=1e-8) and not wft[:, out:].any()
         tailf = fwd2[n_fwd:].view(ft, 2, 3, 4, 2, 32, 8).float().sum(dim=2)    # (tile, hs, k4, hf, i, j)
         mf = tailf.permute(0, 4, 1, 2, 3, 5).reshape(ft * 32, 128)
         wf = torch.empty_like(mf)
@@ -1301,7 +1308,10 @@ def test_training_kernel_streams():
         net.initial_layer.weight, net.initial_layer.bias,
         [(b.linear_layers[0].weight, b.linear_layers[0].bias, b.linear_layers[1].weight, b.linear_layers[1].bias)],
         (net.final_layer.weight, net.final_layer.bias))
-    assert fwd.shape == (2 + 16 + 4, 6144) and bwd.shape == (16 + 2, 6144) and bias.shape == (384,) and fbias.shape == (64,)
+    # (backward stream: 16 hidden stages + W_in^T's tile + W_f^T's ceil(40 / 16) = 3 k-major stages)
+    assert fwd.shape == (2 + 16 + 4, 6144) and bwd.shape == (16 + 2 + 3, 6144) and bias.shape == (384,) and fbias.shape == (64,)
+    wft = bwd[18:].view(3, 4, 3, 2, 32, 8).float().sum(dim=2).permute(1, 3, 0, 2, 4).reshape(128, 48)
+    assert torch.allclose(wft[:52, :40], net.final_layer.weight.detach().t(), atol=1e-8) and not wft[52:].any() and not wft[:, 40:].any()
     w1t = decode_kmajor(bwd[:8])
     assert torch.allclose(w1t[:52, :52], b.linear_layers[1].weight.detach().t(), atol=1e-8) and not w1t[52:].any() \
         and not w1t[:, 52:].any()
@@ -1368,9 +1378,22 @@ def test_training_function_wiring_with_emulated_kernels(monkeypatch):
         assert gx.shape[1] == num_identity
         return gx, (torch.stack(grads) if grads else grad_hidden.new_zeros(0, grad_hidden.shape[0], 128))
 
+    fused_calls = []
+
+    def backward_from_params(grad_params, bwd_w, saved, num_identity):   # nfa_resnet_backward_f32's contract
+        w = book[bwd_w.item()]
+        if grad_params.shape[1] % 4:
+            return None
+        g_hidden = grad_params @ w["final"][0]
+        assert g_hidden.shape[1] == 128
+        fused_calls.append(grad_params.shape[1])
+        gx, grads = backward(g_hidden, bwd_w, saved, num_identity)
+        return gx, grads, g_hidden
+
     monkeypatch.setattr(ops, "pack_resnet_hidden_train", pack)
     monkeypatch.setattr(ops, "resnet_hidden_forward", forward)
     monkeypatch.setattr(ops, "resnet_hidden_backward", backward)
+    monkeypatch.setattr(ops, "resnet_backward", backward_from_params)
     monkeypatch.setattr(ops, "linear_wgrad", lambda x, gy, need_bias=True: (gy.t() @ x, gy.sum(0) if need_bias else None))
     # (round 4: the hidden Linears' weight gradients in one K10 launch pair when every gradient is wanted)
     batched_calls = []
@@ -1403,3 +1426,5 @@ def test_training_function_wiring_with_emulated_kernels(monkeypatch):
                 assert p.grad.shape == p.shape and torch.allclose(p.grad, q.grad, rtol=1e-10, atol=1e-12), name
     # the batched entry served the nets whose hidden gradients were all wanted (2 nb problems each), never a frozen one
     assert batched_calls == [4, 2, 4, 4, 6], batched_calls
+    # (round 4) every net with its final Linear went through the backward kernel's own final GEMM
+    assert fused_calls == [40, 24, 40, 16, 40], fused_calls
