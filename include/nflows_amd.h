@@ -223,7 +223,10 @@ int nfa_rqs_coupling_fused_linear_f32(const float *inputs, const float *hidden,
  *                    [3 pieces][4 k-steps][64 lanes][8], same element rule;
  *                  final_layer's rows are padded / reordered as in K7 (num_bins = 10: every
  *                    feature's 29 rows padded to 32, two tiles per group of two features, row i of
- *                    tile t = logit 16*(t%2) + 4*(i/8) + i%4 of feature 2*(t/2) + (i/4)%2);
+ *                    tile t = logit 16*(t%2) + 4*(i/8) + i%4 of feature 2*(t/2) + (i/4)%2; in general,
+ *                    ABI 9, for every num_bins other than 8: the feature's 3*num_bins - 1 rows padded
+ *                    to 16*T, T = ceil((3*num_bins - 1) / 16) tiles per group of two features, row i of
+ *                    tile t = logit 16*(t%T) + 4*(i/8) + i%4 of feature 2*(t/T) + (i/4)%2);
  *                    its width and height
  *                    rows (and their biases) are multiplied by 1/sqrt(hidden_features)
  *                    (coupling.py:554-556; spec->wh_divisor is ignored here), and by log2(e)
@@ -235,7 +238,8 @@ int nfa_rqs_coupling_fused_linear_f32(const float *inputs, const float *hidden,
  * bit; for num_bins = 8 the spline evaluation therefore uses a shorter rounding sequence than the
  * other kernels (same error class as the reference's fp32 path; environment NFA_K8_PIPE=1 selects
  * the reference's exact sequence, =0 additionally the unwoven loop).
- * Supported: num_bins = 8 or 10 (the reference's default; not with NFA_FLAG_LOGITS_LOG2E), linear
+ * Supported: num_bins = 8 or 10 (the reference's default; not with NFA_FLAG_LOGITS_LOG2E) and, ABI 9,
+ * any other num_bins from 2 to 16 (plain final-layer loop on the spline kernel's own evaluator; no context), linear
  * tails, hidden_features = 128, d_i <= 64, d_t % 4 == 0, d_t <= 64, features % 4 == 0,
  * features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
  */
@@ -309,7 +313,8 @@ int nfa_rqs_flow_resnet_f32(const float *inputs, const void *weights_packed,
  *                  it on the same stream; no host synchronisation in between.  (K8s on 64-row blocks sets
  *                  bit 1 / bit 2 instead: only the lower / upper 64 rows of the block are open, the other
  *                  half is written; the redo entry points honour the bits.)
- * Supported: num_bins = 8 or 10, linear tails, hidden_features = 128 (narrower conditioners: zero-padded by the packer), d_i <= 64, d_t % 4 == 0,
+ * Supported: num_bins = 8 or 10, and (ABI 9, without a context) any other num_bins from 2 to 16 -- final-layer rows as
+ * K8's general rule above, 16 ceil((3 num_bins - 1) / 16) per feature --, linear tails, hidden_features = 128 (narrower conditioners: zero-padded by the packer), d_i <= 64, d_t % 4 == 0,
  * d_t <= 64, features % 4 == 0, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
  * Table slots may repeat a column (d_t + d_i may exceed features): the host side pads other shapes into
  * this family with constant columns outside the spline's box (nflows_amd/ops.py: fused_geometry).
