@@ -76,6 +76,13 @@ extern "C" {
                                              every layer, see nflows_amd/ops.py: fused_geometry), not features: the
                                              density sums over the other `features - n` columns, D = features - n */
 #define NFA_FLAG_PAD_COLUMNS(n) ((n) << NFA_FLAG_PAD_COLUMNS_SHIFT)
+#define NFA_FLAG_ACTIVATION_SHIFT 12      /* nfa_rqs_flow_resnet_* / nfa_rqs_coupling_resnet_f32 (ABI 9): bits 12-14 = the */
+#define NFA_FLAG_ACTIVATION_MASK 0x7000   /* activation of the conditioner's residual blocks (nn/nets/resnet.py:27, :44, :47): */
+#define NFA_ACTIVATION_RELU 0             /* F.relu (the reference's default) */
+#define NFA_ACTIVATION_LEAKY_RELU 1       /* F.leaky_relu, negative_slope 0.01 */
+#define NFA_ACTIVATION_ELU 2              /* F.elu, alpha 1 */
+#define NFA_ACTIVATION_TANH 3             /* torch.tanh / F.tanh.  Other than ReLU: 8 or 10 bins, no context, not K8s. */
+#define NFA_FLAG_ACTIVATION(a) ((a) << NFA_FLAG_ACTIVATION_SHIFT)
 
 /* tails */
 #define NFA_TAILS_NONE 0   /* rational_quadratic_spline: K+1 derivative logits per element */

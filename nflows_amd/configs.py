@@ -14,7 +14,7 @@ from .utils import create_alternating_binary_mask
 
 
 def rq_nsf_flow(num_layers=32, features=64, num_bins=8, hidden_features=128, num_blocks=2,
-                tail_bound=3.0, seed=0):
+                tail_bound=3.0, seed=0, activation=torch.nn.functional.relu):
     """configs[2] (16 layers) / configs[3] + north-star (32 layers): RandomPermutation +
     PiecewiseRationalQuadraticCouplingTransform(alternating mask, ResidualNet conditioner)."""
     if seed is not None:
@@ -25,7 +25,7 @@ def rq_nsf_flow(num_layers=32, features=64, num_bins=8, hidden_features=128, num
         layers.append(PiecewiseRationalQuadraticCouplingTransform(
             mask=create_alternating_binary_mask(features, even=(i % 2 == 0)),
             transform_net_create_fn=lambda i_, o_: ResidualNet(
-                i_, o_, hidden_features=hidden_features, num_blocks=num_blocks),
+                i_, o_, hidden_features=hidden_features, num_blocks=num_blocks, activation=activation),
             num_bins=num_bins, tails="linear", tail_bound=tail_bound))
     return Flow(CompositeTransform(layers), StandardNormal([features]))
 

@@ -81,7 +81,25 @@ __device__ __forceinline__ void relu_pieces(bf16x8& h, bf16x8& m, bf16x8& l) {
 // k-major GEMM (all four output tiles accumulate together, the input pieces of a k-step are dead
 // after it): out^T[128 x 32 samples] += W[128 x 16*NKS] x act^T; one stage ([4 tiles][3 pieces]
 // [64 lanes] x 16 bytes) per k-step
-template <bool RELU, int NKS>
+// any activation of a value given as bf16 pieces: the fp32 value back (two exact additions of three pieces that
+// do not overlap), the activation, three new pieces -- ~15 VALU instructions per value where ReLU's sign mask takes
+// two; only the exact kernel's first Linear of a block pays it, and only for the other activations
+template <int ACT>
+__device__ __forceinline__ void activate_pieces(bf16x8& h, bf16x8& m, bf16x8& l) {
+    bf16x2 hh[4], mm[4], ll[4];
+#pragma unroll
+    for (int j2 = 0; j2 < 4; ++j2) {
+        const float v0 = activate<ACT>(((float)h[2 * j2] + (float)m[2 * j2]) + (float)l[2 * j2]);
+        const float v1 = activate<ACT>(((float)h[2 * j2 + 1] + (float)m[2 * j2 + 1]) + (float)l[2 * j2 + 1]);
+        split3(vec2f{v0, v1}, hh[j2], mm[j2], ll[j2]);
+    }
+    h = join4(hh[0], hh[1], hh[2], hh[3]);
+    m = join4(mm[0], mm[1], mm[2], mm[3]);
+    l = join4(ll[0], ll[1], ll[2], ll[3]);
+}
+
+// ACT: kActNone (false) / kActRelu (true) / the other activations (fused_common.hpp), applied to the input pieces
+template <int ACT, int NKS>
 __device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const bf16x8 (&ph)[8], const bf16x8 (&pm)[8],
                                             const bf16x8 (&pl)[8], WeightStream& sm, int lane) {
 #pragma unroll
@@ -89,7 +107,8 @@ __device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const bf16x8 (&ph)
         stream_request(sm);
         const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
         bf16x8 bh = ph[ks], bm = pm[ks], bl = pl[ks];
-        if (RELU) relu_pieces(bh, bm, bl);  // (the input pieces themselves stay: skip connection)
+        if constexpr (ACT == kActRelu) relu_pieces(bh, bm, bl);  // (the input pieces themselves stay: skip connection)
+        else if constexpr (ACT != kActNone) activate_pieces<ACT>(bh, bm, bl);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(t * 3 + 0) * 64]);
@@ -125,15 +144,12 @@ __device__ __forceinline__ void gemm_tile(f32x16& acc, const bf16x8 (&ph)[8], co
 }
 
 // accumulator tile t, registers 8*hk .. 8*hk+7  ->  pieces of k-step 2t + hk
-template <bool RELU>
+template <int ACT>
 __device__ __forceinline__ void tile_to_pieces(const f32x16& a, bf16x8& h0, bf16x8& m0, bf16x8& l0,
                                                bf16x8& h1, bf16x8& m1, bf16x8& l1) {
     float v[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        v[q] = a[q];
-        if (RELU) v[q] = (v[q] < 0.0f) ? 0.0f : v[q];  // NaN stays NaN
-    }
+    for (int q = 0; q < 16; ++q) v[q] = activate<ACT>(a[q]);  // (ReLU: NaN stays NaN)
     bf16x2 hh[8], mm[8], ll[8];
 #pragma unroll
     for (int q2 = 0; q2 < 8; ++q2) split3(vec2f{v[q2 * 2], v[q2 * 2 + 1]}, hh[q2], mm[q2], ll[q2]);

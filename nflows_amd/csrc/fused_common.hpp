@@ -35,6 +35,42 @@
 
 namespace nfa {
 
+// Activation of the conditioner's residual blocks (nn/nets/resnet.py:27 `activation=F.relu`; round 4: the other
+// functions users pass there).  Codes 0 / 1 are what a `bool RELU` template argument converts to.
+//   leaky_relu: F.leaky_relu's default slope 0.01 -- x > 0 ? x : 0.01 x = max(x, 0.01 x), bit for bit torch's
+//   elu:        F.elu's default alpha 1 -- x > 0 ? x : exp(x) - 1 (torch's CPU kernel subtracts, no expm1)
+//   tanh:       (e^{2x} - 1) / (e^{2x} + 1) on v_exp_f32 / v_rcp_f32 with one residual correction: absolute error <= 2e-7
+//               (the activation is the B operand of the next GEMM at magnitude <= 1: an absolute bound is what counts)
+// NaN propagates through all of them.
+enum : int { kActNone = 0, kActRelu = 1, kActLeakyRelu = 2, kActElu = 3, kActTanh = 4 };
+
+// ReLU and leaky ReLU commute with a positive factor (K8h keeps its accumulators at a power-of-two scale and takes it
+// out while it converts: act(v) x scale); ELU and tanh do not: they are applied to v x scale
+constexpr bool activation_is_homogeneous(int act) { return act <= kActLeakyRelu; }
+
+template <int ACT>
+__device__ __forceinline__ float activate(float v) {
+    if constexpr (ACT == kActRelu) {
+        return v < 0.0f ? 0.0f : v;   // (NaN stays NaN)
+    } else if constexpr (ACT == kActLeakyRelu) {
+        return __builtin_fmaxf(v, 0.01f * v);
+    } else if constexpr (ACT == kActElu) {
+        const float e = __builtin_amdgcn_exp2f(v * 1.44269502162933349609375f) - 1.0f;
+        return v > 0.0f ? v : e;
+    } else if constexpr (ACT == kActTanh) {
+        float t = v * 2.8853900432586669921875f;   // 2 log2(e)
+        t = t > 126.0f ? 126.0f : t;                // (1 + 2^t stays finite; tanh is 1 to fp32 there; NaN stays NaN)
+        const float e = __builtin_amdgcn_exp2f(t);
+        const float dn = e + 1.0f;
+        const float r0 = __builtin_amdgcn_rcpf(dn);
+        const float r = __builtin_fmaf(__builtin_fmaf(-dn, r0, 1.0f), r0, r0);
+        return (e - 1.0f) * r;   // (e - 1 is exact near e = 1, where 1 - 2 r would cancel)
+    } else {
+        return v;
+    }
+}
+
+
 // debug aid (tools/k7_trace.py, tools/k8_trace.py): device buffer of 512 uint64 that lane 0 of
 // wave 0 of workgroups 0 and 256 fills with cycle-counter stamps at phase boundaries; null = off
 extern unsigned long long* g_k7_trace;

@@ -331,14 +331,24 @@ constexpr float kF16Overflow = 65520.0f;   // RN16 of anything >= this is infini
             "v_fma_mixhi_f16 %1, %4, %5, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"          \
         : "=&v"(h), "=&v"(l), "+v"(peak)                                               \
         : "v"(s0), "v"(s1), "v"(scale))
-template <bool RELU, bool GUARD = false>
+// ACT: kActNone / kActRelu (what `false` / `true` convert to) or one of the other activations (fused_common.hpp:
+// round 4, K8h only) -- those are evaluated in front and the plain conversion takes |value| for the peak
+template <int ACT, bool GUARD = false>
 __device__ __forceinline__ void convert_pair(float s0, float s1, float scale, float& peak, unsigned& hi, unsigned& lo) {
     unsigned h, l;
-    if constexpr (RELU) {
+    if constexpr (ACT == kActRelu) {
         float m0, m1;
         if constexpr (GUARD) NFA_CONVERT_RELU("s_nop 2\n\t");
         else NFA_CONVERT_RELU("");
     } else {
+        if constexpr (ACT != kActNone && activation_is_homogeneous(ACT)) {
+            s0 = activate<ACT>(s0);
+            s1 = activate<ACT>(s1);
+        } else if constexpr (ACT != kActNone) {   // ELU, tanh: of the value at its own scale; `peak` is then post-scale
+            s0 = activate<ACT>(s0 * scale);
+            s1 = activate<ACT>(s1 * scale);
+            scale = 1.0f;
+        }
         if constexpr (GUARD) NFA_CONVERT_PLAIN("s_nop 2\n\t");
         else NFA_CONVERT_PLAIN("");
     }

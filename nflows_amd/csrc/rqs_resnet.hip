@@ -235,8 +235,10 @@ __device__ __forceinline__ void gemm_context_tile(f32x16& acc, const float* s_ct
 // CTX: the conditioners take a context (resnet.py:9-52, :92-100): its `ce` columns follow the identity
 // features in the initial layer's input, and every residual block's result is multiplied by
 // sigmoid(context_layer(context)) before the skip connection (F.glu of the concatenation).
-template <bool INVERSE, int PRESCALED, int INIT_KS, int PIPE = 0, int KB = 8, bool CTX = false>  // PIPE: 0 plain loop, 1 woven, 2 woven with FlatSteps<FAST>
+template <bool INVERSE, int PRESCALED, int INIT_KS, int PIPE = 0, int KB = 8, bool CTX = false, int ACT = kActRelu>  // PIPE: 0 plain loop, 1 woven, 2 woven with FlatSteps<FAST>; ACT: the blocks' activation
 __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs a) {
+    static_assert(ACT == kActRelu || (!CTX && PIPE == 0 && PRESCALED == 1 && ACT >= kActLeakyRelu && ACT <= kActTanh),
+                  "other activations: the plain loop, no context");
     static_assert(KB == 8 || (KB == 10 && PIPE != 1 && PRESCALED == 1) || (KB >= 2 && KB <= 16 && PIPE == 0 && PRESCALED == 1 && !CTX),
                   "10 bins: plain loop, or woven with the shorter sequence; other bin counts (2 .. 16): plain loop, no context");
     // rows of the final layer per transformed feature (8 bins: 23 logits padded to 24, two features share three tiles;
@@ -433,10 +435,10 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                     f32x16 u[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) load_bias_tile(u[t], bias + t * 32);
-                    gemm_kmajor<true, 8>(u, ph, pm, pl, sm, lane);
+                    gemm_kmajor<ACT, 8>(u, ph, pm, pl, sm, lane);
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        tile_to_pieces<true>(u[t], qh[2 * t], qm[2 * t], ql[2 * t], qh[2 * t + 1], qm[2 * t + 1], ql[2 * t + 1]);
+                        tile_to_pieces<ACT>(u[t], qh[2 * t], qm[2 * t], ql[2 * t], qh[2 * t + 1], qm[2 * t + 1], ql[2 * t + 1]);
                 }
                 NFA_STAMP()
                 f32x16 v[4];
@@ -733,8 +735,12 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
                                 const int32_t* redo = nullptr, const float* context = nullptr,
                                 int32_t context_features = 0) {
     if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_LOGITS_LOG2E |
-                  NFA_FLAG_STANDARD_NORMAL_LOG_PROB | NFA_FLAG_SKIP_OUTPUTS | NFA_FLAG_PAD_COLUMNS_MASK))
+                  NFA_FLAG_STANDARD_NORMAL_LOG_PROB | NFA_FLAG_SKIP_OUTPUTS | NFA_FLAG_PAD_COLUMNS_MASK |
+                  NFA_FLAG_ACTIVATION_MASK))
         return NFA_ERR_INVALID_ARGUMENT;
+    const int activation = (flags & NFA_FLAG_ACTIVATION_MASK) >> NFA_FLAG_ACTIVATION_SHIFT;
+    if (activation > NFA_ACTIVATION_TANH) return NFA_ERR_INVALID_ARGUMENT;
+    flags &= ~NFA_FLAG_ACTIVATION_MASK;
     if (!density_flags_valid(flags)) return NFA_ERR_INVALID_ARGUMENT;
     if (batch < 0 || features < 1 || num_transform < 1 || num_identity < 1 ||
         num_transform > features || num_identity > features || num_blocks < 0 || num_layers < 1)
@@ -743,6 +749,9 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     int rc = make_dev_spec(spec, &a.sp);
     if (rc != NFA_OK) return rc;
     const bool any_bins = a.sp.K != 8 && a.sp.K != 10;   // 2 .. 16 bins: the plain loop, no context, no log2(e) fold
+    // activations other than ReLU: 8 or 10 bins, the plain loop, no context, no log2(e) fold
+    if (activation != NFA_ACTIVATION_RELU && (any_bins || context_features > 0 || (flags & NFA_FLAG_LOGITS_LOG2E)))
+        return NFA_ERR_UNSUPPORTED;
     const int rows_per_feature = a.sp.K == 8 ? 24 : 16 * ((3 * a.sp.K - 1 + 15) / 16);
     if (a.sp.beta != 1.0f) return NFA_ERR_UNSUPPORTED;  // (identity initialisation: functional callers only)
     if (a.sp.K < 2 || a.sp.K > 16 || (a.sp.K != 8 && (flags & NFA_FLAG_LOGITS_LOG2E)) || (any_bins && context_features > 0) ||
@@ -797,7 +806,7 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         return e ? atoi(e) : 2;
     }();
     // (with the log2(e) fold only the default woven form exists)
-    const bool pipe = !any_bins && use_pipe && ((a.sp.K == 8 && (!(flags & NFA_FLAG_LOGITS_LOG2E) || use_pipe == 2)) ||
+    const bool pipe = !any_bins && activation == NFA_ACTIVATION_RELU && use_pipe && ((a.sp.K == 8 && (!(flags & NFA_FLAG_LOGITS_LOG2E) || use_pipe == 2)) ||
                                   (a.sp.K == 10 && use_pipe == 2));
     if (with_ctx && !(pipe && use_pipe == 2)) return NFA_ERR_UNSUPPORTED;
     const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float) +
@@ -850,6 +859,21 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         NFA_K8_ANY(11) NFA_K8_ANY(12) NFA_K8_ANY(13) NFA_K8_ANY(14) NFA_K8_ANY(15) NFA_K8_ANY(16)
     }
 #undef NFA_K8_ANY
+#define NFA_K8_ACT(ACT_, KB_)                                                                                           \
+    kern = init_ks == 4 ? (inv ? rqs_resnet_kernel<true, 1, 4, 0, KB_, false, ACT_> : rqs_resnet_kernel<false, 1, 4, 0, KB_, false, ACT_>) \
+                        : (inv ? rqs_resnet_kernel<true, 1, 2, 0, KB_, false, ACT_> : rqs_resnet_kernel<false, 1, 2, 0, KB_, false, ACT_>);
+    if (activation != NFA_ACTIVATION_RELU) {
+        if (a.sp.K == 8) {
+            if (activation == NFA_ACTIVATION_LEAKY_RELU) { NFA_K8_ACT(kActLeakyRelu, 8) }
+            else if (activation == NFA_ACTIVATION_ELU) { NFA_K8_ACT(kActElu, 8) }
+            else { NFA_K8_ACT(kActTanh, 8) }
+        } else {
+            if (activation == NFA_ACTIVATION_LEAKY_RELU) { NFA_K8_ACT(kActLeakyRelu, 10) }
+            else if (activation == NFA_ACTIVATION_ELU) { NFA_K8_ACT(kActElu, 10) }
+            else { NFA_K8_ACT(kActTanh, 10) }
+        }
+    }
+#undef NFA_K8_ACT
     if (with_ctx && a.sp.K == 10) {
         if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 2, 10, true> : rqs_resnet_kernel<false, 1, 4, 2, 10, true>;
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 2, 10, true> : rqs_resnet_kernel<false, 1, 2, 2, 10, true>;
@@ -858,8 +882,8 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 2, 8, true> : rqs_resnet_kernel<false, 1, 2, 2, 8, true>;
     }
     if (!redo)
-        note_layer_kernel("rqs_resnet_kernel<inverse=%d, init_ks=%d, pipe=%d, K=%d, ctx=%d>", inv ? 1 : 0, init_ks,
-                          pipe ? use_pipe : 0, a.sp.K, with_ctx ? 1 : 0);
+        note_layer_kernel("rqs_resnet_kernel<inverse=%d, init_ks=%d, pipe=%d, K=%d, ctx=%d, act=%d>", inv ? 1 : 0, init_ks,
+                          pipe ? use_pipe : 0, a.sp.K, with_ctx ? 1 : 0, activation);
     if (with_ctx && lds > 64 * 1024) {
         static unsigned long long raised_ctx[8] = {};   // device masks (raise_dynamic_lds)
         const int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (a.sp.K == 10 ? 4 : 0);
@@ -868,8 +892,9 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
             if (rc_lds != NFA_OK) return rc_lds;
         }
     } else if (lds > 64 * 1024) {
-        static unsigned long long raised[32 + 15 * 4] = {};   // device masks (raise_dynamic_lds)  // opt in to > 64 KB of dynamic LDS once per kernel
-        const int which = any_bins ? 32 + (a.sp.K - 2) * 4 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) : a.sp.K == 10 ? (pipe ? 24 : 12) + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
+        static unsigned long long raised[32 + 15 * 4 + 3 * 8] = {};   // device masks (raise_dynamic_lds)  // opt in to > 64 KB of dynamic LDS once per kernel
+        const int which = activation != NFA_ACTIVATION_RELU ? 32 + 15 * 4 + (activation - 1) * 8 + (a.sp.K == 10 ? 4 : 0) + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
+                          : any_bins ? 32 + (a.sp.K - 2) * 4 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) : a.sp.K == 10 ? (pipe ? 24 : 12) + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
                           : (pipe && use_pipe == 2) ? 16 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (l2e ? 4 : 0)
                           : pipe ? 8 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) : (inv ? 1 : 0) + (l2e ? 2 : 0) + (init_ks == 4 ? 4 : 0);
         {

@@ -69,7 +69,7 @@ struct NoWeave {
 // f16 pieces of k-steps 2t and 2t + 1 of the next GEMM, one pair of values per slice, behind every other
 // MFMA of the first sixteen.  (Members are references to fixed registers-to-be: one object per tile,
 // nothing re-pointed at run time, so that the arrays behind them stay in registers.)
-template <bool RELU>
+template <int RELU>   // (an activation code: kActNone / kActRelu / ...)
 struct ConvWeave {
     const f32x16& src;            // finished tile
     uvec4 &h0, &l0, &h1, &l1;     // pieces of k-steps 2t, 2t + 1
@@ -100,7 +100,7 @@ struct ConvWeave {
 // The same conversion cut for the 24 MFMAs of TWO k-steps of a k-major GEMM (12 each): pair J of the
 // tile takes slots 3J (ReLU, peak), 3J + 1 (high pieces), 3J + 2 (low pieces): 2-3 VALU instructions
 // behind every MFMA.
-template <bool RELU>
+template <int RELU>   // (an activation code: kActNone / kActRelu / ...)
 struct ConvSlices {
     const f32x16& src;
     uvec4 &h0, &l0, &h1, &l1;
@@ -113,30 +113,36 @@ struct ConvSlices {
     __device__ __forceinline__ void step() {
         constexpr int J = SLOT / 3, PH = SLOT % 3;
         if constexpr (PH == 0) {
-            if constexpr (RELU) {
+            if constexpr (RELU == kActRelu) {
                 asm("v_max_f32 %0, %3, 0\n\t"
                     "v_max_f32 %1, %4, 0\n\t"
                     "v_max3_f32 %2, %2, %0, %1"
                     : "=&v"(v0), "=&v"(v1), "+v"(peak)
                     : "v"(src[2 * J]), "v"(src[2 * J + 1]));
-            } else {
-                v0 = src[2 * J];
-                v1 = src[2 * J + 1];
+            } else if constexpr (activation_is_homogeneous(RELU)) {
+                v0 = activate<RELU>(src[2 * J]);       // (kActNone: the value itself)
+                v1 = activate<RELU>(src[2 * J + 1]);
+                asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(peak) : "v"(v0), "v"(v1));
+            } else {   // ELU, tanh: of the value at its own scale (the pieces are then taken with a factor of one)
+                v0 = activate<RELU>(src[2 * J] * scale);
+                v1 = activate<RELU>(src[2 * J + 1] * scale);
                 asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(peak) : "v"(v0), "v"(v1));
             }
         } else if constexpr (PH == 1) {
             unsigned h;
+            const float sc = activation_is_homogeneous(RELU) ? scale : 1.0f;
             asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\t"
                 "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
                 : "=&v"(h)
-                : "v"(v0), "v"(v1), "v"(scale));
+                : "v"(v0), "v"(v1), "v"(sc));
             hi = h;
         } else {
             unsigned lo;
+            const float sc = activation_is_homogeneous(RELU) ? scale : 1.0f;
             asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\t"
                 "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
                 : "=&v"(lo)
-                : "v"(v0), "v"(v1), "v"(scale), "v"(hi));
+                : "v"(v0), "v"(v1), "v"(sc), "v"(hi));
             if constexpr (J < 4) {
                 h0[J] = hi;
                 l0[J] = lo;
@@ -430,20 +436,21 @@ __device__ __forceinline__ void kstep_pair_woven(f32x16 (&acc)[4], uvec4 bh0, uv
 // previous GEMM (ReLU, x `scale`): tile 0 is converted up front, tile t + 1 behind the MFMAs of k-steps
 // 2t, 2t + 1 -- which only read the pieces of tile t.  `worst`: running max of |value x scale| over the
 // row block's conversions (the f16-range check).
-template <class SM>
+template <int ACT = kActRelu, class SM>
 __device__ __forceinline__ void gemm_kmajor_converting(f32x16 (&acc)[4], uvec4 (&ph)[8], uvec4 (&pl)[8],
                                                        const f32x16 (&src)[4], float scale, float& worst, SM& sm,
                                                        Frags& fr, int lane) {
     float peak = 0.0f;
-    ConvWeave<true>{src[0], ph[0], pl[0], ph[1], pl[1], scale, peak}.all();
+    ConvWeave<ACT>{src[0], ph[0], pl[0], ph[1], pl[1], scale, peak}.all();
     kstep_pair_woven(acc, ph[0], pl[0], ph[1], pl[1], sm, fr, lane,
-                     ConvSlices<true>{src[1], ph[2], pl[2], ph[3], pl[3], scale, peak});
+                     ConvSlices<ACT>{src[1], ph[2], pl[2], ph[3], pl[3], scale, peak});
     kstep_pair_woven(acc, ph[2], pl[2], ph[3], pl[3], sm, fr, lane,
-                     ConvSlices<true>{src[2], ph[4], pl[4], ph[5], pl[5], scale, peak});
+                     ConvSlices<ACT>{src[2], ph[4], pl[4], ph[5], pl[5], scale, peak});
     kstep_pair_woven(acc, ph[4], pl[4], ph[5], pl[5], sm, fr, lane,
-                     ConvSlices<true>{src[3], ph[6], pl[6], ph[7], pl[7], scale, peak});
+                     ConvSlices<ACT>{src[3], ph[6], pl[6], ph[7], pl[7], scale, peak});
     kstep_pair_woven(acc, ph[6], pl[6], ph[7], pl[7], sm, fr, lane, NoWeave{});
-    worst = __builtin_fmaxf(worst, peak * scale);
+    // (ELU / tanh: `peak` was taken behind the scale)
+    worst = __builtin_fmaxf(worst, activation_is_homogeneous(ACT) ? peak * scale : peak);
 }
 
 // the initial layer: NKS k-steps (2 or 4) on the pieces of the identity features
@@ -501,9 +508,10 @@ __device__ __forceinline__ bool not_finite(float v) { return !(__builtin_fabsf(v
 // h + (W_1 relu(u) + b_1) * sigmoid(W_c context + b_c): the second Linear then has accumulators of its own
 // (its input pieces are finished first: u's registers are needed), the gate's Linear is one more stage
 // (two k-steps, k-major) and the residual stream takes the product in.
-template <bool INVERSE, int INIT_KS, int NW, int KB = 8, bool CTX = false, int RING = kRing>
+template <bool INVERSE, int INIT_KS, int NW, int KB = 8, bool CTX = false, int RING = kRing, int ACT = kActRelu>
 __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Args a) {
     static_assert(!CTX || INIT_KS == 4, "context: two identity k-steps + two context k-steps");
+    static_assert(ACT == kActRelu || (!CTX && ACT >= kActLeakyRelu && ACT <= kActTanh), "other activations: no context");
     constexpr int kThreads = NW * kWave;
     // dynamic LDS: the weight ring, per wave a [D][33] row tile, two parameter blocks (current / next layer)
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
@@ -713,7 +721,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                     const float* bias = gemm + kHdr + half * 16;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) load_bias_tile(u[t], bias + t * 32);
-                    gemm_kmajor_converting(u, ph, pl, hacc, conv_scale, worst, sm, fr, lane);
+                    gemm_kmajor_converting<ACT>(u, ph, pl, hacc, conv_scale, worst, sm, fr, lane);
                     conv_scale = gemm[0];
                 }
                 gemm += kHdr + 128;
@@ -756,7 +764,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                     InitWeave{hacc[1], bias + 1 * 32, ratio}.all();
                     InitWeave{hacc[2], bias + 2 * 32, ratio}.all();
                     InitWeave{hacc[3], bias + 3 * 32, ratio}.all();
-                    gemm_kmajor_converting(hacc, qh, ql, u, conv_scale, worst, sm, fr, lane);
+                    gemm_kmajor_converting<ACT>(hacc, qh, ql, u, conv_scale, worst, sm, fr, lane);
                     conv_scale = gemm[0];
                 }
                 gemm += kHdr + 128;
@@ -982,8 +990,11 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
                       int32_t num_transform, int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
                       const nfa_rqs_spec* spec, int32_t flags, void* stream) {
     if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_STANDARD_NORMAL_LOG_PROB |
-                  NFA_FLAG_SKIP_OUTPUTS | NFA_FLAG_PAD_COLUMNS_MASK))
+                  NFA_FLAG_SKIP_OUTPUTS | NFA_FLAG_PAD_COLUMNS_MASK | NFA_FLAG_ACTIVATION_MASK))
         return NFA_ERR_INVALID_ARGUMENT;
+    const int activation = (flags & NFA_FLAG_ACTIVATION_MASK) >> NFA_FLAG_ACTIVATION_SHIFT;
+    if (activation > NFA_ACTIVATION_TANH) return NFA_ERR_INVALID_ARGUMENT;
+    flags &= ~NFA_FLAG_ACTIVATION_MASK;
     if (!density_flags_valid(flags)) return NFA_ERR_INVALID_ARGUMENT;
     if (batch < 0 || features < 1 || num_transform < 1 || num_identity < 1 ||
         num_transform > features || num_identity > features || num_blocks < 0 || num_layers < 1 || param_stages < 1)
@@ -994,6 +1005,8 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     if (a.sp.beta != 1.0f) return NFA_ERR_UNSUPPORTED;
     // bin counts: 8 and 10 have their own final-layer loops; 2 .. 16 otherwise (no context there)
     const bool any_bins = a.sp.K != 8 && a.sp.K != 10;
+    // activations other than ReLU: the two tuned bin counts, no context
+    if (activation != NFA_ACTIVATION_RELU && (any_bins || context_features > 0)) return NFA_ERR_UNSUPPORTED;
     if (a.sp.K < 2 || a.sp.K > 16 || (any_bins && context_features > 0) || !a.sp.linear || hidden_features != 128 || (num_transform & 3) != 0 || num_transform > 64 ||
         num_identity > 64 || features > 128 || (features & 3) != 0 || (batch & 127) != 0 || num_blocks > 64 ||
         num_layers > 4096)
@@ -1083,6 +1096,28 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
                        : (init_ks == 4 ? (inv ? k8h::rqs_resnet_f16_kernel<true, 4, 4, KB_> : k8h::rqs_resnet_f16_kernel<false, 4, 4, KB_>)   \
                                        : (inv ? k8h::rqs_resnet_f16_kernel<true, 2, 4, KB_> : k8h::rqs_resnet_f16_kernel<false, 2, 4, KB_>)); \
         break;
+#define NFA_K8H_ACT(ACT_, KB_)                                                                                       \
+    kern = nw == 8 ? (init_ks == 4 ? (inv ? k8h::rqs_resnet_f16_kernel<true, 4, 8, KB_, false, k8h::kRing, ACT_>           \
+                                          : k8h::rqs_resnet_f16_kernel<false, 4, 8, KB_, false, k8h::kRing, ACT_>)          \
+                                   : (inv ? k8h::rqs_resnet_f16_kernel<true, 2, 8, KB_, false, k8h::kRing, ACT_>           \
+                                          : k8h::rqs_resnet_f16_kernel<false, 2, 8, KB_, false, k8h::kRing, ACT_>))         \
+                   : (init_ks == 4 ? (inv ? k8h::rqs_resnet_f16_kernel<true, 4, 4, KB_, false, k8h::kRing, ACT_>           \
+                                          : k8h::rqs_resnet_f16_kernel<false, 4, 4, KB_, false, k8h::kRing, ACT_>)          \
+                                   : (inv ? k8h::rqs_resnet_f16_kernel<true, 2, 4, KB_, false, k8h::kRing, ACT_>           \
+                                          : k8h::rqs_resnet_f16_kernel<false, 2, 4, KB_, false, k8h::kRing, ACT_>));
+    if (activation != NFA_ACTIVATION_RELU) {
+        which = 32 + 15 * 8 + (activation - 1) * 16 + (a.sp.K == 10 ? 8 : 0) + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0);
+        if (a.sp.K == 8) {
+            if (activation == NFA_ACTIVATION_LEAKY_RELU) { NFA_K8H_ACT(kActLeakyRelu, 8) }
+            else if (activation == NFA_ACTIVATION_ELU) { NFA_K8H_ACT(kActElu, 8) }
+            else { NFA_K8H_ACT(kActTanh, 8) }
+        } else {
+            if (activation == NFA_ACTIVATION_LEAKY_RELU) { NFA_K8H_ACT(kActLeakyRelu, 10) }
+            else if (activation == NFA_ACTIVATION_ELU) { NFA_K8H_ACT(kActElu, 10) }
+            else { NFA_K8H_ACT(kActTanh, 10) }
+        }
+    } else
+#undef NFA_K8H_ACT
     if (any_bins) switch (a.sp.K) {
         NFA_K8H_ANY(2) NFA_K8H_ANY(3) NFA_K8H_ANY(4) NFA_K8H_ANY(5) NFA_K8H_ANY(6) NFA_K8H_ANY(7) NFA_K8H_ANY(9)
         NFA_K8H_ANY(11) NFA_K8H_ANY(12) NFA_K8H_ANY(13) NFA_K8H_ANY(14) NFA_K8H_ANY(15) NFA_K8H_ANY(16)
@@ -1120,10 +1155,11 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
         case 14: kern = k8h::rqs_resnet_f16_kernel<false, 4, 8, 10>; break;
         default: kern = k8h::rqs_resnet_f16_kernel<true, 4, 8, 10>; break;
     }
-    note_layer_kernel("k8h::rqs_resnet_f16_kernel<inverse=%d, init_ks=%d, waves=%d, K=%d, ctx=%d, ring=%d>", inv ? 1 : 0,
-                      init_ks, nw, a.sp.K, with_ctx ? 1 : 0, elastic ? k8h::kRingElastic : k8h::kRing);
+    static const char* const act_names[] = {"relu", "leaky_relu", "elu", "tanh"};
+    note_layer_kernel("k8h::rqs_resnet_f16_kernel<inverse=%d, init_ks=%d, waves=%d, K=%d, ctx=%d, ring=%d, act=%s>", inv ? 1 : 0,
+                      init_ks, nw, a.sp.K, with_ctx ? 1 : 0, elastic ? k8h::kRingElastic : k8h::kRing, act_names[activation]);
     if (lds_launch > 64 * 1024) {
-        static unsigned long long raised[32 + 15 * 8] = {};   // device masks (raise_dynamic_lds)
+        static unsigned long long raised[32 + 15 * 8 + 3 * 16] = {};   // device masks (raise_dynamic_lds)
         {
             const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], (int)lds_cap);
             if (rc_lds != NFA_OK) return rc_lds;

@@ -1673,7 +1673,7 @@ def _without_pad_columns(result, features):
 
 def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transform, num_identity, num_blocks,
                         spec, inverse=False, accumulate_into=None, log2e=False, num_layers=1,
-                        standard_normal_log_prob=False, context=None, pad=None, _pad_columns_count=0):
+                        standard_normal_log_prob=False, context=None, pad=None, _pad_columns_count=0, activation=0):
     """K8 -- ResidualNet conditioner + spline coupling layer in one kernel; with num_layers > 1 a
     whole run of such layers (weights / biases concatenated in execution order, tables from
     `flow_layer_tables`).  Returns (outputs, logabsdet), or (None, log_prob) with
@@ -1686,14 +1686,14 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
         # (the density epilogue is told how many trailing columns are padding)
         out = rqs_coupling_resnet(_pad_columns(inputs, pad[0], pad[1]), weights_packed, bias_packed, tables,
                                   num_transform, num_identity, num_blocks, spec, inverse, accumulate_into, log2e,
-                                  num_layers, standard_normal_log_prob, context, None, pad[0] - inputs.shape[1])
+                                  num_layers, standard_normal_log_prob, context, None, pad[0] - inputs.shape[1], activation)
         return _without_pad_columns(out, inputs.shape[1])
     if inputs.shape[0] % 128:
         return _on_full_blocks(
             lambda x_, acc_, ctx_: rqs_coupling_resnet(x_, weights_packed, bias_packed, tables, num_transform,
                                                        num_identity, num_blocks, spec, inverse, acc_, log2e,
                                                        num_layers, standard_normal_log_prob, ctx_, None,
-                                                       _pad_columns_count),
+                                                       _pad_columns_count, activation),
             inputs, accumulate_into, context)
     dev = inputs.device
     B, D = inputs.shape
@@ -1702,6 +1702,7 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
     flags, out = _density_epilogue(flags, standard_normal_log_prob, inverse, x, _pad_columns_count)
     if log2e:
         flags |= N.FLAG_LOGITS_LOG2E
+    flags |= int(activation) << N.FLAG_ACTIVATION_SHIFT
     with torch.cuda.device(dev):
         if context is not None:   # conditioners with a context: [B, context_features] rows
             N.require_device_f32("context", context, 2)
@@ -1724,15 +1725,30 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
     return out, lad
 
 
+def activation_code(fn):
+    """The whole-layer kernels' code of a residual block's `activation` (nn/nets/resnet.py:27), or None: the
+    reference's default F.relu, and (round 4) F.leaky_relu / F.elu with their default parameters and tanh."""
+    F = torch.nn.functional
+    if fn is F.relu or fn is torch.relu:
+        return N.ACTIVATION_RELU
+    if fn is F.leaky_relu:
+        return N.ACTIVATION_LEAKY_RELU
+    if fn is F.elu:
+        return N.ACTIVATION_ELU
+    if fn is torch.tanh or fn is F.tanh:
+        return N.ACTIVATION_TANH
+    return None
+
+
 K8S_ENABLED = os.environ.get("NFA_K8S", "1") != "0"
 K8S_ALWAYS = os.environ.get("NFA_K8S", "1") == "2"     # (measurements: the 16-sample-tile kernel at every batch size)
 _cu_counts = {}
 
 
-def use_tile16(batch, num_bins, context, device):
+def use_tile16(batch, num_bins, context, device, activation=0):
     """K8s (16-sample tiles, csrc/rqs_resnet_f16s.hip) serves the batches that give a CU at most ONE 128-row block
     -- K8h would run them one wave per SIMD (or leave CUs idle): 8 bins, no context.  `NFA_K8S=0` switches it off."""
-    if not K8S_ENABLED or num_bins != 8 or context is not None:
+    if not K8S_ENABLED or num_bins != 8 or context is not None or activation != N.ACTIVATION_RELU:
         return False
     key = device.index if device.index is not None else torch.cuda.current_device()
     cus = _cu_counts.get(key)
@@ -1744,7 +1760,7 @@ def use_tile16(batch, num_bins, context, device):
 def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transform, num_identity, num_blocks,
                             spec, inverse=False, accumulate_into=None, num_layers=1,
                             standard_normal_log_prob=False, pad=None, context=None, _pad_columns_count=0,
-                            tile16=False):
+                            tile16=False, activation=0):
     """K8h -- the run of whole-layer kernels on the f16 matrix pipe (two f16 pieces per operand),
     followed by the exact kernel (three bf16 pieces, full fp32 range) on the row blocks the first
     pass gave up on: blocks with a non-finite result, i.e. an activation beyond the f16 range or
@@ -1758,20 +1774,21 @@ def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transf
         out = rqs_coupling_resnet_f16(_pad_columns(inputs, pad[0], pad[1]), stream_f16, packed_exact, tables,
                                       num_transform, num_identity, num_blocks, spec, inverse, accumulate_into,
                                       num_layers, standard_normal_log_prob, None, context,
-                                      pad[0] - inputs.shape[1], tile16)
+                                      pad[0] - inputs.shape[1], tile16, activation)
         return _without_pad_columns(out, inputs.shape[1])
     if inputs.shape[0] % 128:
         return _on_full_blocks(
             lambda x_, acc_, ctx_: rqs_coupling_resnet_f16(x_, stream_f16, packed_exact, tables, num_transform,
                                                            num_identity, num_blocks, spec, inverse, acc_, num_layers,
                                                            standard_normal_log_prob, None, ctx_, _pad_columns_count,
-                                                           tile16),
+                                                           tile16, activation),
             inputs, accumulate_into, context)
     dev = inputs.device
     B, D = inputs.shape
     x = inputs.detach().contiguous()
     lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
     flags, out = _density_epilogue(flags, standard_normal_log_prob, inverse, x, _pad_columns_count)
+    flags |= int(activation) << N.FLAG_ACTIVATION_SHIFT
     global _last_redo
     redo = torch.empty(max(1, B // 128), dtype=torch.int32, device=dev)
     _last_redo = redo

@@ -234,8 +234,9 @@ class CompositeTransform(Transform):
             if p is not None:
                 p._check(inputs)
         # (batches that give a CU at most one 128-row block: the 16-sample-tile kernel K8s and its own stream)
+        act = first._block_activation() if hasattr(first, "_block_activation") else 0
         tile16 = (hasattr(first, "_use_f16") and inputs.is_cuda
-                  and ops.use_tile16(inputs.shape[0], getattr(first, "num_bins", 0), context, inputs.device))
+                  and ops.use_tile16(inputs.shape[0], getattr(first, "num_bins", 0), context, inputs.device, act))
         weights, biases, tables, plan_f16 = self._run_plan(units, inverse, tile16)
         Dp, dt4, di_u, pad_value = _run_geometry(units)
         pad = (Dp, pad_value)
@@ -249,7 +250,7 @@ class CompositeTransform(Transform):
                 inputs, plan_f16, (weights, biases), tables, dt4,
                 di_u, len(first.transform_net.blocks), first._spec(), inverse,
                 total, num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob, pad=pad,
-                context=context, tile16=tile16 and first._use_f16(_run_geometry(units)))
+                context=context, tile16=tile16 and first._use_f16(_run_geometry(units)), activation=act)
             if head is None and tile16:
                 # K8s declined (its ring + 16-row buffers + two copies of the parameter words exceed the LDS budget:
                 # about six blocks at D = 128): K8h takes these shapes -- its own stream, the same call
@@ -258,13 +259,14 @@ class CompositeTransform(Transform):
                     head = ops.rqs_coupling_resnet_f16(
                         inputs, plan_f16, (weights, biases), tables, dt4, di_u, len(first.transform_net.blocks),
                         first._spec(), inverse, total, num_layers=len(units),
-                        standard_normal_log_prob=standard_normal_log_prob, pad=pad, context=context, tile16=False)
+                        standard_normal_log_prob=standard_normal_log_prob, pad=pad, context=context, tile16=False,
+                        activation=act)
         else:
             head = ops.rqs_coupling_resnet(
                 inputs, weights, biases, tables, dt4, di_u,
                 len(first.transform_net.blocks), first._spec(), inverse, total,
                 log2e=first._log2e() if hasattr(first, "_log2e") else False, num_layers=len(units),
-                standard_normal_log_prob=standard_normal_log_prob, context=context, pad=pad)
+                standard_normal_log_prob=standard_normal_log_prob, context=context, pad=pad, activation=act)
         if head is None:
             return None
         return head[1] if standard_normal_log_prob else head[0]

@@ -514,7 +514,17 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         features, num_blocks, ce = self._static_signature()
         return ("k8", features, num_blocks, self.num_bins, self.tail_bound,
                 self.min_bin_width, self.min_bin_height, self.min_derivative,
-                self._log2e(), self._use_f16(), self.conditioner_act_scale, ce)
+                self._log2e(), self._use_f16(), self.conditioner_act_scale, ce, self._block_activation())
+
+    def _block_activation(self):
+        """The whole-layer kernels' code of the conditioner blocks' activation (one for all blocks), or None"""
+        blocks = getattr(self.transform_net, "blocks", None)
+        if blocks is None:
+            return None
+        if len(blocks) == 0:
+            return N.ACTIVATION_RELU
+        codes = {ops.activation_code(getattr(b, "activation", None)) for b in blocks}
+        return codes.pop() if len(codes) == 1 else None
 
     def _static_signature(self):
         """(features, residual blocks, context features) of the layer's conditioner: read once per cache epoch
@@ -542,9 +552,22 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
                 and (self.num_bins in (8, 10) or (2 <= self.num_bins <= 16 and context is None))
                 and 1 <= self.num_identity_features <= 64 and 1 <= self.num_transform_features
                 and self._fused_geometry()[1] <= 64 and self._fused_geometry()[0] <= 128
-                and all(b.activation is torch.nn.functional.relu
-                        and (not b.training or (b.dropout.p == 0.0 and not b.use_batch_norm)) for b in net.blocks)
+                and self._activation_ok(context)
+                and all(not b.training or (b.dropout.p == 0.0 and not b.use_batch_norm) for b in net.blocks)
                 and (not any(b.use_batch_norm for b in net.blocks) or self._folded_net() is not None))
+
+    def _activation_ok(self, context):
+        """ReLU everywhere; F.leaky_relu / F.elu / tanh (round 4) at 8 or 10 bins without a context, batch norm (its fold
+        moves a positive scale through the ReLU) or the log2(e) fold."""
+        act = self._block_activation()
+        if act is None:
+            return False
+        if act == N.ACTIVATION_RELU:
+            return True
+        # (ELU / tanh are applied to the value at the pieces' scale: the experiment switch NFA_K8_ACT_SCALE must be 1)
+        return (self.num_bins in (8, 10) and context is None and not self._log2e()
+                and (act == N.ACTIVATION_LEAKY_RELU or self.conditioner_act_scale == 1.0)
+                and not any(b.use_batch_norm for b in self.transform_net.blocks))
 
     def _folded_net(self):
         """The conditioner with its eval-mode batch norms folded into weights and biases (ops.fold_batch_norm),
@@ -648,21 +671,22 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         Dp, dt4, di, pad_value = self._fused_geometry()
         spec = self._spec()
         # (ragged batches are padded to full 128-row blocks, odd shapes to multiples of four columns, in `ops`)
-        tile16 = self._use_f16() and inputs.is_cuda and ops.use_tile16(inputs.shape[0], self.num_bins, context, inputs.device)
+        act = self._block_activation()
+        tile16 = self._use_f16() and inputs.is_cuda and ops.use_tile16(inputs.shape[0], self.num_bins, context, inputs.device, act)
         stream = self._f16_stream(tables, tile16) if self._use_f16() else None   # (None: non-finite weights -> exact kernel)
         if stream is not None:
             res = ops.rqs_coupling_resnet_f16(inputs, stream, (wp, bp), tables, dt4, di, nb, spec,
                                               inverse, accumulate_into, pad=(Dp, pad_value), context=context,
-                                              tile16=tile16)
+                                              tile16=tile16, activation=act)
             if res is None and tile16:   # (K8s over its LDS budget: K8h with its own stream)
                 stream = self._f16_stream(tables, False)
                 if stream is not None:
                     res = ops.rqs_coupling_resnet_f16(inputs, stream, (wp, bp), tables, dt4, di, nb, spec,
                                                       inverse, accumulate_into, pad=(Dp, pad_value), context=context,
-                                                      tile16=False)
+                                                      tile16=False, activation=act)
             return res
         return ops.rqs_coupling_resnet(inputs, wp, bp, tables, dt4, di, nb, spec, inverse, accumulate_into,
-                                       log2e=self._log2e(), context=context, pad=(Dp, pad_value))
+                                       log2e=self._log2e(), context=context, pad=(Dp, pad_value), activation=act)
 
     def _packed_final_linear(self, layer):
         split = self.final_linear_engine == "bf16x3"

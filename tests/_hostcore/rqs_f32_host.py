@@ -225,6 +225,33 @@ def _fused8_for_the_host(csrc):
     return src
 
 
+ACT_HARNESS = r'''
+// the conditioner blocks' activations as the whole-layer kernels evaluate them (fused_common.hpp: activate<ACT>)
+extern "C" int host_activate(int act, int64_t n, const float* x, float* y) {
+    for (int64_t i = 0; i < n; ++i) {
+        switch (act) {
+            case nfa::kActNone: y[i] = nfa::activate<nfa::kActNone>(x[i]); break;
+            case nfa::kActRelu: y[i] = nfa::activate<nfa::kActRelu>(x[i]); break;
+            case nfa::kActLeakyRelu: y[i] = nfa::activate<nfa::kActLeakyRelu>(x[i]); break;
+            case nfa::kActElu: y[i] = nfa::activate<nfa::kActElu>(x[i]); break;
+            case nfa::kActTanh: y[i] = nfa::activate<nfa::kActTanh>(x[i]); break;
+            default: return -1;
+        }
+    }
+    return 0;
+}
+'''
+
+
+def _activations_for_the_host(csrc):
+    """`enum { kActNone ... }` and `activate<ACT>` cut out of fused_common.hpp (the rest of that header is MFMA code)"""
+    src = open(os.path.join(csrc, "fused_common.hpp")).read()
+    a = src.index("enum : int { kActNone")
+    b = src.index("template <int ACT>\n__device__ __forceinline__ float activate(float v)", a)
+    end = src.index("\n}\n", b) + 3
+    return "namespace nfa {\n" + src[a:end] + "\n}  // namespace nfa\n"
+
+
 def build(out_dir):
     csrc = os.path.join(ROOT, "nflows_amd", "csrc")
     math_src = open(os.path.join(csrc, "rqs_math.hpp")).read()
@@ -238,7 +265,7 @@ def build(out_dir):
     so = os.path.join(out_dir, "rqs_f32_host.so")
     with open(cpp, "w") as f:
         f.write(math_src.replace('#include "common.hpp"', SHIM).replace("#pragma once", "", 1) + backward
-                + _fused8_for_the_host(csrc) + HARNESS)
+                + _fused8_for_the_host(csrc) + HARNESS + _activations_for_the_host(csrc) + ACT_HARNESS)
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
                            "-I" + os.path.join(ROOT, "include"), cpp, "-o", so])
     lib = ctypes.CDLL(so)
@@ -250,6 +277,8 @@ def build(out_dir):
     lib.host_rqs_forward_flat8.argtypes = [i32, i64, p, p, p, p, p]
     lib.host_rqs_forward_flatsteps.argtypes = [i32, i32, i64, p, p, p, p, p]
     lib.host_rqs_forward_fused.argtypes = [i32, ctypes.c_float, i64, p, p, p, p, p]
+    lib.host_activate.argtypes = [i32, i64, p, p]
+    lib.host_activate.restype = i32
     for fn in (lib.host_rqs_forward, lib.host_rqs_backward, lib.host_rqs_forward_flat8, lib.host_rqs_forward_flatsteps,
                lib.host_rqs_forward_fused):
         fn.restype = i32

@@ -1015,6 +1015,21 @@ def bin_count_flow_cases():
         ("bins_k%d" % K, 300 + K, 2, K, 60.0, 6.0, 10.0, 32, 128) for K in (2, 3, 4, 5, 6, 7, 9, 11, 12, 13, 16)))
 
 
+ACTIVATIONS = {"relu": torch.nn.functional.relu, "leaky_relu": torch.nn.functional.leaky_relu,
+               "elu": torch.nn.functional.elu, "tanh": torch.tanh}
+
+
+def activation_flow_cases():
+    """Round 4: conditioners built with another activation than ReLU (resnet.py:27 `activation=`), steep two-layer
+    coupling flows at D = 32, H = 128, 8 and 10 bins; tests/golden/flows_acts.npz."""
+    steep_flow_cases(file_name="flows_acts.npz", only_nsf=True, nsf_cases=(
+        ("act_leaky_relu_k8", 401, 2, 8, 60.0, 6.0, 10.0, 32, 128, "leaky_relu"),
+        ("act_elu_k8", 402, 2, 8, 60.0, 6.0, 10.0, 32, 128, "elu"),
+        ("act_tanh_k8", 403, 2, 8, 60.0, 6.0, 10.0, 32, 128, "tanh"),
+        ("act_elu_k10", 404, 2, 10, 60.0, 6.0, 10.0, 32, 128, "elu"),
+        ("act_tanh_k10", 405, 2, 10, 60.0, 6.0, 10.0, 32, 128, "tanh")))
+
+
 STEEP_NSF_CASES = (("steep_nsf_k8", 21, 2, 8, 60.0, 6.0, 10.0, 64, 512), ("steep_nsf_k8_deep", 25, 4, 8, 20.0, 2.0, 10.0, 64, 512),
                    ("steep_nsf_k10", 22, 2, 10, 60.0, 6.0, 10.0, 64, 512))
 
@@ -1084,15 +1099,17 @@ def steep_flow_cases(file_name="flows_steep.npz", only_nsf=False, nsf_cases=STEE
     #  returns x (measured: mean |error| 0.7), every fp32 error is then amplified chaotically and a defective
     #  refinement step drowns in the reference's own error.  Two layers at spread ~ 2 (every feature transformed once,
     #  sharp), four layers at spread ~ 1 (deep, round trip asserted), two layers of 10 bins.)
-    for name, seed, L, K, wh, ds, hs, D, B in nsf_cases:
+    for name, seed, L, K, wh, ds, hs, D, B, *rest in nsf_cases:
         H = 128
+        act = rest[0] if rest else "relu"
         torch.manual_seed(seed)
         layers = []
         for i in range(L):
             layers.append(RandomPermutation(D))
             layers.append(PiecewiseRationalQuadraticCouplingTransform(
                 mask=torchutils.create_alternating_binary_mask(D, even=(i % 2 == 0)),
-                transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=H, num_blocks=2),
+                transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=H, num_blocks=2,
+                                                                   activation=ACTIVATIONS[act]),
                 num_bins=K, tails="linear", tail_bound=3.0))
         flow = Flow(CompositeTransform(layers), StandardNormal([D]))
         steepen(flow, K, wh, ds, hs)
@@ -1101,7 +1118,7 @@ def steep_flow_cases(file_name="flows_steep.npz", only_nsf=False, nsf_cases=STEE
         noise = torch.randn(B, D, generator=g)
         spread = logit_spread(flow.eval(), x, K, float(np.sqrt(H)))
         finish(name, flow, x, noise, dict(kind="rq_nsf", L=L, D=D, K=K, H=H, B=B, tail_bound=3.0, seed=seed,
-                                          wh_scale=wh, d_scale=ds, hidden_scale=hs,
+                                          wh_scale=wh, d_scale=ds, hidden_scale=hs, **({"activation": act} if rest else {}),
                                           logit_std_wh_d_per_layer=[(round(a, 3), round(b, 3)) for a, b in spread]))
 
     if only_nsf:
@@ -1172,6 +1189,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "steep":
         steep_flow_cases()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "acts":
+        activation_flow_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bins":
         bin_count_flow_cases()
         sys.exit(0)
@@ -1195,3 +1215,4 @@ if __name__ == "__main__":
     sibling_autoregressive_cases()
     steep_flow_cases()
     bin_count_flow_cases()
+    activation_flow_cases()

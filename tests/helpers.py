@@ -230,7 +230,9 @@ def steep_flow(golden_dir, name, fixture="flows_steep.npz"):
     g = np.load(os.path.join(golden_dir, fixture))
     cfg = parse_kwargs(dict((str(n), str(c)) for n, c in g["meta"])[name])
     if cfg["kind"] == "rq_nsf":
-        flow = configs.rq_nsf_flow(cfg["L"], cfg["D"], cfg["K"], cfg["H"], 2, cfg["tail_bound"], seed=cfg["seed"])
+        F = torch.nn.functional
+        act = {"relu": F.relu, "leaky_relu": F.leaky_relu, "elu": F.elu, "tanh": torch.tanh}[cfg.get("activation", "relu")]
+        flow = configs.rq_nsf_flow(cfg["L"], cfg["D"], cfg["K"], cfg["H"], 2, cfg["tail_bound"], seed=cfg["seed"], activation=act)
         steepen(flow, cfg["K"], cfg["wh_scale"], cfg["d_scale"], cfg["hidden_scale"])
     elif cfg["kind"] == "affine":
         flow = configs.affine_coupling_flow(cfg["L"], cfg["D"], tuple(cfg["hidden"]), seed=cfg["seed"])

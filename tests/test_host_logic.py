@@ -1428,3 +1428,42 @@ def test_training_function_wiring_with_emulated_kernels(monkeypatch):
     assert batched_calls == [4, 2, 4, 4, 6], batched_calls
     # (round 4) every net with its final Linear went through the backward kernel's own final GEMM
     assert fused_calls == [40, 24, 40, 16, 40], fused_calls
+
+
+def test_block_activation_routing():
+    """Round 4: which conditioner activations the whole-layer kernels take (coupling._activation_ok): ReLU as before;
+    F.leaky_relu / F.elu / torch.tanh at 8 or 10 bins without a context or batch norm; anything else (a lambda, GELU,
+    blocks that differ) keeps the layer-by-layer path.  The code is part of the run signature (layers of one launch share
+    it), K8s never takes another activation, and the flag bits round-trip."""
+    import torch
+    from nflows_amd import _native as N, ops
+    from nflows_amd.nn.nets import ResidualNet
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    from nflows_amd.utils import create_alternating_binary_mask
+    F = torch.nn.functional
+
+    def layer(act, K=8, ctx=None, bn=False):
+        return RQ(create_alternating_binary_mask(16, even=True),
+                  lambda i, o: ResidualNet(i, o, hidden_features=64, context_features=ctx, num_blocks=2, activation=act,
+                                           use_batch_norm=bn),
+                  num_bins=K, tails="linear", tail_bound=3.0).eval()
+
+    assert [ops.activation_code(f) for f in (F.relu, torch.relu, F.leaky_relu, F.elu, torch.tanh, F.tanh, F.gelu, None)] == \
+        [N.ACTIVATION_RELU, N.ACTIVATION_RELU, N.ACTIVATION_LEAKY_RELU, N.ACTIVATION_ELU, N.ACTIVATION_TANH, N.ACTIVATION_TANH, None, None]
+    with torch.no_grad():
+        for act, code in ((F.relu, 0), (F.leaky_relu, 1), (F.elu, 2), (torch.tanh, 3)):
+            t = layer(act)
+            assert t._block_activation() == code and t._activation_ok(None) and t._resnet_eligible(None)
+            assert t._run_signature()[-1] == code
+        assert layer(F.relu)._run_signature() != layer(F.elu)._run_signature()
+        gelu = layer(F.gelu)
+        assert gelu._block_activation() is None and not gelu._resnet_eligible(None)
+        mixed = layer(F.elu)
+        mixed.transform_net.blocks[1].activation = torch.tanh
+        assert mixed._block_activation() is None and not mixed._resnet_eligible(None)
+        assert layer(F.relu, K=4)._resnet_eligible(None) and not layer(F.elu, K=4)._resnet_eligible(None)
+        assert not layer(F.elu, bn=True)._activation_ok(None) and layer(F.relu, bn=True)._activation_ok(None)
+        ctx = torch.zeros(4, 3)
+        assert not layer(F.tanh, ctx=3)._activation_ok(ctx) and layer(F.relu, ctx=3)._activation_ok(ctx)
+    assert (N.ACTIVATION_TANH << N.FLAG_ACTIVATION_SHIFT) == 0x3000
+    assert not ops.use_tile16(1024, 8, None, torch.device("cpu"), N.ACTIVATION_ELU)

@@ -207,6 +207,25 @@ def test_eager_port_bit_identical_on_other_bin_counts(golden_dir):
         assert min(min(pair) for pair in cfg["logit_std_wh_d_per_layer"]) > 1.5, (name, cfg["logit_std_wh_d_per_layer"])
 
 
+def test_eager_port_bit_identical_on_other_activations(golden_dir):
+    """tests/golden/flows_acts.npz (round 4): conditioners built with F.leaky_relu / F.elu / torch.tanh
+    (nn/nets/resnet.py:27), steep two-layer flows, forward and inverse of the real reference; the eager port -- which
+    runs the flow's own conditioner modules -- reproduces every vector bit for bit."""
+    import torch
+    from helpers import steep_flow
+    from oracle import eager
+    torch.set_num_threads(1)
+    for name in ("act_leaky_relu_k8", "act_elu_k8", "act_tanh_k8", "act_elu_k10", "act_tanh_k10"):
+        flow, g, cfg = steep_flow(golden_dir, name, "flows_acts.npz")
+        assert flow._transform._transforms[1].transform_net.blocks[0].activation is not torch.nn.functional.relu
+        with torch.no_grad():
+            z, lad = eager.flow_transform(flow, torch.from_numpy(g[name + "/x"]))
+            lp = eager.flow_log_prob(flow, torch.from_numpy(g[name + "/x"]))
+            xi, ladi = eager.flow_transform(flow, torch.from_numpy(g[name + "/noise"]), inverse=True)
+        for got, key in ((z, "z"), (lad, "lad"), (lp, "log_prob"), (xi, "inv_x"), (ladi, "inv_lad")):
+            assert np.array_equal(got.numpy(), g[name + "/" + key]), (name, key)
+
+
 def test_eager_port_other_configs_bit_identical(golden_dir):
     """The eager port on the affine stack (configs[1]'s layer type) and on the autoregressive RQ layer
     (configs[4]) in both directions -- the latter's inverse is the reference's D-pass loop -- : bit-identical to the reference, in float32

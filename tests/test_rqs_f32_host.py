@@ -207,3 +207,31 @@ def test_every_evaluator_stays_in_the_reference_error_class_across_logit_scales(
                     assert e_got.max() <= worst * e_ref.max() + 1e-6, "%s: max %.2e vs %.2e" % (tag, e_got.max(), e_ref.max())
                     q_got, q_ref = np.quantile(e_got, 0.999), np.quantile(e_ref, 0.999)
                     assert q_got <= 2.0 * q_ref + 1e-7, "%s: q999 %.2e vs %.2e" % (tag, q_got, q_ref)
+
+
+def test_block_activations_of_the_kernel_source_match_torch(lib):
+    """fused_common.hpp's `activate<ACT>` (round 4: what K8h / K8 apply between the Linears of a residual block when the
+    conditioner was built with another activation than ReLU, resnet.py:27, :44, :47) against torch's float64 functions:
+    ReLU and leaky ReLU bit for bit with torch's fp32 (also -0.0, infinities, NaN), ELU and tanh within 2e-7 absolute
+    (the value is the next GEMM's operand at magnitude <= ~1; torch's own fp32 results are within 6e-8), saturating
+    correctly at +-large arguments, NaN propagated."""
+    import torch
+    F = torch.nn.functional
+    rng = np.random.RandomState(5)
+    x = np.concatenate([rng.randn(200000) * s for s in (0.01, 1.0, 4.0, 30.0)] +
+                       [np.array([0.0, -0.0, 1e-30, -1e-30, 88.0, -88.0, 200.0, -200.0, np.inf, -np.inf, np.nan])]).astype(np.float32)
+    t = torch.from_numpy(x)
+    y = np.empty_like(x)
+    fin = np.isfinite(x)
+    for code, fn, exact in ((0, lambda v: v, True), (1, F.relu, True), (2, F.leaky_relu, True), (3, F.elu, False), (4, torch.tanh, False)):
+        assert lib.host_activate(code, x.size, P(x), P(y)) == 0
+        ref32, ref64 = fn(t).numpy(), fn(t.double()).numpy()
+        assert np.array_equal(np.isnan(y), np.isnan(ref32)), code
+        if exact:
+            assert np.array_equal(y[~np.isnan(y)], ref32[~np.isnan(ref32)]), code
+        else:
+            err = np.abs(y[fin].astype(np.float64) - ref64[fin])
+            # (relative to max(1, |value|): ELU's positive branch is the identity)
+            assert (err / np.maximum(1.0, np.abs(ref64[fin]))).max() <= 2e-7, (code, err.max())
+            inf = np.isinf(x)
+            assert np.array_equal(y[inf], ref32[inf]), code
