@@ -248,3 +248,17 @@ def steep_flow(golden_dir, name, fixture="flows_steep.npz"):
     want = g[name + "/param_checksums"]
     assert sums.shape == want.shape and np.allclose(sums, want, rtol=1e-12, atol=0), "seeded weights differ from the reference's: " + name
     return flow.eval(), g, cfg
+
+
+def trained_flow(golden_dir, name="trained_nsf"):
+    """The flow of tests/golden/flows_trained.npz -- TRAINED with the reference (make_golden.py `trained`) -- as drop-in
+    classes with the stored state_dict loaded strictly (same keys as the reference's: SURVEY appendix A11).  Returns
+    (flow on CPU in eval mode, npz, cfg)."""
+    import torch
+    from nflows_amd import configs
+    g = np.load(os.path.join(golden_dir, "flows_trained.npz"))
+    cfg = parse_kwargs(dict((str(n), str(c)) for n, c in g["meta"])[name])
+    flow = configs.rq_nsf_flow(cfg["L"], cfg["D"], cfg["K"], cfg["H"], 2, cfg["tail_bound"], seed=cfg["seed"])
+    prefix = name + "/sd/"
+    flow.load_state_dict({k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}, strict=True)
+    return flow.eval(), g, cfg

@@ -493,8 +493,9 @@ def test_whole_layer_kernel_abi_contract(restore_fused_path):
     # the C entry point itself refuses it, and a bin count the kernel does not have
     y200, lad200 = ops.rqs_coupling_resnet(x[:200], wp, bp, tables, 32, 32, 2, spec)
     assert torch.equal(y200, y[:200]) and torch.equal(lad200, lad[:200])
-    spec4 = ops.make_rqs_spec(4, "linear", tail_bound=3.0)
-    assert ops.rqs_coupling_resnet(x, wp, bp, tables, 32, 32, 2, spec4) is None
+    # (round 4: 2 .. 16 bins are served -- with blobs packed for that bin count; 17 and up are refused)
+    spec17 = ops.make_rqs_spec(17, "linear", tail_bound=3.0)
+    assert ops.rqs_coupling_resnet(x, wp, bp, tables, 32, 32, 2, spec17) is None
     lib = N.load()
     out, l2 = torch.empty_like(x), torch.empty(256, device=DEV)
     st = torch.zeros(1, dtype=torch.int32, device=DEV)
