@@ -48,7 +48,7 @@ class StalePackedWeights(RuntimeError):
 # NFA_VERIFY_WEIGHTS=N: every N-th use of a conditioner's cache key re-reads a checksum of its parameters on the
 # device (L1 and L2 norm per parameter, two fused launches and one synchronising comparison) and raises
 # StalePackedWeights when it differs from the one taken when the key last changed visibly.  Default (round 4): every
-# 256th use -- amortised ~ 1 us per layer and call; 0 switches it off, 1 checks every call (debugging).  Skipped while
+# 256th use, staggered over the layers -- amortised ~ 1 us per layer and call; 0 switches it off, 1 checks every call (debugging).  Skipped while
 # a stream is being captured into a HIP graph (the comparison synchronises).
 VERIFY_WEIGHTS_EVERY = int(os.environ.get("NFA_VERIFY_WEIGHTS", "256") or 0)
 
@@ -68,7 +68,9 @@ def _verify_weights(owner, key, params):
         return
     state = owner.__dict__.get("_weights_checksum")
     if state is None or state[0] != key:
-        owner.__dict__["_weights_checksum"] = [key, _checksum(params), 0]
+        # (the count starts at a per-layer offset: the layers of a flow are used once per call each, and 32 synchronising
+        #  comparisons landing in ONE call were a 3 ms spike every 256th step -- 0.14 ms on bench.py's 8 192-row figure)
+        owner.__dict__["_weights_checksum"] = [key, _checksum(params), (id(owner) >> 6) % VERIFY_WEIGHTS_EVERY]
         return
     state[2] += 1
     if state[2] % VERIFY_WEIGHTS_EVERY == 0 and not torch.equal(_checksum(params), state[1]):
