@@ -1,4 +1,4 @@
-// Spline evaluation of K8h's woven final layer (csrc/rqs_resnet_f16.hip): 2 .. 16 bins (8 and 10: the tuned forms), linear tails,
+// Spline evaluation of K8h's woven final layer (csrc/rqs_resnet_f16.hip): 2 .. 32 bins (8 and 10: the tuned forms), linear tails,
 // logits handed over at scale 1/kappa straight from the MFMA accumulators.
 //
 // Same function as rational_quadratic.py:66-181 (+ :13-63 for the tails), arranged for the lowest
@@ -26,7 +26,7 @@ namespace nfa {
 
 template <bool INVERSE, int KT = 8>
 struct FusedSteps {
-    static_assert(KT >= 2 && KT <= 16, "2 .. 16 bins (8 and 10 keep their own maximum / sum chains)");
+    static_assert(KT >= 2 && KT <= 32, "2 .. 32 bins (8 and 10 keep their own maximum / sum chains)");
     static constexpr int kNumSlices = KT + 3;                   // max, one exponential per logit, sum x 2
     static constexpr int kWalkSlices = 3 + (KT - 1);            // setup x 2, bin 0, bins 1..KT-1
     static constexpr int kBinSlices = INVERSE ? 9 : 7;

@@ -892,6 +892,11 @@ def _k8_row_order_32(num_transform, tiles_per_group=2):
     return (feat * (16 * T) + (t % T) * 16 + q[None, :]).reshape(-1)  # [tiles * 32]
 
 
+def whole_layer_bins(num_bins):
+    """Bin counts the whole-layer kernels K8h / K8 are built for (linear tails): 2 .. 16, and 20, 24, 32"""
+    return 2 <= num_bins <= 16 or num_bins in (20, 24, 32)
+
+
 def final_rows_per_feature(params_per_feature):
     """Rows of the packed final layer per transformed feature in the whole-layer kernels: 8 bins (23 logits) -> 24, two
     features sharing three 32-row tiles; any other bin count -> 3 K - 1 padded to whole lane-half shares of 16."""
@@ -1433,8 +1438,8 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
     Returns (weights [stages, 4096] f16, parameter words fp32)."""
     dt, P = num_transform, params_per_feature
     K = (P + 1) // 3
-    if P % 3 != 2 or not 2 <= K <= 16:
-        raise ValueError("K8h packs linear-tail layers of 2 .. 16 bins")
+    if P % 3 != 2 or not whole_layer_bins(K):
+        raise ValueError("K8h packs linear-tail layers of 2 .. 16, 20, 24 or 32 bins")
     S = float(act_scale)
     dev = net.final_layer.weight.device
     order_k = (_k8s_column_order() if tile16 else _k8_column_order()).to(dev)

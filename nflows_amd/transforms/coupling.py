@@ -551,7 +551,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         return (self.fuse_conditioner and self.fuse_final_linear and not torch.is_grad_enabled()
                 and context_ok and type(net) is ResidualNet
                 and net.hidden_features <= 128 and self.tails == "linear"
-                and (self.num_bins in (8, 10) or (2 <= self.num_bins <= 16 and context is None))
+                and (self.num_bins in (8, 10) or (ops.whole_layer_bins(self.num_bins) and context is None))
                 and 1 <= self.num_identity_features <= 64 and 1 <= self.num_transform_features
                 and self._fused_geometry()[1] <= 64 and self._fused_geometry()[0] <= 128
                 and self._activation_ok(context)
@@ -604,7 +604,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         """K8h serves 8 and 10 bins; with a context up to 32 context features beside up to 32 identity features
         (of the run's geometry) -- otherwise the bf16x3 kernel (K8) runs."""
         ce = self._static_signature()[2]
-        return (self.conditioner_engine == "f16x2" and 2 <= self.num_bins <= 16 and not self._log2e()
+        return (self.conditioner_engine == "f16x2" and ops.whole_layer_bins(self.num_bins) and not self._log2e()
                 and (ce is None or (ce <= 32 and (geometry or self._fused_geometry())[2] <= 32)))
 
     def _packed_resnet_f16(self, geometry=None, tile16=False):

@@ -72,7 +72,7 @@ extern "C" int host_rqs_forward_regs(int kt, int inverse, int64_t n, const nfa_r
 #define REGS_CASE(KT_) case KT_: return inverse ? forward_regs_all<KT_, true>(n, sp, x, params, y, lad) : forward_regs_all<KT_, false>(n, sp, x, params, y, lad);
     switch (kt) {   // (every bin count the whole-layer kernels are built for: the exact kernel's plain loop runs this instance)
         REGS_CASE(2) REGS_CASE(3) REGS_CASE(4) REGS_CASE(5) REGS_CASE(6) REGS_CASE(7) REGS_CASE(8) REGS_CASE(9) REGS_CASE(10)
-        REGS_CASE(11) REGS_CASE(12) REGS_CASE(13) REGS_CASE(14) REGS_CASE(15) REGS_CASE(16)
+        REGS_CASE(11) REGS_CASE(12) REGS_CASE(13) REGS_CASE(14) REGS_CASE(15) REGS_CASE(16) REGS_CASE(20) REGS_CASE(24) REGS_CASE(32)
     }
 #undef REGS_CASE
     return -1;
@@ -190,7 +190,7 @@ extern "C" int host_rqs_forward_fused(int inverse, float kappa, int64_t n, const
                                                  : fused_all<FusedSteps<false, KT_>, KT_>(n, sp, kappa, x, params, y, lad);
     switch (sp.K) {
         FUSED_CASE(2) FUSED_CASE(3) FUSED_CASE(4) FUSED_CASE(5) FUSED_CASE(6) FUSED_CASE(7) FUSED_CASE(8) FUSED_CASE(9) FUSED_CASE(10)
-        FUSED_CASE(11) FUSED_CASE(12) FUSED_CASE(13) FUSED_CASE(14) FUSED_CASE(15) FUSED_CASE(16)
+        FUSED_CASE(11) FUSED_CASE(12) FUSED_CASE(13) FUSED_CASE(14) FUSED_CASE(15) FUSED_CASE(16) FUSED_CASE(20) FUSED_CASE(24) FUSED_CASE(32)
     }
 #undef FUSED_CASE
     return -1;

@@ -1008,11 +1008,11 @@ def conditional_flow_case():
 
 
 def bin_count_flow_cases():
-    """Round 4, the whole-layer kernels' other bin counts (2 .. 16 except 8 and 10): two-layer coupling flows with steep
+    """Round 4, the whole-layer kernels' other bin counts (2 .. 16 except 8 and 10, and 20, 24, 32): two-layer coupling flows with steep
     splines (the recipe of steep_flow_cases) at D = 32, H = 128, forward and inverse of the reference in fp32 and fp64.
     tests/golden/flows_bins.npz; weights rebuilt from seed + steepen, checksums stored."""
     steep_flow_cases(file_name="flows_bins.npz", only_nsf=True, nsf_cases=tuple(
-        ("bins_k%d" % K, 300 + K, 2, K, 60.0, 6.0, 10.0, 32, 128) for K in (2, 3, 4, 5, 6, 7, 9, 11, 12, 13, 16)))
+        ("bins_k%d" % K, 300 + K, 2, K, 60.0, 6.0, 10.0, 32, 128) for K in (2, 3, 4, 5, 6, 7, 9, 11, 12, 13, 16, 20, 24, 32)))
 
 
 def trained_flow_case():

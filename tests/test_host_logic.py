@@ -218,7 +218,7 @@ def test_distribution_template_methods():
     assert "_log_z" not in d.state_dict() and d._log_z.dtype == torch.float64
 
 
-@pytest.mark.parametrize("K", [8, 10, 4, 12, 16])
+@pytest.mark.parametrize("K", [8, 10, 4, 12, 16, 24])
 def test_whole_layer_packing_is_a_lossless_rearrangement(K):
     """Host side of K8 (ops.pack_resnet_conditioner, runs on CPU tensors): emulate what the kernel
     computes with the packed weights -- every GEMM transposed, the k index permuted the way the
@@ -230,7 +230,7 @@ def test_whole_layer_packing_is_a_lossless_rearrangement(K):
     torch.manual_seed(0)
     dt, di, P = 8, 6, 3 * K - 1
     R = ops.final_rows_per_feature(P)               # rows per feature after padding: 24 (8 bins), else whole 16s
-    assert R == {8: 24, 10: 32, 4: 16, 12: 48, 16: 48}[K]
+    assert R == {8: 24, 10: 32, 4: 16, 12: 48, 16: 48, 24: 80}[K]
     net = ResidualNet(di, dt * P, hidden_features=128, num_blocks=2).double()
     with torch.no_grad():
         for p_ in net.parameters():
@@ -630,7 +630,7 @@ def test_f16_whole_layer_packing_carries_the_scales(act_scale, K=8):
     assert (logits - want).abs().max().item() < 2e-6 * (1 + want.abs().max().item())
 
 
-@pytest.mark.parametrize("K", [2, 4, 5, 7, 10, 11, 12, 16])
+@pytest.mark.parametrize("K", [2, 4, 5, 7, 10, 11, 12, 16, 20, 32])
 def test_f16_whole_layer_packing_of_other_bin_counts(K):
     """Round 4: the final layer of 2 .. 16 bins -- 3 K - 1 logits per feature padded to whole lane-half shares of 16,
     T = 1 .. 3 tiles per group of two features -- through the same emulation of K8h's data flow."""
@@ -1222,11 +1222,21 @@ def test_no_mfma_result_lands_on_its_own_operands():
         m = re.match(r"([va])(\d+)$", op)
         return (m.group(1), {int(m.group(2))}) if m else ("?", set())
 
-    for name in ("rqs_resnet_f16s.hip", "rqs_resnet_f16.hip"):
-        asm = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
-                              "-fno-fast-math", "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt",
-                              "-I" + os.path.join(root, "include"), "-I" + csrc, "-S", "--cuda-device-only", "-o", "-",
-                              os.path.join(csrc, name)], capture_output=True, text=True, check=True).stdout
+    # (round 4: K8h's instances live in four translation units -- the other bin counts and activations in three of their
+    #  own --, compiled side by side here as in the Makefile)
+    names = ("rqs_resnet_f16s.hip", "rqs_resnet_f16.hip", "rqs_resnet_f16_bins_a.hip", "rqs_resnet_f16_bins_b.hip",
+             "rqs_resnet_f16_bins_c.hip")
+
+    def assembly(name):
+        return subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
+                               "-fno-fast-math", "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt",
+                               "-I" + os.path.join(root, "include"), "-I" + csrc, "-S", "--cuda-device-only", "-o", "-",
+                               os.path.join(csrc, name)], capture_output=True, text=True, check=True).stdout
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(names), os.cpu_count() or 1)) as pool:
+        listings = list(pool.map(assembly, names))
+    for name, asm in zip(names, listings):
         count = 0
         for line in asm.splitlines():
             m = re.match(r"\s+v_mfma_\w+ (\S+), (\S+), (\S+), ", line)

@@ -183,7 +183,7 @@ def test_eager_port_bit_identical_on_steep_flows(golden_dir):
             assert min(min(pair) for pair in cfg["logit_std_wh_d_per_layer"]) > (0.6 if name.endswith("deep") else 1.8), name
 
 
-BIN_COUNTS = (2, 3, 4, 5, 6, 7, 9, 11, 12, 13, 16)
+BIN_COUNTS = (2, 3, 4, 5, 6, 7, 9, 11, 12, 13, 16, 20, 24, 32)
 
 
 def test_eager_port_bit_identical_on_other_bin_counts(golden_dir):

@@ -155,7 +155,7 @@ def test_k8h_inverse_newton_step_has_the_right_slope(lib, golden_dir):
     assert np.abs(back[fin] - xs[fin]).max() <= 1e-4
 
 
-@pytest.mark.parametrize("K", [8, 10, 2, 3, 4, 5, 6, 7, 9, 11, 12, 13, 16])
+@pytest.mark.parametrize("K", [8, 10, 2, 3, 4, 5, 6, 7, 9, 11, 12, 13, 16, 20, 24, 32])
 def test_every_evaluator_stays_in_the_reference_error_class_across_logit_scales(lib, K):
     """Random splines from gentle (logits ~ 0.1 N(0, 1): an untrained flow) to steep (3 N(0, 1)), both directions, every
     per-lane evaluator of the kernels (K1 / K5's rqs_eval, run-time-K and compile-time-K; K7's flat form; K8's sliced
@@ -206,7 +206,9 @@ def test_every_evaluator_stays_in_the_reference_error_class_across_logit_scales(
                     worst = 6.0 if K in (8, 10) else 15.0
                     assert e_got.max() <= worst * e_ref.max() + 1e-6, "%s: max %.2e vs %.2e" % (tag, e_got.max(), e_ref.max())
                     q_got, q_ref = np.quantile(e_got, 0.999), np.quantile(e_ref, 0.999)
-                    assert q_got <= 2.0 * q_ref + 1e-7, "%s: q999 %.2e vs %.2e" % (tag, q_got, q_ref)
+                    # (20+ bins at logits ~ N(0, 3) / N(0, 6): twenty running fp32 knot sums against the reference's
+                    #  once-rounded double sums reach 2.03 x on this statistic; the GPU fixtures -- spread ~ 2 -- hold 2 x)
+                    assert q_got <= (2.0 if K <= 16 else 2.5) * q_ref + 1e-7, "%s: q999 %.2e vs %.2e" % (tag, q_got, q_ref)
 
 
 def test_block_activations_of_the_kernel_source_match_torch(lib):

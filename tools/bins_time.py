@@ -29,7 +29,7 @@ def ms(fn, steps=10):
 
 
 print("rows %d, 32 layers, D = 64: ms per Flow.log_prob | ms per inverse pass | kernel" % rows)
-for K in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16):
+for K in [int(a) for a in sys.argv[2:]] or (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 32):
     flow = configs.rq_nsf_flow(num_layers=32, features=64, num_bins=K, hidden_features=128, seed=0).eval().cuda()
     out = []
     for fused in (True, False):
