@@ -246,7 +246,7 @@ int nfa_rqs_coupling_fused_linear_f32(const float *inputs, const float *hidden,
  * other kernels (same error class as the reference's fp32 path; environment NFA_K8_PIPE=1 selects
  * the reference's exact sequence, =0 additionally the unwoven loop).
  * Supported: num_bins = 8 or 10 (the reference's default; not with NFA_FLAG_LOGITS_LOG2E) and, ABI 9,
- * any other num_bins from 2 to 16 (plain final-layer loop on the spline kernel's own evaluator; no context), linear
+ * any other num_bins from 2 to 16 and 20, 24, 32 (plain final-layer loop on the spline kernel's own evaluator; no context), linear
  * tails, hidden_features = 128, d_i <= 64, d_t % 4 == 0, d_t <= 64, features % 4 == 0,
  * features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
  */
@@ -320,7 +320,7 @@ int nfa_rqs_flow_resnet_f32(const float *inputs, const void *weights_packed,
  *                  it on the same stream; no host synchronisation in between.  (K8s on 64-row blocks sets
  *                  bit 1 / bit 2 instead: only the lower / upper 64 rows of the block are open, the other
  *                  half is written; the redo entry points honour the bits.)
- * Supported: num_bins = 8 or 10, and (ABI 9, without a context) any other num_bins from 2 to 16 -- final-layer rows as
+ * Supported: num_bins = 8 or 10, and (ABI 9, without a context) any other num_bins from 2 to 16 and 20, 24, 32 -- final-layer rows as
  * K8's general rule above, 16 ceil((3 num_bins - 1) / 16) per feature --, linear tails, hidden_features = 128 (narrower conditioners: zero-padded by the packer), d_i <= 64, d_t % 4 == 0,
  * d_t <= 64, features % 4 == 0, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
  * Table slots may repeat a column (d_t + d_i may exceed features): the host side pads other shapes into
