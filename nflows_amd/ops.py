@@ -1730,19 +1730,16 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
     return out, lad
 
 
+_ACTIVATION_CODES = {id(torch.nn.functional.relu): N.ACTIVATION_RELU, id(torch.relu): N.ACTIVATION_RELU,
+                     id(torch.nn.functional.leaky_relu): N.ACTIVATION_LEAKY_RELU, id(torch.nn.functional.elu): N.ACTIVATION_ELU,
+                     id(torch.tanh): N.ACTIVATION_TANH, id(torch.nn.functional.tanh): N.ACTIVATION_TANH}
+
+
 def activation_code(fn):
     """The whole-layer kernels' code of a residual block's `activation` (nn/nets/resnet.py:27), or None: the
-    reference's default F.relu, and (round 4) F.leaky_relu / F.elu with their default parameters and tanh."""
-    F = torch.nn.functional
-    if fn is F.relu or fn is torch.relu:
-        return N.ACTIVATION_RELU
-    if fn is F.leaky_relu:
-        return N.ACTIVATION_LEAKY_RELU
-    if fn is F.elu:
-        return N.ACTIVATION_ELU
-    if fn is torch.tanh or fn is F.tanh:
-        return N.ACTIVATION_TANH
-    return None
+    reference's default F.relu, and (round 4) F.leaky_relu / F.elu with their default parameters and tanh --
+    recognised by identity (the module-level functions live as long as torch does: their ids are stable keys)."""
+    return _ACTIVATION_CODES.get(id(fn))
 
 
 K8S_ENABLED = os.environ.get("NFA_K8S", "1") != "0"

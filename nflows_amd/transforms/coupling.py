@@ -520,13 +520,21 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
 
     def _block_activation(self):
         """The whole-layer kernels' code of the conditioner blocks' activation (one for all blocks), or None"""
-        blocks = getattr(self.transform_net, "blocks", None)
+        # (read on every call -- an activation is a plain attribute, swapping it advances no cache epoch --, so kept to
+        #  dictionary lookups: ~1 us per layer)
+        blocks = self.transform_net._modules.get("blocks")
         if blocks is None:
             return None
-        if len(blocks) == 0:
-            return N.ACTIVATION_RELU
-        codes = {ops.activation_code(getattr(b, "activation", None)) for b in blocks}
-        return codes.pop() if len(codes) == 1 else None
+        first = None
+        for b in blocks._modules.values():
+            act = b.__dict__.get("activation")
+            if first is None:
+                first = act
+                if first is None:
+                    return None
+            elif act is not first:
+                return None
+        return N.ACTIVATION_RELU if first is None else ops.activation_code(first)
 
     def _static_signature(self):
         """(features, residual blocks, context features) of the layer's conditioner: read once per cache epoch

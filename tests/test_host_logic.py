@@ -1477,3 +1477,47 @@ def test_block_activation_routing():
         assert not layer(F.tanh, ctx=3)._activation_ok(ctx) and layer(F.relu, ctx=3)._activation_ok(ctx)
     assert (N.ACTIVATION_TANH << N.FLAG_ACTIVATION_SHIFT) == 0x3000
     assert not ops.use_tile16(1024, 8, None, torch.device("cpu"), N.ACTIVATION_ELU)
+
+
+def test_output_gradient_images_are_swizzled_conflict_free():
+    """K14's backward kernel from d loss / d params (csrc/resnet_train.hip: gp_request / kstep_final): the wave's 32 rows
+    x 16 columns of g_params per k-step arrive by LDS-DMA -- lane l of request i writes LDS position l of its 1-KB half
+    and FETCHES chunk (l & 3) ^ ((row >> 1) & 3) of row 16 i + l / 4 -- and lane (half, r) reads chunks 2 half, 2 half + 1
+    of its row at position chunk ^ ((r >> 1) & 3).  Emulated here: every reader gets exactly its eight columns
+    k = 16 ks + 8 half + j (the B operand's layout, as in the forward kernel's initial layer), columns past out_features
+    come from the row's last chunk (their weights are zero), and eight consecutive lanes of a 16-byte read touch eight
+    different bank quads (an unswizzled image would put them on two)."""
+    import numpy as np
+    for out_features, ks in ((736, 0), (736, 45), (40, 2), (24, 1), (4, 0)):
+        gp = np.arange(32 * out_features, dtype=np.int64).reshape(32, out_features)   # value = row * out + column
+        image = np.full(32 * 16, -1, dtype=np.int64)                                  # 2 KB of floats: [row][4 chunks][4]
+        for i in range(2):
+            for lane in range(64):
+                r = 16 * i + (lane >> 2)
+                chunk = (lane & 3) ^ ((r >> 1) & 3)
+                col = ks * 16 + chunk * 4
+                col = col if col < out_features else out_features - 4
+                dst = i * 256 + lane * 4                                               # floats: request i, LDS position = lane
+                image[dst:dst + 4] = gp[r, col:col + 4]
+        assert (image >= 0).all()
+        for lane in range(64):
+            half, r = lane >> 5, lane & 31
+            sw = (r >> 1) & 3
+            got = []
+            for c in (2 * half, 2 * half + 1):
+                pos = r * 16 + ((c ^ sw) << 2)
+                got += list(image[pos:pos + 4])
+            for j, v in enumerate(got):
+                k = ks * 16 + 8 * half + j
+                if k < out_features:
+                    assert v == r * out_features + k, (out_features, ks, lane, j)
+                else:   # a clamped chunk: some real value of the same row (meets a zero weight)
+                    assert r * out_features <= v < (r + 1) * out_features
+        # bank quads (16 bytes = four banks) of the first read of eight consecutive lanes, both halves
+        for base in range(0, 64, 8):
+            quads = set()
+            for lane in range(base, base + 8):
+                half, r = lane >> 5, lane & 31
+                byte = r * 64 + (((2 * half) ^ ((r >> 1) & 3)) << 4)
+                quads.add((byte // 16) % 8)
+            assert len(quads) == 8, (base, sorted(quads))
