@@ -564,7 +564,10 @@ int nfa_rqs_elementwise_backward_f64(const double *inputs, const double *unnorma
  *
  *   forward:  identity_inputs [batch, num_identity] -> hidden [batch, 128];
  *             saved [2 num_blocks][batch][128]: saved[2k] = relu(h_k), saved[2k+1] = relu(a_k), the inputs of block
- *             k's two Linears (what the weight gradients need, and the ReLU masks of the backward pass).
+ *             k's two Linears (what the weight gradients need); BEHIND the planes (ABI 9) the packed ReLU masks of the
+ *             backward pass: [2 num_blocks][batch / 32][64] 8-byte words (bit 16 t + q of a lane's word = its element q of
+ *             tile t is > 0), i.e. the buffer is 2 num_blocks x batch x (512 + 16) bytes and the backward kernels read
+ *             only that tail of it.
  *   backward: grad_hidden [batch, 128] (+ saved) -> grad_identity_inputs [batch, num_identity] and
  *             grads [2 num_blocks][batch][128]: grads[2k] = d loss / d h_k (= grad_outputs of the Linear that
  *             produced h_k: the initial layer for k = 0, block k-1's second Linear otherwise),

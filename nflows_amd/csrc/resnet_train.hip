@@ -255,11 +255,36 @@ __device__ __forceinline__ void kstep(f32x16 (&acc)[4], const bf16x8& bh, const 
 // point at about the same time, the burst of 33 MB per array waited for itself in the next counted vmcnt (stores share
 // the counter with the ring's requests) and nothing overlapped it: 26 of the forward kernel's 78 us at 65 536 rows
 // (profiles/r4/k14_ablations.txt).
+// 64 ReLU masks of a lane (4 tiles x 16 accumulator registers) as two words: bit 16 t + q of the pair
+struct Mask64 {
+    unsigned lo, hi;   // tiles 0-1, tiles 2-3
+};
+
+// Packed masks (round 4, last change): the forward kernel leaves, behind the 2 nb saved planes, one Mask64 per lane,
+// wave tile and plane -- [2 nb][batch / 32][64 lanes] x 8 bytes, 4 MB at 65 536 rows and two blocks -- and the
+// backward kernel reads those instead of rebuilding the bits from the 134 MB of saved activations (both kernels give
+// lane (half, r) the same elements of a row: the accumulator layout).  mask bit = value > 0 (NaN: 0, as
+// threshold_backward's `output > 0`).
+__device__ __forceinline__ unsigned long long* packed_masks(float* saved, int64_t batch, int num_blocks) {
+    return reinterpret_cast<unsigned long long*>(saved + (int64_t)2 * num_blocks * batch * 128);
+}
+
+// bits of tile t (value > 0) into the lane's mask
+__device__ __forceinline__ void mask_tile(Mask64& m, const f32x16& v, int t) {
+    unsigned bits = 0u;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bits |= (v[q] > 0.0f ? 1u : 0u) << q;
+    if (t < 2) m.lo |= bits << (16 * (t & 1));
+    else m.hi |= bits << (16 * (t & 1));
+}
+
 template <bool RELU, bool SAVE = false>
 __device__ __forceinline__ void gemm_from_tiles(f32x16 (&acc)[4], const f32x16 (&src)[4], TrainStream& sm, int lane,
-                                                float* save = nullptr, int64_t row = 0, int half = 0, float* stage = nullptr) {
+                                                float* save = nullptr, int64_t row = 0, int half = 0, float* stage = nullptr,
+                                                Mask64* mask = nullptr) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+        if (mask) mask_tile(*mask, src[t], t);   // (forward: the packed ReLU masks, tile by tile while the tile is at hand)
 #ifndef NFA_K14_BURST_STORES
         // (SAVE as a template flag or `save` as a run-time pointer: the same code, another register allocation -- hipcc
         //  spills 12-20 bytes in the forward kernel with the flag and 780 in the backward kernel with the pointer)
@@ -373,7 +398,10 @@ __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_forward_kernel(const 
 #endif
                 load_bias_tile(u[t], bias + t * 32);
             }
-            gemm_from_tiles<true>(u, hs, sm, lane, in0, row, half, stage);    // (stores relu(h), the first Linear's input, on the way)
+            unsigned long long* pm = packed_masks(a.saved, a.batch, a.num_blocks) + ((row0 >> 5) << 6) + lane_here;
+            Mask64 mh = {0u, 0u}, ma = {0u, 0u};   // [h_k > 0], [a_k > 0]
+            gemm_from_tiles<true>(u, hs, sm, lane, in0, row, half, stage, &mh);    // (stores relu(h), the first Linear's input, on the way)
+            pm[(int64_t)(2 * blk) * (a.batch << 1)] = ((unsigned long long)mh.hi << 32) | mh.lo;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
 #ifdef NFA_K14_BURST_STORES
@@ -387,7 +415,8 @@ __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_forward_kernel(const 
             {
                 // (the second GEMM accumulates INTO hs while it reads u: relu(a), the second Linear's input, is stored
                 //  from u on the way)
-                gemm_from_tiles<true>(hs, u, sm, lane, in1, row, half, stage);
+                gemm_from_tiles<true>(hs, u, sm, lane, in1, row, half, stage, &ma);
+                pm[(int64_t)(2 * blk + 1) * (a.batch << 1)] = ((unsigned long long)ma.hi << 32) | ma.lo;
             }
             bias += 256;
         }
@@ -472,11 +501,6 @@ __device__ __forceinline__ void kstep_final(f32x16 (&acc)[4], TrainStream& sm, c
     else asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(3 * (kTrainAhead - 1)) : "memory");
     sm.slot = (sm.slot + 1 == kTrainRing) ? 0 : sm.slot + 1;
 }
-
-// 64 ReLU masks of a lane (4 tiles x 16 accumulator registers) as two words: bit 16 t + q of the pair
-struct Mask64 {
-    unsigned lo, hi;   // tiles 0-1, tiles 2-3
-};
 
 // loads the lane's 64 values of a [B, 128] array (accumulator layout); the caller waits
 __device__ __forceinline__ void load_tiles_raw(vec4f (&v)[16], const float* base, int64_t row, int half) {
@@ -563,8 +587,19 @@ __global__ void __launch_bounds__(kBlock, 2) resnet_hidden_backward_kernel(const
         const int64_t row = row0 + r;
         // ---- (without the final Linear: with the ring drained) the ReLU masks of every block, then the incoming gradient
         Mask64 masks[2 * NB > 0 ? 2 * NB : 1];
+        {
+            // (packed by the forward kernel: one 8-byte load per plane; all of them in flight together)
+            const unsigned long long* pm = packed_masks(a.saved, a.batch, NB) + ((row0 >> 5) << 6) + lane_here;
+            unsigned long long w[2 * NB > 0 ? 2 * NB : 1];
 #pragma unroll
-        for (int i = 0; i < 2 * NB; ++i) masks[i] = load_mask(a.saved + i * plane, row, half);
+            for (int i = 0; i < 2 * NB; ++i) w[i] = pm[(int64_t)i * (a.batch << 1)];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 2 * NB; ++i) {
+                masks[i].lo = (unsigned)w[i];
+                masks[i].hi = (unsigned)(w[i] >> 32);
+            }
+        }
         if constexpr (!FINAL) {
             vec4f v[16];
             load_tiles_raw(v, a.x, row, half);

@@ -1242,6 +1242,21 @@ def resnet_hidden_train_supported(batch, num_identity, hidden_features, num_bloc
             and 0 <= num_blocks <= 3 and batch > 0 and batch % 128 == 0)   # (identity features: padded to a multiple of 4)
 
 
+def _train_mask_words(num_blocks, batch):
+    """floats behind K14's saved planes: one 8-byte mask word per lane, 32-row wave tile and plane"""
+    return 2 * num_blocks * batch * 4
+
+
+def _saved_with_masks(saved, num_blocks, batch):
+    """`saved` as the backward kernels want it: the forward kernel's buffer, whose storage carries the packed ReLU
+    masks behind the planes (a clone or a slice of it does not)"""
+    need = (2 * num_blocks * batch * 128 + _train_mask_words(num_blocks, batch)) * 4
+    if saved.untyped_storage().nbytes() - saved.storage_offset() * saved.element_size() < need:
+        raise ValueError("nflows_amd: `saved` must be the tensor nfa_resnet_hidden_forward_f32 filled (its storage holds "
+                         "the packed ReLU masks behind the planes)")
+    return saved
+
+
 def resnet_hidden_forward(x, fwd_stages, fwd_bias, num_blocks, final_bias=None, out_features=0):
     """K14 forward: identity features [B, d_i] -> (hidden [B, 128], saved [2 num_blocks, B, 128], params [B, out]
     or None -- the conditioner's output when the final Linear was packed into the stream)."""
@@ -1250,11 +1265,14 @@ def resnet_hidden_forward(x, fwd_stages, fwd_bias, num_blocks, final_bias=None, 
     B, di = x.shape
     dev = x.device
     hidden = torch.empty(B, 128, dtype=torch.float32, device=dev)
-    saved = torch.empty(2 * num_blocks, B, 128, dtype=torch.float32, device=dev)
+    # the 2 nb planes and, behind them, the packed ReLU masks the backward kernel reads (16 bytes per row and plane)
+    planes = 2 * num_blocks * B * 128
+    saved_all = torch.empty(planes + _train_mask_words(num_blocks, B), dtype=torch.float32, device=dev)
+    saved = saved_all[:planes].view(2 * num_blocks, B, 128)
     params = torch.empty(B, out_features, dtype=torch.float32, device=dev) if final_bias is not None else None
     with torch.cuda.device(dev):
         rc = N.load().nfa_resnet_hidden_forward_f32(N.ptr(x), N.ptr(fwd_stages), N.ptr(fwd_bias),
-                                                    N.ptr(saved) if num_blocks else None, N.ptr(hidden),
+                                                    N.ptr(saved_all) if num_blocks else None, N.ptr(hidden),
                                                     N.ptr(final_bias), N.ptr(params),
                                                     out_features if final_bias is not None else 0, B, di, 128,
                                                     num_blocks, N.stream_handle(dev))
@@ -1269,6 +1287,8 @@ def resnet_hidden_backward(grad_hidden, bwd_stages, saved, num_identity):
     B = g.shape[0]
     dev = g.device
     nb = saved.shape[0] // 2
+    if nb:
+        _saved_with_masks(saved, nb, B)
     grads = torch.empty(2 * nb, B, 128, dtype=torch.float32, device=dev)
     gx = torch.empty(B, num_identity, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -1294,6 +1314,8 @@ def resnet_backward(grad_params, bwd_stages, saved, num_identity):
     nb = saved.shape[0] // 2
     if out % 4 or out < 4:
         return None
+    if nb:
+        _saved_with_masks(saved, nb, B)
     grads = torch.empty(2 * nb, B, 128, dtype=torch.float32, device=dev)
     g_hidden = torch.empty(B, 128, dtype=torch.float32, device=dev)
     gx = torch.empty(B, num_identity, dtype=torch.float32, device=dev)
