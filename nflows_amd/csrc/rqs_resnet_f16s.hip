@@ -541,6 +541,12 @@ __global__ void __launch_bounds__(NW_* kWave, 2) rqs_resnet_f16s_kernel(const Ar
     if (my_status && a.status) atomicOr(a.status, my_status);
 }
 
+// the 64-row form's `redo` words start at zero (each half block ORs its bit in)
+__global__ void zero_words_kernel(int32_t* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
 }  // namespace k8s
 }  // namespace nfa
 
@@ -639,7 +645,10 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float* inputs, const v
         default: kern = k8s::rqs_resnet_f16s_kernel<true, 2, 4, 4>; break;
     }
     note_layer_kernel("k8s::rqs_resnet_f16s_kernel<inverse=%d, init_ks=%d, waves=%d, K=8, ring=%d>", inv ? 1 : 0, init_ks, nw, ring);
-    if (half) NFA_HIP_CHECK(hipMemsetAsync(redo_blocks, 0, (size_t)(batch / 128) * sizeof(int32_t), st));
+    // (a kernel, not hipMemsetAsync: captured into a HIP graph the memset NODE cost ~2 ms per replay -- GraphedLogProb at
+    //  <= 16 384 rows took 2.8 ms where the launches themselves take 0.6, tools/small_batch_probe.py)
+    if (half) hipLaunchKernelGGL(k8s::zero_words_kernel, dim3((unsigned)((batch / 128 + 255) / 256)), dim3(256), 0, st,
+                                 redo_blocks, (int)(batch / 128));
     if (lds_launch > 64 * 1024) {
         static unsigned long long raised[12] = {};   // device masks (raise_dynamic_lds)
         const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], (int)lds_cap);

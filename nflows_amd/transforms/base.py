@@ -80,6 +80,82 @@ class _Run(list):
             self.__dict__["_geometry"] = held
         return held
 
+    # ---- the weights of the whole run in one flat pass (round 4).  coupling._weights_key layer by layer cost ~10 us per
+    #      layer and call -- 0.3-0.4 ms per `log_prob` of a 32-layer flow, more than the kernel takes on 8 192 rows: the
+    #      small-batch figures of bench.py were the HOST's.  Same signs as _weights_key (epoch, identity of every held
+    #      object in its module's dict, version counters, storage pointers), read from lists made once per epoch.
+    def _flatten(self, epoch):
+        from .coupling import _held_parameters
+        nets = [c._modules["transform_net"] for c, _ in self]
+        per_layer = [_held_parameters(net) for net in nets]
+        entries = [e for held in per_layer for e in held]
+        bounds, at = [], 0
+        for held in per_layer:
+            bounds.append((at, at + len(held)))
+            at += len(held)
+        flat = (epoch, nets, entries, [p for _, _, p in entries], bounds)
+        self.__dict__["_flat"] = flat
+        return flat
+
+    def weights_fingerprint(self):
+        from .. import _cache
+        from . import coupling
+        epoch = _cache.epoch()
+        flat = self.__dict__.get("_flat")
+        if flat is None or flat[0] != epoch or not _cache.HOOKED:
+            flat = self._flatten(epoch)
+        else:
+            for (c, _), net in zip(self, flat[1]):
+                if c._modules["transform_net"] is not net:
+                    flat = self._flatten(epoch)
+                    break
+            else:
+                for d, name, p in flat[2]:
+                    if d.get(name) is not p:
+                        flat = self._flatten(epoch)
+                        break
+        params = flat[3]
+        key = (epoch, tuple([p._version for p in params]), tuple([p.data_ptr() for p in params]))
+        every = coupling.VERIFY_WEIGHTS_EVERY
+        if every and params and not (params[0].is_cuda and torch.cuda.is_current_stream_capturing()):
+            # one layer at a time, every layer once per `every` calls (no call pays for all of them)
+            n = self.__dict__["_verify_calls"] = self.__dict__.get("_verify_calls", 0) + 1
+            stride = max(1, every // len(self))
+            if n % stride == 0:
+                i = (n // stride) % len(self)
+                lo, hi = flat[4][i]
+                coupling._verify_weights_now(self[i][0], (epoch, key[1][lo:hi], key[2][lo:hi]), params[lo:hi])
+        return key
+
+    def rebase_verification(self):
+        """called when the run's packed weights are (re)built: the checksums that belong to the current fingerprint"""
+        from . import coupling
+        if not coupling.VERIFY_WEIGHTS_EVERY:
+            return
+        flat = self.__dict__.get("_flat")
+        if flat is None:
+            return
+        params = flat[3]
+        if params and params[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            return
+        versions, ptrs = tuple([p._version for p in params]), tuple([p.data_ptr() for p in params])
+        for (c, _), (lo, hi) in zip(self, flat[4]):
+            coupling._verify_weights_now(c, (flat[0], versions[lo:hi], ptrs[lo:hi]), params[lo:hi], rebase=True)
+
+
+def _permutation_key(p):
+    perm = p._buffers["_permutation"]   # (the registered buffer, without nn.Module's attribute fallback)
+    return id(perm), perm._version
+
+
+def _run_weights_fingerprint(units):
+    """What `_run_plan` keys the run's packed weights on: `_Run.weights_fingerprint()` -- one flat pass over the run --
+    or, for a plain list of units, the per-layer keys."""
+    if isinstance(units, _Run):
+        return units.weights_fingerprint()
+    from .coupling import _weights_key
+    return tuple([_weights_key(c, c.transform_net) for c, _ in units])
+
 
 def _run_geometry(units):
     return units.geometry() if isinstance(units, _Run) else units[0][0]._fused_geometry(tuple(c for c, _ in units[1:]))
@@ -191,22 +267,27 @@ class CompositeTransform(Transform):
         """Concatenated weight / bias blobs and the composed tables of a run, cached until a weight or a
         permutation changes.  (weights, biases, tables, f16 stream or None)."""
         from .. import ops
-        from .coupling import _weights_key
         first = units[0][0]
         mlp = type(first).__name__ in ("AffineCouplingTransform", "AdditiveCouplingTransform")
         geometry = _run_geometry(units)   # one padded geometry for the run
         f16 = (not mlp) and first._use_f16(geometry)
         # (the key reads version counters only; the layers' packed blobs are looked at on a miss)
         tile16 = tile16 and f16
+        ids = units.__dict__.get("_ids") if isinstance(units, _Run) else None
+        if ids is None:
+            ids = tuple([id(c) for c, _ in units])
+            if isinstance(units, _Run):
+                units.__dict__["_ids"] = ids
         key = (inverse, f16, tile16, geometry, first._log2e() if not mlp else None, first.conditioner_act_scale if f16 else None,
-               tuple([id(c) for c, _ in units]),
-               tuple([_weights_key(c, c.transform_net) for c, _ in units]),
-               tuple([None if p is None else (id(p._permutation), p._permutation._version) for _, p in units]))
+               ids, _run_weights_fingerprint(units),
+               tuple([None if p is None else _permutation_key(p) for _, p in units]))
         cache = self.__dict__.setdefault("_run_plans", {})
         plan = cache.get(key)
         if plan is None:
             if len(cache) > 4:
                 cache.clear()
+            if isinstance(units, _Run):
+                units.rebase_verification()
             packed = [c._packed_mlp() if mlp else c._packed_resnet(geometry) for c, _ in units]
             packed_f16 = [c._packed_resnet_f16(geometry, tile16) for c, _ in units] if f16 else None
             weights = torch.cat([w for w, _ in packed], dim=0).contiguous()

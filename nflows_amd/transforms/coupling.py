@@ -63,6 +63,20 @@ def _checksum(params):
         return torch.stack([torch.stack((p.double().abs().sum(), p.double().pow(2).sum())) for p in params]).reshape(-1)
 
 
+def _verify_weights_now(owner, key, params, rebase=False):
+    """The run-level form (transforms/base.py: _Run.weights_fingerprint): `rebase` records the checksum that belongs to
+    `key` (called when the run's packed weights are rebuilt), otherwise the parameters are compared with it now."""
+    state = owner.__dict__.get("_weights_checksum_run")
+    if rebase or state is None or state[0] != key:
+        owner.__dict__["_weights_checksum_run"] = (key, _checksum(params))
+        return
+    if not torch.equal(_checksum(params), state[1]):
+        owner.__dict__.pop("_weights_checksum_run", None)
+        raise StalePackedWeights(
+            "the parameters of %s changed through a write the packed-weight caches cannot see (a write through "
+            "`.data`?): call nflows_amd.invalidate_packed_weights() after such writes" % type(owner).__name__)
+
+
 def _verify_weights(owner, key, params):
     if params and params[0].is_cuda and torch.cuda.is_current_stream_capturing():
         return
@@ -522,7 +536,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         """The whole-layer kernels' code of the conditioner blocks' activation (one for all blocks), or None"""
         # (read on every call -- an activation is a plain attribute, swapping it advances no cache epoch --, so kept to
         #  dictionary lookups: ~1 us per layer)
-        blocks = self.transform_net._modules.get("blocks")
+        blocks = self._modules["transform_net"]._modules.get("blocks")
         if blocks is None:
             return None
         first = None

@@ -1521,3 +1521,53 @@ def test_output_gradient_images_are_swizzled_conflict_free():
                 byte = r * 64 + (((2 * half) ^ ((r >> 1) & 3)) << 4)
                 quads.add((byte // 16) % 8)
             assert len(quads) == 8, (base, sorted(quads))
+
+
+def test_run_level_weight_fingerprint_and_verification(monkeypatch):
+    """transforms/base.py `_Run.weights_fingerprint` (round 4): the weights of a whole run of layers in one flat pass --
+    what `_run_plan` keys the run's packed weights on instead of one coupling._weights_key per layer (0.3-0.4 ms per call
+    of a 32-layer flow on the host).  It follows in-place updates (version counters), rebound storage (`p.data = ...`),
+    swapped parameter objects and swapped conditioners like the per-layer key; and the staggered verification (one layer
+    per few calls) turns a write through `.data` into StalePackedWeights within `NFA_VERIFY_WEIGHTS` calls."""
+    import torch
+    import nflows_amd
+    from nflows_amd import configs
+    from nflows_amd.transforms import coupling as C
+    flow = configs.rq_nsf_flow(4, 16, 8, 32, seed=3).eval()
+    T = flow._transform
+    layers = list(T._transforms)
+    x = torch.zeros(128, 16)
+    monkeypatch.setattr(C, "VERIFY_WEIGHTS_EVERY", 8)
+
+    def plan():
+        with torch.no_grad():
+            units, after = T._collect_run(layers, 0, x, None, False)
+            assert after == len(layers) and len(units) == 4
+            return units, T._run_plan(units, False, False)
+
+    units, p0 = plan()
+    assert plan()[1] is p0 and plan()[0] is units                      # cached: same plan object
+    k0 = units.weights_fingerprint()
+    net2 = layers[5].transform_net
+    with torch.no_grad():
+        net2.final_layer.bias.add_(1.0)                                 # in-place update: version counter
+    k1 = units.weights_fingerprint()
+    assert k1 != k0 and plan()[1] is not p0
+    w = net2.initial_layer.weight
+    w.data = w.data.clone()                                             # rebound storage, same counter
+    assert units.weights_fingerprint() != k1
+    k2 = units.weights_fingerprint()
+    net2.initial_layer.weight = torch.nn.Parameter(w.detach().clone())  # another Parameter object (registration: epoch)
+    assert plan()[0].weights_fingerprint() != k2
+    p3 = plan()[1]
+    assert plan()[1] is p3
+    # a write through .data: invisible to the key, caught by the staggered verification within 8 calls
+    layers[3].transform_net.blocks[0].linear_layers[1].weight.data.mul_(1.5)
+    with pytest.raises(C.StalePackedWeights):
+        for _ in range(9):
+            assert plan()[1] is p3
+    nflows_amd.invalidate_packed_weights()
+    p4 = plan()[1]
+    assert p4 is not p3
+    for _ in range(20):                                                 # and nothing is raised on consistent weights
+        assert plan()[1] is p4
