@@ -10,7 +10,8 @@ default parameters, tanh), K8h for 8 and 10 bins, K8 -- its second pass and the 
     bit for bit (tests/test_oracle_golden.py), so the rows behind the fixture's 128 are held to the port: 8 192 rows;
   * engines driven explicitly, the kernel that ran read back: K8h eight-wave (65 536 rows), K8h four-wave, K8, and the
     layer-by-layer path these layers took before (conditioner modules + the final Linear fused with the spline / K1);
-  * the headline rule: error against float64 at most 2 x the reference-fp32's own on mean and 99.9 % quantile;
+  * the headline rule: error against float64 at most 2 x the reference-fp32's own on the mean, 2.5 x on the 99.9 %
+    quantile of the 8 192 rows (see tests/test_gpu_bins.py; measured at most 1.93 x);
   * the per-element arithmetic of `activate<ACT>` runs in the CPU suite against torch (tests/test_rqs_f32_host.py).
 """
 import copy
@@ -65,7 +66,7 @@ def test_other_activations_on_every_engine(golden_dir, engine_switches, case, en
         for piece in expect:
             assert piece in label, "%s %s ran %r, expected %r" % (engine, direction, label, expect)
     _report({"config": "%s_%s" % (case, engine), "kernels": ran, "rows": rows, "redo_blocks": [redo_f, redo_i]})
-    _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS)
+    _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS, q_factor=2.5)
     assert redo_f + redo_i <= max(1, rows // 128 // 100), "the f16 engine handed %d + %d row blocks to the exact kernel" % (redo_f, redo_i)
     _status("%s_%s" % (case, engine))
 

@@ -14,7 +14,8 @@ What is held to what:
   * every engine is driven explicitly and the kernel that ran is read back from the library: K8h eight-wave (65 536
     rows) and four-wave, K8 (bf16x3), GEMMs + K1 (the path these layers took before);
   * the headline rule (tests/test_gpu_headline_parity.compare): error against float64 at most 2 x the reference-fp32's
-    own on the mean and the 99.9 % quantile, no floor;
+    own on the mean, 2.5 x on the 99.9 % quantile (of 8 192 rows: their 8th largest value, an order statistic with ~ 35 %
+    sampling noise -- measured at most 1.97 x, and that on K8, whose spline arithmetic is the reference's), no floor;
   * the BASELINE widths: D = 64 (d_t = 32: at 11+ bins the layer's parameter words need a second parameter stage) and
     D = 128 (64 identity features: four k-steps in the initial layer) on four-layer flows, against the port.
 """
@@ -98,7 +99,7 @@ def test_other_bin_counts_on_every_engine(golden_dir, engine_switches, K, engine
         if engine != "gemm_k1":
             assert ("inverse=1" in label) == (direction == "inverse"), label
     _report({"config": "%s_%s" % (case, engine), "kernels": ran, "rows": rows, "redo_blocks": [redo_f, redo_i]})
-    _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS)
+    _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS, q_factor=2.5)
     # (a row block in which the f16 engine meets a non-finite value -- on splines this steep about one evaluation in a
     #  million rounds a discriminant below zero in ANY fp32 arithmetic, the reference's included -- is handed to the exact
     #  kernel: by design, reported above.  More than 1 % of the blocks would mean the figures are not the engine's own.)
@@ -137,7 +138,7 @@ def test_other_bin_counts_at_the_baseline_widths(engine_switches, K, D):
             assert ("init_ks=4" in label) == (D == 128), label
         config = "%s_%s" % (key, engine)
         for k, t, tol in (("z", z, OUT_TOL), ("lad", lad, LAD_TOL), ("lp", lp, LAD_TOL), ("xi", xi, OUT_TOL), ("ladi", ladi, LAD_TOL)):
-            compare(config, k, t[:ROWS].cpu().numpy(), o[k + "32"], o[k + "64"], tol, max_factor=8.0)
+            compare(config, k, t[:ROWS].cpu().numpy(), o[k + "32"], o[k + "64"], tol, max_factor=8.0, q_factor=2.5)
         assert redo <= max(1, rows // 128 // 100), redo
         nflows_amd.check_status()
         err = (xr.cpu() - x[:rows]).abs()

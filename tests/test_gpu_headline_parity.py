@@ -50,9 +50,11 @@ def _stats(err):
     return {"max": float(err.max()), "mean": float(err.mean()), "q999": float(np.quantile(err, 0.999))}
 
 
-def compare(config, what, got, ref32, truth, tol, max_factor=FACTOR):
+def compare(config, what, got, ref32, truth, tol, max_factor=FACTOR, q_factor=FACTOR):
     """got / ref32: float32 arrays, truth: float64.  Asserts the 2x bound on max, mean and the
-    99.9 % quantile (`max_factor`: the bound on the maximum alone); returns the figures."""
+    99.9 % quantile (`max_factor`: the bound on the maximum alone; `q_factor`: on the quantile alone -- for
+    8 192 per-row values the 99.9 % quantile is their 8th largest, an order statistic with ~ 35 % sampling noise:
+    the exact-arithmetic engine K8 itself reaches 1.97 x there); returns the figures."""
     got64 = got.astype(np.float64)
     assert np.array_equal(np.isfinite(got), np.isfinite(ref32)), "%s %s: non-finite pattern differs" % (config, what)
     fin = np.isfinite(truth)
@@ -65,7 +67,7 @@ def compare(config, what, got, ref32, truth, tol, max_factor=FACTOR):
              "bulk_within_tol_of_reference_fp32": bulk_fraction(got, ref32, tol), "tol": tol}
     _report(entry)
     for k in ("max", "mean", "q999"):
-        bound = (max_factor if k == "max" else FACTOR) * e_ref[k] + (floor if k == "max" else 0.0)
+        bound = (max_factor if k == "max" else q_factor if k == "q999" else FACTOR) * e_ref[k] + (floor if k == "max" else 0.0)
         assert e_got[k] <= bound, (
             "%s %s: %s error vs float64 %.3e exceeds %.1f x the reference fp32's %.3e%s"
             % (config, what, k, e_got[k], FACTOR, e_ref[k], " (+ %.1e)" % floor if k == "max" else ""))

@@ -10,7 +10,8 @@ logits still moderate (spread 0.06 .. 0.9), derivative logits up to N(0, 4).
 The reference's state_dict loads strictly into the drop-in classes; the eager port is bit-identical on the fixture
 (tests/test_oracle_golden.py), so the rows behind the fixture's 256 are held to the port.  Engines as in
 tests/test_gpu_steep.py (hidden width 64 is zero-padded into the kernels' 128): K8h eight- and four-wave, K8s eight-
-and four-wave, K8, GEMMs + K1 (wave-tile and register-pipelined); forward and inverse; the headline rule; and
+and four-wave, K8, GEMMs + K1 (wave-tile and register-pipelined); forward and inverse; the headline rule (2 x on the
+mean, 2.5 x on the 99.9 % quantile of 8 192 rows; measured at most 1.15 / 1.16); and
 inverse(forward(x)) on the held-out samples against the reference's own fp32 round trip.
 """
 import copy
@@ -70,7 +71,7 @@ def test_trained_flow_on_every_engine(golden_dir, engine_switches, engine):
         for piece in expect:
             assert piece in label, "%s %s ran %r, expected %r" % (engine, direction, label, expect)
     _report({"config": "%s_%s" % (case, engine), "kernels": ran, "rows": rows, "redo_blocks": [redo_f, redo_i]})
-    _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS)
+    _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS, q_factor=2.5)
     assert redo_f + redo_i <= max(1, rows // 128 // 100), (redo_f, redo_i)
     _status("%s_%s" % (case, engine))
     # inverse(forward(x)) on the held-out samples: the mean against the reference's own fp32 round trip
