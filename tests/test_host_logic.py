@@ -1571,3 +1571,36 @@ def test_run_level_weight_fingerprint_and_verification(monkeypatch):
     assert p4 is not p3
     for _ in range(20):                                                 # and nothing is raised on consistent weights
         assert plan()[1] is p4
+
+
+def test_binding_arities_match_the_header():
+    """Every `nfa_*` prototype of include/nflows_amd.h against the ctypes binding: the number of arguments (a slip here
+    passes garbage in registers -- no loader complains) and pointer vs integer width per position where the header is
+    unambiguous (`int64_t` <-> c_int64, `int32_t` / `int` <-> c_int, pointers <-> c_void_p / POINTER)."""
+    import ctypes
+    import re
+    from nflows_amd import _native
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "nflows_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    protos = dict((m.group(1), m.group(2)) for m in re.finditer(r"\b(nfa_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S))
+    lib = _native.load()
+    checked = 0
+    for name, args in protos.items():
+        fn = getattr(lib, name, None)
+        if fn is None or fn.argtypes is None:
+            continue
+        params = [a.strip() for a in args.split(",")] if args.strip() not in ("", "void") else []
+        assert len(params) == len(fn.argtypes), "%s: header %d arguments, binding %d" % (name, len(params), len(fn.argtypes))
+        for pos, (decl, ct) in enumerate(zip(params, fn.argtypes)):
+            pointer = "*" in decl
+            if pointer:
+                assert ct is ctypes.c_void_p or ct is ctypes.c_char_p or hasattr(ct, "contents") or hasattr(ct, "_type_") and \
+                    isinstance(ct._type_, type), (name, pos, decl, ct)
+                assert ctypes.sizeof(ct) == ctypes.sizeof(ctypes.c_void_p), (name, pos, decl, ct)
+            elif "int64_t" in decl:
+                assert ctypes.sizeof(ct) == 8, (name, pos, decl, ct)
+            elif re.search(r"\bint32_t\b|\bint\b", decl):
+                assert ctypes.sizeof(ct) == 4, (name, pos, decl, ct)
+        checked += 1
+    assert checked >= 40, checked
