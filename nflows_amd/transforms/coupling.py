@@ -439,7 +439,45 @@ class AdditiveCouplingTransform(AffineCouplingTransform):
                                    out_scatter=out_scatter, accumulate_into=accumulate_into)
 
 
-class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
+class PiecewiseCouplingTransform(CouplingTransform):
+    """The base of the piecewise (spline) couplings; coupling.py:272-296.  The reference's protocol, for code that
+    subclasses it or asks `isinstance(t, PiecewiseCouplingTransform)`: `_coupling_transform_forward / _inverse(inputs,
+    transform_params)` reshape the conditioner's output to [batch, features, params] (2-D) or [batch, channels, height,
+    width, params] (4-D) (:279-289), call `_piecewise_cdf` and row-sum the log-derivatives (:291-293).  The four spline
+    couplings below are its subclasses -- their `_piecewise_cdf` is the HIP functional of their spline --, and a user
+    subclass that defines only `_piecewise_cdf` and `_transform_dim_multiplier` runs the reference's sequence with its own
+    function (tensor operations on the device)."""
+
+    supports_fused_permutation = False   # (a subclass with a fused layer kernel says so: the rational-quadratic one)
+    supports_image_inputs = True
+
+    def _coupling_transform_forward(self, inputs, transform_params):
+        return self._coupling_transform(inputs, transform_params, inverse=False)
+
+    def _coupling_transform_inverse(self, inputs, transform_params):
+        return self._coupling_transform(inputs, transform_params, inverse=True)
+
+    def _coupling_transform(self, inputs, transform_params, inverse=False):
+        if inputs.dim() == 4:
+            b, c, h, w = inputs.shape
+            transform_params = transform_params.reshape(b, c, -1, h, w).permute(0, 1, 3, 4, 2)
+        elif inputs.dim() == 2:
+            b, d = inputs.shape
+            transform_params = transform_params.reshape(b, d, -1)
+        outputs, logabsdet = self._piecewise_cdf(inputs, transform_params, inverse)
+        return outputs, torchutils.sum_except_batch(logabsdet)
+
+    def _piecewise_cdf(self, inputs, transform_params, inverse=False):
+        # (the spline couplings of this module define `_elementwise`, their functional's kernel: that IS their cdf)
+        if type(self)._elementwise is not PiecewiseCouplingTransform._elementwise:
+            return self._elementwise(inputs, transform_params, inverse)
+        raise NotImplementedError()
+
+    def _elementwise(self, inputs, transform_params, inverse):
+        return self._piecewise_cdf(inputs, transform_params, inverse)
+
+
+class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
     """Neural-spline-flow coupling layer; coupling.py:502-582.
 
     Conditioner output per transformed feature: K width logits, K height logits and K-1
@@ -448,6 +486,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
     `hidden_channels` (coupling.py:554-559) -- done on the fly inside the kernel, the conditioner
     output tensor itself is left untouched."""
 
+    supports_fused_permutation = True    # K1 / the whole-layer kernels
     supports_image_inputs = True
 
     def __init__(self, mask, transform_net_create_fn, num_bins=10, tails=None, tail_bound=1.0,
@@ -770,7 +809,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
                                 accumulate_into=accumulate_into)
 
 
-class PiecewiseLinearCouplingTransform(CouplingTransform):
+class PiecewiseLinearCouplingTransform(PiecewiseCouplingTransform):
     """Piecewise-linear coupling layer (Mueller et al. 2018); coupling.py:297-350.  The conditioner
     emits K pdf logits per transformed element."""
 
@@ -802,7 +841,7 @@ class PiecewiseLinearCouplingTransform(CouplingTransform):
                                                    tail_bound=self.tail_bound)
 
 
-class PiecewiseQuadraticCouplingTransform(CouplingTransform):
+class PiecewiseQuadraticCouplingTransform(PiecewiseCouplingTransform):
     """Piecewise-quadratic coupling layer (Mueller et al. 2018); coupling.py:353-429.  K width
     logits and K+1 (tails=None) / K-1 (linear tails) height logits per transformed element, both
     divided by sqrt(hidden_features) when the conditioner exposes it (coupling.py:408-410)."""
@@ -847,7 +886,7 @@ class PiecewiseQuadraticCouplingTransform(CouplingTransform):
         return ops.quadratic_spline(inputs, transform_params[..., :K], transform_params[..., K:], spec, inverse)
 
 
-class PiecewiseCubicCouplingTransform(CouplingTransform):
+class PiecewiseCubicCouplingTransform(PiecewiseCouplingTransform):
     """Piecewise-cubic coupling layer (Durkan et al. 2019, "Cubic-spline flows"); coupling.py:429-499.
     Per transformed element K width logits, K height logits (both divided by sqrt(hidden_features)
     when the conditioner exposes it) and the two boundary-derivative logits."""

@@ -532,3 +532,34 @@ def test_masked_piecewise_autoregressive_round_trip(name, eps):
     transform = getattr(autoregressive, name)(num_bins=10, features=features, hidden_features=30, num_blocks=5,
                                               use_residual_blocks=True).to(DEV)
     round_trip_is_identity(transform, inputs, eps)
+
+
+def test_user_subclass_of_the_piecewise_coupling_base():
+    """coupling.py:272-296: a `PiecewiseCouplingTransform` subclass that defines only `_piecewise_cdf` and
+    `_transform_dim_multiplier` (the reference's extension point) runs the reference's sequence on the device -- split,
+    conditioner, reshape per feature, the user's function, row-sum, merge --, forward and inverse, 2-D inputs."""
+    from nflows_amd.nn.nets import ResidualNet
+    from nflows_amd.transforms import coupling as C
+    from nflows_amd.utils import create_alternating_binary_mask
+
+    class Shifted(C.PiecewiseCouplingTransform):
+        def _transform_dim_multiplier(self):
+            return 2
+
+        def _piecewise_cdf(self, inputs, transform_params, inverse=False):
+            a, b = transform_params[..., 0], transform_params[..., 1]
+            if inverse:
+                return (inputs - b) * torch.exp(-a), -a
+            return inputs * torch.exp(a) + b, a
+
+    torch.manual_seed(3)
+    t = Shifted(create_alternating_binary_mask(10, even=True), lambda i, o: ResidualNet(i, o, 16, num_blocks=1)).to(DEV)
+    x = torch.randn(64, 10, device=DEV)
+    with torch.no_grad():
+        y, lad = t(x)
+        p = t.transform_net(x[:, t.identity_features]).reshape(64, 5, 2)
+        assert torch.equal(y[:, t.identity_features], x[:, t.identity_features])
+        assert torch.allclose(y[:, t.transform_features], x[:, t.transform_features] * torch.exp(p[..., 0]) + p[..., 1], atol=1e-6)
+        assert torch.allclose(lad, p[..., 0].sum(1), atol=1e-6)
+        xr, ladi = t.inverse(y)
+        assert torch.allclose(xr, x, atol=1e-5) and torch.allclose(ladi, -lad, atol=1e-6)

@@ -1604,3 +1604,43 @@ def test_binding_arities_match_the_header():
                 assert ctypes.sizeof(ct) == 4, (name, pos, decl, ct)
         checked += 1
     assert checked >= 40, checked
+
+
+def test_piecewise_coupling_base_class_protocol():
+    """coupling.py:272-296 `PiecewiseCouplingTransform`: the four spline couplings are its subclasses, and the reference's
+    protocol (`_coupling_transform_forward / _inverse` reshape the conditioner output per feature, call `_piecewise_cdf`,
+    row-sum) works for a user subclass that only defines `_piecewise_cdf` and `_transform_dim_multiplier`."""
+    import torch
+    from nflows_amd.transforms import coupling as C
+    from nflows_amd.nn.nets import ResidualNet
+    from nflows_amd.utils import create_alternating_binary_mask
+    for cls in (C.PiecewiseRationalQuadraticCouplingTransform, C.PiecewiseLinearCouplingTransform,
+                C.PiecewiseQuadraticCouplingTransform, C.PiecewiseCubicCouplingTransform):
+        assert issubclass(cls, C.PiecewiseCouplingTransform) and issubclass(cls, C.CouplingTransform)
+    assert C.PiecewiseRationalQuadraticCouplingTransform.supports_fused_permutation
+    assert not C.PiecewiseLinearCouplingTransform.supports_fused_permutation
+
+    class Shifted(C.PiecewiseCouplingTransform):   # y = x * exp(a) + b with per-element (a, b): a two-parameter "cdf"
+        def _transform_dim_multiplier(self):
+            return 2
+
+        def _piecewise_cdf(self, inputs, transform_params, inverse=False):
+            a, b = transform_params[..., 0], transform_params[..., 1]
+            if inverse:
+                return (inputs - b) * torch.exp(-a), -a
+            return inputs * torch.exp(a) + b, a
+
+    t = Shifted(create_alternating_binary_mask(6, even=True), lambda i, o: ResidualNet(i, o, 8, num_blocks=1))
+    assert isinstance(t, C.PiecewiseCouplingTransform) and not t.supports_fused_permutation
+    x = torch.randn(5, 3)
+    params = torch.randn(5, 6)
+    y, lad = t._coupling_transform_forward(x, params)
+    p = params.reshape(5, 3, 2)
+    assert torch.allclose(y, x * torch.exp(p[..., 0]) + p[..., 1]) and torch.allclose(lad, p[..., 0].sum(1))
+    xr, ladi = t._coupling_transform_inverse(y, params)
+    assert torch.allclose(xr, x, atol=1e-6) and torch.allclose(ladi, -lad)
+    img = torch.randn(2, 3, 4, 4)
+    yi, ladimg = t._coupling_transform_forward(img, torch.randn(2, 6, 4, 4))
+    assert yi.shape == img.shape and ladimg.shape == (2,)
+    with pytest.raises(NotImplementedError):
+        C.PiecewiseCouplingTransform(create_alternating_binary_mask(4, even=True), lambda i, o: ResidualNet(i, o, 8, num_blocks=1))
