@@ -107,7 +107,9 @@ def test_other_bin_counts_on_every_engine(golden_dir, engine_switches, K, engine
     _status("%s_%s" % (case, engine))
 
 
-@pytest.mark.parametrize("K,D", [(4, 64), (12, 64), (16, 64), (5, 128), (9, 128), (11, 24), (24, 64), (32, 32)])
+# ((12, 64) and (9, 128) ran green in the round's full suites and were dropped to keep the suite under ten minutes: their
+#  tile counts and widths are covered by (16, 64) / (24, 64) and (5, 128))
+@pytest.mark.parametrize("K,D", [(4, 64), (16, 64), (5, 128), (11, 24), (24, 64), (32, 32)])
 def test_other_bin_counts_at_the_baseline_widths(engine_switches, K, D):
     """Four-layer flows (the `deep` recipe of the steep fixtures: logits ~ N(0, 0.6 .. 1), invertible in fp32) at the
     BASELINE width and at D = 128, whole batch through ONE launch per direction (the run of layers + the base density),
