@@ -141,6 +141,28 @@ def sustained_mfma_ceiling(seconds=1.5):
     return res or None
 
 
+# the sources that define each profiled kernel: a counter file under profiles/ is only quoted while they are unchanged
+KERNEL_SOURCES = {
+    "k8h_pmc_traffic.json": ("rqs_resnet_f16_kernel.hpp", "rqs_resnet_f16.hip", "k8h_common.hpp", "rqs_fused8.hpp", "rqs_math.hpp",
+                             "fused_common.hpp", "common.hpp"),
+    "k8_pmc_traffic.json": ("rqs_resnet_kernel.hpp", "rqs_resnet.hip", "bf16x3_gemm.hpp", "rqs_math.hpp", "fused_common.hpp",
+                            "common.hpp"),
+    "k7b_pmc_traffic.json": ("rqs_fused_linear.hip", "rqs_math.hpp", "fused_common.hpp", "common.hpp"),
+    "k7_pmc_traffic.json": ("rqs_fused_linear.hip", "rqs_math.hpp", "fused_common.hpp", "common.hpp"),
+    "k1_pmc_traffic.json": ("rqs.hip", "rqs_math.hpp", "common.hpp"),
+}
+
+
+def kernel_source_digest(traffic_file):
+    """sha256 over the kernel's source files (tools/pmc_traffic.py stores it next to the counters it collects)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES[traffic_file]:
+        with open(os.path.join(ROOT, "nflows_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def log(msg):
     print("[bench %.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
@@ -240,7 +262,8 @@ def cpu_baseline(flow_cpu, features, sample_rows, x_consistency=None, budget_s=2
             xr, _ = eager.flow_transform(flow_cpu, z, inverse=True)
             err = (xr - xs).abs()
             consistency = {"max": err.max().item(), "mean": err.mean().item(),
-                           "q999": torch.quantile(err.flatten()[:2 ** 24].double(), 0.999).item(), "rows": xs.shape[0]}
+                           "q999": torch.quantile(err.flatten()[:2 ** 24].double(), 0.999).item(),
+                           "count_above_1e-3": int((err > 1e-3).sum().item()), "rows": xs.shape[0]}
     out = {"value": rows / dt, "unit": "samples/s", "cores": threads, "kind": kind,
            "sample": "same 32-layer flow and weights, %d rows x %d timed passes of %s, %.2f s/pass"
                      % (rows, reps, "the reference classes imported from /root/reference" if ref is not None
@@ -457,6 +480,44 @@ def main():
                           "unit": "samples/s"})
             del xs_
 
+    # extra (N = 1): the same step on the engines whose GEMM arithmetic nobody can dispute -- K8 (three bf16 pieces per
+    # operand: 24-bit significands, full fp32 range) and the layer-by-layer path (PyTorch / hipBLASLt fp32 conditioner +
+    # K1) -- so that the driver's record holds them beside the headline (two f16 pieces: 22-bit significands)
+    exact_engines = None
+    if world == 1 and args.batch_per_gpu is None and not args.skip_extra and args.path == "k8":
+        exact_engines = []
+        saved_engine = RQ.conditioner_engine
+        for label, engine, path in (("K8: whole-layer kernel on three bf16 pieces per operand (6 products, 24-bit significands)", "bf16x3", "k8"),
+                                    ("layer by layer: PyTorch (hipBLASLt) fp32 conditioner GEMMs + K1 spline kernel", saved_engine, "k1")):
+            try:
+                RQ.conditioner_engine = engine
+                select_path(path)
+                flow_e = copy.deepcopy(flow_cpu).to(dev)
+                flow_e._transform.fuse_permutations = not args.no_fuse
+
+                def step_e():
+                    with torch.no_grad():
+                        return parallel.reduce_log_likelihood(flow_e.log_prob(x))
+                for _ in range(2):
+                    acc_e = step_e()
+                torch.cuda.synchronize()
+                te = time.perf_counter()
+                n_e = max(3, args.steps // 4)
+                for _ in range(n_e):
+                    acc_e = step_e()
+                torch.cuda.synchronize()
+                dte = (time.perf_counter() - te) / n_e
+                exact_engines.append({"engine": label, "kernel": ops.last_layer_kernel(), "rows": B, "steps": n_e,
+                                      "ms_per_step": dte * 1e3, "value": B / dte, "unit": "samples/s",
+                                      "mean_log_likelihood": (acc_e[0] / acc_e[1]).item()})
+                del flow_e
+            except Exception as e:  # measurement extra only
+                log("exact-engine extra (%s) skipped: %r" % (path, e))
+            finally:
+                RQ.conditioner_engine = saved_engine
+                select_path(args.path)
+        torch.cuda.empty_cache()
+
     # the same step replayed from a HIP graph (host out of the loop): reported beside the headline
     # number, which keeps per-dispatch events and therefore launches from the host
     graph_ms = None
@@ -492,6 +553,35 @@ def main():
             y1, _ = layer(xs)
             x1, _ = layer.inverse(y1)
             err_layer = (x1 - xs).abs().max().item()
+    # the second half of the metric asks for < 1e-5: neither the reference nor anything else meets that in fp32 on 32
+    # layers.  The same rows through the float64 device path (`flow.double()`: K5d spline kernel, library
+    # fp64 GEMMs) -- the configuration in which the target IS met, by the reference and here
+    fp64_extra = None
+    if world == 1 and not args.skip_consistency and not args.skip_extra:
+        try:
+            flow64 = copy.deepcopy(flow_cpu).double().to(dev)
+            x64 = xs.double()
+            with torch.no_grad():
+                z64, _ = flow64._transform(x64)
+                xr64, _ = flow64._transform.inverse(z64)
+                e64 = (xr64 - x64).abs()
+                lp64 = flow64.log_prob(x64)
+                torch.cuda.synchronize()
+                t64 = time.perf_counter()
+                for _ in range(3):
+                    flow64.log_prob(x64)
+                torch.cuda.synchronize()
+                dt64 = (time.perf_counter() - t64) / 3
+                lp32 = flow.log_prob(xs)
+            fp64_extra = {"rows": int(x64.shape[0]), "dtype": "f64", "max": e64.max().item(), "mean": e64.mean().item(),
+                          "count_above_1e-5": int((e64 > 1e-5).sum().item()), "meets_1e-5": bool(e64.max().item() < 1e-5),
+                          "log_prob_ms": dt64 * 1e3, "log_prob_samples_per_s": x64.shape[0] / dt64,
+                          "max_abs_log_prob_f32_minus_f64": (lp32.double() - lp64).abs().max().item(),
+                          "note": "flow.double() on the device: float64 spline kernel (nfa_rqs_elementwise_f64) + library fp64 GEMMs, "
+                                  "layer by layer; not a fast path"}
+            del flow64
+        except Exception as e:  # measurement extra only
+            log("fp64 extra skipped: %r" % (e,))
 
     if rank == 0:
         total_rows = (CONFIG4_GLOBAL if (world > 1 and args.batch_per_gpu is None) else B * world)
@@ -503,10 +593,19 @@ def main():
         io_bytes = 4 * (B * D + B * D + B)                 # inputs + outputs + logabsdet
 
         def load_traffic(name):
+            """(bytes per launch, provenance): the counters of profiles/<name> -- refused (None) when the kernel's
+            sources have changed since tools/pmc_traffic.py collected them (the file records their digest)."""
             try:
-                return json.load(open(os.path.join(ROOT, "profiles", name))).get("hbm_bytes_per_launch")
+                rec = json.load(open(os.path.join(ROOT, "profiles", name)))
             except Exception:
-                return None
+                return None, "profiles/%s: absent" % name
+            want = rec.get("kernel_source_sha256")
+            have = kernel_source_digest(name) if name in KERNEL_SOURCES else None
+            if want is None or want != have:
+                return None, ("profiles/%s was collected on other kernel sources (digest %s, now %s): not quoted; "
+                              "re-run tools/collect_profiles.sh" % (name, str(want)[:12], str(have)[:12]))
+            return rec.get("hbm_bytes_per_launch"), ("profiles/%s (rocprofv3 --pmc passes of this command on these kernel "
+                                                     "sources, digest %s; not re-measured in this run)" % (name, have[:12]))
 
         timing_note = ("HIP start/stop events attached to each layer-kernel dispatch on its launch "
                        "stream (hipExtLaunchKernelGGL), all launches of the timed region")
@@ -542,8 +641,8 @@ def main():
                     else "nfa::rqs_fused_linear_bf16_kernel<false>"
                 r = {"bound": "mfma", "kernel": ("nfa::" + ran) if ran else kernel,
                      "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
-                     "traffic": load_traffic(traffic_file),
-                     "traffic_from": "profiles/" + traffic_file + " (rocprofv3 --pmc passes of this command, not re-measured in this run)",
+                     "traffic": load_traffic(traffic_file)[0],
+                     "traffic_from": load_traffic(traffic_file)[1],
                      "algorithmic_flops_per_launch": flops,
                      "algorithmic_bytes_per_launch": bytes_,
                      "fp32_flops_per_launch": fp32_flops,
@@ -563,13 +662,14 @@ def main():
                 ach = flops / (avg_ms * 1e-3) / 1e12
                 r = {"bound": "mfma", "kernel": ("nfa::" + ran) if ran else "nfa::rqs_fused_linear_kernel<false>", "achieved": ach,
                      "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
-                     "traffic": load_traffic("k7_pmc_traffic.json"), "algorithmic_flops_per_launch": flops,
+                     "traffic": load_traffic("k7_pmc_traffic.json")[0], "algorithmic_flops_per_launch": flops,
                      "algorithmic_bytes_per_launch": io_bytes + 4 * B * H_}
             else:
                 ach = k1_bytes / (avg_ms * 1e-3) / 1e9
                 r = {"bound": "hbm", "kernel": ("nfa::" + ran) if ran else "nfa::rqs_coupling_pipelined<8, false, true>", "achieved": ach,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                     "traffic": load_traffic("k1_pmc_traffic.json"), "algorithmic_bytes_per_launch": k1_bytes}
+                     "traffic": load_traffic("k1_pmc_traffic.json")[0], "traffic_from": load_traffic("k1_pmc_traffic.json")[1],
+                     "algorithmic_bytes_per_launch": k1_bytes}
             r.update(common)
             return r
 
@@ -615,7 +715,12 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.batch_per_gpu is None else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            # fp32 inputs, outputs, spline arithmetic and accumulation; what the TIMED kernel multiplies in its GEMMs is said here
+            "dtype": ("f32 (conditioner GEMMs: each fp32 operand as 2 f16 pieces, 3 cross products on the f16 MFMA pipe, fp32 "
+                      "accumulate -- 22-bit operand significands; exact_engine_extra: the same step on 24-bit pieces and on fp32 GEMMs)"
+                      if (args.path == "k8" and RQ.conditioner_engine == "f16x2") else
+                      "f32 (conditioner GEMMs: each fp32 operand as 3 bf16 pieces, 6 cross products, fp32 accumulate)"
+                      if args.path in ("k8", "k7b") else "f32"),
             "data": "synthetic standard-Gaussian inputs, random-init weights (seed 0)",
             "config": {"workload": "%d-layer RQ-NSF coupling flow (RandomPermutation + RQ coupling, "
                                    "ResidualNet H=128 x2 blocks), dim=64, K=8, tail_bound=3, "
@@ -648,6 +753,10 @@ def main():
             result["steady_state"] = dict(steady, value=total_rows * steady["steps"] / steady["seconds"], unit="samples/s",
                                           note=">= %.1f s of back-to-back steps, same launch path as the timed region"
                                                % args.steady_seconds)
+        if exact_engines:
+            result["exact_engine_extra"] = exact_engines
+        if fp64_extra is not None:
+            result["fwd_inv_max_err"]["fp64_device_path"] = fp64_extra
         if weak is not None:
             result["rows_65536_per_gpu_extra"] = weak
         if small is not None:

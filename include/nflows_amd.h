@@ -32,8 +32,9 @@
 extern "C" {
 #endif
 
-#define NFA_ABI_VERSION 9  /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 7; round 4: 8,
-                              9: whole-layer kernels for 2 .. 16 bins, nfa_resnet_backward_f32, W_f^T in K14's backward stream) */
+#define NFA_ABI_VERSION 10 /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 7; round 4: 8,
+                              9: whole-layer kernels for 2 .. 16 bins, nfa_resnet_backward_f32, W_f^T in K14's backward stream;
+                              round 5: 10: `bin_idx` outputs of the spline kernels, nfa_searchsorted_f32) */
 
 /* return codes */
 #define NFA_OK 0
@@ -140,11 +141,17 @@ int nfa_last_hip_error(void);          /* hipError_t of the last NFA_ERR_HIP on 
  *                 placed after the layer, permutations.py:22-24, :44-45, fused into the scatter)
  *   outputs       [batch, features]; columns not in transform_idx are copied bit-exactly
  *   logabsdet     [batch]
+ *   bin_idx       [batch, num_transform] int32 or NULL: the bin the kernel's search chose for every spline --
+ *                 the value of `bin_idx` at rational_quadratic.py:115-118, i.e. what torchutils.searchsorted
+ *                 (utils/torchutils.py:134-136) returns on the kernel's own knots: 0 .. K-1 (K when the input
+ *                 reaches the nudged last knot: the reference's gather then fails, here OUTSIDE_DOMAIN), and -1
+ *                 for elements the reference never searches (linear tails, outside the domain, NaN).  The same
+ *                 kernels, the same arithmetic; one more store.  Column j belongs to transform_idx[j].
  *   flags         NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET
  */
 int nfa_rqs_coupling_f32(const float *inputs, const float *params, const int64_t *transform_idx,
                          const int64_t *in_perm, const int64_t *out_scatter, float *outputs,
-                         float *logabsdet, int32_t *status,
+                         float *logabsdet, int32_t *bin_idx, int32_t *status,
                          int64_t batch, int32_t features, int32_t num_transform,
                          const nfa_rqs_spec *spec, int32_t flags, void *stream);
 
@@ -358,6 +365,30 @@ int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float *inputs, const void *stream
                                          const nfa_rqs_spec *spec, int32_t flags, void *stream);
 
 /*
+ * Diagnostic twins of the two launches above (round 5): the SAME kernels compiled with one more store, for the bench's
+ * kernel family only (8 bins, ReLU blocks, no context, d_i <= 32; otherwise NFA_ERR_UNSUPPORTED).
+ *   bin_idx [batch, num_transform] int32: the bin every spline evaluation of the run's LAST layer chose -- the value
+ *   of `bin_idx` at rational_quadratic.py:115-118 (torchutils.searchsorted, utils/torchutils.py:134-136) on the knots
+ *   THIS kernel built (fp32 running sums of its own logits, csrc/rqs_fused8.hpp); -1 for inputs outside the box.
+ *   Column j belongs to the j-th transformed feature of the layer's tables (surplus padded features: -1).
+ * K8h / K8s keep no bin index on the data path; these entry points exist so that a test can compare the chosen bin with
+ * the reference's and hold the elements where they differ to the output tolerances (tests/test_gpu_bin_index.py).  Rows
+ * of blocks flagged in `redo_blocks` carry the first pass's (discarded) choice.
+ */
+int nfa_rqs_flow_resnet_f16x2_bins_f32(const float *inputs, const void *stream_packed, int32_t param_stages,
+                                       const int32_t *final_positions, int32_t num_layers, float *outputs,
+                                       float *logabsdet, int32_t *redo_blocks, int32_t *status, int64_t batch,
+                                       int32_t features, int32_t num_transform, int32_t num_identity,
+                                       int32_t hidden_features, int32_t num_blocks,
+                                       const nfa_rqs_spec *spec, int32_t flags, void *stream, int32_t *bin_idx);
+int nfa_rqs_flow_resnet_f16x2_tile16_bins_f32(const float *inputs, const void *stream_packed, int32_t param_stages,
+                                              const int32_t *final_positions, int32_t num_layers, float *outputs,
+                                              float *logabsdet, int32_t *redo_blocks, int32_t *status, int64_t batch,
+                                              int32_t features, int32_t num_transform, int32_t num_identity,
+                                              int32_t hidden_features, int32_t num_blocks,
+                                              const nfa_rqs_spec *spec, int32_t flags, void *stream, int32_t *bin_idx);
+
+/*
  * nfa_rqs_flow_resnet_f32 for conditioners that take a context (nn/nets/resnet.py:9-52, :92-100):
  *   context        [batch, context_features] fp32, the rows handed to every conditioner of the run
  *                  (Flow._log_prob's embedded context, flows/base.py:42-49).
@@ -520,12 +551,13 @@ int nfa_rqs_made_output_f32(const float *inputs, int64_t row_stride, int32_t fir
  *   uh + i*stride_h (K), ud + i*stride_d (num_derivatives floats); strides in elements.
  *   num_derivatives = K-1 (linear tails) or K+1; larger values are accepted like the reference
  *   accepts them (it pads and gathers by bin index, extra logits are never read).
+ *   bin_idx [n] int32 or NULL: the searched bin of every element (see nfa_rqs_coupling_f32).
  */
 int nfa_rqs_elementwise_f32(const float *inputs, const float *unnormalized_widths, int64_t stride_w,
                             const float *unnormalized_heights, int64_t stride_h,
                             const float *unnormalized_derivatives, int64_t stride_d,
-                            int32_t num_derivatives, float *outputs, float *logabsdet, int32_t *status, int64_t n, const nfa_rqs_spec *spec,
-                            int32_t inverse, void *stream);
+                            int32_t num_derivatives, float *outputs, float *logabsdet, int32_t *bin_idx,
+                            int32_t *status, int64_t n, const nfa_rqs_spec *spec, int32_t inverse, void *stream);
 
 /*
  * K5 in float64: the same functional on double tensors (the reference is dtype-generic,
@@ -536,8 +568,23 @@ int nfa_rqs_elementwise_f32(const float *inputs, const float *unnormalized_width
 int nfa_rqs_elementwise_f64(const double *inputs, const double *unnormalized_widths, int64_t stride_w,
                             const double *unnormalized_heights, int64_t stride_h,
                             const double *unnormalized_derivatives, int64_t stride_d,
-                            int32_t num_derivatives, double *outputs, double *logabsdet, int32_t *status,
-                            int64_t n, const nfa_rqs_spec *spec, int32_t inverse, void *stream);
+                            int32_t num_derivatives, double *outputs, double *logabsdet, int32_t *bin_idx,
+                            int32_t *status, int64_t n, const nfa_rqs_spec *spec, int32_t inverse, void *stream);
+
+/*
+ * torchutils.searchsorted (utils/torchutils.py:134-136) on its own, as the reference's callers outside the
+ * fused kernels use it (splines/linear.py, quadratic.py, cubic.py, rational_quadratic.py:115-118):
+ *   bin_idx[i] = #{ j : inputs[i] >= knot(i, j) } - 1,   knot(i, num_knots - 1) = bin_locations[..] + eps
+ * A COUNT over all knots, not a binary search (equal to one iff the knots are monotone; NaN inputs count 0
+ * knots: -1), with `eps` added in the knots' own precision exactly like the reference's in-place `+=`
+ * (which the reference leaves behind in the caller's tensor; bin_locations is NOT modified here).
+ *   bin_locations  row i at bin_locations + i * row_stride (num_knots floats); row_stride 0 = one row of
+ *                  knots shared by all inputs (the reference's broadcast `bin_locations[None, :]`,
+ *                  tests/utils/torchutils_test.py:80-90)
+ *   inputs [n], bin_idx [n] int64 (the reference's dtype)
+ */
+int nfa_searchsorted_f32(const float *bin_locations, int64_t row_stride, int32_t num_knots, const float *inputs,
+                         int64_t *bin_idx, int64_t n, double eps, void *stream);
 
 /*
  * K5d-backward.  Gradient of nfa_rqs_elementwise_f64 (same inputs, spec and direction) -- what the reference

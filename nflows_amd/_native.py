@@ -33,7 +33,7 @@ ACTIVATION_RELU, ACTIVATION_LEAKY_RELU, ACTIVATION_ELU, ACTIVATION_TANH = 0, 1, 
 TAILS_NONE, TAILS_LINEAR = 0, 1
 SCALE_DEFAULT, SCALE_GENERAL, SCALE_ADDITIVE, SCALE_GIVEN, SCALE_SOFTPLUS = 0, 1, 2, 3, 4
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 EXPORTS = (
     "nfa_abi_version",
@@ -58,6 +58,8 @@ EXPORTS = (
     "nfa_resnet_backward_f32",
     "nfa_rqs_flow_resnet_f16x2_f32",
     "nfa_rqs_flow_resnet_f16x2_tile16_f32",
+    "nfa_rqs_flow_resnet_f16x2_bins_f32",
+    "nfa_rqs_flow_resnet_f16x2_tile16_bins_f32",
     "nfa_rqs_flow_resnet_context_f16x2_f32",
     "nfa_rqs_flow_resnet_context_redo_f32",
     "nfa_linear_spline_f32",
@@ -67,6 +69,7 @@ EXPORTS = (
     "nfa_quadratic_spline_backward_f32",
     "nfa_cubic_spline_backward_f32",
     "nfa_rqs_elementwise_f32",
+    "nfa_searchsorted_f32",
     "nfa_rqs_shared_f32",
     "nfa_affine_coupling_f32",
     "nfa_affine_autoregressive_f32",
@@ -127,7 +130,7 @@ def _declare(lib):
     lib.nfa_strerror.argtypes = [ctypes.c_int]
     lib.nfa_last_hip_error.restype = ctypes.c_int
     lib.nfa_rqs_coupling_f32.restype = ctypes.c_int
-    lib.nfa_rqs_coupling_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, sp, i32, vp]
+    lib.nfa_rqs_coupling_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, sp, i32, vp]
     lib.nfa_rqs_coupling_backward_f32.restype = ctypes.c_int
     lib.nfa_rqs_coupling_backward_f32.argtypes = [vp] * 10 + [i64, i32, i32, sp, i32, vp]
     lib.nfa_rqs_coupling_fused_linear_f32.restype = ctypes.c_int
@@ -152,7 +155,7 @@ def _declare(lib):
     lib.nfa_rqs_flow_resnet_context_f32.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i64, i32, i32, i32, i32,
                                                     i32, sp, i32, vp]
     lib.nfa_rqs_elementwise_f64.restype = ctypes.c_int
-    lib.nfa_rqs_elementwise_f64.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, i64, sp, i32, vp]
+    lib.nfa_rqs_elementwise_f64.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, vp, i64, sp, i32, vp]
     lib.nfa_pack_resnet_hidden_train_f32.restype = ctypes.c_int
     lib.nfa_pack_resnet_hidden_train_f32.argtypes = [vp, vp, ctypes.POINTER(vp), vp, vp, i32, i32, i32, i32, vp, vp, vp,
                                                      vp, vp]
@@ -176,6 +179,9 @@ def _declare(lib):
     lib.nfa_rqs_flow_resnet_f16x2_f32.argtypes = [vp, vp, i32, vp, i32] + [vp] * 4 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
     lib.nfa_rqs_flow_resnet_f16x2_tile16_f32.restype = ctypes.c_int
     lib.nfa_rqs_flow_resnet_f16x2_tile16_f32.argtypes = lib.nfa_rqs_flow_resnet_f16x2_f32.argtypes
+    for fn in (lib.nfa_rqs_flow_resnet_f16x2_bins_f32, lib.nfa_rqs_flow_resnet_f16x2_tile16_bins_f32):
+        fn.restype = ctypes.c_int
+        fn.argtypes = lib.nfa_rqs_flow_resnet_f16x2_f32.argtypes + [vp]
     lib.nfa_rqs_flow_resnet_context_f16x2_f32.restype = ctypes.c_int
     lib.nfa_rqs_flow_resnet_context_f16x2_f32.argtypes = [vp, vp, i32, vp, i32, vp, i32] + [vp] * 4 + \
         [i64, i32, i32, i32, i32, i32, sp, i32, vp]
@@ -185,7 +191,9 @@ def _declare(lib):
     lib.nfa_rqs_coupling_resnet_f32.restype = ctypes.c_int
     lib.nfa_rqs_coupling_resnet_f32.argtypes = [vp] * 7 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
     lib.nfa_rqs_elementwise_f32.restype = ctypes.c_int
-    lib.nfa_rqs_elementwise_f32.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, i64, sp, i32, vp]
+    lib.nfa_rqs_elementwise_f32.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, vp, i64, sp, i32, vp]
+    lib.nfa_searchsorted_f32.restype = ctypes.c_int
+    lib.nfa_searchsorted_f32.argtypes = [vp, i64, i32, vp, vp, i64, ctypes.c_double, vp]
     lib.nfa_rqs_shared_f32.restype = ctypes.c_int
     lib.nfa_rqs_shared_f32.argtypes = [vp] * 7 + [i64, i32, sp, i32, vp]
     lib.nfa_affine_coupling_f32.restype = ctypes.c_int

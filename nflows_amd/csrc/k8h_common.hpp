@@ -71,6 +71,7 @@ struct Args {
     int Ds;                // columns the density sums over (features minus NFA_FLAG_PAD_COLUMNS)
     const float* ctx;           // CTX: [batch, ce] context rows (nn/nets/resnet.py:9-52, :92-100)
     int ce;
+    int32_t* dbg_bins;          // the DBG instances only: [batch, dt] bin chosen by the LAST layer's evaluations
 };
 
 // (debug stamps: the switch and the index are wave-uniform -- scalar registers -- and the pointer is rebuilt from the

@@ -478,3 +478,99 @@ extern "C" int nfa_standard_normal_log_prob_f32(const float* z, const float* log
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// torchutils.searchsorted (utils/torchutils.py:134-136): count of knots <= input, minus one, with eps
+// added to the last knot.  HBM-bound: 4 (num_knots + 1) bytes read and 8 written per element.  Dense rows
+// (row_stride == num_knots) come in as the contiguous image of a 256-row tile through LDS (coalesced
+// 16-byte loads; a lane then reads its own row: stride num_knots words, conflict-free for odd counts --
+// K + 1 knots of an even K); a shared row (row_stride == 0) is staged once per workgroup; other strides
+// read their rows from global memory directly.  The ballot / shuffle form of a monotone search has no
+// place here: the reference's count is defined for ANY knot row (monotone or not) and a count is what
+// this kernel returns.
+namespace nfa {
+struct SearchArgs {
+    const float* knots;
+    int64_t stride;
+    int nk;
+    const float* x;
+    int64_t* out;
+    int64_t n;
+    float eps;
+    int T;       // rows per tile
+    int dense;   // 1: rows are contiguous and a tile of them is staged through LDS
+};
+
+__global__ void __launch_bounds__(kBlock) searchsorted_kernel(const SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nk = a.nk;
+    const int64_t num_tiles = (a.n + a.T - 1) / a.T;
+    const bool dense = a.dense != 0, shared = a.stride == 0;
+    if (shared) {
+        for (int j = tid; j < nk; j += kBlock) lds[j] = a.knots[j];
+        __syncthreads();
+    }
+    for (int64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+        const int64_t i0 = tile * a.T;
+        const int cnt = (int)((a.n - i0) < a.T ? (a.n - i0) : a.T);
+        int off = 0;
+        if (dense) {
+            off = tile_load(a.knots + i0 * nk, cnt * nk, lds, tid);
+            __syncthreads();
+        }
+        for (int e = tid; e < cnt; e += kBlock) {
+            const float x = a.x[i0 + e];
+            int count = 0;
+            if (dense || shared) {
+                const float* row = shared ? lds : lds + off + e * nk;
+                for (int j = 0; j < nk - 1; ++j) count += x >= row[j] ? 1 : 0;
+                count += x >= row[nk - 1] + a.eps ? 1 : 0;
+            } else {
+                const float* row = a.knots + (i0 + e) * a.stride;
+                for (int j = 0; j < nk - 1; ++j) count += x >= row[j] ? 1 : 0;
+                count += x >= row[nk - 1] + a.eps ? 1 : 0;
+            }
+            a.out[i0 + e] = (int64_t)count - 1;
+        }
+        if (dense) __syncthreads();   // before the next tile overwrites the image
+    }
+}
+}  // namespace nfa
+
+extern "C" int nfa_searchsorted_f32(const float* bin_locations, int64_t row_stride, int32_t num_knots,
+                                    const float* inputs, int64_t* bin_idx, int64_t n, double eps, void* stream) {
+    if (n < 0 || num_knots < 1 || row_stride < 0) return NFA_ERR_INVALID_ARGUMENT;
+    if (n == 0) return NFA_OK;
+    if (!bin_locations || !inputs || !bin_idx) return NFA_ERR_INVALID_ARGUMENT;
+    SearchArgs a;
+    a.knots = bin_locations;
+    a.stride = row_stride;
+    a.nk = num_knots;
+    a.x = inputs;
+    a.out = bin_idx;
+    a.n = n;
+    a.eps = (float)eps;
+    int T = kBlock;
+    size_t lds = 16;
+    a.dense = 0;
+    if (row_stride == num_knots && num_knots <= 4096) {
+        auto bytes = [&](int t) { return (size_t)(round_up4(t * num_knots) + 8) * 4; };
+        while (T > 1 && bytes(T) > (size_t)kMaxDynLdsMisc) T >>= 1;
+        if (bytes(T) <= (size_t)kMaxDynLdsMisc) {   // (a longer row is read in place)
+            lds = bytes(T);
+            a.dense = 1;
+        } else {
+            T = kBlock;
+        }
+    } else if (row_stride == 0) {
+        lds = (size_t)round_up4(num_knots) * 4;
+        if (lds > (size_t)kMaxDynLdsMisc) return NFA_ERR_UNSUPPORTED;
+    }
+    a.T = T;
+    const int64_t tiles = (n + T - 1) / T;
+    int64_t g = (int64_t)device_cu_count() * 8;
+    if (g > tiles) g = tiles;
+    hipLaunchKernelGGL(searchsorted_kernel, dim3((unsigned)g), dim3(kBlock), lds, (hipStream_t)stream, a);
+    NFA_HIP_CHECK(hipGetLastError());
+    return NFA_OK;
+}

@@ -48,6 +48,7 @@ struct CouplingArgs {
     const int64_t* scatter;  // out_scatter, may be null
     float* out;
     float* lad;
+    int32_t* bins;    // may be null: [batch, dt] bin chosen for every spline (rqs_eval's `bin`)
     int32_t* status;  // may be null
     int64_t batch;
     int D;   // features
@@ -145,8 +146,9 @@ __global__ void __launch_bounds__(BLOCK) rqs_coupling_kernel(const CouplingArgs 
                 const int col = s_tidx[j];
                 const float xin = s_x[mx + r * D + s_src[col]];
                 float y, l;
-                my_status |= a.sp.linear ? rqs_eval<KT, INVERSE, true>(xin, s_p + mp + ii * P, a.sp, y, l)
-                                         : rqs_eval<KT, INVERSE, false>(xin, s_p + mp + ii * P, a.sp, y, l);
+                int* bin = a.bins ? a.bins + (row0 * dt + i) : nullptr;
+                my_status |= a.sp.linear ? rqs_eval<KT, INVERSE, true>(xin, s_p + mp + ii * P, a.sp, y, l, bin)
+                                         : rqs_eval<KT, INVERSE, false>(xin, s_p + mp + ii * P, a.sp, y, l, bin);
                 s_o[r * D + s_dst[col]] = y;
                 if (chunked)
                     acc += l;
@@ -209,7 +211,7 @@ typedef float vec4 __attribute__((ext_vector_type(4)));  // native 16-byte vecto
 #ifndef NFA_PIPE_WAVES
 #define NFA_PIPE_WAVES 4
 #endif
-template <int KT, bool INVERSE, bool LINEAR>
+template <int KT, bool INVERSE, bool LINEAR, bool BINS = false>   // BINS: the instance that also stores a.bins
 __global__ void __launch_bounds__(kBlock, NFA_PIPE_WAVES) rqs_coupling_pipelined(const CouplingArgs a) {
     // float4 per lane per tile: enough for 256 splines of 3K+1 logits (lanes past the tile's end
     // re-read its last vector)
@@ -334,7 +336,8 @@ __global__ void __launch_bounds__(kBlock, NFA_PIPE_WAVES) rqs_coupling_pipelined
             y = s_x[it_x] + it_p[3];
             l = it_p[5];
 #else
-            my_status |= rqs_eval<KT, INVERSE, LINEAR>(s_x[it_x], const_cast<float*>(it_p), a.sp, y, l);
+            int* bin = BINS ? a.bins + (tile * nitems + tid) : nullptr;
+            my_status |= rqs_eval<KT, INVERSE, LINEAR>(s_x[it_x], const_cast<float*>(it_p), a.sp, y, l, bin);
 #endif
             s_out[it_y] = y;
         }
@@ -379,6 +382,7 @@ struct ElementwiseArgs {
     int64_t sw, sh, sd;  // row strides (elements)
     float* y;
     float* lad;
+    int32_t* bins;    // may be null: [n] bin chosen for every element (rqs_eval's `bin`)
     int32_t* status;
     int64_t n;
     int packed;  // 1: the three logit arrays are one [n, P] buffer starting at uw
@@ -414,8 +418,9 @@ __global__ void __launch_bounds__(kBlock) rqs_elementwise_kernel(const Elementwi
         }
         if (tid < cnt) {
             float y, l;
-            my_status |= a.sp.linear ? rqs_eval<KT, INVERSE, true>(a.x[i0 + tid], mine, a.sp, y, l)
-                                     : rqs_eval<KT, INVERSE, false>(a.x[i0 + tid], mine, a.sp, y, l);
+            int* bin = a.bins ? a.bins + (i0 + tid) : nullptr;
+            my_status |= a.sp.linear ? rqs_eval<KT, INVERSE, true>(a.x[i0 + tid], mine, a.sp, y, l, bin)
+                                     : rqs_eval<KT, INVERSE, false>(a.x[i0 + tid], mine, a.sp, y, l, bin);
             a.y[i0 + tid] = y;
             a.lad[i0 + tid] = l;
         }
@@ -456,7 +461,7 @@ __global__ void __launch_bounds__(kBlock) rqs_elementwise_kernel(const Elementwi
 #define NFA_WT_STORE(v, p) (*(p) = (v))
 #endif
 
-template <int KT, bool INVERSE>
+template <int KT, bool INVERSE, bool BINS = false>   // BINS: the instance that also stores a.bins
 __global__ void __launch_bounds__(kBlock) rqs_coupling_wavetile(const CouplingArgs a) {
     constexpr int P = 3 * KT - 1;
     constexpr int kTileBytes = 64 * P * 4;
@@ -583,7 +588,8 @@ __global__ void __launch_bounds__(kBlock) rqs_coupling_wavetile(const CouplingAr
         y = xs + p[3] + p[P - 1];
         l = p[5] + p[11];
 #else
-        my_status |= rqs_eval<KT, INVERSE, true, true>(xs, p, a.sp, y, l);
+        // (lane = sample r_i, transformed feature lane & (dt - 1) of the tile: element tile * 64 + lane of [batch, dt])
+        my_status |= rqs_eval<KT, INVERSE, true, true>(xs, p, a.sp, y, l, BINS ? a.bins + (tile * 64 + lane) : nullptr);
 #endif
         if (pt_ok0) s_o[pt_off0] = xv0;
         if (pt_ok1) s_o[pt_off1] = xv1;
@@ -668,10 +674,12 @@ static int launch_wavetile(const CouplingArgs& a, int inverse, hipStream_t st) {
     constexpr int P = 3 * KT - 1;
     constexpr int kWaveLds = ((64 * P * 4 + 1023) / 1024) * 1024 + 512;
     const size_t lds = (size_t)(kBlock / kWave) * kWaveLds;
-    void (*kern)(const CouplingArgs) = inverse ? rqs_coupling_wavetile<KT, true> : rqs_coupling_wavetile<KT, false>;
+    void (*kern)(const CouplingArgs) =
+        a.bins ? (inverse ? rqs_coupling_wavetile<KT, true, true> : rqs_coupling_wavetile<KT, false, true>)
+               : (inverse ? rqs_coupling_wavetile<KT, true> : rqs_coupling_wavetile<KT, false>);
     // persistent: exactly the workgroups that are resident together (registers and LDS decide)
-    static int per_cu_cache[2] = {0, 0};
-    int& per_cu = per_cu_cache[inverse ? 1 : 0];
+    static int per_cu_cache[4] = {0, 0, 0, 0};
+    int& per_cu = per_cu_cache[(inverse ? 1 : 0) + (a.bins ? 2 : 0)];
     if (per_cu == 0) {
         int n = 0;
         NFA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kBlock, lds));
@@ -693,7 +701,15 @@ static int launch_wavetile(const CouplingArgs& a, int inverse, hipStream_t st) {
 template <int KT>
 static int launch_pipelined(const CouplingArgs& a, int inverse, dim3 grid, size_t lds, hipStream_t st) {
     note_layer_kernel("rqs_coupling_pipelined<K=%d, inverse=%d, linear=%d>", KT, inverse ? 1 : 0, a.sp.linear ? 1 : 0);
-    if (a.sp.linear) {
+    if (a.bins) {   // (the instances that store the chosen bins: same arithmetic, one more store)
+        if (a.sp.linear) {
+            if (inverse) launch_k1(rqs_coupling_pipelined<KT, true, true, true>, grid, dim3(kBlock), lds, st, a);
+            else launch_k1(rqs_coupling_pipelined<KT, false, true, true>, grid, dim3(kBlock), lds, st, a);
+        } else {
+            if (inverse) launch_k1(rqs_coupling_pipelined<KT, true, false, true>, grid, dim3(kBlock), lds, st, a);
+            else launch_k1(rqs_coupling_pipelined<KT, false, false, true>, grid, dim3(kBlock), lds, st, a);
+        }
+    } else if (a.sp.linear) {
         if (inverse)
             launch_k1(rqs_coupling_pipelined<KT, true, true>, grid, dim3(kBlock), lds, st, a);
         else
@@ -725,7 +741,7 @@ using namespace nfa;
 extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
                                     const int64_t* transform_idx, const int64_t* in_perm,
                                     const int64_t* out_scatter, float* outputs, float* logabsdet,
-                                    int32_t* status, int64_t batch,
+                                    int32_t* bin_idx, int32_t* status, int64_t batch,
                                     int32_t features, int32_t num_transform, const nfa_rqs_spec* spec,
                                     int32_t flags, void* stream) {
     if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET)) return NFA_ERR_INVALID_ARGUMENT;
@@ -782,6 +798,7 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
     a.scatter = out_scatter;
     a.out = outputs;
     a.lad = logabsdet;
+    a.bins = bin_idx;
     a.status = status;
     a.batch = batch;
     a.D = D;
@@ -823,6 +840,7 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
         f.batch = full_rows;
         // wave tiles (LDS-DMA, no workgroup barriers) where the layout allows: linear tails, 8 / 10 bins, d_t a
         // power of two with D = 2 d_t; NFA_K1_WAVETILE=0 keeps the register-pipelined kernel (A/B runs)
+        // (read per launch on purpose: tests/test_gpu_steep.py and bench.py switch it between launches of one process)
         const char* wt_env = getenv("NFA_K1_WAVETILE");
         const bool wavetile = (!wt_env || atoi(wt_env) != 0) && a.sp.linear && (a.sp.K == 8 || a.sp.K == 10) &&
                               dt >= 4 && dt <= 64 && (dt & (dt - 1)) == 0 && D == 2 * dt && a.sp.P == 3 * a.sp.K - 1 &&
@@ -838,6 +856,7 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
             a.params = params + wt_rows * (int64_t)dt * P;
             a.out = outputs + wt_rows * D;
             a.lad = logabsdet + wt_rows;
+            if (bin_idx) a.bins = bin_idx + wt_rows * dt;
             a.batch = batch - wt_rows;
             return a.sp.K == 10 ? launch_coupling<10, kBlock>(a, inverse, dim3(1), lds, st)
                                 : launch_coupling<8, kBlock>(a, inverse, dim3(1), lds, st);
@@ -862,6 +881,7 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
         a.params = params + full_rows * (int64_t)dt * P;
         a.out = outputs + full_rows * D;
         a.lad = logabsdet + full_rows;
+        if (bin_idx) a.bins = bin_idx + full_rows * dt;
         a.batch = batch - full_rows;
         switch (a.sp.K) {
             case 4: return launch_coupling<4, kBlock>(a, inverse, dim3(1), lds, st);
@@ -880,7 +900,7 @@ extern "C" int nfa_rqs_coupling_f32(const float* inputs, const float* params,
 extern "C" int nfa_rqs_elementwise_f32(const float* inputs, const float* uw, int64_t stride_w,
                                        const float* uh, int64_t stride_h, const float* ud,
                                        int64_t stride_d, int32_t num_derivatives, float* outputs,
-                                       float* logabsdet, int32_t* status, int64_t n,
+                                       float* logabsdet, int32_t* bin_idx, int32_t* status, int64_t n,
                                        const nfa_rqs_spec* spec, int32_t inverse, void* stream) {
     if (n < 0) return NFA_ERR_INVALID_ARGUMENT;
     ElementwiseArgs a;
@@ -906,6 +926,7 @@ extern "C" int nfa_rqs_elementwise_f32(const float* inputs, const float* uw, int
     a.sd = stride_d;
     a.y = outputs;
     a.lad = logabsdet;
+    a.bins = bin_idx;
     a.status = status;
     a.n = n;
     a.packed = (uh == uw + K) && (a.nd == 0 || ud == uw + 2 * K) && stride_w == P && stride_h == P &&

@@ -15,6 +15,7 @@ struct Rqs64Args {
     int64_t sw, sh, sd, n;
     double* y;
     double* lad;
+    int32_t* bins;   // may be null
     int32_t* status;
     f64::Spec s;
 };
@@ -23,7 +24,8 @@ __global__ void __launch_bounds__(kBlock) rqs_elementwise_f64_kernel(const Rqs64
     int my_status = 0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
         double y, lad;
-        f64::forward_element(a.s, a.x[i], a.uw + i * a.sw, a.uh + i * a.sh, a.ud + i * a.sd, y, lad, my_status);
+        f64::forward_element(a.s, a.x[i], a.uw + i * a.sw, a.uh + i * a.sh, a.ud + i * a.sd, y, lad, my_status,
+                             a.bins ? a.bins + i : nullptr);
         a.y[i] = y;
         a.lad[i] = lad;
     }
@@ -103,8 +105,9 @@ using namespace nfa;
 extern "C" int nfa_rqs_elementwise_f64(const double* inputs, const double* unnormalized_widths, int64_t stride_w,
                                        const double* unnormalized_heights, int64_t stride_h,
                                        const double* unnormalized_derivatives, int64_t stride_d,
-                                       int32_t num_derivatives, double* outputs, double* logabsdet, int32_t* status,
-                                       int64_t n, const nfa_rqs_spec* spec, int32_t inverse, void* stream) {
+                                       int32_t num_derivatives, double* outputs, double* logabsdet, int32_t* bin_idx,
+                                       int32_t* status, int64_t n, const nfa_rqs_spec* spec, int32_t inverse,
+                                       void* stream) {
     Rqs64Args a;
     const int rc = fill_f64(a, inputs, unnormalized_widths, stride_w, unnormalized_heights, stride_h,
                             unnormalized_derivatives, stride_d, num_derivatives, n, spec, inverse);
@@ -113,6 +116,7 @@ extern "C" int nfa_rqs_elementwise_f64(const double* inputs, const double* unnor
     if (!outputs || !logabsdet) return NFA_ERR_INVALID_ARGUMENT;
     a.y = outputs;
     a.lad = logabsdet;
+    a.bins = bin_idx;
     a.status = status;
     hipLaunchKernelGGL(rqs_elementwise_f64_kernel, dim3(grid_f64(n)), dim3(kBlock), 0, (hipStream_t)stream, a);
     NFA_HIP_CHECK(hipGetLastError());
@@ -135,6 +139,7 @@ extern "C" int nfa_rqs_elementwise_backward_f64(const double* inputs, const doub
         return NFA_ERR_INVALID_ARGUMENT;
     b.f.y = nullptr;
     b.f.lad = nullptr;
+    b.f.bins = nullptr;
     b.f.status = nullptr;
     b.gy = grad_outputs;
     b.gl = grad_logabsdet;

@@ -102,11 +102,11 @@ NFA_HD bool locate(const Spec& a, double x, const double* uw, const double* uh, 
         axis_bin<true>(uw, a.K, a.divisor, a.left, a.right, a.min_w, x, k, aw);
         if (k >= 0 && k < a.K) axis_bin<false>(uh, a.K, a.divisor, a.bottom, a.top, a.min_h, x, k, ah);
     }
+    b.k = k;   // (what searchsorted returns: K past the nudged last knot, -1 when no knot is <= x)
     if (k < 0 || k >= a.K) {
         status |= kOutside;
         return false;
     }
-    b.k = k;
     b.cw0 = aw.knot_lo;
     b.cw1 = aw.knot_hi;
     b.ch0 = ah.knot_lo;
@@ -137,14 +137,18 @@ NFA_HD bool inside_box(const Spec& a, double x, int& status) {
 }
 
 // ---- forward -------------------------------------------------------------------------------------
+// `bin` (optional): the searched bin, -1 for elements the reference never searches (tails / outside / NaN)
 NFA_HD void forward_element(const Spec& a, double x, const double* uw, const double* uh, const double* ud, double& y,
-                            double& lad, int& status) {
+                            double& lad, int& status, int* bin = nullptr) {
     y = x;
     lad = 0.0;
+    if (bin) *bin = -1;
     if (!inside_box(a, x, status)) return;
     Bin b;
     Axis aw, ah;
-    if (!locate(a, x, uw, uh, ud, b, aw, ah, status)) return;
+    const bool located = locate(a, x, uw, uh, ud, b, aw, ah, status);
+    if (bin) *bin = b.k;
+    if (!located) return;
     const double d0 = b.d0, d1 = b.d1;
     const double in_w = b.cw1 - b.cw0, in_h = b.ch1 - b.ch0, delta = in_h / in_w;
     const double s = (d0 + d1) - 2.0 * delta;

@@ -24,7 +24,10 @@
 
 namespace nfa {
 
-template <bool INVERSE, int KT = 8>
+// DBG = true (the diagnostic instances of rqs_resnet_f16_dbg.hip only): `kbin` follows the walk -- the last bin whose
+// lower knot the input reached, i.e. the value torchutils.searchsorted (utils/torchutils.py:134-136) returns on THIS
+// evaluation's knots; -1 for an input outside the box.  The same compares on the same values as the selects use.
+template <bool INVERSE, int KT = 8, bool DBG = false>
 struct FusedSteps {
     static_assert(KT >= 2 && KT <= 32, "2 .. 32 bins (8 and 10 keep their own maximum / sum chains)");
     static constexpr int kNumSlices = KT + 3;                   // max, one exponential per logit, sum x 2
@@ -46,6 +49,7 @@ struct FusedSteps {
     int status;
     float t3, t4;
     float in_w, in_h, r_w, r_den, delta, s_, th, t1mt, den, t0, t1, t2, t5;
+    int kbin;   // DBG only
 
     // Softmax numerators 2^((logit - max) x log2(e) x kappa): max in one slice (two v_max3_f32 + one
     // v_max_f32 for 8 bins), then fma + v_exp_f32 per logit; the rounding of the shared term is common to
@@ -160,8 +164,10 @@ struct FusedSteps {
             kwn = k1w + __builtin_fmaf(ew[1], aw, sp.span_w * sp.min_w);
             khn = k1h + __builtin_fmaf(eh[1], ah, sp.span_w * sp.min_h);
             asm("v_cmp_ge_f32 %0, %1, %2" : "=s"(take) : "v"(x), "v"(INVERSE ? k1h : k1w));
+            if constexpr (DBG) kbin = 0;
         } else if constexpr (S < W) {
             constexpr int I = S - 2;   // bins 1..KT-1: (kw, kh) lower, (kwn, khn) upper knots, `take` = x >= lower
+            if constexpr (DBG) kbin = (x >= (INVERSE ? kh : kw)) ? I : kbin;
             float kw2 = B, kh2 = B;    // upper knots of bin I + 1
             if constexpr (I + 1 < KT - 1) {
                 kw2 = kwn + __builtin_fmaf(ew[I + 1], aw, sp.span_w * sp.min_w);
@@ -183,6 +189,7 @@ struct FusedSteps {
             y = inside ? y : x;
             lad = inside ? lad : 0.0f;
             status = inside ? status : 0;
+            if constexpr (DBG) kbin = inside ? kbin : -1;
         }
     }
 

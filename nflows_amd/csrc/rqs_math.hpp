@@ -206,8 +206,14 @@ __device__ __forceinline__ int rqs_bin_eval(float x, float cw0, float cw1, float
 //   REGS = true: `sl` points at a per-lane register array (KT > 0, LINEAR): the two derivative
 //   logits are picked with a select chain instead of a dynamic index (which would force the
 //   array into scratch memory).
+//   `bin` (optional, a per-lane address): receives the bin the search chose -- what
+//   torchutils.searchsorted (utils/torchutils.py:134-136) returns for this element: 0 .. K-1, K when the
+//   input reaches the nudged last knot (the reference's gather then fails; here OUTSIDE_DOMAIN) -- or -1
+//   for an element the reference never searches (linear tails / outside the domain / NaN).  Stored the
+//   moment it is known; with the default nullptr the stores fold away.
 template <int KT, bool INVERSE, bool LINEAR, bool REGS = false>
-__device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, float& y, float& lad) {
+__device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, float& y, float& lad,
+                                        int* bin = nullptr) {
 #pragma clang fp contract(off)
     const int K = KT > 0 ? KT : sp.K;
     const float left = LINEAR ? -sp.right : sp.left;
@@ -222,11 +228,13 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
         if (!(x >= left && x <= right)) {  // NaN falls outside too
             y = x;
             lad = 0.0f;
+            if (bin) *bin = -1;
             return 0;
         }
     } else if (x < left || x > right) {
         y = x;
         lad = 0.0f;
+        if (bin) *bin = -1;
         return NFA_STATUS_OUTSIDE_DOMAIN;
     }
 
@@ -240,6 +248,7 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
     float cw0 = 0.f, cw1 = 0.f, ch0 = 0.f, ch1 = 0.f;
     if (INVERSE) {
         walk_bins<KT, true>(eh, K, den_h, sp.min_h, sp.om_h, span_h, bottom, top, x, k, ch0, ch1);
+        if (bin) *bin = (k >= 0 && x >= top_eps) ? K : k;
         if (k < 0 || x >= top_eps) {
             y = x;
             lad = 0.0f;
@@ -248,6 +257,7 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
         walk_bins<KT, false>(ew, K, den_w, sp.min_w, sp.om_w, span_w, left, right, x, k, cw0, cw1);
     } else {
         walk_bins<KT, true>(ew, K, den_w, sp.min_w, sp.om_w, span_w, left, right, x, k, cw0, cw1);
+        if (bin) *bin = (k >= 0 && x >= right_eps) ? K : k;
         if (k < 0 || x >= right_eps) {
             y = x;
             lad = 0.0f;

@@ -62,7 +62,7 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
                       int32_t param_stages, const int32_t* final_positions, int32_t num_layers, float* outputs,
                       float* logabsdet, int32_t* redo_blocks, int32_t* status, int64_t batch, int32_t features,
                       int32_t num_transform, int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
-                      const nfa_rqs_spec* spec, int32_t flags, void* stream) {
+                      const nfa_rqs_spec* spec, int32_t flags, void* stream, int32_t* dbg_bins = nullptr) {
     if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_STANDARD_NORMAL_LOG_PROB |
                   NFA_FLAG_SKIP_OUTPUTS | NFA_FLAG_PAD_COLUMNS_MASK | NFA_FLAG_ACTIVATION_MASK))
         return NFA_ERR_INVALID_ARGUMENT;
@@ -102,6 +102,9 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
         return NFA_ERR_INVALID_ARGUMENT;
     a.ctx = with_ctx ? context : nullptr;
     a.ce = context_features;
+    a.dbg_bins = dbg_bins;
+    // the diagnostic instances (nfa_rqs_flow_resnet_f16x2_bins_f32): the bench's kernel family only
+    if (dbg_bins && (a.sp.K != 8 || with_ctx || activation != NFA_ACTIVATION_RELU)) return NFA_ERR_UNSUPPORTED;
     a.normal = (flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB) ? 1 : 0;
     a.skip_out = (flags & NFA_FLAG_SKIP_OUTPUTS) ? 1 : 0;
     a.Ds = density_columns(flags, features);
@@ -144,7 +147,7 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     // the elastic stream (five slots, counters instead of the per-stage barrier) where it fits: eight-wave
     // workgroups of the 8-bin kernel without a context (the bench's shape: 161 984 bytes at D = 64)
 #ifdef NFA_K8H_ELASTIC
-    const bool elastic = nw == 8 && !with_ctx && a.sp.K == 8 && force_ring == 5 && lds_for(8, k8h::kRingElastic) <= lds_cap;
+    const bool elastic = !dbg_bins && nw == 8 && !with_ctx && a.sp.K == 8 && force_ring == 5 && lds_for(8, k8h::kRingElastic) <= lds_cap;
 #else
     const bool elastic = false;
     (void)force_ring;
@@ -164,14 +167,19 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
                          : (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0) + (a.sp.K == 10 ? 8 : 0);
     if (elastic) which = 24 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0);
     if (any_bins) which = 32 + (a.sp.K - 2) * 8 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0);
-    if (activation != NFA_ACTIVATION_RELU) {
+    if (dbg_bins) {
+        which = 32 + 31 * 8 + 3 * 16 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0);
+        kern = k8h::debug_kernel(inv, init_ks, nw);
+        if (!kern) return NFA_ERR_UNSUPPORTED;
+    } else if (activation != NFA_ACTIVATION_RELU) {
         which = 32 + 31 * 8 + (activation - 1) * 16 + (a.sp.K == 10 ? 8 : 0) + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0);
         kern = k8h::activation_kernel(activation, a.sp.K, inv, init_ks, nw);
     } else if (any_bins) {
         kern = a.sp.K <= 9 ? k8h::bins_kernel_a(a.sp.K, inv, init_ks, nw)
                : a.sp.K <= 16 ? k8h::bins_kernel_b(a.sp.K, inv, init_ks, nw) : k8h::bins_kernel_c(a.sp.K, inv, init_ks, nw);
     }
-    if (activation != NFA_ACTIVATION_RELU || any_bins) {
+    if (dbg_bins) {
+    } else if (activation != NFA_ACTIVATION_RELU || any_bins) {
         if (!kern) return NFA_ERR_UNSUPPORTED;
     }
     else switch (which) {
@@ -210,7 +218,7 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     note_layer_kernel("k8h::rqs_resnet_f16_kernel<inverse=%d, init_ks=%d, waves=%d, K=%d, ctx=%d, ring=%d, act=%s>", inv ? 1 : 0,
                       init_ks, nw, a.sp.K, with_ctx ? 1 : 0, elastic ? k8h::kRingElastic : k8h::kRing, act_names[activation]);
     if (lds_launch > 64 * 1024) {
-        static unsigned long long raised[32 + 31 * 8 + 3 * 16] = {};   // device masks (raise_dynamic_lds)
+        static unsigned long long raised[32 + 31 * 8 + 3 * 16 + 8] = {};   // device masks (raise_dynamic_lds)
         {
             const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], (int)lds_cap);
             if (rc_lds != NFA_OK) return rc_lds;
@@ -231,6 +239,20 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_f32(const float* inputs, const void* st
     return launch_f16(inputs, nullptr, 0, stream_packed, param_stages, final_positions, num_layers, outputs, logabsdet,
                       redo_blocks, status, batch, features, num_transform, num_identity, hidden_features, num_blocks,
                       spec, flags, stream);
+}
+
+// the same launch through the diagnostic instances: bin_idx [batch, num_transform] receives the bin every evaluation of
+// the LAST layer of the run chose (include/nflows_amd.h)
+extern "C" int nfa_rqs_flow_resnet_f16x2_bins_f32(const float* inputs, const void* stream_packed, int32_t param_stages,
+                                                  const int32_t* final_positions, int32_t num_layers, float* outputs,
+                                                  float* logabsdet, int32_t* redo_blocks, int32_t* status, int64_t batch,
+                                                  int32_t features, int32_t num_transform, int32_t num_identity,
+                                                  int32_t hidden_features, int32_t num_blocks,
+                                                  const nfa_rqs_spec* spec, int32_t flags, void* stream, int32_t* bin_idx) {
+    if (!bin_idx) return NFA_ERR_INVALID_ARGUMENT;
+    return launch_f16(inputs, nullptr, 0, stream_packed, param_stages, final_positions, num_layers, outputs, logabsdet,
+                      redo_blocks, status, batch, features, num_transform, num_identity, hidden_features, num_blocks,
+                      spec, flags, stream, bin_idx);
 }
 
 extern "C" int nfa_rqs_flow_resnet_context_f16x2_f32(const float* inputs, const float* context,

@@ -485,8 +485,10 @@ __device__ __forceinline__ void any_group_tiles(f32x16& acc, Steps& f, const flo
 // h + (W_1 relu(u) + b_1) * sigmoid(W_c context + b_c): the second Linear then has accumulators of its own
 // (its input pieces are finished first: u's registers are needed), the gate's Linear is one more stage
 // (two k-steps, k-major) and the residual stream takes the product in.
-template <bool INVERSE, int INIT_KS, int NW, int KB = 8, bool CTX = false, int RING = kRing, int ACT = kActRelu>
+// DBG (rqs_resnet_f16_dbg.hip): the same kernel with the last layer's chosen bins stored to a.dbg_bins (FusedSteps' kbin).
+template <bool INVERSE, int INIT_KS, int NW, int KB = 8, bool CTX = false, int RING = kRing, int ACT = kActRelu, bool DBG = false>
 __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Args a) {
+    static_assert(!DBG || KB == 8, "the diagnostic instances: 8 bins");
     static_assert(!CTX || INIT_KS == 4, "context: two identity k-steps + two context k-steps");
     static_assert(ACT == kActRelu || (!CTX && ACT >= kActLeakyRelu && ACT <= kActTanh), "other activations: no context");
     constexpr int kThreads = NW * kWave;
@@ -841,7 +843,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                     quad_status |= f.status;
                 }
             } else {
-                using Steps = FusedSteps8<INVERSE>;
+                using Steps = FusedSteps<INVERSE, 8, DBG>;
                 Steps fa, fb;
                 const float kappa = gemm[0];
                 fa.kappa = fb.kappa = kappa;
@@ -850,10 +852,13 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                 float* slot_b = nullptr;
                 const float* fbias = gemm + kHdr + half * 16;
                 f32x16 acc[3];
-                auto commit = [&](Steps& f, float* slot) {
+                auto commit = [&](Steps& f, float* slot, [[maybe_unused]] int feature) {
                     *slot = f.y;
                     lad_acc += f.lad;
                     quad_status |= f.status;
+                    if constexpr (DBG) {
+                        if (layer == a.num_layers - 1) a.dbg_bins[(row0 + r) * dt + feature] = f.kbin;
+                    }
                 };
                 SplineWeave<kUnitNumA, Steps> w0{fa, fb, a.sp};
                 SplineWeave<kUnitFinishA, Steps> w1{fa, fb, a.sp};
@@ -864,7 +869,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                     load_bias_tile(acc[0], fbias + (g * 3 + 0) * 32);
                     if (g > 0) {
                         tile_gemm(acc[0], ph, pl, sm, fr, lane, w2);
-                        commit(fb, slot_b);
+                        commit(fb, slot_b, (g - 1) * 4 + half * 2 + 1);
                     } else {
                         tile_gemm(acc[0], ph, pl, sm, fr, lane, NoWeave{});
                     }
@@ -884,7 +889,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                     }
                     load_bias_tile(acc[2], fbias + (g * 3 + 2) * 32);
                     tile_gemm(acc[2], ph, pl, sm, fr, lane, w1);
-                    commit(fa, slot0);
+                    commit(fa, slot0, g * 4 + half * 2);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         fb.eh[j] = acc[2][j];
@@ -893,7 +898,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                     slot_b = slot1;
                 }
                 spline_unit_range<kUnitFinishB, 0, spline_unit_slices<kUnitFinishB, Steps>()>(fa, fb, a.sp);
-                commit(fb, slot_b);
+                commit(fb, slot_b, (groups - 1) * 4 + half * 2 + 1);
             }
             NFA_HSTAMP()
             // this wave's spline results must be visible to its own gathers of the next layer
@@ -958,5 +963,6 @@ KernelFn bins_kernel_a(int K, bool inverse, int init_ks, int waves);     // 2 ..
 KernelFn bins_kernel_b(int K, bool inverse, int init_ks, int waves);     // 11 .. 16 bins
 KernelFn bins_kernel_c(int K, bool inverse, int init_ks, int waves);     // 20, 24, 32 bins
 KernelFn activation_kernel(int activation, int K, bool inverse, int init_ks, int waves);   // NFA_ACTIVATION_* > 0, 8 / 10 bins
+KernelFn debug_kernel(bool inverse, int init_ks, int waves);             // 8 bins, ReLU, no context: the DBG instances
 }  // namespace k8h
 }  // namespace nfa

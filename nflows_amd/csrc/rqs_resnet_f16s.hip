@@ -237,7 +237,8 @@ struct NumWeave {
 
 // RING: slots of the weight ring (RING - 1 stages in flight).  A small batch is bound by the bytes one CU has in
 // flight from L2: with 16 rows per wave the row tiles are small enough for seven slots (96 KB in flight instead of 48).
-template <bool INVERSE, int INIT_KS, int RING, int NW_ = kWavesPerGroup>
+// DBG (rqs_resnet_f16_dbg.hip): the same kernel with the last layer's chosen bins stored to a.dbg_bins (FusedSteps' kbin).
+template <bool INVERSE, int INIT_KS, int RING, int NW_ = kWavesPerGroup, bool DBG = false>
 __global__ void __launch_bounds__(NW_* kWave, 2) rqs_resnet_f16s_kernel(const Args a) {
     constexpr int NW = NW_, kThreads = NW * kWave;
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
@@ -427,7 +428,7 @@ __global__ void __launch_bounds__(NW_* kWave, 2) rqs_resnet_f16s_kernel(const Ar
 
             // ---- final layer: the six tiles of a group hold the 24 logits of this lane's feature 4 G + g
             {
-                using Steps = FusedSteps8<INVERSE>;
+                using Steps = FusedSteps<INVERSE, 8, DBG>;
                 Steps f;
                 const float kappa = gemm[0];
                 f.kappa = kappa;
@@ -454,6 +455,9 @@ __global__ void __launch_bounds__(NW_* kWave, 2) rqs_resnet_f16s_kernel(const Ar
                         *slot_prev = f.y;
                         lad_acc += f.lad;
                         quad_status |= f.status;
+                        if constexpr (DBG) {
+                            if (layer == a.num_layers - 1) a.dbg_bins[(row0 + n) * dt + (G - 1) * 4 + g] = f.kbin;
+                        }
                     } else {
                         tile_pair_stage(t[0], t[1], ph, pl, sm, fr, lane, none);
                         tile_pair_stage(t[2], t[3], ph, pl, sm, fr, lane, none);
@@ -478,6 +482,9 @@ __global__ void __launch_bounds__(NW_* kWave, 2) rqs_resnet_f16s_kernel(const Ar
                 *slot_prev = f.y;
                 lad_acc += f.lad;
                 quad_status |= f.status;
+                if constexpr (DBG) {
+                    if (layer == a.num_layers - 1) a.dbg_bins[(row0 + n) * dt + (groups - 1) * 4 + g] = f.kbin;
+                }
             }
             // this wave's spline results must be visible to its own gathers of the next layer
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -552,12 +559,11 @@ __global__ void zero_words_kernel(int32_t* p, int n) {
 
 using namespace nfa;
 
-extern "C" int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float* inputs, const void* stream_packed, int32_t param_stages,
-                                                    const int32_t* final_positions, int32_t num_layers, float* outputs,
-                                                    float* logabsdet, int32_t* redo_blocks, int32_t* status, int64_t batch,
-                                                    int32_t features, int32_t num_transform, int32_t num_identity,
-                                                    int32_t hidden_features, int32_t num_blocks, const nfa_rqs_spec* spec,
-                                                    int32_t flags, void* stream) {
+static int launch_tile16(const float* inputs, const void* stream_packed, int32_t param_stages,
+                         const int32_t* final_positions, int32_t num_layers, float* outputs, float* logabsdet,
+                         int32_t* redo_blocks, int32_t* status, int64_t batch, int32_t features, int32_t num_transform,
+                         int32_t num_identity, int32_t hidden_features, int32_t num_blocks, const nfa_rqs_spec* spec,
+                         int32_t flags, void* stream, int32_t* dbg_bins) {
     if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_STANDARD_NORMAL_LOG_PROB |
                   NFA_FLAG_SKIP_OUTPUTS | NFA_FLAG_PAD_COLUMNS_MASK))
         return NFA_ERR_INVALID_ARGUMENT;
@@ -581,6 +587,7 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float* inputs, const v
         return NFA_ERR_INVALID_ARGUMENT;
     a.ctx = nullptr;
     a.ce = 0;
+    a.dbg_bins = dbg_bins;
     a.normal = (flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB) ? 1 : 0;
     a.skip_out = (flags & NFA_FLAG_SKIP_OUTPUTS) ? 1 : 0;
     a.Ds = density_columns(flags, features);
@@ -629,8 +636,14 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float* inputs, const v
     const dim3 grid((unsigned)blocks), block(nw * kWave);
     const bool inv = (flags & NFA_FLAG_INVERSE) != 0;
     void (*kern)(const k8h::Args) = nullptr;
-    const int which = half ? 8 + (inv ? 1 : 0) + (init_ks == 2 ? 2 : 0) : (inv ? 1 : 0) + (init_ks == 2 ? 2 : 0) + (ring == 7 ? 4 : 0);
-    switch (which) {
+    int which = half ? 8 + (inv ? 1 : 0) + (init_ks == 2 ? 2 : 0) : (inv ? 1 : 0) + (init_ks == 2 ? 2 : 0) + (ring == 7 ? 4 : 0);
+    if (dbg_bins) {   // the diagnostic instances: d_i <= 32, the two workgroup forms the launcher picks by itself
+        if (init_ks != 1 || (!half && ring != 7)) return NFA_ERR_UNSUPPORTED;
+        which = 12 + (inv ? 1 : 0) + (half ? 2 : 0);
+        kern = half ? (inv ? k8s::rqs_resnet_f16s_kernel<true, 1, 4, 4, true> : k8s::rqs_resnet_f16s_kernel<false, 1, 4, 4, true>)
+                    : (inv ? k8s::rqs_resnet_f16s_kernel<true, 1, 7, k8s::kWavesPerGroup, true>
+                           : k8s::rqs_resnet_f16s_kernel<false, 1, 7, k8s::kWavesPerGroup, true>);
+    } else switch (which) {
         case 0: kern = k8s::rqs_resnet_f16s_kernel<false, 1, 4>; break;
         case 1: kern = k8s::rqs_resnet_f16s_kernel<true, 1, 4>; break;
         case 2: kern = k8s::rqs_resnet_f16s_kernel<false, 2, 4>; break;
@@ -650,7 +663,7 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float* inputs, const v
     if (half) hipLaunchKernelGGL(k8s::zero_words_kernel, dim3((unsigned)((batch / 128 + 255) / 256)), dim3(256), 0, st,
                                  redo_blocks, (int)(batch / 128));
     if (lds_launch > 64 * 1024) {
-        static unsigned long long raised[12] = {};   // device masks (raise_dynamic_lds)
+        static unsigned long long raised[16] = {};   // device masks (raise_dynamic_lds)
         const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], (int)lds_cap);
         if (rc_lds != NFA_OK) return rc_lds;
     }
@@ -658,4 +671,29 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float* inputs, const v
     else hipLaunchKernelGGL(kern, grid, block, lds_launch, st, a);
     NFA_HIP_CHECK(hipGetLastError());
     return NFA_OK;
+}
+
+extern "C" int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float* inputs, const void* stream_packed, int32_t param_stages,
+                                                    const int32_t* final_positions, int32_t num_layers, float* outputs,
+                                                    float* logabsdet, int32_t* redo_blocks, int32_t* status, int64_t batch,
+                                                    int32_t features, int32_t num_transform, int32_t num_identity,
+                                                    int32_t hidden_features, int32_t num_blocks, const nfa_rqs_spec* spec,
+                                                    int32_t flags, void* stream) {
+    return launch_tile16(inputs, stream_packed, param_stages, final_positions, num_layers, outputs, logabsdet, redo_blocks,
+                         status, batch, features, num_transform, num_identity, hidden_features, num_blocks, spec, flags,
+                         stream, nullptr);
+}
+
+// the same launch through the diagnostic instances (see nfa_rqs_flow_resnet_f16x2_bins_f32)
+extern "C" int nfa_rqs_flow_resnet_f16x2_tile16_bins_f32(const float* inputs, const void* stream_packed, int32_t param_stages,
+                                                         const int32_t* final_positions, int32_t num_layers, float* outputs,
+                                                         float* logabsdet, int32_t* redo_blocks, int32_t* status,
+                                                         int64_t batch, int32_t features, int32_t num_transform,
+                                                         int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
+                                                         const nfa_rqs_spec* spec, int32_t flags, void* stream,
+                                                         int32_t* bin_idx) {
+    if (!bin_idx) return NFA_ERR_INVALID_ARGUMENT;
+    return launch_tile16(inputs, stream_packed, param_stages, final_positions, num_layers, outputs, logabsdet, redo_blocks,
+                         status, batch, features, num_transform, num_identity, hidden_features, num_blocks, spec, flags,
+                         stream, bin_idx);
 }

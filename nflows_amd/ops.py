@@ -148,10 +148,12 @@ def _after_spline(spec, inverse, device):
 
 
 def rqs_coupling(inputs, params, transform_idx, spec, inverse=False, in_perm=None, out_scatter=None,
-                 accumulate_into=None):
+                 accumulate_into=None, return_bin_idx=False):
     """K1 -- fused rational-quadratic coupling layer.  inputs [B, D], params [B, d_t*P].
     Returns (outputs [B, D], logabsdet [B]).  Differentiable (K1-backward kernel) when an input
-    requires grad."""
+    requires grad.  return_bin_idx=True (no-grad passes): a third result, int32 [B, d_t], the bin the
+    kernel's search chose for every spline (`bin_idx` of rational_quadratic.py:115-118; -1 for elements
+    in the tails, see include/nflows_amd.h)."""
     N.require_device_f32("inputs", inputs, 2)
     N.require_device_f32("transform_params", params, 2)
     dev = inputs.device
@@ -163,6 +165,10 @@ def rqs_coupling(inputs, params, transform_idx, spec, inverse=False, in_perm=Non
     P = 3 * spec.num_bins - 1 if spec.tails == N.TAILS_LINEAR else 3 * spec.num_bins + 1
     if params.shape[0] != B or params.shape[1] != dt * P:
         raise ValueError("transform_params must be [%d, %d], got %s" % (B, dt * P, tuple(params.shape)))
+    if return_bin_idx:
+        if AG.needs_grad(inputs, params):
+            raise ValueError("return_bin_idx: a diagnostic of no-grad passes")
+        return _rqs_coupling_launch(inputs, params, tidx, spec, inverse, perm, scat, accumulate_into, True)
     if AG.needs_grad(inputs, params):
         out, lad = AG.RqsCoupling.apply(inputs.contiguous(), params.contiguous(), tidx, spec, bool(inverse),
                                         perm, scat)
@@ -173,7 +179,7 @@ def rqs_coupling(inputs, params, transform_idx, spec, inverse=False, in_perm=Non
     return _rqs_coupling_launch(inputs, params, tidx, spec, inverse, perm, scat, accumulate_into)
 
 
-def _rqs_coupling_launch(inputs, params, tidx, spec, inverse, perm, scat, accumulate_into):
+def _rqs_coupling_launch(inputs, params, tidx, spec, inverse, perm, scat, accumulate_into, want_bins=False):
     dev = inputs.device
     B, D = inputs.shape
     dt = tidx.numel()
@@ -182,11 +188,12 @@ def _rqs_coupling_launch(inputs, params, tidx, spec, inverse, perm, scat, accumu
     p = params.detach().contiguous()
     out = torch.empty_like(x)
     lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
+    bins = torch.empty(B, dt, dtype=torch.int32, device=dev) if want_bins else None
     hook = _launch_hook
     with torch.cuda.device(dev):
         token = hook.begin("rqs_coupling") if hook is not None else None
         rc = N.load().nfa_rqs_coupling_f32(N.ptr(x), N.ptr(p), N.ptr(tidx), N.ptr(perm), N.ptr(scat),
-                                           N.ptr(out), N.ptr(lad), N.ptr(_status_word(dev)), B, D, dt,
+                                           N.ptr(out), N.ptr(lad), N.ptr(bins), N.ptr(_status_word(dev)), B, D, dt,
                                            ctypes.byref(spec), flags, N.stream_handle(dev))
         if hook is not None:
             # algorithmic bytes: inputs + conditioner output + outputs + logabsdet
@@ -194,17 +201,18 @@ def _rqs_coupling_launch(inputs, params, tidx, spec, inverse, perm, scat, accumu
     if rc == N.ERR_UNSUPPORTED:
         if torch.is_grad_enabled() and (inputs.requires_grad or params.requires_grad):
             raise NotImplementedError("nflows_amd: this layer shape has no backward kernel yet")
-        out, l = _rqs_coupling_unfused(x, p, tidx, perm, scat, spec, inverse)
+        res = _rqs_coupling_unfused(x, p, tidx, perm, scat, spec, inverse, want_bins)
+        out, l = res[0], res[1]
         if accumulate_into is not None:
             accumulate_into += l
             l = accumulate_into
-        return out, l
+        return (out, l, res[2]) if want_bins else (out, l)
     N.check(rc)
     _after_spline(spec, inverse, dev)
-    return out, lad
+    return (out, lad, bins) if want_bins else (out, lad)
 
 
-def _rqs_coupling_unfused(x, p, tidx, perm, scat, spec, inverse):
+def _rqs_coupling_unfused(x, p, tidx, perm, scat, spec, inverse, want_bins=False):
     """Layers whose sample does not fit the fused kernel's LDS tile (d_t*P > ~12k floats): the same
     result from the elementwise spline kernel + row-sum kernel + index copies (all on device)."""
     if perm is not None:
@@ -215,24 +223,34 @@ def _rqs_coupling_unfused(x, p, tidx, perm, scat, spec, inverse):
     pr = p.view(B * dt, -1)
     # the divisor is part of the spec, so the packed [N, P] fast path still applies
     xt = x.index_select(1, tidx).contiguous()
-    y, l = rqs_elementwise(xt.view(-1), pr[:, :K], pr[:, K:2 * K], pr[:, 2 * K:], spec, inverse)
+    res = rqs_elementwise(xt.view(-1), pr[:, :K], pr[:, K:2 * K], pr[:, 2 * K:], spec, inverse,
+                          return_bin_idx=want_bins)
+    y, l = res[0], res[1]
     out = x.clone()
     out[:, tidx] = y.view(B, dt)
     if scat is not None:
         out = permute_cols(out, torch.argsort(scat))
+    if want_bins:
+        return out, rowsum(l.view(B, dt)), res[2].view(B, dt)
     return out, rowsum(l.view(B, dt))
 
 
 def rqs_elementwise(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives,
-                    spec, inverse=False):
+                    spec, inverse=False, return_bin_idx=False):
     """K5 -- elementwise functional on tensors of any leading shape S; logits S+[K], S+[K],
-    S+[K-1 | K+1].  Returns (outputs S, logabsdet S)."""
+    S+[K-1 | K+1].  Returns (outputs S, logabsdet S); with return_bin_idx=True (no-grad passes) also the
+    searched bin of every element, int32 S (`bin_idx` of rational_quadratic.py:115-118; -1 in the tails)."""
     dtype = inputs.dtype if torch.is_tensor(inputs) else torch.float32   # float64: the plain K5d kernel
     N.require_device_real("inputs", inputs, dtype)
     for nm, t in (("unnormalized_widths", unnormalized_widths),
                   ("unnormalized_heights", unnormalized_heights),
                   ("unnormalized_derivatives", unnormalized_derivatives)):
         N.require_device_real(nm, t, dtype)
+    if return_bin_idx:
+        if AG.needs_grad(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives):
+            raise ValueError("return_bin_idx: a diagnostic of no-grad passes")
+        return _rqs_elementwise_launch(inputs, unnormalized_widths, unnormalized_heights,
+                                       unnormalized_derivatives, spec, inverse, True)
     if dtype == torch.float64 and AG.needs_grad(inputs, unnormalized_widths, unnormalized_heights,
                                                 unnormalized_derivatives):
         return AG.RqsElementwise64.apply(inputs, unnormalized_widths, unnormalized_heights,
@@ -245,7 +263,7 @@ def rqs_elementwise(inputs, unnormalized_widths, unnormalized_heights, unnormali
 
 
 def _rqs_elementwise_launch(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives,
-                            spec, inverse):
+                            spec, inverse, want_bins=False):
     inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives = (
         t.detach() for t in (inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives))
     dev = inputs.device
@@ -277,14 +295,16 @@ def _rqs_elementwise_launch(inputs, unnormalized_widths, unnormalized_heights, u
     ud, sd = rows(unnormalized_derivatives, nd)
     y = torch.empty_like(x)
     lad = torch.empty_like(x)
+    bins = torch.empty(n, dtype=torch.int32, device=dev) if want_bins else None
     launch = N.load().nfa_rqs_elementwise_f64 if x.dtype == torch.float64 else N.load().nfa_rqs_elementwise_f32
     with torch.cuda.device(dev):
-        rc = launch(N.ptr(x), N.ptr(uw), sw, N.ptr(uh), sh,
-                                              N.ptr(ud) if nd else N.ptr(uw), sd, nd, N.ptr(y), N.ptr(lad),
-                                              N.ptr(_status_word(dev)), n, ctypes.byref(spec),
-                                              int(bool(inverse)), N.stream_handle(dev))
+        rc = launch(N.ptr(x), N.ptr(uw), sw, N.ptr(uh), sh, N.ptr(ud) if nd else N.ptr(uw), sd, nd, N.ptr(y),
+                    N.ptr(lad), N.ptr(bins), N.ptr(_status_word(dev)), n, ctypes.byref(spec),
+                    int(bool(inverse)), N.stream_handle(dev))
     N.check(rc)
     _after_spline(spec, inverse, dev)
+    if want_bins:
+        return y.view(shape), lad.view(shape), bins.view(shape)
     return y.view(shape), lad.view(shape)
 
 
@@ -503,6 +523,38 @@ def rowsum(x):
         rc = N.load().nfa_rowsum_f32(N.ptr(v), N.ptr(out), B, cols, N.stream_handle(x.device))
     N.check(rc)
     return out
+
+
+def searchsorted(bin_locations, inputs, eps=1e-6):
+    """torchutils.searchsorted (utils/torchutils.py:134-136) on device tensors: knots S_b+[n_knots] float32,
+    inputs S_i float32 (S_b broadcasts against S_i like `inputs[..., None] >= bin_locations` does), int64
+    result of the broadcast shape.  A single row of knots (the reference's `bin_locations[None, :]`) is
+    staged once per workgroup; per-input rows are read through LDS tiles.  `bin_locations` is not modified
+    (the reference leaves `+= eps` behind in the caller's tensor; nobody reads it)."""
+    N.require_device_f32("bin_locations", bin_locations)
+    N.require_device_f32("inputs", inputs)
+    if bin_locations.dim() < 1:
+        raise ValueError("bin_locations needs a last dimension of knots")
+    nk = bin_locations.shape[-1]
+    dev = inputs.device
+    if bin_locations.device != dev:
+        raise ValueError("bin_locations is on %s, inputs on %s" % (bin_locations.device, dev))
+    shape = torch.broadcast_shapes(tuple(inputs.shape), tuple(bin_locations.shape[:-1]))
+    if nk == 0:
+        return torch.full(shape, -1, dtype=torch.int64, device=dev)
+    x = inputs.detach().expand(shape).contiguous().view(-1)
+    n = x.numel()
+    if bin_locations.numel() == nk:
+        knots, stride = bin_locations.detach().reshape(nk).contiguous(), 0
+    else:
+        knots = bin_locations.detach().expand(tuple(shape) + (nk,)).contiguous().view(n, nk)
+        stride = nk
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        rc = N.load().nfa_searchsorted_f32(N.ptr(knots), stride, nk, N.ptr(x), N.ptr(out), n, float(eps),
+                                           N.stream_handle(dev))
+    N.check(rc)
+    return out.view(shape)
 
 
 def standard_normal_log_prob(z, logabsdet=None):
@@ -1781,6 +1833,24 @@ def use_tile16(batch, num_bins, context, device, activation=0):
     return K8S_ALWAYS or (batch + 127) // 128 <= cus
 
 
+class capture_last_layer_bins:
+    """Diagnostic (tests/test_gpu_bin_index.py): while active, launches of the f16 whole-layer kernels (K8h / K8s, 8 bins,
+    ReLU, no context) go through their diagnostic twins (nfa_rqs_flow_resnet_f16x2[_tile16]_bins_f32) and leave the bin
+    every spline evaluation of the run's LAST layer chose in `.bins` (int32 [rows, transformed features of the padded
+    layer], -1 outside the box) together with the launch's `.redo` flags.  Not re-entrant, not for timed runs."""
+    active = None
+
+    def __enter__(self):
+        self.bins = self.redo = None
+        self.launches = 0
+        capture_last_layer_bins.active = self
+        return self
+
+    def __exit__(self, *exc):
+        capture_last_layer_bins.active = None
+        return False
+
+
 def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transform, num_identity, num_blocks,
                             spec, inverse=False, accumulate_into=None, num_layers=1,
                             standard_normal_log_prob=False, pad=None, context=None, _pad_columns_count=0,
@@ -1824,8 +1894,18 @@ def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transf
         ctx = context.detach().contiguous()
         if ctx.shape[0] != B:
             raise ValueError("context must have one row per input row")
+    capture = capture_last_layer_bins.active
     with torch.cuda.device(dev):
-        if ctx is None:
+        if ctx is None and capture is not None:
+            entry = lib.nfa_rqs_flow_resnet_f16x2_tile16_bins_f32 if tile16 else lib.nfa_rqs_flow_resnet_f16x2_bins_f32
+            capture.bins = torch.full((B, num_transform), -2, dtype=torch.int32, device=dev)
+            capture.redo = redo
+            capture.launches += 1
+            rc = entry(
+                N.ptr(x), N.ptr(stream), param_stages, N.ptr(final_table), num_layers, N.ptr(out),
+                N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128,
+                num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev), N.ptr(capture.bins))
+        elif ctx is None:
             entry = lib.nfa_rqs_flow_resnet_f16x2_tile16_f32 if tile16 else lib.nfa_rqs_flow_resnet_f16x2_f32
             rc = entry(
                 N.ptr(x), N.ptr(stream), param_stages, N.ptr(final_table), num_layers, N.ptr(out),

@@ -127,8 +127,15 @@ class _Run(list):
                 coupling._verify_weights_now(self[i][0], (epoch, key[1][lo:hi], key[2][lo:hi]), params[lo:hi])
         return key
 
-    def rebase_verification(self):
-        """called when the run's packed weights are (re)built: the checksums that belong to the current fingerprint"""
+    def verify_before_packing(self):
+        """Called on every plan-cache miss, before the layers' packed weights are looked up.  A miss does not mean the
+        weights changed visibly -- the first inverse call, a batch that crosses the 16-sample-tile threshold, an evicted
+        plan -- and the per-layer packs are keyed on version counters and storage pointers alone: a write through
+        `.data` since the last pack (EMA swap, dist.broadcast(p.data)) would be packed into the NEW plan from the OLD
+        blobs.  So: a layer whose key is the one its checksum was recorded under is COMPARED now (StalePackedWeights on
+        a difference); a layer with a new key (optimizer step, load_state_dict, invalidate_packed_weights: its pack is
+        rebuilt from the current parameters) gets its checksum recorded.  (Round 4 re-recorded every layer here, which
+        defeated the guard in exactly the train -> EMA swap -> sample() sequence.)"""
         from . import coupling
         if not coupling.VERIFY_WEIGHTS_EVERY:
             return
@@ -140,7 +147,7 @@ class _Run(list):
             return
         versions, ptrs = tuple([p._version for p in params]), tuple([p.data_ptr() for p in params])
         for (c, _), (lo, hi) in zip(self, flat[4]):
-            coupling._verify_weights_now(c, (flat[0], versions[lo:hi], ptrs[lo:hi]), params[lo:hi], rebase=True)
+            coupling._verify_weights_now(c, (flat[0], versions[lo:hi], ptrs[lo:hi]), params[lo:hi])
 
 
 def _permutation_key(p):
@@ -287,7 +294,7 @@ class CompositeTransform(Transform):
             if len(cache) > 4:
                 cache.clear()
             if isinstance(units, _Run):
-                units.rebase_verification()
+                units.verify_before_packing()
             packed = [c._packed_mlp() if mlp else c._packed_resnet(geometry) for c, _ in units]
             packed_f16 = [c._packed_resnet_f16(geometry, tile16) for c, _ in units] if f16 else None
             weights = torch.cat([w for w, _ in packed], dim=0).contiguous()

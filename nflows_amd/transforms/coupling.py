@@ -46,7 +46,8 @@ class StalePackedWeights(RuntimeError):
 
 
 # NFA_VERIFY_WEIGHTS=N: every N-th use of a conditioner's cache key re-reads a checksum of its parameters on the
-# device (L1 and L2 norm per parameter, two fused launches and one synchronising comparison) and raises
+# device (L1 and L2 norm per parameter plus the L2 norm of the parameter shifted by one -- a signed component: |p + 1|^2 =
+# |p|^2 + 2 sum(p) + n, so a sign flip shows --, four fused launches and one synchronising comparison) and raises
 # StalePackedWeights when it differs from the one taken when the key last changed visibly.  Default (round 4): every
 # 256th use, staggered over the layers -- amortised ~ 1 us per layer and call; 0 switches it off, 1 checks every call (debugging).  Skipped while
 # a stream is being captured into a HIP graph (the comparison synchronises).
@@ -59,18 +60,25 @@ def _checksum(params):
         if not params:
             return torch.zeros(0)
         if all(p.is_floating_point() for p in params) and len({(p.device, p.dtype) for p in params}) == 1:
-            return torch.stack(list(torch._foreach_norm(params, 1)) + list(torch._foreach_norm(params, 2)))
-        return torch.stack([torch.stack((p.double().abs().sum(), p.double().pow(2).sum())) for p in params]).reshape(-1)
+            return torch.stack(list(torch._foreach_norm(params, 1)) + list(torch._foreach_norm(params, 2)) +
+                               list(torch._foreach_norm(torch._foreach_add(params, 1.0), 2)))
+        return torch.stack([torch.stack((p.double().abs().sum(), p.double().pow(2).sum(), p.double().sum())) for p in params]).reshape(-1)
+
+
+def _same_checksum(a, b):
+    """equal, NaN == NaN (diverged weights are not a stale cache: the kernels then propagate NaN like the reference does)"""
+    return a.shape == b.shape and bool(((a == b) | (a.isnan() & b.isnan())).all())
 
 
 def _verify_weights_now(owner, key, params, rebase=False):
-    """The run-level form (transforms/base.py: _Run.weights_fingerprint): `rebase` records the checksum that belongs to
-    `key` (called when the run's packed weights are rebuilt), otherwise the parameters are compared with it now."""
+    """The run-level form (transforms/base.py: _Run.weights_fingerprint, _Run.verify_before_packing): a key the layer has
+    not been seen with (or `rebase`) records the checksum that belongs to it; a known key compares the parameters with
+    the recorded checksum NOW."""
     state = owner.__dict__.get("_weights_checksum_run")
     if rebase or state is None or state[0] != key:
         owner.__dict__["_weights_checksum_run"] = (key, _checksum(params))
         return
-    if not torch.equal(_checksum(params), state[1]):
+    if not _same_checksum(_checksum(params), state[1]):
         owner.__dict__.pop("_weights_checksum_run", None)
         raise StalePackedWeights(
             "the parameters of %s changed through a write the packed-weight caches cannot see (a write through "
@@ -87,7 +95,7 @@ def _verify_weights(owner, key, params):
         owner.__dict__["_weights_checksum"] = [key, _checksum(params), (id(owner) >> 6) % VERIFY_WEIGHTS_EVERY]
         return
     state[2] += 1
-    if state[2] % VERIFY_WEIGHTS_EVERY == 0 and not torch.equal(_checksum(params), state[1]):
+    if state[2] % VERIFY_WEIGHTS_EVERY == 0 and not _same_checksum(_checksum(params), state[1]):
         owner.__dict__.pop("_weights_checksum", None)
         raise StalePackedWeights(
             "the parameters of %s changed through a write the packed-weight caches cannot see (a write through "

@@ -64,8 +64,15 @@ def create_random_binary_mask(features):
 
 def searchsorted(bin_locations, inputs, eps=1e-6):
     """Bin index by counting knots <= input, last knot nudged by eps (torchutils.py:134-136).
-    Kept for API completeness (host-side bookkeeping on small tensors); the kernels fuse the
-    search.  Unlike the reference it does not modify `bin_locations` in place."""
+    Float32 tensors on the device: the `nfa_searchsorted_f32` kernel (the spline kernels fuse the same
+    search and can report its result: `return_bin_idx` of `ops.rqs_elementwise` / `ops.rqs_coupling`);
+    anything else (host-side bookkeeping on small tensors, other dtypes): the same count in PyTorch.
+    Unlike the reference it does not modify `bin_locations` in place."""
+    if (torch.is_tensor(bin_locations) and torch.is_tensor(inputs) and inputs.is_cuda and bin_locations.is_cuda
+            and inputs.dtype == torch.float32 and bin_locations.dtype == torch.float32
+            and bin_locations.dim() >= 1):
+        from .. import ops
+        return ops.searchsorted(bin_locations, inputs, eps)
     knots = bin_locations.clone()
     knots[..., -1] += eps
     return (inputs[..., None] >= knots).sum(dim=-1) - 1

@@ -123,6 +123,21 @@ def rqs_elementwise(x, uw, uh, ud, spec, inverse=False, return_bins=False):
     return out
 
 
+def rqs_knots(u, spec, axis=0):
+    """`cumwidths` (axis 0) / `cumheights` (axis 1) of rational_quadratic.py:91-98 / :106-113 for logits u [..., K]:
+    [..., K + 1] knots in the dtype of u (linear tails: the box is [-tail_bound, tail_bound]^2 as make_spec set it)."""
+    dtype = u.dtype
+    suf, ct = _dt(dtype)
+    K = spec.num_bins
+    uf = np.ascontiguousarray(u.reshape(-1, K), dtype=dtype)
+    out = np.empty((uf.shape[0], K + 1), dtype)
+    fn = getattr(lib(), "oracle_rqs_knots" + suf)
+    fn.restype = None
+    fn(_ptr(uf, ct), ctypes.c_int64(K), ctypes.c_int64(uf.shape[0]), ctypes.byref(spec), ctypes.c_int(int(axis)),
+       _ptr(out, ct))
+    return out.reshape(u.shape[:-1] + (K + 1,))
+
+
 def linear_spline(x, unnormalized_pdf, spec, inverse=False):
     """splines/linear.py: x [...], unnormalized_pdf [..., K]; spec.tails = 1 -> unconstrained."""
     dtype = x.dtype

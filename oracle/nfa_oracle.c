@@ -209,6 +209,21 @@ int FN(oracle_rqs_elementwise)(const REAL *x, const REAL *uw, int64_t sw, const 
     return status;
 }
 
+/* The knots of one axis as rational_quadratic.py:91-98 (widths: axis 0) / :106-113 (heights: axis 1) builds them --
+ * `cumwidths` / `cumheights`, K + 1 per element, before searchsorted nudges the last one.  For the tests that ask
+ * where an input sits relative to the knot between two bins (tests/test_gpu_bin_index.py). */
+void FN(oracle_rqs_knots)(const REAL *u, int64_t stride, int64_t n, const oracle_rqs_spec *sp, int axis,
+                          REAL *knots) {
+    enum { KMAX = 256 };
+    int K = sp->num_bins;
+    REAL tmp[KMAX];
+    if (K < 1 || K > KMAX) return;
+    for (int64_t i = 0; i < n; ++i)
+        knots_from_logits(u + i * stride, K, (REAL)sp->wh_divisor, axis ? (REAL)sp->bottom : (REAL)sp->left,
+                          axis ? (REAL)sp->top : (REAL)sp->right,
+                          axis ? (REAL)sp->min_bin_height : (REAL)sp->min_bin_width, knots + i * (K + 1), tmp);
+}
+
 /* torch.sum(x, dim=1) (torchutils.sum_except_batch, torchutils.py:19-24); the oracle
  * accumulates in double and rounds once, so it is the best fp32 answer, not aten's order. */
 void FN(oracle_rowsum)(const REAL *x, int64_t rows, int64_t cols, REAL *out) {

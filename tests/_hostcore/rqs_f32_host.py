@@ -78,6 +78,21 @@ extern "C" int host_rqs_forward_regs(int kt, int inverse, int64_t n, const nfa_r
     return -1;
 }
 
+// the bin the search of rqs_eval chose (its `bin` output: what K1 / K5 store to `bin_idx`)
+template <int KT, bool INVERSE, bool LINEAR>
+static int bins_all(int64_t n, const RqsDev& sp, const float* x, const float* params, int32_t* bins) {
+    int status = 0;
+    float slot[3 * 4096 + 2];
+    for (int64_t i = 0; i < n; ++i) {
+        memcpy(slot, params + i * sp.P, sizeof(float) * sp.P);
+        float y, lad;
+        int b = -7;
+        status |= rqs_eval<KT, INVERSE, LINEAR>(x[i], slot, sp, y, lad, &b);
+        bins[i] = b;
+    }
+    return status;
+}
+
 #define DISPATCH(FN, ...)                                                                                     \
     do {                                                                                                      \
         const bool lin = sp.linear != 0;                                                                      \
@@ -97,6 +112,13 @@ extern "C" int host_rqs_forward(int kt, int inverse, int64_t n, const nfa_rqs_sp
     RqsDev sp;
     if (make_dev_spec(spec, &sp) != NFA_OK) return -1;
     DISPATCH(forward_all, n, sp, x, params, y, lad);
+}
+
+extern "C" int host_rqs_bins(int kt, int inverse, int64_t n, const nfa_rqs_spec* spec, const float* x,
+                             const float* params, int32_t* bins) {
+    RqsDev sp;
+    if (make_dev_spec(spec, &sp) != NFA_OK) return -1;
+    DISPATCH(bins_all, n, sp, x, params, bins);
 }
 
 extern "C" int host_rqs_backward(int kt, int inverse, int64_t n, const nfa_rqs_spec* spec, const float* x,
@@ -158,7 +180,8 @@ extern "C" int host_rqs_forward_flatsteps(int variant, int inverse, int64_t n, c
 // the whole-layer kernel K8h's sliced evaluation (rqs_fused8.hpp: FusedSteps, every slice in order) on logits scaled
 // by 1 / kappa (a power of two), the way the kernel hands them over; 8 or 10 bins, linear tails, softplus beta = 1
 template <class Steps, int KT>
-static int fused_all(int64_t n, const RqsDev& sp, float kappa, const float* x, const float* params, float* y, float* lad) {
+static int fused_all(int64_t n, const RqsDev& sp, float kappa, const float* x, const float* params, float* y, float* lad,
+                     int32_t* bins = nullptr) {
     int status = 0;
     const float inv_kappa = 1.0f / kappa;
     for (int64_t i = 0; i < n; ++i) {
@@ -178,8 +201,18 @@ static int fused_all(int64_t n, const RqsDev& sp, float kappa, const float* x, c
         y[i] = f.y;
         lad[i] = f.lad;
         status |= f.status;
+        if (bins) bins[i] = f.kbin;
     }
     return status;
+}
+
+// the diagnostic form of K8h's evaluation (FusedSteps<.., DBG = true>: rqs_resnet_f16_dbg.hip), 8 bins: values AND the bin
+extern "C" int host_rqs_forward_fused_bins(int inverse, float kappa, int64_t n, const nfa_rqs_spec* spec, const float* x,
+                                           const float* params, float* y, float* lad, int32_t* bins) {
+    RqsDev sp;
+    if (make_dev_spec(spec, &sp) != NFA_OK || !sp.linear || sp.K != 8) return -1;
+    return inverse ? fused_all<FusedSteps<true, 8, true>, 8>(n, sp, kappa, x, params, y, lad, bins)
+                   : fused_all<FusedSteps<false, 8, true>, 8>(n, sp, kappa, x, params, y, lad, bins);
 }
 
 extern "C" int host_rqs_forward_fused(int inverse, float kappa, int64_t n, const nfa_rqs_spec* spec, const float* x,
@@ -277,6 +310,10 @@ def build(out_dir):
     lib.host_rqs_forward_flat8.argtypes = [i32, i64, p, p, p, p, p]
     lib.host_rqs_forward_flatsteps.argtypes = [i32, i32, i64, p, p, p, p, p]
     lib.host_rqs_forward_fused.argtypes = [i32, ctypes.c_float, i64, p, p, p, p, p]
+    lib.host_rqs_forward_fused_bins.argtypes = [i32, ctypes.c_float, i64, p, p, p, p, p, p]
+    lib.host_rqs_forward_fused_bins.restype = i32
+    lib.host_rqs_bins.argtypes = [i32, i32, i64, p, p, p, p]
+    lib.host_rqs_bins.restype = i32
     lib.host_activate.argtypes = [i32, i64, p, p]
     lib.host_activate.restype = i32
     for fn in (lib.host_rqs_forward, lib.host_rqs_backward, lib.host_rqs_forward_flat8, lib.host_rqs_forward_flatsteps,

@@ -1245,7 +1245,125 @@ def steep_flow_cases(file_name="flows_steep.npz", only_nsf=False, nsf_cases=STEE
     print("flows_steep:", len(meta), "cases")
 
 
+# --------------------------------------------------------------------------- the reference's bin index
+class _SearchRecorder:
+    """Wraps nflows.utils.torchutils.searchsorted for the duration of one spline call: the reference never returns
+    `bin_idx` (rational_quadratic.py:115-118), so it is caught where it is made, together with the knots it was made
+    from (before the in-place `+= eps` of torchutils.py:135)."""
+
+    def __enter__(self):
+        from nflows.transforms.splines import rational_quadratic as rq
+        self.mod = rq.torchutils
+        self.orig = self.mod.searchsorted
+        self.calls = []
+
+        def recording(bin_locations, inputs, eps=1e-6):
+            knots = bin_locations.clone()
+            idx = self.orig(bin_locations, inputs, eps)
+            self.calls.append((knots, inputs.clone(), idx.clone()))
+            return idx
+        self.mod.searchsorted = recording
+        return self
+
+    def __exit__(self, *exc):
+        self.mod.searchsorted = self.orig
+        return False
+
+
+def _reference_bins(x, uw, uh, ud, inverse, kw):
+    """(y, lad, bin_idx int64 full shape with -1 where the reference does not search, knots of the searched axis
+    [n_searched, K + 1], mask of the searched elements) of one call of the reference."""
+    kw = dict(kw)
+    tails = kw.pop("tails", "linear")
+    if tails is None:
+        fn = splines.rational_quadratic_spline
+        searched = torch.ones_like(x, dtype=torch.bool)
+    else:
+        fn = splines.unconstrained_rational_quadratic_spline
+        kw["tails"] = tails
+        tb = kw.get("tail_bound", 1.0)
+        searched = (x >= -tb) & (x <= tb)
+    with _SearchRecorder() as rec:
+        y, lad = fn(x.clone(), uw.clone(), uh.clone(), ud.clone(), inverse=inverse, **kw)
+    full = torch.full(x.shape, -1, dtype=torch.int64)
+    knots = torch.zeros(0, uw.shape[-1] + 1)
+    if searched.any():
+        assert len(rec.calls) == 1
+        knots, xin, idx = rec.calls[0]
+        assert torch.equal(xin, x[searched])
+        full[searched] = idx
+    else:
+        assert len(rec.calls) == 0
+    return y, lad, full, knots, searched
+
+
+def bin_index_cases():
+    """rqs_bins.npz: (1) the reference's bin_idx for every case of rqs_functional.npz (same inputs, read back from that
+    file); (2) adversarial cases: inputs placed ON the reference's own knots of the searched axis and one ulp to either
+    side (where an off-by-one in a fused search would show), 8 and 10 bins, both directions, mild and steep logits."""
+    G = np.load(os.path.join(HERE, "rqs_functional.npz"))
+    out = {}
+    for name, inv, kw in G["meta"]:
+        kwd = dict(eval(kw))
+        x, uw, uh, ud = (torch.from_numpy(G[name + "/" + k]) for k in ("x", "uw", "uh", "ud"))
+        y, lad, full, _, _ = _reference_bins(x, uw, uh, ud, bool(int(inv)), kwd)
+        assert np.array_equal(npy(y).view(np.uint32), G[name + "/y"].view(np.uint32)), name   # the same call as the fixture's
+        out[name + "/bin_idx"] = npy(full)
+    meta = []
+    g = torch.Generator().manual_seed(20260925)
+    for tag, K, tb, n, scale in [("k8_tb3", 8, 3.0, 4096, 1.0), ("k8_tb3_steep", 8, 3.0, 4096, 3.0),
+                                 ("k10_tb1", 10, 1.0, 2048, 2.0)]:
+        uw = scale * torch.randn(n, K, generator=g)
+        uh = scale * torch.randn(n, K, generator=g)
+        ud = scale * torch.randn(n, K - 1, generator=g)
+        for inv in (False, True):
+            kw = dict(tails="linear", tail_bound=tb)
+            x0 = (0.9 * tb * (2 * torch.rand(n, generator=g) - 1))
+            _, _, _, knots, searched = _reference_bins(x0, uw, uh, ud, inv, kw)
+            assert bool(searched.all())
+            pick = torch.randint(0, K + 1, (n,), generator=g)
+            on = knots[torch.arange(n), pick]
+            f32 = np.float32
+            below = torch.from_numpy(np.nextafter(npy(on), f32(-np.inf)))
+            above = torch.from_numpy(np.nextafter(npy(on), f32(np.inf)))
+            shift = torch.randint(0, 3, (n,), generator=g)
+            x = torch.where(shift == 0, below, torch.where(shift == 1, on, above))
+            if inv:
+                # on a knot the reference's own discriminant can round below zero and its assertion
+                # (rational_quadratic.py:142) then rejects the whole batch: such elements (found one by one) keep
+                # their random position
+                bad = []
+                for i in range(n):
+                    try:
+                        _reference_bins(x[i:i + 1], uw[i:i + 1], uh[i:i + 1], ud[i:i + 1], inv, kw)
+                    except AssertionError:
+                        bad.append(i)
+                if bad:
+                    x[bad] = x0[bad]
+                    shift[bad] = 3
+                print("  %s inverse: %d of %d knot inputs trip the reference's discriminant assertion" % (tag, len(bad), n))
+            y, lad, full, knots2, _ = _reference_bins(x, uw, uh, ud, inv, kw)
+            name = "knots_%s_%s" % (tag, "inv" if inv else "fwd")
+            y64, lad64 = splines.unconstrained_rational_quadratic_spline(x.double(), uw.double(), uh.double(), ud.double(),
+                                                                         inverse=inv, **kw)
+            for k_, v_ in (("x", x), ("uw", uw), ("uh", uh), ("ud", ud), ("y", y), ("lad", lad), ("y64", y64),
+                           ("lad64", lad64), ("bin_idx", full), ("pick", pick), ("shift", shift)):
+                out[name + "/" + k_] = npy(v_)
+            # the searched elements' knots, scattered to the full shape (rows of elements in the tails: zeros)
+            kn_full = torch.zeros(n, K + 1)
+            inside = (x >= -tb) & (x <= tb)
+            kn_full[inside] = knots2
+            out[name + "/knots"] = npy(kn_full)
+            meta.append((name, int(inv), repr(sorted(kw.items()))))
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "rqs_bins.npz"), **out)
+    print("rqs_bins:", len(G["meta"]), "functional cases +", len(meta), "knot cases")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "binidx":
+        bin_index_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ar":
         sibling_autoregressive_cases()
         sys.exit(0)
@@ -1303,3 +1421,4 @@ if __name__ == "__main__":
     bin_count_flow_cases()
     activation_flow_cases()
     trained_flow_case()
+    bin_index_cases()

@@ -147,6 +147,49 @@ def assert_fp32_parity(got, ref, truth, tol, what="", bulk=0.999, factor=4.0, co
     assert_error_ratio(got, ref, truth, what, factor=2.0, max_factor=factor, max_floor=tol * (1 + np.abs(t64).max()))
 
 
+def knot_case_keep(got_y, ref_y, got_lad, ref_lad, status, inverse, what=""):
+    """The adversarial cases of rqs_bins.npz put inputs ON a knot.  In the inverse direction the discriminant
+    (rational_quadratic.py:141) is then a difference of nearly equal terms and can round below zero in one correct fp32
+    evaluation and not in another (the reference's own does for 3 of the generated inputs: its assertion :142 rejected
+    them, make_golden.py moved them; an implementation reports it as NFA_STATUS_NEG_DISCRIMINANT and NaN), and a root one
+    ulp outside [0, 1] can make the argument of a logarithm negative (the reference's own logabsdet is NaN at 6 of the
+    4096 steep inputs).  Returns the mask of the elements to compare: all of them in the forward direction (no status,
+    no NaN allowed), in the inverse those finite on both sides -- at least 99.5 % of them."""
+    got_y, ref_y, got_lad, ref_lad = (np.asarray(a) for a in (got_y, ref_y, got_lad, ref_lad))
+    if not inverse:
+        assert status == 0, (what, status)
+        assert np.array_equal(np.isnan(got_y), np.isnan(ref_y)) and np.array_equal(np.isnan(got_lad), np.isnan(ref_lad)), what
+        return np.ones(got_y.shape, dtype=bool)
+    assert status in (0, 2), (what, status)
+    keep = ~(np.isnan(got_y) | np.isnan(ref_y) | np.isnan(got_lad) | np.isnan(ref_lad))
+    assert keep.mean() >= 0.995, (what, float(keep.mean()))
+    return keep
+
+
+def assert_bins_match(got, ref, x, knots, what="", max_fraction=4e-6):
+    """Bin indices of a fused search against the oracle's on random inputs.  Equal -- except that two correct fp32
+    evaluations disagree on an input that sits between their two versions of a knot.  A knot is
+    RN(span * cumsum + left) (rational_quadratic.py:95): 1-ulp differences of exp / log move the prefix sum by an ulp
+    or two and the product with the span is rounded at magnitude ~ span, so two versions of a knot lie within a few
+    ulp(span) of each other (the oracle's against the real reference's: up to 4, tests/test_oracle_golden.py) and the probability of an input in between is ~ K x 2^-22 per element.  So: at most
+    `max_fraction` of the elements differ (4e-6: four per 2^20), each by ONE bin, each with the input within
+    6 ulp(span) of the oracle's knot between the two bins, and the tail decision (-1: a compare with +-B) never.
+    `knots` [n, K + 1]: the oracle's knots of the searched axis.  Returns the indices of the differing elements."""
+    got, ref = np.asarray(got).reshape(-1).astype(np.int64), np.asarray(ref).reshape(-1).astype(np.int64)
+    x = np.asarray(x).reshape(-1)
+    d = np.nonzero(got != ref)[0]
+    if d.size == 0:
+        return d
+    assert d.size <= max(1, int(np.ceil(max_fraction * got.size))), "%s: %d of %d bins differ" % (what, d.size, got.size)
+    assert np.all(np.abs(got[d] - ref[d]) == 1), what
+    assert not np.any((got[d] == -1) | (ref[d] == -1)), what
+    knots = np.asarray(knots).reshape(got.size, -1)
+    kn = knots[d, np.maximum(got[d], ref[d])]
+    span = (knots[d, -1] - knots[d, 0]).astype(np.float32)
+    assert np.all(np.abs(x[d].astype(np.float64) - kn.astype(np.float64)) <= 6 * np.spacing(span)), what
+    return d
+
+
 def parse_kwargs(text):
     import ast
     return dict(ast.literal_eval(text))

@@ -68,21 +68,24 @@ def test_spec_argument_errors_without_gpu():
     assert abs(spec.tail_logit - np.log(np.exp(1 - 1e-3) - 1)) == 0.0
     # batch == 0 is a valid no-op; negative sizes and bad enums are rejected
     null = None
-    assert lib.nfa_rqs_coupling_f32(null, null, null, null, null, null, null, null, 0, 64, 32,
+    assert lib.nfa_rqs_coupling_f32(null, null, null, null, null, null, null, null, null, 0, 64, 32,
                                     ctypes.byref(spec), 0, null) == N.OK
-    assert lib.nfa_rqs_coupling_f32(null, null, null, null, null, null, null, null, -1, 64, 32,
+    assert lib.nfa_rqs_coupling_f32(null, null, null, null, null, null, null, null, null, -1, 64, 32,
                                     ctypes.byref(spec), 0, null) == N.ERR_INVALID_ARGUMENT
-    assert lib.nfa_rqs_coupling_f32(null, null, null, null, null, null, null, null, 4, 64, 65,
+    assert lib.nfa_rqs_coupling_f32(null, null, null, null, null, null, null, null, null, 4, 64, 65,
                                     ctypes.byref(spec), 0, null) == N.ERR_INVALID_ARGUMENT
-    assert lib.nfa_rqs_coupling_f32(null, null, null, null, null, null, null, null, 4, 64, 32,
+    assert lib.nfa_rqs_coupling_f32(null, null, null, null, null, null, null, null, null, 4, 64, 32,
                                     ctypes.byref(spec), 0, null) == N.ERR_INVALID_ARGUMENT  # NULL data
     bad = ops.make_rqs_spec(8, "linear")
     bad.min_bin_width = 0.5
-    assert lib.nfa_rqs_coupling_f32(null, null, null, null, null, null, null, null, 0, 64, 32,
+    assert lib.nfa_rqs_coupling_f32(null, null, null, null, null, null, null, null, null, 0, 64, 32,
                                     ctypes.byref(bad), 0, null) == N.ERR_MIN_BIN_WIDTH
     assert lib.nfa_affine_coupling_f32(null, null, null, null, null, null, null, null, null, 4, 8, 4,
                                        99, 0, null) == N.ERR_INVALID_ARGUMENT
     assert lib.nfa_rowsum_f32(null, null, 0, 5, null) == N.OK
+    assert lib.nfa_searchsorted_f32(null, 0, 10, null, null, 0, 1e-6, null) == N.OK
+    assert lib.nfa_searchsorted_f32(null, 0, 0, null, null, 4, 1e-6, null) == N.ERR_INVALID_ARGUMENT
+    assert lib.nfa_searchsorted_f32(null, 0, 10, null, null, 4, 1e-6, null) == N.ERR_INVALID_ARGUMENT  # NULL data
     assert lib.nfa_permute_cols_b32(null, null, null, null, 3, 0, null) == N.ERR_INVALID_ARGUMENT
 
 
@@ -1571,6 +1574,60 @@ def test_run_level_weight_fingerprint_and_verification(monkeypatch):
     assert p4 is not p3
     for _ in range(20):                                                 # and nothing is raised on consistent weights
         assert plan()[1] is p4
+
+
+def test_a_plan_miss_does_not_launder_a_data_write(monkeypatch):
+    """`_run_plan` used to re-record every layer's checksum on EVERY plan-cache miss -- also on
+    misses that have nothing to do with the weights (the first inverse / sample() call, a batch crossing the 16-sample
+    tile threshold, an evicted plan).  The per-layer packs are keyed on version counters and storage pointers, so after
+    `p.data.mul_(2)` (EMA swap, dist.broadcast) the new plan was built from the OLD packs and the guard never fired: train
+    -> EMA swap -> sample().  Now a miss COMPARES the layers whose key is unchanged: StalePackedWeights; after
+    invalidate_packed_weights() the new plan holds the NEW weights; NaN weights are not reported as stale; a sign flip
+    is seen (the checksum has a signed component)."""
+    import torch
+    import nflows_amd
+    from nflows_amd import configs
+    from nflows_amd.transforms import coupling as C
+    flow = configs.rq_nsf_flow(4, 16, 8, 32, seed=3).eval()
+    T = flow._transform
+    layers = list(T._transforms)
+    x = torch.zeros(128, 16)
+    monkeypatch.setattr(C, "VERIFY_WEIGHTS_EVERY", 1 << 20)             # (the staggered check out of the way: the miss alone)
+
+    def plan(inverse):
+        with torch.no_grad():
+            order = layers[::-1] if inverse else layers
+            units, after = T._collect_run(order, 0, x, None, inverse)
+            assert len(units) == 4
+            return T._run_plan(units, inverse, False)
+
+    p_fwd = plan(False)
+    w = layers[3].transform_net.blocks[0].linear_layers[1].weight
+    w.data.mul_(2.0)                                                    # invisible to the keys
+    with pytest.raises(C.StalePackedWeights):
+        plan(True)                                                      # first inverse call: a miss -- and a comparison
+    nflows_amd.invalidate_packed_weights()
+    p_inv = plan(True)
+    p_fwd2 = plan(False)
+    assert p_fwd2 is not p_fwd and not torch.equal(p_fwd2[0], p_fwd[0])  # packed from the doubled weights
+    assert plan(True) is p_inv
+    # a sign flip leaves L1 / L2 norms alone; the shifted norm sees it
+    b = layers[1].transform_net.final_layer.bias
+    with torch.no_grad():
+        b.copy_(torch.linspace(-1.0, 2.0, b.numel()))
+    plan(False)
+    T.__dict__["_run_plans"].clear()
+    b.data.neg_()
+    with pytest.raises(C.StalePackedWeights):
+        plan(False)
+    nflows_amd.invalidate_packed_weights()
+    plan(False)
+    # diverged weights: NaN compares equal to NaN (the kernels propagate it like the reference), no exception
+    with torch.no_grad():
+        b.fill_(float("nan"))
+    plan(False)
+    T.__dict__["_run_plans"].clear()
+    plan(False)
 
 
 def test_binding_arities_match_the_header():

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from _hostcore import rqs_f32_host
-from helpers import LAD_TOL, OUT_TOL, assert_fp32_parity, conditioning, parse_kwargs
+from helpers import LAD_TOL, OUT_TOL, assert_bins_match, assert_fp32_parity, conditioning, parse_kwargs
 from oracle import capi
 
 
@@ -93,6 +93,64 @@ def test_forward_values_of_the_kernel_source_match_the_reference(lib, golden_dir
                 assert np.all(lad[outside] == 0), what
             runs += 1
     assert runs >= 80
+
+
+def test_bin_index_of_the_kernel_source(lib, golden_dir):
+    """What K1 / K5 store to `bin_idx` (rqs_eval's `bin`) on the CPU: EXACTLY the reference's bin_idx
+    (rational_quadratic.py:115-118, caught inside the real reference: rqs_bins.npz) on the 24 functional cases, every
+    instance; the oracle's on 2^20 random elements per configuration under helpers.assert_bins_match (equal but for an
+    input between two versions of a knot: at most four per 2^20, by one bin, within 4 ulp(span) of the oracle's
+    knot -- the rule of the GPU test); neighbours only on the inputs placed ON the reference's knots.  K8h's
+    evaluation (FusedSteps: fp32 running knot sums, no index on the data path; `kbin` of its diagnostic form) may differ
+    from the oracle on a random element with probability ~1e-6 -- an input within an ulp of a knot --, and never by more
+    than one bin."""
+    G = np.load(os.path.join(golden_dir, "rqs_functional.npz"))
+    B = np.load(os.path.join(golden_dir, "rqs_bins.npz"))
+    for name, inv, kw in G["meta"]:
+        kw = parse_kwargs(kw)
+        x, uw, uh, ud = (G[name + "/" + k] for k in ("x", "uw", "uh", "ud"))
+        K = uw.shape[-1]
+        spec = product_spec(K, **dict(kw))
+        xs, pr = np.ascontiguousarray(x.reshape(-1)), packed(uw, uh, ud)
+        for kt in [0] + ([K] if K in (4, 8, 10) else []):
+            bins = np.full(xs.size, -9, np.int32)
+            lib.host_rqs_bins(kt, int(inv), xs.size, ctypes.byref(spec), P(xs), P(pr), P(bins))
+            assert np.array_equal(bins.astype(np.int64), B[name + "/bin_idx"].reshape(-1)), (name, kt)
+    for name, inv, kw in B["meta"]:
+        kw = parse_kwargs(kw)
+        x, uw, uh, ud = (B[name + "/" + k] for k in ("x", "uw", "uh", "ud"))
+        K = uw.shape[-1]
+        spec = product_spec(K, **dict(kw))
+        xs, pr = np.ascontiguousarray(x), packed(uw, uh, ud)
+        ref = B[name + "/bin_idx"]
+        bins = np.full(xs.size, -9, np.int32)
+        lib.host_rqs_bins(K, int(inv), xs.size, ctypes.byref(spec), P(xs), P(pr), P(bins))
+        assert np.abs(bins - ref).max() <= 1 and np.array_equal(bins == -1, ref == -1), name
+        assert (bins != ref).mean() < 0.2, name
+        if K == 8:
+            y, lad, fb = np.empty_like(xs), np.empty_like(xs), np.full(xs.size, -9, np.int32)
+            lib.host_rqs_forward_fused_bins(int(inv), 1.0, xs.size, ctypes.byref(spec), P(xs), P(pr), P(y), P(lad), P(fb))
+            assert np.abs(fb - ref).max() <= 1 and np.array_equal(fb == -1, ref == -1), name
+    rng = np.random.default_rng(5)
+    n = 1 << 20
+    for K, scale in ((8, 1.0), (8, 3.0), (10, 2.0), (5, 2.0)):
+        spec = product_spec(K, tails="linear", tail_bound=3.0)
+        ospec = capi.make_spec(K, tails="linear", tail_bound=3.0)
+        for inverse in (False, True):
+            x = (rng.standard_normal(n) * 1.5).astype(np.float32)
+            pr = (rng.standard_normal((n, 3 * K - 1)) * scale).astype(np.float32)
+            oy, ol, _, ob = capi.rqs_elementwise(x, pr[:, :K], pr[:, K:2 * K], pr[:, 2 * K:], ospec, inverse=inverse,
+                                                 return_bins=True)
+            knots = capi.rqs_knots(pr[:, K:2 * K] if inverse else pr[:, :K], ospec, axis=int(inverse))
+            bins = np.full(n, -9, np.int32)
+            lib.host_rqs_bins(K if K in (8, 10) else 0, int(inverse), n, ctypes.byref(spec), P(x), P(pr), P(bins))
+            assert_bins_match(bins, ob, x, knots, "rqs_eval K=%d scale=%g inverse=%d" % (K, scale, inverse))
+            if K == 8:
+                y, lad, fb = np.empty_like(x), np.empty_like(x), np.full(n, -9, np.int32)
+                lib.host_rqs_forward_fused_bins(int(inverse), 1.0, n, ctypes.byref(spec), P(x), P(pr), P(y), P(lad), P(fb))
+                d = assert_bins_match(fb, ob, x, knots, "FusedSteps scale=%g inverse=%d" % (scale, inverse), max_fraction=1.6e-5)
+                # at exactly those elements: the outputs within the tolerance (continuity across the knot)
+                assert np.all(np.abs(y[d] - oy[d]) <= 8 * OUT_TOL * (1 + np.abs(oy[d]))), (scale, inverse)
 
 
 def test_gradients_of_the_kernel_source_match_the_reference_autograd(lib, golden_dir):

@@ -37,6 +37,13 @@ def main(d, out, pat="rqs_coupling_pipelined", algorithmic=None, command=None):
            else 4 * (65536 * 64 * 2 + 65536 * 32 * 23 + 65536),
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `%s`; "
                      "gfx950 x2 correction on reads" % (command or "python bench.py --steps 3 --warmup 1 --no-cpu-baseline")}
+    try:  # the digest of the kernel's sources: bench.py quotes these counters only while they are unchanged
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        res["kernel_source_sha256"] = bench.kernel_source_digest(os.path.basename(out))
+    except Exception as e:
+        res["kernel_source_sha256"] = None
+        res["digest_error"] = repr(e)
     try:  # an explanatory note written into the previous file by hand travels along
         note = json.load(open(out)).get("note")
         if note:
