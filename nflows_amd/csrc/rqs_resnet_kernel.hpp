@@ -230,6 +230,15 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         if (used && (v < 0 || v >= D)) my_status |= NFA_STATUS_BAD_INDEX;
         return v < 0 ? 0 : (v >= D ? D - 1 : v);
     };
+    // Second pass behind K8h / K8s (round 5): in the common step NO block is flagged and this launch used to cost a
+    // weight-ring prologue (two 12 KB stages per workgroup) before its workgroups found that out quad by quad.  Now
+    // the workgroup looks at the flags of ITS quads first and leaves when none is set.
+    if (a.redo) {
+        int any = 0;
+        const int64_t quads = a.batch >> 7;
+        for (int64_t q = blockIdx.x + (int64_t)gridDim.x * tid; q < quads; q += (int64_t)gridDim.x * kBlock) any |= a.redo[q];
+        if (__syncthreads_or(any) == 0) return;
+    }
     if (tid < kTabLayer) {
         s_tab[0][tid] = checked(a.tables[tid], tid < kTabTr ? tid < a.di : tid - kTabTr < dt);
         s_final[tid] = checked(a.tables[a.num_layers * kTabLayer + tid], tid < D);

@@ -1360,7 +1360,35 @@ def bin_index_cases():
     print("rqs_bins:", len(G["meta"]), "functional cases +", len(meta), "knot cases")
 
 
+def config5_inverse_case():
+    """BASELINE configs[4] by name: MaskedPiecewiseRationalQuadraticAutoregressiveTransform(features=784,
+    hidden_features=256, num_bins=8, tails="linear", tail_bound=3.0, num_blocks=2), the INVERSE (sampling) direction --
+    the reference's 784-pass loop (autoregressive.py:43-52) on 64 rows in fp32 and fp64.  Until round 4 the GPU test ran
+    that loop on the GPU box's CPU through the port (147 s of a 538 s suite); the real reference's result is a fixture
+    now.  Weights from the seed (checksums stored), as configs.ar_rq_flow builds them."""
+    torch.manual_seed(0)
+    t = MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
+        features=784, hidden_features=256, num_bins=8, tails="linear", tail_bound=3.0, num_blocks=2)
+    flow = Flow(CompositeTransform([t]), StandardNormal([784])).eval()
+    z = torch.randn(4096, 784, generator=torch.Generator().manual_seed(4321))[:64]
+    with torch.no_grad():
+        x32, lad32 = flow._transform.inverse(z)
+        f64 = flow.double()
+        x64, lad64 = f64._transform.inverse(z.double())
+        flow.float()
+    out = {"cfg5/z": npy(z), "cfg5/inv_x": npy(x32), "cfg5/inv_lad": npy(lad32), "cfg5/inv_x64": npy(x64), "cfg5/inv_lad64": npy(lad64)}
+    sums = [[float(v.double().sum()), float(v.double().abs().sum())] for v in flow.state_dict().values()]
+    out["cfg5/param_checksums"] = np.array(sums, dtype=np.float64)
+    out["meta"] = np.array([("cfg5", repr(dict(kind="ar_rq", D=784, H=256, K=8, tail_bound=3.0, num_blocks=2, seed=0, rows=64,
+                                               batch_seed=4321)))], dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "config5_inverse.npz"), **out)
+    print("config5_inverse: 64 rows")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg5":
+        config5_inverse_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "binidx":
         bin_index_cases()
         sys.exit(0)
@@ -1422,3 +1450,4 @@ if __name__ == "__main__":
     activation_flow_cases()
     trained_flow_case()
     bin_index_cases()
+    config5_inverse_case()

@@ -7,11 +7,11 @@ default parameters, tanh), K8h for 8 and 10 bins, K8 -- its second pass and the 
 
   * tests/golden/flows_acts.npz: the REAL reference on steep two-layer flows with leaky-ReLU / ELU / tanh conditioners
     (8 and 10 bins), forward and inverse, fp32 and fp64; the eager port (which runs the flow's own modules) reproduces it
-    bit for bit (tests/test_oracle_golden.py), so the rows behind the fixture's 128 are held to the port: 8 192 rows;
+    bit for bit (tests/test_oracle_golden.py), so the rows behind the fixture's 128 are held to the port: 65 536 rows per engine (round 5);
   * engines driven explicitly, the kernel that ran read back: K8h eight-wave (65 536 rows), K8h four-wave, K8, and the
     layer-by-layer path these layers took before (conditioner modules + the final Linear fused with the spline / K1);
-  * the headline rule: error against float64 at most 2 x the reference-fp32's own on the mean, 2.5 x on the 99.9 %
-    quantile of the 8 192 rows (see tests/test_gpu_bins.py; measured at most 1.93 x);
+  * the headline rule: error against float64 at most 2 x the reference-fp32's own on the mean and on the 99.9 % quantile,
+    at most eight elements above 4 x the reference's maximum (see tests/test_gpu_bins.py);
   * the per-element arithmetic of `activate<ACT>` runs in the CPU suite against torch (tests/test_rqs_f32_host.py).
 """
 import copy
@@ -23,6 +23,7 @@ from helpers import steep_flow
 from test_gpu_headline_parity import _report
 from test_gpu_steep import _batch, _check_all, _status, engine_switches  # noqa: F401  (fixture)
 from test_gpu_bins import _oracle, ROWS
+from test_gpu_steep import _chunked
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -54,20 +55,28 @@ def test_other_activations_on_every_engine(golden_dir, engine_switches, case, en
     engine_switches(switches["path"], switches["engine"], True)
     _status(case, clear=True)
     ran = {}
+    redo = {"f": 0, "i": 0}
+
+    def counted(fn, key):
+        def run(t):
+            out = fn(t)
+            if engine.startswith("k8h"):
+                redo[key] += ops.last_redo_blocks()
+            return out
+        return run
     with torch.no_grad():
-        z, lad = flow._transform(x[:rows].to(DEV))
+        z, lad = _chunked(counted(flow._transform, "f"), x, rows)
         ran["forward"] = ops.last_layer_kernel()
-        redo_f = ops.last_redo_blocks() if engine.startswith("k8h") else 0
-        lp = flow.log_prob(x[:rows].to(DEV))
-        xi, ladi = flow._transform.inverse(noise[:rows].to(DEV))
+        lp = _chunked(flow.log_prob, x, rows)
+        xi, ladi = _chunked(counted(flow._transform.inverse, "i"), noise, rows)
         ran["inverse"] = ops.last_layer_kernel()
-        redo_i = ops.last_redo_blocks() if engine.startswith("k8h") else 0
+    redo_f, redo_i = redo["f"], redo["i"]
     for direction, label in ran.items():
         for piece in expect:
             assert piece in label, "%s %s ran %r, expected %r" % (engine, direction, label, expect)
     _report({"config": "%s_%s" % (case, engine), "kernels": ran, "rows": rows, "redo_blocks": [redo_f, redo_i]})
-    _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS, q_factor=2.5)
-    assert redo_f + redo_i <= max(1, rows // 128 // 100), "the f16 engine handed %d + %d row blocks to the exact kernel" % (redo_f, redo_i)
+    _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS)
+    assert redo_f + redo_i <= max(1, ROWS // 128 // 100), "the f16 engine handed %d + %d row blocks to the exact kernel" % (redo_f, redo_i)
     _status("%s_%s" % (case, engine))
 
 

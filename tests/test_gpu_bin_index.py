@@ -184,10 +184,13 @@ def test_k5_bin_index_on_a_million_random_elements(ops, K, scale, inverse):
 
 
 # K1: which kernel, by shape -- (features, transformed features (first ones of an alternating / custom mask), bins, rows)
+# (`kernel`: the LAST launch of the call -- a ragged batch ends with the generic kernel on the rows behind the last full tile)
 K1_SHAPES = {
-    "wavetile": (64, 32, 8, 32768 + 3, "rqs_coupling_wavetile<K=8"),
+    "wavetile": (64, 32, 8, 32768, "rqs_coupling_wavetile<K=8"),
+    "wavetile_ragged": (64, 32, 8, 8192 + 3, "rqs_coupling_kernel<K=8"),
     "wavetile_k10": (32, 16, 10, 16384, "rqs_coupling_wavetile<K=10"),
-    "pipelined": (96, 32, 8, 16384 + 5, "rqs_coupling_pipelined<K=8"),
+    "pipelined": (96, 32, 8, 16384, "rqs_coupling_pipelined<K=8"),
+    "pipelined_ragged": (96, 32, 8, 4096 + 5, "rqs_coupling_kernel<K=8"),
     "generic": (10, 5, 5, 40000, "rqs_coupling_kernel<K=0"),
 }
 
@@ -203,7 +206,7 @@ def test_k1_bin_index(ops, shape, inverse):
     P = 3 * K - 1
     x = (rng.standard_normal((rows, D)) * 1.5).astype(np.float32)
     params = (rng.standard_normal((rows, dt * P)) * 12.0).astype(np.float32)   # (/ sqrt(128): logits ~ N(0, 1))
-    tidx = np.sort(rng.permutation(D)[:dt]).astype(np.int64) if shape in ("pipelined", "generic") else np.arange(0, D, 2, dtype=np.int64)
+    tidx = np.sort(rng.permutation(D)[:dt]).astype(np.int64) if shape.startswith(("pipelined", "generic")) else np.arange(0, D, 2, dtype=np.int64)
     perm = rng.permutation(D).astype(np.int64)
     H = 128
     spec = ops.make_rqs_spec(K, "linear", tail_bound=3.0, wh_divisor=math.sqrt(H))

@@ -14,8 +14,9 @@ What is held to what:
   * every engine is driven explicitly and the kernel that ran is read back from the library: K8h eight-wave (65 536
     rows) and four-wave, K8 (bf16x3), GEMMs + K1 (the path these layers took before);
   * the headline rule (tests/test_gpu_headline_parity.compare): error against float64 at most 2 x the reference-fp32's
-    own on the mean, 2.5 x on the 99.9 % quantile (of 8 192 rows: their 8th largest value, an order statistic with ~ 35 %
-    sampling noise -- measured at most 1.97 x, and that on K8, whose spline arithmetic is the reference's), no floor;
+    own on the mean AND on the 99.9 % quantile, no floor, on 65 536 rows per engine (round 5; round 4 compared 8 192 rows,
+    whose 99.9 % quantile is their 8th largest value, and allowed 2.5 x for it); at most eight elements above 4 x the
+    reference's own maximum instead of a factor on the single worst element;
   * the BASELINE widths: D = 64 (d_t = 32: at 11+ bins the layer's parameter words need a second parameter stage) and
     D = 128 (64 identity features: four k-steps in the initial layer) on four-layer flows, against the port.
 """
@@ -28,12 +29,13 @@ import torch
 
 from helpers import LAD_TOL, OUT_TOL, steep_flow, steepen
 from test_gpu_headline_parity import compare, _report
-from test_gpu_steep import _batch, _check_all, _status, engine_switches  # noqa: F401  (fixture)
+from test_gpu_steep import MAX_COUNT, _batch, _check_all, _chunked, _status, engine_switches  # noqa: F401  (fixture)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 BIN_COUNTS = (2, 3, 4, 5, 6, 7, 9, 11, 12, 13, 16, 20, 24, 32)
-ROWS = 8192
+ROWS = 65536            # rows every engine is compared on (the fixture's 128 + rows held to the eager port)
+WIDTH_ROWS = 16384      # test_other_bin_counts_at_the_baseline_widths: four-layer flows up to D = 128 / 32 bins
 _oracle_cache = {}
 
 
@@ -85,25 +87,33 @@ def test_other_bin_counts_on_every_engine(golden_dir, engine_switches, K, engine
     engine_switches(switches["path"], switches["engine"], True)
     _status(case, clear=True)
     ran = {}
+    redo = {"f": 0, "i": 0}
+
+    def counted(fn, key):
+        def run(t):
+            out = fn(t)
+            if engine.startswith("k8h"):
+                redo[key] += ops.last_redo_blocks()
+            return out
+        return run
     with torch.no_grad():
-        z, lad = flow._transform(x[:rows].to(DEV))
+        z, lad = _chunked(counted(flow._transform, "f"), x, rows)
         ran["forward"] = ops.last_layer_kernel()
-        redo_f = ops.last_redo_blocks() if engine.startswith("k8h") else 0
-        lp = flow.log_prob(x[:rows].to(DEV))
-        xi, ladi = flow._transform.inverse(noise[:rows].to(DEV))
+        lp = _chunked(flow.log_prob, x, rows)
+        xi, ladi = _chunked(counted(flow._transform.inverse, "i"), noise, rows)
         ran["inverse"] = ops.last_layer_kernel()
-        redo_i = ops.last_redo_blocks() if engine.startswith("k8h") else 0
+    redo_f, redo_i = redo["f"], redo["i"]
     for direction, label in ran.items():
         for piece in expect:
             assert piece in label, "%s %s ran %r, expected %r" % (engine, direction, label, expect)
         if engine != "gemm_k1":
             assert ("inverse=1" in label) == (direction == "inverse"), label
     _report({"config": "%s_%s" % (case, engine), "kernels": ran, "rows": rows, "redo_blocks": [redo_f, redo_i]})
-    _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS, q_factor=2.5)
+    _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS)
     # (a row block in which the f16 engine meets a non-finite value -- on splines this steep about one evaluation in a
     #  million rounds a discriminant below zero in ANY fp32 arithmetic, the reference's included -- is handed to the exact
     #  kernel: by design, reported above.  More than 1 % of the blocks would mean the figures are not the engine's own.)
-    assert redo_f + redo_i <= max(1, rows // 128 // 100), "the f16 engine handed %d + %d row blocks to the exact kernel" % (redo_f, redo_i)
+    assert redo_f + redo_i <= max(1, ROWS // 128 // 100), "the f16 engine handed %d + %d row blocks to the exact kernel" % (redo_f, redo_i)
     _status("%s_%s" % (case, engine))
 
 
@@ -121,33 +131,34 @@ def test_other_bin_counts_at_the_baseline_widths(engine_switches, K, D):
     x = torch.randn(65536, D, generator=gen) * 1.2
     noise = torch.randn(65536, D, generator=gen)
     key = "deep_k%d_d%d" % (K, D)
-    o = _oracle(key, flow_cpu, x, noise)
+    o = _oracle(key, flow_cpu, x, noise, rows=WIDTH_ROWS)
     flow = copy.deepcopy(flow_cpu).to(DEV).eval()
-    for engine, rows in (("k8h_w8", 65536), ("k8h_w4", 8192 + 40)):   # (a ragged batch on the four-wave form)
+    for engine, rows in (("k8h_w8", 65536), ("k8h_w4", 8192 + 40)):   # (a ragged batch on the four-wave form: two launches cover the oracle rows)
         engine_switches("k8", "f16x2", True)
         _status(key, clear=True)
+        n_eval = 65536 if engine == "k8h_w8" else 2 * rows
         with torch.no_grad():
-            z, lad = flow._transform(x[:rows].to(DEV))
+            z, lad = _chunked(flow._transform, x[:n_eval], rows)
             label_f = ops.last_layer_kernel()
             redo = ops.last_redo_blocks()
-            lp = flow.log_prob(x[:rows].to(DEV))
-            xi, ladi = flow._transform.inverse(noise[:rows].to(DEV))
+            lp = _chunked(flow.log_prob, x[:n_eval], rows)
+            xi, ladi = _chunked(flow._transform.inverse, noise[:n_eval], rows)
             label_i = ops.last_layer_kernel()
             redo += ops.last_redo_blocks()
-            xr, _ = flow._transform.inverse(z)
+            xr, _ = _chunked(flow._transform.inverse, z.cpu(), rows)
         for label in (label_f, label_i):
             assert "k8h::" in label and "K=%d," % K in label and ("waves=8" if engine == "k8h_w8" and D < 128 else "waves=4") in label, label   # (D = 128: eight row tiles do not fit beside the ring)
             assert ("init_ks=4" in label) == (D == 128), label
         config = "%s_%s" % (key, engine)
         for k, t, tol in (("z", z, OUT_TOL), ("lad", lad, LAD_TOL), ("lp", lp, LAD_TOL), ("xi", xi, OUT_TOL), ("ladi", ladi, LAD_TOL)):
-            compare(config, k, t[:ROWS].cpu().numpy(), o[k + "32"], o[k + "64"], tol, max_factor=8.0, q_factor=2.5)
+            compare(config, k, t[:WIDTH_ROWS].cpu().numpy(), o[k + "32"], o[k + "64"], tol, max_count=MAX_COUNT)
         assert redo <= max(1, rows // 128 // 100), redo
         nflows_amd.check_status()
-        err = (xr.cpu() - x[:rows]).abs()
+        err = (xr.cpu() - x[:n_eval]).abs()
         with torch.no_grad():
             from oracle import eager
             xr_ref, _ = eager.flow_transform(flow_cpu, torch.from_numpy(o["z32"]), inverse=True)
-        ref = (xr_ref - x[:ROWS]).abs()
+        ref = (xr_ref - x[:WIDTH_ROWS]).abs()
         _report({"config": config, "what": "|inv(fwd(x)) - x|", "mean": float(err.mean()), "max": float(err.max()),
                  "reference_fp32_mean": float(ref.mean()), "reference_fp32_max": float(ref.max()), "kernels": [label_f, label_i]})
-        assert float(err[:ROWS].mean()) <= 2.0 * float(ref.mean()), (float(err[:ROWS].mean()), float(ref.mean()))
+        assert float(err[:WIDTH_ROWS].mean()) <= 2.0 * float(ref.mean()), (float(err[:WIDTH_ROWS].mean()), float(ref.mean()))

@@ -50,27 +50,38 @@ def _stats(err):
     return {"max": float(err.max()), "mean": float(err.mean()), "q999": float(np.quantile(err, 0.999))}
 
 
-def compare(config, what, got, ref32, truth, tol, max_factor=FACTOR, q_factor=FACTOR):
+def compare(config, what, got, ref32, truth, tol, max_factor=FACTOR, q_factor=FACTOR, max_count=None):
     """got / ref32: float32 arrays, truth: float64.  Asserts the 2x bound on max, mean and the
-    99.9 % quantile (`max_factor`: the bound on the maximum alone; `q_factor`: on the quantile alone -- for
-    8 192 per-row values the 99.9 % quantile is their 8th largest, an order statistic with ~ 35 % sampling noise:
-    the exact-arithmetic engine K8 itself reaches 1.97 x there); returns the figures."""
+    99.9 % quantile (`max_factor`: the bound on the maximum alone; `q_factor`: on the quantile alone); returns the
+    figures.
+    `max_count` (round 5, the steep fixtures at 65 536 rows): the maximum of a heavy-tailed error -- the reference's own
+    is 1e3 .. 1e4 x its mean there -- is ONE element's luck and was bounded by factors of 8 .. 32 in round 4, which
+    bounds nothing.  With `max_count` the maximum is not compared; instead the NUMBER of elements whose error exceeds
+    4 x the reference-fp32's own maximum (+ four ulps of the largest value) must not exceed `max_count`: a correct
+    implementation puts an element there once in a while, a defect puts many."""
     got64 = got.astype(np.float64)
     assert np.array_equal(np.isfinite(got), np.isfinite(ref32)), "%s %s: non-finite pattern differs" % (config, what)
     fin = np.isfinite(truth)
-    e_got = _stats(np.abs(got64 - truth)[fin])
+    err_got = np.abs(got64 - truth)[fin]
+    e_got = _stats(err_got)
     e_ref = _stats(np.abs(ref32.astype(np.float64) - truth)[fin])
     floor = 4.0 * 2.0 ** -23 * float(np.abs(truth[fin]).max())   # four ulps of the largest value, maximum only
-    entry = {"config": config, "what": what, "rows": int(got.shape[0]), "hip_vs_fp64": e_got,
-             "reference_fp32_vs_fp64": e_ref, "floor_on_max": floor,
+    over = int((err_got > 4.0 * e_ref["max"] + floor).sum())
+    entry = {"config": config, "what": what, "rows": int(got.shape[0]), "elements": int(err_got.size), "hip_vs_fp64": e_got,
+             "reference_fp32_vs_fp64": e_ref, "floor_on_max": floor, "elements_above_4x_reference_max": over,
              "ratio": {k: e_got[k] / max(e_ref[k], 1e-300) for k in e_got},
              "bulk_within_tol_of_reference_fp32": bulk_fraction(got, ref32, tol), "tol": tol}
     _report(entry)
     for k in ("max", "mean", "q999"):
+        if k == "max" and max_count is not None:
+            assert over <= max_count, ("%s %s: %d elements with an error above 4 x the reference fp32's maximum %.3e (allowed: %d)"
+                                       % (config, what, over, e_ref["max"], max_count))
+            continue
         bound = (max_factor if k == "max" else q_factor if k == "q999" else FACTOR) * e_ref[k] + (floor if k == "max" else 0.0)
         assert e_got[k] <= bound, (
             "%s %s: %s error vs float64 %.3e exceeds %.1f x the reference fp32's %.3e%s"
-            % (config, what, k, e_got[k], FACTOR, e_ref[k], " (+ %.1e)" % floor if k == "max" else ""))
+            % (config, what, k, e_got[k], max_factor if k == "max" else q_factor if k == "q999" else FACTOR, e_ref[k],
+               " (+ %.1e)" % floor if k == "max" else ""))
     return entry
 
 
@@ -414,30 +425,29 @@ def test_whole_layer_kernel_is_bit_deterministic_across_fresh_flows():
     assert not deviations, deviations
 
 
-def test_config5_autoregressive_inverse_against_the_reference_loop():
+def test_config5_autoregressive_inverse_against_the_reference_loop(golden_dir):
     """configs[4]'s NAMED path: the inverse (sampling direction) of the autoregressive RQ layer at D = 784,
-    H = 256, B = 4 096 -- degree-ordered evaluation + the persistent kernel K12 -- against the reference's
-    784-pass loop (autoregressive.py:43-52, oracle/eager.py: pinned bit for bit on the reference's own
-    vectors) in float32 and float64 on the first 64 rows."""
+    H = 256, B = 4 096 -- degree-ordered evaluation + the persistent kernel K12 -- against the REAL reference's
+    784-pass loop (autoregressive.py:43-52) in float32 and float64 on the first 64 rows: tests/golden/config5_inverse.npz
+    (make_golden.py `cfg5`; until round 4 this test ran the loop through the port on the GPU box's CPU: 147 s of the
+    suite).  The flow is rebuilt from its seed; the fixture's per-parameter checksums say it is the reference's."""
     from nflows_amd import configs
     import copy
     import nflows_amd
+    g = np.load(os.path.join(golden_dir, "config5_inverse.npz"))
     flow_cpu = configs.ar_rq_flow(features=784, hidden_features=256, num_bins=8, tail_bound=3.0, seed=0).eval()
+    sums = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in flow_cpu.state_dict().values()])
+    assert sums.shape == g["cfg5/param_checksums"].shape and np.allclose(sums, g["cfg5/param_checksums"], rtol=1e-12, atol=0)
     z = torch.randn(4096, 784, generator=torch.Generator().manual_seed(4321))
+    assert np.array_equal(z[:64].numpy(), g["cfg5/z"])
     flow = copy.deepcopy(flow_cpu).to(DEV).eval()
     with torch.no_grad():
         x, lad = flow._transform.inverse(z.to(DEV))
         x_solo, lad_solo = flow._transform.inverse(z[:64].to(DEV))
     nflows_amd.check_status()
     assert torch.equal(x_solo, x[:64]) and torch.equal(lad_solo, lad[:64])
-    from oracle import eager
-    with torch.no_grad():
-        x32, lad32 = eager.flow_transform(flow_cpu, z[:64], inverse=True)
-        f64 = flow_cpu.double()
-        x64, lad64 = eager.flow_transform(f64, z[:64].double(), inverse=True)
-        flow_cpu.float()
-    compare("cfg5_ar_rq_d784_k8_b4096_inverse", "x", x[:64].cpu().numpy(), x32.numpy(), x64.numpy(), OUT_TOL)
-    compare("cfg5_ar_rq_d784_k8_b4096_inverse", "logabsdet", lad[:64].cpu().numpy(), lad32.numpy(), lad64.numpy(), LAD_TOL)
+    compare("cfg5_ar_rq_d784_k8_b4096_inverse", "x", x[:64].cpu().numpy(), g["cfg5/inv_x"], g["cfg5/inv_x64"], OUT_TOL)
+    compare("cfg5_ar_rq_d784_k8_b4096_inverse", "logabsdet", lad[:64].cpu().numpy(), g["cfg5/inv_lad"], g["cfg5/inv_lad64"], LAD_TOL)
 
 
 def _spread_rows(weight, decades, gen):

@@ -16,8 +16,9 @@ only, which the reference's own worst ill-conditioned element dominates.  Here
     library (`nfa_last_layer_kernel`): K8h eight-wave and four-wave, K8s eight-wave and four-wave, K8, K7b, K7,
     GEMMs + K1 (wave-tile and register-pipelined form); K11 and K2 for the affine analogue; K13 / K12 (+ the column-wise path) for the autoregressive layer;
   * the rule is the headline rule (tests/test_gpu_headline_parity.compare): error against float64 at most 2 x the
-    reference-fp32's own on the MEAN and the 99.9 % QUANTILE with no floor (4 x + four ulps on the single worst
-    element);
+    reference-fp32's own on the MEAN and the 99.9 % QUANTILE with no floor, on 65 536 rows per engine (round 5: the
+    quantile is the 65th largest value, no looser factor for small samples any more); instead of a factor on the single
+    worst element, at most eight elements above 4 x the reference's own maximum;
   * the fixture's 512 rows sit at the head of a batch large enough for the instance under test; the rows behind them
     are held to oracle/eager.py (bit-identical to the reference on this very fixture:
     tests/test_oracle_golden.py::test_eager_port_bit_identical_on_steep_flows).
@@ -38,7 +39,9 @@ from test_gpu_headline_parity import compare, _report
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-ORACLE_ROWS = 16384         # fixture rows (512) + rows held to the eager port (per-row log-determinants: the 99.9 % quantile is the 16th largest)
+ORACLE_ROWS = 65536         # fixture rows (512) + rows held to the eager port: the 99.9 % quantile of the per-row log-determinants is
+                            # their 65th largest value (round 4 compared 16 384 rows and had to loosen the quantile's factor instead)
+MAX_COUNT = 8               # elements allowed above 4 x the reference-fp32's own maximum error (see compare)
 _oracle_cache = {}
 
 
@@ -101,13 +104,22 @@ def _status(config, clear=False):
             _report({"config": config, "status": str(e)})
 
 
-def _check_all(config, name, g, o, z, lad, lp, xi, ladi, rows=ORACLE_ROWS, q_factor=2.0):
+def _chunked(fn, t, rows):
+    """`fn` on consecutive chunks of `rows` rows (the launch size that selects the kernel instance under test), results
+    concatenated: every engine is compared on ALL oracle rows."""
+    outs = [fn(t[i:i + rows].to(DEV)) for i in range(0, t.shape[0], rows)]
+    if isinstance(outs[0], tuple):
+        return tuple(torch.cat([o[j] for o in outs], 0) for j in range(len(outs[0])))
+    return torch.cat(outs, 0)
+
+
+def _check_all(config, name, g, o, z, lad, lp, xi, ladi, rows=ORACLE_ROWS, q_factor=2.0, max_count=MAX_COUNT):
     """the fixture rows against the reference's own vectors, all oracle rows against the eager port (bit-identical
     to the reference on the fixture: tests/test_oracle_golden.py::test_eager_port_bit_identical_on_steep_flows).
-    On the maximum the factor is 32 (gross defects only): with errors this heavy-tailed -- the reference's own maximum
-    is 1e3 .. 1e4 x its mean -- the worst of 16 384 rows is a different element in every correct implementation
-    (measured: 0.2 .. 10 x between the eight engines and three seeds, profiles/r4/steep_parity.jsonl); the defect this
-    file is for moved it by 16 .. 120 x AND the mean by 2.5 x."""
+    Mean and 99.9 % quantile of the error against float64: at most 2 x the reference-fp32's own, no floor.  The maximum
+    of errors this heavy-tailed -- the reference's own is 1e3 .. 1e4 x its mean -- is a different element in every
+    correct implementation (round 4 measured 0.2 .. 10 x between the eight engines and bounded it by 32 x, which bounds
+    nothing): instead at most `max_count` elements may lie above 4 x the reference's maximum."""
     n_fix = g[name + "/x"].shape[0]
     got = {"z": z, "lad": lad, "lp": lp, "xi": xi, "ladi": ladi}
     fix = {"z": "z", "lad": "lad", "lp": "log_prob", "xi": "inv_x", "ladi": "inv_lad"}
@@ -126,7 +138,7 @@ def _check_all(config, name, g, o, z, lad, lp, xi, ladi, rows=ORACLE_ROWS, q_fac
         else:
             o32, o64 = o[k + "32"], o[k + "64"]
         _robust(config + "_reference_rows", k, a[:n_fix], g[name + "/" + fix[k]], g[name + "/" + fix[k] + "64"])
-        compare(config, k, a, o32, o64, tol, max_factor=32.0, q_factor=q_factor)
+        compare(config, k, a, o32, o64, tol, q_factor=q_factor, max_count=max_count)
 
 
 # engine -> (class switches, batch rows, K8s allowed, substrings of the kernel name that must have run)
@@ -187,15 +199,23 @@ def test_steep_coupling_flow_on_every_engine(golden_dir, engine_switches, case, 
     os.environ.update(switches.get("env", {}))      # (read by the launcher at every launch)
     _status(case, clear=True)
     ran = {}
+    redo = {"f": 0, "i": 0}
+
+    def counted(fn, key):
+        def run(t):
+            out = fn(t)
+            if engine.startswith(("k8h", "k8s")):
+                redo[key] += ops.last_redo_blocks()
+            return out
+        return run
     with torch.no_grad():
-        z, lad = flow._transform(x[:rows].to(DEV))
+        z, lad = _chunked(counted(flow._transform, "f"), x, rows)
         ran["forward"] = ops.last_layer_kernel()
-        redo_f = ops.last_redo_blocks() if engine.startswith(("k8h", "k8s")) else 0
-        lp = flow.log_prob(x[:rows].to(DEV))
-        xi, ladi = flow._transform.inverse(noise[:rows].to(DEV))
+        lp = _chunked(flow.log_prob, x, rows)
+        xi, ladi = _chunked(counted(flow._transform.inverse, "i"), noise, rows)
         ran["inverse"] = ops.last_layer_kernel()
-        redo_i = ops.last_redo_blocks() if engine.startswith(("k8h", "k8s")) else 0
-        xr, _ = flow._transform.inverse(z)
+        xr, _ = _chunked(flow._transform.inverse, z.cpu(), rows)
+    redo_f, redo_i = redo["f"], redo["i"]
     for direction, label in ran.items():
         for piece in expect:
             assert piece in label, "%s %s ran %r, expected %r" % (engine, direction, label, expect)
@@ -210,7 +230,7 @@ def test_steep_coupling_flow_on_every_engine(golden_dir, engine_switches, case, 
         return
     # inverse(forward(x)) where the flow is well enough conditioned for the round trip to mean something in fp32
     # (reference: 1e-4 on average): the mean is what a mis-scaled refinement step moves
-    err = (xr.cpu() - x[:rows]).abs()
+    err = (xr.cpu() - x).abs()
     with torch.no_grad():
         from oracle import eager
         xr_ref, _ = eager.flow_transform(flow_cpu, torch.from_numpy(o["z32"]), inverse=True)
@@ -229,8 +249,8 @@ def test_steep_affine_flow(golden_dir, engine):
     from nflows_amd.transforms import AffineCouplingTransform as AC
     case = "steep_affine"
     flow_cpu, g, cfg = steep_flow(golden_dir, case)
-    x = _batch(g, case, "x", 16384, cfg["D"])
-    noise = _batch(g, case, "noise", 16384, cfg["D"])
+    x = _batch(g, case, "x", ORACLE_ROWS, cfg["D"])
+    noise = _batch(g, case, "noise", ORACLE_ROWS, cfg["D"])
     o = _oracle(case, flow_cpu, x, noise)
     flow = copy.deepcopy(flow_cpu).to(DEV).eval()
     _status(case, clear=True)

@@ -11,7 +11,7 @@ The reference's state_dict loads strictly into the drop-in classes; the eager po
 (tests/test_oracle_golden.py), so the rows behind the fixture's 256 are held to the port.  Engines as in
 tests/test_gpu_steep.py (hidden width 64 is zero-padded into the kernels' 128): K8h eight- and four-wave, K8s eight-
 and four-wave, K8, GEMMs + K1 (wave-tile and register-pipelined); forward and inverse; the headline rule (2 x on the
-mean, 2.5 x on the 99.9 % quantile of 8 192 rows; measured at most 1.15 / 1.16); and
+mean and on the 99.9 % quantile of 65 536 rows per engine (round 4, on 8 192 rows: measured at most 1.15 / 1.16); and
 inverse(forward(x)) on the held-out samples against the reference's own fp32 round trip.
 """
 import copy
@@ -24,6 +24,7 @@ from helpers import trained_flow
 from test_gpu_headline_parity import _report
 from test_gpu_steep import _batch, _check_all, _nsf_engines, _status, engine_switches  # noqa: F401  (fixture)
 from test_gpu_bins import _oracle, ROWS
+from test_gpu_steep import _chunked
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -58,24 +59,32 @@ def test_trained_flow_on_every_engine(golden_dir, engine_switches, engine):
     os.environ.update(switches.get("env", {}))
     _status(case, clear=True)
     ran = {}
+    redo = {"f": 0, "i": 0}
+
+    def counted(fn, key):
+        def run(t):
+            out = fn(t)
+            if engine.startswith(("k8h", "k8s")):
+                redo[key] += ops.last_redo_blocks()
+            return out
+        return run
     with torch.no_grad():
-        z, lad = flow._transform(x[:rows].to(DEV))
+        z, lad = _chunked(counted(flow._transform, "f"), x, rows)
         ran["forward"] = ops.last_layer_kernel()
-        redo_f = ops.last_redo_blocks() if engine.startswith(("k8h", "k8s")) else 0
-        lp = flow.log_prob(x[:rows].to(DEV))
-        xi, ladi = flow._transform.inverse(noise[:rows].to(DEV))
+        lp = _chunked(flow.log_prob, x, rows)
+        xi, ladi = _chunked(counted(flow._transform.inverse, "i"), noise, rows)
         ran["inverse"] = ops.last_layer_kernel()
-        redo_i = ops.last_redo_blocks() if engine.startswith(("k8h", "k8s")) else 0
-        xr, _ = flow._transform.inverse(z)
+        xr, _ = _chunked(flow._transform.inverse, z.cpu(), rows)
+    redo_f, redo_i = redo["f"], redo["i"]
     for direction, label in ran.items():
         for piece in expect:
             assert piece in label, "%s %s ran %r, expected %r" % (engine, direction, label, expect)
     _report({"config": "%s_%s" % (case, engine), "kernels": ran, "rows": rows, "redo_blocks": [redo_f, redo_i]})
-    _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS, q_factor=2.5)
-    assert redo_f + redo_i <= max(1, rows // 128 // 100), (redo_f, redo_i)
+    _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS)
+    assert redo_f + redo_i <= max(1, ROWS // 128 // 100), (redo_f, redo_i)
     _status("%s_%s" % (case, engine))
     # inverse(forward(x)) on the held-out samples: the mean against the reference's own fp32 round trip
-    err = (xr.cpu() - x[:rows]).abs()
+    err = (xr.cpu() - x).abs()
     with torch.no_grad():
         from oracle import eager
         xr_ref, _ = eager.flow_transform(flow_cpu, torch.from_numpy(o["z32"]), inverse=True)

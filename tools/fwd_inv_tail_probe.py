@@ -2,7 +2,7 @@
 """(measurement script, not collected by pytest; lives under tests/ because it uses the oracle)
 Tail of |inv(fwd(x)) - x| for the 32-layer flow: HIP path vs the reference's own fp32 path (eager
 port) on the same rows -- counts above thresholds, the worst elements, and where the HIP path's worst
-element stands in the reference (and vice versa).  Usage: python tests/fwd_inv_tail_probe.py [rows]"""
+element stands in the reference (and vice versa).  Usage: python tools/fwd_inv_tail_probe.py [rows]"""
 import os, sys, copy
 import numpy as np
 import torch
