@@ -147,6 +147,48 @@ def assert_fp32_parity(got, ref, truth, tol, what="", bulk=0.999, factor=4.0, co
     assert_error_ratio(got, ref, truth, what, factor=2.0, max_factor=factor, max_floor=tol * (1 + np.abs(t64).max()))
 
 
+def eager_oracle(flow_cpu, x, noise=None, context=None, fp64_device=None):
+    """The two evaluations every whole-flow parity test needs, both through oracle/eager.py (the op-for-op PyTorch port of
+    the reference's path; tests/test_oracle_golden.py pins it bit for bit to the real reference on the CPU):
+      * float32 ON THE CPU -- the reference's own arithmetic, the yardstick ("the reference-fp32's own error");
+      * float64 -- the truth.  With `fp64_device` the same port is run by stock PyTorch on that device (aten's float64
+        kernels, nothing of libnflows_amd): at 65 536 rows the float64 pass on the GPU box's 16 cores was 2/3 of the
+        GPU suite's running time (round 5), and as a truth to 1e-12 it does not matter which of aten's float64 kernels
+        rounded it (tests/test_gpu_flows.py::test_device_float64_port_is_the_reference_float64 holds the device
+        evaluation to the real reference's float64 vectors).
+    Returns {z32, lad32, lp32, z64, lad64, lp64} and, with `noise`, {xi32, ladi32, xi64, ladi64} (the inverse) as numpy
+    arrays.  `context`: raw context rows of a conditional flow (embedded by the flow's own embedding net)."""
+    import copy
+    import torch
+    from oracle import eager
+    threads = torch.get_num_threads()
+    out = {}
+
+    def run(f, xx, nn_, ctx, tag):
+        emb = None if ctx is None else f._embedding_net(ctx)
+        z, lad = eager.flow_transform(f, xx, context=emb)
+        lp = eager.standard_normal_log_prob(z) + lad
+        res = {"z": z, "lad": lad, "lp": lp}
+        if nn_ is not None:
+            res["xi"], res["ladi"] = eager.flow_transform(f, nn_, inverse=True, context=emb)
+        for k, v in res.items():
+            out[k + tag] = v.cpu().numpy()
+
+    with torch.no_grad():
+        run(flow_cpu.float(), x.float(), None if noise is None else noise.float(), None if context is None else context.float(), "32")
+        if fp64_device is None:
+            f64 = flow_cpu.double()
+            run(f64, x.double(), None if noise is None else noise.double(), None if context is None else context.double(), "64")
+            flow_cpu.float()
+        else:
+            f64 = copy.deepcopy(flow_cpu).double().to(fp64_device)
+            to = lambda t: None if t is None else t.double().to(fp64_device)   # noqa: E731
+            run(f64, to(x), to(noise), to(context), "64")
+            del f64
+    torch.set_num_threads(threads)
+    return out
+
+
 def knot_case_keep(got_y, ref_y, got_lad, ref_lad, status, inverse, what=""):
     """The adversarial cases of rqs_bins.npz put inputs ON a knot.  In the inverse direction the discriminant
     (rational_quadratic.py:141) is then a difference of nearly equal terms and can round below zero in one correct fp32

@@ -3,7 +3,7 @@
 Secondary baseline: the reference's own op sequence (its bit-identical eager port,
 oracle/eager.py) run as PyTorch-eager ON THE SAME MI355X, next to the fused kernels.  Informational."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nflows_amd import configs
 from oracle import eager
 dev = "cuda:0"

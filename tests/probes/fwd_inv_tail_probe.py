@@ -2,11 +2,11 @@
 """(measurement script, not collected by pytest; lives under tests/ because it uses the oracle)
 Tail of |inv(fwd(x)) - x| for the 32-layer flow: HIP path vs the reference's own fp32 path (eager
 port) on the same rows -- counts above thresholds, the worst elements, and where the HIP path's worst
-element stands in the reference (and vice versa).  Usage: python tools/fwd_inv_tail_probe.py [rows]"""
+element stands in the reference (and vice versa).  Usage: python tests/probes/fwd_inv_tail_probe.py [rows]"""
 import os, sys, copy
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from nflows_amd import configs
 from oracle import eager

@@ -4,7 +4,7 @@ Accuracy of K8's evaluation variants against the float64 truth (oracle/eager.py 
 same weights and inputs): NFA_K8_PIPE=0 plain, 1 woven (bit-identical to plain), 2 woven with the
 cheaper rounding sequence.  The switch is read once per process, so the script re-runs itself."""
 import os, subprocess, sys, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import torch
     sys.path.insert(0, ROOT)

@@ -1,7 +1,7 @@
 """Round 4: where does the inverse log-determinant of the K12 + K13 path differ on the steep autoregressive fixture?"""
 import os, sys, copy
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import steep_flow
 from oracle import eager

@@ -86,21 +86,11 @@ def compare(config, what, got, ref32, truth, tol, max_factor=FACTOR, q_factor=FA
 
 
 def oracle_eval(flow_cpu, x_cpu, need=("z", "lad", "lp"), context=None):
-    """float32 and float64 evaluation of the eager port on the host (`context`: the raw context rows of a
-    conditional flow, embedded by the flow's own embedding net in the same precision)."""
-    from oracle import eager
-    threads = torch.get_num_threads()
-    out = {}
-    with torch.no_grad():
-        for tag, dt in (("32", torch.float32), ("64", torch.float64)):
-            f = flow_cpu.to(dt)
-            emb = None if context is None else f._embedding_net(context.to(dt))
-            z, lad = eager.flow_transform(f, x_cpu.to(dt), context=emb)
-            lp = eager.standard_normal_log_prob(z) + lad
-            out["z" + tag], out["lad" + tag], out["lp" + tag] = z.numpy(), lad.numpy(), lp.numpy()
-        flow_cpu.float()
-    torch.set_num_threads(threads)
-    return out
+    """float32 (on the host: the reference's arithmetic) and float64 (the same port run by stock PyTorch on the device)
+    evaluation of the eager port: helpers.eager_oracle (`context`: the raw context rows of a conditional flow, embedded
+    by the flow's own embedding net in the same precision)."""
+    from helpers import eager_oracle
+    return eager_oracle(flow_cpu, x_cpu, context=context, fp64_device=DEV)
 
 
 def hip_eval(flow_cpu, x_cpu, context=None):

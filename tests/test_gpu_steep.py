@@ -18,7 +18,7 @@ only, which the reference's own worst ill-conditioned element dominates.  Here
   * the rule is the headline rule (tests/test_gpu_headline_parity.compare): error against float64 at most 2 x the
     reference-fp32's own on the MEAN and the 99.9 % QUANTILE with no floor, on 65 536 rows per engine (round 5: the
     quantile is the 65th largest value, no looser factor for small samples any more); instead of a factor on the single
-    worst element, at most eight elements above 4 x the reference's own maximum;
+    worst element, at most three elements above 4 x the reference's own maximum;
   * the fixture's 512 rows sit at the head of a batch large enough for the instance under test; the rows behind them
     are held to oracle/eager.py (bit-identical to the reference on this very fixture:
     tests/test_oracle_golden.py::test_eager_port_bit_identical_on_steep_flows).
@@ -41,7 +41,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 ORACLE_ROWS = 65536         # fixture rows (512) + rows held to the eager port: the 99.9 % quantile of the per-row log-determinants is
                             # their 65th largest value (round 4 compared 16 384 rows and had to loosen the quantile's factor instead)
-MAX_COUNT = 8               # elements allowed above 4 x the reference-fp32's own maximum error (see compare)
+MAX_COUNT = 3               # elements allowed above 4 x the reference-fp32's own maximum error (see compare; measured over the 605
+                            # comparisons of the four engine files: none in 599, one in 6 -- profiles/r5/parity_rules.txt)
 _oracle_cache = {}
 
 
@@ -54,22 +55,11 @@ def _batch(g, name, key, rows, features):
 
 
 def _oracle(name, flow_cpu, x, noise, rows=ORACLE_ROWS):
-    """fp32 and fp64 evaluation of the eager port on the first `rows` rows, both directions (once per fixture)."""
+    """fp32 (CPU: the reference's arithmetic) and fp64 (the same port on the device) evaluation of the eager port on the
+    first `rows` rows, both directions (once per fixture): helpers.eager_oracle."""
     if name not in _oracle_cache:
-        from oracle import eager
-        threads = torch.get_num_threads()
-        out = {}
-        with torch.no_grad():
-            for tag, dt in (("32", torch.float32), ("64", torch.float64)):
-                f = flow_cpu.to(dt)
-                z, lad = eager.flow_transform(f, x[:rows].to(dt))
-                lp = eager.standard_normal_log_prob(z) + lad
-                xi, ladi = eager.flow_transform(f, noise[:rows].to(dt), inverse=True)
-                for k, v in (("z", z), ("lad", lad), ("lp", lp), ("xi", xi), ("ladi", ladi)):
-                    out[k + tag] = v.numpy()
-            flow_cpu.float()
-        torch.set_num_threads(threads)
-        _oracle_cache[name] = out
+        from helpers import eager_oracle
+        _oracle_cache[name] = eager_oracle(flow_cpu, x[:rows], noise[:rows], fp64_device=DEV)
     return _oracle_cache[name]
 
 
@@ -133,6 +123,14 @@ def _check_all(config, name, g, o, z, lad, lp, xi, ladi, rows=ORACLE_ROWS, q_fac
         ok = np.isfinite(o[k + "32"].reshape(rows, -1)).all(1)
         assert ok.mean() >= 0.999 and np.isfinite(o[k + "64"]).all(), (config, k, float(ok.mean()))
         ok[:n_fix] = True
+        # ... and the same event in THIS evaluation (the status word then carries NFA_STATUS_NEG_DISCRIMINANT, the
+        # reference's assertion as a flag; `_status` reports it): at most one row in 16 384, left out like the reference's
+        mine = ~np.isfinite(a.reshape(rows, -1)).all(1) & ok
+        mine[:n_fix] = False
+        assert mine.sum() <= max(1, rows // 16384), (config, k, int(mine.sum()))
+        if mine.any():
+            _report({"config": config, "what": k, "rows_with_a_discriminant_rounded_below_zero_here": int(mine.sum())})
+        ok &= ~mine
         if not ok.all():
             a, o32, o64 = a[ok], o[k + "32"][ok], o[k + "64"][ok]
         else:
