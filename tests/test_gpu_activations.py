@@ -21,7 +21,7 @@ import torch
 
 from helpers import steep_flow
 from test_gpu_headline_parity import _report
-from test_gpu_steep import _batch, _check_all, _status, engine_switches  # noqa: F401  (fixture)
+from test_gpu_steep import _batch, _check_all, _checked, _status, engine_switches  # noqa: F401  (fixture)
 from test_gpu_bins import _oracle, ROWS
 from test_gpu_steep import _chunked
 
@@ -75,7 +75,8 @@ def test_other_activations_on_every_engine(golden_dir, engine_switches, case, en
         for piece in expect:
             assert piece in label, "%s %s ran %r, expected %r" % (engine, direction, label, expect)
     _report({"config": "%s_%s" % (case, engine), "kernels": ran, "rows": rows, "redo_blocks": [redo_f, redo_i]})
-    _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS)
+    _checked("%s_%s" % (case, engine), flow, x, rows, z,
+             lambda: _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS))
     assert redo_f + redo_i <= max(1, ROWS // 128 // 100), "the f16 engine handed %d + %d row blocks to the exact kernel" % (redo_f, redo_i)
     _status("%s_%s" % (case, engine))
 

@@ -29,7 +29,7 @@ import torch
 
 from helpers import LAD_TOL, OUT_TOL, steep_flow, steepen
 from test_gpu_headline_parity import compare, _report
-from test_gpu_steep import MAX_COUNT, _batch, _check_all, _chunked, _status, engine_switches  # noqa: F401  (fixture)
+from test_gpu_steep import MAX_COUNT, _batch, _check_all, _checked, _chunked, _status, engine_switches  # noqa: F401  (fixture)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -97,7 +97,8 @@ def test_other_bin_counts_on_every_engine(golden_dir, engine_switches, K, engine
         if engine != "gemm_k1":
             assert ("inverse=1" in label) == (direction == "inverse"), label
     _report({"config": "%s_%s" % (case, engine), "kernels": ran, "rows": rows, "redo_blocks": [redo_f, redo_i]})
-    _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS)
+    _checked("%s_%s" % (case, engine), flow, x, rows, z,
+             lambda: _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS))
     # (a row block in which the f16 engine meets a non-finite value -- on splines this steep about one evaluation in a
     #  million rounds a discriminant below zero in ANY fp32 arithmetic, the reference's included -- is handed to the exact
     #  kernel: by design, reported above.  More than 1 % of the blocks would mean the figures are not the engine's own.)

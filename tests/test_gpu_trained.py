@@ -24,7 +24,7 @@ from helpers import trained_flow
 from test_gpu_headline_parity import _report
 from test_gpu_steep import _batch, _check_all, _nsf_engines, _status, engine_switches  # noqa: F401  (fixture)
 from test_gpu_bins import _oracle, ROWS
-from test_gpu_steep import _chunked
+from test_gpu_steep import _checked, _chunked
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -80,7 +80,8 @@ def test_trained_flow_on_every_engine(golden_dir, engine_switches, engine):
         for piece in expect:
             assert piece in label, "%s %s ran %r, expected %r" % (engine, direction, label, expect)
     _report({"config": "%s_%s" % (case, engine), "kernels": ran, "rows": rows, "redo_blocks": [redo_f, redo_i]})
-    _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS)
+    _checked("%s_%s" % (case, engine), flow, x, rows, z,
+             lambda: _check_all("%s_%s" % (case, engine), case, g, o, z, lad, lp, xi, ladi, rows=ROWS))
     assert redo_f + redo_i <= max(1, ROWS // 128 // 100), (redo_f, redo_i)
     _status("%s_%s" % (case, engine))
     # inverse(forward(x)) on the held-out samples: the mean against the reference's own fp32 round trip
