@@ -299,9 +299,10 @@ class Linear(torch.autograd.Function):
 
 
 class SelectColumns(torch.autograd.Function):
-    """inputs.index_select(1, columns) for UNIQUE columns (a coupling layer's identity split, coupling.py:82) whose
-    backward writes the gradient with index_copy_ into a zero tensor: torch's own backward is index_add_ -- atomic adds,
-    16 us per layer at 65 536 x 64 against 6 us -- because it cannot know the columns are distinct."""
+    """inputs.index_select(1, columns) for DISTINCT columns (a coupling layer's identity split, coupling.py:82) whose
+    backward writes the gradient with index_copy into a zero tensor: torch's own backward is index_add_ -- atomic adds,
+    16 us per layer at 65 536 x 64 against 6 us -- because it cannot know the columns are distinct.  The backward is
+    written with differentiable operations (out-of-place index_copy): double backward works."""
 
     @staticmethod
     def forward(ctx, inputs, columns):
@@ -310,17 +311,31 @@ class SelectColumns(torch.autograd.Function):
         return inputs.index_select(1, columns)
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, grad):
         (columns,) = ctx.saved_tensors
-        out = grad.new_zeros(grad.shape[0], ctx.width)
-        out.index_copy_(1, columns, grad.contiguous())
-        return out, None
+        return grad.new_zeros(grad.shape[0], ctx.width).index_copy(1, columns, grad.contiguous()), None
+
+
+_distinct_columns = {}   # (data_ptr, version, length) of an index tensor -> its entries are pairwise distinct
+
+
+def _columns_are_distinct(columns):
+    """index_copy with repeated indices is nondeterministic and DROPS gradient: the identity split's columns are
+    distinct for a mask alone, and through a fused Permutation only if that permutation is a bijection -- which the
+    reference's Permutation never checks.  Checked once per index tensor (one synchronising comparison), remembered."""
+    key = (columns.data_ptr(), columns._version, columns.numel())
+    known = _distinct_columns.get(key)
+    if known is None:
+        if len(_distinct_columns) > 256:
+            _distinct_columns.clear()
+        known = _distinct_columns[key] = bool(torch.unique(columns).numel() == columns.numel())
+    return known
 
 
 def select_columns(inputs, columns):
-    """`inputs[:, columns]` (distinct columns); under autograd through SelectColumns."""
-    if torch.is_grad_enabled() and inputs.requires_grad and inputs.dim() == 2:
+    """`inputs[:, columns]`; under autograd through SelectColumns when the columns are distinct (torch's index_select,
+    whose backward accumulates, otherwise)."""
+    if torch.is_grad_enabled() and inputs.requires_grad and inputs.dim() == 2 and _columns_are_distinct(columns):
         return SelectColumns.apply(inputs, columns)
     return inputs.index_select(1, columns)
 

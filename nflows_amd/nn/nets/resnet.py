@@ -128,8 +128,11 @@ def _has_inner_hooks(net):
 
 
 class fused_training:
-    """`with fused_training(False): ...` -- the eager conditioner modules under autograd inside the block (double
-    backward, autocast experiments, hooks); restores the previous class-level setting on exit."""
+    """`with fused_training(False): ...` -- the eager conditioner modules under autograd inside the block (autocast
+    experiments, hooks, double backward THROUGH THE CONDITIONER); restores the previous class-level setting on exit.
+    The spline / affine layer kernels behind the conditioner (autograd.RqsCoupling, AffineCoupling, ...) stay
+    once-differentiable either way: a gradient penalty that differentiates twice through the layer's own map needs
+    the float64 functional path or the reference's eager ops."""
 
     def __init__(self, enabled):
         self.enabled = bool(enabled)

@@ -218,14 +218,15 @@ class CompositeTransform(Transform):
 
     @staticmethod
     def _joinable(t, features, context):
-        kind = getattr(t, "_run_kind", None)   # whole-layer kernel this layer can join a run of
+        kind = getattr(t, "_run_kind", None)   # whole-layer kernel this layer can join a run of (None: a user's subclass
+        #                                        with its own hooks, coupling.py: _user_hooks)
         return (kind is not None and t.unconditional_transform is None and t.features == features
                 and kind(context) is not None)
 
     def _watched_state(self, units, layers, after, features, context):
         """What a cached plan is compared with on every call: the state of its layers and of the (up to two)
         layers behind it -- the run may have ended at one of them for a reason that no longer holds."""
-        behind = [(t._run_signature(), self._joinable(t, features, context)) if hasattr(t, "_run_kind") else None
+        behind = [(t._run_signature(), self._joinable(t, features, context)) if getattr(t, "_run_kind", None) is not None else None
                   for t in layers[after:after + 2]]
         return _layer_state(units), behind
 

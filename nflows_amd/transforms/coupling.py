@@ -138,6 +138,21 @@ class CouplingTransform(Transform):
     supports_fused_permutation = True   # 2-D inputs go through one fused kernel per layer
     supports_image_inputs = False       # 4-D inputs allowed (generic path)
 
+    # The reference's extension points (coupling.py:132-136, :234-252, :263-269, :279-296): a subclass DEFINED OUTSIDE this
+    # module that overrides one of them means "run the reference's sequence with MY function".  The fused kernels would
+    # silently bypass such an override (they contain the library's arithmetic), so such a class -- and its subclasses --
+    # takes `_reference_sequence`: the reference's own order of calls (coupling.py:73-130) on device tensors, its hooks
+    # called where the reference calls them; it joins no fused run and takes no fused permutation.
+    _REFERENCE_HOOKS = ("_coupling_transform_forward", "_coupling_transform_inverse", "_piecewise_cdf", "_scale_and_shift")
+    _user_hooks = False
+
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        if cls.__module__ != __name__ and any(h in cls.__dict__ for h in CouplingTransform._REFERENCE_HOOKS):
+            cls._user_hooks = True
+            cls.supports_fused_permutation = False
+            cls._run_kind = None             # (transforms/base.py: _joinable)
+
     def __init__(self, mask, transform_net_create_fn, unconditional_transform=None):
         mask = torch.as_tensor(mask)
         if mask.dim() != 1:
@@ -199,6 +214,8 @@ class CouplingTransform(Transform):
         `logabsdet_accumulator`: a [batch] running total the layer's logabsdet is added to in the
         kernel (CompositeTransform's `total_logabsdet +=`); it is then also the returned tensor."""
         self._check_inputs(inputs)
+        if self._user_hooks:
+            return self._reference_sequence(inputs, context, False, logabsdet_accumulator)
         if inputs.dim() == 4 or inputs.dtype == torch.float64 or not self.supports_fused_permutation:
             return self._generic(inputs, context, False, logabsdet_accumulator)
         if self.unconditional_transform is None:
@@ -222,6 +239,8 @@ class CouplingTransform(Transform):
         """Inverse pass (coupling.py:102-130).  `out_scatter`: store layer column c at
         outputs[:, out_scatter[c]] (a following Permutation.inverse, fused)."""
         self._check_inputs(inputs)
+        if self._user_hooks:
+            return self._reference_sequence(inputs, context, True, logabsdet_accumulator)
         if inputs.dim() == 4 or inputs.dtype == torch.float64 or not self.supports_fused_permutation:
             return self._generic(inputs, context, True, logabsdet_accumulator)
         if self.unconditional_transform is None:
@@ -276,6 +295,39 @@ class CouplingTransform(Transform):
             logabsdet = logabsdet_accumulator
         return outputs, logabsdet
 
+    def _reference_sequence(self, inputs, context, inverse, logabsdet_accumulator):
+        """coupling.py:73-130 call for call, for classes whose hooks a user overrode (`_user_hooks`): split, (inverse:
+        unconditional transform first), conditioner, `_coupling_transform_forward / _inverse(transform_split,
+        transform_params)` -- the user's, or the library's default, which in turn calls the user's `_piecewise_cdf` /
+        `_scale_and_shift` --, (forward: unconditional transform), merge."""
+        identity_split = inputs.index_select(1, self.identity_features)
+        transform_split = inputs.index_select(1, self.transform_features)
+        logabsdet = None
+        if inverse and self.unconditional_transform is not None:
+            identity_split, logabsdet = self.unconditional_transform.inverse(identity_split, context)
+        transform_params = self.transform_net(identity_split, context)
+        hook = self._coupling_transform_inverse if inverse else self._coupling_transform_forward
+        transform_split, lad_split = hook(transform_split, transform_params)
+        logabsdet = lad_split if logabsdet is None else logabsdet + lad_split
+        if not inverse and self.unconditional_transform is not None:
+            identity_split, lad_identity = self.unconditional_transform(identity_split, context)
+            logabsdet = logabsdet + lad_identity
+        outputs = torch.empty_like(inputs)
+        outputs.index_copy_(1, self.identity_features, identity_split)
+        outputs.index_copy_(1, self.transform_features, transform_split)
+        if logabsdet_accumulator is not None:
+            logabsdet_accumulator += logabsdet
+            logabsdet = logabsdet_accumulator
+        return outputs, logabsdet
+
+    def _coupling_transform_forward(self, inputs, transform_params):
+        """coupling.py:132-134 (abstract in the reference's base class)"""
+        raise NotImplementedError()
+
+    def _coupling_transform_inverse(self, inputs, transform_params):
+        """coupling.py:135-136"""
+        raise NotImplementedError()
+
     def _elementwise(self, inputs, transform_params, inverse):
         """Elementwise transform of the transformed part given per-element parameters
         [..., params]; returns (outputs, logabsdet) of the inputs' shape (generic path only)."""
@@ -316,6 +368,20 @@ class AffineCouplingTransform(CouplingTransform):
 
     def _transform_dim_multiplier(self):
         return 2
+
+    # The reference's hooks (coupling.py:234-252), for subclasses that override one of them (`_user_hooks`: the layer then
+    # runs `_reference_sequence`, tensor operations on the device); the library's own layers go through K2 / K11.
+    def _scale_and_shift(self, transform_params):
+        dt = self.num_transform_features
+        return self.scale_activation(transform_params[:, dt:, ...]), transform_params[:, :dt, ...]
+
+    def _coupling_transform_forward(self, inputs, transform_params):
+        scale, shift = self._scale_and_shift(transform_params)
+        return inputs * scale + shift, torchutils.sum_except_batch(torch.log(scale), num_batch_dims=1)
+
+    def _coupling_transform_inverse(self, inputs, transform_params):
+        scale, shift = self._scale_and_shift(transform_params)
+        return (inputs - shift) / scale, -torchutils.sum_except_batch(torch.log(scale), num_batch_dims=1)
 
     def _generic(self, inputs, context, inverse, logabsdet_accumulator):
         """Image inputs [B, C, H, W] (coupling.py:212-252 applies the same expressions to any rank;
@@ -436,6 +502,9 @@ class AdditiveCouplingTransform(AffineCouplingTransform):
 
     def _transform_dim_multiplier(self):
         return 1
+
+    def _scale_and_shift(self, transform_params):   # coupling.py:266-269
+        return torch.ones_like(transform_params), transform_params
 
     def _activation_code(self):
         return N.SCALE_ADDITIVE

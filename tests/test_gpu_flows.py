@@ -1,6 +1,7 @@
 """Whole-flow parity on the GPU: the drop-in classes, loaded with the reference's weights
 (state_dict keys are identical), against reference outputs stored in tests/golden/flows.npz.
 Run with `-m gpu`."""
+import math
 import os
 
 import numpy as np
@@ -1076,6 +1077,63 @@ def test_whole_layer_kernels_take_narrower_conditioners(monkeypatch, hidden, eng
         for got, want in zip(results[True], results[False]):
             assert torch.isfinite(got).all()
             assert (got - want).abs().max().item() <= 5e-5 * (1 + want.abs().max().item())
+
+
+def test_user_hook_overrides_run_the_reference_sequence_on_the_device():
+    """A subclass that overrides one of the reference's hooks takes coupling.py:73-130 call for call (`_user_hooks`,
+    transforms/coupling.py): with an override that changes nothing the layer agrees with the library class's fused
+    kernels (same weights) to fp32 rounding, forward and inverse, alone and inside a CompositeTransform with
+    permutations; with an override that doubles the outputs the doubling is THERE (the fused kernels would have dropped
+    it)."""
+    import copy
+    from nflows_amd import configs
+    from nflows_amd.transforms import CompositeTransform, PiecewiseRationalQuadraticCouplingTransform as RQ, AffineCouplingTransform as AC
+
+    class SameRQ(RQ):
+        def _coupling_transform_forward(self, inputs, transform_params):
+            return super()._coupling_transform_forward(inputs, transform_params)
+
+    class DoubledRQ(RQ):
+        def _coupling_transform_forward(self, inputs, transform_params):
+            y, lad = super()._coupling_transform_forward(inputs, transform_params)
+            return 2 * y, lad + math.log(2.0) * inputs.shape[1]
+
+    class SameAffine(AC):
+        def _scale_and_shift(self, transform_params):
+            return super()._scale_and_shift(transform_params)
+
+    flow = configs.rq_nsf_flow(3, 64, 8, 128, 2, 3.0, seed=5).to("cuda:0").eval()
+    x = torch.randn(4096, 64, generator=torch.Generator().manual_seed(6)).to("cuda:0")
+    lib_layers = list(flow._transform._transforms)
+    with torch.no_grad():
+        want, want_lad = flow._transform(x)
+        mine = copy.deepcopy(lib_layers)
+        for t in mine:
+            if isinstance(t, RQ):
+                t.__class__ = SameRQ
+        assert all(t._user_hooks for t in mine if isinstance(t, RQ))
+        got, got_lad = CompositeTransform(mine)(x)
+        assert (got - want).abs().max().item() <= 2e-5 and (got_lad - want_lad).abs().max().item() <= 2e-4
+        back, back_lad = CompositeTransform(mine).inverse(want)
+        ref_back, ref_back_lad = flow._transform.inverse(want)
+        assert (back - ref_back).abs().max().item() <= 2e-5 and (back_lad - ref_back_lad).abs().max().item() <= 2e-4
+        one, one_lad = lib_layers[1](x)
+        dbl = copy.deepcopy(lib_layers[1])
+        dbl.__class__ = DoubledRQ
+        y2, lad2 = dbl(x)
+        tf = lib_layers[1].transform_features
+        idf = lib_layers[1].identity_features
+        assert torch.equal(y2[:, idf], x[:, idf])
+        assert (y2[:, tf] - 2 * one[:, tf]).abs().max().item() <= 2e-5
+        assert (lad2 - one_lad - math.log(2.0) * tf.numel()).abs().max().item() <= 2e-4
+        aff = configs.affine_coupling_flow(2, 32, (64, 64), seed=3).to("cuda:0").eval()
+        xa = torch.randn(1024, 32, generator=torch.Generator().manual_seed(7)).to("cuda:0")
+        wa, wa_lad = aff._transform(xa)
+        mine_a = copy.deepcopy(list(aff._transform._transforms))
+        for t in mine_a:
+            t.__class__ = SameAffine
+        ga, ga_lad = CompositeTransform(mine_a)(xa)
+        assert (ga - wa).abs().max().item() <= 2e-6 and (ga_lad - wa_lad).abs().max().item() <= 2e-5
 
 
 def test_device_float64_port_is_the_reference_float64(golden_dir):

@@ -1580,6 +1580,82 @@ def test_run_level_weight_fingerprint_and_verification(monkeypatch):
         assert plan()[1] is p4
 
 
+def test_user_overrides_of_the_reference_hooks_are_honoured():
+    """a user subclass that overrides one of the reference's documented hooks
+    (`_coupling_transform_forward / _inverse`, `_piecewise_cdf`, `_scale_and_shift`: coupling.py:132-136, :234-252,
+    :279-296) -- also on the classes that have fused kernels -- must not be bypassed: such classes are marked at class
+    creation (`_user_hooks`), take `_reference_sequence`, join no fused run and take no fused permutation.  (The
+    sequence itself runs tensor operations on the device: the GPU suite runs it, tests/test_gpu_flows.py.)"""
+    import torch
+    from nflows_amd.transforms import coupling as C
+    from nflows_amd.transforms.base import CompositeTransform
+    from nflows_amd.nn.nets import ResidualNet
+    from nflows_amd.utils import create_alternating_binary_mask
+    lib = (C.AffineCouplingTransform, C.AdditiveCouplingTransform, C.PiecewiseRationalQuadraticCouplingTransform,
+           C.PiecewiseLinearCouplingTransform, C.PiecewiseQuadraticCouplingTransform, C.PiecewiseCubicCouplingTransform,
+           C.PiecewiseCouplingTransform, C.CouplingTransform)
+    assert not any(c._user_hooks for c in lib)
+
+    class Plain(C.PiecewiseRationalQuadraticCouplingTransform):   # no hook touched: the fused kernels stay
+        pass
+
+    class Doubled(C.PiecewiseRationalQuadraticCouplingTransform):
+        def _coupling_transform_forward(self, inputs, transform_params):
+            y, lad = super()._coupling_transform_forward(inputs, transform_params)
+            return 2 * y, lad
+
+    class Child(Doubled):
+        pass
+
+    class MyScale(C.AffineCouplingTransform):
+        def _scale_and_shift(self, transform_params):
+            scale, shift = super()._scale_and_shift(transform_params)
+            return scale + 1.0, shift
+
+    assert not Plain._user_hooks and Plain.supports_fused_permutation and Plain._run_kind is not None
+    for cls in (Doubled, Child, MyScale):
+        assert cls._user_hooks and not cls.supports_fused_permutation and cls._run_kind is None
+    mk = lambda cls, **kw: cls(create_alternating_binary_mask(6, even=True), lambda i, o: ResidualNet(i, o, 8, num_blocks=1), **kw)  # noqa: E731
+    t = mk(Doubled, num_bins=4, tails="linear")
+    assert not CompositeTransform._joinable(t, 6, None) and CompositeTransform._joinable(mk(Plain, num_bins=8, tails="linear"), 6, None) in (True, False)
+    # the library's default hooks compute the reference's expressions (checked on the CPU: plain tensor operations)
+    a = mk(MyScale)
+    x, params = torch.randn(5, 3), torch.randn(5, 6)
+    scale, shift = a._scale_and_shift(params)
+    assert torch.allclose(scale, torch.sigmoid(params[:, 3:] + 2) + 1e-3 + 1.0) and torch.equal(shift, params[:, :3])
+    y, lad = a._coupling_transform_forward(x, params)
+    assert torch.allclose(y, x * scale + shift) and torch.allclose(lad, torch.log(scale).sum(1))
+    xr, ladi = a._coupling_transform_inverse(y, params)
+    assert torch.allclose(xr, x, atol=1e-6) and torch.allclose(ladi, -lad)
+    add = mk(C.AdditiveCouplingTransform)
+    s1, sh = add._scale_and_shift(torch.randn(5, 3))
+    assert torch.equal(s1, torch.ones(5, 3))
+
+
+def test_select_columns_backward_is_differentiable_and_checks_distinctness():
+    """autograd.SelectColumns' backward is written with differentiable operations (double backward
+    works), and repeated columns (a fused Permutation that is no bijection) take torch's accumulating index_select."""
+    import torch
+    from nflows_amd import autograd as AG
+    x = torch.randn(4, 6, requires_grad=True)
+    cols = torch.tensor([5, 0, 3])
+    y = AG.select_columns(x, cols)
+    assert torch.equal(y, x.detach()[:, cols]) and type(y.grad_fn).__name__.startswith("SelectColumns")
+    (g,) = torch.autograd.grad((y ** 2).sum(), x, create_graph=True)
+    want = torch.zeros(4, 6)
+    want[:, cols] = 2 * x.detach()[:, cols]
+    assert torch.allclose(g, want)
+    (gg,) = torch.autograd.grad(g.sum(), x)           # second derivative of sum(y^2) through the custom backward
+    want2 = torch.zeros(4, 6)
+    want2[:, cols] = 2.0
+    assert torch.allclose(gg, want2)
+    dup = torch.tensor([1, 1, 2])
+    yd = AG.select_columns(x, dup)
+    assert not type(yd.grad_fn).__name__.startswith("SelectColumns")
+    (gd,) = torch.autograd.grad(yd.sum(), x)
+    assert torch.equal(gd[0], torch.tensor([0.0, 2.0, 1.0, 0.0, 0.0, 0.0]))
+
+
 def test_a_plan_miss_does_not_launder_a_data_write(monkeypatch):
     """`_run_plan` used to re-record every layer's checksum on EVERY plan-cache miss -- also on
     misses that have nothing to do with the weights (the first inverse / sample() call, a batch crossing the 16-sample
