@@ -233,19 +233,28 @@ __device__ __forceinline__ Frags next_frags(unsigned cur, unsigned nxt) {
 #ifdef NFA_ABL_DOUBLE_FRAGS   // (energy probe: every fragment pair is read twice into the same registers)
     if constexpr (G < kPairs - 1) {
         asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\tds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
-                     : "=v"(f.h), "=v"(f.l)
+                     : "=&v"(f.h), "=&v"(f.l)
                      : "v"(cur), "i"((G + 1) * 2048), "i"((G + 1) * 2048 + 1024));
     } else {
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=v"(f.h), "=v"(f.l) : "v"(nxt));
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(f.h), "=&v"(f.l) : "v"(nxt));
     }
     return f;
 #endif
+    // EARLY-CLOBBER on the first destination (round 5).  Two reads, one address register: without the `&` hipcc gives
+    // f.h the address register wherever the address dies in this statement (`ds_read_b128 v[30:33], v32` /
+    // `ds_read_b128 v[66:69], v32 offset:1024`: 91 of the 204 K8h instances had such a site, profiles/r5/
+    // k8h_exposed_fragment_reads_before_fix.txt).  LDS data lands ~100 cycles after the issue, so the second read
+    // normally issues long before the first one's data arrives -- unless the wave is held between the two
+    // instructions: an instruction-cache miss on cold code (the first launch, or a second stream keeping the device busy).
+    // Then the second read takes its address from fragment data and the wave's next tile of logits is off: the
+    // "one wave in a few thousand, 1e-3 off, a different one every launch" of rounds 3 to 5.
+    // tests/test_host_logic.py::test_no_mfma_result_lands_on_its_own_operands checks every asm block of the five files.
     if constexpr (G < kPairs - 1) {
         asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
-                     : "=v"(f.h), "=v"(f.l)
+                     : "=&v"(f.h), "=v"(f.l)
                      : "v"(cur), "i"((G + 1) * 2048), "i"((G + 1) * 2048 + 1024));
     } else {
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=v"(f.h), "=v"(f.l) : "v"(nxt));
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(f.h), "=v"(f.l) : "v"(nxt));
     }
     return f;
 }

@@ -640,7 +640,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                 }
                 stream_ensure_next(sm);
 #ifdef NFA_ABL_CONST_FRAGS
-                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=v"(fr.h), "=v"(fr.l) : "v"(nxt));
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(fr.h), "=v"(fr.l) : "v"(nxt));   // (early-clobber: see next_frags)
 #else
                 fr = next_frags<kPairs - 1>(cur, nxt);   // pair 0 of the stage behind this one (a weight stage after the last p)
 #endif

@@ -53,5 +53,14 @@ for it in range(reps):
         d = (torch.nan_to_num(z) != torch.nan_to_num(ref[0])).any(1).nonzero().flatten()
         print("   DEVIATION iteration %d: %d rows changed, first %s, blocks of 128: %s, max |diff| %.3e"
               % (it, d.numel(), d[:8].tolist(), sorted(set((d // 128).tolist()))[:12], float((torch.nan_to_num(z) - torch.nan_to_num(ref[0])).abs().max())))
+        diff = (torch.nan_to_num(z) != torch.nan_to_num(ref[0]))
+        for blk in sorted(set((d // 128).tolist()))[:6]:
+            rows_b = d[(d // 128) == blk] - blk * 128
+            per_wave = [int(((rows_b // 32) == w).sum()) for w in range(4)]
+            cols = diff[blk * 128:(blk + 1) * 128].any(0).nonzero().flatten().tolist()
+            flagged = any(bool(f[blk - lo // 128] != 0) for lo, f in redo_flags if lo // 128 <= blk < lo // 128 + f.numel())
+            print("      block %d: rows per wave %s, columns changed %d of %d %s, handed to the exact kernel: %s, lad rows changed %d"
+                  % (blk, per_wave, len(cols), z.shape[1], cols[:10], flagged,
+                     int((torch.nan_to_num(lad[blk * 128:(blk + 1) * 128]) != torch.nan_to_num(ref[1][blk * 128:(blk + 1) * 128])).sum())))
     del flow
 print("%s rows/launch %d empty_cache %d  %s: %d of %d fresh flows deviate from the first (%.1f s)" % (case, rows, empty, kern.split("<")[1][:60], bad, reps - 1, time.time() - t0))

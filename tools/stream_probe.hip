@@ -17,6 +17,12 @@
 typedef float vec4f __attribute__((ext_vector_type(4)));
 constexpr int kStageBytes = 16384;
 
+// a bandwidth hog for the second stream of the `verify` mode: read-modify-write sweeps over a large buffer
+__global__ void hog_kernel(float* p, size_t n, int sweeps) {
+    for (int s = 0; s < sweeps; ++s)
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] += 1.0f;
+}
+
 template <int NW, int RING>
 __global__ void __launch_bounds__(NW * 64) stream_kernel(const char* w, int num_stages, int passes, int reads, float* sink) {
     extern __shared__ __attribute__((aligned(16))) char ring[];
@@ -48,6 +54,18 @@ __global__ void __launch_bounds__(NW * 64) stream_kernel(const char* w, int num_
             asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(base + (unsigned)(r & 15) * 1024u));
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
             acc += v;
+        }
+        if (reads < 0) {
+            // verify mode: every float of stage t holds (float)t; the stage in `slot` is complete by the protocol.  All 16
+            // KiB-rows of the slot are checked (one 16-byte vector per lane and row); sink[1 + block] counts stale vectors.
+            const float want = (float)(s % num_stages);
+            int stale = 0;
+            for (int r = 0; r < 16; ++r) {
+                vec4f v;
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(base + (unsigned)r * 1024u));
+                stale += (v.x != want) + (v.y != want) + (v.z != want) + (v.w != want);
+            }
+            if (stale) atomicAdd(reinterpret_cast<int*>(sink) + 1 + blockIdx.x, stale);
         }
         // this wave's share of the NEXT stage has landed: all but the (RING - 2) youngest stages' requests
         if constexpr (PER * (RING - 2) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -94,7 +112,54 @@ static void run(const char* w, int num_stages, int grid, int reads, float* sink)
     hipEventDestroy(e1);
 }
 
-int main() {
+// verify mode: the stream's contents identify their stage; a second stream keeps HBM busy meanwhile
+template <int NW, int RING>
+static void verify(char* w, int num_stages, int grid, float* sink, bool hog, float* hogbuf, size_t hogn, hipStream_t side) {
+    hipFuncSetAttribute((const void*)stream_kernel<NW, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    const size_t lds_launch = 120 * 1024;
+    hipMemset(sink, 0, 4096 * sizeof(float));
+    hipDeviceSynchronize();
+    const int passes = 40;
+    if (hog) hipLaunchKernelGGL(hog_kernel, dim3(2048), dim3(256), 0, side, hogbuf, hogn, 40);
+    hipLaunchKernelGGL((stream_kernel<NW, RING>), dim3(grid), dim3(NW * 64), lds_launch, 0, w, num_stages, passes, -1, sink);
+    hipDeviceSynchronize();
+    std::vector<int> h(4096);
+    hipMemcpy(h.data(), sink, 4096 * sizeof(int), hipMemcpyDeviceToHost);
+    long stale = 0;
+    int blocks = 0;
+    for (int b = 0; b < grid; ++b) {
+        stale += h[1 + b];
+        blocks += h[1 + b] != 0;
+    }
+    printf("stream_probe verify waves=%d ring=%d grid=%3d %s: %ld stale 16-byte vectors in %d workgroups (of %.0f vectors checked)\n", NW, RING, grid,
+           hog ? "under a bandwidth hog" : "quiet device         ", stale / 4, blocks, (double)grid * num_stages * passes * 64.0 * 16 * NW / NW);
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'v') {
+        const int num_stages = 1344;
+        char* w;
+        float *sink, *hogbuf;
+        const size_t hogn = (size_t)1 << 29;
+        hipMalloc(&w, (size_t)num_stages * kStageBytes);
+        hipMalloc(&sink, 4096 * sizeof(float));
+        hipMalloc(&hogbuf, hogn * sizeof(float));
+        hipMemset(hogbuf, 0, hogn * sizeof(float));
+        std::vector<float> host((size_t)num_stages * kStageBytes / 4);
+        for (int t = 0; t < num_stages; ++t)
+            for (int i = 0; i < kStageBytes / 4; ++i) host[(size_t)t * (kStageBytes / 4) + i] = (float)t;
+        hipMemcpy(w, host.data(), host.size() * 4, hipMemcpyHostToDevice);
+        hipStream_t side;
+        hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+        for (int rep = 0; rep < 3; ++rep)
+            for (int hog = 0; hog < 2; ++hog) {
+                verify<4, 4>(w, num_stages, 256, sink, hog, hogbuf, hogn, side);
+                verify<8, 4>(w, num_stages, 256, sink, hog, hogbuf, hogn, side);
+                verify<8, 7>(w, num_stages, 256, sink, hog, hogbuf, hogn, side);
+                verify<4, 4>(w, num_stages, 128, sink, hog, hogbuf, hogn, side);
+            }
+        return 0;
+    }
     const int num_stages = 1344;   // 32 layers x 42 stages: the bench flow's stream
     char* w;
     float* sink;
