@@ -21,7 +21,7 @@ import torch
 
 from helpers import steep_flow
 from test_gpu_headline_parity import _report
-from test_gpu_steep import _batch
+from test_gpu_steep import _batch, engine_switches  # noqa: F401  (fixture)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -83,3 +83,84 @@ def test_results_do_not_depend_on_what_else_the_device_is_doing(case, rows, k8s,
     _report({"config": "concurrency_%s_%d_%s" % (case, rows, "k8s" if k8s else "k8h"), "launches": launches,
              "deviating_from_the_quiet_result": deviating})
     assert deviating == 0, (case, rows, deviating, launches)
+
+
+def _flat(out):
+    if isinstance(out, torch.Tensor):
+        return [out]
+    return [t for o in out for t in _flat(o)]
+
+
+def _beside_the_hog(fn, hog, reps=6, calls=4):
+    """`fn()` on a quiet device (twice to warm up, once for the record), then `reps` x `calls` times while the side stream
+    sweeps `hog`: (calls, calls that deviate from the quiet result in any bit of any output tensor)."""
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    quiet = [t.clone() for t in _flat(fn())]
+    side = torch.cuda.Stream()
+    deviating = 0
+    for _ in range(reps):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                hog.add_(1.0)
+        for _ in range(calls):
+            deviating += not all(_same(a, b) for a, b in zip(quiet, _flat(fn())))
+        side.synchronize()
+    return reps * calls, deviating
+
+
+OTHER_ENGINES = ["k8", "gemm_k1", "gemm_k1_pipelined", "k7b", "k7"]
+
+
+@pytest.mark.parametrize("engine", OTHER_ENGINES)
+def test_the_other_engines_of_the_coupling_layer_beside_foreign_work(engine, hog, engine_switches):
+    """K8 (bf16x3 whole-layer kernel), the layer-by-layer path on K1's wave-tile and register-pipelined kernels, K7b / K7
+    (final Linear fused with the spline): counted vmcnt / LDS-DMA protocols of their own, the same demand."""
+    from nflows_amd import ops
+    from test_gpu_steep import _nsf_engines
+    flow_cpu, g, cfg = steep_flow(GOLDEN, "steep_nsf_k8")
+    switches, rows, k8s, expect = _nsf_engines(8)[engine]
+    x = _batch(g, "steep_nsf_k8", "x", rows, cfg["D"]).to(DEV)
+    noise = _batch(g, "steep_nsf_k8", "noise", rows, cfg["D"]).to(DEV)
+    flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+    engine_switches(switches["path"], switches["engine"], k8s)
+    os.environ.update(switches.get("env", {}))
+    with torch.no_grad():
+        calls, bad_f = _beside_the_hog(lambda: flow._transform(x), hog)
+        assert all(s in ops.last_layer_kernel() for s in expect), ops.last_layer_kernel()
+        _, bad_i = _beside_the_hog(lambda: flow._transform.inverse(noise), hog)
+    _report({"config": "concurrency_steep_nsf_k8_%s" % engine, "calls": 2 * calls, "deviating_from_the_quiet_result": bad_f + bad_i})
+    assert bad_f == 0 and bad_i == 0, (engine, bad_f, bad_i)
+
+
+@pytest.mark.parametrize("case,rows", [("steep_affine", 65536), ("steep_ar_rq", 4096)])
+def test_affine_and_autoregressive_flows_beside_foreign_work(case, rows, hog):
+    flow_cpu, g, cfg = steep_flow(GOLDEN, case)
+    x = _batch(g, case, "x", rows, cfg["D"]).to(DEV)
+    noise = _batch(g, case, "noise", rows, cfg["D"]).to(DEV)
+    flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+    with torch.no_grad():
+        calls, bad_f = _beside_the_hog(lambda: flow._transform(x), hog)
+        _, bad_i = _beside_the_hog(lambda: flow._transform.inverse(noise), hog)
+    _report({"config": "concurrency_%s" % case, "calls": 2 * calls, "deviating_from_the_quiet_result": bad_f + bad_i})
+    assert bad_f == 0 and bad_i == 0, (case, bad_f, bad_i)
+
+
+def test_training_step_gradients_beside_foreign_work(hog):
+    """Forward + backward of the fused training kernels (K14 forward / backward, the spline's backward, the weight-gradient
+    GEMMs): loss and every parameter gradient of an 8-layer RQ-NSF step on 65 536 rows, bit for bit."""
+    from nflows_amd import configs
+    flow = configs.rq_nsf_flow(8, 64, 8, 128, 2, 3.0, seed=0).to(DEV).train()
+    x = torch.randn(65536, 64, device=DEV, generator=torch.Generator(DEV).manual_seed(3))
+
+    def step():
+        for p in flow.parameters():
+            p.grad = None
+        loss = -flow.log_prob(x).mean()
+        loss.backward()
+        return [loss.detach()] + [p.grad for p in flow.parameters() if p.grad is not None]
+
+    calls, bad = _beside_the_hog(step, hog, reps=4, calls=3)
+    _report({"config": "concurrency_training_step", "calls": calls, "deviating_from_the_quiet_result": bad})
+    assert bad == 0, bad
