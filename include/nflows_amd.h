@@ -82,7 +82,7 @@ extern "C" {
 #define NFA_ACTIVATION_RELU 0             /* F.relu (the reference's default) */
 #define NFA_ACTIVATION_LEAKY_RELU 1       /* F.leaky_relu, negative_slope 0.01 */
 #define NFA_ACTIVATION_ELU 2              /* F.elu, alpha 1 */
-#define NFA_ACTIVATION_TANH 3             /* torch.tanh / F.tanh.  Other than ReLU: 8 or 10 bins, no context, not K8s. */
+#define NFA_ACTIVATION_TANH 3             /* torch.tanh / F.tanh.  Other than ReLU: 8 or 10 bins (round 5: also with a context), not K8s. */
 #define NFA_FLAG_ACTIVATION(a) ((a) << NFA_FLAG_ACTIVATION_SHIFT)
 
 /* tails */
@@ -253,7 +253,7 @@ int nfa_rqs_coupling_fused_linear_f32(const float *inputs, const float *hidden,
  * other kernels (same error class as the reference's fp32 path; environment NFA_K8_PIPE=1 selects
  * the reference's exact sequence, =0 additionally the unwoven loop).
  * Supported: num_bins = 8 or 10 (the reference's default; not with NFA_FLAG_LOGITS_LOG2E) and, ABI 9,
- * any other num_bins from 2 to 16 and 20, 24, 32 (plain final-layer loop on the spline kernel's own evaluator; no context), linear
+ * any other num_bins from 2 to 16 and 20, 24, 32 (plain final-layer loop on the spline kernel's own evaluator), linear
  * tails, hidden_features = 128, d_i <= 64, d_t % 4 == 0, d_t <= 64, features % 4 == 0,
  * features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
  */
@@ -327,7 +327,7 @@ int nfa_rqs_flow_resnet_f32(const float *inputs, const void *weights_packed,
  *                  it on the same stream; no host synchronisation in between.  (K8s on 64-row blocks sets
  *                  bit 1 / bit 2 instead: only the lower / upper 64 rows of the block are open, the other
  *                  half is written; the redo entry points honour the bits.)
- * Supported: num_bins = 8 or 10, and (ABI 9, without a context) any other num_bins from 2 to 16 and 20, 24, 32 -- final-layer rows as
+ * Supported: num_bins = 8 or 10, and (ABI 9; with a context: round 5) any other num_bins from 2 to 16 and 20, 24, 32 -- final-layer rows as
  * K8's general rule above, 16 ceil((3 num_bins - 1) / 16) per feature --, linear tails, hidden_features = 128 (narrower conditioners: zero-padded by the packer), d_i <= 64, d_t % 4 == 0,
  * d_t <= 64, features % 4 == 0, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
  * Table slots may repeat a column (d_t + d_i may exceed features): the host side pads other shapes into
@@ -401,8 +401,9 @@ int nfa_rqs_flow_resnet_f16x2_tile16_bins_f32(const float *inputs, const void *s
  *                  context_features zero.
  *   bias_packed    per block 384 floats: linear_layers[0], linear_layers[1], context_layer (accumulator order).
  * The block computes h + (W_1 relu(W_0 relu(h) + b_0) + b_1) * sigmoid(W_c context + b_c) (F.glu of the
- * concatenation, resnet.py:46-52).  Supported: as nfa_rqs_flow_resnet_f32 (8 or 10 bins) without
- * NFA_FLAG_LOGITS_LOG2E; otherwise NFA_ERR_UNSUPPORTED.
+ * concatenation, resnet.py:46-52).  Supported: as nfa_rqs_flow_resnet_f32 without NFA_FLAG_LOGITS_LOG2E -- 8 or 10 bins
+ * (woven final layer with ReLU blocks, the plain loop with NFA_FLAG_ACTIVATION leaky ReLU / ELU / tanh) and, round 5,
+ * every other served bin count with ReLU blocks (csrc/rqs_resnet_ctx.hip) --; otherwise NFA_ERR_UNSUPPORTED.
  */
 int nfa_rqs_flow_resnet_context_f32(const float *inputs, const float *context, int32_t context_features,
                                     const void *weights_packed, const float *bias_packed,
@@ -421,6 +422,8 @@ int nfa_rqs_flow_resnet_context_f32(const float *inputs, const float *context, i
  *                  header {1 / T_c, 0, 0, 0} + the gate's 128 biases x T_c (accumulator order).  The second
  *                  Linear's header keeps {out_scale, skip_scale}: the residual stream is multiplied by
  *                  skip_scale when the gated product is added to it.
+ * Served (round 5: csrc/rqs_resnet_f16_ctx_{a,b}.hip): every bin count of nfa_rqs_flow_resnet_f16x2_f32 with ReLU
+ * blocks, 8 / 10 bins with the other NFA_FLAG_ACTIVATION codes; reference vectors: tests/golden/flows_context_more.npz.
  * The second pass on flagged row blocks is nfa_rqs_flow_resnet_context_redo_f32.
  */
 int nfa_rqs_flow_resnet_context_f16x2_f32(const float *inputs, const float *context, int32_t context_features,

@@ -67,7 +67,7 @@ def ar_rq_flow(features=784, hidden_features=256, num_bins=8, tail_bound=3.0, nu
 
 
 def conditional_rq_nsf_flow(num_layers=3, features=16, num_bins=8, hidden_features=128, raw_context=5,
-                            context_features=12, tail_bound=3.0, seed=7):
+                            context_features=12, tail_bound=3.0, seed=7, activation=torch.nn.functional.relu):
     """A conditional RQ-NSF coupling flow: ResidualNet conditioners with `context_features` (context
     concatenated in front of the initial layer, GLU gate per block: resnet.py:9-52, :92-100), the raw
     context embedded by a Linear (flows/base.py:42-49).  The construction order matches
@@ -80,7 +80,8 @@ def conditional_rq_nsf_flow(num_layers=3, features=16, num_bins=8, hidden_featur
         layers.append(PiecewiseRationalQuadraticCouplingTransform(
             mask=create_alternating_binary_mask(features, even=(i % 2 == 0)),
             transform_net_create_fn=lambda i_, o_: ResidualNet(
-                i_, o_, hidden_features=hidden_features, context_features=context_features, num_blocks=2),
+                i_, o_, hidden_features=hidden_features, context_features=context_features, num_blocks=2,
+                activation=activation),
             num_bins=num_bins, tails="linear", tail_bound=tail_bound))
     return Flow(CompositeTransform(layers), StandardNormal([features]),
                 embedding_net=torch.nn.Linear(raw_context, context_features))

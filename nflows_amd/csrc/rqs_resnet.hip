@@ -53,15 +53,14 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     ResnetArgs a;
     int rc = make_dev_spec(spec, &a.sp);
     if (rc != NFA_OK) return rc;
-    const bool any_bins = a.sp.K != 8 && a.sp.K != 10;   // 2 .. 16 bins: the plain loop, no context, no log2(e) fold
-    // activations other than ReLU: 8 or 10 bins, the plain loop, no context, no log2(e) fold
-    if (activation != NFA_ACTIVATION_RELU && (any_bins || context_features > 0 || (flags & NFA_FLAG_LOGITS_LOG2E)))
+    const bool any_bins = a.sp.K != 8 && a.sp.K != 10;   // 2 .. 16, 20, 24, 32 bins: the plain loop, no log2(e) fold
+    // activations other than ReLU: 8 or 10 bins, the plain loop, no log2(e) fold
+    if (activation != NFA_ACTIVATION_RELU && (any_bins || (flags & NFA_FLAG_LOGITS_LOG2E)))
         return NFA_ERR_UNSUPPORTED;
     const int rows_per_feature = a.sp.K == 8 ? 24 : 16 * ((3 * a.sp.K - 1 + 15) / 16);
     if (a.sp.beta != 1.0f) return NFA_ERR_UNSUPPORTED;  // (identity initialisation: functional callers only)
     const bool bins_served = (a.sp.K >= 2 && a.sp.K <= 16) || a.sp.K == 20 || a.sp.K == 24 || a.sp.K == 32;
-    if (!bins_served || (a.sp.K != 8 && (flags & NFA_FLAG_LOGITS_LOG2E)) || (any_bins && context_features > 0) ||
-        !a.sp.linear ||
+    if (!bins_served || (a.sp.K != 8 && (flags & NFA_FLAG_LOGITS_LOG2E)) || !a.sp.linear ||
         hidden_features != 128 || (num_transform & 3) != 0 ||
         num_transform > 64 || num_identity > 64 || features > 128 || (features & 3) != 0 ||
         (batch & 127) != 0 || num_blocks > 64 || num_layers > 4096)
@@ -114,7 +113,10 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     // (with the log2(e) fold only the default woven form exists)
     const bool pipe = !any_bins && activation == NFA_ACTIVATION_RELU && use_pipe && ((a.sp.K == 8 && (!(flags & NFA_FLAG_LOGITS_LOG2E) || use_pipe == 2)) ||
                                   (a.sp.K == 10 && use_pipe == 2));
-    if (with_ctx && !(pipe && use_pipe == 2)) return NFA_ERR_UNSUPPORTED;
+    // a context: the woven default form at 8 / 10 bins with ReLU; the plain loop for the other bin counts and
+    // activations (round 5: rqs_resnet_ctx.hip)
+    const bool more_ctx = with_ctx && (any_bins || activation != NFA_ACTIVATION_RELU);
+    if (with_ctx && !more_ctx && !(pipe && use_pipe == 2)) return NFA_ERR_UNSUPPORTED;
     const size_t lds = (size_t)kRing * kStageVec4 * 16 + (size_t)(kBlock / kWave) * features * kRowPad * sizeof(float) +
                        (pipe ? (size_t)num_transform * rows_per_feature * sizeof(float) : 0) +
                        (size_t)(kBlock / kWave) * context_features * kRowPad * sizeof(float) +
@@ -158,7 +160,10 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     if (activation != NFA_ACTIVATION_RELU) kern = resnet_activation_kernel(activation, a.sp.K, inv, init_ks);
     else if (any_bins) kern = resnet_bins_kernel(a.sp.K, inv, init_ks);
     if ((activation != NFA_ACTIVATION_RELU || any_bins) && !kern) return NFA_ERR_UNSUPPORTED;
-    if (with_ctx && a.sp.K == 10) {
+    if (more_ctx) {
+        kern = resnet_context_kernel(a.sp.K, activation, inv, init_ks);
+        if (!kern) return NFA_ERR_UNSUPPORTED;
+    } else if (with_ctx && a.sp.K == 10) {
         if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 2, 10, true> : rqs_resnet_kernel<false, 1, 4, 2, 10, true>;
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 2, 10, true> : rqs_resnet_kernel<false, 1, 2, 2, 10, true>;
     } else if (with_ctx) {
@@ -169,8 +174,10 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         note_layer_kernel("rqs_resnet_kernel<inverse=%d, init_ks=%d, pipe=%d, K=%d, ctx=%d, act=%d>", inv ? 1 : 0, init_ks,
                           pipe ? use_pipe : 0, a.sp.K, with_ctx ? 1 : 0, activation);
     if (with_ctx && lds > 64 * 1024) {
-        static unsigned long long raised_ctx[8] = {};   // device masks (raise_dynamic_lds)
-        const int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (a.sp.K == 10 ? 4 : 0);
+        static unsigned long long raised_ctx[8 + 31 * 4 + 3 * 8] = {};   // device masks (raise_dynamic_lds)
+        const int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) +
+                          (!more_ctx ? (a.sp.K == 10 ? 4 : 0)
+                                     : 8 + (any_bins ? (a.sp.K - 2) * 4 : 31 * 4 + (activation - 1) * 8 + (a.sp.K == 10 ? 4 : 0)));
         {
             const int rc_lds = raise_dynamic_lds((const void*)kern, &raised_ctx[which], 160 * 1024 - 2048);
             if (rc_lds != NFA_OK) return rc_lds;

@@ -77,12 +77,12 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     int rc = make_dev_spec(spec, &a.sp);
     if (rc != NFA_OK) return rc;
     if (a.sp.beta != 1.0f) return NFA_ERR_UNSUPPORTED;
-    // bin counts: 8 and 10 have their own final-layer loops; 2 .. 16 and 20, 24, 32 otherwise (no context there)
+    // bin counts: 8 and 10 have their own final-layer loops; 2 .. 16 and 20, 24, 32 otherwise
     const bool any_bins = a.sp.K != 8 && a.sp.K != 10;
-    // activations other than ReLU: the two tuned bin counts, no context
-    if (activation != NFA_ACTIVATION_RELU && (any_bins || context_features > 0)) return NFA_ERR_UNSUPPORTED;
+    // activations other than ReLU: the two tuned bin counts (with or, round 5, without a context)
+    if (activation != NFA_ACTIVATION_RELU && any_bins) return NFA_ERR_UNSUPPORTED;
     const bool bins_served = (a.sp.K >= 2 && a.sp.K <= 16) || a.sp.K == 20 || a.sp.K == 24 || a.sp.K == 32;
-    if (!bins_served || (any_bins && context_features > 0) || !a.sp.linear || hidden_features != 128 || (num_transform & 3) != 0 || num_transform > 64 ||
+    if (!bins_served || !a.sp.linear || hidden_features != 128 || (num_transform & 3) != 0 || num_transform > 64 ||
         num_identity > 64 || features > 128 || (features & 3) != 0 || (batch & 127) != 0 || num_blocks > 64 ||
         num_layers > 4096)
         return NFA_ERR_UNSUPPORTED;
@@ -167,9 +167,18 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
                          : (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0) + (a.sp.K == 10 ? 8 : 0);
     if (elastic) which = 24 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0);
     if (any_bins) which = 32 + (a.sp.K - 2) * 8 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0);
+    constexpr int kWhichContext = 32 + 31 * 8 + 3 * 16 + 8;   // (behind the diagnostic instances' eight)
+    const bool more_ctx = with_ctx && (any_bins || activation != NFA_ACTIVATION_RELU);
     if (dbg_bins) {
         which = 32 + 31 * 8 + 3 * 16 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0);
         kern = k8h::debug_kernel(inv, init_ks, nw);
+        if (!kern) return NFA_ERR_UNSUPPORTED;
+    } else if (more_ctx) {
+        // a context beyond 8 / 10 bins with ReLU (round 5): rqs_resnet_f16_ctx_{a,b}.hip
+        which = kWhichContext + (any_bins ? (a.sp.K - 2) * 4 : 31 * 4 + (activation - 1) * 8 + (a.sp.K == 10 ? 4 : 0)) +
+                (inv ? 1 : 0) + (nw == 8 ? 2 : 0);
+        kern = k8h::context_kernel_a(a.sp.K, activation, inv, nw);
+        if (!kern) kern = k8h::context_kernel_b(a.sp.K, activation, inv, nw);
         if (!kern) return NFA_ERR_UNSUPPORTED;
     } else if (activation != NFA_ACTIVATION_RELU) {
         which = 32 + 31 * 8 + (activation - 1) * 16 + (a.sp.K == 10 ? 8 : 0) + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (nw == 8 ? 4 : 0);
@@ -178,7 +187,7 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
         kern = a.sp.K <= 9 ? k8h::bins_kernel_a(a.sp.K, inv, init_ks, nw)
                : a.sp.K <= 16 ? k8h::bins_kernel_b(a.sp.K, inv, init_ks, nw) : k8h::bins_kernel_c(a.sp.K, inv, init_ks, nw);
     }
-    if (dbg_bins) {
+    if (dbg_bins || more_ctx) {
     } else if (activation != NFA_ACTIVATION_RELU || any_bins) {
         if (!kern) return NFA_ERR_UNSUPPORTED;
     }
@@ -218,7 +227,7 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     note_layer_kernel("k8h::rqs_resnet_f16_kernel<inverse=%d, init_ks=%d, waves=%d, K=%d, ctx=%d, ring=%d, act=%s>", inv ? 1 : 0,
                       init_ks, nw, a.sp.K, with_ctx ? 1 : 0, elastic ? k8h::kRingElastic : k8h::kRing, act_names[activation]);
     if (lds_launch > 64 * 1024) {
-        static unsigned long long raised[32 + 31 * 8 + 3 * 16 + 8] = {};   // device masks (raise_dynamic_lds)
+        static unsigned long long raised[32 + 31 * 8 + 3 * 16 + 8 + 31 * 4 + 3 * 8] = {};   // device masks (raise_dynamic_lds)
         {
             const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], (int)lds_cap);
             if (rc_lds != NFA_OK) return rc_lds;

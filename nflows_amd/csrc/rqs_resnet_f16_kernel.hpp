@@ -490,7 +490,7 @@ template <bool INVERSE, int INIT_KS, int NW, int KB = 8, bool CTX = false, int R
 __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Args a) {
     static_assert(!DBG || KB == 8, "the diagnostic instances: 8 bins");
     static_assert(!CTX || INIT_KS == 4, "context: two identity k-steps + two context k-steps");
-    static_assert(ACT == kActRelu || (!CTX && ACT >= kActLeakyRelu && ACT <= kActTanh), "other activations: no context");
+    static_assert(ACT == kActRelu || (ACT >= kActLeakyRelu && ACT <= kActTanh), "the blocks' activation");
     constexpr int kThreads = NW * kWave;
     // dynamic LDS: the weight ring, per wave a [D][33] row tile, two parameter blocks (current / next layer)
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
@@ -709,11 +709,12 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                     // temps = W_1 relu(u) + b_1 in accumulators of its own (u's registers: its pieces first) ...
                     {
                         float peak = 0.0f;
-                        ConvWeave<true>{u[0], qh[0], ql[0], qh[1], ql[1], conv_scale, peak}.all();
-                        ConvWeave<true>{u[1], qh[2], ql[2], qh[3], ql[3], conv_scale, peak}.all();
-                        ConvWeave<true>{u[2], qh[4], ql[4], qh[5], ql[5], conv_scale, peak}.all();
-                        ConvWeave<true>{u[3], qh[6], ql[6], qh[7], ql[7], conv_scale, peak}.all();
-                        worst = __builtin_fmaxf(worst, peak * conv_scale);
+                        ConvWeave<ACT>{u[0], qh[0], ql[0], qh[1], ql[1], conv_scale, peak}.all();
+                        ConvWeave<ACT>{u[1], qh[2], ql[2], qh[3], ql[3], conv_scale, peak}.all();
+                        ConvWeave<ACT>{u[2], qh[4], ql[4], qh[5], ql[5], conv_scale, peak}.all();
+                        ConvWeave<ACT>{u[3], qh[6], ql[6], qh[7], ql[7], conv_scale, peak}.all();
+                        // (ELU / tanh: `peak` was taken behind the scale, see gemm_kmajor_converting)
+                        worst = __builtin_fmaxf(worst, activation_is_homogeneous(ACT) ? peak * conv_scale : peak);
                     }
                     const float* bias = gemm + kHdr + half * 16;
                     const float ratio = gemm[1];
@@ -963,6 +964,10 @@ KernelFn bins_kernel_a(int K, bool inverse, int init_ks, int waves);     // 2 ..
 KernelFn bins_kernel_b(int K, bool inverse, int init_ks, int waves);     // 11 .. 16 bins
 KernelFn bins_kernel_c(int K, bool inverse, int init_ks, int waves);     // 20, 24, 32 bins
 KernelFn activation_kernel(int activation, int K, bool inverse, int init_ks, int waves);   // NFA_ACTIVATION_* > 0, 8 / 10 bins
+// conditioners with a context (init_ks = 4) beyond the two tuned bin counts with ReLU (round 5): ReLU with 2 .. 7, 9,
+// 11 .. 16, 20, 24, 32 bins, the other activations with 8 / 10 bins
+KernelFn context_kernel_a(int K, int activation, bool inverse, int waves);   // ReLU, 2 .. 7, 9, 11, 12 bins
+KernelFn context_kernel_b(int K, int activation, bool inverse, int waves);   // ReLU, 13 .. 16, 20, 24, 32 bins; leaky ReLU / ELU / tanh, 8 / 10 bins
 KernelFn debug_kernel(bool inverse, int init_ks, int waves);             // 8 bins, ReLU, no context: the DBG instances
 }  // namespace k8h
 }  // namespace nfa

@@ -212,10 +212,10 @@ __device__ __forceinline__ void gemm_context_tile(f32x16& acc, const float* s_ct
 // sigmoid(context_layer(context)) before the skip connection (F.glu of the concatenation).
 template <bool INVERSE, int PRESCALED, int INIT_KS, int PIPE = 0, int KB = 8, bool CTX = false, int ACT = kActRelu>  // PIPE: 0 plain loop, 1 woven, 2 woven with FlatSteps<FAST>; ACT: the blocks' activation
 __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs a) {
-    static_assert(ACT == kActRelu || (!CTX && PIPE == 0 && PRESCALED == 1 && ACT >= kActLeakyRelu && ACT <= kActTanh),
-                  "other activations: the plain loop, no context");
-    static_assert(KB == 8 || (KB == 10 && PIPE != 1 && PRESCALED == 1) || (KB >= 2 && KB <= 32 && PIPE == 0 && PRESCALED == 1 && !CTX),
-                  "10 bins: plain loop, or woven with the shorter sequence; other bin counts (2 .. 16): plain loop, no context");
+    static_assert(ACT == kActRelu || (PIPE == 0 && PRESCALED == 1 && ACT >= kActLeakyRelu && ACT <= kActTanh),
+                  "other activations: the plain loop");
+    static_assert(KB == 8 || (KB == 10 && PIPE != 1 && PRESCALED == 1) || (KB >= 2 && KB <= 32 && PIPE == 0 && PRESCALED == 1),
+                  "10 bins: plain loop, or woven with the shorter sequence; other bin counts (2 .. 16, 20, 24, 32): plain loop");
     // rows of the final layer per transformed feature (8 bins: 23 logits padded to 24, two features share three tiles;
     // otherwise 3 K - 1 padded to whole 16-row lane-half shares)
     constexpr int kFinalRows = KB == 8 ? 24 : 16 * ((3 * KB - 1 + 15) / 16);
@@ -713,5 +713,6 @@ namespace nfa {
 typedef void (*ResnetKernelFn)(const ResnetArgs);
 // instances of rqs_resnet_bins.hip (plain final-layer loop): nullptr when that unit does not hold the combination
 ResnetKernelFn resnet_bins_kernel(int K, bool inverse, int init_ks);                      // 2 .. 16 except 8 / 10, 20, 24, 32
+ResnetKernelFn resnet_context_kernel(int K, int activation, bool inverse, int init_ks);     // with a context (round 5): those of the two lines above
 ResnetKernelFn resnet_activation_kernel(int activation, int K, bool inverse, int init_ks);  // NFA_ACTIVATION_* > 0, 8 / 10 bins
 }  // namespace nfa

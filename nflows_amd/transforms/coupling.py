@@ -689,7 +689,7 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         return (self.fuse_conditioner and self.fuse_final_linear and not torch.is_grad_enabled()
                 and context_ok and type(net) is ResidualNet
                 and net.hidden_features <= 128 and self.tails == "linear"
-                and (self.num_bins in (8, 10) or (ops.whole_layer_bins(self.num_bins) and context is None))
+                and ops.whole_layer_bins(self.num_bins)
                 and 1 <= self.num_identity_features <= 64 and 1 <= self.num_transform_features
                 and self._fused_geometry()[1] <= 64 and self._fused_geometry()[0] <= 128
                 and self._activation_ok(context)
@@ -697,15 +697,15 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
                 and (not any(b.use_batch_norm for b in net.blocks) or self._folded_net() is not None))
 
     def _activation_ok(self, context):
-        """ReLU everywhere; F.leaky_relu / F.elu / tanh (round 4) at 8 or 10 bins without a context, batch norm (its fold
-        moves a positive scale through the ReLU) or the log2(e) fold."""
+        """ReLU everywhere; F.leaky_relu / F.elu / tanh (round 4; with a context: round 5) at 8 or 10 bins without batch
+        norm (its fold moves a positive scale through the ReLU) or the log2(e) fold."""
         act = self._block_activation()
         if act is None:
             return False
         if act == N.ACTIVATION_RELU:
             return True
         # (ELU / tanh are applied to the value at the pieces' scale: the experiment switch NFA_K8_ACT_SCALE must be 1)
-        return (self.num_bins in (8, 10) and context is None and not self._log2e()
+        return (self.num_bins in (8, 10) and not self._log2e()
                 and (act == N.ACTIVATION_LEAKY_RELU or self.conditioner_act_scale == 1.0)
                 and not any(b.use_batch_norm for b in self.transform_net.blocks))
 

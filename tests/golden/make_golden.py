@@ -1007,6 +1007,73 @@ def conditional_flow_case():
     print("flows_context: 1 case")
 
 
+def conditional_flow_more_cases():
+    """Conditional flows beyond 8 / 10 bins with ReLU (round 5: the whole-layer kernels' context instances for every served
+    bin count and for the other block activations): the construction of conditional_flow_case with `num_bins` and the
+    ResidualNets' `activation` varied, 256 rows, forward / inverse / log_prob in fp32 and fp64 from the REAL reference."""
+    out, meta = {}, []
+    cases = [("ctx_k4", 4, "relu"), ("ctx_k6", 6, "relu"), ("ctx_k9", 9, "relu"), ("ctx_k12", 12, "relu"), ("ctx_k16", 16, "relu"),
+             ("ctx_k24", 24, "relu"), ("ctx_leaky_relu_k8", 8, "leaky_relu"), ("ctx_elu_k10", 10, "elu"), ("ctx_tanh_k8", 8, "tanh"),
+             ("ctx_tanh_k10", 10, "tanh")]
+    F = torch.nn.functional
+    acts = {"relu": F.relu, "leaky_relu": F.leaky_relu, "elu": F.elu, "tanh": torch.tanh}
+    for idx, (name, K, act) in enumerate(cases):
+        L, D, H, B, C, E = 3, 16, 128, 256, 5, 12
+        seed = 70 + idx
+        torch.manual_seed(seed)
+        layers = []
+        for i in range(L):
+            layers.append(RandomPermutation(D))
+            layers.append(PiecewiseRationalQuadraticCouplingTransform(
+                mask=torchutils.create_alternating_binary_mask(D, even=(i % 2 == 0)),
+                transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=H, context_features=E,
+                                                                   num_blocks=2, activation=acts[act]),
+                num_bins=K, tails="linear", tail_bound=3.0))
+        flow = Flow(CompositeTransform(layers), StandardNormal([D]), embedding_net=nn.Linear(C, E))
+        # (tanh / ELU blocks saturate: a milder sharpening than the ReLU cases' keeps the splines non-trivial)
+        s_final, s_lin1, s_ctx = (4.0, 30.0, 3.0) if act in ("relu", "leaky_relu") else (8.0, 6.0, 3.0)
+        with torch.no_grad():
+            for p_name, p in flow.named_parameters():
+                if "final_layer" in p_name:
+                    p.mul_(s_final)
+                elif "linear_layers.1" in p_name:
+                    p.mul_(s_lin1)
+                elif "context_layer" in p_name:
+                    p.mul_(s_ctx)
+        g = torch.Generator().manual_seed(700 + idx)
+        x = 1.2 * torch.randn(B, D, generator=g)
+        noise = torch.randn(B, D, generator=g)
+        ctx = torch.randn(B, C, generator=g)
+        flow.eval()
+        with torch.no_grad():
+            emb = flow._embedding_net(ctx)
+            lp = flow.log_prob(x, context=ctx)
+            z, lad = flow._transform(x, context=emb)
+            xs, lad_inv = flow._transform.inverse(noise, context=emb)
+            f64 = flow.double()
+            emb64 = f64._embedding_net(ctx.double())
+            lp64 = f64.log_prob(x.double(), context=ctx.double())
+            z64, lad64 = f64._transform(x.double(), context=emb64)
+            xs64, ladi64 = f64._transform.inverse(noise.double(), context=emb64)
+            flow.float()
+        for k, v in dict(x=x, noise=noise, context=ctx, log_prob=lp, z=z, lad=lad, inv_x=xs, inv_lad=lad_inv,
+                         log_prob64=lp64, z64=z64, lad64=lad64, inv_x64=xs64, inv_lad64=ladi64).items():
+            out[name + "/" + k] = npy(v)
+        names, sums = [], []
+        for k, v in flow.state_dict().items():
+            names.append(k)
+            sums.append([float(v.double().sum()), float(v.double().abs().sum())])
+        out[name + "/param_names"] = np.array(names).astype(str)
+        out[name + "/param_checksums"] = np.array(sums, dtype=np.float64)
+        meta.append((name, repr(dict(kind="rq_nsf_context", L=L, D=D, K=K, H=H, B=B, C=C, E=E, tail_bound=3.0, seed=seed,
+                                     activation=act, scale_final=s_final, scale_linear1=s_lin1, scale_context=s_ctx))))
+        print("   %s: |lad| mean %.2f, reference fp32 vs fp64: z %.2e lad %.2e" % (
+            name, float(lad64.abs().mean()), float((z.double() - z64).abs().max()), float((lad.double() - lad64).abs().max())))
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "flows_context_more.npz"), **out)
+    print("flows_context_more: %d cases" % len(cases))
+
+
 def bin_count_flow_cases():
     """Round 4, the whole-layer kernels' other bin counts (2 .. 16 except 8 and 10, and 20, 24, 32): two-layer coupling flows with steep
     splines (the recipe of steep_flow_cases) at D = 32, H = 128, forward and inverse of the reference in fp32 and fp64.
@@ -1411,6 +1478,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "context":
         conditional_flow_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "context_more":
+        conditional_flow_more_cases()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "grads":
         grad_cases()

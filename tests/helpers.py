@@ -256,16 +256,24 @@ def assert_sibling_spline_parity(got, ref, truth, tol, cap, what=""):
         assert e_got <= max(4.0 * e_ref, cap), "%s: max err vs fp64 %.3e (reference fp32: %.3e)" % (what, e_got, e_ref)
 
 
-def golden_conditional_flow(golden_dir):
-    """The conditional flow of tests/golden/flows_context.npz rebuilt from its seed (weights are not
-    stored; per-parameter checksums are, and are checked here).  Returns (flow on CPU, npz)."""
+CONTEXT_MORE_CASES = ("ctx_k4", "ctx_k6", "ctx_k9", "ctx_k12", "ctx_k16", "ctx_k24", "ctx_leaky_relu_k8", "ctx_elu_k10",
+                      "ctx_tanh_k8", "ctx_tanh_k10")
+
+
+def golden_conditional_flow(golden_dir, case=None):
+    """The conditional flow of tests/golden/flows_context.npz -- or `case` of flows_context_more.npz (round 5: other bin
+    counts and block activations) -- rebuilt from its seed (weights are not stored; per-parameter checksums are, and are
+    checked here).  Returns (flow on CPU, npz, name)."""
     import torch
     from nflows_amd import configs
-    g = np.load(os.path.join(golden_dir, "flows_context.npz"))
-    name, cfg = g["meta"][0]
-    cfg = parse_kwargs(cfg)
+    g = np.load(os.path.join(golden_dir, "flows_context.npz" if case is None else "flows_context_more.npz"))
+    meta = dict((str(n), str(c)) for n, c in g["meta"])
+    name = str(g["meta"][0][0]) if case is None else case
+    cfg = parse_kwargs(meta[name])
+    F = torch.nn.functional
+    act = {"relu": F.relu, "leaky_relu": F.leaky_relu, "elu": F.elu, "tanh": torch.tanh}[cfg.get("activation", "relu")]
     flow = configs.conditional_rq_nsf_flow(cfg["L"], cfg["D"], cfg["K"], cfg["H"], cfg["C"], cfg["E"],
-                                           cfg["tail_bound"], seed=cfg["seed"])
+                                           cfg["tail_bound"], seed=cfg["seed"], activation=act)
     with torch.no_grad():
         for n_, p in flow.named_parameters():
             if "final_layer" in n_:
@@ -279,7 +287,7 @@ def golden_conditional_flow(golden_dir):
         v = sd[str(n_)].double()
         assert abs(float(v.sum()) - total) <= 1e-9 * (1 + abs(total)), n_
         assert abs(float(v.abs().sum()) - absolute) <= 1e-9 * (1 + absolute), n_
-    return flow.eval(), g, str(name)
+    return flow.eval(), g, name
 
 
 def steepen(module, num_bins=None, wh_scale=1.0, d_scale=1.0, hidden_scale=1.0):

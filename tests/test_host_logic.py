@@ -1253,7 +1253,7 @@ def test_no_mfma_result_lands_on_its_own_operands():
     # (round 4: K8h's instances live in four translation units -- the other bin counts and activations in three of their
     #  own --, compiled side by side here as in the Makefile)
     names = ("rqs_resnet_f16s.hip", "rqs_resnet_f16.hip", "rqs_resnet_f16_bins_a.hip", "rqs_resnet_f16_bins_b.hip",
-             "rqs_resnet_f16_bins_c.hip")
+             "rqs_resnet_f16_bins_c.hip", "rqs_resnet_f16_ctx_a.hip", "rqs_resnet_f16_ctx_b.hip")
 
     def assembly(name):
         return subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
@@ -1506,8 +1506,11 @@ def test_block_activation_routing():
         assert mixed._block_activation() is None and not mixed._resnet_eligible(None)
         assert layer(F.relu, K=4)._resnet_eligible(None) and not layer(F.elu, K=4)._resnet_eligible(None)
         assert not layer(F.elu, bn=True)._activation_ok(None) and layer(F.relu, bn=True)._activation_ok(None)
+        # with a context (round 5: context instances for the other activations at 8 / 10 bins, and for every served bin
+        # count with ReLU -- csrc/rqs_resnet_f16_ctx_{a,b}.hip, rqs_resnet_ctx.hip)
         ctx = torch.zeros(4, 3)
-        assert not layer(F.tanh, ctx=3)._activation_ok(ctx) and layer(F.relu, ctx=3)._activation_ok(ctx)
+        assert layer(F.tanh, ctx=3)._activation_ok(ctx) and layer(F.relu, ctx=3)._activation_ok(ctx)
+        assert not layer(F.tanh, K=4, ctx=3)._activation_ok(ctx) and layer(F.relu, K=4, ctx=3)._activation_ok(ctx)
     assert (N.ACTIVATION_TANH << N.FLAG_ACTIVATION_SHIFT) == 0x3000
     assert not ops.use_tile16(1024, 8, None, torch.device("cpu"), N.ACTIVATION_ELU)
 

@@ -330,15 +330,17 @@ def test_eager_port_other_configs_bit_identical(golden_dir):
             flow.float()
 
 
-def test_eager_port_with_context_is_bit_identical(golden_dir):
+@pytest.mark.parametrize("case", [None, "ctx_k4", "ctx_k16", "ctx_k24", "ctx_elu_k10", "ctx_tanh_k8"])
+def test_eager_port_with_context_is_bit_identical(golden_dir, case):
     """The eager port on a conditional flow (context embedded by a Linear, concatenated in front of every
     conditioner's initial layer, GLU gate per residual block) against the vectors the reference produced
-    for it (tests/golden/flows_context.npz): bit-identical in float32, 1e-12 in float64."""
+    for it (tests/golden/flows_context.npz; round 5: other bin counts and block activations,
+    flows_context_more.npz): bit-identical in float32, 1e-12 in float64."""
     import torch
     from helpers import golden_conditional_flow
     from oracle import eager
     torch.set_num_threads(1)
-    flow, g, name = golden_conditional_flow(golden_dir)
+    flow, g, name = golden_conditional_flow(golden_dir, case)
     x, noise, ctx = (torch.from_numpy(g[name + "/" + k]) for k in ("x", "noise", "context"))
     with torch.no_grad():
         emb = flow._embedding_net(ctx)

@@ -3,4 +3,4 @@ set -u
 ROOTDIR=${GRAFT_REPO_ROOT:-$PWD}
 cd $ROOTDIR
 mkdir -p gpurun_out/r5f
-timeout 400 python tests/probes/hog_all_families.py 8 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r5f/hog_all_families.txt
+timeout 600 python -m pytest tests/test_gpu_context.py -q -m gpu 2>&1 | tail -40 | cut -c1-300 | tee gpurun_out/r5f/context_test.txt
