@@ -370,9 +370,14 @@ struct WgradPlan {
 // `count` same-shaped problems share the chip: fewer batch slices each (fewer partial results to write and to sum,
 // a longer stream per workgroup: the two-stage ramp of the ring is paid once per 32 stages instead of once per 8)
 // rows per stage of the 128 x 128 form: 32, or -- NFA_K10_ROWS=16, the bf16 engine only -- 16 with two workgroups per CU
+// (the three switches are read once per process: experiments set them in the environment of a fresh process)
+static const char* wgrad_engine_env() {
+    static const char* const eng = getenv("NFA_K10_ENGINE");
+    return eng;
+}
 static int wgrad_rows(int variant, int problems_times_blocks) {
-    const char* e = getenv("NFA_K10_ROWS");
-    const char* eng = getenv("NFA_K10_ENGINE");
+    static const char* const e = getenv("NFA_K10_ROWS");
+    const char* eng = wgrad_engine_env();
     if (variant != 0 || (eng && eng[0] == 'f')) return kWgRows;
     if (e) return atoi(e) == 16 ? 16 : kWgRows;
     // 16-row stages (49 KB of LDS: two workgroups per CU, the split of one runs beside the MFMAs of the other) where the
@@ -381,7 +386,7 @@ static int wgrad_rows(int variant, int problems_times_blocks) {
     return problems_times_blocks >= 4 ? 16 : kWgRows;
 }
 static int wgrad_wgs_per_cu(int rows) {
-    const char* e = getenv("NFA_K10_WGS");   // (experiment)
+    static const char* const e = getenv("NFA_K10_WGS");   // (experiment)
     return rows == 16 ? (e && atoi(e) > 0 ? atoi(e) : 2) : 1;
 }
 
@@ -456,7 +461,7 @@ extern "C" int nfa_linear_wgrad_batched_f32(int32_t count, const float* const* i
         a.blocks_i = p.blocks_i;
         const dim3 grid((unsigned)(p.blocks_o * p.blocks_i), (unsigned)p.ksplit, (unsigned)count);
         // engine of the 128 x 128 result blocks: "bf16x3" (default since round 4) or "f32" (NFA_K10_ENGINE)
-        const char* eng = getenv("NFA_K10_ENGINE");
+        const char* eng = wgrad_engine_env();
         const bool bf16 = !eng || eng[0] != 'f';
         if (p.variant == 0 && bf16 && p.rows == 16) {
             constexpr size_t lds = (size_t)kWgRing * 16 * (128 + 128) * 4;

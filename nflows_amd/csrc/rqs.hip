@@ -678,8 +678,11 @@ static int launch_wavetile(const CouplingArgs& a, int inverse, hipStream_t st) {
         a.bins ? (inverse ? rqs_coupling_wavetile<KT, true, true> : rqs_coupling_wavetile<KT, false, true>)
                : (inverse ? rqs_coupling_wavetile<KT, true> : rqs_coupling_wavetile<KT, false>);
     // persistent: exactly the workgroups that are resident together (registers and LDS decide)
-    static int per_cu_cache[4] = {0, 0, 0, 0};
-    int& per_cu = per_cu_cache[(inverse ? 1 : 0) + (a.bins ? 2 : 0)];
+    // (per device: occupancy is a property of the device the launch goes to)
+    static int per_cu_cache[64][4] = {};
+    int dev = 0;
+    NFA_HIP_CHECK(hipGetDevice(&dev));
+    int& per_cu = per_cu_cache[dev & 63][(inverse ? 1 : 0) + (a.bins ? 2 : 0)];
     if (per_cu == 0) {
         int n = 0;
         NFA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kBlock, lds));

@@ -2,5 +2,5 @@
 set -u
 ROOTDIR=${GRAFT_REPO_ROOT:-$PWD}
 cd $ROOTDIR
-mkdir -p gpurun_out/r5f
-timeout 600 python -m pytest tests/test_gpu_context.py -q -m gpu 2>&1 | tail -40 | cut -c1-300 | tee gpurun_out/r5f/context_test.txt
+timeout 600 python -m pytest tests/test_gpu_grads.py tests/test_gpu_kernels.py tests/test_gpu_bin_index.py -q -x -m gpu 2>&1 | tail -3
+bash tools/collect_profiles.sh r5 2>&1 | tail -3 | cut -c1-600
