@@ -32,9 +32,9 @@
 extern "C" {
 #endif
 
-#define NFA_ABI_VERSION 10 /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 7; round 4: 8,
+#define NFA_ABI_VERSION 11 /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 7; round 4: 8,
                               9: whole-layer kernels for 2 .. 16 bins, nfa_resnet_backward_f32, W_f^T in K14's backward stream;
-                              round 5: 10: `bin_idx` outputs of the spline kernels, nfa_searchsorted_f32) */
+                              round 5: 10: `bin_idx` outputs of the spline kernels, nfa_searchsorted_f32; 11: NFA_FLAG_RESIDUAL_BLOCKS) */
 
 /* return codes */
 #define NFA_OK 0
@@ -72,6 +72,10 @@ extern "C" {
 #define NFA_FLAG_SKIP_OUTPUTS 32          /* with NFA_FLAG_STANDARD_NORMAL_LOG_PROB: `outputs` (z) is not
                                              written (may be null): Flow.log_prob never looks at it */
 
+#define NFA_FLAG_RESIDUAL_BLOCKS 64        /* nfa_affine_flow_mlp_f32 only (ABI 11): the conditioner is a ResidualNet (nn/nets/resnet.py:55-100,
+                                           * SimpleRealNVP's conditioner, flows/realnvp.py:44-71): the num_hidden_layers (even) hidden Linears are the
+                                           * linear_layers of num_hidden_layers / 2 residual blocks (resnet.py:39-52, ReLU, no batch norm), no
+                                           * activation behind the initial layer or in front of the output layer; same packed layout. */
 #define NFA_FLAG_PAD_COLUMNS_SHIFT 8       /* with NFA_FLAG_STANDARD_NORMAL_LOG_PROB: bits 8-10 = number of trailing */
 #define NFA_FLAG_PAD_COLUMNS_MASK 0x700   /* columns (0-7) that are the host's padding of the row (they pass through
                                              every layer, see nflows_amd/ops.py: fused_geometry), not features: the
@@ -473,7 +477,9 @@ int nfa_rqs_flow_resnet_redo_f32(const float *inputs, const void *weights_packed
  *   tables          as for nfa_rqs_flow_resnet_f32 (int32 [(num_layers + 1) * 128]).
  *   scale_activation NFA_SCALE_DEFAULT | NFA_SCALE_GENERAL | NFA_SCALE_ADDITIVE.
  *   flags           NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_STANDARD_NORMAL_LOG_PROB
- *                   | NFA_FLAG_SKIP_OUTPUTS.
+ *                   | NFA_FLAG_SKIP_OUTPUTS | NFA_FLAG_RESIDUAL_BLOCKS (ABI 11: ResidualNet conditioners -- initial_layer,
+ *                   the blocks' linear_layers in order, final_layer in the places of _input_layer, _hidden_layers,
+ *                   _output_layer; the reference's SimpleRealNVP, flows/realnvp.py:17-71).
  * Supported: hidden_features = 128, d_i <= 64, d_t <= 64, features % 4 == 0, features <= 128,
  * batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED (callers then run the conditioner's GEMMs and K2).
  */

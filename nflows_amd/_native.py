@@ -27,13 +27,14 @@ STATUS_BAD_INDEX = 4
 
 FLAG_INVERSE, FLAG_ACCUMULATE_LOGABSDET, FLAG_WEIGHTS_BF16X3, FLAG_LOGITS_LOG2E = 1, 2, 4, 8
 FLAG_STANDARD_NORMAL_LOG_PROB, FLAG_SKIP_OUTPUTS = 16, 32
+FLAG_RESIDUAL_BLOCKS = 64    # nfa_affine_flow_mlp_f32: the conditioner is a ResidualNet (ABI 11)
 FLAG_PAD_COLUMNS_SHIFT = 8   # bits 8-10: trailing pad columns the density epilogue leaves out
 FLAG_ACTIVATION_SHIFT = 12   # bits 12-14: activation of the conditioner's residual blocks in the whole-layer kernels
 ACTIVATION_RELU, ACTIVATION_LEAKY_RELU, ACTIVATION_ELU, ACTIVATION_TANH = 0, 1, 2, 3
 TAILS_NONE, TAILS_LINEAR = 0, 1
 SCALE_DEFAULT, SCALE_GENERAL, SCALE_ADDITIVE, SCALE_GIVEN, SCALE_SOFTPLUS = 0, 1, 2, 3, 4
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 EXPORTS = (
     "nfa_abi_version",

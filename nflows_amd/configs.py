@@ -45,6 +45,29 @@ def affine_coupling_flow(num_layers=8, features=32, hidden_sizes=(128, 128), see
     return Flow(CompositeTransform(layers), StandardNormal([features]))
 
 
+def simple_realnvp_flow(features=16, hidden_features=128, num_layers=6, num_blocks_per_layer=2,
+                        use_volume_preserving=False, seed=0):
+    """The composition the reference's SimpleRealNVP factory builds (flows/realnvp.py:17-71; the factory itself is outside
+    SURVEY section 8): affine (or additive) couplings on a float +-1 mask that flips from layer to layer, ResidualNet
+    conditioners, no permutations.  Same construction order, so the seed reproduces the factory's weights
+    (tests/golden/make_golden.py `realnvp` stores their checksums)."""
+    from .transforms import AdditiveCouplingTransform
+    from .nn.nets import ResidualNet
+    if seed is not None:
+        torch.manual_seed(seed)
+    coupling = AdditiveCouplingTransform if use_volume_preserving else AffineCouplingTransform
+    mask = torch.ones(features)
+    mask[::2] = -1
+    layers = []
+    for _ in range(num_layers):
+        layers.append(coupling(
+            mask=mask,
+            transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=hidden_features,
+                                                               num_blocks=num_blocks_per_layer)))
+        mask = mask * -1
+    return Flow(CompositeTransform(layers), StandardNormal([features]))
+
+
 def moons_maf_flow(num_layers=2, features=2, hidden_features=4, seed=0):
     """configs[0]: the reference README flow (README.md:41-51), MAF + RandomPermutation."""
     if seed is not None:

@@ -46,7 +46,11 @@ struct AffineMlpArgs {
     int Ds;                // columns the density sums over (features minus NFA_FLAG_PAD_COLUMNS)
 };
 
-template <bool INVERSE, int INIT_KS, bool ADDITIVE>
+// RESNET (round 5): the conditioner is a ResidualNet (nn/nets/resnet.py:55-100, the conditioner of the reference's own
+// SimpleRealNVP, flows/realnvp.py:44-71) -- the same stream of stages (initial Linear, 2 x num_blocks hidden Linears,
+// output tiles), other arithmetic between them: no activation behind the initial layer, every block computes
+// h + W_1 relu(W_0 relu(h) + b_0) + b_1 (resnet.py:39-52) as in K8 (rqs_resnet_kernel.hpp), the output layer takes h itself.
+template <bool INVERSE, int INIT_KS, bool ADDITIVE, bool RESNET = false>
 __global__ void __launch_bounds__(kBlock, 2) affine_mlp_kernel(const AffineMlpArgs a) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
@@ -120,8 +124,13 @@ __global__ void __launch_bounds__(kBlock, 2) affine_mlp_kernel(const AffineMlpAr
             if ((layer + (blockIdx.x >= (gridDim.x >> 1) ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
             const int* tab = s_tab[tb];
-            // the next layer's table goes to the other half now (read after this layer's stage barriers)
-            if (tid < kTabLayer) {
+            // the next layer's table goes to the other half now (read after this layer's stage barriers).
+            // A SCALAR branch (the first two waves, whole): with `tid < kTabLayer` as a per-lane condition hipcc
+            // (ROCm 7.2) put the spill store of `lad_acc` into the join block IN FRONT of the exec restore -- waves 2
+            // and 3 arrive there with exec = 0, never stored it and lost the log-determinants of all layers but the
+            // last (RESNET instances, round 5; tests/test_host_logic.py::test_no_spill_between_a_join_and_its_exec_restore).
+            static_assert(kTabLayer % kWave == 0, "the table is copied by whole waves");
+            if (__builtin_amdgcn_readfirstlane(wave) < kTabLayer / kWave) {
                 const int nl = layer + 1 < a.num_layers ? layer + 1 : 0;
                 s_tab[tb ^ 1][tid] = checked(a.tables[nl * kTabLayer + tid], tid < kTabTr ? tid < a.di : tid - kTabTr < dt);
             }
@@ -158,6 +167,35 @@ __global__ void __launch_bounds__(kBlock, 2) affine_mlp_kernel(const AffineMlpAr
             }
             bias += 128;
 
+            if constexpr (RESNET) {
+                // ---- residual blocks: h += W_1 relu(W_0 relu(h) + b_0) + b_1 (the register budget of K8's blocks: the
+                //      pieces of h survive the first Linear for the skip connection, which goes into the second
+                //      Linear's accumulators tile by tile)
+                for (int blk = 0; blk < (a.num_hidden >> 1); ++blk) {
+                    bf16x8 qh[8], qm[8], ql[8];
+                    {
+                        f32x16 u[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) load_bias_tile(u[t], bias + t * 32);
+                        gemm_kmajor<true, 8>(u, ph, pm, pl, sm, lane);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            tile_to_pieces<true>(u[t], qh[2 * t], qm[2 * t], ql[2 * t], qh[2 * t + 1], qm[2 * t + 1], ql[2 * t + 1]);
+                    }
+                    f32x16 v[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        load_bias_tile(v[t], bias + 128 + t * 32);
+                        add_pieces(v[t], 0, ph[2 * t], pm[2 * t], pl[2 * t]);
+                        add_pieces(v[t], 8, ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
+                    }
+                    gemm_kmajor<false, 8>(v, qh, qm, ql, sm, lane);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        tile_to_pieces<false>(v[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
+                    bias += 256;
+                }
+            } else {
             // ---- hidden layers: h = W relu(h) + b
             for (int hl = 0; hl < a.num_hidden; ++hl) {
                 f32x16 u[4];
@@ -169,13 +207,14 @@ __global__ void __launch_bounds__(kBlock, 2) affine_mlp_kernel(const AffineMlpAr
                     tile_to_pieces<false>(u[t], ph[2 * t], pm[2 * t], pl[2 * t], ph[2 * t + 1], pm[2 * t + 1], pl[2 * t + 1]);
                 bias += 128;
             }
+            }
 
             // ---- output layer, one 32-row tile at a time, and the affine map of the tile's features;
             //      the results replace the inputs in their slots
             for (int t = 0; t < a.final_tiles; ++t) {
                 f32x16 acc;
                 load_bias_tile(acc, bias + t * 32);
-                gemm_tile<true>(acc, ph, pm, pl, sm, lane);
+                gemm_tile<!RESNET>(acc, ph, pm, pl, sm, lane);   // (MLP: ReLU in front of the output layer; ResidualNet: h itself)
 #pragma unroll
                 for (int j = 0; j < kPerTile; ++j) {
                     const int f = (t * 2 + half) * kPerTile + j;
@@ -243,11 +282,14 @@ extern "C" int nfa_affine_flow_mlp_f32(const float* inputs, const void* weights_
                                        int32_t num_hidden_layers, int32_t scale_activation, int32_t flags,
                                        void* stream) {
     if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_STANDARD_NORMAL_LOG_PROB |
-                  NFA_FLAG_SKIP_OUTPUTS | NFA_FLAG_PAD_COLUMNS_MASK))
+                  NFA_FLAG_SKIP_OUTPUTS | NFA_FLAG_PAD_COLUMNS_MASK | NFA_FLAG_RESIDUAL_BLOCKS))
         return NFA_ERR_INVALID_ARGUMENT;
+    const bool resnet = (flags & NFA_FLAG_RESIDUAL_BLOCKS) != 0;
+    flags &= ~NFA_FLAG_RESIDUAL_BLOCKS;
     if (!density_flags_valid(flags)) return NFA_ERR_INVALID_ARGUMENT;
     if (batch < 0 || features < 1 || num_transform < 1 || num_identity < 1 ||
-        num_transform + num_identity > features || num_hidden_layers < 0 || num_layers < 1)
+        num_transform + num_identity > features || num_hidden_layers < 0 || num_layers < 1 ||
+        (resnet && (num_hidden_layers & 1)))   // (residual blocks: two Linears each)
         return NFA_ERR_INVALID_ARGUMENT;
     if (scale_activation != NFA_SCALE_DEFAULT && scale_activation != NFA_SCALE_GENERAL &&
         scale_activation != NFA_SCALE_ADDITIVE)
@@ -292,8 +334,16 @@ extern "C" int nfa_affine_flow_mlp_f32(const float* inputs, const void* weights_
     if (blocks > cap) blocks = cap;
     const bool inv = (flags & NFA_FLAG_INVERSE) != 0;
     void (*kern)(const AffineMlpArgs) = nullptr;
-    const int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (additive ? 4 : 0);
+    const int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (additive ? 4 : 0) + (resnet ? 8 : 0);
     switch (which) {
+        case 8: kern = affine_mlp_kernel<false, 2, false, true>; break;
+        case 9: kern = affine_mlp_kernel<true, 2, false, true>; break;
+        case 10: kern = affine_mlp_kernel<false, 4, false, true>; break;
+        case 11: kern = affine_mlp_kernel<true, 4, false, true>; break;
+        case 12: kern = affine_mlp_kernel<false, 2, true, true>; break;
+        case 13: kern = affine_mlp_kernel<true, 2, true, true>; break;
+        case 14: kern = affine_mlp_kernel<false, 4, true, true>; break;
+        case 15: kern = affine_mlp_kernel<true, 4, true, true>; break;
         case 0: kern = affine_mlp_kernel<false, 2, false>; break;
         case 1: kern = affine_mlp_kernel<true, 2, false>; break;
         case 2: kern = affine_mlp_kernel<false, 4, false>; break;
@@ -303,9 +353,10 @@ extern "C" int nfa_affine_flow_mlp_f32(const float* inputs, const void* weights_
         case 6: kern = affine_mlp_kernel<false, 4, true>; break;
         default: kern = affine_mlp_kernel<true, 4, true>; break;
     }
-    note_layer_kernel("affine_mlp_kernel<inverse=%d, init_ks=%d, additive=%d>", inv ? 1 : 0, init_ks, additive ? 1 : 0);
+    if (resnet) note_layer_kernel("affine_mlp_kernel<inverse=%d, init_ks=%d, additive=%d, resnet=1>", inv ? 1 : 0, init_ks, additive ? 1 : 0);
+    else note_layer_kernel("affine_mlp_kernel<inverse=%d, init_ks=%d, additive=%d>", inv ? 1 : 0, init_ks, additive ? 1 : 0);
     if (lds > 64 * 1024) {
-        static unsigned long long raised[8] = {};   // device masks (raise_dynamic_lds)
+        static unsigned long long raised[16] = {};   // device masks (raise_dynamic_lds)
         {
             const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], 160 * 1024 - 2048);
             if (rc_lds != NFA_OK) return rc_lds;

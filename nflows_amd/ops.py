@@ -1403,31 +1403,41 @@ def _affine_row_order(num_transform, additive):
     return torch.where(feat < dt, row, torch.full_like(row, -1)).reshape(-1)
 
 
+def _conditioner_linears(net):
+    """(input Linear, hidden Linears, output Linear) of a K11 conditioner: an MLP's layers, or (round 5) a ResidualNet's
+    initial_layer, the blocks' linear_layers in order, final_layer (nn/nets/resnet.py:58-100) -- the same stream of
+    stages, told apart by NFA_FLAG_RESIDUAL_BLOCKS."""
+    if hasattr(net, "_input_layer"):
+        return net._input_layer, list(net._hidden_layers), net._output_layer
+    return net.initial_layer, [lin for block in net.blocks for lin in block.linear_layers], net.final_layer
+
+
 def pack_mlp_conditioner(net, num_transform, additive=False):
     """Packs an MLP conditioner (nn/nets/mlp.py: _input_layer, _hidden_layers[*], _output_layer; all
-    hidden widths 128) for K11 (layout in include/nflows_amd.h).  Returns (weights [stages, 768*8]
-    bf16, biases fp32)."""
+    hidden widths 128) -- or a ResidualNet without a context (`_conditioner_linears`) -- for K11 (layout in
+    include/nflows_amd.h).  Returns (weights [stages, 768*8] bf16, biases fp32)."""
     dt = num_transform
-    dev = net._output_layer.weight.device
+    input_layer, hidden_layers, output_layer = _conditioner_linears(net)
+    dev = output_layer.weight.device
     order_k = _k8_column_order().to(dev)
 
     def pieces(w):
         return torch.stack(split_bf16x3(w))  # [3, ...]
 
     stages, biases = [], []
-    wi = _pad_to(net._input_layer.weight.detach().float(), rows=128)   # hidden widths <= 128 are zero-padded
+    wi = _pad_to(input_layer.weight.detach().float(), rows=128)   # hidden widths <= 128 are zero-padded
     di = wi.shape[1]
     init_ks = 4 if di > 32 else 2
     wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
     stages.append(pieces(wi).view(3, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks, -1))
-    biases.append(_bias_accumulator_order(_pad_to(net._input_layer.bias.detach().float(), rows=128)))
-    for lin in net._hidden_layers:
+    biases.append(_bias_accumulator_order(_pad_to(input_layer.bias.detach().float(), rows=128)))
+    for lin in hidden_layers:
         w = _pad_to(lin.weight.detach().float(), rows=128, cols=128).index_select(1, order_k)
         stages.append(pieces(w).view(3, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1))
         biases.append(_bias_accumulator_order(_pad_to(lin.bias.detach().float(), rows=128)))
     order_r = _affine_row_order(dt, additive).to(dev)
-    wo = _pad_to(net._output_layer.weight.detach().float(), cols=128)
-    bo = net._output_layer.bias.detach().float()
+    wo = _pad_to(output_layer.weight.detach().float(), cols=128)
+    bo = output_layer.bias.detach().float()
     wo = torch.cat((wo, wo.new_zeros(1, 128)), dim=0)     # row -1 = zero padding
     bo = torch.cat((bo, bo.new_zeros(1)))
     wf = wo.index_select(0, order_r % wo.shape[0]).index_select(1, order_k)
@@ -1441,28 +1451,31 @@ def pack_mlp_conditioner(net, num_transform, additive=False):
 
 def affine_flow_mlp(inputs, weights_packed, bias_packed, tables, num_transform, num_identity, num_hidden_layers,
                     scale_activation, inverse=False, accumulate_into=None, num_layers=1,
-                    standard_normal_log_prob=False, pad=None, _pad_columns_count=0):
+                    standard_normal_log_prob=False, pad=None, _pad_columns_count=0, residual_blocks=False):
     """K11 -- a run of affine / additive coupling layers with their MLP conditioners in one launch
     (weights / biases of the layers concatenated in execution order, tables from
-    `flow_layer_tables`).  Returns (outputs, logabsdet), or (None, log_prob) with
+    `flow_layer_tables`).  `residual_blocks` (round 5): the conditioners are ResidualNets, `num_hidden_layers` = twice
+    their number of blocks.  Returns (outputs, logabsdet), or (None, log_prob) with
     `standard_normal_log_prob`; None when the shape is outside the fast path."""
     N.require_device_f32("inputs", inputs, 2)
     if pad is not None and inputs.shape[1] != pad[0]:   # rows padded to a multiple of four columns (tables too)
         out = affine_flow_mlp(_pad_columns(inputs, pad[0], pad[1]), weights_packed, bias_packed, tables, num_transform,
                               num_identity, num_hidden_layers, scale_activation, inverse, accumulate_into, num_layers,
-                              standard_normal_log_prob, None, pad[0] - inputs.shape[1])
+                              standard_normal_log_prob, None, pad[0] - inputs.shape[1], residual_blocks)
         return _without_pad_columns(out, inputs.shape[1])
     if inputs.shape[0] % 128:
         return _on_full_blocks(
             lambda x_, acc_, ctx_: affine_flow_mlp(x_, weights_packed, bias_packed, tables, num_transform, num_identity,
                                                    num_hidden_layers, scale_activation, inverse, acc_, num_layers,
-                                                   standard_normal_log_prob, None, _pad_columns_count),
+                                                   standard_normal_log_prob, None, _pad_columns_count, residual_blocks),
             inputs, accumulate_into)
     dev = inputs.device
     B, D = inputs.shape
     x = inputs.detach().contiguous()
     lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
     flags, out = _density_epilogue(flags, standard_normal_log_prob, inverse, x, _pad_columns_count)
+    if residual_blocks:
+        flags |= N.FLAG_RESIDUAL_BLOCKS
     with torch.cuda.device(dev):
         rc = N.load().nfa_affine_flow_mlp_f32(
             N.ptr(x), N.ptr(weights_packed), N.ptr(bias_packed), N.ptr(tables), num_layers, N.ptr(out),

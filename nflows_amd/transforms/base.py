@@ -330,10 +330,12 @@ class CompositeTransform(Transform):
         Dp, dt4, di_u, pad_value = _run_geometry(units)
         pad = (Dp, pad_value)
         if type(first).__name__ in ("AffineCouplingTransform", "AdditiveCouplingTransform"):
+            hidden_linears, residual_blocks = first._conditioner_shape()
             head = ops.affine_flow_mlp(
                 inputs, weights, biases, tables, first.num_transform_features, first.num_identity_features,
-                len(first.transform_net._hidden_layers), first._activation_code(), inverse, total,
-                num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob, pad=pad)
+                hidden_linears, first._activation_code(), inverse, total,
+                num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob, pad=pad,
+                residual_blocks=residual_blocks)
         elif plan_f16 is not None:
             head = ops.rqs_coupling_resnet_f16(
                 inputs, plan_f16, (weights, biases), tables, dt4,

@@ -418,14 +418,41 @@ class AffineCouplingTransform(CouplingTransform):
     fuse_conditioner = os.environ.get("NFA_K11", "1") != "0"
 
     def _run_kind(self, context):
-        from ..nn.nets.mlp import MLP
         net = self.transform_net
-        ok = (self.fuse_conditioner and not torch.is_grad_enabled() and context is None and type(net) is MLP
-              and net._activation is torch.nn.functional.relu and not net._activate_output
-              and all(h <= 128 for h in net._hidden_sizes) and self._activation_code() != N.SCALE_GIVEN
+        ok = (self.fuse_conditioner and not torch.is_grad_enabled() and context is None
+              and self._conditioner_shape() is not None and self._activation_code() != N.SCALE_GIVEN
               and 1 <= self.num_identity_features <= 64 and 1 <= self.num_transform_features <= 64
-              and self._fused_geometry()[0] <= 128)
+              and self._fused_geometry()[0] <= 128
+              and (type(net).__name__ == "MLP"
+                   or all(not b.training or b.dropout.p == 0.0 for b in net.blocks)))   # (an active dropout: layer by layer)
         return "k11" if ok else None
+
+    def _conditioner_shape(self):
+        """(hidden Linears, residual blocks?) of a conditioner K11 runs inside the layer kernel -- an MLP of 128-wide ReLU
+        layers (nn/nets/mlp.py:47-68), or (round 5) a ResidualNet of width <= 128 with ReLU blocks, no context and no batch
+        norm (nn/nets/resnet.py:55-100: the conditioner of the reference's own SimpleRealNVP, flows/realnvp.py:44-71) --,
+        or None.  Read once per cache epoch (a swapped conditioner registers Parameters, which advances it)."""
+        held = self.__dict__.get("_conditioner_shape_held")
+        if held is None or held[0] != _cache.epoch():
+            from ..nn.nets.mlp import MLP
+            from ..nn.nets.resnet import ResidualNet
+            net, shape = self.transform_net, None
+            if type(net) is MLP:
+                if (net._activation is torch.nn.functional.relu and not net._activate_output
+                        and all(h <= 128 for h in net._hidden_sizes)):
+                    shape = (len(net._hidden_layers), False)
+            elif type(net) is ResidualNet:
+                if (net.context_features is None and net.hidden_features <= 128
+                        and not any(b.use_batch_norm for b in net.blocks)):
+                    shape = (2 * len(net.blocks), True)
+            held = (_cache.epoch(), shape)
+            self.__dict__["_conditioner_shape_held"] = held
+        shape = held[1]
+        if shape is not None and shape[1]:   # (a block's activation is a plain attribute: read on every call)
+            relu = (torch.nn.functional.relu, torch.relu)
+            if not all(b.__dict__.get("activation") in relu for b in self.transform_net.blocks):
+                return None
+        return shape
 
     def _fused_geometry(self, others=()):
         """(padded features, transformed features, identity features, pad value): K11 wants the row length in
@@ -434,7 +461,7 @@ class AffineCouplingTransform(CouplingTransform):
 
     def _run_signature(self):
         return ("k11", self.features, self.num_transform_features, self.num_identity_features,
-                len(self.transform_net._hidden_layers), self._activation_code())
+                self._conditioner_shape(), self._activation_code())
 
     def _packed_mlp(self):
         net = self.transform_net

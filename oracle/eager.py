@@ -150,6 +150,26 @@ def affine_coupling_layer(x, net, identity_idx, transform_idx, inverse=False):
     return out, lad
 
 
+def additive_coupling_layer(x, net, identity_idx, transform_idx, inverse=False):
+    """AdditiveCouplingTransform (coupling.py:255-269: `shift = transform_params`, scale = ones; the inherited
+    _coupling_transform_forward / _inverse, :241-252, then give x * 1 + shift, (x - shift) / 1 and sum(log(1)) = 0)."""
+    ident = x[:, identity_idx]
+    xt = x[:, transform_idx]
+    shift = net(ident, None)
+    scale = torch.ones_like(shift)
+    log_scale = torch.log(scale)
+    if inverse:
+        yt = (xt - shift) / scale
+        lad = -torch.sum(log_scale, dim=[1])
+    else:
+        yt = xt * scale + shift
+        lad = torch.sum(log_scale, dim=[1])
+    out = torch.empty_like(x)
+    out[:, identity_idx] = ident
+    out[:, transform_idx] = yt
+    return out, lad
+
+
 def standard_normal_log_prob(z):
     """StandardNormal._log_prob (distributions/normal.py:23-33)."""
     log_z = torch.tensor(0.5 * z.shape[1] * np.log(2 * np.pi), dtype=torch.float64)
@@ -206,6 +226,8 @@ def _layer(t, h, inverse, context=None):
     if name == "AffineCouplingTransform":
         return affine_coupling_layer(h, t.transform_net, t.identity_features, t.transform_features,
                                      inverse=inverse)
+    if name == "AdditiveCouplingTransform":
+        return additive_coupling_layer(h, t.transform_net, t.identity_features, t.transform_features, inverse=inverse)
     if name == "MaskedPiecewiseRationalQuadraticAutoregressiveTransform":
         fn = ar_rq_layer_inverse if inverse else ar_rq_layer_forward
         return fn(h, t.autoregressive_net, t.num_bins, t.tail_bound)

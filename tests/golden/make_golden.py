@@ -1074,6 +1074,60 @@ def conditional_flow_more_cases():
     print("flows_context_more: %d cases" % len(cases))
 
 
+def realnvp_cases():
+    """The reference's own RealNVP (flows/realnvp.py:17-71 `SimpleRealNVP`: affine / additive couplings on a flipping
+    +-1 mask, ResidualNet conditioners, no permutations) at the whole-layer kernel K11's conditioner width, built by the
+    FACTORY itself, weights sharpened (the blocks' second Linears are initialised to +-1e-3: x 100; final layers x 1.5) --
+    forward / inverse / log_prob in fp32 and fp64, 256 rows.  Weights are rebuilt from the seed (checksums stored)."""
+    from nflows.flows.realnvp import SimpleRealNVP
+    out, meta = {}, []
+    cases = [("realnvp_affine", dict(features=16, hidden_features=128, num_layers=6, num_blocks_per_layer=2), False),
+             ("realnvp_additive", dict(features=16, hidden_features=128, num_layers=6, num_blocks_per_layer=2), True),
+             ("realnvp_h64_d22", dict(features=22, hidden_features=64, num_layers=4, num_blocks_per_layer=1), False),
+             ("realnvp_d64_b3", dict(features=64, hidden_features=128, num_layers=3, num_blocks_per_layer=3), False)]
+    for idx, (name, kw, vp) in enumerate(cases):
+        seed = 90 + idx
+        torch.manual_seed(seed)
+        flow = SimpleRealNVP(use_volume_preserving=vp, **kw)
+        with torch.no_grad():
+            for p_name, p in flow.named_parameters():
+                if "final_layer" in p_name:
+                    p.mul_(1.5)
+                elif "linear_layers.1" in p_name:
+                    p.mul_(100.0)
+        B, D = 256, kw["features"]
+        g = torch.Generator().manual_seed(900 + idx)
+        x = 1.2 * torch.randn(B, D, generator=g)
+        noise = torch.randn(B, D, generator=g)
+        flow.eval()
+        with torch.no_grad():
+            lp = flow.log_prob(x)
+            z, lad = flow._transform(x)
+            xs, lad_inv = flow._transform.inverse(noise)
+            f64 = flow.double()
+            lp64 = f64.log_prob(x.double())
+            z64, lad64 = f64._transform(x.double())
+            xs64, ladi64 = f64._transform.inverse(noise.double())
+            flow.float()
+        for k, v in dict(x=x, noise=noise, log_prob=lp, z=z, lad=lad, inv_x=xs, inv_lad=lad_inv,
+                         log_prob64=lp64, z64=z64, lad64=lad64, inv_x64=xs64, inv_lad64=ladi64).items():
+            out[name + "/" + k] = npy(v)
+        names, sums = [], []
+        for k, v in flow.state_dict().items():
+            names.append(k)
+            sums.append([float(v.double().sum()), float(v.double().abs().sum())])
+        out[name + "/param_names"] = np.array(names).astype(str)
+        out[name + "/param_checksums"] = np.array(sums, dtype=np.float64)
+        meta.append((name, repr(dict(kind="realnvp", B=B, seed=seed, use_volume_preserving=vp, scale_final=1.5,
+                                     scale_linear1=100.0, **kw))))
+        print("   %s: |lad| mean %.2f, |z - x| mean %.2f, reference fp32 vs fp64: z %.2e lad %.2e" % (
+            name, float(lad64.abs().mean()), float((z64 - x.double()).abs().mean()),
+            float((z.double() - z64).abs().max()), float((lad.double() - lad64).abs().max())))
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "flows_realnvp.npz"), **out)
+    print("flows_realnvp: %d cases" % len(cases))
+
+
 def bin_count_flow_cases():
     """Round 4, the whole-layer kernels' other bin counts (2 .. 16 except 8 and 10, and 20, 24, 32): two-layer coupling flows with steep
     splines (the recipe of steep_flow_cases) at D = 32, H = 128, forward and inverse of the reference in fp32 and fp64.
@@ -1478,6 +1532,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "context":
         conditional_flow_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "realnvp":
+        realnvp_cases()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "context_more":
         conditional_flow_more_cases()

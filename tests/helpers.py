@@ -290,6 +290,34 @@ def golden_conditional_flow(golden_dir, case=None):
     return flow.eval(), g, name
 
 
+REALNVP_CASES = ("realnvp_affine", "realnvp_additive", "realnvp_h64_d22", "realnvp_d64_b3")
+
+
+def golden_realnvp_flow(golden_dir, case):
+    """`case` of tests/golden/flows_realnvp.npz -- the reference's SimpleRealNVP factory (flows/realnvp.py:17-71) at K11's
+    conditioner width -- rebuilt by configs.simple_realnvp_flow from its seed (weights are not stored; per-parameter
+    checksums of the factory's weights are, and are checked here).  Returns (flow on CPU, npz, cfg)."""
+    import torch
+    from nflows_amd import configs
+    g = np.load(os.path.join(golden_dir, "flows_realnvp.npz"))
+    cfg = parse_kwargs(dict((str(n), str(c)) for n, c in g["meta"])[case])
+    flow = configs.simple_realnvp_flow(cfg["features"], cfg["hidden_features"], cfg["num_layers"], cfg["num_blocks_per_layer"],
+                                       cfg["use_volume_preserving"], seed=cfg["seed"])
+    with torch.no_grad():
+        for n_, p in flow.named_parameters():
+            if "final_layer" in n_:
+                p.mul_(cfg["scale_final"])
+            elif "linear_layers.1" in n_:
+                p.mul_(cfg["scale_linear1"])
+    sd = flow.state_dict()
+    assert [str(n_) for n_ in g[case + "/param_names"]] == list(sd.keys()), "state_dict keys differ from the reference's"
+    for n_, (total, absolute) in zip(g[case + "/param_names"], g[case + "/param_checksums"]):
+        v = sd[str(n_)].double()
+        assert abs(float(v.sum()) - total) <= 1e-9 * (1 + abs(total)), n_
+        assert abs(float(v.abs().sum()) - absolute) <= 1e-9 * (1 + absolute), n_
+    return flow.eval(), g, cfg
+
+
 def steepen(module, num_bins=None, wh_scale=1.0, d_scale=1.0, hidden_scale=1.0):
     """Turns a freshly initialised (near-identity) flow into one with STEEP splines, as after training: every
     conditioner's output layer (`final_layer`, rows per transformed feature [w_0..w_{K-1}, h_0..h_{K-1}, d_1..d_{K-1}],

@@ -1207,6 +1207,69 @@ def test_select_columns_backward_equals_index_select():
         assert AG.select_columns(x, cols).grad_fn is None
 
 
+_ASSEMBLY = {}
+
+
+def kernel_assembly(names):
+    """gfx950 assembly of translation units of nflows_amd/csrc, compiled with the Makefile's flags (side by side, kept for
+    the other disassembly tests of this module)."""
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "nflows_amd", "csrc")
+    makefile = open(os.path.join(csrc, "Makefile")).read().splitlines()
+    no_slp = [ln for ln in makefile if ln.startswith("MFMA_SRCS")][0].split(":=")[1].split()
+
+    def assembly(name):
+        flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+                 "-fhip-fp32-correctly-rounded-divide-sqrt"] + (["-fno-slp-vectorize"] if name in no_slp else [])
+        return subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-I" + os.path.join(root, "include"), "-I" + csrc, "-S",
+                               "--cuda-device-only", "-o", "-", os.path.join(csrc, name)],
+                              capture_output=True, text=True, check=True).stdout
+
+    todo = [n for n in names if n not in _ASSEMBLY]
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1)) as pool:
+            for n, asm in zip(todo, pool.map(assembly, todo)):
+                _ASSEMBLY[n] = asm
+    return [_ASSEMBLY[n] for n in names]
+
+
+def test_no_spill_between_a_join_and_its_exec_restore():
+    """A miscompile of hipcc (ROCm 7.2) met in round 5: behind a per-lane `if` the register allocator placed the spill store
+    of a value that is live ACROSS the `if` at the top of the join block, in front of the `s_or_b64 exec, exec, ...` that
+    restores the lanes -- waves that skipped the `if` whole (exec = 0) never stored it and reloaded a stale slot later (K11's
+    residual instances lost the log-determinants of all layers but the last in waves 2 and 3; the source now branches on a
+    wave-uniform condition there).  Every kernel of the library: no scratch store between a label that an
+    `s_cbranch_execz` jumps to and the exec restore of that block."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    makefile = open(os.path.join(root, "nflows_amd", "csrc", "Makefile")).read().splitlines()
+    names = [ln for ln in makefile if ln.startswith("SRCS")][0].split(":=")[1].split()
+    kernels = 0
+    for name, asm in zip(names, kernel_assembly(names)):
+        for k in re.split(r"\n(?=_Z\w+:\s)", asm):
+            if not re.match(r"_Z\w+:", k):
+                continue
+            kernels += 1
+            targets = set(re.findall(r"s_cbranch_execz (\.LBB\d+_\d+)", k))
+            lines = k.split("\n")
+            for i, line in enumerate(lines):
+                m = re.match(r"(\.LBB\d+_\d+):", line)
+                if not (m and m.group(1) in targets):
+                    continue
+                stores, j = [], i + 1
+                while j < len(lines):
+                    t = lines[j].strip()
+                    if t.startswith("scratch_store"):
+                        stores.append(t)
+                    if "s_or_b64 exec, exec" in t or re.match(r"\.LBB|s_cbranch|s_branch|s_and_saveexec|s_endpgm", t):
+                        break
+                    j += 1
+                assert not (stores and j < len(lines) and "s_or_b64 exec, exec" in lines[j]), (name, k.split(":")[0], m.group(1), stores)
+    assert kernels > 400, kernels
+
+
 def assert_no_read_lands_on_a_later_address(name, asm, minimum=200):
     """Round 5: the defect behind every "one wave in a few thousand is off" of rounds 3-5.  The fragment reads of the
     f16 whole-layer kernels are two ds_read_b128 in ONE asm statement sharing their address register; without an
@@ -1255,15 +1318,7 @@ def test_no_mfma_result_lands_on_its_own_operands():
     names = ("rqs_resnet_f16s.hip", "rqs_resnet_f16.hip", "rqs_resnet_f16_bins_a.hip", "rqs_resnet_f16_bins_b.hip",
              "rqs_resnet_f16_bins_c.hip", "rqs_resnet_f16_ctx_a.hip", "rqs_resnet_f16_ctx_b.hip")
 
-    def assembly(name):
-        return subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
-                               "-fno-fast-math", "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt",
-                               "-I" + os.path.join(root, "include"), "-I" + csrc, "-S", "--cuda-device-only", "-o", "-",
-                               os.path.join(csrc, name)], capture_output=True, text=True, check=True).stdout
-
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=min(len(names), os.cpu_count() or 1)) as pool:
-        listings = list(pool.map(assembly, names))
+    listings = kernel_assembly(names)
     for name, asm in zip(names, listings):
         count = 0
         for line in asm.splitlines():

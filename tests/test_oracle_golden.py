@@ -356,6 +356,31 @@ def test_eager_port_with_context_is_bit_identical(golden_dir, case):
         flow.float()
 
 
+@pytest.mark.parametrize("case", ["realnvp_affine", "realnvp_additive", "realnvp_h64_d22", "realnvp_d64_b3"])
+def test_eager_port_on_the_reference_realnvp_is_bit_identical(golden_dir, case):
+    """The reference's SimpleRealNVP (flows/realnvp.py:17-71: affine / additive couplings with ResidualNet conditioners on a
+    flipping +-1 mask), built by the factory itself for tests/golden/flows_realnvp.npz and rebuilt here from the seed
+    (same state_dict keys, same checksums): the eager port reproduces the reference's fp32 vectors bit for bit and its
+    float64 ones to 1e-12 -- the yardstick of tests/test_gpu_realnvp.py."""
+    import torch
+    from helpers import golden_realnvp_flow
+    from oracle import eager
+    torch.set_num_threads(1)
+    flow, g, cfg = golden_realnvp_flow(golden_dir, case)
+    x, noise = (torch.from_numpy(g[case + "/" + k]) for k in ("x", "noise"))
+    with torch.no_grad():
+        z, lad = eager.flow_transform(flow, x)
+        lp = eager.flow_log_prob(flow, x)
+        xi, ladi = eager.flow_transform(flow, noise, inverse=True)
+        for got, key in ((z, "z"), (lad, "lad"), (lp, "log_prob"), (xi, "inv_x"), (ladi, "inv_lad")):
+            assert np.array_equal(got.numpy(), g[case + "/" + key]), key
+        flow64 = flow.double()
+        z64, lad64 = eager.flow_transform(flow64, x.double())
+        assert np.abs(z64.numpy() - g[case + "/z64"]).max() <= 1e-12
+        assert np.abs(lad64.numpy() - g[case + "/lad64"]).max() <= 1e-11
+        flow.float()
+
+
 def _h128_flow(golden_dir):
     """The flow of tests/golden/flows_h128.npz rebuilt from its seed (weights are not stored)."""
     import torch
