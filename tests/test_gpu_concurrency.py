@@ -164,3 +164,34 @@ def test_training_step_gradients_beside_foreign_work(hog):
     calls, bad = _beside_the_hog(step, hog, reps=4, calls=3)
     _report({"config": "concurrency_training_step", "calls": calls, "deviating_from_the_quiet_result": bad})
     assert bad == 0, bad
+
+
+@pytest.mark.parametrize("family", ["context_k4_f16x2", "context_tanh_k8_bf16x3", "realnvp_affine"])
+def test_the_round_5_instances_beside_foreign_work(family, hog, monkeypatch):
+    """The instances added in round 5 -- whole-layer kernels with a context at other bin counts / activations (K8h and K8),
+    K11's residual form (the reference's RealNVP) -- under the same demand."""
+    from helpers import golden_conditional_flow, golden_realnvp_flow
+    from nflows_amd import ops
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    gen = torch.Generator().manual_seed(17)
+    if family.startswith("context"):
+        case, engine = {"context_k4_f16x2": ("ctx_k4", "f16x2"), "context_tanh_k8_bf16x3": ("ctx_tanh_k8", "bf16x3")}[family]
+        monkeypatch.setattr(RQ, "conditioner_engine", engine)
+        flow_cpu, g, name = golden_conditional_flow(GOLDEN, case)
+        flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+        x = (1.2 * torch.randn(16384, 16, generator=gen)).to(DEV)
+        with torch.no_grad():
+            emb = flow._embedding_net(torch.randn(16384, 5, generator=gen).to(DEV))
+            calls, bad_f = _beside_the_hog(lambda: flow._transform(x, context=emb), hog)
+            assert "ctx=1" in ops.last_layer_kernel(), ops.last_layer_kernel()
+            _, bad_i = _beside_the_hog(lambda: flow._transform.inverse(x, context=emb), hog)
+    else:
+        flow_cpu, g, cfg = golden_realnvp_flow(GOLDEN, family)
+        flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+        x = (1.2 * torch.randn(16384, cfg["features"], generator=gen)).to(DEV)
+        with torch.no_grad():
+            calls, bad_f = _beside_the_hog(lambda: flow._transform(x), hog)
+            assert "resnet=1" in ops.last_layer_kernel(), ops.last_layer_kernel()
+            _, bad_i = _beside_the_hog(lambda: flow._transform.inverse(x), hog)
+    _report({"config": "concurrency_%s" % family, "calls": 2 * calls, "deviating_from_the_quiet_result": bad_f + bad_i})
+    assert bad_f == 0 and bad_i == 0, (family, bad_f, bad_i)
