@@ -1084,7 +1084,9 @@ def realnvp_cases():
     cases = [("realnvp_affine", dict(features=16, hidden_features=128, num_layers=6, num_blocks_per_layer=2), False),
              ("realnvp_additive", dict(features=16, hidden_features=128, num_layers=6, num_blocks_per_layer=2), True),
              ("realnvp_h64_d22", dict(features=22, hidden_features=64, num_layers=4, num_blocks_per_layer=1), False),
-             ("realnvp_d64_b3", dict(features=64, hidden_features=128, num_layers=3, num_blocks_per_layer=3), False)]
+             ("realnvp_d64_b3", dict(features=64, hidden_features=128, num_layers=3, num_blocks_per_layer=3), False),
+             # (40 identity features: the initial layer's four-k-step instances)
+             ("realnvp_d80", dict(features=80, hidden_features=128, num_layers=3, num_blocks_per_layer=1), False)]
     for idx, (name, kw, vp) in enumerate(cases):
         seed = 90 + idx
         torch.manual_seed(seed)

@@ -290,7 +290,7 @@ def golden_conditional_flow(golden_dir, case=None):
     return flow.eval(), g, name
 
 
-REALNVP_CASES = ("realnvp_affine", "realnvp_additive", "realnvp_h64_d22", "realnvp_d64_b3")
+REALNVP_CASES = ("realnvp_affine", "realnvp_additive", "realnvp_h64_d22", "realnvp_d64_b3", "realnvp_d80")
 
 
 def golden_realnvp_flow(golden_dir, case):

@@ -89,3 +89,25 @@ def test_conditional_flows_of_other_bin_counts_and_activations(monkeypatch, gold
                                            factor=2.0, max_factor=4.0, max_floor=3e-6 * scale * (d if "lad" in what else 1))
     _report({"config": "context_%s_%s" % (case, engine), "kernel": ran, "rows": ROWS,
              "mean_error_ratio": {k: v["got"]["mean"] / max(v["reference"]["mean"], 1e-30) for k, v in figures.items() if v}})
+
+
+@pytest.mark.parametrize("case", ["ctx_k4", "ctx_k16", "ctx_elu_k10", "ctx_tanh_k8"])
+def test_eight_wave_context_instances_equal_the_four_wave_ones(golden_dir, case):
+    """K8h picks four waves per workgroup up to 16 384 rows and eight above; a wave runs the same instruction stream in
+    both, so a 65 536-row launch (eight waves: the instances the test above never reaches) must reproduce, bit for bit,
+    the same rows pushed through in 16 384-row pieces (four waves) -- forward and inverse."""
+    from nflows_amd import ops
+    flow_cpu, g, name = golden_conditional_flow(golden_dir, case)
+    flow = copy.deepcopy(flow_cpu).to(DEV)
+    gen = torch.Generator().manual_seed(5)
+    x = (1.2 * torch.randn(65536, 16, generator=gen)).to(DEV)
+    ctx = torch.randn(65536, 5, generator=gen).to(DEV)
+    with torch.no_grad():
+        emb = flow._embedding_net(ctx)
+        for fn in (flow._transform, flow._transform.inverse):
+            big, big_lad = fn(x, context=emb)
+            assert "waves=8" in ops.last_layer_kernel() and "ctx=1" in ops.last_layer_kernel(), ops.last_layer_kernel()
+            parts = [fn(x[i:i + 16384], context=emb[i:i + 16384]) for i in range(0, 65536, 16384)]
+            assert "waves=4" in ops.last_layer_kernel(), ops.last_layer_kernel()
+            assert torch.equal(big, torch.cat([p[0] for p in parts])) and torch.equal(big_lad, torch.cat([p[1] for p in parts]))
+            assert torch.isfinite(big).all()

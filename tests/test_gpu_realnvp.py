@@ -6,8 +6,8 @@
 launches and K2.  The kernel now has the residual form (NFA_FLAG_RESIDUAL_BLOCKS, ABI 11: same packed stream, K8's block
 arithmetic between the stages).
 
-Fixture first: tests/golden/flows_realnvp.npz holds four flows built by the reference's FACTORY (affine, additive /
-volume preserving, a 64-wide conditioner on 22 features, 64 features with three blocks per layer), sharpened, 256 rows,
+Fixture first: tests/golden/flows_realnvp.npz holds five flows built by the reference's FACTORY (affine, additive /
+volume preserving, a 64-wide conditioner on 22 features, 64 features with three blocks per layer, 80 features: the four-k-step initial layer), sharpened, 256 rows,
 forward / inverse / log_prob in fp32 and fp64; configs.simple_realnvp_flow rebuilds them from the seed (same state_dict
 keys and checksums) and the eager port reproduces the vectors bit for bit (tests/test_oracle_golden.py).  Here:
   * the run planner takes the whole flow as ONE run and K11's residual instance is the kernel that ran;

@@ -356,7 +356,7 @@ def test_eager_port_with_context_is_bit_identical(golden_dir, case):
         flow.float()
 
 
-@pytest.mark.parametrize("case", ["realnvp_affine", "realnvp_additive", "realnvp_h64_d22", "realnvp_d64_b3"])
+@pytest.mark.parametrize("case", ["realnvp_affine", "realnvp_additive", "realnvp_h64_d22", "realnvp_d64_b3", "realnvp_d80"])
 def test_eager_port_on_the_reference_realnvp_is_bit_identical(golden_dir, case):
     """The reference's SimpleRealNVP (flows/realnvp.py:17-71: affine / additive couplings with ResidualNet conditioners on a
     flipping +-1 mask), built by the factory itself for tests/golden/flows_realnvp.npz and rebuilt here from the seed
