@@ -111,3 +111,45 @@ def test_eight_wave_context_instances_equal_the_four_wave_ones(golden_dir, case)
             assert "waves=4" in ops.last_layer_kernel(), ops.last_layer_kernel()
             assert torch.equal(big, torch.cat([p[0] for p in parts])) and torch.equal(big_lad, torch.cat([p[1] for p in parts]))
             assert torch.isfinite(big).all()
+
+
+@pytest.mark.parametrize("engine", ["f16x2", "bf16x3"])
+@pytest.mark.parametrize("num_bins,activation", [(4, "relu"), (12, "relu"), (8, "tanh")])
+def test_wider_conditional_flows_against_the_port(monkeypatch, num_bins, activation, engine):
+    """48 features (24 identity + 12 context columns: more than 32, K8's four-k-step initial layer, which the 16-feature
+    fixtures never reach) against the eager port -- pinned to the reference bit for bit on the fixtures' structure
+    (tests/test_oracle_golden.py) -- under the rule of the test above, 16 384 rows."""
+    import nflows_amd
+    from nflows_amd import configs, ops
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    monkeypatch.setattr(RQ, "conditioner_engine", engine)
+    F = torch.nn.functional
+    act = {"relu": F.relu, "tanh": torch.tanh}[activation]
+    flow_cpu = configs.conditional_rq_nsf_flow(3, 48, num_bins, 128, 5, 12, 3.0, seed=31, activation=act).eval()
+    s_final, s_lin1 = (4.0, 30.0) if activation == "relu" else (8.0, 6.0)
+    with torch.no_grad():
+        for n_, p in flow_cpu.named_parameters():
+            if "final_layer" in n_:
+                p.mul_(s_final)
+            elif "linear_layers.1" in n_:
+                p.mul_(s_lin1)
+            elif "context_layer" in n_:
+                p.mul_(3.0)
+    flow = copy.deepcopy(flow_cpu).to(DEV)
+    gen = torch.Generator().manual_seed(23)
+    xb = 1.2 * torch.randn(ROWS, 48, generator=gen)
+    nb = torch.randn(ROWS, 48, generator=gen)
+    cb = torch.randn(ROWS, 5, generator=gen)
+    o = eager_oracle(flow_cpu, xb, nb, cb, fp64_device=DEV)
+    with torch.no_grad():
+        emb = flow._embedding_net(cb.to(DEV))
+        z, lad = flow._transform(xb.to(DEV), context=emb)
+        ran = ops.last_layer_kernel()
+        want = ("k8h::", "ctx=1", "K=%d" % num_bins) if engine == "f16x2" else ("rqs_resnet_kernel<", "init_ks=4", "ctx=1", "K=%d" % num_bins)
+        assert all(s in ran for s in want), ran
+        xi, ladi = flow._transform.inverse(nb.to(DEV), context=emb)
+    nflows_amd.check_status()
+    for what, got, k in (("z", z, "z"), ("lad", lad, "lad"), ("inv_x", xi, "xi"), ("inv_lad", ladi, "ladi")):
+        scale = 1 + np.abs(o[k + "64"]).max()
+        assert_error_ratio(got.cpu().numpy(), o[k + "32"], o[k + "64"], "D48 K%d %s %s %s" % (num_bins, activation, engine, what),
+                           factor=2.0, max_factor=4.0, max_floor=3e-6 * scale * (48 if "lad" in what else 1))
