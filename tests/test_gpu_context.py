@@ -153,3 +153,50 @@ def test_wider_conditional_flows_against_the_port(monkeypatch, num_bins, activat
         scale = 1 + np.abs(o[k + "64"]).max()
         assert_error_ratio(got.cpu().numpy(), o[k + "32"], o[k + "64"], "D48 K%d %s %s %s" % (num_bins, activation, engine, what),
                            factor=2.0, max_factor=4.0, max_floor=3e-6 * scale * (48 if "lad" in what else 1))
+
+
+@pytest.mark.parametrize("engine", ["f16x2", "bf16x3"])
+def test_every_served_bin_count_with_a_context_agrees_with_the_layer_by_layer_path(monkeypatch, engine):
+    """The fixtures cover 4, 6, 9, 12, 16 and 24 bins; the context instances exist for every bin count the whole-layer
+    kernels serve.  All sixteen of them (and 8 / 10), 4 096 rows forward and inverse, against the layer-by-layer path
+    (PyTorch-ROCm GEMMs + K1, held to the reference for every bin count in tests/test_gpu_bins.py): agreement to fp32
+    rounding of three sharpened layers, the kernel that ran read back."""
+    import nflows_amd
+    from nflows_amd import configs, ops
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    monkeypatch.setattr(RQ, "conditioner_engine", engine)
+    gen = torch.Generator().manual_seed(41)
+    x = (1.2 * torch.randn(4096, 16, generator=gen)).to(DEV)
+    noise = torch.randn(4096, 16, generator=gen).to(DEV)
+    ctx = torch.randn(4096, 5, generator=gen).to(DEV)
+    worst = {}
+    for K in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 32):
+        flow = configs.conditional_rq_nsf_flow(3, 16, K, 128, 5, 12, 3.0, seed=100 + K).to(DEV).eval()
+        with torch.no_grad():
+            for n_, p in flow.named_parameters():
+                if "final_layer" in n_:
+                    p.mul_(4.0)
+                elif "linear_layers.1" in n_:
+                    p.mul_(30.0)
+                elif "context_layer" in n_:
+                    p.mul_(3.0)
+            emb = flow._embedding_net(ctx)
+            z, lad = flow._transform(x, context=emb)
+            ran = ops.last_layer_kernel()
+            assert "ctx=1" in ran and "K=%d" % K in ran and ("k8h::" in ran) == (engine == "f16x2"), ran
+            xi, ladi = flow._transform.inverse(noise, context=emb)
+            try:
+                RQ.fuse_conditioner = False
+                z2, lad2 = flow._transform(x, context=emb)
+                xi2, ladi2 = flow._transform.inverse(noise, context=emb)
+            finally:
+                RQ.fuse_conditioner = True
+        nflows_amd.check_status()
+        worst[K] = (float((z - z2).abs().max()), float((lad - lad2).abs().max()), float((xi - xi2).abs().max()),
+                    float((ladi - ladi2).abs().max()))
+        # (the log-determinant of an inverse that lands next to a knot is ill-conditioned -- one element of 4 096 at 15
+        #  bins differs by 5.6e-3 between the two fp32 paths --: the 99.9 % quantile carries the bound, the maximum 10 x it)
+        q999 = [float(torch.quantile((a - b).abs().flatten().float(), 0.999)) for a, b in ((lad, lad2), (ladi, ladi2))]
+        assert worst[K][0] < 5e-4 and worst[K][2] < 5e-4 and max(q999) < 5e-3 and max(worst[K][1], worst[K][3]) < 5e-2, (K, worst[K], q999)
+        assert float(lad.abs().mean()) > 0.5, (K, "the layers are not trivial")
+    _report({"config": "context_all_bin_counts_%s" % engine, "max_abs_difference_to_layer_by_layer (z, lad, inv_x, inv_lad)": worst})
