@@ -1077,6 +1077,57 @@ def test_affine_mlp_packing_orders_the_output_rows_per_lane():
                     assert got[t, half, q] == bo[order[t * 32 + i]]
 
 
+def test_affine_couplings_with_residual_conditioners_route_to_k11():
+    """Round 5: the reference's RealNVP composition (flows/realnvp.py:17-71: affine / additive couplings on a flipping +-1
+    mask, ResidualNet conditioners).  Host side: which layers K11 takes (`_conditioner_shape` / `_run_kind`), that the
+    ResidualNet is packed as the MLP made of the same Linears (initial_layer, the blocks' linear_layers in order,
+    final_layer: the kernel tells the two apart by NFA_FLAG_RESIDUAL_BLOCKS), the flag's value, the planner's run."""
+    import torch
+    from nflows_amd import _native as N, configs, ops
+    from nflows_amd.nn.nets import MLP, ResidualNet
+    from nflows_amd.transforms import AdditiveCouplingTransform, AffineCouplingTransform
+    header = open(os.path.join(ROOT, "include", "nflows_amd.h")).read()
+    assert int(re.search(r"#define\s+NFA_FLAG_RESIDUAL_BLOCKS\s+(\d+)", header).group(1)) == N.FLAG_RESIDUAL_BLOCKS == 64
+    F = torch.nn.functional
+    mask = torch.ones(16)
+    mask[::2] = -1
+
+    def layer(cls=AffineCouplingTransform, **kw):
+        return cls(mask, lambda i, o: ResidualNet(i, o, hidden_features=kw.pop("hidden", 128), num_blocks=2, **kw)).eval()
+
+    with torch.no_grad():
+        plain = layer()
+        assert plain._conditioner_shape() == (4, True) and plain._run_kind(None) == "k11"
+        assert layer(AdditiveCouplingTransform)._run_kind(None) == "k11" and layer(hidden=48)._run_kind(None) == "k11"
+        assert layer(hidden=160)._run_kind(None) is None                       # wider than the kernel's 128
+        assert layer(use_batch_norm=True)._run_kind(None) is None              # (not folded for K11)
+        assert layer(activation=F.elu)._run_kind(None) is None                 # the kernel's blocks are ReLU
+        assert layer(context_features=3)._run_kind(None) is None and plain._run_kind(torch.zeros(4, 3)) is None
+        dropped = layer(dropout_probability=0.3)
+        assert dropped._run_kind(None) == "k11"                                # eval mode: inactive
+        dropped.train()
+        assert dropped._run_kind(None) is None
+        mlp = AffineCouplingTransform(mask, lambda i, o: MLP([i], [o], [128, 128])).eval()
+        assert mlp._conditioner_shape() == (1, False) and mlp._run_signature() != plain._run_signature()
+    assert plain._run_kind(None) is None                                       # (under autograd: the layer-by-layer path)
+    # the packed stream of a ResidualNet = that of the MLP with the same Linears in the same places
+    torch.manual_seed(1)
+    net = ResidualNet(8, 16, hidden_features=128, num_blocks=2)
+    twin = MLP([8], [16], [128] * 5)
+    with torch.no_grad():
+        linears = [net.initial_layer] + [lin for b in net.blocks for lin in b.linear_layers] + [net.final_layer]
+        for dst, src in zip([twin._input_layer] + list(twin._hidden_layers) + [twin._output_layer], linears):
+            dst.weight.copy_(src.weight)
+            dst.bias.copy_(src.bias)
+    (w0, b0), (w1, b1) = ops.pack_mlp_conditioner(net, 8), ops.pack_mlp_conditioner(twin, 8)
+    assert torch.equal(w0, w1) and torch.equal(b0, b1) and w0.shape[0] == 2 + 8 * 4 + 2
+    # the whole factory composition is one run for the planner (CPU tensors: planning only)
+    flow = configs.simple_realnvp_flow(16, 128, 5, 2, seed=0).eval()
+    with torch.no_grad():
+        units, after = flow._transform._collect_run(list(flow._transform._transforms), 0, torch.zeros(256, 16), None, inverse=False)
+    assert len(units) == 5 and after == 5 and all(p is None for _, p in units)
+
+
 @pytest.mark.parametrize("residual,random_mask,features,hidden,blocks", [(True, False, 12, 20, 2), (True, False, 40, 16, 1),
                                                                        (False, True, 12, 24, 2), (False, False, 9, 32, 3)])
 def test_made_schedule_reproduces_the_masked_network(residual, random_mask, features, hidden, blocks):
