@@ -32,9 +32,11 @@
 extern "C" {
 #endif
 
-#define NFA_ABI_VERSION 11 /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 7; round 4: 8,
+#define NFA_ABI_VERSION 12 /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 7; round 4: 8,
                               9: whole-layer kernels for 2 .. 16 bins, nfa_resnet_backward_f32, W_f^T in K14's backward stream;
-                              round 5: 10: `bin_idx` outputs of the spline kernels, nfa_searchsorted_f32; 11: NFA_FLAG_RESIDUAL_BLOCKS) */
+                              round 5: 10: `bin_idx` outputs of the spline kernels, nfa_searchsorted_f32; 11: NFA_FLAG_RESIDUAL_BLOCKS;
+                              round 6: 12: nfa_rqs_flow_resnet_f16x3_f32 (K8x), the *_logits_f32 diagnostic entries,
+                              NFA_FLAG_ALL_PRODUCTS, nfa_weights_checksum_*) */
 
 /* return codes */
 #define NFA_OK 0
@@ -343,6 +345,67 @@ int nfa_rqs_flow_resnet_f16x2_f32(const float *inputs, const void *stream_packed
                                   int32_t features, int32_t num_transform, int32_t num_identity,
                                   int32_t hidden_features, int32_t num_blocks,
                                   const nfa_rqs_spec *spec, int32_t flags, void *stream);
+
+/*
+ * K8x (ABI 12): the same run of whole coupling layers with the conditioner's GEMMs on the f16 matrix pipe from THREE f16
+ * pieces per fp32 operand -- x s = hi + lo + r (s a power of two), 33 significand bits: every fp32 operand is carried
+ * EXACTLY while its last piece stays above f16's smallest subnormal, i.e. at the reference's own operand width
+ * (nn/nets/resnet.py:92-100: F.linear on fp32) -- and five cross products per multiply-add (hi hi, hi lo, lo hi, hi r,
+ * r hi; dropped: lo lo and below, <= 2^-24 relative): 5/6 of K8's matrix work.  Replaces the same reference code as K8
+ * (coupling.py:73-130, :549-582, nn/nets/resnet.py:39-52, :92-100, transforms/base.py:45-52).
+ *   weights_packed f16, [stages][768 x 8]: K8's 12 KB stages, stage order, element and row rules (above), the three
+ *                  pieces being (hi, lo, r) of W x T -- T a power of two per GEMM, max |w T| in [2^13, 2^14); the final
+ *                  layer's width / height rows pre-divided by sqrt(hidden_features) before the scale is chosen.
+ *   bias_packed    K8's order; initial_layer's biases x S T_0, every other GEMM's x S T (its own T), S = act_scale.
+ *   scales         float [num_layers][2 + 2 num_blocks][2]: per GEMM in execution order {1 / T, T}; the final layer's
+ *                  pair is {kappa = 1 / (S T), S T}: the spline evaluation reads logits = accumulators x kappa.
+ *   act_scale      S, a power of two: the scale at which activations (identity features included) are split into
+ *                  pieces.  A value keeps all 24 bits while |v S| >= 2^-1; below, its absolute error is <= 2^-25 / S;
+ *                  |v S| >= 65520 overflows and poisons the row block (next line).
+ *   redo_blocks    as for nfa_rqs_flow_resnet_f16x2_f32: 1 = the 128-row block produced a non-finite value and
+ *                  nothing of it was written; run nfa_rqs_flow_resnet_redo_f32 (K8's blobs) behind it.
+ * Supported: num_bins = 8, linear tails, ReLU blocks, no context, hidden_features = 128, d_i <= 64, d_t % 4 == 0,
+ * d_t <= 64, features % 4 == 0, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED (callers: K8).
+ */
+int nfa_rqs_flow_resnet_f16x3_f32(const float *inputs, const void *weights_packed, const float *bias_packed,
+                                  const float *scales, const int32_t *flow_tables, int32_t num_layers,
+                                  float *outputs, float *logabsdet, int32_t *redo_blocks, int32_t *status,
+                                  int64_t batch, int32_t features, int32_t num_transform, int32_t num_identity,
+                                  int32_t hidden_features, int32_t num_blocks, float act_scale,
+                                  const nfa_rqs_spec *spec, int32_t flags, void *stream);
+
+/*
+ * Diagnostic twins (ABI 12; tests/test_gpu_logits.py): the same launches through instances that also store the LOGITS
+ * of the run's LAST layer -- the final Linear's output as the spline evaluation reads it: what
+ * `transform_net(identity_split)` returns in the reference (coupling.py:85), its width / height entries divided by
+ * sqrt(hidden_features) (coupling.py:554-556) -- so that the conditioner's GEMM arithmetic can be held to an fp32
+ * library GEMM's error against float64 on its own, in front of the spline.
+ *   logits  float [batch, num_transform * 24], PACKED row order: entry 32 * tile + 16 * half + q of a row is
+ *           accumulator register q of lane-half `half` of final-layer tile `tile`, i.e. packed row
+ *           32 * tile + 8 * (q / 4) + 4 * half + q % 4 of K7's row order (above); rows of blocks flagged in
+ *           `redo_blocks` carry the first pass's (discarded) values.
+ * Served: 8 bins, ReLU blocks, no context (the bench's kernel family); K8h: d_i <= 32, also fills `bin_idx` as
+ * nfa_rqs_flow_resnet_f16x2_bins_f32; K8: the plain final-layer loop (same products in the same order as the woven one).
+ */
+int nfa_rqs_flow_resnet_f16x3_logits_f32(const float *inputs, const void *weights_packed, const float *bias_packed,
+                                         const float *scales, const int32_t *flow_tables, int32_t num_layers,
+                                         float *outputs, float *logabsdet, int32_t *redo_blocks, int32_t *status,
+                                         int64_t batch, int32_t features, int32_t num_transform, int32_t num_identity,
+                                         int32_t hidden_features, int32_t num_blocks, float act_scale,
+                                         const nfa_rqs_spec *spec, int32_t flags, void *stream, float *logits);
+int nfa_rqs_flow_resnet_f16x2_logits_f32(const float *inputs, const void *stream_packed, int32_t param_stages,
+                                         const int32_t *final_positions, int32_t num_layers, float *outputs,
+                                         float *logabsdet, int32_t *redo_blocks, int32_t *status, int64_t batch,
+                                         int32_t features, int32_t num_transform, int32_t num_identity,
+                                         int32_t hidden_features, int32_t num_blocks,
+                                         const nfa_rqs_spec *spec, int32_t flags, void *stream, int32_t *bin_idx,
+                                         float *logits);
+int nfa_rqs_flow_resnet_logits_f32(const float *inputs, const void *weights_packed,
+                                   const float *bias_packed, const int32_t *flow_tables,
+                                   int32_t num_layers, float *outputs, float *logabsdet, int32_t *status,
+                                   int64_t batch, int32_t features, int32_t num_transform,
+                                   int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
+                                   const nfa_rqs_spec *spec, int32_t flags, void *stream, float *logits);
 
 /*
  * K8s.  nfa_rqs_flow_resnet_f16x2_f32 (same reference lines: nn/nets/resnet.py:55-100, coupling.py:73-130,

@@ -34,7 +34,7 @@ ACTIVATION_RELU, ACTIVATION_LEAKY_RELU, ACTIVATION_ELU, ACTIVATION_TANH = 0, 1, 
 TAILS_NONE, TAILS_LINEAR = 0, 1
 SCALE_DEFAULT, SCALE_GENERAL, SCALE_ADDITIVE, SCALE_GIVEN, SCALE_SOFTPLUS = 0, 1, 2, 3, 4
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 EXPORTS = (
     "nfa_abi_version",
@@ -62,6 +62,10 @@ EXPORTS = (
     "nfa_rqs_flow_resnet_f16x2_bins_f32",
     "nfa_rqs_flow_resnet_f16x2_tile16_bins_f32",
     "nfa_rqs_flow_resnet_context_f16x2_f32",
+    "nfa_rqs_flow_resnet_f16x3_f32",
+    "nfa_rqs_flow_resnet_f16x3_logits_f32",
+    "nfa_rqs_flow_resnet_f16x2_logits_f32",
+    "nfa_rqs_flow_resnet_logits_f32",
     "nfa_rqs_flow_resnet_context_redo_f32",
     "nfa_linear_spline_f32",
     "nfa_quadratic_spline_f32",
@@ -184,6 +188,15 @@ def _declare(lib):
         fn.restype = ctypes.c_int
         fn.argtypes = lib.nfa_rqs_flow_resnet_f16x2_f32.argtypes + [vp]
     lib.nfa_rqs_flow_resnet_context_f16x2_f32.restype = ctypes.c_int
+    f32 = ctypes.c_float
+    lib.nfa_rqs_flow_resnet_f16x3_f32.restype = ctypes.c_int
+    lib.nfa_rqs_flow_resnet_f16x3_f32.argtypes = [vp] * 5 + [i32] + [vp] * 4 + [i64, i32, i32, i32, i32, i32, f32, sp, i32, vp]
+    lib.nfa_rqs_flow_resnet_f16x3_logits_f32.restype = ctypes.c_int
+    lib.nfa_rqs_flow_resnet_f16x3_logits_f32.argtypes = lib.nfa_rqs_flow_resnet_f16x3_f32.argtypes + [vp]
+    lib.nfa_rqs_flow_resnet_f16x2_logits_f32.restype = ctypes.c_int
+    lib.nfa_rqs_flow_resnet_f16x2_logits_f32.argtypes = lib.nfa_rqs_flow_resnet_f16x2_f32.argtypes + [vp, vp]
+    lib.nfa_rqs_flow_resnet_logits_f32.restype = ctypes.c_int
+    lib.nfa_rqs_flow_resnet_logits_f32.argtypes = lib.nfa_rqs_flow_resnet_f32.argtypes + [vp]
     lib.nfa_rqs_flow_resnet_context_f16x2_f32.argtypes = [vp, vp, i32, vp, i32, vp, i32] + [vp] * 4 + \
         [i64, i32, i32, i32, i32, i32, sp, i32, vp]
     lib.nfa_rqs_flow_resnet_context_redo_f32.restype = ctypes.c_int

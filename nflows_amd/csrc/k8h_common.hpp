@@ -72,6 +72,8 @@ struct Args {
     const float* ctx;           // CTX: [batch, ce] context rows (nn/nets/resnet.py:9-52, :92-100)
     int ce;
     int32_t* dbg_bins;          // the DBG instances only: [batch, dt] bin chosen by the LAST layer's evaluations
+    float* dbg_logits;          // the DBG instances only (round 6), optional: [batch, dt * 24] the LAST layer's logits
+                                // (accumulators x kappa), packed row order (tile, lane-half, register)
 };
 
 // (debug stamps: the switch and the index are wave-uniform -- scalar registers -- and the pointer is rebuilt from the

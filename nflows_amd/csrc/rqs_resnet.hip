@@ -38,7 +38,7 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
                                 int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
                                 const nfa_rqs_spec* spec, int32_t flags, void* stream,
                                 const int32_t* redo = nullptr, const float* context = nullptr,
-                                int32_t context_features = 0) {
+                                int32_t context_features = 0, float* dbg_logits = nullptr) {
     if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_LOGITS_LOG2E |
                   NFA_FLAG_STANDARD_NORMAL_LOG_PROB | NFA_FLAG_SKIP_OUTPUTS | NFA_FLAG_PAD_COLUMNS_MASK |
                   NFA_FLAG_ACTIVATION_MASK))
@@ -77,6 +77,10 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         return NFA_ERR_INVALID_ARGUMENT;
     a.ctx = with_ctx ? context : nullptr;
     a.ce = context_features;
+    a.dbg_logits = dbg_logits;
+    // the diagnostic instances (nfa_rqs_flow_resnet_logits_f32): the bench's kernel family only
+    if (dbg_logits && (a.sp.K != 8 || with_ctx || activation != NFA_ACTIVATION_RELU || (flags & NFA_FLAG_LOGITS_LOG2E) || redo))
+        return NFA_ERR_UNSUPPORTED;
     a.normal = (flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB) ? 1 : 0;
     a.skip_out = (flags & NFA_FLAG_SKIP_OUTPUTS) ? 1 : 0;
     a.Ds = density_columns(flags, features);
@@ -111,7 +115,7 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         return e ? atoi(e) : 2;
     }();
     // (with the log2(e) fold only the default woven form exists)
-    const bool pipe = !any_bins && activation == NFA_ACTIVATION_RELU && use_pipe && ((a.sp.K == 8 && (!(flags & NFA_FLAG_LOGITS_LOG2E) || use_pipe == 2)) ||
+    const bool pipe = !dbg_logits && !any_bins && activation == NFA_ACTIVATION_RELU && use_pipe && ((a.sp.K == 8 && (!(flags & NFA_FLAG_LOGITS_LOG2E) || use_pipe == 2)) ||
                                   (a.sp.K == 10 && use_pipe == 2));
     // a context: the woven default form at 8 / 10 bins with ReLU; the plain loop for the other bin counts and
     // activations (round 5: rqs_resnet_ctx.hip)
@@ -170,6 +174,7 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         if (init_ks == 4) kern = inv ? rqs_resnet_kernel<true, 1, 4, 2, 8, true> : rqs_resnet_kernel<false, 1, 4, 2, 8, true>;
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 2, 8, true> : rqs_resnet_kernel<false, 1, 2, 2, 8, true>;
     }
+    if (dbg_logits) kern = resnet_debug_kernel(inv, init_ks);
     if (!redo)
         note_layer_kernel("rqs_resnet_kernel<inverse=%d, init_ks=%d, pipe=%d, K=%d, ctx=%d, act=%d>", inv ? 1 : 0, init_ks,
                           pipe ? use_pipe : 0, a.sp.K, with_ctx ? 1 : 0, activation);
@@ -182,6 +187,10 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
             const int rc_lds = raise_dynamic_lds((const void*)kern, &raised_ctx[which], 160 * 1024 - 2048);
             if (rc_lds != NFA_OK) return rc_lds;
         }
+    } else if (dbg_logits && lds > 64 * 1024) {
+        static unsigned long long raised_dbg[4] = {};
+        const int rc_lds = raise_dynamic_lds((const void*)kern, &raised_dbg[(inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)], 160 * 1024 - 2048);
+        if (rc_lds != NFA_OK) return rc_lds;
     } else if (lds > 64 * 1024) {
         static unsigned long long raised[32 + 31 * 4 + 3 * 8] = {};   // device masks (raise_dynamic_lds)  // opt in to > 64 KB of dynamic LDS once per kernel
         const int which = activation != NFA_ACTIVATION_RELU ? 32 + 31 * 4 + (activation - 1) * 8 + (a.sp.K == 10 ? 4 : 0) + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)
@@ -221,6 +230,20 @@ extern "C" int nfa_rqs_flow_resnet_f32(const float* inputs, const void* weights_
     return launch_resnet_layers(inputs, weights_packed, bias_packed, flow_tables, num_layers, outputs, logabsdet,
                                 status, batch, features, num_transform, num_identity, hidden_features, num_blocks,
                                 spec, flags, stream);
+}
+
+// the diagnostic instances: the same launch with the LAST layer's logits stored (include/nflows_amd.h)
+extern "C" int nfa_rqs_flow_resnet_logits_f32(const float* inputs, const void* weights_packed,
+                                              const float* bias_packed, const int32_t* flow_tables,
+                                              int32_t num_layers, float* outputs, float* logabsdet,
+                                              int32_t* status, int64_t batch, int32_t features,
+                                              int32_t num_transform, int32_t num_identity,
+                                              int32_t hidden_features, int32_t num_blocks,
+                                              const nfa_rqs_spec* spec, int32_t flags, void* stream, float* logits) {
+    if (!logits) return NFA_ERR_INVALID_ARGUMENT;
+    return launch_resnet_layers(inputs, weights_packed, bias_packed, flow_tables, num_layers, outputs, logabsdet,
+                                status, batch, features, num_transform, num_identity, hidden_features, num_blocks,
+                                spec, flags, stream, nullptr, nullptr, 0, logits);
 }
 
 extern "C" int nfa_rqs_flow_resnet_redo_f32(const float* inputs, const void* weights_packed,

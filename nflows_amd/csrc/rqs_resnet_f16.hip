@@ -62,7 +62,8 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
                       int32_t param_stages, const int32_t* final_positions, int32_t num_layers, float* outputs,
                       float* logabsdet, int32_t* redo_blocks, int32_t* status, int64_t batch, int32_t features,
                       int32_t num_transform, int32_t num_identity, int32_t hidden_features, int32_t num_blocks,
-                      const nfa_rqs_spec* spec, int32_t flags, void* stream, int32_t* dbg_bins = nullptr) {
+                      const nfa_rqs_spec* spec, int32_t flags, void* stream, int32_t* dbg_bins = nullptr,
+                      float* dbg_logits = nullptr) {
     if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_STANDARD_NORMAL_LOG_PROB |
                   NFA_FLAG_SKIP_OUTPUTS | NFA_FLAG_PAD_COLUMNS_MASK | NFA_FLAG_ACTIVATION_MASK))
         return NFA_ERR_INVALID_ARGUMENT;
@@ -103,6 +104,7 @@ static int launch_f16(const float* inputs, const float* context, int32_t context
     a.ctx = with_ctx ? context : nullptr;
     a.ce = context_features;
     a.dbg_bins = dbg_bins;
+    a.dbg_logits = dbg_logits;
     // the diagnostic instances (nfa_rqs_flow_resnet_f16x2_bins_f32): the bench's kernel family only
     if (dbg_bins && (a.sp.K != 8 || with_ctx || activation != NFA_ACTIVATION_RELU)) return NFA_ERR_UNSUPPORTED;
     a.normal = (flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB) ? 1 : 0;
@@ -262,6 +264,21 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_bins_f32(const float* inputs, const voi
     return launch_f16(inputs, nullptr, 0, stream_packed, param_stages, final_positions, num_layers, outputs, logabsdet,
                       redo_blocks, status, batch, features, num_transform, num_identity, hidden_features, num_blocks,
                       spec, flags, stream, bin_idx);
+}
+
+// the diagnostic instances once more, with the logits of the LAST layer (the final Linear's accumulators x kappa: the
+// conditioner's output as the spline evaluation reads it) stored beside the bins (include/nflows_amd.h)
+extern "C" int nfa_rqs_flow_resnet_f16x2_logits_f32(const float* inputs, const void* stream_packed, int32_t param_stages,
+                                                    const int32_t* final_positions, int32_t num_layers, float* outputs,
+                                                    float* logabsdet, int32_t* redo_blocks, int32_t* status, int64_t batch,
+                                                    int32_t features, int32_t num_transform, int32_t num_identity,
+                                                    int32_t hidden_features, int32_t num_blocks,
+                                                    const nfa_rqs_spec* spec, int32_t flags, void* stream, int32_t* bin_idx,
+                                                    float* logits) {
+    if (!bin_idx || !logits) return NFA_ERR_INVALID_ARGUMENT;
+    return launch_f16(inputs, nullptr, 0, stream_packed, param_stages, final_positions, num_layers, outputs, logabsdet,
+                      redo_blocks, status, batch, features, num_transform, num_identity, hidden_features, num_blocks,
+                      spec, flags, stream, bin_idx, logits);
 }
 
 extern "C" int nfa_rqs_flow_resnet_context_f16x2_f32(const float* inputs, const float* context,

@@ -861,6 +861,19 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                         if (layer == a.num_layers - 1) a.dbg_bins[(row0 + r) * dt + feature] = f.kbin;
                     }
                 };
+                // DBG: the tile's sixteen logits of this lane (accumulators x kappa) of the run's last layer
+                [[maybe_unused]] auto store_logits = [&](const f32x16& t, int tile) {
+                    if constexpr (DBG) {
+                        if (a.dbg_logits != nullptr && layer == a.num_layers - 1) {
+                            float* dst = a.dbg_logits + (size_t)(row0 + r) * (dt * 24) + tile * 32 + half * 16;
+#pragma unroll
+                            for (int q_ = 0; q_ < 16; ++q_) dst[q_] = t[q_] * kappa;
+                            // (stores share vmcnt with the LDS-DMA requests and complete out of order with them: the
+                            //  stream's counted waits must not see them)
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
+                    }
+                };
                 SplineWeave<kUnitNumA, Steps> w0{fa, fb, a.sp};
                 SplineWeave<kUnitFinishA, Steps> w1{fa, fb, a.sp};
                 SplineWeave<kUnitFinishB, Steps> w2{fa, fb, a.sp};
@@ -874,6 +887,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                     } else {
                         tile_gemm(acc[0], ph, pl, sm, fr, lane, NoWeave{});
                     }
+                    store_logits(acc[0], g * 3 + 0);
                     fa.x = *slot0;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -882,6 +896,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                     }
                     load_bias_tile(acc[1], fbias + (g * 3 + 1) * 32);
                     tile_gemm(acc[1], ph, pl, sm, fr, lane, w0);
+                    store_logits(acc[1], g * 3 + 1);
                     fb.x = *slot1;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -890,6 +905,7 @@ __global__ void __launch_bounds__(NW * kWave, 2) rqs_resnet_f16_kernel(const Arg
                     }
                     load_bias_tile(acc[2], fbias + (g * 3 + 2) * 32);
                     tile_gemm(acc[2], ph, pl, sm, fr, lane, w1);
+                    store_logits(acc[2], g * 3 + 2);
                     commit(fa, slot0, g * 4 + half * 2);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {

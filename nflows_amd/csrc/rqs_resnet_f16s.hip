@@ -588,6 +588,7 @@ static int launch_tile16(const float* inputs, const void* stream_packed, int32_t
     a.ctx = nullptr;
     a.ce = 0;
     a.dbg_bins = dbg_bins;
+    a.dbg_logits = nullptr;
     a.normal = (flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB) ? 1 : 0;
     a.skip_out = (flags & NFA_FLAG_SKIP_OUTPUTS) ? 1 : 0;
     a.Ds = density_columns(flags, features);

@@ -28,6 +28,7 @@ struct ResnetArgs {
     int Ds;                // columns the density sums over (features minus NFA_FLAG_PAD_COLUMNS)
     const float* ctx;      // [B, ce] context rows of the conditioners (resnet.py:92-100), or null
     int ce;                // context features (columns of ctx)
+    float* dbg_logits;     // the DBG instances only (round 6): [B, dt * 24] the LAST layer's logits, packed row order
 };
 
 // ---- the final layer with the spline evaluation woven into its MFMAs ------------------------
@@ -210,8 +211,10 @@ __device__ __forceinline__ void gemm_context_tile(f32x16& acc, const float* s_ct
 // CTX: the conditioners take a context (resnet.py:9-52, :92-100): its `ce` columns follow the identity
 // features in the initial layer's input, and every residual block's result is multiplied by
 // sigmoid(context_layer(context)) before the skip connection (F.glu of the concatenation).
-template <bool INVERSE, int PRESCALED, int INIT_KS, int PIPE = 0, int KB = 8, bool CTX = false, int ACT = kActRelu>  // PIPE: 0 plain loop, 1 woven, 2 woven with FlatSteps<FAST>; ACT: the blocks' activation
+// DBG (rqs_resnet_dbg.hip, tests): the plain 8-bin loop with the last layer's logits stored as well.
+template <bool INVERSE, int PRESCALED, int INIT_KS, int PIPE = 0, int KB = 8, bool CTX = false, int ACT = kActRelu, bool DBG = false>  // PIPE: 0 plain loop, 1 woven, 2 woven with FlatSteps<FAST>; ACT: the blocks' activation
 __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs a) {
+    static_assert(!DBG || (KB == 8 && PIPE == 0 && !CTX), "the diagnostic instances: 8 bins, the plain loop");
     static_assert(ACT == kActRelu || (PIPE == 0 && PRESCALED == 1 && ACT >= kActLeakyRelu && ACT <= kActTanh),
                   "other activations: the plain loop");
     static_assert(KB == 8 || (KB == 10 && PIPE != 1 && PRESCALED == 1) || (KB >= 2 && KB <= 32 && PIPE == 0 && PRESCALED == 1),
@@ -653,6 +656,14 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                     for (int t = 0; t < 3; ++t) {
                         load_bias_tile(acc[t], bias + (g * 3 + t) * 32);
                         gemm_tile<false>(acc[t], ph, pm, pl, sm, lane);
+                        if constexpr (DBG) {
+                            if (layer == a.num_layers - 1) {
+                                float* dst = a.dbg_logits + (size_t)(row0 + r) * (dt * 24) + (g * 3 + t) * 32 + half * 16;
+#pragma unroll
+                                for (int q_ = 0; q_ < 16; ++q_) dst[q_] = acc[t][q_];
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (not under the stream's counted waits)
+                            }
+                        }
                     }
                     NFA_STAMP()
                     {
@@ -715,4 +726,5 @@ typedef void (*ResnetKernelFn)(const ResnetArgs);
 ResnetKernelFn resnet_bins_kernel(int K, bool inverse, int init_ks);                      // 2 .. 16 except 8 / 10, 20, 24, 32
 ResnetKernelFn resnet_context_kernel(int K, int activation, bool inverse, int init_ks);     // with a context (round 5): those of the two lines above
 ResnetKernelFn resnet_activation_kernel(int activation, int K, bool inverse, int init_ks);  // NFA_ACTIVATION_* > 0, 8 / 10 bins
+ResnetKernelFn resnet_debug_kernel(bool inverse, int init_ks);                              // rqs_resnet_dbg.hip: 8 bins, ReLU, logits stored
 }  // namespace nfa

@@ -1805,6 +1805,14 @@ def rqs_coupling_resnet(inputs, weights_packed, bias_packed, tables, num_transfo
                 N.ptr(x), N.ptr(ctx), ctx.shape[1], N.ptr(weights_packed), N.ptr(bias_packed), N.ptr(tables),
                 num_layers, N.ptr(out), N.ptr(lad), N.ptr(_status_word(dev)), B, D, num_transform, num_identity,
                 128, num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))
+        elif capture_last_layer_logits.active is not None:
+            capture = capture_last_layer_logits.active
+            rc = N.load().nfa_rqs_flow_resnet_logits_f32(
+                N.ptr(x), N.ptr(weights_packed), N.ptr(bias_packed), N.ptr(tables), num_layers, N.ptr(out),
+                N.ptr(lad), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128, num_blocks,
+                ctypes.byref(spec), flags, N.stream_handle(dev), N.ptr(capture.buffer(B, num_transform, dev)))
+            if rc == N.OK:
+                capture.finish(None)
         else:
             rc = N.load().nfa_rqs_flow_resnet_f32(
                 N.ptr(x), N.ptr(weights_packed), N.ptr(bias_packed), N.ptr(tables), num_layers, N.ptr(out),
@@ -1908,8 +1916,18 @@ def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transf
         if ctx.shape[0] != B:
             raise ValueError("context must have one row per input row")
     capture = capture_last_layer_bins.active
+    capture_logits = capture_last_layer_logits.active
     with torch.cuda.device(dev):
-        if ctx is None and capture is not None:
+        if ctx is None and capture_logits is not None and not tile16:
+            bins = torch.full((B, num_transform), -2, dtype=torch.int32, device=dev)
+            rc = lib.nfa_rqs_flow_resnet_f16x2_logits_f32(
+                N.ptr(x), N.ptr(stream), param_stages, N.ptr(final_table), num_layers, N.ptr(out),
+                N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128,
+                num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev), N.ptr(bins),
+                N.ptr(capture_logits.buffer(B, num_transform, dev)))
+            if rc == N.OK:
+                capture_logits.finish(redo)
+        elif ctx is None and capture is not None:
             entry = lib.nfa_rqs_flow_resnet_f16x2_tile16_bins_f32 if tile16 else lib.nfa_rqs_flow_resnet_f16x2_bins_f32
             capture.bins = torch.full((B, num_transform), -2, dtype=torch.int32, device=dev)
             capture.redo = redo
@@ -1944,6 +1962,183 @@ def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transf
                 N.ptr(x), N.ptr(ctx), ctx.shape[1], N.ptr(packed_exact[0]), N.ptr(packed_exact[1]), N.ptr(tables),
                 num_layers, N.ptr(out), N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform,
                 num_identity, 128, num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))
+        N.check(rc)
+    _after_spline(spec, inverse, dev)
+    return out, lad
+
+
+def split_f16x3(w):
+    """fp32 -> three f16 tensors with w == hi + lo + r EXACTLY while the last piece stays above f16's smallest
+    subnormal (2^-24), round to nearest even every time (f16x3_gemm.hpp)."""
+    hi = w.to(torch.float16)
+    r1 = w - hi.float()
+    lo = r1.to(torch.float16)
+    r = (r1 - lo.float()).to(torch.float16)
+    return hi, lo, r
+
+
+K8X_ACT_SCALE = 16.0   # scale of the activations' f16 pieces in K8x: 24 bits kept down to |v| = 2^-5, overflow at |v| >= 4094.9
+
+
+def pack_resnet_conditioner_f16x3(net, num_transform, params_per_feature, act_scale=K8X_ACT_SCALE,
+                                  pad_transform_to=None, pad_identity_to=None):
+    """Packs a ResidualNet for K8x (csrc/rqs_resnet_f16x3.hip; layout in include/nflows_amd.h): K8's stages, stage
+    order, column / row rules and bias order (pack_resnet_conditioner), the three pieces of a weight being the f16
+    triple (hi, lo, r) of weight x T -- T a power of two chosen per GEMM (_f16_weight_scale) --, the biases
+    pre-multiplied by the scale their accumulators carry (S T: activations' pieces live at scale S = `act_scale`),
+    and per GEMM the pair {1 / T, T} ({1 / (S T), S T} for the final layer) the kernel takes the scales out with.
+    8 bins, no context.  Returns (weights [stages, 768 * 8] f16, biases fp32, scales fp32 [(2 + 2 blocks) * 2])."""
+    dt, P = num_transform, params_per_feature
+    K = (P + 1) // 3
+    if P != 23 or getattr(net, "context_features", None):
+        raise ValueError("K8x packs 8-bin linear-tail layers without a context")
+    S = float(act_scale)
+    if S <= 0 or math.frexp(S)[0] != 0.5:
+        raise ValueError("act_scale must be a power of two")
+    dev = net.final_layer.weight.device
+    order_k = _k8_column_order().to(dev)
+
+    def pieces(w):
+        return torch.stack(split_f16x3(w))  # [3, ...]
+
+    stages, biases, scales = [], [], []
+    H = net.initial_layer.weight.shape[0]                      # <= 128: narrower nets are zero-padded
+    wi = _initial_weight(net, pad_identity_to)
+    di = wi.shape[1]
+    init_ks = 4 if di > 32 else 2
+    wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
+    T = _f16_weight_scale(wi)
+    # (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j)
+    stages.append(pieces(wi * T).view(3, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks, -1))
+    biases.append(_bias_accumulator_order(_pad_to(net.initial_layer.bias.detach().float(), rows=128) * (S * T)))
+    scales += [1.0 / T, T]
+    for block in net.blocks:
+        for lin in block.linear_layers:
+            w = _pad_to(lin.weight.detach().float(), rows=128, cols=128).index_select(1, order_k)  # columns in (ks, hf, j) order
+            T = _f16_weight_scale(w)
+            stages.append(pieces(w * T).view(3, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1))
+            biases.append(_bias_accumulator_order(_pad_to(lin.bias.detach().float(), rows=128) * (S * T)))
+            scales += [1.0 / T, T]
+    scale = torch.ones(P, dtype=torch.float64, device=dev)
+    scale[:2 * K] = 1.0 / math.sqrt(net.hidden_features)
+    wf = net.final_layer.weight.detach().double().view(dt, P, H)
+    wf = torch.cat((wf, wf.new_zeros(dt, P, 128 - H)), dim=2) if H < 128 else wf
+    wf = (wf * scale[None, :, None]).float()
+    bf = (net.final_layer.bias.detach().double().view(dt, P) * scale[None, :]).float()
+    if pad_transform_to is not None and pad_transform_to > dt:   # surplus features: zero rows (fused_geometry)
+        wf = torch.cat((wf, wf.new_zeros(pad_transform_to - dt, P, 128)), dim=0)
+        bf = torch.cat((bf, bf.new_zeros(pad_transform_to - dt, P)), dim=0)
+        dt = pad_transform_to
+    R = 24
+    order_r = _k7_row_order(dt).to(dev)
+    wf = torch.cat((wf, wf.new_zeros(dt, R - P, 128)), dim=1).reshape(dt * R, 128)
+    wf = wf.index_select(0, order_r).index_select(1, order_k)
+    bf = torch.cat((bf, bf.new_zeros(dt, R - P)), dim=1).reshape(dt * R).index_select(0, order_r)
+    tiles = dt * R // 32
+    T = _f16_weight_scale(wf)
+    # (p, tile, i, hs, k4, hf, j) -> (tile, hs, p, k4, hf, i, j): two stages per tile
+    stages.append(pieces(wf * T).view(3, tiles, 32, 2, 4, 2, 8).permute(1, 3, 0, 4, 5, 2, 6).reshape(tiles * 2, -1))
+    biases.append(_bias_accumulator_order(bf * (S * T)))
+    scales += [1.0 / (S * T), S * T]
+    return (torch.cat(stages, dim=0).contiguous(), torch.cat(biases).contiguous(),
+            torch.tensor(scales, dtype=torch.float32, device=dev))
+
+
+def unpack_last_layer_logits(logits_packed, num_transform):
+    """[rows, num_transform * 24] in the diagnostic twins' packed order (include/nflows_amd.h: entry 32 tile + 16 half +
+    q = accumulator register q of lane-half `half` of tile `tile`) -> [rows, num_transform, 23] in the reference's order
+    (the conditioner's output reshaped as coupling.py:550-552 does); the pad row of every feature is dropped."""
+    rows = logits_packed.shape[0]
+    tiles = num_transform * 24 // 32
+    v = logits_packed.view(rows, tiles, 2, 4, 4)                          # (tile, half, q // 4, q % 4)
+    packed_rows = v.permute(0, 1, 3, 2, 4).reshape(rows, tiles * 32)      # row i = 8 (q // 4) + 4 half + q % 4 of the tile
+    order = _k7_row_order(num_transform).to(logits_packed.device)         # packed row -> feature-major row
+    out = torch.empty_like(packed_rows).index_copy_(1, order, packed_rows)
+    return out.view(rows, num_transform, 24)[..., :23]
+
+
+class capture_last_layer_logits:
+    """Diagnostic (tests/test_gpu_logits.py): while active, launches of the whole-layer kernels K8h / K8x / K8 (8 bins, ReLU,
+    no context) go through their diagnostic twins (nfa_rqs_flow_resnet_*_logits_f32) and leave the logits of the run's
+    LAST layer -- the final Linear's output as the spline evaluation reads it -- in `.logits` ([rows, transformed
+    features of the padded layer, 23], width / height entries already divided by sqrt(hidden_features)) together with
+    the launch's `.redo` flags (None for K8).  Not re-entrant, not for timed runs."""
+    active = None
+
+    def __enter__(self):
+        self.logits = self.redo = None
+        self.launches = 0
+        capture_last_layer_logits.active = self
+        return self
+
+    def __exit__(self, *exc):
+        capture_last_layer_logits.active = None
+        return False
+
+    def buffer(self, rows, num_transform, device):
+        self._packed = torch.full((rows, num_transform * 24), float("nan"), dtype=torch.float32, device=device)
+        self._dt = num_transform
+        self.launches += 1
+        return self._packed
+
+    def finish(self, redo):
+        self.logits = unpack_last_layer_logits(self._packed, self._dt)
+        self.redo = redo
+
+
+def rqs_coupling_resnet_f16x3(inputs, packed_f16x3, packed_exact, tables, num_transform, num_identity, num_blocks,
+                              spec, inverse=False, accumulate_into=None, num_layers=1,
+                              standard_normal_log_prob=False, pad=None, _pad_columns_count=0,
+                              act_scale=K8X_ACT_SCALE):
+    """K8x -- the run of whole-layer kernels on the f16 matrix pipe with THREE f16 pieces per operand (five
+    products: operands at the reference's fp32 width), followed by the exact kernel (K8: three bf16 pieces, full
+    fp32 range) on the row blocks the first pass gave up on (a value beyond the f16 range at scale `act_scale`, or
+    non-finite inputs).  `packed_f16x3`: (weights, biases, scales) of the run's layers concatenated, from
+    pack_resnet_conditioner_f16x3; `packed_exact`: (weights, biases) from pack_resnet_conditioner; `tables`: the
+    run's `flow_layer_tables`.  Results as for `rqs_coupling_resnet`; None when the shape is outside the kernel's."""
+    N.require_device_f32("inputs", inputs, 2)
+    if pad is not None and inputs.shape[1] != pad[0]:   # (see rqs_coupling_resnet)
+        out = rqs_coupling_resnet_f16x3(_pad_columns(inputs, pad[0], pad[1]), packed_f16x3, packed_exact, tables,
+                                        num_transform, num_identity, num_blocks, spec, inverse, accumulate_into,
+                                        num_layers, standard_normal_log_prob, None, pad[0] - inputs.shape[1], act_scale)
+        return _without_pad_columns(out, inputs.shape[1])
+    if inputs.shape[0] % 128:
+        return _on_full_blocks(
+            lambda x_, acc_, ctx_: rqs_coupling_resnet_f16x3(x_, packed_f16x3, packed_exact, tables, num_transform,
+                                                             num_identity, num_blocks, spec, inverse, acc_, num_layers,
+                                                             standard_normal_log_prob, None, _pad_columns_count,
+                                                             act_scale),
+            inputs, accumulate_into)
+    dev = inputs.device
+    B, D = inputs.shape
+    x = inputs.detach().contiguous()
+    lad, flags = _lad_buffer(accumulate_into, B, dev, inverse)
+    flags, out = _density_epilogue(flags, standard_normal_log_prob, inverse, x, _pad_columns_count)
+    global _last_redo
+    redo = torch.empty(max(1, B // 128), dtype=torch.int32, device=dev)
+    _last_redo = redo
+    lib = N.load()
+    weights, biases, scales = packed_f16x3
+    capture = capture_last_layer_logits.active
+    with torch.cuda.device(dev):
+        args = (N.ptr(x), N.ptr(weights), N.ptr(biases), N.ptr(scales), N.ptr(tables), num_layers, N.ptr(out),
+                N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128, num_blocks,
+                float(act_scale), ctypes.byref(spec), flags, N.stream_handle(dev))
+        if capture is not None:
+            rc = lib.nfa_rqs_flow_resnet_f16x3_logits_f32(*args, N.ptr(capture.buffer(B, num_transform, dev)))
+        else:
+            rc = lib.nfa_rqs_flow_resnet_f16x3_f32(*args)
+        if rc == N.ERR_UNSUPPORTED:
+            return None
+        N.check(rc)
+        if capture is not None:
+            capture.finish(redo)
+        if os.environ.get("NFA_K8H_NOREDO"):
+            return out, lad
+        rc = lib.nfa_rqs_flow_resnet_redo_f32(
+            N.ptr(x), N.ptr(packed_exact[0]), N.ptr(packed_exact[1]), N.ptr(tables), num_layers, N.ptr(out),
+            N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128,
+            num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev))
         N.check(rc)
     _after_spline(spec, inverse, dev)
     return out, lad

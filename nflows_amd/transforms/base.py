@@ -273,12 +273,13 @@ class CompositeTransform(Transform):
 
     def _run_plan(self, units, inverse, tile16=False):
         """Concatenated weight / bias blobs and the composed tables of a run, cached until a weight or a
-        permutation changes.  (weights, biases, tables, f16 stream or None)."""
+        permutation changes.  (weights, biases, tables, f16 stream or None, K8x's (weights, biases, scales) or None)."""
         from .. import ops
         first = units[0][0]
         mlp = type(first).__name__ in ("AffineCouplingTransform", "AdditiveCouplingTransform")
         geometry = _run_geometry(units)   # one padded geometry for the run
         f16 = (not mlp) and first._use_f16(geometry)
+        x3 = (not mlp) and first._use_f16x3(geometry)     # K8x: three f16 pieces per operand (engine "f16x3")
         # (the key reads version counters only; the layers' packed blobs are looked at on a miss)
         tile16 = tile16 and f16
         ids = units.__dict__.get("_ids") if isinstance(units, _Run) else None
@@ -286,7 +287,7 @@ class CompositeTransform(Transform):
             ids = tuple([id(c) for c, _ in units])
             if isinstance(units, _Run):
                 units.__dict__["_ids"] = ids
-        key = (inverse, f16, tile16, geometry, first._log2e() if not mlp else None, first.conditioner_act_scale if f16 else None,
+        key = (inverse, f16, x3, tile16, geometry, first._log2e() if not mlp else None, first.conditioner_act_scale if f16 else None,
                ids, _run_weights_fingerprint(units),
                tuple([None if p is None else _permutation_key(p) for _, p in units]))
         cache = self.__dict__.setdefault("_run_plans", {})
@@ -310,7 +311,11 @@ class CompositeTransform(Transform):
                                            padded_transform=dt4 if not mlp else None,
                                            padded_identity=di_u if not mlp else None)
             plan_f16 = ops.build_f16_stream(packed_f16, tables) if f16 else None
-            plan = (weights, biases, tables, plan_f16)
+            plan_x3 = None
+            if x3:
+                packed_x3 = [c._packed_resnet_f16x3(geometry) for c, _ in units]
+                plan_x3 = tuple(torch.cat([p[i] for p in packed_x3], dim=0).contiguous() for i in range(3))
+            plan = (weights, biases, tables, plan_f16, plan_x3)
             cache[key] = plan
         return plan
 
@@ -326,9 +331,15 @@ class CompositeTransform(Transform):
         act = first._block_activation() if hasattr(first, "_block_activation") else 0
         tile16 = (hasattr(first, "_use_f16") and inputs.is_cuda
                   and ops.use_tile16(inputs.shape[0], getattr(first, "num_bins", 0), context, inputs.device, act))
-        weights, biases, tables, plan_f16 = self._run_plan(units, inverse, tile16)
+        weights, biases, tables, plan_f16, plan_x3 = self._run_plan(units, inverse, tile16)
         Dp, dt4, di_u, pad_value = _run_geometry(units)
         pad = (Dp, pad_value)
+        if plan_x3 is not None:
+            head = ops.rqs_coupling_resnet_f16x3(
+                inputs, plan_x3, (weights, biases), tables, dt4, di_u, len(first.transform_net.blocks), first._spec(),
+                inverse, total, num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob, pad=pad)
+            if head is not None:
+                return head[1] if standard_normal_log_prob else head[0]
         if type(first).__name__ in ("AffineCouplingTransform", "AdditiveCouplingTransform"):
             hidden_linears, residual_blocks = first._conditioner_shape()
             head = ops.affine_flow_mlp(
@@ -345,7 +356,7 @@ class CompositeTransform(Transform):
             if head is None and tile16:
                 # K8s declined (its ring + 16-row buffers + two copies of the parameter words exceed the LDS budget:
                 # about six blocks at D = 128): K8h takes these shapes -- its own stream, the same call
-                weights, biases, tables, plan_f16 = self._run_plan(units, inverse, False)
+                weights, biases, tables, plan_f16, _ = self._run_plan(units, inverse, False)
                 if plan_f16 is not None:
                     head = ops.rqs_coupling_resnet_f16(
                         inputs, plan_f16, (weights, biases), tables, dt4, di_u, len(first.transform_net.blocks),

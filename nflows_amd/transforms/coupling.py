@@ -673,7 +673,8 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         features, num_blocks, ce = self._static_signature()
         return ("k8", features, num_blocks, self.num_bins, self.tail_bound,
                 self.min_bin_width, self.min_bin_height, self.min_derivative,
-                self._log2e(), self._use_f16(), self.conditioner_act_scale, ce, self._block_activation())
+                self._log2e(), self._use_f16(), self.conditioner_act_scale, ce, self._block_activation(),
+                self.conditioner_engine)
 
     def _block_activation(self):
         """The whole-layer kernels' code of the conditioner blocks' activation (one for all blocks), or None"""
@@ -759,8 +760,10 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         return self.resnet_log2e and self.num_bins == 8
 
     # GEMM engine of the whole-layer kernel: "f16x2" = two f16 pieces per operand on the f16 matrix
-    # pipe (K8h; 8 bins; row blocks that leave the f16 range are redone by the bf16x3 kernel),
-    # "bf16x3" = three bf16 pieces (K8)
+    # pipe (K8h / K8s, three products: 22-bit operand significands, the fp32 fma chain's error class; row blocks that
+    # leave the f16 range are redone by the bf16x3 kernel), "bf16x3" = three bf16 pieces (K8, six products: 24-bit
+    # operands, full fp32 range), "f16x3" (round 6) = three f16 pieces (K8x, five products: operands carried at the
+    # reference's fp32 width on the f16 pipe; 8 bins, ReLU, no context -- other shapes take K8; the same redo pass)
     conditioner_engine = os.environ.get("NFA_K8_ENGINE", "f16x2")
     # scale of the hidden activations' f16 pieces (a power of two; K8h)
     conditioner_act_scale = float(os.environ.get("NFA_K8_ACT_SCALE", "1"))
@@ -771,6 +774,24 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         ce = self._static_signature()[2]
         return (self.conditioner_engine == "f16x2" and ops.whole_layer_bins(self.num_bins) and not self._log2e()
                 and (ce is None or (ce <= 32 and (geometry or self._fused_geometry())[2] <= 32)))
+
+    def _use_f16x3(self, geometry=None):
+        """K8x serves 8 bins with ReLU blocks and no context -- otherwise engine "f16x3" means the bf16x3 kernel (K8)."""
+        return (self.conditioner_engine == "f16x3" and self.num_bins == 8 and not self._log2e()
+                and self._static_signature()[2] is None and self._block_activation() == N.ACTIVATION_RELU)
+
+    def _packed_resnet_f16x3(self, geometry=None):
+        """(weights, biases, scales) for K8x (ops.pack_resnet_conditioner_f16x3), per weight key"""
+        net = self.transform_net
+        _, dt4, di_u, _ = geometry or self._fused_geometry()
+        key = (ops.K8X_ACT_SCALE, dt4, di_u) + _weights_key(self, net)
+        cached = self.__dict__.get("_packed_resnet_f16x3_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, ops.pack_resnet_conditioner_f16x3(self._folded_net(), self.num_transform_features,
+                                                             self._transform_dim_multiplier(),
+                                                             pad_transform_to=dt4, pad_identity_to=di_u))
+            self.__dict__["_packed_resnet_f16x3_cache"] = cached
+        return cached[1]
 
     def _packed_resnet_f16(self, geometry=None, tile16=False):
         """(weights, parameter words) for K8h, or -- `tile16` -- for K8s (the 16-sample-tile kernel of small batches)."""
@@ -839,6 +860,11 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         spec = self._spec()
         # (ragged batches are padded to full 128-row blocks, odd shapes to multiples of four columns, in `ops`)
         act = self._block_activation()
+        if self._use_f16x3():
+            res = ops.rqs_coupling_resnet_f16x3(inputs, self._packed_resnet_f16x3(), (wp, bp), tables, dt4, di, nb, spec,
+                                                inverse, accumulate_into, pad=(Dp, pad_value))
+            if res is not None:
+                return res
         tile16 = self._use_f16() and inputs.is_cuda and ops.use_tile16(inputs.shape[0], self.num_bins, context, inputs.device, act)
         stream = self._f16_stream(tables, tile16) if self._use_f16() else None   # (None: non-finite weights -> exact kernel)
         if stream is not None:

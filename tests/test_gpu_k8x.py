@@ -1,0 +1,216 @@
+"""K8x (round 6): the whole-layer kernel on THREE f16 pieces per operand, five products -- the engine bench.py's headline
+line is timed on (`NFA_K8_ENGINE=f16x3` / `RQ.conditioner_engine = "f16x3"`): operands carried at the reference's fp32
+width (nn/nets/resnet.py:92-100) on the f16 matrix pipe.  csrc/rqs_resnet_f16x3.hip, f16x3_gemm.hpp.
+
+  * the headline flow (32 layers, D = 64, K = 8, 65 536 of bench.py's rows) as ONE launch of K8x, under the headline
+    rule (test_gpu_headline_parity.compare: mean / 99.9 % quantile of the error against float64 at most 2 x the
+    reference-fp32's own), rows independent of the batch, no row block handed to the exact kernel;
+  * the steep / trained fixtures of the real reference: tests/test_gpu_steep.py, test_gpu_trained.py (engine "k8x");
+  * the GEMM arithmetic in front of the spline: tests/test_gpu_logits.py;
+  * here also: the inverse pass and inverse(forward(x)); the f16 range -- activations beyond 65 504 / 16 poison their row
+    block, which the exact kernel (K8) redoes: results as K8's, bit for bit, on those blocks; NaN / inf inputs; ragged
+    batches and feature counts the host pads (fused_geometry); a single layer outside a run; shapes K8x does not
+    serve (10 bins, a context) take K8 under the same switch.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import LAD_TOL, OUT_TOL
+from test_gpu_headline_parity import _report, _spread_rows, bench_rows, compare, oracle_eval
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture
+def f16x3(monkeypatch):
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    monkeypatch.setattr(RQ, "conditioner_engine", "f16x3")
+    return RQ
+
+
+def _ran_k8x(inverse=None):
+    from nflows_amd import ops
+    label = ops.last_layer_kernel()
+    assert "k8x::rqs_resnet_f16x3_kernel" in label, label
+    if inverse is not None:
+        assert ("inverse=1" in label) == inverse, label
+
+
+def test_headline_flow_on_the_reference_width_engine(f16x3):
+    import nflows_amd
+    from nflows_amd import configs, ops
+    flow_cpu = configs.rq_nsf_flow(num_layers=32, features=64, num_bins=8, hidden_features=128, seed=0).eval()
+    x = bench_rows()
+    flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+    xd = x.to(DEV)
+    with torch.no_grad():
+        z, lad = flow._transform(xd)
+        _ran_k8x(False)
+        assert ops.last_redo_blocks() == 0
+        lp = flow.log_prob(xd)
+        _ran_k8x(False)
+        xr, ladr = flow._transform.inverse(z)
+        _ran_k8x(True)
+        assert ops.last_redo_blocks() == 0
+    nflows_amd.check_status()
+    rows = torch.arange(16384)
+    o = oracle_eval(flow_cpu, x[rows])
+    compare("k8x_cfg4_32layer", "z", z[:16384].cpu().numpy(), o["z32"], o["z64"], OUT_TOL)
+    compare("k8x_cfg4_32layer", "logabsdet", lad[:16384].cpu().numpy(), o["lad32"], o["lad64"], LAD_TOL)
+    compare("k8x_cfg4_32layer", "log_prob", lp[:16384].cpu().numpy(), o["lp32"], o["lp64"], LAD_TOL)
+    # rows are independent of the batch: the same rows alone (another grid) give the same bits
+    with torch.no_grad():
+        z2, lad2 = flow._transform(xd[4096:12288])
+    assert torch.equal(z2, z[4096:12288]) and torch.equal(lad2, lad[4096:12288])
+    # inverse(forward(x)): the reference's own fp32 round trip on the same rows is the yardstick (bench.py reports both)
+    err = (xr - xd).abs()
+    with torch.no_grad():
+        from oracle import eager
+        xr_ref, _ = eager.flow_transform(flow_cpu, torch.from_numpy(o["z32"]), inverse=True)
+    ref = (xr_ref - x[:16384]).abs()
+    _report({"config": "k8x_cfg4_32layer", "what": "|inv(fwd(x)) - x|", "mean": float(err.mean()), "max": float(err.max()),
+             "reference_fp32_mean": float(ref.mean()), "reference_fp32_max": float(ref.max())})
+    assert float(err[:16384].mean()) <= 2.0 * float(ref.mean())
+    assert float((lad + ladr).abs().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("case", ["wide_weights", "large_activations", "nonfinite_inputs"])
+def test_f16_range_of_the_three_piece_engine(f16x3, case):
+    """Row blocks whose values leave the f16 range at the pieces' scale (|v| x 16 >= 65 520), or whose inputs are not
+    finite, are flagged and redone by K8: the results on those blocks are K8's bits; all rows under the 2 x rule."""
+    import nflows_amd
+    from nflows_amd import configs, ops
+    gen = torch.Generator().manual_seed(99)
+    flow_cpu = configs.rq_nsf_flow(num_layers=6, features=64, num_bins=8, hidden_features=128, seed=3).eval()
+    if case != "nonfinite_inputs":
+        for t in flow_cpu._transform._transforms:
+            net = getattr(t, "transform_net", None)
+            if net is None:
+                continue
+            _spread_rows(net.initial_layer.weight, 4.0, gen)
+            with torch.no_grad():
+                net.initial_layer.weight.mul_(0.3)
+            for b_i, block in enumerate(net.blocks):
+                for l_i, lin in enumerate(block.linear_layers):
+                    _spread_rows(lin.weight, 4.0, gen)
+                    with torch.no_grad():
+                        lin.weight.mul_((0.1, 1.0, 0.03, 0.5)[2 * b_i + l_i])
+            _spread_rows(net.final_layer.weight, 3.0, gen)
+            with torch.no_grad():
+                net.final_layer.weight.mul_(0.5)
+    B = 16384
+    x = torch.randn(B, 64, generator=gen)
+    if case == "large_activations":
+        x[:4096] *= 10.0 ** (torch.rand(4096, 1, generator=gen) * 3.0)
+        x[4096:6144] *= 1e-4
+    if case == "nonfinite_inputs":
+        x[130, 3] = float("nan")
+        x[700, 10] = float("inf")
+        x[701, 11] = -float("inf")
+    flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+    with torch.no_grad():
+        z, lad = flow._transform(x.to(DEV))
+        _ran_k8x(False)
+        redo = ops.last_redo_blocks()
+        flags = ops._last_redo.clone()
+        lp = flow.log_prob(x.to(DEV))
+        f16x3.conditioner_engine = "bf16x3"
+        z8, lad8 = flow._transform(x.to(DEV))
+        assert "rqs_resnet_kernel<" in ops.last_layer_kernel()
+    try:
+        nflows_amd.check_status()
+    except AssertionError as e:   # (non-finite inputs set the reference's own flags)
+        assert case == "nonfinite_inputs", e
+    _report({"config": "k8x_range_" + case, "redo_blocks": redo, "of": B // 128})
+    if case == "wide_weights":
+        assert redo == 0, "%d row blocks left the f16 range with moderate activations" % redo
+    elif case == "large_activations":
+        assert 0 < redo < B // 128
+    else:
+        assert redo == 2 and flags[1] != 0 and flags[5] != 0
+    # flagged blocks: the exact kernel's bits (NaN == NaN)
+    rows = (flags != 0).repeat_interleave(128)
+    assert torch.equal(torch.nan_to_num(z[rows], nan=7.0), torch.nan_to_num(z8[rows], nan=7.0))
+    assert torch.equal(torch.nan_to_num(lad[rows], nan=7.0), torch.nan_to_num(lad8[rows], nan=7.0))
+    if case == "nonfinite_inputs":
+        bad = torch.tensor([130, 700, 701], device=DEV)
+        assert not torch.isfinite(z[bad]).all(1).any()          # the reference's propagation: NaN / inf stay in their rows
+        ok = torch.ones(B, dtype=torch.bool, device=DEV)
+        ok[bad] = False
+        assert torch.isfinite(z[ok]).all() and torch.isfinite(lad[ok]).all()
+        return
+    sub = torch.arange(0, B, 2)
+    o = oracle_eval(flow_cpu, x[sub])
+    idx = sub.to(DEV)
+    compare("k8x_range_" + case, "z", z[idx].cpu().numpy(), o["z32"], o["z64"], OUT_TOL, max_factor=4.0)
+    compare("k8x_range_" + case, "logabsdet", lad[idx].cpu().numpy(), o["lad32"], o["lad64"], LAD_TOL, max_factor=4.0)
+    compare("k8x_range_" + case, "log_prob", lp[idx].cpu().numpy(), o["lp32"], o["lp64"], LAD_TOL, max_factor=4.0)
+
+
+def test_ragged_batches_odd_feature_counts_and_single_layers(f16x3):
+    """What the host pads into the kernel's family (ops.fused_geometry, _on_full_blocks) -- 22 features under an
+    alternating mask (11 + 11: padded to 24 columns, 12 + 12), a batch of 1 000 rows, a 64-wide conditioner, d_i > 32
+    (the four-k-step initial layer) -- and a single layer outside a run: K8x runs them all; results against K8's within
+    fp32 rounding of the spline (both are held to the oracle elsewhere), pass-through columns bit-exact."""
+    import nflows_amd
+    from nflows_amd import configs, ops
+    from nflows_amd.nn.nets import ResidualNet
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    for features, hidden, rows in ((22, 64, 1000), (100, 128, 4100), (64, 128, 128)):
+        flow_cpu = configs.rq_nsf_flow(num_layers=4, features=features, num_bins=8, hidden_features=hidden, seed=5).eval()
+        for t in flow_cpu._transform._transforms:
+            if hasattr(t, "transform_net"):
+                with torch.no_grad():
+                    t.transform_net.final_layer.weight.mul_(20.0)
+        flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+        x = torch.randn(rows, features, generator=torch.Generator().manual_seed(features)).to(DEV)
+        with torch.no_grad():
+            f16x3.conditioner_engine = "f16x3"
+            z, lad = flow._transform(x)
+            _ran_k8x(False)
+            lp = flow.log_prob(x)
+            xr, ladr = flow._transform.inverse(z)
+            _ran_k8x(True)
+            f16x3.conditioner_engine = "bf16x3"
+            z8, lad8 = flow._transform(x)
+            lp8 = flow.log_prob(x)
+        nflows_amd.check_status()
+        assert z.shape == x.shape and lad.shape == (rows,)
+        assert (z - z8).abs().max().item() < 2e-4 and (lad - lad8).abs().max().item() < 2e-3
+        assert (lp - lp8).abs().max().item() < 2e-3
+        assert (xr - x).abs().max().item() < 5e-3 and (lad + ladr).abs().max().item() < 5e-3
+    # a single layer (CouplingTransform._whole_layer): identity columns bit-exact
+    torch.manual_seed(2)
+    mask = torch.ones(64)
+    mask[::2] = -1
+    layer = RQ(mask, lambda i, o: ResidualNet(i, o, hidden_features=128, num_blocks=2), num_bins=8, tails="linear",
+               tail_bound=3.0).to(DEV).eval()
+    with torch.no_grad():
+        layer.transform_net.final_layer.weight.mul_(20.0)
+    x = torch.randn(640, 64, device=DEV)
+    with torch.no_grad():
+        f16x3.conditioner_engine = "f16x3"
+        y, lad = layer(x)
+        _ran_k8x(False)
+        xb, ladb = layer.inverse(y)
+        _ran_k8x(True)
+    idc = layer.identity_features
+    assert torch.equal(y[:, idc], x[:, idc]) and (xb - x).abs().max().item() < 1e-4 and (lad + ladb).abs().max().item() < 1e-3
+
+
+def test_shapes_outside_the_three_piece_kernel_take_the_exact_kernel(f16x3):
+    """engine "f16x3" on 10 bins or with another block activation: K8 (three bf16 pieces) -- the other reference-width
+    engine -- runs, never the two-piece kernels"""
+    from nflows_amd import configs, ops
+    f16x3.conditioner_engine = "f16x3"
+    for kw in (dict(num_bins=10), dict(num_bins=8, activation=torch.nn.functional.elu)):
+        flow = configs.rq_nsf_flow(num_layers=4, features=32, hidden_features=128, seed=1, **kw).to(DEV).eval()
+        x = torch.randn(2048, 32, device=DEV)
+        with torch.no_grad():
+            lp = flow.log_prob(x)
+        assert "rqs_resnet_kernel<" in ops.last_layer_kernel(), ops.last_layer_kernel()
+        assert torch.isfinite(lp).all()

@@ -170,6 +170,9 @@ def _nsf_engines(K):
     }
     if K == 8:
         e.update({
+            # K8x (round 6): three f16 pieces per operand, five products -- the reference-width engine of the bench line
+            "k8x": (dict(path="k8", engine="f16x3"), 65536, True, ("k8x::", "K=8")),
+            "k8x_b16384": (dict(path="k8", engine="f16x3"), 16384, True, ("k8x::", "K=8")),
             "k8s_w8": (dict(path="k8", engine="f16x2"), 32768, True, ("k8s::", "waves=8")),
             "k8s_w4": (dict(path="k8", engine="f16x2"), 16384, True, ("k8s::", "waves=4")),
             "k7b": (dict(path="k7b", engine="f16x2"), 16384, True, ("rqs_fused_linear_bf16_kernel",)),
@@ -221,7 +224,7 @@ def test_steep_coupling_flow_on_every_engine(golden_dir, engine_switches, case, 
     def counted(fn, key):
         def run(t):
             out = fn(t)
-            if engine.startswith(("k8h", "k8s")):
+            if engine.startswith(("k8h", "k8s", "k8x")):
                 redo[key] += ops.last_redo_blocks()
             return out
         return run

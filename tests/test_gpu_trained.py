@@ -28,7 +28,7 @@ from test_gpu_steep import _checked, _chunked
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-ENGINES = ("k8h_w8", "k8h_w4", "k8s_w8", "k8s_w4", "k8", "gemm_k1", "gemm_k1_pipelined")
+ENGINES = ("k8h_w8", "k8h_w4", "k8s_w8", "k8s_w4", "k8", "k8x", "gemm_k1", "gemm_k1_pipelined")
 
 
 def _data_like(g, name, key, rows, features):
@@ -64,7 +64,7 @@ def test_trained_flow_on_every_engine(golden_dir, engine_switches, engine):
     def counted(fn, key):
         def run(t):
             out = fn(t)
-            if engine.startswith(("k8h", "k8s")):
+            if engine.startswith(("k8h", "k8s", "k8x")):
                 redo[key] += ops.last_redo_blocks()
             return out
         return run

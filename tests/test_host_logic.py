@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 
+import math
 import numpy as np
 import pytest
 import torch
@@ -344,6 +345,148 @@ def test_whole_layer_packing_is_a_lossless_rearrangement(K):
                 ref = want[:, feature]
                 assert (got - ref).abs().max().item() < 5e-6 * (1 + ref.abs().max().item()), (g, half, f)
                 assert vals[:, 24 * f + 23].abs().max().item() == 0.0              # the pad row
+
+
+@pytest.mark.parametrize("di", [6, 40])
+def test_f16x3_whole_layer_packing_carries_the_scales(di):
+    """Host side of K8x (ops.pack_resnet_conditioner_f16x3, round 6): emulate csrc/rqs_resnet_f16x3.hip's data flow on one
+    32-row tile from the packed blobs -- K8's stages with (hi, lo, r) f16 triples of weight x T, the FIVE products the
+    kernel keeps (lo lo and everything below dropped, as on the device), activations as three f16 pieces at scale S
+    (exactly what split3_scaled makes), accumulators at S T, the residual stream rebuilt from its pieces x T, the
+    {1 / T, T} pairs, logits = accumulators x kappa -- and compare with the PyTorch network in float64."""
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import ResidualNet
+    torch.manual_seed(0)
+    dt, K = 8, 8
+    P = 23
+    S = ops.K8X_ACT_SCALE
+    net = ResidualNet(di, dt * P, hidden_features=128, num_blocks=2).double()
+    with torch.no_grad():
+        for i_, p_ in enumerate(net.parameters()):
+            p_.copy_(torch.randn_like(p_) * (0.3 if i_ % 3 else 0.004))   # GEMMs of very different magnitudes
+    wp, bp, sc = ops.pack_resnet_conditioner_f16x3(net.float(), dt, P)
+    net = net.double()
+    init_ks = 4 if di > 32 else 2
+    tiles = dt * 24 // 32
+    assert wp.shape == (init_ks + 16 * 2 + 2 * tiles, 768 * 8) and wp.dtype == torch.float16
+    assert bp.shape == (128 + 256 * 2 + tiles * 32,) and sc.shape == (2 * 6,) and sc.dtype == torch.float32
+    assert torch.isfinite(wp.float()).all() and wp.float().abs().max() < 2 ** 14
+    for g in range(6):   # powers of two, {1 / T, T} (final: {1 / (S T), S T})
+        assert math.frexp(float(sc[2 * g]))[0] == 0.5 and float(sc[2 * g]) * float(sc[2 * g + 1]) == 1.0
+    # the pieces are an exact split of weight x T wherever the last piece is a normal or subnormal f16
+    w = wp.double().view(-1, 768, 8)          # [stage][vec4 slot][8 f16]
+    x = torch.randn(32, di, dtype=torch.float64).float().double()    # one wave's 32 samples (fp32 values)
+    lane_r = torch.arange(64) % 32
+    lane_h = torch.arange(64) // 32
+
+    def split3(v):   # what split3_scaled does to (already scaled) fp32 values: three f16 pieces as float64
+        v = v.float()
+        hi = v.to(torch.float16)
+        t = v - hi.float()
+        lo = t.to(torch.float16)
+        r = (t - lo.float()).to(torch.float16)
+        return hi.double(), lo.double(), r.double()
+
+    def acc_to_features(acc):   # acc[t][lane][q] -> [sample, feature]
+        out = torch.zeros(32, 32 * acc.shape[0], dtype=torch.float64)
+        for t in range(acc.shape[0]):
+            for q in range(16):
+                out[lane_r, 32 * t + 8 * (q // 4) + 4 * lane_h + q % 4] = acc[t, :, q]
+        return out
+
+    def bias_tiles(off, n):     # [n tiles][2 halves][16] -> acc[t][lane][q]
+        return bp[off:off + n * 32].double().view(n, 2, 16)[:, lane_h, :].clone()
+
+    def mfma(acc_t, a_frag, b_frag):
+        A = torch.zeros(32, 16, dtype=torch.float64)
+        Bm = torch.zeros(16, 32, dtype=torch.float64)
+        for l in range(64):
+            A[l % 32, 8 * (l // 32):8 * (l // 32) + 8] = a_frag[l]
+            Bm[8 * (l // 32):8 * (l // 32) + 8, l % 32] = b_frag[l]
+        Dm = A @ Bm
+        for l in range(64):
+            for q in range(16):
+                acc_t[l, q] += Dm[8 * (q // 4) + 4 * (l // 32) + q % 4, l % 32]
+
+    def mfma5(acc_t, a3, b3):   # the kernel's five products
+        (ah, al, ar), (bh, bl, br) = a3, b3
+        for a_, b_ in ((ah, br), (ah, bl), (ar, bh), (al, bh), (ah, bh)):
+            mfma(acc_t, a_, b_)
+
+    def a_kmajor(stage, t):
+        return tuple(w[stage, (t * 3 + p_) * 64:(t * 3 + p_) * 64 + 64] for p_ in range(3))
+
+    def b_from_acc(pieces, ks):       # pieces of the previous layer's accumulators -> three [lane][8]
+        return tuple(pc[ks // 2][:, 8 * (ks % 2):8 * (ks % 2) + 8] for pc in pieces)
+
+    def pieces_of(acc, scale, relu):  # [4][64][16] accumulators x scale -> three piece tensors
+        v = acc * scale
+        if relu:
+            v = torch.relu(v)
+        return split3(v)
+
+    stage = 0
+    bx = torch.zeros(init_ks, 64, 8, dtype=torch.float64)
+    for ks in range(init_ks):
+        for l in range(64):
+            for j in range(8):
+                i = ks * 16 + (l // 32) * 8 + j
+                bx[ks, l, j] = x[l % 32, i] if i < di else 0.0
+    xp = split3(bx * S)
+    carried = xp[0] + xp[1] + xp[2]
+    big = (bx * S).abs() >= 0.5
+    assert torch.equal(carried[big], (bx * S)[big])              # all 24 bits while the last piece is >= 2^-24 ...
+    assert (carried - bx * S).abs().max().item() <= 2.0 ** -25   # ... and an absolute 2^-25 (/ S) below that
+    acc = bias_tiles(0, 4)
+    for ks in range(init_ks):                             # initial layer: k-major [4 tiles][3 pieces][64]
+        for t in range(4):
+            mfma5(acc[t], a_kmajor(stage, t), tuple(pc[ks] for pc in xp))
+        stage += 1
+    g = 0
+    h = pieces_of(acc.float().double(), float(sc[0]), False)     # S h as pieces (accumulators are fp32 on the device)
+    boff = 128
+    g += 1
+    for blk in range(2):
+        relu_h = tuple(pc * (h[0] >= 0) for pc in h)             # the sign mask on the pieces
+        acc = bias_tiles(boff, 4)
+        for ks in range(8):
+            for t in range(4):
+                mfma5(acc[t], a_kmajor(stage, t), b_from_acc(relu_h, ks))
+            stage += 1
+        u = pieces_of(acc.float().double(), float(sc[2 * g]), True)
+        g += 1
+        acc = bias_tiles(boff + 128, 4) + (h[0] + h[1] + h[2]) * float(sc[2 * g + 1])   # skip: pieces x T
+        for ks in range(8):
+            for t in range(4):
+                mfma5(acc[t], a_kmajor(stage, t), b_from_acc(u, ks))
+            stage += 1
+        h = pieces_of(acc.float().double(), float(sc[2 * g]), False)
+        g += 1
+        boff += 256
+    got_hidden = acc_to_features(h[0] + h[1] + h[2]) / S
+    want_hidden = net.hidden(x)
+    assert (got_hidden - want_hidden).abs().max().item() < 1e-6 * want_hidden.abs().max().item()
+    out = torch.zeros(tiles, 64, 16, dtype=torch.float64)
+    bfin = bias_tiles(boff, tiles)
+    for t in range(tiles):                                # final layer: two stages per tile [3 pieces][4 k-steps][64]
+        out[t] = bfin[t]
+        for hs in range(2):
+            for k4 in range(4):
+                a3 = tuple(w[stage, (p_ * 4 + k4) * 64:(p_ * 4 + k4) * 64 + 64] for p_ in range(3))
+                mfma5(out[t], a3, b_from_acc(h, hs * 4 + k4))
+            stage += 1
+    assert stage == wp.shape[0]
+    kappa = float(sc[2 * g])
+    assert kappa * float(sc[2 * g + 1]) == 1.0
+    # the diagnostic twins' packed order and its inverse (ops.unpack_last_layer_logits)
+    packed = torch.zeros(32, tiles * 32)
+    for t in range(tiles):
+        for l in range(64):
+            packed[l % 32, 32 * t + 16 * (l // 32):32 * t + 16 * (l // 32) + 16] = (out[t, l] * kappa).float()
+    logits = ops.unpack_last_layer_logits(packed, dt).double()
+    want = net.final_layer(want_hidden).view(32, dt, P).clone()
+    want[..., :2 * K] /= np.sqrt(128.0)
+    assert (logits - want).abs().max().item() < 2e-6 * (1 + want.abs().max().item())
 
 
 def _emulate_f16_whole_layer(wp, prm, x, di, dt, K, num_blocks, ctx=None):
