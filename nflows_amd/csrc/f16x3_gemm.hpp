@@ -51,10 +51,31 @@ struct Pieces {
 // |v s| >= 65520 gives hi = inf, t = -inf, lo = -inf, r = NaN: the overflow poisons every sum it enters, the row
 // block is flagged and redone by the exact kernel.  (One asm block: hipcc puts an `s_nop 0` between two adjacent asm
 // statements; early-clobber everywhere: every output is written before the last input is read.)
+// The conversions are `asm volatile`: a plain asm statement is free to move, and hipcc's scheduler moved these across the
+// stream's (volatile) waits and barriers to right behind the MFMAs whose accumulators they read -- instructions inside an
+// asm statement are invisible to the hazard recogniser, which therefore pads nothing between an MFMA and an asm block
+// that reads its result: the first build had every GEMM's last products missing from some values (logits 2^-12 off,
+// bit-reproducible; found by tests/test_gpu_logits.py, round 6).  Volatile keeps them in program order behind the GEMM's
+// last barrier, and tile_to_pieces puts the matrix pipe's write-back distance (11 wait states behind an 8-pass MFMA)
+// in front of the first block that reads a tile.  NFA_K8X_NO_ASM (measurement builds): the same arithmetic in C++.
+#define NFA_K8X_PRE ""
+#define NFA_K8X_ASM asm volatile
 __device__ __forceinline__ void split3_scaled(float v0, float v1, float scale, unsigned& hi, unsigned& lo, unsigned& rr) {
+#if defined(NFA_K8X_NO_ASM)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const float x0 = v0 * scale, x1 = v1 * scale;
+    const h2 h = {(_Float16)x0, (_Float16)x1};
+    const float t0 = x0 - (float)h[0], t1 = x1 - (float)h[1];
+    const h2 l = {(_Float16)t0, (_Float16)t1};
+    const h2 r = {(_Float16)(t0 - (float)l[0]), (_Float16)(t1 - (float)l[1])};
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+    rr = __builtin_bit_cast(unsigned, r);
+#else
     unsigned h, l, r;
     float t0, t1;
-    asm("v_fma_mixlo_f16 %0, %5, %7, 0 op_sel_hi:[0,0,0]\n\t"
+    NFA_K8X_ASM(NFA_K8X_PRE
+        "v_fma_mixlo_f16 %0, %5, %7, 0 op_sel_hi:[0,0,0]\n\t"
         "v_fma_mixhi_f16 %0, %6, %7, 0 op_sel_hi:[0,0,0]\n\t"
         "v_fma_mix_f32 %3, %5, %7, -%0 op_sel_hi:[0,0,1]\n\t"
         "v_fma_mix_f32 %4, %6, %7, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
@@ -67,18 +88,27 @@ __device__ __forceinline__ void split3_scaled(float v0, float v1, float scale, u
     hi = h;
     lo = l;
     rr = r;
+#endif
 }
 
 // the fp32 value of a piece triple (exact: hi + lo has at most 23 bits, + r at most 24) times `mul`, plus `add`:
 // the skip connection, acc = bias + T x h
 __device__ __forceinline__ void pieces_fma2(unsigned h, unsigned l, unsigned r, float mul, float& acc0, float& acc1) {
     float t0, t1;
-    asm("v_fma_mix_f32 %0, %2, 1.0, %3 op_sel_hi:[1,0,1]\n\t"
+#if defined(NFA_K8X_NO_ASM)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 hh = __builtin_bit_cast(h2, h), ll = __builtin_bit_cast(h2, l), rr = __builtin_bit_cast(h2, r);
+    t0 = ((float)hh[0] + (float)ll[0]) + (float)rr[0];
+    t1 = ((float)hh[1] + (float)ll[1]) + (float)rr[1];
+#else
+    NFA_K8X_ASM(NFA_K8X_PRE
+        "v_fma_mix_f32 %0, %2, 1.0, %3 op_sel_hi:[1,0,1]\n\t"
         "v_fma_mix_f32 %1, %2, 1.0, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]\n\t"
         "v_fma_mix_f32 %0, %4, 1.0, %0 op_sel_hi:[1,0,0]\n\t"
         "v_fma_mix_f32 %1, %4, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
         : "=&v"(t0), "=&v"(t1)
         : "v"(h), "v"(l), "v"(r));
+#endif
     acc0 = __builtin_fmaf(t0, mul, acc0);
     acc1 = __builtin_fmaf(t1, mul, acc1);
 }
@@ -108,6 +138,7 @@ __device__ __forceinline__ void relu_pieces(Pieces& p) {
 // (compare + select: NaN stays NaN, v_max_f32 would return the zero)
 template <bool RELU>
 __device__ __forceinline__ void tile_to_pieces(const f32x16& a, float scale, Pieces& p0, Pieces& p1) {
+    asm volatile("s_nop 7\n\ts_nop 3" : : "v"(a));   // (see NFA_K8X_ASM: the tile's last MFMA has written back)
 #pragma unroll
     for (int q2 = 0; q2 < 8; ++q2) {
         float v0 = a[q2 * 2], v1 = a[q2 * 2 + 1];

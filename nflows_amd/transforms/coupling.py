@@ -673,8 +673,8 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         features, num_blocks, ce = self._static_signature()
         return ("k8", features, num_blocks, self.num_bins, self.tail_bound,
                 self.min_bin_width, self.min_bin_height, self.min_derivative,
-                self._log2e(), self._use_f16(), self.conditioner_act_scale, ce, self._block_activation(),
-                self.conditioner_engine)
+                self._log2e(), self._use_f16(), self.conditioner_act_scale, ce, self.conditioner_engine,
+                self._block_activation())
 
     def _block_activation(self):
         """The whole-layer kernels' code of the conditioner blocks' activation (one for all blocks), or None"""
