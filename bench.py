@@ -147,6 +147,8 @@ KERNEL_SOURCES = {
                              "fused_common.hpp", "common.hpp"),
     "k8_pmc_traffic.json": ("rqs_resnet_kernel.hpp", "rqs_resnet.hip", "bf16x3_gemm.hpp", "rqs_math.hpp", "fused_common.hpp",
                             "common.hpp"),
+    "k8x_pmc_traffic.json": ("rqs_resnet_f16x3.hip", "f16x3_gemm.hpp", "bf16x3_gemm.hpp", "rqs_resnet_f16_kernel.hpp", "k8h_common.hpp",
+                             "rqs_fused8.hpp", "rqs_math.hpp", "fused_common.hpp", "common.hpp"),
     "k7b_pmc_traffic.json": ("rqs_fused_linear.hip", "rqs_math.hpp", "fused_common.hpp", "common.hpp"),
     "k7_pmc_traffic.json": ("rqs_fused_linear.hip", "rqs_math.hpp", "fused_common.hpp", "common.hpp"),
     "k1_pmc_traffic.json": ("rqs.hip", "rqs_math.hpp", "common.hpp"),
@@ -217,7 +219,7 @@ def _reference_flow(flow_cpu):
         return None
 
 
-def cpu_baseline(flow_cpu, features, sample_rows, x_consistency=None, budget_s=20.0):
+def cpu_baseline(flow_cpu, features, sample_rows, x_consistency=None, budget_s=20.0, full_rows=0):
     """The reference's CPU path on the host cores this process may use: the unmodified reference
     classes when /root/reference is importable (build container), else their bit-identical
     PyTorch-eager port (oracle/eager.py; tests/test_oracle_golden.py pins it bit for bit).  Bounded:
@@ -264,13 +266,112 @@ def cpu_baseline(flow_cpu, features, sample_rows, x_consistency=None, budget_s=2
             consistency = {"max": err.max().item(), "mean": err.mean().item(),
                            "q999": torch.quantile(err.flatten()[:2 ** 24].double(), 0.999).item(),
                            "count_above_1e-3": int((err > 1e-3).sum().item()), "rows": xs.shape[0]}
+    full = None
+    if full_rows and full_rows > rows:
+        # BASELINE's own batch (65 536 rows), ONE pass (the reference is ~2 x slower per sample there than at the sample size:
+        # its [N, 8] intermediates leave the caches)
+        with torch.no_grad():
+            torch.set_num_threads(threads)
+            xf = torch.randn(full_rows, features, generator=torch.Generator().manual_seed(1234))
+            t0 = time.perf_counter()
+            run(xf)
+            dtf = time.perf_counter() - t0
+        full = {"rows": full_rows, "passes": 1, "seconds": dtf, "value": full_rows / dtf, "unit": "samples/s", "cores": threads}
+        log("cpu baseline at %d rows: one pass %.1f s" % (full_rows, dtf))
     out = {"value": rows / dt, "unit": "samples/s", "cores": threads, "kind": kind,
            "sample": "same 32-layer flow and weights, %d rows x %d timed passes of %s, %.2f s/pass"
                      % (rows, reps, "the reference classes imported from /root/reference" if ref is not None
                         else "oracle/eager.py (bit-identical port of the reference CPU path)", dt),
            "one_thread": {"value": rows1 / dt1, "unit": "samples/s", "rows": rows1, "passes": reps1}}
+    if full is not None:
+        out["at_baseline_batch"] = full
     if consistency is not None:
         out["reference_fwd_inv_err_same_rows"] = consistency
+    return out
+
+
+def other_configs(dev, steps):
+    """The other BASELINE.json configurations on this GPU, outside the timed region (`other_configs_extra`): configs[1]
+    (8 affine couplings, D = 32, MLP conditioner, 16 384 rows: K11, one launch), configs[2] (16 RQ couplings, D = 64, K = 8,
+    65 536 rows: the headline's kernel), configs[4] (autoregressive RQ spline, D = 784, K = 8, 4 096 rows: forward K13, full
+    inverse K12 + K13).  Per entry: ms per pass, samples/s, the layer kernel the library launched last, and that pass in
+    the unit of its bound -- HBM GB/s over SURVEY 8d's algorithmic bytes and / or the fp32 multiply-adds of its GEMMs."""
+    from nflows_amd import configs, ops
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    out = []
+
+    def timed(fn, reps, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    def entry(name, seconds, rows, bytes_per_row=None, macs_per_row=None, **extra):
+        e = dict(config=name, ms=seconds * 1e3, samples_per_s=rows / seconds, rows=rows, kernel=ops.last_layer_kernel(), **extra)
+        if bytes_per_row is not None:
+            e["hbm"] = {"algorithmic_bytes": rows * bytes_per_row, "achieved_gbs": rows * bytes_per_row / seconds / 1e9,
+                        "frac_of_8000": rows * bytes_per_row / seconds / 1e9 / HBM_PEAK_GBS}
+        if macs_per_row is not None:
+            tf = 2.0 * rows * macs_per_row / seconds / 1e12
+            e["gemm"] = {"fp32_flops": 2.0 * rows * macs_per_row, "achieved_tflops": tf, "frac_of_16bit_mfma_peak": tf / BF16_PEAK_TFLOPS,
+                         "frac_of_fp32_matrix_peak": tf / 157.3}
+        out.append(e)
+
+    with torch.no_grad():
+        try:   # configs[1]
+            flow = configs.affine_coupling_flow(8, 32, (128, 128)).to(dev).eval()
+            x = torch.randn(16384, 32, device=dev)
+            macs = 8 * (16 * 128 + 128 * 128 + 128 * 32)
+            entry("configs[1] 8 x AffineCouplingTransform, D=32, MLP 128x128, log_prob", timed(lambda: flow.log_prob(x), 100, 100), 16384,
+                  bytes_per_row=4 * (32 + 1), macs_per_row=macs)
+            z, _ = flow._transform(x)
+            xr, _ = flow._transform.inverse(z)
+            entry("configs[1] inverse (sampling direction)", timed(lambda: flow._transform.inverse(z), 100, 100), 16384,
+                  bytes_per_row=4 * (32 + 32 + 1), macs_per_row=macs, fwd_inv_max_err=(xr - x).abs().max().item())
+            del flow
+        except Exception as e:
+            log("other_configs: configs[1] skipped: %r" % (e,))
+        try:   # configs[2]
+            flow = configs.rq_nsf_flow(16, 64, 8, 128).to(dev).eval()
+            x = torch.randn(65536, 64, device=dev)
+            macs = 16 * (32 * 23 * 128 + 32 * 128 + 4 * 128 * 128)
+            for engine in ("f16x3", "f16x2"):
+                saved = RQ.conditioner_engine
+                try:
+                    RQ.conditioner_engine = engine
+                    entry("configs[2] 16 x RQ coupling, D=64, K=8, ResidualNet, log_prob, engine %s" % engine,
+                          timed(lambda: flow.log_prob(x), max(10, steps), 5), 65536, bytes_per_row=16 * 3460, macs_per_row=macs, engine=engine)
+                    if engine == "f16x3":
+                        z, _ = flow._transform(x)
+                        xr, _ = flow._transform.inverse(z)
+                        entry("configs[2] inverse (sampling direction), engine f16x3", timed(lambda: flow._transform.inverse(z), max(10, steps), 5),
+                              65536, bytes_per_row=16 * 3460, macs_per_row=macs, engine=engine, fwd_inv_max_err=(xr - x).abs().max().item())
+                finally:
+                    RQ.conditioner_engine = saved
+            del flow
+        except Exception as e:
+            log("other_configs: configs[2] skipped: %r" % (e,))
+        try:   # configs[4]
+            flow = configs.ar_rq_flow(784, 256, 8, 3.0, 2).to(dev).eval()
+            x = torch.randn(4096, 784, device=dev)
+            t = flow._transform._transforms[0]
+            macs = 784 * 256 + 4 * 256 * 256 + 256 * 784 * 23      # MADE: initial, two blocks, output layer
+            entry("configs[4] MaskedPiecewiseRationalQuadraticAutoregressive, D=784, K=8, log_prob (forward)",
+                  timed(lambda: flow.log_prob(x), 20, 5), 4096, bytes_per_row=78404, macs_per_row=macs)
+            z = torch.randn(4096, 784, device=dev)
+            xs, _ = t.inverse(z)
+            zz, _ = t(xs)
+            entry("configs[4] FULL inverse (the sampling path: 784 sequential features)", timed(lambda: t.inverse(z), 10, 3), 4096,
+                  fwd_of_inverse_max_err=(zz - z).abs().max().item(),
+                  note="sequential part in one persistent kernel (K12), the rest K13; the reference runs 784 full passes")
+            del flow
+        except Exception as e:
+            log("other_configs: configs[4] skipped: %r" % (e,))
+    torch.cuda.empty_cache()
     return out
 
 
@@ -291,6 +392,10 @@ def main():
                     help="layer kernel: k8 = whole ResidualNet conditioner + spline in one kernel "
                          "(default), k7b / k7 = only the final Linear fused (split-bf16 / fp32 MFMA), "
                          "k1 = PyTorch conditioner + spline kernel")
+    ap.add_argument("--engine", choices=["f16x3", "f16x2", "bf16x3"], default="f16x3",
+                    help="GEMM engine of the whole-layer kernel (--path k8): f16x3 = K8x, three f16 pieces per operand, five "
+                         "products: operands at the reference's fp32 width (default, the headline); f16x2 = K8h / K8s, two f16 "
+                         "pieces, three products (22-bit operand significands; timed as an extra); bf16x3 = K8, three bf16 pieces")
     ap.add_argument("--no-fuse-linear", action="store_true",
                     help="leave the conditioner's final Linear to hipBLASLt (GEMM + K1 instead of K7)")
     ap.add_argument("--skip-k1-roofline", action="store_true")
@@ -349,6 +454,7 @@ def main():
     if args.no_fuse_linear:
         args.path = "k1"
     select_path(args.path)
+    RQ.conditioner_engine = args.engine
     CONFIG4_GLOBAL = 262144
     if args.batch_per_gpu is not None:
         B = args.batch_per_gpu
@@ -480,15 +586,19 @@ def main():
                           "unit": "samples/s"})
             del xs_
 
-    # extra (N = 1): the same step on the engines whose GEMM arithmetic nobody can dispute -- K8 (three bf16 pieces per
-    # operand: 24-bit significands, full fp32 range) and the layer-by-layer path (PyTorch / hipBLASLt fp32 conditioner +
-    # K1) -- so that the driver's record holds them beside the headline (two f16 pieces: 22-bit significands)
-    exact_engines = None
+    # extra (N = 1): the same step on every OTHER engine -- K8h (two f16 pieces, three products: the fastest, 22-bit operand
+    # significands), K8 (three bf16 pieces, six products), and layer by layer (PyTorch / hipBLASLt fp32 conditioner + K1) --,
+    # each timed like the headline (the same number of steps, per-dispatch HIP events for its roofline block)
+    other_engines = None
     if world == 1 and args.batch_per_gpu is None and not args.skip_extra and args.path == "k8":
-        exact_engines = []
-        saved_engine = RQ.conditioner_engine
-        for label, engine, path in (("K8: whole-layer kernel on three bf16 pieces per operand (6 products, 24-bit significands)", "bf16x3", "k8"),
-                                    ("layer by layer: PyTorch (hipBLASLt) fp32 conditioner GEMMs + K1 spline kernel", saved_engine, "k1")):
+        other_engines = []
+        candidates = [("K8x: whole-layer kernel on three f16 pieces per operand (5 products: operands at fp32 width)", "f16x3", "k8"),
+                      ("K8h: whole-layer kernel on two f16 pieces per operand (3 products, 22-bit operand significands)", "f16x2", "k8"),
+                      ("K8: whole-layer kernel on three bf16 pieces per operand (6 products, 24-bit significands)", "bf16x3", "k8"),
+                      ("layer by layer: PyTorch (hipBLASLt) fp32 conditioner GEMMs + K1 spline kernel", args.engine, "k1")]
+        for label, engine, path in candidates:
+            if path == "k8" and engine == args.engine:
+                continue
             try:
                 RQ.conditioner_engine = engine
                 select_path(path)
@@ -498,23 +608,29 @@ def main():
                 def step_e():
                     with torch.no_grad():
                         return parallel.reduce_log_likelihood(flow_e.log_prob(x))
-                for _ in range(2):
+                for _ in range(3):
                     acc_e = step_e()
                 torch.cuda.synchronize()
+                n_e = max(20, args.steps) if path == "k8" else max(10, args.steps // 2)
+                _native.check(_native.load().nfa_profile_enable(args.layers * n_e))
                 te = time.perf_counter()
-                n_e = max(3, args.steps // 4)
                 for _ in range(n_e):
                     acc_e = step_e()
                 torch.cuda.synchronize()
                 dte = (time.perf_counter() - te) / n_e
-                exact_engines.append({"engine": label, "kernel": ops.last_layer_kernel(), "rows": B, "steps": n_e,
+                ms_e = dispatch_durations_ms(args.layers * n_e)
+                _native.check(_native.load().nfa_profile_enable(0))
+                other_engines.append({"engine": label, "kernel": ops.last_layer_kernel(), "rows": B, "steps": n_e,
                                       "ms_per_step": dte * 1e3, "value": B / dte, "unit": "samples/s",
-                                      "mean_log_likelihood": (acc_e[0] / acc_e[1]).item()})
+                                      "mean_log_likelihood": (acc_e[0] / acc_e[1]).item(),
+                                      "redo_blocks": ops.last_redo_blocks() if (path == "k8" and engine != "bf16x3") else None,
+                                      "_roofline_args": (path, engine, ms_e, len(ms_e) / n_e)})
                 del flow_e
             except Exception as e:  # measurement extra only
-                log("exact-engine extra (%s) skipped: %r" % (path, e))
+                log("engine extra (%s / %s) skipped: %r" % (path, engine, e))
             finally:
-                RQ.conditioner_engine = saved_engine
+                _native.load().nfa_profile_enable(0)
+                RQ.conditioner_engine = args.engine
                 select_path(args.path)
         torch.cuda.empty_cache()
 
@@ -610,53 +726,55 @@ def main():
         timing_note = ("HIP start/stop events attached to each layer-kernel dispatch on its launch "
                        "stream (hipExtLaunchKernelGGL), all launches of the timed region")
 
-        def roofline_of(path, ms, launches_per_step, ran=None):
+        ENGINES = {   # pieces per operand, products per multiply-add, weight-stream bytes per layer, counter file
+            "f16x3": ("three f16 pieces (33 significand bits: the fp32 operand exactly)", 5, "f16",
+                      (2 + 16 * nb_ + 2 * (dt_ * 24 // 32)) * 12288, "k8x_pmc_traffic.json"),
+            "f16x2": ("two f16 pieces (22 significand bits)", 3, "f16",
+                      (2 + 8 * nb_ + dt_ * 24 // 32) * 16384, "k8h_pmc_traffic.json"),   # (+ the parameter stage)
+            "bf16x3": ("three bf16 pieces (24 significand bits)", 6, "bf16",
+                       (2 + 16 * nb_ + 2 * (dt_ * 24 // 32)) * 12288, "k8_pmc_traffic.json"),
+        }
+
+        def roofline_of(path, ms, launches_per_step, ran=None, engine=None):
             """`launches_per_step` layer-kernel dispatches make one step of `args.layers` layers: 32
             (one layer per launch) or 1 (the run of K8 layers in a single launch).  `ran`: the kernel name the
             library reported (nfa_last_layer_kernel) -- `kernel` is then that name, not a guess."""
+            engine = engine or args.engine
             avg_ms, launches = sum(ms) / len(ms), len(ms)
             layers_per_launch = args.layers / launches_per_step
             common = {"avg_launch_ms": avg_ms, "launches_timed": launches, "layers_per_launch": layers_per_launch,
                       "timing": timing_note}
             if path in ("k8", "k7b"):
-                # GEMMs on the matrix pipe with split operands (DESIGN.md section 4): K8h = two f16
-                # pieces, 3 products per fp32 multiply-add; K8 / K7b = three bf16 pieces, 6 products.
-                # Flops of the unpadded layers; f16 and bf16 MFMA have the same dense peak.
-                f16 = path == "k8" and RQ.conditioner_engine == "f16x2"
-                products = 3 if f16 else 6
+                # `achieved` follows SURVEY 8d: the fp32 multiply-adds of the layers' GEMMs (x 2 flop), unpadded -- the work the
+                # reference's F.linear calls do -- over the launch duration.  The kernels do that work on the 16-bit matrix
+                # pipe with split operands (DESIGN.md section 4): `matrix_pipe` says what the pipe itself executed
+                # (products per multiply-add x the same flops) and how busy that kept it.
+                pieces, products, pipe, weight_bytes, traffic_file = ENGINES[engine] if path == "k8" else \
+                    ("three bf16 pieces (24 significand bits)", 6, "bf16", 0, "k7b_pmc_traffic.json")
                 macs = dt_ * P_ * H_ + ((D - dt_) * H_ + nb_ * 2 * H_ * H_ if path == "k8" else 0)
                 fp32_flops = 2.0 * B * macs * layers_per_launch
-                flops = products * fp32_flops
-                ach = flops / (avg_ms * 1e-3) / 1e12
-                # HBM: a run of layers reads its rows once and writes them once, and streams every
-                # layer's packed weights (16 KB stages of f16 pairs / 12 KB stages of bf16 triples) once
-                k8_weights = layers_per_launch * ((2 + 8 * nb_ + dt_ * 24 // 32) * 16384 if f16   # (+ the parameter stage)
-                                                  else (2 + 16 * nb_ + 2 * (dt_ * 24 // 32)) * 12288)
-                bytes_ = io_bytes + k8_weights if path == "k8" else (io_bytes + 4 * B * H_) * layers_per_launch
-                traffic_file = ("k8h_pmc_traffic.json" if f16 else "k8_pmc_traffic.json") if path == "k8" else "k7b_pmc_traffic.json"
-                nw8 = B % 256 == 0 and B // 256 >= 256
-                ring = 5 if (nw8 and os.environ.get("NFA_K8H_RING", "") == "5") else 4   # (5: the elastic-stream experiment, DESIGN.md section 4)
-                kernel = ("nfa::k8h::rqs_resnet_f16_kernel<false, 2, %d, 8, false, %d>" % (8 if nw8 else 4, ring) if f16
-                          else "nfa::rqs_resnet_kernel<false, 1, 2, %s, 8, false>" % os.environ.get("NFA_K8_PIPE", "2")) if path == "k8" \
-                    else "nfa::rqs_fused_linear_bf16_kernel<false>"
-                r = {"bound": "mfma", "kernel": ("nfa::" + ran) if ran else kernel,
+                ach = fp32_flops / (avg_ms * 1e-3) / 1e12
+                # HBM: a run of layers reads its rows once and writes them once, and streams every layer's packed weights once
+                bytes_ = io_bytes + layers_per_launch * weight_bytes if path == "k8" else (io_bytes + 4 * B * H_) * layers_per_launch
+                traffic, traffic_from = load_traffic(traffic_file)
+                r = {"bound": "mfma", "kernel": ("nfa::" + ran) if ran else "?",
                      "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
-                     "traffic": load_traffic(traffic_file)[0],
-                     "traffic_from": load_traffic(traffic_file)[1],
-                     "algorithmic_flops_per_launch": flops,
+                     "traffic": traffic, "traffic_from": traffic_from,
+                     "algorithmic_flops_per_launch": fp32_flops,
                      "algorithmic_bytes_per_launch": bytes_,
-                     "fp32_flops_per_launch": fp32_flops,
-                     "fp32_equivalent_tflops": ach / products,
-                     "frac_of_fp32_matrix_peak": ach / products / 157.3,
+                     "frac_of_fp32_matrix_peak": ach / 157.3,
+                     "matrix_pipe": {"operands": pieces, "products_per_multiply_add": products,
+                                     "executed_flops_per_launch": products * fp32_flops,
+                                     "achieved": products * ach, "unit": "TFLOP/s", "frac_of_peak": products * ach / BF16_PEAK_TFLOPS},
                      "frac_of_hbm_peak_by_survey_bytes": (k1_bytes * layers_per_launch / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
-                     "note": "achieved = %d x (fp32 multiply-adds of the layers' GEMMs) x 2 / time: every fp32 operand "
-                             "is %s and %d cross products per multiply-add run on the %s matrix pipe (fp32-accurate); "
-                             "peak = dense 16-bit MFMA peak.  The same launch expressed as fp32 GEMM work: %.1f TFLOP/s "
-                             "(fp32 matrix peak 157.3); expressed in SURVEY 8d's unfused HBM bytes (3460 B/sample/layer): "
-                             "%.0f GB/s-equivalent of 8000"
-                             % (products, "two f16 pieces" if f16 else "three bf16 pieces", products,
-                                "f16" if f16 else "bf16", ach / products,
-                                k1_bytes * layers_per_launch / (avg_ms * 1e-3) / 1e9)}
+                     "note": "achieved = SURVEY 8d's algorithmic flops -- 2 x the fp32 multiply-adds of the layers' GEMMs, "
+                             "%d per sample and layer -- / the launch duration; peak = the dense 16-bit MFMA peak of the pipe "
+                             "the kernel runs on (the same work against the fp32 matrix peak of 157.3 TFLOP/s: %.2f x).  Every "
+                             "fp32 operand is %s and %d cross products per multiply-add run on the %s matrix pipe with fp32 "
+                             "accumulation: the pipe executed %.0f TFLOP/s = %.3f of its peak.  The same launch in SURVEY 8d's "
+                             "unfused HBM bytes (3460 B/sample/layer): %.0f GB/s-equivalent of 8000"
+                             % (2 * macs, ach / 157.3, pieces, products, pipe, products * ach,
+                                products * ach / BF16_PEAK_TFLOPS, k1_bytes * layers_per_launch / (avg_ms * 1e-3) / 1e9)}
             elif path == "k7":
                 flops = 2.0 * B * H_ * dt_ * P_
                 ach = flops / (avg_ms * 1e-3) / 1e12
@@ -682,7 +800,7 @@ def main():
                     note="v_mfma_f32_32x32x16_f16 issued back to back from registers on every SIMD of this box "
                          "(tools/mfma_power_probe.hip), by operand data: with zeros the pipe reaches the spec peak, "
                          "with Gaussian operands the chip's power cap holds it to the `gaussian` figure (clock ~1.75 GHz)")
-                roofline["frac_of_sustained_ceiling"] = roofline["achieved"] / ceiling["gaussian_32x32x16"]
+                roofline["matrix_pipe"]["frac_of_sustained_ceiling"] = roofline["matrix_pipe"]["achieved"] / ceiling["gaussian_32x32x16"]
         roofline_k1 = None
         if args.path != "k1" and not args.skip_k1_roofline and world == 1:  # (N = 1 only: the other ranks are done)
             # the HBM-bound spline kernel K1 (what the fused kernels replace on this shape), measured
@@ -716,11 +834,16 @@ def main():
             "scaling": "strong" if args.batch_per_gpu is None else "weak",
             "vs_baseline": None,
             # fp32 inputs, outputs, spline arithmetic and accumulation; what the TIMED kernel multiplies in its GEMMs is said here
-            "dtype": ("f32 (conditioner GEMMs: each fp32 operand as 2 f16 pieces, 3 cross products on the f16 MFMA pipe, fp32 "
-                      "accumulate -- 22-bit operand significands; exact_engine_extra: the same step on 24-bit pieces and on fp32 GEMMs)"
-                      if (args.path == "k8" and RQ.conditioner_engine == "f16x2") else
+            "dtype": ({"f16x3": "f32 (inputs, outputs, spline arithmetic, accumulation; conditioner GEMMs: every fp32 operand carried as "
+                                "3 f16 pieces = 33 significand bits, i.e. at the reference's own fp32 operand width, 5 cross products per "
+                                "multiply-add on the f16 MFMA pipe, fp32 accumulate; other_engines_extra: the same step on 2 f16 pieces, "
+                                "on 3 bf16 pieces and on fp32 library GEMMs)",
+                       "f16x2": "f32 (conditioner GEMMs: each fp32 operand as 2 f16 pieces, 3 cross products on the f16 MFMA pipe, fp32 "
+                                "accumulate -- 22-bit operand significands)",
+                       "bf16x3": "f32 (conditioner GEMMs: each fp32 operand as 3 bf16 pieces, 6 cross products, fp32 accumulate)"}[args.engine]
+                      if args.path == "k8" else
                       "f32 (conditioner GEMMs: each fp32 operand as 3 bf16 pieces, 6 cross products, fp32 accumulate)"
-                      if args.path in ("k8", "k7b") else "f32"),
+                      if args.path == "k7b" else "f32"),
             "data": "synthetic standard-Gaussian inputs, random-init weights (seed 0)",
             "config": {"workload": "%d-layer RQ-NSF coupling flow (RandomPermutation + RQ coupling, "
                                    "ResidualNet H=128 x2 blocks), dim=64, K=8, tail_bound=3, "
@@ -730,11 +853,13 @@ def main():
                        "global_batch": total_rows, "features": D, "num_bins": K, "layers": args.layers,
                        "parallelism": "sample-sharded x%d" % world,
                        "fused_permutations": not args.no_fuse,
-                       "layer_kernel": {"k8": "K8h: ResidualNet conditioner (GEMMs on two f16 pieces per operand) + spline "
-                                              "layer in one kernel, the run of layers in one launch"
-                                              if RQ.conditioner_engine == "f16x2" else
-                                              "K8: ResidualNet conditioner (three bf16 pieces) + spline layer in one kernel, "
-                                              "the run of layers in one launch",
+                       "engine": args.engine if args.path == "k8" else None,
+                       "layer_kernel": {"k8": {"f16x3": "K8x: ResidualNet conditioner (GEMMs on three f16 pieces per operand, five "
+                                                        "products) + spline layer in one kernel, the run of layers in one launch",
+                                               "f16x2": "K8h: ResidualNet conditioner (GEMMs on two f16 pieces per operand) + spline "
+                                                        "layer in one kernel, the run of layers in one launch",
+                                               "bf16x3": "K8: ResidualNet conditioner (three bf16 pieces) + spline layer in one kernel, "
+                                                         "the run of layers in one launch"}[args.engine],
                                         "k7b": "K7b: final Linear (split-bf16 MFMA) + spline layer",
                                         "k7": "K7: final Linear (fp32 MFMA) + spline layer",
                                         "k1": "PyTorch conditioner + K1 spline layer"}[args.path]},
@@ -753,21 +878,33 @@ def main():
             result["steady_state"] = dict(steady, value=total_rows * steady["steps"] / steady["seconds"], unit="samples/s",
                                           note=">= %.1f s of back-to-back steps, same launch path as the timed region"
                                                % args.steady_seconds)
-        if exact_engines:
-            result["exact_engine_extra"] = exact_engines
+        if other_engines:
+            for e in other_engines:
+                path_e, engine_e, ms_e, lps_e = e.pop("_roofline_args")
+                if ms_e:
+                    e["roofline"] = roofline_of(path_e, ms_e, lps_e, ran=e["kernel"], engine=engine_e)
+            result["other_engines_extra"] = other_engines
         if fp64_extra is not None:
             result["fwd_inv_max_err"]["fp64_device_path"] = fp64_extra
+        if world == 1 and args.batch_per_gpu is None and not args.skip_extra:
+            try:
+                result["other_configs_extra"] = other_configs(dev, args.steps)
+            except Exception as e:  # measurement extra only
+                log("other_configs_extra skipped: %r" % (e,))
         if weak is not None:
             result["rows_65536_per_gpu_extra"] = weak
         if small is not None:
             result["small_shards_extra"] = small
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(flow_cpu, D, args.cpu_rows,
-                                                  x_consistency=None if args.skip_consistency else xs.cpu())
+                                                  x_consistency=None if args.skip_consistency else xs.cpu(),
+                                                  full_rows=0 if args.skip_extra else 65536)
             ref_c = result["cpu_baseline"].get("reference_fwd_inv_err_same_rows")
             if ref_c is not None:
                 result["fwd_inv_max_err"]["reference_fp32_same_rows"] = ref_c
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+            if "at_baseline_batch" in result["cpu_baseline"]:
+                result["speedup_vs_cpu_baseline_at_65536_rows"] = result["value"] / result["cpu_baseline"]["at_baseline_batch"]["value"]
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

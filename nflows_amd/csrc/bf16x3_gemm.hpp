@@ -102,6 +102,9 @@ __device__ __forceinline__ void activate_pieces(bf16x8& h, bf16x8& m, bf16x8& l)
 template <int ACT, int NKS>
 __device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const bf16x8 (&ph)[8], const bf16x8 (&pm)[8],
                                             const bf16x8 (&pl)[8], WeightStream& sm, int lane) {
+#ifdef NFA_BF16X3_SPLIT_ACC   // (K11: see NFA_MFMA6_SPLIT)
+    f32x16 small[4] = {{0}, {0}, {0}, {0}};
+#endif
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         stream_request(sm);
@@ -114,10 +117,18 @@ __device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const bf16x8 (&ph)
             const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(t * 3 + 0) * 64]);
             const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(t * 3 + 1) * 64]);
             const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(t * 3 + 2) * 64]);
+#ifdef NFA_BF16X3_SPLIT_ACC
+            NFA_MFMA6_SPLIT(acc[t], small[t], ah, am, al, bh, bm, bl);
+#else
             NFA_MFMA6(acc[t], ah, am, al, bh, bm, bl);
+#endif
         }
         stream_advance(sm);
     }
+#ifdef NFA_BF16X3_SPLIT_ACC
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] += small[t];
+#endif
 }
 
 // one 32-row output tile of a 128-wide layer: acc += W_tile[32 x 128] x act^T, act given as pieces
@@ -125,6 +136,9 @@ __device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const bf16x8 (&ph)
 template <bool RELU>
 __device__ __forceinline__ void gemm_tile(f32x16& acc, const bf16x8 (&ph)[8], const bf16x8 (&pm)[8],
                                           const bf16x8 (&pl)[8], WeightStream& sm, int lane) {
+#ifdef NFA_BF16X3_SPLIT_ACC
+    f32x16 small = {0};
+#endif
 #pragma unroll
     for (int hs = 0; hs < 2; ++hs) {
         stream_request(sm);
@@ -137,10 +151,17 @@ __device__ __forceinline__ void gemm_tile(f32x16& acc, const bf16x8 (&ph)[8], co
             const bf16x8 ah = __builtin_bit_cast(bf16x8, cur[(0 * 4 + k4) * 64]);
             const bf16x8 am = __builtin_bit_cast(bf16x8, cur[(1 * 4 + k4) * 64]);
             const bf16x8 al = __builtin_bit_cast(bf16x8, cur[(2 * 4 + k4) * 64]);
+#ifdef NFA_BF16X3_SPLIT_ACC
+            NFA_MFMA6_SPLIT(acc, small, ah, am, al, bh, bm, bl);
+#else
             NFA_MFMA6(acc, ah, am, al, bh, bm, bl);
+#endif
         }
         stream_advance(sm);
     }
+#ifdef NFA_BF16X3_SPLIT_ACC
+    acc += small;
+#endif
 }
 
 // accumulator tile t, registers 8*hk .. 8*hk+7  ->  pieces of k-step 2t + hk

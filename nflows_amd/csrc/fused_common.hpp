@@ -33,6 +33,18 @@
 #endif
 
 
+// NFA_MFMA6_SPLIT (round 6; K11): the leading product accumulates alone, the five small ones in `small` -- the roundings of
+// the small terms then happen at THEIR magnitude (2^-8 of the sum) and the main accumulator is rounded 8 times per 128-term dot
+// product instead of 48: measured error against float64 0.39 x the single accumulator's (rms 2.28e-8 against 5.83e-8 and the
+// sequential fp32 fma chain's 5.26e-8, profiles/r6/gemm_numerics_probe.txt); more products change nothing (9 products: 5.83e-8).
+#define NFA_MFMA6_SPLIT(acc, small, ah, am, al, bh, bm, bl)                             \
+    small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, small, 0, 0, 0);            \
+    small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, small, 0, 0, 0);            \
+    small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, small, 0, 0, 0);            \
+    small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, small, 0, 0, 0);            \
+    small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, small, 0, 0, 0);            \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0)
+
 namespace nfa {
 
 // Activation of the conditioner's residual blocks (nn/nets/resnet.py:27 `activation=F.relu`; round 4: the other

@@ -48,8 +48,8 @@ def _is_column_permutation(t):
 
 
 def _accepts_fused_permutation(t, inputs):
-    return (getattr(t, "supports_fused_permutation", False) and inputs.dim() == 2
-            and inputs.dtype == torch.float32)   # (float64 flows take the generic device path)
+    return (getattr(t, "supports_fused_permutation", False) and not getattr(t, "_user_hooks", False) and inputs.dim() == 2
+            and inputs.dtype == torch.float32)   # (float64 flows take the generic device path; a user's hooks: the reference's sequence)
 
 
 def _switch_state():
@@ -117,25 +117,58 @@ class _Run(list):
         params = flat[3]
         key = (epoch, tuple([p._version for p in params]), tuple([p.data_ptr() for p in params]))
         every = coupling.VERIFY_WEIGHTS_EVERY
-        if every and params and not (params[0].is_cuda and torch.cuda.is_current_stream_capturing()):
-            # one layer at a time, every layer once per `every` calls (no call pays for all of them)
+        de = _cache.data_epoch()
+        if self.__dict__.get("_data_seen") != de:
+            # the `.data` of a watched parameter was touched since the run last looked (or this is its first use): every
+            # layer's record is brought up to date -- ONE checksum over all parameters of the run, one synchronising
+            # comparison; layers whose contents changed under an unchanged visible key get a new `_data_salt`
+            if not coupling._capturing(params):
+                self.__dict__["_data_seen"] = de
+                self._recheck_run(flat, key, de)
+        elif every and params and not coupling._capturing(params):
+            # the periodic check: one layer at a time, every layer once per `every` calls (no call pays for all of them)
             n = self.__dict__["_verify_calls"] = self.__dict__.get("_verify_calls", 0) + 1
             stride = max(1, every // len(self))
             if n % stride == 0:
                 i = (n // stride) % len(self)
                 lo, hi = flat[4][i]
-                coupling._verify_weights_now(self[i][0], (epoch, key[1][lo:hi], key[2][lo:hi]), params[lo:hi])
-        return key
+                coupling._track_contents(self[i][0], "_contents_run", (epoch, key[1][lo:hi], key[2][lo:hi]), params[lo:hi],
+                                         periodic=False, compare_now=True)
+        return key + (tuple([c.__dict__.get("_data_salt", 0) for c, _ in self]),)
+
+    def _recheck_run(self, flat, key, de):
+        """A `.data` event (or the run's first use): per layer, contents on record under the layer's current visible key are
+        compared with the contents now -- a difference, or no such record (the key moved since: nothing to compare with),
+        advances the layer's `_data_salt`, i.e. its packs are rebuilt from the current values --, and the records are renewed."""
+        from . import coupling
+        params, bounds = flat[3], flat[4]
+        now = coupling._checksum(params)
+        verdicts, rows = [], []
+        for i, ((c, _), (lo, hi)) in enumerate(zip(self, bounds)):
+            sub = (flat[0], key[1][lo:hi], key[2][lo:hi])
+            state = c.__dict__.get("_contents_run")
+            if state is not None and state[0] == sub and state[1].shape[0] == hi - lo:
+                verdicts.append((state[1] == now[lo:hi]).all())
+                rows.append(i)
+            else:
+                c.__dict__["_data_salt"] = c.__dict__.get("_data_salt", 0) + 1
+            c.__dict__["_contents_run"] = [sub, now[lo:hi], 0, de]
+            layer_record = c.__dict__.get("_contents")      # (the layer's own record, coupling._weights_key: same event,
+            if layer_record is not None:                     #  same contents -- it must not answer it a second time)
+                layer_record[1], layer_record[3] = now[lo:hi], de
+        if rows:
+            for same, i in zip(torch.stack(verdicts).cpu().tolist(), rows):    # (the one synchronisation)
+                if not same:
+                    c = self[i][0]
+                    c.__dict__["_data_salt"] = c.__dict__.get("_data_salt", 0) + 1
 
     def verify_before_packing(self):
         """Called on every plan-cache miss, before the layers' packed weights are looked up.  A miss does not mean the
         weights changed visibly -- the first inverse call, a batch that crosses the 16-sample-tile threshold, an evicted
-        plan -- and the per-layer packs are keyed on version counters and storage pointers alone: a write through
-        `.data` since the last pack (EMA swap, dist.broadcast(p.data)) would be packed into the NEW plan from the OLD
-        blobs.  So: a layer whose key is the one its checksum was recorded under is COMPARED now (StalePackedWeights on
-        a difference); a layer with a new key (optimizer step, load_state_dict, invalidate_packed_weights: its pack is
-        rebuilt from the current parameters) gets its checksum recorded.  (Round 4 re-recorded every layer here, which
-        defeated the guard in exactly the train -> EMA swap -> sample() sequence.)"""
+        plan -- and the per-layer packs are keyed on version counters, storage pointers and the `.data` salt: a write that
+        announced itself through none of them since the last pack would be packed into the NEW plan from the OLD blobs.
+        So: a layer whose key is the one its checksum was recorded under is COMPARED now (StalePackedWeights on a
+        difference); a layer with a new key gets its checksum recorded."""
         from . import coupling
         if not coupling.VERIFY_WEIGHTS_EVERY:
             return
@@ -143,11 +176,12 @@ class _Run(list):
         if flat is None:
             return
         params = flat[3]
-        if params and params[0].is_cuda and torch.cuda.is_current_stream_capturing():
+        if coupling._capturing(params):
             return
         versions, ptrs = tuple([p._version for p in params]), tuple([p.data_ptr() for p in params])
         for (c, _), (lo, hi) in zip(self, flat[4]):
-            coupling._verify_weights_now(c, (flat[0], versions[lo:hi], ptrs[lo:hi]), params[lo:hi])
+            coupling._track_contents(c, "_contents_run", (flat[0], versions[lo:hi], ptrs[lo:hi]), params[lo:hi],
+                                     periodic=False, compare_now=True)
 
 
 def _permutation_key(p):
@@ -218,9 +252,9 @@ class CompositeTransform(Transform):
 
     @staticmethod
     def _joinable(t, features, context):
-        kind = getattr(t, "_run_kind", None)   # whole-layer kernel this layer can join a run of (None: a user's subclass
-        #                                        with its own hooks, coupling.py: _user_hooks)
-        return (kind is not None and t.unconditional_transform is None and t.features == features
+        kind = getattr(t, "_run_kind", None)   # whole-layer kernel this layer can join a run of
+        # (a user's subclass, mixin or late assignment that overrides one of the reference's hooks joins none: coupling.py: _user_hooks)
+        return (kind is not None and not t._user_hooks and t.unconditional_transform is None and t.features == features
                 and kind(context) is not None)
 
     def _watched_state(self, units, layers, after, features, context):

@@ -34,84 +34,117 @@ from .splines import rational_quadratic
 
 def _held_parameters(net):
     """[(the `_parameters` / `_buffers` dict of a leaf module, name, tensor)] of every parameter and buffer of `net`
-    (buffers: the running statistics of batch-norm layers, folded into the packed weights)."""
-    return ([(m._parameters, name, p) for m in net.modules() for name, p in m._parameters.items() if p is not None] +
-            [(m._buffers, name, b) for m in net.modules() for name, b in m._buffers.items() if b is not None])
+    (buffers: the running statistics of batch-norm layers, folded into the packed weights).  The parameters are re-classed
+    as _cache.WatchedParameter on the way: their `.data` then reports its use (writes through it reach no version counter)."""
+    params = [(m._parameters, name, p) for m in net.modules() for name, p in m._parameters.items() if p is not None]
+    for _, _, p in params:
+        _cache.watch(p)
+    return params + [(m._buffers, name, b) for m in net.modules() for name, b in m._buffers.items() if b is not None]
 
 
 class StalePackedWeights(RuntimeError):
-    """NFA_VERIFY_WEIGHTS: a conditioner's weights changed without any of the signs the packed-weight caches
-    look at (version counters, storage pointers, registrations) -- a write through `.data`, e.g.
-    `p.data.copy_(ema)` or `dist.broadcast(p.data)`.  The fused kernels would have used the OLD weights."""
+    """NFA_VERIFY_WEIGHTS: a conditioner's weights changed without any of the signs the packed-weight caches look at --
+    version counters, storage pointers, registrations, and (round 6) the `.data` of its Parameters (_cache.WatchedParameter):
+    a write into raw storage, through a view's `.data`, by a foreign kernel.  The fused kernels have been using the OLD
+    weights; `nflows_amd.invalidate_packed_weights()` after such writes is the remedy."""
 
 
-# NFA_VERIFY_WEIGHTS=N: every N-th use of a conditioner's cache key re-reads a checksum of its parameters on the
-# device (L1 and L2 norm per parameter plus the L2 norm of the parameter shifted by one -- a signed component: |p + 1|^2 =
-# |p|^2 + 2 sum(p) + n, so a sign flip shows --, four fused launches and one synchronising comparison) and raises
-# StalePackedWeights when it differs from the one taken when the key last changed visibly.  Default (round 4): every
-# 256th use, staggered over the layers -- amortised ~ 1 us per layer and call; 0 switches it off, 1 checks every call (debugging).  Skipped while
-# a stream is being captured into a HIP graph (the comparison synchronises).
+# How the packed weights follow the parameters (round 6).
+#   visible changes   in-place updates (version counters), rebound storage (data_ptr), (re)registered objects,
+#                     load_state_dict / .to() (cache epoch): part of every weight key, the packs are rebuilt.
+#   `.data`           reading or assigning the `.data` of a conditioner Parameter advances _cache.data_epoch(); the next
+#                     use of a weight key compares the parameters' CONTENTS with the checksum recorded when the key was new
+#                     (one synchronising comparison per layer, or one for a whole run) and, on a difference, advances the
+#                     layer's `_data_salt` -- part of the key: repacked from the new values, nothing raised, and no call
+#                     without such an event pays anything.
+#   everything else   NFA_VERIFY_WEIGHTS=N (default 256; 0 = off, 1 = every use): every N-th use of a key repeats the
+#                     comparison, staggered over the layers, and raises StalePackedWeights; also on every plan-cache miss of
+#                     a run (_Run.verify_before_packing).  Skipped while a stream is being captured into a HIP graph.
 VERIFY_WEIGHTS_EVERY = int(os.environ.get("NFA_VERIFY_WEIGHTS", "256") or 0)
+
+_CHECKSUM_LAYOUTS = {}
 
 
 def _checksum(params):
+    """int64 [len(params)] on the parameters' device: per parameter the sum over its elements of (bit pattern as int32) x (an
+    odd multiplier that depends on the position), modulo 2^64 -- exact, sensitive to the sign and the position of every
+    element (round 5's fp32 norms were blind to a sign flip of a small entry), NaNs included (a bit pattern like any
+    other).  fp32 parameters on one device: one concatenation, one multiply, one segmented sum; no synchronisation."""
     with torch.no_grad():
         params = [p.detach() for p in params]
         if not params:
-            return torch.zeros(0)
-        if all(p.is_floating_point() for p in params) and len({(p.device, p.dtype) for p in params}) == 1:
-            return torch.stack(list(torch._foreach_norm(params, 1)) + list(torch._foreach_norm(params, 2)) +
-                               list(torch._foreach_norm(torch._foreach_add(params, 1.0), 2)))
-        return torch.stack([torch.stack((p.double().abs().sum(), p.double().pow(2).sum(), p.double().sum())) for p in params]).reshape(-1)
+            return torch.zeros(0, dtype=torch.int64)
+        if not (all(p.dtype == torch.float32 for p in params) and len({p.device for p in params}) == 1):
+            return torch.stack([(p.double().reshape(-1).view(torch.int64) >> 7).sum().cpu() + p.numel() for p in params])
+        dev = params[0].device
+        sizes = tuple(p.numel() for p in params)
+        layout = _CHECKSUM_LAYOUTS.get((dev, sizes))
+        if layout is None:
+            if len(_CHECKSUM_LAYOUTS) > 64:
+                _CHECKSUM_LAYOUTS.clear()
+            sz = torch.tensor(sizes, device=dev)
+            seg = torch.repeat_interleave(torch.arange(len(sizes), device=dev), sz)
+            # (the position INSIDE the parameter: a parameter's checksum does not depend on what it is concatenated with)
+            at = torch.arange(sum(sizes), dtype=torch.int64, device=dev) - (torch.cumsum(sz, 0) - sz)[seg]
+            mult = ((at * 2654435761) % 2147483647) * 2 + 1
+            layout = _CHECKSUM_LAYOUTS[(dev, sizes)] = (mult, seg)
+        mult, seg = layout
+        bits = torch.cat([p.reshape(-1) for p in params]).view(torch.int32).to(torch.int64)
+        return torch.zeros(len(sizes), dtype=torch.int64, device=dev).index_add_(0, seg, bits * mult)
 
 
 def _same_checksum(a, b):
-    """equal, NaN == NaN (diverged weights are not a stale cache: the kernels then propagate NaN like the reference does)"""
-    return a.shape == b.shape and bool(((a == b) | (a.isnan() & b.isnan())).all())
+    return a.shape == b.shape and bool(torch.equal(a, b))    # (synchronises)
 
 
-def _verify_weights_now(owner, key, params, rebase=False):
-    """The run-level form (transforms/base.py: _Run.weights_fingerprint, _Run.verify_before_packing): a key the layer has
-    not been seen with (or `rebase`) records the checksum that belongs to it; a known key compares the parameters with
-    the recorded checksum NOW."""
-    state = owner.__dict__.get("_weights_checksum_run")
-    if rebase or state is None or state[0] != key:
-        owner.__dict__["_weights_checksum_run"] = (key, _checksum(params))
-        return
-    if not _same_checksum(_checksum(params), state[1]):
-        owner.__dict__.pop("_weights_checksum_run", None)
-        raise StalePackedWeights(
-            "the parameters of %s changed through a write the packed-weight caches cannot see (a write through "
-            "`.data`?): call nflows_amd.invalidate_packed_weights() after such writes" % type(owner).__name__)
+def _capturing(params):
+    return bool(params) and params[0].is_cuda and torch.cuda.is_current_stream_capturing()
 
 
-def _verify_weights(owner, key, params):
-    if params and params[0].is_cuda and torch.cuda.is_current_stream_capturing():
-        return
-    state = owner.__dict__.get("_weights_checksum")
+def _stale(owner):
+    return StalePackedWeights(
+        "the parameters of %s changed through a write the packed-weight caches cannot see (raw storage, a view's `.data`, a "
+        "foreign kernel): call nflows_amd.invalidate_packed_weights() after such writes" % type(owner).__name__)
+
+
+def _track_contents(owner, slot, key, params, periodic=True, compare_now=False):
+    """The record `owner.__dict__[slot]` = [visible key, checksum of the contents when the key was new, use count, data epoch]
+    and what is done with it: a new key records (no synchronisation); a `.data` event since the record compares and, on a
+    difference, advances `_data_salt` (repack, no exception); `periodic` counts uses and compares every
+    NFA_VERIFY_WEIGHTS-th (`compare_now`: at once) -- a difference there is a write nothing announced: StalePackedWeights."""
+    de = _cache.data_epoch()
+    state = owner.__dict__.get(slot)
     if state is None or state[0] != key:
         # (the count starts at a per-layer offset: the layers of a flow are used once per call each, and 32 synchronising
-        #  comparisons landing in ONE call were a 3 ms spike every 256th step -- 0.14 ms on bench.py's 8 192-row figure)
-        owner.__dict__["_weights_checksum"] = [key, _checksum(params), (id(owner) >> 6) % VERIFY_WEIGHTS_EVERY]
+        #  comparisons landing in ONE call were a 3 ms spike every 256th step)
+        owner.__dict__[slot] = [key, _checksum(params), (id(owner) >> 6) % max(1, VERIFY_WEIGHTS_EVERY), de]
         return
-    state[2] += 1
-    if state[2] % VERIFY_WEIGHTS_EVERY == 0 and not _same_checksum(_checksum(params), state[1]):
-        owner.__dict__.pop("_weights_checksum", None)
-        raise StalePackedWeights(
-            "the parameters of %s changed through a write the packed-weight caches cannot see (a write through "
-            "`.data`?): call nflows_amd.invalidate_packed_weights() after such writes" % type(owner).__name__)
+    if state[3] != de:
+        if _capturing(params):
+            return
+        state[3] = de
+        now = _checksum(params)
+        if not _same_checksum(now, state[1]):
+            state[1] = now
+            owner.__dict__["_data_salt"] = owner.__dict__.get("_data_salt", 0) + 1
+        return
+    if not VERIFY_WEIGHTS_EVERY or _capturing(params):
+        return
+    if periodic:
+        state[2] += 1
+    if (compare_now or (periodic and state[2] % VERIFY_WEIGHTS_EVERY == 0)) and not _same_checksum(_checksum(params), state[1]):
+        owner.__dict__.pop(slot, None)
+        raise _stale(owner)
 
 
 def _weights_key(owner, net):
-    """Cheap fingerprint of a conditioner's weights for the packed-weight caches: storage pointers and version
-    counters of its parameters, read from a list made once per cache epoch (walking `net.parameters()` costs ~10 us per call and
-    layer: a millisecond per `log_prob` of a 32-layer flow).  In-place updates advance the counters; moves,
-    `load_state_dict` and (re)registered Parameter objects advance the epoch (_cache.py).  Swaps that bypass the
-    registration hooks -- `torch.func.functional_call`, `stateless._reparametrize_module`, a direct
-    `module._parameters[name] = other` -- are caught by checking on every call that each held object still IS
-    the entry of its module's `_parameters` dict (a dict lookup and an identity test per parameter).  What no key
-    can see is a write through `.data` into the same storage: NFA_VERIFY_WEIGHTS (above; on by default with a period of
-    256 uses) turns that into an exception, `nflows_amd.invalidate_packed_weights()` the remedy."""
+    """Fingerprint of a conditioner's weights for the packed-weight caches: storage pointers and version counters of its
+    parameters, read from a list made once per cache epoch (walking `net.parameters()` costs ~10 us per call and layer: a
+    millisecond per `log_prob` of a 32-layer flow), and the layer's `_data_salt` (see above: writes through `.data`).
+    In-place updates advance the counters; moves, `load_state_dict` and (re)registered Parameter objects advance the epoch
+    (_cache.py).  Swaps that bypass the registration hooks -- `torch.func.functional_call`,
+    `stateless._reparametrize_module`, a direct `module._parameters[name] = other` -- are caught by checking on every
+    call that each held object still IS the entry of its module's `_parameters` dict."""
     epoch = _cache.epoch()
     held = owner.__dict__.get("_weights_list")
     if held is None or held[0] != epoch or held[1] is not net or not _cache.HOOKED:
@@ -125,9 +158,8 @@ def _weights_key(owner, net):
                 break
     # (data_ptr as well: `p.data = other` rebinds the storage without touching the counter)
     key = (epoch,) + tuple([(p.data_ptr(), p._version) for _, _, p in held[2]])
-    if VERIFY_WEIGHTS_EVERY:
-        _verify_weights(owner, key, [p for _, _, p in held[2]])
-    return key
+    _track_contents(owner, "_contents", key, [p for _, _, p in held[2]])
+    return key + (owner.__dict__.get("_data_salt", 0),)
 
 
 class CouplingTransform(Transform):
@@ -144,14 +176,24 @@ class CouplingTransform(Transform):
     # takes `_reference_sequence`: the reference's own order of calls (coupling.py:73-130) on device tensors, its hooks
     # called where the reference calls them; it joins no fused run and takes no fused permutation.
     _REFERENCE_HOOKS = ("_coupling_transform_forward", "_coupling_transform_inverse", "_piecewise_cdf", "_scale_and_shift")
-    _user_hooks = False
+    _HOOK_VERDICTS = {}
 
-    def __init_subclass__(cls, **kwargs):
-        super().__init_subclass__(**kwargs)
-        if cls.__module__ != __name__ and any(h in cls.__dict__ for h in CouplingTransform._REFERENCE_HOOKS):
-            cls._user_hooks = True
-            cls.supports_fused_permutation = False
-            cls._run_kind = None             # (transforms/base.py: _joinable)
+    @property
+    def _user_hooks(self):
+        """True when one of the reference's extension points resolves -- through the MRO: a mixin counts, and so does a
+        function assigned to the class or the instance after its creation (round 5 looked at the new class's own
+        `__dict__` at class-creation time only) -- to a function defined outside this module.  Four attribute lookups per
+        call; the verdict is kept per class and per set of resolved functions."""
+        cls = type(self)
+        hooks = CouplingTransform._REFERENCE_HOOKS
+        if any(h in self.__dict__ for h in hooks):
+            return True
+        fns = tuple([getattr(cls, h, None) for h in hooks])
+        held = CouplingTransform._HOOK_VERDICTS.get(cls)
+        if held is None or any(a is not b for a, b in zip(held[0], fns)):
+            mine = any(f is not None and getattr(f, "__module__", __name__) != __name__ for f in fns)
+            held = CouplingTransform._HOOK_VERDICTS[cls] = (fns, mine)
+        return held[1]
 
     def __init__(self, mask, transform_net_create_fn, unconditional_transform=None):
         mask = torch.as_tensor(mask)

@@ -11,6 +11,12 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "asm: compiles every translation unit of the library to assembly and inspects it (minutes of "
+                                       "hipcc): run by __graft_entry__.build() and with `-m asm` (or NFA_ASM_TESTS=1), skipped otherwise")
+
+
+def _asm_selected(config):
+    return os.environ.get("NFA_ASM_TESTS", "0") == "1" or "asm" in (config.getoption("-m") or "")
 
 
 def _has_gpu():
@@ -22,6 +28,11 @@ def _has_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
+    if not _asm_selected(config):
+        skip_asm = pytest.mark.skip(reason="disassembly checks: run by __graft_entry__.build(), `-m asm` or NFA_ASM_TESTS=1")
+        for item in items:
+            if "asm" in item.keywords:
+                item.add_marker(skip_asm)
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason="no HIP device in this container")

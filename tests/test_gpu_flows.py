@@ -793,28 +793,69 @@ def test_functional_call_sees_the_supplied_weights():
     assert not torch.equal(z1, z0)
 
 
-def test_verify_weights_mode_on_the_device(monkeypatch):
-    """The whole-layer kernels read packed copies of the conditioner weights: an EMA-style `p.data.copy_()`
-    leaves them stale (documented in nflows_amd/_cache.py).  NFA_VERIFY_WEIGHTS turns the silent wrong answer
-    into StalePackedWeights; invalidate_packed_weights() then gives the result of the new weights."""
+@pytest.mark.parametrize("engine", ["f16x2", "f16x3", "bf16x3", "k11"])
+def test_a_write_through_data_is_served_on_the_next_call(monkeypatch, engine):
+    """The whole-layer kernels read packed copies of the conditioner weights; the reference reads
+    `self.transform_net`'s parameters on every call (coupling.py:85).  A write through `.data` (EMA swap,
+    `dist.broadcast(p.data)`) advances no version counter -- until round 5 the kernels then kept the OLD packs until a
+    periodic checksum raised, up to 255 evaluations later.  Round 6: with NFA_VERIFY_WEIGHTS at its DEFAULT, the very next
+    `log_prob` after `p.data.mul_(2)` gives the new weights' result -- bit for bit what a fresh copy of the flow (fresh
+    packs) gives --, nothing is raised, and calls without such a write keep their cached plan."""
     import copy
     import nflows_amd
     from nflows_amd import configs
     from nflows_amd.transforms import coupling as C
-    flow = configs.rq_nsf_flow(num_layers=4, features=64, num_bins=8, hidden_features=128, seed=0).to(DEV).eval()
-    x = torch.randn(256, 64, generator=torch.Generator().manual_seed(5)).to(DEV)
-    monkeypatch.setattr(C, "VERIFY_WEIGHTS_EVERY", 1)
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    assert C.VERIFY_WEIGHTS_EVERY == int(os.environ.get("NFA_VERIFY_WEIGHTS", "256") or 0)
+    if engine == "k11":
+        flow = configs.affine_coupling_flow(6, 32, (128, 128), seed=0).to(DEV).eval()
+        D = 32
+    else:
+        monkeypatch.setattr(RQ, "conditioner_engine", engine)
+        flow = configs.rq_nsf_flow(num_layers=6, features=64, num_bins=8, hidden_features=128, seed=0).to(DEV).eval()
+        D = 64
+    x = torch.randn(1024, D, generator=torch.Generator().manual_seed(5)).to(DEV)
+    T = flow._transform
     with torch.no_grad():
         lp0 = flow.log_prob(x)
         assert torch.equal(flow.log_prob(x), lp0)
-        for p in flow.parameters():
-            p.data.mul_(1.05)
+        plans = dict(T.__dict__.get("_run_plans", {}))
+        params = list(flow.parameters())
+        params[-2].data.mul_(2.0)                                   # one layer's final weight, through `.data`
+        lp1 = flow.log_prob(x)                                      # ... and IMMEDIATELY the new weights' result
+        fresh = copy.deepcopy(flow)
+        assert torch.equal(fresh.log_prob(x), lp1) and not torch.equal(lp1, lp0)
+        assert torch.equal(flow.log_prob(x), lp1)
+        # an EMA-style swap of every parameter
+        shadow = [p.detach().clone() * 0.97 for p in params]
+        for p, s_ in zip(params, shadow):
+            p.data.copy_(s_)
+        lp2 = flow.log_prob(x)
+        assert torch.equal(copy.deepcopy(flow).log_prob(x), lp2) and not torch.equal(lp2, lp1)
+        # the inverse pass plans its own run: the same contents
+        z, _ = flow._transform(x)
+        params[3].data.add_(0.01)
+        xr, _ = flow._transform.inverse(z)
+        xr_fresh, _ = copy.deepcopy(flow)._transform.inverse(z)
+        assert torch.equal(xr, xr_fresh)
+        # reading `.data` (logging a norm) compares contents once and changes nothing
+        before = {k: v for k, v in T.__dict__.get("_run_plans", {}).items()}
+        _ = float(sum(p.data.abs().sum() for p in params))
+        lp3 = flow.log_prob(x)
+        after = T.__dict__.get("_run_plans", {})
+        assert all(after.get(k) is v for k, v in before.items() if k in after) and torch.isfinite(lp3).all()
+        # a write announced by nothing (raw storage) is what NFA_VERIFY_WEIGHTS remains for
+        monkeypatch.setattr(C, "VERIFY_WEIGHTS_EVERY", 1)
+        flow.log_prob(x)
+        torch._C.TensorBase.data.__get__(params[-2]).mul_(1.05)
         with pytest.raises(C.StalePackedWeights):
-            flow.log_prob(x)
+            for _ in range(3):
+                flow.log_prob(x)
         nflows_amd.invalidate_packed_weights()
-        lp1 = flow.log_prob(x)
-        twin = copy.deepcopy(flow)
-        assert torch.equal(twin.log_prob(x), lp1) and not torch.equal(lp1, lp0)
+        lp4 = flow.log_prob(x)
+        assert torch.equal(copy.deepcopy(flow).log_prob(x), lp4)
+    nflows_amd.check_status()
+    del plans
 
 
 def test_f16_engine_leaves_non_finite_weights_to_the_exact_kernel(monkeypatch):

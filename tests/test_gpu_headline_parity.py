@@ -76,6 +76,10 @@ def compare(config, what, got, ref32, truth, tol, max_factor=FACTOR, q_factor=FA
         if k == "max" and max_count is not None:
             assert over <= max_count, ("%s %s: %d elements with an error above 4 x the reference fp32's maximum %.3e (allowed: %d)"
                                        % (config, what, over, e_ref["max"], max_count))
+            # (the few elements the count rule lets through are still bounded -- an isolated O(1) error, one
+            #  wrong bin or one stale lane, is not "an element above 4 x once in a while")
+            assert e_got["max"] <= 64.0 * e_ref["max"] + floor, (
+                "%s %s: max error vs float64 %.3e exceeds 64 x the reference fp32's %.3e" % (config, what, e_got["max"], e_ref["max"]))
             continue
         bound = (max_factor if k == "max" else q_factor if k == "q999" else FACTOR) * e_ref[k] + (floor if k == "max" else 0.0)
         assert e_got[k] <= bound, (

@@ -84,11 +84,12 @@ def test_reference_realnvp_runs_in_one_launch(golden_dir, case):
             assert float(got.abs().max()) == 0.0
             continue
         scale = 1 + np.abs(o[k + "64"]).max()
-        # (the additive flow has no scale and no logarithm: its whole error is the rounding of the conditioners' GEMM sums,
-        #  and there the bf16 x 3 engine -- six of the nine piece products -- measures 2.3 x hipBLASLt's fp32 at the
-        #  99.9 % quantile, 2.6e-6 against 1.1e-6 on values up to 5: held to 3 x; every other case to the usual 2 x)
+        # (the additive flow has no scale and no logarithm: its whole error is the rounding of the conditioners' GEMM sums.
+        #  Round 5 held it to 3 x -- one accumulator for all six piece products measured 2.4 x the reference's error --;
+        #  round 6: K11 keeps the leading product in an accumulator of its own (NFA_MFMA6_SPLIT, csrc/fused_common.hpp) and every
+        #  case is back under the usual 2 x)
         figures[what] = assert_error_ratio(got.cpu().numpy(), o[k + "32"], o[k + "64"], "%s %s" % (case, what),
-                                           factor=3.0 if additive else 2.0,
+                                           factor=2.0,
                                            max_factor=4.0, max_floor=3e-6 * scale * (d if "lad" in what else 1))
     _report({"config": "realnvp_%s" % case, "kernel": ran, "rows": ROWS,
              "mean_error_ratio": {k: v["got"]["mean"] / max(v["reference"]["mean"], 1e-30) for k, v in figures.items() if v},

@@ -209,7 +209,7 @@ with torch.no_grad():
     rows.append("| K5d `rqs_elementwise_f64_kernel` | RQ functional in float64, 2.1 M elements, K=8 | %.1f | %.0f GB/s (the correctness path) |"
                 % ((lambda u: (u, 8 * N * (P + 3) / u / 1e3))(timeit(lambda: NA.check(lib.nfa_rqs_elementwise_f64(
                     NA.ptr(x64), NA.ptr(uw64), K, NA.ptr(uh64), K, NA.ptr(ud64), K - 1, K - 1, NA.ptr(y64), NA.ptr(l64),
-                    NA.ptr(ops._status_word(x64.device)), N, ctypes.byref(s64), 0, NA.stream_handle(x64.device)))))))
+                    None, NA.ptr(ops._status_word(x64.device)), N, ctypes.byref(s64), 0, NA.stream_handle(x64.device)))))))
     gy64, gl64 = gy1.double(), gl1.double()
     gx64, guw64, guh64, gud64 = torch.empty_like(x64), torch.empty_like(uw64), torch.empty_like(uh64), torch.empty_like(ud64)
     rows.append("| K5d-backward `rqs_elementwise_backward_f64_kernel` | its gradient, same elements | %.1f | %.0f GB/s |"

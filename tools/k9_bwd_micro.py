@@ -78,7 +78,7 @@ with torch.no_grad():
     y, lad = torch.empty_like(x64), torch.empty_like(x64)
     status = ops._status_word(torch.device(dev))
     report("K5d float64 functional, K=8", timeit(lambda: NA.check(lib.nfa_rqs_elementwise_f64(
-        NA.ptr(x64), NA.ptr(uw), K, NA.ptr(uh), K, NA.ptr(ud), K - 1, K - 1, NA.ptr(y), NA.ptr(lad), NA.ptr(status), N,
+        NA.ptr(x64), NA.ptr(uw), K, NA.ptr(uh), K, NA.ptr(ud), K - 1, K - 1, NA.ptr(y), NA.ptr(lad), None, NA.ptr(status), N,
         ctypes.byref(spec), 0, S()))), 8 * N * (3 * K - 1 + 3))
     gy64, gl64 = gy.double(), gl.double()
     gx64, guw, guh, gud = torch.empty_like(x64), torch.empty_like(uw), torch.empty_like(uh), torch.empty_like(ud)
