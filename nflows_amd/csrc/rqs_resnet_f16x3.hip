@@ -251,24 +251,32 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16x3_kernel(const Args 
             //      registers) survive the first Linear for the skip connection; u (64 accumulators) turns into the
             //      relu(u) pieces tile by tile; the skip is added into the second Linear's accumulators tile by tile.
             for (int blk = 0; blk < a.num_blocks; ++blk) {
+                // Register budget (what keeps this kernel out of scratch: K8's order -- u into pieces FIRST, then the skip
+                // connection -- holds the pieces of h, the pieces of relu(u) and the second Linear's accumulators at the same
+                // time, 96 + 96 + 64 registers, and spilled 74 x the kernel's algorithmic bytes through HBM, profiles/r6):
+                //   first Linear    pieces of h (96) + u (64)
+                //   skip            v = b_1 + T h from the pieces, which die tile by tile: u (64) + v (64) + at most 96
+                //   u -> pieces     relu(u) / T into q (96), u dies tile by tile: v (64) + q + what is left of u
+                //   second Linear   v (64) + q (96)
+                f32x16 v[4];
                 Pieces q[8];
                 {
                     f32x16 u[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) load_bias_tile(u[t], bias + t * 32);
                     gemm_kmajor<true, 8>(u, p, sm, lane);
+                    const float t1 = sc[3];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        load_bias_tile(v[t], bias + 128 + t * 32);
+                        add_pieces(v[t], 0, p[2 * t], t1);
+                        add_pieces(v[t], 8, p[2 * t + 1], t1);
+                    }
                     const float inv_t = sc[0];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) tile_to_pieces<true>(u[t], inv_t, q[2 * t], q[2 * t + 1]);
                 }
-                f32x16 v[4];
-                const float t1 = sc[3], inv_t1 = sc[2];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    load_bias_tile(v[t], bias + 128 + t * 32);
-                    add_pieces(v[t], 0, p[2 * t], t1);
-                    add_pieces(v[t], 8, p[2 * t + 1], t1);
-                }
+                const float inv_t1 = sc[2];
                 gemm_kmajor<false, 8>(v, q, sm, lane);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) tile_to_pieces<false>(v[t], inv_t1, p[2 * t], p[2 * t + 1]);
