@@ -348,19 +348,29 @@ int nfa_rqs_flow_resnet_f16x2_f32(const float *inputs, const void *stream_packed
 
 /*
  * K8x (ABI 12): the same run of whole coupling layers with the conditioner's GEMMs on the f16 matrix pipe from THREE f16
- * pieces per fp32 operand -- x s = hi + lo + r (s a power of two), 33 significand bits: every fp32 operand is carried
- * EXACTLY while its last piece stays above f16's smallest subnormal, i.e. at the reference's own operand width
- * (nn/nets/resnet.py:92-100: F.linear on fp32) -- and five cross products per multiply-add (hi hi, hi lo, lo hi, hi r,
- * r hi; dropped: lo lo and below, <= 2^-24 relative): 5/6 of K8's matrix work.  Replaces the same reference code as K8
+ * pieces per fp32 operand -- x s = hi + lo + r' 2^-8 (s a power of two; the last piece kept x 2^8), 33 significand bits:
+ * every fp32 operand is carried EXACTLY while its last piece stays above f16's smallest subnormal, i.e. at the reference's
+ * own operand width (nn/nets/resnet.py:92-100: F.linear on fp32).  Products per multiply-add: hi hi, hi lo, lo hi as three
+ * v_mfma_f32_32x32x16_f16 per k-step; hi r and r hi -- 2^-22-level terms: a last piece is one bit, its partner needs a few --
+ * as ONE v_mfma_scale_f32_32x32x64_f8f6f4 (bf8 x bf8, block scale 2^-8) per two k-steps; dropped: lo lo and below
+ * (<= 2^-24 relative).  4 f16-MFMA times per k-step and tile against K8's 6.  Replaces the same reference code as K8
  * (coupling.py:73-130, :549-582, nn/nets/resnet.py:39-52, :92-100, transforms/base.py:45-52).
- *   weights_packed f16, [stages][768 x 8]: K8's 12 KB stages, stage order, element and row rules (above), the three
- *                  pieces being (hi, lo, r) of W x T -- T a power of two per GEMM, max |w T| in [2^13, 2^14); the final
- *                  layer's width / height rows pre-divided by sqrt(hidden_features) before the scale is chosen.
- *   bias_packed    K8's order; initial_layer's biases x S T_0, every other GEMM's x S T (its own T), S = act_scale.
+ *   weights_packed raw bytes (declared f16), [stages][12 KB]: K8's stage COUNT per layer and its column / row rules (above);
+ *                  a stage holds twelve 1 KB fragments of [64 lanes] x 16 B, lane l = 32 (lane-half) + row.  With W' = W x T
+ *                  (T a power of two per GEMM, max |w T| in [2^13, 2^14); the final layer's width / height rows pre-divided
+ *                  by sqrt(hidden_features) before T is chosen), H / L = the f16 pieces hi / lo of the lane's 8 values of a
+ *                  k-step, X = the lane's 32 bf8 (OCP e5m2) bytes of a PAIR of k-steps ks0, ks1:
+ *                  [bf8(hi) ks0 | bf8(256 r) ks0 | bf8(hi) ks1 | bf8(256 r) ks1], r = w T - hi - lo, split into X lo
+ *                  (bytes 0 .. 15) and X hi (16 .. 31):
+ *                    initial_layer and the blocks' Linears (k-major): per pair of k-steps TWO stages -- output tiles 0, 1 and
+ *                    tiles 2, 3 --, each [2 tiles][H ks0, L ks0, H ks1, L ks1, X lo, X hi];
+ *                    final_layer (tile-major): per 32-row tile two stages of four k-steps each,
+ *                    [H0 .. H3][L0 .. L3][X01 lo, X01 hi, X23 lo, X23 hi].
+ *   bias_packed    K8's order; every GEMM's biases x S T (its own T), S = act_scale.
  *   scales         float [num_layers][2 + 2 num_blocks][2]: per GEMM in execution order {1 / T, T}; the final layer's
  *                  pair is {kappa = 1 / (S T), S T}: the spline evaluation reads logits = accumulators x kappa.
  *   act_scale      S, a power of two: the scale at which activations (identity features included) are split into
- *                  pieces.  A value keeps all 24 bits while |v S| >= 2^-1; below, its absolute error is <= 2^-25 / S;
+ *                  pieces.  A value keeps all 24 bits while |v S| >= 2^-9; below, its absolute error is <= 2^-33 / S;
  *                  |v S| >= 65520 overflows and poisons the row block (next line).
  *   redo_blocks    as for nfa_rqs_flow_resnet_f16x2_f32: 1 = the 128-row block produced a non-finite value and
  *                  nothing of it was written; run nfa_rqs_flow_resnet_redo_f32 (K8's blobs) behind it.

@@ -1,18 +1,29 @@
 // The split-f16 GEMM machinery of K8x (rqs_resnet_f16x3.hip): every fp32 operand as THREE f16 pieces
 //
-//   x s = hi + lo + r,   hi = RN16(x s),  lo = RN16(x s - hi),  r = RN16(x s - hi - lo)      (s: a power of two)
+//   x s = hi + lo + r' 2^-8,   hi = RN16(x s),  lo = RN16(x s - hi),  r' = RN16((x s - hi - lo) 2^8)      (s: a power of two)
 //
-// 11 + 11 + 11 significand bits with a sign each: the three pieces hold ANY fp32 value exactly while the last one
-// stays above f16's smallest subnormal (2^-24), i.e. for |x s| >= 2^-2; below that the absolute error is <= 2^-25
-// (see rqs_resnet_f16x3.hip for the scales).  Five v_mfma_f32_32x32x16_f16 per k-step and tile:
+// 11 + 11 + 11 significand bits with a sign each: the three pieces hold ANY fp32 value exactly while the last one stays
+// above f16's smallest subnormal (2^-24), i.e. -- the last piece being kept at 2^8 times its value -- for |x s| >= 2^-9;
+// below that the absolute error is <= 2^-33 (see rqs_resnet_f16x3.hip for the scales).  The product of two such operands,
 //
 //   x w = hi_x hi_w + (hi_x lo_w + lo_x hi_w) + (hi_x r_w + r_x hi_w) + [lo_x lo_w + ...]
 //          1            2^-11                    2^-22                   dropped: <= 2^-22 x 2^-2 |x w|  (lo lo; rms 2^-24.6)
 //
-// against the six bf16 products of the three-piece bf16 scheme (bf16x3_gemm.hpp): the same stage format ([4 tiles]
-// [3 pieces][64 lanes] x 16 bytes k-major, [3 pieces][4 k-steps][64 lanes] tile-major: the LDS-DMA ring, its counted
-// waits and its barriers are bf16x3_gemm.hpp's), 5/6 of the matrix-pipe time, and a piece conversion on
-// v_fma_mix*_f16 (seven instructions per pair of values where the bf16 split takes eleven).
+// runs as THREE v_mfma_f32_32x32x16_f16 per k-step and tile (hi hi, hi lo, lo hi) plus ONE v_mfma_scale_f32_32x32x64_f8f6f4
+// per TWO k-steps and tile for the two 2^-22-level products: a last piece is a single bit (or zero) and its partner only
+// has to be right to a few bits, so both go to the bf8 (e5m2: f16's exponent range, three significand bits) form of the
+// instruction, which moves four times the k-range per instruction at half the issue rate per k (64.1 cycles for K = 64
+// against 32.1 for K = 16: profiles/r6/mx_probe.txt) -- the hi factor truncated to bf8 costs <= 2^-3 of a 2^-22-level
+// term, below the dropped lo lo product; the instruction's block scale (e8m0: 2^-8 on the A side) takes the last pieces'
+// 2^8 out again.  Per k-step and tile: 3 + 1/2 x 2 = 4 f16-MFMA times where the five-product form of this kernel's first
+// build took 5 and the three-piece bf16 scheme (bf16x3_gemm.hpp) takes 6.
+// A bf8 operand of a lane (32 bytes, two k-steps ks0, ks1; the lane's eight k values each):
+//   A (weights)      [bf8(hi_w) ks0 | bf8(r'_w) ks0 | bf8(hi_w) ks1 | bf8(r'_w) ks1]     packed by the host
+//   B (activations)  [bf8(r'_x) ks0 | bf8(hi_x) ks0 | bf8(r'_x) ks1 | bf8(hi_x) ks1]     the high bytes of the f16 pieces
+// (which k the hardware gives byte e of lane-half h is immaterial: A and B use the same map.)
+// The LDS-DMA ring, its counted waits and its barriers are bf16x3_gemm.hpp's; a 12 KB stage holds twelve 1 KB fragments
+// ([64 lanes] x 16 B): k-major stages cover TWO k-steps of TWO output tiles, [2 tiles][H0, L0, H1, L1, X lo, X hi]; a
+// stage of the tile-major final layer covers four k-steps of its tile, [H0..H3][L0..L3][X01 lo, X01 hi, X23 lo, X23 hi].
 #pragma once
 
 #include "bf16x3_gemm.hpp"
@@ -20,37 +31,25 @@
 namespace nfa {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 namespace k8x {
 
-// Order of the five products: grouped by their SECOND operand (the activation pieces: r, lo, hi, hi, hi).  The matrix
-// pipe's energy depends on how often srcB changes between consecutive instructions (fused_common.hpp, round 4), a new
-// srcA costs nothing; within a k-step the order of the additions is immaterial to the result's error (the accumulator
-// already holds the sum of the earlier k-steps).
-#ifdef NFA_ABL_NO_MFMA5   // (measurement builds)
-#define NFA_MFMA5(acc, ah, al, ar, bh, bl, br) asm volatile("" :: "v"(ah), "v"(al), "v"(ar), "v"(bh), "v"(bl), "v"(br))
+constexpr int kScaleA = 119, kScaleB = 127;   // e8m0 block scales of the bf8 instruction: 2^-8 (the last pieces' 2^8), 1
+
+#ifdef NFA_ABL_NO_MFMA   // (measurement builds)
+#define NFA_K8X_F16(a, b, c) (c)
+#define NFA_K8X_BF8(a, b, c) (c)
 #else
-#define NFA_MFMA5(acc, ah, al, ar, bh, bl, br)                                       \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, br, acc, 0, 0, 0);              \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);              \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar, bh, acc, 0, 0, 0);              \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);              \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0)
+#define NFA_K8X_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define NFA_K8X_BF8(a, b, c) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 1, 1, 0, kScaleA, 0, kScaleB)
 #endif
 
-// the pieces of a k-step: 8 values per lane and piece = one register quad each
+// the pieces of a k-step: 8 values per lane and piece = one register quad each (r: the last piece x 2^8)
 struct Pieces {
     uvec4 h, l, r;
 };
 
-// two fp32 values x `scale` (a power of two) -> packed f16 pairs of the three pieces.
-//   hi = RN16(v s)                         v_fma_mixlo / mixhi_f16: fp32 fma, result rounded to f16
-//   t  = v s - hi                          v_fma_mix_f32 with the f16 `hi` as negated addend: exact (<= 13 bits)
-//   lo = RN16(t)
-//   r  = RN16(t - lo)                      exact in fp32; one bit (or zero) in f16 while it is >= 2^-24
-// |v s| >= 65520 gives hi = inf, t = -inf, lo = -inf, r = NaN: the overflow poisons every sum it enters, the row
-// block is flagged and redone by the exact kernel.  (One asm block: hipcc puts an `s_nop 0` between two adjacent asm
-// statements; early-clobber everywhere: every output is written before the last input is read.)
 // The conversions are `asm volatile`: a plain asm statement is free to move, and hipcc's scheduler moved these across the
 // stream's (volatile) waits and barriers to right behind the MFMAs whose accumulators they read -- instructions inside an
 // asm statement are invisible to the hazard recogniser, which therefore pads nothing between an MFMA and an asm block
@@ -58,8 +57,17 @@ struct Pieces {
 // bit-reproducible; found by tests/test_gpu_logits.py, round 6).  Volatile keeps them in program order behind the GEMM's
 // last barrier, and tile_to_pieces puts the matrix pipe's write-back distance (11 wait states behind an 8-pass MFMA)
 // in front of the first block that reads a tile.  NFA_K8X_NO_ASM (measurement builds): the same arithmetic in C++.
-#define NFA_K8X_PRE ""
 #define NFA_K8X_ASM asm volatile
+
+// two fp32 values x `scale` (a power of two) -> packed f16 pairs of the three pieces.
+//   hi = RN16(v s)                         v_fma_mixlo / mixhi_f16: fp32 fma, result rounded to f16
+//   t  = v s - hi                          v_fma_mix_f32 with the f16 `hi` as negated addend: exact (<= 13 bits)
+//   lo = RN16(t)
+//   d  = t - lo                            exact in fp32
+//   r' = RN16(256 d)                       one bit (or zero) where lo is a normal f16; all of d's bits while 256 d >= 2^-24
+// |v s| >= 65520 gives hi = inf, t = -inf, lo = -inf, d = NaN: the overflow poisons every sum it enters, the row block is
+// flagged and redone by the exact kernel.  (One asm block: hipcc puts an `s_nop 0` between two adjacent asm statements;
+// early-clobber everywhere: every output is written before the last input is read.)
 __device__ __forceinline__ void split3_scaled(float v0, float v1, float scale, unsigned& hi, unsigned& lo, unsigned& rr) {
 #if defined(NFA_K8X_NO_ASM)
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -67,47 +75,49 @@ __device__ __forceinline__ void split3_scaled(float v0, float v1, float scale, u
     const h2 h = {(_Float16)x0, (_Float16)x1};
     const float t0 = x0 - (float)h[0], t1 = x1 - (float)h[1];
     const h2 l = {(_Float16)t0, (_Float16)t1};
-    const h2 r = {(_Float16)(t0 - (float)l[0]), (_Float16)(t1 - (float)l[1])};
+    const h2 r = {(_Float16)((t0 - (float)l[0]) * 256.0f), (_Float16)((t1 - (float)l[1]) * 256.0f)};
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
     rr = __builtin_bit_cast(unsigned, r);
 #else
     unsigned h, l, r;
     float t0, t1;
-    NFA_K8X_ASM(NFA_K8X_PRE
+    NFA_K8X_ASM(
         "v_fma_mixlo_f16 %0, %5, %7, 0 op_sel_hi:[0,0,0]\n\t"
         "v_fma_mixhi_f16 %0, %6, %7, 0 op_sel_hi:[0,0,0]\n\t"
         "v_fma_mix_f32 %3, %5, %7, -%0 op_sel_hi:[0,0,1]\n\t"
         "v_fma_mix_f32 %4, %6, %7, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
         "v_fma_mixlo_f16 %1, %3, 1.0, 0 op_sel_hi:[0,0,0]\n\t"
         "v_fma_mixhi_f16 %1, %4, 1.0, 0 op_sel_hi:[0,0,0]\n\t"
-        "v_fma_mixlo_f16 %2, %3, 1.0, -%1 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %2, %4, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        "v_fma_mix_f32 %3, %3, 1.0, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %4, %4, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %2, %3, %8, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %4, %8, 0 op_sel_hi:[0,0,0]"
         : "=&v"(h), "=&v"(l), "=&v"(r), "=&v"(t0), "=&v"(t1)
-        : "v"(v0), "v"(v1), "v"(scale));
+        : "v"(v0), "v"(v1), "v"(scale), "s"(256.0f));
     hi = h;
     lo = l;
     rr = r;
 #endif
 }
 
-// the fp32 value of a piece triple (exact: hi + lo has at most 23 bits, + r at most 24) times `mul`, plus `add`:
-// the skip connection, acc = bias + T x h
+// the fp32 value of a piece triple (exact: hi + lo has at most 23 bits, + r' 2^-8 at most 24) times `mul`, plus what the
+// accumulators hold: the skip connection, acc = bias + T x h
 __device__ __forceinline__ void pieces_fma2(unsigned h, unsigned l, unsigned r, float mul, float& acc0, float& acc1) {
     float t0, t1;
 #if defined(NFA_K8X_NO_ASM)
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const h2 hh = __builtin_bit_cast(h2, h), ll = __builtin_bit_cast(h2, l), rr = __builtin_bit_cast(h2, r);
-    t0 = ((float)hh[0] + (float)ll[0]) + (float)rr[0];
-    t1 = ((float)hh[1] + (float)ll[1]) + (float)rr[1];
+    t0 = ((float)hh[0] + (float)ll[0]) + (float)rr[0] * 0.00390625f;
+    t1 = ((float)hh[1] + (float)ll[1]) + (float)rr[1] * 0.00390625f;
 #else
-    NFA_K8X_ASM(NFA_K8X_PRE
+    NFA_K8X_ASM(
         "v_fma_mix_f32 %0, %2, 1.0, %3 op_sel_hi:[1,0,1]\n\t"
         "v_fma_mix_f32 %1, %2, 1.0, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]\n\t"
-        "v_fma_mix_f32 %0, %4, 1.0, %0 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %1, %4, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        "v_fma_mix_f32 %0, %4, %5, %0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %1, %4, %5, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
         : "=&v"(t0), "=&v"(t1)
-        : "v"(h), "v"(l), "v"(r));
+        : "v"(h), "v"(l), "v"(r), "s"(0.00390625f));
 #endif
     acc0 = __builtin_fmaf(t0, mul, acc0);
     acc1 = __builtin_fmaf(t1, mul, acc1);
@@ -132,6 +142,22 @@ __device__ __forceinline__ void relu_pieces(Pieces& p) {
         p.l[i] &= keep;
         p.r[i] &= keep;
     }
+}
+
+// the bf8 B operand of two k-steps: the high bytes of the r' and hi pieces (an f16's high byte IS its bf8 truncation: same
+// sign, same five exponent bits, the two leading fraction bits; infinities and NaNs stay what they are)
+__device__ __forceinline__ i32x8 bf8_operand(const Pieces& p0, const Pieces& p1) {
+    constexpr unsigned kHigh = 0x07050301u;   // bytes 1, 3 of the second argument, then bytes 1, 3 of the first
+    i32x8 b;
+    b[0] = (int)__builtin_amdgcn_perm(p0.r[1], p0.r[0], kHigh);
+    b[1] = (int)__builtin_amdgcn_perm(p0.r[3], p0.r[2], kHigh);
+    b[2] = (int)__builtin_amdgcn_perm(p0.h[1], p0.h[0], kHigh);
+    b[3] = (int)__builtin_amdgcn_perm(p0.h[3], p0.h[2], kHigh);
+    b[4] = (int)__builtin_amdgcn_perm(p1.r[1], p1.r[0], kHigh);
+    b[5] = (int)__builtin_amdgcn_perm(p1.r[3], p1.r[2], kHigh);
+    b[6] = (int)__builtin_amdgcn_perm(p1.h[1], p1.h[0], kHigh);
+    b[7] = (int)__builtin_amdgcn_perm(p1.h[3], p1.h[2], kHigh);
+    return b;
 }
 
 // accumulator tile (x `scale`), registers 8 hk .. 8 hk + 7  ->  pieces of k-step 2 t + hk.  RELU: `v < 0 ? 0 : v`
@@ -171,49 +197,52 @@ __device__ __forceinline__ void add_pieces(f32x16& a, int q0, const Pieces& p, f
     }
 }
 
-#define NFA_K8X_FRAGS(cur, i_h, i_l, i_r)                                   \
-    const f16x8 ah = __builtin_bit_cast(f16x8, (cur)[(i_h) * 64]);          \
-    const f16x8 al = __builtin_bit_cast(f16x8, (cur)[(i_l) * 64]);          \
-    const f16x8 ar = __builtin_bit_cast(f16x8, (cur)[(i_r) * 64])
-
-// k-major GEMM (all four output tiles accumulate together): out^T[128 x 32 samples] += W[128 x 16 NKS] x act^T; one
-// stage ([4 tiles][3 pieces][64 lanes] x 16 bytes) per k-step.  RELU: applied to the input pieces on the fly (the
-// pieces themselves stay: they are the residual stream)
-template <bool RELU, int NKS>
-__device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const Pieces (&p)[8], WeightStream& sm, int lane) {
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        stream_request(sm);
-        const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
-        Pieces b = p[ks];
-        if (RELU) relu_pieces(b);
-        const f16x8 bh = __builtin_bit_cast(f16x8, b.h), bl = __builtin_bit_cast(f16x8, b.l),
-                    br = __builtin_bit_cast(f16x8, b.r);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            NFA_K8X_FRAGS(cur, t * 3 + 0, t * 3 + 1, t * 3 + 2);
-            NFA_MFMA5(acc[t], ah, al, ar, bh, bl, br);
-        }
-        stream_advance(sm);
-    }
+__device__ __forceinline__ i32x8 join_x(vec4f lo, vec4f hi) {
+    const uvec4 a = __builtin_bit_cast(uvec4, lo), b = __builtin_bit_cast(uvec4, hi);
+    return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
 }
 
-// one 32-row output tile of a 128-wide layer: acc += W_tile[32 x 128] x act^T; two stages of [3 pieces][4 k-steps]
-// [64 lanes] x 16 bytes
-__device__ __forceinline__ void gemm_tile(f32x16& acc, const Pieces (&p)[8], WeightStream& sm, int lane) {
+// the products of two k-steps for one tile.  The three f16 products of a k-step share their srcB as far as they can (the
+// matrix pipe's energy depends on how often srcB changes between consecutive instructions, a new srcA costs nothing:
+// fused_common.hpp, round 4); within a stage the order of the additions is immaterial to the result's error.
+#define NFA_K8X_PAIR(acc, cur, base, b0, b1, bx)                                                                             \
+    {                                                                                                                        \
+        const f16x8 ah0 = __builtin_bit_cast(f16x8, (cur)[((base) + 0) * 64]), al0 = __builtin_bit_cast(f16x8, (cur)[((base) + 1) * 64]); \
+        const f16x8 ah1 = __builtin_bit_cast(f16x8, (cur)[((base) + 2) * 64]), al1 = __builtin_bit_cast(f16x8, (cur)[((base) + 3) * 64]); \
+        const i32x8 ax = join_x((cur)[((base) + 4) * 64], (cur)[((base) + 5) * 64]);                                          \
+        const f16x8 bh0 = __builtin_bit_cast(f16x8, (b0).h), bl0 = __builtin_bit_cast(f16x8, (b0).l);                          \
+        const f16x8 bh1 = __builtin_bit_cast(f16x8, (b1).h), bl1 = __builtin_bit_cast(f16x8, (b1).l);                          \
+        acc = NFA_K8X_F16(ah0, bl0, acc);                                                                                    \
+        acc = NFA_K8X_F16(al0, bh0, acc);                                                                                    \
+        acc = NFA_K8X_F16(ah0, bh0, acc);                                                                                    \
+        acc = NFA_K8X_F16(ah1, bl1, acc);                                                                                    \
+        acc = NFA_K8X_F16(al1, bh1, acc);                                                                                    \
+        acc = NFA_K8X_F16(ah1, bh1, acc);                                                                                    \
+        acc = NFA_K8X_BF8(ax, bx, acc);                                                                                      \
+    }
+
+// k-major GEMM (all four output tiles accumulate together): out^T[128 x 32 samples] += W[128 x 16 NKS] x act^T; two
+// stages ([2 tiles][H0, L0, H1, L1, X lo, X hi][64 lanes] x 16 bytes) per pair of k-steps.  RELU: applied to the input
+// pieces on the fly (the pieces themselves stay: they are the residual stream)
+template <bool RELU, int NKS>
+__device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const Pieces (&p)[8], WeightStream& sm, int lane) {
+    static_assert(NKS % 2 == 0, "pairs of k-steps");
 #pragma unroll
-    for (int hs = 0; hs < 2; ++hs) {
-        stream_request(sm);
-        const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-            const int ks = hs * 4 + k4;
-            const f16x8 bh = __builtin_bit_cast(f16x8, p[ks].h), bl = __builtin_bit_cast(f16x8, p[ks].l),
-                        br = __builtin_bit_cast(f16x8, p[ks].r);
-            NFA_K8X_FRAGS(cur, 0 * 4 + k4, 1 * 4 + k4, 2 * 4 + k4);
-            NFA_MFMA5(acc, ah, al, ar, bh, bl, br);
+    for (int pr = 0; pr < NKS / 2; ++pr) {
+        Pieces b0 = p[2 * pr], b1 = p[2 * pr + 1];
+        if (RELU) {
+            relu_pieces(b0);
+            relu_pieces(b1);
         }
-        stream_advance(sm);
+        const i32x8 bx = bf8_operand(b0, b1);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            stream_request(sm);
+            const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
+            NFA_K8X_PAIR(acc[half * 2 + 0], cur, 0, b0, b1, bx);
+            NFA_K8X_PAIR(acc[half * 2 + 1], cur, 6, b0, b1, bx);
+            stream_advance(sm);
+        }
     }
 }
 

@@ -59,59 +59,82 @@ struct Args {
     float* dbg_logits;       // DBG: [batch][dt * 24], packed row order (tile, lane-half, register)
 };
 
-template <int UNIT, int SLOT, class Steps>
-__device__ __forceinline__ void unit_step(Steps& fa, Steps& fb, const RqsDev& sp) {
+// slices of an evaluation unit behind the MFMAs of a tile: the tile's 24 f16 MFMAs count one time unit each, its four bf8
+// MFMAs two (64 against 32 cycles): 32 units per tile, the unit's slices spread evenly over them
+template <int UNIT, int U0, int U1, class Steps>
+__device__ __forceinline__ void unit_span(Steps& fa, Steps& fb, const RqsDev& sp) {
     if constexpr (UNIT != 0) {
         constexpr int N = k8h::spline_unit_slices<UNIT, Steps>();
-        k8h::spline_unit_range<UNIT, (SLOT * N) / 40, ((SLOT + 1) * N) / 40>(fa, fb, sp);
+        k8h::spline_unit_range<UNIT, (U0 * N) / 32, (U1 * N) / 32>(fa, fb, sp);
     }
 }
 
-#define NFA_K8X_PUMP(SLOT, A_, B_)                                          \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, acc, 0, 0, 0);     \
+#define NFA_K8X_PUMP_F16(U, A_, B_)                                         \
+    acc = NFA_K8X_F16(A_, B_, acc);                                         \
     __builtin_amdgcn_sched_barrier(0);                                      \
-    unit_step<UNIT, SLOT>(fa, fb, sp);                                      \
+    unit_span<UNIT, (U), (U) + 1>(fa, fb, sp);                              \
+    __builtin_amdgcn_sched_barrier(0)
+#define NFA_K8X_PUMP_BF8(U, A_, B_)                                         \
+    acc = NFA_K8X_BF8(A_, B_, acc);                                         \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+    unit_span<UNIT, (U), (U) + 2>(fa, fb, sp);                              \
     __builtin_amdgcn_sched_barrier(0)
 
-// one k-step of the final layer (five MFMAs, one slice of the evaluation behind each); fh / fl / fr hold this k-step's
-// weight fragments on entry and the next k-step's on exit (requested four MFMAs ahead of their use)
-template <int UNIT, int KS, class Steps>
-__device__ __forceinline__ void kstep_pumped(f32x16& acc, const Pieces& b, vec4f& fh, vec4f& fl, vec4f& fr,
-                                             const vec4f* cur, Steps& fa, Steps& fb, const RqsDev& sp) {
-    constexpr int K4 = KS & 3;
-    const f16x8 bh = __builtin_bit_cast(f16x8, b.h), bl = __builtin_bit_cast(f16x8, b.l), br = __builtin_bit_cast(f16x8, b.r);
-    const f16x8 ah = __builtin_bit_cast(f16x8, fh), al = __builtin_bit_cast(f16x8, fl), ar = __builtin_bit_cast(f16x8, fr);
-    NFA_K8X_PUMP(KS * 5 + 0, ar, bh);
-    if (K4 < 3) fr = cur[(2 * 4 + K4 + 1) * 64];
-    NFA_K8X_PUMP(KS * 5 + 1, al, bh);
-    if (K4 < 3) {
-        fl = cur[(1 * 4 + K4 + 1) * 64];
-        fh = cur[(0 * 4 + K4 + 1) * 64];
-    }
-    NFA_K8X_PUMP(KS * 5 + 2, ah, bh);
-    NFA_K8X_PUMP(KS * 5 + 3, ah, bl);
-    NFA_K8X_PUMP(KS * 5 + 4, ah, br);
-}
-#undef NFA_K8X_PUMP
-
+// one stage of the final layer = four k-steps of the tile: two pairs of k-steps, each three f16 products per k-step and one
+// bf8 instruction, a slice of the evaluation behind every MFMA.  Stage layout: fragments H0..H3 | L0..L3 | X01 lo, X01 hi,
+// X23 lo, X23 hi.  The second pair's fragments are requested behind the MFMAs that free the first pair's registers.
 template <int UNIT, int HS, class Steps>
-__device__ __forceinline__ void stage_pumped(f32x16& acc, const Pieces (&p)[8], WeightStream& sm, int lane, Steps& fa,
-                                             Steps& fb, const RqsDev& sp) {
+__device__ __forceinline__ void stage_pumped(f32x16& acc, const Pieces (&p)[8], const i32x8 (&bx)[4], WeightStream& sm, int lane,
+                                             Steps& fa, Steps& fb, const RqsDev& sp) {
     stream_request(sm);
     const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
-    vec4f fh = cur[0 * 4 * 64], fl = cur[1 * 4 * 64], fr = cur[2 * 4 * 64];
-    kstep_pumped<UNIT, HS * 4 + 0>(acc, p[HS * 4 + 0], fh, fl, fr, cur, fa, fb, sp);
-    kstep_pumped<UNIT, HS * 4 + 1>(acc, p[HS * 4 + 1], fh, fl, fr, cur, fa, fb, sp);
-    kstep_pumped<UNIT, HS * 4 + 2>(acc, p[HS * 4 + 2], fh, fl, fr, cur, fa, fb, sp);
-    kstep_pumped<UNIT, HS * 4 + 3>(acc, p[HS * 4 + 3], fh, fl, fr, cur, fa, fb, sp);
+    vec4f fh0 = cur[0 * 64], fl0 = cur[4 * 64], fh1 = cur[1 * 64], fl1 = cur[5 * 64];
+    vec4f xa = cur[8 * 64], xb = cur[9 * 64];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const Pieces& b0 = p[HS * 4 + 2 * j];
+        const Pieces& b1 = p[HS * 4 + 2 * j + 1];
+        const f16x8 bh0 = __builtin_bit_cast(f16x8, b0.h), bl0 = __builtin_bit_cast(f16x8, b0.l);
+        const f16x8 bh1 = __builtin_bit_cast(f16x8, b1.h), bl1 = __builtin_bit_cast(f16x8, b1.l);
+        const f16x8 ah0 = __builtin_bit_cast(f16x8, fh0), al0 = __builtin_bit_cast(f16x8, fl0);
+        const f16x8 ah1 = __builtin_bit_cast(f16x8, fh1), al1 = __builtin_bit_cast(f16x8, fl1);
+        const i32x8 ax = join_x(xa, xb);
+        const int u = HS * 16 + j * 8;   // (constant after unrolling)
+        if (j == 0) {
+            NFA_K8X_PUMP_F16(HS * 16 + 0, ah0, bl0);
+            NFA_K8X_PUMP_F16(HS * 16 + 1, al0, bh0);
+            NFA_K8X_PUMP_F16(HS * 16 + 2, ah0, bh0);
+            fh0 = cur[2 * 64];
+            fl0 = cur[6 * 64];
+            NFA_K8X_PUMP_F16(HS * 16 + 3, ah1, bl1);
+            NFA_K8X_PUMP_F16(HS * 16 + 4, al1, bh1);
+            NFA_K8X_PUMP_F16(HS * 16 + 5, ah1, bh1);
+            fh1 = cur[3 * 64];
+            fl1 = cur[7 * 64];
+            NFA_K8X_PUMP_BF8(HS * 16 + 6, ax, bx[HS * 2 + 0]);
+            xa = cur[10 * 64];
+            xb = cur[11 * 64];
+        } else {
+            NFA_K8X_PUMP_F16(HS * 16 + 8, ah0, bl0);
+            NFA_K8X_PUMP_F16(HS * 16 + 9, al0, bh0);
+            NFA_K8X_PUMP_F16(HS * 16 + 10, ah0, bh0);
+            NFA_K8X_PUMP_F16(HS * 16 + 11, ah1, bl1);
+            NFA_K8X_PUMP_F16(HS * 16 + 12, al1, bh1);
+            NFA_K8X_PUMP_F16(HS * 16 + 13, ah1, bh1);
+            NFA_K8X_PUMP_BF8(HS * 16 + 14, ax, bx[HS * 2 + 1]);
+        }
+        (void)u;
+    }
     stream_advance(sm);
 }
+#undef NFA_K8X_PUMP_F16
+#undef NFA_K8X_PUMP_BF8
 
 template <int UNIT, class Steps>
-__device__ __forceinline__ void gemm_tile_pumped(f32x16& acc, const Pieces (&p)[8], WeightStream& sm, int lane,
+__device__ __forceinline__ void gemm_tile_pumped(f32x16& acc, const Pieces (&p)[8], const i32x8 (&bx)[4], WeightStream& sm, int lane,
                                                  Steps& fa, Steps& fb, const RqsDev& sp) {
-    stage_pumped<UNIT, 0>(acc, p, sm, lane, fa, fb, sp);
-    stage_pumped<UNIT, 1>(acc, p, sm, lane, fa, fb, sp);
+    stage_pumped<UNIT, 0>(acc, p, bx, sm, lane, fa, fb, sp);
+    stage_pumped<UNIT, 1>(acc, p, bx, sm, lane, fa, fb, sp);
 }
 
 __device__ __forceinline__ bool not_finite(float v) { return !(__builtin_fabsf(v) < INFINITY); }
@@ -295,6 +318,11 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16x3_kernel(const Args 
                 fa.tail_s = fb.tail_s = a.sp.tail_logit * sc[1];
                 float* slot_b = nullptr;
                 const float* fbias = s_fbias + half * 16;
+                // the bf8 B operands of the four k-step pairs, made once for the layer's 24 tiles (the r' pieces are read by
+                // nothing else from here on: their registers are these)
+                i32x8 bx[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bx[j] = bf8_operand(p[2 * j], p[2 * j + 1]);
                 f32x16 acc[3];
                 auto commit = [&](Steps& f, float* slot) {
                     *slot = f.y;
@@ -318,10 +346,10 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16x3_kernel(const Args 
                     float* slot1 = s_row + tab[kTabTr + g * 4 + half * 2 + 1] * kRowPad + r;
                     load_bias_tile(acc[0], fbias + (g * 3 + 0) * 32);
                     if (g > 0) {
-                        gemm_tile_pumped<k8h::kUnitFinishB>(acc[0], p, sm, lane, fa, fb, a.sp);
+                        gemm_tile_pumped<k8h::kUnitFinishB>(acc[0], p, bx, sm, lane, fa, fb, a.sp);
                         commit(fb, slot_b);
                     } else {
-                        gemm_tile_pumped<0>(acc[0], p, sm, lane, fa, fb, a.sp);
+                        gemm_tile_pumped<0>(acc[0], p, bx, sm, lane, fa, fb, a.sp);
                     }
                     store_logits(acc[0], g * 3 + 0);
                     fa.x = *slot0;
@@ -331,7 +359,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16x3_kernel(const Args 
                         fa.eh[j] = acc[0][8 + j];
                     }
                     load_bias_tile(acc[1], fbias + (g * 3 + 1) * 32);
-                    gemm_tile_pumped<k8h::kUnitNumA>(acc[1], p, sm, lane, fa, fb, a.sp);
+                    gemm_tile_pumped<k8h::kUnitNumA>(acc[1], p, bx, sm, lane, fa, fb, a.sp);
                     store_logits(acc[1], g * 3 + 1);
                     fb.x = *slot1;
 #pragma unroll
@@ -340,7 +368,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16x3_kernel(const Args 
                         fb.ew[j] = acc[1][8 + j];
                     }
                     load_bias_tile(acc[2], fbias + (g * 3 + 2) * 32);
-                    gemm_tile_pumped<k8h::kUnitFinishA>(acc[2], p, sm, lane, fa, fb, a.sp);
+                    gemm_tile_pumped<k8h::kUnitFinishA>(acc[2], p, bx, sm, lane, fa, fb, a.sp);
                     store_logits(acc[2], g * 3 + 2);
                     commit(fa, slot0);
 #pragma unroll

@@ -1968,26 +1968,85 @@ def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transf
 
 
 def split_f16x3(w):
-    """fp32 -> three f16 tensors with w == hi + lo + r EXACTLY while the last piece stays above f16's smallest
-    subnormal (2^-24), round to nearest even every time (f16x3_gemm.hpp)."""
+    """fp32 -> three f16 tensors with w == hi + lo + r' 2^-8 EXACTLY while the last piece -- kept at 2^8 times its value --
+    stays above f16's smallest subnormal (2^-24), round to nearest even every time (csrc/f16x3_gemm.hpp)."""
     hi = w.to(torch.float16)
     r1 = w - hi.float()
     lo = r1.to(torch.float16)
-    r = (r1 - lo.float()).to(torch.float16)
+    r = ((r1 - lo.float()) * 256.0).to(torch.float16)
     return hi, lo, r
 
 
-K8X_ACT_SCALE = 16.0   # scale of the activations' f16 pieces in K8x: 24 bits kept down to |v| = 2^-5, overflow at |v| >= 4094.9
+def _bf8_bytes(x):
+    """fp32 / f16 values -> their bf8 (OCP e5m2) encodings as uint8, round to nearest even"""
+    return x.float().to(torch.float8_e5m2).view(torch.uint8)
+
+
+def _f16_bytes(x):
+    return x.contiguous().view(torch.uint8)
+
+
+K8X_ACT_SCALE = 16.0   # scale of the activations' f16 pieces in K8x: 24 bits kept down to |v| = 2^-13, overflow at |v| >= 4094.9
+
+
+def _k8x_fragments(w, rows_per_tile=32):
+    """`w` [tiles * 32, k-steps, 2 lane-halves, 8] fp32 (already x T, columns in MFMA order) -> per (tile, k-step) the 1 KB
+    fragments of its f16 pieces and the 16-byte halves of the bf8 operand of every PAIR of k-steps:
+      H, L   uint8 [tiles, k-steps, 64 lanes x 16 B]      lane = 32 half + row, its 8 f16 values
+      X      uint8 [tiles, pairs, 2, 64 x 16 B]           per lane 32 bytes [bf8(hi) ks0 | bf8(r') ks0 | bf8(hi) ks1 | bf8(r') ks1],
+                                                          split into bytes 0 .. 15 and 16 .. 31"""
+    tiles, nks = w.shape[0] // 32, w.shape[1]
+    hi, lo, r = split_f16x3(w)
+
+    def lanes(t):   # [tiles*32, ks, hf, 8] -> [tiles, ks, hf, i, 8]
+        return t.view(tiles, 32, nks, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+    H = _f16_bytes(lanes(hi)).view(tiles, nks, 1024)
+    L = _f16_bytes(lanes(lo)).view(tiles, nks, 1024)
+    h8 = lanes(_bf8_bytes(hi))                         # [tiles, ks, hf, i, 8] uint8
+    r8 = lanes(_bf8_bytes(r))
+    pair = torch.cat((h8[:, 0::2], r8[:, 0::2], h8[:, 1::2], r8[:, 1::2]), dim=-1)     # [tiles, pairs, hf, i, 32]
+    X = torch.stack((pair[..., :16], pair[..., 16:]), dim=2).reshape(tiles, nks // 2, 2, 1024)
+    return H, L, X
+
+
+def _k8x_kmajor_stages(w):
+    """[128, 16 * NKS] (x T, columns in (ks, hf, j) order) -> uint8 [NKS stages, 12 KB]: per pair of k-steps two stages
+    (tiles 0, 1 and tiles 2, 3), each [2 tiles][H0, L0, H1, L1, X lo, X hi]"""
+    nks = w.shape[1] // 16
+    H, L, X = _k8x_fragments(w.view(128, nks, 2, 8))
+    stages = []
+    for pr in range(nks // 2):
+        for half in range(2):
+            frags = []
+            for t in (2 * half, 2 * half + 1):
+                frags += [H[t, 2 * pr], L[t, 2 * pr], H[t, 2 * pr + 1], L[t, 2 * pr + 1], X[t, pr, 0], X[t, pr, 1]]
+            stages.append(torch.cat(frags))
+    return torch.stack(stages)
+
+
+def _k8x_tilemajor_stages(w):
+    """[tiles * 32, 128] (x T, rows / columns in kernel order) -> uint8 [2 tiles stages, 12 KB]: per tile two stages of four
+    k-steps, each [H0 .. H3][L0 .. L3][X01 lo, X01 hi, X23 lo, X23 hi]"""
+    tiles = w.shape[0] // 32
+    H, L, X = _k8x_fragments(w.view(tiles * 32, 8, 2, 8))
+    stages = []
+    for t in range(tiles):
+        for hs in range(2):
+            ks = range(4 * hs, 4 * hs + 4)
+            stages.append(torch.cat([H[t, k] for k in ks] + [L[t, k] for k in ks] +
+                                    [X[t, 2 * hs, 0], X[t, 2 * hs, 1], X[t, 2 * hs + 1, 0], X[t, 2 * hs + 1, 1]]))
+    return torch.stack(stages)
 
 
 def pack_resnet_conditioner_f16x3(net, num_transform, params_per_feature, act_scale=K8X_ACT_SCALE,
                                   pad_transform_to=None, pad_identity_to=None):
-    """Packs a ResidualNet for K8x (csrc/rqs_resnet_f16x3.hip; layout in include/nflows_amd.h): K8's stages, stage
-    order, column / row rules and bias order (pack_resnet_conditioner), the three pieces of a weight being the f16
-    triple (hi, lo, r) of weight x T -- T a power of two chosen per GEMM (_f16_weight_scale) --, the biases
-    pre-multiplied by the scale their accumulators carry (S T: activations' pieces live at scale S = `act_scale`),
-    and per GEMM the pair {1 / T, T} ({1 / (S T), S T} for the final layer) the kernel takes the scales out with.
-    8 bins, no context.  Returns (weights [stages, 768 * 8] f16, biases fp32, scales fp32 [(2 + 2 blocks) * 2])."""
+    """Packs a ResidualNet for K8x (csrc/rqs_resnet_f16x3.hip; layout in include/nflows_amd.h): K8's stage order, column /
+    row rules and bias order (pack_resnet_conditioner); every weight x T -- T a power of two chosen per GEMM
+    (_f16_weight_scale) -- as its f16 pieces hi, lo and the bf8 operand bytes of the two 2^-22-level products
+    (csrc/f16x3_gemm.hpp); the biases pre-multiplied by the scale their accumulators carry (S T: activations' pieces live
+    at scale S = `act_scale`), and per GEMM the pair {1 / T, T} ({1 / (S T), S T} for the final layer) the kernel takes the
+    scales out with.  8 bins, no context.  Returns (weights [stages, 768 * 8] f16 -- 12 KB stages, raw bytes --, biases
+    fp32, scales fp32 [(2 + 2 blocks) * 2])."""
     dt, P = num_transform, params_per_feature
     K = (P + 1) // 3
     if P != 23 or getattr(net, "context_features", None):
@@ -1997,10 +2056,6 @@ def pack_resnet_conditioner_f16x3(net, num_transform, params_per_feature, act_sc
         raise ValueError("act_scale must be a power of two")
     dev = net.final_layer.weight.device
     order_k = _k8_column_order().to(dev)
-
-    def pieces(w):
-        return torch.stack(split_f16x3(w))  # [3, ...]
-
     stages, biases, scales = [], [], []
     H = net.initial_layer.weight.shape[0]                      # <= 128: narrower nets are zero-padded
     wi = _initial_weight(net, pad_identity_to)
@@ -2008,15 +2063,14 @@ def pack_resnet_conditioner_f16x3(net, num_transform, params_per_feature, act_sc
     init_ks = 4 if di > 32 else 2
     wi = torch.cat((wi, wi.new_zeros(128, 16 * init_ks - di)), dim=1)  # k = ks*16 + hf*8 + j
     T = _f16_weight_scale(wi)
-    # (p, t, i, ks, hf, j) -> (ks, t, p, hf, i, j)
-    stages.append(pieces(wi * T).view(3, 4, 32, init_ks, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(init_ks, -1))
+    stages.append(_k8x_kmajor_stages(wi * T))
     biases.append(_bias_accumulator_order(_pad_to(net.initial_layer.bias.detach().float(), rows=128) * (S * T)))
     scales += [1.0 / T, T]
     for block in net.blocks:
         for lin in block.linear_layers:
             w = _pad_to(lin.weight.detach().float(), rows=128, cols=128).index_select(1, order_k)  # columns in (ks, hf, j) order
             T = _f16_weight_scale(w)
-            stages.append(pieces(w * T).view(3, 4, 32, 8, 2, 8).permute(3, 1, 0, 4, 2, 5).reshape(8, -1))
+            stages.append(_k8x_kmajor_stages(w * T))
             biases.append(_bias_accumulator_order(_pad_to(lin.bias.detach().float(), rows=128) * (S * T)))
             scales += [1.0 / T, T]
     scale = torch.ones(P, dtype=torch.float64, device=dev)
@@ -2034,13 +2088,11 @@ def pack_resnet_conditioner_f16x3(net, num_transform, params_per_feature, act_sc
     wf = torch.cat((wf, wf.new_zeros(dt, R - P, 128)), dim=1).reshape(dt * R, 128)
     wf = wf.index_select(0, order_r).index_select(1, order_k)
     bf = torch.cat((bf, bf.new_zeros(dt, R - P)), dim=1).reshape(dt * R).index_select(0, order_r)
-    tiles = dt * R // 32
     T = _f16_weight_scale(wf)
-    # (p, tile, i, hs, k4, hf, j) -> (tile, hs, p, k4, hf, i, j): two stages per tile
-    stages.append(pieces(wf * T).view(3, tiles, 32, 2, 4, 2, 8).permute(1, 3, 0, 4, 5, 2, 6).reshape(tiles * 2, -1))
+    stages.append(_k8x_tilemajor_stages(wf * T))
     biases.append(_bias_accumulator_order(bf * (S * T)))
     scales += [1.0 / (S * T), S * T]
-    return (torch.cat(stages, dim=0).contiguous(), torch.cat(biases).contiguous(),
+    return (torch.cat(stages, dim=0).contiguous().view(torch.float16), torch.cat(biases).contiguous(),
             torch.tensor(scales, dtype=torch.float32, device=dev))
 
 

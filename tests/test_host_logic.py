@@ -350,10 +350,12 @@ def test_whole_layer_packing_is_a_lossless_rearrangement(K):
 @pytest.mark.parametrize("di", [6, 40])
 def test_f16x3_whole_layer_packing_carries_the_scales(di):
     """Host side of K8x (ops.pack_resnet_conditioner_f16x3, round 6): emulate csrc/rqs_resnet_f16x3.hip's data flow on one
-    32-row tile from the packed blobs -- K8's stages with (hi, lo, r) f16 triples of weight x T, the FIVE products the
-    kernel keeps (lo lo and everything below dropped, as on the device), activations as three f16 pieces at scale S
-    (exactly what split3_scaled makes), accumulators at S T, the residual stream rebuilt from its pieces x T, the
-    {1 / T, T} pairs, logits = accumulators x kappa -- and compare with the PyTorch network in float64."""
+    32-row tile from the packed blobs -- 12 KB stages of twelve fragments (k-major: two k-steps of two tiles, [H0, L0, H1, L1,
+    X lo, X hi] per tile; final layer: four k-steps of a tile, [H0..H3][L0..L3][X01][X23]), the three f16 products of every
+    k-step, the bf8 instruction of every pair of k-steps on the packed bytes and the high bytes of the activation pieces (x
+    the 2^-8 block scale), activations as three f16 pieces at scale S with the last one kept x 2^8 (what split3_scaled
+    makes), accumulators at S T, the residual stream rebuilt from its pieces x T, the {1 / T, T} pairs, logits =
+    accumulators x kappa -- and compare with the PyTorch network in float64."""
     from nflows_amd import ops
     from nflows_amd.nn.nets import ResidualNet
     torch.manual_seed(0)
@@ -370,22 +372,33 @@ def test_f16x3_whole_layer_packing_carries_the_scales(di):
     tiles = dt * 24 // 32
     assert wp.shape == (init_ks + 16 * 2 + 2 * tiles, 768 * 8) and wp.dtype == torch.float16
     assert bp.shape == (128 + 256 * 2 + tiles * 32,) and sc.shape == (2 * 6,) and sc.dtype == torch.float32
-    assert torch.isfinite(wp.float()).all() and wp.float().abs().max() < 2 ** 14
     for g in range(6):   # powers of two, {1 / T, T} (final: {1 / (S T), S T})
         assert math.frexp(float(sc[2 * g]))[0] == 0.5 and float(sc[2 * g]) * float(sc[2 * g + 1]) == 1.0
-    # the pieces are an exact split of weight x T wherever the last piece is a normal or subnormal f16
-    w = wp.double().view(-1, 768, 8)          # [stage][vec4 slot][8 f16]
+    raw = wp.view(torch.uint8).view(-1, 12, 1024)                      # [stage][fragment][64 lanes x 16 B]
     x = torch.randn(32, di, dtype=torch.float64).float().double()    # one wave's 32 samples (fp32 values)
     lane_r = torch.arange(64) % 32
     lane_h = torch.arange(64) // 32
 
-    def split3(v):   # what split3_scaled does to (already scaled) fp32 values: three f16 pieces as float64
+    def f16_frag(stage, f):      # -> [64 lanes][8] float64
+        return raw[stage, f].view(torch.float16).view(64, 8).double()
+
+    def x_bytes(stage, f):       # fragments f, f + 1 -> [64 lanes][32] float64 (bf8 decoded)
+        b = torch.cat((raw[stage, f].view(64, 16), raw[stage, f + 1].view(64, 16)), dim=1)
+        return b.view(torch.float8_e5m2).float().double()
+
+    def bf8_trunc(v16):          # an f16 tensor's high bytes, decoded
+        return (v16.view(torch.int16) & -256).view(torch.float16).double()
+
+    def split3(v):   # what split3_scaled does to (already scaled) fp32 values: hi, lo, r' = RN16(256 d) as f16 tensors
         v = v.float()
         hi = v.to(torch.float16)
         t = v - hi.float()
         lo = t.to(torch.float16)
-        r = (t - lo.float()).to(torch.float16)
-        return hi.double(), lo.double(), r.double()
+        r = ((t - lo.float()) * 256.0).to(torch.float16)
+        return hi, lo, r
+
+    def value(pc):
+        return pc[0].double() + pc[1].double() + pc[2].double() / 256.0
 
     def acc_to_features(acc):   # acc[t][lane][q] -> [sample, feature]
         out = torch.zeros(32, 32 * acc.shape[0], dtype=torch.float64)
@@ -397,24 +410,28 @@ def test_f16x3_whole_layer_packing_carries_the_scales(di):
     def bias_tiles(off, n):     # [n tiles][2 halves][16] -> acc[t][lane][q]
         return bp[off:off + n * 32].double().view(n, 2, 16)[:, lane_h, :].clone()
 
-    def mfma(acc_t, a_frag, b_frag):
-        A = torch.zeros(32, 16, dtype=torch.float64)
-        Bm = torch.zeros(16, 32, dtype=torch.float64)
+    def mfma(acc_t, a_frag, b_frag, kpl):   # kpl: k values per lane of this instruction (8: f16 32x32x16, 32: bf8 32x32x64)
+        A = torch.zeros(32, 2 * kpl, dtype=torch.float64)
+        Bm = torch.zeros(2 * kpl, 32, dtype=torch.float64)
         for l in range(64):
-            A[l % 32, 8 * (l // 32):8 * (l // 32) + 8] = a_frag[l]
-            Bm[8 * (l // 32):8 * (l // 32) + 8, l % 32] = b_frag[l]
+            A[l % 32, kpl * (l // 32):kpl * (l // 32) + kpl] = a_frag[l]
+            Bm[kpl * (l // 32):kpl * (l // 32) + kpl, l % 32] = b_frag[l]
         Dm = A @ Bm
         for l in range(64):
             for q in range(16):
                 acc_t[l, q] += Dm[8 * (q // 4) + 4 * (l // 32) + q % 4, l % 32]
 
-    def mfma5(acc_t, a3, b3):   # the kernel's five products
-        (ah, al, ar), (bh, bl, br) = a3, b3
-        for a_, b_ in ((ah, br), (ah, bl), (ar, bh), (al, bh), (ah, bh)):
-            mfma(acc_t, a_, b_)
-
-    def a_kmajor(stage, t):
-        return tuple(w[stage, (t * 3 + p_) * 64:(t * 3 + p_) * 64 + 64] for p_ in range(3))
+    def pair_products(acc_t, stage, base, b0, b1):
+        """NFA_K8X_PAIR: fragments base .. base + 5 = H0, L0, H1, L1, X lo, X hi; b0 / b1: (hi, lo, r') [64][8] f16 of the two k-steps"""
+        for k, b in ((0, b0), (1, b1)):
+            ah, al = f16_frag(stage, base + 2 * k), f16_frag(stage, base + 2 * k + 1)
+            mfma(acc_t, ah, b[1].double(), 8)
+            mfma(acc_t, al, b[0].double(), 8)
+            mfma(acc_t, ah, b[0].double(), 8)
+        bx = torch.cat((bf8_trunc(b0[2]), bf8_trunc(b0[0]), bf8_trunc(b1[2]), bf8_trunc(b1[0])), dim=1)   # [64][32]
+        small = torch.zeros(64, 16, dtype=torch.float64)
+        mfma(small, x_bytes(stage, base + 4), bx, 32)
+        acc_t += small / 256.0
 
     def b_from_acc(pieces, ks):       # pieces of the previous layer's accumulators -> three [lane][8]
         return tuple(pc[ks // 2][:, 8 * (ks % 2):8 * (ks % 2) + 8] for pc in pieces)
@@ -425,55 +442,65 @@ def test_f16x3_whole_layer_packing_carries_the_scales(di):
             v = torch.relu(v)
         return split3(v)
 
+    def gemm_kmajor(acc, stage, nks, b_of):
+        for pr in range(nks // 2):
+            b0, b1 = b_of(2 * pr), b_of(2 * pr + 1)
+            for half in range(2):
+                pair_products(acc[2 * half], stage, 0, b0, b1)
+                pair_products(acc[2 * half + 1], stage, 6, b0, b1)
+                stage += 1
+        return stage
+
     stage = 0
-    bx = torch.zeros(init_ks, 64, 8, dtype=torch.float64)
+    bx0 = torch.zeros(init_ks, 64, 8, dtype=torch.float64)
     for ks in range(init_ks):
         for l in range(64):
             for j in range(8):
                 i = ks * 16 + (l // 32) * 8 + j
-                bx[ks, l, j] = x[l % 32, i] if i < di else 0.0
-    xp = split3(bx * S)
-    carried = xp[0] + xp[1] + xp[2]
-    big = (bx * S).abs() >= 0.5
-    assert torch.equal(carried[big], (bx * S)[big])              # all 24 bits while the last piece is >= 2^-24 ...
-    assert (carried - bx * S).abs().max().item() <= 2.0 ** -25   # ... and an absolute 2^-25 (/ S) below that
+                bx0[ks, l, j] = x[l % 32, i] if i < di else 0.0
+    xp = split3(bx0 * S)
+    big = (bx0 * S).abs() >= 2.0 ** -9
+    assert torch.equal(value(xp)[big], (bx0 * S)[big])                 # all 24 bits while the last piece (x 2^8) is >= 2^-24 ...
+    assert (value(xp) - bx0 * S).abs().max().item() <= 2.0 ** -33      # ... and an absolute 2^-33 (/ S) below that
     acc = bias_tiles(0, 4)
-    for ks in range(init_ks):                             # initial layer: k-major [4 tiles][3 pieces][64]
-        for t in range(4):
-            mfma5(acc[t], a_kmajor(stage, t), tuple(pc[ks] for pc in xp))
-        stage += 1
+    stage = gemm_kmajor(acc, stage, init_ks, lambda ks: tuple(pc[ks] for pc in xp))
     g = 0
     h = pieces_of(acc.float().double(), float(sc[0]), False)     # S h as pieces (accumulators are fp32 on the device)
     boff = 128
     g += 1
     for blk in range(2):
-        relu_h = tuple(pc * (h[0] >= 0) for pc in h)             # the sign mask on the pieces
+        keep = (h[0].double() >= 0) | torch.isnan(h[0].double())
+        relu_h = tuple(torch.where(keep, pc, torch.zeros_like(pc)) for pc in h)   # the sign mask on the pieces
         acc = bias_tiles(boff, 4)
-        for ks in range(8):
-            for t in range(4):
-                mfma5(acc[t], a_kmajor(stage, t), b_from_acc(relu_h, ks))
-            stage += 1
+        stage = gemm_kmajor(acc, stage, 8, lambda ks: b_from_acc(relu_h, ks))
+        skip = bias_tiles(boff + 128, 4) + value(h) * float(sc[2 * (g + 1) + 1])     # skip: pieces x T (before u is converted)
         u = pieces_of(acc.float().double(), float(sc[2 * g]), True)
         g += 1
-        acc = bias_tiles(boff + 128, 4) + (h[0] + h[1] + h[2]) * float(sc[2 * g + 1])   # skip: pieces x T
-        for ks in range(8):
-            for t in range(4):
-                mfma5(acc[t], a_kmajor(stage, t), b_from_acc(u, ks))
-            stage += 1
+        acc = skip.float().double()
+        stage = gemm_kmajor(acc, stage, 8, lambda ks: b_from_acc(u, ks))
         h = pieces_of(acc.float().double(), float(sc[2 * g]), False)
         g += 1
         boff += 256
-    got_hidden = acc_to_features(h[0] + h[1] + h[2]) / S
+    got_hidden = acc_to_features(value(h)) / S
     want_hidden = net.hidden(x)
     assert (got_hidden - want_hidden).abs().max().item() < 1e-6 * want_hidden.abs().max().item()
     out = torch.zeros(tiles, 64, 16, dtype=torch.float64)
     bfin = bias_tiles(boff, tiles)
-    for t in range(tiles):                                # final layer: two stages per tile [3 pieces][4 k-steps][64]
+    for t in range(tiles):                                # final layer: two stages per tile, [H0..H3][L0..L3][X01][X23]
         out[t] = bfin[t]
         for hs in range(2):
-            for k4 in range(4):
-                a3 = tuple(w[stage, (p_ * 4 + k4) * 64:(p_ * 4 + k4) * 64 + 64] for p_ in range(3))
-                mfma5(out[t], a3, b_from_acc(h, hs * 4 + k4))
+            for j in range(2):
+                k0 = hs * 4 + 2 * j
+                b0, b1 = b_from_acc(h, k0), b_from_acc(h, k0 + 1)
+                for k, b in ((2 * j, b0), (2 * j + 1, b1)):
+                    ah, al = f16_frag(stage, k), f16_frag(stage, 4 + k)
+                    mfma(out[t], ah, b[1].double(), 8)
+                    mfma(out[t], al, b[0].double(), 8)
+                    mfma(out[t], ah, b[0].double(), 8)
+                bx = torch.cat((bf8_trunc(b0[2]), bf8_trunc(b0[0]), bf8_trunc(b1[2]), bf8_trunc(b1[0])), dim=1)
+                small = torch.zeros(64, 16, dtype=torch.float64)
+                mfma(small, x_bytes(stage, 8 + 2 * j), bx, 32)
+                out[t] += small / 256.0
             stage += 1
     assert stage == wp.shape[0]
     kappa = float(sc[2 * g])
