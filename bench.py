@@ -582,8 +582,25 @@ def main():
                 step_s()
             torch.cuda.synchronize()
             dts = time.perf_counter() - ts
-            small.append({"rows": rows_s, "ms_per_step": dts / args.steps * 1e3, "value": rows_s * args.steps / dts,
-                          "unit": "samples/s"})
+            entry_s = {"rows": rows_s, "ms_per_step": dts / args.steps * 1e3, "value": rows_s * args.steps / dts,
+                       "unit": "samples/s", "engine": args.engine, "kernel": ops.last_layer_kernel()}
+            if args.engine != "f16x2" and args.path == "k8":
+                # (the library's small-batch kernels -- K8s, 16-sample tiles -- exist for the two-piece engine only)
+                try:
+                    RQ.conditioner_engine = "f16x2"
+                    for _ in range(5):
+                        step_s()
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    for _ in range(args.steps):
+                        step_s()
+                    torch.cuda.synchronize()
+                    dt2 = time.perf_counter() - ts
+                    entry_s["engine_f16x2"] = {"ms_per_step": dt2 / args.steps * 1e3, "value": rows_s * args.steps / dt2,
+                                               "kernel": ops.last_layer_kernel()}
+                finally:
+                    RQ.conditioner_engine = args.engine
+            small.append(entry_s)
             del xs_
 
     # extra (N = 1): the same step on every OTHER engine -- K8h (two f16 pieces, three products: the fastest, 22-bit operand
@@ -689,10 +706,28 @@ def main():
                 torch.cuda.synchronize()
                 dt64 = (time.perf_counter() - t64) / 3
                 lp32 = flow.log_prob(xs)
+            graph64 = None
+            try:   # the same pass replayed from a HIP graph: ~25 small launches per layer, the host out of the loop
+                from nflows_amd.graphs import GraphedLogProb
+                g64 = GraphedLogProb(flow64, x64)
+                for _ in range(2):
+                    g64(x64)
+                torch.cuda.synchronize()
+                tg64 = time.perf_counter()
+                for _ in range(5):
+                    out64 = g64(x64)
+                torch.cuda.synchronize()
+                dtg = (time.perf_counter() - tg64) / 5
+                graph64 = {"log_prob_ms": dtg * 1e3, "log_prob_samples_per_s": x64.shape[0] / dtg,
+                           "bit_identical_to_eager_launches": bool(torch.equal(out64, lp64))}
+                del g64
+            except Exception as e:
+                log("fp64 graph replay skipped: %r" % (e,))
             fp64_extra = {"rows": int(x64.shape[0]), "dtype": "f64", "max": e64.max().item(), "mean": e64.mean().item(),
                           "count_above_1e-5": int((e64 > 1e-5).sum().item()), "meets_1e-5": bool(e64.max().item() < 1e-5),
                           "log_prob_ms": dt64 * 1e3, "log_prob_samples_per_s": x64.shape[0] / dt64,
                           "max_abs_log_prob_f32_minus_f64": (lp32.double() - lp64).abs().max().item(),
+                          "hip_graph_replay": graph64,
                           "note": "flow.double() on the device: float64 spline kernel (nfa_rqs_elementwise_f64) + library fp64 GEMMs, "
                                   "layer by layer; not a fast path"}
             del flow64
