@@ -23,7 +23,8 @@
 // (which k the hardware gives byte e of lane-half h is immaterial: A and B use the same map.)
 // The LDS-DMA ring, its counted waits and its barriers are bf16x3_gemm.hpp's; a 12 KB stage holds twelve 1 KB fragments
 // ([64 lanes] x 16 B): k-major stages cover TWO k-steps of TWO output tiles, [2 tiles][H0, L0, H1, L1, X lo, X hi]; a
-// stage of the tile-major final layer covers four k-steps of its tile, [H0..H3][L0..L3][X01 lo, X01 hi, X23 lo, X23 hi].
+// stage of the tile-major final layer covers four k-steps of its tile, [H0, L0, H1, L1][H2, L2, H3, L3][X01 lo, X01 hi, X23 lo,
+// X23 hi] -- fragments 0 .. 3 of EVERY stage are the f16 fragments its first MFMAs need (read ahead: stage_kmajor).
 #pragma once
 
 #include "bf16x3_gemm.hpp"
@@ -202,31 +203,71 @@ __device__ __forceinline__ i32x8 join_x(vec4f lo, vec4f hi) {
     return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
 }
 
-// the products of two k-steps for one tile.  The three f16 products of a k-step share their srcB as far as they can (the
-// matrix pipe's energy depends on how often srcB changes between consecutive instructions, a new srcA costs nothing:
-// fused_common.hpp, round 4); within a stage the order of the additions is immaterial to the result's error.
-#define NFA_K8X_PAIR(acc, cur, base, b0, b1, bx)                                                                             \
-    {                                                                                                                        \
-        const f16x8 ah0 = __builtin_bit_cast(f16x8, (cur)[((base) + 0) * 64]), al0 = __builtin_bit_cast(f16x8, (cur)[((base) + 1) * 64]); \
-        const f16x8 ah1 = __builtin_bit_cast(f16x8, (cur)[((base) + 2) * 64]), al1 = __builtin_bit_cast(f16x8, (cur)[((base) + 3) * 64]); \
-        const i32x8 ax = join_x((cur)[((base) + 4) * 64], (cur)[((base) + 5) * 64]);                                          \
-        const f16x8 bh0 = __builtin_bit_cast(f16x8, (b0).h), bl0 = __builtin_bit_cast(f16x8, (b0).l);                          \
-        const f16x8 bh1 = __builtin_bit_cast(f16x8, (b1).h), bl1 = __builtin_bit_cast(f16x8, (b1).l);                          \
-        acc = NFA_K8X_F16(ah0, bl0, acc);                                                                                    \
-        acc = NFA_K8X_F16(al0, bh0, acc);                                                                                    \
-        acc = NFA_K8X_F16(ah0, bh0, acc);                                                                                    \
-        acc = NFA_K8X_F16(ah1, bl1, acc);                                                                                    \
-        acc = NFA_K8X_F16(al1, bh1, acc);                                                                                    \
-        acc = NFA_K8X_F16(ah1, bh1, acc);                                                                                    \
-        acc = NFA_K8X_BF8(ax, bx, acc);                                                                                      \
+// the f16 fragments (H ks0, L ks0, H ks1, L ks1) of the FIRST tile of a stage: fragments 0 .. 3 of every stage layout
+struct Lead {
+    vec4f h0, l0, h1, l1;
+};
+__device__ __forceinline__ Lead read_lead(const vec4f* stage) {
+    return Lead{stage[0 * 64], stage[1 * 64], stage[2 * 64], stage[3 * 64]};
+}
+
+#define NFA_K8X_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// One k-major stage: two k-steps (pieces b0, b1, bf8 operand bx) of two output tiles, fragments [H0, L0, H1, L1, X lo, X hi]
+// per tile.  Software pipeline across the stage barrier (round 6): the first tile's f16 fragments arrive in `lead` -- read
+// right behind the PREVIOUS stage's barrier --, and this stage's barrier stands in front of the second tile's last four
+// MFMAs, which only need registers: the next stage's lead fragments are requested behind the barrier and land while those
+// MFMAs run.  (The three-slot ring cannot be read ahead of the barrier that completes a stage; before this the wave paid one
+// LDS latency at every stage start unless the SIMD's other wave happened to cover it.)  LAST: no successor to read ahead
+// (the GEMM's last stage: the conversions that follow would have to keep the fragments alive).
+// The three f16 products of a k-step share their srcB as far as they can (the matrix pipe's energy depends on how often
+// srcB changes between consecutive instructions, a new srcA costs nothing: fused_common.hpp, round 4); within a stage the
+// order of the additions is immaterial to the result's error.
+template <bool LAST>
+__device__ __forceinline__ void stage_kmajor(f32x16& acc0, f32x16& acc1, const Pieces& b0, const Pieces& b1, const i32x8& bx,
+                                             WeightStream& sm, int lane, Lead& lead) {
+    stream_request(sm);
+    const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
+    const f16x8 bh0 = __builtin_bit_cast(f16x8, b0.h), bl0 = __builtin_bit_cast(f16x8, b0.l);
+    const f16x8 bh1 = __builtin_bit_cast(f16x8, b1.h), bl1 = __builtin_bit_cast(f16x8, b1.l);
+    // everything else of the stage is requested now: tile 0's X, tile 1's six fragments
+    const vec4f x0l = cur[4 * 64], x0h = cur[5 * 64];
+    const vec4f h0 = cur[6 * 64], l0 = cur[7 * 64], h1 = cur[8 * 64], l1 = cur[9 * 64], x1l = cur[10 * 64], x1h = cur[11 * 64];
+    NFA_K8X_FENCE();
+    {
+        const f16x8 ah0 = __builtin_bit_cast(f16x8, lead.h0), al0 = __builtin_bit_cast(f16x8, lead.l0);
+        const f16x8 ah1 = __builtin_bit_cast(f16x8, lead.h1), al1 = __builtin_bit_cast(f16x8, lead.l1);
+        acc0 = NFA_K8X_F16(ah0, bl0, acc0);
+        acc0 = NFA_K8X_F16(al0, bh0, acc0);
+        acc0 = NFA_K8X_F16(ah0, bh0, acc0);
+        acc0 = NFA_K8X_F16(ah1, bl1, acc0);
+        acc0 = NFA_K8X_F16(al1, bh1, acc0);
+        acc0 = NFA_K8X_F16(ah1, bh1, acc0);
+        acc0 = NFA_K8X_BF8(join_x(x0l, x0h), bx, acc0);
     }
+    const f16x8 ah0 = __builtin_bit_cast(f16x8, h0), al0 = __builtin_bit_cast(f16x8, l0);
+    const f16x8 ah1 = __builtin_bit_cast(f16x8, h1), al1 = __builtin_bit_cast(f16x8, l1);
+    const i32x8 ax = join_x(x1l, x1h);
+    acc1 = NFA_K8X_F16(ah0, bl0, acc1);
+    acc1 = NFA_K8X_F16(al0, bh0, acc1);
+    acc1 = NFA_K8X_F16(ah0, bh0, acc1);
+    NFA_K8X_FENCE();
+    stream_advance(sm);          // every read of this stage has landed in registers; the next stage is complete
+    if constexpr (!LAST) lead = read_lead(sm.ring + sm.slot * kStageVec4 + lane);
+    NFA_K8X_FENCE();
+    acc1 = NFA_K8X_F16(ah1, bl1, acc1);
+    acc1 = NFA_K8X_F16(al1, bh1, acc1);
+    acc1 = NFA_K8X_F16(ah1, bh1, acc1);
+    acc1 = NFA_K8X_BF8(ax, bx, acc1);
+}
 
 // k-major GEMM (all four output tiles accumulate together): out^T[128 x 32 samples] += W[128 x 16 NKS] x act^T; two
-// stages ([2 tiles][H0, L0, H1, L1, X lo, X hi][64 lanes] x 16 bytes) per pair of k-steps.  RELU: applied to the input
-// pieces on the fly (the pieces themselves stay: they are the residual stream)
+// stages per pair of k-steps (tiles 0, 1 and tiles 2, 3).  RELU: applied to the input pieces on the fly (the pieces
+// themselves stay: they are the residual stream)
 template <bool RELU, int NKS>
 __device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const Pieces (&p)[8], WeightStream& sm, int lane) {
     static_assert(NKS % 2 == 0, "pairs of k-steps");
+    Lead lead = read_lead(sm.ring + sm.slot * kStageVec4 + lane);
 #pragma unroll
     for (int pr = 0; pr < NKS / 2; ++pr) {
         Pieces b0 = p[2 * pr], b1 = p[2 * pr + 1];
@@ -235,14 +276,9 @@ __device__ __forceinline__ void gemm_kmajor(f32x16 (&acc)[4], const Pieces (&p)[
             relu_pieces(b1);
         }
         const i32x8 bx = bf8_operand(b0, b1);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            stream_request(sm);
-            const vec4f* cur = sm.ring + sm.slot * kStageVec4 + lane;
-            NFA_K8X_PAIR(acc[half * 2 + 0], cur, 0, b0, b1, bx);
-            NFA_K8X_PAIR(acc[half * 2 + 1], cur, 6, b0, b1, bx);
-            stream_advance(sm);
-        }
+        stage_kmajor<false>(acc[0], acc[1], b0, b1, bx, sm, lane, lead);
+        if (pr + 1 < NKS / 2) stage_kmajor<false>(acc[2], acc[3], b0, b1, bx, sm, lane, lead);
+        else stage_kmajor<true>(acc[2], acc[3], b0, b1, bx, sm, lane, lead);
     }
 }
 

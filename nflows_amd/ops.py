@@ -2026,15 +2026,15 @@ def _k8x_kmajor_stages(w):
 
 def _k8x_tilemajor_stages(w):
     """[tiles * 32, 128] (x T, rows / columns in kernel order) -> uint8 [2 tiles stages, 12 KB]: per tile two stages of four
-    k-steps, each [H0 .. H3][L0 .. L3][X01 lo, X01 hi, X23 lo, X23 hi]"""
+    k-steps, each [H0, L0, H1, L1][H2, L2, H3, L3][X01 lo, X01 hi, X23 lo, X23 hi]"""
     tiles = w.shape[0] // 32
     H, L, X = _k8x_fragments(w.view(tiles * 32, 8, 2, 8))
     stages = []
     for t in range(tiles):
         for hs in range(2):
-            ks = range(4 * hs, 4 * hs + 4)
-            stages.append(torch.cat([H[t, k] for k in ks] + [L[t, k] for k in ks] +
-                                    [X[t, 2 * hs, 0], X[t, 2 * hs, 1], X[t, 2 * hs + 1, 0], X[t, 2 * hs + 1, 1]]))
+            k = 4 * hs
+            stages.append(torch.cat([H[t, k], L[t, k], H[t, k + 1], L[t, k + 1], H[t, k + 2], L[t, k + 2], H[t, k + 3], L[t, k + 3],
+                                     X[t, 2 * hs, 0], X[t, 2 * hs, 1], X[t, 2 * hs + 1, 0], X[t, 2 * hs + 1, 1]]))
     return torch.stack(stages)
 
 
@@ -2045,12 +2045,12 @@ def pack_resnet_conditioner_f16x3(net, num_transform, params_per_feature, act_sc
     (_f16_weight_scale) -- as its f16 pieces hi, lo and the bf8 operand bytes of the two 2^-22-level products
     (csrc/f16x3_gemm.hpp); the biases pre-multiplied by the scale their accumulators carry (S T: activations' pieces live
     at scale S = `act_scale`), and per GEMM the pair {1 / T, T} ({1 / (S T), S T} for the final layer) the kernel takes the
-    scales out with.  8 bins, no context.  Returns (weights [stages, 768 * 8] f16 -- 12 KB stages, raw bytes --, biases
+    scales out with.  Bin counts of whole_layer_bins (final rows: final_rows_per_feature), no context.  Returns (weights [stages, 768 * 8] f16 -- 12 KB stages, raw bytes --, biases
     fp32, scales fp32 [(2 + 2 blocks) * 2])."""
     dt, P = num_transform, params_per_feature
     K = (P + 1) // 3
-    if P != 23 or getattr(net, "context_features", None):
-        raise ValueError("K8x packs 8-bin linear-tail layers without a context")
+    if P % 3 != 2 or not whole_layer_bins(K) or getattr(net, "context_features", None):
+        raise ValueError("K8x packs linear-tail layers of 2 .. 16, 20, 24 or 32 bins without a context")
     S = float(act_scale)
     if S <= 0 or math.frexp(S)[0] != 0.5:
         raise ValueError("act_scale must be a power of two")
@@ -2083,8 +2083,8 @@ def pack_resnet_conditioner_f16x3(net, num_transform, params_per_feature, act_sc
         wf = torch.cat((wf, wf.new_zeros(pad_transform_to - dt, P, 128)), dim=0)
         bf = torch.cat((bf, bf.new_zeros(pad_transform_to - dt, P)), dim=0)
         dt = pad_transform_to
-    R = 24
-    order_r = _k7_row_order(dt).to(dev)
+    R = final_rows_per_feature(P)   # 8 bins: 23 -> 24 (two features per three tiles); otherwise whole 16-row shares
+    order_r = (_k7_row_order(dt) if P == 23 else _k8_row_order_32(dt, R // 16)).to(dev)
     wf = torch.cat((wf, wf.new_zeros(dt, R - P, 128)), dim=1).reshape(dt * R, 128)
     wf = wf.index_select(0, order_r).index_select(1, order_k)
     bf = torch.cat((bf, bf.new_zeros(dt, R - P)), dim=1).reshape(dt * R).index_select(0, order_r)
@@ -2145,7 +2145,7 @@ def rqs_coupling_resnet_f16x3(inputs, packed_f16x3, packed_exact, tables, num_tr
     """K8x -- the run of whole-layer kernels on the f16 matrix pipe with THREE f16 pieces per operand (five
     products: operands at the reference's fp32 width), followed by the exact kernel (K8: three bf16 pieces, full
     fp32 range) on the row blocks the first pass gave up on (a value beyond the f16 range at scale `act_scale`, or
-    non-finite inputs).  `packed_f16x3`: (weights, biases, scales) of the run's layers concatenated, from
+    non-finite inputs).  Bin counts: whole_layer_bins.  `packed_f16x3`: (weights, biases, scales) of the run's layers concatenated, from
     pack_resnet_conditioner_f16x3; `packed_exact`: (weights, biases) from pack_resnet_conditioner; `tables`: the
     run's `flow_layer_tables`.  Results as for `rqs_coupling_resnet`; None when the shape is outside the kernel's."""
     N.require_device_f32("inputs", inputs, 2)

@@ -805,7 +805,7 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
     # pipe (K8h / K8s, three products: 22-bit operand significands, the fp32 fma chain's error class; row blocks that
     # leave the f16 range are redone by the bf16x3 kernel), "bf16x3" = three bf16 pieces (K8, six products: 24-bit
     # operands, full fp32 range), "f16x3" (round 6) = three f16 pieces (K8x, five products: operands carried at the
-    # reference's fp32 width on the f16 pipe; 8 bins, ReLU, no context -- other shapes take K8; the same redo pass)
+    # reference's fp32 width on the f16 pipe; ReLU, no context -- other shapes take K8; the same redo pass)
     conditioner_engine = os.environ.get("NFA_K8_ENGINE", "f16x2")
     # scale of the hidden activations' f16 pieces (a power of two; K8h)
     conditioner_act_scale = float(os.environ.get("NFA_K8_ACT_SCALE", "1"))
@@ -818,8 +818,9 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
                 and (ce is None or (ce <= 32 and (geometry or self._fused_geometry())[2] <= 32)))
 
     def _use_f16x3(self, geometry=None):
-        """K8x serves 8 bins with ReLU blocks and no context -- otherwise engine "f16x3" means the bf16x3 kernel (K8)."""
-        return (self.conditioner_engine == "f16x3" and self.num_bins == 8 and not self._log2e()
+        """K8x serves the whole-layer bin counts (ops.whole_layer_bins) with ReLU blocks and no context -- otherwise engine
+        "f16x3" means the bf16x3 kernel (K8)."""
+        return (self.conditioner_engine == "f16x3" and ops.whole_layer_bins(self.num_bins) and not self._log2e()
                 and self._static_signature()[2] is None and self._block_activation() == N.ACTIVATION_RELU)
 
     def _packed_resnet_f16x3(self, geometry=None):

@@ -12,7 +12,8 @@ What is held to what:
     oracle/eager.py reproduces the fixture bit for bit (tests/test_oracle_golden.py), so the rows behind the fixture's
     128 are held to the port -- 8 192 rows in all;
   * every engine is driven explicitly and the kernel that ran is read back from the library: K8h eight-wave (65 536
-    rows) and four-wave, K8 (bf16x3), GEMMs + K1 (the path these layers took before);
+    rows) and four-wave, K8 (bf16x3), K8x (f16x3, round 6: K8h's general final layer on the three-piece GEMM), GEMMs + K1
+    (the path these layers took before);
   * the headline rule (tests/test_gpu_headline_parity.compare): error against float64 at most 2 x the reference-fp32's
     own on the mean AND on the 99.9 % quantile, no floor, on 65 536 rows per engine (round 5; round 4 compared 8 192 rows,
     whose 99.9 % quantile is their 8th largest value, and allowed 2.5 x for it); at most three elements above 4 x the
@@ -53,6 +54,7 @@ def _engines(K):
         "k8h_w8": (dict(path="k8", engine="f16x2"), 65536, ("k8h::", "waves=8", "K=%d," % K)),
         "k8h_w4": (dict(path="k8", engine="f16x2"), 16384, ("k8h::", "waves=4", "K=%d," % K)),
         "k8": (dict(path="k8", engine="bf16x3"), 16384, ("rqs_resnet_kernel<", "pipe=0", "K=%d," % K)),
+        "k8x": (dict(path="k8", engine="f16x3"), 16384, ("k8x::", "K=%d," % K)),   # round 6: three f16 pieces per operand
         "gemm_k1": (dict(path="none", engine="f16x2"), 16384, ("rqs_coupling",)),
     }
 
@@ -80,7 +82,7 @@ def test_other_bin_counts_on_every_engine(golden_dir, engine_switches, K, engine
     def counted(fn, key):
         def run(t):
             out = fn(t)
-            if engine.startswith("k8h"):
+            if engine.startswith("k8h") or engine == "k8x":
                 redo[key] += ops.last_redo_blocks()
             return out
         return run
@@ -122,8 +124,9 @@ def test_other_bin_counts_at_the_baseline_widths(engine_switches, K, D):
     key = "deep_k%d_d%d" % (K, D)
     o = _oracle(key, flow_cpu, x, noise, rows=WIDTH_ROWS)
     flow = copy.deepcopy(flow_cpu).to(DEV).eval()
-    for engine, rows in (("k8h_w8", 65536), ("k8h_w4", 8192 + 40)):   # (a ragged batch on the four-wave form: two launches cover the oracle rows)
-        engine_switches("k8", "f16x2", True)
+    # (a ragged batch on the four-wave form and on K8x: two launches cover the oracle rows)
+    for engine, rows in (("k8h_w8", 65536), ("k8h_w4", 8192 + 40), ("k8x", 8192 + 40)):
+        engine_switches("k8", "f16x3" if engine == "k8x" else "f16x2", True)
         _status(key, clear=True)
         n_eval = 65536 if engine == "k8h_w8" else 2 * rows
         with torch.no_grad():
@@ -136,8 +139,11 @@ def test_other_bin_counts_at_the_baseline_widths(engine_switches, K, D):
             redo += ops.last_redo_blocks()
             xr, _ = _chunked(flow._transform.inverse, z.cpu(), rows)
         for label in (label_f, label_i):
-            assert "k8h::" in label and "K=%d," % K in label and ("waves=8" if engine == "k8h_w8" and D < 128 else "waves=4") in label, label   # (D = 128: eight row tiles do not fit beside the ring)
             assert ("init_ks=4" in label) == (D == 128), label
+            if engine == "k8x":
+                assert "k8x::" in label and "K=%d," % K in label, label
+                continue
+            assert "k8h::" in label and "K=%d," % K in label and ("waves=8" if engine == "k8h_w8" and D < 128 else "waves=4") in label, label   # (D = 128: eight row tiles do not fit beside the ring)
         config = "%s_%s" % (key, engine)
         for k, t, tol in (("z", z, OUT_TOL), ("lad", lad, LAD_TOL), ("lp", lp, LAD_TOL), ("xi", xi, OUT_TOL), ("ladi", ladi, LAD_TOL)):
             compare(config, k, t[:WIDTH_ROWS].cpu().numpy(), o[k + "32"], o[k + "64"], tol, max_count=MAX_COUNT)

@@ -347,11 +347,56 @@ def test_whole_layer_packing_is_a_lossless_rearrangement(K):
                 assert vals[:, 24 * f + 23].abs().max().item() == 0.0              # the pad row
 
 
+@pytest.mark.parametrize("K", [3, 5, 11, 13, 32])
+def test_f16x3_packing_of_the_other_bin_counts(K):
+    """K8x's final layer at bin counts other than 8 (round 6): K8h's general row rule -- a feature's 3 K - 1 logits padded to
+    16 T rows, group g's T tiles hand lane-half h the logits of feature 2 g + h (ops._k8_row_order_32) -- in K8x's
+    tile-major 12 KB stages.  The f16 fragments of every (tile, k-step), taken back to rows, are the final Linear's weights
+    (x T, the width / height rows / sqrt(hidden)) to the two pieces' 2^-21; bias and stage counts are the kernel's."""
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import ResidualNet
+    torch.manual_seed(K)
+    dt, di, P = 8, 8, 3 * K - 1
+    R = ops.final_rows_per_feature(P)
+    assert R == 16 * ((P + 15) // 16)
+    net = ResidualNet(di, dt * P, hidden_features=128, num_blocks=1).float()
+    wp, bp, sc = ops.pack_resnet_conditioner_f16x3(net, dt, P)
+    tiles = dt * R // 32
+    assert wp.shape == (2 + 16 + 2 * tiles, 768 * 8) and bp.shape == (128 + 256 + tiles * 32,) and sc.shape == (8,)
+    kappa, ST = float(sc[6]), float(sc[7])
+    assert kappa * ST == 1.0 and math.frexp(ST)[0] == 0.5
+    T = ST / ops.K8X_ACT_SCALE
+    raw = wp.view(torch.uint8).view(-1, 12, 1024)[2 + 16:]             # the final layer's stages
+    scale = torch.ones(P, dtype=torch.float64)
+    scale[:2 * K] = 1.0 / math.sqrt(128)
+    want = net.final_layer.weight.detach().double().view(dt, P, 128) * scale[None, :, None] * T
+    bias = net.final_layer.bias.detach().double().view(dt, P) * scale[None, :] * ST
+    order_k = ops._k8_column_order()
+    tiles_per_group = R // 16
+    for t in range(tiles):
+        rows = torch.zeros(32, 128, dtype=torch.float64)
+        for ks in range(8):
+            st, k = 2 * t + ks // 4, ks % 4
+            hfrag = raw[st, 4 * (k // 2) + 2 * (k % 2)].view(torch.float16).view(2, 32, 8).double()      # [half][row][8]
+            lfrag = raw[st, 4 * (k // 2) + 2 * (k % 2) + 1].view(torch.float16).view(2, 32, 8).double()
+            for hf in range(2):
+                rows[:, order_k[ks * 16 + hf * 8:ks * 16 + hf * 8 + 8]] = (hfrag + lfrag)[hf]
+        g, tg = t // tiles_per_group, t % tiles_per_group
+        for i in range(32):                      # tile row i = 8 (q // 4) + 4 half + q % 4 -> logit 16 tg + q of feature 2 g + half
+            half, q = (i >> 2) & 1, ((i >> 3) << 2) | (i & 3)
+            logit = 16 * tg + q
+            ref = want[2 * g + half, logit] if logit < P else torch.zeros(128, dtype=torch.float64)
+            assert (rows[i] - ref).abs().max().item() <= 2.0 ** -20 * max(1.0, float(ref.abs().max())), (t, i)
+            got_b = float(bp[128 + 256 + t * 32 + half * 16 + q])
+            ref_b = float(bias[2 * g + half, logit]) if logit < P else 0.0
+            assert abs(got_b - ref_b) <= 1e-6 * max(1.0, abs(ref_b)), (t, i)
+
+
 @pytest.mark.parametrize("di", [6, 40])
 def test_f16x3_whole_layer_packing_carries_the_scales(di):
     """Host side of K8x (ops.pack_resnet_conditioner_f16x3, round 6): emulate csrc/rqs_resnet_f16x3.hip's data flow on one
     32-row tile from the packed blobs -- 12 KB stages of twelve fragments (k-major: two k-steps of two tiles, [H0, L0, H1, L1,
-    X lo, X hi] per tile; final layer: four k-steps of a tile, [H0..H3][L0..L3][X01][X23]), the three f16 products of every
+    X lo, X hi] per tile; final layer: four k-steps of a tile, [H0, L0, H1, L1][H2, L2, H3, L3][X01][X23]), the three f16 products of every
     k-step, the bf8 instruction of every pair of k-steps on the packed bytes and the high bytes of the activation pieces (x
     the 2^-8 block scale), activations as three f16 pieces at scale S with the last one kept x 2^8 (what split3_scaled
     makes), accumulators at S T, the residual stream rebuilt from its pieces x T, the {1 / T, T} pairs, logits =
@@ -486,14 +531,14 @@ def test_f16x3_whole_layer_packing_carries_the_scales(di):
     assert (got_hidden - want_hidden).abs().max().item() < 1e-6 * want_hidden.abs().max().item()
     out = torch.zeros(tiles, 64, 16, dtype=torch.float64)
     bfin = bias_tiles(boff, tiles)
-    for t in range(tiles):                                # final layer: two stages per tile, [H0..H3][L0..L3][X01][X23]
+    for t in range(tiles):                                # final layer: two stages per tile, [H0, L0, H1, L1][H2, L2, H3, L3][X01][X23]
         out[t] = bfin[t]
         for hs in range(2):
             for j in range(2):
                 k0 = hs * 4 + 2 * j
                 b0, b1 = b_from_acc(h, k0), b_from_acc(h, k0 + 1)
                 for k, b in ((2 * j, b0), (2 * j + 1, b1)):
-                    ah, al = f16_frag(stage, k), f16_frag(stage, 4 + k)
+                    ah, al = f16_frag(stage, 2 * k), f16_frag(stage, 2 * k + 1)
                     mfma(out[t], ah, b[1].double(), 8)
                     mfma(out[t], al, b[0].double(), 8)
                     mfma(out[t], ah, b[0].double(), 8)
@@ -1508,7 +1553,9 @@ def test_no_spill_between_a_join_and_its_exec_restore():
     of a value that is live ACROSS the `if` at the top of the join block, in front of the `s_or_b64 exec, exec, ...` that
     restores the lanes -- waves that skipped the `if` whole (exec = 0) never stored it and reloaded a stale slot later (K11's
     residual instances lost the log-determinants of all layers but the last in waves 2 and 3; the source now branches on a
-    wave-uniform condition there).  Every kernel of the library: no scratch store between a label that an
+    wave-uniform condition there; round 6: K8x's d_i > 32 instances did the same behind `if (tid < 128)` at the head of the
+    layer loop -- wrong log-determinants of multi-layer runs and a garbage status word, found by tests/test_gpu_k8x.py --,
+    its table prefetch is branch-free now).  Every kernel of the library: no scratch store between a label that an
     `s_cbranch_execz` jumps to and the exec restore of that block."""
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
