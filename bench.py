@@ -147,7 +147,7 @@ KERNEL_SOURCES = {
                              "fused_common.hpp", "common.hpp"),
     "k8_pmc_traffic.json": ("rqs_resnet_kernel.hpp", "rqs_resnet.hip", "bf16x3_gemm.hpp", "rqs_math.hpp", "fused_common.hpp",
                             "common.hpp"),
-    "k8x_pmc_traffic.json": ("rqs_resnet_f16x3.hip", "f16x3_gemm.hpp", "bf16x3_gemm.hpp", "rqs_resnet_f16_kernel.hpp", "k8h_common.hpp",
+    "k8x_pmc_traffic.json": ("rqs_resnet_f16x3.hip", "rqs_resnet_f16x3_kernel.hpp", "f16x3_gemm.hpp", "bf16x3_gemm.hpp", "rqs_resnet_f16_kernel.hpp", "k8h_common.hpp",
                              "rqs_fused8.hpp", "rqs_math.hpp", "fused_common.hpp", "common.hpp"),
     "k7b_pmc_traffic.json": ("rqs_fused_linear.hip", "rqs_math.hpp", "fused_common.hpp", "common.hpp"),
     "k7_pmc_traffic.json": ("rqs_fused_linear.hip", "rqs_math.hpp", "fused_common.hpp", "common.hpp"),
@@ -761,12 +761,16 @@ def main():
         timing_note = ("HIP start/stop events attached to each layer-kernel dispatch on its launch "
                        "stream (hipExtLaunchKernelGGL), all launches of the timed region")
 
-        ENGINES = {   # pieces per operand, products per multiply-add, weight-stream bytes per layer, counter file
-            "f16x3": ("three f16 pieces (33 significand bits: the fp32 operand exactly)", 5, "f16",
+        # pieces per operand, products per multiply-add, the same in instruction TIME at the 16-bit rate (K8x: its two
+        # 2^-22-level products run on the bf8 MX instruction, twice the f16 rate: 3 + 2 / 2), pipe, weight-stream bytes per
+        # layer, counter file
+        ENGINES = {
+            "f16x3": ("three f16 pieces (33 significand bits: the fp32 operand exactly; the two smallest of the five cross "
+                      "products from the pieces' high bytes on v_mfma_scale_f32_32x32x64_f8f6f4, bf8 x bf8)", 5, 4.0, "f16 + bf8",
                       (2 + 16 * nb_ + 2 * (dt_ * 24 // 32)) * 12288, "k8x_pmc_traffic.json"),
-            "f16x2": ("two f16 pieces (22 significand bits)", 3, "f16",
+            "f16x2": ("two f16 pieces (22 significand bits)", 3, 3.0, "f16",
                       (2 + 8 * nb_ + dt_ * 24 // 32) * 16384, "k8h_pmc_traffic.json"),   # (+ the parameter stage)
-            "bf16x3": ("three bf16 pieces (24 significand bits)", 6, "bf16",
+            "bf16x3": ("three bf16 pieces (24 significand bits)", 6, 6.0, "bf16",
                        (2 + 16 * nb_ + 2 * (dt_ * 24 // 32)) * 12288, "k8_pmc_traffic.json"),
         }
 
@@ -784,8 +788,8 @@ def main():
                 # reference's F.linear calls do -- over the launch duration.  The kernels do that work on the 16-bit matrix
                 # pipe with split operands: `matrix_pipe` says what the pipe itself executed
                 # (products per multiply-add x the same flops) and how busy that kept it.
-                pieces, products, pipe, weight_bytes, traffic_file = ENGINES[engine] if path == "k8" else \
-                    ("three bf16 pieces (24 significand bits)", 6, "bf16", 0, "k7b_pmc_traffic.json")
+                pieces, products, slots, pipe, weight_bytes, traffic_file = ENGINES[engine] if path == "k8" else \
+                    ("three bf16 pieces (24 significand bits)", 6, 6.0, "bf16", 0, "k7b_pmc_traffic.json")
                 macs = dt_ * P_ * H_ + ((D - dt_) * H_ + nb_ * 2 * H_ * H_ if path == "k8" else 0)
                 fp32_flops = 2.0 * B * macs * layers_per_launch
                 ach = fp32_flops / (avg_ms * 1e-3) / 1e12
@@ -799,17 +803,20 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_,
                      "frac_of_fp32_matrix_peak": ach / 157.3,
                      "matrix_pipe": {"operands": pieces, "products_per_multiply_add": products,
+                                     "instruction_time_per_multiply_add_at_the_16_bit_rate": slots,
                                      "executed_flops_per_launch": products * fp32_flops,
-                                     "achieved": products * ach, "unit": "TFLOP/s", "frac_of_peak": products * ach / BF16_PEAK_TFLOPS},
+                                     "achieved": slots * ach, "unit": "TFLOP/s (16-bit-rate equivalents)",
+                                     "frac_of_peak": slots * ach / BF16_PEAK_TFLOPS},
                      "frac_of_hbm_peak_by_survey_bytes": (k1_bytes * layers_per_launch / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
                      "note": "achieved = SURVEY 8d's algorithmic flops -- 2 x the fp32 multiply-adds of the layers' GEMMs, "
                              "%d per sample and layer -- / the launch duration; peak = the dense 16-bit MFMA peak of the pipe "
                              "the kernel runs on (the same work against the fp32 matrix peak of 157.3 TFLOP/s: %.2f x).  Every "
                              "fp32 operand is %s and %d cross products per multiply-add run on the %s matrix pipe with fp32 "
-                             "accumulation: the pipe executed %.0f TFLOP/s = %.3f of its peak.  The same launch in SURVEY 8d's "
+                             "accumulation, %.1f instruction times at the 16-bit rate: the pipe was busy for %.0f TFLOP/s of "
+                             "16-bit-rate work = %.3f of its peak.  The same launch in SURVEY 8d's "
                              "unfused HBM bytes (3460 B/sample/layer): %.0f GB/s-equivalent of 8000"
-                             % (2 * macs, ach / 157.3, pieces, products, pipe, products * ach,
-                                products * ach / BF16_PEAK_TFLOPS, k1_bytes * layers_per_launch / (avg_ms * 1e-3) / 1e9)}
+                             % (2 * macs, ach / 157.3, pieces, products, pipe, slots, slots * ach,
+                                slots * ach / BF16_PEAK_TFLOPS, k1_bytes * layers_per_launch / (avg_ms * 1e-3) / 1e9)}
             elif path == "k7":
                 flops = 2.0 * B * H_ * dt_ * P_
                 ach = flops / (avg_ms * 1e-3) / 1e12
@@ -871,7 +878,8 @@ def main():
             # fp32 inputs, outputs, spline arithmetic and accumulation; what the TIMED kernel multiplies in its GEMMs is said here
             "dtype": ({"f16x3": "f32 (inputs, outputs, spline arithmetic, accumulation; conditioner GEMMs: every fp32 operand carried as "
                                 "3 f16 pieces = 33 significand bits, i.e. at the reference's own fp32 operand width, 5 cross products per "
-                                "multiply-add on the f16 MFMA pipe, fp32 accumulate; other_engines_extra: the same step on 2 f16 pieces, "
+                                "multiply-add -- 3 on the f16 MFMA, the 2 at the 2^-22 level from the pieces' high bytes on the bf8 MX "
+                                "MFMA --, fp32 accumulate; other_engines_extra: the same step on 2 f16 pieces, "
                                 "on 3 bf16 pieces and on fp32 library GEMMs)",
                        "f16x2": "f32 (conditioner GEMMs: each fp32 operand as 2 f16 pieces, 3 cross products on the f16 MFMA pipe, fp32 "
                                 "accumulate -- 22-bit operand significands)",

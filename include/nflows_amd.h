@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NFA_ABI_VERSION 12 /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 7; round 4: 8,
+#define NFA_ABI_VERSION 13 /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 7; round 4: 8,
                               9: whole-layer kernels for 2 .. 16 bins, nfa_resnet_backward_f32, W_f^T in K14's backward stream;
                               round 5: 10: `bin_idx` outputs of the spline kernels, nfa_searchsorted_f32; 11: NFA_FLAG_RESIDUAL_BLOCKS;
                               round 6: 12: nfa_rqs_flow_resnet_f16x3_f32 (K8x), the *_logits_f32 diagnostic entries,
@@ -365,7 +365,10 @@ int nfa_rqs_flow_resnet_f16x2_f32(const float *inputs, const void *stream_packed
  *                    initial_layer and the blocks' Linears (k-major): per pair of k-steps TWO stages -- output tiles 0, 1 and
  *                    tiles 2, 3 --, each [2 tiles][H ks0, L ks0, H ks1, L ks1, X lo, X hi];
  *                    final_layer (tile-major): per 32-row tile two stages of four k-steps each,
- *                    [H0 .. H3][L0 .. L3][X01 lo, X01 hi, X23 lo, X23 hi].
+ *                    [H0, L0, H1, L1][H2, L2, H3, L3][X01 lo, X01 hi, X23 lo, X23 hi]
+ *                  (fragments 0 .. 3 of EVERY stage are the f16 fragments its first MFMAs need: the kernel reads them ahead,
+ *                  right behind the previous stage's barrier).  Final-layer rows per feature: 24 for 8 bins (K7's row
+ *                  order), otherwise K8's general rule, 16 ceil((3 num_bins - 1) / 16).
  *   bias_packed    K8's order; every GEMM's biases x S T (its own T), S = act_scale.
  *   scales         float [num_layers][2 + 2 num_blocks][2]: per GEMM in execution order {1 / T, T}; the final layer's
  *                  pair is {kappa = 1 / (S T), S T}: the spline evaluation reads logits = accumulators x kappa.
@@ -374,8 +377,8 @@ int nfa_rqs_flow_resnet_f16x2_f32(const float *inputs, const void *stream_packed
  *                  |v S| >= 65520 overflows and poisons the row block (next line).
  *   redo_blocks    as for nfa_rqs_flow_resnet_f16x2_f32: 1 = the 128-row block produced a non-finite value and
  *                  nothing of it was written; run nfa_rqs_flow_resnet_redo_f32 (K8's blobs) behind it.
- * Supported: num_bins = 8, linear tails, ReLU blocks, no context, hidden_features = 128, d_i <= 64, d_t % 4 == 0,
- * d_t <= 64, features % 4 == 0, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED (callers: K8).
+ * Supported: num_bins from 2 to 16 and 20, 24, 32, linear tails, ReLU blocks, no context, hidden_features = 128, d_i <= 64,
+ * d_t % 4 == 0, d_t <= 64, features % 4 == 0, features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED (callers: K8).
  */
 int nfa_rqs_flow_resnet_f16x3_f32(const float *inputs, const void *weights_packed, const float *bias_packed,
                                   const float *scales, const int32_t *flow_tables, int32_t num_layers,
@@ -440,6 +443,24 @@ int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float *inputs, const void *stream
                                          int32_t features, int32_t num_transform, int32_t num_identity,
                                          int32_t hidden_features, int32_t num_blocks,
                                          const nfa_rqs_spec *spec, int32_t flags, void *stream);
+
+/*
+ * K8c (ABI 13, round 6): K8s's run of whole coupling layers with every GEMM split by COLUMNS over the four waves of a
+ * 64-row workgroup (csrc/rqs_resnet_f16c.hip) -- the form for batches that give a CU at most one 64-row block
+ * (`Flow.sample(n)` / `log_prob` of a few thousand rows: flows/base.py:51-75, distributions/base.py:69-84; replaces the
+ * same reference code as nfa_rqs_flow_resnet_f16x2_f32).  Arguments, results, `redo_blocks` convention (bit 1 / bit 2 of
+ * a 128-row block's word = its lower / upper 64 rows were not written) and restrictions as for
+ * nfa_rqs_flow_resnet_f16x2_tile16_f32; `stream_packed` differs in the FINAL layer's stages only: per round r of four
+ * groups of four transformed features twelve stages, stage 2 i + s = for every wave w (fragment pairs 2 w, 2 w + 1)
+ * k-steps 2 s, 2 s + 1 of 16-row tile i of group 4 r + w (K8s's row order within a group; zero fragments for groups
+ * beyond d_t / 4): stages per layer = param_stages + (d_i > 32 ? 2 : 1) + 8 num_blocks + 12 ceil(d_t / 16).
+ */
+int nfa_rqs_flow_resnet_f16x2_colsplit_f32(const float *inputs, const void *stream_packed, int32_t param_stages,
+                                           const int32_t *final_positions, int32_t num_layers, float *outputs,
+                                           float *logabsdet, int32_t *redo_blocks, int32_t *status, int64_t batch,
+                                           int32_t features, int32_t num_transform, int32_t num_identity,
+                                           int32_t hidden_features, int32_t num_blocks,
+                                           const nfa_rqs_spec *spec, int32_t flags, void *stream);
 
 /*
  * Diagnostic twins of the two launches above (round 5): the SAME kernels compiled with one more store, for the bench's

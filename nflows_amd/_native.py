@@ -34,7 +34,7 @@ ACTIVATION_RELU, ACTIVATION_LEAKY_RELU, ACTIVATION_ELU, ACTIVATION_TANH = 0, 1, 
 TAILS_NONE, TAILS_LINEAR = 0, 1
 SCALE_DEFAULT, SCALE_GENERAL, SCALE_ADDITIVE, SCALE_GIVEN, SCALE_SOFTPLUS = 0, 1, 2, 3, 4
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 EXPORTS = (
     "nfa_abi_version",
@@ -59,6 +59,7 @@ EXPORTS = (
     "nfa_resnet_backward_f32",
     "nfa_rqs_flow_resnet_f16x2_f32",
     "nfa_rqs_flow_resnet_f16x2_tile16_f32",
+    "nfa_rqs_flow_resnet_f16x2_colsplit_f32",
     "nfa_rqs_flow_resnet_f16x2_bins_f32",
     "nfa_rqs_flow_resnet_f16x2_tile16_bins_f32",
     "nfa_rqs_flow_resnet_context_f16x2_f32",
@@ -184,6 +185,8 @@ def _declare(lib):
     lib.nfa_rqs_flow_resnet_f16x2_f32.argtypes = [vp, vp, i32, vp, i32] + [vp] * 4 + [i64, i32, i32, i32, i32, i32, sp, i32, vp]
     lib.nfa_rqs_flow_resnet_f16x2_tile16_f32.restype = ctypes.c_int
     lib.nfa_rqs_flow_resnet_f16x2_tile16_f32.argtypes = lib.nfa_rqs_flow_resnet_f16x2_f32.argtypes
+    lib.nfa_rqs_flow_resnet_f16x2_colsplit_f32.restype = ctypes.c_int
+    lib.nfa_rqs_flow_resnet_f16x2_colsplit_f32.argtypes = lib.nfa_rqs_flow_resnet_f16x2_f32.argtypes
     for fn in (lib.nfa_rqs_flow_resnet_f16x2_bins_f32, lib.nfa_rqs_flow_resnet_f16x2_tile16_bins_f32):
         fn.restype = ctypes.c_int
         fn.argtypes = lib.nfa_rqs_flow_resnet_f16x2_f32.argtypes + [vp]

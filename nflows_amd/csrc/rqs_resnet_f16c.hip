@@ -1,0 +1,626 @@
+// K8c (round 6): the whole-layer kernel of rqs_resnet_f16s.hip (K8s: ResidualNet conditioner, nn/nets/resnet.py:55-100,
+// + everything K1 replaces, coupling.py:73-130, :549-582, for a run of layers in one launch; GEMMs on two f16 pieces per
+// fp32 operand, 16-sample tiles on v_mfma_f32_16x16x32_f16) with the GEMMs split by COLUMNS over the four waves of a
+// 64-row workgroup -- the small-batch form: `Flow.sample(n)` / `log_prob` of a few thousand rows (flows/base.py:51-75,
+// distributions/base.py:69-84) and the per-GPU shard of a many-GPU job.
+//
+// Why.  K8s gives every wave 16 rows and ALL output columns: one wave per SIMD then walks dependent chains -- fragment
+// read -> 24 MFMAs on one or two accumulator tiles per stage -> conversion -> next GEMM -- with nothing to overlap them
+// (0.65 ms for 8 192 rows whatever the ring depth; the weight stream alone would allow 0.2).
+// Here wave w owns output tiles 2 w, 2 w + 1 (32 of the 128 hidden columns) of every hidden GEMM for all FOUR 16-row
+// tiles of the workgroup: eight accumulator tiles, four independent MFMA chains per weight fragment, a quarter of the
+// fragment reads.  The next GEMM needs every column of every row tile as its B operand: each wave converts its 32 x 64
+// block to f16 pieces and leaves them in an LDS exchange buffer -- in B-fragment layout: k-step S of the next GEMM IS
+// wave S's block (K8s's chaining rule, ops._k8s_column_order) -- one extra barrier per GEMM.  The final layer is split by
+// FEATURES: wave w takes group G = 4 r + w of four features in round r (six 16-row tiles: the 24 logits of feature
+// 4 G + g land in lane group g as in K8s) for all four row tiles, its B operand -- all 128 k of all four row tiles --
+// resident in registers (one wave per SIMD: 512 registers); a stage of the final layer carries two k-steps of ONE tile of
+// every wave (pairs 2 w, 2 w + 1), so that every stage feeds all four waves.
+//
+// Stream: K8s's stages and parameter words for the initial layer and the blocks (16 KB stages of eight (hi, lo) fragment
+// pairs, pair T = output tile T of one 32-wide k-step); final layer: per round of four groups 12 stages, stage 2 i + s =
+// k-steps 2 s, 2 s + 1 of tile i of every wave's group (ops.pack_resnet_conditioner_f16(..., colsplit=True); groups
+// beyond d_t / 4 are zero fragments).  Software pipeline as in K8x: the fragments a stage's first MFMAs need are read
+// right behind the previous stage's barrier, the barrier stands between the two halves of a stage's MFMAs.
+//
+// Restrictions: K8s's (8 bins, linear tails, no context, hidden width 128, ReLU blocks, d_i <= 64, d_t % 4 == 0,
+// d_t <= 64, D % 4 == 0, D <= 128, batch % 128 == 0).  Workgroups of four waves = 64 rows: `redo_blocks` as for K8s's
+// four-wave form (bit 1 / bit 2 of a 128-row block's word = its lower / upper 64 rows).
+
+#include "k8h_common.hpp"
+
+namespace nfa {
+namespace k8c {
+
+using namespace k8h;
+
+constexpr int kNW = 4, kThreads = kNW * kWave, kRows = 64;
+constexpr int kRowPadC = 65;        // [column][64 rows + 1]
+constexpr int kRingC = 4;
+constexpr int kXVec4 = 4 * 4 * 2 * 64;   // exchange buffer: [k-step S][row tile][hi, lo][64 lanes] x 16 B = 32 KB
+typedef vec4f f32x4;
+using Stream = WeightStream<kNW, kRingC>;
+
+#ifdef NFA_ABL_NO_MFMA   // (timing ablations: results are garbage)
+#define NFA_K8C_MFMA(a, b, c) (c)
+#else
+#define NFA_K8C_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#endif
+#define NFA_K8C_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifdef NFA_K8C_TRACE   // (debug build: cycle stamps of wave 0 of every workgroup, second layer of its first row block)
+#define NFA_K8C_STAMP(i)                                                                              \
+    if (a.trace != nullptr && layer == 1 && quad == blockIdx.x && tid == 0) a.trace[(size_t)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter();
+#else
+#define NFA_K8C_STAMP(i)
+#endif
+
+// pairs 2 w, 2 w + 1 of a stage: the wave's two fragment pairs
+struct Lead {
+    vec4f h0, l0, h1, l1;
+};
+__device__ __forceinline__ Lead read_lead(const Stream& sm, int wave, int lane) {
+    const vec4f* p = sm.ring + sm.slot * kStageVec4 + wave * 256 + lane;   // pair g at g * 128 vec4: hi, + 64: lo
+    return Lead{p[0], p[64], p[128], p[192]};
+}
+
+// End of a stage's ring traffic.  K8h / K8s read the next stage's first fragments BEFORE the barrier that ends a stage, so
+// their rule is "stage s + 2 has landed at barrier s".  Here every read of stage s + 1 is issued behind barrier s: it is
+// enough that this thread's share of stage s + 1 has landed there -- the shares of stages s + 2 and s + 3 (four requests per
+// thread each) may still be in flight: vmcnt(8).  The slot of stage s is free behind the barrier (every wave's reads of it
+// landed: lgkmcnt(0)), and the request that refills it (stage s + 4) goes out AT ONCE rather than at the next stage's
+// start: a request has three whole stage times to land instead of one and a half -- a stage of 24 MFMAs (0.17 us) is much
+// shorter than the DMA latency of a stream that misses L2 (21 MB of weights per pass; traced: ~0.4 us).
+__device__ __forceinline__ void advance_and_request(Stream& sm) {
+    static_assert(kRingC == 4 && kNW == 4, "vmcnt(8) = two stages of four requests per thread");
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    sm.slot = ring_next<Stream>(sm.slot);
+    stream_request(sm);
+}
+
+// the three products of one weight fragment pair with the pieces of the four row tiles: four independent chains
+__device__ __forceinline__ void products(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, vec4f ahw, vec4f alw, const uvec4 (&bh)[4],
+                                         const uvec4 (&bl)[4]) {
+    const f16x8 ah = __builtin_bit_cast(f16x8, ahw), al = __builtin_bit_cast(f16x8, alw);
+    const f16x8 bh0 = __builtin_bit_cast(f16x8, bh[0]), bh1 = __builtin_bit_cast(f16x8, bh[1]);
+    const f16x8 bh2 = __builtin_bit_cast(f16x8, bh[2]), bh3 = __builtin_bit_cast(f16x8, bh[3]);
+    const f16x8 bl0 = __builtin_bit_cast(f16x8, bl[0]), bl1 = __builtin_bit_cast(f16x8, bl[1]);
+    const f16x8 bl2 = __builtin_bit_cast(f16x8, bl[2]), bl3 = __builtin_bit_cast(f16x8, bl[3]);
+    // (smallest terms first, as K8s)
+    a0 = NFA_K8C_MFMA(al, bh0, a0);
+    a1 = NFA_K8C_MFMA(al, bh1, a1);
+    a2 = NFA_K8C_MFMA(al, bh2, a2);
+    a3 = NFA_K8C_MFMA(al, bh3, a3);
+    a0 = NFA_K8C_MFMA(ah, bl0, a0);
+    a1 = NFA_K8C_MFMA(ah, bl1, a1);
+    a2 = NFA_K8C_MFMA(ah, bl2, a2);
+    a3 = NFA_K8C_MFMA(ah, bl3, a3);
+    a0 = NFA_K8C_MFMA(ah, bh0, a0);
+    a1 = NFA_K8C_MFMA(ah, bh1, a1);
+    a2 = NFA_K8C_MFMA(ah, bh2, a2);
+    a3 = NFA_K8C_MFMA(ah, bh3, a3);
+    // the operands stay live past the last product (rqs_resnet_f16s.hip: hipcc otherwise puts a renamed four-register
+    // result on the registers of an operand that has just had its last use while the matrix pipe may still read it)
+    asm volatile("" ::"v"(ah), "v"(al), "v"(bh0), "v"(bh1), "v"(bh2), "v"(bh3), "v"(bl0), "v"(bl1), "v"(bl2), "v"(bl3));
+}
+
+// pieces of k-step S for the four row tiles from the exchange buffer
+__device__ __forceinline__ void read_pieces(const uvec4* X, int S, int lane, uvec4 (&bh)[4], uvec4 (&bl)[4]) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        bh[rt] = X[((S * 4 + rt) * 2 + 0) * 64 + lane];
+        bl[rt] = X[((S * 4 + rt) * 2 + 1) * 64 + lane];
+    }
+}
+
+// One k-major stage = one 32-wide k-step: the wave's two output tiles x four row tiles.  NEXT_S >= 0: the pieces of
+// k-step NEXT_S are read behind the barrier together with the next stage's fragments.
+template <int NEXT_S>
+__device__ __forceinline__ void stage_kmajor(f32x4 (&acc)[4][2], Lead& lead, uvec4 (&bh)[4], uvec4 (&bl)[4], Stream& sm, const uvec4* X,
+                                             int wave, int lane) {
+    products(acc[0][0], acc[1][0], acc[2][0], acc[3][0], lead.h0, lead.l0, bh, bl);
+    NFA_K8C_FENCE();
+    advance_and_request(sm);   // every read of this stage has landed, the next stage is complete
+    const Lead next = read_lead(sm, wave, lane);
+    uvec4 nh[4], nl[4];
+    if constexpr (NEXT_S >= 0) read_pieces(X, NEXT_S, lane, nh, nl);
+    NFA_K8C_FENCE();
+    products(acc[0][1], acc[1][1], acc[2][1], acc[3][1], lead.h1, lead.l1, bh, bl);
+    NFA_K8C_FENCE();
+    lead = next;
+    if constexpr (NEXT_S >= 0) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            bh[rt] = nh[rt];
+            bl[rt] = nl[rt];
+        }
+    }
+}
+
+// 128 -> 128 GEMM on the pieces in the exchange buffer (four stages)
+__device__ __forceinline__ void gemm_hidden(f32x4 (&acc)[4][2], Lead& lead, Stream& sm, const uvec4* X, int wave, int lane) {
+    uvec4 bh[4], bl[4];
+    read_pieces(X, 0, lane, bh, bl);
+    stage_kmajor<1>(acc, lead, bh, bl, sm, X, wave, lane);
+    stage_kmajor<2>(acc, lead, bh, bl, sm, X, wave, lane);
+    stage_kmajor<3>(acc, lead, bh, bl, sm, X, wave, lane);
+    stage_kmajor<-1>(acc, lead, bh, bl, sm, X, wave, lane);
+}
+
+// The wave's 32 columns x 64 rows (x `scale`, ReLU'd when RELU) -> f16 pieces in the exchange buffer: k-step `wave` of
+// the next GEMM (accumulator tiles 2 w, 2 w + 1 of a row tile are the eight k values lane (n, g) holds of it).  Every
+// wave's reads of the buffer's previous contents landed before the last stage's barrier; a barrier of its own makes the
+// new contents visible.  (The guard orders the conversions -- asm blocks the hazard recogniser does not look into --
+// behind the matrix pipe's write-back of the GEMM's last products.)
+template <bool RELU>
+__device__ __forceinline__ void exchange(f32x4 (&acc)[4][2], uvec4* X, int wave, int lane, float scale, float& worst) {
+    asm volatile("s_nop 7\n\ts_nop 3"
+                 : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),
+                   "+v"(acc[3][0]), "+v"(acc[3][1]));
+    float peak = 0.0f;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        uvec4 h, l;
+        unsigned hi, lo;
+        convert_pair<RELU ? kActRelu : kActNone, false>(acc[rt][0][0], acc[rt][0][1], scale, peak, hi, lo);
+        h[0] = hi;
+        l[0] = lo;
+        convert_pair<RELU ? kActRelu : kActNone, false>(acc[rt][0][2], acc[rt][0][3], scale, peak, hi, lo);
+        h[1] = hi;
+        l[1] = lo;
+        convert_pair<RELU ? kActRelu : kActNone, false>(acc[rt][1][0], acc[rt][1][1], scale, peak, hi, lo);
+        h[2] = hi;
+        l[2] = lo;
+        convert_pair<RELU ? kActRelu : kActNone, false>(acc[rt][1][2], acc[rt][1][3], scale, peak, hi, lo);
+        h[3] = hi;
+        l[3] = lo;
+        X[((wave * 4 + rt) * 2 + 0) * 64 + lane] = h;
+        X[((wave * 4 + rt) * 2 + 1) * 64 + lane] = l;
+    }
+    worst = __builtin_fmaxf(worst, peak * scale);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// one stage of the final layer: k-steps 2 HS, 2 HS + 1 of the wave's current tile, four row tiles
+template <int HS>
+__device__ __forceinline__ void stage_final(f32x4 (&t)[4], Lead& lead, const uvec4 (&fh)[4][4], const uvec4 (&fl)[4][4], Stream& sm,
+                                            int wave, int lane) {
+    products(t[0], t[1], t[2], t[3], lead.h0, lead.l0, fh[2 * HS], fl[2 * HS]);
+    NFA_K8C_FENCE();
+    advance_and_request(sm);
+    const Lead next = read_lead(sm, wave, lane);
+    NFA_K8C_FENCE();
+    products(t[0], t[1], t[2], t[3], lead.h1, lead.l1, fh[2 * HS + 1], fl[2 * HS + 1]);
+    NFA_K8C_FENCE();
+    lead = next;
+}
+
+template <class Steps, int I, int END>
+__device__ __forceinline__ void run_range(Steps& f, const RqsDev& sp) {
+    if constexpr (I < END) {
+        constexpr int N = Steps::kNumSlices;
+        if constexpr (I < N) f.template num_w<I>();
+        else if constexpr (I < 2 * N) f.template num_h<I - N>();
+        else f.template finish<I - 2 * N>(sp);
+        run_range<Steps, I + 1, END>(f, sp);
+    }
+}
+
+__device__ __forceinline__ void load_bias4(f32x4& acc, const float* p) { acc = *reinterpret_cast<const vec4f*>(p); }
+
+template <bool INVERSE, int INIT_KS>
+__global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    __shared__ int s_final[128];
+    __shared__ int s_bad[kNW];
+    __shared__ float s_red[2][kNW][kRows];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = a.D, dt = a.dt;
+    int my_status = 0;
+    {   // (every thread: entry tid mod 128)
+        const int te = tid & 127;
+        const int v = a.final_tab[te];
+        my_status |= (te < D && (v < 0 || v >= D)) ? NFA_STATUS_BAD_INDEX : 0;
+        s_final[te] = v < 0 ? 0 : (v >= D ? D - 1 : v);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no ordinary load in flight once the stream starts)
+
+    Stream sm;
+    sm.w = a.w;
+    sm.ring = reinterpret_cast<vec4f*>(lds_dyn);
+    sm.fetch = 0;
+    sm.num_stages = a.num_stages * a.num_layers;
+    sm.tid = tid;
+    sm.sync = 0;
+    sm.gen = kNW;
+    sm.peek = 0;
+#pragma unroll
+    for (int j = 0; j < kRingC; ++j) {   // stages 0 .. RING - 1 -> slots 0 .. RING - 1 (stage s + RING is requested behind stage s's barrier)
+        sm.slot = ring_next<Stream>(j, 1);
+        stream_request(sm);
+    }
+    sm.slot = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int pblock = (a.param_words + 3) & ~3;
+    uvec4* X = reinterpret_cast<uvec4*>(lds_dyn + kRingC * kStageVec4 * 4);
+    float* s_row = lds_dyn + kRingC * kStageVec4 * 4 + kXVec4 * 4;            // [D][kRowPadC]
+    float* s_param = s_row + D * kRowPadC;                                     // [2][pblock]
+    const int groups = dt >> 2;
+    const int rounds = (groups + 3) >> 2;
+    const int64_t num_quads = a.batch / kRows;
+    const int g = lane >> 4, n = lane & 15;
+    int pb = 0;
+
+    for (int64_t quad = blockIdx.x; quad < num_quads; quad += gridDim.x) {
+        const int64_t row0 = quad * kRows;
+        // ---- the workgroup's 64 rows: one coalesced read; slot j of the tile = input column j
+        {
+            const vec4f* xv = reinterpret_cast<const vec4f*>(a.x + row0 * D);
+            const int nvec = D * (kRows / 4);
+            for (int e = tid; e < nvec; e += kThreads) {
+                const vec4f v = xv[e];
+                const int rr = (e * 4) / D, c0 = e * 4 - rr * D;
+                s_row[(c0 + 0) * kRowPadC + rr] = v.x;
+                s_row[(c0 + 1) * kRowPadC + rr] = v.y;
+                s_row[(c0 + 2) * kRowPadC + rr] = v.z;
+                s_row[(c0 + 3) * kRowPadC + rr] = v.w;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        float lad_acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // per row tile: rows 16 rt + n (this lane's features)
+        float worst = 0.0f;
+        int quad_status = 0;
+        for (int layer = 0; layer < a.num_layers; ++layer) {
+            // ---- the layer's parameter stage(s): ring -> parameter block `pb` (every wave passes its barrier: the
+            //      previous layer's spline results in the row tile are visible behind it)
+            float* prm = s_param + pb * pblock;
+            NFA_K8C_STAMP(0)
+            for (int p = 0; p < a.param_stages; ++p) {
+                const vec4f* src = sm.ring + sm.slot * kStageVec4;
+                vec4f* dst = reinterpret_cast<vec4f*>(prm) + p * kParamVec4;
+                const int used = (pblock >> 2) - p * kParamVec4;
+                for (int i = tid; i < (used < kParamVec4 ? used : kParamVec4); i += kThreads) {
+                    vec4f v = src[i];
+                    if (p == 0 && i < kTabWords / 4) {
+                        uvec4 u = __builtin_bit_cast(uvec4, v);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int idx = i * 4 + c;
+                            const int e = (int)u[c];
+                            const bool used_entry = idx < kTabTr ? idx < a.di : idx - kTabTr < dt;
+                            my_status |= (used_entry && (e < 0 || e >= D)) ? NFA_STATUS_BAD_INDEX : 0;
+                            u[c] = (unsigned)(e < 0 ? 0 : (e >= D ? D - 1 : e));
+                        }
+                        v = __builtin_bit_cast(vec4f, u);
+                    }
+                    dst[i] = v;
+                }
+                advance_and_request(sm);
+            }
+            NFA_K8C_STAMP(1)
+            Lead lead = read_lead(sm, wave, lane);   // the first weight stage's fragments
+            const int* tab = reinterpret_cast<const int*>(prm);
+            const float* gemm = prm + kTabWords;   // header + biases of the next GEMM
+            pb ^= 1;
+
+            f32x4 hacc[4][2];   // the residual stream h of the wave's 32 columns, fp32 (x the scale of the GEMM that wrote it)
+            // ---- initial layer on the identity features (scale 1): k = 32 S + 8 g + j
+            {
+                const float* bias = gemm + kHdr + (2 * wave) * 16 + g * 4;
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    load_bias4(hacc[rt][0], bias);
+                    load_bias4(hacc[rt][1], bias + 16);
+                }
+#pragma unroll
+                for (int S = 0; S < INIT_KS; ++S) {
+                    uvec4 ih[4], il[4];
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+                        for (int j2 = 0; j2 < 4; ++j2) {
+                            const int i0 = S * 32 + g * 8 + j2 * 2;
+                            float v0 = s_row[tab[kTabId + i0] * kRowPadC + rt * 16 + n];
+                            float v1 = s_row[tab[kTabId + i0 + 1] * kRowPadC + rt * 16 + n];
+                            v0 = i0 < a.di ? v0 : 0.0f;
+                            v1 = i0 + 1 < a.di ? v1 : 0.0f;
+                            unsigned hi, lo;
+                            split2(v0, v1, hi, lo);
+                            ih[rt][j2] = hi;
+                            il[rt][j2] = lo;
+                        }
+                    }
+                    stage_kmajor<-1>(hacc, lead, ih, il, sm, X, wave, lane);
+                }
+            }
+            float conv_scale = gemm[0];
+            gemm += kHdr + 128;
+            NFA_K8C_STAMP(2)
+            if (a.num_blocks > 0) exchange<true>(hacc, X, wave, lane, conv_scale, worst);
+            else exchange<false>(hacc, X, wave, lane, conv_scale, worst);
+            NFA_K8C_STAMP(3)
+
+            // ---- residual blocks: h += W_1 relu(W_0 relu(h) + b_0) + b_1
+            for (int blk = 0; blk < a.num_blocks; ++blk) {
+                f32x4 u[4][2];
+                {
+                    const float* bias = gemm + kHdr + (2 * wave) * 16 + g * 4;
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+                        load_bias4(u[rt][0], bias);
+                        load_bias4(u[rt][1], bias + 16);
+                    }
+                    gemm_hidden(u, lead, sm, X, wave, lane);
+                    conv_scale = gemm[0];
+                }
+                gemm += kHdr + 128;
+                NFA_K8C_STAMP(4 + blk * 4)
+                exchange<true>(u, X, wave, lane, conv_scale, worst);
+                NFA_K8C_STAMP(5 + blk * 4)
+                {
+                    // the second Linear accumulates into the residual stream itself: hacc = hacc * ratio + bias, then + W_1 relu(u)
+                    const float* bias = gemm + kHdr + (2 * wave) * 16 + g * 4;
+                    const float ratio = gemm[1];
+                    const vec4f b0 = *reinterpret_cast<const vec4f*>(bias), b1 = *reinterpret_cast<const vec4f*>(bias + 16);
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            hacc[rt][0][i] = __builtin_fmaf(hacc[rt][0][i], ratio, b0[i]);
+                            hacc[rt][1][i] = __builtin_fmaf(hacc[rt][1][i], ratio, b1[i]);
+                        }
+                    }
+                    gemm_hidden(hacc, lead, sm, X, wave, lane);
+                    conv_scale = gemm[0];
+                }
+                gemm += kHdr + 128;
+                NFA_K8C_STAMP(6 + blk * 4)
+                // pieces of relu(h) for the next block, of h itself for the final layer (no ReLU in front of it: resnet.py:99-100)
+                if (blk + 1 < a.num_blocks) exchange<true>(hacc, X, wave, lane, conv_scale, worst);
+                else exchange<false>(hacc, X, wave, lane, conv_scale, worst);
+                NFA_K8C_STAMP(7 + blk * 4)
+            }
+
+            // ---- final layer: wave w evaluates group G = 4 r + w in round r; the six tiles of the group hold the 24 logits
+            //      of this lane's feature 4 G + g for the four row tiles
+            {
+                using Steps = FusedSteps<INVERSE, 8>;
+                const float kappa = gemm[0];
+                const float tail_s = a.sp.tail_logit * gemm[1];   // gemm[1] = 1 / kappa
+                uvec4 fh[4][4], fl[4][4];   // [k-step][row tile]
+#pragma unroll
+                for (int S = 0; S < 4; ++S) read_pieces(X, S, lane, fh[S], fl[S]);
+                NFA_K8C_STAMP(20)
+                for (int r = 0; r < rounds; ++r) {
+                    const int G = 4 * r + wave;
+                    const int Gc = G < groups ? G : groups - 1;   // (a wave without a group: zero fragments, nothing evaluated)
+                    const float* fbias = gemm + kHdr + (Gc * 6) * 16 + g * 4;
+                    f32x4 t[6][4];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        f32x4 b;
+                        load_bias4(b, fbias + i * 16);
+#pragma unroll
+                        for (int rt = 0; rt < 4; ++rt) t[i][rt] = b;
+                        stage_final<0>(t[i], lead, fh, fl, sm, wave, lane);
+                        stage_final<1>(t[i], lead, fh, fl, sm, wave, lane);
+                    }
+                    NFA_K8C_STAMP(21 + 2 * r)
+                    if (G < groups) {
+                        const int slot_col = tab[kTabTr + G * 4 + g] * kRowPadC;
+#pragma unroll
+                        for (int rt = 0; rt < 4; ++rt) {
+                            Steps f;
+                            f.kappa = kappa;
+                            f.kl2e = 1.44269502162933349609375f * kappa;
+                            f.tail_s = tail_s;
+                            float* slot = s_row + slot_col + rt * 16 + n;
+                            f.x = *slot;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                f.ew[j] = t[0][rt][j];
+                                f.ew[4 + j] = t[1][rt][j];
+                                f.eh[j] = t[2][rt][j];
+                                f.eh[4 + j] = t[3][rt][j];
+                                f.sd[j] = t[4][rt][j];
+                                if (j < 3) f.sd[4 + j] = t[5][rt][j];
+                            }
+#ifndef NFA_ABL_NO_WEAVE
+                            run_range<Steps, 0, 2 * Steps::kNumSlices + Steps::kFinishSlices>(f, a.sp);
+#else
+                            f.y = f.x + f.ew[0] + f.sd[6]; f.lad = f.eh[7]; f.status = 0;
+#endif
+                            *slot = f.y;
+                            lad_acc[rt] += f.lad;
+                            quad_status |= f.status;
+                        }
+                    }
+                    NFA_K8C_STAMP(22 + 2 * r)
+                }
+            }
+        }
+
+        // ---- results: position p of a row comes from slot final[p]; a block with any non-finite value or an
+        //      activation beyond the f16 range is not written: the exact kernel redoes it from the inputs
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the stream: ordinary stores / loads follow
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            lad_acc[rt] += __shfl_xor(lad_acc[rt], 16, kWave);
+            lad_acc[rt] += __shfl_xor(lad_acc[rt], 32, kWave);
+        }
+        // (lane group g leaves row tile g's sum: one store per lane)
+        s_red[0][wave][lane] = g == 0 ? lad_acc[0] : g == 1 ? lad_acc[1] : g == 2 ? lad_acc[2] : lad_acc[3];
+        __syncthreads();   // every wave's spline results and log-determinant shares
+        {
+            float sumsq = 0.0f;
+            for (int j = wave; j < a.Ds; j += kNW) {
+                const float v = s_row[j * kRowPadC + lane];
+                sumsq = __builtin_fmaf(v, v, sumsq);
+            }
+            s_red[1][wave][lane] = sumsq;
+        }
+        const bool wave_bad = __builtin_amdgcn_ballot_w64(!(worst < kF16Overflow)) != 0;
+        if (lane == 0) s_bad[wave] = wave_bad ? 1 : 0;
+        __syncthreads();
+        const float lad_row = (s_red[0][0][lane] + s_red[0][1][lane]) + (s_red[0][2][lane] + s_red[0][3][lane]);
+        const float sumsq_row = (s_red[1][0][lane] + s_red[1][1][lane]) + (s_red[1][2][lane] + s_red[1][3][lane]);
+        const bool bad = !(__builtin_fabsf(lad_row) < INFINITY) || !(__builtin_fabsf(sumsq_row) < INFINITY);
+        const bool quad_bad = (__builtin_amdgcn_ballot_w64(bad) != 0) || ((s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) != 0);
+        if (!quad_bad) {
+            if (!a.skip_out) {
+                const int nvec = D * (kRows / 4);
+                vec4f* ov = reinterpret_cast<vec4f*>(a.out + row0 * D);
+                for (int e = tid; e < nvec; e += kThreads) {
+                    const int rr = (e * 4) / D, c0 = e * 4 - rr * D;
+                    vec4f v;
+                    v.x = s_row[s_final[c0 + 0] * kRowPadC + rr];
+                    v.y = s_row[s_final[c0 + 1] * kRowPadC + rr];
+                    v.z = s_row[s_final[c0 + 2] * kRowPadC + rr];
+                    v.w = s_row[s_final[c0 + 3] * kRowPadC + rr];
+                    ov[e] = v;
+                }
+            }
+            if (wave == 0) {
+                float* dst = a.lad + row0 + lane;
+                float v = a.accumulate ? *dst + lad_row : lad_row;
+                if (a.normal) v = (-0.5f * sumsq_row - a.log_z) + v;   // normal.py:31-33, flows/base.py:49
+                *dst = v;
+            }
+            my_status |= quad_status;
+        }
+        // one flag per 128 rows, zeroed by the launcher: bit 1 / bit 2 = its lower / upper 64 rows are open
+        if (tid == 0 && quad_bad) atomicOr(a.redo + (quad >> 1), 2 << (quad & 1));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // the row tile, s_bad and s_red are rewritten by the next row block
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (my_status && a.status) atomicOr(a.status, my_status);
+}
+
+__global__ void zero_words_kernel(int32_t* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
+}  // namespace k8c
+}  // namespace nfa
+
+using namespace nfa;
+
+extern "C" int nfa_rqs_flow_resnet_f16x2_colsplit_f32(const float* inputs, const void* stream_packed, int32_t param_stages,
+                                                      const int32_t* final_positions, int32_t num_layers, float* outputs,
+                                                      float* logabsdet, int32_t* redo_blocks, int32_t* status, int64_t batch,
+                                                      int32_t features, int32_t num_transform, int32_t num_identity,
+                                                      int32_t hidden_features, int32_t num_blocks, const nfa_rqs_spec* spec,
+                                                      int32_t flags, void* stream) {
+    if (flags & ~(NFA_FLAG_INVERSE | NFA_FLAG_ACCUMULATE_LOGABSDET | NFA_FLAG_STANDARD_NORMAL_LOG_PROB |
+                  NFA_FLAG_SKIP_OUTPUTS | NFA_FLAG_PAD_COLUMNS_MASK))
+        return NFA_ERR_INVALID_ARGUMENT;
+    if (!density_flags_valid(flags)) return NFA_ERR_INVALID_ARGUMENT;
+    if (batch < 0 || features < 1 || num_transform < 1 || num_identity < 1 || num_transform > features ||
+        num_identity > features || num_blocks < 0 || num_layers < 1 || param_stages < 1)
+        return NFA_ERR_INVALID_ARGUMENT;
+    k8h::Args a;
+    int rc = make_dev_spec(spec, &a.sp);
+    if (rc != NFA_OK) return rc;
+    if (a.sp.beta != 1.0f) return NFA_ERR_UNSUPPORTED;
+    if (a.sp.K != 8 || !a.sp.linear || hidden_features != 128 || (num_transform & 3) != 0 || num_transform > 64 ||
+        num_identity > 64 || features > 128 || (features & 3) != 0 || (batch & 127) != 0 || num_blocks > 64 ||
+        num_layers > 4096)
+        return NFA_ERR_UNSUPPORTED;
+    const int param_words = k8h::kTabWords + (k8h::kHdr + 128) * (1 + 2 * num_blocks) + k8h::kHdr + num_transform * 24;
+    if (param_stages * 2048 < param_words || param_stages > 4) return NFA_ERR_INVALID_ARGUMENT;
+    if (batch == 0) return NFA_OK;
+    if (!inputs || !stream_packed || !final_positions || !logabsdet || !redo_blocks ||
+        (!outputs && !(flags & NFA_FLAG_SKIP_OUTPUTS)))
+        return NFA_ERR_INVALID_ARGUMENT;
+    a.ctx = nullptr;
+    a.ce = 0;
+    a.dbg_bins = nullptr;
+    a.dbg_logits = nullptr;
+    a.normal = (flags & NFA_FLAG_STANDARD_NORMAL_LOG_PROB) ? 1 : 0;
+    a.skip_out = (flags & NFA_FLAG_SKIP_OUTPUTS) ? 1 : 0;
+    a.Ds = density_columns(flags, features);
+    if (a.Ds < 1) return NFA_ERR_INVALID_ARGUMENT;
+    a.log_z = standard_normal_log_z(a.Ds);
+    a.x = inputs;
+    a.w = reinterpret_cast<const vec4f*>(stream_packed);
+    a.final_tab = final_positions;
+    a.out = outputs;
+    a.lad = logabsdet;
+    a.redo = redo_blocks;
+    a.status = status;
+    a.batch = batch;
+    a.D = features;
+    a.dt = num_transform;
+    a.di = num_identity;
+    a.num_blocks = num_blocks;
+    a.num_layers = num_layers;
+    a.param_stages = param_stages;
+    a.param_words = param_words;
+    const int init_ks = num_identity > 32 ? 2 : 1;
+    // stages per layer: parameters, one per k-step of the initial layer, four per hidden Linear, twelve per round of four
+    // groups of four transformed features
+    const int rounds = (num_transform / 4 + 3) / 4;
+    a.num_stages = param_stages + init_ks + 8 * num_blocks + 12 * rounds;
+    a.accumulate = (flags & NFA_FLAG_ACCUMULATE_LOGABSDET) ? 1 : 0;
+    a.trace = nullptr;
+#ifdef NFA_K8C_TRACE
+    static unsigned long long* trace_dev = nullptr;
+    if (!trace_dev) hipMalloc(&trace_dev, 256 * 64 * 8);
+    hipMemset(trace_dev, 0, 256 * 64 * 8);
+    a.trace = trace_dev;
+#endif
+    const size_t lds = (size_t)k8c::kRingC * k8h::kStageVec4 * 16 + (size_t)k8c::kXVec4 * 16 +
+                       (size_t)features * k8c::kRowPadC * sizeof(float) + (size_t)2 * ((param_words + 3) & ~3) * sizeof(float);
+    const size_t lds_cap = 160 * 1024 - 4096;   // (beside 2.6 KB of static arrays)
+    if (lds > lds_cap) return NFA_ERR_UNSUPPORTED;
+    int64_t blocks = batch / k8c::kRows;
+    const int cus = device_cu_count();
+    if (blocks > cus) blocks = cus;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    profile_next_launch(&e0, &e1);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)blocks), block(k8c::kThreads);
+    const bool inv = (flags & NFA_FLAG_INVERSE) != 0;
+    void (*kern)(const k8h::Args) = nullptr;
+    const int which = (inv ? 1 : 0) + (init_ks == 2 ? 2 : 0);
+    switch (which) {
+        case 0: kern = k8c::rqs_resnet_f16c_kernel<false, 1>; break;
+        case 1: kern = k8c::rqs_resnet_f16c_kernel<true, 1>; break;
+        case 2: kern = k8c::rqs_resnet_f16c_kernel<false, 2>; break;
+        default: kern = k8c::rqs_resnet_f16c_kernel<true, 2>; break;
+    }
+    note_layer_kernel("k8c::rqs_resnet_f16c_kernel<inverse=%d, init_ks=%d, waves=4, K=8, ring=%d>", inv ? 1 : 0, init_ks, k8c::kRingC);
+    hipLaunchKernelGGL(k8c::zero_words_kernel, dim3((unsigned)((batch / 128 + 255) / 256)), dim3(256), 0, st, redo_blocks,
+                       (int)(batch / 128));
+    if (lds > 64 * 1024) {
+        static unsigned long long raised[4] = {};   // device masks (raise_dynamic_lds)
+        const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], (int)lds_cap);
+        if (rc_lds != NFA_OK) return rc_lds;
+    }
+    if (e0) hipExtLaunchKernelGGL(kern, grid, block, lds, st, e0, e1, 0, a);
+    else hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+    NFA_HIP_CHECK(hipGetLastError());
+#ifdef NFA_K8C_TRACE
+    {
+        static int calls = 0;
+        if (++calls == 20) {
+            hipDeviceSynchronize();
+            static unsigned long long host[256 * 64];
+            hipMemcpy(host, trace_dev, sizeof(host), hipMemcpyDeviceToHost);
+            for (int b = 0; b < 2; ++b) {
+                fprintf(stderr, "k8c trace block %d:", b);
+                for (int i = 1; i < 30; ++i)
+                    if (host[b * 64 + i]) fprintf(stderr, " [%d]%lld", i, (long long)(host[b * 64 + i] - host[b * 64]));
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+#endif
+    return NFA_OK;
+}

@@ -1,36 +1,44 @@
 // K8x (round 6): the whole-layer kernel -- ResidualNet conditioner, nn/nets/resnet.py:55-100 (forward :92-100, blocks
 // :39-52), + everything K1 replaces, coupling.py:73-130, :549-582, for a RUN of layers in one launch -- with its GEMMs
-// on the f16 matrix pipe from THREE f16 pieces per fp32 operand, five cross products per multiply-add (f16x3_gemm.hpp):
-// operands carried at the reference's width (nn/nets/resnet.py:92-100 is F.linear on fp32: 24-bit significands; the
-// three pieces hold 33), at 5/6 of the matrix time of the three-piece bf16 kernel (K8, rqs_resnet.hip) whose
-// structure this kernel keeps:
+// on the matrix pipe from THREE f16 pieces per fp32 operand (f16x3_gemm.hpp): operands carried at the reference's width
+// (nn/nets/resnet.py:92-100 is F.linear on fp32: 24-bit significands; the three pieces hold 33).  Five cross products
+// per multiply-add: hi hi, hi lo, lo hi on v_mfma_f32_32x32x16_f16; the two at the 2^-22 level, hi r and r hi, need
+// two significant bits of each factor and run on ONE v_mfma_scale_f32_32x32x64_f8f6f4 (bf8 x bf8) per two k-steps --
+// the activation's bf8 bytes are the HIGH BYTES of its f16 pieces (one v_perm_b32 per register), the weight's are
+// packed by the host, the last pieces are kept x 2^8 and the instruction's e8m0 block scale takes the factor out:
+// 4 instruction times per k-step against the three-piece bf16 kernel's 6 (K8, rqs_resnet.hip), whose structure this
+// kernel keeps:
 //
 //   * a wave owns 32 rows for the whole run; the rows live in an LDS tile by slot, every GEMM is computed transposed
 //     and chained through the register file (the accumulator tiles of one GEMM are the B operand of the next, up to
 //     a column permutation the host applies to the weights);
 //   * the residual stream is NOT kept in fp32: its three pieces are exact, the skip connection rebuilds the value
-//     from them (two v_fma_mix_f32 per value), the first ReLU of a block is a sign mask on the pieces;
-//   * weights: 12 KB stages of [4 tiles][3 pieces][64 lanes] x 16 B (k-major) / [3 pieces][4 k-steps][64 lanes]
-//     (tile-major final layer) through the three-slot LDS-DMA ring of bf16x3_gemm.hpp, four waves per workgroup, two
-//     workgroups per CU;
+//     from them (two v_fma_mix_f32 per value), the first ReLU of a block is a sign mask on the pieces; block order:
+//     skip first (v = bias + T p), then u's pieces, then the second Linear (K8's order spilled 12 GB per launch here);
+//   * weights: 12 KB stages of twelve 1 KB fragments ([64 lanes] x 16 B) -- k-major: two k-steps of two output tiles,
+//     [H0, L0, H1, L1, X lo, X hi] per tile; tile-major final layer: four k-steps of a tile, [H0, L0, H1, L1][H2, L2,
+//     H3, L3][X01 lo, X01 hi, X23 lo, X23 hi] -- through the three-slot LDS-DMA ring of bf16x3_gemm.hpp, four waves per
+//     workgroup, two workgroups per CU; fragments 0 .. 3 of every stage are read right behind the PREVIOUS stage's
+//     barrier (f16x3_gemm.hpp: Lead), the barrier stands in front of a stage's last MFMAs;
 //   * the final layer is tile-major with the spline evaluation (rqs_fused8.hpp: one walk over fp32 running knot
-//     sums, logits read at scale 1 / kappa straight from the accumulators) woven between its MFMAs, 40 slots per tile.
+//     sums, logits read at scale 1 / kappa straight from the accumulators) woven between its MFMAs: 32 time units per
+//     tile (an f16 MFMA one, a bf8 MFMA two).
 //
 // What f16 pieces need that bf16 pieces did not -- range.  Every GEMM's weights are multiplied by a power of two T
 // before the split (host: max |w T| in [2^13, 2^14)), activations -- the row tile's identity features included -- are
-// split at scale S (a power of two, host: 16): a value keeps all its 24 bits while |v S| >= 2^-1 (the last piece then
-// is >= 2^-24, f16's smallest subnormal), below that the absolute error is <= 2^-25 / S; |v S| >= 65520 overflows.
-// Accumulators hold S T x (the reference's pre-activation); `scales` = per GEMM {1 / T, T}: 1 / T takes an accumulator
-// to the next pieces' scale (exact), T takes the residual stream's pieces to the second Linear's accumulator scale;
-// the final layer's pair is {kappa = 1 / (S T), S T} for the spline evaluation.  Overflow poisons (hi = inf, lo = -inf,
-// r = NaN, and ReLU's sign mask keeps NaN): a row block with any non-finite result writes nothing and raises its entry
-// of `redo`, the caller runs K8 (three bf16 pieces: full fp32 range) on the flagged blocks right behind
-// (nfa_rqs_flow_resnet_redo_f32), as for K8h.
+// split at scale S (a power of two, host: 16): a value keeps all its 24 bits while |v S| >= 2^-9 (the last piece,
+// kept x 2^8, then is >= 2^-24, f16's smallest subnormal), below that the absolute error is <= 2^-33 / S; |v S| >=
+// 65520 overflows.  Accumulators hold S T x (the reference's pre-activation); `scales` = per GEMM {1 / T, T}: 1 / T
+// takes an accumulator to the next pieces' scale (exact), T takes the residual stream's pieces to the second Linear's
+// accumulator scale; the final layer's pair is {kappa = 1 / (S T), S T} for the spline evaluation.  Overflow poisons
+// (hi = inf, lo = -inf, r = NaN, and ReLU's sign mask keeps NaN): a row block with any non-finite result writes
+// nothing and raises its entry of `redo`, the caller runs K8 (three bf16 pieces: full fp32 range) on the flagged
+// blocks right behind (nfa_rqs_flow_resnet_redo_f32), as for K8h.
 //
-// Served: 2 .. 16, 20, 24 or 32 bins (8: the two-features-per-three-tiles final layer; the others K8h's general scheme),
-// linear tails, ReLU blocks, no context, hidden width 128 (narrower: zero-padded by the host),
-// d_i <= 64, d_t % 4 == 0, d_t <= 64, D % 4 == 0, D <= 128, batch % 128 == 0.  DBG instances (tests): the logits of
-// the run's LAST layer (accumulators x kappa) are stored as well.
+// Served: 2 .. 16, 20, 24 or 32 bins (8: the two-features-per-three-tiles final layer; the others K8h's general scheme:
+// rqs_resnet_f16x3_bins_{a,b}.hip), linear tails, ReLU blocks, no context, hidden width 128 (narrower: zero-padded by
+// the host), d_i <= 64, d_t % 4 == 0, d_t <= 64, D % 4 == 0, D <= 128, batch % 128 == 0.  DBG instances (tests, 8
+// bins): the logits of the run's LAST layer (accumulators x kappa) are stored as well.
 
 #include "rqs_resnet_f16x3_kernel.hpp"
 
@@ -107,9 +115,6 @@ static int launch_f16x3(const float* inputs, const void* weights_packed, const f
     const bool inv = (flags & NFA_FLAG_INVERSE) != 0;
     void (*kern)(const k8x::Args) = nullptr;
     int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) + (dbg_logits ? 4 : 0);
-#ifdef NFA_K8X_STATUS_DEBUG
-    which &= 3;
-#endif
     if (a.sp.K != 8) {
         which = 8 + (a.sp.K - 2) * 4 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0);
         kern = k8x::bins_kernel_a(a.sp.K, inv, init_ks);

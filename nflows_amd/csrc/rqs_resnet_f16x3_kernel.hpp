@@ -237,9 +237,6 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16x3_kernel(const Args 
 
         float lad_acc = 0.0f;
         int quad_status = 0;
-#ifdef NFA_K8X_STATUS_DEBUG
-        int dbg_first = -1;
-#endif
         for (int layer = 0; layer < a.num_layers; ++layer) {
             // the two workgroups resident on a CU take turns at the higher issue priority (see rqs_resnet_kernel.hpp)
             if ((layer + (blockIdx.x >= (gridDim.x >> 1) ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1);
@@ -450,9 +447,6 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16x3_kernel(const Args 
                     quad_status |= f.status;
                 }
             }
-#ifdef NFA_K8X_STATUS_DEBUG
-            if ((quad_status & ~7) && dbg_first < 0) dbg_first = layer;
-#endif
             tb ^= 1;
             // this wave's spline results must be visible to its own gathers of the next layer
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -493,15 +487,6 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_f16x3_kernel(const Args 
                 if (a.normal) v = (-0.5f * sumsq - a.log_z) + v;   // normal.py:31-33, flows/base.py:49
                 *dst = v;
             }
-#ifdef NFA_K8X_STATUS_DEBUG
-            if (a.dbg_logits != nullptr) {
-                int* dbg = reinterpret_cast<int*>(a.dbg_logits) + ((size_t)quad * kBlock + tid) * 4;
-                dbg[0] = dbg_first;
-                dbg[1] = quad_status;
-                dbg[2] = my_status;
-                dbg[3] = 0x600D;
-            }
-#endif
             my_status |= quad_status;
         }
         if (tid == 0) a.redo[quad] = any_bad ? 1 : 0;

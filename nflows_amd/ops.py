@@ -1506,7 +1506,7 @@ def _f16_weight_scale(w):
 
 
 def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scale=1.0, pad_transform_to=None,
-                                pad_identity_to=None, tile16=False):
+                                pad_identity_to=None, tile16=False, colsplit=False):
     """Packs a ResidualNet for K8h (csrc/rqs_resnet_f16.hip; layout in include/nflows_amd.h).
 
     Weights: every GEMM's weights as TWO f16 pieces of (weight x T), T a power of two chosen per
@@ -1521,7 +1521,10 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
     (that scale) when it prepares its accumulators.  8 bins only.
     `tile16`: the same network for K8s (csrc/rqs_resnet_f16s.hip: 16-sample tiles on the 16x16x32 MFMA) -- the same
     stages and parameter words with the fragments, column / row orders and bias order of that tile shape (no
-    context, 8 bins).
+    context, 8 bins).  `colsplit` (with `tile16`): for K8c (csrc/rqs_resnet_f16c.hip, round 6: the four waves of a 64-row
+    workgroup split every GEMM by columns) -- K8s's stages and words, except the final layer: per ROUND of four groups of
+    four features twelve stages, stage 2 i + s holding for every wave w (pairs 2 w, 2 w + 1) k-steps 2 s, 2 s + 1 of tile
+    i of group 4 r + w; groups beyond d_t / 4 are zero fragments.
     Returns (weights [stages, 4096] f16, parameter words fp32)."""
     dt, P = num_transform, params_per_feature
     K = (P + 1) // 3
@@ -1606,7 +1609,15 @@ def pack_resnet_conditioner_f16(net, num_transform, params_per_feature, act_scal
     wf = wf.index_select(0, order_r).index_select(1, order_k)
     bf = torch.cat((bf, bf.new_zeros(dt, R - P)), dim=1).reshape(dt * R).index_select(0, order_r)
     T = _f16_weight_scale(wf)
-    if tile16:
+    if tile16 and colsplit:
+        groups = dt // 4
+        rounds = (groups + 3) // 4
+        pc = pieces(wf * T).view(2, groups, 6, 16, 4, 4, 8)                       # (p, G, i, m, S, g, j)
+        if rounds * 4 > groups:
+            pc = torch.cat((pc, pc.new_zeros(2, rounds * 4 - groups, 6, 16, 4, 4, 8)), dim=1)
+        # (p, r, w, i, m, s, q, g, j) -> (r, i, s, w, q, p, g, m, j): pair 2 w + q of stage (r, i, s) = k-step 2 s + q
+        stages.append(pc.view(2, rounds, 4, 6, 16, 2, 2, 4, 8).permute(1, 3, 5, 2, 6, 0, 7, 4, 8).reshape(rounds * 12, -1))
+    elif tile16:
         # tile-major, two 16-row tiles per stage: (p, tile, m, S, g, j) -> (tile, S, p, g, m, j)
         tiles = dt * R // 16
         stages.append(pieces(wf * T).view(2, tiles, 16, 4, 4, 8).permute(1, 3, 0, 4, 2, 5).reshape(tiles // 2, -1))
@@ -1839,19 +1850,25 @@ def activation_code(fn):
 
 K8S_ENABLED = os.environ.get("NFA_K8S", "1") != "0"
 K8S_ALWAYS = os.environ.get("NFA_K8S", "1") == "2"     # (measurements: the 16-sample-tile kernel at every batch size)
+K8C_ENABLED = os.environ.get("NFA_K8C", "0") != "0"    # the column-split form of K8s for batches of at most 64 rows per CU (off until it beats K8s)
+K8C_ALWAYS = os.environ.get("NFA_K8C", "0") == "2"
 _cu_counts = {}
 
 
 def use_tile16(batch, num_bins, context, device, activation=0):
     """K8s (16-sample tiles, csrc/rqs_resnet_f16s.hip) serves the batches that give a CU at most ONE 128-row block
-    -- K8h would run them one wave per SIMD (or leave CUs idle): 8 bins, no context.  `NFA_K8S=0` switches it off."""
+    -- K8h would run them one wave per SIMD (or leave CUs idle): 8 bins, no context.  `NFA_K8S=0` switches it off.
+    Returns 0 (K8h), 1 (K8s) or 2 (round 6: K8c, csrc/rqs_resnet_f16c.hip, the column-split form: batches that give a CU
+    at most one 64-row block; `NFA_K8C=0` switches it off, the diagnostic bin capture has no twin of it)."""
     if not K8S_ENABLED or num_bins != 8 or context is not None or activation != N.ACTIVATION_RELU:
-        return False
+        return 0
     key = device.index if device.index is not None else torch.cuda.current_device()
     cus = _cu_counts.get(key)
     if cus is None:
         cus = _cu_counts[key] = torch.cuda.get_device_properties(key).multi_processor_count
-    return K8S_ALWAYS or (batch + 127) // 128 <= cus
+    if K8C_ENABLED and capture_last_layer_bins.active is None and (K8C_ALWAYS or (batch + 63) // 64 <= cus):
+        return 2
+    return 1 if (K8S_ALWAYS or (batch + 127) // 128 <= cus) else 0
 
 
 class capture_last_layer_bins:
@@ -1882,7 +1899,8 @@ def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transf
     non-finite inputs.  `stream_f16`: (stream, parameter stages per layer, final table) from
     `build_f16_stream`; `packed_exact`: (weights, biases) from pack_resnet_conditioner; `tables`:
     the run's `flow_layer_tables` (for the exact kernel).  `tile16`: `stream_f16` was packed for K8s
-    (pack_resnet_conditioner_f16(tile16=True)) and the launch goes to the 16-sample-tile kernel.
+    (pack_resnet_conditioner_f16(tile16=True)) and the launch goes to the 16-sample-tile kernel; 2: packed for K8c
+    (`colsplit=True`), the column-split form.
     Results as for `rqs_coupling_resnet`."""
     N.require_device_f32("inputs", inputs, 2)
     if pad is not None and inputs.shape[1] != pad[0]:   # (see rqs_coupling_resnet)
@@ -1937,7 +1955,8 @@ def rqs_coupling_resnet_f16(inputs, stream_f16, packed_exact, tables, num_transf
                 N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128,
                 num_blocks, ctypes.byref(spec), flags, N.stream_handle(dev), N.ptr(capture.bins))
         elif ctx is None:
-            entry = lib.nfa_rqs_flow_resnet_f16x2_tile16_f32 if tile16 else lib.nfa_rqs_flow_resnet_f16x2_f32
+            entry = (lib.nfa_rqs_flow_resnet_f16x2_colsplit_f32 if tile16 == 2 else
+                     lib.nfa_rqs_flow_resnet_f16x2_tile16_f32 if tile16 else lib.nfa_rqs_flow_resnet_f16x2_f32)
             rc = entry(
                 N.ptr(x), N.ptr(stream), param_stages, N.ptr(final_table), num_layers, N.ptr(out),
                 N.ptr(lad), N.ptr(redo), N.ptr(_status_word(dev)), B, D, num_transform, num_identity, 128,

@@ -315,7 +315,7 @@ class CompositeTransform(Transform):
         f16 = (not mlp) and first._use_f16(geometry)
         x3 = (not mlp) and first._use_f16x3(geometry)     # K8x: three f16 pieces per operand (engine "f16x3")
         # (the key reads version counters only; the layers' packed blobs are looked at on a miss)
-        tile16 = tile16 and f16
+        tile16 = tile16 if f16 else 0
         ids = units.__dict__.get("_ids") if isinstance(units, _Run) else None
         if ids is None:
             ids = tuple([id(c) for c, _ in units])
@@ -386,7 +386,7 @@ class CompositeTransform(Transform):
                 inputs, plan_f16, (weights, biases), tables, dt4,
                 di_u, len(first.transform_net.blocks), first._spec(), inverse,
                 total, num_layers=len(units), standard_normal_log_prob=standard_normal_log_prob, pad=pad,
-                context=context, tile16=tile16 and first._use_f16(_run_geometry(units)), activation=act)
+                context=context, tile16=tile16 if first._use_f16(_run_geometry(units)) else 0, activation=act)
             if head is None and tile16:
                 # K8s declined (its ring + 16-row buffers + two copies of the parameter words exceed the LDS budget:
                 # about six blocks at D = 128): K8h takes these shapes -- its own stream, the same call

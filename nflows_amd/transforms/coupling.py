@@ -623,6 +623,9 @@ class PiecewiseCouplingTransform(CouplingTransform):
         return self._piecewise_cdf(inputs, transform_params, inverse)
 
 
+_F16_PACK_SLOTS = ("_packed_resnet_f16_cache", "_packed_resnet_f16s_cache", "_packed_resnet_f16c_cache")   # K8h, K8s, K8c
+
+
 class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
     """Neural-spline-flow coupling layer; coupling.py:502-582.
 
@@ -837,24 +840,26 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         return cached[1]
 
     def _packed_resnet_f16(self, geometry=None, tile16=False):
-        """(weights, parameter words) for K8h, or -- `tile16` -- for K8s (the 16-sample-tile kernel of small batches)."""
+        """(weights, parameter words) for K8h, or -- `tile16` = 1 / 2 (ops.use_tile16) -- for K8s / K8c (the 16-sample-tile
+        kernels of small batches)."""
         net = self.transform_net
         _, dt4, di_u, _ = geometry or self._fused_geometry()
         key = (self.conditioner_act_scale, dt4, di_u, tile16) + _weights_key(self, net)
-        slot = "_packed_resnet_f16s_cache" if tile16 else "_packed_resnet_f16_cache"
+        slot = _F16_PACK_SLOTS[int(tile16)]
         cached = self.__dict__.get(slot)
         if cached is None or cached[0] != key:
             cached = (key, ops.pack_resnet_conditioner_f16(self._folded_net(), self.num_transform_features,
                                                            self._transform_dim_multiplier(),
                                                            act_scale=self.conditioner_act_scale,
-                                                           pad_transform_to=dt4, pad_identity_to=di_u, tile16=tile16))
+                                                           pad_transform_to=dt4, pad_identity_to=di_u, tile16=bool(tile16),
+                                                           colsplit=int(tile16) == 2))
             self.__dict__[slot] = cached
         return cached[1]
 
     def _f16_stream(self, tables, tile16=False):
         """K8h / K8s stream of this layer alone (its parameter stage carries `tables`), cached per table set."""
         pack = self._packed_resnet_f16(tile16=tile16)
-        key = (self.__dict__["_packed_resnet_f16s_cache" if tile16 else "_packed_resnet_f16_cache"][0],
+        key = (self.__dict__[_F16_PACK_SLOTS[int(tile16)]][0],
                tables.data_ptr(), tables._version)
         cache = self.__dict__.setdefault("_f16_stream_cache", {})
         hit = cache.get(key)

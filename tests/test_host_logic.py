@@ -392,6 +392,39 @@ def test_f16x3_packing_of_the_other_bin_counts(K):
             assert abs(got_b - ref_b) <= 1e-6 * max(1.0, abs(ref_b)), (t, i)
 
 
+@pytest.mark.parametrize("dt", [32, 12, 4])
+def test_f16_colsplit_packing_is_the_tile16_packing_rearranged(dt):
+    """Host side of K8c (ops.pack_resnet_conditioner_f16(tile16=True, colsplit=True), round 6): parameter words and every
+    stage in front of the final layer are K8s's; the final layer's fragment pairs are K8s's, regrouped -- pair 2 w + q of
+    stage (round r, tile i, half s) = K8s's pair of tile 6 (4 r + w) + i, k-step 2 s + q --, zero fragments for the groups a
+    wave has none of in the last round."""
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import ResidualNet
+    torch.manual_seed(dt)
+    di, P, blocks = 20, 23, 2
+    net = ResidualNet(di, dt * P, hidden_features=128, num_blocks=blocks).float()
+    ws, prm_s = ops.pack_resnet_conditioner_f16(net, dt, P, tile16=True)
+    wc, prm_c = ops.pack_resnet_conditioner_f16(net, dt, P, tile16=True, colsplit=True)
+    assert torch.equal(prm_s, prm_c)
+    head = 1 + 8 * blocks                       # one 32-wide k-step of the initial layer, four per hidden Linear
+    groups, rounds = dt // 4, (dt // 4 + 3) // 4
+    assert ws.shape == (head + groups * 3, 8192) and wc.shape == (head + rounds * 12, 8192)
+    assert torch.equal(ws[:head], wc[:head])
+    fs = ws[head:].view(groups * 3, 8, 1024)    # [stage = tile pair][pair = 4 (tile % 2) + k-step][hi | lo: 512 f16 each]
+    fc = wc[head:].view(rounds, 6, 2, 4, 2, 1024)   # [r][i][s][w][q]
+    for r in range(rounds):
+        for w in range(4):
+            G = 4 * r + w
+            for i in range(6):
+                for S in range(4):
+                    got = fc[r, i, S // 2, w, S % 2]
+                    if G >= groups:
+                        assert not got.view(torch.int16).any()
+                        continue
+                    tile = 6 * G + i
+                    assert torch.equal(got.view(torch.int16), fs[tile // 2, 4 * (tile % 2) + S].view(torch.int16)), (r, w, i, S)
+
+
 @pytest.mark.parametrize("di", [6, 40])
 def test_f16x3_whole_layer_packing_carries_the_scales(di):
     """Host side of K8x (ops.pack_resnet_conditioner_f16x3, round 6): emulate csrc/rqs_resnet_f16x3.hip's data flow on one
