@@ -36,10 +36,8 @@ using namespace k8h;
 
 constexpr int kNW = 4, kThreads = kNW * kWave, kRows = 64;
 constexpr int kRowPadC = 65;        // [column][64 rows + 1]
-constexpr int kRingC = 4;
 constexpr int kXVec4 = 4 * 4 * 2 * 64;   // exchange buffer: [k-step S][row tile][hi, lo][64 lanes] x 16 B = 32 KB
 typedef vec4f f32x4;
-using Stream = WeightStream<kNW, kRingC>;
 
 #ifdef NFA_ABL_NO_MFMA   // (timing ablations: results are garbage)
 #define NFA_K8C_MFMA(a, b, c) (c)
@@ -54,27 +52,17 @@ using Stream = WeightStream<kNW, kRingC>;
 #define NFA_K8C_STAMP(i)
 #endif
 
-// pairs 2 w, 2 w + 1 of a stage: the wave's two fragment pairs
-struct Lead {
+// The wave's two fragment pairs (2 w, 2 w + 1) of a 16 KB stage, straight from global memory into registers: no wave
+// reads another wave's pairs, so there is nothing to share through LDS -- and an LDS-DMA request costs its issuing wave
+// 60-185 cycles (MI355X_MICROARCH.md), four of them per wave and stage against a stage's 24 MFMAs = 400 cycles: the ring
+// of the first build cost more than the matrix work.  Plain loads, requested one GEMM (or three final-layer tiles) ahead;
+// hipcc counts them (loads return in order).
+struct Frag {
     vec4f h0, l0, h1, l1;
 };
-__device__ __forceinline__ Lead read_lead(const Stream& sm, int wave, int lane) {
-    const vec4f* p = sm.ring + sm.slot * kStageVec4 + wave * 256 + lane;   // pair g at g * 128 vec4: hi, + 64: lo
-    return Lead{p[0], p[64], p[128], p[192]};
-}
-
-// End of a stage's ring traffic.  K8h / K8s read the next stage's first fragments BEFORE the barrier that ends a stage, so
-// their rule is "stage s + 2 has landed at barrier s".  Here every read of stage s + 1 is issued behind barrier s: it is
-// enough that this thread's share of stage s + 1 has landed there -- the shares of stages s + 2 and s + 3 (four requests per
-// thread each) may still be in flight: vmcnt(8).  The slot of stage s is free behind the barrier (every wave's reads of it
-// landed: lgkmcnt(0)), and the request that refills it (stage s + 4) goes out AT ONCE rather than at the next stage's
-// start: a request has three whole stage times to land instead of one and a half -- a stage of 24 MFMAs (0.17 us) is much
-// shorter than the DMA latency of a stream that misses L2 (21 MB of weights per pass; traced: ~0.4 us).
-__device__ __forceinline__ void advance_and_request(Stream& sm) {
-    static_assert(kRingC == 4 && kNW == 4, "vmcnt(8) = two stages of four requests per thread");
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    sm.slot = ring_next<Stream>(sm.slot);
-    stream_request(sm);
+__device__ __forceinline__ Frag load_frag(const vec4f* wlane, int stage) {
+    const vec4f* p = wlane + (size_t)stage * kStageVec4;   // pair g at g * 128 vec4: hi, + 64: lo
+    return Frag{p[0], p[64], p[128], p[192]};
 }
 
 // the three products of one weight fragment pair with the pieces of the four row tiles: four independent chains
@@ -85,7 +73,7 @@ __device__ __forceinline__ void products(f32x4& a0, f32x4& a1, f32x4& a2, f32x4&
     const f16x8 bh2 = __builtin_bit_cast(f16x8, bh[2]), bh3 = __builtin_bit_cast(f16x8, bh[3]);
     const f16x8 bl0 = __builtin_bit_cast(f16x8, bl[0]), bl1 = __builtin_bit_cast(f16x8, bl[1]);
     const f16x8 bl2 = __builtin_bit_cast(f16x8, bl[2]), bl3 = __builtin_bit_cast(f16x8, bl[3]);
-    // (smallest terms first, as K8s)
+    // (smallest terms first, as K8s: the same products in the same order -- z is K8s's bit for bit)
     a0 = NFA_K8C_MFMA(al, bh0, a0);
     a1 = NFA_K8C_MFMA(al, bh1, a1);
     a2 = NFA_K8C_MFMA(al, bh2, a2);
@@ -113,20 +101,17 @@ __device__ __forceinline__ void read_pieces(const uvec4* X, int S, int lane, uve
 }
 
 // One k-major stage = one 32-wide k-step: the wave's two output tiles x four row tiles.  NEXT_S >= 0: the pieces of
-// k-step NEXT_S are read behind the barrier together with the next stage's fragments.
+// k-step NEXT_S are read between the two halves.
 template <int NEXT_S>
-__device__ __forceinline__ void stage_kmajor(f32x4 (&acc)[4][2], Lead& lead, uvec4 (&bh)[4], uvec4 (&bl)[4], Stream& sm, const uvec4* X,
-                                             int wave, int lane) {
-    products(acc[0][0], acc[1][0], acc[2][0], acc[3][0], lead.h0, lead.l0, bh, bl);
+__device__ __forceinline__ void stage_kmajor(f32x4 (&acc)[4][2], const Frag& fr, uvec4 (&bh)[4], uvec4 (&bl)[4], const uvec4* X, int lane) {
     NFA_K8C_FENCE();
-    advance_and_request(sm);   // every read of this stage has landed, the next stage is complete
-    const Lead next = read_lead(sm, wave, lane);
+    products(acc[0][0], acc[1][0], acc[2][0], acc[3][0], fr.h0, fr.l0, bh, bl);
+    NFA_K8C_FENCE();
     uvec4 nh[4], nl[4];
     if constexpr (NEXT_S >= 0) read_pieces(X, NEXT_S, lane, nh, nl);
     NFA_K8C_FENCE();
-    products(acc[0][1], acc[1][1], acc[2][1], acc[3][1], lead.h1, lead.l1, bh, bl);
+    products(acc[0][1], acc[1][1], acc[2][1], acc[3][1], fr.h1, fr.l1, bh, bl);
     NFA_K8C_FENCE();
-    lead = next;
     if constexpr (NEXT_S >= 0) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
@@ -136,62 +121,85 @@ __device__ __forceinline__ void stage_kmajor(f32x4 (&acc)[4][2], Lead& lead, uve
     }
 }
 
-// 128 -> 128 GEMM on the pieces in the exchange buffer (four stages)
-__device__ __forceinline__ void gemm_hidden(f32x4 (&acc)[4][2], Lead& lead, Stream& sm, const uvec4* X, int wave, int lane) {
+// Where the stages behind the initial layer live: a ring of four register buffers, stage k (counted from the first
+// block's first stage through the final layer's last) in buffer k mod 4 -- a hidden GEMM is four stages, a final-layer tile
+// two, a round twelve: every use has a compile-time buffer -- reloaded with stage k + 4 as soon as it is consumed; past the
+// layer's last stage: the next layer's first ones.
+struct Ahead {
+    const vec4f* wlane;
+    int here, next, total;   // stage numbers of this / the next layer's first hidden stage, stages per layer behind the initial one
+    __device__ __forceinline__ Frag load(int k) const { return load_frag(wlane, k < total ? here + k : next + (k - total)); }
+};
+
+// 128 -> 128 GEMM on the pieces in the exchange buffer (four stages, k0 = the first one's number)
+__device__ __forceinline__ void gemm_hidden(f32x4 (&acc)[4][2], Frag (&rb)[4], const Ahead& ah, int k0, const uvec4* X, int lane) {
     uvec4 bh[4], bl[4];
     read_pieces(X, 0, lane, bh, bl);
-    stage_kmajor<1>(acc, lead, bh, bl, sm, X, wave, lane);
-    stage_kmajor<2>(acc, lead, bh, bl, sm, X, wave, lane);
-    stage_kmajor<3>(acc, lead, bh, bl, sm, X, wave, lane);
-    stage_kmajor<-1>(acc, lead, bh, bl, sm, X, wave, lane);
+    stage_kmajor<1>(acc, rb[0], bh, bl, X, lane);
+    rb[0] = ah.load(k0 + 4);
+    stage_kmajor<2>(acc, rb[1], bh, bl, X, lane);
+    rb[1] = ah.load(k0 + 5);
+    stage_kmajor<3>(acc, rb[2], bh, bl, X, lane);
+    rb[2] = ah.load(k0 + 6);
+    stage_kmajor<-1>(acc, rb[3], bh, bl, X, lane);
+    rb[3] = ah.load(k0 + 7);
+    NFA_K8C_FENCE();
 }
 
 // The wave's 32 columns x 64 rows (x `scale`, ReLU'd when RELU) -> f16 pieces in the exchange buffer: k-step `wave` of
-// the next GEMM (accumulator tiles 2 w, 2 w + 1 of a row tile are the eight k values lane (n, g) holds of it).  Every
-// wave's reads of the buffer's previous contents landed before the last stage's barrier; a barrier of its own makes the
-// new contents visible.  (The guard orders the conversions -- asm blocks the hazard recogniser does not look into --
-// behind the matrix pipe's write-back of the GEMM's last products.)
+// the next GEMM (accumulator tiles 2 w, 2 w + 1 of a row tile are the eight k values lane (n, g) holds of it).  A barrier
+// in front (every wave has read the buffer's previous contents: its last reads are two MFMA groups old) and one behind
+// (the new contents are visible).  (The guard orders the conversions -- asm blocks the hazard recogniser does not look
+// into -- behind the matrix pipe's write-back of the GEMM's last products.)
 template <bool RELU>
 __device__ __forceinline__ void exchange(f32x4 (&acc)[4][2], uvec4* X, int wave, int lane, float scale, float& worst) {
     asm volatile("s_nop 7\n\ts_nop 3"
                  : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),
                    "+v"(acc[3][0]), "+v"(acc[3][1]));
     float peak = 0.0f;
+    uvec4 h[4], l[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-        uvec4 h, l;
         unsigned hi, lo;
         convert_pair<RELU ? kActRelu : kActNone, false>(acc[rt][0][0], acc[rt][0][1], scale, peak, hi, lo);
-        h[0] = hi;
-        l[0] = lo;
+        h[rt][0] = hi;
+        l[rt][0] = lo;
         convert_pair<RELU ? kActRelu : kActNone, false>(acc[rt][0][2], acc[rt][0][3], scale, peak, hi, lo);
-        h[1] = hi;
-        l[1] = lo;
+        h[rt][1] = hi;
+        l[rt][1] = lo;
         convert_pair<RELU ? kActRelu : kActNone, false>(acc[rt][1][0], acc[rt][1][1], scale, peak, hi, lo);
-        h[2] = hi;
-        l[2] = lo;
+        h[rt][2] = hi;
+        l[rt][2] = lo;
         convert_pair<RELU ? kActRelu : kActNone, false>(acc[rt][1][2], acc[rt][1][3], scale, peak, hi, lo);
-        h[3] = hi;
-        l[3] = lo;
-        X[((wave * 4 + rt) * 2 + 0) * 64 + lane] = h;
-        X[((wave * 4 + rt) * 2 + 1) * 64 + lane] = l;
+        h[rt][3] = hi;
+        l[rt][3] = lo;
     }
     worst = __builtin_fmaxf(worst, peak * scale);
+    // (the conversions above overlap the other waves' last MFMAs; nobody may still be reading the buffer when it is written)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        X[((wave * 4 + rt) * 2 + 0) * 64 + lane] = h[rt];
+        X[((wave * 4 + rt) * 2 + 1) * 64 + lane] = l[rt];
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// one stage of the final layer: k-steps 2 HS, 2 HS + 1 of the wave's current tile, four row tiles
-template <int HS>
-__device__ __forceinline__ void stage_final(f32x4 (&t)[4], Lead& lead, const uvec4 (&fh)[4][4], const uvec4 (&fl)[4][4], Stream& sm,
-                                            int wave, int lane) {
-    products(t[0], t[1], t[2], t[3], lead.h0, lead.l0, fh[2 * HS], fl[2 * HS]);
+// one tile of the final layer (two stages: k-steps 0, 1 and 2, 3), four row tiles
+__device__ __forceinline__ void tile_final(f32x4 (&t)[4], Frag& f0, Frag& f1, const Ahead& ah, int k0, const uvec4 (&fh)[4][4],
+                                           const uvec4 (&fl)[4][4]) {
     NFA_K8C_FENCE();
-    advance_and_request(sm);
-    const Lead next = read_lead(sm, wave, lane);
+    products(t[0], t[1], t[2], t[3], f0.h0, f0.l0, fh[0], fl[0]);
     NFA_K8C_FENCE();
-    products(t[0], t[1], t[2], t[3], lead.h1, lead.l1, fh[2 * HS + 1], fl[2 * HS + 1]);
+    products(t[0], t[1], t[2], t[3], f0.h1, f0.l1, fh[1], fl[1]);
     NFA_K8C_FENCE();
-    lead = next;
+    f0 = ah.load(k0 + 4);
+    products(t[0], t[1], t[2], t[3], f1.h0, f1.l0, fh[2], fl[2]);
+    NFA_K8C_FENCE();
+    products(t[0], t[1], t[2], t[3], f1.h1, f1.l1, fh[3], fl[3]);
+    NFA_K8C_FENCE();
+    f1 = ah.load(k0 + 5);
+    NFA_K8C_FENCE();
 }
 
 template <class Steps, int I, int END>
@@ -206,6 +214,23 @@ __device__ __forceinline__ void run_range(Steps& f, const RqsDev& sp) {
 }
 
 __device__ __forceinline__ void load_bias4(f32x4& acc, const float* p) { acc = *reinterpret_cast<const vec4f*>(p); }
+
+// a parameter stage's words (its first 8 KB) -> the parameter block, table entries checked and clamped
+__device__ __forceinline__ void store_params(float* prm, vec4f v, int i, int nvec, const Args& a, int& my_status) {
+    if (i < kTabWords / 4) {
+        uvec4 u = __builtin_bit_cast(uvec4, v);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int idx = i * 4 + c;
+            const int e = (int)u[c];
+            const bool used_entry = idx < kTabTr ? idx < a.di : idx - kTabTr < a.dt;
+            my_status |= (used_entry && (e < 0 || e >= a.D)) ? NFA_STATUS_BAD_INDEX : 0;
+            u[c] = (unsigned)(e < 0 ? 0 : (e >= a.D ? a.D - 1 : e));
+        }
+        v = __builtin_bit_cast(vec4f, u);
+    }
+    if (i < nvec) reinterpret_cast<vec4f*>(prm)[i] = v;
+}
 
 template <bool INVERSE, int INIT_KS>
 __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args a) {
@@ -223,35 +248,35 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
         my_status |= (te < D && (v < 0 || v >= D)) ? NFA_STATUS_BAD_INDEX : 0;
         s_final[te] = v < 0 ? 0 : (v >= D ? D - 1 : v);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no ordinary load in flight once the stream starts)
 
-    Stream sm;
-    sm.w = a.w;
-    sm.ring = reinterpret_cast<vec4f*>(lds_dyn);
-    sm.fetch = 0;
-    sm.num_stages = a.num_stages * a.num_layers;
-    sm.tid = tid;
-    sm.sync = 0;
-    sm.gen = kNW;
-    sm.peek = 0;
-#pragma unroll
-    for (int j = 0; j < kRingC; ++j) {   // stages 0 .. RING - 1 -> slots 0 .. RING - 1 (stage s + RING is requested behind stage s's barrier)
-        sm.slot = ring_next<Stream>(j, 1);
-        stream_request(sm);
-    }
-    sm.slot = 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const int pblock = (a.param_words + 3) & ~3;
-    uvec4* X = reinterpret_cast<uvec4*>(lds_dyn + kRingC * kStageVec4 * 4);
-    float* s_row = lds_dyn + kRingC * kStageVec4 * 4 + kXVec4 * 4;            // [D][kRowPadC]
-    float* s_param = s_row + D * kRowPadC;                                     // [2][pblock]
+    const int pblock = (a.param_words + 3) & ~3, pvec = pblock >> 2;   // (<= 512 vec4: one parameter stage, two per thread)
+    uvec4* X = reinterpret_cast<uvec4*>(lds_dyn);
+    float* s_row = lds_dyn + kXVec4 * 4;                  // [D][kRowPadC]
+    float* s_param = s_row + D * kRowPadC;                // [2][pblock]
     const int groups = dt >> 2;
     const int rounds = (groups + 3) >> 2;
+    const int nb = a.num_blocks;
     const int64_t num_quads = a.batch / kRows;
     const int g = lane >> 4, n = lane & 15;
+    const vec4f* wlane = a.w + wave * 256 + lane;          // this lane's 16 bytes of pair 2 w of stage 0
+    // stage numbers inside a layer: parameters, initial layer, blocks, final layer
+    const int st_init = 1, st_hidden = 1 + INIT_KS;
     int pb = 0;
+    // layer 0's parameters and initial-layer fragments
+    {
+        const vec4f* src = a.w;
+        const int i0 = tid, i1 = tid + kThreads;
+        const vec4f v0 = src[i0 < pvec ? i0 : 0], v1 = src[i1 < pvec ? i1 : 0];
+        store_params(s_param, v0, i0, pvec, a, my_status);
+        store_params(s_param, v1, i1, pvec, a, my_status);
+    }
+    Frag fi[INIT_KS];
+#pragma unroll
+    for (int S = 0; S < INIT_KS; ++S) fi[S] = load_frag(wlane, st_init + S);
+    Frag rb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rb[j] = load_frag(wlane, st_hidden + j);
+    int next_layer_stage0 = a.num_layers > 1 ? a.num_stages : 0;   // stage 0 of the layer after the current one (cyclic)
 
     for (int64_t quad = blockIdx.x; quad < num_quads; quad += gridDim.x) {
         const int64_t row0 = quad * kRows;
@@ -268,45 +293,21 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
                 s_row[(c0 + 3) * kRowPadC + rr] = v.w;
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
         float lad_acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // per row tile: rows 16 rt + n (this lane's features)
         float worst = 0.0f;
         int quad_status = 0;
         for (int layer = 0; layer < a.num_layers; ++layer) {
-            // ---- the layer's parameter stage(s): ring -> parameter block `pb` (every wave passes its barrier: the
-            //      previous layer's spline results in the row tile are visible behind it)
-            float* prm = s_param + pb * pblock;
+            const int stage0 = layer * a.num_stages;             // this layer's stage 0 in the stream
             NFA_K8C_STAMP(0)
-            for (int p = 0; p < a.param_stages; ++p) {
-                const vec4f* src = sm.ring + sm.slot * kStageVec4;
-                vec4f* dst = reinterpret_cast<vec4f*>(prm) + p * kParamVec4;
-                const int used = (pblock >> 2) - p * kParamVec4;
-                for (int i = tid; i < (used < kParamVec4 ? used : kParamVec4); i += kThreads) {
-                    vec4f v = src[i];
-                    if (p == 0 && i < kTabWords / 4) {
-                        uvec4 u = __builtin_bit_cast(uvec4, v);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const int idx = i * 4 + c;
-                            const int e = (int)u[c];
-                            const bool used_entry = idx < kTabTr ? idx < a.di : idx - kTabTr < dt;
-                            my_status |= (used_entry && (e < 0 || e >= D)) ? NFA_STATUS_BAD_INDEX : 0;
-                            u[c] = (unsigned)(e < 0 ? 0 : (e >= D ? D - 1 : e));
-                        }
-                        v = __builtin_bit_cast(vec4f, u);
-                    }
-                    dst[i] = v;
-                }
-                advance_and_request(sm);
-            }
-            NFA_K8C_STAMP(1)
-            Lead lead = read_lead(sm, wave, lane);   // the first weight stage's fragments
+            // ---- the next layer's parameter words: requested now, stored at the end of the layer
+            const vec4f* pnext = a.w + (size_t)next_layer_stage0 * kStageVec4;
+            const vec4f pn0 = pnext[tid < pvec ? tid : 0], pn1 = pnext[tid + kThreads < pvec ? tid + kThreads : 0];
+            float* prm = s_param + pb * pblock;
             const int* tab = reinterpret_cast<const int*>(prm);
             const float* gemm = prm + kTabWords;   // header + biases of the next GEMM
-            pb ^= 1;
-
+            const Ahead ah{wlane, stage0 + st_hidden, next_layer_stage0 + st_hidden, 8 * nb + 12 * rounds};
             f32x4 hacc[4][2];   // the residual stream h of the wave's 32 columns, fp32 (x the scale of the GEMM that wrote it)
             // ---- initial layer on the identity features (scale 1): k = 32 S + 8 g + j
             {
@@ -334,18 +335,18 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
                             il[rt][j2] = lo;
                         }
                     }
-                    stage_kmajor<-1>(hacc, lead, ih, il, sm, X, wave, lane);
+                    stage_kmajor<-1>(hacc, fi[S], ih, il, X, lane);
                 }
             }
             float conv_scale = gemm[0];
             gemm += kHdr + 128;
             NFA_K8C_STAMP(2)
-            if (a.num_blocks > 0) exchange<true>(hacc, X, wave, lane, conv_scale, worst);
+            if (nb > 0) exchange<true>(hacc, X, wave, lane, conv_scale, worst);
             else exchange<false>(hacc, X, wave, lane, conv_scale, worst);
             NFA_K8C_STAMP(3)
 
             // ---- residual blocks: h += W_1 relu(W_0 relu(h) + b_0) + b_1
-            for (int blk = 0; blk < a.num_blocks; ++blk) {
+            for (int blk = 0; blk < nb; ++blk) {
                 f32x4 u[4][2];
                 {
                     const float* bias = gemm + kHdr + (2 * wave) * 16 + g * 4;
@@ -354,7 +355,7 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
                         load_bias4(u[rt][0], bias);
                         load_bias4(u[rt][1], bias + 16);
                     }
-                    gemm_hidden(u, lead, sm, X, wave, lane);
+                    gemm_hidden(u, rb, ah, blk * 8, X, lane);
                     conv_scale = gemm[0];
                 }
                 gemm += kHdr + 128;
@@ -374,13 +375,13 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
                             hacc[rt][1][i] = __builtin_fmaf(hacc[rt][1][i], ratio, b1[i]);
                         }
                     }
-                    gemm_hidden(hacc, lead, sm, X, wave, lane);
+                    gemm_hidden(hacc, rb, ah, blk * 8 + 4, X, lane);
                     conv_scale = gemm[0];
                 }
                 gemm += kHdr + 128;
                 NFA_K8C_STAMP(6 + blk * 4)
                 // pieces of relu(h) for the next block, of h itself for the final layer (no ReLU in front of it: resnet.py:99-100)
-                if (blk + 1 < a.num_blocks) exchange<true>(hacc, X, wave, lane, conv_scale, worst);
+                if (blk + 1 < nb) exchange<true>(hacc, X, wave, lane, conv_scale, worst);
                 else exchange<false>(hacc, X, wave, lane, conv_scale, worst);
                 NFA_K8C_STAMP(7 + blk * 4)
             }
@@ -406,8 +407,13 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
                         load_bias4(b, fbias + i * 16);
 #pragma unroll
                         for (int rt = 0; rt < 4; ++rt) t[i][rt] = b;
-                        stage_final<0>(t[i], lead, fh, fl, sm, wave, lane);
-                        stage_final<1>(t[i], lead, fh, fl, sm, wave, lane);
+                        tile_final(t[i], rb[(2 * i) % 4], rb[(2 * i + 1) % 4], ah, 8 * nb + r * 12 + 2 * i, fh, fl);
+                        // (behind the layer's last tiles: the next layer's initial-layer fragments)
+                        if (r == rounds - 1 && i == 5) {
+#pragma unroll
+                            for (int S = 0; S < INIT_KS; ++S) fi[S] = load_frag(wlane, next_layer_stage0 + st_init + S);
+                        }
+                        NFA_K8C_FENCE();
                     }
                     NFA_K8C_STAMP(21 + 2 * r)
                     if (G < groups) {
@@ -442,11 +448,18 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
                     NFA_K8C_STAMP(22 + 2 * r)
                 }
             }
+            // ---- the next layer's parameters (the other block), and the layer's end: every wave's spline results are in
+            //      the row tile, the exchange buffer is free
+            store_params(s_param + (pb ^ 1) * pblock, pn0, tid, pvec, a, my_status);
+            store_params(s_param + (pb ^ 1) * pblock, pn1, tid + kThreads, pvec, a, my_status);
+            pb ^= 1;
+            next_layer_stage0 = next_layer_stage0 + a.num_stages;
+            if (next_layer_stage0 >= a.num_stages * a.num_layers) next_layer_stage0 = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
 
         // ---- results: position p of a row comes from slot final[p]; a block with any non-finite value or an
         //      activation beyond the f16 range is not written: the exact kernel redoes it from the inputs
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the stream: ordinary stores / loads follow
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             lad_acc[rt] += __shfl_xor(lad_acc[rt], 16, kWave);
@@ -454,7 +467,6 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
         }
         // (lane group g leaves row tile g's sum: one store per lane)
         s_red[0][wave][lane] = g == 0 ? lad_acc[0] : g == 1 ? lad_acc[1] : g == 2 ? lad_acc[2] : lad_acc[3];
-        __syncthreads();   // every wave's spline results and log-determinant shares
         {
             float sumsq = 0.0f;
             for (int j = wave; j < a.Ds; j += kNW) {
@@ -494,10 +506,8 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
         }
         // one flag per 128 rows, zeroed by the launcher: bit 1 / bit 2 = its lower / upper 64 rows are open
         if (tid == 0 && quad_bad) atomicOr(a.redo + (quad >> 1), 2 << (quad & 1));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // the row tile, s_bad and s_red are rewritten by the next row block
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (my_status && a.status) atomicOr(a.status, my_status);
 }
 
@@ -534,6 +544,7 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_colsplit_f32(const float* inputs, const
         return NFA_ERR_UNSUPPORTED;
     const int param_words = k8h::kTabWords + (k8h::kHdr + 128) * (1 + 2 * num_blocks) + k8h::kHdr + num_transform * 24;
     if (param_stages * 2048 < param_words || param_stages > 4) return NFA_ERR_INVALID_ARGUMENT;
+    if (param_stages != 1) return NFA_ERR_UNSUPPORTED;   // (the next layer's words travel in two registers per thread)
     if (batch == 0) return NFA_OK;
     if (!inputs || !stream_packed || !final_positions || !logabsdet || !redo_blocks ||
         (!outputs && !(flags & NFA_FLAG_SKIP_OUTPUTS)))
@@ -575,8 +586,8 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_colsplit_f32(const float* inputs, const
     hipMemset(trace_dev, 0, 256 * 64 * 8);
     a.trace = trace_dev;
 #endif
-    const size_t lds = (size_t)k8c::kRingC * k8h::kStageVec4 * 16 + (size_t)k8c::kXVec4 * 16 +
-                       (size_t)features * k8c::kRowPadC * sizeof(float) + (size_t)2 * ((param_words + 3) & ~3) * sizeof(float);
+    const size_t lds = (size_t)k8c::kXVec4 * 16 + (size_t)features * k8c::kRowPadC * sizeof(float) +
+                       (size_t)2 * ((param_words + 3) & ~3) * sizeof(float);
     const size_t lds_cap = 160 * 1024 - 4096;   // (beside 2.6 KB of static arrays)
     if (lds > lds_cap) return NFA_ERR_UNSUPPORTED;
     int64_t blocks = batch / k8c::kRows;
@@ -595,7 +606,7 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_colsplit_f32(const float* inputs, const
         case 2: kern = k8c::rqs_resnet_f16c_kernel<false, 2>; break;
         default: kern = k8c::rqs_resnet_f16c_kernel<true, 2>; break;
     }
-    note_layer_kernel("k8c::rqs_resnet_f16c_kernel<inverse=%d, init_ks=%d, waves=4, K=8, ring=%d>", inv ? 1 : 0, init_ks, k8c::kRingC);
+    note_layer_kernel("k8c::rqs_resnet_f16c_kernel<inverse=%d, init_ks=%d, waves=4, K=8>", inv ? 1 : 0, init_ks);
     hipLaunchKernelGGL(k8c::zero_words_kernel, dim3((unsigned)((batch / 128 + 255) / 256)), dim3(256), 0, st, redo_blocks,
                        (int)(batch / 128));
     if (lds > 64 * 1024) {
