@@ -564,7 +564,7 @@ def main():
         del xw
 
     # extra (N = 1): the shards config 4 leaves a GPU at 8 / 16 / 32 GPUs -- the small-batch kernels (K8s: 128-row
-    # blocks at 32 768 rows, four-wave 64-row blocks below), same step as the headline
+    # blocks at 32 768 rows; K8c, round 6: column-split 64-row blocks below), same step as the headline
     small = None
     if world == 1 and args.batch_per_gpu is None and not args.skip_extra:
         small = []
@@ -598,6 +598,22 @@ def main():
                     dt2 = time.perf_counter() - ts
                     entry_s["engine_f16x2"] = {"ms_per_step": dt2 / args.steps * 1e3, "value": rows_s * args.steps / dt2,
                                                "kernel": ops.last_layer_kernel()}
+                    if ops.use_tile16(rows_s, K, None, dev) == 2:   # K8c's batches: K8s (the kernel of rounds 3-5) beside it
+                        saved_c = ops.K8C_ENABLED
+                        try:
+                            ops.K8C_ENABLED = False
+                            for _ in range(5):
+                                step_s()
+                            torch.cuda.synchronize()
+                            ts = time.perf_counter()
+                            for _ in range(args.steps):
+                                step_s()
+                            torch.cuda.synchronize()
+                            dt3 = time.perf_counter() - ts
+                            entry_s["engine_f16x2_k8s"] = {"ms_per_step": dt3 / args.steps * 1e3, "value": rows_s * args.steps / dt3,
+                                                           "kernel": ops.last_layer_kernel()}
+                        finally:
+                            ops.K8C_ENABLED = saved_c
                 finally:
                     RQ.conditioner_engine = args.engine
             small.append(entry_s)

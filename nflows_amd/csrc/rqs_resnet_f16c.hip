@@ -147,12 +147,11 @@ __device__ __forceinline__ void gemm_hidden(f32x4 (&acc)[4][2], Frag (&rb)[4], c
 }
 
 // The wave's 32 columns x 64 rows (x `scale`, ReLU'd when RELU) -> f16 pieces in the exchange buffer: k-step `wave` of
-// the next GEMM (accumulator tiles 2 w, 2 w + 1 of a row tile are the eight k values lane (n, g) holds of it).  A barrier
-// in front (every wave has read the buffer's previous contents: its last reads are two MFMA groups old) and one behind
-// (the new contents are visible).  (The guard orders the conversions -- asm blocks the hazard recogniser does not look
+// the next GEMM (accumulator tiles 2 w, 2 w + 1 of a row tile are the eight k values lane (n, g) holds of it).  The buffer
+// has two halves used in turn, so that one barrier per exchange is enough (the new contents are visible behind it).  (The guard orders the conversions -- asm blocks the hazard recogniser does not look
 // into -- behind the matrix pipe's write-back of the GEMM's last products.)
 template <bool RELU>
-__device__ __forceinline__ void exchange(f32x4 (&acc)[4][2], uvec4* X, int wave, int lane, float scale, float& worst) {
+__device__ __forceinline__ void exchange(f32x4 (&acc)[4][2], uvec4*& X, uvec4* X0, int wave, int lane, float scale, float& worst) {
     asm volatile("s_nop 7\n\ts_nop 3"
                  : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),
                    "+v"(acc[3][0]), "+v"(acc[3][1]));
@@ -175,8 +174,9 @@ __device__ __forceinline__ void exchange(f32x4 (&acc)[4][2], uvec4* X, int wave,
         l[rt][3] = lo;
     }
     worst = __builtin_fmaxf(worst, peak * scale);
-    // (the conversions above overlap the other waves' last MFMAs; nobody may still be reading the buffer when it is written)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // the OTHER half of the buffer: a slower wave may still be reading this GEMM's pieces from the current one; the other
+    // half was last read a GEMM ago, and every wave has passed a barrier since
+    X = X == X0 ? X0 + kXVec4 : X0;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
         X[((wave * 4 + rt) * 2 + 0) * 64 + lane] = h[rt];
@@ -250,8 +250,9 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
     }
 
     const int pblock = (a.param_words + 3) & ~3, pvec = pblock >> 2;   // (<= 512 vec4: one parameter stage, two per thread)
-    uvec4* X = reinterpret_cast<uvec4*>(lds_dyn);
-    float* s_row = lds_dyn + kXVec4 * 4;                  // [D][kRowPadC]
+    uvec4* const X0 = reinterpret_cast<uvec4*>(lds_dyn);  // two halves of kXVec4 vectors (exchange)
+    uvec4* X = X0;
+    float* s_row = lds_dyn + 2 * kXVec4 * 4;              // [D][kRowPadC]
     float* s_param = s_row + D * kRowPadC;                // [2][pblock]
     const int groups = dt >> 2;
     const int rounds = (groups + 3) >> 2;
@@ -341,8 +342,8 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
             float conv_scale = gemm[0];
             gemm += kHdr + 128;
             NFA_K8C_STAMP(2)
-            if (nb > 0) exchange<true>(hacc, X, wave, lane, conv_scale, worst);
-            else exchange<false>(hacc, X, wave, lane, conv_scale, worst);
+            if (nb > 0) exchange<true>(hacc, X, X0, wave, lane, conv_scale, worst);
+            else exchange<false>(hacc, X, X0, wave, lane, conv_scale, worst);
             NFA_K8C_STAMP(3)
 
             // ---- residual blocks: h += W_1 relu(W_0 relu(h) + b_0) + b_1
@@ -360,7 +361,7 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
                 }
                 gemm += kHdr + 128;
                 NFA_K8C_STAMP(4 + blk * 4)
-                exchange<true>(u, X, wave, lane, conv_scale, worst);
+                exchange<true>(u, X, X0, wave, lane, conv_scale, worst);
                 NFA_K8C_STAMP(5 + blk * 4)
                 {
                     // the second Linear accumulates into the residual stream itself: hacc = hacc * ratio + bias, then + W_1 relu(u)
@@ -381,8 +382,8 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
                 gemm += kHdr + 128;
                 NFA_K8C_STAMP(6 + blk * 4)
                 // pieces of relu(h) for the next block, of h itself for the final layer (no ReLU in front of it: resnet.py:99-100)
-                if (blk + 1 < nb) exchange<true>(hacc, X, wave, lane, conv_scale, worst);
-                else exchange<false>(hacc, X, wave, lane, conv_scale, worst);
+                if (blk + 1 < nb) exchange<true>(hacc, X, X0, wave, lane, conv_scale, worst);
+                else exchange<false>(hacc, X, X0, wave, lane, conv_scale, worst);
                 NFA_K8C_STAMP(7 + blk * 4)
             }
 
@@ -586,7 +587,7 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_colsplit_f32(const float* inputs, const
     hipMemset(trace_dev, 0, 256 * 64 * 8);
     a.trace = trace_dev;
 #endif
-    const size_t lds = (size_t)k8c::kXVec4 * 16 + (size_t)features * k8c::kRowPadC * sizeof(float) +
+    const size_t lds = (size_t)2 * k8c::kXVec4 * 16 + (size_t)features * k8c::kRowPadC * sizeof(float) +
                        (size_t)2 * ((param_words + 3) & ~3) * sizeof(float);
     const size_t lds_cap = 160 * 1024 - 4096;   // (beside 2.6 KB of static arrays)
     if (lds > lds_cap) return NFA_ERR_UNSUPPORTED;

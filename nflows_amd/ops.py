@@ -1850,8 +1850,8 @@ def activation_code(fn):
 
 K8S_ENABLED = os.environ.get("NFA_K8S", "1") != "0"
 K8S_ALWAYS = os.environ.get("NFA_K8S", "1") == "2"     # (measurements: the 16-sample-tile kernel at every batch size)
-K8C_ENABLED = os.environ.get("NFA_K8C", "0") != "0"    # the column-split form of K8s for batches of at most 64 rows per CU (off until it beats K8s)
-K8C_ALWAYS = os.environ.get("NFA_K8C", "0") == "2"
+K8C_ENABLED = os.environ.get("NFA_K8C", "1") != "0"    # the column-split form of K8s for batches of at most 64 rows per CU
+K8C_ALWAYS = os.environ.get("NFA_K8C", "1") == "2"
 _cu_counts = {}
 
 

@@ -29,7 +29,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FIXTURES = {"act": "flows_acts.npz", "ste": "flows_steep.npz", "bin": "flows_bins.npz"}
 #        case            rows per launch (65 536: the eight-wave instances, 16 384: four waves, two workgroups per CU), K8s
 CASES = [("bins_k4", 65536, False), ("bins_k4", 16384, False), ("act_tanh_k10", 16384, False), ("act_elu_k10", 65536, False),
-         ("bins_k16", 65536, False), ("steep_nsf_k8", 65536, False), ("steep_nsf_k8", 16384, True)]
+         ("bins_k16", 65536, False), ("steep_nsf_k8", 65536, False), ("steep_nsf_k8", 16384, True), ("steep_nsf_k8", 16384, "k8c")]
 REPS = 12
 
 
@@ -42,15 +42,15 @@ def _same(a, b):
     return torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
 
 
-@pytest.mark.parametrize("case,rows,k8s", CASES, ids=["%s-%d-%s" % (c, r, "k8s" if k else "k8h") for c, r, k in CASES])
+@pytest.mark.parametrize("case,rows,k8s", CASES, ids=["%s-%d-%s" % (c, r, k if isinstance(k, str) else "k8s" if k else "k8h") for c, r, k in CASES])
 def test_results_do_not_depend_on_what_else_the_device_is_doing(case, rows, k8s, hog):
     from nflows_amd import ops
     flow_cpu, g, cfg = steep_flow(GOLDEN, case, FIXTURES[case[:3]])
     x = _batch(g, case, "x", 65536, cfg["D"]).to(DEV)
     noise = _batch(g, case, "noise", 65536, cfg["D"]).to(DEV)
     flow = copy.deepcopy(flow_cpu).to(DEV).eval()
-    before = ops.K8S_ENABLED
-    ops.K8S_ENABLED = k8s
+    before = (ops.K8S_ENABLED, ops.K8C_ENABLED)
+    ops.K8S_ENABLED, ops.K8C_ENABLED = bool(k8s), k8s == "k8c"
     try:
         quiet, kernels = {}, set()
         with torch.no_grad():
@@ -63,7 +63,7 @@ def test_results_do_not_depend_on_what_else_the_device_is_doing(case, rows, k8s,
                 kernels.add(ops.last_layer_kernel().split("<")[0])
                 quiet[(lo, 1)] = tuple(t.clone() for t in flow._transform.inverse(noise[lo:lo + rows]))
             torch.cuda.synchronize()
-            assert kernels == {"k8s::rqs_resnet_f16s_kernel" if k8s else "k8h::rqs_resnet_f16_kernel"}, kernels
+            assert kernels == {"k8c::rqs_resnet_f16c_kernel" if k8s == "k8c" else "k8s::rqs_resnet_f16s_kernel" if k8s else "k8h::rqs_resnet_f16_kernel"}, kernels
             side = torch.cuda.Stream()
             deviating = launches = 0
             for _ in range(REPS):
@@ -79,8 +79,8 @@ def test_results_do_not_depend_on_what_else_the_device_is_doing(case, rows, k8s,
                         deviating += not (_same(z, qz) and _same(lad, ql))
                 side.synchronize()
     finally:
-        ops.K8S_ENABLED = before
-    _report({"config": "concurrency_%s_%d_%s" % (case, rows, "k8s" if k8s else "k8h"), "launches": launches,
+        ops.K8S_ENABLED, ops.K8C_ENABLED = before
+    _report({"config": "concurrency_%s_%d_%s" % (case, rows, k8s if isinstance(k8s, str) else "k8s" if k8s else "k8h"), "launches": launches,
              "deviating_from_the_quiet_result": deviating})
     assert deviating == 0, (case, rows, deviating, launches)
 

@@ -232,7 +232,9 @@ def test_small_batch_kernel_on_a_32768_row_shard():
     x = torch.randn(32768, 64, generator=torch.Generator().manual_seed(1234))
     flow = copy.deepcopy(flow_cpu).to(DEV).eval()
     xd = x.to(DEV)
-    assert ops.use_tile16(32768, 8, None, xd.device)
+    assert ops.use_tile16(32768, 8, None, xd.device) == 1
+    saved_c = ops.K8C_ENABLED
+    ops.K8C_ENABLED = False       # (this test is K8s's: the 512- and 1 000-row launches below would be K8c's otherwise)
     with torch.no_grad():
         lp = flow.log_prob(xd)
         z, lad = flow._transform(xd)
@@ -248,6 +250,7 @@ def test_small_batch_kernel_on_a_32768_row_shard():
             z_h, lad_h = flow._transform(xd)
         finally:
             ops.K8S_ENABLED = saved
+    ops.K8C_ENABLED = saved_c
     nflows_amd.check_status()
     assert torch.equal(lp, lp2)
     assert torch.equal(zs, z[rows_solo.to(DEV)]) and torch.equal(lads, lad[rows_solo.to(DEV)])
@@ -280,6 +283,8 @@ def test_small_batch_kernel_four_wave_blocks_on_a_16384_row_shard():
     x = torch.randn(32768, 64, generator=torch.Generator().manual_seed(1234))
     flow = copy.deepcopy(flow_cpu).to(DEV).eval()
     xd = x.to(DEV)
+    saved_c = ops.K8C_ENABLED
+    ops.K8C_ENABLED = False       # (K8s's four-wave form: without this switch these batches are K8c's)
     with torch.no_grad():
         z_full, lad_full = flow._transform(xd)
         z, lad = flow._transform(xd[:16384])
@@ -290,6 +295,7 @@ def test_small_batch_kernel_four_wave_blocks_on_a_16384_row_shard():
         x_hot[64:128] *= 3e4                       # identity features of 3e4 .. 1e5: hidden activations beyond 65 504
         z_hot, lad_hot = flow._transform(x_hot)
         redo_hot = ops.last_redo_blocks()
+    ops.K8C_ENABLED = saved_c
     nflows_amd.check_status()
     assert torch.equal(z, z_full[:16384]) and torch.equal(lad, lad_full[:16384]), "four- and eight-wave blocks differ"
     rows = torch.arange(0, 16384, 4)
@@ -305,6 +311,81 @@ def test_small_batch_kernel_four_wave_blocks_on_a_16384_row_shard():
     o_hot = oracle_eval(flow_cpu, x_hot[:128].cpu())
     compare("k8s_shared_redo_flag", "z", z_hot[:128].cpu().numpy(), o_hot["z32"], o_hot["z64"], OUT_TOL, max_factor=4.0)
     compare("k8s_shared_redo_flag", "logabsdet", lad_hot[:128].cpu().numpy(), o_hot["lad32"], o_hot["lad64"], LAD_TOL, max_factor=4.0)
+
+
+def test_column_split_kernel_on_small_batches():
+    """K8c (csrc/rqs_resnet_f16c.hip, round 6): K8s's whole-layer kernel with every GEMM split by columns over the four waves
+    of a 64-row workgroup, weights straight from global memory into registers -- the form for batches with no more 64-row
+    blocks than CUs (`Flow.sample(n)` / `log_prob` of a few thousand rows, a 16-GPU shard of config 4).  The same products in
+    the same order as K8s: z is K8s's BIT FOR BIT (log-determinants are summed in another order: rounding only); the oracle
+    on every 4th row; inverse; a ragged batch and rows evaluated alone give the same bits; two workgroups share one redo
+    flag (as K8s's four-wave form); D = 100 (two k-steps in the initial layer, 13 groups: a last round with idle waves)."""
+    from nflows_amd import configs, ops
+    import copy
+    import nflows_amd
+    flow_cpu = configs.rq_nsf_flow(num_layers=32, features=64, num_bins=8, hidden_features=128, seed=0).eval()
+    x = torch.randn(16384, 64, generator=torch.Generator().manual_seed(1234))
+    flow = copy.deepcopy(flow_cpu).to(DEV).eval()
+    xd = x.to(DEV)
+    assert ops.K8C_ENABLED and ops.use_tile16(16384, 8, None, xd.device) == 2 and ops.use_tile16(32768, 8, None, xd.device) == 1
+    with torch.no_grad():
+        z, lad = flow._transform(xd)
+        label = ops.last_layer_kernel()
+        assert ops.last_redo_blocks() == 0
+        lp = flow.log_prob(xd)
+        lp2 = flow.log_prob(xd)
+        xr, _ = flow._transform.inverse(z)
+        label_inv = ops.last_layer_kernel()
+        rows_solo = torch.arange(100, 16384, 32)
+        zs, lads = flow._transform(xd[rows_solo.to(DEV)])
+        zr, ladr = flow._transform(xd[:1000])                 # ragged: padded to full blocks inside ops
+        x_hot = xd.clone()
+        x_hot[64:128] *= 3e4                       # identity features of 3e4 .. 1e5: hidden activations beyond 65 504
+        z_hot, lad_hot = flow._transform(x_hot)
+        redo_hot = ops.last_redo_blocks()
+        saved = ops.K8C_ENABLED
+        try:
+            ops.K8C_ENABLED = False
+            z_s, lad_s = flow._transform(xd)
+            assert "k8s::" in ops.last_layer_kernel()
+        finally:
+            ops.K8C_ENABLED = saved
+    nflows_amd.check_status()
+    assert "k8c::" in label and "inverse=0" in label and "k8c::" in label_inv and "inverse=1" in label_inv, (label, label_inv)
+    assert torch.equal(lp, lp2)
+    assert torch.equal(z, z_s), "%d outputs differ from K8s's" % int((z != z_s).sum())
+    assert float((lad - lad_s).abs().max()) < 5e-4
+    assert torch.equal(zs, z[rows_solo.to(DEV)]) and torch.equal(lads, lad[rows_solo.to(DEV)])
+    assert torch.equal(zr, z[:1000]) and torch.equal(ladr, lad[:1000])
+    rows = torch.arange(0, 16384, 4)
+    o = oracle_eval(flow_cpu, x[rows])
+    idx = rows.to(DEV)
+    compare("k8c_32layer_b16384", "z", z[idx].cpu().numpy(), o["z32"], o["z64"], OUT_TOL)
+    compare("k8c_32layer_b16384", "logabsdet", lad[idx].cpu().numpy(), o["lad32"], o["lad64"], LAD_TOL)
+    compare("k8c_32layer_b16384", "log_prob", lp[idx].cpu().numpy(), o["lp32"], o["lp64"], LAD_TOL)
+    err = (xr - xd).abs()
+    _report({"config": "k8c_32layer_b16384", "what": "|inv(fwd(x)) - x|", "max": float(err.max()), "mean": float(err.mean())})
+    assert float(err.mean()) < 2e-5 and float(err.max()) < 2e-2
+    assert redo_hot == 1, "%d blocks redone" % redo_hot
+    assert torch.equal(z_hot[128:], z[128:]) and torch.equal(lad_hot[128:], lad[128:])
+    o_hot = oracle_eval(flow_cpu, x_hot[:128].cpu())
+    compare("k8c_shared_redo_flag", "z", z_hot[:128].cpu().numpy(), o_hot["z32"], o_hot["z64"], OUT_TOL, max_factor=4.0)
+    compare("k8c_shared_redo_flag", "logabsdet", lad_hot[:128].cpu().numpy(), o_hot["lad32"], o_hot["lad64"], LAD_TOL, max_factor=4.0)
+    # D = 100: 50 identity features (two 32-wide k-steps), 52 transformed after padding: 13 groups, four rounds
+    flow_w = configs.rq_nsf_flow(num_layers=4, features=100, num_bins=8, hidden_features=128, seed=3).to(DEV).eval()
+    xw = torch.randn(4100, 100, generator=torch.Generator().manual_seed(7)).to(DEV)
+    with torch.no_grad():
+        zw, ladw = flow_w._transform(xw)
+        assert "k8c::" in ops.last_layer_kernel() and "init_ks=2" in ops.last_layer_kernel(), ops.last_layer_kernel()
+        xwr, ladwr = flow_w._transform.inverse(zw)
+        try:
+            ops.K8C_ENABLED = False
+            zw_s, ladw_s = flow_w._transform(xw)
+        finally:
+            ops.K8C_ENABLED = saved
+    nflows_amd.check_status()
+    assert torch.equal(zw, zw_s) and float((ladw - ladw_s).abs().max()) < 1e-4
+    assert float((xwr - xw).abs().max()) < 1e-3 and float((ladw + ladwr).abs().max()) < 1e-3
 
 
 def test_forward_inverse_consistency_against_the_reference():

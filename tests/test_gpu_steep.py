@@ -175,6 +175,8 @@ def _nsf_engines(K):
             "k8x_b16384": (dict(path="k8", engine="f16x3"), 16384, True, ("k8x::", "K=8")),
             "k8s_w8": (dict(path="k8", engine="f16x2"), 32768, True, ("k8s::", "waves=8")),
             "k8s_w4": (dict(path="k8", engine="f16x2"), 16384, True, ("k8s::", "waves=4")),
+            # K8c (round 6): K8s's GEMMs split by columns over the four waves of a 64-row workgroup
+            "k8c": (dict(path="k8", engine="f16x2"), 16384, "k8c", ("k8c::", "waves=4")),
             "k7b": (dict(path="k7b", engine="f16x2"), 16384, True, ("rqs_fused_linear_bf16_kernel",)),
             "k7": (dict(path="k7", engine="f16x2"), 16384, True, ("rqs_fused_linear_kernel",)),
         })
@@ -185,17 +187,18 @@ def _nsf_engines(K):
 def engine_switches():
     from nflows_amd import ops
     from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
-    saved = (RQ.fuse_conditioner, RQ.fuse_final_linear, RQ.final_linear_engine, RQ.conditioner_engine, ops.K8S_ENABLED)
+    saved = (RQ.fuse_conditioner, RQ.fuse_final_linear, RQ.final_linear_engine, RQ.conditioner_engine, ops.K8S_ENABLED, ops.K8C_ENABLED)
 
     def select(path, engine, k8s):
         RQ.fuse_conditioner = path == "k8"
         RQ.fuse_final_linear = path != "none"
         RQ.final_linear_engine = "f32" if path == "k7" else "bf16x3"
         RQ.conditioner_engine = engine
-        ops.K8S_ENABLED = k8s
+        ops.K8S_ENABLED = bool(k8s)       # (k8s: False = K8h, True = K8s, "k8c" = K8c where the batch is small enough)
+        ops.K8C_ENABLED = k8s == "k8c"
     saved_env = {k: os.environ.get(k) for k in ("NFA_K1_WAVETILE",)}
     yield select
-    RQ.fuse_conditioner, RQ.fuse_final_linear, RQ.final_linear_engine, RQ.conditioner_engine, ops.K8S_ENABLED = saved
+    RQ.fuse_conditioner, RQ.fuse_final_linear, RQ.final_linear_engine, RQ.conditioner_engine, ops.K8S_ENABLED, ops.K8C_ENABLED = saved
     for k, v in saved_env.items():
         if v is None:
             os.environ.pop(k, None)
@@ -224,7 +227,7 @@ def test_steep_coupling_flow_on_every_engine(golden_dir, engine_switches, case, 
     def counted(fn, key):
         def run(t):
             out = fn(t)
-            if engine.startswith(("k8h", "k8s", "k8x")):
+            if engine.startswith(("k8h", "k8s", "k8x", "k8c")):
                 redo[key] += ops.last_redo_blocks()
             return out
         return run
