@@ -122,6 +122,12 @@ __device__ __forceinline__ int ring_next(int slot, int by = 1) {
     return t >= SM::RING ? t - SM::RING : t;
 }
 
+// cache policy of the weight stream's LDS-DMA loads (round 6, the bounded energy experiment: profiles/r6/
+// k8h_energy_experiment.txt -- 0 = default, 2 = nt, 16 = sc1; nothing moved the launch's energy, the default stays)
+#ifndef NFA_K8H_DMA_AUX
+#define NFA_K8H_DMA_AUX 0
+#endif
+
 template <class SM>
 __device__ __forceinline__ void stream_request(SM& sm) {
     constexpr int NW = SM::NW, kThreads = NW * kWave;
@@ -136,7 +142,7 @@ __device__ __forceinline__ void stream_request(SM& sm) {
     for (int i = 0; i < 16 / NW; ++i)
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)((stage + i * kThreads * 16) + lane_off),
-            (__attribute__((address_space(3))) void*)(slot + i * kThreads * 16), 16, 0, 0);
+            (__attribute__((address_space(3))) void*)(slot + i * kThreads * 16), 16, 0, NFA_K8H_DMA_AUX);
 #endif
     sm.fetch = (sm.fetch + 1 == sm.num_stages) ? 0 : sm.fetch + 1;
 }
