@@ -448,9 +448,10 @@ int nfa_rqs_flow_resnet_f16x2_tile16_f32(const float *inputs, const void *stream
  * K8c (ABI 13, round 6): K8s's run of whole coupling layers with every GEMM split by COLUMNS over the four waves of a
  * 64-row workgroup (csrc/rqs_resnet_f16c.hip) -- the form for batches that give a CU at most one 64-row block
  * (`Flow.sample(n)` / `log_prob` of a few thousand rows: flows/base.py:51-75, distributions/base.py:69-84; replaces the
- * same reference code as nfa_rqs_flow_resnet_f16x2_f32).  Arguments, results, `redo_blocks` convention (bit 1 / bit 2 of
- * a 128-row block's word = its lower / upper 64 rows were not written) and restrictions as for
- * nfa_rqs_flow_resnet_f16x2_tile16_f32; `stream_packed` differs in the FINAL layer's stages only: per round r of four
+ * same reference code as nfa_rqs_flow_resnet_f16x2_f32).  Arguments, results and restrictions as for
+ * nfa_rqs_flow_resnet_f16x2_tile16_f32; `redo_blocks`: workgroups are 32 rows (bits 3 .. 6 of a 128-row block's word = its
+ * four quarters were not written; nfa_rqs_flow_resnet_redo_f32 honours them) or, with NFA_K8C_ROWS=64, 64 rows (bits 1 / 2
+ * as for the tile16 entry); `stream_packed` differs in the FINAL layer's stages only: per round r of four
  * groups of four transformed features twelve stages, stage 2 i + s = for every wave w (fragment pairs 2 w, 2 w + 1)
  * k-steps 2 s, 2 s + 1 of 16-row tile i of group 4 r + w (K8s's row order within a group; zero fragments for groups
  * beyond d_t / 4): stages per layer = param_stages + (d_i > 32 ? 2 : 1) + 8 num_blocks + 12 ceil(d_t / 16).

@@ -1,20 +1,20 @@
 // K8c (round 6): the whole-layer kernel of rqs_resnet_f16s.hip (K8s: ResidualNet conditioner, nn/nets/resnet.py:55-100,
 // + everything K1 replaces, coupling.py:73-130, :549-582, for a run of layers in one launch; GEMMs on two f16 pieces per
 // fp32 operand, 16-sample tiles on v_mfma_f32_16x16x32_f16) with the GEMMs split by COLUMNS over the four waves of a
-// 64-row workgroup -- the small-batch form: `Flow.sample(n)` / `log_prob` of a few thousand rows (flows/base.py:51-75,
+// 32-row (or 64-row) workgroup -- the small-batch form: `Flow.sample(n)` / `log_prob` of a few thousand rows (flows/base.py:51-75,
 // distributions/base.py:69-84) and the per-GPU shard of a many-GPU job.
 //
 // Why.  K8s gives every wave 16 rows and ALL output columns: one wave per SIMD then walks dependent chains -- fragment
 // read -> 24 MFMAs on one or two accumulator tiles per stage -> conversion -> next GEMM -- with nothing to overlap them
 // (0.65 ms for 8 192 rows whatever the ring depth; the weight stream alone would allow 0.2).
-// Here wave w owns output tiles 2 w, 2 w + 1 (32 of the 128 hidden columns) of every hidden GEMM for all FOUR 16-row
-// tiles of the workgroup: eight accumulator tiles, four independent MFMA chains per weight fragment, a quarter of the
-// fragment reads.  The next GEMM needs every column of every row tile as its B operand: each wave converts its 32 x 64
+// Here wave w owns output tiles 2 w, 2 w + 1 (32 of the 128 hidden columns) of every hidden GEMM for ALL RT 16-row
+// tiles of the workgroup (RT = 2 or 4): 2 RT accumulator tiles, RT independent MFMA chains per weight fragment, a quarter
+// of the fragment reads.  The next GEMM needs every column of every row tile as its B operand: each wave converts its 32 x 16 RT
 // block to f16 pieces and leaves them in an LDS exchange buffer -- in B-fragment layout: k-step S of the next GEMM IS
 // wave S's block (K8s's chaining rule, ops._k8s_column_order) -- one extra barrier per GEMM.  The final layer is split by
 // FEATURES: wave w takes group G = 4 r + w of four features in round r (six 16-row tiles: the 24 logits of feature
-// 4 G + g land in lane group g as in K8s) for all four row tiles, its B operand -- all 128 k of all four row tiles --
-// resident in registers (one wave per SIMD: 512 registers); a stage of the final layer carries two k-steps of ONE tile of
+// 4 G + g land in lane group g as in K8s) for all RT row tiles, its B operand -- all 128 k of all row tiles --
+// resident in registers; a stage of the final layer carries two k-steps of ONE tile of
 // every wave (pairs 2 w, 2 w + 1), so that every stage feeds all four waves.
 //
 // Stream: K8s's stages and parameter words for the initial layer and the blocks (16 KB stages of eight (hi, lo) fragment
@@ -24,8 +24,10 @@
 // right behind the previous stage's barrier, the barrier stands between the two halves of a stage's MFMAs.
 //
 // Restrictions: K8s's (8 bins, linear tails, no context, hidden width 128, ReLU blocks, d_i <= 64, d_t % 4 == 0,
-// d_t <= 64, D % 4 == 0, D <= 128, batch % 128 == 0).  Workgroups of four waves = 64 rows: `redo_blocks` as for K8s's
-// four-wave form (bit 1 / bit 2 of a 128-row block's word = its lower / upper 64 rows).
+// d_t <= 64, D % 4 == 0, D <= 128, batch % 128 == 0).  Workgroups of four waves on RT 16-row tiles: RT = 2 (32 rows, two
+// workgroups per CU: the default -- half of every serial term of the 64-row form) or RT = 4 (64 rows: NFA_K8C_ROWS=64);
+// `redo_blocks`: bits 3 .. 6 of a 128-row block's word = its four 32-row quarters (RT = 2), bit 1 / bit 2 = its lower /
+// upper 64 rows (RT = 4, as K8s's four-wave form).
 
 #include "k8h_common.hpp"
 
@@ -34,9 +36,12 @@ namespace k8c {
 
 using namespace k8h;
 
-constexpr int kNW = 4, kThreads = kNW * kWave, kRows = 64;
-constexpr int kRowPadC = 65;        // [column][64 rows + 1]
-constexpr int kXVec4 = 4 * 4 * 2 * 64;   // exchange buffer: [k-step S][row tile][hi, lo][64 lanes] x 16 B = 32 KB
+constexpr int kNW = 4, kThreads = kNW * kWave;
+// RT = 16-row tiles per workgroup: 4 (64 rows) or 2 (32 rows: batches with no more 32-row blocks than CUs -- twice the
+// workgroups, half of every serial term; `redo_blocks` then carries a bit per 32 rows)
+constexpr int rows_of(int RT) { return 16 * RT; }
+constexpr int row_pad_of(int RT) { return 16 * RT + 1; }              // [column][rows + 1]
+constexpr int x_vec4_of(int RT) { return 4 * RT * 2 * 64; }           // exchange buffer: [k-step S][row tile][hi, lo][64 lanes] x 16 B
 typedef vec4f f32x4;
 
 #ifdef NFA_ABL_NO_MFMA   // (timing ablations: results are garbage)
@@ -65,56 +70,62 @@ __device__ __forceinline__ Frag load_frag(const vec4f* wlane, int stage) {
     return Frag{p[0], p[64], p[128], p[192]};
 }
 
-// the three products of one weight fragment pair with the pieces of the four row tiles: four independent chains
-__device__ __forceinline__ void products(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, vec4f ahw, vec4f alw, const uvec4 (&bh)[4],
-                                         const uvec4 (&bl)[4]) {
+// the three products of one weight fragment pair with the pieces of the RT row tiles: RT independent chains
+template <int RT>
+__device__ __forceinline__ void products(f32x4* const (&a)[RT], vec4f ahw, vec4f alw, const uvec4 (&bh)[RT], const uvec4 (&bl)[RT]) {
     const f16x8 ah = __builtin_bit_cast(f16x8, ahw), al = __builtin_bit_cast(f16x8, alw);
-    const f16x8 bh0 = __builtin_bit_cast(f16x8, bh[0]), bh1 = __builtin_bit_cast(f16x8, bh[1]);
-    const f16x8 bh2 = __builtin_bit_cast(f16x8, bh[2]), bh3 = __builtin_bit_cast(f16x8, bh[3]);
-    const f16x8 bl0 = __builtin_bit_cast(f16x8, bl[0]), bl1 = __builtin_bit_cast(f16x8, bl[1]);
-    const f16x8 bl2 = __builtin_bit_cast(f16x8, bl[2]), bl3 = __builtin_bit_cast(f16x8, bl[3]);
+    f16x8 h[RT], l[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        h[rt] = __builtin_bit_cast(f16x8, bh[rt]);
+        l[rt] = __builtin_bit_cast(f16x8, bl[rt]);
+    }
     // (smallest terms first, as K8s: the same products in the same order -- z is K8s's bit for bit)
-    a0 = NFA_K8C_MFMA(al, bh0, a0);
-    a1 = NFA_K8C_MFMA(al, bh1, a1);
-    a2 = NFA_K8C_MFMA(al, bh2, a2);
-    a3 = NFA_K8C_MFMA(al, bh3, a3);
-    a0 = NFA_K8C_MFMA(ah, bl0, a0);
-    a1 = NFA_K8C_MFMA(ah, bl1, a1);
-    a2 = NFA_K8C_MFMA(ah, bl2, a2);
-    a3 = NFA_K8C_MFMA(ah, bl3, a3);
-    a0 = NFA_K8C_MFMA(ah, bh0, a0);
-    a1 = NFA_K8C_MFMA(ah, bh1, a1);
-    a2 = NFA_K8C_MFMA(ah, bh2, a2);
-    a3 = NFA_K8C_MFMA(ah, bh3, a3);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) *a[rt] = NFA_K8C_MFMA(al, h[rt], *a[rt]);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) *a[rt] = NFA_K8C_MFMA(ah, l[rt], *a[rt]);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) *a[rt] = NFA_K8C_MFMA(ah, h[rt], *a[rt]);
     // the operands stay live past the last product (rqs_resnet_f16s.hip: hipcc otherwise puts a renamed four-register
     // result on the registers of an operand that has just had its last use while the matrix pipe may still read it)
-    asm volatile("" ::"v"(ah), "v"(al), "v"(bh0), "v"(bh1), "v"(bh2), "v"(bh3), "v"(bl0), "v"(bl1), "v"(bl2), "v"(bl3));
+    asm volatile("" ::"v"(ah), "v"(al));
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) asm volatile("" ::"v"(h[rt]), "v"(l[rt]));
 }
 
-// pieces of k-step S for the four row tiles from the exchange buffer
-__device__ __forceinline__ void read_pieces(const uvec4* X, int S, int lane, uvec4 (&bh)[4], uvec4 (&bl)[4]) {
+// pieces of k-step S for the row tiles from the exchange buffer
+template <int RT>
+__device__ __forceinline__ void read_pieces(const uvec4* X, int S, int lane, uvec4 (&bh)[RT], uvec4 (&bl)[RT]) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-        bh[rt] = X[((S * 4 + rt) * 2 + 0) * 64 + lane];
-        bl[rt] = X[((S * 4 + rt) * 2 + 1) * 64 + lane];
+    for (int rt = 0; rt < RT; ++rt) {
+        bh[rt] = X[((S * RT + rt) * 2 + 0) * 64 + lane];
+        bl[rt] = X[((S * RT + rt) * 2 + 1) * 64 + lane];
     }
 }
 
 // One k-major stage = one 32-wide k-step: the wave's two output tiles x four row tiles.  NEXT_S >= 0: the pieces of
 // k-step NEXT_S are read between the two halves.
-template <int NEXT_S>
-__device__ __forceinline__ void stage_kmajor(f32x4 (&acc)[4][2], const Frag& fr, uvec4 (&bh)[4], uvec4 (&bl)[4], const uvec4* X, int lane) {
+template <int NEXT_S, int RT>
+__device__ __forceinline__ void stage_kmajor(f32x4 (&acc)[RT][2], const Frag& fr, uvec4 (&bh)[RT], uvec4 (&bl)[RT], const uvec4* X, int lane) {
+    f32x4* c0[RT];
+    f32x4* c1[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        c0[rt] = &acc[rt][0];
+        c1[rt] = &acc[rt][1];
+    }
     NFA_K8C_FENCE();
-    products(acc[0][0], acc[1][0], acc[2][0], acc[3][0], fr.h0, fr.l0, bh, bl);
+    products<RT>(c0, fr.h0, fr.l0, bh, bl);
     NFA_K8C_FENCE();
-    uvec4 nh[4], nl[4];
-    if constexpr (NEXT_S >= 0) read_pieces(X, NEXT_S, lane, nh, nl);
+    uvec4 nh[RT], nl[RT];
+    if constexpr (NEXT_S >= 0) read_pieces<RT>(X, NEXT_S, lane, nh, nl);
     NFA_K8C_FENCE();
-    products(acc[0][1], acc[1][1], acc[2][1], acc[3][1], fr.h1, fr.l1, bh, bl);
+    products<RT>(c1, fr.h1, fr.l1, bh, bl);
     NFA_K8C_FENCE();
     if constexpr (NEXT_S >= 0) {
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
             bh[rt] = nh[rt];
             bl[rt] = nl[rt];
         }
@@ -132,16 +143,17 @@ struct Ahead {
 };
 
 // 128 -> 128 GEMM on the pieces in the exchange buffer (four stages, k0 = the first one's number)
-__device__ __forceinline__ void gemm_hidden(f32x4 (&acc)[4][2], Frag (&rb)[4], const Ahead& ah, int k0, const uvec4* X, int lane) {
-    uvec4 bh[4], bl[4];
-    read_pieces(X, 0, lane, bh, bl);
-    stage_kmajor<1>(acc, rb[0], bh, bl, X, lane);
+template <int RT>
+__device__ __forceinline__ void gemm_hidden(f32x4 (&acc)[RT][2], Frag (&rb)[4], const Ahead& ah, int k0, const uvec4* X, int lane) {
+    uvec4 bh[RT], bl[RT];
+    read_pieces<RT>(X, 0, lane, bh, bl);
+    stage_kmajor<1, RT>(acc, rb[0], bh, bl, X, lane);
     rb[0] = ah.load(k0 + 4);
-    stage_kmajor<2>(acc, rb[1], bh, bl, X, lane);
+    stage_kmajor<2, RT>(acc, rb[1], bh, bl, X, lane);
     rb[1] = ah.load(k0 + 5);
-    stage_kmajor<3>(acc, rb[2], bh, bl, X, lane);
+    stage_kmajor<3, RT>(acc, rb[2], bh, bl, X, lane);
     rb[2] = ah.load(k0 + 6);
-    stage_kmajor<-1>(acc, rb[3], bh, bl, X, lane);
+    stage_kmajor<-1, RT>(acc, rb[3], bh, bl, X, lane);
     rb[3] = ah.load(k0 + 7);
     NFA_K8C_FENCE();
 }
@@ -150,15 +162,14 @@ __device__ __forceinline__ void gemm_hidden(f32x4 (&acc)[4][2], Frag (&rb)[4], c
 // the next GEMM (accumulator tiles 2 w, 2 w + 1 of a row tile are the eight k values lane (n, g) holds of it).  The buffer
 // has two halves used in turn, so that one barrier per exchange is enough (the new contents are visible behind it).  (The guard orders the conversions -- asm blocks the hazard recogniser does not look
 // into -- behind the matrix pipe's write-back of the GEMM's last products.)
-template <bool RELU>
-__device__ __forceinline__ void exchange(f32x4 (&acc)[4][2], uvec4*& X, uvec4* X0, int wave, int lane, float scale, float& worst) {
-    asm volatile("s_nop 7\n\ts_nop 3"
-                 : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),
-                   "+v"(acc[3][0]), "+v"(acc[3][1]));
-    float peak = 0.0f;
-    uvec4 h[4], l[4];
+template <bool RELU, int RT>
+__device__ __forceinline__ void exchange(f32x4 (&acc)[RT][2], uvec4*& X, uvec4* X0, int wave, int lane, float scale, float& worst) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) asm volatile("s_nop 7\n\ts_nop 3" : "+v"(acc[rt][0]), "+v"(acc[rt][1]));
+    float peak = 0.0f;
+    uvec4 h[RT], l[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
         unsigned hi, lo;
         convert_pair<RELU ? kActRelu : kActNone, false>(acc[rt][0][0], acc[rt][0][1], scale, peak, hi, lo);
         h[rt][0] = hi;
@@ -176,27 +187,31 @@ __device__ __forceinline__ void exchange(f32x4 (&acc)[4][2], uvec4*& X, uvec4* X
     worst = __builtin_fmaxf(worst, peak * scale);
     // the OTHER half of the buffer: a slower wave may still be reading this GEMM's pieces from the current one; the other
     // half was last read a GEMM ago, and every wave has passed a barrier since
-    X = X == X0 ? X0 + kXVec4 : X0;
+    X = X == X0 ? X0 + x_vec4_of(RT) : X0;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-        X[((wave * 4 + rt) * 2 + 0) * 64 + lane] = h[rt];
-        X[((wave * 4 + rt) * 2 + 1) * 64 + lane] = l[rt];
+    for (int rt = 0; rt < RT; ++rt) {
+        X[((wave * RT + rt) * 2 + 0) * 64 + lane] = h[rt];
+        X[((wave * RT + rt) * 2 + 1) * 64 + lane] = l[rt];
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// one tile of the final layer (two stages: k-steps 0, 1 and 2, 3), four row tiles
-__device__ __forceinline__ void tile_final(f32x4 (&t)[4], Frag& f0, Frag& f1, const Ahead& ah, int k0, const uvec4 (&fh)[4][4],
-                                           const uvec4 (&fl)[4][4]) {
+// one tile of the final layer (two stages: k-steps 0, 1 and 2, 3), RT row tiles
+template <int RT>
+__device__ __forceinline__ void tile_final(f32x4 (&t)[RT], Frag& f0, Frag& f1, const Ahead& ah, int k0, const uvec4 (&fh)[4][RT],
+                                           const uvec4 (&fl)[4][RT]) {
+    f32x4* c[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) c[rt] = &t[rt];
     NFA_K8C_FENCE();
-    products(t[0], t[1], t[2], t[3], f0.h0, f0.l0, fh[0], fl[0]);
+    products<RT>(c, f0.h0, f0.l0, fh[0], fl[0]);
     NFA_K8C_FENCE();
-    products(t[0], t[1], t[2], t[3], f0.h1, f0.l1, fh[1], fl[1]);
+    products<RT>(c, f0.h1, f0.l1, fh[1], fl[1]);
     NFA_K8C_FENCE();
     f0 = ah.load(k0 + 4);
-    products(t[0], t[1], t[2], t[3], f1.h0, f1.l0, fh[2], fl[2]);
+    products<RT>(c, f1.h0, f1.l0, fh[2], fl[2]);
     NFA_K8C_FENCE();
-    products(t[0], t[1], t[2], t[3], f1.h1, f1.l1, fh[3], fl[3]);
+    products<RT>(c, f1.h1, f1.l1, fh[3], fl[3]);
     NFA_K8C_FENCE();
     f1 = ah.load(k0 + 5);
     NFA_K8C_FENCE();
@@ -232,12 +247,16 @@ __device__ __forceinline__ void store_params(float* prm, vec4f v, int i, int nve
     if (i < nvec) reinterpret_cast<vec4f*>(prm)[i] = v;
 }
 
-template <bool INVERSE, int INIT_KS>
-__global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args a) {
+// OCC: workgroups per CU the instance is compiled for (2: 256 registers per lane, a few dozen bytes of scratch; measured no
+// slower than the 512-register build of the same 32-row form even with one workgroup per CU)
+template <bool INVERSE, int INIT_KS, int RT, int OCC = 1>
+__global__ void __launch_bounds__(kThreads, OCC) rqs_resnet_f16c_kernel(const Args a) {
+    constexpr int kRows = rows_of(RT), kRowPadC = row_pad_of(RT), kXVec4 = x_vec4_of(RT);
+    constexpr int kParts = kThreads / kRows;   // threads per row in the epilogue's column sums
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     __shared__ int s_final[128];
     __shared__ int s_bad[kNW];
-    __shared__ float s_red[2][kNW][kRows];
+    __shared__ float s_red[2][8][64];   // [log-determinant shares per wave | squared sums per column part][row]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = a.D, dt = a.dt;
@@ -296,7 +315,9 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
         }
         __syncthreads();
 
-        float lad_acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // per row tile: rows 16 rt + n (this lane's features)
+        float lad_acc[RT];   // per row tile: rows 16 rt + n (this lane's features)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) lad_acc[rt] = 0.0f;
         float worst = 0.0f;
         int quad_status = 0;
         for (int layer = 0; layer < a.num_layers; ++layer) {
@@ -309,20 +330,20 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
             const int* tab = reinterpret_cast<const int*>(prm);
             const float* gemm = prm + kTabWords;   // header + biases of the next GEMM
             const Ahead ah{wlane, stage0 + st_hidden, next_layer_stage0 + st_hidden, 8 * nb + 12 * rounds};
-            f32x4 hacc[4][2];   // the residual stream h of the wave's 32 columns, fp32 (x the scale of the GEMM that wrote it)
+            f32x4 hacc[RT][2];   // the residual stream h of the wave's 32 columns, fp32 (x the scale of the GEMM that wrote it)
             // ---- initial layer on the identity features (scale 1): k = 32 S + 8 g + j
             {
                 const float* bias = gemm + kHdr + (2 * wave) * 16 + g * 4;
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt) {
+                for (int rt = 0; rt < RT; ++rt) {
                     load_bias4(hacc[rt][0], bias);
                     load_bias4(hacc[rt][1], bias + 16);
                 }
 #pragma unroll
                 for (int S = 0; S < INIT_KS; ++S) {
-                    uvec4 ih[4], il[4];
+                    uvec4 ih[RT], il[RT];
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) {
+                    for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
                         for (int j2 = 0; j2 < 4; ++j2) {
                             const int i0 = S * 32 + g * 8 + j2 * 2;
@@ -336,32 +357,32 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
                             il[rt][j2] = lo;
                         }
                     }
-                    stage_kmajor<-1>(hacc, fi[S], ih, il, X, lane);
+                    stage_kmajor<-1, RT>(hacc, fi[S], ih, il, X, lane);
                 }
             }
             float conv_scale = gemm[0];
             gemm += kHdr + 128;
             NFA_K8C_STAMP(2)
-            if (nb > 0) exchange<true>(hacc, X, X0, wave, lane, conv_scale, worst);
-            else exchange<false>(hacc, X, X0, wave, lane, conv_scale, worst);
+            if (nb > 0) exchange<true, RT>(hacc, X, X0, wave, lane, conv_scale, worst);
+            else exchange<false, RT>(hacc, X, X0, wave, lane, conv_scale, worst);
             NFA_K8C_STAMP(3)
 
             // ---- residual blocks: h += W_1 relu(W_0 relu(h) + b_0) + b_1
             for (int blk = 0; blk < nb; ++blk) {
-                f32x4 u[4][2];
+                f32x4 u[RT][2];
                 {
                     const float* bias = gemm + kHdr + (2 * wave) * 16 + g * 4;
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) {
+                    for (int rt = 0; rt < RT; ++rt) {
                         load_bias4(u[rt][0], bias);
                         load_bias4(u[rt][1], bias + 16);
                     }
-                    gemm_hidden(u, rb, ah, blk * 8, X, lane);
+                    gemm_hidden<RT>(u, rb, ah, blk * 8, X, lane);
                     conv_scale = gemm[0];
                 }
                 gemm += kHdr + 128;
                 NFA_K8C_STAMP(4 + blk * 4)
-                exchange<true>(u, X, X0, wave, lane, conv_scale, worst);
+                exchange<true, RT>(u, X, X0, wave, lane, conv_scale, worst);
                 NFA_K8C_STAMP(5 + blk * 4)
                 {
                     // the second Linear accumulates into the residual stream itself: hacc = hacc * ratio + bias, then + W_1 relu(u)
@@ -369,21 +390,21 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
                     const float ratio = gemm[1];
                     const vec4f b0 = *reinterpret_cast<const vec4f*>(bias), b1 = *reinterpret_cast<const vec4f*>(bias + 16);
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) {
+                    for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             hacc[rt][0][i] = __builtin_fmaf(hacc[rt][0][i], ratio, b0[i]);
                             hacc[rt][1][i] = __builtin_fmaf(hacc[rt][1][i], ratio, b1[i]);
                         }
                     }
-                    gemm_hidden(hacc, rb, ah, blk * 8 + 4, X, lane);
+                    gemm_hidden<RT>(hacc, rb, ah, blk * 8 + 4, X, lane);
                     conv_scale = gemm[0];
                 }
                 gemm += kHdr + 128;
                 NFA_K8C_STAMP(6 + blk * 4)
                 // pieces of relu(h) for the next block, of h itself for the final layer (no ReLU in front of it: resnet.py:99-100)
-                if (blk + 1 < nb) exchange<true>(hacc, X, X0, wave, lane, conv_scale, worst);
-                else exchange<false>(hacc, X, X0, wave, lane, conv_scale, worst);
+                if (blk + 1 < nb) exchange<true, RT>(hacc, X, X0, wave, lane, conv_scale, worst);
+                else exchange<false, RT>(hacc, X, X0, wave, lane, conv_scale, worst);
                 NFA_K8C_STAMP(7 + blk * 4)
             }
 
@@ -393,22 +414,22 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
                 using Steps = FusedSteps<INVERSE, 8>;
                 const float kappa = gemm[0];
                 const float tail_s = a.sp.tail_logit * gemm[1];   // gemm[1] = 1 / kappa
-                uvec4 fh[4][4], fl[4][4];   // [k-step][row tile]
+                uvec4 fh[4][RT], fl[4][RT];   // [k-step][row tile]
 #pragma unroll
-                for (int S = 0; S < 4; ++S) read_pieces(X, S, lane, fh[S], fl[S]);
+                for (int S = 0; S < 4; ++S) read_pieces<RT>(X, S, lane, fh[S], fl[S]);
                 NFA_K8C_STAMP(20)
                 for (int r = 0; r < rounds; ++r) {
                     const int G = 4 * r + wave;
                     const int Gc = G < groups ? G : groups - 1;   // (a wave without a group: zero fragments, nothing evaluated)
                     const float* fbias = gemm + kHdr + (Gc * 6) * 16 + g * 4;
-                    f32x4 t[6][4];
+                    f32x4 t[6][RT];
 #pragma unroll
                     for (int i = 0; i < 6; ++i) {
                         f32x4 b;
                         load_bias4(b, fbias + i * 16);
 #pragma unroll
-                        for (int rt = 0; rt < 4; ++rt) t[i][rt] = b;
-                        tile_final(t[i], rb[(2 * i) % 4], rb[(2 * i + 1) % 4], ah, 8 * nb + r * 12 + 2 * i, fh, fl);
+                        for (int rt = 0; rt < RT; ++rt) t[i][rt] = b;
+                        tile_final<RT>(t[i], rb[(2 * i) % 4], rb[(2 * i + 1) % 4], ah, 8 * nb + r * 12 + 2 * i, fh, fl);
                         // (behind the layer's last tiles: the next layer's initial-layer fragments)
                         if (r == rounds - 1 && i == 5) {
 #pragma unroll
@@ -420,7 +441,7 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
                     if (G < groups) {
                         const int slot_col = tab[kTabTr + G * 4 + g] * kRowPadC;
 #pragma unroll
-                        for (int rt = 0; rt < 4; ++rt) {
+                        for (int rt = 0; rt < RT; ++rt) {
                             Steps f;
                             f.kappa = kappa;
                             f.kl2e = 1.44269502162933349609375f * kappa;
@@ -462,25 +483,35 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
         // ---- results: position p of a row comes from slot final[p]; a block with any non-finite value or an
         //      activation beyond the f16 range is not written: the exact kernel redoes it from the inputs
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
             lad_acc[rt] += __shfl_xor(lad_acc[rt], 16, kWave);
             lad_acc[rt] += __shfl_xor(lad_acc[rt], 32, kWave);
         }
-        // (lane group g leaves row tile g's sum: one store per lane)
-        s_red[0][wave][lane] = g == 0 ? lad_acc[0] : g == 1 ? lad_acc[1] : g == 2 ? lad_acc[2] : lad_acc[3];
+        // (lane group g leaves row tile g's sum -- RT = 2: groups 0, 1 --: one store per lane)
         {
+            float mine = lad_acc[0];
+#pragma unroll
+            for (int rt = 1; rt < RT; ++rt) mine = g == rt ? lad_acc[rt] : mine;
+            if (g < RT) s_red[0][wave][lane] = mine;
+        }
+        {
+            const int row = tid % kRows, part = tid / kRows;
             float sumsq = 0.0f;
-            for (int j = wave; j < a.Ds; j += kNW) {
-                const float v = s_row[j * kRowPadC + lane];
+            for (int j = part; j < a.Ds; j += kParts) {
+                const float v = s_row[j * kRowPadC + row];
                 sumsq = __builtin_fmaf(v, v, sumsq);
             }
-            s_red[1][wave][lane] = sumsq;
+            s_red[1][part][row] = sumsq;
         }
         const bool wave_bad = __builtin_amdgcn_ballot_w64(!(worst < kF16Overflow)) != 0;
         if (lane == 0) s_bad[wave] = wave_bad ? 1 : 0;
         __syncthreads();
-        const float lad_row = (s_red[0][0][lane] + s_red[0][1][lane]) + (s_red[0][2][lane] + s_red[0][3][lane]);
-        const float sumsq_row = (s_red[1][0][lane] + s_red[1][1][lane]) + (s_red[1][2][lane] + s_red[1][3][lane]);
+        // (every wave computes all rows' totals: row = lane mod rows)
+        const int erow = lane % kRows;
+        const float lad_row = (s_red[0][0][erow] + s_red[0][1][erow]) + (s_red[0][2][erow] + s_red[0][3][erow]);
+        float sumsq_row = 0.0f;
+#pragma unroll
+        for (int part = 0; part < kParts; ++part) sumsq_row += s_red[1][part][erow];
         const bool bad = !(__builtin_fabsf(lad_row) < INFINITY) || !(__builtin_fabsf(sumsq_row) < INFINITY);
         const bool quad_bad = (__builtin_amdgcn_ballot_w64(bad) != 0) || ((s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) != 0);
         if (!quad_bad) {
@@ -497,7 +528,7 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
                     ov[e] = v;
                 }
             }
-            if (wave == 0) {
+            if (wave == 0 && lane < kRows) {
                 float* dst = a.lad + row0 + lane;
                 float v = a.accumulate ? *dst + lad_row : lad_row;
                 if (a.normal) v = (-0.5f * sumsq_row - a.log_z) + v;   // normal.py:31-33, flows/base.py:49
@@ -505,8 +536,12 @@ __global__ void __launch_bounds__(kThreads, 1) rqs_resnet_f16c_kernel(const Args
             }
             my_status |= quad_status;
         }
-        // one flag per 128 rows, zeroed by the launcher: bit 1 / bit 2 = its lower / upper 64 rows are open
-        if (tid == 0 && quad_bad) atomicOr(a.redo + (quad >> 1), 2 << (quad & 1));
+        // one flag word per 128 rows, zeroed by the launcher: 64-row workgroups set bit 1 / bit 2 (its lower / upper 64 rows are
+        // open), 32-row workgroups bits 3 .. 6 (its four quarters): rqs_resnet_kernel.hpp gives the rows to the redo pass's waves
+        if (tid == 0 && quad_bad) {
+            if constexpr (RT == 4) atomicOr(a.redo + (quad >> 1), 2 << (quad & 1));
+            else atomicOr(a.redo + (quad >> 2), 8 << (quad & 3));
+        }
         __syncthreads();  // the row tile, s_bad and s_red are rewritten by the next row block
     }
     if (my_status && a.status) atomicOr(a.status, my_status);
@@ -587,31 +622,41 @@ extern "C" int nfa_rqs_flow_resnet_f16x2_colsplit_f32(const float* inputs, const
     hipMemset(trace_dev, 0, 256 * 64 * 8);
     a.trace = trace_dev;
 #endif
-    const size_t lds = (size_t)2 * k8c::kXVec4 * 16 + (size_t)features * k8c::kRowPadC * sizeof(float) +
-                       (size_t)2 * ((param_words + 3) & ~3) * sizeof(float);
-    const size_t lds_cap = 160 * 1024 - 4096;   // (beside 2.6 KB of static arrays)
-    if (lds > lds_cap) return NFA_ERR_UNSUPPORTED;
-    int64_t blocks = batch / k8c::kRows;
     const int cus = device_cu_count();
-    if (blocks > cus) blocks = cus;
+    // batches with no more 32-row blocks than CUs: 32-row workgroups (twice the workgroups, half of every serial term)
+    // 32-row workgroups, two per CU (twice the workgroups of the 64-row form, half of every serial term per workgroup: 8 192
+    // rows 0.37 ms against 0.60; 16 384 rows 0.59 against 0.61); NFA_K8C_ROWS=64: the 64-row form, one per CU
+    static const int rt_env = getenv("NFA_K8C_ROWS") ? atoi(getenv("NFA_K8C_ROWS")) : 0;
+    const int RT = rt_env == 64 ? 4 : 2;
+    const int occ = RT == 2 ? 2 : 1;
+    const size_t lds = (size_t)2 * k8c::x_vec4_of(RT) * 16 + (size_t)features * k8c::row_pad_of(RT) * sizeof(float) +
+                       (size_t)2 * ((param_words + 3) & ~3) * sizeof(float);
+    const size_t lds_cap = 160 * 1024 - 8192;   // (beside 4.6 KB of static arrays)
+    if (lds > lds_cap) return NFA_ERR_UNSUPPORTED;
+    int64_t blocks = batch / k8c::rows_of(RT);
+    if (blocks > (int64_t)cus * occ) blocks = (int64_t)cus * occ;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     profile_next_launch(&e0, &e1);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks), block(k8c::kThreads);
     const bool inv = (flags & NFA_FLAG_INVERSE) != 0;
     void (*kern)(const k8h::Args) = nullptr;
-    const int which = (inv ? 1 : 0) + (init_ks == 2 ? 2 : 0);
+    const int which = (inv ? 1 : 0) + (init_ks == 2 ? 2 : 0) + (RT == 2 ? 4 : 0);
     switch (which) {
-        case 0: kern = k8c::rqs_resnet_f16c_kernel<false, 1>; break;
-        case 1: kern = k8c::rqs_resnet_f16c_kernel<true, 1>; break;
-        case 2: kern = k8c::rqs_resnet_f16c_kernel<false, 2>; break;
-        default: kern = k8c::rqs_resnet_f16c_kernel<true, 2>; break;
+        case 0: kern = k8c::rqs_resnet_f16c_kernel<false, 1, 4, 1>; break;
+        case 1: kern = k8c::rqs_resnet_f16c_kernel<true, 1, 4, 1>; break;
+        case 2: kern = k8c::rqs_resnet_f16c_kernel<false, 2, 4, 1>; break;
+        case 3: kern = k8c::rqs_resnet_f16c_kernel<true, 2, 4, 1>; break;
+        case 4: kern = k8c::rqs_resnet_f16c_kernel<false, 1, 2, 2>; break;
+        case 5: kern = k8c::rqs_resnet_f16c_kernel<true, 1, 2, 2>; break;
+        case 6: kern = k8c::rqs_resnet_f16c_kernel<false, 2, 2, 2>; break;
+        default: kern = k8c::rqs_resnet_f16c_kernel<true, 2, 2, 2>; break;
     }
-    note_layer_kernel("k8c::rqs_resnet_f16c_kernel<inverse=%d, init_ks=%d, waves=4, K=8>", inv ? 1 : 0, init_ks);
+    note_layer_kernel("k8c::rqs_resnet_f16c_kernel<inverse=%d, init_ks=%d, waves=4, rows=%d, per_cu=%d, K=8>", inv ? 1 : 0, init_ks, 16 * RT, occ);
     hipLaunchKernelGGL(k8c::zero_words_kernel, dim3((unsigned)((batch / 128 + 255) / 256)), dim3(256), 0, st, redo_blocks,
                        (int)(batch / 128));
     if (lds > 64 * 1024) {
-        static unsigned long long raised[4] = {};   // device masks (raise_dynamic_lds)
+        static unsigned long long raised[8] = {};   // device masks (raise_dynamic_lds)
         const int rc_lds = raise_dynamic_lds((const void*)kern, &raised[which], (int)lds_cap);
         if (rc_lds != NFA_OK) return rc_lds;
     }

@@ -284,7 +284,9 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
         // 64 rows are (K8s's four-wave workgroups: the other half was written, log-determinant accumulated, by them)
         const int redo_flag = a.redo ? a.redo[quad] : 1;
         if (redo_flag == 0) continue;
-        const bool write_rows = (redo_flag & 1) || ((redo_flag >> (1 + (wave >> 1))) & 1);
+        // (bit 0: the whole block; bits 1, 2: its lower / upper 64 rows -- K8s's and K8c's 64-row workgroups --; bits 3 .. 6: its
+        //  four 32-row quarters -- K8c's 32-row workgroups, round 6: wave w of this kernel owns quarter w)
+        const bool write_rows = (redo_flag & 1) || ((redo_flag >> (1 + (wave >> 1))) & 1) || ((redo_flag >> (3 + wave)) & 1);
         const int64_t row0 = (quad << 7) + (wave << 5);
         // (lane-derived values are made opaque per iteration: hoisted out of this loop they would
         // stay live through the whole kernel and push the register allocation into scratch)

@@ -318,8 +318,9 @@ def test_column_split_kernel_on_small_batches():
     of a 64-row workgroup, weights straight from global memory into registers -- the form for batches with no more 64-row
     blocks than CUs (`Flow.sample(n)` / `log_prob` of a few thousand rows, a 16-GPU shard of config 4).  The same products in
     the same order as K8s: z is K8s's BIT FOR BIT (log-determinants are summed in another order: rounding only); the oracle
-    on every 4th row; inverse; a ragged batch and rows evaluated alone give the same bits; two workgroups share one redo
-    flag (as K8s's four-wave form); D = 100 (two k-steps in the initial layer, 13 groups: a last round with idle waves)."""
+    on every 4th row; inverse; a ragged batch and rows evaluated alone give the same bits; workgroups are 32 rows and a
+    128-row block's redo word carries a bit per quarter: a hot quarter is redone by the exact kernel, its three siblings keep
+    their bits; D = 100 (two k-steps in the initial layer, 13 groups: a last round with idle waves)."""
     from nflows_amd import configs, ops
     import copy
     import nflows_amd
@@ -351,7 +352,7 @@ def test_column_split_kernel_on_small_batches():
         finally:
             ops.K8C_ENABLED = saved
     nflows_amd.check_status()
-    assert "k8c::" in label and "inverse=0" in label and "k8c::" in label_inv and "inverse=1" in label_inv, (label, label_inv)
+    assert "k8c::" in label and "inverse=0" in label and "rows=32" in label and "k8c::" in label_inv and "inverse=1" in label_inv, (label, label_inv)
     assert torch.equal(lp, lp2)
     assert torch.equal(z, z_s), "%d outputs differ from K8s's" % int((z != z_s).sum())
     assert float((lad - lad_s).abs().max()) < 5e-4
@@ -368,6 +369,7 @@ def test_column_split_kernel_on_small_batches():
     assert float(err.mean()) < 2e-5 and float(err.max()) < 2e-2
     assert redo_hot == 1, "%d blocks redone" % redo_hot
     assert torch.equal(z_hot[128:], z[128:]) and torch.equal(lad_hot[128:], lad[128:])
+    assert torch.equal(z_hot[:64], z[:64]) and torch.equal(lad_hot[:64], lad[:64])      # (quarters 0, 1 were not touched)
     o_hot = oracle_eval(flow_cpu, x_hot[:128].cpu())
     compare("k8c_shared_redo_flag", "z", z_hot[:128].cpu().numpy(), o_hot["z32"], o_hot["z64"], OUT_TOL, max_factor=4.0)
     compare("k8c_shared_redo_flag", "logabsdet", lad_hot[:128].cpu().numpy(), o_hot["lad32"], o_hot["lad64"], LAD_TOL, max_factor=4.0)
