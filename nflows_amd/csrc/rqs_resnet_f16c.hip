@@ -87,11 +87,13 @@ __device__ __forceinline__ void products(f32x4* const (&a)[RT], vec4f ahw, vec4f
     for (int rt = 0; rt < RT; ++rt) *a[rt] = NFA_K8C_MFMA(ah, l[rt], *a[rt]);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) *a[rt] = NFA_K8C_MFMA(ah, h[rt], *a[rt]);
-    // the operands stay live past the last product (rqs_resnet_f16s.hip: hipcc otherwise puts a renamed four-register
-    // result on the registers of an operand that has just had its last use while the matrix pipe may still read it)
-    asm volatile("" ::"v"(ah), "v"(al));
+    // The operands stay live past the last product (rqs_resnet_f16s.hip: hipcc otherwise puts a renamed four-register
+    // result on the registers of an operand that has just had its last use while the matrix pipe may still read it).  The
+    // statement takes the accumulator as an in / out operand: a plain input-only statement has no dependence on the
+    // MFMAs, and hipcc moved it in FRONT of them (tests/test_host_logic.py's assembly check found `v_mfma v[74:77],
+    // v[74:77], ...` in the two-per-CU instances).  It is empty: nothing reads the result early.
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) asm volatile("" ::"v"(h[rt]), "v"(l[rt]));
+    for (int rt = 0; rt < RT; ++rt) asm volatile("" : "+v"(*a[rt]) : "v"(ah), "v"(al), "v"(h[rt]), "v"(l[rt]));
 }
 
 // pieces of k-step S for the row tiles from the exchange buffer

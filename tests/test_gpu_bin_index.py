@@ -284,8 +284,9 @@ def test_whole_layer_kernels_choose_the_reference_bin(golden_dir, engine, rows, 
     x = torch.randn(rows, D, generator=gen) * 1.3
     flow = copy.deepcopy(flow_cpu).to(DEV).eval()
     layers = list(flow._transform._transforms)
-    saved = ops.K8S_ENABLED
+    saved, saved_c = ops.K8S_ENABLED, ops.K8C_ENABLED
     ops.K8S_ENABLED = engine.startswith("k8s")
+    ops.K8C_ENABLED = False      # (K8s's diagnostic twin is the subject; K8c has none and would take the uncaptured launches)
     try:
         with torch.no_grad():
             if not inverse:
@@ -311,7 +312,7 @@ def test_whole_layer_kernels_choose_the_reference_bin(golden_dir, engine, rows, 
         except AssertionError as e:
             assert "negative discriminant" in str(e)
     finally:
-        ops.K8S_ENABLED = saved
+        ops.K8S_ENABLED, ops.K8C_ENABLED = saved, saved_c
     ref_flow = copy.deepcopy(flow_cpu)
     if inverse:   # the launch's last layer = the flow's first pair
         ref_flow._transform._transforms = torch.nn.ModuleList(list(flow_cpu._transform._transforms)[:2])
