@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NFA_ABI_VERSION 13 /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 7; round 4: 8,
+#define NFA_ABI_VERSION 14 /* bumped whenever a packed layout, a flag set or an entry point changes (round 3: 3 .. 7; round 4: 8,
                               9: whole-layer kernels for 2 .. 16 bins, nfa_resnet_backward_f32, W_f^T in K14's backward stream;
                               round 5: 10: `bin_idx` outputs of the spline kernels, nfa_searchsorted_f32; 11: NFA_FLAG_RESIDUAL_BLOCKS;
                               round 6: 12: nfa_rqs_flow_resnet_f16x3_f32 (K8x), the *_logits_f32 diagnostic entries,
@@ -262,6 +262,12 @@ int nfa_rqs_coupling_fused_linear_f32(const float *inputs, const float *hidden,
  * any other num_bins from 2 to 16 and 20, 24, 32 (plain final-layer loop on the spline kernel's own evaluator), linear
  * tails, hidden_features = 128, d_i <= 64, d_t % 4 == 0, d_t <= 64, features % 4 == 0,
  * features <= 128, batch % 128 == 0; otherwise NFA_ERR_UNSUPPORTED.
+ * ABI 14 (round 6): spec->tails = NFA_TAILS_NONE -- the constructor default of the reference's coupling
+ * (coupling.py:503-515, :543-547, :565-570: the constrained spline on [left, right] x [bottom, top]) -- at every bin count
+ * above, ReLU blocks, no context, no NFA_FLAG_LOGITS_LOG2E: P = 3 K + 1 logits per feature (K + 1 derivative logits), the
+ * final layer's rows padded to 16 ceil((3 K + 1) / 16) per feature in the general row order, the plain loop; an input
+ * outside the box leaves NFA_STATUS_OUTSIDE_DOMAIN in `status` (rational_quadratic.py:81-82).  Table slots must not repeat a
+ * column the layer transforms (no spare columns: a pad feature would lie inside the box).
  */
 int nfa_rqs_coupling_resnet_f32(const float *inputs, const void *weights_packed,
                                 const float *bias_packed, const int32_t *layer_tables,

@@ -34,7 +34,7 @@ ACTIVATION_RELU, ACTIVATION_LEAKY_RELU, ACTIVATION_ELU, ACTIVATION_TANH = 0, 1, 
 TAILS_NONE, TAILS_LINEAR = 0, 1
 SCALE_DEFAULT, SCALE_GENERAL, SCALE_ADDITIVE, SCALE_GIVEN, SCALE_SOFTPLUS = 0, 1, 2, 3, 4
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 EXPORTS = (
     "nfa_abi_version",

@@ -279,6 +279,14 @@ __device__ __forceinline__ int rqs_eval(float x, float* sl, const RqsDev& sp, fl
     } else if (LINEAR) {  // logits padded with the tail constant on both sides
         u0 = (k == 0) ? sp.tail_logit : sd[k - 1];
         u1 = (k >= sp.nd) ? sp.tail_logit : sd[k];  // padded index k+1 past the given logits
+    } else if (REGS) {  // K + 1 logits in registers (the whole-layer kernel K8 with tails=None): selected, not indexed
+        u0 = sd[0];
+        u1 = sd[1];
+#pragma unroll
+        for (int q = 1; q < KT; ++q) {
+            u0 = (k == q) ? sd[q] : u0;
+            u1 = (k == q) ? sd[q + 1] : u1;
+        }
     } else {
         u0 = sd[k];
         u1 = sd[k + 1];

@@ -57,10 +57,14 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
     // activations other than ReLU: 8 or 10 bins, the plain loop, no log2(e) fold
     if (activation != NFA_ACTIVATION_RELU && (any_bins || (flags & NFA_FLAG_LOGITS_LOG2E)))
         return NFA_ERR_UNSUPPORTED;
-    const int rows_per_feature = a.sp.K == 8 ? 24 : 16 * ((3 * a.sp.K - 1 + 15) / 16);
+    // tails=None (round 6): 3 K + 1 logits per feature, the plain loop, ReLU, no context, no log2(e) fold, no redo role
+    const bool no_tails = !a.sp.linear;
+    if (no_tails && (activation != NFA_ACTIVATION_RELU || (flags & NFA_FLAG_LOGITS_LOG2E) || context_features > 0 || dbg_logits || redo))
+        return NFA_ERR_UNSUPPORTED;
+    const int rows_per_feature = no_tails ? 16 * ((3 * a.sp.K + 1 + 15) / 16) : a.sp.K == 8 ? 24 : 16 * ((3 * a.sp.K - 1 + 15) / 16);
     if (a.sp.beta != 1.0f) return NFA_ERR_UNSUPPORTED;  // (identity initialisation: functional callers only)
     const bool bins_served = (a.sp.K >= 2 && a.sp.K <= 16) || a.sp.K == 20 || a.sp.K == 24 || a.sp.K == 32;
-    if (!bins_served || (a.sp.K != 8 && (flags & NFA_FLAG_LOGITS_LOG2E)) || !a.sp.linear ||
+    if (!bins_served || (a.sp.K != 8 && (flags & NFA_FLAG_LOGITS_LOG2E)) ||
         hidden_features != 128 || (num_transform & 3) != 0 ||
         num_transform > 64 || num_identity > 64 || features > 128 || (features & 3) != 0 ||
         (batch & 127) != 0 || num_blocks > 64 || num_layers > 4096)
@@ -115,7 +119,7 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         return e ? atoi(e) : 2;
     }();
     // (with the log2(e) fold only the default woven form exists)
-    const bool pipe = !dbg_logits && !any_bins && activation == NFA_ACTIVATION_RELU && use_pipe && ((a.sp.K == 8 && (!(flags & NFA_FLAG_LOGITS_LOG2E) || use_pipe == 2)) ||
+    const bool pipe = !no_tails && !dbg_logits && !any_bins && activation == NFA_ACTIVATION_RELU && use_pipe && ((a.sp.K == 8 && (!(flags & NFA_FLAG_LOGITS_LOG2E) || use_pipe == 2)) ||
                                   (a.sp.K == 10 && use_pipe == 2));
     // a context: the woven default form at 8 / 10 bins with ReLU; the plain loop for the other bin counts and
     // activations (round 5: rqs_resnet_ctx.hip)
@@ -175,9 +179,13 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
         else kern = inv ? rqs_resnet_kernel<true, 1, 2, 2, 8, true> : rqs_resnet_kernel<false, 1, 2, 2, 8, true>;
     }
     if (dbg_logits) kern = resnet_debug_kernel(inv, init_ks);
+    if (no_tails) {
+        kern = resnet_tails_kernel(a.sp.K, inv, init_ks);
+        if (!kern) return NFA_ERR_UNSUPPORTED;
+    }
     if (!redo)
-        note_layer_kernel("rqs_resnet_kernel<inverse=%d, init_ks=%d, pipe=%d, K=%d, ctx=%d, act=%d>", inv ? 1 : 0, init_ks,
-                          pipe ? use_pipe : 0, a.sp.K, with_ctx ? 1 : 0, activation);
+        note_layer_kernel("rqs_resnet_kernel<inverse=%d, init_ks=%d, pipe=%d, K=%d, ctx=%d, act=%d%s>", inv ? 1 : 0, init_ks,
+                          pipe ? use_pipe : 0, a.sp.K, with_ctx ? 1 : 0, activation, no_tails ? ", tails=none" : "");
     if (with_ctx && lds > 64 * 1024) {
         static unsigned long long raised_ctx[8 + 31 * 4 + 3 * 8] = {};   // device masks (raise_dynamic_lds)
         const int which = (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0) +
@@ -187,6 +195,10 @@ static int launch_resnet_layers(const float* inputs, const void* weights_packed,
             const int rc_lds = raise_dynamic_lds((const void*)kern, &raised_ctx[which], 160 * 1024 - 2048);
             if (rc_lds != NFA_OK) return rc_lds;
         }
+    } else if (no_tails && lds > 64 * 1024) {
+        static unsigned long long raised_tails[31 * 4] = {};
+        const int rc_lds = raise_dynamic_lds((const void*)kern, &raised_tails[(a.sp.K - 2) * 4 + (inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)], 160 * 1024 - 2048);
+        if (rc_lds != NFA_OK) return rc_lds;
     } else if (dbg_logits && lds > 64 * 1024) {
         static unsigned long long raised_dbg[4] = {};
         const int rc_lds = raise_dynamic_lds((const void*)kern, &raised_dbg[(inv ? 1 : 0) + (init_ks == 4 ? 2 : 0)], 160 * 1024 - 2048);

@@ -212,8 +212,13 @@ __device__ __forceinline__ void gemm_context_tile(f32x16& acc, const float* s_ct
 // features in the initial layer's input, and every residual block's result is multiplied by
 // sigmoid(context_layer(context)) before the skip connection (F.glu of the concatenation).
 // DBG (rqs_resnet_dbg.hip, tests): the plain 8-bin loop with the last layer's logits stored as well.
-template <bool INVERSE, int PRESCALED, int INIT_KS, int PIPE = 0, int KB = 8, bool CTX = false, int ACT = kActRelu, bool DBG = false>  // PIPE: 0 plain loop, 1 woven, 2 woven with FlatSteps<FAST>; ACT: the blocks' activation
+// LINEAR = false (round 6): tails=None couplings (coupling.py:565-570: the constrained spline on [left, right] x [bottom, top],
+// K + 1 derivative logits per feature, an input outside the box raises NFA_STATUS_OUTSIDE_DOMAIN) -- the plain loop on K1's
+// register evaluator at every bin count, 3 K + 1 logits per feature padded to whole 16-row lane-half shares
+template <bool INVERSE, int PRESCALED, int INIT_KS, int PIPE = 0, int KB = 8, bool CTX = false, int ACT = kActRelu, bool DBG = false,
+          bool LINEAR = true>  // PIPE: 0 plain loop, 1 woven, 2 woven with FlatSteps<FAST>; ACT: the blocks' activation
 __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs a) {
+    static_assert(LINEAR || (PIPE == 0 && PRESCALED == 1 && !CTX && !DBG && ACT == kActRelu), "tails=None: the plain loop, ReLU, no context");
     static_assert(!DBG || (KB == 8 && PIPE == 0 && !CTX), "the diagnostic instances: 8 bins, the plain loop");
     static_assert(ACT == kActRelu || (PIPE == 0 && PRESCALED == 1 && ACT >= kActLeakyRelu && ACT <= kActTanh),
                   "other activations: the plain loop");
@@ -221,7 +226,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                   "10 bins: plain loop, or woven with the shorter sequence; other bin counts (2 .. 16, 20, 24, 32): plain loop");
     // rows of the final layer per transformed feature (8 bins: 23 logits padded to 24, two features share three tiles;
     // otherwise 3 K - 1 padded to whole 16-row lane-half shares)
-    constexpr int kFinalRows = KB == 8 ? 24 : 16 * ((3 * KB - 1 + 15) / 16);
+    constexpr int kFinalRows = !LINEAR ? 16 * ((3 * KB + 1 + 15) / 16) : KB == 8 ? 24 : 16 * ((3 * KB - 1 + 15) / 16);
     // dynamic LDS: the weight ring, then per wave a [D][33] row tile
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     __shared__ int s_tab[2][kTabLayer];   // tables of the current and the next layer
@@ -535,7 +540,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                     my_status |= f.status;
                 }
                 NFA_STAMP()
-            } else if constexpr (KB != 8 && KB != 10) {
+            } else if constexpr (!LINEAR || (KB != 8 && KB != 10)) {
                 // ---- any other bin count (round 4: the second pass behind K8h's instances for 2 .. 16 bins): 3 K - 1
                 //      logits per feature padded to T tiles' lane-half shares (16 T rows), the rows ordered so that the
                 //      16 T accumulator values of lane-half h are the logits of feature 2g + h; evaluated by the
@@ -556,7 +561,7 @@ __global__ void __launch_bounds__(kBlock, 2) rqs_resnet_kernel(const ResnetArgs 
                         for (int q = 0; q < 16; ++q) p[16 * t + q] = acc[q];
                     }
                     float y, l;
-                    my_status |= rqs_eval<KB, INVERSE, true, true>(xin, p, sp0, y, l);
+                    my_status |= rqs_eval<KB, INVERSE, LINEAR, true>(xin, p, sp0, y, l);
                     *slot = y;
                     lad_acc += l;
                 }
@@ -728,5 +733,6 @@ typedef void (*ResnetKernelFn)(const ResnetArgs);
 ResnetKernelFn resnet_bins_kernel(int K, bool inverse, int init_ks);                      // 2 .. 16 except 8 / 10, 20, 24, 32
 ResnetKernelFn resnet_context_kernel(int K, int activation, bool inverse, int init_ks);     // with a context (round 5): those of the two lines above
 ResnetKernelFn resnet_activation_kernel(int activation, int K, bool inverse, int init_ks);  // NFA_ACTIVATION_* > 0, 8 / 10 bins
+ResnetKernelFn resnet_tails_kernel(int K, bool inverse, int init_ks);                     // rqs_resnet_tails.hip: tails=None, every bin count
 ResnetKernelFn resnet_debug_kernel(bool inverse, int init_ks);                              // rqs_resnet_dbg.hip: 8 bins, ReLU, logits stored
 }  // namespace nfa

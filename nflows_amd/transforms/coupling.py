@@ -716,7 +716,9 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         # (layers of one run may differ in their feature split -- odd feature counts under alternating masks --:
         # the run is given one padded geometry)
         features, num_blocks, ce = self._static_signature()
-        return ("k8", features, num_blocks, self.num_bins, self.tail_bound,
+        # (tails=None: no spare columns -- the layers of a run share their exact split)
+        split = None if self.tails == "linear" else (self.num_transform_features, self.num_identity_features)
+        return ("k8", features, num_blocks, self.num_bins, self.tail_bound, self.tails, split,
                 self.min_bin_width, self.min_bin_height, self.min_derivative,
                 self._log2e(), self._use_f16(), self.conditioner_act_scale, ce, self.conditioner_engine,
                 self._block_activation())
@@ -761,7 +763,12 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
                           and self.num_identity_features + net.context_features <= 64)
         return (self.fuse_conditioner and self.fuse_final_linear and not torch.is_grad_enabled()
                 and context_ok and type(net) is ResidualNet
-                and net.hidden_features <= 128 and self.tails == "linear"
+                and net.hidden_features <= 128
+                # tails=None (round 6: the constrained spline, K8's plain loop -- csrc/rqs_resnet_tails.hip): ReLU, no
+                # context, and a geometry without spare columns (a pad feature would be INSIDE the box: transformed)
+                and (self.tails == "linear" or (self.tails is None and context is None
+                                                and self.num_transform_features % 4 == 0
+                                                and self._block_activation() == N.ACTIVATION_RELU))
                 and ops.whole_layer_bins(self.num_bins)
                 and 1 <= self.num_identity_features <= 64 and 1 <= self.num_transform_features
                 and self._fused_geometry()[1] <= 64 and self._fused_geometry()[0] <= 128
@@ -802,7 +809,7 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
 
     def _log2e(self):
         """The fold is implemented for the 8-bin evaluation only."""
-        return self.resnet_log2e and self.num_bins == 8
+        return self.resnet_log2e and self.num_bins == 8 and self.tails == "linear"
 
     # GEMM engine of the whole-layer kernel: "f16x2" = two f16 pieces per operand on the f16 matrix
     # pipe (K8h / K8s, three products: 22-bit operand significands, the fp32 fma chain's error class; row blocks that
@@ -817,13 +824,13 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         """K8h serves 8 and 10 bins; with a context up to 32 context features beside up to 32 identity features
         (of the run's geometry) -- otherwise the bf16x3 kernel (K8) runs."""
         ce = self._static_signature()[2]
-        return (self.conditioner_engine == "f16x2" and ops.whole_layer_bins(self.num_bins) and not self._log2e()
+        return (self.conditioner_engine == "f16x2" and self.tails == "linear" and ops.whole_layer_bins(self.num_bins) and not self._log2e()
                 and (ce is None or (ce <= 32 and (geometry or self._fused_geometry())[2] <= 32)))
 
     def _use_f16x3(self, geometry=None):
         """K8x serves the whole-layer bin counts (ops.whole_layer_bins) with ReLU blocks and no context -- otherwise engine
         "f16x3" means the bf16x3 kernel (K8)."""
-        return (self.conditioner_engine == "f16x3" and ops.whole_layer_bins(self.num_bins) and not self._log2e()
+        return (self.conditioner_engine == "f16x3" and self.tails == "linear" and ops.whole_layer_bins(self.num_bins) and not self._log2e()
                 and self._static_signature()[2] is None and self._block_activation() == N.ACTIVATION_RELU)
 
     def _packed_resnet_f16x3(self, geometry=None):

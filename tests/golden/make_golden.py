@@ -949,6 +949,53 @@ def flow_h128_case():
     print("flows_h128: 1 case")
 
 
+
+def tails_none_flow_cases():
+    """tails=None couplings (the constructor's default: the constrained spline on [0, 1]^2, K + 1 derivative logits,
+    coupling.py:543-547, :565-570) with ResidualNet conditioners (H = 128 x 2 blocks) -- the shapes the whole-layer kernel
+    K8 serves since round 6 (csrc/rqs_resnet_tails.hip).  Weights rebuilt from the seed (checksums stored)."""
+    out, meta = {}, []
+    for name, seed, (L, D, K, B) in (("none_k8_d16", 0, (3, 16, 8, 200)), ("none_k10_d64", 1, (2, 64, 10, 160)),
+                                     ("none_k4_d24", 2, (4, 24, 4, 136))):
+        torch.manual_seed(seed)
+        layers = []
+        for i in range(L):
+            layers.append(RandomPermutation(D))
+            layers.append(PiecewiseRationalQuadraticCouplingTransform(
+                mask=torchutils.create_alternating_binary_mask(D, even=(i % 2 == 0)),
+                transform_net_create_fn=lambda i_, o_: ResidualNet(i_, o_, hidden_features=128, num_blocks=2),
+                num_bins=K, tails=None))
+        t = CompositeTransform(layers)
+        with torch.no_grad():
+            for p_name, p in t.named_parameters():
+                if "final_layer" in p_name:
+                    p.mul_(6.0)
+        g = torch.Generator().manual_seed(100 + seed)
+        x = 0.02 + 0.96 * torch.rand(B, D, generator=g)
+        y = 0.02 + 0.96 * torch.rand(B, D, generator=g)
+        t.eval()
+        with torch.no_grad():
+            z, lad = t(x)
+            xi, ladi = t.inverse(y)
+            t64 = t.double()
+            z64, lad64 = t64(x.double())
+            xi64, ladi64 = t64.inverse(y.double())
+            t.float()
+        for k, v in dict(x=x, y=y, z=z, lad=lad, inv_x=xi, inv_lad=ladi, z64=z64, lad64=lad64, inv_x64=xi64,
+                         inv_lad64=ladi64).items():
+            out[name + "/" + k] = npy(v)
+        names, sums = [], []
+        for k, v in t.state_dict().items():
+            names.append(k)
+            sums.append([float(v.double().sum()), float(v.double().abs().sum())])
+        out[name + "/param_names"] = np.array(names).astype(str)
+        out[name + "/param_checksums"] = np.array(sums, dtype=np.float64)
+        meta.append((name, repr(dict(L=L, D=D, K=K, H=128, B=B, seed=seed, scale_final=6.0))))
+    out["meta"] = np.array(meta, dtype=object).astype(str)
+    np.savez_compressed(os.path.join(HERE, "flows_tails_none.npz"), **out)
+    print("flows_tails_none:", len(meta), "cases")
+
+
 def conditional_flow_case():
     """A conditional flow at the whole-layer kernels' layer shape: RandomPermutation + RQ coupling with
     ResidualNet(H = 128, 2 blocks, context_features = 12) conditioners (resnet.py:9-52: context
@@ -1528,6 +1575,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "lq":
         sibling_spline_cases()
         sibling_coupling_cases()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "tails_none":
+        tails_none_flow_cases()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "h128":
         flow_h128_case()

@@ -392,6 +392,37 @@ def test_f16x3_packing_of_the_other_bin_counts(K):
             assert abs(got_b - ref_b) <= 1e-6 * max(1.0, abs(ref_b)), (t, i)
 
 
+def test_whole_layer_packing_takes_the_tails_none_parameter_count():
+    """tails=None (round 6): P = 3 K + 1 logits per feature; ops.pack_resnet_conditioner pads them to whole 16-row shares in
+    the general row order (K = 8: 25 -> 32 rows, where linear tails use the 24-row order), width / height rows divided by
+    sqrt(hidden), the K + 1 derivative rows untouched; the eligibility rules keep the f16 engines and padded geometries away."""
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import ResidualNet
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    from nflows_amd.utils import torchutils
+    torch.manual_seed(3)
+    for K, dt in ((8, 8), (10, 4), (4, 12)):
+        P = 3 * K + 1
+        R = ops.final_rows_per_feature(P)
+        assert R == 16 * ((P + 15) // 16)
+        net = ResidualNet(6, dt * P, hidden_features=128, num_blocks=1).float()
+        wp, bp = ops.pack_resnet_conditioner(net, dt, P)
+        assert wp.shape[0] == 2 + 16 + 2 * (dt * R // 32) and bp.shape == (128 + 256 + dt * R,)
+        # the biases of feature 0 (lane-half 0 of the group's tiles): width / height entries scaled, derivative entries not
+        got = bp[128 + 256:].view(-1, 2, 16)[0:R // 16, 0, :].reshape(-1)[:P]
+        want = net.final_layer.bias.detach().view(dt, P)[0].clone()
+        want[:2 * K] /= math.sqrt(128)
+        assert torch.allclose(got, want, atol=1e-7), K
+    layer = RQ(torchutils.create_alternating_binary_mask(16, even=True), lambda i, o: ResidualNet(i, o, hidden_features=128, num_blocks=2),
+               num_bins=10, tails=None)
+    assert layer._transform_dim_multiplier() == 31 and not layer._use_f16() and not layer._use_f16x3() and not layer._log2e()
+    assert layer._run_signature()[5:7] == (None, (8, 8))
+    odd = RQ(torchutils.create_alternating_binary_mask(10, even=True), lambda i, o: ResidualNet(i, o, hidden_features=128, num_blocks=2),
+             num_bins=10, tails=None)
+    with torch.no_grad():
+        assert not odd._resnet_eligible(None)      # five transformed features: a spare column would be needed
+
+
 @pytest.mark.parametrize("dt", [32, 12, 4])
 def test_f16_colsplit_packing_is_the_tile16_packing_rearranged(dt):
     """Host side of K8c (ops.pack_resnet_conditioner_f16(tile16=True, colsplit=True), round 6): parameter words and every
