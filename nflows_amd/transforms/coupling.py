@@ -260,14 +260,18 @@ class CouplingTransform(Transform):
             return self._reference_sequence(inputs, context, False, logabsdet_accumulator)
         if inputs.dim() == 4 or inputs.dtype == torch.float64 or not self.supports_fused_permutation:
             return self._generic(inputs, context, False, logabsdet_accumulator)
-        if self.unconditional_transform is None:
-            whole = self._whole_layer(inputs, context, False, in_perm, None, logabsdet_accumulator)
-            if whole is not None:
-                return whole
+        # (with an unconditional transform -- coupling.py:90-94 -- the whole-layer kernel still does the conditioned half: the
+        #  conditioner sees the identity features as they come in, they are transformed afterwards)
+        whole = self._whole_layer(inputs, context, False, in_perm, None, logabsdet_accumulator)
+        if whole is not None and self.unconditional_transform is None:
+            return whole
         identity_split = _autograd.select_columns(inputs, self._identity_columns(in_perm))
-        outputs, logabsdet = self._condition_and_transform(
-            inputs, identity_split, context, inverse=False, in_perm=in_perm,
-            accumulate_into=logabsdet_accumulator)
+        if whole is not None:
+            outputs, logabsdet = whole
+        else:
+            outputs, logabsdet = self._condition_and_transform(
+                inputs, identity_split, context, inverse=False, in_perm=in_perm,
+                accumulate_into=logabsdet_accumulator)
         if self.unconditional_transform is not None:
             identity_split, logabsdet_identity = self.unconditional_transform(identity_split, context)
             if logabsdet_accumulator is not None:
@@ -293,6 +297,19 @@ class CouplingTransform(Transform):
         logabsdet_identity = None
         if self.unconditional_transform is not None:
             identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
+            if not torch.is_grad_enabled():
+                # (coupling.py:114-118: the conditioner sees the identity features AFTER the unconditional inverse -- the
+                #  whole-layer kernel on the rows with those columns replaced; they pass through it unchanged)
+                moved = inputs.clone()
+                moved.index_copy_(1, self.identity_features, identity_split)
+                whole = self._whole_layer(moved, context, True, None, out_scatter, logabsdet_accumulator)
+                if whole is not None:
+                    outputs, logabsdet = whole
+                    if logabsdet_accumulator is not None:
+                        logabsdet += logabsdet_identity
+                    else:
+                        logabsdet = logabsdet + logabsdet_identity
+                    return outputs, logabsdet
         outputs, logabsdet = self._condition_and_transform(
             inputs, identity_split, context, inverse=True, out_scatter=out_scatter,
             accumulate_into=logabsdet_accumulator)

@@ -1446,3 +1446,54 @@ def test_conditional_flows_of_any_shape_in_the_whole_layer_kernel(monkeypatch, e
     assert (lp.cpu().double() - lp64).abs().max().item() < 5e-5 * (1 + lp64.abs().max().item())
     assert (z - z2).abs().max().item() < 5e-5 and (lad - lad2).abs().max().item() < 5e-4
     assert (xr - xd).abs().max().item() < 2e-4 and (lad + lad_inv).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("tails", ["linear", None])
+def test_whole_layer_kernel_beside_an_unconditional_transform(tails, restore_fused_path):
+    """apply_unconditional_transform=True (coupling.py:524-538, :90-94, :114-118): the identity half goes through a
+    batch-shared spline of its own.  The conditioned half still runs in the whole-layer kernel (round 6) -- the conditioner
+    sees the identity features before (forward) / after (inverse) that spline --; results against the layer-by-layer path,
+    alone and behind a fused permutation."""
+    from nflows_amd import ops
+    from nflows_amd.nn.nets import ResidualNet
+    from nflows_amd.transforms import CompositeTransform, RandomPermutation
+    from nflows_amd.transforms import PiecewiseRationalQuadraticCouplingTransform as RQ
+    from nflows_amd.utils import torchutils
+    import nflows_amd
+    torch.manual_seed(11)
+    D = 16
+    kw = dict(tails="linear", tail_bound=3.0) if tails == "linear" else dict(tails=None)
+    layers = []
+    for i in range(2):
+        layers.append(RandomPermutation(D))
+        layers.append(RQ(torchutils.create_alternating_binary_mask(D, even=(i % 2 == 0)),
+                         lambda i_, o_: ResidualNet(i_, o_, hidden_features=128, num_blocks=2), num_bins=8,
+                         apply_unconditional_transform=True, **kw))
+    t = CompositeTransform(layers).to(DEV).eval()
+    with torch.no_grad():
+        for n, p in t.named_parameters():
+            if "final_layer" in n or "unconditional_transform" in n:
+                p.mul_(4.0) if "final_layer" in n else p.normal_(0.0, 1.0)
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.rand(1000, D, generator=gen) * 0.96 + 0.02 if tails is None else torch.randn(1000, D, generator=gen) * 1.5).to(DEV)
+    res = {}
+    for path in ("k8", "none"):
+        _select_fused_path(path)
+        with torch.no_grad():
+            z, lad = t(x)
+            label = ops.last_layer_kernel()
+            xr, ladr = t.inverse(z)
+            label_i = ops.last_layer_kernel()
+        nflows_amd.check_status()
+        if path == "k8":
+            assert "resnet" in label and "inverse=0" in label and "resnet" in label_i and "inverse=1" in label_i, (label, label_i)
+        res[path] = (z, lad, xr, ladr)
+    a, b = res["k8"], res["none"]
+    # (steep random splines, log-determinants of ~30: two correct fp32 evaluations differ on a few ill-conditioned elements --
+    #  means and 99 % quantiles, and the round trip against the layer-by-layer path's own)
+    def close(u, v, mean_tol, q_tol):
+        d = (u - v).abs().flatten().float()
+        return float(d.mean()) < mean_tol and float(torch.quantile(d, 0.99)) < q_tol
+    assert close(a[0], b[0], 2e-6, 5e-5) and close(a[1], b[1], 1e-4, 2e-3)
+    assert close(a[2], b[2], 2e-5, 5e-4) and close(a[3], b[3], 1e-3, 1e-2)
+    assert float((a[2] - x).abs().mean()) <= 2.0 * float((b[2] - x).abs().mean()) + 1e-6
