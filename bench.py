@@ -371,6 +371,28 @@ def other_configs(dev, steps):
             del flow
         except Exception as e:
             log("other_configs: configs[4] skipped: %r" % (e,))
+        try:   # the reference constructor's DEFAULT coupling (num_bins=10, tails=None: coupling.py:503-515), not a BASELINE config
+            from nflows_amd.transforms import CompositeTransform, RandomPermutation
+            from nflows_amd.nn.nets import ResidualNet
+            from nflows_amd.utils import torchutils
+            torch.manual_seed(0)
+            t = CompositeTransform(sum([[RandomPermutation(64), RQ(torchutils.create_alternating_binary_mask(64, even=(i % 2 == 0)),
+                                         lambda a, b: ResidualNet(a, b, hidden_features=128, num_blocks=2), num_bins=10, tails=None)]
+                                        for i in range(32)], [])).to(dev).eval()
+            x = torch.rand(65536, 64, device=dev) * 0.98 + 0.01
+            macs = 32 * (32 * 31 * 128 + 32 * 128 + 4 * 128 * 128)
+            entry("default constructor: 32 x RQ coupling, D=64, num_bins=10, tails=None (constrained spline on [0, 1]), forward",
+                  timed(lambda: t(x), max(10, steps), 3), 65536, bytes_per_row=32 * (256 + 32 * 31 * 4 + 256 + 4), macs_per_row=macs)
+            saved = (RQ.fuse_conditioner, RQ.fuse_final_linear)
+            try:
+                RQ.fuse_conditioner = RQ.fuse_final_linear = False
+                entry("the same, layer by layer (library GEMMs + K1)", timed(lambda: t(x), 5, 2), 65536,
+                      bytes_per_row=32 * (256 + 32 * 31 * 4 + 256 + 4), macs_per_row=macs)
+            finally:
+                RQ.fuse_conditioner, RQ.fuse_final_linear = saved
+            del t
+        except Exception as e:
+            log("other_configs: tails=None flow skipped: %r" % (e,))
     torch.cuda.empty_cache()
     return out
 
