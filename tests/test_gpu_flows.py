@@ -1497,3 +1497,50 @@ def test_whole_layer_kernel_beside_an_unconditional_transform(tails, restore_fus
     assert close(a[0], b[0], 2e-6, 5e-5) and close(a[1], b[1], 1e-4, 2e-3)
     assert close(a[2], b[2], 2e-5, 5e-4) and close(a[3], b[3], 1e-3, 1e-2)
     assert float((a[2] - x).abs().mean()) <= 2.0 * float((b[2] - x).abs().mean()) + 1e-6
+
+
+@pytest.mark.parametrize("engine,tails", [("f16x3", "linear"), ("f16x2", None)])
+def test_whole_layer_kernel_random_geometries_round_6(engine, tails, restore_fused_path, monkeypatch):
+    """The sweep of test_whole_layer_kernel_random_geometries for what round 6 added: the three-piece engine K8x (every
+    whole-layer bin count, d_i on both sides of 32, ragged batches) and tails=None couplings (K8's constrained-spline
+    instances, whatever the engine switch says), against the layer-by-layer path."""
+    import nflows_amd
+    from nflows_amd import ops
+    from nflows_amd import transforms as T
+    from nflows_amd.nn.nets import ResidualNet
+    monkeypatch.setattr(T.PiecewiseRationalQuadraticCouplingTransform, "conditioner_engine", engine)
+    rng = np.random.RandomState(20260930 + (0 if tails else 1))
+    for case in range(14):
+        D = int(rng.choice([8, 12, 20, 36, 64, 96, 128]))
+        dt = int(rng.choice([v for v in range(4, min(D, 68), 4) if D - v <= 64 and D - v >= 1]))
+        bins = int(rng.choice([3, 4, 8, 8, 10, 12, 16, 24]))
+        blocks = int(rng.randint(0, 4))
+        mask = np.zeros(D, dtype=np.int64)
+        mask[rng.permutation(D)[:dt]] = 1
+        torch.manual_seed(3000 + case)
+        layers = []
+        for i in range(3):
+            if rng.rand() < 0.7:
+                layers.append(T.RandomPermutation(D))
+            m = torch.from_numpy(mask if i % 2 == 0 else np.roll(mask, 1))
+            kw = dict(tails="linear", tail_bound=3.0) if tails else dict(tails=None)
+            layers.append(T.PiecewiseRationalQuadraticCouplingTransform(
+                m, lambda a, b, nb=blocks: ResidualNet(a, b, hidden_features=128, num_blocks=nb), num_bins=bins, **kw))
+        t = T.CompositeTransform(layers).to(DEV).eval()
+        B = int(rng.choice([128, 256 + 17, 1024, 1000, 4096]))
+        x = (torch.randn(B, D, device=DEV) * 1.3) if tails else (torch.rand(B, D, device=DEV) * 0.98 + 0.01)
+        with torch.no_grad():
+            _select_fused_path("k8")
+            assert all(l._resnet_eligible(None) for l in layers if hasattr(l, "_resnet_eligible")), (D, dt)
+            z1, l1 = t(x)
+            label = ops.last_layer_kernel()
+            x1, li1 = t.inverse(z1)
+            _select_fused_path("none")
+            z0, l0 = t(x)
+            x0, li0 = t.inverse(z1)
+        nflows_amd.check_status()
+        what = "case %d: D=%d d_t=%d bins=%d blocks=%d B=%d %s" % (case, D, dt, bins, blocks, B, label)
+        assert ("k8x::" in label) if tails else ("tails=none" in label), what
+        for got, want, tol in ((z1, z0, 1e-4), (l1, l0, 2e-3), (x1, x0, 1e-4), (li1, li0, 2e-3)):
+            d = (got - want).abs()
+            assert d.max().item() < tol and d.median().item() < tol / 30, (what, d.max().item(), d.median().item())
